@@ -1,0 +1,1590 @@
+/*
+ * mtf_oracle.cpp -- CPU parity oracle (TEST INFRASTRUCTURE ONLY, see mtf_oracle.h).
+ *
+ * A plain C++17 / FP64 restatement of the Lucas-Kanade hot path of
+ * abhineet123/MTF without Eigen / OpenCV / Boost.  Every function cites the
+ * reference file:line it follows (paths relative to the reference root).
+ * PARITY UNPINNED (no reference tests / goldens, reference not buildable here).
+ *
+ * Single threaded on purpose: the reference's default build is single threaded
+ * (CMakeLists.txt:170 WITH_OPENMP OFF) and this file doubles as the timed CPU
+ * baseline of bench.py.
+ */
+#include "mtf_oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+namespace {
+
+typedef std::vector<double> vecd;
+
+/* ===================================================================== */
+/* L1: pixel utilities                                                    */
+/* ===================================================================== */
+
+/* Utilities/include/mtf/Utilities/imgUtils.h:51-53 */
+inline bool overflow(double x, double y, unsigned int h, unsigned int w) {
+	return (x < 0) || (x >= w) || (y < 0) || (y >= h);
+}
+
+/* getPixVal<Linear, Constant>: Utilities/include/mtf/Utilities/imgUtils.h:91-113
+ * img is the row-major float image (EigImgT), overflow_val = 128 */
+inline double pix_val(const float *img, int h, int w, double x, double y) {
+	const double overflow_val = 128.0;
+	if (overflow(x, y, h, w)) return overflow_val;
+	int lx = static_cast<int>(x);
+	int ly = static_cast<int>(y);
+	double dx = x - lx;
+	double dy = y - ly;
+	int ux = dx == 0 ? lx : lx + 1;
+	int uy = dy == 0 ? ly : ly + 1;
+	if (overflow(lx, ly, h, w) || overflow(ux, uy, h, w)) return overflow_val;
+	const float *r0 = img + static_cast<size_t>(ly) * w;
+	const float *r1 = img + static_cast<size_t>(uy) * w;
+	return r0[lx] * (1 - dx) * (1 - dy) +
+		r0[ux] * dx * (1 - dy) +
+		r1[lx] * (1 - dx) * dy +
+		r1[ux] * dx * dy;
+}
+
+/* utils::getPixVals: Utilities/src/imgUtils.cc:163-173 */
+void pix_vals(double *out, const float *img, int h, int w, const double *pts, int n,
+	double norm_mult, double norm_add) {
+	for (int i = 0; i < n; ++i)
+		out[i] = norm_mult * pix_val(img, h, w, pts[2 * i], pts[2 * i + 1]) + norm_add;
+}
+
+/* utils::getImgGrad: Utilities/src/imgUtils.cc:233-254 ; grad is N x 2 col-major */
+void img_grad(double *grad, const float *img, int h, int w, const double *pts,
+	double eps, int n, double pix_mult) {
+	double mult = pix_mult / (2 * eps);
+	for (int i = 0; i < n; ++i) {
+		double cx = pts[2 * i], cy = pts[2 * i + 1];
+		double inc = pix_val(img, h, w, cx + eps, cy);
+		double dec = pix_val(img, h, w, cx - eps, cy);
+		grad[i] = (inc - dec) * mult;
+		inc = pix_val(img, h, w, cx, cy + eps);
+		dec = pix_val(img, h, w, cx, cy - eps);
+		grad[n + i] = (inc - dec) * mult;
+	}
+}
+
+/* utils::getWarpedImgGrad: Utilities/src/imgUtils.cc:177-202 ; grad_pts is 8 x N */
+void warped_img_grad(double *grad, const float *img, int h, int w, const double *gp,
+	double eps, int n, double pix_mult) {
+	double mult = pix_mult / (2 * eps);
+	for (int i = 0; i < n; ++i) {
+		const double *p = gp + 8 * i;
+		double inc = pix_val(img, h, w, p[0], p[1]);
+		double dec = pix_val(img, h, w, p[2], p[3]);
+		grad[i] = (inc - dec) * mult;
+		inc = pix_val(img, h, w, p[4], p[5]);
+		dec = pix_val(img, h, w, p[6], p[7]);
+		grad[n + i] = (inc - dec) * mult;
+	}
+}
+
+/* ===================================================================== */
+/* small dense math (Eigen in the reference)                              */
+/* ===================================================================== */
+
+struct Mat3 {
+	double m[9]; /* row-major */
+	double &operator()(int r, int c) { return m[3 * r + c]; }
+	double operator()(int r, int c) const { return m[3 * r + c]; }
+};
+Mat3 identity3() { Mat3 I = {{1, 0, 0, 0, 1, 0, 0, 0, 1}}; return I; }
+Mat3 mul3(const Mat3 &a, const Mat3 &b) {
+	Mat3 c;
+	for (int i = 0; i < 3; ++i)
+		for (int j = 0; j < 3; ++j)
+			c(i, j) = a(i, 0) * b(0, j) + a(i, 1) * b(1, j) + a(i, 2) * b(2, j);
+	return c;
+}
+/* Matrix3d::inverse() (cofactor expansion, as Eigen does for 3x3) */
+Mat3 inv3(const Mat3 &a) {
+	Mat3 c;
+	c(0, 0) = a(1, 1) * a(2, 2) - a(1, 2) * a(2, 1);
+	c(0, 1) = a(0, 2) * a(2, 1) - a(0, 1) * a(2, 2);
+	c(0, 2) = a(0, 1) * a(1, 2) - a(0, 2) * a(1, 1);
+	c(1, 0) = a(1, 2) * a(2, 0) - a(1, 0) * a(2, 2);
+	c(1, 1) = a(0, 0) * a(2, 2) - a(0, 2) * a(2, 0);
+	c(1, 2) = a(0, 2) * a(1, 0) - a(0, 0) * a(1, 2);
+	c(2, 0) = a(1, 0) * a(2, 1) - a(1, 1) * a(2, 0);
+	c(2, 1) = a(0, 1) * a(2, 0) - a(0, 0) * a(2, 1);
+	c(2, 2) = a(0, 0) * a(1, 1) - a(0, 1) * a(1, 0);
+	double det = a(0, 0) * c(0, 0) + a(0, 1) * c(1, 0) + a(0, 2) * c(2, 0);
+	double inv_det = 1.0 / det;
+	for (int i = 0; i < 9; ++i) c.m[i] *= inv_det;
+	return c;
+}
+void scale3(Mat3 &a, double s) { for (int i = 0; i < 9; ++i) a.m[i] *= s; }
+
+/* Null vector of an 8 x 9 matrix through a one-sided (Hestenes) Jacobi SVD:
+ * stands in for JacobiSVD<Matrix89d>(...).matrixV().col(8) at
+ * Utilities/src/warpUtils.cc:197-198.  A is row-major 8 x 9. */
+void null_vector_8x9(const double *A, double *h) {
+	const int m = 8, n = 9;
+	double U[m * n], V[n * n];
+	std::memcpy(U, A, sizeof(U));
+	for (int i = 0; i < n; ++i)
+		for (int j = 0; j < n; ++j) V[i * n + j] = i == j ? 1.0 : 0.0;
+	for (int sweep = 0; sweep < 60; ++sweep) {
+		double off = 0;
+		for (int p = 0; p < n - 1; ++p) {
+			for (int q = p + 1; q < n; ++q) {
+				double alpha = 0, beta = 0, gamma = 0;
+				for (int i = 0; i < m; ++i) {
+					alpha += U[i * n + p] * U[i * n + p];
+					beta += U[i * n + q] * U[i * n + q];
+					gamma += U[i * n + p] * U[i * n + q];
+				}
+				if (gamma == 0) continue;
+				double lim = std::sqrt(alpha * beta);
+				if (std::fabs(gamma) <= 1e-300 || std::fabs(gamma) <= 1e-17 * lim) continue;
+				off = std::max(off, std::fabs(gamma) / (lim > 0 ? lim : 1));
+				double zeta = (beta - alpha) / (2.0 * gamma);
+				double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+				double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
+				for (int i = 0; i < m; ++i) {
+					double up = U[i * n + p], uq = U[i * n + q];
+					U[i * n + p] = c * up - s * uq;
+					U[i * n + q] = s * up + c * uq;
+				}
+				for (int i = 0; i < n; ++i) {
+					double vp = V[i * n + p], vq = V[i * n + q];
+					V[i * n + p] = c * vp - s * vq;
+					V[i * n + q] = s * vp + c * vq;
+				}
+			}
+		}
+		if (off < 1e-15) break;
+	}
+	int best = 0;
+	double best_norm = std::numeric_limits<double>::max();
+	for (int j = 0; j < n; ++j) {
+		double nn = 0;
+		for (int i = 0; i < m; ++i) nn += U[i * n + j] * U[i * n + j];
+		if (nn < best_norm) { best_norm = nn; best = j; }
+	}
+	for (int i = 0; i < n; ++i) h[i] = V[i * n + best];
+}
+
+/* utils::computeHomographyDLT(corners): Utilities/src/warpUtils.cc:171-224
+ * corners are 2 x 4 column-major */
+Mat3 homography_dlt(const double *in, const double *out) {
+	double A[8 * 9];
+	for (int i = 0; i < 4; ++i) {
+		double ix = in[2 * i], iy = in[2 * i + 1];
+		double ox = out[2 * i], oy = out[2 * i + 1];
+		double *r1 = A + (2 * i) * 9;
+		r1[0] = 0; r1[1] = 0; r1[2] = 0;
+		r1[3] = -ix; r1[4] = -iy; r1[5] = -1;
+		r1[6] = oy * ix; r1[7] = oy * iy; r1[8] = oy;
+		double *r2 = A + (2 * i + 1) * 9;
+		r2[0] = ix; r2[1] = iy; r2[2] = 1;
+		r2[3] = 0; r2[4] = 0; r2[5] = 0;
+		r2[6] = -ox * ix; r2[7] = -ox * iy; r2[8] = -ox;
+	}
+	double h[9];
+	null_vector_8x9(A, h);
+	Mat3 H;
+	for (int i = 0; i < 9; ++i) H.m[i] = h[i] / h[8];
+	return H;
+}
+
+/* x = A^{-1} b with a column-pivoted Householder QR; stands in for
+ * hessian.colPivHouseholderQr().solve(...) (SM/src/NT/FCLK.cc:298, NT/ESM.cc:267,
+ * NT/ICLK.cc:264).  A is n x n column-major. */
+void colpiv_qr_solve(int n, const double *Ain, const double *b, double *x) {
+	vecd A(Ain, Ain + n * n), rhs(b, b + n), cn(n);
+	std::vector<int> perm(n);
+	for (int j = 0; j < n; ++j) {
+		perm[j] = j;
+		double s = 0;
+		for (int i = 0; i < n; ++i) s += A[j * n + i] * A[j * n + i];
+		cn[j] = s;
+	}
+	int rank = n;
+	double max_norm0 = 0;
+	for (int j = 0; j < n; ++j) max_norm0 = std::max(max_norm0, cn[j]);
+	for (int k = 0; k < n; ++k) {
+		int piv = k;
+		double best = -1;
+		for (int j = k; j < n; ++j) {
+			double s = 0;
+			for (int i = k; i < n; ++i) s += A[j * n + i] * A[j * n + i];
+			cn[j] = s;
+			if (s > best) { best = s; piv = j; }
+		}
+		if (best <= max_norm0 * 1e-300 || best == 0) { rank = k; break; }
+		if (piv != k) {
+			for (int i = 0; i < n; ++i) std::swap(A[piv * n + i], A[k * n + i]);
+			std::swap(perm[piv], perm[k]);
+		}
+		double *col = &A[k * n];
+		double norm = std::sqrt(best);
+		double alpha = col[k] > 0 ? -norm : norm;
+		vecd v(n, 0.0);
+		for (int i = k; i < n; ++i) v[i] = col[i];
+		v[k] -= alpha;
+		double vnorm2 = 0;
+		for (int i = k; i < n; ++i) vnorm2 += v[i] * v[i];
+		if (vnorm2 > 0) {
+			for (int j = k; j < n; ++j) {
+				double dot = 0;
+				for (int i = k; i < n; ++i) dot += v[i] * A[j * n + i];
+				double f = 2 * dot / vnorm2;
+				for (int i = k; i < n; ++i) A[j * n + i] -= f * v[i];
+			}
+			double dot = 0;
+			for (int i = k; i < n; ++i) dot += v[i] * rhs[i];
+			double f = 2 * dot / vnorm2;
+			for (int i = k; i < n; ++i) rhs[i] -= f * v[i];
+		}
+	}
+	vecd y(n, 0.0);
+	for (int k = rank - 1; k >= 0; --k) {
+		double s = rhs[k];
+		for (int j = k + 1; j < rank; ++j) s -= A[j * n + k] * y[j];
+		y[k] = s / A[k * n + k];
+	}
+	for (int k = 0; k < n; ++k) x[perm[k]] = y[k];
+}
+
+/* utils::getNormUnitSquarePts: Utilities/src/warpUtils.cc:15-34
+ * (VectorXd::LinSpaced(n, lo, hi): lo + i*step with the last element = hi) */
+void norm_unit_square_pts(double *pts, double *corners, int resx, int resy,
+	double min_x, double min_y, double max_x, double max_y) {
+	auto lin = [](int i, int n, double lo, double hi) {
+		if (n == 1) return hi;
+		if (i == n - 1) return hi;
+		return lo + i * ((hi - lo) / (n - 1));
+	};
+	int id = 0;
+	for (int r = 0; r < resy; ++r)
+		for (int c = 0; c < resx; ++c) {
+			pts[2 * id] = lin(c, resx, min_x, max_x);
+			pts[2 * id + 1] = lin(r, resy, min_y, max_y);
+			++id;
+		}
+	double cx[4] = {min_x, max_x, max_x, min_x};
+	double cy[4] = {min_y, min_y, max_y, max_y};
+	for (int i = 0; i < 4; ++i) { corners[2 * i] = cx[i]; corners[2 * i + 1] = cy[i]; }
+}
+
+void homogenize(const double *p2, double *p3, int n) {
+	for (int i = 0; i < n; ++i) { p3[3 * i] = p2[2 * i]; p3[3 * i + 1] = p2[2 * i + 1]; p3[3 * i + 2] = 1; }
+}
+/* utils::dehomogenize: Utilities/include/mtf/Utilities/warpUtils.h:16-22 */
+void dehomogenize(const double *p3, double *p2, int n) {
+	for (int i = 0; i < n; ++i) { p2[2 * i] = p3[3 * i] / p3[3 * i + 2]; p2[2 * i + 1] = p3[3 * i + 1] / p3[3 * i + 2]; }
+}
+void warp_hm(const Mat3 &W, const double *in3, double *out3, int n) {
+	for (int i = 0; i < n; ++i) {
+		double x = in3[3 * i], y = in3[3 * i + 1], z = in3[3 * i + 2];
+		out3[3 * i] = W(0, 0) * x + W(0, 1) * y + W(0, 2) * z;
+		out3[3 * i + 1] = W(1, 0) * x + W(1, 1) * y + W(1, 2) * z;
+		out3[3 * i + 2] = W(2, 0) * x + W(2, 1) * y + W(2, 2) * z;
+	}
+}
+
+} // namespace
+
+/* ===================================================================== */
+/* L2: state space models                                                 */
+/* ===================================================================== */
+
+struct mtfo_ssm {
+	int kind, resx, resy, n, S;
+	vecd norm_pts, norm_pts_hm, norm_corners, norm_corners_hm;
+	vecd init_pts, curr_pts, init_pts_hm, curr_pts_hm;
+	vecd init_corners, curr_corners, init_corners_hm, curr_corners_hm;
+	vecd grad_pts, state;
+	Mat3 curr_warp;
+
+	/* ProjectiveBase ctor (SSM/src/ProjectiveBase.cc:9-18); Affine re-does the
+	 * normalised grid with pixel-like extents (SSM/src/Affine.cc:47-63) */
+	mtfo_ssm(int _kind, int _resx, int _resy) : kind(_kind), resx(_resx), resy(_resy),
+		n(_resx * _resy), S(_kind == MTFO_SSM_HOMOGRAPHY ? 8 : 6) {
+		norm_pts.resize(2 * n); norm_pts_hm.resize(3 * n);
+		norm_corners.resize(8); norm_corners_hm.resize(12);
+		init_pts.resize(2 * n); curr_pts.resize(2 * n);
+		init_pts_hm.resize(3 * n); curr_pts_hm.resize(3 * n);
+		init_corners.resize(8); curr_corners.resize(8);
+		init_corners_hm.resize(12); curr_corners_hm.resize(12);
+		grad_pts.resize(8 * n); state.assign(S, 0.0);
+		curr_warp = identity3();
+		if (kind == MTFO_SSM_HOMOGRAPHY)
+			norm_unit_square_pts(norm_pts.data(), norm_corners.data(), resx, resy, -0.5, -0.5, 0.5, 0.5);
+		else
+			norm_unit_square_pts(norm_pts.data(), norm_corners.data(), resx, resy,
+				1 - resx / 2.0, 1 - resy / 2.0, resx / 2.0, resy / 2.0);
+		homogenize(norm_pts.data(), norm_pts_hm.data(), n);
+		homogenize(norm_corners.data(), norm_corners_hm.data(), 4);
+		if (kind == MTFO_SSM_AFFINE) {
+			init_corners = norm_corners; init_corners_hm = norm_corners_hm;
+			init_pts = norm_pts; init_pts_hm = norm_pts_hm;
+		}
+	}
+
+	/* Homography::getWarpFromState SSM/src/Homography.cc:94-107 ;
+	 * Affine::getWarpFromState SSM/src/Affine.cc:116-130 */
+	Mat3 warp_from_state(const double *p) const {
+		Mat3 W;
+		if (kind == MTFO_SSM_HOMOGRAPHY) {
+			W(0, 0) = 1 + p[0]; W(0, 1) = p[1]; W(0, 2) = p[2];
+			W(1, 0) = p[3]; W(1, 1) = 1 + p[4]; W(1, 2) = p[5];
+			W(2, 0) = p[6]; W(2, 1) = p[7]; W(2, 2) = 1;
+		} else {
+			W(0, 0) = 1 + p[2]; W(0, 1) = p[3]; W(0, 2) = p[0];
+			W(1, 0) = p[4]; W(1, 1) = 1 + p[5]; W(1, 2) = p[1];
+			W(2, 0) = 0; W(2, 1) = 0; W(2, 2) = 1;
+		}
+		return W;
+	}
+	/* Homography::getStateFromWarp :116-132 ; Affine::getStateFromWarp :132-143 */
+	void state_from_warp(double *p, const Mat3 &W) const {
+		if (kind == MTFO_SSM_HOMOGRAPHY) {
+			p[0] = W(0, 0) - 1; p[1] = W(0, 1); p[2] = W(0, 2);
+			p[3] = W(1, 0); p[4] = W(1, 1) - 1; p[5] = W(1, 2);
+			p[6] = W(2, 0); p[7] = W(2, 1);
+		} else {
+			p[0] = W(0, 2); p[1] = W(1, 2);
+			p[2] = W(0, 0) - 1; p[3] = W(0, 1);
+			p[4] = W(1, 0); p[5] = W(1, 1) - 1;
+		}
+	}
+
+	/* ProjectiveBase::getPtsFromCorners SSM/src/ProjectiveBase.cc:20-25 */
+	void pts_from_corners(Mat3 &warp, double *pts, double *pts_hm, const double *corners) {
+		warp = homography_dlt(norm_corners.data(), corners);
+		warp_hm(warp, norm_pts_hm.data(), pts_hm, n);
+		dehomogenize(pts_hm, pts, n);
+	}
+
+	/* Homography::setCorners SSM/src/Homography.cc:50-71 (normalized_init = false,
+	 * HOM_NORMALIZED_BASIS :7) -- note init_pts_hm keeps the un-normalised third
+	 * row of the DLT product; Affine::setCorners SSM/src/Affine.cc:64-88
+	 * (normalized_init = false) re-homogenises instead. */
+	void set_corners(const double *corners) {
+		std::copy(corners, corners + 8, curr_corners.begin());
+		homogenize(curr_corners.data(), curr_corners_hm.data(), 4);
+		pts_from_corners(curr_warp, curr_pts.data(), curr_pts_hm.data(), curr_corners.data());
+		init_corners = curr_corners;
+		init_pts = curr_pts;
+		if (kind == MTFO_SSM_HOMOGRAPHY) {
+			init_corners_hm = curr_corners_hm;
+			init_pts_hm = curr_pts_hm;
+		} else {
+			homogenize(init_corners.data(), init_corners_hm.data(), 4);
+			homogenize(init_pts.data(), init_pts_hm.data(), n);
+		}
+		curr_warp = identity3();
+		std::fill(state.begin(), state.end(), 0.0);
+	}
+
+	void apply_curr_warp() {
+		if (kind == MTFO_SSM_HOMOGRAPHY) {
+			warp_hm(curr_warp, init_pts_hm.data(), curr_pts_hm.data(), n);
+			warp_hm(curr_warp, init_corners_hm.data(), curr_corners_hm.data(), 4);
+			dehomogenize(curr_pts_hm.data(), curr_pts.data(), n);
+			dehomogenize(curr_corners_hm.data(), curr_corners.data(), 4);
+		} else {
+			/* curr_pts = curr_warp.topRows<2>() * init_pts_hm (Affine.cc:104-105,113-114) */
+			for (int i = 0; i < n; ++i) {
+				const double *q = &init_pts_hm[3 * i];
+				curr_pts[2 * i] = curr_warp(0, 0) * q[0] + curr_warp(0, 1) * q[1] + curr_warp(0, 2) * q[2];
+				curr_pts[2 * i + 1] = curr_warp(1, 0) * q[0] + curr_warp(1, 1) * q[1] + curr_warp(1, 2) * q[2];
+			}
+			for (int i = 0; i < 4; ++i) {
+				const double *q = &init_corners_hm[3 * i];
+				curr_corners[2 * i] = curr_warp(0, 0) * q[0] + curr_warp(0, 1) * q[1] + curr_warp(0, 2) * q[2];
+				curr_corners[2 * i + 1] = curr_warp(1, 0) * q[0] + curr_warp(1, 1) * q[1] + curr_warp(1, 2) * q[2];
+			}
+		}
+	}
+
+	/* ProjectiveBase::setState SSM/src/ProjectiveBase.cc:41-49 ; Affine::setState Affine.cc:108-114 */
+	void set_state(const double *p) {
+		std::copy(p, p + S, state.begin());
+		curr_warp = warp_from_state(p);
+		apply_curr_warp();
+	}
+
+	/* Homography::compositionalUpdate SSM/src/Homography.cc:73-92 ;
+	 * Affine::compositionalUpdate SSM/src/Affine.cc:90-106 */
+	void compositional_update(const double *dp) {
+		Mat3 upd = warp_from_state(dp);
+		curr_warp = mul3(curr_warp, upd);
+		if (kind == MTFO_SSM_HOMOGRAPHY) scale3(curr_warp, 1.0 / curr_warp(2, 2));
+		state_from_warp(state.data(), curr_warp);
+		apply_curr_warp();
+	}
+
+	/* Homography::invertState SSM/src/Homography.cc:109-114 ; Affine.cc:145-150 */
+	void invert_state(double *inv_p, const double *p) const {
+		Mat3 W = warp_from_state(p);
+		Mat3 Wi = inv3(W);
+		scale3(Wi, 1.0 / Wi(2, 2));
+		state_from_warp(inv_p, Wi);
+	}
+
+	/* Homography::updateGradPts SSM/src/Homography.cc:803-827 ;
+	 * Affine::updateGradPts SSM/src/Affine.cc:293-313 */
+	void update_grad_pts(double eps) {
+		if (kind == MTFO_SSM_HOMOGRAPHY) {
+			double dx[3] = {curr_warp(0, 0) * eps, curr_warp(1, 0) * eps, curr_warp(2, 0) * eps};
+			double dy[3] = {curr_warp(0, 1) * eps, curr_warp(1, 1) * eps, curr_warp(2, 1) * eps};
+			for (int i = 0; i < n; ++i) {
+				const double *q = &curr_pts_hm[3 * i];
+				double *g = &grad_pts[8 * i];
+				double a0 = q[0] + dx[0], a1 = q[1] + dx[1], a2 = q[2] + dx[2];
+				g[0] = a0 / a2; g[1] = a1 / a2;
+				a0 = q[0] - dx[0]; a1 = q[1] - dx[1]; a2 = q[2] - dx[2];
+				g[2] = a0 / a2; g[3] = a1 / a2;
+				a0 = q[0] + dy[0]; a1 = q[1] + dy[1]; a2 = q[2] + dy[2];
+				g[4] = a0 / a2; g[5] = a1 / a2;
+				a0 = q[0] - dy[0]; a1 = q[1] - dy[1]; a2 = q[2] - dy[2];
+				g[6] = a0 / a2; g[7] = a1 / a2;
+			}
+		} else {
+			double dx[2] = {curr_warp(0, 0) * eps, curr_warp(1, 0) * eps};
+			double dy[2] = {curr_warp(0, 1) * eps, curr_warp(1, 1) * eps};
+			for (int i = 0; i < n; ++i) {
+				double cx = curr_pts[2 * i], cy = curr_pts[2 * i + 1];
+				double *g = &grad_pts[8 * i];
+				g[0] = cx + dx[0]; g[1] = cy + dx[1];
+				g[2] = cx - dx[0]; g[3] = cy - dx[1];
+				g[4] = cx + dy[0]; g[5] = cy + dy[1];
+				g[6] = cx - dy[0]; g[7] = cy - dy[1];
+			}
+		}
+	}
+
+	/* row writers shared by the pixel-Jacobian variants */
+	inline void hom_row(double *J, int i, double Ix, double Iy, double x, double y,
+		double px, double py) const {
+		double Ixx = Ix * x, Iyy = Iy * y, Ixy = Ix * y, Iyx = Iy * x;
+		J[0 * n + i] = Ixx; J[1 * n + i] = Ixy; J[2 * n + i] = Ix;
+		J[3 * n + i] = Iyx; J[4 * n + i] = Iyy; J[5 * n + i] = Iy;
+		J[6 * n + i] = -px * Ixx - py * Iyx;
+		J[7 * n + i] = -px * Ixy - py * Iyy;
+	}
+
+	/* Homography::cmptInitPixJacobian SSM/src/Homography.cc:157-191 ;
+	 * Affine::cmptInitPixJacobian SSM/src/Affine.cc:160-182 */
+	void init_pix_jacobian(double *J, const double *g) const {
+		for (int i = 0; i < n; ++i) {
+			double x = init_pts[2 * i], y = init_pts[2 * i + 1];
+			double Ix = g[i], Iy = g[n + i];
+			if (kind == MTFO_SSM_HOMOGRAPHY) {
+				hom_row(J, i, Ix, Iy, x, y, x, y);
+			} else {
+				J[0 * n + i] = Ix; J[1 * n + i] = Iy;
+				J[2 * n + i] = Ix * x; J[3 * n + i] = Ix * y;
+				J[4 * n + i] = Iy * x; J[5 * n + i] = Iy * y;
+			}
+		}
+	}
+	/* Homography::cmptPixJacobian SSM/src/Homography.cc:193-229 ;
+	 * Affine::cmptPixJacobian == cmptInitPixJacobian (Affine.h:35-37) */
+	void pix_jacobian(double *J, const double *g) const {
+		if (kind == MTFO_SSM_AFFINE) { init_pix_jacobian(J, g); return; }
+		for (int i = 0; i < n; ++i) {
+			double x = init_pts[2 * i], y = init_pts[2 * i + 1];
+			double cx = curr_pts[2 * i], cy = curr_pts[2 * i + 1];
+			double inv_d = 1.0 / curr_pts_hm[3 * i + 2];
+			double Ix = g[i] * inv_d, Iy = g[n + i] * inv_d;
+			hom_row(J, i, Ix, Iy, x, y, cx, cy);
+		}
+	}
+	/* Homography::cmptWarpedPixJacobian SSM/src/Homography.cc:231-294 ;
+	 * Affine::cmptWarpedPixJacobian SSM/src/Affine.cc:213-242 */
+	void warped_pix_jacobian(double *J, const double *g) const {
+		if (kind == MTFO_SSM_HOMOGRAPHY) {
+			double a00 = curr_warp(0, 0), a01 = curr_warp(0, 1);
+			double a10 = curr_warp(1, 0), a11 = curr_warp(1, 1);
+			double a20 = curr_warp(2, 0), a21 = curr_warp(2, 1);
+			for (int i = 0; i < n; ++i) {
+				double wx = curr_pts[2 * i], wy = curr_pts[2 * i + 1];
+				double D = curr_pts_hm[3 * i + 2];
+				double inv_det = 1.0 / D;
+				double dwx_dx = (a00 - a20 * wx), dwx_dy = (a01 - a21 * wx);
+				double dwy_dx = (a10 - a20 * wy), dwy_dy = (a11 - a21 * wy);
+				double x = init_pts[2 * i], y = init_pts[2 * i + 1];
+				double Ix = (dwx_dx * g[i] + dwy_dx * g[n + i]) * inv_det;
+				double Iy = (dwx_dy * g[i] + dwy_dy * g[n + i]) * inv_det;
+				hom_row(J, i, Ix, Iy, x, y, x, y);
+			}
+		} else {
+			double a = state[2] + 1, b = state[3], c = state[4], d = state[5] + 1;
+			for (int i = 0; i < n; ++i) {
+				double x = init_pts[2 * i], y = init_pts[2 * i + 1];
+				double Ix = g[i], Iy = g[n + i];
+				double Ixx = Ix * x, Ixy = Ix * y, Iyy = Iy * y, Iyx = Iy * x;
+				J[0 * n + i] = Ix * a + Iy * c;
+				J[1 * n + i] = Ix * b + Iy * d;
+				J[2 * n + i] = Ixx * a + Iyx * c;
+				J[3 * n + i] = Ixy * a + Iyy * c;
+				J[4 * n + i] = Ixx * b + Iyx * d;
+				J[5 * n + i] = Ixy * b + Iyy * d;
+			}
+		}
+	}
+	/* Homography::cmptApproxPixJacobian SSM/src/Homography.cc:296-358 ;
+	 * Affine::cmptApproxPixJacobian SSM/src/Affine.cc:184-211 */
+	void approx_pix_jacobian(double *J, const double *g) const {
+		if (kind == MTFO_SSM_HOMOGRAPHY) {
+			double h00 = curr_warp(0, 0), h01 = curr_warp(0, 1);
+			double h10 = curr_warp(1, 0), h11 = curr_warp(1, 1);
+			double h20 = curr_warp(2, 0), h21 = curr_warp(2, 1);
+			for (int i = 0; i < n; ++i) {
+				double cx = curr_pts[2 * i], cy = curr_pts[2 * i + 1];
+				double a = (h00 - h20 * cx), b = (h01 - h21 * cx);
+				double c = (h10 - h20 * cy), d = (h11 - h21 * cy);
+				double inv_factor = 1.0 / (a * d - b * c);
+				double x = init_pts[2 * i], y = init_pts[2 * i + 1];
+				double Ix = (d * g[i] - c * g[n + i]) * inv_factor;
+				double Iy = (a * g[n + i] - b * g[i]) * inv_factor;
+				hom_row(J, i, Ix, Iy, x, y, cx, cy);
+			}
+		} else {
+			double a = state[2] + 1, b = state[3], c = state[4], d = state[5] + 1;
+			double inv_det = 1.0 / (a * d - b * c);
+			for (int i = 0; i < n; ++i) {
+				double x = init_pts[2 * i], y = init_pts[2 * i + 1];
+				double Ix = g[i], Iy = g[n + i];
+				double Ixx = Ix * x, Ixy = Ix * y, Iyy = Iy * y, Iyx = Iy * x;
+				J[0 * n + i] = (Ix * d - Iy * c) * inv_det;
+				J[1 * n + i] = (Iy * a - Ix * b) * inv_det;
+				J[2 * n + i] = (Ixx * d - Iyx * c) * inv_det;
+				J[3 * n + i] = (Ixy * d - Iyy * c) * inv_det;
+				J[4 * n + i] = (Iyx * a - Ixx * b) * inv_det;
+				J[5 * n + i] = (Iyy * a - Ixy * b) * inv_det;
+			}
+		}
+	}
+	/* ProjectiveBase::applyWarpToCorners SSM/src/ProjectiveBase.cc:137-144 ;
+	 * Affine::applyWarpToCorners SSM/src/Affine.cc:366-375 */
+	void apply_warp_to_corners(double *out, const double *in, const double *p) const {
+		Mat3 W = warp_from_state(p);
+		for (int i = 0; i < 4; ++i) {
+			double x = in[2 * i], y = in[2 * i + 1];
+			if (kind == MTFO_SSM_HOMOGRAPHY) {
+				double discr = W(2, 0) * x + W(2, 1) * y + W(2, 2);
+				out[2 * i] = (W(0, 0) * x + W(0, 1) * y + W(0, 2)) / discr;
+				out[2 * i + 1] = (W(1, 0) * x + W(1, 1) * y + W(1, 2)) / discr;
+			} else {
+				out[2 * i] = W(0, 0) * x + W(0, 1) * y + W(0, 2);
+				out[2 * i + 1] = W(1, 0) * x + W(1, 1) * y + W(1, 2);
+			}
+		}
+	}
+	/* Homography::compositionalRandomWalk SSM/src/Homography.cc:916-926 with the
+	 * perturbation supplied by the caller (the Boost RNG is not reproducible) */
+	void compositional_random_walk(double *out, const double *base, const double *pert) const {
+		Mat3 B = warp_from_state(base), P = warp_from_state(pert);
+		Mat3 W = mul3(B, P);
+		if (kind == MTFO_SSM_HOMOGRAPHY) scale3(W, 1.0 / W(2, 2));
+		state_from_warp(out, W);
+	}
+};
+
+/* ===================================================================== */
+/* L2: appearance models                                                  */
+/* ===================================================================== */
+
+namespace {
+/* utils::bSpl3WithGrad Utilities/include/mtf/Utilities/histUtils.h:206-226
+ * (keeps the truncated constant _2_BY_3 = 0.66666666666, histUtils.h:11) */
+const double k2By3 = 0.66666666666;
+inline void bspl3_with_grad(double &val, double &diff, double x) {
+	if ((x > -2) && (x <= -1)) {
+		double t = 2 + x; diff = (t * t) / 2; val = (diff * t) / 3;
+	} else if ((x > -1) && (x <= 0)) {
+		double t = x / 2; val = k2By3 - x * x * (1 + t); diff = -x * (t + x + 2);
+	} else if ((x > 0) && (x <= 1)) {
+		double t = x / 2; val = k2By3 - x * x * (1 - t); diff = x * (t + x - 2);
+	} else if ((x > 1) && (x < 2)) {
+		double t = 2 - x; diff = -(t * t) / 2; val = -(diff * t) / 3;
+	}
+}
+/* utils::bSpl3Hess histUtils.h:271-283 */
+inline double bspl3_hess(double x) {
+	if ((x > -2) && (x <= -1)) return 2 + x;
+	if ((x > -1) && (x <= 0)) return -(3 * x + 2);
+	if ((x > 0) && (x <= 1)) return 3 * x - 2;
+	if ((x > 1) && (x < 2)) return 2 - x;
+	return 0;
+}
+} // namespace
+
+struct mtfo_am {
+	int kind, resx, resy, n;
+	double grad_eps, likelihood_alpha;
+	const float *img; int h, w;
+	double norm_mult, norm_add;
+	bool init_pix_vals, init_pix_grad, init_sim, init_grad, init_hess;
+	vecd I0, It, dI0_dx, dIt_dx, df_dI0, df_dIt;
+	double f;
+	/* NCC */
+	double I0_mean, It_mean, a, b, c, bc, b2c;
+	vecd I0_cntr, It_cntr, I0_cntr_c, It_cntr_b, df_dI0_ncntr, df_dIt_ncntr;
+	/* MI */
+	int n_bins; double pre_seed; int pou;
+	double hist_pre_seed, hist_norm_mult, max_similarity;
+	std::vector<int> std_ids, init_ids, curr_ids; /* [.. ,2] row-major */
+	vecd init_hist, curr_hist, init_hist_log, curr_hist_log;
+	vecd init_hist_mat, curr_hist_mat, init_hist_grad, curr_hist_grad; /* n_bins x N col-major */
+	vecd init_hist_hess, curr_hist_hess;
+	vecd joint_hist, joint_hist_log, init_grad_factor, curr_grad_factor; /* (r,c) -> r*n_bins+c */
+	vecd self_joint_hist, self_joint_hist_log, self_grad_factor;
+
+	mtfo_am(int _kind, int _resx, int _resy, double _grad_eps, double _alpha,
+		int _n_bins, double _pre_seed, int _pou) : kind(_kind), resx(_resx), resy(_resy),
+		n(_resx * _resy), grad_eps(_grad_eps), likelihood_alpha(_alpha), img(nullptr), h(0), w(0),
+		norm_mult(1), norm_add(0), init_pix_vals(false), init_pix_grad(false), init_sim(false),
+		init_grad(false), init_hess(false), f(0), n_bins(_n_bins), pre_seed(_pre_seed), pou(_pou) {
+		if (kind == MTFO_AM_MI) {
+			/* MI ctor AM/src/MI.cc:80-122 */
+			double norm_pix_min = 0, norm_pix_max = n_bins - 1;
+			if (pou) { norm_pix_min = 1; norm_pix_max = n_bins - 2; }
+			norm_mult = (norm_pix_max - norm_pix_min) / (255.0 - 0.0 + 1);
+			norm_add = norm_pix_min;
+			hist_pre_seed = n_bins * pre_seed;
+			hist_norm_mult = 1.0 / (static_cast<double>(n) + hist_pre_seed * n_bins);
+			std_ids.resize(2 * n_bins);
+			for (int i = 0; i < n_bins; ++i) {
+				std_ids[2 * i] = std::max(0, i - 1);
+				std_ids[2 * i + 1] = std::min(n_bins - 1, i + 2);
+			}
+		}
+	}
+
+	/* ImageBase::initializePixVals AM/src/ImageBase.cc:62-99 (MI: AM/src/MI.cc:124-158) */
+	void initialize_pix_vals(const double *pts) {
+		if (!init_pix_vals) { I0.resize(n); It.resize(n); }
+		pix_vals(I0.data(), img, h, w, pts, n, norm_mult, norm_add);
+		if (!init_pix_vals) { It = I0; init_pix_vals = true; }
+	}
+	/* ImageBase::updatePixVals AM/src/ImageBase.cc:268-290 */
+	void update_pix_vals(const double *pts) { pix_vals(It.data(), img, h, w, pts, n, norm_mult, norm_add); }
+	/* ImageBase::initializePixGrad(PtsT) AM/src/ImageBase.cc:101-132 */
+	void initialize_pix_grad_pts(const double *pts) {
+		if (!init_pix_grad) { dI0_dx.resize(2 * n); dIt_dx.resize(2 * n); }
+		img_grad(dI0_dx.data(), img, h, w, pts, grad_eps, n, norm_mult);
+		if (!init_pix_grad) { dIt_dx = dI0_dx; init_pix_grad = true; }
+	}
+	/* ImageBase::initializePixGrad(GradPtsT) AM/src/ImageBase.cc:134-172 */
+	void initialize_pix_grad_warped(const double *gp) {
+		if (!init_pix_grad) { dI0_dx.resize(2 * n); dIt_dx.resize(2 * n); }
+		warped_img_grad(dI0_dx.data(), img, h, w, gp, grad_eps, n, norm_mult);
+		if (!init_pix_grad) { dIt_dx = dI0_dx; init_pix_grad = true; }
+	}
+	/* ImageBase::updatePixGrad(PtsT) :292-314 ; (GradPtsT) :340-362 */
+	void update_pix_grad_pts(const double *pts) { img_grad(dIt_dx.data(), img, h, w, pts, grad_eps, n, norm_mult); }
+	void update_pix_grad_warped(const double *gp) { warped_img_grad(dIt_dx.data(), img, h, w, gp, grad_eps, n, norm_mult); }
+
+	/* ---------------- similarity ---------------- */
+	void initialize_similarity() {
+		switch (kind) {
+		case MTFO_AM_SSD: /* SSDBase::initializeSimilarity AM/src/SSDBase.cc:29-45 */
+			if (init_sim) return;
+			df_dI0.assign(n, 0.0); f = 0; init_sim = true;
+			break;
+		case MTFO_AM_NCC: /* NCC::initializeSimilarity AM/src/NCC.cc:55-95 */
+			if (!init_sim) { I0_cntr.resize(n); It_cntr.resize(n); }
+			I0_mean = mean(I0);
+			for (int i = 0; i < n; ++i) I0_cntr[i] = I0[i] - I0_mean;
+			c = norm(I0_cntr);
+			if (!init_sim) { f = 1; It_mean = I0_mean; It_cntr = I0_cntr; b = c; init_sim = true; }
+			break;
+		case MTFO_AM_MI: mi_initialize_similarity(); break;
+		}
+	}
+	void initialize_grad() {
+		switch (kind) {
+		case MTFO_AM_SSD: /* SSDBase::initializeGrad AM/src/SSDBase.cc:47-63 */
+			if (init_grad) return;
+			df_dIt = df_dI0; init_grad = true;
+			break;
+		case MTFO_AM_NCC: /* NCC::initializeGrad AM/src/NCC.cc:97-122 */
+			if (!init_grad) {
+				df_dIt.assign(n, 0.0); df_dI0.assign(n, 0.0);
+				df_dI0_ncntr.assign(n, 0.0); df_dIt_ncntr.assign(n, 0.0);
+				I0_cntr_c.resize(n); It_cntr_b.resize(n);
+			}
+			for (int i = 0; i < n; ++i) I0_cntr_c[i] = I0_cntr[i] / c;
+			if (!init_grad) { It_cntr_b = I0_cntr_c; init_grad = true; }
+			break;
+		case MTFO_AM_MI: mi_initialize_grad(); break;
+		}
+	}
+	void initialize_hess() {
+		if (kind == MTFO_AM_MI) mi_initialize_hess();
+		init_hess = true;
+	}
+	void update_similarity(bool prereq_only) {
+		switch (kind) {
+		case MTFO_AM_SSD: { /* SSDBase::updateSimilarity AM/src/SSDBase.cc:75-96 ; I_diff aliases df_dI0 (:34) */
+			for (int i = 0; i < n; ++i) df_dI0[i] = It[i] - I0[i];
+			if (prereq_only) return;
+			double s = 0;
+			for (int i = 0; i < n; ++i) s += df_dI0[i] * df_dI0[i];
+			f = -s / 2;
+			break;
+		}
+		case MTFO_AM_NCC: { /* NCC::updateSimilarity AM/src/NCC.cc:124-161 */
+			It_mean = mean(It);
+			for (int i = 0; i < n; ++i) It_cntr[i] = It[i] - It_mean;
+			double s = 0;
+			for (int i = 0; i < n; ++i) s += I0_cntr[i] * It_cntr[i];
+			a = s; b = norm(It_cntr);
+			bc = b * c; b2c = bc * b; f = a / bc;
+			break;
+		}
+		case MTFO_AM_MI: mi_update_similarity(prereq_only); break;
+		}
+	}
+	void update_curr_grad() {
+		switch (kind) {
+		case MTFO_AM_SSD: /* SSDBase::updateCurrGrad AM/src/SSDBase.cc:115-121 */
+			for (int i = 0; i < n; ++i) df_dIt[i] = -df_dI0[i];
+			break;
+		case MTFO_AM_NCC: { /* NCC::updateCurrGrad AM/src/NCC.cc:196-234 */
+			double m = 0;
+			for (int i = 0; i < n; ++i) {
+				It_cntr_b[i] = It_cntr[i] / b;
+				df_dIt_ncntr[i] = (I0_cntr_c[i] - f * It_cntr_b[i]) / b;
+				m += df_dIt_ncntr[i];
+			}
+			m /= n;
+			for (int i = 0; i < n; ++i) df_dIt[i] = df_dIt_ncntr[i] - m;
+			break;
+		}
+		case MTFO_AM_MI: mi_update_curr_grad(); break;
+		}
+	}
+	void update_init_grad() {
+		switch (kind) {
+		case MTFO_AM_SSD: break; /* SSDBase.h:67-72: nothing without an ILM */
+		case MTFO_AM_NCC: { /* NCC::updateInitGrad AM/src/NCC.cc:163-194 */
+			double m = 0;
+			for (int i = 0; i < n; ++i) {
+				It_cntr_b[i] = It_cntr[i] / b;
+				df_dI0_ncntr[i] = (It_cntr_b[i] - f * I0_cntr_c[i]) / c;
+				m += df_dI0_ncntr[i];
+			}
+			m /= n;
+			for (int i = 0; i < n; ++i) df_dI0[i] = df_dI0_ncntr[i] - m;
+			break;
+		}
+		case MTFO_AM_MI: mi_update_init_grad(); break;
+		}
+	}
+	/* SSD::getLikelihood AM/include/mtf/AM/SSD.h:41-43 ; NCC::getLikelihood NCC.cc:50-53 ;
+	 * MI::getLikelihood MI.cc:384-387 */
+	double likelihood() const {
+		if (kind == MTFO_AM_SSD) return std::exp(-likelihood_alpha * std::sqrt(-f / static_cast<double>(n)));
+		double d = (1.0 / f) - 1;
+		return std::exp(-likelihood_alpha * d * d);
+	}
+
+	/* ---------------- Jacobians: g = df_dI * J ---------------- */
+	static void row_times_mat(double *g, const double *v, const double *J, int n, int S) {
+		for (int s = 0; s < S; ++s) {
+			double acc = 0;
+			const double *col = J + static_cast<size_t>(s) * n;
+			for (int i = 0; i < n; ++i) acc += v[i] * col[i];
+			g[s] = acc;
+		}
+	}
+	/* AppearanceModel::cmptInitJacobian AppearanceModel.h:146-149 ; SSDBase.cc:123-143 ; NCC.cc:236-250 */
+	void cmpt_init_jacobian(double *g, const double *J0, int S) { row_times_mat(g, df_dI0.data(), J0, n, S); }
+	/* cmptCurrJacobian AppearanceModel.h:150-153 ; SSDBase.cc:144-168 ; NCC.cc:252-266 */
+	void cmpt_curr_jacobian(double *g, const double *Jt, int S) { row_times_mat(g, df_dIt.data(), Jt, n, S); }
+	/* cmptDifferenceOfJacobians: SSD df_dIt*(J0+Jt) SSDBase.cc:169-191 ;
+	 * generic (NCC.cc:268-280, AppearanceModel.h:161-164) df_dIt*Jt - df_dI0*J0 */
+	void cmpt_difference_of_jacobians(double *g, const double *J0, const double *Jt, int S) {
+		if (kind == MTFO_AM_SSD) {
+			for (int s = 0; s < S; ++s) {
+				double acc = 0;
+				const double *c0 = J0 + static_cast<size_t>(s) * n, *ct = Jt + static_cast<size_t>(s) * n;
+				for (int i = 0; i < n; ++i) acc += df_dIt[i] * (c0[i] + ct[i]);
+				g[s] = acc;
+			}
+		} else {
+			vecd g0(S), gt(S);
+			row_times_mat(gt.data(), df_dIt.data(), Jt, n, S);
+			row_times_mat(g0.data(), df_dI0.data(), J0, n, S);
+			for (int s = 0; s < S; ++s) g[s] = gt[s] - g0[s];
+		}
+	}
+
+	/* ---------------- Hessians ---------------- */
+	static void neg_gram(double *H, const double *J, int n, int S) {
+		for (int r = 0; r < S; ++r)
+			for (int c2 = r; c2 < S; ++c2) {
+				double acc = 0;
+				const double *a = J + static_cast<size_t>(r) * n, *b2 = J + static_cast<size_t>(c2) * n;
+				for (int i = 0; i < n; ++i) acc += a[i] * b2[i];
+				H[c2 * S + r] = H[r * S + c2] = -acc;
+			}
+	}
+	/* NCC helper: Jc = (J - colmean(J)) / b, u = Jc^T v */
+	void ncc_centre(vecd &Jc, const double *J, int S) const {
+		Jc.resize(static_cast<size_t>(n) * S);
+		for (int s = 0; s < S; ++s) {
+			const double *col = J + static_cast<size_t>(s) * n;
+			double m = 0;
+			for (int i = 0; i < n; ++i) m += col[i];
+			m /= n;
+			for (int i = 0; i < n; ++i) Jc[static_cast<size_t>(s) * n + i] = (col[i] - m) / b;
+		}
+	}
+	static void mat_t_vec(double *u, const vecd &Jc, const vecd &v, int n, int S) {
+		for (int s = 0; s < S; ++s) {
+			double acc = 0;
+			for (int i = 0; i < n; ++i) acc += Jc[static_cast<size_t>(s) * n + i] * v[i];
+			u[s] = acc;
+		}
+	}
+	void cmpt_init_hessian(double *H, const double *J0, int S) {
+		switch (kind) {
+		case MTFO_AM_SSD: neg_gram(H, J0, n, S); break; /* SSDBase.cc:251-267 */
+		case MTFO_AM_NCC: { /* NCC::cmptInitHessian AM/src/NCC.cc:282-303 (divides by b, quirk kept) */
+			vecd Jc; ncc_centre(Jc, J0, S);
+			vecd G(S * S), ut(S), u0(S);
+			neg_gram(G.data(), Jc.data(), n, S);
+			mat_t_vec(ut.data(), Jc, It_cntr_b, n, S);
+			mat_t_vec(u0.data(), Jc, I0_cntr_c, n, S);
+			for (int r = 0; r < S; ++r)
+				for (int c2 = 0; c2 < S; ++c2)
+					H[c2 * S + r] = f * G[c2 * S + r] - ut[r] * u0[c2] - u0[r] * ut[c2] + 3 * u0[r] * u0[c2];
+			break;
+		}
+		case MTFO_AM_MI: mi_cmpt_init_hessian(H, J0, S); break;
+		}
+	}
+	void cmpt_curr_hessian(double *H, const double *Jt, int S) {
+		switch (kind) {
+		case MTFO_AM_SSD: neg_gram(H, Jt, n, S); break; /* SSDBase.cc:268-285 */
+		case MTFO_AM_NCC: { /* NCC::cmptCurrHessian AM/src/NCC.cc:304-335 */
+			vecd Jc; ncc_centre(Jc, Jt, S);
+			vecd G(S * S), ut(S), u0(S);
+			neg_gram(G.data(), Jc.data(), n, S);
+			mat_t_vec(ut.data(), Jc, It_cntr_b, n, S);
+			mat_t_vec(u0.data(), Jc, I0_cntr_c, n, S);
+			for (int r = 0; r < S; ++r)
+				for (int c2 = 0; c2 < S; ++c2)
+					H[c2 * S + r] = f * G[c2 * S + r] - ut[r] * u0[c2] - u0[r] * ut[c2] + 3 * ut[r] * ut[c2];
+			break;
+		}
+		case MTFO_AM_MI: mi_cmpt_curr_hessian(H, Jt, S); break;
+		}
+	}
+	void cmpt_self_hessian(double *H, const double *Jt, int S) {
+		switch (kind) {
+		case MTFO_AM_SSD: neg_gram(H, Jt, n, S); break; /* SSDBase.h:91-94 */
+		case MTFO_AM_NCC: { /* NCC::cmptSelfHessian AM/src/NCC.cc:337-389 (fast_hess = 0) */
+			vecd Jc; ncc_centre(Jc, Jt, S);
+			vecd G(S * S), ut(S);
+			neg_gram(G.data(), Jc.data(), n, S);
+			mat_t_vec(ut.data(), Jc, It_cntr_b, n, S);
+			for (int r = 0; r < S; ++r)
+				for (int c2 = 0; c2 < S; ++c2)
+					H[c2 * S + r] = G[c2 * S + r] + ut[r] * ut[c2];
+			break;
+		}
+		case MTFO_AM_MI: mi_cmpt_self_hessian(H, Jt, S); break;
+		}
+	}
+	/* cmptSumOfHessians: SSDBase.cc:287-311 ; generic AppearanceModel.h:196-208 */
+	void cmpt_sum_of_hessians(double *H, const double *J0, const double *Jt, int S) {
+		vecd H0(S * S), Ht(S * S);
+		cmpt_init_hessian(H0.data(), J0, S);
+		cmpt_curr_hessian(Ht.data(), Jt, S);
+		for (int i = 0; i < S * S; ++i) H[i] = H0[i] + Ht[i];
+	}
+
+	/* ---------------- helpers ---------------- */
+	static double mean(const vecd &v) { double s = 0; for (double x : v) s += x; return s / v.size(); }
+	static double norm(const vecd &v) { double s = 0; for (double x : v) s += x * x; return std::sqrt(s); }
+
+	/* ================= MI ================= */
+	inline double &HM(vecd &m, int bin, int pix) { return m[static_cast<size_t>(pix) * n_bins + bin]; }
+	inline double HMc(const vecd &m, int bin, int pix) const { return m[static_cast<size_t>(pix) * n_bins + bin]; }
+	inline int lin(int r, int c2) const { return r * n_bins + c2; }
+
+	/* MI::initializeSimilarity AM/src/MI.cc:207-287 */
+	void mi_initialize_similarity() {
+		size_t nb = n_bins;
+		if (!init_sim) {
+			init_hist.resize(nb); curr_hist.resize(nb); init_hist_log.resize(nb); curr_hist_log.resize(nb);
+			init_hist_mat.resize(nb * n); curr_hist_mat.resize(nb * n);
+			init_hist_grad.resize(nb * n); curr_hist_grad.resize(nb * n);
+			joint_hist.resize(nb * nb); joint_hist_log.resize(nb * nb);
+			init_ids.resize(2 * n); curr_ids.resize(2 * n);
+		}
+		std::fill(init_hist.begin(), init_hist.end(), hist_pre_seed);
+		std::fill(init_hist_mat.begin(), init_hist_mat.end(), 0.0);
+		std::fill(init_hist_grad.begin(), init_hist_grad.end(), 0.0);
+		for (int p = 0; p < n; ++p) {
+			int fl = static_cast<int>(I0[p]);
+			init_ids[2 * p] = std_ids[2 * fl]; init_ids[2 * p + 1] = std_ids[2 * fl + 1];
+			double diff = init_ids[2 * p] - I0[p];
+			for (int id = init_ids[2 * p]; id <= init_ids[2 * p + 1]; ++id) {
+				bspl3_with_grad(HM(init_hist_mat, id, p), HM(init_hist_grad, id, p), diff);
+				HM(init_hist_grad, id, p) *= -hist_norm_mult;
+				init_hist[id] += HM(init_hist_mat, id, p);
+				++diff;
+			}
+		}
+		for (int i = 0; i < n_bins; ++i) { init_hist[i] *= hist_norm_mult; init_hist_log[i] = std::log(init_hist[i]); }
+		if (!init_sim) {
+			std::fill(joint_hist.begin(), joint_hist.end(), pre_seed);
+			for (int p = 0; p < n; ++p)
+				for (int i1 = init_ids[2 * p]; i1 <= init_ids[2 * p + 1]; ++i1)
+					for (int i2 = init_ids[2 * p]; i2 <= init_ids[2 * p + 1]; ++i2)
+						joint_hist[lin(i1, i2)] += HMc(init_hist_mat, i1, p) * HMc(init_hist_mat, i2, p);
+			for (size_t i = 0; i < nb * nb; ++i) { joint_hist[i] *= hist_norm_mult; joint_hist_log[i] = std::log(joint_hist[i]); }
+			f = 0;
+			for (int ci = 0; ci < n_bins; ++ci)
+				for (int ii = 0; ii < n_bins; ++ii)
+					f += joint_hist[lin(ci, ii)] * (joint_hist_log[lin(ci, ii)] - init_hist_log[ci] - init_hist_log[ii]);
+			max_similarity = f;
+			curr_ids = init_ids; curr_hist = init_hist; curr_hist_mat = init_hist_mat;
+			curr_hist_log = init_hist_log; curr_hist_grad = init_hist_grad;
+			init_sim = true;
+		}
+	}
+	/* MI::initializeGrad AM/src/MI.cc:299-332 (the n_bins^2 x N joint-gradient matrices
+	 * of :301-302 are never stored here: each entry is a product of two stored factors) */
+	void mi_initialize_grad() {
+		if (init_grad) return;
+		size_t nb = n_bins;
+		init_grad_factor.resize(nb * nb); curr_grad_factor.resize(nb * nb);
+		df_dIt.resize(n); df_dI0.assign(n, 0.0);
+		for (int ci = 0; ci < n_bins; ++ci)
+			for (int ii = 0; ii < n_bins; ++ii)
+				init_grad_factor[lin(ci, ii)] = 1 + joint_hist_log[lin(ci, ii)] - init_hist_log[ci];
+		for (int p = 0; p < n; ++p)
+			for (int ci = init_ids[2 * p]; ci <= init_ids[2 * p + 1]; ++ci)
+				for (int ii = init_ids[2 * p]; ii <= init_ids[2 * p + 1]; ++ii)
+					df_dI0[p] += HMc(init_hist_grad, ci, p) * HMc(init_hist_mat, ii, p) * init_grad_factor[lin(ci, ii)];
+		curr_grad_factor = init_grad_factor;
+		df_dIt = df_dI0;
+		init_grad = true;
+	}
+	/* MI::updateSimilarity AM/src/MI.cc:346-382 */
+	void mi_update_similarity(bool prereq_only) {
+		size_t nb = n_bins;
+		std::fill(curr_hist.begin(), curr_hist.end(), hist_pre_seed);
+		std::fill(joint_hist.begin(), joint_hist.end(), pre_seed);
+		std::fill(curr_hist_mat.begin(), curr_hist_mat.end(), 0.0);
+		std::fill(curr_hist_grad.begin(), curr_hist_grad.end(), 0.0);
+		for (int p = 0; p < n; ++p) {
+			int fl = static_cast<int>(It[p]);
+			curr_ids[2 * p] = std_ids[2 * fl]; curr_ids[2 * p + 1] = std_ids[2 * fl + 1];
+			double diff = curr_ids[2 * p] - It[p];
+			for (int ci = curr_ids[2 * p]; ci <= curr_ids[2 * p + 1]; ++ci) {
+				bspl3_with_grad(HM(curr_hist_mat, ci, p), HM(curr_hist_grad, ci, p), diff);
+				++diff;
+				HM(curr_hist_grad, ci, p) *= -hist_norm_mult;
+				curr_hist[ci] += HMc(curr_hist_mat, ci, p);
+				for (int ii = init_ids[2 * p]; ii <= init_ids[2 * p + 1]; ++ii)
+					joint_hist[lin(ci, ii)] += HMc(curr_hist_mat, ci, p) * HMc(init_hist_mat, ii, p);
+			}
+		}
+		for (int i = 0; i < n_bins; ++i) { curr_hist[i] *= hist_norm_mult; curr_hist_log[i] = std::log(curr_hist[i]); }
+		for (size_t i = 0; i < nb * nb; ++i) { joint_hist[i] *= hist_norm_mult; joint_hist_log[i] = std::log(joint_hist[i]); }
+		if (prereq_only) return;
+		f = 0;
+		for (int ci = 0; ci < n_bins; ++ci)
+			for (int ii = 0; ii < n_bins; ++ii)
+				f += joint_hist[lin(ci, ii)] * (joint_hist_log[lin(ci, ii)] - curr_hist_log[ci] - init_hist_log[ii]);
+	}
+	/* MI::updateInitGrad AM/src/MI.cc:398-416 (init_grad_factor is indexed (init, curr) here) */
+	void mi_update_init_grad() {
+		for (int ii = 0; ii < n_bins; ++ii)
+			for (int ci = 0; ci < n_bins; ++ci)
+				init_grad_factor[lin(ii, ci)] = 1 + joint_hist_log[lin(ci, ii)] - init_hist_log[ii];
+		for (int p = 0; p < n; ++p) {
+			double acc = 0;
+			for (int ii = init_ids[2 * p]; ii <= init_ids[2 * p + 1]; ++ii)
+				for (int ci = curr_ids[2 * p]; ci <= curr_ids[2 * p + 1]; ++ci)
+					acc += HMc(init_hist_grad, ii, p) * HMc(curr_hist_mat, ci, p) * init_grad_factor[lin(ii, ci)];
+			df_dI0[p] = acc;
+		}
+	}
+	/* MI::updateCurrGrad AM/src/MI.cc:426-442 */
+	void mi_update_curr_grad() {
+		for (int ci = 0; ci < n_bins; ++ci)
+			for (int ii = 0; ii < n_bins; ++ii)
+				curr_grad_factor[lin(ci, ii)] = 1 + joint_hist_log[lin(ci, ii)] - curr_hist_log[ci];
+		for (int p = 0; p < n; ++p) {
+			double acc = 0;
+			for (int ci = curr_ids[2 * p]; ci <= curr_ids[2 * p + 1]; ++ci)
+				for (int ii = init_ids[2 * p]; ii <= init_ids[2 * p + 1]; ++ii)
+					acc += HMc(curr_hist_grad, ci, p) * HMc(init_hist_mat, ii, p) * curr_grad_factor[lin(ci, ii)];
+			df_dIt[p] = acc;
+		}
+	}
+	/* MI::initializeHess AM/src/MI.cc:443-459 ; utils::getBSplHistHess Utilities/src/histUtils.cc:234-256 */
+	void mi_initialize_hess() {
+		size_t nb = n_bins;
+		if (!init_hess) {
+			init_hist_hess.resize(nb * n); curr_hist_hess.resize(nb * n);
+			self_joint_hist.resize(nb * nb); self_joint_hist_log.resize(nb * nb); self_grad_factor.resize(nb * nb);
+		}
+		std::fill(init_hist_hess.begin(), init_hist_hess.end(), 0.0);
+		for (int p = 0; p < n; ++p) {
+			double diff = init_ids[2 * p] - I0[p];
+			for (int id = init_ids[2 * p]; id <= init_ids[2 * p + 1]; ++id)
+				HM(init_hist_hess, id, p) = hist_norm_mult * bspl3_hess(diff++);
+		}
+		if (!init_hess) curr_hist_hess = init_hist_hess;
+	}
+	/* adds  sum_k row_k^T row_k * factor_k  for the n_bins^2 x S matrix Q */
+	void mi_add_rank1_terms(double *H, const vecd &Q, const vecd &factor, int S) const {
+		for (int k = 0; k < n_bins * n_bins; ++k) {
+			const double *row = &Q[static_cast<size_t>(k) * S];
+			for (int r = 0; r < S; ++r)
+				for (int c2 = 0; c2 < S; ++c2)
+					H[c2 * S + r] += row[r] * row[c2] * factor[k];
+		}
+	}
+	static void add_outer(double *H, const double *J, int n, int S, int p, double wgt) {
+		for (int r = 0; r < S; ++r) {
+			double jr = J[static_cast<size_t>(r) * n + p] * wgt;
+			for (int c2 = 0; c2 < S; ++c2) H[c2 * S + r] += jr * J[static_cast<size_t>(c2) * n + p];
+		}
+	}
+	/* MI::cmptInitHessian AM/src/MI.cc:461-513 */
+	void mi_cmpt_init_hessian(double *H, const double *J0, int S) {
+		vecd Q(static_cast<size_t>(n_bins) * n_bins * S, 0.0), factor(n_bins * n_bins);
+		std::fill(H, H + S * S, 0.0);
+		for (int p = 0; p < n; ++p) {
+			double hess_term = 0;
+			for (int ii = init_ids[2 * p]; ii <= init_ids[2 * p + 1]; ++ii) {
+				double inner = 0;
+				for (int ci = curr_ids[2 * p]; ci <= curr_ids[2 * p + 1]; ++ci) {
+					double gr = HMc(init_hist_grad, ii, p) * HMc(curr_hist_mat, ci, p); /* init_joint_hist_grad(lin(ii,ci),p) MI.cc:411 */
+					double *row = &Q[static_cast<size_t>(lin(ci, ii)) * S];
+					for (int s = 0; s < S; ++s) row[s] += gr * J0[static_cast<size_t>(s) * n + p];
+					inner += HMc(curr_hist_mat, ci, p) * init_grad_factor[lin(ii, ci)];
+				}
+				hess_term += HMc(init_hist_hess, ii, p) * inner;
+			}
+			add_outer(H, J0, n, S, p, hess_term);
+		}
+		for (int ci = 0; ci < n_bins; ++ci)
+			for (int ii = 0; ii < n_bins; ++ii)
+				factor[lin(ci, ii)] = (1.0 / joint_hist[lin(ci, ii)]) - (1.0 / init_hist[ii]);
+		mi_add_rank1_terms(H, Q, factor, S);
+	}
+	/* MI::cmptCurrHessian AM/src/MI.cc:603-637 */
+	void mi_cmpt_curr_hessian(double *H, const double *Jt, int S) {
+		vecd Q(static_cast<size_t>(n_bins) * n_bins * S, 0.0), factor(n_bins * n_bins);
+		std::fill(H, H + S * S, 0.0);
+		for (int p = 0; p < n; ++p) {
+			double diff = curr_ids[2 * p] - It[p];
+			double hess_term = 0;
+			for (int ci = curr_ids[2 * p]; ci <= curr_ids[2 * p + 1]; ++ci) {
+				HM(curr_hist_hess, ci, p) = hist_norm_mult * bspl3_hess(diff);
+				++diff;
+				double inner = 0;
+				for (int ii = init_ids[2 * p]; ii <= init_ids[2 * p + 1]; ++ii) {
+					double gr = HMc(curr_hist_grad, ci, p) * HMc(init_hist_mat, ii, p); /* curr_joint_hist_grad MI.cc:437 */
+					double *row = &Q[static_cast<size_t>(lin(ci, ii)) * S];
+					for (int s = 0; s < S; ++s) row[s] += gr * Jt[static_cast<size_t>(s) * n + p];
+					inner += HMc(init_hist_mat, ii, p) * curr_grad_factor[lin(ci, ii)];
+				}
+				hess_term += HMc(curr_hist_hess, ci, p) * inner;
+			}
+			add_outer(H, Jt, n, S, p, hess_term);
+		}
+		for (int ci = 0; ci < n_bins; ++ci)
+			for (int ii = 0; ii < n_bins; ++ii)
+				factor[lin(ci, ii)] = (1.0 / joint_hist[lin(ci, ii)]) - (1.0 / curr_hist[ci]);
+		mi_add_rank1_terms(H, Q, factor, S);
+	}
+	/* MI::cmptSelfHist AM/src/MI.cc:639-659 */
+	void mi_cmpt_self_hist() {
+		size_t nb = n_bins;
+		std::fill(self_joint_hist.begin(), self_joint_hist.end(), pre_seed);
+		for (int p = 0; p < n; ++p)
+			for (int i1 = curr_ids[2 * p]; i1 <= curr_ids[2 * p + 1]; ++i1)
+				for (int i2 = curr_ids[2 * p]; i2 <= curr_ids[2 * p + 1]; ++i2)
+					self_joint_hist[lin(i1, i2)] += HMc(curr_hist_mat, i1, p) * HMc(curr_hist_mat, i2, p);
+		for (size_t i = 0; i < nb * nb; ++i) { self_joint_hist[i] *= hist_norm_mult; self_joint_hist_log[i] = std::log(self_joint_hist[i]); }
+		for (int ci = 0; ci < n_bins; ++ci)
+			for (int ii = 0; ii < n_bins; ++ii)
+				self_grad_factor[lin(ci, ii)] = 1 + self_joint_hist_log[lin(ci, ii)] - curr_hist_log[ci];
+	}
+	/* MI::cmptSelfHessian AM/src/MI.cc:515-601 -- the value the reference returns is the
+	 * second pass (:565-590, `self_hessian`); the first pass (:524-562) is discarded there. */
+	void mi_cmpt_self_hessian(double *H, const double *Jt, int S) {
+		mi_cmpt_self_hist();
+		vecd Q(static_cast<size_t>(n_bins) * n_bins * S, 0.0), factor(n_bins * n_bins);
+		std::fill(H, H + S * S, 0.0);
+		for (int p = 0; p < n; ++p) {
+			double diff = curr_ids[2 * p] - It[p];
+			double hess_term = 0;
+			for (int ci = curr_ids[2 * p]; ci <= curr_ids[2 * p + 1]; ++ci) {
+				HM(curr_hist_hess, ci, p) = hist_norm_mult * bspl3_hess(diff);
+				++diff;
+				double inner = 0;
+				for (int ii = curr_ids[2 * p]; ii <= curr_ids[2 * p + 1]; ++ii) {
+					double gr = HMc(curr_hist_grad, ci, p) * HMc(curr_hist_mat, ii, p);
+					double *row = &Q[static_cast<size_t>(lin(ci, ii)) * S];
+					for (int s = 0; s < S; ++s) row[s] += gr * Jt[static_cast<size_t>(s) * n + p];
+					inner += HMc(curr_hist_mat, ii, p) * self_grad_factor[lin(ci, ii)];
+				}
+				hess_term += HMc(curr_hist_hess, ci, p) * inner;
+			}
+			add_outer(H, Jt, n, S, p, hess_term);
+		}
+		for (int ci = 0; ci < n_bins; ++ci)
+			for (int ii = 0; ii < n_bins; ++ii)
+				factor[lin(ci, ii)] = (1.0 / self_joint_hist[lin(ci, ii)]) - (1.0 / curr_hist[ci]);
+		mi_add_rank1_terms(H, Q, factor, S);
+	}
+};
+
+/* ===================================================================== */
+/* L3: search methods (non-templated "NT" variants, virtual-dispatch path) */
+/* ===================================================================== */
+
+struct mtfo_tracker {
+	int sm; mtfo_am *am; mtfo_ssm *ssm; mtfo_sm_params p;
+	int S, N;
+	vecd J0, Jt, Jmean, g, H, H0, dp, inv_dp, prev_corners;
+	vecd trace; int rec_len, n_rec;
+
+	mtfo_tracker(int _sm, mtfo_am *_am, mtfo_ssm *_ssm, const mtfo_sm_params &_p) :
+		sm(_sm), am(_am), ssm(_ssm), p(_p), S(_ssm->S), N(_am->n) {
+		J0.resize(static_cast<size_t>(N) * S); Jt.resize(static_cast<size_t>(N) * S);
+		g.assign(S, 0.0); H.assign(S * S, 0.0); H0.assign(S * S, 0.0);
+		dp.assign(S, 0.0); inv_dp.assign(S, 0.0); prev_corners.resize(8);
+		rec_len = 1 + S + S * S + S + 8; n_rec = 0;
+	}
+
+	void pix_jacobian_init(double *J) {
+		/* ESM::initializePixJacobian NT/ESM.cc:379-388 ; FCLK NT/FCLK.cc:113-118,128-133 ; ICLK NT/ICLK.cc:78-95 */
+		if (p.chained_warp) {
+			am->initialize_pix_grad_pts(ssm->curr_pts.data());
+			ssm->warped_pix_jacobian(J, am->dI0_dx.data());
+		} else {
+			ssm->update_grad_pts(am->grad_eps);
+			am->initialize_pix_grad_warped(ssm->grad_pts.data());
+			ssm->init_pix_jacobian(J, am->dI0_dx.data());
+		}
+	}
+	void pix_jacobian_update(double *J) {
+		/* ESM::updatePixJacobian NT/ESM.cc:390-408 ; FCLK NT/FCLK.cc:222-236 */
+		if (p.chained_warp) {
+			am->update_pix_grad_pts(ssm->curr_pts.data());
+			ssm->warped_pix_jacobian(J, am->dIt_dx.data());
+		} else {
+			ssm->update_grad_pts(am->grad_eps);
+			am->update_pix_grad_warped(ssm->grad_pts.data());
+			ssm->init_pix_jacobian(J, am->dIt_dx.data());
+		}
+	}
+
+	void initialize(const double *corners) {
+		am->init_pix_vals = am->init_pix_grad = am->init_sim = am->init_grad = am->init_hess = false;
+		ssm->set_corners(corners);
+		am->initialize_pix_vals(ssm->curr_pts.data());
+		switch (sm) {
+		case MTFO_SM_ESM: /* nt::ESM::initialize SM/src/NT/ESM.cc:110-146 */
+			pix_jacobian_init(J0.data());
+			am->initialize_similarity(); am->initialize_grad(); am->initialize_hess();
+			if (p.hess_type == 0 /*InitialSelf*/ || p.hess_type == 2 /*SumOfSelf*/) {
+				am->cmpt_self_hessian(H.data(), J0.data(), S);
+				H0 = H;
+			}
+			break;
+		case MTFO_SM_FCLK: /* nt::FCLK::initialize SM/src/NT/FCLK.cc:102-169 */
+			am->initialize_similarity(); am->initialize_grad(); am->initialize_hess();
+			if (p.chained_warp) am->initialize_pix_grad_pts(ssm->curr_pts.data());
+			else { ssm->update_grad_pts(am->grad_eps); am->initialize_pix_grad_warped(ssm->grad_pts.data()); }
+			if (p.hess_type == 0 /*InitialSelf*/) {
+				if (p.chained_warp) ssm->warped_pix_jacobian(J0.data(), am->dI0_dx.data());
+				else ssm->init_pix_jacobian(J0.data(), am->dI0_dx.data());
+				am->cmpt_self_hessian(H.data(), J0.data(), S);
+				if (p.leven_marq) H0 = H;
+			}
+			break;
+		case MTFO_SM_ICLK: /* nt::ICLK::initialize SM/src/NT/ICLK.cc:71-128 */
+			if (p.chained_warp) am->initialize_pix_grad_pts(ssm->curr_pts.data());
+			else { ssm->update_grad_pts(am->grad_eps); am->initialize_pix_grad_warped(ssm->grad_pts.data()); }
+			am->initialize_similarity(); am->initialize_grad(); am->initialize_hess();
+			if (p.chained_warp) ssm->warped_pix_jacobian(J0.data(), am->dI0_dx.data());
+			else ssm->init_pix_jacobian(J0.data(), am->dI0_dx.data());
+			am->cmpt_init_jacobian(g.data(), J0.data(), S);
+			if (p.hess_type == 0 /*InitialSelf*/) {
+				am->cmpt_self_hessian(H.data(), J0.data(), S);
+				if (p.leven_marq) H0 = H;
+			}
+			break;
+		}
+	}
+
+	/* nt::ESM::setRegion NT/ESM.cc:148-168 ; nt::ICLK::setRegion NT/ICLK.cc:131-157 (update_ssm=false) ;
+	 * nt::FCLK::setRegion NT/FCLK.cc:360+ just resets the SSM */
+	void set_region(const double *corners) {
+		ssm->set_corners(corners);
+		if (sm == MTFO_SM_ESM) {
+			ssm->init_pix_jacobian(J0.data(), am->dI0_dx.data());
+			if (p.hess_type == 0 || p.hess_type == 2) { am->cmpt_self_hessian(H.data(), J0.data(), S); H0 = H; }
+		}
+	}
+
+	/* trace record = [f, g, H (before LM damping), dp, corners after the update] */
+	void record(double f, const vecd &Hrec) {
+		size_t off = trace.size();
+		trace.resize(off + rec_len);
+		double *r = &trace[off];
+		r[0] = f;
+		std::copy(g.begin(), g.end(), r + 1);
+		std::copy(Hrec.begin(), Hrec.end(), r + 1 + S);
+		std::copy(dp.begin(), dp.end(), r + 1 + S + S * S);
+		std::copy(ssm->curr_corners.begin(), ssm->curr_corners.end(), r + 1 + 2 * S + S * S);
+		++n_rec;
+	}
+
+	/* hessian += delta * diag(hessian) (NT/FCLK.cc:290-296, NT/ESM.cc:257-263, NT/ICLK.cc:253-259)
+	 * then state_update = -hessian.colPivHouseholderQr().solve(jacobian^T) */
+	void solve_and_negate(double delta) {
+		if (p.leven_marq) for (int i = 0; i < S; ++i) H[i * S + i] += delta * H[i * S + i];
+		colpiv_qr_solve(S, H.data(), g.data(), dp.data());
+		for (int i = 0; i < S; ++i) dp[i] = -dp[i];
+	}
+	double corner_change() const {
+		double s = 0;
+		for (int i = 0; i < 8; ++i) { double d = prev_corners[i] - ssm->curr_corners[i]; s += d * d; }
+		return s;
+	}
+
+	int update() {
+		trace.clear(); n_rec = 0;
+		switch (sm) {
+		case MTFO_SM_ESM: return update_esm();
+		case MTFO_SM_FCLK: return update_fclk();
+		default: return update_iclk();
+		}
+	}
+
+	/* nt::ESM::update SM/src/NT/ESM.cc:170-296, cmptJacobian :298-313, cmptHessian :315-377 */
+	int update_esm() {
+		double prev_sim = 0, delta = p.lm_delta_init;
+		bool state_reset = false;
+		int iters = 0;
+		for (int it = 0; it < p.max_iters; ++it) {
+			++iters;
+			am->update_pix_vals(ssm->curr_pts.data());
+			am->update_similarity(false);
+			if (p.leven_marq && !state_reset) {
+				double cur = am->f;
+				if (it > 0) {
+					if (cur < prev_sim) {
+						delta *= p.lm_delta_update;
+						ssm->invert_state(inv_dp.data(), dp.data());
+						ssm->compositional_update(inv_dp.data());
+						state_reset = true;
+						continue;
+					}
+					if (cur > prev_sim) delta /= p.lm_delta_update;
+				}
+				prev_sim = cur;
+			}
+			state_reset = false;
+			pix_jacobian_update(Jt.data()); /* DISABLE_SPI ordering, NT/ESM.cc:234-238 */
+			bool need_mean = (p.jac_type == 0) || (p.hess_type == 3);
+			if (need_mean) {
+				Jmean.resize(Jt.size());
+				for (size_t i = 0; i < Jt.size(); ++i) Jmean[i] = (J0[i] + Jt[i]) / 2.0;
+			}
+			am->update_curr_grad();
+			am->update_init_grad();
+			if (p.jac_type == 0) am->cmpt_curr_jacobian(g.data(), Jmean.data(), S);
+			else {
+				am->cmpt_difference_of_jacobians(g.data(), J0.data(), Jt.data(), S);
+				for (int i = 0; i < S; ++i) g[i] *= 0.5;
+			}
+			switch (p.hess_type) {
+			case 0: if (p.leven_marq) H = H0; break;                               /* InitialSelf */
+			case 3: am->cmpt_curr_hessian(H.data(), Jmean.data(), S); break;         /* Original */
+			case 4: /* SumOfStd */
+				am->cmpt_sum_of_hessians(H.data(), J0.data(), Jt.data(), S);
+				for (auto &v : H) { v *= 0.5; }
+				break;
+			case 2: /* SumOfSelf */
+				am->cmpt_self_hessian(H.data(), Jt.data(), S);
+				for (int i = 0; i < S * S; ++i) { H[i] = (H[i] + H0[i]) * 0.5; }
+				break;
+			case 1: am->cmpt_self_hessian(H.data(), Jt.data(), S); break;            /* CurrentSelf */
+			case 5: am->cmpt_curr_hessian(H.data(), Jt.data(), S); break;            /* Std */
+			}
+			double f_now = am->f;
+			vecd H_plain = H;
+			solve_and_negate(delta);
+			prev_corners = ssm->curr_corners;
+			ssm->compositional_update(dp.data());
+			record(f_now, H_plain);
+			if (corner_change() < p.epsilon) break;
+		}
+		return iters;
+	}
+
+	/* nt::FCLK::update SM/src/NT/FCLK.cc:171-358 */
+	int update_fclk() {
+		double prev_sim = 0, delta = p.lm_delta_init;
+		bool state_reset = false;
+		int iters = 0, it = 0;
+		while (it < p.max_iters) {
+			++iters;
+			am->update_pix_vals(ssm->curr_pts.data());
+			am->update_similarity(false);
+			if (p.leven_marq && !state_reset) {
+				double cur = am->f;
+				if (it > 0) {
+					if (cur < prev_sim) {
+						delta *= p.lm_delta_update;
+						ssm->invert_state(inv_dp.data(), dp.data());
+						ssm->compositional_update(inv_dp.data());
+						state_reset = true;
+						continue; /* iter_id is not advanced on a rejected step (while loop, NT/FCLK.cc:187,214) */
+					}
+					if (cur > prev_sim) delta /= p.lm_delta_update;
+				}
+				prev_sim = cur;
+			}
+			state_reset = false;
+			am->update_curr_grad();
+			pix_jacobian_update(Jt.data());
+			am->cmpt_curr_jacobian(g.data(), Jt.data(), S);
+			switch (p.hess_type) {
+			case 0: if (p.leven_marq) H = H0; break;                       /* InitialSelf */
+			case 1: am->cmpt_self_hessian(H.data(), Jt.data(), S); break;   /* CurrentSelf */
+			case 2: am->cmpt_curr_hessian(H.data(), Jt.data(), S); break;   /* Std */
+			}
+			double f_now = am->f;
+			vecd H_plain = H;
+			solve_and_negate(delta);
+			prev_corners = ssm->curr_corners;
+			ssm->compositional_update(dp.data());
+			record(f_now, H_plain);
+			if (corner_change() < p.epsilon) break;
+			++it;
+		}
+		return iters;
+	}
+
+	/* nt::ICLK::update SM/src/NT/ICLK.cc:160-299 */
+	int update_iclk() {
+		double prev_sim = 0, delta = p.lm_delta_init;
+		bool state_reset = false;
+		int iters = 0;
+		for (int it = 0; it < p.max_iters; ++it) {
+			++iters;
+			am->update_pix_vals(ssm->curr_pts.data());
+			am->update_similarity(false);
+			if (p.leven_marq && !state_reset) {
+				double cur = am->f;
+				if (it > 0) {
+					if (cur < prev_sim) {
+						delta *= p.lm_delta_update;
+						ssm->compositional_update(dp.data()); /* undo of the inverse update, NT/ICLK.cc:188 */
+						state_reset = true;
+						continue;
+					}
+					if (cur > prev_sim) delta /= p.lm_delta_update;
+				}
+				prev_sim = cur;
+			}
+			state_reset = false;
+			am->update_init_grad();
+			am->cmpt_init_jacobian(g.data(), J0.data(), S);
+			switch (p.hess_type) {
+			case 0: if (p.leven_marq) H = H0; break;                      /* InitialSelf */
+			case 1: pix_jacobian_update(Jt.data());                         /* CurrentSelf */
+				am->cmpt_self_hessian(H.data(), Jt.data(), S); break;
+			case 2: am->cmpt_init_hessian(H.data(), J0.data(), S); break;  /* Std */
+			}
+			double f_now = am->f;
+			vecd H_plain = H;
+			solve_and_negate(delta);
+			prev_corners = ssm->curr_corners;
+			ssm->invert_state(inv_dp.data(), dp.data());
+			ssm->compositional_update(inv_dp.data());
+			record(f_now, H_plain);
+			if (corner_change() < p.epsilon) break;
+		}
+		return iters;
+	}
+};
+
+/* ===================================================================== */
+/* C API                                                                  */
+/* ===================================================================== */
+extern "C" {
+
+double mtfo_get_pix_val(const float *img, int h, int w, double x, double y) { return pix_val(img, h, w, x, y); }
+void mtfo_get_pix_vals(double *out, const float *img, int h, int w, const double *pts, int n,
+	double norm_mult, double norm_add) { pix_vals(out, img, h, w, pts, n, norm_mult, norm_add); }
+void mtfo_get_img_grad(double *grad, const float *img, int h, int w, const double *pts,
+	double grad_eps, int n, double pix_mult) { img_grad(grad, img, h, w, pts, grad_eps, n, pix_mult); }
+void mtfo_get_warped_img_grad(double *grad, const float *img, int h, int w, const double *grad_pts,
+	double grad_eps, int n, double pix_mult) { warped_img_grad(grad, img, h, w, grad_pts, grad_eps, n, pix_mult); }
+
+void mtfo_homography_dlt(const double *in_corners, const double *out_corners, double *warp9) {
+	Mat3 H = homography_dlt(in_corners, out_corners);
+	std::memcpy(warp9, H.m, sizeof(H.m));
+}
+void mtfo_colpiv_qr_solve(int n, const double *A, const double *b, double *x) { colpiv_qr_solve(n, A, b, x); }
+void mtfo_norm_unit_square_pts(double *pts, double *corners, int resx, int resy,
+	double min_x, double min_y, double max_x, double max_y) {
+	norm_unit_square_pts(pts, corners, resx, resy, min_x, min_y, max_x, max_y);
+}
+
+mtfo_ssm *mtfo_ssm_create(int kind, int resx, int resy) { return new mtfo_ssm(kind, resx, resy); }
+void mtfo_ssm_destroy(mtfo_ssm *s) { delete s; }
+int mtfo_ssm_state_size(const mtfo_ssm *s) { return s->S; }
+int mtfo_ssm_n_pts(const mtfo_ssm *s) { return s->n; }
+void mtfo_ssm_set_corners(mtfo_ssm *s, const double *c) { s->set_corners(c); }
+void mtfo_ssm_set_state(mtfo_ssm *s, const double *p) { s->set_state(p); }
+void mtfo_ssm_compositional_update(mtfo_ssm *s, const double *dp) { s->compositional_update(dp); }
+void mtfo_ssm_invert_state(mtfo_ssm *s, double *inv, const double *p) { s->invert_state(inv, p); }
+void mtfo_ssm_update_grad_pts(mtfo_ssm *s, double eps) { s->update_grad_pts(eps); }
+void mtfo_ssm_cmpt_init_pix_jacobian(mtfo_ssm *s, double *J, const double *g) { s->init_pix_jacobian(J, g); }
+void mtfo_ssm_cmpt_pix_jacobian(mtfo_ssm *s, double *J, const double *g) { s->pix_jacobian(J, g); }
+void mtfo_ssm_cmpt_warped_pix_jacobian(mtfo_ssm *s, double *J, const double *g) { s->warped_pix_jacobian(J, g); }
+void mtfo_ssm_cmpt_approx_pix_jacobian(mtfo_ssm *s, double *J, const double *g) { s->approx_pix_jacobian(J, g); }
+void mtfo_ssm_apply_warp_to_corners(mtfo_ssm *s, double *out, const double *in, const double *p) { s->apply_warp_to_corners(out, in, p); }
+void mtfo_ssm_compositional_random_walk(mtfo_ssm *s, double *out, const double *base, const double *pert) {
+	s->compositional_random_walk(out, base, pert);
+}
+void mtfo_ssm_get(const mtfo_ssm *s, int what, double *dst) {
+	const vecd *v = nullptr;
+	switch (what) {
+	case 0: v = &s->curr_pts; break;
+	case 1: v = &s->init_pts; break;
+	case 2: v = &s->curr_corners; break;
+	case 3: v = &s->init_corners; break;
+	case 4: v = &s->state; break;
+	case 5: std::memcpy(dst, s->curr_warp.m, sizeof(s->curr_warp.m)); return;
+	case 6: v = &s->grad_pts; break;
+	case 7: v = &s->curr_pts_hm; break;
+	case 8: v = &s->init_pts_hm; break;
+	default: return;
+	}
+	std::copy(v->begin(), v->end(), dst);
+}
+
+mtfo_am *mtfo_am_create(int kind, int resx, int resy, double grad_eps, double alpha,
+	int n_bins, double pre_seed, int pou) {
+	return new mtfo_am(kind, resx, resy, grad_eps, alpha, n_bins, pre_seed, pou);
+}
+void mtfo_am_destroy(mtfo_am *a) { delete a; }
+int mtfo_am_n_pix(const mtfo_am *a) { return a->n; }
+void mtfo_am_set_curr_img(mtfo_am *a, const float *img, int h, int w) { a->img = img; a->h = h; a->w = w; }
+void mtfo_am_initialize_pix_vals(mtfo_am *a, const double *pts) { a->initialize_pix_vals(pts); }
+void mtfo_am_update_pix_vals(mtfo_am *a, const double *pts) { a->update_pix_vals(pts); }
+void mtfo_am_initialize_pix_grad_pts(mtfo_am *a, const double *pts) { a->initialize_pix_grad_pts(pts); }
+void mtfo_am_initialize_pix_grad_warped(mtfo_am *a, const double *gp) { a->initialize_pix_grad_warped(gp); }
+void mtfo_am_update_pix_grad_pts(mtfo_am *a, const double *pts) { a->update_pix_grad_pts(pts); }
+void mtfo_am_update_pix_grad_warped(mtfo_am *a, const double *gp) { a->update_pix_grad_warped(gp); }
+void mtfo_am_initialize_similarity(mtfo_am *a) { a->initialize_similarity(); }
+void mtfo_am_initialize_grad(mtfo_am *a) { a->initialize_grad(); }
+void mtfo_am_initialize_hess(mtfo_am *a) { a->initialize_hess(); }
+void mtfo_am_update_similarity(mtfo_am *a, int prereq_only) { a->update_similarity(prereq_only != 0); }
+void mtfo_am_update_curr_grad(mtfo_am *a) { a->update_curr_grad(); }
+void mtfo_am_update_init_grad(mtfo_am *a) { a->update_init_grad(); }
+double mtfo_am_get_similarity(const mtfo_am *a) { return a->f; }
+double mtfo_am_get_likelihood(const mtfo_am *a) { return a->likelihood(); }
+void mtfo_am_cmpt_init_jacobian(mtfo_am *a, double *g, const double *J0, int S) { a->cmpt_init_jacobian(g, J0, S); }
+void mtfo_am_cmpt_curr_jacobian(mtfo_am *a, double *g, const double *Jt, int S) { a->cmpt_curr_jacobian(g, Jt, S); }
+void mtfo_am_cmpt_difference_of_jacobians(mtfo_am *a, double *g, const double *J0, const double *Jt, int S) {
+	a->cmpt_difference_of_jacobians(g, J0, Jt, S);
+}
+void mtfo_am_cmpt_init_hessian(mtfo_am *a, double *H, const double *J0, int S) { a->cmpt_init_hessian(H, J0, S); }
+void mtfo_am_cmpt_curr_hessian(mtfo_am *a, double *H, const double *Jt, int S) { a->cmpt_curr_hessian(H, Jt, S); }
+void mtfo_am_cmpt_self_hessian(mtfo_am *a, double *H, const double *Jt, int S) { a->cmpt_self_hessian(H, Jt, S); }
+void mtfo_am_cmpt_sum_of_hessians(mtfo_am *a, double *H, const double *J0, const double *Jt, int S) {
+	a->cmpt_sum_of_hessians(H, J0, Jt, S);
+}
+void mtfo_am_get(const mtfo_am *a, int what, double *dst) {
+	const vecd *v = nullptr;
+	switch (what) {
+	case 0: v = &a->I0; break;
+	case 1: v = &a->It; break;
+	case 2: v = &a->dI0_dx; break;
+	case 3: v = &a->dIt_dx; break;
+	case 4: v = &a->df_dI0; break;
+	case 5: v = &a->df_dIt; break;
+	default: return;
+	}
+	std::copy(v->begin(), v->end(), dst);
+}
+
+mtfo_tracker *mtfo_tracker_create(int sm_kind, mtfo_am *am, mtfo_ssm *ssm, const mtfo_sm_params *params) {
+	return new mtfo_tracker(sm_kind, am, ssm, *params);
+}
+void mtfo_tracker_destroy(mtfo_tracker *t) { delete t; }
+void mtfo_tracker_initialize(mtfo_tracker *t, const double *corners) { t->initialize(corners); }
+int mtfo_tracker_update(mtfo_tracker *t) { return t->update(); }
+void mtfo_tracker_set_region(mtfo_tracker *t, const double *corners) { t->set_region(corners); }
+void mtfo_tracker_get_region(const mtfo_tracker *t, double *corners) {
+	std::copy(t->ssm->curr_corners.begin(), t->ssm->curr_corners.end(), corners);
+}
+int mtfo_tracker_trace_len(const mtfo_tracker *t) { return t->n_rec; }
+int mtfo_tracker_trace(const mtfo_tracker *t, int iter, double *dst) {
+	if (iter < 0 || iter >= t->n_rec) return 0;
+	std::copy(t->trace.begin() + static_cast<size_t>(iter) * t->rec_len,
+		t->trace.begin() + static_cast<size_t>(iter + 1) * t->rec_len, dst);
+	return t->rec_len;
+}
+
+/* per-particle body of PF<AM,SSM>::update, SM/src/PF.cc:198-278 (likelihood_func = AM):
+ * setState -> updatePixVals -> updateSimilarity(false) -> getLikelihood */
+void mtfo_pf_score(mtfo_am *am, mtfo_ssm *ssm, const double *states, int n_particles,
+	double *likelihoods, double *similarities) {
+	int S = ssm->S;
+	for (int k = 0; k < n_particles; ++k) {
+		ssm->set_state(states + static_cast<size_t>(k) * S);
+		am->update_pix_vals(ssm->curr_pts.data());
+		am->update_similarity(false);
+		if (likelihoods) likelihoods[k] = am->likelihood();
+		if (similarities) similarities[k] = am->f;
+	}
+}
+
+/* PF::binaryMultinomialResampling SM/src/PF.cc:345-394 with the uniforms supplied */
+int mtfo_pf_binary_multinomial_resample(const double *wts, int n, const double *uniforms, int *resample_ids) {
+	vecd cum(n);
+	for (int i = 0; i < n; ++i) cum[i] = wts[i] + (i > 0 ? cum[i - 1] : 0.0);
+	for (int i = 0; i < n; ++i) cum[i] /= cum[n - 1];
+	double max_wt = std::numeric_limits<double>::lowest();
+	int max_wt_id = 0;
+	for (int k = 0; k < n; ++k) {
+		double u = uniforms[k];
+		int lo = 0, hi = n - 1, id = (lo + hi) / 2;
+		while (hi > lo) {
+			if (cum[id] >= u) hi = id; else lo = id + 1;
+			id = (lo + hi) / 2;
+		}
+		resample_ids[k] = id;
+		if (wts[id] >= max_wt) { max_wt = wts[id]; max_wt_id = k; }
+	}
+	return max_wt_id;
+}
+
+} // extern "C"

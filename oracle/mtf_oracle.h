@@ -1,0 +1,149 @@
+/*
+ * mtf_oracle.h -- C API of the CPU parity oracle.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain FP64 CPU restatement of the
+ * Lucas-Kanade hot path of abhineet123/MTF (file:line citations are in
+ * mtf_oracle.cpp next to each function).  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it; the product (libmtfhip.so and
+ * everything under mtf_amd/) never links, imports or calls it.
+ *
+ * PARITY UNPINNED: the reference ships no tests / golden vectors for this path
+ * and cannot be built in this image (Eigen, OpenCV and Boost are absent), so
+ * this restatement is pinned only by (i) line-by-line review against the cited
+ * files, (ii) an independent NumPy float64 re-derivation (oracle/numpy_ref.py,
+ * fixtures under tests/golden/) and (iii) the reference's own Diagnostics
+ * relations (Hessian equalities at identity, analytic-vs-numeric Jacobians).
+ *
+ * Layout conventions follow the reference's Eigen typedefs
+ * (Macros/include/mtf/Macros/common.h:190-258), all column-major:
+ *   pts        2 x N   -> x,y interleaved per point
+ *   grad_pts   8 x N   -> 8 doubles interleaved per point
+ *   pix_grad   N x 2   -> N Ix then N Iy
+ *   J          N x S   -> S contiguous columns of N
+ *   H          S x S   -> column-major
+ *   corners    2 x 4   -> x,y interleaved, TL,TR,BR,BL
+ *   image      H x W float32 row-major, contiguous
+ */
+#ifndef MTF_ORACLE_H
+#define MTF_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MTFO_AM_SSD = 0, MTFO_AM_NCC = 1, MTFO_AM_MI = 2 };
+enum { MTFO_SSM_HOMOGRAPHY = 0, MTFO_SSM_AFFINE = 1 };
+enum { MTFO_SM_ESM = 0, MTFO_SM_FCLK = 1, MTFO_SM_ICLK = 2 };
+
+/* ---- L1 pixel utilities (Utilities/imgUtils) ---- */
+double mtfo_get_pix_val(const float *img, int h, int w, double x, double y);
+void mtfo_get_pix_vals(double *out, const float *img, int h, int w,
+	const double *pts, int n, double norm_mult, double norm_add);
+void mtfo_get_img_grad(double *grad, const float *img, int h, int w,
+	const double *pts, double grad_eps, int n, double pix_mult);
+void mtfo_get_warped_img_grad(double *grad, const float *img, int h, int w,
+	const double *grad_pts, double grad_eps, int n, double pix_mult);
+
+/* ---- small host math the SMs / SSMs use (Eigen in the reference) ---- */
+void mtfo_homography_dlt(const double *in_corners, const double *out_corners,
+	double *warp_rowmajor9);
+/* x = A^-1 b through a column-pivoted Householder QR; A is n x n column-major */
+void mtfo_colpiv_qr_solve(int n, const double *A, const double *b, double *x);
+void mtfo_norm_unit_square_pts(double *pts, double *corners, int resx, int resy,
+	double min_x, double min_y, double max_x, double max_y);
+
+/* ---- state space model ---- */
+typedef struct mtfo_ssm mtfo_ssm;
+mtfo_ssm *mtfo_ssm_create(int kind, int resx, int resy);
+void mtfo_ssm_destroy(mtfo_ssm *s);
+int mtfo_ssm_state_size(const mtfo_ssm *s);
+int mtfo_ssm_n_pts(const mtfo_ssm *s);
+void mtfo_ssm_set_corners(mtfo_ssm *s, const double *corners);
+void mtfo_ssm_set_state(mtfo_ssm *s, const double *state);
+void mtfo_ssm_compositional_update(mtfo_ssm *s, const double *state_update);
+void mtfo_ssm_invert_state(mtfo_ssm *s, double *inv_state, const double *state);
+void mtfo_ssm_update_grad_pts(mtfo_ssm *s, double grad_eps);
+void mtfo_ssm_cmpt_init_pix_jacobian(mtfo_ssm *s, double *J, const double *pix_grad);
+void mtfo_ssm_cmpt_pix_jacobian(mtfo_ssm *s, double *J, const double *pix_grad);
+void mtfo_ssm_cmpt_warped_pix_jacobian(mtfo_ssm *s, double *J, const double *pix_grad);
+void mtfo_ssm_cmpt_approx_pix_jacobian(mtfo_ssm *s, double *J, const double *pix_grad);
+void mtfo_ssm_apply_warp_to_corners(mtfo_ssm *s, double *out_corners,
+	const double *in_corners, const double *state);
+void mtfo_ssm_compositional_random_walk(mtfo_ssm *s, double *perturbed_state,
+	const double *base_state, const double *perturbation);
+/* what: 0 curr_pts(2N) 1 init_pts(2N) 2 curr_corners(8) 3 init_corners(8)
+ *       4 curr_state(S) 5 curr_warp(9,row-major) 6 grad_pts(8N)
+ *       7 curr_pts_hm(3N) 8 init_pts_hm(3N) */
+void mtfo_ssm_get(const mtfo_ssm *s, int what, double *dst);
+
+/* ---- appearance model ---- */
+typedef struct mtfo_am mtfo_am;
+mtfo_am *mtfo_am_create(int kind, int resx, int resy, double grad_eps,
+	double likelihood_alpha, int mi_n_bins, double mi_pre_seed, int mi_pou);
+void mtfo_am_destroy(mtfo_am *a);
+int mtfo_am_n_pix(const mtfo_am *a);
+void mtfo_am_set_curr_img(mtfo_am *a, const float *img, int h, int w);
+void mtfo_am_initialize_pix_vals(mtfo_am *a, const double *pts);
+void mtfo_am_update_pix_vals(mtfo_am *a, const double *pts);
+void mtfo_am_initialize_pix_grad_pts(mtfo_am *a, const double *pts);
+void mtfo_am_initialize_pix_grad_warped(mtfo_am *a, const double *grad_pts);
+void mtfo_am_update_pix_grad_pts(mtfo_am *a, const double *pts);
+void mtfo_am_update_pix_grad_warped(mtfo_am *a, const double *grad_pts);
+void mtfo_am_initialize_similarity(mtfo_am *a);
+void mtfo_am_initialize_grad(mtfo_am *a);
+void mtfo_am_initialize_hess(mtfo_am *a);
+void mtfo_am_update_similarity(mtfo_am *a, int prereq_only);
+void mtfo_am_update_curr_grad(mtfo_am *a);
+void mtfo_am_update_init_grad(mtfo_am *a);
+double mtfo_am_get_similarity(const mtfo_am *a);
+double mtfo_am_get_likelihood(const mtfo_am *a);
+void mtfo_am_cmpt_init_jacobian(mtfo_am *a, double *g, const double *J0, int S);
+void mtfo_am_cmpt_curr_jacobian(mtfo_am *a, double *g, const double *Jt, int S);
+void mtfo_am_cmpt_difference_of_jacobians(mtfo_am *a, double *g,
+	const double *J0, const double *Jt, int S);
+void mtfo_am_cmpt_init_hessian(mtfo_am *a, double *H, const double *J0, int S);
+void mtfo_am_cmpt_curr_hessian(mtfo_am *a, double *H, const double *Jt, int S);
+void mtfo_am_cmpt_self_hessian(mtfo_am *a, double *H, const double *Jt, int S);
+void mtfo_am_cmpt_sum_of_hessians(mtfo_am *a, double *H,
+	const double *J0, const double *Jt, int S);
+/* what: 0 I0 1 It 2 dI0_dx(2N) 3 dIt_dx(2N) 4 df_dI0 5 df_dIt */
+void mtfo_am_get(const mtfo_am *a, int what, double *dst);
+
+/* ---- search methods (NT ESM / FCLK / ICLK) ---- */
+typedef struct mtfo_sm_params {
+	int max_iters;
+	double epsilon;
+	int jac_type;     /* ESM only: 0 Original, 1 DiffOfJacs */
+	int hess_type;    /* per-SM enum, see the reference's *Params.h */
+	int chained_warp;
+	int leven_marq;
+	double lm_delta_init;
+	double lm_delta_update;
+} mtfo_sm_params;
+
+typedef struct mtfo_tracker mtfo_tracker;
+mtfo_tracker *mtfo_tracker_create(int sm_kind, mtfo_am *am, mtfo_ssm *ssm,
+	const mtfo_sm_params *params);
+void mtfo_tracker_destroy(mtfo_tracker *t);
+void mtfo_tracker_initialize(mtfo_tracker *t, const double *corners);
+/* returns the number of iterations executed */
+int mtfo_tracker_update(mtfo_tracker *t);
+void mtfo_tracker_set_region(mtfo_tracker *t, const double *corners);
+void mtfo_tracker_get_region(const mtfo_tracker *t, double *corners);
+/* per-iteration trace of the last update(): each record is
+ * [f, g(S), H(S*S col-major), dp(S), corners(8)] ; returns record length */
+int mtfo_tracker_trace_len(const mtfo_tracker *t);
+int mtfo_tracker_trace(const mtfo_tracker *t, int iter, double *dst);
+
+/* ---- PF scoring (SM/src/PF.cc:198-278, deterministic part) ---- */
+void mtfo_pf_score(mtfo_am *am, mtfo_ssm *ssm, const double *states, int n_particles,
+	double *likelihoods, double *similarities);
+/* binary multinomial resampling given the uniforms (PF.cc:345-394);
+ * writes resampled source index per particle; returns max_wt_id */
+int mtfo_pf_binary_multinomial_resample(const double *wts, int n,
+	const double *uniforms, int *resample_ids);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

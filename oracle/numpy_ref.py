@@ -1,0 +1,176 @@
+"""Independent NumPy float64 re-derivation of the LK hot path (TEST INFRASTRUCTURE ONLY).
+
+Written from the mathematics, not from oracle/mtf_oracle.cpp: vectorised bilinear
+sampling, central-difference image gradients, chain-rule steepest-descent rows,
+Gauss-Newton products through numpy matmul and numpy.linalg.solve.  It exists to
+cross-check the C++ restatement and to generate the small golden fixtures under
+tests/golden/ (tests/golden/make_golden.py).  The reference itself cannot run here
+(Eigen/OpenCV/Boost absent), so these fixtures pin the oracle, not the reference:
+PARITY UNPINNED.
+
+Array conventions here are NumPy-natural: pts (2, N), grad (N, 2), J (N, S), H (S, S).
+"""
+import numpy as np
+
+
+# ------------------------------------------------------------------ sampling
+def bilinear(img, x, y, overflow=128.0):
+    """Bilinear interpolant with the constant-border rule: out-of-range points, or points
+    whose upper neighbour (taken only when the fractional part is non-zero) leaves the
+    image, read `overflow`."""
+    h, w = img.shape
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    out = np.full(x.shape, overflow, dtype=np.float64)
+    ok = (x >= 0) & (x < w) & (y >= 0) & (y < h)
+    xs, ys = np.where(ok, x, 0.0), np.where(ok, y, 0.0)
+    lx, ly = np.trunc(xs).astype(np.int64), np.trunc(ys).astype(np.int64)
+    dx, dy = xs - lx, ys - ly
+    ux = np.where(dx == 0, lx, lx + 1)
+    uy = np.where(dy == 0, ly, ly + 1)
+    ok &= (ux < w) & (uy < h)
+    ux, uy = np.minimum(ux, w - 1), np.minimum(uy, h - 1)
+    im = img.astype(np.float64)
+    v = ((im[ly, lx] * (1 - dx)) * (1 - dy) + (im[ly, ux] * dx) * (1 - dy) +
+         (im[uy, lx] * (1 - dx)) * dy + (im[uy, ux] * dx) * dy)
+    return np.where(ok, v, out)
+
+
+def img_grad(img, pts, eps=1e-8, mult=1.0):
+    """Central difference of the interpolant at the given image points: (N, 2)."""
+    x, y = pts
+    gx = (bilinear(img, x + eps, y) - bilinear(img, x - eps, y)) * (mult / (2 * eps))
+    gy = (bilinear(img, x, y + eps) - bilinear(img, x, y - eps)) * (mult / (2 * eps))
+    return np.stack([gx, gy], axis=1)
+
+
+# ------------------------------------------------------------------ warps
+def hom_matrix(p):
+    return np.array([[1 + p[0], p[1], p[2]], [p[3], 1 + p[4], p[5]], [p[6], p[7], 1.0]])
+
+
+def aff_matrix(p):
+    return np.array([[1 + p[2], p[3], p[0]], [p[4], 1 + p[5], p[1]], [0.0, 0.0, 1.0]])
+
+
+def dlt(src, dst):
+    """Homography taking the 4 src corners (2, 4) to dst (2, 4), h22 = 1."""
+    A, b = [], []
+    for (x, y), (u, v) in zip(src.T, dst.T):
+        A.append([x, y, 1, 0, 0, 0, -u * x, -u * y]); b.append(u)
+        A.append([0, 0, 0, x, y, 1, -v * x, -v * y]); b.append(v)
+    h = np.linalg.solve(np.array(A, dtype=np.float64), np.array(b, dtype=np.float64))
+    return np.append(h, 1.0).reshape(3, 3)
+
+
+def unit_grid(resx, resy, lo_x=-0.5, lo_y=-0.5, hi_x=0.5, hi_y=0.5):
+    xs = np.linspace(lo_x, hi_x, resx)
+    ys = np.linspace(lo_y, hi_y, resy)
+    gx, gy = np.meshgrid(xs, ys)  # row-major: y outer, x inner
+    pts = np.stack([gx.ravel(), gy.ravel()])
+    corners = np.array([[lo_x, hi_x, hi_x, lo_x], [lo_y, lo_y, hi_y, hi_y]])
+    return pts, corners
+
+
+def grid_from_corners(corners, resx, resy, affine=False):
+    """(2, N) sample grid spanned by the corners, plus its un-normalised homogeneous form."""
+    if affine:
+        pts, base = unit_grid(resx, resy, 1 - resx / 2.0, 1 - resy / 2.0, resx / 2.0, resy / 2.0)
+    else:
+        pts, base = unit_grid(resx, resy)
+    W = dlt(base, corners)
+    hm = W @ np.vstack([pts, np.ones(pts.shape[1])])
+    return hm[:2] / hm[2], hm
+
+
+def warp_pts(W, pts_hm):
+    q = W @ pts_hm
+    return q[:2] / q[2], q
+
+
+# ------------------------------------------------------------------ steepest-descent rows
+def hom_param_jacobian(x, y):
+    """d(Delta W)(x) / d(Delta p) at Delta p = 0 for the 8-dof homography: (N, 2, 8)."""
+    z, o = np.zeros_like(x), np.ones_like(x)
+    r0 = np.stack([x, y, o, z, z, z, -x * x, -x * y], axis=1)
+    r1 = np.stack([z, z, z, x, y, o, -x * y, -y * y], axis=1)
+    return np.stack([r0, r1], axis=1)
+
+
+def aff_param_jacobian(x, y):
+    z, o = np.zeros_like(x), np.ones_like(x)
+    r0 = np.stack([o, z, x, y, z, z], axis=1)
+    r1 = np.stack([z, o, z, z, x, y], axis=1)
+    return np.stack([r0, r1], axis=1)
+
+
+def hom_spatial_jacobian(W, wpts, D):
+    """dW(x)/dx of the projective map at each point: (N, 2, 2).
+    D is the third homogeneous coordinate as the caller holds it."""
+    wx, wy = wpts
+    J = np.empty((wx.size, 2, 2))
+    J[:, 0, 0] = (W[0, 0] - W[2, 0] * wx) / D
+    J[:, 0, 1] = (W[0, 1] - W[2, 1] * wx) / D
+    J[:, 1, 0] = (W[1, 0] - W[2, 0] * wy) / D
+    J[:, 1, 1] = (W[1, 1] - W[2, 1] * wy) / D
+    return J
+
+
+def sd_rows_chained(grad, spatial_jac, param_jac):
+    """dI/dp = grad(I)(w)^T . dW/dx . d(Delta W)/d(Delta p): (N, S)."""
+    g = np.einsum("ni,nij->nj", grad, spatial_jac)
+    return np.einsum("nj,njs->ns", g, param_jac)
+
+
+def sd_rows_direct(grad, param_jac):
+    return np.einsum("nj,njs->ns", grad, param_jac)
+
+
+# ------------------------------------------------------------------ similarity measures
+def ssd(I0, It):
+    r = It - I0
+    return dict(f=-0.5 * float(r @ r), df_dI0=r, df_dIt=-r)
+
+
+def ncc(I0, It):
+    a0, at = I0 - I0.mean(), It - It.mean()
+    c, b = np.linalg.norm(a0), np.linalg.norm(at)
+    f = float(a0 @ at) / (b * c)
+    u0, ut = a0 / c, at / b
+    dIt = (u0 - f * ut) / b
+    dI0 = (ut - f * u0) / c
+    return dict(f=f, b=b, c=c, u0=u0, ut=ut, df_dIt=dIt - dIt.mean(), df_dI0=dI0 - dI0.mean())
+
+
+def ncc_self_hessian(J, m):
+    Jc = (J - J.mean(axis=0)) / m["b"]
+    v = Jc.T @ m["ut"]
+    return -Jc.T @ Jc + np.outer(v, v)
+
+
+# ------------------------------------------------------------------ one LK step (chained warp)
+def lk_step_hom_ssd(img, init_pts, init_hm, W, I0, J0=None, mode="fclk", eps=1e-8):
+    """One chained-warp Gauss-Newton step for SSD + homography.
+
+    mode 'fclk': g = -r^T Jt,            H = -Jt^T Jt
+    mode 'esm' : g = -r^T (J0 + Jt) / 2, H = -(Jt^T Jt + J0^T J0) / 2   (DiffOfJacs + SumOfSelf)
+    Returns dict with It, grad, Jt, f, g, H, dp.
+    """
+    wpts, q = warp_pts(W, init_hm)
+    It = bilinear(img, wpts[0], wpts[1])
+    grad = img_grad(img, wpts, eps)
+    Jt = sd_rows_chained(grad, hom_spatial_jacobian(W, wpts, q[2]), hom_param_jacobian(init_pts[0], init_pts[1]))
+    m = ssd(I0, It)
+    if mode == "fclk":
+        g = m["df_dIt"] @ Jt
+        H = -Jt.T @ Jt
+    else:
+        g = 0.5 * (m["df_dIt"] @ (J0 + Jt))
+        H = 0.5 * (-Jt.T @ Jt - J0.T @ J0)
+    dp = -np.linalg.solve(H, g)
+    return dict(It=It, grad=grad, Jt=Jt, f=m["f"], g=g, H=H, dp=dp, wpts=wpts)
+
+
+def compose_hom(W, dp):
+    Wn = W @ hom_matrix(dp)
+    return Wn / Wn[2, 2]

@@ -1,0 +1,373 @@
+"""ctypes binding of the CPU parity oracle (oracle/libmtf_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under mtf_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmtf_oracle.so")
+
+AM_SSD, AM_NCC, AM_MI = 0, 1, 2
+SSM_HOM, SSM_AFF = 0, 1
+SM_ESM, SM_FCLK, SM_ICLK = 0, 1, 2
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+
+
+class SMParams(C.Structure):
+    _fields_ = [("max_iters", C.c_int), ("epsilon", C.c_double), ("jac_type", C.c_int),
+                ("hess_type", C.c_int), ("chained_warp", C.c_int), ("leven_marq", C.c_int),
+                ("lm_delta_init", C.c_double), ("lm_delta_update", C.c_double)]
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "mtf_oracle.cpp")):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libmtf_oracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.mtfo_get_pix_val.restype = C.c_double
+        _lib.mtfo_get_pix_val.argtypes = [_fp, C.c_int, C.c_int, C.c_double, C.c_double]
+        _lib.mtfo_am_get_similarity.restype = C.c_double
+        _lib.mtfo_am_get_likelihood.restype = C.c_double
+        for name in ("mtfo_ssm_create", "mtfo_am_create", "mtfo_tracker_create"):
+            getattr(_lib, name).restype = C.c_void_p
+        _lib.mtfo_ssm_create.argtypes = [C.c_int, C.c_int, C.c_int]
+        _lib.mtfo_am_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                        C.c_int, C.c_double, C.c_int]
+        _lib.mtfo_tracker_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.POINTER(SMParams)]
+    return _lib
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _f(a):
+    return a.ctypes.data_as(_fp)
+
+
+def _vec(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float64).ravel())
+
+
+def pts_to_flat(pts):
+    """2 x N array -> interleaved x,y (Eigen column-major Matrix2Xd)."""
+    return np.ascontiguousarray(np.asarray(pts, dtype=np.float64).T.ravel())
+
+
+# ---------------------------------------------------------------- free functions
+def get_pix_val(img, x, y):
+    h, w = img.shape
+    return lib().mtfo_get_pix_val(_f(img), h, w, float(x), float(y))
+
+
+def get_pix_vals(img, pts_flat, mult=1.0, add=0.0):
+    h, w = img.shape
+    n = pts_flat.size // 2
+    out = np.empty(n)
+    lib().mtfo_get_pix_vals(_d(out), _f(img), h, w, _d(pts_flat), n, C.c_double(mult), C.c_double(add))
+    return out
+
+
+def get_img_grad(img, pts_flat, eps=1e-8, mult=1.0):
+    h, w = img.shape
+    n = pts_flat.size // 2
+    out = np.empty(2 * n)
+    lib().mtfo_get_img_grad(_d(out), _f(img), h, w, _d(pts_flat), C.c_double(eps), n, C.c_double(mult))
+    return out
+
+
+def get_warped_img_grad(img, grad_pts_flat, eps=1e-8, mult=1.0):
+    h, w = img.shape
+    n = grad_pts_flat.size // 8
+    out = np.empty(2 * n)
+    lib().mtfo_get_warped_img_grad(_d(out), _f(img), h, w, _d(grad_pts_flat), C.c_double(eps), n,
+                                   C.c_double(mult))
+    return out
+
+
+def homography_dlt(in_corners, out_corners):
+    a, b = pts_to_flat(in_corners), pts_to_flat(out_corners)
+    out = np.empty(9)
+    lib().mtfo_homography_dlt(_d(a), _d(b), _d(out))
+    return out.reshape(3, 3)
+
+
+def colpiv_qr_solve(A, b):
+    A = np.asarray(A, dtype=np.float64)
+    n = A.shape[0]
+    Af = np.ascontiguousarray(A.T.ravel())  # column-major
+    bb = _vec(b)
+    x = np.empty(n)
+    lib().mtfo_colpiv_qr_solve(n, _d(Af), _d(bb), _d(x))
+    return x
+
+
+# ---------------------------------------------------------------- objects
+class SSM:
+    GET = {"curr_pts": (0, 2), "init_pts": (1, 2), "curr_corners": (2, None), "init_corners": (3, None),
+           "state": (4, None), "curr_warp": (5, None), "grad_pts": (6, 8), "curr_pts_hm": (7, 3),
+           "init_pts_hm": (8, 3)}
+
+    def __init__(self, kind, resx, resy):
+        self.kind, self.resx, self.resy = kind, resx, resy
+        self.n = resx * resy
+        self.S = 8 if kind == SSM_HOM else 6
+        self.h = C.c_void_p(lib().mtfo_ssm_create(kind, resx, resy))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().mtfo_ssm_destroy(self.h)
+            self.h = None
+
+    def get(self, what):
+        code, per_pt = self.GET[what]
+        size = {2: 8, 3: 8, 4: self.S, 5: 9}.get(code, (per_pt or 0) * self.n)
+        out = np.empty(size)
+        lib().mtfo_ssm_get(self.h, code, _d(out))
+        return out
+
+    def set_corners(self, corners):
+        c = pts_to_flat(corners)
+        lib().mtfo_ssm_set_corners(self.h, _d(c))
+
+    def set_state(self, p):
+        p = _vec(p)
+        lib().mtfo_ssm_set_state(self.h, _d(p))
+
+    def compositional_update(self, dp):
+        dp = _vec(dp)
+        lib().mtfo_ssm_compositional_update(self.h, _d(dp))
+
+    def invert_state(self, p):
+        p = _vec(p)
+        out = np.empty(self.S)
+        lib().mtfo_ssm_invert_state(self.h, _d(out), _d(p))
+        return out
+
+    def update_grad_pts(self, eps):
+        lib().mtfo_ssm_update_grad_pts(self.h, C.c_double(eps))
+
+    def _jac(self, fn, grad):
+        grad = _vec(grad)
+        J = np.empty(self.n * self.S)
+        fn(self.h, _d(J), _d(grad))
+        return J
+
+    def cmpt_init_pix_jacobian(self, grad):
+        return self._jac(lib().mtfo_ssm_cmpt_init_pix_jacobian, grad)
+
+    def cmpt_pix_jacobian(self, grad):
+        return self._jac(lib().mtfo_ssm_cmpt_pix_jacobian, grad)
+
+    def cmpt_warped_pix_jacobian(self, grad):
+        return self._jac(lib().mtfo_ssm_cmpt_warped_pix_jacobian, grad)
+
+    def cmpt_approx_pix_jacobian(self, grad):
+        return self._jac(lib().mtfo_ssm_cmpt_approx_pix_jacobian, grad)
+
+    def apply_warp_to_corners(self, corners, p):
+        c, p = pts_to_flat(corners), _vec(p)
+        out = np.empty(8)
+        lib().mtfo_ssm_apply_warp_to_corners(self.h, _d(out), _d(c), _d(p))
+        return out.reshape(4, 2).T
+
+    def compositional_random_walk(self, base, pert):
+        base, pert = _vec(base), _vec(pert)
+        out = np.empty(self.S)
+        lib().mtfo_ssm_compositional_random_walk(self.h, _d(out), _d(base), _d(pert))
+        return out
+
+
+class AM:
+    GET = {"I0": (0, 1), "It": (1, 1), "dI0_dx": (2, 2), "dIt_dx": (3, 2), "df_dI0": (4, 1), "df_dIt": (5, 1)}
+
+    def __init__(self, kind, resx, resy, grad_eps=1e-8, likelihood_alpha=1.0, n_bins=8, pre_seed=10.0, pou=0):
+        self.kind, self.resx, self.resy = kind, resx, resy
+        self.n = resx * resy
+        self.h = C.c_void_p(lib().mtfo_am_create(kind, resx, resy, grad_eps, likelihood_alpha,
+                                                 n_bins, pre_seed, pou))
+        self._img = None
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().mtfo_am_destroy(self.h)
+            self.h = None
+
+    def set_curr_img(self, img):
+        assert img.dtype == np.float32 and img.flags["C_CONTIGUOUS"]
+        self._img = img  # the oracle borrows the buffer, as ImageBase::setCurrImg does
+        lib().mtfo_am_set_curr_img(self.h, _f(img), img.shape[0], img.shape[1])
+
+    def get(self, what):
+        code, per = self.GET[what]
+        out = np.empty(per * self.n)
+        lib().mtfo_am_get(self.h, code, _d(out))
+        return out
+
+    def _call_pts(self, fn, arr):
+        arr = _vec(arr)
+        fn(self.h, _d(arr))
+
+    def initialize_pix_vals(self, pts):
+        self._call_pts(lib().mtfo_am_initialize_pix_vals, pts)
+
+    def update_pix_vals(self, pts):
+        self._call_pts(lib().mtfo_am_update_pix_vals, pts)
+
+    def initialize_pix_grad_pts(self, pts):
+        self._call_pts(lib().mtfo_am_initialize_pix_grad_pts, pts)
+
+    def initialize_pix_grad_warped(self, gp):
+        self._call_pts(lib().mtfo_am_initialize_pix_grad_warped, gp)
+
+    def update_pix_grad_pts(self, pts):
+        self._call_pts(lib().mtfo_am_update_pix_grad_pts, pts)
+
+    def update_pix_grad_warped(self, gp):
+        self._call_pts(lib().mtfo_am_update_pix_grad_warped, gp)
+
+    def initialize_similarity(self):
+        lib().mtfo_am_initialize_similarity(self.h)
+
+    def initialize_grad(self):
+        lib().mtfo_am_initialize_grad(self.h)
+
+    def initialize_hess(self):
+        lib().mtfo_am_initialize_hess(self.h)
+
+    def update_similarity(self, prereq_only=False):
+        lib().mtfo_am_update_similarity(self.h, int(prereq_only))
+
+    def update_curr_grad(self):
+        lib().mtfo_am_update_curr_grad(self.h)
+
+    def update_init_grad(self):
+        lib().mtfo_am_update_init_grad(self.h)
+
+    @property
+    def similarity(self):
+        return lib().mtfo_am_get_similarity(self.h)
+
+    @property
+    def likelihood(self):
+        return lib().mtfo_am_get_likelihood(self.h)
+
+    def _g(self, fn, *Js):
+        Js = [_vec(J) for J in Js]
+        S = Js[0].size // self.n
+        g = np.empty(S)
+        fn(self.h, _d(g), *[_d(J) for J in Js], S)
+        return g
+
+    def _H(self, fn, *Js):
+        Js = [_vec(J) for J in Js]
+        S = Js[0].size // self.n
+        H = np.empty(S * S)
+        fn(self.h, _d(H), *[_d(J) for J in Js], S)
+        return H.reshape(S, S).T  # column-major -> [r, c]
+
+    def cmpt_init_jacobian(self, J0):
+        return self._g(lib().mtfo_am_cmpt_init_jacobian, J0)
+
+    def cmpt_curr_jacobian(self, Jt):
+        return self._g(lib().mtfo_am_cmpt_curr_jacobian, Jt)
+
+    def cmpt_difference_of_jacobians(self, J0, Jt):
+        return self._g(lib().mtfo_am_cmpt_difference_of_jacobians, J0, Jt)
+
+    def cmpt_init_hessian(self, J0):
+        return self._H(lib().mtfo_am_cmpt_init_hessian, J0)
+
+    def cmpt_curr_hessian(self, Jt):
+        return self._H(lib().mtfo_am_cmpt_curr_hessian, Jt)
+
+    def cmpt_self_hessian(self, Jt):
+        return self._H(lib().mtfo_am_cmpt_self_hessian, Jt)
+
+    def cmpt_sum_of_hessians(self, J0, Jt):
+        return self._H(lib().mtfo_am_cmpt_sum_of_hessians, J0, Jt)
+
+
+def sm_params(sm_kind, **kw):
+    """Class defaults of the reference's parameter structs (SM/src/ESMParams.cc:4-15,
+    FCLKParams.cc:4-17, ICLKParams.cc:4-14)."""
+    base = dict(max_iters=30, epsilon=1e-4, jac_type=1, hess_type={SM_ESM: 2, SM_FCLK: 1, SM_ICLK: 0}[sm_kind],
+                chained_warp=1, leven_marq=1, lm_delta_init=0.01, lm_delta_update=10.0)
+    base.update(kw)
+    return SMParams(**base)
+
+
+class Tracker:
+    def __init__(self, sm_kind, am, ssm, params=None, **kw):
+        self.am, self.ssm, self.sm_kind = am, ssm, sm_kind
+        self.params = params if params is not None else sm_params(sm_kind, **kw)
+        self.S = ssm.S
+        self.h = C.c_void_p(lib().mtfo_tracker_create(sm_kind, am.h, ssm.h, C.byref(self.params)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().mtfo_tracker_destroy(self.h)
+            self.h = None
+
+    def initialize(self, corners):
+        c = pts_to_flat(corners)
+        lib().mtfo_tracker_initialize(self.h, _d(c))
+
+    def update(self):
+        return lib().mtfo_tracker_update(self.h)
+
+    def set_region(self, corners):
+        c = pts_to_flat(corners)
+        lib().mtfo_tracker_set_region(self.h, _d(c))
+
+    def get_region(self):
+        out = np.empty(8)
+        lib().mtfo_tracker_get_region(self.h, _d(out))
+        return out.reshape(4, 2).T
+
+    def trace(self):
+        """list of dicts f, g, H, dp, corners for each executed (non-rejected) iteration"""
+        S = self.S
+        n = lib().mtfo_tracker_trace_len(self.h)
+        rec = np.empty(1 + S + S * S + S + 8)
+        out = []
+        for i in range(n):
+            lib().mtfo_tracker_trace(self.h, i, _d(rec))
+            out.append(dict(f=rec[0], g=rec[1:1 + S].copy(),
+                            H=rec[1 + S:1 + S + S * S].reshape(S, S).T.copy(),
+                            dp=rec[1 + S + S * S:1 + 2 * S + S * S].copy(),
+                            corners=rec[1 + 2 * S + S * S:].reshape(4, 2).T.copy()))
+        return out
+
+
+def pf_score(am, ssm, states):
+    states = np.ascontiguousarray(np.asarray(states, dtype=np.float64))
+    n = states.shape[0]
+    lik, sim = np.empty(n), np.empty(n)
+    lib().mtfo_pf_score(am.h, ssm.h, _d(states), n, _d(lik), _d(sim))
+    return lik, sim
+
+
+def pf_binary_multinomial_resample(wts, uniforms):
+    wts, uniforms = _vec(wts), _vec(uniforms)
+    ids = np.empty(wts.size, dtype=np.int32)
+    mx = lib().mtfo_pf_binary_multinomial_resample(_d(wts), wts.size, _d(uniforms), ids.ctypes.data_as(_ip))
+    return ids, mx
