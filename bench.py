@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""bench.py -- LK iterations/s of the fused hot path on MI355X (driver contract).
+
+Workload (BASELINE.json metric): ESM + SSD + Homography, 200x200 sample points per target.
+One "step" = one Lucas-Kanade iteration of every target resident on the GPU: the fused
+warp -> bilinear sample -> finite-difference gradient -> steepest-descent row -> J^T r / J^T J
+kernel, the fixed-order partial reduction, and the 8x8 solve + compositional update + corner test,
+all on the device with no host round trip (mtfhip_batch_track).  A single target does not shard
+(SURVEY.md 8e), so N GPUs run N independent replicas of the per-GPU target set: weak scaling, no
+data-path collective.  Inputs (frame, templates, warps) are resident in HBM before the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_pixel(sm, materialize, unit_z=True):
+    """Interface-level traffic per sample point of one LK iteration:
+    image texels 4 (1:1 sampling) + I0 8 + init_pts 16 (+8 init_z for non-parallelogram corners)
+    [+ J0 64 read for ESM / ICLK] [+ It 8 + dIt_dx 16 + Jt 64 written when materialised]."""
+    b = 4 + 8 + 16 + (0 if unit_z else 8)
+    if sm in ("esm", "iclk"):
+        b += 64
+    if materialize:
+        b += 8 + (0 if sm == "iclk" else 16 + 64)
+    return b
+
+
+def cpu_baseline(seconds, res, frame0, frame1, corners):
+    """The CPU oracle (a port of the reference's ESM loop) timed on one host core on the same
+    workload shape: LK iterations/s of a single 200x200 ESM+SSD+Homography target."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    ssm = O.SSM(O.SSM_HOM, res, res)
+    am = O.AM(O.AM_SSD, res, res)
+    am.set_curr_img(frame0)
+    trk = O.Tracker(O.SM_ESM, am, ssm, leven_marq=0, max_iters=10, epsilon=-1.0)
+    trk.initialize(corners)
+    am.set_curr_img(frame1)
+    trk.update()  # warm
+    iters, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        ssm.set_corners(corners)   # back to the initial region; template, J0 and H0 stay
+        iters += trk.update()
+    dt = time.perf_counter() - t0
+    return {"value": iters / dt, "unit": "iters/s", "cores": 1, "kind": "port",
+            "sample": "%d ESM iterations of one %dx%d target in %.1f s (oracle/mtf_oracle.cpp, -O3, 1 thread)" % (iters, res, res, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--targets", type=int, default=64, help="targets per GPU (each 200x200)")
+    ap.add_argument("--res", type=int, default=200)
+    ap.add_argument("--sm", default="esm", choices=["esm", "fclk", "iclk"])
+    ap.add_argument("--mode", default="full", choices=["full", "lean"],
+                    help="full: It, dIt_dx, Jt materialised in HBM as the AM/SSM interface exposes them; lean: registers only")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import mtf_amd
+    from mtf_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    res, B = args.res, args.targets
+    H = W = 1024
+    frame0 = synth.make_frame(H, W)
+    rng = np.random.default_rng(synth.DEFAULT_SEED + 1)
+    p_true = synth.random_small_homography(rng, 0.5)
+    frame1 = synth.warp_frame(frame0, p_true, (W / 2.0, H / 2.0))
+    # B target regions of res x res pixels (1:1 sampling) spread over the frame
+    half = res / 2.0 + 12
+    cx = rng.uniform(half, W - half, size=B)
+    cy = rng.uniform(half, H - half, size=B)
+    corners = np.stack([synth.square_corners(cx[i], cy[i], float(res)) for i in range(B)])
+
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ctx = mtf_amd.Context(local_rank, stream)
+    f0 = torch.from_numpy(frame0).to(dev)
+    f1 = torch.from_numpy(frame1).to(dev)
+    sm_kind = {"esm": mtf_amd.SM_ESM, "fclk": mtf_amd.SM_FCLK, "iclk": mtf_amd.SM_ICLK}[args.sm]
+    materialize = 1 if args.mode == "full" else 0
+    batch = mtf_amd.Batch(ctx, mtf_amd.AM_SSD, mtf_amd.SSM_HOMOGRAPHY, res, res, B)
+    batch.set_corners(corners)
+    ctx.set_image_device(f0.data_ptr(), H, W, keep=f0)
+    sm = mtf_amd.sm_desc(sm_kind, materialize=materialize, leven_marq=0, epsilon=-1.0, max_iters=1)
+    batch.init_template(sm)
+    ctx.set_image_device(f1.data_ptr(), H, W, keep=f1)
+
+    def run(n_iters):
+        sm.max_iters = n_iters
+        batch.set_corners(corners)      # restart every target from its initial region
+        return batch.track(sm)
+
+    run(max(1, args.warmup))
+    torch.cuda.synchronize(dev)
+    ctx.timing(True)
+    ctx.timing_reset()
+    batch.set_corners(corners)
+    sm.max_iters = args.steps
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    n_it, final = batch.track(sm)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    assert int(n_it.min()) == args.steps and int(n_it.max()) == args.steps
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    kern_ms, kern_n = ctx.timing_get("fused_lk")
+    ctx.timing(False)
+
+    if rank == 0:
+        N = res * res
+        bpp = algorithmic_bytes_per_pixel(args.sm, materialize)
+        bytes_per_launch = float(bpp) * N * B
+        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        out = {
+            "metric": "LK iters/sec (warp+grad+Hessian), ESM+SSD+Homography 200x200",
+            "value": B * world * args.steps / dt,
+            "unit": "iters/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s+SSD+Homography %dx%d, %d independent targets per GPU, %s mode, solve+update on device"
+                                   % (args.sm.upper(), res, res, B, args.mode),
+                       "targets_per_gpu": B, "n_pix": N, "mode": args.mode, "frame": "%dx%d float32" % (H, W),
+                       "parallelism": "replicas x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_fused_ssd", "avg_kernel_ms": kern_ms, "launches_timed": kern_n,
+                         "algorithmic_bytes_per_pixel": bpp, "bytes_per_launch": bytes_per_launch},
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, res, frame0, frame1, corners[0])
+        elif not args.no_cpu:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

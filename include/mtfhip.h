@@ -1,0 +1,208 @@
+/*
+ * mtfhip.h -- C ABI of libmtfhip.so: the MI355X (gfx950) implementation of MTF's
+ * Lucas-Kanade inner loop (sample -> image gradient -> steepest-descent image ->
+ * J^T r / J^T J), behind the reference's AppearanceModel / StateSpaceModel boundary.
+ *
+ * The reference (abhineet123/MTF) has no FFI or plugin ABI: its extension mechanism is
+ * C++ subclassing of mtf::AppearanceModel (AM/include/mtf/AM/AppearanceModel.h:63-396,
+ * ImageBase.h:51-191) and mtf::StateSpaceModel (SSM/include/mtf/SSM/StateSpaceModel.h:49-408).
+ * Each entry point below is what one of those virtuals becomes once its data lives in HBM;
+ * the adapter subclasses in mtf_amd/host/ (and the maintainer-side stub in INTEGRATION.md)
+ * forward to them one-to-one.  Plain C types only, caller owns every host buffer, handles
+ * own all device memory, every call returns 0 on success or a negative mtfhip_status
+ * (text via mtfhip_last_error(); the adapters rethrow it as mtf::utils::Exception,
+ * Utilities/include/mtf/Utilities/excpUtils.h:8-55).
+ *
+ * One handle type covers a single target and a batch: a `mtfhip_batch` holds B independent
+ * targets (each with its own template, warp and N = resx*resy sample points) that share the
+ * current image -- B = 1 is the AM/SSM pair of one tracker, B = 256 is GridTracker's patch
+ * set (SM/src/GridTracker.cc:247-261), B = n_trackers is runMTF's concurrent targets.
+ *
+ * Host-side array layouts are the reference's Eigen column-major typedefs
+ * (Macros/include/mtf/Macros/common.h:190-258), target-major when B > 1:
+ *   pts 2xN (x,y interleaved) | grad_pts 8xN | pix_grad Nx2 (N Ix then N Iy)
+ *   J NxS (S columns of N)    | H SxS column-major | corners 2x4 (TL,TR,BR,BL, x,y interleaved)
+ * All arithmetic is IEEE double except the float32 image, exactly as in the reference.
+ */
+#ifndef MTFHIP_H
+#define MTFHIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mtfhip_ctx mtfhip_ctx;
+typedef struct mtfhip_batch mtfhip_batch;
+
+typedef enum mtfhip_status {
+	MTFHIP_OK = 0,
+	MTFHIP_ERR_INVALID_ARG = -1,   /* mtf::utils::InvalidArgument */
+	MTFHIP_ERR_NOT_IMPLEMENTED = -2, /* mtf::utils::FunctonNotImplemented */
+	MTFHIP_ERR_LOGIC = -3,         /* mtf::utils::LogicError (call order) */
+	MTFHIP_ERR_HIP = -4,           /* HIP runtime failure */
+	MTFHIP_ERR_NO_DEVICE = -5
+} mtfhip_status;
+
+enum { MTFHIP_AM_SSD = 0, MTFHIP_AM_NCC = 1, MTFHIP_AM_MI = 2 };
+enum { MTFHIP_SSM_HOMOGRAPHY = 0, MTFHIP_SSM_AFFINE = 1 };
+enum { MTFHIP_SM_ESM = 0, MTFHIP_SM_FCLK = 1, MTFHIP_SM_ICLK = 2 };
+/* pixel-Jacobian variants of StateSpaceModel.h:170-181 */
+enum { MTFHIP_JAC_INIT = 0, MTFHIP_JAC_PIX = 1, MTFHIP_JAC_WARPED = 2, MTFHIP_JAC_APPROX = 3 };
+/* device-resident buffers of a batch (per target sizes in doubles) */
+enum {
+	MTFHIP_BUF_I0 = 0,       /* N      ImageBase::I0 */
+	MTFHIP_BUF_IT = 1,       /* N      ImageBase::It */
+	MTFHIP_BUF_DI0_DX = 2,   /* N x 2  ImageBase::dI0_dx */
+	MTFHIP_BUF_DIT_DX = 3,   /* N x 2  ImageBase::dIt_dx */
+	MTFHIP_BUF_DF_DI0 = 4,   /* N      AppearanceModel::df_dI0 */
+	MTFHIP_BUF_DF_DIT = 5,   /* N      AppearanceModel::df_dIt */
+	MTFHIP_BUF_J0 = 6,       /* N x S  the SM's init_pix_jacobian / dI0_dpssm */
+	MTFHIP_BUF_JT = 7,       /* N x S  the SM's curr_pix_jacobian / dIt_dpssm */
+	MTFHIP_BUF_JM = 8,       /* N x S  the SM's mean_pix_jacobian (ESM jac/hess type Original) */
+	MTFHIP_BUF_INIT_PTS = 9, /* 2 x N  StateSpaceModel::init_pts */
+	MTFHIP_BUF_CURR_PTS = 10,/* 2 x N  StateSpaceModel::curr_pts */
+	MTFHIP_BUF_GRAD_PTS = 11,/* 8 x N  StateSpaceModel::grad_pts */
+	MTFHIP_BUF_INIT_Z = 12,  /* N      third row of ProjectiveBase::init_pts_hm */
+	MTFHIP_BUF_CURR_Z = 13,  /* N      third row of ProjectiveBase::curr_pts_hm */
+	MTFHIP_BUF_COUNT = 14
+};
+
+typedef struct mtfhip_patch_desc {
+	int am;                 /* MTFHIP_AM_* */
+	int ssm;                /* MTFHIP_SSM_* */
+	int resx, resy;         /* ImgParams / SSMParams resx, resy */
+	double grad_eps;        /* ImgParams::grad_eps (1e-8, AM/include/mtf/AM/ImageBase.h:7-8) */
+	double likelihood_alpha;/* AMParams::likelihood_alpha */
+	int mi_n_bins;          /* MIParams::n_bins */
+	double mi_pre_seed;     /* MIParams::pre_seed */
+	int mi_partition_of_unity;
+} mtfhip_patch_desc;
+
+/* Search-method configuration; field meanings and enum values are the reference's
+ * (SM/include/mtf/SM/ESMParams.h:13-17, FCLKParams.h:8, ICLKParams.h) */
+typedef struct mtfhip_sm_desc {
+	int sm;            /* MTFHIP_SM_* */
+	int jac_type;      /* ESM: 0 Original, 1 DiffOfJacs */
+	int hess_type;     /* ESM: 0 InitialSelf 1 CurrentSelf 2 SumOfSelf 3 Original 4 SumOfStd 5 Std
+	                      FCLK/ICLK: 0 InitialSelf 1 CurrentSelf 2 Std */
+	int chained_warp;
+	int materialize;   /* 1: It, dIt_dx and Jt are written to HBM as the interface exposes them;
+	                      0: kept in registers only (getters for them then fail with ERR_LOGIC) */
+	int max_iters;     /* used by mtfhip_batch_track only */
+	double epsilon;
+	int leven_marq;
+	double lm_delta_init, lm_delta_update;
+} mtfhip_sm_desc;
+
+/* ------------------------------------------------------------------ context */
+const char *mtfhip_last_error(void);
+int mtfhip_device_count(void);
+/* `hip_stream` is a hipStream_t (or NULL for a stream owned by the context) */
+int mtfhip_ctx_create(int device, void *hip_stream, mtfhip_ctx **out);
+void mtfhip_ctx_destroy(mtfhip_ctx *ctx);
+int mtfhip_ctx_synchronize(mtfhip_ctx *ctx);
+void *mtfhip_ctx_stream(mtfhip_ctx *ctx);
+
+/* ImageBase::setCurrImg (AM/src/ImageBase.cc:38-60).  The reference borrows the caller's
+ * cv::Mat buffer, which the caller overwrites in place every frame, so upload must be
+ * repeated per frame; `borrow` adopts a float32 image that is already in HBM. */
+int mtfhip_image_upload(mtfhip_ctx *ctx, const float *host_img, int height, int width, int row_stride);
+int mtfhip_image_borrow(mtfhip_ctx *ctx, const float *dev_img, int height, int width, int row_stride);
+
+/* ------------------------------------------------------------------ batch of targets */
+int mtfhip_batch_create(mtfhip_ctx *ctx, const mtfhip_patch_desc *desc, int n_targets, mtfhip_batch **out);
+void mtfhip_batch_destroy(mtfhip_batch *b);
+int mtfhip_batch_n_targets(const mtfhip_batch *b);
+int mtfhip_batch_n_pix(const mtfhip_batch *b);
+int mtfhip_batch_state_size(const mtfhip_batch *b);
+/* lazy read-back / overwrite of a device buffer (all targets, target-major);
+ * the getters of ImageBase.h:83-89 / setters :93-100 and StateSpaceModel.h:82-88 */
+int mtfhip_batch_read(mtfhip_batch *b, int buf, double *dst);
+int mtfhip_batch_write(mtfhip_batch *b, int buf, const double *src);
+/* raw device pointer of a buffer, for zero-copy interop (torch / RCCL) */
+void *mtfhip_batch_device_ptr(mtfhip_batch *b, int buf);
+
+/* ---- StateSpaceModel side ---- */
+/* setCorners / initialize: Homography.cc:50-71, Affine.cc:64-88 (normalized_init = false) */
+int mtfhip_ssm_set_corners(mtfhip_batch *b, const double *corners /* B x 8 */);
+/* setState: ProjectiveBase.cc:41-49, Affine.cc:108-114 */
+int mtfhip_ssm_set_state(mtfhip_batch *b, const double *states /* B x S */);
+/* compositionalUpdate: Homography.cc:73-92, Affine.cc:90-106 */
+int mtfhip_ssm_compositional_update(mtfhip_batch *b, const double *state_updates /* B x S */);
+/* invertState: Homography.cc:109-114, Affine.cc:145-150 (pure host math, per target) */
+int mtfhip_ssm_invert_state(mtfhip_batch *b, const double *states, double *inv_states);
+/* updateGradPts / initializeGradPts: Homography.cc:803-827, Affine.cc:293-313 */
+int mtfhip_ssm_update_grad_pts(mtfhip_batch *b, double grad_eps);
+/* cmpt{Init,,Warped,Approx}PixJacobian: Homography.cc:157-358, Affine.cc:160-242.
+ * grad_buf is MTFHIP_BUF_DI0_DX or _DIT_DX, dst_buf is MTFHIP_BUF_J0 / _JT / _JM */
+int mtfhip_ssm_cmpt_pix_jacobian(mtfhip_batch *b, int variant, int grad_buf, int dst_buf);
+int mtfhip_ssm_get_corners(mtfhip_batch *b, double *corners /* B x 8 */);
+int mtfhip_ssm_get_init_corners(mtfhip_batch *b, double *corners /* B x 8 */);
+int mtfhip_ssm_get_state(mtfhip_batch *b, double *states /* B x S */);
+int mtfhip_ssm_get_warp(mtfhip_batch *b, double *warps /* B x 9 row-major */);
+/* applyWarpToCorners: ProjectiveBase.cc:137-144, Affine.cc:366-375 (host math) */
+int mtfhip_ssm_apply_warp_to_corners(mtfhip_batch *b, const double *in_corners, const double *states,
+	double *out_corners);
+
+/* ---- ImageBase / AppearanceModel side ----
+ * `pts` arguments: NULL means "the SSM's device-resident points of this batch" (the fast path the
+ * adapters use when the PtsT reference they receive is the paired SSM's own getPts()/getGradPts());
+ * otherwise B x 2N (or B x 8N) host doubles that are uploaded first. */
+int mtfhip_am_initialize_pix_vals(mtfhip_batch *b, const double *pts);      /* ImageBase.cc:62-99 */
+int mtfhip_am_update_pix_vals(mtfhip_batch *b, const double *pts);          /* ImageBase.cc:268-290 */
+int mtfhip_am_initialize_pix_grad(mtfhip_batch *b, const double *pts);      /* ImageBase.cc:101-132 (PtsT) */
+int mtfhip_am_update_pix_grad(mtfhip_batch *b, const double *pts);          /* ImageBase.cc:292-314 */
+int mtfhip_am_initialize_pix_grad_warped(mtfhip_batch *b, const double *grad_pts); /* ImageBase.cc:134-172 */
+int mtfhip_am_update_pix_grad_warped(mtfhip_batch *b, const double *grad_pts);     /* ImageBase.cc:340-362 */
+int mtfhip_am_initialize_similarity(mtfhip_batch *b);  /* SSDBase.cc:29-45, NCC.cc:55-95, MI.cc:207-287 */
+int mtfhip_am_initialize_grad(mtfhip_batch *b);        /* SSDBase.cc:47-63, NCC.cc:97-122, MI.cc:299-332 */
+int mtfhip_am_initialize_hess(mtfhip_batch *b);        /* SSDBase.h:58-63, MI.cc:443-459 */
+int mtfhip_am_update_similarity(mtfhip_batch *b, int prereq_only); /* SSDBase.cc:75-96, NCC.cc:124-161, MI.cc:346-382 */
+int mtfhip_am_update_curr_grad(mtfhip_batch *b);       /* SSDBase.cc:115-121, NCC.cc:196-234, MI.cc:426-442 */
+int mtfhip_am_update_init_grad(mtfhip_batch *b);       /* SSDBase.h:67-72, NCC.cc:163-194, MI.cc:398-416 */
+int mtfhip_am_get_similarity(mtfhip_batch *b, double *f /* B */);
+int mtfhip_am_get_likelihood(mtfhip_batch *b, double *l /* B */);  /* SSD.h:41-43, NCC.cc:50-53, MI.cc:384-387 */
+/* interfacing functions; J arguments are buffer ids, results go to host (B x S, B x S x S) */
+int mtfhip_am_cmpt_init_jacobian(mtfhip_batch *b, int j0_buf, double *g);             /* AppearanceModel.h:146-149 */
+int mtfhip_am_cmpt_curr_jacobian(mtfhip_batch *b, int jt_buf, double *g);             /* AppearanceModel.h:150-153 */
+int mtfhip_am_cmpt_difference_of_jacobians(mtfhip_batch *b, int j0_buf, int jt_buf, double *g); /* SSDBase.cc:169-191 */
+int mtfhip_am_cmpt_init_hessian(mtfhip_batch *b, int j0_buf, double *H);              /* SSDBase.cc:251-267, NCC.cc:282-303 */
+int mtfhip_am_cmpt_curr_hessian(mtfhip_batch *b, int jt_buf, double *H);              /* SSDBase.cc:268-285, NCC.cc:304-335 */
+int mtfhip_am_cmpt_self_hessian(mtfhip_batch *b, int jt_buf, double *H);              /* SSDBase.h:91-94, NCC.cc:337-389 */
+int mtfhip_am_cmpt_sum_of_hessians(mtfhip_batch *b, int j0_buf, int jt_buf, double *H); /* SSDBase.cc:287-311 */
+/* JM = (J0 + JT) / 2 on device: the SM-side `mean_pix_jacobian` of NT/ESM.cc:239-242 */
+int mtfhip_sm_mean_jacobian(mtfhip_batch *b);
+
+/* ---- fused path: one launch per LK iteration for all targets of the batch ----
+ * init_template = the body of nt::{ESM,FCLK,ICLK}::initialize after ssm->initialize
+ * (NT/ESM.cc:110-146, NT/FCLK.cc:102-169, NT/ICLK.cc:71-128): I0, dI0_dx, J0 and the constant
+ * Hessian from the current image at the current points. */
+int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm);
+/* One iteration's device work (A2..A9 of SURVEY.md section 8a) at the current warp:
+ * f (B), g (B x S) and H (B x S x S col-major) exactly as the SM holds them before LM damping
+ * and the S x S solve, which stay with the caller as in the reference. */
+int mtfhip_batch_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, double *g, double *H);
+/* The whole update() loop on device (solve, compositional update and the corner-change
+ * convergence test included) without host round trips; returns per-target iteration counts
+ * and final corners.  SM/src/NT/{ESM,FCLK,ICLK}.cc update(). */
+int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters /* B */, double *corners /* B x 8 */);
+
+/* ---- candidate scoring (PF / NN batch axis): target 0's template, C warps ----
+ * per candidate: setState -> updatePixVals -> updateSimilarity(false) -> getLikelihood
+ * (SM/src/PF.cc:247-262).  The *_dev form takes and fills device pointers (for RCCL). */
+int mtfhip_score_candidates(mtfhip_batch *b, const double *states /* C x S */, int n_candidates,
+	double *likelihoods /* C or NULL */, double *similarities /* C or NULL */);
+int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int n_candidates,
+	double *dev_likelihoods, double *dev_similarities);
+
+/* ---- measurement hooks ---- */
+/* average duration in milliseconds of the launches of the named kernel family since the last
+ * reset, measured with hipEvents on the context's stream (0 if timing is disabled) */
+int mtfhip_timing_enable(mtfhip_ctx *ctx, int on);
+int mtfhip_timing_reset(mtfhip_ctx *ctx);
+int mtfhip_timing_get(mtfhip_ctx *ctx, const char *kernel_family, double *avg_ms, int *n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

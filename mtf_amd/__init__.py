@@ -1,0 +1,13 @@
+"""mtf_amd -- MI355X (gfx950) implementation of MTF's Lucas-Kanade inner loop.
+
+Only what the hot path needs: the C-ABI library (csrc/ -> libmtfhip.so, contract in include/mtfhip.h),
+its Python mirror of the reference's AppearanceModel / StateSpaceModel interface (api.py), the
+search-method loops that drive it (sm.py), candidate sharding over GPUs (dist.py) and synthetic
+frames (synth.py).
+"""
+from . import _lib
+from ._lib import (AM_MI, AM_NCC, AM_SSD, SM_ESM, SM_FCLK, SM_ICLK, SSM_AFFINE, SSM_HOMOGRAPHY,  # noqa: F401
+                   FunctionNotImplemented, InvalidArgument, LogicError, MtfHipError)
+from .api import Batch, Context, sm_desc  # noqa: F401
+
+__all__ = ["Batch", "Context", "sm_desc", "_lib"]

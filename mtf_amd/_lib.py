@@ -1,0 +1,119 @@
+"""ctypes loader of libmtfhip.so (the C-ABI declared in include/mtfhip.h).
+
+There is no fallback: if the shared library is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmtfhip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+AM_SSD, AM_NCC, AM_MI = 0, 1, 2
+SSM_HOMOGRAPHY, SSM_AFFINE = 0, 1
+SM_ESM, SM_FCLK, SM_ICLK = 0, 1, 2
+JAC_INIT, JAC_PIX, JAC_WARPED, JAC_APPROX = 0, 1, 2, 3
+(BUF_I0, BUF_IT, BUF_DI0_DX, BUF_DIT_DX, BUF_DF_DI0, BUF_DF_DIT, BUF_J0, BUF_JT, BUF_JM,
+ BUF_INIT_PTS, BUF_CURR_PTS, BUF_GRAD_PTS, BUF_INIT_Z, BUF_CURR_Z) = range(14)
+
+
+class MtfHipError(RuntimeError):
+    """Mirror of mtf::utils::Exception (Utilities/include/mtf/Utilities/excpUtils.h:8-55)."""
+
+    def __init__(self, code, msg):
+        super().__init__("mtfhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class InvalidArgument(MtfHipError):
+    pass
+
+
+class FunctionNotImplemented(MtfHipError):
+    pass
+
+
+class LogicError(MtfHipError):
+    pass
+
+
+_ERR = {-1: InvalidArgument, -2: FunctionNotImplemented, -3: LogicError}
+
+
+class PatchDesc(C.Structure):
+    _fields_ = [("am", C.c_int), ("ssm", C.c_int), ("resx", C.c_int), ("resy", C.c_int),
+                ("grad_eps", C.c_double), ("likelihood_alpha", C.c_double), ("mi_n_bins", C.c_int),
+                ("mi_pre_seed", C.c_double), ("mi_partition_of_unity", C.c_int)]
+
+
+class SMDesc(C.Structure):
+    _fields_ = [("sm", C.c_int), ("jac_type", C.c_int), ("hess_type", C.c_int), ("chained_warp", C.c_int),
+                ("materialize", C.c_int), ("max_iters", C.c_int), ("epsilon", C.c_double),
+                ("leven_marq", C.c_int), ("lm_delta_init", C.c_double), ("lm_delta_update", C.c_double)]
+
+
+# every exported symbol of include/mtfhip.h (tests check that the library exports all of them)
+SYMBOLS = [
+    "mtfhip_last_error", "mtfhip_device_count", "mtfhip_ctx_create", "mtfhip_ctx_destroy",
+    "mtfhip_ctx_synchronize", "mtfhip_ctx_stream", "mtfhip_image_upload", "mtfhip_image_borrow",
+    "mtfhip_batch_create", "mtfhip_batch_destroy", "mtfhip_batch_n_targets", "mtfhip_batch_n_pix",
+    "mtfhip_batch_state_size", "mtfhip_batch_read", "mtfhip_batch_write", "mtfhip_batch_device_ptr",
+    "mtfhip_ssm_set_corners", "mtfhip_ssm_set_state", "mtfhip_ssm_compositional_update",
+    "mtfhip_ssm_invert_state", "mtfhip_ssm_update_grad_pts", "mtfhip_ssm_cmpt_pix_jacobian",
+    "mtfhip_ssm_get_corners", "mtfhip_ssm_get_init_corners", "mtfhip_ssm_get_state", "mtfhip_ssm_get_warp",
+    "mtfhip_ssm_apply_warp_to_corners",
+    "mtfhip_am_initialize_pix_vals", "mtfhip_am_update_pix_vals", "mtfhip_am_initialize_pix_grad",
+    "mtfhip_am_update_pix_grad", "mtfhip_am_initialize_pix_grad_warped", "mtfhip_am_update_pix_grad_warped",
+    "mtfhip_am_initialize_similarity", "mtfhip_am_initialize_grad", "mtfhip_am_initialize_hess",
+    "mtfhip_am_update_similarity", "mtfhip_am_update_curr_grad", "mtfhip_am_update_init_grad",
+    "mtfhip_am_get_similarity", "mtfhip_am_get_likelihood",
+    "mtfhip_am_cmpt_init_jacobian", "mtfhip_am_cmpt_curr_jacobian", "mtfhip_am_cmpt_difference_of_jacobians",
+    "mtfhip_am_cmpt_init_hessian", "mtfhip_am_cmpt_curr_hessian", "mtfhip_am_cmpt_self_hessian",
+    "mtfhip_am_cmpt_sum_of_hessians", "mtfhip_sm_mean_jacobian",
+    "mtfhip_batch_init_template", "mtfhip_batch_iterate", "mtfhip_batch_track",
+    "mtfhip_score_candidates", "mtfhip_score_candidates_dev",
+    "mtfhip_timing_enable", "mtfhip_timing_reset", "mtfhip_timing_get",
+]
+
+
+def build(force=False):
+    """Compile libmtfhip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + \
+           [os.path.join(_HERE, "..", "include", "mtfhip.h")]
+    newest = max(os.path.getmtime(p) for p in srcs)
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-B"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libmtfhip.so is missing (%s); build it with `python -c 'import __graft_entry__ as g; "
+                              "g.build()'` -- there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.mtfhip_last_error.restype = C.c_char_p
+        L.mtfhip_ctx_stream.restype = C.c_void_p
+        L.mtfhip_batch_device_ptr.restype = C.c_void_p
+        L.mtfhip_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.mtfhip_batch_create.argtypes = [C.c_void_p, C.POINTER(PatchDesc), C.c_int, C.POINTER(C.c_void_p)]
+        L.mtfhip_image_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.mtfhip_image_borrow.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.mtfhip_ssm_update_grad_pts.argtypes = [C.c_void_p, C.c_double]
+        L.mtfhip_score_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.mtfhip_score_candidates_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.mtfhip_batch_device_ptr.argtypes = [C.c_void_p, C.c_int]
+        L.mtfhip_timing_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        _lib = L
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        msg = lib().mtfhip_last_error().decode("utf-8", "replace")
+        raise _ERR.get(code, MtfHipError)(code, msg)

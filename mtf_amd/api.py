@@ -1,0 +1,323 @@
+"""Python mirror of the reference's AppearanceModel / StateSpaceModel interface over libmtfhip.so.
+
+Method names and argument meaning follow the reference's virtuals (camelCase -> snake_case):
+AM/include/mtf/AM/ImageBase.h:92-123, AM/include/mtf/AM/AppearanceModel.h:77-219,
+SSM/include/mtf/SSM/StateSpaceModel.h:98-181.  NumPy arrays are in NumPy-natural orientation on
+this side (pts (B, 2, N), grad (B, N, 2), J (B, N, S), H (B, S, S), corners (B, 2, 4)) and are
+converted to/from the Eigen column-major layouts of the C ABI here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import (AM_MI, AM_NCC, AM_SSD, BUF_CURR_PTS, BUF_DF_DI0, BUF_DF_DIT, BUF_DI0_DX, BUF_DIT_DX,
+                   BUF_GRAD_PTS, BUF_I0, BUF_INIT_PTS, BUF_IT, BUF_J0, BUF_JM, BUF_JT, JAC_APPROX, JAC_INIT,
+                   JAC_PIX, JAC_WARPED, SM_ESM, SM_FCLK, SM_ICLK, SSM_AFFINE, SSM_HOMOGRAPHY, PatchDesc, SMDesc)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def sm_desc(sm, **kw):
+    """Class defaults of the reference (SM/src/ESMParams.cc:4-15, FCLKParams.cc:4-17, ICLKParams.cc:4-14)."""
+    base = dict(sm=sm, jac_type=1, hess_type={SM_ESM: 2, SM_FCLK: 1, SM_ICLK: 0}[sm], chained_warp=1,
+                materialize=1, max_iters=30, epsilon=1e-4, leven_marq=0, lm_delta_init=0.01, lm_delta_update=10.0)
+    base.update(kw)
+    return SMDesc(**base)
+
+
+class Context:
+    """Device + stream + the current image (ImageBase::setCurrImg)."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        L.check(L.lib().mtfhip_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        self.device = device
+        self._img_keep = None
+
+    def close(self):
+        if self._h:
+            L.lib().mtfhip_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        L.check(L.lib().mtfhip_ctx_synchronize(self._h))
+
+    @property
+    def stream(self):
+        return L.lib().mtfhip_ctx_stream(self._h)
+
+    def set_image(self, img):
+        """Upload a host float32 H x W image (the CV_32FC1 input of AM/src/ImageBase.cc:38-60)."""
+        img = np.asarray(img)
+        if img.dtype != np.float32 or img.ndim != 2:
+            raise L.InvalidArgument(-1, "Input image type does not match the required type: 32FC1")
+        stride = img.strides[0] // 4
+        if img.strides[1] != 4:
+            img = np.ascontiguousarray(img)
+            stride = img.shape[1]
+        L.check(L.lib().mtfhip_image_upload(self._h, _p(img), img.shape[0], img.shape[1], stride))
+
+    def set_image_device(self, dev_ptr, height, width, row_stride=None, keep=None):
+        """Adopt a float32 image already resident in HBM (e.g. a torch tensor's data_ptr())."""
+        self._img_keep = keep
+        L.check(L.lib().mtfhip_image_borrow(self._h, C.c_void_p(dev_ptr), height, width, row_stride or width))
+
+    def timing(self, on=True):
+        L.check(L.lib().mtfhip_timing_enable(self._h, int(on)))
+
+    def timing_reset(self):
+        L.check(L.lib().mtfhip_timing_reset(self._h))
+
+    def timing_get(self, family):
+        avg, n = C.c_double(), C.c_int()
+        L.check(L.lib().mtfhip_timing_get(self._h, family.encode(), C.byref(avg), C.byref(n)))
+        return avg.value, n.value
+
+
+class Batch:
+    """B independent targets (AM + SSM pairs) sharing the context's current image."""
+
+    def __init__(self, ctx, am=AM_SSD, ssm=SSM_HOMOGRAPHY, resx=50, resy=50, n_targets=1, grad_eps=1e-8,
+                 likelihood_alpha=1.0, mi_n_bins=8, mi_pre_seed=10.0, mi_pou=0):
+        self.ctx = ctx
+        self.desc = PatchDesc(am, ssm, resx, resy, grad_eps, likelihood_alpha, mi_n_bins, mi_pre_seed, mi_pou)
+        self._h = C.c_void_p()
+        L.check(L.lib().mtfhip_batch_create(ctx._h, C.byref(self.desc), int(n_targets), C.byref(self._h)))
+        self.B = n_targets
+        self.N = resx * resy
+        self.S = 8 if ssm == SSM_HOMOGRAPHY else 6
+
+    def close(self):
+        if self._h:
+            L.lib().mtfhip_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------- buffers
+    _PER = {BUF_I0: 1, BUF_IT: 1, BUF_DF_DI0: 1, BUF_DF_DIT: 1}
+
+    def read(self, buf):
+        """Lazy read-back of a device buffer in NumPy-natural orientation."""
+        B, N, S = self.B, self.N, self.S
+        sizes = {BUF_I0: N, BUF_IT: N, BUF_DI0_DX: 2 * N, BUF_DIT_DX: 2 * N, BUF_DF_DI0: N, BUF_DF_DIT: N,
+                 BUF_J0: N * S, BUF_JT: N * S, BUF_JM: N * S, BUF_INIT_PTS: 2 * N, BUF_CURR_PTS: 2 * N,
+                 BUF_GRAD_PTS: 8 * N, 12: N, 13: N}
+        out = np.empty((B, sizes[buf]))
+        L.check(L.lib().mtfhip_batch_read(self._h, buf, _p(out)))
+        if buf in (BUF_DI0_DX, BUF_DIT_DX):
+            return out.reshape(B, 2, N).transpose(0, 2, 1)
+        if buf in (BUF_J0, BUF_JT, BUF_JM):
+            return out.reshape(B, S, N).transpose(0, 2, 1)
+        if buf in (BUF_INIT_PTS, BUF_CURR_PTS):
+            return out.reshape(B, N, 2).transpose(0, 2, 1)
+        if buf == BUF_GRAD_PTS:
+            return out.reshape(B, N, 8)
+        return out
+
+    def device_ptr(self, buf):
+        return L.lib().mtfhip_batch_device_ptr(self._h, buf)
+
+    # ---------------------------------------------------------- StateSpaceModel
+    def _corners_in(self, corners):
+        c = _f64(corners).reshape(self.B, 2, 4)
+        return np.ascontiguousarray(c.transpose(0, 2, 1)).reshape(self.B, 8)
+
+    @staticmethod
+    def _corners_out(flat):
+        return flat.reshape(-1, 4, 2).transpose(0, 2, 1).copy()
+
+    def set_corners(self, corners):
+        c = self._corners_in(corners)
+        L.check(L.lib().mtfhip_ssm_set_corners(self._h, _p(c)))
+
+    initialize = set_corners  # StateSpaceModel::initialize is an alias of setCorners (StateSpaceModel.h:117-121)
+
+    def set_state(self, states):
+        s = _f64(states).reshape(self.B, self.S)
+        L.check(L.lib().mtfhip_ssm_set_state(self._h, _p(s)))
+
+    def compositional_update(self, dps):
+        s = _f64(dps).reshape(self.B, self.S)
+        L.check(L.lib().mtfhip_ssm_compositional_update(self._h, _p(s)))
+
+    def invert_state(self, states):
+        s = _f64(states).reshape(self.B, self.S)
+        out = np.empty_like(s)
+        L.check(L.lib().mtfhip_ssm_invert_state(self._h, _p(s), _p(out)))
+        return out
+
+    def update_grad_pts(self, grad_eps=None):
+        L.check(L.lib().mtfhip_ssm_update_grad_pts(self._h, self.desc.grad_eps if grad_eps is None else grad_eps))
+
+    def cmpt_pix_jacobian(self, variant, grad_buf, dst_buf):
+        L.check(L.lib().mtfhip_ssm_cmpt_pix_jacobian(self._h, variant, grad_buf, dst_buf))
+
+    def cmpt_init_pix_jacobian(self, grad_buf=BUF_DI0_DX, dst_buf=BUF_J0):
+        self.cmpt_pix_jacobian(JAC_INIT, grad_buf, dst_buf)
+
+    def cmpt_warped_pix_jacobian(self, grad_buf=BUF_DIT_DX, dst_buf=BUF_JT):
+        self.cmpt_pix_jacobian(JAC_WARPED, grad_buf, dst_buf)
+
+    def get_corners(self):
+        out = np.empty((self.B, 8))
+        L.check(L.lib().mtfhip_ssm_get_corners(self._h, _p(out)))
+        return self._corners_out(out)
+
+    def get_state(self):
+        out = np.empty((self.B, self.S))
+        L.check(L.lib().mtfhip_ssm_get_state(self._h, _p(out)))
+        return out
+
+    def get_warp(self):
+        out = np.empty((self.B, 9))
+        L.check(L.lib().mtfhip_ssm_get_warp(self._h, _p(out)))
+        return out.reshape(self.B, 3, 3)
+
+    def get_pts(self):
+        return self.read(BUF_CURR_PTS)
+
+    def apply_warp_to_corners(self, corners, states):
+        c = self._corners_in(corners)
+        s = _f64(states).reshape(self.B, self.S)
+        out = np.empty((self.B, 8))
+        L.check(L.lib().mtfhip_ssm_apply_warp_to_corners(self._h, _p(c), _p(s), _p(out)))
+        return self._corners_out(out)
+
+    # ---------------------------------------------------------- ImageBase
+    def _pts_arg(self, pts, per):
+        if pts is None:
+            return None, None
+        a = _f64(pts)
+        if per == 2:  # (B, 2, N) -> interleaved
+            a = np.ascontiguousarray(a.reshape(self.B, 2, self.N).transpose(0, 2, 1))
+        else:
+            a = np.ascontiguousarray(a.reshape(self.B, self.N, 8))
+        return a, _p(a)
+
+    def initialize_pix_vals(self, pts=None):
+        keep, p = self._pts_arg(pts, 2)
+        L.check(L.lib().mtfhip_am_initialize_pix_vals(self._h, p))
+
+    def update_pix_vals(self, pts=None):
+        keep, p = self._pts_arg(pts, 2)
+        L.check(L.lib().mtfhip_am_update_pix_vals(self._h, p))
+
+    def initialize_pix_grad(self, pts=None, warped=False):
+        keep, p = self._pts_arg(pts, 8 if warped else 2)
+        fn = L.lib().mtfhip_am_initialize_pix_grad_warped if warped else L.lib().mtfhip_am_initialize_pix_grad
+        L.check(fn(self._h, p))
+
+    def update_pix_grad(self, pts=None, warped=False):
+        keep, p = self._pts_arg(pts, 8 if warped else 2)
+        fn = L.lib().mtfhip_am_update_pix_grad_warped if warped else L.lib().mtfhip_am_update_pix_grad
+        L.check(fn(self._h, p))
+
+    # ---------------------------------------------------------- AppearanceModel
+    def initialize_similarity(self):
+        L.check(L.lib().mtfhip_am_initialize_similarity(self._h))
+
+    def initialize_grad(self):
+        L.check(L.lib().mtfhip_am_initialize_grad(self._h))
+
+    def initialize_hess(self):
+        L.check(L.lib().mtfhip_am_initialize_hess(self._h))
+
+    def update_similarity(self, prereq_only=True):
+        L.check(L.lib().mtfhip_am_update_similarity(self._h, int(prereq_only)))
+
+    def update_curr_grad(self):
+        L.check(L.lib().mtfhip_am_update_curr_grad(self._h))
+
+    def update_init_grad(self):
+        L.check(L.lib().mtfhip_am_update_init_grad(self._h))
+
+    def get_similarity(self):
+        out = np.empty(self.B)
+        L.check(L.lib().mtfhip_am_get_similarity(self._h, _p(out)))
+        return out
+
+    def get_likelihood(self):
+        out = np.empty(self.B)
+        L.check(L.lib().mtfhip_am_get_likelihood(self._h, _p(out)))
+        return out
+
+    def _g(self, fn, *bufs):
+        out = np.empty((self.B, self.S))
+        L.check(fn(self._h, *bufs, _p(out)))
+        return out
+
+    def _H(self, fn, *bufs):
+        out = np.empty((self.B, self.S, self.S))
+        L.check(fn(self._h, *bufs, _p(out)))
+        return out.transpose(0, 2, 1).copy()  # column-major -> [r, c]
+
+    def cmpt_init_jacobian(self, j0=BUF_J0):
+        return self._g(L.lib().mtfhip_am_cmpt_init_jacobian, j0)
+
+    def cmpt_curr_jacobian(self, jt=BUF_JT):
+        return self._g(L.lib().mtfhip_am_cmpt_curr_jacobian, jt)
+
+    def cmpt_difference_of_jacobians(self, j0=BUF_J0, jt=BUF_JT):
+        return self._g(L.lib().mtfhip_am_cmpt_difference_of_jacobians, j0, jt)
+
+    def cmpt_init_hessian(self, j0=BUF_J0):
+        return self._H(L.lib().mtfhip_am_cmpt_init_hessian, j0)
+
+    def cmpt_curr_hessian(self, jt=BUF_JT):
+        return self._H(L.lib().mtfhip_am_cmpt_curr_hessian, jt)
+
+    def cmpt_self_hessian(self, jt=BUF_JT):
+        return self._H(L.lib().mtfhip_am_cmpt_self_hessian, jt)
+
+    def cmpt_sum_of_hessians(self, j0=BUF_J0, jt=BUF_JT):
+        return self._H(L.lib().mtfhip_am_cmpt_sum_of_hessians, j0, jt)
+
+    def mean_jacobian(self):
+        L.check(L.lib().mtfhip_sm_mean_jacobian(self._h))
+
+    # ---------------------------------------------------------- fused path
+    def init_template(self, sm):
+        L.check(L.lib().mtfhip_batch_init_template(self._h, C.byref(sm)))
+
+    def iterate(self, sm):
+        f = np.empty(self.B)
+        g = np.empty((self.B, self.S))
+        H = np.empty((self.B, self.S, self.S))
+        L.check(L.lib().mtfhip_batch_iterate(self._h, C.byref(sm), _p(f), _p(g), _p(H)))
+        return f, g, H.transpose(0, 2, 1).copy()
+
+    def track(self, sm):
+        n = np.empty(self.B, dtype=np.int32)
+        c = np.empty((self.B, 8))
+        L.check(L.lib().mtfhip_batch_track(self._h, C.byref(sm), _p(n), _p(c)))
+        return n, self._corners_out(c)
+
+    # ---------------------------------------------------------- candidate scoring
+    def score_candidates(self, states, want_similarity=False):
+        s = _f64(states).reshape(-1, self.S)
+        lik = np.empty(s.shape[0])
+        sim = np.empty(s.shape[0]) if want_similarity else None
+        L.check(L.lib().mtfhip_score_candidates(self._h, _p(s), s.shape[0], _p(lik), _p(sim) if want_similarity else None))
+        return (lik, sim) if want_similarity else lik
+
+    def score_candidates_dev(self, dev_states, n, dev_lik, dev_sim=None):
+        L.check(L.lib().mtfhip_score_candidates_dev(self._h, C.c_void_p(dev_states), int(n), C.c_void_p(dev_lik),
+                                                    C.c_void_p(dev_sim) if dev_sim else None))

@@ -1,0 +1,1047 @@
+/*
+ * mtfhip_api.hip -- C-ABI implementation (include/mtfhip.h): handles, device memory, the tiny
+ * host-side math the reference keeps on the host (4-corner DLT at initialisation, 3x3 warp algebra),
+ * and the sequencing of kernels for every AppearanceModel / StateSpaceModel entry point.
+ *
+ * No CPU fallback exists: every entry point either runs its HIP kernels or returns an error.
+ */
+#include "mtfhip_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace mtfhip;
+
+namespace mtfhip {
+void launch_init_grid(const BatchView &bv, const double *dev_w0, int resx, int resy, double lo_x, double lo_y,
+	double hi_x, double hi_y, int force_unit_z, hipStream_t st);
+}
+
+/* ------------------------------------------------------------------ errors */
+static thread_local std::string g_last_error;
+static int fail(int code, const char *fmt, ...) {
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof(buf), fmt, ap);
+	va_end(ap);
+	g_last_error = buf;
+	return code;
+}
+#define HIP_TRY(expr)                                                                        \
+	do {                                                                                     \
+		hipError_t _e = (expr);                                                              \
+		if (_e != hipSuccess)                                                                \
+			return fail(MTFHIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+	} while (0)
+#define TRY(expr)                  \
+	do {                           \
+		int _r = (expr);           \
+		if (_r != MTFHIP_OK) return _r; \
+	} while (0)
+
+/* ------------------------------------------------------------------ small host math */
+struct M3 {
+	double m[9];
+};
+static M3 m3_identity() { return M3{{1, 0, 0, 0, 1, 0, 0, 0, 1}}; }
+static M3 m3_mul(const M3 &a, const M3 &b) {
+	M3 c;
+	for (int i = 0; i < 3; ++i)
+		for (int j = 0; j < 3; ++j)
+			c.m[3 * i + j] = a.m[3 * i] * b.m[j] + a.m[3 * i + 1] * b.m[3 + j] + a.m[3 * i + 2] * b.m[6 + j];
+	return c;
+}
+/* Matrix3d::inverse() as Eigen evaluates it for fixed 3x3: cofactors / determinant */
+static M3 m3_inverse(const M3 &a) {
+	const double *u = a.m;
+	M3 c;
+	c.m[0] = u[4] * u[8] - u[5] * u[7]; c.m[1] = u[2] * u[7] - u[1] * u[8]; c.m[2] = u[1] * u[5] - u[2] * u[4];
+	c.m[3] = u[5] * u[6] - u[3] * u[8]; c.m[4] = u[0] * u[8] - u[2] * u[6]; c.m[5] = u[2] * u[3] - u[0] * u[5];
+	c.m[6] = u[3] * u[7] - u[4] * u[6]; c.m[7] = u[1] * u[6] - u[0] * u[7]; c.m[8] = u[0] * u[4] - u[1] * u[3];
+	double det = u[0] * c.m[0] + u[1] * c.m[3] + u[2] * c.m[6];
+	double inv_det = 1.0 / det;
+	for (int i = 0; i < 9; ++i) c.m[i] *= inv_det;
+	return c;
+}
+/* getWarpFromState: Homography.cc:94-107, Affine.cc:116-130 */
+static M3 warp_from_state(int ssm, const double *p) {
+	M3 W;
+	if (ssm == MTFHIP_SSM_HOMOGRAPHY) {
+		W.m[0] = 1 + p[0]; W.m[1] = p[1]; W.m[2] = p[2];
+		W.m[3] = p[3]; W.m[4] = 1 + p[4]; W.m[5] = p[5];
+		W.m[6] = p[6]; W.m[7] = p[7]; W.m[8] = 1;
+	} else {
+		W.m[0] = 1 + p[2]; W.m[1] = p[3]; W.m[2] = p[0];
+		W.m[3] = p[4]; W.m[4] = 1 + p[5]; W.m[5] = p[1];
+		W.m[6] = 0; W.m[7] = 0; W.m[8] = 1;
+	}
+	return W;
+}
+/* getStateFromWarp: Homography.cc:116-132, Affine.cc:132-143 */
+static void state_from_warp(int ssm, double *p, const M3 &W) {
+	if (ssm == MTFHIP_SSM_HOMOGRAPHY) {
+		p[0] = W.m[0] - 1; p[1] = W.m[1]; p[2] = W.m[2]; p[3] = W.m[3]; p[4] = W.m[4] - 1; p[5] = W.m[5];
+		p[6] = W.m[6]; p[7] = W.m[7];
+	} else {
+		p[0] = W.m[2]; p[1] = W.m[5]; p[2] = W.m[0] - 1; p[3] = W.m[1]; p[4] = W.m[3]; p[5] = W.m[4] - 1;
+		p[6] = p[7] = 0;
+	}
+}
+/* 4-corner homography (utils::computeHomographyDLT, Utilities/src/warpUtils.cc:171-224): the null vector
+ * of the 8x9 constraint matrix scaled to h8 = 1 is the solution of the 8x8 system below; solved by
+ * Gaussian elimination with partial pivoting. corners are 2x4 interleaved. */
+static bool dlt4(const double *in, const double *out, M3 &H) {
+	double A[8][9];
+	for (int i = 0; i < 4; ++i) {
+		double x = in[2 * i], y = in[2 * i + 1], u = out[2 * i], v = out[2 * i + 1];
+		double r0[9] = {x, y, 1, 0, 0, 0, -u * x, -u * y, u};
+		double r1[9] = {0, 0, 0, x, y, 1, -v * x, -v * y, v};
+		std::memcpy(A[2 * i], r0, sizeof(r0));
+		std::memcpy(A[2 * i + 1], r1, sizeof(r1));
+	}
+	for (int k = 0; k < 8; ++k) {
+		int piv = k;
+		for (int i = k + 1; i < 8; ++i)
+			if (std::fabs(A[i][k]) > std::fabs(A[piv][k])) piv = i;
+		if (A[piv][k] == 0) return false;
+		if (piv != k)
+			for (int j = 0; j < 9; ++j) std::swap(A[piv][j], A[k][j]);
+		for (int i = k + 1; i < 8; ++i) {
+			double f = A[i][k] / A[k][k];
+			for (int j = k; j < 9; ++j) A[i][j] -= f * A[k][j];
+		}
+	}
+	double h[8];
+	for (int k = 7; k >= 0; --k) {
+		double s = A[k][8];
+		for (int j = k + 1; j < 8; ++j) s -= A[k][j] * h[j];
+		h[k] = s / A[k][k];
+	}
+	for (int i = 0; i < 8; ++i) H.m[i] = h[i];
+	H.m[8] = 1;
+	return true;
+}
+
+/* ------------------------------------------------------------------ handles */
+struct Timer {
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+	double total_ms = 0;
+	int n = 0;
+};
+
+struct mtfhip_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	ImgView img{nullptr, 0, 0, 0};
+	float *img_owned = nullptr;
+	size_t img_capacity = 0;
+	bool timing = false;
+	std::map<std::string, Timer> timers;
+	std::vector<hipEvent_t> free_events;
+};
+
+struct TimedScope {
+	mtfhip_ctx *ctx;
+	hipEvent_t a = nullptr, b = nullptr;
+	Timer *tm = nullptr;
+	TimedScope(mtfhip_ctx *c, const char *family) : ctx(c) {
+		if (!ctx->timing) return;
+		tm = &ctx->timers[family];
+		auto get = [&]() {
+			hipEvent_t e;
+			if (!ctx->free_events.empty()) { e = ctx->free_events.back(); ctx->free_events.pop_back(); }
+			else (void)hipEventCreate(&e);
+			return e;
+		};
+		a = get(); b = get();
+		(void)hipEventRecord(a, ctx->stream);
+	}
+	~TimedScope() {
+		if (!tm) return;
+		(void)hipEventRecord(b, ctx->stream);
+		tm->pending.emplace_back(a, b);
+	}
+};
+
+struct TargetHost {
+	M3 warp;
+	double state[8];
+	double corners[8], init_corners[8];
+	double init_corners_hm[12];
+	double f;
+	/* NCC scalars (AM/src/NCC.cc members) */
+	double I0_mean, It_mean, a, b, c;
+	double h0[64]; /* constant self Hessian of the template (column-major), set by init_template */
+};
+
+struct mtfhip_batch {
+	mtfhip_ctx *ctx;
+	mtfhip_patch_desc desc;
+	int B, N, S;
+	double norm_mult = 1, norm_add = 0;
+	double *buf[MTFHIP_BUF_COUNT];
+	size_t per_target[MTFHIP_BUF_COUNT];
+	double *d_warps = nullptr, *d_states = nullptr;
+	double *d_partials = nullptr, *d_acc = nullptr, *d_scratch_pts = nullptr, *d_w0 = nullptr;
+	double *d_h0 = nullptr, *d_corners = nullptr, *d_init_corners_hm = nullptr, *d_cand = nullptr;
+	size_t cand_capacity = 0;
+	int *d_active = nullptr, *d_iters = nullptr;
+	double *h_acc = nullptr; /* pinned */
+	int nblk_max;
+	int unit_z = 1;
+	bool have_corners = false, init_pix_vals = false, init_pix_grad = false, init_sim = false, init_grad = false;
+	bool it_valid = false, dit_valid = false, jt_valid = false;
+	std::vector<TargetHost> th;
+
+	BatchView view() const {
+		BatchView v;
+		v.B = B; v.N = N; v.S = S; v.ssm = desc.ssm; v.am = desc.am; v.unit_z = unit_z;
+		for (int i = 0; i < MTFHIP_BUF_COUNT; ++i) v.buf[i] = buf[i];
+		v.warps = d_warps; v.states = d_states;
+		return v;
+	}
+};
+
+static int ensure_buf(mtfhip_batch *b, int id) {
+	if (b->buf[id]) return MTFHIP_OK;
+	HIP_TRY(hipMalloc(&b->buf[id], sizeof(double) * b->per_target[id] * b->B));
+	HIP_TRY(hipMemsetAsync(b->buf[id], 0, sizeof(double) * b->per_target[id] * b->B, b->ctx->stream));
+	return MTFHIP_OK;
+}
+
+static int push_warps(mtfhip_batch *b) {
+	std::vector<double> w(9 * b->B), s(8 * b->B);
+	for (int t = 0; t < b->B; ++t) {
+		std::memcpy(&w[9 * t], b->th[t].warp.m, sizeof(double) * 9);
+		std::memcpy(&s[8 * t], b->th[t].state, sizeof(double) * 8);
+	}
+	HIP_TRY(hipMemcpyAsync(b->d_warps, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice, b->ctx->stream));
+	HIP_TRY(hipMemcpyAsync(b->d_states, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice, b->ctx->stream));
+	HIP_TRY(hipStreamSynchronize(b->ctx->stream)); /* the staging vectors die at scope exit */
+	return MTFHIP_OK;
+}
+
+/* corners = dehomogenise(curr_warp * init_corners_hm) (Homography.cc:87-90) / affine top rows (Affine.cc:105) */
+static void update_corners(mtfhip_batch *b, int t) {
+	TargetHost &h = b->th[t];
+	for (int q = 0; q < 4; ++q) {
+		const double *c = &h.init_corners_hm[3 * q];
+		const double *W = h.warp.m;
+		double x = W[0] * c[0] + W[1] * c[1] + W[2] * c[2];
+		double y = W[3] * c[0] + W[4] * c[1] + W[5] * c[2];
+		if (b->desc.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+			double d = W[6] * c[0] + W[7] * c[1] + W[8] * c[2];
+			x = x / d; y = y / d;
+		}
+		h.corners[2 * q] = x; h.corners[2 * q + 1] = y;
+	}
+}
+
+static int read_acc(mtfhip_batch *b, int nblk) {
+	launch_finish(b->d_partials, nblk, b->d_acc, b->B, b->ctx->stream);
+	HIP_TRY(hipMemcpyAsync(b->h_acc, b->d_acc, sizeof(double) * ACC_COUNT * b->B, hipMemcpyDeviceToHost, b->ctx->stream));
+	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	return MTFHIP_OK;
+}
+
+static int need_image(mtfhip_batch *b) {
+	if (!b->ctx->img.data) return fail(MTFHIP_ERR_LOGIC, "no current image: call mtfhip_image_upload/borrow first");
+	return MTFHIP_OK;
+}
+static int j_buf_ok(int id) { return id == MTFHIP_BUF_J0 || id == MTFHIP_BUF_JT || id == MTFHIP_BUF_JM; }
+
+/* resolves a `pts` argument: NULL -> the batch's own device buffer, else upload into scratch */
+static int resolve_pts(mtfhip_batch *b, const double *host, int own_buf, size_t per_target, const double **out) {
+	if (!host) {
+		if (!b->buf[own_buf]) return fail(MTFHIP_ERR_LOGIC, "device points not available yet");
+		*out = b->buf[own_buf];
+		return MTFHIP_OK;
+	}
+	HIP_TRY(hipMemcpyAsync(b->d_scratch_pts, host, sizeof(double) * per_target * b->B, hipMemcpyHostToDevice, b->ctx->stream));
+	*out = b->d_scratch_pts;
+	return MTFHIP_OK;
+}
+
+extern "C" {
+
+/* ------------------------------------------------------------------ context */
+const char *mtfhip_last_error(void) { return g_last_error.c_str(); }
+
+int mtfhip_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+int mtfhip_ctx_create(int device, void *hip_stream, mtfhip_ctx **out) {
+	if (!out) return fail(MTFHIP_ERR_INVALID_ARG, "ctx_create: out is NULL");
+	int n = mtfhip_device_count();
+	if (n <= 0) return fail(MTFHIP_ERR_NO_DEVICE, "no HIP device visible");
+	if (device < 0 || device >= n) return fail(MTFHIP_ERR_INVALID_ARG, "device %d out of range [0,%d)", device, n);
+	HIP_TRY(hipSetDevice(device));
+	mtfhip_ctx *c = new mtfhip_ctx();
+	c->device = device;
+	if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+	else {
+		hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+		if (e != hipSuccess) { delete c; return fail(MTFHIP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+		c->own_stream = true;
+	}
+	*out = c;
+	return MTFHIP_OK;
+}
+
+void mtfhip_ctx_destroy(mtfhip_ctx *c) {
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	for (auto &kv : c->timers)
+		for (auto &p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+	for (auto e : c->free_events) (void)hipEventDestroy(e);
+	if (c->img_owned) (void)hipFree(c->img_owned);
+	if (c->own_stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+int mtfhip_ctx_synchronize(mtfhip_ctx *c) {
+	if (!c) return fail(MTFHIP_ERR_INVALID_ARG, "ctx is NULL");
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return MTFHIP_OK;
+}
+void *mtfhip_ctx_stream(mtfhip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int mtfhip_image_upload(mtfhip_ctx *c, const float *host_img, int height, int width, int row_stride) {
+	if (!c || !host_img) return fail(MTFHIP_ERR_INVALID_ARG, "image_upload: NULL argument");
+	if (height <= 0 || width <= 0 || row_stride < width) return fail(MTFHIP_ERR_INVALID_ARG, "image_upload: bad shape %dx%d stride %d", height, width, row_stride);
+	HIP_TRY(hipSetDevice(c->device));
+	size_t need = (size_t)height * width;
+	if (need > c->img_capacity) {
+		if (c->img_owned) HIP_TRY(hipFree(c->img_owned));
+		c->img_owned = nullptr;
+		HIP_TRY(hipMalloc(&c->img_owned, need * sizeof(float)));
+		c->img_capacity = need;
+	}
+	HIP_TRY(hipMemcpy2DAsync(c->img_owned, (size_t)width * sizeof(float), host_img, (size_t)row_stride * sizeof(float),
+		(size_t)width * sizeof(float), (size_t)height, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream)); /* the caller may overwrite its buffer right after (TrackerBase.h:22-26) */
+	c->img = ImgView{c->img_owned, height, width, width};
+	return MTFHIP_OK;
+}
+
+int mtfhip_image_borrow(mtfhip_ctx *c, const float *dev_img, int height, int width, int row_stride) {
+	if (!c || !dev_img) return fail(MTFHIP_ERR_INVALID_ARG, "image_borrow: NULL argument");
+	if (height <= 0 || width <= 0 || row_stride < width) return fail(MTFHIP_ERR_INVALID_ARG, "image_borrow: bad shape");
+	c->img = ImgView{dev_img, height, width, row_stride};
+	return MTFHIP_OK;
+}
+
+/* ------------------------------------------------------------------ batch */
+int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets, mtfhip_batch **out) {
+	if (!c || !d || !out) return fail(MTFHIP_ERR_INVALID_ARG, "batch_create: NULL argument");
+	/* ImageBase ctor AM/src/ImageBase.cc:33-35, StateSpaceModel ctor StateSpaceModel.h:58-60 */
+	if (d->resx <= 0 || d->resy <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "Invalid sampling resolution provided");
+	if (n_targets <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "batch_create: n_targets must be positive");
+	if (d->am < MTFHIP_AM_SSD || d->am > MTFHIP_AM_MI) return fail(MTFHIP_ERR_INVALID_ARG, "unknown appearance model %d", d->am);
+	if (d->ssm != MTFHIP_SSM_HOMOGRAPHY && d->ssm != MTFHIP_SSM_AFFINE) return fail(MTFHIP_ERR_INVALID_ARG, "unknown state space model %d", d->ssm);
+	HIP_TRY(hipSetDevice(c->device));
+	mtfhip_batch *b = new mtfhip_batch();
+	b->ctx = c; b->desc = *d; b->B = n_targets; b->N = d->resx * d->resy;
+	b->S = d->ssm == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
+	if (d->am == MTFHIP_AM_MI) {
+		/* MI ctor AM/src/MI.cc:80-94 */
+		double lo = 0, hi = d->mi_n_bins - 1;
+		if (d->mi_partition_of_unity) { lo = 1; hi = d->mi_n_bins - 2; }
+		b->norm_mult = (hi - lo) / (255.0 - 0.0 + 1);
+		b->norm_add = lo;
+	}
+	const size_t N = b->N, S = b->S;
+	size_t per[MTFHIP_BUF_COUNT] = {N, N, 2 * N, 2 * N, N, N, N * S, N * S, N * S, 2 * N, 2 * N, 8 * N, N, N};
+	for (int i = 0; i < MTFHIP_BUF_COUNT; ++i) { b->per_target[i] = per[i]; b->buf[i] = nullptr; }
+	b->th.resize(n_targets);
+	for (auto &h : b->th) { std::memset(&h, 0, sizeof(h)); h.warp = m3_identity(); }
+	b->nblk_max = simple_blocks_per_target(b->N);
+	int nf = fused_blocks_per_target(b->N);
+	if (nf > b->nblk_max) b->nblk_max = nf;
+	auto cleanup = [&](int code) { mtfhip_batch_destroy(b); return code; };
+	const int eager[] = {MTFHIP_BUF_I0, MTFHIP_BUF_IT, MTFHIP_BUF_DI0_DX, MTFHIP_BUF_DIT_DX, MTFHIP_BUF_DF_DI0,
+		MTFHIP_BUF_DF_DIT, MTFHIP_BUF_J0, MTFHIP_BUF_JT, MTFHIP_BUF_INIT_PTS, MTFHIP_BUF_CURR_PTS,
+		MTFHIP_BUF_INIT_Z, MTFHIP_BUF_CURR_Z};
+	for (int id : eager) { int r = ensure_buf(b, id); if (r) return cleanup(r); }
+#define ALLOC(ptr, bytes) do { if (hipMalloc(&(ptr), (bytes)) != hipSuccess) return cleanup(fail(MTFHIP_ERR_HIP, "hipMalloc(%zu) failed", (size_t)(bytes))); } while (0)
+	ALLOC(b->d_warps, sizeof(double) * 9 * n_targets);
+	ALLOC(b->d_states, sizeof(double) * 8 * n_targets);
+	ALLOC(b->d_partials, sizeof(double) * ACC_COUNT * b->nblk_max * n_targets);
+	ALLOC(b->d_acc, sizeof(double) * ACC_COUNT * n_targets);
+	ALLOC(b->d_scratch_pts, sizeof(double) * 8 * N * n_targets);
+	ALLOC(b->d_w0, sizeof(double) * 9 * n_targets);
+	ALLOC(b->d_h0, sizeof(double) * 64 * n_targets);
+	ALLOC(b->d_corners, sizeof(double) * 8 * n_targets);
+	ALLOC(b->d_init_corners_hm, sizeof(double) * 12 * n_targets);
+	ALLOC(b->d_active, sizeof(int) * n_targets);
+	ALLOC(b->d_iters, sizeof(int) * n_targets);
+#undef ALLOC
+	if (hipHostMalloc(&b->h_acc, sizeof(double) * ACC_COUNT * n_targets) != hipSuccess)
+		return cleanup(fail(MTFHIP_ERR_HIP, "hipHostMalloc failed"));
+	(void)hipMemsetAsync(b->d_partials, 0, sizeof(double) * ACC_COUNT * b->nblk_max * n_targets, c->stream);
+	int r = push_warps(b);
+	if (r) return cleanup(r);
+	*out = b;
+	return MTFHIP_OK;
+}
+
+void mtfhip_batch_destroy(mtfhip_batch *b) {
+	if (!b) return;
+	(void)hipSetDevice(b->ctx->device);
+	(void)hipStreamSynchronize(b->ctx->stream);
+	for (int i = 0; i < MTFHIP_BUF_COUNT; ++i)
+		if (b->buf[i]) (void)hipFree(b->buf[i]);
+	void *ptrs[] = {b->d_warps, b->d_states, b->d_partials, b->d_acc, b->d_scratch_pts, b->d_w0, b->d_h0, b->d_corners,
+		b->d_init_corners_hm, b->d_active, b->d_iters, b->d_cand};
+	for (void *p : ptrs)
+		if (p) (void)hipFree(p);
+	if (b->h_acc) (void)hipHostFree(b->h_acc);
+	delete b;
+}
+
+int mtfhip_batch_n_targets(const mtfhip_batch *b) { return b ? b->B : 0; }
+int mtfhip_batch_n_pix(const mtfhip_batch *b) { return b ? b->N : 0; }
+int mtfhip_batch_state_size(const mtfhip_batch *b) { return b ? b->S : 0; }
+
+int mtfhip_batch_read(mtfhip_batch *b, int id, double *dst) {
+	if (!b || !dst || id < 0 || id >= MTFHIP_BUF_COUNT) return fail(MTFHIP_ERR_INVALID_ARG, "batch_read: bad argument");
+	if (!b->buf[id]) return fail(MTFHIP_ERR_LOGIC, "batch_read: buffer %d was never produced", id);
+	if ((id == MTFHIP_BUF_IT && !b->it_valid) || (id == MTFHIP_BUF_DIT_DX && !b->dit_valid) || (id == MTFHIP_BUF_JT && !b->jt_valid))
+		return fail(MTFHIP_ERR_LOGIC, "batch_read: buffer %d is not materialised (last fused iteration ran with materialize=0)", id);
+	HIP_TRY(hipMemcpyAsync(dst, b->buf[id], sizeof(double) * b->per_target[id] * b->B, hipMemcpyDeviceToHost, b->ctx->stream));
+	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	return MTFHIP_OK;
+}
+
+int mtfhip_batch_write(mtfhip_batch *b, int id, const double *src) {
+	if (!b || !src || id < 0 || id >= MTFHIP_BUF_COUNT) return fail(MTFHIP_ERR_INVALID_ARG, "batch_write: bad argument");
+	TRY(ensure_buf(b, id));
+	HIP_TRY(hipMemcpyAsync(b->buf[id], src, sizeof(double) * b->per_target[id] * b->B, hipMemcpyHostToDevice, b->ctx->stream));
+	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	if (id == MTFHIP_BUF_IT) b->it_valid = true;
+	if (id == MTFHIP_BUF_DIT_DX) b->dit_valid = true;
+	if (id == MTFHIP_BUF_JT) b->jt_valid = true;
+	return MTFHIP_OK;
+}
+
+void *mtfhip_batch_device_ptr(mtfhip_batch *b, int id) {
+	if (!b || id < 0 || id >= MTFHIP_BUF_COUNT) return nullptr;
+	if (ensure_buf(b, id) != MTFHIP_OK) return nullptr;
+	return b->buf[id];
+}
+
+/* ------------------------------------------------------------------ SSM */
+int mtfhip_ssm_set_corners(mtfhip_batch *b, const double *corners) {
+	if (!b || !corners) return fail(MTFHIP_ERR_INVALID_ARG, "set_corners: NULL argument");
+	const bool hom = b->desc.ssm == MTFHIP_SSM_HOMOGRAPHY;
+	/* normalised grid extents: ProjectiveBase.cc:14 (unit square) ; Affine.cc:56-57 */
+	double lo_x = -0.5, lo_y = -0.5, hi_x = 0.5, hi_y = 0.5;
+	if (!hom) { lo_x = 1 - b->desc.resx / 2.0; lo_y = 1 - b->desc.resy / 2.0; hi_x = b->desc.resx / 2.0; hi_y = b->desc.resy / 2.0; }
+	const double nc[8] = {lo_x, lo_y, hi_x, lo_y, hi_x, hi_y, lo_x, hi_y};
+	std::vector<double> w0(9 * b->B), chm(12 * b->B);
+	int unit_z = 1;
+	for (int t = 0; t < b->B; ++t) {
+		M3 W0;
+		if (!dlt4(nc, corners + 8 * t, W0)) return fail(MTFHIP_ERR_INVALID_ARG, "set_corners: degenerate corners for target %d", t);
+		if (!hom || (std::fabs(W0.m[6]) < 1e-15 && std::fabs(W0.m[7]) < 1e-15)) {
+			if (hom) { W0.m[6] = 0; W0.m[7] = 0; }
+		} else unit_z = 0;
+		std::memcpy(&w0[9 * t], W0.m, sizeof(double) * 9);
+		TargetHost &h = b->th[t];
+		std::memcpy(h.corners, corners + 8 * t, sizeof(double) * 8);
+		std::memcpy(h.init_corners, corners + 8 * t, sizeof(double) * 8);
+		for (int q = 0; q < 4; ++q) {
+			h.init_corners_hm[3 * q] = corners[8 * t + 2 * q];
+			h.init_corners_hm[3 * q + 1] = corners[8 * t + 2 * q + 1];
+			h.init_corners_hm[3 * q + 2] = 1;
+		}
+		std::memcpy(&chm[12 * t], h.init_corners_hm, sizeof(double) * 12);
+		h.warp = m3_identity();
+		std::memset(h.state, 0, sizeof(h.state));
+	}
+	b->unit_z = hom ? unit_z : 1;
+	HIP_TRY(hipMemcpyAsync(b->d_w0, w0.data(), sizeof(double) * w0.size(), hipMemcpyHostToDevice, b->ctx->stream));
+	HIP_TRY(hipMemcpyAsync(b->d_init_corners_hm, chm.data(), sizeof(double) * chm.size(), hipMemcpyHostToDevice, b->ctx->stream));
+	{
+		TimedScope ts(b->ctx, "init_grid");
+		launch_init_grid(b->view(), b->d_w0, b->desc.resx, b->desc.resy, lo_x, lo_y, hi_x, hi_y, hom ? 0 : 1, b->ctx->stream);
+	}
+	TRY(push_warps(b));
+	b->have_corners = true;
+	return MTFHIP_OK;
+}
+
+static int apply_states(mtfhip_batch *b) {
+	TRY(push_warps(b));
+	TimedScope ts(b->ctx, "apply_warp");
+	launch_apply_warp(b->view(), b->ctx->stream);
+	return MTFHIP_OK;
+}
+
+int mtfhip_ssm_set_state(mtfhip_batch *b, const double *states) {
+	if (!b || !states) return fail(MTFHIP_ERR_INVALID_ARG, "set_state: NULL argument");
+	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "set_state before set_corners");
+	for (int t = 0; t < b->B; ++t) {
+		TargetHost &h = b->th[t];
+		std::memset(h.state, 0, sizeof(h.state));
+		std::memcpy(h.state, states + (size_t)t * b->S, sizeof(double) * b->S);
+		h.warp = warp_from_state(b->desc.ssm, h.state);
+		update_corners(b, t);
+	}
+	return apply_states(b);
+}
+
+int mtfhip_ssm_compositional_update(mtfhip_batch *b, const double *dps) {
+	if (!b || !dps) return fail(MTFHIP_ERR_INVALID_ARG, "compositional_update: NULL argument");
+	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "compositional_update before set_corners");
+	for (int t = 0; t < b->B; ++t) {
+		TargetHost &h = b->th[t];
+		double dp[8] = {0};
+		std::memcpy(dp, dps + (size_t)t * b->S, sizeof(double) * b->S);
+		M3 upd = warp_from_state(b->desc.ssm, dp);
+		h.warp = m3_mul(h.warp, upd);
+		if (b->desc.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+			double s = h.warp.m[8];
+			for (int i = 0; i < 9; ++i) h.warp.m[i] /= s;
+		}
+		state_from_warp(b->desc.ssm, h.state, h.warp);
+		update_corners(b, t);
+	}
+	return apply_states(b);
+}
+
+int mtfhip_ssm_invert_state(mtfhip_batch *b, const double *states, double *inv_states) {
+	if (!b || !states || !inv_states) return fail(MTFHIP_ERR_INVALID_ARG, "invert_state: NULL argument");
+	for (int t = 0; t < b->B; ++t) {
+		double p[8] = {0}, q[8];
+		std::memcpy(p, states + (size_t)t * b->S, sizeof(double) * b->S);
+		M3 Wi = m3_inverse(warp_from_state(b->desc.ssm, p));
+		double s = Wi.m[8];
+		for (int i = 0; i < 9; ++i) Wi.m[i] /= s;
+		state_from_warp(b->desc.ssm, q, Wi);
+		std::memcpy(inv_states + (size_t)t * b->S, q, sizeof(double) * b->S);
+	}
+	return MTFHIP_OK;
+}
+
+int mtfhip_ssm_update_grad_pts(mtfhip_batch *b, double grad_eps) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_grad_pts: NULL batch");
+	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "update_grad_pts before set_corners");
+	TRY(ensure_buf(b, MTFHIP_BUF_GRAD_PTS));
+	TimedScope ts(b->ctx, "grad_pts");
+	launch_grad_pts(b->view(), grad_eps, b->ctx->stream);
+	return MTFHIP_OK;
+}
+
+int mtfhip_ssm_cmpt_pix_jacobian(mtfhip_batch *b, int variant, int grad_buf, int dst_buf) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_pix_jacobian: NULL batch");
+	if (variant < MTFHIP_JAC_INIT || variant > MTFHIP_JAC_APPROX) return fail(MTFHIP_ERR_INVALID_ARG, "unknown Jacobian variant %d", variant);
+	if (grad_buf != MTFHIP_BUF_DI0_DX && grad_buf != MTFHIP_BUF_DIT_DX) return fail(MTFHIP_ERR_INVALID_ARG, "grad_buf must be DI0_DX or DIT_DX");
+	if (!j_buf_ok(dst_buf)) return fail(MTFHIP_ERR_INVALID_ARG, "dst_buf must be J0, JT or JM");
+	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "cmpt_pix_jacobian before set_corners");
+	TRY(ensure_buf(b, dst_buf));
+	TimedScope ts(b->ctx, "pix_jacobian");
+	launch_pix_jacobian(b->view(), variant, b->buf[grad_buf], b->buf[dst_buf], b->ctx->stream);
+	if (dst_buf == MTFHIP_BUF_JT) b->jt_valid = true;
+	return MTFHIP_OK;
+}
+
+int mtfhip_ssm_get_corners(mtfhip_batch *b, double *corners) {
+	if (!b || !corners) return fail(MTFHIP_ERR_INVALID_ARG, "get_corners: NULL argument");
+	for (int t = 0; t < b->B; ++t) std::memcpy(corners + 8 * t, b->th[t].corners, sizeof(double) * 8);
+	return MTFHIP_OK;
+}
+int mtfhip_ssm_get_init_corners(mtfhip_batch *b, double *corners) {
+	if (!b || !corners) return fail(MTFHIP_ERR_INVALID_ARG, "get_init_corners: NULL argument");
+	for (int t = 0; t < b->B; ++t) std::memcpy(corners + 8 * t, b->th[t].init_corners, sizeof(double) * 8);
+	return MTFHIP_OK;
+}
+int mtfhip_ssm_get_state(mtfhip_batch *b, double *states) {
+	if (!b || !states) return fail(MTFHIP_ERR_INVALID_ARG, "get_state: NULL argument");
+	for (int t = 0; t < b->B; ++t) std::memcpy(states + (size_t)t * b->S, b->th[t].state, sizeof(double) * b->S);
+	return MTFHIP_OK;
+}
+int mtfhip_ssm_get_warp(mtfhip_batch *b, double *warps) {
+	if (!b || !warps) return fail(MTFHIP_ERR_INVALID_ARG, "get_warp: NULL argument");
+	for (int t = 0; t < b->B; ++t) std::memcpy(warps + 9 * t, b->th[t].warp.m, sizeof(double) * 9);
+	return MTFHIP_OK;
+}
+int mtfhip_ssm_apply_warp_to_corners(mtfhip_batch *b, const double *in_corners, const double *states, double *out_corners) {
+	if (!b || !in_corners || !states || !out_corners) return fail(MTFHIP_ERR_INVALID_ARG, "apply_warp_to_corners: NULL argument");
+	for (int t = 0; t < b->B; ++t) {
+		double p[8] = {0};
+		std::memcpy(p, states + (size_t)t * b->S, sizeof(double) * b->S);
+		M3 W = warp_from_state(b->desc.ssm, p);
+		for (int q = 0; q < 4; ++q) {
+			double x = in_corners[8 * t + 2 * q], y = in_corners[8 * t + 2 * q + 1];
+			double nx = W.m[0] * x + W.m[1] * y + W.m[2], ny = W.m[3] * x + W.m[4] * y + W.m[5];
+			if (b->desc.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+				double d = W.m[6] * x + W.m[7] * y + W.m[8];
+				nx = nx / d; ny = ny / d;
+			}
+			out_corners[8 * t + 2 * q] = nx; out_corners[8 * t + 2 * q + 1] = ny;
+		}
+	}
+	return MTFHIP_OK;
+}
+
+/* ------------------------------------------------------------------ ImageBase */
+int mtfhip_am_initialize_pix_vals(mtfhip_batch *b, const double *pts) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "initialize_pix_vals: NULL batch");
+	TRY(need_image(b));
+	const double *dp;
+	TRY(resolve_pts(b, pts, MTFHIP_BUF_CURR_PTS, 2 * (size_t)b->N, &dp));
+	{
+		TimedScope ts(b->ctx, "sample");
+		launch_sample(b->view(), b->ctx->img, dp, b->buf[MTFHIP_BUF_I0], b->norm_mult, b->norm_add, b->ctx->stream);
+	}
+	if (!b->init_pix_vals) {
+		HIP_TRY(hipMemcpyAsync(b->buf[MTFHIP_BUF_IT], b->buf[MTFHIP_BUF_I0], sizeof(double) * b->N * b->B, hipMemcpyDeviceToDevice, b->ctx->stream));
+		b->init_pix_vals = true;
+		b->it_valid = true;
+	}
+	return MTFHIP_OK;
+}
+int mtfhip_am_update_pix_vals(mtfhip_batch *b, const double *pts) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_pix_vals: NULL batch");
+	TRY(need_image(b));
+	const double *dp;
+	TRY(resolve_pts(b, pts, MTFHIP_BUF_CURR_PTS, 2 * (size_t)b->N, &dp));
+	TimedScope ts(b->ctx, "sample");
+	launch_sample(b->view(), b->ctx->img, dp, b->buf[MTFHIP_BUF_IT], b->norm_mult, b->norm_add, b->ctx->stream);
+	b->it_valid = true;
+	return MTFHIP_OK;
+}
+static int pix_grad_common(mtfhip_batch *b, const double *pts, bool warped, bool init) {
+	TRY(need_image(b));
+	const double *dp;
+	if (warped) TRY(resolve_pts(b, pts, MTFHIP_BUF_GRAD_PTS, 8 * (size_t)b->N, &dp));
+	else TRY(resolve_pts(b, pts, MTFHIP_BUF_CURR_PTS, 2 * (size_t)b->N, &dp));
+	double *dst = b->buf[init ? MTFHIP_BUF_DI0_DX : MTFHIP_BUF_DIT_DX];
+	{
+		TimedScope ts(b->ctx, warped ? "warped_img_grad" : "img_grad");
+		if (warped) launch_warped_img_grad(b->view(), b->ctx->img, dp, dst, b->desc.grad_eps, b->norm_mult, b->ctx->stream);
+		else launch_img_grad(b->view(), b->ctx->img, dp, dst, b->desc.grad_eps, b->norm_mult, b->ctx->stream);
+	}
+	if (init && !b->init_pix_grad) {
+		HIP_TRY(hipMemcpyAsync(b->buf[MTFHIP_BUF_DIT_DX], b->buf[MTFHIP_BUF_DI0_DX], sizeof(double) * 2 * b->N * b->B, hipMemcpyDeviceToDevice, b->ctx->stream));
+		b->init_pix_grad = true;
+		b->dit_valid = true;
+	}
+	if (!init) b->dit_valid = true;
+	return MTFHIP_OK;
+}
+int mtfhip_am_initialize_pix_grad(mtfhip_batch *b, const double *pts) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "initialize_pix_grad: NULL batch");
+	return pix_grad_common(b, pts, false, true);
+}
+int mtfhip_am_update_pix_grad(mtfhip_batch *b, const double *pts) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_pix_grad: NULL batch");
+	return pix_grad_common(b, pts, false, false);
+}
+int mtfhip_am_initialize_pix_grad_warped(mtfhip_batch *b, const double *gp) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "initialize_pix_grad_warped: NULL batch");
+	return pix_grad_common(b, gp, true, true);
+}
+int mtfhip_am_update_pix_grad_warped(mtfhip_batch *b, const double *gp) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_pix_grad_warped: NULL batch");
+	return pix_grad_common(b, gp, true, false);
+}
+
+/* ------------------------------------------------------------------ AppearanceModel */
+static int am_supported(mtfhip_batch *b, const char *fn) {
+	if (b->desc.am == MTFHIP_AM_SSD) return MTFHIP_OK;
+	return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s :: appearance model %d is not available on the device path yet", fn, b->desc.am);
+}
+
+int mtfhip_am_initialize_similarity(mtfhip_batch *b) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "initialize_similarity: NULL batch");
+	TRY(am_supported(b, "initializeSimilarity"));
+	if (b->init_sim) return MTFHIP_OK;
+	HIP_TRY(hipMemsetAsync(b->buf[MTFHIP_BUF_DF_DI0], 0, sizeof(double) * b->N * b->B, b->ctx->stream));
+	for (auto &h : b->th) h.f = 0;
+	b->init_sim = true;
+	return MTFHIP_OK;
+}
+int mtfhip_am_initialize_grad(mtfhip_batch *b) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "initialize_grad: NULL batch");
+	TRY(am_supported(b, "initializeGrad"));
+	if (b->init_grad) return MTFHIP_OK;
+	HIP_TRY(hipMemcpyAsync(b->buf[MTFHIP_BUF_DF_DIT], b->buf[MTFHIP_BUF_DF_DI0], sizeof(double) * b->N * b->B, hipMemcpyDeviceToDevice, b->ctx->stream));
+	b->init_grad = true;
+	return MTFHIP_OK;
+}
+int mtfhip_am_initialize_hess(mtfhip_batch *b) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "initialize_hess: NULL batch");
+	return am_supported(b, "initializeHess");
+}
+int mtfhip_am_update_similarity(mtfhip_batch *b, int prereq_only) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_similarity: NULL batch");
+	TRY(am_supported(b, "updateSimilarity"));
+	if (!b->init_sim) return fail(MTFHIP_ERR_LOGIC, "updateSimilarity before initializeSimilarity");
+	int nblk = simple_blocks_per_target(b->N);
+	{
+		TimedScope ts(b->ctx, "ssd_residual");
+		launch_ssd_residual(b->view(), b->d_partials, nblk, b->ctx->stream);
+	}
+	if (prereq_only) return MTFHIP_OK;
+	TRY(read_acc(b, nblk));
+	for (int t = 0; t < b->B; ++t) b->th[t].f = -b->h_acc[(size_t)t * ACC_COUNT + ACC_RR] / 2;
+	return MTFHIP_OK;
+}
+int mtfhip_am_update_curr_grad(mtfhip_batch *b) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_curr_grad: NULL batch");
+	TRY(am_supported(b, "updateCurrGrad"));
+	TimedScope ts(b->ctx, "negate");
+	launch_negate(b->buf[MTFHIP_BUF_DF_DI0], b->buf[MTFHIP_BUF_DF_DIT], (size_t)b->N * b->B, b->ctx->stream);
+	return MTFHIP_OK;
+}
+int mtfhip_am_update_init_grad(mtfhip_batch *b) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_init_grad: NULL batch");
+	return am_supported(b, "updateInitGrad");
+}
+int mtfhip_am_get_similarity(mtfhip_batch *b, double *f) {
+	if (!b || !f) return fail(MTFHIP_ERR_INVALID_ARG, "get_similarity: NULL argument");
+	for (int t = 0; t < b->B; ++t) f[t] = b->th[t].f;
+	return MTFHIP_OK;
+}
+int mtfhip_am_get_likelihood(mtfhip_batch *b, double *l) {
+	if (!b || !l) return fail(MTFHIP_ERR_INVALID_ARG, "get_likelihood: NULL argument");
+	for (int t = 0; t < b->B; ++t) {
+		double f = b->th[t].f;
+		if (b->desc.am == MTFHIP_AM_SSD) l[t] = std::exp(-b->desc.likelihood_alpha * std::sqrt(-f / (double)b->N));
+		else { double d = (1.0 / f) - 1; l[t] = std::exp(-b->desc.likelihood_alpha * d * d); }
+	}
+	return MTFHIP_OK;
+}
+
+static int gemv_to_host(mtfhip_batch *b, const double *v1, int j1, const double *v2, int j2, int sum_mode, double *g, int diff) {
+	int nblk = simple_blocks_per_target(b->N);
+	{
+		TimedScope ts(b->ctx, "gemv");
+		launch_gemv(b->view(), v1, b->buf[j1], v2, j2 >= 0 ? b->buf[j2] : nullptr, sum_mode, b->d_partials, nblk, b->ctx->stream);
+	}
+	TRY(read_acc(b, nblk));
+	for (int t = 0; t < b->B; ++t)
+		for (int s = 0; s < b->S; ++s) {
+			double v = b->h_acc[(size_t)t * ACC_COUNT + ACC_G + s];
+			if (diff) v -= b->h_acc[(size_t)t * ACC_COUNT + ACC_G2 + s];
+			g[(size_t)t * b->S + s] = v;
+		}
+	return MTFHIP_OK;
+}
+static int j_ready(mtfhip_batch *b, int id, const char *fn) {
+	if (!j_buf_ok(id)) return fail(MTFHIP_ERR_INVALID_ARG, "%s: Jacobian buffer id %d is not J0/JT/JM", fn, id);
+	if (!b->buf[id]) return fail(MTFHIP_ERR_LOGIC, "%s: Jacobian buffer %d was never produced", fn, id);
+	if (id == MTFHIP_BUF_JT && !b->jt_valid) return fail(MTFHIP_ERR_LOGIC, "%s: JT is not materialised", fn);
+	return MTFHIP_OK;
+}
+int mtfhip_am_cmpt_init_jacobian(mtfhip_batch *b, int j0_buf, double *g) {
+	if (!b || !g) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_init_jacobian: NULL argument");
+	TRY(am_supported(b, "cmptInitJacobian"));
+	TRY(j_ready(b, j0_buf, "cmptInitJacobian"));
+	return gemv_to_host(b, b->buf[MTFHIP_BUF_DF_DI0], j0_buf, nullptr, -1, 0, g, 0);
+}
+int mtfhip_am_cmpt_curr_jacobian(mtfhip_batch *b, int jt_buf, double *g) {
+	if (!b || !g) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_curr_jacobian: NULL argument");
+	TRY(am_supported(b, "cmptCurrJacobian"));
+	TRY(j_ready(b, jt_buf, "cmptCurrJacobian"));
+	return gemv_to_host(b, b->buf[MTFHIP_BUF_DF_DIT], jt_buf, nullptr, -1, 0, g, 0);
+}
+int mtfhip_am_cmpt_difference_of_jacobians(mtfhip_batch *b, int j0_buf, int jt_buf, double *g) {
+	if (!b || !g) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_difference_of_jacobians: NULL argument");
+	TRY(am_supported(b, "cmptDifferenceOfJacobians"));
+	TRY(j_ready(b, j0_buf, "cmptDifferenceOfJacobians"));
+	TRY(j_ready(b, jt_buf, "cmptDifferenceOfJacobians"));
+	/* SSD: df_dIt * (dI0_dpssm + dIt_dpssm), SSDBase.cc:186 */
+	return gemv_to_host(b, b->buf[MTFHIP_BUF_DF_DIT], jt_buf, nullptr, j0_buf, 1, g, 0);
+}
+static int gram_to_host(mtfhip_batch *b, int j_buf, double *H, double scale, bool accumulate) {
+	int nblk = simple_blocks_per_target(b->N);
+	{
+		TimedScope ts(b->ctx, "gram");
+		launch_gram(b->view(), b->buf[j_buf], b->d_partials, nblk, b->ctx->stream);
+	}
+	TRY(read_acc(b, nblk));
+	const int S = b->S;
+	for (int t = 0; t < b->B; ++t) {
+		int k = 0;
+		for (int a = 0; a < 8; ++a)
+			for (int c = a; c < 8; ++c) {
+				if (a < S && c < S) {
+					double v = scale * b->h_acc[(size_t)t * ACC_COUNT + ACC_H + k];
+					double *Ht = H + (size_t)t * S * S;
+					if (accumulate) { Ht[c * S + a] += v; if (a != c) Ht[a * S + c] += v; }
+					else { Ht[c * S + a] = v; Ht[a * S + c] = v; }
+				}
+				++k;
+			}
+	}
+	return MTFHIP_OK;
+}
+int mtfhip_am_cmpt_init_hessian(mtfhip_batch *b, int j0_buf, double *H) {
+	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_init_hessian: NULL argument");
+	TRY(am_supported(b, "cmptInitHessian"));
+	TRY(j_ready(b, j0_buf, "cmptInitHessian"));
+	return gram_to_host(b, j0_buf, H, -1.0, false);
+}
+int mtfhip_am_cmpt_curr_hessian(mtfhip_batch *b, int jt_buf, double *H) {
+	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_curr_hessian: NULL argument");
+	TRY(am_supported(b, "cmptCurrHessian"));
+	TRY(j_ready(b, jt_buf, "cmptCurrHessian"));
+	return gram_to_host(b, jt_buf, H, -1.0, false);
+}
+int mtfhip_am_cmpt_self_hessian(mtfhip_batch *b, int jt_buf, double *H) {
+	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_self_hessian: NULL argument");
+	TRY(am_supported(b, "cmptSelfHessian"));
+	TRY(j_ready(b, jt_buf, "cmptSelfHessian"));
+	return gram_to_host(b, jt_buf, H, -1.0, false);
+}
+int mtfhip_am_cmpt_sum_of_hessians(mtfhip_batch *b, int j0_buf, int jt_buf, double *H) {
+	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_sum_of_hessians: NULL argument");
+	TRY(am_supported(b, "cmptSumOfHessians"));
+	TRY(j_ready(b, j0_buf, "cmptSumOfHessians"));
+	TRY(j_ready(b, jt_buf, "cmptSumOfHessians"));
+	TRY(gram_to_host(b, j0_buf, H, -1.0, false));
+	return gram_to_host(b, jt_buf, H, -1.0, true);
+}
+int mtfhip_sm_mean_jacobian(mtfhip_batch *b) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "mean_jacobian: NULL batch");
+	TRY(j_ready(b, MTFHIP_BUF_J0, "mean_jacobian"));
+	TRY(j_ready(b, MTFHIP_BUF_JT, "mean_jacobian"));
+	TRY(ensure_buf(b, MTFHIP_BUF_JM));
+	TimedScope ts(b->ctx, "mean_jacobian");
+	launch_mean_jacobian(b->view(), b->ctx->stream);
+	return MTFHIP_OK;
+}
+
+/* ------------------------------------------------------------------ fused path */
+static int check_sm(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const char *fn) {
+	if (!b || !sm) return fail(MTFHIP_ERR_INVALID_ARG, "%s: NULL argument", fn);
+	if (sm->sm < MTFHIP_SM_ESM || sm->sm > MTFHIP_SM_ICLK) return fail(MTFHIP_ERR_INVALID_ARG, "%s: unknown search method %d", fn, sm->sm);
+	int max_h = sm->sm == MTFHIP_SM_ESM ? 5 : 2;
+	if (sm->hess_type < 0 || sm->hess_type > max_h) return fail(MTFHIP_ERR_INVALID_ARG, "%s: hess_type %d invalid for search method %d", fn, sm->hess_type, sm->sm);
+	if (b->desc.am != MTFHIP_AM_SSD) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: the fused path supports the SSD appearance model only", fn);
+	return MTFHIP_OK;
+}
+
+int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
+	TRY(check_sm(b, sm, "init_template"));
+	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "init_template before set_corners");
+	/* am->clearInitStatus() (NT/ESM.cc:113, NT/FCLK.cc:105, NT/ICLK.cc:74) */
+	b->init_pix_vals = b->init_pix_grad = b->init_sim = b->init_grad = false;
+	TRY(mtfhip_am_initialize_pix_vals(b, nullptr));
+	if (sm->chained_warp) {
+		TRY(mtfhip_am_initialize_pix_grad(b, nullptr));
+		TRY(mtfhip_ssm_cmpt_pix_jacobian(b, MTFHIP_JAC_WARPED, MTFHIP_BUF_DI0_DX, MTFHIP_BUF_J0));
+	} else {
+		TRY(mtfhip_ssm_update_grad_pts(b, b->desc.grad_eps));
+		TRY(mtfhip_am_initialize_pix_grad_warped(b, nullptr));
+		TRY(mtfhip_ssm_cmpt_pix_jacobian(b, MTFHIP_JAC_INIT, MTFHIP_BUF_DI0_DX, MTFHIP_BUF_J0));
+	}
+	TRY(mtfhip_am_initialize_similarity(b));
+	TRY(mtfhip_am_initialize_grad(b));
+	TRY(mtfhip_am_initialize_hess(b));
+	std::vector<double> H0((size_t)b->B * b->S * b->S), h0dev((size_t)b->B * 64, 0.0);
+	TRY(mtfhip_am_cmpt_self_hessian(b, MTFHIP_BUF_J0, H0.data()));
+	for (int t = 0; t < b->B; ++t) {
+		std::memset(b->th[t].h0, 0, sizeof(b->th[t].h0));
+		std::memcpy(b->th[t].h0, &H0[(size_t)t * b->S * b->S], sizeof(double) * b->S * b->S);
+		std::memcpy(&h0dev[(size_t)t * 64], b->th[t].h0, sizeof(double) * 64);
+	}
+	HIP_TRY(hipMemcpyAsync(b->d_h0, h0dev.data(), sizeof(double) * h0dev.size(), hipMemcpyHostToDevice, b->ctx->stream));
+	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	return MTFHIP_OK;
+}
+
+static int fused_args(const mtfhip_batch *b, const mtfhip_sm_desc *sm, FusedArgs &fa) {
+	fa.chained = sm->chained_warp ? 1 : 0;
+	fa.materialize = sm->materialize ? 1 : 0;
+	fa.hess_mean = 0;
+	fa.grad_eps = b->desc.grad_eps;
+	fa.norm_mult = b->norm_mult; fa.norm_add = b->norm_add;
+	fa.active = nullptr;
+	switch (sm->sm) {
+	case MTFHIP_SM_FCLK: fa.mode = 0; break;
+	case MTFHIP_SM_ESM: fa.mode = 1; fa.hess_mean = sm->hess_type == 3; break;
+	default:
+		if (sm->hess_type == 1) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "fused ICLK with hess_type CurrentSelf: use the un-fused entry points");
+		fa.mode = 2;
+	}
+	return MTFHIP_OK;
+}
+
+/* turns one target's reduced accumulators into the SM's g and H (before LM damping):
+ * NT/FCLK.cc:260-288 ; NT/ESM.cc:298-377 with SSDBase.cc:169-191,287-311 ; NT/ICLK.cc:206-251 */
+static void assemble(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const double *acc, const double *h0,
+	double *f, double *g, double *H) {
+	const int S = b->S;
+	if (f) *f = -acc[ACC_RR] / 2;
+	const double gscale = sm->sm == MTFHIP_SM_ESM ? 0.5 : 1.0;
+	for (int s = 0; s < S; ++s) g[s] = gscale * acc[ACC_G + s];
+	const bool use_h0 = (sm->hess_type == 0) || (sm->sm == MTFHIP_SM_ICLK);
+	const bool sum_h0 = (sm->sm == MTFHIP_SM_ESM) && (sm->hess_type == 2 || sm->hess_type == 4);
+	int k = 0;
+	for (int a = 0; a < 8; ++a)
+		for (int c = a; c < 8; ++c) {
+			if (a < S && c < S) {
+				double v = use_h0 ? h0[c * S + a] : -acc[ACC_H + k];
+				if (sum_h0) v = (v + h0[c * S + a]) * 0.5;
+				H[c * S + a] = v; H[a * S + c] = v;
+			}
+			++k;
+		}
+}
+
+int mtfhip_batch_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, double *g, double *H) {
+	TRY(check_sm(b, sm, "iterate"));
+	if (!g || !H) return fail(MTFHIP_ERR_INVALID_ARG, "iterate: NULL output");
+	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "iterate before init_template");
+	TRY(need_image(b));
+	FusedArgs fa;
+	TRY(fused_args(b, sm, fa));
+	int nblk = fused_blocks_per_target(b->N);
+	{
+		TimedScope ts(b->ctx, "fused_lk");
+		launch_fused_ssd(b->view(), b->ctx->img, fa, b->d_partials, nblk, b->ctx->stream);
+	}
+	b->it_valid = fa.materialize;
+	b->dit_valid = fa.materialize && fa.mode != 2;
+	b->jt_valid = fa.materialize && fa.mode != 2;
+	TRY(read_acc(b, nblk));
+	for (int t = 0; t < b->B; ++t) {
+		double ft;
+		assemble(b, sm, b->h_acc + (size_t)t * ACC_COUNT, b->th[t].h0, &ft, g + (size_t)t * b->S, H + (size_t)t * b->S * b->S);
+		b->th[t].f = ft;
+		if (f) f[t] = ft;
+	}
+	return MTFHIP_OK;
+}
+
+int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners) {
+	TRY(check_sm(b, sm, "track"));
+	if (sm->leven_marq) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: Levenberg-Marquardt is only available through iterate + host solve");
+	if (sm->max_iters <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "track: max_iters must be positive");
+	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "track before init_template");
+	TRY(need_image(b));
+	FusedArgs fa;
+	TRY(fused_args(b, sm, fa));
+	hipStream_t st = b->ctx->stream;
+	std::vector<int> ones(b->B, 1);
+	std::vector<double> cr(8 * (size_t)b->B);
+	for (int t = 0; t < b->B; ++t) std::memcpy(&cr[8 * t], b->th[t].corners, sizeof(double) * 8);
+	HIP_TRY(hipMemcpyAsync(b->d_active, ones.data(), sizeof(int) * b->B, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemsetAsync(b->d_iters, 0, sizeof(int) * b->B, st));
+	HIP_TRY(hipMemcpyAsync(b->d_corners, cr.data(), sizeof(double) * cr.size(), hipMemcpyHostToDevice, st));
+	TRY(push_warps(b));
+	fa.active = b->d_active;
+	TrackState ts{b->d_acc, b->d_h0, b->d_corners, b->d_init_corners_hm, b->d_active, b->d_iters};
+	int nblk = fused_blocks_per_target(b->N);
+	BatchView bv = b->view();
+	for (int it = 0; it < sm->max_iters; ++it) {
+		{
+			TimedScope tsc(b->ctx, "fused_lk");
+			launch_fused_ssd(bv, b->ctx->img, fa, b->d_partials, nblk, st);
+		}
+		launch_finish(b->d_partials, nblk, b->d_acc, b->B, st);
+		launch_track_step(bv, *sm, ts, st);
+	}
+	std::vector<double> w(9 * (size_t)b->B), s(8 * (size_t)b->B);
+	std::vector<int> iters(b->B);
+	HIP_TRY(hipMemcpyAsync(w.data(), b->d_warps, sizeof(double) * w.size(), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(s.data(), b->d_states, sizeof(double) * s.size(), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(cr.data(), b->d_corners, sizeof(double) * cr.size(), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(iters.data(), b->d_iters, sizeof(int) * b->B, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	for (int t = 0; t < b->B; ++t) {
+		std::memcpy(b->th[t].warp.m, &w[9 * t], sizeof(double) * 9);
+		std::memcpy(b->th[t].state, &s[8 * t], sizeof(double) * 8);
+		std::memcpy(b->th[t].corners, &cr[8 * t], sizeof(double) * 8);
+		if (n_iters) n_iters[t] = iters[t];
+		if (corners) std::memcpy(corners + 8 * t, &cr[8 * t], sizeof(double) * 8);
+	}
+	b->it_valid = fa.materialize;
+	b->dit_valid = b->jt_valid = fa.materialize && fa.mode != 2;
+	/* curr_pts follow the final warp */
+	launch_apply_warp(b->view(), st);
+	return MTFHIP_OK;
+}
+
+/* ------------------------------------------------------------------ candidate scoring */
+int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int C, double *dev_lik, double *dev_sim) {
+	if (!b || !dev_states) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: NULL argument");
+	if (C <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: n_candidates must be positive");
+	if (b->desc.am != MTFHIP_AM_SSD) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "score_candidates: SSD only");
+	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "score_candidates before the template was initialised");
+	TRY(need_image(b));
+	TimedScope ts(b->ctx, "score_candidates");
+	launch_score_candidates(b->view(), b->ctx->img, dev_states, C, b->desc.likelihood_alpha, dev_lik, dev_sim, b->ctx->stream);
+	return MTFHIP_OK;
+}
+
+int mtfhip_score_candidates(mtfhip_batch *b, const double *states, int C, double *lik, double *sim) {
+	if (!b || !states) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: NULL argument");
+	if (C <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: n_candidates must be positive");
+	size_t need = (size_t)C * (b->S + 2);
+	if (need > b->cand_capacity) {
+		if (b->d_cand) HIP_TRY(hipFree(b->d_cand));
+		b->d_cand = nullptr;
+		HIP_TRY(hipMalloc(&b->d_cand, sizeof(double) * need));
+		b->cand_capacity = need;
+	}
+	double *d_states = b->d_cand, *d_lik = b->d_cand + (size_t)C * b->S, *d_sim = d_lik + C;
+	HIP_TRY(hipMemcpyAsync(d_states, states, sizeof(double) * C * b->S, hipMemcpyHostToDevice, b->ctx->stream));
+	TRY(mtfhip_score_candidates_dev(b, d_states, C, d_lik, d_sim));
+	if (lik) HIP_TRY(hipMemcpyAsync(lik, d_lik, sizeof(double) * C, hipMemcpyDeviceToHost, b->ctx->stream));
+	if (sim) HIP_TRY(hipMemcpyAsync(sim, d_sim, sizeof(double) * C, hipMemcpyDeviceToHost, b->ctx->stream));
+	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	return MTFHIP_OK;
+}
+
+/* ------------------------------------------------------------------ timing */
+int mtfhip_timing_enable(mtfhip_ctx *c, int on) {
+	if (!c) return fail(MTFHIP_ERR_INVALID_ARG, "timing_enable: NULL ctx");
+	c->timing = on != 0;
+	return MTFHIP_OK;
+}
+static void drain(mtfhip_ctx *c) {
+	(void)hipStreamSynchronize(c->stream);
+	for (auto &kv : c->timers) {
+		for (auto &p : kv.second.pending) {
+			float ms = 0;
+			if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { kv.second.total_ms += ms; kv.second.n += 1; }
+			c->free_events.push_back(p.first);
+			c->free_events.push_back(p.second);
+		}
+		kv.second.pending.clear();
+	}
+}
+int mtfhip_timing_reset(mtfhip_ctx *c) {
+	if (!c) return fail(MTFHIP_ERR_INVALID_ARG, "timing_reset: NULL ctx");
+	drain(c);
+	for (auto &kv : c->timers) { kv.second.total_ms = 0; kv.second.n = 0; }
+	return MTFHIP_OK;
+}
+int mtfhip_timing_get(mtfhip_ctx *c, const char *family, double *avg_ms, int *n_launches) {
+	if (!c || !family) return fail(MTFHIP_ERR_INVALID_ARG, "timing_get: NULL argument");
+	drain(c);
+	auto it = c->timers.find(family);
+	double avg = 0; int n = 0;
+	if (it != c->timers.end() && it->second.n > 0) { avg = it->second.total_ms / it->second.n; n = it->second.n; }
+	if (avg_ms) *avg_ms = avg;
+	if (n_launches) *n_launches = n;
+	return MTFHIP_OK;
+}
+
+} /* extern "C" */

@@ -1,0 +1,95 @@
+/*
+ * mtfhip_internal.h -- shared between the HIP kernels (mtfhip_kernels.hip) and the C-ABI
+ * implementation (mtfhip_api.hip).  Not installed; the public contract is include/mtfhip.h.
+ */
+#ifndef MTFHIP_INTERNAL_H
+#define MTFHIP_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include "../../include/mtfhip.h"
+
+namespace mtfhip {
+
+struct ImgView {
+	const float *data;
+	int h, w, stride;
+};
+
+/* POD view of a batch, passed by value to kernels.  Every buf[i] is [B][per-target size]. */
+struct BatchView {
+	int B, N, S, ssm, am;
+	int unit_z;           /* 1: every init_z == 1 (affine SSM or parallelogram corners) */
+	double *buf[MTFHIP_BUF_COUNT];
+	double *warps;        /* [B][9] row-major curr_warp */
+	double *states;       /* [B][8] curr_state */
+};
+
+/* accumulator slots produced by the reducing kernels, per target */
+enum {
+	ACC_H = 0,            /* 36: upper triangle of sum J_a J_b, row-major over (a<=b) with S=8 stride */
+	ACC_G = 36,           /* 8 : sum v_i * Jrow_i  (v = residual-type vector of the mode) */
+	ACC_RR = 44,          /* 1 : sum r^2 */
+	ACC_G2 = 45,          /* 8 : second gemv (ESM generic: df_dI0 * J0) */
+	ACC_COUNT = 56        /* padded so the halving butterfly divides evenly 3 times */
+};
+
+constexpr int kBlock = 256;       /* threads per workgroup: 4 wave64 */
+constexpr int kFusedPPT = 8;      /* pixels per thread in the fused kernels */
+constexpr int kMaxS = 8;
+
+inline int fused_blocks_per_target(int N) { return (N + kBlock * kFusedPPT - 1) / (kBlock * kFusedPPT); }
+inline int simple_blocks_per_target(int N) {
+	int nb = (N + kBlock * 4 - 1) / (kBlock * 4);
+	return nb < 1 ? 1 : nb;
+}
+
+struct FusedArgs {
+	int mode;          /* accumulation mode: 0 FCLK-type, 1 ESM-type, 2 ICLK-lite (see k_fused_ssd) */
+	int chained;
+	int materialize;
+	int hess_mean;     /* ESM hess_type Original: outer products of (J0+Jt)/2 instead of Jt */
+	double grad_eps;
+	double norm_mult, norm_add;
+	const int *active; /* optional [B] mask: targets with 0 are skipped (device-side loop) */
+};
+
+/* ---- launchers (all asynchronous on `st`) ---- */
+void launch_apply_warp(const BatchView &bv, hipStream_t st);
+void launch_grad_pts(const BatchView &bv, double eps, hipStream_t st);
+void launch_sample(const BatchView &bv, const ImgView &im, const double *pts, double *out,
+	double mult, double add, hipStream_t st);
+void launch_img_grad(const BatchView &bv, const ImgView &im, const double *pts, double *grad,
+	double eps, double mult, hipStream_t st);
+void launch_warped_img_grad(const BatchView &bv, const ImgView &im, const double *grad_pts, double *grad,
+	double eps, double mult, hipStream_t st);
+void launch_pix_jacobian(const BatchView &bv, int variant, const double *grad, double *J, hipStream_t st);
+void launch_mean_jacobian(const BatchView &bv, hipStream_t st);
+/* df_dI0 = It - I0 ; partial sums of r^2 into `partials` ([B][nblk][ACC_COUNT]) */
+void launch_ssd_residual(const BatchView &bv, double *partials, int nblk, hipStream_t st);
+void launch_negate(const double *src, double *dst, size_t n, hipStream_t st);
+/* g-type partials: sum_i (v1[i]*J1[i,:] (+ v2[i]*J2[i,:] into ACC_G2, or + v1[i]*J2[i,:] into ACC_G when sum_mode)) */
+void launch_gemv(const BatchView &bv, const double *v1, const double *J1, const double *v2, const double *J2,
+	int sum_mode, double *partials, int nblk, hipStream_t st);
+/* H-type partials: sum_i J[i,a] J[i,b] */
+void launch_gram(const BatchView &bv, const double *J, double *partials, int nblk, hipStream_t st);
+/* sums partials over blocks: out[B][ACC_COUNT] */
+void launch_finish(double *partials, int nblk, double *out, int B, hipStream_t st);
+/* the fused LK iteration for SSD */
+void launch_fused_ssd(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials,
+	int nblk, hipStream_t st);
+/* candidate scoring: target 0's template under C warps given as states */
+void launch_score_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C,
+	double likelihood_alpha, double *dev_lik, double *dev_sim, hipStream_t st);
+/* device-side solve + compositional update + convergence test for mtfhip_batch_track */
+struct TrackState {
+	double *acc;        /* [B][ACC_COUNT] reduced accumulators of this iteration */
+	double *h0;         /* [B][64] constant (init) self Hessian, column-major, already negated sums */
+	double *corners;    /* [B][8] current corners */
+	double *init_corners_hm; /* [B][12] */
+	int *active;        /* [B] 1 while the target still iterates */
+	int *n_iters;       /* [B] */
+};
+void launch_track_step(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, hipStream_t st);
+
+} // namespace mtfhip
+#endif

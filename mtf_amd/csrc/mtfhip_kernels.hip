@@ -1,0 +1,900 @@
+/*
+ * mtfhip_kernels.hip -- hand-written CDNA4 (gfx950) kernels of MTF's Lucas-Kanade inner loop.
+ *
+ * Compiled with -ffp-contract=off: the per-pixel arithmetic (bilinear sample, finite-difference
+ * gradient, warp, steepest-descent row) is written in the reference's operation order so that,
+ * without FMA contraction, it rounds exactly like the CPU/Eigen path; only the N-wide reductions
+ * (explicit fma accumulation + wavefront shuffles) sum in a different order.
+ *
+ * Execution model: 256-thread workgroups (4 wave64), each thread walks kFusedPPT pixels strided by
+ * the workgroup size so that every wave touches 64 consecutive pixels of a column-major N x S
+ * array per instruction (512-byte coalesced segments).  The S x S Hessian is never a GEMM: 36
+ * upper-triangle products + 8 gradient terms + r^2 are kept in registers per thread, reduced across
+ * the wave with a halving butterfly (each exchange step halves the number of live accumulators, so
+ * 48 accumulators cost 51 exchanges instead of 6 x 48), then across the 4 waves through LDS, and
+ * written as one partial row per workgroup; a second tiny kernel sums the rows in a fixed order
+ * (deterministic, no atomics).
+ */
+#include "mtfhip_internal.h"
+
+namespace mtfhip {
+
+/* ===================================================================== */
+/* device helpers                                                         */
+/* ===================================================================== */
+
+/* utils::getPixVal<Linear, Constant> -- Utilities/include/mtf/Utilities/imgUtils.h:91-113
+ * (overflow test :51-53, overflow_val = 128).  Same operation order as the reference. */
+__device__ __forceinline__ double pix_val(const ImgView &im, double x, double y) {
+	const double w = (double)(unsigned int)im.w, h = (double)(unsigned int)im.h;
+	if ((x < 0) || (x >= w) || (y < 0) || (y >= h)) return 128.0;
+	int lx = (int)x, ly = (int)y;
+	double dx = x - lx, dy = y - ly;
+	int ux = dx == 0 ? lx : lx + 1;
+	int uy = dy == 0 ? ly : ly + 1;
+	if (ux >= im.w || uy >= im.h) return 128.0;
+	const float *r0 = im.data + (size_t)ly * im.stride;
+	const float *r1 = im.data + (size_t)uy * im.stride;
+	double t00 = r0[lx], t01 = r0[ux], t10 = r1[lx], t11 = r1[ux];
+	return t00 * (1 - dx) * (1 - dy) + t01 * dx * (1 - dy) + t10 * (1 - dx) * dy + t11 * dx * dy;
+}
+
+/* The centre sample and its four finite-difference neighbours (step 1e-8) almost always fall in
+ * one bilinear cell; the cell's four texels are fetched once and every sample that lands in the
+ * same cell is evaluated from registers with the reference's expression, so the result is
+ * bit-identical to five independent getPixVal calls while issuing 4 loads instead of 20. */
+struct Cell {
+	int lx, ly, ux, uy;
+	double t00, t01, t10, t11;
+	bool valid;
+};
+__device__ __forceinline__ Cell load_cell(const ImgView &im, double x, double y) {
+	Cell c;
+	c.valid = false;
+	c.lx = c.ly = c.ux = c.uy = -1;
+	c.t00 = c.t01 = c.t10 = c.t11 = 0;
+	const double w = (double)(unsigned int)im.w, h = (double)(unsigned int)im.h;
+	if ((x < 0) || (x >= w) || (y < 0) || (y >= h)) return c;
+	int lx = (int)x, ly = (int)y;
+	double dx = x - lx, dy = y - ly;
+	int ux = dx == 0 ? lx : lx + 1;
+	int uy = dy == 0 ? ly : ly + 1;
+	if (ux >= im.w || uy >= im.h) return c;
+	const float *r0 = im.data + (size_t)ly * im.stride;
+	const float *r1 = im.data + (size_t)uy * im.stride;
+	c.lx = lx; c.ly = ly; c.ux = ux; c.uy = uy;
+	c.t00 = r0[lx]; c.t01 = r0[ux]; c.t10 = r1[lx]; c.t11 = r1[ux];
+	c.valid = true;
+	return c;
+}
+__device__ __forceinline__ double pix_val_cell(const ImgView &im, const Cell &c, double x, double y) {
+	const double w = (double)(unsigned int)im.w, h = (double)(unsigned int)im.h;
+	if ((x < 0) || (x >= w) || (y < 0) || (y >= h)) return 128.0;
+	int lx = (int)x, ly = (int)y;
+	double dx = x - lx, dy = y - ly;
+	int ux = dx == 0 ? lx : lx + 1;
+	int uy = dy == 0 ? ly : ly + 1;
+	if (ux >= im.w || uy >= im.h) return 128.0;
+	if (c.valid && lx == c.lx && ly == c.ly && ux == c.ux && uy == c.uy)
+		return c.t00 * (1 - dx) * (1 - dy) + c.t01 * dx * (1 - dy) + c.t10 * (1 - dx) * dy + c.t11 * dx * dy;
+	const float *r0 = im.data + (size_t)ly * im.stride;
+	const float *r1 = im.data + (size_t)uy * im.stride;
+	double t00 = r0[lx], t01 = r0[ux], t10 = r1[lx], t11 = r1[ux];
+	return t00 * (1 - dx) * (1 - dy) + t01 * dx * (1 - dy) + t10 * (1 - dx) * dy + t11 * dx * dy;
+}
+
+struct Warp9 { double m[9]; };
+__device__ __forceinline__ Warp9 load_warp(const double *p) {
+	Warp9 W;
+#pragma unroll
+	for (int i = 0; i < 9; ++i) W.m[i] = p[i];
+	return W;
+}
+
+/* halving butterfly over the 64 lanes of a wave: on entry every lane holds K partial sums in
+ * v[0..K); on exit slot j of lane l holds the wave total of index final_index<K,32>(j, l). */
+template <int K, int MASK>
+__device__ __forceinline__ void wave_halve(double *v, int lane) {
+	if constexpr (MASK == 0) {
+		return;
+	} else if constexpr (K % 2 == 0) {
+		constexpr int H = K / 2;
+		const bool up = (lane & MASK) != 0;
+#pragma unroll
+		for (int j = 0; j < H; ++j) {
+			double keep = up ? v[j + H] : v[j];
+			double send = up ? v[j] : v[j + H];
+			v[j] = keep + __shfl_xor(send, MASK);
+		}
+		wave_halve<H, (MASK >> 1)>(v, lane);
+	} else {
+#pragma unroll
+		for (int j = 0; j < K; ++j) v[j] += __shfl_xor(v[j], MASK);
+		wave_halve<K, (MASK >> 1)>(v, lane);
+	}
+}
+template <int K, int MASK>
+__device__ __forceinline__ int final_index(int j, int lane) {
+	if constexpr (MASK == 0) return j;
+	else if constexpr (K % 2 == 0) return final_index<K / 2, (MASK >> 1)>(j, lane) + ((lane & MASK) ? K / 2 : 0);
+	else return final_index<K, (MASK >> 1)>(j, lane);
+}
+template <int K, int MASK>
+__device__ __forceinline__ constexpr int final_count() {
+	if constexpr (MASK == 0) return K;
+	else if constexpr (K % 2 == 0) return final_count<K / 2, (MASK >> 1)>();
+	else return final_count<K, (MASK >> 1)>();
+}
+/* lanes that differ only in bits handled by a full (non-halving) step hold duplicates */
+template <int K, int MASK>
+__device__ __forceinline__ constexpr int dup_mask() {
+	if constexpr (MASK == 0) return 0;
+	else if constexpr (K % 2 == 0) return dup_mask<K / 2, (MASK >> 1)>();
+	else return MASK | dup_mask<K, (MASK >> 1)>();
+}
+
+/* reduce K per-thread accumulators over the workgroup and write them to dst[0..K) */
+template <int K>
+__device__ __forceinline__ void block_reduce_store(double *v, double *dst, double *lds /* [4][K] */) {
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	wave_halve<K, 32>(v, lane);
+	constexpr int CNT = final_count<K, 32>();
+	constexpr int DUP = dup_mask<K, 32>();
+	if ((lane & DUP) == 0) {
+#pragma unroll
+		for (int j = 0; j < CNT; ++j) lds[wave * K + final_index<K, 32>(j, lane)] = v[j];
+	}
+	__syncthreads();
+	if (threadIdx.x < K) {
+		double s = lds[threadIdx.x];
+#pragma unroll
+		for (int wv = 1; wv < kBlock / 64; ++wv) s += lds[wv * K + threadIdx.x];
+		dst[threadIdx.x] = s;
+	}
+}
+
+/* steepest-descent row of one pixel: S values */
+template <int SSM>
+struct Row { double v[SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6]; };
+
+/* Homography row writer shared by cmptInitPixJacobian / cmptPixJacobian / cmptWarpedPixJacobian /
+ * cmptApproxPixJacobian (SSM/src/Homography.cc:166-186, 213-224, 270-289, 330-341) */
+__device__ __forceinline__ void hom_row(double *r, double Ix, double Iy, double x, double y, double px, double py) {
+	double Ixx = Ix * x, Iyy = Iy * y, Ixy = Ix * y, Iyx = Iy * x;
+	r[0] = Ixx; r[1] = Ixy; r[2] = Ix; r[3] = Iyx; r[4] = Iyy; r[5] = Iy;
+	r[6] = -px * Ixx - py * Iyx;
+	r[7] = -px * Ixy - py * Iyy;
+}
+
+/* ===================================================================== */
+/* StateSpaceModel kernels                                                */
+/* ===================================================================== */
+
+/* Sample grid of a target from its corners: utils::getNormUnitSquarePts (Utilities/src/warpUtils.cc:15-34,
+ * LinSpaced = lo + i*step with the last element pinned to hi) pushed through the 4-corner DLT warp
+ * (ProjectiveBase::getPtsFromCorners SSM/src/ProjectiveBase.cc:20-25), then the bookkeeping of
+ * Homography::setCorners (Homography.cc:61-69: init_pts_hm keeps the un-normalised third row) or
+ * Affine::setCorners (Affine.cc:74-87: init_pts_hm is re-homogenised, third row = 1). */
+__device__ __forceinline__ double lin_spaced(int i, int n, double lo, double hi) {
+	if (n == 1 || i == n - 1) return hi;
+	return lo + i * ((hi - lo) / (n - 1));
+}
+__global__ __launch_bounds__(kBlock) void k_init_grid(BatchView bv, const double *w0_all, int resx, int resy,
+	double lo_x, double lo_y, double hi_x, double hi_y, int force_unit_z) {
+	const int t = blockIdx.y;
+	const Warp9 W = load_warp(w0_all + 9 * t);
+	double2 *ip = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * bv.N;
+	double2 *cp = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * bv.N;
+	double *iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * bv.N;
+	double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * bv.N;
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < bv.N; i += gridDim.x * kBlock) {
+		const int col = i % resx, row = i / resx;
+		const double nx = lin_spaced(col, resx, lo_x, hi_x), ny = lin_spaced(row, resy, lo_y, hi_y);
+		const double X = W.m[0] * nx + W.m[1] * ny + W.m[2] * 1.0;
+		const double Y = W.m[3] * nx + W.m[4] * ny + W.m[5] * 1.0;
+		const double Z = W.m[6] * nx + W.m[7] * ny + W.m[8] * 1.0;
+		const double2 p = make_double2(X / Z, Y / Z);
+		const double z = force_unit_z ? 1.0 : Z;
+		ip[i] = p; cp[i] = p; iz[i] = z; cz[i] = z;
+	}
+}
+
+/* curr_pts_hm = curr_warp * init_pts_hm, dehomogenise (ProjectiveBase::setState
+ * SSM/src/ProjectiveBase.cc:41-49, Homography::compositionalUpdate Homography.cc:86-90);
+ * affine: curr_pts = curr_warp.topRows<2>() * init_pts_hm (Affine.cc:104,113) */
+__global__ __launch_bounds__(kBlock) void k_apply_warp(BatchView bv) {
+	const int t = blockIdx.y;
+	const Warp9 W = load_warp(bv.warps + 9 * t);
+	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * bv.N;
+	const double *iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * bv.N;
+	double2 *cp = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * bv.N;
+	double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * bv.N;
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < bv.N; i += gridDim.x * kBlock) {
+		double2 p = ip[i];
+		double z = bv.unit_z ? 1.0 : iz[i];
+		double hx = bv.unit_z ? p.x : p.x * z, hy = bv.unit_z ? p.y : p.y * z;
+		double2 o;
+		if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+			double cx = W.m[0] * hx + W.m[1] * hy + W.m[2] * z;
+			double cy = W.m[3] * hx + W.m[4] * hy + W.m[5] * z;
+			double d = W.m[6] * hx + W.m[7] * hy + W.m[8] * z;
+			o.x = cx / d; o.y = cy / d;
+			cz[i] = d;
+		} else {
+			o.x = W.m[0] * hx + W.m[1] * hy + W.m[2] * z;
+			o.y = W.m[3] * hx + W.m[4] * hy + W.m[5] * z;
+			cz[i] = 1.0;
+		}
+		cp[i] = o;
+	}
+}
+
+/* Homography::updateGradPts SSM/src/Homography.cc:803-827 ; Affine::updateGradPts Affine.cc:293-313 */
+__global__ __launch_bounds__(kBlock) void k_grad_pts(BatchView bv, double eps) {
+	const int t = blockIdx.y;
+	const Warp9 W = load_warp(bv.warps + 9 * t);
+	const double2 *cp = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * bv.N;
+	const double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * bv.N;
+	double *gp = bv.buf[MTFHIP_BUF_GRAD_PTS] + (size_t)t * bv.N * 8;
+	const double dx0 = W.m[0] * eps, dx1 = W.m[3] * eps, dx2 = W.m[6] * eps;
+	const double dy0 = W.m[1] * eps, dy1 = W.m[4] * eps, dy2 = W.m[7] * eps;
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < bv.N; i += gridDim.x * kBlock) {
+		double2 p = cp[i];
+		double g[8];
+		if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+			/* the reference keeps curr_pts_hm; it is recovered as (x*D, y*D, D) -- exact when D == 1 */
+			double d = cz[i];
+			double q0 = p.x * d, q1 = p.y * d, q2 = d;
+			double a0 = q0 + dx0, a1 = q1 + dx1, a2 = q2 + dx2;
+			g[0] = a0 / a2; g[1] = a1 / a2;
+			a0 = q0 - dx0; a1 = q1 - dx1; a2 = q2 - dx2;
+			g[2] = a0 / a2; g[3] = a1 / a2;
+			a0 = q0 + dy0; a1 = q1 + dy1; a2 = q2 + dy2;
+			g[4] = a0 / a2; g[5] = a1 / a2;
+			a0 = q0 - dy0; a1 = q1 - dy1; a2 = q2 - dy2;
+			g[6] = a0 / a2; g[7] = a1 / a2;
+		} else {
+			g[0] = p.x + dx0; g[1] = p.y + dx1;
+			g[2] = p.x - dx0; g[3] = p.y - dx1;
+			g[4] = p.x + dy0; g[5] = p.y + dy1;
+			g[6] = p.x - dy0; g[7] = p.y - dy1;
+		}
+		double2 *o = reinterpret_cast<double2 *>(gp + (size_t)i * 8);
+		o[0] = make_double2(g[0], g[1]); o[1] = make_double2(g[2], g[3]);
+		o[2] = make_double2(g[4], g[5]); o[3] = make_double2(g[6], g[7]);
+	}
+}
+
+/* ===================================================================== */
+/* ImageBase kernels                                                      */
+/* ===================================================================== */
+
+/* utils::getPixVals Utilities/src/imgUtils.cc:163-173 */
+__global__ __launch_bounds__(kBlock) void k_sample(int N, ImgView im, const double *pts_all, double *out_all,
+	double mult, double add) {
+	const int t = blockIdx.y;
+	const double2 *pts = reinterpret_cast<const double2 *>(pts_all) + (size_t)t * N;
+	double *out = out_all + (size_t)t * N;
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+		double2 p = pts[i];
+		out[i] = mult * pix_val(im, p.x, p.y) + add;
+	}
+}
+
+/* utils::getImgGrad Utilities/src/imgUtils.cc:233-254 */
+__global__ __launch_bounds__(kBlock) void k_img_grad(int N, ImgView im, const double *pts_all, double *grad_all,
+	double eps, double pix_mult) {
+	const int t = blockIdx.y;
+	const double2 *pts = reinterpret_cast<const double2 *>(pts_all) + (size_t)t * N;
+	double *grad = grad_all + (size_t)t * N * 2;
+	const double mult = pix_mult / (2 * eps);
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+		double2 p = pts[i];
+		Cell c = load_cell(im, p.x, p.y);
+		double inc = pix_val_cell(im, c, p.x + eps, p.y);
+		double dec = pix_val_cell(im, c, p.x - eps, p.y);
+		grad[i] = (inc - dec) * mult;
+		inc = pix_val_cell(im, c, p.x, p.y + eps);
+		dec = pix_val_cell(im, c, p.x, p.y - eps);
+		grad[N + i] = (inc - dec) * mult;
+	}
+}
+
+/* utils::getWarpedImgGrad Utilities/src/imgUtils.cc:177-202 */
+__global__ __launch_bounds__(kBlock) void k_warped_img_grad(int N, ImgView im, const double *gp_all, double *grad_all,
+	double eps, double pix_mult) {
+	const int t = blockIdx.y;
+	const double *gp = gp_all + (size_t)t * N * 8;
+	double *grad = grad_all + (size_t)t * N * 2;
+	const double mult = pix_mult / (2 * eps);
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+		const double2 *q = reinterpret_cast<const double2 *>(gp + (size_t)i * 8);
+		double2 a = q[0], b = q[1], c2 = q[2], d = q[3];
+		Cell c = load_cell(im, a.x, a.y);
+		double inc = pix_val_cell(im, c, a.x, a.y);
+		double dec = pix_val_cell(im, c, b.x, b.y);
+		grad[i] = (inc - dec) * mult;
+		inc = pix_val_cell(im, c, c2.x, c2.y);
+		dec = pix_val_cell(im, c, d.x, d.y);
+		grad[N + i] = (inc - dec) * mult;
+	}
+}
+
+/* SSM pixel Jacobians as stand-alone ops (the fused kernel inlines the same row formulas):
+ * Homography.cc:157-191 (init), :193-229 (pix), :231-294 (warped), :296-358 (approx);
+ * Affine.cc:160-182 (init = pix), :213-242 (warped), :184-211 (approx) */
+__global__ __launch_bounds__(kBlock) void k_pix_jacobian(BatchView bv, int variant, const double *grad_all, double *J_all) {
+	const int t = blockIdx.y, N = bv.N, S = bv.S;
+	const Warp9 W = load_warp(bv.warps + 9 * t);
+	const double *st = bv.states + 8 * t;
+	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * N;
+	const double2 *cp = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * N;
+	const double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * N;
+	const double *grad = grad_all + (size_t)t * N * 2;
+	double *J = J_all + (size_t)t * N * S;
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+		double2 p0 = ip[i];
+		double x = p0.x, y = p0.y;
+		double gx = grad[i], gy = grad[N + i];
+		double r[8];
+		if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+			if (variant == MTFHIP_JAC_INIT) {
+				hom_row(r, gx, gy, x, y, x, y);
+			} else if (variant == MTFHIP_JAC_PIX) {
+				double2 c = cp[i];
+				double inv_d = 1.0 / cz[i];
+				hom_row(r, gx * inv_d, gy * inv_d, x, y, c.x, c.y);
+			} else if (variant == MTFHIP_JAC_WARPED) {
+				double2 c = cp[i];
+				double inv_det = 1.0 / cz[i];
+				double dwx_dx = (W.m[0] - W.m[6] * c.x), dwx_dy = (W.m[1] - W.m[7] * c.x);
+				double dwy_dx = (W.m[3] - W.m[6] * c.y), dwy_dy = (W.m[4] - W.m[7] * c.y);
+				double Ix = (dwx_dx * gx + dwy_dx * gy) * inv_det;
+				double Iy = (dwx_dy * gx + dwy_dy * gy) * inv_det;
+				hom_row(r, Ix, Iy, x, y, x, y);
+			} else {
+				double2 c = cp[i];
+				double a = (W.m[0] - W.m[6] * c.x), b = (W.m[1] - W.m[7] * c.x);
+				double cc = (W.m[3] - W.m[6] * c.y), d = (W.m[4] - W.m[7] * c.y);
+				double inv_factor = 1.0 / (a * d - b * cc);
+				double Ix = (d * gx - cc * gy) * inv_factor;
+				double Iy = (a * gy - b * gx) * inv_factor;
+				hom_row(r, Ix, Iy, x, y, c.x, c.y);
+			}
+		} else {
+			double a = st[2] + 1, b = st[3], c = st[4], d = st[5] + 1;
+			double Ixx = gx * x, Ixy = gx * y, Iyy = gy * y, Iyx = gy * x;
+			if (variant == MTFHIP_JAC_INIT || variant == MTFHIP_JAC_PIX) {
+				r[0] = gx; r[1] = gy; r[2] = Ixx; r[3] = Ixy; r[4] = Iyx; r[5] = Iyy;
+			} else if (variant == MTFHIP_JAC_WARPED) {
+				r[0] = gx * a + gy * c; r[1] = gx * b + gy * d;
+				r[2] = Ixx * a + Iyx * c; r[3] = Ixy * a + Iyy * c;
+				r[4] = Ixx * b + Iyx * d; r[5] = Ixy * b + Iyy * d;
+			} else {
+				double inv_det = 1.0 / (a * d - b * c);
+				r[0] = (gx * d - gy * c) * inv_det; r[1] = (gy * a - gx * b) * inv_det;
+				r[2] = (Ixx * d - Iyx * c) * inv_det; r[3] = (Ixy * d - Iyy * c) * inv_det;
+				r[4] = (Iyx * a - Ixx * b) * inv_det; r[5] = (Iyy * a - Ixy * b) * inv_det;
+			}
+		}
+		for (int s = 0; s < S; ++s) J[(size_t)s * N + i] = r[s];
+	}
+}
+
+/* mean_pix_jacobian = (init_pix_jacobian + curr_pix_jacobian) / 2.0 (SM/src/NT/ESM.cc:239-242) */
+__global__ __launch_bounds__(kBlock) void k_mean_jacobian(const double *a, const double *b, double *o, size_t n) {
+	for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+		o[i] = (a[i] + b[i]) / 2.0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_negate(const double *a, double *o, size_t n) {
+	for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) o[i] = -a[i];
+}
+
+/* ===================================================================== */
+/* reductions used by the un-fused AppearanceModel entry points           */
+/* ===================================================================== */
+
+/* SSDBase::updateSimilarity AM/src/SSDBase.cc:75-96: I_diff (= df_dI0 storage) = It - I0, sum r^2 */
+__global__ __launch_bounds__(kBlock) void k_ssd_residual(BatchView bv, double *partials, int nblk) {
+	__shared__ double lds[4 * 1];
+	const int t = blockIdx.y, N = bv.N;
+	const double *It = bv.buf[MTFHIP_BUF_IT] + (size_t)t * N;
+	const double *I0 = bv.buf[MTFHIP_BUF_I0] + (size_t)t * N;
+	double *r = bv.buf[MTFHIP_BUF_DF_DI0] + (size_t)t * N;
+	double acc[1] = {0.0};
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += nblk * kBlock) {
+		double d = It[i] - I0[i];
+		r[i] = d;
+		acc[0] = fma(d, d, acc[0]);
+	}
+	block_reduce_store<1>(acc, partials + ((size_t)t * nblk + blockIdx.x) * ACC_COUNT + ACC_RR, lds);
+}
+
+/* df_dp = df_dI * dI_dp (AppearanceModel.h:146-153, SSDBase.cc:137,163); with sum_mode the two
+ * Jacobians are added first: df_dIt * (dI0_dpssm + dIt_dpssm) (SSDBase.cc:186); otherwise a second
+ * product v2 * J2 goes to ACC_G2 (AppearanceModel.h:161-164) */
+__global__ __launch_bounds__(kBlock) void k_gemv(int N, int S, const double *v1_all, const double *J1_all,
+	const double *v2_all, const double *J2_all, int sum_mode, double *partials, int nblk) {
+	__shared__ double lds[4 * 16];
+	const int t = blockIdx.y;
+	const double *v1 = v1_all + (size_t)t * N, *J1 = J1_all + (size_t)t * N * S;
+	const double *v2 = v2_all ? v2_all + (size_t)t * N : nullptr;
+	const double *J2 = J2_all ? J2_all + (size_t)t * N * S : nullptr;
+	double acc[16];
+#pragma unroll
+	for (int k = 0; k < 16; ++k) acc[k] = 0.0;
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += nblk * kBlock) {
+		double a = v1[i];
+		double b = v2 ? v2[i] : 0.0;
+#pragma unroll
+		for (int s = 0; s < kMaxS; ++s) {
+			if (s < S) {
+				double j1 = J1[(size_t)s * N + i];
+				if (J2 && sum_mode) {
+					acc[s] = fma(a, j1 + J2[(size_t)s * N + i], acc[s]);
+				} else {
+					acc[s] = fma(a, j1, acc[s]);
+					if (J2) acc[8 + s] = fma(b, J2[(size_t)s * N + i], acc[8 + s]);
+				}
+			}
+		}
+	}
+	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * ACC_COUNT;
+	/* ACC_G .. ACC_G+8 and ACC_G2 .. ACC_G2+8 are not adjacent to ACC_RR: reduce into scratch then scatter */
+	__shared__ double outv[16];
+	block_reduce_store<16>(acc, outv, lds);
+	__syncthreads();
+	if (threadIdx.x < 8) dst[ACC_G + threadIdx.x] = outv[threadIdx.x];
+	else if (threadIdx.x < 16) dst[ACC_G2 + threadIdx.x - 8] = outv[threadIdx.x];
+}
+
+/* d2f_dp2 = -J^T J pieces (SSDBase.cc:263,280): upper triangle of sum_i J[i,a] J[i,b] */
+__global__ __launch_bounds__(kBlock) void k_gram(int N, int S, const double *J_all, double *partials, int nblk) {
+	__shared__ double lds[4 * 36];
+	const int t = blockIdx.y;
+	const double *J = J_all + (size_t)t * N * S;
+	double acc[36];
+#pragma unroll
+	for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += nblk * kBlock) {
+		double r[kMaxS];
+#pragma unroll
+		for (int s = 0; s < kMaxS; ++s) r[s] = s < S ? J[(size_t)s * N + i] : 0.0;
+		int k = 0;
+#pragma unroll
+		for (int a = 0; a < kMaxS; ++a)
+#pragma unroll
+			for (int b = a; b < kMaxS; ++b) { acc[k] = fma(r[a], r[b], acc[k]); ++k; }
+	}
+	block_reduce_store<36>(acc, partials + ((size_t)t * nblk + blockIdx.x) * ACC_COUNT + ACC_H, lds);
+}
+
+/* fixed-order sum of the per-workgroup rows: out[t][k] = sum_b partials[t][b][k] */
+__global__ __launch_bounds__(64) void k_finish(const double *partials, int nblk, double *out) {
+	const int t = blockIdx.x, k = threadIdx.x;
+	if (k >= ACC_COUNT) return;
+	const double *p = partials + (size_t)t * nblk * ACC_COUNT + k;
+	double s = 0;
+	for (int b = 0; b < nblk; ++b) s += p[(size_t)b * ACC_COUNT];
+	out[(size_t)t * ACC_COUNT + k] = s;
+}
+
+/* ===================================================================== */
+/* the fused Lucas-Kanade iteration, SSD                                  */
+/* ===================================================================== */
+/*
+ * One pass per pixel, everything in registers:
+ *   warp the grid point (A11) -> bilinear sample It (A1/A2) -> residual (A7) ->
+ *   finite-difference gradient, chained (A3) or of the warped image (A4) ->
+ *   steepest-descent row (A5 / A6) -> accumulate J^T r (A8) and J^T J (A9)
+ * MODE 0 FCLK: g += -r * Jt            H += Jt (x) Jt
+ * MODE 1 ESM : g += -r * (J0 + Jt)     H += Jt (x) Jt   (or Jm (x) Jm when hess_mean)
+ * MODE 2 ICLK: g += +r * J0            (no gradient, no H: InitialSelf / Std Hessians are constant)
+ * With MAT the interface-visible arrays It, dIt_dx and Jt are also written (88 B/pixel).
+ */
+template <int SSM, bool CHAINED, int MODE, bool MAT>
+__global__ __launch_bounds__(kBlock) void k_fused_ssd(BatchView bv, ImgView im, FusedArgs fa, double *partials, int nblk) {
+	constexpr int S = (SSM == MTFHIP_SSM_HOMOGRAPHY) ? 8 : 6;
+	constexpr int K = 48;
+	__shared__ double lds[4 * K];
+	const int t = blockIdx.y, N = bv.N;
+	if (fa.active && !fa.active[t]) return;
+	const Warp9 W = load_warp(bv.warps + 9 * t);
+	const double *st = bv.states + 8 * t;
+	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * N;
+	const double *iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * N;
+	const double *I0 = bv.buf[MTFHIP_BUF_I0] + (size_t)t * N;
+	const double *J0 = bv.buf[MTFHIP_BUF_J0] + (size_t)t * N * S;
+	double *It = bv.buf[MTFHIP_BUF_IT] + (size_t)t * N;
+	double *dIt = bv.buf[MTFHIP_BUF_DIT_DX] + (size_t)t * N * 2;
+	double *Jt = bv.buf[MTFHIP_BUF_JT] + (size_t)t * N * S;
+	const double eps = fa.grad_eps;
+	const double gmult = fa.norm_mult / (2 * eps);
+	const double ex0 = W.m[0] * eps, ex1 = W.m[3] * eps, ex2 = W.m[6] * eps;
+	const double ey0 = W.m[1] * eps, ey1 = W.m[4] * eps, ey2 = W.m[7] * eps;
+	const double aa = st[2] + 1, ab = st[3], ac = st[4], ad = st[5] + 1; /* affine a,b,c,d (Affine.cc:216-217) */
+
+	double acc[K];
+#pragma unroll
+	for (int k = 0; k < K; ++k) acc[k] = 0.0;
+
+	const int base = blockIdx.x * (kBlock * kFusedPPT) + threadIdx.x;
+#pragma unroll 2
+	for (int kk = 0; kk < kFusedPPT; ++kk) {
+		const int i = base + kk * kBlock;
+		if (i >= N) break;
+		const double2 p0 = ip[i];
+		const double x = p0.x, y = p0.y;
+		const double z = bv.unit_z ? 1.0 : iz[i];
+		const double hx = bv.unit_z ? x : x * z, hy = bv.unit_z ? y : y * z;
+		double wx, wy, cx = 0, cy = 0, D = 1.0;
+		if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+			cx = W.m[0] * hx + W.m[1] * hy + W.m[2] * z;
+			cy = W.m[3] * hx + W.m[4] * hy + W.m[5] * z;
+			D = W.m[6] * hx + W.m[7] * hy + W.m[8] * z;
+			wx = cx / D; wy = cy / D;
+		} else {
+			wx = W.m[0] * hx + W.m[1] * hy + W.m[2] * z;
+			wy = W.m[3] * hx + W.m[4] * hy + W.m[5] * z;
+		}
+		const Cell c = load_cell(im, wx, wy);
+		const double it = fa.norm_mult * pix_val_cell(im, c, wx, wy) + fa.norm_add;
+		const double r = it - I0[i];
+		acc[44] = fma(r, r, acc[44]);
+		if constexpr (MAT) It[i] = it;
+
+		double row[8];
+		if constexpr (MODE != 2) {
+			double gx, gy;
+			if constexpr (CHAINED) {
+				/* utils::getImgGrad at the warped point (imgUtils.cc:233-254) */
+				double inc = pix_val_cell(im, c, wx + eps, wy);
+				double dec = pix_val_cell(im, c, wx - eps, wy);
+				gx = (inc - dec) * gmult;
+				inc = pix_val_cell(im, c, wx, wy + eps);
+				dec = pix_val_cell(im, c, wx, wy - eps);
+				gy = (inc - dec) * gmult;
+			} else {
+				/* updateGradPts + utils::getWarpedImgGrad (Homography.cc:803-827, imgUtils.cc:177-202) */
+				double px0, py0, px1, py1, px2, py2, px3, py3;
+				if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+					double a0 = cx + ex0, a1 = cy + ex1, a2 = D + ex2;
+					px0 = a0 / a2; py0 = a1 / a2;
+					a0 = cx - ex0; a1 = cy - ex1; a2 = D - ex2;
+					px1 = a0 / a2; py1 = a1 / a2;
+					a0 = cx + ey0; a1 = cy + ey1; a2 = D + ey2;
+					px2 = a0 / a2; py2 = a1 / a2;
+					a0 = cx - ey0; a1 = cy - ey1; a2 = D - ey2;
+					px3 = a0 / a2; py3 = a1 / a2;
+				} else {
+					px0 = wx + ex0; py0 = wy + ex1; px1 = wx - ex0; py1 = wy - ex1;
+					px2 = wx + ey0; py2 = wy + ey1; px3 = wx - ey0; py3 = wy - ey1;
+				}
+				double inc = pix_val_cell(im, c, px0, py0);
+				double dec = pix_val_cell(im, c, px1, py1);
+				gx = (inc - dec) * gmult;
+				inc = pix_val_cell(im, c, px2, py2);
+				dec = pix_val_cell(im, c, px3, py3);
+				gy = (inc - dec) * gmult;
+			}
+			if constexpr (MAT) { dIt[i] = gx; dIt[N + i] = gy; }
+			if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+				if constexpr (CHAINED) {
+					/* Homography::cmptWarpedPixJacobian SSM/src/Homography.cc:231-294 */
+					double inv_det = 1.0 / D;
+					double dwx_dx = (W.m[0] - W.m[6] * wx), dwx_dy = (W.m[1] - W.m[7] * wx);
+					double dwy_dx = (W.m[3] - W.m[6] * wy), dwy_dy = (W.m[4] - W.m[7] * wy);
+					double Ix = (dwx_dx * gx + dwy_dx * gy) * inv_det;
+					double Iy = (dwx_dy * gx + dwy_dy * gy) * inv_det;
+					hom_row(row, Ix, Iy, x, y, x, y);
+				} else {
+					/* Homography::cmptInitPixJacobian SSM/src/Homography.cc:157-191 */
+					hom_row(row, gx, gy, x, y, x, y);
+				}
+			} else {
+				double Ixx = gx * x, Ixy = gx * y, Iyy = gy * y, Iyx = gy * x;
+				if constexpr (CHAINED) {
+					/* Affine::cmptWarpedPixJacobian SSM/src/Affine.cc:213-242 */
+					row[0] = gx * aa + gy * ac; row[1] = gx * ab + gy * ad;
+					row[2] = Ixx * aa + Iyx * ac; row[3] = Ixy * aa + Iyy * ac;
+					row[4] = Ixx * ab + Iyx * ad; row[5] = Ixy * ab + Iyy * ad;
+				} else {
+					/* Affine::cmptInitPixJacobian SSM/src/Affine.cc:160-182 */
+					row[0] = gx; row[1] = gy; row[2] = Ixx; row[3] = Ixy; row[4] = Iyx; row[5] = Iyy;
+				}
+				row[6] = row[7] = 0.0;
+			}
+			if constexpr (MAT) {
+#pragma unroll
+				for (int s = 0; s < S; ++s) Jt[(size_t)s * N + i] = row[s];
+			}
+		}
+
+		if constexpr (MODE == 0) {
+			const double v = -r;
+#pragma unroll
+			for (int s = 0; s < S; ++s) acc[36 + s] = fma(v, row[s], acc[36 + s]);
+		} else if constexpr (MODE == 1) {
+			const double v = -r;
+			double j0[8];
+#pragma unroll
+			for (int s = 0; s < S; ++s) j0[s] = J0[(size_t)s * N + i];
+#pragma unroll
+			for (int s = 0; s < S; ++s) acc[36 + s] = fma(v, j0[s] + row[s], acc[36 + s]);
+			if (fa.hess_mean) {
+#pragma unroll
+				for (int s = 0; s < S; ++s) row[s] = (j0[s] + row[s]) / 2.0;
+			}
+		} else {
+#pragma unroll
+			for (int s = 0; s < S; ++s) acc[36 + s] = fma(r, J0[(size_t)s * N + i], acc[36 + s]);
+		}
+		if constexpr (MODE != 2) {
+			int k = 0;
+#pragma unroll
+			for (int a = 0; a < 8; ++a)
+#pragma unroll
+				for (int b = a; b < 8; ++b) {
+					if (a < S && b < S) acc[k] = fma(row[a], row[b], acc[k]);
+					++k;
+				}
+		}
+	}
+	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * ACC_COUNT;
+	block_reduce_store<K>(acc, dst, lds);
+}
+
+/* ===================================================================== */
+/* candidate scoring (PF / NN batch axis)                                 */
+/* ===================================================================== */
+/* One wave64 per candidate: setState -> updatePixVals -> updateSimilarity -> likelihood
+ * (SM/src/PF.cc:247-262, ProjectiveBase.cc:41-49, SSDBase.cc:75-96, SSD.h:41-43). */
+__global__ __launch_bounds__(kBlock) void k_score_candidates(BatchView bv, ImgView im, const double *states, int C,
+	double alpha, double norm_mult, double norm_add, double *lik, double *sim) {
+	const int lane = threadIdx.x & 63;
+	const int cand = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	if (cand >= C) return;
+	const int N = bv.N, S = bv.S;
+	const double *p = states + (size_t)cand * S;
+	double W[9];
+	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+		W[0] = 1 + p[0]; W[1] = p[1]; W[2] = p[2]; W[3] = p[3]; W[4] = 1 + p[4]; W[5] = p[5];
+		W[6] = p[6]; W[7] = p[7]; W[8] = 1;
+	} else {
+		W[0] = 1 + p[2]; W[1] = p[3]; W[2] = p[0]; W[3] = p[4]; W[4] = 1 + p[5]; W[5] = p[1];
+		W[6] = 0; W[7] = 0; W[8] = 1;
+	}
+	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]);
+	const double *iz = bv.buf[MTFHIP_BUF_INIT_Z];
+	const double *I0 = bv.buf[MTFHIP_BUF_I0];
+	double acc = 0.0;
+	for (int i = lane; i < N; i += 64) {
+		double2 q = ip[i];
+		double z = bv.unit_z ? 1.0 : iz[i];
+		double hx = bv.unit_z ? q.x : q.x * z, hy = bv.unit_z ? q.y : q.y * z;
+		double wx, wy;
+		if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+			double cx = W[0] * hx + W[1] * hy + W[2] * z;
+			double cy = W[3] * hx + W[4] * hy + W[5] * z;
+			double d = W[6] * hx + W[7] * hy + W[8] * z;
+			wx = cx / d; wy = cy / d;
+		} else {
+			wx = W[0] * hx + W[1] * hy + W[2] * z;
+			wy = W[3] * hx + W[4] * hy + W[5] * z;
+		}
+		double r = (norm_mult * pix_val(im, wx, wy) + norm_add) - I0[i];
+		acc = fma(r, r, acc);
+	}
+#pragma unroll
+	for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+	if (lane == 0) {
+		double f = -acc / 2;
+		if (sim) sim[cand] = f;
+		if (lik) lik[cand] = exp(-alpha * sqrt(-f / (double)N));
+	}
+}
+
+/* ===================================================================== */
+/* on-device solve + compositional update (batched drivers only)          */
+/* ===================================================================== */
+__device__ inline void solve_dense(int n, double *A /* col-major n x n, destroyed */, double *b /* in: rhs, out: x */) {
+	for (int k = 0; k < n; ++k) {
+		int piv = k;
+		double best = fabs(A[k * n + k]);
+		for (int i = k + 1; i < n; ++i) { double v = fabs(A[k * n + i]); if (v > best) { best = v; piv = i; } }
+		if (piv != k) {
+			for (int j = 0; j < n; ++j) { double tmp = A[j * n + k]; A[j * n + k] = A[j * n + piv]; A[j * n + piv] = tmp; }
+			double tmp = b[k]; b[k] = b[piv]; b[piv] = tmp;
+		}
+		double inv = 1.0 / A[k * n + k];
+		for (int i = k + 1; i < n; ++i) {
+			double f = A[k * n + i] * inv;
+			if (f == 0) continue;
+			for (int j = k; j < n; ++j) A[j * n + i] -= f * A[j * n + k];
+			b[i] -= f * b[k];
+		}
+	}
+	for (int k = n - 1; k >= 0; --k) {
+		double s = b[k];
+		for (int j = k + 1; j < n; ++j) s -= A[j * n + k] * b[j];
+		b[k] = s / A[k * n + k];
+	}
+}
+
+/* one thread per target: assemble g and H of the search method from the reduced accumulators,
+ * solve H dp = -g, apply the compositional (ICLK: inverse compositional) update, test convergence.
+ * SM/src/NT/FCLK.cc:260-339, NT/ESM.cc:252-292, NT/ICLK.cc:206-289; Homography.cc:73-92,109-114. */
+__global__ __launch_bounds__(64) void k_track_step(BatchView bv, mtfhip_sm_desc sm, TrackState ts) {
+	const int t = blockIdx.x * 64 + threadIdx.x;
+	if (t >= bv.B || !ts.active[t]) return;
+	const int S = bv.S;
+	const double *acc = ts.acc + (size_t)t * ACC_COUNT;
+	const double *h0 = ts.h0 + (size_t)t * 64;
+	double g[8], H[64];
+	double gscale = (sm.sm == MTFHIP_SM_ESM) ? 0.5 : 1.0;
+	for (int s = 0; s < S; ++s) g[s] = gscale * acc[ACC_G + s];
+	bool use_h0 = (sm.hess_type == 0) || (sm.sm == MTFHIP_SM_ICLK && sm.hess_type == 2);
+	bool sum_h0 = (sm.sm == MTFHIP_SM_ESM) && (sm.hess_type == 2 || sm.hess_type == 4);
+	int k = 0;
+	for (int a = 0; a < 8; ++a)
+		for (int b = a; b < 8; ++b) {
+			if (a < S && b < S) {
+				double v = use_h0 ? h0[b * S + a] : -acc[ACC_H + k];
+				if (sum_h0) v = (v + h0[b * S + a]) * 0.5;
+				H[b * S + a] = H[a * S + b] = v;
+			}
+			++k;
+		}
+	double dp[8];
+	for (int s = 0; s < S; ++s) dp[s] = g[s];
+	solve_dense(S, H, dp);
+	for (int s = 0; s < S; ++s) dp[s] = -dp[s];
+
+	double *Wp = bv.warps + 9 * t, *st = bv.states + 8 * t;
+	double U[9];
+	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+		U[0] = 1 + dp[0]; U[1] = dp[1]; U[2] = dp[2]; U[3] = dp[3]; U[4] = 1 + dp[4]; U[5] = dp[5];
+		U[6] = dp[6]; U[7] = dp[7]; U[8] = 1;
+	} else {
+		U[0] = 1 + dp[2]; U[1] = dp[3]; U[2] = dp[0]; U[3] = dp[4]; U[4] = 1 + dp[5]; U[5] = dp[1];
+		U[6] = 0; U[7] = 0; U[8] = 1;
+	}
+	if (sm.sm == MTFHIP_SM_ICLK) {
+		/* invertState: inverse through cofactors, normalised by (2,2) */
+		double c[9];
+		c[0] = U[4] * U[8] - U[5] * U[7]; c[1] = U[2] * U[7] - U[1] * U[8]; c[2] = U[1] * U[5] - U[2] * U[4];
+		c[3] = U[5] * U[6] - U[3] * U[8]; c[4] = U[0] * U[8] - U[2] * U[6]; c[5] = U[2] * U[3] - U[0] * U[5];
+		c[6] = U[3] * U[7] - U[4] * U[6]; c[7] = U[1] * U[6] - U[0] * U[7]; c[8] = U[0] * U[4] - U[1] * U[3];
+		double det = U[0] * c[0] + U[1] * c[3] + U[2] * c[6];
+		double inv_det = 1.0 / det;
+		for (int i = 0; i < 9; ++i) c[i] *= inv_det;
+		double n22 = 1.0 / c[8];
+		for (int i = 0; i < 9; ++i) U[i] = c[i] * n22;
+		/* round-trip through the state parameterisation as getStateFromWarp / getWarpFromState do */
+		if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) { U[0] = 1 + (U[0] - 1); U[4] = 1 + (U[4] - 1); U[8] = 1; }
+		else { U[0] = 1 + (U[0] - 1); U[4] = 1 + (U[4] - 1); U[6] = 0; U[7] = 0; U[8] = 1; }
+	}
+	double Wn[9];
+	for (int r = 0; r < 3; ++r)
+		for (int c2 = 0; c2 < 3; ++c2)
+			Wn[3 * r + c2] = Wp[3 * r] * U[c2] + Wp[3 * r + 1] * U[3 + c2] + Wp[3 * r + 2] * U[6 + c2];
+	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+		double n22 = 1.0 / Wn[8];
+		for (int i = 0; i < 9; ++i) Wn[i] *= n22;
+		st[0] = Wn[0] - 1; st[1] = Wn[1]; st[2] = Wn[2]; st[3] = Wn[3]; st[4] = Wn[4] - 1; st[5] = Wn[5];
+		st[6] = Wn[6]; st[7] = Wn[7];
+	} else {
+		st[0] = Wn[2]; st[1] = Wn[5]; st[2] = Wn[0] - 1; st[3] = Wn[1]; st[4] = Wn[3]; st[5] = Wn[4] - 1;
+	}
+	for (int i = 0; i < 9; ++i) Wp[i] = Wn[i];
+	double *cr = ts.corners + 8 * t;
+	const double *ic = ts.init_corners_hm + 12 * t;
+	double change = 0;
+	for (int q = 0; q < 4; ++q) {
+		double X = ic[3 * q], Y = ic[3 * q + 1], Z = ic[3 * q + 2];
+		double nx = Wn[0] * X + Wn[1] * Y + Wn[2] * Z, ny = Wn[3] * X + Wn[4] * Y + Wn[5] * Z;
+		if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+			double d = Wn[6] * X + Wn[7] * Y + Wn[8] * Z;
+			nx = nx / d; ny = ny / d;
+		}
+		double ddx = cr[2 * q] - nx, ddy = cr[2 * q + 1] - ny;
+		change += ddx * ddx + ddy * ddy;
+		cr[2 * q] = nx; cr[2 * q + 1] = ny;
+	}
+	ts.n_iters[t] += 1;
+	if (change < sm.epsilon || ts.n_iters[t] >= sm.max_iters) ts.active[t] = 0;
+}
+
+/* ===================================================================== */
+/* launchers                                                              */
+/* ===================================================================== */
+static inline dim3 grid2(int nblk, int B) { return dim3((unsigned)nblk, (unsigned)B, 1); }
+
+void launch_init_grid(const BatchView &bv, const double *dev_w0, int resx, int resy, double lo_x, double lo_y,
+	double hi_x, double hi_y, int force_unit_z, hipStream_t st) {
+	hipLaunchKernelGGL(k_init_grid, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv, dev_w0, resx, resy,
+		lo_x, lo_y, hi_x, hi_y, force_unit_z);
+}
+void launch_apply_warp(const BatchView &bv, hipStream_t st) {
+	hipLaunchKernelGGL(k_apply_warp, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv);
+}
+void launch_grad_pts(const BatchView &bv, double eps, hipStream_t st) {
+	hipLaunchKernelGGL(k_grad_pts, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv, eps);
+}
+void launch_sample(const BatchView &bv, const ImgView &im, const double *pts, double *out, double mult, double add,
+	hipStream_t st) {
+	hipLaunchKernelGGL(k_sample, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, pts, out, mult, add);
+}
+void launch_img_grad(const BatchView &bv, const ImgView &im, const double *pts, double *grad, double eps, double mult,
+	hipStream_t st) {
+	hipLaunchKernelGGL(k_img_grad, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, pts, grad, eps, mult);
+}
+void launch_warped_img_grad(const BatchView &bv, const ImgView &im, const double *gp, double *grad, double eps,
+	double mult, hipStream_t st) {
+	hipLaunchKernelGGL(k_warped_img_grad, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, gp, grad, eps, mult);
+}
+void launch_pix_jacobian(const BatchView &bv, int variant, const double *grad, double *J, hipStream_t st) {
+	hipLaunchKernelGGL(k_pix_jacobian, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv, variant, grad, J);
+}
+void launch_mean_jacobian(const BatchView &bv, hipStream_t st) {
+	size_t n = (size_t)bv.B * bv.N * bv.S;
+	int nb = (int)((n + kBlock * 4 - 1) / (kBlock * 4));
+	hipLaunchKernelGGL(k_mean_jacobian, dim3(nb), dim3(kBlock), 0, st, bv.buf[MTFHIP_BUF_J0], bv.buf[MTFHIP_BUF_JT],
+		bv.buf[MTFHIP_BUF_JM], n);
+}
+void launch_negate(const double *src, double *dst, size_t n, hipStream_t st) {
+	int nb = (int)((n + kBlock * 4 - 1) / (kBlock * 4));
+	hipLaunchKernelGGL(k_negate, dim3(nb), dim3(kBlock), 0, st, src, dst, n);
+}
+void launch_ssd_residual(const BatchView &bv, double *partials, int nblk, hipStream_t st) {
+	hipLaunchKernelGGL(k_ssd_residual, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv, partials, nblk);
+}
+void launch_gemv(const BatchView &bv, const double *v1, const double *J1, const double *v2, const double *J2,
+	int sum_mode, double *partials, int nblk, hipStream_t st) {
+	hipLaunchKernelGGL(k_gemv, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv.N, bv.S, v1, J1, v2, J2, sum_mode, partials, nblk);
+}
+void launch_gram(const BatchView &bv, const double *J, double *partials, int nblk, hipStream_t st) {
+	hipLaunchKernelGGL(k_gram, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv.N, bv.S, J, partials, nblk);
+}
+void launch_finish(double *partials, int nblk, double *out, int B, hipStream_t st) {
+	hipLaunchKernelGGL(k_finish, dim3(B), dim3(64), 0, st, partials, nblk, out);
+}
+
+template <int SSM, bool CHAINED, int MODE>
+static void launch_fused_mat(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk,
+	hipStream_t st) {
+	dim3 g = grid2(nblk, bv.B);
+	if (fa.materialize)
+		hipLaunchKernelGGL((k_fused_ssd<SSM, CHAINED, MODE, true>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
+	else
+		hipLaunchKernelGGL((k_fused_ssd<SSM, CHAINED, MODE, false>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
+}
+template <int SSM, bool CHAINED>
+static void launch_fused_mode(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk,
+	hipStream_t st) {
+	if (fa.mode == 0) launch_fused_mat<SSM, CHAINED, 0>(bv, im, fa, partials, nblk, st);
+	else if (fa.mode == 1) launch_fused_mat<SSM, CHAINED, 1>(bv, im, fa, partials, nblk, st);
+	else launch_fused_mat<SSM, CHAINED, 2>(bv, im, fa, partials, nblk, st);
+}
+void launch_fused_ssd(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk,
+	hipStream_t st) {
+	const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY;
+	if (hom && fa.chained) launch_fused_mode<MTFHIP_SSM_HOMOGRAPHY, true>(bv, im, fa, partials, nblk, st);
+	else if (hom) launch_fused_mode<MTFHIP_SSM_HOMOGRAPHY, false>(bv, im, fa, partials, nblk, st);
+	else if (fa.chained) launch_fused_mode<MTFHIP_SSM_AFFINE, true>(bv, im, fa, partials, nblk, st);
+	else launch_fused_mode<MTFHIP_SSM_AFFINE, false>(bv, im, fa, partials, nblk, st);
+}
+
+void launch_score_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C,
+	double likelihood_alpha, double *dev_lik, double *dev_sim, hipStream_t st) {
+	int nb = (C + (kBlock / 64) - 1) / (kBlock / 64);
+	hipLaunchKernelGGL(k_score_candidates, dim3(nb), dim3(kBlock), 0, st, bv, im, dev_states, C, likelihood_alpha,
+		1.0, 0.0, dev_lik, dev_sim);
+}
+
+void launch_track_step(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, hipStream_t st) {
+	hipLaunchKernelGGL(k_track_step, dim3((bv.B + 63) / 64), dim3(64), 0, st, bv, sm, ts);
+}
+
+} // namespace mtfhip

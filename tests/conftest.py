@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_py
+    oracle_py.build()
+    return oracle_py
+
+
+@pytest.fixture(scope="session")
+def frame():
+    from mtf_amd import synth
+    return synth.make_frame(512, 512)
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    import mtf_amd
+    if not os.path.exists(mtf_amd._lib.LIB_PATH):
+        pytest.fail("libmtfhip.so is missing on a GPU box: run __graft_entry__.build()")
+    ctx = mtf_amd.Context(0)
+    yield ctx
+    ctx.close()

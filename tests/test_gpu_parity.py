@@ -1,0 +1,261 @@
+"""GPU parity: every C-ABI entry point of the hot path against the CPU oracle on the same seeded
+inputs (sizes the oracle finishes in seconds).  Tolerances: bit-exact where the device replays the
+reference's per-pixel arithmetic (samples, gradients, Jacobian rows), 1e-5 relative (north_star)
+on H / g / parameter updates, 1e-9 relative on PF scores."""
+import numpy as np
+import pytest
+
+import mtf_amd
+from mtf_amd import _lib as L
+from mtf_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    d = np.linalg.norm(a - b)
+    n = np.linalg.norm(b)
+    return d / n if n > 0 else d
+
+
+def make_pair(oracle, ctx, img, am, ssm, res, corners, **kw):
+    o_ssm = oracle.SSM(ssm, res, res)
+    o_am = oracle.AM(am, res, res, **kw)
+    o_am.set_curr_img(img)
+    ctx.set_image(img)
+    b = mtf_amd.Batch(ctx, am, ssm, res, res, 1, **{k: v for k, v in kw.items()})
+    o_ssm.set_corners(corners)
+    b.set_corners(corners[None])
+    return o_am, o_ssm, b
+
+
+CORNER_SETS = {
+    "square": lambda rng: synth.square_corners(256, 256, 100),
+    "quad": lambda rng: synth.square_corners(256, 256, 100) + rng.uniform(-4, 4, size=(2, 4)),
+}
+
+
+@pytest.mark.parametrize("ssm", [L.SSM_HOMOGRAPHY, L.SSM_AFFINE])
+@pytest.mark.parametrize("shape", ["square", "quad"])
+def test_ssm_grid_and_warp(oracle, gpu_ctx, frame, ssm, shape):
+    rng = np.random.default_rng(11)
+    corners = CORNER_SETS[shape](rng)
+    o_am, o_ssm, b = make_pair(oracle, gpu_ctx, frame, L.AM_SSD, ssm, 50, corners)
+    S = b.S
+    np.testing.assert_allclose(b.read(L.BUF_INIT_PTS)[0], o_ssm.get("init_pts").reshape(-1, 2).T, rtol=0, atol=1e-9)
+    p = synth.random_small_homography(rng)[:S] if ssm == L.SSM_HOMOGRAPHY else rng.uniform(-1, 1, 6) * [2, 2, .02, .02, .02, .02]
+    o_ssm.set_state(p)
+    b.set_state(p[None])
+    np.testing.assert_allclose(b.get_pts()[0], o_ssm.get("curr_pts").reshape(-1, 2).T, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(b.get_corners()[0], o_ssm.get("curr_corners").reshape(4, 2).T, rtol=0, atol=1e-9)
+    dp = p * 0.1
+    o_ssm.compositional_update(dp)
+    b.compositional_update(dp[None])
+    np.testing.assert_allclose(b.get_state()[0], o_ssm.get("state"), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(b.get_pts()[0], o_ssm.get("curr_pts").reshape(-1, 2).T, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(b.invert_state(p[None])[0], o_ssm.invert_state(p), rtol=1e-12, atol=1e-14)
+    o_ssm.update_grad_pts(1e-8)
+    b.update_grad_pts(1e-8)
+    np.testing.assert_allclose(b.read(L.BUF_GRAD_PTS)[0].ravel(), o_ssm.get("grad_pts"), rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("ssm", [L.SSM_HOMOGRAPHY, L.SSM_AFFINE])
+def test_unfused_interface_chain(oracle, gpu_ctx, frame, ssm):
+    """updatePixVals -> updateSimilarity -> updateCurrGrad -> updatePixGrad -> cmpt*PixJacobian ->
+    cmptCurrJacobian / cmpt*Hessian, each as its own C-ABI call, fed with the oracle's points."""
+    rng = np.random.default_rng(5)
+    corners = synth.square_corners(250, 260, 90)
+    o_am, o_ssm, b = make_pair(oracle, gpu_ctx, frame, L.AM_SSD, ssm, 40, corners)
+    S = b.S
+    pts0 = o_ssm.get("curr_pts")
+    o_am.initialize_pix_vals(pts0); o_am.initialize_pix_grad_pts(pts0)
+    o_am.initialize_similarity(); o_am.initialize_grad(); o_am.initialize_hess()
+    b.initialize_pix_vals(); b.initialize_pix_grad()
+    b.initialize_similarity(); b.initialize_grad(); b.initialize_hess()
+    assert np.array_equal(b.read(L.BUF_I0)[0], o_am.get("I0"))
+    assert np.array_equal(b.read(L.BUF_DI0_DX)[0], o_am.get("dI0_dx").reshape(2, -1).T)
+    J0_o = o_ssm.cmpt_warped_pix_jacobian(o_am.get("dI0_dx"))
+    b.cmpt_pix_jacobian(L.JAC_WARPED, L.BUF_DI0_DX, L.BUF_J0)
+    np.testing.assert_allclose(b.read(L.BUF_J0)[0], J0_o.reshape(S, -1).T, rtol=1e-13, atol=1e-10)
+
+    p = (synth.random_small_homography(rng) if ssm == L.SSM_HOMOGRAPHY else
+         rng.uniform(-1, 1, 6) * [2, 2, .02, .02, .02, .02])
+    o_ssm.set_state(p); b.set_state(p[None])
+    pts = o_ssm.get("curr_pts")
+    # explicit host points (upload path) must equal the device-resident fast path
+    o_am.update_pix_vals(pts)
+    b.update_pix_vals(pts.reshape(1, -1, 2).transpose(0, 2, 1))
+    it_host = b.read(L.BUF_IT)[0].copy()
+    b.update_pix_vals()
+    np.testing.assert_allclose(b.read(L.BUF_IT)[0], it_host, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(it_host, o_am.get("It"), rtol=0, atol=1e-10)
+
+    o_am.update_similarity(False); b.update_similarity(False)
+    assert rel(b.get_similarity()[0], o_am.similarity) < 1e-12
+    assert rel(b.get_likelihood()[0], o_am.likelihood) < 1e-12
+    o_am.update_curr_grad(); b.update_curr_grad()
+    o_am.update_init_grad(); b.update_init_grad()
+    np.testing.assert_allclose(b.read(L.BUF_DF_DIT)[0], o_am.get("df_dIt"), rtol=0, atol=1e-9)
+
+    # chained: gradient at the warped points + warped Jacobian
+    o_am.update_pix_grad_pts(pts); b.update_pix_grad()
+    np.testing.assert_allclose(b.read(L.BUF_DIT_DX)[0], o_am.get("dIt_dx").reshape(2, -1).T, rtol=0, atol=2e-5)
+    for variant, fn in ((L.JAC_WARPED, o_ssm.cmpt_warped_pix_jacobian), (L.JAC_INIT, o_ssm.cmpt_init_pix_jacobian),
+                        (L.JAC_PIX, o_ssm.cmpt_pix_jacobian), (L.JAC_APPROX, o_ssm.cmpt_approx_pix_jacobian)):
+        Jo = fn(o_am.get("dIt_dx"))
+        b.cmpt_pix_jacobian(variant, L.BUF_DIT_DX, L.BUF_JT)
+        assert rel(b.read(L.BUF_JT)[0], Jo.reshape(S, -1).T) < 1e-6, variant
+    Jt_o = o_ssm.cmpt_warped_pix_jacobian(o_am.get("dIt_dx"))
+    b.cmpt_pix_jacobian(L.JAC_WARPED, L.BUF_DIT_DX, L.BUF_JT)
+    assert rel(b.cmpt_curr_jacobian()[0], o_am.cmpt_curr_jacobian(Jt_o)) < 1e-5
+    assert rel(b.cmpt_init_jacobian()[0], o_am.cmpt_init_jacobian(J0_o)) < 1e-5
+    assert rel(b.cmpt_difference_of_jacobians()[0], o_am.cmpt_difference_of_jacobians(J0_o, Jt_o)) < 1e-5
+    assert rel(b.cmpt_self_hessian()[0], o_am.cmpt_self_hessian(Jt_o)) < 1e-5
+    assert rel(b.cmpt_curr_hessian()[0], o_am.cmpt_curr_hessian(Jt_o)) < 1e-5
+    assert rel(b.cmpt_init_hessian()[0], o_am.cmpt_init_hessian(J0_o)) < 1e-5
+    assert rel(b.cmpt_sum_of_hessians()[0], o_am.cmpt_sum_of_hessians(J0_o, Jt_o)) < 1e-5
+    b.mean_jacobian()
+    np.testing.assert_allclose(b.read(L.BUF_JM)[0], ((J0_o + Jt_o) / 2).reshape(S, -1).T, rtol=1e-6, atol=1e-6)
+
+    # non-chained: gradient of the warped image through the offset points
+    o_ssm.update_grad_pts(1e-8); b.update_grad_pts()
+    o_am.update_pix_grad_warped(o_ssm.get("grad_pts")); b.update_pix_grad(warped=True)
+    np.testing.assert_allclose(b.read(L.BUF_DIT_DX)[0], o_am.get("dIt_dx").reshape(2, -1).T, rtol=0, atol=2e-5)
+
+
+SM_CASES = [
+    # sm, ssm, res, extra
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, 50, dict()),                                  # config 1
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, 50, dict(chained_warp=0)),
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, 40, dict(jac_type=0, hess_type=3)),           # Original + Original
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, 40, dict(hess_type=5)),
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, 40, dict(hess_type=0)),
+    (L.SM_FCLK, L.SSM_HOMOGRAPHY, 100, dict()),                                # config 2 shape, reduced
+    (L.SM_FCLK, L.SSM_HOMOGRAPHY, 60, dict(chained_warp=0)),
+    (L.SM_FCLK, L.SSM_AFFINE, 50, dict()),
+    (L.SM_FCLK, L.SSM_AFFINE, 50, dict(chained_warp=0)),
+    (L.SM_ICLK, L.SSM_HOMOGRAPHY, 50, dict()),
+    (L.SM_ICLK, L.SSM_AFFINE, 25, dict()),                                     # config 3 patch shape
+    (L.SM_ESM, L.SSM_AFFINE, 40, dict()),
+]
+
+
+@pytest.mark.parametrize("materialize", [1, 0])
+@pytest.mark.parametrize("case", SM_CASES, ids=lambda c: "sm%d-ssm%d-res%d-%s" % (c[0], c[1], c[2], "_".join("%s%s" % kv for kv in c[3].items())))
+def test_fused_iterations_follow_oracle(oracle, gpu_ctx, frame, case, materialize):
+    """Drive the SM loop on the host exactly as the reference does (solve + compositional update on the
+    CPU), with the device producing f, g, H per iteration; compare every iteration with the oracle's
+    trace of nt::ESM / nt::FCLK / nt::ICLK::update."""
+    sm_kind, ssm, res, extra = case
+    rng = np.random.default_rng(17)
+    centre = (250.0, 262.0)
+    corners = synth.square_corners(centre[0], centre[1], 2.0 * res if res <= 60 else float(res))
+    p_true = synth.random_small_homography(rng, 0.6)
+    frame2 = synth.warp_frame(frame, p_true, centre)
+
+    params = dict(leven_marq=0, max_iters=8)
+    params.update(extra)
+    o_am, o_ssm, b = make_pair(oracle, gpu_ctx, frame, L.AM_SSD, ssm, res, corners)
+    trk = oracle.Tracker(sm_kind, o_am, o_ssm, **params)
+    trk.initialize(corners)
+    sm = mtf_amd.sm_desc(sm_kind, materialize=materialize, **params)
+    b.init_template(sm)
+
+    o_am.set_curr_img(frame2)
+    gpu_ctx.set_image(frame2)
+    trk.update()
+    trace = trk.trace()
+    assert len(trace) >= 2
+    for it, rec in enumerate(trace):
+        f, g, H = b.iterate(sm)
+        assert rel(f[0], rec["f"]) < 1e-9, it
+        assert rel(g[0], rec["g"]) < 1e-5, it
+        assert rel(H[0], rec["H"]) < 1e-5, it
+        dp = -oracle.colpiv_qr_solve(H[0], g[0])
+        assert rel(dp, rec["dp"]) < 1e-5, it
+        if sm_kind == L.SM_ICLK:
+            dp = b.invert_state(dp[None])[0]
+        b.compositional_update(dp[None])
+        np.testing.assert_allclose(b.get_corners()[0], rec["corners"], rtol=0, atol=1e-5)
+    if materialize and sm_kind != L.SM_ICLK:
+        assert b.read(L.BUF_JT).shape == (1, res * res, b.S)
+    if not materialize:
+        with pytest.raises(mtf_amd.LogicError):
+            b.read(L.BUF_IT)
+
+
+@pytest.mark.parametrize("sm_kind,ssm", [(L.SM_ESM, L.SSM_HOMOGRAPHY), (L.SM_FCLK, L.SSM_HOMOGRAPHY),
+                                         (L.SM_ICLK, L.SSM_AFFINE), (L.SM_ICLK, L.SSM_HOMOGRAPHY)])
+def test_device_side_loop_matches_oracle_tracker(oracle, gpu_ctx, frame, sm_kind, ssm):
+    """mtfhip_batch_track (solve + update + convergence test on the device) lands on the oracle's
+    final corners and iteration count, for several independent targets in one batch."""
+    rng = np.random.default_rng(23)
+    res, B = 40, 5
+    centres = [(150.0 + 60 * i, 200.0 + 25 * i) for i in range(B)]
+    p_true = synth.random_small_homography(rng, 0.4)
+    frame2 = synth.warp_frame(frame, p_true, (256.0, 256.0))
+    corners = np.stack([synth.square_corners(cx, cy, 70) for cx, cy in centres])
+    params = dict(leven_marq=0, max_iters=25, epsilon=1e-4)
+    gpu_ctx.set_image(frame)
+    b = mtf_amd.Batch(gpu_ctx, L.AM_SSD, ssm, res, res, B)
+    b.set_corners(corners)
+    sm = mtf_amd.sm_desc(sm_kind, materialize=0, **params)
+    b.init_template(sm)
+    gpu_ctx.set_image(frame2)
+    n_it, final = b.track(sm)
+    for t in range(B):
+        o_ssm = oracle.SSM(ssm, res, res)
+        o_am = oracle.AM(L.AM_SSD, res, res)
+        o_am.set_curr_img(frame)
+        trk = oracle.Tracker(sm_kind, o_am, o_ssm, **params)
+        trk.initialize(corners[t])
+        o_am.set_curr_img(frame2)
+        iters = trk.update()
+        np.testing.assert_allclose(final[t], trk.get_region(), rtol=0, atol=2e-4)
+        assert abs(int(n_it[t]) - iters) <= 1
+
+
+def test_pf_candidate_scores(oracle, gpu_ctx, frame):
+    rng = np.random.default_rng(31)
+    corners = synth.square_corners(256, 256, 100)
+    o_am, o_ssm, b = make_pair(oracle, gpu_ctx, frame, L.AM_SSD, L.SSM_HOMOGRAPHY, 50, corners)
+    pts0 = o_ssm.get("curr_pts")
+    o_am.initialize_pix_vals(pts0); o_am.initialize_similarity()
+    b.initialize_pix_vals(); b.initialize_similarity()
+    states = synth.pf_candidate_states(rng, 300)
+    lik_o, sim_o = oracle.pf_score(o_am, o_ssm, states)
+    lik, sim = b.score_candidates(states, want_similarity=True)
+    np.testing.assert_allclose(sim, sim_o, rtol=1e-9)
+    np.testing.assert_allclose(lik, lik_o, rtol=1e-9)
+
+
+def test_border_and_integer_coordinate_cases(oracle, gpu_ctx, frame):
+    """Constant border (128) outside the image and at the last row/column, and the dx == 0 branch at
+    exact integer coordinates (imgUtils.h:96-108) -- samples and both gradient flavours."""
+    h, w = frame.shape
+    xs = np.array([-3.0, -1e-9, 0.0, 0.5, 10.0, 10.0 + 1e-8, w - 1.0, w - 1.0 + 1e-9, w - 0.5, w + 2.0, 37.25, 64.0])
+    ys = np.array([5.0, 5.0, 0.0, 0.0, 20.0, 20.0, 30.0, 30.0, h - 1.0, 7.0, h - 1.0, 64.0])
+    n = 16 * 16
+    X = np.resize(xs, n); Y = np.resize(ys, n)
+    pts = np.stack([X, Y])
+    gpu_ctx.set_image(frame)
+    b = mtf_amd.Batch(gpu_ctx, L.AM_SSD, L.SSM_HOMOGRAPHY, 16, 16, 1)
+    b.set_corners(synth.square_corners(100, 100, 16)[None])
+    b.update_pix_vals(pts[None])
+    flat = np.ascontiguousarray(pts.T.ravel())
+    assert np.array_equal(b.read(L.BUF_IT)[0], oracle.get_pix_vals(frame, flat))
+    b.update_pix_grad(pts[None])
+    assert np.array_equal(b.read(L.BUF_DIT_DX)[0], oracle.get_img_grad(frame, flat).reshape(2, -1).T)
+
+
+def test_error_behaviour(gpu_ctx, frame):
+    with pytest.raises(mtf_amd.InvalidArgument):
+        mtf_amd.Batch(gpu_ctx, L.AM_SSD, L.SSM_HOMOGRAPHY, 0, 10, 1)   # ImageBase.cc:33-35
+    b = mtf_amd.Batch(gpu_ctx, L.AM_SSD, L.SSM_HOMOGRAPHY, 10, 10, 1)
+    with pytest.raises(mtf_amd.LogicError):
+        b.set_state(np.zeros((1, 8)))
+    with pytest.raises(mtf_amd.InvalidArgument):
+        gpu_ctx.set_image(np.zeros((8, 8), dtype=np.uint8))             # ImageBase.cc:49-54
+    bn = mtf_amd.Batch(gpu_ctx, L.AM_NCC, L.SSM_AFFINE, 10, 10, 1)
+    bn.set_corners(synth.square_corners(50, 50, 10)[None])
