@@ -64,7 +64,10 @@ enum {
 	MTFHIP_BUF_GRAD_PTS = 11,/* 8 x N  StateSpaceModel::grad_pts */
 	MTFHIP_BUF_INIT_Z = 12,  /* N      third row of ProjectiveBase::init_pts_hm */
 	MTFHIP_BUF_CURR_Z = 13,  /* N      third row of ProjectiveBase::curr_pts_hm */
-	MTFHIP_BUF_COUNT = 14
+	MTFHIP_BUF_INIT_HXY = 14,/* 2 x N  first two rows of ProjectiveBase::init_pts_hm (homography keeps the
+	                                   un-normalised DLT product, Homography.cc:66) */
+	MTFHIP_BUF_CURR_HXY = 15,/* 2 x N  first two rows of ProjectiveBase::curr_pts_hm */
+	MTFHIP_BUF_COUNT = 16
 };
 
 typedef struct mtfhip_patch_desc {

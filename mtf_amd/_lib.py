@@ -15,7 +15,7 @@ SSM_HOMOGRAPHY, SSM_AFFINE = 0, 1
 SM_ESM, SM_FCLK, SM_ICLK = 0, 1, 2
 JAC_INIT, JAC_PIX, JAC_WARPED, JAC_APPROX = 0, 1, 2, 3
 (BUF_I0, BUF_IT, BUF_DI0_DX, BUF_DIT_DX, BUF_DF_DI0, BUF_DF_DIT, BUF_J0, BUF_JT, BUF_JM,
- BUF_INIT_PTS, BUF_CURR_PTS, BUF_GRAD_PTS, BUF_INIT_Z, BUF_CURR_Z) = range(14)
+ BUF_INIT_PTS, BUF_CURR_PTS, BUF_GRAD_PTS, BUF_INIT_Z, BUF_CURR_Z, BUF_INIT_HXY, BUF_CURR_HXY) = range(16)
 
 
 class MtfHipError(RuntimeError):
@@ -108,6 +108,8 @@ def lib():
         L.mtfhip_score_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.mtfhip_score_candidates_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.mtfhip_batch_device_ptr.argtypes = [C.c_void_p, C.c_int]
+        L.mtfhip_batch_read.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.mtfhip_batch_write.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.mtfhip_timing_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         _lib = L
     return _lib

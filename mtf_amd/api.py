@@ -119,18 +119,30 @@ class Batch:
         B, N, S = self.B, self.N, self.S
         sizes = {BUF_I0: N, BUF_IT: N, BUF_DI0_DX: 2 * N, BUF_DIT_DX: 2 * N, BUF_DF_DI0: N, BUF_DF_DIT: N,
                  BUF_J0: N * S, BUF_JT: N * S, BUF_JM: N * S, BUF_INIT_PTS: 2 * N, BUF_CURR_PTS: 2 * N,
-                 BUF_GRAD_PTS: 8 * N, 12: N, 13: N}
+                 BUF_GRAD_PTS: 8 * N, 12: N, 13: N, 14: 2 * N, 15: 2 * N}
         out = np.empty((B, sizes[buf]))
         L.check(L.lib().mtfhip_batch_read(self._h, buf, _p(out)))
         if buf in (BUF_DI0_DX, BUF_DIT_DX):
             return out.reshape(B, 2, N).transpose(0, 2, 1)
         if buf in (BUF_J0, BUF_JT, BUF_JM):
             return out.reshape(B, S, N).transpose(0, 2, 1)
-        if buf in (BUF_INIT_PTS, BUF_CURR_PTS):
+        if buf in (BUF_INIT_PTS, BUF_CURR_PTS, 14, 15):
             return out.reshape(B, N, 2).transpose(0, 2, 1)
         if buf == BUF_GRAD_PTS:
             return out.reshape(B, N, 8)
         return out
+
+    def write(self, buf, arr):
+        """Overwrite a device buffer from a NumPy-natural array (ImageBase setters, ImageBase.h:93-100)."""
+        B, N, S = self.B, self.N, self.S
+        a = _f64(arr)
+        if buf in (BUF_DI0_DX, BUF_DIT_DX):
+            a = np.ascontiguousarray(a.reshape(B, N, 2).transpose(0, 2, 1))
+        elif buf in (BUF_J0, BUF_JT, BUF_JM):
+            a = np.ascontiguousarray(a.reshape(B, N, S).transpose(0, 2, 1))
+        elif buf in (BUF_INIT_PTS, BUF_CURR_PTS, 14, 15):
+            a = np.ascontiguousarray(a.reshape(B, 2, N).transpose(0, 2, 1))
+        L.check(L.lib().mtfhip_batch_write(self._h, buf, _p(a)))
 
     def device_ptr(self, buf):
         return L.lib().mtfhip_batch_device_ptr(self._h, buf)

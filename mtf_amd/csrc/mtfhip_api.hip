@@ -362,7 +362,7 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 		b->norm_add = lo;
 	}
 	const size_t N = b->N, S = b->S;
-	size_t per[MTFHIP_BUF_COUNT] = {N, N, 2 * N, 2 * N, N, N, N * S, N * S, N * S, 2 * N, 2 * N, 8 * N, N, N};
+	size_t per[MTFHIP_BUF_COUNT] = {N, N, 2 * N, 2 * N, N, N, N * S, N * S, N * S, 2 * N, 2 * N, 8 * N, N, N, 2 * N, 2 * N};
 	for (int i = 0; i < MTFHIP_BUF_COUNT; ++i) { b->per_target[i] = per[i]; b->buf[i] = nullptr; }
 	b->th.resize(n_targets);
 	for (auto &h : b->th) { std::memset(&h, 0, sizeof(h)); h.warp = m3_identity(); }
@@ -372,7 +372,7 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 	auto cleanup = [&](int code) { mtfhip_batch_destroy(b); return code; };
 	const int eager[] = {MTFHIP_BUF_I0, MTFHIP_BUF_IT, MTFHIP_BUF_DI0_DX, MTFHIP_BUF_DIT_DX, MTFHIP_BUF_DF_DI0,
 		MTFHIP_BUF_DF_DIT, MTFHIP_BUF_J0, MTFHIP_BUF_JT, MTFHIP_BUF_INIT_PTS, MTFHIP_BUF_CURR_PTS,
-		MTFHIP_BUF_INIT_Z, MTFHIP_BUF_CURR_Z};
+		MTFHIP_BUF_INIT_Z, MTFHIP_BUF_CURR_Z, MTFHIP_BUF_INIT_HXY, MTFHIP_BUF_CURR_HXY};
 	for (int id : eager) { int r = ensure_buf(b, id); if (r) return cleanup(r); }
 #define ALLOC(ptr, bytes) do { if (hipMalloc(&(ptr), (bytes)) != hipSuccess) return cleanup(fail(MTFHIP_ERR_HIP, "hipMalloc(%zu) failed", (size_t)(bytes))); } while (0)
 	ALLOC(b->d_warps, sizeof(double) * 9 * n_targets);
@@ -432,6 +432,8 @@ int mtfhip_batch_write(mtfhip_batch *b, int id, const double *src) {
 	if (id == MTFHIP_BUF_IT) b->it_valid = true;
 	if (id == MTFHIP_BUF_DIT_DX) b->dit_valid = true;
 	if (id == MTFHIP_BUF_JT) b->jt_valid = true;
+	/* a caller that supplies its own homogeneous grid gets the general (non unit-z) kernels */
+	if (id == MTFHIP_BUF_INIT_Z || id == MTFHIP_BUF_INIT_HXY) b->unit_z = 0;
 	return MTFHIP_OK;
 }
 

@@ -187,6 +187,8 @@ __global__ __launch_bounds__(kBlock) void k_init_grid(BatchView bv, const double
 	double2 *cp = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * bv.N;
 	double *iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * bv.N;
 	double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * bv.N;
+	double2 *ih = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]) + (size_t)t * bv.N;
+	double2 *ch = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_CURR_HXY]) + (size_t)t * bv.N;
 	for (int i = blockIdx.x * kBlock + threadIdx.x; i < bv.N; i += gridDim.x * kBlock) {
 		const int col = i % resx, row = i / resx;
 		const double nx = lin_spaced(col, resx, lo_x, hi_x), ny = lin_spaced(row, resy, lo_y, hi_y);
@@ -195,7 +197,9 @@ __global__ __launch_bounds__(kBlock) void k_init_grid(BatchView bv, const double
 		const double Z = W.m[6] * nx + W.m[7] * ny + W.m[8] * 1.0;
 		const double2 p = make_double2(X / Z, Y / Z);
 		const double z = force_unit_z ? 1.0 : Z;
-		ip[i] = p; cp[i] = p; iz[i] = z; cz[i] = z;
+		/* affine re-homogenises (x, y, 1); homography keeps (X, Y, Z) */
+		const double2 hxy = force_unit_z ? p : make_double2(X, Y);
+		ip[i] = p; cp[i] = p; iz[i] = z; cz[i] = z; ih[i] = hxy; ch[i] = hxy;
 	}
 }
 
@@ -207,12 +211,14 @@ __global__ __launch_bounds__(kBlock) void k_apply_warp(BatchView bv) {
 	const Warp9 W = load_warp(bv.warps + 9 * t);
 	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * bv.N;
 	const double *iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * bv.N;
+	const double2 *ih = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]) + (size_t)t * bv.N;
 	double2 *cp = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * bv.N;
+	double2 *ch = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_CURR_HXY]) + (size_t)t * bv.N;
 	double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * bv.N;
 	for (int i = blockIdx.x * kBlock + threadIdx.x; i < bv.N; i += gridDim.x * kBlock) {
-		double2 p = ip[i];
+		double2 hp = bv.unit_z ? ip[i] : ih[i];
 		double z = bv.unit_z ? 1.0 : iz[i];
-		double hx = bv.unit_z ? p.x : p.x * z, hy = bv.unit_z ? p.y : p.y * z;
+		double hx = hp.x, hy = hp.y;
 		double2 o;
 		if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
 			double cx = W.m[0] * hx + W.m[1] * hy + W.m[2] * z;
@@ -220,10 +226,12 @@ __global__ __launch_bounds__(kBlock) void k_apply_warp(BatchView bv) {
 			double d = W.m[6] * hx + W.m[7] * hy + W.m[8] * z;
 			o.x = cx / d; o.y = cy / d;
 			cz[i] = d;
+			ch[i] = make_double2(cx, cy);
 		} else {
 			o.x = W.m[0] * hx + W.m[1] * hy + W.m[2] * z;
 			o.y = W.m[3] * hx + W.m[4] * hy + W.m[5] * z;
 			cz[i] = 1.0;
+			ch[i] = o;
 		}
 		cp[i] = o;
 	}
@@ -235,6 +243,7 @@ __global__ __launch_bounds__(kBlock) void k_grad_pts(BatchView bv, double eps) {
 	const Warp9 W = load_warp(bv.warps + 9 * t);
 	const double2 *cp = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * bv.N;
 	const double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * bv.N;
+	const double2 *ch = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_CURR_HXY]) + (size_t)t * bv.N;
 	double *gp = bv.buf[MTFHIP_BUF_GRAD_PTS] + (size_t)t * bv.N * 8;
 	const double dx0 = W.m[0] * eps, dx1 = W.m[3] * eps, dx2 = W.m[6] * eps;
 	const double dy0 = W.m[1] * eps, dy1 = W.m[4] * eps, dy2 = W.m[7] * eps;
@@ -242,9 +251,8 @@ __global__ __launch_bounds__(kBlock) void k_grad_pts(BatchView bv, double eps) {
 		double2 p = cp[i];
 		double g[8];
 		if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
-			/* the reference keeps curr_pts_hm; it is recovered as (x*D, y*D, D) -- exact when D == 1 */
-			double d = cz[i];
-			double q0 = p.x * d, q1 = p.y * d, q2 = d;
+			double2 h = ch[i];
+			double q0 = h.x, q1 = h.y, q2 = cz[i];
 			double a0 = q0 + dx0, a1 = q1 + dx1, a2 = q2 + dx2;
 			g[0] = a0 / a2; g[1] = a1 / a2;
 			a0 = q0 - dx0; a1 = q1 - dx1; a2 = q2 - dx2;
@@ -504,6 +512,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_ssd(BatchView bv, ImgView im, 
 	const double *st = bv.states + 8 * t;
 	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * N;
 	const double *iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * N;
+	const double2 *ih = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]) + (size_t)t * N;
 	const double *I0 = bv.buf[MTFHIP_BUF_I0] + (size_t)t * N;
 	const double *J0 = bv.buf[MTFHIP_BUF_J0] + (size_t)t * N * S;
 	double *It = bv.buf[MTFHIP_BUF_IT] + (size_t)t * N;
@@ -526,8 +535,8 @@ __global__ __launch_bounds__(kBlock) void k_fused_ssd(BatchView bv, ImgView im, 
 		if (i >= N) break;
 		const double2 p0 = ip[i];
 		const double x = p0.x, y = p0.y;
-		const double z = bv.unit_z ? 1.0 : iz[i];
-		const double hx = bv.unit_z ? x : x * z, hy = bv.unit_z ? y : y * z;
+		double z = 1.0, hx = x, hy = y;
+		if (!bv.unit_z) { const double2 hp = ih[i]; hx = hp.x; hy = hp.y; z = iz[i]; }
 		double wx, wy, cx = 0, cy = 0, D = 1.0;
 		if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
 			cx = W.m[0] * hx + W.m[1] * hy + W.m[2] * z;
@@ -667,12 +676,13 @@ __global__ __launch_bounds__(kBlock) void k_score_candidates(BatchView bv, ImgVi
 	}
 	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]);
 	const double *iz = bv.buf[MTFHIP_BUF_INIT_Z];
+	const double2 *ih = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]);
 	const double *I0 = bv.buf[MTFHIP_BUF_I0];
 	double acc = 0.0;
 	for (int i = lane; i < N; i += 64) {
-		double2 q = ip[i];
+		double2 q = bv.unit_z ? ip[i] : ih[i];
 		double z = bv.unit_z ? 1.0 : iz[i];
-		double hx = bv.unit_z ? q.x : q.x * z, hy = bv.unit_z ? q.y : q.y * z;
+		double hx = q.x, hy = q.y;
 		double wx, wy;
 		if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
 			double cx = W[0] * hx + W[1] * hy + W[2] * z;
@@ -769,8 +779,8 @@ __global__ __launch_bounds__(64) void k_track_step(BatchView bv, mtfhip_sm_desc 
 		double det = U[0] * c[0] + U[1] * c[3] + U[2] * c[6];
 		double inv_det = 1.0 / det;
 		for (int i = 0; i < 9; ++i) c[i] *= inv_det;
-		double n22 = 1.0 / c[8];
-		for (int i = 0; i < 9; ++i) U[i] = c[i] * n22;
+		double n22 = c[8];
+		for (int i = 0; i < 9; ++i) U[i] = c[i] / n22;
 		/* round-trip through the state parameterisation as getStateFromWarp / getWarpFromState do */
 		if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) { U[0] = 1 + (U[0] - 1); U[4] = 1 + (U[4] - 1); U[8] = 1; }
 		else { U[0] = 1 + (U[0] - 1); U[4] = 1 + (U[4] - 1); U[6] = 0; U[7] = 0; U[8] = 1; }
@@ -780,8 +790,8 @@ __global__ __launch_bounds__(64) void k_track_step(BatchView bv, mtfhip_sm_desc 
 		for (int c2 = 0; c2 < 3; ++c2)
 			Wn[3 * r + c2] = Wp[3 * r] * U[c2] + Wp[3 * r + 1] * U[3 + c2] + Wp[3 * r + 2] * U[6 + c2];
 	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
-		double n22 = 1.0 / Wn[8];
-		for (int i = 0; i < 9; ++i) Wn[i] *= n22;
+		double n22 = Wn[8];
+		for (int i = 0; i < 9; ++i) Wn[i] /= n22;
 		st[0] = Wn[0] - 1; st[1] = Wn[1]; st[2] = Wn[2]; st[3] = Wn[3]; st[4] = Wn[4] - 1; st[5] = Wn[5];
 		st[6] = Wn[6]; st[7] = Wn[7];
 	} else {

