@@ -7,7 +7,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmtfhip.so")
+LIB_PATH = os.environ.get("MTFHIP_LIB", os.path.join(_HERE, "libmtfhip.so"))
 CSRC = os.path.join(_HERE, "csrc")
 
 AM_SSD, AM_NCC, AM_MI = 0, 1, 2

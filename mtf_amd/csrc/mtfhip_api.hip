@@ -956,8 +956,10 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 			TimedScope tsc(b->ctx, "fused_lk");
 			launch_fused_ssd(bv, b->ctx->img, fa, b->d_partials, nblk, st);
 		}
-		launch_finish(b->d_partials, nblk, b->d_acc, b->B, st);
-		launch_track_step(bv, *sm, ts, st);
+		{
+			TimedScope tsc(b->ctx, "finish_track");
+			launch_finish_track(bv, *sm, ts, b->d_partials, nblk, st);
+		}
 	}
 	std::vector<double> w(9 * (size_t)b->B), s(8 * (size_t)b->B);
 	std::vector<int> iters(b->B);

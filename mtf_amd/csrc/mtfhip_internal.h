@@ -34,7 +34,10 @@ enum {
 };
 
 constexpr int kBlock = 256;       /* threads per workgroup: 4 wave64 */
-constexpr int kFusedPPT = 8;      /* pixels per thread in the fused kernels */
+#ifndef MTFHIP_PPT
+#define MTFHIP_PPT 8
+#endif
+constexpr int kFusedPPT = MTFHIP_PPT; /* pixels per thread in the fused kernels */
 constexpr int kMaxS = 8;
 
 inline int fused_blocks_per_target(int N) { return (N + kBlock * kFusedPPT - 1) / (kBlock * kFusedPPT); }
@@ -89,7 +92,8 @@ struct TrackState {
 	int *active;        /* [B] 1 while the target still iterates */
 	int *n_iters;       /* [B] */
 };
-void launch_track_step(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, hipStream_t st);
+void launch_finish_track(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, const double *partials,
+	int nblk, hipStream_t st);
 
 } // namespace mtfhip
 #endif

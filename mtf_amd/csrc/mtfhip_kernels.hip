@@ -17,6 +17,14 @@
  */
 #include "mtfhip_internal.h"
 
+/* tuning knobs of the fused kernel ("fused kernel tuning") */
+#ifndef MTFHIP_PIPE
+#define MTFHIP_PIPE 1          /* 0: no software pipeline, 1: operands one row ahead, 3: static three-row ring */
+#endif
+#ifndef MTFHIP_FUSED_WAVES
+#define MTFHIP_FUSED_WAVES 2   /* minimum waves per SIMD requested from the register allocator */
+#endif
+
 namespace mtfhip {
 
 /* ===================================================================== */
@@ -483,9 +491,14 @@ __global__ __launch_bounds__(64) void k_finish(const double *partials, int nblk,
 	const int t = blockIdx.x, k = threadIdx.x;
 	if (k >= ACC_COUNT) return;
 	const double *p = partials + (size_t)t * nblk * ACC_COUNT + k;
-	double s = 0;
-	for (int b = 0; b < nblk; ++b) s += p[(size_t)b * ACC_COUNT];
-	out[(size_t)t * ACC_COUNT + k] = s;
+	double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+	int b = 0;
+	for (; b + 3 < nblk; b += 4) {
+		s0 += p[(size_t)b * ACC_COUNT]; s1 += p[(size_t)(b + 1) * ACC_COUNT];
+		s2 += p[(size_t)(b + 2) * ACC_COUNT]; s3 += p[(size_t)(b + 3) * ACC_COUNT];
+	}
+	for (; b < nblk; ++b) s0 += p[(size_t)b * ACC_COUNT];
+	out[(size_t)t * ACC_COUNT + k] = (s0 + s1) + (s2 + s3);
 }
 
 /* ===================================================================== */
@@ -500,24 +513,68 @@ __global__ __launch_bounds__(64) void k_finish(const double *partials, int nblk,
  * MODE 1 ESM : g += -r * (J0 + Jt)     H += Jt (x) Jt   (or Jm (x) Jm when hess_mean)
  * MODE 2 ICLK: g += +r * J0            (no gradient, no H: InitialSelf / Std Hessians are constant)
  * With MAT the interface-visible arrays It, dIt_dx and Jt are also written (88 B/pixel).
+ *
+ * Memory-level parallelism: the streaming operands of pixel i+256 (grid point, template value, the
+ * eight J0 columns) are fetched into registers before pixel i is processed, so every wave keeps two
+ * rows of HBM requests in flight.  Sampling takes a wave-uniform fast path when, for all 64 lanes,
+ * the centre sample and its four finite-difference neighbours lie in one interior bilinear cell (the
+ * normal case): 4 texel loads, straight-line arithmetic, no divergent control flow.  Any lane near
+ * the border or on an integer coordinate sends the wave through the general per-sample path.  Both
+ * paths evaluate the reference's expressions in the reference's order.
+ */
+__device__ __forceinline__ double bilin(double t00, double t01, double t10, double t11, double dx, double dy) {
+	return t00 * (1 - dx) * (1 - dy) + t01 * dx * (1 - dy) + t10 * (1 - dx) * dy + t11 * dx * dy;
+}
+/* true when (x, y) is sampled from the interior cell (lx, ly) with both upper neighbours lx+1, ly+1 */
+__device__ __forceinline__ bool in_cell(double x, double y, int lx, int ly) {
+	return (x >= 0) && (y >= 0) && ((int)x == lx) && ((int)y == ly) && ((x - lx) != 0) && ((y - ly) != 0);
+}
+
+template <int S, int MODE>
+struct PixIn {
+	double2 p;
+	double2 hp;
+	double z;
+	double i0;
+	double j0[MODE == 0 ? 1 : S];
+};
+/* warped position of a grid point and the four texels of its bilinear cell, fetched one row ahead */
+struct Tex {
+	double wx, wy, cx, cy, D;
+	float t00, t01, t10, t11;
+	int lx, ly;
+	bool ok;   /* interior cell, non-integer coordinates: the texels above are the sample's own */
+};
+
+/*
+ * Software pipeline (per thread, rows are 256 pixels apart):
+ *   iteration i:  [texel loads of row i+1] -> [streaming loads of row i+2: grid point, I0, J0 columns]
+ *                 -> arithmetic of row i -> [stores of row i]
+ * vmcnt retires in order, so the texels of a row are requested before the younger streaming loads and
+ * are consumed one iteration later, when everything older has long completed; each wave keeps two rows
+ * of HBM reads plus one row of writes in flight.
  */
 template <int SSM, bool CHAINED, int MODE, bool MAT>
-__global__ __launch_bounds__(kBlock) void k_fused_ssd(BatchView bv, ImgView im, FusedArgs fa, double *partials, int nblk) {
+__global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchView bv, ImgView im, FusedArgs fa, double *partials, int nblk) {
 	constexpr int S = (SSM == MTFHIP_SSM_HOMOGRAPHY) ? 8 : 6;
 	constexpr int K = 48;
 	__shared__ double lds[4 * K];
-	const int t = blockIdx.y, N = bv.N;
+	const int t = blockIdx.y;
+	const unsigned N = (unsigned)bv.N;
 	if (fa.active && !fa.active[t]) return;
 	const Warp9 W = load_warp(bv.warps + 9 * t);
 	const double *st = bv.states + 8 * t;
-	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * N;
-	const double *iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * N;
-	const double2 *ih = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]) + (size_t)t * N;
-	const double *I0 = bv.buf[MTFHIP_BUF_I0] + (size_t)t * N;
-	const double *J0 = bv.buf[MTFHIP_BUF_J0] + (size_t)t * N * S;
-	double *It = bv.buf[MTFHIP_BUF_IT] + (size_t)t * N;
-	double *dIt = bv.buf[MTFHIP_BUF_DIT_DX] + (size_t)t * N * 2;
-	double *Jt = bv.buf[MTFHIP_BUF_JT] + (size_t)t * N * S;
+	const double2 *__restrict__ ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * N;
+	const double *__restrict__ iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * N;
+	const double2 *__restrict__ ih = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]) + (size_t)t * N;
+	const double *__restrict__ I0 = bv.buf[MTFHIP_BUF_I0] + (size_t)t * N;
+	const double *__restrict__ J0 = bv.buf[MTFHIP_BUF_J0] + (size_t)t * N * S;
+	double *__restrict__ It = bv.buf[MTFHIP_BUF_IT] + (size_t)t * N;
+	double *__restrict__ dIt = bv.buf[MTFHIP_BUF_DIT_DX] + (size_t)t * N * 2;
+	double *__restrict__ Jt = bv.buf[MTFHIP_BUF_JT] + (size_t)t * N * S;
+	const float *__restrict__ img = im.data;
+	const int iw = im.w, ih_ = im.h, istride = im.stride;
+	const bool unit_z = bv.unit_z != 0;
 	const double eps = fa.grad_eps;
 	const double gmult = fa.norm_mult / (2 * eps);
 	const double ex0 = W.m[0] * eps, ex1 = W.m[3] * eps, ex2 = W.m[6] * eps;
@@ -528,58 +585,93 @@ __global__ __launch_bounds__(kBlock) void k_fused_ssd(BatchView bv, ImgView im, 
 #pragma unroll
 	for (int k = 0; k < K; ++k) acc[k] = 0.0;
 
-	const int base = blockIdx.x * (kBlock * kFusedPPT) + threadIdx.x;
-#pragma unroll 2
-	for (int kk = 0; kk < kFusedPPT; ++kk) {
-		const int i = base + kk * kBlock;
-		if (i >= N) break;
-		const double2 p0 = ip[i];
-		const double x = p0.x, y = p0.y;
-		double z = 1.0, hx = x, hy = y;
-		if (!bv.unit_z) { const double2 hp = ih[i]; hx = hp.x; hy = hp.y; z = iz[i]; }
-		double wx, wy, cx = 0, cy = 0, D = 1.0;
-		if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
-			cx = W.m[0] * hx + W.m[1] * hy + W.m[2] * z;
-			cy = W.m[3] * hx + W.m[4] * hy + W.m[5] * z;
-			D = W.m[6] * hx + W.m[7] * hy + W.m[8] * z;
-			wx = cx / D; wy = cy / D;
+	auto load_in = [&](unsigned i) {
+		PixIn<S, MODE> in;
+		in.p = ip[i];
+		in.i0 = I0[i];
+		if constexpr (MODE != 0) {
+#pragma unroll
+			for (int s = 0; s < S; ++s) in.j0[s] = J0[(unsigned)s * N + i];
 		} else {
-			wx = W.m[0] * hx + W.m[1] * hy + W.m[2] * z;
-			wy = W.m[3] * hx + W.m[4] * hy + W.m[5] * z;
+			in.j0[0] = 0;
 		}
-		const Cell c = load_cell(im, wx, wy);
-		const double it = fa.norm_mult * pix_val_cell(im, c, wx, wy) + fa.norm_add;
-		const double r = it - I0[i];
-		acc[44] = fma(r, r, acc[44]);
-		if constexpr (MAT) It[i] = it;
+		if (!unit_z) { in.hp = ih[i]; in.z = iz[i]; }
+		else { in.hp = in.p; in.z = 1.0; }
+		return in;
+	};
+	/* curr_pts_hm = curr_warp * init_pts_hm and its dehomogenisation (Homography.cc:86-90, Affine.cc:104),
+	 * then the texel fetch of the bilinear cell */
+	auto issue_tex = [&](const PixIn<S, MODE> &in) {
+		Tex tx;
+		const double z = in.z, hx = in.hp.x, hy = in.hp.y;
+		if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+			tx.cx = W.m[0] * hx + W.m[1] * hy + W.m[2] * z;
+			tx.cy = W.m[3] * hx + W.m[4] * hy + W.m[5] * z;
+			tx.D = W.m[6] * hx + W.m[7] * hy + W.m[8] * z;
+			tx.wx = tx.cx / tx.D; tx.wy = tx.cy / tx.D;
+		} else {
+			tx.wx = W.m[0] * hx + W.m[1] * hy + W.m[2] * z;
+			tx.wy = W.m[3] * hx + W.m[4] * hy + W.m[5] * z;
+			tx.cx = tx.wx; tx.cy = tx.wy; tx.D = 1.0;
+		}
+		tx.lx = (int)tx.wx; tx.ly = (int)tx.wy;
+		tx.ok = in_cell(tx.wx, tx.wy, tx.lx, tx.ly) && (tx.lx + 1 < iw) && (tx.ly + 1 < ih_);
+		const int sx = tx.ok ? tx.lx : 0, sy = tx.ok ? tx.ly : 0;
+		const float *r0 = img + (unsigned)(sy * istride + sx);
+		const float *r1 = r0 + istride;
+		tx.t00 = r0[0]; tx.t01 = r0[1]; tx.t10 = r1[0]; tx.t11 = r1[1];
+		return tx;
+	};
 
-		double row[8];
+	const unsigned base = blockIdx.x * (unsigned)(kBlock * kFusedPPT) + threadIdx.x;
+	/* arithmetic + stores of one row; `cur` holds its streaming operands, `tcur` its position and texels */
+	auto row_compute = [&](unsigned i, const PixIn<S, MODE> &cur, const Tex &tcur) {
+		const double x = cur.p.x, y = cur.p.y;
+		const double wx = tcur.wx, wy = tcur.wy, cx = tcur.cx, cy = tcur.cy, D = tcur.D;
+		const int lx = tcur.lx, ly = tcur.ly;
+		/* the four finite-difference sample points */
+		double px0, py0, px1, py1, px2, py2, px3, py3;
 		if constexpr (MODE != 2) {
-			double gx, gy;
 			if constexpr (CHAINED) {
 				/* utils::getImgGrad at the warped point (imgUtils.cc:233-254) */
-				double inc = pix_val_cell(im, c, wx + eps, wy);
-				double dec = pix_val_cell(im, c, wx - eps, wy);
-				gx = (inc - dec) * gmult;
-				inc = pix_val_cell(im, c, wx, wy + eps);
-				dec = pix_val_cell(im, c, wx, wy - eps);
-				gy = (inc - dec) * gmult;
+				px0 = wx + eps; py0 = wy; px1 = wx - eps; py1 = wy;
+				px2 = wx; py2 = wy + eps; px3 = wx; py3 = wy - eps;
+			} else if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+				/* Homography::updateGradPts SSM/src/Homography.cc:803-827 */
+				double a0 = cx + ex0, a1 = cy + ex1, a2 = D + ex2;
+				px0 = a0 / a2; py0 = a1 / a2;
+				a0 = cx - ex0; a1 = cy - ex1; a2 = D - ex2;
+				px1 = a0 / a2; py1 = a1 / a2;
+				a0 = cx + ey0; a1 = cy + ey1; a2 = D + ey2;
+				px2 = a0 / a2; py2 = a1 / a2;
+				a0 = cx - ey0; a1 = cy - ey1; a2 = D - ey2;
+				px3 = a0 / a2; py3 = a1 / a2;
 			} else {
-				/* updateGradPts + utils::getWarpedImgGrad (Homography.cc:803-827, imgUtils.cc:177-202) */
-				double px0, py0, px1, py1, px2, py2, px3, py3;
-				if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
-					double a0 = cx + ex0, a1 = cy + ex1, a2 = D + ex2;
-					px0 = a0 / a2; py0 = a1 / a2;
-					a0 = cx - ex0; a1 = cy - ex1; a2 = D - ex2;
-					px1 = a0 / a2; py1 = a1 / a2;
-					a0 = cx + ey0; a1 = cy + ey1; a2 = D + ey2;
-					px2 = a0 / a2; py2 = a1 / a2;
-					a0 = cx - ey0; a1 = cy - ey1; a2 = D - ey2;
-					px3 = a0 / a2; py3 = a1 / a2;
-				} else {
-					px0 = wx + ex0; py0 = wy + ex1; px1 = wx - ex0; py1 = wy - ex1;
-					px2 = wx + ey0; py2 = wy + ey1; px3 = wx - ey0; py3 = wy - ey1;
-				}
+				/* Affine::updateGradPts SSM/src/Affine.cc:293-313 */
+				px0 = wx + ex0; py0 = wy + ex1; px1 = wx - ex0; py1 = wy - ex1;
+				px2 = wx + ey0; py2 = wy + ey1; px3 = wx - ey0; py3 = wy - ey1;
+			}
+		}
+		bool fast = tcur.ok;
+		if constexpr (MODE != 2)
+			fast = fast && in_cell(px0, py0, lx, ly) && in_cell(px1, py1, lx, ly) && in_cell(px2, py2, lx, ly) &&
+				in_cell(px3, py3, lx, ly);
+		double it, gx = 0, gy = 0;
+		if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
+			const double t00 = tcur.t00, t01 = tcur.t01, t10 = tcur.t10, t11 = tcur.t11;
+			it = fa.norm_mult * bilin(t00, t01, t10, t11, wx - lx, wy - ly) + fa.norm_add;
+			if constexpr (MODE != 2) {
+				double inc = bilin(t00, t01, t10, t11, px0 - lx, py0 - ly);
+				double dec = bilin(t00, t01, t10, t11, px1 - lx, py1 - ly);
+				gx = (inc - dec) * gmult;
+				inc = bilin(t00, t01, t10, t11, px2 - lx, py2 - ly);
+				dec = bilin(t00, t01, t10, t11, px3 - lx, py3 - ly);
+				gy = (inc - dec) * gmult;
+			}
+		} else {
+			const Cell c = load_cell(im, wx, wy);
+			it = fa.norm_mult * pix_val_cell(im, c, wx, wy) + fa.norm_add;
+			if constexpr (MODE != 2) {
 				double inc = pix_val_cell(im, c, px0, py0);
 				double dec = pix_val_cell(im, c, px1, py1);
 				gx = (inc - dec) * gmult;
@@ -587,6 +679,13 @@ __global__ __launch_bounds__(kBlock) void k_fused_ssd(BatchView bv, ImgView im, 
 				dec = pix_val_cell(im, c, px3, py3);
 				gy = (inc - dec) * gmult;
 			}
+		}
+		const double r = it - cur.i0;
+		acc[44] = fma(r, r, acc[44]);
+		if constexpr (MAT) It[i] = it;
+
+		double row[8];
+		if constexpr (MODE != 2) {
 			if constexpr (MAT) { dIt[i] = gx; dIt[N + i] = gy; }
 			if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
 				if constexpr (CHAINED) {
@@ -616,7 +715,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_ssd(BatchView bv, ImgView im, 
 			}
 			if constexpr (MAT) {
 #pragma unroll
-				for (int s = 0; s < S; ++s) Jt[(size_t)s * N + i] = row[s];
+				for (int s = 0; s < S; ++s) Jt[(unsigned)s * N + i] = row[s];
 			}
 		}
 
@@ -626,18 +725,15 @@ __global__ __launch_bounds__(kBlock) void k_fused_ssd(BatchView bv, ImgView im, 
 			for (int s = 0; s < S; ++s) acc[36 + s] = fma(v, row[s], acc[36 + s]);
 		} else if constexpr (MODE == 1) {
 			const double v = -r;
-			double j0[8];
 #pragma unroll
-			for (int s = 0; s < S; ++s) j0[s] = J0[(size_t)s * N + i];
-#pragma unroll
-			for (int s = 0; s < S; ++s) acc[36 + s] = fma(v, j0[s] + row[s], acc[36 + s]);
+			for (int s = 0; s < S; ++s) acc[36 + s] = fma(v, cur.j0[s] + row[s], acc[36 + s]);
 			if (fa.hess_mean) {
 #pragma unroll
-				for (int s = 0; s < S; ++s) row[s] = (j0[s] + row[s]) / 2.0;
+				for (int s = 0; s < S; ++s) row[s] = (cur.j0[s] + row[s]) / 2.0;
 			}
 		} else {
 #pragma unroll
-			for (int s = 0; s < S; ++s) acc[36 + s] = fma(r, J0[(size_t)s * N + i], acc[36 + s]);
+			for (int s = 0; s < S; ++s) acc[36 + s] = fma(r, cur.j0[s], acc[36 + s]);
 		}
 		if constexpr (MODE != 2) {
 			int k = 0;
@@ -649,7 +745,56 @@ __global__ __launch_bounds__(kBlock) void k_fused_ssd(BatchView bv, ImgView im, 
 					++k;
 				}
 		}
+	};
+#if MTFHIP_PIPE == 0
+	/* no software pipelining: latency is covered by occupancy alone */
+#pragma unroll 1
+	for (int kk = 0; kk < kFusedPPT; ++kk) {
+		const unsigned i = base + (unsigned)kk * kBlock;
+		if (i >= N) break;
+		const PixIn<S, MODE> cur = load_in(i);
+		const Tex tcur = issue_tex(cur);
+		row_compute(i, cur, tcur);
 	}
+#elif MTFHIP_PIPE == 1
+	/* streaming operands of the next row are requested before the current row is processed */
+	PixIn<S, MODE> cur;
+	if (base < N) cur = load_in(base);
+#pragma unroll 1
+	for (int kk = 0; kk < kFusedPPT; ++kk) {
+		const unsigned i = base + (unsigned)kk * kBlock;
+		if (i >= N) break;
+		const Tex tcur = issue_tex(cur);
+		PixIn<S, MODE> nxt = cur;
+		if (kk + 1 < kFusedPPT && i + kBlock < N) nxt = load_in(i + kBlock);
+		row_compute(i, cur, tcur);
+		cur = nxt;
+	}
+#else
+	static_assert(kFusedPPT % 3 == 0, "the register ring rotates statically over three rows");
+	auto row_step = [&](int kk, const PixIn<S, MODE> &cur, const Tex &tcur, const PixIn<S, MODE> &nxt, Tex &tnxt,
+		PixIn<S, MODE> &nxt2) {
+		const unsigned i = base + (unsigned)kk * kBlock;
+		if (i >= N) return;
+		if (kk + 1 < kFusedPPT && i + kBlock < N) tnxt = issue_tex(nxt);
+		if (kk + 2 < kFusedPPT && i + 2 * kBlock < N) nxt2 = load_in(i + 2 * kBlock);
+		row_compute(i, cur, tcur);
+	};
+	PixIn<S, MODE> inA, inB, inC;
+	Tex txA, txB, txC;
+	if (base < N) {
+		inA = load_in(base);
+		if (base + kBlock < N) inB = load_in(base + kBlock);
+		txA = issue_tex(inA);
+	}
+#pragma unroll 1
+	for (int kk = 0; kk < kFusedPPT; kk += 3) {
+		if (base + (unsigned)kk * kBlock >= N) break;
+		row_step(kk, inA, txA, inB, txB, inC);
+		row_step(kk + 1, inB, txB, inC, txC, inA);
+		row_step(kk + 2, inC, txC, inA, txA, inB);
+	}
+#endif
 	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * ACC_COUNT;
 	block_reduce_store<K>(acc, dst, lds);
 }
@@ -708,59 +853,80 @@ __global__ __launch_bounds__(kBlock) void k_score_candidates(BatchView bv, ImgVi
 /* ===================================================================== */
 /* on-device solve + compositional update (batched drivers only)          */
 /* ===================================================================== */
-__device__ inline void solve_dense(int n, double *A /* col-major n x n, destroyed */, double *b /* in: rhs, out: x */) {
-	for (int k = 0; k < n; ++k) {
-		int piv = k;
-		double best = fabs(A[k * n + k]);
-		for (int i = k + 1; i < n; ++i) { double v = fabs(A[k * n + i]); if (v > best) { best = v; piv = i; } }
-		if (piv != k) {
-			for (int j = 0; j < n; ++j) { double tmp = A[j * n + k]; A[j * n + k] = A[j * n + piv]; A[j * n + piv] = tmp; }
-			double tmp = b[k]; b[k] = b[piv]; b[piv] = tmp;
-		}
-		double inv = 1.0 / A[k * n + k];
-		for (int i = k + 1; i < n; ++i) {
-			double f = A[k * n + i] * inv;
-			if (f == 0) continue;
-			for (int j = k; j < n; ++j) A[j * n + i] -= f * A[j * n + k];
-			b[i] -= f * b[k];
-		}
-	}
-	for (int k = n - 1; k >= 0; --k) {
-		double s = b[k];
-		for (int j = k + 1; j < n; ++j) s -= A[j * n + k] * b[j];
-		b[k] = s / A[k * n + k];
-	}
-}
-
-/* one thread per target: assemble g and H of the search method from the reduced accumulators,
- * solve H dp = -g, apply the compositional (ICLK: inverse compositional) update, test convergence.
- * SM/src/NT/FCLK.cc:260-339, NT/ESM.cc:252-292, NT/ICLK.cc:206-289; Homography.cc:73-92,109-114. */
-__global__ __launch_bounds__(64) void k_track_step(BatchView bv, mtfhip_sm_desc sm, TrackState ts) {
-	const int t = blockIdx.x * 64 + threadIdx.x;
-	if (t >= bv.B || !ts.active[t]) return;
+/* One wave64 per target, one launch per LK iteration:
+ *   (1) fixed-order sum of the per-workgroup partial rows (what k_finish does for the host-driven path),
+ *   (2) g and H of the search method from the accumulators (NT/FCLK.cc:260-288, NT/ESM.cc:298-377 with
+ *       SSDBase.cc:169-191,287-311, NT/ICLK.cc:206-251),
+ *   (3) H dp = -g by Gauss-Jordan elimination spread over the 64 lanes (lane = matrix entry) on the
+ *       symmetrically diagonal-scaled system; every SSD Hessian here is a negated Gram matrix, i.e.
+ *       definite, so no pivoting is needed (the reference uses Eigen's colPivHouseholderQr, NT/FCLK.cc:298),
+ *   (4) the (inverse) compositional update and the corner-change test on lane 0
+ *       (Homography.cc:73-92,109-114, Affine.cc:90-106,145-150, NT/FCLK.cc:314-339). */
+__global__ __launch_bounds__(64) void k_finish_track(BatchView bv, mtfhip_sm_desc sm, TrackState ts,
+	const double *partials, int nblk) {
+	__shared__ double acc_s[ACC_COUNT];
+	__shared__ double A[8][9];
+	__shared__ double dps[8];
+	const int t = blockIdx.x, lane = threadIdx.x;
+	if (!ts.active[t]) return;
 	const int S = bv.S;
-	const double *acc = ts.acc + (size_t)t * ACC_COUNT;
-	const double *h0 = ts.h0 + (size_t)t * 64;
-	double g[8], H[64];
-	double gscale = (sm.sm == MTFHIP_SM_ESM) ? 0.5 : 1.0;
-	for (int s = 0; s < S; ++s) g[s] = gscale * acc[ACC_G + s];
-	bool use_h0 = (sm.hess_type == 0) || (sm.sm == MTFHIP_SM_ICLK && sm.hess_type == 2);
-	bool sum_h0 = (sm.sm == MTFHIP_SM_ESM) && (sm.hess_type == 2 || sm.hess_type == 4);
-	int k = 0;
-	for (int a = 0; a < 8; ++a)
-		for (int b = a; b < 8; ++b) {
-			if (a < S && b < S) {
-				double v = use_h0 ? h0[b * S + a] : -acc[ACC_H + k];
-				if (sum_h0) v = (v + h0[b * S + a]) * 0.5;
-				H[b * S + a] = H[a * S + b] = v;
-			}
-			++k;
+	if (lane < ACC_COUNT) {
+		const double *p = partials + (size_t)t * nblk * ACC_COUNT + lane;
+		double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+		int b = 0;
+		for (; b + 3 < nblk; b += 4) {
+			s0 += p[(size_t)b * ACC_COUNT]; s1 += p[(size_t)(b + 1) * ACC_COUNT];
+			s2 += p[(size_t)(b + 2) * ACC_COUNT]; s3 += p[(size_t)(b + 3) * ACC_COUNT];
 		}
-	double dp[8];
-	for (int s = 0; s < S; ++s) dp[s] = g[s];
-	solve_dense(S, H, dp);
-	for (int s = 0; s < S; ++s) dp[s] = -dp[s];
+		for (; b < nblk; ++b) s0 += p[(size_t)b * ACC_COUNT];
+		const double s = (s0 + s1) + (s2 + s3);
+		acc_s[lane] = s;
+		ts.acc[(size_t)t * ACC_COUNT + lane] = s;
+	}
+	__syncthreads();
+	const int i = lane >> 3, j = lane & 7;
+	const double *h0 = ts.h0 + (size_t)t * 64;
+	const bool use_h0 = (sm.hess_type == 0) || (sm.sm == MTFHIP_SM_ICLK);
+	const bool sum_h0 = (sm.sm == MTFHIP_SM_ESM) && (sm.hess_type == 2 || sm.hess_type == 4);
+	const double gscale = (sm.sm == MTFHIP_SM_ESM) ? 0.5 : 1.0;
+	auto h_entry = [&](int r, int c) -> double {
+		if (r >= S || c >= S) return r == c ? -1.0 : 0.0;
+		const int a = r < c ? r : c, b2 = r < c ? c : r;
+		const int kk = a * 8 - (a * (a - 1)) / 2 + (b2 - a);
+		double v = use_h0 ? h0[b2 * S + a] : -acc_s[ACC_H + kk];
+		if (sum_h0) v = (v + h0[b2 * S + a]) * 0.5;
+		return v;
+	};
+	{
+		const double dii = h_entry(i, i), djj = h_entry(j, j);
+		const double si = dii != 0 ? 1.0 / sqrt(fabs(dii)) : 1.0, sj = djj != 0 ? 1.0 / sqrt(fabs(djj)) : 1.0;
+		A[i][j] = h_entry(i, j) * si * sj;
+		if (j == 0) A[i][8] = (i < S ? gscale * acc_s[ACC_G + i] : 0.0) * si;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		const double piv = A[k][k], aik = A[i][k], akj = A[k][j], bk = A[k][8];
+		const double f = (i != k && piv != 0) ? aik / piv : 0.0;
+		__syncthreads();
+		if (i != k) {
+			A[i][j] -= f * akj;
+			if (j == 0) A[i][8] -= f * bk;
+		}
+		__syncthreads();
+	}
+	if (j == 0) {
+		const double dii = h_entry(i, i);
+		const double si = dii != 0 ? 1.0 / sqrt(fabs(dii)) : 1.0;
+		const double d = A[i][i];
+		dps[i] = (i < S && d != 0) ? -(A[i][8] / d) * si : 0.0;
+	}
+	__syncthreads();
+	if (lane != 0) return;
 
+	double dp[8];
+#pragma unroll
+	for (int s = 0; s < 8; ++s) dp[s] = dps[s];
 	double *Wp = bv.warps + 9 * t, *st = bv.states + 8 * t;
 	double U[9];
 	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
@@ -778,29 +944,38 @@ __global__ __launch_bounds__(64) void k_track_step(BatchView bv, mtfhip_sm_desc 
 		c[6] = U[3] * U[7] - U[4] * U[6]; c[7] = U[1] * U[6] - U[0] * U[7]; c[8] = U[0] * U[4] - U[1] * U[3];
 		double det = U[0] * c[0] + U[1] * c[3] + U[2] * c[6];
 		double inv_det = 1.0 / det;
-		for (int i = 0; i < 9; ++i) c[i] *= inv_det;
+#pragma unroll
+		for (int q = 0; q < 9; ++q) c[q] *= inv_det;
 		double n22 = c[8];
-		for (int i = 0; i < 9; ++i) U[i] = c[i] / n22;
+#pragma unroll
+		for (int q = 0; q < 9; ++q) U[q] = c[q] / n22;
 		/* round-trip through the state parameterisation as getStateFromWarp / getWarpFromState do */
-		if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) { U[0] = 1 + (U[0] - 1); U[4] = 1 + (U[4] - 1); U[8] = 1; }
-		else { U[0] = 1 + (U[0] - 1); U[4] = 1 + (U[4] - 1); U[6] = 0; U[7] = 0; U[8] = 1; }
+		U[0] = 1 + (U[0] - 1); U[4] = 1 + (U[4] - 1); U[8] = 1;
+		if (bv.ssm != MTFHIP_SSM_HOMOGRAPHY) { U[6] = 0; U[7] = 0; }
 	}
-	double Wn[9];
+	double Wo[9], Wn[9];
+#pragma unroll
+	for (int q = 0; q < 9; ++q) Wo[q] = Wp[q];
+#pragma unroll
 	for (int r = 0; r < 3; ++r)
+#pragma unroll
 		for (int c2 = 0; c2 < 3; ++c2)
-			Wn[3 * r + c2] = Wp[3 * r] * U[c2] + Wp[3 * r + 1] * U[3 + c2] + Wp[3 * r + 2] * U[6 + c2];
+			Wn[3 * r + c2] = Wo[3 * r] * U[c2] + Wo[3 * r + 1] * U[3 + c2] + Wo[3 * r + 2] * U[6 + c2];
 	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
 		double n22 = Wn[8];
-		for (int i = 0; i < 9; ++i) Wn[i] /= n22;
+#pragma unroll
+		for (int q = 0; q < 9; ++q) Wn[q] /= n22;
 		st[0] = Wn[0] - 1; st[1] = Wn[1]; st[2] = Wn[2]; st[3] = Wn[3]; st[4] = Wn[4] - 1; st[5] = Wn[5];
 		st[6] = Wn[6]; st[7] = Wn[7];
 	} else {
 		st[0] = Wn[2]; st[1] = Wn[5]; st[2] = Wn[0] - 1; st[3] = Wn[1]; st[4] = Wn[3]; st[5] = Wn[4] - 1;
 	}
-	for (int i = 0; i < 9; ++i) Wp[i] = Wn[i];
+#pragma unroll
+	for (int q = 0; q < 9; ++q) Wp[q] = Wn[q];
 	double *cr = ts.corners + 8 * t;
 	const double *ic = ts.init_corners_hm + 12 * t;
 	double change = 0;
+#pragma unroll
 	for (int q = 0; q < 4; ++q) {
 		double X = ic[3 * q], Y = ic[3 * q + 1], Z = ic[3 * q + 2];
 		double nx = Wn[0] * X + Wn[1] * Y + Wn[2] * Z, ny = Wn[3] * X + Wn[4] * Y + Wn[5] * Z;
@@ -812,8 +987,9 @@ __global__ __launch_bounds__(64) void k_track_step(BatchView bv, mtfhip_sm_desc 
 		change += ddx * ddx + ddy * ddy;
 		cr[2 * q] = nx; cr[2 * q + 1] = ny;
 	}
-	ts.n_iters[t] += 1;
-	if (change < sm.epsilon || ts.n_iters[t] >= sm.max_iters) ts.active[t] = 0;
+	const int n_it = ts.n_iters[t] + 1;
+	ts.n_iters[t] = n_it;
+	if (change < sm.epsilon || n_it >= sm.max_iters) ts.active[t] = 0;
 }
 
 /* ===================================================================== */
@@ -903,8 +1079,9 @@ void launch_score_candidates(const BatchView &bv, const ImgView &im, const doubl
 		1.0, 0.0, dev_lik, dev_sim);
 }
 
-void launch_track_step(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, hipStream_t st) {
-	hipLaunchKernelGGL(k_track_step, dim3((bv.B + 63) / 64), dim3(64), 0, st, bv, sm, ts);
+void launch_finish_track(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, const double *partials,
+	int nblk, hipStream_t st) {
+	hipLaunchKernelGGL(k_finish_track, dim3(bv.B), dim3(64), 0, st, bv, sm, ts, partials, nblk);
 }
 
 } // namespace mtfhip
