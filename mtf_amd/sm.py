@@ -1,0 +1,184 @@
+"""Search methods that drive the device hot path: the callers of SURVEY.md section 8a rows A12 / A13.
+
+ESM / FCLK / ICLK mirror nt::ESM / nt::FCLK / nt::ICLK (SM/src/NT/{ESM,FCLK,ICLK}.cc): `initialize`,
+`update`, `set_region`, `get_region` with the reference's parameter names and defaults.  Two execution
+modes: host_solve=True keeps the S x S solve, Levenberg-Marquardt and the compositional update on the
+host exactly as the reference does (one fused launch + one small read-back per iteration);
+host_solve=False runs the whole loop on the device (mtfhip_batch_track).
+
+PF mirrors SM/src/PF.cc with the per-particle scoring on the device and, optionally, sharded over GPUs.
+"""
+import numpy as np
+
+from . import _lib as L
+from .api import Batch, sm_desc
+
+
+def _solve(H, g):
+    """state_update = -H.colPivHouseholderQr().solve(g^T): any backward-stable solver agrees to ~1e-12
+    on these well-conditioned S x S systems; symmetric diagonal scaling keeps it so for the badly scaled
+    homography Hessian."""
+    d = np.sqrt(np.abs(np.diag(H)))
+    d[d == 0] = 1.0
+    return -np.linalg.solve(H / np.outer(d, d), g / d) / d
+
+
+class LKTracker:
+    """One or many (B) independent targets tracked with ESM / FCLK / ICLK + SSD on one GPU."""
+
+    def __init__(self, ctx, sm, ssm=L.SSM_HOMOGRAPHY, resx=50, resy=50, n_targets=1, host_solve=True, **params):
+        self.ctx = ctx
+        self.batch = Batch(ctx, L.AM_SSD, ssm, resx, resy, n_targets)
+        self.B, self.S = n_targets, self.batch.S
+        self.host_solve = host_solve
+        self.sm = sm_desc(sm, **params)
+        if not host_solve and self.sm.leven_marq:
+            raise L.FunctionNotImplemented(-2, "Levenberg-Marquardt needs host_solve=True")
+        self.n_iters = np.zeros(n_targets, dtype=np.int32)
+
+    # nt::*::initialize (NT/ESM.cc:110-146, NT/FCLK.cc:102-169, NT/ICLK.cc:71-128)
+    def initialize(self, corners):
+        self.batch.set_corners(np.asarray(corners, dtype=np.float64).reshape(self.B, 2, 4))
+        self.batch.init_template(self.sm)
+
+    # nt::*::setRegion: resets the SSM to the given corners, the template is kept
+    def set_region(self, corners):
+        self.batch.set_corners(np.asarray(corners, dtype=np.float64).reshape(self.B, 2, 4))
+
+    def get_region(self):
+        return self.batch.get_corners()
+
+    def update(self):
+        if not self.host_solve:
+            self.n_iters, corners = self.batch.track(self.sm)
+            return corners
+        sm, b = self.sm, self.batch
+        B = self.B
+        active = np.ones(B, dtype=bool)
+        prev_f = np.zeros(B)
+        delta = np.full(B, sm.lm_delta_init)
+        last_dp = np.zeros((B, self.S))
+        self.n_iters[:] = 0
+        # the accept/reject state machine of NT/FCLK.cc:193-217 (same in ESM / ICLK), vectorised over targets
+        it = 0
+        state_reset = np.zeros(B, dtype=bool)
+        while it < sm.max_iters and active.any():
+            f, g, H = b.iterate(sm)
+            dps = np.zeros((B, self.S))
+            undo = np.zeros(B, dtype=bool)
+            if sm.leven_marq:
+                for t in range(B):
+                    if not active[t] or state_reset[t]:
+                        continue
+                    if self.n_iters[t] > 0:
+                        if f[t] < prev_f[t]:
+                            delta[t] *= sm.lm_delta_update
+                            undo[t] = True
+                            continue
+                        if f[t] > prev_f[t]:
+                            delta[t] /= sm.lm_delta_update
+                    prev_f[t] = f[t]
+            prev_corners = b.get_corners()
+            for t in range(B):
+                if not active[t]:
+                    continue
+                if undo[t]:
+                    # undo the last update: FCLK / ESM apply the inverse, ICLK re-applies the forward update
+                    dps[t] = last_dp[t] if sm.sm == L.SM_ICLK else b.invert_state(np.tile(last_dp[t], (B, 1)))[0]
+                    continue
+                Ht = H[t].copy()
+                if sm.leven_marq:
+                    Ht[np.diag_indices(self.S)] += delta[t] * np.diag(Ht)
+                dp = _solve(Ht, g[t])
+                last_dp[t] = dp
+                dps[t] = b.invert_state(np.tile(dp, (B, 1)))[0] if sm.sm == L.SM_ICLK else dp
+            b.compositional_update(dps)
+            corners = b.get_corners()
+            change = ((prev_corners - corners) ** 2).reshape(B, -1).sum(axis=1)
+            for t in range(B):
+                if not active[t]:
+                    continue
+                if undo[t]:
+                    state_reset[t] = True
+                    continue
+                state_reset[t] = False
+                self.n_iters[t] += 1
+                if change[t] < sm.epsilon or self.n_iters[t] >= sm.max_iters:
+                    active[t] = False
+            it += 1 if not undo.any() else 0
+            if it == 0 and undo.all():
+                break
+        return b.get_corners()
+
+
+class ParticleFilter:
+    """PF + SSD + Homography/Affine (SM/src/PF.cc): dynamic model RandomWalk, update type Compositional,
+    likelihood function AM, resampling BinaryMultinomial, mean type None (highest weight) or Corners."""
+
+    def __init__(self, ctx, ssm=L.SSM_HOMOGRAPHY, resx=50, resy=50, n_particles=500,
+                 ssm_sigma=(0.01, 0.01, 2.0, 0.01, 0.01, 2.0, 1e-5, 1e-5), likelihood_alpha=1.0,
+                 max_iters=1, epsilon=0.01, seed=0, scorer=None):
+        self.batch = Batch(ctx, L.AM_SSD, ssm, resx, resy, 1, likelihood_alpha=likelihood_alpha)
+        self.S = self.batch.S
+        self.n = n_particles
+        self.sigma = np.asarray(ssm_sigma, dtype=np.float64)[: self.S]
+        self.max_iters, self.epsilon = max_iters, epsilon
+        self.rng = np.random.default_rng(seed)
+        self.scorer = scorer   # optional dist.ShardedScorer
+        self.states = np.zeros((n_particles, self.S))
+        self.wts = np.full(n_particles, 1.0 / n_particles)
+
+    def initialize(self, corners):
+        self.batch.set_corners(np.asarray(corners, dtype=np.float64).reshape(1, 2, 4))
+        self.batch.initialize_pix_vals()
+        self.batch.initialize_similarity()
+        self.states[:] = 0           # PF::initializeParticles PF.cc:166-180
+        self.wts[:] = 1.0 / self.n
+
+    @staticmethod
+    def _warp(ssm, p):
+        if ssm == L.SSM_HOMOGRAPHY:
+            return np.array([[1 + p[0], p[1], p[2]], [p[3], 1 + p[4], p[5]], [p[6], p[7], 1.0]])
+        return np.array([[1 + p[2], p[3], p[0]], [p[4], 1 + p[5], p[1]], [0, 0, 1.0]])
+
+    def _compose(self, base, pert):
+        """compositionalRandomWalk (Homography.cc:916-926, Affine analogue): W(base) * W(pert)"""
+        ssm = self.batch.desc.ssm
+        out = np.empty_like(base)
+        for k in range(base.shape[0]):
+            W = self._warp(ssm, base[k]) @ self._warp(ssm, pert[k])
+            if ssm == L.SSM_HOMOGRAPHY:
+                W = W / W[2, 2]
+                out[k] = [W[0, 0] - 1, W[0, 1], W[0, 2], W[1, 0], W[1, 1] - 1, W[1, 2], W[2, 0], W[2, 1]]
+            else:
+                out[k] = [W[0, 2], W[1, 2], W[0, 0] - 1, W[0, 1], W[1, 0], W[1, 1] - 1]
+        return out
+
+    @staticmethod
+    def binary_multinomial_resample(wts, uniforms):
+        """PF::binaryMultinomialResampling PF.cc:345-394: smallest index whose normalised cumulative
+        weight is >= the uniform draw."""
+        cum = np.cumsum(wts)
+        cum = cum / cum[-1]
+        return np.minimum(np.searchsorted(cum, uniforms, side="left"), len(wts) - 1)
+
+    def update(self):
+        prev = self.batch.get_corners()
+        for _ in range(self.max_iters):
+            pert = self.rng.normal(0.0, 1.0, size=(self.n, self.S)) * self.sigma
+            self.states = self._compose(self.states, pert)
+            if self.scorer is not None:
+                w = self.scorer.score(self.states)
+                self.wts = w.cpu().numpy() if hasattr(w, "cpu") else np.asarray(w)
+            else:
+                self.wts = self.batch.score_candidates(self.states)
+            max_id = int(np.argmax(self.wts))
+            ids = self.binary_multinomial_resample(self.wts, self.rng.uniform(0.0, 1.0, self.n))
+            best = self.states[max_id].copy()
+            self.states = self.states[ids]
+            self.batch.set_state(best[None])          # MeanType::None: highest weighted particle
+            cur = self.batch.get_corners()
+            if ((prev - cur) ** 2).sum() < self.epsilon:
+                break
+            prev = cur
+        return self.batch.get_corners()

@@ -1,0 +1,97 @@
+#!/usr/bin/env python
+"""Generates tests/golden/lk_golden.npz from the independent NumPy re-derivation (oracle/numpy_ref.py).
+
+The reference cannot run here (Eigen / OpenCV / Boost absent) and ships no golden vectors, so these
+fixtures come from a second, independently written float64 implementation of the maths; they pin
+the C++ oracle (tests/test_oracle_golden.py), which in turn is the checker for the HIP path.
+PARITY UNPINNED with respect to the reference itself.
+
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy_ref as R  # noqa: E402
+from mtf_amd import synth  # noqa: E402
+
+SEED = 424242
+IMG_SEED = 99
+IMG_SHAPE = (192, 192)
+
+
+def main():
+    rng = np.random.default_rng(SEED)
+    img = synth.make_frame(*IMG_SHAPE, seed=IMG_SEED)
+    out = {"img_seed": IMG_SEED, "img_shape": np.array(IMG_SHAPE)}
+
+    # --- raw sampling / gradient at assorted points, incl. border and integer coordinates
+    xs = np.array([-2.0, -1e-9, 0.0, 0.25, 10.0, 10.0 + 1e-8, 190.0, 191.0, 191.5, 195.0, 37.25, 64.0, 100.5, 17.125])
+    ys = np.array([5.0, 5.0, 0.0, 0.0, 20.0, 20.0, 30.0, 30.0, 12.0, 7.0, 191.0, 64.0, 33.75, 190.999])
+    out["pts"] = np.stack([xs, ys])
+    out["pix_vals"] = R.bilinear(img, xs, ys)
+    out["img_grad"] = R.img_grad(img, out["pts"])
+
+    # --- homography + SSD, chained warp: config-1 shape (reduced) and a non-rectangular region
+    for tag, res, corners in (
+        ("sq", 24, synth.square_corners(96, 96, 72)),
+        ("quad", 20, synth.square_corners(96, 90, 60) + rng.uniform(-3, 3, size=(2, 4))),
+    ):
+        init_pts, init_hm = R.grid_from_corners(corners, res, res)
+        I0 = R.bilinear(img, init_pts[0], init_pts[1])
+        W0 = np.eye(3)
+        g0 = R.img_grad(img, init_pts)
+        J0 = R.sd_rows_chained(g0, R.hom_spatial_jacobian(W0, init_pts, init_hm[2]),
+                               R.hom_param_jacobian(init_pts[0], init_pts[1]))
+        p = synth.random_small_homography(rng, 0.5)
+        W = R.hom_matrix(p)
+        fc = R.lk_step_hom_ssd(img, init_pts, init_hm, W, I0, mode="fclk")
+        es = R.lk_step_hom_ssd(img, init_pts, init_hm, W, I0, J0=J0, mode="esm")
+        out.update({
+            tag + "_res": res, tag + "_corners": corners, tag + "_p": p,
+            tag + "_init_pts_head": init_pts[:, :16], tag + "_I0_head": I0[:16], tag + "_J0_head": J0[:16],
+            tag + "_It_head": fc["It"][:16], tag + "_grad_head": fc["grad"][:16], tag + "_Jt_head": fc["Jt"][:16],
+            tag + "_f": fc["f"], tag + "_fclk_g": fc["g"], tag + "_fclk_H": fc["H"], tag + "_fclk_dp": fc["dp"],
+            tag + "_esm_g": es["g"], tag + "_esm_H": es["H"], tag + "_esm_dp": es["dp"],
+        })
+
+    # --- affine + NCC (config-3 patch shape)
+    res = 25
+    corners = synth.square_corners(100, 80, 25)
+    init_pts, init_hm = R.grid_from_corners(corners, res, res, affine=True)
+    I0 = R.bilinear(img, init_pts[0], init_pts[1])
+    g0 = R.img_grad(img, init_pts)
+    J0 = R.sd_rows_direct(g0, R.aff_param_jacobian(init_pts[0], init_pts[1]))  # warp = identity
+    pa = rng.uniform(-1, 1, 6) * [1.5, 1.5, 0.02, 0.02, 0.02, 0.02]
+    A = R.aff_matrix(pa)
+    wpts = (A @ np.vstack([init_pts, np.ones(init_pts.shape[1])]))[:2]
+    It = R.bilinear(img, wpts[0], wpts[1])
+    m = R.ncc(I0, It)
+    out.update({"ncc_corners": corners, "ncc_p": pa, "ncc_f": m["f"], "ncc_df_dIt_head": m["df_dIt"][:16],
+                "ncc_df_dI0_head": m["df_dI0"][:16], "ncc_g_init": m["df_dI0"] @ J0,
+                "ncc_H_self_J0": R.ncc_self_hessian(J0, m), "ncc_J0_head": J0[:16]})
+
+    # --- PF scores for 32 candidates (config 4 shape, reduced)
+    res = 20
+    corners = synth.square_corners(90, 100, 60)
+    init_pts, init_hm = R.grid_from_corners(corners, res, res)
+    I0 = R.bilinear(img, init_pts[0], init_pts[1])
+    states = synth.pf_candidate_states(rng, 32)
+    lik = []
+    for s in states:
+        wp, _ = R.warp_pts(R.hom_matrix(s), init_hm)
+        r = R.bilinear(img, wp[0], wp[1]) - I0
+        lik.append(np.exp(-1.0 * np.sqrt(0.5 * float(r @ r) / I0.size)))
+    out.update({"pf_corners": corners, "pf_states": states, "pf_likelihood": np.array(lik)})
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lk_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,70 @@
+"""CPU: the N > 1 candidate-sharding path with world_size-2 gloo process groups (the scoring kernel is
+replaced by an injected function; the partition + the single all-gather are what is under test)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mtf_amd import dist as mdist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_cover_everything_once():
+    for n in (0, 1, 7, 8, 9, 10000, 10001):
+        for w in (1, 2, 3, 8):
+            b = [mdist.shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1 and sizes == mdist.shard_sizes(n, w)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_cand, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(0)           # identical candidates on every rank
+        states = rng.normal(size=(n_cand, 8))
+        fn = lambda s: np.exp(-np.abs(s).sum(axis=1))   # noqa: E731  stands in for the HIP scorer
+        scorer = mdist.ShardedScorer(score_fn=fn)
+        got = scorer.score(states).numpy()
+        q.put((rank, np.allclose(got, fn(states), rtol=0, atol=0), got.shape[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_cand", [64, 101])
+def test_sharded_scoring_allgather_world2(n_cand):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_cand, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(ok and n == n_cand for _, ok, n in res)
+
+
+def test_binary_multinomial_resampling_matches_oracle(oracle):
+    from mtf_amd.sm import ParticleFilter
+    rng = np.random.default_rng(4)
+    w = rng.uniform(0, 1, 200)
+    u = rng.uniform(0, 1, 200)
+    ids_o, _ = oracle.pf_binary_multinomial_resample(w, u)
+    assert np.array_equal(ParticleFilter.binary_multinomial_resample(w, u), ids_o)

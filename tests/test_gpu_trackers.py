@@ -1,0 +1,86 @@
+"""GPU: the search-method drivers (mtf_amd/sm.py) end to end -- the callers of the hot path."""
+import numpy as np
+import pytest
+
+import mtf_amd
+from mtf_amd import _lib as L
+from mtf_amd import synth
+from mtf_amd.sm import LKTracker, ParticleFilter
+
+pytestmark = pytest.mark.gpu
+
+
+def gt_corners(corners, p_true, centre):
+    W = synth.homography_from_state(p_true)
+    q = W @ np.vstack([corners - np.array(centre)[:, None], np.ones(4)])
+    return q[:2] / q[2] + np.array(centre)[:, None]
+
+
+@pytest.mark.parametrize("host_solve", [True, False])
+@pytest.mark.parametrize("sm", [L.SM_ESM, L.SM_FCLK, L.SM_ICLK])
+def test_lk_trackers_recover_known_warp(gpu_ctx, frame, sm, host_solve):
+    rng = np.random.default_rng(7)
+    centre = (256.0, 250.0)
+    corners = synth.square_corners(centre[0], centre[1], 90)
+    p_true = synth.random_small_homography(rng, 0.4)
+    frame2 = synth.warp_frame(frame, p_true, centre)
+    gpu_ctx.set_image(frame)
+    trk = LKTracker(gpu_ctx, sm, L.SSM_HOMOGRAPHY, 45, 45, 1, host_solve=host_solve, max_iters=40, epsilon=1e-6,
+                    materialize=0)
+    trk.initialize(corners[None])
+    gpu_ctx.set_image(frame2)
+    out = trk.update()
+    assert np.abs(out[0] - gt_corners(corners, p_true, centre)).max() < 0.08
+    assert 2 <= int(trk.n_iters[0]) <= 40
+
+
+def test_lm_host_loop_matches_oracle(oracle, gpu_ctx, frame):
+    """Levenberg-Marquardt accept / reject on the host with device f, g, H: same corners and iteration
+    count as the oracle's nt::FCLK with leven_marq = 1 on a motion large enough to trigger rejections."""
+    centre = (256.0, 250.0)
+    corners = synth.square_corners(centre[0], centre[1], 100)
+    p_true = np.array([0.01, -0.01, 6.0, 0.01, 0.0, -5.0, 0, 0])
+    frame2 = synth.warp_frame(frame, p_true, centre)
+    for sm in (L.SM_FCLK, L.SM_ESM, L.SM_ICLK):
+        o_ssm = oracle.SSM(0, 40, 40); o_am = oracle.AM(0, 40, 40); o_am.set_curr_img(frame)
+        otrk = oracle.Tracker(sm, o_am, o_ssm, leven_marq=1, max_iters=60, epsilon=1e-8)
+        otrk.initialize(corners)
+        o_am.set_curr_img(frame2)
+        otrk.update()
+        gpu_ctx.set_image(frame)
+        trk = LKTracker(gpu_ctx, sm, L.SSM_HOMOGRAPHY, 40, 40, 1, host_solve=True, leven_marq=1, max_iters=60,
+                        epsilon=1e-8, materialize=0)
+        trk.initialize(corners[None])
+        gpu_ctx.set_image(frame2)
+        out = trk.update()
+        np.testing.assert_allclose(out[0], otrk.get_region(), atol=5e-4)
+        assert np.abs(out[0] - gt_corners(corners, p_true, centre)).max() < 0.1
+
+
+def test_particle_filter_follows_translation(gpu_ctx, frame):
+    centre = (256.0, 250.0)
+    corners = synth.square_corners(centre[0], centre[1], 80)
+    p_true = np.array([0, 0, 3.0, 0, 0, -2.0, 0, 0])
+    frame2 = synth.warp_frame(frame, p_true, centre)
+    gpu_ctx.set_image(frame)
+    pf = ParticleFilter(gpu_ctx, L.SSM_HOMOGRAPHY, 40, 40, n_particles=4000, max_iters=4, epsilon=1e-9, seed=3,
+                        ssm_sigma=(0.002, 0.002, 1.5, 0.002, 0.002, 1.5, 1e-6, 1e-6), likelihood_alpha=5.0)
+    pf.initialize(corners[None])
+    gpu_ctx.set_image(frame2)
+    out = pf.update()
+    assert np.abs(out[0] - gt_corners(corners, p_true, centre)).max() < 1.0
+
+
+def test_sharded_scorer_single_rank_uses_hip(gpu_ctx, frame, oracle):
+    import torch
+    from mtf_amd.dist import ShardedScorer
+    rng = np.random.default_rng(31)
+    corners = synth.square_corners(256, 256, 100)
+    gpu_ctx.set_image(frame)
+    b = mtf_amd.Batch(gpu_ctx, L.AM_SSD, L.SSM_HOMOGRAPHY, 50, 50, 1)
+    b.set_corners(corners[None]); b.initialize_pix_vals(); b.initialize_similarity()
+    states = synth.pf_candidate_states(rng, 257)
+    sc = ShardedScorer(batch=b, device=torch.device("cuda", 0))
+    lik = sc.score(states)
+    gpu_ctx.synchronize(); torch.cuda.synchronize()
+    np.testing.assert_allclose(lik.cpu().numpy(), b.score_candidates(states), rtol=1e-14)
