@@ -96,6 +96,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("libmtfhip.so is missing (%s); build it with `python -c 'import __graft_entry__ as g; "
                               "g.build()'` -- there is no CPU fallback" % LIB_PATH)
+        try:
+            # PyTorch-ROCm bundles its own libamdhip64 (SONAME libamdhip64.so.7, requested by torch as the
+            # unversioned name): loaded first, it also satisfies libmtfhip's libamdhip64.so.7 dependency and the
+            # process ends up with ONE HIP runtime.  The other order loads two runtimes that fight over the device.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.mtfhip_last_error.restype = C.c_char_p
         L.mtfhip_ctx_stream.restype = C.c_void_p

@@ -177,7 +177,7 @@ struct TargetHost {
 	double init_corners_hm[12];
 	double f;
 	/* NCC scalars (AM/src/NCC.cc members) */
-	double I0_mean, It_mean, a, b, c;
+	double I0_mean, It_mean, a, b, c, gmean;
 	double h0[64]; /* constant self Hessian of the template (column-major), set by init_template */
 };
 
@@ -191,6 +191,7 @@ struct mtfhip_batch {
 	double *d_warps = nullptr, *d_states = nullptr;
 	double *d_partials = nullptr, *d_acc = nullptr, *d_scratch_pts = nullptr, *d_w0 = nullptr;
 	double *d_h0 = nullptr, *d_corners = nullptr, *d_init_corners_hm = nullptr, *d_cand = nullptr;
+	double *d_ncc = nullptr, *d_colmean = nullptr; /* [B][8] NCC scalars / column means */
 	size_t cand_capacity = 0;
 	int *d_active = nullptr, *d_iters = nullptr;
 	double *h_acc = nullptr; /* pinned */
@@ -384,6 +385,8 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 	ALLOC(b->d_h0, sizeof(double) * 64 * n_targets);
 	ALLOC(b->d_corners, sizeof(double) * 8 * n_targets);
 	ALLOC(b->d_init_corners_hm, sizeof(double) * 12 * n_targets);
+	ALLOC(b->d_ncc, sizeof(double) * 8 * n_targets);
+	ALLOC(b->d_colmean, sizeof(double) * 8 * n_targets);
 	ALLOC(b->d_active, sizeof(int) * n_targets);
 	ALLOC(b->d_iters, sizeof(int) * n_targets);
 #undef ALLOC
@@ -403,7 +406,7 @@ void mtfhip_batch_destroy(mtfhip_batch *b) {
 	for (int i = 0; i < MTFHIP_BUF_COUNT; ++i)
 		if (b->buf[i]) (void)hipFree(b->buf[i]);
 	void *ptrs[] = {b->d_warps, b->d_states, b->d_partials, b->d_acc, b->d_scratch_pts, b->d_w0, b->d_h0, b->d_corners,
-		b->d_init_corners_hm, b->d_active, b->d_iters, b->d_cand};
+		b->d_init_corners_hm, b->d_active, b->d_iters, b->d_cand, b->d_ncc, b->d_colmean};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (b->h_acc) (void)hipHostFree(b->h_acc);
@@ -661,15 +664,136 @@ int mtfhip_am_update_pix_grad_warped(mtfhip_batch *b, const double *gp) {
 	return pix_grad_common(b, gp, true, false);
 }
 
+
+/* ------------------------------------------------------------------ NCC (AM/src/NCC.cc) */
+static int push_ncc(mtfhip_batch *b) {
+	std::vector<double> s(8 * (size_t)b->B, 0.0);
+	for (int t = 0; t < b->B; ++t) {
+		const TargetHost &h = b->th[t];
+		double *p = &s[8 * t];
+		p[0] = h.I0_mean; p[1] = h.c; p[2] = h.It_mean; p[3] = h.b; p[4] = h.f; p[5] = h.gmean;
+	}
+	HIP_TRY(hipMemcpyAsync(b->d_ncc, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice, b->ctx->stream));
+	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	return MTFHIP_OK;
+}
+static int ncc_mean_of(mtfhip_batch *b, int buf, double TargetHost::*dst) {
+	int nblk = simple_blocks_per_target(b->N);
+	{
+		TimedScope ts(b->ctx, "ncc_stats");
+		launch_vec_sum(b->view(), b->buf[buf], b->d_partials, nblk, b->ctx->stream);
+	}
+	TRY(read_acc(b, nblk));
+	for (int t = 0; t < b->B; ++t) b->th[t].*dst = b->h_acc[(size_t)t * ACC_COUNT + ACC_RR] / (double)b->N;
+	return MTFHIP_OK;
+}
+/* NCC::initializeSimilarity NCC.cc:55-95 */
+static int ncc_initialize_similarity(mtfhip_batch *b) {
+	TRY(ncc_mean_of(b, MTFHIP_BUF_I0, &TargetHost::I0_mean));
+	if (!b->init_sim)
+		for (auto &h : b->th) h.It_mean = h.I0_mean;
+	TRY(push_ncc(b));
+	int nblk = simple_blocks_per_target(b->N);
+	{
+		TimedScope ts(b->ctx, "ncc_stats");
+		launch_ncc_centered(b->view(), b->d_ncc, b->d_partials, nblk, b->ctx->stream);
+	}
+	TRY(read_acc(b, nblk));
+	for (int t = 0; t < b->B; ++t) {
+		TargetHost &h = b->th[t];
+		h.c = std::sqrt(b->h_acc[(size_t)t * ACC_COUNT + ACC_G + 2]);
+		if (!b->init_sim) { h.f = 1; h.b = h.c; }
+	}
+	b->init_sim = true;
+	return push_ncc(b);
+}
+/* NCC::updateSimilarity NCC.cc:124-161 */
+static int ncc_update_similarity(mtfhip_batch *b) {
+	TRY(ncc_mean_of(b, MTFHIP_BUF_IT, &TargetHost::It_mean));
+	TRY(push_ncc(b));
+	int nblk = simple_blocks_per_target(b->N);
+	{
+		TimedScope ts(b->ctx, "ncc_stats");
+		launch_ncc_centered(b->view(), b->d_ncc, b->d_partials, nblk, b->ctx->stream);
+	}
+	TRY(read_acc(b, nblk));
+	for (int t = 0; t < b->B; ++t) {
+		TargetHost &h = b->th[t];
+		h.a = b->h_acc[(size_t)t * ACC_COUNT + ACC_G + 0];
+		h.b = std::sqrt(b->h_acc[(size_t)t * ACC_COUNT + ACC_G + 1]);
+		double bc = h.b * h.c;
+		h.f = h.a / bc;
+	}
+	return push_ncc(b);
+}
+/* NCC::updateCurrGrad / updateInitGrad NCC.cc:163-234 */
+static int ncc_update_grad(mtfhip_batch *b, int curr) {
+	int nblk = simple_blocks_per_target(b->N);
+	double *dst = b->buf[curr ? MTFHIP_BUF_DF_DIT : MTFHIP_BUF_DF_DI0];
+	{
+		TimedScope ts(b->ctx, "ncc_grad");
+		launch_ncc_grad(b->view(), b->d_ncc, curr, dst, b->d_partials, nblk, b->ctx->stream);
+	}
+	TRY(read_acc(b, nblk));
+	for (int t = 0; t < b->B; ++t) b->th[t].gmean = b->h_acc[(size_t)t * ACC_COUNT + ACC_RR] / (double)b->N;
+	TRY(push_ncc(b));
+	TimedScope ts(b->ctx, "ncc_grad");
+	launch_sub_mean(b->view(), dst, b->d_ncc, b->ctx->stream);
+	return MTFHIP_OK;
+}
+/* NCC::cmptInitHessian / cmptCurrHessian / cmptSelfHessian NCC.cc:282-389 (fast_hess = 0);
+ * kind 0 init, 1 curr, 2 self.  H is column-major S x S per target. */
+static int ncc_hessian(mtfhip_batch *b, int j_buf, int kind, double *H) {
+	const int S = b->S;
+	int nblk = simple_blocks_per_target(b->N);
+	{
+		TimedScope ts(b->ctx, "ncc_hess");
+		launch_col_sum(b->view(), b->buf[j_buf], b->d_partials, nblk, b->ctx->stream);
+	}
+	TRY(read_acc(b, nblk));
+	std::vector<double> cm(8 * (size_t)b->B, 0.0);
+	for (int t = 0; t < b->B; ++t)
+		for (int s = 0; s < S; ++s) cm[8 * t + s] = b->h_acc[(size_t)t * ACC_COUNT + ACC_G + s] / (double)b->N;
+	HIP_TRY(hipMemcpyAsync(b->d_colmean, cm.data(), sizeof(double) * cm.size(), hipMemcpyHostToDevice, b->ctx->stream));
+	TRY(push_ncc(b));
+	{
+		TimedScope ts(b->ctx, "ncc_hess");
+		launch_ncc_hess(b->view(), b->d_ncc, b->d_colmean, b->buf[j_buf], b->d_partials, nblk, b->ctx->stream);
+	}
+	TRY(read_acc(b, nblk));
+	for (int t = 0; t < b->B; ++t) {
+		const double *acc = b->h_acc + (size_t)t * ACC_COUNT;
+		const double f = b->th[t].f;
+		double *Ht = H + (size_t)t * S * S;
+		int k = 0;
+		for (int r = 0; r < 8; ++r)
+			for (int c = r; c < 8; ++c) {
+				if (r < S && c < S) {
+					const double G = acc[ACC_H + k];
+					const double ut_r = acc[ACC_G + r], ut_c = acc[ACC_G + c];
+					const double u0_r = acc[ACC_G2 + r], u0_c = acc[ACC_G2 + c];
+					double v;
+					if (kind == 0) v = -f * G - ut_r * u0_c - u0_r * ut_c + 3 * u0_r * u0_c;
+					else if (kind == 1) v = -f * G - ut_r * u0_c - u0_r * ut_c + 3 * ut_r * ut_c;
+					else v = -G + ut_r * ut_c;
+					Ht[c * S + r] = v; Ht[r * S + c] = v;
+				}
+				++k;
+			}
+	}
+	return MTFHIP_OK;
+}
+
 /* ------------------------------------------------------------------ AppearanceModel */
 static int am_supported(mtfhip_batch *b, const char *fn) {
-	if (b->desc.am == MTFHIP_AM_SSD) return MTFHIP_OK;
+	if (b->desc.am == MTFHIP_AM_SSD || b->desc.am == MTFHIP_AM_NCC) return MTFHIP_OK;
 	return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s :: appearance model %d is not available on the device path yet", fn, b->desc.am);
 }
 
 int mtfhip_am_initialize_similarity(mtfhip_batch *b) {
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "initialize_similarity: NULL batch");
 	TRY(am_supported(b, "initializeSimilarity"));
+	if (b->desc.am == MTFHIP_AM_NCC) return ncc_initialize_similarity(b);
 	if (b->init_sim) return MTFHIP_OK;
 	HIP_TRY(hipMemsetAsync(b->buf[MTFHIP_BUF_DF_DI0], 0, sizeof(double) * b->N * b->B, b->ctx->stream));
 	for (auto &h : b->th) h.f = 0;
@@ -679,6 +803,15 @@ int mtfhip_am_initialize_similarity(mtfhip_batch *b) {
 int mtfhip_am_initialize_grad(mtfhip_batch *b) {
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "initialize_grad: NULL batch");
 	TRY(am_supported(b, "initializeGrad"));
+	if (b->desc.am == MTFHIP_AM_NCC) {
+		/* NCC::initializeGrad NCC.cc:97-122: gradient vectors start at zero */
+		if (!b->init_grad) {
+			HIP_TRY(hipMemsetAsync(b->buf[MTFHIP_BUF_DF_DI0], 0, sizeof(double) * b->N * b->B, b->ctx->stream));
+			HIP_TRY(hipMemsetAsync(b->buf[MTFHIP_BUF_DF_DIT], 0, sizeof(double) * b->N * b->B, b->ctx->stream));
+			b->init_grad = true;
+		}
+		return MTFHIP_OK;
+	}
 	if (b->init_grad) return MTFHIP_OK;
 	HIP_TRY(hipMemcpyAsync(b->buf[MTFHIP_BUF_DF_DIT], b->buf[MTFHIP_BUF_DF_DI0], sizeof(double) * b->N * b->B, hipMemcpyDeviceToDevice, b->ctx->stream));
 	b->init_grad = true;
@@ -692,6 +825,7 @@ int mtfhip_am_update_similarity(mtfhip_batch *b, int prereq_only) {
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_similarity: NULL batch");
 	TRY(am_supported(b, "updateSimilarity"));
 	if (!b->init_sim) return fail(MTFHIP_ERR_LOGIC, "updateSimilarity before initializeSimilarity");
+	if (b->desc.am == MTFHIP_AM_NCC) return ncc_update_similarity(b);
 	int nblk = simple_blocks_per_target(b->N);
 	{
 		TimedScope ts(b->ctx, "ssd_residual");
@@ -705,13 +839,16 @@ int mtfhip_am_update_similarity(mtfhip_batch *b, int prereq_only) {
 int mtfhip_am_update_curr_grad(mtfhip_batch *b) {
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_curr_grad: NULL batch");
 	TRY(am_supported(b, "updateCurrGrad"));
+	if (b->desc.am == MTFHIP_AM_NCC) return ncc_update_grad(b, 1);
 	TimedScope ts(b->ctx, "negate");
 	launch_negate(b->buf[MTFHIP_BUF_DF_DI0], b->buf[MTFHIP_BUF_DF_DIT], (size_t)b->N * b->B, b->ctx->stream);
 	return MTFHIP_OK;
 }
 int mtfhip_am_update_init_grad(mtfhip_batch *b) {
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_init_grad: NULL batch");
-	return am_supported(b, "updateInitGrad");
+	TRY(am_supported(b, "updateInitGrad"));
+	if (b->desc.am == MTFHIP_AM_NCC) return ncc_update_grad(b, 0);
+	return MTFHIP_OK;
 }
 int mtfhip_am_get_similarity(mtfhip_batch *b, double *f) {
 	if (!b || !f) return fail(MTFHIP_ERR_INVALID_ARG, "get_similarity: NULL argument");
@@ -766,6 +903,8 @@ int mtfhip_am_cmpt_difference_of_jacobians(mtfhip_batch *b, int j0_buf, int jt_b
 	TRY(am_supported(b, "cmptDifferenceOfJacobians"));
 	TRY(j_ready(b, j0_buf, "cmptDifferenceOfJacobians"));
 	TRY(j_ready(b, jt_buf, "cmptDifferenceOfJacobians"));
+	if (b->desc.am != MTFHIP_AM_SSD) /* (df_dIt * dIt_dp) - (df_dI0 * dI0_dp), NCC.cc:268-280, AppearanceModel.h:161-164 */
+		return gemv_to_host(b, b->buf[MTFHIP_BUF_DF_DIT], jt_buf, b->buf[MTFHIP_BUF_DF_DI0], j0_buf, 0, g, 1);
 	/* SSD: df_dIt * (dI0_dpssm + dIt_dpssm), SSDBase.cc:186 */
 	return gemv_to_host(b, b->buf[MTFHIP_BUF_DF_DIT], jt_buf, nullptr, j0_buf, 1, g, 0);
 }
@@ -796,18 +935,21 @@ int mtfhip_am_cmpt_init_hessian(mtfhip_batch *b, int j0_buf, double *H) {
 	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_init_hessian: NULL argument");
 	TRY(am_supported(b, "cmptInitHessian"));
 	TRY(j_ready(b, j0_buf, "cmptInitHessian"));
+	if (b->desc.am == MTFHIP_AM_NCC) return ncc_hessian(b, j0_buf, 0, H);
 	return gram_to_host(b, j0_buf, H, -1.0, false);
 }
 int mtfhip_am_cmpt_curr_hessian(mtfhip_batch *b, int jt_buf, double *H) {
 	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_curr_hessian: NULL argument");
 	TRY(am_supported(b, "cmptCurrHessian"));
 	TRY(j_ready(b, jt_buf, "cmptCurrHessian"));
+	if (b->desc.am == MTFHIP_AM_NCC) return ncc_hessian(b, jt_buf, 1, H);
 	return gram_to_host(b, jt_buf, H, -1.0, false);
 }
 int mtfhip_am_cmpt_self_hessian(mtfhip_batch *b, int jt_buf, double *H) {
 	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_self_hessian: NULL argument");
 	TRY(am_supported(b, "cmptSelfHessian"));
 	TRY(j_ready(b, jt_buf, "cmptSelfHessian"));
+	if (b->desc.am == MTFHIP_AM_NCC) return ncc_hessian(b, jt_buf, 2, H);
 	return gram_to_host(b, jt_buf, H, -1.0, false);
 }
 int mtfhip_am_cmpt_sum_of_hessians(mtfhip_batch *b, int j0_buf, int jt_buf, double *H) {
@@ -815,6 +957,14 @@ int mtfhip_am_cmpt_sum_of_hessians(mtfhip_batch *b, int j0_buf, int jt_buf, doub
 	TRY(am_supported(b, "cmptSumOfHessians"));
 	TRY(j_ready(b, j0_buf, "cmptSumOfHessians"));
 	TRY(j_ready(b, jt_buf, "cmptSumOfHessians"));
+	if (b->desc.am == MTFHIP_AM_NCC) {
+		/* generic AppearanceModel::cmptSumOfHessians AppearanceModel.h:196-208 */
+		std::vector<double> H0((size_t)b->B * b->S * b->S);
+		TRY(ncc_hessian(b, j0_buf, 0, H0.data()));
+		TRY(ncc_hessian(b, jt_buf, 1, H));
+		for (size_t i = 0; i < H0.size(); ++i) H[i] += H0[i];
+		return MTFHIP_OK;
+	}
 	TRY(gram_to_host(b, j0_buf, H, -1.0, false));
 	return gram_to_host(b, jt_buf, H, -1.0, true);
 }

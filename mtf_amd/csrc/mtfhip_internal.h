@@ -75,6 +75,14 @@ void launch_gemv(const BatchView &bv, const double *v1, const double *J1, const 
 	int sum_mode, double *partials, int nblk, hipStream_t st);
 /* H-type partials: sum_i J[i,a] J[i,b] */
 void launch_gram(const BatchView &bv, const double *J, double *partials, int nblk, hipStream_t st);
+/* NCC pieces (see the kernel comments); `sc` is the [B][8] per-target scalar block */
+void launch_vec_sum(const BatchView &bv, const double *v, double *partials, int nblk, hipStream_t st);
+void launch_ncc_centered(const BatchView &bv, const double *sc, double *partials, int nblk, hipStream_t st);
+void launch_ncc_grad(const BatchView &bv, const double *sc, int curr, double *out, double *partials, int nblk, hipStream_t st);
+void launch_sub_mean(const BatchView &bv, double *v, const double *sc, hipStream_t st);
+void launch_col_sum(const BatchView &bv, const double *J, double *partials, int nblk, hipStream_t st);
+void launch_ncc_hess(const BatchView &bv, const double *sc, const double *colmean, const double *J, double *partials,
+	int nblk, hipStream_t st);
 /* sums partials over blocks: out[B][ACC_COUNT] */
 void launch_finish(double *partials, int nblk, double *out, int B, hipStream_t st);
 /* the fused LK iteration for SSD */

@@ -486,6 +486,114 @@ __global__ __launch_bounds__(kBlock) void k_gram(int N, int S, const double *J_a
 	block_reduce_store<36>(acc, partials + ((size_t)t * nblk + blockIdx.x) * ACC_COUNT + ACC_H, lds);
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * NCC (AM/src/NCC.cc).  Per-target scalars live in `sc` ([B][8]): 0 I0_mean, 1 c, 2 It_mean, 3 b, 4 f,
+ * 5 mean of the un-centred gradient vector being built.  The centred / normalised vectors the reference
+ * stores (I0_cntr, It_cntr, I0_cntr_c, It_cntr_b) are recomputed from I0, It and these scalars.
+ * ------------------------------------------------------------------------------------------- */
+enum { NCC_I0_MEAN = 0, NCC_C = 1, NCC_IT_MEAN = 2, NCC_B = 3, NCC_F = 4, NCC_GMEAN = 5, NCC_SC = 8 };
+
+/* sum of a vector (means: NCC.cc:76,141) -> ACC_RR */
+__global__ __launch_bounds__(kBlock) void k_vec_sum(int N, const double *v_all, double *partials, int nblk) {
+	__shared__ double lds[4];
+	const int t = blockIdx.y;
+	const double *v = v_all + (size_t)t * N;
+	double acc[1] = {0.0};
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += nblk * kBlock) acc[0] += v[i];
+	block_reduce_store<1>(acc, partials + ((size_t)t * nblk + blockIdx.x) * ACC_COUNT + ACC_RR, lds);
+}
+/* a = sum I0c*Itc, b^2 = sum Itc^2, c^2 = sum I0c^2 (NCC.cc:77-78,142-144) -> ACC_G[0..2] */
+__global__ __launch_bounds__(kBlock) void k_ncc_centered(BatchView bv, const double *sc_all, double *partials, int nblk) {
+	__shared__ double lds[4 * 4];
+	__shared__ double outv[4];
+	const int t = blockIdx.y, N = bv.N;
+	const double *I0 = bv.buf[MTFHIP_BUF_I0] + (size_t)t * N, *It = bv.buf[MTFHIP_BUF_IT] + (size_t)t * N;
+	const double m0 = sc_all[t * NCC_SC + NCC_I0_MEAN], mt = sc_all[t * NCC_SC + NCC_IT_MEAN];
+	double acc[4] = {0, 0, 0, 0};
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += nblk * kBlock) {
+		const double a0 = I0[i] - m0, at = It[i] - mt;
+		acc[0] = fma(a0, at, acc[0]); acc[1] = fma(at, at, acc[1]); acc[2] = fma(a0, a0, acc[2]);
+	}
+	block_reduce_store<4>(acc, outv, lds);
+	__syncthreads();
+	if (threadIdx.x < 3) partials[((size_t)t * nblk + blockIdx.x) * ACC_COUNT + ACC_G + threadIdx.x] = outv[threadIdx.x];
+}
+/* un-centred gradient vectors of NCC::updateCurrGrad / updateInitGrad (NCC.cc:163-234) + their sum:
+ * curr: (I0c/c - f*Itc/b)/b    init: (Itc/b - f*I0c/c)/c */
+__global__ __launch_bounds__(kBlock) void k_ncc_grad(BatchView bv, const double *sc_all, int curr, double *out_all,
+	double *partials, int nblk) {
+	__shared__ double lds[4];
+	const int t = blockIdx.y, N = bv.N;
+	const double *I0 = bv.buf[MTFHIP_BUF_I0] + (size_t)t * N, *It = bv.buf[MTFHIP_BUF_IT] + (size_t)t * N;
+	double *out = out_all + (size_t)t * N;
+	const double *sc = sc_all + t * NCC_SC;
+	const double m0 = sc[NCC_I0_MEAN], c = sc[NCC_C], mt = sc[NCC_IT_MEAN], b = sc[NCC_B], f = sc[NCC_F];
+	double acc[1] = {0.0};
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += nblk * kBlock) {
+		const double i0c_c = (I0[i] - m0) / c, itc_b = (It[i] - mt) / b;
+		const double v = curr ? (i0c_c - f * itc_b) / b : (itc_b - f * i0c_c) / c;
+		out[i] = v;
+		acc[0] += v;
+	}
+	block_reduce_store<1>(acc, partials + ((size_t)t * nblk + blockIdx.x) * ACC_COUNT + ACC_RR, lds);
+}
+/* v -= mean (df_dI = df_dI_ncntr - mean, NCC.cc:191,231) */
+__global__ __launch_bounds__(kBlock) void k_sub_mean(int N, double *v_all, const double *sc_all) {
+	const int t = blockIdx.y;
+	double *v = v_all + (size_t)t * N;
+	const double m = sc_all[t * NCC_SC + NCC_GMEAN];
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) v[i] -= m;
+}
+/* column sums of a pixel Jacobian (dI_dp.colwise().mean(), NCC.cc:290,322,363) -> ACC_G */
+__global__ __launch_bounds__(kBlock) void k_col_sum(int N, int S, const double *J_all, double *partials, int nblk) {
+	__shared__ double lds[4 * 8];
+	__shared__ double outv[8];
+	const int t = blockIdx.y;
+	const double *J = J_all + (size_t)t * N * S;
+	double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += nblk * kBlock) {
+#pragma unroll
+		for (int s = 0; s < kMaxS; ++s)
+			if (s < S) acc[s] += J[(size_t)s * N + i];
+	}
+	block_reduce_store<8>(acc, outv, lds);
+	__syncthreads();
+	if (threadIdx.x < 8) partials[((size_t)t * nblk + blockIdx.x) * ACC_COUNT + ACC_G + threadIdx.x] = outv[threadIdx.x];
+}
+/* NCC Hessian pieces with Jc = (J - colmean)/b (NCC.cc:290-299, 322-331, 363-382):
+ * ACC_H <- sum Jc_a Jc_b,  ACC_G <- Jc^T It_cntr_b,  ACC_G2 <- Jc^T I0_cntr_c */
+__global__ __launch_bounds__(kBlock) void k_ncc_hess(BatchView bv, const double *sc_all, const double *colmean_all,
+	const double *J_all, double *partials, int nblk) {
+	__shared__ double lds[4 * 52];
+	__shared__ double outv[52];
+	const int t = blockIdx.y, N = bv.N, S = bv.S;
+	const double *J = J_all + (size_t)t * N * S;
+	const double *I0 = bv.buf[MTFHIP_BUF_I0] + (size_t)t * N, *It = bv.buf[MTFHIP_BUF_IT] + (size_t)t * N;
+	const double *sc = sc_all + t * NCC_SC, *cm = colmean_all + t * 8;
+	const double m0 = sc[NCC_I0_MEAN], c = sc[NCC_C], mt = sc[NCC_IT_MEAN], b = sc[NCC_B];
+	double acc[52];
+#pragma unroll
+	for (int k = 0; k < 52; ++k) acc[k] = 0.0;
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += nblk * kBlock) {
+		const double i0c_c = (I0[i] - m0) / c, itc_b = (It[i] - mt) / b;
+		double r[kMaxS];
+#pragma unroll
+		for (int s = 0; s < kMaxS; ++s) r[s] = s < S ? (J[(size_t)s * N + i] - cm[s]) / b : 0.0;
+		int k = 0;
+#pragma unroll
+		for (int a = 0; a < kMaxS; ++a)
+#pragma unroll
+			for (int b2 = a; b2 < kMaxS; ++b2) { acc[k] = fma(r[a], r[b2], acc[k]); ++k; }
+#pragma unroll
+		for (int s = 0; s < kMaxS; ++s) { acc[36 + s] = fma(r[s], itc_b, acc[36 + s]); acc[44 + s] = fma(r[s], i0c_c, acc[44 + s]); }
+	}
+	block_reduce_store<52>(acc, outv, lds);
+	__syncthreads();
+	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * ACC_COUNT;
+	if (threadIdx.x < 44) dst[threadIdx.x] = outv[threadIdx.x];          /* ACC_H (36) + ACC_G (8) are contiguous */
+	else if (threadIdx.x < 52) dst[ACC_G2 + threadIdx.x - 44] = outv[threadIdx.x];
+}
+
 /* fixed-order sum of the per-workgroup rows: out[t][k] = sum_b partials[t][b][k] */
 __global__ __launch_bounds__(64) void k_finish(const double *partials, int nblk, double *out) {
 	const int t = blockIdx.x, k = threadIdx.x;
@@ -1042,6 +1150,25 @@ void launch_gemv(const BatchView &bv, const double *v1, const double *J1, const 
 }
 void launch_gram(const BatchView &bv, const double *J, double *partials, int nblk, hipStream_t st) {
 	hipLaunchKernelGGL(k_gram, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv.N, bv.S, J, partials, nblk);
+}
+void launch_vec_sum(const BatchView &bv, const double *v, double *partials, int nblk, hipStream_t st) {
+	hipLaunchKernelGGL(k_vec_sum, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv.N, v, partials, nblk);
+}
+void launch_ncc_centered(const BatchView &bv, const double *sc, double *partials, int nblk, hipStream_t st) {
+	hipLaunchKernelGGL(k_ncc_centered, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv, sc, partials, nblk);
+}
+void launch_ncc_grad(const BatchView &bv, const double *sc, int curr, double *out, double *partials, int nblk, hipStream_t st) {
+	hipLaunchKernelGGL(k_ncc_grad, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv, sc, curr, out, partials, nblk);
+}
+void launch_sub_mean(const BatchView &bv, double *v, const double *sc, hipStream_t st) {
+	hipLaunchKernelGGL(k_sub_mean, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, v, sc);
+}
+void launch_col_sum(const BatchView &bv, const double *J, double *partials, int nblk, hipStream_t st) {
+	hipLaunchKernelGGL(k_col_sum, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv.N, bv.S, J, partials, nblk);
+}
+void launch_ncc_hess(const BatchView &bv, const double *sc, const double *colmean, const double *J, double *partials,
+	int nblk, hipStream_t st) {
+	hipLaunchKernelGGL(k_ncc_hess, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv, sc, colmean, J, partials, nblk);
 }
 void launch_finish(double *partials, int nblk, double *out, int B, hipStream_t st) {
 	hipLaunchKernelGGL(k_finish, dim3(B), dim3(64), 0, st, partials, nblk, out);

@@ -111,6 +111,132 @@ class LKTracker:
         return b.get_corners()
 
 
+class NTSearchMethod:
+    """nt::ESM / nt::FCLK / nt::ICLK written against the AM / SSM interface only, one C-ABI call per
+    reference virtual, exactly in the reference's order (SM/src/NT/ESM.cc:170-296, NT/FCLK.cc:171-358,
+    NT/ICLK.cc:160-299).  Works for every appearance model the device path implements (SSD, NCC, MI);
+    this is the literal drop-in shape -- LKTracker is the fused fast path for SSD.  Levenberg-Marquardt
+    is not vectorised here (use LKTracker(host_solve=True) for SSD)."""
+
+    def __init__(self, ctx, sm, am=L.AM_SSD, ssm=L.SSM_HOMOGRAPHY, resx=50, resy=50, n_targets=1, am_params=None,
+                 **params):
+        self.batch = Batch(ctx, am, ssm, resx, resy, n_targets, **(am_params or {}))
+        self.B, self.S = n_targets, self.batch.S
+        self.sm = sm_desc(sm, **params)
+        if self.sm.leven_marq:
+            raise L.FunctionNotImplemented(-2, "NTSearchMethod: leven_marq is not vectorised")
+        self.H0 = None
+        self.trace = []
+
+    def _pix_jacobian(self, init):
+        b, sm = self.batch, self.sm
+        grad, dst = (L.BUF_DI0_DX, L.BUF_J0) if init else (L.BUF_DIT_DX, L.BUF_JT)
+        if sm.chained_warp:
+            (b.initialize_pix_grad if init else b.update_pix_grad)()
+            b.cmpt_pix_jacobian(L.JAC_WARPED, grad, dst)
+        else:
+            b.update_grad_pts()
+            (b.initialize_pix_grad if init else b.update_pix_grad)(warped=True)
+            b.cmpt_pix_jacobian(L.JAC_INIT, grad, dst)
+
+    def initialize(self, corners):
+        b, sm = self.batch, self.sm
+        b.set_corners(np.asarray(corners, dtype=np.float64).reshape(self.B, 2, 4))
+        b.initialize_pix_vals()
+        if sm.sm == L.SM_ESM:
+            self._pix_jacobian(True)
+            b.initialize_similarity(); b.initialize_grad(); b.initialize_hess()
+            if sm.hess_type in (0, 2):
+                self.H0 = b.cmpt_self_hessian(L.BUF_J0)
+        elif sm.sm == L.SM_FCLK:
+            b.initialize_similarity(); b.initialize_grad(); b.initialize_hess()
+            self._pix_jacobian(True)
+            if sm.hess_type == 0:
+                self.H0 = b.cmpt_self_hessian(L.BUF_J0)
+        else:
+            self._pix_jacobian(True)
+            b.initialize_similarity(); b.initialize_grad(); b.initialize_hess()
+            b.cmpt_init_jacobian(L.BUF_J0)
+            if sm.hess_type == 0:
+                self.H0 = b.cmpt_self_hessian(L.BUF_J0)
+
+    def get_region(self):
+        return self.batch.get_corners()
+
+    def _esm_iter(self):
+        b, sm = self.batch, self.sm
+        b.update_pix_vals()
+        b.update_similarity(False)
+        self._pix_jacobian(False)
+        if sm.jac_type == 0 or sm.hess_type == 3:
+            b.mean_jacobian()
+        b.update_curr_grad(); b.update_init_grad()
+        g = b.cmpt_curr_jacobian(L.BUF_JM) if sm.jac_type == 0 else 0.5 * b.cmpt_difference_of_jacobians()
+        ht = sm.hess_type
+        if ht == 0:
+            H = self.H0
+        elif ht == 3:
+            H = b.cmpt_curr_hessian(L.BUF_JM)
+        elif ht == 4:
+            H = 0.5 * b.cmpt_sum_of_hessians()
+        elif ht == 2:
+            H = 0.5 * (b.cmpt_self_hessian(L.BUF_JT) + self.H0)
+        elif ht == 1:
+            H = b.cmpt_self_hessian(L.BUF_JT)
+        else:
+            H = b.cmpt_curr_hessian(L.BUF_JT)
+        return g, H
+
+    def _fclk_iter(self):
+        b, sm = self.batch, self.sm
+        b.update_pix_vals()
+        b.update_similarity(False)
+        b.update_curr_grad()
+        self._pix_jacobian(False)
+        g = b.cmpt_curr_jacobian(L.BUF_JT)
+        H = self.H0 if sm.hess_type == 0 else (b.cmpt_self_hessian(L.BUF_JT) if sm.hess_type == 1
+                                               else b.cmpt_curr_hessian(L.BUF_JT))
+        return g, H
+
+    def _iclk_iter(self):
+        b, sm = self.batch, self.sm
+        b.update_pix_vals()
+        b.update_similarity(False)
+        b.update_init_grad()
+        g = b.cmpt_init_jacobian(L.BUF_J0)
+        if sm.hess_type == 0:
+            H = self.H0
+        elif sm.hess_type == 1:
+            self._pix_jacobian(False)
+            H = b.cmpt_self_hessian(L.BUF_JT)
+        else:
+            H = b.cmpt_init_hessian(L.BUF_J0)
+        return g, H
+
+    def update(self):
+        b, sm = self.batch, self.sm
+        step = {L.SM_ESM: self._esm_iter, L.SM_FCLK: self._fclk_iter, L.SM_ICLK: self._iclk_iter}[sm.sm]
+        active = np.ones(self.B, dtype=bool)
+        self.trace = []
+        for _ in range(sm.max_iters):
+            g, H = step()
+            f = b.get_similarity()
+            dps = np.zeros((self.B, self.S))
+            for t in range(self.B):
+                if active[t]:
+                    dps[t] = _solve(H[t], g[t])
+            self.trace.append(dict(f=f.copy(), g=g.copy(), H=H.copy(), dp=dps.copy()))
+            prev = b.get_corners()
+            upd = b.invert_state(dps) if sm.sm == L.SM_ICLK else dps
+            upd[~active] = 0
+            b.compositional_update(upd)
+            change = ((prev - b.get_corners()) ** 2).reshape(self.B, -1).sum(axis=1)
+            active &= ~(change < sm.epsilon)
+            if not active.any():
+                break
+        return b.get_corners()
+
+
 class ParticleFilter:
     """PF + SSD + Homography/Affine (SM/src/PF.cc): dynamic model RandomWalk, update type Compositional,
     likelihood function AM, resampling BinaryMultinomial, mean type None (highest weight) or Corners."""
