@@ -35,6 +35,19 @@ def algorithmic_bytes_per_pixel(sm, materialize, unit_z=True):
     return b
 
 
+def pmc_traffic(sm, mode, res, targets):
+    """HBM bytes per launch of the fused kernel from the committed PMC passes (profiles/pmc_latest.json,
+    produced by tools/profile_round.sh: separate --pmc runs, KiB units, gfx950 FETCH_SIZE x2 correction).
+    Only reported when the profile was taken on this exact workload."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not (sm == "esm" and mode == "full" and res == 200 and targets == 64 and os.path.exists(path)):
+        return None
+    try:
+        return float(json.load(open(path))["traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(seconds, res, frame0, frame1, corners):
     """The CPU oracle (a port of the reference's ESM loop) timed on one host core on the same
     workload shape: LK iterations/s of a single 200x200 ESM+SSD+Homography target."""
@@ -161,7 +174,7 @@ def main():
                        "targets_per_gpu": B, "n_pix": N, "mode": args.mode, "frame": "%dx%d float32" % (H, W),
                        "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.sm, args.mode, res, B),
                          "kernel": "k_fused_ssd", "avg_kernel_ms": kern_ms, "launches_timed": kern_n,
                          "algorithmic_bytes_per_pixel": bpp, "bytes_per_launch": bytes_per_launch},
         }
