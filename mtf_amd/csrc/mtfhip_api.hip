@@ -7,6 +7,7 @@
  */
 #include "mtfhip_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -192,6 +193,10 @@ struct mtfhip_batch {
 	double *d_partials = nullptr, *d_acc = nullptr, *d_scratch_pts = nullptr, *d_w0 = nullptr;
 	double *d_h0 = nullptr, *d_corners = nullptr, *d_init_corners_hm = nullptr, *d_cand = nullptr;
 	double *d_ncc = nullptr, *d_colmean = nullptr; /* [B][8] NCC scalars / column means */
+	/* MI: per-target table block, block partial rows, similarity and Hessian outputs */
+	double *d_mi_tb = nullptr, *d_mi_part = nullptr, *d_mi_f = nullptr, *d_mi_H = nullptr;
+	int mi_row_len = 0;
+	double mi_hist_norm = 0;
 	size_t cand_capacity = 0;
 	int *d_active = nullptr, *d_iters = nullptr;
 	double *h_acc = nullptr; /* pinned */
@@ -350,6 +355,9 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 	if (d->resx <= 0 || d->resy <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "Invalid sampling resolution provided");
 	if (n_targets <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "batch_create: n_targets must be positive");
 	if (d->am < MTFHIP_AM_SSD || d->am > MTFHIP_AM_MI) return fail(MTFHIP_ERR_INVALID_ARG, "unknown appearance model %d", d->am);
+	if (d->am == MTFHIP_AM_MI && (d->mi_n_bins < 2 || d->mi_n_bins > MI_NB)) return fail(MTFHIP_ERR_INVALID_ARG, "MI: n_bins %d outside [2, %d]", d->mi_n_bins, (int)MI_NB);
+	if (d->am == MTFHIP_AM_MI && d->mi_partition_of_unity && d->mi_n_bins < 4) /* MI.cc:83-87 */
+		return fail(MTFHIP_ERR_INVALID_ARG, "MI::Too few bins %d specified to enforce partition of unity constraint", d->mi_n_bins);
 	if (d->ssm != MTFHIP_SSM_HOMOGRAPHY && d->ssm != MTFHIP_SSM_AFFINE) return fail(MTFHIP_ERR_INVALID_ARG, "unknown state space model %d", d->ssm);
 	HIP_TRY(hipSetDevice(c->device));
 	mtfhip_batch *b = new mtfhip_batch();
@@ -387,6 +395,17 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 	ALLOC(b->d_init_corners_hm, sizeof(double) * 12 * n_targets);
 	ALLOC(b->d_ncc, sizeof(double) * 8 * n_targets);
 	ALLOC(b->d_colmean, sizeof(double) * 8 * n_targets);
+	if (d->am == MTFHIP_AM_MI) {
+		const int nb = d->mi_n_bins;
+		b->mi_row_len = std::max(nb + nb * nb, 36 + nb * nb * b->S);
+		/* hist_norm_mult = 1 / (patch_size + hist_pre_seed * n_bins), hist_pre_seed = n_bins * pre_seed (MI.cc:97,104) */
+		b->mi_hist_norm = 1.0 / ((double)b->N + (nb * d->mi_pre_seed) * nb);
+		ALLOC(b->d_mi_tb, sizeof(double) * MI_SIZE * n_targets);
+		ALLOC(b->d_mi_part, sizeof(double) * (size_t)b->mi_row_len * b->nblk_max * n_targets);
+		ALLOC(b->d_mi_f, sizeof(double) * n_targets);
+		ALLOC(b->d_mi_H, sizeof(double) * 64 * n_targets);
+		(void)hipMemsetAsync(b->d_mi_tb, 0, sizeof(double) * MI_SIZE * n_targets, c->stream);
+	}
 	ALLOC(b->d_active, sizeof(int) * n_targets);
 	ALLOC(b->d_iters, sizeof(int) * n_targets);
 #undef ALLOC
@@ -406,7 +425,8 @@ void mtfhip_batch_destroy(mtfhip_batch *b) {
 	for (int i = 0; i < MTFHIP_BUF_COUNT; ++i)
 		if (b->buf[i]) (void)hipFree(b->buf[i]);
 	void *ptrs[] = {b->d_warps, b->d_states, b->d_partials, b->d_acc, b->d_scratch_pts, b->d_w0, b->d_h0, b->d_corners,
-		b->d_init_corners_hm, b->d_active, b->d_iters, b->d_cand, b->d_ncc, b->d_colmean};
+		b->d_init_corners_hm, b->d_active, b->d_iters, b->d_cand, b->d_ncc, b->d_colmean, b->d_mi_tb, b->d_mi_part,
+		b->d_mi_f, b->d_mi_H};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (b->h_acc) (void)hipHostFree(b->h_acc);
@@ -784,9 +804,62 @@ static int ncc_hessian(mtfhip_batch *b, int j_buf, int kind, double *H) {
 	return MTFHIP_OK;
 }
 
+
+/* ------------------------------------------------------------------ MI (AM/src/MI.cc) */
+static int mi_read_f(mtfhip_batch *b) {
+	std::vector<double> f(b->B);
+	HIP_TRY(hipMemcpyAsync(f.data(), b->d_mi_f, sizeof(double) * b->B, hipMemcpyDeviceToHost, b->ctx->stream));
+	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	for (int t = 0; t < b->B; ++t) b->th[t].f = f[t];
+	return MTFHIP_OK;
+}
+/* mode 0 initialise (A = B = I0), 1 update (A = It, B = I0), 2 self (A = B = It) */
+static int mi_hist_pass(mtfhip_batch *b, int mode, int first_init) {
+	const int nb = b->desc.mi_n_bins, nblk = simple_blocks_per_target(b->N);
+	const double *A = b->buf[mode == 0 ? MTFHIP_BUF_I0 : MTFHIP_BUF_IT];
+	const double *Bv = b->buf[mode == 2 ? MTFHIP_BUF_IT : MTFHIP_BUF_I0];
+	TimedScope ts(b->ctx, "mi_hist");
+	launch_mi_hist(b->view(), nb, b->mi_hist_norm, A, Bv, b->d_mi_part, nblk, b->mi_row_len, b->ctx->stream);
+	launch_mi_hist_finish(b->view(), nb, b->desc.mi_pre_seed, b->mi_hist_norm, mode, first_init, b->d_mi_part, nblk,
+		b->mi_row_len, b->d_mi_tb, b->d_mi_f, b->ctx->stream);
+	return MTFHIP_OK;
+}
+/* kind 0 init (MI.cc:461-513), 1 curr (:603-637), 2 self (:515-601, the returned second pass) */
+static int mi_hessian(mtfhip_batch *b, int j_buf, int kind, double *H) {
+	const int nb = b->desc.mi_n_bins, nblk = simple_blocks_per_target(b->N), S = b->S;
+	if (kind == 2) TRY(mi_hist_pass(b, 2, 0));   /* cmptSelfHist MI.cc:639-659 */
+	const double *A = b->buf[kind == 0 ? MTFHIP_BUF_I0 : MTFHIP_BUF_IT];
+	const double *Bv = b->buf[kind == 1 ? MTFHIP_BUF_I0 : MTFHIP_BUF_IT];
+	const int table = kind == 0 ? MI_T_INIT : (kind == 1 ? MI_T_CURR : MI_T_SELF);
+	const int joint = kind == 2 ? MI_SELF_JOINT : MI_JOINT;
+	const int hist = kind == 0 ? MI_HIST_INIT : MI_HIST_CURR;
+	{
+		TimedScope ts(b->ctx, "mi_hess");
+		launch_mi_hess(b->view(), nb, b->mi_hist_norm, A, Bv, b->d_mi_tb, table, kind == 0, b->buf[j_buf], b->d_mi_part, nblk,
+			b->mi_row_len, b->ctx->stream);
+		launch_mi_hess_finish(b->view(), nb, b->d_mi_part, nblk, b->mi_row_len, b->d_mi_tb, joint, hist, kind == 0, b->d_mi_H,
+			b->ctx->stream);
+	}
+	std::vector<double> h(64 * (size_t)b->B);
+	HIP_TRY(hipMemcpyAsync(h.data(), b->d_mi_H, sizeof(double) * h.size(), hipMemcpyDeviceToHost, b->ctx->stream));
+	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	for (int t = 0; t < b->B; ++t) std::memcpy(H + (size_t)t * S * S, &h[64 * t], sizeof(double) * S * S);
+	return MTFHIP_OK;
+}
+static int mi_grad(mtfhip_batch *b, int curr) {
+	const int nb = b->desc.mi_n_bins;
+	TimedScope ts(b->ctx, "mi_grad");
+	launch_mi_factor(b->view(), nb, curr, b->d_mi_tb, b->ctx->stream);
+	if (curr) launch_mi_grad(b->view(), nb, b->mi_hist_norm, b->buf[MTFHIP_BUF_IT], b->buf[MTFHIP_BUF_I0], b->d_mi_tb, MI_T_CURR,
+		b->buf[MTFHIP_BUF_DF_DIT], b->ctx->stream);
+	else launch_mi_grad(b->view(), nb, b->mi_hist_norm, b->buf[MTFHIP_BUF_I0], b->buf[MTFHIP_BUF_IT], b->d_mi_tb, MI_T_INIT,
+		b->buf[MTFHIP_BUF_DF_DI0], b->ctx->stream);
+	return MTFHIP_OK;
+}
+
 /* ------------------------------------------------------------------ AppearanceModel */
 static int am_supported(mtfhip_batch *b, const char *fn) {
-	if (b->desc.am == MTFHIP_AM_SSD || b->desc.am == MTFHIP_AM_NCC) return MTFHIP_OK;
+	if (b->desc.am == MTFHIP_AM_SSD || b->desc.am == MTFHIP_AM_NCC || b->desc.am == MTFHIP_AM_MI) return MTFHIP_OK;
 	return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s :: appearance model %d is not available on the device path yet", fn, b->desc.am);
 }
 
@@ -794,6 +867,14 @@ int mtfhip_am_initialize_similarity(mtfhip_batch *b) {
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "initialize_similarity: NULL batch");
 	TRY(am_supported(b, "initializeSimilarity"));
 	if (b->desc.am == MTFHIP_AM_NCC) return ncc_initialize_similarity(b);
+	if (b->desc.am == MTFHIP_AM_MI) {
+		/* MI::initializeSimilarity MI.cc:207-287 */
+		const int first = b->init_sim ? 0 : 1;
+		TRY(mi_hist_pass(b, 0, first));
+		if (first) TRY(mi_read_f(b));
+		b->init_sim = true;
+		return MTFHIP_OK;
+	}
 	if (b->init_sim) return MTFHIP_OK;
 	HIP_TRY(hipMemsetAsync(b->buf[MTFHIP_BUF_DF_DI0], 0, sizeof(double) * b->N * b->B, b->ctx->stream));
 	for (auto &h : b->th) h.f = 0;
@@ -803,6 +884,18 @@ int mtfhip_am_initialize_similarity(mtfhip_batch *b) {
 int mtfhip_am_initialize_grad(mtfhip_batch *b) {
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "initialize_grad: NULL batch");
 	TRY(am_supported(b, "initializeGrad"));
+	if (b->desc.am == MTFHIP_AM_MI) {
+		/* MI::initializeGrad MI.cc:299-332: df_dI0 from the initial tables, df_dIt = df_dI0 */
+		if (b->init_grad) return MTFHIP_OK;
+		{
+			TimedScope ts(b->ctx, "mi_grad");
+			launch_mi_grad(b->view(), b->desc.mi_n_bins, b->mi_hist_norm, b->buf[MTFHIP_BUF_I0], b->buf[MTFHIP_BUF_I0], b->d_mi_tb,
+				MI_T_INIT, b->buf[MTFHIP_BUF_DF_DI0], b->ctx->stream);
+		}
+		HIP_TRY(hipMemcpyAsync(b->buf[MTFHIP_BUF_DF_DIT], b->buf[MTFHIP_BUF_DF_DI0], sizeof(double) * b->N * b->B, hipMemcpyDeviceToDevice, b->ctx->stream));
+		b->init_grad = true;
+		return MTFHIP_OK;
+	}
 	if (b->desc.am == MTFHIP_AM_NCC) {
 		/* NCC::initializeGrad NCC.cc:97-122: gradient vectors start at zero */
 		if (!b->init_grad) {
@@ -826,6 +919,12 @@ int mtfhip_am_update_similarity(mtfhip_batch *b, int prereq_only) {
 	TRY(am_supported(b, "updateSimilarity"));
 	if (!b->init_sim) return fail(MTFHIP_ERR_LOGIC, "updateSimilarity before initializeSimilarity");
 	if (b->desc.am == MTFHIP_AM_NCC) return ncc_update_similarity(b);
+	if (b->desc.am == MTFHIP_AM_MI) {
+		/* MI::updateSimilarity MI.cc:346-382 */
+		TRY(mi_hist_pass(b, 1, 0));
+		if (!prereq_only) TRY(mi_read_f(b));
+		return MTFHIP_OK;
+	}
 	int nblk = simple_blocks_per_target(b->N);
 	{
 		TimedScope ts(b->ctx, "ssd_residual");
@@ -840,6 +939,7 @@ int mtfhip_am_update_curr_grad(mtfhip_batch *b) {
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_curr_grad: NULL batch");
 	TRY(am_supported(b, "updateCurrGrad"));
 	if (b->desc.am == MTFHIP_AM_NCC) return ncc_update_grad(b, 1);
+	if (b->desc.am == MTFHIP_AM_MI) return mi_grad(b, 1);
 	TimedScope ts(b->ctx, "negate");
 	launch_negate(b->buf[MTFHIP_BUF_DF_DI0], b->buf[MTFHIP_BUF_DF_DIT], (size_t)b->N * b->B, b->ctx->stream);
 	return MTFHIP_OK;
@@ -848,6 +948,7 @@ int mtfhip_am_update_init_grad(mtfhip_batch *b) {
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_init_grad: NULL batch");
 	TRY(am_supported(b, "updateInitGrad"));
 	if (b->desc.am == MTFHIP_AM_NCC) return ncc_update_grad(b, 0);
+	if (b->desc.am == MTFHIP_AM_MI) return mi_grad(b, 0);
 	return MTFHIP_OK;
 }
 int mtfhip_am_get_similarity(mtfhip_batch *b, double *f) {
@@ -936,6 +1037,7 @@ int mtfhip_am_cmpt_init_hessian(mtfhip_batch *b, int j0_buf, double *H) {
 	TRY(am_supported(b, "cmptInitHessian"));
 	TRY(j_ready(b, j0_buf, "cmptInitHessian"));
 	if (b->desc.am == MTFHIP_AM_NCC) return ncc_hessian(b, j0_buf, 0, H);
+	if (b->desc.am == MTFHIP_AM_MI) return mi_hessian(b, j0_buf, 0, H);
 	return gram_to_host(b, j0_buf, H, -1.0, false);
 }
 int mtfhip_am_cmpt_curr_hessian(mtfhip_batch *b, int jt_buf, double *H) {
@@ -943,6 +1045,7 @@ int mtfhip_am_cmpt_curr_hessian(mtfhip_batch *b, int jt_buf, double *H) {
 	TRY(am_supported(b, "cmptCurrHessian"));
 	TRY(j_ready(b, jt_buf, "cmptCurrHessian"));
 	if (b->desc.am == MTFHIP_AM_NCC) return ncc_hessian(b, jt_buf, 1, H);
+	if (b->desc.am == MTFHIP_AM_MI) return mi_hessian(b, jt_buf, 1, H);
 	return gram_to_host(b, jt_buf, H, -1.0, false);
 }
 int mtfhip_am_cmpt_self_hessian(mtfhip_batch *b, int jt_buf, double *H) {
@@ -950,6 +1053,7 @@ int mtfhip_am_cmpt_self_hessian(mtfhip_batch *b, int jt_buf, double *H) {
 	TRY(am_supported(b, "cmptSelfHessian"));
 	TRY(j_ready(b, jt_buf, "cmptSelfHessian"));
 	if (b->desc.am == MTFHIP_AM_NCC) return ncc_hessian(b, jt_buf, 2, H);
+	if (b->desc.am == MTFHIP_AM_MI) return mi_hessian(b, jt_buf, 2, H);
 	return gram_to_host(b, jt_buf, H, -1.0, false);
 }
 int mtfhip_am_cmpt_sum_of_hessians(mtfhip_batch *b, int j0_buf, int jt_buf, double *H) {
@@ -957,11 +1061,11 @@ int mtfhip_am_cmpt_sum_of_hessians(mtfhip_batch *b, int j0_buf, int jt_buf, doub
 	TRY(am_supported(b, "cmptSumOfHessians"));
 	TRY(j_ready(b, j0_buf, "cmptSumOfHessians"));
 	TRY(j_ready(b, jt_buf, "cmptSumOfHessians"));
-	if (b->desc.am == MTFHIP_AM_NCC) {
+	if (b->desc.am != MTFHIP_AM_SSD) {
 		/* generic AppearanceModel::cmptSumOfHessians AppearanceModel.h:196-208 */
 		std::vector<double> H0((size_t)b->B * b->S * b->S);
-		TRY(ncc_hessian(b, j0_buf, 0, H0.data()));
-		TRY(ncc_hessian(b, jt_buf, 1, H));
+		if (b->desc.am == MTFHIP_AM_NCC) { TRY(ncc_hessian(b, j0_buf, 0, H0.data())); TRY(ncc_hessian(b, jt_buf, 1, H)); }
+		else { TRY(mi_hessian(b, j0_buf, 0, H0.data())); TRY(mi_hessian(b, jt_buf, 1, H)); }
 		for (size_t i = 0; i < H0.size(); ++i) H[i] += H0[i];
 		return MTFHIP_OK;
 	}

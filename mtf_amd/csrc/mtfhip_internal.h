@@ -83,6 +83,24 @@ void launch_sub_mean(const BatchView &bv, double *v, const double *sc, hipStream
 void launch_col_sum(const BatchView &bv, const double *J, double *partials, int nblk, hipStream_t st);
 void launch_ncc_hess(const BatchView &bv, const double *sc, const double *colmean, const double *J, double *partials,
 	int nblk, hipStream_t st);
+/* MI pieces; table block offsets (doubles) of the per-target MI state, see mtfhip_kernels.hip */
+enum {
+	MI_NB = 16,
+	MI_HIST_INIT = 0, MI_HIST_CURR = 16, MI_LOG_INIT = 32, MI_LOG_CURR = 48,
+	MI_JOINT = 64, MI_JOINT_LOG = 320, MI_T_CURR = 576, MI_T_INIT = 832,
+	MI_SELF_JOINT = 1088, MI_T_SELF = 1344, MI_SIZE = 1600
+};
+void launch_mi_hist(const BatchView &bv, int nb, double norm_mult, const double *A, const double *Bv, double *partials,
+	int nblk, int row_len, hipStream_t st);
+void launch_mi_hist_finish(const BatchView &bv, int nb, double pre_seed, double norm_mult, int mode, int first_init,
+	const double *partials, int nblk, int row_len, double *tb, double *f_out, hipStream_t st);
+void launch_mi_factor(const BatchView &bv, int nb, int curr, double *tb, hipStream_t st);
+void launch_mi_grad(const BatchView &bv, int nb, double norm_mult, const double *A, const double *Bv, const double *tb,
+	int table_off, double *out, hipStream_t st);
+void launch_mi_hess(const BatchView &bv, int nb, double norm_mult, const double *A, const double *Bv, const double *tb,
+	int table_off, int transpose_q, const double *J, double *partials, int nblk, int row_len, hipStream_t st);
+void launch_mi_hess_finish(const BatchView &bv, int nb, const double *partials, int nblk, int row_len, const double *tb,
+	int joint_off, int hist_off, int transpose_q, double *out, hipStream_t st);
 /* sums partials over blocks: out[B][ACC_COUNT] */
 void launch_finish(double *partials, int nblk, double *out, int B, hipStream_t st);
 /* the fused LK iteration for SSD */

@@ -594,6 +594,243 @@ __global__ __launch_bounds__(kBlock) void k_ncc_hess(BatchView bv, const double 
 	else if (threadIdx.x < 52) dst[ACC_G2 + threadIdx.x - 44] = outv[threadIdx.x];
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * MI (AM/src/MI.cc): cubic B-spline Parzen histograms.  The reference materialises n_bins x N weight /
+ * gradient / Hessian matrices and n_bins^2 x N joint-gradient matrices (MI.cc:297-302, 164 MB per
+ * 400x400 target); each pixel only touches a 4-bin window, so here the window is recomputed from the
+ * pixel value (I0 / It) wherever it is needed and only the n_bins^2-sized tables live in memory.
+ * Per-target table block `tb` (doubles): see the MI_* offsets.  "A" is the image whose B-spline gradient /
+ * Hessian enters (rows r of the joint table), "B" the one whose plain weights enter (columns c).
+ * ------------------------------------------------------------------------------------------- */
+/* utils::bSpl3WithGrad Utilities/include/mtf/Utilities/histUtils.h:206-226 (truncated constant kept, :11) */
+__device__ __forceinline__ void bspl3_with_grad(double &val, double &diff, double x) {
+	const double k2by3 = 0.66666666666;
+	val = 0; diff = 0;
+	if ((x > -2) && (x <= -1)) { double t = 2 + x; diff = (t * t) / 2; val = (diff * t) / 3; }
+	else if ((x > -1) && (x <= 0)) { double t = x / 2; val = k2by3 - x * x * (1 + t); diff = -x * (t + x + 2); }
+	else if ((x > 0) && (x <= 1)) { double t = x / 2; val = k2by3 - x * x * (1 - t); diff = x * (t + x - 2); }
+	else if ((x > 1) && (x < 2)) { double t = 2 - x; diff = -(t * t) / 2; val = -(diff * t) / 3; }
+}
+/* utils::bSpl3Hess histUtils.h:271-283 */
+__device__ __forceinline__ double bspl3_hess(double x) {
+	if ((x > -2) && (x <= -1)) return 2 + x;
+	if ((x > -1) && (x <= 0)) return -(3 * x + 2);
+	if ((x > 0) && (x <= 1)) return 3 * x - 2;
+	if ((x > 1) && (x < 2)) return 2 - x;
+	return 0;
+}
+/* the <= 4-bin window of a pixel value: ids [lo, hi] = std_bspl_ids.row((int)v) (MI.cc:114-117), weights
+ * w[k], derivative d[k] (already * -hist_norm_mult as MI.cc:229,360) and second derivative h[k] */
+struct BsplWin { int lo, n; double w[4], d[4], h[4]; };
+__device__ __forceinline__ BsplWin bspl_window(double v, int nb, double norm_mult, bool want_hess) {
+	BsplWin s;
+	const int fl = (int)v;
+	s.lo = max(0, fl - 1);
+	const int hi = min(nb - 1, fl + 2);
+	s.n = hi - s.lo + 1;
+	double diff = s.lo - v;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		s.w[k] = 0; s.d[k] = 0; s.h[k] = 0;
+		if (k < s.n) {
+			bspl3_with_grad(s.w[k], s.d[k], diff);
+			s.d[k] *= -norm_mult;
+			if (want_hess) s.h[k] = norm_mult * bspl3_hess(diff);
+			diff += 1;   /* ++curr_diff, MI.cc:232,359 */
+		}
+	}
+	return s;
+}
+__device__ __forceinline__ void lds_add(double *p, double v) {
+	__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+/* histogram of A and joint histogram A x B (MI.cc:222-235 init, :245-252 init joint, :352-367 update,
+ * :641-649 self).  Block partial rows: [nb hist | nb*nb joint] */
+__global__ __launch_bounds__(kBlock) void k_mi_hist(int N, int nb, double norm_mult, const double *A_all,
+	const double *B_all, double *partials, int nblk, int row_len) {
+	__shared__ double sh[MI_NB + MI_NB * MI_NB];
+	const int t = blockIdx.y;
+	const double *A = A_all + (size_t)t * N, *Bv = B_all + (size_t)t * N;
+	for (int k = threadIdx.x; k < nb + nb * nb; k += kBlock) sh[k] = 0.0;
+	__syncthreads();
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += nblk * kBlock) {
+		const BsplWin a = bspl_window(A[i], nb, norm_mult, false);
+		const BsplWin b = bspl_window(Bv[i], nb, norm_mult, false);
+		for (int r = 0; r < a.n; ++r) {
+			lds_add(&sh[a.lo + r], a.w[r]);
+			for (int c = 0; c < b.n; ++c) lds_add(&sh[nb + (a.lo + r) * nb + b.lo + c], a.w[r] * b.w[c]);
+		}
+	}
+	__syncthreads();
+	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * row_len;
+	for (int k = threadIdx.x; k < nb + nb * nb; k += kBlock) dst[k] = sh[k];
+}
+/* sums the block rows, applies pre-seeding and normalisation, logs, similarity and the gradient-factor
+ * table of the requested flavour (MI.cc:237-262, 369-381, 310-314, 399-403, 427-431, 651-658).
+ * mode 0: initialise (A = B = I0), 1: update (A = It, B = I0), 2: self (A = B = It) */
+__global__ __launch_bounds__(kBlock) void k_mi_hist_finish(int nb, double pre_seed, double norm_mult, int mode, int first_init,
+	const double *partials, int nblk, int row_len, double *tb_all, double *f_out) {
+	__shared__ double red[kBlock];
+	const int t = blockIdx.x;
+	double *tb = tb_all + (size_t)t * MI_SIZE;
+	const double *p = partials + (size_t)t * nblk * row_len;
+	const double hist_seed = nb * pre_seed;
+	for (int k = threadIdx.x; k < nb + nb * nb; k += kBlock) {
+		double s = 0;
+		for (int b = 0; b < nblk; ++b) s += p[(size_t)b * row_len + k];
+		if (k < nb) {
+			const double hv = (s + hist_seed) * norm_mult;
+			if (mode == 0) { tb[MI_HIST_INIT + k] = hv; tb[MI_LOG_INIT + k] = log(hv); if (first_init) { tb[MI_HIST_CURR + k] = hv; tb[MI_LOG_CURR + k] = log(hv); } }
+			else if (mode == 1) { tb[MI_HIST_CURR + k] = hv; tb[MI_LOG_CURR + k] = log(hv); }
+		} else {
+			const int q = k - nb, r = q / nb, c = q % nb;
+			const double jv = (s + pre_seed) * norm_mult;
+			if (mode == 2) tb[MI_SELF_JOINT + r * MI_NB + c] = jv;
+			else if (mode == 1 || first_init) { tb[MI_JOINT + r * MI_NB + c] = jv; tb[MI_JOINT_LOG + r * MI_NB + c] = log(jv); }
+		}
+	}
+	__syncthreads();
+	double part = 0;
+	for (int q = threadIdx.x; q < nb * nb; q += kBlock) {
+		const int r = q / nb, c = q % nb;
+		if (mode == 2) {
+			const double lg = log(tb[MI_SELF_JOINT + r * MI_NB + c]);
+			tb[MI_T_SELF + r * MI_NB + c] = 1 + lg - tb[MI_LOG_CURR + r];
+		} else if (mode == 1 || first_init) {
+			const double jv = tb[MI_JOINT + r * MI_NB + c], lg = tb[MI_JOINT_LOG + r * MI_NB + c];
+			const double lr = mode == 0 ? tb[MI_LOG_INIT + r] : tb[MI_LOG_CURR + r];
+			part += jv * (lg - lr - tb[MI_LOG_INIT + c]);
+			if (mode == 0) {
+				/* MI::initializeGrad MI.cc:310-314: both tables start as 1 + log(joint/init_hist(row)) */
+				const double v = 1 + lg - tb[MI_LOG_INIT + r];
+				tb[MI_T_INIT + r * MI_NB + c] = v; tb[MI_T_CURR + r * MI_NB + c] = v;
+			}
+		}
+	}
+	red[threadIdx.x] = part;
+	__syncthreads();
+	if (threadIdx.x == 0 && mode != 2) {
+		double s = 0;
+		for (int i = 0; i < kBlock; ++i) s += red[i];
+		f_out[t] = s;
+	}
+}
+/* gradient-factor tables refreshed by updateCurrGrad / updateInitGrad (MI.cc:399-403, 427-431) */
+__global__ __launch_bounds__(kBlock) void k_mi_factor(int nb, int curr, double *tb_all) {
+	double *tb = tb_all + (size_t)blockIdx.x * MI_SIZE;
+	for (int q = threadIdx.x; q < nb * nb; q += kBlock) {
+		const int r = q / nb, c = q % nb;
+		if (curr) tb[MI_T_CURR + r * MI_NB + c] = 1 + tb[MI_JOINT_LOG + r * MI_NB + c] - tb[MI_LOG_CURR + r];
+		else tb[MI_T_INIT + r * MI_NB + c] = 1 + tb[MI_JOINT_LOG + c * MI_NB + r] - tb[MI_LOG_INIT + r]; /* (init, curr) indexing */
+	}
+}
+/* df_dI[p] = sum_r sum_c gradA(r,p) * matB(c,p) * T(r,c)  (MI.cc:318-326, 406-415, 432-441) */
+__global__ __launch_bounds__(kBlock) void k_mi_grad(int N, int nb, double norm_mult, const double *A_all,
+	const double *B_all, const double *tb_all, int table_off, double *out_all) {
+	__shared__ double T[MI_NB * MI_NB];
+	const int t = blockIdx.y;
+	const double *tb = tb_all + (size_t)t * MI_SIZE + table_off;
+	for (int k = threadIdx.x; k < MI_NB * MI_NB; k += kBlock) T[k] = tb[k];
+	__syncthreads();
+	const double *A = A_all + (size_t)t * N, *Bv = B_all + (size_t)t * N;
+	double *out = out_all + (size_t)t * N;
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+		const BsplWin a = bspl_window(A[i], nb, norm_mult, false);
+		const BsplWin b = bspl_window(Bv[i], nb, norm_mult, false);
+		double acc = 0;
+		for (int r = 0; r < a.n; ++r)
+			for (int c = 0; c < b.n; ++c) acc += a.d[r] * b.w[c] * T[(a.lo + r) * MI_NB + b.lo + c];
+		out[i] = acc;
+	}
+}
+/* first-order MI Hessians (MI.cc:461-513 init, 565-601 self (the returned pass), 603-637 curr):
+ *   Hsum  += hess_term(p) * Jrow Jrow^T,  hess_term = sum_r hessA(r) * sum_c matB(c) T(r,c)
+ *   Q[row(r,c)] += gradA(r) matB(c) Jrow          row(r,c) = (r,c), or (c,r) when transpose_q (init flavour)
+ * Block partial rows: [36 Hsum | nb*nb*S Q] */
+__global__ __launch_bounds__(kBlock) void k_mi_hess(int N, int S, int nb, double norm_mult, const double *A_all,
+	const double *B_all, const double *tb_all, int table_off, int transpose_q, const double *J_all,
+	double *partials, int nblk, int row_len) {
+	extern __shared__ __attribute__((aligned(16))) double dyn[];
+	double *T = dyn;                       /* MI_NB*MI_NB */
+	double *Q = dyn + MI_NB * MI_NB;       /* nb*nb*S */
+	double *red = Q + nb * nb * S;         /* 4 * 36 */
+	const int t = blockIdx.y;
+	const double *tb = tb_all + (size_t)t * MI_SIZE + table_off;
+	for (int k = threadIdx.x; k < MI_NB * MI_NB; k += kBlock) T[k] = tb[k];
+	for (int k = threadIdx.x; k < nb * nb * S; k += kBlock) Q[k] = 0.0;
+	__syncthreads();
+	const double *A = A_all + (size_t)t * N, *Bv = B_all + (size_t)t * N;
+	const double *J = J_all + (size_t)t * N * S;
+	double acc[36];
+#pragma unroll
+	for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += nblk * kBlock) {
+		const BsplWin a = bspl_window(A[i], nb, norm_mult, true);
+		const BsplWin b = bspl_window(Bv[i], nb, norm_mult, false);
+		double row[kMaxS];
+#pragma unroll
+		for (int s = 0; s < kMaxS; ++s) row[s] = s < S ? J[(size_t)s * N + i] : 0.0;
+		double hess_term = 0;
+		for (int r = 0; r < a.n; ++r) {
+			double inner = 0;
+			for (int c = 0; c < b.n; ++c) {
+				const int rr = a.lo + r, cc = b.lo + c;
+				const double gr = a.d[r] * b.w[c];
+				double *q = Q + (size_t)((transpose_q ? cc * nb + rr : rr * nb + cc)) * S;
+				for (int s = 0; s < S; ++s) lds_add(&q[s], gr * row[s]);
+				inner += b.w[c] * T[rr * MI_NB + cc];
+			}
+			hess_term += a.h[r] * inner;
+		}
+		int k = 0;
+#pragma unroll
+		for (int x = 0; x < kMaxS; ++x) {
+			const double hx = hess_term * row[x];
+#pragma unroll
+			for (int y = x; y < kMaxS; ++y) { acc[k] = fma(hx, row[y], acc[k]); ++k; }
+		}
+	}
+	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * row_len;
+	block_reduce_store<36>(acc, dst, red);
+	__syncthreads();
+	for (int k = threadIdx.x; k < nb * nb * S; k += kBlock) dst[36 + k] = Q[k];
+}
+/* H = Hsum + sum_k factor_k Q_k^T Q_k,  factor(r,c) = 1/joint_used(r,c) - 1/histA(r)
+ * (MI.cc:505-511, 592-598, 629-635); writes H column-major S x S into out[t][64] */
+__global__ __launch_bounds__(kBlock) void k_mi_hess_finish(int S, int nb, const double *partials, int nblk, int row_len,
+	const double *tb_all, int joint_off, int hist_off, int transpose_q, double *out) {
+	extern __shared__ __attribute__((aligned(16))) double dyn[];
+	double *Q = dyn;               /* nb*nb*S */
+	double *Hs = dyn + nb * nb * S; /* 36 */
+	const int t = blockIdx.x;
+	const double *p = partials + (size_t)t * nblk * row_len;
+	const double *tb = tb_all + (size_t)t * MI_SIZE;
+	for (int k = threadIdx.x; k < 36 + nb * nb * S; k += kBlock) {
+		double s = 0;
+		for (int b = 0; b < nblk; ++b) s += p[(size_t)b * row_len + k];
+		if (k < 36) Hs[k] = s; else Q[k - 36] = s;
+	}
+	__syncthreads();
+	if (threadIdx.x < 64) {
+		const int r2 = threadIdx.x >> 3, c2 = threadIdx.x & 7;
+		if (r2 < S && c2 < S) {
+			const int a = r2 < c2 ? r2 : c2, b2 = r2 < c2 ? c2 : r2;
+			double h = Hs[a * 8 - (a * (a - 1)) / 2 + (b2 - a)];
+			for (int rr = 0; rr < nb; ++rr)
+				for (int cc = 0; cc < nb; ++cc) {
+					/* Q row (rr,cc) is joint_hist_jacobian.row(linear_idx(rr,cc)); its factor uses joint(rr,cc) and the
+					 * histogram of the image whose gradient was taken: rows for curr/self, columns for the init flavour */
+					const double jv = tb[joint_off + rr * MI_NB + cc];
+					const double hv = tb[hist_off + (transpose_q ? cc : rr)];
+					const double fac = (1.0 / jv) - (1.0 / hv);
+					const double *q = Q + (size_t)(rr * nb + cc) * S;
+					h += q[r2] * q[c2] * fac;
+				}
+			out[(size_t)t * 64 + c2 * S + r2] = h;
+		}
+	}
+}
+
 /* fixed-order sum of the per-workgroup rows: out[t][k] = sum_b partials[t][b][k] */
 __global__ __launch_bounds__(64) void k_finish(const double *partials, int nblk, double *out) {
 	const int t = blockIdx.x, k = threadIdx.x;
@@ -1169,6 +1406,35 @@ void launch_col_sum(const BatchView &bv, const double *J, double *partials, int 
 void launch_ncc_hess(const BatchView &bv, const double *sc, const double *colmean, const double *J, double *partials,
 	int nblk, hipStream_t st) {
 	hipLaunchKernelGGL(k_ncc_hess, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv, sc, colmean, J, partials, nblk);
+}
+void launch_mi_hist(const BatchView &bv, int nb, double norm_mult, const double *A, const double *Bv, double *partials,
+	int nblk, int row_len, hipStream_t st) {
+	hipLaunchKernelGGL(k_mi_hist, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv.N, nb, norm_mult, A, Bv, partials, nblk, row_len);
+}
+void launch_mi_hist_finish(const BatchView &bv, int nb, double pre_seed, double norm_mult, int mode, int first_init,
+	const double *partials, int nblk, int row_len, double *tb, double *f_out, hipStream_t st) {
+	hipLaunchKernelGGL(k_mi_hist_finish, dim3(bv.B), dim3(kBlock), 0, st, nb, pre_seed, norm_mult, mode, first_init, partials,
+		nblk, row_len, tb, f_out);
+}
+void launch_mi_factor(const BatchView &bv, int nb, int curr, double *tb, hipStream_t st) {
+	hipLaunchKernelGGL(k_mi_factor, dim3(bv.B), dim3(kBlock), 0, st, nb, curr, tb);
+}
+void launch_mi_grad(const BatchView &bv, int nb, double norm_mult, const double *A, const double *Bv, const double *tb,
+	int table_off, double *out, hipStream_t st) {
+	hipLaunchKernelGGL(k_mi_grad, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, nb, norm_mult, A, Bv,
+		tb, table_off, out);
+}
+void launch_mi_hess(const BatchView &bv, int nb, double norm_mult, const double *A, const double *Bv, const double *tb,
+	int table_off, int transpose_q, const double *J, double *partials, int nblk, int row_len, hipStream_t st) {
+	size_t lds = sizeof(double) * (MI_NB * MI_NB + (size_t)nb * nb * bv.S + 4 * 36);
+	hipLaunchKernelGGL(k_mi_hess, grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, bv.S, nb, norm_mult, A, Bv, tb, table_off,
+		transpose_q, J, partials, nblk, row_len);
+}
+void launch_mi_hess_finish(const BatchView &bv, int nb, const double *partials, int nblk, int row_len, const double *tb,
+	int joint_off, int hist_off, int transpose_q, double *out, hipStream_t st) {
+	size_t lds = sizeof(double) * ((size_t)nb * nb * bv.S + 36);
+	hipLaunchKernelGGL(k_mi_hess_finish, dim3(bv.B), dim3(kBlock), lds, st, bv.S, nb, partials, nblk, row_len, tb, joint_off,
+		hist_off, transpose_q, out);
 }
 void launch_finish(double *partials, int nblk, double *out, int B, hipStream_t st) {
 	hipLaunchKernelGGL(k_finish, dim3(B), dim3(64), 0, st, partials, nblk, out);

@@ -97,6 +97,13 @@ NT_CASES = [
     (L.SM_FCLK, L.AM_NCC, L.SSM_AFFINE, 30, dict()),
     (L.SM_ESM, L.AM_SSD, L.SSM_HOMOGRAPHY, 40, dict()),
     (L.SM_FCLK, L.AM_SSD, L.SSM_AFFINE, 30, dict(chained_warp=0)),
+    (L.SM_ESM, L.AM_MI, L.SSM_HOMOGRAPHY, 40, dict()),                      # config 5 (reduced)
+    (L.SM_ESM, L.AM_MI, L.SSM_HOMOGRAPHY, 40, dict(jac_type=0, hess_type=3)),
+    (L.SM_ESM, L.AM_MI, L.SSM_HOMOGRAPHY, 40, dict(hess_type=4)),
+    (L.SM_ESM, L.AM_MI, L.SSM_HOMOGRAPHY, 40, dict(hess_type=5, chained_warp=0)),
+    (L.SM_FCLK, L.AM_MI, L.SSM_AFFINE, 30, dict()),
+    (L.SM_ICLK, L.AM_MI, L.SSM_HOMOGRAPHY, 40, dict()),
+    (L.SM_ICLK, L.AM_MI, L.SSM_AFFINE, 30, dict(hess_type=2)),
 ]
 
 
