@@ -195,6 +195,7 @@ struct mtfhip_batch {
 	double *d_ncc = nullptr, *d_colmean = nullptr; /* [B][8] NCC scalars / column means */
 	/* MI: per-target table block, block partial rows, similarity and Hessian outputs */
 	double *d_mi_tb = nullptr, *d_mi_part = nullptr, *d_mi_f = nullptr, *d_mi_H = nullptr;
+	double *d_h0inv = nullptr; /* [B][64] inverse of the constant Hessian (one-launch ICLK) */
 	int mi_row_len = 0;
 	double mi_hist_norm = 0;
 	size_t cand_capacity = 0;
@@ -393,6 +394,7 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 	ALLOC(b->d_h0, sizeof(double) * 64 * n_targets);
 	ALLOC(b->d_corners, sizeof(double) * 8 * n_targets);
 	ALLOC(b->d_init_corners_hm, sizeof(double) * 12 * n_targets);
+	ALLOC(b->d_h0inv, sizeof(double) * 64 * n_targets);
 	ALLOC(b->d_ncc, sizeof(double) * 8 * n_targets);
 	ALLOC(b->d_colmean, sizeof(double) * 8 * n_targets);
 	if (d->am == MTFHIP_AM_MI) {
@@ -426,7 +428,7 @@ void mtfhip_batch_destroy(mtfhip_batch *b) {
 		if (b->buf[i]) (void)hipFree(b->buf[i]);
 	void *ptrs[] = {b->d_warps, b->d_states, b->d_partials, b->d_acc, b->d_scratch_pts, b->d_w0, b->d_h0, b->d_corners,
 		b->d_init_corners_hm, b->d_active, b->d_iters, b->d_cand, b->d_ncc, b->d_colmean, b->d_mi_tb, b->d_mi_part,
-		b->d_mi_f, b->d_mi_H};
+		b->d_mi_f, b->d_mi_H, b->d_h0inv};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (b->h_acc) (void)hipHostFree(b->h_acc);
@@ -1088,8 +1090,34 @@ static int check_sm(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const char 
 	if (sm->sm < MTFHIP_SM_ESM || sm->sm > MTFHIP_SM_ICLK) return fail(MTFHIP_ERR_INVALID_ARG, "%s: unknown search method %d", fn, sm->sm);
 	int max_h = sm->sm == MTFHIP_SM_ESM ? 5 : 2;
 	if (sm->hess_type < 0 || sm->hess_type > max_h) return fail(MTFHIP_ERR_INVALID_ARG, "%s: hess_type %d invalid for search method %d", fn, sm->hess_type, sm->sm);
-	if (b->desc.am != MTFHIP_AM_SSD) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: the fused path supports the SSD appearance model only", fn);
+	if (b->desc.am == MTFHIP_AM_NCC && sm->sm == MTFHIP_SM_ICLK && sm->hess_type == 0) return MTFHIP_OK; /* one-launch ICLK */
+	if (b->desc.am != MTFHIP_AM_SSD) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: the fused path supports SSD (all search methods) and NCC with ICLK/InitialSelf; use the per-function entry points", fn);
 	return MTFHIP_OK;
+}
+
+/* inverse of a definite S x S matrix (column-major) by Gauss-Jordan on the diagonally scaled system */
+static bool invert_definite(int S, const double *H, double *Hinv) {
+	double A[8][16], sc[8];
+	for (int i = 0; i < S; ++i) { double d = std::fabs(H[i * S + i]); sc[i] = d > 0 ? 1.0 / std::sqrt(d) : 1.0; }
+	for (int i = 0; i < S; ++i)
+		for (int j = 0; j < S; ++j) { A[i][j] = H[j * S + i] * sc[i] * sc[j]; A[i][S + j] = i == j ? 1.0 : 0.0; }
+	for (int k = 0; k < S; ++k) {
+		int piv = k;
+		for (int i = k + 1; i < S; ++i) if (std::fabs(A[i][k]) > std::fabs(A[piv][k])) piv = i;
+		if (A[piv][k] == 0) return false;
+		if (piv != k) for (int j = 0; j < 2 * S; ++j) std::swap(A[piv][j], A[k][j]);
+		const double p = A[k][k];
+		for (int j = 0; j < 2 * S; ++j) A[k][j] /= p;
+		for (int i = 0; i < S; ++i) {
+			if (i == k) continue;
+			const double f = A[i][k];
+			if (f == 0) continue;
+			for (int j = 0; j < 2 * S; ++j) A[i][j] -= f * A[k][j];
+		}
+	}
+	for (int i = 0; i < S; ++i)
+		for (int j = 0; j < S; ++j) Hinv[j * S + i] = A[i][S + j] * sc[i] * sc[j];
+	return true;
 }
 
 int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
@@ -1117,6 +1145,11 @@ int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 		std::memcpy(&h0dev[(size_t)t * 64], b->th[t].h0, sizeof(double) * 64);
 	}
 	HIP_TRY(hipMemcpyAsync(b->d_h0, h0dev.data(), sizeof(double) * h0dev.size(), hipMemcpyHostToDevice, b->ctx->stream));
+	std::vector<double> hinv((size_t)b->B * 64, 0.0);
+	for (int t = 0; t < b->B; ++t)
+		if (!invert_definite(b->S, b->th[t].h0, &hinv[(size_t)t * 64]))
+			std::fill(hinv.begin() + (size_t)t * 64, hinv.begin() + (size_t)(t + 1) * 64, 0.0); /* flat template: no update */
+	HIP_TRY(hipMemcpyAsync(b->d_h0inv, hinv.data(), sizeof(double) * hinv.size(), hipMemcpyHostToDevice, b->ctx->stream));
 	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
 	return MTFHIP_OK;
 }
@@ -1191,9 +1224,14 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 	if (sm->max_iters <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "track: max_iters must be positive");
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "track before init_template");
 	TRY(need_image(b));
-	FusedArgs fa;
-	TRY(fused_args(b, sm, fa));
 	hipStream_t st = b->ctx->stream;
+	const bool one_launch = sm->sm == MTFHIP_SM_ICLK && (sm->hess_type == 0 || (sm->hess_type == 2 && b->desc.am == MTFHIP_AM_SSD)) &&
+		b->N <= kIclkTrackMaxPix;
+	if (b->desc.am == MTFHIP_AM_NCC && !one_launch)
+		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: NCC patches larger than %d pixels need the per-function entry points", kIclkTrackMaxPix);
+	FusedArgs fa;
+	if (!one_launch) TRY(fused_args(b, sm, fa));
+	else { fa.materialize = 0; fa.mode = 2; fa.active = nullptr; }
 	std::vector<int> ones(b->B, 1);
 	std::vector<double> cr(8 * (size_t)b->B);
 	for (int t = 0; t < b->B; ++t) std::memcpy(&cr[8 * t], b->th[t].corners, sizeof(double) * 8);
@@ -1205,6 +1243,11 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 	TrackState ts{b->d_acc, b->d_h0, b->d_corners, b->d_init_corners_hm, b->d_active, b->d_iters};
 	int nblk = fused_blocks_per_target(b->N);
 	BatchView bv = b->view();
+	if (one_launch) {
+		if (b->desc.am == MTFHIP_AM_NCC) TRY(push_ncc(b));
+		TimedScope tsc(b->ctx, "iclk_track");
+		launch_iclk_track(bv, b->ctx->img, *sm, ts, b->d_h0inv, b->d_ncc, b->norm_mult, b->norm_add, st);
+	} else
 	for (int it = 0; it < sm->max_iters; ++it) {
 		{
 			TimedScope tsc(b->ctx, "fused_lk");

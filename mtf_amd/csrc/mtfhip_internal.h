@@ -118,6 +118,10 @@ struct TrackState {
 	int *active;        /* [B] 1 while the target still iterates */
 	int *n_iters;       /* [B] */
 };
+/* whole ICLK loop in one launch, one workgroup per target (N <= 16 * kBlock); false if N is too large */
+constexpr int kIclkTrackMaxPix = 16 * kBlock;
+bool launch_iclk_track(const BatchView &bv, const ImgView &im, const mtfhip_sm_desc &sm, const TrackState &ts,
+	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, hipStream_t st);
 void launch_finish_track(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, const double *partials,
 	int nblk, hipStream_t st);
 

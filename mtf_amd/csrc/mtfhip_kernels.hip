@@ -1338,6 +1338,192 @@ __global__ __launch_bounds__(64) void k_finish_track(BatchView bv, mtfhip_sm_des
 }
 
 /* ===================================================================== */
+/* one-launch inverse-compositional tracker for small patches (GridTracker) */
+/* ===================================================================== */
+/* sum of K per-thread values over the workgroup, result broadcast to every thread */
+template <int K>
+__device__ __forceinline__ void block_allsum(double *v, double *lds /* [4][K] */) {
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+	for (int k = 0; k < K; ++k)
+#pragma unroll
+		for (int m = 32; m >= 1; m >>= 1) v[k] += __shfl_xor(v[k], m);
+	__syncthreads();   /* previous round's readers are done with lds */
+	if (lane == 0) {
+#pragma unroll
+		for (int k = 0; k < K; ++k) lds[wave * K + k] = v[k];
+	}
+	__syncthreads();
+#pragma unroll
+	for (int k = 0; k < K; ++k) v[k] = (lds[k] + lds[K + k]) + (lds[2 * K + k] + lds[3 * K + k]);
+}
+
+/*
+ * nt::ICLK::update (SM/src/NT/ICLK.cc:160-299) for one patch per workgroup, all iterations inside the
+ * kernel: updatePixVals -> updateSimilarity -> updateInitGrad -> cmptInitJacobian(g, J0) ->
+ * dp = -H0^-1 g (hess_type InitialSelf: the Hessian is the constant computed by initialize) ->
+ * invertState -> compositionalUpdate -> corner-change test.  AM = SSD (SSDBase.cc:75-96,138) or NCC
+ * (NCC.cc:124-194, 236-250).  This is what GridTracker's per-patch loop (SM/src/GridTracker.cc:247-261)
+ * becomes: 256 patches = 256 workgroups, one launch per frame, no host round trips.
+ * Patch operands (grid points, I0, J0: ~35 KB for 25x25 affine) are re-read from L2 every iteration.
+ */
+template <int AM, int PPT>
+__global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im, mtfhip_sm_desc sm, TrackState ts,
+	const double *h0inv_all, const double *ncc_sc_all, double norm_mult, double norm_add) {
+	__shared__ double red[4 * 8];
+	__shared__ double sW[9], sSt[8];
+	__shared__ int sDone;
+	const int t = blockIdx.x, N = bv.N, S = bv.S, tid = threadIdx.x;
+	const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY;
+	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * N;
+	const double2 *ih = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]) + (size_t)t * N;
+	const double *iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * N;
+	const double *I0 = bv.buf[MTFHIP_BUF_I0] + (size_t)t * N;
+	const double *J0 = bv.buf[MTFHIP_BUF_J0] + (size_t)t * N * S;
+	const double *Hinv = h0inv_all + (size_t)t * 64;
+	const double m0 = AM == MTFHIP_AM_NCC ? ncc_sc_all[t * 8 + 0] : 0.0;
+	const double cn = AM == MTFHIP_AM_NCC ? ncc_sc_all[t * 8 + 1] : 1.0;
+	if (tid < 9) sW[tid] = bv.warps[9 * t + tid];
+	if (tid < 8) sSt[tid] = bv.states[8 * t + tid];
+	if (tid == 0) sDone = 0;
+	__syncthreads();
+	int n_it = 0;
+	double f_last = 0;
+	for (int it = 0; it < sm.max_iters; ++it) {
+		double W[9];
+#pragma unroll
+		for (int q = 0; q < 9; ++q) W[q] = sW[q];
+		/* ---- updatePixVals: It = sample(curr_warp * init_pts) ---- */
+		double itv[PPT], i0v[PPT];
+		double s1[1] = {0.0};
+#pragma unroll
+		for (int k = 0; k < PPT; ++k) {
+			const int i = tid + k * kBlock;
+			itv[k] = 0; i0v[k] = 0;
+			if (i < N) {
+				const double2 hp = bv.unit_z ? ip[i] : ih[i];
+				const double z = bv.unit_z ? 1.0 : iz[i];
+				double wx, wy;
+				if (hom) {
+					const double cx = W[0] * hp.x + W[1] * hp.y + W[2] * z, cy = W[3] * hp.x + W[4] * hp.y + W[5] * z;
+					const double d = W[6] * hp.x + W[7] * hp.y + W[8] * z;
+					wx = cx / d; wy = cy / d;
+				} else {
+					wx = W[0] * hp.x + W[1] * hp.y + W[2] * z; wy = W[3] * hp.x + W[4] * hp.y + W[5] * z;
+				}
+				itv[k] = norm_mult * pix_val(im, wx, wy) + norm_add;
+				i0v[k] = I0[i];
+				s1[0] += itv[k];
+			}
+		}
+		double dfv[PPT];
+		if constexpr (AM == MTFHIP_AM_NCC) {
+			/* ---- NCC::updateSimilarity + updateInitGrad ---- */
+			block_allsum<1>(s1, red);
+			const double mt = s1[0] / (double)N;
+			double s2[2] = {0.0, 0.0};
+#pragma unroll
+			for (int k = 0; k < PPT; ++k)
+				if (tid + k * kBlock < N) {
+					const double a0 = i0v[k] - m0, at = itv[k] - mt;
+					s2[0] = fma(a0, at, s2[0]); s2[1] = fma(at, at, s2[1]);
+				}
+			block_allsum<2>(s2, red);
+			const double b = sqrt(s2[1]);
+			const double f = s2[0] / (b * cn);
+			f_last = f;
+			double s3[1] = {0.0};
+#pragma unroll
+			for (int k = 0; k < PPT; ++k) {
+				dfv[k] = 0;
+				if (tid + k * kBlock < N) {
+					const double itc_b = (itv[k] - mt) / b, i0c_c = (i0v[k] - m0) / cn;
+					dfv[k] = (itc_b - f * i0c_c) / cn;
+					s3[0] += dfv[k];
+				}
+			}
+			block_allsum<1>(s3, red);
+			const double gm = s3[0] / (double)N;
+#pragma unroll
+			for (int k = 0; k < PPT; ++k) dfv[k] -= gm;
+		} else {
+			/* ---- SSD: df_dI0 = I_diff = It - I0, f = -|r|^2 / 2 ---- */
+			double s2[1] = {0.0};
+#pragma unroll
+			for (int k = 0; k < PPT; ++k) {
+				dfv[k] = (tid + k * kBlock < N) ? itv[k] - i0v[k] : 0.0;
+				s2[0] = fma(dfv[k], dfv[k], s2[0]);
+			}
+			block_allsum<1>(s2, red);
+			f_last = -s2[0] / 2;
+		}
+		/* ---- cmptInitJacobian: g = df_dI0 * J0 ---- */
+		double g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+		for (int k = 0; k < PPT; ++k) {
+			const int i = tid + k * kBlock;
+			if (i < N) {
+#pragma unroll
+				for (int s = 0; s < 8; ++s)
+					if (s < S) g[s] = fma(dfv[k], J0[(size_t)s * N + i], g[s]);
+			}
+		}
+		block_allsum<8>(g, red);
+		/* ---- solve, invert, compose, converge (thread 0) ---- */
+		if (tid == 0) {
+			double dp[8];
+			for (int r = 0; r < 8; ++r) {
+				double acc = 0;
+				if (r < S) for (int c = 0; c < S; ++c) acc += Hinv[c * S + r] * g[c];
+				dp[r] = -acc;
+			}
+			double U[9];
+			if (hom) { U[0] = 1 + dp[0]; U[1] = dp[1]; U[2] = dp[2]; U[3] = dp[3]; U[4] = 1 + dp[4]; U[5] = dp[5]; U[6] = dp[6]; U[7] = dp[7]; U[8] = 1; }
+			else { U[0] = 1 + dp[2]; U[1] = dp[3]; U[2] = dp[0]; U[3] = dp[4]; U[4] = 1 + dp[5]; U[5] = dp[1]; U[6] = 0; U[7] = 0; U[8] = 1; }
+			double c9[9];
+			c9[0] = U[4] * U[8] - U[5] * U[7]; c9[1] = U[2] * U[7] - U[1] * U[8]; c9[2] = U[1] * U[5] - U[2] * U[4];
+			c9[3] = U[5] * U[6] - U[3] * U[8]; c9[4] = U[0] * U[8] - U[2] * U[6]; c9[5] = U[2] * U[3] - U[0] * U[5];
+			c9[6] = U[3] * U[7] - U[4] * U[6]; c9[7] = U[1] * U[6] - U[0] * U[7]; c9[8] = U[0] * U[4] - U[1] * U[3];
+			const double inv_det = 1.0 / (U[0] * c9[0] + U[1] * c9[3] + U[2] * c9[6]);
+			for (int q = 0; q < 9; ++q) c9[q] *= inv_det;
+			const double n22 = c9[8];
+			for (int q = 0; q < 9; ++q) U[q] = c9[q] / n22;
+			U[0] = 1 + (U[0] - 1); U[4] = 1 + (U[4] - 1); U[8] = 1;
+			if (!hom) { U[6] = 0; U[7] = 0; }
+			double Wn[9];
+			for (int r = 0; r < 3; ++r)
+				for (int c = 0; c < 3; ++c) Wn[3 * r + c] = W[3 * r] * U[c] + W[3 * r + 1] * U[3 + c] + W[3 * r + 2] * U[6 + c];
+			if (hom) {
+				const double w22 = Wn[8];
+				for (int q = 0; q < 9; ++q) Wn[q] /= w22;
+				sSt[0] = Wn[0] - 1; sSt[1] = Wn[1]; sSt[2] = Wn[2]; sSt[3] = Wn[3]; sSt[4] = Wn[4] - 1; sSt[5] = Wn[5]; sSt[6] = Wn[6]; sSt[7] = Wn[7];
+			} else {
+				sSt[0] = Wn[2]; sSt[1] = Wn[5]; sSt[2] = Wn[0] - 1; sSt[3] = Wn[1]; sSt[4] = Wn[3]; sSt[5] = Wn[4] - 1; sSt[6] = 0; sSt[7] = 0;
+			}
+			for (int q = 0; q < 9; ++q) sW[q] = Wn[q];
+			double *cr = ts.corners + 8 * t;
+			const double *ic = ts.init_corners_hm + 12 * t;
+			double change = 0;
+			for (int q = 0; q < 4; ++q) {
+				const double X = ic[3 * q], Y = ic[3 * q + 1], Z = ic[3 * q + 2];
+				double nx = Wn[0] * X + Wn[1] * Y + Wn[2] * Z, ny = Wn[3] * X + Wn[4] * Y + Wn[5] * Z;
+				if (hom) { const double d = Wn[6] * X + Wn[7] * Y + Wn[8] * Z; nx = nx / d; ny = ny / d; }
+				const double ddx = cr[2 * q] - nx, ddy = cr[2 * q + 1] - ny;
+				change += ddx * ddx + ddy * ddy;
+				cr[2 * q] = nx; cr[2 * q + 1] = ny;
+			}
+			if (change < sm.epsilon) sDone = 1;
+		}
+		++n_it;
+		__syncthreads();
+		if (sDone) break;
+	}
+	if (tid < 9) bv.warps[9 * t + tid] = sW[tid];
+	if (tid < 8) bv.states[8 * t + tid] = sSt[tid];
+	if (tid == 0) { ts.n_iters[t] = n_it; ts.acc[(size_t)t * ACC_COUNT + ACC_RR] = f_last; }
+}
+
+/* ===================================================================== */
 /* launchers                                                              */
 /* ===================================================================== */
 static inline dim3 grid2(int nblk, int B) { return dim3((unsigned)nblk, (unsigned)B, 1); }
@@ -1472,6 +1658,26 @@ void launch_score_candidates(const BatchView &bv, const ImgView &im, const doubl
 		1.0, 0.0, dev_lik, dev_sim);
 }
 
+template <int AM>
+static bool launch_iclk_track_am(const BatchView &bv, const ImgView &im, const mtfhip_sm_desc &sm, const TrackState &ts,
+	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, hipStream_t st) {
+	const int ppt = (bv.N + kBlock - 1) / kBlock;
+#define MTFHIP_ICLK_CASE(P) hipLaunchKernelGGL((k_iclk_track<AM, P>), dim3(bv.B), dim3(kBlock), 0, st, bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add)
+	if (ppt <= 1) MTFHIP_ICLK_CASE(1);
+	else if (ppt <= 2) MTFHIP_ICLK_CASE(2);
+	else if (ppt <= 3) MTFHIP_ICLK_CASE(3);
+	else if (ppt <= 4) MTFHIP_ICLK_CASE(4);
+	else if (ppt <= 8) MTFHIP_ICLK_CASE(8);
+	else if (ppt <= 16) MTFHIP_ICLK_CASE(16);
+	else return false;
+#undef MTFHIP_ICLK_CASE
+	return true;
+}
+bool launch_iclk_track(const BatchView &bv, const ImgView &im, const mtfhip_sm_desc &sm, const TrackState &ts,
+	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, hipStream_t st) {
+	if (bv.am == MTFHIP_AM_NCC) return launch_iclk_track_am<MTFHIP_AM_NCC>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, st);
+	return launch_iclk_track_am<MTFHIP_AM_SSD>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, st);
+}
 void launch_finish_track(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, const double *partials,
 	int nblk, hipStream_t st) {
 	hipLaunchKernelGGL(k_finish_track, dim3(bv.B), dim3(64), 0, st, bv, sm, ts, partials, nblk);

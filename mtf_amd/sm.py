@@ -26,9 +26,12 @@ def _solve(H, g):
 class LKTracker:
     """One or many (B) independent targets tracked with ESM / FCLK / ICLK + SSD on one GPU."""
 
-    def __init__(self, ctx, sm, ssm=L.SSM_HOMOGRAPHY, resx=50, resy=50, n_targets=1, host_solve=True, **params):
+    def __init__(self, ctx, sm, ssm=L.SSM_HOMOGRAPHY, resx=50, resy=50, n_targets=1, host_solve=True, am=L.AM_SSD,
+                 **params):
         self.ctx = ctx
-        self.batch = Batch(ctx, L.AM_SSD, ssm, resx, resy, n_targets)
+        if am != L.AM_SSD and host_solve:
+            raise L.FunctionNotImplemented(-2, "LKTracker(host_solve=True) is SSD only; use NTSearchMethod")
+        self.batch = Batch(ctx, am, ssm, resx, resy, n_targets)
         self.B, self.S = n_targets, self.batch.S
         self.host_solve = host_solve
         self.sm = sm_desc(sm, **params)
@@ -235,6 +238,50 @@ class NTSearchMethod:
             if not active.any():
                 break
         return b.get_corners()
+
+
+class GridTracker:
+    """The patch-tracking half of GridTracker (SM/src/GridTracker.cc:247-261,345-392): grid_size x grid_size
+    independent ICLK patch trackers (default NCC + Affine, `patch_size` square patches centred on the grid
+    points of the region, dyn_patch_size = 0), all patches of a frame in ONE kernel launch.  The robust
+    SSM fit over the patch centroids (estimateWarpFromPts, RANSAC/LMS) is out of scope (SURVEY.md section 2);
+    `update` returns the per-patch corners and centroids that feed it."""
+
+    def __init__(self, ctx, grid_size=16, patch_size=25, am=L.AM_NCC, ssm=L.SSM_AFFINE, max_iters=30, epsilon=1e-4):
+        self.grid_size, self.patch_size = grid_size, patch_size
+        self.n = grid_size * grid_size
+        self.tracker = LKTracker(ctx, L.SM_ICLK, ssm, patch_size, patch_size, self.n, host_solve=False, am=am,
+                                 max_iters=max_iters, epsilon=epsilon, hess_type=0, materialize=0)
+
+    def patch_corners(self, region_corners):
+        """axis-aligned patch_size squares centred on the grid_size^2 grid points of the region
+        (GridTracker::resetTrackers :357-380 with patch_centroid_inside = 0)."""
+        c = np.asarray(region_corners, dtype=np.float64).reshape(2, 4)
+        u = np.linspace(0.0, 1.0, self.grid_size)
+        out = np.empty((self.n, 2, 4))
+        half = self.patch_size / 2.0
+        k = 0
+        for r in range(self.grid_size):
+            for q in range(self.grid_size):
+                top = c[:, 0] + (c[:, 1] - c[:, 0]) * u[q]
+                bot = c[:, 3] + (c[:, 2] - c[:, 3]) * u[q]
+                ctr = top + (bot - top) * u[r]
+                x0, y0 = ctr[0] - half, ctr[1] - half
+                out[k] = [[x0, x0 + self.patch_size, x0 + self.patch_size, x0],
+                          [y0, y0, y0 + self.patch_size, y0 + self.patch_size]]
+                k += 1
+        return out
+
+    def initialize(self, region_corners):
+        self.tracker.initialize(self.patch_corners(region_corners))
+
+    def update(self):
+        corners = self.tracker.update()
+        return corners, corners.mean(axis=2)   # utils::getCentroid miscUtils.h:473-480
+
+    @property
+    def n_iters(self):
+        return self.tracker.n_iters
 
 
 class ParticleFilter:

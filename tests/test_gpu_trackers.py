@@ -5,7 +5,7 @@ import pytest
 import mtf_amd
 from mtf_amd import _lib as L
 from mtf_amd import synth
-from mtf_amd.sm import LKTracker, NTSearchMethod, ParticleFilter
+from mtf_amd.sm import GridTracker, LKTracker, NTSearchMethod, ParticleFilter
 
 pytestmark = pytest.mark.gpu
 
@@ -137,3 +137,35 @@ def test_interface_level_sm_matches_oracle_trace(oracle, gpu_ctx, frame, case):
         gs = max(np.linalg.norm(rec["g"]), 1e-3 * np.sqrt(abs(np.trace(rec["H"]))))
         assert np.linalg.norm(got["g"][0] - rec["g"]) <= 1e-4 * gs, it
     np.testing.assert_allclose(nt.get_region()[0], otrk.get_region(), atol=2e-4)
+
+
+@pytest.mark.parametrize("am,ssm", [(L.AM_NCC, L.SSM_AFFINE), (L.AM_SSD, L.SSM_AFFINE), (L.AM_NCC, L.SSM_HOMOGRAPHY)])
+def test_grid_patch_trackers_one_launch(oracle, gpu_ctx, frame, am, ssm):
+    """Config 3 (reduced to 6x6 patches): every patch's ICLK loop runs inside one kernel launch and lands
+    where the oracle's per-patch nt::ICLK does."""
+    rng = np.random.default_rng(41)
+    centre = (256.0, 256.0)
+    region = synth.square_corners(centre[0], centre[1], 300)
+    p_true = synth.random_small_homography(rng, 0.25)
+    frame2 = synth.warp_frame(frame, p_true, centre)
+    gpu_ctx.set_image(frame)
+    gt = GridTracker(gpu_ctx, grid_size=6, patch_size=25, am=am, ssm=ssm, max_iters=30, epsilon=1e-4)
+    gt.initialize(region)
+    patches = gt.patch_corners(region)
+    gpu_ctx.set_image(frame2)
+    corners, centroids = gt.update()
+    assert corners.shape == (36, 2, 4) and centroids.shape == (36, 2)
+    for t in range(0, 36, 5):
+        o_ssm = oracle.SSM(ssm, 25, 25); o_am = oracle.AM(am, 25, 25); o_am.set_curr_img(frame)
+        trk = oracle.Tracker(L.SM_ICLK, o_am, o_ssm, leven_marq=0, max_iters=30, epsilon=1e-4, hess_type=0)
+        trk.initialize(patches[t])
+        o_am.set_curr_img(frame2)
+        iters = trk.update()
+        np.testing.assert_allclose(corners[t], trk.get_region(), atol=5e-4)
+        assert abs(int(gt.n_iters[t]) - iters) <= 1
+    # the patch centroids follow the ground-truth motion of the region
+    W = synth.homography_from_state(p_true)
+    c0 = patches.mean(axis=2) - np.array(centre)
+    q = (W @ np.vstack([c0.T, np.ones(36)]))
+    gt_c = (q[:2] / q[2]).T + np.array(centre)
+    assert np.abs(centroids - gt_c).max() < 0.25
