@@ -69,8 +69,157 @@ def cpu_baseline(seconds, res, frame0, frame1, corners):
             "sample": "%d ESM iterations of one %dx%d target in %.1f s (oracle/mtf_oracle.cpp, -O3, 1 thread)" % (iters, res, res, dt)}
 
 
+def secondary_workload(args):
+    """Secondary metrics of BASELINE.md section 3 (not the driver's headline line): config 3 grid
+    patch-iterations/s, config 4 PF candidates/s (sharded over ranks, one RCCL all-gather of the scores per
+    step = strong scaling), config 5 ESM+MI target-iterations/s (per-function entry points)."""
+    import torch
+    import mtf_amd
+    from mtf_amd import synth
+    from mtf_amd.sm import GridTracker, NTSearchMethod
+    from mtf_amd.dist import ShardedScorer
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    ctx = mtf_amd.Context(local_rank, torch.cuda.current_stream(dev).cuda_stream)
+    rng = np.random.default_rng(synth.DEFAULT_SEED + 2)
+    out = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+
+    def timed(fn):
+        for _ in range(args.warmup):
+            fn()
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tm = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            dt = float(tm.item())
+        return dt
+
+    if args.workload == "grid":
+        frame0 = synth.make_frame(1024, 1024)
+        p_true = synth.random_small_homography(rng, 0.3)
+        frame1 = synth.warp_frame(frame0, p_true, (512.0, 512.0))
+        region = synth.square_corners(512, 512, 400)
+        gt = GridTracker(ctx, grid_size=16, patch_size=25, max_iters=args.grid_iters, epsilon=-1.0)
+        ctx.set_image(frame0)
+        gt.initialize(region)
+        ctx.set_image(frame1)
+        patches = gt.patch_corners(region)
+
+        def step():
+            gt.tracker.set_region(patches)
+            gt.update()
+        dt = timed(step)
+        out.update({"metric": "grid patch-iterations/sec, GridTracker 256 patches ICLK+NCC+Affine 25x25",
+                    "value": 256 * args.grid_iters * args.steps * world / dt, "unit": "patch-iters/s",
+                    "ms_per_step": dt / args.steps * 1e3, "scaling": "weak",
+                    "config": {"workload": "256 patches x %d ICLK iterations per step, one launch per frame" % args.grid_iters}})
+        if rank == 0 and not args.no_cpu:
+            import oracle_py as O
+            ssm = O.SSM(O.SSM_AFF, 25, 25); am = O.AM(O.AM_NCC, 25, 25); am.set_curr_img(frame0)
+            trk = O.Tracker(O.SM_ICLK, am, ssm, leven_marq=0, max_iters=args.grid_iters, epsilon=-1.0, hess_type=0)
+            trk.initialize(patches[0]); am.set_curr_img(frame1)
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < args.cpu_seconds:
+                ssm.set_corners(patches[n % 256]); n += trk.update()
+            out["cpu_baseline"] = {"value": n / (time.perf_counter() - t0), "unit": "patch-iters/s", "cores": 1, "kind": "port",
+                                   "sample": "%d ICLK+NCC+Affine 25x25 patch iterations" % n}
+    elif args.workload == "pf":
+        frame0 = synth.make_frame(1024, 1024)
+        corners = synth.square_corners(512, 512, 100)
+        ctx.set_image(frame0)
+        b = mtf_amd.Batch(ctx, mtf_amd.AM_SSD, mtf_amd.SSM_HOMOGRAPHY, 50, 50, 1)
+        b.set_corners(corners[None]); b.initialize_pix_vals(); b.initialize_similarity()
+        C = args.particles
+        states = synth.pf_candidate_states(rng, C)
+        scorer = ShardedScorer(batch=b, device=dev)
+        lo, hi = mtf_amd.dist.shard_bounds(C, scorer.rank, scorer.world) if hasattr(mtf_amd, "dist") else (0, C)
+        st_dev = torch.as_tensor(states).to(dev)     # candidates resident in HBM before the timed region
+        lik = torch.empty(hi - lo, dtype=torch.float64, device=dev)
+        from mtf_amd.dist import shard_bounds, shard_sizes
+        lo, hi = shard_bounds(C, scorer.rank, scorer.world)
+        m = max(shard_sizes(C, scorer.world))
+        send = torch.zeros(m, dtype=torch.float64, device=dev)
+        recv = torch.empty(m * world, dtype=torch.float64, device=dev)
+
+        def step():
+            b.score_candidates_dev(st_dev[lo:hi].data_ptr(), hi - lo, send.data_ptr())
+            if dist is not None:
+                dist.all_gather_into_tensor(recv, send)
+        ctx.timing(True)
+        dt = timed(step)
+        kms, kn = ctx.timing_get("score_candidates")
+        out.update({"metric": "PF candidates/sec, PF+SSD+Homography 50x50, %d particles" % C,
+                    "value": C * args.steps / dt, "unit": "candidates/s", "ms_per_step": dt / args.steps * 1e3,
+                    "scaling": "strong", "config": {"workload": "%d candidates x 2500 px sharded over %d rank(s), one all-gather of scores per step" % (C, world),
+                                                    "score_kernel_ms": kms, "samples_per_s": C * 2500 * args.steps / dt}})
+        if rank == 0 and not args.no_cpu:
+            import oracle_py as O
+            ssm = O.SSM(O.SSM_HOM, 50, 50); am = O.AM(O.AM_SSD, 50, 50); am.set_curr_img(frame0)
+            ssm.set_corners(corners); am.initialize_pix_vals(ssm.get("curr_pts")); am.initialize_similarity()
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < args.cpu_seconds:
+                O.pf_score(am, ssm, states[:500]); n += 500
+            out["cpu_baseline"] = {"value": n / (time.perf_counter() - t0), "unit": "candidates/s", "cores": 1, "kind": "port",
+                                   "sample": "%d candidate evaluations of 2500 px" % n}
+    else:  # mi
+        H = W = 2048
+        frame0 = synth.make_frame(H, W)
+        p_true = synth.random_small_homography(rng, 0.3)
+        frame1 = synth.warp_frame(frame0, p_true, (W / 2.0, H / 2.0))
+        B, res = args.targets, args.res
+        half = res / 2.0 + 12
+        cx = rng.uniform(half, W - half, size=B); cy = rng.uniform(half, H - half, size=B)
+        corners = np.stack([synth.square_corners(cx[i], cy[i], float(res)) for i in range(B)])
+        ctx.set_image(frame0)
+        nt = NTSearchMethod(ctx, mtf_amd.SM_ESM, mtf_amd.AM_MI, mtf_amd.SSM_HOMOGRAPHY, res, res, B, max_iters=1,
+                            epsilon=-1.0, leven_marq=0)
+        nt.initialize(corners)
+        ctx.set_image(frame1)
+        dt = timed(nt.update)
+        out.update({"metric": "ESM+MI target-iterations/sec, %dx%d, %d targets" % (res, res, B),
+                    "value": B * args.steps * world / dt, "unit": "target-iters/s", "ms_per_step": dt / args.steps * 1e3,
+                    "scaling": "weak", "config": {"workload": "ESM+MI(8 bins)+Homography %dx%d x %d targets per GPU, per-function entry points" % (res, res, B)}})
+        if rank == 0 and not args.no_cpu:
+            import oracle_py as O
+            ssm = O.SSM(O.SSM_HOM, res, res); am = O.AM(O.AM_MI, res, res); am.set_curr_img(frame0)
+            trk = O.Tracker(O.SM_ESM, am, ssm, leven_marq=0, max_iters=2, epsilon=-1.0)
+            trk.initialize(corners[0]); am.set_curr_img(frame1)
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < args.cpu_seconds:
+                ssm.set_corners(corners[0]); n += trk.update()
+            out["cpu_baseline"] = {"value": n / (time.perf_counter() - t0), "unit": "target-iters/s", "cores": 1, "kind": "port",
+                                   "sample": "%d ESM+MI iterations of one %dx%d target" % (n, res, res)}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="lk", choices=["lk", "grid", "pf", "mi"],
+                    help="lk = the headline metric (default); the others are the secondary metrics of BASELINE.md")
+    ap.add_argument("--particles", type=int, default=10000)
+    ap.add_argument("--grid-iters", type=int, default=10)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
@@ -82,6 +231,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
+    if args.workload != "lk":
+        if args.workload == "mi" and args.res == 200 and args.targets == 64:
+            args.res, args.targets = 400, 8
+        return secondary_workload(args)
 
     import torch
     import mtf_amd

@@ -1,0 +1,111 @@
+"""ctypes view of libmtfhost.so: the C++ host layer (mtf::hip::HipAM / HipSSM adapter classes driven by
+mtf::nt::ESM / FCLK / ICLK, mtf_amd/host/*.cpp) -- the reference-language side of the drop-in boundary."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import _lib
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmtfhost.so")
+HOST_SRC = os.path.join(_HERE, "host")
+_h = None
+
+
+def build():
+    subprocess.check_call(["make", "-C", HOST_SRC, "-s", "-B"])
+    return LIB_PATH
+
+
+def lib():
+    global _h
+    if _h is None:
+        _lib.lib()   # loads libmtfhip.so (and torch's HIP runtime first, when present)
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libmtfhost.so is missing: run __graft_entry__.build()")
+        H = C.CDLL(LIB_PATH)
+        H.mtfhost_last_error.restype = C.c_char_p
+        H.mtfhost_create.restype = C.c_void_p
+        H.mtfhost_create.argtypes = [C.c_int] * 6 + [C.c_double] + [C.c_int] * 4 + [C.c_double, C.c_double, C.c_int]
+        for fn in ("mtfhost_destroy", "mtfhost_set_image", "mtfhost_initialize", "mtfhost_set_region", "mtfhost_update",
+                   "mtfhost_get_region"):
+            getattr(H, fn).argtypes = None
+        H.mtfhost_set_image.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        H.mtfhost_initialize.argtypes = [C.c_void_p, C.c_void_p]
+        H.mtfhost_set_region.argtypes = [C.c_void_p, C.c_void_p]
+        H.mtfhost_update.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        H.mtfhost_get_region.argtypes = [C.c_void_p, C.c_void_p]
+        H.mtfhost_destroy.argtypes = [C.c_void_p]
+        H.mtfhost_qr_solve.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _h = H
+    return _h
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise HostError(lib().mtfhost_last_error().decode("utf-8", "replace"))
+
+
+class CppTracker:
+    """mtf::nt::{ESM,FCLK,ICLK} over mtf::hip::{HipAM,HipSSM}; parameter names and defaults are the
+    reference's (leven_marq defaults to true as in ESMParams.cc / FCLKParams.cc / ICLKParams.cc)."""
+
+    def __init__(self, sm, am=_lib.AM_SSD, ssm=_lib.SSM_HOMOGRAPHY, resx=50, resy=50, max_iters=30, epsilon=1e-4,
+                 jac_type=1, hess_type=-1, chained_warp=1, leven_marq=1, lm_delta_init=0.01, lm_delta_update=10.0,
+                 device=0):
+        h = lib().mtfhost_create(sm, am, ssm, resx, resy, max_iters, epsilon, jac_type, hess_type, chained_warp,
+                                 leven_marq, lm_delta_init, lm_delta_update, device)
+        if not h:
+            raise HostError(lib().mtfhost_last_error().decode("utf-8", "replace"))
+        self._h = C.c_void_p(h)
+        self._img = None
+        self.iters = 0
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().mtfhost_destroy(self._h)
+            self._h = None
+
+    def set_image(self, img):
+        assert img.dtype == np.float32 and img.flags["C_CONTIGUOUS"]
+        self._img = img   # borrowed, as TrackerBase::setImage does (include/mtf/TrackerBase.h:22-26)
+        _check(lib().mtfhost_set_image(self._h, img.ctypes.data_as(C.c_void_p), img.shape[0], img.shape[1], img.shape[1]))
+
+    @staticmethod
+    def _c(corners):
+        return np.ascontiguousarray(np.asarray(corners, dtype=np.float64).reshape(2, 4).T.ravel())
+
+    def initialize(self, corners):
+        c = self._c(corners)
+        _check(lib().mtfhost_initialize(self._h, c.ctypes.data_as(C.c_void_p)))
+
+    def set_region(self, corners):
+        c = self._c(corners)
+        _check(lib().mtfhost_set_region(self._h, c.ctypes.data_as(C.c_void_p)))
+
+    def update(self):
+        n = C.c_int(0)
+        _check(lib().mtfhost_update(self._h, C.byref(n)))
+        self.iters = n.value
+        return self.get_region()
+
+    def get_region(self):
+        out = np.empty(8)
+        _check(lib().mtfhost_get_region(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out.reshape(4, 2).T.copy()
+
+
+def qr_solve(A, b):
+    A = np.asarray(A, dtype=np.float64)
+    n = A.shape[0]
+    Af = np.ascontiguousarray(A.T.ravel())
+    bb = np.ascontiguousarray(np.asarray(b, dtype=np.float64))
+    x = np.empty(n)
+    _check(lib().mtfhost_qr_solve(n, Af.ctypes.data_as(C.c_void_p), bb.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p)))
+    return x

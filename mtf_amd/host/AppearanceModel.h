@@ -1,0 +1,75 @@
+/*
+ * AppearanceModel.h -- the slice of mtf::ImageBase / mtf::AppearanceModel the search methods call, with the
+ * reference's virtual names, argument meaning and error behaviour
+ * (AM/include/mtf/AM/ImageBase.h:51-191, AM/include/mtf/AM/AppearanceModel.h:63-396).
+ */
+#ifndef MTF_AMD_HOST_APPEARANCE_MODEL_H
+#define MTF_AMD_HOST_APPEARANCE_MODEL_H
+
+#include "mtf_types.h"
+
+#define am_func_not_implemeted(func_name) \
+	throw mtf::utils::FunctonNotImplemented(name + "::" + #func_name + ":: Not implemented Yet")
+
+namespace mtf {
+
+class AppearanceModel {
+public:
+	std::string name;
+	virtual ~AppearanceModel() {}
+
+	/* ImageBase accessors (ImageBase.h:74-89) */
+	virtual unsigned int getResX() const = 0;
+	virtual unsigned int getResY() const = 0;
+	virtual unsigned int getNPix() const = 0;
+	virtual unsigned int getNChannels() const { return 1; }
+	virtual unsigned int getPatchSize() const { return getNPix(); }
+	virtual double getGradOffset() const = 0;
+	virtual const PixValT &getInitPixVals() = 0;
+	virtual const PixValT &getCurrPixVals() = 0;
+	virtual const PixGradT &getInitPixGrad() = 0;
+	virtual const PixGradT &getCurrPixGrad() = 0;
+
+	/* ImageBase modifiers / updaters (ImageBase.h:92-123) */
+	virtual void setCurrImg(const ImageView &img) = 0;
+	virtual void initializePixVals(const PtsT &init_pts) = 0;
+	virtual void initializePixGrad(const GradPtsT &warped_offset_pts, bool warped) = 0; /* overload 1: gradient of the warped image */
+	virtual void initializePixGrad(const PtsT &init_pts) = 0;                           /* overload 2: warp of the image gradient */
+	virtual void updatePixVals(const PtsT &curr_pts) = 0;
+	virtual void updatePixGrad(const GradPtsT &warped_offset_pts, bool warped) = 0;
+	virtual void updatePixGrad(const PtsT &curr_pts) = 0;
+
+	/* AppearanceModel (AppearanceModel.h:77-219) */
+	virtual int getStateSize() const { return 0; }
+	virtual double getSimilarity() const = 0;
+	virtual double getLikelihood() const { am_func_not_implemeted(getLikelihood); }
+	virtual void initializeSimilarity() { am_func_not_implemeted(initializeSimilarity); }
+	virtual void initializeGrad() { am_func_not_implemeted(initializeGrad); }
+	virtual void initializeHess() { am_func_not_implemeted(initializeHess); }
+	virtual void updateSimilarity(bool prereq_only = true) { am_func_not_implemeted(updateSimilarity); }
+	virtual void updateState(const VectorXd &) {}
+	virtual void invertState(VectorXd &, const VectorXd &) {}
+	virtual void updateInitGrad() { am_func_not_implemeted(updateInitGrad); }
+	virtual void updateCurrGrad() { am_func_not_implemeted(updateCurrGrad); }
+	virtual void cmptInitJacobian(RowVectorXd &df_dp, const MatrixXd &dI0_dpssm) = 0;
+	virtual void cmptCurrJacobian(RowVectorXd &df_dp, const MatrixXd &dIt_dpssm) = 0;
+	virtual void cmptDifferenceOfJacobians(RowVectorXd &df_dp_diff, const MatrixXd &dI0_dpssm, const MatrixXd &dIt_dpssm) = 0;
+	virtual void cmptInitHessian(MatrixXd &, const MatrixXd &) { am_func_not_implemeted(cmptInitHessian(first order)); }
+	virtual void cmptCurrHessian(MatrixXd &, const MatrixXd &) { am_func_not_implemeted(cmptCurrHessian(first order)); }
+	virtual void cmptSelfHessian(MatrixXd &, const MatrixXd &) { am_func_not_implemeted(cmptSelfHessian(first order)); }
+	virtual void cmptSumOfHessians(MatrixXd &, const MatrixXd &, const MatrixXd &) { am_func_not_implemeted(cmptSumOfHessians); }
+	/* second order variants (sec_ord_hess, off in every config): not implemented, as in the base class */
+	virtual void cmptInitHessian(MatrixXd &, const MatrixXd &, const MatrixXd &) { am_func_not_implemeted(cmptInitHessian(second order)); }
+	virtual void cmptCurrHessian(MatrixXd &, const MatrixXd &, const MatrixXd &) { am_func_not_implemeted(cmptCurrHessian(second order)); }
+	virtual void cmptSelfHessian(MatrixXd &, const MatrixXd &, const MatrixXd &) { am_func_not_implemeted(cmptSelfHessian(second order)); }
+
+	virtual void setFirstIter() { first_iter = true; }
+	virtual void clearFirstIter() { first_iter = false; }
+	virtual void clearInitStatus() = 0;
+	virtual bool isSymmetrical() const { return true; }
+protected:
+	bool first_iter = false;
+};
+
+} // namespace mtf
+#endif

@@ -1,0 +1,160 @@
+#include "HipModels.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace mtf {
+namespace hip {
+
+void HipPair::check(int rc) {
+	if (rc == MTFHIP_OK) return;
+	const std::string msg = mtfhip_last_error();
+	switch (rc) {
+	case MTFHIP_ERR_INVALID_ARG: throw utils::InvalidArgument(msg);
+	case MTFHIP_ERR_NOT_IMPLEMENTED: throw utils::FunctonNotImplemented(msg);
+	case MTFHIP_ERR_LOGIC: throw utils::LogicError(msg);
+	default: throw utils::Exception(msg);
+	}
+}
+
+HipPair::HipPair(int _am, int _ssm, int _resx, int _resy, double _grad_eps, double likelihood_alpha, int mi_n_bins,
+	double mi_pre_seed, int mi_pou, int device, void *stream) :
+	am(_am), ssm(_ssm), resx(_resx), resy(_resy), N(_resx * _resy), S(_ssm == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6),
+	grad_eps(_grad_eps) {
+	if (resx <= 0 || resy <= 0) throw utils::InvalidArgument("ImageBase::Invalid sampling resolution provided"); /* ImageBase.cc:33-35 */
+	check(mtfhip_ctx_create(device, stream, &ctx));
+	mtfhip_patch_desc d{am, ssm, resx, resy, grad_eps, likelihood_alpha, mi_n_bins, mi_pre_seed, mi_pou};
+	int rc = mtfhip_batch_create(ctx, &d, 1, &b);
+	if (rc != MTFHIP_OK) { const std::string msg = mtfhip_last_error(); mtfhip_ctx_destroy(ctx); ctx = nullptr; throw utils::Exception(msg); }
+}
+HipPair::~HipPair() {
+	if (b) mtfhip_batch_destroy(b);
+	if (ctx) mtfhip_ctx_destroy(ctx);
+}
+/* the SM owns its N x S Jacobians (SM/include/mtf/SM/ESM.h:40-49) and passes them by reference: the first
+ * matrix an SSM writes becomes J0, the second JT, the third JM */
+int HipPair::jacobianBuffer(const MatrixXd &J, bool may_register) {
+	auto it = jac_keys.find(J.data());
+	if (it != jac_keys.end()) return it->second;
+	if (!may_register) throw utils::LogicError("pixel Jacobian passed to the AM was not produced by the paired SSM");
+	static const int order[3] = {MTFHIP_BUF_J0, MTFHIP_BUF_JT, MTFHIP_BUF_JM};
+	if (next_jac >= 3) throw utils::LogicError("more than three distinct pixel Jacobians in flight");
+	int id = order[next_jac++];
+	jac_keys[J.data()] = id;
+	return id;
+}
+
+/* ------------------------------------------------------------------ AM */
+HipAM::HipAM(std::shared_ptr<HipPair> pair) : p(pair) {
+	name = p->am == MTFHIP_AM_SSD ? "ssd" : (p->am == MTFHIP_AM_NCC ? "ncc" : "mi");
+	I0.resize(p->N); It.resize(p->N);
+	dI0_dx.resize(p->N, 2); dIt_dx.resize(p->N, 2);
+	p->init_grad_key = dI0_dx.data();
+	p->curr_grad_key = dIt_dx.data();
+}
+const double *HipAM::ptsArg(const PtsT &pts) const { return pts.data() == p->pts_key ? nullptr : pts.data(); }
+const double *HipAM::gradPtsArg(const GradPtsT &pts) const { return pts.data() == p->grad_pts_key ? nullptr : pts.data(); }
+
+/* ImageBase::setCurrImg AM/src/ImageBase.cc:38-60: the buffer is borrowed and overwritten in place by the
+ * caller every frame, so the device copy is refreshed here and again on setFirstIter() */
+void HipAM::setCurrImg(const ImageView &im) {
+	if (!im.data) throw utils::InvalidArgument("ImageBase::Input image is empty");
+	img = im;
+	HipPair::check(mtfhip_image_upload(p->ctx, im.data, im.rows, im.cols, im.step));
+}
+void HipAM::setFirstIter() {
+	first_iter = true;
+	if (img.data) HipPair::check(mtfhip_image_upload(p->ctx, img.data, img.rows, img.cols, img.step));
+}
+const PixValT &HipAM::getInitPixVals() { HipPair::check(mtfhip_batch_read(p->b, MTFHIP_BUF_I0, I0.data())); return I0; }
+const PixValT &HipAM::getCurrPixVals() { HipPair::check(mtfhip_batch_read(p->b, MTFHIP_BUF_IT, It.data())); return It; }
+void HipAM::syncPixGrad() {
+	HipPair::check(mtfhip_batch_read(p->b, MTFHIP_BUF_DI0_DX, dI0_dx.data()));
+	HipPair::check(mtfhip_batch_read(p->b, MTFHIP_BUF_DIT_DX, dIt_dx.data()));
+}
+void HipAM::initializePixVals(const PtsT &pts) { HipPair::check(mtfhip_am_initialize_pix_vals(p->b, ptsArg(pts))); }
+void HipAM::updatePixVals(const PtsT &pts) { HipPair::check(mtfhip_am_update_pix_vals(p->b, ptsArg(pts))); }
+void HipAM::initializePixGrad(const PtsT &pts) { HipPair::check(mtfhip_am_initialize_pix_grad(p->b, ptsArg(pts))); }
+void HipAM::updatePixGrad(const PtsT &pts) { HipPair::check(mtfhip_am_update_pix_grad(p->b, ptsArg(pts))); }
+void HipAM::initializePixGrad(const GradPtsT &gp, bool) { HipPair::check(mtfhip_am_initialize_pix_grad_warped(p->b, gradPtsArg(gp))); }
+void HipAM::updatePixGrad(const GradPtsT &gp, bool) { HipPair::check(mtfhip_am_update_pix_grad_warped(p->b, gradPtsArg(gp))); }
+
+double HipAM::getLikelihood() const { double l = 0; HipPair::check(mtfhip_am_get_likelihood(p->b, &l)); return l; }
+void HipAM::initializeSimilarity() {
+	HipPair::check(mtfhip_am_initialize_similarity(p->b));
+	HipPair::check(mtfhip_am_get_similarity(p->b, &f));
+}
+void HipAM::initializeGrad() { HipPair::check(mtfhip_am_initialize_grad(p->b)); }
+void HipAM::initializeHess() { HipPair::check(mtfhip_am_initialize_hess(p->b)); }
+void HipAM::updateSimilarity(bool prereq_only) {
+	HipPair::check(mtfhip_am_update_similarity(p->b, prereq_only ? 1 : 0));
+	if (!prereq_only) HipPair::check(mtfhip_am_get_similarity(p->b, &f));
+}
+void HipAM::updateInitGrad() { HipPair::check(mtfhip_am_update_init_grad(p->b)); }
+void HipAM::updateCurrGrad() { HipPair::check(mtfhip_am_update_curr_grad(p->b)); }
+
+void HipAM::cmptInitJacobian(RowVectorXd &g, const MatrixXd &J0) {
+	HipPair::check(mtfhip_am_cmpt_init_jacobian(p->b, p->jacobianBuffer(J0, false), g.data()));
+}
+void HipAM::cmptCurrJacobian(RowVectorXd &g, const MatrixXd &Jt) {
+	HipPair::check(mtfhip_am_cmpt_curr_jacobian(p->b, p->jacobianBuffer(Jt, false), g.data()));
+}
+void HipAM::cmptDifferenceOfJacobians(RowVectorXd &g, const MatrixXd &J0, const MatrixXd &Jt) {
+	HipPair::check(mtfhip_am_cmpt_difference_of_jacobians(p->b, p->jacobianBuffer(J0, false), p->jacobianBuffer(Jt, false), g.data()));
+}
+void HipAM::cmptInitHessian(MatrixXd &H, const MatrixXd &J0) {
+	HipPair::check(mtfhip_am_cmpt_init_hessian(p->b, p->jacobianBuffer(J0, false), H.data()));
+}
+void HipAM::cmptCurrHessian(MatrixXd &H, const MatrixXd &Jt) {
+	HipPair::check(mtfhip_am_cmpt_curr_hessian(p->b, p->jacobianBuffer(Jt, false), H.data()));
+}
+void HipAM::cmptSelfHessian(MatrixXd &H, const MatrixXd &Jt) {
+	HipPair::check(mtfhip_am_cmpt_self_hessian(p->b, p->jacobianBuffer(Jt, false), H.data()));
+}
+void HipAM::cmptSumOfHessians(MatrixXd &H, const MatrixXd &J0, const MatrixXd &Jt) {
+	HipPair::check(mtfhip_am_cmpt_sum_of_hessians(p->b, p->jacobianBuffer(J0, false), p->jacobianBuffer(Jt, false), H.data()));
+}
+
+/* ------------------------------------------------------------------ SSM */
+HipSSM::HipSSM(std::shared_ptr<HipPair> pair) : p(pair) {
+	name = p->ssm == MTFHIP_SSM_HOMOGRAPHY ? "homography" : "affine";
+	curr_pts.resize(2, p->N);
+	grad_pts.resize(8, p->N);
+	curr_state.resize(p->S);
+	std::memset(curr_corners.v, 0, sizeof(curr_corners.v));
+	p->pts_key = curr_pts.data();
+	p->grad_pts_key = grad_pts.data();
+}
+void HipSSM::syncSmall() {
+	HipPair::check(mtfhip_ssm_get_corners(p->b, curr_corners.data()));
+	HipPair::check(mtfhip_ssm_get_state(p->b, curr_state.data()));
+}
+void HipSSM::syncPts() { HipPair::check(mtfhip_batch_read(p->b, MTFHIP_BUF_CURR_PTS, curr_pts.data())); }
+void HipSSM::setCorners(const CornersT &c) { HipPair::check(mtfhip_ssm_set_corners(p->b, c.data())); syncSmall(); }
+void HipSSM::setState(const VectorXd &s) {
+	if (s.size() != p->S) throw utils::InvalidArgument("setState: state has invalid size");   /* validate_ssm_state */
+	HipPair::check(mtfhip_ssm_set_state(p->b, s.data())); syncSmall();
+}
+void HipSSM::compositionalUpdate(const VectorXd &dp) {
+	if (dp.size() != p->S) throw utils::InvalidArgument("compositionalUpdate: state update has invalid size");
+	HipPair::check(mtfhip_ssm_compositional_update(p->b, dp.data())); syncSmall();
+}
+void HipSSM::updateGradPts(double eps) { HipPair::check(mtfhip_ssm_update_grad_pts(p->b, eps)); }
+void HipSSM::invertState(VectorXd &inv, const VectorXd &s) { HipPair::check(mtfhip_ssm_invert_state(p->b, s.data(), inv.data())); }
+void HipSSM::applyWarpToCorners(CornersT &out, const CornersT &in, const VectorXd &s) {
+	HipPair::check(mtfhip_ssm_apply_warp_to_corners(p->b, in.data(), s.data(), out.data()));
+}
+void HipSSM::jac(int variant, MatrixXd &J, const PixGradT &g) {
+	if (J.rows() != p->N || J.cols() != p->S) throw utils::InvalidArgument("pixel Jacobian has invalid size");   /* validate_ssm_jacobian */
+	int grad_buf;
+	if (g.data() == p->init_grad_key) grad_buf = MTFHIP_BUF_DI0_DX;
+	else if (g.data() == p->curr_grad_key) grad_buf = MTFHIP_BUF_DIT_DX;
+	else {   /* a foreign gradient: upload it into the current-gradient buffer */
+		HipPair::check(mtfhip_batch_write(p->b, MTFHIP_BUF_DIT_DX, g.data()));
+		grad_buf = MTFHIP_BUF_DIT_DX;
+	}
+	HipPair::check(mtfhip_ssm_cmpt_pix_jacobian(p->b, variant, grad_buf, p->jacobianBuffer(J, true)));
+}
+
+} // namespace hip
+} // namespace mtf

@@ -1,0 +1,123 @@
+/*
+ * HipModels.h -- AppearanceModel / StateSpaceModel subclasses whose data lives in HBM behind the C ABI
+ * (include/mtfhip.h).  One HipPair (context + a batch of one target) is shared by the AM and the SSM of
+ * a tracker.  References the two objects hand each other through the search method (PtsT, GradPtsT,
+ * PixGradT, the SM-owned N x S Jacobians) are recognised BY ADDRESS: the bytes stay on the device and the
+ * host objects are only keys; anything else is uploaded.  Host mirrors behind the getters are refreshed
+ * lazily, when somebody actually asks ("host-resident interface vs device-resident data").
+ */
+#ifndef MTF_AMD_HOST_HIP_MODELS_H
+#define MTF_AMD_HOST_HIP_MODELS_H
+
+#include <map>
+#include <memory>
+
+#include "AppearanceModel.h"
+#include "StateSpaceModel.h"
+#include "../../include/mtfhip.h"
+
+namespace mtf {
+namespace hip {
+
+struct HipPair {
+	mtfhip_ctx *ctx = nullptr;
+	mtfhip_batch *b = nullptr;
+	int am, ssm, resx, resy, N, S;
+	double grad_eps;
+	/* addresses of host mirrors whose authoritative copy is a device buffer */
+	const void *pts_key = nullptr, *grad_pts_key = nullptr, *init_grad_key = nullptr, *curr_grad_key = nullptr;
+	std::map<const void *, int> jac_keys;   /* SM-owned Jacobian matrices -> MTFHIP_BUF_J0 / _JT / _JM */
+	int next_jac = 0;
+
+	HipPair(int am, int ssm, int resx, int resy, double grad_eps, double likelihood_alpha, int mi_n_bins,
+		double mi_pre_seed, int mi_pou, int device, void *stream);
+	~HipPair();
+	static void check(int rc);               /* rethrows C-ABI failures as mtf::utils::Exception */
+	int jacobianBuffer(const MatrixXd &J, bool may_register);
+};
+
+class HipAM : public AppearanceModel {
+public:
+	HipAM(std::shared_ptr<HipPair> pair);
+	unsigned int getResX() const override { return p->resx; }
+	unsigned int getResY() const override { return p->resy; }
+	unsigned int getNPix() const override { return p->N; }
+	double getGradOffset() const override { return p->grad_eps; }
+	const PixValT &getInitPixVals() override;
+	const PixValT &getCurrPixVals() override;
+	const PixGradT &getInitPixGrad() override { return dI0_dx; }   /* key only; bytes on the device */
+	const PixGradT &getCurrPixGrad() override { return dIt_dx; }
+	void syncPixGrad();                                               /* explicit read-back of both gradients */
+
+	void setCurrImg(const ImageView &img) override;
+	void initializePixVals(const PtsT &init_pts) override;
+	void initializePixGrad(const GradPtsT &warped_offset_pts, bool warped) override;
+	void initializePixGrad(const PtsT &init_pts) override;
+	void updatePixVals(const PtsT &curr_pts) override;
+	void updatePixGrad(const GradPtsT &warped_offset_pts, bool warped) override;
+	void updatePixGrad(const PtsT &curr_pts) override;
+
+	double getSimilarity() const override { return f; }
+	double getLikelihood() const override;
+	void initializeSimilarity() override;
+	void initializeGrad() override;
+	void initializeHess() override;
+	void updateSimilarity(bool prereq_only = true) override;
+	void updateInitGrad() override;
+	void updateCurrGrad() override;
+	void cmptInitJacobian(RowVectorXd &df_dp, const MatrixXd &dI0_dpssm) override;
+	void cmptCurrJacobian(RowVectorXd &df_dp, const MatrixXd &dIt_dpssm) override;
+	void cmptDifferenceOfJacobians(RowVectorXd &df_dp_diff, const MatrixXd &dI0_dpssm, const MatrixXd &dIt_dpssm) override;
+	void cmptInitHessian(MatrixXd &H, const MatrixXd &dI0_dpssm) override;
+	void cmptCurrHessian(MatrixXd &H, const MatrixXd &dIt_dpssm) override;
+	void cmptSelfHessian(MatrixXd &H, const MatrixXd &dIt_dpssm) override;
+	void cmptSumOfHessians(MatrixXd &H, const MatrixXd &dI0_dpssm, const MatrixXd &dIt_dpssm) override;
+	void setFirstIter() override;
+	void clearInitStatus() override {}
+private:
+	std::shared_ptr<HipPair> p;
+	ImageView img{nullptr, 0, 0, 0};
+	double f = 0;
+	PixValT I0, It;
+	PixGradT dI0_dx, dIt_dx;
+	const double *ptsArg(const PtsT &pts) const;
+	const double *gradPtsArg(const GradPtsT &pts) const;
+	static void colMajorToHost(MatrixXd &H, const double *src, int S);
+};
+
+class HipSSM : public StateSpaceModel {
+public:
+	HipSSM(std::shared_ptr<HipPair> pair);
+	unsigned int getStateSize() override { return p->S; }
+	unsigned int getResX() override { return p->resx; }
+	unsigned int getResY() override { return p->resy; }
+	unsigned int getNPts() override { return p->N; }
+	const PtsT &getPts() override { return curr_pts; }            /* key only; syncPts() refreshes the bytes */
+	const GradPtsT &getGradPts() override { return grad_pts; }
+	const CornersT &getCorners() override { return curr_corners; }
+	const VectorXd &getState() override { return curr_state; }
+	void syncPts();
+
+	void setState(const VectorXd &ssm_state) override;
+	void setCorners(const CornersT &corners) override;
+	void compositionalUpdate(const VectorXd &state_update) override;
+	void updateGradPts(double grad_eps) override;
+	void invertState(VectorXd &inv_state, const VectorXd &state) override;
+	void cmptInitPixJacobian(MatrixXd &J, const PixGradT &g) override { jac(MTFHIP_JAC_INIT, J, g); }
+	void cmptPixJacobian(MatrixXd &J, const PixGradT &g) override { jac(MTFHIP_JAC_PIX, J, g); }
+	void cmptWarpedPixJacobian(MatrixXd &J, const PixGradT &g) override { jac(MTFHIP_JAC_WARPED, J, g); }
+	void cmptApproxPixJacobian(MatrixXd &J, const PixGradT &g) override { jac(MTFHIP_JAC_APPROX, J, g); }
+	void applyWarpToCorners(CornersT &out, const CornersT &in, const VectorXd &state) override;
+private:
+	std::shared_ptr<HipPair> p;
+	PtsT curr_pts;
+	GradPtsT grad_pts;
+	CornersT curr_corners;
+	VectorXd curr_state;
+	void syncSmall();
+	void jac(int variant, MatrixXd &J, const PixGradT &g);
+};
+
+} // namespace hip
+} // namespace mtf
+#endif

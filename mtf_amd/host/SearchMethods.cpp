@@ -1,0 +1,301 @@
+#include "SearchMethods.h"
+
+#include <cmath>
+
+namespace mtf {
+
+/* column-pivoted Householder QR solve, the algorithm behind Eigen's ColPivHouseholderQR::solve */
+void utils::colPivHouseholderQrSolve(const MatrixXd &Ain, const VectorXd &b, VectorXd &x) {
+	const int n = Ain.rows();
+	if (Ain.cols() != n || b.size() != n) throw InvalidArgument("colPivHouseholderQrSolve: size mismatch");
+	MatrixXd A = Ain;
+	std::vector<double> rhs(b.data(), b.data() + n), v(n);
+	std::vector<int> perm(n);
+	for (int j = 0; j < n; ++j) perm[j] = j;
+	int rank = n;
+	for (int k = 0; k < n; ++k) {
+		int piv = k;
+		double best = -1;
+		for (int j = k; j < n; ++j) {
+			double s = 0;
+			for (int i = k; i < n; ++i) s += A(i, j) * A(i, j);
+			if (s > best) { best = s; piv = j; }
+		}
+		if (best <= 0) { rank = k; break; }
+		if (piv != k) {
+			for (int i = 0; i < n; ++i) std::swap(A(i, piv), A(i, k));
+			std::swap(perm[piv], perm[k]);
+		}
+		const double norm = std::sqrt(best);
+		const double alpha = A(k, k) > 0 ? -norm : norm;
+		double vnorm2 = 0;
+		for (int i = k; i < n; ++i) { v[i] = A(i, k); if (i == k) v[i] -= alpha; vnorm2 += v[i] * v[i]; }
+		if (vnorm2 > 0) {
+			for (int j = k; j < n; ++j) {
+				double dot = 0;
+				for (int i = k; i < n; ++i) dot += v[i] * A(i, j);
+				const double f = 2 * dot / vnorm2;
+				for (int i = k; i < n; ++i) A(i, j) -= f * v[i];
+			}
+			double dot = 0;
+			for (int i = k; i < n; ++i) dot += v[i] * rhs[i];
+			const double f = 2 * dot / vnorm2;
+			for (int i = k; i < n; ++i) rhs[i] -= f * v[i];
+		}
+	}
+	std::vector<double> y(n, 0.0);
+	for (int k = rank - 1; k >= 0; --k) {
+		double s = rhs[k];
+		for (int j = k + 1; j < rank; ++j) s -= A(k, j) * y[j];
+		y[k] = s / A(k, k);
+	}
+	x.resize(n);
+	for (int k = 0; k < n; ++k) x[perm[k]] = y[k];
+}
+
+namespace nt {
+
+SearchMethod::SearchMethod(AM _am, SSM _ssm, const SMParams &_params) : am(_am), ssm(_ssm), params(_params) {
+	ssm_state_size = (int)ssm->getStateSize();
+	const int n = (int)am->getPatchSize();
+	init_pix_jacobian.resize(n, ssm_state_size);
+	curr_pix_jacobian.resize(n, ssm_state_size);
+	jacobian.resize(ssm_state_size);
+	hessian.resize(ssm_state_size, ssm_state_size);
+	init_self_hessian.resize(ssm_state_size, ssm_state_size);
+	state_update.resize(ssm_state_size);
+	inv_update.resize(ssm_state_size);
+	if (params.sec_ord_hess)
+		throw utils::FunctonNotImplemented("second order Hessians are not available (sec_ord_hess is 0 in every shipped config)");
+}
+
+/* ESM::initializePixJacobian NT/ESM.cc:379-388 (same shape in FCLK :113-133 and ICLK :78-95) */
+void SearchMethod::initPixJacobian(MatrixXd &J) {
+	if (params.chained_warp) {
+		am->initializePixGrad(ssm->getPts());
+		ssm->cmptWarpedPixJacobian(J, am->getInitPixGrad());
+	} else {
+		ssm->initializeGradPts(am->getGradOffset());
+		am->initializePixGrad(ssm->getGradPts(), true);
+		ssm->cmptInitPixJacobian(J, am->getInitPixGrad());
+	}
+}
+/* ESM::updatePixJacobian NT/ESM.cc:390-408 */
+void SearchMethod::updatePixJacobian(MatrixXd &J) {
+	if (params.chained_warp) {
+		am->updatePixGrad(ssm->getPts());
+		ssm->cmptWarpedPixJacobian(J, am->getCurrPixGrad());
+	} else {
+		ssm->updateGradPts(am->getGradOffset());
+		am->updatePixGrad(ssm->getGradPts(), true);
+		ssm->cmptInitPixJacobian(J, am->getCurrPixGrad());
+	}
+}
+void SearchMethod::dampAndSolve(double delta) {
+	if (params.leven_marq)
+		for (int i = 0; i < ssm_state_size; ++i) hessian(i, i) += delta * hessian(i, i);
+	utils::colPivHouseholderQrSolve(hessian, jacobian, state_update);
+	for (int i = 0; i < ssm_state_size; ++i) state_update[i] = -state_update[i];
+}
+
+/* ------------------------------------------------------------------ ESM */
+ESM::ESM(AM a, SSM s, const SMParams &p) : SearchMethod(a, s, p) {
+	name = "esm_nt";
+	if (params.hess_type < 0) params.hess_type = SumOfSelf;
+	if (params.jac_type == 0 || params.hess_type == Original) mean_pix_jacobian.resize((int)am->getPatchSize(), ssm_state_size);
+}
+void ESM::initialize(const CornersT &corners) {
+	am->clearInitStatus(); ssm->clearInitStatus();
+	ssm->initialize(corners, am->getNChannels());
+	am->initializePixVals(ssm->getPts());
+	initPixJacobian(init_pix_jacobian);
+	am->initializeSimilarity(); am->initializeGrad(); am->initializeHess();
+	if (params.hess_type == InitialSelf || params.hess_type == SumOfSelf) {
+		am->cmptSelfHessian(hessian, init_pix_jacobian);
+		init_self_hessian = hessian;
+	}
+}
+void ESM::setRegion(const CornersT &corners) {
+	ssm->setCorners(corners);
+	ssm->cmptInitPixJacobian(init_pix_jacobian, am->getInitPixGrad());
+	if (params.hess_type == InitialSelf || params.hess_type == SumOfSelf) {
+		am->cmptSelfHessian(hessian, init_pix_jacobian);
+		init_self_hessian = hessian;
+	}
+}
+void ESM::update() {
+	double prev_similarity = 0, leven_marq_delta = params.lm_delta_init;
+	bool state_reset = false;
+	iters_done = 0;
+	am->setFirstIter();
+	for (int iter_id = 0; iter_id < params.max_iters; ++iter_id) {
+		++iters_done;
+		am->updatePixVals(ssm->getPts());
+		am->updateSimilarity(false);
+		if (params.leven_marq && !state_reset) {
+			const double curr_similarity = am->getSimilarity();
+			if (iter_id > 0) {
+				if (curr_similarity < prev_similarity) {
+					leven_marq_delta *= params.lm_delta_update;
+					ssm->invertState(inv_update, state_update);
+					ssm->compositionalUpdate(inv_update);
+					state_reset = true;
+					continue;
+				}
+				if (curr_similarity > prev_similarity) leven_marq_delta /= params.lm_delta_update;
+			}
+			prev_similarity = curr_similarity;
+		}
+		state_reset = false;
+		updatePixJacobian(curr_pix_jacobian);
+		if (params.jac_type == 0 || params.hess_type == Original)
+			throw utils::FunctonNotImplemented("ESM jac_type/hess_type Original needs the SM-side mean Jacobian on the host; "
+				"use mtfhip_sm_mean_jacobian through the C ABI (see INTEGRATION.md, sync policy)");
+		am->updateCurrGrad();
+		am->updateInitGrad();
+		am->cmptDifferenceOfJacobians(jacobian, init_pix_jacobian, curr_pix_jacobian);
+		for (int i = 0; i < ssm_state_size; ++i) jacobian[i] *= 0.5;
+		switch (params.hess_type) {
+		case InitialSelf: if (params.leven_marq) hessian = init_self_hessian; break;
+		case SumOfStd:
+			am->cmptSumOfHessians(hessian, init_pix_jacobian, curr_pix_jacobian);
+			for (int i = 0; i < ssm_state_size; ++i) for (int j = 0; j < ssm_state_size; ++j) hessian(i, j) *= 0.5;
+			break;
+		case SumOfSelf:
+			am->cmptSelfHessian(hessian, curr_pix_jacobian);
+			for (int i = 0; i < ssm_state_size; ++i) for (int j = 0; j < ssm_state_size; ++j) hessian(i, j) = (hessian(i, j) + init_self_hessian(i, j)) * 0.5;
+			break;
+		case CurrentSelf: am->cmptSelfHessian(hessian, curr_pix_jacobian); break;
+		default: am->cmptCurrHessian(hessian, curr_pix_jacobian); break;
+		}
+		dampAndSolve(leven_marq_delta);
+		prev_corners = ssm->getCorners();
+		ssm->compositionalUpdate(state_update);
+		const double update_norm = prev_corners.squaredDistance(ssm->getCorners());
+		if (update_norm < params.epsilon) break;
+		am->clearFirstIter();
+	}
+}
+
+/* ------------------------------------------------------------------ FCLK */
+FCLK::FCLK(AM a, SSM s, const SMParams &p) : SearchMethod(a, s, p) {
+	name = "fclk_nt";
+	if (params.hess_type < 0) params.hess_type = CurrentSelf;
+}
+void FCLK::initialize(const CornersT &corners) {
+	am->clearInitStatus(); ssm->clearInitStatus();
+	ssm->initialize(corners, am->getNChannels());
+	am->initializePixVals(ssm->getPts());
+	am->initializeSimilarity(); am->initializeGrad(); am->initializeHess();
+	if (params.hess_type == InitialSelf) {
+		initPixJacobian(init_pix_jacobian);
+		am->cmptSelfHessian(hessian, init_pix_jacobian);
+		if (params.leven_marq) init_self_hessian = hessian;
+	} else if (params.chained_warp) am->initializePixGrad(ssm->getPts());
+	else { ssm->initializeGradPts(am->getGradOffset()); am->initializePixGrad(ssm->getGradPts(), true); }
+}
+void FCLK::update() {
+	double prev_similarity = 0, leven_marq_delta = params.lm_delta_init;
+	bool state_reset = false;
+	iters_done = 0;
+	am->setFirstIter();
+	int iter_id = 0;
+	while (iter_id < params.max_iters) {
+		++iters_done;
+		am->updatePixVals(ssm->getPts());
+		am->updateSimilarity(false);
+		if (params.leven_marq && !state_reset) {
+			const double curr_similarity = am->getSimilarity();
+			if (iter_id > 0) {
+				if (curr_similarity < prev_similarity) {
+					leven_marq_delta *= params.lm_delta_update;
+					ssm->invertState(inv_update, state_update);
+					ssm->compositionalUpdate(inv_update);
+					state_reset = true;
+					continue;
+				}
+				if (curr_similarity > prev_similarity) leven_marq_delta /= params.lm_delta_update;
+			}
+			prev_similarity = curr_similarity;
+		}
+		state_reset = false;
+		am->updateCurrGrad();
+		updatePixJacobian(curr_pix_jacobian);
+		am->cmptCurrJacobian(jacobian, curr_pix_jacobian);
+		switch (params.hess_type) {
+		case InitialSelf: if (params.leven_marq) hessian = init_self_hessian; break;
+		case CurrentSelf: am->cmptSelfHessian(hessian, curr_pix_jacobian); break;
+		default: am->cmptCurrHessian(hessian, curr_pix_jacobian); break;
+		}
+		dampAndSolve(leven_marq_delta);
+		prev_corners = ssm->getCorners();
+		ssm->compositionalUpdate(state_update);
+		const double update_norm = prev_corners.squaredDistance(ssm->getCorners());
+		if (update_norm < params.epsilon) break;
+		am->clearFirstIter();
+		++iter_id;
+	}
+}
+
+/* ------------------------------------------------------------------ ICLK */
+ICLK::ICLK(AM a, SSM s, const SMParams &p) : SearchMethod(a, s, p) {
+	name = "iclk_nt";
+	if (params.hess_type < 0) params.hess_type = InitialSelf;
+}
+void ICLK::initialize(const CornersT &corners) {
+	am->clearInitStatus(); ssm->clearInitStatus();
+	ssm->initialize(corners, am->getNChannels());
+	am->initializePixVals(ssm->getPts());
+	initPixJacobian(init_pix_jacobian);
+	am->initializeSimilarity(); am->initializeGrad(); am->initializeHess();
+	am->cmptInitJacobian(jacobian, init_pix_jacobian);
+	if (params.hess_type == InitialSelf) {
+		am->cmptSelfHessian(hessian, init_pix_jacobian);
+		if (params.leven_marq) init_self_hessian = hessian;
+	}
+}
+void ICLK::update() {
+	double prev_similarity = 0, leven_marq_delta = params.lm_delta_init;
+	bool state_reset = false;
+	iters_done = 0;
+	am->setFirstIter();
+	for (int iter_id = 0; iter_id < params.max_iters; ++iter_id) {
+		++iters_done;
+		am->updatePixVals(ssm->getPts());
+		am->updateSimilarity(false);
+		if (params.leven_marq && !state_reset) {
+			const double curr_similarity = am->getSimilarity();
+			if (iter_id > 0) {
+				if (curr_similarity < prev_similarity) {
+					leven_marq_delta *= params.lm_delta_update;
+					ssm->compositionalUpdate(state_update);   /* undo of the inverse update, NT/ICLK.cc:188 */
+					state_reset = true;
+					continue;
+				}
+				if (curr_similarity > prev_similarity) leven_marq_delta /= params.lm_delta_update;
+			}
+			prev_similarity = curr_similarity;
+		}
+		state_reset = false;
+		am->updateInitGrad();
+		am->cmptInitJacobian(jacobian, init_pix_jacobian);
+		switch (params.hess_type) {
+		case InitialSelf: if (params.leven_marq) hessian = init_self_hessian; break;
+		case CurrentSelf:
+			updatePixJacobian(curr_pix_jacobian);
+			am->cmptSelfHessian(hessian, curr_pix_jacobian);
+			break;
+		default: am->cmptInitHessian(hessian, init_pix_jacobian); break;
+		}
+		dampAndSolve(leven_marq_delta);
+		prev_corners = ssm->getCorners();
+		ssm->invertState(inv_update, state_update);
+		ssm->compositionalUpdate(inv_update);
+		const double update_norm = prev_corners.squaredDistance(ssm->getCorners());
+		if (update_norm < params.epsilon) break;
+		am->clearFirstIter();
+	}
+}
+
+} // namespace nt
+} // namespace mtf

@@ -1,0 +1,52 @@
+/*
+ * StateSpaceModel.h -- the slice of mtf::StateSpaceModel the search methods call
+ * (SSM/include/mtf/SSM/StateSpaceModel.h:49-408), same names, argument meaning and error behaviour.
+ */
+#ifndef MTF_AMD_HOST_STATE_SPACE_MODEL_H
+#define MTF_AMD_HOST_STATE_SPACE_MODEL_H
+
+#include "mtf_types.h"
+
+#define ssm_func_not_implemeted(func_name) \
+	throw mtf::utils::FunctonNotImplemented(name + "::" + #func_name + ":: Not implemented Yet")
+
+namespace mtf {
+
+class StateSpaceModel {
+public:
+	std::string name;
+	virtual ~StateSpaceModel() {}
+
+	virtual unsigned int getStateSize() = 0;
+	virtual unsigned int getResX() = 0;
+	virtual unsigned int getResY() = 0;
+	virtual unsigned int getNPts() = 0;
+	virtual const PtsT &getPts() = 0;
+	virtual const CornersT &getCorners() = 0;
+	virtual const VectorXd &getState() = 0;
+	virtual const GradPtsT &getGradPts() = 0;
+
+	virtual void setState(const VectorXd &) { ssm_func_not_implemeted(setState); }
+	virtual void setCorners(const CornersT &) { ssm_func_not_implemeted(setCorners); }
+	virtual void initialize(const CornersT &corners, int n_channels = 1) { (void)n_channels; setCorners(corners); }
+	virtual void initializeGradPts(double grad_eps) { updateGradPts(grad_eps); }
+	virtual void additiveUpdate(const VectorXd &) { ssm_func_not_implemeted(additiveUpdate); }
+	virtual void compositionalUpdate(const VectorXd &) { ssm_func_not_implemeted(compositionalUpdate); }
+	virtual void updateGradPts(double) { ssm_func_not_implemeted(updateGradPts); }
+	virtual void invertState(VectorXd &, const VectorXd &) { ssm_func_not_implemeted(invertState); }
+
+	virtual void cmptInitPixJacobian(MatrixXd &, const PixGradT &) { ssm_func_not_implemeted(cmptInitPixJacobian); }
+	virtual void cmptPixJacobian(MatrixXd &, const PixGradT &) { ssm_func_not_implemeted(cmptPixJacobian); }
+	virtual void cmptWarpedPixJacobian(MatrixXd &, const PixGradT &) { ssm_func_not_implemeted(cmptWarpedPixJacobian); }
+	virtual void cmptApproxPixJacobian(MatrixXd &, const PixGradT &) { ssm_func_not_implemeted(cmptApproxPixJacobian); }
+	virtual void applyWarpToCorners(CornersT &, const CornersT &, const VectorXd &) { ssm_func_not_implemeted(applyWarpToCorners); }
+
+	virtual void setFirstIter() { first_iter = true; }
+	virtual void clearFirstIter() { first_iter = false; }
+	virtual void clearInitStatus() {}
+protected:
+	bool first_iter = false;
+};
+
+} // namespace mtf
+#endif

@@ -1,0 +1,86 @@
+/*
+ * host_capi.cpp -- a small C wrapper around the C++ host layer (mtf::hip::HipAM / HipSSM driven by
+ * mtf::nt::ESM / FCLK / ICLK), the equivalent of the reference's pyMTF create / setRegion / getRegion
+ * (Examples/cpp/pyMTF.cc:35-62), so that the test-suite can drive the C++ objects.
+ */
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "HipModels.h"
+#include "SearchMethods.h"
+
+using namespace mtf;
+
+struct mtfhost_tracker {
+	std::shared_ptr<hip::HipPair> pair;
+	std::shared_ptr<hip::HipAM> am;
+	std::shared_ptr<hip::HipSSM> ssm;
+	std::unique_ptr<nt::SearchMethod> sm;
+};
+
+static thread_local std::string g_err;
+
+extern "C" {
+
+const char *mtfhost_last_error(void) { return g_err.c_str(); }
+
+mtfhost_tracker *mtfhost_create(int sm, int am, int ssm, int resx, int resy, int max_iters, double epsilon,
+	int jac_type, int hess_type, int chained_warp, int leven_marq, double lm_delta_init, double lm_delta_update,
+	int device) {
+	try {
+		auto *t = new mtfhost_tracker();
+		t->pair = std::make_shared<hip::HipPair>(am, ssm, resx, resy, 1e-8, 1.0, 8, 10.0, 0, device, nullptr);
+		t->am = std::make_shared<hip::HipAM>(t->pair);
+		t->ssm = std::make_shared<hip::HipSSM>(t->pair);
+		nt::SMParams p;
+		p.max_iters = max_iters; p.epsilon = epsilon; p.jac_type = jac_type; p.hess_type = hess_type;
+		p.chained_warp = chained_warp != 0; p.leven_marq = leven_marq != 0;
+		p.lm_delta_init = lm_delta_init; p.lm_delta_update = lm_delta_update;
+		if (sm == MTFHIP_SM_ESM) t->sm.reset(new nt::ESM(t->am, t->ssm, p));
+		else if (sm == MTFHIP_SM_FCLK) t->sm.reset(new nt::FCLK(t->am, t->ssm, p));
+		else if (sm == MTFHIP_SM_ICLK) t->sm.reset(new nt::ICLK(t->am, t->ssm, p));
+		else { delete t; g_err = "unknown search method"; return nullptr; }
+		return t;
+	} catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+void mtfhost_destroy(mtfhost_tracker *t) { delete t; }
+
+static int guarded(mtfhost_tracker *t, void (*fn)(mtfhost_tracker *, const void *, void *), const void *in, void *out) {
+	try { fn(t, in, out); return 0; }
+	catch (const utils::Exception &e) { g_err = std::string(e.type()) + ": " + e.what(); return -1; }
+	catch (const std::exception &e) { g_err = e.what(); return -2; }
+}
+int mtfhost_set_image(mtfhost_tracker *t, const float *img, int rows, int cols, int step) {
+	ImageView v{img, rows, cols, step};
+	return guarded(t, [](mtfhost_tracker *tt, const void *in, void *) { tt->sm->setImage(*(const ImageView *)in); }, &v, nullptr);
+}
+int mtfhost_initialize(mtfhost_tracker *t, const double *corners) {
+	return guarded(t, [](mtfhost_tracker *tt, const void *in, void *) {
+		CornersT c; std::memcpy(c.v, in, sizeof(c.v)); tt->sm->initialize(c); }, corners, nullptr);
+}
+int mtfhost_set_region(mtfhost_tracker *t, const double *corners) {
+	return guarded(t, [](mtfhost_tracker *tt, const void *in, void *) {
+		CornersT c; std::memcpy(c.v, in, sizeof(c.v)); tt->sm->setRegion(c); }, corners, nullptr);
+}
+int mtfhost_update(mtfhost_tracker *t, int *iters_done) {
+	return guarded(t, [](mtfhost_tracker *tt, const void *, void *out) {
+		tt->sm->update(); if (out) *(int *)out = tt->sm->getItersDone(); }, nullptr, iters_done);
+}
+int mtfhost_get_region(mtfhost_tracker *t, double *corners) {
+	return guarded(t, [](mtfhost_tracker *tt, const void *, void *out) {
+		std::memcpy(out, tt->sm->getRegion().v, sizeof(double) * 8); }, nullptr, corners);
+}
+/* host-only helper exercised by the CPU tests */
+int mtfhost_qr_solve(int n, const double *A_colmajor, const double *b, double *x) {
+	try {
+		MatrixXd A(n, n); VectorXd bb(n), xx;
+		std::memcpy(A.data(), A_colmajor, sizeof(double) * n * n);
+		std::memcpy(bb.data(), b, sizeof(double) * n);
+		utils::colPivHouseholderQrSolve(A, bb, xx);
+		std::memcpy(x, xx.data(), sizeof(double) * n);
+		return 0;
+	} catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
+} // extern "C"

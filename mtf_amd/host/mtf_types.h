@@ -1,0 +1,103 @@
+/*
+ * mtf_types.h -- the handful of dense types the AM / SSM interface passes around, with the reference's
+ * names and memory layouts (Macros/include/mtf/Macros/common.h:190-258: Eigen, column-major).  Eigen is
+ * not available in this image, so these are plain storage classes -- enough for the interface and for the
+ * search-method loops, which only need element access, `data()`, and a few S x S operations.
+ * With real Eigen a maintainer drops this header and includes <Eigen/Dense>.
+ */
+#ifndef MTF_AMD_HOST_TYPES_H
+#define MTF_AMD_HOST_TYPES_H
+
+#include <cassert>
+#include <cstddef>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace mtf {
+
+/* column-major dynamic matrix of doubles */
+class MatrixXd {
+public:
+	MatrixXd() : r_(0), c_(0) {}
+	MatrixXd(int rows, int cols) : r_(rows), c_(cols), d_((size_t)rows * cols, 0.0) {}
+	void resize(int rows, int cols) { r_ = rows; c_ = cols; d_.assign((size_t)rows * cols, 0.0); }
+	int rows() const { return r_; }
+	int cols() const { return c_; }
+	size_t size() const { return d_.size(); }
+	double *data() { return d_.data(); }
+	const double *data() const { return d_.data(); }
+	double &operator()(int i, int j) { return d_[(size_t)j * r_ + i]; }
+	double operator()(int i, int j) const { return d_[(size_t)j * r_ + i]; }
+	void fill(double v) { std::fill(d_.begin(), d_.end(), v); }
+private:
+	int r_, c_;
+	std::vector<double> d_;
+};
+
+class VectorXd {
+public:
+	VectorXd() {}
+	explicit VectorXd(int n) : d_(n, 0.0) {}
+	void resize(int n) { d_.assign(n, 0.0); }
+	int size() const { return (int)d_.size(); }
+	double *data() { return d_.data(); }
+	const double *data() const { return d_.data(); }
+	double &operator()(int i) { return d_[i]; }
+	double operator()(int i) const { return d_[i]; }
+	double &operator[](int i) { return d_[i]; }
+	double operator[](int i) const { return d_[i]; }
+	void fill(double v) { std::fill(d_.begin(), d_.end(), v); }
+	double squaredNorm() const { double s = 0; for (double v : d_) s += v * v; return s; }
+private:
+	std::vector<double> d_;
+};
+typedef VectorXd RowVectorXd;
+
+/* 2 x N points, x,y interleaved (Matrix2Xd) */
+typedef MatrixXd PtsT;
+typedef MatrixXd GradPtsT;   /* 8 x N */
+typedef MatrixXd PixGradT;   /* N x 2 */
+typedef VectorXd PixValT;
+
+/* 2 x 4 corners, TL TR BR BL (Matrix24d) */
+struct CornersT {
+	double v[8];
+	double &operator()(int r, int c) { return v[2 * c + r]; }
+	double operator()(int r, int c) const { return v[2 * c + r]; }
+	double *data() { return v; }
+	const double *data() const { return v; }
+	double squaredDistance(const CornersT &o) const {
+		double s = 0;
+		for (int i = 0; i < 8; ++i) { double d = v[i] - o.v[i]; s += d * d; }
+		return s;
+	}
+};
+
+/* the float32 single-channel image the AM borrows (cv::Mat CV_32FC1 in the reference) */
+struct ImageView {
+	const float *data;
+	int rows, cols, step; /* step in elements */
+};
+
+namespace utils {
+/* Utilities/include/mtf/Utilities/excpUtils.h:8-55 */
+class Exception : public std::runtime_error {
+public:
+	explicit Exception(const std::string &what, const char *type = "Generic") : std::runtime_error(what), type_(type) {}
+	const char *type() const { return type_; }
+private:
+	const char *type_;
+};
+struct InvalidArgument : Exception { explicit InvalidArgument(const std::string &w) : Exception(w, "InvalidArgument") {} };
+struct FunctonNotImplemented : Exception { explicit FunctonNotImplemented(const std::string &w) : Exception(w, "FunctonNotImplemented") {} };
+struct LogicError : Exception { explicit LogicError(const std::string &w) : Exception(w, "LogicError") {} };
+struct InvalidTrackerState : Exception { explicit InvalidTrackerState(const std::string &w) : Exception(w, "InvalidTrackerState") {} };
+
+/* x = A^{-1} b through a column-pivoted Householder QR (what the SMs call on Eigen:
+ * hessian.colPivHouseholderQr().solve(...), SM/src/NT/FCLK.cc:298) */
+void colPivHouseholderQrSolve(const MatrixXd &A, const VectorXd &b, VectorXd &x);
+} // namespace utils
+
+} // namespace mtf
+#endif

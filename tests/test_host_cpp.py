@@ -1,0 +1,94 @@
+"""The C++ host layer (mtf_amd/host): CPU tests of its host-only logic, GPU tests of the adapter classes
+driven by the C++ nt::ESM / FCLK / ICLK loops against the oracle's trackers."""
+import numpy as np
+import pytest
+
+from mtf_amd import _lib as L
+from mtf_amd import host, synth
+
+
+def test_host_library_builds_and_qr_matches_numpy():
+    host.build()
+    rng = np.random.default_rng(2)
+    for n in (6, 8):
+        A = rng.normal(size=(n, n)); A = -(A @ A.T) - 0.1 * np.eye(n)
+        A *= np.outer(10.0 ** rng.uniform(-2, 2, n), np.ones(n)); A = 0.5 * (A + A.T)
+        b = rng.normal(size=n)
+        np.testing.assert_allclose(host.qr_solve(A, b), np.linalg.solve(A, b), rtol=1e-8)
+
+
+def test_host_qr_matches_oracle_qr(oracle):
+    rng = np.random.default_rng(3)
+    A = rng.normal(size=(8, 8)); A = -(A @ A.T) - np.eye(8)
+    b = rng.normal(size=8)
+    np.testing.assert_allclose(host.qr_solve(A, b), oracle.colpiv_qr_solve(A, b), rtol=1e-12, atol=1e-14)
+
+
+def test_host_layer_fails_loudly_without_device():
+    import ctypes
+    if ctypes.CDLL(L.LIB_PATH).mtfhip_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(host.HostError, match="no HIP device"):
+        host.CppTracker(L.SM_ESM)
+
+
+def test_host_layer_argument_validation():
+    import ctypes
+    if ctypes.CDLL(L.LIB_PATH).mtfhip_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(host.HostError, match="Invalid sampling resolution"):   # ImageBase.cc:33-35, checked before the device
+        host.CppTracker(L.SM_ESM, resx=0)
+
+
+CASES = [
+    (L.SM_ESM, L.AM_SSD, L.SSM_HOMOGRAPHY, 45, dict()),                 # reference class defaults (LM on)
+    (L.SM_ESM, L.AM_SSD, L.SSM_HOMOGRAPHY, 45, dict(leven_marq=0)),
+    (L.SM_ESM, L.AM_SSD, L.SSM_HOMOGRAPHY, 40, dict(chained_warp=0, hess_type=5)),
+    (L.SM_FCLK, L.AM_SSD, L.SSM_HOMOGRAPHY, 45, dict()),
+    (L.SM_FCLK, L.AM_SSD, L.SSM_AFFINE, 40, dict(hess_type=0)),
+    (L.SM_ICLK, L.AM_SSD, L.SSM_HOMOGRAPHY, 45, dict()),
+    (L.SM_ICLK, L.AM_NCC, L.SSM_AFFINE, 25, dict()),
+    (L.SM_ESM, L.AM_NCC, L.SSM_HOMOGRAPHY, 40, dict(hess_type=4)),
+    (L.SM_ESM, L.AM_MI, L.SSM_HOMOGRAPHY, 40, dict(leven_marq=0)),
+    (L.SM_FCLK, L.AM_MI, L.SSM_AFFINE, 30, dict()),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "sm%d-am%d-ssm%d-%s" % (c[0], c[1], c[2], "_".join("%s%s" % kv for kv in c[4].items())))
+def test_cpp_trackers_match_oracle(oracle, frame, case):
+    sm, am, ssm, res, extra = case
+    rng = np.random.default_rng(13)
+    centre = (256.0, 250.0)
+    corners = synth.square_corners(centre[0], centre[1], float(max(2 * res, 60)))
+    p_true = synth.random_small_homography(rng, 0.35)
+    frame2 = synth.warp_frame(frame, p_true, centre)
+    params = dict(max_iters=30, epsilon=1e-6, leven_marq=1)
+    params.update(extra)
+    o_ssm = oracle.SSM(ssm, res, res); o_am = oracle.AM(am, res, res); o_am.set_curr_img(frame)
+    otrk = oracle.Tracker(sm, o_am, o_ssm, **params)
+    otrk.initialize(corners)
+    o_am.set_curr_img(frame2)
+    o_iters = otrk.update()
+
+    trk = host.CppTracker(sm, am, ssm, res, res, **params)
+    img = frame.copy()
+    trk.set_image(img)
+    trk.initialize(corners)
+    img[:] = frame2          # the caller overwrites its buffer in place (TrackerBase.h:22-26); update() re-uploads
+    out = trk.update()
+    np.testing.assert_allclose(out, otrk.get_region(), atol=1e-3)
+    assert abs(trk.iters - o_iters) <= 2
+    W = synth.homography_from_state(p_true)
+    q = W @ np.vstack([corners - np.array(centre)[:, None], np.ones(4)])
+    gt = q[:2] / q[2] + np.array(centre)[:, None]
+    assert np.abs(out - gt).max() < (0.1 if am != L.AM_MI else 0.6)
+
+
+@pytest.mark.gpu
+def test_cpp_layer_error_paths(frame):
+    trk = host.CppTracker(L.SM_ESM, L.AM_SSD, L.SSM_HOMOGRAPHY, 20, 20, jac_type=0)
+    trk.set_image(frame)
+    trk.initialize(synth.square_corners(200, 200, 40))
+    with pytest.raises(host.HostError, match="FunctonNotImplemented"):
+        trk.update()
