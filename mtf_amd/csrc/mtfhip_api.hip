@@ -377,7 +377,7 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 	b->th.resize(n_targets);
 	for (auto &h : b->th) { std::memset(&h, 0, sizeof(h)); h.warp = m3_identity(); }
 	b->nblk_max = simple_blocks_per_target(b->N);
-	int nf = fused_blocks_per_target(b->N);
+	int nf = fused_blocks_per_target(b->N, 1);   /* the finest decomposition is the single-target one */
 	if (nf > b->nblk_max) b->nblk_max = nf;
 	auto cleanup = [&](int code) { mtfhip_batch_destroy(b); return code; };
 	const int eager[] = {MTFHIP_BUF_I0, MTFHIP_BUF_IT, MTFHIP_BUF_DI0_DX, MTFHIP_BUF_DIT_DX, MTFHIP_BUF_DF_DI0,
@@ -1161,6 +1161,7 @@ static int fused_args(const mtfhip_batch *b, const mtfhip_sm_desc *sm, FusedArgs
 	fa.grad_eps = b->desc.grad_eps;
 	fa.norm_mult = b->norm_mult; fa.norm_add = b->norm_add;
 	fa.active = nullptr;
+	{ int nb; fused_decomposition(b->N, b->B, nb, fa.rows_per_block); }
 	switch (sm->sm) {
 	case MTFHIP_SM_FCLK: fa.mode = 0; break;
 	case MTFHIP_SM_ESM: fa.mode = 1; fa.hess_mean = sm->hess_type == 3; break;
@@ -1200,7 +1201,7 @@ int mtfhip_batch_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, d
 	TRY(need_image(b));
 	FusedArgs fa;
 	TRY(fused_args(b, sm, fa));
-	int nblk = fused_blocks_per_target(b->N);
+	int nblk = fused_blocks_per_target(b->N, b->B);
 	{
 		TimedScope ts(b->ctx, "fused_lk");
 		launch_fused_ssd(b->view(), b->ctx->img, fa, b->d_partials, nblk, b->ctx->stream);
@@ -1231,7 +1232,7 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: NCC patches larger than %d pixels need the per-function entry points", kIclkTrackMaxPix);
 	FusedArgs fa;
 	if (!one_launch) TRY(fused_args(b, sm, fa));
-	else { fa.materialize = 0; fa.mode = 2; fa.active = nullptr; }
+	else { fa.materialize = 0; fa.mode = 2; fa.active = nullptr; fa.rows_per_block = 1; }
 	std::vector<int> ones(b->B, 1);
 	std::vector<double> cr(8 * (size_t)b->B);
 	for (int t = 0; t < b->B; ++t) std::memcpy(&cr[8 * t], b->th[t].corners, sizeof(double) * 8);
@@ -1241,7 +1242,7 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 	TRY(push_warps(b));
 	fa.active = b->d_active;
 	TrackState ts{b->d_acc, b->d_h0, b->d_corners, b->d_init_corners_hm, b->d_active, b->d_iters};
-	int nblk = fused_blocks_per_target(b->N);
+	int nblk = fused_blocks_per_target(b->N, b->B);
 	BatchView bv = b->view();
 	if (one_launch) {
 		if (b->desc.am == MTFHIP_AM_NCC) TRY(push_ncc(b));
@@ -1253,10 +1254,7 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 			TimedScope tsc(b->ctx, "fused_lk");
 			launch_fused_ssd(bv, b->ctx->img, fa, b->d_partials, nblk, st);
 		}
-		{
-			TimedScope tsc(b->ctx, "finish_track");
-			launch_finish_track(bv, *sm, ts, b->d_partials, nblk, st);
-		}
+		launch_finish_track(bv, *sm, ts, b->d_partials, nblk, st);
 	}
 	std::vector<double> w(9 * (size_t)b->B), s(8 * (size_t)b->B);
 	std::vector<int> iters(b->B);

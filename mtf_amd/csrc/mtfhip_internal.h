@@ -34,13 +34,37 @@ enum {
 };
 
 constexpr int kBlock = 256;       /* threads per workgroup: 4 wave64 */
-#ifndef MTFHIP_PPT
-#define MTFHIP_PPT 8
+#ifndef MTFHIP_SLOTS
+#define MTFHIP_SLOTS 512          /* resident workgroups of the fused kernel: 256 CUs x 2 (2 waves/SIMD, 4-wave groups) */
 #endif
-constexpr int kFusedPPT = MTFHIP_PPT; /* pixels per thread in the fused kernels */
+#ifndef MTFHIP_MIN_ROWS
+#define MTFHIP_MIN_ROWS 4         /* at least this many 256-pixel rows per workgroup (amortises the reduction) */
+#endif
 constexpr int kMaxS = 8;
 
-inline int fused_blocks_per_target(int N) { return (N + kBlock * kFusedPPT - 1) / (kBlock * kFusedPPT); }
+/* Work decomposition of the fused kernel: every target is cut into nblk chunks of `rows` 256-pixel rows so that
+ * B * nblk is as close as possible to the number of resident workgroups -- one full round of workgroups, no
+ * half-empty tail round (a 2.5-round grid costs ~8 % against a 2- or 1-round grid) */
+inline void fused_decomposition(int N, int B, int &nblk, int &rows) {
+	const int total_rows = (N + kBlock - 1) / kBlock;
+	int nb_max = (total_rows + MTFHIP_MIN_ROWS - 1) / MTFHIP_MIN_ROWS;
+	if (nb_max < 1) nb_max = 1;
+	if (B < 1) B = 1;
+	/* cost model: rounds of resident workgroups x (rows per workgroup + the reduction epilogue, ~1.5 rows) */
+	double best = 1e300;
+	int best_nb = 1;
+	for (int nb = 1; nb <= nb_max; ++nb) {
+		const int r = (total_rows + nb - 1) / nb;
+		const int real_nb = (total_rows + r - 1) / r;
+		const long blocks = (long)B * real_nb;
+		const long rounds = (blocks + MTFHIP_SLOTS - 1) / MTFHIP_SLOTS;
+		const double cost = (double)rounds * (r + 1.5);
+		if (cost < best - 1e-9) { best = cost; best_nb = real_nb; }
+	}
+	rows = (total_rows + best_nb - 1) / best_nb;
+	nblk = (total_rows + rows - 1) / rows;
+}
+inline int fused_blocks_per_target(int N, int B) { int nb, r; fused_decomposition(N, B, nb, r); return nb; }
 inline int simple_blocks_per_target(int N) {
 	int nb = (N + kBlock * 4 - 1) / (kBlock * 4);
 	return nb < 1 ? 1 : nb;
@@ -51,6 +75,7 @@ struct FusedArgs {
 	int chained;
 	int materialize;
 	int hess_mean;     /* ESM hess_type Original: outer products of (J0+Jt)/2 instead of Jt */
+	int rows_per_block; /* 256-pixel rows walked by one workgroup (fused_decomposition) */
 	double grad_eps;
 	double norm_mult, norm_add;
 	const int *active; /* optional [B] mask: targets with 0 are skipped (device-side loop) */

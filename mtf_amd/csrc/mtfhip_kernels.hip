@@ -6,7 +6,7 @@
  * without FMA contraction, it rounds exactly like the CPU/Eigen path; only the N-wide reductions
  * (explicit fma accumulation + wavefront shuffles) sum in a different order.
  *
- * Execution model: 256-thread workgroups (4 wave64), each thread walks kFusedPPT pixels strided by
+ * Execution model: 256-thread workgroups (4 wave64), each thread walks n_rows pixels strided by
  * the workgroup size so that every wave touches 64 consecutive pixels of a column-major N x S
  * array per instruction (512-byte coalesced segments).  The S x S Hessian is never a GEMM: 36
  * upper-triangle products + 8 gradient terms + r^2 are kept in registers per thread, reduced across
@@ -23,6 +23,9 @@
 #endif
 #ifndef MTFHIP_FUSED_WAVES
 #define MTFHIP_FUSED_WAVES 2   /* minimum waves per SIMD requested from the register allocator */
+#endif
+#ifndef MTFHIP_COOP
+#define MTFHIP_COOP 0          /* 1: the 36 J^T J products are split over the 4 waves of a workgroup through LDS */
 #endif
 
 namespace mtfhip {
@@ -875,6 +878,31 @@ __device__ __forceinline__ bool in_cell(double x, double y, int lx, int ly) {
 	return (x >= 0) && (y >= 0) && ((int)x == lx) && ((int)y == ly) && ((x - lx) != 0) && ((y - ly) != 0);
 }
 
+/* index of (a, b), a <= b, in the upper-triangle order of the accumulator row (stride 8) */
+__host__ __device__ constexpr int tri8(int a, int b) { return a * 8 - (a * (a - 1)) / 2 + (b - a); }
+/* Cooperative Gram accumulation: the workgroup's 256 steepest-descent rows of one iteration sit in LDS
+ * (component-major, R[s][pixel]); wave WV owns every 4th..: the products with linear index in
+ * [WV*PER, (WV+1)*PER) of the S(S+1)/2 upper-triangle list and sums them over all 256 pixels. */
+template <int S, int WV>
+__device__ __forceinline__ void coop_accumulate(const double *R, int lane, double *h) {
+	constexpr int NK = S * (S + 1) / 2, PER = (NK + 3) / 4;
+#pragma unroll
+	for (int j = 0; j < kBlock / 64; ++j) {
+		const int q = j * 64 + lane;
+		double r[S];
+#pragma unroll
+		for (int s = 0; s < S; ++s) r[s] = R[s * kBlock + q];
+		int k = 0;
+#pragma unroll
+		for (int a = 0; a < S; ++a)
+#pragma unroll
+			for (int b = a; b < S; ++b) {
+				if (k / PER == WV) h[k - WV * PER] = fma(r[a], r[b], h[k - WV * PER]);
+				++k;
+			}
+	}
+}
+
 template <int S, int MODE>
 struct PixIn {
 	double2 p;
@@ -904,6 +932,13 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 	constexpr int S = (SSM == MTFHIP_SSM_HOMOGRAPHY) ? 8 : 6;
 	constexpr int K = 48;
 	__shared__ double lds[4 * K];
+#if MTFHIP_COOP
+	__shared__ double Rbuf[2][8 * kBlock];   /* double-buffered SD rows of the current 256 pixels */
+	double hacc[9];
+#pragma unroll
+	for (int q = 0; q < 9; ++q) hacc[q] = 0.0;
+	int rbuf_sel = 0;
+#endif
 	const int t = blockIdx.y;
 	const unsigned N = (unsigned)bv.N;
 	if (fa.active && !fa.active[t]) return;
@@ -968,7 +1003,8 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 		return tx;
 	};
 
-	const unsigned base = blockIdx.x * (unsigned)(kBlock * kFusedPPT) + threadIdx.x;
+	const int n_rows = fa.rows_per_block;
+	const unsigned base = blockIdx.x * (unsigned)(kBlock * n_rows) + threadIdx.x;
 	/* arithmetic + stores of one row; `cur` holds its streaming operands, `tcur` its position and texels */
 	auto row_compute = [&](unsigned i, const PixIn<S, MODE> &cur, const Tex &tcur) {
 		const double x = cur.p.x, y = cur.p.y;
@@ -1002,6 +1038,9 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 			fast = fast && in_cell(px0, py0, lx, ly) && in_cell(px1, py1, lx, ly) && in_cell(px2, py2, lx, ly) &&
 				in_cell(px3, py3, lx, ly);
 		double it, gx = 0, gy = 0;
+#ifdef MTFHIP_EXPERIMENT_NOMATH
+		if (true) { it = tcur.t00 + tcur.t01 + tcur.t10 + tcur.t11 + wx; gx = wy; gy = px0 + py3; } else
+#endif
 		if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
 			const double t00 = tcur.t00, t01 = tcur.t01, t10 = tcur.t10, t11 = tcur.t11;
 			it = fa.norm_mult * bilin(t00, t01, t10, t11, wx - lx, wy - ly) + fa.norm_add;
@@ -1081,6 +1120,10 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 			for (int s = 0; s < S; ++s) acc[36 + s] = fma(r, cur.j0[s], acc[36 + s]);
 		}
 		if constexpr (MODE != 2) {
+#if MTFHIP_COOP
+#pragma unroll
+			for (int s = 0; s < S; ++s) Rbuf[rbuf_sel][s * kBlock + threadIdx.x] = row[s];
+#else
 			int k = 0;
 #pragma unroll
 			for (int a = 0; a < 8; ++a)
@@ -1089,12 +1132,60 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 					if (a < S && b < S) acc[k] = fma(row[a], row[b], acc[k]);
 					++k;
 				}
+#endif
 		}
 	};
-#if MTFHIP_PIPE == 0
+#if MTFHIP_COOP
+	/* every thread walks all rows of the workgroup (pixels past N contribute zero rows) because each
+	 * iteration ends in a workgroup barrier followed by the cooperative accumulation */
+	const int wave_id = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
+	const unsigned blk_base = blockIdx.x * (unsigned)(kBlock * n_rows);
+	PixIn<S, MODE> cur;
+	if (base < N) cur = load_in(base);
+#pragma unroll 1
+	for (int kk = 0; kk < n_rows; ++kk) {
+		if (blk_base + (unsigned)kk * kBlock >= N) break;          /* uniform over the workgroup */
+		const unsigned i = base + (unsigned)kk * kBlock;
+		if (i < N) {
+			const Tex tcur = issue_tex(cur);
+			PixIn<S, MODE> nxt = cur;
+			if (kk + 1 < n_rows && i + kBlock < N) nxt = load_in(i + kBlock);
+			row_compute(i, cur, tcur);
+			cur = nxt;
+		} else if constexpr (MODE != 2) {
+#pragma unroll
+			for (int s = 0; s < S; ++s) Rbuf[rbuf_sel][s * kBlock + threadIdx.x] = 0.0;
+		}
+		if constexpr (MODE != 2) {
+			__syncthreads();
+			const double *R = Rbuf[rbuf_sel];
+			if (wave_id == 0) coop_accumulate<S, 0>(R, lane_id, hacc);
+			else if (wave_id == 1) coop_accumulate<S, 1>(R, lane_id, hacc);
+			else if (wave_id == 2) coop_accumulate<S, 2>(R, lane_id, hacc);
+			else coop_accumulate<S, 3>(R, lane_id, hacc);
+			rbuf_sel ^= 1;   /* the next iteration's rows go to the other buffer: one barrier per iteration */
+		}
+	}
+	/* wave w holds its PER Gram entries summed over every pixel of the workgroup; g and r^2 are per-thread sums */
+	{
+		constexpr int NK = S * (S + 1) / 2, PER = (NK + 3) / 4;
+		int k = 0;
+#pragma unroll
+		for (int a = 0; a < S; ++a)
+#pragma unroll
+			for (int b = a; b < S; ++b) {
+				const int owner = k / PER, slot = k - owner * PER;
+				double v = 0.0;
+#pragma unroll
+				for (int q = 0; q < 9; ++q) if (q == slot) v = hacc[q];
+				acc[tri8(a, b)] = (owner == wave_id) ? v : 0.0;
+				++k;
+			}
+	}
+#elif MTFHIP_PIPE == 0
 	/* no software pipelining: latency is covered by occupancy alone */
 #pragma unroll 1
-	for (int kk = 0; kk < kFusedPPT; ++kk) {
+	for (int kk = 0; kk < n_rows; ++kk) {
 		const unsigned i = base + (unsigned)kk * kBlock;
 		if (i >= N) break;
 		const PixIn<S, MODE> cur = load_in(i);
@@ -1106,23 +1197,22 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 	PixIn<S, MODE> cur;
 	if (base < N) cur = load_in(base);
 #pragma unroll 1
-	for (int kk = 0; kk < kFusedPPT; ++kk) {
+	for (int kk = 0; kk < n_rows; ++kk) {
 		const unsigned i = base + (unsigned)kk * kBlock;
 		if (i >= N) break;
 		const Tex tcur = issue_tex(cur);
 		PixIn<S, MODE> nxt = cur;
-		if (kk + 1 < kFusedPPT && i + kBlock < N) nxt = load_in(i + kBlock);
+		if (kk + 1 < n_rows && i + kBlock < N) nxt = load_in(i + kBlock);
 		row_compute(i, cur, tcur);
 		cur = nxt;
 	}
 #else
-	static_assert(kFusedPPT % 3 == 0, "the register ring rotates statically over three rows");
-	auto row_step = [&](int kk, const PixIn<S, MODE> &cur, const Tex &tcur, const PixIn<S, MODE> &nxt, Tex &tnxt,
+		auto row_step = [&](int kk, const PixIn<S, MODE> &cur, const Tex &tcur, const PixIn<S, MODE> &nxt, Tex &tnxt,
 		PixIn<S, MODE> &nxt2) {
 		const unsigned i = base + (unsigned)kk * kBlock;
 		if (i >= N) return;
-		if (kk + 1 < kFusedPPT && i + kBlock < N) tnxt = issue_tex(nxt);
-		if (kk + 2 < kFusedPPT && i + 2 * kBlock < N) nxt2 = load_in(i + 2 * kBlock);
+		if (kk + 1 < n_rows && i + kBlock < N) tnxt = issue_tex(nxt);
+		if (kk + 2 < n_rows && i + 2 * kBlock < N) nxt2 = load_in(i + 2 * kBlock);
 		row_compute(i, cur, tcur);
 	};
 	PixIn<S, MODE> inA, inB, inC;
@@ -1133,7 +1223,7 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 		txA = issue_tex(inA);
 	}
 #pragma unroll 1
-	for (int kk = 0; kk < kFusedPPT; kk += 3) {
+	for (int kk = 0; kk < n_rows; kk += 3) {
 		if (base + (unsigned)kk * kBlock >= N) break;
 		row_step(kk, inA, txA, inB, txB, inC);
 		row_step(kk + 1, inB, txB, inC, txC, inA);
@@ -1212,9 +1302,17 @@ __global__ __launch_bounds__(64) void k_finish_track(BatchView bv, mtfhip_sm_des
 	__shared__ double acc_s[ACC_COUNT];
 	__shared__ double A[8][9];
 	__shared__ double dps[8];
+	__shared__ double h0s[64], Ws[9], crs[8], ics[12];
 	const int t = blockIdx.x, lane = threadIdx.x;
 	if (!ts.active[t]) return;
 	const int S = bv.S;
+	/* every global operand of this target is requested up front, in parallel across the lanes: the rest
+	 * of the kernel runs out of LDS / registers (one memory round trip instead of a dozen dependent ones) */
+	h0s[lane] = ts.h0[(size_t)t * 64 + lane];
+	if (lane < 9) Ws[lane] = bv.warps[9 * t + lane];
+	if (lane < 8) crs[lane] = ts.corners[8 * t + lane];
+	if (lane < 12) ics[lane] = ts.init_corners_hm[12 * t + lane];
+	const int n_it_prev = ts.n_iters[t];
 	if (lane < ACC_COUNT) {
 		const double *p = partials + (size_t)t * nblk * ACC_COUNT + lane;
 		double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
@@ -1230,7 +1328,6 @@ __global__ __launch_bounds__(64) void k_finish_track(BatchView bv, mtfhip_sm_des
 	}
 	__syncthreads();
 	const int i = lane >> 3, j = lane & 7;
-	const double *h0 = ts.h0 + (size_t)t * 64;
 	const bool use_h0 = (sm.hess_type == 0) || (sm.sm == MTFHIP_SM_ICLK);
 	const bool sum_h0 = (sm.sm == MTFHIP_SM_ESM) && (sm.hess_type == 2 || sm.hess_type == 4);
 	const double gscale = (sm.sm == MTFHIP_SM_ESM) ? 0.5 : 1.0;
@@ -1238,16 +1335,14 @@ __global__ __launch_bounds__(64) void k_finish_track(BatchView bv, mtfhip_sm_des
 		if (r >= S || c >= S) return r == c ? -1.0 : 0.0;
 		const int a = r < c ? r : c, b2 = r < c ? c : r;
 		const int kk = a * 8 - (a * (a - 1)) / 2 + (b2 - a);
-		double v = use_h0 ? h0[b2 * S + a] : -acc_s[ACC_H + kk];
-		if (sum_h0) v = (v + h0[b2 * S + a]) * 0.5;
+		double v = use_h0 ? h0s[b2 * S + a] : -acc_s[ACC_H + kk];
+		if (sum_h0) v = (v + h0s[b2 * S + a]) * 0.5;
 		return v;
 	};
-	{
-		const double dii = h_entry(i, i), djj = h_entry(j, j);
-		const double si = dii != 0 ? 1.0 / sqrt(fabs(dii)) : 1.0, sj = djj != 0 ? 1.0 / sqrt(fabs(djj)) : 1.0;
-		A[i][j] = h_entry(i, j) * si * sj;
-		if (j == 0) A[i][8] = (i < S ? gscale * acc_s[ACC_G + i] : 0.0) * si;
-	}
+	const double dii = h_entry(i, i), djj = h_entry(j, j);
+	const double si = dii != 0 ? 1.0 / sqrt(fabs(dii)) : 1.0, sj = djj != 0 ? 1.0 / sqrt(fabs(djj)) : 1.0;
+	A[i][j] = h_entry(i, j) * si * sj;
+	if (j == 0) A[i][8] = (i < S ? gscale * acc_s[ACC_G + i] : 0.0) * si;
 	__syncthreads();
 #pragma unroll
 	for (int k = 0; k < 8; ++k) {
@@ -1261,8 +1356,6 @@ __global__ __launch_bounds__(64) void k_finish_track(BatchView bv, mtfhip_sm_des
 		__syncthreads();
 	}
 	if (j == 0) {
-		const double dii = h_entry(i, i);
-		const double si = dii != 0 ? 1.0 / sqrt(fabs(dii)) : 1.0;
 		const double d = A[i][i];
 		dps[i] = (i < S && d != 0) ? -(A[i][8] / d) * si : 0.0;
 	}
@@ -1300,7 +1393,7 @@ __global__ __launch_bounds__(64) void k_finish_track(BatchView bv, mtfhip_sm_des
 	}
 	double Wo[9], Wn[9];
 #pragma unroll
-	for (int q = 0; q < 9; ++q) Wo[q] = Wp[q];
+	for (int q = 0; q < 9; ++q) Wo[q] = Ws[q];
 #pragma unroll
 	for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -1318,21 +1411,20 @@ __global__ __launch_bounds__(64) void k_finish_track(BatchView bv, mtfhip_sm_des
 #pragma unroll
 	for (int q = 0; q < 9; ++q) Wp[q] = Wn[q];
 	double *cr = ts.corners + 8 * t;
-	const double *ic = ts.init_corners_hm + 12 * t;
 	double change = 0;
 #pragma unroll
 	for (int q = 0; q < 4; ++q) {
-		double X = ic[3 * q], Y = ic[3 * q + 1], Z = ic[3 * q + 2];
+		double X = ics[3 * q], Y = ics[3 * q + 1], Z = ics[3 * q + 2];
 		double nx = Wn[0] * X + Wn[1] * Y + Wn[2] * Z, ny = Wn[3] * X + Wn[4] * Y + Wn[5] * Z;
 		if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
 			double d = Wn[6] * X + Wn[7] * Y + Wn[8] * Z;
 			nx = nx / d; ny = ny / d;
 		}
-		double ddx = cr[2 * q] - nx, ddy = cr[2 * q + 1] - ny;
+		double ddx = crs[2 * q] - nx, ddy = crs[2 * q + 1] - ny;
 		change += ddx * ddx + ddy * ddy;
 		cr[2 * q] = nx; cr[2 * q + 1] = ny;
 	}
-	const int n_it = ts.n_iters[t] + 1;
+	const int n_it = n_it_prev + 1;
 	ts.n_iters[t] = n_it;
 	if (change < sm.epsilon || n_it >= sm.max_iters) ts.active[t] = 0;
 }
