@@ -76,6 +76,7 @@ class Context:
         L.check(L.lib().mtfhip_image_borrow(self._h, C.c_void_p(dev_ptr), height, width, row_stride or width))
 
     def timing(self, on=True):
+        """on: False/0 off, True/1 every launch, n > 1 every n-th launch of a kernel family"""
         L.check(L.lib().mtfhip_timing_enable(self._h, int(on)))
 
     def timing_reset(self):

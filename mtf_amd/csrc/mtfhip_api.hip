@@ -134,6 +134,7 @@ struct Timer {
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 	double total_ms = 0;
 	int n = 0;
+	long launches = 0;
 };
 
 struct mtfhip_ctx {
@@ -144,6 +145,7 @@ struct mtfhip_ctx {
 	float *img_owned = nullptr;
 	size_t img_capacity = 0;
 	bool timing = false;
+	int timing_stride = 1;   /* events are recorded around every timing_stride-th launch of a family */
 	std::map<std::string, Timer> timers;
 	std::vector<hipEvent_t> free_events;
 };
@@ -154,7 +156,9 @@ struct TimedScope {
 	Timer *tm = nullptr;
 	TimedScope(mtfhip_ctx *c, const char *family) : ctx(c) {
 		if (!ctx->timing) return;
-		tm = &ctx->timers[family];
+		Timer *cand = &ctx->timers[family];
+		if ((cand->launches++ % ctx->timing_stride) != 0) return;
+		tm = cand;
 		auto get = [&]() {
 			hipEvent_t e;
 			if (!ctx->free_events.empty()) { e = ctx->free_events.back(); ctx->free_events.pop_back(); }
@@ -1312,6 +1316,7 @@ int mtfhip_score_candidates(mtfhip_batch *b, const double *states, int C, double
 int mtfhip_timing_enable(mtfhip_ctx *c, int on) {
 	if (!c) return fail(MTFHIP_ERR_INVALID_ARG, "timing_enable: NULL ctx");
 	c->timing = on != 0;
+	c->timing_stride = on > 1 ? on : 1;
 	return MTFHIP_OK;
 }
 static void drain(mtfhip_ctx *c) {
@@ -1329,7 +1334,7 @@ static void drain(mtfhip_ctx *c) {
 int mtfhip_timing_reset(mtfhip_ctx *c) {
 	if (!c) return fail(MTFHIP_ERR_INVALID_ARG, "timing_reset: NULL ctx");
 	drain(c);
-	for (auto &kv : c->timers) { kv.second.total_ms = 0; kv.second.n = 0; }
+	for (auto &kv : c->timers) { kv.second.total_ms = 0; kv.second.n = 0; kv.second.launches = 0; }
 	return MTFHIP_OK;
 }
 int mtfhip_timing_get(mtfhip_ctx *c, const char *family, double *avg_ms, int *n_launches) {
