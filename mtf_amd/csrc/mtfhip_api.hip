@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -200,6 +201,8 @@ struct mtfhip_batch {
 	/* MI: per-target table block, block partial rows, similarity and Hessian outputs */
 	double *d_mi_tb = nullptr, *d_mi_part = nullptr, *d_mi_f = nullptr, *d_mi_H = nullptr;
 	double *d_h0inv = nullptr; /* [B][64] inverse of the constant Hessian (one-launch ICLK) */
+	double *d_units = nullptr; /* per-work-unit partial sums of the LDS-staged candidate scorer */
+	size_t unit_capacity = 0;
 	int mi_row_len = 0;
 	double mi_hist_norm = 0;
 	size_t cand_capacity = 0;
@@ -207,6 +210,10 @@ struct mtfhip_batch {
 	double *h_acc = nullptr; /* pinned */
 	int nblk_max;
 	int unit_z = 1;
+	/* The LDS-staged candidate scorer (template + image tile in LDS) measured 10 % SLOWER than the plain one
+	 * (116 vs 105 us for 10 000 x 2 500 samples): the kernel is bound by FP64 VALU work (two IEEE divisions per
+	 * sample), not by the gather path.  It stays selectable for A/B runs. */
+	bool score_lds = std::getenv("MTFHIP_SCORE_LDS") != nullptr;
 	bool have_corners = false, init_pix_vals = false, init_pix_grad = false, init_sim = false, init_grad = false;
 	bool it_valid = false, dit_valid = false, jt_valid = false;
 	std::vector<TargetHost> th;
@@ -432,7 +439,7 @@ void mtfhip_batch_destroy(mtfhip_batch *b) {
 		if (b->buf[i]) (void)hipFree(b->buf[i]);
 	void *ptrs[] = {b->d_warps, b->d_states, b->d_partials, b->d_acc, b->d_scratch_pts, b->d_w0, b->d_h0, b->d_corners,
 		b->d_init_corners_hm, b->d_active, b->d_iters, b->d_cand, b->d_ncc, b->d_colmean, b->d_mi_tb, b->d_mi_part,
-		b->d_mi_f, b->d_mi_H, b->d_h0inv};
+		b->d_mi_f, b->d_mi_H, b->d_h0inv, b->d_units};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (b->h_acc) (void)hipHostFree(b->h_acc);
@@ -1289,7 +1296,30 @@ int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int C
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "score_candidates before the template was initialised");
 	TRY(need_image(b));
 	TimedScope ts(b->ctx, "score_candidates");
-	launch_score_candidates(b->view(), b->ctx->img, dev_states, C, b->desc.likelihood_alpha, dev_lik, dev_sim, b->ctx->stream);
+	/* image tile = bounding box of the template region + a margin for the candidate cloud (PF sigmas are a few pixels) */
+	const TargetHost &h0 = b->th[0];
+	double xmin = h0.init_corners[0], xmax = xmin, ymin = h0.init_corners[1], ymax = ymin;
+	for (int q = 1; q < 4; ++q) {
+		xmin = std::min(xmin, h0.init_corners[2 * q]); xmax = std::max(xmax, h0.init_corners[2 * q]);
+		ymin = std::min(ymin, h0.init_corners[2 * q + 1]); ymax = std::max(ymax, h0.init_corners[2 * q + 1]);
+	}
+	const int margin = 16;
+	const size_t lds_left = 160 * 1024 > (size_t)b->N * 32 ? 160 * 1024 - (size_t)b->N * 32 : 0;
+	int tx0 = (int)std::floor(xmin) - margin, ty0 = (int)std::floor(ymin) - margin;
+	int tw = (int)std::ceil(xmax) + margin + 2 - tx0, th = (int)std::ceil(ymax) + margin + 2 - ty0;
+	bool staged = false;
+	if (b->score_lds && C >= 64 && (size_t)tw * th * 4 <= lds_left) {
+		if ((size_t)C * kScoreUnitsPerCandidate > b->unit_capacity) {
+			if (b->d_units) HIP_TRY(hipFree(b->d_units));
+			b->d_units = nullptr;
+			HIP_TRY(hipMalloc(&b->d_units, sizeof(double) * C * kScoreUnitsPerCandidate));
+			b->unit_capacity = (size_t)C * kScoreUnitsPerCandidate;
+		}
+		staged = launch_score_candidates_lds(b->view(), b->ctx->img, dev_states, C, tx0, ty0, tw, th, b->desc.likelihood_alpha,
+			b->d_units, dev_lik, dev_sim, b->ctx->stream);
+	}
+	if (!staged)
+		launch_score_candidates(b->view(), b->ctx->img, dev_states, C, b->desc.likelihood_alpha, dev_lik, dev_sim, b->ctx->stream);
 	return MTFHIP_OK;
 }
 

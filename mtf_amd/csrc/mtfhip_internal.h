@@ -134,6 +134,9 @@ void launch_fused_ssd(const BatchView &bv, const ImgView &im, const FusedArgs &f
 /* candidate scoring: target 0's template under C warps given as states */
 void launch_score_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C,
 	double likelihood_alpha, double *dev_lik, double *dev_sim, hipStream_t st);
+bool launch_score_candidates_lds(const BatchView &bv, const ImgView &im, const double *dev_states, int C, int tx0, int ty0,
+	int tw, int th, double likelihood_alpha, double *unit_sums, double *dev_lik, double *dev_sim, hipStream_t st);
+constexpr int kScoreUnitsPerCandidate = 4;
 /* device-side solve + compositional update + convergence test for mtfhip_batch_track */
 struct TrackState {
 	double *acc;        /* [B][ACC_COUNT] reduced accumulators of this iteration */
