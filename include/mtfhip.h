@@ -67,7 +67,14 @@ enum {
 	MTFHIP_BUF_INIT_HXY = 14,/* 2 x N  first two rows of ProjectiveBase::init_pts_hm (homography keeps the
 	                                   un-normalised DLT product, Homography.cc:66) */
 	MTFHIP_BUF_CURR_HXY = 15,/* 2 x N  first two rows of ProjectiveBase::curr_pts_hm */
-	MTFHIP_BUF_COUNT = 16
+	/* second-order path (sec_ord_hess) */
+	MTFHIP_BUF_D2I0_DX2 = 16,/* 4 x N  ImageBase::d2I0_dx2 (xx, xy, yx, yy per pixel) */
+	MTFHIP_BUF_D2IT_DX2 = 17,/* 4 x N  ImageBase::d2It_dx2 */
+	MTFHIP_BUF_HESS_PTS = 18,/* 16 x N StateSpaceModel::hess_pts */
+	MTFHIP_BUF_D2I0_DP2 = 19,/* the SM's init_pix_hessian (Eigen S^2 x N): stored as S*S planes of N, plane r + S*c = entry (r,c) */
+	MTFHIP_BUF_D2IT_DP2 = 20,/* the SM's curr_pix_hessian, same layout */
+	MTFHIP_BUF_D2IM_DP2 = 21,/* the SM's mean_pix_hessian (ESM hess type Original), same layout */
+	MTFHIP_BUF_COUNT = 22
 };
 
 typedef struct mtfhip_patch_desc {
@@ -79,6 +86,7 @@ typedef struct mtfhip_patch_desc {
 	int mi_n_bins;          /* MIParams::n_bins */
 	double mi_pre_seed;     /* MIParams::pre_seed */
 	int mi_partition_of_unity;
+	double hess_eps;        /* ImgParams::hess_eps (1, AM/include/mtf/AM/ImageBase.h:9); <= 0 selects that default */
 } mtfhip_patch_desc;
 
 /* Search-method configuration; field meanings and enum values are the reference's
@@ -95,6 +103,7 @@ typedef struct mtfhip_sm_desc {
 	double epsilon;
 	int leven_marq;
 	double lm_delta_init, lm_delta_update;
+	int sec_ord_hess;  /* second-order Hessians (ESMParams / FCLKParams / ICLKParams sec_ord_hess; off in every shipped config) */
 } mtfhip_sm_desc;
 
 /* ------------------------------------------------------------------ context */
@@ -176,6 +185,23 @@ int mtfhip_am_cmpt_sum_of_hessians(mtfhip_batch *b, int j0_buf, int jt_buf, doub
 /* JM = (J0 + JT) / 2 on device: the SM-side `mean_pix_jacobian` of NT/ESM.cc:239-242 */
 int mtfhip_sm_mean_jacobian(mtfhip_batch *b);
 
+/* ---- second-order Hessians (sec_ord_hess = 1; NT/ESM.cc:315-377,406-432, NT/FCLK.cc:121-143,243-283, NT/ICLK.cc:96-124,223-252) ----
+ * pts / hess_pts arguments: NULL = the batch's device-resident curr_pts / hess_pts, else host arrays (2 x N, 16 x N per target). */
+int mtfhip_ssm_update_hess_pts(mtfhip_batch *b, double hess_eps);                 /* Homography.cc:829-875, Affine.cc:315-350 (= initializeHessPts) */
+int mtfhip_am_initialize_pix_hess(mtfhip_batch *b, const double *pts);            /* ImageBase.cc:208-240 -> utils::getImgHess imgUtils.cc:334-366 */
+int mtfhip_am_update_pix_hess(mtfhip_batch *b, const double *pts);                /* ImageBase.cc:316-338 */
+int mtfhip_am_initialize_pix_hess_warped(mtfhip_batch *b, const double *pts, const double *hess_pts); /* ImageBase.cc:174-206 -> getWarpedImgHess imgUtils.cc:259-289 */
+int mtfhip_am_update_pix_hess_warped(mtfhip_batch *b, const double *pts, const double *hess_pts);     /* ImageBase.cc:364-386 */
+/* StateSpaceModel::cmpt{Init,,Warped,Approx}PixHessian (variant = MTFHIP_JAC_*): Homography.cc:360-425, 427-513, 515-618,
+ * 696-801; Affine.cc:243-291 (Init, Warped; the other two return MTFHIP_ERR_NOT_IMPLEMENTED as the reference throws).
+ * hess_buf = MTFHIP_BUF_D2I0_DX2 / _D2IT_DX2, grad_buf = _DI0_DX / _DIT_DX, dst_buf = _D2I0_DP2 / _D2IT_DP2 / _D2IM_DP2 */
+int mtfhip_ssm_cmpt_pix_hessian(mtfhip_batch *b, int variant, int hess_buf, int grad_buf, int dst_buf);
+int mtfhip_sm_mean_pix_hessian(mtfhip_batch *b);                                  /* D2IM = (D2I0 + D2IT) / 2, NT/ESM.cc:325 */
+int mtfhip_am_cmpt_init_hessian2(mtfhip_batch *b, int j0_buf, int d2_buf, double *H); /* SSDBase.cc:313-343, NCC.cc:391-400, MI.cc:659-673 */
+int mtfhip_am_cmpt_curr_hessian2(mtfhip_batch *b, int jt_buf, int d2_buf, double *H); /* SSDBase.cc:345-375, NCC.cc:401-410, MI.cc:680-694 */
+int mtfhip_am_cmpt_self_hessian2(mtfhip_batch *b, int jt_buf, int d2_buf, double *H); /* SSDBase.h:95-98, MI.cc:696-733; NCC: not implemented */
+int mtfhip_am_cmpt_sum_of_hessians2(mtfhip_batch *b, int j0_buf, int jt_buf, int d2_0_buf, int d2_t_buf, double *H); /* SSDBase.cc:377-415 */
+
 /* ---- fused path: one launch per LK iteration for all targets of the batch ----
  * init_template = the body of nt::{ESM,FCLK,ICLK}::initialize after ssm->initialize
  * (NT/ESM.cc:110-146, NT/FCLK.cc:102-169, NT/ICLK.cc:71-128): I0, dI0_dx, J0 and the constant
@@ -197,6 +223,13 @@ int mtfhip_score_candidates(mtfhip_batch *b, const double *states /* C x S */, i
 	double *likelihoods /* C or NULL */, double *similarities /* C or NULL */);
 int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int n_candidates,
 	double *dev_likelihoods, double *dev_similarities);
+
+/* ---- NN-SM dataset generation (the second batch axis of the path; the search itself stays with FLANN) ----
+ * Row c of the C x N feature matrix = updateDistFeat() of the patch sampled under state c:
+ * setState / compositionalUpdate -> updatePixVals -> updateDistFeat (SM/src/NT/NN.cc:131-191;
+ * SSD feature = It, AM/include/mtf/AM/SSDBase.h:116-125; NCC feature = (It - mean)/||It - mean||, AM/src/NCC.cc:530-537) */
+int mtfhip_sample_candidates(mtfhip_batch *b, const double *states /* C x S */, int n_samples, double *features /* C x N */);
+int mtfhip_sample_candidates_dev(mtfhip_batch *b, const double *dev_states, int n_samples, double *dev_features);
 
 /* ---- measurement hooks ---- */
 /* average duration in milliseconds of the launches of the named kernel family since the last

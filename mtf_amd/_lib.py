@@ -15,7 +15,8 @@ SSM_HOMOGRAPHY, SSM_AFFINE = 0, 1
 SM_ESM, SM_FCLK, SM_ICLK = 0, 1, 2
 JAC_INIT, JAC_PIX, JAC_WARPED, JAC_APPROX = 0, 1, 2, 3
 (BUF_I0, BUF_IT, BUF_DI0_DX, BUF_DIT_DX, BUF_DF_DI0, BUF_DF_DIT, BUF_J0, BUF_JT, BUF_JM,
- BUF_INIT_PTS, BUF_CURR_PTS, BUF_GRAD_PTS, BUF_INIT_Z, BUF_CURR_Z, BUF_INIT_HXY, BUF_CURR_HXY) = range(16)
+ BUF_INIT_PTS, BUF_CURR_PTS, BUF_GRAD_PTS, BUF_INIT_Z, BUF_CURR_Z, BUF_INIT_HXY, BUF_CURR_HXY,
+ BUF_D2I0_DX2, BUF_D2IT_DX2, BUF_HESS_PTS, BUF_D2I0_DP2, BUF_D2IT_DP2, BUF_D2IM_DP2) = range(22)
 
 
 class MtfHipError(RuntimeError):
@@ -44,13 +45,14 @@ _ERR = {-1: InvalidArgument, -2: FunctionNotImplemented, -3: LogicError}
 class PatchDesc(C.Structure):
     _fields_ = [("am", C.c_int), ("ssm", C.c_int), ("resx", C.c_int), ("resy", C.c_int),
                 ("grad_eps", C.c_double), ("likelihood_alpha", C.c_double), ("mi_n_bins", C.c_int),
-                ("mi_pre_seed", C.c_double), ("mi_partition_of_unity", C.c_int)]
+                ("mi_pre_seed", C.c_double), ("mi_partition_of_unity", C.c_int), ("hess_eps", C.c_double)]
 
 
 class SMDesc(C.Structure):
     _fields_ = [("sm", C.c_int), ("jac_type", C.c_int), ("hess_type", C.c_int), ("chained_warp", C.c_int),
                 ("materialize", C.c_int), ("max_iters", C.c_int), ("epsilon", C.c_double),
-                ("leven_marq", C.c_int), ("lm_delta_init", C.c_double), ("lm_delta_update", C.c_double)]
+                ("leven_marq", C.c_int), ("lm_delta_init", C.c_double), ("lm_delta_update", C.c_double),
+                ("sec_ord_hess", C.c_int)]
 
 
 # every exported symbol of include/mtfhip.h (tests check that the library exports all of them)
@@ -71,8 +73,13 @@ SYMBOLS = [
     "mtfhip_am_cmpt_init_jacobian", "mtfhip_am_cmpt_curr_jacobian", "mtfhip_am_cmpt_difference_of_jacobians",
     "mtfhip_am_cmpt_init_hessian", "mtfhip_am_cmpt_curr_hessian", "mtfhip_am_cmpt_self_hessian",
     "mtfhip_am_cmpt_sum_of_hessians", "mtfhip_sm_mean_jacobian",
+    "mtfhip_ssm_update_hess_pts", "mtfhip_am_initialize_pix_hess", "mtfhip_am_update_pix_hess",
+    "mtfhip_am_initialize_pix_hess_warped", "mtfhip_am_update_pix_hess_warped", "mtfhip_ssm_cmpt_pix_hessian",
+    "mtfhip_sm_mean_pix_hessian", "mtfhip_am_cmpt_init_hessian2", "mtfhip_am_cmpt_curr_hessian2",
+    "mtfhip_am_cmpt_self_hessian2", "mtfhip_am_cmpt_sum_of_hessians2",
     "mtfhip_batch_init_template", "mtfhip_batch_iterate", "mtfhip_batch_track",
     "mtfhip_score_candidates", "mtfhip_score_candidates_dev",
+    "mtfhip_sample_candidates", "mtfhip_sample_candidates_dev",
     "mtfhip_timing_enable", "mtfhip_timing_reset", "mtfhip_timing_get",
 ]
 
@@ -112,8 +119,19 @@ def lib():
         L.mtfhip_image_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.mtfhip_image_borrow.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.mtfhip_ssm_update_grad_pts.argtypes = [C.c_void_p, C.c_double]
+        L.mtfhip_ssm_update_hess_pts.argtypes = [C.c_void_p, C.c_double]
+        for fn in ("mtfhip_am_initialize_pix_hess", "mtfhip_am_update_pix_hess"):
+            getattr(L, fn).argtypes = [C.c_void_p, C.c_void_p]
+        for fn in ("mtfhip_am_initialize_pix_hess_warped", "mtfhip_am_update_pix_hess_warped"):
+            getattr(L, fn).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mtfhip_ssm_cmpt_pix_hessian.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        for fn in ("mtfhip_am_cmpt_init_hessian2", "mtfhip_am_cmpt_curr_hessian2", "mtfhip_am_cmpt_self_hessian2"):
+            getattr(L, fn).argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.mtfhip_am_cmpt_sum_of_hessians2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.mtfhip_score_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.mtfhip_score_candidates_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.mtfhip_sample_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.mtfhip_sample_candidates_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.mtfhip_batch_device_ptr.argtypes = [C.c_void_p, C.c_int]
         L.mtfhip_batch_read.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.mtfhip_batch_write.argtypes = [C.c_void_p, C.c_int, C.c_void_p]

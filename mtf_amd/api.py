@@ -6,12 +6,14 @@ SSM/include/mtf/SSM/StateSpaceModel.h:98-181.  NumPy arrays are in NumPy-natural
 this side (pts (B, 2, N), grad (B, N, 2), J (B, N, S), H (B, S, S), corners (B, 2, 4)) and are
 converted to/from the Eigen column-major layouts of the C ABI here.
 """
+import sys
 import ctypes as C
 
 import numpy as np
 
 from . import _lib as L
-from ._lib import (AM_MI, AM_NCC, AM_SSD, BUF_CURR_PTS, BUF_DF_DI0, BUF_DF_DIT, BUF_DI0_DX, BUF_DIT_DX,
+from ._lib import (AM_MI, AM_NCC, AM_SSD, BUF_CURR_PTS, BUF_D2I0_DP2, BUF_D2I0_DX2, BUF_D2IM_DP2, BUF_D2IT_DP2, BUF_D2IT_DX2,
+                   BUF_DF_DI0, BUF_DF_DIT, BUF_DI0_DX, BUF_DIT_DX, BUF_HESS_PTS,
                    BUF_GRAD_PTS, BUF_I0, BUF_INIT_PTS, BUF_IT, BUF_J0, BUF_JM, BUF_JT, JAC_APPROX, JAC_INIT,
                    JAC_PIX, JAC_WARPED, SM_ESM, SM_FCLK, SM_ICLK, SSM_AFFINE, SSM_HOMOGRAPHY, PatchDesc, SMDesc)
 
@@ -47,6 +49,8 @@ class Context:
             self._h = C.c_void_p()
 
     def __del__(self):
+        if sys.is_finalizing():    # the HIP runtime may already be gone; the OS reclaims the device memory
+            return
         try:
             self.close()
         except Exception:
@@ -92,9 +96,9 @@ class Batch:
     """B independent targets (AM + SSM pairs) sharing the context's current image."""
 
     def __init__(self, ctx, am=AM_SSD, ssm=SSM_HOMOGRAPHY, resx=50, resy=50, n_targets=1, grad_eps=1e-8,
-                 likelihood_alpha=1.0, mi_n_bins=8, mi_pre_seed=10.0, mi_pou=0):
+                 likelihood_alpha=1.0, mi_n_bins=8, mi_pre_seed=10.0, mi_pou=0, hess_eps=1.0):
         self.ctx = ctx
-        self.desc = PatchDesc(am, ssm, resx, resy, grad_eps, likelihood_alpha, mi_n_bins, mi_pre_seed, mi_pou)
+        self.desc = PatchDesc(am, ssm, resx, resy, grad_eps, likelihood_alpha, mi_n_bins, mi_pre_seed, mi_pou, hess_eps)
         self._h = C.c_void_p()
         L.check(L.lib().mtfhip_batch_create(ctx._h, C.byref(self.desc), int(n_targets), C.byref(self._h)))
         self.B = n_targets
@@ -107,6 +111,8 @@ class Batch:
             self._h = C.c_void_p()
 
     def __del__(self):
+        if sys.is_finalizing():    # the HIP runtime may already be gone; the OS reclaims the device memory
+            return
         try:
             self.close()
         except Exception:
@@ -120,7 +126,8 @@ class Batch:
         B, N, S = self.B, self.N, self.S
         sizes = {BUF_I0: N, BUF_IT: N, BUF_DI0_DX: 2 * N, BUF_DIT_DX: 2 * N, BUF_DF_DI0: N, BUF_DF_DIT: N,
                  BUF_J0: N * S, BUF_JT: N * S, BUF_JM: N * S, BUF_INIT_PTS: 2 * N, BUF_CURR_PTS: 2 * N,
-                 BUF_GRAD_PTS: 8 * N, 12: N, 13: N, 14: 2 * N, 15: 2 * N}
+                 BUF_GRAD_PTS: 8 * N, 12: N, 13: N, 14: 2 * N, 15: 2 * N, BUF_D2I0_DX2: 4 * N, BUF_D2IT_DX2: 4 * N,
+                 BUF_HESS_PTS: 16 * N, BUF_D2I0_DP2: S * S * N, BUF_D2IT_DP2: S * S * N, BUF_D2IM_DP2: S * S * N}
         out = np.empty((B, sizes[buf]))
         L.check(L.lib().mtfhip_batch_read(self._h, buf, _p(out)))
         if buf in (BUF_DI0_DX, BUF_DIT_DX):
@@ -131,6 +138,12 @@ class Batch:
             return out.reshape(B, N, 2).transpose(0, 2, 1)
         if buf == BUF_GRAD_PTS:
             return out.reshape(B, N, 8)
+        if buf == BUF_HESS_PTS:
+            return out.reshape(B, N, 16)
+        if buf in (BUF_D2I0_DX2, BUF_D2IT_DX2):
+            return out.reshape(B, N, 2, 2)
+        if buf in (BUF_D2I0_DP2, BUF_D2IT_DP2, BUF_D2IM_DP2):      # planes [c][r][N] -> (B, N, r, c)
+            return out.reshape(B, S, S, N).transpose(0, 3, 2, 1)
         return out
 
     def write(self, buf, arr):
@@ -306,6 +319,45 @@ class Batch:
     def mean_jacobian(self):
         L.check(L.lib().mtfhip_sm_mean_jacobian(self._h))
 
+    # ---------------------------------------------------------- second order (sec_ord_hess)
+    def update_hess_pts(self, hess_eps=None):
+        """StateSpaceModel::updateHessPts / initializeHessPts (Homography.cc:829-875, Affine.cc:315-350)"""
+        L.check(L.lib().mtfhip_ssm_update_hess_pts(self._h, float(self.desc.hess_eps if hess_eps is None else hess_eps)))
+
+    def _pix_hess(self, fn, fn_warped, pts, hess_pts, warped):
+        keep, pp = self._pts_arg(pts, 2)
+        if not warped:
+            L.check(fn(self._h, pp))
+            return
+        hp = None if hess_pts is None else np.ascontiguousarray(_f64(hess_pts).reshape(self.B, self.N * 16))
+        L.check(fn_warped(self._h, pp, None if hp is None else _p(hp)))
+
+    def initialize_pix_hess(self, pts=None, hess_pts=None, warped=False):
+        """ImageBase::initializePixHess(pts) or, with warped=True, (pts, hess_pts); None = device-resident"""
+        self._pix_hess(L.lib().mtfhip_am_initialize_pix_hess, L.lib().mtfhip_am_initialize_pix_hess_warped, pts, hess_pts, warped)
+
+    def update_pix_hess(self, pts=None, hess_pts=None, warped=False):
+        self._pix_hess(L.lib().mtfhip_am_update_pix_hess, L.lib().mtfhip_am_update_pix_hess_warped, pts, hess_pts, warped)
+
+    def cmpt_pix_hessian(self, variant, hess_buf, grad_buf, dst_buf):
+        """cmpt{Init,,Warped,Approx}PixHessian by variant = JAC_*"""
+        L.check(L.lib().mtfhip_ssm_cmpt_pix_hessian(self._h, variant, hess_buf, grad_buf, dst_buf))
+
+    def mean_pix_hessian(self):
+        L.check(L.lib().mtfhip_sm_mean_pix_hessian(self._h))
+
+    def cmpt_init_hessian2(self, j0=BUF_J0, d2=BUF_D2I0_DP2):
+        return self._H(L.lib().mtfhip_am_cmpt_init_hessian2, j0, d2)
+
+    def cmpt_curr_hessian2(self, jt=BUF_JT, d2=BUF_D2IT_DP2):
+        return self._H(L.lib().mtfhip_am_cmpt_curr_hessian2, jt, d2)
+
+    def cmpt_self_hessian2(self, jt=BUF_JT, d2=BUF_D2IT_DP2):
+        return self._H(L.lib().mtfhip_am_cmpt_self_hessian2, jt, d2)
+
+    def cmpt_sum_of_hessians2(self, j0=BUF_J0, jt=BUF_JT, d20=BUF_D2I0_DP2, d2t=BUF_D2IT_DP2):
+        return self._H(L.lib().mtfhip_am_cmpt_sum_of_hessians2, j0, jt, d20, d2t)
+
     # ---------------------------------------------------------- fused path
     def init_template(self, sm):
         L.check(L.lib().mtfhip_batch_init_template(self._h, C.byref(sm)))
@@ -330,6 +382,13 @@ class Batch:
         sim = np.empty(s.shape[0]) if want_similarity else None
         L.check(L.lib().mtfhip_score_candidates(self._h, _p(s), s.shape[0], _p(lik), _p(sim) if want_similarity else None))
         return (lik, sim) if want_similarity else lik
+
+    def sample_candidates(self, states):
+        """NN dataset rows: (C, N) distance features of the patches sampled under the C states."""
+        s = _f64(states).reshape(-1, self.S)
+        out = np.empty((s.shape[0], self.N))
+        L.check(L.lib().mtfhip_sample_candidates(self._h, _p(s), s.shape[0], _p(out)))
+        return out
 
     def score_candidates_dev(self, dev_states, n, dev_lik, dev_sim=None):
         L.check(L.lib().mtfhip_score_candidates_dev(self._h, C.c_void_p(dev_states), int(n), C.c_void_p(dev_lik),

@@ -202,6 +202,9 @@ struct mtfhip_batch {
 	double *d_mi_tb = nullptr, *d_mi_part = nullptr, *d_mi_f = nullptr, *d_mi_H = nullptr;
 	double *d_h0inv = nullptr; /* [B][64] inverse of the constant Hessian (one-launch ICLK) */
 	double *d_units = nullptr; /* per-work-unit partial sums of the LDS-staged candidate scorer */
+	double *d_d2_part = nullptr, *d_d2_out = nullptr, *d_d2_w = nullptr; /* second-order term: block rows, [B][64] sums, MI self weights */
+	double hess_eps = 1.0;
+	bool init_pix_hess = false;
 	size_t unit_capacity = 0;
 	int mi_row_len = 0;
 	double mi_hist_norm = 0;
@@ -316,15 +319,20 @@ int mtfhip_ctx_create(int device, void *hip_stream, mtfhip_ctx **out) {
 	return MTFHIP_OK;
 }
 
+/* The destroy calls may run from a host-language finaliser after the HIP runtime has begun tearing itself
+ * down at process exit (its calls then throw from inside the runtime); nothing may escape a C entry point. */
 void mtfhip_ctx_destroy(mtfhip_ctx *c) {
 	if (!c) return;
-	(void)hipSetDevice(c->device);
-	(void)hipStreamSynchronize(c->stream);
-	for (auto &kv : c->timers)
-		for (auto &p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-	for (auto e : c->free_events) (void)hipEventDestroy(e);
-	if (c->img_owned) (void)hipFree(c->img_owned);
-	if (c->own_stream) (void)hipStreamDestroy(c->stream);
+	try {
+		(void)hipSetDevice(c->device);
+		(void)hipStreamSynchronize(c->stream);
+		for (auto &kv : c->timers)
+			for (auto &p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+		for (auto e : c->free_events) (void)hipEventDestroy(e);
+		if (c->img_owned) (void)hipFree(c->img_owned);
+		if (c->own_stream) (void)hipStreamDestroy(c->stream);
+	} catch (...) {
+	}
 	delete c;
 }
 
@@ -383,7 +391,9 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 		b->norm_add = lo;
 	}
 	const size_t N = b->N, S = b->S;
-	size_t per[MTFHIP_BUF_COUNT] = {N, N, 2 * N, 2 * N, N, N, N * S, N * S, N * S, 2 * N, 2 * N, 8 * N, N, N, 2 * N, 2 * N};
+	size_t per[MTFHIP_BUF_COUNT] = {N, N, 2 * N, 2 * N, N, N, N * S, N * S, N * S, 2 * N, 2 * N, 8 * N, N, N, 2 * N, 2 * N,
+		4 * N, 4 * N, 16 * N, S * S * N, S * S * N, S * S * N};
+	b->hess_eps = d->hess_eps > 0 ? d->hess_eps : 1.0; /* HESS_EPS, AM/include/mtf/AM/ImageBase.h:9 */
 	for (int i = 0; i < MTFHIP_BUF_COUNT; ++i) { b->per_target[i] = per[i]; b->buf[i] = nullptr; }
 	b->th.resize(n_targets);
 	for (auto &h : b->th) { std::memset(&h, 0, sizeof(h)); h.warp = m3_identity(); }
@@ -400,7 +410,7 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 	ALLOC(b->d_states, sizeof(double) * 8 * n_targets);
 	ALLOC(b->d_partials, sizeof(double) * ACC_COUNT * b->nblk_max * n_targets);
 	ALLOC(b->d_acc, sizeof(double) * ACC_COUNT * n_targets);
-	ALLOC(b->d_scratch_pts, sizeof(double) * 8 * N * n_targets);
+	ALLOC(b->d_scratch_pts, sizeof(double) * 18 * N * n_targets); /* largest upload: pts (2N) + hess_pts (16N) */
 	ALLOC(b->d_w0, sizeof(double) * 9 * n_targets);
 	ALLOC(b->d_h0, sizeof(double) * 64 * n_targets);
 	ALLOC(b->d_corners, sizeof(double) * 8 * n_targets);
@@ -433,16 +443,19 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 
 void mtfhip_batch_destroy(mtfhip_batch *b) {
 	if (!b) return;
-	(void)hipSetDevice(b->ctx->device);
-	(void)hipStreamSynchronize(b->ctx->stream);
-	for (int i = 0; i < MTFHIP_BUF_COUNT; ++i)
-		if (b->buf[i]) (void)hipFree(b->buf[i]);
-	void *ptrs[] = {b->d_warps, b->d_states, b->d_partials, b->d_acc, b->d_scratch_pts, b->d_w0, b->d_h0, b->d_corners,
-		b->d_init_corners_hm, b->d_active, b->d_iters, b->d_cand, b->d_ncc, b->d_colmean, b->d_mi_tb, b->d_mi_part,
-		b->d_mi_f, b->d_mi_H, b->d_h0inv, b->d_units};
-	for (void *p : ptrs)
-		if (p) (void)hipFree(p);
-	if (b->h_acc) (void)hipHostFree(b->h_acc);
+	try {
+		(void)hipSetDevice(b->ctx->device);
+		(void)hipStreamSynchronize(b->ctx->stream);
+		for (int i = 0; i < MTFHIP_BUF_COUNT; ++i)
+			if (b->buf[i]) (void)hipFree(b->buf[i]);
+		void *ptrs[] = {b->d_warps, b->d_states, b->d_partials, b->d_acc, b->d_scratch_pts, b->d_w0, b->d_h0, b->d_corners,
+			b->d_init_corners_hm, b->d_active, b->d_iters, b->d_cand, b->d_ncc, b->d_colmean, b->d_mi_tb, b->d_mi_part,
+			b->d_mi_f, b->d_mi_H, b->d_h0inv, b->d_units, b->d_d2_part, b->d_d2_out, b->d_d2_w};
+		for (void *p : ptrs)
+			if (p) (void)hipFree(p);
+		if (b->h_acc) (void)hipHostFree(b->h_acc);
+	} catch (...) {
+	}
 	delete b;
 }
 
@@ -1095,6 +1108,150 @@ int mtfhip_sm_mean_jacobian(mtfhip_batch *b) {
 	return MTFHIP_OK;
 }
 
+/* ------------------------------------------------------------------ second order (sec_ord_hess) */
+static int hess_buf_ok(int id) { return id == MTFHIP_BUF_D2I0_DX2 || id == MTFHIP_BUF_D2IT_DX2; }
+static int d2_buf_ok(int id) { return id == MTFHIP_BUF_D2I0_DP2 || id == MTFHIP_BUF_D2IT_DP2 || id == MTFHIP_BUF_D2IM_DP2; }
+
+int mtfhip_ssm_update_hess_pts(mtfhip_batch *b, double hess_eps) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_hess_pts: NULL batch");
+	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "update_hess_pts before set_corners");
+	TRY(ensure_buf(b, MTFHIP_BUF_HESS_PTS));
+	TimedScope ts(b->ctx, "hess_pts");
+	launch_hess_pts(b->view(), hess_eps, b->ctx->stream);
+	return MTFHIP_OK;
+}
+
+/* ImageBase::initializePixHess / updatePixHess, both overloads (AM/src/ImageBase.cc:174-240, 316-338, 364-386) */
+static int pix_hess_common(mtfhip_batch *b, const double *pts, const double *hess_pts, bool warped, bool init) {
+	TRY(need_image(b));
+	TRY(ensure_buf(b, MTFHIP_BUF_D2I0_DX2));
+	TRY(ensure_buf(b, MTFHIP_BUF_D2IT_DX2));
+	const size_t N = b->N;
+	const double *dp, *dh = nullptr;
+	TRY(resolve_pts(b, pts, MTFHIP_BUF_CURR_PTS, 2 * N, &dp));
+	if (warped) {
+		if (!hess_pts) {
+			if (!b->buf[MTFHIP_BUF_HESS_PTS]) return fail(MTFHIP_ERR_LOGIC, "pix_hess: device hess_pts not available (call update_hess_pts)");
+			dh = b->buf[MTFHIP_BUF_HESS_PTS];
+		} else {
+			double *stage = b->d_scratch_pts + 2 * N * b->B;
+			HIP_TRY(hipMemcpyAsync(stage, hess_pts, sizeof(double) * 16 * N * b->B, hipMemcpyHostToDevice, b->ctx->stream));
+			dh = stage;
+		}
+	}
+	double *dst = b->buf[init ? MTFHIP_BUF_D2I0_DX2 : MTFHIP_BUF_D2IT_DX2];
+	{
+		TimedScope ts(b->ctx, warped ? "warped_img_hess" : "img_hess");
+		if (warped) launch_warped_img_hess(b->view(), b->ctx->img, dp, dh, dst, b->hess_eps, b->norm_mult, b->ctx->stream);
+		else launch_img_hess(b->view(), b->ctx->img, dp, dst, b->hess_eps, b->norm_mult, b->ctx->stream);
+	}
+	if (init && !b->init_pix_hess) {
+		HIP_TRY(hipMemcpyAsync(b->buf[MTFHIP_BUF_D2IT_DX2], b->buf[MTFHIP_BUF_D2I0_DX2], sizeof(double) * 4 * N * b->B, hipMemcpyDeviceToDevice, b->ctx->stream));
+		b->init_pix_hess = true;
+	}
+	return MTFHIP_OK;
+}
+int mtfhip_am_initialize_pix_hess(mtfhip_batch *b, const double *pts) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "initialize_pix_hess: NULL batch");
+	return pix_hess_common(b, pts, nullptr, false, true);
+}
+int mtfhip_am_update_pix_hess(mtfhip_batch *b, const double *pts) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_pix_hess: NULL batch");
+	return pix_hess_common(b, pts, nullptr, false, false);
+}
+int mtfhip_am_initialize_pix_hess_warped(mtfhip_batch *b, const double *pts, const double *hess_pts) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "initialize_pix_hess_warped: NULL batch");
+	return pix_hess_common(b, pts, hess_pts, true, true);
+}
+int mtfhip_am_update_pix_hess_warped(mtfhip_batch *b, const double *pts, const double *hess_pts) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_pix_hess_warped: NULL batch");
+	return pix_hess_common(b, pts, hess_pts, true, false);
+}
+
+int mtfhip_ssm_cmpt_pix_hessian(mtfhip_batch *b, int variant, int hess_buf, int grad_buf, int dst_buf) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_pix_hessian: NULL batch");
+	if (variant < MTFHIP_JAC_INIT || variant > MTFHIP_JAC_APPROX) return fail(MTFHIP_ERR_INVALID_ARG, "unknown pixel Hessian variant %d", variant);
+	if (!hess_buf_ok(hess_buf)) return fail(MTFHIP_ERR_INVALID_ARG, "hess_buf must be D2I0_DX2 or D2IT_DX2");
+	if (grad_buf != MTFHIP_BUF_DI0_DX && grad_buf != MTFHIP_BUF_DIT_DX) return fail(MTFHIP_ERR_INVALID_ARG, "grad_buf must be DI0_DX or DIT_DX");
+	if (!d2_buf_ok(dst_buf)) return fail(MTFHIP_ERR_INVALID_ARG, "dst_buf must be D2I0_DP2, D2IT_DP2 or D2IM_DP2");
+	/* Affine implements Init and Warped only (SSM/include/mtf/SSM/Affine.h); the others are ssm_func_not_implemeted
+	 * (StateSpaceModel.h:186-197) */
+	if (b->desc.ssm == MTFHIP_SSM_AFFINE && (variant == MTFHIP_JAC_PIX || variant == MTFHIP_JAC_APPROX))
+		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s :: function not implemented yet", variant == MTFHIP_JAC_PIX ? "cmptPixHessian" : "cmptApproxPixHessian");
+	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "cmpt_pix_hessian before set_corners");
+	if (!b->buf[hess_buf]) return fail(MTFHIP_ERR_LOGIC, "cmpt_pix_hessian: image Hessian %d was never computed", hess_buf);
+	TRY(ensure_buf(b, dst_buf));
+	TimedScope ts(b->ctx, "pix_hessian");
+	launch_pix_hessian(b->view(), variant, b->buf[hess_buf], b->buf[grad_buf], b->buf[dst_buf], b->ctx->stream);
+	return MTFHIP_OK;
+}
+
+int mtfhip_sm_mean_pix_hessian(mtfhip_batch *b) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "mean_pix_hessian: NULL batch");
+	if (!b->buf[MTFHIP_BUF_D2I0_DP2] || !b->buf[MTFHIP_BUF_D2IT_DP2]) return fail(MTFHIP_ERR_LOGIC, "mean_pix_hessian: init / curr pixel Hessians not computed");
+	TRY(ensure_buf(b, MTFHIP_BUF_D2IM_DP2));
+	TimedScope ts(b->ctx, "mean_pix_hessian");
+	launch_mean_planes(b->buf[MTFHIP_BUF_D2I0_DP2], b->buf[MTFHIP_BUF_D2IT_DP2], b->buf[MTFHIP_BUF_D2IM_DP2],
+		(size_t)b->B * b->N * b->S * b->S, b->ctx->stream);
+	return MTFHIP_OK;
+}
+
+/* H[t] += sum_p w[p] * (d2a[:, p] (+ d2b[:, p])) */
+static int add_second_order(mtfhip_batch *b, int d2a, int d2b, const double *dev_w, double *H) {
+	if (!d2_buf_ok(d2a) || (d2b >= 0 && !d2_buf_ok(d2b))) return fail(MTFHIP_ERR_INVALID_ARG, "pixel-Hessian buffer must be D2I0_DP2, D2IT_DP2 or D2IM_DP2");
+	if (!b->buf[d2a] || (d2b >= 0 && !b->buf[d2b])) return fail(MTFHIP_ERR_LOGIC, "second-order Hessian: pixel Hessian buffer was never computed");
+	const int nblk = simple_blocks_per_target(b->N), S = b->S;
+	if (!b->d_d2_part) {
+		HIP_TRY(hipMalloc(&b->d_d2_part, sizeof(double) * 64 * (size_t)nblk * b->B));
+		HIP_TRY(hipMalloc(&b->d_d2_out, sizeof(double) * 64 * (size_t)b->B));
+	}
+	{
+		TimedScope ts(b->ctx, "pix_hess_weighted_sum");
+		launch_weighted_plane_sum(b->view(), b->buf[d2a], d2b >= 0 ? b->buf[d2b] : nullptr, dev_w, b->d_d2_part, nblk, b->d_d2_out, b->ctx->stream);
+	}
+	std::vector<double> h((size_t)S * S * b->B);
+	HIP_TRY(hipMemcpyAsync(h.data(), b->d_d2_out, sizeof(double) * h.size(), hipMemcpyDeviceToHost, b->ctx->stream));
+	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	for (size_t i = 0; i < h.size(); ++i) H[i] += h[i];
+	return MTFHIP_OK;
+}
+/* SSDBase.cc:313-343 ; NCC.cc:391-400 ; MI.cc:659-673 */
+int mtfhip_am_cmpt_init_hessian2(mtfhip_batch *b, int j0_buf, int d2_buf, double *H) {
+	TRY(mtfhip_am_cmpt_init_hessian(b, j0_buf, H));
+	return add_second_order(b, d2_buf, -1, b->buf[MTFHIP_BUF_DF_DI0], H);
+}
+/* SSDBase.cc:345-375 ; NCC.cc:401-410 ; MI.cc:680-694 */
+int mtfhip_am_cmpt_curr_hessian2(mtfhip_batch *b, int jt_buf, int d2_buf, double *H) {
+	TRY(mtfhip_am_cmpt_curr_hessian(b, jt_buf, H));
+	return add_second_order(b, d2_buf, -1, b->buf[MTFHIP_BUF_DF_DIT], H);
+}
+/* SSD: first order only (SSDBase.h:95-98) ; NCC: am_func_not_implemeted (AppearanceModel.h:188-191) ; MI.cc:696-733 */
+int mtfhip_am_cmpt_self_hessian2(mtfhip_batch *b, int jt_buf, int d2_buf, double *H) {
+	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_self_hessian (second order): NULL argument");
+	if (b->desc.am == MTFHIP_AM_NCC) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "ncc :: cmptSelfHessian(second order) :: function not implemented yet");
+	TRY(mtfhip_am_cmpt_self_hessian(b, jt_buf, H));
+	if (b->desc.am == MTFHIP_AM_SSD) return MTFHIP_OK;
+	/* MI: weight = sum_r curr_hist_grad(r) * sum_t curr_hist_mat(t) * self_grad_factor(r, t)  (MI.cc:710-723);
+	 * the self table was filled by the first-order call above */
+	if (!b->d_d2_w) HIP_TRY(hipMalloc(&b->d_d2_w, sizeof(double) * (size_t)b->N * b->B));
+	launch_mi_grad(b->view(), b->desc.mi_n_bins, b->mi_hist_norm, b->buf[MTFHIP_BUF_IT], b->buf[MTFHIP_BUF_IT], b->d_mi_tb, MI_T_SELF,
+		b->d_d2_w, b->ctx->stream);
+	return add_second_order(b, d2_buf, -1, b->d_d2_w, H);
+}
+/* SSDBase.cc:377-415 (both pixel Hessians weighted by df_dI0) ; NCC / MI: generic AppearanceModel.h:209-219 */
+int mtfhip_am_cmpt_sum_of_hessians2(mtfhip_batch *b, int j0_buf, int jt_buf, int d20_buf, int d2t_buf, double *H) {
+	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_sum_of_hessians (second order): NULL argument");
+	if (b->desc.am == MTFHIP_AM_SSD) {
+		TRY(mtfhip_am_cmpt_sum_of_hessians(b, j0_buf, jt_buf, H));
+		return add_second_order(b, d20_buf, d2t_buf, b->buf[MTFHIP_BUF_DF_DI0], H);
+	}
+	std::vector<double> H0((size_t)b->B * b->S * b->S);
+	TRY(mtfhip_am_cmpt_init_hessian2(b, j0_buf, d20_buf, H0.data()));
+	TRY(mtfhip_am_cmpt_curr_hessian2(b, jt_buf, d2t_buf, H));
+	for (size_t i = 0; i < H0.size(); ++i) H[i] += H0[i];
+	return MTFHIP_OK;
+}
+
 /* ------------------------------------------------------------------ fused path */
 static int check_sm(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const char *fn) {
 	if (!b || !sm) return fail(MTFHIP_ERR_INVALID_ARG, "%s: NULL argument", fn);
@@ -1340,6 +1497,32 @@ int mtfhip_score_candidates(mtfhip_batch *b, const double *states, int C, double
 	if (sim) HIP_TRY(hipMemcpyAsync(sim, d_sim, sizeof(double) * C, hipMemcpyDeviceToHost, b->ctx->stream));
 	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
 	return MTFHIP_OK;
+}
+
+/* ------------------------------------------------------------------ NN dataset generation */
+int mtfhip_sample_candidates_dev(mtfhip_batch *b, const double *dev_states, int C, double *dev_features) {
+	if (!b || !dev_states || !dev_features) return fail(MTFHIP_ERR_INVALID_ARG, "sample_candidates: NULL argument");
+	if (C <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "sample_candidates: n_samples must be positive");
+	if (b->desc.am == MTFHIP_AM_MI) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "sample_candidates: MI distance features (5 x N B-spline rows) are not available");
+	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "sample_candidates before set_corners");
+	TRY(need_image(b));
+	TimedScope ts(b->ctx, "sample_candidates");
+	launch_sample_candidates(b->view(), b->ctx->img, dev_states, C, b->norm_mult, b->norm_add, dev_features, b->ctx->stream);
+	return MTFHIP_OK;
+}
+int mtfhip_sample_candidates(mtfhip_batch *b, const double *states, int C, double *features) {
+	if (!b || !states || !features) return fail(MTFHIP_ERR_INVALID_ARG, "sample_candidates: NULL argument");
+	if (C <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "sample_candidates: n_samples must be positive");
+	double *d_states = nullptr, *d_feat = nullptr;
+	HIP_TRY(hipMalloc(&d_states, sizeof(double) * C * b->S));
+	if (hipMalloc(&d_feat, sizeof(double) * (size_t)C * b->N) != hipSuccess) { (void)hipFree(d_states); return fail(MTFHIP_ERR_HIP, "hipMalloc of the %d x %d feature matrix failed", C, b->N); }
+	int rc = MTFHIP_OK;
+	if (hipMemcpyAsync(d_states, states, sizeof(double) * C * b->S, hipMemcpyHostToDevice, b->ctx->stream) != hipSuccess) rc = fail(MTFHIP_ERR_HIP, "state upload failed");
+	if (rc == MTFHIP_OK) rc = mtfhip_sample_candidates_dev(b, d_states, C, d_feat);
+	if (rc == MTFHIP_OK && hipMemcpyAsync(features, d_feat, sizeof(double) * (size_t)C * b->N, hipMemcpyDeviceToHost, b->ctx->stream) != hipSuccess) rc = fail(MTFHIP_ERR_HIP, "feature read-back failed");
+	if (hipStreamSynchronize(b->ctx->stream) != hipSuccess && rc == MTFHIP_OK) rc = fail(MTFHIP_ERR_HIP, "stream synchronisation failed");
+	(void)hipFree(d_states); (void)hipFree(d_feat);
+	return rc;
 }
 
 /* ------------------------------------------------------------------ timing */

@@ -137,6 +137,18 @@ void launch_score_candidates(const BatchView &bv, const ImgView &im, const doubl
 bool launch_score_candidates_lds(const BatchView &bv, const ImgView &im, const double *dev_states, int C, int tx0, int ty0,
 	int tw, int th, double likelihood_alpha, double *unit_sums, double *dev_lik, double *dev_sim, hipStream_t st);
 constexpr int kScoreUnitsPerCandidate = 4;
+/* second-order path: hess_pts, image Hessians ([N][4]), SSM pixel Hessians ([S*S][N] planes), sum_p w[p] d2[:, p] */
+void launch_hess_pts(const BatchView &bv, double eps, hipStream_t st);
+void launch_img_hess(const BatchView &bv, const ImgView &im, const double *pts, double *hess, double eps, double mult, hipStream_t st);
+void launch_warped_img_hess(const BatchView &bv, const ImgView &im, const double *pts, const double *hp, double *hess, double eps,
+	double mult, hipStream_t st);
+void launch_pix_hessian(const BatchView &bv, int variant, const double *hess, const double *grad, double *D, hipStream_t st);
+void launch_weighted_plane_sum(const BatchView &bv, const double *d2a, const double *d2b, const double *w, double *partials, int nblk,
+	double *out, hipStream_t st);
+void launch_mean_planes(const double *a, const double *b, double *o, size_t n, hipStream_t st);
+/* NN dataset rows: features of C warped patches of target 0 (SSD: It, NCC: centred / normalised It) */
+void launch_sample_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C, double norm_mult,
+	double norm_add, double *dev_feat, hipStream_t st);
 /* device-side solve + compositional update + convergence test for mtfhip_batch_track */
 struct TrackState {
 	double *acc;        /* [B][ACC_COUNT] reduced accumulators of this iteration */

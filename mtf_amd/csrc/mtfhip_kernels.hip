@@ -400,6 +400,280 @@ __global__ __launch_bounds__(kBlock) void k_pix_jacobian(BatchView bv, int varia
 	}
 }
 
+/* ===================================================================== */
+/* second-order path (sec_ord_hess): image Hessians, SSM pixel Hessians    */
+/* ===================================================================== */
+
+/* Homography::updateHessPts SSM/src/Homography.cc:829-875 (ProjectiveBase.cc:88-129) ; Affine.cc:315-350.
+ * 16 doubles per pixel: (+xx, -xx, +yy, -yy, +xy, -xy, +yx, -yx) offsets of the warped point. */
+__global__ __launch_bounds__(kBlock) void k_hess_pts(BatchView bv, double eps) {
+	const int t = blockIdx.y;
+	const Warp9 W = load_warp(bv.warps + 9 * t);
+	const double2 *cp = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * bv.N;
+	const double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * bv.N;
+	const double2 *ch = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_CURR_HXY]) + (size_t)t * bv.N;
+	double *hp = bv.buf[MTFHIP_BUF_HESS_PTS] + (size_t)t * bv.N * 16;
+	const double eps2 = 2 * eps;
+	double dv[4][3];
+#pragma unroll
+	for (int r = 0; r < 3; ++r) {
+		dv[0][r] = W.m[3 * r] * eps2;
+		dv[1][r] = W.m[3 * r + 1] * eps2;
+		dv[2][r] = (W.m[3 * r] + W.m[3 * r + 1]) * eps;
+		dv[3][r] = (W.m[3 * r] - W.m[3 * r + 1]) * eps;
+	}
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < bv.N; i += gridDim.x * kBlock) {
+		double2 *o = reinterpret_cast<double2 *>(hp + (size_t)i * 16);
+		if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+			const double2 h = ch[i];
+			const double q2 = cz[i];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				double a0 = h.x + dv[k][0], a1 = h.y + dv[k][1], a2 = q2 + dv[k][2];
+				o[2 * k] = make_double2(a0 / a2, a1 / a2);
+				a0 = h.x - dv[k][0]; a1 = h.y - dv[k][1]; a2 = q2 - dv[k][2];
+				o[2 * k + 1] = make_double2(a0 / a2, a1 / a2);
+			}
+		} else {
+			const double2 p = cp[i];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				o[2 * k] = make_double2(p.x + dv[k][0], p.y + dv[k][1]);
+				o[2 * k + 1] = make_double2(p.x - dv[k][0], p.y - dv[k][1]);
+			}
+		}
+	}
+}
+
+/* utils::getImgHess Utilities/src/imgUtils.cc:334-366 ; hess is [N][4] = (xx, xy, yx, yy) per pixel (PixHessT 4 x N) */
+__global__ __launch_bounds__(kBlock) void k_img_hess(int N, ImgView im, const double *pts_all, double *hess_all,
+	double eps, double pix_mult) {
+	const int t = blockIdx.y;
+	const double2 *pts = reinterpret_cast<const double2 *>(pts_all) + (size_t)t * N;
+	double2 *hess = reinterpret_cast<double2 *>(hess_all + (size_t)t * N * 4);
+	const double eps2 = 2 * eps;
+	const double mult = pix_mult / (eps2 * eps2);
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+		const double2 p = pts[i];
+		const double c = pix_val(im, p.x, p.y);
+		const double ix = pix_val(im, p.x + eps2, p.y), dx = pix_val(im, p.x - eps2, p.y);
+		const double hxx = (ix + dx - 2 * c) * mult;
+		const double iy = pix_val(im, p.x, p.y + eps2), dy = pix_val(im, p.x, p.y - eps2);
+		const double hyy = (iy + dy - 2 * c) * mult;
+		const double inc_x = p.x + eps, dec_x = p.x - eps, inc_y = p.y + eps, dec_y = p.y - eps;
+		const double ixiy = pix_val(im, inc_x, inc_y), dxdy = pix_val(im, dec_x, dec_y);
+		const double ixdy = pix_val(im, inc_x, dec_y), iydx = pix_val(im, dec_x, inc_y);
+		const double hxy = ((ixiy + dxdy) - (ixdy + iydx)) * mult;
+		hess[2 * i] = make_double2(hxx, hxy);
+		hess[2 * i + 1] = make_double2(hxy, hyy);
+	}
+}
+
+/* utils::getWarpedImgHess Utilities/src/imgUtils.cc:259-289 */
+__global__ __launch_bounds__(kBlock) void k_warped_img_hess(int N, ImgView im, const double *pts_all, const double *hp_all,
+	double *hess_all, double eps, double pix_mult) {
+	const int t = blockIdx.y;
+	const double2 *pts = reinterpret_cast<const double2 *>(pts_all) + (size_t)t * N;
+	const double *hp = hp_all + (size_t)t * N * 16;
+	double2 *hess = reinterpret_cast<double2 *>(hess_all + (size_t)t * N * 4);
+	const double eps2 = 2 * eps;
+	const double mult = pix_mult / (eps2 * eps2);
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+		const double2 p = pts[i];
+		const double2 *q = reinterpret_cast<const double2 *>(hp + (size_t)i * 16);
+		const double c = pix_val(im, p.x, p.y);
+		double inc = pix_val(im, q[0].x, q[0].y), dec = pix_val(im, q[1].x, q[1].y);
+		const double hxx = (inc + dec - 2 * c) * mult;
+		inc = pix_val(im, q[2].x, q[2].y); dec = pix_val(im, q[3].x, q[3].y);
+		const double hyy = (inc + dec - 2 * c) * mult;
+		inc = pix_val(im, q[4].x, q[4].y); dec = pix_val(im, q[5].x, q[5].y);
+		const double inc2 = pix_val(im, q[6].x, q[6].y), dec2 = pix_val(im, q[7].x, q[7].y);
+		const double hxy = ((inc + dec) - (inc2 + dec2)) * mult;
+		hess[2 * i] = make_double2(hxx, hxy);
+		hess[2 * i + 1] = make_double2(hxy, hyy);
+	}
+}
+
+/* d2 (S x S, column-major, in registers) = dw_dp^T * M * dw_dp for the 2 x S dw_dp with rows r0, r1 */
+template <int S>
+__device__ __forceinline__ void sandwich(double *d2, const double *r0, const double *r1, double m00, double m01, double m10, double m11) {
+	double a0[S], a1[S];
+#pragma unroll
+	for (int j = 0; j < S; ++j) { a0[j] = m00 * r0[j] + m01 * r1[j]; a1[j] = m10 * r0[j] + m11 * r1[j]; }
+#pragma unroll
+	for (int j = 0; j < S; ++j)
+#pragma unroll
+		for (int i = 0; i < S; ++i) d2[j * S + i] = r0[i] * a0[j] + r1[i] * a1[j];
+}
+/* third-order tail of Homography's Init / Warped / Approx pixel Hessians (Homography.cc:403-421, :591-613, :778-796):
+ * the reference mirrors only rows 0..4 of columns 6,7 into rows 6,7 -- entries (6,5) and (7,5) keep the plain
+ * sandwich value, so the block is not exactly symmetric.  Kept as is. */
+__device__ __forceinline__ void hom_tail(double *d2, double Ix, double Iy, double x, double y, double sgn, double corner) {
+	const double Ixx = Ix * x, Ixy = Ix * y, Iyy = Iy * y, Iyx = Iy * x;
+	const double Ixxx = Ixx * x, Ixxy = Ixx * y, Ixyy = Ixy * y;
+	const double Iyyy = Iyy * y, Iyyx = Iyy * x, Iyxx = Iyx * x;
+#define D2(r, c) d2[(c) * 8 + (r)]
+	D2(0, 6) += sgn * Ixxx; D2(0, 7) += sgn * Ixxy;
+	D2(1, 6) += sgn * Ixxy; D2(1, 7) += sgn * Ixyy;
+	D2(2, 6) += sgn * Ixx;  D2(2, 7) += sgn * Ixy;
+	D2(3, 6) += sgn * Iyxx; D2(3, 7) += sgn * Iyyx;
+	D2(4, 6) += sgn * Iyyx; D2(4, 7) += sgn * Iyyy;
+	D2(5, 6) += sgn * Iyx;  D2(5, 7) += sgn * Iyy;
+	D2(6, 6) += corner * (Ixxx * x + Iyxx * y);
+	D2(6, 7) += corner * (Ixxy * x + Iyyx * y);
+	D2(7, 6) += corner * (Ixxy * x + Iyyx * y);
+	D2(7, 7) += corner * (Ixyy * x + Iyyy * y);
+#pragma unroll
+	for (int r = 0; r < 5; ++r) { D2(6, r) = D2(r, 6); D2(7, r) = D2(r, 7); }
+#undef D2
+}
+
+/* one pixel's S x S block d2I_dp2 in registers.  Homography.cc:360-425 (init), :427-513 (pix), :515-618 (warped),
+ * :696-801 (approx) ; Affine.cc:243-263 (init), :264-291 (warped).  m = (xx, xy, yx, yy). */
+template <int SSM>
+__device__ __forceinline__ void pix_hessian_block(double *d2, int variant, const Warp9 &W, const double *st, double x, double y,
+	double cx, double cy, double D, double m0, double m1, double m2, double m3, double gx, double gy) {
+	if constexpr (SSM == MTFHIP_SSM_AFFINE) {
+		const double r0[6] = {1, 0, x, y, 0, 0}, r1[6] = {0, 1, 0, 0, x, y};
+		if (variant == MTFHIP_JAC_INIT) { sandwich<6>(d2, r0, r1, m0, m2, m1, m3); return; }
+		const double a2 = st[2] + 1, a3 = st[3], a4 = st[4], a5 = st[5] + 1;
+		const double t00 = m0 * a2 + m2 * a4, t01 = m0 * a3 + m2 * a5;
+		const double t10 = m1 * a2 + m3 * a4, t11 = m1 * a3 + m3 * a5;
+		sandwich<6>(d2, r0, r1, a2 * t00 + a4 * t10, a2 * t01 + a4 * t11, a3 * t00 + a5 * t10, a3 * t01 + a5 * t11);
+	} else {
+		if (variant == MTFHIP_JAC_INIT) {
+			const double r0[8] = {x, y, 1, 0, 0, 0, -x * x, -x * y}, r1[8] = {0, 0, 0, x, y, 1, -y * x, -y * y};
+			sandwich<8>(d2, r0, r1, m0, m2, m1, m3);
+			hom_tail(d2, gx, gy, x, y, -1.0, 2.0);
+		} else if (variant == MTFHIP_JAC_PIX) {
+			double r0[8] = {x, y, 1, 0, 0, 0, -cx * x, -cx * y}, r1[8] = {0, 0, 0, x, y, 1, -cy * x, -cy * y};
+#pragma unroll
+			for (int j = 0; j < 8; ++j) { r0[j] /= D; r1[j] /= D; }
+			const double inv_d2 = 1.0 / (D * D);
+			sandwich<8>(d2, r0, r1, m0, m2, m1, m3);
+			const double Ixx = gx * x, Ixy = gx * y, Iyy = gy * y, Iyx = gy * x;
+			const double Ixxx = Ixx * x, Ixxy = Ixx * y, Ixyy = Ixy * y;
+			const double Iyyy = Iyy * y, Iyyx = Iyy * x, Iyxx = Iyx * x;
+#define D2(r, c) d2[(c) * 8 + (r)]
+			D2(0, 6) -= Ixxx * inv_d2; D2(1, 6) -= Ixxy * inv_d2; D2(2, 6) -= Ixx * inv_d2;
+			D2(3, 6) -= Iyxx * inv_d2; D2(4, 6) -= Iyyx * inv_d2; D2(5, 6) -= Iyx * inv_d2;
+			D2(6, 6) += 2 * (Ixxx * cx + Iyxx * cy) * inv_d2;
+			D2(7, 6) += 2 * (Ixxy * cx + Iyyx * cy) * inv_d2;
+			D2(0, 7) -= Ixxy * inv_d2; D2(1, 7) -= Ixyy * inv_d2; D2(2, 7) -= Ixy * inv_d2;
+			D2(3, 7) -= Iyyx * inv_d2; D2(4, 7) -= Iyyy * inv_d2; D2(5, 7) -= Iyy * inv_d2;
+			D2(6, 7) += 2 * (Ixxy * cx + Iyyx * cy) * inv_d2;
+			D2(7, 7) += 2 * (Ixyy * cx + Iyyy * cy) * inv_d2;
+#pragma unroll
+			for (int r = 0; r < 5; ++r) { D2(6, r) = D2(r, 6); D2(7, r) = D2(r, 7); }
+#undef D2
+		} else if (variant == MTFHIP_JAC_WARPED) {
+			const double a00 = W.m[0], a01 = W.m[1], a10 = W.m[3], a11 = W.m[4], a20 = W.m[6], a21 = W.m[7];
+			const double D_inv = 1.0 / D;
+			const double dwx_dx = (a00 - a20 * cx) * D_inv, dwx_dy = (a01 - a21 * cx) * D_inv;
+			const double dwy_dx = (a10 - a20 * cy) * D_inv, dwy_dy = (a11 - a21 * cy) * D_inv;
+			const double d2wx_dx2 = -2 * a20 * dwx_dx * D_inv, d2wx_dxdy = -(a21 * dwx_dx + a20 * dwx_dy) * D_inv;
+			const double d2wx_dy2 = -2 * a21 * dwx_dy * D_inv;
+			const double d2wy_dx2 = -2 * a20 * dwy_dx * D_inv, d2wy_dxdy = -(a21 * dwy_dx + a20 * dwy_dy) * D_inv;
+			const double d2wy_dy2 = -2 * a21 * dwy_dy * D_inv;
+			const double t00 = m0 * dwx_dx + m2 * dwy_dx, t01 = m0 * dwx_dy + m2 * dwy_dy;
+			const double t10 = m1 * dwx_dx + m3 * dwy_dx, t11 = m1 * dwx_dy + m3 * dwy_dy;
+			double q00 = dwx_dx * t00 + dwy_dx * t10, q01 = dwx_dx * t01 + dwy_dx * t11;
+			double q10 = dwx_dy * t00 + dwy_dy * t10, q11 = dwx_dy * t01 + dwy_dy * t11;
+			q00 = q00 + gx * d2wx_dx2 + gy * d2wy_dx2;
+			q01 = q01 + gx * d2wx_dxdy + gy * d2wy_dxdy;
+			q10 = q10 + gx * d2wx_dxdy + gy * d2wy_dxdy;
+			q11 = q11 + gx * d2wx_dy2 + gy * d2wy_dy2;
+			const double r0[8] = {x, y, 1, 0, 0, 0, -x * x, -x * y}, r1[8] = {0, 0, 0, x, y, 1, -y * x, -y * y};
+			sandwich<8>(d2, r0, r1, q00, q01, q10, q11);
+			hom_tail(d2, dwx_dx * gx + dwy_dx * gy, dwx_dy * gx + dwy_dy * gy, x, y, -1.0, 2.0);
+		} else {
+			const double h00 = W.m[0], h01 = W.m[1], h10 = W.m[3], h11 = W.m[4], h20 = W.m[6], h21 = W.m[7];
+			const double inv_det2 = 1.0 / (D * D), inv_det = 1.0 / D;
+			const double a = (h00 - h20 * cx) * inv_det, b = (h01 - h21 * cx) * inv_det;
+			const double c = (h10 - h20 * cy) * inv_det, d = (h11 - h21 * cy) * inv_det;
+			const double inv_factor = 1.0 / (a * d - b * c);
+			const double i00 = d * inv_factor, i01 = -b * inv_factor, i10 = -c * inv_factor, i11 = a * inv_factor;
+			const double ax = -h20 * (h00 + a * D - h20 * cx) * inv_det2;
+			const double bx = -(h20 * h01 + h21 * (a * D - h20 * cx)) * inv_det2;
+			const double cxx = -h20 * (h10 + c * D - h20 * cy) * inv_det2;
+			const double dx = -(h20 * h11 + h21 * (c * D - h20 * cy)) * inv_det2;
+			const double ay = -(h21 * h00 + h20 * (b * D - h21 * cx)) * inv_det2;
+			const double by = -h21 * (h01 + b * D - h21 * cx) * inv_det2;
+			const double cyy = -(h21 * h10 + h20 * (d * D - h21 * cy)) * inv_det2;
+			const double dy = -h21 * (h11 + d * D - h21 * cy) * inv_det2;
+			const double Ix = (d * gx - c * gy) * inv_factor;
+			const double Iy = (a * gy - b * gx) * inv_factor;
+			const double n00 = m0 - (Ix * ax + Iy * ay), n01 = m2 - (Ix * bx + Iy * by);
+			const double n10 = m1 - (Ix * cxx + Iy * cyy), n11 = m3 - (Ix * dx + Iy * dy);
+			const double t00 = n00 * i00 + n01 * i10, t01 = n00 * i01 + n01 * i11;
+			const double t10 = n10 * i00 + n11 * i10, t11 = n10 * i01 + n11 * i11;
+			const double r0[8] = {x, y, 1, 0, 0, 0, -x * x, -x * y}, r1[8] = {0, 0, 0, x, y, 1, -y * x, -y * y};
+			sandwich<8>(d2, r0, r1, i00 * t00 + i10 * t10, i00 * t01 + i10 * t11, i01 * t00 + i11 * t10, i01 * t01 + i11 * t11);
+			hom_tail(d2, Ix, Iy, x, y, 1.0, -1.0);
+		}
+	}
+}
+
+/* stand-alone SSM pixel Hessian: writes d2I_dp2 as S*S planes of N ([S*S][N], plane r + S*c = entry (r, c)) */
+template <int SSM>
+__global__ __launch_bounds__(kBlock) void k_pix_hessian(BatchView bv, int variant, const double *hess_all, const double *grad_all,
+	double *D_all) {
+	constexpr int S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
+	const int t = blockIdx.y, N = bv.N;
+	const Warp9 W = load_warp(bv.warps + 9 * t);
+	const double *st = bv.states + 8 * t;
+	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * N;
+	const double2 *cp = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * N;
+	const double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * N;
+	const double2 *ph = reinterpret_cast<const double2 *>(hess_all + (size_t)t * N * 4);
+	const double *grad = grad_all + (size_t)t * N * 2;
+	double *Dm = D_all + (size_t)t * N * S * S;
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+		const double2 p0 = ip[i], c = cp[i];
+		const double2 ma = ph[2 * i], mb = ph[2 * i + 1];
+		double d2[S * S];
+		pix_hessian_block<SSM>(d2, variant, W, st, p0.x, p0.y, c.x, c.y, cz[i], ma.x, ma.y, mb.x, mb.y, grad[i], grad[N + i]);
+#pragma unroll
+		for (int k = 0; k < S * S; ++k) Dm[(size_t)k * N + i] = d2[k];
+	}
+}
+
+/* sum_p w[p] * d2[k][p] for the S*S planes (the second-order term of SSDBase.cc:334-342, NCC.cc:396-399, MI.cc:670-672);
+ * with d2b the planes of two matrices are added first (SSDBase::cmptSumOfHessians, SSDBase.cc:405-413).
+ * One partial row of S*S sums per workgroup. */
+template <int S2>
+__global__ __launch_bounds__(kBlock) void k_weighted_plane_sum(int N, const double *d2a_all, const double *d2b_all, const double *w_all,
+	double *partials, int nblk) {
+	__shared__ double lds[4 * S2];
+	const int t = blockIdx.y;
+	const double *da = d2a_all + (size_t)t * N * S2;
+	const double *db = d2b_all ? d2b_all + (size_t)t * N * S2 : nullptr;
+	const double *w = w_all + (size_t)t * N;
+	double acc[S2];
+#pragma unroll
+	for (int k = 0; k < S2; ++k) acc[k] = 0.0;
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += nblk * kBlock) {
+		const double wi = w[i];
+		if (db) {
+#pragma unroll
+			for (int k = 0; k < S2; ++k) acc[k] = fma(wi, da[(size_t)k * N + i] + db[(size_t)k * N + i], acc[k]);
+		} else {
+#pragma unroll
+			for (int k = 0; k < S2; ++k) acc[k] = fma(wi, da[(size_t)k * N + i], acc[k]);
+		}
+	}
+	block_reduce_store<S2>(acc, partials + ((size_t)t * nblk + blockIdx.x) * S2, lds);
+}
+/* fixed-order sum of the per-workgroup rows of k_weighted_plane_sum: out[t][k] */
+__global__ __launch_bounds__(64) void k_plane_sum_finish(const double *partials, int nblk, int S2, double *out) {
+	const int t = blockIdx.x, k = threadIdx.x;
+	if (k >= S2) return;
+	const double *p = partials + (size_t)t * nblk * S2 + k;
+	double s = 0;
+	for (int b = 0; b < nblk; ++b) s += p[(size_t)b * S2];
+	out[(size_t)t * S2 + k] = s;
+}
+
 /* mean_pix_jacobian = (init_pix_jacobian + curr_pix_jacobian) / 2.0 (SM/src/NT/ESM.cc:239-242) */
 __global__ __launch_bounds__(kBlock) void k_mean_jacobian(const double *a, const double *b, double *o, size_t n) {
 	for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
@@ -1539,6 +1813,53 @@ __device__ __forceinline__ void block_allsum(double *v, double *lds /* [4][K] */
 	for (int k = 0; k < K; ++k) v[k] = (lds[k] + lds[K + k]) + (lds[2 * K + k] + lds[3 * K + k]);
 }
 
+/* NN-SM dataset generation (SM/src/NT/NN.cc:131-191): per sample state, setState -> updatePixVals ->
+ * updateDistFeat into row `c` of the n_samples x N feature matrix.  SSD's feature is the patch itself
+ * (AM/include/mtf/AM/SSDBase.h:116-125); NCC's is the centred patch over its norm (AM/src/NCC.cc:530-537),
+ * applied by k_ncc_feature_rows afterwards.  One workgroup per sample. */
+__global__ __launch_bounds__(kBlock) void k_sample_candidates(BatchView bv, ImgView im, const double *states, int C,
+	double norm_mult, double norm_add, double *feat) {
+	const int cand = blockIdx.x;
+	const int N = bv.N, S = bv.S;
+	const double *p = states + (size_t)cand * S;
+	double W[9];
+	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+		W[0] = 1 + p[0]; W[1] = p[1]; W[2] = p[2]; W[3] = p[3]; W[4] = 1 + p[4]; W[5] = p[5]; W[6] = p[6]; W[7] = p[7]; W[8] = 1;
+	} else {
+		W[0] = 1 + p[2]; W[1] = p[3]; W[2] = p[0]; W[3] = p[4]; W[4] = 1 + p[5]; W[5] = p[1]; W[6] = 0; W[7] = 0; W[8] = 1;
+	}
+	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[bv.unit_z ? MTFHIP_BUF_INIT_PTS : MTFHIP_BUF_INIT_HXY]);
+	const double *iz = bv.buf[MTFHIP_BUF_INIT_Z];
+	double *out = feat + (size_t)cand * N;
+	for (int i = threadIdx.x; i < N; i += kBlock) {
+		const double2 q = ip[i];
+		const double z = bv.unit_z ? 1.0 : iz[i];
+		double wx, wy;
+		if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+			const double cx = W[0] * q.x + W[1] * q.y + W[2] * z, cy = W[3] * q.x + W[4] * q.y + W[5] * z;
+			const double d = W[6] * q.x + W[7] * q.y + W[8] * z;
+			wx = cx / d; wy = cy / d;
+		} else {
+			wx = W[0] * q.x + W[1] * q.y + W[2] * z; wy = W[3] * q.x + W[4] * q.y + W[5] * z;
+		}
+		out[i] = norm_mult * pix_val(im, wx, wy) + norm_add;
+	}
+}
+/* NCC::updateDistFeat NCC.cc:530-537: row <- (row - mean) / ||row - mean|| */
+__global__ __launch_bounds__(kBlock) void k_ncc_feature_rows(int N, double *feat) {
+	__shared__ double red[4];
+	double *row = feat + (size_t)blockIdx.x * N;
+	double s[1] = {0.0};
+	for (int i = threadIdx.x; i < N; i += kBlock) s[0] += row[i];
+	block_allsum<1>(s, red);
+	const double mean = s[0] / (double)N;
+	double q[1] = {0.0};
+	for (int i = threadIdx.x; i < N; i += kBlock) { const double d = row[i] - mean; q[0] = fma(d, d, q[0]); }
+	block_allsum<1>(q, red);
+	const double sd = sqrt(q[0]);
+	for (int i = threadIdx.x; i < N; i += kBlock) row[i] = (row[i] - mean) / sd;
+}
+
 /*
  * nt::ICLK::update (SM/src/NT/ICLK.cc:160-299) for one patch per workgroup, all iterations inside the
  * kernel: updatePixVals -> updateSimilarity -> updateInitGrad -> cmptInitJacobian(g, J0) ->
@@ -1735,6 +2056,31 @@ void launch_warped_img_grad(const BatchView &bv, const ImgView &im, const double
 void launch_pix_jacobian(const BatchView &bv, int variant, const double *grad, double *J, hipStream_t st) {
 	hipLaunchKernelGGL(k_pix_jacobian, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv, variant, grad, J);
 }
+void launch_hess_pts(const BatchView &bv, double eps, hipStream_t st) {
+	hipLaunchKernelGGL(k_hess_pts, dim3(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv, eps);
+}
+void launch_img_hess(const BatchView &bv, const ImgView &im, const double *pts, double *hess, double eps, double mult, hipStream_t st) {
+	hipLaunchKernelGGL(k_img_hess, dim3(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, pts, hess, eps, mult);
+}
+void launch_warped_img_hess(const BatchView &bv, const ImgView &im, const double *pts, const double *hp, double *hess, double eps,
+	double mult, hipStream_t st) {
+	hipLaunchKernelGGL(k_warped_img_hess, dim3(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, pts, hp, hess, eps, mult);
+}
+void launch_pix_hessian(const BatchView &bv, int variant, const double *hess, const double *grad, double *D, hipStream_t st) {
+	const dim3 grid(simple_blocks_per_target(bv.N), bv.B);
+	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) hipLaunchKernelGGL(k_pix_hessian<MTFHIP_SSM_HOMOGRAPHY>, grid, dim3(kBlock), 0, st, bv, variant, hess, grad, D);
+	else hipLaunchKernelGGL(k_pix_hessian<MTFHIP_SSM_AFFINE>, grid, dim3(kBlock), 0, st, bv, variant, hess, grad, D);
+}
+void launch_weighted_plane_sum(const BatchView &bv, const double *d2a, const double *d2b, const double *w, double *partials, int nblk,
+	double *out, hipStream_t st) {
+	const dim3 grid(nblk, bv.B);
+	if (bv.S == 8) hipLaunchKernelGGL(k_weighted_plane_sum<64>, grid, dim3(kBlock), 0, st, bv.N, d2a, d2b, w, partials, nblk);
+	else hipLaunchKernelGGL(k_weighted_plane_sum<36>, grid, dim3(kBlock), 0, st, bv.N, d2a, d2b, w, partials, nblk);
+	hipLaunchKernelGGL(k_plane_sum_finish, dim3(bv.B), dim3(64), 0, st, partials, nblk, bv.S * bv.S, out);
+}
+void launch_mean_planes(const double *a, const double *b, double *o, size_t n, hipStream_t st) {
+	hipLaunchKernelGGL(k_mean_jacobian, dim3((unsigned)std::min<size_t>((n + kBlock - 1) / kBlock, 4096)), dim3(kBlock), 0, st, a, b, o, n);
+}
 void launch_mean_jacobian(const BatchView &bv, hipStream_t st) {
 	size_t n = (size_t)bv.B * bv.N * bv.S;
 	int nb = (int)((n + kBlock * 4 - 1) / (kBlock * 4));
@@ -1882,6 +2228,11 @@ bool launch_iclk_track(const BatchView &bv, const ImgView &im, const mtfhip_sm_d
 	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, hipStream_t st) {
 	if (bv.am == MTFHIP_AM_NCC) return launch_iclk_track_am<MTFHIP_AM_NCC>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, st);
 	return launch_iclk_track_am<MTFHIP_AM_SSD>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, st);
+}
+void launch_sample_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C, double norm_mult,
+	double norm_add, double *dev_feat, hipStream_t st) {
+	hipLaunchKernelGGL(k_sample_candidates, dim3(C), dim3(kBlock), 0, st, bv, im, dev_states, C, norm_mult, norm_add, dev_feat);
+	if (bv.am == MTFHIP_AM_NCC) hipLaunchKernelGGL(k_ncc_feature_rows, dim3(C), dim3(kBlock), 0, st, bv.N, dev_feat);
 }
 void launch_finish_track(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, const double *partials,
 	int nblk, hipStream_t st) {

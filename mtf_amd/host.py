@@ -2,6 +2,7 @@
 mtf::nt::ESM / FCLK / ICLK, mtf_amd/host/*.cpp) -- the reference-language side of the drop-in boundary."""
 import ctypes as C
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -68,7 +69,7 @@ class CppTracker:
         self.iters = 0
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and not sys.is_finalizing():
             lib().mtfhost_destroy(self._h)
             self._h = None
 

@@ -319,7 +319,7 @@ class ParticleFilter:
         ssm = self.batch.desc.ssm
         out = np.empty_like(base)
         for k in range(base.shape[0]):
-            W = self._warp(ssm, base[k]) @ self._warp(ssm, pert[k])
+            W = ParticleFilter._warp(ssm, base[k]) @ ParticleFilter._warp(ssm, pert[k])
             if ssm == L.SSM_HOMOGRAPHY:
                 W = W / W[2, 2]
                 out[k] = [W[0, 0] - 1, W[0, 1], W[0, 2], W[1, 0], W[1, 1] - 1, W[1, 2], W[2, 0], W[2, 1]]
@@ -355,3 +355,38 @@ class ParticleFilter:
                 break
             prev = cur
         return self.batch.get_corners()
+
+
+class NNDataset:
+    """Dataset generation of nt::NN (SM/src/NT/NN.cc:131-191, compositional update): sample perturbations of the
+    tracked region, warp by each INVERSE perturbation, and keep the AM's distance feature of every warped patch.
+    The C x N feature matrix comes from one mtfhip_sample_candidates call; the index structure built over it
+    (FLANN in the reference, NN.cc:99-128) is outside the path -- `nearest` is the exhaustive search."""
+
+    def __init__(self, ctx, am=L.AM_SSD, ssm=L.SSM_HOMOGRAPHY, resx=50, resy=50, n_samples=1000,
+                 ssm_sigma=(0.01, 0.01, 2.0, 0.01, 0.01, 2.0, 1e-5, 1e-5), seed=0):
+        self.batch = Batch(ctx, am, ssm, resx, resy, 1)
+        self.S = self.batch.S
+        self.n = n_samples
+        self.sigma = np.asarray(ssm_sigma, dtype=np.float64)[: self.S]
+        self.rng = np.random.default_rng(seed)
+        self.perturbations = None
+        self.features = None
+
+    def initialize(self, corners, perturbations=None):
+        b = self.batch
+        b.set_corners(np.asarray(corners, dtype=np.float64).reshape(1, 2, 4))
+        b.initialize_pix_vals()
+        if perturbations is None:    # ProjectiveBase::generatePerturbation: independent N(0, sigma_k) per component
+            perturbations = self.rng.normal(0.0, 1.0, size=(self.n, self.S)) * self.sigma
+        self.perturbations = np.ascontiguousarray(perturbations, dtype=np.float64).reshape(-1, self.S)
+        inv = np.stack([b.invert_state(q[None])[0] for q in self.perturbations])
+        base = np.repeat(b.get_state(), len(inv), axis=0)
+        states = ParticleFilter._compose(self, base, inv)       # curr_warp * inverse(perturbation)
+        self.features = b.sample_candidates(states)
+        return self.features
+
+    def nearest(self, feature):
+        d = ((self.features - np.asarray(feature)[None]) ** 2).sum(axis=1)
+        k = int(np.argmin(d))
+        return k, float(d[k])

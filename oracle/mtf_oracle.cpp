@@ -88,6 +88,51 @@ void warped_img_grad(double *grad, const float *img, int h, int w, const double 
 	}
 }
 
+/* utils::getImgHess: Utilities/src/imgUtils.cc:334-366 ; hess is 4 x N col-major (xx, xy, yx, yy per pixel) */
+void img_hess(double *hess, const float *img, int h, int w, const double *pts,
+	double eps, int n, double pix_mult) {
+	double eps2 = 2 * eps;
+	double mult = pix_mult / (eps2 * eps2);
+	for (int i = 0; i < n; ++i) {
+		double cx = pts[2 * i], cy = pts[2 * i + 1];
+		double c = pix_val(img, h, w, cx, cy);
+		double ix = pix_val(img, h, w, cx + eps2, cy);
+		double dx = pix_val(img, h, w, cx - eps2, cy);
+		hess[4 * i] = (ix + dx - 2 * c) * mult;
+		double iy = pix_val(img, h, w, cx, cy + eps2);
+		double dy = pix_val(img, h, w, cx, cy - eps2);
+		hess[4 * i + 3] = (iy + dy - 2 * c) * mult;
+		double inc_x = cx + eps, dec_x = cx - eps, inc_y = cy + eps, dec_y = cy - eps;
+		double ixiy = pix_val(img, h, w, inc_x, inc_y);
+		double dxdy = pix_val(img, h, w, dec_x, dec_y);
+		double ixdy = pix_val(img, h, w, inc_x, dec_y);
+		double iydx = pix_val(img, h, w, dec_x, inc_y);
+		hess[4 * i + 1] = hess[4 * i + 2] = ((ixiy + dxdy) - (ixdy + iydx)) * mult;
+	}
+}
+
+/* utils::getWarpedImgHess: Utilities/src/imgUtils.cc:259-289 ; hess_pts is 16 x N */
+void warped_img_hess(double *hess, const float *img, int h, int w, const double *pts,
+	const double *hp, double eps, int n, double pix_mult) {
+	double eps2 = 2 * eps;
+	double mult = pix_mult / (eps2 * eps2);
+	for (int i = 0; i < n; ++i) {
+		const double *p = hp + 16 * i;
+		double c = pix_val(img, h, w, pts[2 * i], pts[2 * i + 1]);
+		double inc = pix_val(img, h, w, p[0], p[1]);
+		double dec = pix_val(img, h, w, p[2], p[3]);
+		hess[4 * i] = (inc + dec - 2 * c) * mult;
+		inc = pix_val(img, h, w, p[4], p[5]);
+		dec = pix_val(img, h, w, p[6], p[7]);
+		hess[4 * i + 3] = (inc + dec - 2 * c) * mult;
+		inc = pix_val(img, h, w, p[8], p[9]);
+		dec = pix_val(img, h, w, p[10], p[11]);
+		double inc2 = pix_val(img, h, w, p[12], p[13]);
+		double dec2 = pix_val(img, h, w, p[14], p[15]);
+		hess[4 * i + 1] = hess[4 * i + 2] = ((inc + dec) - (inc2 + dec2)) * mult;
+	}
+}
+
 /* ===================================================================== */
 /* small dense math (Eigen in the reference)                              */
 /* ===================================================================== */
@@ -305,7 +350,7 @@ struct mtfo_ssm {
 	vecd norm_pts, norm_pts_hm, norm_corners, norm_corners_hm;
 	vecd init_pts, curr_pts, init_pts_hm, curr_pts_hm;
 	vecd init_corners, curr_corners, init_corners_hm, curr_corners_hm;
-	vecd grad_pts, state;
+	vecd grad_pts, hess_pts, state;
 	Mat3 curr_warp;
 
 	/* ProjectiveBase ctor (SSM/src/ProjectiveBase.cc:9-18); Affine re-does the
@@ -570,6 +615,215 @@ struct mtfo_ssm {
 			}
 		}
 	}
+	/* Homography::updateHessPts SSM/src/Homography.cc:829-875 (= ProjectiveBase.cc:88-129) ;
+	 * Affine::updateHessPts SSM/src/Affine.cc:315-350 ; hess_pts is 16 x N */
+	void update_hess_pts(double eps) {
+		hess_pts.resize(16 * static_cast<size_t>(n));
+		double eps2 = 2 * eps;
+		int R = kind == MTFO_SSM_HOMOGRAPHY ? 3 : 2;
+		double xx[3], yy[3], xy[3], yx[3];
+		for (int r = 0; r < R; ++r) {
+			xx[r] = curr_warp(r, 0) * eps2;
+			yy[r] = curr_warp(r, 1) * eps2;
+			xy[r] = (curr_warp(r, 0) + curr_warp(r, 1)) * eps;
+			yx[r] = (curr_warp(r, 0) - curr_warp(r, 1)) * eps;
+		}
+		const double *dv[4] = {xx, yy, xy, yx};
+		for (int i = 0; i < n; ++i) {
+			double *hp = &hess_pts[16 * static_cast<size_t>(i)];
+			for (int k = 0; k < 4; ++k) {
+				if (kind == MTFO_SSM_HOMOGRAPHY) {
+					const double *q = &curr_pts_hm[3 * i];
+					double a0 = q[0] + dv[k][0], a1 = q[1] + dv[k][1], a2 = q[2] + dv[k][2];
+					hp[4 * k] = a0 / a2; hp[4 * k + 1] = a1 / a2;
+					a0 = q[0] - dv[k][0]; a1 = q[1] - dv[k][1]; a2 = q[2] - dv[k][2];
+					hp[4 * k + 2] = a0 / a2; hp[4 * k + 3] = a1 / a2;
+				} else {
+					double cx = curr_pts[2 * i], cy = curr_pts[2 * i + 1];
+					hp[4 * k] = cx + dv[k][0]; hp[4 * k + 1] = cy + dv[k][1];
+					hp[4 * k + 2] = cx - dv[k][0]; hp[4 * k + 3] = cy - dv[k][1];
+				}
+			}
+		}
+	}
+
+	/* out(SxS, col-major) = dw_dp^T * M * dw_dp for a 2 x S dw_dp (rows r0, r1) and 2x2 M (m00 m01; m10 m11) */
+	inline void sandwich(double *out, const double *r0, const double *r1, double m00, double m01, double m10, double m11) const {
+		double a0[8], a1[8];
+		for (int j = 0; j < S; ++j) { a0[j] = m00 * r0[j] + m01 * r1[j]; a1[j] = m10 * r0[j] + m11 * r1[j]; }
+		for (int j = 0; j < S; ++j)
+			for (int i = 0; i < S; ++i) out[j * S + i] = r0[i] * a0[j] + r1[i] * a1[j];
+	}
+	/* the "+= / -= third-order" tail shared by Homography's Init / Warped / Approx pixel Hessians:
+	 * columns 6,7 of rows 0..5 get sgn*(..), the 2x2 corner gets corner*(..), then the 2x5 bottom-left block is
+	 * overwritten by the transpose of the 5x2 top-right block (rows 0..4 only, as the reference does). */
+	inline void hom_tail(double *d2, double Ix, double Iy, double x, double y, double sgn, double corner,
+		double cx, double cy) const {
+		double Ixx = Ix * x, Ixy = Ix * y, Iyy = Iy * y, Iyx = Iy * x;
+		double Ixxx = Ixx * x, Ixxy = Ixx * y, Ixyy = Ixy * y;
+		double Iyyy = Iyy * y, Iyyx = Iyy * x, Iyxx = Iyx * x;
+#define D2(r, c) d2[(c) * 8 + (r)]
+		D2(0, 6) += sgn * Ixxx; D2(0, 7) += sgn * Ixxy;
+		D2(1, 6) += sgn * Ixxy; D2(1, 7) += sgn * Ixyy;
+		D2(2, 6) += sgn * Ixx;  D2(2, 7) += sgn * Ixy;
+		D2(3, 6) += sgn * Iyxx; D2(3, 7) += sgn * Iyyx;
+		D2(4, 6) += sgn * Iyyx; D2(4, 7) += sgn * Iyyy;
+		D2(5, 6) += sgn * Iyx;  D2(5, 7) += sgn * Iyy;
+		D2(6, 6) += corner * (Ixxx * cx + Iyxx * cy);
+		D2(6, 7) += corner * (Ixxy * cx + Iyyx * cy);
+		D2(7, 6) += corner * (Ixxy * cx + Iyyx * cy);
+		D2(7, 7) += corner * (Ixyy * cx + Iyyy * cy);
+		for (int r = 0; r < 5; ++r) { D2(6, r) = D2(r, 6); D2(7, r) = D2(r, 7); }
+#undef D2
+	}
+	inline void dw_dp_rows(double *r0, double *r1, double x, double y, double px, double py) const {
+		if (kind == MTFO_SSM_HOMOGRAPHY) {
+			double a[8] = {x, y, 1, 0, 0, 0, -px * x, -px * y};
+			double b[8] = {0, 0, 0, x, y, 1, -py * x, -py * y};
+			std::copy(a, a + 8, r0); std::copy(b, b + 8, r1);
+		} else {
+			double a[6] = {1, 0, x, y, 0, 0};
+			double b[6] = {0, 1, 0, 0, x, y};
+			std::copy(a, a + 6, r0); std::copy(b, b + 6, r1);
+		}
+	}
+	/* Homography::cmptInitPixHessian SSM/src/Homography.cc:360-425 ; Affine::cmptInitPixHessian SSM/src/Affine.cc:243-263.
+	 * d2 is S^2 x N (one column-major S x S block per pixel), pix_hess 4 x N, pix_grad N x 2 */
+	void init_pix_hessian(double *d2, const double *ph, const double *g) const {
+		double r0[8] = {0}, r1[8] = {0};
+		for (int i = 0; i < n; ++i) {
+			double x = init_pts[2 * i], y = init_pts[2 * i + 1];
+			double *out = d2 + static_cast<size_t>(i) * S * S;
+			const double *m = ph + 4 * i;   /* Map<Matrix2d>: col-major (m0 m2; m1 m3) */
+			dw_dp_rows(r0, r1, x, y, x, y);
+			sandwich(out, r0, r1, m[0], m[2], m[1], m[3]);
+			if (kind == MTFO_SSM_HOMOGRAPHY) hom_tail(out, g[i], g[n + i], x, y, -1.0, 2.0, x, y);
+		}
+	}
+	/* Homography::cmptPixHessian SSM/src/Homography.cc:427-513 (Affine: not implemented, StateSpaceModel.h:186-189) */
+	int pix_hessian(double *d2, const double *ph, const double *g) const {
+		if (kind != MTFO_SSM_HOMOGRAPHY) return -2;
+		double r0[8] = {0}, r1[8] = {0};
+		for (int i = 0; i < n; ++i) {
+			double x = init_pts[2 * i], y = init_pts[2 * i + 1];
+			double cx = curr_pts[2 * i], cy = curr_pts[2 * i + 1];
+			double D = curr_pts_hm[3 * i + 2];
+			double *out = d2 + static_cast<size_t>(i) * 64;
+			const double *m = ph + 4 * i;
+			dw_dp_rows(r0, r1, x, y, cx, cy);
+			for (int j = 0; j < 8; ++j) { r0[j] /= D; r1[j] /= D; }
+			double inv_d2 = 1.0 / (D * D);
+			sandwich(out, r0, r1, m[0], m[2], m[1], m[3]);
+			/* the reference scales each third-order product by inv_d_squared (:490-507) */
+			double Ix = g[i], Iy = g[n + i];
+			double Ixx = Ix * x, Ixy = Ix * y, Iyy = Iy * y, Iyx = Iy * x;
+			double Ixxx = Ixx * x, Ixxy = Ixx * y, Ixyy = Ixy * y;
+			double Iyyy = Iyy * y, Iyyx = Iyy * x, Iyxx = Iyx * x;
+#define D2(r, c) out[(c) * 8 + (r)]
+			D2(0, 6) -= Ixxx * inv_d2; D2(1, 6) -= Ixxy * inv_d2; D2(2, 6) -= Ixx * inv_d2;
+			D2(3, 6) -= Iyxx * inv_d2; D2(4, 6) -= Iyyx * inv_d2; D2(5, 6) -= Iyx * inv_d2;
+			D2(6, 6) += 2 * (Ixxx * cx + Iyxx * cy) * inv_d2;
+			D2(7, 6) += 2 * (Ixxy * cx + Iyyx * cy) * inv_d2;
+			D2(0, 7) -= Ixxy * inv_d2; D2(1, 7) -= Ixyy * inv_d2; D2(2, 7) -= Ixy * inv_d2;
+			D2(3, 7) -= Iyyx * inv_d2; D2(4, 7) -= Iyyy * inv_d2; D2(5, 7) -= Iyy * inv_d2;
+			D2(6, 7) += 2 * (Ixxy * cx + Iyyx * cy) * inv_d2;
+			D2(7, 7) += 2 * (Ixyy * cx + Iyyy * cy) * inv_d2;
+			for (int r = 0; r < 5; ++r) { D2(6, r) = D2(r, 6); D2(7, r) = D2(r, 7); }
+#undef D2
+		}
+		return 0;
+	}
+	/* Homography::cmptWarpedPixHessian SSM/src/Homography.cc:515-618 ; Affine::cmptWarpedPixHessian SSM/src/Affine.cc:264-291 */
+	void warped_pix_hessian(double *d2, const double *ph, const double *g) const {
+		double r0[8] = {0}, r1[8] = {0};
+		if (kind == MTFO_SSM_AFFINE) {
+			double a2 = state[2] + 1, a3 = state[3], a4 = state[4], a5 = state[5] + 1;
+			for (int i = 0; i < n; ++i) {
+				double x = init_pts[2 * i], y = init_pts[2 * i + 1];
+				const double *m = ph + 4 * i;
+				/* dw_dx^T * M * dw_dx with dw_dx = (a2 a3; a4 a5) */
+				double t00 = m[0] * a2 + m[2] * a4, t01 = m[0] * a3 + m[2] * a5;
+				double t10 = m[1] * a2 + m[3] * a4, t11 = m[1] * a3 + m[3] * a5;
+				double q00 = a2 * t00 + a4 * t10, q01 = a2 * t01 + a4 * t11;
+				double q10 = a3 * t00 + a5 * t10, q11 = a3 * t01 + a5 * t11;
+				dw_dp_rows(r0, r1, x, y, x, y);
+				sandwich(d2 + static_cast<size_t>(i) * 36, r0, r1, q00, q01, q10, q11);
+			}
+			return;
+		}
+		double a00 = curr_warp(0, 0), a01 = curr_warp(0, 1), a10 = curr_warp(1, 0), a11 = curr_warp(1, 1);
+		double a20 = curr_warp(2, 0), a21 = curr_warp(2, 1);
+		for (int i = 0; i < n; ++i) {
+			double wx = curr_pts[2 * i], wy = curr_pts[2 * i + 1];
+			double D = curr_pts_hm[3 * i + 2], D_inv = 1.0 / D;
+			double dwx_dx = (a00 - a20 * wx) * D_inv, dwx_dy = (a01 - a21 * wx) * D_inv;
+			double dwy_dx = (a10 - a20 * wy) * D_inv, dwy_dy = (a11 - a21 * wy) * D_inv;
+			double d2wx_dx2 = -2 * a20 * dwx_dx * D_inv, d2wx_dxdy = -(a21 * dwx_dx + a20 * dwx_dy) * D_inv;
+			double d2wx_dy2 = -2 * a21 * dwx_dy * D_inv;
+			double d2wy_dx2 = -2 * a20 * dwy_dx * D_inv, d2wy_dxdy = -(a21 * dwy_dx + a20 * dwy_dy) * D_inv;
+			double d2wy_dy2 = -2 * a21 * dwy_dy * D_inv;
+			double x = init_pts[2 * i], y = init_pts[2 * i + 1];
+			const double *m = ph + 4 * i;
+			double gx = g[i], gy = g[n + i];
+			/* dw_dX^T * M * dw_dX, dw_dX = (dwx_dx dwx_dy; dwy_dx dwy_dy) */
+			double t00 = m[0] * dwx_dx + m[2] * dwy_dx, t01 = m[0] * dwx_dy + m[2] * dwy_dy;
+			double t10 = m[1] * dwx_dx + m[3] * dwy_dx, t11 = m[1] * dwx_dy + m[3] * dwy_dy;
+			double q00 = dwx_dx * t00 + dwy_dx * t10, q01 = dwx_dx * t01 + dwy_dx * t11;
+			double q10 = dwx_dy * t00 + dwy_dy * t10, q11 = dwx_dy * t01 + dwy_dy * t11;
+			q00 = q00 + gx * d2wx_dx2 + gy * d2wy_dx2;
+			q01 = q01 + gx * d2wx_dxdy + gy * d2wy_dxdy;
+			q10 = q10 + gx * d2wx_dxdy + gy * d2wy_dxdy;
+			q11 = q11 + gx * d2wx_dy2 + gy * d2wy_dy2;
+			double *out = d2 + static_cast<size_t>(i) * 64;
+			dw_dp_rows(r0, r1, x, y, x, y);
+			sandwich(out, r0, r1, q00, q01, q10, q11);
+			double Ix = dwx_dx * gx + dwy_dx * gy;
+			double Iy = dwx_dy * gx + dwy_dy * gy;
+			hom_tail(out, Ix, Iy, x, y, -1.0, 2.0, x, y);
+		}
+	}
+	/* Homography::cmptApproxPixHessian SSM/src/Homography.cc:696-801 (Affine: not implemented) */
+	int approx_pix_hessian(double *d2, const double *ph, const double *g) const {
+		if (kind != MTFO_SSM_HOMOGRAPHY) return -2;
+		double h00 = curr_warp(0, 0), h01 = curr_warp(0, 1), h10 = curr_warp(1, 0), h11 = curr_warp(1, 1);
+		double h20 = curr_warp(2, 0), h21 = curr_warp(2, 1);
+		double r0[8] = {0}, r1[8] = {0};
+		for (int i = 0; i < n; ++i) {
+			double cx = curr_pts[2 * i], cy = curr_pts[2 * i + 1];
+			double D = curr_pts_hm[3 * i + 2];
+			double inv_det2 = 1.0 / (D * D), inv_det = 1.0 / D;
+			double a = (h00 - h20 * cx) * inv_det, b = (h01 - h21 * cx) * inv_det;
+			double c = (h10 - h20 * cy) * inv_det, d = (h11 - h21 * cy) * inv_det;
+			double inv_factor = 1.0 / (a * d - b * c);
+			double i00 = d * inv_factor, i01 = -b * inv_factor, i10 = -c * inv_factor, i11 = a * inv_factor; /* dw_dx_inv */
+			double ax = -h20 * (h00 + a * D - h20 * cx) * inv_det2;
+			double bx = -(h20 * h01 + h21 * (a * D - h20 * cx)) * inv_det2;
+			double cxx = -h20 * (h10 + c * D - h20 * cy) * inv_det2;
+			double dx = -(h20 * h11 + h21 * (c * D - h20 * cy)) * inv_det2;
+			double ay = -(h21 * h00 + h20 * (b * D - h21 * cx)) * inv_det2;
+			double by = -h21 * (h01 + b * D - h21 * cx) * inv_det2;
+			double cyy = -(h21 * h10 + h20 * (d * D - h21 * cy)) * inv_det2;
+			double dy = -h21 * (h11 + d * D - h21 * cy) * inv_det2;
+			double x = init_pts[2 * i], y = init_pts[2 * i + 1];
+			const double *m = ph + 4 * i;
+			double Ix = (d * g[i] - c * g[n + i]) * inv_factor;
+			double Iy = (a * g[n + i] - b * g[i]) * inv_factor;
+			/* inner = M - (Ix * d2w_dx2_x + Iy * d2w_dx2_y); `<<` fills row-major: (ax bx; cx dx) */
+			double n00 = m[0] - (Ix * ax + Iy * ay), n01 = m[2] - (Ix * bx + Iy * by);
+			double n10 = m[1] - (Ix * cxx + Iy * cyy), n11 = m[3] - (Ix * dx + Iy * dy);
+			/* dw_dx_inv^T * inner * dw_dx_inv */
+			double t00 = n00 * i00 + n01 * i10, t01 = n00 * i01 + n01 * i11;
+			double t10 = n10 * i00 + n11 * i10, t11 = n10 * i01 + n11 * i11;
+			double q00 = i00 * t00 + i10 * t10, q01 = i00 * t01 + i10 * t11;
+			double q10 = i01 * t00 + i11 * t10, q11 = i01 * t01 + i11 * t11;
+			double *out = d2 + static_cast<size_t>(i) * 64;
+			dw_dp_rows(r0, r1, x, y, x, y);
+			sandwich(out, r0, r1, q00, q01, q10, q11);
+			hom_tail(out, Ix, Iy, x, y, 1.0, -1.0, x, y);
+		}
+		return 0;
+	}
+
 	/* ProjectiveBase::applyWarpToCorners SSM/src/ProjectiveBase.cc:137-144 ;
 	 * Affine::applyWarpToCorners SSM/src/Affine.cc:366-375 */
 	void apply_warp_to_corners(double *out, const double *in, const double *p) const {
@@ -630,8 +884,9 @@ struct mtfo_am {
 	double grad_eps, likelihood_alpha;
 	const float *img; int h, w;
 	double norm_mult, norm_add;
-	bool init_pix_vals, init_pix_grad, init_sim, init_grad, init_hess;
-	vecd I0, It, dI0_dx, dIt_dx, df_dI0, df_dIt;
+	bool init_pix_vals, init_pix_grad, init_sim, init_grad, init_hess, init_pix_hess = false;
+	double hess_eps = 1.0; /* HESS_EPS AM/include/mtf/AM/ImageBase.h:9, Config/mtf.cfg:16 */
+	vecd I0, It, dI0_dx, dIt_dx, df_dI0, df_dIt, d2I0_dx2, d2It_dx2;
 	double f;
 	/* NCC */
 	double I0_mean, It_mean, a, b, c, bc, b2c;
@@ -690,6 +945,23 @@ struct mtfo_am {
 	/* ImageBase::updatePixGrad(PtsT) :292-314 ; (GradPtsT) :340-362 */
 	void update_pix_grad_pts(const double *pts) { img_grad(dIt_dx.data(), img, h, w, pts, grad_eps, n, norm_mult); }
 	void update_pix_grad_warped(const double *gp) { warped_img_grad(dIt_dx.data(), img, h, w, gp, grad_eps, n, norm_mult); }
+
+	/* ImageBase::initializePixHess(PtsT) AM/src/ImageBase.cc:208-240 ; (PtsT, HessPtsT) :174-206 ;
+	 * updatePixHess :316-338 and :364-386 */
+	void initialize_pix_hess_pts(const double *pts) {
+		if (!init_pix_hess) { d2I0_dx2.resize(4 * static_cast<size_t>(n)); d2It_dx2.resize(4 * static_cast<size_t>(n)); }
+		img_hess(d2I0_dx2.data(), img, h, w, pts, hess_eps, n, norm_mult);
+		if (!init_pix_hess) { d2It_dx2 = d2I0_dx2; init_pix_hess = true; }
+	}
+	void initialize_pix_hess_warped(const double *pts, const double *hp) {
+		if (!init_pix_hess) { d2I0_dx2.resize(4 * static_cast<size_t>(n)); d2It_dx2.resize(4 * static_cast<size_t>(n)); }
+		warped_img_hess(d2I0_dx2.data(), img, h, w, pts, hp, hess_eps, n, norm_mult);
+		if (!init_pix_hess) { d2It_dx2 = d2I0_dx2; init_pix_hess = true; }
+	}
+	void update_pix_hess_pts(const double *pts) { img_hess(d2It_dx2.data(), img, h, w, pts, hess_eps, n, norm_mult); }
+	void update_pix_hess_warped(const double *pts, const double *hp) {
+		warped_img_hess(d2It_dx2.data(), img, h, w, pts, hp, hess_eps, n, norm_mult);
+	}
 
 	/* ---------------- similarity ---------------- */
 	void initialize_similarity() {
@@ -911,6 +1183,66 @@ struct mtfo_am {
 		cmpt_init_hessian(H0.data(), J0, S);
 		cmpt_curr_hessian(Ht.data(), Jt, S);
 		for (int i = 0; i < S * S; ++i) H[i] = H0[i] + Ht[i];
+	}
+
+	/* ---------------- second-order Hessians ---------------- */
+	/* H += sum_p w[p] * d2I_dp2[:, p]  (d2 is S^2 x N, one column-major S x S block per pixel) */
+	void add_weighted_pix_hess(double *H, const double *d2, const double *wt, int S) const {
+		for (int p = 0; p < n; ++p) {
+			const double *blk = d2 + static_cast<size_t>(p) * S * S;
+			for (int k = 0; k < S * S; ++k) H[k] += blk[k] * wt[p];
+		}
+	}
+	/* SSDBase::cmptInitHessian (second order) AM/src/SSDBase.cc:313-343 ; NCC AM/src/NCC.cc:391-400 ; MI AM/src/MI.cc:659-673 */
+	int cmpt_init_hessian2(double *H, const double *J0, const double *d2I0, int S) {
+		cmpt_init_hessian(H, J0, S);
+		add_weighted_pix_hess(H, d2I0, df_dI0.data(), S);
+		return 0;
+	}
+	/* SSDBase.cc:345-375 ; NCC.cc:401-410 ; MI.cc:680-694 */
+	int cmpt_curr_hessian2(double *H, const double *Jt, const double *d2It, int S) {
+		cmpt_curr_hessian(H, Jt, S);
+		add_weighted_pix_hess(H, d2It, df_dIt.data(), S);
+		return 0;
+	}
+	/* SSD: first order only (SSDBase.h:95-98) ; NCC: not overridden -> FunctonNotImplemented
+	 * (AppearanceModel.h:188-191) ; MI::cmptSelfHessian (second order) AM/src/MI.cc:696-733 */
+	int cmpt_self_hessian2(double *H, const double *Jt, const double *d2It, int S) {
+		switch (kind) {
+		case MTFO_AM_SSD: cmpt_self_hessian(H, Jt, S); return 0;
+		case MTFO_AM_NCC: return -2;
+		default: {
+			mi_cmpt_self_hessian(H, Jt, S);
+			vecd wt(n);
+			for (int p = 0; p < n; ++p) {
+				double grad_term = 0;
+				for (int r = curr_ids[2 * p]; r <= curr_ids[2 * p + 1]; ++r) {
+					double inner = 0;
+					for (int t = curr_ids[2 * p]; t <= curr_ids[2 * p + 1]; ++t)
+						inner += HMc(curr_hist_mat, t, p) * self_grad_factor[lin(r, t)];
+					grad_term += HMc(curr_hist_grad, r, p) * inner;
+				}
+				wt[p] = grad_term;
+			}
+			add_weighted_pix_hess(H, d2It, wt.data(), S);
+			return 0;
+		}
+		}
+	}
+	/* SSDBase::cmptSumOfHessians (second order) AM/src/SSDBase.cc:377-415 -- weights BOTH pixel Hessians by df_dI0 ;
+	 * NCC / MI: the generic AppearanceModel.h:209-219 (init2 + curr2) */
+	int cmpt_sum_of_hessians2(double *H, const double *J0, const double *Jt, const double *d2I0, const double *d2It, int S) {
+		if (kind == MTFO_AM_SSD) {
+			cmpt_sum_of_hessians(H, J0, Jt, S);
+			add_weighted_pix_hess(H, d2I0, df_dI0.data(), S);
+			add_weighted_pix_hess(H, d2It, df_dI0.data(), S);
+			return 0;
+		}
+		vecd H0(S * S), Ht(S * S);
+		cmpt_init_hessian2(H0.data(), J0, d2I0, S);
+		cmpt_curr_hessian2(Ht.data(), Jt, d2It, S);
+		for (int i = 0; i < S * S; ++i) H[i] = H0[i] + Ht[i];
+		return 0;
 	}
 
 	/* ---------------- helpers ---------------- */
@@ -1166,6 +1498,8 @@ struct mtfo_tracker {
 	int sm; mtfo_am *am; mtfo_ssm *ssm; mtfo_sm_params p;
 	int S, N;
 	vecd J0, Jt, Jmean, g, H, H0, dp, inv_dp, prev_corners;
+	vecd D0, Dt, Dmean; /* init / curr / mean pixel Hessians, S^2 x N (sec_ord_hess) */
+	int status = 0;     /* -2 once an AM/SSM call the reference does not implement was needed */
 	vecd trace; int rec_len, n_rec;
 
 	mtfo_tracker(int _sm, mtfo_am *_am, mtfo_ssm *_ssm, const mtfo_sm_params &_p) :
@@ -1174,6 +1508,7 @@ struct mtfo_tracker {
 		g.assign(S, 0.0); H.assign(S * S, 0.0); H0.assign(S * S, 0.0);
 		dp.assign(S, 0.0); inv_dp.assign(S, 0.0); prev_corners.resize(8);
 		rec_len = 1 + S + S * S + S + 8; n_rec = 0;
+		if (p.sec_ord_hess) { D0.assign(static_cast<size_t>(N) * S * S, 0.0); Dt = D0; }
 	}
 
 	void pix_jacobian_init(double *J) {
@@ -1199,16 +1534,43 @@ struct mtfo_tracker {
 		}
 	}
 
+	/* ESM::initializePixHessian NT/ESM.cc:406-416 (FCLK NT/FCLK.cc:121-142, ICLK NT/ICLK.cc:96-113 inline the same) */
+	void pix_hess_init() {
+		if (p.chained_warp) am->initialize_pix_hess_pts(ssm->curr_pts.data());
+		else { ssm->update_hess_pts(am->hess_eps); am->initialize_pix_hess_warped(ssm->curr_pts.data(), ssm->hess_pts.data()); }
+	}
+	void pix_hessian_from_init(double *D) {
+		if (p.chained_warp) ssm->warped_pix_hessian(D, am->d2I0_dx2.data(), am->dI0_dx.data());
+		else ssm->init_pix_hessian(D, am->d2I0_dx2.data(), am->dI0_dx.data());
+	}
+	/* ESM::updatePixHessian NT/ESM.cc:418-432 ; FCLK NT/FCLK.cc:243-257 ; ICLK NT/ICLK.cc:223-237 */
+	void pix_hessian_update(double *D) {
+		if (p.chained_warp) {
+			am->update_pix_hess_pts(ssm->curr_pts.data());
+			ssm->warped_pix_hessian(D, am->d2It_dx2.data(), am->dIt_dx.data());
+		} else {
+			ssm->update_hess_pts(am->hess_eps);
+			am->update_pix_hess_warped(ssm->curr_pts.data(), ssm->hess_pts.data());
+			ssm->init_pix_hessian(D, am->d2It_dx2.data(), am->dIt_dx.data());
+		}
+	}
+	void self_hessian(double *Hout, const double *J, const double *D) {
+		if (p.sec_ord_hess) { if (am->cmpt_self_hessian2(Hout, J, D, S)) status = -2; }
+		else am->cmpt_self_hessian(Hout, J, S);
+	}
+
 	void initialize(const double *corners) {
-		am->init_pix_vals = am->init_pix_grad = am->init_sim = am->init_grad = am->init_hess = false;
+		am->init_pix_vals = am->init_pix_grad = am->init_sim = am->init_grad = am->init_hess = am->init_pix_hess = false;
+		status = 0;
 		ssm->set_corners(corners);
 		am->initialize_pix_vals(ssm->curr_pts.data());
 		switch (sm) {
 		case MTFO_SM_ESM: /* nt::ESM::initialize SM/src/NT/ESM.cc:110-146 */
 			pix_jacobian_init(J0.data());
+			if (p.sec_ord_hess) { pix_hess_init(); pix_hessian_from_init(D0.data()); }
 			am->initialize_similarity(); am->initialize_grad(); am->initialize_hess();
 			if (p.hess_type == 0 /*InitialSelf*/ || p.hess_type == 2 /*SumOfSelf*/) {
-				am->cmpt_self_hessian(H.data(), J0.data(), S);
+				self_hessian(H.data(), J0.data(), D0.data());
 				H0 = H;
 			}
 			break;
@@ -1216,10 +1578,12 @@ struct mtfo_tracker {
 			am->initialize_similarity(); am->initialize_grad(); am->initialize_hess();
 			if (p.chained_warp) am->initialize_pix_grad_pts(ssm->curr_pts.data());
 			else { ssm->update_grad_pts(am->grad_eps); am->initialize_pix_grad_warped(ssm->grad_pts.data()); }
+			if (p.sec_ord_hess) pix_hess_init();
 			if (p.hess_type == 0 /*InitialSelf*/) {
 				if (p.chained_warp) ssm->warped_pix_jacobian(J0.data(), am->dI0_dx.data());
 				else ssm->init_pix_jacobian(J0.data(), am->dI0_dx.data());
-				am->cmpt_self_hessian(H.data(), J0.data(), S);
+				if (p.sec_ord_hess) pix_hessian_from_init(D0.data());
+				self_hessian(H.data(), J0.data(), D0.data());
 				if (p.leven_marq) H0 = H;
 			}
 			break;
@@ -1230,8 +1594,12 @@ struct mtfo_tracker {
 			if (p.chained_warp) ssm->warped_pix_jacobian(J0.data(), am->dI0_dx.data());
 			else ssm->init_pix_jacobian(J0.data(), am->dI0_dx.data());
 			am->cmpt_init_jacobian(g.data(), J0.data(), S);
+			if (p.sec_ord_hess) {
+				pix_hess_init();
+				if (p.hess_type != 1 /*CurrentSelf*/) pix_hessian_from_init(D0.data());
+			}
 			if (p.hess_type == 0 /*InitialSelf*/) {
-				am->cmpt_self_hessian(H.data(), J0.data(), S);
+				self_hessian(H.data(), J0.data(), D0.data());
 				if (p.leven_marq) H0 = H;
 			}
 			break;
@@ -1244,7 +1612,12 @@ struct mtfo_tracker {
 		ssm->set_corners(corners);
 		if (sm == MTFO_SM_ESM) {
 			ssm->init_pix_jacobian(J0.data(), am->dI0_dx.data());
-			if (p.hess_type == 0 || p.hess_type == 2) { am->cmpt_self_hessian(H.data(), J0.data(), S); H0 = H; }
+			if (p.sec_ord_hess) ssm->init_pix_hessian(D0.data(), am->d2I0_dx2.data(), am->dI0_dx.data());
+			if (p.hess_type == 0 || p.hess_type == 2) { self_hessian(H.data(), J0.data(), D0.data()); H0 = H; }
+		} else if (sm == MTFO_SM_FCLK && p.hess_type == 0) { /* NT/FCLK.cc:360-376: init_self_hessian is NOT refreshed */
+			ssm->init_pix_jacobian(J0.data(), am->dI0_dx.data());
+			if (p.sec_ord_hess) ssm->init_pix_hessian(D0.data(), am->d2I0_dx2.data(), am->dI0_dx.data());
+			self_hessian(H.data(), J0.data(), D0.data());
 		}
 	}
 
@@ -1313,6 +1686,7 @@ struct mtfo_tracker {
 				Jmean.resize(Jt.size());
 				for (size_t i = 0; i < Jt.size(); ++i) Jmean[i] = (J0[i] + Jt[i]) / 2.0;
 			}
+			if (p.sec_ord_hess && p.hess_type != 0) pix_hessian_update(Dt.data());
 			am->update_curr_grad();
 			am->update_init_grad();
 			if (p.jac_type == 0) am->cmpt_curr_jacobian(g.data(), Jmean.data(), S);
@@ -1322,17 +1696,27 @@ struct mtfo_tracker {
 			}
 			switch (p.hess_type) {
 			case 0: if (p.leven_marq) H = H0; break;                               /* InitialSelf */
-			case 3: am->cmpt_curr_hessian(H.data(), Jmean.data(), S); break;         /* Original */
+			case 3: /* Original */
+				if (p.sec_ord_hess) {
+					Dmean.resize(Dt.size());
+					for (size_t i = 0; i < Dt.size(); ++i) Dmean[i] = (D0[i] + Dt[i]) / 2.0;
+					am->cmpt_curr_hessian2(H.data(), Jmean.data(), Dmean.data(), S);
+				} else am->cmpt_curr_hessian(H.data(), Jmean.data(), S);
+				break;
 			case 4: /* SumOfStd */
-				am->cmpt_sum_of_hessians(H.data(), J0.data(), Jt.data(), S);
+				if (p.sec_ord_hess) am->cmpt_sum_of_hessians2(H.data(), J0.data(), Jt.data(), D0.data(), Dt.data(), S);
+				else am->cmpt_sum_of_hessians(H.data(), J0.data(), Jt.data(), S);
 				for (auto &v : H) { v *= 0.5; }
 				break;
 			case 2: /* SumOfSelf */
-				am->cmpt_self_hessian(H.data(), Jt.data(), S);
+				self_hessian(H.data(), Jt.data(), Dt.data());
 				for (int i = 0; i < S * S; ++i) { H[i] = (H[i] + H0[i]) * 0.5; }
 				break;
-			case 1: am->cmpt_self_hessian(H.data(), Jt.data(), S); break;            /* CurrentSelf */
-			case 5: am->cmpt_curr_hessian(H.data(), Jt.data(), S); break;            /* Std */
+			case 1: self_hessian(H.data(), Jt.data(), Dt.data()); break;             /* CurrentSelf */
+			case 5: /* Std */
+				if (p.sec_ord_hess) am->cmpt_curr_hessian2(H.data(), Jt.data(), Dt.data(), S);
+				else am->cmpt_curr_hessian(H.data(), Jt.data(), S);
+				break;
 			}
 			double f_now = am->f;
 			vecd H_plain = H;
@@ -1371,11 +1755,15 @@ struct mtfo_tracker {
 			state_reset = false;
 			am->update_curr_grad();
 			pix_jacobian_update(Jt.data());
+			if (p.sec_ord_hess && p.hess_type != 0) pix_hessian_update(Dt.data());
 			am->cmpt_curr_jacobian(g.data(), Jt.data(), S);
 			switch (p.hess_type) {
 			case 0: if (p.leven_marq) H = H0; break;                       /* InitialSelf */
-			case 1: am->cmpt_self_hessian(H.data(), Jt.data(), S); break;   /* CurrentSelf */
-			case 2: am->cmpt_curr_hessian(H.data(), Jt.data(), S); break;   /* Std */
+			case 1: self_hessian(H.data(), Jt.data(), Dt.data()); break;    /* CurrentSelf */
+			case 2: /* Std */
+				if (p.sec_ord_hess) am->cmpt_curr_hessian2(H.data(), Jt.data(), Dt.data(), S);
+				else am->cmpt_curr_hessian(H.data(), Jt.data(), S);
+				break;
 			}
 			double f_now = am->f;
 			vecd H_plain = H;
@@ -1417,8 +1805,12 @@ struct mtfo_tracker {
 			switch (p.hess_type) {
 			case 0: if (p.leven_marq) H = H0; break;                      /* InitialSelf */
 			case 1: pix_jacobian_update(Jt.data());                         /* CurrentSelf */
-				am->cmpt_self_hessian(H.data(), Jt.data(), S); break;
-			case 2: am->cmpt_init_hessian(H.data(), J0.data(), S); break;  /* Std */
+				if (p.sec_ord_hess) pix_hessian_update(Dt.data());
+				self_hessian(H.data(), Jt.data(), Dt.data()); break;
+			case 2: /* Std */
+				if (p.sec_ord_hess) am->cmpt_init_hessian2(H.data(), J0.data(), D0.data(), S);
+				else am->cmpt_init_hessian(H.data(), J0.data(), S);
+				break;
 			}
 			double f_now = am->f;
 			vecd H_plain = H;
@@ -1446,6 +1838,13 @@ void mtfo_get_img_grad(double *grad, const float *img, int h, int w, const doubl
 void mtfo_get_warped_img_grad(double *grad, const float *img, int h, int w, const double *grad_pts,
 	double grad_eps, int n, double pix_mult) { warped_img_grad(grad, img, h, w, grad_pts, grad_eps, n, pix_mult); }
 
+void mtfo_get_img_hess(double *hess, const float *img, int h, int w, const double *pts, double hess_eps, int n, double pix_mult) {
+	img_hess(hess, img, h, w, pts, hess_eps, n, pix_mult);
+}
+void mtfo_get_warped_img_hess(double *hess, const float *img, int h, int w, const double *pts, const double *hess_pts,
+	double hess_eps, int n, double pix_mult) {
+	warped_img_hess(hess, img, h, w, pts, hess_pts, hess_eps, n, pix_mult);
+}
 void mtfo_homography_dlt(const double *in_corners, const double *out_corners, double *warp9) {
 	Mat3 H = homography_dlt(in_corners, out_corners);
 	std::memcpy(warp9, H.m, sizeof(H.m));
@@ -1469,6 +1868,11 @@ void mtfo_ssm_cmpt_init_pix_jacobian(mtfo_ssm *s, double *J, const double *g) { 
 void mtfo_ssm_cmpt_pix_jacobian(mtfo_ssm *s, double *J, const double *g) { s->pix_jacobian(J, g); }
 void mtfo_ssm_cmpt_warped_pix_jacobian(mtfo_ssm *s, double *J, const double *g) { s->warped_pix_jacobian(J, g); }
 void mtfo_ssm_cmpt_approx_pix_jacobian(mtfo_ssm *s, double *J, const double *g) { s->approx_pix_jacobian(J, g); }
+void mtfo_ssm_update_hess_pts(mtfo_ssm *s, double eps) { s->update_hess_pts(eps); }
+int mtfo_ssm_cmpt_init_pix_hessian(mtfo_ssm *s, double *d2, const double *ph, const double *g) { s->init_pix_hessian(d2, ph, g); return 0; }
+int mtfo_ssm_cmpt_pix_hessian(mtfo_ssm *s, double *d2, const double *ph, const double *g) { return s->pix_hessian(d2, ph, g); }
+int mtfo_ssm_cmpt_warped_pix_hessian(mtfo_ssm *s, double *d2, const double *ph, const double *g) { s->warped_pix_hessian(d2, ph, g); return 0; }
+int mtfo_ssm_cmpt_approx_pix_hessian(mtfo_ssm *s, double *d2, const double *ph, const double *g) { return s->approx_pix_hessian(d2, ph, g); }
 void mtfo_ssm_apply_warp_to_corners(mtfo_ssm *s, double *out, const double *in, const double *p) { s->apply_warp_to_corners(out, in, p); }
 void mtfo_ssm_compositional_random_walk(mtfo_ssm *s, double *out, const double *base, const double *pert) {
 	s->compositional_random_walk(out, base, pert);
@@ -1485,6 +1889,7 @@ void mtfo_ssm_get(const mtfo_ssm *s, int what, double *dst) {
 	case 6: v = &s->grad_pts; break;
 	case 7: v = &s->curr_pts_hm; break;
 	case 8: v = &s->init_pts_hm; break;
+	case 9: v = &s->hess_pts; break;
 	default: return;
 	}
 	std::copy(v->begin(), v->end(), dst);
@@ -1503,6 +1908,17 @@ void mtfo_am_initialize_pix_grad_pts(mtfo_am *a, const double *pts) { a->initial
 void mtfo_am_initialize_pix_grad_warped(mtfo_am *a, const double *gp) { a->initialize_pix_grad_warped(gp); }
 void mtfo_am_update_pix_grad_pts(mtfo_am *a, const double *pts) { a->update_pix_grad_pts(pts); }
 void mtfo_am_update_pix_grad_warped(mtfo_am *a, const double *gp) { a->update_pix_grad_warped(gp); }
+void mtfo_am_set_hess_eps(mtfo_am *a, double eps) { a->hess_eps = eps; }
+void mtfo_am_initialize_pix_hess_pts(mtfo_am *a, const double *pts) { a->initialize_pix_hess_pts(pts); }
+void mtfo_am_initialize_pix_hess_warped(mtfo_am *a, const double *pts, const double *hp) { a->initialize_pix_hess_warped(pts, hp); }
+void mtfo_am_update_pix_hess_pts(mtfo_am *a, const double *pts) { a->update_pix_hess_pts(pts); }
+void mtfo_am_update_pix_hess_warped(mtfo_am *a, const double *pts, const double *hp) { a->update_pix_hess_warped(pts, hp); }
+int mtfo_am_cmpt_init_hessian2(mtfo_am *a, double *H, const double *J0, const double *d2, int S) { return a->cmpt_init_hessian2(H, J0, d2, S); }
+int mtfo_am_cmpt_curr_hessian2(mtfo_am *a, double *H, const double *Jt, const double *d2, int S) { return a->cmpt_curr_hessian2(H, Jt, d2, S); }
+int mtfo_am_cmpt_self_hessian2(mtfo_am *a, double *H, const double *Jt, const double *d2, int S) { return a->cmpt_self_hessian2(H, Jt, d2, S); }
+int mtfo_am_cmpt_sum_of_hessians2(mtfo_am *a, double *H, const double *J0, const double *Jt, const double *d20, const double *d2t, int S) {
+	return a->cmpt_sum_of_hessians2(H, J0, Jt, d20, d2t, S);
+}
 void mtfo_am_initialize_similarity(mtfo_am *a) { a->initialize_similarity(); }
 void mtfo_am_initialize_grad(mtfo_am *a) { a->initialize_grad(); }
 void mtfo_am_initialize_hess(mtfo_am *a) { a->initialize_hess(); }
@@ -1531,6 +1947,8 @@ void mtfo_am_get(const mtfo_am *a, int what, double *dst) {
 	case 3: v = &a->dIt_dx; break;
 	case 4: v = &a->df_dI0; break;
 	case 5: v = &a->df_dIt; break;
+	case 6: v = &a->d2I0_dx2; break;
+	case 7: v = &a->d2It_dx2; break;
 	default: return;
 	}
 	std::copy(v->begin(), v->end(), dst);
@@ -1546,6 +1964,7 @@ void mtfo_tracker_set_region(mtfo_tracker *t, const double *corners) { t->set_re
 void mtfo_tracker_get_region(const mtfo_tracker *t, double *corners) {
 	std::copy(t->ssm->curr_corners.begin(), t->ssm->curr_corners.end(), corners);
 }
+int mtfo_tracker_status(const mtfo_tracker *t) { return t->status; }
 int mtfo_tracker_trace_len(const mtfo_tracker *t) { return t->n_rec; }
 int mtfo_tracker_trace(const mtfo_tracker *t, int iter, double *dst) {
 	if (iter < 0 || iter >= t->n_rec) return 0;

@@ -44,6 +44,12 @@ void mtfo_get_img_grad(double *grad, const float *img, int h, int w,
 void mtfo_get_warped_img_grad(double *grad, const float *img, int h, int w,
 	const double *grad_pts, double grad_eps, int n, double pix_mult);
 
+/* hess: 4 x N col-major (xx, xy, yx, yy per pixel); hess_pts: 16 x N */
+void mtfo_get_img_hess(double *hess, const float *img, int h, int w,
+	const double *pts, double hess_eps, int n, double pix_mult);
+void mtfo_get_warped_img_hess(double *hess, const float *img, int h, int w,
+	const double *pts, const double *hess_pts, double hess_eps, int n, double pix_mult);
+
 /* ---- small host math the SMs / SSMs use (Eigen in the reference) ---- */
 void mtfo_homography_dlt(const double *in_corners, const double *out_corners,
 	double *warp_rowmajor9);
@@ -67,13 +73,20 @@ void mtfo_ssm_cmpt_init_pix_jacobian(mtfo_ssm *s, double *J, const double *pix_g
 void mtfo_ssm_cmpt_pix_jacobian(mtfo_ssm *s, double *J, const double *pix_grad);
 void mtfo_ssm_cmpt_warped_pix_jacobian(mtfo_ssm *s, double *J, const double *pix_grad);
 void mtfo_ssm_cmpt_approx_pix_jacobian(mtfo_ssm *s, double *J, const double *pix_grad);
+/* second order (sec_ord_hess): pix_hess 4 x N, pix_grad N x 2 -> d2I_dp2 S^2 x N (one col-major S x S block per pixel);
+ * return -2 where the reference's SSM leaves the virtual unimplemented (Affine: Pix, Approx) */
+void mtfo_ssm_update_hess_pts(mtfo_ssm *s, double hess_eps);
+int mtfo_ssm_cmpt_init_pix_hessian(mtfo_ssm *s, double *d2, const double *pix_hess, const double *pix_grad);
+int mtfo_ssm_cmpt_pix_hessian(mtfo_ssm *s, double *d2, const double *pix_hess, const double *pix_grad);
+int mtfo_ssm_cmpt_warped_pix_hessian(mtfo_ssm *s, double *d2, const double *pix_hess, const double *pix_grad);
+int mtfo_ssm_cmpt_approx_pix_hessian(mtfo_ssm *s, double *d2, const double *pix_hess, const double *pix_grad);
 void mtfo_ssm_apply_warp_to_corners(mtfo_ssm *s, double *out_corners,
 	const double *in_corners, const double *state);
 void mtfo_ssm_compositional_random_walk(mtfo_ssm *s, double *perturbed_state,
 	const double *base_state, const double *perturbation);
 /* what: 0 curr_pts(2N) 1 init_pts(2N) 2 curr_corners(8) 3 init_corners(8)
  *       4 curr_state(S) 5 curr_warp(9,row-major) 6 grad_pts(8N)
- *       7 curr_pts_hm(3N) 8 init_pts_hm(3N) */
+ *       7 curr_pts_hm(3N) 8 init_pts_hm(3N) 9 hess_pts(16N) */
 void mtfo_ssm_get(const mtfo_ssm *s, int what, double *dst);
 
 /* ---- appearance model ---- */
@@ -89,6 +102,17 @@ void mtfo_am_initialize_pix_grad_pts(mtfo_am *a, const double *pts);
 void mtfo_am_initialize_pix_grad_warped(mtfo_am *a, const double *grad_pts);
 void mtfo_am_update_pix_grad_pts(mtfo_am *a, const double *pts);
 void mtfo_am_update_pix_grad_warped(mtfo_am *a, const double *grad_pts);
+void mtfo_am_set_hess_eps(mtfo_am *a, double hess_eps); /* default 1 (ImageBase.h:9) */
+void mtfo_am_initialize_pix_hess_pts(mtfo_am *a, const double *pts);
+void mtfo_am_initialize_pix_hess_warped(mtfo_am *a, const double *pts, const double *hess_pts);
+void mtfo_am_update_pix_hess_pts(mtfo_am *a, const double *pts);
+void mtfo_am_update_pix_hess_warped(mtfo_am *a, const double *pts, const double *hess_pts);
+/* second-order Hessians; -2 = FunctonNotImplemented in the reference (NCC self) */
+int mtfo_am_cmpt_init_hessian2(mtfo_am *a, double *H, const double *J0, const double *d2I0, int S);
+int mtfo_am_cmpt_curr_hessian2(mtfo_am *a, double *H, const double *Jt, const double *d2It, int S);
+int mtfo_am_cmpt_self_hessian2(mtfo_am *a, double *H, const double *Jt, const double *d2It, int S);
+int mtfo_am_cmpt_sum_of_hessians2(mtfo_am *a, double *H, const double *J0, const double *Jt,
+	const double *d2I0, const double *d2It, int S);
 void mtfo_am_initialize_similarity(mtfo_am *a);
 void mtfo_am_initialize_grad(mtfo_am *a);
 void mtfo_am_initialize_hess(mtfo_am *a);
@@ -106,7 +130,7 @@ void mtfo_am_cmpt_curr_hessian(mtfo_am *a, double *H, const double *Jt, int S);
 void mtfo_am_cmpt_self_hessian(mtfo_am *a, double *H, const double *Jt, int S);
 void mtfo_am_cmpt_sum_of_hessians(mtfo_am *a, double *H,
 	const double *J0, const double *Jt, int S);
-/* what: 0 I0 1 It 2 dI0_dx(2N) 3 dIt_dx(2N) 4 df_dI0 5 df_dIt */
+/* what: 0 I0 1 It 2 dI0_dx(2N) 3 dIt_dx(2N) 4 df_dI0 5 df_dIt 6 d2I0_dx2(4N) 7 d2It_dx2(4N) */
 void mtfo_am_get(const mtfo_am *a, int what, double *dst);
 
 /* ---- search methods (NT ESM / FCLK / ICLK) ---- */
@@ -119,6 +143,7 @@ typedef struct mtfo_sm_params {
 	int leven_marq;
 	double lm_delta_init;
 	double lm_delta_update;
+	int sec_ord_hess; /* second-order Hessians (off in every shipped config) */
 } mtfo_sm_params;
 
 typedef struct mtfo_tracker mtfo_tracker;
@@ -132,6 +157,8 @@ void mtfo_tracker_set_region(mtfo_tracker *t, const double *corners);
 void mtfo_tracker_get_region(const mtfo_tracker *t, double *corners);
 /* per-iteration trace of the last update(): each record is
  * [f, g(S), H(S*S col-major), dp(S), corners(8)] ; returns record length */
+/* 0, or -2 once the loop needed a virtual the reference leaves unimplemented */
+int mtfo_tracker_status(const mtfo_tracker *t);
 int mtfo_tracker_trace_len(const mtfo_tracker *t);
 int mtfo_tracker_trace(const mtfo_tracker *t, int iter, double *dst);
 

@@ -24,7 +24,7 @@ _ip = C.POINTER(C.c_int)
 class SMParams(C.Structure):
     _fields_ = [("max_iters", C.c_int), ("epsilon", C.c_double), ("jac_type", C.c_int),
                 ("hess_type", C.c_int), ("chained_warp", C.c_int), ("leven_marq", C.c_int),
-                ("lm_delta_init", C.c_double), ("lm_delta_update", C.c_double)]
+                ("lm_delta_init", C.c_double), ("lm_delta_update", C.c_double), ("sec_ord_hess", C.c_int)]
 
 
 def build(force=False):
@@ -103,6 +103,23 @@ def get_warped_img_grad(img, grad_pts_flat, eps=1e-8, mult=1.0):
     return out
 
 
+def get_img_hess(img, pts_flat, eps=1.0, mult=1.0):
+    h, w = img.shape
+    n = pts_flat.size // 2
+    out = np.empty(4 * n)
+    lib().mtfo_get_img_hess(_d(out), _f(img), h, w, _d(pts_flat), C.c_double(eps), n, C.c_double(mult))
+    return out
+
+
+def get_warped_img_hess(img, pts_flat, hess_pts_flat, eps=1.0, mult=1.0):
+    h, w = img.shape
+    n = pts_flat.size // 2
+    out = np.empty(4 * n)
+    lib().mtfo_get_warped_img_hess(_d(out), _f(img), h, w, _d(pts_flat), _d(hess_pts_flat), C.c_double(eps), n,
+                                   C.c_double(mult))
+    return out
+
+
 def homography_dlt(in_corners, out_corners):
     a, b = pts_to_flat(in_corners), pts_to_flat(out_corners)
     out = np.empty(9)
@@ -124,7 +141,7 @@ def colpiv_qr_solve(A, b):
 class SSM:
     GET = {"curr_pts": (0, 2), "init_pts": (1, 2), "curr_corners": (2, None), "init_corners": (3, None),
            "state": (4, None), "curr_warp": (5, None), "grad_pts": (6, 8), "curr_pts_hm": (7, 3),
-           "init_pts_hm": (8, 3)}
+           "init_pts_hm": (8, 3), "hess_pts": (9, 16)}
 
     def __init__(self, kind, resx, resy):
         self.kind, self.resx, self.resy = kind, resx, resy
@@ -183,6 +200,30 @@ class SSM:
     def cmpt_approx_pix_jacobian(self, grad):
         return self._jac(lib().mtfo_ssm_cmpt_approx_pix_jacobian, grad)
 
+    def update_hess_pts(self, eps):
+        lib().mtfo_ssm_update_hess_pts(self.h, C.c_double(eps))
+
+    def _pix_hess(self, fn, pix_hess, grad):
+        """(4N,) pix_hess + (2N,) pix_grad -> d2I_dp2 as (N, S, S) [pixel, row, col]; None where unimplemented"""
+        pix_hess, grad = _vec(pix_hess), _vec(grad)
+        d2 = np.empty(self.n * self.S * self.S)
+        rc = fn(self.h, _d(d2), _d(pix_hess), _d(grad))
+        if rc != 0:
+            return None
+        return d2.reshape(self.n, self.S, self.S).transpose(0, 2, 1)
+
+    def cmpt_init_pix_hessian(self, pix_hess, grad):
+        return self._pix_hess(lib().mtfo_ssm_cmpt_init_pix_hessian, pix_hess, grad)
+
+    def cmpt_pix_hessian(self, pix_hess, grad):
+        return self._pix_hess(lib().mtfo_ssm_cmpt_pix_hessian, pix_hess, grad)
+
+    def cmpt_warped_pix_hessian(self, pix_hess, grad):
+        return self._pix_hess(lib().mtfo_ssm_cmpt_warped_pix_hessian, pix_hess, grad)
+
+    def cmpt_approx_pix_hessian(self, pix_hess, grad):
+        return self._pix_hess(lib().mtfo_ssm_cmpt_approx_pix_hessian, pix_hess, grad)
+
     def apply_warp_to_corners(self, corners, p):
         c, p = pts_to_flat(corners), _vec(p)
         out = np.empty(8)
@@ -197,7 +238,8 @@ class SSM:
 
 
 class AM:
-    GET = {"I0": (0, 1), "It": (1, 1), "dI0_dx": (2, 2), "dIt_dx": (3, 2), "df_dI0": (4, 1), "df_dIt": (5, 1)}
+    GET = {"I0": (0, 1), "It": (1, 1), "dI0_dx": (2, 2), "dIt_dx": (3, 2), "df_dI0": (4, 1), "df_dIt": (5, 1),
+           "d2I0_dx2": (6, 4), "d2It_dx2": (7, 4)}
 
     def __init__(self, kind, resx, resy, grad_eps=1e-8, likelihood_alpha=1.0, n_bins=8, pre_seed=10.0, pou=0):
         self.kind, self.resx, self.resy = kind, resx, resy
@@ -284,6 +326,44 @@ class AM:
         fn(self.h, _d(H), *[_d(J) for J in Js], S)
         return H.reshape(S, S).T  # column-major -> [r, c]
 
+    def set_hess_eps(self, eps):
+        lib().mtfo_am_set_hess_eps(self.h, C.c_double(eps))
+
+    def initialize_pix_hess_pts(self, pts):
+        self._call_pts(lib().mtfo_am_initialize_pix_hess_pts, pts)
+
+    def update_pix_hess_pts(self, pts):
+        self._call_pts(lib().mtfo_am_update_pix_hess_pts, pts)
+
+    def initialize_pix_hess_warped(self, pts, hess_pts):
+        a, b = _vec(pts), _vec(hess_pts)
+        lib().mtfo_am_initialize_pix_hess_warped(self.h, _d(a), _d(b))
+
+    def update_pix_hess_warped(self, pts, hess_pts):
+        a, b = _vec(pts), _vec(hess_pts)
+        lib().mtfo_am_update_pix_hess_warped(self.h, _d(a), _d(b))
+
+    def _H2(self, fn, Js, Ds):
+        """second-order Hessians; Ds are (N, S, S) [pixel, row, col]; None where the reference does not implement it"""
+        Js = [_vec(J) for J in Js]
+        S = Js[0].size // self.n
+        Ds = [np.ascontiguousarray(np.asarray(D, dtype=np.float64).reshape(self.n, S, S).transpose(0, 2, 1)).ravel() for D in Ds]
+        H = np.empty(S * S)
+        rc = fn(self.h, _d(H), *[_d(J) for J in Js], *[_d(D) for D in Ds], S)
+        return None if rc != 0 else H.reshape(S, S).T
+
+    def cmpt_init_hessian2(self, J0, D0):
+        return self._H2(lib().mtfo_am_cmpt_init_hessian2, [J0], [D0])
+
+    def cmpt_curr_hessian2(self, Jt, Dt):
+        return self._H2(lib().mtfo_am_cmpt_curr_hessian2, [Jt], [Dt])
+
+    def cmpt_self_hessian2(self, Jt, Dt):
+        return self._H2(lib().mtfo_am_cmpt_self_hessian2, [Jt], [Dt])
+
+    def cmpt_sum_of_hessians2(self, J0, Jt, D0, Dt):
+        return self._H2(lib().mtfo_am_cmpt_sum_of_hessians2, [J0, Jt], [D0, Dt])
+
     def cmpt_init_jacobian(self, J0):
         return self._g(lib().mtfo_am_cmpt_init_jacobian, J0)
 
@@ -310,7 +390,7 @@ def sm_params(sm_kind, **kw):
     """Class defaults of the reference's parameter structs (SM/src/ESMParams.cc:4-15,
     FCLKParams.cc:4-17, ICLKParams.cc:4-14)."""
     base = dict(max_iters=30, epsilon=1e-4, jac_type=1, hess_type={SM_ESM: 2, SM_FCLK: 1, SM_ICLK: 0}[sm_kind],
-                chained_warp=1, leven_marq=1, lm_delta_init=0.01, lm_delta_update=10.0)
+                chained_warp=1, leven_marq=1, lm_delta_init=0.01, lm_delta_update=10.0, sec_ord_hess=0)
     base.update(kw)
     return SMParams(**base)
 
@@ -333,6 +413,9 @@ class Tracker:
 
     def update(self):
         return lib().mtfo_tracker_update(self.h)
+
+    def status(self):
+        return lib().mtfo_tracker_status(self.h)
 
     def set_region(self, corners):
         c = pts_to_flat(corners)

@@ -26,6 +26,15 @@ def frame():
 
 
 @pytest.fixture(scope="session")
+def frame2(frame):
+    """the next frame: `frame` seen through a small known homography about the image centre"""
+    import numpy as np
+    from mtf_amd import synth
+    p_true = synth.random_small_homography(np.random.default_rng(2026)) * 0.5
+    return synth.warp_frame(frame, p_true, (256.0, 256.0))
+
+
+@pytest.fixture(scope="session")
 def gpu_ctx():
     import mtf_amd
     if not os.path.exists(mtf_amd._lib.LIB_PATH):

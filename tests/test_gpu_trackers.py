@@ -169,3 +169,24 @@ def test_grid_patch_trackers_one_launch(oracle, gpu_ctx, frame, am, ssm):
     q = (W @ np.vstack([c0.T, np.ones(36)]))
     gt_c = (q[:2] / q[2]).T + np.array(centre)
     assert np.abs(centroids - gt_c).max() < 0.25
+
+
+def test_nn_dataset_generation(gpu_ctx, frame):
+    """nt::NN::generateDataset mirror: the zero perturbation reproduces the template, every row is the feature
+    of its own inverse-perturbed warp, and the exhaustive search finds a stored sample at distance 0."""
+    from mtf_amd.sm import NNDataset
+    gpu_ctx.set_image(frame)
+    ds = NNDataset(gpu_ctx, am=L.AM_SSD, resx=40, resy=40, n_samples=300, seed=5)
+    corners = synth.square_corners(250, 260, 90)
+    perts = ds.rng.normal(0, 1, size=(300, 8)) * ds.sigma
+    perts[0] = 0
+    feats = ds.initialize(corners, perts)
+    assert feats.shape == (300, 1600)
+    np.testing.assert_allclose(feats[0], ds.batch.read(L.BUF_I0)[0], rtol=0, atol=1e-9)
+    k, d = ds.nearest(feats[137])
+    assert k == 137 and d == 0.0
+    # NCC features are unit-norm and zero-mean
+    dn = NNDataset(gpu_ctx, am=L.AM_NCC, resx=40, resy=40, n_samples=64, seed=6)
+    fn = dn.initialize(corners)
+    np.testing.assert_allclose(np.linalg.norm(fn, axis=1), 1.0, rtol=1e-12)
+    np.testing.assert_allclose(fn.sum(axis=1), 0.0, atol=1e-10)
