@@ -111,7 +111,7 @@ const char *mtfhip_last_error(void);
 int mtfhip_device_count(void);
 /* `hip_stream` is a hipStream_t (or NULL for a stream owned by the context) */
 int mtfhip_ctx_create(int device, void *hip_stream, mtfhip_ctx **out);
-void mtfhip_ctx_destroy(mtfhip_ctx *ctx);
+void mtfhip_ctx_destroy(mtfhip_ctx *ctx); /* destroy every batch created on the context first (a batch keeps a pointer to it) */
 int mtfhip_ctx_synchronize(mtfhip_ctx *ctx);
 void *mtfhip_ctx_stream(mtfhip_ctx *ctx);
 

@@ -7,6 +7,7 @@ this side (pts (B, 2, N), grad (B, N, 2), J (B, N, S), H (B, S, S), corners (B, 
 converted to/from the Eigen column-major layouts of the C ABI here.
 """
 import sys
+import weakref
 import ctypes as C
 
 import numpy as np
@@ -29,7 +30,8 @@ def _f64(a):
 def sm_desc(sm, **kw):
     """Class defaults of the reference (SM/src/ESMParams.cc:4-15, FCLKParams.cc:4-17, ICLKParams.cc:4-14)."""
     base = dict(sm=sm, jac_type=1, hess_type={SM_ESM: 2, SM_FCLK: 1, SM_ICLK: 0}[sm], chained_warp=1,
-                materialize=1, max_iters=30, epsilon=1e-4, leven_marq=0, lm_delta_init=0.01, lm_delta_update=10.0)
+                materialize=1, max_iters=30, epsilon=1e-4, leven_marq=0, lm_delta_init=0.01, lm_delta_update=10.0,
+                sec_ord_hess=0)
     base.update(kw)
     return SMDesc(**base)
 
@@ -42,9 +44,12 @@ class Context:
         L.check(L.lib().mtfhip_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)))
         self.device = device
         self._img_keep = None
+        self._batches = weakref.WeakSet()   # a batch holds a raw pointer to its context: close them first
 
     def close(self):
         if self._h:
+            for b in list(self._batches):
+                b.close()
             L.lib().mtfhip_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -101,6 +106,7 @@ class Batch:
         self.desc = PatchDesc(am, ssm, resx, resy, grad_eps, likelihood_alpha, mi_n_bins, mi_pre_seed, mi_pou, hess_eps)
         self._h = C.c_void_p()
         L.check(L.lib().mtfhip_batch_create(ctx._h, C.byref(self.desc), int(n_targets), C.byref(self._h)))
+        ctx._batches.add(self)
         self.B = n_targets
         self.N = resx * resy
         self.S = 8 if ssm == SSM_HOMOGRAPHY else 6

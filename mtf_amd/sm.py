@@ -142,26 +142,58 @@ class NTSearchMethod:
             (b.initialize_pix_grad if init else b.update_pix_grad)(warped=True)
             b.cmpt_pix_jacobian(L.JAC_INIT, grad, dst)
 
+    # second order (sec_ord_hess): ESM::initializePixHessian / updatePixHessian NT/ESM.cc:406-432, inlined by
+    # FCLK (NT/FCLK.cc:121-143,243-257) and ICLK (NT/ICLK.cc:96-113,223-237)
+    def _pix_hess(self, init):
+        b = self.batch
+        fn = b.initialize_pix_hess if init else b.update_pix_hess
+        if self.sm.chained_warp:
+            fn()
+        else:
+            b.update_hess_pts()
+            fn(warped=True)
+
+    def _pix_hessian(self, init):
+        b = self.batch
+        hess, grad, dst = ((L.BUF_D2I0_DX2, L.BUF_DI0_DX, L.BUF_D2I0_DP2) if init else
+                           (L.BUF_D2IT_DX2, L.BUF_DIT_DX, L.BUF_D2IT_DP2))
+        b.cmpt_pix_hessian(L.JAC_WARPED if self.sm.chained_warp else L.JAC_INIT, hess, grad, dst)
+
+    def _self_hessian(self, j, d2):
+        b = self.batch
+        return b.cmpt_self_hessian2(j, d2) if self.sm.sec_ord_hess else b.cmpt_self_hessian(j)
+
     def initialize(self, corners):
         b, sm = self.batch, self.sm
+        so = bool(sm.sec_ord_hess)
         b.set_corners(np.asarray(corners, dtype=np.float64).reshape(self.B, 2, 4))
         b.initialize_pix_vals()
         if sm.sm == L.SM_ESM:
             self._pix_jacobian(True)
+            if so:
+                self._pix_hess(True); self._pix_hessian(True)
             b.initialize_similarity(); b.initialize_grad(); b.initialize_hess()
             if sm.hess_type in (0, 2):
-                self.H0 = b.cmpt_self_hessian(L.BUF_J0)
+                self.H0 = self._self_hessian(L.BUF_J0, L.BUF_D2I0_DP2)
         elif sm.sm == L.SM_FCLK:
             b.initialize_similarity(); b.initialize_grad(); b.initialize_hess()
             self._pix_jacobian(True)
+            if so:
+                self._pix_hess(True)
             if sm.hess_type == 0:
-                self.H0 = b.cmpt_self_hessian(L.BUF_J0)
+                if so:
+                    self._pix_hessian(True)
+                self.H0 = self._self_hessian(L.BUF_J0, L.BUF_D2I0_DP2)
         else:
             self._pix_jacobian(True)
             b.initialize_similarity(); b.initialize_grad(); b.initialize_hess()
             b.cmpt_init_jacobian(L.BUF_J0)
+            if so:
+                self._pix_hess(True)
+                if sm.hess_type != 1:
+                    self._pix_hessian(True)
             if sm.hess_type == 0:
-                self.H0 = b.cmpt_self_hessian(L.BUF_J0)
+                self.H0 = self._self_hessian(L.BUF_J0, L.BUF_D2I0_DP2)
 
     def get_region(self):
         return self.batch.get_corners()
@@ -173,21 +205,28 @@ class NTSearchMethod:
         self._pix_jacobian(False)
         if sm.jac_type == 0 or sm.hess_type == 3:
             b.mean_jacobian()
+        so = bool(sm.sec_ord_hess)
+        if so and sm.hess_type != 0:
+            self._pix_hess(False); self._pix_hessian(False)
         b.update_curr_grad(); b.update_init_grad()
         g = b.cmpt_curr_jacobian(L.BUF_JM) if sm.jac_type == 0 else 0.5 * b.cmpt_difference_of_jacobians()
         ht = sm.hess_type
         if ht == 0:
             H = self.H0
         elif ht == 3:
-            H = b.cmpt_curr_hessian(L.BUF_JM)
+            if so:
+                b.mean_pix_hessian()
+                H = b.cmpt_curr_hessian2(L.BUF_JM, L.BUF_D2IM_DP2)
+            else:
+                H = b.cmpt_curr_hessian(L.BUF_JM)
         elif ht == 4:
-            H = 0.5 * b.cmpt_sum_of_hessians()
+            H = 0.5 * (b.cmpt_sum_of_hessians2() if so else b.cmpt_sum_of_hessians())
         elif ht == 2:
-            H = 0.5 * (b.cmpt_self_hessian(L.BUF_JT) + self.H0)
+            H = 0.5 * (self._self_hessian(L.BUF_JT, L.BUF_D2IT_DP2) + self.H0)
         elif ht == 1:
-            H = b.cmpt_self_hessian(L.BUF_JT)
+            H = self._self_hessian(L.BUF_JT, L.BUF_D2IT_DP2)
         else:
-            H = b.cmpt_curr_hessian(L.BUF_JT)
+            H = b.cmpt_curr_hessian2() if so else b.cmpt_curr_hessian(L.BUF_JT)
         return g, H
 
     def _fclk_iter(self):
@@ -196,9 +235,16 @@ class NTSearchMethod:
         b.update_similarity(False)
         b.update_curr_grad()
         self._pix_jacobian(False)
+        so = bool(sm.sec_ord_hess)
+        if so and sm.hess_type != 0:
+            self._pix_hess(False); self._pix_hessian(False)
         g = b.cmpt_curr_jacobian(L.BUF_JT)
-        H = self.H0 if sm.hess_type == 0 else (b.cmpt_self_hessian(L.BUF_JT) if sm.hess_type == 1
-                                               else b.cmpt_curr_hessian(L.BUF_JT))
+        if sm.hess_type == 0:
+            H = self.H0
+        elif sm.hess_type == 1:
+            H = self._self_hessian(L.BUF_JT, L.BUF_D2IT_DP2)
+        else:
+            H = b.cmpt_curr_hessian2() if so else b.cmpt_curr_hessian(L.BUF_JT)
         return g, H
 
     def _iclk_iter(self):
@@ -211,9 +257,11 @@ class NTSearchMethod:
             H = self.H0
         elif sm.hess_type == 1:
             self._pix_jacobian(False)
-            H = b.cmpt_self_hessian(L.BUF_JT)
+            if sm.sec_ord_hess:
+                self._pix_hess(False); self._pix_hessian(False)
+            H = self._self_hessian(L.BUF_JT, L.BUF_D2IT_DP2)
         else:
-            H = b.cmpt_init_hessian(L.BUF_J0)
+            H = b.cmpt_init_hessian2() if sm.sec_ord_hess else b.cmpt_init_hessian(L.BUF_J0)
         return g, H
 
     def update(self):

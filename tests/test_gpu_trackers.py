@@ -104,7 +104,33 @@ NT_CASES = [
     (L.SM_FCLK, L.AM_MI, L.SSM_AFFINE, 30, dict()),
     (L.SM_ICLK, L.AM_MI, L.SSM_HOMOGRAPHY, 40, dict()),
     (L.SM_ICLK, L.AM_MI, L.SSM_AFFINE, 30, dict(hess_type=2)),
+    # second-order Hessians (sec_ord_hess = 1), every branch of NT/ESM.cc:315-377, NT/FCLK.cc:262-283, NT/ICLK.cc:204-252
+    (L.SM_ESM, L.AM_SSD, L.SSM_HOMOGRAPHY, 40, dict(sec_ord_hess=1, hess_type=5)),
+    (L.SM_ESM, L.AM_SSD, L.SSM_HOMOGRAPHY, 40, dict(sec_ord_hess=1, hess_type=4, chained_warp=0)),
+    (L.SM_ESM, L.AM_SSD, L.SSM_AFFINE, 30, dict(sec_ord_hess=1, hess_type=3, jac_type=0)),
+    (L.SM_ESM, L.AM_SSD, L.SSM_AFFINE, 30, dict(sec_ord_hess=1)),
+    (L.SM_FCLK, L.AM_SSD, L.SSM_HOMOGRAPHY, 40, dict(sec_ord_hess=1, hess_type=2)),
+    (L.SM_ICLK, L.AM_SSD, L.SSM_AFFINE, 30, dict(sec_ord_hess=1, hess_type=2)),
+    (L.SM_ICLK, L.AM_NCC, L.SSM_AFFINE, 25, dict(sec_ord_hess=1, hess_type=2)),
+    (L.SM_FCLK, L.AM_NCC, L.SSM_HOMOGRAPHY, 40, dict(sec_ord_hess=1, hess_type=2, chained_warp=0)),
+    (L.SM_ESM, L.AM_NCC, L.SSM_AFFINE, 30, dict(sec_ord_hess=1, hess_type=4)),
+    (L.SM_ESM, L.AM_MI, L.SSM_HOMOGRAPHY, 40, dict(sec_ord_hess=1)),
+    (L.SM_ICLK, L.AM_MI, L.SSM_AFFINE, 30, dict(sec_ord_hess=1, hess_type=1)),
+    (L.SM_FCLK, L.AM_MI, L.SSM_AFFINE, 30, dict(sec_ord_hess=1, hess_type=0)),
 ]
+
+
+def oracle_first_order_H(oracle, case, frame, frame2, corners):
+    """H of the first iteration with sec_ord_hess = 0 (to show that the second-order term is not vacuous)"""
+    sm_kind, am, ssm, res, extra = case
+    params = dict(leven_marq=0, max_iters=1, epsilon=-1.0)
+    params.update(extra); params["sec_ord_hess"] = 0
+    o_ssm = oracle.SSM(ssm, res, res); o_am = oracle.AM(am, res, res); o_am.set_curr_img(frame)
+    trk = oracle.Tracker(sm_kind, o_am, o_ssm, **params)
+    trk.initialize(corners)
+    o_am.set_curr_img(frame2)
+    trk.update()
+    return trk.trace()[0]["H"]
 
 
 @pytest.mark.parametrize("case", NT_CASES, ids=lambda c: "sm%d-am%d-ssm%d-%s" % (c[0], c[1], c[2], "_".join("%s%s" % kv for kv in c[4].items())))
@@ -128,15 +154,29 @@ def test_interface_level_sm_matches_oracle_trace(oracle, gpu_ctx, frame, case):
     o_am.set_curr_img(frame2); gpu_ctx.set_image(frame2)
     otrk.update()
     nt.update()
+    assert otrk.status() == 0
     otrace = otrk.trace()
     assert len(otrace) == len(nt.trace) == 6
-    for it in range(2):   # the first iterations run on (numerically) identical inputs
+    # The first iterations run on (numerically) identical inputs.  A second-order Hessian is not definite and is far
+    # worse conditioned (x^4 terms for the homography), so the first step already amplifies the FD-gradient jitter
+    # between the two grids: compare iteration 0 tightly, the trajectory loosely.
+    so = bool(params.get("sec_ord_hess"))
+    for it in range(1 if so else 2):
         rec, got = otrace[it], nt.trace[it]
         assert abs(got["f"][0] - rec["f"]) <= 1e-7 * abs(rec["f"]), it
         assert np.linalg.norm(got["H"][0] - rec["H"]) <= 1e-5 * np.linalg.norm(rec["H"]), it
         gs = max(np.linalg.norm(rec["g"]), 1e-3 * np.sqrt(abs(np.trace(rec["H"]))))
         assert np.linalg.norm(got["g"][0] - rec["g"]) <= 1e-4 * gs, it
-    np.testing.assert_allclose(nt.get_region()[0], otrk.get_region(), atol=2e-4)
+    if so:
+        # SSD's second-order self Hessian IS its first-order one (SSDBase.h:95-98); everywhere else the term is live
+        ht = params.get("hess_type", {L.SM_ESM: 2, L.SM_FCLK: 1, L.SM_ICLK: 0}[sm_kind])
+        self_type = ht in ((0, 1, 2) if sm_kind == L.SM_ESM else (0, 1))
+        same = np.abs(otrace[0]["H"] - oracle_first_order_H(oracle, case, frame, frame2, corners)).max() == 0
+        assert same == (am == L.AM_SSD and self_type)
+        assert abs(nt.trace[1]["f"][0] - otrace[1]["f"]) <= 1e-3 * abs(otrace[1]["f"])
+        np.testing.assert_allclose(nt.get_region()[0], otrk.get_region(), atol=5e-2)
+    else:
+        np.testing.assert_allclose(nt.get_region()[0], otrk.get_region(), atol=2e-4)
 
 
 @pytest.mark.parametrize("am,ssm", [(L.AM_NCC, L.SSM_AFFINE), (L.AM_SSD, L.SSM_AFFINE), (L.AM_NCC, L.SSM_HOMOGRAPHY)])
@@ -190,3 +230,11 @@ def test_nn_dataset_generation(gpu_ctx, frame):
     fn = dn.initialize(corners)
     np.testing.assert_allclose(np.linalg.norm(fn, axis=1), 1.0, rtol=1e-12)
     np.testing.assert_allclose(fn.sum(axis=1), 0.0, atol=1e-10)
+
+
+def test_second_order_self_hessian_ncc_not_implemented(gpu_ctx, frame):
+    """NCC does not override the second-order cmptSelfHessian (AppearanceModel.h:188-191 throws); neither do we."""
+    gpu_ctx.set_image(frame)
+    nt = NTSearchMethod(gpu_ctx, L.SM_ESM, L.AM_NCC, L.SSM_AFFINE, 20, 20, 1, sec_ord_hess=1, hess_type=2)
+    with pytest.raises(mtf_amd.FunctionNotImplemented):
+        nt.initialize(synth.square_corners(250, 250, 60)[None])
