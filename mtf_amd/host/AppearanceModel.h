@@ -25,10 +25,13 @@ public:
 	virtual unsigned int getNChannels() const { return 1; }
 	virtual unsigned int getPatchSize() const { return getNPix(); }
 	virtual double getGradOffset() const = 0;
+	virtual double getHessOffset() const = 0;
 	virtual const PixValT &getInitPixVals() = 0;
 	virtual const PixValT &getCurrPixVals() = 0;
 	virtual const PixGradT &getInitPixGrad() = 0;
 	virtual const PixGradT &getCurrPixGrad() = 0;
+	virtual const PixHessT &getInitPixHess() = 0;
+	virtual const PixHessT &getCurrPixHess() = 0;
 
 	/* ImageBase modifiers / updaters (ImageBase.h:92-123) */
 	virtual void setCurrImg(const ImageView &img) = 0;
@@ -38,6 +41,11 @@ public:
 	virtual void updatePixVals(const PtsT &curr_pts) = 0;
 	virtual void updatePixGrad(const GradPtsT &warped_offset_pts, bool warped) = 0;
 	virtual void updatePixGrad(const PtsT &curr_pts) = 0;
+	/* ImageBase.h:112-114,122-123 */
+	virtual void initializePixHess(const PtsT &init_pts, const HessPtsT &warped_offset_pts) = 0;
+	virtual void initializePixHess(const PtsT &init_pts) = 0;
+	virtual void updatePixHess(const PtsT &curr_pts, const HessPtsT &warped_offset_pts) = 0;
+	virtual void updatePixHess(const PtsT &curr_pts) = 0;
 
 	/* AppearanceModel (AppearanceModel.h:77-219) */
 	virtual int getStateSize() const { return 0; }
@@ -58,10 +66,18 @@ public:
 	virtual void cmptCurrHessian(MatrixXd &, const MatrixXd &) { am_func_not_implemeted(cmptCurrHessian(first order)); }
 	virtual void cmptSelfHessian(MatrixXd &, const MatrixXd &) { am_func_not_implemeted(cmptSelfHessian(first order)); }
 	virtual void cmptSumOfHessians(MatrixXd &, const MatrixXd &, const MatrixXd &) { am_func_not_implemeted(cmptSumOfHessians); }
-	/* second order variants (sec_ord_hess, off in every config): not implemented, as in the base class */
+	/* second order variants (AppearanceModel.h:180-192,209-219): d2I_dpssm2 is the SM's S^2 x N pixel Hessian */
 	virtual void cmptInitHessian(MatrixXd &, const MatrixXd &, const MatrixXd &) { am_func_not_implemeted(cmptInitHessian(second order)); }
 	virtual void cmptCurrHessian(MatrixXd &, const MatrixXd &, const MatrixXd &) { am_func_not_implemeted(cmptCurrHessian(second order)); }
 	virtual void cmptSelfHessian(MatrixXd &, const MatrixXd &, const MatrixXd &) { am_func_not_implemeted(cmptSelfHessian(second order)); }
+	virtual void cmptSumOfHessians(MatrixXd &, const MatrixXd &, const MatrixXd &, const MatrixXd &, const MatrixXd &) { am_func_not_implemeted(cmptSumOfHessians(second order)); }
+
+	/* EXTENSION (not a reference virtual): the ESM variants Original average two SM-owned matrices with plain Eigen
+	 * arithmetic (mean_pix_jacobian NT/ESM.cc:239-242, mean_pix_hessian NT/ESM.cc:325).  A device-resident AM overrides
+	 * this so that those N x S / S^2 x N matrices never have to visit the host; the default is that arithmetic. */
+	virtual void cmptMeanOf(MatrixXd &mean, const MatrixXd &a, const MatrixXd &b) {
+		for (size_t i = 0; i < mean.size(); ++i) mean.data()[i] = (a.data()[i] + b.data()[i]) / 2.0;
+	}
 
 	virtual void setFirstIter() { first_iter = true; }
 	virtual void clearFirstIter() { first_iter = false; }

@@ -23,7 +23,7 @@ HipPair::HipPair(int _am, int _ssm, int _resx, int _resy, double _grad_eps, doub
 	grad_eps(_grad_eps) {
 	if (resx <= 0 || resy <= 0) throw utils::InvalidArgument("ImageBase::Invalid sampling resolution provided"); /* ImageBase.cc:33-35 */
 	check(mtfhip_ctx_create(device, stream, &ctx));
-	mtfhip_patch_desc d{am, ssm, resx, resy, grad_eps, likelihood_alpha, mi_n_bins, mi_pre_seed, mi_pou};
+	mtfhip_patch_desc d{am, ssm, resx, resy, grad_eps, likelihood_alpha, mi_n_bins, mi_pre_seed, mi_pou, hess_eps};
 	int rc = mtfhip_batch_create(ctx, &d, 1, &b);
 	if (rc != MTFHIP_OK) { const std::string msg = mtfhip_last_error(); mtfhip_ctx_destroy(ctx); ctx = nullptr; throw utils::Exception(msg); }
 }
@@ -44,14 +44,30 @@ int HipPair::jacobianBuffer(const MatrixXd &J, bool may_register) {
 	return id;
 }
 
+/* same for the SM-owned S^2 x N pixel Hessians (SM/include/mtf/SM/NT/ESM.h: init / curr / mean_pix_hessian) */
+int HipPair::hessianBuffer(const MatrixXd &D, bool may_register) {
+	auto it = hess_keys.find(D.data());
+	if (it != hess_keys.end()) return it->second;
+	if (!may_register) throw utils::LogicError("pixel Hessian passed to the AM was not produced by the paired SSM");
+	static const int order[3] = {MTFHIP_BUF_D2I0_DP2, MTFHIP_BUF_D2IT_DP2, MTFHIP_BUF_D2IM_DP2};
+	if (next_hess >= 3) throw utils::LogicError("more than three distinct pixel Hessians in flight");
+	int id = order[next_hess++];
+	hess_keys[D.data()] = id;
+	return id;
+}
+
 /* ------------------------------------------------------------------ AM */
 HipAM::HipAM(std::shared_ptr<HipPair> pair) : p(pair) {
 	name = p->am == MTFHIP_AM_SSD ? "ssd" : (p->am == MTFHIP_AM_NCC ? "ncc" : "mi");
 	I0.resize(p->N); It.resize(p->N);
 	dI0_dx.resize(p->N, 2); dIt_dx.resize(p->N, 2);
+	d2I0_dx2.resize(4, p->N); d2It_dx2.resize(4, p->N);
 	p->init_grad_key = dI0_dx.data();
 	p->curr_grad_key = dIt_dx.data();
+	p->init_hess_key = d2I0_dx2.data();
+	p->curr_hess_key = d2It_dx2.data();
 }
+const double *HipAM::hessPtsArg(const HessPtsT &pts) const { return pts.data() == p->hess_pts_key ? nullptr : pts.data(); }
 const double *HipAM::ptsArg(const PtsT &pts) const { return pts.data() == p->pts_key ? nullptr : pts.data(); }
 const double *HipAM::gradPtsArg(const GradPtsT &pts) const { return pts.data() == p->grad_pts_key ? nullptr : pts.data(); }
 
@@ -78,6 +94,15 @@ void HipAM::initializePixGrad(const PtsT &pts) { HipPair::check(mtfhip_am_initia
 void HipAM::updatePixGrad(const PtsT &pts) { HipPair::check(mtfhip_am_update_pix_grad(p->b, ptsArg(pts))); }
 void HipAM::initializePixGrad(const GradPtsT &gp, bool) { HipPair::check(mtfhip_am_initialize_pix_grad_warped(p->b, gradPtsArg(gp))); }
 void HipAM::updatePixGrad(const GradPtsT &gp, bool) { HipPair::check(mtfhip_am_update_pix_grad_warped(p->b, gradPtsArg(gp))); }
+
+void HipAM::initializePixHess(const PtsT &pts) { HipPair::check(mtfhip_am_initialize_pix_hess(p->b, ptsArg(pts))); }
+void HipAM::updatePixHess(const PtsT &pts) { HipPair::check(mtfhip_am_update_pix_hess(p->b, ptsArg(pts))); }
+void HipAM::initializePixHess(const PtsT &pts, const HessPtsT &hp) {
+	HipPair::check(mtfhip_am_initialize_pix_hess_warped(p->b, ptsArg(pts), hessPtsArg(hp)));
+}
+void HipAM::updatePixHess(const PtsT &pts, const HessPtsT &hp) {
+	HipPair::check(mtfhip_am_update_pix_hess_warped(p->b, ptsArg(pts), hessPtsArg(hp)));
+}
 
 double HipAM::getLikelihood() const { double l = 0; HipPair::check(mtfhip_am_get_likelihood(p->b, &l)); return l; }
 void HipAM::initializeSimilarity() {
@@ -115,11 +140,45 @@ void HipAM::cmptSumOfHessians(MatrixXd &H, const MatrixXd &J0, const MatrixXd &J
 	HipPair::check(mtfhip_am_cmpt_sum_of_hessians(p->b, p->jacobianBuffer(J0, false), p->jacobianBuffer(Jt, false), H.data()));
 }
 
+void HipAM::cmptInitHessian(MatrixXd &H, const MatrixXd &J0, const MatrixXd &D0) {
+	HipPair::check(mtfhip_am_cmpt_init_hessian2(p->b, p->jacobianBuffer(J0, false), p->hessianBuffer(D0, false), H.data()));
+}
+void HipAM::cmptCurrHessian(MatrixXd &H, const MatrixXd &Jt, const MatrixXd &Dt) {
+	HipPair::check(mtfhip_am_cmpt_curr_hessian2(p->b, p->jacobianBuffer(Jt, false), p->hessianBuffer(Dt, false), H.data()));
+}
+void HipAM::cmptSelfHessian(MatrixXd &H, const MatrixXd &Jt, const MatrixXd &Dt) {
+	HipPair::check(mtfhip_am_cmpt_self_hessian2(p->b, p->jacobianBuffer(Jt, false), p->hessianBuffer(Dt, false), H.data()));
+}
+void HipAM::cmptSumOfHessians(MatrixXd &H, const MatrixXd &J0, const MatrixXd &Jt, const MatrixXd &D0, const MatrixXd &Dt) {
+	HipPair::check(mtfhip_am_cmpt_sum_of_hessians2(p->b, p->jacobianBuffer(J0, false), p->jacobianBuffer(Jt, false),
+		p->hessianBuffer(D0, false), p->hessianBuffer(Dt, false), H.data()));
+}
+/* the SM's mean_pix_jacobian / mean_pix_hessian (NT/ESM.cc:239-242,325) of two device-resident matrices */
+void HipAM::cmptMeanOf(MatrixXd &mean, const MatrixXd &a, const MatrixXd &b) {
+	if (mean.rows() == p->N && mean.cols() == p->S) {
+		if (p->jacobianBuffer(a, false) != MTFHIP_BUF_J0 || p->jacobianBuffer(b, false) != MTFHIP_BUF_JT)
+			throw utils::LogicError("cmptMeanOf: expected (init_pix_jacobian, curr_pix_jacobian)");
+		auto it = p->jac_keys.find(mean.data());
+		if (it == p->jac_keys.end()) p->jac_keys[mean.data()] = MTFHIP_BUF_JM;
+		else if (it->second != MTFHIP_BUF_JM) throw utils::LogicError("cmptMeanOf: the mean Jacobian aliases another device matrix");
+		HipPair::check(mtfhip_sm_mean_jacobian(p->b));
+	} else if (mean.rows() == p->S * p->S && mean.cols() == p->N) {
+		if (p->hessianBuffer(a, false) != MTFHIP_BUF_D2I0_DP2 || p->hessianBuffer(b, false) != MTFHIP_BUF_D2IT_DP2)
+			throw utils::LogicError("cmptMeanOf: expected (init_pix_hessian, curr_pix_hessian)");
+		auto it = p->hess_keys.find(mean.data());
+		if (it == p->hess_keys.end()) p->hess_keys[mean.data()] = MTFHIP_BUF_D2IM_DP2;
+		else if (it->second != MTFHIP_BUF_D2IM_DP2) throw utils::LogicError("cmptMeanOf: the mean pixel Hessian aliases another device matrix");
+		HipPair::check(mtfhip_sm_mean_pix_hessian(p->b));
+	} else throw utils::InvalidArgument("cmptMeanOf: matrix is neither N x S nor S^2 x N");
+}
+
 /* ------------------------------------------------------------------ SSM */
 HipSSM::HipSSM(std::shared_ptr<HipPair> pair) : p(pair) {
 	name = p->ssm == MTFHIP_SSM_HOMOGRAPHY ? "homography" : "affine";
 	curr_pts.resize(2, p->N);
 	grad_pts.resize(8, p->N);
+	hess_pts.resize(16, p->N);
+	p->hess_pts_key = hess_pts.data();
 	curr_state.resize(p->S);
 	std::memset(curr_corners.v, 0, sizeof(curr_corners.v));
 	p->pts_key = curr_pts.data();
@@ -140,20 +199,29 @@ void HipSSM::compositionalUpdate(const VectorXd &dp) {
 	HipPair::check(mtfhip_ssm_compositional_update(p->b, dp.data())); syncSmall();
 }
 void HipSSM::updateGradPts(double eps) { HipPair::check(mtfhip_ssm_update_grad_pts(p->b, eps)); }
+void HipSSM::updateHessPts(double eps) { HipPair::check(mtfhip_ssm_update_hess_pts(p->b, eps)); }
 void HipSSM::invertState(VectorXd &inv, const VectorXd &s) { HipPair::check(mtfhip_ssm_invert_state(p->b, s.data(), inv.data())); }
 void HipSSM::applyWarpToCorners(CornersT &out, const CornersT &in, const VectorXd &s) {
 	HipPair::check(mtfhip_ssm_apply_warp_to_corners(p->b, in.data(), s.data(), out.data()));
 }
+int HipSSM::gradBuffer(const PixGradT &g) {
+	if (g.data() == p->init_grad_key) return MTFHIP_BUF_DI0_DX;
+	if (g.data() == p->curr_grad_key) return MTFHIP_BUF_DIT_DX;
+	/* a foreign gradient: upload it into the current-gradient buffer */
+	HipPair::check(mtfhip_batch_write(p->b, MTFHIP_BUF_DIT_DX, g.data()));
+	return MTFHIP_BUF_DIT_DX;
+}
 void HipSSM::jac(int variant, MatrixXd &J, const PixGradT &g) {
 	if (J.rows() != p->N || J.cols() != p->S) throw utils::InvalidArgument("pixel Jacobian has invalid size");   /* validate_ssm_jacobian */
-	int grad_buf;
-	if (g.data() == p->init_grad_key) grad_buf = MTFHIP_BUF_DI0_DX;
-	else if (g.data() == p->curr_grad_key) grad_buf = MTFHIP_BUF_DIT_DX;
-	else {   /* a foreign gradient: upload it into the current-gradient buffer */
-		HipPair::check(mtfhip_batch_write(p->b, MTFHIP_BUF_DIT_DX, g.data()));
-		grad_buf = MTFHIP_BUF_DIT_DX;
-	}
-	HipPair::check(mtfhip_ssm_cmpt_pix_jacobian(p->b, variant, grad_buf, p->jacobianBuffer(J, true)));
+	HipPair::check(mtfhip_ssm_cmpt_pix_jacobian(p->b, variant, gradBuffer(g), p->jacobianBuffer(J, true)));
+}
+void HipSSM::pixHess(int variant, MatrixXd &D, const PixHessT &h, const PixGradT &g) {
+	if (D.rows() != p->S * p->S || D.cols() != p->N) throw utils::InvalidArgument("pixel Hessian has invalid size");   /* validate_ssm_hessian */
+	int hess_buf;
+	if (h.data() == p->init_hess_key) hess_buf = MTFHIP_BUF_D2I0_DX2;
+	else if (h.data() == p->curr_hess_key) hess_buf = MTFHIP_BUF_D2IT_DX2;
+	else { HipPair::check(mtfhip_batch_write(p->b, MTFHIP_BUF_D2IT_DX2, h.data())); hess_buf = MTFHIP_BUF_D2IT_DX2; }
+	HipPair::check(mtfhip_ssm_cmpt_pix_hessian(p->b, variant, hess_buf, gradBuffer(g), p->hessianBuffer(D, true)));
 }
 
 } // namespace hip

@@ -23,17 +23,20 @@ struct HipPair {
 	mtfhip_ctx *ctx = nullptr;
 	mtfhip_batch *b = nullptr;
 	int am, ssm, resx, resy, N, S;
-	double grad_eps;
+	double grad_eps, hess_eps = 1.0;
 	/* addresses of host mirrors whose authoritative copy is a device buffer */
 	const void *pts_key = nullptr, *grad_pts_key = nullptr, *init_grad_key = nullptr, *curr_grad_key = nullptr;
+	const void *hess_pts_key = nullptr, *init_hess_key = nullptr, *curr_hess_key = nullptr;
 	std::map<const void *, int> jac_keys;   /* SM-owned Jacobian matrices -> MTFHIP_BUF_J0 / _JT / _JM */
-	int next_jac = 0;
+	std::map<const void *, int> hess_keys;  /* SM-owned pixel Hessians -> MTFHIP_BUF_D2I0_DP2 / _D2IT_DP2 / _D2IM_DP2 */
+	int next_jac = 0, next_hess = 0;
 
 	HipPair(int am, int ssm, int resx, int resy, double grad_eps, double likelihood_alpha, int mi_n_bins,
 		double mi_pre_seed, int mi_pou, int device, void *stream);
 	~HipPair();
 	static void check(int rc);               /* rethrows C-ABI failures as mtf::utils::Exception */
 	int jacobianBuffer(const MatrixXd &J, bool may_register);
+	int hessianBuffer(const MatrixXd &D, bool may_register);
 };
 
 class HipAM : public AppearanceModel {
@@ -43,10 +46,13 @@ public:
 	unsigned int getResY() const override { return p->resy; }
 	unsigned int getNPix() const override { return p->N; }
 	double getGradOffset() const override { return p->grad_eps; }
+	double getHessOffset() const override { return p->hess_eps; }
 	const PixValT &getInitPixVals() override;
 	const PixValT &getCurrPixVals() override;
 	const PixGradT &getInitPixGrad() override { return dI0_dx; }   /* key only; bytes on the device */
 	const PixGradT &getCurrPixGrad() override { return dIt_dx; }
+	const PixHessT &getInitPixHess() override { return d2I0_dx2; }   /* keys only, like the gradients */
+	const PixHessT &getCurrPixHess() override { return d2It_dx2; }
 	void syncPixGrad();                                               /* explicit read-back of both gradients */
 
 	void setCurrImg(const ImageView &img) override;
@@ -56,6 +62,10 @@ public:
 	void updatePixVals(const PtsT &curr_pts) override;
 	void updatePixGrad(const GradPtsT &warped_offset_pts, bool warped) override;
 	void updatePixGrad(const PtsT &curr_pts) override;
+	void initializePixHess(const PtsT &init_pts, const HessPtsT &warped_offset_pts) override;
+	void initializePixHess(const PtsT &init_pts) override;
+	void updatePixHess(const PtsT &curr_pts, const HessPtsT &warped_offset_pts) override;
+	void updatePixHess(const PtsT &curr_pts) override;
 
 	double getSimilarity() const override { return f; }
 	double getLikelihood() const override;
@@ -72,6 +82,12 @@ public:
 	void cmptCurrHessian(MatrixXd &H, const MatrixXd &dIt_dpssm) override;
 	void cmptSelfHessian(MatrixXd &H, const MatrixXd &dIt_dpssm) override;
 	void cmptSumOfHessians(MatrixXd &H, const MatrixXd &dI0_dpssm, const MatrixXd &dIt_dpssm) override;
+	void cmptInitHessian(MatrixXd &H, const MatrixXd &dI0_dpssm, const MatrixXd &d2I0_dpssm2) override;
+	void cmptCurrHessian(MatrixXd &H, const MatrixXd &dIt_dpssm, const MatrixXd &d2It_dpssm2) override;
+	void cmptSelfHessian(MatrixXd &H, const MatrixXd &dIt_dpssm, const MatrixXd &d2It_dpssm2) override;
+	void cmptSumOfHessians(MatrixXd &H, const MatrixXd &dI0_dpssm, const MatrixXd &dIt_dpssm, const MatrixXd &d2I0_dpssm2,
+		const MatrixXd &d2It_dpssm2) override;
+	void cmptMeanOf(MatrixXd &mean, const MatrixXd &a, const MatrixXd &b) override;
 	void setFirstIter() override;
 	void clearInitStatus() override {}
 private:
@@ -80,6 +96,8 @@ private:
 	double f = 0;
 	PixValT I0, It;
 	PixGradT dI0_dx, dIt_dx;
+	PixHessT d2I0_dx2, d2It_dx2;
+	const double *hessPtsArg(const HessPtsT &pts) const;
 	const double *ptsArg(const PtsT &pts) const;
 	const double *gradPtsArg(const GradPtsT &pts) const;
 	static void colMajorToHost(MatrixXd &H, const double *src, int S);
@@ -94,6 +112,7 @@ public:
 	unsigned int getNPts() override { return p->N; }
 	const PtsT &getPts() override { return curr_pts; }            /* key only; syncPts() refreshes the bytes */
 	const GradPtsT &getGradPts() override { return grad_pts; }
+	const HessPtsT &getHessPts() override { return hess_pts; }
 	const CornersT &getCorners() override { return curr_corners; }
 	const VectorXd &getState() override { return curr_state; }
 	void syncPts();
@@ -102,20 +121,28 @@ public:
 	void setCorners(const CornersT &corners) override;
 	void compositionalUpdate(const VectorXd &state_update) override;
 	void updateGradPts(double grad_eps) override;
+	void updateHessPts(double hess_eps) override;
 	void invertState(VectorXd &inv_state, const VectorXd &state) override;
 	void cmptInitPixJacobian(MatrixXd &J, const PixGradT &g) override { jac(MTFHIP_JAC_INIT, J, g); }
 	void cmptPixJacobian(MatrixXd &J, const PixGradT &g) override { jac(MTFHIP_JAC_PIX, J, g); }
 	void cmptWarpedPixJacobian(MatrixXd &J, const PixGradT &g) override { jac(MTFHIP_JAC_WARPED, J, g); }
 	void cmptApproxPixJacobian(MatrixXd &J, const PixGradT &g) override { jac(MTFHIP_JAC_APPROX, J, g); }
+	void cmptInitPixHessian(MatrixXd &D, const PixHessT &h, const PixGradT &g) override { pixHess(MTFHIP_JAC_INIT, D, h, g); }
+	void cmptPixHessian(MatrixXd &D, const PixHessT &h, const PixGradT &g) override { pixHess(MTFHIP_JAC_PIX, D, h, g); }
+	void cmptWarpedPixHessian(MatrixXd &D, const PixHessT &h, const PixGradT &g) override { pixHess(MTFHIP_JAC_WARPED, D, h, g); }
+	void cmptApproxPixHessian(MatrixXd &D, const PixHessT &h, const PixGradT &g) override { pixHess(MTFHIP_JAC_APPROX, D, h, g); }
 	void applyWarpToCorners(CornersT &out, const CornersT &in, const VectorXd &state) override;
 private:
 	std::shared_ptr<HipPair> p;
 	PtsT curr_pts;
 	GradPtsT grad_pts;
+	HessPtsT hess_pts;
 	CornersT curr_corners;
 	VectorXd curr_state;
 	void syncSmall();
 	void jac(int variant, MatrixXd &J, const PixGradT &g);
+	void pixHess(int variant, MatrixXd &D, const PixHessT &h, const PixGradT &g);
+	int gradBuffer(const PixGradT &g);
 };
 
 } // namespace hip

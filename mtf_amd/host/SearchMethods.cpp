@@ -65,8 +65,6 @@ SearchMethod::SearchMethod(AM _am, SSM _ssm, const SMParams &_params) : am(_am),
 	init_self_hessian.resize(ssm_state_size, ssm_state_size);
 	state_update.resize(ssm_state_size);
 	inv_update.resize(ssm_state_size);
-	if (params.sec_ord_hess)
-		throw utils::FunctonNotImplemented("second order Hessians are not available (sec_ord_hess is 0 in every shipped config)");
 }
 
 /* ESM::initializePixJacobian NT/ESM.cc:379-388 (same shape in FCLK :113-133 and ICLK :78-95) */
@@ -91,6 +89,33 @@ void SearchMethod::updatePixJacobian(MatrixXd &J) {
 		ssm->cmptInitPixJacobian(J, am->getCurrPixGrad());
 	}
 }
+/* ESM::initializePixHessian NT/ESM.cc:406-416 ; FCLK NT/FCLK.cc:121-142 ; ICLK NT/ICLK.cc:96-113 */
+void SearchMethod::initPixHess() {
+	if (params.chained_warp) am->initializePixHess(ssm->getPts());
+	else {
+		ssm->initializeHessPts(am->getHessOffset());
+		am->initializePixHess(ssm->getPts(), ssm->getHessPts());
+	}
+}
+void SearchMethod::pixHessianFromInit(MatrixXd &D) {
+	if (params.chained_warp) ssm->cmptWarpedPixHessian(D, am->getInitPixHess(), am->getInitPixGrad());
+	else ssm->cmptInitPixHessian(D, am->getInitPixHess(), am->getInitPixGrad());
+}
+/* ESM::updatePixHessian NT/ESM.cc:418-432 ; FCLK NT/FCLK.cc:243-257 ; ICLK NT/ICLK.cc:223-237 */
+void SearchMethod::updatePixHessian(MatrixXd &D) {
+	if (params.chained_warp) {
+		am->updatePixHess(ssm->getPts());
+		ssm->cmptWarpedPixHessian(D, am->getCurrPixHess(), am->getCurrPixGrad());
+	} else {
+		ssm->updateHessPts(am->getHessOffset());
+		am->updatePixHess(ssm->getPts(), ssm->getHessPts());
+		ssm->cmptInitPixHessian(D, am->getCurrPixHess(), am->getCurrPixGrad());
+	}
+}
+void SearchMethod::selfHessian(MatrixXd &H, const MatrixXd &J, const MatrixXd &D) {
+	if (params.sec_ord_hess) am->cmptSelfHessian(H, J, D);
+	else am->cmptSelfHessian(H, J);
+}
 void SearchMethod::dampAndSolve(double delta) {
 	if (params.leven_marq)
 		for (int i = 0; i < ssm_state_size; ++i) hessian(i, i) += delta * hessian(i, i);
@@ -102,24 +127,34 @@ void SearchMethod::dampAndSolve(double delta) {
 ESM::ESM(AM a, SSM s, const SMParams &p) : SearchMethod(a, s, p) {
 	name = "esm_nt";
 	if (params.hess_type < 0) params.hess_type = SumOfSelf;
-	if (params.jac_type == 0 || params.hess_type == Original) mean_pix_jacobian.resize((int)am->getPatchSize(), ssm_state_size);
+	const int n = (int)am->getPatchSize(), s2 = ssm_state_size * ssm_state_size;
+	if (params.jac_type == 0 || params.hess_type == Original) mean_pix_jacobian.resize(n, ssm_state_size);
+	if (params.sec_ord_hess) {   /* NT/ESM.cc:99-107 */
+		init_pix_hessian.resize(s2, n);
+		if (params.hess_type != InitialSelf) {
+			curr_pix_hessian.resize(s2, n);
+			if (params.hess_type == Original) mean_pix_hessian.resize(s2, n);
+		}
+	}
 }
 void ESM::initialize(const CornersT &corners) {
 	am->clearInitStatus(); ssm->clearInitStatus();
 	ssm->initialize(corners, am->getNChannels());
 	am->initializePixVals(ssm->getPts());
 	initPixJacobian(init_pix_jacobian);
+	if (params.sec_ord_hess) { initPixHess(); pixHessianFromInit(init_pix_hessian); }
 	am->initializeSimilarity(); am->initializeGrad(); am->initializeHess();
 	if (params.hess_type == InitialSelf || params.hess_type == SumOfSelf) {
-		am->cmptSelfHessian(hessian, init_pix_jacobian);
+		selfHessian(hessian, init_pix_jacobian, init_pix_hessian);
 		init_self_hessian = hessian;
 	}
 }
 void ESM::setRegion(const CornersT &corners) {
 	ssm->setCorners(corners);
 	ssm->cmptInitPixJacobian(init_pix_jacobian, am->getInitPixGrad());
+	if (params.sec_ord_hess) ssm->cmptInitPixHessian(init_pix_hessian, am->getInitPixHess(), am->getInitPixGrad());
 	if (params.hess_type == InitialSelf || params.hess_type == SumOfSelf) {
-		am->cmptSelfHessian(hessian, init_pix_jacobian);
+		selfHessian(hessian, init_pix_jacobian, init_pix_hessian);
 		init_self_hessian = hessian;
 	}
 }
@@ -148,25 +183,38 @@ void ESM::update() {
 		}
 		state_reset = false;
 		updatePixJacobian(curr_pix_jacobian);
-		if (params.jac_type == 0 || params.hess_type == Original)
-			throw utils::FunctonNotImplemented("ESM jac_type/hess_type Original needs the SM-side mean Jacobian on the host; "
-				"use mtfhip_sm_mean_jacobian through the C ABI (see INTEGRATION.md, sync policy)");
+		/* mean_pix_jacobian = (init_pix_jacobian + curr_pix_jacobian) / 2.0, NT/ESM.cc:239-242 */
+		if (params.jac_type == 0 || params.hess_type == Original) am->cmptMeanOf(mean_pix_jacobian, init_pix_jacobian, curr_pix_jacobian);
+		if (params.sec_ord_hess && params.hess_type != InitialSelf) updatePixHessian(curr_pix_hessian);
 		am->updateCurrGrad();
 		am->updateInitGrad();
-		am->cmptDifferenceOfJacobians(jacobian, init_pix_jacobian, curr_pix_jacobian);
-		for (int i = 0; i < ssm_state_size; ++i) jacobian[i] *= 0.5;
-		switch (params.hess_type) {
+		if (params.jac_type == 0) am->cmptCurrJacobian(jacobian, mean_pix_jacobian);    /* cmptJacobian NT/ESM.cc:298-313 */
+		else {
+			am->cmptDifferenceOfJacobians(jacobian, init_pix_jacobian, curr_pix_jacobian);
+			for (int i = 0; i < ssm_state_size; ++i) jacobian[i] *= 0.5;
+		}
+		switch (params.hess_type) {                                                       /* cmptHessian NT/ESM.cc:315-377 */
 		case InitialSelf: if (params.leven_marq) hessian = init_self_hessian; break;
+		case Original:
+			if (params.sec_ord_hess) {
+				am->cmptMeanOf(mean_pix_hessian, init_pix_hessian, curr_pix_hessian);
+				am->cmptCurrHessian(hessian, mean_pix_jacobian, mean_pix_hessian);
+			} else am->cmptCurrHessian(hessian, mean_pix_jacobian);
+			break;
 		case SumOfStd:
-			am->cmptSumOfHessians(hessian, init_pix_jacobian, curr_pix_jacobian);
+			if (params.sec_ord_hess) am->cmptSumOfHessians(hessian, init_pix_jacobian, curr_pix_jacobian, init_pix_hessian, curr_pix_hessian);
+			else am->cmptSumOfHessians(hessian, init_pix_jacobian, curr_pix_jacobian);
 			for (int i = 0; i < ssm_state_size; ++i) for (int j = 0; j < ssm_state_size; ++j) hessian(i, j) *= 0.5;
 			break;
 		case SumOfSelf:
-			am->cmptSelfHessian(hessian, curr_pix_jacobian);
+			selfHessian(hessian, curr_pix_jacobian, curr_pix_hessian);
 			for (int i = 0; i < ssm_state_size; ++i) for (int j = 0; j < ssm_state_size; ++j) hessian(i, j) = (hessian(i, j) + init_self_hessian(i, j)) * 0.5;
 			break;
-		case CurrentSelf: am->cmptSelfHessian(hessian, curr_pix_jacobian); break;
-		default: am->cmptCurrHessian(hessian, curr_pix_jacobian); break;
+		case CurrentSelf: selfHessian(hessian, curr_pix_jacobian, curr_pix_hessian); break;
+		default:
+			if (params.sec_ord_hess) am->cmptCurrHessian(hessian, curr_pix_jacobian, curr_pix_hessian);
+			else am->cmptCurrHessian(hessian, curr_pix_jacobian);
+			break;
 		}
 		dampAndSolve(leven_marq_delta);
 		prev_corners = ssm->getCorners();
@@ -181,18 +229,36 @@ void ESM::update() {
 FCLK::FCLK(AM a, SSM s, const SMParams &p) : SearchMethod(a, s, p) {
 	name = "fclk_nt";
 	if (params.hess_type < 0) params.hess_type = CurrentSelf;
+	if (params.sec_ord_hess) {   /* NT/FCLK.cc:66-75 */
+		const int n = (int)am->getPatchSize(), s2 = ssm_state_size * ssm_state_size;
+		if (params.hess_type == InitialSelf) init_pix_hessian.resize(s2, n);
+		else curr_pix_hessian.resize(s2, n);
+	}
 }
 void FCLK::initialize(const CornersT &corners) {
 	am->clearInitStatus(); ssm->clearInitStatus();
 	ssm->initialize(corners, am->getNChannels());
 	am->initializePixVals(ssm->getPts());
 	am->initializeSimilarity(); am->initializeGrad(); am->initializeHess();
-	if (params.hess_type == InitialSelf) {
-		initPixJacobian(init_pix_jacobian);
-		am->cmptSelfHessian(hessian, init_pix_jacobian);
-		if (params.leven_marq) init_self_hessian = hessian;
-	} else if (params.chained_warp) am->initializePixGrad(ssm->getPts());
+	if (params.chained_warp) am->initializePixGrad(ssm->getPts());
 	else { ssm->initializeGradPts(am->getGradOffset()); am->initializePixGrad(ssm->getGradPts(), true); }
+	if (params.sec_ord_hess) initPixHess();
+	if (params.hess_type == InitialSelf) {
+		if (params.chained_warp) ssm->cmptWarpedPixJacobian(init_pix_jacobian, am->getInitPixGrad());
+		else ssm->cmptInitPixJacobian(init_pix_jacobian, am->getInitPixGrad());
+		if (params.sec_ord_hess) pixHessianFromInit(init_pix_hessian);
+		selfHessian(hessian, init_pix_jacobian, init_pix_hessian);
+		if (params.leven_marq) init_self_hessian = hessian;
+	}
+}
+/* NT/FCLK.cc:360-376: the recomputed Hessian is NOT copied to init_self_hessian there */
+void FCLK::setRegion(const CornersT &corners) {
+	ssm->setCorners(corners);
+	if (params.hess_type == InitialSelf) {
+		ssm->cmptInitPixJacobian(init_pix_jacobian, am->getInitPixGrad());
+		if (params.sec_ord_hess) ssm->cmptInitPixHessian(init_pix_hessian, am->getInitPixHess(), am->getInitPixGrad());
+		selfHessian(hessian, init_pix_jacobian, init_pix_hessian);
+	}
 }
 void FCLK::update() {
 	double prev_similarity = 0, leven_marq_delta = params.lm_delta_init;
@@ -221,11 +287,15 @@ void FCLK::update() {
 		state_reset = false;
 		am->updateCurrGrad();
 		updatePixJacobian(curr_pix_jacobian);
+		if (params.sec_ord_hess && params.hess_type != InitialSelf) updatePixHessian(curr_pix_hessian);
 		am->cmptCurrJacobian(jacobian, curr_pix_jacobian);
 		switch (params.hess_type) {
 		case InitialSelf: if (params.leven_marq) hessian = init_self_hessian; break;
-		case CurrentSelf: am->cmptSelfHessian(hessian, curr_pix_jacobian); break;
-		default: am->cmptCurrHessian(hessian, curr_pix_jacobian); break;
+		case CurrentSelf: selfHessian(hessian, curr_pix_jacobian, curr_pix_hessian); break;
+		default:
+			if (params.sec_ord_hess) am->cmptCurrHessian(hessian, curr_pix_jacobian, curr_pix_hessian);
+			else am->cmptCurrHessian(hessian, curr_pix_jacobian);
+			break;
 		}
 		dampAndSolve(leven_marq_delta);
 		prev_corners = ssm->getCorners();
@@ -241,6 +311,11 @@ void FCLK::update() {
 ICLK::ICLK(AM a, SSM s, const SMParams &p) : SearchMethod(a, s, p) {
 	name = "iclk_nt";
 	if (params.hess_type < 0) params.hess_type = InitialSelf;
+	if (params.sec_ord_hess) {   /* NT/ICLK.cc:61-67 */
+		const int n = (int)am->getPatchSize(), s2 = ssm_state_size * ssm_state_size;
+		if (params.hess_type == CurrentSelf) curr_pix_hessian.resize(s2, n);
+		else init_pix_hessian.resize(s2, n);
+	}
 }
 void ICLK::initialize(const CornersT &corners) {
 	am->clearInitStatus(); ssm->clearInitStatus();
@@ -249,8 +324,12 @@ void ICLK::initialize(const CornersT &corners) {
 	initPixJacobian(init_pix_jacobian);
 	am->initializeSimilarity(); am->initializeGrad(); am->initializeHess();
 	am->cmptInitJacobian(jacobian, init_pix_jacobian);
+	if (params.sec_ord_hess) {
+		initPixHess();
+		if (params.hess_type != CurrentSelf) pixHessianFromInit(init_pix_hessian);
+	}
 	if (params.hess_type == InitialSelf) {
-		am->cmptSelfHessian(hessian, init_pix_jacobian);
+		selfHessian(hessian, init_pix_jacobian, init_pix_hessian);
 		if (params.leven_marq) init_self_hessian = hessian;
 	}
 }
@@ -283,9 +362,13 @@ void ICLK::update() {
 		case InitialSelf: if (params.leven_marq) hessian = init_self_hessian; break;
 		case CurrentSelf:
 			updatePixJacobian(curr_pix_jacobian);
-			am->cmptSelfHessian(hessian, curr_pix_jacobian);
+			if (params.sec_ord_hess) updatePixHessian(curr_pix_hessian);
+			selfHessian(hessian, curr_pix_jacobian, curr_pix_hessian);
 			break;
-		default: am->cmptInitHessian(hessian, init_pix_jacobian); break;
+		default:
+			if (params.sec_ord_hess) am->cmptInitHessian(hessian, init_pix_jacobian, init_pix_hessian);
+			else am->cmptInitHessian(hessian, init_pix_jacobian);
+			break;
 		}
 		dampAndSolve(leven_marq_delta);
 		prev_corners = ssm->getCorners();

@@ -47,12 +47,17 @@ protected:
 	SMParams params;
 	int ssm_state_size, iters_done = 0;
 	MatrixXd init_pix_jacobian, curr_pix_jacobian, mean_pix_jacobian;
+	MatrixXd init_pix_hessian, curr_pix_hessian, mean_pix_hessian;   /* S^2 x N, sec_ord_hess only */
 	RowVectorXd jacobian;
 	MatrixXd hessian, init_self_hessian;
 	VectorXd state_update, inv_update;
 	CornersT prev_corners;
 	void initPixJacobian(MatrixXd &J);
 	void updatePixJacobian(MatrixXd &J);
+	void initPixHess();                          /* am->initializePixHess, either overload */
+	void pixHessianFromInit(MatrixXd &D);        /* ssm->cmpt{Warped,Init}PixHessian of the template */
+	void updatePixHessian(MatrixXd &D);          /* ESM::updatePixHessian */
+	void selfHessian(MatrixXd &H, const MatrixXd &J, const MatrixXd &D);
 	void dampAndSolve(double delta);    /* hessian += delta*diag(hessian); state_update = -H^-1 g */
 };
 
@@ -70,6 +75,7 @@ public:
 	FCLK(AM am, SSM ssm, const SMParams &params);
 	void initialize(const CornersT &corners) override;
 	void update() override;
+	void setRegion(const CornersT &corners) override;
 };
 class ICLK : public SearchMethod {
 public:

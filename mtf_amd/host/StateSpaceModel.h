@@ -25,20 +25,28 @@ public:
 	virtual const CornersT &getCorners() = 0;
 	virtual const VectorXd &getState() = 0;
 	virtual const GradPtsT &getGradPts() = 0;
+	virtual const HessPtsT &getHessPts() = 0;
 
 	virtual void setState(const VectorXd &) { ssm_func_not_implemeted(setState); }
 	virtual void setCorners(const CornersT &) { ssm_func_not_implemeted(setCorners); }
 	virtual void initialize(const CornersT &corners, int n_channels = 1) { (void)n_channels; setCorners(corners); }
 	virtual void initializeGradPts(double grad_eps) { updateGradPts(grad_eps); }
+	virtual void initializeHessPts(double hess_eps) { updateHessPts(hess_eps); }   /* StateSpaceModel.h:131-136 */
 	virtual void additiveUpdate(const VectorXd &) { ssm_func_not_implemeted(additiveUpdate); }
 	virtual void compositionalUpdate(const VectorXd &) { ssm_func_not_implemeted(compositionalUpdate); }
 	virtual void updateGradPts(double) { ssm_func_not_implemeted(updateGradPts); }
+	virtual void updateHessPts(double) { ssm_func_not_implemeted(updateHessPts); }
 	virtual void invertState(VectorXd &, const VectorXd &) { ssm_func_not_implemeted(invertState); }
 
 	virtual void cmptInitPixJacobian(MatrixXd &, const PixGradT &) { ssm_func_not_implemeted(cmptInitPixJacobian); }
 	virtual void cmptPixJacobian(MatrixXd &, const PixGradT &) { ssm_func_not_implemeted(cmptPixJacobian); }
 	virtual void cmptWarpedPixJacobian(MatrixXd &, const PixGradT &) { ssm_func_not_implemeted(cmptWarpedPixJacobian); }
 	virtual void cmptApproxPixJacobian(MatrixXd &, const PixGradT &) { ssm_func_not_implemeted(cmptApproxPixJacobian); }
+	/* StateSpaceModel.h:182-197 */
+	virtual void cmptInitPixHessian(MatrixXd &, const PixHessT &, const PixGradT &) { ssm_func_not_implemeted(cmptInitPixHessian); }
+	virtual void cmptPixHessian(MatrixXd &, const PixHessT &, const PixGradT &) { ssm_func_not_implemeted(cmptPixHessian); }
+	virtual void cmptWarpedPixHessian(MatrixXd &, const PixHessT &, const PixGradT &) { ssm_func_not_implemeted(cmptWarpedPixHessian); }
+	virtual void cmptApproxPixHessian(MatrixXd &, const PixHessT &, const PixGradT &) { ssm_func_not_implemeted(cmptApproxPixHessian); }
 	virtual void applyWarpToCorners(CornersT &, const CornersT &, const VectorXd &) { ssm_func_not_implemeted(applyWarpToCorners); }
 
 	virtual void setFirstIter() { first_iter = true; }

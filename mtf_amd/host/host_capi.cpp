@@ -27,7 +27,7 @@ const char *mtfhost_last_error(void) { return g_err.c_str(); }
 
 mtfhost_tracker *mtfhost_create(int sm, int am, int ssm, int resx, int resy, int max_iters, double epsilon,
 	int jac_type, int hess_type, int chained_warp, int leven_marq, double lm_delta_init, double lm_delta_update,
-	int device) {
+	int device, int sec_ord_hess) {
 	try {
 		auto *t = new mtfhost_tracker();
 		t->pair = std::make_shared<hip::HipPair>(am, ssm, resx, resy, 1e-8, 1.0, 8, 10.0, 0, device, nullptr);
@@ -37,6 +37,7 @@ mtfhost_tracker *mtfhost_create(int sm, int am, int ssm, int resx, int resy, int
 		p.max_iters = max_iters; p.epsilon = epsilon; p.jac_type = jac_type; p.hess_type = hess_type;
 		p.chained_warp = chained_warp != 0; p.leven_marq = leven_marq != 0;
 		p.lm_delta_init = lm_delta_init; p.lm_delta_update = lm_delta_update;
+		p.sec_ord_hess = sec_ord_hess != 0;
 		if (sm == MTFHIP_SM_ESM) t->sm.reset(new nt::ESM(t->am, t->ssm, p));
 		else if (sm == MTFHIP_SM_FCLK) t->sm.reset(new nt::FCLK(t->am, t->ssm, p));
 		else if (sm == MTFHIP_SM_ICLK) t->sm.reset(new nt::ICLK(t->am, t->ssm, p));

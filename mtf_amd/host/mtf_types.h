@@ -58,6 +58,8 @@ typedef VectorXd RowVectorXd;
 typedef MatrixXd PtsT;
 typedef MatrixXd GradPtsT;   /* 8 x N */
 typedef MatrixXd PixGradT;   /* N x 2 */
+typedef MatrixXd PixHessT;   /* 4 x N */
+typedef MatrixXd HessPtsT;   /* 16 x N */
 typedef VectorXd PixValT;
 
 /* 2 x 4 corners, TL TR BR BL (Matrix24d) */

@@ -51,6 +51,18 @@ CASES = [
     (L.SM_ESM, L.AM_NCC, L.SSM_HOMOGRAPHY, 40, dict(hess_type=4)),
     (L.SM_ESM, L.AM_MI, L.SSM_HOMOGRAPHY, 40, dict(leven_marq=0)),
     (L.SM_FCLK, L.AM_MI, L.SSM_AFFINE, 30, dict()),
+    # ESM variants Original: the SM-side mean Jacobian stays on the device through AppearanceModel::cmptMeanOf
+    (L.SM_ESM, L.AM_SSD, L.SSM_HOMOGRAPHY, 40, dict(jac_type=0, hess_type=3, leven_marq=0)),
+    (L.SM_ESM, L.AM_NCC, L.SSM_AFFINE, 30, dict(jac_type=0, hess_type=3)),
+    # second-order Hessians
+    (L.SM_ESM, L.AM_SSD, L.SSM_AFFINE, 30, dict(sec_ord_hess=1, hess_type=5, leven_marq=0)),
+    (L.SM_ESM, L.AM_SSD, L.SSM_AFFINE, 30, dict(sec_ord_hess=1, hess_type=3, jac_type=0, leven_marq=0, chained_warp=0)),
+    (L.SM_ESM, L.AM_NCC, L.SSM_AFFINE, 30, dict(sec_ord_hess=1, hess_type=4, leven_marq=0)),
+    (L.SM_FCLK, L.AM_SSD, L.SSM_AFFINE, 30, dict(sec_ord_hess=1, hess_type=2, leven_marq=0)),
+    (L.SM_FCLK, L.AM_MI, L.SSM_AFFINE, 30, dict(sec_ord_hess=1, hess_type=0)),
+    (L.SM_ICLK, L.AM_SSD, L.SSM_AFFINE, 30, dict(sec_ord_hess=1, hess_type=2, leven_marq=0)),
+    (L.SM_ICLK, L.AM_MI, L.SSM_AFFINE, 30, dict(sec_ord_hess=1, hess_type=1, leven_marq=0)),
+    (L.SM_ESM, L.AM_MI, L.SSM_HOMOGRAPHY, 40, dict(sec_ord_hess=1, leven_marq=0)),
 ]
 
 
@@ -87,8 +99,10 @@ def test_cpp_trackers_match_oracle(oracle, frame, case):
 
 @pytest.mark.gpu
 def test_cpp_layer_error_paths(frame):
-    trk = host.CppTracker(L.SM_ESM, L.AM_SSD, L.SSM_HOMOGRAPHY, 20, 20, jac_type=0)
+    # NCC leaves the second-order cmptSelfHessian unimplemented (AppearanceModel.h:188-191): the exception type and
+    # text cross the C ABI and come back as the reference's FunctonNotImplemented
+    trk = host.CppTracker(L.SM_ESM, L.AM_NCC, L.SSM_HOMOGRAPHY, 20, 20, sec_ord_hess=1)
     trk.set_image(frame)
-    trk.initialize(synth.square_corners(200, 200, 40))
     with pytest.raises(host.HostError, match="FunctonNotImplemented"):
-        trk.update()
+        trk.initialize(synth.square_corners(200, 200, 40))
+    # Affine has no cmptApproxPixHessian / cmptPixHessian; a size mismatch is an InvalidArgument
