@@ -205,6 +205,7 @@ struct mtfhip_batch {
 	double *d_d2_part = nullptr, *d_d2_out = nullptr, *d_d2_w = nullptr; /* second-order term: block rows, [B][64] sums, MI self weights */
 	double hess_eps = 1.0;
 	bool init_pix_hess = false;
+	int d0_variant = MTFHIP_JAC_WARPED; /* how the template's pixel Hessian was formed (fused second-order path) */
 	size_t unit_capacity = 0;
 	int mi_row_len = 0;
 	double mi_hist_norm = 0;
@@ -1302,6 +1303,13 @@ int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 		TRY(mtfhip_am_initialize_pix_grad_warped(b, nullptr));
 		TRY(mtfhip_ssm_cmpt_pix_jacobian(b, MTFHIP_JAC_INIT, MTFHIP_BUF_DI0_DX, MTFHIP_BUF_J0));
 	}
+	if (sm->sec_ord_hess) {   /* initializePixHess, NT/ESM.cc:406-416 ; the template's pixel Hessian is rebuilt per pixel from
+	                           * d2I0_dx2 and dI0_dx inside k_second_order_ssd instead of being stored as an S^2 x N matrix */
+		b->init_pix_hess = false;
+		if (sm->chained_warp) TRY(mtfhip_am_initialize_pix_hess(b, nullptr));
+		else { TRY(mtfhip_ssm_update_hess_pts(b, b->hess_eps)); TRY(mtfhip_am_initialize_pix_hess_warped(b, nullptr, nullptr)); }
+		b->d0_variant = sm->chained_warp ? MTFHIP_JAC_WARPED : MTFHIP_JAC_INIT;
+	}
 	TRY(mtfhip_am_initialize_similarity(b));
 	TRY(mtfhip_am_initialize_grad(b));
 	TRY(mtfhip_am_initialize_hess(b));
@@ -1338,6 +1346,17 @@ static int fused_args(const mtfhip_batch *b, const mtfhip_sm_desc *sm, FusedArgs
 		fa.mode = 2;
 	}
 	return MTFHIP_OK;
+}
+
+/* The second-order term an SSD search method adds to its Hessian (k_second_order_ssd's `term`), -1 for none:
+ * SSD's self Hessians are first order by definition (SSDBase.h:95-98) and InitialSelf never looks at the frame. */
+static int second_order_term(const mtfhip_sm_desc *sm) {
+	if (!sm->sec_ord_hess) return -1;
+	switch (sm->sm) {
+	case MTFHIP_SM_FCLK: return sm->hess_type == 2 ? 0 : -1;
+	case MTFHIP_SM_ESM: return sm->hess_type == 5 ? 0 : (sm->hess_type == 4 ? 1 : (sm->hess_type == 3 ? 2 : -1));
+	default: return sm->hess_type == 2 ? 3 : -1;
+	}
 }
 
 /* turns one target's reduced accumulators into the SM's g and H (before LM damping):
@@ -1377,10 +1396,33 @@ int mtfhip_batch_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, d
 	b->it_valid = fa.materialize;
 	b->dit_valid = fa.materialize && fa.mode != 2;
 	b->jt_valid = fa.materialize && fa.mode != 2;
+	const int term = second_order_term(sm);
+	std::vector<double> so;
+	if (term >= 0) {
+		if (term != 0 && !b->init_pix_hess) return fail(MTFHIP_ERR_LOGIC, "iterate: init_template was run without sec_ord_hess");
+		const int nb2 = simple_blocks_per_target(b->N);
+		if (!b->d_d2_part) {
+			HIP_TRY(hipMalloc(&b->d_d2_part, sizeof(double) * 64 * (size_t)nb2 * b->B));
+			HIP_TRY(hipMalloc(&b->d_d2_out, sizeof(double) * 64 * (size_t)b->B));
+		}
+		{
+			TimedScope ts(b->ctx, "second_order");
+			launch_second_order_ssd(b->view(), b->ctx->img, term, fa.chained, b->d0_variant, fa.grad_eps, b->hess_eps, b->norm_mult,
+				b->norm_add, b->d_d2_part, nb2, b->d_d2_out, b->ctx->stream);
+		}
+		so.resize((size_t)b->S * b->S * b->B);
+		HIP_TRY(hipMemcpyAsync(so.data(), b->d_d2_out, sizeof(double) * so.size(), hipMemcpyDeviceToHost, b->ctx->stream));
+	}
 	TRY(read_acc(b, nblk));
+	const int S2 = b->S * b->S;
 	for (int t = 0; t < b->B; ++t) {
 		double ft;
-		assemble(b, sm, b->h_acc + (size_t)t * ACC_COUNT, b->th[t].h0, &ft, g + (size_t)t * b->S, H + (size_t)t * b->S * b->S);
+		double *Ht = H + (size_t)t * S2;
+		assemble(b, sm, b->h_acc + (size_t)t * ACC_COUNT, b->th[t].h0, &ft, g + (size_t)t * b->S, Ht);
+		if (term >= 0) {   /* SumOfStd halves the whole sum (NT/ESM.cc:339) */
+			const double sc = term == 1 ? 0.5 : 1.0;
+			for (int k = 0; k < S2; ++k) Ht[k] += sc * so[(size_t)t * S2 + k];
+		}
 		b->th[t].f = ft;
 		if (f) f[t] = ft;
 	}
@@ -1391,6 +1433,8 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 	TRY(check_sm(b, sm, "track"));
 	if (sm->leven_marq) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: Levenberg-Marquardt is only available through iterate + host solve");
 	if (sm->max_iters <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "track: max_iters must be positive");
+	if (b->desc.am != MTFHIP_AM_SSD ? sm->sec_ord_hess != 0 : second_order_term(sm) >= 0)
+		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: a second-order Hessian is indefinite and needs the pivoted host solve; use iterate");
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "track before init_template");
 	TRY(need_image(b));
 	hipStream_t st = b->ctx->stream;

@@ -146,6 +146,9 @@ void launch_pix_hessian(const BatchView &bv, int variant, const double *hess, co
 void launch_weighted_plane_sum(const BatchView &bv, const double *d2a, const double *d2b, const double *w, double *partials, int nblk,
 	double *out, hipStream_t st);
 void launch_mean_planes(const double *a, const double *b, double *o, size_t n, hipStream_t st);
+/* fused second-order term of the SSD Hessians, pixel-Hessian blocks in registers only; out[t][S*S] */
+void launch_second_order_ssd(const BatchView &bv, const ImgView &im, int term, int chained, int d0_variant, double grad_eps,
+	double hess_eps, double norm_mult, double norm_add, double *partials, int nblk, double *out, hipStream_t st);
 /* NN dataset rows: features of C warped patches of target 0 (SSD: It, NCC: centred / normalised It) */
 void launch_sample_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C, double norm_mult,
 	double norm_add, double *dev_feat, hipStream_t st);

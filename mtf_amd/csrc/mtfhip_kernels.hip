@@ -674,6 +674,105 @@ __global__ __launch_bounds__(64) void k_plane_sum_finish(const double *partials,
 	out[(size_t)t * S2 + k] = s;
 }
 
+/* The second-order term of the SSD Hessians for the fused path: sum_p (wt[p] * Dt[:, p] + w0[p] * D0[:, p]) in one
+ * pass, the S x S pixel-Hessian blocks living in registers only (the reference materialises two S^2 x N matrices:
+ * 20 MB each at 200 x 200).  Per pixel: re-sample It (residual r), the image Hessian of the current image by the 9-sample
+ * stencil of getImgHess / getWarpedImgHess, its FD gradient, the current block Dt (Warped variant when chained, Init
+ * otherwise, NT/ESM.cc:418-432), and the template block D0 rebuilt from the stored d2I0_dx2 / dI0_dx (6 doubles per pixel).
+ *   term  0: -r * Dt                 cmptCurrHessian (2nd order), SSDBase.cc:345-375   (FCLK / ESM Std)
+ *   term  1:  r * (D0 + Dt)          cmptSumOfHessians (2nd order), SSDBase.cc:377-415 (ESM SumOfStd)
+ *   term  2: -r * ((D0 + Dt) / 2)    cmptCurrHessian on the mean pixel Hessian, NT/ESM.cc:324-327 (ESM Original)
+ *   term  3:  r * D0                 cmptInitHessian (2nd order), SSDBase.cc:313-343   (ICLK Std)
+ * d0_variant: how init_pix_hessian was produced (Warped at the identity warp by initialize, Init after setRegion). */
+template <int SSM>
+__global__ __launch_bounds__(kBlock) void k_second_order_ssd(BatchView bv, ImgView im, int term, int chained, int d0_variant,
+	double grad_eps, double hess_eps, double norm_mult, double norm_add, double *partials, int nblk) {
+	constexpr int S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
+	__shared__ double lds[4 * S * S];
+	const int t = blockIdx.y, N = bv.N;
+	const Warp9 W = load_warp(bv.warps + 9 * t);
+	const double *st = bv.states + 8 * t;
+	Warp9 Wid;
+#pragma unroll
+	for (int q = 0; q < 9; ++q) Wid.m[q] = (q == 0 || q == 4 || q == 8) ? 1.0 : 0.0;
+	const double st0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * N;
+	const double2 *cp = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * N;
+	const double2 *ch = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_CURR_HXY]) + (size_t)t * N;
+	const double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * N;
+	const double *I0 = bv.buf[MTFHIP_BUF_I0] + (size_t)t * N;
+	const double *g0 = bv.buf[MTFHIP_BUF_DI0_DX] + (size_t)t * N * 2;
+	const double2 *h0 = term != 0 ? reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_D2I0_DX2] + (size_t)t * N * 4) : nullptr;
+	const double heps2 = 2 * hess_eps;
+	const double hmult = norm_mult / (heps2 * heps2), gmult = norm_mult / (2 * grad_eps);
+	double acc[S * S];
+#pragma unroll
+	for (int k = 0; k < S * S; ++k) acc[k] = 0.0;
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += nblk * kBlock) {
+		const double2 p0 = ip[i], c = cp[i];
+		const double D = cz[i];
+		const double cv = pix_val(im, c.x, c.y);
+		const double r = (norm_mult * cv + norm_add) - I0[i];
+		double d2[S * S];
+		if (term != 3) {
+			double hxx, hyy, hxy, gx, gy;
+			if (chained) {   /* getImgHess imgUtils.cc:334-366 + getImgGrad :233-254 at the current points */
+				const double ix = pix_val(im, c.x + heps2, c.y), dx = pix_val(im, c.x - heps2, c.y);
+				hxx = (ix + dx - 2 * cv) * hmult;
+				const double iy = pix_val(im, c.x, c.y + heps2), dy = pix_val(im, c.x, c.y - heps2);
+				hyy = (iy + dy - 2 * cv) * hmult;
+				const double inc_x = c.x + hess_eps, dec_x = c.x - hess_eps, inc_y = c.y + hess_eps, dec_y = c.y - hess_eps;
+				hxy = ((pix_val(im, inc_x, inc_y) + pix_val(im, dec_x, dec_y)) - (pix_val(im, inc_x, dec_y) + pix_val(im, dec_x, inc_y))) * hmult;
+				gx = (pix_val(im, c.x + grad_eps, c.y) - pix_val(im, c.x - grad_eps, c.y)) * gmult;
+				gy = (pix_val(im, c.x, c.y + grad_eps) - pix_val(im, c.x, c.y - grad_eps)) * gmult;
+			} else {         /* updateHessPts + getWarpedImgHess imgUtils.cc:259-289 ; updateGradPts + getWarpedImgGrad :177-202 */
+				double q0, q1, q2;
+				if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) { const double2 h = ch[i]; q0 = h.x; q1 = h.y; q2 = D; }
+				else { q0 = c.x; q1 = c.y; q2 = 1.0; }
+				auto at = [&](double o0, double o1, double o2, double sgn) -> double {
+					if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+						const double a0 = q0 + sgn * o0, a1 = q1 + sgn * o1, a2 = q2 + sgn * o2;
+						return pix_val(im, a0 / a2, a1 / a2);
+					} else {
+						return pix_val(im, q0 + sgn * o0, q1 + sgn * o1);
+					}
+				};
+				const double xx0 = W.m[0] * heps2, xx1 = W.m[3] * heps2, xx2 = W.m[6] * heps2;
+				const double yy0 = W.m[1] * heps2, yy1 = W.m[4] * heps2, yy2 = W.m[7] * heps2;
+				const double xy0 = (W.m[0] + W.m[1]) * hess_eps, xy1 = (W.m[3] + W.m[4]) * hess_eps, xy2 = (W.m[6] + W.m[7]) * hess_eps;
+				const double yx0 = (W.m[0] - W.m[1]) * hess_eps, yx1 = (W.m[3] - W.m[4]) * hess_eps, yx2 = (W.m[6] - W.m[7]) * hess_eps;
+				hxx = (at(xx0, xx1, xx2, 1.0) + at(xx0, xx1, xx2, -1.0) - 2 * cv) * hmult;
+				hyy = (at(yy0, yy1, yy2, 1.0) + at(yy0, yy1, yy2, -1.0) - 2 * cv) * hmult;
+				hxy = ((at(xy0, xy1, xy2, 1.0) + at(xy0, xy1, xy2, -1.0)) - (at(yx0, yx1, yx2, 1.0) + at(yx0, yx1, yx2, -1.0))) * hmult;
+				const double gx0 = W.m[0] * grad_eps, gx1 = W.m[3] * grad_eps, gx2 = W.m[6] * grad_eps;
+				const double gy0 = W.m[1] * grad_eps, gy1 = W.m[4] * grad_eps, gy2 = W.m[7] * grad_eps;
+				gx = (at(gx0, gx1, gx2, 1.0) - at(gx0, gx1, gx2, -1.0)) * gmult;
+				gy = (at(gy0, gy1, gy2, 1.0) - at(gy0, gy1, gy2, -1.0)) * gmult;
+			}
+			pix_hessian_block<SSM>(d2, chained ? MTFHIP_JAC_WARPED : MTFHIP_JAC_INIT, W, st, p0.x, p0.y, c.x, c.y, D, hxx, hxy, hxy, hyy, gx, gy);
+		}
+		if (term == 0) {
+#pragma unroll
+			for (int k = 0; k < S * S; ++k) acc[k] = fma(-r, d2[k], acc[k]);
+		} else {
+			const double2 ma = h0[2 * i], mb = h0[2 * i + 1];
+			double d0[S * S];
+			pix_hessian_block<SSM>(d0, d0_variant, Wid, st0, p0.x, p0.y, p0.x, p0.y, 1.0, ma.x, ma.y, mb.x, mb.y, g0[i], g0[N + i]);
+			if (term == 1) {
+#pragma unroll
+				for (int k = 0; k < S * S; ++k) acc[k] = fma(r, d0[k] + d2[k], acc[k]);
+			} else if (term == 2) {
+#pragma unroll
+				for (int k = 0; k < S * S; ++k) acc[k] = fma(-r, (d0[k] + d2[k]) / 2.0, acc[k]);
+			} else {
+#pragma unroll
+				for (int k = 0; k < S * S; ++k) acc[k] = fma(r, d0[k], acc[k]);
+			}
+		}
+	}
+	block_reduce_store<S * S>(acc, partials + ((size_t)t * nblk + blockIdx.x) * (S * S), lds);
+}
+
 /* mean_pix_jacobian = (init_pix_jacobian + curr_pix_jacobian) / 2.0 (SM/src/NT/ESM.cc:239-242) */
 __global__ __launch_bounds__(kBlock) void k_mean_jacobian(const double *a, const double *b, double *o, size_t n) {
 	for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
@@ -2076,6 +2175,17 @@ void launch_weighted_plane_sum(const BatchView &bv, const double *d2a, const dou
 	const dim3 grid(nblk, bv.B);
 	if (bv.S == 8) hipLaunchKernelGGL(k_weighted_plane_sum<64>, grid, dim3(kBlock), 0, st, bv.N, d2a, d2b, w, partials, nblk);
 	else hipLaunchKernelGGL(k_weighted_plane_sum<36>, grid, dim3(kBlock), 0, st, bv.N, d2a, d2b, w, partials, nblk);
+	hipLaunchKernelGGL(k_plane_sum_finish, dim3(bv.B), dim3(64), 0, st, partials, nblk, bv.S * bv.S, out);
+}
+void launch_second_order_ssd(const BatchView &bv, const ImgView &im, int term, int chained, int d0_variant, double grad_eps,
+	double hess_eps, double norm_mult, double norm_add, double *partials, int nblk, double *out, hipStream_t st) {
+	const dim3 grid(nblk, bv.B);
+	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY)
+		hipLaunchKernelGGL(k_second_order_ssd<MTFHIP_SSM_HOMOGRAPHY>, grid, dim3(kBlock), 0, st, bv, im, term, chained, d0_variant, grad_eps,
+			hess_eps, norm_mult, norm_add, partials, nblk);
+	else
+		hipLaunchKernelGGL(k_second_order_ssd<MTFHIP_SSM_AFFINE>, grid, dim3(kBlock), 0, st, bv, im, term, chained, d0_variant, grad_eps,
+			hess_eps, norm_mult, norm_add, partials, nblk);
 	hipLaunchKernelGGL(k_plane_sum_finish, dim3(bv.B), dim3(64), 0, st, partials, nblk, bv.S * bv.S, out);
 }
 void launch_mean_planes(const double *a, const double *b, double *o, size_t n, hipStream_t st) {

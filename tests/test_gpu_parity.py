@@ -143,6 +143,15 @@ SM_CASES = [
     (L.SM_ICLK, L.SSM_HOMOGRAPHY, 50, dict()),
     (L.SM_ICLK, L.SSM_AFFINE, 25, dict()),                                     # config 3 patch shape
     (L.SM_ESM, L.SSM_AFFINE, 40, dict()),
+    # second-order Hessians through the fused path (k_second_order_ssd keeps the S x S pixel-Hessian blocks in registers)
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, 40, dict(sec_ord_hess=1, hess_type=5)),
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, 40, dict(sec_ord_hess=1, hess_type=4, chained_warp=0)),
+    (L.SM_ESM, L.SSM_AFFINE, 40, dict(sec_ord_hess=1, hess_type=3, jac_type=0)),
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, 40, dict(sec_ord_hess=1)),                    # SumOfSelf: SSD's self Hessian stays first order
+    (L.SM_FCLK, L.SSM_HOMOGRAPHY, 50, dict(sec_ord_hess=1, hess_type=2)),
+    (L.SM_FCLK, L.SSM_AFFINE, 40, dict(sec_ord_hess=1, hess_type=2, chained_warp=0)),
+    (L.SM_ICLK, L.SSM_HOMOGRAPHY, 40, dict(sec_ord_hess=1, hess_type=2)),
+    (L.SM_ICLK, L.SSM_AFFINE, 25, dict(sec_ord_hess=1, hess_type=2, chained_warp=0)),
 ]
 
 

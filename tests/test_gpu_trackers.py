@@ -238,3 +238,21 @@ def test_second_order_self_hessian_ncc_not_implemented(gpu_ctx, frame):
     nt = NTSearchMethod(gpu_ctx, L.SM_ESM, L.AM_NCC, L.SSM_AFFINE, 20, 20, 1, sec_ord_hess=1, hess_type=2)
     with pytest.raises(mtf_amd.FunctionNotImplemented):
         nt.initialize(synth.square_corners(250, 250, 60)[None])
+
+
+def test_device_loop_refuses_second_order_hessians(gpu_ctx, frame):
+    """mtfhip_batch_track solves with an unpivoted Gauss-Jordan on the device, fine for the definite first-order
+    Hessians only; a second-order Hessian has to go through iterate + the pivoted host solve.  SSD's self Hessians
+    are first order by definition, so those configurations still run on the device."""
+    gpu_ctx.set_image(frame)
+    trk = LKTracker(gpu_ctx, L.SM_FCLK, L.SSM_HOMOGRAPHY, 30, 30, 2, host_solve=False, sec_ord_hess=1, hess_type=2, max_iters=5)
+    c = np.stack([synth.square_corners(200, 200, 60), synth.square_corners(300, 280, 60)])
+    trk.initialize(c)
+    with pytest.raises(mtf_amd.FunctionNotImplemented):
+        trk.update()
+    ok = LKTracker(gpu_ctx, L.SM_FCLK, L.SSM_HOMOGRAPHY, 30, 30, 2, host_solve=False, sec_ord_hess=1, hess_type=1, max_iters=5)
+    ok.initialize(c)
+    np.testing.assert_allclose(ok.update(), c, atol=1e-6)     # same frame: already converged
+    hs = LKTracker(gpu_ctx, L.SM_FCLK, L.SSM_HOMOGRAPHY, 30, 30, 2, host_solve=True, sec_ord_hess=1, hess_type=2, max_iters=5)
+    hs.initialize(c)
+    np.testing.assert_allclose(hs.update(), c, atol=1e-6)
