@@ -15,6 +15,8 @@
  * written as one partial row per workgroup; a second tiny kernel sums the rows in a fixed order
  * (deterministic, no atomics).
  */
+#include <type_traits>
+
 #include "mtfhip_internal.h"
 
 /* tuning knobs of the fused kernel ("fused kernel tuning") */
@@ -23,6 +25,17 @@
 #endif
 #ifndef MTFHIP_FUSED_WAVES
 #define MTFHIP_FUSED_WAVES 2   /* minimum waves per SIMD requested from the register allocator */
+#endif
+#ifndef MTFHIP_NT_STORE
+#define MTFHIP_NT_STORE 1      /* 1: the materialised It / dIt_dx / Jt are written with non-temporal stores */
+#endif
+#if MTFHIP_NT_STORE
+#define MAT_STORE(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#else
+#define MAT_STORE(ptr, v) (*(ptr) = (v))
+#endif
+#ifndef MTFHIP_NT_LOAD
+#define MTFHIP_NT_LOAD 0       /* 1: the read-once operands (grid points, I0, J0 columns) are fetched with non-temporal loads */
 #endif
 #ifndef MTFHIP_COOP
 #define MTFHIP_COOP 0          /* 1: the 36 J^T J products are split over the 4 waves of a workgroup through LDS */
@@ -1338,8 +1351,19 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 #pragma unroll
 	for (int k = 0; k < K; ++k) acc[k] = 0.0;
 
-	auto load_in = [&](unsigned i) {
+	auto load_in = [&](unsigned i, auto uz) {
 		PixIn<S, MODE> in;
+#if MTFHIP_NT_LOAD
+		typedef double d2v __attribute__((ext_vector_type(2)));
+		{ const d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(ip) + i); in.p = make_double2(v.x, v.y); }
+		in.i0 = __builtin_nontemporal_load(&I0[i]);
+		if constexpr (MODE != 0) {
+#pragma unroll
+			for (int s = 0; s < S; ++s) in.j0[s] = __builtin_nontemporal_load(&J0[(unsigned)s * N + i]);
+		} else {
+			in.j0[0] = 0;
+		}
+#else
 		in.p = ip[i];
 		in.i0 = I0[i];
 		if constexpr (MODE != 0) {
@@ -1348,15 +1372,17 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 		} else {
 			in.j0[0] = 0;
 		}
-		if (!unit_z) { in.hp = ih[i]; in.z = iz[i]; }
-		else { in.hp = in.p; in.z = 1.0; }
+#endif
+		if constexpr (decltype(uz)::value) { in.hp = make_double2(0.0, 0.0); in.z = 1.0; }   /* hp is taken from p at use */
+		else { in.hp = ih[i]; in.z = iz[i]; }
 		return in;
 	};
 	/* curr_pts_hm = curr_warp * init_pts_hm and its dehomogenisation (Homography.cc:86-90, Affine.cc:104),
 	 * then the texel fetch of the bilinear cell */
-	auto issue_tex = [&](const PixIn<S, MODE> &in) {
+	auto issue_tex = [&](const PixIn<S, MODE> &in, auto uz) {
 		Tex tx;
-		const double z = in.z, hx = in.hp.x, hy = in.hp.y;
+		constexpr bool UZ = decltype(uz)::value;
+		const double z = UZ ? 1.0 : in.z, hx = UZ ? in.p.x : in.hp.x, hy = UZ ? in.p.y : in.hp.y;
 		if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
 			tx.cx = W.m[0] * hx + W.m[1] * hy + W.m[2] * z;
 			tx.cy = W.m[3] * hx + W.m[4] * hy + W.m[5] * z;
@@ -1372,7 +1398,11 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 		const int sx = tx.ok ? tx.lx : 0, sy = tx.ok ? tx.ly : 0;
 		const float *r0 = img + (unsigned)(sy * istride + sx);
 		const float *r1 = r0 + istride;
+#ifdef MTFHIP_EXPERIMENT_NOTEX
+		tx.t00 = tx.t01 = tx.t10 = tx.t11 = (float)in.i0; (void)r0; (void)r1;
+#else
 		tx.t00 = r0[0]; tx.t01 = r0[1]; tx.t10 = r1[0]; tx.t11 = r1[1];
+#endif
 		return tx;
 	};
 
@@ -1380,6 +1410,18 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 	const unsigned base = blockIdx.x * (unsigned)(kBlock * n_rows) + threadIdx.x;
 	/* arithmetic + stores of one row; `cur` holds its streaming operands, `tcur` its position and texels */
 	auto row_compute = [&](unsigned i, const PixIn<S, MODE> &cur, const Tex &tcur) {
+#ifdef MTFHIP_EXPERIMENT_TRIVIAL   /* membench-equivalent body: same loads and stores, no arithmetic to speak of */
+		{
+			const double v = cur.p.x + cur.p.y + cur.i0 + tcur.wx;
+			acc[44] += v;
+			if constexpr (MAT) {
+				MAT_STORE(&It[i], v); MAT_STORE(&dIt[i], v * 2); MAT_STORE(&dIt[N + i], v * 3);
+#pragma unroll
+				for (int s = 0; s < S; ++s) MAT_STORE(&Jt[(unsigned)s * N + i], (MODE != 0 ? cur.j0[s] : 0.0) + v);
+			}
+			return;
+		}
+#endif
 		const double x = cur.p.x, y = cur.p.y;
 		const double wx = tcur.wx, wy = tcur.wy, cx = tcur.cx, cy = tcur.cy, D = tcur.D;
 		const int lx = tcur.lx, ly = tcur.ly;
@@ -1439,11 +1481,11 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 		}
 		const double r = it - cur.i0;
 		acc[44] = fma(r, r, acc[44]);
-		if constexpr (MAT) It[i] = it;
+		if constexpr (MAT) MAT_STORE(&It[i], it);
 
 		double row[8];
 		if constexpr (MODE != 2) {
-			if constexpr (MAT) { dIt[i] = gx; dIt[N + i] = gy; }
+			if constexpr (MAT) { MAT_STORE(&dIt[i], gx); MAT_STORE(&dIt[N + i], gy); }
 			if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
 				if constexpr (CHAINED) {
 					/* Homography::cmptWarpedPixJacobian SSM/src/Homography.cc:231-294 */
@@ -1472,7 +1514,7 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 			}
 			if constexpr (MAT) {
 #pragma unroll
-				for (int s = 0; s < S; ++s) Jt[(unsigned)s * N + i] = row[s];
+				for (int s = 0; s < S; ++s) MAT_STORE(&Jt[(unsigned)s * N + i], row[s]);
 			}
 		}
 
@@ -1497,6 +1539,7 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 #pragma unroll
 			for (int s = 0; s < S; ++s) Rbuf[rbuf_sel][s * kBlock + threadIdx.x] = row[s];
 #else
+#ifndef MTFHIP_EXPERIMENT_NOACC
 			int k = 0;
 #pragma unroll
 			for (int a = 0; a < 8; ++a)
@@ -1505,6 +1548,7 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 					if (a < S && b < S) acc[k] = fma(row[a], row[b], acc[k]);
 					++k;
 				}
+#endif
 #endif
 		}
 	};
@@ -1561,24 +1605,52 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 	for (int kk = 0; kk < n_rows; ++kk) {
 		const unsigned i = base + (unsigned)kk * kBlock;
 		if (i >= N) break;
-		const PixIn<S, MODE> cur = load_in(i);
-		const Tex tcur = issue_tex(cur);
+		PixIn<S, MODE> cur; Tex tcur;
+		if (unit_z) { cur = load_in(i, std::true_type{}); tcur = issue_tex(cur, std::true_type{}); }
+		else { cur = load_in(i, std::false_type{}); tcur = issue_tex(cur, std::false_type{}); }
 		row_compute(i, cur, tcur);
 	}
 #elif MTFHIP_PIPE == 1
-	/* streaming operands of the next row are requested before the current row is processed */
-	PixIn<S, MODE> cur;
-	if (base < N) cur = load_in(base);
+	/* Streaming operands of the next row are requested before the current row is processed.  Every load of the
+	 * loop over full rows is issued unconditionally (the prefetch index is clamped into the target instead of being
+	 * guarded, the unit-z variant is chosen at compile time, the partial last row is peeled off): the number of
+	 * memory operations issued after a row's texel fetch is then a compile-time constant and the compiler can wait
+	 * for the texels with `s_waitcnt vmcnt(<next-row loads>)` and for the next row with `vmcnt(<stores>)`.
+	 * With guarded loads it has to assume the shortest path and emits vmcnt(0), which silently serialises the
+	 * prefetch behind the current row (that is what the ISA of the first version did). */
+	auto run_rows = [&](auto uz) {
+		const unsigned blk_first = blockIdx.x * (unsigned)(kBlock * n_rows);
+		/* full 256-pixel rows of this workgroup: no lane is masked, so nothing in the loop body is conditional */
+		int full = 0;
+		if (blk_first < N) {
+			const unsigned avail = (N - blk_first) / kBlock;
+			full = avail < (unsigned)n_rows ? (int)avail : n_rows;
+		}
+		if (full > 0) {
+			PixIn<S, MODE> cur = load_in(base, uz);
 #pragma unroll 1
-	for (int kk = 0; kk < n_rows; ++kk) {
-		const unsigned i = base + (unsigned)kk * kBlock;
-		if (i >= N) break;
-		const Tex tcur = issue_tex(cur);
-		PixIn<S, MODE> nxt = cur;
-		if (kk + 1 < n_rows && i + kBlock < N) nxt = load_in(i + kBlock);
-		row_compute(i, cur, tcur);
-		cur = nxt;
-	}
+			for (int kk = 0; kk < full; ++kk) {
+				const unsigned i = base + (unsigned)kk * kBlock;
+				const Tex tcur = issue_tex(cur, uz);
+				asm volatile("" ::: "memory");      /* texel fetch first, then the next row's operands: keeps the order */
+				const unsigned inext = i + kBlock;
+				const PixIn<S, MODE> nxt = load_in(inext < N ? inext : N - 1, uz);
+				asm volatile("" ::: "memory");
+				row_compute(i, cur, tcur);
+				cur = nxt;
+			}
+		}
+		/* the partial last row of a target (only the workgroup that owns the end of the patch gets here) */
+		if (full < n_rows) {
+			const unsigned i = base + (unsigned)full * kBlock;
+			if (i < N) {
+				const PixIn<S, MODE> c = load_in(i, uz);
+				const Tex tc = issue_tex(c, uz);
+				row_compute(i, c, tc);
+			}
+		}
+	};
+	if (unit_z) run_rows(std::true_type{}); else run_rows(std::false_type{});
 #else
 		auto row_step = [&](int kk, const PixIn<S, MODE> &cur, const Tex &tcur, const PixIn<S, MODE> &nxt, Tex &tnxt,
 		PixIn<S, MODE> &nxt2) {
