@@ -1,0 +1,173 @@
+"""GPU: BASELINE.json's configurations at their FULL sizes, checked through size-independent properties
+(the oracle comparisons at sizes it finishes in seconds are in test_gpu_parity.py / test_gpu_trackers.py):
+zero residual at the identity, the fused sums against a float64 checksum of the materialised arrays, batch
+independence (a target inside a 64-wide batch gives the bits it gives alone), permutation / sharding
+equivariance of candidate scoring, convergence to a known synthetic warp."""
+import numpy as np
+import pytest
+
+import mtf_amd
+from mtf_amd import _lib as L
+from mtf_amd import synth
+from mtf_amd.sm import GridTracker, LKTracker, NTSearchMethod
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big_frames():
+    f0 = synth.make_frame(1024, 1024)
+    p_true = synth.random_small_homography(np.random.default_rng(77), 0.3)
+    return f0, synth.warp_frame(f0, p_true, (512.0, 512.0)), p_true
+
+
+def gt_corners(corners, p_true, centre=(512.0, 512.0)):
+    W = synth.homography_from_state(p_true)
+    c = np.asarray(centre)[:, None]
+    q = W @ np.vstack([corners - c, np.ones(corners.shape[1])])
+    return q[:2] / q[2] + c
+
+
+@pytest.mark.parametrize("chained", [1, 0])
+def test_config2_fclk_200x200_checksums(gpu_ctx, big_frames, chained):
+    """Config 2: FCLK + SSD + Homography, 200 x 200, both chained_warp settings."""
+    f0, f1, p_true = big_frames
+    corners = synth.square_corners(512, 512, 200)
+    gpu_ctx.set_image(f0)
+    b = mtf_amd.Batch(gpu_ctx, L.AM_SSD, L.SSM_HOMOGRAPHY, 200, 200, 1)
+    b.set_corners(corners[None])
+    sm = mtf_amd.sm_desc(L.SM_FCLK, chained_warp=chained, hess_type=1, materialize=1)
+    b.init_template(sm)
+    # same frame, identity warp: the residual is exactly zero, so are f and g; H is the negated Gram of J0
+    f, g, H = b.iterate(sm)
+    assert f[0] == 0.0 and np.all(g[0] == 0.0)
+    J = b.read(L.BUF_JT)[0]
+    np.testing.assert_array_equal(J, b.read(L.BUF_J0)[0])
+    np.testing.assert_allclose(H[0], -(J.T @ J), rtol=1e-12)
+    assert np.linalg.eigvalsh(H[0]).max() < 0
+    # next frame: the fused sums against float64 checksums of what the same launch materialised
+    gpu_ctx.set_image(f1)
+    f, g, H = b.iterate(sm)
+    It, I0, J = b.read(L.BUF_IT)[0], b.read(L.BUF_I0)[0], b.read(L.BUF_JT)[0]
+    r = It - I0
+    assert abs(f[0] + 0.5 * (r @ r)) <= 1e-12 * abs(f[0])
+    np.testing.assert_allclose(H[0], -(J.T @ J), rtol=1e-12)
+    np.testing.assert_allclose(g[0], -(r @ J), rtol=1e-9, atol=1e-12 * np.abs(J).max() * np.abs(r).sum())
+    # lean mode (nothing materialised) produces the same sums bit for bit
+    lean = mtf_amd.sm_desc(L.SM_FCLK, chained_warp=chained, hess_type=1, materialize=0)
+    f2, g2, H2 = b.iterate(lean)
+    assert f2[0] == f[0] and np.array_equal(g2, g) and np.array_equal(H2, H)
+    # and the loop converges on the known warp
+    trk = LKTracker(gpu_ctx, L.SM_FCLK, L.SSM_HOMOGRAPHY, 200, 200, 1, host_solve=False, chained_warp=chained,
+                    hess_type=1, max_iters=30, epsilon=1e-6)
+    gpu_ctx.set_image(f0); trk.initialize(corners[None]); gpu_ctx.set_image(f1)
+    out = trk.update()[0]
+    assert np.abs(out - gt_corners(corners, p_true)).max() < 0.05
+
+
+def test_headline_esm_200x200_batch_independence(gpu_ctx, big_frames):
+    """The metric's workload (ESM + SSD + Homography, 200 x 200, 64 targets per launch): every target of the batch
+    produces exactly the bits it produces alone, and lands on the ground-truth region."""
+    f0, f1, p_true = big_frames
+    B = 64
+    rng = np.random.default_rng(5)
+    cx = rng.uniform(250, 774, B); cy = rng.uniform(250, 774, B)
+    corners = np.stack([synth.square_corners(cx[i], cy[i], 200) for i in range(B)])
+    sm = mtf_amd.sm_desc(L.SM_ESM, materialize=1)
+    gpu_ctx.set_image(f0)
+    b = mtf_amd.Batch(gpu_ctx, L.AM_SSD, L.SSM_HOMOGRAPHY, 200, 200, B)
+    b.set_corners(corners); b.init_template(sm)
+    gpu_ctx.set_image(f1)
+    f, g, H = b.iterate(sm)
+    for t in (0, 17, 63):
+        gpu_ctx.set_image(f0)
+        s = mtf_amd.Batch(gpu_ctx, L.AM_SSD, L.SSM_HOMOGRAPHY, 200, 200, 1)
+        s.set_corners(corners[t][None]); s.init_template(sm)
+        gpu_ctx.set_image(f1)
+        fs, gs, Hs = s.iterate(sm)
+        # per-pixel results are identical; the work decomposition (hence the summation tree) depends on B
+        np.testing.assert_array_equal(s.read(L.BUF_JT)[0], b.read(L.BUF_JT)[t])
+        np.testing.assert_allclose(Hs[0], H[t], rtol=1e-12)
+        np.testing.assert_allclose(gs[0], g[t], rtol=1e-9, atol=1e-9 * np.abs(g[t]).max())
+        assert abs(fs[0] - f[t]) <= 1e-12 * abs(f[t])
+        s.close()
+    trk_sm = mtf_amd.sm_desc(L.SM_ESM, materialize=0, max_iters=30, epsilon=1e-6)
+    gpu_ctx.set_image(f0); b.set_corners(corners); b.init_template(trk_sm); gpu_ctx.set_image(f1)
+    n_it, out = b.track(trk_sm)
+    for t in range(B):
+        assert np.abs(out[t] - gt_corners(corners[t], p_true)).max() < 0.05, t
+    assert n_it.max() < 30
+
+
+def test_config3_grid_256_patches(gpu_ctx, big_frames):
+    """Config 3: 16 x 16 patches, ICLK + NCC + Affine 25 x 25, the whole patch loop in one launch."""
+    f0, f1, p_true = big_frames
+    region = synth.square_corners(512, 512, 400)
+    gpu_ctx.set_image(f0)
+    gt = GridTracker(gpu_ctx, grid_size=16, patch_size=25, am=L.AM_NCC, ssm=L.SSM_AFFINE, max_iters=30, epsilon=1e-4)
+    gt.initialize(region)
+    patches = gt.patch_corners(region)
+    assert patches.shape == (256, 2, 4)
+    gpu_ctx.set_image(f1)
+    corners, centroids = gt.update()
+    want = np.stack([gt_corners(patches[k], p_true).mean(axis=1) for k in range(256)])
+    err = np.abs(centroids - want).max(axis=1)
+    assert np.median(err) < 0.05 and (err < 0.5).mean() > 0.97
+    # idempotence: re-initialised on the same frame, a second update leaves every patch where it is
+    gpu_ctx.set_image(f0); gt.initialize(region)
+    c0, _ = gt.update()
+    np.testing.assert_allclose(c0, patches, atol=1e-6)
+
+
+def test_config4_pf_10000_candidates(gpu_ctx, big_frames):
+    """Config 4: 10 000 candidates x 2 500 px: permutation and sharding equivariance, identity candidate."""
+    f0, f1, _ = big_frames
+    rng = np.random.default_rng(9)
+    gpu_ctx.set_image(f0)
+    b = mtf_amd.Batch(gpu_ctx, L.AM_SSD, L.SSM_HOMOGRAPHY, 50, 50, 1)
+    b.set_corners(synth.square_corners(512, 512, 100)[None]); b.initialize_pix_vals(); b.initialize_similarity()
+    states = synth.pf_candidate_states(rng, 10000)
+    states[1234] = 0
+    lik, sim = b.score_candidates(states, want_similarity=True)
+    assert lik.shape == (10000,) and sim[1234] == 0.0 and lik[1234] == 1.0 and np.all(sim <= 0) and np.all(lik <= 1)
+    perm = rng.permutation(10000)
+    lik_p = b.score_candidates(states[perm])
+    assert np.array_equal(lik_p, lik[perm])                                   # a candidate's score does not depend on its slot
+    shards = np.concatenate([b.score_candidates(states[k * 1250:(k + 1) * 1250]) for k in range(8)])
+    assert np.array_equal(shards, lik)                                        # the 8-rank partition of dist.py gathers to the same vector
+    gpu_ctx.set_image(f1)
+    assert b.score_candidates(states[:100]).max() < 1.0
+
+
+def test_config5_mi_400x400_64_targets(gpu_ctx):
+    """Config 5: ESM + MI (8 bins) + Homography, 400 x 400, 64 concurrent targets on a 2048 x 2048 frame."""
+    f0 = synth.make_frame(2048, 2048)
+    p_true = synth.random_small_homography(np.random.default_rng(3), 0.2)
+    f1 = synth.warp_frame(f0, p_true, (1024.0, 1024.0))
+    B = 64
+    rng = np.random.default_rng(11)
+    cx = rng.uniform(450, 1600, B); cy = rng.uniform(450, 1600, B)
+    corners = np.stack([synth.square_corners(cx[i], cy[i], 400) for i in range(B)])
+    gpu_ctx.set_image(f0)
+    nt = NTSearchMethod(gpu_ctx, L.SM_ESM, L.AM_MI, L.SSM_HOMOGRAPHY, 400, 400, B, max_iters=4, epsilon=-1.0)
+    nt.initialize(corners)
+    H0 = nt.H0.copy()
+    for t in range(0, B, 9):
+        assert np.allclose(H0[t], H0[t].T, rtol=1e-9, atol=1e-9 * np.abs(H0[t]).max())
+        assert np.linalg.eigvalsh(0.5 * (H0[t] + H0[t].T)).max() < 0                 # MI is at its maximum on the template
+    gpu_ctx.set_image(f1)
+    nt.update()
+    f_first, f_last = nt.trace[0]["f"], nt.batch.get_similarity()
+    assert np.all(f_last > f_first)                                                   # every target's MI rises
+    want = np.stack([gt_corners(corners[t], p_true, (1024.0, 1024.0)) for t in range(B)])
+    before = np.abs(corners - want).max(axis=(1, 2)); after = np.abs(nt.get_region() - want).max(axis=(1, 2))
+    assert np.all(after < 0.5 * before)
+    # batch independence at full size: target 20 alone reproduces its first-iteration g and H
+    gpu_ctx.set_image(f0)
+    one = NTSearchMethod(gpu_ctx, L.SM_ESM, L.AM_MI, L.SSM_HOMOGRAPHY, 400, 400, 1, max_iters=1, epsilon=-1.0)
+    one.initialize(corners[20][None])
+    gpu_ctx.set_image(f1)
+    one.update()
+    np.testing.assert_allclose(one.trace[0]["H"][0], nt.trace[0]["H"][20], rtol=1e-10)
+    np.testing.assert_allclose(one.trace[0]["g"][0], nt.trace[0]["g"][20], rtol=1e-8, atol=1e-12)
+    assert abs(one.trace[0]["f"][0] - nt.trace[0]["f"][20]) <= 1e-12 * abs(nt.trace[0]["f"][20])
