@@ -115,6 +115,23 @@ void mtfhip_ctx_destroy(mtfhip_ctx *ctx); /* destroy every batch created on the 
 int mtfhip_ctx_synchronize(mtfhip_ctx *ctx);
 void *mtfhip_ctx_stream(mtfhip_ctx *ctx);
 
+/* Pre-processing on the device: what PreProcBase::processFrame + GaussianSmoothing::apply do with OpenCV for the default
+ * CV_32FC1 output (Utilities/include/mtf/Utilities/preprocUtils.h:20-73, Utilities/src/preprocUtils.cc:108-127):
+ * raw frame (uint8 or float32, 1 channel or 3 interleaved BGR) -> float32 -> gray (B*0.114f + G*0.587f + R*0.299f) ->
+ * GaussianBlur(ksize x ksize, sigma_x, sigma_y) with BORDER_REFLECT_101 -> the context's current image.  The frame crosses
+ * PCIe once, as it was captured (1 or 3 bytes per pixel instead of 4).  ksize 5 (the reference's default, sigma 3) or 0
+ * (no smoothing); hist_eq and resize_factor are not provided.  OpenCV itself is absent from this image: the arithmetic
+ * follows its float32 filter engine as restated in oracle/preproc_ref.py. */
+enum { MTFHIP_DEPTH_U8 = 0, MTFHIP_DEPTH_F32 = 1 };
+int mtfhip_image_preprocess(mtfhip_ctx *ctx, const void *host_raw, int rows, int cols, int row_stride_bytes, int channels,
+	int depth, int ksize, double sigma_x, double sigma_y);
+/* One level of PyramidalTracker's image pyramid (SM/src/PyramidalTracker.cc:88-97): dst's current image =
+ * cv::pyrDown(src's image) when use_pyr_down (scale_factor 0.5), else cv::resize(INTER_LINEAR) + GaussianBlur(5x5, 3). */
+int mtfhip_image_pyramid_level(mtfhip_ctx *dst, mtfhip_ctx *src, int dst_rows, int dst_cols, int use_pyr_down);
+/* read-back of the current image (PreProcBase::getFrame) and its shape */
+int mtfhip_image_download(mtfhip_ctx *ctx, float *host_img, int rows, int cols);
+int mtfhip_image_shape(mtfhip_ctx *ctx, int *rows, int *cols);
+
 /* ImageBase::setCurrImg (AM/src/ImageBase.cc:38-60).  The reference borrows the caller's
  * cv::Mat buffer, which the caller overwrites in place every frame, so upload must be
  * repeated per frame; `borrow` adopts a float32 image that is already in HBM. */

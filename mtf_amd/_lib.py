@@ -59,6 +59,7 @@ class SMDesc(C.Structure):
 SYMBOLS = [
     "mtfhip_last_error", "mtfhip_device_count", "mtfhip_ctx_create", "mtfhip_ctx_destroy",
     "mtfhip_ctx_synchronize", "mtfhip_ctx_stream", "mtfhip_image_upload", "mtfhip_image_borrow",
+    "mtfhip_image_preprocess", "mtfhip_image_pyramid_level", "mtfhip_image_download", "mtfhip_image_shape",
     "mtfhip_batch_create", "mtfhip_batch_destroy", "mtfhip_batch_n_targets", "mtfhip_batch_n_pix",
     "mtfhip_batch_state_size", "mtfhip_batch_read", "mtfhip_batch_write", "mtfhip_batch_device_ptr",
     "mtfhip_ssm_set_corners", "mtfhip_ssm_set_state", "mtfhip_ssm_compositional_update",
@@ -118,6 +119,11 @@ def lib():
         L.mtfhip_batch_create.argtypes = [C.c_void_p, C.POINTER(PatchDesc), C.c_int, C.POINTER(C.c_void_p)]
         L.mtfhip_image_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.mtfhip_image_borrow.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.mtfhip_image_preprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_double, C.c_double]
+        L.mtfhip_image_pyramid_level.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.mtfhip_image_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.mtfhip_image_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.mtfhip_ssm_update_grad_pts.argtypes = [C.c_void_p, C.c_double]
         L.mtfhip_ssm_update_hess_pts.argtypes = [C.c_void_p, C.c_double]
         for fn in ("mtfhip_am_initialize_pix_hess", "mtfhip_am_update_pix_hess"):

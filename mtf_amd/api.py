@@ -79,6 +79,34 @@ class Context:
             stride = img.shape[1]
         L.check(L.lib().mtfhip_image_upload(self._h, _p(img), img.shape[0], img.shape[1], stride))
 
+    def preprocess(self, raw, ksize=5, sigma_x=3.0, sigma_y=0.0):
+        """PreProcBase::update with GaussianSmoothing (preprocUtils.h:20-73): raw uint8 / float32 frame, H x W or
+        H x W x 3 (BGR) -> gray float32 -> Gaussian ksize x ksize -> the current image, all on the device."""
+        raw = np.asarray(raw)
+        if raw.dtype not in (np.uint8, np.float32) or raw.ndim not in (2, 3) or (raw.ndim == 3 and raw.shape[2] != 3):
+            raise L.InvalidArgument(-1, "PreProcBase::processFrame : Invalid input image type provided")
+        if not raw.flags["C_CONTIGUOUS"]:
+            raw = np.ascontiguousarray(raw)
+        ch = 1 if raw.ndim == 2 else 3
+        L.check(L.lib().mtfhip_image_preprocess(self._h, _p(raw), raw.shape[0], raw.shape[1], raw.strides[0], ch,
+                                                0 if raw.dtype == np.uint8 else 1, int(ksize), float(sigma_x), float(sigma_y)))
+
+    def pyramid_level_from(self, src, rows, cols, pyr_down=True):
+        """this context's image = one pyramid level below `src`'s (PyramidalTracker::updateImagePyramid)"""
+        L.check(L.lib().mtfhip_image_pyramid_level(self._h, src._h, int(rows), int(cols), 1 if pyr_down else 0))
+
+    def image_shape(self):
+        r, c = C.c_int(), C.c_int()
+        L.check(L.lib().mtfhip_image_shape(self._h, C.byref(r), C.byref(c)))
+        return r.value, c.value
+
+    def get_image(self):
+        """PreProcBase::getFrame: read-back of the current float32 image"""
+        r, c = self.image_shape()
+        out = np.empty((r, c), dtype=np.float32)
+        L.check(L.lib().mtfhip_image_download(self._h, _p(out), r, c))
+        return out
+
     def set_image_device(self, dev_ptr, height, width, row_stride=None, keep=None):
         """Adopt a float32 image already resident in HBM (e.g. a torch tensor's data_ptr())."""
         self._img_keep = keep

@@ -145,6 +145,8 @@ struct mtfhip_ctx {
 	ImgView img{nullptr, 0, 0, 0};
 	float *img_owned = nullptr;
 	size_t img_capacity = 0;
+	unsigned char *raw = nullptr; size_t raw_capacity = 0;      /* staging of the raw frame (pre-processing) */
+	float *tmp_a = nullptr, *tmp_b = nullptr; size_t tmp_capacity = 0; /* gray / row-pass intermediates */
 	bool timing = false;
 	int timing_stride = 1;   /* events are recorded around every timing_stride-th launch of a family */
 	std::map<std::string, Timer> timers;
@@ -331,6 +333,9 @@ void mtfhip_ctx_destroy(mtfhip_ctx *c) {
 			for (auto &p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
 		for (auto e : c->free_events) (void)hipEventDestroy(e);
 		if (c->img_owned) (void)hipFree(c->img_owned);
+		if (c->raw) (void)hipFree(c->raw);
+		if (c->tmp_a) (void)hipFree(c->tmp_a);
+		if (c->tmp_b) (void)hipFree(c->tmp_b);
 		if (c->own_stream) (void)hipStreamDestroy(c->stream);
 	} catch (...) {
 	}
@@ -366,6 +371,120 @@ int mtfhip_image_borrow(mtfhip_ctx *c, const float *dev_img, int height, int wid
 	if (!c || !dev_img) return fail(MTFHIP_ERR_INVALID_ARG, "image_borrow: NULL argument");
 	if (height <= 0 || width <= 0 || row_stride < width) return fail(MTFHIP_ERR_INVALID_ARG, "image_borrow: bad shape");
 	c->img = ImgView{dev_img, height, width, row_stride};
+	return MTFHIP_OK;
+}
+
+/* ------------------------------------------------------------------ pre-processing / pyramid */
+static int ensure_image(mtfhip_ctx *c, int rows, int cols) {
+	const size_t need = (size_t)rows * cols;
+	if (need > c->img_capacity) {
+		if (c->img_owned) HIP_TRY(hipFree(c->img_owned));
+		c->img_owned = nullptr;
+		HIP_TRY(hipMalloc(&c->img_owned, need * sizeof(float)));
+		c->img_capacity = need;
+	}
+	return MTFHIP_OK;
+}
+static int ensure_tmp(mtfhip_ctx *c, size_t need) {
+	if (need > c->tmp_capacity) {
+		if (c->tmp_a) HIP_TRY(hipFree(c->tmp_a));
+		if (c->tmp_b) HIP_TRY(hipFree(c->tmp_b));
+		c->tmp_a = c->tmp_b = nullptr;
+		HIP_TRY(hipMalloc(&c->tmp_a, need * sizeof(float)));
+		HIP_TRY(hipMalloc(&c->tmp_b, need * sizeof(float)));
+		c->tmp_capacity = need;
+	}
+	return MTFHIP_OK;
+}
+/* cv::getGaussianKernel(ksize, sigma, CV_32F) for sigma > 0: exp(-x^2 / (2 sigma^2)) rounded to float, normalised by the
+ * double sum of those floats; k[0] is the centre tap, k[1], k[2] the taps one and two samples out */
+static void gaussian5(double sigma, float k[3]) {
+	const double scale2x = -0.5 / (sigma * sigma);
+	float cf[5];
+	double sum = 0;
+	for (int i = 0; i < 5; ++i) { const double x = i - 2.0; cf[i] = (float)std::exp(scale2x * x * x); sum += cf[i]; }
+	sum = 1. / sum;
+	for (int i = 0; i < 5; ++i) cf[i] = (float)(cf[i] * sum);
+	k[0] = cf[2]; k[1] = cf[3]; k[2] = cf[4];
+}
+
+int mtfhip_image_preprocess(mtfhip_ctx *c, const void *host_raw, int rows, int cols, int row_stride_bytes, int channels, int depth,
+	int ksize, double sigma_x, double sigma_y) {
+	if (!c || !host_raw) return fail(MTFHIP_ERR_INVALID_ARG, "image_preprocess: NULL argument");
+	if (rows <= 0 || cols <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "image_preprocess: bad shape %dx%d", rows, cols);
+	if (channels != 1 && channels != 3) return fail(MTFHIP_ERR_INVALID_ARG, "image_preprocess: %d channels (1 or 3 expected)", channels);
+	if (depth != MTFHIP_DEPTH_U8 && depth != MTFHIP_DEPTH_F32) return fail(MTFHIP_ERR_INVALID_ARG, "PreProcBase::processFrame : Invalid input image depth provided: %d", depth);
+	const size_t px = (size_t)channels * (depth == MTFHIP_DEPTH_F32 ? 4 : 1);
+	if ((size_t)row_stride_bytes < px * cols) return fail(MTFHIP_ERR_INVALID_ARG, "image_preprocess: row stride %d shorter than a row", row_stride_bytes);
+	if (ksize != 0 && ksize != 5) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "image_preprocess: Gaussian kernel size %d (5, or 0 for no smoothing)", ksize);
+	if (ksize == 5 && sigma_x <= 0) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "image_preprocess: sigma <= 0 selects OpenCV's fixed kernel table, not available");
+	HIP_TRY(hipSetDevice(c->device));
+	const size_t raw_bytes = px * cols * rows;
+	if (raw_bytes > c->raw_capacity) {
+		if (c->raw) HIP_TRY(hipFree(c->raw));
+		c->raw = nullptr;
+		HIP_TRY(hipMalloc(&c->raw, raw_bytes));
+		c->raw_capacity = raw_bytes;
+	}
+	TRY(ensure_image(c, rows, cols));
+	TRY(ensure_tmp(c, (size_t)rows * cols));
+	HIP_TRY(hipMemcpy2DAsync(c->raw, px * cols, host_raw, (size_t)row_stride_bytes, px * cols, (size_t)rows, hipMemcpyHostToDevice, c->stream));
+	{
+		TimedScope ts(c, "preprocess");
+		if (ksize == 0) launch_to_gray(c->raw, rows, cols, px * cols, channels, depth == MTFHIP_DEPTH_F32, c->img_owned, c->stream);
+		else {
+			float kx[3], ky[3];
+			gaussian5(sigma_x, kx);
+			gaussian5(sigma_y > 0 ? sigma_y : sigma_x, ky);   /* sigma2 <= 0 -> sigma2 = sigma1 (createGaussianKernels) */
+			launch_to_gray(c->raw, rows, cols, px * cols, channels, depth == MTFHIP_DEPTH_F32, c->tmp_a, c->stream);
+			launch_sym5(c->tmp_a, c->tmp_b, c->img_owned, rows, cols, kx, ky, c->stream);
+		}
+	}
+	HIP_TRY(hipStreamSynchronize(c->stream)); /* the caller may reuse its frame buffer */
+	c->img = ImgView{c->img_owned, rows, cols, cols};
+	return MTFHIP_OK;
+}
+
+int mtfhip_image_pyramid_level(mtfhip_ctx *dst, mtfhip_ctx *src, int dst_rows, int dst_cols, int use_pyr_down) {
+	if (!dst || !src) return fail(MTFHIP_ERR_INVALID_ARG, "image_pyramid_level: NULL argument");
+	if (!src->img.data) return fail(MTFHIP_ERR_LOGIC, "image_pyramid_level: the source context has no image");
+	if (dst == src) return fail(MTFHIP_ERR_INVALID_ARG, "image_pyramid_level: source and destination contexts must differ");
+	if (dst->device != src->device) return fail(MTFHIP_ERR_INVALID_ARG, "image_pyramid_level: contexts live on different devices");
+	if (dst_rows <= 0 || dst_cols <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "image_pyramid_level: bad destination shape");
+	if (src->img.stride != src->img.w) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "image_pyramid_level: padded source rows");
+	const int sr = src->img.h, sc = src->img.w;
+	if (use_pyr_down && (std::abs(dst_cols * 2 - sc) > 2 || std::abs(dst_rows * 2 - sr) > 2))   /* cv::pyrDown's own assertion */
+		return fail(MTFHIP_ERR_INVALID_ARG, "pyrDown: destination %dx%d is not half of %dx%d", dst_rows, dst_cols, sr, sc);
+	HIP_TRY(hipSetDevice(dst->device));
+	HIP_TRY(hipStreamSynchronize(src->stream));
+	TRY(ensure_image(dst, dst_rows, dst_cols));
+	{
+		TimedScope ts(dst, "pyramid_level");
+		if (use_pyr_down) launch_pyr_down(src->img.data, sr, sc, dst->img_owned, dst_rows, dst_cols, dst->stream);
+		else {   /* cv::resize + GaussianBlur(5x5, 3), PyramidalTracker.cc:93-94 */
+			TRY(ensure_tmp(dst, (size_t)dst_rows * dst_cols));
+			float k[3];
+			gaussian5(3.0, k);
+			launch_resize_linear(src->img.data, sr, sc, dst->tmp_a, dst_rows, dst_cols, dst->stream);
+			launch_sym5(dst->tmp_a, dst->tmp_b, dst->img_owned, dst_rows, dst_cols, k, k, dst->stream);
+		}
+	}
+	dst->img = ImgView{dst->img_owned, dst_rows, dst_cols, dst_cols};
+	return MTFHIP_OK;
+}
+
+int mtfhip_image_download(mtfhip_ctx *c, float *host_img, int rows, int cols) {
+	if (!c || !host_img) return fail(MTFHIP_ERR_INVALID_ARG, "image_download: NULL argument");
+	if (!c->img.data) return fail(MTFHIP_ERR_LOGIC, "image_download: no current image");
+	if (rows != c->img.h || cols != c->img.w) return fail(MTFHIP_ERR_INVALID_ARG, "image_download: the image is %dx%d", c->img.h, c->img.w);
+	HIP_TRY(hipMemcpy2DAsync(host_img, (size_t)cols * sizeof(float), c->img.data, (size_t)c->img.stride * sizeof(float),
+		(size_t)cols * sizeof(float), (size_t)rows, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return MTFHIP_OK;
+}
+int mtfhip_image_shape(mtfhip_ctx *c, int *rows, int *cols) {
+	if (!c || !rows || !cols) return fail(MTFHIP_ERR_INVALID_ARG, "image_shape: NULL argument");
+	*rows = c->img.h; *cols = c->img.w;
 	return MTFHIP_OK;
 }
 

@@ -149,6 +149,11 @@ void launch_mean_planes(const double *a, const double *b, double *o, size_t n, h
 /* fused second-order term of the SSD Hessians, pixel-Hessian blocks in registers only; out[t][S*S] */
 void launch_second_order_ssd(const BatchView &bv, const ImgView &im, int term, int chained, int d0_variant, double grad_eps,
 	double hess_eps, double norm_mult, double norm_add, double *partials, int nblk, double *out, hipStream_t st);
+/* pre-processing / pyramid (float32 images) */
+void launch_to_gray(const void *raw, int rows, int cols, size_t stride_bytes, int channels, int depth_f32, float *out, hipStream_t st);
+void launch_sym5(const float *src, float *tmp, float *dst, int rows, int cols, const float kx[3], const float ky[3], hipStream_t st);
+void launch_pyr_down(const float *src, int srows, int scols, float *dst, int drows, int dcols, hipStream_t st);
+void launch_resize_linear(const float *src, int srows, int scols, float *dst, int drows, int dcols, hipStream_t st);
 /* NN dataset rows: features of C warped patches of target 0 (SSD: It, NCC: centred / normalised It) */
 void launch_sample_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C, double norm_mult,
 	double norm_add, double *dev_feat, hipStream_t st);

@@ -438,3 +438,57 @@ class NNDataset:
         d = ((self.features - np.asarray(feature)[None]) ** 2).sum(axis=1)
         k = int(np.argmin(d))
         return k, float(d[k])
+
+
+class PyramidalTracker:
+    """PyramidalTracker (SM/src/PyramidalTracker.cc): one tracker per pyramid level, coarse to fine.  Each level owns
+    a Context whose image is derived on the device from the level above (cv::pyrDown for scale_factor 0.5, else
+    resize + GaussianBlur), so a frame is uploaded once.  `make_tracker(ctx, level)` builds the per-level tracker
+    (anything with initialize / update / set_region / get_region over (1, 2, 4) corners, e.g. LKTracker)."""
+
+    def __init__(self, ctx0, make_tracker, no_of_levels=3, scale_factor=0.5):
+        from .api import Context
+        self.n, self.scale = no_of_levels, float(scale_factor)
+        self.ctxs = [ctx0] + [Context(ctx0.device) for _ in range(no_of_levels - 1)]
+        self.trackers = [make_tracker(c, k) for k, c in enumerate(self.ctxs)]
+        self.sizes = None
+        self.overall = self.scale ** (no_of_levels - 1)
+
+    def update_image_pyramid(self):
+        """PyramidalTracker::updateImagePyramid :88-97 (level sizes as in setImage :50-53)"""
+        if self.sizes is None:
+            r, c = self.ctxs[0].image_shape()
+            self.sizes = [(r, c)]
+            for _ in range(1, self.n):
+                r, c = int(r * self.scale), int(c * self.scale)
+                self.sizes.append((r, c))
+        for k in range(1, self.n):
+            self.ctxs[k].pyramid_level_from(self.ctxs[k - 1], self.sizes[k][0], self.sizes[k][1], pyr_down=(self.scale == 0.5))
+
+    def initialize(self, corners):
+        self.update_image_pyramid()
+        c = np.asarray(corners, dtype=np.float64).reshape(1, 2, 4).copy()
+        self.trackers[0].initialize(c)
+        for k in range(1, self.n):
+            c = c * self.scale
+            self.trackers[k].initialize(c)
+
+    def update(self):
+        """:117-131: coarsest level first, every finer level starts from the scaled-up result"""
+        self.update_image_pyramid()
+        self.trackers[-1].update()
+        for k in range(self.n - 2, -1, -1):
+            self.trackers[k].set_region(self.trackers[k + 1].get_region() / self.scale)
+            self.trackers[k].update()
+        self.trackers[-1].set_region(self.trackers[0].get_region() * self.overall)
+        return self.trackers[0].get_region()
+
+    def set_region(self, corners):
+        c = np.asarray(corners, dtype=np.float64).reshape(1, 2, 4).copy()
+        self.trackers[0].set_region(c)
+        for k in range(1, self.n):
+            c = c * self.scale
+            self.trackers[k].set_region(c)
+
+    def get_region(self):
+        return self.trackers[0].get_region()
