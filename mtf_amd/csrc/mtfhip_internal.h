@@ -70,6 +70,16 @@ inline int simple_blocks_per_target(int N) {
 	return nb < 1 ? 1 : nb;
 }
 
+/* device-side solve + compositional update + convergence test for mtfhip_batch_track */
+struct TrackState {
+	double *acc;        /* [B][ACC_COUNT] reduced accumulators of this iteration */
+	double *h0;         /* [B][64] constant (init) self Hessian, column-major, already negated sums */
+	double *corners;    /* [B][8] current corners */
+	double *init_corners_hm; /* [B][12] */
+	int *active;        /* [B] 1 while the target still iterates */
+	int *n_iters;       /* [B] */
+};
+
 struct FusedArgs {
 	int mode;          /* accumulation mode: 0 FCLK-type, 1 ESM-type, 2 ICLK-lite (see k_fused_ssd) */
 	int chained;
@@ -79,6 +89,11 @@ struct FusedArgs {
 	double grad_eps;
 	double norm_mult, norm_add;
 	const int *active; /* optional [B] mask: targets with 0 are skipped (device-side loop) */
+	/* last-workgroup-done epilogue (device-side loop): when `done` is set, the workgroup that completes a target's
+	 * partial rows also runs the finish (sum, solve, compositional update, convergence test) -- no second launch */
+	int *done;         /* [B] arrival counters, all zero between launches; NULL = no epilogue */
+	mtfhip_sm_desc sm;
+	TrackState ts;
 };
 
 /* ---- launchers (all asynchronous on `st`) ---- */
@@ -157,15 +172,6 @@ void launch_resize_linear(const float *src, int srows, int scols, float *dst, in
 /* NN dataset rows: features of C warped patches of target 0 (SSD: It, NCC: centred / normalised It) */
 void launch_sample_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C, double norm_mult,
 	double norm_add, double *dev_feat, hipStream_t st);
-/* device-side solve + compositional update + convergence test for mtfhip_batch_track */
-struct TrackState {
-	double *acc;        /* [B][ACC_COUNT] reduced accumulators of this iteration */
-	double *h0;         /* [B][64] constant (init) self Hessian, column-major, already negated sums */
-	double *corners;    /* [B][8] current corners */
-	double *init_corners_hm; /* [B][12] */
-	int *active;        /* [B] 1 while the target still iterates */
-	int *n_iters;       /* [B] */
-};
 /* whole ICLK loop in one launch, one workgroup per target (N <= 16 * kBlock); false if N is too large */
 constexpr int kIclkTrackMaxPix = 16 * kBlock;
 bool launch_iclk_track(const BatchView &bv, const ImgView &im, const mtfhip_sm_desc &sm, const TrackState &ts,

@@ -158,7 +158,7 @@ __device__ __forceinline__ constexpr int dup_mask() {
 }
 
 /* reduce K per-thread accumulators over the workgroup and write them to dst[0..K) */
-template <int K>
+template <int K, bool COHERENT = false>
 __device__ __forceinline__ void block_reduce_store(double *v, double *dst, double *lds /* [4][K] */) {
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	wave_halve<K, 32>(v, lane);
@@ -173,7 +173,9 @@ __device__ __forceinline__ void block_reduce_store(double *v, double *dst, doubl
 		double s = lds[threadIdx.x];
 #pragma unroll
 		for (int wv = 1; wv < kBlock / 64; ++wv) s += lds[wv * K + threadIdx.x];
-		dst[threadIdx.x] = s;
+		/* COHERENT: written through to the device coherence point (sc1), for readers on another XCD in the same launch */
+		if constexpr (COHERENT) __hip_atomic_store(&dst[threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		else dst[threadIdx.x] = s;
 	}
 }
 
@@ -1313,6 +1315,10 @@ struct Tex {
  * are consumed one iteration later, when everything older has long completed; each wave keeps two rows
  * of HBM reads plus one row of writes in flight.
  */
+template <bool COHERENT>
+__device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts,
+	const double *partials, int nblk, int t);
+
 template <int SSM, bool CHAINED, int MODE, bool MAT>
 __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchView bv, ImgView im, FusedArgs fa, double *partials, int nblk) {
 	constexpr int S = (SSM == MTFHIP_SSM_HOMOGRAPHY) ? 8 : 6;
@@ -1676,7 +1682,21 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 	}
 #endif
 	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * ACC_COUNT;
-	block_reduce_store<K>(acc, dst, lds);
+	if (!fa.done) { block_reduce_store<K>(acc, dst, lds); return; }
+	/* Last-workgroup-done epilogue.  The only data that crosses workgroups inside the launch are the partial rows and
+	 * the arrival counter; both are accessed with agent-scope (sc1) atomics, which are performed at the device
+	 * coherence point, so no L2 write-back / invalidate is needed (a __threadfence() per workgroup flushes the whole
+	 * XCD L2 and doubled the kernel time when tried).  Order: row stores -> vmcnt(0) -> workgroup barrier -> counter. */
+	block_reduce_store<K, true>(acc, dst, lds);
+	__shared__ int s_last;
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(&fa.done[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1);
+	__syncthreads();
+	if (s_last) {
+		finish_track_body<true>(bv, fa.sm, fa.ts, partials, nblk, t);
+		if (threadIdx.x == 0) __hip_atomic_store(&fa.done[t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
 }
 
 /* ===================================================================== */
@@ -1920,37 +1940,50 @@ __global__ __launch_bounds__(kBlock) void k_score_finish(const double *unit_sums
  *       definite, so no pivoting is needed (the reference uses Eigen's colPivHouseholderQr, NT/FCLK.cc:298),
  *   (4) the (inverse) compositional update and the corner-change test on lane 0
  *       (Homography.cc:73-92,109-114, Affine.cc:90-106,145-150, NT/FCLK.cc:314-339). */
-__global__ __launch_bounds__(64) void k_finish_track(BatchView bv, mtfhip_sm_desc sm, TrackState ts,
-	const double *partials, int nblk) {
+/* Body of the device-side finish, executed by the first wave of the calling workgroup (all threads of the workgroup
+ * must call it: it contains workgroup barriers).  COHERENT: the partial rows were written by OTHER workgroups of the
+ * same launch (last-workgroup-done epilogue of k_fused_ssd), possibly on another XCD whose L2 is not coherent with
+ * ours, so they are read with agent-scope atomic loads instead of plain ones. */
+template <bool COHERENT>
+__device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts,
+	const double *partials, int nblk, int t) {
 	__shared__ double acc_s[ACC_COUNT];
 	__shared__ double A[8][9];
 	__shared__ double dps[8];
 	__shared__ double h0s[64], Ws[9], crs[8], ics[12];
-	const int t = blockIdx.x, lane = threadIdx.x;
+	const int lane = threadIdx.x;
+	const bool wv0 = lane < 64;
 	if (!ts.active[t]) return;
 	const int S = bv.S;
+	int n_it_prev = 0;
 	/* every global operand of this target is requested up front, in parallel across the lanes: the rest
-	 * of the kernel runs out of LDS / registers (one memory round trip instead of a dozen dependent ones) */
-	h0s[lane] = ts.h0[(size_t)t * 64 + lane];
-	if (lane < 9) Ws[lane] = bv.warps[9 * t + lane];
-	if (lane < 8) crs[lane] = ts.corners[8 * t + lane];
-	if (lane < 12) ics[lane] = ts.init_corners_hm[12 * t + lane];
-	const int n_it_prev = ts.n_iters[t];
-	if (lane < ACC_COUNT) {
-		const double *p = partials + (size_t)t * nblk * ACC_COUNT + lane;
-		double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-		int b = 0;
-		for (; b + 3 < nblk; b += 4) {
-			s0 += p[(size_t)b * ACC_COUNT]; s1 += p[(size_t)(b + 1) * ACC_COUNT];
-			s2 += p[(size_t)(b + 2) * ACC_COUNT]; s3 += p[(size_t)(b + 3) * ACC_COUNT];
+	 * of the routine runs out of LDS / registers (one memory round trip instead of a dozen dependent ones) */
+	if (wv0) {
+		h0s[lane] = ts.h0[(size_t)t * 64 + lane];
+		if (lane < 9) Ws[lane] = bv.warps[9 * t + lane];
+		if (lane < 8) crs[lane] = ts.corners[8 * t + lane];
+		if (lane < 12) ics[lane] = ts.init_corners_hm[12 * t + lane];
+		n_it_prev = ts.n_iters[t];
+		if (lane < ACC_COUNT) {
+			const double *p = partials + (size_t)t * nblk * ACC_COUNT + lane;
+			auto ld = [&](size_t off) -> double {
+				if constexpr (COHERENT) return __hip_atomic_load(p + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				else return p[off];
+			};
+			double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+			int b = 0;
+			for (; b + 3 < nblk; b += 4) {
+				s0 += ld((size_t)b * ACC_COUNT); s1 += ld((size_t)(b + 1) * ACC_COUNT);
+				s2 += ld((size_t)(b + 2) * ACC_COUNT); s3 += ld((size_t)(b + 3) * ACC_COUNT);
+			}
+			for (; b < nblk; ++b) s0 += ld((size_t)b * ACC_COUNT);
+			const double s = (s0 + s1) + (s2 + s3);
+			acc_s[lane] = s;
+			ts.acc[(size_t)t * ACC_COUNT + lane] = s;
 		}
-		for (; b < nblk; ++b) s0 += p[(size_t)b * ACC_COUNT];
-		const double s = (s0 + s1) + (s2 + s3);
-		acc_s[lane] = s;
-		ts.acc[(size_t)t * ACC_COUNT + lane] = s;
 	}
 	__syncthreads();
-	const int i = lane >> 3, j = lane & 7;
+	const int i = (lane >> 3) & 7, j = lane & 7;
 	const bool use_h0 = (sm.hess_type == 0) || (sm.sm == MTFHIP_SM_ICLK);
 	const bool sum_h0 = (sm.sm == MTFHIP_SM_ESM) && (sm.hess_type == 2 || sm.hess_type == 4);
 	const double gscale = (sm.sm == MTFHIP_SM_ESM) ? 0.5 : 1.0;
@@ -1964,21 +1997,23 @@ __global__ __launch_bounds__(64) void k_finish_track(BatchView bv, mtfhip_sm_des
 	};
 	const double dii = h_entry(i, i), djj = h_entry(j, j);
 	const double si = dii != 0 ? 1.0 / sqrt(fabs(dii)) : 1.0, sj = djj != 0 ? 1.0 / sqrt(fabs(djj)) : 1.0;
-	A[i][j] = h_entry(i, j) * si * sj;
-	if (j == 0) A[i][8] = (i < S ? gscale * acc_s[ACC_G + i] : 0.0) * si;
+	if (wv0) {
+		A[i][j] = h_entry(i, j) * si * sj;
+		if (j == 0) A[i][8] = (i < S ? gscale * acc_s[ACC_G + i] : 0.0) * si;
+	}
 	__syncthreads();
 #pragma unroll
 	for (int k = 0; k < 8; ++k) {
 		const double piv = A[k][k], aik = A[i][k], akj = A[k][j], bk = A[k][8];
 		const double f = (i != k && piv != 0) ? aik / piv : 0.0;
 		__syncthreads();
-		if (i != k) {
+		if (wv0 && i != k) {
 			A[i][j] -= f * akj;
 			if (j == 0) A[i][8] -= f * bk;
 		}
 		__syncthreads();
 	}
-	if (j == 0) {
+	if (wv0 && j == 0) {
 		const double d = A[i][i];
 		dps[i] = (i < S && d != 0) ? -(A[i][8] / d) * si : 0.0;
 	}
@@ -2050,6 +2085,11 @@ __global__ __launch_bounds__(64) void k_finish_track(BatchView bv, mtfhip_sm_des
 	const int n_it = n_it_prev + 1;
 	ts.n_iters[t] = n_it;
 	if (change < sm.epsilon || n_it >= sm.max_iters) ts.active[t] = 0;
+}
+/* stand-alone finish: one wave per target */
+__global__ __launch_bounds__(64) void k_finish_track(BatchView bv, mtfhip_sm_desc sm, TrackState ts,
+	const double *partials, int nblk) {
+	finish_track_body<false>(bv, sm, ts, partials, nblk, blockIdx.x);
 }
 
 /* ===================================================================== */
