@@ -312,7 +312,10 @@ def main():
     if rank == 0:
         N = res * res
         bpp = algorithmic_bytes_per_pixel(args.sm, materialize)
-        bytes_per_launch = float(bpp) * N * B
+        per_launch = batch.track_targets_per_launch(sm)   # all B, or an Infinity-Cache sized chunk of them
+        if B % per_launch:                                 # a ragged last chunk would mix two launch sizes in the average
+            per_launch = B / float(-(-B // per_launch))
+        bytes_per_launch = float(bpp) * N * per_launch
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         out = {
             "metric": "LK iters/sec (warp+grad+Hessian), ESM+SSD+Homography 200x200",
@@ -329,7 +332,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.sm, args.mode, res, B),
                          "kernel": "k_fused_ssd", "avg_kernel_ms": kern_ms, "launches_timed": kern_n,
-                         "algorithmic_bytes_per_pixel": bpp, "bytes_per_launch": bytes_per_launch},
+                         "algorithmic_bytes_per_pixel": bpp, "bytes_per_launch": bytes_per_launch,
+                         "targets_per_launch": per_launch},
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, res, frame0, frame1, corners[0])

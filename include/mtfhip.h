@@ -232,6 +232,8 @@ int mtfhip_batch_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, d
  * convergence test included) without host round trips; returns per-target iteration counts
  * and final corners.  SM/src/NT/{ESM,FCLK,ICLK}.cc update(). */
 int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters /* B */, double *corners /* B x 8 */);
+/* how many targets one launch of the loop above covers (all of them, or an Infinity-Cache sized chunk) */
+int mtfhip_batch_track_targets_per_launch(mtfhip_batch *b, const mtfhip_sm_desc *sm);
 
 /* ---- candidate scoring (PF / NN batch axis): target 0's template, C warps ----
  * per candidate: setState -> updatePixVals -> updateSimilarity(false) -> getLikelihood

@@ -79,6 +79,7 @@ SYMBOLS = [
     "mtfhip_sm_mean_pix_hessian", "mtfhip_am_cmpt_init_hessian2", "mtfhip_am_cmpt_curr_hessian2",
     "mtfhip_am_cmpt_self_hessian2", "mtfhip_am_cmpt_sum_of_hessians2",
     "mtfhip_batch_init_template", "mtfhip_batch_iterate", "mtfhip_batch_track",
+    "mtfhip_batch_track_targets_per_launch",
     "mtfhip_score_candidates", "mtfhip_score_candidates_dev",
     "mtfhip_sample_candidates", "mtfhip_sample_candidates_dev",
     "mtfhip_timing_enable", "mtfhip_timing_reset", "mtfhip_timing_get",

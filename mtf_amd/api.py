@@ -396,6 +396,9 @@ class Batch:
     def init_template(self, sm):
         L.check(L.lib().mtfhip_batch_init_template(self._h, C.byref(sm)))
 
+    def track_targets_per_launch(self, sm):
+        return L.lib().mtfhip_batch_track_targets_per_launch(self._h, C.byref(sm))
+
     def iterate(self, sm):
         f = np.empty(self.B)
         g = np.empty((self.B, self.S))

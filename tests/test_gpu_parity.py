@@ -259,6 +259,16 @@ def test_device_side_loop_matches_oracle_tracker(oracle, gpu_ctx, frame, sm_kind
         iters = trk.update()
         np.testing.assert_allclose(final[t], trk.get_region(), rtol=0, atol=2e-4)
         assert abs(int(n_it[t]) - iters) <= 1
+    # target chunking (all iterations of 2 targets, then the next 2, ...) changes the schedule, not the result
+    import os
+    os.environ["MTFHIP_TRACK_CHUNK_PX"] = str(2 * res * res)
+    try:
+        gpu_ctx.set_image(frame); b.set_corners(corners); b.init_template(sm); gpu_ctx.set_image(frame2)
+        n_it2, final2 = b.track(sm)
+    finally:
+        del os.environ["MTFHIP_TRACK_CHUNK_PX"]
+    np.testing.assert_allclose(final2, final, rtol=0, atol=1e-7)
+    assert np.array_equal(n_it2, n_it)
 
 
 def test_pf_candidate_scores(oracle, gpu_ctx, frame):
