@@ -962,9 +962,17 @@ static int mi_read_f(mtfhip_batch *b) {
 	for (int t = 0; t < b->B; ++t) b->th[t].f = f[t];
 	return MTFHIP_OK;
 }
+/* workgroups per target for the MI histogram / Hessian passes: enough to fill the chip (~4 per CU over the batch), few
+ * enough that every wave amortises its register-resident bin accumulators over many 64-pixel chunks and that the
+ * fixed-order finish has short columns to add */
+static int mi_blocks(const mtfhip_batch *b) {
+	int nb = 1024 / b->B;
+	if (nb < 1) nb = 1;
+	return std::min(nb, simple_blocks_per_target(b->N));
+}
 /* mode 0 initialise (A = B = I0), 1 update (A = It, B = I0), 2 self (A = B = It) */
 static int mi_hist_pass(mtfhip_batch *b, int mode, int first_init) {
-	const int nb = b->desc.mi_n_bins, nblk = simple_blocks_per_target(b->N);
+	const int nb = b->desc.mi_n_bins, nblk = mi_blocks(b);
 	const double *A = b->buf[mode == 0 ? MTFHIP_BUF_I0 : MTFHIP_BUF_IT];
 	const double *Bv = b->buf[mode == 2 ? MTFHIP_BUF_IT : MTFHIP_BUF_I0];
 	TimedScope ts(b->ctx, "mi_hist");
@@ -975,7 +983,7 @@ static int mi_hist_pass(mtfhip_batch *b, int mode, int first_init) {
 }
 /* kind 0 init (MI.cc:461-513), 1 curr (:603-637), 2 self (:515-601, the returned second pass) */
 static int mi_hessian(mtfhip_batch *b, int j_buf, int kind, double *H) {
-	const int nb = b->desc.mi_n_bins, nblk = simple_blocks_per_target(b->N), S = b->S;
+	const int nb = b->desc.mi_n_bins, nblk = mi_blocks(b), S = b->S;
 	if (kind == 2) TRY(mi_hist_pass(b, 2, 0));   /* cmptSelfHist MI.cc:639-659 */
 	const double *A = b->buf[kind == 0 ? MTFHIP_BUF_I0 : MTFHIP_BUF_IT];
 	const double *Bv = b->buf[kind == 1 ? MTFHIP_BUF_I0 : MTFHIP_BUF_IT];

@@ -1035,26 +1035,82 @@ __device__ __forceinline__ BsplWin bspl_window(double v, int nb, double norm_mul
 __device__ __forceinline__ void lds_add(double *p, double v) {
 	__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+/* ---------------------------------------------------------------------------------------------
+ * Bin-owner accumulation.  MI's histograms and the `joint_hist_jacobian` rows are scatter-adds whose targets are
+ * decided by pixel intensities; neighbouring pixels hit the same few bins, so LDS atomics serialise almost
+ * completely inside a wave (the first version: 682 us for one Hessian of 8 x 160 000 px).  Here the roles are
+ * swapped per 64-pixel chunk: in "pixel mode" lane p evaluates pixel p's B-spline windows and writes them as DENSE
+ * n_bins vectors to the wave's LDS slab; in "bin mode" lane q owns the bin pair (r, c) = (q / nb, q % nb) and walks
+ * the 64 staged pixels, accumulating in registers.  No atomics, no conflicts (lanes with equal r read one address:
+ * a broadcast), deterministic sums.  pairs per lane = ceil(nb^2 / 64): 1 for the reference's 8 bins, 4 for 16.
+ * ------------------------------------------------------------------------------------------- */
+constexpr int kMiPairs = (MI_NB * MI_NB + 63) / 64;
+constexpr int kMiRow = 65;
+
 /* histogram of A and joint histogram A x B (MI.cc:222-235 init, :245-252 init joint, :352-367 update,
  * :641-649 self).  Block partial rows: [nb hist | nb*nb joint] */
 __global__ __launch_bounds__(kBlock) void k_mi_hist(int N, int nb, double norm_mult, const double *A_all,
 	const double *B_all, double *partials, int nblk, int row_len) {
-	__shared__ double sh[MI_NB + MI_NB * MI_NB];
+	extern __shared__ __attribute__((aligned(16))) double dyn[];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	/* slabs are bin-major with rows of kMiRow = 65 doubles: pixel-mode lanes write consecutive words, bin-mode lanes
+	 * (different r, same p) land in different banks */
+	double *wa = dyn + (size_t)wave * 2 * nb * kMiRow;  /* [nb][65] dense A weights of this wave's chunk */
+	double *wb = wa + nb * kMiRow;                      /* [nb][65] dense B weights */
 	const int t = blockIdx.y;
 	const double *A = A_all + (size_t)t * N, *Bv = B_all + (size_t)t * N;
-	for (int k = threadIdx.x; k < nb + nb * nb; k += kBlock) sh[k] = 0.0;
-	__syncthreads();
-	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += nblk * kBlock) {
-		const BsplWin a = bspl_window(A[i], nb, norm_mult, false);
-		const BsplWin b = bspl_window(Bv[i], nb, norm_mult, false);
-		for (int r = 0; r < a.n; ++r) {
-			lds_add(&sh[a.lo + r], a.w[r]);
-			for (int c = 0; c < b.n; ++c) lds_add(&sh[nb + (a.lo + r) * nb + b.lo + c], a.w[r] * b.w[c]);
+	double accj[kMiPairs], acch = 0.0;
+#pragma unroll
+	for (int m = 0; m < kMiPairs; ++m) accj[m] = 0.0;
+	int pr[kMiPairs], pc[kMiPairs];
+#pragma unroll
+	for (int m = 0; m < kMiPairs; ++m) { const int q = lane + 64 * m; pr[m] = q < nb * nb ? q / nb : -1; pc[m] = q < nb * nb ? q % nb : 0; }
+	for (int base = (blockIdx.x * (kBlock / 64) + wave) * 64; base < N; base += nblk * kBlock) {
+		const int i = base + lane;
+		for (int k2 = 0; k2 < nb; ++k2) { wa[k2 * kMiRow + lane] = 0.0; wb[k2 * kMiRow + lane] = 0.0; }
+		if (i < N) {
+			const BsplWin a = bspl_window(A[i], nb, norm_mult, false);
+			const BsplWin b = bspl_window(Bv[i], nb, norm_mult, false);
+			/* static indices only: a runtime-indexed window array would live in scratch memory */
+#pragma unroll
+			for (int r = 0; r < 4; ++r) if (r < a.n) wa[(a.lo + r) * kMiRow + lane] = a.w[r];
+#pragma unroll
+			for (int c = 0; c < 4; ++c) if (c < b.n) wb[(b.lo + c) * kMiRow + lane] = b.w[c];
 		}
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll 8
+		for (int p = 0; p < 64; ++p) {
+#pragma unroll
+			for (int m = 0; m < kMiPairs; ++m)
+				if (pr[m] >= 0) accj[m] = fma(wa[pr[m] * kMiRow + p], wb[pc[m] * kMiRow + p], accj[m]);
+			if (lane < nb) acch += wa[lane * kMiRow + p];
+		}
+		__builtin_amdgcn_wave_barrier();
 	}
+	/* four waves -> one partial row per workgroup */
+	__syncthreads();
+	double *red = dyn;                                  /* [4][nb + nb*nb], the slabs are free now */
+	const int rl = nb + nb * nb;
+	if (lane < nb) red[wave * rl + lane] = acch;
+#pragma unroll
+	for (int m = 0; m < kMiPairs; ++m)
+		if (pr[m] >= 0) red[wave * rl + nb + pr[m] * nb + pc[m]] = accj[m];
 	__syncthreads();
 	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * row_len;
-	for (int k = threadIdx.x; k < nb + nb * nb; k += kBlock) dst[k] = sh[k];
+	for (int k2 = threadIdx.x; k2 < rl; k2 += kBlock) dst[k2] = (red[k2] + red[rl + k2]) + (red[2 * rl + k2] + red[3 * rl + k2]);
+}
+/* fixed-order sum of one column of the block rows, eight loads in flight */
+__device__ __forceinline__ double column_sum(const double *col, int nblk, int row_len) {
+	double s[8];
+#pragma unroll
+	for (int u = 0; u < 8; ++u) s[u] = 0.0;
+	int b = 0;
+	for (; b + 7 < nblk; b += 8) {
+#pragma unroll
+		for (int u = 0; u < 8; ++u) s[u] += col[(size_t)(b + u) * row_len];
+	}
+	for (; b < nblk; ++b) s[0] += col[(size_t)b * row_len];
+	return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 /* sums the block rows, applies pre-seeding and normalisation, logs, similarity and the gradient-factor
  * table of the requested flavour (MI.cc:237-262, 369-381, 310-314, 399-403, 427-431, 651-658).
@@ -1067,8 +1123,7 @@ __global__ __launch_bounds__(kBlock) void k_mi_hist_finish(int nb, double pre_se
 	const double *p = partials + (size_t)t * nblk * row_len;
 	const double hist_seed = nb * pre_seed;
 	for (int k = threadIdx.x; k < nb + nb * nb; k += kBlock) {
-		double s = 0;
-		for (int b = 0; b < nblk; ++b) s += p[(size_t)b * row_len + k];
+		const double s = column_sum(p + k, nblk, row_len);
 		if (k < nb) {
 			const double hv = (s + hist_seed) * norm_mult;
 			if (mode == 0) { tb[MI_HIST_INIT + k] = hv; tb[MI_LOG_INIT + k] = log(hv); if (first_init) { tb[MI_HIST_CURR + k] = hv; tb[MI_LOG_CURR + k] = log(hv); } }
@@ -1129,8 +1184,11 @@ __global__ __launch_bounds__(kBlock) void k_mi_grad(int N, int nb, double norm_m
 		const BsplWin a = bspl_window(A[i], nb, norm_mult, false);
 		const BsplWin b = bspl_window(Bv[i], nb, norm_mult, false);
 		double acc = 0;
-		for (int r = 0; r < a.n; ++r)
-			for (int c = 0; c < b.n; ++c) acc += a.d[r] * b.w[c] * T[(a.lo + r) * MI_NB + b.lo + c];
+#pragma unroll
+		for (int r = 0; r < 4; ++r)
+#pragma unroll
+			for (int c = 0; c < 4; ++c)
+				if (r < a.n && c < b.n) acc += a.d[r] * b.w[c] * T[(a.lo + r) * MI_NB + b.lo + c];
 		out[i] = acc;
 	}
 }
@@ -1142,52 +1200,103 @@ __global__ __launch_bounds__(kBlock) void k_mi_hess(int N, int S, int nb, double
 	const double *B_all, const double *tb_all, int table_off, int transpose_q, const double *J_all,
 	double *partials, int nblk, int row_len) {
 	extern __shared__ __attribute__((aligned(16))) double dyn[];
-	double *T = dyn;                       /* MI_NB*MI_NB */
-	double *Q = dyn + MI_NB * MI_NB;       /* nb*nb*S */
-	double *red = Q + nb * nb * S;         /* 4 * 36 */
+	double *T = dyn;                                    /* MI_NB*MI_NB gradient-factor table */
+	double *red = dyn + MI_NB * MI_NB;                  /* 4 * 36 */
+	double *slabs = red + 4 * 36;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int slab = kMiRow * (2 * nb + kMaxS);
+	double *gd = slabs + (size_t)wave * slab;           /* [nb][65] dense curr_hist_grad-type vector of A */
+	double *wd = gd + nb * kMiRow;                      /* [nb][65] dense weights of B */
+	double *rw = wd + nb * kMiRow;                      /* [kMaxS][65] J rows */
 	const int t = blockIdx.y;
 	const double *tb = tb_all + (size_t)t * MI_SIZE + table_off;
-	for (int k = threadIdx.x; k < MI_NB * MI_NB; k += kBlock) T[k] = tb[k];
-	for (int k = threadIdx.x; k < nb * nb * S; k += kBlock) Q[k] = 0.0;
+	for (int k2 = threadIdx.x; k2 < MI_NB * MI_NB; k2 += kBlock) T[k2] = tb[k2];
 	__syncthreads();
 	const double *A = A_all + (size_t)t * N, *Bv = B_all + (size_t)t * N;
 	const double *J = J_all + (size_t)t * N * S;
 	double acc[36];
 #pragma unroll
-	for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += nblk * kBlock) {
-		const BsplWin a = bspl_window(A[i], nb, norm_mult, true);
-		const BsplWin b = bspl_window(Bv[i], nb, norm_mult, false);
+	for (int k2 = 0; k2 < 36; ++k2) acc[k2] = 0.0;
+	double accq[kMiPairs][kMaxS];
+	int pr[kMiPairs], pc[kMiPairs];
+#pragma unroll
+	for (int m = 0; m < kMiPairs; ++m) {
+		const int q = lane + 64 * m;
+		pr[m] = q < nb * nb ? q / nb : -1; pc[m] = q < nb * nb ? q % nb : 0;
+#pragma unroll
+		for (int s = 0; s < kMaxS; ++s) accq[m][s] = 0.0;
+	}
+	for (int base = (blockIdx.x * (kBlock / 64) + wave) * 64; base < N; base += nblk * kBlock) {
+		const int i = base + lane;
+		for (int k2 = 0; k2 < nb; ++k2) { gd[k2 * kMiRow + lane] = 0.0; wd[k2 * kMiRow + lane] = 0.0; }
 		double row[kMaxS];
 #pragma unroll
-		for (int s = 0; s < kMaxS; ++s) row[s] = s < S ? J[(size_t)s * N + i] : 0.0;
-		double hess_term = 0;
-		for (int r = 0; r < a.n; ++r) {
-			double inner = 0;
-			for (int c = 0; c < b.n; ++c) {
-				const int rr = a.lo + r, cc = b.lo + c;
-				const double gr = a.d[r] * b.w[c];
-				double *q = Q + (size_t)((transpose_q ? cc * nb + rr : rr * nb + cc)) * S;
-				for (int s = 0; s < S; ++s) lds_add(&q[s], gr * row[s]);
-				inner += b.w[c] * T[rr * MI_NB + cc];
+		for (int s = 0; s < kMaxS; ++s) row[s] = 0.0;
+		if (i < N) {
+			/* pixel mode: windows, the scalar hess_term and its rank-1 contribution (MI.cc:478-496, 574-583, 620-629) */
+			const BsplWin a = bspl_window(A[i], nb, norm_mult, true);
+			const BsplWin b = bspl_window(Bv[i], nb, norm_mult, false);
+#pragma unroll
+			for (int s = 0; s < kMaxS; ++s) row[s] = s < S ? J[(size_t)s * N + i] : 0.0;
+			double hess_term = 0;
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				if (r < a.n) {
+					double inner = 0;
+#pragma unroll
+					for (int c = 0; c < 4; ++c) if (c < b.n) inner += b.w[c] * T[(a.lo + r) * MI_NB + b.lo + c];
+					hess_term += a.h[r] * inner;
+					gd[(a.lo + r) * kMiRow + lane] = a.d[r];
+				}
 			}
-			hess_term += a.h[r] * inner;
-		}
-		int k = 0;
 #pragma unroll
-		for (int x = 0; x < kMaxS; ++x) {
-			const double hx = hess_term * row[x];
+			for (int c = 0; c < 4; ++c) if (c < b.n) wd[(b.lo + c) * kMiRow + lane] = b.w[c];
+			int k2 = 0;
 #pragma unroll
-			for (int y = x; y < kMaxS; ++y) { acc[k] = fma(hx, row[y], acc[k]); ++k; }
+			for (int x = 0; x < kMaxS; ++x) {
+				const double hx = hess_term * row[x];
+#pragma unroll
+				for (int y = x; y < kMaxS; ++y) { acc[k2] = fma(hx, row[y], acc[k2]); ++k2; }
+			}
 		}
+#pragma unroll
+		for (int s = 0; s < kMaxS; ++s) rw[s * kMiRow + lane] = row[s];
+		__builtin_amdgcn_wave_barrier();
+		/* bin mode: joint_hist_jacobian.row(r, c) += grad(r, p) * mat(c, p) * J.row(p)  (MI.cc:484-486, 576-577, 622-623) */
+#pragma unroll 4
+		for (int p = 0; p < 64; ++p) {
+			double jr[kMaxS];
+#pragma unroll
+			for (int s = 0; s < kMaxS; ++s) jr[s] = rw[s * kMiRow + p];
+#pragma unroll
+			for (int m = 0; m < kMiPairs; ++m) {
+				if (pr[m] >= 0) {
+					const double gr = gd[pr[m] * kMiRow + p] * wd[pc[m] * kMiRow + p];
+#pragma unroll
+					for (int s = 0; s < kMaxS; ++s) accq[m][s] = fma(gr, jr[s], accq[m][s]);
+				}
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
 	}
 	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * row_len;
 	block_reduce_store<36>(acc, dst, red);
 	__syncthreads();
-	for (int k = threadIdx.x; k < nb * nb * S; k += kBlock) dst[36 + k] = Q[k];
+	/* the four waves' Q blocks through the (now free) slabs: [4][nb*nb*S], indexed as the finish expects */
+	double *qred = slabs;
+	const int ql = nb * nb * S;
+#pragma unroll
+	for (int m = 0; m < kMiPairs; ++m) {
+		if (pr[m] >= 0) {
+			const int row_idx = transpose_q ? pc[m] * nb + pr[m] : pr[m] * nb + pc[m];
+#pragma unroll
+			for (int s = 0; s < kMaxS; ++s) if (s < S) qred[wave * ql + row_idx * S + s] = accq[m][s];
+		}
+	}
+	__syncthreads();
+	for (int k2 = threadIdx.x; k2 < ql; k2 += kBlock)
+		dst[36 + k2] = (qred[k2] + qred[ql + k2]) + (qred[2 * ql + k2] + qred[3 * ql + k2]);
 }
-/* H = Hsum + sum_k factor_k Q_k^T Q_k,  factor(r,c) = 1/joint_used(r,c) - 1/histA(r)
- * (MI.cc:505-511, 592-598, 629-635); writes H column-major S x S into out[t][64] */
 __global__ __launch_bounds__(kBlock) void k_mi_hess_finish(int S, int nb, const double *partials, int nblk, int row_len,
 	const double *tb_all, int joint_off, int hist_off, int transpose_q, double *out) {
 	extern __shared__ __attribute__((aligned(16))) double dyn[];
@@ -1197,8 +1306,7 @@ __global__ __launch_bounds__(kBlock) void k_mi_hess_finish(int S, int nb, const 
 	const double *p = partials + (size_t)t * nblk * row_len;
 	const double *tb = tb_all + (size_t)t * MI_SIZE;
 	for (int k = threadIdx.x; k < 36 + nb * nb * S; k += kBlock) {
-		double s = 0;
-		for (int b = 0; b < nblk; ++b) s += p[(size_t)b * row_len + k];
+		const double s = column_sum(p + k, nblk, row_len);
 		if (k < 36) Hs[k] = s; else Q[k - 36] = s;
 	}
 	__syncthreads();
@@ -2433,7 +2541,9 @@ void launch_ncc_hess(const BatchView &bv, const double *sc, const double *colmea
 }
 void launch_mi_hist(const BatchView &bv, int nb, double norm_mult, const double *A, const double *Bv, double *partials,
 	int nblk, int row_len, hipStream_t st) {
-	hipLaunchKernelGGL(k_mi_hist, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv.N, nb, norm_mult, A, Bv, partials, nblk, row_len);
+	/* per-wave staging slabs [64][2 nb]; the same LDS later holds the four waves' [nb + nb^2] rows */
+	const size_t lds = sizeof(double) * std::max<size_t>((size_t)4 * kMiRow * 2 * nb, (size_t)4 * (nb + nb * nb));
+	hipLaunchKernelGGL(k_mi_hist, grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, nb, norm_mult, A, Bv, partials, nblk, row_len);
 }
 void launch_mi_hist_finish(const BatchView &bv, int nb, double pre_seed, double norm_mult, int mode, int first_init,
 	const double *partials, int nblk, int row_len, double *tb, double *f_out, hipStream_t st) {
@@ -2450,7 +2560,13 @@ void launch_mi_grad(const BatchView &bv, int nb, double norm_mult, const double 
 }
 void launch_mi_hess(const BatchView &bv, int nb, double norm_mult, const double *A, const double *Bv, const double *tb,
 	int table_off, int transpose_q, const double *J, double *partials, int nblk, int row_len, hipStream_t st) {
-	size_t lds = sizeof(double) * (MI_NB * MI_NB + (size_t)nb * nb * bv.S + 4 * 36);
+	const size_t slabs = std::max<size_t>((size_t)4 * kMiRow * (2 * nb + kMaxS), (size_t)4 * nb * nb * bv.S);
+	const size_t lds = sizeof(double) * (MI_NB * MI_NB + 4 * 36 + slabs);
+	static bool attr_set = false;
+	if (!attr_set) {   /* 16 bins need 82 KB of dynamic LDS; the default cap is 64 KB */
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_mi_hess), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		attr_set = true;
+	}
 	hipLaunchKernelGGL(k_mi_hess, grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, bv.S, nb, norm_mult, A, Bv, tb, table_off,
 		transpose_q, J, partials, nblk, row_len);
 }
