@@ -766,23 +766,19 @@ __global__ __launch_bounds__(kBlock) void k_second_order_ssd(BatchView bv, ImgVi
 			}
 			pix_hessian_block<SSM>(d2, chained ? MTFHIP_JAC_WARPED : MTFHIP_JAC_INIT, W, st, p0.x, p0.y, c.x, c.y, D, hxx, hxy, hxy, hyy, gx, gy);
 		}
-		if (term == 0) {
+		/* one block live at a time (acc + d2 + d0 together would not fit the register file):
+		 * r (D0 + Dt) = r Dt + r D0 and -r (D0 + Dt) / 2 = (-r / 2) Dt + (-r / 2) D0, equal to the reference's order to round-off */
+		const double wt = term == 0 ? -r : (term == 1 ? r : (term == 2 ? -r / 2.0 : 0.0));
+		const double w0 = term == 1 ? r : (term == 2 ? -r / 2.0 : (term == 3 ? r : 0.0));
+		if (term != 3) {
 #pragma unroll
-			for (int k = 0; k < S * S; ++k) acc[k] = fma(-r, d2[k], acc[k]);
-		} else {
+			for (int k = 0; k < S * S; ++k) acc[k] = fma(wt, d2[k], acc[k]);
+		}
+		if (term != 0) {
 			const double2 ma = h0[2 * i], mb = h0[2 * i + 1];
-			double d0[S * S];
-			pix_hessian_block<SSM>(d0, d0_variant, Wid, st0, p0.x, p0.y, p0.x, p0.y, 1.0, ma.x, ma.y, mb.x, mb.y, g0[i], g0[N + i]);
-			if (term == 1) {
+			pix_hessian_block<SSM>(d2, d0_variant, Wid, st0, p0.x, p0.y, p0.x, p0.y, 1.0, ma.x, ma.y, mb.x, mb.y, g0[i], g0[N + i]);
 #pragma unroll
-				for (int k = 0; k < S * S; ++k) acc[k] = fma(r, d0[k] + d2[k], acc[k]);
-			} else if (term == 2) {
-#pragma unroll
-				for (int k = 0; k < S * S; ++k) acc[k] = fma(-r, (d0[k] + d2[k]) / 2.0, acc[k]);
-			} else {
-#pragma unroll
-				for (int k = 0; k < S * S; ++k) acc[k] = fma(r, d0[k], acc[k]);
-			}
+			for (int k = 0; k < S * S; ++k) acc[k] = fma(w0, d2[k], acc[k]);
 		}
 	}
 	block_reduce_store<S * S>(acc, partials + ((size_t)t * nblk + blockIdx.x) * (S * S), lds);
