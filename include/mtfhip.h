@@ -87,6 +87,9 @@ typedef struct mtfhip_patch_desc {
 	double mi_pre_seed;     /* MIParams::pre_seed */
 	int mi_partition_of_unity;
 	double hess_eps;        /* ImgParams::hess_eps (1, AM/include/mtf/AM/ImageBase.h:9); <= 0 selects that default */
+	int n_channels;         /* 1 (or 0): SSD / NCC / MI ; 3: MCSSD / MCNCC / MCMI (AM/src/MCSSD.cc, MCNCC.cc, MCMI.cc: the same class
+	                           built with n_channels = 3).  Every per-pixel AM array then has n_pix * 3 rows interleaved per pixel,
+	                           the image is CV_32FC3 (mtfhip_image_upload_mc), and only the per-function entry points apply */
 } mtfhip_patch_desc;
 
 /* Search-method configuration; field meanings and enum values are the reference's
@@ -136,13 +139,16 @@ int mtfhip_image_shape(mtfhip_ctx *ctx, int *rows, int *cols);
  * cv::Mat buffer, which the caller overwrites in place every frame, so upload must be
  * repeated per frame; `borrow` adopts a float32 image that is already in HBM. */
 int mtfhip_image_upload(mtfhip_ctx *ctx, const float *host_img, int height, int width, int row_stride);
+/* CV_32FC3 input of the multi-channel appearance models: `channels` (1 or 3) interleaved floats per pixel, row_stride in floats */
+int mtfhip_image_upload_mc(mtfhip_ctx *ctx, const float *host_img, int height, int width, int row_stride, int channels);
 int mtfhip_image_borrow(mtfhip_ctx *ctx, const float *dev_img, int height, int width, int row_stride);
 
 /* ------------------------------------------------------------------ batch of targets */
 int mtfhip_batch_create(mtfhip_ctx *ctx, const mtfhip_patch_desc *desc, int n_targets, mtfhip_batch **out);
 void mtfhip_batch_destroy(mtfhip_batch *b);
 int mtfhip_batch_n_targets(const mtfhip_batch *b);
-int mtfhip_batch_n_pix(const mtfhip_batch *b);
+int mtfhip_batch_n_pix(const mtfhip_batch *b);       /* ImageBase::getNPix: sample points per target */
+int mtfhip_batch_patch_size(const mtfhip_batch *b);  /* ImageBase::getPatchSize: n_pix * n_channels rows */
 int mtfhip_batch_state_size(const mtfhip_batch *b);
 /* lazy read-back / overwrite of a device buffer (all targets, target-major);
  * the getters of ImageBase.h:83-89 / setters :93-100 and StateSpaceModel.h:82-88 */

@@ -45,7 +45,8 @@ _ERR = {-1: InvalidArgument, -2: FunctionNotImplemented, -3: LogicError}
 class PatchDesc(C.Structure):
     _fields_ = [("am", C.c_int), ("ssm", C.c_int), ("resx", C.c_int), ("resy", C.c_int),
                 ("grad_eps", C.c_double), ("likelihood_alpha", C.c_double), ("mi_n_bins", C.c_int),
-                ("mi_pre_seed", C.c_double), ("mi_partition_of_unity", C.c_int), ("hess_eps", C.c_double)]
+                ("mi_pre_seed", C.c_double), ("mi_partition_of_unity", C.c_int), ("hess_eps", C.c_double),
+                ("n_channels", C.c_int)]
 
 
 class SMDesc(C.Structure):
@@ -58,9 +59,9 @@ class SMDesc(C.Structure):
 # every exported symbol of include/mtfhip.h (tests check that the library exports all of them)
 SYMBOLS = [
     "mtfhip_last_error", "mtfhip_device_count", "mtfhip_ctx_create", "mtfhip_ctx_destroy",
-    "mtfhip_ctx_synchronize", "mtfhip_ctx_stream", "mtfhip_image_upload", "mtfhip_image_borrow",
+    "mtfhip_ctx_synchronize", "mtfhip_ctx_stream", "mtfhip_image_upload", "mtfhip_image_upload_mc", "mtfhip_image_borrow",
     "mtfhip_image_preprocess", "mtfhip_image_pyramid_level", "mtfhip_image_download", "mtfhip_image_shape",
-    "mtfhip_batch_create", "mtfhip_batch_destroy", "mtfhip_batch_n_targets", "mtfhip_batch_n_pix",
+    "mtfhip_batch_create", "mtfhip_batch_destroy", "mtfhip_batch_n_targets", "mtfhip_batch_n_pix", "mtfhip_batch_patch_size",
     "mtfhip_batch_state_size", "mtfhip_batch_read", "mtfhip_batch_write", "mtfhip_batch_device_ptr",
     "mtfhip_ssm_set_corners", "mtfhip_ssm_set_state", "mtfhip_ssm_compositional_update",
     "mtfhip_ssm_invert_state", "mtfhip_ssm_update_grad_pts", "mtfhip_ssm_cmpt_pix_jacobian",
@@ -120,6 +121,7 @@ def lib():
         L.mtfhip_batch_create.argtypes = [C.c_void_p, C.POINTER(PatchDesc), C.c_int, C.POINTER(C.c_void_p)]
         L.mtfhip_image_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.mtfhip_image_borrow.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.mtfhip_image_upload_mc.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.mtfhip_image_preprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_double, C.c_double]
         L.mtfhip_image_pyramid_level.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]

@@ -71,8 +71,12 @@ class Context:
     def set_image(self, img):
         """Upload a host float32 H x W image (the CV_32FC1 input of AM/src/ImageBase.cc:38-60)."""
         img = np.asarray(img)
+        if img.dtype == np.float32 and img.ndim == 3 and img.shape[2] == 3:     # CV_32FC3 for MCSSD / MCNCC / MCMI
+            img = np.ascontiguousarray(img)
+            L.check(L.lib().mtfhip_image_upload_mc(self._h, _p(img), img.shape[0], img.shape[1], img.shape[1] * 3, 3))
+            return
         if img.dtype != np.float32 or img.ndim != 2:
-            raise L.InvalidArgument(-1, "Input image type does not match the required type: 32FC1")
+            raise L.InvalidArgument(-1, "Input image type does not match the required type: 32FC1 / 32FC3")
         stride = img.strides[0] // 4
         if img.strides[1] != 4:
             img = np.ascontiguousarray(img)
@@ -129,14 +133,17 @@ class Batch:
     """B independent targets (AM + SSM pairs) sharing the context's current image."""
 
     def __init__(self, ctx, am=AM_SSD, ssm=SSM_HOMOGRAPHY, resx=50, resy=50, n_targets=1, grad_eps=1e-8,
-                 likelihood_alpha=1.0, mi_n_bins=8, mi_pre_seed=10.0, mi_pou=0, hess_eps=1.0):
+                 likelihood_alpha=1.0, mi_n_bins=8, mi_pre_seed=10.0, mi_pou=0, hess_eps=1.0, n_channels=1):
         self.ctx = ctx
-        self.desc = PatchDesc(am, ssm, resx, resy, grad_eps, likelihood_alpha, mi_n_bins, mi_pre_seed, mi_pou, hess_eps)
+        self.desc = PatchDesc(am, ssm, resx, resy, grad_eps, likelihood_alpha, mi_n_bins, mi_pre_seed, mi_pou, hess_eps,
+                              n_channels)
         self._h = C.c_void_p()
         L.check(L.lib().mtfhip_batch_create(ctx._h, C.byref(self.desc), int(n_targets), C.byref(self._h)))
         ctx._batches.add(self)
         self.B = n_targets
-        self.N = resx * resy
+        self.C = n_channels
+        self.NP = resx * resy            # sample points (ImageBase::getNPix)
+        self.N = self.NP * n_channels    # rows of every per-pixel AM array (getPatchSize); == NP for single channel
         self.S = 8 if ssm == SSM_HOMOGRAPHY else 6
 
     def close(self):
@@ -157,11 +164,11 @@ class Batch:
 
     def read(self, buf):
         """Lazy read-back of a device buffer in NumPy-natural orientation."""
-        B, N, S = self.B, self.N, self.S
+        B, N, S, NP = self.B, self.N, self.S, self.NP
         sizes = {BUF_I0: N, BUF_IT: N, BUF_DI0_DX: 2 * N, BUF_DIT_DX: 2 * N, BUF_DF_DI0: N, BUF_DF_DIT: N,
-                 BUF_J0: N * S, BUF_JT: N * S, BUF_JM: N * S, BUF_INIT_PTS: 2 * N, BUF_CURR_PTS: 2 * N,
-                 BUF_GRAD_PTS: 8 * N, 12: N, 13: N, 14: 2 * N, 15: 2 * N, BUF_D2I0_DX2: 4 * N, BUF_D2IT_DX2: 4 * N,
-                 BUF_HESS_PTS: 16 * N, BUF_D2I0_DP2: S * S * N, BUF_D2IT_DP2: S * S * N, BUF_D2IM_DP2: S * S * N}
+                 BUF_J0: N * S, BUF_JT: N * S, BUF_JM: N * S, BUF_INIT_PTS: 2 * NP, BUF_CURR_PTS: 2 * NP,
+                 BUF_GRAD_PTS: 8 * NP, 12: NP, 13: NP, 14: 2 * NP, 15: 2 * NP, BUF_D2I0_DX2: 4 * N, BUF_D2IT_DX2: 4 * N,
+                 BUF_HESS_PTS: 16 * NP, BUF_D2I0_DP2: S * S * N, BUF_D2IT_DP2: S * S * N, BUF_D2IM_DP2: S * S * N}
         out = np.empty((B, sizes[buf]))
         L.check(L.lib().mtfhip_batch_read(self._h, buf, _p(out)))
         if buf in (BUF_DI0_DX, BUF_DIT_DX):
@@ -169,11 +176,11 @@ class Batch:
         if buf in (BUF_J0, BUF_JT, BUF_JM):
             return out.reshape(B, S, N).transpose(0, 2, 1)
         if buf in (BUF_INIT_PTS, BUF_CURR_PTS, 14, 15):
-            return out.reshape(B, N, 2).transpose(0, 2, 1)
+            return out.reshape(B, NP, 2).transpose(0, 2, 1)
         if buf == BUF_GRAD_PTS:
-            return out.reshape(B, N, 8)
+            return out.reshape(B, NP, 8)
         if buf == BUF_HESS_PTS:
-            return out.reshape(B, N, 16)
+            return out.reshape(B, NP, 16)
         if buf in (BUF_D2I0_DX2, BUF_D2IT_DX2):
             return out.reshape(B, N, 2, 2)
         if buf in (BUF_D2I0_DP2, BUF_D2IT_DP2, BUF_D2IM_DP2):      # planes [c][r][N] -> (B, N, r, c)
@@ -189,7 +196,7 @@ class Batch:
         elif buf in (BUF_J0, BUF_JT, BUF_JM):
             a = np.ascontiguousarray(a.reshape(B, N, S).transpose(0, 2, 1))
         elif buf in (BUF_INIT_PTS, BUF_CURR_PTS, 14, 15):
-            a = np.ascontiguousarray(a.reshape(B, 2, N).transpose(0, 2, 1))
+            a = np.ascontiguousarray(a.reshape(B, 2, self.NP).transpose(0, 2, 1))
         L.check(L.lib().mtfhip_batch_write(self._h, buf, _p(a)))
 
     def device_ptr(self, buf):
@@ -266,10 +273,10 @@ class Batch:
         if pts is None:
             return None, None
         a = _f64(pts)
-        if per == 2:  # (B, 2, N) -> interleaved
-            a = np.ascontiguousarray(a.reshape(self.B, 2, self.N).transpose(0, 2, 1))
+        if per == 2:  # (B, 2, NP) -> interleaved
+            a = np.ascontiguousarray(a.reshape(self.B, 2, self.NP).transpose(0, 2, 1))
         else:
-            a = np.ascontiguousarray(a.reshape(self.B, self.N, 8))
+            a = np.ascontiguousarray(a.reshape(self.B, self.NP, 8))
         return a, _p(a)
 
     def initialize_pix_vals(self, pts=None):
@@ -363,7 +370,7 @@ class Batch:
         if not warped:
             L.check(fn(self._h, pp))
             return
-        hp = None if hess_pts is None else np.ascontiguousarray(_f64(hess_pts).reshape(self.B, self.N * 16))
+        hp = None if hess_pts is None else np.ascontiguousarray(_f64(hess_pts).reshape(self.B, self.NP * 16))
         L.check(fn_warped(self._h, pp, None if hp is None else _p(hp)))
 
     def initialize_pix_hess(self, pts=None, hess_pts=None, warped=False):

@@ -192,7 +192,8 @@ struct TargetHost {
 struct mtfhip_batch {
 	mtfhip_ctx *ctx;
 	mtfhip_patch_desc desc;
-	int B, N, S;
+	int B, N, S;          /* N = patch_size = NP * C (rows of the per-pixel AM arrays) */
+	int NP = 0, C = 1;    /* sample points per target, channels */
 	double norm_mult = 1, norm_add = 0;
 	double *buf[MTFHIP_BUF_COUNT];
 	size_t per_target[MTFHIP_BUF_COUNT];
@@ -229,7 +230,7 @@ struct mtfhip_batch {
 
 	BatchView view() const {
 		BatchView v;
-		v.B = B; v.N = N; v.S = S; v.ssm = desc.ssm; v.am = desc.am; v.unit_z = unit_z;
+		v.B = B; v.N = N; v.S = S; v.ssm = desc.ssm; v.am = desc.am; v.unit_z = unit_z; v.NP = NP; v.C = C;
 		for (int i = 0; i < MTFHIP_BUF_COUNT; ++i) v.buf[i] = buf[i];
 		v.warps = d_warps; v.states = d_states;
 		return v;
@@ -280,6 +281,13 @@ static int read_acc(mtfhip_batch *b, int nblk) {
 
 static int need_image(mtfhip_batch *b) {
 	if (!b->ctx->img.data) return fail(MTFHIP_ERR_LOGIC, "no current image: call mtfhip_image_upload/borrow first");
+	if (b->ctx->img.channels != b->C)   /* ImageBase::setCurrImg: "Input image type does not match the required type" */
+		return fail(MTFHIP_ERR_INVALID_ARG, "ImageBase::setCurrImg::Input image has %d channel(s), the appearance model expects %d", b->ctx->img.channels, b->C);
+	return MTFHIP_OK;
+}
+/* the fused, one-launch and candidate kernels are single-channel; MCSSD / MCNCC / MCMI go through the per-function entry points */
+static int single_channel(const mtfhip_batch *b, const char *fn) {
+	if (b->C != 1) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: multi-channel appearance models use the per-function entry points", fn);
 	return MTFHIP_OK;
 }
 static int j_buf_ok(int id) { return id == MTFHIP_BUF_J0 || id == MTFHIP_BUF_JT || id == MTFHIP_BUF_JM; }
@@ -353,9 +361,16 @@ int mtfhip_ctx_synchronize(mtfhip_ctx *c) {
 void *mtfhip_ctx_stream(mtfhip_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 int mtfhip_image_upload(mtfhip_ctx *c, const float *host_img, int height, int width, int row_stride) {
+	return mtfhip_image_upload_mc(c, host_img, height, width, row_stride, 1);
+}
+/* CV_32FC3: `channels` interleaved floats per pixel, row_stride in floats */
+int mtfhip_image_upload_mc(mtfhip_ctx *c, const float *host_img, int height, int width, int row_stride, int channels) {
 	if (!c || !host_img) return fail(MTFHIP_ERR_INVALID_ARG, "image_upload: NULL argument");
-	if (height <= 0 || width <= 0 || row_stride < width) return fail(MTFHIP_ERR_INVALID_ARG, "image_upload: bad shape %dx%d stride %d", height, width, row_stride);
+	if (channels != 1 && channels != 3) return fail(MTFHIP_ERR_INVALID_ARG, "image_upload: %d channels (1 or 3 expected)", channels);
+	if (height <= 0 || width <= 0 || row_stride < width * channels) return fail(MTFHIP_ERR_INVALID_ARG, "image_upload: bad shape %dx%d stride %d", height, width, row_stride);
 	HIP_TRY(hipSetDevice(c->device));
+	const int logical_width = width;
+	width *= channels;   /* floats per row */
 	size_t need = (size_t)height * width;
 	if (need > c->img_capacity) {
 		if (c->img_owned) HIP_TRY(hipFree(c->img_owned));
@@ -366,7 +381,7 @@ int mtfhip_image_upload(mtfhip_ctx *c, const float *host_img, int height, int wi
 	HIP_TRY(hipMemcpy2DAsync(c->img_owned, (size_t)width * sizeof(float), host_img, (size_t)row_stride * sizeof(float),
 		(size_t)width * sizeof(float), (size_t)height, hipMemcpyHostToDevice, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream)); /* the caller may overwrite its buffer right after (TrackerBase.h:22-26) */
-	c->img = ImgView{c->img_owned, height, width, width};
+	c->img = ImgView{c->img_owned, height, logical_width, width, channels};
 	return MTFHIP_OK;
 }
 
@@ -502,9 +517,12 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 	if (d->am == MTFHIP_AM_MI && d->mi_partition_of_unity && d->mi_n_bins < 4) /* MI.cc:83-87 */
 		return fail(MTFHIP_ERR_INVALID_ARG, "MI::Too few bins %d specified to enforce partition of unity constraint", d->mi_n_bins);
 	if (d->ssm != MTFHIP_SSM_HOMOGRAPHY && d->ssm != MTFHIP_SSM_AFFINE) return fail(MTFHIP_ERR_INVALID_ARG, "unknown state space model %d", d->ssm);
+	if (d->n_channels != 0 && d->n_channels != 1 && d->n_channels != 3) return fail(MTFHIP_ERR_INVALID_ARG, "n_channels %d (1 or 3 expected)", d->n_channels);
 	HIP_TRY(hipSetDevice(c->device));
 	mtfhip_batch *b = new mtfhip_batch();
-	b->ctx = c; b->desc = *d; b->B = n_targets; b->N = d->resx * d->resy;
+	b->ctx = c; b->desc = *d; b->B = n_targets;
+	b->C = d->n_channels > 1 ? d->n_channels : 1;
+	b->NP = d->resx * d->resy; b->N = b->NP * b->C;   /* ImageBase: patch_size = n_pix * n_channels */
 	b->S = d->ssm == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
 	if (d->am == MTFHIP_AM_MI) {
 		/* MI ctor AM/src/MI.cc:80-94 */
@@ -513,9 +531,9 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 		b->norm_mult = (hi - lo) / (255.0 - 0.0 + 1);
 		b->norm_add = lo;
 	}
-	const size_t N = b->N, S = b->S;
-	size_t per[MTFHIP_BUF_COUNT] = {N, N, 2 * N, 2 * N, N, N, N * S, N * S, N * S, 2 * N, 2 * N, 8 * N, N, N, 2 * N, 2 * N,
-		4 * N, 4 * N, 16 * N, S * S * N, S * S * N, S * S * N};
+	const size_t N = b->N, S = b->S, NP = b->NP;
+	size_t per[MTFHIP_BUF_COUNT] = {N, N, 2 * N, 2 * N, N, N, N * S, N * S, N * S, 2 * NP, 2 * NP, 8 * NP, NP, NP, 2 * NP, 2 * NP,
+		4 * N, 4 * N, 16 * NP, S * S * N, S * S * N, S * S * N};
 	b->hess_eps = d->hess_eps > 0 ? d->hess_eps : 1.0; /* HESS_EPS, AM/include/mtf/AM/ImageBase.h:9 */
 	for (int i = 0; i < MTFHIP_BUF_COUNT; ++i) { b->per_target[i] = per[i]; b->buf[i] = nullptr; }
 	b->th.resize(n_targets);
@@ -533,7 +551,7 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 	ALLOC(b->d_states, sizeof(double) * 8 * n_targets);
 	ALLOC(b->d_partials, sizeof(double) * ACC_COUNT * b->nblk_max * n_targets);
 	ALLOC(b->d_acc, sizeof(double) * ACC_COUNT * n_targets);
-	ALLOC(b->d_scratch_pts, sizeof(double) * 18 * N * n_targets); /* largest upload: pts (2N) + hess_pts (16N) */
+	ALLOC(b->d_scratch_pts, sizeof(double) * 18 * NP * n_targets); /* largest upload: pts (2 NP) + hess_pts (16 NP) */
 	ALLOC(b->d_w0, sizeof(double) * 9 * n_targets);
 	ALLOC(b->d_h0, sizeof(double) * 64 * n_targets);
 	ALLOC(b->d_corners, sizeof(double) * 8 * n_targets);
@@ -583,7 +601,8 @@ void mtfhip_batch_destroy(mtfhip_batch *b) {
 }
 
 int mtfhip_batch_n_targets(const mtfhip_batch *b) { return b ? b->B : 0; }
-int mtfhip_batch_n_pix(const mtfhip_batch *b) { return b ? b->N : 0; }
+int mtfhip_batch_n_pix(const mtfhip_batch *b) { return b ? b->NP : 0; }          /* ImageBase::getNPix */
+int mtfhip_batch_patch_size(const mtfhip_batch *b) { return b ? b->N : 0; }      /* ImageBase::getPatchSize = n_pix * n_channels */
 int mtfhip_batch_state_size(const mtfhip_batch *b) { return b ? b->S : 0; }
 
 int mtfhip_batch_read(mtfhip_batch *b, int id, double *dst) {
@@ -775,7 +794,7 @@ int mtfhip_am_initialize_pix_vals(mtfhip_batch *b, const double *pts) {
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "initialize_pix_vals: NULL batch");
 	TRY(need_image(b));
 	const double *dp;
-	TRY(resolve_pts(b, pts, MTFHIP_BUF_CURR_PTS, 2 * (size_t)b->N, &dp));
+	TRY(resolve_pts(b, pts, MTFHIP_BUF_CURR_PTS, 2 * (size_t)b->NP, &dp));
 	{
 		TimedScope ts(b->ctx, "sample");
 		launch_sample(b->view(), b->ctx->img, dp, b->buf[MTFHIP_BUF_I0], b->norm_mult, b->norm_add, b->ctx->stream);
@@ -791,7 +810,7 @@ int mtfhip_am_update_pix_vals(mtfhip_batch *b, const double *pts) {
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_pix_vals: NULL batch");
 	TRY(need_image(b));
 	const double *dp;
-	TRY(resolve_pts(b, pts, MTFHIP_BUF_CURR_PTS, 2 * (size_t)b->N, &dp));
+	TRY(resolve_pts(b, pts, MTFHIP_BUF_CURR_PTS, 2 * (size_t)b->NP, &dp));
 	TimedScope ts(b->ctx, "sample");
 	launch_sample(b->view(), b->ctx->img, dp, b->buf[MTFHIP_BUF_IT], b->norm_mult, b->norm_add, b->ctx->stream);
 	b->it_valid = true;
@@ -800,8 +819,8 @@ int mtfhip_am_update_pix_vals(mtfhip_batch *b, const double *pts) {
 static int pix_grad_common(mtfhip_batch *b, const double *pts, bool warped, bool init) {
 	TRY(need_image(b));
 	const double *dp;
-	if (warped) TRY(resolve_pts(b, pts, MTFHIP_BUF_GRAD_PTS, 8 * (size_t)b->N, &dp));
-	else TRY(resolve_pts(b, pts, MTFHIP_BUF_CURR_PTS, 2 * (size_t)b->N, &dp));
+	if (warped) TRY(resolve_pts(b, pts, MTFHIP_BUF_GRAD_PTS, 8 * (size_t)b->NP, &dp));
+	else TRY(resolve_pts(b, pts, MTFHIP_BUF_CURR_PTS, 2 * (size_t)b->NP, &dp));
 	double *dst = b->buf[init ? MTFHIP_BUF_DI0_DX : MTFHIP_BUF_DIT_DX];
 	{
 		TimedScope ts(b->ctx, warped ? "warped_img_grad" : "img_grad");
@@ -1257,16 +1276,16 @@ static int pix_hess_common(mtfhip_batch *b, const double *pts, const double *hes
 	TRY(need_image(b));
 	TRY(ensure_buf(b, MTFHIP_BUF_D2I0_DX2));
 	TRY(ensure_buf(b, MTFHIP_BUF_D2IT_DX2));
-	const size_t N = b->N;
+	const size_t N = b->N, NP = b->NP;
 	const double *dp, *dh = nullptr;
-	TRY(resolve_pts(b, pts, MTFHIP_BUF_CURR_PTS, 2 * N, &dp));
+	TRY(resolve_pts(b, pts, MTFHIP_BUF_CURR_PTS, 2 * NP, &dp));
 	if (warped) {
 		if (!hess_pts) {
 			if (!b->buf[MTFHIP_BUF_HESS_PTS]) return fail(MTFHIP_ERR_LOGIC, "pix_hess: device hess_pts not available (call update_hess_pts)");
 			dh = b->buf[MTFHIP_BUF_HESS_PTS];
 		} else {
-			double *stage = b->d_scratch_pts + 2 * N * b->B;
-			HIP_TRY(hipMemcpyAsync(stage, hess_pts, sizeof(double) * 16 * N * b->B, hipMemcpyHostToDevice, b->ctx->stream));
+			double *stage = b->d_scratch_pts + 2 * NP * b->B;
+			HIP_TRY(hipMemcpyAsync(stage, hess_pts, sizeof(double) * 16 * NP * b->B, hipMemcpyHostToDevice, b->ctx->stream));
 			dh = stage;
 		}
 	}
@@ -1421,6 +1440,7 @@ static bool invert_definite(int S, const double *H, double *Hinv) {
 
 int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	TRY(check_sm(b, sm, "init_template"));
+	TRY(single_channel(b, "init_template"));
 	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "init_template before set_corners");
 	/* am->clearInitStatus() (NT/ESM.cc:113, NT/FCLK.cc:105, NT/ICLK.cc:74) */
 	b->init_pix_vals = b->init_pix_grad = b->init_sim = b->init_grad = false;
@@ -1514,6 +1534,7 @@ static void assemble(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const doub
 
 int mtfhip_batch_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, double *g, double *H) {
 	TRY(check_sm(b, sm, "iterate"));
+	TRY(single_channel(b, "iterate"));
 	if (!g || !H) return fail(MTFHIP_ERR_INVALID_ARG, "iterate: NULL output");
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "iterate before init_template");
 	TRY(need_image(b));
@@ -1587,6 +1608,7 @@ int mtfhip_batch_track_targets_per_launch(mtfhip_batch *b, const mtfhip_sm_desc 
 
 int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners) {
 	TRY(check_sm(b, sm, "track"));
+	TRY(single_channel(b, "track"));
 	if (sm->leven_marq) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: Levenberg-Marquardt is only available through iterate + host solve");
 	if (sm->max_iters <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "track: max_iters must be positive");
 	if (b->desc.am != MTFHIP_AM_SSD ? sm->sec_ord_hess != 0 : second_order_term(sm) >= 0)
@@ -1679,6 +1701,7 @@ int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int C
 	if (!b || !dev_states) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: NULL argument");
 	if (C <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: n_candidates must be positive");
 	if (b->desc.am != MTFHIP_AM_SSD) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "score_candidates: SSD only");
+	TRY(single_channel(b, "score_candidates"));
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "score_candidates before the template was initialised");
 	TRY(need_image(b));
 	TimedScope ts(b->ctx, "score_candidates");
@@ -1733,6 +1756,7 @@ int mtfhip_sample_candidates_dev(mtfhip_batch *b, const double *dev_states, int 
 	if (!b || !dev_states || !dev_features) return fail(MTFHIP_ERR_INVALID_ARG, "sample_candidates: NULL argument");
 	if (C <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "sample_candidates: n_samples must be positive");
 	if (b->desc.am == MTFHIP_AM_MI) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "sample_candidates: MI distance features (5 x N B-spline rows) are not available");
+	TRY(single_channel(b, "sample_candidates"));
 	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "sample_candidates before set_corners");
 	TRY(need_image(b));
 	TimedScope ts(b->ctx, "sample_candidates");

@@ -12,12 +12,14 @@ namespace mtfhip {
 
 struct ImgView {
 	const float *data;
-	int h, w, stride;
+	int h, w, stride;     /* stride in floats between rows */
+	int channels = 1;     /* 1: CV_32FC1 ; 3: CV_32FC3, interleaved (the mc:: sampling path) */
 };
 
 /* POD view of a batch, passed by value to kernels.  Every buf[i] is [B][per-target size]. */
 struct BatchView {
-	int B, N, S, ssm, am;
+	int B, N, S, ssm, am; /* N = patch_size = NP * C rows of every per-pixel AM array */
+	int NP, C;            /* sample points per target, channels (MCSSD / MCNCC / MCMI: 3) */
 	int unit_z;           /* 1: every init_z == 1 (affine SSM or parallelogram corners) */
 	double *buf[MTFHIP_BUF_COUNT];
 	double *warps;        /* [B][9] row-major curr_warp */

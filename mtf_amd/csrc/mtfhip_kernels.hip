@@ -209,13 +209,13 @@ __global__ __launch_bounds__(kBlock) void k_init_grid(BatchView bv, const double
 	double lo_x, double lo_y, double hi_x, double hi_y, int force_unit_z) {
 	const int t = blockIdx.y;
 	const Warp9 W = load_warp(w0_all + 9 * t);
-	double2 *ip = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * bv.N;
-	double2 *cp = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * bv.N;
-	double *iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * bv.N;
-	double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * bv.N;
-	double2 *ih = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]) + (size_t)t * bv.N;
-	double2 *ch = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_CURR_HXY]) + (size_t)t * bv.N;
-	for (int i = blockIdx.x * kBlock + threadIdx.x; i < bv.N; i += gridDim.x * kBlock) {
+	double2 *ip = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * bv.NP;
+	double2 *cp = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * bv.NP;
+	double *iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * bv.NP;
+	double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * bv.NP;
+	double2 *ih = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]) + (size_t)t * bv.NP;
+	double2 *ch = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_CURR_HXY]) + (size_t)t * bv.NP;
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < bv.NP; i += gridDim.x * kBlock) {
 		const int col = i % resx, row = i / resx;
 		const double nx = lin_spaced(col, resx, lo_x, hi_x), ny = lin_spaced(row, resy, lo_y, hi_y);
 		const double X = W.m[0] * nx + W.m[1] * ny + W.m[2] * 1.0;
@@ -235,13 +235,13 @@ __global__ __launch_bounds__(kBlock) void k_init_grid(BatchView bv, const double
 __global__ __launch_bounds__(kBlock) void k_apply_warp(BatchView bv) {
 	const int t = blockIdx.y;
 	const Warp9 W = load_warp(bv.warps + 9 * t);
-	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * bv.N;
-	const double *iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * bv.N;
-	const double2 *ih = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]) + (size_t)t * bv.N;
-	double2 *cp = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * bv.N;
-	double2 *ch = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_CURR_HXY]) + (size_t)t * bv.N;
-	double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * bv.N;
-	for (int i = blockIdx.x * kBlock + threadIdx.x; i < bv.N; i += gridDim.x * kBlock) {
+	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * bv.NP;
+	const double *iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * bv.NP;
+	const double2 *ih = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]) + (size_t)t * bv.NP;
+	double2 *cp = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * bv.NP;
+	double2 *ch = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_CURR_HXY]) + (size_t)t * bv.NP;
+	double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * bv.NP;
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < bv.NP; i += gridDim.x * kBlock) {
 		double2 hp = bv.unit_z ? ip[i] : ih[i];
 		double z = bv.unit_z ? 1.0 : iz[i];
 		double hx = hp.x, hy = hp.y;
@@ -267,13 +267,13 @@ __global__ __launch_bounds__(kBlock) void k_apply_warp(BatchView bv) {
 __global__ __launch_bounds__(kBlock) void k_grad_pts(BatchView bv, double eps) {
 	const int t = blockIdx.y;
 	const Warp9 W = load_warp(bv.warps + 9 * t);
-	const double2 *cp = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * bv.N;
-	const double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * bv.N;
-	const double2 *ch = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_CURR_HXY]) + (size_t)t * bv.N;
-	double *gp = bv.buf[MTFHIP_BUF_GRAD_PTS] + (size_t)t * bv.N * 8;
+	const double2 *cp = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * bv.NP;
+	const double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * bv.NP;
+	const double2 *ch = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_CURR_HXY]) + (size_t)t * bv.NP;
+	double *gp = bv.buf[MTFHIP_BUF_GRAD_PTS] + (size_t)t * bv.NP * 8;
 	const double dx0 = W.m[0] * eps, dx1 = W.m[3] * eps, dx2 = W.m[6] * eps;
 	const double dy0 = W.m[1] * eps, dy1 = W.m[4] * eps, dy2 = W.m[7] * eps;
-	for (int i = blockIdx.x * kBlock + threadIdx.x; i < bv.N; i += gridDim.x * kBlock) {
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < bv.NP; i += gridDim.x * kBlock) {
 		double2 p = cp[i];
 		double g[8];
 		if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
@@ -354,20 +354,99 @@ __global__ __launch_bounds__(kBlock) void k_warped_img_grad(int N, ImgView im, c
 	}
 }
 
+/* ---- multi-channel (mc::) sampling: image H x W x C interleaved; one thread per (pixel, channel) row.
+ * mc::PixVal<Linear, Constant>::get (imgUtils.h:505-551) forms the four bilinear weights first and applies them per
+ * channel -- not the single-channel operation order -- and so does this. ---- */
+__device__ __forceinline__ double pix_val_mc(const ImgView &im, double x, double y, int ch) {
+	const double w = (double)(unsigned int)im.w, h = (double)(unsigned int)im.h;
+	if ((x < 0) || (x >= w) || (y < 0) || (y >= h)) return 128.0;
+	int lx = (int)x, ly = (int)y;
+	double dx = x - lx, dy = y - ly;
+	int ux = dx == 0 ? lx : lx + 1;
+	int uy = dy == 0 ? ly : ly + 1;
+	if (ux >= im.w || uy >= im.h) return 128.0;
+	const double ly_lx = (1 - dx) * (1 - dy), ly_ux = dx * (1 - dy), uy_lx = (1 - dx) * dy, uy_ux = dx * dy;
+	const float *r0 = im.data + (size_t)ly * im.stride, *r1 = im.data + (size_t)uy * im.stride;
+	const int C = im.channels;
+	const double t00 = r0[lx * C + ch], t01 = r0[ux * C + ch], t10 = r1[lx * C + ch], t11 = r1[ux * C + ch];
+	return t00 * ly_lx + t01 * ly_ux + t10 * uy_lx + t11 * uy_ux;
+}
+/* mc::getPixVals imgUtils.cc:867-882 */
+__global__ __launch_bounds__(kBlock) void k_sample_mc(int NP, int C, ImgView im, const double *pts_all, double *out_all, double mult, double add) {
+	const int t = blockIdx.y, P = NP * C;
+	const double2 *pts = reinterpret_cast<const double2 *>(pts_all) + (size_t)t * NP;
+	double *out = out_all + (size_t)t * P;
+	for (int q = blockIdx.x * kBlock + threadIdx.x; q < P; q += gridDim.x * kBlock) {
+		const double2 p = pts[q / C];
+		out[q] = mult * pix_val_mc(im, p.x, p.y, q % C) + add;
+	}
+}
+/* mc::getImgGrad imgUtils.cc:977-1005 ; mc::getWarpedImgGrad :914-944 (gp != NULL) */
+__global__ __launch_bounds__(kBlock) void k_img_grad_mc(int NP, int C, ImgView im, const double *pts_all, const double *gp_all,
+	double *grad_all, double eps, double pix_mult) {
+	const int t = blockIdx.y, P = NP * C;
+	double *grad = grad_all + (size_t)t * P * 2;
+	const double mult = pix_mult / (2 * eps);
+	for (int q = blockIdx.x * kBlock + threadIdx.x; q < P; q += gridDim.x * kBlock) {
+		const int i = q / C, ch = q % C;
+		double ix, dx, iy, dy;
+		if (gp_all) {
+			const double2 *g = reinterpret_cast<const double2 *>(gp_all + ((size_t)t * NP + i) * 8);
+			ix = pix_val_mc(im, g[0].x, g[0].y, ch); dx = pix_val_mc(im, g[1].x, g[1].y, ch);
+			iy = pix_val_mc(im, g[2].x, g[2].y, ch); dy = pix_val_mc(im, g[3].x, g[3].y, ch);
+		} else {
+			const double2 p = (reinterpret_cast<const double2 *>(pts_all) + (size_t)t * NP)[i];
+			ix = pix_val_mc(im, p.x + eps, p.y, ch); dx = pix_val_mc(im, p.x - eps, p.y, ch);
+			iy = pix_val_mc(im, p.x, p.y + eps, ch); dy = pix_val_mc(im, p.x, p.y - eps, ch);
+		}
+		grad[q] = (ix - dx) * mult;
+		grad[P + q] = (iy - dy) * mult;
+	}
+}
+/* mc::getImgHess imgUtils.cc:1127-1168 ; mc::getWarpedImgHess :1036-1075 (hp != NULL) */
+__global__ __launch_bounds__(kBlock) void k_img_hess_mc(int NP, int C, ImgView im, const double *pts_all, const double *hp_all,
+	double *hess_all, double eps, double pix_mult) {
+	const int t = blockIdx.y, P = NP * C;
+	double2 *hess = reinterpret_cast<double2 *>(hess_all + (size_t)t * P * 4);
+	const double eps2 = 2 * eps, mult = pix_mult / (eps2 * eps2);
+	for (int q = blockIdx.x * kBlock + threadIdx.x; q < P; q += gridDim.x * kBlock) {
+		const int i = q / C, ch = q % C;
+		const double2 p = (reinterpret_cast<const double2 *>(pts_all) + (size_t)t * NP)[i];
+		const double c = pix_val_mc(im, p.x, p.y, ch);
+		double hxx, hyy, hxy;
+		if (hp_all) {
+			const double2 *s = reinterpret_cast<const double2 *>(hp_all + ((size_t)t * NP + i) * 16);
+			hxx = (pix_val_mc(im, s[0].x, s[0].y, ch) + pix_val_mc(im, s[1].x, s[1].y, ch) - 2 * c) * mult;
+			hyy = (pix_val_mc(im, s[2].x, s[2].y, ch) + pix_val_mc(im, s[3].x, s[3].y, ch) - 2 * c) * mult;
+			hxy = ((pix_val_mc(im, s[4].x, s[4].y, ch) + pix_val_mc(im, s[5].x, s[5].y, ch)) -
+				(pix_val_mc(im, s[6].x, s[6].y, ch) + pix_val_mc(im, s[7].x, s[7].y, ch))) * mult;
+		} else {
+			hxx = (pix_val_mc(im, p.x + eps2, p.y, ch) + pix_val_mc(im, p.x - eps2, p.y, ch) - 2 * c) * mult;
+			hyy = (pix_val_mc(im, p.x, p.y + eps2, ch) + pix_val_mc(im, p.x, p.y - eps2, ch) - 2 * c) * mult;
+			const double inc_x = p.x + eps, dec_x = p.x - eps, inc_y = p.y + eps, dec_y = p.y - eps;
+			hxy = ((pix_val_mc(im, inc_x, inc_y, ch) + pix_val_mc(im, dec_x, dec_y, ch)) -
+				(pix_val_mc(im, inc_x, dec_y, ch) + pix_val_mc(im, dec_x, inc_y, ch))) * mult;
+		}
+		hess[2 * q] = make_double2(hxx, hxy);
+		hess[2 * q + 1] = make_double2(hxy, hyy);
+	}
+}
+
 /* SSM pixel Jacobians as stand-alone ops (the fused kernel inlines the same row formulas):
  * Homography.cc:157-191 (init), :193-229 (pix), :231-294 (warped), :296-358 (approx);
  * Affine.cc:160-182 (init = pix), :213-242 (warped), :184-211 (approx) */
 __global__ __launch_bounds__(kBlock) void k_pix_jacobian(BatchView bv, int variant, const double *grad_all, double *J_all) {
-	const int t = blockIdx.y, N = bv.N, S = bv.S;
+	const int t = blockIdx.y, N = bv.N, S = bv.S, NP = bv.NP, C = bv.C;
 	const Warp9 W = load_warp(bv.warps + 9 * t);
 	const double *st = bv.states + 8 * t;
-	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * N;
-	const double2 *cp = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * N;
-	const double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * N;
+	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * NP;
+	const double2 *cp = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * NP;
+	const double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * NP;
 	const double *grad = grad_all + (size_t)t * N * 2;
 	double *J = J_all + (size_t)t * N * S;
 	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
-		double2 p0 = ip[i];
+		const int pt = C == 1 ? i : i / C;   /* row (pixel, channel) -> sample point (Homography.cc:160-189 inner ch loop) */
+		double2 p0 = ip[pt];
 		double x = p0.x, y = p0.y;
 		double gx = grad[i], gy = grad[N + i];
 		double r[8];
@@ -375,19 +454,19 @@ __global__ __launch_bounds__(kBlock) void k_pix_jacobian(BatchView bv, int varia
 			if (variant == MTFHIP_JAC_INIT) {
 				hom_row(r, gx, gy, x, y, x, y);
 			} else if (variant == MTFHIP_JAC_PIX) {
-				double2 c = cp[i];
-				double inv_d = 1.0 / cz[i];
+				double2 c = cp[pt];
+				double inv_d = 1.0 / cz[pt];
 				hom_row(r, gx * inv_d, gy * inv_d, x, y, c.x, c.y);
 			} else if (variant == MTFHIP_JAC_WARPED) {
-				double2 c = cp[i];
-				double inv_det = 1.0 / cz[i];
+				double2 c = cp[pt];
+				double inv_det = 1.0 / cz[pt];
 				double dwx_dx = (W.m[0] - W.m[6] * c.x), dwx_dy = (W.m[1] - W.m[7] * c.x);
 				double dwy_dx = (W.m[3] - W.m[6] * c.y), dwy_dy = (W.m[4] - W.m[7] * c.y);
 				double Ix = (dwx_dx * gx + dwy_dx * gy) * inv_det;
 				double Iy = (dwx_dy * gx + dwy_dy * gy) * inv_det;
 				hom_row(r, Ix, Iy, x, y, x, y);
 			} else {
-				double2 c = cp[i];
+				double2 c = cp[pt];
 				double a = (W.m[0] - W.m[6] * c.x), b = (W.m[1] - W.m[7] * c.x);
 				double cc = (W.m[3] - W.m[6] * c.y), d = (W.m[4] - W.m[7] * c.y);
 				double inv_factor = 1.0 / (a * d - b * cc);
@@ -424,10 +503,10 @@ __global__ __launch_bounds__(kBlock) void k_pix_jacobian(BatchView bv, int varia
 __global__ __launch_bounds__(kBlock) void k_hess_pts(BatchView bv, double eps) {
 	const int t = blockIdx.y;
 	const Warp9 W = load_warp(bv.warps + 9 * t);
-	const double2 *cp = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * bv.N;
-	const double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * bv.N;
-	const double2 *ch = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_CURR_HXY]) + (size_t)t * bv.N;
-	double *hp = bv.buf[MTFHIP_BUF_HESS_PTS] + (size_t)t * bv.N * 16;
+	const double2 *cp = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * bv.NP;
+	const double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * bv.NP;
+	const double2 *ch = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_CURR_HXY]) + (size_t)t * bv.NP;
+	double *hp = bv.buf[MTFHIP_BUF_HESS_PTS] + (size_t)t * bv.NP * 16;
 	const double eps2 = 2 * eps;
 	double dv[4][3];
 #pragma unroll
@@ -437,7 +516,7 @@ __global__ __launch_bounds__(kBlock) void k_hess_pts(BatchView bv, double eps) {
 		dv[2][r] = (W.m[3 * r] + W.m[3 * r + 1]) * eps;
 		dv[3][r] = (W.m[3 * r] - W.m[3 * r + 1]) * eps;
 	}
-	for (int i = blockIdx.x * kBlock + threadIdx.x; i < bv.N; i += gridDim.x * kBlock) {
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < bv.NP; i += gridDim.x * kBlock) {
 		double2 *o = reinterpret_cast<double2 *>(hp + (size_t)i * 16);
 		if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
 			const double2 h = ch[i];
@@ -634,20 +713,21 @@ template <int SSM>
 __global__ __launch_bounds__(kBlock) void k_pix_hessian(BatchView bv, int variant, const double *hess_all, const double *grad_all,
 	double *D_all) {
 	constexpr int S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
-	const int t = blockIdx.y, N = bv.N;
+	const int t = blockIdx.y, N = bv.N, NP = bv.NP, C = bv.C;
 	const Warp9 W = load_warp(bv.warps + 9 * t);
 	const double *st = bv.states + 8 * t;
-	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * N;
-	const double2 *cp = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * N;
-	const double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * N;
+	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * NP;
+	const double2 *cp = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * NP;
+	const double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * NP;
 	const double2 *ph = reinterpret_cast<const double2 *>(hess_all + (size_t)t * N * 4);
 	const double *grad = grad_all + (size_t)t * N * 2;
 	double *Dm = D_all + (size_t)t * N * S * S;
 	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
-		const double2 p0 = ip[i], c = cp[i];
+		const int pt = C == 1 ? i : i / C;
+		const double2 p0 = ip[pt], c = cp[pt];
 		const double2 ma = ph[2 * i], mb = ph[2 * i + 1];
 		double d2[S * S];
-		pix_hessian_block<SSM>(d2, variant, W, st, p0.x, p0.y, c.x, c.y, cz[i], ma.x, ma.y, mb.x, mb.y, grad[i], grad[N + i]);
+		pix_hessian_block<SSM>(d2, variant, W, st, p0.x, p0.y, c.x, c.y, cz[pt], ma.x, ma.y, mb.x, mb.y, grad[i], grad[N + i]);
 #pragma unroll
 		for (int k = 0; k < S * S; ++k) Dm[(size_t)k * N + i] = d2[k];
 	}
@@ -2442,19 +2522,28 @@ void launch_init_grid(const BatchView &bv, const double *dev_w0, int resx, int r
 void launch_apply_warp(const BatchView &bv, hipStream_t st) {
 	hipLaunchKernelGGL(k_apply_warp, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv);
 }
-void launch_grad_pts(const BatchView &bv, double eps, hipStream_t st) {
+void launch_grad_pts(const BatchView &bv, double eps, hipStream_t st) {   /* per sample point */
 	hipLaunchKernelGGL(k_grad_pts, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv, eps);
 }
 void launch_sample(const BatchView &bv, const ImgView &im, const double *pts, double *out, double mult, double add,
 	hipStream_t st) {
+	if (bv.C > 1) { hipLaunchKernelGGL(k_sample_mc, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.NP, bv.C, im, pts, out, mult, add); return; }
 	hipLaunchKernelGGL(k_sample, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, pts, out, mult, add);
 }
 void launch_img_grad(const BatchView &bv, const ImgView &im, const double *pts, double *grad, double eps, double mult,
 	hipStream_t st) {
+	if (bv.C > 1) {
+		hipLaunchKernelGGL(k_img_grad_mc, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.NP, bv.C, im, pts, (const double *)nullptr, grad, eps, mult);
+		return;
+	}
 	hipLaunchKernelGGL(k_img_grad, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, pts, grad, eps, mult);
 }
 void launch_warped_img_grad(const BatchView &bv, const ImgView &im, const double *gp, double *grad, double eps,
 	double mult, hipStream_t st) {
+	if (bv.C > 1) {
+		hipLaunchKernelGGL(k_img_grad_mc, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.NP, bv.C, im, (const double *)nullptr, gp, grad, eps, mult);
+		return;
+	}
 	hipLaunchKernelGGL(k_warped_img_grad, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, gp, grad, eps, mult);
 }
 void launch_pix_jacobian(const BatchView &bv, int variant, const double *grad, double *J, hipStream_t st) {
@@ -2464,10 +2553,18 @@ void launch_hess_pts(const BatchView &bv, double eps, hipStream_t st) {
 	hipLaunchKernelGGL(k_hess_pts, dim3(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv, eps);
 }
 void launch_img_hess(const BatchView &bv, const ImgView &im, const double *pts, double *hess, double eps, double mult, hipStream_t st) {
+	if (bv.C > 1) {
+		hipLaunchKernelGGL(k_img_hess_mc, dim3(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.NP, bv.C, im, pts, (const double *)nullptr, hess, eps, mult);
+		return;
+	}
 	hipLaunchKernelGGL(k_img_hess, dim3(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, pts, hess, eps, mult);
 }
 void launch_warped_img_hess(const BatchView &bv, const ImgView &im, const double *pts, const double *hp, double *hess, double eps,
 	double mult, hipStream_t st) {
+	if (bv.C > 1) {
+		hipLaunchKernelGGL(k_img_hess_mc, dim3(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.NP, bv.C, im, pts, hp, hess, eps, mult);
+		return;
+	}
 	hipLaunchKernelGGL(k_warped_img_hess, dim3(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, pts, hp, hess, eps, mult);
 }
 void launch_pix_hessian(const BatchView &bv, int variant, const double *hess, const double *grad, double *D, hipStream_t st) {

@@ -29,7 +29,7 @@ def lib():
         H = C.CDLL(LIB_PATH)
         H.mtfhost_last_error.restype = C.c_char_p
         H.mtfhost_create.restype = C.c_void_p
-        H.mtfhost_create.argtypes = [C.c_int] * 6 + [C.c_double] + [C.c_int] * 4 + [C.c_double, C.c_double, C.c_int, C.c_int]
+        H.mtfhost_create.argtypes = [C.c_int] * 6 + [C.c_double] + [C.c_int] * 4 + [C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
         for fn in ("mtfhost_destroy", "mtfhost_set_image", "mtfhost_initialize", "mtfhost_set_region", "mtfhost_update",
                    "mtfhost_get_region"):
             getattr(H, fn).argtypes = None
@@ -59,9 +59,10 @@ class CppTracker:
 
     def __init__(self, sm, am=_lib.AM_SSD, ssm=_lib.SSM_HOMOGRAPHY, resx=50, resy=50, max_iters=30, epsilon=1e-4,
                  jac_type=1, hess_type=-1, chained_warp=1, leven_marq=1, lm_delta_init=0.01, lm_delta_update=10.0,
-                 device=0, sec_ord_hess=0):
+                 device=0, sec_ord_hess=0, n_channels=1):
         h = lib().mtfhost_create(sm, am, ssm, resx, resy, max_iters, epsilon, jac_type, hess_type, chained_warp,
-                                 leven_marq, lm_delta_init, lm_delta_update, device, sec_ord_hess)
+                                 leven_marq, lm_delta_init, lm_delta_update, device, sec_ord_hess, n_channels)
+        self.n_channels = n_channels
         if not h:
             raise HostError(lib().mtfhost_last_error().decode("utf-8", "replace"))
         self._h = C.c_void_p(h)
@@ -76,7 +77,9 @@ class CppTracker:
     def set_image(self, img):
         assert img.dtype == np.float32 and img.flags["C_CONTIGUOUS"]
         self._img = img   # borrowed, as TrackerBase::setImage does (include/mtf/TrackerBase.h:22-26)
-        _check(lib().mtfhost_set_image(self._h, img.ctypes.data_as(C.c_void_p), img.shape[0], img.shape[1], img.shape[1]))
+        step = img.shape[1] * (img.shape[2] if img.ndim == 3 else 1)     # floats per row
+        assert (img.shape[2] if img.ndim == 3 else 1) == getattr(self, "n_channels", 1)
+        _check(lib().mtfhost_set_image(self._h, img.ctypes.data_as(C.c_void_p), img.shape[0], img.shape[1], step))
 
     @staticmethod
     def _c(corners):

@@ -18,12 +18,13 @@ void HipPair::check(int rc) {
 }
 
 HipPair::HipPair(int _am, int _ssm, int _resx, int _resy, double _grad_eps, double likelihood_alpha, int mi_n_bins,
-	double mi_pre_seed, int mi_pou, int device, void *stream) :
-	am(_am), ssm(_ssm), resx(_resx), resy(_resy), N(_resx * _resy), S(_ssm == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6),
+	double mi_pre_seed, int mi_pou, int device, void *stream, int _n_channels) :
+	am(_am), ssm(_ssm), resx(_resx), resy(_resy), N(_resx * _resy * (_n_channels > 1 ? _n_channels : 1)),
+	S(_ssm == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6), n_pix(_resx * _resy), n_channels(_n_channels > 1 ? _n_channels : 1),
 	grad_eps(_grad_eps) {
 	if (resx <= 0 || resy <= 0) throw utils::InvalidArgument("ImageBase::Invalid sampling resolution provided"); /* ImageBase.cc:33-35 */
 	check(mtfhip_ctx_create(device, stream, &ctx));
-	mtfhip_patch_desc d{am, ssm, resx, resy, grad_eps, likelihood_alpha, mi_n_bins, mi_pre_seed, mi_pou, hess_eps};
+	mtfhip_patch_desc d{am, ssm, resx, resy, grad_eps, likelihood_alpha, mi_n_bins, mi_pre_seed, mi_pou, hess_eps, n_channels};
 	int rc = mtfhip_batch_create(ctx, &d, 1, &b);
 	if (rc != MTFHIP_OK) { const std::string msg = mtfhip_last_error(); mtfhip_ctx_destroy(ctx); ctx = nullptr; throw utils::Exception(msg); }
 }
@@ -76,11 +77,11 @@ const double *HipAM::gradPtsArg(const GradPtsT &pts) const { return pts.data() =
 void HipAM::setCurrImg(const ImageView &im) {
 	if (!im.data) throw utils::InvalidArgument("ImageBase::Input image is empty");
 	img = im;
-	HipPair::check(mtfhip_image_upload(p->ctx, im.data, im.rows, im.cols, im.step));
+	HipPair::check(mtfhip_image_upload_mc(p->ctx, im.data, im.rows, im.cols, im.step, im.channels));
 }
 void HipAM::setFirstIter() {
 	first_iter = true;
-	if (img.data) HipPair::check(mtfhip_image_upload(p->ctx, img.data, img.rows, img.cols, img.step));
+	if (img.data) HipPair::check(mtfhip_image_upload_mc(p->ctx, img.data, img.rows, img.cols, img.step, img.channels));
 }
 const PixValT &HipAM::getInitPixVals() { HipPair::check(mtfhip_batch_read(p->b, MTFHIP_BUF_I0, I0.data())); return I0; }
 const PixValT &HipAM::getCurrPixVals() { HipPair::check(mtfhip_batch_read(p->b, MTFHIP_BUF_IT, It.data())); return It; }
@@ -175,9 +176,9 @@ void HipAM::cmptMeanOf(MatrixXd &mean, const MatrixXd &a, const MatrixXd &b) {
 /* ------------------------------------------------------------------ SSM */
 HipSSM::HipSSM(std::shared_ptr<HipPair> pair) : p(pair) {
 	name = p->ssm == MTFHIP_SSM_HOMOGRAPHY ? "homography" : "affine";
-	curr_pts.resize(2, p->N);
-	grad_pts.resize(8, p->N);
-	hess_pts.resize(16, p->N);
+	curr_pts.resize(2, p->n_pix);
+	grad_pts.resize(8, p->n_pix);
+	hess_pts.resize(16, p->n_pix);
 	p->hess_pts_key = hess_pts.data();
 	curr_state.resize(p->S);
 	std::memset(curr_corners.v, 0, sizeof(curr_corners.v));

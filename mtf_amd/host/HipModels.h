@@ -22,7 +22,8 @@ namespace hip {
 struct HipPair {
 	mtfhip_ctx *ctx = nullptr;
 	mtfhip_batch *b = nullptr;
-	int am, ssm, resx, resy, N, S;
+	int am, ssm, resx, resy, N, S;   /* N = patch size = n_pix * n_channels */
+	int n_pix, n_channels;
 	double grad_eps, hess_eps = 1.0;
 	/* addresses of host mirrors whose authoritative copy is a device buffer */
 	const void *pts_key = nullptr, *grad_pts_key = nullptr, *init_grad_key = nullptr, *curr_grad_key = nullptr;
@@ -32,7 +33,7 @@ struct HipPair {
 	int next_jac = 0, next_hess = 0;
 
 	HipPair(int am, int ssm, int resx, int resy, double grad_eps, double likelihood_alpha, int mi_n_bins,
-		double mi_pre_seed, int mi_pou, int device, void *stream);
+		double mi_pre_seed, int mi_pou, int device, void *stream, int n_channels = 1);
 	~HipPair();
 	static void check(int rc);               /* rethrows C-ABI failures as mtf::utils::Exception */
 	int jacobianBuffer(const MatrixXd &J, bool may_register);
@@ -44,7 +45,9 @@ public:
 	HipAM(std::shared_ptr<HipPair> pair);
 	unsigned int getResX() const override { return p->resx; }
 	unsigned int getResY() const override { return p->resy; }
-	unsigned int getNPix() const override { return p->N; }
+	unsigned int getNPix() const override { return p->n_pix; }
+	unsigned int getNChannels() const override { return p->n_channels; }   /* MCSSD / MCNCC / MCMI: 3 */
+	unsigned int getPatchSize() const override { return p->N; }
 	double getGradOffset() const override { return p->grad_eps; }
 	double getHessOffset() const override { return p->hess_eps; }
 	const PixValT &getInitPixVals() override;
@@ -109,7 +112,7 @@ public:
 	unsigned int getStateSize() override { return p->S; }
 	unsigned int getResX() override { return p->resx; }
 	unsigned int getResY() override { return p->resy; }
-	unsigned int getNPts() override { return p->N; }
+	unsigned int getNPts() override { return p->n_pix; }
 	const PtsT &getPts() override { return curr_pts; }            /* key only; syncPts() refreshes the bytes */
 	const GradPtsT &getGradPts() override { return grad_pts; }
 	const HessPtsT &getHessPts() override { return hess_pts; }

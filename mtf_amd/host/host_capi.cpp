@@ -27,10 +27,10 @@ const char *mtfhost_last_error(void) { return g_err.c_str(); }
 
 mtfhost_tracker *mtfhost_create(int sm, int am, int ssm, int resx, int resy, int max_iters, double epsilon,
 	int jac_type, int hess_type, int chained_warp, int leven_marq, double lm_delta_init, double lm_delta_update,
-	int device, int sec_ord_hess) {
+	int device, int sec_ord_hess, int n_channels) {
 	try {
 		auto *t = new mtfhost_tracker();
-		t->pair = std::make_shared<hip::HipPair>(am, ssm, resx, resy, 1e-8, 1.0, 8, 10.0, 0, device, nullptr);
+		t->pair = std::make_shared<hip::HipPair>(am, ssm, resx, resy, 1e-8, 1.0, 8, 10.0, 0, device, nullptr, n_channels);
 		t->am = std::make_shared<hip::HipAM>(t->pair);
 		t->ssm = std::make_shared<hip::HipSSM>(t->pair);
 		nt::SMParams p;
@@ -53,7 +53,7 @@ static int guarded(mtfhost_tracker *t, void (*fn)(mtfhost_tracker *, const void 
 	catch (const std::exception &e) { g_err = e.what(); return -2; }
 }
 int mtfhost_set_image(mtfhost_tracker *t, const float *img, int rows, int cols, int step) {
-	ImageView v{img, rows, cols, step};
+	ImageView v{img, rows, cols, step, (int)t->am->getNChannels()};
 	return guarded(t, [](mtfhost_tracker *tt, const void *in, void *) { tt->sm->setImage(*(const ImageView *)in); }, &v, nullptr);
 }
 int mtfhost_initialize(mtfhost_tracker *t, const double *corners) {

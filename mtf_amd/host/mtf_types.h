@@ -79,7 +79,8 @@ struct CornersT {
 /* the float32 single-channel image the AM borrows (cv::Mat CV_32FC1 in the reference) */
 struct ImageView {
 	const float *data;
-	int rows, cols, step; /* step in elements */
+	int rows, cols, step; /* step in elements (floats) */
+	int channels = 1;     /* 1: CV_32FC1, 3: CV_32FC3 interleaved */
 };
 
 namespace utils {

@@ -123,6 +123,7 @@ class NTSearchMethod:
 
     def __init__(self, ctx, sm, am=L.AM_SSD, ssm=L.SSM_HOMOGRAPHY, resx=50, resy=50, n_targets=1, am_params=None,
                  **params):
+        """am_params may carry n_channels=3: MCSSD / MCNCC / MCMI (the context then holds an H x W x 3 float32 frame)"""
         self.batch = Batch(ctx, am, ssm, resx, resy, n_targets, **(am_params or {}))
         self.B, self.S = n_targets, self.batch.S
         self.sm = sm_desc(sm, **params)

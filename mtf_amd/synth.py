@@ -52,6 +52,11 @@ def make_frame(h=1024, w=1024, seed=DEFAULT_SEED, n_waves=32):
     return np.ascontiguousarray(img.astype(np.float32))
 
 
+def make_frame_mc(h=512, w=512, seed=DEFAULT_SEED, channels=3):
+    """float32 H x W x C frame (CV_32FC3 layout, interleaved): one independent texture per channel."""
+    return np.ascontiguousarray(np.stack([make_frame(h, w, seed + 101 * c) for c in range(channels)], axis=2))
+
+
 def homography_from_state(p):
     """3x3 warp of the reference's 8-dof parameterisation (SSM/src/Homography.cc:94-107)."""
     p = np.asarray(p, dtype=np.float64)
@@ -82,6 +87,9 @@ def warp_frame(img, p_true, centre):
     A point q of the new frame shows frame t at W^{-1}(q - c) + c ... i.e. an object at x in
     frame t appears at W(x - c) + c in the new frame.
     """
+    if img.ndim == 3:
+        return np.ascontiguousarray(np.stack([warp_frame(np.ascontiguousarray(img[..., c]), p_true, centre)
+                                              for c in range(img.shape[2])], axis=2))
     h, w = img.shape
     W = homography_from_state(p_true)
     Wi = np.linalg.inv(W)

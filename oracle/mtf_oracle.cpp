@@ -133,6 +133,92 @@ void warped_img_hess(double *hess, const float *img, int h, int w, const double 
 	}
 }
 
+/* ---- multi-channel (mc::) variants: image H x W x C float32 interleaved, outputs interleaved per pixel
+ * (ch_pix_id = pix_id * C + channel).  mc::PixVal<Linear, Constant>::get Utilities/include/mtf/Utilities/imgUtils.h:505-551:
+ * the four bilinear WEIGHTS are formed first and then applied per channel -- a different rounding order from the
+ * single-channel expression, kept as is. ---- */
+void pix_val_mc(double *out, const float *img, int h, int w, int C, double x, double y) {
+	const double overflow_val = 128.0;
+	if (overflow(x, y, h, w)) { for (int c = 0; c < C; ++c) out[c] = overflow_val; return; }
+	int lx = static_cast<int>(x), ly = static_cast<int>(y);
+	double dx = x - lx, dy = y - ly;
+	int ux = dx == 0 ? lx : lx + 1, uy = dy == 0 ? ly : ly + 1;
+	if (overflow(lx, ly, h, w) || overflow(ux, uy, h, w)) { for (int c = 0; c < C; ++c) out[c] = overflow_val; return; }
+	double ly_lx = (1 - dx) * (1 - dy), ly_ux = dx * (1 - dy), uy_lx = (1 - dx) * dy, uy_ux = dx * dy;
+	const float *p00 = img + (static_cast<size_t>(ly) * w + lx) * C, *p01 = img + (static_cast<size_t>(ly) * w + ux) * C;
+	const float *p10 = img + (static_cast<size_t>(uy) * w + lx) * C, *p11 = img + (static_cast<size_t>(uy) * w + ux) * C;
+	for (int c = 0; c < C; ++c) out[c] = p00[c] * ly_lx + p01[c] * ly_ux + p10[c] * uy_lx + p11[c] * uy_ux;
+}
+/* mc::getPixVals imgUtils.cc:867-882 */
+void pix_vals_mc(double *out, const float *img, int h, int w, int C, const double *pts, int npix, double mult, double add) {
+	for (int i = 0; i < npix; ++i) {
+		double v[4];
+		pix_val_mc(v, img, h, w, C, pts[2 * i], pts[2 * i + 1]);
+		for (int c = 0; c < C; ++c) out[i * C + c] = mult * v[c] + add;
+	}
+}
+/* mc::getImgGrad imgUtils.cc:977-1005 ; grad is (npix*C) x 2 col-major */
+void img_grad_mc(double *grad, const float *img, int h, int w, int C, const double *pts, double eps, int npix, double pix_mult) {
+	double mult = pix_mult / (2 * eps);
+	const int P = npix * C;
+	for (int i = 0; i < npix; ++i) {
+		double cx = pts[2 * i], cy = pts[2 * i + 1];
+		double ix[4], dx[4], iy[4], dy[4];
+		pix_val_mc(ix, img, h, w, C, cx + eps, cy); pix_val_mc(dx, img, h, w, C, cx - eps, cy);
+		pix_val_mc(iy, img, h, w, C, cx, cy + eps); pix_val_mc(dy, img, h, w, C, cx, cy - eps);
+		for (int c = 0; c < C; ++c) { grad[i * C + c] = (ix[c] - dx[c]) * mult; grad[P + i * C + c] = (iy[c] - dy[c]) * mult; }
+	}
+}
+/* mc::getWarpedImgGrad imgUtils.cc:914-944 */
+void warped_img_grad_mc(double *grad, const float *img, int h, int w, int C, const double *gp, double eps, int npix, double pix_mult) {
+	double mult = pix_mult / (2 * eps);
+	const int P = npix * C;
+	for (int i = 0; i < npix; ++i) {
+		const double *p = gp + 8 * i;
+		double ix[4], dx[4], iy[4], dy[4];
+		pix_val_mc(ix, img, h, w, C, p[0], p[1]); pix_val_mc(dx, img, h, w, C, p[2], p[3]);
+		pix_val_mc(iy, img, h, w, C, p[4], p[5]); pix_val_mc(dy, img, h, w, C, p[6], p[7]);
+		for (int c = 0; c < C; ++c) { grad[i * C + c] = (ix[c] - dx[c]) * mult; grad[P + i * C + c] = (iy[c] - dy[c]) * mult; }
+	}
+}
+/* mc::getImgHess imgUtils.cc:1127-1168 ; hess is 4 x (npix*C) */
+void img_hess_mc(double *hess, const float *img, int h, int w, int C, const double *pts, double eps, int npix, double pix_mult) {
+	double eps2 = 2 * eps, mult = pix_mult / (eps2 * eps2);
+	for (int i = 0; i < npix; ++i) {
+		double cx = pts[2 * i], cy = pts[2 * i + 1];
+		double c0[4], ix[4], dx[4], iy[4], dy[4], a[4], b[4], c2[4], d[4];
+		pix_val_mc(c0, img, h, w, C, cx, cy);
+		pix_val_mc(ix, img, h, w, C, cx + eps2, cy); pix_val_mc(dx, img, h, w, C, cx - eps2, cy);
+		pix_val_mc(iy, img, h, w, C, cx, cy + eps2); pix_val_mc(dy, img, h, w, C, cx, cy - eps2);
+		double inc_x = cx + eps, dec_x = cx - eps, inc_y = cy + eps, dec_y = cy - eps;
+		pix_val_mc(a, img, h, w, C, inc_x, inc_y); pix_val_mc(b, img, h, w, C, dec_x, dec_y);
+		pix_val_mc(c2, img, h, w, C, inc_x, dec_y); pix_val_mc(d, img, h, w, C, dec_x, inc_y);
+		for (int c = 0; c < C; ++c) {
+			double *o = hess + 4 * (i * C + c);
+			o[0] = (ix[c] + dx[c] - 2 * c0[c]) * mult;
+			o[3] = (iy[c] + dy[c] - 2 * c0[c]) * mult;
+			o[1] = o[2] = ((a[c] + b[c]) - (c2[c] + d[c])) * mult;
+		}
+	}
+}
+/* mc::getWarpedImgHess imgUtils.cc:1036-1075 */
+void warped_img_hess_mc(double *hess, const float *img, int h, int w, int C, const double *pts, const double *hp, double eps,
+	int npix, double pix_mult) {
+	double eps2 = 2 * eps, mult = pix_mult / (eps2 * eps2);
+	for (int i = 0; i < npix; ++i) {
+		const double *p = hp + 16 * i;
+		double c0[4], s[8][4];
+		pix_val_mc(c0, img, h, w, C, pts[2 * i], pts[2 * i + 1]);
+		for (int k = 0; k < 8; ++k) pix_val_mc(s[k], img, h, w, C, p[2 * k], p[2 * k + 1]);
+		for (int c = 0; c < C; ++c) {
+			double *o = hess + 4 * (i * C + c);
+			o[0] = (s[0][c] + s[1][c] - 2 * c0[c]) * mult;
+			o[3] = (s[2][c] + s[3][c] - 2 * c0[c]) * mult;
+			o[1] = o[2] = ((s[4][c] + s[5][c]) - (s[6][c] + s[7][c])) * mult;
+		}
+	}
+}
+
 /* ===================================================================== */
 /* small dense math (Eigen in the reference)                              */
 /* ===================================================================== */
@@ -347,6 +433,7 @@ void warp_hm(const Mat3 &W, const double *in3, double *out3, int n) {
 
 struct mtfo_ssm {
 	int kind, resx, resy, n, S;
+	int C = 1, P = 0; /* channels of the paired AM (StateSpaceModel::initialize(corners, n_channels)) and rows n * C */
 	vecd norm_pts, norm_pts_hm, norm_corners, norm_corners_hm;
 	vecd init_pts, curr_pts, init_pts_hm, curr_pts_hm;
 	vecd init_corners, curr_corners, init_corners_hm, curr_corners_hm;
@@ -357,6 +444,7 @@ struct mtfo_ssm {
 	 * normalised grid with pixel-like extents (SSM/src/Affine.cc:47-63) */
 	mtfo_ssm(int _kind, int _resx, int _resy) : kind(_kind), resx(_resx), resy(_resy),
 		n(_resx * _resy), S(_kind == MTFO_SSM_HOMOGRAPHY ? 8 : 6) {
+		P = n;
 		norm_pts.resize(2 * n); norm_pts_hm.resize(3 * n);
 		norm_corners.resize(8); norm_corners_hm.resize(12);
 		init_pts.resize(2 * n); curr_pts.resize(2 * n);
@@ -513,27 +601,30 @@ struct mtfo_ssm {
 	}
 
 	/* row writers shared by the pixel-Jacobian variants */
-	inline void hom_row(double *J, int i, double Ix, double Iy, double x, double y,
+	inline void hom_row(double *J, int q, double Ix, double Iy, double x, double y,
 		double px, double py) const {
 		double Ixx = Ix * x, Iyy = Iy * y, Ixy = Ix * y, Iyx = Iy * x;
-		J[0 * n + i] = Ixx; J[1 * n + i] = Ixy; J[2 * n + i] = Ix;
-		J[3 * n + i] = Iyx; J[4 * n + i] = Iyy; J[5 * n + i] = Iy;
-		J[6 * n + i] = -px * Ixx - py * Iyx;
-		J[7 * n + i] = -px * Ixy - py * Iyy;
+		J[0 * P + q] = Ixx; J[1 * P + q] = Ixy; J[2 * P + q] = Ix;
+		J[3 * P + q] = Iyx; J[4 * P + q] = Iyy; J[5 * P + q] = Iy;
+		J[6 * P + q] = -px * Ixx - py * Iyx;
+		J[7 * P + q] = -px * Ixy - py * Iyy;
 	}
 
 	/* Homography::cmptInitPixJacobian SSM/src/Homography.cc:157-191 ;
 	 * Affine::cmptInitPixJacobian SSM/src/Affine.cc:160-182 */
 	void init_pix_jacobian(double *J, const double *g) const {
 		for (int i = 0; i < n; ++i) {
+			for (int ch = 0; ch < C; ++ch) {
+			const int q = i * C + ch;
 			double x = init_pts[2 * i], y = init_pts[2 * i + 1];
-			double Ix = g[i], Iy = g[n + i];
+			double Ix = g[q], Iy = g[P + q];
 			if (kind == MTFO_SSM_HOMOGRAPHY) {
-				hom_row(J, i, Ix, Iy, x, y, x, y);
+				hom_row(J, q, Ix, Iy, x, y, x, y);
 			} else {
-				J[0 * n + i] = Ix; J[1 * n + i] = Iy;
-				J[2 * n + i] = Ix * x; J[3 * n + i] = Ix * y;
-				J[4 * n + i] = Iy * x; J[5 * n + i] = Iy * y;
+				J[0 * P + q] = Ix; J[1 * P + q] = Iy;
+				J[2 * P + q] = Ix * x; J[3 * P + q] = Ix * y;
+				J[4 * P + q] = Iy * x; J[5 * P + q] = Iy * y;
+			}
 			}
 		}
 	}
@@ -542,11 +633,14 @@ struct mtfo_ssm {
 	void pix_jacobian(double *J, const double *g) const {
 		if (kind == MTFO_SSM_AFFINE) { init_pix_jacobian(J, g); return; }
 		for (int i = 0; i < n; ++i) {
+			for (int ch = 0; ch < C; ++ch) {
+			const int q = i * C + ch;
 			double x = init_pts[2 * i], y = init_pts[2 * i + 1];
 			double cx = curr_pts[2 * i], cy = curr_pts[2 * i + 1];
 			double inv_d = 1.0 / curr_pts_hm[3 * i + 2];
-			double Ix = g[i] * inv_d, Iy = g[n + i] * inv_d;
-			hom_row(J, i, Ix, Iy, x, y, cx, cy);
+			double Ix = g[q] * inv_d, Iy = g[P + q] * inv_d;
+			hom_row(J, q, Ix, Iy, x, y, cx, cy);
+			}
 		}
 	}
 	/* Homography::cmptWarpedPixJacobian SSM/src/Homography.cc:231-294 ;
@@ -557,28 +651,34 @@ struct mtfo_ssm {
 			double a10 = curr_warp(1, 0), a11 = curr_warp(1, 1);
 			double a20 = curr_warp(2, 0), a21 = curr_warp(2, 1);
 			for (int i = 0; i < n; ++i) {
+				for (int ch = 0; ch < C; ++ch) {
+				const int q = i * C + ch;
 				double wx = curr_pts[2 * i], wy = curr_pts[2 * i + 1];
 				double D = curr_pts_hm[3 * i + 2];
 				double inv_det = 1.0 / D;
 				double dwx_dx = (a00 - a20 * wx), dwx_dy = (a01 - a21 * wx);
 				double dwy_dx = (a10 - a20 * wy), dwy_dy = (a11 - a21 * wy);
 				double x = init_pts[2 * i], y = init_pts[2 * i + 1];
-				double Ix = (dwx_dx * g[i] + dwy_dx * g[n + i]) * inv_det;
-				double Iy = (dwx_dy * g[i] + dwy_dy * g[n + i]) * inv_det;
-				hom_row(J, i, Ix, Iy, x, y, x, y);
+				double Ix = (dwx_dx * g[q] + dwy_dx * g[P + q]) * inv_det;
+				double Iy = (dwx_dy * g[q] + dwy_dy * g[P + q]) * inv_det;
+				hom_row(J, q, Ix, Iy, x, y, x, y);
+				}
 			}
 		} else {
 			double a = state[2] + 1, b = state[3], c = state[4], d = state[5] + 1;
 			for (int i = 0; i < n; ++i) {
+				for (int ch = 0; ch < C; ++ch) {
+				const int q = i * C + ch;
 				double x = init_pts[2 * i], y = init_pts[2 * i + 1];
-				double Ix = g[i], Iy = g[n + i];
+				double Ix = g[q], Iy = g[P + q];
 				double Ixx = Ix * x, Ixy = Ix * y, Iyy = Iy * y, Iyx = Iy * x;
-				J[0 * n + i] = Ix * a + Iy * c;
-				J[1 * n + i] = Ix * b + Iy * d;
-				J[2 * n + i] = Ixx * a + Iyx * c;
-				J[3 * n + i] = Ixy * a + Iyy * c;
-				J[4 * n + i] = Ixx * b + Iyx * d;
-				J[5 * n + i] = Ixy * b + Iyy * d;
+				J[0 * P + q] = Ix * a + Iy * c;
+				J[1 * P + q] = Ix * b + Iy * d;
+				J[2 * P + q] = Ixx * a + Iyx * c;
+				J[3 * P + q] = Ixy * a + Iyy * c;
+				J[4 * P + q] = Ixx * b + Iyx * d;
+				J[5 * P + q] = Ixy * b + Iyy * d;
+				}
 			}
 		}
 	}
@@ -590,28 +690,34 @@ struct mtfo_ssm {
 			double h10 = curr_warp(1, 0), h11 = curr_warp(1, 1);
 			double h20 = curr_warp(2, 0), h21 = curr_warp(2, 1);
 			for (int i = 0; i < n; ++i) {
+				for (int ch = 0; ch < C; ++ch) {
+				const int q = i * C + ch;
 				double cx = curr_pts[2 * i], cy = curr_pts[2 * i + 1];
 				double a = (h00 - h20 * cx), b = (h01 - h21 * cx);
 				double c = (h10 - h20 * cy), d = (h11 - h21 * cy);
 				double inv_factor = 1.0 / (a * d - b * c);
 				double x = init_pts[2 * i], y = init_pts[2 * i + 1];
-				double Ix = (d * g[i] - c * g[n + i]) * inv_factor;
-				double Iy = (a * g[n + i] - b * g[i]) * inv_factor;
-				hom_row(J, i, Ix, Iy, x, y, cx, cy);
+				double Ix = (d * g[q] - c * g[P + q]) * inv_factor;
+				double Iy = (a * g[P + q] - b * g[q]) * inv_factor;
+				hom_row(J, q, Ix, Iy, x, y, cx, cy);
+				}
 			}
 		} else {
 			double a = state[2] + 1, b = state[3], c = state[4], d = state[5] + 1;
 			double inv_det = 1.0 / (a * d - b * c);
 			for (int i = 0; i < n; ++i) {
+				for (int ch = 0; ch < C; ++ch) {
+				const int q = i * C + ch;
 				double x = init_pts[2 * i], y = init_pts[2 * i + 1];
-				double Ix = g[i], Iy = g[n + i];
+				double Ix = g[q], Iy = g[P + q];
 				double Ixx = Ix * x, Ixy = Ix * y, Iyy = Iy * y, Iyx = Iy * x;
-				J[0 * n + i] = (Ix * d - Iy * c) * inv_det;
-				J[1 * n + i] = (Iy * a - Ix * b) * inv_det;
-				J[2 * n + i] = (Ixx * d - Iyx * c) * inv_det;
-				J[3 * n + i] = (Ixy * d - Iyy * c) * inv_det;
-				J[4 * n + i] = (Iyx * a - Ixx * b) * inv_det;
-				J[5 * n + i] = (Iyy * a - Ixy * b) * inv_det;
+				J[0 * P + q] = (Ix * d - Iy * c) * inv_det;
+				J[1 * P + q] = (Iy * a - Ix * b) * inv_det;
+				J[2 * P + q] = (Ixx * d - Iyx * c) * inv_det;
+				J[3 * P + q] = (Ixy * d - Iyy * c) * inv_det;
+				J[4 * P + q] = (Iyx * a - Ixx * b) * inv_det;
+				J[5 * P + q] = (Iyy * a - Ixy * b) * inv_det;
+				}
 			}
 		}
 	}
@@ -692,12 +798,15 @@ struct mtfo_ssm {
 	void init_pix_hessian(double *d2, const double *ph, const double *g) const {
 		double r0[8] = {0}, r1[8] = {0};
 		for (int i = 0; i < n; ++i) {
+			for (int ch = 0; ch < C; ++ch) {
+			const int q = i * C + ch;
 			double x = init_pts[2 * i], y = init_pts[2 * i + 1];
-			double *out = d2 + static_cast<size_t>(i) * S * S;
-			const double *m = ph + 4 * i;   /* Map<Matrix2d>: col-major (m0 m2; m1 m3) */
+			double *out = d2 + static_cast<size_t>(q) * S * S;
+			const double *m = ph + 4 * q;   /* Map<Matrix2d>: col-major (m0 m2; m1 m3) */
 			dw_dp_rows(r0, r1, x, y, x, y);
 			sandwich(out, r0, r1, m[0], m[2], m[1], m[3]);
-			if (kind == MTFO_SSM_HOMOGRAPHY) hom_tail(out, g[i], g[n + i], x, y, -1.0, 2.0, x, y);
+			if (kind == MTFO_SSM_HOMOGRAPHY) hom_tail(out, g[q], g[P + q], x, y, -1.0, 2.0, x, y);
+			}
 		}
 	}
 	/* Homography::cmptPixHessian SSM/src/Homography.cc:427-513 (Affine: not implemented, StateSpaceModel.h:186-189) */
@@ -705,17 +814,19 @@ struct mtfo_ssm {
 		if (kind != MTFO_SSM_HOMOGRAPHY) return -2;
 		double r0[8] = {0}, r1[8] = {0};
 		for (int i = 0; i < n; ++i) {
+			for (int ch = 0; ch < C; ++ch) {
+			const int q = i * C + ch;
 			double x = init_pts[2 * i], y = init_pts[2 * i + 1];
 			double cx = curr_pts[2 * i], cy = curr_pts[2 * i + 1];
 			double D = curr_pts_hm[3 * i + 2];
-			double *out = d2 + static_cast<size_t>(i) * 64;
-			const double *m = ph + 4 * i;
+			double *out = d2 + static_cast<size_t>(q) * 64;
+			const double *m = ph + 4 * q;
 			dw_dp_rows(r0, r1, x, y, cx, cy);
 			for (int j = 0; j < 8; ++j) { r0[j] /= D; r1[j] /= D; }
 			double inv_d2 = 1.0 / (D * D);
 			sandwich(out, r0, r1, m[0], m[2], m[1], m[3]);
 			/* the reference scales each third-order product by inv_d_squared (:490-507) */
-			double Ix = g[i], Iy = g[n + i];
+			double Ix = g[q], Iy = g[P + q];
 			double Ixx = Ix * x, Ixy = Ix * y, Iyy = Iy * y, Iyx = Iy * x;
 			double Ixxx = Ixx * x, Ixxy = Ixx * y, Ixyy = Ixy * y;
 			double Iyyy = Iyy * y, Iyyx = Iyy * x, Iyxx = Iyx * x;
@@ -730,6 +841,7 @@ struct mtfo_ssm {
 			D2(7, 7) += 2 * (Ixyy * cx + Iyyy * cy) * inv_d2;
 			for (int r = 0; r < 5; ++r) { D2(6, r) = D2(r, 6); D2(7, r) = D2(r, 7); }
 #undef D2
+			}
 		}
 		return 0;
 	}
@@ -739,21 +851,26 @@ struct mtfo_ssm {
 		if (kind == MTFO_SSM_AFFINE) {
 			double a2 = state[2] + 1, a3 = state[3], a4 = state[4], a5 = state[5] + 1;
 			for (int i = 0; i < n; ++i) {
+				for (int ch = 0; ch < C; ++ch) {
+				const int q = i * C + ch;
 				double x = init_pts[2 * i], y = init_pts[2 * i + 1];
-				const double *m = ph + 4 * i;
+				const double *m = ph + 4 * q;
 				/* dw_dx^T * M * dw_dx with dw_dx = (a2 a3; a4 a5) */
 				double t00 = m[0] * a2 + m[2] * a4, t01 = m[0] * a3 + m[2] * a5;
 				double t10 = m[1] * a2 + m[3] * a4, t11 = m[1] * a3 + m[3] * a5;
 				double q00 = a2 * t00 + a4 * t10, q01 = a2 * t01 + a4 * t11;
 				double q10 = a3 * t00 + a5 * t10, q11 = a3 * t01 + a5 * t11;
 				dw_dp_rows(r0, r1, x, y, x, y);
-				sandwich(d2 + static_cast<size_t>(i) * 36, r0, r1, q00, q01, q10, q11);
+				sandwich(d2 + static_cast<size_t>(q) * 36, r0, r1, q00, q01, q10, q11);
+				}
 			}
 			return;
 		}
 		double a00 = curr_warp(0, 0), a01 = curr_warp(0, 1), a10 = curr_warp(1, 0), a11 = curr_warp(1, 1);
 		double a20 = curr_warp(2, 0), a21 = curr_warp(2, 1);
 		for (int i = 0; i < n; ++i) {
+			for (int ch = 0; ch < C; ++ch) {
+			const int q = i * C + ch;
 			double wx = curr_pts[2 * i], wy = curr_pts[2 * i + 1];
 			double D = curr_pts_hm[3 * i + 2], D_inv = 1.0 / D;
 			double dwx_dx = (a00 - a20 * wx) * D_inv, dwx_dy = (a01 - a21 * wx) * D_inv;
@@ -763,8 +880,8 @@ struct mtfo_ssm {
 			double d2wy_dx2 = -2 * a20 * dwy_dx * D_inv, d2wy_dxdy = -(a21 * dwy_dx + a20 * dwy_dy) * D_inv;
 			double d2wy_dy2 = -2 * a21 * dwy_dy * D_inv;
 			double x = init_pts[2 * i], y = init_pts[2 * i + 1];
-			const double *m = ph + 4 * i;
-			double gx = g[i], gy = g[n + i];
+			const double *m = ph + 4 * q;
+			double gx = g[q], gy = g[P + q];
 			/* dw_dX^T * M * dw_dX, dw_dX = (dwx_dx dwx_dy; dwy_dx dwy_dy) */
 			double t00 = m[0] * dwx_dx + m[2] * dwy_dx, t01 = m[0] * dwx_dy + m[2] * dwy_dy;
 			double t10 = m[1] * dwx_dx + m[3] * dwy_dx, t11 = m[1] * dwx_dy + m[3] * dwy_dy;
@@ -774,12 +891,13 @@ struct mtfo_ssm {
 			q01 = q01 + gx * d2wx_dxdy + gy * d2wy_dxdy;
 			q10 = q10 + gx * d2wx_dxdy + gy * d2wy_dxdy;
 			q11 = q11 + gx * d2wx_dy2 + gy * d2wy_dy2;
-			double *out = d2 + static_cast<size_t>(i) * 64;
+			double *out = d2 + static_cast<size_t>(q) * 64;
 			dw_dp_rows(r0, r1, x, y, x, y);
 			sandwich(out, r0, r1, q00, q01, q10, q11);
 			double Ix = dwx_dx * gx + dwy_dx * gy;
 			double Iy = dwx_dy * gx + dwy_dy * gy;
 			hom_tail(out, Ix, Iy, x, y, -1.0, 2.0, x, y);
+			}
 		}
 	}
 	/* Homography::cmptApproxPixHessian SSM/src/Homography.cc:696-801 (Affine: not implemented) */
@@ -789,6 +907,8 @@ struct mtfo_ssm {
 		double h20 = curr_warp(2, 0), h21 = curr_warp(2, 1);
 		double r0[8] = {0}, r1[8] = {0};
 		for (int i = 0; i < n; ++i) {
+			for (int ch = 0; ch < C; ++ch) {
+			const int q = i * C + ch;
 			double cx = curr_pts[2 * i], cy = curr_pts[2 * i + 1];
 			double D = curr_pts_hm[3 * i + 2];
 			double inv_det2 = 1.0 / (D * D), inv_det = 1.0 / D;
@@ -805,9 +925,9 @@ struct mtfo_ssm {
 			double cyy = -(h21 * h10 + h20 * (d * D - h21 * cy)) * inv_det2;
 			double dy = -h21 * (h11 + d * D - h21 * cy) * inv_det2;
 			double x = init_pts[2 * i], y = init_pts[2 * i + 1];
-			const double *m = ph + 4 * i;
-			double Ix = (d * g[i] - c * g[n + i]) * inv_factor;
-			double Iy = (a * g[n + i] - b * g[i]) * inv_factor;
+			const double *m = ph + 4 * q;
+			double Ix = (d * g[q] - c * g[P + q]) * inv_factor;
+			double Iy = (a * g[P + q] - b * g[q]) * inv_factor;
 			/* inner = M - (Ix * d2w_dx2_x + Iy * d2w_dx2_y); `<<` fills row-major: (ax bx; cx dx) */
 			double n00 = m[0] - (Ix * ax + Iy * ay), n01 = m[2] - (Ix * bx + Iy * by);
 			double n10 = m[1] - (Ix * cxx + Iy * cyy), n11 = m[3] - (Ix * dx + Iy * dy);
@@ -816,10 +936,11 @@ struct mtfo_ssm {
 			double t10 = n10 * i00 + n11 * i10, t11 = n10 * i01 + n11 * i11;
 			double q00 = i00 * t00 + i10 * t10, q01 = i00 * t01 + i10 * t11;
 			double q10 = i01 * t00 + i11 * t10, q11 = i01 * t01 + i11 * t11;
-			double *out = d2 + static_cast<size_t>(i) * 64;
+			double *out = d2 + static_cast<size_t>(q) * 64;
 			dw_dp_rows(r0, r1, x, y, x, y);
 			sandwich(out, r0, r1, q00, q01, q10, q11);
 			hom_tail(out, Ix, Iy, x, y, 1.0, -1.0, x, y);
+			}
 		}
 		return 0;
 	}
@@ -880,7 +1001,8 @@ inline double bspl3_hess(double x) {
 } // namespace
 
 struct mtfo_am {
-	int kind, resx, resy, n;
+	int kind, resx, resy, n;   /* n = patch_size = npix * C rows (ImageBase: patch_size = n_pix * n_channels) */
+	int npix, C = 1;
 	double grad_eps, likelihood_alpha;
 	const float *img; int h, w;
 	double norm_mult, norm_add;
@@ -903,7 +1025,7 @@ struct mtfo_am {
 
 	mtfo_am(int _kind, int _resx, int _resy, double _grad_eps, double _alpha,
 		int _n_bins, double _pre_seed, int _pou) : kind(_kind), resx(_resx), resy(_resy),
-		n(_resx * _resy), grad_eps(_grad_eps), likelihood_alpha(_alpha), img(nullptr), h(0), w(0),
+		n(_resx * _resy), npix(_resx * _resy), grad_eps(_grad_eps), likelihood_alpha(_alpha), img(nullptr), h(0), w(0),
 		norm_mult(1), norm_add(0), init_pix_vals(false), init_pix_grad(false), init_sim(false),
 		init_grad(false), init_hess(false), f(0), n_bins(_n_bins), pre_seed(_pre_seed), pou(_pou) {
 		if (kind == MTFO_AM_MI) {
@@ -922,45 +1044,71 @@ struct mtfo_am {
 		}
 	}
 
+	/* MCSSD / MCNCC / MCMI: the same classes constructed with n_channels = 3 (AM/src/MCSSD.cc, MCNCC.cc, MCMI.cc);
+	 * only the sampling differs (ImageBase.cc switches on MTF_32FC3 to the utils::mc:: functions) */
+	void set_channels(int c) {
+		C = c; n = npix * C;
+		if (kind == MTFO_AM_MI) hist_norm_mult = 1.0 / (static_cast<double>(n) + hist_pre_seed * n_bins);   /* MI.cc:104 (patch_size) */
+	}
+	void s_vals(double *out, const double *pts) const {
+		if (C == 1) pix_vals(out, img, h, w, pts, npix, norm_mult, norm_add);
+		else pix_vals_mc(out, img, h, w, C, pts, npix, norm_mult, norm_add);
+	}
+	void s_grad(double *out, const double *pts) const {
+		if (C == 1) img_grad(out, img, h, w, pts, grad_eps, npix, norm_mult);
+		else img_grad_mc(out, img, h, w, C, pts, grad_eps, npix, norm_mult);
+	}
+	void s_wgrad(double *out, const double *gp) const {
+		if (C == 1) warped_img_grad(out, img, h, w, gp, grad_eps, npix, norm_mult);
+		else warped_img_grad_mc(out, img, h, w, C, gp, grad_eps, npix, norm_mult);
+	}
+	void s_hess(double *out, const double *pts) const {
+		if (C == 1) img_hess(out, img, h, w, pts, hess_eps, npix, norm_mult);
+		else img_hess_mc(out, img, h, w, C, pts, hess_eps, npix, norm_mult);
+	}
+	void s_whess(double *out, const double *pts, const double *hp) const {
+		if (C == 1) warped_img_hess(out, img, h, w, pts, hp, hess_eps, npix, norm_mult);
+		else warped_img_hess_mc(out, img, h, w, C, pts, hp, hess_eps, npix, norm_mult);
+	}
 	/* ImageBase::initializePixVals AM/src/ImageBase.cc:62-99 (MI: AM/src/MI.cc:124-158) */
 	void initialize_pix_vals(const double *pts) {
 		if (!init_pix_vals) { I0.resize(n); It.resize(n); }
-		pix_vals(I0.data(), img, h, w, pts, n, norm_mult, norm_add);
+		s_vals(I0.data(), pts);
 		if (!init_pix_vals) { It = I0; init_pix_vals = true; }
 	}
 	/* ImageBase::updatePixVals AM/src/ImageBase.cc:268-290 */
-	void update_pix_vals(const double *pts) { pix_vals(It.data(), img, h, w, pts, n, norm_mult, norm_add); }
+	void update_pix_vals(const double *pts) { s_vals(It.data(), pts); }
 	/* ImageBase::initializePixGrad(PtsT) AM/src/ImageBase.cc:101-132 */
 	void initialize_pix_grad_pts(const double *pts) {
 		if (!init_pix_grad) { dI0_dx.resize(2 * n); dIt_dx.resize(2 * n); }
-		img_grad(dI0_dx.data(), img, h, w, pts, grad_eps, n, norm_mult);
+		s_grad(dI0_dx.data(), pts);
 		if (!init_pix_grad) { dIt_dx = dI0_dx; init_pix_grad = true; }
 	}
 	/* ImageBase::initializePixGrad(GradPtsT) AM/src/ImageBase.cc:134-172 */
 	void initialize_pix_grad_warped(const double *gp) {
 		if (!init_pix_grad) { dI0_dx.resize(2 * n); dIt_dx.resize(2 * n); }
-		warped_img_grad(dI0_dx.data(), img, h, w, gp, grad_eps, n, norm_mult);
+		s_wgrad(dI0_dx.data(), gp);
 		if (!init_pix_grad) { dIt_dx = dI0_dx; init_pix_grad = true; }
 	}
 	/* ImageBase::updatePixGrad(PtsT) :292-314 ; (GradPtsT) :340-362 */
-	void update_pix_grad_pts(const double *pts) { img_grad(dIt_dx.data(), img, h, w, pts, grad_eps, n, norm_mult); }
-	void update_pix_grad_warped(const double *gp) { warped_img_grad(dIt_dx.data(), img, h, w, gp, grad_eps, n, norm_mult); }
+	void update_pix_grad_pts(const double *pts) { s_grad(dIt_dx.data(), pts); }
+	void update_pix_grad_warped(const double *gp) { s_wgrad(dIt_dx.data(), gp); }
 
 	/* ImageBase::initializePixHess(PtsT) AM/src/ImageBase.cc:208-240 ; (PtsT, HessPtsT) :174-206 ;
 	 * updatePixHess :316-338 and :364-386 */
 	void initialize_pix_hess_pts(const double *pts) {
 		if (!init_pix_hess) { d2I0_dx2.resize(4 * static_cast<size_t>(n)); d2It_dx2.resize(4 * static_cast<size_t>(n)); }
-		img_hess(d2I0_dx2.data(), img, h, w, pts, hess_eps, n, norm_mult);
+		s_hess(d2I0_dx2.data(), pts);
 		if (!init_pix_hess) { d2It_dx2 = d2I0_dx2; init_pix_hess = true; }
 	}
 	void initialize_pix_hess_warped(const double *pts, const double *hp) {
 		if (!init_pix_hess) { d2I0_dx2.resize(4 * static_cast<size_t>(n)); d2It_dx2.resize(4 * static_cast<size_t>(n)); }
-		warped_img_hess(d2I0_dx2.data(), img, h, w, pts, hp, hess_eps, n, norm_mult);
+		s_whess(d2I0_dx2.data(), pts, hp);
 		if (!init_pix_hess) { d2It_dx2 = d2I0_dx2; init_pix_hess = true; }
 	}
-	void update_pix_hess_pts(const double *pts) { img_hess(d2It_dx2.data(), img, h, w, pts, hess_eps, n, norm_mult); }
+	void update_pix_hess_pts(const double *pts) { s_hess(d2It_dx2.data(), pts); }
 	void update_pix_hess_warped(const double *pts, const double *hp) {
-		warped_img_hess(d2It_dx2.data(), img, h, w, pts, hp, hess_eps, n, norm_mult);
+		s_whess(d2It_dx2.data(), pts, hp);
 	}
 
 	/* ---------------- similarity ---------------- */
@@ -1902,6 +2050,9 @@ mtfo_am *mtfo_am_create(int kind, int resx, int resy, double grad_eps, double al
 void mtfo_am_destroy(mtfo_am *a) { delete a; }
 int mtfo_am_n_pix(const mtfo_am *a) { return a->n; }
 void mtfo_am_set_curr_img(mtfo_am *a, const float *img, int h, int w) { a->img = img; a->h = h; a->w = w; }
+void mtfo_am_set_channels(mtfo_am *a, int n_channels) { a->set_channels(n_channels); }
+void mtfo_ssm_set_channels(mtfo_ssm *s, int n_channels) { s->C = n_channels; s->P = s->n * n_channels; }
+int mtfo_am_patch_size(const mtfo_am *a) { return a->n; }
 void mtfo_am_initialize_pix_vals(mtfo_am *a, const double *pts) { a->initialize_pix_vals(pts); }
 void mtfo_am_update_pix_vals(mtfo_am *a, const double *pts) { a->update_pix_vals(pts); }
 void mtfo_am_initialize_pix_grad_pts(mtfo_am *a, const double *pts) { a->initialize_pix_grad_pts(pts); }

@@ -96,6 +96,13 @@ mtfo_am *mtfo_am_create(int kind, int resx, int resy, double grad_eps,
 void mtfo_am_destroy(mtfo_am *a);
 int mtfo_am_n_pix(const mtfo_am *a);
 void mtfo_am_set_curr_img(mtfo_am *a, const float *img, int h, int w);
+/* multi-channel variants (MCSSD / MCNCC / MCMI = the same AM with n_channels 3, AM/src/MCSSD.cc etc.): the image is then
+ * H x W x C float32 interleaved (CV_32FC3), every per-pixel AM vector has n_pix * C entries interleaved per pixel, and the
+ * SSM's pixel Jacobians / Hessians have one row / block per (pixel, channel) (StateSpaceModel::initialize(corners, n_channels)).
+ * Call both before initialize. */
+void mtfo_am_set_channels(mtfo_am *a, int n_channels);
+void mtfo_ssm_set_channels(mtfo_ssm *s, int n_channels);
+int mtfo_am_patch_size(const mtfo_am *a);
 void mtfo_am_initialize_pix_vals(mtfo_am *a, const double *pts);
 void mtfo_am_update_pix_vals(mtfo_am *a, const double *pts);
 void mtfo_am_initialize_pix_grad_pts(mtfo_am *a, const double *pts);

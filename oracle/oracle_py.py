@@ -147,12 +147,18 @@ class SSM:
         self.kind, self.resx, self.resy = kind, resx, resy
         self.n = resx * resy
         self.S = 8 if kind == SSM_HOM else 6
+        self.C, self.P = 1, self.n
         self.h = C.c_void_p(lib().mtfo_ssm_create(kind, resx, resy))
 
     def __del__(self):
         if getattr(self, "h", None):
             lib().mtfo_ssm_destroy(self.h)
             self.h = None
+
+    def set_channels(self, c):
+        """StateSpaceModel::initialize(corners, n_channels): rows of the pixel Jacobians = n_pts * n_channels"""
+        self.C, self.P = c, self.n * c
+        lib().mtfo_ssm_set_channels(self.h, c)
 
     def get(self, what):
         code, per_pt = self.GET[what]
@@ -184,7 +190,7 @@ class SSM:
 
     def _jac(self, fn, grad):
         grad = _vec(grad)
-        J = np.empty(self.n * self.S)
+        J = np.empty(self.P * self.S)
         fn(self.h, _d(J), _d(grad))
         return J
 
@@ -206,11 +212,11 @@ class SSM:
     def _pix_hess(self, fn, pix_hess, grad):
         """(4N,) pix_hess + (2N,) pix_grad -> d2I_dp2 as (N, S, S) [pixel, row, col]; None where unimplemented"""
         pix_hess, grad = _vec(pix_hess), _vec(grad)
-        d2 = np.empty(self.n * self.S * self.S)
+        d2 = np.empty(self.P * self.S * self.S)
         rc = fn(self.h, _d(d2), _d(pix_hess), _d(grad))
         if rc != 0:
             return None
-        return d2.reshape(self.n, self.S, self.S).transpose(0, 2, 1)
+        return d2.reshape(self.P, self.S, self.S).transpose(0, 2, 1)
 
     def cmpt_init_pix_hessian(self, pix_hess, grad):
         return self._pix_hess(lib().mtfo_ssm_cmpt_init_pix_hessian, pix_hess, grad)
@@ -253,7 +259,15 @@ class AM:
             lib().mtfo_am_destroy(self.h)
             self.h = None
 
+    def set_channels(self, c):
+        """MCSSD / MCNCC / MCMI: n_channels = 3; every per-pixel vector then has n_pix * c entries"""
+        self.C = c
+        self.n = self.resx * self.resy * c
+        lib().mtfo_am_set_channels(self.h, c)
+
     def set_curr_img(self, img):
+        if img.ndim == 3:
+            assert img.shape[2] == getattr(self, "C", 1)
         assert img.dtype == np.float32 and img.flags["C_CONTIGUOUS"]
         self._img = img  # the oracle borrows the buffer, as ImageBase::setCurrImg does
         lib().mtfo_am_set_curr_img(self.h, _f(img), img.shape[0], img.shape[1])

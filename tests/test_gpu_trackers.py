@@ -256,3 +256,62 @@ def test_device_loop_refuses_second_order_hessians(gpu_ctx, frame):
     hs = LKTracker(gpu_ctx, L.SM_FCLK, L.SSM_HOMOGRAPHY, 30, 30, 2, host_solve=True, sec_ord_hess=1, hess_type=2, max_iters=5)
     hs.initialize(c)
     np.testing.assert_allclose(hs.update(), c, atol=1e-6)
+
+
+# ------------------------------------------------------------------ multi-channel appearance models (mc::)
+MC_CASES = [
+    (L.SM_ESM, L.AM_SSD, L.SSM_HOMOGRAPHY, 30, dict()),                                  # MCSSD
+    (L.SM_FCLK, L.AM_SSD, L.SSM_AFFINE, 30, dict(chained_warp=0, hess_type=2)),
+    (L.SM_ICLK, L.AM_NCC, L.SSM_AFFINE, 25, dict()),                                     # MCNCC
+    (L.SM_ESM, L.AM_NCC, L.SSM_HOMOGRAPHY, 30, dict(hess_type=4)),
+    (L.SM_ESM, L.AM_MI, L.SSM_HOMOGRAPHY, 30, dict()),                                   # MCMI
+    (L.SM_FCLK, L.AM_MI, L.SSM_AFFINE, 30, dict()),
+    (L.SM_ESM, L.AM_SSD, L.SSM_AFFINE, 30, dict(sec_ord_hess=1, hess_type=5)),           # second order over (pixel, channel) rows
+    (L.SM_ICLK, L.AM_SSD, L.SSM_HOMOGRAPHY, 30, dict(sec_ord_hess=1, hess_type=2, chained_warp=0)),
+]
+
+
+@pytest.mark.parametrize("case", MC_CASES, ids=lambda c: "sm%d-am%d-ssm%d-%s" % (c[0], c[1], c[2], "_".join("%s%s" % kv for kv in c[4].items())))
+def test_multichannel_models_match_oracle(oracle, gpu_ctx, case):
+    """MCSSD / MCNCC / MCMI (the single-channel classes built with n_channels = 3, AM/src/MCSSD.cc etc.) on a 32FC3 frame:
+    per-channel bilinear sampling with the mc:: operation order (imgUtils.h:505-551), one Jacobian row / Hessian block per
+    (pixel, channel), against the oracle's trackers."""
+    sm_kind, am, ssm, res, extra = case
+    rng = np.random.default_rng(37)
+    centre = (128.0, 120.0)
+    frame = synth.make_frame_mc(256, 256)
+    corners = synth.square_corners(centre[0], centre[1], 70.0)
+    p_true = synth.random_small_homography(rng, 0.3)
+    frame2 = synth.warp_frame(frame, p_true, centre)
+    params = dict(leven_marq=0, max_iters=5, epsilon=-1.0)
+    params.update(extra)
+    o_ssm = oracle.SSM(ssm, res, res); o_am = oracle.AM(am, res, res)
+    o_am.set_channels(3); o_ssm.set_channels(3)
+    o_am.set_curr_img(frame)
+    otrk = oracle.Tracker(sm_kind, o_am, o_ssm, **params)
+    otrk.initialize(corners)
+    gpu_ctx.set_image(frame)
+    nt = NTSearchMethod(gpu_ctx, sm_kind, am, ssm, res, res, 1, am_params=dict(n_channels=3), **params)
+    assert nt.batch.N == 3 * res * res and nt.batch.NP == res * res
+    nt.initialize(corners[None])
+    # template samples are bit-identical (same grid to 1e-13, hess/grad aside): interleaved per pixel, channel fastest
+    np.testing.assert_allclose(nt.batch.read(L.BUF_I0)[0], o_am.get("I0"), rtol=0, atol=1e-9)
+    o_am.set_curr_img(frame2); gpu_ctx.set_image(frame2)
+    otrk.update(); nt.update()
+    assert otrk.status() == 0
+    otrace = otrk.trace()
+    rec, got = otrace[0], nt.trace[0]
+    assert abs(got["f"][0] - rec["f"]) <= 1e-7 * abs(rec["f"])
+    assert np.linalg.norm(got["H"][0] - rec["H"]) <= 1e-5 * np.linalg.norm(rec["H"])
+    gs = max(np.linalg.norm(rec["g"]), 1e-3 * np.sqrt(abs(np.trace(rec["H"]))))
+    assert np.linalg.norm(got["g"][0] - rec["g"]) <= 1e-4 * gs
+    so = bool(params.get("sec_ord_hess"))
+    np.testing.assert_allclose(nt.get_region()[0], otrk.get_region(), atol=5e-2 if so else 5e-4)
+    # a single-channel frame is refused, as ImageBase::setCurrImg does on a type mismatch
+    gpu_ctx.set_image(np.ascontiguousarray(frame[..., 0]))
+    with pytest.raises(mtf_amd.InvalidArgument):
+        nt.batch.update_pix_vals()
+    # the fused / candidate paths are single-channel only
+    gpu_ctx.set_image(frame)
+    with pytest.raises(mtf_amd.FunctionNotImplemented):
+        nt.batch.init_template(nt.sm)

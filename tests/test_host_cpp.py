@@ -106,3 +106,29 @@ def test_cpp_layer_error_paths(frame):
     with pytest.raises(host.HostError, match="FunctonNotImplemented"):
         trk.initialize(synth.square_corners(200, 200, 40))
     # Affine has no cmptApproxPixHessian / cmptPixHessian; a size mismatch is an InvalidArgument
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("am,sm", [(L.AM_SSD, L.SM_ESM), (L.AM_NCC, L.SM_ICLK), (L.AM_MI, L.SM_FCLK)])
+def test_cpp_multichannel_trackers(oracle, am, sm):
+    """MCSSD / MCNCC / MCMI through the C++ host layer (getNChannels() = 3, getPatchSize() = 3 n_pix, 32FC3 frames)."""
+    rng = np.random.default_rng(19)
+    centre = (128.0, 124.0)
+    frame = synth.make_frame_mc(256, 256)
+    corners = synth.square_corners(centre[0], centre[1], 70.0)
+    frame2 = synth.warp_frame(frame, synth.random_small_homography(rng, 0.3), centre)
+    params = dict(max_iters=25, epsilon=1e-6, leven_marq=0)
+    o_ssm = oracle.SSM(L.SSM_AFFINE, 30, 30); o_am = oracle.AM(am, 30, 30)
+    o_am.set_channels(3); o_ssm.set_channels(3); o_am.set_curr_img(frame)
+    otrk = oracle.Tracker(sm, o_am, o_ssm, **params)
+    otrk.initialize(corners)
+    o_am.set_curr_img(frame2)
+    o_iters = otrk.update()
+    trk = host.CppTracker(sm, am, L.SSM_AFFINE, 30, 30, n_channels=3, **params)
+    img = frame.copy()
+    trk.set_image(img)
+    trk.initialize(corners)
+    img[:] = frame2
+    out = trk.update()
+    np.testing.assert_allclose(out, otrk.get_region(), atol=2e-3)
+    assert abs(trk.iters - o_iters) <= 2

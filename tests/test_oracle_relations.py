@@ -313,3 +313,28 @@ def test_second_order_trackers_recover_known_warp(oracle, frame, sm, chained):
     W = synth.homography_from_state(p_true)
     want = np.stack(_apply(W, corners[0] - centre[0], corners[1] - centre[1])) + np.array(centre)[:, None]
     assert np.abs(trk.get_region() - want).max() < 0.25
+
+
+@pytest.mark.parametrize("am_kind", [0, 1])
+def test_multichannel_reduces_to_single_channel_on_replicated_frames(oracle, frame, am_kind):
+    """MCSSD / MCNCC on a frame whose three channels are equal: f and H are 3x (SSD) / 1x (NCC) the single-channel ones up
+    to the mc:: sampling order (weights first, imgUtils.h:523), and the Gauss-Newton step is the same."""
+    g = np.ascontiguousarray(frame[:256, :256])
+    mc = np.ascontiguousarray(np.stack([g, g, g], axis=2))
+    c = synth.square_corners(128, 120, 60)
+    p = synth.random_small_homography(np.random.default_rng(1), 0.4)
+    g2 = synth.warp_frame(g, p, (128.0, 120.0)); mc2 = np.ascontiguousarray(np.stack([g2] * 3, axis=2))
+    a1 = oracle.AM(am_kind, 20, 20); s1 = oracle.SSM(0, 20, 20); a1.set_curr_img(g)
+    a3 = oracle.AM(am_kind, 20, 20); s3 = oracle.SSM(0, 20, 20); a3.set_channels(3); s3.set_channels(3); a3.set_curr_img(mc)
+    t1 = oracle.Tracker(0, a1, s1, leven_marq=0, max_iters=2, epsilon=-1)
+    t3 = oracle.Tracker(0, a3, s3, leven_marq=0, max_iters=2, epsilon=-1)
+    t1.initialize(c); t3.initialize(c)
+    assert a3.n == 3 * a1.n
+    np.testing.assert_allclose(a3.get("I0").reshape(-1, 3), np.repeat(a1.get("I0")[:, None], 3, axis=1), rtol=0, atol=1e-11)
+    a1.set_curr_img(g2); a3.set_curr_img(mc2)
+    t1.update(); t3.update()
+    r1, r3 = t1.trace()[0], t3.trace()[0]
+    k = 3.0 if am_kind == 0 else 1.0
+    assert abs(r3["f"] - k * r1["f"]) <= 1e-9 * abs(r1["f"])
+    assert rel(r3["H"], k * r1["H"]) < 1e-5
+    assert np.abs(r3["dp"] - r1["dp"]).max() < 1e-5
