@@ -214,6 +214,12 @@ struct mtfhip_batch {
 	double mi_hist_norm = 0;
 	size_t cand_capacity = 0;
 	int *d_active = nullptr, *d_iters = nullptr, *d_done = nullptr;
+	/* The small per-target state lives in ONE device allocation (warps | states | corners | init_corners_hm | ncc | w0 |
+	 * active | iters) mirrored by two pinned staging buffers, so that set_corners and track each move it with a single
+	 * copy (a grid frame used to cost 14 small copies and 4 stream syncs around a 100 us kernel). */
+	char *d_slab = nullptr, *h_stage_a = nullptr, *h_stage_b = nullptr;
+	hipEvent_t ev_a = nullptr, ev_b = nullptr;
+	size_t slab_bytes = 0, slab_dbl_bytes = 0;
 	/* last-workgroup-done epilogue instead of the separate k_finish_track launch: measured equal per step (84.3 vs 84.6 us at
 	 * B = 64, 19.6 vs 19.2 us for one target -- the finish's dependent scalar chain is the cost, not the launch), so off */
 	bool epilogue = std::getenv("MTFHIP_EPILOGUE") && std::getenv("MTFHIP_EPILOGUE")[0] == '1';
@@ -242,6 +248,26 @@ static int ensure_buf(mtfhip_batch *b, int id) {
 	HIP_TRY(hipMalloc(&b->buf[id], sizeof(double) * b->per_target[id] * b->B));
 	HIP_TRY(hipMemsetAsync(b->buf[id], 0, sizeof(double) * b->per_target[id] * b->B, b->ctx->stream));
 	return MTFHIP_OK;
+}
+
+/* host state of every target -> one staging image of the slab */
+static void fill_stage(const mtfhip_batch *b, char *stage, const double *w0 /* [B][9] or NULL */, int active, bool zero_iters) {
+	const size_t Bt = (size_t)b->B;
+	double *p = reinterpret_cast<double *>(stage);
+	double *w = p, *s = p + 9 * Bt, *cr = p + 17 * Bt, *ic = p + 25 * Bt, *nc = p + 37 * Bt, *pw0 = p + 45 * Bt;
+	int *act = reinterpret_cast<int *>(stage + b->slab_dbl_bytes), *it = act + Bt;
+	for (int t = 0; t < b->B; ++t) {
+		const TargetHost &h = b->th[t];
+		std::memcpy(w + 9 * t, h.warp.m, sizeof(double) * 9);
+		std::memcpy(s + 8 * t, h.state, sizeof(double) * 8);
+		std::memcpy(cr + 8 * t, h.corners, sizeof(double) * 8);
+		std::memcpy(ic + 12 * t, h.init_corners_hm, sizeof(double) * 12);
+		double *q = nc + 8 * t;
+		q[0] = h.I0_mean; q[1] = h.c; q[2] = h.It_mean; q[3] = h.b; q[4] = h.f; q[5] = h.gmean; q[6] = q[7] = 0;
+		if (w0) std::memcpy(pw0 + 9 * t, w0 + 9 * t, sizeof(double) * 9);
+		act[t] = active;
+		if (zero_iters) it[t] = 0;
+	}
 }
 
 static int push_warps(mtfhip_batch *b) {
@@ -546,18 +572,26 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 		MTFHIP_BUF_DF_DIT, MTFHIP_BUF_J0, MTFHIP_BUF_JT, MTFHIP_BUF_INIT_PTS, MTFHIP_BUF_CURR_PTS,
 		MTFHIP_BUF_INIT_Z, MTFHIP_BUF_CURR_Z, MTFHIP_BUF_INIT_HXY, MTFHIP_BUF_CURR_HXY};
 	for (int id : eager) { int r = ensure_buf(b, id); if (r) return cleanup(r); }
+	{
+		const size_t Bt = (size_t)n_targets, d = sizeof(double);
+		b->slab_dbl_bytes = 54 * Bt * d;
+		b->slab_bytes = b->slab_dbl_bytes + 2 * sizeof(int) * Bt;
+		if (hipMalloc(&b->d_slab, b->slab_bytes) != hipSuccess || hipHostMalloc(&b->h_stage_a, b->slab_bytes) != hipSuccess ||
+			hipHostMalloc(&b->h_stage_b, b->slab_bytes) != hipSuccess || hipEventCreateWithFlags(&b->ev_a, hipEventDisableTiming) != hipSuccess ||
+			hipEventCreateWithFlags(&b->ev_b, hipEventDisableTiming) != hipSuccess)
+			return cleanup(fail(MTFHIP_ERR_HIP, "allocation of the per-target state slab failed"));
+		double *p = reinterpret_cast<double *>(b->d_slab);
+		b->d_warps = p; b->d_states = p + 9 * Bt; b->d_corners = p + 17 * Bt; b->d_init_corners_hm = p + 25 * Bt;
+		b->d_ncc = p + 37 * Bt; b->d_w0 = p + 45 * Bt;
+		b->d_active = reinterpret_cast<int *>(b->d_slab + b->slab_dbl_bytes); b->d_iters = b->d_active + Bt;
+		(void)hipMemsetAsync(b->d_slab, 0, b->slab_bytes, c->stream);
+	}
 #define ALLOC(ptr, bytes) do { if (hipMalloc(&(ptr), (bytes)) != hipSuccess) return cleanup(fail(MTFHIP_ERR_HIP, "hipMalloc(%zu) failed", (size_t)(bytes))); } while (0)
-	ALLOC(b->d_warps, sizeof(double) * 9 * n_targets);
-	ALLOC(b->d_states, sizeof(double) * 8 * n_targets);
 	ALLOC(b->d_partials, sizeof(double) * ACC_COUNT * b->nblk_max * n_targets);
 	ALLOC(b->d_acc, sizeof(double) * ACC_COUNT * n_targets);
 	ALLOC(b->d_scratch_pts, sizeof(double) * 18 * NP * n_targets); /* largest upload: pts (2 NP) + hess_pts (16 NP) */
-	ALLOC(b->d_w0, sizeof(double) * 9 * n_targets);
 	ALLOC(b->d_h0, sizeof(double) * 64 * n_targets);
-	ALLOC(b->d_corners, sizeof(double) * 8 * n_targets);
-	ALLOC(b->d_init_corners_hm, sizeof(double) * 12 * n_targets);
 	ALLOC(b->d_h0inv, sizeof(double) * 64 * n_targets);
-	ALLOC(b->d_ncc, sizeof(double) * 8 * n_targets);
 	ALLOC(b->d_colmean, sizeof(double) * 8 * n_targets);
 	if (d->am == MTFHIP_AM_MI) {
 		const int nb = d->mi_n_bins;
@@ -570,8 +604,6 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 		ALLOC(b->d_mi_H, sizeof(double) * 64 * n_targets);
 		(void)hipMemsetAsync(b->d_mi_tb, 0, sizeof(double) * MI_SIZE * n_targets, c->stream);
 	}
-	ALLOC(b->d_active, sizeof(int) * n_targets);
-	ALLOC(b->d_iters, sizeof(int) * n_targets);
 #undef ALLOC
 	if (hipHostMalloc(&b->h_acc, sizeof(double) * ACC_COUNT * n_targets) != hipSuccess)
 		return cleanup(fail(MTFHIP_ERR_HIP, "hipHostMalloc failed"));
@@ -589,12 +621,16 @@ void mtfhip_batch_destroy(mtfhip_batch *b) {
 		(void)hipStreamSynchronize(b->ctx->stream);
 		for (int i = 0; i < MTFHIP_BUF_COUNT; ++i)
 			if (b->buf[i]) (void)hipFree(b->buf[i]);
-		void *ptrs[] = {b->d_warps, b->d_states, b->d_partials, b->d_acc, b->d_scratch_pts, b->d_w0, b->d_h0, b->d_corners,
-			b->d_init_corners_hm, b->d_active, b->d_iters, b->d_cand, b->d_ncc, b->d_colmean, b->d_mi_tb, b->d_mi_part,
+		void *ptrs[] = {b->d_slab, b->d_partials, b->d_acc, b->d_scratch_pts, b->d_h0,
+			b->d_cand, b->d_colmean, b->d_mi_tb, b->d_mi_part,
 			b->d_mi_f, b->d_mi_H, b->d_h0inv, b->d_units, b->d_d2_part, b->d_d2_out, b->d_d2_w, b->d_done};
 		for (void *p : ptrs)
 			if (p) (void)hipFree(p);
 		if (b->h_acc) (void)hipHostFree(b->h_acc);
+		if (b->h_stage_a) (void)hipHostFree(b->h_stage_a);
+		if (b->h_stage_b) (void)hipHostFree(b->h_stage_b);
+		if (b->ev_a) (void)hipEventDestroy(b->ev_a);
+		if (b->ev_b) (void)hipEventDestroy(b->ev_b);
 	} catch (...) {
 	}
 	delete b;
@@ -642,7 +678,7 @@ int mtfhip_ssm_set_corners(mtfhip_batch *b, const double *corners) {
 	double lo_x = -0.5, lo_y = -0.5, hi_x = 0.5, hi_y = 0.5;
 	if (!hom) { lo_x = 1 - b->desc.resx / 2.0; lo_y = 1 - b->desc.resy / 2.0; hi_x = b->desc.resx / 2.0; hi_y = b->desc.resy / 2.0; }
 	const double nc[8] = {lo_x, lo_y, hi_x, lo_y, hi_x, hi_y, lo_x, hi_y};
-	std::vector<double> w0(9 * b->B), chm(12 * b->B);
+	std::vector<double> w0(9 * b->B);
 	int unit_z = 1;
 	for (int t = 0; t < b->B; ++t) {
 		M3 W0;
@@ -659,18 +695,20 @@ int mtfhip_ssm_set_corners(mtfhip_batch *b, const double *corners) {
 			h.init_corners_hm[3 * q + 1] = corners[8 * t + 2 * q + 1];
 			h.init_corners_hm[3 * q + 2] = 1;
 		}
-		std::memcpy(&chm[12 * t], h.init_corners_hm, sizeof(double) * 12);
 		h.warp = m3_identity();
 		std::memset(h.state, 0, sizeof(h.state));
 	}
 	b->unit_z = hom ? unit_z : 1;
-	HIP_TRY(hipMemcpyAsync(b->d_w0, w0.data(), sizeof(double) * w0.size(), hipMemcpyHostToDevice, b->ctx->stream));
-	HIP_TRY(hipMemcpyAsync(b->d_init_corners_hm, chm.data(), sizeof(double) * chm.size(), hipMemcpyHostToDevice, b->ctx->stream));
+	/* w0, init_corners_hm, identity warps, zero states and the corners in ONE pinned async copy; the staging buffer is
+	 * protected by an event instead of a stream sync */
+	HIP_TRY(hipEventSynchronize(b->ev_a));
+	fill_stage(b, b->h_stage_a, w0.data(), 0, false);
+	HIP_TRY(hipMemcpyAsync(b->d_slab, b->h_stage_a, b->slab_dbl_bytes, hipMemcpyHostToDevice, b->ctx->stream));
+	HIP_TRY(hipEventRecord(b->ev_a, b->ctx->stream));
 	{
 		TimedScope ts(b->ctx, "init_grid");
 		launch_init_grid(b->view(), b->d_w0, b->desc.resx, b->desc.resy, lo_x, lo_y, hi_x, hi_y, hom ? 0 : 1, b->ctx->stream);
 	}
-	TRY(push_warps(b));
 	b->have_corners = true;
 	return MTFHIP_OK;
 }
@@ -1623,18 +1661,16 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 	FusedArgs fa;
 	if (!one_launch) TRY(fused_args(b, sm, fa));
 	else { fa.materialize = 0; fa.mode = 2; fa.active = nullptr; fa.done = nullptr; fa.rows_per_block = 1; }
-	std::vector<int> ones(b->B, 1);
-	std::vector<double> cr(8 * (size_t)b->B);
-	for (int t = 0; t < b->B; ++t) std::memcpy(&cr[8 * t], b->th[t].corners, sizeof(double) * 8);
-	HIP_TRY(hipMemcpyAsync(b->d_active, ones.data(), sizeof(int) * b->B, hipMemcpyHostToDevice, st));
-	HIP_TRY(hipMemsetAsync(b->d_iters, 0, sizeof(int) * b->B, st));
-	HIP_TRY(hipMemcpyAsync(b->d_corners, cr.data(), sizeof(double) * cr.size(), hipMemcpyHostToDevice, st));
-	TRY(push_warps(b));
+	/* active = 1, iters = 0, corners, warps, states, NCC scalars: one pinned async copy of the whole slab
+	 * (w0 is copied along; init_grid consumed it long ago) */
+	HIP_TRY(hipEventSynchronize(b->ev_b));
+	std::memcpy(b->h_stage_b + 45 * sizeof(double) * (size_t)b->B, b->h_stage_a + 45 * sizeof(double) * (size_t)b->B, 9 * sizeof(double) * (size_t)b->B);
+	fill_stage(b, b->h_stage_b, nullptr, 1, true);
+	HIP_TRY(hipMemcpyAsync(b->d_slab, b->h_stage_b, b->slab_bytes, hipMemcpyHostToDevice, st));
 	fa.active = b->d_active;
 	TrackState ts{b->d_acc, b->d_h0, b->d_corners, b->d_init_corners_hm, b->d_active, b->d_iters};
 	BatchView bv = b->view();
 	if (one_launch) {
-		if (b->desc.am == MTFHIP_AM_NCC) TRY(push_ncc(b));
 		TimedScope tsc(b->ctx, "iclk_track");
 		launch_iclk_track(bv, b->ctx->img, *sm, ts, b->d_h0inv, b->d_ncc, b->norm_mult, b->norm_add, st);
 	} else {
@@ -1675,19 +1711,22 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 			}
 		}
 	}
-	std::vector<double> w(9 * (size_t)b->B), s(8 * (size_t)b->B);
-	std::vector<int> iters(b->B);
-	HIP_TRY(hipMemcpyAsync(w.data(), b->d_warps, sizeof(double) * w.size(), hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(s.data(), b->d_states, sizeof(double) * s.size(), hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(cr.data(), b->d_corners, sizeof(double) * cr.size(), hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(iters.data(), b->d_iters, sizeof(int) * b->B, hipMemcpyDeviceToHost, st));
+	/* one download of the slab (warps, states, corners, iteration counts), one sync */
+	HIP_TRY(hipMemcpyAsync(b->h_stage_b, b->d_slab, b->slab_bytes, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipEventRecord(b->ev_b, st));
 	HIP_TRY(hipStreamSynchronize(st));
-	for (int t = 0; t < b->B; ++t) {
-		std::memcpy(b->th[t].warp.m, &w[9 * t], sizeof(double) * 9);
-		std::memcpy(b->th[t].state, &s[8 * t], sizeof(double) * 8);
-		std::memcpy(b->th[t].corners, &cr[8 * t], sizeof(double) * 8);
-		if (n_iters) n_iters[t] = iters[t];
-		if (corners) std::memcpy(corners + 8 * t, &cr[8 * t], sizeof(double) * 8);
+	{
+		const size_t Bt = (size_t)b->B;
+		const double *p = reinterpret_cast<const double *>(b->h_stage_b);
+		const double *w = p, *s = p + 9 * Bt, *cr = p + 17 * Bt;
+		const int *iters = reinterpret_cast<const int *>(b->h_stage_b + b->slab_dbl_bytes) + Bt;
+		for (int t = 0; t < b->B; ++t) {
+			std::memcpy(b->th[t].warp.m, w + 9 * t, sizeof(double) * 9);
+			std::memcpy(b->th[t].state, s + 8 * t, sizeof(double) * 8);
+			std::memcpy(b->th[t].corners, cr + 8 * t, sizeof(double) * 8);
+			if (n_iters) n_iters[t] = iters[t];
+			if (corners) std::memcpy(corners + 8 * t, cr + 8 * t, sizeof(double) * 8);
+		}
 	}
 	b->it_valid = fa.materialize;
 	b->dit_valid = b->jt_valid = fa.materialize && fa.mode != 2;

@@ -2353,11 +2353,29 @@ __global__ __launch_bounds__(kBlock) void k_ncc_feature_rows(int N, double *feat
  * becomes: 256 patches = 256 workgroups, one launch per frame, no host round trips.
  * Patch operands (grid points, I0, J0: ~35 KB for 25x25 affine) are re-read from L2 every iteration.
  */
+/* getPixVal<Linear, Constant> without control flow: the four texel loads are always issued (from clamped, valid
+ * addresses) and the border value is selected afterwards, so several independent samples of one thread can be in
+ * flight together.  Same expression and operation order as pix_val() for every in-range sample. */
+__device__ __forceinline__ double pix_val_select(const ImgView &im, double x, double y) {
+	const double w = (double)(unsigned int)im.w, h = (double)(unsigned int)im.h;
+	const bool in0 = !((x < 0) || (x >= w) || (y < 0) || (y >= h));
+	const double xs = in0 ? x : 0.0, ys = in0 ? y : 0.0;
+	const int lx = (int)xs, ly = (int)ys;
+	const double dx = xs - lx, dy = ys - ly;
+	const int ux = dx == 0 ? lx : lx + 1, uy = dy == 0 ? ly : ly + 1;
+	const bool in1 = !(ux >= im.w || uy >= im.h);
+	const int uxc = in1 ? ux : lx, uyc = in1 ? uy : ly;
+	const float *r0 = im.data + (size_t)ly * im.stride, *r1 = im.data + (size_t)uyc * im.stride;
+	const double t00 = r0[lx], t01 = r0[uxc], t10 = r1[lx], t11 = r1[uxc];
+	const double v = t00 * (1 - dx) * (1 - dy) + t01 * dx * (1 - dy) + t10 * (1 - dx) * dy + t11 * dx * dy;
+	return (in0 && in1) ? v : 128.0;
+}
+
 template <int AM, int PPT>
 __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im, mtfhip_sm_desc sm, TrackState ts,
 	const double *h0inv_all, const double *ncc_sc_all, double norm_mult, double norm_add) {
 	__shared__ double red[4 * 8];
-	__shared__ double sW[9], sSt[8];
+	__shared__ double sW[9], sSt[8], sHinv[64], sIc[12], sCr[8];
 	__shared__ int sDone;
 	const int t = blockIdx.x, N = bv.N, S = bv.S, tid = threadIdx.x;
 	const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY;
@@ -2366,9 +2384,30 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 	const double *iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * N;
 	const double *I0 = bv.buf[MTFHIP_BUF_I0] + (size_t)t * N;
 	const double *J0 = bv.buf[MTFHIP_BUF_J0] + (size_t)t * N * S;
-	const double *Hinv = h0inv_all + (size_t)t * 64;
 	const double m0 = AM == MTFHIP_AM_NCC ? ncc_sc_all[t * 8 + 0] : 0.0;
 	const double cn = AM == MTFHIP_AM_NCC ? ncc_sc_all[t * 8 + 1] : 1.0;
+	/* Everything that does not change over the iterations is fetched ONCE: the thread's grid points, template values
+	 * and J0 rows into registers, the inverse Hessian and the corner sets into LDS.  An iteration then touches global
+	 * memory only for its texels (the loop is a chain of dependent latencies: one workgroup per patch, nothing to
+	 * overlap with). */
+	constexpr bool HOIST_J = PPT <= 4;   /* 8 J0 values per pixel: beyond 4 pixels per thread they would spill */
+	double2 hpv[PPT];
+	double zv[PPT], i0v[PPT], j0v[HOIST_J ? PPT : 1][8];
+#pragma unroll
+	for (int k = 0; k < PPT; ++k) {
+		const int i = tid + k * kBlock;
+		const int ic = i < N ? i : N - 1;
+		hpv[k] = bv.unit_z ? ip[ic] : ih[ic];
+		zv[k] = bv.unit_z ? 1.0 : iz[ic];
+		i0v[k] = i < N ? I0[ic] : 0.0;
+		if constexpr (HOIST_J) {
+#pragma unroll
+			for (int s = 0; s < 8; ++s) j0v[k][s] = (s < S && i < N) ? J0[(size_t)s * N + ic] : 0.0;
+		}
+	}
+	if (tid < 64) sHinv[tid] = h0inv_all[(size_t)t * 64 + tid];
+	if (tid < 12) sIc[tid] = ts.init_corners_hm[12 * t + tid];
+	if (tid < 8) sCr[tid] = ts.corners[8 * t + tid];
 	if (tid < 9) sW[tid] = bv.warps[9 * t + tid];
 	if (tid < 8) sSt[tid] = bv.states[8 * t + tid];
 	if (tid == 0) sDone = 0;
@@ -2380,28 +2419,25 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 #pragma unroll
 		for (int q = 0; q < 9; ++q) W[q] = sW[q];
 		/* ---- updatePixVals: It = sample(curr_warp * init_pts) ---- */
-		double itv[PPT], i0v[PPT];
+		double itv[PPT];
 		double s1[1] = {0.0};
 #pragma unroll
 		for (int k = 0; k < PPT; ++k) {
-			const int i = tid + k * kBlock;
-			itv[k] = 0; i0v[k] = 0;
-			if (i < N) {
-				const double2 hp = bv.unit_z ? ip[i] : ih[i];
-				const double z = bv.unit_z ? 1.0 : iz[i];
-				double wx, wy;
-				if (hom) {
-					const double cx = W[0] * hp.x + W[1] * hp.y + W[2] * z, cy = W[3] * hp.x + W[4] * hp.y + W[5] * z;
-					const double d = W[6] * hp.x + W[7] * hp.y + W[8] * z;
-					wx = cx / d; wy = cy / d;
-				} else {
-					wx = W[0] * hp.x + W[1] * hp.y + W[2] * z; wy = W[3] * hp.x + W[4] * hp.y + W[5] * z;
-				}
-				itv[k] = norm_mult * pix_val(im, wx, wy) + norm_add;
-				i0v[k] = I0[i];
-				s1[0] += itv[k];
+			const double2 hp = hpv[k];
+			const double z = zv[k];
+			double wx, wy;
+			if (hom) {
+				const double cx = W[0] * hp.x + W[1] * hp.y + W[2] * z, cy = W[3] * hp.x + W[4] * hp.y + W[5] * z;
+				const double d = W[6] * hp.x + W[7] * hp.y + W[8] * z;
+				wx = cx / d; wy = cy / d;
+			} else {
+				wx = W[0] * hp.x + W[1] * hp.y + W[2] * z; wy = W[3] * hp.x + W[4] * hp.y + W[5] * z;
 			}
+			const double v = norm_mult * pix_val_select(im, wx, wy) + norm_add;
+			itv[k] = (tid + k * kBlock < N) ? v : 0.0;
 		}
+#pragma unroll
+		for (int k = 0; k < PPT; ++k) if (tid + k * kBlock < N) s1[0] += itv[k];
 		double dfv[PPT];
 		if constexpr (AM == MTFHIP_AM_NCC) {
 			/* ---- NCC::updateSimilarity + updateInitGrad ---- */
@@ -2447,11 +2483,10 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 		double g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
 		for (int k = 0; k < PPT; ++k) {
-			const int i = tid + k * kBlock;
-			if (i < N) {
+			if (tid + k * kBlock < N) {
 #pragma unroll
 				for (int s = 0; s < 8; ++s)
-					if (s < S) g[s] = fma(dfv[k], J0[(size_t)s * N + i], g[s]);
+					if (s < S) g[s] = fma(dfv[k], HOIST_J ? j0v[HOIST_J ? k : 0][s] : J0[(size_t)s * N + tid + k * kBlock], g[s]);
 			}
 		}
 		block_allsum<8>(g, red);
@@ -2460,7 +2495,7 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 			double dp[8];
 			for (int r = 0; r < 8; ++r) {
 				double acc = 0;
-				if (r < S) for (int c = 0; c < S; ++c) acc += Hinv[c * S + r] * g[c];
+				if (r < S) for (int c = 0; c < S; ++c) acc += sHinv[c * S + r] * g[c];
 				dp[r] = -acc;
 			}
 			double U[9];
@@ -2487,16 +2522,14 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 				sSt[0] = Wn[2]; sSt[1] = Wn[5]; sSt[2] = Wn[0] - 1; sSt[3] = Wn[1]; sSt[4] = Wn[3]; sSt[5] = Wn[4] - 1; sSt[6] = 0; sSt[7] = 0;
 			}
 			for (int q = 0; q < 9; ++q) sW[q] = Wn[q];
-			double *cr = ts.corners + 8 * t;
-			const double *ic = ts.init_corners_hm + 12 * t;
 			double change = 0;
 			for (int q = 0; q < 4; ++q) {
-				const double X = ic[3 * q], Y = ic[3 * q + 1], Z = ic[3 * q + 2];
+				const double X = sIc[3 * q], Y = sIc[3 * q + 1], Z = sIc[3 * q + 2];
 				double nx = Wn[0] * X + Wn[1] * Y + Wn[2] * Z, ny = Wn[3] * X + Wn[4] * Y + Wn[5] * Z;
 				if (hom) { const double d = Wn[6] * X + Wn[7] * Y + Wn[8] * Z; nx = nx / d; ny = ny / d; }
-				const double ddx = cr[2 * q] - nx, ddy = cr[2 * q + 1] - ny;
+				const double ddx = sCr[2 * q] - nx, ddy = sCr[2 * q + 1] - ny;
 				change += ddx * ddx + ddy * ddy;
-				cr[2 * q] = nx; cr[2 * q + 1] = ny;
+				sCr[2 * q] = nx; sCr[2 * q + 1] = ny;
 			}
 			if (change < sm.epsilon) sDone = 1;
 		}
@@ -2506,6 +2539,7 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 	}
 	if (tid < 9) bv.warps[9 * t + tid] = sW[tid];
 	if (tid < 8) bv.states[8 * t + tid] = sSt[tid];
+	if (tid < 8) ts.corners[8 * t + tid] = sCr[tid];
 	if (tid == 0) { ts.n_iters[t] = n_it; ts.acc[(size_t)t * ACC_COUNT + ACC_RR] = f_last; }
 }
 
