@@ -2391,14 +2391,17 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 	 * memory only for its texels (the loop is a chain of dependent latencies: one workgroup per patch, nothing to
 	 * overlap with). */
 	constexpr bool HOIST_J = PPT <= 4;   /* 8 J0 values per pixel: beyond 4 pixels per thread they would spill */
-	double2 hpv[PPT];
-	double zv[PPT], i0v[PPT], j0v[HOIST_J ? PPT : 1][8];
+	constexpr bool HOIST_P = PPT <= 8;   /* grid point + z: 3 doubles per pixel */
+	double2 hpv[HOIST_P ? PPT : 1];
+	double zv[HOIST_P ? PPT : 1], i0v[PPT], j0v[HOIST_J ? PPT : 1][8];
 #pragma unroll
 	for (int k = 0; k < PPT; ++k) {
 		const int i = tid + k * kBlock;
 		const int ic = i < N ? i : N - 1;
-		hpv[k] = bv.unit_z ? ip[ic] : ih[ic];
-		zv[k] = bv.unit_z ? 1.0 : iz[ic];
+		if constexpr (HOIST_P) {
+			hpv[k] = bv.unit_z ? ip[ic] : ih[ic];
+			zv[k] = bv.unit_z ? 1.0 : iz[ic];
+		}
 		i0v[k] = i < N ? I0[ic] : 0.0;
 		if constexpr (HOIST_J) {
 #pragma unroll
@@ -2423,8 +2426,9 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 		double s1[1] = {0.0};
 #pragma unroll
 		for (int k = 0; k < PPT; ++k) {
-			const double2 hp = hpv[k];
-			const double z = zv[k];
+			const int ick = (tid + k * kBlock < N) ? tid + k * kBlock : N - 1;
+			const double2 hp = HOIST_P ? hpv[HOIST_P ? k : 0] : (bv.unit_z ? ip[ick] : ih[ick]);
+			const double z = HOIST_P ? zv[HOIST_P ? k : 0] : (bv.unit_z ? 1.0 : iz[ick]);
 			double wx, wy;
 			if (hom) {
 				const double cx = W[0] * hp.x + W[1] * hp.y + W[2] * z, cy = W[3] * hp.x + W[4] * hp.y + W[5] * z;

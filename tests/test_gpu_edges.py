@@ -1,0 +1,115 @@
+"""GPU: edge cases of the domain -- tiny and ragged patches (N below one wave, not a multiple of the workgroup), regions
+partly or wholly outside the frame (constant border 128: zero gradient, singular Hessian), degenerate corners, one
+candidate, many targets with different fates in one batch."""
+import numpy as np
+import pytest
+
+import mtf_amd
+from mtf_amd import _lib as L
+from mtf_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize("resx,resy", [(2, 2), (2, 3), (7, 9), (16, 17), (33, 31)])
+@pytest.mark.parametrize("sm_kind", [L.SM_ESM, L.SM_FCLK, L.SM_ICLK])
+def test_tiny_and_ragged_patches(oracle, gpu_ctx, frame, frame2, resx, resy, sm_kind):
+    """N = 4 ... 1023 (below a wave, below a workgroup, not a multiple of 256): fused sums against the oracle's first
+    iteration, materialised and lean."""
+    corners = synth.square_corners(250, 244, 40)
+    o_ssm = oracle.SSM(L.SSM_AFFINE, resx, resy); o_am = oracle.AM(L.AM_SSD, resx, resy); o_am.set_curr_img(frame)
+    trk = oracle.Tracker(sm_kind, o_am, o_ssm, leven_marq=0, max_iters=1, epsilon=-1.0)
+    trk.initialize(corners)
+    o_am.set_curr_img(frame2)
+    trk.update()
+    rec = trk.trace()[0]
+    for mat in (1, 0):
+        gpu_ctx.set_image(frame)
+        b = mtf_amd.Batch(gpu_ctx, L.AM_SSD, L.SSM_AFFINE, resx, resy, 1)
+        b.set_corners(corners[None])
+        sm = mtf_amd.sm_desc(sm_kind, materialize=mat, leven_marq=0)
+        b.init_template(sm)
+        gpu_ctx.set_image(frame2)
+        f, g, H = b.iterate(sm)
+        assert abs(f[0] - rec["f"]) <= 1e-8 * abs(rec["f"]) + 1e-12
+        assert rel(H[0], rec["H"]) < 1e-5
+        gs = max(np.linalg.norm(rec["g"]), np.sqrt(abs(np.trace(rec["H"])) * abs(2 * rec["f"])))
+        assert np.linalg.norm(g[0] - rec["g"]) <= 1e-5 * gs
+        b.close()
+
+
+def test_regions_outside_the_frame(oracle, gpu_ctx, frame):
+    """A region wholly outside samples the constant border: It = 128 everywhere, zero gradient, H = 0 -- the device loop
+    must leave such a target where it is while its neighbours in the same batch converge; a region half outside matches the
+    oracle's border handling sample for sample."""
+    h, w = frame.shape
+    inside = synth.square_corners(256, 256, 80)
+    outside = synth.square_corners(-300, -300, 80)
+    half = synth.square_corners(w - 10, 200, 80)
+    corners = np.stack([inside, outside, half])
+    p_true = synth.random_small_homography(np.random.default_rng(4), 0.3)
+    frame2 = synth.warp_frame(frame, p_true, (256.0, 256.0))
+    gpu_ctx.set_image(frame)
+    b = mtf_amd.Batch(gpu_ctx, L.AM_SSD, L.SSM_HOMOGRAPHY, 30, 30, 3)
+    b.set_corners(corners)
+    sm = mtf_amd.sm_desc(L.SM_FCLK, materialize=1, leven_marq=0, max_iters=20, epsilon=1e-5, hess_type=1)
+    b.init_template(sm)
+    assert np.all(b.read(L.BUF_I0)[1] == 128.0)
+    o_ssm = oracle.SSM(L.SSM_HOMOGRAPHY, 30, 30); o_am = oracle.AM(L.AM_SSD, 30, 30); o_am.set_curr_img(frame)
+    o_ssm.set_corners(half); o_am.initialize_pix_vals(o_ssm.get("curr_pts"))
+    np.testing.assert_allclose(b.read(L.BUF_I0)[2], o_am.get("I0"), rtol=0, atol=1e-9)
+    assert (o_am.get("I0") == 128.0).sum() > 300            # a good part of it is border
+    gpu_ctx.set_image(frame2)
+    f, g, H = b.iterate(sm)
+    assert f[1] == 0.0 and np.all(g[1] == 0.0) and np.all(H[1] == 0.0)
+    n_it, final = b.track(sm)
+    np.testing.assert_allclose(final[1], outside, rtol=0, atol=0)        # singular system: no update, no NaN
+    assert np.all(np.isfinite(final))
+    W = synth.homography_from_state(p_true)
+    q = W @ np.vstack([inside - 256.0, np.ones(4)])
+    assert np.abs(final[0] - (q[:2] / q[2] + 256.0)).max() < 0.05       # the healthy neighbour converged
+
+
+def test_degenerate_inputs(gpu_ctx, frame):
+    gpu_ctx.set_image(frame)
+    b = mtf_amd.Batch(gpu_ctx, L.AM_SSD, L.SSM_HOMOGRAPHY, 10, 10, 2)
+    good = synth.square_corners(100, 100, 30)
+    point = np.repeat(np.array([[50.0], [60.0]]), 4, axis=1)           # four coincident corners: no homography
+    with pytest.raises(mtf_amd.InvalidArgument):
+        b.set_corners(np.stack([good, point]))
+    line = np.array([[10.0, 20.0, 30.0, 40.0], [10.0, 20.0, 30.0, 40.0]])   # collinear corners
+    with pytest.raises(mtf_amd.InvalidArgument):
+        b.set_corners(np.stack([good, line]))
+    b.set_corners(np.stack([good, good + 40]))
+    b.initialize_pix_vals(); b.initialize_similarity()
+    one = b2 = None
+    s = mtf_amd.Batch(gpu_ctx, L.AM_SSD, L.SSM_HOMOGRAPHY, 10, 10, 1)
+    s.set_corners(good[None]); s.initialize_pix_vals(); s.initialize_similarity()
+    lik = s.score_candidates(np.zeros((1, 8)))                          # a single candidate
+    assert lik.shape == (1,) and lik[0] == 1.0
+    with pytest.raises(mtf_amd.InvalidArgument):
+        s.score_candidates(np.zeros((0, 8)))
+    with pytest.raises(mtf_amd.InvalidArgument):
+        mtf_amd.Batch(gpu_ctx, L.AM_SSD, L.SSM_HOMOGRAPHY, 10, 10, 0)
+    with pytest.raises(mtf_amd.InvalidArgument):
+        mtf_amd.Batch(gpu_ctx, L.AM_MI, L.SSM_HOMOGRAPHY, 10, 10, 1, mi_n_bins=17)
+
+
+def test_flat_template_has_no_update(gpu_ctx):
+    """A texture-less frame: J = 0, the constant Hessian is singular; every search method must return the region unchanged."""
+    flat = np.full((256, 256), 77.0, dtype=np.float32)
+    gpu_ctx.set_image(flat)
+    c = synth.square_corners(128, 128, 50)
+    for sm_kind in (L.SM_ESM, L.SM_FCLK, L.SM_ICLK):
+        b = mtf_amd.Batch(gpu_ctx, L.AM_SSD, L.SSM_AFFINE, 25, 25, 1)
+        b.set_corners(c[None])
+        sm = mtf_amd.sm_desc(sm_kind, materialize=0, leven_marq=0, max_iters=5, epsilon=1e-4)
+        b.init_template(sm)
+        n_it, final = b.track(sm)
+        np.testing.assert_allclose(final[0], c, rtol=0, atol=0)
+        assert n_it[0] == 1                                          # converged at once: zero update
+        b.close()
