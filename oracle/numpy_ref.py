@@ -174,3 +174,82 @@ def lk_step_hom_ssd(img, init_pts, init_hm, W, I0, J0=None, mode="fclk", eps=1e-
 def compose_hom(W, dp):
     Wn = W @ hom_matrix(dp)
     return Wn / Wn[2, 2]
+
+
+# ---------------------------------------------------------------------------------------------
+# Mutual information with cubic B-spline Parzen windows, from the definition (independent of mtf_oracle.cpp):
+#   h_c(r)   = (seed_h + sum_p b3(r - It[p])) * norm          marginal of the current patch
+#   h_i(c)   = (seed_h + sum_p b3(c - I0[p])) * norm          marginal of the template
+#   h(r, c)  = (seed   + sum_p b3(r - It[p]) b3(c - I0[p])) * norm
+#   f        = sum_{r,c} h(r,c) log( h(r,c) / (h_c(r) h_i(c)) )
+# with seed = pre_seed, seed_h = n_bins * pre_seed, norm = 1 / (N + seed_h * n_bins)   (AM/src/MI.cc:97-104, 237-262, 369-381).
+# The reference's B-spline uses the truncated constant 0.66666666666 (histUtils.h:11); the exact 2/3 here differs by 6.7e-12.
+# ---------------------------------------------------------------------------------------------
+def bspline3(x):
+    ax = np.abs(x)
+    out = np.zeros_like(ax)
+    m1 = ax < 1
+    m2 = (ax >= 1) & (ax < 2)
+    out[m1] = 2.0 / 3.0 - ax[m1] ** 2 + ax[m1] ** 3 / 2.0
+    out[m2] = (2.0 - ax[m2]) ** 3 / 6.0
+    return out
+
+
+def mi_similarity(I0n, Itn, n_bins=8, pre_seed=10.0):
+    """I0n, Itn: patches already scaled to [0, n_bins - 1] (what the AM stores)."""
+    I0n = np.asarray(I0n, dtype=np.float64); Itn = np.asarray(Itn, dtype=np.float64)
+    N = I0n.size
+    bins = np.arange(n_bins, dtype=np.float64)
+    Bt = bspline3(bins[:, None] - Itn[None, :])       # n_bins x N
+    B0 = bspline3(bins[:, None] - I0n[None, :])
+    seed_h = n_bins * pre_seed
+    norm = 1.0 / (N + seed_h * n_bins)
+    hc = (seed_h + Bt.sum(axis=1)) * norm
+    hi = (seed_h + B0.sum(axis=1)) * norm
+    hj = (pre_seed + Bt @ B0.T) * norm
+    return float(np.sum(hj * np.log(hj / (hc[:, None] * hi[None, :]))))
+
+
+def bspline3_d1(x):
+    ax = np.abs(x); sg = np.sign(x)
+    out = np.zeros_like(ax)
+    m1 = ax < 1
+    m2 = (ax >= 1) & (ax < 2)
+    out[m1] = -2.0 * x[m1] + 1.5 * x[m1] * ax[m1]
+    out[m2] = -sg[m2] * (2.0 - ax[m2]) ** 2 / 2.0
+    return out
+
+
+def bspline3_d2(x):
+    ax = np.abs(x)
+    out = np.zeros_like(ax)
+    m1 = ax < 1
+    m2 = (ax >= 1) & (ax < 2)
+    out[m1] = -2.0 + 3.0 * ax[m1]
+    out[m2] = 2.0 - ax[m2]
+    return out
+
+
+def mi_curr_hessian(I0n, Itn, J, n_bins=8, pre_seed=10.0):
+    """The reference's first-order MI Hessian w.r.t. the current patch (AM/src/MI.cc:603-637), written densely:
+    H = J^T diag(t) J + sum_{r,c} (1/h(r,c) - 1/h_c(r)) Q(r,c)^T Q(r,c),
+    t_p = sum_r d2/dIt2 b3(r - It_p) norm * sum_c b3(c - I0_p) (1 + log h(r,c) - log h_c(r)),
+    Q(r,c) = sum_p d/dIt b3(r - It_p) norm * b3(c - I0_p) * J[p, :].
+    (Not the exact second derivative: the 1/h_c term keeps the per-cell outer products -- Dame & Marchand's form.)"""
+    I0n = np.asarray(I0n, dtype=np.float64); Itn = np.asarray(Itn, dtype=np.float64)
+    N = I0n.size
+    bins = np.arange(n_bins, dtype=np.float64)
+    X = bins[:, None] - Itn[None, :]
+    Bt, B0 = bspline3(X), bspline3(bins[:, None] - I0n[None, :])
+    seed_h = n_bins * pre_seed
+    norm = 1.0 / (N + seed_h * n_bins)
+    hc = (seed_h + Bt.sum(axis=1)) * norm
+    hj = (pre_seed + Bt @ B0.T) * norm
+    G = 1.0 + np.log(hj) - np.log(hc)[:, None]
+    dBt = -bspline3_d1(X) * norm
+    d2Bt = bspline3_d2(X) * norm
+    t = np.einsum("rp,rc,cp->p", d2Bt, G, B0)
+    H = J.T @ (t[:, None] * J)
+    Q = np.einsum("rp,cp,ps->rcs", dBt, B0, J)
+    fac = 1.0 / hj - 1.0 / hc[:, None]
+    return H + np.einsum("rc,rcs,rcu->su", fac, Q, Q)

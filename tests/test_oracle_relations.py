@@ -338,3 +338,34 @@ def test_multichannel_reduces_to_single_channel_on_replicated_frames(oracle, fra
     assert abs(r3["f"] - k * r1["f"]) <= 1e-9 * abs(r1["f"])
     assert rel(r3["H"], k * r1["H"]) < 1e-5
     assert np.abs(r3["dp"] - r1["dp"]).max() < 1e-5
+
+
+def test_mi_against_its_definition(oracle, frame):
+    """MI pinned independently of mtf_oracle.cpp: the similarity against a NumPy evaluation of the definition
+    (oracle/numpy_ref.py::mi_similarity), df_dIt / df_dI0 against central differences of that function, and
+    cmptCurrHessian(J) against a dense evaluation of the reference's first-order form (MI.cc:346-382, 398-442, 603-637).
+    The reference's truncated 2/3 (histUtils.h:11) shows up at the 1e-11 level only."""
+    import numpy_ref as R
+    res = 7
+    am, ssm = setup(oracle, frame, 2, oracle.SSM_AFF, res, synth.square_corners(300, 310, 40))
+    ssm.set_state(np.array([2.1, -1.3, 0.02, -0.01, 0.015, 0.01]))
+    pts = ssm.get("curr_pts")
+    am.update_pix_vals(pts); am.update_pix_grad_pts(pts)
+    am.update_similarity(False); am.update_curr_grad(); am.update_init_grad()
+    I0, It = am.get("I0"), am.get("It")
+    f = oracle_similarity = oracle.lib().mtfo_am_get_similarity(am.h)
+    assert abs(f - R.mi_similarity(I0, It)) < 1e-10
+    h = 1e-5
+    N = It.size
+    g_t, g_0 = np.zeros(N), np.zeros(N)
+    for i in range(N):
+        e = np.zeros(N); e[i] = h
+        g_t[i] = (R.mi_similarity(I0, It + e) - R.mi_similarity(I0, It - e)) / (2 * h)
+        g_0[i] = (R.mi_similarity(I0 + e, It) - R.mi_similarity(I0 - e, It)) / (2 * h)
+    np.testing.assert_allclose(am.get("df_dIt"), g_t, rtol=0, atol=2e-9)
+    np.testing.assert_allclose(am.get("df_dI0"), g_0, rtol=0, atol=2e-9)
+    # the Hessian is the reference's first-order form (not the exact second derivative: its 1/h_c term keeps per-cell outer
+    # products), so it is checked against a dense NumPy evaluation of that form instead of a numerical Hessian
+    J = ssm.cmpt_warped_pix_jacobian(am.get("dIt_dx")).reshape(6, N).T       # N x S
+    Hc = am.cmpt_curr_hessian(ssm.cmpt_warped_pix_jacobian(am.get("dIt_dx")))
+    assert rel(Hc, R.mi_curr_hessian(I0, It, J)) < 1e-9
