@@ -72,6 +72,13 @@ def cpu_baseline(seconds, res, frame0, frame1, corners):
     # ctypes releases the GIL for the duration of every oracle call.
     import threading
     n_thr = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    try:    # a container may see every hardware thread but own only a CPU quota (cgroup v2 cpu.max: "<quota> <period>")
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n_thr = max(1, min(n_thr, int(-(-int(q) // int(per)))))
+    except (OSError, ValueError):
+        pass
+    n_thr = min(n_thr, 64)
     budget = min(6.0, seconds / 2.0)
     counts = [0] * n_thr
 
@@ -94,12 +101,13 @@ def cpu_baseline(seconds, res, frame0, frame1, corners):
         for th in threads:
             th.start()
         barrier.wait()
-        t1 = time.perf_counter()
+        t1, c1 = time.perf_counter(), time.process_time()
         for th in threads:
             th.join()
-        dt_all = time.perf_counter() - t1
+        dt_all, cpu_all = time.perf_counter() - t1, time.process_time() - c1
         out["all_cores"] = {"value": sum(counts) / dt_all, "unit": "iters/s", "cores": n_thr,
-                            "sample": "%d threads x one %dx%d target each, %d iterations in %.1f s" % (n_thr, res, res, sum(counts), dt_all)}
+                            "sample": "%d threads x one %dx%d target each, %d iterations in %.1f s; %.1f CPU-seconds per second actually obtained"
+                                      % (n_thr, res, res, sum(counts), dt_all, cpu_all / dt_all)}
     return out
 
 
