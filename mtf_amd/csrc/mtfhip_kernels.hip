@@ -2137,16 +2137,18 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 	__shared__ double h0s[64], Ws[9], crs[8], ics[12];
 	const int lane = threadIdx.x;
 	const bool wv0 = lane < 64;
-	if (!ts.active[t]) return;
 	const int S = bv.S;
+	/* every global operand of this target -- the `active` flag included -- is requested up front, in parallel across
+	 * the lanes, and only then is the flag tested: one memory round trip instead of two (flag, then operands); the
+	 * rest of the routine runs out of LDS / registers */
+	const int act = ts.active[t];
 	int n_it_prev = 0;
-	/* every global operand of this target is requested up front, in parallel across the lanes: the rest
-	 * of the routine runs out of LDS / registers (one memory round trip instead of a dozen dependent ones) */
+	double v_h0 = 0, v_w = 0, v_cr = 0, v_ic = 0, v_acc = 0;
 	if (wv0) {
-		h0s[lane] = ts.h0[(size_t)t * 64 + lane];
-		if (lane < 9) Ws[lane] = bv.warps[9 * t + lane];
-		if (lane < 8) crs[lane] = ts.corners[8 * t + lane];
-		if (lane < 12) ics[lane] = ts.init_corners_hm[12 * t + lane];
+		v_h0 = ts.h0[(size_t)t * 64 + lane];
+		if (lane < 9) v_w = bv.warps[9 * t + lane];
+		if (lane < 8) v_cr = ts.corners[8 * t + lane];
+		if (lane < 12) v_ic = ts.init_corners_hm[12 * t + lane];
 		n_it_prev = ts.n_iters[t];
 		if (lane < ACC_COUNT) {
 			const double *p = partials + (size_t)t * nblk * ACC_COUNT + lane;
@@ -2161,10 +2163,16 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 				s2 += ld((size_t)(b + 2) * ACC_COUNT); s3 += ld((size_t)(b + 3) * ACC_COUNT);
 			}
 			for (; b < nblk; ++b) s0 += ld((size_t)b * ACC_COUNT);
-			const double s = (s0 + s1) + (s2 + s3);
-			acc_s[lane] = s;
-			ts.acc[(size_t)t * ACC_COUNT + lane] = s;
+			v_acc = (s0 + s1) + (s2 + s3);
 		}
+	}
+	if (!act) return;
+	if (wv0) {
+		h0s[lane] = v_h0;
+		if (lane < 9) Ws[lane] = v_w;
+		if (lane < 8) crs[lane] = v_cr;
+		if (lane < 12) ics[lane] = v_ic;
+		if (lane < ACC_COUNT) { acc_s[lane] = v_acc; ts.acc[(size_t)t * ACC_COUNT + lane] = v_acc; }
 	}
 	__syncthreads();
 	const int i = (lane >> 3) & 7, j = lane & 7;
