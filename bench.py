@@ -23,13 +23,14 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def algorithmic_bytes_per_pixel(sm, materialize, unit_z=True):
+def algorithmic_bytes_per_pixel(sm, materialize, unit_z=True, j0_recompute=True):
     """Interface-level traffic per sample point of one LK iteration:
     image texels 4 (1:1 sampling) + I0 8 + init_pts 16 (+8 init_z for non-parallelogram corners)
-    [+ J0 64 read for ESM / ICLK] [+ It 8 + dIt_dx 16 + Jt 64 written when materialised]."""
+    [+ J0 for ESM / ICLK: 64 when its rows are read back, 16 (dI0_dx) when the kernel rebuilds them -- only bytes that
+    are actually moved are credited] [+ It 8 + dIt_dx 16 + Jt 64 written when materialised]."""
     b = 4 + 8 + 16 + (0 if unit_z else 8)
     if sm in ("esm", "iclk"):
-        b += 64
+        b += 16 if j0_recompute else 64
     if materialize:
         b += 8 + (0 if sm == "iclk" else 16 + 64)
     return b
@@ -43,7 +44,10 @@ def pmc_traffic(sm, mode, res, targets):
     if not (sm == "esm" and mode == "full" and res == 200 and targets == 64 and os.path.exists(path)):
         return None
     try:
-        return float(json.load(open(path))["traffic_bytes_per_launch"])
+        d = json.load(open(path))
+        if d.get("j0_recompute", False) != (os.environ.get("MTFHIP_J0_RECOMPUTE", "1") != "0"):
+            return None      # the profile was taken with the other J0 source
+        return float(d["traffic_bytes_per_launch"])
     except Exception:
         return None
 
@@ -325,14 +329,14 @@ def main():
 
     def run(n_iters):
         sm.max_iters = n_iters
-        batch.set_corners(corners)      # restart every target from its initial region
+        batch.set_region(corners, sm)   # restart every target from its initial region (setRegion of the search method)
         return batch.track(sm)
 
     run(max(1, args.warmup))
     torch.cuda.synchronize(dev)
     ctx.timing(4)            # hipEvents around every 4th fused launch of the timed region
     ctx.timing_reset()
-    batch.set_corners(corners)
+    batch.set_region(corners, sm)
     sm.max_iters = args.steps
     if dist is not None:
         dist.barrier()
@@ -353,7 +357,8 @@ def main():
 
     if rank == 0:
         N = res * res
-        bpp = algorithmic_bytes_per_pixel(args.sm, materialize)
+        j0_rec = os.environ.get("MTFHIP_J0_RECOMPUTE", "1") != "0" and args.sm in ("esm", "iclk")
+        bpp = algorithmic_bytes_per_pixel(args.sm, materialize, j0_recompute=j0_rec)
         per_launch = batch.track_targets_per_launch(sm)   # all B, or an Infinity-Cache sized chunk of them
         if B % per_launch:                                 # a ragged last chunk would mix two launch sizes in the average
             per_launch = B / float(-(-B // per_launch))
@@ -374,7 +379,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.sm, args.mode, res, B),
                          "kernel": "k_fused_ssd", "avg_kernel_ms": kern_ms, "launches_timed": kern_n,
-                         "algorithmic_bytes_per_pixel": bpp, "bytes_per_launch": bytes_per_launch,
+                         "algorithmic_bytes_per_pixel": bpp, "j0_rows": "rebuilt from dI0_dx" if j0_rec else "read back", "bytes_per_launch": bytes_per_launch,
                          "targets_per_launch": per_launch},
         }
         if not args.no_cpu and world == 1:

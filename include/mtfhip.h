@@ -230,6 +230,10 @@ int mtfhip_am_cmpt_sum_of_hessians2(mtfhip_batch *b, int j0_buf, int jt_buf, int
  * (NT/ESM.cc:110-146, NT/FCLK.cc:102-169, NT/ICLK.cc:71-128): I0, dI0_dx, J0 and the constant
  * Hessian from the current image at the current points. */
 int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm);
+/* setRegion of the search method between frames (NT/ESM.cc:148-168, NT/FCLK.cc:360-376, NT/ICLK.cc:131-157): SSM reset to
+ * the new corners, template kept; ESM (and FCLK / InitialSelf) refresh init_pix_jacobian on the new grid and the constant
+ * Hessian where the Hessian type uses it; ICLK keeps its template Jacobian.  (mtfhip_ssm_set_corners alone = SSM reset only.) */
+int mtfhip_batch_set_region(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm);
 /* One iteration's device work (A2..A9 of SURVEY.md section 8a) at the current warp:
  * f (B), g (B x S) and H (B x S x S col-major) exactly as the SM holds them before LM damping
  * and the S x S solve, which stay with the caller as in the reference. */

@@ -403,6 +403,11 @@ class Batch:
     def init_template(self, sm):
         L.check(L.lib().mtfhip_batch_init_template(self._h, C.byref(sm)))
 
+    def set_region(self, corners, sm):
+        """the search method's setRegion (ESM / FCLK-InitialSelf refresh J0 and the constant Hessian on the new grid)"""
+        c = self._corners_in(corners)
+        L.check(L.lib().mtfhip_batch_set_region(self._h, _p(c), C.byref(sm)))
+
     def track_targets_per_launch(self, sm):
         return L.lib().mtfhip_batch_track_targets_per_launch(self._h, C.byref(sm))
 

@@ -208,6 +208,13 @@ struct mtfhip_batch {
 	double *d_d2_part = nullptr, *d_d2_out = nullptr, *d_d2_w = nullptr; /* second-order term: block rows, [B][64] sums, MI self weights */
 	double hess_eps = 1.0;
 	bool init_pix_hess = false;
+	/* J0 and dI0_dx are still exactly what init_template produced (no setter / pixel-Jacobian call touched them since): the
+	 * fused kernel may then rebuild J0's rows from dI0_dx instead of reading them (MTFHIP_J0_RECOMPUTE=0 disables) */
+	bool j0_is_template = false;
+	long corners_epoch = 0, j0_template_corners_epoch = -1;   /* set_corners moves the grid: J0 rows depend on init_pts */
+	int j0_variant = MTFHIP_JAC_WARPED;
+	std::vector<double> template_corners;   /* [B][8] corners the stored J0 was computed on */
+	bool j0_recompute_enabled = !(std::getenv("MTFHIP_J0_RECOMPUTE") && std::getenv("MTFHIP_J0_RECOMPUTE")[0] == '0');
 	int d0_variant = MTFHIP_JAC_WARPED; /* how the template's pixel Hessian was formed (fused second-order path) */
 	size_t unit_capacity = 0;
 	int mi_row_len = 0;
@@ -659,6 +666,7 @@ int mtfhip_batch_write(mtfhip_batch *b, int id, const double *src) {
 	if (id == MTFHIP_BUF_IT) b->it_valid = true;
 	if (id == MTFHIP_BUF_DIT_DX) b->dit_valid = true;
 	if (id == MTFHIP_BUF_JT) b->jt_valid = true;
+	if (id == MTFHIP_BUF_J0 || id == MTFHIP_BUF_DI0_DX || id == MTFHIP_BUF_INIT_PTS || id == MTFHIP_BUF_INIT_Z) b->j0_is_template = false;
 	/* a caller that supplies its own homogeneous grid gets the general (non unit-z) kernels */
 	if (id == MTFHIP_BUF_INIT_Z || id == MTFHIP_BUF_INIT_HXY) b->unit_z = 0;
 	return MTFHIP_OK;
@@ -710,6 +718,7 @@ int mtfhip_ssm_set_corners(mtfhip_batch *b, const double *corners) {
 		launch_init_grid(b->view(), b->d_w0, b->desc.resx, b->desc.resy, lo_x, lo_y, hi_x, hi_y, hom ? 0 : 1, b->ctx->stream);
 	}
 	b->have_corners = true;
+	++b->corners_epoch;
 	return MTFHIP_OK;
 }
 
@@ -785,6 +794,7 @@ int mtfhip_ssm_cmpt_pix_jacobian(mtfhip_batch *b, int variant, int grad_buf, int
 	TimedScope ts(b->ctx, "pix_jacobian");
 	launch_pix_jacobian(b->view(), variant, b->buf[grad_buf], b->buf[dst_buf], b->ctx->stream);
 	if (dst_buf == MTFHIP_BUF_JT) b->jt_valid = true;
+	if (dst_buf == MTFHIP_BUF_J0) b->j0_is_template = false;
 	return MTFHIP_OK;
 }
 
@@ -865,6 +875,7 @@ static int pix_grad_common(mtfhip_batch *b, const double *pts, bool warped, bool
 		if (warped) launch_warped_img_grad(b->view(), b->ctx->img, dp, dst, b->desc.grad_eps, b->norm_mult, b->ctx->stream);
 		else launch_img_grad(b->view(), b->ctx->img, dp, dst, b->desc.grad_eps, b->norm_mult, b->ctx->stream);
 	}
+	if (init) b->j0_is_template = false;
 	if (init && !b->init_pix_grad) {
 		HIP_TRY(hipMemcpyAsync(b->buf[MTFHIP_BUF_DIT_DX], b->buf[MTFHIP_BUF_DI0_DX], sizeof(double) * 2 * b->N * b->B, hipMemcpyDeviceToDevice, b->ctx->stream));
 		b->init_pix_grad = true;
@@ -1515,6 +1526,51 @@ int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 			std::fill(hinv.begin() + (size_t)t * 64, hinv.begin() + (size_t)(t + 1) * 64, 0.0); /* flat template: no update */
 	HIP_TRY(hipMemcpyAsync(b->d_h0inv, hinv.data(), sizeof(double) * hinv.size(), hipMemcpyHostToDevice, b->ctx->stream));
 	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	b->j0_is_template = true;
+	b->j0_template_corners_epoch = b->corners_epoch;
+	b->j0_variant = sm->chained_warp ? MTFHIP_JAC_WARPED : MTFHIP_JAC_INIT;
+	b->template_corners.resize(8 * (size_t)b->B);
+	for (int t = 0; t < b->B; ++t) std::memcpy(&b->template_corners[8 * t], b->th[t].init_corners, sizeof(double) * 8);
+	return MTFHIP_OK;
+}
+
+/* nt::ESM::setRegion NT/ESM.cc:148-168, nt::FCLK::setRegion NT/FCLK.cc:360-376, nt::ICLK::setRegion NT/ICLK.cc:131-157 (update_ssm
+ * off): the SSM is reset to the new corners; ESM (and FCLK with the InitialSelf Hessian) recompute init_pix_jacobian with
+ * cmptInitPixJacobian on the new grid and, for the Hessian types that use it, the constant self Hessian; ICLK keeps its
+ * template Jacobian.  The template (I0, dI0_dx) is kept in every case. */
+int mtfhip_batch_set_region(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm) {
+	TRY(check_sm(b, sm, "set_region"));
+	TRY(single_channel(b, "set_region"));
+	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "set_region before init_template");
+	TRY(mtfhip_ssm_set_corners(b, corners));
+	const bool refresh = sm->sm == MTFHIP_SM_ESM || (sm->sm == MTFHIP_SM_FCLK && sm->hess_type == 0);
+	if (!refresh) {
+		/* back on exactly the grid the kept template Jacobian was computed on: its rows can still be rebuilt from dI0_dx */
+		if (b->j0_is_template && b->template_corners.size() == 8 * (size_t)b->B &&
+			std::memcmp(b->template_corners.data(), corners, sizeof(double) * 8 * b->B) == 0)
+			b->j0_template_corners_epoch = b->corners_epoch;
+		return MTFHIP_OK;
+	}
+	TRY(mtfhip_ssm_cmpt_pix_jacobian(b, MTFHIP_JAC_INIT, MTFHIP_BUF_DI0_DX, MTFHIP_BUF_J0));
+	const bool need_h0 = sm->hess_type == 0 || (sm->sm == MTFHIP_SM_ESM && sm->hess_type == 2);
+	if (need_h0) {
+		std::vector<double> H0((size_t)b->B * b->S * b->S), h0dev((size_t)b->B * 64, 0.0), hinv((size_t)b->B * 64, 0.0);
+		TRY(mtfhip_am_cmpt_self_hessian(b, MTFHIP_BUF_J0, H0.data()));
+		for (int t = 0; t < b->B; ++t) {
+			std::memset(b->th[t].h0, 0, sizeof(b->th[t].h0));
+			std::memcpy(b->th[t].h0, &H0[(size_t)t * b->S * b->S], sizeof(double) * b->S * b->S);
+			std::memcpy(&h0dev[(size_t)t * 64], b->th[t].h0, sizeof(double) * 64);
+			if (!invert_definite(b->S, b->th[t].h0, &hinv[(size_t)t * 64]))
+				std::fill(hinv.begin() + (size_t)t * 64, hinv.begin() + (size_t)(t + 1) * 64, 0.0);
+		}
+		HIP_TRY(hipMemcpyAsync(b->d_h0, h0dev.data(), sizeof(double) * h0dev.size(), hipMemcpyHostToDevice, b->ctx->stream));
+		HIP_TRY(hipMemcpyAsync(b->d_h0inv, hinv.data(), sizeof(double) * hinv.size(), hipMemcpyHostToDevice, b->ctx->stream));
+		HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	}
+	b->j0_is_template = true;
+	b->j0_template_corners_epoch = b->corners_epoch;
+	b->j0_variant = MTFHIP_JAC_INIT;
+	b->template_corners.assign(corners, corners + 8 * (size_t)b->B);
 	return MTFHIP_OK;
 }
 
@@ -1522,6 +1578,8 @@ static int fused_args(const mtfhip_batch *b, const mtfhip_sm_desc *sm, FusedArgs
 	fa.chained = sm->chained_warp ? 1 : 0;
 	fa.materialize = sm->materialize ? 1 : 0;
 	fa.hess_mean = 0;
+	fa.j0_recompute = (b->j0_is_template && b->j0_recompute_enabled && b->j0_template_corners_epoch == b->corners_epoch) ? 1 : 0;
+	fa.j0_init_variant = b->j0_variant == MTFHIP_JAC_INIT ? 1 : 0;
 	fa.grad_eps = b->desc.grad_eps;
 	fa.norm_mult = b->norm_mult; fa.norm_add = b->norm_add;
 	fa.active = nullptr;
@@ -1660,7 +1718,7 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: NCC patches larger than %d pixels need the per-function entry points", kIclkTrackMaxPix);
 	FusedArgs fa;
 	if (!one_launch) TRY(fused_args(b, sm, fa));
-	else { fa.materialize = 0; fa.mode = 2; fa.active = nullptr; fa.done = nullptr; fa.rows_per_block = 1; }
+	else { fa.materialize = 0; fa.mode = 2; fa.active = nullptr; fa.done = nullptr; fa.rows_per_block = 1; fa.j0_recompute = 0; }
 	/* active = 1, iters = 0, corners, warps, states, NCC scalars: one pinned async copy of the whole slab
 	 * (w0 is copied along; init_grid consumed it long ago) */
 	HIP_TRY(hipEventSynchronize(b->ev_b));

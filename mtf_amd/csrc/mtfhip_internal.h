@@ -87,6 +87,8 @@ struct FusedArgs {
 	int chained;
 	int materialize;
 	int hess_mean;     /* ESM hess_type Original: outer products of (J0+Jt)/2 instead of Jt */
+	int j0_init_variant; /* with j0_recompute: J0 is the Init variant (non-chained initialize, or refreshed by set_region), else Warped at identity */
+	int j0_recompute;  /* 1: the template's SD rows are rebuilt from dI0_dx (bit-identical to the stored J0, 16 instead of 8 S bytes per pixel) */
 	int rows_per_block; /* 256-pixel rows walked by one workgroup (fused_decomposition) */
 	double grad_eps;
 	double norm_mult, norm_add;

@@ -1525,6 +1525,7 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 	const double2 *__restrict__ ih = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]) + (size_t)t * N;
 	const double *__restrict__ I0 = bv.buf[MTFHIP_BUF_I0] + (size_t)t * N;
 	const double *__restrict__ J0 = bv.buf[MTFHIP_BUF_J0] + (size_t)t * N * S;
+	const double *__restrict__ dI0 = bv.buf[MTFHIP_BUF_DI0_DX] + (size_t)t * N * 2;
 	double *__restrict__ It = bv.buf[MTFHIP_BUF_IT] + (size_t)t * N;
 	double *__restrict__ dIt = bv.buf[MTFHIP_BUF_DIT_DX] + (size_t)t * N * 2;
 	double *__restrict__ Jt = bv.buf[MTFHIP_BUF_JT] + (size_t)t * N * S;
@@ -1541,8 +1542,9 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 #pragma unroll
 	for (int k = 0; k < K; ++k) acc[k] = 0.0;
 
-	auto load_in = [&](unsigned i, auto uz) {
+	auto load_in = [&](unsigned i, auto uz, auto jr) {
 		PixIn<S, MODE> in;
+		constexpr bool JR = decltype(jr)::value;   /* J0 rows rebuilt from dI0_dx (2 loads) instead of read back (S loads) */
 #if MTFHIP_NT_LOAD
 		typedef double d2v __attribute__((ext_vector_type(2)));
 		{ const d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(ip) + i); in.p = make_double2(v.x, v.y); }
@@ -1556,7 +1558,9 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 #else
 		in.p = ip[i];
 		in.i0 = I0[i];
-		if constexpr (MODE != 0) {
+		if constexpr (MODE != 0 && JR) {
+			in.j0[0] = dI0[i]; in.j0[1] = dI0[N + i];
+		} else if constexpr (MODE != 0) {
 #pragma unroll
 			for (int s = 0; s < S; ++s) in.j0[s] = J0[(unsigned)s * N + i];
 		} else {
@@ -1599,7 +1603,8 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 	const int n_rows = fa.rows_per_block;
 	const unsigned base = blockIdx.x * (unsigned)(kBlock * n_rows) + threadIdx.x;
 	/* arithmetic + stores of one row; `cur` holds its streaming operands, `tcur` its position and texels */
-	auto row_compute = [&](unsigned i, const PixIn<S, MODE> &cur, const Tex &tcur) {
+	auto row_compute = [&](unsigned i, const PixIn<S, MODE> &cur, const Tex &tcur, auto jr) {
+		constexpr bool JR = decltype(jr)::value;
 #ifdef MTFHIP_EXPERIMENT_TRIVIAL   /* membench-equivalent body: same loads and stores, no arithmetic to speak of */
 		{
 			const double v = cur.p.x + cur.p.y + cur.i0 + tcur.wx;
@@ -1708,6 +1713,39 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 			}
 		}
 
+		/* the template's steepest-descent row: read back, or rebuilt from dI0_dx with the expressions (and operation
+		 * order) k_pix_jacobian used when J0 was produced -- Warped at the identity warp by a chained initialize
+		 * (Homography.cc:231-294 with curr_warp = I, curr_pts_hm = init_pts_hm), Init by a non-chained initialize and by
+		 * setRegion (NT/ESM.cc:153) -- so the bits are those of the stored matrix, for 16 B/px of traffic instead of 8 S */
+		double r0[8];
+		if constexpr (MODE != 0) {
+			if constexpr (JR) {
+				const double g0x = cur.j0[0], g0y = cur.j0[1];
+				if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+					double Ix0 = g0x, Iy0 = g0y;
+					if (!fa.j0_init_variant) {   /* produced by cmptWarpedPixJacobian at the identity warp (chained initialize) */
+						const double inv_det0 = 1.0 / cur.z;
+						const double dwx_dx = (1.0 - 0.0 * x), dwx_dy = (0.0 - 0.0 * x), dwy_dx = (0.0 - 0.0 * y), dwy_dy = (1.0 - 0.0 * y);
+						Ix0 = (dwx_dx * g0x + dwy_dx * g0y) * inv_det0;
+						Iy0 = (dwx_dy * g0x + dwy_dy * g0y) * inv_det0;
+					}
+					hom_row(r0, Ix0, Iy0, x, y, x, y);
+				} else {
+					const double Ixx0 = g0x * x, Ixy0 = g0x * y, Iyy0 = g0y * y, Iyx0 = g0y * x;
+					if (!fa.j0_init_variant) {   /* Affine.cc:213-242 with a = d = 1, b = c = 0 */
+						r0[0] = g0x * 1.0 + g0y * 0.0; r0[1] = g0x * 0.0 + g0y * 1.0;
+						r0[2] = Ixx0 * 1.0 + Iyx0 * 0.0; r0[3] = Ixy0 * 1.0 + Iyy0 * 0.0;
+						r0[4] = Ixx0 * 0.0 + Iyx0 * 1.0; r0[5] = Ixy0 * 0.0 + Iyy0 * 1.0;
+					} else {
+						r0[0] = g0x; r0[1] = g0y; r0[2] = Ixx0; r0[3] = Ixy0; r0[4] = Iyx0; r0[5] = Iyy0;
+					}
+					r0[6] = r0[7] = 0.0;
+				}
+			} else {
+#pragma unroll
+				for (int s = 0; s < S; ++s) r0[s] = cur.j0[s];
+			}
+		}
 		if constexpr (MODE == 0) {
 			const double v = -r;
 #pragma unroll
@@ -1715,14 +1753,14 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 		} else if constexpr (MODE == 1) {
 			const double v = -r;
 #pragma unroll
-			for (int s = 0; s < S; ++s) acc[36 + s] = fma(v, cur.j0[s] + row[s], acc[36 + s]);
+			for (int s = 0; s < S; ++s) acc[36 + s] = fma(v, r0[s] + row[s], acc[36 + s]);
 			if (fa.hess_mean) {
 #pragma unroll
-				for (int s = 0; s < S; ++s) row[s] = (cur.j0[s] + row[s]) / 2.0;
+				for (int s = 0; s < S; ++s) row[s] = (r0[s] + row[s]) / 2.0;
 			}
 		} else {
 #pragma unroll
-			for (int s = 0; s < S; ++s) acc[36 + s] = fma(r, cur.j0[s], acc[36 + s]);
+			for (int s = 0; s < S; ++s) acc[36 + s] = fma(r, r0[s], acc[36 + s]);
 		}
 		if constexpr (MODE != 2) {
 #if MTFHIP_COOP
@@ -1796,9 +1834,9 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 		const unsigned i = base + (unsigned)kk * kBlock;
 		if (i >= N) break;
 		PixIn<S, MODE> cur; Tex tcur;
-		if (unit_z) { cur = load_in(i, std::true_type{}); tcur = issue_tex(cur, std::true_type{}); }
-		else { cur = load_in(i, std::false_type{}); tcur = issue_tex(cur, std::false_type{}); }
-		row_compute(i, cur, tcur);
+		if (unit_z) { cur = load_in(i, std::true_type{}, std::false_type{}); tcur = issue_tex(cur, std::true_type{}); }
+		else { cur = load_in(i, std::false_type{}, std::false_type{}); tcur = issue_tex(cur, std::false_type{}); }
+		row_compute(i, cur, tcur, std::false_type{});
 	}
 #elif MTFHIP_PIPE == 1
 	/* Streaming operands of the next row are requested before the current row is processed.  Every load of the
@@ -1808,7 +1846,7 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 	 * for the texels with `s_waitcnt vmcnt(<next-row loads>)` and for the next row with `vmcnt(<stores>)`.
 	 * With guarded loads it has to assume the shortest path and emits vmcnt(0), which silently serialises the
 	 * prefetch behind the current row (that is what the ISA of the first version did). */
-	auto run_rows = [&](auto uz) {
+	auto run_rows = [&](auto uz, auto jr) {
 		const unsigned blk_first = blockIdx.x * (unsigned)(kBlock * n_rows);
 		/* full 256-pixel rows of this workgroup: no lane is masked, so nothing in the loop body is conditional */
 		int full = 0;
@@ -1817,16 +1855,16 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 			full = avail < (unsigned)n_rows ? (int)avail : n_rows;
 		}
 		if (full > 0) {
-			PixIn<S, MODE> cur = load_in(base, uz);
+			PixIn<S, MODE> cur = load_in(base, uz, jr);
 #pragma unroll 1
 			for (int kk = 0; kk < full; ++kk) {
 				const unsigned i = base + (unsigned)kk * kBlock;
 				const Tex tcur = issue_tex(cur, uz);
 				asm volatile("" ::: "memory");      /* texel fetch first, then the next row's operands: keeps the order */
 				const unsigned inext = i + kBlock;
-				const PixIn<S, MODE> nxt = load_in(inext < N ? inext : N - 1, uz);
+				const PixIn<S, MODE> nxt = load_in(inext < N ? inext : N - 1, uz, jr);
 				asm volatile("" ::: "memory");
-				row_compute(i, cur, tcur);
+				row_compute(i, cur, tcur, jr);
 				cur = nxt;
 			}
 		}
@@ -1834,13 +1872,19 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 		if (full < n_rows) {
 			const unsigned i = base + (unsigned)full * kBlock;
 			if (i < N) {
-				const PixIn<S, MODE> c = load_in(i, uz);
+				const PixIn<S, MODE> c = load_in(i, uz, jr);
 				const Tex tc = issue_tex(c, uz);
-				row_compute(i, c, tc);
+				row_compute(i, c, tc, jr);
 			}
 		}
 	};
-	if (unit_z) run_rows(std::true_type{}); else run_rows(std::false_type{});
+	if constexpr (MODE == 0) {      /* no template row in the FCLK accumulation */
+		if (unit_z) run_rows(std::true_type{}, std::false_type{}); else run_rows(std::false_type{}, std::false_type{});
+	} else if (fa.j0_recompute) {
+		if (unit_z) run_rows(std::true_type{}, std::true_type{}); else run_rows(std::false_type{}, std::true_type{});
+	} else {
+		if (unit_z) run_rows(std::true_type{}, std::false_type{}); else run_rows(std::false_type{}, std::false_type{});
+	}
 #else
 		auto row_step = [&](int kk, const PixIn<S, MODE> &cur, const Tex &tcur, const PixIn<S, MODE> &nxt, Tex &tnxt,
 		PixIn<S, MODE> &nxt2) {

@@ -44,9 +44,9 @@ class LKTracker:
         self.batch.set_corners(np.asarray(corners, dtype=np.float64).reshape(self.B, 2, 4))
         self.batch.init_template(self.sm)
 
-    # nt::*::setRegion: resets the SSM to the given corners, the template is kept
+    # nt::*::setRegion (NT/ESM.cc:148-168, NT/FCLK.cc:360-376, NT/ICLK.cc:131-157): SSM reset, template kept, ESM's J0 / H0 refreshed
     def set_region(self, corners):
-        self.batch.set_corners(np.asarray(corners, dtype=np.float64).reshape(self.B, 2, 4))
+        self.batch.set_region(np.asarray(corners, dtype=np.float64).reshape(self.B, 2, 4), self.sm)
 
     def get_region(self):
         return self.batch.get_corners()

@@ -426,3 +426,49 @@ def test_second_order_interface(oracle, gpu_ctx, frame, frame2, am, ssm):
         close(b.cmpt_self_hessian2()[0], want_self, "self2")
     b.mean_pix_hessian()
     np.testing.assert_allclose(b.read(L.BUF_D2IM_DP2)[0], (D0_o + Dt_o) / 2.0, rtol=1e-5, atol=1e-6 * np.abs(D0_o).max())
+
+
+@pytest.mark.parametrize("shape", ["square", "quad"])
+@pytest.mark.parametrize("sm_kind,extra", [(L.SM_ESM, dict()), (L.SM_ESM, dict(chained_warp=0, hess_type=0)),
+                                           (L.SM_FCLK, dict(hess_type=0)), (L.SM_ICLK, dict())])
+def test_set_region_follows_the_search_method(oracle, gpu_ctx, frame, frame2, sm_kind, extra, shape):
+    """nt::ESM / FCLK / ICLK::setRegion (NT/ESM.cc:148-168, NT/FCLK.cc:360-376, NT/ICLK.cc:131-157) between frames, to a
+    DIFFERENT region: ESM (and FCLK / InitialSelf) refresh init_pix_jacobian and the constant Hessian on the new grid, ICLK
+    keeps its template Jacobian.  The fused kernel rebuilds J0's rows from dI0_dx (or reads them back with
+    MTFHIP_J0_RECOMPUTE=0): both must give the oracle's g and H, bit-identical to each other."""
+    import os
+    rng = np.random.default_rng(61)
+    res = 30
+    c0 = CORNER_SETS[shape](rng)
+    c1 = c0 + np.array([[3.3], [-2.1]]) + rng.uniform(-1.5, 1.5, size=(2, 4)) * (shape == "quad")
+    params = dict(leven_marq=0, max_iters=1, epsilon=-1.0)
+    params.update(extra)
+    o_am, o_ssm, b = make_pair(oracle, gpu_ctx, frame, L.AM_SSD, L.SSM_HOMOGRAPHY, res, c0)
+    trk = oracle.Tracker(sm_kind, o_am, o_ssm, **params)
+    trk.initialize(c0)
+    o_am.set_curr_img(frame2)
+    trk.set_region(c1)
+    trk.update()
+    rec = trk.trace()[0]
+    results = []
+    for env in ("1", "0"):
+        os.environ["MTFHIP_J0_RECOMPUTE"] = env
+        try:
+            gpu_ctx.set_image(frame)
+            bb = mtf_amd.Batch(gpu_ctx, L.AM_SSD, L.SSM_HOMOGRAPHY, res, res, 1)
+            bb.set_corners(c0[None])
+            sm = mtf_amd.sm_desc(sm_kind, materialize=0, **params)
+            bb.init_template(sm)
+            gpu_ctx.set_image(frame2)
+            bb.set_region(c1[None], sm)
+            f, g, H = bb.iterate(sm)
+        finally:
+            del os.environ["MTFHIP_J0_RECOMPUTE"]
+        assert rel(f[0], rec["f"]) < 1e-8
+        assert rel(H[0], rec["H"]) < 1e-5
+        gs = max(np.linalg.norm(rec["g"]), np.sqrt(abs(np.trace(rec["H"])) * abs(2 * rec["f"])))
+        assert np.linalg.norm(g[0] - rec["g"]) < 1e-5 * gs
+        results.append((f.copy(), g.copy(), H.copy()))
+        bb.close()
+    for x, y in zip(results[0], results[1]):
+        assert np.array_equal(x, y)           # rebuilt rows == stored rows, bit for bit
