@@ -15,7 +15,9 @@ import os
 import sys
 import time
 
-import numpy as np
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # before torch touches the GPU; see mtf_amd/__init__.py
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -5,7 +5,13 @@ its Python mirror of the reference's AppearanceModel / StateSpaceModel interface
 search-method loops that drive it (sm.py), candidate sharding over GPUs (dist.py) and synthetic
 frames (synth.py).
 """
-from . import _lib
+import os as _os
+
+# Kernel arguments in device memory (see the constructor in csrc/mtfhip_api.hip): read by the HIP runtime at its first
+# call, so it is set here as well in case the library is loaded after some other module initialised HIP.
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
+from . import _lib  # noqa: E402
 from ._lib import (AM_MI, AM_NCC, AM_SSD, SM_ESM, SM_FCLK, SM_ICLK, SSM_AFFINE, SSM_HOMOGRAPHY,  # noqa: F401
                    FunctionNotImplemented, InvalidArgument, LogicError, MtfHipError)
 from .api import Batch, Context, sm_desc  # noqa: F401

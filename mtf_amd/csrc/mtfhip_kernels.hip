@@ -20,9 +20,6 @@
 #include "mtfhip_internal.h"
 
 /* tuning knobs of the fused kernel ("fused kernel tuning") */
-#ifndef MTFHIP_PIPE
-#define MTFHIP_PIPE 1          /* 0: no software pipeline, 1: operands one row ahead, 3: static three-row ring */
-#endif
 #ifndef MTFHIP_FUSED_WAVES
 #define MTFHIP_FUSED_WAVES 2   /* minimum waves per SIMD requested from the register allocator */
 #endif
@@ -36,9 +33,6 @@
 #endif
 #ifndef MTFHIP_NT_LOAD
 #define MTFHIP_NT_LOAD 0       /* 1: the read-once operands (grid points, I0, J0 columns) are fetched with non-temporal loads */
-#endif
-#ifndef MTFHIP_COOP
-#define MTFHIP_COOP 0          /* 1: the 36 J^T J products are split over the 4 waves of a workgroup through LDS */
 #endif
 
 namespace mtfhip {
@@ -1442,39 +1436,29 @@ __global__ __launch_bounds__(64) void k_finish(const double *partials, int nblk,
  * the border or on an integer coordinate sends the wave through the general per-sample path.  Both
  * paths evaluate the reference's expressions in the reference's order.
  */
+/* Uniform base + 32-bit byte offset: the form the `global_load/store v, v_off, s[base]` encodings take directly.
+ * With `ptr[i]` the compiler cannot prove that i * sizeof(T) stays below 2^32 and builds a 64-bit address per
+ * access (v_lshl_add_u64 / v_mad_u64), ~50 extra VALU instructions per row in a loop that is VALU-issue bound.
+ * mtfhip_batch_create bounds the per-target arrays to < 4 GiB so the offsets cannot wrap. */
+template <typename T>
+__device__ __forceinline__ T ld_off(const void *base, unsigned byte_off) {
+	return *reinterpret_cast<const T *>(static_cast<const char *>(base) + byte_off);
+}
+template <typename T>
+__device__ __forceinline__ void st_off(void *base, unsigned byte_off, T v) {
+	MAT_STORE(reinterpret_cast<T *>(static_cast<char *>(base) + byte_off), v);
+}
 __device__ __forceinline__ double bilin(double t00, double t01, double t10, double t11, double dx, double dy) {
 	return t00 * (1 - dx) * (1 - dy) + t01 * dx * (1 - dy) + t10 * (1 - dx) * dy + t11 * dx * dy;
 }
 /* true when (x, y) is sampled from the interior cell (lx, ly) with both upper neighbours lx+1, ly+1 */
 __device__ __forceinline__ bool in_cell(double x, double y, int lx, int ly) {
-	return (x >= 0) && (y >= 0) && ((int)x == lx) && ((int)y == ly) && ((x - lx) != 0) && ((y - ly) != 0);
+	/* bitwise on purpose: six compares and five s_and instead of a chain of exec-masked branches */
+	return (x >= 0) & (y >= 0) & ((int)x == lx) & ((int)y == ly) & ((x - lx) != 0) & ((y - ly) != 0);
 }
 
 /* index of (a, b), a <= b, in the upper-triangle order of the accumulator row (stride 8) */
 __host__ __device__ constexpr int tri8(int a, int b) { return a * 8 - (a * (a - 1)) / 2 + (b - a); }
-/* Cooperative Gram accumulation: the workgroup's 256 steepest-descent rows of one iteration sit in LDS
- * (component-major, R[s][pixel]); wave WV owns every 4th..: the products with linear index in
- * [WV*PER, (WV+1)*PER) of the S(S+1)/2 upper-triangle list and sums them over all 256 pixels. */
-template <int S, int WV>
-__device__ __forceinline__ void coop_accumulate(const double *R, int lane, double *h) {
-	constexpr int NK = S * (S + 1) / 2, PER = (NK + 3) / 4;
-#pragma unroll
-	for (int j = 0; j < kBlock / 64; ++j) {
-		const int q = j * 64 + lane;
-		double r[S];
-#pragma unroll
-		for (int s = 0; s < S; ++s) r[s] = R[s * kBlock + q];
-		int k = 0;
-#pragma unroll
-		for (int a = 0; a < S; ++a)
-#pragma unroll
-			for (int b = a; b < S; ++b) {
-				if (k / PER == WV) h[k - WV * PER] = fma(r[a], r[b], h[k - WV * PER]);
-				++k;
-			}
-	}
-}
-
 template <int S, int MODE>
 struct PixIn {
 	double2 p;
@@ -1488,6 +1472,7 @@ struct Tex {
 	double wx, wy, cx, cy, D;
 	float t00, t01, t10, t11;
 	int lx, ly;
+	double lxd, lyd;   /* (double)lx, (double)ly */
 	bool ok;   /* interior cell, non-integer coordinates: the texels above are the sample's own */
 };
 
@@ -1508,18 +1493,19 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 	constexpr int S = (SSM == MTFHIP_SSM_HOMOGRAPHY) ? 8 : 6;
 	constexpr int K = 48;
 	__shared__ double lds[4 * K];
-#if MTFHIP_COOP
-	__shared__ double Rbuf[2][8 * kBlock];   /* double-buffered SD rows of the current 256 pixels */
-	double hacc[9];
-#pragma unroll
-	for (int q = 0; q < 9; ++q) hacc[q] = 0.0;
-	int rbuf_sel = 0;
-#endif
 	const int t = blockIdx.y;
 	const unsigned N = (unsigned)bv.N;
-	if (fa.active && !fa.active[t]) return;
+	/* The per-target scalars (live flag, warp, state) sit a scalar-load round trip behind the kernel arguments and
+	 * the first row's streaming operands do not depend on them: the scalar loads are requested here, but nothing
+	 * waits for them (no early exit, no derived constant) until the first row's vector loads have been issued
+	 * (setup_target, called from run_rows).  They must stay ahead of the asm memory fences to remain s_loads. */
+	/* branch-free: without a flag array the load is pointed at this target's warp (always readable) and ignored */
+	const int *live_ptr = fa.active ? fa.active + t : reinterpret_cast<const int *>(bv.warps + 9 * t);
+	const int live_word = *live_ptr;
+	const int live = fa.active ? live_word : 1;
 	const Warp9 W = load_warp(bv.warps + 9 * t);
 	const double *st = bv.states + 8 * t;
+	const double st2 = st[2], st3 = st[3], st4 = st[4], st5 = st[5];
 	const double2 *__restrict__ ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * N;
 	const double *__restrict__ iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * N;
 	const double2 *__restrict__ ih = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]) + (size_t)t * N;
@@ -1531,12 +1517,17 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 	double *__restrict__ Jt = bv.buf[MTFHIP_BUF_JT] + (size_t)t * N * S;
 	const float *__restrict__ img = im.data;
 	const int iw = im.w, ih_ = im.h, istride = im.stride;
+	const float *__restrict__ img_row1 = img + istride;
 	const bool unit_z = bv.unit_z != 0;
 	const double eps = fa.grad_eps;
 	const double gmult = fa.norm_mult / (2 * eps);
-	const double ex0 = W.m[0] * eps, ex1 = W.m[3] * eps, ex2 = W.m[6] * eps;
-	const double ey0 = W.m[1] * eps, ey1 = W.m[4] * eps, ey2 = W.m[7] * eps;
-	const double aa = st[2] + 1, ab = st[3], ac = st[4], ad = st[5] + 1; /* affine a,b,c,d (Affine.cc:216-217) */
+	double ex0, ex1, ex2, ey0, ey1, ey2;
+	double aa, ab, ac, ad;   /* affine a,b,c,d (Affine.cc:216-217) */
+	auto setup_target = [&]() {
+		ex0 = W.m[0] * eps; ex1 = W.m[3] * eps; ex2 = W.m[6] * eps;
+		ey0 = W.m[1] * eps; ey1 = W.m[4] * eps; ey2 = W.m[7] * eps;
+		aa = st2 + 1; ab = st3; ac = st4; ad = st5 + 1;
+	};
 
 	double acc[K];
 #pragma unroll
@@ -1556,19 +1547,20 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 			in.j0[0] = 0;
 		}
 #else
-		in.p = ip[i];
-		in.i0 = I0[i];
+		const unsigned o8 = i * 8u, o16 = i * 16u;
+		in.p = ld_off<double2>(ip, o16);
+		in.i0 = ld_off<double>(I0, o8);
 		if constexpr (MODE != 0 && JR) {
-			in.j0[0] = dI0[i]; in.j0[1] = dI0[N + i];
+			in.j0[0] = ld_off<double>(dI0, o8); in.j0[1] = ld_off<double>(dI0 + N, o8);
 		} else if constexpr (MODE != 0) {
 #pragma unroll
-			for (int s = 0; s < S; ++s) in.j0[s] = J0[(unsigned)s * N + i];
+			for (int s = 0; s < S; ++s) in.j0[s] = ld_off<double>(J0 + (size_t)s * N, o8);
 		} else {
 			in.j0[0] = 0;
 		}
 #endif
 		if constexpr (decltype(uz)::value) { in.hp = make_double2(0.0, 0.0); in.z = 1.0; }   /* hp is taken from p at use */
-		else { in.hp = ih[i]; in.z = iz[i]; }
+		else { in.hp = ld_off<double2>(ih, o16); in.z = ld_off<double>(iz, o8); }
 		return in;
 	};
 	/* curr_pts_hm = curr_warp * init_pts_hm and its dehomogenisation (Homography.cc:86-90, Affine.cc:104),
@@ -1588,13 +1580,16 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 			tx.cx = tx.wx; tx.cy = tx.wy; tx.D = 1.0;
 		}
 		tx.lx = (int)tx.wx; tx.ly = (int)tx.wy;
-		tx.ok = in_cell(tx.wx, tx.wy, tx.lx, tx.ly) && (tx.lx + 1 < iw) && (tx.ly + 1 < ih_);
+		tx.lxd = (double)tx.lx; tx.lyd = (double)tx.ly;
+		/* in_cell(wx, wy, (int)wx, (int)wy) with the trivially true terms dropped, and both upper neighbours inside */
+		tx.ok = (tx.wx >= 0) & (tx.wy >= 0) & (tx.wx != tx.lxd) & (tx.wy != tx.lyd) & (tx.lx < iw - 1) & (tx.ly < ih_ - 1);
 		const int sx = tx.ok ? tx.lx : 0, sy = tx.ok ? tx.ly : 0;
-		const float *r0 = img + (unsigned)(sy * istride + sx);
-		const float *r1 = r0 + istride;
+		const unsigned to = (unsigned)(sy * istride + sx) * 4u;
 #ifdef MTFHIP_EXPERIMENT_NOTEX
-		tx.t00 = tx.t01 = tx.t10 = tx.t11 = (float)in.i0; (void)r0; (void)r1;
+		tx.t00 = tx.t01 = tx.t10 = tx.t11 = (float)in.i0; (void)to;
 #else
+		const float *r0 = reinterpret_cast<const float *>(reinterpret_cast<const char *>(img) + to);
+		const float *r1 = reinterpret_cast<const float *>(reinterpret_cast<const char *>(img_row1) + to);
 		tx.t00 = r0[0]; tx.t01 = r0[1]; tx.t10 = r1[0]; tx.t11 = r1[1];
 #endif
 		return tx;
@@ -1620,6 +1615,8 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 		const double x = cur.p.x, y = cur.p.y;
 		const double wx = tcur.wx, wy = tcur.wy, cx = tcur.cx, cy = tcur.cy, D = tcur.D;
 		const int lx = tcur.lx, ly = tcur.ly;
+		const double lxd = tcur.lxd, lyd = tcur.lyd;
+		const unsigned o8 = i * 8u;
 		/* the four finite-difference sample points */
 		double px0, py0, px1, py1, px2, py2, px3, py3;
 		if constexpr (MODE != 2) {
@@ -1644,22 +1641,27 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 			}
 		}
 		bool fast = tcur.ok;
-		if constexpr (MODE != 2)
-			fast = fast && in_cell(px0, py0, lx, ly) && in_cell(px1, py1, lx, ly) && in_cell(px2, py2, lx, ly) &&
+		if constexpr (MODE != 2 && CHAINED) {
+			/* axis-aligned neighbours of a centre that is strictly inside the cell (eps > 0, rounding is monotonic):
+			 * wx + eps >= wx > lx and wx - eps <= wx < lx + 1 hold already, so in_cell reduces to the other bound */
+			fast = fast & (px0 < lxd + 1) & (px1 > lxd) & (py2 < lyd + 1) & (py3 > lyd);
+		} else if constexpr (MODE != 2) {
+			fast = fast & in_cell(px0, py0, lx, ly) & in_cell(px1, py1, lx, ly) & in_cell(px2, py2, lx, ly) &
 				in_cell(px3, py3, lx, ly);
+		}
 		double it, gx = 0, gy = 0;
 #ifdef MTFHIP_EXPERIMENT_NOMATH
 		if (true) { it = tcur.t00 + tcur.t01 + tcur.t10 + tcur.t11 + wx; gx = wy; gy = px0 + py3; } else
 #endif
 		if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
 			const double t00 = tcur.t00, t01 = tcur.t01, t10 = tcur.t10, t11 = tcur.t11;
-			it = fa.norm_mult * bilin(t00, t01, t10, t11, wx - lx, wy - ly) + fa.norm_add;
+			it = fa.norm_mult * bilin(t00, t01, t10, t11, wx - lxd, wy - lyd) + fa.norm_add;
 			if constexpr (MODE != 2) {
-				double inc = bilin(t00, t01, t10, t11, px0 - lx, py0 - ly);
-				double dec = bilin(t00, t01, t10, t11, px1 - lx, py1 - ly);
+				double inc = bilin(t00, t01, t10, t11, px0 - lxd, py0 - lyd);
+				double dec = bilin(t00, t01, t10, t11, px1 - lxd, py1 - lyd);
 				gx = (inc - dec) * gmult;
-				inc = bilin(t00, t01, t10, t11, px2 - lx, py2 - ly);
-				dec = bilin(t00, t01, t10, t11, px3 - lx, py3 - ly);
+				inc = bilin(t00, t01, t10, t11, px2 - lxd, py2 - lyd);
+				dec = bilin(t00, t01, t10, t11, px3 - lxd, py3 - lyd);
 				gy = (inc - dec) * gmult;
 			}
 		} else {
@@ -1676,11 +1678,11 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 		}
 		const double r = it - cur.i0;
 		acc[44] = fma(r, r, acc[44]);
-		if constexpr (MAT) MAT_STORE(&It[i], it);
+		if constexpr (MAT) st_off<double>(It, o8, it);
 
 		double row[8];
 		if constexpr (MODE != 2) {
-			if constexpr (MAT) { MAT_STORE(&dIt[i], gx); MAT_STORE(&dIt[N + i], gy); }
+			if constexpr (MAT) { st_off<double>(dIt, o8, gx); st_off<double>(dIt + N, o8, gy); }
 			if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
 				if constexpr (CHAINED) {
 					/* Homography::cmptWarpedPixJacobian SSM/src/Homography.cc:231-294 */
@@ -1709,7 +1711,7 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 			}
 			if constexpr (MAT) {
 #pragma unroll
-				for (int s = 0; s < S; ++s) MAT_STORE(&Jt[(unsigned)s * N + i], row[s]);
+				for (int s = 0; s < S; ++s) st_off<double>(Jt + (size_t)s * N, o8, row[s]);
 			}
 		}
 
@@ -1763,10 +1765,6 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 			for (int s = 0; s < S; ++s) acc[36 + s] = fma(r, r0[s], acc[36 + s]);
 		}
 		if constexpr (MODE != 2) {
-#if MTFHIP_COOP
-#pragma unroll
-			for (int s = 0; s < S; ++s) Rbuf[rbuf_sel][s * kBlock + threadIdx.x] = row[s];
-#else
 #ifndef MTFHIP_EXPERIMENT_NOACC
 			int k = 0;
 #pragma unroll
@@ -1777,68 +1775,8 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 					++k;
 				}
 #endif
-#endif
 		}
 	};
-#if MTFHIP_COOP
-	/* every thread walks all rows of the workgroup (pixels past N contribute zero rows) because each
-	 * iteration ends in a workgroup barrier followed by the cooperative accumulation */
-	const int wave_id = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
-	const unsigned blk_base = blockIdx.x * (unsigned)(kBlock * n_rows);
-	PixIn<S, MODE> cur;
-	if (base < N) cur = load_in(base);
-#pragma unroll 1
-	for (int kk = 0; kk < n_rows; ++kk) {
-		if (blk_base + (unsigned)kk * kBlock >= N) break;          /* uniform over the workgroup */
-		const unsigned i = base + (unsigned)kk * kBlock;
-		if (i < N) {
-			const Tex tcur = issue_tex(cur);
-			PixIn<S, MODE> nxt = cur;
-			if (kk + 1 < n_rows && i + kBlock < N) nxt = load_in(i + kBlock);
-			row_compute(i, cur, tcur);
-			cur = nxt;
-		} else if constexpr (MODE != 2) {
-#pragma unroll
-			for (int s = 0; s < S; ++s) Rbuf[rbuf_sel][s * kBlock + threadIdx.x] = 0.0;
-		}
-		if constexpr (MODE != 2) {
-			__syncthreads();
-			const double *R = Rbuf[rbuf_sel];
-			if (wave_id == 0) coop_accumulate<S, 0>(R, lane_id, hacc);
-			else if (wave_id == 1) coop_accumulate<S, 1>(R, lane_id, hacc);
-			else if (wave_id == 2) coop_accumulate<S, 2>(R, lane_id, hacc);
-			else coop_accumulate<S, 3>(R, lane_id, hacc);
-			rbuf_sel ^= 1;   /* the next iteration's rows go to the other buffer: one barrier per iteration */
-		}
-	}
-	/* wave w holds its PER Gram entries summed over every pixel of the workgroup; g and r^2 are per-thread sums */
-	{
-		constexpr int NK = S * (S + 1) / 2, PER = (NK + 3) / 4;
-		int k = 0;
-#pragma unroll
-		for (int a = 0; a < S; ++a)
-#pragma unroll
-			for (int b = a; b < S; ++b) {
-				const int owner = k / PER, slot = k - owner * PER;
-				double v = 0.0;
-#pragma unroll
-				for (int q = 0; q < 9; ++q) if (q == slot) v = hacc[q];
-				acc[tri8(a, b)] = (owner == wave_id) ? v : 0.0;
-				++k;
-			}
-	}
-#elif MTFHIP_PIPE == 0
-	/* no software pipelining: latency is covered by occupancy alone */
-#pragma unroll 1
-	for (int kk = 0; kk < n_rows; ++kk) {
-		const unsigned i = base + (unsigned)kk * kBlock;
-		if (i >= N) break;
-		PixIn<S, MODE> cur; Tex tcur;
-		if (unit_z) { cur = load_in(i, std::true_type{}, std::false_type{}); tcur = issue_tex(cur, std::true_type{}); }
-		else { cur = load_in(i, std::false_type{}, std::false_type{}); tcur = issue_tex(cur, std::false_type{}); }
-		row_compute(i, cur, tcur, std::false_type{});
-	}
-#elif MTFHIP_PIPE == 1
 	/* Streaming operands of the next row are requested before the current row is processed.  Every load of the
 	 * loop over full rows is issued unconditionally (the prefetch index is clamped into the target instead of being
 	 * guarded, the unit-z variant is chosen at compile time, the partial last row is peeled off): the number of
@@ -1856,6 +1794,9 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 		}
 		if (full > 0) {
 			PixIn<S, MODE> cur = load_in(base, uz, jr);
+			asm volatile("" ::: "memory");
+			setup_target();
+			if (!live) return;
 #pragma unroll 1
 			for (int kk = 0; kk < full; ++kk) {
 				const unsigned i = base + (unsigned)kk * kBlock;
@@ -1871,6 +1812,7 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 		/* the partial last row of a target (only the workgroup that owns the end of the patch gets here) */
 		if (full < n_rows) {
 			const unsigned i = base + (unsigned)full * kBlock;
+			if (full == 0) { setup_target(); if (!live) return; }
 			if (i < N) {
 				const PixIn<S, MODE> c = load_in(i, uz, jr);
 				const Tex tc = issue_tex(c, uz);
@@ -1885,30 +1827,7 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 	} else {
 		if (unit_z) run_rows(std::true_type{}, std::false_type{}); else run_rows(std::false_type{}, std::false_type{});
 	}
-#else
-		auto row_step = [&](int kk, const PixIn<S, MODE> &cur, const Tex &tcur, const PixIn<S, MODE> &nxt, Tex &tnxt,
-		PixIn<S, MODE> &nxt2) {
-		const unsigned i = base + (unsigned)kk * kBlock;
-		if (i >= N) return;
-		if (kk + 1 < n_rows && i + kBlock < N) tnxt = issue_tex(nxt);
-		if (kk + 2 < n_rows && i + 2 * kBlock < N) nxt2 = load_in(i + 2 * kBlock);
-		row_compute(i, cur, tcur);
-	};
-	PixIn<S, MODE> inA, inB, inC;
-	Tex txA, txB, txC;
-	if (base < N) {
-		inA = load_in(base);
-		if (base + kBlock < N) inB = load_in(base + kBlock);
-		txA = issue_tex(inA);
-	}
-#pragma unroll 1
-	for (int kk = 0; kk < n_rows; kk += 3) {
-		if (base + (unsigned)kk * kBlock >= N) break;
-		row_step(kk, inA, txA, inB, txB, inC);
-		row_step(kk + 1, inB, txB, inC, txC, inA);
-		row_step(kk + 2, inC, txC, inA, txA, inB);
-	}
-#endif
+	if (!live) return;
 	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * ACC_COUNT;
 	if (!fa.done) { block_reduce_store<K>(acc, dst, lds); return; }
 	/* Last-workgroup-done epilogue.  The only data that crosses workgroups inside the launch are the partial rows and
