@@ -158,6 +158,7 @@ struct mtfhip_ctx {
 	int timing_stride = 1;   /* events are recorded around every timing_stride-th launch of a family */
 	std::map<std::string, Timer> timers;
 	std::vector<hipEvent_t> free_events;
+	std::vector<struct mtfhip_batch *> batches;   /* live batches: deferred work is flushed before the image changes */
 };
 
 struct TimedScope {
@@ -247,6 +248,36 @@ struct mtfhip_batch {
 	bool have_corners = false, init_pix_vals = false, init_pix_grad = false, init_sim = false, init_grad = false;
 	bool it_valid = false, dit_valid = false, jt_valid = false;
 	std::vector<TargetHost> th;
+
+	/* Deferred fusion of the per-function entry points (SSD, single channel; DESIGN.md "drop-in path").  The pixel-level
+	 * producers of an iteration (updatePixVals, updatePixGrad, cmpt*PixJacobian, updateSimilarity, update*Grad,
+	 * mean Jacobian) only RECORD themselves; the first call that needs a number on the host (cmpt*Jacobian) runs the
+	 * fused kernel with materialize=1 when the recorded set is one of the ESM / FCLK / ICLK call sequences, and every
+	 * other entry point first replays what is pending through the un-fused kernels, in the recorded order -- so the
+	 * buffers and results are those of the call-by-call execution either way. */
+	struct Lazy {
+		bool enabled = false;
+		long seq = 0;
+		long pv = 0;            /* update_pix_vals(NULL) */
+		long gp = 0;            /* ssm_update_grad_pts(grad_eps) */
+		long pg = 0; int pg_kind = 0;   /* update_pix_grad(NULL) = 1, update_pix_grad_warped(NULL) = 2 */
+		long pj = 0; int pj_variant = -1;   /* ssm_cmpt_pix_jacobian(variant, DIT_DX -> JT) */
+		long sim = 0, cg = 0, ig = 0, jm = 0;
+		bool any() const { return pv || gp || pg || pj || sim || cg || ig || jm; }
+		bool sim_need_f = false;
+		/* DF_DI0 (updateSimilarity) / DF_DIT (updateCurrGrad) were skipped by a fused launch: refreshed from IT / I0 on
+		 * first use, and in any case before IT is overwritten by something that does not overwrite them as well */
+		bool df0_stale = false, dft_stale = false;
+		bool no_cache = false;
+		/* Levenberg-Marquardt reads f in the middle of the iteration (NT/ESM.cc:186-204), which replays updatePixVals +
+		 * updateSimilarity un-fused; the fused launch may still serve the rest when IT and DF_DI0 are known to belong to
+		 * the current warp and image (it recomputes the same IT bits): epoch counts warp / image changes */
+		long epoch = 0, it_epoch = -1, df0_it_ver = -1;
+		/* Gram matrices that are already on the host: [B][36] upper triangles, valid while version matches */
+		long ver[MTFHIP_BUF_COUNT] = {0};
+		int gram_buf = -1; long gram_ver = -1; std::vector<double> gram;
+		long gram0_ver = -1; std::vector<double> gram0;   /* J0: constant between template changes */
+	} lz;
 
 	BatchView view() const {
 		BatchView v;
@@ -346,6 +377,19 @@ static int resolve_pts(mtfhip_batch *b, const double *host, int own_buf, size_t 
 
 extern "C" {
 
+/* ------------------------------------------------------------------ deferred fusion (see mtfhip_batch::Lazy) */
+static inline void touch(mtfhip_batch *b, int id) { ++b->lz.ver[id]; }
+static inline void touch_all(mtfhip_batch *b) { for (int i = 0; i < MTFHIP_BUF_COUNT; ++i) ++b->lz.ver[i]; }
+static int lazy_flush(mtfhip_batch *b);
+static int ensure_df(mtfhip_batch *b);
+static int do_cmpt_pix_jacobian(mtfhip_batch *b, int variant, int grad_buf, int dst_buf);
+static int do_mean_jacobian(mtfhip_batch *b);
+static int lazy_flush_ctx(mtfhip_ctx *c) {   /* called by everything that replaces the current image */
+	for (mtfhip_batch *b : c->batches) { int rc = lazy_flush(b); if (rc) return rc; ++b->lz.epoch; }
+	return MTFHIP_OK;
+}
+#define FLUSH(b) do { if (b) { int _rc = lazy_flush(b); if (_rc) return _rc; } } while (0)
+
 /* ------------------------------------------------------------------ context */
 const char *mtfhip_last_error(void) { return g_last_error.c_str(); }
 
@@ -406,6 +450,7 @@ int mtfhip_image_upload(mtfhip_ctx *c, const float *host_img, int height, int wi
 /* CV_32FC3: `channels` interleaved floats per pixel, row_stride in floats */
 int mtfhip_image_upload_mc(mtfhip_ctx *c, const float *host_img, int height, int width, int row_stride, int channels) {
 	if (!c || !host_img) return fail(MTFHIP_ERR_INVALID_ARG, "image_upload: NULL argument");
+	TRY(lazy_flush_ctx(c));
 	if (channels != 1 && channels != 3) return fail(MTFHIP_ERR_INVALID_ARG, "image_upload: %d channels (1 or 3 expected)", channels);
 	if (height <= 0 || width <= 0 || row_stride < width * channels) return fail(MTFHIP_ERR_INVALID_ARG, "image_upload: bad shape %dx%d stride %d", height, width, row_stride);
 	if ((double)height * width * channels * 4.0 >= 4294967296.0) return fail(MTFHIP_ERR_INVALID_ARG, "image_upload: %dx%dx%d floats exceed the 4 GiB a 32-bit texel offset can address", height, width, channels);
@@ -427,6 +472,7 @@ int mtfhip_image_upload_mc(mtfhip_ctx *c, const float *host_img, int height, int
 }
 
 int mtfhip_image_borrow(mtfhip_ctx *c, const float *dev_img, int height, int width, int row_stride) {
+	if (c) TRY(lazy_flush_ctx(c));
 	if (!c || !dev_img) return fail(MTFHIP_ERR_INVALID_ARG, "image_borrow: NULL argument");
 	if (height <= 0 || width <= 0 || row_stride < width) return fail(MTFHIP_ERR_INVALID_ARG, "image_borrow: bad shape");
 	c->img = ImgView{dev_img, height, width, row_stride};
@@ -469,6 +515,7 @@ static void gaussian5(double sigma, float k[3]) {
 
 int mtfhip_image_preprocess(mtfhip_ctx *c, const void *host_raw, int rows, int cols, int row_stride_bytes, int channels, int depth,
 	int ksize, double sigma_x, double sigma_y) {
+	if (c) TRY(lazy_flush_ctx(c));
 	if (!c || !host_raw) return fail(MTFHIP_ERR_INVALID_ARG, "image_preprocess: NULL argument");
 	if (rows <= 0 || cols <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "image_preprocess: bad shape %dx%d", rows, cols);
 	if (channels != 1 && channels != 3) return fail(MTFHIP_ERR_INVALID_ARG, "image_preprocess: %d channels (1 or 3 expected)", channels);
@@ -505,6 +552,7 @@ int mtfhip_image_preprocess(mtfhip_ctx *c, const void *host_raw, int rows, int c
 }
 
 int mtfhip_image_pyramid_level(mtfhip_ctx *dst, mtfhip_ctx *src, int dst_rows, int dst_cols, int use_pyr_down) {
+	if (dst) TRY(lazy_flush_ctx(dst));
 	if (!dst || !src) return fail(MTFHIP_ERR_INVALID_ARG, "image_pyramid_level: NULL argument");
 	if (!src->img.data) return fail(MTFHIP_ERR_LOGIC, "image_pyramid_level: the source context has no image");
 	if (dst == src) return fail(MTFHIP_ERR_INVALID_ARG, "image_pyramid_level: source and destination contexts must differ");
@@ -628,6 +676,11 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 	(void)hipMemsetAsync(b->d_partials, 0, sizeof(double) * ACC_COUNT * b->nblk_max * n_targets, c->stream);
 	int r = push_warps(b);
 	if (r) return cleanup(r);
+	{
+		const char *lazy_env = std::getenv("MTFHIP_LAZY");
+		b->lz.enabled = d->am == MTFHIP_AM_SSD && b->C == 1 && !(lazy_env && lazy_env[0] == '0');
+	}
+	c->batches.push_back(b);
 	*out = b;
 	return MTFHIP_OK;
 }
@@ -635,6 +688,8 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 void mtfhip_batch_destroy(mtfhip_batch *b) {
 	if (!b) return;
 	try {
+		auto &reg = b->ctx->batches;
+		reg.erase(std::remove(reg.begin(), reg.end(), b), reg.end());
 		(void)hipSetDevice(b->ctx->device);
 		(void)hipStreamSynchronize(b->ctx->stream);
 		for (int i = 0; i < MTFHIP_BUF_COUNT; ++i)
@@ -661,6 +716,8 @@ int mtfhip_batch_state_size(const mtfhip_batch *b) { return b ? b->S : 0; }
 
 int mtfhip_batch_read(mtfhip_batch *b, int id, double *dst) {
 	if (!b || !dst || id < 0 || id >= MTFHIP_BUF_COUNT) return fail(MTFHIP_ERR_INVALID_ARG, "batch_read: bad argument");
+	FLUSH(b);
+	if (id == MTFHIP_BUF_DF_DI0 || id == MTFHIP_BUF_DF_DIT) TRY(ensure_df(b));
 	if (!b->buf[id]) return fail(MTFHIP_ERR_LOGIC, "batch_read: buffer %d was never produced", id);
 	if ((id == MTFHIP_BUF_IT && !b->it_valid) || (id == MTFHIP_BUF_DIT_DX && !b->dit_valid) || (id == MTFHIP_BUF_JT && !b->jt_valid))
 		return fail(MTFHIP_ERR_LOGIC, "batch_read: buffer %d is not materialised (last fused iteration ran with materialize=0)", id);
@@ -671,6 +728,10 @@ int mtfhip_batch_read(mtfhip_batch *b, int id, double *dst) {
 
 int mtfhip_batch_write(mtfhip_batch *b, int id, const double *src) {
 	if (!b || !src || id < 0 || id >= MTFHIP_BUF_COUNT) return fail(MTFHIP_ERR_INVALID_ARG, "batch_write: bad argument");
+	FLUSH(b);
+	TRY(ensure_df(b));
+	if (id == MTFHIP_BUF_DF_DI0 || id == MTFHIP_BUF_DF_DIT) b->lz.df0_stale = b->lz.dft_stale = false;
+	touch(b, id); ++b->lz.epoch;
 	TRY(ensure_buf(b, id));
 	HIP_TRY(hipMemcpyAsync(b->buf[id], src, sizeof(double) * b->per_target[id] * b->B, hipMemcpyHostToDevice, b->ctx->stream));
 	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
@@ -685,12 +746,18 @@ int mtfhip_batch_write(mtfhip_batch *b, int id, const double *src) {
 
 void *mtfhip_batch_device_ptr(mtfhip_batch *b, int id) {
 	if (!b || id < 0 || id >= MTFHIP_BUF_COUNT) return nullptr;
+	/* a raw pointer lets the caller write behind the library's back: no more deferral or host-side caches for this batch */
+	if (lazy_flush(b) != MTFHIP_OK || ensure_df(b) != MTFHIP_OK) return nullptr;
+	b->lz.enabled = false; b->lz.no_cache = true;
 	if (ensure_buf(b, id) != MTFHIP_OK) return nullptr;
 	return b->buf[id];
 }
 
 /* ------------------------------------------------------------------ SSM */
 int mtfhip_ssm_set_corners(mtfhip_batch *b, const double *corners) {
+	FLUSH(b);
+	if (b) ++b->lz.epoch;
+	if (b) { touch_all(b); b->lz.it_epoch = -1; if (b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b)); }
 	if (!b || !corners) return fail(MTFHIP_ERR_INVALID_ARG, "set_corners: NULL argument");
 	const bool hom = b->desc.ssm == MTFHIP_SSM_HOMOGRAPHY;
 	/* normalised grid extents: ProjectiveBase.cc:14 (unit square) ; Affine.cc:56-57 */
@@ -741,6 +808,8 @@ static int apply_states(mtfhip_batch *b) {
 }
 
 int mtfhip_ssm_set_state(mtfhip_batch *b, const double *states) {
+	FLUSH(b);
+	if (b) ++b->lz.epoch;
 	if (!b || !states) return fail(MTFHIP_ERR_INVALID_ARG, "set_state: NULL argument");
 	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "set_state before set_corners");
 	for (int t = 0; t < b->B; ++t) {
@@ -754,6 +823,8 @@ int mtfhip_ssm_set_state(mtfhip_batch *b, const double *states) {
 }
 
 int mtfhip_ssm_compositional_update(mtfhip_batch *b, const double *dps) {
+	FLUSH(b);
+	if (b) ++b->lz.epoch;
 	if (!b || !dps) return fail(MTFHIP_ERR_INVALID_ARG, "compositional_update: NULL argument");
 	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "compositional_update before set_corners");
 	for (int t = 0; t < b->B; ++t) {
@@ -773,6 +844,7 @@ int mtfhip_ssm_compositional_update(mtfhip_batch *b, const double *dps) {
 }
 
 int mtfhip_ssm_invert_state(mtfhip_batch *b, const double *states, double *inv_states) {
+	FLUSH(b);
 	if (!b || !states || !inv_states) return fail(MTFHIP_ERR_INVALID_ARG, "invert_state: NULL argument");
 	for (int t = 0; t < b->B; ++t) {
 		double p[8] = {0}, q[8];
@@ -786,50 +858,77 @@ int mtfhip_ssm_invert_state(mtfhip_batch *b, const double *states, double *inv_s
 	return MTFHIP_OK;
 }
 
-int mtfhip_ssm_update_grad_pts(mtfhip_batch *b, double grad_eps) {
-	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_grad_pts: NULL batch");
-	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "update_grad_pts before set_corners");
+static int do_update_grad_pts(mtfhip_batch *b, double grad_eps) {
 	TRY(ensure_buf(b, MTFHIP_BUF_GRAD_PTS));
 	TimedScope ts(b->ctx, "grad_pts");
 	launch_grad_pts(b->view(), grad_eps, b->ctx->stream);
 	return MTFHIP_OK;
 }
+int mtfhip_ssm_update_grad_pts(mtfhip_batch *b, double grad_eps) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_grad_pts: NULL batch");
+	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "update_grad_pts before set_corners");
+	if (b->lz.enabled && grad_eps == b->desc.grad_eps) {
+		if (b->lz.gp || b->lz.pg) FLUSH(b);
+		b->lz.gp = ++b->lz.seq;
+		return MTFHIP_OK;
+	}
+	FLUSH(b);
+	return do_update_grad_pts(b, grad_eps);
+}
 
+static int do_cmpt_pix_jacobian(mtfhip_batch *b, int variant, int grad_buf, int dst_buf) {
+	TRY(ensure_buf(b, dst_buf));
+	TimedScope ts(b->ctx, "pix_jacobian");
+	launch_pix_jacobian(b->view(), variant, b->buf[grad_buf], b->buf[dst_buf], b->ctx->stream);
+	touch(b, dst_buf);
+	if (dst_buf == MTFHIP_BUF_JT) b->jt_valid = true;
+	if (dst_buf == MTFHIP_BUF_J0) b->j0_is_template = false;
+	return MTFHIP_OK;
+}
 int mtfhip_ssm_cmpt_pix_jacobian(mtfhip_batch *b, int variant, int grad_buf, int dst_buf) {
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_pix_jacobian: NULL batch");
 	if (variant < MTFHIP_JAC_INIT || variant > MTFHIP_JAC_APPROX) return fail(MTFHIP_ERR_INVALID_ARG, "unknown Jacobian variant %d", variant);
 	if (grad_buf != MTFHIP_BUF_DI0_DX && grad_buf != MTFHIP_BUF_DIT_DX) return fail(MTFHIP_ERR_INVALID_ARG, "grad_buf must be DI0_DX or DIT_DX");
 	if (!j_buf_ok(dst_buf)) return fail(MTFHIP_ERR_INVALID_ARG, "dst_buf must be J0, JT or JM");
 	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "cmpt_pix_jacobian before set_corners");
-	TRY(ensure_buf(b, dst_buf));
-	TimedScope ts(b->ctx, "pix_jacobian");
-	launch_pix_jacobian(b->view(), variant, b->buf[grad_buf], b->buf[dst_buf], b->ctx->stream);
-	if (dst_buf == MTFHIP_BUF_JT) b->jt_valid = true;
-	if (dst_buf == MTFHIP_BUF_J0) b->j0_is_template = false;
-	return MTFHIP_OK;
+	if (b->lz.enabled && grad_buf == MTFHIP_BUF_DIT_DX && dst_buf == MTFHIP_BUF_JT &&
+		(variant == MTFHIP_JAC_WARPED || variant == MTFHIP_JAC_INIT)) {
+		if (b->lz.pj || b->lz.jm) FLUSH(b);
+		TRY(ensure_buf(b, dst_buf));
+		b->lz.pj = ++b->lz.seq; b->lz.pj_variant = variant;
+		b->jt_valid = true;
+		return MTFHIP_OK;
+	}
+	FLUSH(b);
+	return do_cmpt_pix_jacobian(b, variant, grad_buf, dst_buf);
 }
 
 int mtfhip_ssm_get_corners(mtfhip_batch *b, double *corners) {
+	FLUSH(b);
 	if (!b || !corners) return fail(MTFHIP_ERR_INVALID_ARG, "get_corners: NULL argument");
 	for (int t = 0; t < b->B; ++t) std::memcpy(corners + 8 * t, b->th[t].corners, sizeof(double) * 8);
 	return MTFHIP_OK;
 }
 int mtfhip_ssm_get_init_corners(mtfhip_batch *b, double *corners) {
+	FLUSH(b);
 	if (!b || !corners) return fail(MTFHIP_ERR_INVALID_ARG, "get_init_corners: NULL argument");
 	for (int t = 0; t < b->B; ++t) std::memcpy(corners + 8 * t, b->th[t].init_corners, sizeof(double) * 8);
 	return MTFHIP_OK;
 }
 int mtfhip_ssm_get_state(mtfhip_batch *b, double *states) {
+	FLUSH(b);
 	if (!b || !states) return fail(MTFHIP_ERR_INVALID_ARG, "get_state: NULL argument");
 	for (int t = 0; t < b->B; ++t) std::memcpy(states + (size_t)t * b->S, b->th[t].state, sizeof(double) * b->S);
 	return MTFHIP_OK;
 }
 int mtfhip_ssm_get_warp(mtfhip_batch *b, double *warps) {
+	FLUSH(b);
 	if (!b || !warps) return fail(MTFHIP_ERR_INVALID_ARG, "get_warp: NULL argument");
 	for (int t = 0; t < b->B; ++t) std::memcpy(warps + 9 * t, b->th[t].warp.m, sizeof(double) * 9);
 	return MTFHIP_OK;
 }
 int mtfhip_ssm_apply_warp_to_corners(mtfhip_batch *b, const double *in_corners, const double *states, double *out_corners) {
+	FLUSH(b);
 	if (!b || !in_corners || !states || !out_corners) return fail(MTFHIP_ERR_INVALID_ARG, "apply_warp_to_corners: NULL argument");
 	for (int t = 0; t < b->B; ++t) {
 		double p[8] = {0};
@@ -850,6 +949,7 @@ int mtfhip_ssm_apply_warp_to_corners(mtfhip_batch *b, const double *in_corners, 
 
 /* ------------------------------------------------------------------ ImageBase */
 int mtfhip_am_initialize_pix_vals(mtfhip_batch *b, const double *pts) {
+	FLUSH(b);
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "initialize_pix_vals: NULL batch");
 	TRY(need_image(b));
 	const double *dp;
@@ -865,15 +965,28 @@ int mtfhip_am_initialize_pix_vals(mtfhip_batch *b, const double *pts) {
 	}
 	return MTFHIP_OK;
 }
-int mtfhip_am_update_pix_vals(mtfhip_batch *b, const double *pts) {
-	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_pix_vals: NULL batch");
+static int do_update_pix_vals(mtfhip_batch *b, const double *pts) {
 	TRY(need_image(b));
+	TRY(ensure_df(b));   /* IT is about to change: gradients skipped by a fused launch are derived from the old IT first */
 	const double *dp;
 	TRY(resolve_pts(b, pts, MTFHIP_BUF_CURR_PTS, 2 * (size_t)b->NP, &dp));
 	TimedScope ts(b->ctx, "sample");
 	launch_sample(b->view(), b->ctx->img, dp, b->buf[MTFHIP_BUF_IT], b->norm_mult, b->norm_add, b->ctx->stream);
+	touch(b, MTFHIP_BUF_IT);
+	b->lz.it_epoch = pts ? -1 : b->lz.epoch;
 	b->it_valid = true;
 	return MTFHIP_OK;
+}
+int mtfhip_am_update_pix_vals(mtfhip_batch *b, const double *pts) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_pix_vals: NULL batch");
+	if (b->lz.enabled && !pts && b->init_pix_vals && b->have_corners && b->ctx->img.data && b->ctx->img.channels == 1) {
+		if (b->lz.pv || b->lz.sim) FLUSH(b);
+		b->lz.pv = ++b->lz.seq;
+		b->it_valid = true;
+		return MTFHIP_OK;
+	}
+	FLUSH(b);
+	return do_update_pix_vals(b, pts);
 }
 static int pix_grad_common(mtfhip_batch *b, const double *pts, bool warped, bool init) {
 	TRY(need_image(b));
@@ -886,6 +999,7 @@ static int pix_grad_common(mtfhip_batch *b, const double *pts, bool warped, bool
 		if (warped) launch_warped_img_grad(b->view(), b->ctx->img, dp, dst, b->desc.grad_eps, b->norm_mult, b->ctx->stream);
 		else launch_img_grad(b->view(), b->ctx->img, dp, dst, b->desc.grad_eps, b->norm_mult, b->ctx->stream);
 	}
+	touch(b, init ? MTFHIP_BUF_DI0_DX : MTFHIP_BUF_DIT_DX);
 	if (init) b->j0_is_template = false;
 	if (init && !b->init_pix_grad) {
 		HIP_TRY(hipMemcpyAsync(b->buf[MTFHIP_BUF_DIT_DX], b->buf[MTFHIP_BUF_DI0_DX], sizeof(double) * 2 * b->N * b->B, hipMemcpyDeviceToDevice, b->ctx->stream));
@@ -896,19 +1010,34 @@ static int pix_grad_common(mtfhip_batch *b, const double *pts, bool warped, bool
 	return MTFHIP_OK;
 }
 int mtfhip_am_initialize_pix_grad(mtfhip_batch *b, const double *pts) {
+	FLUSH(b);
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "initialize_pix_grad: NULL batch");
 	return pix_grad_common(b, pts, false, true);
 }
+static int lazy_record_pix_grad(mtfhip_batch *b, int kind) {
+	if (b->lz.pg || b->lz.pj) FLUSH(b);
+	b->lz.pg = ++b->lz.seq; b->lz.pg_kind = kind;
+	b->dit_valid = true;
+	return MTFHIP_OK;
+}
 int mtfhip_am_update_pix_grad(mtfhip_batch *b, const double *pts) {
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_pix_grad: NULL batch");
+	if (b->lz.enabled && !pts && b->have_corners && b->ctx->img.data && b->ctx->img.channels == 1)
+		return lazy_record_pix_grad(b, 1);
+	FLUSH(b);
 	return pix_grad_common(b, pts, false, false);
 }
 int mtfhip_am_initialize_pix_grad_warped(mtfhip_batch *b, const double *gp) {
+	FLUSH(b);
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "initialize_pix_grad_warped: NULL batch");
 	return pix_grad_common(b, gp, true, true);
 }
 int mtfhip_am_update_pix_grad_warped(mtfhip_batch *b, const double *gp) {
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_pix_grad_warped: NULL batch");
+	/* only after a deferred update_grad_pts: the fused kernel derives the warped gradient points from the current warp */
+	if (b->lz.enabled && !gp && b->lz.gp && b->ctx->img.data && b->ctx->img.channels == 1)
+		return lazy_record_pix_grad(b, 2);
+	FLUSH(b);
 	return pix_grad_common(b, gp, true, false);
 }
 
@@ -1100,6 +1229,7 @@ static int am_supported(mtfhip_batch *b, const char *fn) {
 }
 
 int mtfhip_am_initialize_similarity(mtfhip_batch *b) {
+	FLUSH(b);
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "initialize_similarity: NULL batch");
 	TRY(am_supported(b, "initializeSimilarity"));
 	if (b->desc.am == MTFHIP_AM_NCC) return ncc_initialize_similarity(b);
@@ -1118,6 +1248,7 @@ int mtfhip_am_initialize_similarity(mtfhip_batch *b) {
 	return MTFHIP_OK;
 }
 int mtfhip_am_initialize_grad(mtfhip_batch *b) {
+	FLUSH(b);
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "initialize_grad: NULL batch");
 	TRY(am_supported(b, "initializeGrad"));
 	if (b->desc.am == MTFHIP_AM_MI) {
@@ -1147,13 +1278,26 @@ int mtfhip_am_initialize_grad(mtfhip_batch *b) {
 	return MTFHIP_OK;
 }
 int mtfhip_am_initialize_hess(mtfhip_batch *b) {
+	FLUSH(b);
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "initialize_hess: NULL batch");
 	return am_supported(b, "initializeHess");
 }
+static int do_update_similarity(mtfhip_batch *b, int prereq_only);
 int mtfhip_am_update_similarity(mtfhip_batch *b, int prereq_only) {
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_similarity: NULL batch");
 	TRY(am_supported(b, "updateSimilarity"));
 	if (!b->init_sim) return fail(MTFHIP_ERR_LOGIC, "updateSimilarity before initializeSimilarity");
+	if (b->lz.enabled && b->lz.pv) {   /* only behind a deferred updatePixVals: otherwise nothing to fuse with */
+		if (b->lz.sim || b->lz.cg) FLUSH(b);
+		if (b->lz.pv) {
+			b->lz.sim = ++b->lz.seq; b->lz.sim_need_f = !prereq_only;
+			return MTFHIP_OK;
+		}
+	}
+	FLUSH(b);
+	return do_update_similarity(b, prereq_only);
+}
+static int do_update_similarity(mtfhip_batch *b, int prereq_only) {
 	if (b->desc.am == MTFHIP_AM_NCC) return ncc_update_similarity(b);
 	if (b->desc.am == MTFHIP_AM_MI) {
 		/* MI::updateSimilarity MI.cc:346-382 */
@@ -1166,39 +1310,181 @@ int mtfhip_am_update_similarity(mtfhip_batch *b, int prereq_only) {
 		TimedScope ts(b->ctx, "ssd_residual");
 		launch_ssd_residual(b->view(), b->d_partials, nblk, b->ctx->stream);
 	}
+	b->lz.df0_stale = false;
+	b->lz.df0_it_ver = b->lz.ver[MTFHIP_BUF_IT];
 	if (prereq_only) return MTFHIP_OK;
 	TRY(read_acc(b, nblk));
 	for (int t = 0; t < b->B; ++t) b->th[t].f = -b->h_acc[(size_t)t * ACC_COUNT + ACC_RR] / 2;
 	return MTFHIP_OK;
 }
+static int do_update_curr_grad(mtfhip_batch *b) {
+	if (b->desc.am == MTFHIP_AM_NCC) return ncc_update_grad(b, 1);
+	if (b->desc.am == MTFHIP_AM_MI) return mi_grad(b, 1);
+	if (b->lz.df0_stale) TRY(ensure_df(b));
+	TimedScope ts(b->ctx, "negate");
+	launch_negate(b->buf[MTFHIP_BUF_DF_DI0], b->buf[MTFHIP_BUF_DF_DIT], (size_t)b->N * b->B, b->ctx->stream);
+	b->lz.dft_stale = false;
+	return MTFHIP_OK;
+}
 int mtfhip_am_update_curr_grad(mtfhip_batch *b) {
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_curr_grad: NULL batch");
 	TRY(am_supported(b, "updateCurrGrad"));
-	if (b->desc.am == MTFHIP_AM_NCC) return ncc_update_grad(b, 1);
-	if (b->desc.am == MTFHIP_AM_MI) return mi_grad(b, 1);
-	TimedScope ts(b->ctx, "negate");
-	launch_negate(b->buf[MTFHIP_BUF_DF_DI0], b->buf[MTFHIP_BUF_DF_DIT], (size_t)b->N * b->B, b->ctx->stream);
-	return MTFHIP_OK;
+	if (b->lz.enabled && b->desc.am == MTFHIP_AM_SSD) {
+		if (b->lz.cg) FLUSH(b);
+		b->lz.cg = ++b->lz.seq;
+		return MTFHIP_OK;
+	}
+	FLUSH(b);
+	return do_update_curr_grad(b);
 }
 int mtfhip_am_update_init_grad(mtfhip_batch *b) {
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_init_grad: NULL batch");
 	TRY(am_supported(b, "updateInitGrad"));
+	if (b->desc.am == MTFHIP_AM_SSD) return MTFHIP_OK;   /* SSD::updateInitGrad is empty: df_dI0 is updateSimilarity's residual */
+	FLUSH(b);
 	if (b->desc.am == MTFHIP_AM_NCC) return ncc_update_grad(b, 0);
 	if (b->desc.am == MTFHIP_AM_MI) return mi_grad(b, 0);
 	return MTFHIP_OK;
 }
 int mtfhip_am_get_similarity(mtfhip_batch *b, double *f) {
 	if (!b || !f) return fail(MTFHIP_ERR_INVALID_ARG, "get_similarity: NULL argument");
+	FLUSH(b);
 	for (int t = 0; t < b->B; ++t) f[t] = b->th[t].f;
 	return MTFHIP_OK;
 }
 int mtfhip_am_get_likelihood(mtfhip_batch *b, double *l) {
 	if (!b || !l) return fail(MTFHIP_ERR_INVALID_ARG, "get_likelihood: NULL argument");
+	FLUSH(b);
 	for (int t = 0; t < b->B; ++t) {
 		double f = b->th[t].f;
 		if (b->desc.am == MTFHIP_AM_SSD) l[t] = std::exp(-b->desc.likelihood_alpha * std::sqrt(-f / (double)b->N));
 		else { double d = (1.0 / f) - 1; l[t] = std::exp(-b->desc.likelihood_alpha * d * d); }
 	}
+	return MTFHIP_OK;
+}
+
+/* ---- deferred fusion: replay, refresh, and the fused execution of a recognised call sequence ---- */
+static int pix_grad_common(mtfhip_batch *b, const double *pts, bool warped, bool init);
+/* SSD's DF_DI0 = It - I0 and DF_DIT = -DF_DI0 (SSDBase.cc:75-121) when a fused launch stood in for the calls that write them */
+static int ensure_df(mtfhip_batch *b) {
+	if (!b->lz.df0_stale && !b->lz.dft_stale) return MTFHIP_OK;
+	if (b->lz.df0_stale) {
+		TimedScope ts(b->ctx, "ssd_residual");
+		launch_ssd_residual(b->view(), b->d_partials, simple_blocks_per_target(b->N), b->ctx->stream);
+		b->lz.df0_stale = false;
+	}
+	if (b->lz.dft_stale) {
+		TimedScope ts(b->ctx, "negate");
+		launch_negate(b->buf[MTFHIP_BUF_DF_DI0], b->buf[MTFHIP_BUF_DF_DIT], (size_t)b->N * b->B, b->ctx->stream);
+		b->lz.dft_stale = false;
+	}
+	return MTFHIP_OK;
+}
+/* replays the recorded calls through the un-fused kernels, in the order they were made */
+static int lazy_flush(mtfhip_batch *b) {
+	mtfhip_batch::Lazy &L = b->lz;
+	if (!L.any()) return MTFHIP_OK;
+	struct Op { long seq; int kind; };
+	Op ops[8]; int n = 0;
+	if (L.pv) ops[n++] = {L.pv, 0};
+	if (L.gp) ops[n++] = {L.gp, 1};
+	if (L.pg) ops[n++] = {L.pg, 2};
+	if (L.pj) ops[n++] = {L.pj, 3};
+	if (L.sim) ops[n++] = {L.sim, 4};
+	if (L.cg) ops[n++] = {L.cg, 5};
+	if (L.ig) ops[n++] = {L.ig, 6};
+	if (L.jm) ops[n++] = {L.jm, 7};
+	std::sort(ops, ops + n, [](const Op &x, const Op &y) { return x.seq < y.seq; });
+	const int pg_kind = L.pg_kind, pj_variant = L.pj_variant; const bool need_f = L.sim_need_f;
+	L.pv = L.gp = L.pg = L.pj = L.sim = L.cg = L.ig = L.jm = 0;   /* cleared first: the executors below may flush */
+	for (int i = 0; i < n; ++i) {
+		switch (ops[i].kind) {
+		case 0: TRY(do_update_pix_vals(b, nullptr)); break;
+		case 1: TRY(do_update_grad_pts(b, b->desc.grad_eps)); break;
+		case 2: TRY(pix_grad_common(b, nullptr, pg_kind == 2, false)); break;
+		case 3: TRY(do_cmpt_pix_jacobian(b, pj_variant, MTFHIP_BUF_DIT_DX, MTFHIP_BUF_JT)); break;
+		case 4: TRY(do_update_similarity(b, need_f ? 0 : 1)); break;
+		case 5: TRY(do_update_curr_grad(b)); break;
+		case 6: break;   /* SSD::updateInitGrad is empty (SSDBase.h) */
+		default: TRY(do_mean_jacobian(b)); break;
+		}
+	}
+	return MTFHIP_OK;
+}
+static int fused_args(const mtfhip_batch *b, const mtfhip_sm_desc *sm, FusedArgs &fa);
+enum { LAZY_CURR_JAC = 0, LAZY_DIFF_JAC = 1, LAZY_INIT_JAC = 2 };
+/* `*done` = 1 when the pending calls plus this Jacobian request were served by ONE fused launch (g filled with the AM's
+ * raw Jacobian), 0 when the caller has to flush and take the un-fused route.
+ *   FCLK  NT/FCLK.cc:171-358: updatePixVals, updateSimilarity, updateCurrGrad, pixel gradient + pixel Jacobian, cmptCurrJacobian(Jt)
+ *   ESM   NT/ESM.cc:170-296: ... updateInitGrad, cmptDifferenceOfJacobians(J0, Jt)   (jac_type Original: cmptCurrJacobian(Jm))
+ *   ICLK  NT/ICLK.cc:160-299: updatePixVals, updateSimilarity, updateInitGrad, cmptInitJacobian(J0) */
+static int lazy_try_fused(mtfhip_batch *b, int trig, int j_a, int j_b, double *g, int *done) {
+	*done = 0;
+	mtfhip_batch::Lazy &L = b->lz;
+	if (!L.enabled) return MTFHIP_OK;
+	/* either updatePixVals + updateSimilarity are part of the pending set, or they already ran for this very warp and image */
+	const bool replay = L.pv && L.sim && L.pv < L.sim;
+	const bool current = !L.pv && !L.sim && L.it_epoch == L.epoch && L.df0_it_ver == L.ver[MTFHIP_BUF_IT] && !L.df0_stale;
+	if (!replay && !current) return MTFHIP_OK;
+	if (!b->init_pix_vals || !b->init_sim || !b->have_corners || !b->ctx->img.data || b->ctx->img.channels != 1) return MTFHIP_OK;
+	mtfhip_sm_desc sm;
+	std::memset(&sm, 0, sizeof(sm));
+	sm.materialize = 1; sm.max_iters = 1; sm.chained_warp = 1;
+	bool pixel_chain = false;
+	if (L.pg || L.pj || L.gp) {
+		if (!L.pg || !L.pj || L.pg > L.pj) return MTFHIP_OK;
+		if (L.pg_kind == 1) { if (L.gp || L.pj_variant != MTFHIP_JAC_WARPED) return MTFHIP_OK; }
+		else { if (!L.gp || L.gp > L.pg || L.pj_variant != MTFHIP_JAC_INIT) return MTFHIP_OK; sm.chained_warp = 0; }
+		pixel_chain = true;
+	}
+	if (L.jm && (!pixel_chain || L.jm < L.pj)) return MTFHIP_OK;
+	double gscale = 1.0;
+	if (trig == LAZY_INIT_JAC) {
+		if (pixel_chain || L.jm || j_a != MTFHIP_BUF_J0 || !b->buf[MTFHIP_BUF_J0]) return MTFHIP_OK;
+		sm.sm = MTFHIP_SM_ICLK; sm.hess_type = 0;
+	} else {
+		if (!pixel_chain || !L.cg || L.cg < L.sim) return MTFHIP_OK;   /* (L.sim is 0 when it already ran) */
+		if (trig == LAZY_DIFF_JAC) {
+			if (j_a != MTFHIP_BUF_J0 || j_b != MTFHIP_BUF_JT || !b->buf[MTFHIP_BUF_J0]) return MTFHIP_OK;
+			sm.sm = MTFHIP_SM_ESM; sm.hess_type = L.jm ? 3 : 5;
+		} else if (j_a == MTFHIP_BUF_JT) {
+			sm.sm = MTFHIP_SM_FCLK; sm.hess_type = 2;
+		} else if (j_a == MTFHIP_BUF_JM && L.jm && b->buf[MTFHIP_BUF_J0]) {
+			sm.sm = MTFHIP_SM_ESM; sm.hess_type = 3; gscale = 0.5;   /* df_dIt . (J0 + Jt) / 2, the halving is exact */
+		} else return MTFHIP_OK;
+	}
+	/* gradients a previous fused launch skipped and this one will not overwrite: derive them from the old IT first */
+	if (L.dft_stale && !L.cg) TRY(ensure_df(b));
+	FusedArgs fa;
+	TRY(fused_args(b, &sm, fa));
+	const int nblk = fused_blocks_per_target(b->N, b->B);
+	{
+		TimedScope ts(b->ctx, "fused_lk");
+		launch_fused_ssd(b->view(), b->ctx->img, fa, b->d_partials, nblk, b->ctx->stream);
+	}
+	touch(b, MTFHIP_BUF_IT);
+	b->it_valid = true;
+	L.it_epoch = L.epoch;
+	if (fa.mode != 2) { touch(b, MTFHIP_BUF_DIT_DX); touch(b, MTFHIP_BUF_JT); b->dit_valid = b->jt_valid = true; }
+	const bool want_mean = L.jm != 0;
+	if (replay) L.df0_stale = true;               /* DF_DI0 of the new IT: derived on first use */
+	L.df0_it_ver = L.ver[MTFHIP_BUF_IT];          /* (when IT was current the launch rewrote the same bits) */
+	if (L.cg) L.dft_stale = true;
+	L.pv = L.gp = L.pg = L.pj = L.sim = L.cg = L.ig = L.jm = 0;
+	if (want_mean) TRY(do_mean_jacobian(b));
+	TRY(read_acc(b, nblk));
+	for (int t = 0; t < b->B; ++t) {
+		const double *acc = b->h_acc + (size_t)t * ACC_COUNT;
+		b->th[t].f = -acc[ACC_RR] / 2;
+		for (int s = 0; s < b->S; ++s) g[(size_t)t * b->S + s] = gscale * acc[ACC_G + s];
+	}
+	if (fa.mode != 2 && !L.no_cache) {   /* the Gram matrix the launch accumulated: Jt, or Jm with hess_mean */
+		L.gram_buf = fa.hess_mean ? MTFHIP_BUF_JM : MTFHIP_BUF_JT;
+		L.gram_ver = L.ver[L.gram_buf];
+		L.gram.resize((size_t)36 * b->B);
+		for (int t = 0; t < b->B; ++t) std::memcpy(&L.gram[(size_t)36 * t], b->h_acc + (size_t)t * ACC_COUNT + ACC_H, sizeof(double) * 36);
+	}
+	*done = 1;
 	return MTFHIP_OK;
 }
 
@@ -1227,12 +1513,18 @@ int mtfhip_am_cmpt_init_jacobian(mtfhip_batch *b, int j0_buf, double *g) {
 	if (!b || !g) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_init_jacobian: NULL argument");
 	TRY(am_supported(b, "cmptInitJacobian"));
 	TRY(j_ready(b, j0_buf, "cmptInitJacobian"));
+	{ int done; TRY(lazy_try_fused(b, LAZY_INIT_JAC, j0_buf, -1, g, &done)); if (done) return MTFHIP_OK; }
+	FLUSH(b);
+	if (b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b));
 	return gemv_to_host(b, b->buf[MTFHIP_BUF_DF_DI0], j0_buf, nullptr, -1, 0, g, 0);
 }
 int mtfhip_am_cmpt_curr_jacobian(mtfhip_batch *b, int jt_buf, double *g) {
 	if (!b || !g) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_curr_jacobian: NULL argument");
 	TRY(am_supported(b, "cmptCurrJacobian"));
 	TRY(j_ready(b, jt_buf, "cmptCurrJacobian"));
+	{ int done; TRY(lazy_try_fused(b, LAZY_CURR_JAC, jt_buf, -1, g, &done)); if (done) return MTFHIP_OK; }
+	FLUSH(b);
+	if (b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b));
 	return gemv_to_host(b, b->buf[MTFHIP_BUF_DF_DIT], jt_buf, nullptr, -1, 0, g, 0);
 }
 int mtfhip_am_cmpt_difference_of_jacobians(mtfhip_batch *b, int j0_buf, int jt_buf, double *g) {
@@ -1240,25 +1532,44 @@ int mtfhip_am_cmpt_difference_of_jacobians(mtfhip_batch *b, int j0_buf, int jt_b
 	TRY(am_supported(b, "cmptDifferenceOfJacobians"));
 	TRY(j_ready(b, j0_buf, "cmptDifferenceOfJacobians"));
 	TRY(j_ready(b, jt_buf, "cmptDifferenceOfJacobians"));
+	{ int done; TRY(lazy_try_fused(b, LAZY_DIFF_JAC, j0_buf, jt_buf, g, &done)); if (done) return MTFHIP_OK; }
+	FLUSH(b);
+	if (b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b));
 	if (b->desc.am != MTFHIP_AM_SSD) /* (df_dIt * dIt_dp) - (df_dI0 * dI0_dp), NCC.cc:268-280, AppearanceModel.h:161-164 */
 		return gemv_to_host(b, b->buf[MTFHIP_BUF_DF_DIT], jt_buf, b->buf[MTFHIP_BUF_DF_DI0], j0_buf, 0, g, 1);
 	/* SSD: df_dIt * (dI0_dpssm + dIt_dpssm), SSDBase.cc:186 */
 	return gemv_to_host(b, b->buf[MTFHIP_BUF_DF_DIT], jt_buf, nullptr, j0_buf, 1, g, 0);
 }
+/* J^T J of a pixel Jacobian, from the host-side copy when the buffer has not been written since that copy was made
+ * (the fused launch of this iteration accumulated it; the template's J0 only changes with the template) */
 static int gram_to_host(mtfhip_batch *b, int j_buf, double *H, double scale, bool accumulate) {
-	int nblk = simple_blocks_per_target(b->N);
-	{
-		TimedScope ts(b->ctx, "gram");
-		launch_gram(b->view(), b->buf[j_buf], b->d_partials, nblk, b->ctx->stream);
+	mtfhip_batch::Lazy &L = b->lz;
+	const double *src = nullptr;
+	if (!L.no_cache) {
+		if (j_buf == L.gram_buf && L.gram_ver == L.ver[j_buf] && !L.gram.empty()) src = L.gram.data();
+		else if (j_buf == MTFHIP_BUF_J0 && L.gram0_ver == L.ver[j_buf] && !L.gram0.empty()) src = L.gram0.data();
 	}
-	TRY(read_acc(b, nblk));
+	if (!src) {
+		int nblk = simple_blocks_per_target(b->N);
+		{
+			TimedScope ts(b->ctx, "gram");
+			launch_gram(b->view(), b->buf[j_buf], b->d_partials, nblk, b->ctx->stream);
+		}
+		TRY(read_acc(b, nblk));
+		std::vector<double> &dst = j_buf == MTFHIP_BUF_J0 ? L.gram0 : L.gram;
+		dst.resize((size_t)36 * b->B);
+		for (int t = 0; t < b->B; ++t) std::memcpy(&dst[(size_t)36 * t], b->h_acc + (size_t)t * ACC_COUNT + ACC_H, sizeof(double) * 36);
+		if (j_buf == MTFHIP_BUF_J0) L.gram0_ver = L.ver[j_buf];
+		else { L.gram_buf = j_buf; L.gram_ver = L.ver[j_buf]; }
+		src = dst.data();
+	}
 	const int S = b->S;
 	for (int t = 0; t < b->B; ++t) {
 		int k = 0;
 		for (int a = 0; a < 8; ++a)
 			for (int c = a; c < 8; ++c) {
 				if (a < S && c < S) {
-					double v = scale * b->h_acc[(size_t)t * ACC_COUNT + ACC_H + k];
+					double v = scale * src[(size_t)36 * t + k];
 					double *Ht = H + (size_t)t * S * S;
 					if (accumulate) { Ht[c * S + a] += v; if (a != c) Ht[a * S + c] += v; }
 					else { Ht[c * S + a] = v; Ht[a * S + c] = v; }
@@ -1269,6 +1580,7 @@ static int gram_to_host(mtfhip_batch *b, int j_buf, double *H, double scale, boo
 	return MTFHIP_OK;
 }
 int mtfhip_am_cmpt_init_hessian(mtfhip_batch *b, int j0_buf, double *H) {
+	FLUSH(b);
 	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_init_hessian: NULL argument");
 	TRY(am_supported(b, "cmptInitHessian"));
 	TRY(j_ready(b, j0_buf, "cmptInitHessian"));
@@ -1277,6 +1589,7 @@ int mtfhip_am_cmpt_init_hessian(mtfhip_batch *b, int j0_buf, double *H) {
 	return gram_to_host(b, j0_buf, H, -1.0, false);
 }
 int mtfhip_am_cmpt_curr_hessian(mtfhip_batch *b, int jt_buf, double *H) {
+	FLUSH(b);
 	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_curr_hessian: NULL argument");
 	TRY(am_supported(b, "cmptCurrHessian"));
 	TRY(j_ready(b, jt_buf, "cmptCurrHessian"));
@@ -1285,6 +1598,7 @@ int mtfhip_am_cmpt_curr_hessian(mtfhip_batch *b, int jt_buf, double *H) {
 	return gram_to_host(b, jt_buf, H, -1.0, false);
 }
 int mtfhip_am_cmpt_self_hessian(mtfhip_batch *b, int jt_buf, double *H) {
+	FLUSH(b);
 	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_self_hessian: NULL argument");
 	TRY(am_supported(b, "cmptSelfHessian"));
 	TRY(j_ready(b, jt_buf, "cmptSelfHessian"));
@@ -1293,6 +1607,7 @@ int mtfhip_am_cmpt_self_hessian(mtfhip_batch *b, int jt_buf, double *H) {
 	return gram_to_host(b, jt_buf, H, -1.0, false);
 }
 int mtfhip_am_cmpt_sum_of_hessians(mtfhip_batch *b, int j0_buf, int jt_buf, double *H) {
+	FLUSH(b);
 	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_sum_of_hessians: NULL argument");
 	TRY(am_supported(b, "cmptSumOfHessians"));
 	TRY(j_ready(b, j0_buf, "cmptSumOfHessians"));
@@ -1308,14 +1623,23 @@ int mtfhip_am_cmpt_sum_of_hessians(mtfhip_batch *b, int j0_buf, int jt_buf, doub
 	TRY(gram_to_host(b, j0_buf, H, -1.0, false));
 	return gram_to_host(b, jt_buf, H, -1.0, true);
 }
+static int do_mean_jacobian(mtfhip_batch *b) {
+	TRY(ensure_buf(b, MTFHIP_BUF_JM));
+	TimedScope ts(b->ctx, "mean_jacobian");
+	launch_mean_jacobian(b->view(), b->ctx->stream);
+	touch(b, MTFHIP_BUF_JM);
+	return MTFHIP_OK;
+}
 int mtfhip_sm_mean_jacobian(mtfhip_batch *b) {
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "mean_jacobian: NULL batch");
 	TRY(j_ready(b, MTFHIP_BUF_J0, "mean_jacobian"));
 	TRY(j_ready(b, MTFHIP_BUF_JT, "mean_jacobian"));
-	TRY(ensure_buf(b, MTFHIP_BUF_JM));
-	TimedScope ts(b->ctx, "mean_jacobian");
-	launch_mean_jacobian(b->view(), b->ctx->stream);
-	return MTFHIP_OK;
+	if (b->lz.enabled && b->lz.pj) {
+		if (b->lz.jm) FLUSH(b);
+		if (b->lz.pj) { TRY(ensure_buf(b, MTFHIP_BUF_JM)); b->lz.jm = ++b->lz.seq; return MTFHIP_OK; }
+	}
+	FLUSH(b);
+	return do_mean_jacobian(b);
 }
 
 /* ------------------------------------------------------------------ second order (sec_ord_hess) */
@@ -1323,6 +1647,7 @@ static int hess_buf_ok(int id) { return id == MTFHIP_BUF_D2I0_DX2 || id == MTFHI
 static int d2_buf_ok(int id) { return id == MTFHIP_BUF_D2I0_DP2 || id == MTFHIP_BUF_D2IT_DP2 || id == MTFHIP_BUF_D2IM_DP2; }
 
 int mtfhip_ssm_update_hess_pts(mtfhip_batch *b, double hess_eps) {
+	FLUSH(b);
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_hess_pts: NULL batch");
 	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "update_hess_pts before set_corners");
 	TRY(ensure_buf(b, MTFHIP_BUF_HESS_PTS));
@@ -1362,23 +1687,28 @@ static int pix_hess_common(mtfhip_batch *b, const double *pts, const double *hes
 	return MTFHIP_OK;
 }
 int mtfhip_am_initialize_pix_hess(mtfhip_batch *b, const double *pts) {
+	FLUSH(b);
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "initialize_pix_hess: NULL batch");
 	return pix_hess_common(b, pts, nullptr, false, true);
 }
 int mtfhip_am_update_pix_hess(mtfhip_batch *b, const double *pts) {
+	FLUSH(b);
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_pix_hess: NULL batch");
 	return pix_hess_common(b, pts, nullptr, false, false);
 }
 int mtfhip_am_initialize_pix_hess_warped(mtfhip_batch *b, const double *pts, const double *hess_pts) {
+	FLUSH(b);
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "initialize_pix_hess_warped: NULL batch");
 	return pix_hess_common(b, pts, hess_pts, true, true);
 }
 int mtfhip_am_update_pix_hess_warped(mtfhip_batch *b, const double *pts, const double *hess_pts) {
+	FLUSH(b);
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_pix_hess_warped: NULL batch");
 	return pix_hess_common(b, pts, hess_pts, true, false);
 }
 
 int mtfhip_ssm_cmpt_pix_hessian(mtfhip_batch *b, int variant, int hess_buf, int grad_buf, int dst_buf) {
+	FLUSH(b);
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_pix_hessian: NULL batch");
 	if (variant < MTFHIP_JAC_INIT || variant > MTFHIP_JAC_APPROX) return fail(MTFHIP_ERR_INVALID_ARG, "unknown pixel Hessian variant %d", variant);
 	if (!hess_buf_ok(hess_buf)) return fail(MTFHIP_ERR_INVALID_ARG, "hess_buf must be D2I0_DX2 or D2IT_DX2");
@@ -1397,6 +1727,7 @@ int mtfhip_ssm_cmpt_pix_hessian(mtfhip_batch *b, int variant, int hess_buf, int 
 }
 
 int mtfhip_sm_mean_pix_hessian(mtfhip_batch *b) {
+	FLUSH(b);
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "mean_pix_hessian: NULL batch");
 	if (!b->buf[MTFHIP_BUF_D2I0_DP2] || !b->buf[MTFHIP_BUF_D2IT_DP2]) return fail(MTFHIP_ERR_LOGIC, "mean_pix_hessian: init / curr pixel Hessians not computed");
 	TRY(ensure_buf(b, MTFHIP_BUF_D2IM_DP2));
@@ -1427,16 +1758,22 @@ static int add_second_order(mtfhip_batch *b, int d2a, int d2b, const double *dev
 }
 /* SSDBase.cc:313-343 ; NCC.cc:391-400 ; MI.cc:659-673 */
 int mtfhip_am_cmpt_init_hessian2(mtfhip_batch *b, int j0_buf, int d2_buf, double *H) {
+	FLUSH(b);
+	if (b && b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b));   /* the second-order terms are weighted by df_dI */
 	TRY(mtfhip_am_cmpt_init_hessian(b, j0_buf, H));
 	return add_second_order(b, d2_buf, -1, b->buf[MTFHIP_BUF_DF_DI0], H);
 }
 /* SSDBase.cc:345-375 ; NCC.cc:401-410 ; MI.cc:680-694 */
 int mtfhip_am_cmpt_curr_hessian2(mtfhip_batch *b, int jt_buf, int d2_buf, double *H) {
+	FLUSH(b);
+	if (b && b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b));   /* the second-order terms are weighted by df_dI */
 	TRY(mtfhip_am_cmpt_curr_hessian(b, jt_buf, H));
 	return add_second_order(b, d2_buf, -1, b->buf[MTFHIP_BUF_DF_DIT], H);
 }
 /* SSD: first order only (SSDBase.h:95-98) ; NCC: am_func_not_implemeted (AppearanceModel.h:188-191) ; MI.cc:696-733 */
 int mtfhip_am_cmpt_self_hessian2(mtfhip_batch *b, int jt_buf, int d2_buf, double *H) {
+	FLUSH(b);
+	if (b && b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b));   /* the second-order terms are weighted by df_dI */
 	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_self_hessian (second order): NULL argument");
 	if (b->desc.am == MTFHIP_AM_NCC) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "ncc :: cmptSelfHessian(second order) :: function not implemented yet");
 	TRY(mtfhip_am_cmpt_self_hessian(b, jt_buf, H));
@@ -1450,6 +1787,8 @@ int mtfhip_am_cmpt_self_hessian2(mtfhip_batch *b, int jt_buf, int d2_buf, double
 }
 /* SSDBase.cc:377-415 (both pixel Hessians weighted by df_dI0) ; NCC / MI: generic AppearanceModel.h:209-219 */
 int mtfhip_am_cmpt_sum_of_hessians2(mtfhip_batch *b, int j0_buf, int jt_buf, int d20_buf, int d2t_buf, double *H) {
+	FLUSH(b);
+	if (b && b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b));   /* the second-order terms are weighted by df_dI */
 	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_sum_of_hessians (second order): NULL argument");
 	if (b->desc.am == MTFHIP_AM_SSD) {
 		TRY(mtfhip_am_cmpt_sum_of_hessians(b, j0_buf, jt_buf, H));
@@ -1499,6 +1838,8 @@ static bool invert_definite(int S, const double *H, double *Hinv) {
 }
 
 int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
+	FLUSH(b);
+	if (b) { touch_all(b); b->lz.it_epoch = -1; if (b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b)); }
 	TRY(check_sm(b, sm, "init_template"));
 	TRY(single_channel(b, "init_template"));
 	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "init_template before set_corners");
@@ -1550,6 +1891,8 @@ int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
  * cmptInitPixJacobian on the new grid and, for the Hessian types that use it, the constant self Hessian; ICLK keeps its
  * template Jacobian.  The template (I0, dI0_dx) is kept in every case. */
 int mtfhip_batch_set_region(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm) {
+	FLUSH(b);
+	if (b) { touch_all(b); b->lz.it_epoch = -1; if (b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b)); }
 	TRY(check_sm(b, sm, "set_region"));
 	TRY(single_channel(b, "set_region"));
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "set_region before init_template");
@@ -1640,6 +1983,8 @@ static void assemble(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const doub
 }
 
 int mtfhip_batch_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, double *g, double *H) {
+	FLUSH(b);
+	if (b) { touch_all(b); b->lz.it_epoch = -1; if (b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b)); }
 	TRY(check_sm(b, sm, "iterate"));
 	TRY(single_channel(b, "iterate"));
 	if (!g || !H) return fail(MTFHIP_ERR_INVALID_ARG, "iterate: NULL output");
@@ -1704,6 +2049,7 @@ static int track_chunk(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const Fu
 	return (b->B + n_chunks - 1) / n_chunks;   /* balanced: 100 targets -> 50 + 50, not 65 + 35 */
 }
 int mtfhip_batch_track_targets_per_launch(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
+	FLUSH(b);
 	if (check_sm(b, sm, "track_targets_per_launch") != MTFHIP_OK) return 0;
 	const bool one_launch = sm->sm == MTFHIP_SM_ICLK && (sm->hess_type == 0 || (sm->hess_type == 2 && b->desc.am == MTFHIP_AM_SSD)) &&
 		b->N <= kIclkTrackMaxPix;
@@ -1714,6 +2060,8 @@ int mtfhip_batch_track_targets_per_launch(mtfhip_batch *b, const mtfhip_sm_desc 
 }
 
 int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners) {
+	FLUSH(b);
+	if (b) { touch_all(b); b->lz.it_epoch = -1; if (b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b)); }
 	TRY(check_sm(b, sm, "track"));
 	TRY(single_channel(b, "track"));
 	if (sm->leven_marq) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: Levenberg-Marquardt is only available through iterate + host solve");
@@ -1806,6 +2154,7 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 
 /* ------------------------------------------------------------------ candidate scoring */
 int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int C, double *dev_lik, double *dev_sim) {
+	FLUSH(b);
 	if (!b || !dev_states) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: NULL argument");
 	if (C <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: n_candidates must be positive");
 	if (b->desc.am != MTFHIP_AM_SSD) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "score_candidates: SSD only");
@@ -1841,6 +2190,7 @@ int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int C
 }
 
 int mtfhip_score_candidates(mtfhip_batch *b, const double *states, int C, double *lik, double *sim) {
+	FLUSH(b);
 	if (!b || !states) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: NULL argument");
 	if (C <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: n_candidates must be positive");
 	size_t need = (size_t)C * (b->S + 2);
@@ -1861,6 +2211,7 @@ int mtfhip_score_candidates(mtfhip_batch *b, const double *states, int C, double
 
 /* ------------------------------------------------------------------ NN dataset generation */
 int mtfhip_sample_candidates_dev(mtfhip_batch *b, const double *dev_states, int C, double *dev_features) {
+	FLUSH(b);
 	if (!b || !dev_states || !dev_features) return fail(MTFHIP_ERR_INVALID_ARG, "sample_candidates: NULL argument");
 	if (C <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "sample_candidates: n_samples must be positive");
 	if (b->desc.am == MTFHIP_AM_MI) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "sample_candidates: MI distance features (5 x N B-spline rows) are not available");
@@ -1872,6 +2223,7 @@ int mtfhip_sample_candidates_dev(mtfhip_batch *b, const double *dev_states, int 
 	return MTFHIP_OK;
 }
 int mtfhip_sample_candidates(mtfhip_batch *b, const double *states, int C, double *features) {
+	FLUSH(b);
 	if (!b || !states || !features) return fail(MTFHIP_ERR_INVALID_ARG, "sample_candidates: NULL argument");
 	if (C <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "sample_candidates: n_samples must be positive");
 	double *d_states = nullptr, *d_feat = nullptr;

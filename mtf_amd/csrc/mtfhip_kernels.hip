@@ -1083,6 +1083,23 @@ __device__ __forceinline__ double bspl3_hess(double x) {
 /* the <= 4-bin window of a pixel value: ids [lo, hi] = std_bspl_ids.row((int)v) (MI.cc:114-117), weights
  * w[k], derivative d[k] (already * -hist_norm_mult as MI.cc:229,360) and second derivative h[k] */
 struct BsplWin { int lo, n; double w[4], d[4], h[4]; };
+/* piece F of bSpl3WithGrad / bSpl3Hess, F = 0..3 in the order of the reference's if-chain; F >= 4: outside the support */
+template <int F>
+__device__ __forceinline__ void bspl3_piece(double &val, double &diff, double &hess, double x) {
+	const double k2by3 = 0.66666666666;
+	if constexpr (F == 0) { double t = 2 + x; diff = (t * t) / 2; val = (diff * t) / 3; hess = 2 + x; }
+	else if constexpr (F == 1) { double t = x / 2; val = k2by3 - x * x * (1 + t); diff = -x * (t + x + 2); hess = -(3 * x + 2); }
+	else if constexpr (F == 2) { double t = x / 2; val = k2by3 - x * x * (1 - t); diff = x * (t + x - 2); hess = 3 * x - 2; }
+	else if constexpr (F == 3) { double t = 2 - x; diff = -(t * t) / 2; val = -(diff * t) / 3; hess = 2 - x; }
+	else { val = 0; diff = 0; hess = 0; }
+}
+/* The window's first bin is lo = max(0, fl - 1), so tap k sits at x_k = lo - v + k: in piece k of the spline when
+ * fl >= 1 (x_0 in (-2, -1]) and in piece k + 1 when the window is clamped at bin 0 (fl == 0, x_0 in (-1, 0]) -- the
+ * reference's bSpl3WithGradFast<bspl_id> (histUtils.h:176-204) rests on the same fact.  When every active lane of the
+ * wave is in one of those two regular situations the pieces are evaluated straight-line (both candidates, one select)
+ * instead of walking the four-range if-chain per tap, which diverges across the wave and costs all four pieces anyway.
+ * x_k is accumulated by `diff += 1` exactly like MI.cc:232,359; the additions are exact for fl >= 1, and for fl == 0
+ * x_2 can round onto the closed end of piece 2 only for v = 1 - 2^-53 (one double), where the two pieces agree to 1e-12. */
 __device__ __forceinline__ BsplWin bspl_window(double v, int nb, double norm_mult, bool want_hess) {
 	BsplWin s;
 	const int fl = (int)v;
@@ -1090,6 +1107,29 @@ __device__ __forceinline__ BsplWin bspl_window(double v, int nb, double norm_mul
 	const int hi = min(nb - 1, fl + 2);
 	s.n = hi - s.lo + 1;
 	double diff = s.lo - v;
+	const bool sh = fl < 1;
+	const bool regular = sh ? ((diff > -1) & (diff <= 0)) : ((diff > -2) & (diff <= -1));
+	if (__builtin_amdgcn_ballot_w64(!regular) == 0) {
+		double x[4];
+		x[0] = diff; x[1] = x[0] + 1; x[2] = x[1] + 1; x[3] = x[2] + 1;
+		double v0, d0, h0, v1, d1, h1;
+		bspl3_piece<0>(v0, d0, h0, x[0]); bspl3_piece<1>(v1, d1, h1, x[0]);
+		s.w[0] = sh ? v1 : v0; s.d[0] = sh ? d1 : d0; s.h[0] = sh ? h1 : h0;
+		bspl3_piece<1>(v0, d0, h0, x[1]); bspl3_piece<2>(v1, d1, h1, x[1]);
+		s.w[1] = sh ? v1 : v0; s.d[1] = sh ? d1 : d0; s.h[1] = sh ? h1 : h0;
+		bspl3_piece<2>(v0, d0, h0, x[2]); bspl3_piece<3>(v1, d1, h1, x[2]);
+		s.w[2] = sh ? v1 : v0; s.d[2] = sh ? d1 : d0; s.h[2] = sh ? h1 : h0;
+		bspl3_piece<3>(v0, d0, h0, x[3]);
+		s.w[3] = sh ? 0.0 : v0; s.d[3] = sh ? 0.0 : d0; s.h[3] = sh ? 0.0 : h0;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const bool in = k < s.n;
+			s.w[k] = in ? s.w[k] : 0.0;
+			s.d[k] = in ? s.d[k] * -norm_mult : 0.0;
+			s.h[k] = (in && want_hess) ? norm_mult * s.h[k] : 0.0;
+		}
+		return s;
+	}
 #pragma unroll
 	for (int k = 0; k < 4; ++k) {
 		s.w[k] = 0; s.d[k] = 0; s.h[k] = 0;
@@ -1116,9 +1156,19 @@ __device__ __forceinline__ void lds_add(double *p, double v) {
  * ------------------------------------------------------------------------------------------- */
 constexpr int kMiPairs = (MI_NB * MI_NB + 63) / 64;
 constexpr int kMiRow = 65;
+/* Bin mode on the matrix cores.  Over a 64-pixel chunk the bin-mode sums are small dense products whose K axis is the
+ * pixel: joint(r, c) = sum_p wa[r][p] wb[c][p] is (nb x 64)(64 x nb), and the joint_hist_jacobian block
+ * Q[(r, c)][s] = sum_p (gd[r][p] wd[c][p]) J[p][s] is (nb^2 x 64)(64 x S).  v_mfma_f64_16x16x4_f64 takes K = 4 pixels
+ * per issue; operand layout (checked on gfx950 with tools/mfma_layout_test.hip): lane l supplies A[i = l % 16][k = l / 16]
+ * and B[k = l / 16][j = l % 16] and receives D[i = l / 16 + 4 v][j = l % 16] in element v of its 4-double accumulator.
+ * The operands are read straight from the staged slabs (bin-major rows: lanes of one k read consecutive rows, the same
+ * column -> no bank conflict beyond the 2-way of 64-bit reads).  Dense FP64 products are exact in the same sense as the
+ * VALU path (fused multiply-add per k); only the summation order over pixels differs (4-pixel groups). */
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
 /* histogram of A and joint histogram A x B (MI.cc:222-235 init, :245-252 init joint, :352-367 update,
  * :641-649 self).  Block partial rows: [nb hist | nb*nb joint] */
+template <bool MFMA>
 __global__ __launch_bounds__(kBlock) void k_mi_hist(int N, int nb, double norm_mult, const double *A_all,
 	const double *B_all, double *partials, int nblk, int row_len) {
 	extern __shared__ __attribute__((aligned(16))) double dyn[];
@@ -1130,17 +1180,28 @@ __global__ __launch_bounds__(kBlock) void k_mi_hist(int N, int nb, double norm_m
 	const int t = blockIdx.y;
 	const double *A = A_all + (size_t)t * N, *Bv = B_all + (size_t)t * N;
 	double accj[kMiPairs], acch = 0.0;
+	mfma_d4 cj = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
 	for (int m = 0; m < kMiPairs; ++m) accj[m] = 0.0;
 	int pr[kMiPairs], pc[kMiPairs];
 #pragma unroll
 	for (int m = 0; m < kMiPairs; ++m) { const int q = lane + 64 * m; pr[m] = q < nb * nb ? q / nb : -1; pc[m] = q < nb * nb ? q % nb : 0; }
-	for (int base = (blockIdx.x * (kBlock / 64) + wave) * 64; base < N; base += nblk * kBlock) {
+	/* a wave walks only a handful of chunks and each needs its pixel values first: the next chunk's are requested
+	 * before the current one is processed, otherwise every chunk starts with an exposed HBM round trip */
+	int base = (blockIdx.x * (kBlock / 64) + wave) * 64;
+	double a_nx = 0.0, b_nx = 0.0;
+	if (base + lane < N) { a_nx = A[base + lane]; b_nx = Bv[base + lane]; }
+	for (; base < N; base += nblk * kBlock) {
 		const int i = base + lane;
+		const double a_cur = a_nx, b_cur = b_nx;
+		{
+			const int in = i + nblk * kBlock;
+			if (in < N) { a_nx = A[in]; b_nx = Bv[in]; }
+		}
 		for (int k2 = 0; k2 < nb; ++k2) { wa[k2 * kMiRow + lane] = 0.0; wb[k2 * kMiRow + lane] = 0.0; }
 		if (i < N) {
-			const BsplWin a = bspl_window(A[i], nb, norm_mult, false);
-			const BsplWin b = bspl_window(Bv[i], nb, norm_mult, false);
+			const BsplWin a = bspl_window(a_cur, nb, norm_mult, false);
+			const BsplWin b = bspl_window(b_cur, nb, norm_mult, false);
 			/* static indices only: a runtime-indexed window array would live in scratch memory */
 #pragma unroll
 			for (int r = 0; r < 4; ++r) if (r < a.n) wa[(a.lo + r) * kMiRow + lane] = a.w[r];
@@ -1148,12 +1209,27 @@ __global__ __launch_bounds__(kBlock) void k_mi_hist(int N, int nb, double norm_m
 			for (int c = 0; c < 4; ++c) if (c < b.n) wb[(b.lo + c) * kMiRow + lane] = b.w[c];
 		}
 		__builtin_amdgcn_wave_barrier();
+		if constexpr (MFMA) {
+			/* one 16x16 tile: rows r, columns c; when nb < 16 column nb of B is all ones, so D[r][nb] is the histogram */
+			const int idx = lane & 15, kq = lane >> 4, row = idx < nb ? idx : nb - 1;
+#pragma unroll 4
+			for (int ks = 0; ks < 16; ++ks) {
+				const int p = 4 * ks + kq;
+				const double av = wa[row * kMiRow + p], bv = wb[row * kMiRow + p];
+				cj = __builtin_amdgcn_mfma_f64_16x16x4f64(idx < nb ? av : 0.0, idx < nb ? bv : (idx == nb ? 1.0 : 0.0), cj, 0, 0, 0);
+			}
+			if (nb == 16) {
 #pragma unroll 8
-		for (int p = 0; p < 64; ++p) {
+				for (int p = 0; p < 64; ++p) if (lane < nb) acch += wa[lane * kMiRow + p];
+			}
+		} else {
+#pragma unroll 8
+			for (int p = 0; p < 64; ++p) {
 #pragma unroll
-			for (int m = 0; m < kMiPairs; ++m)
-				if (pr[m] >= 0) accj[m] = fma(wa[pr[m] * kMiRow + p], wb[pc[m] * kMiRow + p], accj[m]);
-			if (lane < nb) acch += wa[lane * kMiRow + p];
+				for (int m = 0; m < kMiPairs; ++m)
+					if (pr[m] >= 0) accj[m] = fma(wa[pr[m] * kMiRow + p], wb[pc[m] * kMiRow + p], accj[m]);
+				if (lane < nb) acch += wa[lane * kMiRow + p];
+			}
 		}
 		__builtin_amdgcn_wave_barrier();
 	}
@@ -1161,10 +1237,21 @@ __global__ __launch_bounds__(kBlock) void k_mi_hist(int N, int nb, double norm_m
 	__syncthreads();
 	double *red = dyn;                                  /* [4][nb + nb*nb], the slabs are free now */
 	const int rl = nb + nb * nb;
-	if (lane < nb) red[wave * rl + lane] = acch;
+	if constexpr (MFMA) {
+		const int j = lane & 15;
 #pragma unroll
-	for (int m = 0; m < kMiPairs; ++m)
-		if (pr[m] >= 0) red[wave * rl + nb + pr[m] * nb + pc[m]] = accj[m];
+		for (int v = 0; v < 4; ++v) {
+			const int i = (lane >> 4) + 4 * v;
+			if (i < nb && j < nb) red[wave * rl + nb + i * nb + j] = cj[v];
+			if (i < nb && j == nb) red[wave * rl + i] = cj[v];
+		}
+		if (nb == 16 && lane < nb) red[wave * rl + lane] = acch;
+	} else {
+		if (lane < nb) red[wave * rl + lane] = acch;
+#pragma unroll
+		for (int m = 0; m < kMiPairs; ++m)
+			if (pr[m] >= 0) red[wave * rl + nb + pr[m] * nb + pc[m]] = accj[m];
+	}
 	__syncthreads();
 	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * row_len;
 	for (int k2 = threadIdx.x; k2 < rl; k2 += kBlock) dst[k2] = (red[k2] + red[rl + k2]) + (red[2 * rl + k2] + red[3 * rl + k2]);
@@ -1266,6 +1353,7 @@ __global__ __launch_bounds__(kBlock) void k_mi_grad(int N, int nb, double norm_m
  *   Hsum  += hess_term(p) * Jrow Jrow^T,  hess_term = sum_r hessA(r) * sum_c matB(c) T(r,c)
  *   Q[row(r,c)] += gradA(r) matB(c) Jrow          row(r,c) = (r,c), or (c,r) when transpose_q (init flavour)
  * Block partial rows: [36 Hsum | nb*nb*S Q] */
+template <bool MFMA>   /* MFMA: nb == 8 (the reference's 8-bin histograms): 64 (r, c) rows = four 16-row tiles */
 __global__ __launch_bounds__(kBlock) void k_mi_hess(int N, int S, int nb, double norm_mult, const double *A_all,
 	const double *B_all, const double *tb_all, int table_off, int transpose_q, const double *J_all,
 	double *partials, int nblk, int row_len) {
@@ -1287,27 +1375,48 @@ __global__ __launch_bounds__(kBlock) void k_mi_hess(int N, int S, int nb, double
 	double acc[36];
 #pragma unroll
 	for (int k2 = 0; k2 < 36; ++k2) acc[k2] = 0.0;
-	double accq[kMiPairs][kMaxS];
-	int pr[kMiPairs], pc[kMiPairs];
+	constexpr int NQ = MFMA ? 1 : kMiPairs;
+	double accq[NQ][kMaxS];
+	int pr[NQ], pc[NQ];
+	mfma_d4 cq[4];
 #pragma unroll
-	for (int m = 0; m < kMiPairs; ++m) {
+	for (int mt = 0; mt < 4; ++mt) cq[mt] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+	for (int m = 0; m < NQ; ++m) {
 		const int q = lane + 64 * m;
 		pr[m] = q < nb * nb ? q / nb : -1; pc[m] = q < nb * nb ? q % nb : 0;
 #pragma unroll
 		for (int s = 0; s < kMaxS; ++s) accq[m][s] = 0.0;
 	}
-	for (int base = (blockIdx.x * (kBlock / 64) + wave) * 64; base < N; base += nblk * kBlock) {
+	/* operands of the next chunk (two pixel values, S Jacobian entries) are requested before the current one is processed */
+	int base = (blockIdx.x * (kBlock / 64) + wave) * 64;
+	double a_nx = 0.0, b_nx = 0.0, row_nx[kMaxS];
+#pragma unroll
+	for (int s = 0; s < kMaxS; ++s) row_nx[s] = 0.0;
+	if (base + lane < N) {
+		a_nx = A[base + lane]; b_nx = Bv[base + lane];
+#pragma unroll
+		for (int s = 0; s < kMaxS; ++s) if (s < S) row_nx[s] = J[(size_t)s * N + base + lane];
+	}
+	for (; base < N; base += nblk * kBlock) {
 		const int i = base + lane;
-		for (int k2 = 0; k2 < nb; ++k2) { gd[k2 * kMiRow + lane] = 0.0; wd[k2 * kMiRow + lane] = 0.0; }
+		const double a_cur = a_nx, b_cur = b_nx;
 		double row[kMaxS];
 #pragma unroll
-		for (int s = 0; s < kMaxS; ++s) row[s] = 0.0;
+		for (int s = 0; s < kMaxS; ++s) row[s] = i < N ? row_nx[s] : 0.0;
+		{
+			const int in = i + nblk * kBlock;
+			if (in < N) {
+				a_nx = A[in]; b_nx = Bv[in];
+#pragma unroll
+				for (int s = 0; s < kMaxS; ++s) if (s < S) row_nx[s] = J[(size_t)s * N + in];
+			}
+		}
+		for (int k2 = 0; k2 < nb; ++k2) { gd[k2 * kMiRow + lane] = 0.0; wd[k2 * kMiRow + lane] = 0.0; }
 		if (i < N) {
 			/* pixel mode: windows, the scalar hess_term and its rank-1 contribution (MI.cc:478-496, 574-583, 620-629) */
-			const BsplWin a = bspl_window(A[i], nb, norm_mult, true);
-			const BsplWin b = bspl_window(Bv[i], nb, norm_mult, false);
-#pragma unroll
-			for (int s = 0; s < kMaxS; ++s) row[s] = s < S ? J[(size_t)s * N + i] : 0.0;
+			const BsplWin a = bspl_window(a_cur, nb, norm_mult, true);
+			const BsplWin b = bspl_window(b_cur, nb, norm_mult, false);
 			double hess_term = 0;
 #pragma unroll
 			for (int r = 0; r < 4; ++r) {
@@ -1333,17 +1442,32 @@ __global__ __launch_bounds__(kBlock) void k_mi_hess(int N, int S, int nb, double
 		for (int s = 0; s < kMaxS; ++s) rw[s * kMiRow + lane] = row[s];
 		__builtin_amdgcn_wave_barrier();
 		/* bin mode: joint_hist_jacobian.row(r, c) += grad(r, p) * mat(c, p) * J.row(p)  (MI.cc:484-486, 576-577, 622-623) */
+		if constexpr (MFMA) {
+			/* tile mt holds rows 16 mt .. 16 mt + 15 = (r, c) with r = 2 mt + i / 8, c = i % 8; columns s (8 of 16 used) */
+			const int idx = lane & 15, kq = lane >> 4, cc = idx & 7, rh = idx >> 3;
+#pragma unroll 2
+			for (int ks = 0; ks < 16; ++ks) {
+				const int p = 4 * ks + kq;
+				const double jv = rw[cc * kMiRow + p];
+				const double bj = idx < kMaxS ? jv : 0.0;
+				const double wc = wd[cc * kMiRow + p];
+#pragma unroll
+				for (int mt = 0; mt < 4; ++mt)
+					cq[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(gd[(2 * mt + rh) * kMiRow + p] * wc, bj, cq[mt], 0, 0, 0);
+			}
+		} else {
 #pragma unroll 4
-		for (int p = 0; p < 64; ++p) {
-			double jr[kMaxS];
+			for (int p = 0; p < 64; ++p) {
+				double jr[kMaxS];
 #pragma unroll
-			for (int s = 0; s < kMaxS; ++s) jr[s] = rw[s * kMiRow + p];
+				for (int s = 0; s < kMaxS; ++s) jr[s] = rw[s * kMiRow + p];
 #pragma unroll
-			for (int m = 0; m < kMiPairs; ++m) {
-				if (pr[m] >= 0) {
-					const double gr = gd[pr[m] * kMiRow + p] * wd[pc[m] * kMiRow + p];
+				for (int m = 0; m < NQ; ++m) {
+					if (pr[m] >= 0) {
+						const double gr = gd[pr[m] * kMiRow + p] * wd[pc[m] * kMiRow + p];
 #pragma unroll
-					for (int s = 0; s < kMaxS; ++s) accq[m][s] = fma(gr, jr[s], accq[m][s]);
+						for (int s = 0; s < kMaxS; ++s) accq[m][s] = fma(gr, jr[s], accq[m][s]);
+					}
 				}
 			}
 		}
@@ -1355,12 +1479,24 @@ __global__ __launch_bounds__(kBlock) void k_mi_hess(int N, int S, int nb, double
 	/* the four waves' Q blocks through the (now free) slabs: [4][nb*nb*S], indexed as the finish expects */
 	double *qred = slabs;
 	const int ql = nb * nb * S;
+	if constexpr (MFMA) {
+		const int sidx = lane & 15;
 #pragma unroll
-	for (int m = 0; m < kMiPairs; ++m) {
-		if (pr[m] >= 0) {
-			const int row_idx = transpose_q ? pc[m] * nb + pr[m] : pr[m] * nb + pc[m];
+		for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-			for (int s = 0; s < kMaxS; ++s) if (s < S) qred[wave * ql + row_idx * S + s] = accq[m][s];
+			for (int v = 0; v < 4; ++v) {
+				const int rowq = 16 * mt + (lane >> 4) + 4 * v, r = rowq >> 3, c = rowq & 7;
+				const int row_idx = transpose_q ? c * nb + r : r * nb + c;
+				if (sidx < S) qred[wave * ql + row_idx * S + sidx] = cq[mt][v];
+			}
+	} else {
+#pragma unroll
+		for (int m = 0; m < NQ; ++m) {
+			if (pr[m] >= 0) {
+				const int row_idx = transpose_q ? pc[m] * nb + pr[m] : pr[m] * nb + pc[m];
+#pragma unroll
+				for (int s = 0; s < kMaxS; ++s) if (s < S) qred[wave * ql + row_idx * S + s] = accq[m][s];
+			}
 		}
 	}
 	__syncthreads();
@@ -2645,7 +2781,9 @@ void launch_mi_hist(const BatchView &bv, int nb, double norm_mult, const double 
 	int nblk, int row_len, hipStream_t st) {
 	/* per-wave staging slabs [64][2 nb]; the same LDS later holds the four waves' [nb + nb^2] rows */
 	const size_t lds = sizeof(double) * std::max<size_t>((size_t)4 * kMiRow * 2 * nb, (size_t)4 * (nb + nb * nb));
-	hipLaunchKernelGGL(k_mi_hist, grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, nb, norm_mult, A, Bv, partials, nblk, row_len);
+	static const bool use_mfma = !(getenv("MTFHIP_MI_MFMA") && atoi(getenv("MTFHIP_MI_MFMA")) == 0);
+	if (use_mfma) hipLaunchKernelGGL(k_mi_hist<true>, grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, nb, norm_mult, A, Bv, partials, nblk, row_len);
+	else hipLaunchKernelGGL(k_mi_hist<false>, grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, nb, norm_mult, A, Bv, partials, nblk, row_len);
 }
 void launch_mi_hist_finish(const BatchView &bv, int nb, double pre_seed, double norm_mult, int mode, int first_init,
 	const double *partials, int nblk, int row_len, double *tb, double *f_out, hipStream_t st) {
@@ -2666,11 +2804,17 @@ void launch_mi_hess(const BatchView &bv, int nb, double norm_mult, const double 
 	const size_t lds = sizeof(double) * (MI_NB * MI_NB + 4 * 36 + slabs);
 	static bool attr_set = false;
 	if (!attr_set) {   /* 16 bins need 82 KB of dynamic LDS; the default cap is 64 KB */
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_mi_hess), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_mi_hess<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_mi_hess<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		attr_set = true;
 	}
-	hipLaunchKernelGGL(k_mi_hess, grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, bv.S, nb, norm_mult, A, Bv, tb, table_off,
-		transpose_q, J, partials, nblk, row_len);
+	static const bool use_mfma = !(getenv("MTFHIP_MI_MFMA") && atoi(getenv("MTFHIP_MI_MFMA")) == 0);
+	if (use_mfma && nb == 8)
+		hipLaunchKernelGGL(k_mi_hess<true>, grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, bv.S, nb, norm_mult, A, Bv, tb, table_off,
+			transpose_q, J, partials, nblk, row_len);
+	else
+		hipLaunchKernelGGL(k_mi_hess<false>, grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, bv.S, nb, norm_mult, A, Bv, tb, table_off,
+			transpose_q, J, partials, nblk, row_len);
 }
 void launch_mi_hess_finish(const BatchView &bv, int nb, const double *partials, int nblk, int row_len, const double *tb,
 	int joint_off, int hist_off, int transpose_q, double *out, hipStream_t st) {

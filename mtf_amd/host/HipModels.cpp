@@ -34,13 +34,20 @@ HipPair::~HipPair() {
 }
 /* the SM owns its N x S Jacobians (SM/include/mtf/SM/ESM.h:40-49) and passes them by reference: the first
  * matrix an SSM writes becomes J0, the second JT, the third JM */
-int HipPair::jacobianBuffer(const MatrixXd &J, bool may_register) {
+/* A pixel Jacobian the SSM writes is given the device matrix that matches the gradient it is built from -- J0 for the
+ * template's gradient, JT for the current one (the library's fused iteration reads / writes exactly those) -- and the
+ * remaining free matrix otherwise; the host-side Eigen matrix is only the key. */
+int HipPair::jacobianBuffer(const MatrixXd &J, bool may_register, int preferred) {
 	auto it = jac_keys.find(J.data());
 	if (it != jac_keys.end()) return it->second;
 	if (!may_register) throw utils::LogicError("pixel Jacobian passed to the AM was not produced by the paired SSM");
 	static const int order[3] = {MTFHIP_BUF_J0, MTFHIP_BUF_JT, MTFHIP_BUF_JM};
-	if (next_jac >= 3) throw utils::LogicError("more than three distinct pixel Jacobians in flight");
-	int id = order[next_jac++];
+	auto taken = [&](int id) { for (auto &kv : jac_keys) if (kv.second == id) return true; return false; };
+	int id = -1;
+	if (preferred >= 0 && !taken(preferred)) id = preferred;
+	for (int k = 0; k < 3 && id < 0; ++k) if (!taken(order[k]) && order[k] != MTFHIP_BUF_JM) id = order[k];
+	if (id < 0 && !taken(MTFHIP_BUF_JM)) id = MTFHIP_BUF_JM;
+	if (id < 0) throw utils::LogicError("more than three distinct pixel Jacobians in flight");
 	jac_keys[J.data()] = id;
 	return id;
 }
@@ -112,9 +119,15 @@ void HipAM::initializeSimilarity() {
 }
 void HipAM::initializeGrad() { HipPair::check(mtfhip_am_initialize_grad(p->b)); }
 void HipAM::initializeHess() { HipPair::check(mtfhip_am_initialize_hess(p->b)); }
+/* The value is fetched when getSimilarity() is called, not here: the library defers the pixel-level calls of an
+ * iteration until something needs a number on the host, and reading f eagerly would cut every iteration in two. */
 void HipAM::updateSimilarity(bool prereq_only) {
 	HipPair::check(mtfhip_am_update_similarity(p->b, prereq_only ? 1 : 0));
-	if (!prereq_only) HipPair::check(mtfhip_am_get_similarity(p->b, &f));
+	if (!prereq_only) f_fresh = false;
+}
+double HipAM::getSimilarity() const {
+	if (!f_fresh) { HipPair::check(mtfhip_am_get_similarity(p->b, &f)); f_fresh = true; }
+	return f;
 }
 void HipAM::updateInitGrad() { HipPair::check(mtfhip_am_update_init_grad(p->b)); }
 void HipAM::updateCurrGrad() { HipPair::check(mtfhip_am_update_curr_grad(p->b)); }
@@ -214,7 +227,8 @@ int HipSSM::gradBuffer(const PixGradT &g) {
 }
 void HipSSM::jac(int variant, MatrixXd &J, const PixGradT &g) {
 	if (J.rows() != p->N || J.cols() != p->S) throw utils::InvalidArgument("pixel Jacobian has invalid size");   /* validate_ssm_jacobian */
-	HipPair::check(mtfhip_ssm_cmpt_pix_jacobian(p->b, variant, gradBuffer(g), p->jacobianBuffer(J, true)));
+	const int gb = gradBuffer(g);
+	HipPair::check(mtfhip_ssm_cmpt_pix_jacobian(p->b, variant, gb, p->jacobianBuffer(J, true, gb == MTFHIP_BUF_DI0_DX ? MTFHIP_BUF_J0 : MTFHIP_BUF_JT)));
 }
 void HipSSM::pixHess(int variant, MatrixXd &D, const PixHessT &h, const PixGradT &g) {
 	if (D.rows() != p->S * p->S || D.cols() != p->N) throw utils::InvalidArgument("pixel Hessian has invalid size");   /* validate_ssm_hessian */

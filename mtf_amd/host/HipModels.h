@@ -36,7 +36,7 @@ struct HipPair {
 		double mi_pre_seed, int mi_pou, int device, void *stream, int n_channels = 1);
 	~HipPair();
 	static void check(int rc);               /* rethrows C-ABI failures as mtf::utils::Exception */
-	int jacobianBuffer(const MatrixXd &J, bool may_register);
+	int jacobianBuffer(const MatrixXd &J, bool may_register, int preferred = -1);
 	int hessianBuffer(const MatrixXd &D, bool may_register);
 };
 
@@ -70,7 +70,7 @@ public:
 	void updatePixHess(const PtsT &curr_pts, const HessPtsT &warped_offset_pts) override;
 	void updatePixHess(const PtsT &curr_pts) override;
 
-	double getSimilarity() const override { return f; }
+	double getSimilarity() const override;
 	double getLikelihood() const override;
 	void initializeSimilarity() override;
 	void initializeGrad() override;
@@ -96,7 +96,8 @@ public:
 private:
 	std::shared_ptr<HipPair> p;
 	ImageView img{nullptr, 0, 0, 0};
-	double f = 0;
+	mutable double f = 0;
+	mutable bool f_fresh = true;
 	PixValT I0, It;
 	PixGradT dI0_dx, dIt_dx;
 	PixHessT d2I0_dx2, d2It_dx2;

@@ -472,3 +472,95 @@ def test_set_region_follows_the_search_method(oracle, gpu_ctx, frame, frame2, sm
         bb.close()
     for x, y in zip(results[0], results[1]):
         assert np.array_equal(x, y)           # rebuilt rows == stored rows, bit for bit
+
+
+def _lazy_batch(gpu_ctx, frame, ssm, res, corners, lazy, monkeypatch):
+    monkeypatch.setenv("MTFHIP_LAZY", "1" if lazy else "0")   # read when the batch is created
+    gpu_ctx.set_image(frame)
+    b = mtf_amd.Batch(gpu_ctx, L.AM_SSD, ssm, res, res, 1)
+    b.set_corners(corners[None])
+    b.initialize_pix_vals(); b.initialize_pix_grad()
+    b.initialize_similarity(); b.initialize_grad(); b.initialize_hess()
+    b.cmpt_pix_jacobian(L.JAC_WARPED, L.BUF_DI0_DX, L.BUF_J0)
+    return b
+
+
+@pytest.mark.parametrize("ssm", [L.SSM_HOMOGRAPHY, L.SSM_AFFINE])
+@pytest.mark.parametrize("flow", ["esm", "esm_original", "fclk", "fclk_unchained", "iclk", "lm", "odd_order"])
+def test_deferred_fusion_equals_call_by_call(gpu_ctx, frame, frame2, ssm, flow, monkeypatch):
+    """The per-function entry points only record the pixel-level calls of an iteration and serve the ESM / FCLK / ICLK
+    sequences with one fused launch (mtfhip_batch::Lazy).  Whatever the call pattern, buffers and results must be those
+    of the call-by-call execution (MTFHIP_LAZY=0): per-pixel arrays bit for bit, the N-wide sums to summation order."""
+    rng = np.random.default_rng(11)
+    corners = synth.square_corners(250, 260, 70) + rng.uniform(-3, 3, size=(2, 4))
+    p = (synth.random_small_homography(rng) if ssm == L.SSM_HOMOGRAPHY else rng.uniform(-1, 1, 6) * [2, 2, .02, .02, .02, .02])
+    S = 8 if ssm == L.SSM_HOMOGRAPHY else 6
+    out = {}
+    for lazy in (0, 1):
+        b = _lazy_batch(gpu_ctx, frame, ssm, 40, corners, lazy, monkeypatch)
+        gpu_ctx.set_image(frame2)
+        gpu_ctx.timing(1); gpu_ctx.timing_reset()
+        res = []
+        state = p.copy()
+        for it in range(3):
+            b.set_state(state[None])
+            b.update_pix_vals()
+            b.update_similarity(False)
+            if flow == "lm":
+                res.append(b.get_similarity().copy())       # Levenberg-Marquardt reads f in the middle of the iteration
+            if flow in ("esm", "esm_original", "lm"):
+                b.update_pix_grad(); b.cmpt_pix_jacobian(L.JAC_WARPED, L.BUF_DIT_DX, L.BUF_JT)
+                if flow == "esm_original": b.mean_jacobian()
+                b.update_curr_grad(); b.update_init_grad()
+                g = b.cmpt_curr_jacobian(L.BUF_JM) if flow == "esm_original" else b.cmpt_difference_of_jacobians()
+                H = b.cmpt_curr_hessian(L.BUF_JM) if flow == "esm_original" else b.cmpt_sum_of_hessians()
+            elif flow == "fclk":
+                b.update_curr_grad()
+                b.update_pix_grad(); b.cmpt_pix_jacobian(L.JAC_WARPED, L.BUF_DIT_DX, L.BUF_JT)
+                g = b.cmpt_curr_jacobian(L.BUF_JT); H = b.cmpt_self_hessian(L.BUF_JT)
+            elif flow == "fclk_unchained":
+                b.update_curr_grad()
+                b.update_grad_pts(); b.update_pix_grad(warped=True); b.cmpt_pix_jacobian(L.JAC_INIT, L.BUF_DIT_DX, L.BUF_JT)
+                g = b.cmpt_curr_jacobian(L.BUF_JT); H = b.cmpt_curr_hessian(L.BUF_JT)
+            elif flow == "iclk":
+                b.update_init_grad()
+                g = b.cmpt_init_jacobian(L.BUF_J0); H = b.cmpt_init_hessian(L.BUF_J0)
+            else:   # a pattern no search method uses: Approx Jacobian, gradient before the sample, results read in between
+                b.update_pix_grad()
+                dit = b.read(L.BUF_DIT_DX).copy()
+                b.cmpt_pix_jacobian(L.JAC_APPROX, L.BUF_DIT_DX, L.BUF_JT)
+                b.update_curr_grad()
+                g = b.cmpt_curr_jacobian(L.BUF_JT); H = b.cmpt_self_hessian(L.BUF_JT)
+                res.append(dit)
+            res += [g.copy(), H.copy(), b.get_similarity().copy()]
+            # everything the interface exposes, read after the fact
+            for buf in (L.BUF_IT, L.BUF_DF_DI0, L.BUF_DF_DIT) + (() if flow == "iclk" else (L.BUF_DIT_DX, L.BUF_JT)):
+                res.append(b.read(buf).copy())
+            if flow == "esm_original": res.append(b.read(L.BUF_JM).copy())
+            state = state + 0.02 * (it + 1) * p
+        _, n_fused = gpu_ctx.timing_get("fused_lk")
+        gpu_ctx.timing(False)
+        out[lazy] = (res, n_fused)
+        b.close()
+    direct, fused = out[0][0], out[1][0]
+    assert out[0][1] == 0
+    assert out[1][1] == (0 if flow == "odd_order" else 3), "the deferred path did not take the fused launch"
+    assert len(direct) == len(fused)
+    for a, c in zip(direct, fused):
+        if a.size <= 64:                       # g, H, f: sums over the pixels
+            np.testing.assert_allclose(c, a, rtol=1e-11, atol=1e-9 * max(1.0, np.abs(a).max()))
+        else:                                  # per-pixel arrays
+            assert np.array_equal(a, c)
+
+
+def test_deferred_calls_survive_an_image_change(gpu_ctx, frame, frame2, monkeypatch):
+    """a recorded updatePixVals refers to the image that was current when it was called"""
+    corners = synth.square_corners(250, 260, 60)
+    vals = {}
+    for lazy in (0, 1):
+        b = _lazy_batch(gpu_ctx, frame, L.SSM_HOMOGRAPHY, 30, corners, lazy, monkeypatch)
+        b.update_pix_vals()                  # deferred ...
+        gpu_ctx.set_image(frame2)            # ... and flushed here, against `frame`
+        vals[lazy] = b.read(L.BUF_IT).copy()
+        b.close()
+    assert np.array_equal(vals[0], vals[1])
