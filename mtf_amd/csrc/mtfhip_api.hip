@@ -234,6 +234,13 @@ struct mtfhip_batch {
 	 * copy (a grid frame used to cost 14 small copies and 4 stream syncs around a 100 us kernel). */
 	char *d_slab = nullptr, *h_stage_a = nullptr, *h_stage_b = nullptr;
 	hipEvent_t ev_a = nullptr, ev_b = nullptr;
+	/* warp + state of every target after setState / compositionalUpdate: one copy from a pinned double buffer, no sync */
+	double *h_wstage[2] = {nullptr, nullptr};
+	hipEvent_t ev_w[2] = {nullptr, nullptr};
+	int wflip = 0;
+	/* CURR_PTS / CURR_HXY / CURR_Z lag behind the warp: only the un-fused kernels read them, so k_apply_warp runs when
+	 * one of those is about to be launched (lazy_flush) or the arrays are read, not after every update */
+	bool pts_stale = false;
 	size_t slab_bytes = 0, slab_dbl_bytes = 0;
 	/* last-workgroup-done epilogue instead of the separate k_finish_track launch: measured equal per step (84.3 vs 84.6 us at
 	 * B = 64, 19.6 vs 19.2 us for one target -- the finish's dependent scalar chain is the cost, not the launch), so off */
@@ -316,14 +323,15 @@ static void fill_stage(const mtfhip_batch *b, char *stage, const double *w0 /* [
 }
 
 static int push_warps(mtfhip_batch *b) {
-	std::vector<double> w(9 * b->B), s(8 * b->B);
+	const int k = b->wflip; b->wflip ^= 1;
+	HIP_TRY(hipEventSynchronize(b->ev_w[k]));   /* the copy that last read this buffer (two updates ago) is long done */
+	double *w = b->h_wstage[k], *s = w + 9 * (size_t)b->B;   /* d_states follows d_warps in the slab */
 	for (int t = 0; t < b->B; ++t) {
 		std::memcpy(&w[9 * t], b->th[t].warp.m, sizeof(double) * 9);
 		std::memcpy(&s[8 * t], b->th[t].state, sizeof(double) * 8);
 	}
-	HIP_TRY(hipMemcpyAsync(b->d_warps, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice, b->ctx->stream));
-	HIP_TRY(hipMemcpyAsync(b->d_states, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice, b->ctx->stream));
-	HIP_TRY(hipStreamSynchronize(b->ctx->stream)); /* the staging vectors die at scope exit */
+	HIP_TRY(hipMemcpyAsync(b->d_warps, w, sizeof(double) * 17 * (size_t)b->B, hipMemcpyHostToDevice, b->ctx->stream));
+	HIP_TRY(hipEventRecord(b->ev_w[k], b->ctx->stream));
 	return MTFHIP_OK;
 }
 
@@ -644,7 +652,10 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 		b->slab_bytes = b->slab_dbl_bytes + 2 * sizeof(int) * Bt;
 		if (hipMalloc(&b->d_slab, b->slab_bytes) != hipSuccess || hipHostMalloc(&b->h_stage_a, b->slab_bytes) != hipSuccess ||
 			hipHostMalloc(&b->h_stage_b, b->slab_bytes) != hipSuccess || hipEventCreateWithFlags(&b->ev_a, hipEventDisableTiming) != hipSuccess ||
-			hipEventCreateWithFlags(&b->ev_b, hipEventDisableTiming) != hipSuccess)
+			hipEventCreateWithFlags(&b->ev_b, hipEventDisableTiming) != hipSuccess ||
+			hipHostMalloc(&b->h_wstage[0], 17 * Bt * d) != hipSuccess || hipHostMalloc(&b->h_wstage[1], 17 * Bt * d) != hipSuccess ||
+			hipEventCreateWithFlags(&b->ev_w[0], hipEventDisableTiming) != hipSuccess ||
+			hipEventCreateWithFlags(&b->ev_w[1], hipEventDisableTiming) != hipSuccess)
 			return cleanup(fail(MTFHIP_ERR_HIP, "allocation of the per-target state slab failed"));
 		double *p = reinterpret_cast<double *>(b->d_slab);
 		b->d_warps = p; b->d_states = p + 9 * Bt; b->d_corners = p + 17 * Bt; b->d_init_corners_hm = p + 25 * Bt;
@@ -704,6 +715,10 @@ void mtfhip_batch_destroy(mtfhip_batch *b) {
 		if (b->h_stage_b) (void)hipHostFree(b->h_stage_b);
 		if (b->ev_a) (void)hipEventDestroy(b->ev_a);
 		if (b->ev_b) (void)hipEventDestroy(b->ev_b);
+		for (int k = 0; k < 2; ++k) {
+			if (b->h_wstage[k]) (void)hipHostFree(b->h_wstage[k]);
+			if (b->ev_w[k]) (void)hipEventDestroy(b->ev_w[k]);
+		}
 	} catch (...) {
 	}
 	delete b;
@@ -796,14 +811,22 @@ int mtfhip_ssm_set_corners(mtfhip_batch *b, const double *corners) {
 		launch_init_grid(b->view(), b->d_w0, b->desc.resx, b->desc.resy, lo_x, lo_y, hi_x, hi_y, hom ? 0 : 1, b->ctx->stream);
 	}
 	b->have_corners = true;
+	b->pts_stale = false;   /* k_init_grid writes the current points too */
 	++b->corners_epoch;
 	return MTFHIP_OK;
 }
 
-static int apply_states(mtfhip_batch *b) {
-	TRY(push_warps(b));
+static int ensure_pts(mtfhip_batch *b) {
+	if (!b->pts_stale) return MTFHIP_OK;
+	b->pts_stale = false;
 	TimedScope ts(b->ctx, "apply_warp");
 	launch_apply_warp(b->view(), b->ctx->stream);
+	return MTFHIP_OK;
+}
+static int apply_states(mtfhip_batch *b) {
+	TRY(push_warps(b));
+	b->pts_stale = true;
+	if (!b->lz.enabled) return ensure_pts(b);
 	return MTFHIP_OK;
 }
 
@@ -844,7 +867,6 @@ int mtfhip_ssm_compositional_update(mtfhip_batch *b, const double *dps) {
 }
 
 int mtfhip_ssm_invert_state(mtfhip_batch *b, const double *states, double *inv_states) {
-	FLUSH(b);
 	if (!b || !states || !inv_states) return fail(MTFHIP_ERR_INVALID_ARG, "invert_state: NULL argument");
 	for (int t = 0; t < b->B; ++t) {
 		double p[8] = {0}, q[8];
@@ -904,31 +926,26 @@ int mtfhip_ssm_cmpt_pix_jacobian(mtfhip_batch *b, int variant, int grad_buf, int
 }
 
 int mtfhip_ssm_get_corners(mtfhip_batch *b, double *corners) {
-	FLUSH(b);
 	if (!b || !corners) return fail(MTFHIP_ERR_INVALID_ARG, "get_corners: NULL argument");
 	for (int t = 0; t < b->B; ++t) std::memcpy(corners + 8 * t, b->th[t].corners, sizeof(double) * 8);
 	return MTFHIP_OK;
 }
 int mtfhip_ssm_get_init_corners(mtfhip_batch *b, double *corners) {
-	FLUSH(b);
 	if (!b || !corners) return fail(MTFHIP_ERR_INVALID_ARG, "get_init_corners: NULL argument");
 	for (int t = 0; t < b->B; ++t) std::memcpy(corners + 8 * t, b->th[t].init_corners, sizeof(double) * 8);
 	return MTFHIP_OK;
 }
 int mtfhip_ssm_get_state(mtfhip_batch *b, double *states) {
-	FLUSH(b);
 	if (!b || !states) return fail(MTFHIP_ERR_INVALID_ARG, "get_state: NULL argument");
 	for (int t = 0; t < b->B; ++t) std::memcpy(states + (size_t)t * b->S, b->th[t].state, sizeof(double) * b->S);
 	return MTFHIP_OK;
 }
 int mtfhip_ssm_get_warp(mtfhip_batch *b, double *warps) {
-	FLUSH(b);
 	if (!b || !warps) return fail(MTFHIP_ERR_INVALID_ARG, "get_warp: NULL argument");
 	for (int t = 0; t < b->B; ++t) std::memcpy(warps + 9 * t, b->th[t].warp.m, sizeof(double) * 9);
 	return MTFHIP_OK;
 }
 int mtfhip_ssm_apply_warp_to_corners(mtfhip_batch *b, const double *in_corners, const double *states, double *out_corners) {
-	FLUSH(b);
 	if (!b || !in_corners || !states || !out_corners) return fail(MTFHIP_ERR_INVALID_ARG, "apply_warp_to_corners: NULL argument");
 	for (int t = 0; t < b->B; ++t) {
 		double p[8] = {0};
@@ -1383,6 +1400,7 @@ static int ensure_df(mtfhip_batch *b) {
 /* replays the recorded calls through the un-fused kernels, in the order they were made */
 static int lazy_flush(mtfhip_batch *b) {
 	mtfhip_batch::Lazy &L = b->lz;
+	TRY(ensure_pts(b));   /* whatever follows a flush may launch a kernel that reads the current points */
 	if (!L.any()) return MTFHIP_OK;
 	struct Op { long seq; int kind; };
 	Op ops[8]; int n = 0;
@@ -2149,6 +2167,7 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 	b->dit_valid = b->jt_valid = fa.materialize && fa.mode != 2;
 	/* curr_pts follow the final warp */
 	launch_apply_warp(b->view(), st);
+	b->pts_stale = false;
 	return MTFHIP_OK;
 }
 
