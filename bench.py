@@ -228,6 +228,38 @@ def secondary_workload(args):
                 O.pf_score(am, ssm, states[:500]); n += 500
             out["cpu_baseline"] = {"value": n / (time.perf_counter() - t0), "unit": "candidates/s", "cores": 1, "kind": "port",
                                    "sample": "%d candidate evaluations of 2500 px" % n}
+    elif args.workload == "dropin":
+        # the literal drop-in boundary: C++ mtf::nt::ESM / FCLK / ICLK driving mtf::hip::HipAM / HipSSM through the
+        # reference's virtuals (one C-ABI call per virtual), ONE target -- configs 1 / 2 as an MTF user runs them
+        from mtf_amd import host
+        H = W = 1024
+        frame0 = synth.make_frame(H, W)
+        frame1 = synth.warp_frame(frame0, synth.random_small_homography(rng, 0.5), (W / 2.0, H / 2.0))
+        res = args.res
+        c = synth.square_corners(W / 2.0, H / 2.0, float(res))
+        sm_kind = {"esm": mtf_amd.SM_ESM, "fclk": mtf_amd.SM_FCLK, "iclk": mtf_amd.SM_ICLK}[args.sm]
+        K = 50
+        tr = host.CppTracker(sm_kind, am=mtf_amd.AM_SSD, resx=res, resy=res, max_iters=K, epsilon=-1.0, leven_marq=0, device=local_rank)
+        tr.set_image(frame0); tr.initialize(c); tr.set_image(frame1)
+
+        def step():
+            tr.set_region(c)
+            tr.update()
+        dt = timed(step)
+        out.update({"metric": "drop-in LK iters/sec, one target, C++ nt::%s + SSD + Homography %dx%d over the AM/SSM virtuals" % (args.sm.upper(), res, res),
+                    "value": K * args.steps * world / dt, "unit": "iters/s", "ms_per_step": dt / args.steps * 1e3, "scaling": "weak",
+                    "config": {"workload": "%d iterations per update(), one C-ABI call per virtual, deferred fusion %s" %
+                                           (K, "off" if os.environ.get("MTFHIP_LAZY") == "0" else "on"), "us_per_iter": dt / (K * args.steps) * 1e6}})
+        if rank == 0 and not args.no_cpu:
+            import oracle_py as O
+            ssm = O.SSM(O.SSM_HOM, res, res); am = O.AM(O.AM_SSD, res, res); am.set_curr_img(frame0)
+            trk = O.Tracker({"esm": O.SM_ESM, "fclk": O.SM_FCLK, "iclk": O.SM_ICLK}[args.sm], am, ssm, leven_marq=0, max_iters=K, epsilon=-1.0)
+            trk.initialize(c); am.set_curr_img(frame1)
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < args.cpu_seconds:
+                ssm.set_corners(c); n += trk.update()
+            out["cpu_baseline"] = {"value": n / (time.perf_counter() - t0), "unit": "iters/s", "cores": 1, "kind": "port",
+                                   "sample": "%d iterations of one %dx%d target" % (n, res, res)}
     else:  # mi
         H = W = 2048
         frame0 = synth.make_frame(H, W)
@@ -264,7 +296,7 @@ def secondary_workload(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="lk", choices=["lk", "grid", "pf", "mi"],
+    ap.add_argument("--workload", default="lk", choices=["lk", "grid", "pf", "mi", "dropin"],
                     help="lk = the headline metric (default); the others are the secondary metrics of BASELINE.md")
     ap.add_argument("--particles", type=int, default=10000)
     ap.add_argument("--grid-iters", type=int, default=10)
