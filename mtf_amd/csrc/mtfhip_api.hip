@@ -186,6 +186,8 @@ struct TimedScope {
 	}
 };
 
+constexpr int kAccRowMax = NCC_ACC_COUNT > ACC_COUNT ? NCC_ACC_COUNT : ACC_COUNT;   /* widest partial / reduced row */
+
 struct TargetHost {
 	M3 warp;
 	double state[8];
@@ -195,6 +197,8 @@ struct TargetHost {
 	/* NCC scalars (AM/src/NCC.cc members) */
 	double I0_mean, It_mean, a, b, c, gmean;
 	double h0[64]; /* constant self Hessian of the template (column-major), set by init_template */
+	/* NCC, fused path: moments of the template's pixel Jacobian (constant while J0 is): sum J0, sum I0 J0, Gram(J0) */
+	double ncc_sj0[8], ncc_i0j0[8], ncc_gram0[36];
 };
 
 struct mtfhip_batch {
@@ -241,6 +245,8 @@ struct mtfhip_batch {
 	/* CURR_PTS / CURR_HXY / CURR_Z lag behind the warp: only the un-fused kernels read them, so k_apply_warp runs when
 	 * one of those is about to be launched (lazy_flush) or the arrays are read, not after every update */
 	bool pts_stale = false;
+	/* NCC: a fused iteration updated the scalars (It_mean, a, b, f) on the host only; the un-fused kernels read d_ncc */
+	bool ncc_host_newer = false;
 	size_t slab_bytes = 0, slab_dbl_bytes = 0;
 	/* last-workgroup-done epilogue instead of the separate k_finish_track launch: measured equal per step (84.3 vs 84.6 us at
 	 * B = 64, 19.6 vs 19.2 us for one target -- the finish's dependent scalar chain is the cost, not the launch), so off */
@@ -664,8 +670,8 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 		(void)hipMemsetAsync(b->d_slab, 0, b->slab_bytes, c->stream);
 	}
 #define ALLOC(ptr, bytes) do { if (hipMalloc(&(ptr), (bytes)) != hipSuccess) return cleanup(fail(MTFHIP_ERR_HIP, "hipMalloc(%zu) failed", (size_t)(bytes))); } while (0)
-	ALLOC(b->d_partials, sizeof(double) * ACC_COUNT * b->nblk_max * n_targets);
-	ALLOC(b->d_acc, sizeof(double) * ACC_COUNT * n_targets);
+	ALLOC(b->d_partials, sizeof(double) * kAccRowMax * b->nblk_max * n_targets);
+	ALLOC(b->d_acc, sizeof(double) * kAccRowMax * n_targets);
 	ALLOC(b->d_scratch_pts, sizeof(double) * 18 * NP * n_targets); /* largest upload: pts (2 NP) + hess_pts (16 NP) */
 	ALLOC(b->d_h0, sizeof(double) * 64 * n_targets);
 	ALLOC(b->d_h0inv, sizeof(double) * 64 * n_targets);
@@ -682,9 +688,9 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 		(void)hipMemsetAsync(b->d_mi_tb, 0, sizeof(double) * MI_SIZE * n_targets, c->stream);
 	}
 #undef ALLOC
-	if (hipHostMalloc(&b->h_acc, sizeof(double) * ACC_COUNT * n_targets) != hipSuccess)
+	if (hipHostMalloc(&b->h_acc, sizeof(double) * kAccRowMax * n_targets) != hipSuccess)
 		return cleanup(fail(MTFHIP_ERR_HIP, "hipHostMalloc failed"));
-	(void)hipMemsetAsync(b->d_partials, 0, sizeof(double) * ACC_COUNT * b->nblk_max * n_targets, c->stream);
+	(void)hipMemsetAsync(b->d_partials, 0, sizeof(double) * kAccRowMax * b->nblk_max * n_targets, c->stream);
 	int r = push_warps(b);
 	if (r) return cleanup(r);
 	{
@@ -1122,6 +1128,7 @@ static int ncc_update_similarity(mtfhip_batch *b) {
 }
 /* NCC::updateCurrGrad / updateInitGrad NCC.cc:163-234 */
 static int ncc_update_grad(mtfhip_batch *b, int curr) {
+	if (b->ncc_host_newer) { TRY(push_ncc(b)); b->ncc_host_newer = false; }
 	int nblk = simple_blocks_per_target(b->N);
 	double *dst = b->buf[curr ? MTFHIP_BUF_DF_DIT : MTFHIP_BUF_DF_DI0];
 	{
@@ -1825,8 +1832,11 @@ static int check_sm(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const char 
 	if (sm->sm < MTFHIP_SM_ESM || sm->sm > MTFHIP_SM_ICLK) return fail(MTFHIP_ERR_INVALID_ARG, "%s: unknown search method %d", fn, sm->sm);
 	int max_h = sm->sm == MTFHIP_SM_ESM ? 5 : 2;
 	if (sm->hess_type < 0 || sm->hess_type > max_h) return fail(MTFHIP_ERR_INVALID_ARG, "%s: hess_type %d invalid for search method %d", fn, sm->hess_type, sm->sm);
-	if (b->desc.am == MTFHIP_AM_NCC && sm->sm == MTFHIP_SM_ICLK && sm->hess_type == 0) return MTFHIP_OK; /* one-launch ICLK */
-	if (b->desc.am != MTFHIP_AM_SSD) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: the fused path supports SSD (all search methods) and NCC with ICLK/InitialSelf; use the per-function entry points", fn);
+	if (b->desc.am == MTFHIP_AM_NCC) {
+		if (sm->sec_ord_hess) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: second-order NCC Hessians go through the per-function entry points", fn);
+		return MTFHIP_OK;
+	}
+	if (b->desc.am != MTFHIP_AM_SSD) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: the fused path supports SSD and NCC; MI uses the per-function entry points", fn);
 	return MTFHIP_OK;
 }
 
@@ -1853,6 +1863,117 @@ static bool invert_definite(int S, const double *H, double *Hinv) {
 	for (int i = 0; i < S; ++i)
 		for (int j = 0; j < S; ++j) Hinv[j * S + i] = A[i][S + j] * sc[i] * sc[j];
 	return true;
+}
+
+/* ---- NCC on the fused path: everything NCC.cc derives from centred vectors, written in raw moments ----
+ * With mt = mean(It), m0 = mean(I0), b = |It - mt|, c = |I0 - m0|, f = a / (b c)  (NCC.cc:124-161) and, for a pixel
+ * Jacobian X with column sums sX, Gram(X), sum It X = itX, sum I0 X = i0X:
+ *   Jc = (X - mean(X)) / b                       G(X)  = -Jc^T Jc            = -(Gram(X) - sX sX^T / N) / b^2
+ *   ut(X) = Jc^T (It - mt) / b = (itX - mt sX) / b^2        u0(X) = Jc^T (I0 - m0) / c = (i0X - m0 sX) / (b c)
+ *   df_dIt . X = u0 - f ut   (NCC.cc:196-234, 252-266)       df_dI0 . X = (b / c) (ut - f u0)   (NCC.cc:163-194, 236-250)
+ *   cmptCurrHessian = f G - ut u0^T - u0 ut^T + 3 ut ut^T   (NCC.cc:304-335)    cmptInitHessian: ... + 3 u0 u0^T (NCC.cc:282-303)
+ *   cmptSelfHessian = G + ut ut^T   (NCC.cc:337-389)
+ * (the reference also subtracts the mean of the gradient vectors, which is zero up to rounding because the centred
+ * vectors sum to zero; it does not survive into the moments).  Moments of the mean Jacobian (J0 + Jt) / 2 are the means of
+ * the moments, except its Gram matrix, which the kernel accumulates itself when hess_mean is set. */
+struct NccX { const double *gram; double s[8], it[8], i0[8]; };
+struct NccScalars { double N, mt, m0, b, b2, c, f; };
+static void ncc_vecs(const NccScalars &q, const NccX &X, int S, double *ut, double *u0) {
+	for (int s = 0; s < S; ++s) {
+		ut[s] = (X.it[s] - q.mt * X.s[s]) / q.b2;
+		u0[s] = (X.i0[s] - q.m0 * X.s[s]) / (q.b * q.c);
+	}
+}
+/* kind 0 init, 1 curr, 2 self; H column-major S x S */
+static void ncc_hess_from_moments(const NccScalars &q, const NccX &X, int S, int kind, double *H) {
+	double ut[8], u0[8];
+	ncc_vecs(q, X, S, ut, u0);
+	for (int r = 0; r < S; ++r)
+		for (int c = 0; c < S; ++c) {
+			const int a = r < c ? r : c, d = r < c ? c : r;
+			const double G = -(X.gram[a * 8 - (a * (a - 1)) / 2 + (d - a)] - X.s[r] * X.s[c] / q.N) / q.b2;
+			double v;
+			if (kind == 2) v = G + ut[r] * ut[c];
+			else v = q.f * G - ut[r] * u0[c] - u0[r] * ut[c] + 3 * (kind == 1 ? ut[r] * ut[c] : u0[r] * u0[c]);
+			H[c * S + r] = v;
+		}
+}
+static NccScalars ncc_scalars(const mtfhip_batch *b, const TargetHost &h, const double *M) {
+	NccScalars q;
+	q.N = (double)b->N; q.mt = M[NCC_IT] / q.N; q.m0 = h.I0_mean; q.c = h.c;
+	const double a = M[NCC_I0IT] - q.N * q.m0 * q.mt;
+	q.b2 = M[NCC_IT2] - q.N * q.mt * q.mt; q.b = std::sqrt(q.b2);
+	q.f = a / (q.b * q.c);
+	return q;
+}
+static void ncc_x(const mtfhip_batch *b, const TargetHost &h, const double *M, int which /* 0 J0, 1 Jt, 2 Jm */, bool gram_is_mean, NccX &X) {
+	const int S = b->S;
+	for (int s = 0; s < 8; ++s) X.s[s] = X.it[s] = X.i0[s] = 0;
+	for (int s = 0; s < S; ++s) {
+		const double s0 = h.ncc_sj0[s], it0 = M[NCC_ITJ0 + s], i00 = h.ncc_i0j0[s];
+		const double st = M[NCC_SJ + s], itt = M[NCC_ITJ + s], i0t = M[NCC_I0J + s];
+		if (which == 0) { X.s[s] = s0; X.it[s] = it0; X.i0[s] = i00; }
+		else if (which == 1) { X.s[s] = st; X.it[s] = itt; X.i0[s] = i0t; }
+		else { X.s[s] = (s0 + st) / 2; X.it[s] = (it0 + itt) / 2; X.i0[s] = (i00 + i0t) / 2; }
+	}
+	X.gram = which == 0 ? h.ncc_gram0 : ((which == 2) == gram_is_mean ? M + NCC_GRAM : nullptr);
+}
+/* one target's reduced moment row -> the SM's f, g, H (before LM damping); NT/ESM.cc:298-377, NT/FCLK.cc:260-288, NT/ICLK.cc:206-251 */
+static int ncc_assemble(const mtfhip_batch *b, const mtfhip_sm_desc *sm, bool hess_mean, const double *M, TargetHost &h,
+	double *f, double *g, double *H) {
+	const int S = b->S;
+	const NccScalars q = ncc_scalars(b, h, M);
+	h.It_mean = q.mt; h.b = q.b; h.a = M[NCC_I0IT] - q.N * q.m0 * q.mt; h.f = q.f;
+	if (f) *f = q.f;
+	NccX X0, Xt, Xm;
+	ncc_x(b, h, M, 0, hess_mean, X0); ncc_x(b, h, M, 1, hess_mean, Xt); ncc_x(b, h, M, 2, hess_mean, Xm);
+	double ut[8], u0[8];
+	auto curr_jac = [&](const NccX &X, double *o) { ncc_vecs(q, X, S, ut, u0); for (int s = 0; s < S; ++s) o[s] = u0[s] - q.f * ut[s]; };
+	auto init_jac = [&](const NccX &X, double *o) { ncc_vecs(q, X, S, ut, u0); for (int s = 0; s < S; ++s) o[s] = (q.b / q.c) * (ut[s] - q.f * u0[s]); };
+	if (sm->sm == MTFHIP_SM_FCLK) curr_jac(Xt, g);
+	else if (sm->sm == MTFHIP_SM_ICLK) init_jac(X0, g);
+	else if (sm->jac_type == 0) curr_jac(Xm, g);
+	else { double gt[8], g0[8]; curr_jac(Xt, gt); init_jac(X0, g0); for (int s = 0; s < S; ++s) g[s] = 0.5 * (gt[s] - g0[s]); }
+	const int ht = sm->hess_type;
+	auto need = [&](const NccX &X) { return X.gram ? MTFHIP_OK : fail(MTFHIP_ERR_LOGIC, "fused NCC: the Gram matrix this Hessian needs was not accumulated"); };
+	if (ht == 0) { std::memcpy(H, h.h0, sizeof(double) * S * S); return MTFHIP_OK; }
+	if (sm->sm == MTFHIP_SM_ICLK) { ncc_hess_from_moments(q, X0, S, 0, H); return MTFHIP_OK; }   /* Std: cmptInitHessian(J0) */
+	if (sm->sm == MTFHIP_SM_FCLK || ht == 1 || ht == 5) { TRY(need(Xt)); ncc_hess_from_moments(q, Xt, S, ht == 1 ? 2 : 1, H); return MTFHIP_OK; }
+	if (ht == 2) {   /* SumOfSelf */
+		TRY(need(Xt)); ncc_hess_from_moments(q, Xt, S, 2, H);
+		for (int k = 0; k < S * S; ++k) H[k] = 0.5 * (H[k] + h.h0[k]);
+		return MTFHIP_OK;
+	}
+	if (ht == 3) { TRY(need(Xm)); ncc_hess_from_moments(q, Xm, S, 1, H); return MTFHIP_OK; }   /* Original: cmptCurrHessian(mean) */
+	/* SumOfStd: (cmptInitHessian(J0) + cmptCurrHessian(Jt)) / 2 */
+	TRY(need(Xt));
+	double Hi[64];
+	ncc_hess_from_moments(q, X0, S, 0, Hi); ncc_hess_from_moments(q, Xt, S, 1, H);
+	for (int k = 0; k < S * S; ++k) H[k] = 0.5 * (H[k] + Hi[k]);
+	return MTFHIP_OK;
+}
+/* sum J0, sum I0 J0 and Gram(J0) of the template (after every change of J0) */
+static int gemv_to_host(mtfhip_batch *b, const double *v1, int j1, const double *v2, int j2, int sum_mode, double *g, int diff);
+static int ncc_template_moments(mtfhip_batch *b) {
+	const int nblk = simple_blocks_per_target(b->N), S = b->S;
+	{
+		TimedScope ts(b->ctx, "ncc_hess");
+		launch_col_sum(b->view(), b->buf[MTFHIP_BUF_J0], b->d_partials, nblk, b->ctx->stream);
+	}
+	TRY(read_acc(b, nblk));
+	for (int t = 0; t < b->B; ++t)
+		for (int s = 0; s < 8; ++s) b->th[t].ncc_sj0[s] = s < S ? b->h_acc[(size_t)t * ACC_COUNT + ACC_G + s] : 0.0;
+	std::vector<double> g((size_t)b->B * S);
+	TRY(gemv_to_host(b, b->buf[MTFHIP_BUF_I0], MTFHIP_BUF_J0, nullptr, -1, 0, g.data(), 0));
+	for (int t = 0; t < b->B; ++t)
+		for (int s = 0; s < 8; ++s) b->th[t].ncc_i0j0[s] = s < S ? g[(size_t)t * S + s] : 0.0;
+	{
+		TimedScope ts(b->ctx, "gram");
+		launch_gram(b->view(), b->buf[MTFHIP_BUF_J0], b->d_partials, nblk, b->ctx->stream);
+	}
+	TRY(read_acc(b, nblk));
+	for (int t = 0; t < b->B; ++t) std::memcpy(b->th[t].ncc_gram0, b->h_acc + (size_t)t * ACC_COUNT + ACC_H, sizeof(double) * 36);
+	return MTFHIP_OK;
 }
 
 int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
@@ -1896,6 +2017,7 @@ int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 			std::fill(hinv.begin() + (size_t)t * 64, hinv.begin() + (size_t)(t + 1) * 64, 0.0); /* flat template: no update */
 	HIP_TRY(hipMemcpyAsync(b->d_h0inv, hinv.data(), sizeof(double) * hinv.size(), hipMemcpyHostToDevice, b->ctx->stream));
 	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	if (b->desc.am == MTFHIP_AM_NCC) TRY(ncc_template_moments(b));
 	b->j0_is_template = true;
 	b->j0_template_corners_epoch = b->corners_epoch;
 	b->j0_variant = sm->chained_warp ? MTFHIP_JAC_WARPED : MTFHIP_JAC_INIT;
@@ -1939,6 +2061,7 @@ int mtfhip_batch_set_region(mtfhip_batch *b, const double *corners, const mtfhip
 		HIP_TRY(hipMemcpyAsync(b->d_h0inv, hinv.data(), sizeof(double) * hinv.size(), hipMemcpyHostToDevice, b->ctx->stream));
 		HIP_TRY(hipStreamSynchronize(b->ctx->stream));
 	}
+	if (b->desc.am == MTFHIP_AM_NCC) TRY(ncc_template_moments(b));
 	b->j0_is_template = true;
 	b->j0_template_corners_epoch = b->corners_epoch;
 	b->j0_variant = MTFHIP_JAC_INIT;
@@ -2018,6 +2141,19 @@ int mtfhip_batch_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, d
 	b->it_valid = fa.materialize;
 	b->dit_valid = fa.materialize && fa.mode != 2;
 	b->jt_valid = fa.materialize && fa.mode != 2;
+	if (b->desc.am == MTFHIP_AM_NCC) {
+		launch_finish_rows(b->d_partials, nblk, NCC_ACC_COUNT, b->d_acc, b->B, b->ctx->stream);
+		HIP_TRY(hipMemcpyAsync(b->h_acc, b->d_acc, sizeof(double) * NCC_ACC_COUNT * b->B, hipMemcpyDeviceToHost, b->ctx->stream));
+		HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+		for (int t = 0; t < b->B; ++t) {
+			double ft;
+			TRY(ncc_assemble(b, sm, fa.hess_mean != 0, b->h_acc + (size_t)t * NCC_ACC_COUNT, b->th[t], &ft, g + (size_t)t * b->S,
+				H + (size_t)t * b->S * b->S));
+			if (f) f[t] = ft;
+		}
+		b->ncc_host_newer = true;
+		return MTFHIP_OK;
+	}
 	const int term = second_order_term(sm);
 	std::vector<double> so;
 	if (term >= 0) {
@@ -2092,7 +2228,7 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 	const bool one_launch = sm->sm == MTFHIP_SM_ICLK && (sm->hess_type == 0 || (sm->hess_type == 2 && b->desc.am == MTFHIP_AM_SSD)) &&
 		b->N <= kIclkTrackMaxPix;
 	if (b->desc.am == MTFHIP_AM_NCC && !one_launch)
-		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: NCC patches larger than %d pixels need the per-function entry points", kIclkTrackMaxPix);
+		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: the device-side loop covers SSD, and NCC with ICLK / InitialSelf on patches of up to %d pixels; use iterate (fused NCC moments + host solve)", kIclkTrackMaxPix);
 	FusedArgs fa;
 	if (!one_launch) TRY(fused_args(b, sm, fa));
 	else { fa.materialize = 0; fa.mode = 2; fa.active = nullptr; fa.done = nullptr; fa.rows_per_block = 1; fa.j0_recompute = 0; }

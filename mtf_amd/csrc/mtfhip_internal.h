@@ -34,6 +34,17 @@ enum {
 	ACC_G2 = 45,          /* 8 : second gemv (ESM generic: df_dI0 * J0) */
 	ACC_COUNT = 56        /* padded so the halving butterfly divides evenly 3 times */
 };
+/* partial / reduced row of the fused NCC iteration: raw moments over the pixels of a target (J = the row the Hessian is
+ * built from -- Jt, or the mean of J0 and Jt for ESM's Original Hessian; the g-type sums always use Jt and J0 themselves) */
+enum {
+	NCC_GRAM = 0,         /* 36: sum J_a J_b, upper triangle as ACC_H */
+	NCC_SJ = 36,          /* 8 : sum Jt */
+	NCC_ITJ = 44,         /* 8 : sum It Jt */
+	NCC_I0J = 52,         /* 8 : sum I0 Jt */
+	NCC_ITJ0 = 60,        /* 8 : sum It J0 */
+	NCC_IT = 68, NCC_IT2 = 69, NCC_I0IT = 70,
+	NCC_ACC_COUNT = 72    /* 72 -> 36 -> 18 -> 9 under the halving butterfly */
+};
 
 constexpr int kBlock = 256;       /* threads per workgroup: 4 wave64 */
 #ifndef MTFHIP_SLOTS
@@ -147,6 +158,7 @@ void launch_mi_hess_finish(const BatchView &bv, int nb, const double *partials, 
 	int joint_off, int hist_off, int transpose_q, double *out, hipStream_t st);
 /* sums partials over blocks: out[B][ACC_COUNT] */
 void launch_finish(double *partials, int nblk, double *out, int B, hipStream_t st);
+void launch_finish_rows(double *partials, int nblk, int row_len, double *out, int B, hipStream_t st);
 /* the fused LK iteration for SSD */
 void launch_fused_ssd(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials,
 	int nblk, hipStream_t st);

@@ -1536,6 +1536,12 @@ __global__ __launch_bounds__(kBlock) void k_mi_hess_finish(int S, int nb, const 
 	}
 }
 
+/* the same for rows of any length (the NCC moment rows) */
+__global__ __launch_bounds__(128) void k_finish_rows(const double *partials, int nblk, int row_len, double *out) {
+	const int t = blockIdx.x, k = threadIdx.x;
+	if (k >= row_len) return;
+	out[(size_t)t * row_len + k] = column_sum(partials + (size_t)t * nblk * row_len + k, nblk, row_len);
+}
 /* fixed-order sum of the per-workgroup rows: out[t][k] = sum_b partials[t][b][k] */
 __global__ __launch_bounds__(64) void k_finish(const double *partials, int nblk, double *out) {
 	const int t = blockIdx.x, k = threadIdx.x;
@@ -1624,10 +1630,16 @@ template <bool COHERENT>
 __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts,
 	const double *partials, int nblk, int t);
 
-template <int SSM, bool CHAINED, int MODE, bool MAT>
-__global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchView bv, ImgView im, FusedArgs fa, double *partials, int nblk) {
+/* AM = MTFHIP_AM_SSD: the residual-weighted sums above.  AM = MTFHIP_AM_NCC: the same pass accumulates the raw moments
+ * NCC's similarity, Jacobians and first-order Hessians are functions of (NCC.cc:124-389 restated in ncc_from_moments,
+ * mtfhip_api.hip) -- Gram(row) | sum Jt | sum It Jt | sum I0 Jt | sum It J0 | sum It, It^2, I0 It -- so an NCC iteration
+ * needs no second pass over the pixels for the means; the partial rows are NCC_ACC_COUNT wide. */
+template <int AM, int SSM, bool CHAINED, int MODE, bool MAT>
+__device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk) {
 	constexpr int S = (SSM == MTFHIP_SSM_HOMOGRAPHY) ? 8 : 6;
-	constexpr int K = 48;
+	constexpr bool NCC = AM == MTFHIP_AM_NCC;
+	constexpr int K = NCC ? NCC_ACC_COUNT : 48;
+	constexpr int ROW_LEN = NCC ? NCC_ACC_COUNT : ACC_COUNT;
 	__shared__ double lds[4 * K];
 	const int t = blockIdx.y;
 	const unsigned N = (unsigned)bv.N;
@@ -1813,7 +1825,11 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 			}
 		}
 		const double r = it - cur.i0;
-		acc[44] = fma(r, r, acc[44]);
+		if constexpr (NCC) {
+			acc[NCC_IT] += it; acc[NCC_IT2] = fma(it, it, acc[NCC_IT2]); acc[NCC_I0IT] = fma(cur.i0, it, acc[NCC_I0IT]);
+		} else {
+			acc[44] = fma(r, r, acc[44]);
+		}
 		if constexpr (MAT) st_off<double>(It, o8, it);
 
 		double row[8];
@@ -1884,7 +1900,26 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 				for (int s = 0; s < S; ++s) r0[s] = cur.j0[s];
 			}
 		}
-		if constexpr (MODE == 0) {
+		if constexpr (NCC) {
+			if constexpr (MODE != 2) {
+#pragma unroll
+				for (int s = 0; s < S; ++s) {
+					acc[NCC_SJ + s] += row[s];
+					acc[NCC_ITJ + s] = fma(it, row[s], acc[NCC_ITJ + s]);
+					acc[NCC_I0J + s] = fma(cur.i0, row[s], acc[NCC_I0J + s]);
+				}
+			}
+			if constexpr (MODE != 0) {
+#pragma unroll
+				for (int s = 0; s < S; ++s) acc[NCC_ITJ0 + s] = fma(it, r0[s], acc[NCC_ITJ0 + s]);
+			}
+			if constexpr (MODE == 1) {
+				if (fa.hess_mean) {
+#pragma unroll
+					for (int s = 0; s < S; ++s) row[s] = (r0[s] + row[s]) / 2.0;
+				}
+			}
+		} else if constexpr (MODE == 0) {
 			const double v = -r;
 #pragma unroll
 			for (int s = 0; s < S; ++s) acc[36 + s] = fma(v, row[s], acc[36 + s]);
@@ -1964,8 +1999,8 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 		if (unit_z) run_rows(std::true_type{}, std::false_type{}); else run_rows(std::false_type{}, std::false_type{});
 	}
 	if (!live) return;
-	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * ACC_COUNT;
-	if (!fa.done) { block_reduce_store<K>(acc, dst, lds); return; }
+	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * ROW_LEN;
+	if (NCC || !fa.done) { block_reduce_store<K>(acc, dst, lds); return; }
 	/* Last-workgroup-done epilogue.  The only data that crosses workgroups inside the launch are the partial rows and
 	 * the arrival counter; both are accessed with agent-scope (sc1) atomics, which are performed at the device
 	 * coherence point, so no L2 write-back / invalidate is needed (a __threadfence() per workgroup flushes the whole
@@ -1980,6 +2015,14 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 		finish_track_body<true>(bv, fa.sm, fa.ts, partials, nblk, t);
 		if (threadIdx.x == 0) __hip_atomic_store(&fa.done[t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
+}
+template <int SSM, bool CHAINED, int MODE, bool MAT>
+__global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchView bv, ImgView im, FusedArgs fa, double *partials, int nblk) {
+	fused_lk_body<MTFHIP_AM_SSD, SSM, CHAINED, MODE, MAT>(bv, im, fa, partials, nblk);
+}
+template <int SSM, bool CHAINED, int MODE, bool MAT>
+__global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ncc(BatchView bv, ImgView im, FusedArgs fa, double *partials, int nblk) {
+	fused_lk_body<MTFHIP_AM_NCC, SSM, CHAINED, MODE, MAT>(bv, im, fa, partials, nblk);
 }
 
 /* ===================================================================== */
@@ -2822,6 +2865,9 @@ void launch_mi_hess_finish(const BatchView &bv, int nb, const double *partials, 
 	hipLaunchKernelGGL(k_mi_hess_finish, dim3(bv.B), dim3(kBlock), lds, st, bv.S, nb, partials, nblk, row_len, tb, joint_off,
 		hist_off, transpose_q, out);
 }
+void launch_finish_rows(double *partials, int nblk, int row_len, double *out, int B, hipStream_t st) {
+	hipLaunchKernelGGL(k_finish_rows, dim3(B), dim3(128), 0, st, partials, nblk, row_len, out);
+}
 void launch_finish(double *partials, int nblk, double *out, int B, hipStream_t st) {
 	hipLaunchKernelGGL(k_finish, dim3(B), dim3(64), 0, st, partials, nblk, out);
 }
@@ -2830,6 +2876,13 @@ template <int SSM, bool CHAINED, int MODE>
 static void launch_fused_mat(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk,
 	hipStream_t st) {
 	dim3 g = grid2(nblk, bv.B);
+	if (bv.am == MTFHIP_AM_NCC) {
+		if (fa.materialize)
+			hipLaunchKernelGGL((k_fused_ncc<SSM, CHAINED, MODE, true>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
+		else
+			hipLaunchKernelGGL((k_fused_ncc<SSM, CHAINED, MODE, false>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
+		return;
+	}
 	if (fa.materialize)
 		hipLaunchKernelGGL((k_fused_ssd<SSM, CHAINED, MODE, true>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
 	else

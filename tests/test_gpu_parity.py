@@ -159,10 +159,39 @@ def _case_id(c):
     return "sm%d-ssm%d-res%d-%s" % (c[0], c[1], c[2], "_".join("%s%s" % kv for kv in c[3].items()))
 
 
+NCC_CASES = [
+    # the fused kernel accumulates raw moments for NCC; f, g and every first-order Hessian type are assembled from them
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, 50, dict()),                                  # DiffOfJacs + SumOfSelf (class defaults)
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, 40, dict(jac_type=0, hess_type=3)),           # Original + Original (mean Jacobian)
+    (L.SM_ESM, L.SSM_AFFINE, 40, dict(hess_type=4, chained_warp=0)),           # SumOfStd
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, 40, dict(hess_type=5, jac_type=0)),           # Original Jacobian + Std Hessian
+    (L.SM_ESM, L.SSM_AFFINE, 40, dict(hess_type=1)),
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, 40, dict(hess_type=0)),
+    (L.SM_FCLK, L.SSM_HOMOGRAPHY, 60, dict()),                                 # CurrentSelf
+    (L.SM_FCLK, L.SSM_AFFINE, 50, dict(hess_type=2, chained_warp=0)),
+    (L.SM_FCLK, L.SSM_HOMOGRAPHY, 40, dict(hess_type=0)),
+    (L.SM_ICLK, L.SSM_HOMOGRAPHY, 50, dict()),
+    (L.SM_ICLK, L.SSM_AFFINE, 25, dict(hess_type=2)),                          # Std: cmptInitHessian depends on the frame
+]
+
+
+@pytest.mark.parametrize("grid", ["oracle_grid", "device_grid"])
+@pytest.mark.parametrize("materialize", [1, 0])
+@pytest.mark.parametrize("case", NCC_CASES, ids=_case_id)
+def test_fused_ncc_iterations_follow_oracle(oracle, gpu_ctx, frame, case, materialize, grid):
+    """NCC through the fused kernel (k_fused_ncc: one pass, raw moments) against the oracle's nt:: trackers, iteration by
+    iteration, as test_fused_iterations_follow_oracle does for SSD."""
+    _fused_follow(oracle, gpu_ctx, frame, L.AM_NCC, case, materialize, grid)
+
+
 @pytest.mark.parametrize("grid", ["oracle_grid", "device_grid"])
 @pytest.mark.parametrize("materialize", [1, 0])
 @pytest.mark.parametrize("case", SM_CASES, ids=_case_id)
 def test_fused_iterations_follow_oracle(oracle, gpu_ctx, frame, case, materialize, grid):
+    _fused_follow(oracle, gpu_ctx, frame, L.AM_SSD, case, materialize, grid)
+
+
+def _fused_follow(oracle, gpu_ctx, frame, am, case, materialize, grid):
     """Drive the SM loop on the host exactly as the reference does (solve + compositional update on the
     CPU), with the device producing f, g, H per iteration; compare every iteration with the oracle's
     trace of nt::ESM / nt::FCLK / nt::ICLK::update.
@@ -183,7 +212,8 @@ def test_fused_iterations_follow_oracle(oracle, gpu_ctx, frame, case, materializ
 
     params = dict(leven_marq=0, max_iters=8)
     params.update(extra)
-    o_am, o_ssm, b = make_pair(oracle, gpu_ctx, frame, L.AM_SSD, ssm, res, corners)
+    o_am, o_ssm, b = make_pair(oracle, gpu_ctx, frame, am, ssm, res, corners)
+    ncc = am == L.AM_NCC
     if grid == "oracle_grid":
         hm = o_ssm.get("init_pts_hm").reshape(-1, 3)
         b.write(L.BUF_INIT_PTS, o_ssm.get("init_pts").reshape(1, -1, 2).transpose(0, 2, 1))
@@ -204,15 +234,16 @@ def test_fused_iterations_follow_oracle(oracle, gpu_ctx, frame, case, materializ
     for it, rec in enumerate(trace):
         f, g, H = b.iterate(sm)
         dp = -oracle.colpiv_qr_solve(H[0], g[0])
+        # scale of g: Cauchy-Schwarz ||J|| ||r|| for SSD; for NCC the gradient vectors have norm <= 2 / b, so ||Jc|| ~ sqrt(|tr H|)
+        g_scale = np.sqrt(abs(np.trace(rec["H"]))) * (1.0 if ncc else np.sqrt(abs(2 * rec["f"])))
         if tight:
             assert rel(f[0], rec["f"]) < 1e-12, it
             assert rel(H[0], rec["H"]) < 1e-9, it
-            assert np.linalg.norm(g[0] - rec["g"]) < 1e-10 * max(np.linalg.norm(rec["g"]), np.sqrt(abs(np.trace(rec["H"])) * abs(2 * rec["f"]))), it
+            assert np.linalg.norm(g[0] - rec["g"]) < 1e-10 * max(np.linalg.norm(rec["g"]), g_scale), it
             assert rel(dp, rec["dp"]) < 1e-6 or np.abs(dp - rec["dp"]).max() < 1e-12, it
         else:
             assert rel(f[0], rec["f"]) < 1e-8, it
             assert rel(H[0], rec["H"]) < 1e-5, it
-            g_scale = np.sqrt(abs(np.trace(rec["H"])) * abs(2 * rec["f"]))
             assert np.linalg.norm(g[0] - rec["g"]) < 1e-5 * max(np.linalg.norm(rec["g"]), g_scale), it
             c_gpu = b.apply_warp_to_corners(corners[None], dp[None])[0]
             c_ref = b.apply_warp_to_corners(corners[None], rec["dp"][None])[0]
