@@ -286,6 +286,9 @@ struct mtfhip_batch {
 		 * updateSimilarity un-fused; the fused launch may still serve the rest when IT and DF_DI0 are known to belong to
 		 * the current warp and image (it recomputes the same IT bits): epoch counts warp / image changes */
 		long epoch = 0, it_epoch = -1, df0_it_ver = -1;
+		/* NCC: the moment rows of the last fused launch ([B][NCC_ACC_COUNT]); Hessian requests are answered from them while
+		 * IT and the Jacobian they were taken from are unchanged.  ncc_tm_ver: J0 version of the template moments. */
+		std::vector<double> ncc_M; bool ncc_M_mean = false; long ncc_M_it = -1, ncc_M_jt = -1, ncc_M_jm = -1, ncc_tm_ver = -1;
 		/* Gram matrices that are already on the host: [B][36] upper triangles, valid while version matches */
 		long ver[MTFHIP_BUF_COUNT] = {0};
 		int gram_buf = -1; long gram_ver = -1; std::vector<double> gram;
@@ -695,7 +698,7 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 	if (r) return cleanup(r);
 	{
 		const char *lazy_env = std::getenv("MTFHIP_LAZY");
-		b->lz.enabled = d->am == MTFHIP_AM_SSD && b->C == 1 && !(lazy_env && lazy_env[0] == '0');
+		b->lz.enabled = (d->am == MTFHIP_AM_SSD || d->am == MTFHIP_AM_NCC) && b->C == 1 && !(lazy_env && lazy_env[0] == '0');
 	}
 	c->batches.push_back(b);
 	*out = b;
@@ -778,7 +781,7 @@ void *mtfhip_batch_device_ptr(mtfhip_batch *b, int id) {
 int mtfhip_ssm_set_corners(mtfhip_batch *b, const double *corners) {
 	FLUSH(b);
 	if (b) ++b->lz.epoch;
-	if (b) { touch_all(b); b->lz.it_epoch = -1; if (b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b)); }
+	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
 	if (!b || !corners) return fail(MTFHIP_ERR_INVALID_ARG, "set_corners: NULL argument");
 	const bool hom = b->desc.ssm == MTFHIP_SSM_HOMOGRAPHY;
 	/* normalised grid extents: ProjectiveBase.cc:14 (unit square) ; Affine.cc:56-57 */
@@ -1144,7 +1147,10 @@ static int ncc_update_grad(mtfhip_batch *b, int curr) {
 }
 /* NCC::cmptInitHessian / cmptCurrHessian / cmptSelfHessian NCC.cc:282-389 (fast_hess = 0);
  * kind 0 init, 1 curr, 2 self.  H is column-major S x S per target. */
+static int ncc_hessian_from_cache(mtfhip_batch *b, int j_buf, int kind, double *H);
 static int ncc_hessian(mtfhip_batch *b, int j_buf, int kind, double *H) {
+	if (ncc_hessian_from_cache(b, j_buf, kind, H)) return MTFHIP_OK;
+	if (b->ncc_host_newer) { TRY(push_ncc(b)); b->ncc_host_newer = false; }
 	const int S = b->S;
 	int nblk = simple_blocks_per_target(b->N);
 	{
@@ -1322,7 +1328,7 @@ int mtfhip_am_update_similarity(mtfhip_batch *b, int prereq_only) {
 	return do_update_similarity(b, prereq_only);
 }
 static int do_update_similarity(mtfhip_batch *b, int prereq_only) {
-	if (b->desc.am == MTFHIP_AM_NCC) return ncc_update_similarity(b);
+	if (b->desc.am == MTFHIP_AM_NCC) { int rc = ncc_update_similarity(b); b->lz.df0_it_ver = b->lz.ver[MTFHIP_BUF_IT]; return rc; }
 	if (b->desc.am == MTFHIP_AM_MI) {
 		/* MI::updateSimilarity MI.cc:346-382 */
 		TRY(mi_hist_pass(b, 1, 0));
@@ -1342,7 +1348,7 @@ static int do_update_similarity(mtfhip_batch *b, int prereq_only) {
 	return MTFHIP_OK;
 }
 static int do_update_curr_grad(mtfhip_batch *b) {
-	if (b->desc.am == MTFHIP_AM_NCC) return ncc_update_grad(b, 1);
+	if (b->desc.am == MTFHIP_AM_NCC) { int rc = ncc_update_grad(b, 1); b->lz.dft_stale = false; return rc; }
 	if (b->desc.am == MTFHIP_AM_MI) return mi_grad(b, 1);
 	if (b->lz.df0_stale) TRY(ensure_df(b));
 	TimedScope ts(b->ctx, "negate");
@@ -1353,7 +1359,7 @@ static int do_update_curr_grad(mtfhip_batch *b) {
 int mtfhip_am_update_curr_grad(mtfhip_batch *b) {
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_curr_grad: NULL batch");
 	TRY(am_supported(b, "updateCurrGrad"));
-	if (b->lz.enabled && b->desc.am == MTFHIP_AM_SSD) {
+	if (b->lz.enabled) {
 		if (b->lz.cg) FLUSH(b);
 		b->lz.cg = ++b->lz.seq;
 		return MTFHIP_OK;
@@ -1365,8 +1371,13 @@ int mtfhip_am_update_init_grad(mtfhip_batch *b) {
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_init_grad: NULL batch");
 	TRY(am_supported(b, "updateInitGrad"));
 	if (b->desc.am == MTFHIP_AM_SSD) return MTFHIP_OK;   /* SSD::updateInitGrad is empty: df_dI0 is updateSimilarity's residual */
+	if (b->lz.enabled) {   /* NCC */
+		if (b->lz.ig) FLUSH(b);
+		b->lz.ig = ++b->lz.seq;
+		return MTFHIP_OK;
+	}
 	FLUSH(b);
-	if (b->desc.am == MTFHIP_AM_NCC) return ncc_update_grad(b, 0);
+	if (b->desc.am == MTFHIP_AM_NCC) { int rc = ncc_update_grad(b, 0); b->lz.df0_stale = false; return rc; }
 	if (b->desc.am == MTFHIP_AM_MI) return mi_grad(b, 0);
 	return MTFHIP_OK;
 }
@@ -1392,6 +1403,11 @@ static int pix_grad_common(mtfhip_batch *b, const double *pts, bool warped, bool
 /* SSD's DF_DI0 = It - I0 and DF_DIT = -DF_DI0 (SSDBase.cc:75-121) when a fused launch stood in for the calls that write them */
 static int ensure_df(mtfhip_batch *b) {
 	if (!b->lz.df0_stale && !b->lz.dft_stale) return MTFHIP_OK;
+	if (b->desc.am == MTFHIP_AM_NCC) {   /* NCC.cc:163-234 from the scalars the fused launch left on the host */
+		if (b->lz.dft_stale) { b->lz.dft_stale = false; TRY(ncc_update_grad(b, 1)); }
+		if (b->lz.df0_stale) { b->lz.df0_stale = false; TRY(ncc_update_grad(b, 0)); }
+		return MTFHIP_OK;
+	}
 	if (b->lz.df0_stale) {
 		TimedScope ts(b->ctx, "ssd_residual");
 		launch_ssd_residual(b->view(), b->d_partials, simple_blocks_per_target(b->N), b->ctx->stream);
@@ -1430,13 +1446,17 @@ static int lazy_flush(mtfhip_batch *b) {
 		case 3: TRY(do_cmpt_pix_jacobian(b, pj_variant, MTFHIP_BUF_DIT_DX, MTFHIP_BUF_JT)); break;
 		case 4: TRY(do_update_similarity(b, need_f ? 0 : 1)); break;
 		case 5: TRY(do_update_curr_grad(b)); break;
-		case 6: break;   /* SSD::updateInitGrad is empty (SSDBase.h) */
+		case 6:          /* SSD::updateInitGrad is empty (SSDBase.h) */
+			if (b->desc.am == MTFHIP_AM_NCC) { TRY(ncc_update_grad(b, 0)); L.df0_stale = false; }
+			break;
 		default: TRY(do_mean_jacobian(b)); break;
 		}
 	}
 	return MTFHIP_OK;
 }
 static int fused_args(const mtfhip_batch *b, const mtfhip_sm_desc *sm, FusedArgs &fa);
+static int ncc_template_moments(mtfhip_batch *b);
+static int ncc_lazy_outputs(mtfhip_batch *b, int trig, int j_a, bool hess_mean, double *g);
 enum { LAZY_CURR_JAC = 0, LAZY_DIFF_JAC = 1, LAZY_INIT_JAC = 2 };
 /* `*done` = 1 when the pending calls plus this Jacobian request were served by ONE fused launch (g filled with the AM's
  * raw Jacobian), 0 when the caller has to flush and take the un-fused route.
@@ -1478,8 +1498,14 @@ static int lazy_try_fused(mtfhip_batch *b, int trig, int j_a, int j_b, double *g
 			sm.sm = MTFHIP_SM_ESM; sm.hess_type = 3; gscale = 0.5;   /* df_dIt . (J0 + Jt) / 2, the halving is exact */
 		} else return MTFHIP_OK;
 	}
+	const bool ncc = b->desc.am == MTFHIP_AM_NCC;
+	if (ncc && trig == LAZY_INIT_JAC && !L.ig) return MTFHIP_OK;   /* NCC's df_dI0 comes from updateInitGrad */
 	/* gradients a previous fused launch skipped and this one will not overwrite: derive them from the old IT first */
-	if (L.dft_stale && !L.cg) TRY(ensure_df(b));
+	if ((L.dft_stale && !L.cg) || (ncc && L.df0_stale && !L.ig)) TRY(ensure_df(b));
+	if (ncc && sm.sm != MTFHIP_SM_FCLK && L.ncc_tm_ver != L.ver[MTFHIP_BUF_J0]) {   /* moments of the template's Jacobian */
+		TRY(ncc_template_moments(b));
+		L.ncc_tm_ver = L.ver[MTFHIP_BUF_J0];
+	}
 	FusedArgs fa;
 	TRY(fused_args(b, &sm, fa));
 	const int nblk = fused_blocks_per_target(b->N, b->B);
@@ -1492,11 +1518,21 @@ static int lazy_try_fused(mtfhip_batch *b, int trig, int j_a, int j_b, double *g
 	L.it_epoch = L.epoch;
 	if (fa.mode != 2) { touch(b, MTFHIP_BUF_DIT_DX); touch(b, MTFHIP_BUF_JT); b->dit_valid = b->jt_valid = true; }
 	const bool want_mean = L.jm != 0;
-	if (replay) L.df0_stale = true;               /* DF_DI0 of the new IT: derived on first use */
+	/* the N-sized gradient vectors the consumed calls would have written: SSD's df_dI0 is updateSimilarity's residual,
+	 * NCC's comes from updateInitGrad; df_dIt from updateCurrGrad in both */
+	if (ncc ? L.ig != 0 : replay) L.df0_stale = true;
 	L.df0_it_ver = L.ver[MTFHIP_BUF_IT];          /* (when IT was current the launch rewrote the same bits) */
 	if (L.cg) L.dft_stale = true;
 	L.pv = L.gp = L.pg = L.pj = L.sim = L.cg = L.ig = L.jm = 0;
 	if (want_mean) TRY(do_mean_jacobian(b));
+	if (ncc) {
+		launch_finish_rows(b->d_partials, nblk, NCC_ACC_COUNT, b->d_acc, b->B, b->ctx->stream);
+		HIP_TRY(hipMemcpyAsync(b->h_acc, b->d_acc, sizeof(double) * NCC_ACC_COUNT * b->B, hipMemcpyDeviceToHost, b->ctx->stream));
+		HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+		TRY(ncc_lazy_outputs(b, trig, j_a, fa.hess_mean != 0, g));
+		*done = 1;
+		return MTFHIP_OK;
+	}
 	TRY(read_acc(b, nblk));
 	for (int t = 0; t < b->B; ++t) {
 		const double *acc = b->h_acc + (size_t)t * ACC_COUNT;
@@ -1540,7 +1576,7 @@ int mtfhip_am_cmpt_init_jacobian(mtfhip_batch *b, int j0_buf, double *g) {
 	TRY(j_ready(b, j0_buf, "cmptInitJacobian"));
 	{ int done; TRY(lazy_try_fused(b, LAZY_INIT_JAC, j0_buf, -1, g, &done)); if (done) return MTFHIP_OK; }
 	FLUSH(b);
-	if (b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b));
+	TRY(ensure_df(b));
 	return gemv_to_host(b, b->buf[MTFHIP_BUF_DF_DI0], j0_buf, nullptr, -1, 0, g, 0);
 }
 int mtfhip_am_cmpt_curr_jacobian(mtfhip_batch *b, int jt_buf, double *g) {
@@ -1549,7 +1585,7 @@ int mtfhip_am_cmpt_curr_jacobian(mtfhip_batch *b, int jt_buf, double *g) {
 	TRY(j_ready(b, jt_buf, "cmptCurrJacobian"));
 	{ int done; TRY(lazy_try_fused(b, LAZY_CURR_JAC, jt_buf, -1, g, &done)); if (done) return MTFHIP_OK; }
 	FLUSH(b);
-	if (b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b));
+	TRY(ensure_df(b));
 	return gemv_to_host(b, b->buf[MTFHIP_BUF_DF_DIT], jt_buf, nullptr, -1, 0, g, 0);
 }
 int mtfhip_am_cmpt_difference_of_jacobians(mtfhip_batch *b, int j0_buf, int jt_buf, double *g) {
@@ -1559,7 +1595,7 @@ int mtfhip_am_cmpt_difference_of_jacobians(mtfhip_batch *b, int j0_buf, int jt_b
 	TRY(j_ready(b, jt_buf, "cmptDifferenceOfJacobians"));
 	{ int done; TRY(lazy_try_fused(b, LAZY_DIFF_JAC, j0_buf, jt_buf, g, &done)); if (done) return MTFHIP_OK; }
 	FLUSH(b);
-	if (b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b));
+	TRY(ensure_df(b));
 	if (b->desc.am != MTFHIP_AM_SSD) /* (df_dIt * dIt_dp) - (df_dI0 * dI0_dp), NCC.cc:268-280, AppearanceModel.h:161-164 */
 		return gemv_to_host(b, b->buf[MTFHIP_BUF_DF_DIT], jt_buf, b->buf[MTFHIP_BUF_DF_DI0], j0_buf, 0, g, 1);
 	/* SSD: df_dIt * (dI0_dpssm + dIt_dpssm), SSDBase.cc:186 */
@@ -1784,21 +1820,21 @@ static int add_second_order(mtfhip_batch *b, int d2a, int d2b, const double *dev
 /* SSDBase.cc:313-343 ; NCC.cc:391-400 ; MI.cc:659-673 */
 int mtfhip_am_cmpt_init_hessian2(mtfhip_batch *b, int j0_buf, int d2_buf, double *H) {
 	FLUSH(b);
-	if (b && b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b));   /* the second-order terms are weighted by df_dI */
+	if (b) TRY(ensure_df(b));   /* the second-order terms are weighted by df_dI */
 	TRY(mtfhip_am_cmpt_init_hessian(b, j0_buf, H));
 	return add_second_order(b, d2_buf, -1, b->buf[MTFHIP_BUF_DF_DI0], H);
 }
 /* SSDBase.cc:345-375 ; NCC.cc:401-410 ; MI.cc:680-694 */
 int mtfhip_am_cmpt_curr_hessian2(mtfhip_batch *b, int jt_buf, int d2_buf, double *H) {
 	FLUSH(b);
-	if (b && b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b));   /* the second-order terms are weighted by df_dI */
+	if (b) TRY(ensure_df(b));   /* the second-order terms are weighted by df_dI */
 	TRY(mtfhip_am_cmpt_curr_hessian(b, jt_buf, H));
 	return add_second_order(b, d2_buf, -1, b->buf[MTFHIP_BUF_DF_DIT], H);
 }
 /* SSD: first order only (SSDBase.h:95-98) ; NCC: am_func_not_implemeted (AppearanceModel.h:188-191) ; MI.cc:696-733 */
 int mtfhip_am_cmpt_self_hessian2(mtfhip_batch *b, int jt_buf, int d2_buf, double *H) {
 	FLUSH(b);
-	if (b && b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b));   /* the second-order terms are weighted by df_dI */
+	if (b) TRY(ensure_df(b));   /* the second-order terms are weighted by df_dI */
 	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_self_hessian (second order): NULL argument");
 	if (b->desc.am == MTFHIP_AM_NCC) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "ncc :: cmptSelfHessian(second order) :: function not implemented yet");
 	TRY(mtfhip_am_cmpt_self_hessian(b, jt_buf, H));
@@ -1813,7 +1849,7 @@ int mtfhip_am_cmpt_self_hessian2(mtfhip_batch *b, int jt_buf, int d2_buf, double
 /* SSDBase.cc:377-415 (both pixel Hessians weighted by df_dI0) ; NCC / MI: generic AppearanceModel.h:209-219 */
 int mtfhip_am_cmpt_sum_of_hessians2(mtfhip_batch *b, int j0_buf, int jt_buf, int d20_buf, int d2t_buf, double *H) {
 	FLUSH(b);
-	if (b && b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b));   /* the second-order terms are weighted by df_dI */
+	if (b) TRY(ensure_df(b));   /* the second-order terms are weighted by df_dI */
 	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_sum_of_hessians (second order): NULL argument");
 	if (b->desc.am == MTFHIP_AM_SSD) {
 		TRY(mtfhip_am_cmpt_sum_of_hessians(b, j0_buf, jt_buf, H));
@@ -1976,9 +2012,59 @@ static int ncc_template_moments(mtfhip_batch *b) {
 	return MTFHIP_OK;
 }
 
+/* deferred fusion, NCC: the AM-level Jacobian the trigger asked for, and the moment rows kept for the Hessian calls */
+static int ncc_lazy_outputs(mtfhip_batch *b, int trig, int j_a, bool hess_mean, double *g) {
+	mtfhip_batch::Lazy &L = b->lz;
+	const int S = b->S;
+	for (int t = 0; t < b->B; ++t) {
+		const double *M = b->h_acc + (size_t)t * NCC_ACC_COUNT;
+		TargetHost &h = b->th[t];
+		const NccScalars q = ncc_scalars(b, h, M);
+		h.It_mean = q.mt; h.b = q.b; h.a = M[NCC_I0IT] - q.N * q.m0 * q.mt; h.f = q.f;
+		NccX X;
+		double ut[8], u0[8], *o = g + (size_t)t * S;
+		if (trig == LAZY_INIT_JAC) {
+			ncc_x(b, h, M, 0, hess_mean, X); ncc_vecs(q, X, S, ut, u0);
+			for (int s = 0; s < S; ++s) o[s] = (q.b / q.c) * (ut[s] - q.f * u0[s]);
+		} else {
+			ncc_x(b, h, M, (trig == LAZY_CURR_JAC && j_a == MTFHIP_BUF_JM) ? 2 : 1, hess_mean, X); ncc_vecs(q, X, S, ut, u0);
+			for (int s = 0; s < S; ++s) o[s] = u0[s] - q.f * ut[s];
+			if (trig == LAZY_DIFF_JAC) {   /* (df_dIt . Jt) - (df_dI0 . J0), NCC.cc:268-280 */
+				ncc_x(b, h, M, 0, hess_mean, X); ncc_vecs(q, X, S, ut, u0);
+				for (int s = 0; s < S; ++s) o[s] -= (q.b / q.c) * (ut[s] - q.f * u0[s]);
+			}
+		}
+	}
+	b->ncc_host_newer = true;
+	if (!L.no_cache) {
+		L.ncc_M.assign(b->h_acc, b->h_acc + (size_t)NCC_ACC_COUNT * b->B);
+		L.ncc_M_mean = hess_mean;
+		L.ncc_M_it = L.ver[MTFHIP_BUF_IT]; L.ncc_M_jt = L.ver[MTFHIP_BUF_JT]; L.ncc_M_jm = L.ver[MTFHIP_BUF_JM];
+	}
+	return MTFHIP_OK;
+}
+/* 1 when H was produced from the cached moment rows */
+static int ncc_hessian_from_cache(mtfhip_batch *b, int j_buf, int kind, double *H) {
+	mtfhip_batch::Lazy &L = b->lz;
+	if (L.no_cache || L.ncc_M.empty() || L.ncc_M_it != L.ver[MTFHIP_BUF_IT]) return 0;
+	int which;
+	if (j_buf == MTFHIP_BUF_J0) { if (L.ncc_tm_ver != L.ver[MTFHIP_BUF_J0]) return 0; which = 0; }
+	else if (j_buf == MTFHIP_BUF_JT) { if (L.ncc_M_mean || L.ncc_M_jt != L.ver[MTFHIP_BUF_JT]) return 0; which = 1; }
+	else { if (!L.ncc_M_mean || L.ncc_M_jm != L.ver[MTFHIP_BUF_JM] || L.ncc_M_jt != L.ver[MTFHIP_BUF_JT] || L.ncc_tm_ver != L.ver[MTFHIP_BUF_J0]) return 0; which = 2; }
+	for (int t = 0; t < b->B; ++t) {
+		const double *M = &L.ncc_M[(size_t)t * NCC_ACC_COUNT];
+		const NccScalars q = ncc_scalars(b, b->th[t], M);
+		NccX X;
+		ncc_x(b, b->th[t], M, which, L.ncc_M_mean, X);
+		if (!X.gram) return 0;
+		ncc_hess_from_moments(q, X, b->S, kind, H + (size_t)t * b->S * b->S);
+	}
+	return 1;
+}
+
 int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	FLUSH(b);
-	if (b) { touch_all(b); b->lz.it_epoch = -1; if (b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b)); }
+	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
 	TRY(check_sm(b, sm, "init_template"));
 	TRY(single_channel(b, "init_template"));
 	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "init_template before set_corners");
@@ -2032,7 +2118,7 @@ int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
  * template Jacobian.  The template (I0, dI0_dx) is kept in every case. */
 int mtfhip_batch_set_region(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm) {
 	FLUSH(b);
-	if (b) { touch_all(b); b->lz.it_epoch = -1; if (b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b)); }
+	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
 	TRY(check_sm(b, sm, "set_region"));
 	TRY(single_channel(b, "set_region"));
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "set_region before init_template");
@@ -2125,7 +2211,7 @@ static void assemble(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const doub
 
 int mtfhip_batch_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, double *g, double *H) {
 	FLUSH(b);
-	if (b) { touch_all(b); b->lz.it_epoch = -1; if (b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b)); }
+	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
 	TRY(check_sm(b, sm, "iterate"));
 	TRY(single_channel(b, "iterate"));
 	if (!g || !H) return fail(MTFHIP_ERR_INVALID_ARG, "iterate: NULL output");
@@ -2215,7 +2301,7 @@ int mtfhip_batch_track_targets_per_launch(mtfhip_batch *b, const mtfhip_sm_desc 
 
 int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners) {
 	FLUSH(b);
-	if (b) { touch_all(b); b->lz.it_epoch = -1; if (b->desc.am == MTFHIP_AM_SSD) TRY(ensure_df(b)); }
+	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
 	TRY(check_sm(b, sm, "track"));
 	TRY(single_channel(b, "track"));
 	if (sm->leven_marq) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: Levenberg-Marquardt is only available through iterate + host solve");
