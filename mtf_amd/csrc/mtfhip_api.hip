@@ -245,6 +245,7 @@ struct mtfhip_batch {
 	/* CURR_PTS / CURR_HXY / CURR_Z lag behind the warp: only the un-fused kernels read them, so k_apply_warp runs when
 	 * one of those is about to be launched (lazy_flush) or the arrays are read, not after every update */
 	bool pts_stale = false;
+	double *d_it_shadow = nullptr;
 	/* NCC: a fused iteration updated the scalars (It_mean, a, b, f) on the host only; the un-fused kernels read d_ncc */
 	bool ncc_host_newer = false;
 	size_t slab_bytes = 0, slab_dbl_bytes = 0;
@@ -281,6 +282,11 @@ struct mtfhip_batch {
 		/* DF_DI0 (updateSimilarity) / DF_DIT (updateCurrGrad) were skipped by a fused launch: refreshed from IT / I0 on
 		 * first use, and in any case before IT is overwritten by something that does not overwrite them as well */
 		bool df0_stale = false, dft_stale = false;
+		/* ...and when IT has to change first, the old IT is kept instead of being consumed: the launch writes the other
+		 * of two IT buffers (pointer swap, no copy) and the stale vector remembers that it refers to the shadow */
+		bool df0_sh = false, dft_sh = false, shadow_valid = false;
+		struct NccSave { double It_mean, a, b, f; };
+		std::vector<NccSave> ncc_shadow;   /* NCC scalars that belong to the shadow IT */
 		bool no_cache = false;
 		/* Levenberg-Marquardt reads f in the middle of the iteration (NT/ESM.cc:186-204), which replays updatePixVals +
 		 * updateSimilarity un-fused; the fused launch may still serve the rest when IT and DF_DI0 are known to belong to
@@ -289,6 +295,8 @@ struct mtfhip_batch {
 		/* NCC: the moment rows of the last fused launch ([B][NCC_ACC_COUNT]); Hessian requests are answered from them while
 		 * IT and the Jacobian they were taken from are unchanged.  ncc_tm_ver: J0 version of the template moments. */
 		std::vector<double> ncc_M; bool ncc_M_mean = false; long ncc_M_it = -1, ncc_M_jt = -1, ncc_M_jm = -1, ncc_tm_ver = -1;
+		/* SSD: sum r J0 of the lean launch that served getSimilarity() -- it IS cmptInitJacobian(J0) for this IT and J0 */
+		std::vector<double> sim_g; long sim_g_it = -1, sim_g_j0 = -1;
 		/* Gram matrices that are already on the host: [B][36] upper triangles, valid while version matches */
 		long ver[MTFHIP_BUF_COUNT] = {0};
 		int gram_buf = -1; long gram_ver = -1; std::vector<double> gram;
@@ -399,6 +407,10 @@ static inline void touch(mtfhip_batch *b, int id) { ++b->lz.ver[id]; }
 static inline void touch_all(mtfhip_batch *b) { for (int i = 0; i < MTFHIP_BUF_COUNT; ++i) ++b->lz.ver[i]; }
 static int lazy_flush(mtfhip_batch *b);
 static int ensure_df(mtfhip_batch *b);
+static int ensure_one(mtfhip_batch *b, bool curr);
+static void stale_clear(mtfhip_batch *b, bool df0, bool dft);
+static int protect_stale(mtfhip_batch *b, bool w0, bool wt);
+static int lazy_try_similarity(mtfhip_batch *b);
 static int do_cmpt_pix_jacobian(mtfhip_batch *b, int variant, int grad_buf, int dst_buf);
 static int do_mean_jacobian(mtfhip_batch *b);
 static int lazy_flush_ctx(mtfhip_ctx *c) {   /* called by everything that replaces the current image */
@@ -716,7 +728,7 @@ void mtfhip_batch_destroy(mtfhip_batch *b) {
 			if (b->buf[i]) (void)hipFree(b->buf[i]);
 		void *ptrs[] = {b->d_slab, b->d_partials, b->d_acc, b->d_scratch_pts, b->d_h0,
 			b->d_cand, b->d_colmean, b->d_mi_tb, b->d_mi_part,
-			b->d_mi_f, b->d_mi_H, b->d_h0inv, b->d_units, b->d_d2_part, b->d_d2_out, b->d_d2_w, b->d_done};
+			b->d_mi_f, b->d_mi_H, b->d_h0inv, b->d_units, b->d_d2_part, b->d_d2_out, b->d_d2_w, b->d_done, b->d_it_shadow};
 		for (void *p : ptrs)
 			if (p) (void)hipFree(p);
 		if (b->h_acc) (void)hipHostFree(b->h_acc);
@@ -754,7 +766,7 @@ int mtfhip_batch_write(mtfhip_batch *b, int id, const double *src) {
 	if (!b || !src || id < 0 || id >= MTFHIP_BUF_COUNT) return fail(MTFHIP_ERR_INVALID_ARG, "batch_write: bad argument");
 	FLUSH(b);
 	TRY(ensure_df(b));
-	if (id == MTFHIP_BUF_DF_DI0 || id == MTFHIP_BUF_DF_DIT) b->lz.df0_stale = b->lz.dft_stale = false;
+	if (id == MTFHIP_BUF_DF_DI0 || id == MTFHIP_BUF_DF_DIT) stale_clear(b, true, true);
 	touch(b, id); ++b->lz.epoch;
 	TRY(ensure_buf(b, id));
 	HIP_TRY(hipMemcpyAsync(b->buf[id], src, sizeof(double) * b->per_target[id] * b->B, hipMemcpyHostToDevice, b->ctx->stream));
@@ -993,7 +1005,7 @@ int mtfhip_am_initialize_pix_vals(mtfhip_batch *b, const double *pts) {
 }
 static int do_update_pix_vals(mtfhip_batch *b, const double *pts) {
 	TRY(need_image(b));
-	TRY(ensure_df(b));   /* IT is about to change: gradients skipped by a fused launch are derived from the old IT first */
+	TRY(protect_stale(b, false, false));   /* IT is about to change: gradients skipped by a fused launch keep the old IT */
 	const double *dp;
 	TRY(resolve_pts(b, pts, MTFHIP_BUF_CURR_PTS, 2 * (size_t)b->NP, &dp));
 	TimedScope ts(b->ctx, "sample");
@@ -1340,7 +1352,7 @@ static int do_update_similarity(mtfhip_batch *b, int prereq_only) {
 		TimedScope ts(b->ctx, "ssd_residual");
 		launch_ssd_residual(b->view(), b->d_partials, nblk, b->ctx->stream);
 	}
-	b->lz.df0_stale = false;
+	stale_clear(b, true, false);
 	b->lz.df0_it_ver = b->lz.ver[MTFHIP_BUF_IT];
 	if (prereq_only) return MTFHIP_OK;
 	TRY(read_acc(b, nblk));
@@ -1348,12 +1360,12 @@ static int do_update_similarity(mtfhip_batch *b, int prereq_only) {
 	return MTFHIP_OK;
 }
 static int do_update_curr_grad(mtfhip_batch *b) {
-	if (b->desc.am == MTFHIP_AM_NCC) { int rc = ncc_update_grad(b, 1); b->lz.dft_stale = false; return rc; }
+	if (b->desc.am == MTFHIP_AM_NCC) { int rc = ncc_update_grad(b, 1); stale_clear(b, false, true); return rc; }
 	if (b->desc.am == MTFHIP_AM_MI) return mi_grad(b, 1);
-	if (b->lz.df0_stale) TRY(ensure_df(b));
+	if (b->lz.df0_stale) TRY(ensure_one(b, false));
 	TimedScope ts(b->ctx, "negate");
 	launch_negate(b->buf[MTFHIP_BUF_DF_DI0], b->buf[MTFHIP_BUF_DF_DIT], (size_t)b->N * b->B, b->ctx->stream);
-	b->lz.dft_stale = false;
+	stale_clear(b, false, true);
 	return MTFHIP_OK;
 }
 int mtfhip_am_update_curr_grad(mtfhip_batch *b) {
@@ -1377,18 +1389,20 @@ int mtfhip_am_update_init_grad(mtfhip_batch *b) {
 		return MTFHIP_OK;
 	}
 	FLUSH(b);
-	if (b->desc.am == MTFHIP_AM_NCC) { int rc = ncc_update_grad(b, 0); b->lz.df0_stale = false; return rc; }
+	if (b->desc.am == MTFHIP_AM_NCC) { int rc = ncc_update_grad(b, 0); stale_clear(b, true, false); return rc; }
 	if (b->desc.am == MTFHIP_AM_MI) return mi_grad(b, 0);
 	return MTFHIP_OK;
 }
 int mtfhip_am_get_similarity(mtfhip_batch *b, double *f) {
 	if (!b || !f) return fail(MTFHIP_ERR_INVALID_ARG, "get_similarity: NULL argument");
+	TRY(lazy_try_similarity(b));
 	FLUSH(b);
 	for (int t = 0; t < b->B; ++t) f[t] = b->th[t].f;
 	return MTFHIP_OK;
 }
 int mtfhip_am_get_likelihood(mtfhip_batch *b, double *l) {
 	if (!b || !l) return fail(MTFHIP_ERR_INVALID_ARG, "get_likelihood: NULL argument");
+	TRY(lazy_try_similarity(b));
 	FLUSH(b);
 	for (int t = 0; t < b->B; ++t) {
 		double f = b->th[t].f;
@@ -1400,24 +1414,70 @@ int mtfhip_am_get_likelihood(mtfhip_batch *b, double *l) {
 
 /* ---- deferred fusion: replay, refresh, and the fused execution of a recognised call sequence ---- */
 static int pix_grad_common(mtfhip_batch *b, const double *pts, bool warped, bool init);
-/* SSD's DF_DI0 = It - I0 and DF_DIT = -DF_DI0 (SSDBase.cc:75-121) when a fused launch stood in for the calls that write them */
+/* SSD's DF_DI0 = It - I0 and DF_DIT = -DF_DI0 (SSDBase.cc:75-121), NCC's gradient vectors (NCC.cc:163-234), when a fused
+ * launch stood in for the calls that write them: derived from the IT (current or shadow) and scalars they belong to */
+static void stale_clear(mtfhip_batch *b, bool df0, bool dft) {
+	mtfhip_batch::Lazy &L = b->lz;
+	if (df0) L.df0_stale = L.df0_sh = false;
+	if (dft) L.dft_stale = L.dft_sh = false;
+	if (!L.df0_sh && !L.dft_sh) L.shadow_valid = false;
+}
+static void swap_shadow(mtfhip_batch *b) {
+	std::swap(b->buf[MTFHIP_BUF_IT], b->d_it_shadow);
+	if (b->desc.am == MTFHIP_AM_NCC)
+		for (int t = 0; t < b->B; ++t) {
+			TargetHost &h = b->th[t]; mtfhip_batch::Lazy::NccSave &v = b->lz.ncc_shadow[t];
+			std::swap(h.It_mean, v.It_mean); std::swap(h.a, v.a); std::swap(h.b, v.b); std::swap(h.f, v.f);
+		}
+	b->ncc_host_newer = true;   /* d_ncc has to follow whichever set of scalars is current */
+}
+static int ensure_one(mtfhip_batch *b, bool curr) {
+	mtfhip_batch::Lazy &L = b->lz;
+	if (curr ? !L.dft_stale : !L.df0_stale) return MTFHIP_OK;
+	const bool sh = curr ? L.dft_sh : L.df0_sh;
+	if (sh) swap_shadow(b);
+	int rc = MTFHIP_OK;
+	if (b->desc.am == MTFHIP_AM_NCC) {
+		rc = ncc_update_grad(b, curr ? 1 : 0);
+	} else {
+		/* the residual kernel writes It - I0 into the view's DF_DI0; for df_dIt it is pointed at DF_DIT and negated in place */
+		BatchView v = b->view();
+		if (curr) v.buf[MTFHIP_BUF_DF_DI0] = b->buf[MTFHIP_BUF_DF_DIT];
+		{
+			TimedScope ts(b->ctx, "ssd_residual");
+			launch_ssd_residual(v, b->d_partials, simple_blocks_per_target(b->N), b->ctx->stream);
+		}
+		if (curr) {
+			TimedScope ts(b->ctx, "negate");
+			launch_negate(b->buf[MTFHIP_BUF_DF_DIT], b->buf[MTFHIP_BUF_DF_DIT], (size_t)b->N * b->B, b->ctx->stream);
+		}
+	}
+	if (sh) swap_shadow(b);
+	if (rc) return rc;
+	stale_clear(b, !curr, curr);
+	return MTFHIP_OK;
+}
 static int ensure_df(mtfhip_batch *b) {
-	if (!b->lz.df0_stale && !b->lz.dft_stale) return MTFHIP_OK;
-	if (b->desc.am == MTFHIP_AM_NCC) {   /* NCC.cc:163-234 from the scalars the fused launch left on the host */
-		if (b->lz.dft_stale) { b->lz.dft_stale = false; TRY(ncc_update_grad(b, 1)); }
-		if (b->lz.df0_stale) { b->lz.df0_stale = false; TRY(ncc_update_grad(b, 0)); }
-		return MTFHIP_OK;
+	TRY(ensure_one(b, false));
+	return ensure_one(b, true);
+}
+/* IT is about to be overwritten by a launch that re-produces df_dI0 (w0) / df_dIt (wt) or not: stale vectors that it does
+ * not re-produce keep their IT by a buffer swap instead of being derived now */
+static int protect_stale(mtfhip_batch *b, bool w0, bool wt) {
+	mtfhip_batch::Lazy &L = b->lz;
+	const bool cur0 = L.df0_stale && !w0 && !L.df0_sh, curt = L.dft_stale && !wt && !L.dft_sh;
+	if (!cur0 && !curt) return MTFHIP_OK;
+	if (L.shadow_valid) {   /* an older shadow is still referenced (rare): settle it first */
+		if (L.df0_sh) TRY(ensure_one(b, false));
+		if (L.dft_sh) TRY(ensure_one(b, true));
 	}
-	if (b->lz.df0_stale) {
-		TimedScope ts(b->ctx, "ssd_residual");
-		launch_ssd_residual(b->view(), b->d_partials, simple_blocks_per_target(b->N), b->ctx->stream);
-		b->lz.df0_stale = false;
-	}
-	if (b->lz.dft_stale) {
-		TimedScope ts(b->ctx, "negate");
-		launch_negate(b->buf[MTFHIP_BUF_DF_DI0], b->buf[MTFHIP_BUF_DF_DIT], (size_t)b->N * b->B, b->ctx->stream);
-		b->lz.dft_stale = false;
-	}
+	if (!b->d_it_shadow) HIP_TRY(hipMalloc(&b->d_it_shadow, sizeof(double) * b->per_target[MTFHIP_BUF_IT] * b->B));
+	L.ncc_shadow.resize(b->B);
+	for (int t = 0; t < b->B; ++t) { const TargetHost &h = b->th[t]; L.ncc_shadow[t] = {h.It_mean, h.a, h.b, h.f}; }
+	std::swap(b->buf[MTFHIP_BUF_IT], b->d_it_shadow);   /* the launch fills the other buffer; th keeps the current scalars */
+	L.shadow_valid = true;
+	if (cur0) L.df0_sh = true;
+	if (curt) L.dft_sh = true;
 	return MTFHIP_OK;
 }
 /* replays the recorded calls through the un-fused kernels, in the order they were made */
@@ -1447,7 +1507,7 @@ static int lazy_flush(mtfhip_batch *b) {
 		case 4: TRY(do_update_similarity(b, need_f ? 0 : 1)); break;
 		case 5: TRY(do_update_curr_grad(b)); break;
 		case 6:          /* SSD::updateInitGrad is empty (SSDBase.h) */
-			if (b->desc.am == MTFHIP_AM_NCC) { TRY(ncc_update_grad(b, 0)); L.df0_stale = false; }
+			if (b->desc.am == MTFHIP_AM_NCC) { TRY(ncc_update_grad(b, 0)); stale_clear(b, true, false); }
 			break;
 		default: TRY(do_mean_jacobian(b)); break;
 		}
@@ -1469,7 +1529,7 @@ static int lazy_try_fused(mtfhip_batch *b, int trig, int j_a, int j_b, double *g
 	if (!L.enabled) return MTFHIP_OK;
 	/* either updatePixVals + updateSimilarity are part of the pending set, or they already ran for this very warp and image */
 	const bool replay = L.pv && L.sim && L.pv < L.sim;
-	const bool current = !L.pv && !L.sim && L.it_epoch == L.epoch && L.df0_it_ver == L.ver[MTFHIP_BUF_IT] && !L.df0_stale;
+	const bool current = !L.pv && !L.sim && L.it_epoch == L.epoch && L.df0_it_ver == L.ver[MTFHIP_BUF_IT];
 	if (!replay && !current) return MTFHIP_OK;
 	if (!b->init_pix_vals || !b->init_sim || !b->have_corners || !b->ctx->img.data || b->ctx->img.channels != 1) return MTFHIP_OK;
 	mtfhip_sm_desc sm;
@@ -1500,8 +1560,29 @@ static int lazy_try_fused(mtfhip_batch *b, int trig, int j_a, int j_b, double *g
 	}
 	const bool ncc = b->desc.am == MTFHIP_AM_NCC;
 	if (ncc && trig == LAZY_INIT_JAC && !L.ig) return MTFHIP_OK;   /* NCC's df_dI0 comes from updateInitGrad */
-	/* gradients a previous fused launch skipped and this one will not overwrite: derive them from the old IT first */
-	if ((L.dft_stale && !L.cg) || (ncc && L.df0_stale && !L.ig)) TRY(ensure_df(b));
+	/* gradients a previous fused launch skipped and this one will not re-produce keep their IT (when IT is current the
+	 * launch rewrites the same bits, nothing to protect) */
+	if (replay) TRY(protect_stale(b, ncc ? L.ig != 0 : true, L.cg != 0));
+	if (current && trig == LAZY_INIT_JAC && !L.no_cache) {
+		/* the lean launch behind getSimilarity() already accumulated this Jacobian for the same IT and J0: no launch */
+		bool served = false;
+		if (!ncc && L.sim_g_it == L.ver[MTFHIP_BUF_IT] && L.sim_g_j0 == L.ver[MTFHIP_BUF_J0] && !L.sim_g.empty()) {
+			for (int t = 0; t < b->B; ++t) std::memcpy(g + (size_t)t * b->S, &L.sim_g[(size_t)8 * t], sizeof(double) * b->S);
+			served = true;
+		} else if (ncc && !L.ncc_M.empty() && L.ncc_M_it == L.ver[MTFHIP_BUF_IT] && L.ncc_tm_ver == L.ver[MTFHIP_BUF_J0]) {
+			std::memcpy(b->h_acc, L.ncc_M.data(), sizeof(double) * L.ncc_M.size());
+			const long jt = L.ncc_M_jt, jm = L.ncc_M_jm; const bool mean = L.ncc_M_mean;
+			TRY(ncc_lazy_outputs(b, trig, j_a, mean, g));
+			L.ncc_M_jt = jt; L.ncc_M_jm = jm;   /* the rows are unchanged: what they hold about Jt / Jm stays as it was */
+			served = true;
+		}
+		if (served) {
+			if (ncc && L.ig) { L.df0_stale = true; L.df0_sh = false; if (!L.dft_sh) L.shadow_valid = false; }
+			L.ig = 0;
+			*done = 1;
+			return MTFHIP_OK;
+		}
+	}
 	if (ncc && sm.sm != MTFHIP_SM_FCLK && L.ncc_tm_ver != L.ver[MTFHIP_BUF_J0]) {   /* moments of the template's Jacobian */
 		TRY(ncc_template_moments(b));
 		L.ncc_tm_ver = L.ver[MTFHIP_BUF_J0];
@@ -1520,9 +1601,10 @@ static int lazy_try_fused(mtfhip_batch *b, int trig, int j_a, int j_b, double *g
 	const bool want_mean = L.jm != 0;
 	/* the N-sized gradient vectors the consumed calls would have written: SSD's df_dI0 is updateSimilarity's residual,
 	 * NCC's comes from updateInitGrad; df_dIt from updateCurrGrad in both */
-	if (ncc ? L.ig != 0 : replay) L.df0_stale = true;
+	if (ncc ? L.ig != 0 : replay) { L.df0_stale = true; L.df0_sh = false; }
 	L.df0_it_ver = L.ver[MTFHIP_BUF_IT];          /* (when IT was current the launch rewrote the same bits) */
-	if (L.cg) L.dft_stale = true;
+	if (L.cg) { L.dft_stale = true; L.dft_sh = false; }
+	if (!L.df0_sh && !L.dft_sh) L.shadow_valid = false;
 	L.pv = L.gp = L.pg = L.pj = L.sim = L.cg = L.ig = L.jm = 0;
 	if (want_mean) TRY(do_mean_jacobian(b));
 	if (ncc) {
@@ -2060,6 +2142,59 @@ static int ncc_hessian_from_cache(mtfhip_batch *b, int j_buf, int kind, double *
 		ncc_hess_from_moments(q, X, b->S, kind, H + (size_t)t * b->S * b->S);
 	}
 	return 1;
+}
+
+/* getSimilarity() right after updatePixVals + updateSimilarity -- Levenberg-Marquardt's test in the middle of every
+ * iteration (NT/ESM.cc:186-204, FCLK.cc:205-223, ICLK.cc:181-199): one launch of the lean (ICLK-type) fused kernel
+ * writes IT and accumulates what f needs, instead of sample + residual (SSD) or sample + two reduction passes with
+ * two host round trips (NCC).  Anything else pending, or nothing pending: not taken, the caller flushes. */
+static int lazy_try_similarity(mtfhip_batch *b) {
+	mtfhip_batch::Lazy &L = b->lz;
+	if (!L.enabled || !L.pv || !L.sim || L.pv > L.sim || L.gp || L.pg || L.pj || L.cg || L.ig || L.jm) return MTFHIP_OK;
+	if (!b->init_pix_vals || !b->init_sim || !b->have_corners || !b->ctx->img.data || b->ctx->img.channels != 1) return MTFHIP_OK;
+	const bool ncc = b->desc.am == MTFHIP_AM_NCC;
+	mtfhip_sm_desc sm;
+	std::memset(&sm, 0, sizeof(sm));
+	sm.sm = MTFHIP_SM_ICLK; sm.hess_type = 0; sm.materialize = 1; sm.max_iters = 1; sm.chained_warp = 1;
+	FusedArgs fa;
+	TRY(fused_args(b, &sm, fa));
+	TRY(protect_stale(b, !ncc, false));   /* SSD's updateSimilarity re-produces df_dI0 */
+	const int nblk = fused_blocks_per_target(b->N, b->B);
+	{
+		TimedScope ts(b->ctx, "fused_lk");
+		launch_fused_ssd(b->view(), b->ctx->img, fa, b->d_partials, nblk, b->ctx->stream);
+	}
+	touch(b, MTFHIP_BUF_IT);
+	b->it_valid = true;
+	L.it_epoch = L.epoch;
+	L.df0_it_ver = L.ver[MTFHIP_BUF_IT];
+	if (!ncc) { L.df0_stale = true; L.df0_sh = false; if (!L.dft_sh) L.shadow_valid = false; }
+	L.pv = L.sim = 0;
+	if (ncc) {
+		launch_finish_rows(b->d_partials, nblk, NCC_ACC_COUNT, b->d_acc, b->B, b->ctx->stream);
+		HIP_TRY(hipMemcpyAsync(b->h_acc, b->d_acc, sizeof(double) * NCC_ACC_COUNT * b->B, hipMemcpyDeviceToHost, b->ctx->stream));
+		HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+		for (int t = 0; t < b->B; ++t) {
+			const double *M = b->h_acc + (size_t)t * NCC_ACC_COUNT;
+			TargetHost &h = b->th[t];
+			const NccScalars q = ncc_scalars(b, h, M);
+			h.It_mean = q.mt; h.b = q.b; h.a = M[NCC_I0IT] - q.N * q.m0 * q.mt; h.f = q.f;
+		}
+		b->ncc_host_newer = true;
+		if (!L.no_cache) {   /* sum It J0 and the scalars: enough for cmptInitJacobian / cmptInitHessian of this IT */
+			L.ncc_M.assign(b->h_acc, b->h_acc + (size_t)NCC_ACC_COUNT * b->B);
+			L.ncc_M_mean = false; L.ncc_M_it = L.ver[MTFHIP_BUF_IT]; L.ncc_M_jt = L.ncc_M_jm = -1;
+		}
+		return MTFHIP_OK;
+	}
+	TRY(read_acc(b, nblk));
+	for (int t = 0; t < b->B; ++t) b->th[t].f = -b->h_acc[(size_t)t * ACC_COUNT + ACC_RR] / 2;
+	if (!L.no_cache) {
+		L.sim_g.resize((size_t)8 * b->B);
+		for (int t = 0; t < b->B; ++t) std::memcpy(&L.sim_g[(size_t)8 * t], b->h_acc + (size_t)t * ACC_COUNT + ACC_G, sizeof(double) * 8);
+		L.sim_g_it = L.ver[MTFHIP_BUF_IT]; L.sim_g_j0 = L.ver[MTFHIP_BUF_J0];
+	}
+	return MTFHIP_OK;
 }
 
 int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
