@@ -239,21 +239,23 @@ def secondary_workload(args):
         c = synth.square_corners(W / 2.0, H / 2.0, float(res))
         sm_kind = {"esm": mtf_amd.SM_ESM, "fclk": mtf_amd.SM_FCLK, "iclk": mtf_amd.SM_ICLK}[args.sm]
         K = 50
-        tr = host.CppTracker(sm_kind, am=mtf_amd.AM_SSD, resx=res, resy=res, max_iters=K, epsilon=-1.0, leven_marq=0, device=local_rank)
+        am_kind = {"ssd": mtf_amd.AM_SSD, "ncc": mtf_amd.AM_NCC}[args.am]
+        tr = host.CppTracker(sm_kind, am=am_kind, resx=res, resy=res, max_iters=K, epsilon=-1.0, leven_marq=args.lm, device=local_rank)
         tr.set_image(frame0); tr.initialize(c); tr.set_image(frame1)
 
         def step():
             tr.set_region(c)
             tr.update()
         dt = timed(step)
-        out.update({"metric": "drop-in LK iters/sec, one target, C++ nt::%s + SSD + Homography %dx%d over the AM/SSM virtuals" % (args.sm.upper(), res, res),
+        out.update({"metric": "drop-in LK iters/sec, one target, C++ nt::%s + %s + Homography %dx%d over the AM/SSM virtuals" % (args.sm.upper(), args.am.upper(), res, res),
                     "value": K * args.steps * world / dt, "unit": "iters/s", "ms_per_step": dt / args.steps * 1e3, "scaling": "weak",
-                    "config": {"workload": "%d iterations per update(), one C-ABI call per virtual, deferred fusion %s" %
-                                           (K, "off" if os.environ.get("MTFHIP_LAZY") == "0" else "on"), "us_per_iter": dt / (K * args.steps) * 1e6}})
+                    "config": {"workload": "%d iterations per update(), one C-ABI call per virtual, Levenberg-Marquardt %s, deferred fusion %s" %
+                                           (K, "on" if args.lm else "off", "off" if os.environ.get("MTFHIP_LAZY") == "0" else "on"),
+                               "us_per_iter": dt / (K * args.steps) * 1e6}})
         if rank == 0 and not args.no_cpu:
             import oracle_py as O
-            ssm = O.SSM(O.SSM_HOM, res, res); am = O.AM(O.AM_SSD, res, res); am.set_curr_img(frame0)
-            trk = O.Tracker({"esm": O.SM_ESM, "fclk": O.SM_FCLK, "iclk": O.SM_ICLK}[args.sm], am, ssm, leven_marq=0, max_iters=K, epsilon=-1.0)
+            ssm = O.SSM(O.SSM_HOM, res, res); am = O.AM({"ssd": O.AM_SSD, "ncc": O.AM_NCC}[args.am], res, res); am.set_curr_img(frame0)
+            trk = O.Tracker({"esm": O.SM_ESM, "fclk": O.SM_FCLK, "iclk": O.SM_ICLK}[args.sm], am, ssm, leven_marq=args.lm, max_iters=K, epsilon=-1.0)
             trk.initialize(c); am.set_curr_img(frame1)
             n, t0 = 0, time.perf_counter()
             while time.perf_counter() - t0 < args.cpu_seconds:
@@ -306,6 +308,8 @@ def main():
     ap.add_argument("--targets", type=int, default=64, help="targets per GPU (each 200x200)")
     ap.add_argument("--res", type=int, default=200)
     ap.add_argument("--sm", default="esm", choices=["esm", "fclk", "iclk"])
+    ap.add_argument("--am", default="ssd", choices=["ssd", "ncc"], help="dropin workload: appearance model")
+    ap.add_argument("--lm", type=int, default=1, help="dropin workload: Levenberg-Marquardt (the reference's class default is on)")
     ap.add_argument("--mode", default="full", choices=["full", "lean"],
                     help="full: It, dIt_dx, Jt materialised in HBM as the AM/SSM interface exposes them; lean: registers only")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
