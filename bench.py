@@ -308,7 +308,7 @@ def main():
     ap.add_argument("--targets", type=int, default=64, help="targets per GPU (each 200x200)")
     ap.add_argument("--res", type=int, default=200)
     ap.add_argument("--sm", default="esm", choices=["esm", "fclk", "iclk"])
-    ap.add_argument("--am", default="ssd", choices=["ssd", "ncc"], help="dropin workload: appearance model")
+    ap.add_argument("--am", default="ssd", choices=["ssd", "ncc"], help="appearance model (lk and dropin workloads)")
     ap.add_argument("--lm", type=int, default=1, help="dropin workload: Levenberg-Marquardt (the reference's class default is on)")
     ap.add_argument("--mode", default="full", choices=["full", "lean"],
                     help="full: It, dIt_dx, Jt materialised in HBM as the AM/SSM interface exposes them; lean: registers only")
@@ -358,7 +358,8 @@ def main():
     f1 = torch.from_numpy(frame1).to(dev)
     sm_kind = {"esm": mtf_amd.SM_ESM, "fclk": mtf_amd.SM_FCLK, "iclk": mtf_amd.SM_ICLK}[args.sm]
     materialize = 1 if args.mode == "full" else 0
-    batch = mtf_amd.Batch(ctx, mtf_amd.AM_SSD, mtf_amd.SSM_HOMOGRAPHY, res, res, B)
+    am_kind = {"ssd": mtf_amd.AM_SSD, "ncc": mtf_amd.AM_NCC}[args.am]
+    batch = mtf_amd.Batch(ctx, am_kind, mtf_amd.SSM_HOMOGRAPHY, res, res, B)
     batch.set_corners(corners)
     ctx.set_image_device(f0.data_ptr(), H, W, keep=f0)
     sm = mtf_amd.sm_desc(sm_kind, materialize=materialize, leven_marq=0, epsilon=-1.0, max_iters=1)
@@ -403,20 +404,20 @@ def main():
         bytes_per_launch = float(bpp) * N * per_launch
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         out = {
-            "metric": "LK iters/sec (warp+grad+Hessian), ESM+SSD+Homography 200x200",
+            "metric": "LK iters/sec (warp+grad+Hessian), ESM+%s+Homography 200x200" % args.am.upper(),
             "value": B * world * args.steps / dt,
             "unit": "iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s+SSD+Homography %dx%d, %d independent targets per GPU, %s mode, solve+update on device"
-                                   % (args.sm.upper(), res, res, B, args.mode),
+            "config": {"workload": "%s+%s+Homography %dx%d, %d independent targets per GPU, %s mode, solve+update on device"
+                                   % (args.sm.upper(), args.am.upper(), res, res, B, args.mode),
                        "targets_per_gpu": B, "n_pix": N, "mode": args.mode, "frame": "%dx%d float32" % (H, W),
                        "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.sm, args.mode, res, B),
-                         "kernel": "k_fused_ssd", "avg_kernel_ms": kern_ms, "launches_timed": kern_n,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.sm, args.mode, res, B) if args.am == "ssd" else None,
+                         "kernel": "k_fused_%s" % args.am, "avg_kernel_ms": kern_ms, "launches_timed": kern_n,
                          "algorithmic_bytes_per_pixel": bpp, "j0_rows": "rebuilt from dI0_dx" if j0_rec else "read back", "bytes_per_launch": bytes_per_launch,
                          "targets_per_launch": per_launch},
         }

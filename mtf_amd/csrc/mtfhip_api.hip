@@ -246,6 +246,7 @@ struct mtfhip_batch {
 	 * one of those is about to be launched (lazy_flush) or the arrays are read, not after every update */
 	bool pts_stale = false;
 	double *d_it_shadow = nullptr;
+	double *d_ncc_tm = nullptr;   /* [B][52] NCC template moments for the device-side finish */
 	/* NCC: a fused iteration updated the scalars (It_mean, a, b, f) on the host only; the un-fused kernels read d_ncc */
 	bool ncc_host_newer = false;
 	size_t slab_bytes = 0, slab_dbl_bytes = 0;
@@ -728,7 +729,7 @@ void mtfhip_batch_destroy(mtfhip_batch *b) {
 			if (b->buf[i]) (void)hipFree(b->buf[i]);
 		void *ptrs[] = {b->d_slab, b->d_partials, b->d_acc, b->d_scratch_pts, b->d_h0,
 			b->d_cand, b->d_colmean, b->d_mi_tb, b->d_mi_part,
-			b->d_mi_f, b->d_mi_H, b->d_h0inv, b->d_units, b->d_d2_part, b->d_d2_out, b->d_d2_w, b->d_done, b->d_it_shadow};
+			b->d_mi_f, b->d_mi_H, b->d_h0inv, b->d_units, b->d_d2_part, b->d_d2_out, b->d_d2_w, b->d_done, b->d_it_shadow, b->d_ncc_tm};
 		for (void *p : ptrs)
 			if (p) (void)hipFree(p);
 		if (b->h_acc) (void)hipHostFree(b->h_acc);
@@ -2091,6 +2092,16 @@ static int ncc_template_moments(mtfhip_batch *b) {
 	}
 	TRY(read_acc(b, nblk));
 	for (int t = 0; t < b->B; ++t) std::memcpy(b->th[t].ncc_gram0, b->h_acc + (size_t)t * ACC_COUNT + ACC_H, sizeof(double) * 36);
+	/* device copy for the device-side finish (k_finish_track) */
+	if (!b->d_ncc_tm) HIP_TRY(hipMalloc(&b->d_ncc_tm, sizeof(double) * 52 * (size_t)b->B));
+	std::vector<double> tm((size_t)52 * b->B);
+	for (int t = 0; t < b->B; ++t) {
+		std::memcpy(&tm[52 * (size_t)t], b->th[t].ncc_sj0, sizeof(double) * 8);
+		std::memcpy(&tm[52 * (size_t)t + 8], b->th[t].ncc_i0j0, sizeof(double) * 8);
+		std::memcpy(&tm[52 * (size_t)t + 16], b->th[t].ncc_gram0, sizeof(double) * 36);
+	}
+	HIP_TRY(hipMemcpyAsync(b->d_ncc_tm, tm.data(), sizeof(double) * tm.size(), hipMemcpyHostToDevice, b->ctx->stream));
+	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
 	return MTFHIP_OK;
 }
 
@@ -2448,8 +2459,6 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 	hipStream_t st = b->ctx->stream;
 	const bool one_launch = sm->sm == MTFHIP_SM_ICLK && (sm->hess_type == 0 || (sm->hess_type == 2 && b->desc.am == MTFHIP_AM_SSD)) &&
 		b->N <= kIclkTrackMaxPix;
-	if (b->desc.am == MTFHIP_AM_NCC && !one_launch)
-		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: the device-side loop covers SSD, and NCC with ICLK / InitialSelf on patches of up to %d pixels; use iterate (fused NCC moments + host solve)", kIclkTrackMaxPix);
 	FusedArgs fa;
 	if (!one_launch) TRY(fused_args(b, sm, fa));
 	else { fa.materialize = 0; fa.mode = 2; fa.active = nullptr; fa.done = nullptr; fa.rows_per_block = 1; fa.j0_recompute = 0; }
@@ -2460,7 +2469,10 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 	fill_stage(b, b->h_stage_b, nullptr, 1, true);
 	HIP_TRY(hipMemcpyAsync(b->d_slab, b->h_stage_b, b->slab_bytes, hipMemcpyHostToDevice, st));
 	fa.active = b->d_active;
-	TrackState ts{b->d_acc, b->d_h0, b->d_corners, b->d_init_corners_hm, b->d_active, b->d_iters};
+	const bool ncc = b->desc.am == MTFHIP_AM_NCC;
+	const size_t RL = ncc ? NCC_ACC_COUNT : ACC_COUNT;   /* partial / reduced row length */
+	if (ncc && !one_launch && !b->d_ncc_tm) return fail(MTFHIP_ERR_LOGIC, "track before init_template");
+	TrackState ts{b->d_acc, b->d_h0, b->d_corners, b->d_init_corners_hm, b->d_active, b->d_iters, ncc ? b->d_ncc : nullptr, ncc ? b->d_ncc_tm : nullptr};
 	BatchView bv = b->view();
 	if (one_launch) {
 		TimedScope tsc(b->ctx, "iclk_track");
@@ -2468,7 +2480,7 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 	} else {
 		/* MTFHIP_EPILOGUE=1: one launch per iteration, the workgroup that completes a target's partial rows also runs the
 		 * finish; default: the separate k_finish_track launch (same step time, cleaner kernel timing). */
-		if (b->epilogue) {
+		if (b->epilogue && !ncc) {
 			if (!b->d_done) {
 				HIP_TRY(hipMalloc(&b->d_done, sizeof(int) * b->B));
 				HIP_TRY(hipMemsetAsync(b->d_done, 0, sizeof(int) * b->B, st));
@@ -2489,17 +2501,18 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 			bc.warps += 9 * (size_t)t0; bc.states += 8 * (size_t)t0;
 			FusedArgs fc = fa;
 			fc.active = fa.active + t0;
-			TrackState tc{ts.acc + (size_t)t0 * ACC_COUNT, ts.h0 + (size_t)t0 * 64, ts.corners + 8 * (size_t)t0,
-				ts.init_corners_hm + 12 * (size_t)t0, ts.active + t0, ts.n_iters + t0};
+			TrackState tc{ts.acc + (size_t)t0 * RL, ts.h0 + (size_t)t0 * 64, ts.corners + 8 * (size_t)t0,
+				ts.init_corners_hm + 12 * (size_t)t0, ts.active + t0, ts.n_iters + t0, ncc ? ts.ncc + 8 * (size_t)t0 : nullptr,
+				ncc ? ts.ncc_tm + 52 * (size_t)t0 : nullptr};
 			if (fc.done) { fc.done = fa.done + t0; fc.ts = tc; }
 			int nblk_c; { int rows; fused_decomposition(b->N, nt, nblk_c, rows); fc.rows_per_block = rows; }
-			double *part = b->d_partials + (size_t)t0 * b->nblk_max * ACC_COUNT;
+			double *part = b->d_partials + (size_t)t0 * b->nblk_max * RL;
 			for (int it = 0; it < sm->max_iters; ++it) {
 				{
 					TimedScope tsc(b->ctx, "fused_lk");
 					launch_fused_ssd(bc, b->ctx->img, fc, part, nblk_c, st);
 				}
-				if (!b->epilogue) launch_finish_track(bc, *sm, tc, part, nblk_c, st);
+				if (!b->epilogue || ncc) launch_finish_track(bc, *sm, tc, part, nblk_c, st);
 			}
 		}
 	}

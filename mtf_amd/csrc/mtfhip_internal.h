@@ -91,6 +91,8 @@ struct TrackState {
 	double *init_corners_hm; /* [B][12] */
 	int *active;        /* [B] 1 while the target still iterates */
 	int *n_iters;       /* [B] */
+	const double *ncc;    /* [B][8] NCC scalars (mean(I0), |I0 - mean|, ...), NULL for SSD */
+	const double *ncc_tm; /* [B][52] NCC template moments: sum J0 | sum I0 J0 | Gram(J0) */
 };
 
 struct FusedArgs {

@@ -2273,40 +2273,48 @@ __global__ __launch_bounds__(kBlock) void k_score_finish(const double *unit_sums
 template <bool COHERENT>
 __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts,
 	const double *partials, int nblk, int t) {
-	__shared__ double acc_s[ACC_COUNT];
+	__shared__ double acc_s[NCC_ACC_COUNT];   /* >= ACC_COUNT */
 	__shared__ double A[8][9];
 	__shared__ double dps[8];
-	__shared__ double h0s[64], Ws[9], crs[8], ics[12];
+	__shared__ double h0s[64], Ws[9], crs[8], ics[12], tms[52], ncs[2];
 	const int lane = threadIdx.x;
 	const bool wv0 = lane < 64;
 	const int S = bv.S;
+	/* NCC: the reduced row holds raw moments (NCC_* slots, NCC_ACC_COUNT wide); tms = sum J0 | sum I0 J0 | Gram(J0) of the
+	 * template, ncs = mean(I0), |I0 - mean|.  The calling workgroup then has at least 128 threads. */
+	const bool ncc = bv.am == MTFHIP_AM_NCC;
+	const int RL = ncc ? (int)NCC_ACC_COUNT : (int)ACC_COUNT;
 	/* every global operand of this target -- the `active` flag included -- is requested up front, in parallel across
 	 * the lanes, and only then is the flag tested: one memory round trip instead of two (flag, then operands); the
 	 * rest of the routine runs out of LDS / registers */
 	const int act = ts.active[t];
 	int n_it_prev = 0;
-	double v_h0 = 0, v_w = 0, v_cr = 0, v_ic = 0, v_acc = 0;
+	double v_h0 = 0, v_w = 0, v_cr = 0, v_ic = 0, v_acc = 0, v_tm = 0, v_nc = 0;
 	if (wv0) {
 		v_h0 = ts.h0[(size_t)t * 64 + lane];
 		if (lane < 9) v_w = bv.warps[9 * t + lane];
 		if (lane < 8) v_cr = ts.corners[8 * t + lane];
 		if (lane < 12) v_ic = ts.init_corners_hm[12 * t + lane];
 		n_it_prev = ts.n_iters[t];
-		if (lane < ACC_COUNT) {
-			const double *p = partials + (size_t)t * nblk * ACC_COUNT + lane;
-			auto ld = [&](size_t off) -> double {
-				if constexpr (COHERENT) return __hip_atomic_load(p + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				else return p[off];
-			};
-			double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-			int b = 0;
-			for (; b + 3 < nblk; b += 4) {
-				s0 += ld((size_t)b * ACC_COUNT); s1 += ld((size_t)(b + 1) * ACC_COUNT);
-				s2 += ld((size_t)(b + 2) * ACC_COUNT); s3 += ld((size_t)(b + 3) * ACC_COUNT);
-			}
-			for (; b < nblk; ++b) s0 += ld((size_t)b * ACC_COUNT);
-			v_acc = (s0 + s1) + (s2 + s3);
+		if (ncc) {
+			if (lane < 52) v_tm = ts.ncc_tm[(size_t)t * 52 + lane];
+			if (lane < 2) v_nc = ts.ncc[(size_t)t * 8 + lane];
 		}
+	}
+	if (lane < RL) {
+		const double *p = partials + (size_t)t * nblk * RL + lane;
+		auto ld = [&](size_t off) -> double {
+			if constexpr (COHERENT) return __hip_atomic_load(p + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			else return p[off];
+		};
+		double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+		int b = 0;
+		for (; b + 3 < nblk; b += 4) {
+			s0 += ld((size_t)b * RL); s1 += ld((size_t)(b + 1) * RL);
+			s2 += ld((size_t)(b + 2) * RL); s3 += ld((size_t)(b + 3) * RL);
+		}
+		for (; b < nblk; ++b) s0 += ld((size_t)b * RL);
+		v_acc = (s0 + s1) + (s2 + s3);
 	}
 	if (!act) return;
 	if (wv0) {
@@ -2314,26 +2322,66 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 		if (lane < 9) Ws[lane] = v_w;
 		if (lane < 8) crs[lane] = v_cr;
 		if (lane < 12) ics[lane] = v_ic;
-		if (lane < ACC_COUNT) { acc_s[lane] = v_acc; ts.acc[(size_t)t * ACC_COUNT + lane] = v_acc; }
+		if (lane < 52) tms[lane] = v_tm;
+		if (lane < 2) ncs[lane] = v_nc;
 	}
+	if (lane < RL) { acc_s[lane] = v_acc; ts.acc[(size_t)t * RL + lane] = v_acc; }
 	__syncthreads();
 	const int i = (lane >> 3) & 7, j = lane & 7;
 	const bool use_h0 = (sm.hess_type == 0) || (sm.sm == MTFHIP_SM_ICLK);
 	const bool sum_h0 = (sm.sm == MTFHIP_SM_ESM) && (sm.hess_type == 2 || sm.hess_type == 4);
 	const double gscale = (sm.sm == MTFHIP_SM_ESM) ? 0.5 : 1.0;
+	/* NCC from its moments (ncc_assemble in mtfhip_api.hip is the host twin; formulas and citations there) */
+	const double nN = (double)bv.N;
+	const double n_mt = ncc ? acc_s[NCC_IT] / nN : 0.0, n_m0 = ncs[0], n_c = ncc ? ncs[1] : 1.0;
+	const double n_b2 = ncc ? acc_s[NCC_IT2] - nN * n_mt * n_mt : 1.0, n_b = ncc ? sqrt(n_b2) : 1.0;
+	const double n_f = ncc ? (acc_s[NCC_I0IT] - nN * n_m0 * n_mt) / (n_b * n_c) : 0.0;
+	auto mom = [&](int which, int c0, int ct, int s) -> double {   /* which: 0 J0, 1 Jt, 2 their mean */
+		const double v0 = c0 >= 0 ? tms[c0 + s] : acc_s[NCC_ITJ0 + s], vt = acc_s[ct + s];
+		return which == 0 ? v0 : (which == 1 ? vt : (v0 + vt) / 2);
+	};
+	auto n_ut = [&](int which, int s) { return (mom(which, -1, NCC_ITJ, s) - n_mt * mom(which, 0, NCC_SJ, s)) / n_b2; };
+	auto n_u0 = [&](int which, int s) { return (mom(which, 8, NCC_I0J, s) - n_m0 * mom(which, 0, NCC_SJ, s)) / (n_b * n_c); };
+	auto n_hess = [&](int kind, int which, int r, int c, int kk) -> double {   /* kind: 0 init, 1 curr, 2 self */
+		const double gram = which == 0 ? tms[16 + kk] : acc_s[NCC_GRAM + kk];
+		const double G = -(gram - mom(which, 0, NCC_SJ, r) * mom(which, 0, NCC_SJ, c) / nN) / n_b2;
+		const double utr = n_ut(which, r), utc = n_ut(which, c);
+		if (kind == 2) return G + utr * utc;
+		const double u0r = n_u0(which, r), u0c = n_u0(which, c);
+		return n_f * G - utr * u0c - u0r * utc + 3 * (kind == 1 ? utr * utc : u0r * u0c);
+	};
 	auto h_entry = [&](int r, int c) -> double {
 		if (r >= S || c >= S) return r == c ? -1.0 : 0.0;
 		const int a = r < c ? r : c, b2 = r < c ? c : r;
 		const int kk = a * 8 - (a * (a - 1)) / 2 + (b2 - a);
+		if (ncc) {
+			const int ht = sm.hess_type;
+			const double h0v = h0s[b2 * S + a];
+			if (ht == 0) return h0v;
+			if (sm.sm == MTFHIP_SM_ICLK) return n_hess(0, 0, r, c, kk);
+			if (sm.sm == MTFHIP_SM_FCLK || ht == 1 || ht == 5) return n_hess(ht == 1 ? 2 : 1, 1, r, c, kk);
+			if (ht == 2) return 0.5 * (n_hess(2, 1, r, c, kk) + h0v);
+			if (ht == 3) return n_hess(1, 2, r, c, kk);
+			return 0.5 * (n_hess(0, 0, r, c, kk) + n_hess(1, 1, r, c, kk));
+		}
 		double v = use_h0 ? h0s[b2 * S + a] : -acc_s[ACC_H + kk];
 		if (sum_h0) v = (v + h0s[b2 * S + a]) * 0.5;
 		return v;
+	};
+	auto g_entry = [&](int s) -> double {
+		if (!ncc) return gscale * acc_s[ACC_G + s];
+		auto cj = [&](int which) { return n_u0(which, s) - n_f * n_ut(which, s); };
+		auto ij = [&](int which) { return (n_b / n_c) * (n_ut(which, s) - n_f * n_u0(which, s)); };
+		if (sm.sm == MTFHIP_SM_FCLK) return cj(1);
+		if (sm.sm == MTFHIP_SM_ICLK) return ij(0);
+		if (sm.jac_type == 0) return cj(2);
+		return 0.5 * (cj(1) - ij(0));
 	};
 	const double dii = h_entry(i, i), djj = h_entry(j, j);
 	const double si = dii != 0 ? 1.0 / sqrt(fabs(dii)) : 1.0, sj = djj != 0 ? 1.0 / sqrt(fabs(djj)) : 1.0;
 	if (wv0) {
 		A[i][j] = h_entry(i, j) * si * sj;
-		if (j == 0) A[i][8] = (i < S ? gscale * acc_s[ACC_G + i] : 0.0) * si;
+		if (j == 0) A[i][8] = (i < S ? g_entry(i) : 0.0) * si;
 	}
 	__syncthreads();
 #pragma unroll
@@ -2421,7 +2469,7 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 	if (change < sm.epsilon || n_it >= sm.max_iters) ts.active[t] = 0;
 }
 /* stand-alone finish: one wave per target */
-__global__ __launch_bounds__(64) void k_finish_track(BatchView bv, mtfhip_sm_desc sm, TrackState ts,
+__global__ __launch_bounds__(128) void k_finish_track(BatchView bv, mtfhip_sm_desc sm, TrackState ts,
 	const double *partials, int nblk) {
 	finish_track_body<false>(bv, sm, ts, partials, nblk, blockIdx.x);
 }
@@ -2977,7 +3025,8 @@ void launch_sample_candidates(const BatchView &bv, const ImgView &im, const doub
 }
 void launch_finish_track(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, const double *partials,
 	int nblk, hipStream_t st) {
-	hipLaunchKernelGGL(k_finish_track, dim3(bv.B), dim3(64), 0, st, bv, sm, ts, partials, nblk);
+	/* NCC rows are 72 wide: two waves load them, the first one solves */
+	hipLaunchKernelGGL(k_finish_track, dim3(bv.B), dim3(bv.am == MTFHIP_AM_NCC ? 128 : 64), 0, st, bv, sm, ts, partials, nblk);
 }
 
 } // namespace mtfhip

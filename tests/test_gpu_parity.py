@@ -261,20 +261,34 @@ def _fused_follow(oracle, gpu_ctx, frame, am, case, materialize, grid):
             b.read(L.BUF_IT)
 
 
+@pytest.mark.parametrize("extra", [dict(), dict(hess_type=5, jac_type=0), dict(hess_type=2)], ids=["default", "std", "ht2"])
+@pytest.mark.parametrize("sm_kind,ssm", [(L.SM_ESM, L.SSM_HOMOGRAPHY), (L.SM_FCLK, L.SSM_AFFINE), (L.SM_ICLK, L.SSM_HOMOGRAPHY)])
+def test_device_side_loop_ncc(oracle, gpu_ctx, frame, sm_kind, ssm, extra):
+    """the device-side loop with NCC: k_fused_ncc + the moment assembly and solve inside k_finish_track"""
+    if sm_kind != L.SM_ESM and extra.get("hess_type") == 5:
+        pytest.skip("ESM-only Hessian type")
+    _device_loop(oracle, gpu_ctx, frame, sm_kind, ssm, L.AM_NCC, 100, extra)   # > kIclkTrackMaxPix: not the one-launch kernel
+
+
 @pytest.mark.parametrize("sm_kind,ssm", [(L.SM_ESM, L.SSM_HOMOGRAPHY), (L.SM_FCLK, L.SSM_HOMOGRAPHY),
                                          (L.SM_ICLK, L.SSM_AFFINE), (L.SM_ICLK, L.SSM_HOMOGRAPHY)])
 def test_device_side_loop_matches_oracle_tracker(oracle, gpu_ctx, frame, sm_kind, ssm):
+    _device_loop(oracle, gpu_ctx, frame, sm_kind, ssm, L.AM_SSD, 40, dict())
+
+
+def _device_loop(oracle, gpu_ctx, frame, sm_kind, ssm, am, res, extra):
     """mtfhip_batch_track (solve + update + convergence test on the device) lands on the oracle's
     final corners and iteration count, for several independent targets in one batch."""
     rng = np.random.default_rng(23)
-    res, B = 40, 5
+    B = 5
     centres = [(150.0 + 60 * i, 200.0 + 25 * i) for i in range(B)]
     p_true = synth.random_small_homography(rng, 0.4)
     frame2 = synth.warp_frame(frame, p_true, (256.0, 256.0))
     corners = np.stack([synth.square_corners(cx, cy, 70) for cx, cy in centres])
     params = dict(leven_marq=0, max_iters=25, epsilon=1e-4)
+    params.update(extra)
     gpu_ctx.set_image(frame)
-    b = mtf_amd.Batch(gpu_ctx, L.AM_SSD, ssm, res, res, B)
+    b = mtf_amd.Batch(gpu_ctx, am, ssm, res, res, B)
     b.set_corners(corners)
     sm = mtf_amd.sm_desc(sm_kind, materialize=0, **params)
     b.init_template(sm)
@@ -282,7 +296,7 @@ def test_device_side_loop_matches_oracle_tracker(oracle, gpu_ctx, frame, sm_kind
     n_it, final = b.track(sm)
     for t in range(B):
         o_ssm = oracle.SSM(ssm, res, res)
-        o_am = oracle.AM(L.AM_SSD, res, res)
+        o_am = oracle.AM(am, res, res)
         o_am.set_curr_img(frame)
         trk = oracle.Tracker(sm_kind, o_am, o_ssm, **params)
         trk.initialize(corners[t])
