@@ -406,7 +406,7 @@ extern "C" {
 /* ------------------------------------------------------------------ deferred fusion (see mtfhip_batch::Lazy) */
 static inline void touch(mtfhip_batch *b, int id) { ++b->lz.ver[id]; }
 static inline void touch_all(mtfhip_batch *b) { for (int i = 0; i < MTFHIP_BUF_COUNT; ++i) ++b->lz.ver[i]; }
-static int lazy_flush(mtfhip_batch *b);
+static int lazy_flush(mtfhip_batch *b, bool pts = true);
 static int ensure_df(mtfhip_batch *b);
 static int ensure_one(mtfhip_batch *b, bool curr);
 static void stale_clear(mtfhip_batch *b, bool df0, bool dft);
@@ -419,6 +419,8 @@ static int lazy_flush_ctx(mtfhip_ctx *c) {   /* called by everything that replac
 	return MTFHIP_OK;
 }
 #define FLUSH(b) do { if (b) { int _rc = lazy_flush(b); if (_rc) return _rc; } } while (0)
+/* for entry points whose own kernels never read the current points (the AM's reductions over It / I0 / J buffers) */
+#define FLUSH_AM(b) do { if (b) { int _rc = lazy_flush(b, false); if (_rc) return _rc; } } while (0)
 
 /* ------------------------------------------------------------------ context */
 const char *mtfhip_last_error(void) { return g_last_error.c_str(); }
@@ -1397,14 +1399,14 @@ int mtfhip_am_update_init_grad(mtfhip_batch *b) {
 int mtfhip_am_get_similarity(mtfhip_batch *b, double *f) {
 	if (!b || !f) return fail(MTFHIP_ERR_INVALID_ARG, "get_similarity: NULL argument");
 	TRY(lazy_try_similarity(b));
-	FLUSH(b);
+	FLUSH_AM(b);
 	for (int t = 0; t < b->B; ++t) f[t] = b->th[t].f;
 	return MTFHIP_OK;
 }
 int mtfhip_am_get_likelihood(mtfhip_batch *b, double *l) {
 	if (!b || !l) return fail(MTFHIP_ERR_INVALID_ARG, "get_likelihood: NULL argument");
 	TRY(lazy_try_similarity(b));
-	FLUSH(b);
+	FLUSH_AM(b);
 	for (int t = 0; t < b->B; ++t) {
 		double f = b->th[t].f;
 		if (b->desc.am == MTFHIP_AM_SSD) l[t] = std::exp(-b->desc.likelihood_alpha * std::sqrt(-f / (double)b->N));
@@ -1482,9 +1484,10 @@ static int protect_stale(mtfhip_batch *b, bool w0, bool wt) {
 	return MTFHIP_OK;
 }
 /* replays the recorded calls through the un-fused kernels, in the order they were made */
-static int lazy_flush(mtfhip_batch *b) {
+static int lazy_flush(mtfhip_batch *b, bool pts) {
 	mtfhip_batch::Lazy &L = b->lz;
-	TRY(ensure_pts(b));   /* whatever follows a flush may launch a kernel that reads the current points */
+	/* whatever follows a full flush may launch a kernel that reads the current points; so may the replayed calls */
+	if (pts || L.pv || L.gp || L.pg || L.pj) TRY(ensure_pts(b));
 	if (!L.any()) return MTFHIP_OK;
 	struct Op { long seq; int kind; };
 	Op ops[8]; int n = 0;
@@ -1658,7 +1661,7 @@ int mtfhip_am_cmpt_init_jacobian(mtfhip_batch *b, int j0_buf, double *g) {
 	TRY(am_supported(b, "cmptInitJacobian"));
 	TRY(j_ready(b, j0_buf, "cmptInitJacobian"));
 	{ int done; TRY(lazy_try_fused(b, LAZY_INIT_JAC, j0_buf, -1, g, &done)); if (done) return MTFHIP_OK; }
-	FLUSH(b);
+	FLUSH_AM(b);
 	TRY(ensure_df(b));
 	return gemv_to_host(b, b->buf[MTFHIP_BUF_DF_DI0], j0_buf, nullptr, -1, 0, g, 0);
 }
@@ -1667,7 +1670,7 @@ int mtfhip_am_cmpt_curr_jacobian(mtfhip_batch *b, int jt_buf, double *g) {
 	TRY(am_supported(b, "cmptCurrJacobian"));
 	TRY(j_ready(b, jt_buf, "cmptCurrJacobian"));
 	{ int done; TRY(lazy_try_fused(b, LAZY_CURR_JAC, jt_buf, -1, g, &done)); if (done) return MTFHIP_OK; }
-	FLUSH(b);
+	FLUSH_AM(b);
 	TRY(ensure_df(b));
 	return gemv_to_host(b, b->buf[MTFHIP_BUF_DF_DIT], jt_buf, nullptr, -1, 0, g, 0);
 }
@@ -1677,7 +1680,7 @@ int mtfhip_am_cmpt_difference_of_jacobians(mtfhip_batch *b, int j0_buf, int jt_b
 	TRY(j_ready(b, j0_buf, "cmptDifferenceOfJacobians"));
 	TRY(j_ready(b, jt_buf, "cmptDifferenceOfJacobians"));
 	{ int done; TRY(lazy_try_fused(b, LAZY_DIFF_JAC, j0_buf, jt_buf, g, &done)); if (done) return MTFHIP_OK; }
-	FLUSH(b);
+	FLUSH_AM(b);
 	TRY(ensure_df(b));
 	if (b->desc.am != MTFHIP_AM_SSD) /* (df_dIt * dIt_dp) - (df_dI0 * dI0_dp), NCC.cc:268-280, AppearanceModel.h:161-164 */
 		return gemv_to_host(b, b->buf[MTFHIP_BUF_DF_DIT], jt_buf, b->buf[MTFHIP_BUF_DF_DI0], j0_buf, 0, g, 1);
@@ -1724,7 +1727,7 @@ static int gram_to_host(mtfhip_batch *b, int j_buf, double *H, double scale, boo
 	return MTFHIP_OK;
 }
 int mtfhip_am_cmpt_init_hessian(mtfhip_batch *b, int j0_buf, double *H) {
-	FLUSH(b);
+	FLUSH_AM(b);
 	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_init_hessian: NULL argument");
 	TRY(am_supported(b, "cmptInitHessian"));
 	TRY(j_ready(b, j0_buf, "cmptInitHessian"));
@@ -1733,7 +1736,7 @@ int mtfhip_am_cmpt_init_hessian(mtfhip_batch *b, int j0_buf, double *H) {
 	return gram_to_host(b, j0_buf, H, -1.0, false);
 }
 int mtfhip_am_cmpt_curr_hessian(mtfhip_batch *b, int jt_buf, double *H) {
-	FLUSH(b);
+	FLUSH_AM(b);
 	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_curr_hessian: NULL argument");
 	TRY(am_supported(b, "cmptCurrHessian"));
 	TRY(j_ready(b, jt_buf, "cmptCurrHessian"));
@@ -1742,7 +1745,7 @@ int mtfhip_am_cmpt_curr_hessian(mtfhip_batch *b, int jt_buf, double *H) {
 	return gram_to_host(b, jt_buf, H, -1.0, false);
 }
 int mtfhip_am_cmpt_self_hessian(mtfhip_batch *b, int jt_buf, double *H) {
-	FLUSH(b);
+	FLUSH_AM(b);
 	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_self_hessian: NULL argument");
 	TRY(am_supported(b, "cmptSelfHessian"));
 	TRY(j_ready(b, jt_buf, "cmptSelfHessian"));
@@ -1751,7 +1754,7 @@ int mtfhip_am_cmpt_self_hessian(mtfhip_batch *b, int jt_buf, double *H) {
 	return gram_to_host(b, jt_buf, H, -1.0, false);
 }
 int mtfhip_am_cmpt_sum_of_hessians(mtfhip_batch *b, int j0_buf, int jt_buf, double *H) {
-	FLUSH(b);
+	FLUSH_AM(b);
 	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_sum_of_hessians: NULL argument");
 	TRY(am_supported(b, "cmptSumOfHessians"));
 	TRY(j_ready(b, j0_buf, "cmptSumOfHessians"));
@@ -1871,7 +1874,7 @@ int mtfhip_ssm_cmpt_pix_hessian(mtfhip_batch *b, int variant, int hess_buf, int 
 }
 
 int mtfhip_sm_mean_pix_hessian(mtfhip_batch *b) {
-	FLUSH(b);
+	FLUSH_AM(b);
 	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "mean_pix_hessian: NULL batch");
 	if (!b->buf[MTFHIP_BUF_D2I0_DP2] || !b->buf[MTFHIP_BUF_D2IT_DP2]) return fail(MTFHIP_ERR_LOGIC, "mean_pix_hessian: init / curr pixel Hessians not computed");
 	TRY(ensure_buf(b, MTFHIP_BUF_D2IM_DP2));
@@ -1902,21 +1905,21 @@ static int add_second_order(mtfhip_batch *b, int d2a, int d2b, const double *dev
 }
 /* SSDBase.cc:313-343 ; NCC.cc:391-400 ; MI.cc:659-673 */
 int mtfhip_am_cmpt_init_hessian2(mtfhip_batch *b, int j0_buf, int d2_buf, double *H) {
-	FLUSH(b);
+	FLUSH_AM(b);
 	if (b) TRY(ensure_df(b));   /* the second-order terms are weighted by df_dI */
 	TRY(mtfhip_am_cmpt_init_hessian(b, j0_buf, H));
 	return add_second_order(b, d2_buf, -1, b->buf[MTFHIP_BUF_DF_DI0], H);
 }
 /* SSDBase.cc:345-375 ; NCC.cc:401-410 ; MI.cc:680-694 */
 int mtfhip_am_cmpt_curr_hessian2(mtfhip_batch *b, int jt_buf, int d2_buf, double *H) {
-	FLUSH(b);
+	FLUSH_AM(b);
 	if (b) TRY(ensure_df(b));   /* the second-order terms are weighted by df_dI */
 	TRY(mtfhip_am_cmpt_curr_hessian(b, jt_buf, H));
 	return add_second_order(b, d2_buf, -1, b->buf[MTFHIP_BUF_DF_DIT], H);
 }
 /* SSD: first order only (SSDBase.h:95-98) ; NCC: am_func_not_implemeted (AppearanceModel.h:188-191) ; MI.cc:696-733 */
 int mtfhip_am_cmpt_self_hessian2(mtfhip_batch *b, int jt_buf, int d2_buf, double *H) {
-	FLUSH(b);
+	FLUSH_AM(b);
 	if (b) TRY(ensure_df(b));   /* the second-order terms are weighted by df_dI */
 	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_self_hessian (second order): NULL argument");
 	if (b->desc.am == MTFHIP_AM_NCC) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "ncc :: cmptSelfHessian(second order) :: function not implemented yet");
@@ -1931,7 +1934,7 @@ int mtfhip_am_cmpt_self_hessian2(mtfhip_batch *b, int jt_buf, int d2_buf, double
 }
 /* SSDBase.cc:377-415 (both pixel Hessians weighted by df_dI0) ; NCC / MI: generic AppearanceModel.h:209-219 */
 int mtfhip_am_cmpt_sum_of_hessians2(mtfhip_batch *b, int j0_buf, int jt_buf, int d20_buf, int d2t_buf, double *H) {
-	FLUSH(b);
+	FLUSH_AM(b);
 	if (b) TRY(ensure_df(b));   /* the second-order terms are weighted by df_dI */
 	if (!b || !H) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_sum_of_hessians (second order): NULL argument");
 	if (b->desc.am == MTFHIP_AM_SSD) {
