@@ -93,7 +93,7 @@ def build(force=False):
            [os.path.join(_HERE, "..", "include", "mtfhip.h")]
     newest = max(os.path.getmtime(p) for p in srcs)
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
-        subprocess.check_call(["make", "-C", CSRC, "-s", "-B"])
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-B", "-j%d" % min(8, os.cpu_count() or 1)])
     return LIB_PATH
 
 

@@ -1,0 +1,483 @@
+/*
+ * kernels_batch.hip -- the batch axis: PF / NN candidate scoring and sampling, GridTracker's one-launch ICLK patch loop
+ * (one of the translation units of libmtfhip.so; conventions and the shared device helpers: mtfhip_device.h)
+ */
+#include "mtfhip_device.h"
+
+namespace mtfhip {
+
+/* ===================================================================== */
+/* candidate scoring (PF / NN batch axis)                                 */
+/* ===================================================================== */
+/* One wave64 per candidate: setState -> updatePixVals -> updateSimilarity -> likelihood
+ * (SM/src/PF.cc:247-262, ProjectiveBase.cc:41-49, SSDBase.cc:75-96, SSD.h:41-43). */
+__global__ __launch_bounds__(kBlock) void k_score_candidates(BatchView bv, ImgView im, const double *states, int C,
+	double alpha, double norm_mult, double norm_add, double *lik, double *sim) {
+	const int lane = threadIdx.x & 63;
+	const int cand = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	if (cand >= C) return;
+	const int N = bv.N, S = bv.S;
+	const double *p = states + (size_t)cand * S;
+	double W[9];
+	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+		W[0] = 1 + p[0]; W[1] = p[1]; W[2] = p[2]; W[3] = p[3]; W[4] = 1 + p[4]; W[5] = p[5];
+		W[6] = p[6]; W[7] = p[7]; W[8] = 1;
+	} else {
+		W[0] = 1 + p[2]; W[1] = p[3]; W[2] = p[0]; W[3] = p[4]; W[4] = 1 + p[5]; W[5] = p[1];
+		W[6] = 0; W[7] = 0; W[8] = 1;
+	}
+	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]);
+	const double *iz = bv.buf[MTFHIP_BUF_INIT_Z];
+	const double2 *ih = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]);
+	const double *I0 = bv.buf[MTFHIP_BUF_I0];
+	double acc = 0.0;
+	for (int i = lane; i < N; i += 64) {
+		double2 q = bv.unit_z ? ip[i] : ih[i];
+		double z = bv.unit_z ? 1.0 : iz[i];
+		double hx = q.x, hy = q.y;
+		double wx, wy;
+		if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+			double cx = W[0] * hx + W[1] * hy + W[2] * z;
+			double cy = W[3] * hx + W[4] * hy + W[5] * z;
+			double d = W[6] * hx + W[7] * hy + W[8] * z;
+			wx = cx / d; wy = cy / d;
+		} else {
+			wx = W[0] * hx + W[1] * hy + W[2] * z;
+			wy = W[3] * hx + W[4] * hy + W[5] * z;
+		}
+		double r = (norm_mult * pix_val(im, wx, wy) + norm_add) - I0[i];
+		acc = fma(r, r, acc);
+	}
+#pragma unroll
+	for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+	if (lane == 0) {
+		double f = -acc / 2;
+		if (sim) sim[cand] = f;
+		if (lik) lik[cand] = exp(-alpha * sqrt(-f / (double)N));
+	}
+}
+
+/* LDS-staged candidate scoring.  All candidates of a frame sample the same template through slightly
+ * different warps, so a workgroup stages, once, (a) the template's homogeneous grid points and I0 and (b) the
+ * image tile that covers the template's bounding box plus a margin, then its 16 waves score CPW candidates
+ * each entirely out of LDS: ds_read_b128 / _b64 for the template, two ds_read2_b32 for the four texels.
+ * A sample whose bilinear cell is not inside the tile (a far-out candidate) takes the global-memory path;
+ * either way the reference's sampling expression is evaluated unchanged (imgUtils.h:91-113). */
+constexpr int kScoreBlock = 1024;
+constexpr int kScoreSplit = 4;      /* a candidate's pixels are cut into this many work units (load balance) */
+template <int SSM>
+__global__ __launch_bounds__(kScoreBlock) void k_score_candidates_lds(BatchView bv, ImgView im, const double *states, int C,
+	int tx0, int ty0, int tw, int th, double norm_mult, double norm_add, double *unit_sums /* [C][kScoreSplit] */) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const int N = bv.N;
+	double2 *sp = reinterpret_cast<double2 *>(smem);                 /* N grid points (x, y or X, Y) */
+	double *sz = reinterpret_cast<double *>(sp + N);                  /* N third homogeneous coordinates */
+	double *s0 = sz + N;                                              /* N template values */
+	float *tile = reinterpret_cast<float *>(s0 + N);                  /* th x tw texels */
+	const double2 *gp = reinterpret_cast<const double2 *>(bv.buf[bv.unit_z ? MTFHIP_BUF_INIT_PTS : MTFHIP_BUF_INIT_HXY]);
+	const double *gz = bv.buf[MTFHIP_BUF_INIT_Z], *g0 = bv.buf[MTFHIP_BUF_I0];
+	for (int i = threadIdx.x; i < N; i += kScoreBlock) { sp[i] = gp[i]; sz[i] = bv.unit_z ? 1.0 : gz[i]; s0[i] = g0[i]; }
+	for (int i = threadIdx.x; i < tw * th; i += kScoreBlock) {
+		const int yy = ty0 + i / tw, xx = tx0 + i % tw;
+		tile[i] = (yy >= 0 && yy < im.h && xx >= 0 && xx < im.w) ? im.data[(size_t)yy * im.stride + xx] : 0.0f;
+	}
+	__syncthreads();
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int n_waves = gridDim.x * (kScoreBlock / 64);
+	const double w = (double)(unsigned)im.w, h = (double)(unsigned)im.h;
+	const int chunk = ((N + kScoreSplit - 1) / kScoreSplit + 63) / 64 * 64;   /* pixels per work unit, multiple of 64 */
+	/* work unit u = (candidate, pixel chunk); waves take units round-robin over the whole launch */
+	for (int u = blockIdx.x * (kScoreBlock / 64) + wave; u < C * kScoreSplit; u += n_waves) {
+		const int cand = u / kScoreSplit, part = u % kScoreSplit;
+		const double *p = states + (size_t)cand * bv.S;
+		double W[9];
+		if (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+			W[0] = 1 + p[0]; W[1] = p[1]; W[2] = p[2]; W[3] = p[3]; W[4] = 1 + p[4]; W[5] = p[5]; W[6] = p[6]; W[7] = p[7]; W[8] = 1;
+		} else {
+			W[0] = 1 + p[2]; W[1] = p[3]; W[2] = p[0]; W[3] = p[4]; W[4] = 1 + p[5]; W[5] = p[1]; W[6] = 0; W[7] = 0; W[8] = 1;
+		}
+		double acc = 0.0;
+		const int i_end = min(N, (part + 1) * chunk);
+		for (int i = part * chunk + lane; i < i_end; i += 64) {
+			const double2 hp = sp[i];
+			const double z = sz[i];
+			double x, y;
+			if (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+				const double cx = W[0] * hp.x + W[1] * hp.y + W[2] * z, cy = W[3] * hp.x + W[4] * hp.y + W[5] * z;
+				const double d = W[6] * hp.x + W[7] * hp.y + W[8] * z;
+				x = cx / d; y = cy / d;
+			} else {
+				x = W[0] * hp.x + W[1] * hp.y + W[2] * z; y = W[3] * hp.x + W[4] * hp.y + W[5] * z;
+			}
+			double v = 128.0;
+			if (!((x < 0) || (x >= w) || (y < 0) || (y >= h))) {
+				const int lx = (int)x, ly = (int)y;
+				const double dx = x - lx, dy = y - ly;
+				const int ux = dx == 0 ? lx : lx + 1, uy = dy == 0 ? ly : ly + 1;
+				if (ux < im.w && uy < im.h) {
+					double t00, t01, t10, t11;
+					if (lx >= tx0 && ux < tx0 + tw && ly >= ty0 && uy < ty0 + th) {
+						const float *r0 = tile + (ly - ty0) * tw + (lx - tx0), *r1 = tile + (uy - ty0) * tw + (lx - tx0);
+						t00 = r0[0]; t01 = r0[ux - lx]; t10 = r1[0]; t11 = r1[ux - lx];
+					} else {
+						const float *r0 = im.data + (size_t)ly * im.stride, *r1 = im.data + (size_t)uy * im.stride;
+						t00 = r0[lx]; t01 = r0[ux]; t10 = r1[lx]; t11 = r1[ux];
+					}
+					v = t00 * (1 - dx) * (1 - dy) + t01 * dx * (1 - dy) + t10 * (1 - dx) * dy + t11 * dx * dy;
+				}
+			}
+			const double r = (norm_mult * v + norm_add) - s0[i];
+			acc = fma(r, r, acc);
+		}
+#pragma unroll
+		for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+		if (lane == 0) unit_sums[u] = acc;
+	}
+}
+/* fixed-order sum of a candidate's work units, then f = -|r|^2/2 and the SSD likelihood (SSD.h:41-43) */
+__global__ __launch_bounds__(kBlock) void k_score_finish(const double *unit_sums, int C, int N, double alpha, double *lik, double *sim) {
+	const int c = blockIdx.x * kBlock + threadIdx.x;
+	if (c >= C) return;
+	double s = 0;
+#pragma unroll
+	for (int q = 0; q < kScoreSplit; ++q) s += unit_sums[(size_t)c * kScoreSplit + q];
+	const double f = -s / 2;
+	if (sim) sim[c] = f;
+	if (lik) lik[c] = exp(-alpha * sqrt(-f / (double)N));
+}
+
+
+/* ===================================================================== */
+/* one-launch inverse-compositional tracker for small patches (GridTracker) */
+/* ===================================================================== */
+/* sum of K per-thread values over the workgroup, result broadcast to every thread */
+template <int K>
+__device__ __forceinline__ void block_allsum(double *v, double *lds /* [4][K] */) {
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+	for (int k = 0; k < K; ++k)
+#pragma unroll
+		for (int m = 32; m >= 1; m >>= 1) v[k] += __shfl_xor(v[k], m);
+	__syncthreads();   /* previous round's readers are done with lds */
+	if (lane == 0) {
+#pragma unroll
+		for (int k = 0; k < K; ++k) lds[wave * K + k] = v[k];
+	}
+	__syncthreads();
+#pragma unroll
+	for (int k = 0; k < K; ++k) v[k] = (lds[k] + lds[K + k]) + (lds[2 * K + k] + lds[3 * K + k]);
+}
+
+/* NN-SM dataset generation (SM/src/NT/NN.cc:131-191): per sample state, setState -> updatePixVals ->
+ * updateDistFeat into row `c` of the n_samples x N feature matrix.  SSD's feature is the patch itself
+ * (AM/include/mtf/AM/SSDBase.h:116-125); NCC's is the centred patch over its norm (AM/src/NCC.cc:530-537),
+ * applied by k_ncc_feature_rows afterwards.  One workgroup per sample. */
+__global__ __launch_bounds__(kBlock) void k_sample_candidates(BatchView bv, ImgView im, const double *states, int C,
+	double norm_mult, double norm_add, double *feat) {
+	const int cand = blockIdx.x;
+	const int N = bv.N, S = bv.S;
+	const double *p = states + (size_t)cand * S;
+	double W[9];
+	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+		W[0] = 1 + p[0]; W[1] = p[1]; W[2] = p[2]; W[3] = p[3]; W[4] = 1 + p[4]; W[5] = p[5]; W[6] = p[6]; W[7] = p[7]; W[8] = 1;
+	} else {
+		W[0] = 1 + p[2]; W[1] = p[3]; W[2] = p[0]; W[3] = p[4]; W[4] = 1 + p[5]; W[5] = p[1]; W[6] = 0; W[7] = 0; W[8] = 1;
+	}
+	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[bv.unit_z ? MTFHIP_BUF_INIT_PTS : MTFHIP_BUF_INIT_HXY]);
+	const double *iz = bv.buf[MTFHIP_BUF_INIT_Z];
+	double *out = feat + (size_t)cand * N;
+	for (int i = threadIdx.x; i < N; i += kBlock) {
+		const double2 q = ip[i];
+		const double z = bv.unit_z ? 1.0 : iz[i];
+		double wx, wy;
+		if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+			const double cx = W[0] * q.x + W[1] * q.y + W[2] * z, cy = W[3] * q.x + W[4] * q.y + W[5] * z;
+			const double d = W[6] * q.x + W[7] * q.y + W[8] * z;
+			wx = cx / d; wy = cy / d;
+		} else {
+			wx = W[0] * q.x + W[1] * q.y + W[2] * z; wy = W[3] * q.x + W[4] * q.y + W[5] * z;
+		}
+		out[i] = norm_mult * pix_val(im, wx, wy) + norm_add;
+	}
+}
+/* NCC::updateDistFeat NCC.cc:530-537: row <- (row - mean) / ||row - mean|| */
+__global__ __launch_bounds__(kBlock) void k_ncc_feature_rows(int N, double *feat) {
+	__shared__ double red[4];
+	double *row = feat + (size_t)blockIdx.x * N;
+	double s[1] = {0.0};
+	for (int i = threadIdx.x; i < N; i += kBlock) s[0] += row[i];
+	block_allsum<1>(s, red);
+	const double mean = s[0] / (double)N;
+	double q[1] = {0.0};
+	for (int i = threadIdx.x; i < N; i += kBlock) { const double d = row[i] - mean; q[0] = fma(d, d, q[0]); }
+	block_allsum<1>(q, red);
+	const double sd = sqrt(q[0]);
+	for (int i = threadIdx.x; i < N; i += kBlock) row[i] = (row[i] - mean) / sd;
+}
+
+/*
+ * nt::ICLK::update (SM/src/NT/ICLK.cc:160-299) for one patch per workgroup, all iterations inside the
+ * kernel: updatePixVals -> updateSimilarity -> updateInitGrad -> cmptInitJacobian(g, J0) ->
+ * dp = -H0^-1 g (hess_type InitialSelf: the Hessian is the constant computed by initialize) ->
+ * invertState -> compositionalUpdate -> corner-change test.  AM = SSD (SSDBase.cc:75-96,138) or NCC
+ * (NCC.cc:124-194, 236-250).  This is what GridTracker's per-patch loop (SM/src/GridTracker.cc:247-261)
+ * becomes: 256 patches = 256 workgroups, one launch per frame, no host round trips.
+ * Patch operands (grid points, I0, J0: ~35 KB for 25x25 affine) are re-read from L2 every iteration.
+ */
+/* getPixVal<Linear, Constant> without control flow: the four texel loads are always issued (from clamped, valid
+ * addresses) and the border value is selected afterwards, so several independent samples of one thread can be in
+ * flight together.  Same expression and operation order as pix_val() for every in-range sample. */
+__device__ __forceinline__ double pix_val_select(const ImgView &im, double x, double y) {
+	const double w = (double)(unsigned int)im.w, h = (double)(unsigned int)im.h;
+	const bool in0 = !((x < 0) || (x >= w) || (y < 0) || (y >= h));
+	const double xs = in0 ? x : 0.0, ys = in0 ? y : 0.0;
+	const int lx = (int)xs, ly = (int)ys;
+	const double dx = xs - lx, dy = ys - ly;
+	const int ux = dx == 0 ? lx : lx + 1, uy = dy == 0 ? ly : ly + 1;
+	const bool in1 = !(ux >= im.w || uy >= im.h);
+	const int uxc = in1 ? ux : lx, uyc = in1 ? uy : ly;
+	const float *r0 = im.data + (size_t)ly * im.stride, *r1 = im.data + (size_t)uyc * im.stride;
+	const double t00 = r0[lx], t01 = r0[uxc], t10 = r1[lx], t11 = r1[uxc];
+	const double v = t00 * (1 - dx) * (1 - dy) + t01 * dx * (1 - dy) + t10 * (1 - dx) * dy + t11 * dx * dy;
+	return (in0 && in1) ? v : 128.0;
+}
+
+template <int AM, int PPT>
+__global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im, mtfhip_sm_desc sm, TrackState ts,
+	const double *h0inv_all, const double *ncc_sc_all, double norm_mult, double norm_add) {
+	__shared__ double red[4 * 8];
+	__shared__ double sW[9], sSt[8], sHinv[64], sIc[12], sCr[8];
+	__shared__ int sDone;
+	const int t = blockIdx.x, N = bv.N, S = bv.S, tid = threadIdx.x;
+	const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY;
+	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * N;
+	const double2 *ih = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]) + (size_t)t * N;
+	const double *iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * N;
+	const double *I0 = bv.buf[MTFHIP_BUF_I0] + (size_t)t * N;
+	const double *J0 = bv.buf[MTFHIP_BUF_J0] + (size_t)t * N * S;
+	const double m0 = AM == MTFHIP_AM_NCC ? ncc_sc_all[t * 8 + 0] : 0.0;
+	const double cn = AM == MTFHIP_AM_NCC ? ncc_sc_all[t * 8 + 1] : 1.0;
+	/* Everything that does not change over the iterations is fetched ONCE: the thread's grid points, template values
+	 * and J0 rows into registers, the inverse Hessian and the corner sets into LDS.  An iteration then touches global
+	 * memory only for its texels (the loop is a chain of dependent latencies: one workgroup per patch, nothing to
+	 * overlap with). */
+	constexpr bool HOIST_J = PPT <= 4;   /* 8 J0 values per pixel: beyond 4 pixels per thread they would spill */
+	constexpr bool HOIST_P = PPT <= 8;   /* grid point + z: 3 doubles per pixel */
+	double2 hpv[HOIST_P ? PPT : 1];
+	double zv[HOIST_P ? PPT : 1], i0v[PPT], j0v[HOIST_J ? PPT : 1][8];
+#pragma unroll
+	for (int k = 0; k < PPT; ++k) {
+		const int i = tid + k * kBlock;
+		const int ic = i < N ? i : N - 1;
+		if constexpr (HOIST_P) {
+			hpv[k] = bv.unit_z ? ip[ic] : ih[ic];
+			zv[k] = bv.unit_z ? 1.0 : iz[ic];
+		}
+		i0v[k] = i < N ? I0[ic] : 0.0;
+		if constexpr (HOIST_J) {
+#pragma unroll
+			for (int s = 0; s < 8; ++s) j0v[k][s] = (s < S && i < N) ? J0[(size_t)s * N + ic] : 0.0;
+		}
+	}
+	if (tid < 64) sHinv[tid] = h0inv_all[(size_t)t * 64 + tid];
+	if (tid < 12) sIc[tid] = ts.init_corners_hm[12 * t + tid];
+	if (tid < 8) sCr[tid] = ts.corners[8 * t + tid];
+	if (tid < 9) sW[tid] = bv.warps[9 * t + tid];
+	if (tid < 8) sSt[tid] = bv.states[8 * t + tid];
+	if (tid == 0) sDone = 0;
+	__syncthreads();
+	int n_it = 0;
+	double f_last = 0;
+	for (int it = 0; it < sm.max_iters; ++it) {
+		double W[9];
+#pragma unroll
+		for (int q = 0; q < 9; ++q) W[q] = sW[q];
+		/* ---- updatePixVals: It = sample(curr_warp * init_pts) ---- */
+		double itv[PPT];
+		double s1[1] = {0.0};
+#pragma unroll
+		for (int k = 0; k < PPT; ++k) {
+			const int ick = (tid + k * kBlock < N) ? tid + k * kBlock : N - 1;
+			const double2 hp = HOIST_P ? hpv[HOIST_P ? k : 0] : (bv.unit_z ? ip[ick] : ih[ick]);
+			const double z = HOIST_P ? zv[HOIST_P ? k : 0] : (bv.unit_z ? 1.0 : iz[ick]);
+			double wx, wy;
+			if (hom) {
+				const double cx = W[0] * hp.x + W[1] * hp.y + W[2] * z, cy = W[3] * hp.x + W[4] * hp.y + W[5] * z;
+				const double d = W[6] * hp.x + W[7] * hp.y + W[8] * z;
+				wx = cx / d; wy = cy / d;
+			} else {
+				wx = W[0] * hp.x + W[1] * hp.y + W[2] * z; wy = W[3] * hp.x + W[4] * hp.y + W[5] * z;
+			}
+			const double v = norm_mult * pix_val_select(im, wx, wy) + norm_add;
+			itv[k] = (tid + k * kBlock < N) ? v : 0.0;
+		}
+#pragma unroll
+		for (int k = 0; k < PPT; ++k) if (tid + k * kBlock < N) s1[0] += itv[k];
+		double dfv[PPT];
+		if constexpr (AM == MTFHIP_AM_NCC) {
+			/* ---- NCC::updateSimilarity + updateInitGrad ---- */
+			block_allsum<1>(s1, red);
+			const double mt = s1[0] / (double)N;
+			double s2[2] = {0.0, 0.0};
+#pragma unroll
+			for (int k = 0; k < PPT; ++k)
+				if (tid + k * kBlock < N) {
+					const double a0 = i0v[k] - m0, at = itv[k] - mt;
+					s2[0] = fma(a0, at, s2[0]); s2[1] = fma(at, at, s2[1]);
+				}
+			block_allsum<2>(s2, red);
+			const double b = sqrt(s2[1]);
+			const double f = s2[0] / (b * cn);
+			f_last = f;
+			double s3[1] = {0.0};
+#pragma unroll
+			for (int k = 0; k < PPT; ++k) {
+				dfv[k] = 0;
+				if (tid + k * kBlock < N) {
+					const double itc_b = (itv[k] - mt) / b, i0c_c = (i0v[k] - m0) / cn;
+					dfv[k] = (itc_b - f * i0c_c) / cn;
+					s3[0] += dfv[k];
+				}
+			}
+			block_allsum<1>(s3, red);
+			const double gm = s3[0] / (double)N;
+#pragma unroll
+			for (int k = 0; k < PPT; ++k) dfv[k] -= gm;
+		} else {
+			/* ---- SSD: df_dI0 = I_diff = It - I0, f = -|r|^2 / 2 ---- */
+			double s2[1] = {0.0};
+#pragma unroll
+			for (int k = 0; k < PPT; ++k) {
+				dfv[k] = (tid + k * kBlock < N) ? itv[k] - i0v[k] : 0.0;
+				s2[0] = fma(dfv[k], dfv[k], s2[0]);
+			}
+			block_allsum<1>(s2, red);
+			f_last = -s2[0] / 2;
+		}
+		/* ---- cmptInitJacobian: g = df_dI0 * J0 ---- */
+		double g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+		for (int k = 0; k < PPT; ++k) {
+			if (tid + k * kBlock < N) {
+#pragma unroll
+				for (int s = 0; s < 8; ++s)
+					if (s < S) g[s] = fma(dfv[k], HOIST_J ? j0v[HOIST_J ? k : 0][s] : J0[(size_t)s * N + tid + k * kBlock], g[s]);
+			}
+		}
+		block_allsum<8>(g, red);
+		/* ---- solve, invert, compose, converge (thread 0) ---- */
+		if (tid == 0) {
+			double dp[8];
+			for (int r = 0; r < 8; ++r) {
+				double acc = 0;
+				if (r < S) for (int c = 0; c < S; ++c) acc += sHinv[c * S + r] * g[c];
+				dp[r] = -acc;
+			}
+			double U[9];
+			if (hom) { U[0] = 1 + dp[0]; U[1] = dp[1]; U[2] = dp[2]; U[3] = dp[3]; U[4] = 1 + dp[4]; U[5] = dp[5]; U[6] = dp[6]; U[7] = dp[7]; U[8] = 1; }
+			else { U[0] = 1 + dp[2]; U[1] = dp[3]; U[2] = dp[0]; U[3] = dp[4]; U[4] = 1 + dp[5]; U[5] = dp[1]; U[6] = 0; U[7] = 0; U[8] = 1; }
+			double c9[9];
+			c9[0] = U[4] * U[8] - U[5] * U[7]; c9[1] = U[2] * U[7] - U[1] * U[8]; c9[2] = U[1] * U[5] - U[2] * U[4];
+			c9[3] = U[5] * U[6] - U[3] * U[8]; c9[4] = U[0] * U[8] - U[2] * U[6]; c9[5] = U[2] * U[3] - U[0] * U[5];
+			c9[6] = U[3] * U[7] - U[4] * U[6]; c9[7] = U[1] * U[6] - U[0] * U[7]; c9[8] = U[0] * U[4] - U[1] * U[3];
+			const double inv_det = 1.0 / (U[0] * c9[0] + U[1] * c9[3] + U[2] * c9[6]);
+			for (int q = 0; q < 9; ++q) c9[q] *= inv_det;
+			const double n22 = c9[8];
+			for (int q = 0; q < 9; ++q) U[q] = c9[q] / n22;
+			U[0] = 1 + (U[0] - 1); U[4] = 1 + (U[4] - 1); U[8] = 1;
+			if (!hom) { U[6] = 0; U[7] = 0; }
+			double Wn[9];
+			for (int r = 0; r < 3; ++r)
+				for (int c = 0; c < 3; ++c) Wn[3 * r + c] = W[3 * r] * U[c] + W[3 * r + 1] * U[3 + c] + W[3 * r + 2] * U[6 + c];
+			if (hom) {
+				const double w22 = Wn[8];
+				for (int q = 0; q < 9; ++q) Wn[q] /= w22;
+				sSt[0] = Wn[0] - 1; sSt[1] = Wn[1]; sSt[2] = Wn[2]; sSt[3] = Wn[3]; sSt[4] = Wn[4] - 1; sSt[5] = Wn[5]; sSt[6] = Wn[6]; sSt[7] = Wn[7];
+			} else {
+				sSt[0] = Wn[2]; sSt[1] = Wn[5]; sSt[2] = Wn[0] - 1; sSt[3] = Wn[1]; sSt[4] = Wn[3]; sSt[5] = Wn[4] - 1; sSt[6] = 0; sSt[7] = 0;
+			}
+			for (int q = 0; q < 9; ++q) sW[q] = Wn[q];
+			double change = 0;
+			for (int q = 0; q < 4; ++q) {
+				const double X = sIc[3 * q], Y = sIc[3 * q + 1], Z = sIc[3 * q + 2];
+				double nx = Wn[0] * X + Wn[1] * Y + Wn[2] * Z, ny = Wn[3] * X + Wn[4] * Y + Wn[5] * Z;
+				if (hom) { const double d = Wn[6] * X + Wn[7] * Y + Wn[8] * Z; nx = nx / d; ny = ny / d; }
+				const double ddx = sCr[2 * q] - nx, ddy = sCr[2 * q + 1] - ny;
+				change += ddx * ddx + ddy * ddy;
+				sCr[2 * q] = nx; sCr[2 * q + 1] = ny;
+			}
+			if (change < sm.epsilon) sDone = 1;
+		}
+		++n_it;
+		__syncthreads();
+		if (sDone) break;
+	}
+	if (tid < 9) bv.warps[9 * t + tid] = sW[tid];
+	if (tid < 8) bv.states[8 * t + tid] = sSt[tid];
+	if (tid < 8) ts.corners[8 * t + tid] = sCr[tid];
+	if (tid == 0) { ts.n_iters[t] = n_it; ts.acc[(size_t)t * ACC_COUNT + ACC_RR] = f_last; }
+}
+
+
+/* ===================================================================== */
+/* launchers                                                              */
+/* ===================================================================== */
+
+/* LDS-staged scorer: returns false (nothing launched) when template + tile do not fit the 160 KB of a CU */
+bool launch_score_candidates_lds(const BatchView &bv, const ImgView &im, const double *dev_states, int C, int tx0, int ty0,
+	int tw, int th, double likelihood_alpha, double *unit_sums, double *dev_lik, double *dev_sim, hipStream_t st) {
+	const size_t lds = (size_t)bv.N * (16 + 8 + 8) + (size_t)tw * th * 4;
+	if (lds > 160 * 1024 || tw <= 1 || th <= 1) return false;
+	static bool attr_set = false;
+	if (!attr_set) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_candidates_lds<MTFHIP_SSM_HOMOGRAPHY>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_candidates_lds<MTFHIP_SSM_AFFINE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		attr_set = true;
+	}
+	/* one workgroup per CU (the staged template + tile take most of its LDS); work units are dealt round-robin */
+	const int units = C * kScoreSplit, waves = kScoreBlock / 64;
+	int nb = (units + waves - 1) / waves;
+	if (nb > 256) nb = 256;
+	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY)
+		hipLaunchKernelGGL(k_score_candidates_lds<MTFHIP_SSM_HOMOGRAPHY>, dim3(nb), dim3(kScoreBlock), lds, st, bv, im, dev_states, C,
+			tx0, ty0, tw, th, 1.0, 0.0, unit_sums);
+	else
+		hipLaunchKernelGGL(k_score_candidates_lds<MTFHIP_SSM_AFFINE>, dim3(nb), dim3(kScoreBlock), lds, st, bv, im, dev_states, C,
+			tx0, ty0, tw, th, 1.0, 0.0, unit_sums);
+	hipLaunchKernelGGL(k_score_finish, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, st, unit_sums, C, bv.N, likelihood_alpha, dev_lik, dev_sim);
+	return true;
+}
+void launch_score_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C,
+	double likelihood_alpha, double *dev_lik, double *dev_sim, hipStream_t st) {
+	int nb = (C + (kBlock / 64) - 1) / (kBlock / 64);
+	hipLaunchKernelGGL(k_score_candidates, dim3(nb), dim3(kBlock), 0, st, bv, im, dev_states, C, likelihood_alpha,
+		1.0, 0.0, dev_lik, dev_sim);
+}
+
+template <int AM>
+static bool launch_iclk_track_am(const BatchView &bv, const ImgView &im, const mtfhip_sm_desc &sm, const TrackState &ts,
+	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, hipStream_t st) {
+	const int ppt = (bv.N + kBlock - 1) / kBlock;
+#define MTFHIP_ICLK_CASE(P) hipLaunchKernelGGL((k_iclk_track<AM, P>), dim3(bv.B), dim3(kBlock), 0, st, bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add)
+	if (ppt <= 1) MTFHIP_ICLK_CASE(1);
+	else if (ppt <= 2) MTFHIP_ICLK_CASE(2);
+	else if (ppt <= 3) MTFHIP_ICLK_CASE(3);
+	else if (ppt <= 4) MTFHIP_ICLK_CASE(4);
+	else if (ppt <= 8) MTFHIP_ICLK_CASE(8);
+	else if (ppt <= 16) MTFHIP_ICLK_CASE(16);
+	else return false;
+#undef MTFHIP_ICLK_CASE
+	return true;
+}
+bool launch_iclk_track(const BatchView &bv, const ImgView &im, const mtfhip_sm_desc &sm, const TrackState &ts,
+	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, hipStream_t st) {
+	if (bv.am == MTFHIP_AM_NCC) return launch_iclk_track_am<MTFHIP_AM_NCC>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, st);
+	return launch_iclk_track_am<MTFHIP_AM_SSD>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, st);
+}
+void launch_sample_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C, double norm_mult,
+	double norm_add, double *dev_feat, hipStream_t st) {
+	hipLaunchKernelGGL(k_sample_candidates, dim3(C), dim3(kBlock), 0, st, bv, im, dev_states, C, norm_mult, norm_add, dev_feat);
+	if (bv.am == MTFHIP_AM_NCC) hipLaunchKernelGGL(k_ncc_feature_rows, dim3(C), dim3(kBlock), 0, st, bv.N, dev_feat);
+}
+
+} // namespace mtfhip

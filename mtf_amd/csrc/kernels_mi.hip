@@ -1,0 +1,527 @@
+/*
+ * kernels_mi.hip -- mutual information (AM/src/MI.cc): B-spline Parzen histograms, gradients, first-order Hessians
+ * (one of the translation units of libmtfhip.so; conventions and the shared device helpers: mtfhip_device.h)
+ */
+#include "mtfhip_device.h"
+
+namespace mtfhip {
+
+/* ---------------------------------------------------------------------------------------------
+ * MI (AM/src/MI.cc): cubic B-spline Parzen histograms.  The reference materialises n_bins x N weight /
+ * gradient / Hessian matrices and n_bins^2 x N joint-gradient matrices (MI.cc:297-302, 164 MB per
+ * 400x400 target); each pixel only touches a 4-bin window, so here the window is recomputed from the
+ * pixel value (I0 / It) wherever it is needed and only the n_bins^2-sized tables live in memory.
+ * Per-target table block `tb` (doubles): see the MI_* offsets.  "A" is the image whose B-spline gradient /
+ * Hessian enters (rows r of the joint table), "B" the one whose plain weights enter (columns c).
+ * ------------------------------------------------------------------------------------------- */
+/* utils::bSpl3WithGrad Utilities/include/mtf/Utilities/histUtils.h:206-226 (truncated constant kept, :11) */
+__device__ __forceinline__ void bspl3_with_grad(double &val, double &diff, double x) {
+	const double k2by3 = 0.66666666666;
+	val = 0; diff = 0;
+	if ((x > -2) && (x <= -1)) { double t = 2 + x; diff = (t * t) / 2; val = (diff * t) / 3; }
+	else if ((x > -1) && (x <= 0)) { double t = x / 2; val = k2by3 - x * x * (1 + t); diff = -x * (t + x + 2); }
+	else if ((x > 0) && (x <= 1)) { double t = x / 2; val = k2by3 - x * x * (1 - t); diff = x * (t + x - 2); }
+	else if ((x > 1) && (x < 2)) { double t = 2 - x; diff = -(t * t) / 2; val = -(diff * t) / 3; }
+}
+/* utils::bSpl3Hess histUtils.h:271-283 */
+__device__ __forceinline__ double bspl3_hess(double x) {
+	if ((x > -2) && (x <= -1)) return 2 + x;
+	if ((x > -1) && (x <= 0)) return -(3 * x + 2);
+	if ((x > 0) && (x <= 1)) return 3 * x - 2;
+	if ((x > 1) && (x < 2)) return 2 - x;
+	return 0;
+}
+/* the <= 4-bin window of a pixel value: ids [lo, hi] = std_bspl_ids.row((int)v) (MI.cc:114-117), weights
+ * w[k], derivative d[k] (already * -hist_norm_mult as MI.cc:229,360) and second derivative h[k] */
+struct BsplWin { int lo, n; double w[4], d[4], h[4]; };
+/* piece F of bSpl3WithGrad / bSpl3Hess, F = 0..3 in the order of the reference's if-chain; F >= 4: outside the support */
+template <int F>
+__device__ __forceinline__ void bspl3_piece(double &val, double &diff, double &hess, double x) {
+	const double k2by3 = 0.66666666666;
+	if constexpr (F == 0) { double t = 2 + x; diff = (t * t) / 2; val = (diff * t) / 3; hess = 2 + x; }
+	else if constexpr (F == 1) { double t = x / 2; val = k2by3 - x * x * (1 + t); diff = -x * (t + x + 2); hess = -(3 * x + 2); }
+	else if constexpr (F == 2) { double t = x / 2; val = k2by3 - x * x * (1 - t); diff = x * (t + x - 2); hess = 3 * x - 2; }
+	else if constexpr (F == 3) { double t = 2 - x; diff = -(t * t) / 2; val = -(diff * t) / 3; hess = 2 - x; }
+	else { val = 0; diff = 0; hess = 0; }
+}
+/* The window's first bin is lo = max(0, fl - 1), so tap k sits at x_k = lo - v + k: in piece k of the spline when
+ * fl >= 1 (x_0 in (-2, -1]) and in piece k + 1 when the window is clamped at bin 0 (fl == 0, x_0 in (-1, 0]) -- the
+ * reference's bSpl3WithGradFast<bspl_id> (histUtils.h:176-204) rests on the same fact.  When every active lane of the
+ * wave is in one of those two regular situations the pieces are evaluated straight-line (both candidates, one select)
+ * instead of walking the four-range if-chain per tap, which diverges across the wave and costs all four pieces anyway.
+ * x_k is accumulated by `diff += 1` exactly like MI.cc:232,359; the additions are exact for fl >= 1, and for fl == 0
+ * x_2 can round onto the closed end of piece 2 only for v = 1 - 2^-53 (one double), where the two pieces agree to 1e-12. */
+__device__ __forceinline__ BsplWin bspl_window(double v, int nb, double norm_mult, bool want_hess) {
+	BsplWin s;
+	const int fl = (int)v;
+	s.lo = max(0, fl - 1);
+	const int hi = min(nb - 1, fl + 2);
+	s.n = hi - s.lo + 1;
+	double diff = s.lo - v;
+	const bool sh = fl < 1;
+	const bool regular = sh ? ((diff > -1) & (diff <= 0)) : ((diff > -2) & (diff <= -1));
+	if (__builtin_amdgcn_ballot_w64(!regular) == 0) {
+		double x[4];
+		x[0] = diff; x[1] = x[0] + 1; x[2] = x[1] + 1; x[3] = x[2] + 1;
+		double v0, d0, h0, v1, d1, h1;
+		bspl3_piece<0>(v0, d0, h0, x[0]); bspl3_piece<1>(v1, d1, h1, x[0]);
+		s.w[0] = sh ? v1 : v0; s.d[0] = sh ? d1 : d0; s.h[0] = sh ? h1 : h0;
+		bspl3_piece<1>(v0, d0, h0, x[1]); bspl3_piece<2>(v1, d1, h1, x[1]);
+		s.w[1] = sh ? v1 : v0; s.d[1] = sh ? d1 : d0; s.h[1] = sh ? h1 : h0;
+		bspl3_piece<2>(v0, d0, h0, x[2]); bspl3_piece<3>(v1, d1, h1, x[2]);
+		s.w[2] = sh ? v1 : v0; s.d[2] = sh ? d1 : d0; s.h[2] = sh ? h1 : h0;
+		bspl3_piece<3>(v0, d0, h0, x[3]);
+		s.w[3] = sh ? 0.0 : v0; s.d[3] = sh ? 0.0 : d0; s.h[3] = sh ? 0.0 : h0;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const bool in = k < s.n;
+			s.w[k] = in ? s.w[k] : 0.0;
+			s.d[k] = in ? s.d[k] * -norm_mult : 0.0;
+			s.h[k] = (in && want_hess) ? norm_mult * s.h[k] : 0.0;
+		}
+		return s;
+	}
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		s.w[k] = 0; s.d[k] = 0; s.h[k] = 0;
+		if (k < s.n) {
+			bspl3_with_grad(s.w[k], s.d[k], diff);
+			s.d[k] *= -norm_mult;
+			if (want_hess) s.h[k] = norm_mult * bspl3_hess(diff);
+			diff += 1;   /* ++curr_diff, MI.cc:232,359 */
+		}
+	}
+	return s;
+}
+__device__ __forceinline__ void lds_add(double *p, double v) {
+	__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+/* ---------------------------------------------------------------------------------------------
+ * Bin-owner accumulation.  MI's histograms and the `joint_hist_jacobian` rows are scatter-adds whose targets are
+ * decided by pixel intensities; neighbouring pixels hit the same few bins, so LDS atomics serialise almost
+ * completely inside a wave (the first version: 682 us for one Hessian of 8 x 160 000 px).  Here the roles are
+ * swapped per 64-pixel chunk: in "pixel mode" lane p evaluates pixel p's B-spline windows and writes them as DENSE
+ * n_bins vectors to the wave's LDS slab; in "bin mode" lane q owns the bin pair (r, c) = (q / nb, q % nb) and walks
+ * the 64 staged pixels, accumulating in registers.  No atomics, no conflicts (lanes with equal r read one address:
+ * a broadcast), deterministic sums.  pairs per lane = ceil(nb^2 / 64): 1 for the reference's 8 bins, 4 for 16.
+ * ------------------------------------------------------------------------------------------- */
+constexpr int kMiPairs = (MI_NB * MI_NB + 63) / 64;
+constexpr int kMiRow = 65;
+/* Bin mode on the matrix cores.  Over a 64-pixel chunk the bin-mode sums are small dense products whose K axis is the
+ * pixel: joint(r, c) = sum_p wa[r][p] wb[c][p] is (nb x 64)(64 x nb), and the joint_hist_jacobian block
+ * Q[(r, c)][s] = sum_p (gd[r][p] wd[c][p]) J[p][s] is (nb^2 x 64)(64 x S).  v_mfma_f64_16x16x4_f64 takes K = 4 pixels
+ * per issue; operand layout (checked on gfx950 with tools/mfma_layout_test.hip): lane l supplies A[i = l % 16][k = l / 16]
+ * and B[k = l / 16][j = l % 16] and receives D[i = l / 16 + 4 v][j = l % 16] in element v of its 4-double accumulator.
+ * The operands are read straight from the staged slabs (bin-major rows: lanes of one k read consecutive rows, the same
+ * column -> no bank conflict beyond the 2-way of 64-bit reads).  Dense FP64 products are exact in the same sense as the
+ * VALU path (fused multiply-add per k); only the summation order over pixels differs (4-pixel groups). */
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+
+/* histogram of A and joint histogram A x B (MI.cc:222-235 init, :245-252 init joint, :352-367 update,
+ * :641-649 self).  Block partial rows: [nb hist | nb*nb joint] */
+template <bool MFMA>
+__global__ __launch_bounds__(kBlock) void k_mi_hist(int N, int nb, double norm_mult, const double *A_all,
+	const double *B_all, double *partials, int nblk, int row_len) {
+	extern __shared__ __attribute__((aligned(16))) double dyn[];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	/* slabs are bin-major with rows of kMiRow = 65 doubles: pixel-mode lanes write consecutive words, bin-mode lanes
+	 * (different r, same p) land in different banks */
+	double *wa = dyn + (size_t)wave * 2 * nb * kMiRow;  /* [nb][65] dense A weights of this wave's chunk */
+	double *wb = wa + nb * kMiRow;                      /* [nb][65] dense B weights */
+	const int t = blockIdx.y;
+	const double *A = A_all + (size_t)t * N, *Bv = B_all + (size_t)t * N;
+	double accj[kMiPairs], acch = 0.0;
+	mfma_d4 cj = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+	for (int m = 0; m < kMiPairs; ++m) accj[m] = 0.0;
+	int pr[kMiPairs], pc[kMiPairs];
+#pragma unroll
+	for (int m = 0; m < kMiPairs; ++m) { const int q = lane + 64 * m; pr[m] = q < nb * nb ? q / nb : -1; pc[m] = q < nb * nb ? q % nb : 0; }
+	/* a wave walks only a handful of chunks and each needs its pixel values first: the next chunk's are requested
+	 * before the current one is processed, otherwise every chunk starts with an exposed HBM round trip */
+	int base = (blockIdx.x * (kBlock / 64) + wave) * 64;
+	double a_nx = 0.0, b_nx = 0.0;
+	if (base + lane < N) { a_nx = A[base + lane]; b_nx = Bv[base + lane]; }
+	for (; base < N; base += nblk * kBlock) {
+		const int i = base + lane;
+		const double a_cur = a_nx, b_cur = b_nx;
+		{
+			const int in = i + nblk * kBlock;
+			if (in < N) { a_nx = A[in]; b_nx = Bv[in]; }
+		}
+		for (int k2 = 0; k2 < nb; ++k2) { wa[k2 * kMiRow + lane] = 0.0; wb[k2 * kMiRow + lane] = 0.0; }
+		if (i < N) {
+			const BsplWin a = bspl_window(a_cur, nb, norm_mult, false);
+			const BsplWin b = bspl_window(b_cur, nb, norm_mult, false);
+			/* static indices only: a runtime-indexed window array would live in scratch memory */
+#pragma unroll
+			for (int r = 0; r < 4; ++r) if (r < a.n) wa[(a.lo + r) * kMiRow + lane] = a.w[r];
+#pragma unroll
+			for (int c = 0; c < 4; ++c) if (c < b.n) wb[(b.lo + c) * kMiRow + lane] = b.w[c];
+		}
+		__builtin_amdgcn_wave_barrier();
+		if constexpr (MFMA) {
+			/* one 16x16 tile: rows r, columns c; when nb < 16 column nb of B is all ones, so D[r][nb] is the histogram */
+			const int idx = lane & 15, kq = lane >> 4, row = idx < nb ? idx : nb - 1;
+#pragma unroll 4
+			for (int ks = 0; ks < 16; ++ks) {
+				const int p = 4 * ks + kq;
+				const double av = wa[row * kMiRow + p], bv = wb[row * kMiRow + p];
+				cj = __builtin_amdgcn_mfma_f64_16x16x4f64(idx < nb ? av : 0.0, idx < nb ? bv : (idx == nb ? 1.0 : 0.0), cj, 0, 0, 0);
+			}
+			if (nb == 16) {
+#pragma unroll 8
+				for (int p = 0; p < 64; ++p) if (lane < nb) acch += wa[lane * kMiRow + p];
+			}
+		} else {
+#pragma unroll 8
+			for (int p = 0; p < 64; ++p) {
+#pragma unroll
+				for (int m = 0; m < kMiPairs; ++m)
+					if (pr[m] >= 0) accj[m] = fma(wa[pr[m] * kMiRow + p], wb[pc[m] * kMiRow + p], accj[m]);
+				if (lane < nb) acch += wa[lane * kMiRow + p];
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
+	/* four waves -> one partial row per workgroup */
+	__syncthreads();
+	double *red = dyn;                                  /* [4][nb + nb*nb], the slabs are free now */
+	const int rl = nb + nb * nb;
+	if constexpr (MFMA) {
+		const int j = lane & 15;
+#pragma unroll
+		for (int v = 0; v < 4; ++v) {
+			const int i = (lane >> 4) + 4 * v;
+			if (i < nb && j < nb) red[wave * rl + nb + i * nb + j] = cj[v];
+			if (i < nb && j == nb) red[wave * rl + i] = cj[v];
+		}
+		if (nb == 16 && lane < nb) red[wave * rl + lane] = acch;
+	} else {
+		if (lane < nb) red[wave * rl + lane] = acch;
+#pragma unroll
+		for (int m = 0; m < kMiPairs; ++m)
+			if (pr[m] >= 0) red[wave * rl + nb + pr[m] * nb + pc[m]] = accj[m];
+	}
+	__syncthreads();
+	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * row_len;
+	for (int k2 = threadIdx.x; k2 < rl; k2 += kBlock) dst[k2] = (red[k2] + red[rl + k2]) + (red[2 * rl + k2] + red[3 * rl + k2]);
+}
+/* sums the block rows, applies pre-seeding and normalisation, logs, similarity and the gradient-factor
+ * table of the requested flavour (MI.cc:237-262, 369-381, 310-314, 399-403, 427-431, 651-658).
+ * mode 0: initialise (A = B = I0), 1: update (A = It, B = I0), 2: self (A = B = It) */
+__global__ __launch_bounds__(kBlock) void k_mi_hist_finish(int nb, double pre_seed, double norm_mult, int mode, int first_init,
+	const double *partials, int nblk, int row_len, double *tb_all, double *f_out) {
+	__shared__ double red[kBlock];
+	const int t = blockIdx.x;
+	double *tb = tb_all + (size_t)t * MI_SIZE;
+	const double *p = partials + (size_t)t * nblk * row_len;
+	const double hist_seed = nb * pre_seed;
+	for (int k = threadIdx.x; k < nb + nb * nb; k += kBlock) {
+		const double s = column_sum(p + k, nblk, row_len);
+		if (k < nb) {
+			const double hv = (s + hist_seed) * norm_mult;
+			if (mode == 0) { tb[MI_HIST_INIT + k] = hv; tb[MI_LOG_INIT + k] = log(hv); if (first_init) { tb[MI_HIST_CURR + k] = hv; tb[MI_LOG_CURR + k] = log(hv); } }
+			else if (mode == 1) { tb[MI_HIST_CURR + k] = hv; tb[MI_LOG_CURR + k] = log(hv); }
+		} else {
+			const int q = k - nb, r = q / nb, c = q % nb;
+			const double jv = (s + pre_seed) * norm_mult;
+			if (mode == 2) tb[MI_SELF_JOINT + r * MI_NB + c] = jv;
+			else if (mode == 1 || first_init) { tb[MI_JOINT + r * MI_NB + c] = jv; tb[MI_JOINT_LOG + r * MI_NB + c] = log(jv); }
+		}
+	}
+	__syncthreads();
+	double part = 0;
+	for (int q = threadIdx.x; q < nb * nb; q += kBlock) {
+		const int r = q / nb, c = q % nb;
+		if (mode == 2) {
+			const double lg = log(tb[MI_SELF_JOINT + r * MI_NB + c]);
+			tb[MI_T_SELF + r * MI_NB + c] = 1 + lg - tb[MI_LOG_CURR + r];
+		} else if (mode == 1 || first_init) {
+			const double jv = tb[MI_JOINT + r * MI_NB + c], lg = tb[MI_JOINT_LOG + r * MI_NB + c];
+			const double lr = mode == 0 ? tb[MI_LOG_INIT + r] : tb[MI_LOG_CURR + r];
+			part += jv * (lg - lr - tb[MI_LOG_INIT + c]);
+			if (mode == 0) {
+				/* MI::initializeGrad MI.cc:310-314: both tables start as 1 + log(joint/init_hist(row)) */
+				const double v = 1 + lg - tb[MI_LOG_INIT + r];
+				tb[MI_T_INIT + r * MI_NB + c] = v; tb[MI_T_CURR + r * MI_NB + c] = v;
+			}
+		}
+	}
+	red[threadIdx.x] = part;
+	__syncthreads();
+	if (threadIdx.x == 0 && mode != 2) {
+		double s = 0;
+		for (int i = 0; i < kBlock; ++i) s += red[i];
+		f_out[t] = s;
+	}
+}
+/* gradient-factor tables refreshed by updateCurrGrad / updateInitGrad (MI.cc:399-403, 427-431) */
+__global__ __launch_bounds__(kBlock) void k_mi_factor(int nb, int curr, double *tb_all) {
+	double *tb = tb_all + (size_t)blockIdx.x * MI_SIZE;
+	for (int q = threadIdx.x; q < nb * nb; q += kBlock) {
+		const int r = q / nb, c = q % nb;
+		if (curr) tb[MI_T_CURR + r * MI_NB + c] = 1 + tb[MI_JOINT_LOG + r * MI_NB + c] - tb[MI_LOG_CURR + r];
+		else tb[MI_T_INIT + r * MI_NB + c] = 1 + tb[MI_JOINT_LOG + c * MI_NB + r] - tb[MI_LOG_INIT + r]; /* (init, curr) indexing */
+	}
+}
+/* df_dI[p] = sum_r sum_c gradA(r,p) * matB(c,p) * T(r,c)  (MI.cc:318-326, 406-415, 432-441) */
+__global__ __launch_bounds__(kBlock) void k_mi_grad(int N, int nb, double norm_mult, const double *A_all,
+	const double *B_all, const double *tb_all, int table_off, double *out_all) {
+	__shared__ double T[MI_NB * MI_NB];
+	const int t = blockIdx.y;
+	const double *tb = tb_all + (size_t)t * MI_SIZE + table_off;
+	for (int k = threadIdx.x; k < MI_NB * MI_NB; k += kBlock) T[k] = tb[k];
+	__syncthreads();
+	const double *A = A_all + (size_t)t * N, *Bv = B_all + (size_t)t * N;
+	double *out = out_all + (size_t)t * N;
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+		const BsplWin a = bspl_window(A[i], nb, norm_mult, false);
+		const BsplWin b = bspl_window(Bv[i], nb, norm_mult, false);
+		double acc = 0;
+#pragma unroll
+		for (int r = 0; r < 4; ++r)
+#pragma unroll
+			for (int c = 0; c < 4; ++c)
+				if (r < a.n && c < b.n) acc += a.d[r] * b.w[c] * T[(a.lo + r) * MI_NB + b.lo + c];
+		out[i] = acc;
+	}
+}
+/* first-order MI Hessians (MI.cc:461-513 init, 565-601 self (the returned pass), 603-637 curr):
+ *   Hsum  += hess_term(p) * Jrow Jrow^T,  hess_term = sum_r hessA(r) * sum_c matB(c) T(r,c)
+ *   Q[row(r,c)] += gradA(r) matB(c) Jrow          row(r,c) = (r,c), or (c,r) when transpose_q (init flavour)
+ * Block partial rows: [36 Hsum | nb*nb*S Q] */
+template <bool MFMA>   /* MFMA: nb == 8 (the reference's 8-bin histograms): 64 (r, c) rows = four 16-row tiles */
+__global__ __launch_bounds__(kBlock) void k_mi_hess(int N, int S, int nb, double norm_mult, const double *A_all,
+	const double *B_all, const double *tb_all, int table_off, int transpose_q, const double *J_all,
+	double *partials, int nblk, int row_len) {
+	extern __shared__ __attribute__((aligned(16))) double dyn[];
+	double *T = dyn;                                    /* MI_NB*MI_NB gradient-factor table */
+	double *red = dyn + MI_NB * MI_NB;                  /* 4 * 36 */
+	double *slabs = red + 4 * 36;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int slab = kMiRow * (2 * nb + kMaxS);
+	double *gd = slabs + (size_t)wave * slab;           /* [nb][65] dense curr_hist_grad-type vector of A */
+	double *wd = gd + nb * kMiRow;                      /* [nb][65] dense weights of B */
+	double *rw = wd + nb * kMiRow;                      /* [kMaxS][65] J rows */
+	const int t = blockIdx.y;
+	const double *tb = tb_all + (size_t)t * MI_SIZE + table_off;
+	for (int k2 = threadIdx.x; k2 < MI_NB * MI_NB; k2 += kBlock) T[k2] = tb[k2];
+	__syncthreads();
+	const double *A = A_all + (size_t)t * N, *Bv = B_all + (size_t)t * N;
+	const double *J = J_all + (size_t)t * N * S;
+	double acc[36];
+#pragma unroll
+	for (int k2 = 0; k2 < 36; ++k2) acc[k2] = 0.0;
+	constexpr int NQ = MFMA ? 1 : kMiPairs;
+	double accq[NQ][kMaxS];
+	int pr[NQ], pc[NQ];
+	mfma_d4 cq[4];
+#pragma unroll
+	for (int mt = 0; mt < 4; ++mt) cq[mt] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+	for (int m = 0; m < NQ; ++m) {
+		const int q = lane + 64 * m;
+		pr[m] = q < nb * nb ? q / nb : -1; pc[m] = q < nb * nb ? q % nb : 0;
+#pragma unroll
+		for (int s = 0; s < kMaxS; ++s) accq[m][s] = 0.0;
+	}
+	/* operands of the next chunk (two pixel values, S Jacobian entries) are requested before the current one is processed */
+	int base = (blockIdx.x * (kBlock / 64) + wave) * 64;
+	double a_nx = 0.0, b_nx = 0.0, row_nx[kMaxS];
+#pragma unroll
+	for (int s = 0; s < kMaxS; ++s) row_nx[s] = 0.0;
+	if (base + lane < N) {
+		a_nx = A[base + lane]; b_nx = Bv[base + lane];
+#pragma unroll
+		for (int s = 0; s < kMaxS; ++s) if (s < S) row_nx[s] = J[(size_t)s * N + base + lane];
+	}
+	for (; base < N; base += nblk * kBlock) {
+		const int i = base + lane;
+		const double a_cur = a_nx, b_cur = b_nx;
+		double row[kMaxS];
+#pragma unroll
+		for (int s = 0; s < kMaxS; ++s) row[s] = i < N ? row_nx[s] : 0.0;
+		{
+			const int in = i + nblk * kBlock;
+			if (in < N) {
+				a_nx = A[in]; b_nx = Bv[in];
+#pragma unroll
+				for (int s = 0; s < kMaxS; ++s) if (s < S) row_nx[s] = J[(size_t)s * N + in];
+			}
+		}
+		for (int k2 = 0; k2 < nb; ++k2) { gd[k2 * kMiRow + lane] = 0.0; wd[k2 * kMiRow + lane] = 0.0; }
+		if (i < N) {
+			/* pixel mode: windows, the scalar hess_term and its rank-1 contribution (MI.cc:478-496, 574-583, 620-629) */
+			const BsplWin a = bspl_window(a_cur, nb, norm_mult, true);
+			const BsplWin b = bspl_window(b_cur, nb, norm_mult, false);
+			double hess_term = 0;
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				if (r < a.n) {
+					double inner = 0;
+#pragma unroll
+					for (int c = 0; c < 4; ++c) if (c < b.n) inner += b.w[c] * T[(a.lo + r) * MI_NB + b.lo + c];
+					hess_term += a.h[r] * inner;
+					gd[(a.lo + r) * kMiRow + lane] = a.d[r];
+				}
+			}
+#pragma unroll
+			for (int c = 0; c < 4; ++c) if (c < b.n) wd[(b.lo + c) * kMiRow + lane] = b.w[c];
+			int k2 = 0;
+#pragma unroll
+			for (int x = 0; x < kMaxS; ++x) {
+				const double hx = hess_term * row[x];
+#pragma unroll
+				for (int y = x; y < kMaxS; ++y) { acc[k2] = fma(hx, row[y], acc[k2]); ++k2; }
+			}
+		}
+#pragma unroll
+		for (int s = 0; s < kMaxS; ++s) rw[s * kMiRow + lane] = row[s];
+		__builtin_amdgcn_wave_barrier();
+		/* bin mode: joint_hist_jacobian.row(r, c) += grad(r, p) * mat(c, p) * J.row(p)  (MI.cc:484-486, 576-577, 622-623) */
+		if constexpr (MFMA) {
+			/* tile mt holds rows 16 mt .. 16 mt + 15 = (r, c) with r = 2 mt + i / 8, c = i % 8; columns s (8 of 16 used) */
+			const int idx = lane & 15, kq = lane >> 4, cc = idx & 7, rh = idx >> 3;
+#pragma unroll 2
+			for (int ks = 0; ks < 16; ++ks) {
+				const int p = 4 * ks + kq;
+				const double jv = rw[cc * kMiRow + p];
+				const double bj = idx < kMaxS ? jv : 0.0;
+				const double wc = wd[cc * kMiRow + p];
+#pragma unroll
+				for (int mt = 0; mt < 4; ++mt)
+					cq[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(gd[(2 * mt + rh) * kMiRow + p] * wc, bj, cq[mt], 0, 0, 0);
+			}
+		} else {
+#pragma unroll 4
+			for (int p = 0; p < 64; ++p) {
+				double jr[kMaxS];
+#pragma unroll
+				for (int s = 0; s < kMaxS; ++s) jr[s] = rw[s * kMiRow + p];
+#pragma unroll
+				for (int m = 0; m < NQ; ++m) {
+					if (pr[m] >= 0) {
+						const double gr = gd[pr[m] * kMiRow + p] * wd[pc[m] * kMiRow + p];
+#pragma unroll
+						for (int s = 0; s < kMaxS; ++s) accq[m][s] = fma(gr, jr[s], accq[m][s]);
+					}
+				}
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
+	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * row_len;
+	block_reduce_store<36>(acc, dst, red);
+	__syncthreads();
+	/* the four waves' Q blocks through the (now free) slabs: [4][nb*nb*S], indexed as the finish expects */
+	double *qred = slabs;
+	const int ql = nb * nb * S;
+	if constexpr (MFMA) {
+		const int sidx = lane & 15;
+#pragma unroll
+		for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+			for (int v = 0; v < 4; ++v) {
+				const int rowq = 16 * mt + (lane >> 4) + 4 * v, r = rowq >> 3, c = rowq & 7;
+				const int row_idx = transpose_q ? c * nb + r : r * nb + c;
+				if (sidx < S) qred[wave * ql + row_idx * S + sidx] = cq[mt][v];
+			}
+	} else {
+#pragma unroll
+		for (int m = 0; m < NQ; ++m) {
+			if (pr[m] >= 0) {
+				const int row_idx = transpose_q ? pc[m] * nb + pr[m] : pr[m] * nb + pc[m];
+#pragma unroll
+				for (int s = 0; s < kMaxS; ++s) if (s < S) qred[wave * ql + row_idx * S + s] = accq[m][s];
+			}
+		}
+	}
+	__syncthreads();
+	for (int k2 = threadIdx.x; k2 < ql; k2 += kBlock)
+		dst[36 + k2] = (qred[k2] + qred[ql + k2]) + (qred[2 * ql + k2] + qred[3 * ql + k2]);
+}
+__global__ __launch_bounds__(kBlock) void k_mi_hess_finish(int S, int nb, const double *partials, int nblk, int row_len,
+	const double *tb_all, int joint_off, int hist_off, int transpose_q, double *out) {
+	extern __shared__ __attribute__((aligned(16))) double dyn[];
+	double *Q = dyn;               /* nb*nb*S */
+	double *Hs = dyn + nb * nb * S; /* 36 */
+	const int t = blockIdx.x;
+	const double *p = partials + (size_t)t * nblk * row_len;
+	const double *tb = tb_all + (size_t)t * MI_SIZE;
+	for (int k = threadIdx.x; k < 36 + nb * nb * S; k += kBlock) {
+		const double s = column_sum(p + k, nblk, row_len);
+		if (k < 36) Hs[k] = s; else Q[k - 36] = s;
+	}
+	__syncthreads();
+	if (threadIdx.x < 64) {
+		const int r2 = threadIdx.x >> 3, c2 = threadIdx.x & 7;
+		if (r2 < S && c2 < S) {
+			const int a = r2 < c2 ? r2 : c2, b2 = r2 < c2 ? c2 : r2;
+			double h = Hs[a * 8 - (a * (a - 1)) / 2 + (b2 - a)];
+			for (int rr = 0; rr < nb; ++rr)
+				for (int cc = 0; cc < nb; ++cc) {
+					/* Q row (rr,cc) is joint_hist_jacobian.row(linear_idx(rr,cc)); its factor uses joint(rr,cc) and the
+					 * histogram of the image whose gradient was taken: rows for curr/self, columns for the init flavour */
+					const double jv = tb[joint_off + rr * MI_NB + cc];
+					const double hv = tb[hist_off + (transpose_q ? cc : rr)];
+					const double fac = (1.0 / jv) - (1.0 / hv);
+					const double *q = Q + (size_t)(rr * nb + cc) * S;
+					h += q[r2] * q[c2] * fac;
+				}
+			out[(size_t)t * 64 + c2 * S + r2] = h;
+		}
+	}
+}
+
+
+/* ===================================================================== */
+/* launchers                                                              */
+/* ===================================================================== */
+void launch_mi_hist(const BatchView &bv, int nb, double norm_mult, const double *A, const double *Bv, double *partials,
+	int nblk, int row_len, hipStream_t st) {
+	/* per-wave staging slabs [64][2 nb]; the same LDS later holds the four waves' [nb + nb^2] rows */
+	const size_t lds = sizeof(double) * std::max<size_t>((size_t)4 * kMiRow * 2 * nb, (size_t)4 * (nb + nb * nb));
+	static const bool use_mfma = !(getenv("MTFHIP_MI_MFMA") && atoi(getenv("MTFHIP_MI_MFMA")) == 0);
+	if (use_mfma) hipLaunchKernelGGL(k_mi_hist<true>, grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, nb, norm_mult, A, Bv, partials, nblk, row_len);
+	else hipLaunchKernelGGL(k_mi_hist<false>, grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, nb, norm_mult, A, Bv, partials, nblk, row_len);
+}
+void launch_mi_hist_finish(const BatchView &bv, int nb, double pre_seed, double norm_mult, int mode, int first_init,
+	const double *partials, int nblk, int row_len, double *tb, double *f_out, hipStream_t st) {
+	hipLaunchKernelGGL(k_mi_hist_finish, dim3(bv.B), dim3(kBlock), 0, st, nb, pre_seed, norm_mult, mode, first_init, partials,
+		nblk, row_len, tb, f_out);
+}
+void launch_mi_factor(const BatchView &bv, int nb, int curr, double *tb, hipStream_t st) {
+	hipLaunchKernelGGL(k_mi_factor, dim3(bv.B), dim3(kBlock), 0, st, nb, curr, tb);
+}
+void launch_mi_grad(const BatchView &bv, int nb, double norm_mult, const double *A, const double *Bv, const double *tb,
+	int table_off, double *out, hipStream_t st) {
+	hipLaunchKernelGGL(k_mi_grad, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, nb, norm_mult, A, Bv,
+		tb, table_off, out);
+}
+void launch_mi_hess(const BatchView &bv, int nb, double norm_mult, const double *A, const double *Bv, const double *tb,
+	int table_off, int transpose_q, const double *J, double *partials, int nblk, int row_len, hipStream_t st) {
+	const size_t slabs = std::max<size_t>((size_t)4 * kMiRow * (2 * nb + kMaxS), (size_t)4 * nb * nb * bv.S);
+	const size_t lds = sizeof(double) * (MI_NB * MI_NB + 4 * 36 + slabs);
+	static bool attr_set = false;
+	if (!attr_set) {   /* 16 bins need 82 KB of dynamic LDS; the default cap is 64 KB */
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_mi_hess<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_mi_hess<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		attr_set = true;
+	}
+	static const bool use_mfma = !(getenv("MTFHIP_MI_MFMA") && atoi(getenv("MTFHIP_MI_MFMA")) == 0);
+	if (use_mfma && nb == 8)
+		hipLaunchKernelGGL(k_mi_hess<true>, grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, bv.S, nb, norm_mult, A, Bv, tb, table_off,
+			transpose_q, J, partials, nblk, row_len);
+	else
+		hipLaunchKernelGGL(k_mi_hess<false>, grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, bv.S, nb, norm_mult, A, Bv, tb, table_off,
+			transpose_q, J, partials, nblk, row_len);
+}
+void launch_mi_hess_finish(const BatchView &bv, int nb, const double *partials, int nblk, int row_len, const double *tb,
+	int joint_off, int hist_off, int transpose_q, double *out, hipStream_t st) {
+	size_t lds = sizeof(double) * ((size_t)nb * nb * bv.S + 36);
+	hipLaunchKernelGGL(k_mi_hess_finish, dim3(bv.B), dim3(kBlock), lds, st, bv.S, nb, partials, nblk, row_len, tb, joint_off,
+		hist_off, transpose_q, out);
+}
+
+} // namespace mtfhip

@@ -1,0 +1,227 @@
+/*
+ * mtfhip_device.h -- device-side helpers shared by the kernel translation units of libmtfhip.so (gfx950).
+ *
+ * Compiled with -ffp-contract=off: the per-pixel arithmetic (bilinear sample, finite-difference
+ * gradient, warp, steepest-descent row) is written in the reference's operation order so that,
+ * without FMA contraction, it rounds exactly like the CPU/Eigen path; only the N-wide reductions
+ * (explicit fma accumulation + wavefront shuffles) sum in a different order.
+ *
+ * Execution model: 256-thread workgroups (4 wave64), each thread walks n_rows pixels strided by
+ * the workgroup size so that every wave touches 64 consecutive pixels of a column-major N x S
+ * array per instruction (512-byte coalesced segments).  The S x S Hessian is never a GEMM: 36
+ * upper-triangle products + 8 gradient terms + r^2 are kept in registers per thread, reduced across
+ * the wave with a halving butterfly (each exchange step halves the number of live accumulators, so
+ * 48 accumulators cost 51 exchanges instead of 6 x 48), then across the 4 waves through LDS, and
+ * written as one partial row per workgroup; a second tiny kernel sums the rows in a fixed order
+ * (deterministic, no atomics).
+ */
+#ifndef MTFHIP_DEVICE_H
+#define MTFHIP_DEVICE_H
+#include <type_traits>
+
+#include "mtfhip_internal.h"
+
+/* tuning knobs of the fused kernel ("fused kernel tuning") */
+#ifndef MTFHIP_FUSED_WAVES
+#define MTFHIP_FUSED_WAVES 2   /* minimum waves per SIMD requested from the register allocator */
+#endif
+#ifndef MTFHIP_NT_STORE
+#define MTFHIP_NT_STORE 1      /* 1: the materialised It / dIt_dx / Jt are written with non-temporal stores */
+#endif
+#if MTFHIP_NT_STORE
+#define MAT_STORE(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#else
+#define MAT_STORE(ptr, v) (*(ptr) = (v))
+#endif
+#ifndef MTFHIP_NT_LOAD
+#define MTFHIP_NT_LOAD 0       /* 1: the read-once operands (grid points, I0, J0 columns) are fetched with non-temporal loads */
+#endif
+
+namespace mtfhip {
+
+/* ===================================================================== */
+/* device helpers                                                         */
+/* ===================================================================== */
+
+/* utils::getPixVal<Linear, Constant> -- Utilities/include/mtf/Utilities/imgUtils.h:91-113
+ * (overflow test :51-53, overflow_val = 128).  Same operation order as the reference. */
+__device__ __forceinline__ double pix_val(const ImgView &im, double x, double y) {
+	const double w = (double)(unsigned int)im.w, h = (double)(unsigned int)im.h;
+	if ((x < 0) || (x >= w) || (y < 0) || (y >= h)) return 128.0;
+	int lx = (int)x, ly = (int)y;
+	double dx = x - lx, dy = y - ly;
+	int ux = dx == 0 ? lx : lx + 1;
+	int uy = dy == 0 ? ly : ly + 1;
+	if (ux >= im.w || uy >= im.h) return 128.0;
+	const float *r0 = im.data + (size_t)ly * im.stride;
+	const float *r1 = im.data + (size_t)uy * im.stride;
+	double t00 = r0[lx], t01 = r0[ux], t10 = r1[lx], t11 = r1[ux];
+	return t00 * (1 - dx) * (1 - dy) + t01 * dx * (1 - dy) + t10 * (1 - dx) * dy + t11 * dx * dy;
+}
+
+/* The centre sample and its four finite-difference neighbours (step 1e-8) almost always fall in
+ * one bilinear cell; the cell's four texels are fetched once and every sample that lands in the
+ * same cell is evaluated from registers with the reference's expression, so the result is
+ * bit-identical to five independent getPixVal calls while issuing 4 loads instead of 20. */
+struct Cell {
+	int lx, ly, ux, uy;
+	double t00, t01, t10, t11;
+	bool valid;
+};
+__device__ __forceinline__ Cell load_cell(const ImgView &im, double x, double y) {
+	Cell c;
+	c.valid = false;
+	c.lx = c.ly = c.ux = c.uy = -1;
+	c.t00 = c.t01 = c.t10 = c.t11 = 0;
+	const double w = (double)(unsigned int)im.w, h = (double)(unsigned int)im.h;
+	if ((x < 0) || (x >= w) || (y < 0) || (y >= h)) return c;
+	int lx = (int)x, ly = (int)y;
+	double dx = x - lx, dy = y - ly;
+	int ux = dx == 0 ? lx : lx + 1;
+	int uy = dy == 0 ? ly : ly + 1;
+	if (ux >= im.w || uy >= im.h) return c;
+	const float *r0 = im.data + (size_t)ly * im.stride;
+	const float *r1 = im.data + (size_t)uy * im.stride;
+	c.lx = lx; c.ly = ly; c.ux = ux; c.uy = uy;
+	c.t00 = r0[lx]; c.t01 = r0[ux]; c.t10 = r1[lx]; c.t11 = r1[ux];
+	c.valid = true;
+	return c;
+}
+__device__ __forceinline__ double pix_val_cell(const ImgView &im, const Cell &c, double x, double y) {
+	const double w = (double)(unsigned int)im.w, h = (double)(unsigned int)im.h;
+	if ((x < 0) || (x >= w) || (y < 0) || (y >= h)) return 128.0;
+	int lx = (int)x, ly = (int)y;
+	double dx = x - lx, dy = y - ly;
+	int ux = dx == 0 ? lx : lx + 1;
+	int uy = dy == 0 ? ly : ly + 1;
+	if (ux >= im.w || uy >= im.h) return 128.0;
+	if (c.valid && lx == c.lx && ly == c.ly && ux == c.ux && uy == c.uy)
+		return c.t00 * (1 - dx) * (1 - dy) + c.t01 * dx * (1 - dy) + c.t10 * (1 - dx) * dy + c.t11 * dx * dy;
+	const float *r0 = im.data + (size_t)ly * im.stride;
+	const float *r1 = im.data + (size_t)uy * im.stride;
+	double t00 = r0[lx], t01 = r0[ux], t10 = r1[lx], t11 = r1[ux];
+	return t00 * (1 - dx) * (1 - dy) + t01 * dx * (1 - dy) + t10 * (1 - dx) * dy + t11 * dx * dy;
+}
+
+struct Warp9 { double m[9]; };
+__device__ __forceinline__ Warp9 load_warp(const double *p) {
+	Warp9 W;
+#pragma unroll
+	for (int i = 0; i < 9; ++i) W.m[i] = p[i];
+	return W;
+}
+
+/* halving butterfly over the 64 lanes of a wave: on entry every lane holds K partial sums in
+ * v[0..K); on exit slot j of lane l holds the wave total of index final_index<K,32>(j, l). */
+template <int K, int MASK>
+__device__ __forceinline__ void wave_halve(double *v, int lane) {
+	if constexpr (MASK == 0) {
+		return;
+	} else if constexpr (K % 2 == 0) {
+		constexpr int H = K / 2;
+		const bool up = (lane & MASK) != 0;
+#pragma unroll
+		for (int j = 0; j < H; ++j) {
+			double keep = up ? v[j + H] : v[j];
+			double send = up ? v[j] : v[j + H];
+			v[j] = keep + __shfl_xor(send, MASK);
+		}
+		wave_halve<H, (MASK >> 1)>(v, lane);
+	} else {
+#pragma unroll
+		for (int j = 0; j < K; ++j) v[j] += __shfl_xor(v[j], MASK);
+		wave_halve<K, (MASK >> 1)>(v, lane);
+	}
+}
+template <int K, int MASK>
+__device__ __forceinline__ int final_index(int j, int lane) {
+	if constexpr (MASK == 0) return j;
+	else if constexpr (K % 2 == 0) return final_index<K / 2, (MASK >> 1)>(j, lane) + ((lane & MASK) ? K / 2 : 0);
+	else return final_index<K, (MASK >> 1)>(j, lane);
+}
+template <int K, int MASK>
+__device__ __forceinline__ constexpr int final_count() {
+	if constexpr (MASK == 0) return K;
+	else if constexpr (K % 2 == 0) return final_count<K / 2, (MASK >> 1)>();
+	else return final_count<K, (MASK >> 1)>();
+}
+/* lanes that differ only in bits handled by a full (non-halving) step hold duplicates */
+template <int K, int MASK>
+__device__ __forceinline__ constexpr int dup_mask() {
+	if constexpr (MASK == 0) return 0;
+	else if constexpr (K % 2 == 0) return dup_mask<K / 2, (MASK >> 1)>();
+	else return MASK | dup_mask<K, (MASK >> 1)>();
+}
+
+/* reduce K per-thread accumulators over the workgroup and write them to dst[0..K) */
+template <int K, bool COHERENT = false>
+__device__ __forceinline__ void block_reduce_store(double *v, double *dst, double *lds /* [4][K] */) {
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	wave_halve<K, 32>(v, lane);
+	constexpr int CNT = final_count<K, 32>();
+	constexpr int DUP = dup_mask<K, 32>();
+	if ((lane & DUP) == 0) {
+#pragma unroll
+		for (int j = 0; j < CNT; ++j) lds[wave * K + final_index<K, 32>(j, lane)] = v[j];
+	}
+	__syncthreads();
+	if (threadIdx.x < K) {
+		double s = lds[threadIdx.x];
+#pragma unroll
+		for (int wv = 1; wv < kBlock / 64; ++wv) s += lds[wv * K + threadIdx.x];
+		/* COHERENT: written through to the device coherence point (sc1), for readers on another XCD in the same launch */
+		if constexpr (COHERENT) __hip_atomic_store(&dst[threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		else dst[threadIdx.x] = s;
+	}
+}
+
+/* steepest-descent row of one pixel: S values */
+template <int SSM>
+struct Row { double v[SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6]; };
+
+/* Homography row writer shared by cmptInitPixJacobian / cmptPixJacobian / cmptWarpedPixJacobian /
+ * cmptApproxPixJacobian (SSM/src/Homography.cc:166-186, 213-224, 270-289, 330-341) */
+__device__ __forceinline__ void hom_row(double *r, double Ix, double Iy, double x, double y, double px, double py) {
+	double Ixx = Ix * x, Iyy = Iy * y, Ixy = Ix * y, Iyx = Iy * x;
+	r[0] = Ixx; r[1] = Ixy; r[2] = Ix; r[3] = Iyx; r[4] = Iyy; r[5] = Iy;
+	r[6] = -px * Ixx - py * Iyx;
+	r[7] = -px * Ixy - py * Iyy;
+}
+
+/* fixed-order sum of one column of the block rows, eight loads in flight */
+__device__ __forceinline__ double column_sum(const double *col, int nblk, int row_len) {
+	double s[8];
+#pragma unroll
+	for (int u = 0; u < 8; ++u) s[u] = 0.0;
+	int b = 0;
+	for (; b + 7 < nblk; b += 8) {
+#pragma unroll
+		for (int u = 0; u < 8; ++u) s[u] += col[(size_t)(b + u) * row_len];
+	}
+	for (; b < nblk; ++b) s[0] += col[(size_t)b * row_len];
+	return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+
+/* ---- multi-channel (mc::) sampling: image H x W x C interleaved; one thread per (pixel, channel) row.
+ * mc::PixVal<Linear, Constant>::get (imgUtils.h:505-551) forms the four bilinear weights first and applies them per
+ * channel -- not the single-channel operation order -- and so does this. ---- */
+__device__ __forceinline__ double pix_val_mc(const ImgView &im, double x, double y, int ch) {
+	const double w = (double)(unsigned int)im.w, h = (double)(unsigned int)im.h;
+	if ((x < 0) || (x >= w) || (y < 0) || (y >= h)) return 128.0;
+	int lx = (int)x, ly = (int)y;
+	double dx = x - lx, dy = y - ly;
+	int ux = dx == 0 ? lx : lx + 1;
+	int uy = dy == 0 ? ly : ly + 1;
+	if (ux >= im.w || uy >= im.h) return 128.0;
+	const double ly_lx = (1 - dx) * (1 - dy), ly_ux = dx * (1 - dy), uy_lx = (1 - dx) * dy, uy_ux = dx * dy;
+	const float *r0 = im.data + (size_t)ly * im.stride, *r1 = im.data + (size_t)uy * im.stride;
+	const int C = im.channels;
+	const double t00 = r0[lx * C + ch], t01 = r0[ux * C + ch], t10 = r1[lx * C + ch], t11 = r1[ux * C + ch];
+	return t00 * ly_lx + t01 * ly_ux + t10 * uy_lx + t11 * uy_ux;
+}
+
+/* launch grid: x = workgroups per target, y = targets */
+static inline dim3 grid2(int nblk, int B) { return dim3((unsigned)nblk, (unsigned)B, 1); }
+
+} // namespace mtfhip
+#endif

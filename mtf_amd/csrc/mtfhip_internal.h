@@ -1,5 +1,5 @@
 /*
- * mtfhip_internal.h -- shared between the HIP kernels (mtfhip_kernels.hip) and the C-ABI
+ * mtfhip_internal.h -- shared between the HIP kernel translation units (kernels_*.hip) and the C-ABI
  * implementation (mtfhip_api.hip).  Not installed; the public contract is include/mtfhip.h.
  */
 #ifndef MTFHIP_INTERNAL_H
@@ -140,7 +140,7 @@ void launch_sub_mean(const BatchView &bv, double *v, const double *sc, hipStream
 void launch_col_sum(const BatchView &bv, const double *J, double *partials, int nblk, hipStream_t st);
 void launch_ncc_hess(const BatchView &bv, const double *sc, const double *colmean, const double *J, double *partials,
 	int nblk, hipStream_t st);
-/* MI pieces; table block offsets (doubles) of the per-target MI state, see mtfhip_kernels.hip */
+/* MI pieces; table block offsets (doubles) of the per-target MI state, see kernels_mi.hip */
 enum {
 	MI_NB = 16,
 	MI_HIST_INIT = 0, MI_HIST_CURR = 16, MI_LOG_INIT = 32, MI_LOG_CURR = 48,
