@@ -470,6 +470,23 @@ __global__ __launch_bounds__(128) void k_finish_rows(const double *partials, int
 	if (k >= row_len) return;
 	out[(size_t)t * row_len + k] = column_sum(partials + (size_t)t * nblk * row_len + k, nblk, row_len);
 }
+/* the same, delivered straight into host-coherent pinned memory: every target's row, then -- by the workgroup that
+ * finishes last -- a sequence number the host is spinning on (system-scope release after the rows) */
+__global__ __launch_bounds__(128) void k_finish_host(const double *partials, int nblk, int row_len, double *out_host, int *count,
+	unsigned long long *flag_host, unsigned long long seq) {
+	const int t = blockIdx.x, k = threadIdx.x;
+	if (k < row_len) out_host[(size_t)t * row_len + k] = column_sum(partials + (size_t)t * nblk * row_len + k, nblk, row_len);
+	__threadfence_system();
+	__syncthreads();
+	if (k == 0) {
+		const int done = __hip_atomic_fetch_add(count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+		if (done == (int)gridDim.x - 1) {
+			__hip_atomic_store(count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__threadfence_system();
+			__hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+	}
+}
 /* fixed-order sum of the per-workgroup rows: out[t][k] = sum_b partials[t][b][k] */
 __global__ __launch_bounds__(64) void k_finish(const double *partials, int nblk, double *out) {
 	const int t = blockIdx.x, k = threadIdx.x;
@@ -562,6 +579,10 @@ void launch_col_sum(const BatchView &bv, const double *J, double *partials, int 
 void launch_ncc_hess(const BatchView &bv, const double *sc, const double *colmean, const double *J, double *partials,
 	int nblk, hipStream_t st) {
 	hipLaunchKernelGGL(k_ncc_hess, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv, sc, colmean, J, partials, nblk);
+}
+void launch_finish_host(double *partials, int nblk, int row_len, double *out_host, int *count, unsigned long long *flag_host,
+	unsigned long long seq, int B, hipStream_t st) {
+	hipLaunchKernelGGL(k_finish_host, dim3(B), dim3(128), 0, st, partials, nblk, row_len, out_host, count, flag_host, seq);
 }
 void launch_finish_rows(double *partials, int nblk, int row_len, double *out, int B, hipStream_t st) {
 	hipLaunchKernelGGL(k_finish_rows, dim3(B), dim3(128), 0, st, partials, nblk, row_len, out);

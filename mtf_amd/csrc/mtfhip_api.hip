@@ -8,6 +8,7 @@
 #include "mtfhip_internal.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -254,6 +255,12 @@ struct mtfhip_batch {
 	 * B = 64, 19.6 vs 19.2 us for one target -- the finish's dependent scalar chain is the cost, not the launch), so off */
 	bool epilogue = std::getenv("MTFHIP_EPILOGUE") && std::getenv("MTFHIP_EPILOGUE")[0] == '1';
 	double *h_acc = nullptr; /* pinned */
+	/* Zero-copy read-back of the reduced rows: h_acc is host-coherent pinned memory the reduction kernel writes directly
+	 * (h_acc_dev = its device address) followed by a sequence number in h_flag; the host spins on the flag instead of
+	 * paying a copy command plus a stream synchronisation per iteration (MTFHIP_ZERO_COPY=0: copy + sync) */
+	double *h_acc_dev = nullptr;
+	unsigned long long *h_flag = nullptr, *h_flag_dev = nullptr, acc_seq = 0;
+	int *d_fin_count = nullptr;
 	int nblk_max;
 	int unit_z = 1;
 	/* The LDS-staged candidate scorer (template + image tile in LDS) measured 10 % SLOWER than the plain one
@@ -369,12 +376,29 @@ static void update_corners(mtfhip_batch *b, int t) {
 	}
 }
 
-static int read_acc(mtfhip_batch *b, int nblk) {
-	launch_finish(b->d_partials, nblk, b->d_acc, b->B, b->ctx->stream);
-	HIP_TRY(hipMemcpyAsync(b->h_acc, b->d_acc, sizeof(double) * ACC_COUNT * b->B, hipMemcpyDeviceToHost, b->ctx->stream));
+/* fixed-order sum of the per-workgroup rows -> h_acc ([B][row_len]) on the host, and wait for it */
+static int read_rows(mtfhip_batch *b, int nblk, int row_len) {
+	if (b->h_acc_dev) {
+		const unsigned long long seq = ++b->acc_seq;
+		launch_finish_host(b->d_partials, nblk, row_len, b->h_acc_dev, b->d_fin_count, b->h_flag_dev, seq, b->B, b->ctx->stream);
+		const auto t0 = std::chrono::steady_clock::now();
+		for (unsigned spins = 0;; ++spins) {
+			if (__atomic_load_n(b->h_flag, __ATOMIC_ACQUIRE) == seq) return MTFHIP_OK;
+			__builtin_ia32_pause();
+			if ((spins & 0xffff) == 0xffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+		}
+		/* the kernel did not report in: let the runtime tell why */
+		HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+		if (__atomic_load_n(b->h_flag, __ATOMIC_ACQUIRE) == seq) return MTFHIP_OK;
+		return fail(MTFHIP_ERR_HIP, "reduced rows were not delivered to host memory");
+	}
+	if (row_len == ACC_COUNT) launch_finish(b->d_partials, nblk, b->d_acc, b->B, b->ctx->stream);
+	else launch_finish_rows(b->d_partials, nblk, row_len, b->d_acc, b->B, b->ctx->stream);
+	HIP_TRY(hipMemcpyAsync(b->h_acc, b->d_acc, sizeof(double) * row_len * b->B, hipMemcpyDeviceToHost, b->ctx->stream));
 	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
 	return MTFHIP_OK;
 }
+static int read_acc(mtfhip_batch *b, int nblk) { return read_rows(b, nblk, ACC_COUNT); }
 
 static int need_image(mtfhip_batch *b) {
 	if (!b->ctx->img.data) return fail(MTFHIP_ERR_LOGIC, "no current image: call mtfhip_image_upload/borrow first");
@@ -706,8 +730,19 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 		(void)hipMemsetAsync(b->d_mi_tb, 0, sizeof(double) * MI_SIZE * n_targets, c->stream);
 	}
 #undef ALLOC
-	if (hipHostMalloc(&b->h_acc, sizeof(double) * kAccRowMax * n_targets) != hipSuccess)
+	if (hipHostMalloc(&b->h_acc, sizeof(double) * kAccRowMax * n_targets, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
 		return cleanup(fail(MTFHIP_ERR_HIP, "hipHostMalloc failed"));
+	{
+		const char *zc = std::getenv("MTFHIP_ZERO_COPY");
+		void *dp = nullptr, *fp = nullptr;
+		if (!(zc && zc[0] == '0') && hipHostGetDevicePointer(&dp, b->h_acc, 0) == hipSuccess &&
+			hipHostMalloc(&b->h_flag, sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+			hipHostGetDevicePointer(&fp, b->h_flag, 0) == hipSuccess && hipMalloc(&b->d_fin_count, sizeof(int)) == hipSuccess) {
+			*b->h_flag = 0;
+			(void)hipMemsetAsync(b->d_fin_count, 0, sizeof(int), c->stream);
+			b->h_acc_dev = static_cast<double *>(dp); b->h_flag_dev = static_cast<unsigned long long *>(fp);
+		} else (void)hipGetLastError();
+	}
 	(void)hipMemsetAsync(b->d_partials, 0, sizeof(double) * kAccRowMax * b->nblk_max * n_targets, c->stream);
 	int r = push_warps(b);
 	if (r) return cleanup(r);
@@ -735,6 +770,8 @@ void mtfhip_batch_destroy(mtfhip_batch *b) {
 		for (void *p : ptrs)
 			if (p) (void)hipFree(p);
 		if (b->h_acc) (void)hipHostFree(b->h_acc);
+		if (b->h_flag) (void)hipHostFree(b->h_flag);
+		if (b->d_fin_count) (void)hipFree(b->d_fin_count);
 		if (b->h_stage_a) (void)hipHostFree(b->h_stage_a);
 		if (b->h_stage_b) (void)hipHostFree(b->h_stage_b);
 		if (b->ev_a) (void)hipEventDestroy(b->ev_a);
@@ -1612,9 +1649,7 @@ static int lazy_try_fused(mtfhip_batch *b, int trig, int j_a, int j_b, double *g
 	L.pv = L.gp = L.pg = L.pj = L.sim = L.cg = L.ig = L.jm = 0;
 	if (want_mean) TRY(do_mean_jacobian(b));
 	if (ncc) {
-		launch_finish_rows(b->d_partials, nblk, NCC_ACC_COUNT, b->d_acc, b->B, b->ctx->stream);
-		HIP_TRY(hipMemcpyAsync(b->h_acc, b->d_acc, sizeof(double) * NCC_ACC_COUNT * b->B, hipMemcpyDeviceToHost, b->ctx->stream));
-		HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+		TRY(read_rows(b, nblk, NCC_ACC_COUNT));
 		TRY(ncc_lazy_outputs(b, trig, j_a, fa.hess_mean != 0, g));
 		*done = 1;
 		return MTFHIP_OK;
@@ -2185,9 +2220,7 @@ static int lazy_try_similarity(mtfhip_batch *b) {
 	if (!ncc) { L.df0_stale = true; L.df0_sh = false; if (!L.dft_sh) L.shadow_valid = false; }
 	L.pv = L.sim = 0;
 	if (ncc) {
-		launch_finish_rows(b->d_partials, nblk, NCC_ACC_COUNT, b->d_acc, b->B, b->ctx->stream);
-		HIP_TRY(hipMemcpyAsync(b->h_acc, b->d_acc, sizeof(double) * NCC_ACC_COUNT * b->B, hipMemcpyDeviceToHost, b->ctx->stream));
-		HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+		TRY(read_rows(b, nblk, NCC_ACC_COUNT));
 		for (int t = 0; t < b->B; ++t) {
 			const double *M = b->h_acc + (size_t)t * NCC_ACC_COUNT;
 			TargetHost &h = b->th[t];
@@ -2377,9 +2410,7 @@ int mtfhip_batch_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, d
 	b->dit_valid = fa.materialize && fa.mode != 2;
 	b->jt_valid = fa.materialize && fa.mode != 2;
 	if (b->desc.am == MTFHIP_AM_NCC) {
-		launch_finish_rows(b->d_partials, nblk, NCC_ACC_COUNT, b->d_acc, b->B, b->ctx->stream);
-		HIP_TRY(hipMemcpyAsync(b->h_acc, b->d_acc, sizeof(double) * NCC_ACC_COUNT * b->B, hipMemcpyDeviceToHost, b->ctx->stream));
-		HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+		TRY(read_rows(b, nblk, NCC_ACC_COUNT));
 		for (int t = 0; t < b->B; ++t) {
 			double ft;
 			TRY(ncc_assemble(b, sm, fa.hess_mean != 0, b->h_acc + (size_t)t * NCC_ACC_COUNT, b->th[t], &ft, g + (size_t)t * b->S,

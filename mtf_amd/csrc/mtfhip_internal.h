@@ -161,6 +161,8 @@ void launch_mi_hess_finish(const BatchView &bv, int nb, const double *partials, 
 /* sums partials over blocks: out[B][ACC_COUNT] */
 void launch_finish(double *partials, int nblk, double *out, int B, hipStream_t st);
 void launch_finish_rows(double *partials, int nblk, int row_len, double *out, int B, hipStream_t st);
+void launch_finish_host(double *partials, int nblk, int row_len, double *out_host, int *count, unsigned long long *flag_host,
+	unsigned long long seq, int B, hipStream_t st);
 /* the fused LK iteration for SSD */
 void launch_fused_ssd(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials,
 	int nblk, hipStream_t st);
