@@ -54,13 +54,14 @@ def pmc_traffic(sm, mode, res, targets):
         return None
 
 
-def cpu_baseline(seconds, res, frame0, frame1, corners):
+def cpu_baseline(seconds, res, frame0, frame1, corners, am_name="ssd"):
     """The CPU oracle (a port of the reference's ESM loop) timed on one host core on the same
     workload shape: LK iterations/s of a single 200x200 ESM+SSD+Homography target."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
+    am_kind = {"ssd": O.AM_SSD, "ncc": O.AM_NCC}[am_name]
     ssm = O.SSM(O.SSM_HOM, res, res)
-    am = O.AM(O.AM_SSD, res, res)
+    am = O.AM(am_kind, res, res)
     am.set_curr_img(frame0)
     trk = O.Tracker(O.SM_ESM, am, ssm, leven_marq=0, max_iters=10, epsilon=-1.0)
     trk.initialize(corners)
@@ -72,7 +73,7 @@ def cpu_baseline(seconds, res, frame0, frame1, corners):
         iters += trk.update()
     dt = time.perf_counter() - t0
     out = {"value": iters / dt, "unit": "iters/s", "cores": 1, "kind": "port",
-           "sample": "%d ESM iterations of one %dx%d target in %.1f s (oracle/mtf_oracle.cpp, -O3, 1 thread)" % (iters, res, res, dt)}
+           "sample": "%d ESM+%s iterations of one %dx%d target in %.1f s (oracle/mtf_oracle.cpp, -O3, 1 thread)" % (iters, am_name.upper(), res, res, dt)}
     # all host cores: one independent target per thread (the reference's OpenMP-over-targets pattern, PF.cc:195-197,
     # GridTracker.cc:254-256; its default build is single-threaded, so the 1-core figure above stays the like-for-like one).
     # ctypes releases the GIL for the duration of every oracle call.
@@ -90,7 +91,7 @@ def cpu_baseline(seconds, res, frame0, frame1, corners):
 
     def worker(k):
         s_k = O.SSM(O.SSM_HOM, res, res)
-        a_k = O.AM(O.AM_SSD, res, res)
+        a_k = O.AM(am_kind, res, res)
         a_k.set_curr_img(frame0)
         t_k = O.Tracker(O.SM_ESM, a_k, s_k, leven_marq=0, max_iters=10, epsilon=-1.0)
         t_k.initialize(corners)
@@ -115,6 +116,45 @@ def cpu_baseline(seconds, res, frame0, frame1, corners):
                             "sample": "%d threads x one %dx%d target each, %d iterations in %.1f s; %.1f CPU-seconds per second actually obtained"
                                       % (n_thr, res, res, sum(counts), dt_all, cpu_all / dt_all)}
     return out
+
+
+def parity_gate(ctx, am_name, res, frame0, frame1, corners):
+    """SURVEY 8(d) "parity gate in the same run": the oracle's nt::ESM trace of one target of this workload against the
+    fused path (mtfhip_batch_iterate + the oracle's pivoted QR for the step, following the oracle's trajectory), first
+    five iterations and the last one.  Returns the worst relative errors; the budget is 1e-5 (north_star)."""
+    import mtf_amd
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    am_o = {"ssd": O.AM_SSD, "ncc": O.AM_NCC}[am_name]
+    am_d = {"ssd": mtf_amd.AM_SSD, "ncc": mtf_amd.AM_NCC}[am_name]
+    ssm = O.SSM(O.SSM_HOM, res, res); am = O.AM(am_o, res, res); am.set_curr_img(frame0)
+    trk = O.Tracker(O.SM_ESM, am, ssm, leven_marq=0, max_iters=12, epsilon=1e-6)
+    trk.initialize(corners); am.set_curr_img(frame1); trk.update()
+    trace = trk.trace()
+    ctx.set_image(frame0)
+    b = mtf_amd.Batch(ctx, am_d, mtf_amd.SSM_HOMOGRAPHY, res, res, 1)
+    b.set_corners(corners[None])
+    sm = mtf_amd.sm_desc(mtf_amd.SM_ESM, materialize=1, leven_marq=0, max_iters=12, epsilon=1e-6)
+    b.init_template(sm)
+    ctx.set_image(frame1)
+    rel = lambda a, r: float(np.linalg.norm(np.asarray(a) - np.asarray(r)) / max(np.linalg.norm(r), 1e-300))
+    worst = {"H": 0.0, "g": 0.0, "dp": 0.0}
+    checked = []
+    for it, rec in enumerate(trace):
+        f, g, H = b.iterate(sm)
+        if it < 5 or it == len(trace) - 1:
+            dp = -O.colpiv_qr_solve(H[0], g[0])
+            g_scale = np.sqrt(abs(np.trace(rec["H"]))) * (1.0 if am_name == "ncc" else np.sqrt(abs(2 * rec["f"])))
+            worst["H"] = max(worst["H"], rel(H[0], rec["H"]))
+            worst["g"] = max(worst["g"], float(np.linalg.norm(g[0] - rec["g"]) / max(np.linalg.norm(rec["g"]), g_scale)))
+            worst["dp"] = max(worst["dp"], min(rel(dp, rec["dp"]), float(np.abs(dp - rec["dp"]).max() / 1e-7)))
+            checked.append(it)
+        b.compositional_update(rec["dp"][None])
+    b.close()
+    worst.update({"iterations_checked": checked, "budget": 1e-5, "pass": bool(max(worst["H"], worst["g"], worst["dp"]) <= 1e-5),
+                  "note": "vs the CPU oracle's nt::ESM trace on the device's own sample grid; g relative to its Cauchy-Schwarz scale, "
+                          "dp relative or below 1e-12 absolute"})
+    return worst
 
 
 def secondary_workload(args):
@@ -422,7 +462,8 @@ def main():
                          "targets_per_launch": per_launch},
         }
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, res, frame0, frame1, corners[0])
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, res, frame0, frame1, corners[0], args.am)
+            out["parity"] = parity_gate(ctx, args.am, res, frame0, frame1, corners[0])
         elif not args.no_cpu:
             out["cpu_baseline"] = None
         print(json.dumps(out))
