@@ -24,13 +24,15 @@ def _solve(H, g):
 
 
 class LKTracker:
-    """One or many (B) independent targets tracked with ESM / FCLK / ICLK + SSD on one GPU."""
+    """One or many (B) independent targets tracked with ESM / FCLK / ICLK + SSD or NCC on one GPU through the fused kernels
+    (k_fused_ssd / k_fused_ncc): host_solve=True = one fused launch per iteration + the reference's pivoted QR and
+    Levenberg-Marquardt on the host; False = the whole loop on the device (mtfhip_batch_track)."""
 
     def __init__(self, ctx, sm, ssm=L.SSM_HOMOGRAPHY, resx=50, resy=50, n_targets=1, host_solve=True, am=L.AM_SSD,
                  **params):
         self.ctx = ctx
-        if am != L.AM_SSD and host_solve:
-            raise L.FunctionNotImplemented(-2, "LKTracker(host_solve=True) is SSD only; use NTSearchMethod")
+        if am not in (L.AM_SSD, L.AM_NCC):
+            raise L.FunctionNotImplemented(-2, "LKTracker drives the fused kernels (SSD, NCC); MI: use NTSearchMethod")
         self.batch = Batch(ctx, am, ssm, resx, resy, n_targets)
         self.B, self.S = n_targets, self.batch.S
         self.host_solve = host_solve

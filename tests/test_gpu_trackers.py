@@ -16,9 +16,10 @@ def gt_corners(corners, p_true, centre):
     return q[:2] / q[2] + np.array(centre)[:, None]
 
 
+@pytest.mark.parametrize("am", [L.AM_SSD, L.AM_NCC])
 @pytest.mark.parametrize("host_solve", [True, False])
 @pytest.mark.parametrize("sm", [L.SM_ESM, L.SM_FCLK, L.SM_ICLK])
-def test_lk_trackers_recover_known_warp(gpu_ctx, frame, sm, host_solve):
+def test_lk_trackers_recover_known_warp(gpu_ctx, frame, sm, host_solve, am):
     rng = np.random.default_rng(7)
     centre = (256.0, 250.0)
     corners = synth.square_corners(centre[0], centre[1], 90)
@@ -26,7 +27,7 @@ def test_lk_trackers_recover_known_warp(gpu_ctx, frame, sm, host_solve):
     frame2 = synth.warp_frame(frame, p_true, centre)
     gpu_ctx.set_image(frame)
     trk = LKTracker(gpu_ctx, sm, L.SSM_HOMOGRAPHY, 45, 45, 1, host_solve=host_solve, max_iters=40, epsilon=1e-6,
-                    materialize=0)
+                    materialize=0, am=am)
     trk.initialize(corners[None])
     gpu_ctx.set_image(frame2)
     out = trk.update()
@@ -41,15 +42,15 @@ def test_lm_host_loop_matches_oracle(oracle, gpu_ctx, frame):
     corners = synth.square_corners(centre[0], centre[1], 100)
     p_true = np.array([0.01, -0.01, 6.0, 0.01, 0.0, -5.0, 0, 0])
     frame2 = synth.warp_frame(frame, p_true, centre)
-    for sm in (L.SM_FCLK, L.SM_ESM, L.SM_ICLK):
-        o_ssm = oracle.SSM(0, 40, 40); o_am = oracle.AM(0, 40, 40); o_am.set_curr_img(frame)
+    for sm, am in ((L.SM_FCLK, L.AM_SSD), (L.SM_ESM, L.AM_SSD), (L.SM_ICLK, L.AM_SSD), (L.SM_ESM, L.AM_NCC), (L.SM_FCLK, L.AM_NCC)):
+        o_ssm = oracle.SSM(0, 40, 40); o_am = oracle.AM(am, 40, 40); o_am.set_curr_img(frame)
         otrk = oracle.Tracker(sm, o_am, o_ssm, leven_marq=1, max_iters=60, epsilon=1e-8)
         otrk.initialize(corners)
         o_am.set_curr_img(frame2)
         otrk.update()
         gpu_ctx.set_image(frame)
         trk = LKTracker(gpu_ctx, sm, L.SSM_HOMOGRAPHY, 40, 40, 1, host_solve=True, leven_marq=1, max_iters=60,
-                        epsilon=1e-8, materialize=0)
+                        epsilon=1e-8, materialize=0, am=am)
         trk.initialize(corners[None])
         gpu_ctx.set_image(frame2)
         out = trk.update()
