@@ -316,3 +316,36 @@ def test_multichannel_models_match_oracle(oracle, gpu_ctx, case):
     gpu_ctx.set_image(frame)
     with pytest.raises(mtf_amd.FunctionNotImplemented):
         nt.batch.init_template(nt.sm)
+
+
+@pytest.mark.parametrize("am", [L.AM_SSD, L.AM_NCC])
+@pytest.mark.parametrize("sm_kind", [L.SM_ESM, L.SM_FCLK, L.SM_ICLK])
+def test_interface_level_sm_several_targets_deferred_vs_eager(gpu_ctx, frame, sm_kind, am, monkeypatch):
+    """B targets in one batch through the per-function entry points: the deferred-fusion path (one fused launch per
+    iteration for all targets) and the call-by-call path (MTFHIP_LAZY=0) produce the same trajectories."""
+    rng = np.random.default_rng(31)
+    B, res = 3, 40
+    centre = (250.0, 262.0)
+    corners = np.stack([synth.square_corners(centre[0] + 40 * k - 40, centre[1] + 15 * k, 80.0) for k in range(B)])
+    frame2 = synth.warp_frame(frame, synth.random_small_homography(rng, 0.3), centre)
+    out = {}
+    for lazy in ("0", "1"):
+        monkeypatch.setenv("MTFHIP_LAZY", lazy)
+        gpu_ctx.set_image(frame)
+        nt = NTSearchMethod(gpu_ctx, sm_kind, am, L.SSM_HOMOGRAPHY, res, res, B, leven_marq=0, max_iters=5, epsilon=-1.0)
+        nt.initialize(corners)
+        gpu_ctx.set_image(frame2)
+        gpu_ctx.timing(1); gpu_ctx.timing_reset()
+        nt.update()
+        _, n_fused = gpu_ctx.timing_get("fused_lk")
+        gpu_ctx.timing(False)
+        out[lazy] = (nt.get_region().copy(), [dict((k, v.copy()) for k, v in r.items()) for r in nt.trace], n_fused)
+        nt.batch.close()
+    assert out["0"][2] == 0 and out["1"][2] == 5
+    # iteration 0 runs on identical inputs: sums differ in order only.  From then on a 1e-16 difference in the state moves
+    # the sample points by ~1e-13 px, which the reference's 1e-8 finite difference turns into its ~5e-6 gradient noise.
+    np.testing.assert_allclose(out["1"][0], out["0"][0], rtol=0, atol=1e-5)
+    for it, (a, c) in enumerate(zip(out["0"][1], out["1"][1])):
+        tol = 1e-10 if it == 0 else 1e-4
+        for key in ("f", "g", "H") if it == 0 else ("f", "H"):   # g cancels towards 0 at convergence: noise-dominated there
+            np.testing.assert_allclose(c[key], a[key], rtol=tol, atol=tol * max(1.0, np.abs(a[key]).max()), err_msg="%s %d" % (key, it))
