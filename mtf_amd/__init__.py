@@ -7,7 +7,7 @@ frames (synth.py).
 """
 import os as _os
 
-# Kernel arguments in device memory (see the constructor in csrc/mtfhip_api.hip): read by the HIP runtime at its first
+# Kernel arguments in device memory (see the constructor in csrc/api_core.hip): read by the HIP runtime at its first
 # call, so it is set here as well in case the library is loaded after some other module initialised HIP.
 _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 

@@ -1,0 +1,636 @@
+/*
+ * api_core.hip -- context, image / pre-processing, batch lifecycle and buffers, the StateSpaceModel entry points, timing
+ * (C-ABI implementation, include/mtfhip.h; shared declarations: mtfhip_api_internal.h)
+ *
+ * No CPU fallback exists: every entry point either runs its HIP kernels or returns an error.
+ */
+#include "mtfhip_api_internal.h"
+
+/* Kernel arguments in device memory instead of host-coherent memory: the fused kernel's first instruction is a
+ * scalar load of its 400-byte argument block, and every step is two launches, so the PCIe round trip of that load is
+ * 2-3 us of a 65 us step (measured: 68.6 -> 65.6 us/step at 64 targets, 22.0 -> 17.9 us at one).  The HIP runtime
+ * reads the variable when it initialises (first HIP call of the process), so this has to run at load time; a value
+ * already present in the environment wins. */
+__attribute__((constructor)) static void mtfhip_runtime_defaults() { setenv("HIP_FORCE_DEV_KERNARG", "1", 0); }
+
+thread_local std::string g_last_error;
+
+extern "C" {
+
+/* ------------------------------------------------------------------ context */
+const char *mtfhip_last_error(void) { return g_last_error.c_str(); }
+
+int mtfhip_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+int mtfhip_ctx_create(int device, void *hip_stream, mtfhip_ctx **out) {
+	if (!out) return fail(MTFHIP_ERR_INVALID_ARG, "ctx_create: out is NULL");
+	int n = mtfhip_device_count();
+	if (n <= 0) return fail(MTFHIP_ERR_NO_DEVICE, "no HIP device visible");
+	if (device < 0 || device >= n) return fail(MTFHIP_ERR_INVALID_ARG, "device %d out of range [0,%d)", device, n);
+	HIP_TRY(hipSetDevice(device));
+	mtfhip_ctx *c = new mtfhip_ctx();
+	c->device = device;
+	if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+	else {
+		hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+		if (e != hipSuccess) { delete c; return fail(MTFHIP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+		c->own_stream = true;
+	}
+	*out = c;
+	return MTFHIP_OK;
+}
+
+/* The destroy calls may run from a host-language finaliser after the HIP runtime has begun tearing itself
+ * down at process exit (its calls then throw from inside the runtime); nothing may escape a C entry point. */
+void mtfhip_ctx_destroy(mtfhip_ctx *c) {
+	if (!c) return;
+	try {
+		(void)hipSetDevice(c->device);
+		(void)hipStreamSynchronize(c->stream);
+		for (auto &kv : c->timers)
+			for (auto &p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+		for (auto e : c->free_events) (void)hipEventDestroy(e);
+		if (c->img_owned) (void)hipFree(c->img_owned);
+		if (c->raw) (void)hipFree(c->raw);
+		if (c->tmp_a) (void)hipFree(c->tmp_a);
+		if (c->tmp_b) (void)hipFree(c->tmp_b);
+		if (c->own_stream) (void)hipStreamDestroy(c->stream);
+	} catch (...) {
+	}
+	delete c;
+}
+
+int mtfhip_ctx_synchronize(mtfhip_ctx *c) {
+	if (!c) return fail(MTFHIP_ERR_INVALID_ARG, "ctx is NULL");
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return MTFHIP_OK;
+}
+void *mtfhip_ctx_stream(mtfhip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int mtfhip_image_upload(mtfhip_ctx *c, const float *host_img, int height, int width, int row_stride) {
+	return mtfhip_image_upload_mc(c, host_img, height, width, row_stride, 1);
+}
+/* CV_32FC3: `channels` interleaved floats per pixel, row_stride in floats */
+int mtfhip_image_upload_mc(mtfhip_ctx *c, const float *host_img, int height, int width, int row_stride, int channels) {
+	if (!c || !host_img) return fail(MTFHIP_ERR_INVALID_ARG, "image_upload: NULL argument");
+	TRY(lazy_flush_ctx(c));
+	if (channels != 1 && channels != 3) return fail(MTFHIP_ERR_INVALID_ARG, "image_upload: %d channels (1 or 3 expected)", channels);
+	if (height <= 0 || width <= 0 || row_stride < width * channels) return fail(MTFHIP_ERR_INVALID_ARG, "image_upload: bad shape %dx%d stride %d", height, width, row_stride);
+	if ((double)height * width * channels * 4.0 >= 4294967296.0) return fail(MTFHIP_ERR_INVALID_ARG, "image_upload: %dx%dx%d floats exceed the 4 GiB a 32-bit texel offset can address", height, width, channels);
+	HIP_TRY(hipSetDevice(c->device));
+	const int logical_width = width;
+	width *= channels;   /* floats per row */
+	size_t need = (size_t)height * width;
+	if (need > c->img_capacity) {
+		if (c->img_owned) HIP_TRY(hipFree(c->img_owned));
+		c->img_owned = nullptr;
+		HIP_TRY(hipMalloc(&c->img_owned, need * sizeof(float)));
+		c->img_capacity = need;
+	}
+	HIP_TRY(hipMemcpy2DAsync(c->img_owned, (size_t)width * sizeof(float), host_img, (size_t)row_stride * sizeof(float),
+		(size_t)width * sizeof(float), (size_t)height, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream)); /* the caller may overwrite its buffer right after (TrackerBase.h:22-26) */
+	c->img = ImgView{c->img_owned, height, logical_width, width, channels};
+	return MTFHIP_OK;
+}
+
+int mtfhip_image_borrow(mtfhip_ctx *c, const float *dev_img, int height, int width, int row_stride) {
+	if (c) TRY(lazy_flush_ctx(c));
+	if (!c || !dev_img) return fail(MTFHIP_ERR_INVALID_ARG, "image_borrow: NULL argument");
+	if (height <= 0 || width <= 0 || row_stride < width) return fail(MTFHIP_ERR_INVALID_ARG, "image_borrow: bad shape");
+	c->img = ImgView{dev_img, height, width, row_stride};
+	return MTFHIP_OK;
+}
+
+/* ------------------------------------------------------------------ pre-processing / pyramid */
+static int ensure_image(mtfhip_ctx *c, int rows, int cols) {
+	const size_t need = (size_t)rows * cols;
+	if (need > c->img_capacity) {
+		if (c->img_owned) HIP_TRY(hipFree(c->img_owned));
+		c->img_owned = nullptr;
+		HIP_TRY(hipMalloc(&c->img_owned, need * sizeof(float)));
+		c->img_capacity = need;
+	}
+	return MTFHIP_OK;
+}
+static int ensure_tmp(mtfhip_ctx *c, size_t need) {
+	if (need > c->tmp_capacity) {
+		if (c->tmp_a) HIP_TRY(hipFree(c->tmp_a));
+		if (c->tmp_b) HIP_TRY(hipFree(c->tmp_b));
+		c->tmp_a = c->tmp_b = nullptr;
+		HIP_TRY(hipMalloc(&c->tmp_a, need * sizeof(float)));
+		HIP_TRY(hipMalloc(&c->tmp_b, need * sizeof(float)));
+		c->tmp_capacity = need;
+	}
+	return MTFHIP_OK;
+}
+/* cv::getGaussianKernel(ksize, sigma, CV_32F) for sigma > 0: exp(-x^2 / (2 sigma^2)) rounded to float, normalised by the
+ * double sum of those floats; k[0] is the centre tap, k[1], k[2] the taps one and two samples out */
+static void gaussian5(double sigma, float k[3]) {
+	const double scale2x = -0.5 / (sigma * sigma);
+	float cf[5];
+	double sum = 0;
+	for (int i = 0; i < 5; ++i) { const double x = i - 2.0; cf[i] = (float)std::exp(scale2x * x * x); sum += cf[i]; }
+	sum = 1. / sum;
+	for (int i = 0; i < 5; ++i) cf[i] = (float)(cf[i] * sum);
+	k[0] = cf[2]; k[1] = cf[3]; k[2] = cf[4];
+}
+
+int mtfhip_image_preprocess(mtfhip_ctx *c, const void *host_raw, int rows, int cols, int row_stride_bytes, int channels, int depth,
+	int ksize, double sigma_x, double sigma_y) {
+	if (c) TRY(lazy_flush_ctx(c));
+	if (!c || !host_raw) return fail(MTFHIP_ERR_INVALID_ARG, "image_preprocess: NULL argument");
+	if (rows <= 0 || cols <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "image_preprocess: bad shape %dx%d", rows, cols);
+	if (channels != 1 && channels != 3) return fail(MTFHIP_ERR_INVALID_ARG, "image_preprocess: %d channels (1 or 3 expected)", channels);
+	if (depth != MTFHIP_DEPTH_U8 && depth != MTFHIP_DEPTH_F32) return fail(MTFHIP_ERR_INVALID_ARG, "PreProcBase::processFrame : Invalid input image depth provided: %d", depth);
+	const size_t px = (size_t)channels * (depth == MTFHIP_DEPTH_F32 ? 4 : 1);
+	if ((size_t)row_stride_bytes < px * cols) return fail(MTFHIP_ERR_INVALID_ARG, "image_preprocess: row stride %d shorter than a row", row_stride_bytes);
+	if (ksize != 0 && ksize != 5) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "image_preprocess: Gaussian kernel size %d (5, or 0 for no smoothing)", ksize);
+	if (ksize == 5 && sigma_x <= 0) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "image_preprocess: sigma <= 0 selects OpenCV's fixed kernel table, not available");
+	HIP_TRY(hipSetDevice(c->device));
+	const size_t raw_bytes = px * cols * rows;
+	if (raw_bytes > c->raw_capacity) {
+		if (c->raw) HIP_TRY(hipFree(c->raw));
+		c->raw = nullptr;
+		HIP_TRY(hipMalloc(&c->raw, raw_bytes));
+		c->raw_capacity = raw_bytes;
+	}
+	TRY(ensure_image(c, rows, cols));
+	TRY(ensure_tmp(c, (size_t)rows * cols));
+	HIP_TRY(hipMemcpy2DAsync(c->raw, px * cols, host_raw, (size_t)row_stride_bytes, px * cols, (size_t)rows, hipMemcpyHostToDevice, c->stream));
+	{
+		TimedScope ts(c, "preprocess");
+		if (ksize == 0) launch_to_gray(c->raw, rows, cols, px * cols, channels, depth == MTFHIP_DEPTH_F32, c->img_owned, c->stream);
+		else {
+			float kx[3], ky[3];
+			gaussian5(sigma_x, kx);
+			gaussian5(sigma_y > 0 ? sigma_y : sigma_x, ky);   /* sigma2 <= 0 -> sigma2 = sigma1 (createGaussianKernels) */
+			launch_to_gray(c->raw, rows, cols, px * cols, channels, depth == MTFHIP_DEPTH_F32, c->tmp_a, c->stream);
+			launch_sym5(c->tmp_a, c->tmp_b, c->img_owned, rows, cols, kx, ky, c->stream);
+		}
+	}
+	HIP_TRY(hipStreamSynchronize(c->stream)); /* the caller may reuse its frame buffer */
+	c->img = ImgView{c->img_owned, rows, cols, cols};
+	return MTFHIP_OK;
+}
+
+int mtfhip_image_pyramid_level(mtfhip_ctx *dst, mtfhip_ctx *src, int dst_rows, int dst_cols, int use_pyr_down) {
+	if (dst) TRY(lazy_flush_ctx(dst));
+	if (!dst || !src) return fail(MTFHIP_ERR_INVALID_ARG, "image_pyramid_level: NULL argument");
+	if (!src->img.data) return fail(MTFHIP_ERR_LOGIC, "image_pyramid_level: the source context has no image");
+	if (dst == src) return fail(MTFHIP_ERR_INVALID_ARG, "image_pyramid_level: source and destination contexts must differ");
+	if (dst->device != src->device) return fail(MTFHIP_ERR_INVALID_ARG, "image_pyramid_level: contexts live on different devices");
+	if (dst_rows <= 0 || dst_cols <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "image_pyramid_level: bad destination shape");
+	if (src->img.stride != src->img.w) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "image_pyramid_level: padded source rows");
+	const int sr = src->img.h, sc = src->img.w;
+	if (use_pyr_down && (std::abs(dst_cols * 2 - sc) > 2 || std::abs(dst_rows * 2 - sr) > 2))   /* cv::pyrDown's own assertion */
+		return fail(MTFHIP_ERR_INVALID_ARG, "pyrDown: destination %dx%d is not half of %dx%d", dst_rows, dst_cols, sr, sc);
+	HIP_TRY(hipSetDevice(dst->device));
+	HIP_TRY(hipStreamSynchronize(src->stream));
+	TRY(ensure_image(dst, dst_rows, dst_cols));
+	{
+		TimedScope ts(dst, "pyramid_level");
+		if (use_pyr_down) launch_pyr_down(src->img.data, sr, sc, dst->img_owned, dst_rows, dst_cols, dst->stream);
+		else {   /* cv::resize + GaussianBlur(5x5, 3), PyramidalTracker.cc:93-94 */
+			TRY(ensure_tmp(dst, (size_t)dst_rows * dst_cols));
+			float k[3];
+			gaussian5(3.0, k);
+			launch_resize_linear(src->img.data, sr, sc, dst->tmp_a, dst_rows, dst_cols, dst->stream);
+			launch_sym5(dst->tmp_a, dst->tmp_b, dst->img_owned, dst_rows, dst_cols, k, k, dst->stream);
+		}
+	}
+	dst->img = ImgView{dst->img_owned, dst_rows, dst_cols, dst_cols};
+	return MTFHIP_OK;
+}
+
+int mtfhip_image_download(mtfhip_ctx *c, float *host_img, int rows, int cols) {
+	if (!c || !host_img) return fail(MTFHIP_ERR_INVALID_ARG, "image_download: NULL argument");
+	if (!c->img.data) return fail(MTFHIP_ERR_LOGIC, "image_download: no current image");
+	if (rows != c->img.h || cols != c->img.w) return fail(MTFHIP_ERR_INVALID_ARG, "image_download: the image is %dx%d", c->img.h, c->img.w);
+	HIP_TRY(hipMemcpy2DAsync(host_img, (size_t)cols * sizeof(float), c->img.data, (size_t)c->img.stride * sizeof(float),
+		(size_t)cols * sizeof(float), (size_t)rows, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return MTFHIP_OK;
+}
+int mtfhip_image_shape(mtfhip_ctx *c, int *rows, int *cols) {
+	if (!c || !rows || !cols) return fail(MTFHIP_ERR_INVALID_ARG, "image_shape: NULL argument");
+	*rows = c->img.h; *cols = c->img.w;
+	return MTFHIP_OK;
+}
+
+/* ------------------------------------------------------------------ batch */
+int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets, mtfhip_batch **out) {
+	if (!c || !d || !out) return fail(MTFHIP_ERR_INVALID_ARG, "batch_create: NULL argument");
+	/* ImageBase ctor AM/src/ImageBase.cc:33-35, StateSpaceModel ctor StateSpaceModel.h:58-60 */
+	if (d->resx <= 0 || d->resy <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "Invalid sampling resolution provided");
+	if (n_targets <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "batch_create: n_targets must be positive");
+	/* the fused kernel addresses a target's arrays with 32-bit byte offsets (ld_off / st_off): 8 columns of N doubles */
+	if ((double)d->resx * d->resy * 3.0 >= (double)(1u << 26)) return fail(MTFHIP_ERR_INVALID_ARG, "batch_create: %dx%d sample points per target exceed the 2^26-row limit", d->resx, d->resy);
+	if (d->grad_eps <= 0 || d->hess_eps < 0) return fail(MTFHIP_ERR_INVALID_ARG, "batch_create: grad_eps must be positive (got %g)", d->grad_eps);
+	if (d->am < MTFHIP_AM_SSD || d->am > MTFHIP_AM_MI) return fail(MTFHIP_ERR_INVALID_ARG, "unknown appearance model %d", d->am);
+	if (d->am == MTFHIP_AM_MI && (d->mi_n_bins < 2 || d->mi_n_bins > MI_NB)) return fail(MTFHIP_ERR_INVALID_ARG, "MI: n_bins %d outside [2, %d]", d->mi_n_bins, (int)MI_NB);
+	if (d->am == MTFHIP_AM_MI && d->mi_partition_of_unity && d->mi_n_bins < 4) /* MI.cc:83-87 */
+		return fail(MTFHIP_ERR_INVALID_ARG, "MI::Too few bins %d specified to enforce partition of unity constraint", d->mi_n_bins);
+	if (d->ssm != MTFHIP_SSM_HOMOGRAPHY && d->ssm != MTFHIP_SSM_AFFINE) return fail(MTFHIP_ERR_INVALID_ARG, "unknown state space model %d", d->ssm);
+	if (d->n_channels != 0 && d->n_channels != 1 && d->n_channels != 3) return fail(MTFHIP_ERR_INVALID_ARG, "n_channels %d (1 or 3 expected)", d->n_channels);
+	HIP_TRY(hipSetDevice(c->device));
+	mtfhip_batch *b = new mtfhip_batch();
+	b->ctx = c; b->desc = *d; b->B = n_targets;
+	b->C = d->n_channels > 1 ? d->n_channels : 1;
+	b->NP = d->resx * d->resy; b->N = b->NP * b->C;   /* ImageBase: patch_size = n_pix * n_channels */
+	b->S = d->ssm == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
+	if (d->am == MTFHIP_AM_MI) {
+		/* MI ctor AM/src/MI.cc:80-94 */
+		double lo = 0, hi = d->mi_n_bins - 1;
+		if (d->mi_partition_of_unity) { lo = 1; hi = d->mi_n_bins - 2; }
+		b->norm_mult = (hi - lo) / (255.0 - 0.0 + 1);
+		b->norm_add = lo;
+	}
+	const size_t N = b->N, S = b->S, NP = b->NP;
+	size_t per[MTFHIP_BUF_COUNT] = {N, N, 2 * N, 2 * N, N, N, N * S, N * S, N * S, 2 * NP, 2 * NP, 8 * NP, NP, NP, 2 * NP, 2 * NP,
+		4 * N, 4 * N, 16 * NP, S * S * N, S * S * N, S * S * N};
+	b->hess_eps = d->hess_eps > 0 ? d->hess_eps : 1.0; /* HESS_EPS, AM/include/mtf/AM/ImageBase.h:9 */
+	for (int i = 0; i < MTFHIP_BUF_COUNT; ++i) { b->per_target[i] = per[i]; b->buf[i] = nullptr; }
+	b->th.resize(n_targets);
+	for (auto &h : b->th) { std::memset(&h, 0, sizeof(h)); h.warp = m3_identity(); }
+	b->nblk_max = simple_blocks_per_target(b->N);
+	int nf = fused_blocks_per_target(b->N, 1);   /* the finest decomposition is the single-target one */
+	if (nf > b->nblk_max) b->nblk_max = nf;
+	auto cleanup = [&](int code) { mtfhip_batch_destroy(b); return code; };
+	const int eager[] = {MTFHIP_BUF_I0, MTFHIP_BUF_IT, MTFHIP_BUF_DI0_DX, MTFHIP_BUF_DIT_DX, MTFHIP_BUF_DF_DI0,
+		MTFHIP_BUF_DF_DIT, MTFHIP_BUF_J0, MTFHIP_BUF_JT, MTFHIP_BUF_INIT_PTS, MTFHIP_BUF_CURR_PTS,
+		MTFHIP_BUF_INIT_Z, MTFHIP_BUF_CURR_Z, MTFHIP_BUF_INIT_HXY, MTFHIP_BUF_CURR_HXY};
+	for (int id : eager) { int r = ensure_buf(b, id); if (r) return cleanup(r); }
+	{
+		const size_t Bt = (size_t)n_targets, d = sizeof(double);
+		b->slab_dbl_bytes = 54 * Bt * d;
+		b->slab_bytes = b->slab_dbl_bytes + 2 * sizeof(int) * Bt;
+		if (hipMalloc(&b->d_slab, b->slab_bytes) != hipSuccess || hipHostMalloc(&b->h_stage_a, b->slab_bytes) != hipSuccess ||
+			hipHostMalloc(&b->h_stage_b, b->slab_bytes) != hipSuccess || hipEventCreateWithFlags(&b->ev_a, hipEventDisableTiming) != hipSuccess ||
+			hipEventCreateWithFlags(&b->ev_b, hipEventDisableTiming) != hipSuccess ||
+			hipHostMalloc(&b->h_wstage[0], 17 * Bt * d) != hipSuccess || hipHostMalloc(&b->h_wstage[1], 17 * Bt * d) != hipSuccess ||
+			hipEventCreateWithFlags(&b->ev_w[0], hipEventDisableTiming) != hipSuccess ||
+			hipEventCreateWithFlags(&b->ev_w[1], hipEventDisableTiming) != hipSuccess)
+			return cleanup(fail(MTFHIP_ERR_HIP, "allocation of the per-target state slab failed"));
+		double *p = reinterpret_cast<double *>(b->d_slab);
+		b->d_warps = p; b->d_states = p + 9 * Bt; b->d_corners = p + 17 * Bt; b->d_init_corners_hm = p + 25 * Bt;
+		b->d_ncc = p + 37 * Bt; b->d_w0 = p + 45 * Bt;
+		b->d_active = reinterpret_cast<int *>(b->d_slab + b->slab_dbl_bytes); b->d_iters = b->d_active + Bt;
+		(void)hipMemsetAsync(b->d_slab, 0, b->slab_bytes, c->stream);
+	}
+#define ALLOC(ptr, bytes) do { if (hipMalloc(&(ptr), (bytes)) != hipSuccess) return cleanup(fail(MTFHIP_ERR_HIP, "hipMalloc(%zu) failed", (size_t)(bytes))); } while (0)
+	ALLOC(b->d_partials, sizeof(double) * kAccRowMax * b->nblk_max * n_targets);
+	ALLOC(b->d_acc, sizeof(double) * kAccRowMax * n_targets);
+	ALLOC(b->d_scratch_pts, sizeof(double) * 18 * NP * n_targets); /* largest upload: pts (2 NP) + hess_pts (16 NP) */
+	ALLOC(b->d_h0, sizeof(double) * 64 * n_targets);
+	ALLOC(b->d_h0inv, sizeof(double) * 64 * n_targets);
+	ALLOC(b->d_colmean, sizeof(double) * 8 * n_targets);
+	if (d->am == MTFHIP_AM_MI) {
+		const int nb = d->mi_n_bins;
+		b->mi_row_len = std::max(nb + nb * nb, 36 + nb * nb * b->S);
+		/* hist_norm_mult = 1 / (patch_size + hist_pre_seed * n_bins), hist_pre_seed = n_bins * pre_seed (MI.cc:97,104) */
+		b->mi_hist_norm = 1.0 / ((double)b->N + (nb * d->mi_pre_seed) * nb);
+		ALLOC(b->d_mi_tb, sizeof(double) * MI_SIZE * n_targets);
+		ALLOC(b->d_mi_part, sizeof(double) * (size_t)b->mi_row_len * b->nblk_max * n_targets);
+		ALLOC(b->d_mi_f, sizeof(double) * n_targets);
+		ALLOC(b->d_mi_H, sizeof(double) * 64 * n_targets);
+		(void)hipMemsetAsync(b->d_mi_tb, 0, sizeof(double) * MI_SIZE * n_targets, c->stream);
+	}
+#undef ALLOC
+	if (hipHostMalloc(&b->h_acc, sizeof(double) * kAccRowMax * n_targets, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+		return cleanup(fail(MTFHIP_ERR_HIP, "hipHostMalloc failed"));
+	{
+		const char *zc = std::getenv("MTFHIP_ZERO_COPY");
+		void *dp = nullptr, *fp = nullptr;
+		if (!(zc && zc[0] == '0') && hipHostGetDevicePointer(&dp, b->h_acc, 0) == hipSuccess &&
+			hipHostMalloc(&b->h_flag, sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+			hipHostGetDevicePointer(&fp, b->h_flag, 0) == hipSuccess && hipMalloc(&b->d_fin_count, sizeof(int)) == hipSuccess) {
+			*b->h_flag = 0;
+			(void)hipMemsetAsync(b->d_fin_count, 0, sizeof(int), c->stream);
+			b->h_acc_dev = static_cast<double *>(dp); b->h_flag_dev = static_cast<unsigned long long *>(fp);
+		} else (void)hipGetLastError();
+	}
+	(void)hipMemsetAsync(b->d_partials, 0, sizeof(double) * kAccRowMax * b->nblk_max * n_targets, c->stream);
+	int r = push_warps(b);
+	if (r) return cleanup(r);
+	{
+		const char *lazy_env = std::getenv("MTFHIP_LAZY");
+		b->lz.enabled = (d->am == MTFHIP_AM_SSD || d->am == MTFHIP_AM_NCC) && b->C == 1 && !(lazy_env && lazy_env[0] == '0');
+	}
+	c->batches.push_back(b);
+	*out = b;
+	return MTFHIP_OK;
+}
+
+void mtfhip_batch_destroy(mtfhip_batch *b) {
+	if (!b) return;
+	try {
+		auto &reg = b->ctx->batches;
+		reg.erase(std::remove(reg.begin(), reg.end(), b), reg.end());
+		(void)hipSetDevice(b->ctx->device);
+		(void)hipStreamSynchronize(b->ctx->stream);
+		for (int i = 0; i < MTFHIP_BUF_COUNT; ++i)
+			if (b->buf[i]) (void)hipFree(b->buf[i]);
+		void *ptrs[] = {b->d_slab, b->d_partials, b->d_acc, b->d_scratch_pts, b->d_h0,
+			b->d_cand, b->d_colmean, b->d_mi_tb, b->d_mi_part,
+			b->d_mi_f, b->d_mi_H, b->d_h0inv, b->d_units, b->d_d2_part, b->d_d2_out, b->d_d2_w, b->d_done, b->d_it_shadow, b->d_ncc_tm};
+		for (void *p : ptrs)
+			if (p) (void)hipFree(p);
+		if (b->h_acc) (void)hipHostFree(b->h_acc);
+		if (b->h_flag) (void)hipHostFree(b->h_flag);
+		if (b->d_fin_count) (void)hipFree(b->d_fin_count);
+		if (b->h_stage_a) (void)hipHostFree(b->h_stage_a);
+		if (b->h_stage_b) (void)hipHostFree(b->h_stage_b);
+		if (b->ev_a) (void)hipEventDestroy(b->ev_a);
+		if (b->ev_b) (void)hipEventDestroy(b->ev_b);
+		for (int k = 0; k < 2; ++k) {
+			if (b->h_wstage[k]) (void)hipHostFree(b->h_wstage[k]);
+			if (b->ev_w[k]) (void)hipEventDestroy(b->ev_w[k]);
+		}
+	} catch (...) {
+	}
+	delete b;
+}
+
+int mtfhip_batch_n_targets(const mtfhip_batch *b) { return b ? b->B : 0; }
+int mtfhip_batch_n_pix(const mtfhip_batch *b) { return b ? b->NP : 0; }          /* ImageBase::getNPix */
+int mtfhip_batch_patch_size(const mtfhip_batch *b) { return b ? b->N : 0; }      /* ImageBase::getPatchSize = n_pix * n_channels */
+int mtfhip_batch_state_size(const mtfhip_batch *b) { return b ? b->S : 0; }
+
+int mtfhip_batch_read(mtfhip_batch *b, int id, double *dst) {
+	if (!b || !dst || id < 0 || id >= MTFHIP_BUF_COUNT) return fail(MTFHIP_ERR_INVALID_ARG, "batch_read: bad argument");
+	FLUSH(b);
+	if (id == MTFHIP_BUF_DF_DI0 || id == MTFHIP_BUF_DF_DIT) TRY(ensure_df(b));
+	if (!b->buf[id]) return fail(MTFHIP_ERR_LOGIC, "batch_read: buffer %d was never produced", id);
+	if ((id == MTFHIP_BUF_IT && !b->it_valid) || (id == MTFHIP_BUF_DIT_DX && !b->dit_valid) || (id == MTFHIP_BUF_JT && !b->jt_valid))
+		return fail(MTFHIP_ERR_LOGIC, "batch_read: buffer %d is not materialised (last fused iteration ran with materialize=0)", id);
+	HIP_TRY(hipMemcpyAsync(dst, b->buf[id], sizeof(double) * b->per_target[id] * b->B, hipMemcpyDeviceToHost, b->ctx->stream));
+	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	return MTFHIP_OK;
+}
+
+int mtfhip_batch_write(mtfhip_batch *b, int id, const double *src) {
+	if (!b || !src || id < 0 || id >= MTFHIP_BUF_COUNT) return fail(MTFHIP_ERR_INVALID_ARG, "batch_write: bad argument");
+	FLUSH(b);
+	TRY(ensure_df(b));
+	if (id == MTFHIP_BUF_DF_DI0 || id == MTFHIP_BUF_DF_DIT) stale_clear(b, true, true);
+	touch(b, id); ++b->lz.epoch;
+	TRY(ensure_buf(b, id));
+	HIP_TRY(hipMemcpyAsync(b->buf[id], src, sizeof(double) * b->per_target[id] * b->B, hipMemcpyHostToDevice, b->ctx->stream));
+	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	if (id == MTFHIP_BUF_IT) b->it_valid = true;
+	if (id == MTFHIP_BUF_DIT_DX) b->dit_valid = true;
+	if (id == MTFHIP_BUF_JT) b->jt_valid = true;
+	if (id == MTFHIP_BUF_J0 || id == MTFHIP_BUF_DI0_DX || id == MTFHIP_BUF_INIT_PTS || id == MTFHIP_BUF_INIT_Z) b->j0_is_template = false;
+	/* a caller that supplies its own homogeneous grid gets the general (non unit-z) kernels */
+	if (id == MTFHIP_BUF_INIT_Z || id == MTFHIP_BUF_INIT_HXY) b->unit_z = 0;
+	return MTFHIP_OK;
+}
+
+void *mtfhip_batch_device_ptr(mtfhip_batch *b, int id) {
+	if (!b || id < 0 || id >= MTFHIP_BUF_COUNT) return nullptr;
+	/* a raw pointer lets the caller write behind the library's back: no more deferral or host-side caches for this batch */
+	if (lazy_flush(b) != MTFHIP_OK || ensure_df(b) != MTFHIP_OK) return nullptr;
+	b->lz.enabled = false; b->lz.no_cache = true;
+	if (ensure_buf(b, id) != MTFHIP_OK) return nullptr;
+	return b->buf[id];
+}
+
+/* ------------------------------------------------------------------ SSM */
+int mtfhip_ssm_set_corners(mtfhip_batch *b, const double *corners) {
+	FLUSH(b);
+	if (b) ++b->lz.epoch;
+	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
+	if (!b || !corners) return fail(MTFHIP_ERR_INVALID_ARG, "set_corners: NULL argument");
+	const bool hom = b->desc.ssm == MTFHIP_SSM_HOMOGRAPHY;
+	/* normalised grid extents: ProjectiveBase.cc:14 (unit square) ; Affine.cc:56-57 */
+	double lo_x = -0.5, lo_y = -0.5, hi_x = 0.5, hi_y = 0.5;
+	if (!hom) { lo_x = 1 - b->desc.resx / 2.0; lo_y = 1 - b->desc.resy / 2.0; hi_x = b->desc.resx / 2.0; hi_y = b->desc.resy / 2.0; }
+	const double nc[8] = {lo_x, lo_y, hi_x, lo_y, hi_x, hi_y, lo_x, hi_y};
+	std::vector<double> w0(9 * b->B);
+	int unit_z = 1;
+	for (int t = 0; t < b->B; ++t) {
+		M3 W0;
+		if (!dlt4(nc, corners + 8 * t, W0)) return fail(MTFHIP_ERR_INVALID_ARG, "set_corners: degenerate corners for target %d", t);
+		if (!hom || (std::fabs(W0.m[6]) < 1e-15 && std::fabs(W0.m[7]) < 1e-15)) {
+			if (hom) { W0.m[6] = 0; W0.m[7] = 0; }
+		} else unit_z = 0;
+		std::memcpy(&w0[9 * t], W0.m, sizeof(double) * 9);
+		TargetHost &h = b->th[t];
+		std::memcpy(h.corners, corners + 8 * t, sizeof(double) * 8);
+		std::memcpy(h.init_corners, corners + 8 * t, sizeof(double) * 8);
+		for (int q = 0; q < 4; ++q) {
+			h.init_corners_hm[3 * q] = corners[8 * t + 2 * q];
+			h.init_corners_hm[3 * q + 1] = corners[8 * t + 2 * q + 1];
+			h.init_corners_hm[3 * q + 2] = 1;
+		}
+		h.warp = m3_identity();
+		std::memset(h.state, 0, sizeof(h.state));
+	}
+	b->unit_z = hom ? unit_z : 1;
+	/* w0, init_corners_hm, identity warps, zero states and the corners in ONE pinned async copy; the staging buffer is
+	 * protected by an event instead of a stream sync */
+	HIP_TRY(hipEventSynchronize(b->ev_a));
+	fill_stage(b, b->h_stage_a, w0.data(), 0, false);
+	HIP_TRY(hipMemcpyAsync(b->d_slab, b->h_stage_a, b->slab_dbl_bytes, hipMemcpyHostToDevice, b->ctx->stream));
+	HIP_TRY(hipEventRecord(b->ev_a, b->ctx->stream));
+	{
+		TimedScope ts(b->ctx, "init_grid");
+		launch_init_grid(b->view(), b->d_w0, b->desc.resx, b->desc.resy, lo_x, lo_y, hi_x, hi_y, hom ? 0 : 1, b->ctx->stream);
+	}
+	b->have_corners = true;
+	b->pts_stale = false;   /* k_init_grid writes the current points too */
+	++b->corners_epoch;
+	return MTFHIP_OK;
+}
+
+int ensure_pts(mtfhip_batch *b) {
+	if (!b->pts_stale) return MTFHIP_OK;
+	b->pts_stale = false;
+	TimedScope ts(b->ctx, "apply_warp");
+	launch_apply_warp(b->view(), b->ctx->stream);
+	return MTFHIP_OK;
+}
+static int apply_states(mtfhip_batch *b) {
+	TRY(push_warps(b));
+	b->pts_stale = true;
+	if (!b->lz.enabled) return ensure_pts(b);
+	return MTFHIP_OK;
+}
+
+int mtfhip_ssm_set_state(mtfhip_batch *b, const double *states) {
+	FLUSH(b);
+	if (b) ++b->lz.epoch;
+	if (!b || !states) return fail(MTFHIP_ERR_INVALID_ARG, "set_state: NULL argument");
+	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "set_state before set_corners");
+	for (int t = 0; t < b->B; ++t) {
+		TargetHost &h = b->th[t];
+		std::memset(h.state, 0, sizeof(h.state));
+		std::memcpy(h.state, states + (size_t)t * b->S, sizeof(double) * b->S);
+		h.warp = warp_from_state(b->desc.ssm, h.state);
+		update_corners(b, t);
+	}
+	return apply_states(b);
+}
+
+int mtfhip_ssm_compositional_update(mtfhip_batch *b, const double *dps) {
+	FLUSH(b);
+	if (b) ++b->lz.epoch;
+	if (!b || !dps) return fail(MTFHIP_ERR_INVALID_ARG, "compositional_update: NULL argument");
+	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "compositional_update before set_corners");
+	for (int t = 0; t < b->B; ++t) {
+		TargetHost &h = b->th[t];
+		double dp[8] = {0};
+		std::memcpy(dp, dps + (size_t)t * b->S, sizeof(double) * b->S);
+		M3 upd = warp_from_state(b->desc.ssm, dp);
+		h.warp = m3_mul(h.warp, upd);
+		if (b->desc.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+			double s = h.warp.m[8];
+			for (int i = 0; i < 9; ++i) h.warp.m[i] /= s;
+		}
+		state_from_warp(b->desc.ssm, h.state, h.warp);
+		update_corners(b, t);
+	}
+	return apply_states(b);
+}
+
+int mtfhip_ssm_invert_state(mtfhip_batch *b, const double *states, double *inv_states) {
+	if (!b || !states || !inv_states) return fail(MTFHIP_ERR_INVALID_ARG, "invert_state: NULL argument");
+	for (int t = 0; t < b->B; ++t) {
+		double p[8] = {0}, q[8];
+		std::memcpy(p, states + (size_t)t * b->S, sizeof(double) * b->S);
+		M3 Wi = m3_inverse(warp_from_state(b->desc.ssm, p));
+		double s = Wi.m[8];
+		for (int i = 0; i < 9; ++i) Wi.m[i] /= s;
+		state_from_warp(b->desc.ssm, q, Wi);
+		std::memcpy(inv_states + (size_t)t * b->S, q, sizeof(double) * b->S);
+	}
+	return MTFHIP_OK;
+}
+
+int do_update_grad_pts(mtfhip_batch *b, double grad_eps) {
+	TRY(ensure_buf(b, MTFHIP_BUF_GRAD_PTS));
+	TimedScope ts(b->ctx, "grad_pts");
+	launch_grad_pts(b->view(), grad_eps, b->ctx->stream);
+	return MTFHIP_OK;
+}
+int mtfhip_ssm_update_grad_pts(mtfhip_batch *b, double grad_eps) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_grad_pts: NULL batch");
+	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "update_grad_pts before set_corners");
+	if (b->lz.enabled && grad_eps == b->desc.grad_eps) {
+		if (b->lz.gp || b->lz.pg) FLUSH(b);
+		b->lz.gp = ++b->lz.seq;
+		return MTFHIP_OK;
+	}
+	FLUSH(b);
+	return do_update_grad_pts(b, grad_eps);
+}
+
+int do_cmpt_pix_jacobian(mtfhip_batch *b, int variant, int grad_buf, int dst_buf) {
+	TRY(ensure_buf(b, dst_buf));
+	TimedScope ts(b->ctx, "pix_jacobian");
+	launch_pix_jacobian(b->view(), variant, b->buf[grad_buf], b->buf[dst_buf], b->ctx->stream);
+	touch(b, dst_buf);
+	if (dst_buf == MTFHIP_BUF_JT) b->jt_valid = true;
+	if (dst_buf == MTFHIP_BUF_J0) b->j0_is_template = false;
+	return MTFHIP_OK;
+}
+int mtfhip_ssm_cmpt_pix_jacobian(mtfhip_batch *b, int variant, int grad_buf, int dst_buf) {
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "cmpt_pix_jacobian: NULL batch");
+	if (variant < MTFHIP_JAC_INIT || variant > MTFHIP_JAC_APPROX) return fail(MTFHIP_ERR_INVALID_ARG, "unknown Jacobian variant %d", variant);
+	if (grad_buf != MTFHIP_BUF_DI0_DX && grad_buf != MTFHIP_BUF_DIT_DX) return fail(MTFHIP_ERR_INVALID_ARG, "grad_buf must be DI0_DX or DIT_DX");
+	if (!j_buf_ok(dst_buf)) return fail(MTFHIP_ERR_INVALID_ARG, "dst_buf must be J0, JT or JM");
+	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "cmpt_pix_jacobian before set_corners");
+	if (b->lz.enabled && grad_buf == MTFHIP_BUF_DIT_DX && dst_buf == MTFHIP_BUF_JT &&
+		(variant == MTFHIP_JAC_WARPED || variant == MTFHIP_JAC_INIT)) {
+		if (b->lz.pj || b->lz.jm) FLUSH(b);
+		TRY(ensure_buf(b, dst_buf));
+		b->lz.pj = ++b->lz.seq; b->lz.pj_variant = variant;
+		b->jt_valid = true;
+		return MTFHIP_OK;
+	}
+	FLUSH(b);
+	return do_cmpt_pix_jacobian(b, variant, grad_buf, dst_buf);
+}
+
+int mtfhip_ssm_get_corners(mtfhip_batch *b, double *corners) {
+	if (!b || !corners) return fail(MTFHIP_ERR_INVALID_ARG, "get_corners: NULL argument");
+	for (int t = 0; t < b->B; ++t) std::memcpy(corners + 8 * t, b->th[t].corners, sizeof(double) * 8);
+	return MTFHIP_OK;
+}
+int mtfhip_ssm_get_init_corners(mtfhip_batch *b, double *corners) {
+	if (!b || !corners) return fail(MTFHIP_ERR_INVALID_ARG, "get_init_corners: NULL argument");
+	for (int t = 0; t < b->B; ++t) std::memcpy(corners + 8 * t, b->th[t].init_corners, sizeof(double) * 8);
+	return MTFHIP_OK;
+}
+int mtfhip_ssm_get_state(mtfhip_batch *b, double *states) {
+	if (!b || !states) return fail(MTFHIP_ERR_INVALID_ARG, "get_state: NULL argument");
+	for (int t = 0; t < b->B; ++t) std::memcpy(states + (size_t)t * b->S, b->th[t].state, sizeof(double) * b->S);
+	return MTFHIP_OK;
+}
+int mtfhip_ssm_get_warp(mtfhip_batch *b, double *warps) {
+	if (!b || !warps) return fail(MTFHIP_ERR_INVALID_ARG, "get_warp: NULL argument");
+	for (int t = 0; t < b->B; ++t) std::memcpy(warps + 9 * t, b->th[t].warp.m, sizeof(double) * 9);
+	return MTFHIP_OK;
+}
+int mtfhip_ssm_apply_warp_to_corners(mtfhip_batch *b, const double *in_corners, const double *states, double *out_corners) {
+	if (!b || !in_corners || !states || !out_corners) return fail(MTFHIP_ERR_INVALID_ARG, "apply_warp_to_corners: NULL argument");
+	for (int t = 0; t < b->B; ++t) {
+		double p[8] = {0};
+		std::memcpy(p, states + (size_t)t * b->S, sizeof(double) * b->S);
+		M3 W = warp_from_state(b->desc.ssm, p);
+		for (int q = 0; q < 4; ++q) {
+			double x = in_corners[8 * t + 2 * q], y = in_corners[8 * t + 2 * q + 1];
+			double nx = W.m[0] * x + W.m[1] * y + W.m[2], ny = W.m[3] * x + W.m[4] * y + W.m[5];
+			if (b->desc.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+				double d = W.m[6] * x + W.m[7] * y + W.m[8];
+				nx = nx / d; ny = ny / d;
+			}
+			out_corners[8 * t + 2 * q] = nx; out_corners[8 * t + 2 * q + 1] = ny;
+		}
+	}
+	return MTFHIP_OK;
+}
+
+/* ------------------------------------------------------------------ timing */
+int mtfhip_timing_enable(mtfhip_ctx *c, int on) {
+	if (!c) return fail(MTFHIP_ERR_INVALID_ARG, "timing_enable: NULL ctx");
+	c->timing = on != 0;
+	c->timing_stride = on > 1 ? on : 1;
+	return MTFHIP_OK;
+}
+static void drain(mtfhip_ctx *c) {
+	(void)hipStreamSynchronize(c->stream);
+	for (auto &kv : c->timers) {
+		for (auto &p : kv.second.pending) {
+			float ms = 0;
+			if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { kv.second.total_ms += ms; kv.second.n += 1; }
+			c->free_events.push_back(p.first);
+			c->free_events.push_back(p.second);
+		}
+		kv.second.pending.clear();
+	}
+}
+int mtfhip_timing_reset(mtfhip_ctx *c) {
+	if (!c) return fail(MTFHIP_ERR_INVALID_ARG, "timing_reset: NULL ctx");
+	drain(c);
+	for (auto &kv : c->timers) { kv.second.total_ms = 0; kv.second.n = 0; kv.second.launches = 0; }
+	return MTFHIP_OK;
+}
+int mtfhip_timing_get(mtfhip_ctx *c, const char *family, double *avg_ms, int *n_launches) {
+	if (!c || !family) return fail(MTFHIP_ERR_INVALID_ARG, "timing_get: NULL argument");
+	drain(c);
+	auto it = c->timers.find(family);
+	double avg = 0; int n = 0;
+	if (it != c->timers.end() && it->second.n > 0) { avg = it->second.total_ms / it->second.n; n = it->second.n; }
+	if (avg_ms) *avg_ms = avg;
+	if (n_launches) *n_launches = n;
+	return MTFHIP_OK;
+}
+
+
+} /* extern "C" */

@@ -1,0 +1,690 @@
+/*
+ * api_fused.hip -- the fused path: template initialisation, iterate / track, NCC moment forms, candidate scoring, NN dataset rows
+ * (C-ABI implementation, include/mtfhip.h; shared declarations: mtfhip_api_internal.h)
+ *
+ * No CPU fallback exists: every entry point either runs its HIP kernels or returns an error.
+ */
+#include "mtfhip_api_internal.h"
+
+extern "C" {
+
+/* ------------------------------------------------------------------ fused path */
+static int check_sm(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const char *fn) {
+	if (!b || !sm) return fail(MTFHIP_ERR_INVALID_ARG, "%s: NULL argument", fn);
+	if (sm->sm < MTFHIP_SM_ESM || sm->sm > MTFHIP_SM_ICLK) return fail(MTFHIP_ERR_INVALID_ARG, "%s: unknown search method %d", fn, sm->sm);
+	int max_h = sm->sm == MTFHIP_SM_ESM ? 5 : 2;
+	if (sm->hess_type < 0 || sm->hess_type > max_h) return fail(MTFHIP_ERR_INVALID_ARG, "%s: hess_type %d invalid for search method %d", fn, sm->hess_type, sm->sm);
+	if (b->desc.am == MTFHIP_AM_NCC) {
+		if (sm->sec_ord_hess) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: second-order NCC Hessians go through the per-function entry points", fn);
+		return MTFHIP_OK;
+	}
+	if (b->desc.am != MTFHIP_AM_SSD) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: the fused path supports SSD and NCC; MI uses the per-function entry points", fn);
+	return MTFHIP_OK;
+}
+
+/* inverse of a definite S x S matrix (column-major) by Gauss-Jordan on the diagonally scaled system */
+static bool invert_definite(int S, const double *H, double *Hinv) {
+	double A[8][16], sc[8];
+	for (int i = 0; i < S; ++i) { double d = std::fabs(H[i * S + i]); sc[i] = d > 0 ? 1.0 / std::sqrt(d) : 1.0; }
+	for (int i = 0; i < S; ++i)
+		for (int j = 0; j < S; ++j) { A[i][j] = H[j * S + i] * sc[i] * sc[j]; A[i][S + j] = i == j ? 1.0 : 0.0; }
+	for (int k = 0; k < S; ++k) {
+		int piv = k;
+		for (int i = k + 1; i < S; ++i) if (std::fabs(A[i][k]) > std::fabs(A[piv][k])) piv = i;
+		if (A[piv][k] == 0) return false;
+		if (piv != k) for (int j = 0; j < 2 * S; ++j) std::swap(A[piv][j], A[k][j]);
+		const double p = A[k][k];
+		for (int j = 0; j < 2 * S; ++j) A[k][j] /= p;
+		for (int i = 0; i < S; ++i) {
+			if (i == k) continue;
+			const double f = A[i][k];
+			if (f == 0) continue;
+			for (int j = 0; j < 2 * S; ++j) A[i][j] -= f * A[k][j];
+		}
+	}
+	for (int i = 0; i < S; ++i)
+		for (int j = 0; j < S; ++j) Hinv[j * S + i] = A[i][S + j] * sc[i] * sc[j];
+	return true;
+}
+
+/* ---- NCC on the fused path: everything NCC.cc derives from centred vectors, written in raw moments ----
+ * With mt = mean(It), m0 = mean(I0), b = |It - mt|, c = |I0 - m0|, f = a / (b c)  (NCC.cc:124-161) and, for a pixel
+ * Jacobian X with column sums sX, Gram(X), sum It X = itX, sum I0 X = i0X:
+ *   Jc = (X - mean(X)) / b                       G(X)  = -Jc^T Jc            = -(Gram(X) - sX sX^T / N) / b^2
+ *   ut(X) = Jc^T (It - mt) / b = (itX - mt sX) / b^2        u0(X) = Jc^T (I0 - m0) / c = (i0X - m0 sX) / (b c)
+ *   df_dIt . X = u0 - f ut   (NCC.cc:196-234, 252-266)       df_dI0 . X = (b / c) (ut - f u0)   (NCC.cc:163-194, 236-250)
+ *   cmptCurrHessian = f G - ut u0^T - u0 ut^T + 3 ut ut^T   (NCC.cc:304-335)    cmptInitHessian: ... + 3 u0 u0^T (NCC.cc:282-303)
+ *   cmptSelfHessian = G + ut ut^T   (NCC.cc:337-389)
+ * (the reference also subtracts the mean of the gradient vectors, which is zero up to rounding because the centred
+ * vectors sum to zero; it does not survive into the moments).  Moments of the mean Jacobian (J0 + Jt) / 2 are the means of
+ * the moments, except its Gram matrix, which the kernel accumulates itself when hess_mean is set. */
+struct NccX { const double *gram; double s[8], it[8], i0[8]; };
+struct NccScalars { double N, mt, m0, b, b2, c, f; };
+static void ncc_vecs(const NccScalars &q, const NccX &X, int S, double *ut, double *u0) {
+	for (int s = 0; s < S; ++s) {
+		ut[s] = (X.it[s] - q.mt * X.s[s]) / q.b2;
+		u0[s] = (X.i0[s] - q.m0 * X.s[s]) / (q.b * q.c);
+	}
+}
+/* kind 0 init, 1 curr, 2 self; H column-major S x S */
+static void ncc_hess_from_moments(const NccScalars &q, const NccX &X, int S, int kind, double *H) {
+	double ut[8], u0[8];
+	ncc_vecs(q, X, S, ut, u0);
+	for (int r = 0; r < S; ++r)
+		for (int c = 0; c < S; ++c) {
+			const int a = r < c ? r : c, d = r < c ? c : r;
+			const double G = -(X.gram[a * 8 - (a * (a - 1)) / 2 + (d - a)] - X.s[r] * X.s[c] / q.N) / q.b2;
+			double v;
+			if (kind == 2) v = G + ut[r] * ut[c];
+			else v = q.f * G - ut[r] * u0[c] - u0[r] * ut[c] + 3 * (kind == 1 ? ut[r] * ut[c] : u0[r] * u0[c]);
+			H[c * S + r] = v;
+		}
+}
+static NccScalars ncc_scalars(const mtfhip_batch *b, const TargetHost &h, const double *M) {
+	NccScalars q;
+	q.N = (double)b->N; q.mt = M[NCC_IT] / q.N; q.m0 = h.I0_mean; q.c = h.c;
+	const double a = M[NCC_I0IT] - q.N * q.m0 * q.mt;
+	q.b2 = M[NCC_IT2] - q.N * q.mt * q.mt; q.b = std::sqrt(q.b2);
+	q.f = a / (q.b * q.c);
+	return q;
+}
+static void ncc_x(const mtfhip_batch *b, const TargetHost &h, const double *M, int which /* 0 J0, 1 Jt, 2 Jm */, bool gram_is_mean, NccX &X) {
+	const int S = b->S;
+	for (int s = 0; s < 8; ++s) X.s[s] = X.it[s] = X.i0[s] = 0;
+	for (int s = 0; s < S; ++s) {
+		const double s0 = h.ncc_sj0[s], it0 = M[NCC_ITJ0 + s], i00 = h.ncc_i0j0[s];
+		const double st = M[NCC_SJ + s], itt = M[NCC_ITJ + s], i0t = M[NCC_I0J + s];
+		if (which == 0) { X.s[s] = s0; X.it[s] = it0; X.i0[s] = i00; }
+		else if (which == 1) { X.s[s] = st; X.it[s] = itt; X.i0[s] = i0t; }
+		else { X.s[s] = (s0 + st) / 2; X.it[s] = (it0 + itt) / 2; X.i0[s] = (i00 + i0t) / 2; }
+	}
+	X.gram = which == 0 ? h.ncc_gram0 : ((which == 2) == gram_is_mean ? M + NCC_GRAM : nullptr);
+}
+/* one target's reduced moment row -> the SM's f, g, H (before LM damping); NT/ESM.cc:298-377, NT/FCLK.cc:260-288, NT/ICLK.cc:206-251 */
+static int ncc_assemble(const mtfhip_batch *b, const mtfhip_sm_desc *sm, bool hess_mean, const double *M, TargetHost &h,
+	double *f, double *g, double *H) {
+	const int S = b->S;
+	const NccScalars q = ncc_scalars(b, h, M);
+	h.It_mean = q.mt; h.b = q.b; h.a = M[NCC_I0IT] - q.N * q.m0 * q.mt; h.f = q.f;
+	if (f) *f = q.f;
+	NccX X0, Xt, Xm;
+	ncc_x(b, h, M, 0, hess_mean, X0); ncc_x(b, h, M, 1, hess_mean, Xt); ncc_x(b, h, M, 2, hess_mean, Xm);
+	double ut[8], u0[8];
+	auto curr_jac = [&](const NccX &X, double *o) { ncc_vecs(q, X, S, ut, u0); for (int s = 0; s < S; ++s) o[s] = u0[s] - q.f * ut[s]; };
+	auto init_jac = [&](const NccX &X, double *o) { ncc_vecs(q, X, S, ut, u0); for (int s = 0; s < S; ++s) o[s] = (q.b / q.c) * (ut[s] - q.f * u0[s]); };
+	if (sm->sm == MTFHIP_SM_FCLK) curr_jac(Xt, g);
+	else if (sm->sm == MTFHIP_SM_ICLK) init_jac(X0, g);
+	else if (sm->jac_type == 0) curr_jac(Xm, g);
+	else { double gt[8], g0[8]; curr_jac(Xt, gt); init_jac(X0, g0); for (int s = 0; s < S; ++s) g[s] = 0.5 * (gt[s] - g0[s]); }
+	const int ht = sm->hess_type;
+	auto need = [&](const NccX &X) { return X.gram ? MTFHIP_OK : fail(MTFHIP_ERR_LOGIC, "fused NCC: the Gram matrix this Hessian needs was not accumulated"); };
+	if (ht == 0) { std::memcpy(H, h.h0, sizeof(double) * S * S); return MTFHIP_OK; }
+	if (sm->sm == MTFHIP_SM_ICLK) { ncc_hess_from_moments(q, X0, S, 0, H); return MTFHIP_OK; }   /* Std: cmptInitHessian(J0) */
+	if (sm->sm == MTFHIP_SM_FCLK || ht == 1 || ht == 5) { TRY(need(Xt)); ncc_hess_from_moments(q, Xt, S, ht == 1 ? 2 : 1, H); return MTFHIP_OK; }
+	if (ht == 2) {   /* SumOfSelf */
+		TRY(need(Xt)); ncc_hess_from_moments(q, Xt, S, 2, H);
+		for (int k = 0; k < S * S; ++k) H[k] = 0.5 * (H[k] + h.h0[k]);
+		return MTFHIP_OK;
+	}
+	if (ht == 3) { TRY(need(Xm)); ncc_hess_from_moments(q, Xm, S, 1, H); return MTFHIP_OK; }   /* Original: cmptCurrHessian(mean) */
+	/* SumOfStd: (cmptInitHessian(J0) + cmptCurrHessian(Jt)) / 2 */
+	TRY(need(Xt));
+	double Hi[64];
+	ncc_hess_from_moments(q, X0, S, 0, Hi); ncc_hess_from_moments(q, Xt, S, 1, H);
+	for (int k = 0; k < S * S; ++k) H[k] = 0.5 * (H[k] + Hi[k]);
+	return MTFHIP_OK;
+}
+/* sum J0, sum I0 J0 and Gram(J0) of the template (after every change of J0) */
+int gemv_to_host(mtfhip_batch *b, const double *v1, int j1, const double *v2, int j2, int sum_mode, double *g, int diff);
+int ncc_template_moments(mtfhip_batch *b) {
+	const int nblk = simple_blocks_per_target(b->N), S = b->S;
+	{
+		TimedScope ts(b->ctx, "ncc_hess");
+		launch_col_sum(b->view(), b->buf[MTFHIP_BUF_J0], b->d_partials, nblk, b->ctx->stream);
+	}
+	TRY(read_acc(b, nblk));
+	for (int t = 0; t < b->B; ++t)
+		for (int s = 0; s < 8; ++s) b->th[t].ncc_sj0[s] = s < S ? b->h_acc[(size_t)t * ACC_COUNT + ACC_G + s] : 0.0;
+	std::vector<double> g((size_t)b->B * S);
+	TRY(gemv_to_host(b, b->buf[MTFHIP_BUF_I0], MTFHIP_BUF_J0, nullptr, -1, 0, g.data(), 0));
+	for (int t = 0; t < b->B; ++t)
+		for (int s = 0; s < 8; ++s) b->th[t].ncc_i0j0[s] = s < S ? g[(size_t)t * S + s] : 0.0;
+	{
+		TimedScope ts(b->ctx, "gram");
+		launch_gram(b->view(), b->buf[MTFHIP_BUF_J0], b->d_partials, nblk, b->ctx->stream);
+	}
+	TRY(read_acc(b, nblk));
+	for (int t = 0; t < b->B; ++t) std::memcpy(b->th[t].ncc_gram0, b->h_acc + (size_t)t * ACC_COUNT + ACC_H, sizeof(double) * 36);
+	/* device copy for the device-side finish (k_finish_track) */
+	if (!b->d_ncc_tm) HIP_TRY(hipMalloc(&b->d_ncc_tm, sizeof(double) * 52 * (size_t)b->B));
+	std::vector<double> tm((size_t)52 * b->B);
+	for (int t = 0; t < b->B; ++t) {
+		std::memcpy(&tm[52 * (size_t)t], b->th[t].ncc_sj0, sizeof(double) * 8);
+		std::memcpy(&tm[52 * (size_t)t + 8], b->th[t].ncc_i0j0, sizeof(double) * 8);
+		std::memcpy(&tm[52 * (size_t)t + 16], b->th[t].ncc_gram0, sizeof(double) * 36);
+	}
+	HIP_TRY(hipMemcpyAsync(b->d_ncc_tm, tm.data(), sizeof(double) * tm.size(), hipMemcpyHostToDevice, b->ctx->stream));
+	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	return MTFHIP_OK;
+}
+
+/* deferred fusion, NCC: the AM-level Jacobian the trigger asked for, and the moment rows kept for the Hessian calls */
+int ncc_lazy_outputs(mtfhip_batch *b, int trig, int j_a, bool hess_mean, double *g) {
+	mtfhip_batch::Lazy &L = b->lz;
+	const int S = b->S;
+	for (int t = 0; t < b->B; ++t) {
+		const double *M = b->h_acc + (size_t)t * NCC_ACC_COUNT;
+		TargetHost &h = b->th[t];
+		const NccScalars q = ncc_scalars(b, h, M);
+		h.It_mean = q.mt; h.b = q.b; h.a = M[NCC_I0IT] - q.N * q.m0 * q.mt; h.f = q.f;
+		NccX X;
+		double ut[8], u0[8], *o = g + (size_t)t * S;
+		if (trig == LAZY_INIT_JAC) {
+			ncc_x(b, h, M, 0, hess_mean, X); ncc_vecs(q, X, S, ut, u0);
+			for (int s = 0; s < S; ++s) o[s] = (q.b / q.c) * (ut[s] - q.f * u0[s]);
+		} else {
+			ncc_x(b, h, M, (trig == LAZY_CURR_JAC && j_a == MTFHIP_BUF_JM) ? 2 : 1, hess_mean, X); ncc_vecs(q, X, S, ut, u0);
+			for (int s = 0; s < S; ++s) o[s] = u0[s] - q.f * ut[s];
+			if (trig == LAZY_DIFF_JAC) {   /* (df_dIt . Jt) - (df_dI0 . J0), NCC.cc:268-280 */
+				ncc_x(b, h, M, 0, hess_mean, X); ncc_vecs(q, X, S, ut, u0);
+				for (int s = 0; s < S; ++s) o[s] -= (q.b / q.c) * (ut[s] - q.f * u0[s]);
+			}
+		}
+	}
+	b->ncc_host_newer = true;
+	if (!L.no_cache) {
+		L.ncc_M.assign(b->h_acc, b->h_acc + (size_t)NCC_ACC_COUNT * b->B);
+		L.ncc_M_mean = hess_mean;
+		L.ncc_M_it = L.ver[MTFHIP_BUF_IT]; L.ncc_M_jt = L.ver[MTFHIP_BUF_JT]; L.ncc_M_jm = L.ver[MTFHIP_BUF_JM];
+	}
+	return MTFHIP_OK;
+}
+/* 1 when H was produced from the cached moment rows */
+int ncc_hessian_from_cache(mtfhip_batch *b, int j_buf, int kind, double *H) {
+	mtfhip_batch::Lazy &L = b->lz;
+	if (L.no_cache || L.ncc_M.empty() || L.ncc_M_it != L.ver[MTFHIP_BUF_IT]) return 0;
+	int which;
+	if (j_buf == MTFHIP_BUF_J0) { if (L.ncc_tm_ver != L.ver[MTFHIP_BUF_J0]) return 0; which = 0; }
+	else if (j_buf == MTFHIP_BUF_JT) { if (L.ncc_M_mean || L.ncc_M_jt != L.ver[MTFHIP_BUF_JT]) return 0; which = 1; }
+	else { if (!L.ncc_M_mean || L.ncc_M_jm != L.ver[MTFHIP_BUF_JM] || L.ncc_M_jt != L.ver[MTFHIP_BUF_JT] || L.ncc_tm_ver != L.ver[MTFHIP_BUF_J0]) return 0; which = 2; }
+	for (int t = 0; t < b->B; ++t) {
+		const double *M = &L.ncc_M[(size_t)t * NCC_ACC_COUNT];
+		const NccScalars q = ncc_scalars(b, b->th[t], M);
+		NccX X;
+		ncc_x(b, b->th[t], M, which, L.ncc_M_mean, X);
+		if (!X.gram) return 0;
+		ncc_hess_from_moments(q, X, b->S, kind, H + (size_t)t * b->S * b->S);
+	}
+	return 1;
+}
+
+/* getSimilarity() right after updatePixVals + updateSimilarity -- Levenberg-Marquardt's test in the middle of every
+ * iteration (NT/ESM.cc:186-204, FCLK.cc:205-223, ICLK.cc:181-199): one launch of the lean (ICLK-type) fused kernel
+ * writes IT and accumulates what f needs, instead of sample + residual (SSD) or sample + two reduction passes with
+ * two host round trips (NCC).  Anything else pending, or nothing pending: not taken, the caller flushes. */
+int lazy_try_similarity(mtfhip_batch *b) {
+	mtfhip_batch::Lazy &L = b->lz;
+	if (!L.enabled || !L.pv || !L.sim || L.pv > L.sim || L.gp || L.pg || L.pj || L.cg || L.ig || L.jm) return MTFHIP_OK;
+	if (!b->init_pix_vals || !b->init_sim || !b->have_corners || !b->ctx->img.data || b->ctx->img.channels != 1) return MTFHIP_OK;
+	const bool ncc = b->desc.am == MTFHIP_AM_NCC;
+	mtfhip_sm_desc sm;
+	std::memset(&sm, 0, sizeof(sm));
+	sm.sm = MTFHIP_SM_ICLK; sm.hess_type = 0; sm.materialize = 1; sm.max_iters = 1; sm.chained_warp = 1;
+	FusedArgs fa;
+	TRY(fused_args(b, &sm, fa));
+	TRY(protect_stale(b, !ncc, false));   /* SSD's updateSimilarity re-produces df_dI0 */
+	const int nblk = fused_blocks_per_target(b->N, b->B);
+	{
+		TimedScope ts(b->ctx, "fused_lk");
+		launch_fused_ssd(b->view(), b->ctx->img, fa, b->d_partials, nblk, b->ctx->stream);
+	}
+	touch(b, MTFHIP_BUF_IT);
+	b->it_valid = true;
+	L.it_epoch = L.epoch;
+	L.df0_it_ver = L.ver[MTFHIP_BUF_IT];
+	if (!ncc) { L.df0_stale = true; L.df0_sh = false; if (!L.dft_sh) L.shadow_valid = false; }
+	L.pv = L.sim = 0;
+	if (ncc) {
+		TRY(read_rows(b, nblk, NCC_ACC_COUNT));
+		for (int t = 0; t < b->B; ++t) {
+			const double *M = b->h_acc + (size_t)t * NCC_ACC_COUNT;
+			TargetHost &h = b->th[t];
+			const NccScalars q = ncc_scalars(b, h, M);
+			h.It_mean = q.mt; h.b = q.b; h.a = M[NCC_I0IT] - q.N * q.m0 * q.mt; h.f = q.f;
+		}
+		b->ncc_host_newer = true;
+		if (!L.no_cache) {   /* sum It J0 and the scalars: enough for cmptInitJacobian / cmptInitHessian of this IT */
+			L.ncc_M.assign(b->h_acc, b->h_acc + (size_t)NCC_ACC_COUNT * b->B);
+			L.ncc_M_mean = false; L.ncc_M_it = L.ver[MTFHIP_BUF_IT]; L.ncc_M_jt = L.ncc_M_jm = -1;
+		}
+		return MTFHIP_OK;
+	}
+	TRY(read_acc(b, nblk));
+	for (int t = 0; t < b->B; ++t) b->th[t].f = -b->h_acc[(size_t)t * ACC_COUNT + ACC_RR] / 2;
+	if (!L.no_cache) {
+		L.sim_g.resize((size_t)8 * b->B);
+		for (int t = 0; t < b->B; ++t) std::memcpy(&L.sim_g[(size_t)8 * t], b->h_acc + (size_t)t * ACC_COUNT + ACC_G, sizeof(double) * 8);
+		L.sim_g_it = L.ver[MTFHIP_BUF_IT]; L.sim_g_j0 = L.ver[MTFHIP_BUF_J0];
+	}
+	return MTFHIP_OK;
+}
+
+int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
+	FLUSH(b);
+	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
+	TRY(check_sm(b, sm, "init_template"));
+	TRY(single_channel(b, "init_template"));
+	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "init_template before set_corners");
+	/* am->clearInitStatus() (NT/ESM.cc:113, NT/FCLK.cc:105, NT/ICLK.cc:74) */
+	b->init_pix_vals = b->init_pix_grad = b->init_sim = b->init_grad = false;
+	TRY(mtfhip_am_initialize_pix_vals(b, nullptr));
+	if (sm->chained_warp) {
+		TRY(mtfhip_am_initialize_pix_grad(b, nullptr));
+		TRY(mtfhip_ssm_cmpt_pix_jacobian(b, MTFHIP_JAC_WARPED, MTFHIP_BUF_DI0_DX, MTFHIP_BUF_J0));
+	} else {
+		TRY(mtfhip_ssm_update_grad_pts(b, b->desc.grad_eps));
+		TRY(mtfhip_am_initialize_pix_grad_warped(b, nullptr));
+		TRY(mtfhip_ssm_cmpt_pix_jacobian(b, MTFHIP_JAC_INIT, MTFHIP_BUF_DI0_DX, MTFHIP_BUF_J0));
+	}
+	if (sm->sec_ord_hess) {   /* initializePixHess, NT/ESM.cc:406-416 ; the template's pixel Hessian is rebuilt per pixel from
+	                           * d2I0_dx2 and dI0_dx inside k_second_order_ssd instead of being stored as an S^2 x N matrix */
+		b->init_pix_hess = false;
+		if (sm->chained_warp) TRY(mtfhip_am_initialize_pix_hess(b, nullptr));
+		else { TRY(mtfhip_ssm_update_hess_pts(b, b->hess_eps)); TRY(mtfhip_am_initialize_pix_hess_warped(b, nullptr, nullptr)); }
+		b->d0_variant = sm->chained_warp ? MTFHIP_JAC_WARPED : MTFHIP_JAC_INIT;
+	}
+	TRY(mtfhip_am_initialize_similarity(b));
+	TRY(mtfhip_am_initialize_grad(b));
+	TRY(mtfhip_am_initialize_hess(b));
+	std::vector<double> H0((size_t)b->B * b->S * b->S), h0dev((size_t)b->B * 64, 0.0);
+	TRY(mtfhip_am_cmpt_self_hessian(b, MTFHIP_BUF_J0, H0.data()));
+	for (int t = 0; t < b->B; ++t) {
+		std::memset(b->th[t].h0, 0, sizeof(b->th[t].h0));
+		std::memcpy(b->th[t].h0, &H0[(size_t)t * b->S * b->S], sizeof(double) * b->S * b->S);
+		std::memcpy(&h0dev[(size_t)t * 64], b->th[t].h0, sizeof(double) * 64);
+	}
+	HIP_TRY(hipMemcpyAsync(b->d_h0, h0dev.data(), sizeof(double) * h0dev.size(), hipMemcpyHostToDevice, b->ctx->stream));
+	std::vector<double> hinv((size_t)b->B * 64, 0.0);
+	for (int t = 0; t < b->B; ++t)
+		if (!invert_definite(b->S, b->th[t].h0, &hinv[(size_t)t * 64]))
+			std::fill(hinv.begin() + (size_t)t * 64, hinv.begin() + (size_t)(t + 1) * 64, 0.0); /* flat template: no update */
+	HIP_TRY(hipMemcpyAsync(b->d_h0inv, hinv.data(), sizeof(double) * hinv.size(), hipMemcpyHostToDevice, b->ctx->stream));
+	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	if (b->desc.am == MTFHIP_AM_NCC) TRY(ncc_template_moments(b));
+	b->j0_is_template = true;
+	b->j0_template_corners_epoch = b->corners_epoch;
+	b->j0_variant = sm->chained_warp ? MTFHIP_JAC_WARPED : MTFHIP_JAC_INIT;
+	b->template_corners.resize(8 * (size_t)b->B);
+	for (int t = 0; t < b->B; ++t) std::memcpy(&b->template_corners[8 * t], b->th[t].init_corners, sizeof(double) * 8);
+	return MTFHIP_OK;
+}
+
+/* nt::ESM::setRegion NT/ESM.cc:148-168, nt::FCLK::setRegion NT/FCLK.cc:360-376, nt::ICLK::setRegion NT/ICLK.cc:131-157 (update_ssm
+ * off): the SSM is reset to the new corners; ESM (and FCLK with the InitialSelf Hessian) recompute init_pix_jacobian with
+ * cmptInitPixJacobian on the new grid and, for the Hessian types that use it, the constant self Hessian; ICLK keeps its
+ * template Jacobian.  The template (I0, dI0_dx) is kept in every case. */
+int mtfhip_batch_set_region(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm) {
+	FLUSH(b);
+	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
+	TRY(check_sm(b, sm, "set_region"));
+	TRY(single_channel(b, "set_region"));
+	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "set_region before init_template");
+	TRY(mtfhip_ssm_set_corners(b, corners));
+	const bool refresh = sm->sm == MTFHIP_SM_ESM || (sm->sm == MTFHIP_SM_FCLK && sm->hess_type == 0);
+	if (!refresh) {
+		/* back on exactly the grid the kept template Jacobian was computed on: its rows can still be rebuilt from dI0_dx */
+		if (b->j0_is_template && b->template_corners.size() == 8 * (size_t)b->B &&
+			std::memcmp(b->template_corners.data(), corners, sizeof(double) * 8 * b->B) == 0)
+			b->j0_template_corners_epoch = b->corners_epoch;
+		return MTFHIP_OK;
+	}
+	TRY(mtfhip_ssm_cmpt_pix_jacobian(b, MTFHIP_JAC_INIT, MTFHIP_BUF_DI0_DX, MTFHIP_BUF_J0));
+	const bool need_h0 = sm->hess_type == 0 || (sm->sm == MTFHIP_SM_ESM && sm->hess_type == 2);
+	if (need_h0) {
+		std::vector<double> H0((size_t)b->B * b->S * b->S), h0dev((size_t)b->B * 64, 0.0), hinv((size_t)b->B * 64, 0.0);
+		TRY(mtfhip_am_cmpt_self_hessian(b, MTFHIP_BUF_J0, H0.data()));
+		for (int t = 0; t < b->B; ++t) {
+			std::memset(b->th[t].h0, 0, sizeof(b->th[t].h0));
+			std::memcpy(b->th[t].h0, &H0[(size_t)t * b->S * b->S], sizeof(double) * b->S * b->S);
+			std::memcpy(&h0dev[(size_t)t * 64], b->th[t].h0, sizeof(double) * 64);
+			if (!invert_definite(b->S, b->th[t].h0, &hinv[(size_t)t * 64]))
+				std::fill(hinv.begin() + (size_t)t * 64, hinv.begin() + (size_t)(t + 1) * 64, 0.0);
+		}
+		HIP_TRY(hipMemcpyAsync(b->d_h0, h0dev.data(), sizeof(double) * h0dev.size(), hipMemcpyHostToDevice, b->ctx->stream));
+		HIP_TRY(hipMemcpyAsync(b->d_h0inv, hinv.data(), sizeof(double) * hinv.size(), hipMemcpyHostToDevice, b->ctx->stream));
+		HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	}
+	if (b->desc.am == MTFHIP_AM_NCC) TRY(ncc_template_moments(b));
+	b->j0_is_template = true;
+	b->j0_template_corners_epoch = b->corners_epoch;
+	b->j0_variant = MTFHIP_JAC_INIT;
+	b->template_corners.assign(corners, corners + 8 * (size_t)b->B);
+	return MTFHIP_OK;
+}
+
+int fused_args(const mtfhip_batch *b, const mtfhip_sm_desc *sm, FusedArgs &fa) {
+	fa.chained = sm->chained_warp ? 1 : 0;
+	fa.materialize = sm->materialize ? 1 : 0;
+	fa.hess_mean = 0;
+	fa.j0_recompute = (b->j0_is_template && b->j0_recompute_enabled && b->j0_template_corners_epoch == b->corners_epoch) ? 1 : 0;
+	fa.j0_init_variant = b->j0_variant == MTFHIP_JAC_INIT ? 1 : 0;
+	fa.grad_eps = b->desc.grad_eps;
+	fa.norm_mult = b->norm_mult; fa.norm_add = b->norm_add;
+	fa.active = nullptr;
+	fa.done = nullptr;
+	{ int nb; fused_decomposition(b->N, b->B, nb, fa.rows_per_block); }
+	switch (sm->sm) {
+	case MTFHIP_SM_FCLK: fa.mode = 0; break;
+	case MTFHIP_SM_ESM: fa.mode = 1; fa.hess_mean = sm->hess_type == 3; break;
+	default:
+		if (sm->hess_type == 1) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "fused ICLK with hess_type CurrentSelf: use the un-fused entry points");
+		fa.mode = 2;
+	}
+	return MTFHIP_OK;
+}
+
+/* The second-order term an SSD search method adds to its Hessian (k_second_order_ssd's `term`), -1 for none:
+ * SSD's self Hessians are first order by definition (SSDBase.h:95-98) and InitialSelf never looks at the frame. */
+static int second_order_term(const mtfhip_sm_desc *sm) {
+	if (!sm->sec_ord_hess) return -1;
+	switch (sm->sm) {
+	case MTFHIP_SM_FCLK: return sm->hess_type == 2 ? 0 : -1;
+	case MTFHIP_SM_ESM: return sm->hess_type == 5 ? 0 : (sm->hess_type == 4 ? 1 : (sm->hess_type == 3 ? 2 : -1));
+	default: return sm->hess_type == 2 ? 3 : -1;
+	}
+}
+
+/* turns one target's reduced accumulators into the SM's g and H (before LM damping):
+ * NT/FCLK.cc:260-288 ; NT/ESM.cc:298-377 with SSDBase.cc:169-191,287-311 ; NT/ICLK.cc:206-251 */
+static void assemble(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const double *acc, const double *h0,
+	double *f, double *g, double *H) {
+	const int S = b->S;
+	if (f) *f = -acc[ACC_RR] / 2;
+	const double gscale = sm->sm == MTFHIP_SM_ESM ? 0.5 : 1.0;
+	for (int s = 0; s < S; ++s) g[s] = gscale * acc[ACC_G + s];
+	const bool use_h0 = (sm->hess_type == 0) || (sm->sm == MTFHIP_SM_ICLK);
+	const bool sum_h0 = (sm->sm == MTFHIP_SM_ESM) && (sm->hess_type == 2 || sm->hess_type == 4);
+	int k = 0;
+	for (int a = 0; a < 8; ++a)
+		for (int c = a; c < 8; ++c) {
+			if (a < S && c < S) {
+				double v = use_h0 ? h0[c * S + a] : -acc[ACC_H + k];
+				if (sum_h0) v = (v + h0[c * S + a]) * 0.5;
+				H[c * S + a] = v; H[a * S + c] = v;
+			}
+			++k;
+		}
+}
+
+int mtfhip_batch_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, double *g, double *H) {
+	FLUSH(b);
+	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
+	TRY(check_sm(b, sm, "iterate"));
+	TRY(single_channel(b, "iterate"));
+	if (!g || !H) return fail(MTFHIP_ERR_INVALID_ARG, "iterate: NULL output");
+	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "iterate before init_template");
+	TRY(need_image(b));
+	FusedArgs fa;
+	TRY(fused_args(b, sm, fa));
+	int nblk = fused_blocks_per_target(b->N, b->B);
+	{
+		TimedScope ts(b->ctx, "fused_lk");
+		launch_fused_ssd(b->view(), b->ctx->img, fa, b->d_partials, nblk, b->ctx->stream);
+	}
+	b->it_valid = fa.materialize;
+	b->dit_valid = fa.materialize && fa.mode != 2;
+	b->jt_valid = fa.materialize && fa.mode != 2;
+	if (b->desc.am == MTFHIP_AM_NCC) {
+		TRY(read_rows(b, nblk, NCC_ACC_COUNT));
+		for (int t = 0; t < b->B; ++t) {
+			double ft;
+			TRY(ncc_assemble(b, sm, fa.hess_mean != 0, b->h_acc + (size_t)t * NCC_ACC_COUNT, b->th[t], &ft, g + (size_t)t * b->S,
+				H + (size_t)t * b->S * b->S));
+			if (f) f[t] = ft;
+		}
+		b->ncc_host_newer = true;
+		return MTFHIP_OK;
+	}
+	const int term = second_order_term(sm);
+	std::vector<double> so;
+	if (term >= 0) {
+		if (term != 0 && !b->init_pix_hess) return fail(MTFHIP_ERR_LOGIC, "iterate: init_template was run without sec_ord_hess");
+		const int nb2 = simple_blocks_per_target(b->N);
+		if (!b->d_d2_part) {
+			HIP_TRY(hipMalloc(&b->d_d2_part, sizeof(double) * 64 * (size_t)nb2 * b->B));
+			HIP_TRY(hipMalloc(&b->d_d2_out, sizeof(double) * 64 * (size_t)b->B));
+		}
+		{
+			TimedScope ts(b->ctx, "second_order");
+			launch_second_order_ssd(b->view(), b->ctx->img, term, fa.chained, b->d0_variant, fa.grad_eps, b->hess_eps, b->norm_mult,
+				b->norm_add, b->d_d2_part, nb2, b->d_d2_out, b->ctx->stream);
+		}
+		so.resize((size_t)b->S * b->S * b->B);
+		HIP_TRY(hipMemcpyAsync(so.data(), b->d_d2_out, sizeof(double) * so.size(), hipMemcpyDeviceToHost, b->ctx->stream));
+	}
+	TRY(read_acc(b, nblk));
+	const int S2 = b->S * b->S;
+	for (int t = 0; t < b->B; ++t) {
+		double ft;
+		double *Ht = H + (size_t)t * S2;
+		assemble(b, sm, b->h_acc + (size_t)t * ACC_COUNT, b->th[t].h0, &ft, g + (size_t)t * b->S, Ht);
+		if (term >= 0) {   /* SumOfStd halves the whole sum (NT/ESM.cc:339) */
+			const double sc = term == 1 ? 0.5 : 1.0;
+			for (int k = 0; k < S2; ++k) Ht[k] += sc * so[(size_t)t * S2 + k];
+		}
+		b->th[t].f = ft;
+		if (f) f[t] = ft;
+	}
+	return MTFHIP_OK;
+}
+
+/* Targets per launch of the device-side loop.  Chunking pays where an iteration both re-reads a large constant operand
+ * set and writes as much again (ESM with materialisation: 88 B/px read, 88 B/px written): +15-17 % at B = 128-256.
+ * FCLK reads only 24 B/px (fits anyway) and the lean / ICLK variants barely write, so for them a chunk only multiplies
+ * the per-iteration finish launches (measured 7-20 % slower) and they keep one launch for all targets.
+ * MTFHIP_TRACK_CHUNK_PX overrides the pixel budget (tests force tiny chunks with it, in every mode). */
+static int track_chunk(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const FusedArgs &fa) {
+	const char *env_px = std::getenv("MTFHIP_TRACK_CHUNK_PX");
+	if (!env_px && !(fa.mode == 1 && fa.materialize)) return b->B;
+	const double chunk_px = env_px ? std::atof(env_px) : 2.6e6;
+	int chunk = (int)(chunk_px / (double)b->N);
+	if (chunk < 1) chunk = 1;
+	if (chunk >= b->B || sm->max_iters == 1) return b->B;
+	const int n_chunks = (b->B + chunk - 1) / chunk;
+	return (b->B + n_chunks - 1) / n_chunks;   /* balanced: 100 targets -> 50 + 50, not 65 + 35 */
+}
+int mtfhip_batch_track_targets_per_launch(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
+	FLUSH(b);
+	if (check_sm(b, sm, "track_targets_per_launch") != MTFHIP_OK) return 0;
+	const bool one_launch = sm->sm == MTFHIP_SM_ICLK && (sm->hess_type == 0 || (sm->hess_type == 2 && b->desc.am == MTFHIP_AM_SSD)) &&
+		b->N <= kIclkTrackMaxPix;
+	if (one_launch) return b->B;
+	FusedArgs fa;
+	if (fused_args(b, sm, fa) != MTFHIP_OK) return 0;
+	return track_chunk(b, sm, fa);
+}
+
+int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners) {
+	FLUSH(b);
+	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
+	TRY(check_sm(b, sm, "track"));
+	TRY(single_channel(b, "track"));
+	if (sm->leven_marq) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: Levenberg-Marquardt is only available through iterate + host solve");
+	if (sm->max_iters <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "track: max_iters must be positive");
+	if (b->desc.am != MTFHIP_AM_SSD ? sm->sec_ord_hess != 0 : second_order_term(sm) >= 0)
+		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: a second-order Hessian is indefinite and needs the pivoted host solve; use iterate");
+	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "track before init_template");
+	TRY(need_image(b));
+	hipStream_t st = b->ctx->stream;
+	const bool one_launch = sm->sm == MTFHIP_SM_ICLK && (sm->hess_type == 0 || (sm->hess_type == 2 && b->desc.am == MTFHIP_AM_SSD)) &&
+		b->N <= kIclkTrackMaxPix;
+	FusedArgs fa;
+	if (!one_launch) TRY(fused_args(b, sm, fa));
+	else { fa.materialize = 0; fa.mode = 2; fa.active = nullptr; fa.done = nullptr; fa.rows_per_block = 1; fa.j0_recompute = 0; }
+	/* active = 1, iters = 0, corners, warps, states, NCC scalars: one pinned async copy of the whole slab
+	 * (w0 is copied along; init_grid consumed it long ago) */
+	HIP_TRY(hipEventSynchronize(b->ev_b));
+	std::memcpy(b->h_stage_b + 45 * sizeof(double) * (size_t)b->B, b->h_stage_a + 45 * sizeof(double) * (size_t)b->B, 9 * sizeof(double) * (size_t)b->B);
+	fill_stage(b, b->h_stage_b, nullptr, 1, true);
+	HIP_TRY(hipMemcpyAsync(b->d_slab, b->h_stage_b, b->slab_bytes, hipMemcpyHostToDevice, st));
+	fa.active = b->d_active;
+	const bool ncc = b->desc.am == MTFHIP_AM_NCC;
+	const size_t RL = ncc ? NCC_ACC_COUNT : ACC_COUNT;   /* partial / reduced row length */
+	if (ncc && !one_launch && !b->d_ncc_tm) return fail(MTFHIP_ERR_LOGIC, "track before init_template");
+	TrackState ts{b->d_acc, b->d_h0, b->d_corners, b->d_init_corners_hm, b->d_active, b->d_iters, ncc ? b->d_ncc : nullptr, ncc ? b->d_ncc_tm : nullptr};
+	BatchView bv = b->view();
+	if (one_launch) {
+		TimedScope tsc(b->ctx, "iclk_track");
+		launch_iclk_track(bv, b->ctx->img, *sm, ts, b->d_h0inv, b->d_ncc, b->norm_mult, b->norm_add, st);
+	} else {
+		/* MTFHIP_EPILOGUE=1: one launch per iteration, the workgroup that completes a target's partial rows also runs the
+		 * finish; default: the separate k_finish_track launch (same step time, cleaner kernel timing). */
+		if (b->epilogue && !ncc) {
+			if (!b->d_done) {
+				HIP_TRY(hipMalloc(&b->d_done, sizeof(int) * b->B));
+				HIP_TRY(hipMemsetAsync(b->d_done, 0, sizeof(int) * b->B, st));
+			}
+			fa.done = b->d_done; fa.sm = *sm; fa.ts = ts;
+		}
+		/* Targets are independent, so the loops commute: all iterations of a chunk of targets run before the next chunk
+		 * starts.  A chunk is sized so that what an iteration reads once (J0, I0, grid: 88 B/px for ESM) stays resident in
+		 * the 256 MB Infinity Cache from one iteration to the next -- B = 64 at 200 x 200; larger batches used to fall back
+		 * to plain HBM for both streams (0.62 instead of 0.75 of peak).  See track_chunk(). */
+		const int chunk = track_chunk(b, sm, fa);
+		for (int t0 = 0; t0 < b->B; t0 += chunk) {
+			const int nt = std::min(chunk, b->B - t0);
+			BatchView bc = bv;
+			bc.B = nt;
+			for (int i = 0; i < MTFHIP_BUF_COUNT; ++i)
+				if (bc.buf[i]) bc.buf[i] += (size_t)t0 * b->per_target[i];
+			bc.warps += 9 * (size_t)t0; bc.states += 8 * (size_t)t0;
+			FusedArgs fc = fa;
+			fc.active = fa.active + t0;
+			TrackState tc{ts.acc + (size_t)t0 * RL, ts.h0 + (size_t)t0 * 64, ts.corners + 8 * (size_t)t0,
+				ts.init_corners_hm + 12 * (size_t)t0, ts.active + t0, ts.n_iters + t0, ncc ? ts.ncc + 8 * (size_t)t0 : nullptr,
+				ncc ? ts.ncc_tm + 52 * (size_t)t0 : nullptr};
+			if (fc.done) { fc.done = fa.done + t0; fc.ts = tc; }
+			int nblk_c; { int rows; fused_decomposition(b->N, nt, nblk_c, rows); fc.rows_per_block = rows; }
+			double *part = b->d_partials + (size_t)t0 * b->nblk_max * RL;
+			for (int it = 0; it < sm->max_iters; ++it) {
+				{
+					TimedScope tsc(b->ctx, "fused_lk");
+					launch_fused_ssd(bc, b->ctx->img, fc, part, nblk_c, st);
+				}
+				if (!b->epilogue || ncc) launch_finish_track(bc, *sm, tc, part, nblk_c, st);
+			}
+		}
+	}
+	/* one download of the slab (warps, states, corners, iteration counts), one sync */
+	HIP_TRY(hipMemcpyAsync(b->h_stage_b, b->d_slab, b->slab_bytes, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipEventRecord(b->ev_b, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	{
+		const size_t Bt = (size_t)b->B;
+		const double *p = reinterpret_cast<const double *>(b->h_stage_b);
+		const double *w = p, *s = p + 9 * Bt, *cr = p + 17 * Bt;
+		const int *iters = reinterpret_cast<const int *>(b->h_stage_b + b->slab_dbl_bytes) + Bt;
+		for (int t = 0; t < b->B; ++t) {
+			std::memcpy(b->th[t].warp.m, w + 9 * t, sizeof(double) * 9);
+			std::memcpy(b->th[t].state, s + 8 * t, sizeof(double) * 8);
+			std::memcpy(b->th[t].corners, cr + 8 * t, sizeof(double) * 8);
+			if (n_iters) n_iters[t] = iters[t];
+			if (corners) std::memcpy(corners + 8 * t, cr + 8 * t, sizeof(double) * 8);
+		}
+	}
+	b->it_valid = fa.materialize;
+	b->dit_valid = b->jt_valid = fa.materialize && fa.mode != 2;
+	/* curr_pts follow the final warp */
+	launch_apply_warp(b->view(), st);
+	b->pts_stale = false;
+	return MTFHIP_OK;
+}
+
+/* ------------------------------------------------------------------ candidate scoring */
+int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int C, double *dev_lik, double *dev_sim) {
+	FLUSH(b);
+	if (!b || !dev_states) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: NULL argument");
+	if (C <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: n_candidates must be positive");
+	if (b->desc.am != MTFHIP_AM_SSD) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "score_candidates: SSD only");
+	TRY(single_channel(b, "score_candidates"));
+	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "score_candidates before the template was initialised");
+	TRY(need_image(b));
+	TimedScope ts(b->ctx, "score_candidates");
+	/* image tile = bounding box of the template region + a margin for the candidate cloud (PF sigmas are a few pixels) */
+	const TargetHost &h0 = b->th[0];
+	double xmin = h0.init_corners[0], xmax = xmin, ymin = h0.init_corners[1], ymax = ymin;
+	for (int q = 1; q < 4; ++q) {
+		xmin = std::min(xmin, h0.init_corners[2 * q]); xmax = std::max(xmax, h0.init_corners[2 * q]);
+		ymin = std::min(ymin, h0.init_corners[2 * q + 1]); ymax = std::max(ymax, h0.init_corners[2 * q + 1]);
+	}
+	const int margin = 16;
+	const size_t lds_left = 160 * 1024 > (size_t)b->N * 32 ? 160 * 1024 - (size_t)b->N * 32 : 0;
+	int tx0 = (int)std::floor(xmin) - margin, ty0 = (int)std::floor(ymin) - margin;
+	int tw = (int)std::ceil(xmax) + margin + 2 - tx0, th = (int)std::ceil(ymax) + margin + 2 - ty0;
+	bool staged = false;
+	if (b->score_lds && C >= 64 && (size_t)tw * th * 4 <= lds_left) {
+		if ((size_t)C * kScoreUnitsPerCandidate > b->unit_capacity) {
+			if (b->d_units) HIP_TRY(hipFree(b->d_units));
+			b->d_units = nullptr;
+			HIP_TRY(hipMalloc(&b->d_units, sizeof(double) * C * kScoreUnitsPerCandidate));
+			b->unit_capacity = (size_t)C * kScoreUnitsPerCandidate;
+		}
+		staged = launch_score_candidates_lds(b->view(), b->ctx->img, dev_states, C, tx0, ty0, tw, th, b->desc.likelihood_alpha,
+			b->d_units, dev_lik, dev_sim, b->ctx->stream);
+	}
+	if (!staged)
+		launch_score_candidates(b->view(), b->ctx->img, dev_states, C, b->desc.likelihood_alpha, dev_lik, dev_sim, b->ctx->stream);
+	return MTFHIP_OK;
+}
+
+int mtfhip_score_candidates(mtfhip_batch *b, const double *states, int C, double *lik, double *sim) {
+	FLUSH(b);
+	if (!b || !states) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: NULL argument");
+	if (C <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: n_candidates must be positive");
+	size_t need = (size_t)C * (b->S + 2);
+	if (need > b->cand_capacity) {
+		if (b->d_cand) HIP_TRY(hipFree(b->d_cand));
+		b->d_cand = nullptr;
+		HIP_TRY(hipMalloc(&b->d_cand, sizeof(double) * need));
+		b->cand_capacity = need;
+	}
+	double *d_states = b->d_cand, *d_lik = b->d_cand + (size_t)C * b->S, *d_sim = d_lik + C;
+	HIP_TRY(hipMemcpyAsync(d_states, states, sizeof(double) * C * b->S, hipMemcpyHostToDevice, b->ctx->stream));
+	TRY(mtfhip_score_candidates_dev(b, d_states, C, d_lik, d_sim));
+	if (lik) HIP_TRY(hipMemcpyAsync(lik, d_lik, sizeof(double) * C, hipMemcpyDeviceToHost, b->ctx->stream));
+	if (sim) HIP_TRY(hipMemcpyAsync(sim, d_sim, sizeof(double) * C, hipMemcpyDeviceToHost, b->ctx->stream));
+	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	return MTFHIP_OK;
+}
+
+/* ------------------------------------------------------------------ NN dataset generation */
+int mtfhip_sample_candidates_dev(mtfhip_batch *b, const double *dev_states, int C, double *dev_features) {
+	FLUSH(b);
+	if (!b || !dev_states || !dev_features) return fail(MTFHIP_ERR_INVALID_ARG, "sample_candidates: NULL argument");
+	if (C <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "sample_candidates: n_samples must be positive");
+	if (b->desc.am == MTFHIP_AM_MI) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "sample_candidates: MI distance features (5 x N B-spline rows) are not available");
+	TRY(single_channel(b, "sample_candidates"));
+	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "sample_candidates before set_corners");
+	TRY(need_image(b));
+	TimedScope ts(b->ctx, "sample_candidates");
+	launch_sample_candidates(b->view(), b->ctx->img, dev_states, C, b->norm_mult, b->norm_add, dev_features, b->ctx->stream);
+	return MTFHIP_OK;
+}
+int mtfhip_sample_candidates(mtfhip_batch *b, const double *states, int C, double *features) {
+	FLUSH(b);
+	if (!b || !states || !features) return fail(MTFHIP_ERR_INVALID_ARG, "sample_candidates: NULL argument");
+	if (C <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "sample_candidates: n_samples must be positive");
+	double *d_states = nullptr, *d_feat = nullptr;
+	HIP_TRY(hipMalloc(&d_states, sizeof(double) * C * b->S));
+	if (hipMalloc(&d_feat, sizeof(double) * (size_t)C * b->N) != hipSuccess) { (void)hipFree(d_states); return fail(MTFHIP_ERR_HIP, "hipMalloc of the %d x %d feature matrix failed", C, b->N); }
+	int rc = MTFHIP_OK;
+	if (hipMemcpyAsync(d_states, states, sizeof(double) * C * b->S, hipMemcpyHostToDevice, b->ctx->stream) != hipSuccess) rc = fail(MTFHIP_ERR_HIP, "state upload failed");
+	if (rc == MTFHIP_OK) rc = mtfhip_sample_candidates_dev(b, d_states, C, d_feat);
+	if (rc == MTFHIP_OK && hipMemcpyAsync(features, d_feat, sizeof(double) * (size_t)C * b->N, hipMemcpyDeviceToHost, b->ctx->stream) != hipSuccess) rc = fail(MTFHIP_ERR_HIP, "feature read-back failed");
+	if (hipStreamSynchronize(b->ctx->stream) != hipSuccess && rc == MTFHIP_OK) rc = fail(MTFHIP_ERR_HIP, "stream synchronisation failed");
+	(void)hipFree(d_states); (void)hipFree(d_feat);
+	return rc;
+}
+
+
+} /* extern "C" */

@@ -81,7 +81,7 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 
 /* AM = MTFHIP_AM_SSD: the residual-weighted sums above.  AM = MTFHIP_AM_NCC: the same pass accumulates the raw moments
  * NCC's similarity, Jacobians and first-order Hessians are functions of (NCC.cc:124-389 restated in ncc_from_moments,
- * mtfhip_api.hip) -- Gram(row) | sum Jt | sum It Jt | sum I0 Jt | sum It J0 | sum It, It^2, I0 It -- so an NCC iteration
+ * api_fused.hip) -- Gram(row) | sum Jt | sum It Jt | sum I0 Jt | sum It J0 | sum It, It^2, I0 It -- so an NCC iteration
  * needs no second pass over the pixels for the means; the partial rows are NCC_ACC_COUNT wide. */
 template <int AM, int SSM, bool CHAINED, int MODE, bool MAT>
 __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk) {
@@ -552,7 +552,7 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 	const bool use_h0 = (sm.hess_type == 0) || (sm.sm == MTFHIP_SM_ICLK);
 	const bool sum_h0 = (sm.sm == MTFHIP_SM_ESM) && (sm.hess_type == 2 || sm.hess_type == 4);
 	const double gscale = (sm.sm == MTFHIP_SM_ESM) ? 0.5 : 1.0;
-	/* NCC from its moments (ncc_assemble in mtfhip_api.hip is the host twin; formulas and citations there) */
+	/* NCC from its moments (ncc_assemble in api_fused.hip is the host twin; formulas and citations there) */
 	const double nN = (double)bv.N;
 	const double n_mt = ncc ? acc_s[NCC_IT] / nN : 0.0, n_m0 = ncs[0], n_c = ncc ? ncs[1] : 1.0;
 	const double n_b2 = ncc ? acc_s[NCC_IT2] - nN * n_mt * n_mt : 1.0, n_b = ncc ? sqrt(n_b2) : 1.0;

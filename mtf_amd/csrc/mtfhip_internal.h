@@ -1,6 +1,6 @@
 /*
  * mtfhip_internal.h -- shared between the HIP kernel translation units (kernels_*.hip) and the C-ABI
- * implementation (mtfhip_api.hip).  Not installed; the public contract is include/mtfhip.h.
+ * implementation (api_core.hip, api_am.hip, api_fused.hip).  Not installed; the public contract is include/mtfhip.h.
  */
 #ifndef MTFHIP_INTERNAL_H
 #define MTFHIP_INTERNAL_H
