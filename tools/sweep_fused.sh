@@ -7,7 +7,7 @@ for v in "$@"; do
   set -- $v
   pipe=$1; waves=$2; ppt=$3; coop=${4:-0}; slots=${5:-512}
   so=/tmp/libmtfhip_${pipe}_${waves}_${ppt}_${coop}_${slots}.so
-  make -C mtf_amd/csrc -s -B OUT=$so EXTRA="-DMTFHIP_FUSED_WAVES=$waves -DMTFHIP_MIN_ROWS=$ppt -DMTFHIP_SLOTS=$slots $SWEEP_EXTRA" 2>&1 | grep -E "error" | head -3
+  make -C mtf_amd/csrc -s -B -j8 OUT=$so EXTRA="-DMTFHIP_FUSED_WAVES=$waves -DMTFHIP_MIN_ROWS=$ppt -DMTFHIP_SLOTS=$slots $SWEEP_EXTRA" 2>&1 | grep -E "error" | head -3
   for mode in full lean; do
     MTFHIP_LIB=$so python bench.py --steps 40 --warmup 8 --no-cpu --mode $mode 2>&1 | tail -1 | python -c "
 import sys,json
