@@ -238,7 +238,7 @@ static int mi_read_f(mtfhip_batch *b) {
 /* workgroups per target for the MI histogram / Hessian passes: enough to fill the chip (~4 per CU over the batch), few
  * enough that every wave amortises its register-resident bin accumulators over many 64-pixel chunks and that the
  * fixed-order finish has short columns to add */
-static int mi_blocks(const mtfhip_batch *b) {
+int mi_blocks(const mtfhip_batch *b) {
 	int nb = 1024 / b->B;
 	if (nb < 1) nb = 1;
 	return std::min(nb, simple_blocks_per_target(b->N));
@@ -267,7 +267,9 @@ static int mi_hessian(mtfhip_batch *b, int j_buf, int kind, double *H) {
 		TimedScope ts(b->ctx, "mi_hess");
 		launch_mi_hess(b->view(), nb, b->mi_hist_norm, A, Bv, b->d_mi_tb, table, kind == 0, b->buf[j_buf], b->d_mi_part, nblk,
 			b->mi_row_len, b->ctx->stream);
-		launch_mi_hess_finish(b->view(), nb, b->d_mi_part, nblk, b->mi_row_len, b->d_mi_tb, joint, hist, kind == 0, b->d_mi_H,
+		/* two short launches instead of one long one: the column sums are spread over the chip, the assembly reads one row */
+		launch_finish_rows(b->d_mi_part, nblk, b->mi_row_len, b->d_mi_red, b->B, b->ctx->stream);
+		launch_mi_hess_finish(b->view(), nb, b->d_mi_red, 1, b->mi_row_len, b->d_mi_tb, joint, hist, kind == 0, b->d_mi_H,
 			b->ctx->stream);
 	}
 	std::vector<double> h(64 * (size_t)b->B);

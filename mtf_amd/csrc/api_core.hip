@@ -291,13 +291,14 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 	ALLOC(b->d_colmean, sizeof(double) * 8 * n_targets);
 	if (d->am == MTFHIP_AM_MI) {
 		const int nb = d->mi_n_bins;
-		b->mi_row_len = std::max(nb + nb * nb, 36 + nb * nb * b->S);
+		b->mi_row_len = std::max(nb + 2 * nb * nb, 36 + nb * nb * b->S);   /* widest of the MI partial rows (fused passes incl.) */
 		/* hist_norm_mult = 1 / (patch_size + hist_pre_seed * n_bins), hist_pre_seed = n_bins * pre_seed (MI.cc:97,104) */
 		b->mi_hist_norm = 1.0 / ((double)b->N + (nb * d->mi_pre_seed) * nb);
 		ALLOC(b->d_mi_tb, sizeof(double) * MI_SIZE * n_targets);
 		ALLOC(b->d_mi_part, sizeof(double) * (size_t)b->mi_row_len * b->nblk_max * n_targets);
 		ALLOC(b->d_mi_f, sizeof(double) * n_targets);
-		ALLOC(b->d_mi_H, sizeof(double) * 64 * n_targets);
+		ALLOC(b->d_mi_red, sizeof(double) * (size_t)b->mi_row_len * n_targets);
+		ALLOC(b->d_mi_H, sizeof(double) * (64 + 16) * n_targets);   /* [B][64] Hessians, then [B][16] Jacobian sums of the fused pass */
 		(void)hipMemsetAsync(b->d_mi_tb, 0, sizeof(double) * MI_SIZE * n_targets, c->stream);
 	}
 #undef ALLOC
@@ -337,7 +338,7 @@ void mtfhip_batch_destroy(mtfhip_batch *b) {
 			if (b->buf[i]) (void)hipFree(b->buf[i]);
 		void *ptrs[] = {b->d_slab, b->d_partials, b->d_acc, b->d_scratch_pts, b->d_h0,
 			b->d_cand, b->d_colmean, b->d_mi_tb, b->d_mi_part,
-			b->d_mi_f, b->d_mi_H, b->d_h0inv, b->d_units, b->d_d2_part, b->d_d2_out, b->d_d2_w, b->d_done, b->d_it_shadow, b->d_ncc_tm};
+			b->d_mi_f, b->d_mi_H, b->d_h0inv, b->d_units, b->d_d2_part, b->d_d2_out, b->d_d2_w, b->d_done, b->d_it_shadow, b->d_ncc_tm, b->d_mi_red};
 		for (void *p : ptrs)
 			if (p) (void)hipFree(p);
 		if (b->h_acc) (void)hipHostFree(b->h_acc);
@@ -457,8 +458,7 @@ int ensure_pts(mtfhip_batch *b) {
 }
 static int apply_states(mtfhip_batch *b) {
 	TRY(push_warps(b));
-	b->pts_stale = true;
-	if (!b->lz.enabled) return ensure_pts(b);
+	b->pts_stale = true;   /* refreshed by the next entry point that may read them (lazy_flush) */
 	return MTFHIP_OK;
 }
 

@@ -18,7 +18,14 @@ static int check_sm(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const char 
 		if (sm->sec_ord_hess) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: second-order NCC Hessians go through the per-function entry points", fn);
 		return MTFHIP_OK;
 	}
-	if (b->desc.am != MTFHIP_AM_SSD) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: the fused path supports SSD and NCC; MI uses the per-function entry points", fn);
+	if (b->desc.am == MTFHIP_AM_MI) {
+		/* fused MI iteration: the class-default (self-type) Hessians of the three search methods, 8-bin histograms */
+		const bool ht_ok = sm->sm == MTFHIP_SM_ESM ? sm->hess_type <= 2 : (sm->sm == MTFHIP_SM_FCLK ? sm->hess_type <= 1 : sm->hess_type == 0);
+		if (b->desc.mi_n_bins != 8 || sm->sec_ord_hess || !ht_ok || (sm->sm == MTFHIP_SM_ESM && sm->jac_type == 0))
+			return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: the fused MI iteration covers 8 bins, first order, the self-type Hessians and ESM's DiffOfJacs; use the per-function entry points", fn);
+		return MTFHIP_OK;
+	}
+	if (b->desc.am != MTFHIP_AM_SSD) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: unknown appearance model", fn);
 	return MTFHIP_OK;
 }
 
@@ -416,14 +423,87 @@ static void assemble(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const doub
 		}
 }
 
+/* One ESM / FCLK / ICLK iteration with MI in four pixel-level launches instead of seventeen:
+ *   0. the fused LK kernel (SSD instantiation, FCLK-type, materialising): warp -> It, dIt_dx, Jt in one pass (its SSD
+ *      sums are ignored; MI's pixel scaling travels in norm_mult / norm_add).  ICLK: It only.
+ *   1. k_mi_hist<MFMA, SELF>: histogram of It, joint (It, I0) and -- for the self Hessians -- joint (It, It), one pass;
+ *      k_mi_tables_iter: pre-seeding, logs, similarity and the three gradient-factor tables in one launch
+ *      (MI.cc:346-382, 399-403, 427-431, 651-658).
+ *   2. k_mi_grad_gemv: both gradient vectors and df_dIt . Jt, df_dI0 . J0 in one pass (instead of 2 x k_mi_grad, k_gemv, k_finish).
+ *   3. k_mi_hess<MFMA> + k_mi_hess_finish for the self Hessian (MI.cc:565-601) when the Hessian type needs it.
+ * (Folding 2 into 3 was tried: 294 VGPRs, one wave per SIMD, 223 us instead of 95 + 35.)
+ * g, H of the search method as in NT/ESM.cc:298-377, NT/FCLK.cc:260-288, NT/ICLK.cc:206-251. */
+static int mi_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, double *g, double *H) {
+	const int nb = b->desc.mi_n_bins, S = b->S, nblk = mi_blocks(b);
+	hipStream_t st = b->ctx->stream;
+	const bool iclk = sm->sm == MTFHIP_SM_ICLK;
+	const bool self = !iclk && sm->hess_type != 0;   /* CurrentSelf / SumOfSelf: cmptSelfHessian(Jt) */
+	/* 0 */
+	mtfhip_sm_desc s0 = *sm;
+	s0.sm = iclk ? MTFHIP_SM_ICLK : MTFHIP_SM_FCLK; s0.hess_type = iclk ? 0 : 1; s0.materialize = 1; s0.sec_ord_hess = 0;
+	FusedArgs fa;
+	TRY(fused_args(b, &s0, fa));
+	{
+		TimedScope ts(b->ctx, "fused_lk");
+		launch_fused_ssd(b->view(), b->ctx->img, fa, b->d_partials, fused_blocks_per_target(b->N, b->B), st);
+	}
+	b->it_valid = true;
+	b->dit_valid = b->jt_valid = !iclk;
+	/* 1 */
+	const double *It = b->buf[MTFHIP_BUF_IT], *I0 = b->buf[MTFHIP_BUF_I0];
+	{
+		TimedScope ts(b->ctx, "mi_hist");
+		if (self) launch_mi_hist_self(b->view(), nb, b->mi_hist_norm, It, I0, b->d_mi_part, nblk, b->mi_row_len, st);
+		else launch_mi_hist(b->view(), nb, b->mi_hist_norm, It, I0, b->d_mi_part, nblk, b->mi_row_len, st);
+		launch_mi_tables_iter(b->view(), nb, b->desc.mi_pre_seed, b->mi_hist_norm, self ? 1 : 0, b->d_mi_part, nblk, b->mi_row_len, b->d_mi_tb,
+			b->d_mi_f, st);
+	}
+	/* 2, 3 */
+	double *d_g = b->d_mi_H + 64 * (size_t)b->B;
+	{
+		TimedScope ts(b->ctx, "mi_grad");
+		const int ng = simple_blocks_per_target(b->N) < 64 ? simple_blocks_per_target(b->N) : 64;
+		launch_mi_grad_gemv(b->view(), nb, b->mi_hist_norm, It, I0, b->d_mi_tb, iclk ? nullptr : b->buf[MTFHIP_BUF_JT],
+			sm->sm == MTFHIP_SM_FCLK ? nullptr : b->buf[MTFHIP_BUF_J0], sm->materialize ? b->buf[MTFHIP_BUF_DF_DIT] : nullptr,
+			sm->materialize ? b->buf[MTFHIP_BUF_DF_DI0] : nullptr, b->d_partials, ng, st);
+		launch_finish_rows(b->d_partials, ng, 16, d_g, b->B, st);
+	}
+	if (self) {
+		TimedScope ts(b->ctx, "mi_hess");
+		launch_mi_hess(b->view(), nb, b->mi_hist_norm, It, It, b->d_mi_tb, MI_T_SELF, 0, b->buf[MTFHIP_BUF_JT], b->d_mi_part, nblk, b->mi_row_len, st);
+		launch_finish_rows(b->d_mi_part, nblk, b->mi_row_len, b->d_mi_red, b->B, st);
+		launch_mi_hess_finish(b->view(), nb, b->d_mi_red, 1, b->mi_row_len, b->d_mi_tb, MI_SELF_JOINT, MI_HIST_CURR, 0, b->d_mi_H, st);
+	}
+	std::vector<double> out((size_t)b->B * 81);
+	HIP_TRY(hipMemcpyAsync(out.data(), b->d_mi_H, sizeof(double) * 80 * b->B, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(out.data() + (size_t)80 * b->B, b->d_mi_f, sizeof(double) * b->B, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	for (int t = 0; t < b->B; ++t) {
+		const double *Hs = &out[64 * (size_t)t], *gs = &out[64 * (size_t)b->B + 16 * (size_t)t];
+		TargetHost &h = b->th[t];
+		h.f = out[(size_t)80 * b->B + t];
+		if (f) f[t] = h.f;
+		double *gt = g + (size_t)t * S, *Ht = H + (size_t)t * S * S;
+		for (int s = 0; s < S; ++s) gt[s] = iclk ? gs[8 + s] : (sm->sm == MTFHIP_SM_FCLK ? gs[s] : 0.5 * (gs[s] - gs[8 + s]));
+		for (int k = 0; k < S * S; ++k) {
+			const int r = k % S, c = k / S;
+			const double hv = Hs[c * S + r];   /* k_mi_hess_finish writes column-major S x S */
+			Ht[k] = !self ? h.h0[k] : (sm->sm == MTFHIP_SM_ESM && sm->hess_type == 2 ? 0.5 * (hv + h.h0[k]) : hv);
+		}
+	}
+	return MTFHIP_OK;
+}
+
 int mtfhip_batch_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, double *g, double *H) {
-	FLUSH(b);
+	FLUSH_AM(b);   /* the fused kernels derive the sample points from the warp: CURR_PTS may stay stale */
 	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
 	TRY(check_sm(b, sm, "iterate"));
 	TRY(single_channel(b, "iterate"));
 	if (!g || !H) return fail(MTFHIP_ERR_INVALID_ARG, "iterate: NULL output");
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "iterate before init_template");
 	TRY(need_image(b));
+	if (b->desc.am == MTFHIP_AM_MI) return mi_iterate(b, sm, f, g, H);
+	if (second_order_term(sm) >= 0) TRY(ensure_pts(b));   /* k_second_order_ssd reads the current points */
 	FusedArgs fa;
 	TRY(fused_args(b, sm, fa));
 	int nblk = fused_blocks_per_target(b->N, b->B);
@@ -510,6 +590,7 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 	TRY(check_sm(b, sm, "track"));
 	TRY(single_channel(b, "track"));
 	if (sm->leven_marq) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: Levenberg-Marquardt is only available through iterate + host solve");
+	if (b->desc.am == MTFHIP_AM_MI) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: MI iterates through mtfhip_batch_iterate (fused passes + host solve)");
 	if (sm->max_iters <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "track: max_iters must be positive");
 	if (b->desc.am != MTFHIP_AM_SSD ? sm->sec_ord_hess != 0 : second_order_term(sm) >= 0)
 		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: a second-order Hessian is indefinite and needs the pivoted host solve; use iterate");

@@ -466,7 +466,7 @@ __global__ __launch_bounds__(kBlock) void k_ncc_hess(BatchView bv, const double 
 
 /* the same for rows of any length (the NCC moment rows) */
 __global__ __launch_bounds__(128) void k_finish_rows(const double *partials, int nblk, int row_len, double *out) {
-	const int t = blockIdx.x, k = threadIdx.x;
+	const int t = blockIdx.x, k = blockIdx.y * 128 + threadIdx.x;   /* grid.y covers rows longer than one workgroup */
 	if (k >= row_len) return;
 	out[(size_t)t * row_len + k] = column_sum(partials + (size_t)t * nblk * row_len + k, nblk, row_len);
 }
@@ -585,7 +585,7 @@ void launch_finish_host(double *partials, int nblk, int row_len, double *out_hos
 	hipLaunchKernelGGL(k_finish_host, dim3(B), dim3(128), 0, st, partials, nblk, row_len, out_host, count, flag_host, seq);
 }
 void launch_finish_rows(double *partials, int nblk, int row_len, double *out, int B, hipStream_t st) {
-	hipLaunchKernelGGL(k_finish_rows, dim3(B), dim3(128), 0, st, partials, nblk, row_len, out);
+	hipLaunchKernelGGL(k_finish_rows, dim3(B, (row_len + 127) / 128), dim3(128), 0, st, partials, nblk, row_len, out);
 }
 void launch_finish(double *partials, int nblk, double *out, int B, hipStream_t st) {
 	hipLaunchKernelGGL(k_finish, dim3(B), dim3(64), 0, st, partials, nblk, out);

@@ -119,7 +119,9 @@ typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
 /* histogram of A and joint histogram A x B (MI.cc:222-235 init, :245-252 init joint, :352-367 update,
  * :641-649 self).  Block partial rows: [nb hist | nb*nb joint] */
-template <bool MFMA>
+/* SELF (MFMA only): the joint histogram of A with itself (cmptSelfHist MI.cc:639-659) is accumulated in the same pass and
+ * written behind the ordinary row: [nb hist | nb*nb joint | nb*nb self] */
+template <bool MFMA, bool SELF = false>
 __global__ __launch_bounds__(kBlock) void k_mi_hist(int N, int nb, double norm_mult, const double *A_all,
 	const double *B_all, double *partials, int nblk, int row_len) {
 	extern __shared__ __attribute__((aligned(16))) double dyn[];
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void k_mi_hist(int N, int nb, double norm_m
 	const int t = blockIdx.y;
 	const double *A = A_all + (size_t)t * N, *Bv = B_all + (size_t)t * N;
 	double accj[kMiPairs], acch = 0.0;
-	mfma_d4 cj = {0.0, 0.0, 0.0, 0.0};
+	mfma_d4 cj = {0.0, 0.0, 0.0, 0.0}, cs = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
 	for (int m = 0; m < kMiPairs; ++m) accj[m] = 0.0;
 	int pr[kMiPairs], pc[kMiPairs];
@@ -168,6 +170,7 @@ __global__ __launch_bounds__(kBlock) void k_mi_hist(int N, int nb, double norm_m
 				const int p = 4 * ks + kq;
 				const double av = wa[row * kMiRow + p], bv = wb[row * kMiRow + p];
 				cj = __builtin_amdgcn_mfma_f64_16x16x4f64(idx < nb ? av : 0.0, idx < nb ? bv : (idx == nb ? 1.0 : 0.0), cj, 0, 0, 0);
+				if constexpr (SELF) cs = __builtin_amdgcn_mfma_f64_16x16x4f64(idx < nb ? av : 0.0, idx < nb ? av : 0.0, cs, 0, 0, 0);
 			}
 			if (nb == 16) {
 #pragma unroll 8
@@ -186,8 +189,8 @@ __global__ __launch_bounds__(kBlock) void k_mi_hist(int N, int nb, double norm_m
 	}
 	/* four waves -> one partial row per workgroup */
 	__syncthreads();
-	double *red = dyn;                                  /* [4][nb + nb*nb], the slabs are free now */
-	const int rl = nb + nb * nb;
+	double *red = dyn;                                  /* [4][nb + nb*nb (+ nb*nb)], the slabs are free now */
+	const int rl = nb + nb * nb + (SELF ? nb * nb : 0);
 	if constexpr (MFMA) {
 		const int j = lane & 15;
 #pragma unroll
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(kBlock) void k_mi_hist(int N, int nb, double norm_m
 			const int i = (lane >> 4) + 4 * v;
 			if (i < nb && j < nb) red[wave * rl + nb + i * nb + j] = cj[v];
 			if (i < nb && j == nb) red[wave * rl + i] = cj[v];
+			if constexpr (SELF) { if (i < nb && j < nb) red[wave * rl + nb + nb * nb + i * nb + j] = cs[v]; }
 		}
 		if (nb == 16 && lane < nb) red[wave * rl + lane] = acch;
 	} else {
@@ -256,6 +260,48 @@ __global__ __launch_bounds__(kBlock) void k_mi_hist_finish(int nb, double pre_se
 		f_out[t] = s;
 	}
 }
+/* Fused MI iteration: everything between the histogram pass and the gradient pass in ONE launch -- k_mi_hist_finish in
+ * update mode (histogram of It, joint, logs, similarity: MI.cc:369-381), optionally in self mode (MI.cc:651-658), and the
+ * two k_mi_factor tables (MI.cc:399-403, 427-431).  Rows: [nb hist | nb*nb joint | nb*nb self (with_self)]. */
+__global__ __launch_bounds__(kBlock) void k_mi_tables_iter(int nb, double pre_seed, double norm_mult, int with_self, const double *partials,
+	int nblk, int row_len, double *tb_all, double *f_out) {
+	__shared__ double red[kBlock];
+	const int t = blockIdx.x;
+	double *tb = tb_all + (size_t)t * MI_SIZE;
+	const double *p = partials + (size_t)t * nblk * row_len;
+	const double hist_seed = nb * pre_seed;
+	for (int k = threadIdx.x; k < nb + nb * nb * (with_self ? 2 : 1); k += kBlock) {
+		const double s = column_sum(p + k, nblk, row_len);
+		if (k < nb) {
+			const double hv = (s + hist_seed) * norm_mult;
+			tb[MI_HIST_CURR + k] = hv; tb[MI_LOG_CURR + k] = log(hv);
+		} else if (k < nb + nb * nb) {
+			const int q = k - nb, r = q / nb, c = q % nb;
+			const double jv = (s + pre_seed) * norm_mult;
+			tb[MI_JOINT + r * MI_NB + c] = jv; tb[MI_JOINT_LOG + r * MI_NB + c] = log(jv);
+		} else {
+			const int q = k - nb - nb * nb, r = q / nb, c = q % nb;
+			tb[MI_SELF_JOINT + r * MI_NB + c] = (s + pre_seed) * norm_mult;
+		}
+	}
+	__syncthreads();
+	double part = 0;
+	for (int q = threadIdx.x; q < nb * nb; q += kBlock) {
+		const int r = q / nb, c = q % nb;
+		const double jv = tb[MI_JOINT + r * MI_NB + c], lg = tb[MI_JOINT_LOG + r * MI_NB + c];
+		part += jv * (lg - tb[MI_LOG_CURR + r] - tb[MI_LOG_INIT + c]);
+		tb[MI_T_CURR + r * MI_NB + c] = 1 + lg - tb[MI_LOG_CURR + r];
+		tb[MI_T_INIT + r * MI_NB + c] = 1 + tb[MI_JOINT_LOG + c * MI_NB + r] - tb[MI_LOG_INIT + r];   /* (init, curr) indexing */
+		if (with_self) tb[MI_T_SELF + r * MI_NB + c] = 1 + log(tb[MI_SELF_JOINT + r * MI_NB + c]) - tb[MI_LOG_CURR + r];
+	}
+	red[threadIdx.x] = part;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		double s = 0;
+		for (int i = 0; i < kBlock; ++i) s += red[i];
+		f_out[t] = s;
+	}
+}
 /* gradient-factor tables refreshed by updateCurrGrad / updateInitGrad (MI.cc:399-403, 427-431) */
 __global__ __launch_bounds__(kBlock) void k_mi_factor(int nb, int curr, double *tb_all) {
 	double *tb = tb_all + (size_t)blockIdx.x * MI_SIZE;
@@ -286,6 +332,44 @@ __global__ __launch_bounds__(kBlock) void k_mi_grad(int N, int nb, double norm_m
 				if (r < a.n && c < b.n) acc += a.d[r] * b.w[c] * T[(a.lo + r) * MI_NB + b.lo + c];
 		out[i] = acc;
 	}
+}
+/* Fused gradient pass of an MI iteration: both gradient vectors per pixel --
+ *   df_dIt = sum gradIt(r) matI0(c) T_curr(r, c),  df_dI0 = sum gradI0(r) matIt(c) T_init(r, c)   (MI.cc:406-415, 432-441)
+ * -- and the Jacobian products df_dIt . Jt, df_dI0 . J0 (cmptCurrJacobian / cmptInitJacobian) in the same pass, so that
+ * 2 x k_mi_grad, k_gemv and its reduction are one launch and It, I0 are read once.  Block partial rows: [8 | 8]. */
+__global__ __launch_bounds__(kBlock) void k_mi_grad_gemv(int N, int S, int nb, double norm_mult, const double *It_all, const double *I0_all,
+	const double *tb_all, const double *Jt_all, const double *J0_all, double *dft_out, double *df0_out, double *partials, int nblk) {
+	__shared__ double Tc[MI_NB * MI_NB], Ti[MI_NB * MI_NB];
+	__shared__ double lds[4 * 16];
+	const int t = blockIdx.y;
+	const double *tb = tb_all + (size_t)t * MI_SIZE;
+	for (int k = threadIdx.x; k < MI_NB * MI_NB; k += kBlock) { Tc[k] = tb[MI_T_CURR + k]; Ti[k] = tb[MI_T_INIT + k]; }
+	__syncthreads();
+	const double *It = It_all + (size_t)t * N, *I0 = I0_all + (size_t)t * N;
+	const double *Jt = Jt_all ? Jt_all + (size_t)t * N * S : nullptr, *J0 = J0_all ? J0_all + (size_t)t * N * S : nullptr;
+	double acc[16];
+#pragma unroll
+	for (int k = 0; k < 16; ++k) acc[k] = 0.0;
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+		double jt[kMaxS], j0[kMaxS];
+#pragma unroll
+		for (int s = 0; s < kMaxS; ++s) { jt[s] = (Jt && s < S) ? Jt[(size_t)s * N + i] : 0.0; j0[s] = (J0 && s < S) ? J0[(size_t)s * N + i] : 0.0; }
+		const BsplWin a = bspl_window(It[i], nb, norm_mult, false);
+		const BsplWin c0 = bspl_window(I0[i], nb, norm_mult, false);
+		double dft = 0, df0 = 0;
+#pragma unroll
+		for (int r = 0; r < 4; ++r)
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				if (r < a.n && c < c0.n) dft += a.d[r] * c0.w[c] * Tc[(a.lo + r) * MI_NB + c0.lo + c];
+				if (r < c0.n && c < a.n) df0 += c0.d[r] * a.w[c] * Ti[(c0.lo + r) * MI_NB + a.lo + c];
+			}
+		if (dft_out) dft_out[(size_t)t * N + i] = dft;
+		if (df0_out) df0_out[(size_t)t * N + i] = df0;
+#pragma unroll
+		for (int s = 0; s < kMaxS; ++s) { acc[s] = fma(dft, jt[s], acc[s]); acc[8 + s] = fma(df0, j0[s], acc[8 + s]); }
+	}
+	block_reduce_store<16>(acc, partials + ((size_t)t * nblk + blockIdx.x) * 16, lds);
 }
 /* first-order MI Hessians (MI.cc:461-513 init, 565-601 self (the returned pass), 603-637 curr):
  *   Hsum  += hess_term(p) * Jrow Jrow^T,  hess_term = sum_r hessA(r) * sum_c matB(c) T(r,c)
@@ -412,11 +496,11 @@ __global__ __launch_bounds__(kBlock) void k_mi_hess(int N, int S, int nb, double
 		__builtin_amdgcn_wave_barrier();
 	}
 	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * row_len;
+	const int ql = nb * nb * S;
 	block_reduce_store<36>(acc, dst, red);
 	__syncthreads();
 	/* the four waves' Q blocks through the (now free) slabs: [4][nb*nb*S], indexed as the finish expects */
 	double *qred = slabs;
-	const int ql = nb * nb * S;
 	if constexpr (MFMA) {
 		const int sidx = lane & 15;
 #pragma unroll
@@ -483,8 +567,18 @@ void launch_mi_hist(const BatchView &bv, int nb, double norm_mult, const double 
 	/* per-wave staging slabs [64][2 nb]; the same LDS later holds the four waves' [nb + nb^2] rows */
 	const size_t lds = sizeof(double) * std::max<size_t>((size_t)4 * kMiRow * 2 * nb, (size_t)4 * (nb + nb * nb));
 	static const bool use_mfma = !(getenv("MTFHIP_MI_MFMA") && atoi(getenv("MTFHIP_MI_MFMA")) == 0);
-	if (use_mfma) hipLaunchKernelGGL(k_mi_hist<true>, grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, nb, norm_mult, A, Bv, partials, nblk, row_len);
-	else hipLaunchKernelGGL(k_mi_hist<false>, grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, nb, norm_mult, A, Bv, partials, nblk, row_len);
+	if (use_mfma) hipLaunchKernelGGL((k_mi_hist<true, false>), grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, nb, norm_mult, A, Bv, partials, nblk, row_len);
+	else hipLaunchKernelGGL((k_mi_hist<false, false>), grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, nb, norm_mult, A, Bv, partials, nblk, row_len);
+}
+/* A = It against B = I0 and against itself in one pass (fused MI iteration); row: [nb | nb*nb | nb*nb] */
+void launch_mi_hist_self(const BatchView &bv, int nb, double norm_mult, const double *A, const double *Bv, double *partials,
+	int nblk, int row_len, hipStream_t st) {
+	const size_t lds = sizeof(double) * std::max<size_t>((size_t)4 * kMiRow * 2 * nb, (size_t)4 * (nb + 2 * nb * nb));
+	hipLaunchKernelGGL((k_mi_hist<true, true>), grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, nb, norm_mult, A, Bv, partials, nblk, row_len);
+}
+void launch_mi_tables_iter(const BatchView &bv, int nb, double pre_seed, double norm_mult, int with_self, const double *partials, int nblk,
+	int row_len, double *tb, double *f_out, hipStream_t st) {
+	hipLaunchKernelGGL(k_mi_tables_iter, dim3(bv.B), dim3(kBlock), 0, st, nb, pre_seed, norm_mult, with_self, partials, nblk, row_len, tb, f_out);
 }
 void launch_mi_hist_finish(const BatchView &bv, int nb, double pre_seed, double norm_mult, int mode, int first_init,
 	const double *partials, int nblk, int row_len, double *tb, double *f_out, hipStream_t st) {
@@ -516,6 +610,12 @@ void launch_mi_hess(const BatchView &bv, int nb, double norm_mult, const double 
 	else
 		hipLaunchKernelGGL(k_mi_hess<false>, grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, bv.S, nb, norm_mult, A, Bv, tb, table_off,
 			transpose_q, J, partials, nblk, row_len);
+}
+/* df_dIt, df_dI0 (optionally stored) and the two Jacobian products; partial rows of 16 (sum them with launch_finish_rows) */
+void launch_mi_grad_gemv(const BatchView &bv, int nb, double norm_mult, const double *It, const double *I0, const double *tb,
+	const double *Jt, const double *J0, double *df_dIt, double *df_dI0, double *partials, int nblk, hipStream_t st) {
+	hipLaunchKernelGGL(k_mi_grad_gemv, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv.N, bv.S, nb, norm_mult, It, I0, tb, Jt, J0, df_dIt, df_dI0,
+		partials, nblk);
 }
 void launch_mi_hess_finish(const BatchView &bv, int nb, const double *partials, int nblk, int row_len, const double *tb,
 	int joint_off, int hist_off, int transpose_q, double *out, hipStream_t st) {

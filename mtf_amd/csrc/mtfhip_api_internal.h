@@ -210,6 +210,7 @@ struct mtfhip_batch {
 	double *d_ncc = nullptr, *d_colmean = nullptr; /* [B][8] NCC scalars / column means */
 	/* MI: per-target table block, block partial rows, similarity and Hessian outputs */
 	double *d_mi_tb = nullptr, *d_mi_part = nullptr, *d_mi_f = nullptr, *d_mi_H = nullptr;
+	double *d_mi_red = nullptr;   /* [B][mi_row_len] block rows summed (the Hessian assembly then reads one row per target) */
 	double *d_h0inv = nullptr; /* [B][64] inverse of the constant Hessian (one-launch ICLK) */
 	double *d_units = nullptr; /* per-work-unit partial sums of the LDS-staged candidate scorer */
 	double *d_d2_part = nullptr, *d_d2_out = nullptr, *d_d2_w = nullptr; /* second-order term: block rows, [B][64] sums, MI self weights */
@@ -449,5 +450,6 @@ int ncc_template_moments(mtfhip_batch *b);
 int ncc_lazy_outputs(mtfhip_batch *b, int trig, int j_a, bool hess_mean, double *g);
 int ncc_hessian_from_cache(mtfhip_batch *b, int j_buf, int kind, double *H);
 int fused_args(const mtfhip_batch *b, const mtfhip_sm_desc *sm, FusedArgs &fa);
+int mi_blocks(const mtfhip_batch *b);
 } /* extern "C" */
 #endif

@@ -158,6 +158,12 @@ void launch_mi_hess(const BatchView &bv, int nb, double norm_mult, const double 
 	int table_off, int transpose_q, const double *J, double *partials, int nblk, int row_len, hipStream_t st);
 void launch_mi_hess_finish(const BatchView &bv, int nb, const double *partials, int nblk, int row_len, const double *tb,
 	int joint_off, int hist_off, int transpose_q, double *out, hipStream_t st);
+void launch_mi_tables_iter(const BatchView &bv, int nb, double pre_seed, double norm_mult, int with_self, const double *partials, int nblk,
+	int row_len, double *tb, double *f_out, hipStream_t st);
+void launch_mi_hist_self(const BatchView &bv, int nb, double norm_mult, const double *A, const double *Bv, double *partials,
+	int nblk, int row_len, hipStream_t st);
+void launch_mi_grad_gemv(const BatchView &bv, int nb, double norm_mult, const double *It, const double *I0, const double *tb,
+	const double *Jt, const double *J0, double *df_dIt, double *df_dI0, double *partials, int nblk, hipStream_t st);
 /* sums partials over blocks: out[B][ACC_COUNT] */
 void launch_finish(double *partials, int nblk, double *out, int B, hipStream_t st);
 void launch_finish_rows(double *partials, int nblk, int row_len, double *out, int B, hipStream_t st);

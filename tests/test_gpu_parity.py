@@ -184,6 +184,25 @@ def test_fused_ncc_iterations_follow_oracle(oracle, gpu_ctx, frame, case, materi
     _fused_follow(oracle, gpu_ctx, frame, L.AM_NCC, case, materialize, grid)
 
 
+MI_CASES = [
+    # fused MI iteration (8 bins): pass 0 = the fused LK kernel materialising It / dIt_dx / Jt, then one histogram pass and
+    # one gradient + Hessian pass; the class-default (self-type) Hessians
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, 50, dict()),                                  # config 5 shape (DiffOfJacs + SumOfSelf), reduced
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, 40, dict(hess_type=1, chained_warp=0)),
+    (L.SM_ESM, L.SSM_AFFINE, 40, dict(hess_type=0)),
+    (L.SM_FCLK, L.SSM_HOMOGRAPHY, 50, dict()),                                 # CurrentSelf
+    (L.SM_FCLK, L.SSM_AFFINE, 40, dict(hess_type=0, chained_warp=0)),
+    (L.SM_ICLK, L.SSM_HOMOGRAPHY, 40, dict()),
+]
+
+
+@pytest.mark.parametrize("grid", ["oracle_grid", "device_grid"])
+@pytest.mark.parametrize("materialize", [1, 0])
+@pytest.mark.parametrize("case", MI_CASES, ids=_case_id)
+def test_fused_mi_iterations_follow_oracle(oracle, gpu_ctx, frame, case, materialize, grid):
+    _fused_follow(oracle, gpu_ctx, frame, L.AM_MI, case, materialize, grid)
+
+
 @pytest.mark.parametrize("grid", ["oracle_grid", "device_grid"])
 @pytest.mark.parametrize("materialize", [1, 0])
 @pytest.mark.parametrize("case", SM_CASES, ids=_case_id)
@@ -235,7 +254,7 @@ def _fused_follow(oracle, gpu_ctx, frame, am, case, materialize, grid):
         f, g, H = b.iterate(sm)
         dp = -oracle.colpiv_qr_solve(H[0], g[0])
         # scale of g: Cauchy-Schwarz ||J|| ||r|| for SSD; for NCC the gradient vectors have norm <= 2 / b, so ||Jc|| ~ sqrt(|tr H|)
-        g_scale = np.sqrt(abs(np.trace(rec["H"]))) * (1.0 if ncc else np.sqrt(abs(2 * rec["f"])))
+        g_scale = np.sqrt(abs(np.trace(rec["H"]))) * (np.sqrt(abs(2 * rec["f"])) if am == L.AM_SSD else 1.0)
         if tight:
             assert rel(f[0], rec["f"]) < 1e-12, it
             assert rel(H[0], rec["H"]) < 1e-9, it
@@ -256,7 +275,7 @@ def _fused_follow(oracle, gpu_ctx, frame, am, case, materialize, grid):
         np.testing.assert_allclose(b.get_corners()[0], rec["corners"], rtol=0, atol=1e-9)
     if materialize and sm_kind != L.SM_ICLK:
         assert b.read(L.BUF_JT).shape == (1, res * res, b.S)
-    if not materialize:
+    if not materialize and am != L.AM_MI:   # (the fused MI iteration always materialises It / Jt: its second pass reads them)
         with pytest.raises(mtf_amd.LogicError):
             b.read(L.BUF_IT)
 
