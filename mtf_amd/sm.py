@@ -85,7 +85,16 @@ class LKTracker:
                             delta[t] /= sm.lm_delta_update
                     prev_f[t] = f[t]
             prev_corners = b.get_corners()
-            for t in range(B):
+            if not sm.leven_marq:
+                # no accept / reject bookkeeping: all targets solved in one batched call (same scaling as _solve)
+                d = np.sqrt(np.abs(np.diagonal(H, axis1=1, axis2=2)))
+                d[d == 0] = 1.0
+                dp_all = -np.linalg.solve(H / (d[:, :, None] * d[:, None, :]), (g / d)[..., None])[..., 0] / d
+                dp_all[~active] = 0
+                last_dp = dp_all
+                dps = b.invert_state(dp_all) if sm.sm == L.SM_ICLK else dp_all.copy()
+                dps[~active] = 0
+            for t in range(B if sm.leven_marq else 0):
                 if not active[t]:
                     continue
                 if undo[t]:
