@@ -403,7 +403,7 @@ void *mtfhip_batch_device_ptr(mtfhip_batch *b, int id) {
 
 /* ------------------------------------------------------------------ SSM */
 int mtfhip_ssm_set_corners(mtfhip_batch *b, const double *corners) {
-	FLUSH(b);
+	FLUSH_AM(b);   /* pending calls are replayed (with the points they need); the points themselves are about to change */
 	if (b) ++b->lz.epoch;
 	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
 	if (!b || !corners) return fail(MTFHIP_ERR_INVALID_ARG, "set_corners: NULL argument");
@@ -463,7 +463,7 @@ static int apply_states(mtfhip_batch *b) {
 }
 
 int mtfhip_ssm_set_state(mtfhip_batch *b, const double *states) {
-	FLUSH(b);
+	FLUSH_AM(b);   /* pending calls are replayed (with the points they need); the points themselves are about to change */
 	if (b) ++b->lz.epoch;
 	if (!b || !states) return fail(MTFHIP_ERR_INVALID_ARG, "set_state: NULL argument");
 	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "set_state before set_corners");
@@ -478,7 +478,7 @@ int mtfhip_ssm_set_state(mtfhip_batch *b, const double *states) {
 }
 
 int mtfhip_ssm_compositional_update(mtfhip_batch *b, const double *dps) {
-	FLUSH(b);
+	FLUSH_AM(b);   /* pending calls are replayed (with the points they need); the points themselves are about to change */
 	if (b) ++b->lz.epoch;
 	if (!b || !dps) return fail(MTFHIP_ERR_INVALID_ARG, "compositional_update: NULL argument");
 	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "compositional_update before set_corners");
