@@ -252,12 +252,16 @@ static int mi_hist_pass(mtfhip_batch *b, int mode, int first_init) {
 	launch_mi_hist(b->view(), nb, b->mi_hist_norm, A, Bv, b->d_mi_part, nblk, b->mi_row_len, b->ctx->stream);
 	launch_mi_hist_finish(b->view(), nb, b->desc.mi_pre_seed, b->mi_hist_norm, mode, first_init, b->d_mi_part, nblk,
 		b->mi_row_len, b->d_mi_tb, b->d_mi_f, b->ctx->stream);
+	if (mode == 2) b->lz.mi_self_it = b->lz.ver[MTFHIP_BUF_IT];
 	return MTFHIP_OK;
 }
 /* kind 0 init (MI.cc:461-513), 1 curr (:603-637), 2 self (:515-601, the returned second pass) */
 static int mi_hessian(mtfhip_batch *b, int j_buf, int kind, double *H) {
 	const int nb = b->desc.mi_n_bins, nblk = mi_blocks(b), S = b->S;
-	if (kind == 2) TRY(mi_hist_pass(b, 2, 0));   /* cmptSelfHist MI.cc:639-659 */
+	if (kind == 2) {   /* cmptSelfHist MI.cc:639-659 -- unless the fused histogram pass of this iteration took it along */
+		b->lz.mi_want_self = true;
+		if (b->lz.no_cache || b->lz.mi_self_it != b->lz.ver[MTFHIP_BUF_IT]) TRY(mi_hist_pass(b, 2, 0));
+	}
 	const double *A = b->buf[kind == 0 ? MTFHIP_BUF_I0 : MTFHIP_BUF_IT];
 	const double *Bv = b->buf[kind == 1 ? MTFHIP_BUF_I0 : MTFHIP_BUF_IT];
 	const int table = kind == 0 ? MI_T_INIT : (kind == 1 ? MI_T_CURR : MI_T_SELF);
@@ -369,6 +373,7 @@ static int do_update_similarity(mtfhip_batch *b, int prereq_only) {
 	if (b->desc.am == MTFHIP_AM_MI) {
 		/* MI::updateSimilarity MI.cc:346-382 */
 		TRY(mi_hist_pass(b, 1, 0));
+		b->lz.df0_it_ver = b->lz.ver[MTFHIP_BUF_IT];
 		if (!prereq_only) TRY(mi_read_f(b));
 		return MTFHIP_OK;
 	}
@@ -534,6 +539,7 @@ int lazy_flush(mtfhip_batch *b, bool pts) {
 		case 5: TRY(do_update_curr_grad(b)); break;
 		case 6:          /* SSD::updateInitGrad is empty (SSDBase.h) */
 			if (b->desc.am == MTFHIP_AM_NCC) { TRY(ncc_update_grad(b, 0)); stale_clear(b, true, false); }
+			else if (b->desc.am == MTFHIP_AM_MI) TRY(mi_grad(b, 0));
 			break;
 		default: TRY(do_mean_jacobian(b)); break;
 		}
@@ -548,6 +554,74 @@ int ncc_lazy_outputs(mtfhip_batch *b, int trig, int j_a, bool hess_mean, double 
  *   FCLK  NT/FCLK.cc:171-358: updatePixVals, updateSimilarity, updateCurrGrad, pixel gradient + pixel Jacobian, cmptCurrJacobian(Jt)
  *   ESM   NT/ESM.cc:170-296: ... updateInitGrad, cmptDifferenceOfJacobians(J0, Jt)   (jac_type Original: cmptCurrJacobian(Jm))
  *   ICLK  NT/ICLK.cc:160-299: updatePixVals, updateSimilarity, updateInitGrad, cmptInitJacobian(J0) */
+/* Deferred fusion, MI: the recognised sequence is served by the fused MI passes (api_fused.hip: mi_iterate describes
+ * them) -- the fused LK kernel materialising It / dIt_dx / Jt, one histogram pass (with the self histogram when the search
+ * method has been asking for self Hessians), one table kernel, one gradient + Jacobian-product pass that also writes the
+ * gradient vectors the recorded update*Grad calls would have written.  `sm` carries what lazy_try_fused classified. */
+static int mi_lazy_fused(mtfhip_batch *b, int trig, int j_a, const mtfhip_sm_desc &sm, bool replay, double *g, int *done) {
+	mtfhip_batch::Lazy &L = b->lz;
+	const bool iclk = sm.sm == MTFHIP_SM_ICLK;
+	if (trig == LAZY_CURR_JAC && j_a != MTFHIP_BUF_JT) return MTFHIP_OK;   /* Original Jacobian: df_dIt . Jm is not accumulated */
+	if (sm.sm != MTFHIP_SM_FCLK && !L.ig) return MTFHIP_OK;                /* df_dI0 comes from updateInitGrad */
+	const int nb = b->desc.mi_n_bins, nblk = mi_blocks(b), S = b->S;
+	hipStream_t st = b->ctx->stream;
+	if (replay || !iclk) {   /* (ICLK on a current IT needs nothing from the image) */
+		mtfhip_sm_desc s0 = sm;
+		s0.sm = iclk ? MTFHIP_SM_ICLK : MTFHIP_SM_FCLK; s0.hess_type = iclk ? 0 : 1; s0.materialize = 1;
+		FusedArgs fa;
+		TRY(fused_args(b, &s0, fa));
+		{
+			TimedScope ts(b->ctx, "fused_lk");
+			launch_fused_ssd(b->view(), b->ctx->img, fa, b->d_partials, fused_blocks_per_target(b->N, b->B), st);
+		}
+		const bool self_was = L.mi_self_it == L.ver[MTFHIP_BUF_IT];
+		touch(b, MTFHIP_BUF_IT);
+		if (!replay && self_was) L.mi_self_it = L.ver[MTFHIP_BUF_IT];   /* same bits */
+		b->it_valid = true;
+		L.it_epoch = L.epoch;
+		if (!iclk) { touch(b, MTFHIP_BUF_DIT_DX); touch(b, MTFHIP_BUF_JT); b->dit_valid = b->jt_valid = true; }
+	}
+	const double *It = b->buf[MTFHIP_BUF_IT], *I0 = b->buf[MTFHIP_BUF_I0];
+	{
+		TimedScope ts(b->ctx, "mi_hist");
+		if (replay) {
+			const bool self = L.mi_want_self && !L.no_cache;
+			if (self) launch_mi_hist_self(b->view(), nb, b->mi_hist_norm, It, I0, b->d_mi_part, nblk, b->mi_row_len, st);
+			else launch_mi_hist(b->view(), nb, b->mi_hist_norm, It, I0, b->d_mi_part, nblk, b->mi_row_len, st);
+			launch_mi_tables_iter(b->view(), nb, b->desc.mi_pre_seed, b->mi_hist_norm, self ? 1 : 0, b->d_mi_part, nblk, b->mi_row_len, b->d_mi_tb,
+				b->d_mi_f, st);
+			L.mi_self_it = self ? L.ver[MTFHIP_BUF_IT] : -1;
+		} else {   /* updateSimilarity already ran for this IT: only the factor tables update*Grad would refresh */
+			launch_mi_factor(b->view(), nb, 1, b->d_mi_tb, st);
+			launch_mi_factor(b->view(), nb, 0, b->d_mi_tb, st);
+		}
+	}
+	L.df0_it_ver = L.ver[MTFHIP_BUF_IT];
+	double *d_g = b->d_mi_H + 64 * (size_t)b->B;
+	{
+		TimedScope ts(b->ctx, "mi_grad");
+		const int ng = std::min(simple_blocks_per_target(b->N), 64);
+		launch_mi_grad_gemv(b->view(), nb, b->mi_hist_norm, It, I0, b->d_mi_tb, iclk ? nullptr : b->buf[MTFHIP_BUF_JT],
+			sm.sm == MTFHIP_SM_FCLK ? nullptr : b->buf[MTFHIP_BUF_J0], L.cg ? b->buf[MTFHIP_BUF_DF_DIT] : nullptr,
+			L.ig ? b->buf[MTFHIP_BUF_DF_DI0] : nullptr, b->d_partials, ng, st);
+		launch_finish_rows(b->d_partials, ng, 16, d_g, b->B, st);
+	}
+	const bool want_mean = L.jm != 0;
+	L.pv = L.gp = L.pg = L.pj = L.sim = L.cg = L.ig = L.jm = 0;
+	if (want_mean) TRY(do_mean_jacobian(b));
+	std::vector<double> out((size_t)17 * b->B);
+	HIP_TRY(hipMemcpyAsync(out.data(), d_g, sizeof(double) * 16 * b->B, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(out.data() + (size_t)16 * b->B, b->d_mi_f, sizeof(double) * b->B, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	for (int t = 0; t < b->B; ++t) {
+		const double *gs = &out[(size_t)16 * t];
+		if (replay) b->th[t].f = out[(size_t)16 * b->B + t];
+		for (int s = 0; s < S; ++s)
+			g[(size_t)t * S + s] = trig == LAZY_INIT_JAC ? gs[8 + s] : (trig == LAZY_CURR_JAC ? gs[s] : gs[s] - gs[8 + s]);
+	}
+	*done = 1;
+	return MTFHIP_OK;
+}
 static int lazy_try_fused(mtfhip_batch *b, int trig, int j_a, int j_b, double *g, int *done) {
 	*done = 0;
 	mtfhip_batch::Lazy &L = b->lz;
@@ -583,6 +657,7 @@ static int lazy_try_fused(mtfhip_batch *b, int trig, int j_a, int j_b, double *g
 			sm.sm = MTFHIP_SM_ESM; sm.hess_type = 3; gscale = 0.5;   /* df_dIt . (J0 + Jt) / 2, the halving is exact */
 		} else return MTFHIP_OK;
 	}
+	if (b->desc.am == MTFHIP_AM_MI) return mi_lazy_fused(b, trig, j_a, sm, replay, g, done);
 	const bool ncc = b->desc.am == MTFHIP_AM_NCC;
 	if (ncc && trig == LAZY_INIT_JAC && !L.ig) return MTFHIP_OK;   /* NCC's df_dI0 comes from updateInitGrad */
 	/* gradients a previous fused launch skipped and this one will not re-produce keep their IT (when IT is current the

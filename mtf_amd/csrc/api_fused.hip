@@ -239,6 +239,35 @@ int lazy_try_similarity(mtfhip_batch *b) {
 	sm.sm = MTFHIP_SM_ICLK; sm.hess_type = 0; sm.materialize = 1; sm.max_iters = 1; sm.chained_warp = 1;
 	FusedArgs fa;
 	TRY(fused_args(b, &sm, fa));
+	if (b->desc.am == MTFHIP_AM_MI) {
+		/* MI: the lean launch writes It (its SSD sums are ignored), then the histogram pass and the table kernel */
+		const int nb = b->desc.mi_n_bins, nblk_mi = mi_blocks(b);
+		hipStream_t st = b->ctx->stream;
+		{
+			TimedScope ts(b->ctx, "fused_lk");
+			launch_fused_ssd(b->view(), b->ctx->img, fa, b->d_partials, fused_blocks_per_target(b->N, b->B), st);
+		}
+		touch(b, MTFHIP_BUF_IT);
+		b->it_valid = true;
+		L.it_epoch = L.epoch;
+		L.df0_it_ver = L.ver[MTFHIP_BUF_IT];
+		L.pv = L.sim = 0;
+		const bool self = L.mi_want_self && !L.no_cache;
+		{
+			TimedScope ts(b->ctx, "mi_hist");
+			const double *It = b->buf[MTFHIP_BUF_IT], *I0 = b->buf[MTFHIP_BUF_I0];
+			if (self) launch_mi_hist_self(b->view(), nb, b->mi_hist_norm, It, I0, b->d_mi_part, nblk_mi, b->mi_row_len, st);
+			else launch_mi_hist(b->view(), nb, b->mi_hist_norm, It, I0, b->d_mi_part, nblk_mi, b->mi_row_len, st);
+			launch_mi_tables_iter(b->view(), nb, b->desc.mi_pre_seed, b->mi_hist_norm, self ? 1 : 0, b->d_mi_part, nblk_mi, b->mi_row_len, b->d_mi_tb,
+				b->d_mi_f, st);
+		}
+		L.mi_self_it = self ? L.ver[MTFHIP_BUF_IT] : -1;
+		std::vector<double> fv(b->B);
+		HIP_TRY(hipMemcpyAsync(fv.data(), b->d_mi_f, sizeof(double) * b->B, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		for (int t = 0; t < b->B; ++t) b->th[t].f = fv[t];
+		return MTFHIP_OK;
+	}
 	TRY(protect_stale(b, !ncc, false));   /* SSD's updateSimilarity re-produces df_dI0 */
 	const int nblk = fused_blocks_per_target(b->N, b->B);
 	{

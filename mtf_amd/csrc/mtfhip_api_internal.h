@@ -300,6 +300,9 @@ struct mtfhip_batch {
 		std::vector<double> ncc_M; bool ncc_M_mean = false; long ncc_M_it = -1, ncc_M_jt = -1, ncc_M_jm = -1, ncc_tm_ver = -1;
 		/* SSD: sum r J0 of the lean launch that served getSimilarity() -- it IS cmptInitJacobian(J0) for this IT and J0 */
 		std::vector<double> sim_g; long sim_g_it = -1, sim_g_j0 = -1;
+		/* MI: IT version the self joint histogram / its factor table belong to, and whether the search method has been
+		 * asking for the self Hessian (then the fused histogram pass takes the self histogram along) */
+		long mi_self_it = -1; bool mi_want_self = false;
 		/* Gram matrices that are already on the host: [B][36] upper triangles, valid while version matches */
 		long ver[MTFHIP_BUF_COUNT] = {0};
 		int gram_buf = -1; long gram_ver = -1; std::vector<double> gram;
