@@ -413,12 +413,11 @@ int mtfhip_ssm_set_corners(mtfhip_batch *b, const double *corners) {
 	/* normalised grid extents: ProjectiveBase.cc:14 (unit square) ; Affine.cc:56-57 */
 	double lo_x = -0.5, lo_y = -0.5, hi_x = 0.5, hi_y = 0.5;
 	if (!hom) { lo_x = 1 - b->desc.resx / 2.0; lo_y = 1 - b->desc.resy / 2.0; hi_x = b->desc.resx / 2.0; hi_y = b->desc.resy / 2.0; }
-	const double nc[8] = {lo_x, lo_y, hi_x, lo_y, hi_x, hi_y, lo_x, hi_y};
 	std::vector<double> w0(9 * b->B);
 	int unit_z = 1;
 	for (int t = 0; t < b->B; ++t) {
 		M3 W0;
-		if (!dlt4(nc, corners + 8 * t, W0)) return fail(MTFHIP_ERR_INVALID_ARG, "set_corners: degenerate corners for target %d", t);
+		if (!rect_to_quad(lo_x, lo_y, hi_x, hi_y, corners + 8 * t, W0)) return fail(MTFHIP_ERR_INVALID_ARG, "set_corners: degenerate corners for target %d", t);
 		if (!hom || (std::fabs(W0.m[6]) < 1e-15 && std::fabs(W0.m[7]) < 1e-15)) {
 			if (hom) { W0.m[6] = 0; W0.m[7] = 0; }
 		} else unit_z = 0;

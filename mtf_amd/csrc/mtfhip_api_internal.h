@@ -97,37 +97,38 @@ static void state_from_warp(int ssm, double *p, const M3 &W) {
 		p[6] = p[7] = 0;
 	}
 }
-/* 4-corner homography (utils::computeHomographyDLT, Utilities/src/warpUtils.cc:171-224): the null vector
- * of the 8x9 constraint matrix scaled to h8 = 1 is the solution of the 8x8 system below; solved by
- * Gaussian elimination with partial pivoting. corners are 2x4 interleaved. */
-static bool dlt4(const double *in, const double *out, M3 &H) {
-	double A[8][9];
-	for (int i = 0; i < 4; ++i) {
-		double x = in[2 * i], y = in[2 * i + 1], u = out[2 * i], v = out[2 * i + 1];
-		double r0[9] = {x, y, 1, 0, 0, 0, -u * x, -u * y, u};
-		double r1[9] = {0, 0, 0, x, y, 1, -v * x, -v * y, v};
-		std::memcpy(A[2 * i], r0, sizeof(r0));
-		std::memcpy(A[2 * i + 1], r1, sizeof(r1));
+/* The homography that maps the corners of the axis-aligned rectangle [lo_x, hi_x] x [lo_y, hi_y] (TL, TR, BR, BL) onto
+ * four given corners -- what the reference obtains from the 4-point DLT (utils::computeHomographyDLT,
+ * Utilities/src/warpUtils.cc:171-224, JacobiSVD of the 8 x 9 system).  Four point pairs determine the matrix uniquely up
+ * to scale, so the closed form of the square-to-quadrilateral map (Heckbert 1989, eq. 2.12), composed with the
+ * rectangle's normalisation and scaled to m[8] = 1, is the same matrix to rounding -- ~40 flops instead of an 8 x 8
+ * elimination per target (GridTracker sets 256 of them per frame).  false: degenerate corners. */
+static bool rect_to_quad(double lo_x, double lo_y, double hi_x, double hi_y, const double *q, M3 &H) {
+	const double x0 = q[0], y0 = q[1], x1 = q[2], y1 = q[3], x2 = q[4], y2 = q[5], x3 = q[6], y3 = q[7];
+	const double dx1 = x1 - x2, dx2 = x3 - x2, sx = x0 - x1 + x2 - x3;
+	const double dy1 = y1 - y2, dy2 = y3 - y2, sy = y0 - y1 + y2 - y3;
+	double a, b, c, d, e, f, g, h;
+	if (sx == 0 && sy == 0) {   /* parallelogram: affine */
+		a = x1 - x0; b = x3 - x0; c = x0; d = y1 - y0; e = y3 - y0; f = y0; g = 0; h = 0;
+		if (a * e - b * d == 0) return false;
+	} else {
+		const double den = dx1 * dy2 - dy1 * dx2;
+		if (den == 0) return false;
+		g = (sx * dy2 - dx2 * sy) / den; h = (dx1 * sy - sx * dy1) / den;
+		a = x1 - x0 + g * x1; b = x3 - x0 + h * x3; c = x0;
+		d = y1 - y0 + g * y1; e = y3 - y0 + h * y3; f = y0;
 	}
-	for (int k = 0; k < 8; ++k) {
-		int piv = k;
-		for (int i = k + 1; i < 8; ++i)
-			if (std::fabs(A[i][k]) > std::fabs(A[piv][k])) piv = i;
-		if (A[piv][k] == 0) return false;
-		if (piv != k)
-			for (int j = 0; j < 9; ++j) std::swap(A[piv][j], A[k][j]);
-		for (int i = k + 1; i < 8; ++i) {
-			double f = A[i][k] / A[k][k];
-			for (int j = k; j < 9; ++j) A[i][j] -= f * A[k][j];
-		}
+	/* (u, v) = ((x - lo_x) / wx, (y - lo_y) / wy) */
+	const double wx = hi_x - lo_x, wy = hi_y - lo_y;
+	const double r0[3] = {a, b, c}, r1[3] = {d, e, f}, r2[3] = {g, h, 1.0};
+	const double *rows[3] = {r0, r1, r2};
+	double m[9];
+	for (int r = 0; r < 3; ++r) {
+		m[3 * r] = rows[r][0] / wx; m[3 * r + 1] = rows[r][1] / wy;
+		m[3 * r + 2] = rows[r][2] - rows[r][0] * lo_x / wx - rows[r][1] * lo_y / wy;
 	}
-	double h[8];
-	for (int k = 7; k >= 0; --k) {
-		double s = A[k][8];
-		for (int j = k + 1; j < 8; ++j) s -= A[k][j] * h[j];
-		h[k] = s / A[k][k];
-	}
-	for (int i = 0; i < 8; ++i) H.m[i] = h[i];
+	if (m[8] == 0 || !std::isfinite(m[8])) return false;
+	for (int i = 0; i < 9; ++i) H.m[i] = m[i] / m[8];
 	H.m[8] = 1;
 	return true;
 }
