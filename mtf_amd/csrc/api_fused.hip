@@ -704,9 +704,7 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 	}
 	b->it_valid = fa.materialize;
 	b->dit_valid = b->jt_valid = fa.materialize && fa.mode != 2;
-	/* curr_pts follow the final warp */
-	launch_apply_warp(b->view(), st);
-	b->pts_stale = false;
+	b->pts_stale = true;   /* CURR_PTS follow the final warp when an un-fused kernel next needs them */
 	return MTFHIP_OK;
 }
 
