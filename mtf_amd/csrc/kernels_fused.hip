@@ -27,18 +27,6 @@ namespace mtfhip {
  * the border or on an integer coordinate sends the wave through the general per-sample path.  Both
  * paths evaluate the reference's expressions in the reference's order.
  */
-/* Uniform base + 32-bit byte offset: the form the `global_load/store v, v_off, s[base]` encodings take directly.
- * With `ptr[i]` the compiler cannot prove that i * sizeof(T) stays below 2^32 and builds a 64-bit address per
- * access (v_lshl_add_u64 / v_mad_u64), ~50 extra VALU instructions per row in a loop that is VALU-issue bound.
- * mtfhip_batch_create bounds the per-target arrays to < 4 GiB so the offsets cannot wrap. */
-template <typename T>
-__device__ __forceinline__ T ld_off(const void *base, unsigned byte_off) {
-	return *reinterpret_cast<const T *>(static_cast<const char *>(base) + byte_off);
-}
-template <typename T>
-__device__ __forceinline__ void st_off(void *base, unsigned byte_off, T v) {
-	MAT_STORE(reinterpret_cast<T *>(static_cast<char *>(base) + byte_off), v);
-}
 __device__ __forceinline__ double bilin(double t00, double t01, double t10, double t11, double dx, double dy) {
 	return t00 * (1 - dx) * (1 - dy) + t01 * dx * (1 - dy) + t10 * (1 - dx) * dy + t11 * dx * dy;
 }
