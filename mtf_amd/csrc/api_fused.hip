@@ -407,7 +407,6 @@ int fused_args(const mtfhip_batch *b, const mtfhip_sm_desc *sm, FusedArgs &fa) {
 	fa.grad_eps = b->desc.grad_eps;
 	fa.norm_mult = b->norm_mult; fa.norm_add = b->norm_add;
 	fa.active = nullptr;
-	fa.done = nullptr;
 	{ int nb; fused_decomposition(b->N, b->B, nb, fa.rows_per_block); }
 	switch (sm->sm) {
 	case MTFHIP_SM_FCLK: fa.mode = 0; break;
@@ -630,7 +629,7 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 		b->N <= kIclkTrackMaxPix;
 	FusedArgs fa;
 	if (!one_launch) TRY(fused_args(b, sm, fa));
-	else { fa.materialize = 0; fa.mode = 2; fa.active = nullptr; fa.done = nullptr; fa.rows_per_block = 1; fa.j0_recompute = 0; }
+	else { fa.materialize = 0; fa.mode = 2; fa.active = nullptr; fa.rows_per_block = 1; fa.j0_recompute = 0; }
 	/* active = 1, iters = 0, corners, warps, states, NCC scalars: one pinned async copy of the whole slab
 	 * (w0 is copied along; init_grid consumed it long ago) */
 	HIP_TRY(hipEventSynchronize(b->ev_b));
@@ -647,15 +646,6 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 		TimedScope tsc(b->ctx, "iclk_track");
 		launch_iclk_track(bv, b->ctx->img, *sm, ts, b->d_h0inv, b->d_ncc, b->norm_mult, b->norm_add, st);
 	} else {
-		/* MTFHIP_EPILOGUE=1: one launch per iteration, the workgroup that completes a target's partial rows also runs the
-		 * finish; default: the separate k_finish_track launch (same step time, cleaner kernel timing). */
-		if (b->epilogue && !ncc) {
-			if (!b->d_done) {
-				HIP_TRY(hipMalloc(&b->d_done, sizeof(int) * b->B));
-				HIP_TRY(hipMemsetAsync(b->d_done, 0, sizeof(int) * b->B, st));
-			}
-			fa.done = b->d_done; fa.sm = *sm; fa.ts = ts;
-		}
 		/* Targets are independent, so the loops commute: all iterations of a chunk of targets run before the next chunk
 		 * starts.  A chunk is sized so that what an iteration reads once (J0, I0, grid: 88 B/px for ESM) stays resident in
 		 * the 256 MB Infinity Cache from one iteration to the next -- B = 64 at 200 x 200; larger batches used to fall back
@@ -673,7 +663,6 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 			TrackState tc{ts.acc + (size_t)t0 * RL, ts.h0 + (size_t)t0 * 64, ts.corners + 8 * (size_t)t0,
 				ts.init_corners_hm + 12 * (size_t)t0, ts.active + t0, ts.n_iters + t0, ncc ? ts.ncc + 8 * (size_t)t0 : nullptr,
 				ncc ? ts.ncc_tm + 52 * (size_t)t0 : nullptr};
-			if (fc.done) { fc.done = fa.done + t0; fc.ts = tc; }
 			int nblk_c; { int rows; fused_decomposition(b->N, nt, nblk_c, rows); fc.rows_per_block = rows; }
 			double *part = b->d_partials + (size_t)t0 * b->nblk_max * RL;
 			for (int it = 0; it < sm->max_iters; ++it) {
@@ -681,7 +670,7 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 					TimedScope tsc(b->ctx, "fused_lk");
 					launch_fused_ssd(bc, b->ctx->img, fc, part, nblk_c, st);
 				}
-				if (!b->epilogue || ncc) launch_finish_track(bc, *sm, tc, part, nblk_c, st);
+				launch_finish_track(bc, *sm, tc, part, nblk_c, st);
 			}
 		}
 	}

@@ -63,9 +63,6 @@ struct Tex {
  * are consumed one iteration later, when everything older has long completed; each wave keeps two rows
  * of HBM reads plus one row of writes in flight.
  */
-template <bool COHERENT>
-__device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts,
-	const double *partials, int nblk, int t);
 
 /* AM = MTFHIP_AM_SSD: the residual-weighted sums above.  AM = MTFHIP_AM_NCC: the same pass accumulates the raw moments
  * NCC's similarity, Jacobians and first-order Hessians are functions of (NCC.cc:124-389 restated in ncc_from_moments,
@@ -437,21 +434,7 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 	}
 	if (!live) return;
 	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * ROW_LEN;
-	if (NCC || !fa.done) { block_reduce_store<K>(acc, dst, lds); return; }
-	/* Last-workgroup-done epilogue.  The only data that crosses workgroups inside the launch are the partial rows and
-	 * the arrival counter; both are accessed with agent-scope (sc1) atomics, which are performed at the device
-	 * coherence point, so no L2 write-back / invalidate is needed (a __threadfence() per workgroup flushes the whole
-	 * XCD L2 and doubled the kernel time when tried).  Order: row stores -> vmcnt(0) -> workgroup barrier -> counter. */
-	block_reduce_store<K, true>(acc, dst, lds);
-	__shared__ int s_last;
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	__syncthreads();
-	if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(&fa.done[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1);
-	__syncthreads();
-	if (s_last) {
-		finish_track_body<true>(bv, fa.sm, fa.ts, partials, nblk, t);
-		if (threadIdx.x == 0) __hip_atomic_store(&fa.done[t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	}
+	block_reduce_store<K>(acc, dst, lds);
 }
 template <int SSM, bool CHAINED, int MODE, bool MAT>
 __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchView bv, ImgView im, FusedArgs fa, double *partials, int nblk) {
@@ -476,10 +459,7 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ncc(BatchV
  *   (4) the (inverse) compositional update and the corner-change test on lane 0
  *       (Homography.cc:73-92,109-114, Affine.cc:90-106,145-150, NT/FCLK.cc:314-339). */
 /* Body of the device-side finish, executed by the first wave of the calling workgroup (all threads of the workgroup
- * must call it: it contains workgroup barriers).  COHERENT: the partial rows were written by OTHER workgroups of the
- * same launch (last-workgroup-done epilogue of k_fused_ssd), possibly on another XCD whose L2 is not coherent with
- * ours, so they are read with agent-scope atomic loads instead of plain ones. */
-template <bool COHERENT>
+ * must call it: it contains workgroup barriers). */
 __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts,
 	const double *partials, int nblk, int t) {
 	__shared__ double acc_s[NCC_ACC_COUNT];   /* >= ACC_COUNT */
@@ -512,10 +492,7 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 	}
 	if (lane < RL) {
 		const double *p = partials + (size_t)t * nblk * RL + lane;
-		auto ld = [&](size_t off) -> double {
-			if constexpr (COHERENT) return __hip_atomic_load(p + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			else return p[off];
-		};
+		auto ld = [&](size_t off) -> double { return p[off]; };
 		double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 		int b = 0;
 		for (; b + 3 < nblk; b += 4) {
@@ -680,7 +657,7 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 /* stand-alone finish: one wave per target */
 __global__ __launch_bounds__(128) void k_finish_track(BatchView bv, mtfhip_sm_desc sm, TrackState ts,
 	const double *partials, int nblk) {
-	finish_track_body<false>(bv, sm, ts, partials, nblk, blockIdx.x);
+	finish_track_body(bv, sm, ts, partials, nblk, blockIdx.x);
 }
 
 

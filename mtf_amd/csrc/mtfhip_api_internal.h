@@ -229,7 +229,7 @@ struct mtfhip_batch {
 	int mi_row_len = 0;
 	double mi_hist_norm = 0;
 	size_t cand_capacity = 0;
-	int *d_active = nullptr, *d_iters = nullptr, *d_done = nullptr;
+	int *d_active = nullptr, *d_iters = nullptr;
 	/* The small per-target state lives in ONE device allocation (warps | states | corners | init_corners_hm | ncc | w0 |
 	 * active | iters) mirrored by two pinned staging buffers, so that set_corners and track each move it with a single
 	 * copy (a grid frame used to cost 14 small copies and 4 stream syncs around a 100 us kernel). */
@@ -247,9 +247,6 @@ struct mtfhip_batch {
 	/* NCC: a fused iteration updated the scalars (It_mean, a, b, f) on the host only; the un-fused kernels read d_ncc */
 	bool ncc_host_newer = false;
 	size_t slab_bytes = 0, slab_dbl_bytes = 0;
-	/* last-workgroup-done epilogue instead of the separate k_finish_track launch: measured equal per step (84.3 vs 84.6 us at
-	 * B = 64, 19.6 vs 19.2 us for one target -- the finish's dependent scalar chain is the cost, not the launch), so off */
-	bool epilogue = std::getenv("MTFHIP_EPILOGUE") && std::getenv("MTFHIP_EPILOGUE")[0] == '1';
 	double *h_acc = nullptr; /* pinned */
 	/* Zero-copy read-back of the reduced rows: h_acc is host-coherent pinned memory the reduction kernel writes directly
 	 * (h_acc_dev = its device address) followed by a sequence number in h_flag; the host spins on the flag instead of

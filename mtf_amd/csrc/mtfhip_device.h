@@ -154,7 +154,7 @@ __device__ __forceinline__ constexpr int dup_mask() {
 }
 
 /* reduce K per-thread accumulators over the workgroup and write them to dst[0..K) */
-template <int K, bool COHERENT = false>
+template <int K>
 __device__ __forceinline__ void block_reduce_store(double *v, double *dst, double *lds /* [4][K] */) {
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	wave_halve<K, 32>(v, lane);
@@ -169,9 +169,7 @@ __device__ __forceinline__ void block_reduce_store(double *v, double *dst, doubl
 		double s = lds[threadIdx.x];
 #pragma unroll
 		for (int wv = 1; wv < kBlock / 64; ++wv) s += lds[wv * K + threadIdx.x];
-		/* COHERENT: written through to the device coherence point (sc1), for readers on another XCD in the same launch */
-		if constexpr (COHERENT) __hip_atomic_store(&dst[threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		else dst[threadIdx.x] = s;
+		dst[threadIdx.x] = s;
 	}
 }
 

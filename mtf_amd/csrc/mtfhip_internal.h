@@ -106,11 +106,6 @@ struct FusedArgs {
 	double grad_eps;
 	double norm_mult, norm_add;
 	const int *active; /* optional [B] mask: targets with 0 are skipped (device-side loop) */
-	/* last-workgroup-done epilogue (device-side loop): when `done` is set, the workgroup that completes a target's
-	 * partial rows also runs the finish (sum, solve, compositional update, convergence test) -- no second launch */
-	int *done;         /* [B] arrival counters, all zero between launches; NULL = no epilogue */
-	mtfhip_sm_desc sm;
-	TrackState ts;
 };
 
 /* ---- launchers (all asynchronous on `st`) ---- */
