@@ -707,30 +707,7 @@ int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int C
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "score_candidates before the template was initialised");
 	TRY(need_image(b));
 	TimedScope ts(b->ctx, "score_candidates");
-	/* image tile = bounding box of the template region + a margin for the candidate cloud (PF sigmas are a few pixels) */
-	const TargetHost &h0 = b->th[0];
-	double xmin = h0.init_corners[0], xmax = xmin, ymin = h0.init_corners[1], ymax = ymin;
-	for (int q = 1; q < 4; ++q) {
-		xmin = std::min(xmin, h0.init_corners[2 * q]); xmax = std::max(xmax, h0.init_corners[2 * q]);
-		ymin = std::min(ymin, h0.init_corners[2 * q + 1]); ymax = std::max(ymax, h0.init_corners[2 * q + 1]);
-	}
-	const int margin = 16;
-	const size_t lds_left = 160 * 1024 > (size_t)b->N * 32 ? 160 * 1024 - (size_t)b->N * 32 : 0;
-	int tx0 = (int)std::floor(xmin) - margin, ty0 = (int)std::floor(ymin) - margin;
-	int tw = (int)std::ceil(xmax) + margin + 2 - tx0, th = (int)std::ceil(ymax) + margin + 2 - ty0;
-	bool staged = false;
-	if (b->score_lds && C >= 64 && (size_t)tw * th * 4 <= lds_left) {
-		if ((size_t)C * kScoreUnitsPerCandidate > b->unit_capacity) {
-			if (b->d_units) HIP_TRY(hipFree(b->d_units));
-			b->d_units = nullptr;
-			HIP_TRY(hipMalloc(&b->d_units, sizeof(double) * C * kScoreUnitsPerCandidate));
-			b->unit_capacity = (size_t)C * kScoreUnitsPerCandidate;
-		}
-		staged = launch_score_candidates_lds(b->view(), b->ctx->img, dev_states, C, tx0, ty0, tw, th, b->desc.likelihood_alpha,
-			b->d_units, dev_lik, dev_sim, b->ctx->stream);
-	}
-	if (!staged)
-		launch_score_candidates(b->view(), b->ctx->img, dev_states, C, b->desc.likelihood_alpha, dev_lik, dev_sim, b->ctx->stream);
+	launch_score_candidates(b->view(), b->ctx->img, dev_states, C, b->desc.likelihood_alpha, dev_lik, dev_sim, b->ctx->stream);
 	return MTFHIP_OK;
 }
 

@@ -57,94 +57,6 @@ __global__ __launch_bounds__(kBlock) void k_score_candidates(BatchView bv, ImgVi
 	}
 }
 
-/* LDS-staged candidate scoring.  All candidates of a frame sample the same template through slightly
- * different warps, so a workgroup stages, once, (a) the template's homogeneous grid points and I0 and (b) the
- * image tile that covers the template's bounding box plus a margin, then its 16 waves score CPW candidates
- * each entirely out of LDS: ds_read_b128 / _b64 for the template, two ds_read2_b32 for the four texels.
- * A sample whose bilinear cell is not inside the tile (a far-out candidate) takes the global-memory path;
- * either way the reference's sampling expression is evaluated unchanged (imgUtils.h:91-113). */
-constexpr int kScoreBlock = 1024;
-constexpr int kScoreSplit = 4;      /* a candidate's pixels are cut into this many work units (load balance) */
-template <int SSM>
-__global__ __launch_bounds__(kScoreBlock) void k_score_candidates_lds(BatchView bv, ImgView im, const double *states, int C,
-	int tx0, int ty0, int tw, int th, double norm_mult, double norm_add, double *unit_sums /* [C][kScoreSplit] */) {
-	extern __shared__ __attribute__((aligned(16))) char smem[];
-	const int N = bv.N;
-	double2 *sp = reinterpret_cast<double2 *>(smem);                 /* N grid points (x, y or X, Y) */
-	double *sz = reinterpret_cast<double *>(sp + N);                  /* N third homogeneous coordinates */
-	double *s0 = sz + N;                                              /* N template values */
-	float *tile = reinterpret_cast<float *>(s0 + N);                  /* th x tw texels */
-	const double2 *gp = reinterpret_cast<const double2 *>(bv.buf[bv.unit_z ? MTFHIP_BUF_INIT_PTS : MTFHIP_BUF_INIT_HXY]);
-	const double *gz = bv.buf[MTFHIP_BUF_INIT_Z], *g0 = bv.buf[MTFHIP_BUF_I0];
-	for (int i = threadIdx.x; i < N; i += kScoreBlock) { sp[i] = gp[i]; sz[i] = bv.unit_z ? 1.0 : gz[i]; s0[i] = g0[i]; }
-	for (int i = threadIdx.x; i < tw * th; i += kScoreBlock) {
-		const int yy = ty0 + i / tw, xx = tx0 + i % tw;
-		tile[i] = (yy >= 0 && yy < im.h && xx >= 0 && xx < im.w) ? im.data[(size_t)yy * im.stride + xx] : 0.0f;
-	}
-	__syncthreads();
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const int n_waves = gridDim.x * (kScoreBlock / 64);
-	const double w = (double)(unsigned)im.w, h = (double)(unsigned)im.h;
-	const int chunk = ((N + kScoreSplit - 1) / kScoreSplit + 63) / 64 * 64;   /* pixels per work unit, multiple of 64 */
-	/* work unit u = (candidate, pixel chunk); waves take units round-robin over the whole launch */
-	for (int u = blockIdx.x * (kScoreBlock / 64) + wave; u < C * kScoreSplit; u += n_waves) {
-		const int cand = u / kScoreSplit, part = u % kScoreSplit;
-		const double *p = states + (size_t)cand * bv.S;
-		double W[9];
-		if (SSM == MTFHIP_SSM_HOMOGRAPHY) {
-			W[0] = 1 + p[0]; W[1] = p[1]; W[2] = p[2]; W[3] = p[3]; W[4] = 1 + p[4]; W[5] = p[5]; W[6] = p[6]; W[7] = p[7]; W[8] = 1;
-		} else {
-			W[0] = 1 + p[2]; W[1] = p[3]; W[2] = p[0]; W[3] = p[4]; W[4] = 1 + p[5]; W[5] = p[1]; W[6] = 0; W[7] = 0; W[8] = 1;
-		}
-		double acc = 0.0;
-		const int i_end = min(N, (part + 1) * chunk);
-		for (int i = part * chunk + lane; i < i_end; i += 64) {
-			const double2 hp = sp[i];
-			const double z = sz[i];
-			double x, y;
-			if (SSM == MTFHIP_SSM_HOMOGRAPHY) {
-				const double cx = W[0] * hp.x + W[1] * hp.y + W[2] * z, cy = W[3] * hp.x + W[4] * hp.y + W[5] * z;
-				const double d = W[6] * hp.x + W[7] * hp.y + W[8] * z;
-				x = cx / d; y = cy / d;
-			} else {
-				x = W[0] * hp.x + W[1] * hp.y + W[2] * z; y = W[3] * hp.x + W[4] * hp.y + W[5] * z;
-			}
-			double v = 128.0;
-			if (!((x < 0) || (x >= w) || (y < 0) || (y >= h))) {
-				const int lx = (int)x, ly = (int)y;
-				const double dx = x - lx, dy = y - ly;
-				const int ux = dx == 0 ? lx : lx + 1, uy = dy == 0 ? ly : ly + 1;
-				if (ux < im.w && uy < im.h) {
-					double t00, t01, t10, t11;
-					if (lx >= tx0 && ux < tx0 + tw && ly >= ty0 && uy < ty0 + th) {
-						const float *r0 = tile + (ly - ty0) * tw + (lx - tx0), *r1 = tile + (uy - ty0) * tw + (lx - tx0);
-						t00 = r0[0]; t01 = r0[ux - lx]; t10 = r1[0]; t11 = r1[ux - lx];
-					} else {
-						const float *r0 = im.data + (size_t)ly * im.stride, *r1 = im.data + (size_t)uy * im.stride;
-						t00 = r0[lx]; t01 = r0[ux]; t10 = r1[lx]; t11 = r1[ux];
-					}
-					v = t00 * (1 - dx) * (1 - dy) + t01 * dx * (1 - dy) + t10 * (1 - dx) * dy + t11 * dx * dy;
-				}
-			}
-			const double r = (norm_mult * v + norm_add) - s0[i];
-			acc = fma(r, r, acc);
-		}
-#pragma unroll
-		for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
-		if (lane == 0) unit_sums[u] = acc;
-	}
-}
-/* fixed-order sum of a candidate's work units, then f = -|r|^2/2 and the SSD likelihood (SSD.h:41-43) */
-__global__ __launch_bounds__(kBlock) void k_score_finish(const double *unit_sums, int C, int N, double alpha, double *lik, double *sim) {
-	const int c = blockIdx.x * kBlock + threadIdx.x;
-	if (c >= C) return;
-	double s = 0;
-#pragma unroll
-	for (int q = 0; q < kScoreSplit; ++q) s += unit_sums[(size_t)c * kScoreSplit + q];
-	const double f = -s / 2;
-	if (sim) sim[c] = f;
-	if (lik) lik[c] = exp(-alpha * sqrt(-f / (double)N));
-}
 
 
 /* ===================================================================== */
@@ -423,30 +335,6 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 /* launchers                                                              */
 /* ===================================================================== */
 
-/* LDS-staged scorer: returns false (nothing launched) when template + tile do not fit the 160 KB of a CU */
-bool launch_score_candidates_lds(const BatchView &bv, const ImgView &im, const double *dev_states, int C, int tx0, int ty0,
-	int tw, int th, double likelihood_alpha, double *unit_sums, double *dev_lik, double *dev_sim, hipStream_t st) {
-	const size_t lds = (size_t)bv.N * (16 + 8 + 8) + (size_t)tw * th * 4;
-	if (lds > 160 * 1024 || tw <= 1 || th <= 1) return false;
-	static bool attr_set = false;
-	if (!attr_set) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_candidates_lds<MTFHIP_SSM_HOMOGRAPHY>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_candidates_lds<MTFHIP_SSM_AFFINE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		attr_set = true;
-	}
-	/* one workgroup per CU (the staged template + tile take most of its LDS); work units are dealt round-robin */
-	const int units = C * kScoreSplit, waves = kScoreBlock / 64;
-	int nb = (units + waves - 1) / waves;
-	if (nb > 256) nb = 256;
-	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY)
-		hipLaunchKernelGGL(k_score_candidates_lds<MTFHIP_SSM_HOMOGRAPHY>, dim3(nb), dim3(kScoreBlock), lds, st, bv, im, dev_states, C,
-			tx0, ty0, tw, th, 1.0, 0.0, unit_sums);
-	else
-		hipLaunchKernelGGL(k_score_candidates_lds<MTFHIP_SSM_AFFINE>, dim3(nb), dim3(kScoreBlock), lds, st, bv, im, dev_states, C,
-			tx0, ty0, tw, th, 1.0, 0.0, unit_sums);
-	hipLaunchKernelGGL(k_score_finish, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, st, unit_sums, C, bv.N, likelihood_alpha, dev_lik, dev_sim);
-	return true;
-}
 void launch_score_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C,
 	double likelihood_alpha, double *dev_lik, double *dev_sim, hipStream_t st) {
 	int nb = (C + (kBlock / 64) - 1) / (kBlock / 64);

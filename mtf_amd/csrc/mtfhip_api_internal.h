@@ -213,7 +213,6 @@ struct mtfhip_batch {
 	double *d_mi_tb = nullptr, *d_mi_part = nullptr, *d_mi_f = nullptr, *d_mi_H = nullptr;
 	double *d_mi_red = nullptr;   /* [B][mi_row_len] block rows summed (the Hessian assembly then reads one row per target) */
 	double *d_h0inv = nullptr; /* [B][64] inverse of the constant Hessian (one-launch ICLK) */
-	double *d_units = nullptr; /* per-work-unit partial sums of the LDS-staged candidate scorer */
 	double *d_d2_part = nullptr, *d_d2_out = nullptr, *d_d2_w = nullptr; /* second-order term: block rows, [B][64] sums, MI self weights */
 	double hess_eps = 1.0;
 	bool init_pix_hess = false;
@@ -225,7 +224,6 @@ struct mtfhip_batch {
 	std::vector<double> template_corners;   /* [B][8] corners the stored J0 was computed on */
 	bool j0_recompute_enabled = !(std::getenv("MTFHIP_J0_RECOMPUTE") && std::getenv("MTFHIP_J0_RECOMPUTE")[0] == '0');
 	int d0_variant = MTFHIP_JAC_WARPED; /* how the template's pixel Hessian was formed (fused second-order path) */
-	size_t unit_capacity = 0;
 	int mi_row_len = 0;
 	double mi_hist_norm = 0;
 	size_t cand_capacity = 0;
@@ -256,10 +254,6 @@ struct mtfhip_batch {
 	int *d_fin_count = nullptr;
 	int nblk_max;
 	int unit_z = 1;
-	/* The LDS-staged candidate scorer (template + image tile in LDS) measured 10 % SLOWER than the plain one
-	 * (116 vs 105 us for 10 000 x 2 500 samples): the kernel is bound by FP64 VALU work (two IEEE divisions per
-	 * sample), not by the gather path.  It stays selectable for A/B runs. */
-	bool score_lds = std::getenv("MTFHIP_SCORE_LDS") != nullptr;
 	bool have_corners = false, init_pix_vals = false, init_pix_grad = false, init_sim = false, init_grad = false;
 	bool it_valid = false, dit_valid = false, jt_valid = false;
 	std::vector<TargetHost> th;
