@@ -349,8 +349,8 @@ def main():
     ap.add_argument("--particles", type=int, default=10000)
     ap.add_argument("--grid-iters", type=int, default=10)
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--targets", type=int, default=64, help="targets per GPU (each 200x200)")
     ap.add_argument("--res", type=int, default=200)
     ap.add_argument("--sm", default="esm", choices=["esm", "fclk", "iclk"])
