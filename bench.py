@@ -183,18 +183,31 @@ def secondary_workload(args):
            "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
 
     def timed(fn):
+        import gc
         for _ in range(args.warmup):
             fn()
         torch.cuda.synchronize(dev)
+        # these workloads loop in Python: a generation-2 collection over torch's ~10^6 live objects is a 30-40 ms pause
+        # (seen as one outlier step in 200), so the collector is parked for the timed region
+        gc.collect(); gc.disable()
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            fn()
+        if os.environ.get("BENCH_STEP_TIMES"):   # debugging aid: distribution of the per-step wall times
+            ts = []
+            for _ in range(args.steps):
+                t1 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t1)
+            ts = np.array(ts) * 1e6
+            print("step times us: median %.0f p95 %.0f max %.0f, first 5 %s, last 5 %s" % (np.median(ts), np.percentile(ts, 95), ts.max(),
+                  np.round(ts[:5]), np.round(ts[-5:])), file=sys.stderr)
+        else:
+            for _ in range(args.steps):
+                fn()
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
         dt = time.perf_counter() - t0
+        gc.enable()
         if dist is not None:
             tm = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
