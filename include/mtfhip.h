@@ -226,6 +226,10 @@ int mtfhip_am_cmpt_self_hessian2(mtfhip_batch *b, int jt_buf, int d2_buf, double
 int mtfhip_am_cmpt_sum_of_hessians2(mtfhip_batch *b, int j0_buf, int jt_buf, int d2_0_buf, int d2_t_buf, double *H); /* SSDBase.cc:377-415 */
 
 /* ---- fused path: one launch per LK iteration for all targets of the batch ----
+ * Appearance models: SSD (k_fused_ssd), NCC (k_fused_ncc: one pass over raw moments, every first-order Hessian type) and
+ * MI with 8 bins (four pixel-level launches; the self-type Hessians, ESM's DiffOfJacs; iterate only).  Anything outside
+ * returns MTFHIP_ERR_NOT_IMPLEMENTED and belongs to the per-function entry points above -- which defer and fuse the same
+ * way internally when the call sequence is one of the search methods' ("Deferred fusion").
  * init_template = the body of nt::{ESM,FCLK,ICLK}::initialize after ssm->initialize
  * (NT/ESM.cc:110-146, NT/FCLK.cc:102-169, NT/ICLK.cc:71-128): I0, dI0_dx, J0 and the constant
  * Hessian from the current image at the current points. */
@@ -247,7 +251,8 @@ int mtfhip_batch_track_targets_per_launch(mtfhip_batch *b, const mtfhip_sm_desc 
 
 /* ---- candidate scoring (PF / NN batch axis): target 0's template, C warps ----
  * per candidate: setState -> updatePixVals -> updateSimilarity(false) -> getLikelihood
- * (SM/src/PF.cc:247-262).  The *_dev form takes and fills device pointers (for RCCL). */
+ * (SM/src/PF.cc:247-262), SSD (SSD.h:41-43) and NCC (NCC.cc:50-53, 124-161; the candidate's scalars from its raw
+ * moments).  The *_dev form takes and fills device pointers (for RCCL). */
 int mtfhip_score_candidates(mtfhip_batch *b, const double *states /* C x S */, int n_candidates,
 	double *likelihoods /* C or NULL */, double *similarities /* C or NULL */);
 int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int n_candidates,

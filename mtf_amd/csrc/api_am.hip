@@ -104,7 +104,7 @@ int mtfhip_am_update_pix_grad_warped(mtfhip_batch *b, const double *gp) {
 
 
 /* ------------------------------------------------------------------ NCC (AM/src/NCC.cc) */
-static int push_ncc(mtfhip_batch *b) {
+int push_ncc(mtfhip_batch *b) {
 	std::vector<double> s(8 * (size_t)b->B, 0.0);
 	for (int t = 0; t < b->B; ++t) {
 		const TargetHost &h = b->th[t];

@@ -702,12 +702,18 @@ int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int C
 	FLUSH(b);
 	if (!b || !dev_states) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: NULL argument");
 	if (C <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: n_candidates must be positive");
-	if (b->desc.am != MTFHIP_AM_SSD) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "score_candidates: SSD only");
+	if (b->desc.am == MTFHIP_AM_MI) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "score_candidates: SSD and NCC");
 	TRY(single_channel(b, "score_candidates"));
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "score_candidates before the template was initialised");
 	TRY(need_image(b));
 	TimedScope ts(b->ctx, "score_candidates");
-	launch_score_candidates(b->view(), b->ctx->img, dev_states, C, b->desc.likelihood_alpha, dev_lik, dev_sim, b->ctx->stream);
+	const double *ncc_sc = nullptr;
+	if (b->desc.am == MTFHIP_AM_NCC) {   /* mean(I0), |I0 - mean| of the template, as the un-fused NCC kernels read them */
+		if (!b->init_sim) return fail(MTFHIP_ERR_LOGIC, "score_candidates before initializeSimilarity");
+		TRY(push_ncc(b));
+		ncc_sc = b->d_ncc;
+	}
+	launch_score_candidates(b->view(), b->ctx->img, dev_states, C, b->desc.likelihood_alpha, ncc_sc, dev_lik, dev_sim, b->ctx->stream);
 	return MTFHIP_OK;
 }
 

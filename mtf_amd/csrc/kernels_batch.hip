@@ -11,8 +11,11 @@ namespace mtfhip {
 /* ===================================================================== */
 /* One wave64 per candidate: setState -> updatePixVals -> updateSimilarity -> likelihood
  * (SM/src/PF.cc:247-262, ProjectiveBase.cc:41-49, SSDBase.cc:75-96, SSD.h:41-43). */
+/* ncc_sc: NULL for SSD; for NCC the template's scalars ([0] mean(I0), [1] |I0 - mean|): the candidate's similarity is
+ * a / (b c) from the raw moments sum It, sum It^2, sum I0 It of its own samples (NCC.cc:124-161), its likelihood
+ * exp(-alpha (1/f - 1)^2) (NCC.cc:50-53) */
 __global__ __launch_bounds__(kBlock) void k_score_candidates(BatchView bv, ImgView im, const double *states, int C,
-	double alpha, double norm_mult, double norm_add, double *lik, double *sim) {
+	double alpha, double norm_mult, double norm_add, const double *ncc_sc, double *lik, double *sim) {
 	const int lane = threadIdx.x & 63;
 	const int cand = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 	if (cand >= C) return;
@@ -30,7 +33,7 @@ __global__ __launch_bounds__(kBlock) void k_score_candidates(BatchView bv, ImgVi
 	const double *iz = bv.buf[MTFHIP_BUF_INIT_Z];
 	const double2 *ih = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]);
 	const double *I0 = bv.buf[MTFHIP_BUF_I0];
-	double acc = 0.0;
+	double acc = 0.0, s_it = 0.0, s_i0it = 0.0;
 	for (int i = lane; i < N; i += 64) {
 		double2 q = bv.unit_z ? ip[i] : ih[i];
 		double z = bv.unit_z ? 1.0 : iz[i];
@@ -45,15 +48,23 @@ __global__ __launch_bounds__(kBlock) void k_score_candidates(BatchView bv, ImgVi
 			wx = W[0] * hx + W[1] * hy + W[2] * z;
 			wy = W[3] * hx + W[4] * hy + W[5] * z;
 		}
-		double r = (norm_mult * pix_val(im, wx, wy) + norm_add) - I0[i];
-		acc = fma(r, r, acc);
+		const double it = norm_mult * pix_val(im, wx, wy) + norm_add, i0 = I0[i];
+		if (ncc_sc) { s_it += it; acc = fma(it, it, acc); s_i0it = fma(i0, it, s_i0it); }
+		else { const double r = it - i0; acc = fma(r, r, acc); }
 	}
 #pragma unroll
-	for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+	for (int m = 32; m >= 1; m >>= 1) { acc += __shfl_xor(acc, m); s_it += __shfl_xor(s_it, m); s_i0it += __shfl_xor(s_i0it, m); }
 	if (lane == 0) {
-		double f = -acc / 2;
-		if (sim) sim[cand] = f;
-		if (lik) lik[cand] = exp(-alpha * sqrt(-f / (double)N));
+		if (ncc_sc) {
+			const double n = (double)N, m0 = ncc_sc[0], c = ncc_sc[1], mt = s_it / n;
+			const double f = (s_i0it - n * m0 * mt) / (sqrt(acc - n * mt * mt) * c);
+			if (sim) sim[cand] = f;
+			if (lik) { const double d = (1.0 / f) - 1; lik[cand] = exp(-alpha * d * d); }
+		} else {
+			double f = -acc / 2;
+			if (sim) sim[cand] = f;
+			if (lik) lik[cand] = exp(-alpha * sqrt(-f / (double)N));
+		}
 	}
 }
 
@@ -336,10 +347,10 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 /* ===================================================================== */
 
 void launch_score_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C,
-	double likelihood_alpha, double *dev_lik, double *dev_sim, hipStream_t st) {
+	double likelihood_alpha, const double *ncc_sc, double *dev_lik, double *dev_sim, hipStream_t st) {
 	int nb = (C + (kBlock / 64) - 1) / (kBlock / 64);
 	hipLaunchKernelGGL(k_score_candidates, dim3(nb), dim3(kBlock), 0, st, bv, im, dev_states, C, likelihood_alpha,
-		1.0, 0.0, dev_lik, dev_sim);
+		1.0, 0.0, ncc_sc, dev_lik, dev_sim);
 }
 
 template <int AM>

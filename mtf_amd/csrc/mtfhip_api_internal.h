@@ -446,5 +446,6 @@ int ncc_lazy_outputs(mtfhip_batch *b, int trig, int j_a, bool hess_mean, double 
 int ncc_hessian_from_cache(mtfhip_batch *b, int j_buf, int kind, double *H);
 int fused_args(const mtfhip_batch *b, const mtfhip_sm_desc *sm, FusedArgs &fa);
 int mi_blocks(const mtfhip_batch *b);
+int push_ncc(mtfhip_batch *b);
 } /* extern "C" */
 #endif

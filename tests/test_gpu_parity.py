@@ -335,10 +335,11 @@ def _device_loop(oracle, gpu_ctx, frame, sm_kind, ssm, am, res, extra):
     assert np.array_equal(n_it2, n_it)
 
 
-def test_pf_candidate_scores(oracle, gpu_ctx, frame):
+@pytest.mark.parametrize("am", [L.AM_SSD, L.AM_NCC])
+def test_pf_candidate_scores(oracle, gpu_ctx, frame, am):
     rng = np.random.default_rng(31)
     corners = synth.square_corners(256, 256, 100)
-    o_am, o_ssm, b = make_pair(oracle, gpu_ctx, frame, L.AM_SSD, L.SSM_HOMOGRAPHY, 50, corners)
+    o_am, o_ssm, b = make_pair(oracle, gpu_ctx, frame, am, L.SSM_HOMOGRAPHY, 50, corners)
     pts0 = o_ssm.get("curr_pts")
     o_am.initialize_pix_vals(pts0); o_am.initialize_similarity()
     b.initialize_pix_vals(); b.initialize_similarity()
