@@ -346,13 +346,13 @@ class GridTracker:
 
 
 class ParticleFilter:
-    """PF + SSD + Homography/Affine (SM/src/PF.cc): dynamic model RandomWalk, update type Compositional,
+    """PF + SSD or NCC + Homography/Affine (SM/src/PF.cc): dynamic model RandomWalk, update type Compositional,
     likelihood function AM, resampling BinaryMultinomial, mean type None (highest weight) or Corners."""
 
     def __init__(self, ctx, ssm=L.SSM_HOMOGRAPHY, resx=50, resy=50, n_particles=500,
                  ssm_sigma=(0.01, 0.01, 2.0, 0.01, 0.01, 2.0, 1e-5, 1e-5), likelihood_alpha=1.0,
-                 max_iters=1, epsilon=0.01, seed=0, scorer=None):
-        self.batch = Batch(ctx, L.AM_SSD, ssm, resx, resy, 1, likelihood_alpha=likelihood_alpha)
+                 max_iters=1, epsilon=0.01, seed=0, scorer=None, am=L.AM_SSD):
+        self.batch = Batch(ctx, am, ssm, resx, resy, 1, likelihood_alpha=likelihood_alpha)
         self.S = self.batch.S
         self.n = n_particles
         self.sigma = np.asarray(ssm_sigma, dtype=np.float64)[: self.S]

@@ -58,14 +58,15 @@ def test_lm_host_loop_matches_oracle(oracle, gpu_ctx, frame):
         assert np.abs(out[0] - gt_corners(corners, p_true, centre)).max() < 0.1
 
 
-def test_particle_filter_follows_translation(gpu_ctx, frame):
+@pytest.mark.parametrize("am,alpha", [(L.AM_SSD, 5.0), (L.AM_NCC, 2000.0)])
+def test_particle_filter_follows_translation(gpu_ctx, frame, am, alpha):
     centre = (256.0, 250.0)
     corners = synth.square_corners(centre[0], centre[1], 80)
     p_true = np.array([0, 0, 3.0, 0, 0, -2.0, 0, 0])
     frame2 = synth.warp_frame(frame, p_true, centre)
     gpu_ctx.set_image(frame)
     pf = ParticleFilter(gpu_ctx, L.SSM_HOMOGRAPHY, 40, 40, n_particles=4000, max_iters=4, epsilon=1e-9, seed=3,
-                        ssm_sigma=(0.002, 0.002, 1.5, 0.002, 0.002, 1.5, 1e-6, 1e-6), likelihood_alpha=5.0)
+                        ssm_sigma=(0.002, 0.002, 1.5, 0.002, 0.002, 1.5, 1e-6, 1e-6), likelihood_alpha=alpha, am=am)
     pf.initialize(corners[None])
     gpu_ctx.set_image(frame2)
     out = pf.update()
