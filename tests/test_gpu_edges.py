@@ -15,6 +15,38 @@ def rel(a, b):
     return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
 
 
+@pytest.mark.parametrize("resx,resy", [(5, 7), (7, 9), (16, 17), (33, 31)])
+@pytest.mark.parametrize("sm_kind", [L.SM_ESM, L.SM_FCLK, L.SM_ICLK])
+@pytest.mark.parametrize("am", [L.AM_NCC, L.AM_MI])
+def test_ragged_patches_ncc_mi(oracle, gpu_ctx, frame, frame2, resx, resy, sm_kind, am):
+    """The same sizes through the fused NCC kernel (72-wide rows, partial last row) and the fused MI iteration (64-pixel
+    chunks of the histogram / Hessian kernels with a ragged tail, MFMA bin mode): first iteration against the oracle on
+    the oracle's own sample grid, so only summation order differs."""
+    corners = synth.square_corners(250, 244, 40)
+    o_ssm = oracle.SSM(L.SSM_AFFINE, resx, resy); o_am = oracle.AM(am, resx, resy); o_am.set_curr_img(frame)
+    trk = oracle.Tracker(sm_kind, o_am, o_ssm, leven_marq=0, max_iters=1, epsilon=-1.0)
+    trk.initialize(corners)
+    o_am.set_curr_img(frame2)
+    trk.update()
+    rec = trk.trace()[0]
+    gpu_ctx.set_image(frame)
+    b = mtf_amd.Batch(gpu_ctx, am, L.SSM_AFFINE, resx, resy, 1)
+    b.set_corners(corners[None])
+    hm = o_ssm.get("init_pts_hm").reshape(-1, 3)
+    b.write(L.BUF_INIT_PTS, o_ssm.get("init_pts").reshape(1, -1, 2).transpose(0, 2, 1))
+    b.write(L.BUF_INIT_HXY, hm[:, :2].T[None])
+    b.write(L.BUF_INIT_Z, hm[:, 2][None])
+    b.set_state(np.zeros((1, b.S)))
+    sm = mtf_amd.sm_desc(sm_kind, materialize=1, leven_marq=0)
+    b.init_template(sm)
+    gpu_ctx.set_image(frame2)
+    f, g, H = b.iterate(sm)
+    assert abs(f[0] - rec["f"]) <= 1e-9 * abs(rec["f"]) + 1e-12
+    assert rel(H[0], rec["H"]) < 1e-8
+    assert np.linalg.norm(g[0] - rec["g"]) <= 1e-8 * max(np.linalg.norm(rec["g"]), np.sqrt(abs(np.trace(rec["H"]))) * 1e-3)
+    b.close()
+
+
 @pytest.mark.parametrize("resx,resy", [(2, 2), (2, 3), (7, 9), (16, 17), (33, 31)])
 @pytest.mark.parametrize("sm_kind", [L.SM_ESM, L.SM_FCLK, L.SM_ICLK])
 def test_tiny_and_ragged_patches(oracle, gpu_ctx, frame, frame2, resx, resy, sm_kind):
