@@ -122,6 +122,36 @@ NT_CASES = [
 ]
 
 
+@pytest.mark.parametrize("n_bins", [5, 12, 16])
+@pytest.mark.parametrize("sm_kind,extra", [(L.SM_ESM, dict()), (L.SM_ESM, dict(hess_type=4, jac_type=0)), (L.SM_FCLK, dict(hess_type=2)),
+                                           (L.SM_ICLK, dict()), (L.SM_ESM, dict(sec_ord_hess=1))],
+                         ids=["esm", "esm_sumofstd_original", "fclk_std", "iclk", "esm_second_order"])
+def test_mi_histogram_sizes(oracle, gpu_ctx, frame, n_bins, sm_kind, extra):
+    """MI with other histogram sizes than the reference's default 8 (mi_n_bins of the patch descriptor; MI.cc:14-15,97-104):
+    the VALU bin mode (the FP64 MFMA tiles cover 8 bins), 16 bins = the widest rows, an odd count = ragged bin pairs."""
+    rng = np.random.default_rng(31)
+    res, centre = 36, (250.0, 262.0)
+    corners = synth.square_corners(centre[0], centre[1], 60.0)
+    frame2 = synth.warp_frame(frame, synth.random_small_homography(rng, 0.3), centre)
+    params = dict(leven_marq=0, max_iters=3, epsilon=-1.0)
+    params.update(extra)
+    o_ssm = oracle.SSM(L.SSM_HOMOGRAPHY, res, res); o_am = oracle.AM(L.AM_MI, res, res, n_bins=n_bins); o_am.set_curr_img(frame)
+    otrk = oracle.Tracker(sm_kind, o_am, o_ssm, **params)
+    otrk.initialize(corners)
+    gpu_ctx.set_image(frame)
+    nt = NTSearchMethod(gpu_ctx, sm_kind, L.AM_MI, L.SSM_HOMOGRAPHY, res, res, 1, am_params=dict(mi_n_bins=n_bins), **params)
+    nt.initialize(corners[None])
+    o_am.set_curr_img(frame2); gpu_ctx.set_image(frame2)
+    otrk.update(); nt.update()
+    rec, got = otrk.trace()[0], nt.trace[0]
+    assert abs(got["f"][0] - rec["f"]) <= 1e-7 * abs(rec["f"])
+    assert np.linalg.norm(got["H"][0] - rec["H"]) <= 1e-5 * np.linalg.norm(rec["H"])
+    gs = max(np.linalg.norm(rec["g"]), 1e-3 * np.sqrt(abs(np.trace(rec["H"]))))
+    assert np.linalg.norm(got["g"][0] - rec["g"]) <= 1e-4 * gs
+    if not extra.get("sec_ord_hess"):
+        np.testing.assert_allclose(nt.get_region()[0], otrk.get_region(), atol=2e-4)
+
+
 def oracle_first_order_H(oracle, case, frame, frame2, corners):
     """H of the first iteration with sec_ord_hess = 0 (to show that the second-order term is not vacuous)"""
     sm_kind, am, ssm, res, extra = case
