@@ -320,8 +320,8 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 	if (r) return cleanup(r);
 	{
 		const char *lazy_env = std::getenv("MTFHIP_LAZY");
-		/* SSD and NCC have a fused kernel each; MI has the fused passes of its 8-bin form */
-		b->lz.enabled = (d->am == MTFHIP_AM_SSD || d->am == MTFHIP_AM_NCC || (d->am == MTFHIP_AM_MI && d->mi_n_bins == 8)) && b->C == 1 &&
+		/* SSD and NCC have a fused kernel each; MI has its fused passes */
+		b->lz.enabled = (d->am == MTFHIP_AM_SSD || d->am == MTFHIP_AM_NCC || d->am == MTFHIP_AM_MI) && b->C == 1 &&
 			!(lazy_env && lazy_env[0] == '0');
 	}
 	c->batches.push_back(b);

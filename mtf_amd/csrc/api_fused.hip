@@ -19,10 +19,10 @@ static int check_sm(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const char 
 		return MTFHIP_OK;
 	}
 	if (b->desc.am == MTFHIP_AM_MI) {
-		/* fused MI iteration: the class-default (self-type) Hessians of the three search methods, 8-bin histograms */
+		/* fused MI iteration: the class-default (self-type) Hessians of the three search methods */
 		const bool ht_ok = sm->sm == MTFHIP_SM_ESM ? sm->hess_type <= 2 : (sm->sm == MTFHIP_SM_FCLK ? sm->hess_type <= 1 : sm->hess_type == 0);
-		if (b->desc.mi_n_bins != 8 || sm->sec_ord_hess || !ht_ok || (sm->sm == MTFHIP_SM_ESM && sm->jac_type == 0))
-			return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: the fused MI iteration covers 8 bins, first order, the self-type Hessians and ESM's DiffOfJacs; use the per-function entry points", fn);
+		if (sm->sec_ord_hess || !ht_ok || (sm->sm == MTFHIP_SM_ESM && sm->jac_type == 0))
+			return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: the fused MI iteration covers first order, the self-type Hessians and ESM's DiffOfJacs; use the per-function entry points", fn);
 		return MTFHIP_OK;
 	}
 	if (b->desc.am != MTFHIP_AM_SSD) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: unknown appearance model", fn);

@@ -150,6 +150,19 @@ def test_mi_histogram_sizes(oracle, gpu_ctx, frame, n_bins, sm_kind, extra):
     assert np.linalg.norm(got["g"][0] - rec["g"]) <= 1e-4 * gs
     if not extra.get("sec_ord_hess"):
         np.testing.assert_allclose(nt.get_region()[0], otrk.get_region(), atol=2e-4)
+    if not extra:
+        # the fused MI iteration (mtfhip_batch_iterate) at the same histogram size
+        gpu_ctx.set_image(frame)
+        b = mtf_amd.Batch(gpu_ctx, L.AM_MI, L.SSM_HOMOGRAPHY, res, res, 1, mi_n_bins=n_bins)
+        b.set_corners(corners[None])
+        sm = mtf_amd.sm_desc(sm_kind, **params)
+        b.init_template(sm)
+        gpu_ctx.set_image(frame2)
+        f, g, H = b.iterate(sm)
+        assert abs(f[0] - rec["f"]) <= 1e-7 * abs(rec["f"])
+        assert np.linalg.norm(H[0] - rec["H"]) <= 1e-5 * np.linalg.norm(rec["H"])
+        assert np.linalg.norm(g[0] - rec["g"]) <= 1e-4 * gs
+        b.close()
 
 
 def oracle_first_order_H(oracle, case, frame, frame2, corners):
