@@ -19,10 +19,9 @@ static int check_sm(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const char 
 		return MTFHIP_OK;
 	}
 	if (b->desc.am == MTFHIP_AM_MI) {
-		/* fused MI iteration: the class-default (self-type) Hessians of the three search methods */
-		const bool ht_ok = sm->sm == MTFHIP_SM_ESM ? sm->hess_type <= 2 : (sm->sm == MTFHIP_SM_FCLK ? sm->hess_type <= 1 : sm->hess_type == 0);
-		if (sm->sec_ord_hess || !ht_ok || (sm->sm == MTFHIP_SM_ESM && sm->jac_type == 0))
-			return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: the fused MI iteration covers first order, the self-type Hessians and ESM's DiffOfJacs; use the per-function entry points", fn);
+		/* fused MI iteration: every first-order Jacobian / Hessian type of the three search methods */
+		if (sm->sec_ord_hess)
+			return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: second-order MI Hessians go through the per-function entry points", fn);
 		return MTFHIP_OK;
 	}
 	if (b->desc.am != MTFHIP_AM_SSD) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: unknown appearance model", fn);
@@ -464,11 +463,21 @@ static void assemble(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const doub
 static int mi_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, double *g, double *H) {
 	const int nb = b->desc.mi_n_bins, S = b->S, nblk = mi_blocks(b);
 	hipStream_t st = b->ctx->stream;
-	const bool iclk = sm->sm == MTFHIP_SM_ICLK;
-	const bool self = !iclk && sm->hess_type != 0;   /* CurrentSelf / SumOfSelf: cmptSelfHessian(Jt) */
+	const bool iclk = sm->sm == MTFHIP_SM_ICLK, esm = sm->sm == MTFHIP_SM_ESM, fclk = sm->sm == MTFHIP_SM_FCLK;
+	/* which AM Hessian the search method asks for (NT/ESM.cc:315-377, NT/FCLK.cc:262-283, NT/ICLK.cc:204-252) */
+	enum { H_CONST, H_SELF_JT, H_CURR_JT, H_CURR_JM, H_SUM_STD, H_INIT_J0 };
+	const int ht = sm->hess_type;
+	const int hk = ht == 0 ? H_CONST
+		: esm ? (ht <= 2 ? H_SELF_JT : (ht == 3 ? H_CURR_JM : (ht == 4 ? H_SUM_STD : H_CURR_JT)))
+		: fclk ? (ht == 1 ? H_SELF_JT : H_CURR_JT)
+		: (ht == 1 ? H_SELF_JT : H_INIT_J0);
+	const bool self = hk == H_SELF_JT;                /* cmptSelfHessian(Jt): the self histogram rides along with pass 1 */
+	const bool need_jt = !iclk || self;               /* ICLK's CurrentSelf refreshes the current pixel Jacobian (NT/ICLK.cc:215-237) */
+	const bool orig_jac = esm && sm->jac_type == 0;   /* cmptCurrJacobian(mean Jacobian) */
+	const bool need_mean = orig_jac || hk == H_CURR_JM;
 	/* 0 */
 	mtfhip_sm_desc s0 = *sm;
-	s0.sm = iclk ? MTFHIP_SM_ICLK : MTFHIP_SM_FCLK; s0.hess_type = iclk ? 0 : 1; s0.materialize = 1; s0.sec_ord_hess = 0;
+	s0.sm = need_jt ? MTFHIP_SM_FCLK : MTFHIP_SM_ICLK; s0.hess_type = need_jt ? 1 : 0; s0.materialize = 1; s0.sec_ord_hess = 0;
 	FusedArgs fa;
 	TRY(fused_args(b, &s0, fa));
 	{
@@ -476,7 +485,12 @@ static int mi_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, doub
 		launch_fused_ssd(b->view(), b->ctx->img, fa, b->d_partials, fused_blocks_per_target(b->N, b->B), st);
 	}
 	b->it_valid = true;
-	b->dit_valid = b->jt_valid = !iclk;
+	b->dit_valid = b->jt_valid = need_jt;
+	if (need_mean) {
+		TRY(ensure_buf(b, MTFHIP_BUF_JM));
+		TimedScope ts(b->ctx, "mean_jacobian");
+		launch_mean_jacobian(b->view(), st);
+	}
 	/* 1 */
 	const double *It = b->buf[MTFHIP_BUF_IT], *I0 = b->buf[MTFHIP_BUF_I0];
 	{
@@ -486,22 +500,37 @@ static int mi_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, doub
 		launch_mi_tables_iter(b->view(), nb, b->desc.mi_pre_seed, b->mi_hist_norm, self ? 1 : 0, b->d_mi_part, nblk, b->mi_row_len, b->d_mi_tb,
 			b->d_mi_f, st);
 	}
-	/* 2, 3 */
+	/* 2 */
 	double *d_g = b->d_mi_H + 64 * (size_t)b->B;
 	{
 		TimedScope ts(b->ctx, "mi_grad");
 		const int ng = simple_blocks_per_target(b->N) < 64 ? simple_blocks_per_target(b->N) : 64;
-		launch_mi_grad_gemv(b->view(), nb, b->mi_hist_norm, It, I0, b->d_mi_tb, iclk ? nullptr : b->buf[MTFHIP_BUF_JT],
-			sm->sm == MTFHIP_SM_FCLK ? nullptr : b->buf[MTFHIP_BUF_J0], sm->materialize ? b->buf[MTFHIP_BUF_DF_DIT] : nullptr,
+		launch_mi_grad_gemv(b->view(), nb, b->mi_hist_norm, It, I0, b->d_mi_tb,
+			iclk ? nullptr : b->buf[orig_jac ? MTFHIP_BUF_JM : MTFHIP_BUF_JT],
+			(fclk || orig_jac) ? nullptr : b->buf[MTFHIP_BUF_J0], sm->materialize ? b->buf[MTFHIP_BUF_DF_DIT] : nullptr,
 			sm->materialize ? b->buf[MTFHIP_BUF_DF_DI0] : nullptr, b->d_partials, ng, st);
 		launch_finish_rows(b->d_partials, ng, 16, d_g, b->B, st);
 	}
-	if (self) {
+	/* 3: kind 0 init (MI.cc:461-513), 1 curr (:603-637), 2 self (:515-601), as mi_hessian in api_am.hip */
+	auto hess_pass = [&](int kind, int j_buf) {
+		const double *A = b->buf[kind == 0 ? MTFHIP_BUF_I0 : MTFHIP_BUF_IT], *Bv = b->buf[kind == 1 ? MTFHIP_BUF_I0 : MTFHIP_BUF_IT];
 		TimedScope ts(b->ctx, "mi_hess");
-		launch_mi_hess(b->view(), nb, b->mi_hist_norm, It, It, b->d_mi_tb, MI_T_SELF, 0, b->buf[MTFHIP_BUF_JT], b->d_mi_part, nblk, b->mi_row_len, st);
+		launch_mi_hess(b->view(), nb, b->mi_hist_norm, A, Bv, b->d_mi_tb, kind == 0 ? MI_T_INIT : (kind == 1 ? MI_T_CURR : MI_T_SELF), kind == 0,
+			b->buf[j_buf], b->d_mi_part, nblk, b->mi_row_len, st);
 		launch_finish_rows(b->d_mi_part, nblk, b->mi_row_len, b->d_mi_red, b->B, st);
-		launch_mi_hess_finish(b->view(), nb, b->d_mi_red, 1, b->mi_row_len, b->d_mi_tb, MI_SELF_JOINT, MI_HIST_CURR, 0, b->d_mi_H, st);
-	}
+		launch_mi_hess_finish(b->view(), nb, b->d_mi_red, 1, b->mi_row_len, b->d_mi_tb, kind == 2 ? MI_SELF_JOINT : MI_JOINT,
+			kind == 0 ? MI_HIST_INIT : MI_HIST_CURR, kind == 0, b->d_mi_H, st);
+	};
+	std::vector<double> h_first;
+	if (hk == H_SUM_STD) {   /* cmptSumOfHessians = cmptInitHessian(J0) + cmptCurrHessian(Jt) (MI.h): the first one leaves before the second lands */
+		hess_pass(0, MTFHIP_BUF_J0);
+		h_first.resize((size_t)64 * b->B);
+		HIP_TRY(hipMemcpyAsync(h_first.data(), b->d_mi_H, sizeof(double) * 64 * b->B, hipMemcpyDeviceToHost, st));
+		hess_pass(1, MTFHIP_BUF_JT);
+	} else if (hk == H_SELF_JT) hess_pass(2, MTFHIP_BUF_JT);
+	else if (hk == H_CURR_JT) hess_pass(1, MTFHIP_BUF_JT);
+	else if (hk == H_CURR_JM) hess_pass(1, MTFHIP_BUF_JM);
+	else if (hk == H_INIT_J0) hess_pass(0, MTFHIP_BUF_J0);
 	std::vector<double> out((size_t)b->B * 81);
 	HIP_TRY(hipMemcpyAsync(out.data(), b->d_mi_H, sizeof(double) * 80 * b->B, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(out.data() + (size_t)80 * b->B, b->d_mi_f, sizeof(double) * b->B, hipMemcpyDeviceToHost, st));
@@ -512,11 +541,14 @@ static int mi_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, doub
 		h.f = out[(size_t)80 * b->B + t];
 		if (f) f[t] = h.f;
 		double *gt = g + (size_t)t * S, *Ht = H + (size_t)t * S * S;
-		for (int s = 0; s < S; ++s) gt[s] = iclk ? gs[8 + s] : (sm->sm == MTFHIP_SM_FCLK ? gs[s] : 0.5 * (gs[s] - gs[8 + s]));
+		for (int s = 0; s < S; ++s) gt[s] = iclk ? gs[8 + s] : ((fclk || orig_jac) ? gs[s] : 0.5 * (gs[s] - gs[8 + s]));
 		for (int k = 0; k < S * S; ++k) {
 			const int r = k % S, c = k / S;
 			const double hv = Hs[c * S + r];   /* k_mi_hess_finish writes column-major S x S */
-			Ht[k] = !self ? h.h0[k] : (sm->sm == MTFHIP_SM_ESM && sm->hess_type == 2 ? 0.5 * (hv + h.h0[k]) : hv);
+			Ht[k] = hk == H_CONST ? h.h0[k]
+				: (esm && ht == 2) ? 0.5 * (hv + h.h0[k])
+				: hk == H_SUM_STD ? 0.5 * (hv + h_first[64 * (size_t)t + c * S + r])
+				: hv;
 		}
 	}
 	return MTFHIP_OK;

@@ -185,7 +185,7 @@ def test_fused_ncc_iterations_follow_oracle(oracle, gpu_ctx, frame, case, materi
 
 
 MI_CASES = [
-    # fused MI iteration (8 bins): pass 0 = the fused LK kernel materialising It / dIt_dx / Jt, then one histogram pass and
+    # fused MI iteration: pass 0 = the fused LK kernel materialising It / dIt_dx / Jt, then one histogram pass and
     # one gradient + Hessian pass; the class-default (self-type) Hessians
     (L.SM_ESM, L.SSM_HOMOGRAPHY, 50, dict()),                                  # config 5 shape (DiffOfJacs + SumOfSelf), reduced
     (L.SM_ESM, L.SSM_HOMOGRAPHY, 40, dict(hess_type=1, chained_warp=0)),
@@ -193,6 +193,14 @@ MI_CASES = [
     (L.SM_FCLK, L.SSM_HOMOGRAPHY, 50, dict()),                                 # CurrentSelf
     (L.SM_FCLK, L.SSM_AFFINE, 40, dict(hess_type=0, chained_warp=0)),
     (L.SM_ICLK, L.SSM_HOMOGRAPHY, 40, dict()),
+    # the other first-order types: cmptCurrHessian / cmptInitHessian / cmptSumOfHessians, the mean Jacobian
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, 40, dict(hess_type=5)),                       # Std
+    (L.SM_ESM, L.SSM_AFFINE, 40, dict(hess_type=4, chained_warp=0)),           # SumOfStd
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, 40, dict(hess_type=3, jac_type=0)),           # Original + Original
+    (L.SM_ESM, L.SSM_AFFINE, 36, dict(jac_type=0)),                            # Original Jacobian, SumOfSelf
+    (L.SM_FCLK, L.SSM_HOMOGRAPHY, 40, dict(hess_type=2)),                      # Std
+    (L.SM_ICLK, L.SSM_AFFINE, 30, dict(hess_type=2)),                          # Std: cmptInitHessian(J0)
+    (L.SM_ICLK, L.SSM_HOMOGRAPHY, 36, dict(hess_type=1)),                      # CurrentSelf: needs the current Jacobian
 ]
 
 
