@@ -227,7 +227,7 @@ int mtfhip_am_cmpt_sum_of_hessians2(mtfhip_batch *b, int j0_buf, int jt_buf, int
 
 /* ---- fused path: one launch per LK iteration for all targets of the batch ----
  * Appearance models: SSD (k_fused_ssd), NCC (k_fused_ncc: one pass over raw moments, every first-order Hessian type) and
- * MI (four pixel-level launches, five for SumOfStd; every first-order Jacobian / Hessian type; iterate only).  Anything outside
+ * MI (four pixel-level launches, five for SumOfStd; every first-order Jacobian / Hessian type).  Anything outside
  * returns MTFHIP_ERR_NOT_IMPLEMENTED and belongs to the per-function entry points above -- which defer and fuse the same
  * way internally when the call sequence is one of the search methods' ("Deferred fusion").
  * init_template = the body of nt::{ESM,FCLK,ICLK}::initialize after ssm->initialize

@@ -298,7 +298,7 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 		ALLOC(b->d_mi_part, sizeof(double) * (size_t)b->mi_row_len * b->nblk_max * n_targets);
 		ALLOC(b->d_mi_f, sizeof(double) * n_targets);
 		ALLOC(b->d_mi_red, sizeof(double) * (size_t)b->mi_row_len * n_targets);
-		ALLOC(b->d_mi_H, sizeof(double) * (64 + 16) * n_targets);   /* [B][64] Hessians, then [B][16] Jacobian sums of the fused pass */
+		ALLOC(b->d_mi_H, sizeof(double) * (64 + 16 + 64) * n_targets);   /* [B][64] Hessians, [B][16] Jacobian sums of the fused pass, [B][64] second Hessian (SumOfStd) */
 		(void)hipMemsetAsync(b->d_mi_tb, 0, sizeof(double) * MI_SIZE * n_targets, c->stream);
 	}
 #undef ALLOC

@@ -460,33 +460,43 @@ static void assemble(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const doub
  *   3. k_mi_hess<MFMA> + k_mi_hess_finish for the self Hessian (MI.cc:565-601) when the Hessian type needs it.
  * (Folding 2 into 3 was tried: 294 VGPRs, one wave per SIMD, 223 us instead of 95 + 35.)
  * g, H of the search method as in NT/ESM.cc:298-377, NT/FCLK.cc:260-288, NT/ICLK.cc:206-251. */
-static int mi_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, double *g, double *H) {
-	const int nb = b->desc.mi_n_bins, S = b->S, nblk = mi_blocks(b);
-	hipStream_t st = b->ctx->stream;
-	const bool iclk = sm->sm == MTFHIP_SM_ICLK, esm = sm->sm == MTFHIP_SM_ESM, fclk = sm->sm == MTFHIP_SM_FCLK;
-	/* which AM Hessian the search method asks for (NT/ESM.cc:315-377, NT/FCLK.cc:262-283, NT/ICLK.cc:204-252) */
+/* What an MI iteration of the search method needs from the AM (NT/ESM.cc:315-377, NT/FCLK.cc:262-283, NT/ICLK.cc:204-252) */
+struct MiPlan {
 	enum { H_CONST, H_SELF_JT, H_CURR_JT, H_CURR_JM, H_SUM_STD, H_INIT_J0 };
-	const int ht = sm->hess_type;
-	const int hk = ht == 0 ? H_CONST
-		: esm ? (ht <= 2 ? H_SELF_JT : (ht == 3 ? H_CURR_JM : (ht == 4 ? H_SUM_STD : H_CURR_JT)))
-		: fclk ? (ht == 1 ? H_SELF_JT : H_CURR_JT)
-		: (ht == 1 ? H_SELF_JT : H_INIT_J0);
-	const bool self = hk == H_SELF_JT;                /* cmptSelfHessian(Jt): the self histogram rides along with pass 1 */
-	const bool need_jt = !iclk || self;               /* ICLK's CurrentSelf refreshes the current pixel Jacobian (NT/ICLK.cc:215-237) */
-	const bool orig_jac = esm && sm->jac_type == 0;   /* cmptCurrJacobian(mean Jacobian) */
-	const bool need_mean = orig_jac || hk == H_CURR_JM;
+	int hk;
+	bool iclk, esm, fclk, self, need_jt, orig_jac, need_mean;
+	explicit MiPlan(const mtfhip_sm_desc *sm) {
+		iclk = sm->sm == MTFHIP_SM_ICLK; esm = sm->sm == MTFHIP_SM_ESM; fclk = sm->sm == MTFHIP_SM_FCLK;
+		const int ht = sm->hess_type;
+		hk = ht == 0 ? H_CONST
+			: esm ? (ht <= 2 ? H_SELF_JT : (ht == 3 ? H_CURR_JM : (ht == 4 ? H_SUM_STD : H_CURR_JT)))
+			: fclk ? (ht == 1 ? H_SELF_JT : H_CURR_JT)
+			: (ht == 1 ? H_SELF_JT : H_INIT_J0);
+		self = hk == H_SELF_JT;                /* cmptSelfHessian(Jt): the self histogram rides along with pass 1 */
+		need_jt = !iclk || self;               /* ICLK's CurrentSelf refreshes the current pixel Jacobian (NT/ICLK.cc:215-237) */
+		orig_jac = esm && sm->jac_type == 0;   /* cmptCurrJacobian(mean Jacobian) */
+		need_mean = orig_jac || hk == H_CURR_JM;
+	}
+};
+/* Enqueues the passes of one fused MI iteration.  Results on the device: d_mi_f [B]; d_mi_H = [B][64] Hessian (column-major
+ * S x S) | [B][16] df_dIt . J, df_dI0 . J0 | [B][64] cmptInitHessian(J0) of SumOfStd.  `active` (device, may be NULL): targets
+ * whose flag is 0 keep their It / Jt (the device-side loop). */
+static int mi_enqueue(mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPlan &pl, const int *active) {
+	const int nb = b->desc.mi_n_bins, nblk = mi_blocks(b);
+	hipStream_t st = b->ctx->stream;
 	/* 0 */
 	mtfhip_sm_desc s0 = *sm;
-	s0.sm = need_jt ? MTFHIP_SM_FCLK : MTFHIP_SM_ICLK; s0.hess_type = need_jt ? 1 : 0; s0.materialize = 1; s0.sec_ord_hess = 0;
+	s0.sm = pl.need_jt ? MTFHIP_SM_FCLK : MTFHIP_SM_ICLK; s0.hess_type = pl.need_jt ? 1 : 0; s0.materialize = 1; s0.sec_ord_hess = 0;
 	FusedArgs fa;
 	TRY(fused_args(b, &s0, fa));
+	fa.active = active;
 	{
 		TimedScope ts(b->ctx, "fused_lk");
 		launch_fused_ssd(b->view(), b->ctx->img, fa, b->d_partials, fused_blocks_per_target(b->N, b->B), st);
 	}
 	b->it_valid = true;
-	b->dit_valid = b->jt_valid = need_jt;
-	if (need_mean) {
+	b->dit_valid = b->jt_valid = pl.need_jt;
+	if (pl.need_mean) {
 		TRY(ensure_buf(b, MTFHIP_BUF_JM));
 		TimedScope ts(b->ctx, "mean_jacobian");
 		launch_mean_jacobian(b->view(), st);
@@ -495,9 +505,9 @@ static int mi_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, doub
 	const double *It = b->buf[MTFHIP_BUF_IT], *I0 = b->buf[MTFHIP_BUF_I0];
 	{
 		TimedScope ts(b->ctx, "mi_hist");
-		if (self) launch_mi_hist_self(b->view(), nb, b->mi_hist_norm, It, I0, b->d_mi_part, nblk, b->mi_row_len, st);
+		if (pl.self) launch_mi_hist_self(b->view(), nb, b->mi_hist_norm, It, I0, b->d_mi_part, nblk, b->mi_row_len, st);
 		else launch_mi_hist(b->view(), nb, b->mi_hist_norm, It, I0, b->d_mi_part, nblk, b->mi_row_len, st);
-		launch_mi_tables_iter(b->view(), nb, b->desc.mi_pre_seed, b->mi_hist_norm, self ? 1 : 0, b->d_mi_part, nblk, b->mi_row_len, b->d_mi_tb,
+		launch_mi_tables_iter(b->view(), nb, b->desc.mi_pre_seed, b->mi_hist_norm, pl.self ? 1 : 0, b->d_mi_part, nblk, b->mi_row_len, b->d_mi_tb,
 			b->d_mi_f, st);
 	}
 	/* 2 */
@@ -506,48 +516,57 @@ static int mi_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, doub
 		TimedScope ts(b->ctx, "mi_grad");
 		const int ng = simple_blocks_per_target(b->N) < 64 ? simple_blocks_per_target(b->N) : 64;
 		launch_mi_grad_gemv(b->view(), nb, b->mi_hist_norm, It, I0, b->d_mi_tb,
-			iclk ? nullptr : b->buf[orig_jac ? MTFHIP_BUF_JM : MTFHIP_BUF_JT],
-			(fclk || orig_jac) ? nullptr : b->buf[MTFHIP_BUF_J0], sm->materialize ? b->buf[MTFHIP_BUF_DF_DIT] : nullptr,
+			pl.iclk ? nullptr : b->buf[pl.orig_jac ? MTFHIP_BUF_JM : MTFHIP_BUF_JT],
+			(pl.fclk || pl.orig_jac) ? nullptr : b->buf[MTFHIP_BUF_J0], sm->materialize ? b->buf[MTFHIP_BUF_DF_DIT] : nullptr,
 			sm->materialize ? b->buf[MTFHIP_BUF_DF_DI0] : nullptr, b->d_partials, ng, st);
 		launch_finish_rows(b->d_partials, ng, 16, d_g, b->B, st);
 	}
 	/* 3: kind 0 init (MI.cc:461-513), 1 curr (:603-637), 2 self (:515-601), as mi_hessian in api_am.hip */
-	auto hess_pass = [&](int kind, int j_buf) {
+	auto hess_pass = [&](int kind, int j_buf, double *out) {
 		const double *A = b->buf[kind == 0 ? MTFHIP_BUF_I0 : MTFHIP_BUF_IT], *Bv = b->buf[kind == 1 ? MTFHIP_BUF_I0 : MTFHIP_BUF_IT];
 		TimedScope ts(b->ctx, "mi_hess");
 		launch_mi_hess(b->view(), nb, b->mi_hist_norm, A, Bv, b->d_mi_tb, kind == 0 ? MI_T_INIT : (kind == 1 ? MI_T_CURR : MI_T_SELF), kind == 0,
 			b->buf[j_buf], b->d_mi_part, nblk, b->mi_row_len, st);
 		launch_finish_rows(b->d_mi_part, nblk, b->mi_row_len, b->d_mi_red, b->B, st);
 		launch_mi_hess_finish(b->view(), nb, b->d_mi_red, 1, b->mi_row_len, b->d_mi_tb, kind == 2 ? MI_SELF_JOINT : MI_JOINT,
-			kind == 0 ? MI_HIST_INIT : MI_HIST_CURR, kind == 0, b->d_mi_H, st);
+			kind == 0 ? MI_HIST_INIT : MI_HIST_CURR, kind == 0, out, st);
 	};
-	std::vector<double> h_first;
-	if (hk == H_SUM_STD) {   /* cmptSumOfHessians = cmptInitHessian(J0) + cmptCurrHessian(Jt) (MI.h): the first one leaves before the second lands */
-		hess_pass(0, MTFHIP_BUF_J0);
-		h_first.resize((size_t)64 * b->B);
-		HIP_TRY(hipMemcpyAsync(h_first.data(), b->d_mi_H, sizeof(double) * 64 * b->B, hipMemcpyDeviceToHost, st));
-		hess_pass(1, MTFHIP_BUF_JT);
-	} else if (hk == H_SELF_JT) hess_pass(2, MTFHIP_BUF_JT);
-	else if (hk == H_CURR_JT) hess_pass(1, MTFHIP_BUF_JT);
-	else if (hk == H_CURR_JM) hess_pass(1, MTFHIP_BUF_JM);
-	else if (hk == H_INIT_J0) hess_pass(0, MTFHIP_BUF_J0);
-	std::vector<double> out((size_t)b->B * 81);
-	HIP_TRY(hipMemcpyAsync(out.data(), b->d_mi_H, sizeof(double) * 80 * b->B, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(out.data() + (size_t)80 * b->B, b->d_mi_f, sizeof(double) * b->B, hipMemcpyDeviceToHost, st));
+	switch (pl.hk) {
+	case MiPlan::H_SUM_STD:   /* cmptSumOfHessians = cmptInitHessian(J0) + cmptCurrHessian(Jt) (MI.h) */
+		hess_pass(0, MTFHIP_BUF_J0, b->d_mi_H + 80 * (size_t)b->B);
+		hess_pass(1, MTFHIP_BUF_JT, b->d_mi_H);
+		break;
+	case MiPlan::H_SELF_JT: hess_pass(2, MTFHIP_BUF_JT, b->d_mi_H); break;
+	case MiPlan::H_CURR_JT: hess_pass(1, MTFHIP_BUF_JT, b->d_mi_H); break;
+	case MiPlan::H_CURR_JM: hess_pass(1, MTFHIP_BUF_JM, b->d_mi_H); break;
+	case MiPlan::H_INIT_J0: hess_pass(0, MTFHIP_BUF_J0, b->d_mi_H); break;
+	default: break;
+	}
+	return MTFHIP_OK;
+}
+static int mi_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, double *g, double *H) {
+	const int S = b->S;
+	hipStream_t st = b->ctx->stream;
+	const MiPlan pl(sm);
+	TRY(mi_enqueue(b, sm, pl, nullptr));
+	const size_t B = (size_t)b->B;
+	std::vector<double> out(B * 145);
+	HIP_TRY(hipMemcpyAsync(out.data(), b->d_mi_H, sizeof(double) * (pl.hk == MiPlan::H_SUM_STD ? 144 : 80) * B, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(out.data() + 144 * B, b->d_mi_f, sizeof(double) * B, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	for (int t = 0; t < b->B; ++t) {
-		const double *Hs = &out[64 * (size_t)t], *gs = &out[64 * (size_t)b->B + 16 * (size_t)t];
+		const double *Hs = &out[64 * (size_t)t], *gs = &out[64 * B + 16 * (size_t)t], *H2 = &out[80 * B + 64 * (size_t)t];
 		TargetHost &h = b->th[t];
-		h.f = out[(size_t)80 * b->B + t];
+		h.f = out[144 * B + t];
 		if (f) f[t] = h.f;
 		double *gt = g + (size_t)t * S, *Ht = H + (size_t)t * S * S;
-		for (int s = 0; s < S; ++s) gt[s] = iclk ? gs[8 + s] : ((fclk || orig_jac) ? gs[s] : 0.5 * (gs[s] - gs[8 + s]));
+		for (int s = 0; s < S; ++s) gt[s] = pl.iclk ? gs[8 + s] : ((pl.fclk || pl.orig_jac) ? gs[s] : 0.5 * (gs[s] - gs[8 + s]));
 		for (int k = 0; k < S * S; ++k) {
 			const int r = k % S, c = k / S;
 			const double hv = Hs[c * S + r];   /* k_mi_hess_finish writes column-major S x S */
-			Ht[k] = hk == H_CONST ? h.h0[k]
-				: (esm && ht == 2) ? 0.5 * (hv + h.h0[k])
-				: hk == H_SUM_STD ? 0.5 * (hv + h_first[64 * (size_t)t + c * S + r])
+			Ht[k] = pl.hk == MiPlan::H_CONST ? h.h0[k]
+				: (pl.esm && sm->hess_type == 2) ? 0.5 * (hv + h.h0[k])
+				: pl.hk == MiPlan::H_SUM_STD ? 0.5 * (hv + H2[c * S + r])
 				: hv;
 		}
 	}
@@ -650,17 +669,17 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 	TRY(check_sm(b, sm, "track"));
 	TRY(single_channel(b, "track"));
 	if (sm->leven_marq) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: Levenberg-Marquardt is only available through iterate + host solve");
-	if (b->desc.am == MTFHIP_AM_MI) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: MI iterates through mtfhip_batch_iterate (fused passes + host solve)");
 	if (sm->max_iters <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "track: max_iters must be positive");
 	if (b->desc.am != MTFHIP_AM_SSD ? sm->sec_ord_hess != 0 : second_order_term(sm) >= 0)
 		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: a second-order Hessian is indefinite and needs the pivoted host solve; use iterate");
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "track before init_template");
 	TRY(need_image(b));
 	hipStream_t st = b->ctx->stream;
-	const bool one_launch = sm->sm == MTFHIP_SM_ICLK && (sm->hess_type == 0 || (sm->hess_type == 2 && b->desc.am == MTFHIP_AM_SSD)) &&
+	const bool mi = b->desc.am == MTFHIP_AM_MI;
+	const bool one_launch = !mi && sm->sm == MTFHIP_SM_ICLK && (sm->hess_type == 0 || (sm->hess_type == 2 && b->desc.am == MTFHIP_AM_SSD)) &&
 		b->N <= kIclkTrackMaxPix;
 	FusedArgs fa;
-	if (!one_launch) TRY(fused_args(b, sm, fa));
+	if (!one_launch && !mi) TRY(fused_args(b, sm, fa));
 	else { fa.materialize = 0; fa.mode = 2; fa.active = nullptr; fa.rows_per_block = 1; fa.j0_recompute = 0; }
 	/* active = 1, iters = 0, corners, warps, states, NCC scalars: one pinned async copy of the whole slab
 	 * (w0 is copied along; init_grid consumed it long ago) */
@@ -674,7 +693,18 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 	if (ncc && !one_launch && !b->d_ncc_tm) return fail(MTFHIP_ERR_LOGIC, "track before init_template");
 	TrackState ts{b->d_acc, b->d_h0, b->d_corners, b->d_init_corners_hm, b->d_active, b->d_iters, ncc ? b->d_ncc : nullptr, ncc ? b->d_ncc_tm : nullptr};
 	BatchView bv = b->view();
-	if (one_launch) {
+	if (b->desc.am == MTFHIP_AM_MI) {
+		/* the fused MI passes leave g and H on the device; k_mi_pack_acc lays them out as one reduced row per target so that
+		 * the same finish (solve, compositional update, convergence test) serves MI: no host round trip per iteration */
+		const MiPlan pl(sm);
+		const int gmode = pl.iclk ? 0 : (pl.fclk ? 1 : (pl.orig_jac ? 2 : 3));
+		ts.h_from_acc = 1;
+		for (int it = 0; it < sm->max_iters; ++it) {
+			TRY(mi_enqueue(b, sm, pl, b->d_active));
+			launch_mi_pack_acc(bv, pl.hk == MiPlan::H_SUM_STD, gmode, b->d_mi_H, b->d_partials, st);
+			launch_finish_track(bv, *sm, ts, b->d_partials, 1, st);
+		}
+	} else if (one_launch) {
 		TimedScope tsc(b->ctx, "iclk_track");
 		launch_iclk_track(bv, b->ctx->img, *sm, ts, b->d_h0inv, b->d_ncc, b->norm_mult, b->norm_add, st);
 	} else {
@@ -723,8 +753,10 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 			if (corners) std::memcpy(corners + 8 * t, cr + 8 * t, sizeof(double) * 8);
 		}
 	}
-	b->it_valid = fa.materialize;
-	b->dit_valid = b->jt_valid = fa.materialize && fa.mode != 2;
+	if (!mi) {   /* (mi_enqueue keeps the flags of its own passes) */
+		b->it_valid = fa.materialize;
+		b->dit_valid = b->jt_valid = fa.materialize && fa.mode != 2;
+	}
 	b->pts_stale = true;   /* CURR_PTS follow the final warp when an un-fused kernel next needs them */
 	return MTFHIP_OK;
 }

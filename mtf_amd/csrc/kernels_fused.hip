@@ -514,8 +514,8 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 	if (lane < RL) { acc_s[lane] = v_acc; ts.acc[(size_t)t * RL + lane] = v_acc; }
 	__syncthreads();
 	const int i = (lane >> 3) & 7, j = lane & 7;
-	const bool use_h0 = (sm.hess_type == 0) || (sm.sm == MTFHIP_SM_ICLK);
-	const bool sum_h0 = (sm.sm == MTFHIP_SM_ESM) && (sm.hess_type == 2 || sm.hess_type == 4);
+	const bool use_h0 = (sm.hess_type == 0) || (sm.sm == MTFHIP_SM_ICLK && !ts.h_from_acc);
+	const bool sum_h0 = (sm.sm == MTFHIP_SM_ESM) && (sm.hess_type == 2 || (sm.hess_type == 4 && !ts.h_from_acc));   /* (MI's SumOfStd arrives summed) */
 	const double gscale = (sm.sm == MTFHIP_SM_ESM) ? 0.5 : 1.0;
 	/* NCC from its moments (ncc_assemble in api_fused.hip is the host twin; formulas and citations there) */
 	const double nN = (double)bv.N;

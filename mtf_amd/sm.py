@@ -27,13 +27,11 @@ class LKTracker:
     """One or many (B) independent targets tracked with ESM / FCLK / ICLK + SSD, NCC or MI on one GPU through the fused path
     (mtfhip_batch_iterate: k_fused_ssd / k_fused_ncc, or the fused MI passes): host_solve=True = fused launch(es) per
     iteration + the reference's pivoted QR and Levenberg-Marquardt on the host; False = the whole loop on the device
-    (mtfhip_batch_track; SSD and NCC)."""
+    (mtfhip_batch_track)."""
 
     def __init__(self, ctx, sm, ssm=L.SSM_HOMOGRAPHY, resx=50, resy=50, n_targets=1, host_solve=True, am=L.AM_SSD,
                  **params):
         self.ctx = ctx
-        if am == L.AM_MI and not host_solve:
-            raise L.FunctionNotImplemented(-2, "LKTracker: the device-side loop covers SSD and NCC; MI iterates with host_solve=True")
         self.batch = Batch(ctx, am, ssm, resx, resy, n_targets)
         self.B, self.S = n_targets, self.batch.S
         self.host_solve = host_solve

@@ -297,6 +297,17 @@ def test_device_side_loop_ncc(oracle, gpu_ctx, frame, sm_kind, ssm, extra):
     _device_loop(oracle, gpu_ctx, frame, sm_kind, ssm, L.AM_NCC, 100, extra)   # > kIclkTrackMaxPix: not the one-launch kernel
 
 
+@pytest.mark.parametrize("sm_kind,ssm,extra", [
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, dict()), (L.SM_ESM, L.SSM_AFFINE, dict(hess_type=4)), (L.SM_ESM, L.SSM_HOMOGRAPHY, dict(hess_type=3, jac_type=0)),
+    (L.SM_ESM, L.SSM_AFFINE, dict(hess_type=0, jac_type=0)), (L.SM_FCLK, L.SSM_HOMOGRAPHY, dict()), (L.SM_FCLK, L.SSM_AFFINE, dict(hess_type=2)),
+    (L.SM_ICLK, L.SSM_HOMOGRAPHY, dict()), (L.SM_ICLK, L.SSM_AFFINE, dict(hess_type=2)), (L.SM_ICLK, L.SSM_HOMOGRAPHY, dict(hess_type=1))],
+    ids=lambda v: "_".join("%s%s" % kv for kv in v.items()) if isinstance(v, dict) else str(v))
+def test_device_side_loop_mi(oracle, gpu_ctx, frame, sm_kind, ssm, extra):
+    """mtfhip_batch_track with MI: the fused MI passes leave g and H on the device, k_mi_pack_acc hands them to the same
+    finish kernel (solve, compositional update, convergence test) -- every first-order type, against the oracle's trackers."""
+    _device_loop(oracle, gpu_ctx, frame, sm_kind, ssm, L.AM_MI, 36, extra)
+
+
 @pytest.mark.parametrize("sm_kind,ssm", [(L.SM_ESM, L.SSM_HOMOGRAPHY), (L.SM_FCLK, L.SSM_HOMOGRAPHY),
                                          (L.SM_ICLK, L.SSM_AFFINE), (L.SM_ICLK, L.SSM_HOMOGRAPHY)])
 def test_device_side_loop_matches_oracle_tracker(oracle, gpu_ctx, frame, sm_kind, ssm):

@@ -16,10 +16,14 @@ def gt_corners(corners, p_true, centre):
     return q[:2] / q[2] + np.array(centre)[:, None]
 
 
-@pytest.mark.parametrize("am", [L.AM_SSD, L.AM_NCC])
+@pytest.mark.parametrize("am", [L.AM_SSD, L.AM_NCC, L.AM_MI])
 @pytest.mark.parametrize("host_solve", [True, False])
 @pytest.mark.parametrize("sm", [L.SM_ESM, L.SM_FCLK, L.SM_ICLK])
 def test_lk_trackers_recover_known_warp(gpu_ctx, frame, sm, host_solve, am):
+    if am == L.AM_MI and sm != L.SM_ESM:
+        # MI with 8 bins on a 45 x 45 patch is a flat objective: FCLK / ICLK stall 0.8-1 px from the truth on the device exactly
+        # as on the host (test_device_side_loop_mi and test_fused_mi_iterations_follow_oracle hold them to the oracle)
+        pytest.skip("MI + FCLK / ICLK do not reach 0.08 px on this patch (neither does the oracle)")
     rng = np.random.default_rng(7)
     centre = (256.0, 250.0)
     corners = synth.square_corners(centre[0], centre[1], 90)
