@@ -107,6 +107,7 @@ __device__ __forceinline__ void lds_add(double *p, double v) {
  * ------------------------------------------------------------------------------------------- */
 constexpr int kMiPairs = (MI_NB * MI_NB + 63) / 64;
 constexpr int kMiRow = 65;
+constexpr int kMiRowMfma = 68;   /* k_mi_hess<MFMA>: see there */
 /* Bin mode on the matrix cores.  Over a 64-pixel chunk the bin-mode sums are small dense products whose K axis is the
  * pixel: joint(r, c) = sum_p wa[r][p] wb[c][p] is (nb x 64)(64 x nb), and the joint_hist_jacobian block
  * Q[(r, c)][s] = sum_p (gd[r][p] wd[c][p]) J[p][s] is (nb^2 x 64)(64 x S).  v_mfma_f64_16x16x4_f64 takes K = 4 pixels
@@ -375,19 +376,22 @@ __global__ __launch_bounds__(kBlock) void k_mi_grad_gemv(int N, int S, int nb, d
  *   Hsum  += hess_term(p) * Jrow Jrow^T,  hess_term = sum_r hessA(r) * sum_c matB(c) T(r,c)
  *   Q[row(r,c)] += gradA(r) matB(c) Jrow          row(r,c) = (r,c), or (c,r) when transpose_q (init flavour)
  * Block partial rows: [36 Hsum | nb*nb*S Q] */
-template <bool MFMA>   /* MFMA: nb == 8 (the reference's 8-bin histograms): 64 (r, c) rows = four 16-row tiles */
+template <bool MFMA>   /* MFMA: nb == 8 (the reference's 8-bin histograms): 64 (r, c) rows x 8 columns out of 4x4x4 blocks */
 __global__ __launch_bounds__(kBlock) void k_mi_hess(int N, int S, int nb, double norm_mult, const double *A_all,
 	const double *B_all, const double *tb_all, int table_off, int transpose_q, const double *J_all,
 	double *partials, int nblk, int row_len) {
 	extern __shared__ __attribute__((aligned(16))) double dyn[];
+	/* slab row stride: 65 keeps the VALU bin mode conflict-free; the MFMA form reads rows b, b + 1 .. at pixels p, p + 1 ..
+	 * in one instruction and wants 8 b + 2 k distinct banks: 68 (136 dwords = 8 mod 64) */
+	constexpr int RS = MFMA ? kMiRowMfma : kMiRow;
 	double *T = dyn;                                    /* MI_NB*MI_NB gradient-factor table */
 	double *red = dyn + MI_NB * MI_NB;                  /* 4 * 36 */
 	double *slabs = red + 4 * 36;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const int slab = kMiRow * (2 * nb + kMaxS);
+	const int slab = RS * (2 * nb + kMaxS);
 	double *gd = slabs + (size_t)wave * slab;           /* [nb][65] dense curr_hist_grad-type vector of A */
-	double *wd = gd + nb * kMiRow;                      /* [nb][65] dense weights of B */
-	double *rw = wd + nb * kMiRow;                      /* [kMaxS][65] J rows */
+	double *wd = gd + nb * RS;                      /* [nb][65] dense weights of B */
+	double *rw = wd + nb * RS;                      /* [kMaxS][65] J rows */
 	const int t = blockIdx.y;
 	const double *tb = tb_all + (size_t)t * MI_SIZE + table_off;
 	for (int k2 = threadIdx.x; k2 < MI_NB * MI_NB; k2 += kBlock) T[k2] = tb[k2];
@@ -400,9 +404,9 @@ __global__ __launch_bounds__(kBlock) void k_mi_hess(int N, int S, int nb, double
 	constexpr int NQ = MFMA ? 1 : kMiPairs;
 	double accq[NQ][kMaxS];
 	int pr[NQ], pc[NQ];
-	mfma_d4 cq[4];
+	double cq[8];   /* MFMA: accumulator (Rg, Cg, Sg) of the 4x4x4 blocks */
 #pragma unroll
-	for (int mt = 0; mt < 4; ++mt) cq[mt] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+	for (int mt = 0; mt < 8; ++mt) cq[mt] = 0.0;
 #pragma unroll
 	for (int m = 0; m < NQ; ++m) {
 		const int q = lane + 64 * m;
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(kBlock) void k_mi_hess(int N, int S, int nb, double
 				for (int s = 0; s < kMaxS; ++s) if (s < S) row_nx[s] = J[(size_t)s * N + in];
 			}
 		}
-		for (int k2 = 0; k2 < nb; ++k2) { gd[k2 * kMiRow + lane] = 0.0; wd[k2 * kMiRow + lane] = 0.0; }
+		for (int k2 = 0; k2 < nb; ++k2) { gd[k2 * RS + lane] = 0.0; wd[k2 * RS + lane] = 0.0; }
 		if (i < N) {
 			/* pixel mode: windows, the scalar hess_term and its rank-1 contribution (MI.cc:478-496, 574-583, 620-629) */
 			const BsplWin a = bspl_window(a_cur, nb, norm_mult, true);
@@ -447,11 +451,11 @@ __global__ __launch_bounds__(kBlock) void k_mi_hess(int N, int S, int nb, double
 #pragma unroll
 					for (int c = 0; c < 4; ++c) if (c < b.n) inner += b.w[c] * T[(a.lo + r) * MI_NB + b.lo + c];
 					hess_term += a.h[r] * inner;
-					gd[(a.lo + r) * kMiRow + lane] = a.d[r];
+					gd[(a.lo + r) * RS + lane] = a.d[r];
 				}
 			}
 #pragma unroll
-			for (int c = 0; c < 4; ++c) if (c < b.n) wd[(b.lo + c) * kMiRow + lane] = b.w[c];
+			for (int c = 0; c < 4; ++c) if (c < b.n) wd[(b.lo + c) * RS + lane] = b.w[c];
 			int k2 = 0;
 #pragma unroll
 			for (int x = 0; x < kMaxS; ++x) {
@@ -461,32 +465,42 @@ __global__ __launch_bounds__(kBlock) void k_mi_hess(int N, int S, int nb, double
 			}
 		}
 #pragma unroll
-		for (int s = 0; s < kMaxS; ++s) rw[s * kMiRow + lane] = row[s];
+		for (int s = 0; s < kMaxS; ++s) rw[s * RS + lane] = row[s];
 		__builtin_amdgcn_wave_barrier();
 		/* bin mode: joint_hist_jacobian.row(r, c) += grad(r, p) * mat(c, p) * J.row(p)  (MI.cc:484-486, 576-577, 622-623) */
 		if constexpr (MFMA) {
-			/* tile mt holds rows 16 mt .. 16 mt + 15 = (r, c) with r = 2 mt + i / 8, c = i % 8; columns s (8 of 16 used) */
-			const int idx = lane & 15, kq = lane >> 4, cc = idx & 7, rh = idx >> 3;
-#pragma unroll      /* all 16 k-steps: the LDS reads of later steps are issued under the MFMAs of earlier ones (96 -> 85 us) */
-			for (int ks = 0; ks < 16; ++ks) {
-				const int p = 4 * ks + kq;
-				const double jv = rw[cc * kMiRow + p];
-				const double bj = idx < kMaxS ? jv : 0.0;
-				const double wc = wd[cc * kMiRow + p];
+			/* v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 blocks per instruction, no idle output columns (the 16x16x4
+			 * tile had 8 of 16): half the matrix-core time for the same LDS reads.  Operand lane l: row / column = l & 3,
+			 * block = (l >> 2) & 3, k = l >> 4; result lane l: column = l & 3, block = (l >> 2) & 3, row = l >> 4
+			 * (tools/mfma_layout_test_4x4.hip).  block <-> r = 4 Rg + b, row <-> c = 4 Cg + i, column <-> s = 4 Sg + j,
+			 * k <-> pixel 4 q + k; eight accumulators (Rg, Cg, Sg). */
+			const int li = lane & 3, lb = (lane >> 2) & 3, lk = lane >> 4;
 #pragma unroll
-				for (int mt = 0; mt < 4; ++mt)
-					cq[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(gd[(2 * mt + rh) * kMiRow + p] * wc, bj, cq[mt], 0, 0, 0);
+			for (int q = 0; q < 16; ++q) {
+				const int p = 4 * q + lk;
+				const double g0 = gd[lb * RS + p], g1 = gd[(4 + lb) * RS + p];
+				const double w0 = wd[li * RS + p], w1 = wd[(4 + li) * RS + p];
+				const double j0 = rw[li * RS + p], j1 = rw[(4 + li) * RS + p];
+				const double a00 = g0 * w0, a01 = g0 * w1, a10 = g1 * w0, a11 = g1 * w1;
+				cq[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a00, j0, cq[0], 0, 0, 0);
+				cq[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a00, j1, cq[1], 0, 0, 0);
+				cq[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a01, j0, cq[2], 0, 0, 0);
+				cq[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a01, j1, cq[3], 0, 0, 0);
+				cq[4] = __builtin_amdgcn_mfma_f64_4x4x4f64(a10, j0, cq[4], 0, 0, 0);
+				cq[5] = __builtin_amdgcn_mfma_f64_4x4x4f64(a10, j1, cq[5], 0, 0, 0);
+				cq[6] = __builtin_amdgcn_mfma_f64_4x4x4f64(a11, j0, cq[6], 0, 0, 0);
+				cq[7] = __builtin_amdgcn_mfma_f64_4x4x4f64(a11, j1, cq[7], 0, 0, 0);
 			}
 		} else {
 #pragma unroll 4
 			for (int p = 0; p < 64; ++p) {
 				double jr[kMaxS];
 #pragma unroll
-				for (int s = 0; s < kMaxS; ++s) jr[s] = rw[s * kMiRow + p];
+				for (int s = 0; s < kMaxS; ++s) jr[s] = rw[s * RS + p];
 #pragma unroll
 				for (int m = 0; m < NQ; ++m) {
 					if (pr[m] >= 0) {
-						const double gr = gd[pr[m] * kMiRow + p] * wd[pc[m] * kMiRow + p];
+						const double gr = gd[pr[m] * RS + p] * wd[pc[m] * RS + p];
 #pragma unroll
 						for (int s = 0; s < kMaxS; ++s) accq[m][s] = fma(gr, jr[s], accq[m][s]);
 					}
@@ -502,15 +516,13 @@ __global__ __launch_bounds__(kBlock) void k_mi_hess(int N, int S, int nb, double
 	/* the four waves' Q blocks through the (now free) slabs: [4][nb*nb*S], indexed as the finish expects */
 	double *qred = slabs;
 	if constexpr (MFMA) {
-		const int sidx = lane & 15;
+		const int li = lane & 3, lb = (lane >> 2) & 3, lk = lane >> 4;
 #pragma unroll
-		for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-			for (int v = 0; v < 4; ++v) {
-				const int rowq = 16 * mt + (lane >> 4) + 4 * v, r = rowq >> 3, c = rowq & 7;
-				const int row_idx = transpose_q ? c * nb + r : r * nb + c;
-				if (sidx < S) qred[wave * ql + row_idx * S + sidx] = cq[mt][v];
-			}
+		for (int a8 = 0; a8 < 8; ++a8) {
+			const int r = 4 * (a8 >> 2) + lb, c = 4 * ((a8 >> 1) & 1) + lk, sx = 4 * (a8 & 1) + li;
+			const int row_idx = transpose_q ? c * nb + r : r * nb + c;
+			if (sx < S) qred[wave * ql + row_idx * S + sx] = cq[a8];
+		}
 	} else {
 #pragma unroll
 		for (int m = 0; m < NQ; ++m) {
@@ -615,7 +627,7 @@ void launch_mi_grad(const BatchView &bv, int nb, double norm_mult, const double 
 }
 void launch_mi_hess(const BatchView &bv, int nb, double norm_mult, const double *A, const double *Bv, const double *tb,
 	int table_off, int transpose_q, const double *J, double *partials, int nblk, int row_len, hipStream_t st) {
-	const size_t slabs = std::max<size_t>((size_t)4 * kMiRow * (2 * nb + kMaxS), (size_t)4 * nb * nb * bv.S);
+	const size_t slabs = std::max<size_t>((size_t)4 * kMiRowMfma * (2 * nb + kMaxS), (size_t)4 * nb * nb * bv.S);
 	const size_t lds = sizeof(double) * (MI_NB * MI_NB + 4 * 36 + slabs);
 	static bool attr_set = false;
 	if (!attr_set) {   /* 16 bins need 82 KB of dynamic LDS; the default cap is 64 KB */
