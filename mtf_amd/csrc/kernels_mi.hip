@@ -126,15 +126,18 @@ template <bool MFMA, bool SELF = false>
 __global__ __launch_bounds__(kBlock) void k_mi_hist(int N, int nb, double norm_mult, const double *A_all,
 	const double *B_all, double *partials, int nblk, int row_len) {
 	extern __shared__ __attribute__((aligned(16))) double dyn[];
+	constexpr int RS = MFMA ? kMiRowMfma : kMiRow;   /* as in k_mi_hess */
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	/* slabs are bin-major with rows of kMiRow = 65 doubles: pixel-mode lanes write consecutive words, bin-mode lanes
+	/* slabs are bin-major with rows of RS = 65 doubles: pixel-mode lanes write consecutive words, bin-mode lanes
 	 * (different r, same p) land in different banks */
-	double *wa = dyn + (size_t)wave * 2 * nb * kMiRow;  /* [nb][65] dense A weights of this wave's chunk */
-	double *wb = wa + nb * kMiRow;                      /* [nb][65] dense B weights */
+	double *wa = dyn + (size_t)wave * 2 * nb * RS;  /* [nb][65] dense A weights of this wave's chunk */
+	double *wb = wa + nb * RS;                      /* [nb][65] dense B weights */
 	const int t = blockIdx.y;
 	const double *A = A_all + (size_t)t * N, *Bv = B_all + (size_t)t * N;
 	double accj[kMiPairs], acch = 0.0;
 	mfma_d4 cj = {0.0, 0.0, 0.0, 0.0}, cs = {0.0, 0.0, 0.0, 0.0};
+	double bj8 = 0.0, bs8 = 0.0, bh8 = 0.0;   /* nb == 8: the 8 x 8 tables as four 4x4x4 blocks (Rg, Cg), one value per lane */
+	const bool blocks8 = MFMA && nb == 8;
 #pragma unroll
 	for (int m = 0; m < kMiPairs; ++m) accj[m] = 0.0;
 	int pr[kMiPairs], pc[kMiPairs];
@@ -152,38 +155,52 @@ __global__ __launch_bounds__(kBlock) void k_mi_hist(int N, int nb, double norm_m
 			const int in = i + nblk * kBlock;
 			if (in < N) { a_nx = A[in]; b_nx = Bv[in]; }
 		}
-		for (int k2 = 0; k2 < nb; ++k2) { wa[k2 * kMiRow + lane] = 0.0; wb[k2 * kMiRow + lane] = 0.0; }
+		for (int k2 = 0; k2 < nb; ++k2) { wa[k2 * RS + lane] = 0.0; wb[k2 * RS + lane] = 0.0; }
 		if (i < N) {
 			const BsplWin a = bspl_window(a_cur, nb, norm_mult, false);
 			const BsplWin b = bspl_window(b_cur, nb, norm_mult, false);
 			/* static indices only: a runtime-indexed window array would live in scratch memory */
 #pragma unroll
-			for (int r = 0; r < 4; ++r) if (r < a.n) wa[(a.lo + r) * kMiRow + lane] = a.w[r];
+			for (int r = 0; r < 4; ++r) if (r < a.n) wa[(a.lo + r) * RS + lane] = a.w[r];
 #pragma unroll
-			for (int c = 0; c < 4; ++c) if (c < b.n) wb[(b.lo + c) * kMiRow + lane] = b.w[c];
+			for (int c = 0; c < 4; ++c) if (c < b.n) wb[(b.lo + c) * RS + lane] = b.w[c];
 		}
 		__builtin_amdgcn_wave_barrier();
-		if constexpr (MFMA) {
+		if (blocks8) {
+			/* v_mfma_f64_4x4x4_4b_f64 (operand layout: k_mi_hess): block b = (Rg, Cg) holds joint(4 Rg + i, 4 Cg + j) -- one
+			 * instruction per four pixels gives the whole 8 x 8 table, where the 16 x 16 tile used a quarter of its outputs;
+			 * a third operand of ones in column 0 gives the histogram */
+			const int li = lane & 3, lb = (lane >> 2) & 3, lk = lane >> 4;
+			const double one0 = li == 0 ? 1.0 : 0.0;
+#pragma unroll
+			for (int q = 0; q < 16; ++q) {
+				const int p = 4 * q + lk;
+				const double av = wa[(4 * (lb >> 1) + li) * RS + p], bv = wb[(4 * (lb & 1) + li) * RS + p];
+				bj8 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, bj8, 0, 0, 0);
+				bh8 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, one0, bh8, 0, 0, 0);
+				if constexpr (SELF) bs8 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, wa[(4 * (lb & 1) + li) * RS + p], bs8, 0, 0, 0);
+			}
+		} else if constexpr (MFMA) {
 			/* one 16x16 tile: rows r, columns c; when nb < 16 column nb of B is all ones, so D[r][nb] is the histogram */
 			const int idx = lane & 15, kq = lane >> 4, row = idx < nb ? idx : nb - 1;
 #pragma unroll
 			for (int ks = 0; ks < 16; ++ks) {
 				const int p = 4 * ks + kq;
-				const double av = wa[row * kMiRow + p], bv = wb[row * kMiRow + p];
+				const double av = wa[row * RS + p], bv = wb[row * RS + p];
 				cj = __builtin_amdgcn_mfma_f64_16x16x4f64(idx < nb ? av : 0.0, idx < nb ? bv : (idx == nb ? 1.0 : 0.0), cj, 0, 0, 0);
 				if constexpr (SELF) cs = __builtin_amdgcn_mfma_f64_16x16x4f64(idx < nb ? av : 0.0, idx < nb ? av : 0.0, cs, 0, 0, 0);
 			}
 			if (nb == 16) {
 #pragma unroll 8
-				for (int p = 0; p < 64; ++p) if (lane < nb) acch += wa[lane * kMiRow + p];
+				for (int p = 0; p < 64; ++p) if (lane < nb) acch += wa[lane * RS + p];
 			}
 		} else {
 #pragma unroll 8
 			for (int p = 0; p < 64; ++p) {
 #pragma unroll
 				for (int m = 0; m < kMiPairs; ++m)
-					if (pr[m] >= 0) accj[m] = fma(wa[pr[m] * kMiRow + p], wb[pc[m] * kMiRow + p], accj[m]);
-				if (lane < nb) acch += wa[lane * kMiRow + p];
+					if (pr[m] >= 0) accj[m] = fma(wa[pr[m] * RS + p], wb[pc[m] * RS + p], accj[m]);
+				if (lane < nb) acch += wa[lane * RS + p];
 			}
 		}
 		__builtin_amdgcn_wave_barrier();
@@ -192,7 +209,13 @@ __global__ __launch_bounds__(kBlock) void k_mi_hist(int N, int nb, double norm_m
 	__syncthreads();
 	double *red = dyn;                                  /* [4][nb + nb*nb (+ nb*nb)], the slabs are free now */
 	const int rl = nb + nb * nb + (SELF ? nb * nb : 0);
-	if constexpr (MFMA) {
+	if (blocks8) {
+		/* result lane l: column j = l & 3, block = (l >> 2) & 3, row i = l >> 4 */
+		const int lb = (lane >> 2) & 3, r = 4 * (lb >> 1) + (lane >> 4), c = 4 * (lb & 1) + (lane & 3);
+		red[wave * rl + nb + r * nb + c] = bj8;
+		if constexpr (SELF) red[wave * rl + nb + nb * nb + r * nb + c] = bs8;
+		if ((lb & 1) == 0 && (lane & 3) == 0) red[wave * rl + r] = bh8;
+	} else if constexpr (MFMA) {
 		const int j = lane & 15;
 #pragma unroll
 		for (int v = 0; v < 4; ++v) {
@@ -597,7 +620,7 @@ __global__ __launch_bounds__(64) void k_mi_pack_acc(int S, int B, int sum_std, i
 void launch_mi_hist(const BatchView &bv, int nb, double norm_mult, const double *A, const double *Bv, double *partials,
 	int nblk, int row_len, hipStream_t st) {
 	/* per-wave staging slabs [64][2 nb]; the same LDS later holds the four waves' [nb + nb^2] rows */
-	const size_t lds = sizeof(double) * std::max<size_t>((size_t)4 * kMiRow * 2 * nb, (size_t)4 * (nb + nb * nb));
+	const size_t lds = sizeof(double) * std::max<size_t>((size_t)4 * kMiRowMfma * 2 * nb, (size_t)4 * (nb + nb * nb));
 	static const bool use_mfma = !(getenv("MTFHIP_MI_MFMA") && atoi(getenv("MTFHIP_MI_MFMA")) == 0);
 	if (use_mfma) hipLaunchKernelGGL((k_mi_hist<true, false>), grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, nb, norm_mult, A, Bv, partials, nblk, row_len);
 	else hipLaunchKernelGGL((k_mi_hist<false, false>), grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, nb, norm_mult, A, Bv, partials, nblk, row_len);
@@ -605,7 +628,7 @@ void launch_mi_hist(const BatchView &bv, int nb, double norm_mult, const double 
 /* A = It against B = I0 and against itself in one pass (fused MI iteration); row: [nb | nb*nb | nb*nb] */
 void launch_mi_hist_self(const BatchView &bv, int nb, double norm_mult, const double *A, const double *Bv, double *partials,
 	int nblk, int row_len, hipStream_t st) {
-	const size_t lds = sizeof(double) * std::max<size_t>((size_t)4 * kMiRow * 2 * nb, (size_t)4 * (nb + 2 * nb * nb));
+	const size_t lds = sizeof(double) * std::max<size_t>((size_t)4 * kMiRowMfma * 2 * nb, (size_t)4 * (nb + 2 * nb * nb));
 	hipLaunchKernelGGL((k_mi_hist<true, true>), grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, nb, norm_mult, A, Bv, partials, nblk, row_len);
 }
 void launch_mi_tables_iter(const BatchView &bv, int nb, double pre_seed, double norm_mult, int with_self, const double *partials, int nblk,
