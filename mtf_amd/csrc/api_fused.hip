@@ -481,7 +481,7 @@ struct MiPlan {
 /* Enqueues the passes of one fused MI iteration.  Results on the device: d_mi_f [B]; d_mi_H = [B][64] Hessian (column-major
  * S x S) | [B][16] df_dIt . J, df_dI0 . J0 | [B][64] cmptInitHessian(J0) of SumOfStd.  `active` (device, may be NULL): targets
  * whose flag is 0 keep their It / Jt (the device-side loop). */
-static int mi_enqueue(mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPlan &pl, const int *active) {
+static int mi_enqueue(mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPlan &pl, const int *active, bool reduce_g = true) {
 	const int nb = b->desc.mi_n_bins, nblk = mi_blocks(b);
 	hipStream_t st = b->ctx->stream;
 	/* 0 */
@@ -519,7 +519,7 @@ static int mi_enqueue(mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPlan &p
 			pl.iclk ? nullptr : b->buf[pl.orig_jac ? MTFHIP_BUF_JM : MTFHIP_BUF_JT],
 			(pl.fclk || pl.orig_jac) ? nullptr : b->buf[MTFHIP_BUF_J0], sm->materialize ? b->buf[MTFHIP_BUF_DF_DIT] : nullptr,
 			sm->materialize ? b->buf[MTFHIP_BUF_DF_DI0] : nullptr, b->d_partials, ng, st);
-		launch_finish_rows(b->d_partials, ng, 16, d_g, b->B, st);
+		if (reduce_g) launch_finish_rows(b->d_partials, ng, 16, d_g, b->B, st);   /* (the device-side loop sums the rows in its finish) */
 	}
 	/* 3: kind 0 init (MI.cc:461-513), 1 curr (:603-637), 2 self (:515-601), as mi_hessian in api_am.hip */
 	auto hess_pass = [&](int kind, int j_buf, double *out) {
@@ -694,15 +694,15 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 	TrackState ts{b->d_acc, b->d_h0, b->d_corners, b->d_init_corners_hm, b->d_active, b->d_iters, ncc ? b->d_ncc : nullptr, ncc ? b->d_ncc_tm : nullptr};
 	BatchView bv = b->view();
 	if (b->desc.am == MTFHIP_AM_MI) {
-		/* the fused MI passes leave g and H on the device; k_mi_pack_acc lays them out as one reduced row per target so that
-		 * the same finish (solve, compositional update, convergence test) serves MI: no host round trip per iteration */
+		/* the fused MI passes leave g and H on the device; k_finish_track_mi lays them out as one reduced row per target and
+		 * runs the same finish (solve, compositional update, convergence test): no host round trip per iteration */
 		const MiPlan pl(sm);
 		const int gmode = pl.iclk ? 0 : (pl.fclk ? 1 : (pl.orig_jac ? 2 : 3));
 		ts.h_from_acc = 1;
+		const int ng = simple_blocks_per_target(b->N) < 64 ? simple_blocks_per_target(b->N) : 64;   /* as the gradient pass of mi_enqueue */
 		for (int it = 0; it < sm->max_iters; ++it) {
-			TRY(mi_enqueue(b, sm, pl, b->d_active));
-			launch_mi_pack_acc(bv, pl.hk == MiPlan::H_SUM_STD, gmode, b->d_mi_H, b->d_partials, st);
-			launch_finish_track(bv, *sm, ts, b->d_partials, 1, st);
+			TRY(mi_enqueue(b, sm, pl, b->d_active, false));
+			launch_finish_track_mi(bv, *sm, ts, pl.hk == MiPlan::H_SUM_STD, gmode, b->d_mi_H, b->d_partials, ng, b->d_mi_red, st);
 		}
 	} else if (one_launch) {
 		TimedScope tsc(b->ctx, "iclk_track");

@@ -661,6 +661,33 @@ __global__ __launch_bounds__(128) void k_finish_track(BatchView bv, mtfhip_sm_de
 }
 
 
+/* MI device-side loop: g and H of the fused MI passes (mi_H = [B][64] H column-major | [B][16] unused here | [B][64] second H of
+ * SumOfStd; gpart = the gradient pass's block rows [B][ng][16]) laid out as the reduced row the finish reads for SSD --
+ * ACC_H = upper triangle of -H, ACC_G = the Jacobian sum the search method scales (ESM halves it, NT/ESM.cc:246-255) -- and
+ * the finish itself, in one launch.  gmode: 0 ICLK, 1 FCLK, 2 ESM Original, 3 ESM DiffOfJacs. */
+__global__ __launch_bounds__(64) void k_finish_track_mi(BatchView bv, mtfhip_sm_desc sm, TrackState ts, int sum_std, int gmode,
+	const double *mi_H, const double *gpart, int ng, double *rows) {
+	const int t = blockIdx.x, lane = threadIdx.x, S = bv.S, B = bv.B;
+	const double *Hs = mi_H + 64 * (size_t)t, *H2 = mi_H + 80 * (size_t)B + 64 * (size_t)t;
+	double *row = rows + (size_t)t * ACC_COUNT;
+	__shared__ double gs[16];
+	if (lane < 16) gs[lane] = column_sum(gpart + (size_t)t * ng * 16 + lane, ng, 16);
+	if (lane < ACC_COUNT - 36) row[36 + lane] = 0.0;
+	const int a = lane >> 3, c = lane & 7;
+	if (a <= c) {
+		double hv = 0.0;
+		if (c < S) { hv = Hs[c * S + a]; if (sum_std) hv = 0.5 * (hv + H2[c * S + a]); }
+		row[ACC_H + a * 8 - (a * (a - 1)) / 2 + (c - a)] = -hv;
+	}
+	__syncthreads();
+	if (lane < S) {
+		const double gt = gs[lane], g0 = gs[8 + lane];
+		row[ACC_G + lane] = gmode == 0 ? g0 : (gmode == 1 ? gt : (gmode == 2 ? 2.0 * gt : gt - g0));
+	}
+	__syncthreads();   /* the row is read back by the same workgroup */
+	finish_track_body(bv, sm, ts, rows, 1, t);
+}
+
 /* ===================================================================== */
 /* launchers                                                              */
 /* ===================================================================== */
@@ -700,6 +727,11 @@ void launch_finish_track(const BatchView &bv, const mtfhip_sm_desc &sm, const Tr
 	int nblk, hipStream_t st) {
 	/* NCC rows are 72 wide: two waves load them, the first one solves */
 	hipLaunchKernelGGL(k_finish_track, dim3(bv.B), dim3(bv.am == MTFHIP_AM_NCC ? 128 : 64), 0, st, bv, sm, ts, partials, nblk);
+}
+
+void launch_finish_track_mi(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, int sum_std, int gmode,
+	const double *mi_H, const double *gpart, int ng, double *rows, hipStream_t st) {
+	hipLaunchKernelGGL(k_finish_track_mi, dim3(bv.B), dim3(64), 0, st, bv, sm, ts, sum_std, gmode, mi_H, gpart, ng, rows);
 }
 
 } // namespace mtfhip

@@ -594,26 +594,6 @@ __global__ __launch_bounds__(kBlock) void k_mi_hess_finish(int S, int nb, const 
 }
 
 
-/* Device-side MI loop: lays g and H of the fused MI passes out as the reduced row k_finish_track reads for SSD
- * (ACC_H = upper triangle of -H, ACC_G = the Jacobian sum the search method scales: ESM halves it, NT/ESM.cc:246-255). */
-__global__ __launch_bounds__(64) void k_mi_pack_acc(int S, int B, int sum_std, int gmode, const double *mi_H, double *rows) {
-	const int t = blockIdx.x, lane = threadIdx.x;
-	const double *Hs = mi_H + 64 * (size_t)t, *gs = mi_H + 64 * (size_t)B + 16 * (size_t)t, *H2 = mi_H + 80 * (size_t)B + 64 * (size_t)t;
-	double *row = rows + (size_t)t * ACC_COUNT;
-	if (lane < ACC_COUNT - 36) row[36 + lane] = 0.0;
-	const int a = lane >> 3, c = lane & 7;
-	if (a <= c) {
-		double hv = 0.0;
-		if (c < S) { hv = Hs[c * S + a]; if (sum_std) hv = 0.5 * (hv + H2[c * S + a]); }
-		row[ACC_H + a * 8 - (a * (a - 1)) / 2 + (c - a)] = -hv;
-	}
-	__syncthreads();
-	if (lane < S) {
-		const double gt = gs[lane], g0 = gs[8 + lane];
-		row[ACC_G + lane] = gmode == 0 ? g0 : (gmode == 1 ? gt : (gmode == 2 ? 2.0 * gt : gt - g0));
-	}
-}
-
 /* ===================================================================== */
 /* launchers                                                              */
 /* ===================================================================== */
@@ -677,10 +657,6 @@ void launch_mi_hess_finish(const BatchView &bv, int nb, const double *partials, 
 	size_t lds = sizeof(double) * ((size_t)nb * nb * bv.S + 36);
 	hipLaunchKernelGGL(k_mi_hess_finish, dim3(bv.B), dim3(kBlock), lds, st, bv.S, nb, partials, nblk, row_len, tb, joint_off,
 		hist_off, transpose_q, out);
-}
-
-void launch_mi_pack_acc(const BatchView &bv, int sum_std, int gmode, const double *mi_H, double *rows, hipStream_t st) {
-	hipLaunchKernelGGL(k_mi_pack_acc, dim3(bv.B), dim3(64), 0, st, bv.S, bv.B, sum_std, gmode, mi_H, rows);
 }
 
 } // namespace mtfhip

@@ -93,7 +93,7 @@ struct TrackState {
 	int *n_iters;       /* [B] */
 	const double *ncc;    /* [B][8] NCC scalars (mean(I0), |I0 - mean|, ...), NULL for SSD */
 	const double *ncc_tm; /* [B][52] NCC template moments: sum J0 | sum I0 J0 | Gram(J0) */
-	int h_from_acc;       /* 1: every non-constant Hessian type reads the reduced row, ICLK's included (MI: k_mi_pack_acc) */
+	int h_from_acc;       /* 1: every non-constant Hessian type reads the reduced row, ICLK's included (MI: k_finish_track_mi) */
 };
 
 struct FusedArgs {
@@ -120,9 +120,9 @@ void launch_warped_img_grad(const BatchView &bv, const ImgView &im, const double
 	double eps, double mult, hipStream_t st);
 void launch_pix_jacobian(const BatchView &bv, int variant, const double *grad, double *J, hipStream_t st);
 void launch_mean_jacobian(const BatchView &bv, hipStream_t st);
-/* MI device-side loop: g and H of the fused MI passes (mi_H = [B][64] H | [B][16] Jacobian sums | [B][64] second H) as one
- * SSD-layout reduced row per target for k_finish_track.  gmode: 0 ICLK, 1 FCLK, 2 ESM Original, 3 ESM DiffOfJacs */
-void launch_mi_pack_acc(const BatchView &bv, int sum_std, int gmode, const double *mi_H, double *rows, hipStream_t st);
+/* MI device-side loop: g and H of the fused MI passes handed to the finish in one launch (k_finish_track_mi) */
+void launch_finish_track_mi(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, int sum_std, int gmode,
+	const double *mi_H, const double *gpart, int ng, double *rows, hipStream_t st);
 /* df_dI0 = It - I0 ; partial sums of r^2 into `partials` ([B][nblk][ACC_COUNT]) */
 void launch_ssd_residual(const BatchView &bv, double *partials, int nblk, hipStream_t st);
 void launch_negate(const double *src, double *dst, size_t n, hipStream_t st);

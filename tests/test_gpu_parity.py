@@ -303,7 +303,7 @@ def test_device_side_loop_ncc(oracle, gpu_ctx, frame, sm_kind, ssm, extra):
     (L.SM_ICLK, L.SSM_HOMOGRAPHY, dict()), (L.SM_ICLK, L.SSM_AFFINE, dict(hess_type=2)), (L.SM_ICLK, L.SSM_HOMOGRAPHY, dict(hess_type=1))],
     ids=lambda v: "_".join("%s%s" % kv for kv in v.items()) if isinstance(v, dict) else str(v))
 def test_device_side_loop_mi(oracle, gpu_ctx, frame, sm_kind, ssm, extra):
-    """mtfhip_batch_track with MI: the fused MI passes leave g and H on the device, k_mi_pack_acc hands them to the same
+    """mtfhip_batch_track with MI: the fused MI passes leave g and H on the device, k_finish_track_mi hands them to the same
     finish kernel (solve, compositional update, convergence test) -- every first-order type, against the oracle's trackers."""
     _device_loop(oracle, gpu_ctx, frame, sm_kind, ssm, L.AM_MI, 36, extra)
 
