@@ -61,6 +61,41 @@ def test_sharded_scoring_allgather_world2(n_cand):
     assert all(ok and n == n_cand for _, ok, n in res)
 
 
+def _worker_targets(rank, world, port, n_targets, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(1)           # the same target list on every rank
+        corners0 = rng.uniform(50, 400, size=(n_targets, 2, 4))
+        track = lambda c: (c.reshape(len(c), 8) * 0.01, c + 0.5)   # noqa: E731  stands in for Batch.track on this rank's block
+        sh = mdist.ShardedTargets(n_targets)
+        st, cr = track(sh.local(corners0))
+        states, corners = sh.gather(st, cr)
+        want_s, want_c = track(corners0)
+        q.put((rank, np.array_equal(states, want_s) and np.array_equal(corners, want_c), sh.hi - sh.lo))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_targets", [64, 7])
+def test_sharded_targets_gather_world2(n_targets):
+    """Config 5 / grid axis: each rank tracks its own block of targets, one gather of (state, corners) at the end."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_targets, args=(r, world, port, n_targets, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert sum(n for _, _, n in res) == n_targets
+
+
 def test_binary_multinomial_resampling_matches_oracle(oracle):
     from mtf_amd.sm import ParticleFilter
     rng = np.random.default_rng(4)
