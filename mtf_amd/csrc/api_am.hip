@@ -602,7 +602,7 @@ static int mi_lazy_fused(mtfhip_batch *b, int trig, int j_a, const mtfhip_sm_des
 		TimedScope ts(b->ctx, "mi_grad");
 		const int ng = std::min(simple_blocks_per_target(b->N), 64);
 		launch_mi_grad_gemv(b->view(), nb, b->mi_hist_norm, It, I0, b->d_mi_tb, iclk ? nullptr : b->buf[MTFHIP_BUF_JT],
-			sm.sm == MTFHIP_SM_FCLK ? nullptr : b->buf[MTFHIP_BUF_J0], L.cg ? b->buf[MTFHIP_BUF_DF_DIT] : nullptr,
+			sm.sm == MTFHIP_SM_FCLK ? nullptr : b->buf[MTFHIP_BUF_J0], mi_j0_rebuild(b), L.cg ? b->buf[MTFHIP_BUF_DF_DIT] : nullptr,
 			L.ig ? b->buf[MTFHIP_BUF_DF_DI0] : nullptr, b->d_partials, ng, st);
 		launch_finish_rows(b->d_partials, ng, 16, d_g, b->B, st);
 	}

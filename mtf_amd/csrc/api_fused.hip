@@ -517,7 +517,7 @@ static int mi_enqueue(mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPlan &p
 		const int ng = simple_blocks_per_target(b->N) < 64 ? simple_blocks_per_target(b->N) : 64;
 		launch_mi_grad_gemv(b->view(), nb, b->mi_hist_norm, It, I0, b->d_mi_tb,
 			pl.iclk ? nullptr : b->buf[pl.orig_jac ? MTFHIP_BUF_JM : MTFHIP_BUF_JT],
-			(pl.fclk || pl.orig_jac) ? nullptr : b->buf[MTFHIP_BUF_J0], sm->materialize ? b->buf[MTFHIP_BUF_DF_DIT] : nullptr,
+			(pl.fclk || pl.orig_jac) ? nullptr : b->buf[MTFHIP_BUF_J0], mi_j0_rebuild(b), sm->materialize ? b->buf[MTFHIP_BUF_DF_DIT] : nullptr,
 			sm->materialize ? b->buf[MTFHIP_BUF_DF_DI0] : nullptr, b->d_partials, ng, st);
 		if (reduce_g) launch_finish_rows(b->d_partials, ng, 16, d_g, b->B, st);   /* (the device-side loop sums the rows in its finish) */
 	}

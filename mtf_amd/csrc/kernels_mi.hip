@@ -362,7 +362,7 @@ __global__ __launch_bounds__(kBlock) void k_mi_grad(int N, int nb, double norm_m
  * -- and the Jacobian products df_dIt . Jt, df_dI0 . J0 (cmptCurrJacobian / cmptInitJacobian) in the same pass, so that
  * 2 x k_mi_grad, k_gemv and its reduction are one launch and It, I0 are read once.  Block partial rows: [8 | 8]. */
 __global__ __launch_bounds__(kBlock) void k_mi_grad_gemv(int N, int S, int nb, double norm_mult, const double *It_all, const double *I0_all,
-	const double *tb_all, const double *Jt_all, const double *J0_all, double *dft_out, double *df0_out, double *partials, int nblk) {
+	const double *tb_all, const double *Jt_all, const double *J0_all, MiJ0Rebuild rb, double *dft_out, double *df0_out, double *partials, int nblk) {
 	__shared__ double Tc[MI_NB * MI_NB], Ti[MI_NB * MI_NB];
 	__shared__ double lds[4 * 16];
 	const int t = blockIdx.y;
@@ -377,7 +377,22 @@ __global__ __launch_bounds__(kBlock) void k_mi_grad_gemv(int N, int S, int nb, d
 	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
 		double jt[kMaxS], j0[kMaxS];
 #pragma unroll
-		for (int s = 0; s < kMaxS; ++s) { jt[s] = (Jt && s < S) ? Jt[(size_t)s * N + i] : 0.0; j0[s] = (J0 && s < S) ? J0[(size_t)s * N + i] : 0.0; }
+		for (int s = 0; s < kMaxS; ++s) { jt[s] = (Jt && s < S) ? Jt[(size_t)s * N + i] : 0.0; j0[s] = (J0 && !rb.dI0 && s < S) ? J0[(size_t)s * N + i] : 0.0; }
+		if (J0 && rb.dI0) {
+			/* the template's steepest-descent row from dI0_dx and the grid point (32-40 B instead of 8 S), as the fused LK
+			 * kernel rebuilds it: cmptWarpedPixJacobian at the identity warp (Homography.cc:231-294: gradient / z) after a
+			 * chained initialize, cmptInitPixJacobian (:157-191) otherwise; Affine.cc:160-182, 213-242 coincide there */
+			const double *g0 = rb.dI0 + (size_t)t * 2 * N;
+			const double g0x = g0[i], g0y = g0[(size_t)N + i];
+			const double2 p0 = reinterpret_cast<const double2 *>(rb.pts + (size_t)t * 2 * N)[i];
+			if (rb.hom) {
+				double Ix0 = g0x, Iy0 = g0y;
+				if (!rb.init_variant) { const double inv = 1.0 / (rb.z ? rb.z[(size_t)t * N + i] : 1.0); Ix0 = g0x * inv; Iy0 = g0y * inv; }
+				hom_row(j0, Ix0, Iy0, p0.x, p0.y, p0.x, p0.y);
+			} else {
+				j0[0] = g0x; j0[1] = g0y; j0[2] = g0x * p0.x; j0[3] = g0x * p0.y; j0[4] = g0y * p0.x; j0[5] = g0y * p0.y; j0[6] = j0[7] = 0.0;
+			}
+		}
 		const BsplWin a = bspl_window(It[i], nb, norm_mult, false);
 		const BsplWin c0 = bspl_window(I0[i], nb, norm_mult, false);
 		double dft = 0, df0 = 0;
@@ -648,8 +663,8 @@ void launch_mi_hess(const BatchView &bv, int nb, double norm_mult, const double 
 }
 /* df_dIt, df_dI0 (optionally stored) and the two Jacobian products; partial rows of 16 (sum them with launch_finish_rows) */
 void launch_mi_grad_gemv(const BatchView &bv, int nb, double norm_mult, const double *It, const double *I0, const double *tb,
-	const double *Jt, const double *J0, double *df_dIt, double *df_dI0, double *partials, int nblk, hipStream_t st) {
-	hipLaunchKernelGGL(k_mi_grad_gemv, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv.N, bv.S, nb, norm_mult, It, I0, tb, Jt, J0, df_dIt, df_dI0,
+	const double *Jt, const double *J0, const MiJ0Rebuild &rb, double *df_dIt, double *df_dI0, double *partials, int nblk, hipStream_t st) {
+	hipLaunchKernelGGL(k_mi_grad_gemv, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv.N, bv.S, nb, norm_mult, It, I0, tb, Jt, J0, rb, df_dIt, df_dI0,
 		partials, nblk);
 }
 void launch_mi_hess_finish(const BatchView &bv, int nb, const double *partials, int nblk, int row_len, const double *tb,

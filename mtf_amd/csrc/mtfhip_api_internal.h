@@ -436,6 +436,20 @@ static int lazy_flush_ctx(mtfhip_ctx *c) {   /* called by everything that replac
 /* for entry points whose own kernels never read the current points (the AM's reductions over It / I0 / J buffers) */
 #define FLUSH_AM(b) do { if (b) { int _rc = lazy_flush(b, false); if (_rc) return _rc; } } while (0)
 
+/* MI gradient pass: rebuild the template rows instead of reading J0, under the conditions of FusedArgs::j0_recompute
+ * (J0 is the search method's own template Jacobian on the current grid) */
+static inline mtfhip::MiJ0Rebuild mi_j0_rebuild(const mtfhip_batch *b) {
+	mtfhip::MiJ0Rebuild rb{nullptr, nullptr, nullptr, 0, 0};
+	const bool ok = b->j0_is_template && b->j0_recompute_enabled && b->j0_template_corners_epoch == b->corners_epoch &&
+		b->buf[MTFHIP_BUF_DI0_DX] && b->buf[MTFHIP_BUF_INIT_PTS] && (b->unit_z || b->buf[MTFHIP_BUF_INIT_Z]);
+	if (ok) {
+		rb.dI0 = b->buf[MTFHIP_BUF_DI0_DX]; rb.pts = b->buf[MTFHIP_BUF_INIT_PTS];
+		rb.z = b->unit_z ? nullptr : b->buf[MTFHIP_BUF_INIT_Z];
+		rb.hom = b->desc.ssm == MTFHIP_SSM_HOMOGRAPHY; rb.init_variant = b->j0_variant == MTFHIP_JAC_INIT;
+	}
+	return rb;
+}
+
 /* ---- functions defined in one api_*.hip unit and used in another ---- */
 enum { LAZY_CURR_JAC = 0, LAZY_DIFF_JAC = 1, LAZY_INIT_JAC = 2 };
 int ensure_pts(mtfhip_batch *b);

@@ -161,8 +161,11 @@ void launch_mi_tables_iter(const BatchView &bv, int nb, double pre_seed, double 
 	int row_len, double *tb, double *f_out, hipStream_t st);
 void launch_mi_hist_self(const BatchView &bv, int nb, double norm_mult, const double *A, const double *Bv, double *partials,
 	int nblk, int row_len, hipStream_t st);
+/* dI0 != NULL: k_mi_grad_gemv rebuilds the template's steepest-descent row from dI0_dx [B][2][N], the grid points [B][N] x,y
+ * (and z [B][N] of the homogeneous grid, NULL = 1) instead of reading J0 -- valid under the conditions of FusedArgs::j0_recompute */
+struct MiJ0Rebuild { const double *dI0, *pts, *z; int hom, init_variant; };
 void launch_mi_grad_gemv(const BatchView &bv, int nb, double norm_mult, const double *It, const double *I0, const double *tb,
-	const double *Jt, const double *J0, double *df_dIt, double *df_dI0, double *partials, int nblk, hipStream_t st);
+	const double *Jt, const double *J0, const MiJ0Rebuild &rb, double *df_dIt, double *df_dI0, double *partials, int nblk, hipStream_t st);
 /* sums partials over blocks: out[B][ACC_COUNT] */
 void launch_finish(double *partials, int nblk, double *out, int B, hipStream_t st);
 void launch_finish_rows(double *partials, int nblk, int row_len, double *out, int B, hipStream_t st);
