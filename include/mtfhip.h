@@ -178,6 +178,14 @@ int mtfhip_ssm_get_warp(mtfhip_batch *b, double *warps /* B x 9 row-major */);
 /* applyWarpToCorners: ProjectiveBase.cc:137-144, Affine.cc:366-375 (host math) */
 int mtfhip_ssm_apply_warp_to_corners(mtfhip_batch *b, const double *in_corners, const double *states,
 	double *out_corners);
+/* ---- SSM functions that are 3 x 3 algebra on the host: no device and no context needed (corners / points x, y interleaved) ---- */
+int mtfhip_ssm_identity_warp(int ssm, double *state /* S */);                                         /* ProjectiveBase.cc:321-323 */
+int mtfhip_ssm_compose_warps(int ssm, const double *state_1, const double *state_2, double *composed);  /* ProjectiveBase.cc:324-331: W(state_2) * W(state_1) */
+int mtfhip_ssm_estimate_warp_from_corners(int ssm, const double *in_corners /* 8 */, const double *out_corners /* 8 */,
+	double *state_update /* S */);                                                                      /* Homography.cc:877-883, Affine.cc:352-357 */
+int mtfhip_ssm_apply_warp_to_pts(int ssm, const double *in_pts /* n x 2 */, int n_pts, const double *state, double *out_pts);
+                                                                                                       /* ProjectiveBase.cc:142-160, Affine.cc:382-393 */
+int mtfhip_ssm_additive_update(mtfhip_batch *b, const double *state_updates /* B x S */);              /* ProjectiveBase.cc:51-55 */
 
 /* ---- ImageBase / AppearanceModel side ----
  * `pts` arguments: NULL means "the SSM's device-resident points of this batch" (the fast path the

@@ -66,7 +66,8 @@ SYMBOLS = [
     "mtfhip_ssm_set_corners", "mtfhip_ssm_set_state", "mtfhip_ssm_compositional_update",
     "mtfhip_ssm_invert_state", "mtfhip_ssm_update_grad_pts", "mtfhip_ssm_cmpt_pix_jacobian",
     "mtfhip_ssm_get_corners", "mtfhip_ssm_get_init_corners", "mtfhip_ssm_get_state", "mtfhip_ssm_get_warp",
-    "mtfhip_ssm_apply_warp_to_corners",
+    "mtfhip_ssm_apply_warp_to_corners", "mtfhip_ssm_identity_warp", "mtfhip_ssm_compose_warps",
+    "mtfhip_ssm_estimate_warp_from_corners", "mtfhip_ssm_apply_warp_to_pts", "mtfhip_ssm_additive_update",
     "mtfhip_am_initialize_pix_vals", "mtfhip_am_update_pix_vals", "mtfhip_am_initialize_pix_grad",
     "mtfhip_am_update_pix_grad", "mtfhip_am_initialize_pix_grad_warped", "mtfhip_am_update_pix_grad_warped",
     "mtfhip_am_initialize_similarity", "mtfhip_am_initialize_grad", "mtfhip_am_initialize_hess",

@@ -261,6 +261,11 @@ class Batch:
     def get_pts(self):
         return self.read(BUF_CURR_PTS)
 
+    def additive_update(self, state_updates):
+        """ProjectiveBase::additiveUpdate (SSM/src/ProjectiveBase.cc:51-55)"""
+        s = _f64(state_updates).reshape(self.B, self.S)
+        L.check(L.lib().mtfhip_ssm_additive_update(self._h, _p(s)))
+
     def apply_warp_to_corners(self, corners, states):
         c = self._corners_in(corners)
         s = _f64(states).reshape(self.B, self.S)
@@ -442,3 +447,40 @@ class Batch:
     def score_candidates_dev(self, dev_states, n, dev_lik, dev_sim=None):
         L.check(L.lib().mtfhip_score_candidates_dev(self._h, C.c_void_p(dev_states), int(n), C.c_void_p(dev_lik),
                                                     C.c_void_p(dev_sim) if dev_sim else None))
+
+
+# ---- SSM functions that are 3 x 3 algebra on the host (no device, no context): ProjectiveBase.cc:142-160,321-331,
+# Homography.cc:877-883, Affine.cc:352-357,382-393 ----
+def _state_size(ssm):
+    return 8 if ssm == L.SSM_HOMOGRAPHY else 6
+
+
+def identity_warp(ssm):
+    out = np.empty(_state_size(ssm))
+    L.check(L.lib().mtfhip_ssm_identity_warp(ssm, _p(out)))
+    return out
+
+
+def compose_warps(ssm, state_1, state_2):
+    """state of W(state_2) * W(state_1), read back as the reference does (no renormalisation)"""
+    a, b, out = _f64(state_1).reshape(-1), _f64(state_2).reshape(-1), np.empty(_state_size(ssm))
+    L.check(L.lib().mtfhip_ssm_compose_warps(ssm, _p(a), _p(b), _p(out)))
+    return out
+
+
+def estimate_warp_from_corners(ssm, in_corners, out_corners):
+    """in_corners, out_corners: (2, 4).  Homography: the 4-point DLT; Affine: the least-squares affine map."""
+    a = np.ascontiguousarray(_f64(in_corners).reshape(2, 4).T); b = np.ascontiguousarray(_f64(out_corners).reshape(2, 4).T)
+    out = np.empty(_state_size(ssm))
+    L.check(L.lib().mtfhip_ssm_estimate_warp_from_corners(ssm, _p(a), _p(b), _p(out)))
+    return out
+
+
+def apply_warp_to_pts(ssm, pts, state):
+    """pts: (2, n) -> (2, n)"""
+    a = np.ascontiguousarray(_f64(pts).reshape(2, -1).T)
+    st = _f64(state).reshape(-1)
+    out = np.empty_like(a)
+    L.check(L.lib().mtfhip_ssm_apply_warp_to_pts(ssm, _p(a), a.shape[0], _p(st), _p(out)))
+    return out.T.copy()
+

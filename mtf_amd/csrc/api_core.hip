@@ -597,6 +597,93 @@ int mtfhip_ssm_apply_warp_to_corners(mtfhip_batch *b, const double *in_corners, 
 	return MTFHIP_OK;
 }
 
+/* ---- SSM functions that are 3 x 3 algebra on the host: no device, no context (callable on a machine without a GPU) ---- */
+static int ssm_kind_ok(int ssm, const char *fn) {
+	if (ssm != MTFHIP_SSM_HOMOGRAPHY && ssm != MTFHIP_SSM_AFFINE) return fail(MTFHIP_ERR_INVALID_ARG, "%s: unknown state space model %d", fn, ssm);
+	return MTFHIP_OK;
+}
+int mtfhip_ssm_identity_warp(int ssm, double *state) {
+	TRY(ssm_kind_ok(ssm, "identity_warp"));
+	if (!state) return fail(MTFHIP_ERR_INVALID_ARG, "identity_warp: NULL argument");
+	std::memset(state, 0, sizeof(double) * (ssm == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6));
+	return MTFHIP_OK;
+}
+int mtfhip_ssm_compose_warps(int ssm, const double *state_1, const double *state_2, double *composed) {
+	TRY(ssm_kind_ok(ssm, "compose_warps"));
+	if (!state_1 || !state_2 || !composed) return fail(MTFHIP_ERR_INVALID_ARG, "compose_warps: NULL argument");
+	const int S = ssm == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
+	double p1[8] = {0}, p2[8] = {0}, out[8] = {0};
+	std::memcpy(p1, state_1, sizeof(double) * S); std::memcpy(p2, state_2, sizeof(double) * S);
+	/* warp_2 * warp_1, read back entry by entry: the reference does not renormalise by (2, 2) here (ProjectiveBase.cc:324-331) */
+	state_from_warp(ssm, out, m3_mul(warp_from_state(ssm, p2), warp_from_state(ssm, p1)));
+	std::memcpy(composed, out, sizeof(double) * S);
+	return MTFHIP_OK;
+}
+int mtfhip_ssm_estimate_warp_from_corners(int ssm, const double *in_corners, const double *out_corners, double *state_update) {
+	TRY(ssm_kind_ok(ssm, "estimate_warp_from_corners"));
+	if (!in_corners || !out_corners || !state_update) return fail(MTFHIP_ERR_INVALID_ARG, "estimate_warp_from_corners: NULL argument");
+	double out[8] = {0};
+	if (ssm == MTFHIP_SSM_HOMOGRAPHY) {
+		/* the 4-point DLT (warpUtils.cc:171-224) is the unique homography through the four pairs: unit square -> out composed
+		 * with the inverse of unit square -> in, scaled to (2, 2) = 1 (Homography.cc:877-883) */
+		M3 Qi, Qo;
+		if (!rect_to_quad(0, 0, 1, 1, in_corners, Qi) || !rect_to_quad(0, 0, 1, 1, out_corners, Qo))
+			return fail(MTFHIP_ERR_INVALID_ARG, "estimate_warp_from_corners: degenerate corners");
+		M3 H = m3_mul(Qo, m3_inverse(Qi));
+		if (H.m[8] == 0 || !std::isfinite(H.m[8])) return fail(MTFHIP_ERR_INVALID_ARG, "estimate_warp_from_corners: degenerate corners");
+		for (int i = 0; i < 9; ++i) H.m[i] /= H.m[8];
+		H.m[8] = 1;
+		state_from_warp(ssm, out, H);
+	} else {
+		/* least-squares affine map of the four pairs (computeAffineDLT, warpUtils.cc:276-342: pseudo-inverse of the 8 x 6
+		 * system, whose x and y halves share the 3 x 3 normal matrix) */
+		M3 G{{0, 0, 0, 0, 0, 0, 0, 0, 0}};
+		double bx[3] = {0, 0, 0}, by[3] = {0, 0, 0};
+		for (int q = 0; q < 4; ++q) {
+			const double r[3] = {in_corners[2 * q], in_corners[2 * q + 1], 1.0};
+			for (int i = 0; i < 3; ++i) {
+				for (int j = 0; j < 3; ++j) G.m[3 * i + j] += r[i] * r[j];
+				bx[i] += r[i] * out_corners[2 * q]; by[i] += r[i] * out_corners[2 * q + 1];
+			}
+		}
+		const double det = G.m[0] * (G.m[4] * G.m[8] - G.m[5] * G.m[7]) - G.m[1] * (G.m[3] * G.m[8] - G.m[5] * G.m[6]) +
+			G.m[2] * (G.m[3] * G.m[7] - G.m[4] * G.m[6]);
+		if (det == 0 || !std::isfinite(det)) return fail(MTFHIP_ERR_INVALID_ARG, "estimate_warp_from_corners: degenerate corners");
+		const M3 Gi = m3_inverse(G);
+		M3 W = m3_identity();
+		for (int i = 0; i < 3; ++i) {
+			W.m[i] = Gi.m[3 * i] * bx[0] + Gi.m[3 * i + 1] * bx[1] + Gi.m[3 * i + 2] * bx[2];
+			W.m[3 + i] = Gi.m[3 * i] * by[0] + Gi.m[3 * i + 1] * by[1] + Gi.m[3 * i + 2] * by[2];
+		}
+		state_from_warp(ssm, out, W);
+	}
+	std::memcpy(state_update, out, sizeof(double) * (ssm == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6));
+	return MTFHIP_OK;
+}
+int mtfhip_ssm_apply_warp_to_pts(int ssm, const double *in_pts, int n_pts, const double *state, double *out_pts) {
+	TRY(ssm_kind_ok(ssm, "apply_warp_to_pts"));
+	if (!in_pts || !state || !out_pts || n_pts < 0) return fail(MTFHIP_ERR_INVALID_ARG, "apply_warp_to_pts: invalid argument");
+	double p[8] = {0};
+	std::memcpy(p, state, sizeof(double) * (ssm == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6));
+	const M3 W = warp_from_state(ssm, p);
+	for (int i = 0; i < n_pts; ++i) {
+		const double x = in_pts[2 * i], y = in_pts[2 * i + 1];
+		double nx = W.m[0] * x + W.m[1] * y + W.m[2], ny = W.m[3] * x + W.m[4] * y + W.m[5];
+		if (ssm == MTFHIP_SSM_HOMOGRAPHY) { const double d = W.m[6] * x + W.m[7] * y + W.m[8]; nx = nx / d; ny = ny / d; }
+		out_pts[2 * i] = nx; out_pts[2 * i + 1] = ny;
+	}
+	return MTFHIP_OK;
+}
+/* ProjectiveBase::additiveUpdate SSM/src/ProjectiveBase.cc:51-55: curr_state += update; setState(curr_state) */
+int mtfhip_ssm_additive_update(mtfhip_batch *b, const double *state_updates) {
+	if (!b || !state_updates) return fail(MTFHIP_ERR_INVALID_ARG, "additive_update: NULL argument");
+	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "additive_update before set_corners");
+	std::vector<double> st((size_t)b->B * b->S);
+	for (int t = 0; t < b->B; ++t)
+		for (int s = 0; s < b->S; ++s) st[(size_t)t * b->S + s] = b->th[t].state[s] + state_updates[(size_t)t * b->S + s];
+	return mtfhip_ssm_set_state(b, st.data());
+}
+
 /* ------------------------------------------------------------------ timing */
 int mtfhip_timing_enable(mtfhip_ctx *c, int on) {
 	if (!c) return fail(MTFHIP_ERR_INVALID_ARG, "timing_enable: NULL ctx");

@@ -40,6 +40,7 @@ def lib():
         H.mtfhost_get_region.argtypes = [C.c_void_p, C.c_void_p]
         H.mtfhost_destroy.argtypes = [C.c_void_p]
         H.mtfhost_qr_solve.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        H.mtfhost_ssm_algebra.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _h = H
     return _h
 
@@ -98,6 +99,15 @@ class CppTracker:
         _check(lib().mtfhost_update(self._h, C.byref(n)))
         self.iters = n.value
         return self.get_region()
+
+    def ssm_algebra(self, what, a=None, b=None, n_out=None):
+        """StateSpaceModel virtuals that are host algebra (see mtfhost_ssm_algebra)"""
+        za = np.ascontiguousarray(a, dtype=np.float64) if a is not None else np.zeros(8)
+        zb = np.ascontiguousarray(b, dtype=np.float64) if b is not None else np.zeros(8)
+        out = np.zeros(n_out or 8)
+        _check(lib().mtfhost_ssm_algebra(self._h, int(what), za.ctypes.data_as(C.c_void_p), zb.ctypes.data_as(C.c_void_p),
+                                         out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def get_region(self):
         out = np.empty(8)

@@ -218,6 +218,27 @@ void HipSSM::invertState(VectorXd &inv, const VectorXd &s) { HipPair::check(mtfh
 void HipSSM::applyWarpToCorners(CornersT &out, const CornersT &in, const VectorXd &s) {
 	HipPair::check(mtfhip_ssm_apply_warp_to_corners(p->b, in.data(), s.data(), out.data()));
 }
+void HipSSM::additiveUpdate(const VectorXd &dp) {
+	if (dp.size() != p->S) throw utils::InvalidArgument("additiveUpdate: state update has invalid size");
+	HipPair::check(mtfhip_ssm_additive_update(p->b, dp.data())); syncSmall();
+}
+void HipSSM::applyWarpToPts(PtsT &out, const PtsT &in, const VectorXd &s) {
+	if (out.rows() != in.rows() || out.cols() != in.cols()) out.resize(in.rows(), in.cols());
+	HipPair::check(mtfhip_ssm_apply_warp_to_pts(p->ssm, in.data(), in.cols(), s.data(), out.data()));   /* 2 x n column-major = x, y interleaved */
+}
+void HipSSM::getIdentityWarp(VectorXd &w) {
+	if (w.size() != p->S) w.resize(p->S);
+	HipPair::check(mtfhip_ssm_identity_warp(p->ssm, w.data()));
+}
+void HipSSM::composeWarps(VectorXd &out, const VectorXd &s1, const VectorXd &s2) {
+	if (s1.size() != p->S || s2.size() != p->S) throw utils::InvalidArgument("composeWarps: state has invalid size");
+	if (out.size() != p->S) out.resize(p->S);
+	HipPair::check(mtfhip_ssm_compose_warps(p->ssm, s1.data(), s2.data(), out.data()));
+}
+void HipSSM::estimateWarpFromCorners(VectorXd &out, const CornersT &in, const CornersT &oc) {
+	if (out.size() != p->S) throw utils::InvalidArgument("estimateWarpFromCorners: state update has invalid size");   /* validate_ssm_state */
+	HipPair::check(mtfhip_ssm_estimate_warp_from_corners(p->ssm, in.data(), oc.data(), out.data()));
+}
 int HipSSM::gradBuffer(const PixGradT &g) {
 	if (g.data() == p->init_grad_key) return MTFHIP_BUF_DI0_DX;
 	if (g.data() == p->curr_grad_key) return MTFHIP_BUF_DIT_DX;

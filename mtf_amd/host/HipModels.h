@@ -136,6 +136,12 @@ public:
 	void cmptWarpedPixHessian(MatrixXd &D, const PixHessT &h, const PixGradT &g) override { pixHess(MTFHIP_JAC_WARPED, D, h, g); }
 	void cmptApproxPixHessian(MatrixXd &D, const PixHessT &h, const PixGradT &g) override { pixHess(MTFHIP_JAC_APPROX, D, h, g); }
 	void applyWarpToCorners(CornersT &out, const CornersT &in, const VectorXd &state) override;
+	/* 3 x 3 algebra on the host, no device work (ProjectiveBase.cc:51-55,142-160,321-331; Homography.cc:877-883; Affine.cc:352-357,382-393) */
+	void additiveUpdate(const VectorXd &state_update) override;
+	void applyWarpToPts(PtsT &out, const PtsT &in, const VectorXd &state) override;
+	void getIdentityWarp(VectorXd &identity_warp) override;
+	void composeWarps(VectorXd &composed, const VectorXd &state_1, const VectorXd &state_2) override;
+	void estimateWarpFromCorners(VectorXd &state_update, const CornersT &in_corners, const CornersT &out_corners) override;
 private:
 	std::shared_ptr<HipPair> p;
 	PtsT curr_pts;

@@ -48,6 +48,10 @@ public:
 	virtual void cmptWarpedPixHessian(MatrixXd &, const PixHessT &, const PixGradT &) { ssm_func_not_implemeted(cmptWarpedPixHessian); }
 	virtual void cmptApproxPixHessian(MatrixXd &, const PixHessT &, const PixGradT &) { ssm_func_not_implemeted(cmptApproxPixHessian); }
 	virtual void applyWarpToCorners(CornersT &, const CornersT &, const VectorXd &) { ssm_func_not_implemeted(applyWarpToCorners); }
+	virtual void applyWarpToPts(PtsT &, const PtsT &, const VectorXd &) { ssm_func_not_implemeted(applyWarpToPts); }
+	virtual void getIdentityWarp(VectorXd &) { ssm_func_not_implemeted(getIdentityWarp); }                      /* StateSpaceModel.h:200-280 */
+	virtual void composeWarps(VectorXd &, const VectorXd &, const VectorXd &) { ssm_func_not_implemeted(composeWarps); }
+	virtual void estimateWarpFromCorners(VectorXd &, const CornersT &, const CornersT &) { ssm_func_not_implemeted(estimateWarpFromCorners); }
 
 	virtual void setFirstIter() { first_iter = true; }
 	virtual void clearFirstIter() { first_iter = false; }

@@ -72,6 +72,31 @@ int mtfhost_get_region(mtfhost_tracker *t, double *corners) {
 	return guarded(t, [](mtfhost_tracker *tt, const void *, void *out) {
 		std::memcpy(out, tt->sm->getRegion().v, sizeof(double) * 8); }, nullptr, corners);
 }
+/* the SSM's host-side algebra through the StateSpaceModel virtuals (tests): what = 0 getIdentityWarp(out S), 1 composeWarps(out S;
+ * a, b states), 2 estimateWarpFromCorners(out S; a, b corners 2 x 4), 3 applyWarpToCorners(out 8; a corners, b state),
+ * 4 additiveUpdate(a) then getState(out S) */
+int mtfhost_ssm_algebra(mtfhost_tracker *t, int what, const double *a, const double *b, double *out) {
+	try {
+		StateSpaceModel *ssm = t->ssm.get();
+		const int S = (int)ssm->getStateSize();
+		VectorXd r(S), va(S), vb(S);
+		CornersT ca, cb;
+		if (what == 1 || what == 4) std::memcpy(va.data(), a, sizeof(double) * S);
+		if (what == 1 || what == 3) std::memcpy(vb.data(), b, sizeof(double) * S);
+		if (what == 2 || what == 3) std::memcpy(ca.data(), a, sizeof(double) * 8);
+		if (what == 2) std::memcpy(cb.data(), b, sizeof(double) * 8);
+		switch (what) {
+		case 0: ssm->getIdentityWarp(r); break;
+		case 1: ssm->composeWarps(r, va, vb); break;
+		case 2: ssm->estimateWarpFromCorners(r, ca, cb); break;
+		case 3: { CornersT o; ssm->applyWarpToCorners(o, ca, vb); std::memcpy(out, o.data(), sizeof(double) * 8); return 0; }
+		case 4: ssm->additiveUpdate(va); r = ssm->getState(); break;
+		default: g_err = "mtfhost_ssm_algebra: unknown selector"; return -1;
+		}
+		std::memcpy(out, r.data(), sizeof(double) * S);
+		return 0;
+	} catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
 /* host-only helper exercised by the CPU tests */
 int mtfhost_qr_solve(int n, const double *A_colmajor, const double *b, double *x) {
 	try {

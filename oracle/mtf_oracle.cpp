@@ -961,6 +961,57 @@ struct mtfo_ssm {
 			}
 		}
 	}
+	/* ProjectiveBase::applyWarpToPts SSM/src/ProjectiveBase.cc:142-160 ; Affine::applyWarpToPts SSM/src/Affine.cc:382-393 */
+	void apply_warp_to_pts(double *out, const double *in, int n_pts, const double *p) const {
+		Mat3 W = warp_from_state(p);
+		for (int i = 0; i < n_pts; ++i) {
+			double x = in[2 * i], y = in[2 * i + 1];
+			if (kind == MTFO_SSM_HOMOGRAPHY) {
+				double discr = W(2, 0) * x + W(2, 1) * y + W(2, 2);
+				out[2 * i] = (W(0, 0) * x + W(0, 1) * y + W(0, 2)) / discr;
+				out[2 * i + 1] = (W(1, 0) * x + W(1, 1) * y + W(1, 2)) / discr;
+			} else {
+				out[2 * i] = W(0, 0) * x + W(0, 1) * y + W(0, 2);
+				out[2 * i + 1] = W(1, 0) * x + W(1, 1) * y + W(1, 2);
+			}
+		}
+	}
+	/* ProjectiveBase::composeWarps SSM/src/ProjectiveBase.cc:324-331: warp_2 * warp_1, state read back without
+	 * renormalising (2, 2) */
+	void compose_warps(double *out, const double *p1, const double *p2) const {
+		Mat3 W1 = warp_from_state(p1), W2 = warp_from_state(p2);
+		state_from_warp(out, mul3(W2, W1));
+	}
+	/* Homography::estimateWarpFromCorners SSM/src/Homography.cc:877-883 (DLT, / (2, 2)) ;
+	 * Affine::estimateWarpFromCorners SSM/src/Affine.cc:352-357 with utils::computeAffineDLT
+	 * Utilities/src/warpUtils.cc:276-342: least-squares solution of the 8 x 6 system [x y 1 0 0 0; 0 0 0 x y 1] a = out
+	 * (the reference takes it from the thin SVD; the normal equations give the same minimiser for a full-rank system) */
+	void estimate_warp_from_corners(double *out, const double *in_c, const double *out_c) const {
+		if (kind == MTFO_SSM_HOMOGRAPHY) {
+			Mat3 H = homography_dlt(in_c, out_c);
+			div3(H, H(2, 2));
+			state_from_warp(out, H);
+			return;
+		}
+		double AtA[36] = {0}, Atb[6] = {0}, x[6];
+		for (int i = 0; i < 4; ++i) {
+			double r1[6] = {in_c[2 * i], in_c[2 * i + 1], 1, 0, 0, 0}, r2[6] = {0, 0, 0, in_c[2 * i], in_c[2 * i + 1], 1};
+			for (int a = 0; a < 6; ++a) {
+				for (int b = 0; b < 6; ++b) AtA[b * 6 + a] += r1[a] * r1[b] + r2[a] * r2[b];
+				Atb[a] += r1[a] * out_c[2 * i] + r2[a] * out_c[2 * i + 1];
+			}
+		}
+		colpiv_qr_solve(6, AtA, Atb, x);
+		Mat3 W = identity3();
+		W(0, 0) = x[0]; W(0, 1) = x[1]; W(0, 2) = x[2]; W(1, 0) = x[3]; W(1, 1) = x[4]; W(1, 2) = x[5];
+		state_from_warp(out, W);
+	}
+	/* ProjectiveBase::additiveUpdate SSM/src/ProjectiveBase.cc:51-55 */
+	void additive_update(const double *dp) {
+		vecd p(state);
+		for (int i = 0; i < S; ++i) p[i] += dp[i];
+		set_state(p.data());
+	}
 	/* Homography::compositionalRandomWalk SSM/src/Homography.cc:916-926 with the
 	 * perturbation supplied by the caller (the Boost RNG is not reproducible) */
 	void compositional_random_walk(double *out, const double *base, const double *pert) const {
@@ -2022,6 +2073,10 @@ int mtfo_ssm_cmpt_pix_hessian(mtfo_ssm *s, double *d2, const double *ph, const d
 int mtfo_ssm_cmpt_warped_pix_hessian(mtfo_ssm *s, double *d2, const double *ph, const double *g) { s->warped_pix_hessian(d2, ph, g); return 0; }
 int mtfo_ssm_cmpt_approx_pix_hessian(mtfo_ssm *s, double *d2, const double *ph, const double *g) { return s->approx_pix_hessian(d2, ph, g); }
 void mtfo_ssm_apply_warp_to_corners(mtfo_ssm *s, double *out, const double *in, const double *p) { s->apply_warp_to_corners(out, in, p); }
+void mtfo_ssm_apply_warp_to_pts(mtfo_ssm *s, double *out, const double *in, int n_pts, const double *p) { s->apply_warp_to_pts(out, in, n_pts, p); }
+void mtfo_ssm_compose_warps(mtfo_ssm *s, double *out, const double *p1, const double *p2) { s->compose_warps(out, p1, p2); }
+void mtfo_ssm_estimate_warp_from_corners(mtfo_ssm *s, double *out, const double *in_c, const double *out_c) { s->estimate_warp_from_corners(out, in_c, out_c); }
+void mtfo_ssm_additive_update(mtfo_ssm *s, const double *dp) { s->additive_update(dp); }
 void mtfo_ssm_compositional_random_walk(mtfo_ssm *s, double *out, const double *base, const double *pert) {
 	s->compositional_random_walk(out, base, pert);
 }

@@ -82,6 +82,10 @@ int mtfo_ssm_cmpt_warped_pix_hessian(mtfo_ssm *s, double *d2, const double *pix_
 int mtfo_ssm_cmpt_approx_pix_hessian(mtfo_ssm *s, double *d2, const double *pix_hess, const double *pix_grad);
 void mtfo_ssm_apply_warp_to_corners(mtfo_ssm *s, double *out_corners,
 	const double *in_corners, const double *state);
+void mtfo_ssm_apply_warp_to_pts(mtfo_ssm *s, double *out_pts, const double *in_pts, int n_pts, const double *state);
+void mtfo_ssm_compose_warps(mtfo_ssm *s, double *composed, const double *state_1, const double *state_2);
+void mtfo_ssm_estimate_warp_from_corners(mtfo_ssm *s, double *state_update, const double *in_corners, const double *out_corners);
+void mtfo_ssm_additive_update(mtfo_ssm *s, const double *state_update);
 void mtfo_ssm_compositional_random_walk(mtfo_ssm *s, double *perturbed_state,
 	const double *base_state, const double *perturbation);
 /* what: 0 curr_pts(2N) 1 init_pts(2N) 2 curr_corners(8) 3 init_corners(8)

@@ -188,6 +188,27 @@ class SSM:
     def update_grad_pts(self, eps):
         lib().mtfo_ssm_update_grad_pts(self.h, C.c_double(eps))
 
+    def apply_warp_to_pts(self, pts, p):
+        """pts: (2, n) -> (2, n)"""
+        a = np.ascontiguousarray(np.asarray(pts, dtype=np.float64).T)
+        out = np.empty_like(a)
+        lib().mtfo_ssm_apply_warp_to_pts(self.h, _d(out), _d(a), C.c_int(a.shape[0]), _d(_vec(p)))
+        return out.T.copy()
+
+    def compose_warps(self, p1, p2):
+        out = np.empty(self.S)
+        lib().mtfo_ssm_compose_warps(self.h, _d(out), _d(_vec(p1)), _d(_vec(p2)))
+        return out
+
+    def estimate_warp_from_corners(self, in_corners, out_corners):
+        out = np.empty(self.S)
+        a = np.ascontiguousarray(np.asarray(in_corners, dtype=np.float64).T); b = np.ascontiguousarray(np.asarray(out_corners, dtype=np.float64).T)
+        lib().mtfo_ssm_estimate_warp_from_corners(self.h, _d(out), _d(a), _d(b))
+        return out
+
+    def additive_update(self, dp):
+        lib().mtfo_ssm_additive_update(self.h, _d(_vec(dp)))
+
     def _jac(self, fn, grad):
         grad = _vec(grad)
         J = np.empty(self.P * self.S)

@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 
+import numpy as np
 import pytest
 
 import mtf_amd
@@ -61,3 +62,32 @@ def test_product_does_not_reach_into_the_oracle():
                 if re.search(r"oracle_py|mtf_oracle|numpy_ref|libmtf_oracle", s):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("ssm", [0, 1], ids=["homography", "affine"])
+def test_host_side_ssm_algebra_matches_oracle(oracle, ssm):
+    """The SSM functions that are pure 3 x 3 algebra run on the host and need neither a device nor a context
+    (ProjectiveBase.cc:142-160,321-331, Homography.cc:877-883, Affine.cc:352-357,382-393): against the oracle's restatement."""
+    import mtf_amd
+    from mtf_amd import synth
+    rng = np.random.default_rng(91)
+    S = 8 if ssm == mtf_amd.SSM_HOMOGRAPHY else 6
+    o = oracle.SSM(ssm, 10, 10)
+    scale = np.array([.02, .02, 2, .02, .02, 2, 1e-4, 1e-4]) if S == 8 else np.array([2, 2, .02, .02, .02, .02])
+    p1, p2 = rng.uniform(-1, 1, S) * scale, rng.uniform(-1, 1, S) * scale
+    assert np.array_equal(mtf_amd.identity_warp(ssm), np.zeros(S))
+    np.testing.assert_allclose(mtf_amd.compose_warps(ssm, p1, p2), o.compose_warps(p1, p2), rtol=1e-13, atol=1e-15)
+    pts = rng.uniform(0, 400, size=(2, 37))
+    np.testing.assert_allclose(mtf_amd.apply_warp_to_pts(ssm, pts, p1), o.apply_warp_to_pts(pts, p1), rtol=1e-14)
+    cin = synth.square_corners(200, 180, 90) + rng.uniform(-3, 3, size=(2, 4))
+    for trial in range(3):
+        cout = o.apply_warp_to_pts(cin, p2) + (0 if trial == 0 else rng.uniform(-2, 2, size=(2, 4)))
+        got, want = mtf_amd.estimate_warp_from_corners(ssm, cin, cout), o.estimate_warp_from_corners(cin, cout)
+        np.testing.assert_allclose(got, want, rtol=1e-7, atol=1e-9)
+        if trial == 0:   # corners that ARE a warp of the SSM's family: the warp comes back
+            np.testing.assert_allclose(got, p2, rtol=1e-7, atol=1e-9)
+        if ssm == mtf_amd.SSM_HOMOGRAPHY:   # four pairs determine the homography: it maps every corner exactly
+            np.testing.assert_allclose(mtf_amd.apply_warp_to_pts(ssm, cin, got), cout, rtol=0, atol=1e-8)
+    with pytest.raises(mtf_amd.InvalidArgument):
+        mtf_amd.estimate_warp_from_corners(ssm, np.zeros((2, 4)), cin)
+

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from mtf_amd import _lib as L
+import mtf_amd
 from mtf_amd import host, synth
 
 
@@ -132,3 +133,29 @@ def test_cpp_multichannel_trackers(oracle, am, sm):
     out = trk.update()
     np.testing.assert_allclose(out, otrk.get_region(), atol=2e-3)
     assert abs(trk.iters - o_iters) <= 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ssm", [L.SSM_HOMOGRAPHY, L.SSM_AFFINE])
+def test_cpp_ssm_algebra_virtuals(frame, ssm):
+    """getIdentityWarp / composeWarps / estimateWarpFromCorners / applyWarpToCorners / additiveUpdate called through the
+    StateSpaceModel base class of the C++ layer: the same numbers as the C-ABI functions (held to the oracle on the CPU by
+    tests/test_abi.py)."""
+    rng = np.random.default_rng(93)
+    S = 8 if ssm == L.SSM_HOMOGRAPHY else 6
+    scale = np.array([.02, .02, 2, .02, .02, 2, 1e-4, 1e-4]) if S == 8 else np.array([2, 2, .02, .02, .02, .02])
+    p1, p2 = rng.uniform(-1, 1, S) * scale, rng.uniform(-1, 1, S) * scale
+    trk = host.CppTracker(L.SM_FCLK, L.AM_SSD, ssm, 20, 20, max_iters=2)
+    trk.set_image(frame)
+    c0 = synth.square_corners(220, 210, 60)
+    trk.initialize(c0)
+    cflat = np.ascontiguousarray(c0.T).reshape(-1)
+    assert np.array_equal(trk.ssm_algebra(0, n_out=S), np.zeros(S))
+    np.testing.assert_array_equal(trk.ssm_algebra(1, p1, p2, n_out=S), mtf_amd.compose_warps(ssm, p1, p2))
+    cout = mtf_amd.apply_warp_to_pts(ssm, c0, p2)
+    np.testing.assert_array_equal(trk.ssm_algebra(3, cflat, p2, n_out=8).reshape(4, 2).T, cout)
+    est = trk.ssm_algebra(2, cflat, np.ascontiguousarray(cout.T).reshape(-1), n_out=S)
+    np.testing.assert_allclose(est, p2, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(trk.ssm_algebra(4, p1, n_out=S), p1, rtol=0, atol=1e-15)    # state was 0 after initialize
+    np.testing.assert_allclose(trk.get_region(), mtf_amd.apply_warp_to_pts(ssm, c0, p1), rtol=0, atol=1e-9)
+
