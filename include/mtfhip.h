@@ -193,6 +193,10 @@ int mtfhip_ssm_additive_update(mtfhip_batch *b, const double *state_updates /* B
  * otherwise B x 2N (or B x 8N) host doubles that are uploaded first. */
 int mtfhip_am_initialize_pix_vals(mtfhip_batch *b, const double *pts);      /* ImageBase.cc:62-99 */
 int mtfhip_am_update_pix_vals(mtfhip_batch *b, const double *pts);          /* ImageBase.cc:268-290 */
+/* SSD::updateModel AM/src/SSD.cc:49-75, NCC::updateModel AM/src/NCC.cc:539-566 (called by the search methods when enable_learning is
+ * set, NT/ESM.cc:293-295): template <- running (learning_rate outside [0, 1]) or weighted average with the patch at pts (NULL = the
+ * current points), then AppearanceModel::reinitialize.  MI: ERR_NOT_IMPLEMENTED, as in the reference. */
+int mtfhip_am_update_model(mtfhip_batch *b, const double *pts /* B x N x 2 or NULL */, double learning_rate);
 int mtfhip_am_initialize_pix_grad(mtfhip_batch *b, const double *pts);      /* ImageBase.cc:101-132 (PtsT) */
 int mtfhip_am_update_pix_grad(mtfhip_batch *b, const double *pts);          /* ImageBase.cc:292-314 */
 int mtfhip_am_initialize_pix_grad_warped(mtfhip_batch *b, const double *grad_pts); /* ImageBase.cc:134-172 */

@@ -68,7 +68,7 @@ SYMBOLS = [
     "mtfhip_ssm_get_corners", "mtfhip_ssm_get_init_corners", "mtfhip_ssm_get_state", "mtfhip_ssm_get_warp",
     "mtfhip_ssm_apply_warp_to_corners", "mtfhip_ssm_identity_warp", "mtfhip_ssm_compose_warps",
     "mtfhip_ssm_estimate_warp_from_corners", "mtfhip_ssm_apply_warp_to_pts", "mtfhip_ssm_additive_update",
-    "mtfhip_am_initialize_pix_vals", "mtfhip_am_update_pix_vals", "mtfhip_am_initialize_pix_grad",
+    "mtfhip_am_initialize_pix_vals", "mtfhip_am_update_pix_vals", "mtfhip_am_update_model", "mtfhip_am_initialize_pix_grad",
     "mtfhip_am_update_pix_grad", "mtfhip_am_initialize_pix_grad_warped", "mtfhip_am_update_pix_grad_warped",
     "mtfhip_am_initialize_similarity", "mtfhip_am_initialize_grad", "mtfhip_am_initialize_hess",
     "mtfhip_am_update_similarity", "mtfhip_am_update_curr_grad", "mtfhip_am_update_init_grad",

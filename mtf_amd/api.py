@@ -292,6 +292,11 @@ class Batch:
         keep, p = self._pts_arg(pts, 2)
         L.check(L.lib().mtfhip_am_update_pix_vals(self._h, p))
 
+    def update_model(self, pts=None, learning_rate=0.5):
+        """SSD / NCC::updateModel (AM/src/SSD.cc:49-75): online template update at pts (None = the current points)"""
+        keep, p = self._pts_arg(pts, 2)
+        L.check(L.lib().mtfhip_am_update_model(self._h, p, C.c_double(learning_rate)))
+
     def initialize_pix_grad(self, pts=None, warped=False):
         keep, p = self._pts_arg(pts, 8 if warped else 2)
         fn = L.lib().mtfhip_am_initialize_pix_grad_warped if warped else L.lib().mtfhip_am_initialize_pix_grad

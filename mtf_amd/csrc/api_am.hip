@@ -15,6 +15,7 @@ int mtfhip_am_initialize_pix_vals(mtfhip_batch *b, const double *pts) {
 	TRY(need_image(b));
 	const double *dp;
 	TRY(resolve_pts(b, pts, MTFHIP_BUF_CURR_PTS, 2 * (size_t)b->NP, &dp));
+	++b->frame_count;   /* ImageBase.cc:74 */
 	{
 		TimedScope ts(b->ctx, "sample");
 		launch_sample(b->view(), b->ctx->img, dp, b->buf[MTFHIP_BUF_I0], b->norm_mult, b->norm_add, b->ctx->stream);
@@ -24,6 +25,35 @@ int mtfhip_am_initialize_pix_vals(mtfhip_batch *b, const double *pts) {
 		b->init_pix_vals = true;
 		b->it_valid = true;
 	}
+	return MTFHIP_OK;
+}
+/* SSD::updateModel AM/src/SSD.cc:49-75, NCC::updateModel AM/src/NCC.cc:539-566 (the search methods call it at the end of update()
+ * when enable_learning is set, NT/ESM.cc:293-295): template <- average with the patch at pts, then AppearanceModel::reinitialize
+ * (AppearanceModel.h:119-123).  learning_rate outside [0, 1] = running average over the frames seen (SSD.cc:45). */
+int mtfhip_am_update_model(mtfhip_batch *b, const double *pts, double learning_rate) {
+	FLUSH(b);
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "update_model: NULL batch");
+	if (b->desc.am == MTFHIP_AM_MI) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "updateModel :: MI has no online template update in the reference either");
+	if (b->desc.am != MTFHIP_AM_SSD && b->desc.am != MTFHIP_AM_NCC) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "updateModel :: appearance model %d", b->desc.am);
+	TRY(single_channel(b, "update_model"));
+	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "update_model before initializePixVals");
+	TRY(need_image(b));
+	TRY(ensure_df(b));
+	const double *dp;
+	TRY(resolve_pts(b, pts, MTFHIP_BUF_CURR_PTS, 2 * (size_t)b->NP, &dp));
+	++b->frame_count;
+	const int running = (learning_rate < 0 || learning_rate > 1) ? 1 : 0;
+	{
+		TimedScope ts(b->ctx, "sample");
+		launch_update_model(b->view(), b->ctx->img, dp, b->buf[MTFHIP_BUF_I0], b->norm_mult, b->norm_add, (double)b->frame_count,
+			learning_rate, running, b->ctx->stream);
+	}
+	/* everything cached about the template is void: buffer versions (Gram / moment caches), NCC's template scalars and moments */
+	touch_all(b); b->lz.it_epoch = -1;
+	/* reinitialize(): the initialize* functions called again refresh what depends on the template only (NCC: mean and norm of I0,
+	 * NCC.cc:50-95; SSD: nothing; initializeGrad / initializeHess hold no template state for SSD and NCC) */
+	if (b->init_sim) TRY(mtfhip_am_initialize_similarity(b));
+	if (b->desc.am == MTFHIP_AM_NCC && b->d_ncc_tm && b->j0_is_template) TRY(ncc_template_moments(b));
 	return MTFHIP_OK;
 }
 static int do_update_pix_vals(mtfhip_batch *b, const double *pts) {

@@ -130,6 +130,27 @@ __global__ __launch_bounds__(kBlock) void k_sample(int N, ImgView im, const doub
 	}
 }
 
+/* utils::getWeightedPixVals Utilities/src/imgUtils.cc:506-523 (SSD::updateModel AM/src/SSD.cc:49-75, NCC::updateModel
+ * AM/src/NCC.cc:539-566): the template moves towards the patch at the given points -- running average over frame_count
+ * frames, or weight alpha for the new patch (the reference applies the pixel normalisation only in the running average) */
+__global__ __launch_bounds__(kBlock) void k_update_model(int N, ImgView im, const double *pts_all, double *I0_all,
+	double mult, double add, double frame_count, double alpha, int running_avg) {
+	const int t = blockIdx.y;
+	const double2 *pts = reinterpret_cast<const double2 *>(pts_all) + (size_t)t * N;
+	double *I0 = I0_all + (size_t)t * N;
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+		const double2 p = pts[i];
+		const double old = I0[i];
+		if (running_avg) {
+			const double v = mult * pix_val(im, p.x, p.y) + add;
+			I0[i] = old + (v - old) / frame_count;
+		} else {
+			const double v = pix_val(im, p.x, p.y);
+			I0[i] = alpha * v + (1 - alpha) * old;
+		}
+	}
+}
+
 /* utils::getImgGrad Utilities/src/imgUtils.cc:233-254 */
 __global__ __launch_bounds__(kBlock) void k_img_grad(int N, ImgView im, const double *pts_all, double *grad_all,
 	double eps, double pix_mult) {
@@ -521,6 +542,11 @@ void launch_sample(const BatchView &bv, const ImgView &im, const double *pts, do
 	hipStream_t st) {
 	if (bv.C > 1) { hipLaunchKernelGGL(k_sample_mc, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.NP, bv.C, im, pts, out, mult, add); return; }
 	hipLaunchKernelGGL(k_sample, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, pts, out, mult, add);
+}
+void launch_update_model(const BatchView &bv, const ImgView &im, const double *pts, double *I0, double mult, double add,
+	double frame_count, double alpha, int running_avg, hipStream_t st) {
+	hipLaunchKernelGGL(k_update_model, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, pts, I0, mult, add,
+		frame_count, alpha, running_avg);
 }
 void launch_img_grad(const BatchView &bv, const ImgView &im, const double *pts, double *grad, double eps, double mult,
 	hipStream_t st) {

@@ -218,6 +218,7 @@ struct mtfhip_batch {
 	bool init_pix_hess = false;
 	/* J0 and dI0_dx are still exactly what init_template produced (no setter / pixel-Jacobian call touched them since): the
 	 * fused kernel may then rebuild J0's rows from dI0_dx instead of reading them (MTFHIP_J0_RECOMPUTE=0 disables) */
+	unsigned int frame_count = 0;   /* ImageBase::frame_count: ++ in initializePixVals and updateModel (ImageBase.cc:74, SSD.cc:51) */
 	bool j0_is_template = false;
 	long corners_epoch = 0, j0_template_corners_epoch = -1;   /* set_corners moves the grid: J0 rows depend on init_pts */
 	int j0_variant = MTFHIP_JAC_WARPED;

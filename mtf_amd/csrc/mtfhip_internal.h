@@ -114,6 +114,8 @@ void launch_apply_warp(const BatchView &bv, hipStream_t st);
 void launch_grad_pts(const BatchView &bv, double eps, hipStream_t st);
 void launch_sample(const BatchView &bv, const ImgView &im, const double *pts, double *out,
 	double mult, double add, hipStream_t st);
+void launch_update_model(const BatchView &bv, const ImgView &im, const double *pts, double *I0, double mult, double add,
+	double frame_count, double alpha, int running_avg, hipStream_t st);
 void launch_img_grad(const BatchView &bv, const ImgView &im, const double *pts, double *grad,
 	double eps, double mult, hipStream_t st);
 void launch_warped_img_grad(const BatchView &bv, const ImgView &im, const double *grad_pts, double *grad,

@@ -41,6 +41,7 @@ def lib():
         H.mtfhost_destroy.argtypes = [C.c_void_p]
         H.mtfhost_qr_solve.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         H.mtfhost_ssm_algebra.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        H.mtfhost_set_learning.argtypes = [C.c_void_p, C.c_int, C.c_double]
         _h = H
     return _h
 
@@ -99,6 +100,10 @@ class CppTracker:
         _check(lib().mtfhost_update(self._h, C.byref(n)))
         self.iters = n.value
         return self.get_region()
+
+    def set_learning(self, enable, learning_rate=0.5):
+        """enable_learning of the search method + learning_rate of the AM (online template update after every update())"""
+        _check(lib().mtfhost_set_learning(self._h, int(bool(enable)), C.c_double(learning_rate)))
 
     def ssm_algebra(self, what, a=None, b=None, n_out=None):
         """StateSpaceModel virtuals that are host algebra (see mtfhost_ssm_algebra)"""

@@ -59,6 +59,7 @@ public:
 	virtual void invertState(VectorXd &, const VectorXd &) {}
 	virtual void updateInitGrad() { am_func_not_implemeted(updateInitGrad); }
 	virtual void updateCurrGrad() { am_func_not_implemeted(updateCurrGrad); }
+	virtual void updateModel(const PtsT &) { am_func_not_implemeted(updateModel); }   /* AppearanceModel.h:261; SSD.cc:49-75, NCC.cc:539-566 */
 	virtual void cmptInitJacobian(RowVectorXd &df_dp, const MatrixXd &dI0_dpssm) = 0;
 	virtual void cmptCurrJacobian(RowVectorXd &df_dp, const MatrixXd &dIt_dpssm) = 0;
 	virtual void cmptDifferenceOfJacobians(RowVectorXd &df_dp_diff, const MatrixXd &dI0_dpssm, const MatrixXd &dIt_dpssm) = 0;

@@ -131,6 +131,9 @@ double HipAM::getSimilarity() const {
 }
 void HipAM::updateInitGrad() { HipPair::check(mtfhip_am_update_init_grad(p->b)); }
 void HipAM::updateCurrGrad() { HipPair::check(mtfhip_am_update_curr_grad(p->b)); }
+void HipAM::updateModel(const PtsT &pts) {
+	HipPair::check(mtfhip_am_update_model(p->b, ptsArg(pts), learning_rate));
+}
 
 void HipAM::cmptInitJacobian(RowVectorXd &g, const MatrixXd &J0) {
 	HipPair::check(mtfhip_am_cmpt_init_jacobian(p->b, p->jacobianBuffer(J0, false), g.data()));

@@ -78,6 +78,10 @@ public:
 	void updateSimilarity(bool prereq_only = true) override;
 	void updateInitGrad() override;
 	void updateCurrGrad() override;
+	/* online template update (enable_learning of the search methods); learning_rate as SSDParams / NCCParams (default 0.5,
+	 * Config/parameters.h:200), outside [0, 1] = running average */
+	void updateModel(const PtsT &curr_pts) override;
+	void setLearningRate(double lr) { learning_rate = lr; }
 	void cmptInitJacobian(RowVectorXd &df_dp, const MatrixXd &dI0_dpssm) override;
 	void cmptCurrJacobian(RowVectorXd &df_dp, const MatrixXd &dIt_dpssm) override;
 	void cmptDifferenceOfJacobians(RowVectorXd &df_dp_diff, const MatrixXd &dI0_dpssm, const MatrixXd &dIt_dpssm) override;
@@ -94,6 +98,7 @@ public:
 	void setFirstIter() override;
 	void clearInitStatus() override {}
 private:
+	double learning_rate = 0.5;
 	std::shared_ptr<HipPair> p;
 	ImageView img{nullptr, 0, 0, 0};
 	mutable double f = 0;

@@ -223,6 +223,7 @@ void ESM::update() {
 		if (update_norm < params.epsilon) break;
 		am->clearFirstIter();
 	}
+	if (params.enable_learning) am->updateModel(ssm->getPts());
 }
 
 /* ------------------------------------------------------------------ FCLK */
@@ -305,6 +306,7 @@ void FCLK::update() {
 		am->clearFirstIter();
 		++iter_id;
 	}
+	if (params.enable_learning) am->updateModel(ssm->getPts());   /* NT/FCLK.cc:352-354 */
 }
 
 /* ------------------------------------------------------------------ ICLK */
@@ -378,6 +380,7 @@ void ICLK::update() {
 		if (update_norm < params.epsilon) break;
 		am->clearFirstIter();
 	}
+	if (params.enable_learning) am->updateModel(ssm->getPts());
 }
 
 } // namespace nt

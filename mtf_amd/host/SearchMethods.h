@@ -26,6 +26,7 @@ struct SMParams {
 	bool leven_marq = true;
 	double lm_delta_init = 0.01;
 	double lm_delta_update = 10;
+	bool enable_learning = false;   /* ESM / FC / IC_ENABLE_LEARNING: am->updateModel(ssm->getPts()) after update() (NT/ESM.cc:293-295) */
 };
 
 class SearchMethod {
@@ -39,6 +40,7 @@ public:
 	virtual void update() = 0;
 	virtual void setRegion(const CornersT &corners) { ssm->setCorners(corners); }
 	virtual const CornersT &getRegion() { return ssm->getCorners(); }
+	void setLearning(bool on) { params.enable_learning = on; }
 	virtual void setImage(const ImageView &img) { am->setCurrImg(img); }
 	int getItersDone() const { return iters_done; }
 protected:

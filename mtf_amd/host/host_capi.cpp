@@ -46,6 +46,13 @@ mtfhost_tracker *mtfhost_create(int sm, int am, int ssm, int resx, int resy, int
 	} catch (const std::exception &e) { g_err = e.what(); return nullptr; }
 }
 void mtfhost_destroy(mtfhost_tracker *t) { delete t; }
+/* ESM / FC / IC_ENABLE_LEARNING + the AM's learning_rate: am->updateModel(ssm->getPts()) at the end of every update() */
+int mtfhost_set_learning(mtfhost_tracker *t, int enable, double learning_rate) {
+	if (!t) { g_err = "NULL tracker"; return -1; }
+	t->sm->setLearning(enable != 0);
+	t->am->setLearningRate(learning_rate);
+	return 0;
+}
 
 static int guarded(mtfhost_tracker *t, void (*fn)(mtfhost_tracker *, const void *, void *), const void *in, void *out) {
 	try { fn(t, in, out); return 0; }

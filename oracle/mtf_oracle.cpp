@@ -1058,6 +1058,7 @@ struct mtfo_am {
 	const float *img; int h, w;
 	double norm_mult, norm_add;
 	bool init_pix_vals, init_pix_grad, init_sim, init_grad, init_hess, init_pix_hess = false;
+	unsigned int frame_count = 0;   /* ImageBase.h:169 */
 	double hess_eps = 1.0; /* HESS_EPS AM/include/mtf/AM/ImageBase.h:9, Config/mtf.cfg:16 */
 	vecd I0, It, dI0_dx, dIt_dx, df_dI0, df_dIt, d2I0_dx2, d2It_dx2;
 	double f;
@@ -1124,11 +1125,28 @@ struct mtfo_am {
 	/* ImageBase::initializePixVals AM/src/ImageBase.cc:62-99 (MI: AM/src/MI.cc:124-158) */
 	void initialize_pix_vals(const double *pts) {
 		if (!init_pix_vals) { I0.resize(n); It.resize(n); }
+		++frame_count;   /* ImageBase.cc:74 */
 		s_vals(I0.data(), pts);
 		if (!init_pix_vals) { It = I0; init_pix_vals = true; }
 	}
 	/* ImageBase::updatePixVals AM/src/ImageBase.cc:268-290 */
 	void update_pix_vals(const double *pts) { s_vals(It.data(), pts); }
+	/* SSD::updateModel AM/src/SSD.cc:49-75 / NCC::updateModel AM/src/NCC.cc:539-566 with utils::getWeightedPixVals
+	 * Utilities/src/imgUtils.cc:506-523 (MTF_32FC1 branch: the pixel normalisation is applied in the running average only),
+	 * then AppearanceModel::reinitialize AppearanceModel.h:119-123.  Returns -1 where the reference throws (MI). */
+	int update_model(const double *pts, double learning_rate) {
+		if (kind == MTFO_AM_MI || C > 1) return -1;
+		++frame_count;
+		const bool running = learning_rate < 0 || learning_rate > 1;
+		for (int i = 0; i < n; ++i) {
+			const double v = pix_val(img, h, w, pts[2 * i], pts[2 * i + 1]);
+			if (running) I0[i] += (norm_mult * v + norm_add - I0[i]) / frame_count;
+			else I0[i] = learning_rate * v + (1 - learning_rate) * I0[i];
+		}
+		if (init_sim) initialize_similarity();
+		if (init_grad) initialize_grad();
+		return 0;
+	}
 	/* ImageBase::initializePixGrad(PtsT) AM/src/ImageBase.cc:101-132 */
 	void initialize_pix_grad_pts(const double *pts) {
 		if (!init_pix_grad) { dI0_dx.resize(2 * n); dIt_dx.resize(2 * n); }
@@ -2110,6 +2128,7 @@ void mtfo_ssm_set_channels(mtfo_ssm *s, int n_channels) { s->C = n_channels; s->
 int mtfo_am_patch_size(const mtfo_am *a) { return a->n; }
 void mtfo_am_initialize_pix_vals(mtfo_am *a, const double *pts) { a->initialize_pix_vals(pts); }
 void mtfo_am_update_pix_vals(mtfo_am *a, const double *pts) { a->update_pix_vals(pts); }
+int mtfo_am_update_model(mtfo_am *a, const double *pts, double learning_rate) { return a->update_model(pts, learning_rate); }
 void mtfo_am_initialize_pix_grad_pts(mtfo_am *a, const double *pts) { a->initialize_pix_grad_pts(pts); }
 void mtfo_am_initialize_pix_grad_warped(mtfo_am *a, const double *gp) { a->initialize_pix_grad_warped(gp); }
 void mtfo_am_update_pix_grad_pts(mtfo_am *a, const double *pts) { a->update_pix_grad_pts(pts); }

@@ -109,6 +109,7 @@ void mtfo_ssm_set_channels(mtfo_ssm *s, int n_channels);
 int mtfo_am_patch_size(const mtfo_am *a);
 void mtfo_am_initialize_pix_vals(mtfo_am *a, const double *pts);
 void mtfo_am_update_pix_vals(mtfo_am *a, const double *pts);
+int mtfo_am_update_model(mtfo_am *a, const double *pts, double learning_rate); /* -1: FunctonNotImplemented (MI) */
 void mtfo_am_initialize_pix_grad_pts(mtfo_am *a, const double *pts);
 void mtfo_am_initialize_pix_grad_warped(mtfo_am *a, const double *grad_pts);
 void mtfo_am_update_pix_grad_pts(mtfo_am *a, const double *pts);

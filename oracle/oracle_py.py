@@ -309,6 +309,10 @@ class AM:
     def update_pix_vals(self, pts):
         self._call_pts(lib().mtfo_am_update_pix_vals, pts)
 
+    def update_model(self, pts, learning_rate=0.5):
+        """SSD / NCC::updateModel; False where the reference throws FunctonNotImplemented"""
+        return lib().mtfo_am_update_model(self.h, _d(pts_to_flat(pts)), C.c_double(learning_rate)) == 0
+
     def initialize_pix_grad_pts(self, pts):
         self._call_pts(lib().mtfo_am_initialize_pix_grad_pts, pts)
 

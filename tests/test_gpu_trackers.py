@@ -397,3 +397,53 @@ def test_interface_level_sm_several_targets_deferred_vs_eager(gpu_ctx, frame, sm
         tol = 1e-10 if it == 0 else 1e-4
         for key in ("f", "g", "H") if it == 0 else ("f", "H"):   # g cancels towards 0 at convergence: noise-dominated there
             np.testing.assert_allclose(c[key], a[key], rtol=tol, atol=tol * max(1.0, np.abs(a[key]).max()), err_msg="%s %d" % (key, it))
+
+
+@pytest.mark.parametrize("am", [L.AM_SSD, L.AM_NCC])
+@pytest.mark.parametrize("lr", [0.3, -1.0], ids=["weighted", "running"])
+def test_online_template_update(oracle, gpu_ctx, frame, am, lr):
+    """updateModel (enable_learning of the search methods): the template after two updates, and the next fused iteration on the
+    updated template, against the oracle; the C++ search methods call it through the AppearanceModel virtual."""
+    rng = np.random.default_rng(67)
+    res, centre = 30, (250.0, 262.0)
+    corners = synth.square_corners(centre[0], centre[1], 60.0)
+    frame2 = synth.warp_frame(frame, synth.random_small_homography(rng, 0.3), centre)
+    params = dict(leven_marq=0, max_iters=3, epsilon=-1.0)
+    o_ssm = oracle.SSM(L.SSM_HOMOGRAPHY, res, res); o_am = oracle.AM(am, res, res); o_am.set_curr_img(frame)
+    otrk = oracle.Tracker(L.SM_ESM, o_am, o_ssm, **params)
+    otrk.initialize(corners)
+    gpu_ctx.set_image(frame)
+    b = mtf_amd.Batch(gpu_ctx, am, L.SSM_HOMOGRAPHY, res, res, 1)
+    b.set_corners(corners[None])
+    sm = mtf_amd.sm_desc(L.SM_ESM, **params)
+    b.init_template(sm)
+    o_am.set_curr_img(frame2); gpu_ctx.set_image(frame2)
+    otrk.update()
+    b.track(sm)
+    np.testing.assert_allclose(b.get_corners()[0], otrk.get_region(), atol=2e-5)
+    # learn from a deliberately displaced patch, twice, so that the template (and, for NCC, its mean, norm and moments) really
+    # changes; both sides get the same state
+    p_trk = o_ssm.get("state").copy()
+    p_off = p_trk + np.array([0, 0, 2.5, 0, 0, -1.5, 0, 0])
+    I0_before = o_am.get("I0").copy()
+    for rnd in range(2):
+        o_ssm.set_state(p_off); b.set_state(p_off[None])
+        assert o_am.update_model(o_ssm.get("curr_pts"), lr)
+        b.update_model(None, lr)
+    assert np.abs(o_am.get("I0") - I0_before).max() > 1.0
+    np.testing.assert_allclose(b.read(L.BUF_I0)[0], o_am.get("I0"), rtol=0, atol=1e-7)
+    # the next iteration on the updated template, from the same state: f, g, H of both sides
+    o_ssm.set_state(p_trk); b.set_state(p_trk[None])
+    otrk.update()
+    rec = otrk.trace()[0]
+    f, g, H = b.iterate(sm)
+    assert abs(f[0] - rec["f"]) <= 1e-6 * max(abs(rec["f"]), 1e-6)
+    assert np.linalg.norm(H[0] - rec["H"]) <= 1e-5 * np.linalg.norm(rec["H"])
+    gs = max(np.linalg.norm(rec["g"]), 1e-3 * np.sqrt(abs(np.trace(rec["H"]))))
+    assert np.linalg.norm(g[0] - rec["g"]) <= 1e-4 * gs
+    b.close()
+    with pytest.raises(mtf_amd.FunctionNotImplemented):
+        bm = mtf_amd.Batch(gpu_ctx, L.AM_MI, L.SSM_HOMOGRAPHY, res, res, 1)
+        bm.set_corners(corners[None]); bm.init_template(mtf_amd.sm_desc(L.SM_ESM, **params))
+        bm.update_model(None, 0.5)
+

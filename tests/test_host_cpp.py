@@ -159,3 +159,27 @@ def test_cpp_ssm_algebra_virtuals(frame, ssm):
     np.testing.assert_allclose(trk.ssm_algebra(4, p1, n_out=S), p1, rtol=0, atol=1e-15)    # state was 0 after initialize
     np.testing.assert_allclose(trk.get_region(), mtf_amd.apply_warp_to_pts(ssm, c0, p1), rtol=0, atol=1e-9)
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("am", [L.AM_SSD, L.AM_NCC])
+def test_cpp_search_method_learns_the_template(oracle, frame, am):
+    """enable_learning: nt::ESM calls am->updateModel(ssm->getPts()) after update() (NT/ESM.cc:293-295); three frames against the
+    oracle's tracker followed by the oracle's updateModel."""
+    rng = np.random.default_rng(71)
+    res, centre, lr = 30, (250.0, 262.0), 0.4
+    corners = synth.square_corners(centre[0], centre[1], 60.0)
+    o_ssm = oracle.SSM(L.SSM_HOMOGRAPHY, res, res); o_am = oracle.AM(am, res, res); o_am.set_curr_img(frame)
+    otrk = oracle.Tracker(L.SM_ESM, o_am, o_ssm, leven_marq=0, max_iters=6, epsilon=1e-6)
+    otrk.initialize(corners)
+    trk = host.CppTracker(L.SM_ESM, am, L.SSM_HOMOGRAPHY, res, res, max_iters=6, epsilon=1e-6, leven_marq=0)
+    trk.set_learning(True, lr)
+    trk.set_image(frame)
+    trk.initialize(corners)
+    f_prev = frame
+    for k in range(3):
+        f_next = synth.warp_frame(f_prev, synth.random_small_homography(rng, 0.25), centre)
+        o_am.set_curr_img(f_next); otrk.update(); assert o_am.update_model(o_ssm.get("curr_pts"), lr)
+        trk.set_image(f_next); trk.update()
+        np.testing.assert_allclose(trk.get_region(), otrk.get_region(), atol=5e-4)
+        f_prev = f_next
+

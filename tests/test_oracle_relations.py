@@ -369,3 +369,33 @@ def test_mi_against_its_definition(oracle, frame):
     J = ssm.cmpt_warped_pix_jacobian(am.get("dIt_dx")).reshape(6, N).T       # N x S
     Hc = am.cmpt_curr_hessian(ssm.cmpt_warped_pix_jacobian(am.get("dIt_dx")))
     assert rel(Hc, R.mi_curr_hessian(I0, It, J)) < 1e-9
+
+
+def test_update_model_is_the_documented_average(oracle, frame, frame2):
+    """SSD / NCC::updateModel (AM/src/SSD.cc:49-75, imgUtils.cc:506-523): weighted average I0 <- a p + (1 - a) I0 for a learning
+    rate in [0, 1], running average over the frames seen otherwise; NCC's template statistics follow (reinitialize); MI throws."""
+    rng = np.random.default_rng(61)
+    corners = synth.square_corners(240, 250, 60)
+    for am_kind in (oracle.AM_SSD, oracle.AM_NCC):
+        ssm = oracle.SSM(oracle.SSM_HOM, 20, 20); ssm.set_corners(corners)
+        am = oracle.AM(am_kind, 20, 20); am.set_curr_img(frame)
+        am.initialize_pix_vals(ssm.get("curr_pts")); am.initialize_similarity(); am.initialize_grad(); am.initialize_hess()
+        I0 = am.get("I0").copy()
+        ssm.set_state(synth.random_small_homography(rng, 0.3)); am.set_curr_img(frame2)
+        pts = ssm.get("curr_pts")
+        am.update_pix_vals(pts)
+        patch = am.get("It").copy()
+        assert am.update_model(pts, 0.25)
+        np.testing.assert_allclose(am.get("I0"), 0.25 * patch + 0.75 * I0, rtol=1e-15)
+        I1 = am.get("I0").copy()
+        assert am.update_model(pts, -1.0)      # running average: frame_count is 3 by now (initialize + two updates)
+        np.testing.assert_allclose(am.get("I0"), I1 + (patch - I1) / 3, rtol=1e-15)
+        if am_kind == oracle.AM_NCC:                # similarity of the template with itself through the refreshed statistics
+            am.update_pix_vals(pts); am.update_similarity(False)
+            I2 = am.get("I0"); a, b = I2 - I2.mean(), patch - patch.mean()
+            assert abs(am.similarity - a @ b / np.linalg.norm(a) / np.linalg.norm(b)) < 1e-12
+    mi = oracle.AM(oracle.AM_MI, 20, 20); mi.set_curr_img(frame)
+    ssm = oracle.SSM(oracle.SSM_HOM, 20, 20); ssm.set_corners(corners)
+    mi.initialize_pix_vals(ssm.get("curr_pts"))
+    assert not mi.update_model(ssm.get("curr_pts"), 0.5)
+
