@@ -42,6 +42,7 @@ def lib():
         H.mtfhost_qr_solve.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         H.mtfhost_ssm_algebra.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         H.mtfhost_set_learning.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        H.mtfhost_dist_feat.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         _h = H
     return _h
 
@@ -100,6 +101,14 @@ class CppTracker:
         _check(lib().mtfhost_update(self._h, C.byref(n)))
         self.iters = n.value
         return self.get_region()
+
+    def dist_feat(self):
+        """AppearanceModel::updateDistFeat + getDistFeat of the patch at the tracker's current state"""
+        n = C.c_int(0)
+        _check(lib().mtfhost_dist_feat(self._h, None, C.byref(n)))
+        out = np.empty(n.value)
+        _check(lib().mtfhost_dist_feat(self._h, out.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return out
 
     def set_learning(self, enable, learning_rate=0.5):
         """enable_learning of the search method + learning_rate of the AM (online template update after every update())"""

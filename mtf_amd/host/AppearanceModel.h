@@ -60,6 +60,17 @@ public:
 	virtual void updateInitGrad() { am_func_not_implemeted(updateInitGrad); }
 	virtual void updateCurrGrad() { am_func_not_implemeted(updateCurrGrad); }
 	virtual void updateModel(const PtsT &) { am_func_not_implemeted(updateModel); }   /* AppearanceModel.h:261; SSD.cc:49-75, NCC.cc:539-566 */
+	/* selective pixel integration (AppearanceModel.h:228-236): the device path does not take a mask, as the reference's own AMs
+	 * outside SSDBase do not */
+	virtual void setSPIMask(const bool *) { am_func_not_implemeted(setSPIMask); }
+	virtual void clearSPIMask() {}
+	virtual bool supportsSPI() const { return false; }
+	/* distance features for the NN / FLANN search (AppearanceModel.h:266-297) */
+	virtual void initializeDistFeat() { am_func_not_implemeted(initializeDistFeat); }
+	virtual void updateDistFeat() { am_func_not_implemeted(updateDistFeat); }
+	virtual void updateDistFeat(double *) { am_func_not_implemeted(updateDistFeat); }
+	virtual const double *getDistFeat() { am_func_not_implemeted(getDistFeat); }
+	virtual unsigned int getDistFeatSize() { am_func_not_implemeted(getDistFeatSize); }
 	virtual void cmptInitJacobian(RowVectorXd &df_dp, const MatrixXd &dI0_dpssm) = 0;
 	virtual void cmptCurrJacobian(RowVectorXd &df_dp, const MatrixXd &dIt_dpssm) = 0;
 	virtual void cmptDifferenceOfJacobians(RowVectorXd &df_dp_diff, const MatrixXd &dI0_dpssm, const MatrixXd &dIt_dpssm) = 0;

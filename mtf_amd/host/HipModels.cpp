@@ -131,6 +131,11 @@ double HipAM::getSimilarity() const {
 }
 void HipAM::updateInitGrad() { HipPair::check(mtfhip_am_update_init_grad(p->b)); }
 void HipAM::updateCurrGrad() { HipPair::check(mtfhip_am_update_curr_grad(p->b)); }
+void HipAM::updateDistFeat(double *feat_addr) {
+	double st[8] = {0};
+	HipPair::check(mtfhip_ssm_get_state(p->b, st));
+	HipPair::check(mtfhip_sample_candidates(p->b, st, 1, feat_addr));
+}
 void HipAM::updateModel(const PtsT &pts) {
 	HipPair::check(mtfhip_am_update_model(p->b, ptsArg(pts), learning_rate));
 }

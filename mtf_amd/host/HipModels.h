@@ -82,6 +82,13 @@ public:
 	 * Config/parameters.h:200), outside [0, 1] = running average */
 	void updateModel(const PtsT &curr_pts) override;
 	void setLearningRate(double lr) { learning_rate = lr; }
+	/* NN / FLANN distance feature of the patch at the SSM's current state: SSD = the pixel values (SSDBase.h:116-125), NCC =
+	 * centred and normalised (NCC.cc:530-537); computed on the device (mtfhip_sample_candidates), MI has none here */
+	void initializeDistFeat() override { dist_feat.resize((int)p->N); }
+	void updateDistFeat() override { if (dist_feat.size() != (int)p->N) dist_feat.resize((int)p->N); updateDistFeat(dist_feat.data()); }
+	void updateDistFeat(double *feat_addr) override;
+	const double *getDistFeat() override { return dist_feat.data(); }
+	unsigned int getDistFeatSize() override { return p->N; }
 	void cmptInitJacobian(RowVectorXd &df_dp, const MatrixXd &dI0_dpssm) override;
 	void cmptCurrJacobian(RowVectorXd &df_dp, const MatrixXd &dIt_dpssm) override;
 	void cmptDifferenceOfJacobians(RowVectorXd &df_dp_diff, const MatrixXd &dI0_dpssm, const MatrixXd &dIt_dpssm) override;
@@ -99,6 +106,7 @@ public:
 	void clearInitStatus() override {}
 private:
 	double learning_rate = 0.5;
+	VectorXd dist_feat;
 	std::shared_ptr<HipPair> p;
 	ImageView img{nullptr, 0, 0, 0};
 	mutable double f = 0;

@@ -104,6 +104,15 @@ int mtfhost_ssm_algebra(mtfhost_tracker *t, int what, const double *a, const dou
 		return 0;
 	} catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
+/* AppearanceModel::updateDistFeat(double *) through the base-class pointer (tests) */
+int mtfhost_dist_feat(mtfhost_tracker *t, double *feat, int *size) {
+	try {
+		AppearanceModel *am = t->am.get();
+		if (size) *size = (int)am->getDistFeatSize();
+		if (feat) { am->initializeDistFeat(); am->updateDistFeat(); std::memcpy(feat, am->getDistFeat(), sizeof(double) * am->getDistFeatSize()); }
+		return 0;
+	} catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
 /* host-only helper exercised by the CPU tests */
 int mtfhost_qr_solve(int n, const double *A_colmajor, const double *b, double *x) {
 	try {

@@ -182,4 +182,9 @@ def test_cpp_search_method_learns_the_template(oracle, frame, am):
         trk.set_image(f_next); trk.update()
         np.testing.assert_allclose(trk.get_region(), otrk.get_region(), atol=5e-4)
         f_prev = f_next
+    # NN / FLANN distance feature of the patch at the final state, through AppearanceModel::updateDistFeat
+    o_am.update_pix_vals(o_ssm.get("curr_pts"))
+    It = o_am.get("It")
+    want = It if am == L.AM_SSD else (It - It.mean()) / np.linalg.norm(It - It.mean())
+    np.testing.assert_allclose(trk.dist_feat(), want, rtol=0, atol=2e-3 if am == L.AM_SSD else 2e-5)   # states differ by the trackers' 5e-4 px
 
