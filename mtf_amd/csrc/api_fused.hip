@@ -691,6 +691,18 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 	const bool ncc = b->desc.am == MTFHIP_AM_NCC;
 	const size_t RL = ncc ? NCC_ACC_COUNT : ACC_COUNT;   /* partial / reduced row length */
 	if (ncc && !one_launch && !b->d_ncc_tm) return fail(MTFHIP_ERR_LOGIC, "track before init_template");
+	/* The loop is enqueued without waiting for the device, so iterations after the last target has converged would still be
+	 * launched (kernels that find every flag cleared, a few microseconds each).  With a reachable convergence test the flags are
+	 * looked at every eighth iteration: one small copy + sync against up to seven idle iterations. */
+	std::vector<int> h_active;
+	auto all_converged = [&](const int *d_flags, int n, int it) -> bool {
+		if (!(sm->epsilon > 0) || (it + 1) % 8 != 0 || it + 1 >= sm->max_iters) return false;
+		h_active.resize(n);
+		if (hipMemcpyAsync(h_active.data(), d_flags, sizeof(int) * n, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+		if (hipStreamSynchronize(st) != hipSuccess) return false;
+		for (int v : h_active) if (v) return false;
+		return true;
+	};
 	TrackState ts{b->d_acc, b->d_h0, b->d_corners, b->d_init_corners_hm, b->d_active, b->d_iters, ncc ? b->d_ncc : nullptr, ncc ? b->d_ncc_tm : nullptr};
 	BatchView bv = b->view();
 	if (b->desc.am == MTFHIP_AM_MI) {
@@ -703,6 +715,7 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 		for (int it = 0; it < sm->max_iters; ++it) {
 			TRY(mi_enqueue(b, sm, pl, b->d_active, false));
 			launch_finish_track_mi(bv, *sm, ts, pl.hk == MiPlan::H_SUM_STD, gmode, b->d_mi_H, b->d_partials, ng, b->d_mi_red, st);
+			if (all_converged(b->d_active, b->B, it)) break;
 		}
 	} else if (one_launch) {
 		TimedScope tsc(b->ctx, "iclk_track");
@@ -733,6 +746,7 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 					launch_fused_ssd(bc, b->ctx->img, fc, part, nblk_c, st);
 				}
 				launch_finish_track(bc, *sm, tc, part, nblk_c, st);
+				if (all_converged(tc.active, nt, it)) break;
 			}
 		}
 	}
