@@ -313,6 +313,10 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 			*b->h_flag = 0;
 			(void)hipMemsetAsync(b->d_fin_count, 0, sizeof(int), c->stream);
 			b->h_acc_dev = static_cast<double *>(dp); b->h_flag_dev = static_cast<unsigned long long *>(fp);
+			void *pp = nullptr;
+			if (hipHostMalloc(&b->h_pub, b->slab_bytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+				hipHostGetDevicePointer(&pp, b->h_pub, 0) == hipSuccess) b->h_pub_dev = static_cast<char *>(pp);
+			else (void)hipGetLastError();
 		} else (void)hipGetLastError();
 	}
 	(void)hipMemsetAsync(b->d_partials, 0, sizeof(double) * kAccRowMax * b->nblk_max * n_targets, c->stream);
@@ -345,6 +349,7 @@ void mtfhip_batch_destroy(mtfhip_batch *b) {
 			if (p) (void)hipFree(p);
 		if (b->h_acc) (void)hipHostFree(b->h_acc);
 		if (b->h_flag) (void)hipHostFree(b->h_flag);
+		if (b->h_pub) (void)hipHostFree(b->h_pub);
 		if (b->d_fin_count) (void)hipFree(b->d_fin_count);
 		if (b->h_stage_a) (void)hipHostFree(b->h_stage_a);
 		if (b->h_stage_b) (void)hipHostFree(b->h_stage_b);

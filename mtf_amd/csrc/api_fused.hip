@@ -687,6 +687,7 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 	std::memcpy(b->h_stage_b + 45 * sizeof(double) * (size_t)b->B, b->h_stage_a + 45 * sizeof(double) * (size_t)b->B, 9 * sizeof(double) * (size_t)b->B);
 	fill_stage(b, b->h_stage_b, nullptr, 1, true);
 	HIP_TRY(hipMemcpyAsync(b->d_slab, b->h_stage_b, b->slab_bytes, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipEventRecord(b->ev_b, st));   /* h_stage_b may be refilled once this upload has been consumed */
 	fa.active = b->d_active;
 	const bool ncc = b->desc.am == MTFHIP_AM_NCC;
 	const size_t RL = ncc ? NCC_ACC_COUNT : ACC_COUNT;   /* partial / reduced row length */
@@ -750,15 +751,24 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 			}
 		}
 	}
-	/* one download of the slab (warps, states, corners, iteration counts), one sync */
-	HIP_TRY(hipMemcpyAsync(b->h_stage_b, b->d_slab, b->slab_bytes, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipEventRecord(b->ev_b, st));
-	HIP_TRY(hipStreamSynchronize(st));
+	/* the slab (warps, states, corners, iteration counts) comes back either through a kernel that writes it into host-coherent
+	 * memory and raises a flag the host spins on, or as one copy + one sync (MTFHIP_ZERO_COPY=0) */
+	const char *h_res = b->h_stage_b;
+	if (b->h_pub_dev) {
+		const unsigned long long seq = ++b->acc_seq;
+		launch_publish_host(b->d_slab, b->h_pub_dev, b->slab_bytes, b->d_fin_count, b->h_flag_dev, seq, st);
+		TRY(wait_host_flag(b, seq));
+		h_res = b->h_pub;
+	} else {
+		HIP_TRY(hipMemcpyAsync(b->h_stage_b, b->d_slab, b->slab_bytes, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipEventRecord(b->ev_b, st));
+		HIP_TRY(hipStreamSynchronize(st));
+	}
 	{
 		const size_t Bt = (size_t)b->B;
-		const double *p = reinterpret_cast<const double *>(b->h_stage_b);
+		const double *p = reinterpret_cast<const double *>(h_res);
 		const double *w = p, *s = p + 9 * Bt, *cr = p + 17 * Bt;
-		const int *iters = reinterpret_cast<const int *>(b->h_stage_b + b->slab_dbl_bytes) + Bt;
+		const int *iters = reinterpret_cast<const int *>(h_res + b->slab_dbl_bytes) + Bt;
 		for (int t = 0; t < b->B; ++t) {
 			std::memcpy(b->th[t].warp.m, w + 9 * t, sizeof(double) * 9);
 			std::memcpy(b->th[t].state, s + 8 * t, sizeof(double) * 8);

@@ -508,6 +508,22 @@ __global__ __launch_bounds__(128) void k_finish_host(const double *partials, int
 		}
 	}
 }
+/* a device buffer delivered straight into host-coherent pinned memory (32-bit words), then the sequence number the host is
+ * spinning on: replaces a device-to-host copy + stream synchronisation at the end of the device-side loop */
+__global__ __launch_bounds__(256) void k_publish_host(const unsigned *src, unsigned *dst_host, unsigned n_words, int *count,
+	unsigned long long *flag_host, unsigned long long seq) {
+	for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n_words; i += gridDim.x * 256) dst_host[i] = src[i];
+	__threadfence_system();
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		const int done = __hip_atomic_fetch_add(count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+		if (done == (int)gridDim.x - 1) {
+			__hip_atomic_store(count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__threadfence_system();
+			__hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+	}
+}
 /* fixed-order sum of the per-workgroup rows: out[t][k] = sum_b partials[t][b][k] */
 __global__ __launch_bounds__(64) void k_finish(const double *partials, int nblk, double *out) {
 	const int t = blockIdx.x, k = threadIdx.x;
@@ -609,6 +625,13 @@ void launch_ncc_hess(const BatchView &bv, const double *sc, const double *colmea
 void launch_finish_host(double *partials, int nblk, int row_len, double *out_host, int *count, unsigned long long *flag_host,
 	unsigned long long seq, int B, hipStream_t st) {
 	hipLaunchKernelGGL(k_finish_host, dim3(B), dim3(128), 0, st, partials, nblk, row_len, out_host, count, flag_host, seq);
+}
+void launch_publish_host(const void *src, void *dst_host, size_t bytes, int *count, unsigned long long *flag_host,
+	unsigned long long seq, hipStream_t st) {
+	const unsigned n_words = (unsigned)(bytes / 4);
+	const unsigned blocks = std::max(1u, std::min(64u, (n_words + 1023) / 1024));
+	hipLaunchKernelGGL(k_publish_host, dim3(blocks), dim3(256), 0, st, static_cast<const unsigned *>(src), static_cast<unsigned *>(dst_host),
+		n_words, count, flag_host, seq);
 }
 void launch_finish_rows(double *partials, int nblk, int row_len, double *out, int B, hipStream_t st) {
 	hipLaunchKernelGGL(k_finish_rows, dim3(B, (row_len + 127) / 128), dim3(128), 0, st, partials, nblk, row_len, out);

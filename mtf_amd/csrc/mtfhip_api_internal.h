@@ -252,6 +252,7 @@ struct mtfhip_batch {
 	 * paying a copy command plus a stream synchronisation per iteration (MTFHIP_ZERO_COPY=0: copy + sync) */
 	double *h_acc_dev = nullptr;
 	unsigned long long *h_flag = nullptr, *h_flag_dev = nullptr, acc_seq = 0;
+	char *h_pub = nullptr, *h_pub_dev = nullptr;   /* host-coherent mirror of the state slab, written by k_publish_host (track's read-back) */
 	int *d_fin_count = nullptr;
 	int nblk_max;
 	int unit_z = 1;
@@ -367,21 +368,25 @@ static void update_corners(mtfhip_batch *b, int t) {
 	}
 }
 
+/* spin until the kernel that was given `seq` has stored it behind its host-coherent writes */
+static int wait_host_flag(mtfhip_batch *b, unsigned long long seq) {
+	const auto t0 = std::chrono::steady_clock::now();
+	for (unsigned spins = 0;; ++spins) {
+		if (__atomic_load_n(b->h_flag, __ATOMIC_ACQUIRE) == seq) return MTFHIP_OK;
+		__builtin_ia32_pause();
+		if ((spins & 0xffff) == 0xffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+	}
+	/* the kernel did not report in: let the runtime tell why */
+	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	if (__atomic_load_n(b->h_flag, __ATOMIC_ACQUIRE) == seq) return MTFHIP_OK;
+	return fail(MTFHIP_ERR_HIP, "device results were not delivered to host memory");
+}
 /* fixed-order sum of the per-workgroup rows -> h_acc ([B][row_len]) on the host, and wait for it */
 static int read_rows(mtfhip_batch *b, int nblk, int row_len) {
 	if (b->h_acc_dev) {
 		const unsigned long long seq = ++b->acc_seq;
 		launch_finish_host(b->d_partials, nblk, row_len, b->h_acc_dev, b->d_fin_count, b->h_flag_dev, seq, b->B, b->ctx->stream);
-		const auto t0 = std::chrono::steady_clock::now();
-		for (unsigned spins = 0;; ++spins) {
-			if (__atomic_load_n(b->h_flag, __ATOMIC_ACQUIRE) == seq) return MTFHIP_OK;
-			__builtin_ia32_pause();
-			if ((spins & 0xffff) == 0xffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
-		}
-		/* the kernel did not report in: let the runtime tell why */
-		HIP_TRY(hipStreamSynchronize(b->ctx->stream));
-		if (__atomic_load_n(b->h_flag, __ATOMIC_ACQUIRE) == seq) return MTFHIP_OK;
-		return fail(MTFHIP_ERR_HIP, "reduced rows were not delivered to host memory");
+		return wait_host_flag(b, seq);
 	}
 	if (row_len == ACC_COUNT) launch_finish(b->d_partials, nblk, b->d_acc, b->B, b->ctx->stream);
 	else launch_finish_rows(b->d_partials, nblk, row_len, b->d_acc, b->B, b->ctx->stream);

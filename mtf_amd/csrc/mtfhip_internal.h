@@ -173,6 +173,8 @@ void launch_finish(double *partials, int nblk, double *out, int B, hipStream_t s
 void launch_finish_rows(double *partials, int nblk, int row_len, double *out, int B, hipStream_t st);
 void launch_finish_host(double *partials, int nblk, int row_len, double *out_host, int *count, unsigned long long *flag_host,
 	unsigned long long seq, int B, hipStream_t st);
+void launch_publish_host(const void *src, void *dst_host, size_t bytes, int *count, unsigned long long *flag_host,
+	unsigned long long seq, hipStream_t st);
 /* the fused LK iteration for SSD */
 void launch_fused_ssd(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials,
 	int nblk, hipStream_t st);
