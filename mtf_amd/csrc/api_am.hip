@@ -602,7 +602,7 @@ static int mi_lazy_fused(mtfhip_batch *b, int trig, int j_a, const mtfhip_sm_des
 		TRY(fused_args(b, &s0, fa));
 		{
 			TimedScope ts(b->ctx, "fused_lk");
-			launch_fused_ssd(b->view(), b->ctx->img, fa, b->d_partials, fused_blocks_per_target(b->N, b->B), st);
+			launch_fused_ssd(fused_view(b, fa), b->ctx->img, fa, b->d_partials, fused_blocks_per_target(b->N, b->B), st);
 		}
 		const bool self_was = L.mi_self_it == L.ver[MTFHIP_BUF_IT];
 		touch(b, MTFHIP_BUF_IT);
@@ -722,7 +722,7 @@ static int lazy_try_fused(mtfhip_batch *b, int trig, int j_a, int j_b, double *g
 	const int nblk = fused_blocks_per_target(b->N, b->B);
 	{
 		TimedScope ts(b->ctx, "fused_lk");
-		launch_fused_ssd(b->view(), b->ctx->img, fa, b->d_partials, nblk, b->ctx->stream);
+		launch_fused_ssd(fused_view(b, fa), b->ctx->img, fa, b->d_partials, nblk, b->ctx->stream);
 	}
 	touch(b, MTFHIP_BUF_IT);
 	b->it_valid = true;

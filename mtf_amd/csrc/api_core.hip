@@ -323,6 +323,8 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 	int r = push_warps(b);
 	if (r) return cleanup(r);
 	{
+		const char *iw_env = std::getenv("MTFHIP_INLINE_WARP");
+		b->inline_warp_ok = b->B == 1 && !(iw_env && iw_env[0] == '0');
 		const char *lazy_env = std::getenv("MTFHIP_LAZY");
 		/* SSD and NCC have a fused kernel each; MI has its fused passes */
 		b->lz.enabled = (d->am == MTFHIP_AM_SSD || d->am == MTFHIP_AM_NCC || d->am == MTFHIP_AM_MI) && b->C == 1 &&
@@ -444,6 +446,7 @@ int mtfhip_ssm_set_corners(mtfhip_batch *b, const double *corners) {
 	HIP_TRY(hipEventSynchronize(b->ev_a));
 	fill_stage(b, b->h_stage_a, w0.data(), 0, false);
 	HIP_TRY(hipMemcpyAsync(b->d_slab, b->h_stage_a, b->slab_dbl_bytes, hipMemcpyHostToDevice, b->ctx->stream));
+	b->warps_dirty = false;   /* the slab carries the (identity) warps */
 	HIP_TRY(hipEventRecord(b->ev_a, b->ctx->stream));
 	{
 		TimedScope ts(b->ctx, "init_grid");
@@ -463,7 +466,8 @@ int ensure_pts(mtfhip_batch *b) {
 	return MTFHIP_OK;
 }
 static int apply_states(mtfhip_batch *b) {
-	TRY(push_warps(b));
+	if (b->inline_warp_ok) b->warps_dirty = true;   /* uploaded by whoever needs it, or carried by the next fused launch */
+	else TRY(push_warps(b));
 	b->pts_stale = true;   /* refreshed by the next entry point that may read them (lazy_flush) */
 	return MTFHIP_OK;
 }

@@ -244,7 +244,7 @@ int lazy_try_similarity(mtfhip_batch *b) {
 		hipStream_t st = b->ctx->stream;
 		{
 			TimedScope ts(b->ctx, "fused_lk");
-			launch_fused_ssd(b->view(), b->ctx->img, fa, b->d_partials, fused_blocks_per_target(b->N, b->B), st);
+			launch_fused_ssd(fused_view(b, fa), b->ctx->img, fa, b->d_partials, fused_blocks_per_target(b->N, b->B), st);
 		}
 		touch(b, MTFHIP_BUF_IT);
 		b->it_valid = true;
@@ -271,7 +271,7 @@ int lazy_try_similarity(mtfhip_batch *b) {
 	const int nblk = fused_blocks_per_target(b->N, b->B);
 	{
 		TimedScope ts(b->ctx, "fused_lk");
-		launch_fused_ssd(b->view(), b->ctx->img, fa, b->d_partials, nblk, b->ctx->stream);
+		launch_fused_ssd(fused_view(b, fa), b->ctx->img, fa, b->d_partials, nblk, b->ctx->stream);
 	}
 	touch(b, MTFHIP_BUF_IT);
 	b->it_valid = true;
@@ -406,6 +406,7 @@ int fused_args(const mtfhip_batch *b, const mtfhip_sm_desc *sm, FusedArgs &fa) {
 	fa.grad_eps = b->desc.grad_eps;
 	fa.norm_mult = b->norm_mult; fa.norm_add = b->norm_add;
 	fa.active = nullptr;
+	fa.inline_warp = 0;
 	{ int nb; fused_decomposition(b->N, b->B, nb, fa.rows_per_block); }
 	switch (sm->sm) {
 	case MTFHIP_SM_FCLK: fa.mode = 0; break;
@@ -492,7 +493,7 @@ static int mi_enqueue(mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPlan &p
 	fa.active = active;
 	{
 		TimedScope ts(b->ctx, "fused_lk");
-		launch_fused_ssd(b->view(), b->ctx->img, fa, b->d_partials, fused_blocks_per_target(b->N, b->B), st);
+		launch_fused_ssd(fused_view(b, fa), b->ctx->img, fa, b->d_partials, fused_blocks_per_target(b->N, b->B), st);
 	}
 	b->it_valid = true;
 	b->dit_valid = b->jt_valid = pl.need_jt;
@@ -588,7 +589,7 @@ int mtfhip_batch_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, d
 	int nblk = fused_blocks_per_target(b->N, b->B);
 	{
 		TimedScope ts(b->ctx, "fused_lk");
-		launch_fused_ssd(b->view(), b->ctx->img, fa, b->d_partials, nblk, b->ctx->stream);
+		launch_fused_ssd(fused_view(b, fa), b->ctx->img, fa, b->d_partials, nblk, b->ctx->stream);
 	}
 	b->it_valid = fa.materialize;
 	b->dit_valid = fa.materialize && fa.mode != 2;
@@ -680,7 +681,7 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 		b->N <= kIclkTrackMaxPix;
 	FusedArgs fa;
 	if (!one_launch && !mi) TRY(fused_args(b, sm, fa));
-	else { fa.materialize = 0; fa.mode = 2; fa.active = nullptr; fa.rows_per_block = 1; fa.j0_recompute = 0; }
+	else { fa.materialize = 0; fa.mode = 2; fa.active = nullptr; fa.rows_per_block = 1; fa.j0_recompute = 0; fa.inline_warp = 0; }
 	/* active = 1, iters = 0, corners, warps, states, NCC scalars: one pinned async copy of the whole slab
 	 * (w0 is copied along; init_grid consumed it long ago) */
 	HIP_TRY(hipEventSynchronize(b->ev_b));
@@ -688,6 +689,7 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 	fill_stage(b, b->h_stage_b, nullptr, 1, true);
 	HIP_TRY(hipMemcpyAsync(b->d_slab, b->h_stage_b, b->slab_bytes, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipEventRecord(b->ev_b, st));   /* h_stage_b may be refilled once this upload has been consumed */
+	b->warps_dirty = false;   /* the slab carries the warps */
 	fa.active = b->d_active;
 	const bool ncc = b->desc.am == MTFHIP_AM_NCC;
 	const size_t RL = ncc ? NCC_ACC_COUNT : ACC_COUNT;   /* partial / reduced row length */

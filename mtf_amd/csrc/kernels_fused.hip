@@ -85,8 +85,13 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 	const int *live_ptr = fa.active ? fa.active + t : reinterpret_cast<const int *>(bv.warps + 9 * t);
 	const int live_word = *live_ptr;
 	const int live = fa.active ? live_word : 1;
-	const Warp9 W = load_warp(bv.warps + 9 * t);
-	const double *st = bv.states + 8 * t;
+	/* inline_warp (one target): the same scalar loads, pointed at the copy inside the kernel-argument segment -- the explicit
+	 * arguments are laid out in declaration order at their natural alignment: bv, im, fa */
+	const char *kernarg = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
+	const double *kw = reinterpret_cast<const double *>(kernarg + sizeof(BatchView) + sizeof(ImgView) + offsetof(FusedArgs, iw));
+	const double *wsrc = fa.inline_warp ? kw : bv.warps + 9 * t;
+	const Warp9 W = load_warp(wsrc);
+	const double *st = fa.inline_warp ? kw + 9 : bv.states + 8 * t;
 	const double st2 = st[2], st3 = st[3], st4 = st[4], st5 = st[5];
 	const double2 *__restrict__ ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * N;
 	const double *__restrict__ iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * N;
@@ -435,6 +440,11 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 	if (!live) return;
 	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * ROW_LEN;
 	block_reduce_store<K>(acc, dst, lds);
+	if (fa.inline_warp && blockIdx.x == 0 && threadIdx.x < 17) {   /* keep the device copy current for whoever reads it next */
+		const double v = kw[threadIdx.x];   /* iw[9] | is[8] */
+		if (threadIdx.x < 9) bv.warps[9 * t + threadIdx.x] = v;
+		else bv.states[8 * t + threadIdx.x - 9] = v;
+	}
 }
 template <int SSM, bool CHAINED, int MODE, bool MAT>
 __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchView bv, ImgView im, FusedArgs fa, double *partials, int nblk) {

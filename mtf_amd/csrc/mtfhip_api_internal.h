@@ -197,6 +197,8 @@ struct TargetHost {
 	double ncc_sj0[8], ncc_i0j0[8], ncc_gram0[36];
 };
 
+struct mtfhip_batch;
+static int push_warps(mtfhip_batch *b);
 struct mtfhip_batch {
 	mtfhip_ctx *ctx;
 	mtfhip_patch_desc desc;
@@ -303,7 +305,16 @@ struct mtfhip_batch {
 		long gram0_ver = -1; std::vector<double> gram0;   /* J0: constant between template changes */
 	} lz;
 
+	/* Single-target batches (the literal drop-in shape): set_state / compositional_update only mark the device copy of the warp
+	 * stale.  The fused launch that normally follows carries the warp in its kernel arguments (fused_view) and refreshes the
+	 * device copy itself; anything else that builds a BatchView uploads it first (view).  MTFHIP_INLINE_WARP=0: always upload. */
+	mutable bool warps_dirty = false;
+	bool inline_warp_ok = false;
 	BatchView view() const {
+		if (warps_dirty) { warps_dirty = false; (void)push_warps(const_cast<mtfhip_batch *>(this)); }
+		return view_raw();
+	}
+	BatchView view_raw() const {
 		BatchView v;
 		v.B = B; v.N = N; v.S = S; v.ssm = desc.ssm; v.am = desc.am; v.unit_z = unit_z; v.NP = NP; v.C = C;
 		for (int i = 0; i < MTFHIP_BUF_COUNT; ++i) v.buf[i] = buf[i];
@@ -352,6 +363,18 @@ static int push_warps(mtfhip_batch *b) {
 	return MTFHIP_OK;
 }
 
+/* the BatchView of a fused launch: a stale single-target warp goes into the kernel arguments instead of being uploaded */
+static inline BatchView fused_view(mtfhip_batch *b, FusedArgs &fa) {
+	fa.inline_warp = 0;
+	if (b->warps_dirty && b->B == 1) {
+		b->warps_dirty = false;
+		fa.inline_warp = 1;
+		std::memcpy(fa.iw, b->th[0].warp.m, sizeof(double) * 9);
+		std::memcpy(fa.is, b->th[0].state, sizeof(double) * 8);
+		return b->view_raw();
+	}
+	return b->view();
+}
 /* corners = dehomogenise(curr_warp * init_corners_hm) (Homography.cc:87-90) / affine top rows (Affine.cc:105) */
 static void update_corners(mtfhip_batch *b, int t) {
 	TargetHost &h = b->th[t];

@@ -107,6 +107,10 @@ struct FusedArgs {
 	double grad_eps;
 	double norm_mult, norm_add;
 	const int *active; /* optional [B] mask: targets with 0 are skipped (device-side loop) */
+	/* single-target batches: the warp and state travel in the kernel arguments (read from the kernarg segment instead of
+	 * bv.warps / bv.states; the kernel stores them there afterwards) -- no separate upload in front of every launch */
+	int inline_warp;
+	double iw[9], is[8];
 };
 
 /* ---- launchers (all asynchronous on `st`) ---- */
