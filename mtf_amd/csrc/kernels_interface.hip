@@ -493,13 +493,24 @@ __global__ __launch_bounds__(128) void k_finish_rows(const double *partials, int
 }
 /* the same, delivered straight into host-coherent pinned memory: every target's row, then -- by the workgroup that
  * finishes last -- a sequence number the host is spinning on (system-scope release after the rows) */
-__global__ __launch_bounds__(128) void k_finish_host(const double *partials, int nblk, int row_len, double *out_host, int *count,
+__global__ __launch_bounds__(1024) void k_finish_host(const double *partials, int nblk, int row_len, double *out_host, int *count,
 	unsigned long long *flag_host, unsigned long long seq) {
-	const int t = blockIdx.x, k = threadIdx.x;
-	if (k < row_len) out_host[(size_t)t * row_len + k] = column_sum(partials + (size_t)t * nblk * row_len + k, nblk, row_len);
+	/* blockDim.x = 128 G: group j sums the rows j, j + G, ... of its column, group 0 adds the G partial sums in order -- a single
+	 * target has hundreds of block rows, and one thread per column walking all of them was most of this kernel's 4 us */
+	__shared__ double part[8][128];
+	const int t = blockIdx.x, k = threadIdx.x & 127, j = threadIdx.x >> 7, G = blockDim.x >> 7;
+	const double *p = partials + (size_t)t * nblk * row_len;
+	double mine = 0.0;
+	if (k < row_len && j < nblk) mine = column_sum(p + (size_t)j * row_len + k, (nblk - j + G - 1) / G, G * row_len);
+	if (G > 1) {
+		part[j][k] = mine;
+		__syncthreads();
+		if (j == 0) for (int g = 1; g < G; ++g) mine += part[g][k];
+	}
+	if (j == 0 && k < row_len) out_host[(size_t)t * row_len + k] = mine;
 	__threadfence_system();
 	__syncthreads();
-	if (k == 0) {
+	if (threadIdx.x == 0) {
 		const int done = __hip_atomic_fetch_add(count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
 		if (done == (int)gridDim.x - 1) {
 			__hip_atomic_store(count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -624,7 +635,8 @@ void launch_ncc_hess(const BatchView &bv, const double *sc, const double *colmea
 }
 void launch_finish_host(double *partials, int nblk, int row_len, double *out_host, int *count, unsigned long long *flag_host,
 	unsigned long long seq, int B, hipStream_t st) {
-	hipLaunchKernelGGL(k_finish_host, dim3(B), dim3(128), 0, st, partials, nblk, row_len, out_host, count, flag_host, seq);
+	const int G = nblk >= 256 ? 8 : (nblk >= 64 ? 4 : 1);
+	hipLaunchKernelGGL(k_finish_host, dim3(B), dim3(128 * G), 0, st, partials, nblk, row_len, out_host, count, flag_host, seq);
 }
 void launch_publish_host(const void *src, void *dst_host, size_t bytes, int *count, unsigned long long *flag_host,
 	unsigned long long seq, hipStream_t st) {
