@@ -503,14 +503,18 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 	if (lane < RL) {
 		const double *p = partials + (size_t)t * nblk * RL + lane;
 		auto ld = [&](size_t off) -> double { return p[off]; };
-		double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+		/* eight block rows in flight per lane: the headline batch has exactly eight per target (one round trip), a single
+		 * target has 157 (20 rounds instead of 40) */
+		double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
 		int b = 0;
-		for (; b + 3 < nblk; b += 4) {
+		for (; b + 7 < nblk; b += 8) {
 			s0 += ld((size_t)b * RL); s1 += ld((size_t)(b + 1) * RL);
 			s2 += ld((size_t)(b + 2) * RL); s3 += ld((size_t)(b + 3) * RL);
+			s4 += ld((size_t)(b + 4) * RL); s5 += ld((size_t)(b + 5) * RL);
+			s6 += ld((size_t)(b + 6) * RL); s7 += ld((size_t)(b + 7) * RL);
 		}
 		for (; b < nblk; ++b) s0 += ld((size_t)b * RL);
-		v_acc = (s0 + s1) + (s2 + s3);
+		v_acc = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
 	}
 	if (!act) return;
 	if (wv0) {
