@@ -447,3 +447,24 @@ def test_online_template_update(oracle, gpu_ctx, frame, am, lr):
         bm.set_corners(corners[None]); bm.init_template(mtf_amd.sm_desc(L.SM_ESM, **params))
         bm.update_model(None, 0.5)
 
+
+@pytest.mark.parametrize("am", [L.AM_SSD, L.AM_NCC])
+@pytest.mark.parametrize("sm_kind", [L.SM_ESM, L.SM_FCLK])
+def test_single_large_target_device_loop_equals_host_loop(gpu_ctx, frame, am, sm_kind):
+    """One 160 x 160 target has a hundred block rows per iteration (the batched tests have a handful): the device-side loop follows
+    the same trajectory as the fused launch + host solve, iteration count included."""
+    rng = np.random.default_rng(83)
+    centre = (256.0, 250.0)
+    corners = synth.square_corners(centre[0], centre[1], 160)
+    frame2 = synth.warp_frame(frame, synth.random_small_homography(rng, 0.3), centre)
+    out = {}
+    for host_solve in (True, False):
+        gpu_ctx.set_image(frame)
+        trk = LKTracker(gpu_ctx, sm_kind, L.SSM_HOMOGRAPHY, 160, 160, 1, host_solve=host_solve, max_iters=12, epsilon=1e-8,
+                        materialize=0, am=am, leven_marq=0)
+        trk.initialize(corners[None])
+        gpu_ctx.set_image(frame2)
+        out[host_solve] = (trk.update()[0].copy(), int(trk.n_iters[0]))
+    np.testing.assert_allclose(out[False][0], out[True][0], rtol=0, atol=1e-6)
+    assert abs(out[False][1] - out[True][1]) <= 1
+
