@@ -87,6 +87,9 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 	const int live = fa.active ? live_word : 1;
 	/* inline_warp (one target): the same scalar loads, pointed at the copy inside the kernel-argument segment -- the explicit
 	 * arguments are laid out in declaration order at their natural alignment: bv, im, fa */
+	static_assert(sizeof(BatchView) % 8 == 0 && sizeof(ImgView) % 8 == 0 && alignof(BatchView) == 8 && alignof(ImgView) <= 8 &&
+		alignof(FusedArgs) == 8 && offsetof(FusedArgs, is) == offsetof(FusedArgs, iw) + 9 * sizeof(double),
+		"kernarg layout assumed below: bv at 0, im right behind it, fa right behind im, iw[9] | is[8] contiguous");
 	const char *kernarg = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
 	const double *kw = reinterpret_cast<const double *>(kernarg + sizeof(BatchView) + sizeof(ImgView) + offsetof(FusedArgs, iw));
 	const double *wsrc = fa.inline_warp ? kw : bv.warps + 9 * t;
