@@ -382,6 +382,9 @@ def main():
     ap.add_argument("--lm", type=int, default=1, help="dropin workload: Levenberg-Marquardt (the reference's class default is on)")
     ap.add_argument("--mode", default="full", choices=["full", "lean"],
                     help="full: It, dIt_dx, Jt materialised in HBM as the AM/SSM interface exposes them; lean: registers only")
+    ap.add_argument("--math", default="fast", choices=["fast", "replay"],
+                    help="arithmetic of the non-materialising kernels: fast = FMA / one reciprocal per point / closed-form gradient "
+                         "(within 1e-5), replay = the reference's rounding bit for bit (mtfhip_batch_set_math_mode)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -430,6 +433,7 @@ def main():
     materialize = 1 if args.mode == "full" else 0
     am_kind = {"ssd": mtf_amd.AM_SSD, "ncc": mtf_amd.AM_NCC}[args.am]
     batch = mtf_amd.Batch(ctx, am_kind, mtf_amd.SSM_HOMOGRAPHY, res, res, B)
+    batch.set_math_mode(mtf_amd.MATH_FAST if args.math == "fast" else mtf_amd.MATH_REPLAY)
     batch.set_corners(corners)
     ctx.set_image_device(f0.data_ptr(), H, W, keep=f0)
     sm = mtf_amd.sm_desc(sm_kind, materialize=materialize, leven_marq=0, epsilon=-1.0, max_iters=1)

@@ -150,6 +150,20 @@ int mtfhip_batch_n_targets(const mtfhip_batch *b);
 int mtfhip_batch_n_pix(const mtfhip_batch *b);       /* ImageBase::getNPix: sample points per target */
 int mtfhip_batch_patch_size(const mtfhip_batch *b);  /* ImageBase::getPatchSize: n_pix * n_channels rows */
 int mtfhip_batch_state_size(const mtfhip_batch *b);
+/* Arithmetic of the kernels that are FP64-issue bound rather than HBM bound (the lean fused iteration, the one-launch
+ * ICLK / grid loop, candidate scoring, the MI device passes):
+ *   MTFHIP_MATH_REPLAY  the reference's operation order bit for bit (unfused mul/add, IEEE divisions, the grad_eps = 1e-8
+ *                       central difference of utils::getImgGrad, Utilities/src/imgUtils.cc:233-254): per-pixel quantities
+ *                       are bit-identical to the CPU path;
+ *   MTFHIP_MATH_FAST    the same quantities with FMA contraction, one reciprocal per homography point
+ *                       (SSM/src/Homography.cc:803-827 needs eight divisions) and the closed-form derivative of the bilinear
+ *                       interpolant on interior non-integer points (integer coordinates / cell edges / borders replay the
+ *                       finite difference): within north_star's 1e-5 on H, dp and 1e-9 on candidate scores.
+ * Default: FAST (environment MTFHIP_MATH=replay selects REPLAY for new batches).  Everything that materialises
+ * interface-visible arrays (It, dIt_dx, Jt ...) is always REPLAY: those kernels are bound by their stores. */
+enum { MTFHIP_MATH_REPLAY = 0, MTFHIP_MATH_FAST = 1 };
+int mtfhip_batch_set_math_mode(mtfhip_batch *b, int mode);
+int mtfhip_batch_get_math_mode(const mtfhip_batch *b);
 /* lazy read-back / overwrite of a device buffer (all targets, target-major);
  * the getters of ImageBase.h:83-89 / setters :93-100 and StateSpaceModel.h:82-88 */
 int mtfhip_batch_read(mtfhip_batch *b, int buf, double *dst);

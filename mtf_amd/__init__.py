@@ -12,7 +12,7 @@ import os as _os
 _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 from . import _lib  # noqa: E402
-from ._lib import (AM_MI, AM_NCC, AM_SSD, SM_ESM, SM_FCLK, SM_ICLK, SSM_AFFINE, SSM_HOMOGRAPHY,  # noqa: F401
+from ._lib import (AM_MI, AM_NCC, AM_SSD, MATH_FAST, MATH_REPLAY, SM_ESM, SM_FCLK, SM_ICLK, SSM_AFFINE, SSM_HOMOGRAPHY,  # noqa: F401
                    FunctionNotImplemented, InvalidArgument, LogicError, MtfHipError)
 from .api import (Batch, Context, sm_desc, identity_warp, compose_warps, estimate_warp_from_corners,  # noqa: F401
                   apply_warp_to_pts)

@@ -14,6 +14,7 @@ AM_SSD, AM_NCC, AM_MI = 0, 1, 2
 SSM_HOMOGRAPHY, SSM_AFFINE = 0, 1
 SM_ESM, SM_FCLK, SM_ICLK = 0, 1, 2
 JAC_INIT, JAC_PIX, JAC_WARPED, JAC_APPROX = 0, 1, 2, 3
+MATH_REPLAY, MATH_FAST = 0, 1
 (BUF_I0, BUF_IT, BUF_DI0_DX, BUF_DIT_DX, BUF_DF_DI0, BUF_DF_DIT, BUF_J0, BUF_JT, BUF_JM,
  BUF_INIT_PTS, BUF_CURR_PTS, BUF_GRAD_PTS, BUF_INIT_Z, BUF_CURR_Z, BUF_INIT_HXY, BUF_CURR_HXY,
  BUF_D2I0_DX2, BUF_D2IT_DX2, BUF_HESS_PTS, BUF_D2I0_DP2, BUF_D2IT_DP2, BUF_D2IM_DP2) = range(22)
@@ -62,7 +63,7 @@ SYMBOLS = [
     "mtfhip_ctx_synchronize", "mtfhip_ctx_stream", "mtfhip_image_upload", "mtfhip_image_upload_mc", "mtfhip_image_borrow",
     "mtfhip_image_preprocess", "mtfhip_image_pyramid_level", "mtfhip_image_download", "mtfhip_image_shape",
     "mtfhip_batch_create", "mtfhip_batch_destroy", "mtfhip_batch_n_targets", "mtfhip_batch_n_pix", "mtfhip_batch_patch_size",
-    "mtfhip_batch_state_size", "mtfhip_batch_read", "mtfhip_batch_write", "mtfhip_batch_device_ptr",
+    "mtfhip_batch_state_size", "mtfhip_batch_set_math_mode", "mtfhip_batch_get_math_mode", "mtfhip_batch_read", "mtfhip_batch_write", "mtfhip_batch_device_ptr",
     "mtfhip_ssm_set_corners", "mtfhip_ssm_set_state", "mtfhip_ssm_compositional_update",
     "mtfhip_ssm_invert_state", "mtfhip_ssm_update_grad_pts", "mtfhip_ssm_cmpt_pix_jacobian",
     "mtfhip_ssm_get_corners", "mtfhip_ssm_get_init_corners", "mtfhip_ssm_get_state", "mtfhip_ssm_get_warp",

@@ -159,6 +159,14 @@ class Batch:
         except Exception:
             pass
 
+    def set_math_mode(self, mode):
+        """MATH_REPLAY (the reference's rounding, bit for bit) or MATH_FAST (FMA / reciprocal / closed-form gradient) for
+        the kernels that do not materialise interface arrays; see include/mtfhip.h"""
+        L.check(L.lib().mtfhip_batch_set_math_mode(self._h, int(mode)))
+
+    def get_math_mode(self):
+        return L.lib().mtfhip_batch_get_math_mode(self._h)
+
     # ---------------------------------------------------------- buffers
     _PER = {BUF_I0: 1, BUF_IT: 1, BUF_DF_DI0: 1, BUF_DF_DIT: 1}
 

@@ -367,6 +367,14 @@ void mtfhip_batch_destroy(mtfhip_batch *b) {
 }
 
 int mtfhip_batch_n_targets(const mtfhip_batch *b) { return b ? b->B : 0; }
+int mtfhip_batch_set_math_mode(mtfhip_batch *b, int mode) {
+	FLUSH(b);
+	if (!b) return fail(MTFHIP_ERR_INVALID_ARG, "set_math_mode: NULL batch");
+	if (mode != MTFHIP_MATH_REPLAY && mode != MTFHIP_MATH_FAST) return fail(MTFHIP_ERR_INVALID_ARG, "set_math_mode: unknown mode %d", mode);
+	b->math_mode = mode;
+	return MTFHIP_OK;
+}
+int mtfhip_batch_get_math_mode(const mtfhip_batch *b) { return b ? b->math_mode : -1; }
 int mtfhip_batch_n_pix(const mtfhip_batch *b) { return b ? b->NP : 0; }          /* ImageBase::getNPix */
 int mtfhip_batch_patch_size(const mtfhip_batch *b) { return b ? b->N : 0; }      /* ImageBase::getPatchSize = n_pix * n_channels */
 int mtfhip_batch_state_size(const mtfhip_batch *b) { return b ? b->S : 0; }

@@ -407,6 +407,7 @@ int fused_args(const mtfhip_batch *b, const mtfhip_sm_desc *sm, FusedArgs &fa) {
 	fa.norm_mult = b->norm_mult; fa.norm_add = b->norm_add;
 	fa.active = nullptr;
 	fa.inline_warp = 0;
+	fa.fast_math = (b->math_mode == MTFHIP_MATH_FAST && !fa.materialize) ? 1 : 0;
 	{ int nb; fused_decomposition(b->N, b->B, nb, fa.rows_per_block); }
 	switch (sm->sm) {
 	case MTFHIP_SM_FCLK: fa.mode = 0; break;
@@ -681,7 +682,7 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 		b->N <= kIclkTrackMaxPix;
 	FusedArgs fa;
 	if (!one_launch && !mi) TRY(fused_args(b, sm, fa));
-	else { fa.materialize = 0; fa.mode = 2; fa.active = nullptr; fa.rows_per_block = 1; fa.j0_recompute = 0; fa.inline_warp = 0; }
+	else { fa.materialize = 0; fa.mode = 2; fa.active = nullptr; fa.rows_per_block = 1; fa.j0_recompute = 0; fa.inline_warp = 0; fa.fast_math = 0; }
 	/* active = 1, iters = 0, corners, warps, states, NCC scalars: one pinned async copy of the whole slab
 	 * (w0 is copied along; init_grid consumed it long ago) */
 	HIP_TRY(hipEventSynchronize(b->ev_b));
@@ -722,7 +723,7 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 		}
 	} else if (one_launch) {
 		TimedScope tsc(b->ctx, "iclk_track");
-		launch_iclk_track(bv, b->ctx->img, *sm, ts, b->d_h0inv, b->d_ncc, b->norm_mult, b->norm_add, st);
+		launch_iclk_track(bv, b->ctx->img, *sm, ts, b->d_h0inv, b->d_ncc, b->norm_mult, b->norm_add, b->math_mode == MTFHIP_MATH_FAST, st);
 	} else {
 		/* Targets are independent, so the loops commute: all iterations of a chunk of targets run before the next chunk
 		 * starts.  A chunk is sized so that what an iteration reads once (J0, I0, grid: 88 B/px for ESM) stays resident in
@@ -803,7 +804,7 @@ int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int C
 		TRY(push_ncc(b));
 		ncc_sc = b->d_ncc;
 	}
-	launch_score_candidates(b->view(), b->ctx->img, dev_states, C, b->desc.likelihood_alpha, ncc_sc, dev_lik, dev_sim, b->ctx->stream);
+	launch_score_candidates(b->view(), b->ctx->img, dev_states, C, b->desc.likelihood_alpha, ncc_sc, dev_lik, dev_sim, b->math_mode == MTFHIP_MATH_FAST, b->ctx->stream);
 	return MTFHIP_OK;
 }
 

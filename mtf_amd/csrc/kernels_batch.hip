@@ -14,6 +14,7 @@ namespace mtfhip {
 /* ncc_sc: NULL for SSD; for NCC the template's scalars ([0] mean(I0), [1] |I0 - mean|): the candidate's similarity is
  * a / (b c) from the raw moments sum It, sum It^2, sum I0 It of its own samples (NCC.cc:124-161), its likelihood
  * exp(-alpha (1/f - 1)^2) (NCC.cc:50-53) */
+template <bool FAST>   /* FAST: tolerance-mode arithmetic (mtfhip_device.h): one reciprocal per point, factored interpolant, FMAs */
 __global__ __launch_bounds__(kBlock) void k_score_candidates(BatchView bv, ImgView im, const double *states, int C,
 	double alpha, double norm_mult, double norm_add, const double *ncc_sc, double *lik, double *sim) {
 	const int lane = threadIdx.x & 63;
@@ -38,17 +39,28 @@ __global__ __launch_bounds__(kBlock) void k_score_candidates(BatchView bv, ImgVi
 		double2 q = bv.unit_z ? ip[i] : ih[i];
 		double z = bv.unit_z ? 1.0 : iz[i];
 		double hx = q.x, hy = q.y;
-		double wx, wy;
-		if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
-			double cx = W[0] * hx + W[1] * hy + W[2] * z;
-			double cy = W[3] * hx + W[4] * hy + W[5] * z;
-			double d = W[6] * hx + W[7] * hy + W[8] * z;
-			wx = cx / d; wy = cy / d;
+		double wx, wy, it;
+		if constexpr (FAST) {
+			wx = fma(W[0], hx, fma(W[1], hy, W[2] * z));
+			wy = fma(W[3], hx, fma(W[4], hy, W[5] * z));
+			if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+				const double inv = rcp_fast(fma(W[6], hx, fma(W[7], hy, W[8] * z)));
+				wx *= inv; wy *= inv;
+			}
+			it = fma(norm_mult, pix_val_fast(im, wx, wy), norm_add);
 		} else {
-			wx = W[0] * hx + W[1] * hy + W[2] * z;
-			wy = W[3] * hx + W[4] * hy + W[5] * z;
+			if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+				double cx = W[0] * hx + W[1] * hy + W[2] * z;
+				double cy = W[3] * hx + W[4] * hy + W[5] * z;
+				double d = W[6] * hx + W[7] * hy + W[8] * z;
+				wx = cx / d; wy = cy / d;
+			} else {
+				wx = W[0] * hx + W[1] * hy + W[2] * z;
+				wy = W[3] * hx + W[4] * hy + W[5] * z;
+			}
+			it = norm_mult * pix_val(im, wx, wy) + norm_add;
 		}
-		const double it = norm_mult * pix_val(im, wx, wy) + norm_add, i0 = I0[i];
+		const double i0 = I0[i];
 		if (ncc_sc) { s_it += it; acc = fma(it, it, acc); s_i0it = fma(i0, it, s_i0it); }
 		else { const double r = it - i0; acc = fma(r, r, acc); }
 	}
@@ -69,6 +81,92 @@ __global__ __launch_bounds__(kBlock) void k_score_candidates(BatchView bv, ImgVi
 }
 
 
+
+/* Tolerance-mode scorer (MTFHIP_MATH_FAST).  PMC of the kernel above on config 4 (10 000 x 2 500 samples, profiles/
+ * r02_base_pf_pmc_summary.txt and r02_pf_pmc_summary.txt): 84-110 VALU instructions per 64 samples of which only ~30 are
+ * FP64 arithmetic (the rest: 64-bit addressing, clamps, conversions, the second IEEE division), and the texture
+ * addresser is busy 76 % of the time -- six gather instructions per 64 samples, two of them re-fetching the grid point and
+ * the template value every candidate fetches.  Here one workgroup scores K = 4 candidates: each wave takes a quarter of
+ * the pixels and evaluates all four warps on every grid point it loads (2 + 2 K loads per K samples instead of 6 K), the
+ * two texels of a cell row come in one 8-byte load, the warps live in scalar registers (the candidate index is uniform
+ * per workgroup), addresses are 32-bit offsets from uniform bases, and the interior case (every lane of the wave samples
+ * an interior cell: the normal case) runs without clamps or selects; anything else takes pix_val_fast. */
+struct __attribute__((packed, aligned(4))) TexPair { float a, b; };
+template <int SSM, bool NCC>
+__global__ __launch_bounds__(kBlock) void k_score_candidates_fast(BatchView bv, ImgView im, const double *__restrict__ states, int C,
+	double alpha, double norm_mult, double norm_add, const double *__restrict__ ncc_sc, double *lik, double *sim) {
+	constexpr int K = 4, M = NCC ? 3 : 1, S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
+	__shared__ double red[4 * K * M], tot[K * M];
+	const int c0 = blockIdx.x * K;
+	double W[K][9];
+#pragma unroll
+	for (int k = 0; k < K; ++k) {
+		const double *p = states + (size_t)min(c0 + k, C - 1) * S;   /* uniform address: scalar loads */
+		if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+			W[k][0] = 1 + p[0]; W[k][1] = p[1]; W[k][2] = p[2]; W[k][3] = p[3]; W[k][4] = 1 + p[4]; W[k][5] = p[5];
+			W[k][6] = p[6]; W[k][7] = p[7]; W[k][8] = 1;
+		} else {
+			W[k][0] = 1 + p[2]; W[k][1] = p[3]; W[k][2] = p[0]; W[k][3] = p[4]; W[k][4] = 1 + p[5]; W[k][5] = p[1];
+			W[k][6] = 0; W[k][7] = 0; W[k][8] = 1;
+		}
+	}
+	const unsigned N = (unsigned)bv.N;
+	const bool uz = bv.unit_z != 0;
+	const double *__restrict__ pp = bv.buf[uz ? MTFHIP_BUF_INIT_PTS : MTFHIP_BUF_INIT_HXY];
+	const double *__restrict__ iz = bv.buf[MTFHIP_BUF_INIT_Z];
+	const double *__restrict__ I0 = bv.buf[MTFHIP_BUF_I0];
+	const float *__restrict__ img = im.data;
+	const int iw1 = im.w - 1, ih1 = im.h - 1, stride = im.stride;
+	double acc[K * M];
+#pragma unroll
+	for (int k = 0; k < K * M; ++k) acc[k] = 0.0;
+	for (unsigned i = threadIdx.x; i < N; i += kBlock) {
+		const double2 q = ld_off<double2>(pp, i * 16u);
+		const double z = uz ? 1.0 : ld_off<double>(iz, i * 8u);
+		const double i0 = ld_off<double>(I0, i * 8u);
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			double wx = fma(W[k][0], q.x, fma(W[k][1], q.y, uz ? W[k][2] : W[k][2] * z));
+			double wy = fma(W[k][3], q.x, fma(W[k][4], q.y, uz ? W[k][5] : W[k][5] * z));
+			if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+				const double inv = rcp_fast(fma(W[k][6], q.x, fma(W[k][7], q.y, uz ? W[k][8] : W[k][8] * z)));
+				wx *= inv; wy *= inv;
+			}
+			const int lx = (int)wx, ly = (int)wy;
+			const bool ok = (wx >= 0) & (wy >= 0) & (lx < iw1) & (ly < ih1);
+			double v;
+			if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
+				const unsigned off = (unsigned)(ly * stride + lx) * 4u;
+				const TexPair t0 = ld_off<TexPair>(img, off), t1 = ld_off<TexPair>(img + stride, off);
+				v = bilin_val_fast(t0.a, t0.b, t1.a, t1.b, wx - (double)lx, wy - (double)ly);
+			} else {
+				v = pix_val_fast(im, wx, wy);
+			}
+			const double it = fma(norm_mult, v, norm_add);
+			if constexpr (NCC) {
+				acc[3 * k] += it; acc[3 * k + 1] = fma(it, it, acc[3 * k + 1]); acc[3 * k + 2] = fma(i0, it, acc[3 * k + 2]);
+			} else {
+				const double r = it - i0;
+				acc[k] = fma(r, r, acc[k]);
+			}
+		}
+	}
+	block_reduce_store<K * M>(acc, tot, red);
+	__syncthreads();
+	const int k = threadIdx.x, cand = c0 + k;
+	if (k < K && cand < C) {
+		if constexpr (NCC) {
+			const double n = (double)N, m0 = ncc_sc[0], c = ncc_sc[1], mt = tot[3 * k] / n;
+			const double f = (tot[3 * k + 2] - n * m0 * mt) / (sqrt(tot[3 * k + 1] - n * mt * mt) * c);
+			if (sim) sim[cand] = f;
+			if (lik) { const double d = (1.0 / f) - 1; lik[cand] = exp(-alpha * d * d); }
+		} else {
+			const double f = -tot[k] / 2;
+			if (sim) sim[cand] = f;
+			if (lik) lik[cand] = exp(-alpha * sqrt(-f / (double)N));
+		}
+	}
+}
 
 /* ===================================================================== */
 /* one-launch inverse-compositional tracker for small patches (GridTracker) */
@@ -165,7 +263,7 @@ __device__ __forceinline__ double pix_val_select(const ImgView &im, double x, do
 	return (in0 && in1) ? v : 128.0;
 }
 
-template <int AM, int PPT>
+template <int AM, int PPT, bool FAST>
 __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im, mtfhip_sm_desc sm, TrackState ts,
 	const double *h0inv_all, const double *ncc_sc_all, double norm_mult, double norm_add) {
 	__shared__ double red[4 * 8];
@@ -223,15 +321,21 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 			const int ick = (tid + k * kBlock < N) ? tid + k * kBlock : N - 1;
 			const double2 hp = HOIST_P ? hpv[HOIST_P ? k : 0] : (bv.unit_z ? ip[ick] : ih[ick]);
 			const double z = HOIST_P ? zv[HOIST_P ? k : 0] : (bv.unit_z ? 1.0 : iz[ick]);
-			double wx, wy;
-			if (hom) {
-				const double cx = W[0] * hp.x + W[1] * hp.y + W[2] * z, cy = W[3] * hp.x + W[4] * hp.y + W[5] * z;
-				const double d = W[6] * hp.x + W[7] * hp.y + W[8] * z;
-				wx = cx / d; wy = cy / d;
+			double wx, wy, v;
+			if constexpr (FAST) {
+				wx = fma(W[0], hp.x, fma(W[1], hp.y, W[2] * z)); wy = fma(W[3], hp.x, fma(W[4], hp.y, W[5] * z));
+				if (hom) { const double inv = rcp_fast(fma(W[6], hp.x, fma(W[7], hp.y, W[8] * z))); wx *= inv; wy *= inv; }
+				v = fma(norm_mult, pix_val_fast(im, wx, wy), norm_add);
 			} else {
-				wx = W[0] * hp.x + W[1] * hp.y + W[2] * z; wy = W[3] * hp.x + W[4] * hp.y + W[5] * z;
+				if (hom) {
+					const double cx = W[0] * hp.x + W[1] * hp.y + W[2] * z, cy = W[3] * hp.x + W[4] * hp.y + W[5] * z;
+					const double d = W[6] * hp.x + W[7] * hp.y + W[8] * z;
+					wx = cx / d; wy = cy / d;
+				} else {
+					wx = W[0] * hp.x + W[1] * hp.y + W[2] * z; wy = W[3] * hp.x + W[4] * hp.y + W[5] * z;
+				}
+				v = norm_mult * pix_val_select(im, wx, wy) + norm_add;
 			}
-			const double v = norm_mult * pix_val_select(im, wx, wy) + norm_add;
 			itv[k] = (tid + k * kBlock < N) ? v : 0.0;
 		}
 #pragma unroll
@@ -347,17 +451,28 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 /* ===================================================================== */
 
 void launch_score_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C,
-	double likelihood_alpha, const double *ncc_sc, double *dev_lik, double *dev_sim, hipStream_t st) {
+	double likelihood_alpha, const double *ncc_sc, double *dev_lik, double *dev_sim, int fast_math, hipStream_t st) {
 	int nb = (C + (kBlock / 64) - 1) / (kBlock / 64);
-	hipLaunchKernelGGL(k_score_candidates, dim3(nb), dim3(kBlock), 0, st, bv, im, dev_states, C, likelihood_alpha,
-		1.0, 0.0, ncc_sc, dev_lik, dev_sim);
+	if (fast_math) {
+		const dim3 g((C + 3) / 4);
+		const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY;
+#define MTFHIP_SCORE_FAST(SSM_, NCC_) hipLaunchKernelGGL((k_score_candidates_fast<SSM_, NCC_>), g, dim3(kBlock), 0, st, bv, im, dev_states, C, \
+			likelihood_alpha, 1.0, 0.0, ncc_sc, dev_lik, dev_sim)
+		if (hom && ncc_sc) MTFHIP_SCORE_FAST(MTFHIP_SSM_HOMOGRAPHY, true);
+		else if (hom) MTFHIP_SCORE_FAST(MTFHIP_SSM_HOMOGRAPHY, false);
+		else if (ncc_sc) MTFHIP_SCORE_FAST(MTFHIP_SSM_AFFINE, true);
+		else MTFHIP_SCORE_FAST(MTFHIP_SSM_AFFINE, false);
+#undef MTFHIP_SCORE_FAST
+	} else
+		hipLaunchKernelGGL(k_score_candidates<false>, dim3(nb), dim3(kBlock), 0, st, bv, im, dev_states, C, likelihood_alpha,
+			1.0, 0.0, ncc_sc, dev_lik, dev_sim);
 }
 
-template <int AM>
+template <int AM, bool FAST>
 static bool launch_iclk_track_am(const BatchView &bv, const ImgView &im, const mtfhip_sm_desc &sm, const TrackState &ts,
 	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, hipStream_t st) {
 	const int ppt = (bv.N + kBlock - 1) / kBlock;
-#define MTFHIP_ICLK_CASE(P) hipLaunchKernelGGL((k_iclk_track<AM, P>), dim3(bv.B), dim3(kBlock), 0, st, bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add)
+#define MTFHIP_ICLK_CASE(P) hipLaunchKernelGGL((k_iclk_track<AM, P, FAST>), dim3(bv.B), dim3(kBlock), 0, st, bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add)
 	if (ppt <= 1) MTFHIP_ICLK_CASE(1);
 	else if (ppt <= 2) MTFHIP_ICLK_CASE(2);
 	else if (ppt <= 3) MTFHIP_ICLK_CASE(3);
@@ -369,9 +484,13 @@ static bool launch_iclk_track_am(const BatchView &bv, const ImgView &im, const m
 	return true;
 }
 bool launch_iclk_track(const BatchView &bv, const ImgView &im, const mtfhip_sm_desc &sm, const TrackState &ts,
-	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, hipStream_t st) {
-	if (bv.am == MTFHIP_AM_NCC) return launch_iclk_track_am<MTFHIP_AM_NCC>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, st);
-	return launch_iclk_track_am<MTFHIP_AM_SSD>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, st);
+	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, int fast_math, hipStream_t st) {
+	if (fast_math) {
+		if (bv.am == MTFHIP_AM_NCC) return launch_iclk_track_am<MTFHIP_AM_NCC, true>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, st);
+		return launch_iclk_track_am<MTFHIP_AM_SSD, true>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, st);
+	}
+	if (bv.am == MTFHIP_AM_NCC) return launch_iclk_track_am<MTFHIP_AM_NCC, false>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, st);
+	return launch_iclk_track_am<MTFHIP_AM_SSD, false>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, st);
 }
 void launch_sample_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C, double norm_mult,
 	double norm_add, double *dev_feat, hipStream_t st) {

@@ -49,6 +49,7 @@ struct PixIn {
 /* warped position of a grid point and the four texels of its bilinear cell, fetched one row ahead */
 struct Tex {
 	double wx, wy, cx, cy, D;
+	double inv;        /* FAST: 1 / D */
 	float t00, t01, t10, t11;
 	int lx, ly;
 	double lxd, lyd;   /* (double)lx, (double)ly */
@@ -68,7 +69,12 @@ struct Tex {
  * NCC's similarity, Jacobians and first-order Hessians are functions of (NCC.cc:124-389 restated in ncc_from_moments,
  * api_fused.hip) -- Gram(row) | sum Jt | sum It Jt | sum I0 Jt | sum It J0 | sum It, It^2, I0 It -- so an NCC iteration
  * needs no second pass over the pixels for the means; the partial rows are NCC_ACC_COUNT wide. */
-template <int AM, int SSM, bool CHAINED, int MODE, bool MAT>
+/* FAST (lean launches only, MAT = false, instantiated with CHAINED = true): tolerance-mode arithmetic -- one reciprocal
+ * per point, FMA-contracted warp / interpolant / rows, and the closed-form gradient of the bilinear interpolant instead of
+ * its 1e-8 central difference on the wave-uniform interior path (on integer coordinates, cell edges and the border the wave
+ * falls back to the replay of the reference's five samples, SURVEY A4's corner case).  The chained and the non-chained
+ * route (Homography.cc:803-827 + cmptInitPixJacobian) are the same mathematical row, so FAST serves both. */
+template <int AM, int SSM, bool CHAINED, int MODE, bool MAT, bool FAST = false>
 __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk) {
 	constexpr int S = (SSM == MTFHIP_SSM_HOMOGRAPHY) ? 8 : 6;
 	constexpr bool NCC = AM == MTFHIP_AM_NCC;
@@ -159,7 +165,18 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 		Tex tx;
 		constexpr bool UZ = decltype(uz)::value;
 		const double z = UZ ? 1.0 : in.z, hx = UZ ? in.p.x : in.hp.x, hy = UZ ? in.p.y : in.hp.y;
-		if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+		tx.inv = 1.0;
+		if constexpr (FAST && SSM == MTFHIP_SSM_HOMOGRAPHY) {
+			tx.cx = fma(W.m[0], hx, fma(W.m[1], hy, UZ ? W.m[2] : W.m[2] * z));
+			tx.cy = fma(W.m[3], hx, fma(W.m[4], hy, UZ ? W.m[5] : W.m[5] * z));
+			tx.D = fma(W.m[6], hx, fma(W.m[7], hy, UZ ? W.m[8] : W.m[8] * z));
+			tx.inv = rcp_fast(tx.D);
+			tx.wx = tx.cx * tx.inv; tx.wy = tx.cy * tx.inv;
+		} else if constexpr (FAST) {
+			tx.wx = fma(W.m[0], hx, fma(W.m[1], hy, UZ ? W.m[2] : W.m[2] * z));
+			tx.wy = fma(W.m[3], hx, fma(W.m[4], hy, UZ ? W.m[5] : W.m[5] * z));
+			tx.cx = tx.wx; tx.cy = tx.wy; tx.D = 1.0;
+		} else if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
 			tx.cx = W.m[0] * hx + W.m[1] * hy + W.m[2] * z;
 			tx.cy = W.m[3] * hx + W.m[4] * hy + W.m[5] * z;
 			tx.D = W.m[6] * hx + W.m[7] * hy + W.m[8] * z;
@@ -243,7 +260,13 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 #ifdef MTFHIP_EXPERIMENT_NOMATH
 		if (true) { it = tcur.t00 + tcur.t01 + tcur.t10 + tcur.t11 + wx; gx = wy; gy = px0 + py3; } else
 #endif
-		if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
+		if (FAST && __builtin_amdgcn_ballot_w64(!fast) == 0) {
+			/* closed form: value and both partial derivatives of the cell's interpolant from one evaluation */
+			double v, bgx, bgy;
+			bilin_fast(tcur.t00, tcur.t01, tcur.t10, tcur.t11, wx - lxd, wy - lyd, v, bgx, bgy);
+			it = fma(fa.norm_mult, v, fa.norm_add);
+			if constexpr (MODE != 2) { gx = bgx * fa.norm_mult; gy = bgy * fa.norm_mult; }
+		} else if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
 			const double t00 = tcur.t00, t01 = tcur.t01, t10 = tcur.t10, t11 = tcur.t11;
 			it = fa.norm_mult * bilin(t00, t01, t10, t11, wx - lxd, wy - lyd) + fa.norm_add;
 			if constexpr (MODE != 2) {
@@ -277,7 +300,19 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 		double row[8];
 		if constexpr (MODE != 2) {
 			if constexpr (MAT) { st_off<double>(dIt, o8, gx); st_off<double>(dIt + N, o8, gy); }
-			if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+			if constexpr (FAST && SSM == MTFHIP_SSM_HOMOGRAPHY) {
+				/* the same row (Homography.cc:252-289) with the point's reciprocal reused and FMAs */
+				const double inv_det = tcur.inv;
+				const double dwx_dx = fma(-W.m[6], wx, W.m[0]), dwx_dy = fma(-W.m[7], wx, W.m[1]);
+				const double dwy_dx = fma(-W.m[6], wy, W.m[3]), dwy_dy = fma(-W.m[7], wy, W.m[4]);
+				const double Ix = fma(dwx_dx, gx, dwy_dx * gy) * inv_det;
+				const double Iy = fma(dwx_dy, gx, dwy_dy * gy) * inv_det;
+				hom_row_fast(row, Ix, Iy, x, y);
+			} else if constexpr (FAST) {
+				const double Ix = fma(gx, aa, gy * ac), Iy = fma(gx, ab, gy * ad);   /* Affine.cc:213-242, factored */
+				row[0] = Ix; row[1] = Iy; row[2] = Ix * x; row[3] = Ix * y; row[4] = Iy * x; row[5] = Iy * y;
+				row[6] = row[7] = 0.0;
+			} else if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
 				if constexpr (CHAINED) {
 					/* Homography::cmptWarpedPixJacobian SSM/src/Homography.cc:231-294 */
 					double inv_det = 1.0 / D;
@@ -317,7 +352,14 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 		if constexpr (MODE != 0) {
 			if constexpr (JR) {
 				const double g0x = cur.j0[0], g0y = cur.j0[1];
-				if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+				if constexpr (FAST && SSM == MTFHIP_SSM_HOMOGRAPHY) {
+					/* Warped at the identity = gradient / z, Init = gradient (z folds to 1 in the unit-z instantiation) */
+					const double inv0 = fa.j0_init_variant ? 1.0 : 1.0 / cur.z;
+					hom_row_fast(r0, g0x * inv0, g0y * inv0, x, y);
+				} else if constexpr (FAST) {
+					r0[0] = g0x; r0[1] = g0y; r0[2] = g0x * x; r0[3] = g0x * y; r0[4] = g0y * x; r0[5] = g0y * y;
+					r0[6] = r0[7] = 0.0;
+				} else if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
 					double Ix0 = g0x, Iy0 = g0y;
 					if (!fa.j0_init_variant) {   /* produced by cmptWarpedPixJacobian at the identity warp (chained initialize) */
 						const double inv_det0 = 1.0 / cur.z;
@@ -456,6 +498,11 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ssd(BatchV
 template <int SSM, bool CHAINED, int MODE, bool MAT>
 __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ncc(BatchView bv, ImgView im, FusedArgs fa, double *partials, int nblk) {
 	fused_lk_body<MTFHIP_AM_NCC, SSM, CHAINED, MODE, MAT>(bv, im, fa, partials, nblk);
+}
+/* tolerance-mode lean launches (see fused_lk_body) */
+template <int AM, int SSM, int MODE>
+__global__ __launch_bounds__(kBlock, MTFHIP_FAST_WAVES) void k_fused_fast(BatchView bv, ImgView im, FusedArgs fa, double *partials, int nblk) {
+	fused_lk_body<AM, SSM, true, MODE, false, true>(bv, im, fa, partials, nblk);
 }
 
 
@@ -732,9 +779,24 @@ static void launch_fused_mode(const BatchView &bv, const ImgView &im, const Fuse
 	else if (fa.mode == 1) launch_fused_mat<SSM, CHAINED, 1>(bv, im, fa, partials, nblk, st);
 	else launch_fused_mat<SSM, CHAINED, 2>(bv, im, fa, partials, nblk, st);
 }
+template <int AM, int SSM>
+static void launch_fused_fast(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk, hipStream_t st) {
+	dim3 g = grid2(nblk, bv.B);
+	if (fa.mode == 0) hipLaunchKernelGGL((k_fused_fast<AM, SSM, 0>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
+	else if (fa.mode == 1) hipLaunchKernelGGL((k_fused_fast<AM, SSM, 1>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
+	else hipLaunchKernelGGL((k_fused_fast<AM, SSM, 2>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
+}
 void launch_fused_ssd(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk,
 	hipStream_t st) {
 	const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY;
+	if (fa.fast_math && !fa.materialize) {
+		const bool ncc = bv.am == MTFHIP_AM_NCC;
+		if (hom && ncc) launch_fused_fast<MTFHIP_AM_NCC, MTFHIP_SSM_HOMOGRAPHY>(bv, im, fa, partials, nblk, st);
+		else if (hom) launch_fused_fast<MTFHIP_AM_SSD, MTFHIP_SSM_HOMOGRAPHY>(bv, im, fa, partials, nblk, st);
+		else if (ncc) launch_fused_fast<MTFHIP_AM_NCC, MTFHIP_SSM_AFFINE>(bv, im, fa, partials, nblk, st);
+		else launch_fused_fast<MTFHIP_AM_SSD, MTFHIP_SSM_AFFINE>(bv, im, fa, partials, nblk, st);
+		return;
+	}
 	if (hom && fa.chained) launch_fused_mode<MTFHIP_SSM_HOMOGRAPHY, true>(bv, im, fa, partials, nblk, st);
 	else if (hom) launch_fused_mode<MTFHIP_SSM_HOMOGRAPHY, false>(bv, im, fa, partials, nblk, st);
 	else if (fa.chained) launch_fused_mode<MTFHIP_SSM_AFFINE, true>(bv, im, fa, partials, nblk, st);

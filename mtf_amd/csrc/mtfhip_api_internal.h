@@ -217,6 +217,8 @@ struct mtfhip_batch {
 	double *d_h0inv = nullptr; /* [B][64] inverse of the constant Hessian (one-launch ICLK) */
 	double *d_d2_part = nullptr, *d_d2_out = nullptr, *d_d2_w = nullptr; /* second-order term: block rows, [B][64] sums, MI self weights */
 	double hess_eps = 1.0;
+	/* MTFHIP_MATH_*: arithmetic of the non-materialising kernels (include/mtfhip.h) */
+	int math_mode = (std::getenv("MTFHIP_MATH") && (std::getenv("MTFHIP_MATH")[0] == 'r' || std::getenv("MTFHIP_MATH")[0] == '0')) ? MTFHIP_MATH_REPLAY : MTFHIP_MATH_FAST;
 	bool init_pix_hess = false;
 	/* J0 and dI0_dx are still exactly what init_template produced (no setter / pixel-Jacobian call touched them since): the
 	 * fused kernel may then rebuild J0's rows from dI0_dx instead of reading them (MTFHIP_J0_RECOMPUTE=0 disables) */

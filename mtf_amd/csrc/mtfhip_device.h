@@ -25,6 +25,9 @@
 #ifndef MTFHIP_FUSED_WAVES
 #define MTFHIP_FUSED_WAVES 2   /* minimum waves per SIMD requested from the register allocator */
 #endif
+#ifndef MTFHIP_FAST_WAVES
+#define MTFHIP_FAST_WAVES 2    /* k_fused_fast: 3 or 4 waves per SIMD spill 90-1070 registers (checked with -Rpass-analysis) */
+#endif
 #ifndef MTFHIP_NT_STORE
 #define MTFHIP_NT_STORE 1      /* 1: the materialised It / dIt_dx / Jt are written with non-temporal stores */
 #endif
@@ -101,6 +104,66 @@ __device__ __forceinline__ double pix_val_cell(const ImgView &im, const Cell &c,
 	const float *r1 = im.data + (size_t)uy * im.stride;
 	double t00 = r0[lx], t01 = r0[ux], t10 = r1[lx], t11 = r1[ux];
 	return t00 * (1 - dx) * (1 - dy) + t01 * dx * (1 - dy) + t10 * (1 - dx) * dy + t11 * dx * dy;
+}
+
+/* ===================================================================== */
+/* tolerance-mode arithmetic (mtfhip_batch_set_math_mode(MTFHIP_MATH_FAST)) */
+/* ===================================================================== */
+/* The replay build above reproduces the reference's rounding (unfused mul/add, IEEE divisions, the 1e-8 finite
+ * difference of the interpolant); north_star only asks for 1e-5 on H / dp and 1e-9 on candidate scores.  The helpers
+ * below compute the same mathematical quantities with explicit FMAs, one reciprocal per homography point and the
+ * closed-form derivative of the bilinear interpolant -- the kernels that are FP64-issue bound (lean LK, ICLK, candidate
+ * scoring, the grid loop, the MI passes) use them unless the batch is switched to MTFHIP_MATH_REPLAY.
+ * Differences against the replay: ~1e-15 relative on samples, and on gradients the reference's own finite-difference
+ * noise (128 * 2^-52 / 2e-8 ~ 1.4e-6 absolute), which the closed form does not have. */
+
+/* 1 / d to ~1 ulp: v_rcp_f64 (~2^-26 relative) + two Newton steps; d is a homography denominator (~1), no scaling needed */
+__device__ __forceinline__ double rcp_fast(double d) {
+	double r = __builtin_amdgcn_rcp(d);
+	double e = fma(-d, r, 1.0);
+	r = fma(r, e, r);
+	e = fma(-d, r, 1.0);
+	return fma(r, e, r);
+}
+/* bilinear interpolant of one cell and its two partial derivatives at fractional position (dx, dy):
+ *   v = t00 + dx a + dy b + dx dy c,  dv/dx = a + dy c,  dv/dy = b + dx c   (a = t01 - t00, b = t10 - t00, c = t11 - t10 - a)
+ * The reference's central difference with step 1e-8 (imgUtils.cc:233-254) of this function is exactly dv/dx, dv/dy
+ * while both neighbours stay inside the cell (the interpolant is linear along each axis). */
+__device__ __forceinline__ void bilin_fast(float t00f, float t01f, float t10f, float t11f, double dx, double dy,
+	double &v, double &gx, double &gy) {
+	const double t00 = t00f, t10 = t10f;
+	const double a = (double)t01f - t00, b = t10 - t00, c = ((double)t11f - t10) - a;
+	gx = fma(dy, c, a);
+	gy = fma(dx, c, b);
+	v = fma(dx, gx, fma(dy, b, t00));
+}
+__device__ __forceinline__ double bilin_val_fast(float t00f, float t01f, float t10f, float t11f, double dx, double dy) {
+	const double t00 = t00f, t10 = t10f;
+	const double a = (double)t01f - t00, b = t10 - t00, c = ((double)t11f - t10) - a;
+	return fma(dx, fma(dy, c, a), fma(dy, b, t00));
+}
+/* getPixVal<Linear, Constant> (imgUtils.h:91-113) without control flow and with the factored interpolant: the four
+ * texel loads are always issued from clamped addresses and the border value 128 is selected afterwards.  The
+ * reference's `dx == 0 ? lx : lx + 1` rule only matters for the overflow test (the weight of the upper texel is zero
+ * there), which is reproduced: a sample is inside iff (x, y) is and every upper neighbour that carries weight is. */
+__device__ __forceinline__ double pix_val_fast(const ImgView &im, double x, double y) {
+	const double w = (double)(unsigned int)im.w, h = (double)(unsigned int)im.h;
+	const bool in0 = (x >= 0) & (x < w) & (y >= 0) & (y < h);
+	const double xs = in0 ? x : 0.0, ys = in0 ? y : 0.0;
+	const int lx = (int)xs, ly = (int)ys;
+	const double dx = xs - (double)lx, dy = ys - (double)ly;
+	const bool in1 = ((lx + 1 < im.w) | (dx == 0)) & ((ly + 1 < im.h) | (dy == 0));
+	const int ux = min(lx + 1, im.w - 1), uy = min(ly + 1, im.h - 1);
+	const float *r0 = im.data + (unsigned)(ly * im.stride), *r1 = im.data + (unsigned)(uy * im.stride);
+	const double v = bilin_val_fast(r0[lx], r0[ux], r1[lx], r1[ux], dx, dy);
+	return (in0 & in1) ? v : 128.0;
+}
+/* steepest-descent row of a homography pixel (Homography.cc:166-186 etc.), contracted */
+__device__ __forceinline__ void hom_row_fast(double *r, double Ix, double Iy, double x, double y) {
+	const double Ixx = Ix * x, Iyy = Iy * y, Ixy = Ix * y, Iyx = Iy * x;
+	r[0] = Ixx; r[1] = Ixy; r[2] = Ix; r[3] = Iyx; r[4] = Iyy; r[5] = Iy;
+	r[6] = -fma(x, Ixx, y * Iyx);
+	r[7] = -fma(x, Ixy, y * Iyy);
 }
 
 struct Warp9 { double m[9]; };

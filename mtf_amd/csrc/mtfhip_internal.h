@@ -111,6 +111,9 @@ struct FusedArgs {
 	 * bv.warps / bv.states; the kernel stores them there afterwards) -- no separate upload in front of every launch */
 	int inline_warp;
 	double iw[9], is[8];
+	/* 1: tolerance-mode arithmetic (mtfhip_device.h, "tolerance-mode arithmetic"); only with materialize == 0 -- the
+	 * materialised arrays stay bit-identical to what the per-function kernels write */
+	int fast_math;
 };
 
 /* ---- launchers (all asynchronous on `st`) ---- */
@@ -184,7 +187,7 @@ void launch_fused_ssd(const BatchView &bv, const ImgView &im, const FusedArgs &f
 	int nblk, hipStream_t st);
 /* candidate scoring: target 0's template under C warps given as states */
 void launch_score_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C,
-	double likelihood_alpha, const double *ncc_sc, double *dev_lik, double *dev_sim, hipStream_t st);
+	double likelihood_alpha, const double *ncc_sc, double *dev_lik, double *dev_sim, int fast_math, hipStream_t st);
 /* second-order path: hess_pts, image Hessians ([N][4]), SSM pixel Hessians ([S*S][N] planes), sum_p w[p] d2[:, p] */
 void launch_hess_pts(const BatchView &bv, double eps, hipStream_t st);
 void launch_img_hess(const BatchView &bv, const ImgView &im, const double *pts, double *hess, double eps, double mult, hipStream_t st);
@@ -208,7 +211,7 @@ void launch_sample_candidates(const BatchView &bv, const ImgView &im, const doub
 /* whole ICLK loop in one launch, one workgroup per target (N <= 16 * kBlock); false if N is too large */
 constexpr int kIclkTrackMaxPix = 16 * kBlock;
 bool launch_iclk_track(const BatchView &bv, const ImgView &im, const mtfhip_sm_desc &sm, const TrackState &ts,
-	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, hipStream_t st);
+	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, int fast_math, hipStream_t st);
 void launch_finish_track(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, const double *partials,
 	int nblk, hipStream_t st);
 

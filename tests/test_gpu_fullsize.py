@@ -55,8 +55,17 @@ def test_config2_fclk_200x200_checksums(gpu_ctx, big_frames, chained):
     np.testing.assert_allclose(g[0], -(r @ J), rtol=1e-9, atol=1e-12 * np.abs(J).max() * np.abs(r).sum())
     # lean mode (nothing materialised) produces the same sums bit for bit
     lean = mtf_amd.sm_desc(L.SM_FCLK, chained_warp=chained, hess_type=1, materialize=0)
+    b.set_math_mode(mtf_amd.MATH_REPLAY)
     f2, g2, H2 = b.iterate(lean)
     assert f2[0] == f[0] and np.array_equal(g2, g) and np.array_equal(H2, H)
+    # ... and in tolerance mode (FMA, one reciprocal per point, closed-form gradient) within the north-star budget, plain relative
+    b.set_math_mode(mtf_amd.MATH_FAST)
+    f3, g3, H3 = b.iterate(lean)
+    assert abs(f3[0] - f[0]) <= 1e-9 * abs(f[0])
+    assert np.linalg.norm(H3 - H) <= 1e-5 * np.linalg.norm(H)
+    assert np.linalg.norm(g3 - g) <= 1e-5 * np.linalg.norm(g)
+    dp, dp3 = np.linalg.solve(H[0], -g[0]), np.linalg.solve(H3[0], -g3[0])
+    assert np.linalg.norm(dp3 - dp) <= 1e-5 * np.linalg.norm(dp)
     # and the loop converges on the known warp
     trk = LKTracker(gpu_ctx, L.SM_FCLK, L.SSM_HOMOGRAPHY, 200, 200, 1, host_solve=False, chained_warp=chained,
                     hess_type=1, max_iters=30, epsilon=1e-6)
