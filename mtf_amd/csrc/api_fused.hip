@@ -546,10 +546,54 @@ static int mi_enqueue(mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPlan &p
 	}
 	return MTFHIP_OK;
 }
+/* The recompute form of the same iteration (kernels_mi_fused.hip): two pixel-level launches that read 28 + 44 B/px and write
+ * nothing per pixel, instead of four that move 324 B/px.  Tolerance-mode arithmetic, the reference's 8 bins, nothing
+ * materialised, every first-order type but SumOfStd (two Hessian passes: it keeps the materialising form). */
+static bool mi_fast_ok(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPlan &pl) {
+	static const bool enabled = !(std::getenv("MTFHIP_MI_RECOMPUTE") && std::getenv("MTFHIP_MI_RECOMPUTE")[0] == '0');
+	return enabled && b->math_mode == MTFHIP_MATH_FAST && b->desc.mi_n_bins == 8 && !sm->materialize && pl.hk != MiPlan::H_SUM_STD;
+}
+static MiFastPlan mi_fast_plan(const mtfhip_batch *b, const MiPlan &pl, const int *active) {
+	MiFastPlan fp;
+	fp.hk = pl.hk == MiPlan::H_CONST ? 0 : (pl.hk == MiPlan::H_SELF_JT ? 1 : (pl.hk == MiPlan::H_INIT_J0 ? 3 : 2));
+	fp.hrow = pl.hk == MiPlan::H_CURR_JM ? 2 : (pl.hk == MiPlan::H_INIT_J0 ? 1 : 0);
+	fp.need_dft = !pl.iclk; fp.need_df0 = !(pl.fclk || pl.orig_jac); fp.g_mean = pl.orig_jac;
+	const bool need_j0 = fp.need_df0 || fp.g_mean || fp.hrow != 0;
+	const MiJ0Rebuild rb = mi_j0_rebuild(b);
+	fp.j0_mode = !need_j0 ? 0 : (rb.dI0 ? 1 : 2);
+	fp.j0_init_variant = rb.init_variant;
+	fp.grad_eps = b->desc.grad_eps; fp.norm_mult = b->norm_mult; fp.norm_add = b->norm_add; fp.hist_norm = b->mi_hist_norm;
+	fp.active = active; fp.tb = b->d_mi_tb;
+	return fp;
+}
+static int mi_gmode(const MiPlan &pl) { return pl.iclk ? 0 : (pl.fclk ? 1 : (pl.orig_jac ? 2 : 3)); }
+/* enqueues pass 1, the tables, pass 2 and the finish; do_track: the finish also solves, updates and tests convergence */
+static int mi_enqueue_fast(mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPlan &pl, const int *active, const TrackState &ts, int do_track) {
+	const int nblk = mi_blocks(b);
+	hipStream_t st = b->ctx->stream;
+	const MiFastPlan fp = mi_fast_plan(b, pl, active);
+	const BatchView bv = b->view();
+	{
+		TimedScope tsc(b->ctx, "mi_pass1");
+		launch_mi_pass_hist(bv, b->ctx->img, fp, b->d_mi_part, nblk, b->mi_row_len, st);
+	}
+	launch_mi_tables_iter(bv, 8, b->desc.mi_pre_seed, b->mi_hist_norm, fp.hk == 1 ? 1 : 0, b->d_mi_part, nblk, b->mi_row_len, b->d_mi_tb, b->d_mi_f, st);
+	{
+		TimedScope tsc(b->ctx, "mi_pass2");
+		launch_mi_pass_grad_hess(bv, b->ctx->img, fp, b->d_mi_part, nblk, st);
+	}
+	launch_mi_finish_fast(bv, *sm, ts, fp, mi_gmode(pl), do_track, b->d_mi_part, nblk, b->d_mi_H, b->d_mi_H + 64 * (size_t)b->B, b->d_mi_red, st);
+	b->it_valid = b->dit_valid = b->jt_valid = false;
+	return MTFHIP_OK;
+}
 static int mi_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, double *g, double *H) {
 	const int S = b->S;
 	hipStream_t st = b->ctx->stream;
 	const MiPlan pl(sm);
+	if (mi_fast_ok(b, sm, pl)) {
+		TrackState ts{b->d_acc, b->d_h0, b->d_corners, b->d_init_corners_hm, b->d_active, b->d_iters, nullptr, nullptr, 1};
+		TRY(mi_enqueue_fast(b, sm, pl, nullptr, ts, 0));
+	} else
 	TRY(mi_enqueue(b, sm, pl, nullptr));
 	const size_t B = (size_t)b->B;
 	std::vector<double> out(B * 145);
@@ -716,9 +760,14 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 		const int gmode = pl.iclk ? 0 : (pl.fclk ? 1 : (pl.orig_jac ? 2 : 3));
 		ts.h_from_acc = 1;
 		const int ng = simple_blocks_per_target(b->N) < 64 ? simple_blocks_per_target(b->N) : 64;   /* as the gradient pass of mi_enqueue */
+		const bool fast = mi_fast_ok(b, sm, pl);
 		for (int it = 0; it < sm->max_iters; ++it) {
-			TRY(mi_enqueue(b, sm, pl, b->d_active, false));
-			launch_finish_track_mi(bv, *sm, ts, pl.hk == MiPlan::H_SUM_STD, gmode, b->d_mi_H, b->d_partials, ng, b->d_mi_red, st);
+			if (fast) {
+				TRY(mi_enqueue_fast(b, sm, pl, b->d_active, ts, 1));
+			} else {
+				TRY(mi_enqueue(b, sm, pl, b->d_active, false));
+				launch_finish_track_mi(bv, *sm, ts, pl.hk == MiPlan::H_SUM_STD, gmode, b->d_mi_H, b->d_partials, ng, b->d_mi_red, st);
+			}
 			if (all_converged(b->d_active, b->B, it)) break;
 		}
 	} else if (one_launch) {

@@ -2,7 +2,7 @@
  * kernels_fused.hip -- the fused Lucas-Kanade iteration (SSD and NCC) and the device-side solve + update
  * (one of the translation units of libmtfhip.so; conventions and the shared device helpers: mtfhip_device.h)
  */
-#include "mtfhip_device.h"
+#include "mtfhip_finish_device.h"
 
 namespace mtfhip {
 
@@ -506,218 +506,6 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FAST_WAVES) void k_fused_fast(BatchV
 }
 
 
-/* ===================================================================== */
-/* on-device solve + compositional update (batched drivers only)          */
-/* ===================================================================== */
-/* One wave64 per target, one launch per LK iteration:
- *   (1) fixed-order sum of the per-workgroup partial rows (what k_finish does for the host-driven path),
- *   (2) g and H of the search method from the accumulators (NT/FCLK.cc:260-288, NT/ESM.cc:298-377 with
- *       SSDBase.cc:169-191,287-311, NT/ICLK.cc:206-251),
- *   (3) H dp = -g by Gauss-Jordan elimination spread over the 64 lanes (lane = matrix entry) on the
- *       symmetrically diagonal-scaled system; every SSD Hessian here is a negated Gram matrix, i.e.
- *       definite, so no pivoting is needed (the reference uses Eigen's colPivHouseholderQr, NT/FCLK.cc:298),
- *   (4) the (inverse) compositional update and the corner-change test on lane 0
- *       (Homography.cc:73-92,109-114, Affine.cc:90-106,145-150, NT/FCLK.cc:314-339). */
-/* Body of the device-side finish, executed by the first wave of the calling workgroup (all threads of the workgroup
- * must call it: it contains workgroup barriers). */
-__device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts,
-	const double *partials, int nblk, int t) {
-	__shared__ double acc_s[NCC_ACC_COUNT];   /* >= ACC_COUNT */
-	__shared__ double A[8][9];
-	__shared__ double dps[8];
-	__shared__ double h0s[64], Ws[9], crs[8], ics[12], tms[52], ncs[2];
-	const int lane = threadIdx.x;
-	const bool wv0 = lane < 64;
-	const int S = bv.S;
-	/* NCC: the reduced row holds raw moments (NCC_* slots, NCC_ACC_COUNT wide); tms = sum J0 | sum I0 J0 | Gram(J0) of the
-	 * template, ncs = mean(I0), |I0 - mean|.  The calling workgroup then has at least 128 threads. */
-	const bool ncc = bv.am == MTFHIP_AM_NCC;
-	const int RL = ncc ? (int)NCC_ACC_COUNT : (int)ACC_COUNT;
-	/* every global operand of this target -- the `active` flag included -- is requested up front, in parallel across
-	 * the lanes, and only then is the flag tested: one memory round trip instead of two (flag, then operands); the
-	 * rest of the routine runs out of LDS / registers */
-	const int act = ts.active[t];
-	int n_it_prev = 0;
-	double v_h0 = 0, v_w = 0, v_cr = 0, v_ic = 0, v_acc = 0, v_tm = 0, v_nc = 0;
-	if (wv0) {
-		v_h0 = ts.h0[(size_t)t * 64 + lane];
-		if (lane < 9) v_w = bv.warps[9 * t + lane];
-		if (lane < 8) v_cr = ts.corners[8 * t + lane];
-		if (lane < 12) v_ic = ts.init_corners_hm[12 * t + lane];
-		n_it_prev = ts.n_iters[t];
-		if (ncc) {
-			if (lane < 52) v_tm = ts.ncc_tm[(size_t)t * 52 + lane];
-			if (lane < 2) v_nc = ts.ncc[(size_t)t * 8 + lane];
-		}
-	}
-	if (lane < RL) {
-		const double *p = partials + (size_t)t * nblk * RL + lane;
-		auto ld = [&](size_t off) -> double { return p[off]; };
-		/* eight block rows in flight per lane: the headline batch has exactly eight per target (one round trip), a single
-		 * target has 157 (20 rounds instead of 40) */
-		double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
-		int b = 0;
-		for (; b + 7 < nblk; b += 8) {
-			s0 += ld((size_t)b * RL); s1 += ld((size_t)(b + 1) * RL);
-			s2 += ld((size_t)(b + 2) * RL); s3 += ld((size_t)(b + 3) * RL);
-			s4 += ld((size_t)(b + 4) * RL); s5 += ld((size_t)(b + 5) * RL);
-			s6 += ld((size_t)(b + 6) * RL); s7 += ld((size_t)(b + 7) * RL);
-		}
-		for (; b < nblk; ++b) s0 += ld((size_t)b * RL);
-		v_acc = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
-	}
-	if (!act) return;
-	if (wv0) {
-		h0s[lane] = v_h0;
-		if (lane < 9) Ws[lane] = v_w;
-		if (lane < 8) crs[lane] = v_cr;
-		if (lane < 12) ics[lane] = v_ic;
-		if (lane < 52) tms[lane] = v_tm;
-		if (lane < 2) ncs[lane] = v_nc;
-	}
-	if (lane < RL) { acc_s[lane] = v_acc; ts.acc[(size_t)t * RL + lane] = v_acc; }
-	__syncthreads();
-	const int i = (lane >> 3) & 7, j = lane & 7;
-	const bool use_h0 = (sm.hess_type == 0) || (sm.sm == MTFHIP_SM_ICLK && !ts.h_from_acc);
-	const bool sum_h0 = (sm.sm == MTFHIP_SM_ESM) && (sm.hess_type == 2 || (sm.hess_type == 4 && !ts.h_from_acc));   /* (MI's SumOfStd arrives summed) */
-	const double gscale = (sm.sm == MTFHIP_SM_ESM) ? 0.5 : 1.0;
-	/* NCC from its moments (ncc_assemble in api_fused.hip is the host twin; formulas and citations there) */
-	const double nN = (double)bv.N;
-	const double n_mt = ncc ? acc_s[NCC_IT] / nN : 0.0, n_m0 = ncs[0], n_c = ncc ? ncs[1] : 1.0;
-	const double n_b2 = ncc ? acc_s[NCC_IT2] - nN * n_mt * n_mt : 1.0, n_b = ncc ? sqrt(n_b2) : 1.0;
-	const double n_f = ncc ? (acc_s[NCC_I0IT] - nN * n_m0 * n_mt) / (n_b * n_c) : 0.0;
-	auto mom = [&](int which, int c0, int ct, int s) -> double {   /* which: 0 J0, 1 Jt, 2 their mean */
-		const double v0 = c0 >= 0 ? tms[c0 + s] : acc_s[NCC_ITJ0 + s], vt = acc_s[ct + s];
-		return which == 0 ? v0 : (which == 1 ? vt : (v0 + vt) / 2);
-	};
-	auto n_ut = [&](int which, int s) { return (mom(which, -1, NCC_ITJ, s) - n_mt * mom(which, 0, NCC_SJ, s)) / n_b2; };
-	auto n_u0 = [&](int which, int s) { return (mom(which, 8, NCC_I0J, s) - n_m0 * mom(which, 0, NCC_SJ, s)) / (n_b * n_c); };
-	auto n_hess = [&](int kind, int which, int r, int c, int kk) -> double {   /* kind: 0 init, 1 curr, 2 self */
-		const double gram = which == 0 ? tms[16 + kk] : acc_s[NCC_GRAM + kk];
-		const double G = -(gram - mom(which, 0, NCC_SJ, r) * mom(which, 0, NCC_SJ, c) / nN) / n_b2;
-		const double utr = n_ut(which, r), utc = n_ut(which, c);
-		if (kind == 2) return G + utr * utc;
-		const double u0r = n_u0(which, r), u0c = n_u0(which, c);
-		return n_f * G - utr * u0c - u0r * utc + 3 * (kind == 1 ? utr * utc : u0r * u0c);
-	};
-	auto h_entry = [&](int r, int c) -> double {
-		if (r >= S || c >= S) return r == c ? -1.0 : 0.0;
-		const int a = r < c ? r : c, b2 = r < c ? c : r;
-		const int kk = a * 8 - (a * (a - 1)) / 2 + (b2 - a);
-		if (ncc) {
-			const int ht = sm.hess_type;
-			const double h0v = h0s[b2 * S + a];
-			if (ht == 0) return h0v;
-			if (sm.sm == MTFHIP_SM_ICLK) return n_hess(0, 0, r, c, kk);
-			if (sm.sm == MTFHIP_SM_FCLK || ht == 1 || ht == 5) return n_hess(ht == 1 ? 2 : 1, 1, r, c, kk);
-			if (ht == 2) return 0.5 * (n_hess(2, 1, r, c, kk) + h0v);
-			if (ht == 3) return n_hess(1, 2, r, c, kk);
-			return 0.5 * (n_hess(0, 0, r, c, kk) + n_hess(1, 1, r, c, kk));
-		}
-		double v = use_h0 ? h0s[b2 * S + a] : -acc_s[ACC_H + kk];
-		if (sum_h0) v = (v + h0s[b2 * S + a]) * 0.5;
-		return v;
-	};
-	auto g_entry = [&](int s) -> double {
-		if (!ncc) return gscale * acc_s[ACC_G + s];
-		auto cj = [&](int which) { return n_u0(which, s) - n_f * n_ut(which, s); };
-		auto ij = [&](int which) { return (n_b / n_c) * (n_ut(which, s) - n_f * n_u0(which, s)); };
-		if (sm.sm == MTFHIP_SM_FCLK) return cj(1);
-		if (sm.sm == MTFHIP_SM_ICLK) return ij(0);
-		if (sm.jac_type == 0) return cj(2);
-		return 0.5 * (cj(1) - ij(0));
-	};
-	const double dii = h_entry(i, i), djj = h_entry(j, j);
-	const double si = dii != 0 ? 1.0 / sqrt(fabs(dii)) : 1.0, sj = djj != 0 ? 1.0 / sqrt(fabs(djj)) : 1.0;
-	if (wv0) {
-		A[i][j] = h_entry(i, j) * si * sj;
-		if (j == 0) A[i][8] = (i < S ? g_entry(i) : 0.0) * si;
-	}
-	__syncthreads();
-#pragma unroll
-	for (int k = 0; k < 8; ++k) {
-		const double piv = A[k][k], aik = A[i][k], akj = A[k][j], bk = A[k][8];
-		const double f = (i != k && piv != 0) ? aik / piv : 0.0;
-		__syncthreads();
-		if (wv0 && i != k) {
-			A[i][j] -= f * akj;
-			if (j == 0) A[i][8] -= f * bk;
-		}
-		__syncthreads();
-	}
-	if (wv0 && j == 0) {
-		const double d = A[i][i];
-		dps[i] = (i < S && d != 0) ? -(A[i][8] / d) * si : 0.0;
-	}
-	__syncthreads();
-	if (lane != 0) return;
-
-	double dp[8];
-#pragma unroll
-	for (int s = 0; s < 8; ++s) dp[s] = dps[s];
-	double *Wp = bv.warps + 9 * t, *st = bv.states + 8 * t;
-	double U[9];
-	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
-		U[0] = 1 + dp[0]; U[1] = dp[1]; U[2] = dp[2]; U[3] = dp[3]; U[4] = 1 + dp[4]; U[5] = dp[5];
-		U[6] = dp[6]; U[7] = dp[7]; U[8] = 1;
-	} else {
-		U[0] = 1 + dp[2]; U[1] = dp[3]; U[2] = dp[0]; U[3] = dp[4]; U[4] = 1 + dp[5]; U[5] = dp[1];
-		U[6] = 0; U[7] = 0; U[8] = 1;
-	}
-	if (sm.sm == MTFHIP_SM_ICLK) {
-		/* invertState: inverse through cofactors, normalised by (2,2) */
-		double c[9];
-		c[0] = U[4] * U[8] - U[5] * U[7]; c[1] = U[2] * U[7] - U[1] * U[8]; c[2] = U[1] * U[5] - U[2] * U[4];
-		c[3] = U[5] * U[6] - U[3] * U[8]; c[4] = U[0] * U[8] - U[2] * U[6]; c[5] = U[2] * U[3] - U[0] * U[5];
-		c[6] = U[3] * U[7] - U[4] * U[6]; c[7] = U[1] * U[6] - U[0] * U[7]; c[8] = U[0] * U[4] - U[1] * U[3];
-		double det = U[0] * c[0] + U[1] * c[3] + U[2] * c[6];
-		double inv_det = 1.0 / det;
-#pragma unroll
-		for (int q = 0; q < 9; ++q) c[q] *= inv_det;
-		double n22 = c[8];
-#pragma unroll
-		for (int q = 0; q < 9; ++q) U[q] = c[q] / n22;
-		/* round-trip through the state parameterisation as getStateFromWarp / getWarpFromState do */
-		U[0] = 1 + (U[0] - 1); U[4] = 1 + (U[4] - 1); U[8] = 1;
-		if (bv.ssm != MTFHIP_SSM_HOMOGRAPHY) { U[6] = 0; U[7] = 0; }
-	}
-	double Wo[9], Wn[9];
-#pragma unroll
-	for (int q = 0; q < 9; ++q) Wo[q] = Ws[q];
-#pragma unroll
-	for (int r = 0; r < 3; ++r)
-#pragma unroll
-		for (int c2 = 0; c2 < 3; ++c2)
-			Wn[3 * r + c2] = Wo[3 * r] * U[c2] + Wo[3 * r + 1] * U[3 + c2] + Wo[3 * r + 2] * U[6 + c2];
-	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
-		double n22 = Wn[8];
-#pragma unroll
-		for (int q = 0; q < 9; ++q) Wn[q] /= n22;
-		st[0] = Wn[0] - 1; st[1] = Wn[1]; st[2] = Wn[2]; st[3] = Wn[3]; st[4] = Wn[4] - 1; st[5] = Wn[5];
-		st[6] = Wn[6]; st[7] = Wn[7];
-	} else {
-		st[0] = Wn[2]; st[1] = Wn[5]; st[2] = Wn[0] - 1; st[3] = Wn[1]; st[4] = Wn[3]; st[5] = Wn[4] - 1;
-	}
-#pragma unroll
-	for (int q = 0; q < 9; ++q) Wp[q] = Wn[q];
-	double *cr = ts.corners + 8 * t;
-	double change = 0;
-#pragma unroll
-	for (int q = 0; q < 4; ++q) {
-		double X = ics[3 * q], Y = ics[3 * q + 1], Z = ics[3 * q + 2];
-		double nx = Wn[0] * X + Wn[1] * Y + Wn[2] * Z, ny = Wn[3] * X + Wn[4] * Y + Wn[5] * Z;
-		if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
-			double d = Wn[6] * X + Wn[7] * Y + Wn[8] * Z;
-			nx = nx / d; ny = ny / d;
-		}
-		double ddx = crs[2 * q] - nx, ddy = crs[2 * q + 1] - ny;
-		change += ddx * ddx + ddy * ddy;
-		cr[2 * q] = nx; cr[2 * q + 1] = ny;
-	}
-	const int n_it = n_it_prev + 1;
-	ts.n_iters[t] = n_it;
-	if (change < sm.epsilon || n_it >= sm.max_iters) ts.active[t] = 0;
-}
 /* stand-alone finish: one wave per target */
 __global__ __launch_bounds__(128) void k_finish_track(BatchView bv, mtfhip_sm_desc sm, TrackState ts,
 	const double *partials, int nblk) {

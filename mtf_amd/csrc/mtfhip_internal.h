@@ -175,6 +175,22 @@ void launch_mi_hist_self(const BatchView &bv, int nb, double norm_mult, const do
 struct MiJ0Rebuild { const double *dI0, *pts, *z; int hom, init_variant; };
 void launch_mi_grad_gemv(const BatchView &bv, int nb, double norm_mult, const double *It, const double *I0, const double *tb,
 	const double *Jt, const double *J0, const MiJ0Rebuild &rb, double *df_dIt, double *df_dI0, double *partials, int nblk, hipStream_t st);
+/* ---- the recompute form of the MI iteration (kernels_mi_fused.hip; tolerance-mode arithmetic, 8 bins) ---- */
+struct MiFastPlan {
+	int hk;               /* Hessian pass: 0 none (constant Hessian), 1 self(Jt), 2 curr, 3 init(J0) */
+	int hrow;             /* pixel Jacobian of the Hessian pass: 0 Jt, 1 J0, 2 (J0 + Jt) / 2 */
+	int j0_mode;          /* 0 the template's row is not needed, 1 rebuilt from dI0_dx, 2 read from J0 */
+	int j0_init_variant;
+	int need_dft, need_df0, g_mean;
+	double grad_eps, norm_mult, norm_add, hist_norm;
+	const int *active;    /* device flags, NULL = all */
+	const double *tb;     /* [B][MI_SIZE] */
+};
+void launch_mi_pass_hist(const BatchView &bv, const ImgView &im, const MiFastPlan &pl, double *partials, int nblk, int row_len, hipStream_t st);
+void launch_mi_pass_grad_hess(const BatchView &bv, const ImgView &im, const MiFastPlan &pl, double *partials, int nblk, hipStream_t st);
+void launch_mi_finish_fast(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, const MiFastPlan &pl, int gmode, int do_track,
+	const double *partials, int nblk, double *out_H, double *out_g, double *rows, hipStream_t st);
+int mi_fast_row_len();
 /* sums partials over blocks: out[B][ACC_COUNT] */
 void launch_finish(double *partials, int nblk, double *out, int B, hipStream_t st);
 void launch_finish_rows(double *partials, int nblk, int row_len, double *out, int B, hipStream_t st);

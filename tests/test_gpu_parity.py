@@ -260,7 +260,7 @@ def _fused_follow(oracle, gpu_ctx, frame, am, case, materialize, grid):
     tight = grid == "oracle_grid"
     b.set_math_mode(mtf_amd.MATH_REPLAY)
     for it, rec in enumerate(trace):
-        if not materialize and am != L.AM_MI:
+        if not materialize:
             # tolerance-mode arithmetic of the lean launch (FMA, one reciprocal per point, closed-form gradient): the
             # north-star budget as PLAIN relative errors -- H always, g and dp on the first two iterations (afterwards both shrink
             # towards zero and the reference's own grad_eps noise, ~5e-6 per gradient component, is what is left of them)
@@ -270,15 +270,19 @@ def _fused_follow(oracle, gpu_ctx, frame, am, case, materialize, grid):
             dpf = -oracle.colpiv_qr_solve(Hf[0], gf[0])
             assert rel(ff[0], rec["f"]) < 1e-8, it
             assert rel(Hf[0], rec["H"]) < 1e-5, it
-            if it <= 1:
+            if it <= 1 and am != L.AM_MI:
                 assert rel(gf[0], rec["g"]) < 1e-5, it
                 assert rel(dpf, rec["dp"]) < 1e-5, it
-            else:
+            else:   # (MI: the 8-bin Hessian of a 40 x 40 patch amplifies 1e-6 on g, H to a few 1e-5 on dp: corner criterion from the start)
                 gs = np.sqrt(abs(np.trace(rec["H"]))) * (np.sqrt(abs(2 * rec["f"])) if am == L.AM_SSD else 1.0)
                 assert np.linalg.norm(gf[0] - rec["g"]) < 1e-5 * max(np.linalg.norm(rec["g"]), gs), it
                 cf = b.apply_warp_to_corners(corners[None], dpf[None])[0]
                 cr = b.apply_warp_to_corners(corners[None], rec["dp"][None])[0]
-                assert rel(dpf, rec["dp"]) < 1e-5 or np.abs(cf - cr).max() < 1e-6, it
+                if am == L.AM_MI:   # the oracle's own dp moves by 1.5e-5 .. 2.8e-5 here when grad_eps goes from 1e-8 to 2e-8, or
+                    # chained_warp from 1 to 0 (tests/test_oracle_relations.py::test_mi_update_noise_floor): that is the floor
+                    assert rel(dpf, rec["dp"]) < 5e-5 or np.abs(cf - cr).max() < 1e-5, it
+                else:
+                    assert rel(dpf, rec["dp"]) < 1e-5 or np.abs(cf - cr).max() < 1e-6, it
         f, g, H = b.iterate(sm)
         dp = -oracle.colpiv_qr_solve(H[0], g[0])
         if it <= 1 and not tight:    # plain relative errors while g and dp are far from zero (north_star's literal wording)

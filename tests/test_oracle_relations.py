@@ -399,3 +399,31 @@ def test_update_model_is_the_documented_average(oracle, frame, frame2):
     mi.initialize_pix_vals(ssm.get("curr_pts"))
     assert not mi.update_model(ssm.get("curr_pts"), 0.5)
 
+
+
+def test_mi_update_noise_floor(oracle, frame):
+    """How far the REFERENCE's own MI parameter update moves when its finite-difference step or the (mathematically
+    equivalent) chained / non-chained gradient route changes: grad_eps = 1e-8 (ImageBase.h:7-8) leaves ~1e-6 absolute
+    noise on every gradient component, and the 8-bin MI Hessian of a 40 x 40 patch amplifies it to a few 1e-5 on dp from the
+    second iteration on.  This is the floor the tolerance-mode device arithmetic (closed-form gradient: no such noise) is
+    compared against in tests/test_gpu_parity.py::_fused_follow -- a dp tolerance tighter than this would test the oracle's
+    noise, not the device."""
+    rng = np.random.default_rng(17)
+    centre, res = (250.0, 262.0), 40
+    corners = synth.square_corners(centre[0], centre[1], 2.0 * res)
+    frame_2 = synth.warp_frame(frame, synth.random_small_homography(rng, 0.6), centre)
+
+    def run(eps, chained):
+        ssm = oracle.SSM(oracle.SSM_HOM, res, res)
+        am = oracle.AM(oracle.AM_MI, res, res, grad_eps=eps)
+        am.set_curr_img(frame)
+        trk = oracle.Tracker(oracle.SM_ESM, am, ssm, leven_marq=0, max_iters=3, hess_type=1, chained_warp=chained)
+        trk.initialize(corners); am.set_curr_img(frame_2); trk.update()
+        return trk.trace()
+
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    a, b, c = run(1e-8, 0), run(2e-8, 0), run(1e-8, 1)
+    assert rel(a[0]["H"], b[0]["H"]) < 1e-5 and rel(a[0]["g"], b[0]["g"]) < 1e-5      # H and g themselves stay inside the budget
+    assert rel(a[0]["dp"], c[0]["dp"]) < 1e-7                                          # same route at identity
+    floor = max(rel(a[1]["dp"], b[1]["dp"]), rel(a[1]["dp"], c[1]["dp"]))
+    assert 5e-6 < floor < 2e-4, floor
