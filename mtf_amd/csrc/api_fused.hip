@@ -591,7 +591,7 @@ static int mi_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, doub
 	hipStream_t st = b->ctx->stream;
 	const MiPlan pl(sm);
 	if (mi_fast_ok(b, sm, pl)) {
-		TrackState ts{b->d_acc, b->d_h0, b->d_corners, b->d_init_corners_hm, b->d_active, b->d_iters, nullptr, nullptr, 1};
+		TrackState ts{b->d_acc, b->d_h0, b->d_corners, b->d_init_corners_hm, b->d_active, b->d_iters, nullptr, nullptr, 1, nullptr, nullptr};
 		TRY(mi_enqueue_fast(b, sm, pl, nullptr, ts, 0));
 	} else
 	TRY(mi_enqueue(b, sm, pl, nullptr));
@@ -714,7 +714,6 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
 	TRY(check_sm(b, sm, "track"));
 	TRY(single_channel(b, "track"));
-	if (sm->leven_marq) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: Levenberg-Marquardt is only available through iterate + host solve");
 	if (sm->max_iters <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "track: max_iters must be positive");
 	if (b->desc.am != MTFHIP_AM_SSD ? sm->sec_ord_hess != 0 : second_order_term(sm) >= 0)
 		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: a second-order Hessian is indefinite and needs the pivoted host solve; use iterate");
@@ -722,7 +721,8 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 	TRY(need_image(b));
 	hipStream_t st = b->ctx->stream;
 	const bool mi = b->desc.am == MTFHIP_AM_MI;
-	const bool one_launch = !mi && sm->sm == MTFHIP_SM_ICLK && (sm->hess_type == 0 || (sm->hess_type == 2 && b->desc.am == MTFHIP_AM_SSD)) &&
+	/* (the one-launch grid kernel has no Levenberg-Marquardt: with it ICLK takes the fused launch + finish per pass) */
+	const bool one_launch = !mi && !sm->leven_marq && sm->sm == MTFHIP_SM_ICLK && (sm->hess_type == 0 || (sm->hess_type == 2 && b->desc.am == MTFHIP_AM_SSD)) &&
 		b->N <= kIclkTrackMaxPix;
 	FusedArgs fa;
 	if (!one_launch && !mi) TRY(fused_args(b, sm, fa));
@@ -751,7 +751,20 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 		for (int v : h_active) if (v) return false;
 		return true;
 	};
-	TrackState ts{b->d_acc, b->d_h0, b->d_corners, b->d_init_corners_hm, b->d_active, b->d_iters, ncc ? b->d_ncc : nullptr, ncc ? b->d_ncc_tm : nullptr};
+	TrackState ts{b->d_acc, b->d_h0, b->d_corners, b->d_init_corners_hm, b->d_active, b->d_iters, ncc ? b->d_ncc : nullptr, ncc ? b->d_ncc_tm : nullptr, 0, nullptr, nullptr};
+	if (sm->leven_marq) {
+		/* per-target LM state: prev_similarity 0, leven_marq_delta = lm_delta_init, no pending reset, iteration 0 */
+		if (!b->d_lm) HIP_TRY(hipMalloc(&b->d_lm, sizeof(double) * kLmStride * (size_t)b->B));
+		std::vector<double> lm0((size_t)kLmStride * b->B, 0.0);
+		for (int t = 0; t < b->B; ++t) lm0[(size_t)kLmStride * t + 1] = sm->lm_delta_init;
+		HIP_TRY(hipMemcpyAsync(b->d_lm, lm0.data(), sizeof(double) * lm0.size(), hipMemcpyHostToDevice, st));
+		HIP_TRY(hipStreamSynchronize(st));   /* lm0 is a stack-lifetime buffer */
+		ts.lm = b->d_lm;
+		if (mi) ts.f_ext = b->d_mi_f;
+	}
+	/* passes to enqueue: a rejected Levenberg-Marquardt step does not consume an iteration of FCLK's while loop (NT/FCLK.cc:193-223),
+	 * and two rejections never follow each other (the pass after an undo skips the test) */
+	const int max_passes = (sm->leven_marq && sm->sm == MTFHIP_SM_FCLK) ? 2 * sm->max_iters : sm->max_iters;
 	BatchView bv = b->view();
 	if (b->desc.am == MTFHIP_AM_MI) {
 		/* the fused MI passes leave g and H on the device; k_finish_track_mi lays them out as one reduced row per target and
@@ -761,7 +774,7 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 		ts.h_from_acc = 1;
 		const int ng = simple_blocks_per_target(b->N) < 64 ? simple_blocks_per_target(b->N) : 64;   /* as the gradient pass of mi_enqueue */
 		const bool fast = mi_fast_ok(b, sm, pl);
-		for (int it = 0; it < sm->max_iters; ++it) {
+		for (int it = 0; it < max_passes; ++it) {
 			if (fast) {
 				TRY(mi_enqueue_fast(b, sm, pl, b->d_active, ts, 1));
 			} else {
@@ -790,10 +803,10 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 			fc.active = fa.active + t0;
 			TrackState tc{ts.acc + (size_t)t0 * RL, ts.h0 + (size_t)t0 * 64, ts.corners + 8 * (size_t)t0,
 				ts.init_corners_hm + 12 * (size_t)t0, ts.active + t0, ts.n_iters + t0, ncc ? ts.ncc + 8 * (size_t)t0 : nullptr,
-				ncc ? ts.ncc_tm + 52 * (size_t)t0 : nullptr};
+				ncc ? ts.ncc_tm + 52 * (size_t)t0 : nullptr, 0, ts.lm ? ts.lm + (size_t)kLmStride * t0 : nullptr, nullptr};
 			int nblk_c; { int rows; fused_decomposition(b->N, nt, nblk_c, rows); fc.rows_per_block = rows; }
 			double *part = b->d_partials + (size_t)t0 * b->nblk_max * RL;
-			for (int it = 0; it < sm->max_iters; ++it) {
+			for (int it = 0; it < max_passes; ++it) {
 				{
 					TimedScope tsc(b->ctx, "fused_lk");
 					launch_fused_ssd(bc, b->ctx->img, fc, part, nblk_c, st);

@@ -247,6 +247,7 @@ struct mtfhip_batch {
 	bool pts_stale = false;
 	double *d_it_shadow = nullptr;
 	double *d_ncc_tm = nullptr;   /* [B][52] NCC template moments for the device-side finish */
+	double *d_lm = nullptr;       /* [B][kLmStride] Levenberg-Marquardt state of the device-side loop */
 	/* NCC: a fused iteration updated the scalars (It_mean, a, b, f) on the host only; the un-fused kernels read d_ncc */
 	bool ncc_host_newer = false;
 	size_t slab_bytes = 0, slab_dbl_bytes = 0;

@@ -81,6 +81,35 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 	if (lane < RL) { acc_s[lane] = v_acc; ts.acc[(size_t)t * RL + lane] = v_acc; }
 	__syncthreads();
 	const int i = (lane >> 3) & 7, j = lane & 7;
+	/* ---- Levenberg-Marquardt: the accept / undo test on the similarity of this pass (uniform over the workgroup) ---- */
+	double *lmp = ts.lm ? ts.lm + (size_t)t * kLmStride : nullptr;
+	double lm_delta = 0.0;
+	int lm_iter_id = n_it_prev;   /* (only lane 0's copy of n_it_prev is loaded; LM keeps its own counter) */
+	bool undo = false;
+	if (lmp) {
+		const double f_now = ts.f_ext ? ts.f_ext[t] : (ncc ? 0.0 : -acc_s[ACC_RR] / 2);
+		const double prev_f = lmp[0];
+		lm_delta = lmp[1];
+		const bool state_reset = lmp[2] != 0.0;
+		lm_iter_id = (int)lmp[3];
+		double f_use = f_now;
+		if (ncc) {
+			const double nN0 = (double)bv.N, mt0 = acc_s[NCC_IT] / nN0, b20 = acc_s[NCC_IT2] - nN0 * mt0 * mt0;
+			f_use = (acc_s[NCC_I0IT] - nN0 * ncs[0] * mt0) / (sqrt(b20) * ncs[1]);
+		}
+		if (!state_reset) {
+			if (lm_iter_id > 0) {
+				if (f_use < prev_f) { lm_delta *= sm.lm_delta_update; undo = true; }
+				else if (f_use > prev_f) lm_delta /= sm.lm_delta_update;
+			}
+		}
+		__syncthreads();   /* every thread has read the LM block before lane 0 rewrites it */
+		if (lane == 0) {
+			lmp[1] = lm_delta;
+			if (undo) lmp[2] = 1.0;
+			else { lmp[2] = 0.0; if (!state_reset) lmp[0] = f_use; }
+		}
+	}
 	const bool use_h0 = (sm.hess_type == 0) || (sm.sm == MTFHIP_SM_ICLK && !ts.h_from_acc);
 	const bool sum_h0 = (sm.sm == MTFHIP_SM_ESM) && (sm.hess_type == 2 || (sm.hess_type == 4 && !ts.h_from_acc));   /* (MI's SumOfStd arrives summed) */
 	const double gscale = (sm.sm == MTFHIP_SM_ESM) ? 0.5 : 1.0;
@@ -133,12 +162,25 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 	const double dii = h_entry(i, i), djj = h_entry(j, j);
 	const double si = dii != 0 ? 1.0 / sqrt(fabs(dii)) : 1.0, sj = djj != 0 ? 1.0 / sqrt(fabs(djj)) : 1.0;
 	if (wv0) {
-		A[i][j] = h_entry(i, j) * si * sj;
+		/* hessian(i, i) += leven_marq_delta * hessian(i, i) (NT/ESM.cc:262-265) */
+		A[i][j] = h_entry(i, j) * si * sj * ((lmp && i == j && i < S) ? 1.0 + lm_delta : 1.0);
 		if (j == 0) A[i][8] = (i < S ? g_entry(i) : 0.0) * si;
 	}
 	__syncthreads();
+	/* Gauss-Jordan with partial pivoting: the SSD Hessians are negated Gram matrices, but NCC's Std / SumOfStd and MI's
+	 * Hessians can be indefinite away from convergence, where the reference's colPivHouseholderQr (NT/FCLK.cc:298) does
+	 * not care either.  A column whose remaining entries are all zero (flat template) leaves its unknown at zero. */
 #pragma unroll
 	for (int k = 0; k < 8; ++k) {
+		int pr = k;
+		double best = fabs(A[k][k]);
+#pragma unroll
+		for (int r = k + 1; r < 8; ++r) { const double v = fabs(A[r][k]); if (v > best) { best = v; pr = r; } }
+		const int src = i == k ? pr : (i == pr ? k : i);   /* row i after the swap of rows k and pr */
+		const double mine = A[src][j], rhs = A[src][8];
+		__syncthreads();
+		if (wv0) { A[i][j] = mine; if (j == 0) A[i][8] = rhs; }
+		__syncthreads();
 		const double piv = A[k][k], aik = A[i][k], akj = A[k][j], bk = A[k][8];
 		const double f = (i != k && piv != 0) ? aik / piv : 0.0;
 		__syncthreads();
@@ -157,7 +199,11 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 
 	double dp[8];
 #pragma unroll
-	for (int s = 0; s < 8; ++s) dp[s] = dps[s];
+	for (int s = 0; s < 8; ++s) dp[s] = undo ? lmp[4 + s] : dps[s];   /* undo: the previous state_update is taken back */
+	if (lmp && !undo) {
+#pragma unroll
+		for (int s = 0; s < 8; ++s) lmp[4 + s] = dp[s];
+	}
 	double *Wp = bv.warps + 9 * t, *st = bv.states + 8 * t;
 	double U[9];
 	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
@@ -167,7 +213,9 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 		U[0] = 1 + dp[2]; U[1] = dp[3]; U[2] = dp[0]; U[3] = dp[4]; U[4] = 1 + dp[5]; U[5] = dp[1];
 		U[6] = 0; U[7] = 0; U[8] = 1;
 	}
-	if (sm.sm == MTFHIP_SM_ICLK) {
+	/* forward step: ICLK applies the inverse of the solved update (NT/ICLK.cc:266-267); undo: ESM / FCLK apply the inverse of
+	 * the previous update (NT/ESM.cc:194-195), ICLK re-applies it (NT/ICLK.cc:188) */
+	if ((sm.sm == MTFHIP_SM_ICLK) != undo) {
 		/* invertState: inverse through cofactors, normalised by (2,2) */
 		double c[9];
 		c[0] = U[4] * U[8] - U[5] * U[7]; c[1] = U[2] * U[7] - U[1] * U[8]; c[2] = U[1] * U[5] - U[2] * U[4];
@@ -217,9 +265,15 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 		change += ddx * ddx + ddy * ddy;
 		cr[2 * q] = nx; cr[2 * q + 1] = ny;
 	}
-	const int n_it = n_it_prev + 1;
+	const int n_it = n_it_prev + 1;   /* passes done (the reference's iters_done) */
 	ts.n_iters[t] = n_it;
-	if (change < sm.epsilon || n_it >= sm.max_iters) ts.active[t] = 0;
+	if (lmp) {
+		/* an undo pass skips the convergence test (`continue`); it consumes an iteration in the for loops of ESM and ICLK
+		 * (NT/ESM.cc:179, NT/ICLK.cc:169) but not in FCLK's while loop (NT/FCLK.cc:193-223) */
+		const int id = lm_iter_id + ((undo && sm.sm == MTFHIP_SM_FCLK) ? 0 : 1);
+		lmp[3] = (double)id;
+		if ((!undo && change < sm.epsilon) || id >= sm.max_iters) ts.active[t] = 0;
+	} else if (change < sm.epsilon || n_it >= sm.max_iters) ts.active[t] = 0;
 }
 
 } // namespace mtfhip

@@ -94,7 +94,12 @@ struct TrackState {
 	const double *ncc;    /* [B][8] NCC scalars (mean(I0), |I0 - mean|, ...), NULL for SSD */
 	const double *ncc_tm; /* [B][52] NCC template moments: sum J0 | sum I0 J0 | Gram(J0) */
 	int h_from_acc;       /* 1: every non-constant Hessian type reads the reduced row, ICLK's included (MI: k_finish_track_mi) */
+	/* Levenberg-Marquardt (NT/ESM.cc:186-232, NT/FCLK.cc:205-250, NT/ICLK.cc:181-199) inside the device-side loop, per target:
+	 * [0] prev_similarity [1] leven_marq_delta [2] state_reset [3] iter_id [4..11] the last state_update.  NULL: no LM. */
+	double *lm;
+	const double *f_ext;  /* [B] similarity of this pass when it is not a function of the reduced row (MI: d_mi_f), else NULL */
 };
+constexpr int kLmStride = 12;
 
 struct FusedArgs {
 	int mode;          /* accumulation mode: 0 FCLK-type, 1 ESM-type, 2 ICLK-lite (see k_fused_ssd) */

@@ -36,8 +36,6 @@ class LKTracker:
         self.B, self.S = n_targets, self.batch.S
         self.host_solve = host_solve
         self.sm = sm_desc(sm, **params)
-        if not host_solve and self.sm.leven_marq:
-            raise L.FunctionNotImplemented(-2, "Levenberg-Marquardt needs host_solve=True")
         self.n_iters = np.zeros(n_targets, dtype=np.int32)
 
     # nt::*::initialize (NT/ESM.cc:110-146, NT/FCLK.cc:102-169, NT/ICLK.cc:71-128)
@@ -63,7 +61,8 @@ class LKTracker:
         delta = np.full(B, sm.lm_delta_init)
         last_dp = np.zeros((B, self.S))
         self.n_iters[:] = 0
-        # the accept/reject state machine of NT/FCLK.cc:193-217 (same in ESM / ICLK), vectorised over targets
+        # the accept/reject state machine of NT/FCLK.cc:193-217, vectorised over targets.  ESM (NT/ESM.cc:179,224) and ICLK
+        # (NT/ICLK.cc:169,187) are `for` loops whose `continue` still advances iter_id: there a rejected pass consumes an iteration
         it = 0
         state_reset = np.zeros(B, dtype=bool)
         while it < sm.max_iters and active.any():
@@ -113,6 +112,10 @@ class LKTracker:
                     continue
                 if undo[t]:
                     state_reset[t] = True
+                    if sm.sm != L.SM_FCLK:
+                        self.n_iters[t] += 1
+                        if self.n_iters[t] >= sm.max_iters:
+                            active[t] = False
                     continue
                 state_reset[t] = False
                 self.n_iters[t] += 1

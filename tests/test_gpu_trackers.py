@@ -39,9 +39,11 @@ def test_lk_trackers_recover_known_warp(gpu_ctx, frame, sm, host_solve, am):
     assert 2 <= int(trk.n_iters[0]) <= 40
 
 
-def test_lm_host_loop_matches_oracle(oracle, gpu_ctx, frame):
-    """Levenberg-Marquardt accept / reject on the host with device f, g, H: same corners and iteration
-    count as the oracle's nt::FCLK with leven_marq = 1 on a motion large enough to trigger rejections."""
+@pytest.mark.parametrize("host_solve", [True, False])
+def test_lm_host_loop_matches_oracle(oracle, gpu_ctx, frame, host_solve):
+    """Levenberg-Marquardt accept / undo -- on the host with device f, g, H, and inside the device-side loop
+    (mtfhip_batch_track: the test and the undo are part of k_finish_track): same corners as the oracle's nt:: trackers with
+    leven_marq = 1 (the class default, ESMParams.cc:4-15) on a motion large enough to trigger rejections."""
     centre = (256.0, 250.0)
     corners = synth.square_corners(centre[0], centre[1], 100)
     p_true = np.array([0.01, -0.01, 6.0, 0.01, 0.0, -5.0, 0, 0])
@@ -51,14 +53,16 @@ def test_lm_host_loop_matches_oracle(oracle, gpu_ctx, frame):
         otrk = oracle.Tracker(sm, o_am, o_ssm, leven_marq=1, max_iters=60, epsilon=1e-8)
         otrk.initialize(corners)
         o_am.set_curr_img(frame2)
-        otrk.update()
+        o_iters = otrk.update()
         gpu_ctx.set_image(frame)
-        trk = LKTracker(gpu_ctx, sm, L.SSM_HOMOGRAPHY, 40, 40, 1, host_solve=True, leven_marq=1, max_iters=60,
+        trk = LKTracker(gpu_ctx, sm, L.SSM_HOMOGRAPHY, 40, 40, 1, host_solve=host_solve, leven_marq=1, max_iters=60,
                         epsilon=1e-8, materialize=0, am=am)
         trk.initialize(corners[None])
         gpu_ctx.set_image(frame2)
         out = trk.update()
         np.testing.assert_allclose(out[0], otrk.get_region(), atol=5e-4)
+        if not host_solve:   # the device loop counts passes like the reference's iters_done
+            assert abs(int(trk.n_iters[0]) - o_iters) <= 2, (sm, am, trk.n_iters, o_iters)
         assert np.abs(out[0] - gt_corners(corners, p_true, centre)).max() < 0.1
 
 
