@@ -284,6 +284,55 @@ int mtfhip_score_candidates(mtfhip_batch *b, const double *states /* C x S */, i
 int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int n_candidates,
 	double *dev_likelihoods, double *dev_similarities);
 
+/* ---- the particle filter on the device: nt::PF (SM/src/NT/PF.cc) over the batch's single target ----
+ * Sample generation (the SSM's stochastic sampler and dynamic models: ProjectiveBase.cc:163-317, Homography.cc:899-942),
+ * scoring, cumulative weights, multinomial resampling and the estimate run as four launches per iteration; only the estimate
+ * (state, corners, best weight) crosses PCIe.  Enum values are the reference's (SM/include/mtf/SM/PFParams.h:10-33).
+ * Not provided: several sampler distributions (n_distr > 1), jacobian_as_sigma, residual resampling, the geometric
+ * (SVD based) sampler of Affine.cc:464-552 -- the calls return MTFHIP_ERR_NOT_IMPLEMENTED. */
+typedef struct mtfhip_pf mtfhip_pf;
+typedef struct mtfhip_comm mtfhip_comm;
+typedef struct mtfhip_pf_desc {
+	int n_particles, max_iters;
+	double epsilon;
+	int dynamic_model;        /* 0 RandomWalk, 1 AutoRegression1 */
+	int update_type;          /* 0 Additive, 1 Compositional */
+	int likelihood_func;      /* 0 AM, 1 Gaussian, 2 Reciprocal */
+	int resampling_type;      /* 0 None, 1 BinaryMultinomial, 2 LinearMultinomial, (3 Residual: not implemented) */
+	int mean_type;            /* 0 None (highest weight), 1 SSM (mean state), 2 Corners (mean corners, then setCorners) */
+	int corner_based_sampling;/* HomographyParams::corner_based_sampling (on by default, parameters.h:262) */
+	int reset_to_mean;
+	double measurement_sigma; /* Gaussian likelihood (PF.cc:69-70, 352-354) */
+	double ar_coeff;          /* a of the AutoRegression1 models (StateSpaceModel.h:311-318: 0.5) */
+	double ssm_sigma[8], ssm_mean[8]; /* the sampler's normal distributions (ProjectiveBase::initializeSampler) */
+	unsigned long long seed;  /* device generator (Philox4x32-10), used when no draws are handed in */
+} mtfhip_pf_desc;
+int mtfhip_pf_create(mtfhip_batch *b, const mtfhip_pf_desc *desc, mtfhip_pf **out);
+void mtfhip_pf_destroy(mtfhip_pf *pf);   /* before the batch it was created on */
+/* nt::PF::initialize after ssm->initialize / am->initializePixVals / am->initializeSimilarity (PF.cc:136-183) */
+int mtfhip_pf_initialize(mtfhip_pf *pf);
+int mtfhip_pf_set_region(mtfhip_pf *pf, const double *corners /* 8 */);          /* PF.cc:616-620 */
+int mtfhip_pf_set_sampler(mtfhip_pf *pf, const double *sigma, const double *mean); /* ProjectiveBase.cc:208-215 */
+/* one iteration of update()'s loop (PF.cc:260-447); normals n x nz (nz = 10 with corner based homography sampling, else S)
+ * and uniforms n: host arrays, or NULL for the device generator; update_norm = squared corner change of the estimate */
+int mtfhip_pf_iteration(mtfhip_pf *pf, const double *normals, const double *uniforms, double *update_norm);
+int mtfhip_pf_update(mtfhip_pf *pf, int *n_iters);                                   /* PF.cc:207-447 */
+int mtfhip_pf_get_particles(mtfhip_pf *pf, double *states /* n x S */, double *ars, double *wts /* n */, int *resample_ids /* n */);
+int mtfhip_pf_set_particles(mtfhip_pf *pf, const double *states, const double *ars /* or NULL: zeros */);
+double mtfhip_pf_max_similarity(const mtfhip_pf *pf);
+/* ---- the collective of the sharded candidate axis: RCCL directly (no torch), bound with dlopen at first use ----
+ * rank 0 obtains the 128-byte id and hands it to the other ranks by whatever channel the host program has (MPI, a file, a
+ * socket, torch.distributed); every rank then creates its communicator.  SM/src/PF.cc:262-277 is the weights vector this
+ * replaces once particles are sharded: rank r scores its contiguous block, ONE all-gather puts every weight on every rank,
+ * resampling runs redundantly on identical data. */
+int mtfhip_comm_unique_id(void *id128);
+int mtfhip_comm_create(const void *id128 /* NULL allowed for world 1 */, int rank, int world, int device, mtfhip_comm **out);
+void mtfhip_comm_destroy(mtfhip_comm *comm);
+int mtfhip_comm_rank(const mtfhip_comm *comm);
+int mtfhip_comm_world(const mtfhip_comm *comm);
+int mtfhip_allgather_scores(mtfhip_comm *comm, const double *dev_send, int count_per_rank, double *dev_recv /* world x count */, void *hip_stream);
+int mtfhip_pf_set_comm(mtfhip_pf *pf, mtfhip_comm *comm);   /* shard the filter's scoring over the communicator's ranks */
+
 /* ---- NN-SM dataset generation (the second batch axis of the path; the search itself stays with FLANN) ----
  * Row c of the C x N feature matrix = updateDistFeat() of the patch sampled under state c:
  * setState / compositionalUpdate -> updatePixVals -> updateDistFeat (SM/src/NT/NN.cc:131-191;

@@ -57,6 +57,13 @@ class SMDesc(C.Structure):
                 ("sec_ord_hess", C.c_int)]
 
 
+class PFDesc(C.Structure):
+    _fields_ = [("n_particles", C.c_int), ("max_iters", C.c_int), ("epsilon", C.c_double), ("dynamic_model", C.c_int),
+                ("update_type", C.c_int), ("likelihood_func", C.c_int), ("resampling_type", C.c_int), ("mean_type", C.c_int),
+                ("corner_based_sampling", C.c_int), ("reset_to_mean", C.c_int), ("measurement_sigma", C.c_double),
+                ("ar_coeff", C.c_double), ("ssm_sigma", C.c_double * 8), ("ssm_mean", C.c_double * 8), ("seed", C.c_ulonglong)]
+
+
 # every exported symbol of include/mtfhip.h (tests check that the library exports all of them)
 SYMBOLS = [
     "mtfhip_last_error", "mtfhip_device_count", "mtfhip_ctx_create", "mtfhip_ctx_destroy",
@@ -85,6 +92,10 @@ SYMBOLS = [
     "mtfhip_batch_track_targets_per_launch",
     "mtfhip_score_candidates", "mtfhip_score_candidates_dev",
     "mtfhip_sample_candidates", "mtfhip_sample_candidates_dev",
+    "mtfhip_pf_create", "mtfhip_pf_destroy", "mtfhip_pf_initialize", "mtfhip_pf_set_region", "mtfhip_pf_set_sampler",
+    "mtfhip_pf_iteration", "mtfhip_pf_update", "mtfhip_pf_get_particles", "mtfhip_pf_set_particles", "mtfhip_pf_max_similarity",
+    "mtfhip_comm_unique_id", "mtfhip_comm_create", "mtfhip_comm_destroy", "mtfhip_comm_rank", "mtfhip_comm_world",
+    "mtfhip_allgather_scores", "mtfhip_pf_set_comm",
     "mtfhip_timing_enable", "mtfhip_timing_reset", "mtfhip_timing_get",
 ]
 
@@ -119,6 +130,7 @@ def lib():
         L.mtfhip_last_error.restype = C.c_char_p
         L.mtfhip_ctx_stream.restype = C.c_void_p
         L.mtfhip_batch_device_ptr.restype = C.c_void_p
+        L.mtfhip_pf_max_similarity.restype = C.c_double
         L.mtfhip_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.mtfhip_batch_create.argtypes = [C.c_void_p, C.POINTER(PatchDesc), C.c_int, C.POINTER(C.c_void_p)]
         L.mtfhip_image_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]

@@ -196,6 +196,20 @@ void launch_mi_pass_grad_hess(const BatchView &bv, const ImgView &im, const MiFa
 void launch_mi_finish_fast(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, const MiFastPlan &pl, int gmode, int do_track,
 	const double *partials, int nblk, double *out_H, double *out_g, double *rows, hipStream_t st);
 int mi_fast_row_len();
+/* ---- particle filter besides scoring (kernels_pf.hip) ---- */
+struct PfLaunch {
+	int n, S;
+	int dynamic_model, update_type, corner_based, likelihood_func, resampling_type, mean_type;
+	double ar_coeff, measurement_sigma, max_similarity;
+	double sigma[8], mean[8], init_corners[8], init_corners_hm[12], sq_inv[9];
+	unsigned long long seed;
+	unsigned iter;
+	const double *normals, *uniforms;   /* device arrays or NULL (Philox) */
+};
+void launch_pf_propagate(int ssm, const PfLaunch &p, double *states, double *ars, hipStream_t st);
+void launch_pf_resample(int ssm, const PfLaunch &p, const double *lik, const double *sim, double *wts, double *cum, const double *st_in,
+	const double *ar_in, double *st_out, double *ar_out, int *ids, double *out, hipStream_t st);
+void launch_pf_fill(int n, int S, const double *dev_state, double *states, double *ars, hipStream_t st);
 /* sums partials over blocks: out[B][ACC_COUNT] */
 void launch_finish(double *partials, int nblk, double *out, int B, hipStream_t st);
 void launch_finish_rows(double *partials, int nblk, int row_len, double *out, int B, hipStream_t st);

@@ -49,7 +49,17 @@ class ShardedScorer:
             raise RuntimeError("ShardedScorer needs a Batch (HIP scorer); there is no CPU fallback")
         st = torch.as_tensor(np.ascontiguousarray(states_shard, dtype=np.float64)).to(self.device)
         lik = torch.empty(st.shape[0], dtype=torch.float64, device=self.device)
-        self.batch.score_candidates_dev(st.data_ptr(), st.shape[0], lik.data_ptr())
+        # The scorer runs on the Context's stream, which need not be torch's current stream (a default Context owns a private
+        # non-blocking one): order the two explicitly.  `st` was produced on torch's stream -> the context waits for it; `lik` is
+        # consumed on torch's stream (copy, all-gather) -> torch waits for the context; and the temporary `st` must outlive the
+        # kernel that reads it, so it is only released after the context's stream has drained.
+        cur = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
+        if cur is not None and cur.cuda_stream != (self.batch.ctx.stream or 0):
+            cur.synchronize()
+            self.batch.score_candidates_dev(st.data_ptr(), st.shape[0], lik.data_ptr())
+            self.batch.ctx.synchronize()
+        else:
+            self.batch.score_candidates_dev(st.data_ptr(), st.shape[0], lik.data_ptr())
         return lik
 
     def score(self, states):

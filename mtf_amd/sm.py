@@ -346,29 +346,127 @@ class GridTracker:
         return self.tracker.n_iters
 
 
+class Comm:
+    """A communicator of the C-ABI collective (mtfhip_comm_*: RCCL directly, no torch).  rank 0 calls Comm.unique_id() and hands
+    the 128 bytes to the other ranks over whatever channel the host program has; `torch_bootstrap` does it with a
+    torch.distributed object broadcast when a process group exists (the bench and the tests use that)."""
+
+    def __init__(self, rank=0, world=1, device=0, unique_id=None):
+        import ctypes as C
+        self._h = C.c_void_p()
+        buf = (C.c_char * 128).from_buffer_copy(unique_id) if unique_id is not None else None
+        L.check(L.lib().mtfhip_comm_create(buf, int(rank), int(world), int(device), C.byref(self._h)))
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        buf = (C.c_char * 128)()
+        L.check(L.lib().mtfhip_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def torch_bootstrap(cls, device):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return cls(0, 1, device)
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls(rank, world, device, box[0])
+
+    def allgather(self, dev_send, count, dev_recv, stream=None):
+        import ctypes as C
+        L.check(L.lib().mtfhip_allgather_scores(self._h, C.c_void_p(dev_send), int(count), C.c_void_p(dev_recv),
+                                                C.c_void_p(stream) if stream else None))
+
+    def close(self):
+        if self._h:
+            L.lib().mtfhip_comm_destroy(self._h)
+            self._h = None
+
+
 class ParticleFilter:
-    """PF + SSD or NCC + Homography/Affine (SM/src/PF.cc): dynamic model RandomWalk, update type Compositional,
-    likelihood function AM, resampling BinaryMultinomial, mean type None (highest weight) or Corners."""
+    """nt::PF (SM/src/NT/PF.cc) over the device filter of the C ABI (mtfhip_pf_*): sample generation, scoring, cumulative
+    weights, multinomial resampling and the estimate all run on the device; parameter names and enum values are the
+    reference's (PFParams.h).  `comm` shards the scoring over the ranks of a Comm (one RCCL all-gather per iteration)."""
 
     def __init__(self, ctx, ssm=L.SSM_HOMOGRAPHY, resx=50, resy=50, n_particles=500,
-                 ssm_sigma=(0.01, 0.01, 2.0, 0.01, 0.01, 2.0, 1e-5, 1e-5), likelihood_alpha=1.0,
-                 max_iters=1, epsilon=0.01, seed=0, scorer=None, am=L.AM_SSD):
+                 ssm_sigma=(0.01, 0.01, 2.0, 0.01, 0.01, 2.0, 1e-5, 1e-5), ssm_mean=(0.0,) * 8, likelihood_alpha=1.0,
+                 max_iters=1, epsilon=0.01, seed=0, am=L.AM_SSD, dynamic_model=0, update_type=1, likelihood_func=0,
+                 resampling_type=1, mean_type=0, corner_based_sampling=0, reset_to_mean=0, measurement_sigma=0.1, ar_coeff=0.5,
+                 comm=None):
+        import ctypes as C
         self.batch = Batch(ctx, am, ssm, resx, resy, 1, likelihood_alpha=likelihood_alpha)
-        self.S = self.batch.S
-        self.n = n_particles
-        self.sigma = np.asarray(ssm_sigma, dtype=np.float64)[: self.S]
-        self.max_iters, self.epsilon = max_iters, epsilon
-        self.rng = np.random.default_rng(seed)
-        self.scorer = scorer   # optional dist.ShardedScorer
-        self.states = np.zeros((n_particles, self.S))
-        self.wts = np.full(n_particles, 1.0 / n_particles)
+        self.S, self.n = self.batch.S, n_particles
+        self.desc = L.PFDesc(n_particles, max_iters, epsilon, dynamic_model, update_type, likelihood_func, resampling_type, mean_type,
+                             corner_based_sampling, reset_to_mean, measurement_sigma, ar_coeff)
+        for k in range(8):
+            self.desc.ssm_sigma[k] = float(ssm_sigma[k]) if k < len(ssm_sigma) else 0.0
+            self.desc.ssm_mean[k] = float(ssm_mean[k]) if k < len(ssm_mean) else 0.0
+        self.desc.seed = int(seed)
+        self._h = C.c_void_p()
+        L.check(L.lib().mtfhip_pf_create(self.batch._h, C.byref(self.desc), C.byref(self._h)))
+        self.comm = comm
+        if comm is not None:
+            L.check(L.lib().mtfhip_pf_set_comm(self._h, comm._h))
+        self.nz = 10 if (ssm == L.SSM_HOMOGRAPHY and corner_based_sampling) else self.S
+        self.n_iters = 0
 
+    def close(self):
+        if self._h:
+            L.lib().mtfhip_pf_destroy(self._h)
+            self._h = None
+        self.batch.close()
+
+    # nt::PF::initialize (NT/PF.cc:136-183)
     def initialize(self, corners):
         self.batch.set_corners(np.asarray(corners, dtype=np.float64).reshape(1, 2, 4))
         self.batch.initialize_pix_vals()
         self.batch.initialize_similarity()
-        self.states[:] = 0           # PF::initializeParticles PF.cc:166-180
-        self.wts[:] = 1.0 / self.n
+        L.check(L.lib().mtfhip_pf_initialize(self._h))
+
+    def set_region(self, corners):
+        c = self.batch._corners_in(np.asarray(corners, dtype=np.float64).reshape(1, 2, 4))
+        L.check(L.lib().mtfhip_pf_set_region(self._h, c.ctypes.data_as(L.C.c_void_p)))
+
+    def get_region(self):
+        return self.batch.get_corners()
+
+    def iteration(self, normals=None, uniforms=None):
+        """one iteration of update()'s loop; normals (n, nz) / uniforms (n,) or None for the device generator"""
+        import ctypes as C
+        nz = None if normals is None else np.ascontiguousarray(np.asarray(normals, dtype=np.float64).reshape(self.n, self.nz))
+        un = None if uniforms is None else np.ascontiguousarray(np.asarray(uniforms, dtype=np.float64).reshape(self.n))
+        norm = C.c_double()
+        L.check(L.lib().mtfhip_pf_iteration(self._h, None if nz is None else nz.ctypes.data_as(C.c_void_p),
+                                            None if un is None else un.ctypes.data_as(C.c_void_p), C.byref(norm)))
+        return norm.value
+
+    def update(self):
+        import ctypes as C
+        n = C.c_int()
+        L.check(L.lib().mtfhip_pf_update(self._h, C.byref(n)))
+        self.n_iters = n.value
+        return self.batch.get_corners()
+
+    def particles(self):
+        import ctypes as C
+        st, ar, w = np.empty((self.n, self.S)), np.empty((self.n, self.S)), np.empty(self.n)
+        ids = np.empty(self.n, dtype=np.int32)
+        L.check(L.lib().mtfhip_pf_get_particles(self._h, st.ctypes.data_as(C.c_void_p), ar.ctypes.data_as(C.c_void_p),
+                                                w.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p)))
+        return st, ar, w, ids
+
+    def set_particles(self, states, ars=None):
+        import ctypes as C
+        st = np.ascontiguousarray(np.asarray(states, dtype=np.float64).reshape(self.n, self.S))
+        ar = None if ars is None else np.ascontiguousarray(np.asarray(ars, dtype=np.float64).reshape(self.n, self.S))
+        L.check(L.lib().mtfhip_pf_set_particles(self._h, st.ctypes.data_as(C.c_void_p), None if ar is None else ar.ctypes.data_as(C.c_void_p)))
+
+    @property
+    def max_similarity(self):
+        return L.lib().mtfhip_pf_max_similarity(self._h)
 
     @staticmethod
     def _warp(ssm, p):
@@ -377,7 +475,7 @@ class ParticleFilter:
         return np.array([[1 + p[2], p[3], p[0]], [p[4], 1 + p[5], p[1]], [0, 0, 1.0]])
 
     def _compose(self, base, pert):
-        """compositionalRandomWalk (Homography.cc:916-926, Affine analogue): W(base) * W(pert)"""
+        """compositionalRandomWalk (Homography.cc:916-926, Affine analogue): W(base) * W(pert) -- host helper of NNDataset"""
         ssm = self.batch.desc.ssm
         out = np.empty_like(base)
         for k in range(base.shape[0]):
@@ -391,32 +489,11 @@ class ParticleFilter:
 
     @staticmethod
     def binary_multinomial_resample(wts, uniforms):
-        """PF::binaryMultinomialResampling PF.cc:345-394: smallest index whose normalised cumulative
-        weight is >= the uniform draw."""
+        """PF::binaryMultinomialResampling PF.cc:455-502 (host twin of k_pf_resample, used by the CPU tests): smallest index
+        whose normalised cumulative weight is >= the uniform draw."""
         cum = np.cumsum(wts)
         cum = cum / cum[-1]
         return np.minimum(np.searchsorted(cum, uniforms, side="left"), len(wts) - 1)
-
-    def update(self):
-        prev = self.batch.get_corners()
-        for _ in range(self.max_iters):
-            pert = self.rng.normal(0.0, 1.0, size=(self.n, self.S)) * self.sigma
-            self.states = self._compose(self.states, pert)
-            if self.scorer is not None:
-                w = self.scorer.score(self.states)
-                self.wts = w.cpu().numpy() if hasattr(w, "cpu") else np.asarray(w)
-            else:
-                self.wts = self.batch.score_candidates(self.states)
-            max_id = int(np.argmax(self.wts))
-            ids = self.binary_multinomial_resample(self.wts, self.rng.uniform(0.0, 1.0, self.n))
-            best = self.states[max_id].copy()
-            self.states = self.states[ids]
-            self.batch.set_state(best[None])          # MeanType::None: highest weighted particle
-            cur = self.batch.get_corners()
-            if ((prev - cur) ** 2).sum() < self.epsilon:
-                break
-            prev = cur
-        return self.batch.get_corners()
 
 
 class NNDataset:

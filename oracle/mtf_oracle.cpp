@@ -2232,4 +2232,108 @@ int mtfo_pf_binary_multinomial_resample(const double *wts, int n, const double *
 	return max_wt_id;
 }
 
+/* ---- one iteration of nt::PF::update's loop (SM/src/NT/PF.cc:260-447) with the random draws supplied by the caller
+ * (the reference seeds boost::random from random_device, PF.cc:97-105, ProjectiveBase.cc:192-197: not reproducible).
+ * normals: n x nz standard normals, nz = 10 (corner based homography sampling, Homography.cc:899-915: two draws of
+ * distribution 0 for the common translation, then eight of distribution 1 for the four corners) or S (one per state
+ * component, ProjectiveBase.cc:283-288); a draw of N(mean_k, sigma_k) is mean_k + sigma_k z.  uniforms: n draws for the
+ * multinomial resampling.  states / ars: the particle set, replaced by the resampled one.  The SSM ends at the estimate. */
+int mtfo_pf_iteration(mtfo_am *am, mtfo_ssm *ssm, const mtfo_pf_params *pp, double *states, double *ars, const double *normals,
+	const double *uniforms, double max_similarity, double *wts_out, int *resample_ids, int *max_wt_id_out) {
+	const int n = pp->n_particles, S = ssm->S;
+	const bool hom = ssm->kind == MTFO_SSM_HOMOGRAPHY;
+	const bool corner_based = hom && pp->corner_based_sampling;
+	const int nz = corner_based ? 10 : S;
+	vecd wts(n), cum(n), pert(S), ns(S), nar(S);
+	int max_wt_id = 0;
+	double max_wt = std::numeric_limits<double>::lowest();
+	const double pi = 3.14159265358979323846;
+	const double measurement_factor = 1.0 / std::sqrt(2 * pi * pp->measurement_sigma);   /* PF.cc:69-70 */
+	for (int k = 0; k < n; ++k) {
+		const double *z = normals + static_cast<size_t>(k) * nz;
+		double *st = states + static_cast<size_t>(k) * S, *ar = ars + static_cast<size_t>(k) * S;
+		/* generatePerturbation: Homography.cc:899-915 / ProjectiveBase.cc:283-288 */
+		if (corner_based) {
+			double dc[8];
+			const double tx = pp->mean[0] + pp->sigma[0] * z[0], ty = pp->mean[0] + pp->sigma[0] * z[1];
+			for (int c = 0; c < 4; ++c) {
+				dc[2 * c] = ssm->init_corners[2 * c] + (pp->mean[1] + pp->sigma[1] * z[2 + 2 * c]) + tx;
+				dc[2 * c + 1] = ssm->init_corners[2 * c + 1] + (pp->mean[1] + pp->sigma[1] * z[3 + 2 * c]) + ty;
+			}
+			ssm->estimate_warp_from_corners(pert.data(), ssm->init_corners.data(), dc);
+		} else {
+			for (int s2 = 0; s2 < S; ++s2) pert[s2] = pp->mean[s2] + pp->sigma[s2] * z[s2];
+		}
+		/* dynamic model x update type: PF.cc:307-333 */
+		if (pp->dynamic_model == 1) {
+			if (pp->update_type == 0) {   /* ProjectiveBase::additiveAutoRegression1 :254-259 */
+				for (int s2 = 0; s2 < S; ++s2) { ns[s2] = st[s2] + ar[s2] + pert[s2]; nar[s2] = pp->ar_coeff * (ns[s2] - st[s2]); }
+			} else {                      /* Homography::compositionalAutoRegression1 Homography.cc:928-942 (ProjectiveBase :260-276 without the normalisations) */
+				Mat3 B = ssm->warp_from_state(st), P = ssm->warp_from_state(pert.data()), A = ssm->warp_from_state(ar);
+				Mat3 W = mul3(mul3(B, A), P);
+				if (hom) div3(W, W(2, 2));
+				Mat3 AW = mul3(inv3(B), W);
+				if (hom) div3(AW, AW(2, 2));
+				ssm->state_from_warp(ns.data(), W); ssm->state_from_warp(nar.data(), AW);
+				for (int s2 = 0; s2 < S; ++s2) nar[s2] *= pp->ar_coeff;
+			}
+			for (int s2 = 0; s2 < S; ++s2) ar[s2] = nar[s2];
+		} else if (pp->update_type == 0) {   /* additiveRandomWalk :236-240 */
+			for (int s2 = 0; s2 < S; ++s2) ns[s2] = st[s2] + pert[s2];
+		} else {
+			ssm->compositional_random_walk(ns.data(), st, pert.data());
+		}
+		for (int s2 = 0; s2 < S; ++s2) st[s2] = ns[s2];
+		/* PF.cc:341-365 */
+		ssm->set_state(st);
+		am->update_pix_vals(ssm->curr_pts.data());
+		am->update_similarity(false);
+		const double val = max_similarity - am->f;
+		double lik;
+		if (pp->likelihood_func == 0) lik = am->likelihood();
+		else if (pp->likelihood_func == 1) lik = measurement_factor * std::exp(-0.5 * val / pp->measurement_sigma);
+		else lik = 1.0 / (1.0 + val);
+		wts[k] = lik;
+		cum[k] = k == 0 ? lik : lik + cum[k - 1];
+		if (lik >= max_wt) { max_wt = lik; max_wt_id = k; }
+	}
+	if (wts_out) std::memcpy(wts_out, wts.data(), sizeof(double) * n);
+	if (pp->resampling_type == 1 || pp->resampling_type == 2) {   /* binary / linear multinomial: PF.cc:455-502, 505-536 */
+		for (int k = 0; k < n; ++k) cum[k] /= cum[n - 1];
+		vecd ns2(static_cast<size_t>(n) * S), na2(static_cast<size_t>(n) * S);
+		max_wt = std::numeric_limits<double>::lowest();
+		for (int k = 0; k < n; ++k) {
+			const double u = uniforms[k];
+			int id;
+			if (pp->resampling_type == 1) {
+				int lo = 0, hi = n - 1;
+				id = (lo + hi) / 2;
+				while (hi > lo) { if (cum[id] >= u) hi = id; else lo = id + 1; id = (lo + hi) / 2; }
+			} else { id = 0; while (cum[id] < u) ++id; }
+			if (resample_ids) resample_ids[k] = id;
+			std::memcpy(&ns2[static_cast<size_t>(k) * S], states + static_cast<size_t>(id) * S, sizeof(double) * S);
+			std::memcpy(&na2[static_cast<size_t>(k) * S], ars + static_cast<size_t>(id) * S, sizeof(double) * S);
+			if (wts[id] >= max_wt) { max_wt = wts[id]; max_wt_id = k; }
+		}
+		std::memcpy(states, ns2.data(), sizeof(double) * ns2.size());
+		std::memcpy(ars, na2.data(), sizeof(double) * na2.size());
+	} else if (pp->resampling_type != 0) return -2;   /* residual resampling: not restated */
+	/* mean type: PF.cc:421-437 */
+	if (pp->mean_type == 0) ssm->set_state(states + static_cast<size_t>(max_wt_id) * S);
+	else if (pp->mean_type == 1) {   /* ProjectiveBase::estimateMeanOfSamples :311-317 */
+		vecd m(S, 0.0);
+		for (int k = 0; k < n; ++k) for (int s2 = 0; s2 < S; ++s2) m[s2] += (states[static_cast<size_t>(k) * S + s2] - m[s2]) / (k + 1);
+		ssm->set_state(m.data());
+	} else {   /* updateMeanCorners :607-614, then setCorners */
+		vecd mc(8, 0.0);
+		for (int k = 0; k < n; ++k) {
+			ssm->set_state(states + static_cast<size_t>(k) * S);
+			for (int q = 0; q < 8; ++q) mc[q] += (ssm->curr_corners[q] - mc[q]) / (k + 1);
+		}
+		ssm->set_corners(mc.data());
+	}
+	if (max_wt_id_out) *max_wt_id_out = max_wt_id;
+	return 0;
+}
+
 } // extern "C"

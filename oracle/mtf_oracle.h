@@ -182,6 +182,22 @@ void mtfo_pf_score(mtfo_am *am, mtfo_ssm *ssm, const double *states, int n_parti
 int mtfo_pf_binary_multinomial_resample(const double *wts, int n,
 	const double *uniforms, int *resample_ids);
 
+/* one iteration of nt::PF::update's loop (SM/src/NT/PF.cc:260-447) with the random draws supplied; enum values are
+ * PFParams.h:10-33 */
+typedef struct mtfo_pf_params {
+	int n_particles;
+	int dynamic_model;        /* 0 RandomWalk, 1 AutoRegression1 */
+	int update_type;          /* 0 Additive, 1 Compositional */
+	int likelihood_func;      /* 0 AM, 1 Gaussian, 2 Reciprocal */
+	int resampling_type;      /* 0 None, 1 BinaryMultinomial, 2 LinearMultinomial (3 Residual: not restated) */
+	int mean_type;            /* 0 None, 1 SSM, 2 Corners */
+	int corner_based_sampling;/* HomographyParams::corner_based_sampling */
+	double measurement_sigma, ar_coeff;
+	double sigma[8], mean[8]; /* the sampler's normal distributions (ProjectiveBase::initializeSampler) */
+} mtfo_pf_params;
+int mtfo_pf_iteration(mtfo_am *am, mtfo_ssm *ssm, const mtfo_pf_params *pp, double *states, double *ars, const double *normals,
+	const double *uniforms, double max_similarity, double *wts_out, int *resample_ids, int *max_wt_id_out);
+
 #ifdef __cplusplus
 }
 #endif

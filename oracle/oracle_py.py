@@ -493,3 +493,37 @@ def pf_binary_multinomial_resample(wts, uniforms):
     ids = np.empty(wts.size, dtype=np.int32)
     mx = lib().mtfo_pf_binary_multinomial_resample(_d(wts), wts.size, _d(uniforms), ids.ctypes.data_as(_ip))
     return ids, mx
+
+
+class PFParams(C.Structure):
+    """mtfo_pf_params: the PFParams.h:10-33 enums as integers"""
+    _fields_ = [("n_particles", C.c_int), ("dynamic_model", C.c_int), ("update_type", C.c_int), ("likelihood_func", C.c_int),
+                ("resampling_type", C.c_int), ("mean_type", C.c_int), ("corner_based_sampling", C.c_int),
+                ("measurement_sigma", C.c_double), ("ar_coeff", C.c_double), ("sigma", C.c_double * 8), ("mean", C.c_double * 8)]
+
+
+def pf_params(n_particles, dynamic_model=0, update_type=1, likelihood_func=0, resampling_type=1, mean_type=0,
+              corner_based_sampling=0, measurement_sigma=0.1, ar_coeff=0.5, sigma=(0.01, 0.01, 2.0, 0.01, 0.01, 2.0, 1e-5, 1e-5),
+              mean=(0,) * 8):
+    pp = PFParams(n_particles, dynamic_model, update_type, likelihood_func, resampling_type, mean_type, corner_based_sampling,
+                  measurement_sigma, ar_coeff)
+    for k in range(8):
+        pp.sigma[k] = float(sigma[k]) if k < len(sigma) else 0.0
+        pp.mean[k] = float(mean[k]) if k < len(mean) else 0.0
+    return pp
+
+
+def pf_iteration(am, ssm, pp, states, ars, normals, uniforms, max_similarity):
+    """one iteration of nt::PF::update's loop (NT/PF.cc:260-447) with the draws supplied; returns
+    (new states, new ars, weights before resampling, resample ids, max_wt_id); the SSM is left at the estimate"""
+    states = np.ascontiguousarray(np.asarray(states, dtype=np.float64)).copy()
+    ars = np.ascontiguousarray(np.asarray(ars, dtype=np.float64)).copy()
+    normals = np.ascontiguousarray(np.asarray(normals, dtype=np.float64))
+    uniforms = _vec(uniforms)
+    n = pp.n_particles
+    wts = np.empty(n); ids = np.zeros(n, dtype=np.int32); mx = C.c_int(0)
+    rc = lib().mtfo_pf_iteration(am.h, ssm.h, C.byref(pp), _d(states), _d(ars), _d(normals), _d(uniforms), C.c_double(max_similarity),
+                                 _d(wts), ids.ctypes.data_as(_ip), C.byref(mx))
+    if rc != 0:
+        raise NotImplementedError("mtfo_pf_iteration: %d" % rc)
+    return states, ars, wts, ids, mx.value

@@ -137,8 +137,14 @@ def test_config4_pf_10000_candidates(gpu_ctx, big_frames):
     b.set_corners(synth.square_corners(512, 512, 100)[None]); b.initialize_pix_vals(); b.initialize_similarity()
     states = synth.pf_candidate_states(rng, 10000)
     states[1234] = 0
+    b.set_math_mode(mtf_amd.MATH_REPLAY)      # the reference's arithmetic: the identity candidate reproduces the template bit for bit
     lik, sim = b.score_candidates(states, want_similarity=True)
     assert lik.shape == (10000,) and sim[1234] == 0.0 and lik[1234] == 1.0 and np.all(sim <= 0) and np.all(lik <= 1)
+    b.set_math_mode(mtf_amd.MATH_FAST)        # tolerance mode (the default): the same scores to 1e-9, the identity to rounding
+    lik_r, sim_r = lik, sim
+    lik, sim = b.score_candidates(states, want_similarity=True)
+    np.testing.assert_allclose(lik, lik_r, rtol=1e-9, atol=1e-300)
+    assert abs(sim[1234]) < 1e-18 and abs(lik[1234] - 1.0) < 1e-10 and np.all(sim <= 0) and np.all(lik <= 1)
     perm = rng.permutation(10000)
     lik_p = b.score_candidates(states[perm])
     assert np.array_equal(lik_p, lik[perm])                                   # a candidate's score does not depend on its slot

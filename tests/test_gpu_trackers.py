@@ -472,3 +472,90 @@ def test_single_large_target_device_loop_equals_host_loop(gpu_ctx, frame, am, sm
     np.testing.assert_allclose(out[False][0], out[True][0], rtol=0, atol=1e-6)
     assert abs(out[False][1] - out[True][1]) <= 1
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("am", [L.AM_SSD, L.AM_NCC])
+@pytest.mark.parametrize("corner_based,dynamic_model,update_type,mean_type,likelihood_func,resampling_type", [
+    (0, 0, 1, 0, 0, 1),    # config 4: RandomWalk + Compositional + AM likelihood + BinaryMultinomial, highest weight
+    (1, 0, 1, 0, 0, 1),    # the reference's default sampler: 4-corner perturbations (parameters.h:262)
+    (1, 1, 1, 1, 0, 1),    # shipped cfg: AutoRegression1 + Compositional (modules.cfg:163-166), mean of the states
+    (0, 1, 0, 1, 1, 2),    # additive AR1, Gaussian likelihood, linear multinomial
+    (0, 0, 0, 2, 2, 1),    # additive random walk, reciprocal likelihood, mean of the corners
+    (1, 0, 1, 0, 0, 0),    # no resampling
+])
+def test_pf_iteration_matches_oracle(oracle, gpu_ctx, frame, am, corner_based, dynamic_model, update_type, mean_type, likelihood_func,
+                                     resampling_type):
+    """mtfhip_pf_iteration (sample generation, scoring, cumulative weights, resampling, estimate -- all on the device) against
+    the oracle's restatement of one iteration of nt::PF::update's loop (NT/PF.cc:260-447) fed the SAME normal and uniform draws,
+    two iterations in a row (the second starts from the resampled set and its auto-regression terms)."""
+    rng = np.random.default_rng(101)
+    n, res = 600, 30
+    centre = (250.0, 240.0)
+    corners = synth.square_corners(centre[0], centre[1], 80) + rng.uniform(-2, 2, size=(2, 4))
+    sigma = (1.0, 0.6, 1, 1, 1, 1, 1, 1) if corner_based else (0.004, 0.004, 0.8, 0.004, 0.004, 0.8, 2e-6, 2e-6)
+    alpha = 5.0 if am == L.AM_SSD else 500.0
+    o_ssm = oracle.SSM(0, res, res); o_am = oracle.AM(am, res, res, likelihood_alpha=alpha); o_am.set_curr_img(frame)
+    o_ssm.set_corners(corners); o_am.initialize_pix_vals(o_ssm.get("curr_pts")); o_am.initialize_similarity()
+    pp = oracle.pf_params(n, dynamic_model=dynamic_model, update_type=update_type, likelihood_func=likelihood_func,
+                          resampling_type=resampling_type, mean_type=mean_type, corner_based_sampling=corner_based, sigma=sigma,
+                          measurement_sigma=0.4 if am == L.AM_SSD else 0.01)
+    gpu_ctx.set_image(frame)
+    pf = ParticleFilter(gpu_ctx, L.SSM_HOMOGRAPHY, res, res, n_particles=n, ssm_sigma=sigma, likelihood_alpha=alpha, am=am,
+                        dynamic_model=dynamic_model, update_type=update_type, likelihood_func=likelihood_func,
+                        resampling_type=resampling_type, mean_type=mean_type, corner_based_sampling=corner_based,
+                        measurement_sigma=pp.measurement_sigma)
+    pf.initialize(corners[None])
+    assert abs(pf.max_similarity - o_am.similarity) <= 1e-12 * max(1.0, abs(o_am.similarity))
+    frame_b = synth.warp_frame(frame, np.array([0, 0, 1.2, 0, 0, -0.8, 0, 0]), centre)
+    o_am.set_curr_img(frame_b); gpu_ctx.set_image(frame_b)
+    st_o, ar_o = np.zeros((n, 8)), np.zeros((n, 8))
+    nz = 10 if corner_based else 8
+    for it in range(2):
+        normals, uniforms = rng.normal(size=(n, nz)), rng.uniform(size=n)
+        st_o, ar_o, w_o, ids_o, mx_o = oracle.pf_iteration(o_am, o_ssm, pp, st_o, ar_o, normals, uniforms, pf.max_similarity)
+        pf.iteration(normals, uniforms)
+        st_d, ar_d, w_d, ids_d = pf.particles()
+        np.testing.assert_allclose(w_d, w_o, rtol=1e-9, atol=1e-300)
+        if resampling_type:
+            # the device's cumulative sum is a parallel scan: an id may differ only where a draw sits within rounding of a boundary
+            cum = np.cumsum(w_o) / np.sum(w_o)
+            bad = np.nonzero(ids_d != ids_o)[0]
+            assert all(abs(cum[min(ids_d[k], ids_o[k])] - uniforms[k]) < 1e-12 for k in bad), bad
+            same = ids_d == ids_o
+        else:
+            same = np.ones(n, dtype=bool)
+        np.testing.assert_allclose(st_d[same], st_o[same], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(ar_d[same], ar_o[same], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(pf.get_region()[0], o_ssm.get("curr_corners").reshape(4, 2).T, rtol=0, atol=1e-7)
+        if mean_type == 2:   # MeanType::Corners re-bases the SSM on the mean corners (setCorners): follow it on the oracle side too
+            assert np.allclose(pf.batch.get_state(), 0)
+        else:
+            np.testing.assert_allclose(pf.batch.get_state()[0], o_ssm.get("state"), rtol=1e-7, atol=1e-10)
+    pf.close()
+
+
+@pytest.mark.gpu
+def test_pf_device_generator_and_comm(gpu_ctx, frame):
+    """the Philox draws are a function of (seed, iteration, particle) only -- two filters with one seed produce identical particle
+    sets (what lets every rank of a sharded filter regenerate them without communication) -- and are standard normal / uniform;
+    the C-ABI all-gather with a one-rank communicator is a device copy"""
+    import torch
+    from mtf_amd.sm import Comm
+    corners = synth.square_corners(250, 240, 80)
+    gpu_ctx.set_image(frame)
+    sets = []
+    for seed in (11, 11, 12):
+        pf = ParticleFilter(gpu_ctx, L.SSM_HOMOGRAPHY, 20, 20, n_particles=20000, seed=seed, update_type=0, resampling_type=0,
+                            ssm_sigma=(1.0,) * 8, comm=Comm(0, 1, 0))
+        pf.initialize(corners[None]); pf.iteration()
+        sets.append(pf.particles()[0]); pf.close()
+    assert np.array_equal(sets[0], sets[1]) and not np.array_equal(sets[0], sets[2])
+    z = sets[0].ravel()      # additive random walk from the zero state with unit sigma: the states ARE the normal draws
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02 and abs((z ** 3).mean()) < 0.05 and abs((z ** 4).mean() - 3) < 0.15
+    c = Comm(0, 1, 0)
+    a = torch.arange(1000, dtype=torch.float64, device="cuda"); b = torch.zeros_like(a)
+    c.allgather(a.data_ptr(), 1000, b.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    c.close()
