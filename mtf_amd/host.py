@@ -43,6 +43,9 @@ def lib():
         H.mtfhost_ssm_algebra.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         H.mtfhost_set_learning.argtypes = [C.c_void_p, C.c_int, C.c_double]
         H.mtfhost_dist_feat.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        H.mtfhost_pf_create.restype = C.c_void_p
+        H.mtfhost_pf_create.argtypes = [C.c_int] * 7 + [C.c_double] + [C.c_int] * 6 + [C.c_void_p, C.c_double, C.c_ulonglong, C.c_int]
+        H.mtfhost_ssm_random_walk.argtypes = [C.c_void_p, C.c_ulonglong, C.c_int, C.c_void_p, C.c_void_p]
         _h = H
     return _h
 
@@ -127,6 +130,34 @@ class CppTracker:
         out = np.empty(8)
         _check(lib().mtfhost_get_region(self._h, out.ctypes.data_as(C.c_void_p)))
         return out.reshape(4, 2).T.copy()
+
+
+class CppParticleFilter(CppTracker):
+    """the particle filter of the C++ host layer: device_filter=True -> mtf::hip::PF (all particles of an iteration on the
+    device, mtfhip_pf_*), False -> mtf::nt::PF, the literal loop of SM/src/NT/PF.cc over the AM / SSM virtuals"""
+
+    def __init__(self, device_filter=True, am=_lib.AM_SSD, ssm=_lib.SSM_HOMOGRAPHY, resx=50, resy=50, n_particles=500, max_iters=1,
+                 epsilon=0.01, dynamic_model=0, update_type=1, likelihood_func=0, resampling_type=1, mean_type=0,
+                 corner_based_sampling=1, ssm_sigma=(0.01, 0.01, 2.0, 0.01, 0.01, 2.0, 1e-5, 1e-5), likelihood_alpha=1.0, seed=1,
+                 device=0):
+        sg = np.ascontiguousarray(np.asarray(list(ssm_sigma) + [0.0] * 8, dtype=np.float64)[:8])
+        h = lib().mtfhost_pf_create(int(bool(device_filter)), am, ssm, resx, resy, n_particles, max_iters, epsilon, dynamic_model,
+                                    update_type, likelihood_func, resampling_type, mean_type, int(bool(corner_based_sampling)),
+                                    sg.ctypes.data_as(C.c_void_p), likelihood_alpha, seed, device)
+        if not h:
+            raise HostError(lib().mtfhost_last_error().decode("utf-8", "replace"))
+        self._h = C.c_void_p(h)
+        self._img = None
+        self.iters = 0
+        self.n_channels = 1
+        self.S = 8 if ssm == _lib.SSM_HOMOGRAPHY else 6
+
+    def random_walk_samples(self, seed, n, sigma):
+        """n draws of StateSpaceModel::compositionalRandomWalk from the current state (the SSM sampler virtuals)"""
+        sg = np.ascontiguousarray(np.asarray(list(sigma) + [0.0] * 8, dtype=np.float64)[:8])
+        out = np.empty((n, self.S))
+        _check(lib().mtfhost_ssm_random_walk(self._h, seed, n, sg.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+        return out
 
 
 def qr_solve(A, b):

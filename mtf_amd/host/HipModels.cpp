@@ -270,3 +270,133 @@ void HipSSM::pixHess(int variant, MatrixXd &D, const PixHessT &h, const PixGradT
 
 } // namespace hip
 } // namespace mtf
+
+/* ------------------------------------------------------------------ HipSSM: stochastic sampler (host side) */
+#include <random>
+namespace mtf {
+namespace hip {
+
+struct HipSSM::Rng {
+	std::vector<std::mt19937_64> gen;   /* one generator per state component, as ProjectiveBase::initializeSampler :163-199 */
+	std::vector<std::normal_distribution<double>> dist;
+};
+namespace {
+struct W3 { double m[9]; };
+W3 warpOf(int ssm, const double *p) {
+	W3 W;
+	if (ssm == MTFHIP_SSM_HOMOGRAPHY) { W = W3{{1 + p[0], p[1], p[2], p[3], 1 + p[4], p[5], p[6], p[7], 1}}; }
+	else { W = W3{{1 + p[2], p[3], p[0], p[4], 1 + p[5], p[1], 0, 0, 1}}; }
+	return W;
+}
+void stateOf(int ssm, double *p, const W3 &W) {
+	if (ssm == MTFHIP_SSM_HOMOGRAPHY) { p[0] = W.m[0] - 1; p[1] = W.m[1]; p[2] = W.m[2]; p[3] = W.m[3]; p[4] = W.m[4] - 1; p[5] = W.m[5]; p[6] = W.m[6]; p[7] = W.m[7]; }
+	else { p[0] = W.m[2]; p[1] = W.m[5]; p[2] = W.m[0] - 1; p[3] = W.m[1]; p[4] = W.m[3]; p[5] = W.m[4] - 1; }
+}
+W3 mul(const W3 &a, const W3 &b) {
+	W3 c;
+	for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) c.m[3 * i + j] = a.m[3 * i] * b.m[j] + a.m[3 * i + 1] * b.m[3 + j] + a.m[3 * i + 2] * b.m[6 + j];
+	return c;
+}
+W3 inv(const W3 &a) {
+	const double *u = a.m;
+	W3 c;
+	c.m[0] = u[4] * u[8] - u[5] * u[7]; c.m[1] = u[2] * u[7] - u[1] * u[8]; c.m[2] = u[1] * u[5] - u[2] * u[4];
+	c.m[3] = u[5] * u[6] - u[3] * u[8]; c.m[4] = u[0] * u[8] - u[2] * u[6]; c.m[5] = u[2] * u[3] - u[0] * u[5];
+	c.m[6] = u[3] * u[7] - u[4] * u[6]; c.m[7] = u[1] * u[6] - u[0] * u[7]; c.m[8] = u[0] * u[4] - u[1] * u[3];
+	const double id = 1.0 / (u[0] * c.m[0] + u[1] * c.m[3] + u[2] * c.m[6]);
+	for (double &v : c.m) v *= id;
+	return c;
+}
+void norm22(W3 &w) { const double s = w.m[8]; for (double &v : w.m) v /= s; }
+}  // namespace
+
+/* ProjectiveBase::initializeSampler :163-199 (a sigma / mean of size 1 is broadcast) */
+void HipSSM::initializeSampler(const VectorXd &sg, const VectorXd &mn) {
+	const int S = p->S;
+	if (sg.size() != 1 && sg.size() != S) throw utils::InvalidArgument("ProjectiveBase::initializeSampler :: SSM sigma has invalid size " + std::to_string(sg.size()));
+	if (mn.size() != 1 && mn.size() != S) throw utils::InvalidArgument("ProjectiveBase::initializeSampler :: SSM mean has invalid size " + std::to_string(mn.size()));
+	sampler_sigma.resize(S); sampler_mean.resize(S);
+	for (int s = 0; s < S; ++s) { sampler_sigma[s] = sg.size() == 1 ? sg[0] : sg[s]; sampler_mean[s] = mn.size() == 1 ? mn[0] : mn[s]; }
+	rng = std::make_shared<Rng>();
+	std::random_device rd;
+	for (int s = 0; s < S; ++s) {
+		std::seed_seq seq{rd(), rd(), rd(), rd(), rd(), rd(), rd(), rd()};
+		rng->gen.emplace_back(seq);
+		rng->dist.emplace_back(sampler_mean[s], sampler_sigma[s]);
+	}
+	sampler_ready = true;
+}
+void HipSSM::setSamplerSeed(unsigned long long seed) {
+	if (!sampler_ready) throw utils::LogicError("setSamplerSeed before initializeSampler");
+	for (int s = 0; s < p->S; ++s) { rng->gen[s].seed(seed * 1000003ULL + s); rng->dist[s].reset(); }
+}
+void HipSSM::setSampler(const VectorXd &sg, const VectorXd &mn) {   /* :208-215 */
+	if (!sampler_ready) throw utils::LogicError("setSampler before initializeSampler");
+	for (int s = 0; s < p->S; ++s) { sampler_sigma[s] = sg[s]; sampler_mean[s] = mn[s]; rng->dist[s] = std::normal_distribution<double>(mn[s], sg[s]); }
+}
+void HipSSM::setSamplerMean(const VectorXd &mn) { setSampler(sampler_sigma, mn); }     /* :217-223 */
+void HipSSM::setSamplerSigma(const VectorXd &sg) { setSampler(sg, sampler_mean); }     /* :224-230 */
+double HipSSM::draw(int state_id) {
+	if (!sampler_ready) throw utils::LogicError("the SSM's sampler is used before initializeSampler");
+	return rng->dist[state_id](rng->gen[state_id]);
+}
+/* Homography::generatePerturbation Homography.cc:899-915 (corner based: the warp that takes the template corners to randomly
+ * displaced ones) / ProjectiveBase::generatePerturbation :283-288 */
+void HipSSM::generatePerturbation(VectorXd &pert) {
+	const int S = p->S;
+	if (pert.size() != S) pert.resize(S);
+	if (p->ssm == MTFHIP_SSM_HOMOGRAPHY && corner_based_sampling) {
+		CornersT ic, dc;
+		HipPair::check(mtfhip_ssm_get_init_corners(p->b, ic.data()));
+		const double tx = draw(0), ty = draw(0);
+		double rd[8];
+		for (int c = 0; c < 4; ++c) { rd[2 * c] = draw(1); rd[2 * c + 1] = draw(1); }
+		for (int c = 0; c < 4; ++c) { dc.v[2 * c] = ic.v[2 * c] + rd[2 * c] + tx; dc.v[2 * c + 1] = ic.v[2 * c + 1] + rd[2 * c + 1] + ty; }
+		estimateWarpFromCorners(pert, ic, dc);
+		return;
+	}
+	for (int s = 0; s < S; ++s) pert[s] = draw(s);
+}
+void HipSSM::additiveRandomWalk(VectorXd &out, const VectorXd &base) {   /* :236-240 */
+	VectorXd pert(p->S);
+	generatePerturbation(pert);
+	if (out.size() != p->S) out.resize(p->S);
+	for (int s = 0; s < p->S; ++s) out[s] = base[s] + pert[s];
+}
+void HipSSM::compositionalRandomWalk(VectorXd &out, const VectorXd &base) {   /* Homography.cc:916-926 */
+	VectorXd pert(p->S);
+	generatePerturbation(pert);
+	W3 W = mul(warpOf(p->ssm, base.data()), warpOf(p->ssm, pert.data()));
+	if (p->ssm == MTFHIP_SSM_HOMOGRAPHY) norm22(W);
+	if (out.size() != p->S) out.resize(p->S);
+	stateOf(p->ssm, out.data(), W);
+}
+void HipSSM::additiveAutoRegression1(VectorXd &out, VectorXd &out_ar, const VectorXd &base, const VectorXd &base_ar, double a) {   /* :254-259 */
+	VectorXd pert(p->S);
+	generatePerturbation(pert);
+	if (out.size() != p->S) out.resize(p->S);
+	if (out_ar.size() != p->S) out_ar.resize(p->S);
+	for (int s = 0; s < p->S; ++s) { out[s] = base[s] + base_ar[s] + pert[s]; out_ar[s] = a * (out[s] - base[s]); }
+}
+void HipSSM::compositionalAutoRegression1(VectorXd &out, VectorXd &out_ar, const VectorXd &base, const VectorXd &base_ar, double a) {   /* Homography.cc:928-942 */
+	VectorXd pert(p->S);
+	generatePerturbation(pert);
+	const bool hom = p->ssm == MTFHIP_SSM_HOMOGRAPHY;
+	const W3 B = warpOf(p->ssm, base.data());
+	W3 W = mul(mul(B, warpOf(p->ssm, base_ar.data())), warpOf(p->ssm, pert.data()));
+	if (hom) norm22(W);
+	W3 AW = mul(inv(B), W);
+	if (hom) norm22(AW);
+	if (out.size() != p->S) out.resize(p->S);
+	if (out_ar.size() != p->S) out_ar.resize(p->S);
+	stateOf(p->ssm, out.data(), W); stateOf(p->ssm, out_ar.data(), AW);
+	for (int s = 0; s < p->S; ++s) out_ar[s] *= a;
+}
+void HipSSM::estimateMeanOfSamples(VectorXd &mean, const std::vector<VectorXd> &samples, int n) {   /* :311-317 */
+	if (mean.size() != p->S) mean.resize(p->S);
+	mean.fill(0.0);
+	for (int k = 0; k < n; ++k) for (int s = 0; s < p->S; ++s) mean[s] += (samples[k][s] - mean[s]) / (k + 1);
+}
+
+} // namespace hip
+} // namespace mtf

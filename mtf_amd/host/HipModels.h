@@ -108,6 +108,9 @@ private:
 	double learning_rate = 0.5;
 	VectorXd dist_feat;
 	std::shared_ptr<HipPair> p;
+public:
+	const std::shared_ptr<HipPair> &pair() const { return p; }
+private:
 	ImageView img{nullptr, 0, 0, 0};
 	mutable double f = 0;
 	mutable bool f_fresh = true;
@@ -155,8 +158,35 @@ public:
 	void getIdentityWarp(VectorXd &identity_warp) override;
 	void composeWarps(VectorXd &composed, const VectorXd &state_1, const VectorXd &state_2) override;
 	void estimateWarpFromCorners(VectorXd &state_update, const CornersT &in_corners, const CornersT &out_corners) override;
+	/* stochastic sampler (ProjectiveBase.cc:163-317, Homography.cc:899-942) on the host, one state per call as the interface
+	 * has it -- what the literal nt::PF / nt::NN loops call.  The device filter (hip::PF, mtfhip_pf_*) generates all particles
+	 * of an iteration in one launch instead.  The reference draws from boost::mt11213b seeded by random_device; here
+	 * std::mt19937_64, seeded the same way unless setSamplerSeed() fixes it. */
+	void initializeSampler(const VectorXd &state_sigma, const VectorXd &state_mean) override;
+	void setSampler(const VectorXd &state_sigma, const VectorXd &state_mean) override;
+	void setSamplerMean(const VectorXd &mean) override;
+	void setSamplerSigma(const VectorXd &sigma) override;
+	VectorXd getSamplerSigma() override { return sampler_sigma; }
+	VectorXd getSamplerMean() override { return sampler_mean; }
+	void compositionalRandomWalk(VectorXd &perturbed_state, const VectorXd &base_state) override;
+	void additiveRandomWalk(VectorXd &perturbed_state, const VectorXd &base_state) override;
+	void compositionalAutoRegression1(VectorXd &perturbed_state, VectorXd &perturbed_ar, const VectorXd &base_state,
+		const VectorXd &base_ar, double a = 0.5) override;
+	void additiveAutoRegression1(VectorXd &perturbed_state, VectorXd &perturbed_ar, const VectorXd &base_state,
+		const VectorXd &base_ar, double a = 0.5) override;
+	void generatePerturbation(VectorXd &perturbation) override;
+	void estimateMeanOfSamples(VectorXd &sample_mean, const std::vector<VectorXd> &samples, int n_samples) override;
+	void setSamplerSeed(unsigned long long seed);
+	void setCornerBasedSampling(bool on) { corner_based_sampling = on; }   /* HomographyParams::corner_based_sampling */
+	bool getCornerBasedSampling() const { return corner_based_sampling; }
+	const std::shared_ptr<HipPair> &pair() const { return p; }
 private:
 	std::shared_ptr<HipPair> p;
+	VectorXd sampler_sigma, sampler_mean;
+	bool corner_based_sampling = true, sampler_ready = false;
+	struct Rng;
+	std::shared_ptr<Rng> rng;
+	double draw(int state_id);   /* one draw of N(mean[state_id], sigma[state_id]) */
 	PtsT curr_pts;
 	GradPtsT grad_pts;
 	HessPtsT hess_pts;

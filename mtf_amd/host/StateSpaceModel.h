@@ -53,6 +53,25 @@ public:
 	virtual void composeWarps(VectorXd &, const VectorXd &, const VectorXd &) { ssm_func_not_implemeted(composeWarps); }
 	virtual void estimateWarpFromCorners(VectorXd &, const CornersT &, const CornersT &) { ssm_func_not_implemeted(estimateWarpFromCorners); }
 
+	/* ---- stochastic sampler (StateSpaceModel.h:286-338): what nt::PF and nt::NN call ---- */
+	virtual void initializeSampler(const VectorXd &, const VectorXd &) { ssm_func_not_implemeted(initializeSampler(VectorXd, VectorXd)); }
+	virtual void setSampler(const VectorXd &, const VectorXd &) { ssm_func_not_implemeted(setSampler); }
+	virtual void setSamplerMean(const VectorXd &) { ssm_func_not_implemeted(setSamplerMean(VectorXd)); }
+	virtual void setSamplerSigma(const VectorXd &) { ssm_func_not_implemeted(setSamplerSigma(VectorXd)); }
+	virtual VectorXd getSamplerSigma() { ssm_func_not_implemeted(getSamplerSigma); }
+	virtual VectorXd getSamplerMean() { ssm_func_not_implemeted(getSamplerMean); }
+	virtual void compositionalRandomWalk(VectorXd &, const VectorXd &) { ssm_func_not_implemeted(compositionalRandomWalk); }
+	virtual void additiveRandomWalk(VectorXd &, const VectorXd &) { ssm_func_not_implemeted(additiveRandomWalk); }
+	virtual void compositionalAutoRegression1(VectorXd &, VectorXd &, const VectorXd &, const VectorXd &, double = 0.5) {
+		ssm_func_not_implemeted(compositionalAutoRegression1);
+	}
+	virtual void additiveAutoRegression1(VectorXd &, VectorXd &, const VectorXd &, const VectorXd &, double = 0.5) {
+		ssm_func_not_implemeted(additiveAutoRegression1);
+	}
+	virtual void generatePerturbation(VectorXd &) { ssm_func_not_implemeted(generatePerturbation); }
+	virtual void estimateMeanOfSamples(VectorXd &, const std::vector<VectorXd> &, int) { ssm_func_not_implemeted(estimateMeanOfSamples); }
+	virtual void estimateStateSigma(VectorXd &, double) { ssm_func_not_implemeted(estimateStateSigma); }
+
 	virtual void setFirstIter() { first_iter = true; }
 	virtual void clearFirstIter() { first_iter = false; }
 	virtual void clearInitStatus() {}

@@ -9,6 +9,7 @@
 
 #include "HipModels.h"
 #include "SearchMethods.h"
+#include "PF.h"
 
 using namespace mtf;
 
@@ -110,6 +111,42 @@ int mtfhost_dist_feat(mtfhost_tracker *t, double *feat, int *size) {
 		AppearanceModel *am = t->am.get();
 		if (size) *size = (int)am->getDistFeatSize();
 		if (feat) { am->initializeDistFeat(); am->updateDistFeat(); std::memcpy(feat, am->getDistFeat(), sizeof(double) * am->getDistFeatSize()); }
+		return 0;
+	} catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+/* the particle filter: device = 1 -> mtf::hip::PF (mtfhip_pf_*), 0 -> mtf::nt::PF over the AM / SSM virtuals (one C-ABI round trip
+ * per particle: the literal drop-in of SM/src/NT/PF.cc) */
+mtfhost_tracker *mtfhost_pf_create(int device_filter, int am, int ssm, int resx, int resy, int n_particles, int max_iters, double epsilon,
+	int dynamic_model, int update_type, int likelihood_func, int resampling_type, int mean_type, int corner_based_sampling,
+	const double *ssm_sigma, double likelihood_alpha, unsigned long long seed, int device) {
+	try {
+		auto *t = new mtfhost_tracker();
+		t->pair = std::make_shared<hip::HipPair>(am, ssm, resx, resy, 1e-8, likelihood_alpha, 8, 10.0, 0, device, nullptr, 1);
+		t->am = std::make_shared<hip::HipAM>(t->pair);
+		t->ssm = std::make_shared<hip::HipSSM>(t->pair);
+		t->ssm->setCornerBasedSampling(corner_based_sampling != 0);
+		PFParams p;
+		p.n_particles = n_particles; p.max_iters = max_iters; p.epsilon = epsilon;
+		p.dynamic_model = (PFParams::DynamicModel)dynamic_model; p.update_type = (PFParams::UpdateType)update_type;
+		p.likelihood_func = (PFParams::LikelihoodFunc)likelihood_func; p.resampling_type = (PFParams::ResamplingType)resampling_type;
+		p.mean_type = (PFParams::MeanType)mean_type; p.seed = seed;
+		p.ssm_sigma.assign(ssm_sigma, ssm_sigma + t->pair->S);
+		if (device_filter) t->sm.reset(new hip::PF(t->am, t->ssm, p));
+		else t->sm.reset(new nt::PF(t->am, t->ssm, p));
+		return t;
+	} catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+/* StateSpaceModel sampler virtuals through the base class (tests): n draws of compositionalRandomWalk from the current state */
+int mtfhost_ssm_random_walk(mtfhost_tracker *t, unsigned long long seed, int n, const double *sigma, double *out) {
+	try {
+		StateSpaceModel *ssm = t->ssm.get();
+		const int S = (int)ssm->getStateSize();
+		VectorXd sg(S), mn(S), st(S);
+		for (int s = 0; s < S; ++s) sg[s] = sigma[s];
+		ssm->initializeSampler(sg, mn);
+		t->ssm->setSamplerSeed(seed);
+		const VectorXd base = ssm->getState();
+		for (int k = 0; k < n; ++k) { ssm->compositionalRandomWalk(st, base); std::memcpy(out + (size_t)k * S, st.data(), sizeof(double) * S); }
 		return 0;
 	} catch (const std::exception &e) { g_err = e.what(); return -1; }
 }

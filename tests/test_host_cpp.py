@@ -188,3 +188,37 @@ def test_cpp_search_method_learns_the_template(oracle, frame, am):
     want = It if am == L.AM_SSD else (It - It.mean()) / np.linalg.norm(It - It.mean())
     np.testing.assert_allclose(trk.dist_feat(), want, rtol=0, atol=2e-3 if am == L.AM_SSD else 2e-5)   # states differ by the trackers' 5e-4 px
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_filter,n", [(True, 4000), (False, 300)])
+def test_cpp_particle_filter(frame, device_filter, n):
+    """mtf::hip::PF (the device filter behind nt::PF's interface) and mtf::nt::PF (the literal per-particle loop over the AM /
+    SSM virtuals, incl. the SSM's sampler family) follow a translation; corner based homography sampling as in the reference's
+    defaults."""
+    from mtf_amd import host
+    centre = (256.0, 250.0)
+    corners = synth.square_corners(centre[0], centre[1], 80)
+    p_true = np.array([0, 0, 3.0, 0, 0, -2.0, 0, 0])
+    frame2 = synth.warp_frame(frame, p_true, centre)
+    pf = host.CppParticleFilter(device_filter, resx=30, resy=30, n_particles=n, max_iters=4, epsilon=1e-9, likelihood_alpha=5.0,
+                                ssm_sigma=(1.5, 0.2, 1, 1, 1, 1, 1, 1), corner_based_sampling=1, seed=5)
+    pf.set_image(frame); pf.initialize(corners); pf.set_image(frame2)
+    out = pf.update()
+    gt = corners + np.array([[3.0], [-2.0]])
+    assert np.abs(out - gt).max() < 1.2, np.abs(out - gt).max()
+    assert 1 <= pf.iters <= 4
+
+
+@pytest.mark.gpu
+def test_cpp_ssm_sampler_virtuals(frame):
+    """StateSpaceModel::initializeSampler / compositionalRandomWalk through the base class: draws are reproducible under a seed,
+    and (direct sampling, identity base state) each state component is N(0, sigma_k)"""
+    from mtf_amd import host
+    pf = host.CppParticleFilter(False, resx=10, resy=10, n_particles=10, corner_based_sampling=0)
+    pf.set_image(frame); pf.initialize(synth.square_corners(200, 200, 60))
+    sigma = (0.01, 0.02, 2.0, 0.01, 0.02, 1.0, 1e-5, 2e-5)
+    a = pf.random_walk_samples(7, 20000, sigma); b = pf.random_walk_samples(7, 20000, sigma)
+    assert np.array_equal(a, b)
+    np.testing.assert_allclose(a.std(axis=0), sigma, rtol=0.05)
+    assert np.all(np.abs(a.mean(axis=0)) < 0.05 * np.asarray(sigma))
