@@ -14,6 +14,22 @@
 __attribute__((constructor)) static void mtfhip_runtime_defaults() { setenv("HIP_FORCE_DEV_KERNARG", "1", 0); }
 
 thread_local std::string g_last_error;
+/* sticky launch error (MTFHIP_LAUNCH): reported by the next call that waits for the device */
+namespace mtfhip {
+static char g_launch_msg[320];
+static volatile int g_launch_failed = 0;
+void note_launch_error(hipError_t e, const char *file, int line) {
+	if (g_launch_failed) return;
+	snprintf(g_launch_msg, sizeof(g_launch_msg), "kernel launch failed: %s (%s:%d)", hipGetErrorString(e), file, line);
+	g_launch_failed = 1;
+	fprintf(stderr, "libmtfhip: %s\n", g_launch_msg);
+}
+}
+int launch_error_pending() {
+	if (!mtfhip::g_launch_failed) return MTFHIP_OK;
+	mtfhip::g_launch_failed = 0;
+	return fail(MTFHIP_ERR_HIP, "%s", mtfhip::g_launch_msg);
+}
 
 extern "C" {
 
@@ -66,6 +82,7 @@ void mtfhip_ctx_destroy(mtfhip_ctx *c) {
 
 int mtfhip_ctx_synchronize(mtfhip_ctx *c) {
 	if (!c) return fail(MTFHIP_ERR_INVALID_ARG, "ctx is NULL");
+	TRY(launch_error_pending());
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	return MTFHIP_OK;
 }

@@ -456,7 +456,7 @@ void launch_score_candidates(const BatchView &bv, const ImgView &im, const doubl
 	if (fast_math) {
 		const dim3 g((C + 3) / 4);
 		const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY;
-#define MTFHIP_SCORE_FAST(SSM_, NCC_) hipLaunchKernelGGL((k_score_candidates_fast<SSM_, NCC_>), g, dim3(kBlock), 0, st, bv, im, dev_states, C, \
+#define MTFHIP_SCORE_FAST(SSM_, NCC_) MTFHIP_LAUNCH((k_score_candidates_fast<SSM_, NCC_>), g, dim3(kBlock), 0, st, bv, im, dev_states, C, \
 			likelihood_alpha, 1.0, 0.0, ncc_sc, dev_lik, dev_sim)
 		if (hom && ncc_sc) MTFHIP_SCORE_FAST(MTFHIP_SSM_HOMOGRAPHY, true);
 		else if (hom) MTFHIP_SCORE_FAST(MTFHIP_SSM_HOMOGRAPHY, false);
@@ -464,7 +464,7 @@ void launch_score_candidates(const BatchView &bv, const ImgView &im, const doubl
 		else MTFHIP_SCORE_FAST(MTFHIP_SSM_AFFINE, false);
 #undef MTFHIP_SCORE_FAST
 	} else
-		hipLaunchKernelGGL(k_score_candidates<false>, dim3(nb), dim3(kBlock), 0, st, bv, im, dev_states, C, likelihood_alpha,
+		MTFHIP_LAUNCH(k_score_candidates<false>, dim3(nb), dim3(kBlock), 0, st, bv, im, dev_states, C, likelihood_alpha,
 			1.0, 0.0, ncc_sc, dev_lik, dev_sim);
 }
 
@@ -472,7 +472,7 @@ template <int AM, bool FAST>
 static bool launch_iclk_track_am(const BatchView &bv, const ImgView &im, const mtfhip_sm_desc &sm, const TrackState &ts,
 	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, hipStream_t st) {
 	const int ppt = (bv.N + kBlock - 1) / kBlock;
-#define MTFHIP_ICLK_CASE(P) hipLaunchKernelGGL((k_iclk_track<AM, P, FAST>), dim3(bv.B), dim3(kBlock), 0, st, bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add)
+#define MTFHIP_ICLK_CASE(P) MTFHIP_LAUNCH((k_iclk_track<AM, P, FAST>), dim3(bv.B), dim3(kBlock), 0, st, bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add)
 	if (ppt <= 1) MTFHIP_ICLK_CASE(1);
 	else if (ppt <= 2) MTFHIP_ICLK_CASE(2);
 	else if (ppt <= 3) MTFHIP_ICLK_CASE(3);
@@ -494,8 +494,8 @@ bool launch_iclk_track(const BatchView &bv, const ImgView &im, const mtfhip_sm_d
 }
 void launch_sample_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C, double norm_mult,
 	double norm_add, double *dev_feat, hipStream_t st) {
-	hipLaunchKernelGGL(k_sample_candidates, dim3(C), dim3(kBlock), 0, st, bv, im, dev_states, C, norm_mult, norm_add, dev_feat);
-	if (bv.am == MTFHIP_AM_NCC) hipLaunchKernelGGL(k_ncc_feature_rows, dim3(C), dim3(kBlock), 0, st, bv.N, dev_feat);
+	MTFHIP_LAUNCH(k_sample_candidates, dim3(C), dim3(kBlock), 0, st, bv, im, dev_states, C, norm_mult, norm_add, dev_feat);
+	if (bv.am == MTFHIP_AM_NCC) MTFHIP_LAUNCH(k_ncc_feature_rows, dim3(C), dim3(kBlock), 0, st, bv.N, dev_feat);
 }
 
 } // namespace mtfhip

@@ -550,15 +550,15 @@ static void launch_fused_mat(const BatchView &bv, const ImgView &im, const Fused
 	dim3 g = grid2(nblk, bv.B);
 	if (bv.am == MTFHIP_AM_NCC) {
 		if (fa.materialize)
-			hipLaunchKernelGGL((k_fused_ncc<SSM, CHAINED, MODE, true>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
+			MTFHIP_LAUNCH((k_fused_ncc<SSM, CHAINED, MODE, true>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
 		else
-			hipLaunchKernelGGL((k_fused_ncc<SSM, CHAINED, MODE, false>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
+			MTFHIP_LAUNCH((k_fused_ncc<SSM, CHAINED, MODE, false>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
 		return;
 	}
 	if (fa.materialize)
-		hipLaunchKernelGGL((k_fused_ssd<SSM, CHAINED, MODE, true>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
+		MTFHIP_LAUNCH((k_fused_ssd<SSM, CHAINED, MODE, true>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
 	else
-		hipLaunchKernelGGL((k_fused_ssd<SSM, CHAINED, MODE, false>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
+		MTFHIP_LAUNCH((k_fused_ssd<SSM, CHAINED, MODE, false>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
 }
 template <int SSM, bool CHAINED>
 static void launch_fused_mode(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk,
@@ -570,9 +570,9 @@ static void launch_fused_mode(const BatchView &bv, const ImgView &im, const Fuse
 template <int AM, int SSM>
 static void launch_fused_fast(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk, hipStream_t st) {
 	dim3 g = grid2(nblk, bv.B);
-	if (fa.mode == 0) hipLaunchKernelGGL((k_fused_fast<AM, SSM, 0>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
-	else if (fa.mode == 1) hipLaunchKernelGGL((k_fused_fast<AM, SSM, 1>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
-	else hipLaunchKernelGGL((k_fused_fast<AM, SSM, 2>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
+	if (fa.mode == 0) MTFHIP_LAUNCH((k_fused_fast<AM, SSM, 0>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
+	else if (fa.mode == 1) MTFHIP_LAUNCH((k_fused_fast<AM, SSM, 1>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
+	else MTFHIP_LAUNCH((k_fused_fast<AM, SSM, 2>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
 }
 void launch_fused_ssd(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk,
 	hipStream_t st) {
@@ -593,12 +593,12 @@ void launch_fused_ssd(const BatchView &bv, const ImgView &im, const FusedArgs &f
 void launch_finish_track(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, const double *partials,
 	int nblk, hipStream_t st) {
 	/* NCC rows are 72 wide: two waves load them, the first one solves */
-	hipLaunchKernelGGL(k_finish_track, dim3(bv.B), dim3(bv.am == MTFHIP_AM_NCC ? 128 : 64), 0, st, bv, sm, ts, partials, nblk);
+	MTFHIP_LAUNCH(k_finish_track, dim3(bv.B), dim3(bv.am == MTFHIP_AM_NCC ? 128 : 64), 0, st, bv, sm, ts, partials, nblk);
 }
 
 void launch_finish_track_mi(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, int sum_std, int gmode,
 	const double *mi_H, const double *gpart, int ng, double *rows, hipStream_t st) {
-	hipLaunchKernelGGL(k_finish_track_mi, dim3(bv.B), dim3(64), 0, st, bv, sm, ts, sum_std, gmode, mi_H, gpart, ng, rows);
+	MTFHIP_LAUNCH(k_finish_track_mi, dim3(bv.B), dim3(64), 0, st, bv, sm, ts, sum_std, gmode, mi_H, gpart, ng, rows);
 }
 
 } // namespace mtfhip

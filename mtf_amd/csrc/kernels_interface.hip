@@ -556,104 +556,104 @@ __global__ __launch_bounds__(64) void k_finish(const double *partials, int nblk,
 /* ===================================================================== */
 void launch_init_grid(const BatchView &bv, const double *dev_w0, int resx, int resy, double lo_x, double lo_y,
 	double hi_x, double hi_y, int force_unit_z, hipStream_t st) {
-	hipLaunchKernelGGL(k_init_grid, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv, dev_w0, resx, resy,
+	MTFHIP_LAUNCH(k_init_grid, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv, dev_w0, resx, resy,
 		lo_x, lo_y, hi_x, hi_y, force_unit_z);
 }
 void launch_apply_warp(const BatchView &bv, hipStream_t st) {
-	hipLaunchKernelGGL(k_apply_warp, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv);
+	MTFHIP_LAUNCH(k_apply_warp, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv);
 }
 void launch_grad_pts(const BatchView &bv, double eps, hipStream_t st) {   /* per sample point */
-	hipLaunchKernelGGL(k_grad_pts, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv, eps);
+	MTFHIP_LAUNCH(k_grad_pts, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv, eps);
 }
 void launch_sample(const BatchView &bv, const ImgView &im, const double *pts, double *out, double mult, double add,
 	hipStream_t st) {
-	if (bv.C > 1) { hipLaunchKernelGGL(k_sample_mc, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.NP, bv.C, im, pts, out, mult, add); return; }
-	hipLaunchKernelGGL(k_sample, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, pts, out, mult, add);
+	if (bv.C > 1) { MTFHIP_LAUNCH(k_sample_mc, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.NP, bv.C, im, pts, out, mult, add); return; }
+	MTFHIP_LAUNCH(k_sample, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, pts, out, mult, add);
 }
 void launch_update_model(const BatchView &bv, const ImgView &im, const double *pts, double *I0, double mult, double add,
 	double frame_count, double alpha, int running_avg, hipStream_t st) {
-	hipLaunchKernelGGL(k_update_model, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, pts, I0, mult, add,
+	MTFHIP_LAUNCH(k_update_model, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, pts, I0, mult, add,
 		frame_count, alpha, running_avg);
 }
 void launch_img_grad(const BatchView &bv, const ImgView &im, const double *pts, double *grad, double eps, double mult,
 	hipStream_t st) {
 	if (bv.C > 1) {
-		hipLaunchKernelGGL(k_img_grad_mc, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.NP, bv.C, im, pts, (const double *)nullptr, grad, eps, mult);
+		MTFHIP_LAUNCH(k_img_grad_mc, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.NP, bv.C, im, pts, (const double *)nullptr, grad, eps, mult);
 		return;
 	}
-	hipLaunchKernelGGL(k_img_grad, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, pts, grad, eps, mult);
+	MTFHIP_LAUNCH(k_img_grad, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, pts, grad, eps, mult);
 }
 void launch_warped_img_grad(const BatchView &bv, const ImgView &im, const double *gp, double *grad, double eps,
 	double mult, hipStream_t st) {
 	if (bv.C > 1) {
-		hipLaunchKernelGGL(k_img_grad_mc, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.NP, bv.C, im, (const double *)nullptr, gp, grad, eps, mult);
+		MTFHIP_LAUNCH(k_img_grad_mc, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.NP, bv.C, im, (const double *)nullptr, gp, grad, eps, mult);
 		return;
 	}
-	hipLaunchKernelGGL(k_warped_img_grad, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, gp, grad, eps, mult);
+	MTFHIP_LAUNCH(k_warped_img_grad, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, gp, grad, eps, mult);
 }
 void launch_pix_jacobian(const BatchView &bv, int variant, const double *grad, double *J, hipStream_t st) {
-	hipLaunchKernelGGL(k_pix_jacobian, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv, variant, grad, J);
+	MTFHIP_LAUNCH(k_pix_jacobian, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv, variant, grad, J);
 }
 void launch_mean_jacobian(const BatchView &bv, hipStream_t st) {
 	size_t n = (size_t)bv.B * bv.N * bv.S;
 	int nb = (int)((n + kBlock * 4 - 1) / (kBlock * 4));
-	hipLaunchKernelGGL(k_mean_jacobian, dim3(nb), dim3(kBlock), 0, st, bv.buf[MTFHIP_BUF_J0], bv.buf[MTFHIP_BUF_JT],
+	MTFHIP_LAUNCH(k_mean_jacobian, dim3(nb), dim3(kBlock), 0, st, bv.buf[MTFHIP_BUF_J0], bv.buf[MTFHIP_BUF_JT],
 		bv.buf[MTFHIP_BUF_JM], n);
 }
 void launch_negate(const double *src, double *dst, size_t n, hipStream_t st) {
 	int nb = (int)((n + kBlock * 4 - 1) / (kBlock * 4));
-	hipLaunchKernelGGL(k_negate, dim3(nb), dim3(kBlock), 0, st, src, dst, n);
+	MTFHIP_LAUNCH(k_negate, dim3(nb), dim3(kBlock), 0, st, src, dst, n);
 }
 void launch_ssd_residual(const BatchView &bv, double *partials, int nblk, hipStream_t st) {
-	hipLaunchKernelGGL(k_ssd_residual, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv, partials, nblk);
+	MTFHIP_LAUNCH(k_ssd_residual, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv, partials, nblk);
 }
 void launch_gemv(const BatchView &bv, const double *v1, const double *J1, const double *v2, const double *J2,
 	int sum_mode, double *partials, int nblk, hipStream_t st) {
-	hipLaunchKernelGGL(k_gemv, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv.N, bv.S, v1, J1, v2, J2, sum_mode, partials, nblk);
+	MTFHIP_LAUNCH(k_gemv, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv.N, bv.S, v1, J1, v2, J2, sum_mode, partials, nblk);
 }
 void launch_gram(const BatchView &bv, const double *J, double *partials, int nblk, hipStream_t st) {
-	hipLaunchKernelGGL(k_gram, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv.N, bv.S, J, partials, nblk);
+	MTFHIP_LAUNCH(k_gram, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv.N, bv.S, J, partials, nblk);
 }
 void launch_vec_sum(const BatchView &bv, const double *v, double *partials, int nblk, hipStream_t st) {
-	hipLaunchKernelGGL(k_vec_sum, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv.N, v, partials, nblk);
+	MTFHIP_LAUNCH(k_vec_sum, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv.N, v, partials, nblk);
 }
 void launch_ncc_centered(const BatchView &bv, const double *sc, double *partials, int nblk, hipStream_t st) {
-	hipLaunchKernelGGL(k_ncc_centered, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv, sc, partials, nblk);
+	MTFHIP_LAUNCH(k_ncc_centered, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv, sc, partials, nblk);
 }
 void launch_ncc_grad(const BatchView &bv, const double *sc, int curr, double *out, double *partials, int nblk, hipStream_t st) {
-	hipLaunchKernelGGL(k_ncc_grad, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv, sc, curr, out, partials, nblk);
+	MTFHIP_LAUNCH(k_ncc_grad, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv, sc, curr, out, partials, nblk);
 }
 void launch_sub_mean(const BatchView &bv, double *v, const double *sc, hipStream_t st) {
-	hipLaunchKernelGGL(k_sub_mean, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, v, sc);
+	MTFHIP_LAUNCH(k_sub_mean, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, v, sc);
 }
 void launch_col_sum(const BatchView &bv, const double *J, double *partials, int nblk, hipStream_t st) {
-	hipLaunchKernelGGL(k_col_sum, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv.N, bv.S, J, partials, nblk);
+	MTFHIP_LAUNCH(k_col_sum, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv.N, bv.S, J, partials, nblk);
 }
 void launch_ncc_hess(const BatchView &bv, const double *sc, const double *colmean, const double *J, double *partials,
 	int nblk, hipStream_t st) {
-	hipLaunchKernelGGL(k_ncc_hess, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv, sc, colmean, J, partials, nblk);
+	MTFHIP_LAUNCH(k_ncc_hess, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv, sc, colmean, J, partials, nblk);
 }
 void launch_finish_host(double *partials, int nblk, int row_len, double *out_host, int *count, unsigned long long *flag_host,
 	unsigned long long seq, int B, hipStream_t st) {
 	const int G = nblk >= 256 ? 8 : (nblk >= 64 ? 4 : 1);
-	hipLaunchKernelGGL(k_finish_host, dim3(B), dim3(128 * G), 0, st, partials, nblk, row_len, out_host, count, flag_host, seq);
+	MTFHIP_LAUNCH(k_finish_host, dim3(B), dim3(128 * G), 0, st, partials, nblk, row_len, out_host, count, flag_host, seq);
 }
 void launch_publish_host(const void *src, void *dst_host, size_t bytes, int *count, unsigned long long *flag_host,
 	unsigned long long seq, hipStream_t st) {
 	const unsigned n_words = (unsigned)(bytes / 4);
 	const unsigned blocks = std::max(1u, std::min(64u, (n_words + 1023) / 1024));
-	hipLaunchKernelGGL(k_publish_host, dim3(blocks), dim3(256), 0, st, static_cast<const unsigned *>(src), static_cast<unsigned *>(dst_host),
+	MTFHIP_LAUNCH(k_publish_host, dim3(blocks), dim3(256), 0, st, static_cast<const unsigned *>(src), static_cast<unsigned *>(dst_host),
 		n_words, count, flag_host, seq);
 }
 void launch_finish_rows(double *partials, int nblk, int row_len, double *out, int B, hipStream_t st) {
-	hipLaunchKernelGGL(k_finish_rows, dim3(B, (row_len + 127) / 128), dim3(128), 0, st, partials, nblk, row_len, out);
+	MTFHIP_LAUNCH(k_finish_rows, dim3(B, (row_len + 127) / 128), dim3(128), 0, st, partials, nblk, row_len, out);
 }
 void launch_finish(double *partials, int nblk, double *out, int B, hipStream_t st) {
-	hipLaunchKernelGGL(k_finish, dim3(B), dim3(64), 0, st, partials, nblk, out);
+	MTFHIP_LAUNCH(k_finish, dim3(B), dim3(64), 0, st, partials, nblk, out);
 }
 
 void launch_mean_planes(const double *a, const double *b, double *o, size_t n, hipStream_t st) {
-	hipLaunchKernelGGL(k_mean_jacobian, dim3((unsigned)std::min<size_t>((n + kBlock - 1) / kBlock, 4096)), dim3(kBlock), 0, st, a, b, o, n);
+	MTFHIP_LAUNCH(k_mean_jacobian, dim3((unsigned)std::min<size_t>((n + kBlock - 1) / kBlock, 4096)), dim3(kBlock), 0, st, a, b, o, n);
 }
 
 } // namespace mtfhip

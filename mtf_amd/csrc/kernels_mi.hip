@@ -505,30 +505,30 @@ void launch_mi_hist(const BatchView &bv, int nb, double norm_mult, const double 
 	/* per-wave staging slabs [64][2 nb]; the same LDS later holds the four waves' [nb + nb^2] rows */
 	const size_t lds = sizeof(double) * std::max<size_t>((size_t)4 * kMiRowMfma * 2 * nb, (size_t)4 * (nb + nb * nb));
 	static const bool use_mfma = !(getenv("MTFHIP_MI_MFMA") && atoi(getenv("MTFHIP_MI_MFMA")) == 0);
-	if (use_mfma) hipLaunchKernelGGL((k_mi_hist<true, false>), grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, nb, norm_mult, A, Bv, partials, nblk, row_len);
-	else hipLaunchKernelGGL((k_mi_hist<false, false>), grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, nb, norm_mult, A, Bv, partials, nblk, row_len);
+	if (use_mfma) MTFHIP_LAUNCH((k_mi_hist<true, false>), grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, nb, norm_mult, A, Bv, partials, nblk, row_len);
+	else MTFHIP_LAUNCH((k_mi_hist<false, false>), grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, nb, norm_mult, A, Bv, partials, nblk, row_len);
 }
 /* A = It against B = I0 and against itself in one pass (fused MI iteration); row: [nb | nb*nb | nb*nb] */
 void launch_mi_hist_self(const BatchView &bv, int nb, double norm_mult, const double *A, const double *Bv, double *partials,
 	int nblk, int row_len, hipStream_t st) {
 	const size_t lds = sizeof(double) * std::max<size_t>((size_t)4 * kMiRowMfma * 2 * nb, (size_t)4 * (nb + 2 * nb * nb));
-	hipLaunchKernelGGL((k_mi_hist<true, true>), grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, nb, norm_mult, A, Bv, partials, nblk, row_len);
+	MTFHIP_LAUNCH((k_mi_hist<true, true>), grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, nb, norm_mult, A, Bv, partials, nblk, row_len);
 }
 void launch_mi_tables_iter(const BatchView &bv, int nb, double pre_seed, double norm_mult, int with_self, const double *partials, int nblk,
 	int row_len, double *tb, double *f_out, hipStream_t st) {
-	hipLaunchKernelGGL(k_mi_tables_iter, dim3(bv.B), dim3(kBlock), 0, st, nb, pre_seed, norm_mult, with_self, partials, nblk, row_len, tb, f_out);
+	MTFHIP_LAUNCH(k_mi_tables_iter, dim3(bv.B), dim3(kBlock), 0, st, nb, pre_seed, norm_mult, with_self, partials, nblk, row_len, tb, f_out);
 }
 void launch_mi_hist_finish(const BatchView &bv, int nb, double pre_seed, double norm_mult, int mode, int first_init,
 	const double *partials, int nblk, int row_len, double *tb, double *f_out, hipStream_t st) {
-	hipLaunchKernelGGL(k_mi_hist_finish, dim3(bv.B), dim3(kBlock), 0, st, nb, pre_seed, norm_mult, mode, first_init, partials,
+	MTFHIP_LAUNCH(k_mi_hist_finish, dim3(bv.B), dim3(kBlock), 0, st, nb, pre_seed, norm_mult, mode, first_init, partials,
 		nblk, row_len, tb, f_out);
 }
 void launch_mi_factor(const BatchView &bv, int nb, int curr, double *tb, hipStream_t st) {
-	hipLaunchKernelGGL(k_mi_factor, dim3(bv.B), dim3(kBlock), 0, st, nb, curr, tb);
+	MTFHIP_LAUNCH(k_mi_factor, dim3(bv.B), dim3(kBlock), 0, st, nb, curr, tb);
 }
 void launch_mi_grad(const BatchView &bv, int nb, double norm_mult, const double *A, const double *Bv, const double *tb,
 	int table_off, double *out, hipStream_t st) {
-	hipLaunchKernelGGL(k_mi_grad, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, nb, norm_mult, A, Bv,
+	MTFHIP_LAUNCH(k_mi_grad, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, nb, norm_mult, A, Bv,
 		tb, table_off, out);
 }
 void launch_mi_hess(const BatchView &bv, int nb, double norm_mult, const double *A, const double *Bv, const double *tb,
@@ -543,22 +543,22 @@ void launch_mi_hess(const BatchView &bv, int nb, double norm_mult, const double 
 	}
 	static const bool use_mfma = !(getenv("MTFHIP_MI_MFMA") && atoi(getenv("MTFHIP_MI_MFMA")) == 0);
 	if (use_mfma && nb == 8)
-		hipLaunchKernelGGL(k_mi_hess<true>, grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, bv.S, nb, norm_mult, A, Bv, tb, table_off,
+		MTFHIP_LAUNCH(k_mi_hess<true>, grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, bv.S, nb, norm_mult, A, Bv, tb, table_off,
 			transpose_q, J, partials, nblk, row_len);
 	else
-		hipLaunchKernelGGL(k_mi_hess<false>, grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, bv.S, nb, norm_mult, A, Bv, tb, table_off,
+		MTFHIP_LAUNCH(k_mi_hess<false>, grid2(nblk, bv.B), dim3(kBlock), lds, st, bv.N, bv.S, nb, norm_mult, A, Bv, tb, table_off,
 			transpose_q, J, partials, nblk, row_len);
 }
 /* df_dIt, df_dI0 (optionally stored) and the two Jacobian products; partial rows of 16 (sum them with launch_finish_rows) */
 void launch_mi_grad_gemv(const BatchView &bv, int nb, double norm_mult, const double *It, const double *I0, const double *tb,
 	const double *Jt, const double *J0, const MiJ0Rebuild &rb, double *df_dIt, double *df_dI0, double *partials, int nblk, hipStream_t st) {
-	hipLaunchKernelGGL(k_mi_grad_gemv, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv.N, bv.S, nb, norm_mult, It, I0, tb, Jt, J0, rb, df_dIt, df_dI0,
+	MTFHIP_LAUNCH(k_mi_grad_gemv, grid2(nblk, bv.B), dim3(kBlock), 0, st, bv.N, bv.S, nb, norm_mult, It, I0, tb, Jt, J0, rb, df_dIt, df_dI0,
 		partials, nblk);
 }
 void launch_mi_hess_finish(const BatchView &bv, int nb, const double *partials, int nblk, int row_len, const double *tb,
 	int joint_off, int hist_off, int transpose_q, double *out, hipStream_t st) {
 	size_t lds = sizeof(double) * ((size_t)nb * nb * bv.S + 36);
-	hipLaunchKernelGGL(k_mi_hess_finish, dim3(bv.B), dim3(kBlock), lds, st, bv.S, nb, partials, nblk, row_len, tb, joint_off,
+	MTFHIP_LAUNCH(k_mi_hess_finish, dim3(bv.B), dim3(kBlock), lds, st, bv.S, nb, partials, nblk, row_len, tb, joint_off,
 		hist_off, transpose_q, out);
 }
 

@@ -547,15 +547,15 @@ void launch_mi_pass_hist(const BatchView &bv, const ImgView &im, const MiFastPla
 	const MiPassArgs pa = make_args(pl);
 	const dim3 g = grid2(nblk, bv.B);
 	const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY, self = pl.hk == 1;
-	if (hom && self) hipLaunchKernelGGL((k_mi_pass_hist<MTFHIP_SSM_HOMOGRAPHY, true>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
-	else if (hom) hipLaunchKernelGGL((k_mi_pass_hist<MTFHIP_SSM_HOMOGRAPHY, false>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
-	else if (self) hipLaunchKernelGGL((k_mi_pass_hist<MTFHIP_SSM_AFFINE, true>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
-	else hipLaunchKernelGGL((k_mi_pass_hist<MTFHIP_SSM_AFFINE, false>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
+	if (hom && self) MTFHIP_LAUNCH((k_mi_pass_hist<MTFHIP_SSM_HOMOGRAPHY, true>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
+	else if (hom) MTFHIP_LAUNCH((k_mi_pass_hist<MTFHIP_SSM_HOMOGRAPHY, false>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
+	else if (self) MTFHIP_LAUNCH((k_mi_pass_hist<MTFHIP_SSM_AFFINE, true>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
+	else MTFHIP_LAUNCH((k_mi_pass_hist<MTFHIP_SSM_AFFINE, false>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
 }
 template <int SSM>
 static void launch_pass2(const BatchView &bv, const ImgView &im, const MiPassArgs &pa, int hk, int hrow, double *partials, int nblk, hipStream_t st) {
 	const dim3 g = grid2(nblk, bv.B);
-#define MTFHIP_MI_P2(HK_, HR_) hipLaunchKernelGGL((k_mi_pass_grad_hess<SSM, HK_, HR_>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk)
+#define MTFHIP_MI_P2(HK_, HR_) MTFHIP_LAUNCH((k_mi_pass_grad_hess<SSM, HK_, HR_>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk)
 	if (hk == 0) MTFHIP_MI_P2(0, 0);
 	else if (hk == 1) MTFHIP_MI_P2(1, 0);
 	else if (hk == 2 && hrow == 2) MTFHIP_MI_P2(2, 2);
@@ -571,7 +571,7 @@ void launch_mi_pass_grad_hess(const BatchView &bv, const ImgView &im, const MiFa
 void launch_mi_finish_fast(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, const MiFastPlan &pl, int gmode, int do_track,
 	const double *partials, int nblk, double *out_H, double *out_g, double *rows, hipStream_t st) {
 	const int joint = pl.hk == 1 ? MI_SELF_JOINT : MI_JOINT, hist = pl.hk == 3 ? MI_HIST_INIT : MI_HIST_CURR;
-	hipLaunchKernelGGL(k_mi_finish_fast, dim3(bv.B), dim3(kBlock), 0, st, bv, sm, ts, pl.hk != 0, pl.hk == 3, joint, hist, 0, gmode, do_track,
+	MTFHIP_LAUNCH(k_mi_finish_fast, dim3(bv.B), dim3(kBlock), 0, st, bv, sm, ts, pl.hk != 0, pl.hk == 3, joint, hist, 0, gmode, do_track,
 		partials, nblk, pl.tb, out_H, out_g, rows);
 }
 int mi_fast_row_len() { return kMiFastRow; }

@@ -331,8 +331,8 @@ void launch_pf_propagate(int ssm, const PfLaunch &p, double *states, double *ars
 	for (int k = 0; k < 9; ++k) a.sq_inv[k] = p.sq_inv[k];
 	a.seed = p.seed; a.iter = p.iter; a.normals = p.normals;
 	const dim3 g((p.n + kBlock - 1) / kBlock);
-	if (ssm == MTFHIP_SSM_HOMOGRAPHY) hipLaunchKernelGGL(k_pf_propagate<MTFHIP_SSM_HOMOGRAPHY>, g, dim3(kBlock), 0, st, a, states, ars);
-	else hipLaunchKernelGGL(k_pf_propagate<MTFHIP_SSM_AFFINE>, g, dim3(kBlock), 0, st, a, states, ars);
+	if (ssm == MTFHIP_SSM_HOMOGRAPHY) MTFHIP_LAUNCH(k_pf_propagate<MTFHIP_SSM_HOMOGRAPHY>, g, dim3(kBlock), 0, st, a, states, ars);
+	else MTFHIP_LAUNCH(k_pf_propagate<MTFHIP_SSM_AFFINE>, g, dim3(kBlock), 0, st, a, states, ars);
 }
 void launch_pf_resample(int ssm, const PfLaunch &p, const double *lik, const double *sim, double *wts, double *cum, const double *st_in,
 	const double *ar_in, double *st_out, double *ar_out, int *ids, double *out, hipStream_t st) {
@@ -342,10 +342,10 @@ void launch_pf_resample(int ssm, const PfLaunch &p, const double *lik, const dou
 	a.lik = lik; a.sim = sim; a.wts = wts; a.cum = cum; a.st_in = st_in; a.ar_in = ar_in; a.st_out = st_out; a.ar_out = ar_out; a.ids = ids;
 	for (int k = 0; k < 12; ++k) a.init_corners_hm[k] = p.init_corners_hm[k];
 	a.out = out;
-	hipLaunchKernelGGL(k_pf_resample, dim3(1), dim3(kPfBlock), 0, st, a);
+	MTFHIP_LAUNCH(k_pf_resample, dim3(1), dim3(kPfBlock), 0, st, a);
 }
 void launch_pf_fill(int n, int S, const double *dev_state, double *states, double *ars, hipStream_t st) {
-	hipLaunchKernelGGL(k_pf_fill, dim3((n + 255) / 256), dim3(256), 0, st, n, S, dev_state, states, ars);
+	MTFHIP_LAUNCH(k_pf_fill, dim3((n + 255) / 256), dim3(256), 0, st, n, S, dev_state, states, ars);
 }
 
 } // namespace mtfhip

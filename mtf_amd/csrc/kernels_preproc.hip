@@ -100,19 +100,19 @@ __global__ __launch_bounds__(kBlock) void k_resize_linear(const float *src, int 
 /* launchers                                                              */
 /* ===================================================================== */
 void launch_to_gray(const void *raw, int rows, int cols, size_t stride_bytes, int channels, int depth_f32, float *out, hipStream_t st) {
-	hipLaunchKernelGGL(k_to_gray_f32, dim3((cols + kBlock - 1) / kBlock, rows), dim3(kBlock), 0, st, (const unsigned char *)raw, rows, cols,
+	MTFHIP_LAUNCH(k_to_gray_f32, dim3((cols + kBlock - 1) / kBlock, rows), dim3(kBlock), 0, st, (const unsigned char *)raw, rows, cols,
 		stride_bytes, channels, depth_f32, out);
 }
 void launch_sym5(const float *src, float *tmp, float *dst, int rows, int cols, const float kx[3], const float ky[3], hipStream_t st) {
 	const dim3 grid((cols + kBlock - 1) / kBlock, rows);
-	hipLaunchKernelGGL(k_sym5_rows, grid, dim3(kBlock), 0, st, src, rows, cols, kx[0], kx[1], kx[2], tmp);
-	hipLaunchKernelGGL(k_sym5_cols, grid, dim3(kBlock), 0, st, (const float *)tmp, rows, cols, ky[0], ky[1], ky[2], dst);
+	MTFHIP_LAUNCH(k_sym5_rows, grid, dim3(kBlock), 0, st, src, rows, cols, kx[0], kx[1], kx[2], tmp);
+	MTFHIP_LAUNCH(k_sym5_cols, grid, dim3(kBlock), 0, st, (const float *)tmp, rows, cols, ky[0], ky[1], ky[2], dst);
 }
 void launch_pyr_down(const float *src, int srows, int scols, float *dst, int drows, int dcols, hipStream_t st) {
-	hipLaunchKernelGGL(k_pyr_down, dim3((dcols + kBlock - 1) / kBlock, drows), dim3(kBlock), 0, st, src, srows, scols, drows, dcols, dst);
+	MTFHIP_LAUNCH(k_pyr_down, dim3((dcols + kBlock - 1) / kBlock, drows), dim3(kBlock), 0, st, src, srows, scols, drows, dcols, dst);
 }
 void launch_resize_linear(const float *src, int srows, int scols, float *dst, int drows, int dcols, hipStream_t st) {
-	hipLaunchKernelGGL(k_resize_linear, dim3((dcols + kBlock - 1) / kBlock, drows), dim3(kBlock), 0, st, src, srows, scols, drows, dcols, dst);
+	MTFHIP_LAUNCH(k_resize_linear, dim3((dcols + kBlock - 1) / kBlock, drows), dim3(kBlock), 0, st, src, srows, scols, drows, dcols, dst);
 }
 
 } // namespace mtfhip

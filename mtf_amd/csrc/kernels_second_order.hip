@@ -410,45 +410,45 @@ __global__ __launch_bounds__(kBlock) void k_img_hess_mc(int NP, int C, ImgView i
 /* launchers                                                              */
 /* ===================================================================== */
 void launch_hess_pts(const BatchView &bv, double eps, hipStream_t st) {
-	hipLaunchKernelGGL(k_hess_pts, dim3(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv, eps);
+	MTFHIP_LAUNCH(k_hess_pts, dim3(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv, eps);
 }
 void launch_img_hess(const BatchView &bv, const ImgView &im, const double *pts, double *hess, double eps, double mult, hipStream_t st) {
 	if (bv.C > 1) {
-		hipLaunchKernelGGL(k_img_hess_mc, dim3(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.NP, bv.C, im, pts, (const double *)nullptr, hess, eps, mult);
+		MTFHIP_LAUNCH(k_img_hess_mc, dim3(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.NP, bv.C, im, pts, (const double *)nullptr, hess, eps, mult);
 		return;
 	}
-	hipLaunchKernelGGL(k_img_hess, dim3(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, pts, hess, eps, mult);
+	MTFHIP_LAUNCH(k_img_hess, dim3(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, pts, hess, eps, mult);
 }
 void launch_warped_img_hess(const BatchView &bv, const ImgView &im, const double *pts, const double *hp, double *hess, double eps,
 	double mult, hipStream_t st) {
 	if (bv.C > 1) {
-		hipLaunchKernelGGL(k_img_hess_mc, dim3(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.NP, bv.C, im, pts, hp, hess, eps, mult);
+		MTFHIP_LAUNCH(k_img_hess_mc, dim3(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.NP, bv.C, im, pts, hp, hess, eps, mult);
 		return;
 	}
-	hipLaunchKernelGGL(k_warped_img_hess, dim3(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, pts, hp, hess, eps, mult);
+	MTFHIP_LAUNCH(k_warped_img_hess, dim3(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv.N, im, pts, hp, hess, eps, mult);
 }
 void launch_pix_hessian(const BatchView &bv, int variant, const double *hess, const double *grad, double *D, hipStream_t st) {
 	const dim3 grid(simple_blocks_per_target(bv.N), bv.B);
-	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) hipLaunchKernelGGL(k_pix_hessian<MTFHIP_SSM_HOMOGRAPHY>, grid, dim3(kBlock), 0, st, bv, variant, hess, grad, D);
-	else hipLaunchKernelGGL(k_pix_hessian<MTFHIP_SSM_AFFINE>, grid, dim3(kBlock), 0, st, bv, variant, hess, grad, D);
+	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) MTFHIP_LAUNCH(k_pix_hessian<MTFHIP_SSM_HOMOGRAPHY>, grid, dim3(kBlock), 0, st, bv, variant, hess, grad, D);
+	else MTFHIP_LAUNCH(k_pix_hessian<MTFHIP_SSM_AFFINE>, grid, dim3(kBlock), 0, st, bv, variant, hess, grad, D);
 }
 void launch_weighted_plane_sum(const BatchView &bv, const double *d2a, const double *d2b, const double *w, double *partials, int nblk,
 	double *out, hipStream_t st) {
 	const dim3 grid(nblk, bv.B);
-	if (bv.S == 8) hipLaunchKernelGGL(k_weighted_plane_sum<64>, grid, dim3(kBlock), 0, st, bv.N, d2a, d2b, w, partials, nblk);
-	else hipLaunchKernelGGL(k_weighted_plane_sum<36>, grid, dim3(kBlock), 0, st, bv.N, d2a, d2b, w, partials, nblk);
-	hipLaunchKernelGGL(k_plane_sum_finish, dim3(bv.B), dim3(64), 0, st, partials, nblk, bv.S * bv.S, out);
+	if (bv.S == 8) MTFHIP_LAUNCH(k_weighted_plane_sum<64>, grid, dim3(kBlock), 0, st, bv.N, d2a, d2b, w, partials, nblk);
+	else MTFHIP_LAUNCH(k_weighted_plane_sum<36>, grid, dim3(kBlock), 0, st, bv.N, d2a, d2b, w, partials, nblk);
+	MTFHIP_LAUNCH(k_plane_sum_finish, dim3(bv.B), dim3(64), 0, st, partials, nblk, bv.S * bv.S, out);
 }
 void launch_second_order_ssd(const BatchView &bv, const ImgView &im, int term, int chained, int d0_variant, double grad_eps,
 	double hess_eps, double norm_mult, double norm_add, double *partials, int nblk, double *out, hipStream_t st) {
 	const dim3 grid(nblk, bv.B);
 	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY)
-		hipLaunchKernelGGL(k_second_order_ssd<MTFHIP_SSM_HOMOGRAPHY>, grid, dim3(kBlock), 0, st, bv, im, term, chained, d0_variant, grad_eps,
+		MTFHIP_LAUNCH(k_second_order_ssd<MTFHIP_SSM_HOMOGRAPHY>, grid, dim3(kBlock), 0, st, bv, im, term, chained, d0_variant, grad_eps,
 			hess_eps, norm_mult, norm_add, partials, nblk);
 	else
-		hipLaunchKernelGGL(k_second_order_ssd<MTFHIP_SSM_AFFINE>, grid, dim3(kBlock), 0, st, bv, im, term, chained, d0_variant, grad_eps,
+		MTFHIP_LAUNCH(k_second_order_ssd<MTFHIP_SSM_AFFINE>, grid, dim3(kBlock), 0, st, bv, im, term, chained, d0_variant, grad_eps,
 			hess_eps, norm_mult, norm_add, partials, nblk);
-	hipLaunchKernelGGL(k_plane_sum_finish, dim3(bv.B), dim3(64), 0, st, partials, nblk, bv.S * bv.S, out);
+	MTFHIP_LAUNCH(k_plane_sum_finish, dim3(bv.B), dim3(64), 0, st, partials, nblk, bv.S * bv.S, out);
 }
 
 } // namespace mtfhip

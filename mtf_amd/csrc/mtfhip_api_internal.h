@@ -394,13 +394,24 @@ static void update_corners(mtfhip_batch *b, int t) {
 	}
 }
 
-/* spin until the kernel that was given `seq` has stored it behind its host-coherent writes */
+int launch_error_pending();   /* api_core.hip: the sticky status of MTFHIP_LAUNCH, cleared when reported */
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+	__builtin_ia32_pause();
+#elif defined(__aarch64__)
+	__asm__ __volatile__("yield");
+#endif
+}
+/* spin until the kernel that was given `seq` has stored it behind its host-coherent writes.  The kernel normally reports within a
+ * few microseconds of the launch that precedes this call; when the stream is busy with earlier work the spin gives way to a
+ * blocking stream synchronisation after ~100 us instead of burning a core. */
 static int wait_host_flag(mtfhip_batch *b, unsigned long long seq) {
+	TRY(launch_error_pending());
 	const auto t0 = std::chrono::steady_clock::now();
 	for (unsigned spins = 0;; ++spins) {
 		if (__atomic_load_n(b->h_flag, __ATOMIC_ACQUIRE) == seq) return MTFHIP_OK;
-		__builtin_ia32_pause();
-		if ((spins & 0xffff) == 0xffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+		cpu_relax();
+		if ((spins & 0x3ff) == 0x3ff && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100)) break;
 	}
 	/* the kernel did not report in: let the runtime tell why */
 	HIP_TRY(hipStreamSynchronize(b->ctx->stream));

@@ -46,6 +46,12 @@ enum {
 	NCC_ACC_COUNT = 72    /* 72 -> 36 -> 18 -> 9 under the halving butterfly */
 };
 
+/* Every kernel launch of the library goes through this macro: the launch status (invalid configuration, missing code object,
+ * out-of-resources ...) is read back at once and kept as a sticky error that the next C-ABI call which synchronises reports,
+ * instead of surfacing as a timeout of the host-flag wait or at some later, unrelated call. */
+void note_launch_error(hipError_t e, const char *file, int line);
+#define MTFHIP_LAUNCH(...) do { hipLaunchKernelGGL(__VA_ARGS__); const hipError_t _le = hipGetLastError(); \
+	if (_le != hipSuccess) ::mtfhip::note_launch_error(_le, __FILE__, __LINE__); } while (0)
 constexpr int kBlock = 256;       /* threads per workgroup: 4 wave64 */
 #ifndef MTFHIP_SLOTS
 #define MTFHIP_SLOTS 512          /* resident workgroups of the fused kernel: 256 CUs x 2 (2 waves/SIMD, 4-wave groups) */

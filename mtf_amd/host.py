@@ -46,6 +46,7 @@ def lib():
         H.mtfhost_pf_create.restype = C.c_void_p
         H.mtfhost_pf_create.argtypes = [C.c_int] * 7 + [C.c_double] + [C.c_int] * 6 + [C.c_void_p, C.c_double, C.c_ulonglong, C.c_int]
         H.mtfhost_ssm_random_walk.argtypes = [C.c_void_p, C.c_ulonglong, C.c_int, C.c_void_p, C.c_void_p]
+        H.mtfhost_ssm_pts_after_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _h = H
     return _h
 
@@ -125,6 +126,13 @@ class CppTracker:
         _check(lib().mtfhost_ssm_algebra(self._h, int(what), za.ctypes.data_as(C.c_void_p), zb.ctypes.data_as(C.c_void_p),
                                          out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def pts_after_update(self, dp, eager, n_pts):
+        """ssm->compositionalUpdate(dp), then the bytes behind ssm->getPts() read through the base class (2, n_pts)"""
+        d = np.ascontiguousarray(np.asarray(dp, dtype=np.float64))
+        out = np.empty((n_pts, 2))
+        _check(lib().mtfhost_ssm_pts_after_update(self._h, d.ctypes.data_as(C.c_void_p), int(bool(eager)), out.ctypes.data_as(C.c_void_p)))
+        return out.T.copy()
 
     def get_region(self):
         out = np.empty(8)

@@ -36,10 +36,10 @@ public:
 	/* ImageBase modifiers / updaters (ImageBase.h:92-123) */
 	virtual void setCurrImg(const ImageView &img) = 0;
 	virtual void initializePixVals(const PtsT &init_pts) = 0;
-	virtual void initializePixGrad(const GradPtsT &warped_offset_pts, bool warped) = 0; /* overload 1: gradient of the warped image */
+	virtual void initializePixGrad(const GradPtsT &warped_offset_pts) = 0; /* overload 1: gradient of the warped image */
 	virtual void initializePixGrad(const PtsT &init_pts) = 0;                           /* overload 2: warp of the image gradient */
 	virtual void updatePixVals(const PtsT &curr_pts) = 0;
-	virtual void updatePixGrad(const GradPtsT &warped_offset_pts, bool warped) = 0;
+	virtual void updatePixGrad(const GradPtsT &warped_offset_pts) = 0;
 	virtual void updatePixGrad(const PtsT &curr_pts) = 0;
 	/* ImageBase.h:112-114,122-123 */
 	virtual void initializePixHess(const PtsT &init_pts, const HessPtsT &warped_offset_pts) = 0;

@@ -1,6 +1,7 @@
 #include "HipModels.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace mtf {
@@ -23,6 +24,7 @@ HipPair::HipPair(int _am, int _ssm, int _resx, int _resy, double _grad_eps, doub
 	S(_ssm == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6), n_pix(_resx * _resy), n_channels(_n_channels > 1 ? _n_channels : 1),
 	grad_eps(_grad_eps) {
 	if (resx <= 0 || resy <= 0) throw utils::InvalidArgument("ImageBase::Invalid sampling resolution provided"); /* ImageBase.cc:33-35 */
+	if (const char *e = std::getenv("MTFHIP_EAGER_GETTERS")) eager_getters = e[0] == '1';
 	check(mtfhip_ctx_create(device, stream, &ctx));
 	mtfhip_patch_desc d{am, ssm, resx, resy, grad_eps, likelihood_alpha, mi_n_bins, mi_pre_seed, mi_pou, hess_eps, n_channels};
 	int rc = mtfhip_batch_create(ctx, &d, 1, &b);
@@ -98,18 +100,18 @@ void HipAM::syncPixGrad() {
 }
 void HipAM::initializePixVals(const PtsT &pts) { HipPair::check(mtfhip_am_initialize_pix_vals(p->b, ptsArg(pts))); }
 void HipAM::updatePixVals(const PtsT &pts) { HipPair::check(mtfhip_am_update_pix_vals(p->b, ptsArg(pts))); }
-void HipAM::initializePixGrad(const PtsT &pts) { HipPair::check(mtfhip_am_initialize_pix_grad(p->b, ptsArg(pts))); }
-void HipAM::updatePixGrad(const PtsT &pts) { HipPair::check(mtfhip_am_update_pix_grad(p->b, ptsArg(pts))); }
-void HipAM::initializePixGrad(const GradPtsT &gp, bool) { HipPair::check(mtfhip_am_initialize_pix_grad_warped(p->b, gradPtsArg(gp))); }
-void HipAM::updatePixGrad(const GradPtsT &gp, bool) { HipPair::check(mtfhip_am_update_pix_grad_warped(p->b, gradPtsArg(gp))); }
+void HipAM::initializePixGrad(const PtsT &pts) { HipPair::check(mtfhip_am_initialize_pix_grad(p->b, ptsArg(pts))); d_dI0 = true; }
+void HipAM::updatePixGrad(const PtsT &pts) { HipPair::check(mtfhip_am_update_pix_grad(p->b, ptsArg(pts))); d_dIt = true; }
+void HipAM::initializePixGrad(const GradPtsT &gp) { HipPair::check(mtfhip_am_initialize_pix_grad_warped(p->b, gradPtsArg(gp))); d_dI0 = true; }
+void HipAM::updatePixGrad(const GradPtsT &gp) { HipPair::check(mtfhip_am_update_pix_grad_warped(p->b, gradPtsArg(gp))); d_dIt = true; }
 
-void HipAM::initializePixHess(const PtsT &pts) { HipPair::check(mtfhip_am_initialize_pix_hess(p->b, ptsArg(pts))); }
-void HipAM::updatePixHess(const PtsT &pts) { HipPair::check(mtfhip_am_update_pix_hess(p->b, ptsArg(pts))); }
+void HipAM::initializePixHess(const PtsT &pts) { HipPair::check(mtfhip_am_initialize_pix_hess(p->b, ptsArg(pts))); d_h0 = true; }
+void HipAM::updatePixHess(const PtsT &pts) { HipPair::check(mtfhip_am_update_pix_hess(p->b, ptsArg(pts))); d_ht = true; }
 void HipAM::initializePixHess(const PtsT &pts, const HessPtsT &hp) {
-	HipPair::check(mtfhip_am_initialize_pix_hess_warped(p->b, ptsArg(pts), hessPtsArg(hp)));
+	HipPair::check(mtfhip_am_initialize_pix_hess_warped(p->b, ptsArg(pts), hessPtsArg(hp))); d_h0 = true;
 }
 void HipAM::updatePixHess(const PtsT &pts, const HessPtsT &hp) {
-	HipPair::check(mtfhip_am_update_pix_hess_warped(p->b, ptsArg(pts), hessPtsArg(hp)));
+	HipPair::check(mtfhip_am_update_pix_hess_warped(p->b, ptsArg(pts), hessPtsArg(hp))); d_ht = true;
 }
 
 double HipAM::getLikelihood() const { double l = 0; HipPair::check(mtfhip_am_get_likelihood(p->b, &l)); return l; }
@@ -210,25 +212,25 @@ void HipSSM::syncSmall() {
 	HipPair::check(mtfhip_ssm_get_corners(p->b, curr_corners.data()));
 	HipPair::check(mtfhip_ssm_get_state(p->b, curr_state.data()));
 }
-void HipSSM::syncPts() { HipPair::check(mtfhip_batch_read(p->b, MTFHIP_BUF_CURR_PTS, curr_pts.data())); }
-void HipSSM::setCorners(const CornersT &c) { HipPair::check(mtfhip_ssm_set_corners(p->b, c.data())); syncSmall(); }
+void HipSSM::syncPts() { HipPair::check(mtfhip_batch_read(p->b, MTFHIP_BUF_CURR_PTS, curr_pts.data())); d_pts = false; }
+void HipSSM::setCorners(const CornersT &c) { HipPair::check(mtfhip_ssm_set_corners(p->b, c.data())); syncSmall(); d_pts = d_gpts = d_hpts = true; }
 void HipSSM::setState(const VectorXd &s) {
 	if (s.size() != p->S) throw utils::InvalidArgument("setState: state has invalid size");   /* validate_ssm_state */
-	HipPair::check(mtfhip_ssm_set_state(p->b, s.data())); syncSmall();
+	HipPair::check(mtfhip_ssm_set_state(p->b, s.data())); syncSmall(); d_pts = d_gpts = d_hpts = true;
 }
 void HipSSM::compositionalUpdate(const VectorXd &dp) {
 	if (dp.size() != p->S) throw utils::InvalidArgument("compositionalUpdate: state update has invalid size");
-	HipPair::check(mtfhip_ssm_compositional_update(p->b, dp.data())); syncSmall();
+	HipPair::check(mtfhip_ssm_compositional_update(p->b, dp.data())); syncSmall(); d_pts = d_gpts = d_hpts = true;
 }
-void HipSSM::updateGradPts(double eps) { HipPair::check(mtfhip_ssm_update_grad_pts(p->b, eps)); }
-void HipSSM::updateHessPts(double eps) { HipPair::check(mtfhip_ssm_update_hess_pts(p->b, eps)); }
+void HipSSM::updateGradPts(double eps) { HipPair::check(mtfhip_ssm_update_grad_pts(p->b, eps)); d_gpts = true; }
+void HipSSM::updateHessPts(double eps) { HipPair::check(mtfhip_ssm_update_hess_pts(p->b, eps)); d_hpts = true; }
 void HipSSM::invertState(VectorXd &inv, const VectorXd &s) { HipPair::check(mtfhip_ssm_invert_state(p->b, s.data(), inv.data())); }
 void HipSSM::applyWarpToCorners(CornersT &out, const CornersT &in, const VectorXd &s) {
 	HipPair::check(mtfhip_ssm_apply_warp_to_corners(p->b, in.data(), s.data(), out.data()));
 }
 void HipSSM::additiveUpdate(const VectorXd &dp) {
 	if (dp.size() != p->S) throw utils::InvalidArgument("additiveUpdate: state update has invalid size");
-	HipPair::check(mtfhip_ssm_additive_update(p->b, dp.data())); syncSmall();
+	HipPair::check(mtfhip_ssm_additive_update(p->b, dp.data())); syncSmall(); d_pts = d_gpts = d_hpts = true;
 }
 void HipSSM::applyWarpToPts(PtsT &out, const PtsT &in, const VectorXd &s) {
 	if (out.rows() != in.rows() || out.cols() != in.cols()) out.resize(in.rows(), in.cols());

@@ -31,6 +31,14 @@ struct HipPair {
 	std::map<const void *, int> jac_keys;   /* SM-owned Jacobian matrices -> MTFHIP_BUF_J0 / _JT / _JM */
 	std::map<const void *, int> hess_keys;  /* SM-owned pixel Hessians -> MTFHIP_BUF_D2I0_DP2 / _D2IT_DP2 / _D2IM_DP2 */
 	int next_jac = 0, next_hess = 0;
+	/* The host objects behind getPts(), getGradPts(), getCurrPixGrad() ... are keys: the adapters recognise them by address and
+	 * their bytes stay on the device.  A reader that is NOT one of the adapters (the reference has a few: the SPI helpers next to
+	 * NT/ESM.cc:466-472, NN's walk over ssm->getPts()) needs the bytes: with eager getters every such getter first reads its array
+	 * back when a mutator has changed it since (a dirty flag per array) -- never stale, one D2H copy per changed array and getter
+	 * call.  Off by default (the search methods call these getters every iteration only to pass the keys on);
+	 * MTFHIP_EAGER_GETTERS=1 or setEagerGetters(true) turns it on. */
+	bool eager_getters = false;
+	void setEagerGetters(bool on) { eager_getters = on; }
 
 	HipPair(int am, int ssm, int resx, int resy, double grad_eps, double likelihood_alpha, int mi_n_bins,
 		double mi_pre_seed, int mi_pou, int device, void *stream, int n_channels = 1);
@@ -52,18 +60,18 @@ public:
 	double getHessOffset() const override { return p->hess_eps; }
 	const PixValT &getInitPixVals() override;
 	const PixValT &getCurrPixVals() override;
-	const PixGradT &getInitPixGrad() override { return dI0_dx; }   /* key only; bytes on the device */
-	const PixGradT &getCurrPixGrad() override { return dIt_dx; }
-	const PixHessT &getInitPixHess() override { return d2I0_dx2; }   /* keys only, like the gradients */
-	const PixHessT &getCurrPixHess() override { return d2It_dx2; }
+	const PixGradT &getInitPixGrad() override { return fresh(dI0_dx, MTFHIP_BUF_DI0_DX, d_dI0); }   /* key; bytes on the device unless eager */
+	const PixGradT &getCurrPixGrad() override { return fresh(dIt_dx, MTFHIP_BUF_DIT_DX, d_dIt); }
+	const PixHessT &getInitPixHess() override { return fresh(d2I0_dx2, MTFHIP_BUF_D2I0_DX2, d_h0); }
+	const PixHessT &getCurrPixHess() override { return fresh(d2It_dx2, MTFHIP_BUF_D2IT_DX2, d_ht); }
 	void syncPixGrad();                                               /* explicit read-back of both gradients */
 
 	void setCurrImg(const ImageView &img) override;
 	void initializePixVals(const PtsT &init_pts) override;
-	void initializePixGrad(const GradPtsT &warped_offset_pts, bool warped) override;
+	void initializePixGrad(const GradPtsT &warped_offset_pts) override;
 	void initializePixGrad(const PtsT &init_pts) override;
 	void updatePixVals(const PtsT &curr_pts) override;
-	void updatePixGrad(const GradPtsT &warped_offset_pts, bool warped) override;
+	void updatePixGrad(const GradPtsT &warped_offset_pts) override;
 	void updatePixGrad(const PtsT &curr_pts) override;
 	void initializePixHess(const PtsT &init_pts, const HessPtsT &warped_offset_pts) override;
 	void initializePixHess(const PtsT &init_pts) override;
@@ -117,6 +125,11 @@ private:
 	PixValT I0, It;
 	PixGradT dI0_dx, dIt_dx;
 	PixHessT d2I0_dx2, d2It_dx2;
+	bool d_dI0 = false, d_dIt = false, d_h0 = false, d_ht = false;   /* host mirror older than the device array */
+	template <typename T> const T &fresh(T &m, int buf, bool &dirty) {
+		if (p->eager_getters && dirty) { HipPair::check(mtfhip_batch_read(p->b, buf, m.data())); dirty = false; }
+		return m;
+	}
 	const double *hessPtsArg(const HessPtsT &pts) const;
 	const double *ptsArg(const PtsT &pts) const;
 	const double *gradPtsArg(const GradPtsT &pts) const;
@@ -130,11 +143,13 @@ public:
 	unsigned int getResX() override { return p->resx; }
 	unsigned int getResY() override { return p->resy; }
 	unsigned int getNPts() override { return p->n_pix; }
-	const PtsT &getPts() override { return curr_pts; }            /* key only; syncPts() refreshes the bytes */
-	const GradPtsT &getGradPts() override { return grad_pts; }
-	const HessPtsT &getHessPts() override { return hess_pts; }
-	const CornersT &getCorners() override { return curr_corners; }
-	const VectorXd &getState() override { return curr_state; }
+	const PtsT &getPts() override { return fresh(curr_pts, MTFHIP_BUF_CURR_PTS, d_pts); }   /* key; syncPts() / eager getters refresh the bytes */
+	const GradPtsT &getGradPts() override { return fresh(grad_pts, MTFHIP_BUF_GRAD_PTS, d_gpts); }
+	const HessPtsT &getHessPts() override { return fresh(hess_pts, MTFHIP_BUF_HESS_PTS, d_hpts); }
+	/* corners and state live in host memory behind the C ABI: always current, also after the device-side drivers
+	 * (mtfhip_batch_track, mtfhip_pf_update) moved the SSM without going through this object */
+	const CornersT &getCorners() override { syncSmall(); return curr_corners; }
+	const VectorXd &getState() override { syncSmall(); return curr_state; }
 	void syncPts();
 
 	void setState(const VectorXd &ssm_state) override;
@@ -177,11 +192,17 @@ public:
 	void generatePerturbation(VectorXd &perturbation) override;
 	void estimateMeanOfSamples(VectorXd &sample_mean, const std::vector<VectorXd> &samples, int n_samples) override;
 	void setSamplerSeed(unsigned long long seed);
+	void markMoved() { d_pts = d_gpts = d_hpts = true; }   /* a device-side driver (hip::PF, mtfhip_batch_track) moved the SSM */
 	void setCornerBasedSampling(bool on) { corner_based_sampling = on; }   /* HomographyParams::corner_based_sampling */
 	bool getCornerBasedSampling() const { return corner_based_sampling; }
 	const std::shared_ptr<HipPair> &pair() const { return p; }
 private:
 	std::shared_ptr<HipPair> p;
+	bool d_pts = true, d_gpts = true, d_hpts = true;   /* host mirror older than the device array */
+	template <typename T> const T &fresh(T &m, int buf, bool &dirty) {
+		if (p->eager_getters && dirty) { HipPair::check(mtfhip_batch_read(p->b, buf, m.data())); dirty = false; }
+		return m;
+	}
 	VectorXd sampler_sigma, sampler_mean;
 	bool corner_based_sampling = true, sampler_ready = false;
 	struct Rng;

@@ -178,10 +178,12 @@ void PF::initialize(const CornersT &corners) {   /* NT/PF.cc:136-183 */
 void PF::setRegion(const CornersT &corners) {   /* NT/PF.cc:616-620 */
 	ssm->setCorners(corners);                                    /* (keeps the adapter's host mirrors current) */
 	HipPair::check(mtfhip_pf_set_region(h, corners.data()));     /* same corners again + initializeParticles */
+	hssm->markMoved();
 }
 void PF::update() {
 	am->setFirstIter();
 	HipPair::check(mtfhip_pf_update(h, &iters_done));
+	hssm->markMoved();
 	if (pf.enable_learning) am->updateModel(ssm->getPts());
 }
 const CornersT &PF::getRegion() {

@@ -74,7 +74,7 @@ void SearchMethod::initPixJacobian(MatrixXd &J) {
 		ssm->cmptWarpedPixJacobian(J, am->getInitPixGrad());
 	} else {
 		ssm->initializeGradPts(am->getGradOffset());
-		am->initializePixGrad(ssm->getGradPts(), true);
+		am->initializePixGrad(ssm->getGradPts());
 		ssm->cmptInitPixJacobian(J, am->getInitPixGrad());
 	}
 }
@@ -85,7 +85,7 @@ void SearchMethod::updatePixJacobian(MatrixXd &J) {
 		ssm->cmptWarpedPixJacobian(J, am->getCurrPixGrad());
 	} else {
 		ssm->updateGradPts(am->getGradOffset());
-		am->updatePixGrad(ssm->getGradPts(), true);
+		am->updatePixGrad(ssm->getGradPts());
 		ssm->cmptInitPixJacobian(J, am->getCurrPixGrad());
 	}
 }
@@ -242,7 +242,7 @@ void FCLK::initialize(const CornersT &corners) {
 	am->initializePixVals(ssm->getPts());
 	am->initializeSimilarity(); am->initializeGrad(); am->initializeHess();
 	if (params.chained_warp) am->initializePixGrad(ssm->getPts());
-	else { ssm->initializeGradPts(am->getGradOffset()); am->initializePixGrad(ssm->getGradPts(), true); }
+	else { ssm->initializeGradPts(am->getGradOffset()); am->initializePixGrad(ssm->getGradPts()); }
 	if (params.sec_ord_hess) initPixHess();
 	if (params.hess_type == InitialSelf) {
 		if (params.chained_warp) ssm->cmptWarpedPixJacobian(init_pix_jacobian, am->getInitPixGrad());

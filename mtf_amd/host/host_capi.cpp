@@ -150,6 +150,21 @@ int mtfhost_ssm_random_walk(mtfhost_tracker *t, unsigned long long seed, int n, 
 		return 0;
 	} catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
+/* A reader that is not an adapter: compositionalUpdate(dp) and then the BYTES behind getPts() through the base class, with or
+ * without eager getters (HipPair::eager_getters); out = 2 x N, x,y interleaved */
+int mtfhost_ssm_pts_after_update(mtfhost_tracker *t, const double *dp, int eager, double *out) {
+	try {
+		t->pair->setEagerGetters(eager != 0);
+		StateSpaceModel *ssm = t->ssm.get();
+		VectorXd v((int)ssm->getStateSize());
+		std::memcpy(v.data(), dp, sizeof(double) * v.size());
+		ssm->compositionalUpdate(v);
+		const PtsT &pts = ssm->getPts();
+		std::memcpy(out, pts.data(), sizeof(double) * 2 * ssm->getNPts());
+		t->pair->setEagerGetters(false);
+		return 0;
+	} catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
 /* host-only helper exercised by the CPU tests */
 int mtfhost_qr_solve(int n, const double *A_colmajor, const double *b, double *x) {
 	try {

