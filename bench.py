@@ -228,11 +228,19 @@ def secondary_workload(args):
         def step():
             gt.tracker.set_region(patches)
             gt.update()
+        ctx.timing(True)
         dt = timed(step)
+        kms, kn = ctx.timing_get("iclk_track")
+        gb = 84.0 * 625 * 256 * args.grid_iters   # ICLK (InitialSelf) + Affine moves (36 + 8 S) N = 84 N bytes per patch-iteration
         out.update({"metric": "grid patch-iterations/sec, GridTracker 256 patches ICLK+NCC+Affine 25x25",
                     "value": 256 * args.grid_iters * args.steps * world / dt, "unit": "patch-iters/s",
                     "ms_per_step": dt / args.steps * 1e3, "scaling": "weak",
-                    "config": {"workload": "256 patches x %d ICLK iterations per step, one launch per frame" % args.grid_iters}})
+                    "config": {"workload": "256 patches x %d ICLK iterations per step, one launch per frame" % args.grid_iters},
+                    "roofline": {"bound": "hbm", "note": "latency bound by construction: 256 workgroups, one per patch, ten dependent iterations "
+                                 "each; the patch operands (35 KB) are register / L2 resident after the first iteration",
+                                 "achieved": gb / (kms * 1e-3) / 1e9 if kms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": gb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms > 0 else None, "traffic": None,
+                                 "kernel": "k_iclk_track", "avg_kernel_ms": kms, "launches_timed": kn, "algorithmic_bytes_per_launch": gb}})
         if rank == 0 and not args.no_cpu:
             import oracle_py as O
             ssm = O.SSM(O.SSM_AFF, 25, 25); am = O.AM(O.AM_NCC, 25, 25); am.set_curr_img(frame0)
@@ -244,43 +252,59 @@ def secondary_workload(args):
             out["cpu_baseline"] = {"value": n / (time.perf_counter() - t0), "unit": "patch-iters/s", "cores": 1, "kind": "port",
                                    "sample": "%d ICLK+NCC+Affine 25x25 patch iterations" % n}
     elif args.workload == "pf":
+        # config 4: the whole iteration of nt::PF::update's loop on the device -- sample generation (corner based homography
+        # sampling, the reference's default), scoring, cumulative weights, multinomial resampling, estimate -- with the scoring
+        # sharded over the ranks and ONE all-gather of the weights through the C-ABI collective (RCCL directly)
+        from mtf_amd.sm import ParticleFilter, Comm
         frame0 = synth.make_frame(1024, 1024)
         corners = synth.square_corners(512, 512, 100)
         ctx.set_image(frame0)
-        b = mtf_amd.Batch(ctx, mtf_amd.AM_SSD, mtf_amd.SSM_HOMOGRAPHY, 50, 50, 1)
-        b.set_corners(corners[None]); b.initialize_pix_vals(); b.initialize_similarity()
         C = args.particles
-        states = synth.pf_candidate_states(rng, C)
-        scorer = ShardedScorer(batch=b, device=dev)
-        lo, hi = mtf_amd.dist.shard_bounds(C, scorer.rank, scorer.world) if hasattr(mtf_amd, "dist") else (0, C)
-        st_dev = torch.as_tensor(states).to(dev)     # candidates resident in HBM before the timed region
-        lik = torch.empty(hi - lo, dtype=torch.float64, device=dev)
-        from mtf_amd.dist import shard_bounds, shard_sizes
-        lo, hi = shard_bounds(C, scorer.rank, scorer.world)
-        m = max(shard_sizes(C, scorer.world))
-        send = torch.zeros(m, dtype=torch.float64, device=dev)
-        recv = torch.empty(m * world, dtype=torch.float64, device=dev)
+        comm = Comm.torch_bootstrap(local_rank) if world > 1 else None
+        pf = ParticleFilter(ctx, mtf_amd.SSM_HOMOGRAPHY, 50, 50, n_particles=C, ssm_sigma=(1.0, 0.5, 1, 1, 1, 1, 1, 1), corner_based_sampling=1,
+                            dynamic_model=0, update_type=1, likelihood_func=0, resampling_type=1, mean_type=0, likelihood_alpha=1.0,
+                            max_iters=1, epsilon=-1.0, seed=synth.DEFAULT_SEED, comm=comm)
+        pf.batch.set_math_mode(mtf_amd.MATH_REPLAY if os.environ.get("MTFHIP_MATH", "fast")[0] == "r" else mtf_amd.MATH_FAST)
+        pf.initialize(corners[None])
 
         def step():
-            b.score_candidates_dev(st_dev[lo:hi].data_ptr(), hi - lo, send.data_ptr())
-            if dist is not None:
-                dist.all_gather_into_tensor(recv, send)
+            pf.iteration()        # one read-back of the estimate per iteration, as nt::PF needs it for its convergence test
         ctx.timing(True)
         dt = timed(step)
         kms, kn = ctx.timing_get("score_candidates")
+        pms, _ = ctx.timing_get("pf_propagate"); rms, _ = ctx.timing_get("pf_resample")
+        n_local = -(-C // world)
+        flop_per_sample = 60.0   # ~60 FP64 flop per bilinear sample of a homography candidate
+        tf = n_local * 2500 * flop_per_sample / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
         out.update({"metric": "PF candidates/sec, PF+SSD+Homography 50x50, %d particles" % C,
                     "value": C * args.steps / dt, "unit": "candidates/s", "ms_per_step": dt / args.steps * 1e3,
-                    "scaling": "strong", "config": {"workload": "%d candidates x 2500 px sharded over %d rank(s), one all-gather of scores per step" % (C, world),
-                                                    "score_kernel_ms": kms, "samples_per_s": C * 2500 * args.steps / dt}})
+                    "scaling": "strong", "config": {"workload": "%d particles x 2500 px: generation + scoring (sharded over %d rank(s), one all-gather of "
+                                                                "the weights) + resampling + estimate per step" % (C, world),
+                                                    "score_kernel_ms": kms, "propagate_kernel_ms": pms, "resample_kernel_ms": rms,
+                                                    "samples_per_s": C * 2500 * args.steps / dt},
+                    "roofline": {"bound": "fp64-valu", "note": "the candidate scorer is not HBM bound (SURVEY 8d: ~1 MB of compulsory traffic for 25 M "
+                                 "samples): fraction of the FP64 vector peak at ~60 flop per sample, and the texel gather rate served by L1 / L2",
+                                 "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6, "traffic": None,
+                                 "kernel": "k_score_candidates_fast" if pf.batch.get_math_mode() else "k_score_candidates", "avg_kernel_ms": kms,
+                                 "launches_timed": kn, "samples_per_launch": n_local * 2500,
+                                 "texel_gather_GBs": n_local * 2500 * 16 / (kms * 1e-3) / 1e9 if kms > 0 else None}})
         if rank == 0 and not args.no_cpu:
             import oracle_py as O
             ssm = O.SSM(O.SSM_HOM, 50, 50); am = O.AM(O.AM_SSD, 50, 50); am.set_curr_img(frame0)
             ssm.set_corners(corners); am.initialize_pix_vals(ssm.get("curr_pts")); am.initialize_similarity()
+            pp = O.pf_params(500, corner_based_sampling=1, sigma=(1.0, 0.5, 1, 1, 1, 1, 1, 1))
+            st, ar = np.zeros((500, 8)), np.zeros((500, 8))
             n, t0 = 0, time.perf_counter()
             while time.perf_counter() - t0 < args.cpu_seconds:
-                O.pf_score(am, ssm, states[:500]); n += 500
+                st, ar, _, _, _ = O.pf_iteration(am, ssm, pp, st, ar, rng.normal(size=(500, 10)), rng.uniform(size=500), 0.0)
+                n += 500
+                if n % 5000 == 0:
+                    st[:] = 0; ar[:] = 0; ssm.set_corners(corners)
             out["cpu_baseline"] = {"value": n / (time.perf_counter() - t0), "unit": "candidates/s", "cores": 1, "kind": "port",
-                                   "sample": "%d candidate evaluations of 2500 px" % n}
+                                   "sample": "%d particle evaluations of 2500 px incl. the 4-corner DLT per sample and resampling (500-particle filter)" % n}
+        pf.close()
+        if comm is not None:
+            comm.close()
     elif args.workload == "dropin":
         # the literal drop-in boundary: C++ mtf::nt::ESM / FCLK / ICLK driving mtf::hip::HipAM / HipSSM through the
         # reference's virtuals (one C-ABI call per virtual), ONE target -- configs 1 / 2 as an MTF user runs them
@@ -340,7 +364,20 @@ def secondary_workload(args):
                                 epsilon=-1.0, leven_marq=0)
         nt.initialize(corners)
         ctx.set_image(frame1)
+        ctx.timing(True)
         dt = timed(nt.update)
+        p1, n1 = ctx.timing_get("mi_pass1"); p2, n2 = ctx.timing_get("mi_pass2")
+        recompute = n1 > 0
+        if recompute:     # the recompute form: pass 1 reads 28 B/px (texels 4, I0 8, grid point 16), pass 2 44 B/px (+ dI0_dx 16); nothing written
+            mi_bytes = 72.0 * res * res * B
+            mi_roof = {"bound": "hbm", "note": "72 B/px moved per iteration (the materialising form moved 324); the two passes are bound by "
+                       "FP64 / LDS / matrix-core issue, not by HBM: the fraction is reported for what it is",
+                       "achieved": mi_bytes / ((p1 + p2) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": mi_bytes / ((p1 + p2) * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_mi_pass_hist + k_mi_pass_grad_hess",
+                       "avg_kernel_ms": {"pass1": p1, "pass2": p2}, "launches_timed": n1, "algorithmic_bytes_per_pixel": 72}
+        else:
+            mi_roof = None
+        out.update({"roofline": mi_roof})
         out.update({"metric": "ESM+MI target-iterations/sec, %dx%d, %d targets" % (res, res, B),
                     "value": B * KI * args.steps * world / dt, "unit": "target-iters/s", "ms_per_step": dt / args.steps * 1e3,
                     "scaling": "weak", "config": {"workload": "ESM+MI(8 bins)+Homography %dx%d x %d targets per GPU, %s" %
@@ -387,6 +424,7 @@ def main():
                          "(within 1e-5), replay = the reference's rounding bit for bit (mtfhip_batch_set_math_mode)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-lean", action="store_true", help="skip the lean sub-record of the headline line")
     args = ap.parse_args()
     if args.workload != "lk":
         if args.workload == "mi" and args.res == 200 and args.targets == 64:
@@ -445,10 +483,14 @@ def main():
         batch.set_region(corners, sm)   # restart every target from its initial region (setRegion of the search method)
         return batch.track(sm)
 
+    # W untimed warm-up steps, and then more of them until the device has been busy for >= 50 ms: a fresh box needs that long to
+    # leave its idle clocks, whatever --warmup says (the driver's --steps 20 --warmup 5 is a 1.7 ms run otherwise)
     run(max(1, args.warmup))
     torch.cuda.synchronize(dev)
-    ctx.timing(4)            # hipEvents around every 4th fused launch of the timed region
-    ctx.timing_reset()
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < 0.05:
+        run(50)
+        torch.cuda.synchronize(dev)
     batch.set_region(corners, sm)
     sm.max_iters = args.steps
     if dist is not None:
@@ -465,8 +507,34 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    # kernel duration for the roofline: hipEvents around EVERY fused launch of a second, untimed pass of the same loop (at least 40
+    # launches whatever --steps is; the events cost ~5 % of a step, which is why they stay out of the timed region above)
+    k_steps = max(40, args.steps)
+    ctx.timing(1)
+    ctx.timing_reset()
+    run(k_steps)
+    torch.cuda.synchronize(dev)
     kern_ms, kern_n = ctx.timing_get("fused_lk")
     ctx.timing(False)
+    # the lean variant of the same workload (nothing materialised: the form the device-side loop needs): FP64-issue / latency bound
+    lean = None
+    if rank == 0 and args.mode == "full" and not args.no_lean:
+        sm_l = mtf_amd.sm_desc(sm_kind, materialize=0, leven_marq=0, epsilon=-1.0, max_iters=k_steps)
+        batch.set_region(corners, sm_l); batch.track(sm_l)
+        torch.cuda.synchronize(dev)
+        batch.set_region(corners, sm_l)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter(); batch.track(sm_l); torch.cuda.synchronize(dev); dt_l = time.perf_counter() - t1
+        ctx.timing(1); ctx.timing_reset()
+        batch.set_region(corners, sm_l); batch.track(sm_l); torch.cuda.synchronize(dev)
+        lk_ms, lk_n = ctx.timing_get("fused_lk")
+        ctx.timing(False)
+        bpp_l = algorithmic_bytes_per_pixel(args.sm, 0, j0_recompute=os.environ.get("MTFHIP_J0_RECOMPUTE", "1") != "0" and args.sm in ("esm", "iclk"))
+        flops_px = 190.0   # ~190 FP64 flop per pixel-iteration (5 samples, chain rule, SD row, 44 accumulations)
+        lean = {"value": B * k_steps / dt_l, "unit": "iters/s", "us_per_step": dt_l / k_steps * 1e6, "kernel_us": lk_ms * 1e3,
+                "launches_timed": lk_n, "math": args.math, "bound": "fp64-valu / latency (not HBM)",
+                "algorithmic_bytes_per_pixel": bpp_l, "frac_of_hbm_peak": bpp_l * res * res * B / (lk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if lk_ms > 0 else None,
+                "frac_of_fp64_vector_peak_78.6TF": flops_px * res * res * B / (lk_ms * 1e-3) / 78.6e12 if lk_ms > 0 else None}
 
     if rank == 0:
         N = res * res
@@ -493,8 +561,18 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.sm, args.mode, res, B) if args.am == "ssd" else None,
                          "kernel": "k_fused_%s" % args.am, "avg_kernel_ms": kern_ms, "launches_timed": kern_n,
                          "algorithmic_bytes_per_pixel": bpp, "j0_rows": "rebuilt from dI0_dx" if j0_rec else "read back", "bytes_per_launch": bytes_per_launch,
-                         "targets_per_launch": per_launch},
+                         "targets_per_launch": per_launch,
+                         # what the figure means: algorithmic bytes / kernel time.  The read set of a launch (grid points, I0, dI0_dx:
+                         # 40 B/px) is re-read every iteration and fits the 256 MB Infinity Cache, so after the first iteration it is
+                         # served from there; the 88 B/px of non-temporal stores do reach HBM.
+                         "infinity_cache_resident_read_bytes": float(bpp - (88 if materialize and args.sm != "iclk" else (8 if materialize else 0))) * N * per_launch,
+                         "hbm_write_bytes": float(88 if materialize and args.sm != "iclk" else (8 if materialize else 0)) * N * per_launch,
+                         "timing": "hipEvents around every fused launch of an untimed second pass (%d launches); rocprofv3 --kernel-trace of the "
+                                   "same command: profiles/r02_kernel_stats.csv" % kern_n,
+                         "traffic_source": "rocprofv3 --pmc passes committed under profiles/ (pmc_latest.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB), not this run"},
         }
+        if lean is not None:
+            out["lean"] = lean
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, res, frame0, frame1, corners[0], args.am)
             out["parity"] = parity_gate(ctx, args.am, res, frame0, frame1, corners[0])

@@ -62,6 +62,7 @@ struct mtfhip_pf {
 	bool initialized = false;
 	double *d_states[2] = {nullptr, nullptr}, *d_ars[2] = {nullptr, nullptr};
 	double *d_lik = nullptr, *d_sim = nullptr, *d_wts = nullptr, *d_cum = nullptr, *d_out = nullptr, *d_normals = nullptr, *d_uniforms = nullptr;
+	double *d_parts = nullptr;   /* per-workgroup partial results of the selection pass */
 	double *d_send = nullptr, *d_recv = nullptr;   /* sharded scoring: [2 m] send, [2 m world] receive (likelihood | similarity) */
 	int *d_ids = nullptr;
 	double prev_corners[8];
@@ -121,7 +122,7 @@ int mtfhip_allgather_scores(mtfhip_comm *c, const double *dev_send, int count, d
 /* ------------------------------------------------------------------ the particle filter */
 static void pf_free(mtfhip_pf *pf) {
 	void *ptrs[] = {pf->d_states[0], pf->d_states[1], pf->d_ars[0], pf->d_ars[1], pf->d_lik, pf->d_sim, pf->d_wts, pf->d_cum, pf->d_out,
-		pf->d_normals, pf->d_uniforms, pf->d_send, pf->d_recv, pf->d_ids};
+		pf->d_normals, pf->d_uniforms, pf->d_send, pf->d_recv, pf->d_ids, pf->d_parts};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 }
 int mtfhip_pf_create(mtfhip_batch *b, const mtfhip_pf_desc *d, mtfhip_pf **out) {
@@ -143,7 +144,7 @@ int mtfhip_pf_create(mtfhip_batch *b, const mtfhip_pf_desc *d, mtfhip_pf **out) 
 	auto A = [&](auto &p, size_t bytes) { if (hipMalloc(reinterpret_cast<void **>(&p), bytes) != hipSuccess) okm = false; };
 	for (int k = 0; k < 2; ++k) { A(pf->d_states[k], sizeof(double) * nS); A(pf->d_ars[k], sizeof(double) * nS); }
 	A(pf->d_lik, sizeof(double) * n); A(pf->d_sim, sizeof(double) * n); A(pf->d_wts, sizeof(double) * n); A(pf->d_cum, sizeof(double) * n);
-	A(pf->d_out, sizeof(double) * 32); A(pf->d_normals, sizeof(double) * n * 10); A(pf->d_uniforms, sizeof(double) * n); A(pf->d_ids, sizeof(int) * n);
+	A(pf->d_out, sizeof(double) * 32); A(pf->d_parts, sizeof(double) * 18 * ((n + 255) / 256)); A(pf->d_normals, sizeof(double) * n * 10); A(pf->d_uniforms, sizeof(double) * n); A(pf->d_ids, sizeof(int) * n);
 	if (!okm) { pf_free(pf); delete pf; return fail(MTFHIP_ERR_HIP, "pf_create: hipMalloc failed"); }
 	*out = pf;
 	return MTFHIP_OK;
@@ -269,7 +270,7 @@ int mtfhip_pf_iteration(mtfhip_pf *pf, const double *normals, const double *unif
 	{
 		TimedScope ts(b->ctx, "pf_resample");
 		launch_pf_resample(b->desc.ssm, p, pf->d_lik, pf->d_sim, pf->d_wts, pf->d_cum, stc, arc, pf->d_states[1 - pf->cur], pf->d_ars[1 - pf->cur],
-			pf->d_ids, pf->d_out, st);
+			pf->d_ids, pf->d_out, pf->d_parts, st);
 	}
 	if (p.resampling_type == 1 || p.resampling_type == 2) pf->cur = 1 - pf->cur;   /* curr_set_id = 1 - curr_set_id (PF.cc:501) */
 	double out[32];

@@ -209,16 +209,19 @@ __device__ __forceinline__ double block_scan_incl(double v, double *lds /* [kPfB
 	__syncthreads();
 	return r;
 }
-__global__ __launch_bounds__(kPfBlock) void k_pf_resample(PfResampleArgs a) {
+/* Three launches: (1) one workgroup: weights, their inclusive scan, the normalised cumulative weights, the best particle before
+ * resampling; (2) n / 256 workgroups: one particle per thread draws, searches, copies its source particle into the other set and
+ * contributes to its workgroup's best / sums (a single workgroup doing all n dependent binary searches was 270 us of the 400 us
+ * iteration); (3) one workgroup folds the per-workgroup results into the estimate. */
+__global__ __launch_bounds__(kPfBlock) void k_pf_weights(PfResampleArgs a) {
 	__shared__ double lds[kPfBlock / 64 + 1];
 	__shared__ double red_v[kPfBlock / 64]; __shared__ int red_i[kPfBlock / 64];
-	__shared__ int s_max_id; __shared__ double s_max_wt;
-	const int n = a.n, S = a.S, tid = threadIdx.x;
+	const int n = a.n, tid = threadIdx.x;
 	const int per = (n + kPfBlock - 1) / kPfBlock;   /* contiguous run of particles per thread: the scan is a scan of run sums */
 	const int lo = min(tid * per, n), hi = min(lo + per, n);
 	const double pi = 3.14159265358979323846;
 	const double mfac = 1.0 / sqrt(2 * pi * a.measurement_sigma);   /* PF.cc:69-70 */
-	/* 1. particle_wts (PF.cc:348-365) and their running sum */
+	/* particle_wts (PF.cc:348-365) and their running sum */
 	double run = 0;
 	for (int k = lo; k < hi; ++k) {
 		double w;
@@ -237,81 +240,97 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_resample(PfResampleArgs a) {
 		for (int k = lo; k < hi; ++k) { c += a.wts[k]; a.cum[k] = c / total; }   /* particle_cum_wts /= particle_cum_wts[n - 1] */
 	}
 	/* the highest weighted particle, last index on ties (`>=`, PF.cc:378-381) */
-	auto block_argmax = [&](double v, int idx) {
+	double bv = -1.7976931348623157e308; int bi = -1;
+	for (int k = lo; k < hi; ++k) if (a.wts[k] >= bv) { bv = a.wts[k]; bi = k; }
 #pragma unroll
-		for (int d = 32; d >= 1; d >>= 1) {
-			const double ov = __shfl_xor(v, d); const int oi = __shfl_xor(idx, d);
-			if (ov > v || (ov == v && oi > idx)) { v = ov; idx = oi; }
-		}
-		if ((tid & 63) == 0) { red_v[tid >> 6] = v; red_i[tid >> 6] = idx; }
-		__syncthreads();
-		if (tid == 0) {
-			double bv = red_v[0]; int bi = red_i[0];
-			for (int w = 1; w < kPfBlock / 64; ++w) if (red_v[w] > bv || (red_v[w] == bv && red_i[w] > bi)) { bv = red_v[w]; bi = red_i[w]; }
-			s_max_wt = bv; s_max_id = bi;
-		}
-		__syncthreads();
-	};
-	{
-		double bv = -1.7976931348623157e308; int bi = -1;
-		for (int k = lo; k < hi; ++k) if (a.wts[k] >= bv) { bv = a.wts[k]; bi = k; }
-		block_argmax(bv, bi);
+	for (int d = 32; d >= 1; d >>= 1) {
+		const double ov = __shfl_xor(bv, d); const int oi = __shfl_xor(bi, d);
+		if (ov > bv || (ov == bv && oi > bi)) { bv = ov; bi = oi; }
 	}
-	__threadfence_block();
+	if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bi; }
 	__syncthreads();
-	const double *st_final = a.st_in;
-	if (a.resampling_type == 1 || a.resampling_type == 2) {
-		/* 2. multinomial resampling (PF.cc:455-502 binary search; :505-536 linear search: the same smallest index whose
-		 * normalised cumulative weight reaches the draw), into the other particle set */
-		double bv = -1.7976931348623157e308; int bi = -1;
-		for (int k = tid; k < n; k += kPfBlock) {
+	if (tid == 0) {
+		for (int w = 1; w < kPfBlock / 64; ++w) if (red_v[w] > bv || (red_v[w] == bv && red_i[w] > bi)) { bv = red_v[w]; bi = red_i[w]; }
+		a.out[8] = bv; a.out[9] = (double)bi;
+	}
+}
+/* per-workgroup partial results of the selection pass: [0] best weight [1] its new index [2..9] sum of states [10..17] sum of corners */
+constexpr int kPfPart = 18;
+__global__ __launch_bounds__(kBlock) void k_pf_select(PfResampleArgs a, double *parts) {
+	__shared__ double red_v[kBlock / 64]; __shared__ int red_i[kBlock / 64];
+	__shared__ double lds[4 * 16];
+	const int n = a.n, S = a.S, tid = threadIdx.x, k = blockIdx.x * kBlock + tid;
+	const bool resample = a.resampling_type == 1 || a.resampling_type == 2;
+	double bv = -1.7976931348623157e308; int bi = -1;
+	double acc[16];
+#pragma unroll
+	for (int s = 0; s < 16; ++s) acc[s] = 0.0;
+	if (k < n) {
+		int id = k;
+		if (resample) {
+			/* multinomial resampling (PF.cc:455-502 binary search; :505-536 linear search: the same smallest index whose
+			 * normalised cumulative weight reaches the draw), into the other particle set */
 			const double u = a.uniforms ? a.uniforms[k] : philox_uniform(a.seed, a.iter, (unsigned)k);
-			int l = 0, h = n - 1, id = (l + h) / 2;
+			int l = 0, h = n - 1;
+			id = (l + h) / 2;
 			while (h > l) { if (a.cum[id] >= u) h = id; else l = id + 1; id = (l + h) / 2; }
 			if (a.ids) a.ids[k] = id;
-			for (int s = 0; s < S; ++s) { a.st_out[(size_t)k * S + s] = a.st_in[(size_t)id * S + s]; a.ar_out[(size_t)k * S + s] = a.ar_in[(size_t)id * S + s]; }
-			const double w = a.wts[id];
-			if (w > bv || (w == bv && k > bi)) { bv = w; bi = k; }
 		}
-		__syncthreads();
-		block_argmax(bv, bi);
-		st_final = a.st_out;
-		__threadfence_block();
-		__syncthreads();
-	}
-	/* 3. the estimate (PF.cc:421-437) */
-	if (a.mean_type == 1) {   /* ProjectiveBase::estimateMeanOfSamples :311-317 (the running mean is the arithmetic mean) */
-		double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-		for (int k = tid; k < n; k += kPfBlock)
-			for (int s = 0; s < S; ++s) acc[s] += st_final[(size_t)k * S + s];
+		double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 		for (int s = 0; s < S; ++s) {
-			double tot;
-			(void)block_scan_incl(acc[s], lds, tot);
-			if (tid == 0) a.out[s] = tot / (double)n;
+			p[s] = a.st_in[(size_t)id * S + s];
+			if (resample) { a.st_out[(size_t)k * S + s] = p[s]; a.ar_out[(size_t)k * S + s] = a.ar_in[(size_t)id * S + s]; }
 		}
-	} else if (a.mean_type == 2) {   /* updateMeanCorners :607-614 */
-		double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-		for (int k = tid; k < n; k += kPfBlock) {
-			double p[8] = {0, 0, 0, 0, 0, 0, 0, 0}, W[9];
-			for (int s = 0; s < S; ++s) p[s] = st_final[(size_t)k * S + s];
+		bv = a.wts[id]; bi = k;
+		if (a.mean_type == 1) {
+#pragma unroll
+			for (int s = 0; s < 8; ++s) acc[s] = p[s];
+		} else if (a.mean_type == 2) {   /* updateMeanCorners :607-614 */
+			double W[9];
 			if (a.ssm == MTFHIP_SSM_HOMOGRAPHY) warp_from_state_dev<MTFHIP_SSM_HOMOGRAPHY>(p, W); else warp_from_state_dev<MTFHIP_SSM_AFFINE>(p, W);
+#pragma unroll
 			for (int q = 0; q < 4; ++q) {
 				const double X = a.init_corners_hm[3 * q], Y = a.init_corners_hm[3 * q + 1], Z = a.init_corners_hm[3 * q + 2];
 				double nx = W[0] * X + W[1] * Y + W[2] * Z, ny = W[3] * X + W[4] * Y + W[5] * Z;
 				if (a.ssm == MTFHIP_SSM_HOMOGRAPHY) { const double d = W[6] * X + W[7] * Y + W[8] * Z; nx = nx / d; ny = ny / d; }
-				acc[2 * q] += nx; acc[2 * q + 1] += ny;
+				acc[8 + 2 * q] = nx; acc[9 + 2 * q] = ny;
 			}
 		}
-		for (int s = 0; s < 8; ++s) {
-			double tot;
-			(void)block_scan_incl(acc[s], lds, tot);
-			if (tid == 0) a.out[10 + s] = tot / (double)n;
-		}
 	}
+	/* the best of the (resampled) set, last index on ties (PF.cc:487-490) */
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) {
+		const double ov = __shfl_xor(bv, d); const int oi = __shfl_xor(bi, d);
+		if (ov > bv || (ov == bv && oi > bi)) { bv = ov; bi = oi; }
+	}
+	if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bi; }
+	__syncthreads();
+	double *part = parts + (size_t)blockIdx.x * kPfPart;
 	if (tid == 0) {
-		if (a.mean_type != 1) for (int s = 0; s < S; ++s) a.out[s] = st_final[(size_t)s_max_id * S + s];
-		a.out[8] = s_max_wt; a.out[9] = (double)s_max_id;
+		for (int w = 1; w < kBlock / 64; ++w) if (red_v[w] > bv || (red_v[w] == bv && red_i[w] > bi)) { bv = red_v[w]; bi = red_i[w]; }
+		part[0] = bv; part[1] = (double)bi;
 	}
+	__syncthreads();
+	block_reduce_store<16>(acc, part + 2, lds);
+}
+__global__ __launch_bounds__(64) void k_pf_estimate(PfResampleArgs a, const double *parts, int nparts) {
+	const int lane = threadIdx.x, S = a.S, n = a.n;
+	const bool resample = a.resampling_type == 1 || a.resampling_type == 2;
+	const double *st_final = resample ? a.st_out : a.st_in;
+	/* best over the workgroups, in workgroup order (= particle order): last index on ties */
+	double bv = a.out[8]; int bi = (int)a.out[9];
+	if (resample) {
+		bv = -1.7976931348623157e308; bi = -1;
+		for (int w = 0; w < nparts; ++w) { const double v = parts[(size_t)w * kPfPart]; const int i2 = (int)parts[(size_t)w * kPfPart + 1]; if (v > bv || (v == bv && i2 > bi)) { bv = v; bi = i2; } }
+	}
+	if (lane < 16) {
+		double s = 0;
+		for (int w = 0; w < nparts; ++w) s += parts[(size_t)w * kPfPart + 2 + lane];
+		if (a.mean_type == 1 && lane < S) a.out[lane] = s / (double)n;             /* estimateMeanOfSamples :311-317 */
+		if (a.mean_type == 2 && lane >= 8) a.out[10 + lane - 8] = s / (double)n;   /* mean corners */
+	}
+	if (a.mean_type != 1 && lane < S) a.out[lane] = st_final[(size_t)bi * S + lane];
+	if (lane == 0) { a.out[8] = bv; a.out[9] = (double)bi; }
 }
 
 /* PF::initializeParticles (PF.cc:185-197): every particle at the current state, AR terms zero */
@@ -335,14 +354,17 @@ void launch_pf_propagate(int ssm, const PfLaunch &p, double *states, double *ars
 	else MTFHIP_LAUNCH(k_pf_propagate<MTFHIP_SSM_AFFINE>, g, dim3(kBlock), 0, st, a, states, ars);
 }
 void launch_pf_resample(int ssm, const PfLaunch &p, const double *lik, const double *sim, double *wts, double *cum, const double *st_in,
-	const double *ar_in, double *st_out, double *ar_out, int *ids, double *out, hipStream_t st) {
+	const double *ar_in, double *st_out, double *ar_out, int *ids, double *out, double *parts, hipStream_t st) {
 	PfResampleArgs a;
 	a.n = p.n; a.S = p.S; a.ssm = ssm; a.likelihood_func = p.likelihood_func; a.resampling_type = p.resampling_type; a.mean_type = p.mean_type;
 	a.measurement_sigma = p.measurement_sigma; a.max_similarity = p.max_similarity; a.seed = p.seed; a.iter = p.iter; a.uniforms = p.uniforms;
 	a.lik = lik; a.sim = sim; a.wts = wts; a.cum = cum; a.st_in = st_in; a.ar_in = ar_in; a.st_out = st_out; a.ar_out = ar_out; a.ids = ids;
 	for (int k = 0; k < 12; ++k) a.init_corners_hm[k] = p.init_corners_hm[k];
 	a.out = out;
-	MTFHIP_LAUNCH(k_pf_resample, dim3(1), dim3(kPfBlock), 0, st, a);
+	const int nparts = (p.n + kBlock - 1) / kBlock;
+	MTFHIP_LAUNCH(k_pf_weights, dim3(1), dim3(kPfBlock), 0, st, a);
+	MTFHIP_LAUNCH(k_pf_select, dim3(nparts), dim3(kBlock), 0, st, a, parts);
+	MTFHIP_LAUNCH(k_pf_estimate, dim3(1), dim3(64), 0, st, a, parts, nparts);
 }
 void launch_pf_fill(int n, int S, const double *dev_state, double *states, double *ars, hipStream_t st) {
 	MTFHIP_LAUNCH(k_pf_fill, dim3((n + 255) / 256), dim3(256), 0, st, n, S, dev_state, states, ars);

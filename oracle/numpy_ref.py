@@ -253,3 +253,19 @@ def mi_curr_hessian(I0n, Itn, J, n_bins=8, pre_seed=10.0):
     Q = np.einsum("rp,cp,ps->rcs", dBt, B0, J)
     fac = 1.0 / hj - 1.0 / hc[:, None]
     return H + np.einsum("rc,rcs,rcu->su", fac, Q, Q)
+
+
+def mi_curr_grad(I0n, Itn, n_bins=8, pre_seed=10.0):
+    """df / dIt per pixel (AM/src/MI.cc:426-442 written densely): sum_{r,c} d/dIt b3(r - It_p) norm * b3(c - I0_p) *
+    (1 + log h(r,c) - log h_c(r)); the derivative of b3(r - It) with respect to It is -b3'(r - It)."""
+    I0n = np.asarray(I0n, dtype=np.float64); Itn = np.asarray(Itn, dtype=np.float64)
+    N = I0n.size
+    bins = np.arange(n_bins, dtype=np.float64)
+    X = bins[:, None] - Itn[None, :]
+    Bt, B0 = bspline3(X), bspline3(bins[:, None] - I0n[None, :])
+    seed_h = n_bins * pre_seed
+    norm = 1.0 / (N + seed_h * n_bins)
+    hc = (seed_h + Bt.sum(axis=1)) * norm
+    hj = (pre_seed + Bt @ B0.T) * norm
+    G = 1.0 + np.log(hj) - np.log(hc)[:, None]
+    return np.einsum("rp,rc,cp->p", -bspline3_d1(X) * norm, G, B0)

@@ -75,6 +75,28 @@ def main():
                 "ncc_df_dI0_head": m["df_dI0"][:16], "ncc_g_init": m["df_dI0"] @ J0,
                 "ncc_H_self_J0": R.ncc_self_hessian(J0, m), "ncc_J0_head": J0[:16]})
 
+    # --- homography + MI, 8 bins, 40 x 40 (config 5 shape, reduced): similarity, df_dIt . Jt, cmptCurrHessian(Jt)
+    res, nb = 40, 8
+    corners = synth.square_corners(96, 100, 80) + rng.uniform(-1, 1, size=(2, 4))
+    init_pts, init_hm = R.grid_from_corners(corners, res, res)
+    mult = (nb - 1) / 256.0                                        # MI.cc:80-94: pixel values scaled to [0, n_bins - 1]
+    I0n = mult * R.bilinear(img, init_pts[0], init_pts[1])
+    p = synth.random_small_homography(rng, 0.4)
+    W = R.hom_matrix(p)
+    wpts, q = R.warp_pts(W, init_hm)
+    Itn = mult * R.bilinear(img, wpts[0], wpts[1])
+    gt = R.img_grad(img, wpts, mult=mult)
+    Jt = R.sd_rows_chained(gt, R.hom_spatial_jacobian(W, wpts, q[2]), R.hom_param_jacobian(init_pts[0], init_pts[1]))
+    mi_f = R.mi_similarity(I0n, Itn, nb)
+    dft = R.mi_curr_grad(I0n, Itn, nb)
+    mi_g = dft @ Jt
+    for s_ in range(8):   # the analytic gradient against a directional central difference of the definition
+        h = 1e-4 / np.abs(Jt[:, s_]).max()
+        fd = (R.mi_similarity(I0n, Itn + h * Jt[:, s_], nb) - R.mi_similarity(I0n, Itn - h * Jt[:, s_], nb)) / (2 * h)
+        assert abs(fd - mi_g[s_]) <= 1e-6 * max(abs(mi_g[s_]), np.abs(mi_g).max() * 1e-3), (s_, fd, mi_g[s_])
+    out.update({"mi_corners": corners, "mi_p": p, "mi_f": mi_f, "mi_g_curr": mi_g, "mi_H_curr": R.mi_curr_hessian(I0n, Itn, Jt, nb),
+                "mi_It_head": Itn[:16], "mi_df_dIt_head": dft[:16]})
+
     # --- PF scores for 32 candidates (config 4 shape, reduced)
     res = 20
     corners = synth.square_corners(90, 100, 60)
