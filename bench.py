@@ -226,8 +226,7 @@ def secondary_workload(args):
         patches = gt.patch_corners(region)
 
         def step():
-            gt.tracker.set_region(patches)
-            gt.update()
+            gt.update(patches)     # setRegion + update of every patch tracker: one C-ABI call, one upload, one launch of the loop
         ctx.timing(True)
         dt = timed(step)
         kms, kn = ctx.timing_get("iclk_track")

@@ -272,6 +272,11 @@ int mtfhip_batch_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, d
  * convergence test included) without host round trips; returns per-target iteration counts
  * and final corners.  SM/src/NT/{ESM,FCLK,ICLK}.cc update(). */
 int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters /* B */, double *corners /* B x 8 */);
+/* setRegion(region_corners) followed by update() in one call -- the pair GridTracker::update issues per patch tracker
+ * (SM/src/GridTracker.cc:345-363) and PyramidalTracker per level (SM/src/PyramidalTracker.cc:70-96).  Same results as
+ * mtfhip_batch_set_region + mtfhip_batch_track; one staged upload per frame where the search method keeps its template Jacobian. */
+int mtfhip_batch_track_region(mtfhip_batch *b, const mtfhip_sm_desc *sm, const double *region_corners /* B x 8 */,
+	int *n_iters /* B */, double *corners /* B x 8 */);
 /* how many targets one launch of the loop above covers (all of them, or an Infinity-Cache sized chunk) */
 int mtfhip_batch_track_targets_per_launch(mtfhip_batch *b, const mtfhip_sm_desc *sm);
 

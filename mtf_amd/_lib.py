@@ -88,7 +88,7 @@ SYMBOLS = [
     "mtfhip_am_initialize_pix_hess_warped", "mtfhip_am_update_pix_hess_warped", "mtfhip_ssm_cmpt_pix_hessian",
     "mtfhip_sm_mean_pix_hessian", "mtfhip_am_cmpt_init_hessian2", "mtfhip_am_cmpt_curr_hessian2",
     "mtfhip_am_cmpt_self_hessian2", "mtfhip_am_cmpt_sum_of_hessians2",
-    "mtfhip_batch_init_template", "mtfhip_batch_set_region", "mtfhip_batch_iterate", "mtfhip_batch_track",
+    "mtfhip_batch_init_template", "mtfhip_batch_set_region", "mtfhip_batch_iterate", "mtfhip_batch_track", "mtfhip_batch_track_region",
     "mtfhip_batch_track_targets_per_launch",
     "mtfhip_score_candidates", "mtfhip_score_candidates_dev",
     "mtfhip_sample_candidates", "mtfhip_sample_candidates_dev",

@@ -442,6 +442,14 @@ class Batch:
         L.check(L.lib().mtfhip_batch_track(self._h, C.byref(sm), _p(n), _p(c)))
         return n, self._corners_out(c)
 
+    def track_region(self, corners, sm):
+        """setRegion(corners) + update() of one frame in one C-ABI call (mtfhip_batch_track_region)"""
+        r = self._corners_in(corners)
+        n = np.empty(self.B, dtype=np.int32)
+        c = np.empty((self.B, 8))
+        L.check(L.lib().mtfhip_batch_track_region(self._h, C.byref(sm), _p(r), _p(n), _p(c)))
+        return n, self._corners_out(c)
+
     # ---------------------------------------------------------- candidate scoring
     def score_candidates(self, states, want_similarity=False):
         s = _f64(states).reshape(-1, self.S)

@@ -436,7 +436,11 @@ void *mtfhip_batch_device_ptr(mtfhip_batch *b, int id) {
 }
 
 /* ------------------------------------------------------------------ SSM */
-int mtfhip_ssm_set_corners(mtfhip_batch *b, const double *corners) {
+int mtfhip_ssm_set_corners(mtfhip_batch *b, const double *corners) { return set_corners_core(b, corners, false); }
+
+/* for_track: the upload also carries active = 1 / iteration counts = 0, i.e. it is the slab mtfhip_batch_track would
+ * upload next (mtfhip_batch_track_region: one staging pass and one copy per frame instead of two) */
+int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track) {
 	FLUSH_AM(b);   /* pending calls are replayed (with the points they need); the points themselves are about to change */
 	if (b) ++b->lz.epoch;
 	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
@@ -469,8 +473,8 @@ int mtfhip_ssm_set_corners(mtfhip_batch *b, const double *corners) {
 	/* w0, init_corners_hm, identity warps, zero states and the corners in ONE pinned async copy; the staging buffer is
 	 * protected by an event instead of a stream sync */
 	HIP_TRY(hipEventSynchronize(b->ev_a));
-	fill_stage(b, b->h_stage_a, w0.data(), 0, false);
-	HIP_TRY(hipMemcpyAsync(b->d_slab, b->h_stage_a, b->slab_dbl_bytes, hipMemcpyHostToDevice, b->ctx->stream));
+	fill_stage(b, b->h_stage_a, w0.data(), for_track ? 1 : 0, for_track);
+	HIP_TRY(hipMemcpyAsync(b->d_slab, b->h_stage_a, for_track ? b->slab_bytes : b->slab_dbl_bytes, hipMemcpyHostToDevice, b->ctx->stream));
 	b->warps_dirty = false;   /* the slab carries the (identity) warps */
 	HIP_TRY(hipEventRecord(b->ev_a, b->ctx->stream));
 	{

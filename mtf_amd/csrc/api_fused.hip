@@ -358,14 +358,19 @@ int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
  * off): the SSM is reset to the new corners; ESM (and FCLK with the InitialSelf Hessian) recompute init_pix_jacobian with
  * cmptInitPixJacobian on the new grid and, for the Hessian types that use it, the constant self Hessian; ICLK keeps its
  * template Jacobian.  The template (I0, dI0_dx) is kept in every case. */
-int mtfhip_batch_set_region(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm) {
+static int set_region_core(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm, bool for_track);
+int mtfhip_batch_set_region(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm) { return set_region_core(b, corners, sm, false); }
+
+static bool region_refreshes(const mtfhip_sm_desc *sm) { return sm->sm == MTFHIP_SM_ESM || (sm->sm == MTFHIP_SM_FCLK && sm->hess_type == 0); }
+
+static int set_region_core(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm, bool for_track) {
 	FLUSH(b);
 	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
 	TRY(check_sm(b, sm, "set_region"));
 	TRY(single_channel(b, "set_region"));
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "set_region before init_template");
-	TRY(mtfhip_ssm_set_corners(b, corners));
-	const bool refresh = sm->sm == MTFHIP_SM_ESM || (sm->sm == MTFHIP_SM_FCLK && sm->hess_type == 0);
+	TRY(set_corners_core(b, corners, for_track));
+	const bool refresh = region_refreshes(sm);
 	if (!refresh) {
 		/* back on exactly the grid the kept template Jacobian was computed on: its rows can still be rebuilt from dI0_dx */
 		if (b->j0_is_template && b->template_corners.size() == 8 * (size_t)b->B &&
@@ -709,7 +714,22 @@ int mtfhip_batch_track_targets_per_launch(mtfhip_batch *b, const mtfhip_sm_desc 
 	return track_chunk(b, sm, fa);
 }
 
-int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners) {
+static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners, bool slab_uploaded);
+int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners) { return track_core(b, sm, n_iters, corners, false); }
+
+/* setRegion + update of one frame in one call: what GridTracker::update does with every patch tracker (GridTracker.cc:345-363:
+ * tracker->setRegion(patch corners); tracker->update()) and a pyramid level with the level above's result.  For the search
+ * methods that keep their template Jacobian (ICLK; FCLK without the InitialSelf Hessian) the reset state and the loop's
+ * active flags / iteration counts travel in ONE staged copy; the others take the two steps one after the other. */
+int mtfhip_batch_track_region(mtfhip_batch *b, const mtfhip_sm_desc *sm, const double *region_corners, int *n_iters, double *corners) {
+	if (!b || !sm || !region_corners) return fail(MTFHIP_ERR_INVALID_ARG, "track_region: NULL argument");
+	if (sm->max_iters <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "track: max_iters must be positive");
+	const bool folded = !region_refreshes(sm);
+	TRY(set_region_core(b, region_corners, sm, folded));
+	return track_core(b, sm, n_iters, corners, folded);
+}
+
+static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners, bool slab_uploaded) {
 	FLUSH(b);
 	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
 	TRY(check_sm(b, sm, "track"));
@@ -729,11 +749,13 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
 	else { fa.materialize = 0; fa.mode = 2; fa.active = nullptr; fa.rows_per_block = 1; fa.j0_recompute = 0; fa.inline_warp = 0; fa.fast_math = 0; }
 	/* active = 1, iters = 0, corners, warps, states, NCC scalars: one pinned async copy of the whole slab
 	 * (w0 is copied along; init_grid consumed it long ago) */
-	HIP_TRY(hipEventSynchronize(b->ev_b));
-	std::memcpy(b->h_stage_b + 45 * sizeof(double) * (size_t)b->B, b->h_stage_a + 45 * sizeof(double) * (size_t)b->B, 9 * sizeof(double) * (size_t)b->B);
-	fill_stage(b, b->h_stage_b, nullptr, 1, true);
-	HIP_TRY(hipMemcpyAsync(b->d_slab, b->h_stage_b, b->slab_bytes, hipMemcpyHostToDevice, st));
-	HIP_TRY(hipEventRecord(b->ev_b, st));   /* h_stage_b may be refilled once this upload has been consumed */
+	if (!slab_uploaded) {
+		HIP_TRY(hipEventSynchronize(b->ev_b));
+		std::memcpy(b->h_stage_b + 45 * sizeof(double) * (size_t)b->B, b->h_stage_a + 45 * sizeof(double) * (size_t)b->B, 9 * sizeof(double) * (size_t)b->B);
+		fill_stage(b, b->h_stage_b, nullptr, 1, true);
+		HIP_TRY(hipMemcpyAsync(b->d_slab, b->h_stage_b, b->slab_bytes, hipMemcpyHostToDevice, st));
+		HIP_TRY(hipEventRecord(b->ev_b, st));   /* h_stage_b may be refilled once this upload has been consumed */
+	}
 	b->warps_dirty = false;   /* the slab carries the warps */
 	fa.active = b->d_active;
 	const bool ncc = b->desc.am == MTFHIP_AM_NCC;

@@ -189,6 +189,22 @@ __device__ __forceinline__ void block_allsum(double *v, double *lds /* [4][K] */
 	for (int k = 0; k < K; ++k) v[k] = (lds[k] + lds[K + k]) + (lds[2 * K + k] + lds[3 * K + k]);
 }
 
+/* the same with DPP wave sums (wave_sum_dpp): for loops whose critical path is this reduction */
+template <int K>
+__device__ __forceinline__ void block_allsum_dpp(double *v, double *lds /* [4][K] */) {
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+	for (int k = 0; k < K; ++k) v[k] = wave_sum_dpp(v[k]);
+	__syncthreads();   /* previous round's readers are done with lds */
+	if (lane == 0) {
+#pragma unroll
+		for (int k = 0; k < K; ++k) lds[wave * K + k] = v[k];
+	}
+	__syncthreads();
+#pragma unroll
+	for (int k = 0; k < K; ++k) v[k] = (lds[k] + lds[K + k]) + (lds[2 * K + k] + lds[3 * K + k]);
+}
+
 /* NN-SM dataset generation (SM/src/NT/NN.cc:131-191): per sample state, setState -> updatePixVals ->
  * updateDistFeat into row `c` of the n_samples x N feature matrix.  SSD's feature is the patch itself
  * (AM/include/mtf/AM/SSDBase.h:116-125); NCC's is the centred patch over its norm (AM/src/NCC.cc:530-537),
@@ -267,7 +283,7 @@ template <int AM, int PPT, bool FAST>
 __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im, mtfhip_sm_desc sm, TrackState ts,
 	const double *h0inv_all, const double *ncc_sc_all, double norm_mult, double norm_add) {
 	__shared__ double red[4 * 8];
-	__shared__ double sW[9], sSt[8], sHinv[64], sIc[12], sCr[8];
+	__shared__ double sW[9], sSt[8], sHinv[64], sH8[64], sIc[12], sCr[8];
 	__shared__ int sDone;
 	const int t = blockIdx.x, N = bv.N, S = bv.S, tid = threadIdx.x;
 	const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY;
@@ -301,6 +317,7 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 		}
 	}
 	if (tid < 64) sHinv[tid] = h0inv_all[(size_t)t * 64 + tid];
+	if (tid < 64) { const int r = tid >> 3, c = tid & 7; sH8[tid] = (r < S && c < S) ? h0inv_all[(size_t)t * 64 + c * S + r] : 0.0; }   /* [r][c], zero padded */
 	if (tid < 12) sIc[tid] = ts.init_corners_hm[12 * t + tid];
 	if (tid < 8) sCr[tid] = ts.corners[8 * t + tid];
 	if (tid < 9) sW[tid] = bv.warps[9 * t + tid];
@@ -309,6 +326,156 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 	__syncthreads();
 	int n_it = 0;
 	double f_last = 0;
+	if constexpr (FAST) {
+		/* Tolerance mode: ONE workgroup-wide reduction per iteration instead of four (NCC) / two (SSD), and no serial section.
+		 * NCC's similarity and df_dI0 . J0 are functions of raw moments -- sum It, sum It^2, sum I0 It, sum It J0 plus the
+		 * template's constants sum J0, sum I0 J0 (the fused NCC kernel's algebra, api_fused.hip::ncc_assemble) -- so the two-pass
+		 * mean / norm / gradient-mean chain of NCC.cc:124-194 collapses into one pass; SSD accumulates r^2 and r J0 together.
+		 * The S x S product with the pre-inverted Hessian, the inverse compositional update and the corner test are then
+		 * evaluated redundantly by every thread from the broadcast sums: no thread-0 section, no barrier behind it, the warp stays
+		 * in registers.  An iteration is two barriers instead of nine. */
+		constexpr bool NCC = AM == MTFHIP_AM_NCC;
+		constexpr int K = NCC ? 11 : 9;
+		__shared__ double redk[4 * 16];
+		double W[9], St[8], Cr[8];
+#pragma unroll
+		for (int q = 0; q < 9; ++q) W[q] = sW[q];
+#pragma unroll
+		for (int q = 0; q < 8; ++q) { St[q] = sSt[q]; Cr[q] = sCr[q]; }
+		double tc[16];   /* NCC: sum J0 | sum I0 J0 of this patch */
+#pragma unroll
+		for (int q = 0; q < 16; ++q) tc[q] = 0.0;
+		if constexpr (NCC) {
+#pragma unroll
+			for (int k = 0; k < PPT; ++k) {
+				const int i = tid + k * kBlock;
+				if (i < N) {
+#pragma unroll
+					for (int s = 0; s < 8; ++s) {
+						const double j = s < S ? (HOIST_J ? j0v[HOIST_J ? k : 0][s] : J0[(size_t)s * N + i]) : 0.0;
+						tc[s] += j; tc[8 + s] = fma(i0v[k], j, tc[8 + s]);
+					}
+				}
+			}
+			block_allsum<16>(tc, redk);
+		}
+		const double nN = (double)N, inv_n = 1.0 / nN, inv_cn = 1.0 / cn;
+		for (int it = 0; it < sm.max_iters; ++it) {
+			double m[K];
+#pragma unroll
+			for (int q = 0; q < K; ++q) m[q] = 0.0;
+#pragma unroll
+			for (int k = 0; k < PPT; ++k) {
+				const int i = tid + k * kBlock;
+				const int ick = i < N ? i : N - 1;
+				const double2 hp = HOIST_P ? hpv[HOIST_P ? k : 0] : (bv.unit_z ? ip[ick] : ih[ick]);
+				const double z = HOIST_P ? zv[HOIST_P ? k : 0] : (bv.unit_z ? 1.0 : iz[ick]);
+				double wx = fma(W[0], hp.x, fma(W[1], hp.y, W[2] * z)), wy = fma(W[3], hp.x, fma(W[4], hp.y, W[5] * z));
+				if (hom) { const double inv = rcp_fast(fma(W[6], hp.x, fma(W[7], hp.y, W[8] * z))); wx *= inv; wy *= inv; }
+#if defined(MTFHIP_GRID_ABL) && (MTFHIP_GRID_ABL & 1)   /* ablation builds (tools/grid_ablation.sh): no texel fetch */
+				const double v = i < N ? wx + wy : 0.0;
+#else
+				const double v = i < N ? fma(norm_mult, pix_val_fast(im, wx, wy), norm_add) : 0.0;
+#endif
+				const double i0 = i0v[k];
+				if constexpr (NCC) {
+					m[0] += v; m[1] = fma(v, v, m[1]); m[2] = fma(i0, v, m[2]);
+				} else {
+					const double r = i < N ? v - i0 : 0.0;
+					m[0] = fma(r, r, m[0]);
+				}
+				const double wgt = NCC ? v : (i < N ? v - i0 : 0.0);
+#pragma unroll
+				for (int s = 0; s < 8; ++s)
+					if (s < S) m[K - 8 + s] = fma(wgt, HOIST_J ? j0v[HOIST_J ? k : 0][s] : J0[(size_t)s * N + ick], m[K - 8 + s]);
+			}
+#if !(defined(MTFHIP_GRID_ABL) && (MTFHIP_GRID_ABL & 2))   /* ablation: no workgroup reduction */
+			block_allsum_dpp<K>(m, redk);
+#endif
+			double g[8];
+			if constexpr (NCC) {
+				/* (the whole section runs on one wave per SIMD with nothing to overlap: an IEEE division is ~30 dependent
+				 * instructions, so the ~40 of the straightforward form were 3 us of every 7 us iteration -- reciprocals once) */
+				const double mt = m[0] * inv_n, b2 = fma(-nN * mt, mt, m[1]), b = sqrt(b2);
+				const double inv_b = rcp_fast(b), inv_bc = inv_b * inv_cn, inv_b2 = inv_b * inv_b;
+				const double f = fma(-nN * m0, mt, m[2]) * inv_bc;
+				f_last = f;
+				const double b_c = b * inv_cn;
+#pragma unroll
+				for (int s = 0; s < 8; ++s) {
+					const double ut = fma(-mt, tc[s], m[3 + s]) * inv_b2, u0 = fma(-m0, tc[s], tc[8 + s]) * inv_bc;
+					g[s] = b_c * fma(-f, u0, ut);   /* df_dI0 . J0, NCC.cc:163-194, 236-250 in moments */
+				}
+			} else {
+				f_last = -m[0] / 2;
+#pragma unroll
+				for (int s = 0; s < 8; ++s) g[s] = m[1 + s];
+			}
+#if defined(MTFHIP_GRID_ABL) && (MTFHIP_GRID_ABL & 4)   /* ablation: no solve / update */
+			W[2] += g[0] * 1e-30; ++n_it; continue;
+#endif
+			/* dp = -H0^-1 g, invertState, compositionalUpdate, corner test (NT/ICLK.cc:253-290) -- every thread, same values.
+			 * This is a chain of dependent FP64 operations on a wave that has its SIMD to itself (~20 cycles per dependent
+			 * operation): it is written for DEPTH -- pairwise sums, reciprocals instead of divisions, the affine inverse in closed
+			 * form -- not for operation count (the straightforward form was 2.2 us of a 4.8 us iteration). */
+			double dp[8];
+#pragma unroll
+			for (int r = 0; r < 8; ++r) {
+				const double *h = sH8 + 8 * r;
+				dp[r] = -(((h[0] * g[0] + h[1] * g[1]) + (h[2] * g[2] + h[3] * g[3])) + ((h[4] * g[4] + h[5] * g[5]) + (h[6] * g[6] + h[7] * g[7])));
+			}
+			double Wn[9];
+			if (hom) {
+				const double U0 = 1 + dp[0], U1 = dp[1], U2 = dp[2], U3 = dp[3], U4 = 1 + dp[4], U5 = dp[5], U6 = dp[6], U7 = dp[7];
+				/* cofactors of U (U8 = 1); inverse / its (2, 2) entry: the determinant cancels */
+				const double c0 = U4 - U5 * U7, c1 = U2 * U7 - U1, c2 = U1 * U5 - U2 * U4;
+				const double c3 = U5 * U6 - U3, c4 = U0 - U2 * U6, c5 = U2 * U3 - U0 * U5;
+				const double c6 = U3 * U7 - U4 * U6, c7 = U1 * U6 - U0 * U7, c8 = U0 * U4 - U1 * U3;
+				const double ic8 = rcp_fast(c8);
+				const double V[9] = {c0 * ic8, c1 * ic8, c2 * ic8, c3 * ic8, c4 * ic8, c5 * ic8, c6 * ic8, c7 * ic8, 1.0};
+#pragma unroll
+				for (int r = 0; r < 3; ++r)
+#pragma unroll
+					for (int c = 0; c < 3; ++c) Wn[3 * r + c] = fma(W[3 * r], V[c], fma(W[3 * r + 1], V[3 + c], W[3 * r + 2] * V[6 + c]));
+				const double inv_w22 = rcp_fast(Wn[8]);
+#pragma unroll
+				for (int q = 0; q < 8; ++q) Wn[q] *= inv_w22;
+				Wn[8] = 1;
+				St[0] = Wn[0] - 1; St[1] = Wn[1]; St[2] = Wn[2]; St[3] = Wn[3]; St[4] = Wn[4] - 1; St[5] = Wn[5]; St[6] = Wn[6]; St[7] = Wn[7];
+			} else {
+				/* affine: U = [a b tx; c d ty; 0 0 1], inverse in closed form (Affine.cc:145-150) */
+				const double a = 1 + dp[2], b = dp[3], tx = dp[0], c = dp[4], d = 1 + dp[5], ty = dp[1];
+				const double idet = rcp_fast(a * d - b * c);
+				const double ia = d * idet, ib = -b * idet, ic = -c * idet, id = a * idet;
+				const double itx = -(ia * tx + ib * ty), ity = -(ic * tx + id * ty);
+				Wn[0] = W[0] * ia + W[1] * ic; Wn[1] = W[0] * ib + W[1] * id; Wn[2] = (W[0] * itx + W[1] * ity) + W[2];
+				Wn[3] = W[3] * ia + W[4] * ic; Wn[4] = W[3] * ib + W[4] * id; Wn[5] = (W[3] * itx + W[4] * ity) + W[5];
+				Wn[6] = 0; Wn[7] = 0; Wn[8] = 1;
+				St[0] = Wn[2]; St[1] = Wn[5]; St[2] = Wn[0] - 1; St[3] = Wn[1]; St[4] = Wn[3]; St[5] = Wn[4] - 1; St[6] = 0; St[7] = 0;
+			}
+			double ch[4];
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const double X = sIc[3 * q], Y = sIc[3 * q + 1], Z = sIc[3 * q + 2];
+				double nx = (Wn[0] * X + Wn[1] * Y) + Wn[2] * Z, ny = (Wn[3] * X + Wn[4] * Y) + Wn[5] * Z;
+				if (hom) { const double idn = rcp_fast((Wn[6] * X + Wn[7] * Y) + Wn[8] * Z); nx *= idn; ny *= idn; }
+				const double ddx = Cr[2 * q] - nx, ddy = Cr[2 * q + 1] - ny;
+				ch[q] = ddx * ddx + ddy * ddy;
+				Cr[2 * q] = nx; Cr[2 * q + 1] = ny;
+			}
+			const double change = (ch[0] + ch[1]) + (ch[2] + ch[3]);
+#pragma unroll
+			for (int q = 0; q < 9; ++q) W[q] = Wn[q];
+			++n_it;
+			if (change < sm.epsilon) break;   /* uniform: every thread holds the same numbers */
+		}
+		if (tid == 0) {
+			for (int q = 0; q < 9; ++q) bv.warps[9 * t + q] = W[q];
+			for (int q = 0; q < 8; ++q) { bv.states[8 * t + q] = St[q]; ts.corners[8 * t + q] = Cr[q]; }
+			ts.n_iters[t] = n_it; ts.acc[(size_t)t * ACC_COUNT + ACC_RR] = f_last;
+		}
+		return;
+	}
 	for (int it = 0; it < sm.max_iters; ++it) {
 		double W[9];
 #pragma unroll

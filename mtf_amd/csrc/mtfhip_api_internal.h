@@ -496,6 +496,7 @@ static inline mtfhip::MiJ0Rebuild mi_j0_rebuild(const mtfhip_batch *b) {
 /* ---- functions defined in one api_*.hip unit and used in another ---- */
 enum { LAZY_CURR_JAC = 0, LAZY_DIFF_JAC = 1, LAZY_INIT_JAC = 2 };
 int ensure_pts(mtfhip_batch *b);
+int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track);   /* api_core.hip */
 int do_update_grad_pts(mtfhip_batch *b, double grad_eps);
 int gemv_to_host(mtfhip_batch *b, const double *v1, int j1, const double *v2, int j2, int sum_mode, double *g, int diff);
 int ncc_template_moments(mtfhip_batch *b);

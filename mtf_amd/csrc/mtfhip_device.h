@@ -216,6 +216,30 @@ __device__ __forceinline__ constexpr int dup_mask() {
 	else return MASK | dup_mask<K, (MASK >> 1)>();
 }
 
+/* Wave total of a double with DPP moves instead of ds_bpermute: the four in-row steps (xor 1, xor 2, half-row mirror, row mirror)
+ * and the two row broadcasts stay in the VALU (a DPP move is ~8 cycles; a ds_bpermute round trip through the LDS crossbar
+ * ~120), which matters where a loop of dependent reductions is the critical path (the one-launch grid kernel: one wave per SIMD,
+ * nothing to overlap).  The result is uniform (read from lane 63). */
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+	auto step = [](double x, int ctrl, int row_mask) {
+		const int lo = __double2loint(x), hi = __double2hiint(x);
+		int tl, th;
+		switch (ctrl) {   /* the control word must be an immediate */
+		case 0: tl = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false); th = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false); break;     /* quad_perm [1,0,3,2] */
+		case 1: tl = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, false); th = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, false); break;     /* quad_perm [2,3,0,1] */
+		case 2: tl = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, false); th = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, false); break;   /* row_half_mirror */
+		case 3: tl = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, false); th = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, false); break;   /* row_mirror */
+		case 4: tl = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false); th = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false); break;   /* row_bcast:15 -> rows 1, 3 */
+		default: tl = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, false); th = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, false); break;  /* row_bcast:31 -> rows 2, 3 */
+		}
+		(void)row_mask;
+		return x + __hiloint2double(th, tl);
+	};
+	v = step(v, 0, 0xF); v = step(v, 1, 0xF); v = step(v, 2, 0xF); v = step(v, 3, 0xF); v = step(v, 4, 0xA); v = step(v, 5, 0xC);
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+	return __hiloint2double(hi, lo);
+}
+
 /* reduce K per-thread accumulators over the workgroup and write them to dst[0..K) */
 template <int K>
 __device__ __forceinline__ void block_reduce_store(double *v, double *dst, double *lds /* [4][K] */) {

@@ -50,6 +50,15 @@ class LKTracker:
     def get_region(self):
         return self.batch.get_corners()
 
+    def update_region(self, corners):
+        """set_region(corners) followed by update(): the pair GridTracker and PyramidalTracker issue per frame, as one
+        C-ABI call on the device-loop path (mtfhip_batch_track_region)"""
+        if self.host_solve:
+            self.set_region(corners)
+            return self.update()
+        self.n_iters, out = self.batch.track_region(np.asarray(corners, dtype=np.float64).reshape(self.B, 2, 4), self.sm)
+        return out
+
     def update(self):
         if not self.host_solve:
             self.n_iters, corners = self.batch.track(self.sm)
@@ -337,8 +346,14 @@ class GridTracker:
     def initialize(self, region_corners):
         self.tracker.initialize(self.patch_corners(region_corners))
 
-    def update(self):
-        corners = self.tracker.update()
+    def update(self, region_corners=None):
+        """GridTracker::update's patch half (GridTracker.cc:345-363).  With region_corners the patch trackers are first reset to
+        the grid laid over that region (the reference's reset_at_each_frame behaviour), in the same C-ABI call."""
+        if region_corners is None:
+            corners = self.tracker.update()
+        else:
+            pc = region_corners if np.ndim(region_corners) == 3 else self.patch_corners(region_corners)
+            corners = self.tracker.update_region(pc)
         return corners, corners.mean(axis=2)   # utils::getCentroid miscUtils.h:473-480
 
     @property

@@ -264,6 +264,32 @@ def test_grid_patch_trackers_one_launch(oracle, gpu_ctx, frame, am, ssm):
     assert np.abs(centroids - gt_c).max() < 0.25
 
 
+@pytest.mark.parametrize("sm_kind,am", [(L.SM_ICLK, L.AM_NCC), (L.SM_ICLK, L.AM_SSD), (L.SM_FCLK, L.AM_SSD), (L.SM_ESM, L.AM_NCC)])
+def test_track_region_equals_set_region_then_track(gpu_ctx, frame, sm_kind, am):
+    """mtfhip_batch_track_region (one staged upload per frame) against the two calls it replaces, frame after frame:
+    the same bits -- for the search methods that keep their template Jacobian (folded upload) and for ESM (which refreshes it)."""
+    rng = np.random.default_rng(43)
+    centre = (256.0, 256.0)
+    region = synth.square_corners(centre[0], centre[1], 280)
+    gpu_ctx.set_image(frame)
+    a = GridTracker(gpu_ctx, grid_size=4, patch_size=25, am=am, ssm=L.SSM_AFFINE, max_iters=12, epsilon=1e-4)
+    b = GridTracker(gpu_ctx, grid_size=4, patch_size=25, am=am, ssm=L.SSM_AFFINE, max_iters=12, epsilon=1e-4)
+    for g in (a, b):
+        g.tracker.sm.sm = sm_kind
+        g.initialize(region)
+    patches = a.patch_corners(region)
+    for k in range(3):
+        frame2 = synth.warp_frame(frame, synth.random_small_homography(rng, 0.2), centre)
+        gpu_ctx.set_image(frame2)
+        a.tracker.set_region(patches)
+        ca, _ = a.update()
+        cb, _ = b.update(region if k % 2 == 0 else patches)
+        assert np.array_equal(ca, cb)
+        assert np.array_equal(a.n_iters, b.n_iters)
+        assert np.array_equal(a.tracker.get_region(), b.tracker.get_region())
+        assert np.array_equal(a.tracker.batch.get_state(), b.tracker.batch.get_state())
+
+
 def test_nn_dataset_generation(gpu_ctx, frame):
     """nt::NN::generateDataset mirror: the zero perturbation reproduces the template, every row is the feature
     of its own inverse-perturbed warp, and the exhaustive search finds a stored sample at distance 0."""
