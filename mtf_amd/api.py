@@ -444,11 +444,14 @@ class Batch:
 
     def track_region(self, corners, sm):
         """setRegion(corners) + update() of one frame in one C-ABI call (mtfhip_batch_track_region)"""
-        r = self._corners_in(corners)
-        n = np.empty(self.B, dtype=np.int32)
-        c = np.empty((self.B, 8))
-        L.check(L.lib().mtfhip_batch_track_region(self._h, C.byref(sm), _p(r), _p(n), _p(c)))
-        return n, self._corners_out(c)
+        tr = getattr(self, "_tr", None)
+        if tr is None:     # per-frame call: the argument buffers and their ctypes pointers are built once
+            r, n, c = np.empty((self.B, 4, 2)), np.empty(self.B, dtype=np.int32), np.empty((self.B, 4, 2))
+            tr = self._tr = (r, n, c, _p(r), _p(n), _p(c), L.lib().mtfhip_batch_track_region)
+        r, n, c, pr, pn, pc, fn = tr
+        r[...] = np.asarray(corners, dtype=np.float64).reshape(self.B, 2, 4).transpose(0, 2, 1)
+        L.check(fn(self._h, C.byref(sm), pr, pn, pc))
+        return n.copy(), c.transpose(0, 2, 1).copy()
 
     # ---------------------------------------------------------- candidate scoring
     def score_candidates(self, states, want_similarity=False):

@@ -334,6 +334,11 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 			if (hipHostMalloc(&b->h_pub, b->slab_bytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
 				hipHostGetDevicePointer(&pp, b->h_pub, 0) == hipSuccess) b->h_pub_dev = static_cast<char *>(pp);
 			else (void)hipGetLastError();
+			void *sp = nullptr;
+			if (hipHostGetDevicePointer(&sp, b->h_stage_a, 0) == hipSuccess) b->h_stage_a_dev = static_cast<char *>(sp);
+			else (void)hipGetLastError();
+			if (hipHostGetDevicePointer(&sp, b->h_stage_b, 0) == hipSuccess) b->h_stage_b_dev = static_cast<char *>(sp);
+			else (void)hipGetLastError();
 		} else (void)hipGetLastError();
 	}
 	(void)hipMemsetAsync(b->d_partials, 0, sizeof(double) * kAccRowMax * b->nblk_max * n_targets, c->stream);
@@ -472,15 +477,24 @@ int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track) {
 	b->unit_z = hom ? unit_z : 1;
 	/* w0, init_corners_hm, identity warps, zero states and the corners in ONE pinned async copy; the staging buffer is
 	 * protected by an event instead of a stream sync */
-	HIP_TRY(hipEventSynchronize(b->ev_a));
+	if (b->stage_a_busy) HIP_TRY(hipEventSynchronize(b->ev_a));
 	fill_stage(b, b->h_stage_a, w0.data(), for_track ? 1 : 0, for_track);
-	HIP_TRY(hipMemcpyAsync(b->d_slab, b->h_stage_a, for_track ? b->slab_bytes : b->slab_dbl_bytes, hipMemcpyHostToDevice, b->ctx->stream));
+	const size_t up_bytes = for_track ? b->slab_bytes : b->slab_dbl_bytes;
+	bool grid_done = false;
+	if (b->h_stage_a_dev) {
+		/* the kernel that lays out the grid reads the slab from the pinned staging buffer itself: no copy-engine transfer, no
+		 * second launch (w0 is taken from the host copy, 45 B doubles into the slab) */
+		TimedScope ts(b->ctx, "init_grid");
+		grid_done = launch_init_grid_ingest(b->view(), reinterpret_cast<const double *>(b->h_stage_a_dev) + 45 * (size_t)b->B, b->desc.resx, b->desc.resy,
+			lo_x, lo_y, hi_x, hi_y, hom ? 0 : 1, b->h_stage_a_dev, b->d_slab, up_bytes, b->ctx->stream);
+		if (!grid_done) launch_ingest_host(b->h_stage_a_dev, b->d_slab, up_bytes, b->ctx->stream);
+	} else HIP_TRY(hipMemcpyAsync(b->d_slab, b->h_stage_a, up_bytes, hipMemcpyHostToDevice, b->ctx->stream));
 	b->warps_dirty = false;   /* the slab carries the (identity) warps */
-	HIP_TRY(hipEventRecord(b->ev_a, b->ctx->stream));
-	{
+	if (!grid_done) {
 		TimedScope ts(b->ctx, "init_grid");
 		launch_init_grid(b->view(), b->d_w0, b->desc.resx, b->desc.resy, lo_x, lo_y, hi_x, hi_y, hom ? 0 : 1, b->ctx->stream);
 	}
+	if (!for_track) { HIP_TRY(hipEventRecord(b->ev_a, b->ctx->stream)); b->stage_a_busy = true; }   /* (for_track: the caller waits for the loop that follows) */
 	b->have_corners = true;
 	b->pts_stale = false;   /* k_init_grid writes the current points too */
 	++b->corners_epoch;

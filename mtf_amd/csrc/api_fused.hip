@@ -364,7 +364,7 @@ int mtfhip_batch_set_region(mtfhip_batch *b, const double *corners, const mtfhip
 static bool region_refreshes(const mtfhip_sm_desc *sm) { return sm->sm == MTFHIP_SM_ESM || (sm->sm == MTFHIP_SM_FCLK && sm->hess_type == 0); }
 
 static int set_region_core(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm, bool for_track) {
-	FLUSH(b);
+	FLUSH_AM(b);   /* (the current points are about to be replaced: only pending calls need them brought up to date) */
 	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
 	TRY(check_sm(b, sm, "set_region"));
 	TRY(single_channel(b, "set_region"));
@@ -730,7 +730,7 @@ int mtfhip_batch_track_region(mtfhip_batch *b, const mtfhip_sm_desc *sm, const d
 }
 
 static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners, bool slab_uploaded) {
-	FLUSH(b);
+	FLUSH_AM(b);   /* (none of the loop's kernels reads CURR_PTS: they warp the template grid themselves) */
 	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
 	TRY(check_sm(b, sm, "track"));
 	TRY(single_channel(b, "track"));
@@ -750,11 +750,11 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 	/* active = 1, iters = 0, corners, warps, states, NCC scalars: one pinned async copy of the whole slab
 	 * (w0 is copied along; init_grid consumed it long ago) */
 	if (!slab_uploaded) {
-		HIP_TRY(hipEventSynchronize(b->ev_b));
+		/* (h_stage_b needs no guard: every return path below has waited for the device to finish this call's work) */
 		std::memcpy(b->h_stage_b + 45 * sizeof(double) * (size_t)b->B, b->h_stage_a + 45 * sizeof(double) * (size_t)b->B, 9 * sizeof(double) * (size_t)b->B);
 		fill_stage(b, b->h_stage_b, nullptr, 1, true);
-		HIP_TRY(hipMemcpyAsync(b->d_slab, b->h_stage_b, b->slab_bytes, hipMemcpyHostToDevice, st));
-		HIP_TRY(hipEventRecord(b->ev_b, st));   /* h_stage_b may be refilled once this upload has been consumed */
+		if (b->h_stage_b_dev) launch_ingest_host(b->h_stage_b_dev, b->d_slab, b->slab_bytes, st);
+		else HIP_TRY(hipMemcpyAsync(b->d_slab, b->h_stage_b, b->slab_bytes, hipMemcpyHostToDevice, st));
 	}
 	b->warps_dirty = false;   /* the slab carries the warps */
 	fa.active = b->d_active;
@@ -788,6 +788,7 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 	 * and two rejections never follow each other (the pass after an undo skips the test) */
 	const int max_passes = (sm->leven_marq && sm->sm == MTFHIP_SM_FCLK) ? 2 * sm->max_iters : sm->max_iters;
 	BatchView bv = b->view();
+	unsigned long long pub_seq = 0;   /* non-zero: the loop's own kernel delivers the results to the host */
 	if (b->desc.am == MTFHIP_AM_MI) {
 		/* the fused MI passes leave g and H on the device; k_finish_track_mi lays them out as one reduced row per target and
 		 * runs the same finish (solve, compositional update, convergence test): no host round trip per iteration */
@@ -807,7 +808,12 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 		}
 	} else if (one_launch) {
 		TimedScope tsc(b->ctx, "iclk_track");
-		launch_iclk_track(bv, b->ctx->img, *sm, ts, b->d_h0inv, b->d_ncc, b->norm_mult, b->norm_add, b->math_mode == MTFHIP_MATH_FAST, st);
+		HostPublish pub{nullptr, 0, 0, nullptr, nullptr, 0};
+		if (b->h_pub_dev) {
+			pub_seq = ++b->acc_seq;
+			pub = HostPublish{b->h_pub_dev, b->slab_dbl_bytes, b->B, b->d_fin_count, b->h_flag_dev, pub_seq};
+		}
+		launch_iclk_track(bv, b->ctx->img, *sm, ts, b->d_h0inv, b->d_ncc, b->norm_mult, b->norm_add, b->math_mode == MTFHIP_MATH_FAST, pub, st);
 	} else {
 		/* Targets are independent, so the loops commute: all iterations of a chunk of targets run before the next chunk
 		 * starts.  A chunk is sized so that what an iteration reads once (J0, I0, grid: 88 B/px for ESM) stays resident in
@@ -841,14 +847,16 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 	/* the slab (warps, states, corners, iteration counts) comes back either through a kernel that writes it into host-coherent
 	 * memory and raises a flag the host spins on, or as one copy + one sync (MTFHIP_ZERO_COPY=0) */
 	const char *h_res = b->h_stage_b;
-	if (b->h_pub_dev) {
+	if (pub_seq) {
+		TRY(wait_host_flag(b, pub_seq));
+		h_res = b->h_pub;
+	} else if (b->h_pub_dev) {
 		const unsigned long long seq = ++b->acc_seq;
 		launch_publish_host(b->d_slab, b->h_pub_dev, b->slab_bytes, b->d_fin_count, b->h_flag_dev, seq, st);
 		TRY(wait_host_flag(b, seq));
 		h_res = b->h_pub;
 	} else {
 		HIP_TRY(hipMemcpyAsync(b->h_stage_b, b->d_slab, b->slab_bytes, hipMemcpyDeviceToHost, st));
-		HIP_TRY(hipEventRecord(b->ev_b, st));
 		HIP_TRY(hipStreamSynchronize(st));
 	}
 	{
@@ -869,6 +877,7 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 		b->dit_valid = b->jt_valid = fa.materialize && fa.mode != 2;
 	}
 	b->pts_stale = true;   /* CURR_PTS follow the final warp when an un-fused kernel next needs them */
+	b->stage_a_busy = false;   /* the stream has drained: whatever set_corners staged has been consumed */
 	return MTFHIP_OK;
 }
 

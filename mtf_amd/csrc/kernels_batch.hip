@@ -279,9 +279,36 @@ __device__ __forceinline__ double pix_val_select(const ImgView &im, double x, do
 	return (in0 && in1) ? v : 128.0;
 }
 
+/* the tail of k_iclk_track: target t's final warp / state / corners / iteration count go to the host mirror of the slab, and the
+ * last workgroup of the launch releases the host (one kernel launch and its gap less per frame than k_publish_host).
+ * Called by wave 0 only, lane q holding entry q: the stores are system-scope (write-through to the pinned page), ONE agent-scope
+ * release per workgroup orders them before the counter -- a system-scope fence in every wave of every workgroup walks the L2
+ * for dirty lines 1024 times and cost 25 us of a 47 us launch -- and only the last arriver pays the system-scope release
+ * (cumulative over the counter it acquired) before it raises the flag. */
+__device__ __forceinline__ void publish_target(const HostPublish &pub, int t, double wq, double sq, double cq, int n_it) {
+	const int lane = threadIdx.x;
+	double *p = reinterpret_cast<double *>(pub.host);
+	const size_t Bt = (size_t)pub.B;
+	if (lane < 9) __hip_atomic_store(p + 9 * (size_t)t + lane, wq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	if (lane < 8) {
+		__hip_atomic_store(p + 9 * Bt + 8 * (size_t)t + lane, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		__hip_atomic_store(p + 17 * Bt + 8 * (size_t)t + lane, cq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+	if (lane == 0) __hip_atomic_store(reinterpret_cast<int *>(pub.host + pub.dbl_bytes) + Bt + t, n_it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   /* (the whole wave's stores: s_waitcnt vmcnt(0) is per wave) */
+	if (lane == 0) {
+		const int done = __hip_atomic_fetch_add(pub.count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+		if (done == (int)gridDim.x - 1) {
+			__hip_atomic_store(pub.count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__threadfence_system();
+			__hip_atomic_store(pub.flag, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+	}
+}
+
 template <int AM, int PPT, bool FAST>
 __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im, mtfhip_sm_desc sm, TrackState ts,
-	const double *h0inv_all, const double *ncc_sc_all, double norm_mult, double norm_add) {
+	const double *h0inv_all, const double *ncc_sc_all, double norm_mult, double norm_add, HostPublish pub) {
 	__shared__ double red[4 * 8];
 	__shared__ double sW[9], sSt[8], sHinv[64], sH8[64], sIc[12], sCr[8];
 	__shared__ int sDone;
@@ -469,10 +496,20 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 			++n_it;
 			if (change < sm.epsilon) break;   /* uniform: every thread holds the same numbers */
 		}
-		if (tid == 0) {
-			for (int q = 0; q < 9; ++q) bv.warps[9 * t + q] = W[q];
-			for (int q = 0; q < 8; ++q) { bv.states[8 * t + q] = St[q]; ts.corners[8 * t + q] = Cr[q]; }
-			ts.n_iters[t] = n_it; ts.acc[(size_t)t * ACC_COUNT + ACC_RR] = f_last;
+		/* (every thread holds the same W / St / Cr: the first lanes store one entry each) */
+#pragma unroll
+		for (int q = 0; q < 9; ++q) if (tid == q) bv.warps[9 * t + q] = W[q];
+#pragma unroll
+		for (int q = 0; q < 8; ++q) if (tid == q) { bv.states[8 * t + q] = St[q]; ts.corners[8 * t + q] = Cr[q]; }
+		if (tid == 0) { ts.n_iters[t] = n_it; ts.acc[(size_t)t * ACC_COUNT + ACC_RR] = f_last; }
+		if (pub.host && tid < 64) {
+			/* lane q holds entry q after the selects below (register arrays cannot be indexed by the lane id) */
+			double wq = 0, sq = 0, cq = 0;
+#pragma unroll
+			for (int q = 0; q < 9; ++q) if (tid == q) wq = W[q];
+#pragma unroll
+			for (int q = 0; q < 8; ++q) if (tid == q) { sq = St[q]; cq = Cr[q]; }
+			publish_target(pub, t, wq, sq, cq, n_it);
 		}
 		return;
 	}
@@ -610,6 +647,7 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 	if (tid < 8) bv.states[8 * t + tid] = sSt[tid];
 	if (tid < 8) ts.corners[8 * t + tid] = sCr[tid];
 	if (tid == 0) { ts.n_iters[t] = n_it; ts.acc[(size_t)t * ACC_COUNT + ACC_RR] = f_last; }
+	if (pub.host && tid < 64) publish_target(pub, t, tid < 9 ? sW[tid] : 0.0, tid < 8 ? sSt[tid] : 0.0, tid < 8 ? sCr[tid] : 0.0, n_it);
 }
 
 
@@ -637,9 +675,9 @@ void launch_score_candidates(const BatchView &bv, const ImgView &im, const doubl
 
 template <int AM, bool FAST>
 static bool launch_iclk_track_am(const BatchView &bv, const ImgView &im, const mtfhip_sm_desc &sm, const TrackState &ts,
-	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, hipStream_t st) {
+	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, const HostPublish &pub, hipStream_t st) {
 	const int ppt = (bv.N + kBlock - 1) / kBlock;
-#define MTFHIP_ICLK_CASE(P) MTFHIP_LAUNCH((k_iclk_track<AM, P, FAST>), dim3(bv.B), dim3(kBlock), 0, st, bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add)
+#define MTFHIP_ICLK_CASE(P) MTFHIP_LAUNCH((k_iclk_track<AM, P, FAST>), dim3(bv.B), dim3(kBlock), 0, st, bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, pub)
 	if (ppt <= 1) MTFHIP_ICLK_CASE(1);
 	else if (ppt <= 2) MTFHIP_ICLK_CASE(2);
 	else if (ppt <= 3) MTFHIP_ICLK_CASE(3);
@@ -651,13 +689,13 @@ static bool launch_iclk_track_am(const BatchView &bv, const ImgView &im, const m
 	return true;
 }
 bool launch_iclk_track(const BatchView &bv, const ImgView &im, const mtfhip_sm_desc &sm, const TrackState &ts,
-	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, int fast_math, hipStream_t st) {
+	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, int fast_math, const HostPublish &pub, hipStream_t st) {
 	if (fast_math) {
-		if (bv.am == MTFHIP_AM_NCC) return launch_iclk_track_am<MTFHIP_AM_NCC, true>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, st);
-		return launch_iclk_track_am<MTFHIP_AM_SSD, true>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, st);
+		if (bv.am == MTFHIP_AM_NCC) return launch_iclk_track_am<MTFHIP_AM_NCC, true>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, pub, st);
+		return launch_iclk_track_am<MTFHIP_AM_SSD, true>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, pub, st);
 	}
-	if (bv.am == MTFHIP_AM_NCC) return launch_iclk_track_am<MTFHIP_AM_NCC, false>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, st);
-	return launch_iclk_track_am<MTFHIP_AM_SSD, false>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, st);
+	if (bv.am == MTFHIP_AM_NCC) return launch_iclk_track_am<MTFHIP_AM_NCC, false>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, pub, st);
+	return launch_iclk_track_am<MTFHIP_AM_SSD, false>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, pub, st);
 }
 void launch_sample_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C, double norm_mult,
 	double norm_add, double *dev_feat, hipStream_t st) {

@@ -19,9 +19,17 @@ __device__ __forceinline__ double lin_spaced(int i, int n, double lo, double hi)
 	if (n == 1 || i == n - 1) return hi;
 	return lo + i * ((hi - lo) / (n - 1));
 }
+/* (ing: the staged state slab, read from pinned host memory by the first workgroups of the same launch -- w0_all then points into
+ * the host copy too, so nothing in this kernel depends on the ingest having landed) */
+struct SlabIngest { const uint4 *src; uint4 *dst; unsigned n16; const unsigned *src_tail; unsigned *dst_tail; unsigned n_tail; };
 __global__ __launch_bounds__(kBlock) void k_init_grid(BatchView bv, const double *w0_all, int resx, int resy,
-	double lo_x, double lo_y, double hi_x, double hi_y, int force_unit_z) {
+	double lo_x, double lo_y, double hi_x, double hi_y, int force_unit_z, SlabIngest ing) {
 	const int t = blockIdx.y;
+	if (ing.src) {
+		const unsigned i = (blockIdx.y * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+		if (i < ing.n16) ing.dst[i] = ing.src[i];
+		if (i < ing.n_tail) ing.dst_tail[i] = ing.src_tail[i];
+	}
 	const Warp9 W = load_warp(w0_all + 9 * t);
 	double2 *ip = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * bv.NP;
 	double2 *cp = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_CURR_PTS]) + (size_t)t * bv.NP;
@@ -535,6 +543,13 @@ __global__ __launch_bounds__(256) void k_publish_host(const unsigned *src, unsig
 		}
 	}
 }
+/* the other direction: the staged state slab is read from pinned host memory by the kernel itself (16 bytes per lane, one PCIe
+ * round trip) instead of through a copy-engine transfer and the cross-queue dependency that follows it */
+__global__ __launch_bounds__(256) void k_ingest_host(const uint4 *src_host, uint4 *dst, unsigned n16, const unsigned *src_tail, unsigned *dst_tail, unsigned n_tail) {
+	const unsigned i = blockIdx.x * 256 + threadIdx.x;
+	if (i < n16) dst[i] = src_host[i];
+	if (i < n_tail) dst_tail[i] = src_tail[i];
+}
 /* fixed-order sum of the per-workgroup rows: out[t][k] = sum_b partials[t][b][k] */
 __global__ __launch_bounds__(64) void k_finish(const double *partials, int nblk, double *out) {
 	const int t = blockIdx.x, k = threadIdx.x;
@@ -557,7 +572,19 @@ __global__ __launch_bounds__(64) void k_finish(const double *partials, int nblk,
 void launch_init_grid(const BatchView &bv, const double *dev_w0, int resx, int resy, double lo_x, double lo_y,
 	double hi_x, double hi_y, int force_unit_z, hipStream_t st) {
 	MTFHIP_LAUNCH(k_init_grid, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv, dev_w0, resx, resy,
-		lo_x, lo_y, hi_x, hi_y, force_unit_z);
+		lo_x, lo_y, hi_x, hi_y, force_unit_z, SlabIngest{nullptr, nullptr, 0, nullptr, nullptr, 0});
+}
+/* the same with the slab ingest folded in; false: the launch is too small to carry it (the caller ingests separately) */
+bool launch_init_grid_ingest(const BatchView &bv, const double *host_w0_dev, int resx, int resy, double lo_x, double lo_y,
+	double hi_x, double hi_y, int force_unit_z, const void *src_host, void *dst, size_t bytes, hipStream_t st) {
+	const unsigned n16 = (unsigned)(bytes / 16), n_tail = (unsigned)((bytes % 16) / 4);
+	const dim3 g = grid2(simple_blocks_per_target(bv.N), bv.B);
+	if ((size_t)g.x * g.y * kBlock < std::max(n16, n_tail)) return false;
+	const SlabIngest ing{static_cast<const uint4 *>(src_host), static_cast<uint4 *>(dst), n16,
+		reinterpret_cast<const unsigned *>(static_cast<const char *>(src_host) + 16 * (size_t)n16),
+		reinterpret_cast<unsigned *>(static_cast<char *>(dst) + 16 * (size_t)n16), n_tail};
+	MTFHIP_LAUNCH(k_init_grid, g, dim3(kBlock), 0, st, bv, host_w0_dev, resx, resy, lo_x, lo_y, hi_x, hi_y, force_unit_z, ing);
+	return true;
 }
 void launch_apply_warp(const BatchView &bv, hipStream_t st) {
 	MTFHIP_LAUNCH(k_apply_warp, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv);
@@ -644,6 +671,13 @@ void launch_publish_host(const void *src, void *dst_host, size_t bytes, int *cou
 	const unsigned blocks = std::max(1u, std::min(64u, (n_words + 1023) / 1024));
 	MTFHIP_LAUNCH(k_publish_host, dim3(blocks), dim3(256), 0, st, static_cast<const unsigned *>(src), static_cast<unsigned *>(dst_host),
 		n_words, count, flag_host, seq);
+}
+void launch_ingest_host(const void *src_host, void *dst, size_t bytes, hipStream_t st) {
+	const unsigned n16 = (unsigned)(bytes / 16), n_tail = (unsigned)((bytes % 16) / 4);   /* (the slab is a multiple of 4 bytes) */
+	const unsigned blocks = std::max(1u, (std::max(n16, n_tail) + 255) / 256);
+	MTFHIP_LAUNCH(k_ingest_host, dim3(blocks), dim3(256), 0, st, static_cast<const uint4 *>(src_host), static_cast<uint4 *>(dst), n16,
+		reinterpret_cast<const unsigned *>(static_cast<const char *>(src_host) + 16 * (size_t)n16),
+		reinterpret_cast<unsigned *>(static_cast<char *>(dst) + 16 * (size_t)n16), n_tail);
 }
 void launch_finish_rows(double *partials, int nblk, int row_len, double *out, int B, hipStream_t st) {
 	MTFHIP_LAUNCH(k_finish_rows, dim3(B, (row_len + 127) / 128), dim3(128), 0, st, partials, nblk, row_len, out);

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -128,7 +129,8 @@ static bool rect_to_quad(double lo_x, double lo_y, double hi_x, double hi_y, con
 		m[3 * r + 2] = rows[r][2] - rows[r][0] * lo_x / wx - rows[r][1] * lo_y / wy;
 	}
 	if (m[8] == 0 || !std::isfinite(m[8])) return false;
-	for (int i = 0; i < 9; ++i) H.m[i] = m[i] / m[8];
+	if (m[8] == 1.0) for (int i = 0; i < 9; ++i) H.m[i] = m[i];   /* (x / 1.0 == x: a parallelogram's nine divisions are skipped) */
+	else for (int i = 0; i < 9; ++i) H.m[i] = m[i] / m[8];
 	H.m[8] = 1;
 	return true;
 }
@@ -238,6 +240,7 @@ struct mtfhip_batch {
 	 * copy (a grid frame used to cost 14 small copies and 4 stream syncs around a 100 us kernel). */
 	char *d_slab = nullptr, *h_stage_a = nullptr, *h_stage_b = nullptr;
 	hipEvent_t ev_a = nullptr, ev_b = nullptr;
+	bool stage_a_busy = false;   /* ev_a guards an upload from h_stage_a that may still be in flight */
 	/* warp + state of every target after setState / compositionalUpdate: one copy from a pinned double buffer, no sync */
 	double *h_wstage[2] = {nullptr, nullptr};
 	hipEvent_t ev_w[2] = {nullptr, nullptr};
@@ -257,6 +260,7 @@ struct mtfhip_batch {
 	 * paying a copy command plus a stream synchronisation per iteration (MTFHIP_ZERO_COPY=0: copy + sync) */
 	double *h_acc_dev = nullptr;
 	unsigned long long *h_flag = nullptr, *h_flag_dev = nullptr, acc_seq = 0;
+	char *h_stage_a_dev = nullptr, *h_stage_b_dev = nullptr;   /* device addresses of the staging buffers when kernels may read them (k_ingest_host), else NULL */
 	char *h_pub = nullptr, *h_pub_dev = nullptr;   /* host-coherent mirror of the state slab, written by k_publish_host (track's read-back) */
 	int *d_fin_count = nullptr;
 	int nblk_max;
@@ -402,16 +406,22 @@ static inline void cpu_relax() {
 	__asm__ __volatile__("yield");
 #endif
 }
-/* spin until the kernel that was given `seq` has stored it behind its host-coherent writes.  The kernel normally reports within a
- * few microseconds of the launch that precedes this call; when the stream is busy with earlier work the spin gives way to a
- * blocking stream synchronisation after ~100 us instead of burning a core. */
+/* wait until the kernel that was given `seq` has stored it behind its host-coherent writes.  The kernel normally reports within a
+ * few microseconds of the launch that precedes this call, so the wait starts as a spin; when the stream is busy with longer
+ * work (a whole device-side loop: tens to hundreds of microseconds) the spin gives the core away between polls after 200 us,
+ * and after 50 ms the runtime's blocking synchronisation takes over (it costs ~100 us of its own, hence not earlier). */
 static int wait_host_flag(mtfhip_batch *b, unsigned long long seq) {
 	TRY(launch_error_pending());
 	const auto t0 = std::chrono::steady_clock::now();
+	bool yielding = false;
 	for (unsigned spins = 0;; ++spins) {
 		if (__atomic_load_n(b->h_flag, __ATOMIC_ACQUIRE) == seq) return MTFHIP_OK;
-		cpu_relax();
-		if ((spins & 0x3ff) == 0x3ff && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100)) break;
+		if (yielding) std::this_thread::yield(); else cpu_relax();
+		if ((spins & 0x3ff) == 0x3ff || yielding) {
+			const auto dt = std::chrono::steady_clock::now() - t0;
+			if (dt > std::chrono::milliseconds(50)) break;
+			if (dt > std::chrono::microseconds(200)) yielding = true;
+		}
 	}
 	/* the kernel did not report in: let the runtime tell why */
 	HIP_TRY(hipStreamSynchronize(b->ctx->stream));

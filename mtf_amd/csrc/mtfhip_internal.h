@@ -107,6 +107,17 @@ struct TrackState {
 };
 constexpr int kLmStride = 12;
 
+/* results of the one-launch loop delivered straight into the host-coherent mirror of the state slab (warps | states | corners |
+ * ... | iteration counts) by the workgroup that produced them; the last workgroup to finish raises the flag the host spins on.
+ * host == NULL: nothing is published (k_publish_host does it in a launch of its own). */
+struct HostPublish {
+	char *host;
+	size_t dbl_bytes;   /* offset of the int part of the slab */
+	int B;
+	int *count;
+	unsigned long long *flag, seq;
+};
+
 struct FusedArgs {
 	int mode;          /* accumulation mode: 0 FCLK-type, 1 ESM-type, 2 ICLK-lite (see k_fused_ssd) */
 	int chained;
@@ -252,7 +263,10 @@ void launch_sample_candidates(const BatchView &bv, const ImgView &im, const doub
 /* whole ICLK loop in one launch, one workgroup per target (N <= 16 * kBlock); false if N is too large */
 constexpr int kIclkTrackMaxPix = 16 * kBlock;
 bool launch_iclk_track(const BatchView &bv, const ImgView &im, const mtfhip_sm_desc &sm, const TrackState &ts,
-	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, int fast_math, hipStream_t st);
+	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, int fast_math, const HostPublish &pub, hipStream_t st);
+void launch_ingest_host(const void *src_host, void *dst, size_t bytes, hipStream_t st);
+bool launch_init_grid_ingest(const BatchView &bv, const double *host_w0_dev, int resx, int resy, double lo_x, double lo_y,
+	double hi_x, double hi_y, int force_unit_z, const void *src_host, void *dst, size_t bytes, hipStream_t st);
 void launch_finish_track(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, const double *partials,
 	int nblk, hipStream_t st);
 

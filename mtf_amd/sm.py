@@ -354,7 +354,7 @@ class GridTracker:
         else:
             pc = region_corners if np.ndim(region_corners) == 3 else self.patch_corners(region_corners)
             corners = self.tracker.update_region(pc)
-        return corners, corners.mean(axis=2)   # utils::getCentroid miscUtils.h:473-480
+        return corners, np.add.reduce(corners, axis=2) * 0.25   # utils::getCentroid miscUtils.h:473-480 (mean of the four corners)
 
     @property
     def n_iters(self):
