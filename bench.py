@@ -404,7 +404,8 @@ def secondary_workload(args):
             out["cpu_baseline"] = {"value": n / (time.perf_counter() - t0), "unit": "target-iters/s", "cores": 1, "kind": "port",
                                    "sample": "%d ESM+MI iterations of one %dx%d target" % (n, res, res)}
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    ctx.close()    # handles released while the HIP runtime is whole (the library's atexit hook would do the same)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -586,7 +587,8 @@ def main():
             out["parity"] = parity_gate(ctx, args.am, res, frame0, frame1, corners[0])
         elif not args.no_cpu:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    ctx.close()    # handles released while the HIP runtime is whole (the library's atexit hook would do the same)
     if dist is not None:
         dist.destroy_process_group()
 

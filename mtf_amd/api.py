@@ -7,6 +7,7 @@ this side (pts (B, 2, N), grad (B, N, 2), J (B, N, S), H (B, S, S), corners (B, 
 converted to/from the Eigen column-major layouts of the C ABI here.
 """
 import sys
+import atexit
 import weakref
 import ctypes as C
 
@@ -36,6 +37,22 @@ def sm_desc(sm, **kw):
     return SMDesc(**base)
 
 
+_live_contexts = weakref.WeakSet()
+
+
+def _close_all_contexts():
+    # at interpreter exit, BEFORE the HIP runtime's own static destructors run: handles released in order (batches, then their
+    # context) while the runtime is still whole
+    for c in list(_live_contexts):
+        try:
+            c.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_all_contexts)
+
+
 class Context:
     """Device + stream + the current image (ImageBase::setCurrImg)."""
 
@@ -45,9 +62,13 @@ class Context:
         self.device = device
         self._img_keep = None
         self._batches = weakref.WeakSet()   # a batch holds a raw pointer to its context: close them first
+        self._dependents = weakref.WeakSet()   # ... and whatever holds a raw pointer to a batch (the device particle filter) before those
+        _live_contexts.add(self)
 
     def close(self):
         if self._h:
+            for d in list(self._dependents):
+                d.close()
             for b in list(self._batches):
                 b.close()
             L.lib().mtfhip_ctx_destroy(self._h)

@@ -714,7 +714,39 @@ int mtfhip_batch_track_targets_per_launch(mtfhip_batch *b, const mtfhip_sm_desc 
 	return track_chunk(b, sm, fa);
 }
 
-static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners, bool slab_uploaded);
+static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners, bool slab_uploaded, bool resume = false);
+/* ---- the persistent one-launch loop (kernels_persist.hip) ---- */
+/* rows per workgroup so that every target's workgroups are resident together: the default decomposition when it fits, else the
+ * smallest number of rows that does */
+static void persist_decomposition(const mtfhip_batch *b, int &nblk, int &rows) {
+	fused_decomposition(b->N, b->B, nblk, rows);
+	const int per_target = b->ctx->n_cus / b->B;
+	if (per_target >= 1 && nblk > per_target) {
+		const int total_rows = (b->N + kBlock - 1) / kBlock;
+		rows = (total_rows + per_target - 1) / per_target;
+		nblk = (total_rows + rows - 1) / rows;
+	}
+}
+static unsigned long long persist_timeout_ticks() {   /* 100 MHz ticks; MTFHIP_PERSIST_TIMEOUT_US for tests (default 20 ms) */
+	const char *e = std::getenv("MTFHIP_PERSIST_TIMEOUT_US");
+	const double us = e ? std::atof(e) : 20000.0;
+	return (unsigned long long)(us * 100.0);
+}
+/* Opt-in (MTFHIP_PERSIST=1).  Measured on MI355X (profiles/README.md, r02): a hand-over between workgroups through memory costs what
+ * the gap between two dependent launches costs (~2 us), so one launch per loop does not beat two launches per iteration --
+ * 200 x 200 x 1: 17.1 us per iteration against 13.0, 50 x 50 x 1: 12.3 against 12.3 -- and the per-iteration time is the solve's
+ * latency either way. */
+static bool persist_fits(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const FusedArgs &fa) {
+	const char *e = std::getenv("MTFHIP_PERSIST");
+	if (!(e && e[0] == '1') || !b->persist_ok || fa.materialize || b->ctx->n_cus <= 0 || b->B > b->ctx->n_cus || !b->h_pub_dev) return false;
+	if (b->B > 8) return false;   /* a batch is better served by its own decomposition (eight workgroups per target) */
+	if (sm->max_iters < 2) return false;
+	int nblk, rows;
+	persist_decomposition(b, nblk, rows);
+	return (long)nblk * b->B <= b->ctx->n_cus && nblk <= b->nblk_max;
+}
+/* the rest of a loop the persistent launch left unfinished: the slab on the device is current (warps, flags, iteration counts) */
+static int track_resume(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners) { return track_core(b, sm, n_iters, corners, true, true); }
 int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners) { return track_core(b, sm, n_iters, corners, false); }
 
 /* setRegion + update of one frame in one call: what GridTracker::update does with every patch tracker (GridTracker.cc:345-363:
@@ -729,7 +761,7 @@ int mtfhip_batch_track_region(mtfhip_batch *b, const mtfhip_sm_desc *sm, const d
 	return track_core(b, sm, n_iters, corners, folded);
 }
 
-static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners, bool slab_uploaded) {
+static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners, bool slab_uploaded, bool resume) {
 	FLUSH_AM(b);   /* (none of the loop's kernels reads CURR_PTS: they warp the template grid themselves) */
 	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
 	TRY(check_sm(b, sm, "track"));
@@ -774,7 +806,8 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 		return true;
 	};
 	TrackState ts{b->d_acc, b->d_h0, b->d_corners, b->d_init_corners_hm, b->d_active, b->d_iters, ncc ? b->d_ncc : nullptr, ncc ? b->d_ncc_tm : nullptr, 0, nullptr, nullptr};
-	if (sm->leven_marq) {
+	if (sm->leven_marq && resume) { ts.lm = b->d_lm; if (mi) ts.f_ext = b->d_mi_f; }
+	else if (sm->leven_marq) {
 		/* per-target LM state: prev_similarity 0, leven_marq_delta = lm_delta_init, no pending reset, iteration 0 */
 		if (!b->d_lm) HIP_TRY(hipMalloc(&b->d_lm, sizeof(double) * kLmStride * (size_t)b->B));
 		std::vector<double> lm0((size_t)kLmStride * b->B, 0.0);
@@ -789,6 +822,7 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 	const int max_passes = (sm->leven_marq && sm->sm == MTFHIP_SM_FCLK) ? 2 * sm->max_iters : sm->max_iters;
 	BatchView bv = b->view();
 	unsigned long long pub_seq = 0;   /* non-zero: the loop's own kernel delivers the results to the host */
+	bool persisted = false;
 	if (b->desc.am == MTFHIP_AM_MI) {
 		/* the fused MI passes leave g and H on the device; k_finish_track_mi lays them out as one reduced row per target and
 		 * runs the same finish (solve, compositional update, convergence test): no host round trip per iteration */
@@ -814,6 +848,24 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 			pub = HostPublish{b->h_pub_dev, b->slab_dbl_bytes, b->B, b->d_fin_count, b->h_flag_dev, pub_seq};
 		}
 		launch_iclk_track(bv, b->ctx->img, *sm, ts, b->d_h0inv, b->d_ncc, b->norm_mult, b->norm_add, b->math_mode == MTFHIP_MATH_FAST, pub, st);
+	} else if (persist_fits(b, sm, fa)) {
+		/* a grid that fits the device at one workgroup per CU (a single large target, a few small ones): every pass of the loop in
+		 * ONE launch, the workgroups meeting at an in-kernel barrier between the pixel pass and the solve (kernels_persist.hip) */
+		persisted = true;
+		if (!b->d_persist) {
+			HIP_TRY(hipMalloc(&b->d_persist, 2 * sizeof(int) * (size_t)b->B));
+			HIP_TRY(hipMemsetAsync(b->d_persist, 0, 2 * sizeof(int) * (size_t)b->B, st));
+		}
+		int nblk_p, rows_p;
+		persist_decomposition(b, nblk_p, rows_p);
+		FusedArgs fp = fa;
+		fp.rows_per_block = rows_p;
+		PersistState ps{b->d_persist, reinterpret_cast<unsigned *>(b->d_persist) + b->B, b->persist_gen, persist_timeout_ticks()};
+		b->persist_gen += (unsigned)max_passes + 1u;
+		{
+			TimedScope tsc(b->ctx, "track_persist");
+			launch_track_persist(bv, b->ctx->img, fp, *sm, ts, b->d_partials, nblk_p, ps, max_passes, st);
+		}
 	} else {
 		/* Targets are independent, so the loops commute: all iterations of a chunk of targets run before the next chunk
 		 * starts.  A chunk is sized so that what an iteration reads once (J0, I0, grid: 88 B/px for ESM) stays resident in
@@ -870,6 +922,19 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 			std::memcpy(b->th[t].corners, cr + 8 * t, sizeof(double) * 8);
 			if (n_iters) n_iters[t] = iters[t];
 			if (corners) std::memcpy(corners + 8 * t, cr + 8 * t, sizeof(double) * 8);
+		}
+	}
+	if (persisted) {
+		/* a workgroup that could not wait any longer for its peers (CUs held by another process) leaves its target active with
+		 * iterations to go: the two-launch loop takes the call from where the device stopped, and this batch stays with it */
+		const int *act = reinterpret_cast<const int *>(h_res + b->slab_dbl_bytes);
+		bool cut = false;
+		for (int t = 0; t < b->B; ++t) cut = cut || act[t] != 0;
+		if (cut) {
+			b->persist_ok = false;
+			HIP_TRY(hipStreamSynchronize(st));
+			HIP_TRY(hipMemsetAsync(b->d_persist, 0, 2 * sizeof(int) * (size_t)b->B, st));
+			return track_resume(b, sm, n_iters, corners);
 		}
 	}
 	if (!mi) {   /* (mi_enqueue keeps the flags of its own passes) */
@@ -952,3 +1017,8 @@ int mtfhip_sample_candidates(mtfhip_batch *b, const double *states, int C, doubl
 
 
 } /* extern "C" */
+
+#ifdef MTFHIP_FIN_TRACE
+namespace mtfhip { void debug_fin_trace(unsigned long long *out); }
+extern "C" void mtfhip_debug_fin_trace(unsigned long long *out) { mtfhip::debug_fin_trace(out); }
+#endif

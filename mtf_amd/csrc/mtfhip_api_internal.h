@@ -152,6 +152,7 @@ struct mtfhip_ctx {
 	size_t img_capacity = 0;
 	unsigned char *raw = nullptr; size_t raw_capacity = 0;      /* staging of the raw frame (pre-processing) */
 	float *tmp_a = nullptr, *tmp_b = nullptr; size_t tmp_capacity = 0; /* gray / row-pass intermediates */
+	int n_cus = 0;   /* compute units: the persistent loop needs its whole grid resident */
 	bool timing = false;
 	int timing_stride = 1;   /* events are recorded around every timing_stride-th launch of a family */
 	std::map<std::string, Timer> timers;
@@ -240,6 +241,11 @@ struct mtfhip_batch {
 	 * copy (a grid frame used to cost 14 small copies and 4 stream syncs around a 100 us kernel). */
 	char *d_slab = nullptr, *h_stage_a = nullptr, *h_stage_b = nullptr;
 	hipEvent_t ev_a = nullptr, ev_b = nullptr;
+	/* k_track_persist: barrier words, the generation counter the host advances per launch; persist_ok is cleared for good when a
+	 * launch could not keep its workgroups resident (the two-launch loop finishes the call and serves the later ones) */
+	int *d_persist = nullptr;
+	unsigned persist_gen = 0;
+	bool persist_ok = true;
 	bool stage_a_busy = false;   /* ev_a guards an upload from h_stage_a that may still be in flight */
 	/* warp + state of every target after setState / compositionalUpdate: one copy from a pinned double buffer, no sync */
 	double *h_wstage[2] = {nullptr, nullptr};

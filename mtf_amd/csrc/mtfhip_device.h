@@ -240,8 +240,21 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
 	return __hiloint2double(hi, lo);
 }
 
+/* Data handed from one workgroup to another INSIDE a launch (k_track_persist): agent-scope relaxed atomics are sc1 accesses --
+ * stores write through to the memory side, loads never hit a stale line of this XCD's L2 -- so the hand-over needs no L2
+ * write-back / invalidate (`buffer_wbl2` / `buffer_inv`, microseconds each on eight 4 MB L2s): the producer waits for its stores
+ * to be acknowledged (vmcnt) and then raises a flag the same way. */
+template <typename T> __device__ __forceinline__ void st_coh(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T> __device__ __forceinline__ T ld_coh(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+/* lane `src` (a compile-time constant or a wave-uniform value) of a double, through the scalar unit */
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+	return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void wait_stores_acked() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 /* reduce K per-thread accumulators over the workgroup and write them to dst[0..K) */
-template <int K>
+template <int K, bool COH = false>
 __device__ __forceinline__ void block_reduce_store(double *v, double *dst, double *lds /* [4][K] */) {
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	wave_halve<K, 32>(v, lane);
@@ -256,7 +269,7 @@ __device__ __forceinline__ void block_reduce_store(double *v, double *dst, doubl
 		double s = lds[threadIdx.x];
 #pragma unroll
 		for (int wv = 1; wv < kBlock / 64; ++wv) s += lds[wv * K + threadIdx.x];
-		dst[threadIdx.x] = s;
+		if constexpr (COH) st_coh(dst + threadIdx.x, s); else dst[threadIdx.x] = s;
 	}
 }
 

@@ -9,6 +9,13 @@
 
 namespace mtfhip {
 
+#ifdef MTFHIP_FIN_TRACE
+__device__ unsigned long long g_fin_trace[16];
+#define FIN_STAMP(k) do { if (t == 0 && threadIdx.x == 0) g_fin_trace[k] = clock64(); } while (0)
+#else
+#define FIN_STAMP(k) do { } while (0)
+#endif
+
 /* ===================================================================== */
 /* on-device solve + compositional update (batched drivers only)          */
 /* ===================================================================== */
@@ -23,8 +30,16 @@ namespace mtfhip {
  *       (Homography.cc:73-92,109-114, Affine.cc:90-106,145-150, NT/FCLK.cc:314-339). */
 /* Body of the device-side finish, executed by the first wave of the calling workgroup (all threads of the workgroup
  * must call it: it contains workgroup barriers). */
+/* COH (k_track_persist): everything the loop rewrites between passes -- partial rows, warp, state, corners, counters, flags, the
+ * Levenberg-Marquardt block -- is read and written with the coherent accessors of mtfhip_device.h (st_coh / ld_coh). */
+template <bool COH = false>
 __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts,
 	const double *partials, int nblk, int t) {
+	auto LD = [](const double *p) -> double { if constexpr (COH) return ld_coh(p); else return *p; };
+	auto LDI = [](const int *p) -> int { if constexpr (COH) return ld_coh(p); else return *p; };
+	auto ST = [](double *p, double v) { if constexpr (COH) st_coh(p, v); else *p = v; };
+	auto STI = [](int *p, int v) { if constexpr (COH) st_coh(p, v); else *p = v; };
+	FIN_STAMP(0);
 	__shared__ double acc_s[NCC_ACC_COUNT];   /* >= ACC_COUNT */
 	__shared__ double A[8][9];
 	__shared__ double dps[8];
@@ -39,37 +54,49 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 	/* every global operand of this target -- the `active` flag included -- is requested up front, in parallel across
 	 * the lanes, and only then is the flag tested: one memory round trip instead of two (flag, then operands); the
 	 * rest of the routine runs out of LDS / registers */
-	const int act = ts.active[t];
+	const int act = LDI(ts.active + t);
 	int n_it_prev = 0;
 	double v_h0 = 0, v_w = 0, v_cr = 0, v_ic = 0, v_acc = 0, v_tm = 0, v_nc = 0;
 	if (wv0) {
 		v_h0 = ts.h0[(size_t)t * 64 + lane];
-		if (lane < 9) v_w = bv.warps[9 * t + lane];
-		if (lane < 8) v_cr = ts.corners[8 * t + lane];
+		if (lane < 9) v_w = LD(bv.warps + 9 * t + lane);
+		if (lane < 8) v_cr = LD(ts.corners + 8 * t + lane);
 		if (lane < 12) v_ic = ts.init_corners_hm[12 * t + lane];
-		n_it_prev = ts.n_iters[t];
+		n_it_prev = LDI(ts.n_iters + t);
 		if (ncc) {
 			if (lane < 52) v_tm = ts.ncc_tm[(size_t)t * 52 + lane];
 			if (lane < 2) v_nc = ts.ncc[(size_t)t * 8 + lane];
 		}
 	}
-	if (lane < RL) {
-		const double *p = partials + (size_t)t * nblk * RL + lane;
-		auto ld = [&](size_t off) -> double { return p[off]; };
-		/* eight block rows in flight per lane: the headline batch has exactly eight per target (one round trip), a single
-		 * target has 157 (20 rounds instead of 40) */
-		double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
-		int b = 0;
-		for (; b + 7 < nblk; b += 8) {
-			s0 += ld((size_t)b * RL); s1 += ld((size_t)(b + 1) * RL);
-			s2 += ld((size_t)(b + 2) * RL); s3 += ld((size_t)(b + 3) * RL);
-			s4 += ld((size_t)(b + 4) * RL); s5 += ld((size_t)(b + 5) * RL);
-			s6 += ld((size_t)(b + 6) * RL); s7 += ld((size_t)(b + 7) * RL);
+	/* fixed-order sum of the block rows.  Up to eight rows (the batched decomposition) one lane per column sums them in one round
+	 * trip; a single large target has 157: the rows are cut into three contiguous runs (multiples of eight rows) summed by
+	 * three groups of 80 lanes and combined in run order -- 7 rounds instead of 20.  (Workgroups of fewer than 240 threads keep
+	 * the single run.) */
+	__shared__ double part_s[3][80];
+	const int n_runs = (nblk > 8 && blockDim.x >= 240) ? 3 : 1;
+	const int run_len = n_runs == 1 ? nblk : ((nblk + 3 * 8 - 1) / (3 * 8)) * 8;
+	{
+		const int run = n_runs == 1 ? 0 : lane / 80, col = n_runs == 1 ? lane : lane % 80;
+		if (col < RL && run < n_runs) {
+			const int b0 = run * run_len, b1 = (b0 + run_len < nblk) ? b0 + run_len : nblk;
+			const double *p = partials + (size_t)t * nblk * RL + col;
+			auto ld = [&](size_t off) -> double { return LD(p + off); };
+			/* eight block rows in flight per lane */
+			double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
+			int b = b0;
+			for (; b + 7 < b1; b += 8) {
+				s0 += ld((size_t)b * RL); s1 += ld((size_t)(b + 1) * RL);
+				s2 += ld((size_t)(b + 2) * RL); s3 += ld((size_t)(b + 3) * RL);
+				s4 += ld((size_t)(b + 4) * RL); s5 += ld((size_t)(b + 5) * RL);
+				s6 += ld((size_t)(b + 6) * RL); s7 += ld((size_t)(b + 7) * RL);
+			}
+			for (; b < b1; ++b) s0 += ld((size_t)b * RL);
+			const double v = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+			if (n_runs == 1) v_acc = v; else part_s[run][col] = v;
 		}
-		for (; b < nblk; ++b) s0 += ld((size_t)b * RL);
-		v_acc = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
 	}
 	if (!act) return;
+	FIN_STAMP(1);
 	if (wv0) {
 		h0s[lane] = v_h0;
 		if (lane < 9) Ws[lane] = v_w;
@@ -78,8 +105,13 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 		if (lane < 52) tms[lane] = v_tm;
 		if (lane < 2) ncs[lane] = v_nc;
 	}
-	if (lane < RL) { acc_s[lane] = v_acc; ts.acc[(size_t)t * RL + lane] = v_acc; }
+	if (n_runs > 1) {
+		__syncthreads();
+		if (lane < RL) v_acc = (part_s[0][lane] + part_s[1][lane]) + part_s[2][lane];
+	}
+	if (lane < RL) { acc_s[lane] = v_acc; ST(ts.acc + (size_t)t * RL + lane, v_acc); }
 	__syncthreads();
+	FIN_STAMP(2);
 	const int i = (lane >> 3) & 7, j = lane & 7;
 	/* ---- Levenberg-Marquardt: the accept / undo test on the similarity of this pass (uniform over the workgroup) ---- */
 	double *lmp = ts.lm ? ts.lm + (size_t)t * kLmStride : nullptr;
@@ -87,11 +119,11 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 	int lm_iter_id = n_it_prev;   /* (only lane 0's copy of n_it_prev is loaded; LM keeps its own counter) */
 	bool undo = false;
 	if (lmp) {
-		const double f_now = ts.f_ext ? ts.f_ext[t] : (ncc ? 0.0 : -acc_s[ACC_RR] / 2);
-		const double prev_f = lmp[0];
-		lm_delta = lmp[1];
-		const bool state_reset = lmp[2] != 0.0;
-		lm_iter_id = (int)lmp[3];
+		const double f_now = ts.f_ext ? LD(ts.f_ext + t) : (ncc ? 0.0 : -acc_s[ACC_RR] / 2);
+		const double prev_f = LD(lmp + 0);
+		lm_delta = LD(lmp + 1);
+		const bool state_reset = LD(lmp + 2) != 0.0;
+		lm_iter_id = (int)LD(lmp + 3);
 		double f_use = f_now;
 		if (ncc) {
 			const double nN0 = (double)bv.N, mt0 = acc_s[NCC_IT] / nN0, b20 = acc_s[NCC_IT2] - nN0 * mt0 * mt0;
@@ -105,9 +137,9 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 		}
 		__syncthreads();   /* every thread has read the LM block before lane 0 rewrites it */
 		if (lane == 0) {
-			lmp[1] = lm_delta;
-			if (undo) lmp[2] = 1.0;
-			else { lmp[2] = 0.0; if (!state_reset) lmp[0] = f_use; }
+			ST(lmp + 1, lm_delta);
+			if (undo) ST(lmp + 2, 1.0);
+			else { ST(lmp + 2, 0.0); if (!state_reset) ST(lmp + 0, f_use); }
 		}
 	}
 	const bool use_h0 = (sm.hess_type == 0) || (sm.sm == MTFHIP_SM_ICLK && !ts.h_from_acc);
@@ -159,28 +191,36 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 		if (sm.jac_type == 0) return cj(2);
 		return 0.5 * (cj(1) - ij(0));
 	};
-	const double dii = h_entry(i, i), djj = h_entry(j, j);
-	const double si = dii != 0 ? 1.0 / sqrt(fabs(dii)) : 1.0, sj = djj != 0 ? 1.0 / sqrt(fabs(djj)) : 1.0;
+	/* Symmetric diagonal equilibration by POWERS OF TWO: the products are exact, so the scaled elimination follows the unscaled
+	 * one bit for bit while its pivots stay near one (and a frexp / ldexp pair replaces the square root and the division of
+	 * 1 / sqrt|d|, a microsecond of dependent arithmetic on an idle workgroup). */
+	auto pow2_scale = [](double d) -> double { return d != 0 ? ldexp(1.0, -(ilogb(fabs(d)) / 2)) : 1.0; };
+	/* Gauss-Jordan; with partial pivoting where the system can be indefinite: the SSD Hessians are negated Gram matrices (definite;
+	 * a flat template's zero pivot leaves its unknown at zero), but NCC's Std / SumOfStd and MI's Hessians can be indefinite away
+	 * from convergence, where the reference's colPivHouseholderQr (NT/FCLK.cc:298) does not care either.  (A row-per-lane
+	 * elimination in registers with v_readlane broadcasts was measured slower than this LDS form: 8.9 k against 6.9 k clocks.) */
+	const bool pivoting = ncc || ts.h_from_acc;   /* (the search and the row swap are two barriers and eight LDS reads per step: skipped for SSD) */
+	const double si = pow2_scale(h_entry(i, i)), sj = pow2_scale(h_entry(j, j));
 	if (wv0) {
 		/* hessian(i, i) += leven_marq_delta * hessian(i, i) (NT/ESM.cc:262-265) */
 		A[i][j] = h_entry(i, j) * si * sj * ((lmp && i == j && i < S) ? 1.0 + lm_delta : 1.0);
 		if (j == 0) A[i][8] = (i < S ? g_entry(i) : 0.0) * si;
 	}
 	__syncthreads();
-	/* Gauss-Jordan with partial pivoting: the SSD Hessians are negated Gram matrices, but NCC's Std / SumOfStd and MI's
-	 * Hessians can be indefinite away from convergence, where the reference's colPivHouseholderQr (NT/FCLK.cc:298) does
-	 * not care either.  A column whose remaining entries are all zero (flat template) leaves its unknown at zero. */
+	FIN_STAMP(3);
 #pragma unroll
 	for (int k = 0; k < 8; ++k) {
-		int pr = k;
-		double best = fabs(A[k][k]);
+		if (pivoting) {
+			int pr = k;
+			double best = fabs(A[k][k]);
 #pragma unroll
-		for (int r = k + 1; r < 8; ++r) { const double v = fabs(A[r][k]); if (v > best) { best = v; pr = r; } }
-		const int src = i == k ? pr : (i == pr ? k : i);   /* row i after the swap of rows k and pr */
-		const double mine = A[src][j], rhs = A[src][8];
-		__syncthreads();
-		if (wv0) { A[i][j] = mine; if (j == 0) A[i][8] = rhs; }
-		__syncthreads();
+			for (int r = k + 1; r < 8; ++r) { const double v = fabs(A[r][k]); if (v > best) { best = v; pr = r; } }
+			const int src = i == k ? pr : (i == pr ? k : i);   /* row i after the swap of rows k and pr */
+			const double mine = A[src][j], rhs = A[src][8];
+			__syncthreads();
+			if (wv0) { A[i][j] = mine; if (j == 0) A[i][8] = rhs; }
+			__syncthreads();
+		}
 		const double piv = A[k][k], aik = A[i][k], akj = A[k][j], bk = A[k][8];
 		const double f = (i != k && piv != 0) ? aik / piv : 0.0;
 		__syncthreads();
@@ -195,18 +235,24 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 		dps[i] = (i < S && d != 0) ? -(A[i][8] / d) * si : 0.0;
 	}
 	__syncthreads();
-	if (lane != 0) return;
-
+	FIN_STAMP(4);
+	/* ---- compositional update and corner test.  The expressions (and their order) are those of the straightforward serial form;
+	 * what is independent is spread over the lanes -- the 9 + 9 + 8 IEEE divisions of invertState, of the homography
+	 * normalisation and of the corner dehomogenisation were ~35 dependent division latencies on one lane of an otherwise
+	 * idle workgroup, now four. ---- */
+	__shared__ double xs[9], nxy[8];
+	const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY;
+	if (lane < 8) {
+		const double v = undo ? LD(lmp + 4 + lane) : dps[lane];   /* undo: the previous state_update is taken back */
+		if (lmp && !undo) ST(lmp + 4 + lane, v);
+		dps[lane] = v;
+	}
+	__syncthreads();
 	double dp[8];
 #pragma unroll
-	for (int s = 0; s < 8; ++s) dp[s] = undo ? lmp[4 + s] : dps[s];   /* undo: the previous state_update is taken back */
-	if (lmp && !undo) {
-#pragma unroll
-		for (int s = 0; s < 8; ++s) lmp[4 + s] = dp[s];
-	}
-	double *Wp = bv.warps + 9 * t, *st = bv.states + 8 * t;
+	for (int s = 0; s < 8; ++s) dp[s] = dps[s];
 	double U[9];
-	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+	if (hom) {
 		U[0] = 1 + dp[0]; U[1] = dp[1]; U[2] = dp[2]; U[3] = dp[3]; U[4] = 1 + dp[4]; U[5] = dp[5];
 		U[6] = dp[6]; U[7] = dp[7]; U[8] = 1;
 	} else {
@@ -226,11 +272,17 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 #pragma unroll
 		for (int q = 0; q < 9; ++q) c[q] *= inv_det;
 		double n22 = c[8];
+		double cq = 0;
 #pragma unroll
-		for (int q = 0; q < 9; ++q) U[q] = c[q] / n22;
+		for (int q = 0; q < 9; ++q) if (lane == q) cq = c[q];
+		if (lane < 9) xs[lane] = cq / n22;
+		__syncthreads();
+#pragma unroll
+		for (int q = 0; q < 9; ++q) U[q] = xs[q];
+		__syncthreads();   /* xs is reused below */
 		/* round-trip through the state parameterisation as getStateFromWarp / getWarpFromState do */
 		U[0] = 1 + (U[0] - 1); U[4] = 1 + (U[4] - 1); U[8] = 1;
-		if (bv.ssm != MTFHIP_SSM_HOMOGRAPHY) { U[6] = 0; U[7] = 0; }
+		if (!hom) { U[6] = 0; U[7] = 0; }
 	}
 	double Wo[9], Wn[9];
 #pragma unroll
@@ -240,40 +292,60 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 #pragma unroll
 		for (int c2 = 0; c2 < 3; ++c2)
 			Wn[3 * r + c2] = Wo[3 * r] * U[c2] + Wo[3 * r + 1] * U[3 + c2] + Wo[3 * r + 2] * U[6 + c2];
-	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+	double *Wp = bv.warps + 9 * t, *st = bv.states + 8 * t;
+	if (hom) {
 		double n22 = Wn[8];
+		double wq = 0;
 #pragma unroll
-		for (int q = 0; q < 9; ++q) Wn[q] /= n22;
-		st[0] = Wn[0] - 1; st[1] = Wn[1]; st[2] = Wn[2]; st[3] = Wn[3]; st[4] = Wn[4] - 1; st[5] = Wn[5];
-		st[6] = Wn[6]; st[7] = Wn[7];
-	} else {
-		st[0] = Wn[2]; st[1] = Wn[5]; st[2] = Wn[0] - 1; st[3] = Wn[1]; st[4] = Wn[3]; st[5] = Wn[4] - 1;
+		for (int q = 0; q < 9; ++q) if (lane == q) wq = Wn[q];
+		if (lane < 9) xs[lane] = wq / n22;
+		__syncthreads();
+#pragma unroll
+		for (int q = 0; q < 9; ++q) Wn[q] = xs[q];
+		if (lane == 0) {
+			ST(st + 0, Wn[0] - 1); ST(st + 1, Wn[1]); ST(st + 2, Wn[2]); ST(st + 3, Wn[3]); ST(st + 4, Wn[4] - 1); ST(st + 5, Wn[5]);
+			ST(st + 6, Wn[6]); ST(st + 7, Wn[7]);
+		}
+	} else if (lane == 0) {
+		ST(st + 0, Wn[2]); ST(st + 1, Wn[5]); ST(st + 2, Wn[0] - 1); ST(st + 3, Wn[1]); ST(st + 4, Wn[3]); ST(st + 5, Wn[4] - 1);
 	}
+	{
+		double wq = 0;
 #pragma unroll
-	for (int q = 0; q < 9; ++q) Wp[q] = Wn[q];
+		for (int q = 0; q < 9; ++q) if (lane == q) wq = Wn[q];
+		if (lane < 9) ST(Wp + lane, wq);
+	}
 	double *cr = ts.corners + 8 * t;
-	double change = 0;
-#pragma unroll
-	for (int q = 0; q < 4; ++q) {
+	if (lane < 4) {
+		const int q = lane;
 		double X = ics[3 * q], Y = ics[3 * q + 1], Z = ics[3 * q + 2];
 		double nx = Wn[0] * X + Wn[1] * Y + Wn[2] * Z, ny = Wn[3] * X + Wn[4] * Y + Wn[5] * Z;
-		if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+		if (hom) {
 			double d = Wn[6] * X + Wn[7] * Y + Wn[8] * Z;
 			nx = nx / d; ny = ny / d;
 		}
-		double ddx = crs[2 * q] - nx, ddy = crs[2 * q + 1] - ny;
+		nxy[2 * q] = nx; nxy[2 * q + 1] = ny;
+		ST(cr + 2 * q, nx); ST(cr + 2 * q + 1, ny);
+	}
+	__syncthreads();
+	FIN_STAMP(5);
+	if (lane != 0) return;
+	double change = 0;
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		double ddx = crs[2 * q] - nxy[2 * q], ddy = crs[2 * q + 1] - nxy[2 * q + 1];
 		change += ddx * ddx + ddy * ddy;
-		cr[2 * q] = nx; cr[2 * q + 1] = ny;
 	}
 	const int n_it = n_it_prev + 1;   /* passes done (the reference's iters_done) */
-	ts.n_iters[t] = n_it;
+	STI(ts.n_iters + t, n_it);
 	if (lmp) {
 		/* an undo pass skips the convergence test (`continue`); it consumes an iteration in the for loops of ESM and ICLK
 		 * (NT/ESM.cc:179, NT/ICLK.cc:169) but not in FCLK's while loop (NT/FCLK.cc:193-223) */
 		const int id = lm_iter_id + ((undo && sm.sm == MTFHIP_SM_FCLK) ? 0 : 1);
-		lmp[3] = (double)id;
-		if ((!undo && change < sm.epsilon) || id >= sm.max_iters) ts.active[t] = 0;
-	} else if (change < sm.epsilon || n_it >= sm.max_iters) ts.active[t] = 0;
+		ST(lmp + 3, (double)id);
+		if ((!undo && change < sm.epsilon) || id >= sm.max_iters) STI(ts.active + t, 0);
+	} else if (change < sm.epsilon || n_it >= sm.max_iters) STI(ts.active + t, 0);
+	FIN_STAMP(6);
 }
 
 } // namespace mtfhip

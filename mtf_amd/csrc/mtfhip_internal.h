@@ -107,6 +107,14 @@ struct TrackState {
 };
 constexpr int kLmStride = 12;
 
+/* k_track_persist: per-target arrival counter and generation number of the in-kernel barrier between the pixel pass and the solve */
+struct PersistState {
+	int *arrive;            /* [B] zero between launches */
+	unsigned *gen;          /* [B] monotonic: gen_base + pass + 1 once pass `pass` has been solved */
+	unsigned gen_base;
+	unsigned long long timeout_ticks;   /* of the 100 MHz wall clock */
+};
+
 /* results of the one-launch loop delivered straight into the host-coherent mirror of the state slab (warps | states | corners |
  * ... | iteration counts) by the workgroup that produced them; the last workgroup to finish raises the flag the host spins on.
  * host == NULL: nothing is published (k_publish_host does it in a launch of its own). */
@@ -265,6 +273,8 @@ constexpr int kIclkTrackMaxPix = 16 * kBlock;
 bool launch_iclk_track(const BatchView &bv, const ImgView &im, const mtfhip_sm_desc &sm, const TrackState &ts,
 	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, int fast_math, const HostPublish &pub, hipStream_t st);
 void launch_ingest_host(const void *src_host, void *dst, size_t bytes, hipStream_t st);
+void launch_track_persist(const BatchView &bv, const ImgView &im, const FusedArgs &fa, const mtfhip_sm_desc &sm, const TrackState &ts,
+	double *partials, int nblk, const PersistState &ps, int max_passes, hipStream_t st);
 bool launch_init_grid_ingest(const BatchView &bv, const double *host_w0_dev, int resx, int resy, double lo_x, double lo_y,
 	double hi_x, double hi_y, int force_unit_z, const void *src_host, void *dst, size_t bytes, hipStream_t st);
 void launch_finish_track(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, const double *partials,

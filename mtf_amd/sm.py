@@ -422,6 +422,7 @@ class ParticleFilter:
         self.desc.seed = int(seed)
         self._h = C.c_void_p()
         L.check(L.lib().mtfhip_pf_create(self.batch._h, C.byref(self.desc), C.byref(self._h)))
+        ctx._dependents.add(self)
         self.comm = comm
         if comm is not None:
             L.check(L.lib().mtfhip_pf_set_comm(self._h, comm._h))

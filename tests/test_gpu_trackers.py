@@ -500,6 +500,62 @@ def test_single_large_target_device_loop_equals_host_loop(gpu_ctx, frame, am, sm
 
 
 
+PERSIST_CASES = [
+    # sm, am, ssm, res, B, leven_marq, math
+    (L.SM_ESM, L.AM_SSD, L.SSM_HOMOGRAPHY, 160, 1, 0, "replay"),
+    (L.SM_ESM, L.AM_SSD, L.SSM_HOMOGRAPHY, 160, 1, 1, "fast"),
+    (L.SM_ESM, L.AM_NCC, L.SSM_HOMOGRAPHY, 120, 1, 0, "fast"),
+    (L.SM_FCLK, L.AM_SSD, L.SSM_AFFINE, 100, 1, 1, "replay"),
+    (L.SM_FCLK, L.AM_NCC, L.SSM_HOMOGRAPHY, 160, 1, 0, "replay"),
+    (L.SM_ICLK, L.AM_SSD, L.SSM_HOMOGRAPHY, 200, 1, 0, "fast"),     # (above the one-launch grid kernel's patch size)
+    (L.SM_ESM, L.AM_SSD, L.SSM_HOMOGRAPHY, 50, 5, 0, "replay"),     # a few small targets: 5 x 10 workgroups resident together
+    (L.SM_ESM, L.AM_SSD, L.SSM_HOMOGRAPHY, 400, 1, 0, "fast"),      # 625 rows: three rows per workgroup to fit 256 CUs
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", PERSIST_CASES, ids=lambda c: "sm%d-am%d-ssm%d-%dx%d-lm%d-%s" % c)
+def test_persistent_loop_equals_two_launch_loop(gpu_ctx, case, monkeypatch):
+    """mtfhip_batch_track through k_track_persist (every pass in one launch, in-kernel barrier between the pixel pass and the solve)
+    against the launch-per-pass loop it replaces: same bits where the decomposition into workgroups is the same, and the
+    bounded wait's give-up path (timeout forced to zero) finishes the loop with the launch-per-pass form to the same result."""
+    sm_kind, am, ssm, res, B, lm, math = case
+    rng = np.random.default_rng(97)
+    big = synth.make_frame(768, 768)
+    centre = (384.0, 384.0)
+    frame2 = synth.warp_frame(big, synth.random_small_homography(rng, 0.3), centre)
+    if B == 1:
+        corners = synth.square_corners(centre[0], centre[1], float(res))[None]
+    else:
+        corners = np.stack([synth.square_corners(200.0 + 90 * k, 250.0 + 60 * k, float(res)) for k in range(B)])
+    out = {}
+    for mode in ("two-launch", "persist", "persist-gives-up"):
+        monkeypatch.setenv("MTFHIP_PERSIST", "0" if mode == "two-launch" else "1")
+        if mode == "persist-gives-up":
+            monkeypatch.setenv("MTFHIP_PERSIST_TIMEOUT_US", "0")
+        else:
+            monkeypatch.delenv("MTFHIP_PERSIST_TIMEOUT_US", raising=False)
+        gpu_ctx.set_image(big)
+        trk = LKTracker(gpu_ctx, sm_kind, ssm, res, res, B, host_solve=False, max_iters=15, epsilon=1e-7, materialize=0, am=am,
+                        leven_marq=lm)
+        trk.batch.set_math_mode(mtf_amd.MATH_REPLAY if math == "replay" else mtf_amd.MATH_FAST)
+        trk.initialize(corners)
+        gpu_ctx.set_image(frame2)
+        c1 = trk.update().copy()
+        n1 = np.array(trk.n_iters).copy()
+        c2 = trk.update().copy()          # a second call on the same batch (after a give-up it stays with the launch-per-pass loop)
+        out[mode] = (c1, n1, c2, trk.batch.get_state().copy())
+        trk.batch.close()
+    assert out["two-launch"][1].max() > 2
+    same_split = res * res <= 256 * 256 // B     # the default decomposition already fits the device
+    for mode in ("persist", "persist-gives-up"):
+        for a, b in zip(out[mode], out["two-launch"]):
+            if same_split:
+                assert np.array_equal(a, b), mode
+            else:
+                np.testing.assert_allclose(a, b, rtol=0, atol=1e-7, err_msg=mode)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("am", [L.AM_SSD, L.AM_NCC])
 @pytest.mark.parametrize("corner_based,dynamic_model,update_type,mean_type,likelihood_func,resampling_type", [
