@@ -421,6 +421,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--targets", type=int, default=64, help="targets per GPU (each 200x200)")
     ap.add_argument("--res", type=int, default=200)
+    ap.add_argument("--channels", type=int, default=1, choices=[1, 3],
+                    help="lk workload: 3 = the multi-channel models (MCSSD / MCNCC) on a 32FC3 frame through k_fused_mc")
     ap.add_argument("--sm", default="esm", choices=["esm", "fclk", "iclk"])
     ap.add_argument("--am", default="ssd", choices=["ssd", "ncc"], help="appearance model (lk and dropin workloads)")
     ap.add_argument("--mi-path", default="device", choices=["fused", "device", "interface"],
@@ -462,7 +464,8 @@ def main():
 
     res, B = args.res, args.targets
     H = W = 1024
-    frame0 = synth.make_frame(H, W)
+    CH = args.channels
+    frame0 = synth.make_frame(H, W) if CH == 1 else synth.make_frame_mc(H, W)
     rng = np.random.default_rng(synth.DEFAULT_SEED + 1)
     p_true = synth.random_small_homography(rng, 0.5)
     frame1 = synth.warp_frame(frame0, p_true, (W / 2.0, H / 2.0))
@@ -479,13 +482,18 @@ def main():
     sm_kind = {"esm": mtf_amd.SM_ESM, "fclk": mtf_amd.SM_FCLK, "iclk": mtf_amd.SM_ICLK}[args.sm]
     materialize = 1 if args.mode == "full" else 0
     am_kind = {"ssd": mtf_amd.AM_SSD, "ncc": mtf_amd.AM_NCC}[args.am]
-    batch = mtf_amd.Batch(ctx, am_kind, mtf_amd.SSM_HOMOGRAPHY, res, res, B)
+    batch = mtf_amd.Batch(ctx, am_kind, mtf_amd.SSM_HOMOGRAPHY, res, res, B, n_channels=CH)
     batch.set_math_mode(mtf_amd.MATH_FAST if args.math == "fast" else mtf_amd.MATH_REPLAY)
     batch.set_corners(corners)
-    ctx.set_image_device(f0.data_ptr(), H, W, keep=f0)
+    def set_frame(dev_t, host_a):
+        if CH == 1:
+            ctx.set_image_device(dev_t.data_ptr(), H, W, keep=dev_t)
+        else:
+            ctx.set_image(host_a)     # 32FC3: uploaded once, outside the timed region
+    set_frame(f0, frame0)
     sm = mtf_amd.sm_desc(sm_kind, materialize=materialize, leven_marq=0, epsilon=-1.0, max_iters=1)
     batch.init_template(sm)
-    ctx.set_image_device(f1.data_ptr(), H, W, keep=f1)
+    set_frame(f1, frame1)
 
     def run(n_iters):
         sm.max_iters = n_iters
@@ -527,7 +535,7 @@ def main():
     ctx.timing(False)
     # the lean variant of the same workload (nothing materialised: the form the device-side loop needs): FP64-issue / latency bound
     lean = None
-    if rank == 0 and args.mode == "full" and not args.no_lean:
+    if rank == 0 and args.mode == "full" and not args.no_lean and CH == 1:
         sm_l = mtf_amd.sm_desc(sm_kind, materialize=0, leven_marq=0, epsilon=-1.0, max_iters=k_steps)
         batch.set_region(corners, sm_l); batch.track(sm_l)
         torch.cuda.synchronize(dev)
@@ -546,16 +554,18 @@ def main():
                 "frac_of_fp64_vector_peak_78.6TF": flops_px * res * res * B / (lk_ms * 1e-3) / 78.6e12 if lk_ms > 0 else None}
 
     if rank == 0:
-        N = res * res
+        N = res * res * CH       # rows of the per-pixel arrays: (pixel, channel) pairs for the multi-channel models
         j0_rec = os.environ.get("MTFHIP_J0_RECOMPUTE", "1") != "0" and args.sm in ("esm", "iclk")
         bpp = algorithmic_bytes_per_pixel(args.sm, materialize, j0_recompute=j0_rec)
+        if CH > 1:
+            bpp = bpp - 16 + 16.0 / CH   # a pixel's grid point is shared by its C rows
         per_launch = batch.track_targets_per_launch(sm)   # all B, or an Infinity-Cache sized chunk of them
         if B % per_launch:                                 # a ragged last chunk would mix two launch sizes in the average
             per_launch = B / float(-(-B // per_launch))
         bytes_per_launch = float(bpp) * N * per_launch
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         out = {
-            "metric": "LK iters/sec (warp+grad+Hessian), ESM+%s+Homography 200x200" % args.am.upper(),
+            "metric": "LK iters/sec (warp+grad+Hessian), ESM+%s%s+Homography 200x200" % ("MC" if CH > 1 else "", args.am.upper()),
             "value": B * world * args.steps / dt,
             "unit": "iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -564,10 +574,10 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s+%s+Homography %dx%d, %d independent targets per GPU, %s mode, solve+update on device"
                                    % (args.sm.upper(), args.am.upper(), res, res, B, args.mode),
-                       "targets_per_gpu": B, "n_pix": N, "mode": args.mode, "frame": "%dx%d float32" % (H, W),
+                       "targets_per_gpu": B, "n_pix": N, "channels": CH, "mode": args.mode, "frame": "%dx%d float32%s" % (H, W, " x %d channels" % CH if CH > 1 else ""),
                        "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.sm, args.mode, res, B) if args.am == "ssd" else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.sm, args.mode, res, B) if (args.am == "ssd" and CH == 1) else None,
                          "kernel": "k_fused_%s" % args.am, "avg_kernel_ms": kern_ms, "launches_timed": kern_n,
                          "algorithmic_bytes_per_pixel": bpp, "j0_rows": "rebuilt from dI0_dx" if j0_rec else "read back", "bytes_per_launch": bytes_per_launch,
                          "targets_per_launch": per_launch,

@@ -304,11 +304,18 @@ int lazy_try_similarity(mtfhip_batch *b) {
 	return MTFHIP_OK;
 }
 
+/* The fused iteration serves MCSSD / MCNCC (k_fused_mc); MCMI's passes are single-channel and stay with the per-function entry points */
+static int fused_channels_ok(const mtfhip_batch *b, const char *fn) {
+	if (b->C != 1 && b->desc.am == MTFHIP_AM_MI)
+		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: the multi-channel MI model uses the per-function entry points", fn);
+	return MTFHIP_OK;
+}
+
 int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	FLUSH(b);
 	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
 	TRY(check_sm(b, sm, "init_template"));
-	TRY(single_channel(b, "init_template"));
+	TRY(fused_channels_ok(b, "init_template"));
 	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "init_template before set_corners");
 	/* am->clearInitStatus() (NT/ESM.cc:113, NT/FCLK.cc:105, NT/ICLK.cc:74) */
 	b->init_pix_vals = b->init_pix_grad = b->init_sim = b->init_grad = false;
@@ -367,7 +374,7 @@ static int set_region_core(mtfhip_batch *b, const double *corners, const mtfhip_
 	FLUSH_AM(b);   /* (the current points are about to be replaced: only pending calls need them brought up to date) */
 	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
 	TRY(check_sm(b, sm, "set_region"));
-	TRY(single_channel(b, "set_region"));
+	TRY(fused_channels_ok(b, "set_region"));
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "set_region before init_template");
 	TRY(set_corners_core(b, corners, for_track));
 	const bool refresh = region_refreshes(sm);
@@ -628,7 +635,8 @@ int mtfhip_batch_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, d
 	FLUSH_AM(b);   /* the fused kernels derive the sample points from the warp: CURR_PTS may stay stale */
 	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
 	TRY(check_sm(b, sm, "iterate"));
-	TRY(single_channel(b, "iterate"));
+	TRY(fused_channels_ok(b, "iterate"));
+	if (b->C != 1 && sm->sec_ord_hess) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "iterate: second-order Hessians of the multi-channel models use the per-function entry points");
 	if (!g || !H) return fail(MTFHIP_ERR_INVALID_ARG, "iterate: NULL output");
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "iterate before init_template");
 	TRY(need_image(b));
@@ -706,7 +714,7 @@ static int track_chunk(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const Fu
 int mtfhip_batch_track_targets_per_launch(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	FLUSH(b);
 	if (check_sm(b, sm, "track_targets_per_launch") != MTFHIP_OK) return 0;
-	const bool one_launch = sm->sm == MTFHIP_SM_ICLK && (sm->hess_type == 0 || (sm->hess_type == 2 && b->desc.am == MTFHIP_AM_SSD)) &&
+	const bool one_launch = b->C == 1 && sm->sm == MTFHIP_SM_ICLK && (sm->hess_type == 0 || (sm->hess_type == 2 && b->desc.am == MTFHIP_AM_SSD)) &&
 		b->N <= kIclkTrackMaxPix;
 	if (one_launch) return b->B;
 	FusedArgs fa;
@@ -739,6 +747,7 @@ static unsigned long long persist_timeout_ticks() {   /* 100 MHz ticks; MTFHIP_P
 static bool persist_fits(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const FusedArgs &fa) {
 	const char *e = std::getenv("MTFHIP_PERSIST");
 	if (!(e && e[0] == '1') || !b->persist_ok || fa.materialize || b->ctx->n_cus <= 0 || b->B > b->ctx->n_cus || !b->h_pub_dev) return false;
+	if (b->C != 1) return false;   /* (no multi-channel instantiation of the persistent kernel) */
 	if (b->B > 8) return false;   /* a batch is better served by its own decomposition (eight workgroups per target) */
 	if (sm->max_iters < 2) return false;
 	int nblk, rows;
@@ -765,7 +774,7 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 	FLUSH_AM(b);   /* (none of the loop's kernels reads CURR_PTS: they warp the template grid themselves) */
 	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
 	TRY(check_sm(b, sm, "track"));
-	TRY(single_channel(b, "track"));
+	TRY(fused_channels_ok(b, "track"));
 	if (sm->max_iters <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "track: max_iters must be positive");
 	if (b->desc.am != MTFHIP_AM_SSD ? sm->sec_ord_hess != 0 : second_order_term(sm) >= 0)
 		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: a second-order Hessian is indefinite and needs the pivoted host solve; use iterate");
@@ -774,7 +783,7 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 	hipStream_t st = b->ctx->stream;
 	const bool mi = b->desc.am == MTFHIP_AM_MI;
 	/* (the one-launch grid kernel has no Levenberg-Marquardt: with it ICLK takes the fused launch + finish per pass) */
-	const bool one_launch = !mi && !sm->leven_marq && sm->sm == MTFHIP_SM_ICLK && (sm->hess_type == 0 || (sm->hess_type == 2 && b->desc.am == MTFHIP_AM_SSD)) &&
+	const bool one_launch = !mi && b->C == 1 && !sm->leven_marq && sm->sm == MTFHIP_SM_ICLK && (sm->hess_type == 0 || (sm->hess_type == 2 && b->desc.am == MTFHIP_AM_SSD)) &&
 		b->N <= kIclkTrackMaxPix;
 	FusedArgs fa;
 	if (!one_launch && !mi) TRY(fused_args(b, sm, fa));

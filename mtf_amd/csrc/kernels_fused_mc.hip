@@ -1,0 +1,38 @@
+/*
+ * kernels_fused_mc.hip -- the fused Lucas-Kanade iteration of the multi-channel appearance models (MCSSD, MCNCC: SSD / NCC with
+ * n_channels = 3, AM/src/MCSSD.cc, AM/src/MCNCC.cc over Utilities/src/imgUtils.cc:861-1005).  One of the translation units of
+ * libmtfhip.so; the body is fused_lk_body<..., MC = true> (mtfhip_fused_device.h): one launch per iteration, a thread per
+ * (pixel, channel) row, the pixel's grid point shared by its C rows, the partial rows those of the single-channel pass
+ * (so k_finish_track, the host assembly and the NCC moment algebra serve both).
+ */
+#include "mtfhip_fused_device.h"
+
+namespace mtfhip {
+
+template <int AM, int SSM, bool CHAINED, int MODE, bool MAT>
+__global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_mc(BatchView bv, ImgView im, FusedArgs fa, double *partials, int nblk) {
+	fused_lk_body<AM, SSM, CHAINED, MODE, MAT, false, false, true>(bv, im, fa, partials, nblk);
+}
+
+template <int AM, int SSM, bool CHAINED>
+static void launch_mc_mode(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk, hipStream_t st) {
+	const dim3 g = grid2(nblk, bv.B);
+#define MTFHIP_MC(MD, MT) MTFHIP_LAUNCH((k_fused_mc<AM, SSM, CHAINED, MD, MT>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk)
+	if (fa.materialize) { if (fa.mode == 0) MTFHIP_MC(0, true); else if (fa.mode == 1) MTFHIP_MC(1, true); else MTFHIP_MC(2, true); }
+	else { if (fa.mode == 0) MTFHIP_MC(0, false); else if (fa.mode == 1) MTFHIP_MC(1, false); else MTFHIP_MC(2, false); }
+#undef MTFHIP_MC
+}
+template <int AM>
+static void launch_mc_am(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk, hipStream_t st) {
+	const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY;
+	if (hom && fa.chained) launch_mc_mode<AM, MTFHIP_SSM_HOMOGRAPHY, true>(bv, im, fa, partials, nblk, st);
+	else if (hom) launch_mc_mode<AM, MTFHIP_SSM_HOMOGRAPHY, false>(bv, im, fa, partials, nblk, st);
+	else if (fa.chained) launch_mc_mode<AM, MTFHIP_SSM_AFFINE, true>(bv, im, fa, partials, nblk, st);
+	else launch_mc_mode<AM, MTFHIP_SSM_AFFINE, false>(bv, im, fa, partials, nblk, st);
+}
+void launch_fused_mc(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk, hipStream_t st) {
+	if (bv.am == MTFHIP_AM_NCC) launch_mc_am<MTFHIP_AM_NCC>(bv, im, fa, partials, nblk, st);
+	else launch_mc_am<MTFHIP_AM_SSD>(bv, im, fa, partials, nblk, st);
+}
+
+} // namespace mtfhip

@@ -48,6 +48,7 @@ struct PixIn {
 	double z;
 	double i0;
 	double j0[MODE == 0 ? 1 : S];
+	int ch;   /* MC: the row's channel */
 };
 /* warped position of a grid point and the four texels of its bilinear cell, fetched one row ahead */
 struct Tex {
@@ -85,7 +86,15 @@ __device__ __forceinline__ double uniform_fresh_load(const double *p) {
 	const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
 	return __hiloint2double(hi, lo);
 }
-template <int AM, int SSM, bool CHAINED, int MODE, bool MAT, bool FAST = false, bool PERSIST = false>
+/* MC (kernels_fused_mc.hip): the multi-channel models -- MCSSD / MCNCC = SSD / NCC constructed with n_channels = 3 (AM/src/MCSSD.cc)
+ * -- through the same pass.  A row of every per-pixel array is a (pixel, channel) pair, row = pixel * C + channel
+ * (mc::getPixVals imgUtils.cc:867-882): the grid point is the pixel's, the texels are the channel's (interleaved image), and
+ * the interpolant is evaluated in mc::PixVal's order -- the four weights first, then the weighted texels (imgUtils.h:505-551). */
+__device__ __forceinline__ double bilin_mc(double t00, double t01, double t10, double t11, double dx, double dy) {
+	const double ly_lx = (1 - dx) * (1 - dy), ly_ux = dx * (1 - dy), uy_lx = (1 - dx) * dy, uy_ux = dx * dy;
+	return t00 * ly_lx + t01 * ly_ux + t10 * uy_lx + t11 * uy_ux;
+}
+template <int AM, int SSM, bool CHAINED, int MODE, bool MAT, bool FAST = false, bool PERSIST = false, bool MC = false>
 __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk) {
 	constexpr int S = (SSM == MTFHIP_SSM_HOMOGRAPHY) ? 8 : 6;
 	constexpr bool NCC = AM == MTFHIP_AM_NCC;
@@ -121,9 +130,11 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 		W = load_warp(wsrc);
 		st2 = st[2]; st3 = st[3]; st4 = st[4]; st5 = st[5];
 	}
-	const double2 *__restrict__ ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * N;
-	const double *__restrict__ iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * N;
-	const double2 *__restrict__ ih = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]) + (size_t)t * N;
+	static_assert(!(MC && FAST), "the multi-channel pass has no tolerance-mode form");
+	const unsigned NPt = MC ? (unsigned)bv.NP : N, Cc = MC ? (unsigned)bv.C : 1u;   /* points per target, channels */
+	const double2 *__restrict__ ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * NPt;
+	const double *__restrict__ iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * NPt;
+	const double2 *__restrict__ ih = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]) + (size_t)t * NPt;
 	const double *__restrict__ I0 = bv.buf[MTFHIP_BUF_I0] + (size_t)t * N;
 	const double *__restrict__ J0 = bv.buf[MTFHIP_BUF_J0] + (size_t)t * N * S;
 	const double *__restrict__ dI0 = bv.buf[MTFHIP_BUF_DI0_DX] + (size_t)t * N * 2;
@@ -151,9 +162,11 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 	auto load_in = [&](unsigned i, auto uz, auto jr) {
 		PixIn<S, MODE> in;
 		constexpr bool JR = decltype(jr)::value;   /* J0 rows rebuilt from dI0_dx (2 loads) instead of read back (S loads) */
+		const unsigned pi = MC ? i / Cc : i;   /* the row's pixel */
+		if constexpr (MC) in.ch = (int)(i - pi * Cc);
 #if MTFHIP_NT_LOAD
 		typedef double d2v __attribute__((ext_vector_type(2)));
-		{ const d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(ip) + i); in.p = make_double2(v.x, v.y); }
+		{ const d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(ip) + pi); in.p = make_double2(v.x, v.y); }
 		in.i0 = __builtin_nontemporal_load(&I0[i]);
 		if constexpr (MODE != 0) {
 #pragma unroll
@@ -161,8 +174,9 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 		} else {
 			in.j0[0] = 0;
 		}
+		const unsigned o16 = pi * 16u, oz = pi * 8u;
 #else
-		const unsigned o8 = i * 8u, o16 = i * 16u;
+		const unsigned o8 = i * 8u, o16 = pi * 16u, oz = pi * 8u;
 		in.p = ld_off<double2>(ip, o16);
 		in.i0 = ld_off<double>(I0, o8);
 		if constexpr (MODE != 0 && JR) {
@@ -175,7 +189,7 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 		}
 #endif
 		if constexpr (decltype(uz)::value) { in.hp = make_double2(0.0, 0.0); in.z = 1.0; }   /* hp is taken from p at use */
-		else { in.hp = ld_off<double2>(ih, o16); in.z = ld_off<double>(iz, o8); }
+		else { in.hp = ld_off<double2>(ih, o16); in.z = ld_off<double>(iz, oz); }
 		return in;
 	};
 	/* curr_pts_hm = curr_warp * init_pts_hm and its dehomogenisation (Homography.cc:86-90, Affine.cc:104),
@@ -210,13 +224,13 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 		/* in_cell(wx, wy, (int)wx, (int)wy) with the trivially true terms dropped, and both upper neighbours inside */
 		tx.ok = (tx.wx >= 0) & (tx.wy >= 0) & (tx.wx != tx.lxd) & (tx.wy != tx.lyd) & (tx.lx < iw - 1) & (tx.ly < ih_ - 1);
 		const int sx = tx.ok ? tx.lx : 0, sy = tx.ok ? tx.ly : 0;
-		const unsigned to = (unsigned)(sy * istride + sx) * 4u;
+		const unsigned to = MC ? (unsigned)(sy * istride + sx * (int)Cc + in.ch) * 4u : (unsigned)(sy * istride + sx) * 4u;
 #ifdef MTFHIP_EXPERIMENT_NOTEX
 		tx.t00 = tx.t01 = tx.t10 = tx.t11 = (float)in.i0; (void)to;
 #else
 		const float *r0 = reinterpret_cast<const float *>(reinterpret_cast<const char *>(img) + to);
 		const float *r1 = reinterpret_cast<const float *>(reinterpret_cast<const char *>(img_row1) + to);
-		tx.t00 = r0[0]; tx.t01 = r0[1]; tx.t10 = r1[0]; tx.t11 = r1[1];
+		tx.t00 = r0[0]; tx.t01 = r0[MC ? Cc : 1u]; tx.t10 = r1[0]; tx.t11 = r1[MC ? Cc : 1u];
 #endif
 		return tx;
 	};
@@ -287,14 +301,23 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 			if constexpr (MODE != 2) { gx = bgx * fa.norm_mult; gy = bgy * fa.norm_mult; }
 		} else if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
 			const double t00 = tcur.t00, t01 = tcur.t01, t10 = tcur.t10, t11 = tcur.t11;
-			it = fa.norm_mult * bilin(t00, t01, t10, t11, wx - lxd, wy - lyd) + fa.norm_add;
+			auto bl = [&](double dx, double dy) { if constexpr (MC) return bilin_mc(t00, t01, t10, t11, dx, dy); else return bilin(t00, t01, t10, t11, dx, dy); };
+			it = fa.norm_mult * bl(wx - lxd, wy - lyd) + fa.norm_add;
 			if constexpr (MODE != 2) {
-				double inc = bilin(t00, t01, t10, t11, px0 - lxd, py0 - lyd);
-				double dec = bilin(t00, t01, t10, t11, px1 - lxd, py1 - lyd);
+				double inc = bl(px0 - lxd, py0 - lyd);
+				double dec = bl(px1 - lxd, py1 - lyd);
 				gx = (inc - dec) * gmult;
-				inc = bilin(t00, t01, t10, t11, px2 - lxd, py2 - lyd);
-				dec = bilin(t00, t01, t10, t11, px3 - lxd, py3 - lyd);
+				inc = bl(px2 - lxd, py2 - lyd);
+				dec = bl(px3 - lxd, py3 - lyd);
 				gy = (inc - dec) * gmult;
+			}
+		} else if constexpr (MC) {
+			/* border / integer coordinates: the general sampler, sample by sample (mc::getPixVals, mc::getImgGrad imgUtils.cc:867-1005) */
+			const int ch = cur.ch;
+			it = fa.norm_mult * pix_val_mc(im, wx, wy, ch) + fa.norm_add;
+			if constexpr (MODE != 2) {
+				gx = (pix_val_mc(im, px0, py0, ch) - pix_val_mc(im, px1, py1, ch)) * gmult;
+				gy = (pix_val_mc(im, px2, py2, ch) - pix_val_mc(im, px3, py3, ch)) * gmult;
 			}
 		} else {
 			const Cell c = load_cell(im, wx, wy);

@@ -30,9 +30,9 @@ class LKTracker:
     (mtfhip_batch_track)."""
 
     def __init__(self, ctx, sm, ssm=L.SSM_HOMOGRAPHY, resx=50, resy=50, n_targets=1, host_solve=True, am=L.AM_SSD,
-                 **params):
+                 am_params=None, **params):
         self.ctx = ctx
-        self.batch = Batch(ctx, am, ssm, resx, resy, n_targets)
+        self.batch = Batch(ctx, am, ssm, resx, resy, n_targets, **(am_params or {}))   # e.g. n_channels=3: MCSSD / MCNCC
         self.B, self.S = n_targets, self.batch.S
         self.host_solve = host_solve
         self.sm = sm_desc(sm, **params)

@@ -390,10 +390,38 @@ def test_multichannel_models_match_oracle(oracle, gpu_ctx, case):
     gpu_ctx.set_image(np.ascontiguousarray(frame[..., 0]))
     with pytest.raises(mtf_amd.InvalidArgument):
         nt.batch.update_pix_vals()
-    # the fused / candidate paths are single-channel only
-    gpu_ctx.set_image(frame)
-    with pytest.raises(mtf_amd.FunctionNotImplemented):
-        nt.batch.init_template(nt.sm)
+    # the fused iteration (k_fused_mc: one launch per iteration over (pixel, channel) rows) serves MCSSD / MCNCC: the same numbers
+    # as the call-by-call path above, through batch.iterate + host solve and through the device-side loop (batch.track);
+    # MCMI and the second-order Hessians stay with the per-function entry points and say so
+    fused_ok = am != L.AM_MI and not so
+    for host_solve in (True, False):
+        gpu_ctx.set_image(frame)
+        if am == L.AM_MI:
+            with pytest.raises(mtf_amd.FunctionNotImplemented):
+                nt.batch.init_template(nt.sm)
+            break
+        lk = LKTracker(gpu_ctx, sm_kind, ssm, res, res, 1, host_solve=host_solve, am=am, am_params=dict(n_channels=3), **params)
+        lk.initialize(corners[None])
+        gpu_ctx.set_image(frame2)
+        if not fused_ok:
+            with pytest.raises(mtf_amd.FunctionNotImplemented):
+                lk.update()
+            lk.batch.close()
+            continue
+        if host_solve:
+            f, g, H = lk.batch.iterate(lk.sm)
+            assert abs(f[0] - rec["f"]) <= 1e-7 * abs(rec["f"])
+            assert np.linalg.norm(H[0] - rec["H"]) <= 1e-5 * np.linalg.norm(rec["H"])
+            assert np.linalg.norm(g[0] - rec["g"]) <= 1e-4 * gs
+            # the interface-visible arrays of a materialising launch are the bits of the per-function kernels
+            nt2 = NTSearchMethod(gpu_ctx, sm_kind, am, ssm, res, res, 1, am_params=dict(n_channels=3), **params)
+            gpu_ctx.set_image(frame); nt2.initialize(corners[None]); gpu_ctx.set_image(frame2)
+            nt2.batch.update_pix_vals()
+            assert np.array_equal(lk.batch.read(L.BUF_IT), nt2.batch.read(L.BUF_IT))
+            nt2.batch.close()
+        out = lk.update()
+        np.testing.assert_allclose(out[0], otrk.get_region(), atol=5e-4)
+        lk.batch.close()
 
 
 @pytest.mark.parametrize("am", [L.AM_SSD, L.AM_NCC])
