@@ -110,6 +110,34 @@ def main():
         lik.append(np.exp(-1.0 * np.sqrt(0.5 * float(r @ r) / I0.size)))
     out.update({"pf_corners": corners, "pf_states": states, "pf_likelihood": np.array(lik)})
 
+    # --- second order: affine + SSD, chained warp, 22 x 22 (FCLK / ESM with sec_ord_hess): the image Hessian is the reference's
+    # nine-sample stencil at hess_eps = 1 (imgUtils.cc:334-366) at the warped points; the pixel Hessian of I(A u + t) with
+    # respect to the compositional affine parameters is P^T (A2^T Hess A2) P -- the warp is linear in its parameters, so
+    # there is no second term (Affine.cc:264-291) -- and SSD's second-order current Hessian adds sum_p df_dIt[p] times it
+    # to -Jt^T Jt (SSDBase.cc:334-342, df_dIt = -(It - I0))
+    res = 22
+    corners = synth.square_corners(98, 92, 66)
+    init_pts, init_hm = R.grid_from_corners(corners, res, res, affine=True)
+    x, y = init_pts
+    I0 = R.bilinear(img, x, y)
+    pa = rng.uniform(-1, 1, 6) * [1.2, 1.2, 0.02, 0.02, 0.02, 0.02]
+    A = R.aff_matrix(pa)
+    wx, wy = (A @ np.vstack([x, y, np.ones_like(x)]))[:2]
+    It = R.bilinear(img, wx, wy)
+    P = R.aff_param_jacobian(x, y)
+    Jt = R.sd_rows_chained(R.img_grad(img, np.stack([wx, wy])), np.broadcast_to(A[:2, :2], (x.size, 2, 2)), P)
+    c = R.bilinear(img, wx, wy)
+    Hi = np.empty((x.size, 2, 2))
+    Hi[:, 0, 0] = (R.bilinear(img, wx + 2, wy) + R.bilinear(img, wx - 2, wy) - 2 * c) / 4
+    Hi[:, 1, 1] = (R.bilinear(img, wx, wy + 2) + R.bilinear(img, wx, wy - 2) - 2 * c) / 4
+    Hi[:, 0, 1] = Hi[:, 1, 0] = ((R.bilinear(img, wx + 1, wy + 1) + R.bilinear(img, wx - 1, wy - 1)) -
+                                 (R.bilinear(img, wx + 1, wy - 1) + R.bilinear(img, wx - 1, wy + 1))) / 4
+    Hw = np.einsum("ia,nij,jb->nab", A[:2, :2], Hi, A[:2, :2])
+    D = np.einsum("nis,nij,njt->nst", P, Hw, P)
+    so_H = -(Jt.T @ Jt) + np.einsum("n,nst->st", -(It - I0), D)
+    out.update({"so_corners": corners, "so_p": pa, "so_img_hess_head": Hi[:16].reshape(16, 4), "so_pix_hess_head": D[:8],
+                "so_H_curr2": so_H})
+
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lk_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -186,3 +186,49 @@ def test_config5_mi_400x400_64_targets(gpu_ctx):
     np.testing.assert_allclose(one.trace[0]["H"][0], nt.trace[0]["H"][20], rtol=1e-10)
     np.testing.assert_allclose(one.trace[0]["g"][0], nt.trace[0]["g"][20], rtol=1e-8, atol=1e-12)
     assert abs(one.trace[0]["f"][0] - nt.trace[0]["f"][20]) <= 1e-12 * abs(nt.trace[0]["f"][20])
+
+
+@pytest.mark.parametrize("math", ["fast", "replay"])
+def test_config5_mi_device_loop_full_size(gpu_ctx, math):
+    """Config 5 at full size through mtfhip_batch_track -- the recompute passes (k_mi_pass_hist, k_mi_pass_grad_hess: nothing N-sized
+    written) + the device-side finish: the trajectory of the call-by-call search method above (the interface-level path
+    over the materialising kernels) is followed by every target, MI rises, and the regions land where the ground truth says."""
+    from mtf_amd.sm import LKTracker
+    f0 = synth.make_frame(2048, 2048)
+    p_true = synth.random_small_homography(np.random.default_rng(3), 0.2)
+    f1 = synth.warp_frame(f0, p_true, (1024.0, 1024.0))
+    B = 64
+    rng = np.random.default_rng(11)
+    cx = rng.uniform(450, 1600, B); cy = rng.uniform(450, 1600, B)
+    corners = np.stack([synth.square_corners(cx[i], cy[i], 400) for i in range(B)])
+    n_it = 4
+    gpu_ctx.set_image(f0)
+    nt = NTSearchMethod(gpu_ctx, L.SM_ESM, L.AM_MI, L.SSM_HOMOGRAPHY, 400, 400, B, max_iters=n_it, epsilon=-1.0)
+    nt.initialize(corners)
+    gpu_ctx.set_image(f1)
+    nt.update()
+    ref = nt.get_region().copy()
+    nt.batch.close()
+    gpu_ctx.set_image(f0)
+    trk = LKTracker(gpu_ctx, L.SM_ESM, L.SSM_HOMOGRAPHY, 400, 400, B, host_solve=False, am=L.AM_MI, max_iters=n_it, epsilon=-1.0,
+                    leven_marq=0, materialize=0)
+    trk.batch.set_math_mode(mtf_amd.MATH_FAST if math == "fast" else mtf_amd.MATH_REPLAY)
+    trk.initialize(corners)
+    gpu_ctx.set_image(f1)
+    out = trk.update()
+    assert np.all(trk.n_iters == n_it)
+    want = np.stack([gt_corners(corners[t], p_true, (1024.0, 1024.0)) for t in range(B)])
+    before = np.abs(corners - want).max(axis=(1, 2)); after = np.abs(out - want).max(axis=(1, 2))
+    assert np.all(after < 0.5 * before)
+    # the same trajectory as the call-by-call path: MI's update moves by 1.5-2.8e-5 relative under a one-ulp change of the grid
+    # (test_mi_update_noise_floor), four iterations of 400-pixel-wide corners stay within a few 1e-3 px of each other
+    assert np.abs(out - ref).max() < 5e-3
+    # replay arithmetic: a target tracked alone follows the same path (batch independence of the recompute passes)
+    if math == "replay":
+        gpu_ctx.set_image(f0)
+        one = LKTracker(gpu_ctx, L.SM_ESM, L.SSM_HOMOGRAPHY, 400, 400, 1, host_solve=False, am=L.AM_MI, max_iters=n_it, epsilon=-1.0,
+                        leven_marq=0, materialize=0)
+        one.batch.set_math_mode(mtf_amd.MATH_REPLAY)
+        one.initialize(corners[20][None])
+        gpu_ctx.set_image(f1)
+        np.testing.assert_allclose(one.update()[0], out[20], rtol=0, atol=1e-6)   # (its own workgroup decomposition: summation order only)

@@ -123,6 +123,28 @@ def test_mi_golden(oracle, img):
     assert rel(oracle.colpiv_qr_solve(H, g), np.linalg.solve(G["mi_H_curr"], G["mi_g_curr"])) < 1e-4   # (the MI Hessian amplifies: noise floor test)
 
 
+def test_second_order_affine_ssd_golden(oracle, img):
+    """sec_ord_hess: the nine-sample image Hessian at the warped points, the affine pixel Hessian of the chained warp and SSD's
+    second-order current Hessian of the C++ oracle against the NumPy re-derivation (make_golden.py)."""
+    res = 22
+    ssm = oracle.SSM(oracle.SSM_AFF, res, res)
+    am = oracle.AM(oracle.AM_SSD, res, res)
+    am.set_curr_img(img)
+    ssm.set_corners(G["so_corners"])
+    pts0 = ssm.get("curr_pts")
+    am.initialize_pix_vals(pts0); am.initialize_pix_grad_pts(pts0); am.initialize_pix_hess_pts(pts0)
+    am.initialize_similarity(); am.initialize_grad(); am.initialize_hess()
+    ssm.set_state(G["so_p"])
+    pts = ssm.get("curr_pts")
+    am.update_pix_vals(pts); am.update_pix_grad_pts(pts); am.update_pix_hess_pts(pts)
+    am.update_similarity(False); am.update_curr_grad(); am.update_init_grad()
+    np.testing.assert_allclose(am.get("d2It_dx2").reshape(-1, 4)[:16], G["so_img_hess_head"], rtol=0, atol=1e-10)
+    Jt = ssm.cmpt_warped_pix_jacobian(am.get("dIt_dx"))
+    Dt = ssm.cmpt_warped_pix_hessian(am.get("d2It_dx2"), am.get("dIt_dx"))
+    assert rel(Dt[:8], G["so_pix_hess_head"]) < 1e-10
+    assert rel(am.cmpt_curr_hessian2(Jt, Dt), G["so_H_curr2"]) < 1e-5
+
+
 def test_pf_scores_golden(oracle, img):
     res = 20
     ssm = oracle.SSM(oracle.SSM_HOM, res, res)
