@@ -366,20 +366,21 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 			 * is harmless).  At a class boundary the two running accumulators -- Q_rel[fl][k][m][s half] -- are added into this
 			 * wave's absolute table: Q[(fl - 1 + k, fl - 1 + m)][s]. */
 			const double *pd = sd + lb * kRS2 + lk, *pw = sw + li * kRS2 + lk, *pr0 = srw + li * kRS2 + lk, *pr1 = pr0 + 4 * kRS2;
-			const double *pha = srw + (4 * (lb >> 1) + li) * kRS2 + lk, *phb = srw + (4 * (lb & 1) + li) * kRS2 + lk, *pht = sht + lk;
+			const double *pht = sht + lk;
+			const bool hx = (lb >> 1) != 0, hy = (lb & 1) != 0;   /* sum hess_term J J^T: block (lb >> 1, lb & 1) of the 8 x 8, from the J operands already held */
 			int c = 0;
 			while (((cs.ends >> (8 * c)) & 255) == 0) ++c;   /* first class with pixels (a chunk has at least one) */
 			int bound = (int)((cs.ends >> (8 * c)) & 255);
 			double acc0 = 0.0, acc1 = 0.0;
-			double o_d = pd[0], o_w = pw[0], o_r0 = pr0[0], o_r1 = pr1[0], o_ha = pha[0], o_hb = phb[0], o_ht = pht[0];
+			double o_d = pd[0], o_w = pw[0], o_r0 = pr0[0], o_r1 = pr1[0], o_ht = pht[0];
 			for (int g = 0; g < cs.total; g += 4) {
-				pd += 4; pw += 4; pr0 += 4; pr1 += 4; pha += 4; phb += 4; pht += 4;
-				const double n_d = pd[0], n_w = pw[0], n_r0 = pr0[0], n_r1 = pr1[0], n_ha = pha[0], n_hb = phb[0], n_ht = pht[0];
+				pd += 4; pw += 4; pr0 += 4; pr1 += 4; pht += 4;
+				const double n_d = pd[0], n_w = pw[0], n_r0 = pr0[0], n_r1 = pr1[0], n_ht = pht[0];
 				const double av = o_d * o_w;   /* block = gradient tap k, row = weight tap m */
 				acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, o_r0, acc0, 0, 0, 0);
 				acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, o_r1, acc1, 0, 0, 0);
-				chs = __builtin_amdgcn_mfma_f64_4x4x4f64(o_ha * o_ht, o_hb, chs, 0, 0, 0);
-				o_d = n_d; o_w = n_w; o_r0 = n_r0; o_r1 = n_r1; o_ha = n_ha; o_hb = n_hb; o_ht = n_ht;
+				chs = __builtin_amdgcn_mfma_f64_4x4x4f64((hx ? o_r1 : o_r0) * o_ht, hy ? o_r1 : o_r0, chs, 0, 0, 0);
+				o_d = n_d; o_w = n_w; o_r0 = n_r0; o_r1 = n_r1; o_ht = n_ht;
 				if (g + 4 == bound) {
 					const int r = c - 1 + lb, cc = c - 1 + lk;   /* result lane: block = k, row = m, column = s in its half */
 					if (r >= 0 && r < nb && cc >= 0 && cc < nb) {
