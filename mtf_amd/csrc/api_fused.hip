@@ -957,7 +957,7 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 
 /* ------------------------------------------------------------------ candidate scoring */
 int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int C, double *dev_lik, double *dev_sim) {
-	FLUSH(b);
+	FLUSH_AM(b);   /* (every candidate warps the template grid itself: CURR_PTS are not read) */
 	if (!b || !dev_states) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: NULL argument");
 	if (C <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: n_candidates must be positive");
 	if (b->desc.am == MTFHIP_AM_MI) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "score_candidates: SSD and NCC");

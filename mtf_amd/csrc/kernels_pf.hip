@@ -221,27 +221,46 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_weights(PfResampleArgs a) {
 	const int lo = min(tid * per, n), hi = min(lo + per, n);
 	const double pi = 3.14159265358979323846;
 	const double mfac = 1.0 / sqrt(2 * pi * a.measurement_sigma);   /* PF.cc:69-70 */
-	/* particle_wts (PF.cc:348-365) and their running sum */
-	double run = 0;
-	for (int k = lo; k < hi; ++k) {
-		double w;
-		if (a.likelihood_func == 0) w = a.lik[k];
-		else {
-			const double val = a.max_similarity - a.sim[k];
-			w = a.likelihood_func == 1 ? mfac * exp(-0.5 * val / a.measurement_sigma) : 1.0 / (1.0 + val);
-		}
-		a.wts[k] = w;
-		run += w;
-	}
-	double total;
-	const double incl = block_scan_incl(run, lds, total);
-	{
-		double c = incl - run;
-		for (int k = lo; k < hi; ++k) { c += a.wts[k]; a.cum[k] = c / total; }   /* particle_cum_wts /= particle_cum_wts[n - 1] */
-	}
-	/* the highest weighted particle, last index on ties (`>=`, PF.cc:378-381) */
+	/* particle_wts (PF.cc:348-365) and their running sum.  Up to 16 particles per thread (n <= 16 384) the run lives in registers:
+	 * every load is issued before the first use and nothing is read back -- the loop form below re-reads wts[] after writing
+	 * cum[] through pointers the compiler must assume to alias, one dependent memory round trip per particle (15 of the
+	 * kernel's 24 us at 10 000 particles).  Same operations in the same order either way. */
+	constexpr int kRun = 16;
+	auto weight = [&](double lik, double sim) -> double {
+		if (a.likelihood_func == 0) return lik;
+		const double val = a.max_similarity - sim;
+		return a.likelihood_func == 1 ? mfac * exp(-0.5 * val / a.measurement_sigma) : 1.0 / (1.0 + val);
+	};
+	double run = 0, total;
 	double bv = -1.7976931348623157e308; int bi = -1;
-	for (int k = lo; k < hi; ++k) if (a.wts[k] >= bv) { bv = a.wts[k]; bi = k; }
+	if (per <= kRun) {
+		double wv[kRun];
+		const double *src = a.likelihood_func == 0 ? a.lik : a.sim;
+#pragma unroll
+		for (int j = 0; j < kRun; ++j) wv[j] = lo + j < hi ? src[lo + j] : 0.0;
+#pragma unroll
+		for (int j = 0; j < kRun; ++j)
+			if (lo + j < hi) { wv[j] = a.likelihood_func == 0 ? wv[j] : weight(0.0, wv[j]); run += wv[j]; }
+		const double incl = block_scan_incl(run, lds, total);
+		double c = incl - run;
+#pragma unroll
+		for (int j = 0; j < kRun; ++j)
+			if (lo + j < hi) {
+				c += wv[j];
+				a.wts[lo + j] = wv[j]; a.cum[lo + j] = c / total;   /* particle_cum_wts /= particle_cum_wts[n - 1] */
+				if (wv[j] >= bv) { bv = wv[j]; bi = lo + j; }         /* the highest weighted particle, last index on ties (`>=`, PF.cc:378-381) */
+			}
+	} else {
+		for (int k = lo; k < hi; ++k) {
+			const double w = weight(a.likelihood_func == 0 ? a.lik[k] : 0.0, a.likelihood_func == 0 ? 0.0 : a.sim[k]);
+			a.wts[k] = w;
+			run += w;
+		}
+		const double incl = block_scan_incl(run, lds, total);
+		double c = incl - run;
+		for (int k = lo; k < hi; ++k) { c += a.wts[k]; a.cum[k] = c / total; }
+		for (int k = lo; k < hi; ++k) if (a.wts[k] >= bv) { bv = a.wts[k]; bi = k; }
+	}
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1) {
 		const double ov = __shfl_xor(bv, d); const int oi = __shfl_xor(bi, d);
@@ -259,8 +278,17 @@ constexpr int kPfPart = 18;
 __global__ __launch_bounds__(kBlock) void k_pf_select(PfResampleArgs a, double *parts) {
 	__shared__ double red_v[kBlock / 64]; __shared__ int red_i[kBlock / 64];
 	__shared__ double lds[4 * 16];
+	/* every kCoarse-th (or coarser) cumulative weight: the first levels of each particle's binary search run out of LDS instead of
+	 * being fourteen dependent global loads (10 of the kernel's 14.6 us) */
+	constexpr int kCoarse = 2048;
+	__shared__ double coarse[kCoarse];
 	const int n = a.n, S = a.S, tid = threadIdx.x, k = blockIdx.x * kBlock + tid;
 	const bool resample = a.resampling_type == 1 || a.resampling_type == 2;
+	const int cstride = max(32, (n + kCoarse - 1) / kCoarse), ncoarse = (n + cstride - 1) / cstride;
+	if (resample) {
+		for (int j = tid; j < ncoarse; j += kBlock) coarse[j] = a.cum[min((j + 1) * cstride, n) - 1];   /* last element of block j */
+		__syncthreads();
+	}
 	double bv = -1.7976931348623157e308; int bi = -1;
 	double acc[16];
 #pragma unroll
@@ -271,7 +299,12 @@ __global__ __launch_bounds__(kBlock) void k_pf_select(PfResampleArgs a, double *
 			/* multinomial resampling (PF.cc:455-502 binary search; :505-536 linear search: the same smallest index whose
 			 * normalised cumulative weight reaches the draw), into the other particle set */
 			const double u = a.uniforms ? a.uniforms[k] : philox_uniform(a.seed, a.iter, (unsigned)k);
-			int l = 0, h = n - 1;
+			/* the smallest index whose normalised cumulative weight reaches the draw: first the block (its last element reaches
+			 * it), then inside the block -- the index the one-level search over cum[] returns */
+			int l = 0, h = ncoarse - 1;
+			int j = (l + h) / 2;
+			while (h > l) { if (coarse[j] >= u) h = j; else l = j + 1; j = (l + h) / 2; }
+			l = j * cstride; h = min(l + cstride, n) - 1;
 			id = (l + h) / 2;
 			while (h > l) { if (a.cum[id] >= u) h = id; else l = id + 1; id = (l + h) / 2; }
 			if (a.ids) a.ids[k] = id;
@@ -317,15 +350,25 @@ __global__ __launch_bounds__(64) void k_pf_estimate(PfResampleArgs a, const doub
 	const int lane = threadIdx.x, S = a.S, n = a.n;
 	const bool resample = a.resampling_type == 1 || a.resampling_type == 2;
 	const double *st_final = resample ? a.st_out : a.st_in;
+	/* the per-workgroup rows are fetched by all lanes at once into LDS and folded from there in workgroup order (a loop of
+	 * dependent global loads was 12 of this kernel's 16 us) */
+	constexpr int kStage = 256;   /* rows staged: 65 536 particles; beyond that the rows are read from memory */
+	__shared__ double rows[kStage * kPfPart];
+	const bool staged = nparts <= kStage;
+	if (staged) {
+		for (int q = lane; q < nparts * kPfPart; q += 64) rows[q] = parts[q];
+		__syncthreads();
+	}
+	const double *pr = staged ? rows : parts;
 	/* best over the workgroups, in workgroup order (= particle order): last index on ties */
 	double bv = a.out[8]; int bi = (int)a.out[9];
 	if (resample) {
 		bv = -1.7976931348623157e308; bi = -1;
-		for (int w = 0; w < nparts; ++w) { const double v = parts[(size_t)w * kPfPart]; const int i2 = (int)parts[(size_t)w * kPfPart + 1]; if (v > bv || (v == bv && i2 > bi)) { bv = v; bi = i2; } }
+		for (int w = 0; w < nparts; ++w) { const double v = pr[(size_t)w * kPfPart]; const int i2 = (int)pr[(size_t)w * kPfPart + 1]; if (v > bv || (v == bv && i2 > bi)) { bv = v; bi = i2; } }
 	}
 	if (lane < 16) {
 		double s = 0;
-		for (int w = 0; w < nparts; ++w) s += parts[(size_t)w * kPfPart + 2 + lane];
+		for (int w = 0; w < nparts; ++w) s += pr[(size_t)w * kPfPart + 2 + lane];
 		if (a.mean_type == 1 && lane < S) a.out[lane] = s / (double)n;             /* estimateMeanOfSamples :311-317 */
 		if (a.mean_type == 2 && lane >= 8) a.out[10 + lane - 8] = s / (double)n;   /* mean corners */
 	}
