@@ -246,6 +246,7 @@ int mtfhip_pf_iteration(mtfhip_pf *pf, const double *normals, const double *unif
 		p.uniforms = pf->d_uniforms;
 	}
 	double *stc = pf->d_states[pf->cur], *arc = pf->d_ars[pf->cur];
+	unsigned long long pub_seq = 0;
 	{
 		TimedScope ts(b->ctx, "pf_propagate");
 		launch_pf_propagate(b->desc.ssm, p, stc, arc, st);
@@ -269,17 +270,16 @@ int mtfhip_pf_iteration(mtfhip_pf *pf, const double *normals, const double *unif
 	}
 	{
 		TimedScope ts(b->ctx, "pf_resample");
+		if (b->h_acc_dev) pub_seq = ++b->acc_seq;
 		launch_pf_resample(b->desc.ssm, p, pf->d_lik, pf->d_sim, pf->d_wts, pf->d_cum, stc, arc, pf->d_states[1 - pf->cur], pf->d_ars[1 - pf->cur],
-			pf->d_ids, pf->d_out, pf->d_parts, st);
+			pf->d_ids, pf->d_out, pf->d_parts, pub_seq ? b->h_acc_dev : nullptr, b->h_flag_dev, pub_seq, st);
 	}
 	if (p.resampling_type == 1 || p.resampling_type == 2) pf->cur = 1 - pf->cur;   /* curr_set_id = 1 - curr_set_id (PF.cc:501) */
 	/* the estimate (32 doubles) comes back through host-coherent pinned memory + the flag the host spins on, like every other
 	 * per-iteration result of the library (a copy into pageable memory + stream synchronisation was 15 us of a 137 us iteration) */
 	double out[32];
-	if (b->h_acc_dev) {
-		const unsigned long long seq = ++b->acc_seq;
-		launch_publish_host(pf->d_out, b->h_acc_dev, sizeof(out), b->d_fin_count, b->h_flag_dev, seq, st);
-		TRY(wait_host_flag(b, seq));
+	if (pub_seq) {   /* k_pf_estimate delivered it itself */
+		TRY(wait_host_flag(b, pub_seq));
 		std::memcpy(out, b->h_acc, sizeof(out));
 	} else {
 		HIP_TRY(hipMemcpyAsync(out, pf->d_out, sizeof(out), hipMemcpyDeviceToHost, st));

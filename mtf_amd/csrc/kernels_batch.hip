@@ -525,21 +525,15 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 			const int ick = (tid + k * kBlock < N) ? tid + k * kBlock : N - 1;
 			const double2 hp = HOIST_P ? hpv[HOIST_P ? k : 0] : (bv.unit_z ? ip[ick] : ih[ick]);
 			const double z = HOIST_P ? zv[HOIST_P ? k : 0] : (bv.unit_z ? 1.0 : iz[ick]);
-			double wx, wy, v;
-			if constexpr (FAST) {
-				wx = fma(W[0], hp.x, fma(W[1], hp.y, W[2] * z)); wy = fma(W[3], hp.x, fma(W[4], hp.y, W[5] * z));
-				if (hom) { const double inv = rcp_fast(fma(W[6], hp.x, fma(W[7], hp.y, W[8] * z))); wx *= inv; wy *= inv; }
-				v = fma(norm_mult, pix_val_fast(im, wx, wy), norm_add);
+			double wx, wy, v;   /* (replay arithmetic: the tolerance-mode loop above has returned) */
+			if (hom) {
+				const double cx = W[0] * hp.x + W[1] * hp.y + W[2] * z, cy = W[3] * hp.x + W[4] * hp.y + W[5] * z;
+				const double d = W[6] * hp.x + W[7] * hp.y + W[8] * z;
+				wx = cx / d; wy = cy / d;
 			} else {
-				if (hom) {
-					const double cx = W[0] * hp.x + W[1] * hp.y + W[2] * z, cy = W[3] * hp.x + W[4] * hp.y + W[5] * z;
-					const double d = W[6] * hp.x + W[7] * hp.y + W[8] * z;
-					wx = cx / d; wy = cy / d;
-				} else {
-					wx = W[0] * hp.x + W[1] * hp.y + W[2] * z; wy = W[3] * hp.x + W[4] * hp.y + W[5] * z;
-				}
-				v = norm_mult * pix_val_select(im, wx, wy) + norm_add;
+				wx = W[0] * hp.x + W[1] * hp.y + W[2] * z; wy = W[3] * hp.x + W[4] * hp.y + W[5] * z;
 			}
+			v = norm_mult * pix_val_select(im, wx, wy) + norm_add;
 			itv[k] = (tid + k * kBlock < N) ? v : 0.0;
 		}
 #pragma unroll

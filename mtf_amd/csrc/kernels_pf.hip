@@ -346,7 +346,10 @@ __global__ __launch_bounds__(kBlock) void k_pf_select(PfResampleArgs a, double *
 	__syncthreads();
 	block_reduce_store<16>(acc, part + 2, lds);
 }
-__global__ __launch_bounds__(64) void k_pf_estimate(PfResampleArgs a, const double *parts, int nparts) {
+/* (pub: the 32 doubles of `out` also go to host-coherent memory, followed by the sequence number the host spins on -- the estimate is
+ * what nt::PF reads back every iteration for its convergence test) */
+struct PfPublish { double *host; unsigned long long *flag, seq; };
+__global__ __launch_bounds__(64) void k_pf_estimate(PfResampleArgs a, const double *parts, int nparts, PfPublish pub) {
 	const int lane = threadIdx.x, S = a.S, n = a.n;
 	const bool resample = a.resampling_type == 1 || a.resampling_type == 2;
 	const double *st_final = resample ? a.st_out : a.st_in;
@@ -374,6 +377,13 @@ __global__ __launch_bounds__(64) void k_pf_estimate(PfResampleArgs a, const doub
 	}
 	if (a.mean_type != 1 && lane < S) a.out[lane] = st_final[(size_t)bi * S + lane];
 	if (lane == 0) { a.out[8] = bv; a.out[9] = (double)bi; }
+	if (pub.host) {
+		__threadfence();
+		__syncthreads();
+		if (lane < 32) __hip_atomic_store(pub.host + lane, ld_coh(a.out + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		__threadfence_system();
+		if (lane == 0) __hip_atomic_store(pub.flag, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
 }
 
 /* PF::initializeParticles (PF.cc:185-197): every particle at the current state, AR terms zero */
@@ -397,7 +407,8 @@ void launch_pf_propagate(int ssm, const PfLaunch &p, double *states, double *ars
 	else MTFHIP_LAUNCH(k_pf_propagate<MTFHIP_SSM_AFFINE>, g, dim3(kBlock), 0, st, a, states, ars);
 }
 void launch_pf_resample(int ssm, const PfLaunch &p, const double *lik, const double *sim, double *wts, double *cum, const double *st_in,
-	const double *ar_in, double *st_out, double *ar_out, int *ids, double *out, double *parts, hipStream_t st) {
+	const double *ar_in, double *st_out, double *ar_out, int *ids, double *out, double *parts, double *host_out, unsigned long long *host_flag,
+	unsigned long long seq, hipStream_t st) {
 	PfResampleArgs a;
 	a.n = p.n; a.S = p.S; a.ssm = ssm; a.likelihood_func = p.likelihood_func; a.resampling_type = p.resampling_type; a.mean_type = p.mean_type;
 	a.measurement_sigma = p.measurement_sigma; a.max_similarity = p.max_similarity; a.seed = p.seed; a.iter = p.iter; a.uniforms = p.uniforms;
@@ -407,7 +418,7 @@ void launch_pf_resample(int ssm, const PfLaunch &p, const double *lik, const dou
 	const int nparts = (p.n + kBlock - 1) / kBlock;
 	MTFHIP_LAUNCH(k_pf_weights, dim3(1), dim3(kPfBlock), 0, st, a);
 	MTFHIP_LAUNCH(k_pf_select, dim3(nparts), dim3(kBlock), 0, st, a, parts);
-	MTFHIP_LAUNCH(k_pf_estimate, dim3(1), dim3(64), 0, st, a, parts, nparts);
+	MTFHIP_LAUNCH(k_pf_estimate, dim3(1), dim3(64), 0, st, a, parts, nparts, PfPublish{host_out, host_flag, seq});
 }
 void launch_pf_fill(int n, int S, const double *dev_state, double *states, double *ars, hipStream_t st) {
 	MTFHIP_LAUNCH(k_pf_fill, dim3((n + 255) / 256), dim3(256), 0, st, n, S, dev_state, states, ars);

@@ -233,7 +233,8 @@ struct PfLaunch {
 };
 void launch_pf_propagate(int ssm, const PfLaunch &p, double *states, double *ars, hipStream_t st);
 void launch_pf_resample(int ssm, const PfLaunch &p, const double *lik, const double *sim, double *wts, double *cum, const double *st_in,
-	const double *ar_in, double *st_out, double *ar_out, int *ids, double *out, double *parts /* [ceil(n / 256)][18] */, hipStream_t st);
+	const double *ar_in, double *st_out, double *ar_out, int *ids, double *out, double *parts, double *host_out /* or NULL */,
+	unsigned long long *host_flag, unsigned long long seq, hipStream_t st);
 void launch_pf_fill(int n, int S, const double *dev_state, double *states, double *ars, hipStream_t st);
 /* sums partials over blocks: out[B][ACC_COUNT] */
 void launch_finish(double *partials, int nblk, double *out, int B, hipStream_t st);
