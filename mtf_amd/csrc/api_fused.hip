@@ -805,9 +805,12 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 	/* The loop is enqueued without waiting for the device, so iterations after the last target has converged would still be
 	 * launched (kernels that find every flag cleared, a few microseconds each).  With a reachable convergence test the flags are
 	 * looked at every eighth iteration: one small copy + sync against up to seven idle iterations. */
+	/* passes to enqueue: a rejected Levenberg-Marquardt step does not consume an iteration of FCLK's while loop (NT/FCLK.cc:193-223),
+	 * and two rejections never follow each other (the pass after an undo skips the test) */
+	const int max_passes = (sm->leven_marq && sm->sm == MTFHIP_SM_FCLK) ? 2 * sm->max_iters : sm->max_iters;
 	std::vector<int> h_active;
 	auto all_converged = [&](const int *d_flags, int n, int it) -> bool {
-		if (!(sm->epsilon > 0) || (it + 1) % 8 != 0 || it + 1 >= sm->max_iters) return false;
+		if (!(sm->epsilon > 0) || (it + 1) % 8 != 0 || it + 1 >= max_passes) return false;
 		h_active.resize(n);
 		if (hipMemcpyAsync(h_active.data(), d_flags, sizeof(int) * n, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
 		if (hipStreamSynchronize(st) != hipSuccess) return false;
@@ -826,9 +829,7 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 		ts.lm = b->d_lm;
 		if (mi) ts.f_ext = b->d_mi_f;
 	}
-	/* passes to enqueue: a rejected Levenberg-Marquardt step does not consume an iteration of FCLK's while loop (NT/FCLK.cc:193-223),
-	 * and two rejections never follow each other (the pass after an undo skips the test) */
-	const int max_passes = (sm->leven_marq && sm->sm == MTFHIP_SM_FCLK) ? 2 * sm->max_iters : sm->max_iters;
+
 	BatchView bv = b->view();
 	unsigned long long pub_seq = 0;   /* non-zero: the loop's own kernel delivers the results to the host */
 	bool persisted = false;
