@@ -646,6 +646,35 @@ def test_pf_iteration_matches_oracle(oracle, gpu_ctx, frame, am, corner_based, d
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [37, 5000, 20000, 70000])
+def test_pf_resampling_kernels_at_other_sizes(gpu_ctx, frame, n):
+    """The cumulative-weight scan (register-resident runs up to 16 384 particles, the loop form beyond) and the two-level
+    multinomial search (coarse table in LDS: stride 32 up to 65 536 particles, wider beyond) against NumPy on the device's own
+    weights: the smallest index whose normalised cumulative weight reaches the draw."""
+    rng = np.random.default_rng(7 + n)
+    res = 12
+    corners = synth.square_corners(250.0, 240.0, 60)
+    gpu_ctx.set_image(frame)
+    pf = ParticleFilter(gpu_ctx, L.SSM_HOMOGRAPHY, res, res, n_particles=n, ssm_sigma=(0.004, 0.004, 0.8, 0.004, 0.004, 0.8, 2e-6, 2e-6),
+                        likelihood_alpha=5.0, am=L.AM_SSD, dynamic_model=0, update_type=1, likelihood_func=0, resampling_type=1,
+                        mean_type=0, corner_based_sampling=0)
+    pf.initialize(corners[None])
+    normals, uniforms = rng.normal(size=(n, 8)), rng.uniform(size=n)
+    uniforms[:3] = [0.0, 1.0 - 1e-16, 0.5]
+    pf.iteration(normals, uniforms)
+    st, ar, w, ids = pf.particles()
+    assert w.shape == (n,) and np.all(w > 0)
+    cum = np.cumsum(w) / np.sum(w)
+    cum[-1] = max(cum[-1], 1.0)
+    want = np.searchsorted(cum, uniforms, side="left")
+    bad = np.nonzero(ids != want)[0]
+    # (a parallel scan rounds differently from cumsum: an id may differ only where the draw sits within rounding of a boundary)
+    assert all(abs(cum[min(ids[k], want[k])] - uniforms[k]) < 1e-12 for k in bad), bad[:10]
+    assert ids.min() >= 0 and ids.max() < n
+    pf.close()
+
+
+@pytest.mark.gpu
 def test_pf_device_generator_and_comm(gpu_ctx, frame):
     """the Philox draws are a function of (seed, iteration, particle) only -- two filters with one seed produce identical particle
     sets (what lets every rank of a sharded filter regenerate them without communication) -- and are standard normal / uniform;
