@@ -572,8 +572,8 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s+%s+Homography %dx%d, %d independent targets per GPU, %s mode, solve+update on device"
-                                   % (args.sm.upper(), args.am.upper(), res, res, B, args.mode),
+            "config": {"workload": "%s+%s%s+Homography %dx%d%s, %d independent targets per GPU, %s mode, solve+update on device"
+                                   % (args.sm.upper(), "MC" if CH > 1 else "", args.am.upper(), res, res, "x%d" % CH if CH > 1 else "", B, args.mode),
                        "targets_per_gpu": B, "n_pix": N, "channels": CH, "mode": args.mode, "frame": "%dx%d float32%s" % (H, W, " x %d channels" % CH if CH > 1 else ""),
                        "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
