@@ -325,17 +325,20 @@ def secondary_workload(args):
         sm_kind = {"esm": mtf_amd.SM_ESM, "fclk": mtf_amd.SM_FCLK, "iclk": mtf_amd.SM_ICLK}[args.sm]
         K = 50
         am_kind = {"ssd": mtf_amd.AM_SSD, "ncc": mtf_amd.AM_NCC}[args.am]
-        tr = host.CppTracker(sm_kind, am=am_kind, resx=res, resy=res, max_iters=K, epsilon=-1.0, leven_marq=args.lm, device=local_rank)
+        tr = host.CppTracker(sm_kind, am=am_kind, resx=res, resy=res, max_iters=K, epsilon=-1.0, leven_marq=args.lm, device=local_rank,
+                             device_loop=args.device_loop)
         tr.set_image(frame0); tr.initialize(c); tr.set_image(frame1)
 
         def step():
             tr.set_region(c)
             tr.update()
         dt = timed(step)
-        out.update({"metric": "drop-in LK iters/sec, one target, C++ nt::%s + %s + Homography %dx%d over the AM/SSM virtuals" % (args.sm.upper(), args.am.upper(), res, res),
+        how = "mtf::hip::LK (one C-ABI call per update(), loop on the device)" if args.device_loop else "nt::%s over the AM/SSM virtuals" % args.sm.upper()
+        out.update({"metric": "drop-in LK iters/sec, one target, C++ %s, %s + %s + Homography %dx%d" % (how, args.sm.upper(), args.am.upper(), res, res),
                     "value": K * args.steps * world / dt, "unit": "iters/s", "ms_per_step": dt / args.steps * 1e3, "scaling": "weak",
-                    "config": {"workload": "%d iterations per update(), one C-ABI call per virtual, Levenberg-Marquardt %s, deferred fusion %s" %
-                                           (K, "on" if args.lm else "off", "off" if os.environ.get("MTFHIP_LAZY") == "0" else "on"),
+                    "config": {"workload": "%d iterations per update(), %s, Levenberg-Marquardt %s, deferred fusion %s" %
+                                           (K, "one C-ABI call per update()" if args.device_loop else "one C-ABI call per virtual",
+                                            "on" if args.lm else "off", "off" if os.environ.get("MTFHIP_LAZY") == "0" else "on"),
                                "us_per_iter": dt / (K * args.steps) * 1e6}})
         if rank == 0 and not args.no_cpu:
             import oracle_py as O
@@ -428,6 +431,7 @@ def main():
     ap.add_argument("--mi-path", default="device", choices=["fused", "device", "interface"],
                     help="mi workload: fused iterate + host solve, the device-side loop, or one call per virtual")
     ap.add_argument("--lm", type=int, default=1, help="dropin workload: Levenberg-Marquardt (the reference's class default is on)")
+    ap.add_argument("--device-loop", action="store_true", help="dropin workload: the C++ search method is mtf::hip::LK (whole update() in one C-ABI call)")
     ap.add_argument("--mode", default="full", choices=["full", "lean"],
                     help="full: It, dIt_dx, Jt materialised in HBM as the AM/SSM interface exposes them; lean: registers only")
     ap.add_argument("--math", default="fast", choices=["fast", "replay"],

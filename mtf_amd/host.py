@@ -61,13 +61,15 @@ def _check(rc):
 
 
 class CppTracker:
-    """mtf::nt::{ESM,FCLK,ICLK} over mtf::hip::{HipAM,HipSSM}; parameter names and defaults are the
-    reference's (leven_marq defaults to true as in ESMParams.cc / FCLKParams.cc / ICLKParams.cc)."""
+    """mtf::nt::{ESM,FCLK,ICLK} (or, with device_loop, mtf::hip::LK) over mtf::hip::{HipAM,HipSSM}; parameter names and defaults
+    are the reference's (leven_marq defaults to true as in ESMParams.cc / FCLKParams.cc / ICLKParams.cc)."""
 
     def __init__(self, sm, am=_lib.AM_SSD, ssm=_lib.SSM_HOMOGRAPHY, resx=50, resy=50, max_iters=30, epsilon=1e-4,
                  jac_type=1, hess_type=-1, chained_warp=1, leven_marq=1, lm_delta_init=0.01, lm_delta_update=10.0,
-                 device=0, sec_ord_hess=0, n_channels=1):
-        h = lib().mtfhost_create(sm, am, ssm, resx, resy, max_iters, epsilon, jac_type, hess_type, chained_warp,
+                 device=0, sec_ord_hess=0, n_channels=1, device_loop=False):
+        # device_loop: mtf::hip::LK instead of mtf::nt::ESM / FCLK / ICLK -- the same search method and parameters with the whole
+        # update() loop behind one C-ABI call (mtfhip_batch_track) instead of a loop over the AM / SSM virtuals
+        h = lib().mtfhost_create(sm + (16 if device_loop else 0), am, ssm, resx, resy, max_iters, epsilon, jac_type, hess_type, chained_warp,
                                  leven_marq, lm_delta_init, lm_delta_update, device, sec_ord_hess, n_channels)
         self.n_channels = n_channels
         if not h:

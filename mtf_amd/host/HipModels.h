@@ -118,6 +118,8 @@ private:
 	std::shared_ptr<HipPair> p;
 public:
 	const std::shared_ptr<HipPair> &pair() const { return p; }
+	/* a device-side driver (hip::LK: mtfhip_batch_init_template / track / set_region) rewrote the AM's arrays behind this object */
+	void markDeviceUpdated() { d_dI0 = d_dIt = d_h0 = d_ht = true; f_fresh = false; }
 private:
 	ImageView img{nullptr, 0, 0, 0};
 	mutable double f = 0;

@@ -10,6 +10,7 @@
 #include "HipModels.h"
 #include "SearchMethods.h"
 #include "PF.h"
+#include "DeviceLK.h"
 
 using namespace mtf;
 
@@ -39,7 +40,9 @@ mtfhost_tracker *mtfhost_create(int sm, int am, int ssm, int resx, int resy, int
 		p.chained_warp = chained_warp != 0; p.leven_marq = leven_marq != 0;
 		p.lm_delta_init = lm_delta_init; p.lm_delta_update = lm_delta_update;
 		p.sec_ord_hess = sec_ord_hess != 0;
-		if (sm == MTFHIP_SM_ESM) t->sm.reset(new nt::ESM(t->am, t->ssm, p));
+		/* sm + 16: the same search method as ONE call per update() (mtf::hip::LK: the loop runs on the device) */
+		if (sm >= 16) t->sm.reset(new hip::LK(sm - 16, t->am, t->ssm, p));
+		else if (sm == MTFHIP_SM_ESM) t->sm.reset(new nt::ESM(t->am, t->ssm, p));
 		else if (sm == MTFHIP_SM_FCLK) t->sm.reset(new nt::FCLK(t->am, t->ssm, p));
 		else if (sm == MTFHIP_SM_ICLK) t->sm.reset(new nt::ICLK(t->am, t->ssm, p));
 		else { delete t; g_err = "unknown search method"; return nullptr; }

@@ -98,6 +98,48 @@ def test_cpp_trackers_match_oracle(oracle, frame, case):
     assert np.abs(out - gt).max() < (0.1 if am != L.AM_MI else 0.6)
 
 
+DEVICE_LOOP_CASES = [c for c in CASES if not c[4].get("sec_ord_hess") and not (c[0] == L.SM_ICLK and c[4].get("hess_type") == 1)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", DEVICE_LOOP_CASES, ids=lambda c: "sm%d-am%d-ssm%d-%s" % (c[0], c[1], c[2], "_".join("%s%s" % kv for kv in c[4].items())))
+def test_cpp_device_loop_search_method(oracle, frame, case):
+    """mtf::hip::LK -- the C++ search-method object whose update() is ONE call (mtfhip_batch_track: the whole loop, Levenberg-Marquardt
+    included, on the device) -- against the oracle's nt:: tracker and against the literal C++ nt:: loop over the virtuals, with the
+    reference's parameters (class defaults: LM on).  Two frames: the second update() starts from the first one's result."""
+    sm, am, ssm, res, extra = case
+    rng = np.random.default_rng(13)
+    centre = (256.0, 250.0)
+    corners = synth.square_corners(centre[0], centre[1], float(max(2 * res, 60)))
+    frame2 = synth.warp_frame(frame, synth.random_small_homography(rng, 0.35), centre)
+    frame3 = synth.warp_frame(frame, synth.random_small_homography(rng, 0.45), centre)
+    params = dict(max_iters=30, epsilon=1e-6, leven_marq=1)
+    params.update(extra)
+    o_ssm = oracle.SSM(ssm, res, res); o_am = oracle.AM(am, res, res); o_am.set_curr_img(frame)
+    otrk = oracle.Tracker(sm, o_am, o_ssm, **params)
+    otrk.initialize(corners)
+    dev = host.CppTracker(sm, am, ssm, res, res, device_loop=True, **params)
+    lit = host.CppTracker(sm, am, ssm, res, res, **params)
+    for t in (dev, lit):
+        t.set_image(frame.copy()); t.initialize(corners)
+    tol = 1e-3 if am != L.AM_MI else 5e-3
+    for f in (frame2, frame3):
+        o_am.set_curr_img(f)
+        o_iters = otrk.update()
+        outs = []
+        for t in (dev, lit):
+            t.set_image(f.copy())
+            outs.append(t.update())
+        np.testing.assert_allclose(outs[0], otrk.get_region(), atol=tol)
+        np.testing.assert_allclose(outs[0], outs[1], atol=tol)
+        assert abs(dev.iters - o_iters) <= 2
+    # setRegion of the search method, then one more frame
+    otrk.set_region(corners); dev.set_region(corners)
+    o_am.set_curr_img(frame2); otrk.update()
+    dev.set_image(frame2.copy())
+    np.testing.assert_allclose(dev.update(), otrk.get_region(), atol=tol)
+
+
 @pytest.mark.gpu
 def test_cpp_layer_error_paths(frame):
     # NCC leaves the second-order cmptSelfHessian unimplemented (AppearanceModel.h:188-191): the exception type and
