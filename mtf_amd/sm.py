@@ -584,11 +584,17 @@ class PyramidalTracker:
         """:117-131: coarsest level first, every finer level starts from the scaled-up result"""
         self.update_image_pyramid()
         self.trackers[-1].update()
+        out = self.trackers[-1].get_region()
         for k in range(self.n - 2, -1, -1):
-            self.trackers[k].set_region(self.trackers[k + 1].get_region() / self.scale)
-            self.trackers[k].update()
-        self.trackers[-1].set_region(self.trackers[0].get_region() * self.overall)
-        return self.trackers[0].get_region()
+            t = self.trackers[k]
+            if hasattr(t, "update_region"):     # setRegion + update of the level in one C-ABI call (mtfhip_batch_track_region)
+                t.update_region(out / self.scale)
+            else:
+                t.set_region(out / self.scale)
+                t.update()
+            out = t.get_region()
+        self.trackers[-1].set_region(out * self.overall)
+        return out
 
     def set_region(self, corners):
         c = np.asarray(corners, dtype=np.float64).reshape(1, 2, 4).copy()
