@@ -372,25 +372,40 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 			while (((cs.ends >> (8 * c)) & 255) == 0) ++c;   /* first class with pixels (a chunk has at least one) */
 			int bound = (int)((cs.ends >> (8 * c)) & 255);
 			double acc0 = 0.0, acc1 = 0.0;
-			double o_d = pd[0], o_w = pw[0], o_r0 = pr0[0], o_r1 = pr1[0], o_ht = pht[0];
-			for (int g = 0; g < cs.total; g += 4) {
-				pd += 4; pw += 4; pr0 += 4; pr1 += 4; pht += 4;
-				const double n_d = pd[0], n_w = pw[0], n_r0 = pr0[0], n_r1 = pr1[0], n_ht = pht[0];
-				const double av = o_d * o_w;   /* block = gradient tap k, row = weight tap m */
-				acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, o_r0, acc0, 0, 0, 0);
-				acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, o_r1, acc1, 0, 0, 0);
-				chs = __builtin_amdgcn_mfma_f64_4x4x4f64((hx ? o_r1 : o_r0) * o_ht, hy ? o_r1 : o_r0, chs, 0, 0, 0);
-				o_d = n_d; o_w = n_w; o_r0 = n_r0; o_r1 = n_r1; o_ht = n_ht;
-				if (g + 4 == bound) {
+			/* two groups per trip, each group's operands requested two groups ahead (one group ahead the LDS latency was exposed
+			 * behind three block products in every trip).  An odd number of groups ends with an all-zero padding group: slots
+			 * behind the last class keep a zero gradient tap and a zero hess_term, and kRS2 leaves room for the look-ahead. */
+			auto flush_if = [&](int end) {
+				if (end == bound) {
 					const int r = c - 1 + lb, cc = c - 1 + lk;   /* result lane: block = k, row = m, column = s in its half */
 					if (r >= 0 && r < nb && cc >= 0 && cc < nb) {
 						double *qe = qabs + (r * nb + cc) * 8 + li;
 						qe[0] += acc0; qe[4] += acc1;
 					}
 					acc0 = 0.0; acc1 = 0.0;
-					do { ++c; } while (c < 8 && (int)((cs.ends >> (8 * c)) & 255) <= g + 4);
+					do { ++c; } while (c < 8 && (int)((cs.ends >> (8 * c)) & 255) <= end);
 					bound = c < 8 ? (int)((cs.ends >> (8 * c)) & 255) : 1 << 30;
 				}
+			};
+			double a_d = pd[0], a_w = pw[0], a_r0 = pr0[0], a_r1 = pr1[0], a_ht = pht[0];
+			double b_d = pd[4], b_w = pw[4], b_r0 = pr0[4], b_r1 = pr1[4], b_ht = pht[4];
+			for (int g = 0; g < cs.total; g += 8) {
+				{
+					const double av = a_d * a_w;   /* block = gradient tap k, row = weight tap m */
+					acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, a_r0, acc0, 0, 0, 0);
+					acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, a_r1, acc1, 0, 0, 0);
+					chs = __builtin_amdgcn_mfma_f64_4x4x4f64((hx ? a_r1 : a_r0) * a_ht, hy ? a_r1 : a_r0, chs, 0, 0, 0);
+				}
+				a_d = pd[g + 8]; a_w = pw[g + 8]; a_r0 = pr0[g + 8]; a_r1 = pr1[g + 8]; a_ht = pht[g + 8];
+				flush_if(g + 4);
+				{
+					const double av = b_d * b_w;
+					acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b_r0, acc0, 0, 0, 0);
+					acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b_r1, acc1, 0, 0, 0);
+					chs = __builtin_amdgcn_mfma_f64_4x4x4f64((hx ? b_r1 : b_r0) * b_ht, hy ? b_r1 : b_r0, chs, 0, 0, 0);
+				}
+				b_d = pd[g + 12]; b_w = pw[g + 12]; b_r0 = pr0[g + 12]; b_r1 = pr1[g + 12]; b_ht = pht[g + 12];
+				flush_if(g + 8);
 			}
 			__builtin_amdgcn_wave_barrier();
 			if (valid) {   /* padding slots must keep a zero gradient tap and a zero hess_term */
