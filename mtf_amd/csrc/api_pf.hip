@@ -2,9 +2,10 @@
  * api_pf.hip -- the particle filter behind the C ABI (nt::PF, SM/src/NT/PF.cc) and the collective of its sharded form
  * (C-ABI implementation, include/mtfhip.h; shared declarations: mtfhip_api_internal.h)
  *
- * One iteration of nt::PF::update's loop is four launches and one 20-double read-back: sample generation (k_pf_propagate),
- * scoring (k_score_candidates[_fast]; on R ranks each scores its contiguous block and ONE all-gather over RCCL puts every
- * weight on every rank, PF.cc:262-277), weights -> cumulative weights -> resampling -> estimate (k_pf_resample).  The
+ * One iteration of nt::PF::update's loop is five launches: sample generation (k_pf_propagate), scoring
+ * (k_score_candidates[_fast]; on R ranks each scores its contiguous block and ONE all-gather over RCCL puts every weight on
+ * every rank, PF.cc:262-277), weights -> cumulative weights (k_pf_weights), resampling (k_pf_select), estimate
+ * (k_pf_estimate, which also delivers its 32 doubles to host-coherent memory and raises the flag the host waits on).  The
  * reference does all of it per particle on the host, including a 4-corner DLT (8 x 9 JacobiSVD) per sample.
  *
  * RCCL is bound at run time (dlopen): libmtfhip.so has no link-time dependency on it, a process that already carries an
