@@ -49,6 +49,7 @@ def pmc_traffic(sm, mode, res, targets):
         d = json.load(open(path))
         if d.get("j0_recompute", False) != (os.environ.get("MTFHIP_J0_RECOMPUTE", "1") != "0"):
             return None      # the profile was taken with the other J0 source
+        pmc_traffic.commit = d.get("commit")
         return float(d["traffic_bytes_per_launch"])
     except Exception:
         return None
@@ -592,7 +593,8 @@ def main():
                          "hbm_write_bytes": float(88 if materialize and args.sm != "iclk" else (8 if materialize else 0)) * N * per_launch,
                          "timing": "hipEvents around every fused launch of an untimed second pass (%d launches); rocprofv3 --kernel-trace of the "
                                    "same command: profiles/r02_kernel_stats.csv" % kern_n,
-                         "traffic_source": "rocprofv3 --pmc passes committed under profiles/ (pmc_latest.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB), not this run"},
+                         "traffic_source": "rocprofv3 --pmc passes committed under profiles/ (pmc_latest.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB), not this run",
+                         "traffic_commit": getattr(pmc_traffic, "commit", None)},
         }
         if lean is not None:
             out["lean"] = lean
