@@ -291,7 +291,7 @@ int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int n
 
 /* ---- the particle filter on the device: nt::PF (SM/src/NT/PF.cc) over the batch's single target ----
  * Sample generation (the SSM's stochastic sampler and dynamic models: ProjectiveBase.cc:163-317, Homography.cc:899-942),
- * scoring, cumulative weights, multinomial resampling and the estimate run as four launches per iteration; only the estimate
+ * scoring, cumulative weights, multinomial resampling and the estimate run as five launches per iteration; only the estimate
  * (state, corners, best weight) crosses PCIe.  Enum values are the reference's (SM/include/mtf/SM/PFParams.h:10-33).
  * Not provided: several sampler distributions (n_distr > 1), jacobian_as_sigma, residual resampling, the geometric
  * (SVD based) sampler of Affine.cc:464-552 -- the calls return MTFHIP_ERR_NOT_IMPLEMENTED. */
