@@ -290,6 +290,40 @@ def test_track_region_equals_set_region_then_track(gpu_ctx, frame, sm_kind, am):
         assert np.array_equal(a.tracker.batch.get_state(), b.tracker.batch.get_state())
 
 
+def test_copy_and_sync_fallback_gives_the_same_results(gpu_ctx, frame, monkeypatch):
+    """MTFHIP_ZERO_COPY=0 (read at batch creation): state slabs go up with hipMemcpyAsync and results come back by copy + stream
+    synchronisation instead of kernels reading / writing pinned host memory -- the grid frame, the device-side loop and the
+    particle filter give the same results either way."""
+    rng = np.random.default_rng(47)
+    centre = (256.0, 256.0)
+    region = synth.square_corners(centre[0], centre[1], 280)
+    frame2 = synth.warp_frame(frame, synth.random_small_homography(rng, 0.2), centre)
+    normals, uniforms = rng.normal(size=(300, 8)), rng.uniform(size=300)
+    out = {}
+    for zc in ("1", "0"):
+        monkeypatch.setenv("MTFHIP_ZERO_COPY", zc)
+        gpu_ctx.set_image(frame)
+        g = GridTracker(gpu_ctx, grid_size=4, patch_size=25, max_iters=10, epsilon=1e-4)
+        g.initialize(region)
+        lk = LKTracker(gpu_ctx, L.SM_ESM, L.SSM_HOMOGRAPHY, 60, 60, 3, host_solve=False, max_iters=8, epsilon=1e-6, materialize=0, leven_marq=1)
+        lk.initialize(np.stack([synth.square_corners(200 + 40 * k, 230 + 20 * k, 70) for k in range(3)]))
+        pf = ParticleFilter(gpu_ctx, L.SSM_HOMOGRAPHY, 20, 20, n_particles=300, ssm_sigma=(0.004, 0.004, 0.8, 0.004, 0.004, 0.8, 2e-6, 2e-6),
+                            likelihood_alpha=5.0, mean_type=1)
+        pf.initialize(synth.square_corners(250.0, 240.0, 60)[None])
+        gpu_ctx.set_image(frame2)
+        c1, _ = g.update(region)
+        c2, _ = g.update()
+        l1 = lk.update().copy()
+        lk.set_region(lk.get_region()); l2 = lk.update().copy()
+        pf.iteration(normals, uniforms)
+        out[zc] = (c1, c2, l1, l2, np.array(lk.n_iters), pf.get_region().copy(), pf.batch.get_state().copy())
+        pf.close(); lk.batch.close(); g.tracker.batch.close()
+    # (the constant template Hessian is reduced by k_finish_host on one path and k_finish_rows on the other: two fixed summation
+    # orders, so everything downstream agrees to rounding, not to the bit)
+    for a, b in zip(out["1"], out["0"]):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-9)
+
+
 def test_nn_dataset_generation(gpu_ctx, frame):
     """nt::NN::generateDataset mirror: the zero perturbation reproduces the template, every row is the feature
     of its own inverse-perturbed warp, and the exhaustive search finds a stored sample at distance 0."""
