@@ -126,6 +126,16 @@ def test_config3_grid_256_patches(gpu_ctx, big_frames):
     gpu_ctx.set_image(f0); gt.initialize(region)
     c0, _ = gt.update()
     np.testing.assert_allclose(c0, patches, atol=1e-6)
+    # the frame loop as GridTracker::update runs it -- every patch tracker reset to the grid, then updated -- in ONE call
+    # (mtfhip_batch_track_region) against the two calls, in both arithmetic modes
+    for math in (mtf_amd.MATH_FAST, mtf_amd.MATH_REPLAY):
+        gt.tracker.batch.set_math_mode(math)
+        gpu_ctx.set_image(f1)
+        gt.tracker.set_region(patches); two, _ = gt.update()
+        one, cen = gt.update(region)
+        assert np.array_equal(one, two)
+        err = np.abs(cen - want).max(axis=1)
+        assert np.median(err) < 0.05 and (err < 0.5).mean() > 0.97
 
 
 def test_config4_pf_10000_candidates(gpu_ctx, big_frames):
