@@ -242,3 +242,50 @@ def test_config5_mi_device_loop_full_size(gpu_ctx, math):
         one.initialize(corners[20][None])
         gpu_ctx.set_image(f1)
         np.testing.assert_allclose(one.update()[0], out[20], rtol=0, atol=1e-6)   # (its own workgroup decomposition: summation order only)
+
+
+def test_multichannel_200x200x3_fused_iteration(gpu_ctx):
+    """MCSSD at the headline patch size (200 x 200 x 3 rows per target) through the fused iteration: a target's g / H do not depend
+    on the batch it is in, replicated channels give three times the single-channel sums, and the device loop converges."""
+    f0 = synth.make_frame_mc(1024, 1024)
+    p_true = synth.random_small_homography(np.random.default_rng(5), 0.3)
+    f1 = synth.warp_frame(f0, p_true, (512.0, 512.0))
+    B = 6
+    rng = np.random.default_rng(9)
+    corners = np.stack([synth.square_corners(rng.uniform(300, 700), rng.uniform(300, 700), 200.0) for _ in range(B)])
+    sm = mtf_amd.sm_desc(L.SM_ESM, materialize=1, leven_marq=0, max_iters=10, epsilon=1e-6)
+    gpu_ctx.set_image(f0)
+    b = mtf_amd.Batch(gpu_ctx, L.AM_SSD, L.SSM_HOMOGRAPHY, 200, 200, B, n_channels=3)
+    b.set_corners(corners); b.init_template(sm)
+    gpu_ctx.set_image(f1)
+    f, g, H = b.iterate(sm)
+    gpu_ctx.set_image(f0)
+    one = mtf_amd.Batch(gpu_ctx, L.AM_SSD, L.SSM_HOMOGRAPHY, 200, 200, 1, n_channels=3)
+    one.set_corners(corners[4][None]); one.init_template(sm)
+    gpu_ctx.set_image(f1)
+    f1_, g1, H1 = one.iterate(sm)
+    np.testing.assert_allclose(H1[0], H[4], rtol=1e-11)
+    np.testing.assert_allclose(g1[0], g[4], rtol=1e-9, atol=1e-9 * np.abs(g[4]).max())
+    assert abs(f1_[0] - f[4]) <= 1e-12 * abs(f[4])
+    # three copies of one channel: every row sum is three times the single-channel one
+    g0 = np.repeat(f0[..., :1], 3, axis=2).copy(); g1f = np.repeat(f1[..., :1], 3, axis=2).copy()
+    gpu_ctx.set_image(g0)
+    rep = mtf_amd.Batch(gpu_ctx, L.AM_SSD, L.SSM_HOMOGRAPHY, 200, 200, 1, n_channels=3)
+    rep.set_corners(corners[1][None]); rep.init_template(sm)
+    gpu_ctx.set_image(g1f)
+    fr, gr, Hr = rep.iterate(sm)
+    gpu_ctx.set_image(np.ascontiguousarray(f0[..., 0]))
+    sc = mtf_amd.Batch(gpu_ctx, L.AM_SSD, L.SSM_HOMOGRAPHY, 200, 200, 1)
+    sc.set_corners(corners[1][None]); sc.init_template(sm)
+    gpu_ctx.set_image(np.ascontiguousarray(f1[..., 0]))
+    fs, gs, Hs = sc.iterate(sm)
+    np.testing.assert_allclose(Hr[0], 3 * Hs[0], rtol=1e-6)      # (mc:: forms the bilinear weights first: rounding differs from the single-channel sampler)
+    np.testing.assert_allclose(gr[0], 3 * gs[0], rtol=1e-6, atol=1e-6 * np.abs(gs[0]).max())
+    assert abs(fr[0] - 3 * fs[0]) <= 1e-9 * abs(fs[0])
+    # device loop
+    gpu_ctx.set_image(f1)
+    n_it, out = b.track(sm)
+    want = np.stack([gt_corners(corners[t], p_true, (512.0, 512.0)) for t in range(B)])
+    assert np.abs(out - want).max() < 0.1 and n_it.max() <= 10
+    for x in (b, one, rep, sc):
+        x.close()
