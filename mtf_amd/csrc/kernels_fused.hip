@@ -93,7 +93,7 @@ static void launch_fused_fast(const BatchView &bv, const ImgView &im, const Fuse
 void launch_fused_ssd(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk,
 	hipStream_t st) {
 	const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY;
-	if (bv.C > 1) { launch_fused_mc(bv, im, fa, partials, nblk, st); return; }   /* MCSSD / MCNCC (replay arithmetic only) */
+	if (bv.C > 1) { launch_fused_mc(bv, im, fa, partials, nblk, st); return; }   /* MCSSD / MCNCC */
 	if (fa.fast_math && !fa.materialize) {
 		const bool ncc = bv.am == MTFHIP_AM_NCC;
 		if (hom && ncc) launch_fused_fast<MTFHIP_AM_NCC, MTFHIP_SSM_HOMOGRAPHY>(bv, im, fa, partials, nblk, st);

@@ -130,7 +130,7 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 		W = load_warp(wsrc);
 		st2 = st[2]; st3 = st[3]; st4 = st[4]; st5 = st[5];
 	}
-	static_assert(!(MC && FAST), "the multi-channel pass has no tolerance-mode form");
+	static_assert(!(MC && PERSIST), "no multi-channel instantiation of the persistent loop");
 	const unsigned NPt = MC ? (unsigned)bv.NP : N, Cc = MC ? (unsigned)bv.C : 1u;   /* points per target, channels */
 	const double2 *__restrict__ ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * NPt;
 	const double *__restrict__ iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * NPt;
