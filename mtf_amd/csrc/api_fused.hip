@@ -304,12 +304,10 @@ int lazy_try_similarity(mtfhip_batch *b) {
 	return MTFHIP_OK;
 }
 
-/* The fused iteration serves MCSSD / MCNCC (k_fused_mc); MCMI's passes are single-channel and stay with the per-function entry points */
-static int fused_channels_ok(const mtfhip_batch *b, const char *fn) {
-	if (b->C != 1 && b->desc.am == MTFHIP_AM_MI)
-		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: the multi-channel MI model uses the per-function entry points", fn);
-	return MTFHIP_OK;
-}
+/* The fused iteration serves the multi-channel models too: MCSSD / MCNCC through k_fused_mc, MCMI through the materialising MI
+ * iteration (k_fused_mc + the histogram / gradient / Hessian kernels, which see (pixel, channel) rows like any other rows); the
+ * MI recompute passes are single-channel (mi_fast_ok). */
+static int fused_channels_ok(const mtfhip_batch *b, const char *fn) { (void)b; (void)fn; return MTFHIP_OK; }
 
 int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	FLUSH(b);
@@ -563,7 +561,7 @@ static int mi_enqueue(mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPlan &p
  * materialised, every first-order type but SumOfStd (two Hessian passes: it keeps the materialising form). */
 static bool mi_fast_ok(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPlan &pl) {
 	static const bool enabled = !(std::getenv("MTFHIP_MI_RECOMPUTE") && std::getenv("MTFHIP_MI_RECOMPUTE")[0] == '0');
-	return enabled && b->math_mode == MTFHIP_MATH_FAST && b->desc.mi_n_bins == 8 && !sm->materialize && pl.hk != MiPlan::H_SUM_STD;
+	return enabled && b->C == 1 && b->math_mode == MTFHIP_MATH_FAST && b->desc.mi_n_bins == 8 && !sm->materialize && pl.hk != MiPlan::H_SUM_STD;
 }
 static MiFastPlan mi_fast_plan(const mtfhip_batch *b, const MiPlan &pl, const int *active) {
 	MiFastPlan fp;

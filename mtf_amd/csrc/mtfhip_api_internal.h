@@ -499,7 +499,7 @@ static int lazy_flush_ctx(mtfhip_ctx *c) {   /* called by everything that replac
  * (J0 is the search method's own template Jacobian on the current grid) */
 static inline mtfhip::MiJ0Rebuild mi_j0_rebuild(const mtfhip_batch *b) {
 	mtfhip::MiJ0Rebuild rb{nullptr, nullptr, nullptr, 0, 0};
-	const bool ok = b->j0_is_template && b->j0_recompute_enabled && b->j0_template_corners_epoch == b->corners_epoch &&
+	const bool ok = b->C == 1 && b->j0_is_template && b->j0_recompute_enabled && b->j0_template_corners_epoch == b->corners_epoch &&
 		b->buf[MTFHIP_BUF_DI0_DX] && b->buf[MTFHIP_BUF_INIT_PTS] && (b->unit_z || b->buf[MTFHIP_BUF_INIT_Z]);
 	if (ok) {
 		rb.dI0 = b->buf[MTFHIP_BUF_DI0_DX]; rb.pts = b->buf[MTFHIP_BUF_INIT_PTS];

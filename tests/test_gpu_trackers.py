@@ -424,16 +424,13 @@ def test_multichannel_models_match_oracle(oracle, gpu_ctx, case):
     gpu_ctx.set_image(np.ascontiguousarray(frame[..., 0]))
     with pytest.raises(mtf_amd.InvalidArgument):
         nt.batch.update_pix_vals()
-    # the fused iteration (k_fused_mc: one launch per iteration over (pixel, channel) rows) serves MCSSD / MCNCC: the same numbers
-    # as the call-by-call path above, through batch.iterate + host solve and through the device-side loop (batch.track);
-    # MCMI and the second-order Hessians stay with the per-function entry points and say so
-    fused_ok = am != L.AM_MI and not so
+    # the fused iteration (k_fused_mc: one launch per iteration over (pixel, channel) rows; MCMI: that launch + the MI kernels over
+    # the same rows) gives the same numbers as the call-by-call path above, through batch.iterate + host solve and through the
+    # device-side loop (batch.track); the second-order Hessians stay with the per-function entry points and say so
+    fused_ok = not so
+    mi = am == L.AM_MI
     for host_solve in (True, False):
         gpu_ctx.set_image(frame)
-        if am == L.AM_MI:
-            with pytest.raises(mtf_amd.FunctionNotImplemented):
-                nt.batch.init_template(nt.sm)
-            break
         lk = LKTracker(gpu_ctx, sm_kind, ssm, res, res, 1, host_solve=host_solve, am=am, am_params=dict(n_channels=3), **params)
         lk.initialize(corners[None])
         gpu_ctx.set_image(frame2)
@@ -445,7 +442,7 @@ def test_multichannel_models_match_oracle(oracle, gpu_ctx, case):
         if host_solve:
             f, g, H = lk.batch.iterate(lk.sm)
             assert abs(f[0] - rec["f"]) <= 1e-7 * abs(rec["f"])
-            assert np.linalg.norm(H[0] - rec["H"]) <= 1e-5 * np.linalg.norm(rec["H"])
+            assert np.linalg.norm(H[0] - rec["H"]) <= (1e-5 if not mi else 1e-4) * np.linalg.norm(rec["H"])
             assert np.linalg.norm(g[0] - rec["g"]) <= 1e-4 * gs
             # the interface-visible arrays of a materialising launch are the bits of the per-function kernels
             nt2 = NTSearchMethod(gpu_ctx, sm_kind, am, ssm, res, res, 1, am_params=dict(n_channels=3), **params)
@@ -454,9 +451,9 @@ def test_multichannel_models_match_oracle(oracle, gpu_ctx, case):
             assert np.array_equal(lk.batch.read(L.BUF_IT), nt2.batch.read(L.BUF_IT))
             nt2.batch.close()
         out = lk.update()
-        np.testing.assert_allclose(out[0], otrk.get_region(), atol=5e-4)
+        np.testing.assert_allclose(out[0], otrk.get_region(), atol=5e-4 if not mi else 5e-3)
         lk.batch.close()
-        if not host_solve:
+        if not host_solve and not mi:
             # nothing materialised: the tolerance-mode multi-channel kernels (k_fused_mc_fast) and their replay twins
             for math in (mtf_amd.MATH_FAST, mtf_amd.MATH_REPLAY):
                 gpu_ctx.set_image(frame)
