@@ -453,15 +453,16 @@ def test_multichannel_models_match_oracle(oracle, gpu_ctx, case):
         out = lk.update()
         np.testing.assert_allclose(out[0], otrk.get_region(), atol=5e-4 if not mi else 5e-3)
         lk.batch.close()
-        if not host_solve and not mi:
-            # nothing materialised: the tolerance-mode multi-channel kernels (k_fused_mc_fast) and their replay twins
+        if not host_solve:
+            # nothing materialised: the tolerance-mode multi-channel kernels (k_fused_mc_fast; MCMI: the recompute passes over
+            # (pixel, channel) rows) and their replay twins
             for math in (mtf_amd.MATH_FAST, mtf_amd.MATH_REPLAY):
                 gpu_ctx.set_image(frame)
                 lean = LKTracker(gpu_ctx, sm_kind, ssm, res, res, 1, host_solve=False, am=am, am_params=dict(n_channels=3), materialize=0, **params)
                 lean.batch.set_math_mode(math)
                 lean.initialize(corners[None])
                 gpu_ctx.set_image(frame2)
-                np.testing.assert_allclose(lean.update()[0], otrk.get_region(), atol=5e-4)
+                np.testing.assert_allclose(lean.update()[0], otrk.get_region(), atol=5e-4 if not mi else 5e-3)
                 lean.batch.close()
 
 
