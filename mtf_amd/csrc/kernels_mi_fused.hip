@@ -506,12 +506,20 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 __global__ __launch_bounds__(kBlock) void k_mi_finish_fast(BatchView bv, mtfhip_sm_desc sm, TrackState ts, int have_hess, int transpose_q,
 	int joint_off, int hist_off, int sum_h0_host, int gmode, int do_track, const double *partials, int nblk, const double *tb_all,
 	double *out_H, double *out_g, double *rows) {
-	__shared__ double gs[16], Hs[64], Q[512];
+	__shared__ double gs[16], Hs[64], Q[512], fac[64];
 	const int t = blockIdx.x, S = bv.S;
 	if (do_track && !ts.active[t]) return;   /* (uniform per workgroup) */
 	const double *p = partials + (size_t)t * nblk * kMiFastRow;
 	const double *tb = tb_all + (size_t)t * MI_SIZE;
 	const int ncol = have_hess ? kMiFastRow : 16;
+	if (have_hess && threadIdx.x >= kBlock - 64) {
+		/* the 64 bin-pair factors (1 / joint - 1 / hist), one per thread of the last wave, while the others sum the block rows:
+		 * evaluated inside the assembly loop below they were 64 dependent global loads and 128 divisions per entry of H */
+		const int k = threadIdx.x - (kBlock - 64), rr = k >> 3, cc = k & 7;
+		const double jv = tb[joint_off + rr * MI_NB + cc];
+		const double hv = tb[hist_off + (transpose_q ? cc : rr)];
+		fac[k] = (1.0 / jv) - (1.0 / hv);
+	}
 	for (int k = threadIdx.x; k < ncol; k += kBlock) {
 		const double s = column_sum(p + k, nblk, kMiFastRow);
 		if (k < 16) gs[k] = s; else if (k < 80) Hs[k - 16] = s; else Q[k - 80] = s;
@@ -527,10 +535,8 @@ __global__ __launch_bounds__(kBlock) void k_mi_finish_fast(BatchView bv, mtfhip_
 			for (int rr = 0; rr < 8; ++rr)
 				for (int cc = 0; cc < 8; ++cc) {
 					/* MI.cc:497-511, 590-600, 626-636: joint_hist_jacobian.row(idx)^T row(idx) * (1 / joint - 1 / hist) */
-					const double jv = tb[joint_off + rr * MI_NB + cc];
-					const double hv = tb[hist_off + (transpose_q ? cc : rr)];
 					const double *q = Q + (rr * 8 + cc) * 8;
-					h += q[r2] * q[c2] * ((1.0 / jv) - (1.0 / hv));
+					h += q[r2] * q[c2] * fac[rr * 8 + cc];
 				}
 			out_H[(size_t)t * 64 + c2 * S + r2] = h;
 		}
