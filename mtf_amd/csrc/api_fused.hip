@@ -970,7 +970,8 @@ int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int C
 		TRY(push_ncc(b));
 		ncc_sc = b->d_ncc;
 	}
-	launch_score_candidates(b->view(), b->ctx->img, dev_states, C, b->desc.likelihood_alpha, ncc_sc, dev_lik, dev_sim, b->math_mode == MTFHIP_MATH_FAST, b->ctx->stream);
+	/* (view_raw: the candidates bring their own warps; a stale device copy of the batch's warp is not uploaded for them) */
+	launch_score_candidates(b->view_raw(), b->ctx->img, dev_states, C, b->desc.likelihood_alpha, ncc_sc, dev_lik, dev_sim, b->math_mode == MTFHIP_MATH_FAST, b->ctx->stream);
 	return MTFHIP_OK;
 }
 
@@ -1004,7 +1005,7 @@ int mtfhip_sample_candidates_dev(mtfhip_batch *b, const double *dev_states, int 
 	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "sample_candidates before set_corners");
 	TRY(need_image(b));
 	TimedScope ts(b->ctx, "sample_candidates");
-	launch_sample_candidates(b->view(), b->ctx->img, dev_states, C, b->norm_mult, b->norm_add, dev_features, b->ctx->stream);
+	launch_sample_candidates(b->view_raw(), b->ctx->img, dev_states, C, b->norm_mult, b->norm_add, dev_features, b->ctx->stream);
 	return MTFHIP_OK;
 }
 int mtfhip_sample_candidates(mtfhip_batch *b, const double *states, int C, double *features) {
