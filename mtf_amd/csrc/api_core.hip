@@ -455,7 +455,14 @@ int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track) {
 	/* normalised grid extents: ProjectiveBase.cc:14 (unit square) ; Affine.cc:56-57 */
 	double lo_x = -0.5, lo_y = -0.5, hi_x = 0.5, hi_y = 0.5;
 	if (!hom) { lo_x = 1 - b->desc.resx / 2.0; lo_y = 1 - b->desc.resy / 2.0; hi_x = b->desc.resx / 2.0; hi_y = b->desc.resy / 2.0; }
-	std::vector<double> w0(9 * b->B);
+	/* the staging buffer is protected by an event instead of a stream sync; one pass over the targets fills the host mirrors
+	 * AND the staged slab (w | s | corners | init_corners_hm | NCC scalars | w0 | flags: the layout of fill_stage) */
+	if (b->stage_a_busy) HIP_TRY(hipEventSynchronize(b->ev_a));
+	const size_t Bt = (size_t)b->B;
+	double *sp = reinterpret_cast<double *>(b->h_stage_a);
+	double *s_w = sp, *s_s = sp + 9 * Bt, *s_cr = sp + 17 * Bt, *s_ic = sp + 25 * Bt, *s_nc = sp + 37 * Bt, *s_w0 = sp + 45 * Bt;
+	int *s_act = reinterpret_cast<int *>(b->h_stage_a + b->slab_dbl_bytes), *s_it = s_act + Bt;
+	static const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 	int unit_z = 1;
 	for (int t = 0; t < b->B; ++t) {
 		M3 W0;
@@ -463,7 +470,6 @@ int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track) {
 		if (!hom || (std::fabs(W0.m[6]) < 1e-15 && std::fabs(W0.m[7]) < 1e-15)) {
 			if (hom) { W0.m[6] = 0; W0.m[7] = 0; }
 		} else unit_z = 0;
-		std::memcpy(&w0[9 * t], W0.m, sizeof(double) * 9);
 		TargetHost &h = b->th[t];
 		std::memcpy(h.corners, corners + 8 * t, sizeof(double) * 8);
 		std::memcpy(h.init_corners, corners + 8 * t, sizeof(double) * 8);
@@ -474,12 +480,17 @@ int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track) {
 		}
 		h.warp = m3_identity();
 		std::memset(h.state, 0, sizeof(h.state));
+		std::memcpy(s_w + 9 * t, ident, sizeof(ident));
+		std::memset(s_s + 8 * t, 0, sizeof(double) * 8);
+		std::memcpy(s_cr + 8 * t, corners + 8 * t, sizeof(double) * 8);
+		std::memcpy(s_ic + 12 * t, h.init_corners_hm, sizeof(double) * 12);
+		double *q8 = s_nc + 8 * t;
+		q8[0] = h.I0_mean; q8[1] = h.c; q8[2] = h.It_mean; q8[3] = h.b; q8[4] = h.f; q8[5] = h.gmean; q8[6] = q8[7] = 0;
+		std::memcpy(s_w0 + 9 * t, W0.m, sizeof(double) * 9);
+		s_act[t] = for_track ? 1 : 0;
+		if (for_track) s_it[t] = 0;
 	}
 	b->unit_z = hom ? unit_z : 1;
-	/* w0, init_corners_hm, identity warps, zero states and the corners in ONE pinned async copy; the staging buffer is
-	 * protected by an event instead of a stream sync */
-	if (b->stage_a_busy) HIP_TRY(hipEventSynchronize(b->ev_a));
-	fill_stage(b, b->h_stage_a, w0.data(), for_track ? 1 : 0, for_track);
 	const size_t up_bytes = for_track ? b->slab_bytes : b->slab_dbl_bytes;
 	bool grid_done = false;
 	if (b->h_stage_a_dev) {
@@ -487,7 +498,7 @@ int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track) {
 		 * second launch (w0 is taken from the host copy, 45 B doubles into the slab) */
 		TimedScope ts(b->ctx, "init_grid");
 		grid_done = launch_init_grid_ingest(b->view(), reinterpret_cast<const double *>(b->h_stage_a_dev) + 45 * (size_t)b->B, b->desc.resx, b->desc.resy,
-			lo_x, lo_y, hi_x, hi_y, hom ? 0 : 1, b->h_stage_a_dev, b->d_slab, up_bytes, b->ctx->stream);
+			lo_x, lo_y, hi_x, hi_y, hom ? 0 : 1, b->h_stage_a_dev, b->d_slab, up_bytes, for_track ? 0 : 1, b->ctx->stream);
 		if (!grid_done) launch_ingest_host(b->h_stage_a_dev, b->d_slab, up_bytes, b->ctx->stream);
 	} else HIP_TRY(hipMemcpyAsync(b->d_slab, b->h_stage_a, up_bytes, hipMemcpyHostToDevice, b->ctx->stream));
 	b->warps_dirty = false;   /* the slab carries the (identity) warps */
@@ -497,7 +508,7 @@ int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track) {
 	}
 	if (!for_track) { HIP_TRY(hipEventRecord(b->ev_a, b->ctx->stream)); b->stage_a_busy = true; }   /* (for_track: the caller waits for the loop that follows) */
 	b->have_corners = true;
-	b->pts_stale = false;   /* k_init_grid writes the current points too */
+	b->pts_stale = grid_done && for_track;   /* k_init_grid writes the current points too, except in front of a device loop */
 	++b->corners_epoch;
 	return MTFHIP_OK;
 }

@@ -22,8 +22,11 @@ __device__ __forceinline__ double lin_spaced(int i, int n, double lo, double hi)
 /* (ing: the staged state slab, read from pinned host memory by the first workgroups of the same launch -- w0_all then points into
  * the host copy too, so nothing in this kernel depends on the ingest having landed) */
 struct SlabIngest { const uint4 *src; uint4 *dst; unsigned n16; const unsigned *src_tail; unsigned *dst_tail; unsigned n_tail; };
+/* write_curr = 0: only the template grid is laid out; CURR_PTS / CURR_HXY / CURR_Z (40 of the 64 bytes per point) are left to
+ * k_apply_warp, which the caller's pts_stale flag triggers if an un-fused kernel ever asks for them (mtfhip_batch_track_region:
+ * the loop that follows warps the template grid itself) */
 __global__ __launch_bounds__(kBlock) void k_init_grid(BatchView bv, const double *w0_all, int resx, int resy,
-	double lo_x, double lo_y, double hi_x, double hi_y, int force_unit_z, SlabIngest ing) {
+	double lo_x, double lo_y, double hi_x, double hi_y, int force_unit_z, SlabIngest ing, int write_curr) {
 	const int t = blockIdx.y;
 	if (ing.src) {
 		const unsigned i = (blockIdx.y * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
@@ -47,7 +50,8 @@ __global__ __launch_bounds__(kBlock) void k_init_grid(BatchView bv, const double
 		const double z = force_unit_z ? 1.0 : Z;
 		/* affine re-homogenises (x, y, 1); homography keeps (X, Y, Z) */
 		const double2 hxy = force_unit_z ? p : make_double2(X, Y);
-		ip[i] = p; cp[i] = p; iz[i] = z; cz[i] = z; ih[i] = hxy; ch[i] = hxy;
+		ip[i] = p; iz[i] = z; ih[i] = hxy;
+		if (write_curr) { cp[i] = p; cz[i] = z; ch[i] = hxy; }
 	}
 }
 
@@ -572,18 +576,18 @@ __global__ __launch_bounds__(64) void k_finish(const double *partials, int nblk,
 void launch_init_grid(const BatchView &bv, const double *dev_w0, int resx, int resy, double lo_x, double lo_y,
 	double hi_x, double hi_y, int force_unit_z, hipStream_t st) {
 	MTFHIP_LAUNCH(k_init_grid, grid2(simple_blocks_per_target(bv.N), bv.B), dim3(kBlock), 0, st, bv, dev_w0, resx, resy,
-		lo_x, lo_y, hi_x, hi_y, force_unit_z, SlabIngest{nullptr, nullptr, 0, nullptr, nullptr, 0});
+		lo_x, lo_y, hi_x, hi_y, force_unit_z, SlabIngest{nullptr, nullptr, 0, nullptr, nullptr, 0}, 1);
 }
 /* the same with the slab ingest folded in; false: the launch is too small to carry it (the caller ingests separately) */
 bool launch_init_grid_ingest(const BatchView &bv, const double *host_w0_dev, int resx, int resy, double lo_x, double lo_y,
-	double hi_x, double hi_y, int force_unit_z, const void *src_host, void *dst, size_t bytes, hipStream_t st) {
+	double hi_x, double hi_y, int force_unit_z, const void *src_host, void *dst, size_t bytes, int write_curr, hipStream_t st) {
 	const unsigned n16 = (unsigned)(bytes / 16), n_tail = (unsigned)((bytes % 16) / 4);
 	const dim3 g = grid2(simple_blocks_per_target(bv.N), bv.B);
 	if ((size_t)g.x * g.y * kBlock < std::max(n16, n_tail)) return false;
 	const SlabIngest ing{static_cast<const uint4 *>(src_host), static_cast<uint4 *>(dst), n16,
 		reinterpret_cast<const unsigned *>(static_cast<const char *>(src_host) + 16 * (size_t)n16),
 		reinterpret_cast<unsigned *>(static_cast<char *>(dst) + 16 * (size_t)n16), n_tail};
-	MTFHIP_LAUNCH(k_init_grid, g, dim3(kBlock), 0, st, bv, host_w0_dev, resx, resy, lo_x, lo_y, hi_x, hi_y, force_unit_z, ing);
+	MTFHIP_LAUNCH(k_init_grid, g, dim3(kBlock), 0, st, bv, host_w0_dev, resx, resy, lo_x, lo_y, hi_x, hi_y, force_unit_z, ing, write_curr);
 	return true;
 }
 void launch_apply_warp(const BatchView &bv, hipStream_t st) {

@@ -278,7 +278,7 @@ void launch_fused_mc(const BatchView &bv, const ImgView &im, const FusedArgs &fa
 void launch_track_persist(const BatchView &bv, const ImgView &im, const FusedArgs &fa, const mtfhip_sm_desc &sm, const TrackState &ts,
 	double *partials, int nblk, const PersistState &ps, int max_passes, hipStream_t st);
 bool launch_init_grid_ingest(const BatchView &bv, const double *host_w0_dev, int resx, int resy, double lo_x, double lo_y,
-	double hi_x, double hi_y, int force_unit_z, const void *src_host, void *dst, size_t bytes, hipStream_t st);
+	double hi_x, double hi_y, int force_unit_z, const void *src_host, void *dst, size_t bytes, int write_curr, hipStream_t st);
 void launch_finish_track(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, const double *partials,
 	int nblk, hipStream_t st);
 
