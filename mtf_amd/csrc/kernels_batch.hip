@@ -373,18 +373,24 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 #pragma unroll
 		for (int q = 0; q < 16; ++q) tc[q] = 0.0;
 		if constexpr (NCC) {
+			if (ts.ncc_tm) {
+				/* the template's moments were reduced when the template was (ncc_template_moments: sum J0 | sum I0 J0 | Gram) */
 #pragma unroll
-			for (int k = 0; k < PPT; ++k) {
-				const int i = tid + k * kBlock;
-				if (i < N) {
+				for (int q = 0; q < 16; ++q) tc[q] = ts.ncc_tm[(size_t)t * 52 + q];
+			} else {
 #pragma unroll
-					for (int s = 0; s < 8; ++s) {
-						const double j = s < S ? (HOIST_J ? j0v[HOIST_J ? k : 0][s] : J0[(size_t)s * N + i]) : 0.0;
-						tc[s] += j; tc[8 + s] = fma(i0v[k], j, tc[8 + s]);
+				for (int k = 0; k < PPT; ++k) {
+					const int i = tid + k * kBlock;
+					if (i < N) {
+#pragma unroll
+						for (int s = 0; s < 8; ++s) {
+							const double j = s < S ? (HOIST_J ? j0v[HOIST_J ? k : 0][s] : J0[(size_t)s * N + i]) : 0.0;
+							tc[s] += j; tc[8 + s] = fma(i0v[k], j, tc[8 + s]);
+						}
 					}
 				}
+				block_allsum<16>(tc, redk);
 			}
-			block_allsum<16>(tc, redk);
 		}
 		const double nN = (double)N, inv_n = 1.0 / nN, inv_cn = 1.0 / cn;
 		for (int it = 0; it < sm.max_iters; ++it) {
