@@ -236,20 +236,39 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_weights(PfResampleArgs a) {
 	if (per <= kRun) {
 		double wv[kRun];
 		const double *src = a.likelihood_func == 0 ? a.lik : a.sim;
+		/* a thread's run is contiguous, so a wave's loads / stores are strided (80 bytes apart at 10 000 particles): pairs of
+		 * doubles halve the number of requests the single CU this kernel runs on has to issue (lo is even whenever per is) */
+		const bool pairs = (per & 1) == 0;
 #pragma unroll
-		for (int j = 0; j < kRun; ++j) wv[j] = lo + j < hi ? src[lo + j] : 0.0;
+		for (int j = 0; j < kRun; j += 2) {
+			if (pairs && lo + j + 1 < hi) { const double2 v = *reinterpret_cast<const double2 *>(src + lo + j); wv[j] = v.x; wv[j + 1] = v.y; }
+			else { wv[j] = lo + j < hi ? src[lo + j] : 0.0; wv[j + 1] = lo + j + 1 < hi ? src[lo + j + 1] : 0.0; }
+		}
 #pragma unroll
 		for (int j = 0; j < kRun; ++j)
 			if (lo + j < hi) { wv[j] = a.likelihood_func == 0 ? wv[j] : weight(0.0, wv[j]); run += wv[j]; }
 		const double incl = block_scan_incl(run, lds, total);
 		double c = incl - run;
+		double cv[kRun];
 #pragma unroll
-		for (int j = 0; j < kRun; ++j)
+		for (int j = 0; j < kRun; ++j) {
+			cv[j] = 0.0;
 			if (lo + j < hi) {
 				c += wv[j];
-				a.wts[lo + j] = wv[j]; a.cum[lo + j] = c / total;   /* particle_cum_wts /= particle_cum_wts[n - 1] */
+				cv[j] = c / total;                                    /* particle_cum_wts /= particle_cum_wts[n - 1] */
 				if (wv[j] >= bv) { bv = wv[j]; bi = lo + j; }         /* the highest weighted particle, last index on ties (`>=`, PF.cc:378-381) */
 			}
+		}
+#pragma unroll
+		for (int j = 0; j < kRun; j += 2) {
+			if (pairs && lo + j + 1 < hi) {
+				*reinterpret_cast<double2 *>(a.wts + lo + j) = make_double2(wv[j], wv[j + 1]);
+				*reinterpret_cast<double2 *>(a.cum + lo + j) = make_double2(cv[j], cv[j + 1]);
+			} else {
+				if (lo + j < hi) { a.wts[lo + j] = wv[j]; a.cum[lo + j] = cv[j]; }
+				if (lo + j + 1 < hi) { a.wts[lo + j + 1] = wv[j + 1]; a.cum[lo + j + 1] = cv[j + 1]; }
+			}
+		}
 	} else {
 		for (int k = lo; k < hi; ++k) {
 			const double w = weight(a.likelihood_func == 0 ? a.lik[k] : 0.0, a.likelihood_func == 0 ? 0.0 : a.sim[k]);
