@@ -329,9 +329,20 @@ __global__ __launch_bounds__(kBlock) void k_pf_select(PfResampleArgs a, double *
 			if (a.ids) a.ids[k] = id;
 		}
 		double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-		for (int s = 0; s < S; ++s) {
-			p[s] = a.st_in[(size_t)id * S + s];
-			if (resample) { a.st_out[(size_t)k * S + s] = p[s]; a.ar_out[(size_t)k * S + s] = a.ar_in[(size_t)id * S + s]; }
+		/* a particle's row is S (6 or 8) contiguous doubles: copied as pairs (rows start 16-byte aligned), all loads first */
+		const double2 *src_s = reinterpret_cast<const double2 *>(a.st_in + (size_t)id * S), *src_a = reinterpret_cast<const double2 *>(a.ar_in + (size_t)id * S);
+		double2 ps[4], pa[4];
+#pragma unroll
+		for (int s2 = 0; s2 < 4; ++s2) {
+			ps[s2] = 2 * s2 < S ? src_s[s2] : make_double2(0.0, 0.0);
+			pa[s2] = (resample && 2 * s2 < S) ? src_a[s2] : make_double2(0.0, 0.0);
+		}
+#pragma unroll
+		for (int s2 = 0; s2 < 4; ++s2) { p[2 * s2] = ps[s2].x; p[2 * s2 + 1] = ps[s2].y; }
+		if (resample) {
+			double2 *dst_s = reinterpret_cast<double2 *>(a.st_out + (size_t)k * S), *dst_a = reinterpret_cast<double2 *>(a.ar_out + (size_t)k * S);
+#pragma unroll
+			for (int s2 = 0; s2 < 4; ++s2) if (2 * s2 < S) { dst_s[s2] = ps[s2]; dst_a[s2] = pa[s2]; }
 		}
 		bv = a.wts[id]; bi = k;
 		if (a.mean_type == 1) {
