@@ -145,8 +145,16 @@ __global__ __launch_bounds__(kBlock) void k_pf_propagate(PfArgs a, double *state
 		for (int s = 0; s < S; ++s) pert[s] = a.mean[s] + a.sigma[s] * z[s];   /* ProjectiveBase::generatePerturbation :283-288 */
 	}
 	double st[8], ar[8], ns[8], nar[8];
+	{   /* rows of S contiguous doubles, 16-byte aligned: pairs */
+		const double2 *ps = reinterpret_cast<const double2 *>(states + (size_t)k * S), *pa = reinterpret_cast<const double2 *>(ars + (size_t)k * S);
 #pragma unroll
-	for (int s = 0; s < 8; ++s) { st[s] = s < S ? states[(size_t)k * S + s] : 0.0; ar[s] = s < S ? ars[(size_t)k * S + s] : 0.0; nar[s] = ar[s]; }
+		for (int s2 = 0; s2 < 4; ++s2) {
+			const double2 v = 2 * s2 < S ? ps[s2] : make_double2(0.0, 0.0), w = 2 * s2 < S ? pa[s2] : make_double2(0.0, 0.0);
+			st[2 * s2] = v.x; st[2 * s2 + 1] = v.y; ar[2 * s2] = w.x; ar[2 * s2 + 1] = w.y;
+		}
+#pragma unroll
+		for (int s = 0; s < 8; ++s) nar[s] = ar[s];
+	}
 	if (a.dynamic_model == 1 && a.update_type == 0) {          /* additiveAutoRegression1 :254-259 */
 #pragma unroll
 		for (int s = 0; s < 8; ++s) { ns[s] = st[s] + ar[s] + pert[s]; nar[s] = a.ar_coeff * (ns[s] - st[s]); }
@@ -170,8 +178,12 @@ __global__ __launch_bounds__(kBlock) void k_pf_propagate(PfArgs a, double *state
 		if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) { const double n22 = W[8]; for (int q = 0; q < 9; ++q) W[q] /= n22; }
 		state_from_warp_dev<SSM>(ns, W);
 	}
+	{
+		double2 *ps = reinterpret_cast<double2 *>(states + (size_t)k * S), *pa = reinterpret_cast<double2 *>(ars + (size_t)k * S);
 #pragma unroll
-	for (int s = 0; s < 8; ++s) if (s < S) { states[(size_t)k * S + s] = ns[s]; ars[(size_t)k * S + s] = nar[s]; }
+		for (int s2 = 0; s2 < 4; ++s2)
+			if (2 * s2 < S) { ps[s2] = make_double2(ns[2 * s2], ns[2 * s2 + 1]); pa[s2] = make_double2(nar[2 * s2], nar[2 * s2 + 1]); }
+	}
 }
 
 /* ---- weights -> cumulative weights -> resampling -> the estimate, one workgroup ---- */
