@@ -529,9 +529,11 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    # kernel duration for the roofline: hipEvents around EVERY fused launch of a second, untimed pass of the same loop (at least 40
-    # launches whatever --steps is; the events cost ~5 % of a step, which is why they stay out of the timed region above)
-    k_steps = max(40, args.steps)
+    # kernel duration for the roofline: hipEvents around EVERY fused launch of a second, untimed pass of the same loop (at least 200
+    # launches whatever --steps is -- with 40 the first launches after the region reset still weighed on the average, 0.720-0.727
+    # against 0.734-0.738 for the same code at --steps 200; the events cost ~5 % of a step, which is why they stay out of the timed
+    # region above)
+    k_steps = max(200, args.steps)
     ctx.timing(1)
     ctx.timing_reset()
     run(k_steps)
