@@ -158,6 +158,34 @@ def parity_gate(ctx, am_name, res, frame0, frame1, corners):
     return worst
 
 
+def pf_parity(ctx, frame0, corners, n=32):
+    """candidate weights of the tolerance-mode (fast) scorer against the CPU oracle on the bench's own template: n particles
+    proposed from shared draws, scored on the device and by the oracle's nt::PF iteration"""
+    import mtf_amd
+    from mtf_amd.sm import ParticleFilter
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    rng = np.random.default_rng(5)
+    sigma = (1.0, 0.5, 1, 1, 1, 1, 1, 1)
+    ssm = O.SSM(O.SSM_HOM, 50, 50); am = O.AM(O.AM_SSD, 50, 50); am.set_curr_img(frame0)
+    ssm.set_corners(corners); am.initialize_pix_vals(ssm.get("curr_pts")); am.initialize_similarity()
+    pp = O.pf_params(n, corner_based_sampling=1, sigma=sigma, resampling_type=0)
+    normals, uniforms = rng.normal(size=(n, 10)), rng.uniform(size=n)
+    _, _, w_o, _, _ = O.pf_iteration(am, ssm, pp, np.zeros((n, 8)), np.zeros((n, 8)), normals, uniforms, 0.0)
+    out = {}
+    for name, mode in (("fast", mtf_amd.MATH_FAST), ("replay", mtf_amd.MATH_REPLAY)):
+        pf = ParticleFilter(ctx, mtf_amd.SSM_HOMOGRAPHY, 50, 50, n_particles=n, ssm_sigma=sigma, corner_based_sampling=1, resampling_type=0)
+        pf.batch.set_math_mode(mode)
+        pf.initialize(corners[None])
+        pf.iteration(normals, uniforms)
+        w_d = pf.particles()[2]
+        out[name] = float(np.max(np.abs(w_d - w_o) / np.abs(w_o)))
+        pf.close()
+    out.update({"candidates": n, "budget": 1e-9, "pass": bool(max(out["fast"], out["replay"]) <= 1e-9),
+                "note": "max relative error of the particle weights vs the CPU oracle's nt::PF iteration on shared draws"})
+    return out
+
+
 def secondary_workload(args):
     """Secondary metrics of BASELINE.md section 3 (not the driver's headline line): config 3 grid
     patch-iterations/s, config 4 PF candidates/s (sharded over ranks, one RCCL all-gather of the scores per
@@ -166,7 +194,6 @@ def secondary_workload(args):
     import mtf_amd
     from mtf_amd import synth
     from mtf_amd.sm import GridTracker, NTSearchMethod
-    from mtf_amd.dist import ShardedScorer
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -270,33 +297,44 @@ def secondary_workload(args):
         ctx.set_image(frame0)
         C = args.particles
         comm = Comm.torch_bootstrap(local_rank) if world > 1 else None
+        KI = max(1, args.pf_iters)
         pf = ParticleFilter(ctx, mtf_amd.SSM_HOMOGRAPHY, 50, 50, n_particles=C, ssm_sigma=(1.0, 0.5, 1, 1, 1, 1, 1, 1), corner_based_sampling=1,
                             dynamic_model=0, update_type=1, likelihood_func=0, resampling_type=1, mean_type=0, likelihood_alpha=1.0,
-                            max_iters=1, epsilon=-1.0, seed=synth.DEFAULT_SEED, comm=comm)
+                            max_iters=KI, epsilon=-1.0, seed=synth.DEFAULT_SEED, comm=comm)
         pf.batch.set_math_mode(mtf_amd.MATH_REPLAY if os.environ.get("MTFHIP_MATH", "fast")[0] == "r" else mtf_amd.MATH_FAST)
         pf.initialize(corners[None])
 
         def step():
-            pf.iteration()        # one read-back of the estimate per iteration, as nt::PF needs it for its convergence test
+            # KI = 1: one iteration + the read-back of its estimate (what nt::PF::update with max_iters = 1 is: the caller reads the
+            # corners every frame).  KI > 1: update() with epsilon < 0 enqueues its KI iterations back to back, one read-back.
+            pf.update()
         dt = timed(step)
         kernel_pass(step)
-        kms, kn = ctx.timing_get("score_candidates")
-        pms, _ = ctx.timing_get("pf_propagate"); rms, _ = ctx.timing_get("pf_resample")
-        n_local = -(-C // world)
+        kms, kn = ctx.timing_get("pf_score")
+        rms, _ = ctx.timing_get("pf_resample"); gms, _ = ctx.timing_get("pf_allgather"); pms, pn = ctx.timing_get("pf_propose")
+        pms = pms * pn / max(kn, 1)     # (a launch of its own only where the proposals could not be made ahead: per iteration)
+        n_local = Comm.shard_bounds(C, world, rank)[1]
         flop_per_sample = 60.0   # ~60 FP64 flop per bilinear sample of a homography candidate
         tf = n_local * 2500 * flop_per_sample / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+        us_iter = dt / (args.steps * KI) * 1e6
         out.update({"metric": "PF candidates/sec, PF+SSD+Homography 50x50, %d particles" % C,
-                    "value": C * args.steps / dt, "unit": "candidates/s", "ms_per_step": dt / args.steps * 1e3,
-                    "scaling": "strong", "config": {"workload": "%d particles x 2500 px: generation + scoring (sharded over %d rank(s), one all-gather of "
-                                                                "the weights) + resampling + estimate per step" % (C, world),
-                                                    "score_kernel_ms": kms, "propagate_kernel_ms": pms, "resample_kernel_ms": rms,
-                                                    "samples_per_s": C * 2500 * args.steps / dt},
+                    "value": C * KI * args.steps / dt, "unit": "candidates/s", "ms_per_step": dt / args.steps * 1e3,
+                    "scaling": "strong", "config": {"workload": "%d particles x 2500 px: proposal + scoring (sharded over %d rank(s), one in-place "
+                                                                "all-gather of the weights) + cumulative weights + resampling + estimate; "
+                                                                "%d iteration(s) per update(), one read-back per update()" % (C, world, KI),
+                                                    "iterations_per_step": KI, "us_per_iteration": us_iter,
+                                                    "score_kernel_ms": kms, "resample_kernels_ms": rms, "allgather_ms": gms, "propose_kernel_ms": pms,
+                                                    # share of the scorer in the device time of an iteration (same event pass for all terms)
+                                                    "scorer_share_of_iteration": kms / (kms + rms + gms + pms) if kms > 0 else None,
+                                                    "samples_per_s": C * 2500 * KI * args.steps / dt},
                     "roofline": {"bound": "fp64-valu", "note": "the candidate scorer is not HBM bound (SURVEY 8d: ~1 MB of compulsory traffic for 25 M "
                                  "samples): fraction of the FP64 vector peak at ~60 flop per sample, and the texel gather rate served by L1 / L2",
                                  "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6, "traffic": None,
-                                 "kernel": "k_score_candidates_fast" if pf.batch.get_math_mode() else "k_score_candidates", "avg_kernel_ms": kms,
+                                 "kernel": "k_pf_score", "avg_kernel_ms": kms,
                                  "launches_timed": kn, "samples_per_launch": n_local * 2500,
                                  "texel_gather_GBs": n_local * 2500 * 16 / (kms * 1e-3) / 1e9 if kms > 0 else None}})
+        if rank == 0 and world == 1 and not args.no_cpu:
+            out["parity"] = pf_parity(ctx, frame0, corners)
         if rank == 0 and not args.no_cpu:
             import oracle_py as O
             ssm = O.SSM(O.SSM_HOM, 50, 50); am = O.AM(O.AM_SSD, 50, 50); am.set_curr_img(frame0)
@@ -419,6 +457,7 @@ def main():
     ap.add_argument("--workload", default="lk", choices=["lk", "grid", "pf", "mi", "dropin"],
                     help="lk = the headline metric (default); the others are the secondary metrics of BASELINE.md")
     ap.add_argument("--particles", type=int, default=10000)
+    ap.add_argument("--pf-iters", type=int, default=1, help="pf workload: iterations per update() call (epsilon < 0: enqueued back to back)")
     ap.add_argument("--grid-iters", type=int, default=10)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)

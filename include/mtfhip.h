@@ -292,11 +292,16 @@ int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int n
 	double *dev_likelihoods, double *dev_similarities);
 
 /* ---- the particle filter on the device: nt::PF (SM/src/NT/PF.cc) over the batch's single target ----
- * Sample generation (the SSM's stochastic sampler and dynamic models: ProjectiveBase.cc:163-317, Homography.cc:899-942),
- * scoring, cumulative weights, multinomial resampling and the estimate run as five launches per iteration; only the estimate
- * (state, corners, best weight) crosses PCIe.  Enum values are the reference's (SM/include/mtf/SM/PFParams.h:10-33).
- * Not provided: several sampler distributions (n_distr > 1), jacobian_as_sigma, residual resampling, the geometric
- * (SVD based) sampler of Affine.cc:464-552 -- the calls return MTFHIP_ERR_NOT_IMPLEMENTED. */
+ * One iteration of update()'s loop is three launches: proposal (the SSM's stochastic sampler and dynamic models:
+ * ProjectiveBase.cc:163-317, Homography.cc:899-942, Affine.cc:464-553) + scoring + particle weight; chunked cumulative weights;
+ * multinomial resampling + estimate.  Only the estimate (state, corners, best weight) crosses PCIe.  Enum values are the
+ * reference's (SM/include/mtf/SM/PFParams.h:10-33).
+ * Affine follows Affine.cc: compositional updates with point based sampling (pt_based_sampling 1 / 2: three canonical points
+ * disturbed, affine map of the three pairs) or, for AutoRegression1, the geometric perturbation (geomToState of six draws);
+ * the combinations the reference itself throws for (additive + point based, compositional RandomWalk + geometric) return
+ * MTFHIP_ERR_NOT_IMPLEMENTED with its message, and so does additive + geometric, which needs Affine::stateToGeom -- a 2 x 2
+ * JacobiSVD whose sign / ordering conventions decide its branches and cannot be reproduced without Eigen.
+ * Not provided: several sampler distributions (n_distr > 1), jacobian_as_sigma, residual resampling. */
 typedef struct mtfhip_pf mtfhip_pf;
 typedef struct mtfhip_comm mtfhip_comm;
 typedef struct mtfhip_pf_desc {
@@ -313,6 +318,7 @@ typedef struct mtfhip_pf_desc {
 	double ar_coeff;          /* a of the AutoRegression1 models (StateSpaceModel.h:311-318: 0.5) */
 	double ssm_sigma[8], ssm_mean[8]; /* the sampler's normal distributions (ProjectiveBase::initializeSampler) */
 	unsigned long long seed;  /* device generator (Philox4x32-10), used when no draws are handed in */
+	int pt_based_sampling;    /* AffineParams::pt_based_sampling (0 geometric, 1, 2: Affine.cc:464-503; default 0, parameters.h:254) */
 } mtfhip_pf_desc;
 int mtfhip_pf_create(mtfhip_batch *b, const mtfhip_pf_desc *desc, mtfhip_pf **out);
 void mtfhip_pf_destroy(mtfhip_pf *pf);   /* before the batch it was created on */
@@ -320,25 +326,37 @@ void mtfhip_pf_destroy(mtfhip_pf *pf);   /* before the batch it was created on *
 int mtfhip_pf_initialize(mtfhip_pf *pf);
 int mtfhip_pf_set_region(mtfhip_pf *pf, const double *corners /* 8 */);          /* PF.cc:616-620 */
 int mtfhip_pf_set_sampler(mtfhip_pf *pf, const double *sigma, const double *mean); /* ProjectiveBase.cc:208-215 */
-/* one iteration of update()'s loop (PF.cc:260-447); normals n x nz (nz = 10 with corner based homography sampling, else S)
- * and uniforms n: host arrays, or NULL for the device generator; update_norm = squared corner change of the estimate */
+/* one iteration of update()'s loop (PF.cc:260-447); normals n x nz (nz = 10 with corner based homography sampling, 6 / 8 / 6 for
+ * Affine point based 1 / 2 / geometric, else S) and uniforms n: host arrays, or NULL for the device generator; update_norm =
+ * squared corner change of the estimate */
 int mtfhip_pf_iteration(mtfhip_pf *pf, const double *normals, const double *uniforms, double *update_norm);
-int mtfhip_pf_update(mtfhip_pf *pf, int *n_iters);                                   /* PF.cc:207-447 */
+/* PF.cc:207-447.  epsilon < 0 (no convergence test) and mean_type != Corners: the max_iters iterations are enqueued back to
+ * back and only the last estimate is read back */
+int mtfhip_pf_update(mtfhip_pf *pf, int *n_iters);
 int mtfhip_pf_get_particles(mtfhip_pf *pf, double *states /* n x S */, double *ars, double *wts /* n */, int *resample_ids /* n */);
 int mtfhip_pf_set_particles(mtfhip_pf *pf, const double *states, const double *ars /* or NULL: zeros */);
 double mtfhip_pf_max_similarity(const mtfhip_pf *pf);
+int mtfhip_pf_set_max_similarity(mtfhip_pf *pf, double max_similarity);   /* PF.cc:443-446: after am->updateModel (enable_learning) */
 /* ---- the collective of the sharded candidate axis: RCCL directly (no torch), bound with dlopen at first use ----
  * rank 0 obtains the 128-byte id and hands it to the other ranks by whatever channel the host program has (MPI, a file, a
  * socket, torch.distributed); every rank then creates its communicator.  SM/src/PF.cc:262-277 is the weights vector this
- * replaces once particles are sharded: rank r scores its contiguous block, ONE all-gather puts every weight on every rank,
- * resampling runs redundantly on identical data. */
+ * replaces once particles are sharded: rank r scores the contiguous block [r m, (r + 1) m), m = ceil(n / world) (the last
+ * blocks may be short or empty: mtfhip_pf_shard_bounds), ONE all-gather of m weights per rank -- in place, the blocks already
+ * sit at their global positions -- puts every weight on every rank, and resampling runs redundantly on identical data. */
 int mtfhip_comm_unique_id(void *id128);
 int mtfhip_comm_create(const void *id128 /* NULL allowed for world 1 */, int rank, int world, int device, mtfhip_comm **out);
+/* `world` ranks as threads of ONE process on ONE device (out[r] = rank r's communicator, one host thread per rank): the
+ * all-gather is a rendezvous of the threads plus device copies.  It exists so that the sharded code path can be executed and
+ * compared with the unsharded filter where only one GPU is available; everything but the exchange itself is the RCCL path. */
+int mtfhip_comm_create_loopback(int world, int device, mtfhip_comm **out /* [world] */);
 void mtfhip_comm_destroy(mtfhip_comm *comm);
 int mtfhip_comm_rank(const mtfhip_comm *comm);
 int mtfhip_comm_world(const mtfhip_comm *comm);
+/* in place when dev_send == dev_recv + rank * count_per_rank (ncclAllGather's in-place form) */
 int mtfhip_allgather_scores(mtfhip_comm *comm, const double *dev_send, int count_per_rank, double *dev_recv /* world x count */, void *hip_stream);
 int mtfhip_pf_set_comm(mtfhip_pf *pf, mtfhip_comm *comm);   /* shard the filter's scoring over the communicator's ranks */
+/* the partition mtfhip_pf_set_comm uses (host arithmetic, no device): rank's block [lo, lo + count), per_rank = ceil(n / world) */
+int mtfhip_pf_shard_bounds(int n_particles, int world, int rank, int *lo, int *count, int *per_rank);
 
 /* ---- NN-SM dataset generation (the second batch axis of the path; the search itself stays with FLANN) ----
  * Row c of the C x N feature matrix = updateDistFeat() of the patch sampled under state c:

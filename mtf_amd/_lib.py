@@ -61,7 +61,8 @@ class PFDesc(C.Structure):
     _fields_ = [("n_particles", C.c_int), ("max_iters", C.c_int), ("epsilon", C.c_double), ("dynamic_model", C.c_int),
                 ("update_type", C.c_int), ("likelihood_func", C.c_int), ("resampling_type", C.c_int), ("mean_type", C.c_int),
                 ("corner_based_sampling", C.c_int), ("reset_to_mean", C.c_int), ("measurement_sigma", C.c_double),
-                ("ar_coeff", C.c_double), ("ssm_sigma", C.c_double * 8), ("ssm_mean", C.c_double * 8), ("seed", C.c_ulonglong)]
+                ("ar_coeff", C.c_double), ("ssm_sigma", C.c_double * 8), ("ssm_mean", C.c_double * 8), ("seed", C.c_ulonglong),
+                ("pt_based_sampling", C.c_int)]
 
 
 # every exported symbol of include/mtfhip.h (tests check that the library exports all of them)
@@ -94,6 +95,7 @@ SYMBOLS = [
     "mtfhip_sample_candidates", "mtfhip_sample_candidates_dev",
     "mtfhip_pf_create", "mtfhip_pf_destroy", "mtfhip_pf_initialize", "mtfhip_pf_set_region", "mtfhip_pf_set_sampler",
     "mtfhip_pf_iteration", "mtfhip_pf_update", "mtfhip_pf_get_particles", "mtfhip_pf_set_particles", "mtfhip_pf_max_similarity",
+    "mtfhip_pf_set_max_similarity", "mtfhip_comm_create_loopback", "mtfhip_pf_shard_bounds",
     "mtfhip_comm_unique_id", "mtfhip_comm_create", "mtfhip_comm_destroy", "mtfhip_comm_rank", "mtfhip_comm_world",
     "mtfhip_allgather_scores", "mtfhip_pf_set_comm",
     "mtfhip_timing_enable", "mtfhip_timing_reset", "mtfhip_timing_get",

@@ -2,11 +2,12 @@
  * api_pf.hip -- the particle filter behind the C ABI (nt::PF, SM/src/NT/PF.cc) and the collective of its sharded form
  * (C-ABI implementation, include/mtfhip.h; shared declarations: mtfhip_api_internal.h)
  *
- * One iteration of nt::PF::update's loop is five launches: sample generation (k_pf_propagate), scoring
- * (k_score_candidates[_fast]; on R ranks each scores its contiguous block and ONE all-gather over RCCL puts every weight on
- * every rank, PF.cc:262-277), weights -> cumulative weights (k_pf_weights), resampling (k_pf_select), estimate
- * (k_pf_estimate, which also delivers its 32 doubles to host-coherent memory and raises the flag the host waits on).  The
- * reference does all of it per particle on the host, including a 4-corner DLT (8 x 9 JacobiSVD) per sample.
+ * One iteration of nt::PF::update's loop is three launches (kernels_pf.hip): scoring + weight (k_pf_score; on R ranks each
+ * scores its contiguous block and ONE in-place all-gather over RCCL leaves the flat weight vector on every rank,
+ * PF.cc:262-277), chunk-local cumulative weights (k_pf_scan), resampling + estimate + the proposals of the next iteration
+ * (k_pf_select, whose last workgroup also delivers the 32 doubles of the estimate to host-coherent memory and raises the flag
+ * the host waits on); a fourth launch (k_pf_propose) only where the proposals could not be made ahead.  The reference does all
+ * of it per particle on the host, including a 4-corner DLT (8 x 9 JacobiSVD) per sample.
  *
  * RCCL is bound at run time (dlopen): libmtfhip.so has no link-time dependency on it, a process that already carries an
  * RCCL (PyTorch-ROCm bundles one) shares it, and the single-GPU library works where RCCL is absent.
@@ -14,6 +15,8 @@
 #include "mtfhip_api_internal.h"
 
 #include <dlfcn.h>
+#include <condition_variable>
+#include <mutex>
 
 /* ------------------------------------------------------------------ RCCL, bound at run time */
 namespace {
@@ -28,6 +31,7 @@ struct Rccl {
 	int (*AllGather)(const void *, void *, size_t, int, rccl_comm_t, hipStream_t) = nullptr;
 	const char *(*GetErrorString)(int) = nullptr;
 	bool ok = false;
+	std::string why = "symbols missing";   /* dlerror() is read once: a second call returns NULL */
 };
 Rccl &rccl() {
 	static Rccl r;
@@ -37,7 +41,7 @@ Rccl &rccl() {
 	const char *names[] = {"librccl.so.1", "librccl.so"};
 	for (const char *n : names) if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);   /* the copy the process already has */
 	for (const char *n : names) if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-	if (!r.handle) return r;
+	if (!r.handle) { const char *e = dlerror(); r.why = e ? e : "librccl.so not found"; return r; }
 	r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.handle, "ncclGetUniqueId"));
 	r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.handle, "ncclCommInitRank"));
 	r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
@@ -48,34 +52,78 @@ Rccl &rccl() {
 }
 }  // namespace
 
+/* A communicator is either an RCCL one (one process per GPU, the production form), a single rank (no exchange), or a member of a
+ * LOOPBACK group: `world` ranks that are threads of one process sharing one GPU.  The loopback group exists so that the sharded
+ * code path -- block bounds, ragged last blocks, the in-place all-gather layout, the re-evaluated proposals -- can be executed
+ * and compared with the unsharded filter on a single GPU; its all-gather is a rendezvous of the member threads plus
+ * device-to-device copies.  Everything outside mtfhip_allgather_scores is the same for the three kinds. */
+struct LoopGroup {
+	int world = 1, refs = 0;
+	std::mutex mu;
+	std::condition_variable cv;
+	int arrived = 0;
+	unsigned long gen = 0;
+	std::vector<const double *> send;
+	void barrier() {
+		std::unique_lock<std::mutex> lk(mu);
+		const unsigned long g = gen;
+		if (++arrived == world) { arrived = 0; ++gen; cv.notify_all(); }
+		else cv.wait(lk, [&] { return gen != g; });
+	}
+};
 struct mtfhip_comm {
 	int rank = 0, world = 1, device = 0;
-	rccl_comm_t comm = nullptr;   /* NULL when world == 1: the all-gather is a device copy */
+	rccl_comm_t comm = nullptr;   /* NULL when world == 1 or loopback */
+	LoopGroup *loop = nullptr;
 };
 
 struct mtfhip_pf {
 	mtfhip_batch *b = nullptr;
 	mtfhip_pf_desc d;
 	mtfhip_comm *comm = nullptr;
-	int n = 0, S = 0, cur = 0;
+	int n = 0, S = 0;
+	int sampler = PF_SAMPLER_STATE, nz = 8;
 	unsigned iter = 0;
 	double max_similarity = 0;
 	bool initialized = false;
-	double *d_states[2] = {nullptr, nullptr}, *d_ars[2] = {nullptr, nullptr};
-	double *d_lik = nullptr, *d_sim = nullptr, *d_wts = nullptr, *d_cum = nullptr, *d_out = nullptr, *d_normals = nullptr, *d_uniforms = nullptr;
-	double *d_parts = nullptr;   /* per-workgroup partial results of the selection pass */
-	double *d_send = nullptr, *d_recv = nullptr;   /* sharded scoring: [2 m] send, [2 m world] receive (likelihood | similarity) */
-	int *d_ids = nullptr;
+	/* look-ahead: the selection pass of iteration t leaves the proposals of iteration t + 1 in d_prop[1 - pc] (device generator
+	 * only); valid while nothing they depend on has changed -- the particle set, the sampler's distributions, the template
+	 * corners.  MTFHIP_PF_LOOKAHEAD=0: every iteration proposes in a launch of its own. */
+	bool lookahead_enabled = true, prop_valid = false;
+	unsigned prop_iter = 0;
+	long prop_corners_epoch = -1;
+	int pc = 0;
+	size_t wts_capacity = 0;
+	double *d_st = nullptr, *d_ar = nullptr;                                   /* the current (resampled) set */
+	double *d_prop[2] = {nullptr, nullptr}, *d_prop_ar[2] = {nullptr, nullptr}; /* proposals: this iteration's | the next one's */
+	double *d_wts = nullptr, *d_cum = nullptr, *d_chunk = nullptr, *d_out = nullptr, *d_normals = nullptr, *d_uniforms = nullptr;
+	double *d_parts = nullptr, *d_gparts = nullptr;   /* per-workgroup rows of the selection pass and their per-group folds */
+	int *d_ids = nullptr, *d_counters = nullptr;
 	double prev_corners[8];
 };
 
+/* block of rank `rank`: [lo, lo + cnt) with m = ceil(n / world) particles per rank (the last blocks may be short or empty), so
+ * that the all-gather of m weights per rank IS the flat weight vector */
+static void pf_shard(int n, int world, int rank, int *lo, int *cnt, int *m) {
+	const int mm = (n + world - 1) / world;
+	const int l = std::min(n, rank * mm), h = std::min(n, l + mm);
+	*lo = l; *cnt = h - l; *m = mm;
+}
+
 extern "C" {
+
+int mtfhip_pf_shard_bounds(int n_particles, int world, int rank, int *lo, int *count, int *per_rank) {
+	if (n_particles < 0 || world < 1 || rank < 0 || rank >= world || !lo || !count || !per_rank)
+		return fail(MTFHIP_ERR_INVALID_ARG, "pf_shard_bounds: invalid argument");
+	pf_shard(n_particles, world, rank, lo, count, per_rank);
+	return MTFHIP_OK;
+}
 
 /* ------------------------------------------------------------------ the collective */
 int mtfhip_comm_unique_id(void *id128) {
 	if (!id128) return fail(MTFHIP_ERR_INVALID_ARG, "comm_unique_id: NULL argument");
 	Rccl &r = rccl();
-	if (!r.ok) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "RCCL (librccl.so) could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+	if (!r.ok) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "RCCL (librccl.so) could not be loaded: %s", r.why.c_str());
 	rccl_unique_id id;
 	const int rc = r.GetUniqueId(&id);
 	if (rc != 0) return fail(MTFHIP_ERR_HIP, "ncclGetUniqueId failed: %s", r.GetErrorString ? r.GetErrorString(rc) : "?");
@@ -89,7 +137,7 @@ int mtfhip_comm_create(const void *id128, int rank, int world, int device, mtfhi
 	if (world > 1) {
 		if (!id128) { delete c; return fail(MTFHIP_ERR_INVALID_ARG, "comm_create: the unique id of rank 0 is required for world > 1"); }
 		Rccl &r = rccl();
-		if (!r.ok) { delete c; return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "RCCL (librccl.so) could not be loaded"); }
+		if (!r.ok) { delete c; return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "RCCL (librccl.so) could not be loaded: %s", r.why.c_str()); }
 		if (hipSetDevice(device) != hipSuccess) { delete c; return fail(MTFHIP_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device); }
 		rccl_unique_id id;
 		std::memcpy(id.internal, id128, sizeof(id.internal));
@@ -99,20 +147,52 @@ int mtfhip_comm_create(const void *id128, int rank, int world, int device, mtfhi
 	*out = c;
 	return MTFHIP_OK;
 }
+/* `world` loopback ranks on one device: out[r] is rank r's communicator; each is used by its own host thread */
+int mtfhip_comm_create_loopback(int world, int device, mtfhip_comm **out) {
+	if (!out || world < 1) return fail(MTFHIP_ERR_INVALID_ARG, "comm_create_loopback: invalid world %d", world);
+	LoopGroup *g = new LoopGroup;
+	g->world = world; g->refs = world; g->send.assign((size_t)world, nullptr);
+	for (int r = 0; r < world; ++r) {
+		mtfhip_comm *c = new mtfhip_comm;
+		c->rank = r; c->world = world; c->device = device; c->loop = g;
+		out[r] = c;
+	}
+	return MTFHIP_OK;
+}
 void mtfhip_comm_destroy(mtfhip_comm *c) {
 	if (!c) return;
 	if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
+	if (c->loop) {
+		bool last;
+		{ std::lock_guard<std::mutex> lk(c->loop->mu); last = --c->loop->refs == 0; }
+		if (last) delete c->loop;
+	}
 	delete c;
 }
 int mtfhip_comm_rank(const mtfhip_comm *c) { return c ? c->rank : 0; }
 int mtfhip_comm_world(const mtfhip_comm *c) { return c ? c->world : 1; }
 /* every rank contributes `count` doubles; every rank receives world x count, rank-major (PF.cc:262-277's weights vector once
- * the particles are sharded).  world == 1: a device-to-device copy. */
+ * the particles are sharded).  In place when dev_send == dev_recv + rank * count (ncclAllGather's in-place form).
+ * world == 1: a device-to-device copy (nothing when in place). */
 int mtfhip_allgather_scores(mtfhip_comm *c, const double *dev_send, int count, double *dev_recv, void *hip_stream) {
 	if (!c || !dev_send || !dev_recv || count <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "allgather_scores: invalid argument");
 	hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+	const bool in_place = dev_send == dev_recv + (size_t)c->rank * count;
+	if (c->loop) {
+		LoopGroup *g = c->loop;
+		HIP_TRY(hipStreamSynchronize(st));            /* this rank's block is complete */
+		g->send[(size_t)c->rank] = dev_send;
+		g->barrier();                                 /* ... and so is everybody's */
+		for (int q = 0; q < c->world; ++q) {
+			if (q == c->rank && in_place) continue;
+			HIP_TRY(hipMemcpyAsync(dev_recv + (size_t)q * count, g->send[(size_t)q], sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, st));
+		}
+		HIP_TRY(hipStreamSynchronize(st));
+		g->barrier();                                 /* nobody's send block is overwritten before everybody has read it */
+		return MTFHIP_OK;
+	}
 	if (c->world == 1 || !c->comm) {
-		HIP_TRY(hipMemcpyAsync(dev_recv, dev_send, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, st));
+		if (!in_place) HIP_TRY(hipMemcpyAsync(dev_recv, dev_send, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, st));
 		return MTFHIP_OK;
 	}
 	const int rc = rccl().AllGather(dev_send, dev_recv, (size_t)count, RCCL_FLOAT64, c->comm, st);
@@ -122,10 +202,34 @@ int mtfhip_allgather_scores(mtfhip_comm *c, const double *dev_send, int count, d
 
 /* ------------------------------------------------------------------ the particle filter */
 static void pf_free(mtfhip_pf *pf) {
-	void *ptrs[] = {pf->d_states[0], pf->d_states[1], pf->d_ars[0], pf->d_ars[1], pf->d_lik, pf->d_sim, pf->d_wts, pf->d_cum, pf->d_out,
-		pf->d_normals, pf->d_uniforms, pf->d_send, pf->d_recv, pf->d_ids, pf->d_parts};
+	void *ptrs[] = {pf->d_st, pf->d_ar, pf->d_prop[0], pf->d_prop[1], pf->d_prop_ar[0], pf->d_prop_ar[1], pf->d_wts, pf->d_cum, pf->d_chunk, pf->d_out,
+		pf->d_normals, pf->d_uniforms, pf->d_ids, pf->d_parts, pf->d_gparts, pf->d_counters};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 }
+/* which sampler the (SSM, update type, dynamic model, sampling switches) combination selects -- and which combinations the
+ * reference itself refuses */
+static int pf_pick_sampler(const mtfhip_batch *b, const mtfhip_pf_desc *d, int *sampler, int *nz) {
+	if (b->desc.ssm == MTFHIP_SSM_HOMOGRAPHY) {
+		*sampler = d->corner_based_sampling ? PF_SAMPLER_HOM_CORNERS : PF_SAMPLER_STATE;
+		*nz = d->corner_based_sampling ? 10 : 8;
+		return MTFHIP_OK;
+	}
+	const int pt = d->pt_based_sampling;
+	if (pt < 0 || pt > 2) return fail(MTFHIP_ERR_INVALID_ARG, "pf_create: pt_based_sampling must be 0, 1 or 2 (AffineParams, Affine.h)");
+	if (d->update_type == 0) {
+		if (pt) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "Affine::additive%s :: point based sampling is not implemented yet", d->dynamic_model ? "AutoRegression1" : "RandomWalk");   /* Affine.cc:509-511, 525-527 */
+		/* Affine.cc:512-519, 528-538: base and AR state go through stateToGeom (Affine.cc:411-462), whose branches depend on the sign
+		 * and ordering conventions of Eigen's 2 x 2 JacobiSVD -- Eigen is not in this image, so the result could not be pinned */
+		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "pf_create: Affine additive sampling perturbs the geometric parametrisation through Affine::stateToGeom "
+			"(a JacobiSVD whose conventions cannot be reproduced without Eigen): use update_type Compositional");
+	}
+	if (d->dynamic_model == 0 && pt == 0)
+		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "Affine::compositionalRandomWalk :: geometric sampling is not implemented yet");   /* Affine.cc:550-552 */
+	*sampler = pt == 1 ? PF_SAMPLER_AFF_PTS1 : pt == 2 ? PF_SAMPLER_AFF_PTS2 : PF_SAMPLER_AFF_GEOM;
+	*nz = pt == 2 ? 8 : 6;
+	return MTFHIP_OK;
+}
+static size_t pf_round_chunk(size_t n) { const size_t c = (size_t)pf_chunk(); return (n + c - 1) / c * c; }
 int mtfhip_pf_create(mtfhip_batch *b, const mtfhip_pf_desc *d, mtfhip_pf **out) {
 	if (!b || !d || !out) return fail(MTFHIP_ERR_INVALID_ARG, "pf_create: NULL argument");
 	if (b->B != 1) return fail(MTFHIP_ERR_INVALID_ARG, "pf_create: the particle filter tracks one target (batch of %d)", b->B);
@@ -135,17 +239,24 @@ int mtfhip_pf_create(mtfhip_batch *b, const mtfhip_pf_desc *d, mtfhip_pf **out) 
 	if (d->resampling_type < 0 || d->resampling_type > 3) return fail(MTFHIP_ERR_INVALID_ARG, "pf_create: unknown resampling type %d", d->resampling_type);
 	if (d->resampling_type == 3) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "pf_create: residual resampling (PF.cc:538-582) is not available on the device");
 	if (b->desc.am == MTFHIP_AM_MI) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "pf_create: candidate scoring covers SSD and NCC");
-	if (b->desc.ssm == MTFHIP_SSM_AFFINE && d->update_type == 1 && d->corner_based_sampling == 0)
-		/* Affine::compositionalRandomWalk throws for geometric sampling (Affine.cc:540-552); point based sampling is the DLT of three points */
-		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "pf_create: Affine compositional sampling needs point based perturbations, which are not implemented");
+	TRY(single_channel(b, "pf_create"));
+	int sampler = 0, nz = 0;
+	TRY(pf_pick_sampler(b, d, &sampler, &nz));
 	mtfhip_pf *pf = new mtfhip_pf;
-	pf->b = b; pf->d = *d; pf->n = d->n_particles; pf->S = b->S;
-	const size_t nS = (size_t)pf->n * pf->S, n = (size_t)pf->n;
+	pf->b = b; pf->d = *d; pf->n = d->n_particles; pf->S = b->S; pf->sampler = sampler; pf->nz = nz;
+	{ const char *e = std::getenv("MTFHIP_PF_LOOKAHEAD"); pf->lookahead_enabled = !(e && e[0] == '0'); }
+	const size_t nS = (size_t)pf->n * pf->S, n = (size_t)pf->n, npad = pf_round_chunk(n), nch = npad / (size_t)pf_chunk();
 	bool okm = true;
 	auto A = [&](auto &p, size_t bytes) { if (hipMalloc(reinterpret_cast<void **>(&p), bytes) != hipSuccess) okm = false; };
-	for (int k = 0; k < 2; ++k) { A(pf->d_states[k], sizeof(double) * nS); A(pf->d_ars[k], sizeof(double) * nS); }
-	A(pf->d_lik, sizeof(double) * n); A(pf->d_sim, sizeof(double) * n); A(pf->d_wts, sizeof(double) * n); A(pf->d_cum, sizeof(double) * n);
-	A(pf->d_out, sizeof(double) * 32); A(pf->d_parts, sizeof(double) * 18 * ((n + 255) / 256)); A(pf->d_normals, sizeof(double) * n * 10); A(pf->d_uniforms, sizeof(double) * n); A(pf->d_ids, sizeof(int) * n);
+	A(pf->d_st, sizeof(double) * nS); A(pf->d_ar, sizeof(double) * nS);
+	for (int k = 0; k < 2; ++k) { A(pf->d_prop[k], sizeof(double) * nS); A(pf->d_prop_ar[k], sizeof(double) * nS); }
+	A(pf->d_wts, sizeof(double) * npad); pf->wts_capacity = npad;
+	A(pf->d_cum, sizeof(double) * npad); A(pf->d_chunk, sizeof(double) * 2 * nch);
+	const size_t nblk = (n + 255) / 256, ngrp = (nblk + 63) / 64;
+	A(pf->d_out, sizeof(double) * 32); A(pf->d_parts, sizeof(double) * pf_parts_per_block() * nblk); A(pf->d_gparts, sizeof(double) * pf_parts_per_block() * ngrp);
+	A(pf->d_normals, sizeof(double) * n * 10); A(pf->d_uniforms, sizeof(double) * n); A(pf->d_ids, sizeof(int) * n); A(pf->d_counters, sizeof(int) * (2 + ngrp));
+	if (okm && hipMemsetAsync(pf->d_counters, 0, sizeof(int) * (2 + ngrp), b->ctx->stream) != hipSuccess) okm = false;
+	if (okm && hipMemsetAsync(pf->d_out, 0, sizeof(double) * 32, b->ctx->stream) != hipSuccess) okm = false;
 	if (!okm) { pf_free(pf); delete pf; return fail(MTFHIP_ERR_HIP, "pf_create: hipMalloc failed"); }
 	*out = pf;
 	return MTFHIP_OK;
@@ -155,17 +266,21 @@ void mtfhip_pf_destroy(mtfhip_pf *pf) {
 	pf_free(pf);
 	delete pf;
 }
-/* shard the scoring over the communicator: rank r scores particles [r n / R, (r + 1) n / R) and one all-gather distributes the
- * weights; sample generation and resampling are replicated (identical draws on every rank) */
+/* shard the scoring over the communicator: rank r scores particles [r m, (r + 1) m), m = ceil(n / R), and one in-place all-gather
+ * distributes the weights; proposals and resampling are replicated (identical draws and identical weights on every rank) */
 int mtfhip_pf_set_comm(mtfhip_pf *pf, mtfhip_comm *c) {
 	if (!pf) return fail(MTFHIP_ERR_INVALID_ARG, "pf_set_comm: NULL filter");
 	pf->comm = c;
-	if (pf->d_send) { (void)hipFree(pf->d_send); pf->d_send = nullptr; }
-	if (pf->d_recv) { (void)hipFree(pf->d_recv); pf->d_recv = nullptr; }
 	if (c && c->world > 1) {
-		const size_t m = (size_t)(pf->n + c->world - 1) / c->world;
-		HIP_TRY(hipMalloc(&pf->d_send, sizeof(double) * 2 * m));
-		HIP_TRY(hipMalloc(&pf->d_recv, sizeof(double) * 2 * m * c->world));
+		int lo, cnt, m;
+		pf_shard(pf->n, c->world, c->rank, &lo, &cnt, &m);
+		const size_t need = std::max(pf_round_chunk((size_t)pf->n), (size_t)m * c->world);
+		if (need > pf->wts_capacity) {
+			HIP_TRY(hipStreamSynchronize(pf->b->ctx->stream));
+			(void)hipFree(pf->d_wts); pf->d_wts = nullptr;
+			HIP_TRY(hipMalloc(&pf->d_wts, sizeof(double) * need));
+			pf->wts_capacity = need;
+		}
 	}
 	return MTFHIP_OK;
 }
@@ -173,6 +288,7 @@ int mtfhip_pf_set_comm(mtfhip_pf *pf, mtfhip_comm *c) {
 int mtfhip_pf_set_sampler(mtfhip_pf *pf, const double *sigma, const double *mean) {
 	if (!pf || !sigma || !mean) return fail(MTFHIP_ERR_INVALID_ARG, "pf_set_sampler: NULL argument");
 	for (int s = 0; s < pf->S; ++s) { pf->d.ssm_sigma[s] = sigma[s]; pf->d.ssm_mean[s] = mean[s]; }
+	pf->prop_valid = false;   /* proposals made ahead used the old distributions */
 	return MTFHIP_OK;
 }
 /* PF::initializeParticles (PF.cc:185-197) */
@@ -180,7 +296,8 @@ static int pf_initialize_particles(mtfhip_pf *pf) {
 	mtfhip_batch *b = pf->b;
 	hipStream_t st = b->ctx->stream;
 	(void)b->view();   /* a stale single-target warp is uploaded first: the fill reads the device copy of the state */
-	launch_pf_fill(pf->n, pf->S, b->d_states, pf->d_states[pf->cur], pf->d_ars[pf->cur], st);
+	launch_pf_fill(pf->n, pf->S, b->d_states, pf->d_st, pf->d_ar, st);
+	pf->prop_valid = false;
 	return MTFHIP_OK;
 }
 /* the part of nt::PF::initialize that follows ssm->initialize, am->initializePixVals and am->initializeSimilarity
@@ -193,7 +310,7 @@ int mtfhip_pf_initialize(mtfhip_pf *pf) {
 	double f = 0;
 	TRY(mtfhip_am_get_similarity(b, &f));
 	pf->max_similarity = f;
-	pf->cur = 0; pf->iter = 0;
+	pf->iter = 0;
 	TRY(pf_initialize_particles(pf));
 	std::memcpy(pf->prev_corners, b->th[0].corners, sizeof(pf->prev_corners));
 	pf->initialized = true;
@@ -207,88 +324,114 @@ int mtfhip_pf_set_region(mtfhip_pf *pf, const double *corners) {
 	std::memcpy(pf->prev_corners, pf->b->th[0].corners, sizeof(pf->prev_corners));
 	return MTFHIP_OK;
 }
+/* max_similarity = am->getSimilarity() after am->updateModel (PF.cc:443-446, enable_learning) */
+int mtfhip_pf_set_max_similarity(mtfhip_pf *pf, double max_similarity) {
+	if (!pf) return fail(MTFHIP_ERR_INVALID_ARG, "pf_set_max_similarity: NULL filter");
+	pf->max_similarity = max_similarity;
+	return MTFHIP_OK;
+}
 
-/* One iteration of the loop of nt::PF::update (PF.cc:260-447).  normals: n x nz standard normals (nz = 10 with corner based
- * homography sampling, else the state size), uniforms: n draws in (0, 1]; host arrays, or NULL: the device generator
- * (Philox4x32-10 keyed by desc.seed, the iteration count and the particle).  update_norm: squared corner change of the
- * estimate (PF.cc:438-439). */
-int mtfhip_pf_iteration(mtfhip_pf *pf, const double *normals, const double *uniforms, double *update_norm) {
-	if (!pf) return fail(MTFHIP_ERR_INVALID_ARG, "pf_iteration: NULL filter");
-	if (!pf->initialized) return fail(MTFHIP_ERR_LOGIC, "pf_iteration before pf_initialize");
+/* the launches of one iteration; publish: the estimate is also delivered to host-coherent memory (*pub_seq = the sequence
+ * number to wait for, 0 when the read-back is a copy) */
+static int pf_enqueue_iteration(mtfhip_pf *pf, const double *normals, const double *uniforms, bool publish, unsigned long long *pub_seq) {
 	mtfhip_batch *b = pf->b;
-	FLUSH_AM(b);   /* (the candidates carry their own warps: the batch's CURR_PTS are not read) */
-	TRY(need_image(b));
 	hipStream_t st = b->ctx->stream;
 	const int n = pf->n, S = pf->S;
 	const bool hom = b->desc.ssm == MTFHIP_SSM_HOMOGRAPHY;
 	PfLaunch p;
 	p.n = n; p.S = S; p.dynamic_model = pf->d.dynamic_model; p.update_type = pf->d.update_type;
-	p.corner_based = (hom && pf->d.corner_based_sampling) ? 1 : 0;
+	p.sampler = pf->sampler; p.nz = pf->nz;
 	p.likelihood_func = pf->d.likelihood_func; p.resampling_type = pf->d.resampling_type; p.mean_type = pf->d.mean_type;
 	p.ar_coeff = pf->d.ar_coeff; p.measurement_sigma = pf->d.measurement_sigma; p.max_similarity = pf->max_similarity;
 	for (int k = 0; k < 8; ++k) { p.sigma[k] = pf->d.ssm_sigma[k]; p.mean[k] = pf->d.ssm_mean[k]; p.init_corners[k] = b->th[0].init_corners[k]; }
 	for (int k = 0; k < 12; ++k) p.init_corners_hm[k] = b->th[0].init_corners_hm[k];
-	{
+	for (int k = 0; k < 9; ++k) p.aux_inv[k] = k % 4 == 0 ? 1.0 : 0.0;
+	for (int k = 0; k < 6; ++k) p.canon[k] = 0.0;
+	if (hom) {
 		/* template corners -> unit square: the inverse of the closed-form square-to-quadrilateral map (rect_to_quad) */
 		M3 sq;
 		if (!rect_to_quad(0.0, 0.0, 1.0, 1.0, b->th[0].init_corners, sq)) return fail(MTFHIP_ERR_INVALID_ARG, "pf_iteration: degenerate template corners");
 		const M3 inv = m3_inverse(sq);
-		std::memcpy(p.sq_inv, inv.m, sizeof(p.sq_inv));
+		std::memcpy(p.aux_inv, inv.m, sizeof(p.aux_inv));
+	} else if (pf->sampler == PF_SAMPLER_AFF_PTS1 || pf->sampler == PF_SAMPLER_AFF_PTS2) {
+		/* the canonical points of Affine::generatePerturbation (Affine.cc:470-473): bottom right, bottom left, top centre */
+		const double *ic = b->th[0].init_corners;
+		p.canon[0] = ic[4]; p.canon[1] = ic[5]; p.canon[2] = ic[6]; p.canon[3] = ic[7];
+		p.canon[4] = (ic[0] + ic[2]) / 2.0; p.canon[5] = (ic[1] + ic[3]) / 2.0;
+		M3 m;
+		for (int i = 0; i < 3; ++i) { m.m[3 * i] = p.canon[2 * i]; m.m[3 * i + 1] = p.canon[2 * i + 1]; m.m[3 * i + 2] = 1.0; }
+		const double det = m.m[0] * (m.m[4] - m.m[7]) - m.m[1] * (m.m[3] - m.m[6]) + (m.m[3] * m.m[7] - m.m[4] * m.m[6]);
+		if (det == 0) return fail(MTFHIP_ERR_INVALID_ARG, "pf_iteration: degenerate template corners");
+		const M3 inv = m3_inverse(m);
+		std::memcpy(p.aux_inv, inv.m, sizeof(p.aux_inv));
 	}
 	p.seed = pf->d.seed; p.iter = pf->iter;
 	p.normals = nullptr; p.uniforms = nullptr;
-	const int nz = p.corner_based ? 10 : S;
 	if (normals) {
-		HIP_TRY(hipMemcpyAsync(pf->d_normals, normals, sizeof(double) * (size_t)n * nz, hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(pf->d_normals, normals, sizeof(double) * (size_t)n * pf->nz, hipMemcpyHostToDevice, st));
 		p.normals = pf->d_normals;
 	}
 	if (uniforms) {
 		HIP_TRY(hipMemcpyAsync(pf->d_uniforms, uniforms, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
 		p.uniforms = pf->d_uniforms;
 	}
-	double *stc = pf->d_states[pf->cur], *arc = pf->d_ars[pf->cur];
-	unsigned long long pub_seq = 0;
-	{
-		TimedScope ts(b->ctx, "pf_propagate");
-		launch_pf_propagate(b->desc.ssm, p, stc, arc, st);
-	}
-	/* scoring: setState -> updatePixVals -> updateSimilarity -> likelihood per particle (PF.cc:341-365) */
+	const double *ncc_sc = nullptr;
+	if (b->desc.am == MTFHIP_AM_NCC) { TRY(push_ncc(b)); ncc_sc = b->d_ncc; }   /* mean(I0), |I0 - mean| of the template */
+	const size_t nch = pf_round_chunk((size_t)n) / (size_t)pf_chunk();
 	const mtfhip_comm *c = pf->comm;
-	if (c && c->world > 1) {
-		const int m = (n + c->world - 1) / c->world;
-		const int lo = std::min(n, c->rank * m), hi = std::min(n, lo + m);
-		if (hi > lo) TRY(mtfhip_score_candidates_dev(b, stc + (size_t)lo * S, hi - lo, pf->d_send, pf->d_send + m));
-		TRY(mtfhip_allgather_scores(pf->comm, pf->d_send, 2 * m, pf->d_recv, st));
-		/* rank-major [likelihood m | similarity m] blocks -> the two flat vectors */
-		for (int r = 0; r < c->world; ++r) {
-			const int rlo = std::min(n, r * m), cnt = std::min(n, rlo + m) - rlo;
-			if (cnt <= 0) continue;
-			HIP_TRY(hipMemcpyAsync(pf->d_lik + rlo, pf->d_recv + (size_t)2 * m * r, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
-			HIP_TRY(hipMemcpyAsync(pf->d_sim + rlo, pf->d_recv + (size_t)2 * m * r + m, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
-		}
-	} else {
-		TRY(mtfhip_score_candidates_dev(b, stc, n, pf->d_lik, pf->d_sim));
+	const bool sharded = c && c->world > 1;
+	int lo = 0, cnt = n, m = n;
+	if (sharded) pf_shard(n, c->world, c->rank, &lo, &cnt, &m);
+	/* this iteration's proposals (PF.cc:307-335): left behind by the previous selection pass, or made now */
+	const bool ahead = pf->prop_valid && !normals && pf->prop_iter == pf->iter && pf->prop_corners_epoch == b->corners_epoch;
+	if (!ahead) {
+		TimedScope ts(b->ctx, "pf_propose");
+		launch_pf_propose(b->desc.ssm, p, pf->d_st, pf->d_ar, pf->d_prop[pf->pc], pf->d_prop_ar[pf->pc], st);
+	}
+	/* the next iteration's can be made by this one's selection pass when its draws are the device generator's and nothing the
+	 * sampler reads moves in between (MeanType::Corners re-bases the SSM on the mean corners: setCorners, PF.cc:434-436) */
+	const bool lookahead = pf->lookahead_enabled && !normals && pf->d.mean_type != 2;
+	PfBuffers bf;
+	bf.st = pf->d_st; bf.ar = pf->d_ar; bf.prop = pf->d_prop[pf->pc]; bf.prop_ar = pf->d_prop_ar[pf->pc];
+	bf.next = pf->d_prop[1 - pf->pc]; bf.next_ar = pf->d_prop_ar[1 - pf->pc];
+	bf.wts = pf->d_wts; bf.sim = nullptr; bf.cum = pf->d_cum; bf.chunk_tot = pf->d_chunk; bf.chunk_incl = pf->d_chunk + nch;
+	bf.parts = pf->d_parts; bf.gparts = pf->d_gparts; bf.out = pf->d_out; bf.ids = pf->d_ids; bf.counters = pf->d_counters;
+	/* scoring: setState -> updatePixVals -> updateSimilarity -> likelihood per particle (PF.cc:341-365); sharded: this rank's block */
+	{
+		TimedScope ts(b->ctx, "pf_score");
+		launch_pf_score(b->view_raw(), b->ctx->img, p, bf, lo, cnt, b->desc.likelihood_alpha, b->norm_mult, b->norm_add, ncc_sc,
+			b->math_mode == MTFHIP_MATH_FAST, st);
+	}
+	if (sharded) {
+		TimedScope ts(b->ctx, "pf_allgather");
+		TRY(mtfhip_allgather_scores(pf->comm, pf->d_wts + (size_t)c->rank * m, m, pf->d_wts, st));   /* in place: block r of m weights at r m */
 	}
 	{
 		TimedScope ts(b->ctx, "pf_resample");
-		if (b->h_acc_dev) pub_seq = ++b->acc_seq;
-		launch_pf_resample(b->desc.ssm, p, pf->d_lik, pf->d_sim, pf->d_wts, pf->d_cum, stc, arc, pf->d_states[1 - pf->cur], pf->d_ars[1 - pf->cur],
-			pf->d_ids, pf->d_out, pf->d_parts, pub_seq ? b->h_acc_dev : nullptr, b->h_flag_dev, pub_seq, st);
+		unsigned long long seq = 0;
+		if (publish && b->h_acc_dev) seq = ++b->acc_seq;
+		launch_pf_resample(b->desc.ssm, p, bf, lookahead ? 1 : 0, seq ? b->h_acc_dev : nullptr, b->h_flag_dev, seq, st);
+		if (pub_seq) *pub_seq = seq;
 	}
-	if (p.resampling_type == 1 || p.resampling_type == 2) pf->cur = 1 - pf->cur;   /* curr_set_id = 1 - curr_set_id (PF.cc:501) */
-	/* the estimate (32 doubles) comes back through host-coherent pinned memory + the flag the host spins on, like every other
-	 * per-iteration result of the library (a copy into pageable memory + stream synchronisation was 15 us of a 137 us iteration) */
+	++pf->iter;
+	pf->prop_valid = lookahead;
+	if (lookahead) { pf->pc = 1 - pf->pc; pf->prop_iter = pf->iter; pf->prop_corners_epoch = b->corners_epoch; }
+	return MTFHIP_OK;
+}
+/* the estimate (32 doubles) comes back through host-coherent pinned memory + the flag the host spins on, like every other
+ * per-iteration result of the library, and becomes the SSM's state (PF.cc:421-437) */
+static int pf_collect_estimate(mtfhip_pf *pf, unsigned long long pub_seq, double *update_norm) {
+	mtfhip_batch *b = pf->b;
+	hipStream_t st = b->ctx->stream;
 	double out[32];
-	if (pub_seq) {   /* k_pf_estimate delivered it itself */
+	if (pub_seq) {
 		TRY(wait_host_flag(b, pub_seq));
 		std::memcpy(out, b->h_acc, sizeof(out));
 	} else {
 		HIP_TRY(hipMemcpyAsync(out, pf->d_out, sizeof(out), hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
 	}
-	++pf->iter;
-	/* the estimate becomes the SSM's state (PF.cc:421-437) */
-	if (p.mean_type == 2) TRY(mtfhip_ssm_set_corners(b, out + 10));
+	if (pf->d.mean_type == 2) TRY(mtfhip_ssm_set_corners(b, out + 10));
 	else TRY(mtfhip_ssm_set_state(b, out));
 	double un = 0;
 	for (int q = 0; q < 8; ++q) { const double d = pf->prev_corners[q] - b->th[0].corners[q]; un += d * d; }
@@ -296,15 +439,42 @@ int mtfhip_pf_iteration(mtfhip_pf *pf, const double *normals, const double *unif
 	if (update_norm) *update_norm = un;
 	return MTFHIP_OK;
 }
+
+/* One iteration of the loop of nt::PF::update (PF.cc:260-447).  normals: n x nz standard normals (nz = 10 with corner based
+ * homography sampling, 6 / 8 for the affine samplers, else the state size), uniforms: n draws in (0, 1]; host arrays, or NULL:
+ * the device generator (Philox4x32-10 keyed by desc.seed, the iteration count and the particle).  update_norm: squared corner
+ * change of the estimate (PF.cc:438-439). */
+int mtfhip_pf_iteration(mtfhip_pf *pf, const double *normals, const double *uniforms, double *update_norm) {
+	if (!pf) return fail(MTFHIP_ERR_INVALID_ARG, "pf_iteration: NULL filter");
+	if (!pf->initialized) return fail(MTFHIP_ERR_LOGIC, "pf_iteration before pf_initialize");
+	mtfhip_batch *b = pf->b;
+	FLUSH_AM(b);   /* (the candidates carry their own warps: the batch's CURR_PTS are not read) */
+	TRY(need_image(b));
+	unsigned long long seq = 0;
+	TRY(pf_enqueue_iteration(pf, normals, uniforms, true, &seq));
+	return pf_collect_estimate(pf, seq, update_norm);
+}
 /* nt::PF::update (PF.cc:207-447) with the device generator: up to max_iters iterations, stop when the estimate's corners move
- * by less than epsilon; reset_to_mean re-initialises the particles at the estimate */
+ * by less than epsilon; reset_to_mean re-initialises the particles at the estimate.  With a negative epsilon the test can never
+ * fire and nothing on the host depends on an intermediate estimate (unless MeanType::Corners re-bases the SSM every iteration):
+ * the iterations are then enqueued back to back and only the last one reports to the host. */
 int mtfhip_pf_update(mtfhip_pf *pf, int *n_iters) {
 	if (!pf) return fail(MTFHIP_ERR_INVALID_ARG, "pf_update: NULL filter");
+	if (!pf->initialized) return fail(MTFHIP_ERR_LOGIC, "pf_update before pf_initialize");
 	int it = 0;
-	for (; it < pf->d.max_iters; ++it) {
-		double un = 0;
-		TRY(mtfhip_pf_iteration(pf, nullptr, nullptr, &un));
-		if (un < pf->d.epsilon) { ++it; break; }
+	if (pf->d.epsilon < 0 && pf->d.mean_type != 2 && pf->d.max_iters > 0) {
+		mtfhip_batch *b = pf->b;
+		FLUSH_AM(b);
+		TRY(need_image(b));
+		unsigned long long seq = 0;
+		for (; it < pf->d.max_iters; ++it) TRY(pf_enqueue_iteration(pf, nullptr, nullptr, it == pf->d.max_iters - 1, &seq));
+		TRY(pf_collect_estimate(pf, seq, nullptr));
+	} else {
+		for (; it < pf->d.max_iters; ++it) {
+			double un = 0;
+			TRY(mtfhip_pf_iteration(pf, nullptr, nullptr, &un));
+			if (un < pf->d.epsilon) { ++it; break; }
+		}
 	}
 	if (pf->d.reset_to_mean) TRY(pf_initialize_particles(pf));
 	if (n_iters) *n_iters = it;
@@ -314,8 +484,8 @@ int mtfhip_pf_get_particles(mtfhip_pf *pf, double *states, double *ars, double *
 	if (!pf) return fail(MTFHIP_ERR_INVALID_ARG, "pf_get_particles: NULL filter");
 	hipStream_t st = pf->b->ctx->stream;
 	const size_t nS = (size_t)pf->n * pf->S;
-	if (states) HIP_TRY(hipMemcpyAsync(states, pf->d_states[pf->cur], sizeof(double) * nS, hipMemcpyDeviceToHost, st));
-	if (ars) HIP_TRY(hipMemcpyAsync(ars, pf->d_ars[pf->cur], sizeof(double) * nS, hipMemcpyDeviceToHost, st));
+	if (states) HIP_TRY(hipMemcpyAsync(states, pf->d_st, sizeof(double) * nS, hipMemcpyDeviceToHost, st));
+	if (ars) HIP_TRY(hipMemcpyAsync(ars, pf->d_ar, sizeof(double) * nS, hipMemcpyDeviceToHost, st));
 	if (wts) HIP_TRY(hipMemcpyAsync(wts, pf->d_wts, sizeof(double) * pf->n, hipMemcpyDeviceToHost, st));
 	if (resample_ids) HIP_TRY(hipMemcpyAsync(resample_ids, pf->d_ids, sizeof(int) * pf->n, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
@@ -325,10 +495,11 @@ int mtfhip_pf_set_particles(mtfhip_pf *pf, const double *states, const double *a
 	if (!pf || !states) return fail(MTFHIP_ERR_INVALID_ARG, "pf_set_particles: NULL argument");
 	hipStream_t st = pf->b->ctx->stream;
 	const size_t nS = (size_t)pf->n * pf->S;
-	HIP_TRY(hipMemcpyAsync(pf->d_states[pf->cur], states, sizeof(double) * nS, hipMemcpyHostToDevice, st));
-	if (ars) HIP_TRY(hipMemcpyAsync(pf->d_ars[pf->cur], ars, sizeof(double) * nS, hipMemcpyHostToDevice, st));
-	else HIP_TRY(hipMemsetAsync(pf->d_ars[pf->cur], 0, sizeof(double) * nS, st));
+	HIP_TRY(hipMemcpyAsync(pf->d_st, states, sizeof(double) * nS, hipMemcpyHostToDevice, st));
+	if (ars) HIP_TRY(hipMemcpyAsync(pf->d_ar, ars, sizeof(double) * nS, hipMemcpyHostToDevice, st));
+	else HIP_TRY(hipMemsetAsync(pf->d_ar, 0, sizeof(double) * nS, st));
 	HIP_TRY(hipStreamSynchronize(st));
+	pf->prop_valid = false;
 	return MTFHIP_OK;
 }
 double mtfhip_pf_max_similarity(const mtfhip_pf *pf) { return pf ? pf->max_similarity : 0.0; }

@@ -1,20 +1,37 @@
 /*
- * kernels_pf.hip -- the particle filter's per-iteration work besides scoring, on the device: sample generation (the SSM's
- * stochastic sampler and dynamic models), likelihood mapping, cumulative weights, multinomial resampling, the estimate.
- * (one of the translation units of libmtfhip.so; the scorer itself is k_score_candidates[_fast] in kernels_batch.hip)
+ * kernels_pf.hip -- one iteration of the particle filter on the device in three launches: scoring + particle weight (k_pf_score),
+ * cumulative weights (k_pf_scan), multinomial resampling + estimate + the next iteration's proposals (k_pf_select).
+ * (one of the translation units of libmtfhip.so)
  *
  * Reference: nt::PF::update SM/src/NT/PF.cc:207-447, binaryMultinomialResampling :455-502, linearMultinomialResampling
  * :505-536, updateMeanCorners :607-614; Homography::generatePerturbation / compositionalRandomWalk /
  * compositionalAutoRegression1 SSM/src/Homography.cc:899-942; ProjectiveBase::additiveRandomWalk / additiveAutoRegression1 /
- * generatePerturbation / estimateMeanOfSamples SSM/src/ProjectiveBase.cc:236-317.
+ * compositionalRandomWalk / compositionalAutoRegression1 / generatePerturbation / estimateMeanOfSamples
+ * SSM/src/ProjectiveBase.cc:236-317; Affine::generatePerturbation / geomToState SSM/src/Affine.cc:380-410,464-503.
  *
  * In the reference every particle of every iteration pays a 4-corner DLT through an 8 x 9 JacobiSVD
- * (hom_corner_based_sampling is on by default, parameters.h:262) on one host core; here a particle is one thread and the
- * corner perturbation is the closed-form square-to-quadrilateral map composed with the inverse of the template's.
+ * (hom_corner_based_sampling is on by default, parameters.h:262) on one host core; here the corner perturbation is the
+ * closed-form square-to-quadrilateral map composed with the inverse of the template's.
  * Random draws: the reference seeds boost::mt11213b from random_device (not reproducible), so the draws are an INPUT here --
  * either arrays of standard normals / uniforms handed in by the caller (parity tests, reproducible runs), or a counter-based
- * Philox4x32-10 generator + Box-Muller on the device keyed by (seed, iteration, particle): every rank of a sharded filter
- * regenerates the same particle set without communication.
+ * Philox4x32-10 generator + Box-Muller on the device keyed by (seed, iteration, particle).
+ *
+ * The shape of an iteration (r03).  A particle's proposal is a pure function of (its resampled state, the draws of its index
+ * and iteration).  With the device generator the draws of iteration t + 1 are known at iteration t, so k_pf_select -- one thread
+ * per particle, all lanes busy -- follows "copy the selected particle" directly with "propose its successor" and leaves the
+ * proposal set of the NEXT iteration behind; k_pf_score then finds its four candidates' states ready (scalar loads, as
+ * k_score_candidates_fast) and maps the similarity to the particle weight in its epilogue -- no propagation launch and no
+ * likelihood / similarity vectors in between.  (When the draws are handed in by the caller, after initialize / setRegion /
+ * set_particles / setSampler, and with MeanType::Corners, whose setCorners moves the sampler's reference corners every
+ * iteration, the proposals come from a launch of their own, k_pf_propose.)  On R ranks each rank scores the contiguous block
+ * [r m, (r + 1) m), m = ceil(n / R), and writes its weights at their global positions, so that ONE in-place all-gather of m
+ * doubles per rank leaves the flat weight vector on every rank (SM/src/PF.cc:262-277) -- no second vector, no unscrambling
+ * copies; proposals and resampling are replicated (identical draws and weights everywhere: re-evaluating a proposal costs less
+ * than moving its 128 bytes over xGMI).  k_pf_scan turns the weights into chunk-local running sums (256 particles per
+ * wave) and the last workgroup to arrive scans the chunk totals; k_pf_select draws, finds the source particle with a
+ * two-level search (chunk table in LDS, then three rounds of independent probes inside the chunk instead of ten dependent
+ * loads), writes the resampled set, and its last workgroup folds the per-workgroup rows into the estimate and hands it to the
+ * host.  Every sum is taken in a fixed order that depends on n only: all ranks of a sharded filter resample identically.
  */
 #include "mtfhip_device.h"
 
@@ -38,12 +55,53 @@ __device__ __forceinline__ void philox_uniform2(const Philox4 &r, double &u0, do
 	u0 = ((double)a + 1.0) * (1.0 / 9007199254740992.0);
 	u1 = ((double)b + 1.0) * (1.0 / 9007199254740992.0);
 }
+/* log(u) for u in (0, 1]: u = m 2^e with m in [sqrt(1/2), sqrt(2)), log m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.1716 --
+ * twelve terms of the odd series (the next one is below 1e-18).  ~1 ulp; about a quarter of the instructions of the library
+ * routine, whose special cases (negative, zero, infinite, subnormal arguments) cannot occur here. */
+__device__ __forceinline__ double pf_log_unit(double u) {
+	int e;
+	double m = frexp(u, &e);                 /* m in [0.5, 1) */
+	if (m < 0.70710678118654752440) { m *= 2.0; e -= 1; }
+	const double s = (m - 1.0) / (m + 1.0), s2 = s * s;
+	double p = 1.0 / 23.0;
+	p = fma(p, s2, 1.0 / 21.0); p = fma(p, s2, 1.0 / 19.0); p = fma(p, s2, 1.0 / 17.0); p = fma(p, s2, 1.0 / 15.0);
+	p = fma(p, s2, 1.0 / 13.0); p = fma(p, s2, 1.0 / 11.0); p = fma(p, s2, 1.0 / 9.0); p = fma(p, s2, 1.0 / 7.0);
+	p = fma(p, s2, 1.0 / 5.0); p = fma(p, s2, 1.0 / 3.0);
+	const double lm = 2.0 * fma(s * s2, p, s);
+	const double ed = (double)e;
+	return fma(ed, 0.69314718055994528623, fma(ed, 2.3190468138462995584e-17, lm));   /* ln 2 = hi + lo */
+}
+/* (sin, cos)(2 pi u) for u in (0, 1]: octant reduction in units of pi / 4 (exact: 8 u, its floor and the remainder are all
+ * representable), Taylor polynomials on [-pi/4, pi/4] (degree 17 / 16: truncation below 1e-18), quadrant rotation */
+__device__ __forceinline__ void pf_sincos_2pi(double u, double &sn, double &cs) {
+	const double t = u * 8.0;
+	int o = (int)t;                           /* 0 .. 8 */
+	double f = t - (double)o;                 /* [0, 1) */
+	if (o & 1) { o += 1; f -= 1.0; }
+	const double y = f * 0.78539816339744830962, y2 = y * y;
+	double ps = -1.0 / 355687428096000.0;     /* -1 / 17! */
+	ps = fma(ps, y2, 1.0 / 1307674368000.0); ps = fma(ps, y2, -1.0 / 6227020800.0); ps = fma(ps, y2, 1.0 / 39916800.0);
+	ps = fma(ps, y2, -1.0 / 362880.0); ps = fma(ps, y2, 1.0 / 5040.0); ps = fma(ps, y2, -1.0 / 120.0); ps = fma(ps, y2, 1.0 / 6.0);
+	const double sy = fma(-(y * y2), ps, y);
+	double pc = 1.0 / 20922789888000.0;       /* 1 / 16! */
+	pc = fma(pc, y2, -1.0 / 87178291200.0); pc = fma(pc, y2, 1.0 / 479001600.0); pc = fma(pc, y2, -1.0 / 3628800.0);
+	pc = fma(pc, y2, 1.0 / 40320.0); pc = fma(pc, y2, -1.0 / 720.0); pc = fma(pc, y2, 1.0 / 24.0); pc = fma(pc, y2, -0.5);
+	const double cy = fma(y2, pc, 1.0);
+	const int k = (o >> 1) & 3;
+	const double a = (k & 1) ? cy : sy, b = (k & 1) ? sy : cy;
+	sn = (k & 2) ? -a : a;
+	cs = (k == 1 || k == 2) ? -b : b;
+}
+/* Box-Muller (the reference draws from boost::normal_distribution over mt11213b, ProjectiveBase.cc:192-197: any exact N(0, 1)
+ * sampler is equivalent) */
 __device__ __forceinline__ void philox_normal2(unsigned long long seed, unsigned iter, unsigned particle, unsigned draw, double &z0, double &z1) {
 	const Philox4 r = philox4x32_10(particle, draw, iter, 0x4E4F524Du /* "NORM" */, (unsigned)seed, (unsigned)(seed >> 32));
 	double u0, u1;
 	philox_uniform2(r, u0, u1);
-	const double rad = sqrt(-2.0 * log(u0)), ang = 6.283185307179586476925 * u1;
-	z0 = rad * cos(ang); z1 = rad * sin(ang);
+	const double rad = sqrt(-2.0 * pf_log_unit(u0));
+	double sn, cs;
+	pf_sincos_2pi(u1, sn, cs);
+	z0 = rad * cs; z1 = rad * sn;
 }
 __device__ __forceinline__ double philox_uniform(unsigned long long seed, unsigned iter, unsigned particle) {
 	const Philox4 r = philox4x32_10(particle, 0u, iter, 0x554E4946u /* "UNIF" */, (unsigned)seed, (unsigned)(seed >> 32));
@@ -96,34 +154,40 @@ __device__ __forceinline__ void square_to_quad_dev(const double *q, double *H) {
 	H[6] = g; H[7] = h; H[8] = 1.0;
 }
 
+/* ---- the sampler and the dynamic models ---- */
 struct PfArgs {
 	int n, S;
-	int dynamic_model, update_type, corner_based;
+	int dynamic_model, update_type;
+	int sampler;               /* PF_SAMPLER_* (mtfhip_internal.h) */
+	int nz;                    /* standard normals per particle */
 	double ar_coeff;
 	double sigma[8], mean[8];
 	double init_corners[8];
-	double sq_inv[9];          /* inverse of square_to_quad(init_corners): template corners -> unit square */
+	double aux_inv[9];         /* homography, corner based: inverse of square_to_quad(init_corners) (template corners -> unit square);
+	                              affine, point based: inverse of the 3 x 3 matrix with rows (x_i, y_i, 1) of the three canonical points */
+	double canon[6];           /* affine, point based: the canonical points (bottom right, bottom left, top centre), x,y interleaved */
 	unsigned long long seed;
 	unsigned iter;
 	const double *normals;     /* [n][nz] standard normals, or NULL: Philox */
 };
 
-/* sample generation: particle_states[k] <- dynamic model(particle_states[k], particle_ar[k], perturbation) (PF.cc:307-335) */
-template <int SSM>
-__global__ __launch_bounds__(kBlock) void k_pf_propagate(PfArgs a, double *states, double *ars) {
-	constexpr int S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
-	const int k = blockIdx.x * kBlock + threadIdx.x;
-	if (k >= a.n) return;
-	const int nz = a.corner_based ? 10 : S;
-	double z[10];
+/* pair `q` (draws 2 q, 2 q + 1) of particle k's normals */
+__device__ __forceinline__ void pf_normal_pair(const PfArgs &a, unsigned k, int q, double &z0, double &z1) {
 	if (a.normals) {
-		for (int j = 0; j < nz; ++j) z[j] = a.normals[(size_t)k * nz + j];
+		const double2 v = *reinterpret_cast<const double2 *>(a.normals + (size_t)k * a.nz + 2 * q);   /* nz is even: rows and pairs are 16-byte aligned */
+		z0 = v.x; z1 = v.y;
 	} else {
-#pragma unroll
-		for (int j = 0; j < 10; j += 2) philox_normal2(a.seed, a.iter, (unsigned)k, (unsigned)(j >> 1), z[j], z[j + 1]);
+		philox_normal2(a.seed, a.iter, k, (unsigned)q, z0, z1);
 	}
-	double pert[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-	if (SSM == MTFHIP_SSM_HOMOGRAPHY && a.corner_based) {
+}
+
+/* the SSM's generatePerturbation for one particle from its standard normals z[0..nz) */
+template <int SSM>
+__device__ __forceinline__ void pf_perturbation(const PfArgs &a, const double *z, double *pert) {
+	constexpr int S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
+#pragma unroll
+	for (int s = 0; s < 8; ++s) pert[s] = 0.0;
+	if (SSM == MTFHIP_SSM_HOMOGRAPHY && a.sampler == PF_SAMPLER_HOM_CORNERS) {
 		/* Homography::generatePerturbation, corner based (Homography.cc:899-911): one translation for all corners from
 		 * distribution 0, one displacement per corner coordinate from distribution 1, then the warp that takes the template
 		 * corners to the disturbed ones */
@@ -135,30 +199,68 @@ __global__ __launch_bounds__(kBlock) void k_pf_propagate(PfArgs a, double *state
 			dc[2 * c + 1] = a.init_corners[2 * c + 1] + (a.mean[1] + a.sigma[1] * z[3 + 2 * c]) + ty;
 		}
 		square_to_quad_dev(dc, Hq);
-		m3_mul_dev(Hq, a.sq_inv, Hp);
+		m3_mul_dev(Hq, a.aux_inv, Hp);
 		const double n22 = Hp[8];
 #pragma unroll
 		for (int q = 0; q < 9; ++q) Hp[q] /= n22;
 		state_from_warp_dev<SSM>(pert, Hp);
+	} else if (SSM == MTFHIP_SSM_AFFINE && (a.sampler == PF_SAMPLER_AFF_PTS1 || a.sampler == PF_SAMPLER_AFF_PTS2)) {
+		/* Affine::generatePerturbation, point based (Affine.cc:466-494): bottom right, bottom left and top centre of the template
+		 * are disturbed -- 1: coordinate j by distribution j; 2: every coordinate by distribution 1 plus one translation from
+		 * distribution 0 -- and the affine map of the three point pairs (utils::computeAffineDLT of three points,
+		 * warpUtils.cc:388-421: an exactly determined 6 x 6 system) is the perturbation */
+		double px[3], py[3];
+		if (a.sampler == PF_SAMPLER_AFF_PTS1) {
+#pragma unroll
+			for (int i = 0; i < 3; ++i) {
+				px[i] = a.canon[2 * i] + (a.mean[2 * i] + a.sigma[2 * i] * z[2 * i]);
+				py[i] = a.canon[2 * i + 1] + (a.mean[2 * i + 1] + a.sigma[2 * i + 1] * z[2 * i + 1]);
+			}
+		} else {
+			const double tx = a.mean[0] + a.sigma[0] * z[6], ty = a.mean[0] + a.sigma[0] * z[7];
+#pragma unroll
+			for (int i = 0; i < 3; ++i) {
+				px[i] = (a.canon[2 * i] + (a.mean[1] + a.sigma[1] * z[2 * i])) + tx;
+				py[i] = (a.canon[2 * i + 1] + (a.mean[1] + a.sigma[1] * z[2 * i + 1])) + ty;
+			}
+		}
+		double W[9];
+#pragma unroll
+		for (int j = 0; j < 3; ++j) {
+			W[j] = a.aux_inv[3 * j] * px[0] + a.aux_inv[3 * j + 1] * px[1] + a.aux_inv[3 * j + 2] * px[2];
+			W[3 + j] = a.aux_inv[3 * j] * py[0] + a.aux_inv[3 * j + 1] * py[1] + a.aux_inv[3 * j + 2] * py[2];
+		}
+		W[6] = 0; W[7] = 0; W[8] = 1;
+		state_from_warp_dev<SSM>(pert, W);
+	} else if (SSM == MTFHIP_SSM_AFFINE && a.sampler == PF_SAMPLER_AFF_GEOM) {
+		/* Affine::generatePerturbation, geometric (Affine.cc:495-502) = geomToState of six draws (Affine.cc:393-410):
+		 * (tx, ty, scale, theta, aspect, phi) */
+		double gm[6];
+#pragma unroll
+		for (int s = 0; s < 6; ++s) gm[s] = a.mean[s] + a.sigma[s] * z[s];
+		const double sc = gm[2], r = gm[4], theta = gm[3], phi = gm[5];
+		const double cos_theta = cos(theta), sin_theta = sin(theta), cos_phi = cos(phi), sin_phi = sin(phi);
+		const double ccc = cos_theta * cos_phi * cos_phi, ccs = cos_theta * cos_phi * sin_phi, css = cos_theta * sin_phi * sin_phi;
+		const double scc = sin_theta * cos_phi * cos_phi, scs = sin_theta * cos_phi * sin_phi, sss = sin_theta * sin_phi * sin_phi;
+		pert[0] = gm[0]; pert[1] = gm[1];
+		pert[2] = sc * (ccc + scs + r * (css - scs)) - 1;
+		pert[3] = sc * (r * (ccs - scc) - ccs - sss);
+		pert[4] = sc * (scc - ccs + r * (ccs + sss));
+		pert[5] = sc * (r * (ccc + scs) - scs + css) - 1;
 	} else {
 #pragma unroll
 		for (int s = 0; s < S; ++s) pert[s] = a.mean[s] + a.sigma[s] * z[s];   /* ProjectiveBase::generatePerturbation :283-288 */
 	}
-	double st[8], ar[8], ns[8], nar[8];
-	{   /* rows of S contiguous doubles, 16-byte aligned: pairs */
-		const double2 *ps = reinterpret_cast<const double2 *>(states + (size_t)k * S), *pa = reinterpret_cast<const double2 *>(ars + (size_t)k * S);
+}
+/* (st, ar) -> (ns, nar): PF.cc:307-335 */
+template <int SSM>
+__device__ __forceinline__ void pf_dynamics(const PfArgs &a, const double *pert, const double *st, const double *ar, double *ns, double *nar) {
 #pragma unroll
-		for (int s2 = 0; s2 < 4; ++s2) {
-			const double2 v = 2 * s2 < S ? ps[s2] : make_double2(0.0, 0.0), w = 2 * s2 < S ? pa[s2] : make_double2(0.0, 0.0);
-			st[2 * s2] = v.x; st[2 * s2 + 1] = v.y; ar[2 * s2] = w.x; ar[2 * s2 + 1] = w.y;
-		}
-#pragma unroll
-		for (int s = 0; s < 8; ++s) nar[s] = ar[s];
-	}
+	for (int s = 0; s < 8; ++s) nar[s] = ar[s];
 	if (a.dynamic_model == 1 && a.update_type == 0) {          /* additiveAutoRegression1 :254-259 */
 #pragma unroll
 		for (int s = 0; s < 8; ++s) { ns[s] = st[s] + ar[s] + pert[s]; nar[s] = a.ar_coeff * (ns[s] - st[s]); }
-	} else if (a.dynamic_model == 1) {                         /* compositionalAutoRegression1 Homography.cc:928-942 */
+	} else if (a.dynamic_model == 1) {                         /* compositionalAutoRegression1 Homography.cc:928-942, ProjectiveBase.cc:260-276 */
 		double B[9], P[9], A[9], BA[9], W[9], Bi[9], AW[9];
 		warp_from_state_dev<SSM>(st, B); warp_from_state_dev<SSM>(pert, P); warp_from_state_dev<SSM>(ar, A);
 		m3_mul_dev(B, A, BA); m3_mul_dev(BA, P, W);
@@ -171,208 +273,389 @@ __global__ __launch_bounds__(kBlock) void k_pf_propagate(PfArgs a, double *state
 	} else if (a.update_type == 0) {                           /* additiveRandomWalk :236-240 */
 #pragma unroll
 		for (int s = 0; s < 8; ++s) ns[s] = st[s] + pert[s];
-	} else {                                                   /* compositionalRandomWalk Homography.cc:916-926 */
+	} else {                                                   /* compositionalRandomWalk Homography.cc:916-926, ProjectiveBase.cc:241-249 */
 		double B[9], P[9], W[9];
 		warp_from_state_dev<SSM>(st, B); warp_from_state_dev<SSM>(pert, P);
 		m3_mul_dev(B, P, W);
 		if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) { const double n22 = W[8]; for (int q = 0; q < 9; ++q) W[q] /= n22; }
 		state_from_warp_dev<SSM>(ns, W);
 	}
-	{
-		double2 *ps = reinterpret_cast<double2 *>(states + (size_t)k * S), *pa = reinterpret_cast<double2 *>(ars + (size_t)k * S);
+}
+/* a particle's row is S (6 or 8) contiguous doubles, 16-byte aligned: moved as pairs, all loads first */
+template <int S>
+__device__ __forceinline__ void pf_load_row(const double *base, size_t k, double *v) {
+	const double2 *p = reinterpret_cast<const double2 *>(base + k * S);
+	double2 t[4];
 #pragma unroll
-		for (int s2 = 0; s2 < 4; ++s2)
-			if (2 * s2 < S) { ps[s2] = make_double2(ns[2 * s2], ns[2 * s2 + 1]); pa[s2] = make_double2(nar[2 * s2], nar[2 * s2 + 1]); }
+	for (int s2 = 0; s2 < 4; ++s2) t[s2] = 2 * s2 < S ? p[s2] : make_double2(0.0, 0.0);
+#pragma unroll
+	for (int s2 = 0; s2 < 4; ++s2) { v[2 * s2] = t[s2].x; v[2 * s2 + 1] = t[s2].y; }
+}
+template <int S>
+__device__ __forceinline__ void pf_store_row(double *base, size_t k, const double *v) {
+	double2 *p = reinterpret_cast<double2 *>(base + k * S);
+#pragma unroll
+	for (int s2 = 0; s2 < 4; ++s2) if (2 * s2 < S) p[s2] = make_double2(v[2 * s2], v[2 * s2 + 1]);
+}
+/* one thread: (st, ar) of particle k -> its proposal */
+template <int SSM>
+__device__ __forceinline__ void pf_propose(const PfArgs &a, unsigned k, const double *st, const double *ar, double *ns, double *nar) {
+	double z[10], pert[8];
+#pragma unroll
+	for (int q = 0; q < 5; ++q) {
+		z[2 * q] = z[2 * q + 1] = 0.0;
+		if (2 * q < a.nz) pf_normal_pair(a, k, q, z[2 * q], z[2 * q + 1]);
+	}
+	pf_perturbation<SSM>(a, z, pert);
+	pf_dynamics<SSM>(a, pert, st, ar, ns, nar);
+}
+/* the proposals of a whole set in a launch of their own: the first iteration after the particles were (re)initialised, draws
+ * handed in by the caller, MeanType::Corners */
+template <int SSM>
+__global__ __launch_bounds__(kBlock) void k_pf_propose(PfArgs a, const double *st_in, const double *ar_in, double *st_out, double *ar_out) {
+	constexpr int S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
+	const int k = blockIdx.x * kBlock + threadIdx.x;
+	if (k >= a.n) return;
+	double st[8], ar[8], ns[8], nar[8];
+	pf_load_row<S>(st_in, (size_t)k, st); pf_load_row<S>(ar_in, (size_t)k, ar);
+	pf_propose<SSM>(a, (unsigned)k, st, ar, ns, nar);
+	pf_store_row<S>(st_out, (size_t)k, ns); pf_store_row<S>(ar_out, (size_t)k, nar);
+}
+
+/* ===================================================================== */
+/* launch 1: scoring + weight                                             */
+/* ===================================================================== */
+/* One workgroup scores K = 4 consecutive particles of this rank's block (the structure of k_score_candidates_fast,
+ * kernels_batch.hip: every wave takes a quarter of the pixels and evaluates all four warps on each grid point it loads; the
+ * candidate index is uniform per workgroup, so the proposals arrive through scalar loads and the warps live in scalar registers).
+ * Epilogue: similarity -> AM likelihood (SSD.h:41-43, NCC.cc:50-53) -> particle weight (PF.cc:341-365). */
+struct PfScoreArgs {
+	const double *prop;            /* [n][S] the proposals */
+	int lo, cnt;                   /* this rank's block of particles */
+	double alpha, norm_mult, norm_add;
+	const double *ncc_sc;          /* NCC: [0] mean(I0) [1] |I0 - mean| */
+	int likelihood_func;
+	double measurement_sigma, max_similarity;
+	double *wts;                   /* [>= n] particle_wts, written at the particles' global indices */
+	double *sim;                   /* [n] similarities or NULL */
+};
+struct __attribute__((packed, aligned(4))) PfTexPair { float a, b; };
+template <int SSM, bool NCC, bool FAST>
+__global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, PfScoreArgs s) {
+	constexpr int K = 4, M = NCC ? 3 : 1, S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
+	__shared__ double red[4 * K * M], tot[K * M];
+	const int c0 = s.lo + blockIdx.x * K, cend = s.lo + s.cnt;
+	const int tid = threadIdx.x;
+	double W[K][9];
+#pragma unroll
+	for (int k = 0; k < K; ++k) warp_from_state_dev<SSM>(s.prop + (size_t)min(c0 + k, cend - 1) * S, W[k]);   /* uniform address: scalar loads */
+	const unsigned N = (unsigned)bv.N;
+	const bool uz = bv.unit_z != 0;
+	const double *__restrict__ pp = bv.buf[uz ? MTFHIP_BUF_INIT_PTS : MTFHIP_BUF_INIT_HXY];
+	const double *__restrict__ iz = bv.buf[MTFHIP_BUF_INIT_Z];
+	const double *__restrict__ I0 = bv.buf[MTFHIP_BUF_I0];
+	const float *__restrict__ img = im.data;
+	const int iw1 = im.w - 1, ih1 = im.h - 1, stride = im.stride;
+	double acc[K * M];
+#pragma unroll
+	for (int k = 0; k < K * M; ++k) acc[k] = 0.0;
+	for (unsigned i = tid; i < N; i += kBlock) {
+		const double2 q = ld_off<double2>(pp, i * 16u);
+		const double z = uz ? 1.0 : ld_off<double>(iz, i * 8u);
+		const double i0 = ld_off<double>(I0, i * 8u);
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			double it;
+			if constexpr (FAST) {
+				double wx = fma(W[k][0], q.x, fma(W[k][1], q.y, uz ? W[k][2] : W[k][2] * z));
+				double wy = fma(W[k][3], q.x, fma(W[k][4], q.y, uz ? W[k][5] : W[k][5] * z));
+				if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+					const double inv = rcp_fast(fma(W[k][6], q.x, fma(W[k][7], q.y, uz ? W[k][8] : W[k][8] * z)));
+					wx *= inv; wy *= inv;
+				}
+				const int lx = (int)wx, ly = (int)wy;
+				const bool ok = (wx >= 0) & (wy >= 0) & (lx < iw1) & (ly < ih1);
+				double v;
+				if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
+					const unsigned off = (unsigned)(ly * stride + lx) * 4u;
+					const PfTexPair t0 = ld_off<PfTexPair>(img, off), t1 = ld_off<PfTexPair>(img + stride, off);
+					v = bilin_val_fast(t0.a, t0.b, t1.a, t1.b, wx - (double)lx, wy - (double)ly);
+				} else {
+					v = pix_val_fast(im, wx, wy);
+				}
+				it = fma(s.norm_mult, v, s.norm_add);
+			} else {   /* the reference's operation order (ProjectiveBase.cc:41-49, imgUtils.h:91-113) */
+				double wx = W[k][0] * q.x + W[k][1] * q.y + W[k][2] * z, wy = W[k][3] * q.x + W[k][4] * q.y + W[k][5] * z;
+				if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+					const double d = W[k][6] * q.x + W[k][7] * q.y + W[k][8] * z;
+					wx = wx / d; wy = wy / d;
+				}
+				it = s.norm_mult * pix_val(im, wx, wy) + s.norm_add;
+			}
+			if constexpr (NCC) {
+				acc[3 * k] += it; acc[3 * k + 1] = fma(it, it, acc[3 * k + 1]); acc[3 * k + 2] = fma(i0, it, acc[3 * k + 2]);
+			} else {
+				const double r = it - i0;
+				acc[k] = fma(r, r, acc[k]);
+			}
+		}
+	}
+	block_reduce_store<K * M>(acc, tot, red);
+	__syncthreads();
+	const int k = tid, cand = c0 + k;
+	if (k < K && cand < cend) {
+		double f, lik;
+		if constexpr (NCC) {
+			const double n = (double)N, m0 = s.ncc_sc[0], c = s.ncc_sc[1], mt = tot[3 * k] / n;
+			f = (tot[3 * k + 2] - n * m0 * mt) / (sqrt(tot[3 * k + 1] - n * mt * mt) * c);
+			const double d = (1.0 / f) - 1;
+			lik = exp(-s.alpha * d * d);
+		} else {
+			f = -tot[k] / 2;
+			lik = exp(-s.alpha * sqrt(-f / (double)N));
+		}
+		double w = lik;
+		if (s.likelihood_func != 0) {
+			const double pi = 3.14159265358979323846;
+			const double val = s.max_similarity - f;
+			w = s.likelihood_func == 1 ? (1.0 / sqrt(2 * pi * s.measurement_sigma)) * exp(-0.5 * val / s.measurement_sigma)   /* PF.cc:69-70, 352-354 */
+			                           : 1.0 / (1.0 + val);
+		}
+		s.wts[cand] = w;
+		if (s.sim) s.sim[cand] = f;
 	}
 }
 
-/* ---- weights -> cumulative weights -> resampling -> the estimate, one workgroup ---- */
-struct PfResampleArgs {
-	int n, S, ssm;
-	int likelihood_func, resampling_type, mean_type;
-	double measurement_sigma, max_similarity;
-	unsigned long long seed;
-	unsigned iter;
-	const double *uniforms;       /* [n] or NULL: Philox */
-	const double *lik, *sim;      /* [n] AM likelihoods and similarities of the scorer */
-	double *wts, *cum;            /* [n] out: particle_wts, normalised particle_cum_wts */
-	const double *st_in, *ar_in;  /* current set */
-	double *st_out, *ar_out;      /* the other set (resampling) */
-	int *ids;                     /* [n] resample ids (diagnostics / tests) */
-	double init_corners_hm[12];
-	double *out;                  /* [32]: estimate state (8) | max_wt | max_wt_id | mean corners (8) | n_eff */
+/* ===================================================================== */
+/* launch 2: cumulative weights                                           */
+/* ===================================================================== */
+/* A chunk is 256 consecutive particles = what one wave of the scan covers (four per lane): the wave turns its weights into
+ * chunk-local inclusive sums cum[] (entries past n repeat the chunk total, so a search inside a chunk never needs a bound) and
+ * hands the chunk total to the last workgroup to arrive, which scans the totals into chunk_incl[] (inclusive).
+ * particle_cum_wts[k] of the reference (PF.cc:366-367) is chunk_incl[c - 1] + cum[k]; its normalisation (PF.cc:455-459) becomes a
+ * scaled draw in the selection pass.  (256 and not more: the chunk table of up to a million particles then fits the selection
+ * pass's LDS, and what is left to search in memory is 32 cache lines.) */
+constexpr int kPfChunk = 256;
+struct PfScanArgs {
+	int n, nch;
+	const double *wts;
+	double *cum;          /* [nch * 256] */
+	double *chunk_tot;    /* [nch] */
+	double *chunk_incl;   /* [nch] */
+	int *counter;         /* zero between launches */
 };
-constexpr int kPfBlock = 1024;
-__device__ __forceinline__ double block_scan_incl(double v, double *lds /* [kPfBlock / 64 + 1] */, double &total) {
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	double x = v;
+__device__ __forceinline__ double wave_scan_incl(double x, int lane) {
 #pragma unroll
 	for (int d = 1; d < 64; d <<= 1) { const double y = __shfl_up(x, d); if (lane >= d) x += y; }
-	if (lane == 63) lds[wave] = x;
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		double run = 0;
-		for (int w = 0; w < kPfBlock / 64; ++w) { const double t = lds[w]; lds[w] = run; run += t; }
-		lds[kPfBlock / 64] = run;
-	}
-	__syncthreads();
-	const double r = x + lds[wave];
-	total = lds[kPfBlock / 64];
-	__syncthreads();
-	return r;
+	return x;
 }
-/* Three launches: (1) one workgroup: weights, their inclusive scan, the normalised cumulative weights, the best particle before
- * resampling; (2) n / 256 workgroups: one particle per thread draws, searches, copies its source particle into the other set and
- * contributes to its workgroup's best / sums (a single workgroup doing all n dependent binary searches was 270 us of the 400 us
- * iteration); (3) one workgroup folds the per-workgroup results into the estimate. */
-__global__ __launch_bounds__(kPfBlock) void k_pf_weights(PfResampleArgs a) {
-	__shared__ double lds[kPfBlock / 64 + 1];
-	__shared__ double red_v[kPfBlock / 64]; __shared__ int red_i[kPfBlock / 64];
-	const int n = a.n, tid = threadIdx.x;
-	const int per = (n + kPfBlock - 1) / kPfBlock;   /* contiguous run of particles per thread: the scan is a scan of run sums */
-	const int lo = min(tid * per, n), hi = min(lo + per, n);
-	const double pi = 3.14159265358979323846;
-	const double mfac = 1.0 / sqrt(2 * pi * a.measurement_sigma);   /* PF.cc:69-70 */
-	/* particle_wts (PF.cc:348-365) and their running sum.  Up to 16 particles per thread (n <= 16 384) the run lives in registers:
-	 * every load is issued before the first use and nothing is read back -- the loop form below re-reads wts[] after writing
-	 * cum[] through pointers the compiler must assume to alias, one dependent memory round trip per particle (15 of the
-	 * kernel's 24 us at 10 000 particles).  Same operations in the same order either way. */
-	constexpr int kRun = 16;
-	auto weight = [&](double lik, double sim) -> double {
-		if (a.likelihood_func == 0) return lik;
-		const double val = a.max_similarity - sim;
-		return a.likelihood_func == 1 ? mfac * exp(-0.5 * val / a.measurement_sigma) : 1.0 / (1.0 + val);
-	};
-	double run = 0, total;
-	double bv = -1.7976931348623157e308; int bi = -1;
-	if (per <= kRun) {
-		double wv[kRun];
-		const double *src = a.likelihood_func == 0 ? a.lik : a.sim;
-		/* a thread's run is contiguous, so a wave's loads / stores are strided (80 bytes apart at 10 000 particles): pairs of
-		 * doubles halve the number of requests the single CU this kernel runs on has to issue (lo is even whenever per is) */
-		const bool pairs = (per & 1) == 0;
+__global__ __launch_bounds__(kBlock) void k_pf_scan(PfScanArgs a) {
+	__shared__ double wsum[kBlock / 64];
+	__shared__ int is_last;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int chunk = blockIdx.x * (kBlock / 64) + wave;
+	const int base = chunk * kPfChunk + 4 * lane;
+	const int nch = a.nch;
+	if (chunk < nch) {
+		double w[4];
+		if (base + 3 < a.n) {
+			const double2 v0 = *reinterpret_cast<const double2 *>(a.wts + base), v1 = *reinterpret_cast<const double2 *>(a.wts + base + 2);
+			w[0] = v0.x; w[1] = v0.y; w[2] = v1.x; w[3] = v1.y;
+		} else {
 #pragma unroll
-		for (int j = 0; j < kRun; j += 2) {
-			if (pairs && lo + j + 1 < hi) { const double2 v = *reinterpret_cast<const double2 *>(src + lo + j); wv[j] = v.x; wv[j + 1] = v.y; }
-			else { wv[j] = lo + j < hi ? src[lo + j] : 0.0; wv[j + 1] = lo + j + 1 < hi ? src[lo + j + 1] : 0.0; }
+			for (int j = 0; j < 4; ++j) w[j] = base + j < a.n ? a.wts[base + j] : 0.0;
 		}
-#pragma unroll
-		for (int j = 0; j < kRun; ++j)
-			if (lo + j < hi) { wv[j] = a.likelihood_func == 0 ? wv[j] : weight(0.0, wv[j]); run += wv[j]; }
-		const double incl = block_scan_incl(run, lds, total);
-		double c = incl - run;
-		double cv[kRun];
-#pragma unroll
-		for (int j = 0; j < kRun; ++j) {
-			cv[j] = 0.0;
-			if (lo + j < hi) {
-				c += wv[j];
-				cv[j] = c / total;                                    /* particle_cum_wts /= particle_cum_wts[n - 1] */
-				if (wv[j] >= bv) { bv = wv[j]; bi = lo + j; }         /* the highest weighted particle, last index on ties (`>=`, PF.cc:378-381) */
-			}
-		}
-#pragma unroll
-		for (int j = 0; j < kRun; j += 2) {
-			if (pairs && lo + j + 1 < hi) {
-				*reinterpret_cast<double2 *>(a.wts + lo + j) = make_double2(wv[j], wv[j + 1]);
-				*reinterpret_cast<double2 *>(a.cum + lo + j) = make_double2(cv[j], cv[j + 1]);
-			} else {
-				if (lo + j < hi) { a.wts[lo + j] = wv[j]; a.cum[lo + j] = cv[j]; }
-				if (lo + j + 1 < hi) { a.wts[lo + j + 1] = wv[j + 1]; a.cum[lo + j + 1] = cv[j + 1]; }
-			}
-		}
-	} else {
-		for (int k = lo; k < hi; ++k) {
-			const double w = weight(a.likelihood_func == 0 ? a.lik[k] : 0.0, a.likelihood_func == 0 ? 0.0 : a.sim[k]);
-			a.wts[k] = w;
-			run += w;
-		}
-		const double incl = block_scan_incl(run, lds, total);
-		double c = incl - run;
-		for (int k = lo; k < hi; ++k) { c += a.wts[k]; a.cum[k] = c / total; }
-		for (int k = lo; k < hi; ++k) if (a.wts[k] >= bv) { bv = a.wts[k]; bi = k; }
+		const double p0 = w[0], p1 = p0 + w[1], p2 = p1 + w[2], p3 = p2 + w[3];
+		const double incl = wave_scan_incl(p3, lane);
+		const double off = incl - p3;
+		*reinterpret_cast<double2 *>(a.cum + base) = make_double2(off + p0, off + p1);
+		*reinterpret_cast<double2 *>(a.cum + base + 2) = make_double2(off + p2, off + p3);
+		if (lane == 63) st_coh(a.chunk_tot + chunk, incl);
 	}
+	wait_stores_acked();
+	__syncthreads();
+	if (tid == 0) is_last = __hip_atomic_fetch_add(a.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+	__syncthreads();
+	if (!is_last) return;
+	/* chunk totals -> inclusive prefix: a thread sums a contiguous run (up to 16 totals -- a million particles -- are fetched with
+	 * independent loads first: these are L2-bypassing loads, a microsecond each when they wait for one another), the runs are
+	 * scanned over the workgroup */
+	const int per = (nch + kBlock - 1) / kBlock, lo = min(tid * per, nch), hi = min(lo + per, nch);
+	constexpr int kRun = 16;
+	double run = 0.0, tv[kRun];
+	if (per <= kRun) {
+#pragma unroll
+		for (int j = 0; j < kRun; ++j) tv[j] = lo + j < hi ? ld_coh(a.chunk_tot + lo + j) : 0.0;
+#pragma unroll
+		for (int j = 0; j < kRun; ++j) run += tv[j];   /* (+ 0.0 past the run: exact) */
+	} else {
+		for (int c = lo; c < hi; ++c) run += ld_coh(a.chunk_tot + c);
+	}
+	const double ri = wave_scan_incl(run, lane);
+	if (lane == 63) wsum[wave] = ri;
+	__syncthreads();
+	double c0 = ri - run;
+#pragma unroll
+	for (int v = 0; v < kBlock / 64 - 1; ++v) if (v < wave) c0 += wsum[v];
+	if (per <= kRun) {
+#pragma unroll
+		for (int j = 0; j < kRun; ++j) if (lo + j < hi) { c0 += tv[j]; a.chunk_incl[lo + j] = c0; }
+	} else {
+		for (int c = lo; c < hi; ++c) { c0 += ld_coh(a.chunk_tot + c); a.chunk_incl[c] = c0; }
+	}
+	if (tid == 0) __hip_atomic_store(a.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+/* ===================================================================== */
+/* launch 3: resampling + estimate (+ the proposals of the next iteration) */
+/* ===================================================================== */
+/* per-workgroup row of the selection pass: [0] best weight [1] its new index [2..9] sum of states [10..17] sum of corners
+ * [18..25] the state of the workgroup's best particle */
+constexpr int kPfPart = 26;
+constexpr int kPfTable = 4096;   /* chunk table in LDS: up to 1 048 576 particles; beyond, the table is searched in memory */
+struct PfPublish { double *host; unsigned long long *flag, seq; };
+struct PfSelectArgs {
+	int resampling_type, mean_type;
+	int lookahead;                /* 1: the proposals of the next iteration (draws of a.iter + 1) are produced here */
+	const double *uniforms;       /* [n] or NULL: Philox */
+	const double *wts, *cum, *chunk_incl;
+	const double *prop, *prop_ar; /* [n][S] this iteration's proposals */
+	double *st_out, *ar_out;      /* [n][S] the (resampled) set the iteration leaves behind */
+	double *next, *next_ar;       /* [n][S] lookahead: the proposal set of the next iteration */
+	int *ids;                     /* [n] resample ids (diagnostics / tests) */
+	double init_corners_hm[12];
+	double *parts;                /* [nblocks][kPfPart] */
+	double *gparts;               /* [ceil(nblocks / 64)][kPfPart] group rows */
+	int *counter;                 /* [1 + ceil(nblocks / 64)]: top-level counter, then one per group; zero between launches */
+	double *out;                  /* [32]: estimate state (8) | max_wt | max_wt_id | mean corners (8) */
+	PfPublish pub;
+};
+/* a folded row: best weight and its index, the sixteen sums, the state of the best particle (all wave-uniform) */
+struct PfRow { double v; int i; double sum[16]; double st[8]; };
+/* element `idx` (per-lane) of a small uniform array without indexing registers dynamically */
+template <int N>
+__device__ __forceinline__ double pf_pick(const double (&a)[N], int idx) {
+	double v = a[0];
+#pragma unroll
+	for (int q = 1; q < N; ++q) v = idx == q ? a[q] : v;
+	return v;
+}
+/* `count` <= 64 rows of kPfPart doubles, one per lane, every load issued before the first use; best: larger weight, then
+ * larger index (rows are in particle order: `>=` in index order); sums: xor butterfly = a fixed balanced tree */
+__device__ __forceinline__ void pf_fold64(const double *rows, int count, int lane, PfRow &o) {
+	double x[kPfPart];
+	const double *p = rows + (size_t)min(lane, count - 1) * kPfPart;
+#pragma unroll
+	for (int q = 0; q < kPfPart; ++q) x[q] = ld_coh(p + q);
+	const bool live = lane < count;
+	double bv = live ? x[0] : -1.7976931348623157e308;
+	int bi = live ? (int)x[1] : -1, bl = lane;
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1) {
-		const double ov = __shfl_xor(bv, d); const int oi = __shfl_xor(bi, d);
-		if (ov > bv || (ov == bv && oi > bi)) { bv = ov; bi = oi; }
+		const double ov = __shfl_xor(bv, d); const int oi = __shfl_xor(bi, d), ol = __shfl_xor(bl, d);
+		if (ov > bv || (ov == bv && oi > bi)) { bv = ov; bi = oi; bl = ol; }
 	}
-	if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bi; }
-	__syncthreads();
-	if (tid == 0) {
-		for (int w = 1; w < kPfBlock / 64; ++w) if (red_v[w] > bv || (red_v[w] == bv && red_i[w] > bi)) { bv = red_v[w]; bi = red_i[w]; }
-		a.out[8] = bv; a.out[9] = (double)bi;
+	o.v = bv; o.i = bi;
+#pragma unroll
+	for (int q = 0; q < 16; ++q) {
+		double sv = live ? x[2 + q] : 0.0;
+#pragma unroll
+		for (int d = 32; d >= 1; d >>= 1) sv += __shfl_xor(sv, d);
+		o.sum[q] = sv;
 	}
+#pragma unroll
+	for (int q = 0; q < 8; ++q) o.st[q] = __shfl(x[18 + q], bl);
 }
-/* per-workgroup partial results of the selection pass: [0] best weight [1] its new index [2..9] sum of states [10..17] sum of corners */
-constexpr int kPfPart = 18;
-__global__ __launch_bounds__(kBlock) void k_pf_select(PfResampleArgs a, double *parts) {
-	__shared__ double red_v[kBlock / 64]; __shared__ int red_i[kBlock / 64];
+template <int SSM>
+__global__ __launch_bounds__(kBlock) void k_pf_select(PfArgs a, PfSelectArgs r) {
+	constexpr int S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
+	__shared__ double table[kPfTable];
 	__shared__ double lds[4 * 16];
-	/* every kCoarse-th (or coarser) cumulative weight: the first levels of each particle's binary search run out of LDS instead of
-	 * being fourteen dependent global loads (10 of the kernel's 14.6 us) */
-	constexpr int kCoarse = 2048;
-	__shared__ double coarse[kCoarse];
-	const int n = a.n, S = a.S, tid = threadIdx.x, k = blockIdx.x * kBlock + tid;
-	const bool resample = a.resampling_type == 1 || a.resampling_type == 2;
-	const int cstride = max(32, (n + kCoarse - 1) / kCoarse), ncoarse = (n + cstride - 1) / cstride;
+	__shared__ double red_v[kBlock / 64]; __shared__ int red_i[kBlock / 64];
+	__shared__ double best_state[8];
+	__shared__ int wg_best, is_last;
+	const int n = a.n, tid = threadIdx.x, k = blockIdx.x * kBlock + tid;
+	const bool resample = r.resampling_type == 1 || r.resampling_type == 2;
+	const int nch = (n + kPfChunk - 1) / kPfChunk;
+	const bool in_lds = nch <= kPfTable;
+	double total = 0.0;
 	if (resample) {
-		for (int j = tid; j < ncoarse; j += kBlock) coarse[j] = a.cum[min((j + 1) * cstride, n) - 1];   /* last element of block j */
+		if (in_lds) for (int j = tid; j < nch; j += kBlock) table[j] = r.chunk_incl[j];
+		total = r.chunk_incl[nch - 1];
 		__syncthreads();
 	}
 	double bv = -1.7976931348623157e308; int bi = -1;
-	double acc[16];
+	double acc[16], ns[8], nar[8];
 #pragma unroll
 	for (int s = 0; s < 16; ++s) acc[s] = 0.0;
+#pragma unroll
+	for (int s = 0; s < 8; ++s) ns[s] = nar[s] = 0.0;
 	if (k < n) {
 		int id = k;
 		if (resample) {
-			/* multinomial resampling (PF.cc:455-502 binary search; :505-536 linear search: the same smallest index whose
-			 * normalised cumulative weight reaches the draw), into the other particle set */
-			const double u = a.uniforms ? a.uniforms[k] : philox_uniform(a.seed, a.iter, (unsigned)k);
-			/* the smallest index whose normalised cumulative weight reaches the draw: first the block (its last element reaches
-			 * it), then inside the block -- the index the one-level search over cum[] returns */
-			int l = 0, h = ncoarse - 1;
-			int j = (l + h) / 2;
-			while (h > l) { if (coarse[j] >= u) h = j; else l = j + 1; j = (l + h) / 2; }
-			l = j * cstride; h = min(l + cstride, n) - 1;
-			id = (l + h) / 2;
-			while (h > l) { if (a.cum[id] >= u) h = id; else l = id + 1; id = (l + h) / 2; }
-			if (a.ids) a.ids[k] = id;
+			/* multinomial resampling (PF.cc:455-502 binary search; :505-536 linear search: both return the smallest index whose
+			 * normalised cumulative weight reaches the draw): the draw is scaled by the total instead of every weight being divided */
+			const double u = r.uniforms ? r.uniforms[k] : philox_uniform(a.seed, a.iter, (unsigned)k);
+			const double tgt = u * total;
+			int l = 0, h = nch - 1, c = (l + h) / 2;
+			if (in_lds) { while (h > l) { if (table[c] >= tgt) h = c; else l = c + 1; c = (l + h) / 2; } }
+			else { while (h > l) { if (r.chunk_incl[c] >= tgt) h = c; else l = c + 1; c = (l + h) / 2; } }
+			const double off = c > 0 ? (in_lds ? table[c - 1] : r.chunk_incl[c - 1]) : 0.0;
+			const double *cl = r.cum + (size_t)c * kPfChunk;
+			int lo = 0;
+			if (n <= 65536) {
+				/* few workgroups, nothing to hide a chain of dependent loads behind: two rounds of independent loads -- fifteen
+				 * probes sixteen apart, then the sixteen neighbours */
+				double p[15];
+#pragma unroll
+				for (int q = 0; q < 15; ++q) p[q] = cl[16 * (q + 1) - 1];
+				int cnt = 0;
+#pragma unroll
+				for (int q = 0; q < 15; ++q) cnt += (off + p[q] < tgt) ? 1 : 0;
+				lo = 16 * cnt;
+				const double2 *p2 = reinterpret_cast<const double2 *>(cl + lo);
+				double2 v[8];
+#pragma unroll
+				for (int q = 0; q < 8; ++q) v[q] = p2[q];
+				cnt = 0;
+#pragma unroll
+				for (int q = 0; q < 8; ++q) cnt += ((off + v[q].x < tgt) ? 1 : 0) + ((off + v[q].y < tgt) ? 1 : 0);
+				lo += min(cnt, 15);
+			} else {
+				/* many workgroups: the latency is hidden, the cache lines are not -- plain bisection touches six of the chunk's 32 lines */
+				int hh = kPfChunk - 1;
+				int j = (lo + hh) / 2;
+				while (hh > lo) { if (off + cl[j] >= tgt) hh = j; else lo = j + 1; j = (lo + hh) / 2; }
+			}
+			id = min(c * kPfChunk + lo, n - 1);
+			if (r.ids) r.ids[k] = id;
 		}
-		double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-		/* a particle's row is S (6 or 8) contiguous doubles: copied as pairs (rows start 16-byte aligned), all loads first */
-		const double2 *src_s = reinterpret_cast<const double2 *>(a.st_in + (size_t)id * S), *src_a = reinterpret_cast<const double2 *>(a.ar_in + (size_t)id * S);
-		double2 ps[4], pa[4];
-#pragma unroll
-		for (int s2 = 0; s2 < 4; ++s2) {
-			ps[s2] = 2 * s2 < S ? src_s[s2] : make_double2(0.0, 0.0);
-			pa[s2] = (resample && 2 * s2 < S) ? src_a[s2] : make_double2(0.0, 0.0);
+		pf_load_row<S>(r.prop, (size_t)id, ns); pf_load_row<S>(r.prop_ar, (size_t)id, nar);
+		pf_store_row<S>(r.st_out, (size_t)k, ns); pf_store_row<S>(r.ar_out, (size_t)k, nar);
+		if (r.lookahead) {
+			PfArgs an = a;
+			an.iter = a.iter + 1;
+			double ps[8], pa[8];
+			pf_propose<SSM>(an, (unsigned)k, ns, nar, ps, pa);
+			pf_store_row<S>(r.next, (size_t)k, ps); pf_store_row<S>(r.next_ar, (size_t)k, pa);
 		}
+		bv = r.wts[id]; bi = k;
+		if (r.mean_type == 1) {
 #pragma unroll
-		for (int s2 = 0; s2 < 4; ++s2) { p[2 * s2] = ps[s2].x; p[2 * s2 + 1] = ps[s2].y; }
-		if (resample) {
-			double2 *dst_s = reinterpret_cast<double2 *>(a.st_out + (size_t)k * S), *dst_a = reinterpret_cast<double2 *>(a.ar_out + (size_t)k * S);
-#pragma unroll
-			for (int s2 = 0; s2 < 4; ++s2) if (2 * s2 < S) { dst_s[s2] = ps[s2]; dst_a[s2] = pa[s2]; }
-		}
-		bv = a.wts[id]; bi = k;
-		if (a.mean_type == 1) {
-#pragma unroll
-			for (int s = 0; s < 8; ++s) acc[s] = p[s];
-		} else if (a.mean_type == 2) {   /* updateMeanCorners :607-614 */
+			for (int s = 0; s < 8; ++s) acc[s] = ns[s];
+		} else if (r.mean_type == 2) {   /* updateMeanCorners :607-614 */
 			double W[9];
-			if (a.ssm == MTFHIP_SSM_HOMOGRAPHY) warp_from_state_dev<MTFHIP_SSM_HOMOGRAPHY>(p, W); else warp_from_state_dev<MTFHIP_SSM_AFFINE>(p, W);
+			warp_from_state_dev<SSM>(ns, W);
 #pragma unroll
 			for (int q = 0; q < 4; ++q) {
-				const double X = a.init_corners_hm[3 * q], Y = a.init_corners_hm[3 * q + 1], Z = a.init_corners_hm[3 * q + 2];
+				const double X = r.init_corners_hm[3 * q], Y = r.init_corners_hm[3 * q + 1], Z = r.init_corners_hm[3 * q + 2];
 				double nx = W[0] * X + W[1] * Y + W[2] * Z, ny = W[3] * X + W[4] * Y + W[5] * Z;
-				if (a.ssm == MTFHIP_SSM_HOMOGRAPHY) { const double d = W[6] * X + W[7] * Y + W[8] * Z; nx = nx / d; ny = ny / d; }
+				if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) { const double d = W[6] * X + W[7] * Y + W[8] * Z; nx = nx / d; ny = ny / d; }
 				acc[8 + 2 * q] = nx; acc[9 + 2 * q] = ny;
 			}
 		}
 	}
-	/* the best of the (resampled) set, last index on ties (PF.cc:487-490) */
+	/* the best of the (resampled) set, last index on ties (`>=` in index order, PF.cc:378-381, 487-490) */
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1) {
 		const double ov = __shfl_xor(bv, d); const int oi = __shfl_xor(bi, d);
@@ -380,51 +663,72 @@ __global__ __launch_bounds__(kBlock) void k_pf_select(PfResampleArgs a, double *
 	}
 	if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bi; }
 	__syncthreads();
-	double *part = parts + (size_t)blockIdx.x * kPfPart;
 	if (tid == 0) {
 		for (int w = 1; w < kBlock / 64; ++w) if (red_v[w] > bv || (red_v[w] == bv && red_i[w] > bi)) { bv = red_v[w]; bi = red_i[w]; }
-		part[0] = bv; part[1] = (double)bi;
+		red_v[0] = bv; wg_best = bi;
 	}
 	__syncthreads();
-	block_reduce_store<16>(acc, part + 2, lds);
-}
-/* (pub: the 32 doubles of `out` also go to host-coherent memory, followed by the sequence number the host spins on -- the estimate is
- * what nt::PF reads back every iteration for its convergence test) */
-struct PfPublish { double *host; unsigned long long *flag, seq; };
-__global__ __launch_bounds__(64) void k_pf_estimate(PfResampleArgs a, const double *parts, int nparts, PfPublish pub) {
-	const int lane = threadIdx.x, S = a.S, n = a.n;
-	const bool resample = a.resampling_type == 1 || a.resampling_type == 2;
-	const double *st_final = resample ? a.st_out : a.st_in;
-	/* the per-workgroup rows are fetched by all lanes at once into LDS and folded from there in workgroup order (a loop of
-	 * dependent global loads was 12 of this kernel's 16 us) */
-	constexpr int kStage = 256;   /* rows staged: 65 536 particles; beyond that the rows are read from memory */
-	__shared__ double rows[kStage * kPfPart];
-	const bool staged = nparts <= kStage;
-	if (staged) {
-		for (int q = lane; q < nparts * kPfPart; q += 64) rows[q] = parts[q];
-		__syncthreads();
+	if (k < n && k == wg_best) {
+#pragma unroll
+		for (int s = 0; s < 8; ++s) best_state[s] = ns[s];
 	}
-	const double *pr = staged ? rows : parts;
-	/* best over the workgroups, in workgroup order (= particle order): last index on ties */
-	double bv = a.out[8]; int bi = (int)a.out[9];
-	if (resample) {
-		bv = -1.7976931348623157e308; bi = -1;
-		for (int w = 0; w < nparts; ++w) { const double v = pr[(size_t)w * kPfPart]; const int i2 = (int)pr[(size_t)w * kPfPart + 1]; if (v > bv || (v == bv && i2 > bi)) { bv = v; bi = i2; } }
+	double *part = r.parts + (size_t)blockIdx.x * kPfPart;
+	block_reduce_store<16, true>(acc, part + 2, lds);   /* (its barrier also orders best_state) */
+	if (tid == 0) { st_coh(part, red_v[0]); st_coh(part + 1, (double)wg_best); }
+	if (tid >= 64 && tid < 72) st_coh(part + 18 + (tid - 64), best_state[tid - 64]);
+	wait_stores_acked();
+	__syncthreads();
+	/* ---- the estimate (PF.cc:421-437).  The rows are folded by a two-level tree of last arrivers: workgroups form groups of 64,
+	 * the last one of a group folds the group's rows (one row per lane, every load in flight at once -- a single workgroup
+	 * walking thousands of rows through L2-bypassing loads was 340 of the 410 us of this kernel at a million particles), the last
+	 * group to finish folds the group rows.  Sums are taken in a fixed tree, the same on every rank. ---- */
+	const int nparts = gridDim.x, ngroups = (nparts + 63) / 64, grp = blockIdx.x >> 6;
+	const int gsize = min(64, nparts - grp * 64);
+	if (tid == 0) is_last = __hip_atomic_fetch_add(r.counter + 1 + grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1;
+	__syncthreads();
+	if (!is_last || tid >= 64) return;
+	const int lane = tid;
+	PfRow row;
+	pf_fold64(r.parts + (size_t)grp * 64 * kPfPart, gsize, lane, row);
+	if (lane == 0) __hip_atomic_store(r.counter + 1 + grp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (ngroups > 1) {
+		double *gp = r.gparts + (size_t)grp * kPfPart;
+		if (lane == 0) { st_coh(gp, row.v); st_coh(gp + 1, (double)row.i); }
+		if (lane < 16) st_coh(gp + 2 + lane, pf_pick(row.sum, lane));
+		if (lane < 8) st_coh(gp + 18 + lane, pf_pick(row.st, lane));
+		wait_stores_acked();
+		int last = 0;
+		if (lane == 0) last = __hip_atomic_fetch_add(r.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1;
+		if (!__shfl(last, 0)) return;
+		PfRow tot;
+		pf_fold64(r.gparts, min(64, ngroups), lane, tot);
+		for (int g0 = 64; g0 < ngroups; g0 += 64) {   /* more than 4096 workgroups (a million particles): passes of 64 group rows, combined in order */
+			PfRow nx;
+			pf_fold64(r.gparts + (size_t)g0 * kPfPart, min(64, ngroups - g0), lane, nx);
+			if (nx.v > tot.v || (nx.v == tot.v && nx.i > tot.i)) {
+				tot.v = nx.v; tot.i = nx.i;
+#pragma unroll
+				for (int q = 0; q < 8; ++q) tot.st[q] = nx.st[q];
+			}
+#pragma unroll
+			for (int q = 0; q < 16; ++q) tot.sum[q] += nx.sum[q];
+		}
+		row = tot;
+		if (lane == 0) __hip_atomic_store(r.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
-	if (lane < 16) {
-		double s = 0;
-		for (int w = 0; w < nparts; ++w) s += pr[(size_t)w * kPfPart + 2 + lane];
-		if (a.mean_type == 1 && lane < S) a.out[lane] = s / (double)n;             /* estimateMeanOfSamples :311-317 */
-		if (a.mean_type == 2 && lane >= 8) a.out[10 + lane - 8] = s / (double)n;   /* mean corners */
-	}
-	if (a.mean_type != 1 && lane < S) a.out[lane] = st_final[(size_t)bi * S + lane];
-	if (lane == 0) { a.out[8] = bv; a.out[9] = (double)bi; }
-	if (pub.host) {
-		__threadfence();
-		__syncthreads();
-		if (lane < 32) __hip_atomic_store(pub.host + lane, ld_coh(a.out + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	/* lane q < 32 ends up holding out[q]: state estimate (8) | max_wt | max_wt_id | mean corners (8) | 0 ... */
+	double o = 0.0;
+	if (lane < 8) {
+		if (r.mean_type == 1) o = lane < S ? pf_pick(row.sum, lane) / (double)n : 0.0;   /* estimateMeanOfSamples :311-317 */
+		else o = lane < S ? pf_pick(row.st, lane) : 0.0;
+	} else if (lane == 8) o = row.v;
+	else if (lane == 9) o = (double)row.i;
+	else if (lane >= 10 && lane < 18 && r.mean_type == 2) o = pf_pick(row.sum, lane - 2) / (double)n;   /* mean corners: sum slots 8..15 */
+	if (lane < 32) r.out[lane] = o;
+	if (r.pub.host) {
+		if (lane < 32) __hip_atomic_store(r.pub.host + lane, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		__threadfence_system();
-		if (lane == 0) __hip_atomic_store(pub.flag, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		if (lane == 0) __hip_atomic_store(r.pub.flag, r.pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 }
 
@@ -438,32 +742,63 @@ __global__ void k_pf_fill(int n, int S, const double *state, double *states, dou
 /* ===================================================================== */
 /* launchers                                                              */
 /* ===================================================================== */
-void launch_pf_propagate(int ssm, const PfLaunch &p, double *states, double *ars, hipStream_t st) {
+static PfArgs pf_args(const PfLaunch &p) {
 	PfArgs a;
-	a.n = p.n; a.S = p.S; a.dynamic_model = p.dynamic_model; a.update_type = p.update_type; a.corner_based = p.corner_based; a.ar_coeff = p.ar_coeff;
+	a.n = p.n; a.S = p.S; a.dynamic_model = p.dynamic_model; a.update_type = p.update_type; a.sampler = p.sampler; a.nz = p.nz; a.ar_coeff = p.ar_coeff;
 	for (int k = 0; k < 8; ++k) { a.sigma[k] = p.sigma[k]; a.mean[k] = p.mean[k]; a.init_corners[k] = p.init_corners[k]; }
-	for (int k = 0; k < 9; ++k) a.sq_inv[k] = p.sq_inv[k];
+	for (int k = 0; k < 9; ++k) a.aux_inv[k] = p.aux_inv[k];
+	for (int k = 0; k < 6; ++k) a.canon[k] = p.canon[k];
 	a.seed = p.seed; a.iter = p.iter; a.normals = p.normals;
-	const dim3 g((p.n + kBlock - 1) / kBlock);
-	if (ssm == MTFHIP_SSM_HOMOGRAPHY) MTFHIP_LAUNCH(k_pf_propagate<MTFHIP_SSM_HOMOGRAPHY>, g, dim3(kBlock), 0, st, a, states, ars);
-	else MTFHIP_LAUNCH(k_pf_propagate<MTFHIP_SSM_AFFINE>, g, dim3(kBlock), 0, st, a, states, ars);
+	return a;
 }
-void launch_pf_resample(int ssm, const PfLaunch &p, const double *lik, const double *sim, double *wts, double *cum, const double *st_in,
-	const double *ar_in, double *st_out, double *ar_out, int *ids, double *out, double *parts, double *host_out, unsigned long long *host_flag,
+void launch_pf_propose(int ssm, const PfLaunch &p, const double *st_in, const double *ar_in, double *st_out, double *ar_out, hipStream_t st) {
+	const PfArgs a = pf_args(p);
+	const dim3 g((p.n + kBlock - 1) / kBlock);
+	if (ssm == MTFHIP_SSM_HOMOGRAPHY) MTFHIP_LAUNCH(k_pf_propose<MTFHIP_SSM_HOMOGRAPHY>, g, dim3(kBlock), 0, st, a, st_in, ar_in, st_out, ar_out);
+	else MTFHIP_LAUNCH(k_pf_propose<MTFHIP_SSM_AFFINE>, g, dim3(kBlock), 0, st, a, st_in, ar_in, st_out, ar_out);
+}
+void launch_pf_score(const BatchView &bv, const ImgView &im, const PfLaunch &p, const PfBuffers &bf, int lo, int cnt,
+	double alpha, double norm_mult, double norm_add, const double *ncc_sc, int fast_math, hipStream_t st) {
+	if (cnt <= 0) return;
+	PfScoreArgs s;
+	s.prop = bf.prop; s.lo = lo; s.cnt = cnt; s.alpha = alpha; s.norm_mult = norm_mult; s.norm_add = norm_add; s.ncc_sc = ncc_sc;
+	s.likelihood_func = p.likelihood_func; s.measurement_sigma = p.measurement_sigma; s.max_similarity = p.max_similarity;
+	s.wts = bf.wts; s.sim = bf.sim;
+	const dim3 g((cnt + 3) / 4);
+#define MTFHIP_PF_SCORE(SSM_, NCC_, FAST_) MTFHIP_LAUNCH((k_pf_score<SSM_, NCC_, FAST_>), g, dim3(kBlock), 0, st, bv, im, s)
+	const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY, ncc = ncc_sc != nullptr;
+	if (fast_math) {
+		if (hom) { if (ncc) MTFHIP_PF_SCORE(MTFHIP_SSM_HOMOGRAPHY, true, true); else MTFHIP_PF_SCORE(MTFHIP_SSM_HOMOGRAPHY, false, true); }
+		else { if (ncc) MTFHIP_PF_SCORE(MTFHIP_SSM_AFFINE, true, true); else MTFHIP_PF_SCORE(MTFHIP_SSM_AFFINE, false, true); }
+	} else {
+		if (hom) { if (ncc) MTFHIP_PF_SCORE(MTFHIP_SSM_HOMOGRAPHY, true, false); else MTFHIP_PF_SCORE(MTFHIP_SSM_HOMOGRAPHY, false, false); }
+		else { if (ncc) MTFHIP_PF_SCORE(MTFHIP_SSM_AFFINE, true, false); else MTFHIP_PF_SCORE(MTFHIP_SSM_AFFINE, false, false); }
+	}
+#undef MTFHIP_PF_SCORE
+}
+void launch_pf_resample(int ssm, const PfLaunch &p, const PfBuffers &bf, int lookahead, double *host_out, unsigned long long *host_flag,
 	unsigned long long seq, hipStream_t st) {
-	PfResampleArgs a;
-	a.n = p.n; a.S = p.S; a.ssm = ssm; a.likelihood_func = p.likelihood_func; a.resampling_type = p.resampling_type; a.mean_type = p.mean_type;
-	a.measurement_sigma = p.measurement_sigma; a.max_similarity = p.max_similarity; a.seed = p.seed; a.iter = p.iter; a.uniforms = p.uniforms;
-	a.lik = lik; a.sim = sim; a.wts = wts; a.cum = cum; a.st_in = st_in; a.ar_in = ar_in; a.st_out = st_out; a.ar_out = ar_out; a.ids = ids;
-	for (int k = 0; k < 12; ++k) a.init_corners_hm[k] = p.init_corners_hm[k];
-	a.out = out;
-	const int nparts = (p.n + kBlock - 1) / kBlock;
-	MTFHIP_LAUNCH(k_pf_weights, dim3(1), dim3(kPfBlock), 0, st, a);
-	MTFHIP_LAUNCH(k_pf_select, dim3(nparts), dim3(kBlock), 0, st, a, parts);
-	MTFHIP_LAUNCH(k_pf_estimate, dim3(1), dim3(64), 0, st, a, parts, nparts, PfPublish{host_out, host_flag, seq});
+	const PfArgs a = pf_args(p);
+	const bool resample = p.resampling_type == 1 || p.resampling_type == 2;
+	const int nch = (p.n + kPfChunk - 1) / kPfChunk;
+	if (resample) {
+		PfScanArgs sc{p.n, nch, bf.wts, bf.cum, bf.chunk_tot, bf.chunk_incl, bf.counters};
+		MTFHIP_LAUNCH(k_pf_scan, dim3((nch + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, sc);
+	}
+	PfSelectArgs r;
+	r.resampling_type = p.resampling_type; r.mean_type = p.mean_type; r.lookahead = lookahead; r.uniforms = p.uniforms;
+	r.wts = bf.wts; r.cum = bf.cum; r.chunk_incl = bf.chunk_incl; r.prop = bf.prop; r.prop_ar = bf.prop_ar;
+	r.st_out = bf.st; r.ar_out = bf.ar; r.next = bf.next; r.next_ar = bf.next_ar; r.ids = bf.ids;
+	for (int k = 0; k < 12; ++k) r.init_corners_hm[k] = p.init_corners_hm[k];
+	r.parts = bf.parts; r.gparts = bf.gparts; r.counter = bf.counters + 1; r.out = bf.out; r.pub = PfPublish{host_out, host_flag, seq};
+	const dim3 g((p.n + kBlock - 1) / kBlock);
+	if (ssm == MTFHIP_SSM_HOMOGRAPHY) MTFHIP_LAUNCH(k_pf_select<MTFHIP_SSM_HOMOGRAPHY>, g, dim3(kBlock), 0, st, a, r);
+	else MTFHIP_LAUNCH(k_pf_select<MTFHIP_SSM_AFFINE>, g, dim3(kBlock), 0, st, a, r);
 }
 void launch_pf_fill(int n, int S, const double *dev_state, double *states, double *ars, hipStream_t st) {
 	MTFHIP_LAUNCH(k_pf_fill, dim3((n + 255) / 256), dim3(256), 0, st, n, S, dev_state, states, ars);
 }
+int pf_parts_per_block() { return kPfPart; }
+int pf_chunk() { return kPfChunk; }
 
 } // namespace mtfhip

@@ -426,7 +426,7 @@ static int wait_host_flag(mtfhip_batch *b, unsigned long long seq) {
 		if ((spins & 0x3ff) == 0x3ff || yielding) {
 			const auto dt = std::chrono::steady_clock::now() - t0;
 			if (dt > std::chrono::milliseconds(50)) break;
-			if (dt > std::chrono::microseconds(200)) yielding = true;
+			if (dt > std::chrono::microseconds(1000)) yielding = true;
 		}
 	}
 	/* the kernel did not report in: let the runtime tell why */

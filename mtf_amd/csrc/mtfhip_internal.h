@@ -221,21 +221,39 @@ void launch_mi_pass_grad_hess(const BatchView &bv, const ImgView &im, const MiFa
 void launch_mi_finish_fast(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, const MiFastPlan &pl, int gmode, int do_track,
 	const double *partials, int nblk, double *out_H, double *out_g, double *rows, hipStream_t st);
 int mi_fast_row_len();
-/* ---- particle filter besides scoring (kernels_pf.hip) ---- */
+/* ---- particle filter (kernels_pf.hip): proposal + scoring, cumulative weights, resampling + estimate ---- */
+enum { PF_SAMPLER_STATE = 0,       /* one normal per state component (ProjectiveBase::generatePerturbation) */
+	PF_SAMPLER_HOM_CORNERS = 1,    /* Homography, corner based: 10 normals (Homography.cc:899-911) */
+	PF_SAMPLER_AFF_PTS1 = 2,       /* Affine, pt_based_sampling 1: 6 normals (Affine.cc:475-482) */
+	PF_SAMPLER_AFF_PTS2 = 3,       /* Affine, pt_based_sampling 2: 8 normals (Affine.cc:483-491) */
+	PF_SAMPLER_AFF_GEOM = 4 };     /* Affine, geometric: 6 normals through geomToState (Affine.cc:495-502) */
 struct PfLaunch {
 	int n, S;
-	int dynamic_model, update_type, corner_based, likelihood_func, resampling_type, mean_type;
+	int dynamic_model, update_type, sampler, nz, likelihood_func, resampling_type, mean_type;
 	double ar_coeff, measurement_sigma, max_similarity;
-	double sigma[8], mean[8], init_corners[8], init_corners_hm[12], sq_inv[9];
+	double sigma[8], mean[8], init_corners[8], init_corners_hm[12], aux_inv[9], canon[6];
 	unsigned long long seed;
 	unsigned iter;
 	const double *normals, *uniforms;   /* device arrays or NULL (Philox) */
 };
-void launch_pf_propagate(int ssm, const PfLaunch &p, double *states, double *ars, hipStream_t st);
-void launch_pf_resample(int ssm, const PfLaunch &p, const double *lik, const double *sim, double *wts, double *cum, const double *st_in,
-	const double *ar_in, double *st_out, double *ar_out, int *ids, double *out, double *parts, double *host_out /* or NULL */,
+struct PfBuffers {
+	double *st, *ar;            /* [n][S] the current (resampled) particle set */
+	double *prop, *prop_ar;     /* [n][S] this iteration's proposals */
+	double *next, *next_ar;     /* [n][S] where the selection pass leaves the proposals of the next iteration (look-ahead) */
+	double *wts, *sim;          /* [>= n] weights at global particle indices; similarities or NULL */
+	double *cum, *chunk_tot, *chunk_incl;
+	double *parts, *gparts, *out;   /* per-workgroup rows of the selection pass, their per-group folds, the estimate */
+	int *ids, *counters;        /* [0] the scan's arrival counter, [1] the selection pass's top-level counter, [2 ...] one per group of 64
+	                               workgroups of the selection pass; zero between launches */
+};
+void launch_pf_propose(int ssm, const PfLaunch &p, const double *st_in, const double *ar_in, double *st_out, double *ar_out, hipStream_t st);
+void launch_pf_score(const BatchView &bv, const ImgView &im, const PfLaunch &p, const PfBuffers &bf, int lo, int cnt,
+	double alpha, double norm_mult, double norm_add, const double *ncc_sc, int fast_math, hipStream_t st);
+void launch_pf_resample(int ssm, const PfLaunch &p, const PfBuffers &bf, int lookahead, double *host_out /* or NULL */,
 	unsigned long long *host_flag, unsigned long long seq, hipStream_t st);
 void launch_pf_fill(int n, int S, const double *dev_state, double *states, double *ars, hipStream_t st);
+int pf_parts_per_block();
+int pf_chunk();
 /* sums partials over blocks: out[B][ACC_COUNT] */
 void launch_finish(double *partials, int nblk, double *out, int B, hipStream_t st);
 void launch_finish_rows(double *partials, int nblk, int row_len, double *out, int B, hipStream_t st);

@@ -1,11 +1,10 @@
-"""Candidate-axis sharding over the GPUs of one node.
+"""Independent-target sharding over the GPUs of one node.
 
-The only batch axis of the hot path that spans GPUs with a real exchange step is the PF / NN candidate
-set: every rank holds the frame and the template, scores a contiguous block of the candidates, and one
-all-gather of the per-candidate scores (RCCL over xGMI when the backend is "nccl") gives every rank all
-weights, so that resampling runs redundantly from identical data with no second collective
-(SM/src/PF.cc:283-306).  Independent targets (GridTracker patches, concurrent trackers) shard with no
-collective at all.
+The only batch axis of the hot path that spans GPUs with a real exchange step is the PF candidate set, and that one lives
+behind the C ABI: mtfhip_pf_set_comm + mtfhip_allgather_scores (RCCL directly; mtf_amd.sm.Comm / ParticleFilter) -- every rank
+scores a contiguous block of the particles and ONE in-place all-gather leaves the flat weight vector on every rank
+(SM/src/PF.cc:262-277).  Independent targets (GridTracker patches, concurrent trackers) shard with no collective at all;
+this module holds that partition and the final gather of their results.
 """
 import numpy as np
 
@@ -20,68 +19,6 @@ def shard_bounds(n_items, rank, world):
 
 def shard_sizes(n_items, world):
     return [shard_bounds(n_items, r, world)[1] - shard_bounds(n_items, r, world)[0] for r in range(world)]
-
-
-class ShardedScorer:
-    """Scores C candidate states against one template, sharded over the ranks of a process group.
-
-    score_fn(states_shard) -> (n_shard,) float64 array-like on `device`; the default uses the HIP
-    scorer of a Batch (mtfhip_score_candidates_dev) with device-resident inputs and outputs.
-    """
-
-    def __init__(self, batch=None, group=None, device=None, score_fn=None):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        self.batch, self.group = batch, group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.device = device if device is not None else torch.device("cpu")
-        self.score_fn = score_fn
-        self._buf = None
-
-    def _score_local(self, states_shard):
-        torch = self.torch
-        if self.score_fn is not None:
-            out = self.score_fn(states_shard)
-            return torch.as_tensor(np.asarray(out, dtype=np.float64), device=self.device)
-        if self.batch is None:
-            raise RuntimeError("ShardedScorer needs a Batch (HIP scorer); there is no CPU fallback")
-        st = torch.as_tensor(np.ascontiguousarray(states_shard, dtype=np.float64)).to(self.device)
-        lik = torch.empty(st.shape[0], dtype=torch.float64, device=self.device)
-        # The scorer runs on the Context's stream, which need not be torch's current stream (a default Context owns a private
-        # non-blocking one): order the two explicitly.  `st` was produced on torch's stream -> the context waits for it; `lik` is
-        # consumed on torch's stream (copy, all-gather) -> torch waits for the context; and the temporary `st` must outlive the
-        # kernel that reads it, so it is only released after the context's stream has drained.
-        cur = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
-        if cur is not None and cur.cuda_stream != (self.batch.ctx.stream or 0):
-            cur.synchronize()
-            self.batch.score_candidates_dev(st.data_ptr(), st.shape[0], lik.data_ptr())
-            self.batch.ctx.synchronize()
-        else:
-            self.batch.score_candidates_dev(st.data_ptr(), st.shape[0], lik.data_ptr())
-        return lik
-
-    def score(self, states):
-        """states: (C, S) on every rank (identical).  Returns the (C,) likelihoods on every rank."""
-        torch, dist = self.torch, self.dist
-        C = states.shape[0]
-        lo, hi = shard_bounds(C, self.rank, self.world)
-        local = self._score_local(states[lo:hi])
-        if self.world == 1:
-            return local
-        sizes = shard_sizes(C, self.world)
-        m = max(sizes)
-        # equal-size all-gather (one collective, as ncclAllGather requires); ragged tails are padded
-        send = torch.zeros(m, dtype=torch.float64, device=self.device)
-        send[: hi - lo] = local
-        if self._buf is None or self._buf.numel() != m * self.world:
-            self._buf = torch.empty(m * self.world, dtype=torch.float64, device=self.device)
-        dist.all_gather_into_tensor(self._buf, send, group=self.group)
-        if all(s == m for s in sizes):
-            return self._buf
-        parts = [self._buf[r * m: r * m + sizes[r]] for r in range(self.world)]
-        return torch.cat(parts)
 
 
 class ShardedTargets:

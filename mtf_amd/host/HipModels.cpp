@@ -343,7 +343,9 @@ double HipSSM::draw(int state_id) {
 	return rng->dist[state_id](rng->gen[state_id]);
 }
 /* Homography::generatePerturbation Homography.cc:899-915 (corner based: the warp that takes the template corners to randomly
- * displaced ones) / ProjectiveBase::generatePerturbation :283-288 */
+ * displaced ones) / ProjectiveBase::generatePerturbation :283-288 / Affine::generatePerturbation Affine.cc:464-503 (point
+ * based: bottom right, bottom left and top centre of the template disturbed, affine map of the three pairs; geometric:
+ * geomToState of six draws, Affine.cc:393-410) */
 void HipSSM::generatePerturbation(VectorXd &pert) {
 	const int S = p->S;
 	if (pert.size() != S) pert.resize(S);
@@ -357,15 +359,62 @@ void HipSSM::generatePerturbation(VectorXd &pert) {
 		estimateWarpFromCorners(pert, ic, dc);
 		return;
 	}
+	if (p->ssm == MTFHIP_SSM_AFFINE && pt_based_sampling) {
+		CornersT ic;
+		HipPair::check(mtfhip_ssm_get_init_corners(p->b, ic.data()));
+		const double ox[3] = {ic.v[4], ic.v[6], (ic.v[0] + ic.v[2]) / 2.0}, oy[3] = {ic.v[5], ic.v[7], (ic.v[1] + ic.v[3]) / 2.0};
+		double px[3], py[3];
+		if (pt_based_sampling == 1) {
+			for (int i = 0; i < 3; ++i) { px[i] = ox[i] + draw(2 * i); py[i] = oy[i] + draw(2 * i + 1); }
+		} else {
+			double rd[6];
+			for (int i = 0; i < 3; ++i) { rd[2 * i] = draw(1); rd[2 * i + 1] = draw(1); }
+			const double tx = draw(0), ty = draw(0);
+			for (int i = 0; i < 3; ++i) { px[i] = (ox[i] + rd[2 * i]) + tx; py[i] = (oy[i] + rd[2 * i + 1]) + ty; }
+		}
+		/* utils::computeAffineDLT for three point pairs (warpUtils.cc:388-421): an exactly determined system */
+		const W3 Mi = inv(W3{{ox[0], oy[0], 1, ox[1], oy[1], 1, ox[2], oy[2], 1}});
+		W3 W{{0, 0, 0, 0, 0, 0, 0, 0, 1}};
+		for (int j = 0; j < 3; ++j) {
+			W.m[j] = Mi.m[3 * j] * px[0] + Mi.m[3 * j + 1] * px[1] + Mi.m[3 * j + 2] * px[2];
+			W.m[3 + j] = Mi.m[3 * j] * py[0] + Mi.m[3 * j + 1] * py[1] + Mi.m[3 * j + 2] * py[2];
+		}
+		stateOf(p->ssm, pert.data(), W);
+		return;
+	}
+	if (p->ssm == MTFHIP_SSM_AFFINE) {   /* geometric: Affine.cc:495-502 */
+		double gm[6];
+		for (int s = 0; s < 6; ++s) gm[s] = draw(s);
+		const double sc = gm[2], r = gm[4], theta = gm[3], phi = gm[5];
+		const double cos_theta = std::cos(theta), sin_theta = std::sin(theta), cos_phi = std::cos(phi), sin_phi = std::sin(phi);
+		const double ccc = cos_theta * cos_phi * cos_phi, ccs = cos_theta * cos_phi * sin_phi, css = cos_theta * sin_phi * sin_phi;
+		const double scc = sin_theta * cos_phi * cos_phi, scs = sin_theta * cos_phi * sin_phi, sss = sin_theta * sin_phi * sin_phi;
+		pert[0] = gm[0]; pert[1] = gm[1];
+		pert[2] = sc * (ccc + scs + r * (css - scs)) - 1;
+		pert[3] = sc * (r * (ccs - scc) - ccs - sss);
+		pert[4] = sc * (scc - ccs + r * (ccs + sss));
+		pert[5] = sc * (r * (ccc + scs) - scs + css) - 1;
+		return;
+	}
 	for (int s = 0; s < S; ++s) pert[s] = draw(s);
 }
+/* Affine's additive models perturb the geometric parametrisation (Affine.cc:507-538): stateToGeom is a 2 x 2 JacobiSVD whose
+ * sign / ordering conventions select its branches -- not reproducible without Eigen, so they are refused rather than replaced
+ * by raw-state noise; with point based sampling the reference itself throws */
+void HipSSM::affineAdditiveRefused(const char *fn) const {
+	if (pt_based_sampling) throw utils::FunctonNotImplemented(std::string("Affine::") + fn + " :: point based sampling is not implemented yet");
+	throw utils::FunctonNotImplemented(std::string("Affine::") + fn + " :: geometric sampling needs Affine::stateToGeom (Eigen JacobiSVD conventions); use the compositional models");
+}
 void HipSSM::additiveRandomWalk(VectorXd &out, const VectorXd &base) {   /* :236-240 */
+	if (p->ssm == MTFHIP_SSM_AFFINE) affineAdditiveRefused("additiveRandomWalk");
 	VectorXd pert(p->S);
 	generatePerturbation(pert);
 	if (out.size() != p->S) out.resize(p->S);
 	for (int s = 0; s < p->S; ++s) out[s] = base[s] + pert[s];
 }
-void HipSSM::compositionalRandomWalk(VectorXd &out, const VectorXd &base) {   /* Homography.cc:916-926 */
+void HipSSM::compositionalRandomWalk(VectorXd &out, const VectorXd &base) {   /* Homography.cc:916-926, Affine.cc:539-553 */
+	if (p->ssm == MTFHIP_SSM_AFFINE && !pt_based_sampling)
+		throw utils::FunctonNotImplemented("Affine::compositionalRandomWalk :: geometric sampling is not implemented yet");
 	VectorXd pert(p->S);
 	generatePerturbation(pert);
 	W3 W = mul(warpOf(p->ssm, base.data()), warpOf(p->ssm, pert.data()));
@@ -374,6 +423,7 @@ void HipSSM::compositionalRandomWalk(VectorXd &out, const VectorXd &base) {   /*
 	stateOf(p->ssm, out.data(), W);
 }
 void HipSSM::additiveAutoRegression1(VectorXd &out, VectorXd &out_ar, const VectorXd &base, const VectorXd &base_ar, double a) {   /* :254-259 */
+	if (p->ssm == MTFHIP_SSM_AFFINE) affineAdditiveRefused("additiveAutoRegression1");
 	VectorXd pert(p->S);
 	generatePerturbation(pert);
 	if (out.size() != p->S) out.resize(p->S);

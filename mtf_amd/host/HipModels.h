@@ -197,6 +197,8 @@ public:
 	void markMoved() { d_pts = d_gpts = d_hpts = true; }   /* a device-side driver (hip::PF, mtfhip_batch_track) moved the SSM */
 	void setCornerBasedSampling(bool on) { corner_based_sampling = on; }   /* HomographyParams::corner_based_sampling */
 	bool getCornerBasedSampling() const { return corner_based_sampling; }
+	void setPtBasedSampling(int mode) { pt_based_sampling = mode; }        /* AffineParams::pt_based_sampling (0 geometric, 1, 2) */
+	int getPtBasedSampling() const { return pt_based_sampling; }
 	const std::shared_ptr<HipPair> &pair() const { return p; }
 private:
 	std::shared_ptr<HipPair> p;
@@ -207,6 +209,8 @@ private:
 	}
 	VectorXd sampler_sigma, sampler_mean;
 	bool corner_based_sampling = true, sampler_ready = false;
+	int pt_based_sampling = 0;
+	[[noreturn]] void affineAdditiveRefused(const char *fn) const;
 	struct Rng;
 	std::shared_ptr<Rng> rng;
 	double draw(int state_id);   /* one draw of N(mean[state_id], sigma[state_id]) */

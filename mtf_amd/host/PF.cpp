@@ -158,6 +158,7 @@ PF::PF(std::shared_ptr<HipAM> a, std::shared_ptr<HipSSM> s, const PFParams &pp) 
 	d.dynamic_model = (int)pf.dynamic_model; d.update_type = (int)pf.update_type; d.likelihood_func = (int)pf.likelihood_func;
 	d.resampling_type = (int)pf.resampling_type; d.mean_type = (int)pf.mean_type;
 	d.corner_based_sampling = s->getCornerBasedSampling() ? 1 : 0;
+	d.pt_based_sampling = s->getPtBasedSampling();
 	d.reset_to_mean = pf.reset_to_mean ? 1 : 0; d.measurement_sigma = pf.measurement_sigma; d.ar_coeff = 0.5; d.seed = pf.seed;
 	const int S = ssm_state_size;
 	for (int k = 0; k < S; ++k) {
@@ -184,7 +185,10 @@ void PF::update() {
 	am->setFirstIter();
 	HipPair::check(mtfhip_pf_update(h, &iters_done));
 	hssm->markMoved();
-	if (pf.enable_learning) am->updateModel(ssm->getPts());
+	if (pf.enable_learning) {   /* NT/PF.cc:443-446 */
+		am->updateModel(ssm->getPts());
+		HipPair::check(mtfhip_pf_set_max_similarity(h, am->getSimilarity()));
+	}
 }
 const CornersT &PF::getRegion() {
 	HipPair::check(mtfhip_ssm_get_corners(ham->pair()->b, region.data()));

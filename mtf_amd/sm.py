@@ -8,6 +8,8 @@ host_solve=False runs the whole loop on the device (mtfhip_batch_track).
 
 PF mirrors SM/src/PF.cc with the per-particle scoring on the device and, optionally, sharded over GPUs.
 """
+import os
+
 import numpy as np
 
 from . import _lib as L
@@ -381,6 +383,28 @@ class Comm:
         return bytes(buf)
 
     @classmethod
+    def loopback(cls, world, device=0):
+        """`world` ranks as threads of this process on one device (mtfhip_comm_create_loopback): the sharded code path with the
+        exchange done by a rendezvous of the threads -- one Comm per rank, each used from its own thread"""
+        import ctypes as C
+        arr = (C.c_void_p * world)()
+        L.check(L.lib().mtfhip_comm_create_loopback(int(world), int(device), arr))
+        out = []
+        for r in range(world):
+            c = cls.__new__(cls)
+            c._h, c.rank, c.world = C.c_void_p(arr[r]), r, world
+            out.append(c)
+        return out
+
+    @staticmethod
+    def shard_bounds(n, world, rank):
+        """(lo, count, per_rank) of mtfhip_pf_shard_bounds: the block a rank scores, per_rank = ceil(n / world)"""
+        import ctypes as C
+        lo, cnt, m = C.c_int(), C.c_int(), C.c_int()
+        L.check(L.lib().mtfhip_pf_shard_bounds(int(n), int(world), int(rank), C.byref(lo), C.byref(cnt), C.byref(m)))
+        return lo.value, cnt.value, m.value
+
+    @classmethod
     def torch_bootstrap(cls, device):
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -410,7 +434,7 @@ class ParticleFilter:
                  ssm_sigma=(0.01, 0.01, 2.0, 0.01, 0.01, 2.0, 1e-5, 1e-5), ssm_mean=(0.0,) * 8, likelihood_alpha=1.0,
                  max_iters=1, epsilon=0.01, seed=0, am=L.AM_SSD, dynamic_model=0, update_type=1, likelihood_func=0,
                  resampling_type=1, mean_type=0, corner_based_sampling=0, reset_to_mean=0, measurement_sigma=0.1, ar_coeff=0.5,
-                 comm=None):
+                 comm=None, pt_based_sampling=0):
         import ctypes as C
         self.batch = Batch(ctx, am, ssm, resx, resy, 1, likelihood_alpha=likelihood_alpha)
         self.S, self.n = self.batch.S, n_particles
@@ -419,21 +443,41 @@ class ParticleFilter:
         for k in range(8):
             self.desc.ssm_sigma[k] = float(ssm_sigma[k]) if k < len(ssm_sigma) else 0.0
             self.desc.ssm_mean[k] = float(ssm_mean[k]) if k < len(ssm_mean) else 0.0
-        self.desc.seed = int(seed)
+        # the reference seeds its generators from random_device (PF.cc:97-105): seed 0 = "draw one", anything else is reproducible
+        self.desc.seed = int(seed) if seed else int.from_bytes(os.urandom(8), "little") | 1
+        self.desc.pt_based_sampling = int(pt_based_sampling)
         self._h = C.c_void_p()
-        L.check(L.lib().mtfhip_pf_create(self.batch._h, C.byref(self.desc), C.byref(self._h)))
+        rc = L.lib().mtfhip_pf_create(self.batch._h, C.byref(self.desc), C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            self.batch.close()
+            L.check(rc)
         ctx._dependents.add(self)
         self.comm = comm
         if comm is not None:
             L.check(L.lib().mtfhip_pf_set_comm(self._h, comm._h))
-        self.nz = 10 if (ssm == L.SSM_HOMOGRAPHY and corner_based_sampling) else self.S
+        if ssm == L.SSM_HOMOGRAPHY:
+            self.nz = 10 if corner_based_sampling else 8
+        else:
+            self.nz = 8 if pt_based_sampling == 2 else 6
         self.n_iters = 0
 
     def close(self):
-        if self._h:
+        if getattr(self, "_h", None):
             L.lib().mtfhip_pf_destroy(self._h)
             self._h = None
-        self.batch.close()
+        if getattr(self, "batch", None) is not None:
+            self.batch.close()
+
+    def __del__(self):   # a filter dropped without close() must not keep its device buffers until the Context goes
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_max_similarity(self, f):
+        """max_similarity = am->getSimilarity() after am->updateModel (PF.cc:443-446)"""
+        L.check(L.lib().mtfhip_pf_set_max_similarity(self._h, L.C.c_double(float(f))))
 
     # nt::PF::initialize (NT/PF.cc:136-183)
     def initialize(self, corners):

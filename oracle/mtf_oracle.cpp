@@ -1020,6 +1020,62 @@ struct mtfo_ssm {
 		if (kind == MTFO_SSM_HOMOGRAPHY) div3(W, W(2, 2));
 		state_from_warp(out, W);
 	}
+	/* Affine::geomToState SSM/src/Affine.cc:393-410: (tx, ty, s, theta, r, phi) -> state */
+	static void affine_geom_to_state(double *state, const double *geom) {
+		double s = geom[2], r = geom[4];
+		double theta = geom[3], phi = geom[5];
+		double cos_theta = std::cos(theta), sin_theta = std::sin(theta);
+		double cos_phi = std::cos(phi), sin_phi = std::sin(phi);
+		double ccc = cos_theta * cos_phi * cos_phi;
+		double ccs = cos_theta * cos_phi * sin_phi;
+		double css = cos_theta * sin_phi * sin_phi;
+		double scc = sin_theta * cos_phi * cos_phi;
+		double scs = sin_theta * cos_phi * sin_phi;
+		double sss = sin_theta * sin_phi * sin_phi;
+		state[0] = geom[0];
+		state[1] = geom[1];
+		state[2] = s * (ccc + scs + r * (css - scs)) - 1;
+		state[3] = s * (r * (ccs - scc) - ccs - sss);
+		state[4] = s * (scc - ccs + r * (ccs + sss));
+		state[5] = s * (r * (ccc + scs) - scs + css) - 1;
+	}
+	/* Affine::generatePerturbation SSM/src/Affine.cc:464-503 with the draws supplied: draw(j) = mean[j] + sigma[j] z.
+	 * pt_based 1: coordinate j of (bottom right, bottom left, top centre) disturbed by distribution j (z[0..6));
+	 * pt_based 2: every coordinate by distribution 1 (z[0..6)), then one translation from distribution 0 (z[6], z[7]);
+	 * the perturbation is utils::computeAffineDLT of the three pairs (Utilities/src/warpUtils.cc:388-421: V (U^T b / S) of the
+	 * 6 x 6 system = its exact solution for non-collinear points, taken here with the pivoted QR solve);
+	 * pt_based 0: geomToState of six draws (z[0..6)). */
+	void affine_generate_perturbation(double *pert, int pt_based, const double *mean, const double *sigma, const double *z) const {
+		if (pt_based) {
+			double orig[6], pts[6];   /* x, y interleaved per point: init_corners.col(2), col(3), (col(0) + col(1)) / 2 */
+			orig[0] = init_corners[4]; orig[1] = init_corners[5];
+			orig[2] = init_corners[6]; orig[3] = init_corners[7];
+			orig[4] = (init_corners[0] + init_corners[2]) / 2.0; orig[5] = (init_corners[1] + init_corners[3]) / 2.0;
+			if (pt_based == 1) {
+				for (int j = 0; j < 6; ++j) pts[j] = orig[j] + (mean[j] + sigma[j] * z[j]);
+			} else {
+				const double tx = mean[0] + sigma[0] * z[6], ty = mean[0] + sigma[0] * z[7];
+				for (int i = 0; i < 3; ++i) {
+					pts[2 * i] = (orig[2 * i] + (mean[1] + sigma[1] * z[2 * i])) + tx;
+					pts[2 * i + 1] = (orig[2 * i + 1] + (mean[1] + sigma[1] * z[2 * i + 1])) + ty;
+				}
+			}
+			double A[36] = {0}, x[6];   /* column-major 6 x 6 */
+			for (int i = 0; i < 3; ++i) {
+				const int r1 = 2 * i, r2 = 2 * i + 1;
+				A[0 * 6 + r1] = orig[2 * i]; A[1 * 6 + r1] = orig[2 * i + 1]; A[2 * 6 + r1] = 1;
+				A[3 * 6 + r2] = orig[2 * i]; A[4 * 6 + r2] = orig[2 * i + 1]; A[5 * 6 + r2] = 1;
+			}
+			colpiv_qr_solve(6, A, pts, x);
+			Mat3 W = identity3();
+			W(0, 0) = x[0]; W(0, 1) = x[1]; W(0, 2) = x[2]; W(1, 0) = x[3]; W(1, 1) = x[4]; W(1, 2) = x[5];
+			state_from_warp(pert, W);
+		} else {
+			double geom[6];
+			for (int j = 0; j < 6; ++j) geom[j] = mean[j] + sigma[j] * z[j];
+			affine_geom_to_state(pert, geom);
+		}
+	}
 };
 
 /* ===================================================================== */
@@ -2243,7 +2299,15 @@ int mtfo_pf_iteration(mtfo_am *am, mtfo_ssm *ssm, const mtfo_pf_params *pp, doub
 	const int n = pp->n_particles, S = ssm->S;
 	const bool hom = ssm->kind == MTFO_SSM_HOMOGRAPHY;
 	const bool corner_based = hom && pp->corner_based_sampling;
-	const int nz = corner_based ? 10 : S;
+	const int pt_based = hom ? 0 : pp->pt_based_sampling;
+	if (!hom) {
+		/* Affine.cc:505-553: additive + point based and compositional RandomWalk + geometric throw FunctonNotImplemented in the
+		 * reference; additive + geometric goes through Affine::stateToGeom (Affine.cc:411-462), a 2 x 2 JacobiSVD whose sign and
+		 * ordering conventions select its branches -- not restated here (Eigen is absent, the conventions could not be pinned) */
+		if (pp->update_type == 0) return -3;
+		if (pp->dynamic_model == 0 && pt_based == 0) return -3;
+	}
+	const int nz = corner_based ? 10 : (hom ? S : (pt_based == 2 ? 8 : 6));
 	vecd wts(n), cum(n), pert(S), ns(S), nar(S);
 	int max_wt_id = 0;
 	double max_wt = std::numeric_limits<double>::lowest();
@@ -2261,6 +2325,8 @@ int mtfo_pf_iteration(mtfo_am *am, mtfo_ssm *ssm, const mtfo_pf_params *pp, doub
 				dc[2 * c + 1] = ssm->init_corners[2 * c + 1] + (pp->mean[1] + pp->sigma[1] * z[3 + 2 * c]) + ty;
 			}
 			ssm->estimate_warp_from_corners(pert.data(), ssm->init_corners.data(), dc);
+		} else if (!hom) {
+			ssm->affine_generate_perturbation(pert.data(), pt_based, pp->mean, pp->sigma, z);
 		} else {
 			for (int s2 = 0; s2 < S; ++s2) pert[s2] = pp->mean[s2] + pp->sigma[s2] * z[s2];
 		}
@@ -2268,7 +2334,7 @@ int mtfo_pf_iteration(mtfo_am *am, mtfo_ssm *ssm, const mtfo_pf_params *pp, doub
 		if (pp->dynamic_model == 1) {
 			if (pp->update_type == 0) {   /* ProjectiveBase::additiveAutoRegression1 :254-259 */
 				for (int s2 = 0; s2 < S; ++s2) { ns[s2] = st[s2] + ar[s2] + pert[s2]; nar[s2] = pp->ar_coeff * (ns[s2] - st[s2]); }
-			} else {                      /* Homography::compositionalAutoRegression1 Homography.cc:928-942 (ProjectiveBase :260-276 without the normalisations) */
+			} else {                      /* Homography::compositionalAutoRegression1 Homography.cc:928-942; Affine: ProjectiveBase :260-276 (no normalisations) */
 				Mat3 B = ssm->warp_from_state(st), P = ssm->warp_from_state(pert.data()), A = ssm->warp_from_state(ar);
 				Mat3 W = mul3(mul3(B, A), P);
 				if (hom) div3(W, W(2, 2));

@@ -194,7 +194,10 @@ typedef struct mtfo_pf_params {
 	int corner_based_sampling;/* HomographyParams::corner_based_sampling */
 	double measurement_sigma, ar_coeff;
 	double sigma[8], mean[8]; /* the sampler's normal distributions (ProjectiveBase::initializeSampler) */
+	int pt_based_sampling;    /* AffineParams::pt_based_sampling (Affine.cc:464-503): 0 geometric, 1, 2 */
 } mtfo_pf_params;
+/* returns 0; -2 residual resampling (not restated); -3 an Affine sampler combination the reference throws for, or the additive
+ * geometric one (Affine::stateToGeom: Eigen JacobiSVD conventions, not restated) */
 int mtfo_pf_iteration(mtfo_am *am, mtfo_ssm *ssm, const mtfo_pf_params *pp, double *states, double *ars, const double *normals,
 	const double *uniforms, double max_similarity, double *wts_out, int *resample_ids, int *max_wt_id_out);
 

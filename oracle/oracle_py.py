@@ -499,14 +499,16 @@ class PFParams(C.Structure):
     """mtfo_pf_params: the PFParams.h:10-33 enums as integers"""
     _fields_ = [("n_particles", C.c_int), ("dynamic_model", C.c_int), ("update_type", C.c_int), ("likelihood_func", C.c_int),
                 ("resampling_type", C.c_int), ("mean_type", C.c_int), ("corner_based_sampling", C.c_int),
-                ("measurement_sigma", C.c_double), ("ar_coeff", C.c_double), ("sigma", C.c_double * 8), ("mean", C.c_double * 8)]
+                ("measurement_sigma", C.c_double), ("ar_coeff", C.c_double), ("sigma", C.c_double * 8), ("mean", C.c_double * 8),
+                ("pt_based_sampling", C.c_int)]
 
 
 def pf_params(n_particles, dynamic_model=0, update_type=1, likelihood_func=0, resampling_type=1, mean_type=0,
               corner_based_sampling=0, measurement_sigma=0.1, ar_coeff=0.5, sigma=(0.01, 0.01, 2.0, 0.01, 0.01, 2.0, 1e-5, 1e-5),
-              mean=(0,) * 8):
+              mean=(0,) * 8, pt_based_sampling=0):
     pp = PFParams(n_particles, dynamic_model, update_type, likelihood_func, resampling_type, mean_type, corner_based_sampling,
                   measurement_sigma, ar_coeff)
+    pp.pt_based_sampling = int(pt_based_sampling)
     for k in range(8):
         pp.sigma[k] = float(sigma[k]) if k < len(sigma) else 0.0
         pp.mean[k] = float(mean[k]) if k < len(mean) else 0.0

@@ -1,5 +1,6 @@
-"""CPU: the N > 1 candidate-sharding path with world_size-2 gloo process groups (the scoring kernel is
-replaced by an injected function; the partition + the single all-gather are what is under test)."""
+"""CPU: the N > 1 paths with world_size-2 gloo process groups -- the particle filter's partition (the C ABI's own
+mtfhip_pf_shard_bounds) + its single all-gather with the scoring kernel replaced by a stand-in, and the independent-target
+shards.  The device side of the sharded filter runs in tests/test_gpu_trackers.py::test_pf_sharded_loopback_equals_unsharded."""
 import os
 import socket
 import sys
@@ -30,22 +31,29 @@ def _free_port():
 
 
 def _worker(rank, world, port, n_cand, q):
+    """the sharded particle filter's exchange step with the device work replaced by a stand-in: the rank's block from
+    mtfhip_pf_shard_bounds (the C ABI's own partition, host arithmetic), scored into its global position of a ceil(n / world) x
+    world buffer, ONE in-place all-gather -- the flat weight vector must come out in particle order on every rank"""
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        rng = np.random.default_rng(0)           # identical candidates on every rank
+        from mtf_amd.sm import Comm
+        rng = np.random.default_rng(0)           # identical particles on every rank (the device generator is keyed by index)
         states = rng.normal(size=(n_cand, 8))
-        fn = lambda s: np.exp(-np.abs(s).sum(axis=1))   # noqa: E731  stands in for the HIP scorer
-        scorer = mdist.ShardedScorer(score_fn=fn)
-        got = scorer.score(states).numpy()
-        q.put((rank, np.allclose(got, fn(states), rtol=0, atol=0), got.shape[0]))
+        fn = lambda s: np.exp(-np.abs(s).sum(axis=1))   # noqa: E731  stands in for k_pf_score
+        lo, cnt, m = Comm.shard_bounds(n_cand, world, rank)
+        wts = torch.full((m * world,), -1.0, dtype=torch.float64)
+        wts[lo:lo + cnt] = torch.from_numpy(fn(states[lo:lo + cnt]))
+        dist.all_gather_into_tensor(wts, wts[rank * m:(rank + 1) * m].clone())   # (gloo has no in-place form: same layout)
+        got = wts[:n_cand].numpy()
+        q.put((rank, np.array_equal(got, fn(states)), got.shape[0]))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_cand", [64, 101])
+@pytest.mark.parametrize("n_cand", [64, 101, 1])
 def test_sharded_scoring_allgather_world2(n_cand):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
@@ -59,6 +67,19 @@ def test_sharded_scoring_allgather_world2(n_cand):
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(ok and n == n_cand for _, ok, n in res)
+
+
+def test_pf_shard_bounds_partition():
+    """mtfhip_pf_shard_bounds (no device needed): blocks of ceil(n / world), contiguous, covering every particle once, so that
+    rank-major blocks of per_rank weights ARE the flat vector"""
+    from mtf_amd.sm import Comm
+    for n in (0, 1, 5, 7, 8, 9, 10000, 10001):
+        for w in (1, 2, 3, 8):
+            b = [Comm.shard_bounds(n, w, r) for r in range(w)]
+            m = b[0][2]
+            assert m == -(-n // w) and all(x[2] == m for x in b)
+            assert all(x[0] == min(n, r * m) for r, x in enumerate(b))
+            assert sum(x[1] for x in b) == n and all(0 <= x[1] <= m for x in b)
 
 
 def _worker_targets(rank, world, port, n_targets, q):

@@ -159,7 +159,7 @@ def test_config4_pf_10000_candidates(gpu_ctx, big_frames):
     lik_p = b.score_candidates(states[perm])
     assert np.array_equal(lik_p, lik[perm])                                   # a candidate's score does not depend on its slot
     shards = np.concatenate([b.score_candidates(states[k * 1250:(k + 1) * 1250]) for k in range(8)])
-    assert np.array_equal(shards, lik)                                        # the 8-rank partition of dist.py gathers to the same vector
+    assert np.array_equal(shards, lik)                                        # an 8-way partition of the candidates gathers to the same vector
     gpu_ctx.set_image(f1)
     assert b.score_candidates(states[:100]).max() < 1.0
 

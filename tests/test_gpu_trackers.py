@@ -81,21 +81,6 @@ def test_particle_filter_follows_translation(gpu_ctx, frame, am, alpha):
     assert np.abs(out[0] - gt_corners(corners, p_true, centre)).max() < 1.0
 
 
-def test_sharded_scorer_single_rank_uses_hip(gpu_ctx, frame, oracle):
-    import torch
-    from mtf_amd.dist import ShardedScorer
-    rng = np.random.default_rng(31)
-    corners = synth.square_corners(256, 256, 100)
-    gpu_ctx.set_image(frame)
-    b = mtf_amd.Batch(gpu_ctx, L.AM_SSD, L.SSM_HOMOGRAPHY, 50, 50, 1)
-    b.set_corners(corners[None]); b.initialize_pix_vals(); b.initialize_similarity()
-    states = synth.pf_candidate_states(rng, 257)
-    sc = ShardedScorer(batch=b, device=torch.device("cuda", 0))
-    lik = sc.score(states)
-    gpu_ctx.synchronize(); torch.cuda.synchronize()
-    np.testing.assert_allclose(lik.cpu().numpy(), b.score_candidates(states), rtol=1e-14)
-
-
 NT_CASES = [
     (L.SM_ICLK, L.AM_NCC, L.SSM_AFFINE, 25, dict()),                       # config 3 patch tracker
     (L.SM_ICLK, L.AM_NCC, L.SSM_AFFINE, 25, dict(hess_type=2)),
@@ -688,13 +673,14 @@ def test_pf_iteration_matches_oracle(oracle, gpu_ctx, frame, am, corner_based, d
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [37, 5000, 20000, 70000])
+@pytest.mark.parametrize("n", [1, 37, 256, 257, 5000, 20000, 65536, 70000, 1048576, 1100000, 4300000])
 def test_pf_resampling_kernels_at_other_sizes(gpu_ctx, frame, n):
-    """The cumulative-weight scan (register-resident runs up to 16 384 particles, the loop form beyond) and the two-level
-    multinomial search (coarse table in LDS: stride 32 up to 65 536 particles, wider beyond) against NumPy on the device's own
-    weights: the smallest index whose normalised cumulative weight reaches the draw."""
+    """The chunked cumulative-weight scan (256 particles per wave, chunk totals scanned by the last workgroup to arrive) and the
+    two-level multinomial search (chunk table in LDS up to 1 048 576 particles, searched in memory beyond; inside the chunk two
+    rounds of independent probes up to 65 536 particles, bisection beyond) against NumPy on the device's own weights: the
+    smallest index whose normalised cumulative weight reaches the draw."""
     rng = np.random.default_rng(7 + n)
-    res = 12
+    res = 12 if n < 1000000 else 4
     corners = synth.square_corners(250.0, 240.0, 60)
     gpu_ctx.set_image(frame)
     pf = ParticleFilter(gpu_ctx, L.SSM_HOMOGRAPHY, res, res, n_particles=n, ssm_sigma=(0.004, 0.004, 0.8, 0.004, 0.004, 0.8, 2e-6, 2e-6),
@@ -702,17 +688,69 @@ def test_pf_resampling_kernels_at_other_sizes(gpu_ctx, frame, n):
                         mean_type=0, corner_based_sampling=0)
     pf.initialize(corners[None])
     normals, uniforms = rng.normal(size=(n, 8)), rng.uniform(size=n)
-    uniforms[:3] = [0.0, 1.0 - 1e-16, 0.5]
+    uniforms[:3] = [0.0, 1.0 - 1e-16, 0.5][: min(n, 3)]
     pf.iteration(normals, uniforms)
     st, ar, w, ids = pf.particles()
     assert w.shape == (n,) and np.all(w > 0)
-    cum = np.cumsum(w) / np.sum(w)
+    cum = np.cumsum(w.astype(np.longdouble))
+    cum = (cum / cum[-1]).astype(np.float64)
     cum[-1] = max(cum[-1], 1.0)
     want = np.searchsorted(cum, uniforms, side="left")
     bad = np.nonzero(ids != want)[0]
-    # (a parallel scan rounds differently from cumsum: an id may differ only where the draw sits within rounding of a boundary)
-    assert all(abs(cum[min(ids[k], want[k])] - uniforms[k]) < 1e-12 for k in bad), bad[:10]
+    # (a parallel scan rounds differently from a running sum: an id may differ only where the draw sits within rounding of a
+    # boundary -- the running sum of n terms carries up to n eps / 2 itself, so the margin grows with n; the spacing of the
+    # boundaries is ~1 / n)
+    tol = max(1e-12, 8 * n * 1.1e-16)
+    assert all(abs(cum[min(ids[k], want[k])] - uniforms[k]) < tol for k in bad), bad[:10]
+    assert len(bad) <= max(3, n // 100000)
     assert ids.min() >= 0 and ids.max() < n
+    pf.close()
+
+
+def _philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon et al., SC'11) on uint64 arrays holding 32-bit words: the device generator's definition"""
+    M0, M1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    c0, c1, c2, c3 = [np.asarray(c, dtype=np.uint64) & MASK for c in (c0, c1, c2, c3)]
+    k0, k1 = np.uint64(k0) & MASK, np.uint64(k1) & MASK
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        c0, c1, c2, c3 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & MASK, p1 & MASK, ((p0 >> np.uint64(32)) ^ c3 ^ k1) & MASK, p0 & MASK
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & MASK, (k1 + np.uint64(0xBB67AE85)) & MASK
+    return c0, c1, c2, c3
+
+
+def _philox_u2(r):
+    a = (r[0] << np.uint64(21)) | (r[1] >> np.uint64(11)); b = (r[2] << np.uint64(21)) | (r[3] >> np.uint64(11))
+    return (a.astype(np.float64) + 1.0) / 2.0 ** 53, (b.astype(np.float64) + 1.0) / 2.0 ** 53
+
+
+def test_pf_device_generator_matches_its_definition(gpu_ctx, frame):
+    """the device draws against a NumPy evaluation of their definition: Philox4x32-10 keyed by the seed with counter (particle,
+    pair, iteration, tag), 53-bit uniforms in (0, 1], Box-Muller -- the normals through an additive random walk from the zero
+    state with unit sigma (the states ARE the draws), the resampling uniforms through the ids they select"""
+    n, seed = 30000, 0x1234567887654321
+    corners = synth.square_corners(250, 240, 80)
+    gpu_ctx.set_image(frame)
+    pf = ParticleFilter(gpu_ctx, L.SSM_HOMOGRAPHY, 12, 12, n_particles=n, seed=seed, update_type=0, dynamic_model=0, resampling_type=1,
+                        ssm_sigma=(1.0,) * 8, corner_based_sampling=0)
+    pf.initialize(corners[None])
+    k = np.arange(n, dtype=np.uint64)
+    for it in range(2):
+        prev = pf.particles()[0].copy()
+        pf.iteration()
+        st, _, w, ids = pf.particles()
+        z = np.empty((n, 8))
+        for q in range(4):
+            u0, u1 = _philox_u2(_philox4x32_10(k, q, it, 0x4E4F524D, seed & 0xFFFFFFFF, seed >> 32))
+            rad = np.sqrt(-2.0 * np.log(u0))
+            z[:, 2 * q], z[:, 2 * q + 1] = rad * np.cos(2 * np.pi * u1), rad * np.sin(2 * np.pi * u1)
+        u = _philox_u2(_philox4x32_10(k, 0, it, 0x554E4946, seed & 0xFFFFFFFF, seed >> 32))[0]
+        cum = np.cumsum(w.astype(np.longdouble)); cum = (cum / cum[-1]).astype(np.float64); cum[-1] = 1.0
+        want = np.searchsorted(cum, u, side="left")
+        bad = np.nonzero(ids != want)[0]
+        assert all(abs(cum[min(ids[j], want[j])] - u[j]) < 1e-11 for j in bad) and len(bad) <= 3, bad[:10]
+        prop = prev + z                       # additiveRandomWalk: state + N(0, 1) draws
+        np.testing.assert_allclose(st, prop[ids], rtol=0, atol=2e-13)
     pf.close()
 
 
@@ -740,3 +778,198 @@ def test_pf_device_generator_and_comm(gpu_ctx, frame):
     torch.cuda.synchronize()
     assert torch.equal(a, b)
     c.close()
+
+
+def _run_ranks(world, fn):
+    """fn(rank) on `world` host threads (ctypes releases the GIL inside every C-ABI call: the loopback all-gather rendezvous needs
+    the ranks to be inside the library at the same time)"""
+    import threading
+    out, err = [None] * world, []
+
+    def work(r):
+        try:
+            out[r] = fn(r)
+        except BaseException as e:   # noqa: BLE001  (reported by the main thread)
+            err.append((r, e))
+    ths = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in ths), "a loopback rank did not come back"
+    if err:
+        raise err[0][1]
+    return out
+
+
+@pytest.mark.parametrize("world,n", [(2, 10001), (3, 10001), (8, 10001), (8, 10000), (8, 5), (3, 600)])
+@pytest.mark.parametrize("cfg", [
+    dict(corner_based_sampling=1, dynamic_model=0, update_type=1, mean_type=0, resampling_type=1),     # config 4
+    dict(corner_based_sampling=1, dynamic_model=1, update_type=1, mean_type=1, resampling_type=2),     # shipped cfg: AR1, mean of states
+    dict(corner_based_sampling=0, dynamic_model=0, update_type=0, mean_type=2, resampling_type=0, likelihood_func=2),
+])
+def test_pf_sharded_loopback_equals_unsharded(frame, world, n, cfg):
+    """The sharded filter as bench.py --workload pf --gpus N runs it -- mtfhip_pf_set_comm, block bounds with a ragged (or
+    empty) last block, ONE in-place all-gather of ceil(n / world) weights per rank, replicated proposals and resampling --
+    executed with world ranks as threads of this process over a loopback communicator (the exchange is a rendezvous + device
+    copies; everything else is the RCCL path), three iterations with the device generator, against the unsharded filter:
+    every rank must hold bit-identical weights, resample ids, particle sets and estimates."""
+    from mtf_amd.sm import Comm
+    corners = synth.square_corners(250.0, 240.0, 80) + np.array([[0.3, -0.2, 0.1, 0.4], [0.2, 0.1, -0.3, 0.2]])
+    sigma = (1.0, 0.6, 1, 1, 1, 1, 1, 1) if cfg["corner_based_sampling"] else (0.004, 0.004, 0.8, 0.004, 0.004, 0.8, 2e-6, 2e-6)
+    frame_b = synth.warp_frame(frame, np.array([0, 0, 1.2, 0, 0, -0.8, 0, 0]), (250.0, 240.0))
+    kw = dict(n_particles=n, ssm_sigma=sigma, likelihood_alpha=5.0, seed=77, **cfg)
+
+    def run(comm):
+        ctx = mtf_amd.Context(0)
+        ctx.set_image(frame)
+        pf = ParticleFilter(ctx, L.SSM_HOMOGRAPHY, 24, 24, comm=comm, **kw)
+        pf.initialize(corners[None])
+        ctx.set_image(frame_b)
+        rec = []
+        for _ in range(3):
+            pf.iteration()
+            st, ar, w, ids = pf.particles()
+            rec.append((st.copy(), ar.copy(), w.copy(), ids.copy(), pf.get_region().copy(), pf.batch.get_state().copy()))
+        pf.close(); ctx.close()
+        return rec
+    ref = run(None)
+    comms = Comm.loopback(world)
+    got = _run_ranks(world, lambda r: run(comms[r]))
+    for c in comms:
+        c.close()
+    for r in range(world):
+        for it in range(3):
+            for a, b, what in zip(got[r][it], ref[it], ("states", "ars", "weights", "ids", "corners", "state")):
+                if what == "ids" and cfg["resampling_type"] == 0:
+                    continue
+                assert np.array_equal(a, b), "rank %d iteration %d: %s differ from the unsharded filter" % (r, it, what)
+
+
+def test_pf_shard_bounds_and_inplace_allgather(gpu_ctx):
+    """mtfhip_pf_shard_bounds is the partition the sharded filter uses, and the loopback all-gather in its in-place form leaves
+    the flat vector on every rank (ragged world: the last block is short, the tail of the buffer is padding)"""
+    import torch
+    from mtf_amd.sm import Comm
+    n, world = 1003, 4
+    b = [Comm.shard_bounds(n, world, r) for r in range(world)]
+    m = b[0][2]
+    assert m == 251 and [x[0] for x in b] == [0, 251, 502, 753] and [x[1] for x in b] == [251, 251, 251, 250]
+    assert Comm.shard_bounds(5, 8, 7) == (5, 0, 1) and Comm.shard_bounds(5, 8, 2) == (2, 1, 1)
+    comms = Comm.loopback(world)
+    full = torch.arange(m * world, dtype=torch.float64, device="cuda") + 0.5
+
+    def rank(r):
+        buf = torch.full((m * world,), -1.0, dtype=torch.float64, device="cuda")
+        lo, cnt, _ = b[r]
+        buf[lo:lo + cnt] = full[lo:lo + cnt]
+        torch.cuda.synchronize()
+        st = torch.cuda.Stream()
+        comms[r].allgather(buf.data_ptr() + 8 * r * m, m, buf.data_ptr(), st.cuda_stream)
+        st.synchronize()
+        return buf[:n].cpu().numpy()
+    got = _run_ranks(world, rank)
+    for c in comms:
+        c.close()
+    for r in range(world):
+        assert np.array_equal(got[r], full[:n].cpu().numpy())
+
+
+@pytest.mark.parametrize("cfg", [dict(dynamic_model=0, mean_type=0), dict(dynamic_model=1, mean_type=1), dict(dynamic_model=1, mean_type=2),
+                                 dict(dynamic_model=0, mean_type=0, resampling_type=0, update_type=0, corner_based_sampling=0)])
+def test_pf_lookahead_proposals_equal_separate_proposals(gpu_ctx, frame, cfg, monkeypatch):
+    """With the device generator the selection pass of iteration t also makes the proposals of iteration t + 1
+    (MTFHIP_PF_LOOKAHEAD=0: a k_pf_propose launch per iteration; MeanType::Corners always takes that form): the same particle
+    sets, weights and estimates bit for bit -- also across a set_region / set_sampler / set_particles in between, which
+    invalidate proposals made ahead"""
+    corners = synth.square_corners(250.0, 240.0, 80)
+    kw = dict(n_particles=2500, ssm_sigma=(1.0, 0.6, 1, 1, 1, 1, 1, 1), corner_based_sampling=1, likelihood_alpha=5.0, seed=9)
+    kw.update(cfg)
+    if not kw["corner_based_sampling"]:
+        kw["ssm_sigma"] = (0.004, 0.004, 0.8, 0.004, 0.004, 0.8, 2e-6, 2e-6)
+    gpu_ctx.set_image(frame)
+    rec = {}
+    for la in ("1", "0"):
+        monkeypatch.setenv("MTFHIP_PF_LOOKAHEAD", la)
+        pf = ParticleFilter(gpu_ctx, L.SSM_HOMOGRAPHY, 20, 20, **kw); pf.initialize(corners[None])
+        out = []
+        for it in range(6):
+            if it == 2:
+                pf.set_region(corners + 0.75)
+            if it == 3:
+                L.check(L.lib().mtfhip_pf_set_sampler(pf._h, (L.C.c_double * 8)(*[1.5 * v for v in kw["ssm_sigma"]]), (L.C.c_double * 8)()))
+            if it == 4:
+                st, ar, _, _ = pf.particles(); pf.set_particles(st[::-1].copy(), ar[::-1].copy())
+            pf.iteration()
+            out.append([x.copy() for x in pf.particles()] + [pf.get_region().copy(), pf.batch.get_state().copy()])
+        rec[la] = out
+        pf.close()
+    for it in range(6):
+        for a, b in zip(rec["1"][it], rec["0"][it]):
+            assert np.array_equal(a, b), it
+
+
+def test_pf_update_chained_iterations_equal_single_steps(gpu_ctx, frame):
+    """mtfhip_pf_update with a negative epsilon enqueues its iterations back to back and reads only the last estimate back:
+    same particle set and estimate as the same number of mtfhip_pf_iteration calls"""
+    corners = synth.square_corners(250.0, 240.0, 80)
+    kw = dict(n_particles=3000, ssm_sigma=(1.0, 0.6, 1, 1, 1, 1, 1, 1), corner_based_sampling=1, likelihood_alpha=5.0, seed=5,
+              dynamic_model=1, mean_type=1, epsilon=-1.0, max_iters=4)
+    gpu_ctx.set_image(frame)
+    a = ParticleFilter(gpu_ctx, L.SSM_HOMOGRAPHY, 20, 20, **kw); a.initialize(corners[None])
+    b = ParticleFilter(gpu_ctx, L.SSM_HOMOGRAPHY, 20, 20, **kw); b.initialize(corners[None])
+    ca = a.update()
+    assert a.n_iters == 4
+    for _ in range(4):
+        b.iteration()
+    for x, y in zip(a.particles(), b.particles()):
+        assert np.array_equal(x, y)
+    assert np.array_equal(ca, b.get_region()) and np.array_equal(a.batch.get_state(), b.batch.get_state())
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("pt_based,dynamic_model", [(1, 0), (2, 0), (1, 1), (2, 1), (0, 1)])
+def test_pf_affine_sampler_matches_oracle(oracle, gpu_ctx, frame, pt_based, dynamic_model):
+    """Affine particle filter: Affine::generatePerturbation (point based 1 / 2: three canonical points disturbed + the affine
+    map of the three pairs; geometric: geomToState of six draws, Affine.cc:464-503) under the compositional models, against
+    the oracle's restatement fed the same draws"""
+    rng = np.random.default_rng(55 + pt_based)
+    n, res = 500, 24
+    corners = synth.square_corners(250.0, 240.0, 70) + rng.uniform(-1.5, 1.5, size=(2, 4))
+    if pt_based:
+        sigma, mean = (0.8, 0.5, 0.7, 0.6, 0.9, 0.4, 0, 0), (0.0,) * 8
+    else:   # geometric: (tx, ty, scale, theta, aspect, phi); scale and aspect are drawn around 1
+        sigma, mean = (0.8, 0.6, 0.01, 0.01, 0.01, 0.05, 0, 0), (0, 0, 1.0, 0, 1.0, 0, 0, 0)
+    nz = 8 if pt_based == 2 else 6
+    o_ssm = oracle.SSM(1, res, res); o_am = oracle.AM(L.AM_SSD, res, res, likelihood_alpha=5.0); o_am.set_curr_img(frame)
+    o_ssm.set_corners(corners); o_am.initialize_pix_vals(o_ssm.get("curr_pts")); o_am.initialize_similarity()
+    pp = oracle.pf_params(n, dynamic_model=dynamic_model, update_type=1, mean_type=1, sigma=sigma, mean=mean, pt_based_sampling=pt_based)
+    gpu_ctx.set_image(frame)
+    pf = ParticleFilter(gpu_ctx, L.SSM_AFFINE, res, res, n_particles=n, ssm_sigma=sigma, ssm_mean=mean, likelihood_alpha=5.0,
+                        dynamic_model=dynamic_model, update_type=1, mean_type=1, pt_based_sampling=pt_based)
+    pf.initialize(corners[None])
+    st_o, ar_o = np.zeros((n, 6)), np.zeros((n, 6))
+    for it in range(2):
+        normals, uniforms = rng.normal(size=(n, nz)), rng.uniform(size=n)
+        st_o, ar_o, w_o, ids_o, _ = oracle.pf_iteration(o_am, o_ssm, pp, st_o, ar_o, normals, uniforms, pf.max_similarity)
+        pf.iteration(normals, uniforms)
+        st_d, ar_d, w_d, ids_d = pf.particles()
+        np.testing.assert_allclose(w_d, w_o, rtol=1e-9, atol=1e-300)
+        same = ids_d == ids_o
+        cum = np.cumsum(w_o) / np.sum(w_o)
+        assert all(abs(cum[min(ids_d[k], ids_o[k])] - uniforms[k]) < 1e-12 for k in np.nonzero(~same)[0])
+        np.testing.assert_allclose(st_d[same], st_o[same], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(ar_d[same], ar_o[same], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(pf.batch.get_state()[0][:6], o_ssm.get("state"), rtol=1e-7, atol=1e-9)
+    pf.close()
+
+
+@pytest.mark.parametrize("kw,msg", [
+    (dict(update_type=0, pt_based_sampling=1), "point based sampling is not implemented yet"),      # Affine.cc:509-511: the reference throws
+    (dict(update_type=0, pt_based_sampling=0), "stateToGeom"),                                        # additive geometric: Eigen JacobiSVD conventions
+    (dict(update_type=1, dynamic_model=0, pt_based_sampling=0), "geometric sampling is not implemented yet"),   # Affine.cc:550-552
+])
+def test_pf_affine_sampler_refusals(gpu_ctx, frame, kw, msg):
+    gpu_ctx.set_image(frame)
+    with pytest.raises(L.FunctionNotImplemented, match=msg):
+        ParticleFilter(gpu_ctx, L.SSM_AFFINE, 20, 20, n_particles=100, **kw)
