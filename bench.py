@@ -140,22 +140,107 @@ def parity_gate(ctx, am_name, res, frame0, frame1, corners):
     ctx.set_image(frame1)
     rel = lambda a, r: float(np.linalg.norm(np.asarray(a) - np.asarray(r)) / max(np.linalg.norm(r), 1e-300))
     worst = {"H": 0.0, "g": 0.0, "dp": 0.0}
+    # the tolerance-mode arithmetic (what the `lean` sub-record and every device-side loop run: FMA, one reciprocal per point,
+    # closed-form gradient of the interpolant) at the same states: against the same restatement with grad_eps = 1e-6 / 1e-7 (a
+    # hundred / ten times less finite-difference quantisation noise than the reference's 1e-8, no truncation error: the interpolant
+    # is linear along each axis; the better of the two per quantity, a 1e-6 step now and then straddles a texel edge) -- and its
+    # distance to the 1e-8 oracle, which is that oracle's own noise floor
+    sm_f = mtf_amd.sm_desc(mtf_amd.SM_ESM, materialize=0, leven_marq=0, max_iters=12, epsilon=1e-6)
+    low = []
+    for eps in (1e-6, 1e-7):
+        s_l = O.SSM(O.SSM_HOM, res, res); a_l = O.AM(am_o, res, res, grad_eps=eps); a_l.set_curr_img(frame0)
+        t_l = O.Tracker(O.SM_ESM, a_l, s_l, leven_marq=0, max_iters=1)
+        t_l.initialize(corners); a_l.set_curr_img(frame1)
+        low.append((t_l, s_l, a_l))
+    fast_low = {"H": 0.0, "g": 0.0, "dp": 0.0}; fast_ref = {"H": 0.0, "g": 0.0, "dp": 0.0}
     checked = []
     for it, rec in enumerate(trace):
-        f, g, H = b.iterate(sm)
         if it < 5 or it == len(trace) - 1:
-            dp = -O.colpiv_qr_solve(H[0], g[0])
             g_scale = np.sqrt(abs(np.trace(rec["H"]))) * (1.0 if am_name == "ncc" else np.sqrt(abs(2 * rec["f"])))
-            worst["H"] = max(worst["H"], rel(H[0], rec["H"]))
-            worst["g"] = max(worst["g"], float(np.linalg.norm(g[0] - rec["g"]) / max(np.linalg.norm(rec["g"]), g_scale)))
-            worst["dp"] = max(worst["dp"], min(rel(dp, rec["dp"]), float(np.abs(dp - rec["dp"]).max() / 1e-7)))
+            errs = lambda H, g, dp, r: {"H": rel(H, r["H"]), "g": float(np.linalg.norm(g - r["g"]) / max(np.linalg.norm(r["g"]), g_scale)),
+                                        "dp": min(rel(dp, r["dp"]), float(np.abs(dp - r["dp"]).max() / 1e-7))}
+            b.set_math_mode(mtf_amd.MATH_FAST)
+            _, gf, Hf = b.iterate(sm_f)
+            b.set_math_mode(mtf_amd.MATH_REPLAY)
+            dpf = -O.colpiv_qr_solve(Hf[0], gf[0])
+            st = b.get_state()[0]
+            el = None
+            for t_l, s_l, _ in low:
+                s_l.set_state(st); t_l.update()
+                e = errs(Hf[0], gf[0], dpf, t_l.trace()[0])
+                el = e if el is None else {q: min(el[q], e[q]) for q in e}
+            e8 = errs(Hf[0], gf[0], dpf, rec)
+            for q in fast_low:
+                fast_low[q] = max(fast_low[q], el[q]); fast_ref[q] = max(fast_ref[q], e8[q])
+            f, g, H = b.iterate(sm)
+            dp = -O.colpiv_qr_solve(H[0], g[0])
+            e = errs(H[0], g[0], dp, rec)
+            for q in worst:
+                worst[q] = max(worst[q], e[q])
             checked.append(it)
         b.compositional_update(rec["dp"][None])
     b.close()
-    worst.update({"iterations_checked": checked, "budget": 1e-5, "pass": bool(max(worst["H"], worst["g"], worst["dp"]) <= 1e-5),
-                  "note": "vs the CPU oracle's nt::ESM trace on the device's own sample grid; g relative to its Cauchy-Schwarz scale, "
-                          "dp relative or below 1e-12 absolute"})
+    fast_ok = bool(max(fast_low.values()) <= 1e-5)
+    worst.update({"iterations_checked": checked, "budget": 1e-05, "pass": bool(max(worst["H"], worst["g"], worst["dp"]) <= 1e-5) and fast_ok,
+                  "note": "replay arithmetic (materialising launch) vs the CPU oracle's nt::ESM trace on the device's own sample grid; g relative to "
+                          "its Cauchy-Schwarz scale, dp relative or below 1e-12 absolute",
+                  "fast": {"vs_low_noise_oracle": fast_low, "vs_reference_parameters_grad_eps_1e-8": fast_ref, "pass": fast_ok,
+                           "note": "the lean tolerance-mode launch at the same states; low-noise oracle = the same restatement with grad_eps 1e-6 / 1e-7 "
+                                   "(better of the two per quantity); the distance to the 1e-8 oracle is that oracle's finite-difference noise "
+                                   "(ulp(500) / 1e-8 = 5.7e-6 per gradient)"}})
     return worst
+
+
+def loop_parity(ctx, sm_kind, am, ssm, res, frame0, frame1, corners, max_iters, hess_type=None):
+    """One target of a secondary workload through the device-side loop in tolerance mode with the per-pass trace on
+    (mtfhip_batch_track_trace), against the CPU trackers with grad_eps 1e-8 (the reference's) and 1e-6 (low finite-difference
+    noise): H, g, dp of the first pass (identical state) and every later update relative to the first one, final corners."""
+    import mtf_amd
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    kw = dict(leven_marq=0, max_iters=max_iters, epsilon=-1.0)
+    if hess_type is not None:
+        kw["hess_type"] = hess_type
+    rel = lambda a, r: float(np.linalg.norm(np.asarray(a) - np.asarray(r)) / max(np.linalg.norm(r), 1e-300))
+    ctx.set_image(frame0)
+    b = mtf_amd.Batch(ctx, am, ssm, res, res, 1)
+    b.set_math_mode(mtf_amd.MATH_FAST)
+    b.set_corners(corners[None])
+    sm = mtf_amd.sm_desc(sm_kind, materialize=0, **kw)
+    b.init_template(sm)
+    ctx.set_image(frame1)
+    b.track_trace(max_iters)
+    n_it, final = b.track(sm)
+    recs = b.read_track_trace(n_it)[0]
+    out = {}
+    otr = {}
+    for eps, name in ((1e-8, "vs_reference_parameters_grad_eps_1e-8"), (1e-6, "vs_low_noise_oracle_grad_eps_1e-6")):
+        o_ssm = O.SSM(ssm, res, res); o_am = O.AM(am, res, res, grad_eps=eps); o_am.set_curr_img(frame0)
+        trk = O.Tracker(sm_kind, o_am, o_ssm, **kw)
+        trk.initialize(corners); o_am.set_curr_img(frame1); trk.update()
+        tr = trk.trace()
+        otr[eps] = tr
+        r0, d0 = tr[0], recs[0]
+        gs = np.sqrt(abs(np.trace(r0["H"]))) * (np.sqrt(abs(2 * r0["f"])) if am == mtf_amd.AM_SSD else 1.0)
+        e = {"g": float(np.linalg.norm(d0["g"] - r0["g"]) / max(np.linalg.norm(r0["g"]), gs)), "dp": rel(d0["dp"], r0["dp"])}
+        if d0["has_H"]:
+            e["H"] = rel(d0["H"], r0["H"])
+        scale = np.linalg.norm(r0["dp"])
+        e["later_updates_over_first"] = max(float(np.linalg.norm(recs[k]["dp"] - tr[k]["dp"]) / scale) for k in range(min(len(tr), len(recs))))
+        e["final_corners_px"] = float(np.abs(final[0] - trk.get_region()).max())
+        out[name] = e
+    b.track_trace(0)
+    b.close()
+    # how far the two oracles' own trajectories are from each other: the reference's sensitivity to its finite-difference step
+    a, c = otr[1e-8], otr[1e-6]
+    spread = max(float(np.linalg.norm(a[k]["dp"] - c[k]["dp"]) / np.linalg.norm(a[0]["dp"])) for k in range(min(len(a), len(c))))
+    low = out["vs_low_noise_oracle_grad_eps_1e-6"]
+    first_ok = max(low[q] for q in ("H", "g", "dp") if q in low) <= 1e-5
+    out.update({"iterations": int(n_it[0]), "budget": 1e-5, "oracle_1e-8_vs_1e-6_later_updates_over_first": spread,
+                "pass": bool(first_ok and low["later_updates_over_first"] <= max(1e-5, 4 * spread)),
+                "note": "device-side loop of one target, tolerance-mode arithmetic, per-pass trace vs the CPU trackers: H, g, dp of the first pass "
+                        "(identical state) within the budget; later updates within the budget or four times the two oracles' own disagreement"})
+    return out
 
 
 def pf_parity(ctx, frame0, corners, n=32):
@@ -287,6 +372,7 @@ def secondary_workload(args):
                 ssm.set_corners(patches[n % 256]); n += trk.update()
             out["cpu_baseline"] = {"value": n / (time.perf_counter() - t0), "unit": "patch-iters/s", "cores": 1, "kind": "port",
                                    "sample": "%d ICLK+NCC+Affine 25x25 patch iterations" % n}
+            out["parity"] = loop_parity(ctx, mtf_amd.SM_ICLK, mtf_amd.AM_NCC, mtf_amd.SSM_AFFINE, 25, frame0, frame1, patches[100], args.grid_iters, hess_type=0)
     elif args.workload == "pf":
         # config 4: the whole iteration of nt::PF::update's loop on the device -- sample generation (corner based homography
         # sampling, the reference's default), scoring, cumulative weights, multinomial resampling, estimate -- with the scoring
@@ -445,6 +531,10 @@ def secondary_workload(args):
                 ssm.set_corners(corners[0]); n += trk.update()
             out["cpu_baseline"] = {"value": n / (time.perf_counter() - t0), "unit": "target-iters/s", "cores": 1, "kind": "port",
                                    "sample": "%d ESM+MI iterations of one %dx%d target" % (n, res, res)}
+            if args.mi_path == "device":
+                out["parity"] = loop_parity(ctx, mtf_amd.SM_ESM, mtf_amd.AM_MI, mtf_amd.SSM_HOMOGRAPHY, res, frame0, frame1, corners[0], 4)
+                out["parity"]["budget_note"] = ("MI's update is ill-conditioned: the two oracles themselves differ by 1e-5 .. 1e-4 in dp "
+                                                "(tests/test_oracle_relations.py::test_mi_update_noise_floor); H and g are the 1e-5 quantities")
     if rank == 0:
         print(json.dumps(out), flush=True)
     ctx.close()    # handles released while the HIP runtime is whole (the library's atexit hook would do the same)

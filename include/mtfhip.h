@@ -279,6 +279,13 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters /
  * mtfhip_batch_set_region + mtfhip_batch_track; one staged upload per frame where the search method keeps its template Jacobian. */
 int mtfhip_batch_track_region(mtfhip_batch *b, const mtfhip_sm_desc *sm, const double *region_corners /* B x 8 */,
 	int *n_iters /* B */, double *corners /* B x 8 */);
+/* Debug trace of the loop above: with max_passes > 0 every pass also records what it solved, per target
+ * [max_passes][96]: H (64, row-major 8 x 8, before Levenberg-Marquardt damping) | g (8) | the state update applied (8) | the
+ * corners it produced (8) | f | pass | LM undo | LM damping | 1 when H was recorded (the one-launch grid loop uses the
+ * constant template Hessian and records 0).  This is how the parity tests compare the device-side loop with the CPU trackers
+ * iteration by iteration; 0 switches it off (the default).  _read copies B x max_passes x 96 doubles. */
+int mtfhip_batch_track_trace(mtfhip_batch *b, int max_passes);
+int mtfhip_batch_track_trace_read(mtfhip_batch *b, double *dst);
 /* how many targets one launch of the loop above covers (all of them, or an Infinity-Cache sized chunk) */
 int mtfhip_batch_track_targets_per_launch(mtfhip_batch *b, const mtfhip_sm_desc *sm);
 

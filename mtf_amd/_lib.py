@@ -96,6 +96,7 @@ SYMBOLS = [
     "mtfhip_pf_create", "mtfhip_pf_destroy", "mtfhip_pf_initialize", "mtfhip_pf_set_region", "mtfhip_pf_set_sampler",
     "mtfhip_pf_iteration", "mtfhip_pf_update", "mtfhip_pf_get_particles", "mtfhip_pf_set_particles", "mtfhip_pf_max_similarity",
     "mtfhip_pf_set_max_similarity", "mtfhip_comm_create_loopback", "mtfhip_pf_shard_bounds",
+    "mtfhip_batch_track_trace", "mtfhip_batch_track_trace_read",
     "mtfhip_comm_unique_id", "mtfhip_comm_create", "mtfhip_comm_destroy", "mtfhip_comm_rank", "mtfhip_comm_world",
     "mtfhip_allgather_scores", "mtfhip_pf_set_comm",
     "mtfhip_timing_enable", "mtfhip_timing_reset", "mtfhip_timing_get",

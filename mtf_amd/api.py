@@ -463,6 +463,28 @@ class Batch:
         L.check(L.lib().mtfhip_batch_track(self._h, C.byref(sm), _p(n), _p(c)))
         return n, self._corners_out(c)
 
+    def track_trace(self, max_passes):
+        """debug trace of the device-side loop on (max_passes > 0) / off (0): mtfhip_batch_track_trace"""
+        L.check(L.lib().mtfhip_batch_track_trace(self._h, int(max_passes)))
+        self._trace_cap = int(max_passes)
+
+    def read_track_trace(self, n_iters):
+        """per target the list of per-pass records of the last track() call -- dicts with H (S x S), g, dp (the state update
+        applied), corners (2 x 4) after it, f, undo, lm_delta, has_H -- the shape of the CPU trackers' trace()"""
+        cap, S = self._trace_cap, self.S
+        raw = np.empty((self.B, cap, 96))
+        L.check(L.lib().mtfhip_batch_track_trace_read(self._h, _p(raw)))
+        out = []
+        for t in range(self.B):
+            recs = []
+            for k in range(min(int(n_iters[t]), cap)):
+                r = raw[t, k]
+                recs.append(dict(H=r[:64].reshape(8, 8)[:S, :S].copy(), g=r[64:64 + S].copy(), dp=r[72:72 + S].copy(),
+                                 corners=r[80:88].reshape(4, 2).T.copy(), f=float(r[88]), undo=bool(r[90]), lm_delta=float(r[91]),
+                                 has_H=bool(r[92])))
+            out.append(recs)
+        return out
+
     def track_region(self, corners, sm):
         """setRegion(corners) + update() of one frame in one C-ABI call (mtfhip_batch_track_region)"""
         tr = getattr(self, "_tr", None)

@@ -815,7 +815,10 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 		for (int v : h_active) if (v) return false;
 		return true;
 	};
-	TrackState ts{b->d_acc, b->d_h0, b->d_corners, b->d_init_corners_hm, b->d_active, b->d_iters, ncc ? b->d_ncc : nullptr, ncc ? b->d_ncc_tm : nullptr, 0, nullptr, nullptr};
+	TrackState ts{b->d_acc, b->d_h0, b->d_corners, b->d_init_corners_hm, b->d_active, b->d_iters, ncc ? b->d_ncc : nullptr, ncc ? b->d_ncc_tm : nullptr, 0, nullptr, nullptr,
+		b->d_trace, b->trace_cap};
+	if (b->d_trace && !resume) HIP_TRY(hipMemsetAsync(b->d_trace, 0, sizeof(double) * kTraceStride * (size_t)b->trace_cap * b->B, st));
+	if (mi && b->d_trace) ts.f_ext = b->d_mi_f;   /* (the trace records the similarity; Levenberg-Marquardt sets it below as well) */
 	if (sm->leven_marq && resume) { ts.lm = b->d_lm; if (mi) ts.f_ext = b->d_mi_f; }
 	else if (sm->leven_marq) {
 		/* per-target LM state: prev_similarity 0, leven_marq_delta = lm_delta_init, no pending reset, iteration 0 */
@@ -891,7 +894,8 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 			fc.active = fa.active + t0;
 			TrackState tc{ts.acc + (size_t)t0 * RL, ts.h0 + (size_t)t0 * 64, ts.corners + 8 * (size_t)t0,
 				ts.init_corners_hm + 12 * (size_t)t0, ts.active + t0, ts.n_iters + t0, ncc ? ts.ncc + 8 * (size_t)t0 : nullptr,
-				ncc ? ts.ncc_tm + 52 * (size_t)t0 : nullptr, 0, ts.lm ? ts.lm + (size_t)kLmStride * t0 : nullptr, nullptr};
+				ncc ? ts.ncc_tm + 52 * (size_t)t0 : nullptr, 0, ts.lm ? ts.lm + (size_t)kLmStride * t0 : nullptr, nullptr,
+				ts.trace ? ts.trace + (size_t)t0 * ts.trace_cap * kTraceStride : nullptr, ts.trace_cap};
 			int nblk_c; { int rows; fused_decomposition(b->N, nt, nblk_c, rows); fc.rows_per_block = rows; }
 			double *part = b->d_partials + (size_t)t0 * b->nblk_max * RL;
 			for (int it = 0; it < max_passes; ++it) {
@@ -951,6 +955,28 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 	}
 	b->pts_stale = true;   /* CURR_PTS follow the final warp when an un-fused kernel next needs them */
 	b->stage_a_busy = false;   /* the stream has drained: whatever set_corners staged has been consumed */
+	return MTFHIP_OK;
+}
+
+/* debug trace of the device-side loop: with max_passes > 0 every pass of mtfhip_batch_track / _track_region also records what it
+ * solved (H, g, the state update, the corners it produced, f) -- the per-iteration quantities the parity tests compare with the
+ * CPU trackers' traces; 0 switches it off (the default: a NULL test per pass) */
+int mtfhip_batch_track_trace(mtfhip_batch *b, int max_passes) {
+	if (!b || max_passes < 0) return fail(MTFHIP_ERR_INVALID_ARG, "track_trace: invalid argument");
+	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	if (b->d_trace) { (void)hipFree(b->d_trace); b->d_trace = nullptr; }
+	b->trace_cap = max_passes;
+	if (max_passes > 0) {
+		HIP_TRY(hipMalloc(&b->d_trace, sizeof(double) * kTraceStride * (size_t)max_passes * b->B));
+		HIP_TRY(hipMemsetAsync(b->d_trace, 0, sizeof(double) * kTraceStride * (size_t)max_passes * b->B, b->ctx->stream));
+	}
+	return MTFHIP_OK;
+}
+int mtfhip_batch_track_trace_read(mtfhip_batch *b, double *dst) {
+	if (!b || !dst) return fail(MTFHIP_ERR_INVALID_ARG, "track_trace_read: NULL argument");
+	if (!b->d_trace) return fail(MTFHIP_ERR_LOGIC, "track_trace_read: tracing is off (mtfhip_batch_track_trace)");
+	HIP_TRY(hipMemcpyAsync(dst, b->d_trace, sizeof(double) * kTraceStride * (size_t)b->trace_cap * b->B, hipMemcpyDeviceToHost, b->ctx->stream));
+	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
 	return MTFHIP_OK;
 }
 

@@ -497,6 +497,12 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 				Cr[2 * q] = nx; Cr[2 * q + 1] = ny;
 			}
 			const double change = (ch[0] + ch[1]) + (ch[2] + ch[3]);
+			if (ts.trace && n_it < ts.trace_cap && tid == 0) {   /* debug trace (mtfhip_batch_track_trace); the Hessian is the constant H0 */
+				double *trec = ts.trace + ((size_t)t * ts.trace_cap + n_it) * kTraceStride;
+#pragma unroll
+				for (int q = 0; q < 8; ++q) { trec[64 + q] = g[q]; trec[72 + q] = dp[q]; trec[80 + q] = Cr[q]; }
+				trec[88] = f_last; trec[89] = (double)n_it; trec[90] = 0.0; trec[91] = 0.0; trec[92] = 0.0;
+			}
 #pragma unroll
 			for (int q = 0; q < 9; ++q) W[q] = Wn[q];
 			++n_it;
@@ -636,6 +642,11 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 				const double ddx = sCr[2 * q] - nx, ddy = sCr[2 * q + 1] - ny;
 				change += ddx * ddx + ddy * ddy;
 				sCr[2 * q] = nx; sCr[2 * q + 1] = ny;
+			}
+			if (ts.trace && n_it < ts.trace_cap) {
+				double *trec = ts.trace + ((size_t)t * ts.trace_cap + n_it) * kTraceStride;
+				for (int q = 0; q < 8; ++q) { trec[64 + q] = g[q]; trec[72 + q] = dp[q]; trec[80 + q] = sCr[q]; }
+				trec[88] = f_last; trec[89] = (double)n_it; trec[90] = 0.0; trec[91] = 0.0; trec[92] = 0.0;
 			}
 			if (change < sm.epsilon) sDone = 1;
 		}

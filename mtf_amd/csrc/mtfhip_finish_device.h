@@ -55,14 +55,13 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 	 * the lanes, and only then is the flag tested: one memory round trip instead of two (flag, then operands); the
 	 * rest of the routine runs out of LDS / registers */
 	const int act = LDI(ts.active + t);
-	int n_it_prev = 0;
+	const int n_it_prev = LDI(ts.n_iters + t);   /* passes done so far (uniform: a scalar load) */
 	double v_h0 = 0, v_w = 0, v_cr = 0, v_ic = 0, v_acc = 0, v_tm = 0, v_nc = 0;
 	if (wv0) {
 		v_h0 = ts.h0[(size_t)t * 64 + lane];
 		if (lane < 9) v_w = LD(bv.warps + 9 * t + lane);
 		if (lane < 8) v_cr = LD(ts.corners + 8 * t + lane);
 		if (lane < 12) v_ic = ts.init_corners_hm[12 * t + lane];
-		n_it_prev = LDI(ts.n_iters + t);
 		if (ncc) {
 			if (lane < 52) v_tm = ts.ncc_tm[(size_t)t * 52 + lane];
 			if (lane < 2) v_nc = ts.ncc[(size_t)t * 8 + lane];
@@ -116,7 +115,7 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 	/* ---- Levenberg-Marquardt: the accept / undo test on the similarity of this pass (uniform over the workgroup) ---- */
 	double *lmp = ts.lm ? ts.lm + (size_t)t * kLmStride : nullptr;
 	double lm_delta = 0.0;
-	int lm_iter_id = n_it_prev;   /* (only lane 0's copy of n_it_prev is loaded; LM keeps its own counter) */
+	int lm_iter_id = n_it_prev;   /* (LM keeps its own counter) */
 	bool undo = false;
 	if (lmp) {
 		const double f_now = ts.f_ext ? LD(ts.f_ext + t) : (ncc ? 0.0 : -acc_s[ACC_RR] / 2);
@@ -201,10 +200,20 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 	 * elimination in registers with v_readlane broadcasts was measured slower than this LDS form: 8.9 k against 6.9 k clocks.) */
 	const bool pivoting = ncc || ts.h_from_acc;   /* (the search and the row swap are two barriers and eight LDS reads per step: skipped for SSD) */
 	const double si = pow2_scale(h_entry(i, i)), sj = pow2_scale(h_entry(j, j));
+	double *trec = (ts.trace && n_it_prev < ts.trace_cap) ? ts.trace + ((size_t)t * ts.trace_cap + n_it_prev) * kTraceStride : nullptr;   /* debug trace */
 	if (wv0) {
 		/* hessian(i, i) += leven_marq_delta * hessian(i, i) (NT/ESM.cc:262-265) */
-		A[i][j] = h_entry(i, j) * si * sj * ((lmp && i == j && i < S) ? 1.0 + lm_delta : 1.0);
-		if (j == 0) A[i][8] = (i < S ? g_entry(i) : 0.0) * si;
+		const double hij = h_entry(i, j), gi = (j == 0 && i < S) ? g_entry(i) : 0.0;
+		A[i][j] = hij * si * sj * ((lmp && i == j && i < S) ? 1.0 + lm_delta : 1.0);
+		if (j == 0) A[i][8] = gi * si;
+		if (trec) {
+			trec[8 * i + j] = (i < S && j < S) ? hij : 0.0;
+			if (j == 0) trec[64 + i] = gi;
+			if (lane == 0) {
+				trec[88] = ts.f_ext ? LD(ts.f_ext + t) : (ncc ? n_f : -acc_s[ACC_RR] / 2);
+				trec[90] = undo ? 1.0 : 0.0; trec[91] = lm_delta; trec[92] = 1.0;
+			}
+		}
 	}
 	__syncthreads();
 	FIN_STAMP(3);
@@ -246,6 +255,7 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 		const double v = undo ? LD(lmp + 4 + lane) : dps[lane];   /* undo: the previous state_update is taken back */
 		if (lmp && !undo) ST(lmp + 4 + lane, v);
 		dps[lane] = v;
+		if (trec) trec[72 + lane] = v;
 	}
 	__syncthreads();
 	double dp[8];
@@ -326,6 +336,7 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 		}
 		nxy[2 * q] = nx; nxy[2 * q + 1] = ny;
 		ST(cr + 2 * q, nx); ST(cr + 2 * q + 1, ny);
+		if (trec) { trec[80 + 2 * q] = nx; trec[81 + 2 * q] = ny; }
 	}
 	__syncthreads();
 	FIN_STAMP(5);
@@ -338,6 +349,7 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 	}
 	const int n_it = n_it_prev + 1;   /* passes done (the reference's iters_done) */
 	STI(ts.n_iters + t, n_it);
+	if (trec) trec[89] = (double)n_it_prev;
 	if (lmp) {
 		/* an undo pass skips the convergence test (`continue`); it consumes an iteration in the for loops of ESM and ICLK
 		 * (NT/ESM.cc:179, NT/ICLK.cc:169) but not in FCLK's while loop (NT/FCLK.cc:193-223) */

@@ -104,8 +104,14 @@ struct TrackState {
 	 * [0] prev_similarity [1] leven_marq_delta [2] state_reset [3] iter_id [4..11] the last state_update.  NULL: no LM. */
 	double *lm;
 	const double *f_ext;  /* [B] similarity of this pass when it is not a function of the reduced row (MI: d_mi_f), else NULL */
+	/* debug trace of the device-side loop (mtfhip_batch_track_trace): record `pass` of target t at trace + (t cap + pass) kTraceStride:
+	 * [0..63] H as the search method holds it before damping, row-major 8 x 8 | [64..71] g | [72..79] the state update applied |
+	 * [80..87] corners after it | [88] f [89] pass [90] Levenberg-Marquardt undo [91] damping [92] 1 if H was recorded.  NULL: off. */
+	double *trace;
+	int trace_cap;
 };
 constexpr int kLmStride = 12;
+constexpr int kTraceStride = 96;
 
 /* k_track_persist: per-target arrival counter and generation number of the in-kernel barrier between the pixel pass and the solve */
 struct PersistState {

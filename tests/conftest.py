@@ -42,3 +42,23 @@ def gpu_ctx():
     ctx = mtf_amd.Context(0)
     yield ctx
     ctx.close()
+
+
+# Measured parity errors (not just pass / fail): tests append dicts to PARITY_RECORD; with MTFHIP_PARITY_RECORD=<path> the session
+# writes them out as JSON lines (tools/r03_parity_record.sh copies the file into profiles/).
+PARITY_RECORD = []
+
+
+@pytest.fixture(scope="session")
+def parity_record():
+    return PARITY_RECORD
+
+
+def pytest_sessionfinish(session, exitstatus):
+    path = os.environ.get("MTFHIP_PARITY_RECORD")
+    if path and PARITY_RECORD:
+        import json
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            for r in PARITY_RECORD:
+                f.write(json.dumps(r) + "\n")
