@@ -57,6 +57,9 @@ def main():
             tag + "_It_head": fc["It"][:16], tag + "_grad_head": fc["grad"][:16], tag + "_Jt_head": fc["Jt"][:16],
             tag + "_f": fc["f"], tag + "_fclk_g": fc["g"], tag + "_fclk_H": fc["H"], tag + "_fclk_dp": fc["dp"],
             tag + "_esm_g": es["g"], tag + "_esm_H": es["H"], tag + "_esm_dp": es["dp"],
+            # the whole per-pixel arrays of these two cases, not only their first 16 entries (576 and 400 sample points)
+            tag + "_init_pts_full": init_pts, tag + "_I0_full": I0, tag + "_J0_full": J0,
+            tag + "_It_full": fc["It"], tag + "_grad_full": fc["grad"], tag + "_Jt_full": fc["Jt"],
         })
 
     # --- affine + NCC (config-3 patch shape)
