@@ -125,11 +125,17 @@ void *mtfhip_ctx_stream(mtfhip_ctx *ctx);
  * raw frame (uint8 or float32, 1 channel or 3 interleaved BGR) -> float32 -> gray (B*0.114f + G*0.587f + R*0.299f) ->
  * GaussianBlur(ksize x ksize, sigma_x, sigma_y) with BORDER_REFLECT_101 -> the context's current image.  The frame crosses
  * PCIe once, as it was captured (1 or 3 bytes per pixel instead of 4).  ksize 5 (the reference's default, sigma 3) or 0
- * (no smoothing); hist_eq and resize_factor are not provided.  OpenCV itself is absent from this image: the arithmetic
+ * (no smoothing); hist_eq and resize_factor: mtfhip_image_preprocess_ex.  OpenCV itself is absent from this image: the arithmetic
  * follows its float32 filter engine as restated in oracle/preproc_ref.py. */
 enum { MTFHIP_DEPTH_U8 = 0, MTFHIP_DEPTH_F32 = 1 };
 int mtfhip_image_preprocess(mtfhip_ctx *ctx, const void *host_raw, int rows, int cols, int row_stride_bytes, int channels,
 	int depth, int ksize, double sigma_x, double sigma_y);
+/* ... with the pre-processor's other two switches (PreProcBase(name, output_type, resize_factor, hist_eq), preprocUtils.h:28,56-58;
+ * preprocUtils.cc:120-137): hist_eq -- the gray frame goes through 8 bits and cv::equalizeHist before the smoothing -- and
+ * resize_factor != 1 -- cv::resize(INTER_LINEAR) of the smoothed frame to (int)(rows f) x (int)(cols f), which becomes the
+ * current image */
+int mtfhip_image_preprocess_ex(mtfhip_ctx *ctx, const void *host_raw, int rows, int cols, int row_stride_bytes, int channels,
+	int depth, int ksize, double sigma_x, double sigma_y, int hist_eq, double resize_factor);
 /* One level of PyramidalTracker's image pyramid (SM/src/PyramidalTracker.cc:88-97): dst's current image =
  * cv::pyrDown(src's image) when use_pyr_down (scale_factor 0.5), else cv::resize(INTER_LINEAR) + GaussianBlur(5x5, 3). */
 int mtfhip_image_pyramid_level(mtfhip_ctx *dst, mtfhip_ctx *src, int dst_rows, int dst_cols, int use_pyr_down);
@@ -308,7 +314,7 @@ int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int n
  * the combinations the reference itself throws for (additive + point based, compositional RandomWalk + geometric) return
  * MTFHIP_ERR_NOT_IMPLEMENTED with its message, and so does additive + geometric, which needs Affine::stateToGeom -- a 2 x 2
  * JacobiSVD whose sign / ordering conventions decide its branches and cannot be reproduced without Eigen.
- * Not provided: several sampler distributions (n_distr > 1), jacobian_as_sigma, residual resampling. */
+ * Not provided: several sampler distributions (n_distr > 1), jacobian_as_sigma. */
 typedef struct mtfhip_pf mtfhip_pf;
 typedef struct mtfhip_comm mtfhip_comm;
 typedef struct mtfhip_pf_desc {
@@ -317,7 +323,7 @@ typedef struct mtfhip_pf_desc {
 	int dynamic_model;        /* 0 RandomWalk, 1 AutoRegression1 */
 	int update_type;          /* 0 Additive, 1 Compositional */
 	int likelihood_func;      /* 0 AM, 1 Gaussian, 2 Reciprocal */
-	int resampling_type;      /* 0 None, 1 BinaryMultinomial, 2 LinearMultinomial, (3 Residual: not implemented) */
+	int resampling_type;      /* 0 None, 1 BinaryMultinomial, 2 LinearMultinomial, 3 Residual (PF.cc:538-582: particle_wts are normalised in place) */
 	int mean_type;            /* 0 None (highest weight), 1 SSM (mean state), 2 Corners (mean corners, then setCorners) */
 	int corner_based_sampling;/* HomographyParams::corner_based_sampling (on by default, parameters.h:262) */
 	int reset_to_mean;

@@ -96,7 +96,7 @@ SYMBOLS = [
     "mtfhip_pf_create", "mtfhip_pf_destroy", "mtfhip_pf_initialize", "mtfhip_pf_set_region", "mtfhip_pf_set_sampler",
     "mtfhip_pf_iteration", "mtfhip_pf_update", "mtfhip_pf_get_particles", "mtfhip_pf_set_particles", "mtfhip_pf_max_similarity",
     "mtfhip_pf_set_max_similarity", "mtfhip_comm_create_loopback", "mtfhip_pf_shard_bounds",
-    "mtfhip_batch_track_trace", "mtfhip_batch_track_trace_read",
+    "mtfhip_batch_track_trace", "mtfhip_batch_track_trace_read", "mtfhip_image_preprocess_ex",
     "mtfhip_comm_unique_id", "mtfhip_comm_create", "mtfhip_comm_destroy", "mtfhip_comm_rank", "mtfhip_comm_world",
     "mtfhip_allgather_scores", "mtfhip_pf_set_comm",
     "mtfhip_timing_enable", "mtfhip_timing_reset", "mtfhip_timing_get",
@@ -141,6 +141,8 @@ def lib():
         L.mtfhip_image_upload_mc.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.mtfhip_image_preprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_double, C.c_double]
+        L.mtfhip_image_preprocess_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.c_double, C.c_double, C.c_int, C.c_double]
         L.mtfhip_image_pyramid_level.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.mtfhip_image_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.mtfhip_image_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]

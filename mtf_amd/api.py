@@ -104,17 +104,19 @@ class Context:
             stride = img.shape[1]
         L.check(L.lib().mtfhip_image_upload(self._h, _p(img), img.shape[0], img.shape[1], stride))
 
-    def preprocess(self, raw, ksize=5, sigma_x=3.0, sigma_y=0.0):
-        """PreProcBase::update with GaussianSmoothing (preprocUtils.h:20-73): raw uint8 / float32 frame, H x W or
-        H x W x 3 (BGR) -> gray float32 -> Gaussian ksize x ksize -> the current image, all on the device."""
+    def preprocess(self, raw, ksize=5, sigma_x=3.0, sigma_y=0.0, hist_eq=False, resize_factor=1.0):
+        """PreProcBase::update with GaussianSmoothing (preprocUtils.h:20-73, preprocUtils.cc:108-137): raw uint8 / float32 frame,
+        H x W or H x W x 3 (BGR) -> gray float32 -> [hist_eq: 8 bit, cv::equalizeHist] -> Gaussian ksize x ksize ->
+        [resize_factor: cv::resize] -> the current image, all on the device."""
         raw = np.asarray(raw)
         if raw.dtype not in (np.uint8, np.float32) or raw.ndim not in (2, 3) or (raw.ndim == 3 and raw.shape[2] != 3):
             raise L.InvalidArgument(-1, "PreProcBase::processFrame : Invalid input image type provided")
         if not raw.flags["C_CONTIGUOUS"]:
             raw = np.ascontiguousarray(raw)
         ch = 1 if raw.ndim == 2 else 3
-        L.check(L.lib().mtfhip_image_preprocess(self._h, _p(raw), raw.shape[0], raw.shape[1], raw.strides[0], ch,
-                                                0 if raw.dtype == np.uint8 else 1, int(ksize), float(sigma_x), float(sigma_y)))
+        L.check(L.lib().mtfhip_image_preprocess_ex(self._h, _p(raw), raw.shape[0], raw.shape[1], raw.strides[0], ch,
+                                                   0 if raw.dtype == np.uint8 else 1, int(ksize), float(sigma_x), float(sigma_y),
+                                                   1 if hist_eq else 0, float(resize_factor)))
 
     def pyramid_level_from(self, src, rows, cols, pyr_down=True):
         """this context's image = one pyramid level below `src`'s (PyramidalTracker::updateImagePyramid)"""

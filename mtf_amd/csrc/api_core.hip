@@ -160,6 +160,13 @@ static void gaussian5(double sigma, float k[3]) {
 
 int mtfhip_image_preprocess(mtfhip_ctx *c, const void *host_raw, int rows, int cols, int row_stride_bytes, int channels, int depth,
 	int ksize, double sigma_x, double sigma_y) {
+	return mtfhip_image_preprocess_ex(c, host_raw, rows, cols, row_stride_bytes, channels, depth, ksize, sigma_x, sigma_y, 0, 1.0);
+}
+/* PreProcBase::processFrame for the CV_32FC1 output with all of its switches (Utilities/src/preprocUtils.cc:108-137): gray ->
+ * [hist_eq: to 8 bit, cv::equalizeHist, back to float] -> apply() (the Gaussian smoothing, or nothing) -> [resize_factor != 1:
+ * cv::resize(INTER_LINEAR) to (int)(rows f) x (int)(cols f)] */
+int mtfhip_image_preprocess_ex(mtfhip_ctx *c, const void *host_raw, int rows, int cols, int row_stride_bytes, int channels, int depth,
+	int ksize, double sigma_x, double sigma_y, int hist_eq, double resize_factor) {
 	if (c) TRY(lazy_flush_ctx(c));
 	if (!c || !host_raw) return fail(MTFHIP_ERR_INVALID_ARG, "image_preprocess: NULL argument");
 	if (rows <= 0 || cols <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "image_preprocess: bad shape %dx%d", rows, cols);
@@ -169,6 +176,10 @@ int mtfhip_image_preprocess(mtfhip_ctx *c, const void *host_raw, int rows, int c
 	if ((size_t)row_stride_bytes < px * cols) return fail(MTFHIP_ERR_INVALID_ARG, "image_preprocess: row stride %d shorter than a row", row_stride_bytes);
 	if (ksize != 0 && ksize != 5) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "image_preprocess: Gaussian kernel size %d (5, or 0 for no smoothing)", ksize);
 	if (ksize == 5 && sigma_x <= 0) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "image_preprocess: sigma <= 0 selects OpenCV's fixed kernel table, not available");
+	if (!(resize_factor > 0)) return fail(MTFHIP_ERR_INVALID_ARG, "image_preprocess: resize_factor must be positive");
+	const bool resize = resize_factor != 1.0;
+	const int orows = resize ? (int)(rows * resize_factor) : rows, ocols = resize ? (int)(cols * resize_factor) : cols;   /* static_cast<int>(rows * resize_factor), :63-64 */
+	if (orows <= 0 || ocols <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "image_preprocess: resize_factor %g leaves no pixels", resize_factor);
 	HIP_TRY(hipSetDevice(c->device));
 	const size_t raw_bytes = px * cols * rows;
 	if (raw_bytes > c->raw_capacity) {
@@ -177,22 +188,37 @@ int mtfhip_image_preprocess(mtfhip_ctx *c, const void *host_raw, int rows, int c
 		HIP_TRY(hipMalloc(&c->raw, raw_bytes));
 		c->raw_capacity = raw_bytes;
 	}
-	TRY(ensure_image(c, rows, cols));
-	TRY(ensure_tmp(c, (size_t)rows * cols));
+	TRY(ensure_image(c, std::max(rows, orows), std::max(cols, ocols)));
+	TRY(ensure_tmp(c, (size_t)rows * cols + 512));   /* (+ the 256-bin histogram and the look-up table of hist_eq behind tmp_b) */
 	HIP_TRY(hipMemcpy2DAsync(c->raw, px * cols, host_raw, (size_t)row_stride_bytes, px * cols, (size_t)rows, hipMemcpyHostToDevice, c->stream));
 	{
 		TimedScope ts(c, "preprocess");
-		if (ksize == 0) launch_to_gray(c->raw, rows, cols, px * cols, channels, depth == MTFHIP_DEPTH_F32, c->img_owned, c->stream);
-		else {
+		/* stages ping-pong between tmp_a and the image buffer so that the last one lands in the image */
+		const int n_after = (ksize ? 1 : 0) + (resize ? 1 : 0);
+		float *gray = n_after == 1 ? c->tmp_a : c->img_owned;   /* 0 or 2 later stages: start in the image buffer */
+		launch_to_gray(c->raw, rows, cols, px * cols, channels, depth == MTFHIP_DEPTH_F32, gray, c->stream);
+		if (hist_eq) {
+			unsigned *hist = reinterpret_cast<unsigned *>(c->tmp_b + (size_t)rows * cols);
+			launch_hist_eq(gray, rows, cols, hist, reinterpret_cast<float *>(hist + 256), c->stream);
+		}
+		float *cur = gray;
+		if (ksize) {
 			float kx[3], ky[3];
 			gaussian5(sigma_x, kx);
 			gaussian5(sigma_y > 0 ? sigma_y : sigma_x, ky);   /* sigma2 <= 0 -> sigma2 = sigma1 (createGaussianKernels) */
-			launch_to_gray(c->raw, rows, cols, px * cols, channels, depth == MTFHIP_DEPTH_F32, c->tmp_a, c->stream);
-			launch_sym5(c->tmp_a, c->tmp_b, c->img_owned, rows, cols, kx, ky, c->stream);
+			float *dst = cur == c->tmp_a ? c->img_owned : c->tmp_a;
+			launch_sym5(cur, c->tmp_b, dst, rows, cols, kx, ky, c->stream);
+			cur = dst;
 		}
+		if (resize) {
+			float *dst = cur == c->tmp_a ? c->img_owned : c->tmp_a;
+			launch_resize_linear(cur, rows, cols, dst, orows, ocols, c->stream);
+			cur = dst;
+		}
+		if (cur != c->img_owned) return fail(MTFHIP_ERR_LOGIC, "image_preprocess: stage bookkeeping");
 	}
 	HIP_TRY(hipStreamSynchronize(c->stream)); /* the caller may reuse its frame buffer */
-	c->img = ImgView{c->img_owned, rows, cols, cols};
+	c->img = ImgView{c->img_owned, orows, ocols, ocols};
 	return MTFHIP_OK;
 }
 

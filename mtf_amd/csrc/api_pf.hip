@@ -15,6 +15,7 @@
 #include "mtfhip_api_internal.h"
 
 #include <dlfcn.h>
+#include <hipcub/hipcub.hpp>   /* residual resampling: one radix sort + one exclusive scan per iteration (not the hot configuration) */
 #include <condition_variable>
 #include <mutex>
 
@@ -99,6 +100,10 @@ struct mtfhip_pf {
 	double *d_wts = nullptr, *d_cum = nullptr, *d_chunk = nullptr, *d_out = nullptr, *d_normals = nullptr, *d_uniforms = nullptr;
 	double *d_parts = nullptr, *d_gparts = nullptr;   /* per-workgroup rows of the selection pass and their per-group folds */
 	int *d_ids = nullptr, *d_counters = nullptr;
+	/* residual resampling (PF.cc:538-582): sort keys in / out, particle order in / out, copies, their starts, hipCUB's scratch */
+	double *d_res_keys = nullptr;
+	int *d_res_idx = nullptr;
+	void *d_res_tmp = nullptr; size_t res_tmp_bytes = 0;
 	double prev_corners[8];
 };
 
@@ -203,7 +208,7 @@ int mtfhip_allgather_scores(mtfhip_comm *c, const double *dev_send, int count, d
 /* ------------------------------------------------------------------ the particle filter */
 static void pf_free(mtfhip_pf *pf) {
 	void *ptrs[] = {pf->d_st, pf->d_ar, pf->d_prop[0], pf->d_prop[1], pf->d_prop_ar[0], pf->d_prop_ar[1], pf->d_wts, pf->d_cum, pf->d_chunk, pf->d_out,
-		pf->d_normals, pf->d_uniforms, pf->d_ids, pf->d_parts, pf->d_gparts, pf->d_counters};
+		pf->d_normals, pf->d_uniforms, pf->d_ids, pf->d_parts, pf->d_gparts, pf->d_counters, pf->d_res_keys, pf->d_res_idx, pf->d_res_tmp};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 }
 /* which sampler the (SSM, update type, dynamic model, sampling switches) combination selects -- and which combinations the
@@ -237,7 +242,6 @@ int mtfhip_pf_create(mtfhip_batch *b, const mtfhip_pf_desc *d, mtfhip_pf **out) 
 	if (d->dynamic_model < 0 || d->dynamic_model > 1 || d->update_type < 0 || d->update_type > 1 || d->likelihood_func < 0 || d->likelihood_func > 2 ||
 		d->mean_type < 0 || d->mean_type > 2) return fail(MTFHIP_ERR_INVALID_ARG, "pf_create: enum value out of range (PFParams.h:10-33)");
 	if (d->resampling_type < 0 || d->resampling_type > 3) return fail(MTFHIP_ERR_INVALID_ARG, "pf_create: unknown resampling type %d", d->resampling_type);
-	if (d->resampling_type == 3) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "pf_create: residual resampling (PF.cc:538-582) is not available on the device");
 	if (b->desc.am == MTFHIP_AM_MI) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "pf_create: candidate scoring covers SSD and NCC");
 	TRY(single_channel(b, "pf_create"));
 	int sampler = 0, nz = 0;
@@ -256,6 +260,14 @@ int mtfhip_pf_create(mtfhip_batch *b, const mtfhip_pf_desc *d, mtfhip_pf **out) 
 	A(pf->d_out, sizeof(double) * 32); A(pf->d_parts, sizeof(double) * pf_parts_per_block() * nblk); A(pf->d_gparts, sizeof(double) * pf_parts_per_block() * ngrp);
 	A(pf->d_normals, sizeof(double) * n * 10); A(pf->d_uniforms, sizeof(double) * n); A(pf->d_ids, sizeof(int) * n); A(pf->d_counters, sizeof(int) * (2 + ngrp));
 	if (okm && hipMemsetAsync(pf->d_counters, 0, sizeof(int) * (2 + ngrp), b->ctx->stream) != hipSuccess) okm = false;
+	if (d->resampling_type == 3) {
+		A(pf->d_res_keys, sizeof(double) * 2 * n); A(pf->d_res_idx, sizeof(int) * 4 * n);   /* keys in | out ; idx in | order | copies | starts */
+		size_t t1 = 0, t2 = 0;
+		(void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, t1, (const double *)nullptr, (double *)nullptr, (const int *)nullptr, (int *)nullptr, (int)n);
+		(void)hipcub::DeviceScan::ExclusiveSum(nullptr, t2, (const int *)nullptr, (int *)nullptr, (int)n);
+		pf->res_tmp_bytes = std::max(t1, t2) + 256;
+		A(pf->d_res_tmp, pf->res_tmp_bytes);
+	}
 	if (okm && hipMemsetAsync(pf->d_out, 0, sizeof(double) * 32, b->ctx->stream) != hipSuccess) okm = false;
 	if (!okm) { pf_free(pf); delete pf; return fail(MTFHIP_ERR_HIP, "pf_create: hipMalloc failed"); }
 	*out = pf;
@@ -331,6 +343,32 @@ int mtfhip_pf_set_max_similarity(mtfhip_pf *pf, double max_similarity) {
 	return MTFHIP_OK;
 }
 
+/* residual resampling (PF.cc:538-582): where every slot of the new set comes from -- d_ids -- and the order's first index, which is
+ * max_wt_id (d_res_idx + n).  particle_wts are normalised in place as the reference does. */
+static int pf_residual_sources(mtfhip_pf *pf, PfBuffers &bf, size_t nch, hipStream_t st) {
+	const int n = pf->n;
+	int *idx_in = pf->d_res_idx, *order = idx_in + n, *copies = order + n, *starts = copies + n;
+	double *keys_in = pf->d_res_keys, *keys_out = keys_in + n;
+	const double *total = bf.chunk_incl + (nch - 1);   /* particle_cum_wts[n - 1] */
+	launch_pf_residual_prep(n, total, pf->d_wts, keys_in, idx_in, st);
+	if (n > 1) {
+		size_t tb = pf->res_tmp_bytes;
+		/* std::sort(idx, idx + n - 1, wts[a] > wts[b]): the last index is not part of the range */
+		if (hipcub::DeviceRadixSort::SortPairsDescending(pf->d_res_tmp, tb, (const double *)keys_in, keys_out, (const int *)idx_in, order, n - 1, 0, 64, st) != hipSuccess)
+			return fail(MTFHIP_ERR_HIP, "pf_iteration: radix sort of the particle weights failed");
+	}
+	HIP_TRY(hipMemcpyAsync(order + (n - 1), idx_in + (n - 1), sizeof(int), hipMemcpyDeviceToDevice, st));
+	launch_pf_residual_copies(n, pf->d_wts, order, copies, st);
+	{
+		size_t tb = pf->res_tmp_bytes;
+		if (hipcub::DeviceScan::ExclusiveSum(pf->d_res_tmp, tb, (const int *)copies, starts, n, st) != hipSuccess)
+			return fail(MTFHIP_ERR_HIP, "pf_iteration: scan of the copy counts failed");
+	}
+	launch_pf_residual_map(n, order, copies, starts, pf->d_ids, st);
+	bf.res_order = order;
+	return MTFHIP_OK;
+}
+
 /* the launches of one iteration; publish: the estimate is also delivered to host-coherent memory (*pub_seq = the sequence
  * number to wait for, 0 when the read-back is a copy) */
 static int pf_enqueue_iteration(mtfhip_pf *pf, const double *normals, const double *uniforms, bool publish, unsigned long long *pub_seq) {
@@ -395,6 +433,7 @@ static int pf_enqueue_iteration(mtfhip_pf *pf, const double *normals, const doub
 	bf.st = pf->d_st; bf.ar = pf->d_ar; bf.prop = pf->d_prop[pf->pc]; bf.prop_ar = pf->d_prop_ar[pf->pc];
 	bf.next = pf->d_prop[1 - pf->pc]; bf.next_ar = pf->d_prop_ar[1 - pf->pc];
 	bf.wts = pf->d_wts; bf.sim = nullptr; bf.cum = pf->d_cum; bf.chunk_tot = pf->d_chunk; bf.chunk_incl = pf->d_chunk + nch;
+	bf.res_order = nullptr;
 	bf.parts = pf->d_parts; bf.gparts = pf->d_gparts; bf.out = pf->d_out; bf.ids = pf->d_ids; bf.counters = pf->d_counters;
 	/* scoring: setState -> updatePixVals -> updateSimilarity -> likelihood per particle (PF.cc:341-365); sharded: this rank's block */
 	{
@@ -410,7 +449,9 @@ static int pf_enqueue_iteration(mtfhip_pf *pf, const double *normals, const doub
 		TimedScope ts(b->ctx, "pf_resample");
 		unsigned long long seq = 0;
 		if (publish && b->h_acc_dev) seq = ++b->acc_seq;
-		launch_pf_resample(b->desc.ssm, p, bf, lookahead ? 1 : 0, seq ? b->h_acc_dev : nullptr, b->h_flag_dev, seq, st);
+		if (p.resampling_type != 0) launch_pf_scan(p, bf, st);
+		if (p.resampling_type == 3) TRY(pf_residual_sources(pf, bf, nch, st));
+		launch_pf_select(b->desc.ssm, p, bf, lookahead ? 1 : 0, seq ? b->h_acc_dev : nullptr, b->h_flag_dev, seq, st);
 		if (pub_seq) *pub_seq = seq;
 	}
 	++pf->iter;

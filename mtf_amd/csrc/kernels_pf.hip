@@ -522,7 +522,8 @@ struct PfSelectArgs {
 	const double *prop, *prop_ar; /* [n][S] this iteration's proposals */
 	double *st_out, *ar_out;      /* [n][S] the (resampled) set the iteration leaves behind */
 	double *next, *next_ar;       /* [n][S] lookahead: the proposal set of the next iteration */
-	int *ids;                     /* [n] resample ids (diagnostics / tests) */
+	int *ids;                     /* [n] resample ids (diagnostics / tests); residual resampling: an INPUT (k_pf_residual_map) */
+	const int *forced_best;       /* residual resampling: max_wt_id = particle_idx[0] (PF.cc:581), else NULL */
 	double init_corners_hm[12];
 	double *parts;                /* [nblocks][kPfPart] */
 	double *gparts;               /* [ceil(nblocks / 64)][kPfPart] group rows */
@@ -630,6 +631,7 @@ __global__ __launch_bounds__(kBlock) void k_pf_select(PfArgs a, PfSelectArgs r) 
 			id = min(c * kPfChunk + lo, n - 1);
 			if (r.ids) r.ids[k] = id;
 		}
+		if (r.resampling_type == 3) id = r.ids[k];   /* residual resampling: the sources were laid out by k_pf_residual_map */
 		pf_load_row<S>(r.prop, (size_t)id, ns); pf_load_row<S>(r.prop_ar, (size_t)id, nar);
 		pf_store_row<S>(r.st_out, (size_t)k, ns); pf_store_row<S>(r.ar_out, (size_t)k, nar);
 		if (r.lookahead) {
@@ -640,6 +642,7 @@ __global__ __launch_bounds__(kBlock) void k_pf_select(PfArgs a, PfSelectArgs r) 
 			pf_store_row<S>(r.next, (size_t)k, ps); pf_store_row<S>(r.next_ar, (size_t)k, pa);
 		}
 		bv = r.wts[id]; bi = k;
+		if (r.forced_best && k != *r.forced_best) bv = -1.7976931348623157e308;   /* max_wt_id is handed down, not searched for */
 		if (r.mean_type == 1) {
 #pragma unroll
 			for (int s = 0; s < 8; ++s) acc[s] = ns[s];
@@ -732,6 +735,35 @@ __global__ __launch_bounds__(kBlock) void k_pf_select(PfArgs a, PfSelectArgs r) 
 	}
 }
 
+/* ---- residual resampling (PF.cc:538-582) ----
+ * particle_wts /= particle_cum_wts[n - 1]; the particle indices EXCEPT THE LAST ONE are sorted by weight, highest first
+ * (std::sort(idx, idx + n - 1): the reference's range ends one short); every particle in that order is copied
+ * round(weight n) times until n slots are filled, the rest take the first of the order, which is also max_wt_id.
+ * Here: normalise + keys (k_pf_residual_prep), a stable radix sort of the n - 1 keys (hipCUB; std::sort leaves the order of
+ * equal weights unspecified, index order is one of its outcomes), copies (k_pf_residual_copies), their exclusive scan, and a
+ * search of every destination slot in the scanned starts (k_pf_residual_map). */
+__global__ __launch_bounds__(kBlock) void k_pf_residual_prep(int n, const double *total, double *wts, double *keys, int *idx) {
+	const int k = blockIdx.x * kBlock + threadIdx.x;
+	if (k >= n) return;
+	const double w = wts[k] / *total;
+	wts[k] = w; keys[k] = w; idx[k] = k;
+}
+__global__ __launch_bounds__(kBlock) void k_pf_residual_copies(int n, const double *wts, const int *order, int *copies) {
+	const int j = blockIdx.x * kBlock + threadIdx.x;
+	if (j >= n) return;
+	copies[j] = (int)round(wts[order[j]] * (double)n);   /* static_cast<int>(round(particle_wts[resample_id] * n_particles)) */
+}
+__global__ __launch_bounds__(kBlock) void k_pf_residual_map(int n, const int *order, const int *copies, const int *starts, int *ids) {
+	const int k = blockIdx.x * kBlock + threadIdx.x;
+	if (k >= n) return;
+	/* the last position j whose first slot is <= k (the starts are non-decreasing); it owns slot k if its copies reach that far */
+	int lo = 0, hi = n;   /* first position with starts > k */
+	while (lo < hi) { const int mid = (lo + hi) >> 1; if (starts[mid] > k) hi = mid; else lo = mid + 1; }
+	const int j = lo - 1;
+	const bool owned = j >= 0 && k < starts[j] + copies[j];
+	ids[k] = owned ? order[j] : order[0];   /* leftovers: "duplicate particle with highest weight to get exactly same number again" */
+}
+
 /* PF::initializeParticles (PF.cc:185-197): every particle at the current state, AR terms zero */
 __global__ void k_pf_fill(int n, int S, const double *state, double *states, double *ars) {
 	const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -776,19 +808,19 @@ void launch_pf_score(const BatchView &bv, const ImgView &im, const PfLaunch &p, 
 	}
 #undef MTFHIP_PF_SCORE
 }
-void launch_pf_resample(int ssm, const PfLaunch &p, const PfBuffers &bf, int lookahead, double *host_out, unsigned long long *host_flag,
+void launch_pf_scan(const PfLaunch &p, const PfBuffers &bf, hipStream_t st) {
+	const int nch = (p.n + kPfChunk - 1) / kPfChunk;
+	PfScanArgs sc{p.n, nch, bf.wts, bf.cum, bf.chunk_tot, bf.chunk_incl, bf.counters};
+	MTFHIP_LAUNCH(k_pf_scan, dim3((nch + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, sc);
+}
+void launch_pf_select(int ssm, const PfLaunch &p, const PfBuffers &bf, int lookahead, double *host_out, unsigned long long *host_flag,
 	unsigned long long seq, hipStream_t st) {
 	const PfArgs a = pf_args(p);
-	const bool resample = p.resampling_type == 1 || p.resampling_type == 2;
-	const int nch = (p.n + kPfChunk - 1) / kPfChunk;
-	if (resample) {
-		PfScanArgs sc{p.n, nch, bf.wts, bf.cum, bf.chunk_tot, bf.chunk_incl, bf.counters};
-		MTFHIP_LAUNCH(k_pf_scan, dim3((nch + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, sc);
-	}
 	PfSelectArgs r;
 	r.resampling_type = p.resampling_type; r.mean_type = p.mean_type; r.lookahead = lookahead; r.uniforms = p.uniforms;
 	r.wts = bf.wts; r.cum = bf.cum; r.chunk_incl = bf.chunk_incl; r.prop = bf.prop; r.prop_ar = bf.prop_ar;
 	r.st_out = bf.st; r.ar_out = bf.ar; r.next = bf.next; r.next_ar = bf.next_ar; r.ids = bf.ids;
+	r.forced_best = p.resampling_type == 3 ? bf.res_order : nullptr;
 	for (int k = 0; k < 12; ++k) r.init_corners_hm[k] = p.init_corners_hm[k];
 	r.parts = bf.parts; r.gparts = bf.gparts; r.counter = bf.counters + 1; r.out = bf.out; r.pub = PfPublish{host_out, host_flag, seq};
 	const dim3 g((p.n + kBlock - 1) / kBlock);
@@ -797,6 +829,15 @@ void launch_pf_resample(int ssm, const PfLaunch &p, const PfBuffers &bf, int loo
 }
 void launch_pf_fill(int n, int S, const double *dev_state, double *states, double *ars, hipStream_t st) {
 	MTFHIP_LAUNCH(k_pf_fill, dim3((n + 255) / 256), dim3(256), 0, st, n, S, dev_state, states, ars);
+}
+void launch_pf_residual_prep(int n, const double *total, double *wts, double *keys, int *idx, hipStream_t st) {
+	MTFHIP_LAUNCH(k_pf_residual_prep, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, total, wts, keys, idx);
+}
+void launch_pf_residual_copies(int n, const double *wts, const int *order, int *copies, hipStream_t st) {
+	MTFHIP_LAUNCH(k_pf_residual_copies, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, wts, order, copies);
+}
+void launch_pf_residual_map(int n, const int *order, const int *copies, const int *starts, int *ids, hipStream_t st) {
+	MTFHIP_LAUNCH(k_pf_residual_map, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, order, copies, starts, ids);
 }
 int pf_parts_per_block() { return kPfPart; }
 int pf_chunk() { return kPfChunk; }

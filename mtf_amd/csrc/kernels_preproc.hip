@@ -3,6 +3,7 @@
  * (one of the translation units of libmtfhip.so; conventions and the shared device helpers: mtfhip_device.h)
  */
 #include "mtfhip_device.h"
+#include <algorithm>
 
 namespace mtfhip {
 
@@ -95,10 +96,45 @@ __global__ __launch_bounds__(kBlock) void k_resize_linear(const float *src, int 
 	dst[(size_t)y * dcols + x] = h0 * b0 + h1 * b1;
 }
 
+/* ---- hist_eq (Utilities/src/preprocUtils.cc:120-125): frame_gs.convertTo(CV_8UC1) -> cv::equalizeHist -> convertTo(CV_32FC1).
+ * convertTo rounds to nearest even and saturates (cvRound + saturate_cast<uchar>); equalizeHist (imgproc/histogram.cpp): the 256-bin
+ * histogram, i = first occupied bin, a constant image is left alone, otherwise scale = 255.f / (total - hist[i]) in float and
+ * lut[j] = saturate_cast<uchar>(sum_{i < k <= j} hist[k] * scale), lut[i] = 0.  All integer / float32 work: bit-exact. ---- */
+__device__ __forceinline__ int to_u8(float v) { const int r = __float2int_rn(v); return r < 0 ? 0 : (r > 255 ? 255 : r); }
+__global__ __launch_bounds__(kBlock) void k_hist_u8(const float *gray, size_t n, unsigned *hist) {
+	__shared__ unsigned h[256];
+	h[threadIdx.x] = 0;
+	__syncthreads();
+	for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) atomicAdd(&h[to_u8(gray[i])], 1u);
+	__syncthreads();
+	if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void k_hist_lut(const unsigned *hist, unsigned total, float *lut) {
+	if (threadIdx.x || blockIdx.x) return;
+	int i = 0;
+	while (!hist[i]) ++i;
+	if (hist[i] == total) { for (int j = 0; j < 256; ++j) lut[j] = (float)j; return; }   /* dst.setTo(i): the only value that occurs maps to itself */
+	const float scale = 255.f / (float)(total - hist[i]);
+	int sum = 0;
+	for (int j = 0; j <= i; ++j) lut[j] = 0.f;
+	for (int j = i + 1; j < 256; ++j) { sum += (int)hist[j]; lut[j] = (float)to_u8((float)sum * scale); }
+}
+__global__ __launch_bounds__(kBlock) void k_apply_lut(float *gray, size_t n, const float *lut) {
+	const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+	if (i < n) gray[i] = lut[to_u8(gray[i])];
+}
 
 /* ===================================================================== */
 /* launchers                                                              */
 /* ===================================================================== */
+void launch_hist_eq(float *gray, int rows, int cols, unsigned *hist256, float *lut256, hipStream_t st) {
+	const size_t n = (size_t)rows * cols;
+	(void)hipMemsetAsync(hist256, 0, 256 * sizeof(unsigned), st);
+	const unsigned nb = (unsigned)std::min<size_t>((n + kBlock - 1) / kBlock, 1024);
+	MTFHIP_LAUNCH(k_hist_u8, dim3(nb), dim3(kBlock), 0, st, (const float *)gray, n, hist256);
+	MTFHIP_LAUNCH(k_hist_lut, dim3(1), dim3(1), 0, st, (const unsigned *)hist256, (unsigned)n, lut256);
+	MTFHIP_LAUNCH(k_apply_lut, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, gray, n, (const float *)lut256);
+}
 void launch_to_gray(const void *raw, int rows, int cols, size_t stride_bytes, int channels, int depth_f32, float *out, hipStream_t st) {
 	MTFHIP_LAUNCH(k_to_gray_f32, dim3((cols + kBlock - 1) / kBlock, rows), dim3(kBlock), 0, st, (const unsigned char *)raw, rows, cols,
 		stride_bytes, channels, depth_f32, out);

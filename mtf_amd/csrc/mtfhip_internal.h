@@ -249,15 +249,20 @@ struct PfBuffers {
 	double *wts, *sim;          /* [>= n] weights at global particle indices; similarities or NULL */
 	double *cum, *chunk_tot, *chunk_incl;
 	double *parts, *gparts, *out;   /* per-workgroup rows of the selection pass, their per-group folds, the estimate */
+	int *res_order;             /* residual resampling: particle indices by weight, highest first (the last index stays last) */
 	int *ids, *counters;        /* [0] the scan's arrival counter, [1] the selection pass's top-level counter, [2 ...] one per group of 64
 	                               workgroups of the selection pass; zero between launches */
 };
 void launch_pf_propose(int ssm, const PfLaunch &p, const double *st_in, const double *ar_in, double *st_out, double *ar_out, hipStream_t st);
 void launch_pf_score(const BatchView &bv, const ImgView &im, const PfLaunch &p, const PfBuffers &bf, int lo, int cnt,
 	double alpha, double norm_mult, double norm_add, const double *ncc_sc, int fast_math, hipStream_t st);
-void launch_pf_resample(int ssm, const PfLaunch &p, const PfBuffers &bf, int lookahead, double *host_out /* or NULL */,
+void launch_pf_scan(const PfLaunch &p, const PfBuffers &bf, hipStream_t st);   /* weights -> chunk-local cumulative weights + chunk table */
+void launch_pf_select(int ssm, const PfLaunch &p, const PfBuffers &bf, int lookahead, double *host_out /* or NULL */,
 	unsigned long long *host_flag, unsigned long long seq, hipStream_t st);
 void launch_pf_fill(int n, int S, const double *dev_state, double *states, double *ars, hipStream_t st);
+void launch_pf_residual_prep(int n, const double *total, double *wts, double *keys, int *idx, hipStream_t st);
+void launch_pf_residual_copies(int n, const double *wts, const int *order, int *copies, hipStream_t st);
+void launch_pf_residual_map(int n, const int *order, const int *copies, const int *starts, int *ids, hipStream_t st);
 int pf_parts_per_block();
 int pf_chunk();
 /* sums partials over blocks: out[B][ACC_COUNT] */
@@ -286,6 +291,7 @@ void launch_mean_planes(const double *a, const double *b, double *o, size_t n, h
 void launch_second_order_ssd(const BatchView &bv, const ImgView &im, int term, int chained, int d0_variant, double grad_eps,
 	double hess_eps, double norm_mult, double norm_add, double *partials, int nblk, double *out, hipStream_t st);
 /* pre-processing / pyramid (float32 images) */
+void launch_hist_eq(float *gray, int rows, int cols, unsigned *hist256, float *lut256, hipStream_t st);
 void launch_to_gray(const void *raw, int rows, int cols, size_t stride_bytes, int channels, int depth_f32, float *out, hipStream_t st);
 void launch_sym5(const float *src, float *tmp, float *dst, int rows, int cols, const float kx[3], const float ky[3], hipStream_t st);
 void launch_pyr_down(const float *src, int srows, int scols, float *dst, int drows, int dcols, hipStream_t st);

@@ -2383,7 +2383,37 @@ int mtfo_pf_iteration(mtfo_am *am, mtfo_ssm *ssm, const mtfo_pf_params *pp, doub
 		}
 		std::memcpy(states, ns2.data(), sizeof(double) * ns2.size());
 		std::memcpy(ars, na2.data(), sizeof(double) * na2.size());
-	} else if (pp->resampling_type != 0) return -2;   /* residual resampling: not restated */
+	} else if (pp->resampling_type == 3) {   /* PF::residualResampling PF.cc:538-582 */
+		/* normalize the weights */
+		for (int k = 0; k < n; ++k) wts[k] /= cum[n - 1];
+		if (wts_out) std::memcpy(wts_out, wts.data(), sizeof(double) * n);   /* (particle_wts stay normalised in the reference) */
+		/* vector of particle indices; sort, with highest weight first -- std::sort(data(), data() + n - 1): the range ends one
+		 * short of the last index.  std::sort leaves the order of equal weights unspecified; the stable order is one of its
+		 * outcomes and the one fixed here. */
+		std::vector<int> particle_idx(n);
+		for (int k = 0; k < n; ++k) particle_idx[k] = k;
+		std::stable_sort(particle_idx.begin(), particle_idx.begin() + (n - 1), [&](int a, int b) { return wts[a] > wts[b]; });
+		vecd ns2(static_cast<size_t>(n) * S), na2(static_cast<size_t>(n) * S);
+		auto put = [&](int dst, int src) {
+			std::memcpy(&ns2[static_cast<size_t>(dst) * S], states + static_cast<size_t>(src) * S, sizeof(double) * S);
+			std::memcpy(&na2[static_cast<size_t>(dst) * S], ars + static_cast<size_t>(src) * S, sizeof(double) * S);
+			if (resample_ids) resample_ids[dst] = src;
+		};
+		int particles_found = 0;
+		for (int particle_id = 0; particle_id < n; ++particle_id) {
+			const int resample_id = particle_idx[particle_id];
+			const int particle_copies = static_cast<int>(std::round(wts[resample_id] * n));
+			for (int copy_id = 0; copy_id < particle_copies; ++copy_id) {
+				put(particles_found, resample_id);
+				if (++particles_found == n) break;
+			}
+			if (particles_found == n) break;
+		}
+		for (int particle_id = particles_found; particle_id < n; ++particle_id) put(particle_id, particle_idx[0]);   /* duplicate the highest weight */
+		std::memcpy(states, ns2.data(), sizeof(double) * ns2.size());
+		std::memcpy(ars, na2.data(), sizeof(double) * na2.size());
+		max_wt_id = particle_idx[0];   /* (an index of the OLD set, used with the new one: PF.cc:581, kept) */
+	} else if (pp->resampling_type != 0) return -2;
 	/* mean type: PF.cc:421-437 */
 	if (pp->mean_type == 0) ssm->set_state(states + static_cast<size_t>(max_wt_id) * S);
 	else if (pp->mean_type == 1) {   /* ProjectiveBase::estimateMeanOfSamples :311-317 */

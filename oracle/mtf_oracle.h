@@ -189,14 +189,14 @@ typedef struct mtfo_pf_params {
 	int dynamic_model;        /* 0 RandomWalk, 1 AutoRegression1 */
 	int update_type;          /* 0 Additive, 1 Compositional */
 	int likelihood_func;      /* 0 AM, 1 Gaussian, 2 Reciprocal */
-	int resampling_type;      /* 0 None, 1 BinaryMultinomial, 2 LinearMultinomial (3 Residual: not restated) */
+	int resampling_type;      /* 0 None, 1 BinaryMultinomial, 2 LinearMultinomial, 3 Residual */
 	int mean_type;            /* 0 None, 1 SSM, 2 Corners */
 	int corner_based_sampling;/* HomographyParams::corner_based_sampling */
 	double measurement_sigma, ar_coeff;
 	double sigma[8], mean[8]; /* the sampler's normal distributions (ProjectiveBase::initializeSampler) */
 	int pt_based_sampling;    /* AffineParams::pt_based_sampling (Affine.cc:464-503): 0 geometric, 1, 2 */
 } mtfo_pf_params;
-/* returns 0; -2 residual resampling (not restated); -3 an Affine sampler combination the reference throws for, or the additive
+/* returns 0; -2 unknown resampling type; -3 an Affine sampler combination the reference throws for, or the additive
  * geometric one (Affine::stateToGeom: Eigen JacobiSVD conventions, not restated) */
 int mtfo_pf_iteration(mtfo_am *am, mtfo_ssm *ssm, const mtfo_pf_params *pp, double *states, double *ars, const double *normals,
 	const double *uniforms, double max_similarity, double *wts_out, int *resample_ids, int *max_wt_id_out);

@@ -11,6 +11,7 @@ that is absent from /root/reference and from this image, so this file restates i
     s = k0*S0; s += k1*(S+1 + S-1); s += k2*(S+2 + S-2) (SymmColumnFilter); BORDER_REFLECT_101
   * pyrDown: [1 4 6 4 1] x [1 4 6 4 1] / 256 with the same pair-sum order, BORDER_REFLECT_101
   * resize(INTER_LINEAR): fx = (float)((dx + 0.5) * scale - 0.5), floor, clamp at both ends, float weights
+  * convertTo(CV_8U): cvRound (to nearest even) + saturation; equalizeHist: 256-bin histogram -> look-up table as below
 Every intermediate is rounded to float32 exactly where OpenCV's float code rounds."""
 import numpy as np
 
@@ -63,9 +64,38 @@ def gaussian_blur5(img, sigma_x=3.0, sigma_y=0.0):
     return sym5(img, kx, ky)
 
 
-def preprocess(raw, ksize=5, sigma_x=3.0, sigma_y=0.0):
+def to_u8(img):
+    """Mat::convertTo(CV_8U) of a float image: cvRound (round half to even) + saturate_cast<uchar>"""
+    return np.clip(np.rint(np.asarray(img, dtype=f32)), 0, 255).astype(np.uint8)
+
+
+def equalize_hist_u8(src):
+    """cv::equalizeHist (imgproc/histogram.cpp, OpenCV 2.4 / 3.x): hist of the 256 levels; i = first occupied level; an image
+    with one level only is set to that level; else scale = 255.f / (total - hist[i]) (float), lut[i] = 0 and
+    lut[j] = saturate_cast<uchar>(sum_{i < k <= j} hist[k] * scale) for j > i (int sum times float scale, cvRound)"""
+    src = np.asarray(src, dtype=np.uint8)
+    hist = np.bincount(src.ravel(), minlength=256)
+    i = int(np.nonzero(hist)[0][0])
+    total = src.size
+    if hist[i] == total:
+        return np.full_like(src, i)
+    scale = f32(255.0) / f32(total - hist[i])
+    lut = np.zeros(256, dtype=np.uint8)
+    csum = np.cumsum(hist[i + 1:]).astype(np.int64)
+    lut[i + 1:] = np.clip(np.rint((csum.astype(f32) * scale).astype(f32)), 0, 255).astype(np.uint8)
+    return lut[src]
+
+
+def preprocess(raw, ksize=5, sigma_x=3.0, sigma_y=0.0, hist_eq=False, resize_factor=1.0):
+    """PreProcBase::processFrame, CV_32FC1 output (Utilities/src/preprocUtils.cc:108-137)"""
     g = to_gray_f32(raw)
-    return g if ksize == 0 else gaussian_blur5(g, sigma_x, sigma_y)
+    if hist_eq:      # :120-125  frame_gs.convertTo(uchar); equalizeHist; convertTo(float)
+        g = equalize_hist_u8(to_u8(g)).astype(f32)
+    if ksize != 0:   # apply(): GaussianSmoothing, preprocUtils.h:67-73
+        g = gaussian_blur5(g, sigma_x, sigma_y)
+    if resize_factor != 1:   # :127-129  cv::resize(frame_gs, frame_resized, frame_resized.size()), size from :63-64
+        g = resize_linear(g, int(g.shape[0] * resize_factor), int(g.shape[1] * resize_factor))
+    return g
 
 
 def pyr_down(img, drows, dcols):

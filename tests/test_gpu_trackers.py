@@ -620,6 +620,8 @@ def test_persistent_loop_equals_two_launch_loop(gpu_ctx, case, monkeypatch):
     (0, 1, 0, 1, 1, 2),    # additive AR1, Gaussian likelihood, linear multinomial
     (0, 0, 0, 2, 2, 1),    # additive random walk, reciprocal likelihood, mean of the corners
     (1, 0, 1, 0, 0, 0),    # no resampling
+    (1, 0, 1, 0, 0, 3),    # residual resampling (PF.cc:538-582), highest weight = the first of the sorted order
+    (0, 1, 0, 1, 1, 3),    # residual + additive AR1 + Gaussian likelihood + mean of the states
 ])
 def test_pf_iteration_matches_oracle(oracle, gpu_ctx, frame, am, corner_based, dynamic_model, update_type, mean_type, likelihood_func,
                                      resampling_type):
@@ -654,7 +656,12 @@ def test_pf_iteration_matches_oracle(oracle, gpu_ctx, frame, am, corner_based, d
         pf.iteration(normals, uniforms)
         st_d, ar_d, w_d, ids_d = pf.particles()
         np.testing.assert_allclose(w_d, w_o, rtol=1e-9, atol=1e-300)
-        if resampling_type:
+        if resampling_type == 3:
+            # deterministic given the weights: the sorted order (ties by index), round(w n) copies each, leftovers = the first
+            assert np.array_equal(ids_d, ids_o)
+            assert abs(w_d.sum() - 1.0) < 1e-12            # particle_wts are normalised in place (PF.cc:540)
+            same = np.ones(n, dtype=bool)
+        elif resampling_type:
             # the device's cumulative sum is a parallel scan: an id may differ only where a draw sits within rounding of a boundary
             cum = np.cumsum(w_o) / np.sum(w_o)
             bad = np.nonzero(ids_d != ids_o)[0]

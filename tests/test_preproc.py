@@ -9,6 +9,7 @@ import pytest
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
 import preproc_ref as P  # noqa: E402
 
+import mtf_amd  # noqa: E402
 from mtf_amd import synth  # noqa: E402
 
 
@@ -54,6 +55,48 @@ def test_gray_conversion_and_pyramid_restatements():
     np.testing.assert_allclose(h, 0.25 * (ramp[0::2, 0::2] + ramp[1::2, 0::2] + ramp[0::2, 1::2] + ramp[1::2, 1::2]), atol=1e-4)
     lvl = P.pyramid_level(smooth.astype(np.float32), 100, 125, use_pyr_down=False)
     assert lvl.shape == (100, 125) and lvl.dtype == np.float32
+
+
+def test_equalize_hist_restatement_properties():
+    """cv::equalizeHist as restated: a look-up table that is monotone, maps the lowest occupied level to 0 and the highest to
+    255, flattens the cumulative distribution (every level's output ~ 255 x the fraction of pixels below it), leaves a constant
+    image alone; convertTo(CV_8U) rounds to nearest even and saturates"""
+    assert list(P.to_u8(np.array([-3.0, 0.5, 1.5, 2.5, 254.5, 255.5, 300.0], dtype=np.float32))) == [0, 0, 2, 2, 254, 255, 255]
+    _, _, smooth = raw_frames()
+    out = P.equalize_hist_u8(smooth)
+    lo, hi = smooth.min(), smooth.max()
+    assert out[smooth == lo].max() == 0 and out[smooth == hi].min() == 255
+    order = np.argsort(smooth.ravel(), kind="stable")
+    assert np.all(np.diff(out.ravel()[order].astype(int)) >= 0)            # monotone in the input level
+    hist = np.bincount(smooth.ravel(), minlength=256)
+    cdf = (np.cumsum(hist) - hist[lo]) / float(smooth.size - hist[lo])      # mass strictly above the lowest level, up to each level
+    lev = np.nonzero(hist)[0]
+    want = np.clip(np.rint(255.0 * cdf[lev]), 0, 255)
+    got = np.array([out[smooth == v][0] for v in lev])
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1            # (float32 scale: at most one level off the float64 form)
+    const = np.full((9, 11), 37, dtype=np.uint8)
+    assert np.array_equal(P.equalize_hist_u8(const), const)
+    full = P.preprocess(smooth, hist_eq=True, resize_factor=0.5)
+    assert full.shape == (80, 100) and full.dtype == np.float32
+
+
+@pytest.mark.gpu
+def test_device_preprocess_hist_eq_and_resize(gpu_ctx):
+    """hist_eq and resize_factor of PreProcBase (preprocUtils.cc:120-137) on the device against the restatement, bit for bit"""
+    gray, bgr, smooth = raw_frames()
+    for raw in (gray, bgr, smooth, gray.astype(np.float32) * 0.7 + 3.3):
+        for kw in (dict(hist_eq=True), dict(resize_factor=0.5), dict(hist_eq=True, resize_factor=0.75), dict(hist_eq=True, ksize=0),
+                   dict(resize_factor=1.6, ksize=0), dict(hist_eq=True, resize_factor=2.0)):
+            gpu_ctx.preprocess(raw, **kw)
+            want = P.preprocess(raw, **kw)
+            got = gpu_ctx.get_image()
+            assert got.shape == want.shape, (kw, got.shape, want.shape)
+            assert np.array_equal(got, want), kw
+    const = np.full((33, 47), 91, dtype=np.uint8)
+    gpu_ctx.preprocess(const, hist_eq=True, ksize=0)
+    assert np.all(gpu_ctx.get_image() == 91.0)
+    with pytest.raises(mtf_amd.InvalidArgument):
+        gpu_ctx.preprocess(gray, resize_factor=0.0)
 
 
 @pytest.mark.gpu
