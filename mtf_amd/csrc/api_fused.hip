@@ -774,15 +774,18 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 	TRY(check_sm(b, sm, "track"));
 	TRY(fused_channels_ok(b, "track"));
 	if (sm->max_iters <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "track: max_iters must be positive");
-	if (b->desc.am != MTFHIP_AM_SSD ? sm->sec_ord_hess != 0 : second_order_term(sm) >= 0)
-		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: a second-order Hessian is indefinite and needs the pivoted host solve; use iterate");
+	const int so_term = second_order_term(sm);
+	if (b->desc.am != MTFHIP_AM_SSD && sm->sec_ord_hess != 0)
+		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: second-order Hessians of NCC and MI go through iterate / the per-function entry points");
+	if (so_term >= 0 && b->C != 1) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: second-order Hessians of the multi-channel models use the per-function entry points");
+	if (so_term > 0 && !b->init_pix_hess) return fail(MTFHIP_ERR_LOGIC, "track: init_template was run without sec_ord_hess");
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "track before init_template");
 	TRY(need_image(b));
 	hipStream_t st = b->ctx->stream;
 	const bool mi = b->desc.am == MTFHIP_AM_MI;
 	/* (the one-launch grid kernel has no Levenberg-Marquardt: with it ICLK takes the fused launch + finish per pass) */
 	const bool one_launch = !mi && b->C == 1 && !sm->leven_marq && sm->sm == MTFHIP_SM_ICLK && (sm->hess_type == 0 || (sm->hess_type == 2 && b->desc.am == MTFHIP_AM_SSD)) &&
-		b->N <= kIclkTrackMaxPix;
+		b->N <= kIclkTrackMaxPix && so_term < 0;
 	FusedArgs fa;
 	if (!one_launch && !mi) TRY(fused_args(b, sm, fa));
 	else { fa.materialize = 0; fa.mode = 2; fa.active = nullptr; fa.rows_per_block = 1; fa.j0_recompute = 0; fa.inline_warp = 0; fa.fast_math = 0; }
@@ -831,6 +834,17 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 		if (mi) ts.f_ext = b->d_mi_f;
 	}
 
+	int nb2 = 0;
+	if (so_term >= 0) {
+		/* second-order term of SSD's Hessian inside the loop: one more pixel pass per iteration (k_second_order_ssd, the points
+		 * re-derived from the warp), its S x S sums added by the finish, which then solves with pivoting */
+		nb2 = simple_blocks_per_target(b->N);
+		if (!b->d_d2_part) {
+			HIP_TRY(hipMalloc(&b->d_d2_part, sizeof(double) * 64 * (size_t)nb2 * b->B));
+			HIP_TRY(hipMalloc(&b->d_d2_out, sizeof(double) * 64 * (size_t)b->B));
+		}
+		ts.h_extra = b->d_d2_out; ts.h_extra_scale = so_term == 1 ? 0.5 : 1.0;
+	}
 	BatchView bv = b->view();
 	unsigned long long pub_seq = 0;   /* non-zero: the loop's own kernel delivers the results to the host */
 	bool persisted = false;
@@ -859,7 +873,7 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 			pub = HostPublish{b->h_pub_dev, b->slab_dbl_bytes, b->B, b->d_fin_count, b->h_flag_dev, pub_seq};
 		}
 		launch_iclk_track(bv, b->ctx->img, *sm, ts, b->d_h0inv, b->d_ncc, b->norm_mult, b->norm_add, b->math_mode == MTFHIP_MATH_FAST, pub, st);
-	} else if (persist_fits(b, sm, fa)) {
+	} else if (so_term < 0 && persist_fits(b, sm, fa)) {
 		/* a grid that fits the device at one workgroup per CU (a single large target, a few small ones): every pass of the loop in
 		 * ONE launch, the workgroups meeting at an in-kernel barrier between the pixel pass and the solve (kernels_persist.hip) */
 		persisted = true;
@@ -895,13 +909,19 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 			TrackState tc{ts.acc + (size_t)t0 * RL, ts.h0 + (size_t)t0 * 64, ts.corners + 8 * (size_t)t0,
 				ts.init_corners_hm + 12 * (size_t)t0, ts.active + t0, ts.n_iters + t0, ncc ? ts.ncc + 8 * (size_t)t0 : nullptr,
 				ncc ? ts.ncc_tm + 52 * (size_t)t0 : nullptr, 0, ts.lm ? ts.lm + (size_t)kLmStride * t0 : nullptr, nullptr,
-				ts.trace ? ts.trace + (size_t)t0 * ts.trace_cap * kTraceStride : nullptr, ts.trace_cap};
+				ts.trace ? ts.trace + (size_t)t0 * ts.trace_cap * kTraceStride : nullptr, ts.trace_cap,
+				ts.h_extra ? ts.h_extra + (size_t)t0 * b->S * b->S : nullptr, ts.h_extra_scale};
 			int nblk_c; { int rows; fused_decomposition(b->N, nt, nblk_c, rows); fc.rows_per_block = rows; }
 			double *part = b->d_partials + (size_t)t0 * b->nblk_max * RL;
 			for (int it = 0; it < max_passes; ++it) {
 				{
 					TimedScope tsc(b->ctx, "fused_lk");
 					launch_fused_ssd(bc, b->ctx->img, fc, part, nblk_c, st);
+				}
+				if (so_term >= 0) {
+					TimedScope tsc(b->ctx, "second_order");
+					launch_second_order_ssd(bc, b->ctx->img, so_term, fa.chained, b->d0_variant, fa.grad_eps, b->hess_eps, b->norm_mult, b->norm_add,
+						b->d_d2_part + (size_t)t0 * nb2 * 64, nb2, b->d_d2_out + (size_t)t0 * b->S * b->S, st, 1);
 				}
 				launch_finish_track(bc, *sm, tc, part, nblk_c, st);
 				if (all_converged(tc.active, nt, it)) break;

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64) void k_plane_sum_finish(const double *partials,
  * d0_variant: how init_pix_hessian was produced (Warped at the identity warp by initialize, Init after setRegion). */
 template <int SSM>
 __global__ __launch_bounds__(kBlock) void k_second_order_ssd(BatchView bv, ImgView im, int term, int chained, int d0_variant,
-	double grad_eps, double hess_eps, double norm_mult, double norm_add, double *partials, int nblk) {
+	double grad_eps, double hess_eps, double norm_mult, double norm_add, double *partials, int nblk, int own_pts) {
 	constexpr int S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
 	__shared__ double lds[4 * S * S];
 	const int t = blockIdx.y, N = bv.N;
@@ -316,8 +316,25 @@ __global__ __launch_bounds__(kBlock) void k_second_order_ssd(BatchView bv, ImgVi
 #pragma unroll
 	for (int k = 0; k < S * S; ++k) acc[k] = 0.0;
 	for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += nblk * kBlock) {
-		const double2 p0 = ip[i], c = cp[i];
-		const double D = cz[i];
+		const double2 p0 = ip[i];
+		double2 c, chv;
+		double D;
+		if (own_pts) {
+			/* the device-side loop: curr_pts_hm = curr_warp * init_pts_hm and its dehomogenisation in registers, with k_apply_warp's
+			 * expressions (Homography.cc:86-90, Affine.cc:104) -- CURR_PTS / CURR_HXY / CURR_Z are not refreshed between its passes */
+			const double2 hp = bv.unit_z ? p0 : (reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]) + (size_t)t * N)[i];
+			const double z = bv.unit_z ? 1.0 : (bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * N)[i];
+			if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+				const double cx = W.m[0] * hp.x + W.m[1] * hp.y + W.m[2] * z, cy = W.m[3] * hp.x + W.m[4] * hp.y + W.m[5] * z;
+				D = W.m[6] * hp.x + W.m[7] * hp.y + W.m[8] * z;
+				c = make_double2(cx / D, cy / D); chv = make_double2(cx, cy);
+			} else {
+				c = make_double2(W.m[0] * hp.x + W.m[1] * hp.y + W.m[2] * z, W.m[3] * hp.x + W.m[4] * hp.y + W.m[5] * z);
+				D = 1.0; chv = c;
+			}
+		} else {
+			c = cp[i]; D = cz[i]; chv = ch[i];
+		}
 		const double cv = pix_val(im, c.x, c.y);
 		const double r = (norm_mult * cv + norm_add) - I0[i];
 		double d2[S * S];
@@ -334,7 +351,7 @@ __global__ __launch_bounds__(kBlock) void k_second_order_ssd(BatchView bv, ImgVi
 				gy = (pix_val(im, c.x, c.y + grad_eps) - pix_val(im, c.x, c.y - grad_eps)) * gmult;
 			} else {         /* updateHessPts + getWarpedImgHess imgUtils.cc:259-289 ; updateGradPts + getWarpedImgGrad :177-202 */
 				double q0, q1, q2;
-				if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) { const double2 h = ch[i]; q0 = h.x; q1 = h.y; q2 = D; }
+				if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) { const double2 h = chv; q0 = h.x; q1 = h.y; q2 = D; }
 				else { q0 = c.x; q1 = c.y; q2 = 1.0; }
 				auto at = [&](double o0, double o1, double o2, double sgn) -> double {
 					if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
@@ -440,14 +457,14 @@ void launch_weighted_plane_sum(const BatchView &bv, const double *d2a, const dou
 	MTFHIP_LAUNCH(k_plane_sum_finish, dim3(bv.B), dim3(64), 0, st, partials, nblk, bv.S * bv.S, out);
 }
 void launch_second_order_ssd(const BatchView &bv, const ImgView &im, int term, int chained, int d0_variant, double grad_eps,
-	double hess_eps, double norm_mult, double norm_add, double *partials, int nblk, double *out, hipStream_t st) {
+	double hess_eps, double norm_mult, double norm_add, double *partials, int nblk, double *out, hipStream_t st, int own_pts) {
 	const dim3 grid(nblk, bv.B);
 	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY)
 		MTFHIP_LAUNCH(k_second_order_ssd<MTFHIP_SSM_HOMOGRAPHY>, grid, dim3(kBlock), 0, st, bv, im, term, chained, d0_variant, grad_eps,
-			hess_eps, norm_mult, norm_add, partials, nblk);
+			hess_eps, norm_mult, norm_add, partials, nblk, own_pts);
 	else
 		MTFHIP_LAUNCH(k_second_order_ssd<MTFHIP_SSM_AFFINE>, grid, dim3(kBlock), 0, st, bv, im, term, chained, d0_variant, grad_eps,
-			hess_eps, norm_mult, norm_add, partials, nblk);
+			hess_eps, norm_mult, norm_add, partials, nblk, own_pts);
 	MTFHIP_LAUNCH(k_plane_sum_finish, dim3(bv.B), dim3(64), 0, st, partials, nblk, bv.S * bv.S, out);
 }
 

@@ -179,6 +179,9 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 		}
 		double v = use_h0 ? h0s[b2 * S + a] : -acc_s[ACC_H + kk];
 		if (sum_h0) v = (v + h0s[b2 * S + a]) * 0.5;
+		/* sec_ord_hess: + sum_p df_dI[p] d2I_dp2[:, p] (SSDBase.cc:313-415); the homography blocks are not symmetric in their
+		 * last two rows / columns (Homography.cc:421,613,796), so the entry is taken as (r, c), not from a triangle */
+		if (ts.h_extra) v += ts.h_extra_scale * ts.h_extra[(size_t)t * S * S + c * S + r];
 		return v;
 	};
 	auto g_entry = [&](int s) -> double {
@@ -198,7 +201,7 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 	 * a flat template's zero pivot leaves its unknown at zero), but NCC's Std / SumOfStd and MI's Hessians can be indefinite away
 	 * from convergence, where the reference's colPivHouseholderQr (NT/FCLK.cc:298) does not care either.  (A row-per-lane
 	 * elimination in registers with v_readlane broadcasts was measured slower than this LDS form: 8.9 k against 6.9 k clocks.) */
-	const bool pivoting = ncc || ts.h_from_acc;   /* (the search and the row swap are two barriers and eight LDS reads per step: skipped for SSD) */
+	const bool pivoting = ncc || ts.h_from_acc || ts.h_extra != nullptr;   /* (the search and the row swap are two barriers and eight LDS reads per step: skipped for SSD) */
 	const double si = pow2_scale(h_entry(i, i)), sj = pow2_scale(h_entry(j, j));
 	double *trec = (ts.trace && n_it_prev < ts.trace_cap) ? ts.trace + ((size_t)t * ts.trace_cap + n_it_prev) * kTraceStride : nullptr;   /* debug trace */
 	if (wv0) {

@@ -109,6 +109,11 @@ struct TrackState {
 	 * [80..87] corners after it | [88] f [89] pass [90] Levenberg-Marquardt undo [91] damping [92] 1 if H was recorded.  NULL: off. */
 	double *trace;
 	int trace_cap;
+	/* second-order term of the Hessian (sec_ord_hess; k_second_order_ssd's output [B][S * S], entry (r, c) at c S + r), added to the
+	 * first-order one times h_extra_scale (ESM SumOfStd halves the whole sum, NT/ESM.cc:339); the system is then solved with pivoting.
+	 * NULL: none. */
+	const double *h_extra;
+	double h_extra_scale;
 };
 constexpr int kLmStride = 12;
 constexpr int kTraceStride = 96;
@@ -289,7 +294,7 @@ void launch_weighted_plane_sum(const BatchView &bv, const double *d2a, const dou
 void launch_mean_planes(const double *a, const double *b, double *o, size_t n, hipStream_t st);
 /* fused second-order term of the SSD Hessians, pixel-Hessian blocks in registers only; out[t][S*S] */
 void launch_second_order_ssd(const BatchView &bv, const ImgView &im, int term, int chained, int d0_variant, double grad_eps,
-	double hess_eps, double norm_mult, double norm_add, double *partials, int nblk, double *out, hipStream_t st);
+	double hess_eps, double norm_mult, double norm_add, double *partials, int nblk, double *out, hipStream_t st, int own_pts = 0);
 /* pre-processing / pyramid (float32 images) */
 void launch_hist_eq(float *gray, int rows, int cols, unsigned *hist256, float *lut256, hipStream_t st);
 void launch_to_gray(const void *raw, int rows, int cols, size_t stride_bytes, int channels, int depth_f32, float *out, hipStream_t st);

@@ -338,22 +338,53 @@ def test_second_order_self_hessian_ncc_not_implemented(gpu_ctx, frame):
         nt.initialize(synth.square_corners(250, 250, 60)[None])
 
 
-def test_device_loop_refuses_second_order_hessians(gpu_ctx, frame):
-    """mtfhip_batch_track solves with an unpivoted Gauss-Jordan on the device, fine for the definite first-order
-    Hessians only; a second-order Hessian has to go through iterate + the pivoted host solve.  SSD's self Hessians
-    are first order by definition, so those configurations still run on the device."""
+@pytest.mark.parametrize("sm_kind,ssm,extra", [
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, dict(hess_type=5)), (L.SM_ESM, L.SSM_AFFINE, dict(hess_type=4)), (L.SM_ESM, L.SSM_HOMOGRAPHY, dict(hess_type=3, jac_type=0)),
+    (L.SM_ESM, L.SSM_AFFINE, dict(hess_type=5, chained_warp=0)), (L.SM_FCLK, L.SSM_HOMOGRAPHY, dict(hess_type=2)),
+    (L.SM_FCLK, L.SSM_AFFINE, dict(hess_type=2, chained_warp=0)), (L.SM_ICLK, L.SSM_AFFINE, dict(hess_type=2)),
+    (L.SM_ICLK, L.SSM_HOMOGRAPHY, dict(hess_type=2)), (L.SM_ESM, L.SSM_HOMOGRAPHY, dict(hess_type=5, leven_marq=1))],
+    ids=lambda v: "_".join("%s%s" % kv for kv in v.items()) if isinstance(v, dict) else str(v))
+def test_device_loop_second_order_hessians(oracle, gpu_ctx, frame, sm_kind, ssm, extra):
+    """mtfhip_batch_track with sec_ord_hess (SSD): the second-order term of every search method's Hessian
+    (NT/ESM.cc:315-377, NT/FCLK.cc:262-283, NT/ICLK.cc:204-252; SSDBase.cc:313-415) is taken by one more pixel pass per
+    iteration and the finish solves the (indefinite) system with pivoting -- final corners, iteration counts and the
+    per-pass H / g / update of the trace against the oracle's second-order trackers"""
+    rng = np.random.default_rng(29)
+    res, B = 30, 3
+    p_true = synth.random_small_homography(rng, 0.35)
+    frame_b = synth.warp_frame(frame, p_true, (256.0, 256.0))
+    corners = np.stack([synth.square_corners(180.0 + 70 * i, 210.0 + 30 * i, 66) + 0.25 * i for i in range(B)])
+    params = dict(leven_marq=0, max_iters=12, epsilon=1e-5, sec_ord_hess=1)
+    params.update(extra)
     gpu_ctx.set_image(frame)
-    trk = LKTracker(gpu_ctx, L.SM_FCLK, L.SSM_HOMOGRAPHY, 30, 30, 2, host_solve=False, sec_ord_hess=1, hess_type=2, max_iters=5)
-    c = np.stack([synth.square_corners(200, 200, 60), synth.square_corners(300, 280, 60)])
-    trk.initialize(c)
+    b = mtf_amd.Batch(gpu_ctx, L.AM_SSD, ssm, res, res, B)
+    b.set_math_mode(mtf_amd.MATH_REPLAY)
+    b.set_corners(corners)
+    sm = mtf_amd.sm_desc(sm_kind, materialize=0, **params)
+    b.init_template(sm)
+    gpu_ctx.set_image(frame_b)
+    b.track_trace(params["max_iters"] * 2)
+    n_it, final = b.track(sm)
+    recs = b.read_track_trace(n_it)
+    rel = lambda a, r: float(np.linalg.norm(np.asarray(a) - np.asarray(r)) / max(np.linalg.norm(r), 1e-300))
+    for t in range(B):
+        o_ssm = oracle.SSM(ssm, res, res); o_am = oracle.AM(L.AM_SSD, res, res); o_am.set_curr_img(frame)
+        trk = oracle.Tracker(sm_kind, o_am, o_ssm, **params)
+        trk.initialize(corners[t]); o_am.set_curr_img(frame_b)
+        iters = trk.update()
+        tr = trk.trace()
+        np.testing.assert_allclose(final[t], trk.get_region(), rtol=0, atol=2e-4)
+        assert abs(int(n_it[t]) - iters) <= 1
+        # first pass: identical state -> H (with its second-order term), g and the update directly
+        d0 = [r for r in recs[t] if not r["undo"]][0]
+        assert d0["has_H"] and rel(d0["H"], tr[0]["H"]) < 1e-5 and rel(d0["g"], tr[0]["g"]) < 1e-5 and rel(d0["dp"], tr[0]["dp"]) < 1e-5
+    b.track_trace(0); b.close()
+    # NCC / MI second order stay with iterate and the per-function entry points
+    gpu_ctx.set_image(frame)
+    trk = LKTracker(gpu_ctx, L.SM_FCLK, L.SSM_HOMOGRAPHY, 30, 30, 2, host_solve=False, am=L.AM_NCC, sec_ord_hess=1, hess_type=2, max_iters=5)
     with pytest.raises(mtf_amd.FunctionNotImplemented):
+        trk.initialize(corners[:2])
         trk.update()
-    ok = LKTracker(gpu_ctx, L.SM_FCLK, L.SSM_HOMOGRAPHY, 30, 30, 2, host_solve=False, sec_ord_hess=1, hess_type=1, max_iters=5)
-    ok.initialize(c)
-    np.testing.assert_allclose(ok.update(), c, atol=1e-6)     # same frame: already converged
-    hs = LKTracker(gpu_ctx, L.SM_FCLK, L.SSM_HOMOGRAPHY, 30, 30, 2, host_solve=True, sec_ord_hess=1, hess_type=2, max_iters=5)
-    hs.initialize(c)
-    np.testing.assert_allclose(hs.update(), c, atol=1e-6)
 
 
 # ------------------------------------------------------------------ multi-channel appearance models (mc::)
