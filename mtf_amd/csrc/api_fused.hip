@@ -1006,7 +1006,6 @@ int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int C
 	if (!b || !dev_states) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: NULL argument");
 	if (C <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: n_candidates must be positive");
 	if (b->desc.am == MTFHIP_AM_MI) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "score_candidates: SSD and NCC");
-	TRY(single_channel(b, "score_candidates"));
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "score_candidates before the template was initialised");
 	TRY(need_image(b));
 	TimedScope ts(b->ctx, "score_candidates");
@@ -1017,7 +1016,8 @@ int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int C
 		ncc_sc = b->d_ncc;
 	}
 	/* (view_raw: the candidates bring their own warps; a stale device copy of the batch's warp is not uploaded for them) */
-	launch_score_candidates(b->view_raw(), b->ctx->img, dev_states, C, b->desc.likelihood_alpha, ncc_sc, dev_lik, dev_sim, b->math_mode == MTFHIP_MATH_FAST, b->ctx->stream);
+	launch_score_candidates(b->view_raw(), b->ctx->img, dev_states, C, b->desc.likelihood_alpha, b->norm_mult, b->norm_add, ncc_sc, dev_lik, dev_sim,
+		b->math_mode == MTFHIP_MATH_FAST, b->ctx->stream);
 	return MTFHIP_OK;
 }
 

@@ -243,7 +243,6 @@ int mtfhip_pf_create(mtfhip_batch *b, const mtfhip_pf_desc *d, mtfhip_pf **out) 
 		d->mean_type < 0 || d->mean_type > 2) return fail(MTFHIP_ERR_INVALID_ARG, "pf_create: enum value out of range (PFParams.h:10-33)");
 	if (d->resampling_type < 0 || d->resampling_type > 3) return fail(MTFHIP_ERR_INVALID_ARG, "pf_create: unknown resampling type %d", d->resampling_type);
 	if (b->desc.am == MTFHIP_AM_MI) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "pf_create: candidate scoring covers SSD and NCC");
-	TRY(single_channel(b, "pf_create"));
 	int sampler = 0, nz = 0;
 	TRY(pf_pick_sampler(b, d, &sampler, &nz));
 	mtfhip_pf *pf = new mtfhip_pf;

@@ -1,172 +1,11 @@
 /*
- * kernels_batch.hip -- the batch axis: PF / NN candidate scoring and sampling, GridTracker's one-launch ICLK patch loop
+ * kernels_batch.hip -- the batch axis: NN candidate sampling, GridTracker's one-launch ICLK patch loop (candidate scoring: k_pf_score,
+ * kernels_pf.hip)
  * (one of the translation units of libmtfhip.so; conventions and the shared device helpers: mtfhip_device.h)
  */
 #include "mtfhip_device.h"
 
 namespace mtfhip {
-
-/* ===================================================================== */
-/* candidate scoring (PF / NN batch axis)                                 */
-/* ===================================================================== */
-/* One wave64 per candidate: setState -> updatePixVals -> updateSimilarity -> likelihood
- * (SM/src/PF.cc:247-262, ProjectiveBase.cc:41-49, SSDBase.cc:75-96, SSD.h:41-43). */
-/* ncc_sc: NULL for SSD; for NCC the template's scalars ([0] mean(I0), [1] |I0 - mean|): the candidate's similarity is
- * a / (b c) from the raw moments sum It, sum It^2, sum I0 It of its own samples (NCC.cc:124-161), its likelihood
- * exp(-alpha (1/f - 1)^2) (NCC.cc:50-53) */
-template <bool FAST>   /* FAST: tolerance-mode arithmetic (mtfhip_device.h): one reciprocal per point, factored interpolant, FMAs */
-__global__ __launch_bounds__(kBlock) void k_score_candidates(BatchView bv, ImgView im, const double *states, int C,
-	double alpha, double norm_mult, double norm_add, const double *ncc_sc, double *lik, double *sim) {
-	const int lane = threadIdx.x & 63;
-	const int cand = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-	if (cand >= C) return;
-	const int N = bv.N, S = bv.S;
-	const double *p = states + (size_t)cand * S;
-	double W[9];
-	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
-		W[0] = 1 + p[0]; W[1] = p[1]; W[2] = p[2]; W[3] = p[3]; W[4] = 1 + p[4]; W[5] = p[5];
-		W[6] = p[6]; W[7] = p[7]; W[8] = 1;
-	} else {
-		W[0] = 1 + p[2]; W[1] = p[3]; W[2] = p[0]; W[3] = p[4]; W[4] = 1 + p[5]; W[5] = p[1];
-		W[6] = 0; W[7] = 0; W[8] = 1;
-	}
-	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]);
-	const double *iz = bv.buf[MTFHIP_BUF_INIT_Z];
-	const double2 *ih = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]);
-	const double *I0 = bv.buf[MTFHIP_BUF_I0];
-	double acc = 0.0, s_it = 0.0, s_i0it = 0.0;
-	for (int i = lane; i < N; i += 64) {
-		double2 q = bv.unit_z ? ip[i] : ih[i];
-		double z = bv.unit_z ? 1.0 : iz[i];
-		double hx = q.x, hy = q.y;
-		double wx, wy, it;
-		if constexpr (FAST) {
-			wx = fma(W[0], hx, fma(W[1], hy, W[2] * z));
-			wy = fma(W[3], hx, fma(W[4], hy, W[5] * z));
-			if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
-				const double inv = rcp_fast(fma(W[6], hx, fma(W[7], hy, W[8] * z)));
-				wx *= inv; wy *= inv;
-			}
-			it = fma(norm_mult, pix_val_fast(im, wx, wy), norm_add);
-		} else {
-			if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) {
-				double cx = W[0] * hx + W[1] * hy + W[2] * z;
-				double cy = W[3] * hx + W[4] * hy + W[5] * z;
-				double d = W[6] * hx + W[7] * hy + W[8] * z;
-				wx = cx / d; wy = cy / d;
-			} else {
-				wx = W[0] * hx + W[1] * hy + W[2] * z;
-				wy = W[3] * hx + W[4] * hy + W[5] * z;
-			}
-			it = norm_mult * pix_val(im, wx, wy) + norm_add;
-		}
-		const double i0 = I0[i];
-		if (ncc_sc) { s_it += it; acc = fma(it, it, acc); s_i0it = fma(i0, it, s_i0it); }
-		else { const double r = it - i0; acc = fma(r, r, acc); }
-	}
-#pragma unroll
-	for (int m = 32; m >= 1; m >>= 1) { acc += __shfl_xor(acc, m); s_it += __shfl_xor(s_it, m); s_i0it += __shfl_xor(s_i0it, m); }
-	if (lane == 0) {
-		if (ncc_sc) {
-			const double n = (double)N, m0 = ncc_sc[0], c = ncc_sc[1], mt = s_it / n;
-			const double f = (s_i0it - n * m0 * mt) / (sqrt(acc - n * mt * mt) * c);
-			if (sim) sim[cand] = f;
-			if (lik) { const double d = (1.0 / f) - 1; lik[cand] = exp(-alpha * d * d); }
-		} else {
-			double f = -acc / 2;
-			if (sim) sim[cand] = f;
-			if (lik) lik[cand] = exp(-alpha * sqrt(-f / (double)N));
-		}
-	}
-}
-
-
-
-/* Tolerance-mode scorer (MTFHIP_MATH_FAST).  PMC of the kernel above on config 4 (10 000 x 2 500 samples, profiles/
- * r02_base_pf_pmc_summary.txt and r02_pf_pmc_summary.txt): 84-110 VALU instructions per 64 samples of which only ~30 are
- * FP64 arithmetic (the rest: 64-bit addressing, clamps, conversions, the second IEEE division), and the texture
- * addresser is busy 76 % of the time -- six gather instructions per 64 samples, two of them re-fetching the grid point and
- * the template value every candidate fetches.  Here one workgroup scores K = 4 candidates: each wave takes a quarter of
- * the pixels and evaluates all four warps on every grid point it loads (2 + 2 K loads per K samples instead of 6 K), the
- * two texels of a cell row come in one 8-byte load, the warps live in scalar registers (the candidate index is uniform
- * per workgroup), addresses are 32-bit offsets from uniform bases, and the interior case (every lane of the wave samples
- * an interior cell: the normal case) runs without clamps or selects; anything else takes pix_val_fast. */
-struct __attribute__((packed, aligned(4))) TexPair { float a, b; };
-template <int SSM, bool NCC>
-__global__ __launch_bounds__(kBlock) void k_score_candidates_fast(BatchView bv, ImgView im, const double *__restrict__ states, int C,
-	double alpha, double norm_mult, double norm_add, const double *__restrict__ ncc_sc, double *lik, double *sim) {
-	constexpr int K = 4, M = NCC ? 3 : 1, S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
-	__shared__ double red[4 * K * M], tot[K * M];
-	const int c0 = blockIdx.x * K;
-	double W[K][9];
-#pragma unroll
-	for (int k = 0; k < K; ++k) {
-		const double *p = states + (size_t)min(c0 + k, C - 1) * S;   /* uniform address: scalar loads */
-		if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
-			W[k][0] = 1 + p[0]; W[k][1] = p[1]; W[k][2] = p[2]; W[k][3] = p[3]; W[k][4] = 1 + p[4]; W[k][5] = p[5];
-			W[k][6] = p[6]; W[k][7] = p[7]; W[k][8] = 1;
-		} else {
-			W[k][0] = 1 + p[2]; W[k][1] = p[3]; W[k][2] = p[0]; W[k][3] = p[4]; W[k][4] = 1 + p[5]; W[k][5] = p[1];
-			W[k][6] = 0; W[k][7] = 0; W[k][8] = 1;
-		}
-	}
-	const unsigned N = (unsigned)bv.N;
-	const bool uz = bv.unit_z != 0;
-	const double *__restrict__ pp = bv.buf[uz ? MTFHIP_BUF_INIT_PTS : MTFHIP_BUF_INIT_HXY];
-	const double *__restrict__ iz = bv.buf[MTFHIP_BUF_INIT_Z];
-	const double *__restrict__ I0 = bv.buf[MTFHIP_BUF_I0];
-	const float *__restrict__ img = im.data;
-	const int iw1 = im.w - 1, ih1 = im.h - 1, stride = im.stride;
-	double acc[K * M];
-#pragma unroll
-	for (int k = 0; k < K * M; ++k) acc[k] = 0.0;
-	for (unsigned i = threadIdx.x; i < N; i += kBlock) {
-		const double2 q = ld_off<double2>(pp, i * 16u);
-		const double z = uz ? 1.0 : ld_off<double>(iz, i * 8u);
-		const double i0 = ld_off<double>(I0, i * 8u);
-#pragma unroll
-		for (int k = 0; k < K; ++k) {
-			double wx = fma(W[k][0], q.x, fma(W[k][1], q.y, uz ? W[k][2] : W[k][2] * z));
-			double wy = fma(W[k][3], q.x, fma(W[k][4], q.y, uz ? W[k][5] : W[k][5] * z));
-			if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
-				const double inv = rcp_fast(fma(W[k][6], q.x, fma(W[k][7], q.y, uz ? W[k][8] : W[k][8] * z)));
-				wx *= inv; wy *= inv;
-			}
-			const int lx = (int)wx, ly = (int)wy;
-			const bool ok = (wx >= 0) & (wy >= 0) & (lx < iw1) & (ly < ih1);
-			double v;
-			if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
-				const unsigned off = (unsigned)(ly * stride + lx) * 4u;
-				const TexPair t0 = ld_off<TexPair>(img, off), t1 = ld_off<TexPair>(img + stride, off);
-				v = bilin_val_fast(t0.a, t0.b, t1.a, t1.b, wx - (double)lx, wy - (double)ly);
-			} else {
-				v = pix_val_fast(im, wx, wy);
-			}
-			const double it = fma(norm_mult, v, norm_add);
-			if constexpr (NCC) {
-				acc[3 * k] += it; acc[3 * k + 1] = fma(it, it, acc[3 * k + 1]); acc[3 * k + 2] = fma(i0, it, acc[3 * k + 2]);
-			} else {
-				const double r = it - i0;
-				acc[k] = fma(r, r, acc[k]);
-			}
-		}
-	}
-	block_reduce_store<K * M>(acc, tot, red);
-	__syncthreads();
-	const int k = threadIdx.x, cand = c0 + k;
-	if (k < K && cand < C) {
-		if constexpr (NCC) {
-			const double n = (double)N, m0 = ncc_sc[0], c = ncc_sc[1], mt = tot[3 * k] / n;
-			const double f = (tot[3 * k + 2] - n * m0 * mt) / (sqrt(tot[3 * k + 1] - n * mt * mt) * c);
-			if (sim) sim[cand] = f;
-			if (lik) { const double d = (1.0 / f) - 1; lik[cand] = exp(-alpha * d * d); }
-		} else {
-			const double f = -tot[k] / 2;
-			if (sim) sim[cand] = f;
-			if (lik) lik[cand] = exp(-alpha * sqrt(-f / (double)N));
-		}
-	}
-}
 
 /* ===================================================================== */
 /* one-launch inverse-compositional tracker for small patches (GridTracker) */
@@ -665,24 +504,6 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 /* ===================================================================== */
 /* launchers                                                              */
 /* ===================================================================== */
-
-void launch_score_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C,
-	double likelihood_alpha, const double *ncc_sc, double *dev_lik, double *dev_sim, int fast_math, hipStream_t st) {
-	int nb = (C + (kBlock / 64) - 1) / (kBlock / 64);
-	if (fast_math) {
-		const dim3 g((C + 3) / 4);
-		const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY;
-#define MTFHIP_SCORE_FAST(SSM_, NCC_) MTFHIP_LAUNCH((k_score_candidates_fast<SSM_, NCC_>), g, dim3(kBlock), 0, st, bv, im, dev_states, C, \
-			likelihood_alpha, 1.0, 0.0, ncc_sc, dev_lik, dev_sim)
-		if (hom && ncc_sc) MTFHIP_SCORE_FAST(MTFHIP_SSM_HOMOGRAPHY, true);
-		else if (hom) MTFHIP_SCORE_FAST(MTFHIP_SSM_HOMOGRAPHY, false);
-		else if (ncc_sc) MTFHIP_SCORE_FAST(MTFHIP_SSM_AFFINE, true);
-		else MTFHIP_SCORE_FAST(MTFHIP_SSM_AFFINE, false);
-#undef MTFHIP_SCORE_FAST
-	} else
-		MTFHIP_LAUNCH(k_score_candidates<false>, dim3(nb), dim3(kBlock), 0, st, bv, im, dev_states, C, likelihood_alpha,
-			1.0, 0.0, ncc_sc, dev_lik, dev_sim);
-}
 
 template <int AM, bool FAST>
 static bool launch_iclk_track_am(const BatchView &bv, const ImgView &im, const mtfhip_sm_desc &sm, const TrackState &ts,

@@ -340,7 +340,10 @@ struct PfScoreArgs {
 	double *sim;                   /* [n] similarities or NULL */
 };
 struct __attribute__((packed, aligned(4))) PfTexPair { float a, b; };
-template <int SSM, bool NCC, bool FAST>
+/* MC: the multi-channel models (MCSSD / MCNCC = SSD / NCC built with n_channels = 3, AM/src/MCSSD.cc): a row of the per-pixel
+ * arrays is a (pixel, channel) pair, row = pixel * C + channel (mc::getPixVals imgUtils.cc:867-882); the grid point is the
+ * pixel's, the texels the channel's (interleaved image); replay arithmetic uses mc::PixVal's weights-first order (pix_val_mc). */
+template <int SSM, bool NCC, bool FAST, bool MC>
 __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, PfScoreArgs s) {
 	constexpr int K = 4, M = NCC ? 3 : 1, S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
 	__shared__ double red[4 * K * M], tot[K * M];
@@ -350,6 +353,7 @@ __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, P
 #pragma unroll
 	for (int k = 0; k < K; ++k) warp_from_state_dev<SSM>(s.prop + (size_t)min(c0 + k, cend - 1) * S, W[k]);   /* uniform address: scalar loads */
 	const unsigned N = (unsigned)bv.N;
+	const unsigned Cc = MC ? (unsigned)bv.C : 1u;
 	const bool uz = bv.unit_z != 0;
 	const double *__restrict__ pp = bv.buf[uz ? MTFHIP_BUF_INIT_PTS : MTFHIP_BUF_INIT_HXY];
 	const double *__restrict__ iz = bv.buf[MTFHIP_BUF_INIT_Z];
@@ -360,8 +364,10 @@ __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, P
 #pragma unroll
 	for (int k = 0; k < K * M; ++k) acc[k] = 0.0;
 	for (unsigned i = tid; i < N; i += kBlock) {
-		const double2 q = ld_off<double2>(pp, i * 16u);
-		const double z = uz ? 1.0 : ld_off<double>(iz, i * 8u);
+		const unsigned pi = MC ? i / Cc : i;          /* the row's pixel */
+		const int ch = MC ? (int)(i - pi * Cc) : 0;   /* ... and channel */
+		const double2 q = ld_off<double2>(pp, pi * 16u);
+		const double z = uz ? 1.0 : ld_off<double>(iz, pi * 8u);
 		const double i0 = ld_off<double>(I0, i * 8u);
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
@@ -377,20 +383,27 @@ __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, P
 				const bool ok = (wx >= 0) & (wy >= 0) & (lx < iw1) & (ly < ih1);
 				double v;
 				if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
-					const unsigned off = (unsigned)(ly * stride + lx) * 4u;
-					const PfTexPair t0 = ld_off<PfTexPair>(img, off), t1 = ld_off<PfTexPair>(img + stride, off);
-					v = bilin_val_fast(t0.a, t0.b, t1.a, t1.b, wx - (double)lx, wy - (double)ly);
+					if constexpr (MC) {
+						const unsigned off = (unsigned)(ly * stride + lx * (int)Cc + ch) * 4u;
+						const float t00 = ld_off<float>(img, off), t01 = ld_off<float>(img, off + 4u * Cc);
+						const float t10 = ld_off<float>(img + stride, off), t11 = ld_off<float>(img + stride, off + 4u * Cc);
+						v = bilin_val_fast(t00, t01, t10, t11, wx - (double)lx, wy - (double)ly);
+					} else {
+						const unsigned off = (unsigned)(ly * stride + lx) * 4u;
+						const PfTexPair t0 = ld_off<PfTexPair>(img, off), t1 = ld_off<PfTexPair>(img + stride, off);
+						v = bilin_val_fast(t0.a, t0.b, t1.a, t1.b, wx - (double)lx, wy - (double)ly);
+					}
 				} else {
-					v = pix_val_fast(im, wx, wy);
+					if constexpr (MC) v = pix_val_mc(im, wx, wy, ch); else v = pix_val_fast(im, wx, wy);
 				}
 				it = fma(s.norm_mult, v, s.norm_add);
-			} else {   /* the reference's operation order (ProjectiveBase.cc:41-49, imgUtils.h:91-113) */
+			} else {   /* the reference's operation order (ProjectiveBase.cc:41-49, imgUtils.h:91-113, 505-551) */
 				double wx = W[k][0] * q.x + W[k][1] * q.y + W[k][2] * z, wy = W[k][3] * q.x + W[k][4] * q.y + W[k][5] * z;
 				if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
 					const double d = W[k][6] * q.x + W[k][7] * q.y + W[k][8] * z;
 					wx = wx / d; wy = wy / d;
 				}
-				it = s.norm_mult * pix_val(im, wx, wy) + s.norm_add;
+				it = s.norm_mult * (MC ? pix_val_mc(im, wx, wy, ch) : pix_val(im, wx, wy)) + s.norm_add;
 			}
 			if constexpr (NCC) {
 				acc[3 * k] += it; acc[3 * k + 1] = fma(it, it, acc[3 * k + 1]); acc[3 * k + 2] = fma(i0, it, acc[3 * k + 2]);
@@ -421,7 +434,7 @@ __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, P
 			w = s.likelihood_func == 1 ? (1.0 / sqrt(2 * pi * s.measurement_sigma)) * exp(-0.5 * val / s.measurement_sigma)   /* PF.cc:69-70, 352-354 */
 			                           : 1.0 / (1.0 + val);
 		}
-		s.wts[cand] = w;
+		if (s.wts) s.wts[cand] = w;
 		if (s.sim) s.sim[cand] = f;
 	}
 }
@@ -789,24 +802,39 @@ void launch_pf_propose(int ssm, const PfLaunch &p, const double *st_in, const do
 	if (ssm == MTFHIP_SSM_HOMOGRAPHY) MTFHIP_LAUNCH(k_pf_propose<MTFHIP_SSM_HOMOGRAPHY>, g, dim3(kBlock), 0, st, a, st_in, ar_in, st_out, ar_out);
 	else MTFHIP_LAUNCH(k_pf_propose<MTFHIP_SSM_AFFINE>, g, dim3(kBlock), 0, st, a, st_in, ar_in, st_out, ar_out);
 }
+static void launch_pf_score_args(const BatchView &bv, const ImgView &im, const PfScoreArgs &s, int fast_math, hipStream_t st) {
+	if (s.cnt <= 0) return;
+	const dim3 g((s.cnt + 3) / 4);
+	const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY, ncc = s.ncc_sc != nullptr, mc = bv.C > 1;
+#define MTFHIP_PF_SCORE(SSM_, NCC_, FAST_, MC_) MTFHIP_LAUNCH((k_pf_score<SSM_, NCC_, FAST_, MC_>), g, dim3(kBlock), 0, st, bv, im, s)
+#define MTFHIP_PF_SCORE_MC(SSM_, NCC_, FAST_) do { if (mc) MTFHIP_PF_SCORE(SSM_, NCC_, FAST_, true); else MTFHIP_PF_SCORE(SSM_, NCC_, FAST_, false); } while (0)
+	if (fast_math) {
+		if (hom) { if (ncc) MTFHIP_PF_SCORE_MC(MTFHIP_SSM_HOMOGRAPHY, true, true); else MTFHIP_PF_SCORE_MC(MTFHIP_SSM_HOMOGRAPHY, false, true); }
+		else { if (ncc) MTFHIP_PF_SCORE_MC(MTFHIP_SSM_AFFINE, true, true); else MTFHIP_PF_SCORE_MC(MTFHIP_SSM_AFFINE, false, true); }
+	} else {
+		if (hom) { if (ncc) MTFHIP_PF_SCORE_MC(MTFHIP_SSM_HOMOGRAPHY, true, false); else MTFHIP_PF_SCORE_MC(MTFHIP_SSM_HOMOGRAPHY, false, false); }
+		else { if (ncc) MTFHIP_PF_SCORE_MC(MTFHIP_SSM_AFFINE, true, false); else MTFHIP_PF_SCORE_MC(MTFHIP_SSM_AFFINE, false, false); }
+	}
+#undef MTFHIP_PF_SCORE_MC
+#undef MTFHIP_PF_SCORE
+}
 void launch_pf_score(const BatchView &bv, const ImgView &im, const PfLaunch &p, const PfBuffers &bf, int lo, int cnt,
 	double alpha, double norm_mult, double norm_add, const double *ncc_sc, int fast_math, hipStream_t st) {
-	if (cnt <= 0) return;
 	PfScoreArgs s;
 	s.prop = bf.prop; s.lo = lo; s.cnt = cnt; s.alpha = alpha; s.norm_mult = norm_mult; s.norm_add = norm_add; s.ncc_sc = ncc_sc;
 	s.likelihood_func = p.likelihood_func; s.measurement_sigma = p.measurement_sigma; s.max_similarity = p.max_similarity;
 	s.wts = bf.wts; s.sim = bf.sim;
-	const dim3 g((cnt + 3) / 4);
-#define MTFHIP_PF_SCORE(SSM_, NCC_, FAST_) MTFHIP_LAUNCH((k_pf_score<SSM_, NCC_, FAST_>), g, dim3(kBlock), 0, st, bv, im, s)
-	const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY, ncc = ncc_sc != nullptr;
-	if (fast_math) {
-		if (hom) { if (ncc) MTFHIP_PF_SCORE(MTFHIP_SSM_HOMOGRAPHY, true, true); else MTFHIP_PF_SCORE(MTFHIP_SSM_HOMOGRAPHY, false, true); }
-		else { if (ncc) MTFHIP_PF_SCORE(MTFHIP_SSM_AFFINE, true, true); else MTFHIP_PF_SCORE(MTFHIP_SSM_AFFINE, false, true); }
-	} else {
-		if (hom) { if (ncc) MTFHIP_PF_SCORE(MTFHIP_SSM_HOMOGRAPHY, true, false); else MTFHIP_PF_SCORE(MTFHIP_SSM_HOMOGRAPHY, false, false); }
-		else { if (ncc) MTFHIP_PF_SCORE(MTFHIP_SSM_AFFINE, true, false); else MTFHIP_PF_SCORE(MTFHIP_SSM_AFFINE, false, false); }
-	}
-#undef MTFHIP_PF_SCORE
+	launch_pf_score_args(bv, im, s, fast_math, st);
+}
+/* candidate scoring outside the filter (mtfhip_score_candidates: PF.cc:247-262 per candidate, NN): the same kernel with the AM's own
+ * likelihood as the weight */
+void launch_score_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C,
+	double likelihood_alpha, double norm_mult, double norm_add, const double *ncc_sc, double *dev_lik, double *dev_sim, int fast_math, hipStream_t st) {
+	PfScoreArgs s;
+	s.prop = dev_states; s.lo = 0; s.cnt = C; s.alpha = likelihood_alpha; s.norm_mult = norm_mult; s.norm_add = norm_add; s.ncc_sc = ncc_sc;
+	s.likelihood_func = 0; s.measurement_sigma = 1.0; s.max_similarity = 0.0;
+	s.wts = dev_lik; s.sim = dev_sim;
+	launch_pf_score_args(bv, im, s, fast_math, st);
 }
 void launch_pf_scan(const PfLaunch &p, const PfBuffers &bf, hipStream_t st) {
 	const int nch = (p.n + kPfChunk - 1) / kPfChunk;

@@ -282,7 +282,7 @@ void launch_fused_ssd(const BatchView &bv, const ImgView &im, const FusedArgs &f
 	int nblk, hipStream_t st);
 /* candidate scoring: target 0's template under C warps given as states */
 void launch_score_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C,
-	double likelihood_alpha, const double *ncc_sc, double *dev_lik, double *dev_sim, int fast_math, hipStream_t st);
+	double likelihood_alpha, double norm_mult, double norm_add, const double *ncc_sc, double *dev_lik, double *dev_sim, int fast_math, hipStream_t st);
 /* second-order path: hess_pts, image Hessians ([N][4]), SSM pixel Hessians ([S*S][N] planes), sum_p w[p] d2[:, p] */
 void launch_hess_pts(const BatchView &bv, double eps, hipStream_t st);
 void launch_img_hess(const BatchView &bv, const ImgView &im, const double *pts, double *hess, double eps, double mult, hipStream_t st);

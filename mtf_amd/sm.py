@@ -434,9 +434,10 @@ class ParticleFilter:
                  ssm_sigma=(0.01, 0.01, 2.0, 0.01, 0.01, 2.0, 1e-5, 1e-5), ssm_mean=(0.0,) * 8, likelihood_alpha=1.0,
                  max_iters=1, epsilon=0.01, seed=0, am=L.AM_SSD, dynamic_model=0, update_type=1, likelihood_func=0,
                  resampling_type=1, mean_type=0, corner_based_sampling=0, reset_to_mean=0, measurement_sigma=0.1, ar_coeff=0.5,
-                 comm=None, pt_based_sampling=0):
+                 comm=None, pt_based_sampling=0, n_channels=1):
         import ctypes as C
-        self.batch = Batch(ctx, am, ssm, resx, resy, 1, likelihood_alpha=likelihood_alpha)
+        # n_channels = 3: MCSSD / MCNCC (the context then holds an H x W x 3 float32 frame)
+        self.batch = Batch(ctx, am, ssm, resx, resy, 1, likelihood_alpha=likelihood_alpha, n_channels=n_channels)
         self.S, self.n = self.batch.S, n_particles
         self.desc = L.PFDesc(n_particles, max_iters, epsilon, dynamic_model, update_type, likelihood_func, resampling_type, mean_type,
                              corner_based_sampling, reset_to_mean, measurement_sigma, ar_coeff)

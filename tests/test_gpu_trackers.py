@@ -387,6 +387,51 @@ def test_device_loop_second_order_hessians(oracle, gpu_ctx, frame, sm_kind, ssm,
         trk.update()
 
 
+@pytest.mark.parametrize("am", [L.AM_SSD, L.AM_NCC])
+@pytest.mark.parametrize("math", [mtf_amd.MATH_REPLAY, mtf_amd.MATH_FAST])
+def test_multichannel_candidate_scores_and_particle_filter(oracle, gpu_ctx, am, math):
+    """The candidate scorer and the particle filter over MCSSD / MCNCC (n_channels = 3, 32FC3 frame): one row per (pixel,
+    channel), the pixel's grid point shared by its three rows, mc::PixVal's interpolation order -- candidate likelihoods and
+    similarities against the oracle's per-candidate loop, then two filter iterations against its nt::PF restatement on shared
+    draws"""
+    rng = np.random.default_rng(41)
+    res, n = 20, 300
+    frame = synth.make_frame_mc(256, 256)
+    corners = synth.square_corners(128.0, 120.0, 70.0) + rng.uniform(-1, 1, size=(2, 4))
+    alpha = 5.0 if am == L.AM_SSD else 500.0
+    o_ssm = oracle.SSM(0, res, res); o_am = oracle.AM(am, res, res, likelihood_alpha=alpha)
+    o_am.set_channels(3); o_ssm.set_channels(3)
+    o_am.set_curr_img(frame)
+    o_ssm.set_corners(corners); o_am.initialize_pix_vals(o_ssm.get("curr_pts")); o_am.initialize_similarity()
+    gpu_ctx.set_image(frame)
+    pf = ParticleFilter(gpu_ctx, L.SSM_HOMOGRAPHY, res, res, n_particles=n, am=am, likelihood_alpha=alpha, n_channels=3,
+                        ssm_sigma=(1.0, 0.6, 1, 1, 1, 1, 1, 1), corner_based_sampling=1, dynamic_model=1, mean_type=1)
+    pf.batch.set_math_mode(math)
+    pf.initialize(corners[None])
+    assert pf.batch.N == 3 * res * res
+    states = synth.pf_candidate_states(rng, 130)
+    lik_o, sim_o = oracle.pf_score(o_am, o_ssm, states)
+    lik, sim = pf.batch.score_candidates(states, want_similarity=True)
+    np.testing.assert_allclose(sim, sim_o, rtol=1e-9)
+    np.testing.assert_allclose(lik, lik_o, rtol=1e-9)
+    frame_b = synth.warp_frame(frame, np.array([0, 0, 1.1, 0, 0, -0.7, 0, 0]), (128.0, 120.0))
+    o_am.set_curr_img(frame_b); gpu_ctx.set_image(frame_b)
+    pp = oracle.pf_params(n, dynamic_model=1, update_type=1, mean_type=1, corner_based_sampling=1, sigma=(1.0, 0.6, 1, 1, 1, 1, 1, 1))
+    o_ssm.set_corners(corners)
+    st_o, ar_o = np.zeros((n, 8)), np.zeros((n, 8))
+    for it in range(2):
+        normals, uniforms = rng.normal(size=(n, 10)), rng.uniform(size=n)
+        st_o, ar_o, w_o, ids_o, _ = oracle.pf_iteration(o_am, o_ssm, pp, st_o, ar_o, normals, uniforms, pf.max_similarity)
+        pf.iteration(normals, uniforms)
+        st_d, ar_d, w_d, ids_d = pf.particles()
+        np.testing.assert_allclose(w_d, w_o, rtol=1e-9, atol=1e-300)
+        same = ids_d == ids_o
+        assert same.mean() > 0.99
+        np.testing.assert_allclose(st_d[same], st_o[same], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(pf.batch.get_state()[0], o_ssm.get("state"), rtol=1e-6, atol=1e-9)
+    pf.close()
+
+
 # ------------------------------------------------------------------ multi-channel appearance models (mc::)
 MC_CASES = [
     (L.SM_ESM, L.AM_SSD, L.SSM_HOMOGRAPHY, 30, dict()),                                  # MCSSD
