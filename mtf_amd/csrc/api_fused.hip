@@ -1001,14 +1001,33 @@ int mtfhip_batch_track_trace_read(mtfhip_batch *b, double *dst) {
 }
 
 /* ------------------------------------------------------------------ candidate scoring */
-int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int C, double *dev_lik, double *dev_sim) {
-	FLUSH_AM(b);   /* (every candidate warps the template grid itself: CURR_PTS are not read) */
-	if (!b || !dev_states) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: NULL argument");
-	if (C <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: n_candidates must be positive");
-	if (b->desc.am == MTFHIP_AM_MI) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "score_candidates: SSD and NCC");
-	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "score_candidates before the template was initialised");
-	TRY(need_image(b));
-	TimedScope ts(b->ctx, "score_candidates");
+/* candidates [lo, lo + cnt) of dev_states: weight (the AM's likelihood, or PF's Gaussian / reciprocal mapping of the similarity) and
+ * similarity at their global indices.  SSD / NCC (also multi-channel): k_pf_score; MI (8 bins): the histogram pass over the candidate
+ * axis + k_mi_cand_score.  Shared by mtfhip_score_candidates_dev and the particle filter. */
+int score_block_dev(mtfhip_batch *b, const double *dev_states, int lo, int cnt, double *wts, double *sim, int likelihood_func,
+	double measurement_sigma, double max_similarity) {
+	hipStream_t st = b->ctx->stream;
+	if (b->desc.am == MTFHIP_AM_MI) {
+		if (b->desc.mi_n_bins != 8) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "score_candidates: MI candidates are scored with 8 bins (the reference's default, parameters.h:344)");
+		if (b->C != 1) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "score_candidates: MCMI candidates are not available");
+		if (!b->init_sim) return fail(MTFHIP_ERR_LOGIC, "score_candidates before initializeSimilarity");
+		const int nblk = 1;
+		const size_t need = (size_t)std::max(cnt, 1) * nblk * b->mi_row_len;
+		if (need > b->cand_mi_capacity) {
+			HIP_TRY(hipStreamSynchronize(st));
+			if (b->d_cand_mi) (void)hipFree(b->d_cand_mi);
+			b->d_cand_mi = nullptr;
+			HIP_TRY(hipMalloc(&b->d_cand_mi, sizeof(double) * need));
+			b->cand_mi_capacity = need;
+		}
+		MiFastPlan fp;
+		fp.hk = 0; fp.hrow = 0; fp.j0_mode = 0; fp.j0_init_variant = 0; fp.need_dft = 0; fp.need_df0 = 0; fp.g_mean = 0;
+		fp.grad_eps = b->desc.grad_eps; fp.norm_mult = b->norm_mult; fp.norm_add = b->norm_add; fp.hist_norm = b->mi_hist_norm;
+		fp.active = nullptr; fp.tb = b->d_mi_tb;
+		launch_mi_score_candidates(b->view_raw(), b->ctx->img, fp, dev_states, lo, cnt, b->d_cand_mi, nblk, b->mi_row_len, b->desc.mi_pre_seed,
+			b->desc.likelihood_alpha, likelihood_func, measurement_sigma, max_similarity, wts, sim, st);
+		return MTFHIP_OK;
+	}
 	const double *ncc_sc = nullptr;
 	if (b->desc.am == MTFHIP_AM_NCC) {   /* mean(I0), |I0 - mean| of the template, as the un-fused NCC kernels read them */
 		if (!b->init_sim) return fail(MTFHIP_ERR_LOGIC, "score_candidates before initializeSimilarity");
@@ -1016,9 +1035,18 @@ int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int C
 		ncc_sc = b->d_ncc;
 	}
 	/* (view_raw: the candidates bring their own warps; a stale device copy of the batch's warp is not uploaded for them) */
-	launch_score_candidates(b->view_raw(), b->ctx->img, dev_states, C, b->desc.likelihood_alpha, b->norm_mult, b->norm_add, ncc_sc, dev_lik, dev_sim,
-		b->math_mode == MTFHIP_MATH_FAST, b->ctx->stream);
+	launch_score_block(b->view_raw(), b->ctx->img, dev_states, lo, cnt, b->desc.likelihood_alpha, b->norm_mult, b->norm_add, ncc_sc, wts, sim,
+		likelihood_func, measurement_sigma, max_similarity, b->math_mode == MTFHIP_MATH_FAST, st);
 	return MTFHIP_OK;
+}
+int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int C, double *dev_lik, double *dev_sim) {
+	FLUSH_AM(b);   /* (every candidate warps the template grid itself: CURR_PTS are not read) */
+	if (!b || !dev_states) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: NULL argument");
+	if (C <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "score_candidates: n_candidates must be positive");
+	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "score_candidates before the template was initialised");
+	TRY(need_image(b));
+	TimedScope ts(b->ctx, "score_candidates");
+	return score_block_dev(b, dev_states, 0, C, dev_lik, dev_sim, 0, 1.0, 0.0);
 }
 
 int mtfhip_score_candidates(mtfhip_batch *b, const double *states, int C, double *lik, double *sim) {

@@ -242,7 +242,7 @@ int mtfhip_pf_create(mtfhip_batch *b, const mtfhip_pf_desc *d, mtfhip_pf **out) 
 	if (d->dynamic_model < 0 || d->dynamic_model > 1 || d->update_type < 0 || d->update_type > 1 || d->likelihood_func < 0 || d->likelihood_func > 2 ||
 		d->mean_type < 0 || d->mean_type > 2) return fail(MTFHIP_ERR_INVALID_ARG, "pf_create: enum value out of range (PFParams.h:10-33)");
 	if (d->resampling_type < 0 || d->resampling_type > 3) return fail(MTFHIP_ERR_INVALID_ARG, "pf_create: unknown resampling type %d", d->resampling_type);
-	if (b->desc.am == MTFHIP_AM_MI) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "pf_create: candidate scoring covers SSD and NCC");
+	if (b->desc.am == MTFHIP_AM_MI && b->desc.mi_n_bins != 8) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "pf_create: MI particles are scored with 8 bins");
 	int sampler = 0, nz = 0;
 	TRY(pf_pick_sampler(b, d, &sampler, &nz));
 	mtfhip_pf *pf = new mtfhip_pf;
@@ -412,8 +412,6 @@ static int pf_enqueue_iteration(mtfhip_pf *pf, const double *normals, const doub
 		HIP_TRY(hipMemcpyAsync(pf->d_uniforms, uniforms, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
 		p.uniforms = pf->d_uniforms;
 	}
-	const double *ncc_sc = nullptr;
-	if (b->desc.am == MTFHIP_AM_NCC) { TRY(push_ncc(b)); ncc_sc = b->d_ncc; }   /* mean(I0), |I0 - mean| of the template */
 	const size_t nch = pf_round_chunk((size_t)n) / (size_t)pf_chunk();
 	const mtfhip_comm *c = pf->comm;
 	const bool sharded = c && c->world > 1;
@@ -437,8 +435,7 @@ static int pf_enqueue_iteration(mtfhip_pf *pf, const double *normals, const doub
 	/* scoring: setState -> updatePixVals -> updateSimilarity -> likelihood per particle (PF.cc:341-365); sharded: this rank's block */
 	{
 		TimedScope ts(b->ctx, "pf_score");
-		launch_pf_score(b->view_raw(), b->ctx->img, p, bf, lo, cnt, b->desc.likelihood_alpha, b->norm_mult, b->norm_add, ncc_sc,
-			b->math_mode == MTFHIP_MATH_FAST, st);
+		TRY(score_block_dev(b, bf.prop, lo, cnt, bf.wts, bf.sim, p.likelihood_func, p.measurement_sigma, p.max_similarity));
 	}
 	if (sharded) {
 		TimedScope ts(b->ctx, "pf_allgather");

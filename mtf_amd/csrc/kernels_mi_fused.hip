@@ -88,6 +88,7 @@ struct MiPassArgs {
 	double grad_eps, norm_mult, norm_add, hist_norm;
 	const int *active;
 	const double *tb;       /* [B][MI_SIZE] */
+	const double *cand_states;   /* candidate mode of pass 1 (k_mi_pass_hist<.., CAND = true>): [n][S] warps of ONE template */
 };
 
 /* ---------------------------------------------------------------------------------------------
@@ -96,20 +97,33 @@ struct MiPassArgs {
 /* slab rows are indexed with (bin + 1): row 0 and rows 9, 10 take the taps of the un-clamped windows that fall outside the
  * histogram (bspl_window4) and are never read by the bin mode */
 constexpr int kWinRows = 11;
-template <int SSM, bool SELF>
+/* CAND: the candidate axis (PF / NN, SM/src/PF.cc:247-262 with MI as the appearance model): blockIdx.y is a candidate of target 0 --
+ * its warp comes from the candidate's state, the template arrays are target 0's */
+template <int SSM, bool SELF, bool CAND = false>
 __global__ __launch_bounds__(kBlock) void k_mi_pass_hist(BatchView bv, ImgView im, MiPassArgs pa, double *partials, int nblk, int row_len) {
 	__shared__ __attribute__((aligned(16))) double slabs[4 * 2 * kWinRows * kRS];
 	constexpr int nb = 8;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int t = blockIdx.y;
-	if (pa.active && !pa.active[t]) return;
+	if (!CAND && pa.active && !pa.active[t]) return;
 	double *wa = slabs + (size_t)wave * 2 * kWinRows * kRS, *wb = wa + kWinRows * kRS;
 	const unsigned N = (unsigned)bv.N;
 	const bool uz = bv.unit_z != 0;
-	const Warp9 W = load_warp(bv.warps + 9 * t);
-	const double *pp = bv.buf[uz ? MTFHIP_BUF_INIT_PTS : MTFHIP_BUF_INIT_HXY] + (size_t)t * 2 * N;
-	const double *iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * N;
-	const double *I0 = bv.buf[MTFHIP_BUF_I0] + (size_t)t * N;
+	Warp9 W;
+	if constexpr (CAND) {   /* getWarpFromState (Homography.cc:94-107, Affine.cc:116-130) of candidate t */
+		const double *p = pa.cand_states + (size_t)t * (SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6);
+		if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+			W.m[0] = 1 + p[0]; W.m[1] = p[1]; W.m[2] = p[2]; W.m[3] = p[3]; W.m[4] = 1 + p[4]; W.m[5] = p[5]; W.m[6] = p[6]; W.m[7] = p[7]; W.m[8] = 1;
+		} else {
+			W.m[0] = 1 + p[2]; W.m[1] = p[3]; W.m[2] = p[0]; W.m[3] = p[4]; W.m[4] = 1 + p[5]; W.m[5] = p[1]; W.m[6] = 0; W.m[7] = 0; W.m[8] = 1;
+		}
+	} else {
+		W = load_warp(bv.warps + 9 * t);
+	}
+	const size_t tt = CAND ? 0 : (size_t)t;   /* whose template */
+	const double *pp = bv.buf[uz ? MTFHIP_BUF_INIT_PTS : MTFHIP_BUF_INIT_HXY] + tt * 2 * N;
+	const double *iz = bv.buf[MTFHIP_BUF_INIT_Z] + tt * N;
+	const double *I0 = bv.buf[MTFHIP_BUF_I0] + tt * N;
 	for (int k2 = 0; k2 < 2 * kWinRows; ++k2) wa[k2 * kRS + lane] = 0.0;   /* the slabs start clean and every chunk leaves them clean */
 	double bj8 = 0.0, bs8 = 0.0, bh8 = 0.0;
 	const int li = lane & 3, lb = (lane >> 2) & 3, lk = lane >> 4;
@@ -499,6 +513,39 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 }
 
 /* ---------------------------------------------------------------------------------------------
+ * candidate mode: the histogram rows of a candidate -> MI (MI.cc:369-381) -> its likelihood (MI.cc:384-387) -> the particle
+ * weight (PF.cc:341-365).  One wave per candidate, lane = bin pair; the wave sum is a fixed butterfly.
+ * ------------------------------------------------------------------------------------------- */
+__global__ __launch_bounds__(64) void k_mi_cand_score(int n, int lo, const double *partials, int nblk, int row_len, const double *tb0, double pre_seed,
+	double hist_norm, double alpha, int likelihood_func, double measurement_sigma, double max_similarity, double *wts, double *sim) {
+	constexpr int nb = 8;
+	const int cnd = blockIdx.x, lane = threadIdx.x;
+	if (cnd >= n) return;
+	const double *p = partials + (size_t)cnd * nblk * row_len;
+	const int r = lane >> 3, c = lane & 7;
+	const double js = column_sum(p + nb + lane, nblk, row_len);
+	const double hs = lane < nb ? column_sum(p + lane, nblk, row_len) : 0.0;
+	const double jv = (js + pre_seed) * hist_norm;
+	const double lhc_own = lane < nb ? log((hs + nb * pre_seed) * hist_norm) : 0.0;   /* log curr_hist(lane) */
+	const double lhc = __shfl(lhc_own, r);
+	double part = jv * (log(jv) - lhc - tb0[MI_LOG_INIT + c]);
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+	if (lane == 0) {
+		const double f = part;
+		const double dd = (1.0 / f) - 1;
+		double w = exp(-alpha * dd * dd);
+		if (likelihood_func != 0) {
+			const double pi = 3.14159265358979323846;
+			const double val = max_similarity - f;
+			w = likelihood_func == 1 ? (1.0 / sqrt(2 * pi * measurement_sigma)) * exp(-0.5 * val / measurement_sigma) : 1.0 / (1.0 + val);
+		}
+		if (wts) wts[lo + cnd] = w;
+		if (sim) sim[lo + cnd] = f;
+	}
+}
+
+/* ---------------------------------------------------------------------------------------------
  * finish: block rows -> g, H of the search method -> (device-side loop) solve + update + convergence test.
  * out_H [B][64] column-major S x S Hessian of the pass, out_g [B][16] the two Jacobian products (for iterate's host solve).
  * gmode: 0 ICLK (df_dI0 . J0), 1 FCLK (df_dIt . Jt), 2 ESM Original (df_dIt . Jm), 3 ESM DiffOfJacs.
@@ -562,7 +609,7 @@ static MiPassArgs make_args(const MiFastPlan &pl) {
 	pa.nb = 8; pa.j0_mode = pl.j0_mode; pa.j0_init_variant = pl.j0_init_variant; pa.need_dft = pl.need_dft; pa.need_df0 = pl.need_df0;
 	pa.g_mean = pl.g_mean; pa.table_off = 0; pa.transpose_q = pl.hk == 3;
 	pa.grad_eps = pl.grad_eps; pa.norm_mult = pl.norm_mult; pa.norm_add = pl.norm_add; pa.hist_norm = pl.hist_norm;
-	pa.active = pl.active; pa.tb = pl.tb;
+	pa.active = pl.active; pa.tb = pl.tb; pa.cand_states = nullptr;
 	return pa;
 }
 void launch_mi_pass_hist(const BatchView &bv, const ImgView &im, const MiFastPlan &pl, double *partials, int nblk, int row_len, hipStream_t st) {
@@ -573,6 +620,20 @@ void launch_mi_pass_hist(const BatchView &bv, const ImgView &im, const MiFastPla
 	else if (hom) MTFHIP_LAUNCH((k_mi_pass_hist<MTFHIP_SSM_HOMOGRAPHY, false>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
 	else if (self) MTFHIP_LAUNCH((k_mi_pass_hist<MTFHIP_SSM_AFFINE, true>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
 	else MTFHIP_LAUNCH((k_mi_pass_hist<MTFHIP_SSM_AFFINE, false>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
+}
+/* MI over the candidate axis: candidates [lo, lo + cnt) of dev_states ([.][S]), weights / similarities at their global indices */
+void launch_mi_score_candidates(const BatchView &bv, const ImgView &im, const MiFastPlan &pl, const double *dev_states, int lo, int cnt,
+	double *partials, int nblk, int row_len, double pre_seed, double alpha, int likelihood_func, double measurement_sigma, double max_similarity,
+	double *wts, double *sim, hipStream_t st) {
+	if (cnt <= 0) return;
+	MiPassArgs pa = make_args(pl);
+	pa.active = nullptr;
+	pa.cand_states = dev_states + (size_t)lo * bv.S;
+	const dim3 g(nblk, cnt);
+	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY) MTFHIP_LAUNCH((k_mi_pass_hist<MTFHIP_SSM_HOMOGRAPHY, false, true>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
+	else MTFHIP_LAUNCH((k_mi_pass_hist<MTFHIP_SSM_AFFINE, false, true>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
+	MTFHIP_LAUNCH(k_mi_cand_score, dim3(cnt), dim3(64), 0, st, cnt, lo, (const double *)partials, nblk, row_len, pl.tb, pre_seed, pl.hist_norm, alpha,
+		likelihood_func, measurement_sigma, max_similarity, wts, sim);
 }
 template <int SSM>
 static void launch_pass2(const BatchView &bv, const ImgView &im, const MiPassArgs &pa, int hk, int hrow, double *partials, int nblk, hipStream_t st) {

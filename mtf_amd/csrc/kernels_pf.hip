@@ -818,22 +818,15 @@ static void launch_pf_score_args(const BatchView &bv, const ImgView &im, const P
 #undef MTFHIP_PF_SCORE_MC
 #undef MTFHIP_PF_SCORE
 }
-void launch_pf_score(const BatchView &bv, const ImgView &im, const PfLaunch &p, const PfBuffers &bf, int lo, int cnt,
-	double alpha, double norm_mult, double norm_add, const double *ncc_sc, int fast_math, hipStream_t st) {
+/* candidates [lo, lo + cnt) of `states`: weight and similarity at their global indices (the particle filter's scoring launch and
+ * mtfhip_score_candidates: PF.cc:247-262, 341-365 per candidate) */
+void launch_score_block(const BatchView &bv, const ImgView &im, const double *states, int lo, int cnt, double alpha, double norm_mult,
+	double norm_add, const double *ncc_sc, double *wts, double *sim, int likelihood_func, double measurement_sigma, double max_similarity,
+	int fast_math, hipStream_t st) {
 	PfScoreArgs s;
-	s.prop = bf.prop; s.lo = lo; s.cnt = cnt; s.alpha = alpha; s.norm_mult = norm_mult; s.norm_add = norm_add; s.ncc_sc = ncc_sc;
-	s.likelihood_func = p.likelihood_func; s.measurement_sigma = p.measurement_sigma; s.max_similarity = p.max_similarity;
-	s.wts = bf.wts; s.sim = bf.sim;
-	launch_pf_score_args(bv, im, s, fast_math, st);
-}
-/* candidate scoring outside the filter (mtfhip_score_candidates: PF.cc:247-262 per candidate, NN): the same kernel with the AM's own
- * likelihood as the weight */
-void launch_score_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C,
-	double likelihood_alpha, double norm_mult, double norm_add, const double *ncc_sc, double *dev_lik, double *dev_sim, int fast_math, hipStream_t st) {
-	PfScoreArgs s;
-	s.prop = dev_states; s.lo = 0; s.cnt = C; s.alpha = likelihood_alpha; s.norm_mult = norm_mult; s.norm_add = norm_add; s.ncc_sc = ncc_sc;
-	s.likelihood_func = 0; s.measurement_sigma = 1.0; s.max_similarity = 0.0;
-	s.wts = dev_lik; s.sim = dev_sim;
+	s.prop = states; s.lo = lo; s.cnt = cnt; s.alpha = alpha; s.norm_mult = norm_mult; s.norm_add = norm_add; s.ncc_sc = ncc_sc;
+	s.likelihood_func = likelihood_func; s.measurement_sigma = measurement_sigma; s.max_similarity = max_similarity;
+	s.wts = wts; s.sim = sim;
 	launch_pf_score_args(bv, im, s, fast_math, st);
 }
 void launch_pf_scan(const PfLaunch &p, const PfBuffers &bf, hipStream_t st) {

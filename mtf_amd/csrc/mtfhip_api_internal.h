@@ -235,6 +235,7 @@ struct mtfhip_batch {
 	int mi_row_len = 0;
 	double mi_hist_norm = 0;
 	size_t cand_capacity = 0;
+	double *d_cand_mi = nullptr; size_t cand_mi_capacity = 0;   /* MI candidate scoring: histogram rows per candidate */
 	int *d_active = nullptr, *d_iters = nullptr;
 	/* The small per-target state lives in ONE device allocation (warps | states | corners | init_corners_hm | ncc | w0 |
 	 * active | iters) mirrored by two pinned staging buffers, so that set_corners and track each move it with a single
@@ -522,5 +523,7 @@ int ncc_hessian_from_cache(mtfhip_batch *b, int j_buf, int kind, double *H);
 int fused_args(const mtfhip_batch *b, const mtfhip_sm_desc *sm, FusedArgs &fa);
 int mi_blocks(const mtfhip_batch *b);
 int push_ncc(mtfhip_batch *b);
+int score_block_dev(mtfhip_batch *b, const double *dev_states, int lo, int cnt, double *wts, double *sim, int likelihood_func,
+	double measurement_sigma, double max_similarity);   /* api_fused.hip */
 } /* extern "C" */
 #endif

@@ -299,7 +299,7 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 			bilin_fast(tcur.t00, tcur.t01, tcur.t10, tcur.t11, wx - lxd, wy - lyd, v, bgx, bgy);
 			it = fma(fa.norm_mult, v, fa.norm_add);
 			if constexpr (MODE != 2) { gx = bgx * fa.norm_mult; gy = bgy * fa.norm_mult; }
-		} else if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
+		} else if (!FAST && __builtin_amdgcn_ballot_w64(!fast) == 0) {
 			const double t00 = tcur.t00, t01 = tcur.t01, t10 = tcur.t10, t11 = tcur.t11;
 			auto bl = [&](double dx, double dy) { if constexpr (MC) return bilin_mc(t00, t01, t10, t11, dx, dy); else return bilin(t00, t01, t10, t11, dx, dy); };
 			it = fa.norm_mult * bl(wx - lxd, wy - lyd) + fa.norm_add;
@@ -318,6 +318,15 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 			if constexpr (MODE != 2) {
 				gx = (pix_val_mc(im, px0, py0, ch) - pix_val_mc(im, px1, py1, ch)) * gmult;
 				gy = (pix_val_mc(im, px2, py2, ch) - pix_val_mc(im, px3, py3, ch)) * gmult;
+			}
+		} else if constexpr (FAST) {
+			/* border / integer coordinates / cell edges in a tolerance-mode launch: the reference's five samples one after the other
+			 * (utils::getPixVal + getImgGrad, imgUtils.h:91-113, imgUtils.cc:233-254).  Rare, so written for few live registers, not
+			 * for speed: the cached-cell form below keeps a dozen values alive across the hot loop's accumulators. */
+			it = fa.norm_mult * pix_val(im, wx, wy) + fa.norm_add;
+			if constexpr (MODE != 2) {
+				gx = (pix_val(im, px0, py0) - pix_val(im, px1, py1)) * gmult;
+				gy = (pix_val(im, px2, py2) - pix_val(im, px3, py3)) * gmult;
 			}
 		} else {
 			const Cell c = load_cell(im, wx, wy);

@@ -231,6 +231,9 @@ void launch_mi_pass_hist(const BatchView &bv, const ImgView &im, const MiFastPla
 void launch_mi_pass_grad_hess(const BatchView &bv, const ImgView &im, const MiFastPlan &pl, double *partials, int nblk, hipStream_t st);
 void launch_mi_finish_fast(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, const MiFastPlan &pl, int gmode, int do_track,
 	const double *partials, int nblk, double *out_H, double *out_g, double *rows, hipStream_t st);
+void launch_mi_score_candidates(const BatchView &bv, const ImgView &im, const MiFastPlan &pl, const double *dev_states, int lo, int cnt,
+	double *partials, int nblk, int row_len, double pre_seed, double alpha, int likelihood_func, double measurement_sigma, double max_similarity,
+	double *wts, double *sim, hipStream_t st);
 int mi_fast_row_len();
 /* ---- particle filter (kernels_pf.hip): proposal + scoring, cumulative weights, resampling + estimate ---- */
 enum { PF_SAMPLER_STATE = 0,       /* one normal per state component (ProjectiveBase::generatePerturbation) */
@@ -259,8 +262,9 @@ struct PfBuffers {
 	                               workgroups of the selection pass; zero between launches */
 };
 void launch_pf_propose(int ssm, const PfLaunch &p, const double *st_in, const double *ar_in, double *st_out, double *ar_out, hipStream_t st);
-void launch_pf_score(const BatchView &bv, const ImgView &im, const PfLaunch &p, const PfBuffers &bf, int lo, int cnt,
-	double alpha, double norm_mult, double norm_add, const double *ncc_sc, int fast_math, hipStream_t st);
+void launch_score_block(const BatchView &bv, const ImgView &im, const double *states, int lo, int cnt, double alpha, double norm_mult,
+	double norm_add, const double *ncc_sc, double *wts, double *sim, int likelihood_func, double measurement_sigma, double max_similarity,
+	int fast_math, hipStream_t st);
 void launch_pf_scan(const PfLaunch &p, const PfBuffers &bf, hipStream_t st);   /* weights -> chunk-local cumulative weights + chunk table */
 void launch_pf_select(int ssm, const PfLaunch &p, const PfBuffers &bf, int lookahead, double *host_out /* or NULL */,
 	unsigned long long *host_flag, unsigned long long seq, hipStream_t st);
@@ -280,9 +284,6 @@ void launch_publish_host(const void *src, void *dst_host, size_t bytes, int *cou
 /* the fused LK iteration for SSD */
 void launch_fused_ssd(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials,
 	int nblk, hipStream_t st);
-/* candidate scoring: target 0's template under C warps given as states */
-void launch_score_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C,
-	double likelihood_alpha, double norm_mult, double norm_add, const double *ncc_sc, double *dev_lik, double *dev_sim, int fast_math, hipStream_t st);
 /* second-order path: hess_pts, image Hessians ([N][4]), SSM pixel Hessians ([S*S][N] planes), sum_p w[p] d2[:, p] */
 void launch_hess_pts(const BatchView &bv, double eps, hipStream_t st);
 void launch_img_hess(const BatchView &bv, const ImgView &im, const double *pts, double *hess, double eps, double mult, hipStream_t st);

@@ -688,7 +688,7 @@ def test_persistent_loop_equals_two_launch_loop(gpu_ctx, case, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("am", [L.AM_SSD, L.AM_NCC])
+@pytest.mark.parametrize("am", [L.AM_SSD, L.AM_NCC, L.AM_MI])
 @pytest.mark.parametrize("corner_based,dynamic_model,update_type,mean_type,likelihood_func,resampling_type", [
     (0, 0, 1, 0, 0, 1),    # config 4: RandomWalk + Compositional + AM likelihood + BinaryMultinomial, highest weight
     (1, 0, 1, 0, 0, 1),    # the reference's default sampler: 4-corner perturbations (parameters.h:262)
@@ -709,12 +709,12 @@ def test_pf_iteration_matches_oracle(oracle, gpu_ctx, frame, am, corner_based, d
     centre = (250.0, 240.0)
     corners = synth.square_corners(centre[0], centre[1], 80) + rng.uniform(-2, 2, size=(2, 4))
     sigma = (1.0, 0.6, 1, 1, 1, 1, 1, 1) if corner_based else (0.004, 0.004, 0.8, 0.004, 0.004, 0.8, 2e-6, 2e-6)
-    alpha = 5.0 if am == L.AM_SSD else 500.0
+    alpha = {L.AM_SSD: 5.0, L.AM_NCC: 500.0, L.AM_MI: 0.05}[am]   # MI (8 bins, MI.cc:384-387) is O(1): exp(-alpha (1 / f - 1)^2)
     o_ssm = oracle.SSM(0, res, res); o_am = oracle.AM(am, res, res, likelihood_alpha=alpha); o_am.set_curr_img(frame)
     o_ssm.set_corners(corners); o_am.initialize_pix_vals(o_ssm.get("curr_pts")); o_am.initialize_similarity()
     pp = oracle.pf_params(n, dynamic_model=dynamic_model, update_type=update_type, likelihood_func=likelihood_func,
                           resampling_type=resampling_type, mean_type=mean_type, corner_based_sampling=corner_based, sigma=sigma,
-                          measurement_sigma=0.4 if am == L.AM_SSD else 0.01)
+                          measurement_sigma={L.AM_SSD: 0.4, L.AM_NCC: 0.01, L.AM_MI: 0.05}[am])
     gpu_ctx.set_image(frame)
     pf = ParticleFilter(gpu_ctx, L.SSM_HOMOGRAPHY, res, res, n_particles=n, ssm_sigma=sigma, likelihood_alpha=alpha, am=am,
                         dynamic_model=dynamic_model, update_type=update_type, likelihood_func=likelihood_func,
@@ -731,7 +731,7 @@ def test_pf_iteration_matches_oracle(oracle, gpu_ctx, frame, am, corner_based, d
         st_o, ar_o, w_o, ids_o, mx_o = oracle.pf_iteration(o_am, o_ssm, pp, st_o, ar_o, normals, uniforms, pf.max_similarity)
         pf.iteration(normals, uniforms)
         st_d, ar_d, w_d, ids_d = pf.particles()
-        np.testing.assert_allclose(w_d, w_o, rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(w_d, w_o, rtol=1e-9 if am != L.AM_MI else 1e-7, atol=1e-300)
         if resampling_type == 3:
             # deterministic given the weights: the sorted order (ties by index), round(w n) copies each, leftovers = the first
             assert np.array_equal(ids_d, ids_o)
