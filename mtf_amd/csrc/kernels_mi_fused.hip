@@ -27,7 +27,11 @@
 
 namespace mtfhip {
 
-constexpr int kRS = kMiRowMfma;   /* slab row stride, doubles */
+#ifndef MTFHIP_MI_RS
+#define MTFHIP_MI_RS 65   /* r03 A/B (profiles/r03_experiments.md): any stride that is not a multiple of 4 -- 65, 66, 67, 69, 70, 73 -- takes pass 1
+                            * from 150 to 119 us; 68 (kMiRowMfma), 72 and 80 put the per-lane-row window stores of lanes 4 / 8 / 12 apart on one bank */
+#endif
+constexpr int kRS = MTFHIP_MI_RS;   /* slab row stride, doubles (build-time knob of tools/r03_mi_stride_ab.sh) */
 
 /* warp one grid point and sample the current image there (tolerance-mode arithmetic); GRAD: also the gradient with
  * respect to the warped coordinates.  Wave-uniform interior path (closed-form gradient); any lane on a cell edge, an
@@ -199,7 +203,14 @@ __global__ __launch_bounds__(kBlock) void k_mi_pass_hist(BatchView bv, ImgView i
  * column: no bank conflicts, nothing to zero but the gradient taps), and every group of four same-class pixels costs two
  * block products into that class's accumulators -- Q_rel[fl][k][m][s] -- plus one for sum hess_term J J^T.  ~20 groups x 3
  * = 60 matrix instructions per chunk instead of 144; the classes are folded into the absolute table once per workgroup. */
-constexpr int kRS2 = 100;   /* slot-major row stride: >= 64 + 8 * 3 padded slots; 100 = 4 mod 32 keeps 4 rows x 4 slots on 16 banks */
+#ifndef MTFHIP_MI_RS2
+#define MTFHIP_MI_RS2 100
+#endif
+#ifndef MTFHIP_MI_QR
+#define MTFHIP_MI_QR 64
+#endif
+constexpr int kQR = MTFHIP_MI_QR;     /* row stride (doubles) of a wave's absolute table Q[r][c][s]: 64 = dense */
+constexpr int kRS2 = MTFHIP_MI_RS2;   /* slot-major row stride: >= 64 + 8 * 3 padded slots; 100 = 4 mod 32 keeps 4 rows x 4 slots on 16 banks */
 struct ClassSort { int slot; unsigned long long ends; int total; };   /* ends: byte c = end slot of class c (<= 88) */
 __device__ __forceinline__ ClassSort class_sort8(int key /* 0..7, or negative: not placed */) {
 	ClassSort cs;
@@ -223,7 +234,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 	constexpr int S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
 	constexpr int nb = 8;
 	constexpr bool SORTED = HK == 1;
-	constexpr int SLAB = SORTED ? 17 * kRS2 + 512 : (HK ? (2 * kWinRows + 9) * kRS : 0);   /* dense: gd[11] | wd[11] | rw[8] | ht ; sorted: d[4] | w[4] | rw[8] | ht | Q[512] */
+	constexpr int SLAB = SORTED ? 17 * kRS2 + 8 * kQR : (HK ? (2 * kWinRows + 9) * kRS : 0);   /* dense: gd[11] | wd[11] | rw[8] | ht ; sorted: d[4] | w[4] | rw[8] | ht | Q[512] */
 	__shared__ __attribute__((aligned(16))) double Tc[kTRows * MI_NB], Ti[kTRows * MI_NB], Th[HK == 1 ? kTRows * MI_NB : 1];
 	__shared__ __attribute__((aligned(16))) double slabs[HK ? 4 * SLAB : 4 * 16];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -393,7 +404,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 				if (end == bound) {
 					const int r = c - 1 + lb, cc = c - 1 + lk;   /* result lane: block = k, row = m, column = s in its half */
 					if (r >= 0 && r < nb && cc >= 0 && cc < nb) {
-						double *qe = qabs + (r * nb + cc) * 8 + li;
+						double *qe = qabs + r * kQR + cc * 8 + li;
 						qe[0] += acc0; qe[4] += acc1;
 					}
 					acc0 = 0.0; acc1 = 0.0;
@@ -503,8 +514,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 			for (int k2 = threadIdx.x; k2 < 64; k2 += kBlock)
 				dst[16 + k2] = (qred[k2] + qred[64 + k2]) + (qred[128 + k2] + qred[192 + k2]);
 			const double *q0 = slabs + 17 * kRS2;
-			for (int k2 = threadIdx.x; k2 < 512; k2 += kBlock)
-				dst[80 + k2] = (q0[k2] + q0[SLAB + k2]) + (q0[2 * SLAB + k2] + q0[3 * SLAB + k2]);
+			for (int k2 = threadIdx.x; k2 < 512; k2 += kBlock) {
+				const int q = (k2 >> 6) * kQR + (k2 & 63);
+				dst[80 + k2] = (q0[q] + q0[SLAB + q]) + (q0[2 * SLAB + q] + q0[3 * SLAB + q]);
+			}
 		} else {
 			for (int k2 = threadIdx.x; k2 < ql; k2 += kBlock)
 				dst[16 + k2] = (qred[k2] + qred[ql + k2]) + (qred[2 * ql + k2] + qred[3 * ql + k2]);
