@@ -38,11 +38,24 @@ def algorithmic_bytes_per_pixel(sm, materialize, unit_z=True, j0_recompute=True)
     return b
 
 
+def kernel_sources_sha():
+    """fingerprint of the HIP sources the library is built from (mtf_amd/csrc/*.hip, *.h): a PMC traffic figure is only quoted
+    next to a bench line when it was collected on exactly these sources"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mtf_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(sm, mode, res, targets):
-    """HBM bytes per launch of the fused kernel from the committed PMC passes (profiles/pmc_latest.json,
-    produced by tools/profile_round.sh: separate --pmc runs, KiB units, gfx950 FETCH_SIZE x2 correction).
-    Only reported when the profile was taken on this exact workload."""
+    """HBM bytes per launch of the fused kernel from the PMC passes of tools/profile_round.sh (profiles/pmc_latest.json: separate
+    --pmc runs, KiB units, gfx950 FETCH_SIZE x2 correction).  Only reported for the workload it was collected on AND only while
+    the kernel sources are the ones it was collected on (kernel_sources_sha): a stale figure is withheld, not printed."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    pmc_traffic.note = None
     if not (sm == "esm" and mode == "full" and res == 200 and targets == 64 and os.path.exists(path)):
         return None
     try:
@@ -50,6 +63,10 @@ def pmc_traffic(sm, mode, res, targets):
         if d.get("j0_recompute", False) != (os.environ.get("MTFHIP_J0_RECOMPUTE", "1") != "0"):
             return None      # the profile was taken with the other J0 source
         pmc_traffic.commit = d.get("commit")
+        if d.get("kernel_sources_sha") != kernel_sources_sha():
+            pmc_traffic.note = "withheld: profiles/pmc_latest.json was collected on other kernel sources (%s, now %s); re-run tools/profile_round.sh" % (
+                d.get("kernel_sources_sha"), kernel_sources_sha())
+            return None
         return float(d["traffic_bytes_per_launch"])
     except Exception:
         return None
@@ -723,9 +740,11 @@ def main():
                          "infinity_cache_resident_read_bytes": float(bpp - (88 if materialize and args.sm != "iclk" else (8 if materialize else 0))) * N * per_launch,
                          "hbm_write_bytes": float(88 if materialize and args.sm != "iclk" else (8 if materialize else 0)) * N * per_launch,
                          "timing": "hipEvents around every fused launch of an untimed second pass (%d launches); rocprofv3 --kernel-trace of the "
-                                   "same command: profiles/r02_kernel_stats.csv" % kern_n,
-                         "traffic_source": "rocprofv3 --pmc passes committed under profiles/ (pmc_latest.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB), not this run",
-                         "traffic_commit": getattr(pmc_traffic, "commit", None)},
+                                   "same command: profiles/r03_kernel_stats.csv" % kern_n,
+                         "traffic_source": "rocprofv3 --pmc passes of tools/profile_round.sh on these kernel sources (profiles/pmc_latest.json: "
+                                           "(2 x FETCH_SIZE + WRITE_SIZE) KiB, the guide's gfx950 correction); counters cannot be read inside a timed run",
+                         "traffic_commit": getattr(pmc_traffic, "commit", None), "traffic_note": getattr(pmc_traffic, "note", None),
+                         "kernel_sources_sha": kernel_sources_sha()},
         }
         if lean is not None:
             out["lean"] = lean

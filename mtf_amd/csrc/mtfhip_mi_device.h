@@ -159,7 +159,7 @@ __device__ __forceinline__ void lds_add(double *p, double v) {
  * ------------------------------------------------------------------------------------------- */
 constexpr int kMiPairs = (MI_NB * MI_NB + 63) / 64;
 constexpr int kMiRow = 65;
-constexpr int kMiRowMfma = 68;   /* k_mi_hess<MFMA>: see there */
+constexpr int kMiRowMfma = 65;   /* (r03: was 68 -- a multiple of 4 puts the window stores of lanes 4 / 8 / 12 apart on one bank, profiles/r03_mi_stride_ab.txt) */
 /* Bin mode on the matrix cores.  Over a 64-pixel chunk the bin-mode sums are small dense products whose K axis is the
  * pixel: joint(r, c) = sum_p wa[r][p] wb[c][p] is (nb x 64)(64 x nb), and the joint_hist_jacobian block
  * Q[(r, c)][s] = sum_p (gd[r][p] wd[c][p]) J[p][s] is (nb^2 x 64)(64 x S).  v_mfma_f64_16x16x4_f64 takes K = 4 pixels

@@ -27,8 +27,11 @@ for f in glob.glob("$out/pmc/p*/*counter_collection.csv"):
 f = sum(agg["FETCH_SIZE"]) / max(1, len(agg["FETCH_SIZE"]))
 w = sum(agg["WRITE_SIZE"]) / max(1, len(agg["WRITE_SIZE"]))
 # MI355X_MICROARCH.md "HBM": counters are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream
-import os
-json.dump({"kernel": "k_fused_ssd", "bench_args": "$args", "j0_recompute": os.environ.get("MTFHIP_J0_RECOMPUTE", "1") != "0", "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w,
+import os, sys, subprocess
+sys.path.insert(0, ".")
+import bench
+commit = open(".git_head").read().strip() if os.path.exists(".git_head") else None
+json.dump({"kernel": "k_fused_ssd", "bench_args": "$args", "commit": commit, "kernel_sources_sha": bench.kernel_sources_sha(), "j0_recompute": os.environ.get("MTFHIP_J0_RECOMPUTE", "1") != "0", "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w,
            "traffic_bytes_per_launch": (2.0 * f + w) * 1024.0,
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE half-count, MI355X_MICROARCH.md HBM section)"},
           open("$out/${tag}_pmc_traffic.json", "w"), indent=1)
