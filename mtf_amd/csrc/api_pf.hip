@@ -254,7 +254,7 @@ int mtfhip_pf_create(mtfhip_batch *b, const mtfhip_pf_desc *d, mtfhip_pf **out) 
 	A(pf->d_st, sizeof(double) * nS); A(pf->d_ar, sizeof(double) * nS);
 	for (int k = 0; k < 2; ++k) { A(pf->d_prop[k], sizeof(double) * nS); A(pf->d_prop_ar[k], sizeof(double) * nS); }
 	A(pf->d_wts, sizeof(double) * npad); pf->wts_capacity = npad;
-	A(pf->d_cum, sizeof(double) * npad); A(pf->d_chunk, sizeof(double) * 2 * nch);
+	A(pf->d_cum, sizeof(double) * npad); A(pf->d_chunk, sizeof(double) * (2 + 16) * nch);   /* chunk totals | their prefix | sub-block sums */
 	const size_t nblk = (n + 255) / 256, ngrp = (nblk + 63) / 64;
 	A(pf->d_out, sizeof(double) * 32); A(pf->d_parts, sizeof(double) * pf_parts_per_block() * nblk); A(pf->d_gparts, sizeof(double) * pf_parts_per_block() * ngrp);
 	A(pf->d_normals, sizeof(double) * n * 10); A(pf->d_uniforms, sizeof(double) * n); A(pf->d_ids, sizeof(int) * n); A(pf->d_counters, sizeof(int) * (2 + ngrp));
@@ -429,7 +429,7 @@ static int pf_enqueue_iteration(mtfhip_pf *pf, const double *normals, const doub
 	PfBuffers bf;
 	bf.st = pf->d_st; bf.ar = pf->d_ar; bf.prop = pf->d_prop[pf->pc]; bf.prop_ar = pf->d_prop_ar[pf->pc];
 	bf.next = pf->d_prop[1 - pf->pc]; bf.next_ar = pf->d_prop_ar[1 - pf->pc];
-	bf.wts = pf->d_wts; bf.sim = nullptr; bf.cum = pf->d_cum; bf.chunk_tot = pf->d_chunk; bf.chunk_incl = pf->d_chunk + nch;
+	bf.wts = pf->d_wts; bf.sim = nullptr; bf.cum = pf->d_cum; bf.chunk_tot = pf->d_chunk; bf.chunk_incl = pf->d_chunk + nch; bf.sub16 = pf->d_chunk + 2 * nch;
 	bf.res_order = nullptr;
 	bf.parts = pf->d_parts; bf.gparts = pf->d_gparts; bf.out = pf->d_out; bf.ids = pf->d_ids; bf.counters = pf->d_counters;
 	/* scoring: setState -> updatePixVals -> updateSimilarity -> likelihood per particle (PF.cc:341-365); sharded: this rank's block */

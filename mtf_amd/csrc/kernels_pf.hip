@@ -29,8 +29,8 @@
  * copies; proposals and resampling are replicated (identical draws and weights everywhere: re-evaluating a proposal costs less
  * than moving its 128 bytes over xGMI).  k_pf_scan turns the weights into chunk-local running sums (256 particles per
  * wave) and the last workgroup to arrive scans the chunk totals; k_pf_select draws, finds the source particle with a
- * two-level search (chunk table in LDS, then three rounds of independent probes inside the chunk instead of ten dependent
- * loads), writes the resampled set, and its last workgroup folds the per-workgroup rows into the estimate and hands it to the
+ * three-level search (chunk table in LDS, the chunk's sixteen sub-block sums, the sub-block's sixteen particles: two rounds of
+ * independent loads, four cache lines), writes the resampled set, and its last workgroup folds the per-workgroup rows into the estimate and hands it to the
  * host.  Every sum is taken in a fixed order that depends on n only: all ranks of a sharded filter resample identically.
  */
 #include "mtfhip_device.h"
@@ -453,6 +453,7 @@ struct PfScanArgs {
 	int n, nch;
 	const double *wts;
 	double *cum;          /* [nch * 256] */
+	double *sub16;        /* [nch * 16] chunk-local inclusive sum at the end of every 16 particles: the middle level of the search */
 	double *chunk_tot;    /* [nch] */
 	double *chunk_incl;   /* [nch] */
 	int *counter;         /* zero between launches */
@@ -483,6 +484,7 @@ __global__ __launch_bounds__(kBlock) void k_pf_scan(PfScanArgs a) {
 		const double off = incl - p3;
 		*reinterpret_cast<double2 *>(a.cum + base) = make_double2(off + p0, off + p1);
 		*reinterpret_cast<double2 *>(a.cum + base + 2) = make_double2(off + p2, off + p3);
+		if ((lane & 3) == 3) a.sub16[chunk * 16 + (lane >> 2)] = off + p3;
 		if (lane == 63) st_coh(a.chunk_tot + chunk, incl);
 	}
 	wait_stores_acked();
@@ -531,7 +533,7 @@ struct PfSelectArgs {
 	int resampling_type, mean_type;
 	int lookahead;                /* 1: the proposals of the next iteration (draws of a.iter + 1) are produced here */
 	const double *uniforms;       /* [n] or NULL: Philox */
-	const double *wts, *cum, *chunk_incl;
+	const double *wts, *cum, *sub16, *chunk_incl;
 	const double *prop, *prop_ar; /* [n][S] this iteration's proposals */
 	double *st_out, *ar_out;      /* [n][S] the (resampled) set the iteration leaves behind */
 	double *next, *next_ar;       /* [n][S] lookahead: the proposal set of the next iteration */
@@ -615,44 +617,50 @@ __global__ __launch_bounds__(kBlock) void k_pf_select(PfArgs a, PfSelectArgs r) 
 			if (in_lds) { while (h > l) { if (table[c] >= tgt) h = c; else l = c + 1; c = (l + h) / 2; } }
 			else { while (h > l) { if (r.chunk_incl[c] >= tgt) h = c; else l = c + 1; c = (l + h) / 2; } }
 			const double off = c > 0 ? (in_lds ? table[c - 1] : r.chunk_incl[c - 1]) : 0.0;
+			/* inside the chunk: the sixteen 16-particle sub-blocks (their end sums are contiguous: two cache lines), then the sixteen
+			 * particles of the sub-block (two more) -- two rounds of independent loads, four lines; bisecting cum[] itself touched six
+			 * and took eight dependent rounds */
 			const double *cl = r.cum + (size_t)c * kPfChunk;
-			int lo = 0;
-			if (n <= 65536) {
-				/* few workgroups, nothing to hide a chain of dependent loads behind: two rounds of independent loads -- fifteen
-				 * probes sixteen apart, then the sixteen neighbours */
-				double p[15];
+			int lo;
+			{
+				const double2 *p2 = reinterpret_cast<const double2 *>(r.sub16 + (size_t)c * 16);
+				double2 v[8];
 #pragma unroll
-				for (int q = 0; q < 15; ++q) p[q] = cl[16 * (q + 1) - 1];
+				for (int q = 0; q < 8; ++q) v[q] = p2[q];
 				int cnt = 0;
 #pragma unroll
-				for (int q = 0; q < 15; ++q) cnt += (off + p[q] < tgt) ? 1 : 0;
-				lo = 16 * cnt;
+				for (int q = 0; q < 8; ++q) cnt += ((off + v[q].x < tgt) ? 1 : 0) + ((off + v[q].y < tgt) ? 1 : 0);
+				lo = 16 * min(cnt, 15);
+			}
+			{
 				const double2 *p2 = reinterpret_cast<const double2 *>(cl + lo);
 				double2 v[8];
 #pragma unroll
 				for (int q = 0; q < 8; ++q) v[q] = p2[q];
-				cnt = 0;
+				int cnt = 0;
 #pragma unroll
 				for (int q = 0; q < 8; ++q) cnt += ((off + v[q].x < tgt) ? 1 : 0) + ((off + v[q].y < tgt) ? 1 : 0);
 				lo += min(cnt, 15);
-			} else {
-				/* many workgroups: the latency is hidden, the cache lines are not -- plain bisection touches six of the chunk's 32 lines */
-				int hh = kPfChunk - 1;
-				int j = (lo + hh) / 2;
-				while (hh > lo) { if (off + cl[j] >= tgt) hh = j; else lo = j + 1; j = (lo + hh) / 2; }
 			}
 			id = min(c * kPfChunk + lo, n - 1);
 			if (r.ids) r.ids[k] = id;
 		}
 		if (r.resampling_type == 3) id = r.ids[k];   /* residual resampling: the sources were laid out by k_pf_residual_map */
-		pf_load_row<S>(r.prop, (size_t)id, ns); pf_load_row<S>(r.prop_ar, (size_t)id, nar);
-		pf_store_row<S>(r.st_out, (size_t)k, ns); pf_store_row<S>(r.ar_out, (size_t)k, nar);
+		/* the auto-regression terms travel with the particle only where a model reads them (AutoRegression1): under RandomWalk they
+		 * stay what initializeParticles made them -- zero -- and three of the seven 64-byte rows this pass moves per particle go away
+		 * (it is bound by those rows at a million particles: 832 -> 640 bytes of cache lines per particle) */
+		const bool use_ar = a.dynamic_model == 1;
+		pf_load_row<S>(r.prop, (size_t)id, ns);
+		if (use_ar) pf_load_row<S>(r.prop_ar, (size_t)id, nar);
+		pf_store_row<S>(r.st_out, (size_t)k, ns);
+		if (use_ar) pf_store_row<S>(r.ar_out, (size_t)k, nar);
 		if (r.lookahead) {
 			PfArgs an = a;
 			an.iter = a.iter + 1;
 			double ps[8], pa[8];
 			pf_propose<SSM>(an, (unsigned)k, ns, nar, ps, pa);
-			pf_store_row<S>(r.next, (size_t)k, ps); pf_store_row<S>(r.next_ar, (size_t)k, pa);
+			pf_store_row<S>(r.next, (size_t)k, ps);
+			if (use_ar) pf_store_row<S>(r.next_ar, (size_t)k, pa);
 		}
 		bv = r.wts[id]; bi = k;
 		if (r.forced_best && k != *r.forced_best) bv = -1.7976931348623157e308;   /* max_wt_id is handed down, not searched for */
@@ -831,7 +839,7 @@ void launch_score_block(const BatchView &bv, const ImgView &im, const double *st
 }
 void launch_pf_scan(const PfLaunch &p, const PfBuffers &bf, hipStream_t st) {
 	const int nch = (p.n + kPfChunk - 1) / kPfChunk;
-	PfScanArgs sc{p.n, nch, bf.wts, bf.cum, bf.chunk_tot, bf.chunk_incl, bf.counters};
+	PfScanArgs sc{p.n, nch, bf.wts, bf.cum, bf.sub16, bf.chunk_tot, bf.chunk_incl, bf.counters};
 	MTFHIP_LAUNCH(k_pf_scan, dim3((nch + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, sc);
 }
 void launch_pf_select(int ssm, const PfLaunch &p, const PfBuffers &bf, int lookahead, double *host_out, unsigned long long *host_flag,
@@ -839,7 +847,7 @@ void launch_pf_select(int ssm, const PfLaunch &p, const PfBuffers &bf, int looka
 	const PfArgs a = pf_args(p);
 	PfSelectArgs r;
 	r.resampling_type = p.resampling_type; r.mean_type = p.mean_type; r.lookahead = lookahead; r.uniforms = p.uniforms;
-	r.wts = bf.wts; r.cum = bf.cum; r.chunk_incl = bf.chunk_incl; r.prop = bf.prop; r.prop_ar = bf.prop_ar;
+	r.wts = bf.wts; r.cum = bf.cum; r.sub16 = bf.sub16; r.chunk_incl = bf.chunk_incl; r.prop = bf.prop; r.prop_ar = bf.prop_ar;
 	r.st_out = bf.st; r.ar_out = bf.ar; r.next = bf.next; r.next_ar = bf.next_ar; r.ids = bf.ids;
 	r.forced_best = p.resampling_type == 3 ? bf.res_order : nullptr;
 	for (int k = 0; k < 12; ++k) r.init_corners_hm[k] = p.init_corners_hm[k];

@@ -255,7 +255,7 @@ struct PfBuffers {
 	double *prop, *prop_ar;     /* [n][S] this iteration's proposals */
 	double *next, *next_ar;     /* [n][S] where the selection pass leaves the proposals of the next iteration (look-ahead) */
 	double *wts, *sim;          /* [>= n] weights at global particle indices; similarities or NULL */
-	double *cum, *chunk_tot, *chunk_incl;
+	double *cum, *sub16, *chunk_tot, *chunk_incl;
 	double *parts, *gparts, *out;   /* per-workgroup rows of the selection pass, their per-group folds, the estimate */
 	int *res_order;             /* residual resampling: particle indices by weight, highest first (the last index stays last) */
 	int *ids, *counters;        /* [0] the scan's arrival counter, [1] the selection pass's top-level counter, [2 ...] one per group of 64
