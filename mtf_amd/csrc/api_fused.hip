@@ -15,7 +15,10 @@ static int check_sm(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const char 
 	int max_h = sm->sm == MTFHIP_SM_ESM ? 5 : 2;
 	if (sm->hess_type < 0 || sm->hess_type > max_h) return fail(MTFHIP_ERR_INVALID_ARG, "%s: hess_type %d invalid for search method %d", fn, sm->hess_type, sm->sm);
 	if (b->desc.am == MTFHIP_AM_NCC) {
-		if (sm->sec_ord_hess) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: second-order NCC Hessians go through the per-function entry points", fn);
+		/* NCC overrides the second-order cmptInit / CurrHessian (NCC.cc:391-410) but not cmptSelfHessian: the self types throw
+		 * FunctonNotImplemented in the reference (AppearanceModel.h:188-191) */
+		if (sm->sec_ord_hess && !(sm->sm == MTFHIP_SM_ESM ? sm->hess_type >= 3 : sm->hess_type == 2))
+			return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: NCC has no second-order self Hessian (AppearanceModel.h:188-191)", fn);
 		return MTFHIP_OK;
 	}
 	if (b->desc.am == MTFHIP_AM_MI) {
@@ -650,18 +653,9 @@ int mtfhip_batch_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, d
 	b->it_valid = fa.materialize;
 	b->dit_valid = fa.materialize && fa.mode != 2;
 	b->jt_valid = fa.materialize && fa.mode != 2;
-	if (b->desc.am == MTFHIP_AM_NCC) {
-		TRY(read_rows(b, nblk, NCC_ACC_COUNT));
-		for (int t = 0; t < b->B; ++t) {
-			double ft;
-			TRY(ncc_assemble(b, sm, fa.hess_mean != 0, b->h_acc + (size_t)t * NCC_ACC_COUNT, b->th[t], &ft, g + (size_t)t * b->S,
-				H + (size_t)t * b->S * b->S));
-			if (f) f[t] = ft;
-		}
-		b->ncc_host_newer = true;
-		return MTFHIP_OK;
-	}
+	const bool ncc = b->desc.am == MTFHIP_AM_NCC;
 	const int term = second_order_term(sm);
+	const int S2 = b->S * b->S;
 	std::vector<double> so;
 	if (term >= 0) {
 		if (term != 0 && !b->init_pix_hess) return fail(MTFHIP_ERR_LOGIC, "iterate: init_template was run without sec_ord_hess");
@@ -670,16 +664,32 @@ int mtfhip_batch_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, d
 			HIP_TRY(hipMalloc(&b->d_d2_part, sizeof(double) * 64 * (size_t)nb2 * b->B));
 			HIP_TRY(hipMalloc(&b->d_d2_out, sizeof(double) * 64 * (size_t)b->B));
 		}
+		if (ncc) TRY(push_ncc(b));   /* mean(I0), |I0 - mean| of the template */
 		{
 			TimedScope ts(b->ctx, "second_order");
 			launch_second_order_ssd(b->view(), b->ctx->img, term, fa.chained, b->d0_variant, fa.grad_eps, b->hess_eps, b->norm_mult,
-				b->norm_add, b->d_d2_part, nb2, b->d_d2_out, b->ctx->stream);
+				b->norm_add, b->d_d2_part, nb2, b->d_d2_out, b->ctx->stream, 0,
+				ncc ? SecondOrderNcc{b->d_partials, nblk, b->d_ncc} : SecondOrderNcc{nullptr, 0, nullptr});
 		}
-		so.resize((size_t)b->S * b->S * b->B);
+		so.resize((size_t)S2 * b->B);
 		HIP_TRY(hipMemcpyAsync(so.data(), b->d_d2_out, sizeof(double) * so.size(), hipMemcpyDeviceToHost, b->ctx->stream));
 	}
+	if (ncc) {
+		TRY(read_rows(b, nblk, NCC_ACC_COUNT));
+		for (int t = 0; t < b->B; ++t) {
+			double ft;
+			double *Ht = H + (size_t)t * S2;
+			TRY(ncc_assemble(b, sm, fa.hess_mean != 0, b->h_acc + (size_t)t * NCC_ACC_COUNT, b->th[t], &ft, g + (size_t)t * b->S, Ht));
+			if (term >= 0) {   /* (NT/ESM.cc:339 halves the whole SumOfStd sum) */
+				const double sc = term == 1 ? 0.5 : 1.0;
+				for (int k = 0; k < S2; ++k) Ht[k] += sc * so[(size_t)t * S2 + k];
+			}
+			if (f) f[t] = ft;
+		}
+		b->ncc_host_newer = true;
+		return MTFHIP_OK;
+	}
 	TRY(read_acc(b, nblk));
-	const int S2 = b->S * b->S;
 	for (int t = 0; t < b->B; ++t) {
 		double ft;
 		double *Ht = H + (size_t)t * S2;
@@ -775,8 +785,8 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 	TRY(fused_channels_ok(b, "track"));
 	if (sm->max_iters <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "track: max_iters must be positive");
 	const int so_term = second_order_term(sm);
-	if (b->desc.am != MTFHIP_AM_SSD && sm->sec_ord_hess != 0)
-		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: second-order Hessians of NCC and MI go through iterate / the per-function entry points");
+	if (b->desc.am == MTFHIP_AM_MI && sm->sec_ord_hess != 0)
+		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: second-order MI Hessians go through the per-function entry points");
 	if (so_term >= 0 && b->C != 1) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: second-order Hessians of the multi-channel models use the per-function entry points");
 	if (so_term > 0 && !b->init_pix_hess) return fail(MTFHIP_ERR_LOGIC, "track: init_template was run without sec_ord_hess");
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "track before init_template");
@@ -921,7 +931,8 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 				if (so_term >= 0) {
 					TimedScope tsc(b->ctx, "second_order");
 					launch_second_order_ssd(bc, b->ctx->img, so_term, fa.chained, b->d0_variant, fa.grad_eps, b->hess_eps, b->norm_mult, b->norm_add,
-						b->d_d2_part + (size_t)t0 * nb2 * 64, nb2, b->d_d2_out + (size_t)t0 * b->S * b->S, st, 1);
+						b->d_d2_part + (size_t)t0 * nb2 * 64, nb2, b->d_d2_out + (size_t)t0 * b->S * b->S, st, 1,
+						ncc ? SecondOrderNcc{part, nblk_c, tc.ncc} : SecondOrderNcc{nullptr, 0, nullptr});
 				}
 				launch_finish_track(bc, *sm, tc, part, nblk_c, st);
 				if (all_converged(tc.active, nt, it)) break;

@@ -290,13 +290,39 @@ __global__ __launch_bounds__(64) void k_plane_sum_finish(const double *partials,
  *   term  1:  r * (D0 + Dt)          cmptSumOfHessians (2nd order), SSDBase.cc:377-415 (ESM SumOfStd)
  *   term  2: -r * ((D0 + Dt) / 2)    cmptCurrHessian on the mean pixel Hessian, NT/ESM.cc:324-327 (ESM Original)
  *   term  3:  r * D0                 cmptInitHessian (2nd order), SSDBase.cc:313-343   (ICLK Std)
- * d0_variant: how init_pix_hessian was produced (Warped at the identity warp by initialize, Init after setRegion). */
+ * d0_variant: how init_pix_hessian was produced (Warped at the identity warp by initialize, Init after setRegion).
+ * With nc.rows set the weights are NCC's: term 0 df_dIt Dt (NCC.cc:401-410), 1 df_dIt Dt + df_dI0 D0, 2 df_dIt (D0 + Dt) / 2,
+ * 3 df_dI0 D0 (NCC.cc:391-400). */
 template <int SSM>
 __global__ __launch_bounds__(kBlock) void k_second_order_ssd(BatchView bv, ImgView im, int term, int chained, int d0_variant,
-	double grad_eps, double hess_eps, double norm_mult, double norm_add, double *partials, int nblk, int own_pts) {
+	double grad_eps, double hess_eps, double norm_mult, double norm_add, double *partials, int nblk, int own_pts, SecondOrderNcc nc) {
 	constexpr int S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
 	__shared__ double lds[4 * S * S];
 	const int t = blockIdx.y, N = bv.N;
+	/* NCC (NCC.cc:391-410): the weights are its gradients df_dIt = (I0c / c - f Itc / b) / b and df_dI0 = (Itc / b - f I0c / c) / c
+	 * (NCC.cc:163-234), functions of this pass's It moments: every workgroup sums the three moment columns of the fused pass's
+	 * partial rows (same order everywhere: identical scalars in every workgroup) instead of waiting for a launch that would */
+	const bool ncc = nc.rows != nullptr;
+	double n_m0 = 0, n_c = 1, n_mt = 0, n_b = 1, n_f = 0;
+	if (ncc) {
+		__shared__ double mom_s[3];
+		if (threadIdx.x < 64) {
+			double s0 = 0, s1 = 0, s2 = 0;
+			for (int r = threadIdx.x; r < nc.nblk; r += 64) {
+				const double *row = nc.rows + ((size_t)t * nc.nblk + r) * NCC_ACC_COUNT;
+				s0 += row[NCC_IT]; s1 += row[NCC_IT2]; s2 += row[NCC_I0IT];
+			}
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+			if (threadIdx.x == 0) { mom_s[0] = s0; mom_s[1] = s1; mom_s[2] = s2; }
+		}
+		__syncthreads();
+		const double nN = (double)N;
+		n_m0 = nc.sc[(size_t)t * 8 + 0]; n_c = nc.sc[(size_t)t * 8 + 1];
+		n_mt = mom_s[0] / nN;
+		n_b = sqrt(mom_s[1] - nN * n_mt * n_mt);
+		n_f = (mom_s[2] - nN * n_m0 * n_mt) / (n_b * n_c);
+	}
 	const Warp9 W = load_warp(bv.warps + 9 * t);
 	const double *st = bv.states + 8 * t;
 	Warp9 Wid;
@@ -377,8 +403,14 @@ __global__ __launch_bounds__(kBlock) void k_second_order_ssd(BatchView bv, ImgVi
 		}
 		/* one block live at a time (acc + d2 + d0 together would not fit the register file):
 		 * r (D0 + Dt) = r Dt + r D0 and -r (D0 + Dt) / 2 = (-r / 2) Dt + (-r / 2) D0, equal to the reference's order to round-off */
-		const double wt = term == 0 ? -r : (term == 1 ? r : (term == 2 ? -r / 2.0 : 0.0));
-		const double w0 = term == 1 ? r : (term == 2 ? -r / 2.0 : (term == 3 ? r : 0.0));
+		double wt = term == 0 ? -r : (term == 1 ? r : (term == 2 ? -r / 2.0 : 0.0));
+		double w0 = term == 1 ? r : (term == 2 ? -r / 2.0 : (term == 3 ? r : 0.0));
+		if (ncc) {   /* the generic sum weights each block by its own gradient (AppearanceModel.h:209-219), not SSD's df_dI0 for both */
+			const double i0c_c = (I0[i] - n_m0) / n_c, itc_b = ((norm_mult * cv + norm_add) - n_mt) / n_b;
+			const double dft = (i0c_c - n_f * itc_b) / n_b, df0 = (itc_b - n_f * i0c_c) / n_c;
+			wt = term == 0 ? dft : (term == 1 ? dft : (term == 2 ? dft / 2.0 : 0.0));
+			w0 = term == 1 ? df0 : (term == 2 ? dft / 2.0 : (term == 3 ? df0 : 0.0));
+		}
 		if (term != 3) {
 #pragma unroll
 			for (int k = 0; k < S * S; ++k) acc[k] = fma(wt, d2[k], acc[k]);
@@ -457,14 +489,14 @@ void launch_weighted_plane_sum(const BatchView &bv, const double *d2a, const dou
 	MTFHIP_LAUNCH(k_plane_sum_finish, dim3(bv.B), dim3(64), 0, st, partials, nblk, bv.S * bv.S, out);
 }
 void launch_second_order_ssd(const BatchView &bv, const ImgView &im, int term, int chained, int d0_variant, double grad_eps,
-	double hess_eps, double norm_mult, double norm_add, double *partials, int nblk, double *out, hipStream_t st, int own_pts) {
+	double hess_eps, double norm_mult, double norm_add, double *partials, int nblk, double *out, hipStream_t st, int own_pts, SecondOrderNcc nc) {
 	const dim3 grid(nblk, bv.B);
 	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY)
 		MTFHIP_LAUNCH(k_second_order_ssd<MTFHIP_SSM_HOMOGRAPHY>, grid, dim3(kBlock), 0, st, bv, im, term, chained, d0_variant, grad_eps,
-			hess_eps, norm_mult, norm_add, partials, nblk, own_pts);
+			hess_eps, norm_mult, norm_add, partials, nblk, own_pts, nc);
 	else
 		MTFHIP_LAUNCH(k_second_order_ssd<MTFHIP_SSM_AFFINE>, grid, dim3(kBlock), 0, st, bv, im, term, chained, d0_variant, grad_eps,
-			hess_eps, norm_mult, norm_add, partials, nblk, own_pts);
+			hess_eps, norm_mult, norm_add, partials, nblk, own_pts, nc);
 	MTFHIP_LAUNCH(k_plane_sum_finish, dim3(bv.B), dim3(64), 0, st, partials, nblk, bv.S * bv.S, out);
 }
 

@@ -170,12 +170,14 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 		if (ncc) {
 			const int ht = sm.hess_type;
 			const double h0v = h0s[b2 * S + a];
+			/* sec_ord_hess (NCC.cc:391-410): the weighted pixel-Hessian sums of k_second_order_ssd's NCC form, entry (r, c) */
+			const double ex = ts.h_extra ? ts.h_extra_scale * ts.h_extra[(size_t)t * S * S + c * S + r] : 0.0;
 			if (ht == 0) return h0v;
-			if (sm.sm == MTFHIP_SM_ICLK) return n_hess(0, 0, r, c, kk);
-			if (sm.sm == MTFHIP_SM_FCLK || ht == 1 || ht == 5) return n_hess(ht == 1 ? 2 : 1, 1, r, c, kk);
+			if (sm.sm == MTFHIP_SM_ICLK) return n_hess(0, 0, r, c, kk) + ex;
+			if (sm.sm == MTFHIP_SM_FCLK || ht == 1 || ht == 5) return n_hess(ht == 1 ? 2 : 1, 1, r, c, kk) + ex;
 			if (ht == 2) return 0.5 * (n_hess(2, 1, r, c, kk) + h0v);
-			if (ht == 3) return n_hess(1, 2, r, c, kk);
-			return 0.5 * (n_hess(0, 0, r, c, kk) + n_hess(1, 1, r, c, kk));
+			if (ht == 3) return n_hess(1, 2, r, c, kk) + ex;
+			return 0.5 * (n_hess(0, 0, r, c, kk) + n_hess(1, 1, r, c, kk)) + ex;
 		}
 		double v = use_h0 ? h0s[b2 * S + a] : -acc_s[ACC_H + kk];
 		if (sum_h0) v = (v + h0s[b2 * S + a]) * 0.5;

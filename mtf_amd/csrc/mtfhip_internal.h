@@ -294,8 +294,12 @@ void launch_weighted_plane_sum(const BatchView &bv, const double *d2a, const dou
 	double *out, hipStream_t st);
 void launch_mean_planes(const double *a, const double *b, double *o, size_t n, hipStream_t st);
 /* fused second-order term of the SSD Hessians, pixel-Hessian blocks in registers only; out[t][S*S] */
+/* NCC weights for the fused second-order term: the fused NCC pass's partial rows of this iteration ([B][nblk][NCC_ACC_COUNT]) and
+ * the template scalars ([B][8]: mean(I0), |I0 - mean|); rows == nullptr selects SSD's residual weights */
+struct SecondOrderNcc { const double *rows; int nblk; const double *sc; };
 void launch_second_order_ssd(const BatchView &bv, const ImgView &im, int term, int chained, int d0_variant, double grad_eps,
-	double hess_eps, double norm_mult, double norm_add, double *partials, int nblk, double *out, hipStream_t st, int own_pts = 0);
+	double hess_eps, double norm_mult, double norm_add, double *partials, int nblk, double *out, hipStream_t st, int own_pts = 0,
+	SecondOrderNcc nc = SecondOrderNcc{nullptr, 0, nullptr});
 /* pre-processing / pyramid (float32 images) */
 void launch_hist_eq(float *gray, int rows, int cols, unsigned *hist256, float *lut256, hipStream_t st);
 void launch_to_gray(const void *raw, int rows, int cols, size_t stride_bytes, int channels, int depth_f32, float *out, hipStream_t st);

@@ -172,6 +172,14 @@ NCC_CASES = [
     (L.SM_FCLK, L.SSM_HOMOGRAPHY, 40, dict(hess_type=0)),
     (L.SM_ICLK, L.SSM_HOMOGRAPHY, 50, dict()),
     (L.SM_ICLK, L.SSM_AFFINE, 25, dict(hess_type=2)),                          # Std: cmptInitHessian depends on the frame
+    # second order (NCC.cc:391-410): the weighted pixel-Hessian sums with NCC's own gradients as weights
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, 40, dict(sec_ord_hess=1, hess_type=5)),
+    (L.SM_ESM, L.SSM_AFFINE, 40, dict(sec_ord_hess=1, hess_type=4, chained_warp=0)),
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, 40, dict(sec_ord_hess=1, hess_type=3, jac_type=0)),
+    (L.SM_FCLK, L.SSM_HOMOGRAPHY, 40, dict(sec_ord_hess=1, hess_type=2)),
+    (L.SM_FCLK, L.SSM_AFFINE, 40, dict(sec_ord_hess=1, hess_type=2, chained_warp=0)),
+    (L.SM_ICLK, L.SSM_HOMOGRAPHY, 40, dict(sec_ord_hess=1, hess_type=2)),
+    (L.SM_ICLK, L.SSM_AFFINE, 25, dict(sec_ord_hess=1, hess_type=2, chained_warp=0)),
 ]
 
 

@@ -344,9 +344,10 @@ def test_second_order_self_hessian_ncc_not_implemented(gpu_ctx, frame):
     (L.SM_FCLK, L.SSM_AFFINE, dict(hess_type=2, chained_warp=0)), (L.SM_ICLK, L.SSM_AFFINE, dict(hess_type=2)),
     (L.SM_ICLK, L.SSM_HOMOGRAPHY, dict(hess_type=2)), (L.SM_ESM, L.SSM_HOMOGRAPHY, dict(hess_type=5, leven_marq=1))],
     ids=lambda v: "_".join("%s%s" % kv for kv in v.items()) if isinstance(v, dict) else str(v))
-def test_device_loop_second_order_hessians(oracle, gpu_ctx, frame, sm_kind, ssm, extra):
-    """mtfhip_batch_track with sec_ord_hess (SSD): the second-order term of every search method's Hessian
-    (NT/ESM.cc:315-377, NT/FCLK.cc:262-283, NT/ICLK.cc:204-252; SSDBase.cc:313-415) is taken by one more pixel pass per
+@pytest.mark.parametrize("am", [L.AM_SSD, L.AM_NCC])
+def test_device_loop_second_order_hessians(oracle, gpu_ctx, frame, sm_kind, ssm, extra, am):
+    """mtfhip_batch_track with sec_ord_hess (SSD, NCC): the second-order term of every search method's Hessian
+    (NT/ESM.cc:315-377, NT/FCLK.cc:262-283, NT/ICLK.cc:204-252; SSDBase.cc:313-415, NCC.cc:391-410) is taken by one more pixel pass per
     iteration and the finish solves the (indefinite) system with pivoting -- final corners, iteration counts and the
     per-pass H / g / update of the trace against the oracle's second-order trackers"""
     rng = np.random.default_rng(29)
@@ -357,7 +358,7 @@ def test_device_loop_second_order_hessians(oracle, gpu_ctx, frame, sm_kind, ssm,
     params = dict(leven_marq=0, max_iters=12, epsilon=1e-5, sec_ord_hess=1)
     params.update(extra)
     gpu_ctx.set_image(frame)
-    b = mtf_amd.Batch(gpu_ctx, L.AM_SSD, ssm, res, res, B)
+    b = mtf_amd.Batch(gpu_ctx, am, ssm, res, res, B)
     b.set_math_mode(mtf_amd.MATH_REPLAY)
     b.set_corners(corners)
     sm = mtf_amd.sm_desc(sm_kind, materialize=0, **params)
@@ -368,7 +369,7 @@ def test_device_loop_second_order_hessians(oracle, gpu_ctx, frame, sm_kind, ssm,
     recs = b.read_track_trace(n_it)
     rel = lambda a, r: float(np.linalg.norm(np.asarray(a) - np.asarray(r)) / max(np.linalg.norm(r), 1e-300))
     for t in range(B):
-        o_ssm = oracle.SSM(ssm, res, res); o_am = oracle.AM(L.AM_SSD, res, res); o_am.set_curr_img(frame)
+        o_ssm = oracle.SSM(ssm, res, res); o_am = oracle.AM(am, res, res); o_am.set_curr_img(frame)
         trk = oracle.Tracker(sm_kind, o_am, o_ssm, **params)
         trk.initialize(corners[t]); o_am.set_curr_img(frame_b)
         iters = trk.update()
@@ -378,13 +379,19 @@ def test_device_loop_second_order_hessians(oracle, gpu_ctx, frame, sm_kind, ssm,
         # first pass: identical state -> H (with its second-order term), g and the update directly
         d0 = [r for r in recs[t] if not r["undo"]][0]
         assert d0["has_H"] and rel(d0["H"], tr[0]["H"]) < 1e-5 and rel(d0["g"], tr[0]["g"]) < 1e-5 and rel(d0["dp"], tr[0]["dp"]) < 1e-5
+        # the term is not vacuous: without it the first-pass Hessian is measurably another matrix
+        o_ssm1 = oracle.SSM(ssm, res, res); o_am1 = oracle.AM(am, res, res); o_am1.set_curr_img(frame)
+        trk1 = oracle.Tracker(sm_kind, o_am1, o_ssm1, **dict(params, sec_ord_hess=0))
+        trk1.initialize(corners[t]); o_am1.set_curr_img(frame_b); trk1.update()
+        assert rel(trk1.trace()[0]["H"], tr[0]["H"]) > 1e-4   # (the parity gate above is 1e-5)
     b.track_trace(0); b.close()
-    # NCC / MI second order stay with iterate and the per-function entry points
+    # MI second order stays with the per-function entry points; NCC has no second-order self Hessian (AppearanceModel.h:188-191)
     gpu_ctx.set_image(frame)
-    trk = LKTracker(gpu_ctx, L.SM_FCLK, L.SSM_HOMOGRAPHY, 30, 30, 2, host_solve=False, am=L.AM_NCC, sec_ord_hess=1, hess_type=2, max_iters=5)
-    with pytest.raises(mtf_amd.FunctionNotImplemented):
-        trk.initialize(corners[:2])
-        trk.update()
+    for bad_am, kw in ((L.AM_MI, dict(hess_type=2)), (L.AM_NCC, dict(hess_type=0))):
+        trk = LKTracker(gpu_ctx, L.SM_FCLK, L.SSM_HOMOGRAPHY, 30, 30, 2, host_solve=False, am=bad_am, sec_ord_hess=1, max_iters=5, **kw)
+        with pytest.raises(mtf_amd.FunctionNotImplemented):
+            trk.initialize(corners[:2])
+            trk.update()
 
 
 @pytest.mark.parametrize("am", [L.AM_SSD, L.AM_NCC])
