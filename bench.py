@@ -494,7 +494,9 @@ def secondary_workload(args):
                                    "sample": "%d iterations of one %dx%d target" % (n, res, res)}
     else:  # mi
         H = W = 2048
-        frame0 = synth.make_frame(H, W)
+        mc = args.channels == 3   # MCMI: MI over (pixel, channel) rows of a 32FC3 frame (AM/src/MCMI.cc)
+        amp = dict(n_channels=3) if mc else None
+        frame0 = synth.make_frame_mc(H, W) if mc else synth.make_frame(H, W)
         p_true = synth.random_small_homography(rng, 0.3)
         frame1 = synth.warp_frame(frame0, p_true, (W / 2.0, H / 2.0))
         B, res = args.targets, args.res
@@ -505,16 +507,16 @@ def secondary_workload(args):
         KI = 1
         if args.mi_path == "fused":      # mtfhip_batch_iterate: four pixel-level launches per iteration + host solve
             from mtf_amd.sm import LKTracker
-            nt = LKTracker(ctx, mtf_amd.SM_ESM, mtf_amd.SSM_HOMOGRAPHY, res, res, B, host_solve=True, am=mtf_amd.AM_MI,
+            nt = LKTracker(ctx, mtf_amd.SM_ESM, mtf_amd.SSM_HOMOGRAPHY, res, res, B, host_solve=True, am=mtf_amd.AM_MI, am_params=amp,
                            max_iters=1, epsilon=-1.0, leven_marq=0, materialize=0)
         elif args.mi_path == "device":   # mtfhip_batch_track: the same passes, solve + update on the device, KI iterations per call
             from mtf_amd.sm import LKTracker
             KI = 10
-            nt = LKTracker(ctx, mtf_amd.SM_ESM, mtf_amd.SSM_HOMOGRAPHY, res, res, B, host_solve=False, am=mtf_amd.AM_MI,
+            nt = LKTracker(ctx, mtf_amd.SM_ESM, mtf_amd.SSM_HOMOGRAPHY, res, res, B, host_solve=False, am=mtf_amd.AM_MI, am_params=amp,
                            max_iters=KI, epsilon=-1.0, leven_marq=0, materialize=0)
         else:                            # one C-ABI call per reference virtual
             nt = NTSearchMethod(ctx, mtf_amd.SM_ESM, mtf_amd.AM_MI, mtf_amd.SSM_HOMOGRAPHY, res, res, B, max_iters=1,
-                                epsilon=-1.0, leven_marq=0)
+                                epsilon=-1.0, leven_marq=0, am_params=amp)
         nt.initialize(corners)
         ctx.set_image(frame1)
         dt = timed(nt.update)
@@ -522,23 +524,25 @@ def secondary_workload(args):
         p1, n1 = ctx.timing_get("mi_pass1"); p2, n2 = ctx.timing_get("mi_pass2")
         recompute = n1 > 0
         if recompute:     # the recompute form: pass 1 reads 28 B/px (texels 4, I0 8, grid point 16), pass 2 44 B/px (+ dI0_dx 16); nothing written
-            mi_bytes = 72.0 * res * res * B
-            mi_roof = {"bound": "hbm", "note": "72 B/px moved per iteration (the materialising form moved 324); the two passes are bound by "
+            Cn = 3 if mc else 1   # rows are (pixel, channel) pairs; the pixel's grid point (16 B) is shared by its rows
+            bpr = (12.0 + 16.0 / Cn) + (28.0 + 16.0 / Cn)
+            mi_bytes = bpr * res * res * Cn * B
+            mi_roof = {"bound": "hbm", "note": "72 B/px (multi-channel: 50.7 B per (pixel, channel) row) moved per iteration (the materialising form moved 324); the two passes are bound by "
                        "FP64 / LDS / matrix-core issue, not by HBM: the fraction is reported for what it is",
                        "achieved": mi_bytes / ((p1 + p2) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": mi_bytes / ((p1 + p2) * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_mi_pass_hist + k_mi_pass_grad_hess",
-                       "avg_kernel_ms": {"pass1": p1, "pass2": p2}, "launches_timed": n1, "algorithmic_bytes_per_pixel": 72}
+                       "avg_kernel_ms": {"pass1": p1, "pass2": p2}, "launches_timed": n1, "algorithmic_bytes_per_row": bpr, "rows_per_target": res * res * Cn}
         else:
             mi_roof = None
         out.update({"roofline": mi_roof})
         out.update({"metric": "ESM+MI target-iterations/sec, %dx%d, %d targets" % (res, res, B),
                     "value": B * KI * args.steps * world / dt, "unit": "target-iters/s", "ms_per_step": dt / args.steps * 1e3,
-                    "scaling": "weak", "config": {"workload": "ESM+MI(8 bins)+Homography %dx%d x %d targets per GPU, %s" %
-                                                  (res, res, B, {"fused": "fused MI passes (mtfhip_batch_iterate) + host solve",
+                    "scaling": "weak", "config": {"workload": "ESM+%s(8 bins)+Homography %dx%d%s x %d targets per GPU, %s" %
+                                                  ("MCMI" if mc else "MI", res, res, "x3" if mc else "", B, {"fused": "fused MI passes (mtfhip_batch_iterate) + host solve",
                                                                  "device": "fused MI passes, solve + update on the device (mtfhip_batch_track), %d iterations per step" % KI,
                                                                  "interface": "per-function entry points"}[args.mi_path]),
                                                   "iterations_per_step": KI}})
-        if rank == 0 and not args.no_cpu:
+        if rank == 0 and not args.no_cpu and not mc:
             import oracle_py as O
             ssm = O.SSM(O.SSM_HOM, res, res); am = O.AM(O.AM_MI, res, res); am.set_curr_img(frame0)
             trk = O.Tracker(O.SM_ESM, am, ssm, leven_marq=0, max_iters=2, epsilon=-1.0)

@@ -89,9 +89,10 @@ typedef struct mtfhip_patch_desc {
 	double hess_eps;        /* ImgParams::hess_eps (1, AM/include/mtf/AM/ImageBase.h:9); <= 0 selects that default */
 	int n_channels;         /* 1 (or 0): SSD / NCC / MI ; 3: MCSSD / MCNCC / MCMI (AM/src/MCSSD.cc, MCNCC.cc, MCMI.cc: the same class
 	                           built with n_channels = 3).  Every per-pixel AM array then has n_pix * 3 rows interleaved per pixel,
-	                           the image is CV_32FC3 (mtfhip_image_upload_mc).  The per-function entry points and the fused
-	                           init_template / set_region / iterate / track calls apply (first-order Hessians); the one-launch grid
-	                           loop, the candidate scorer and the particle filter are single-channel */
+	                           the image is CV_32FC3 (mtfhip_image_upload_mc).  The per-function entry points, the fused
+	                           init_template / set_region / iterate / track calls (first-order Hessians; MCMI on the recompute
+	                           passes), the candidate scorer and the particle filter apply; a grid of multi-channel patches takes
+	                           the launch-per-pass loop instead of the one-launch grid kernel */
 } mtfhip_patch_desc;
 
 /* Search-method configuration; field meanings and enum values are the reference's

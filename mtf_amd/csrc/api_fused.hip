@@ -564,7 +564,7 @@ static int mi_enqueue(mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPlan &p
  * materialised, every first-order type but SumOfStd (two Hessian passes: it keeps the materialising form). */
 static bool mi_fast_ok(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPlan &pl) {
 	static const bool enabled = !(std::getenv("MTFHIP_MI_RECOMPUTE") && std::getenv("MTFHIP_MI_RECOMPUTE")[0] == '0');
-	return enabled && b->C == 1 && b->math_mode == MTFHIP_MATH_FAST && b->desc.mi_n_bins == 8 && !sm->materialize && pl.hk != MiPlan::H_SUM_STD;
+	return enabled && b->math_mode == MTFHIP_MATH_FAST && b->desc.mi_n_bins == 8 && !sm->materialize && pl.hk != MiPlan::H_SUM_STD;
 }
 static MiFastPlan mi_fast_plan(const mtfhip_batch *b, const MiPlan &pl, const int *active) {
 	MiFastPlan fp;
@@ -1020,7 +1020,6 @@ int score_block_dev(mtfhip_batch *b, const double *dev_states, int lo, int cnt, 
 	hipStream_t st = b->ctx->stream;
 	if (b->desc.am == MTFHIP_AM_MI) {
 		if (b->desc.mi_n_bins != 8) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "score_candidates: MI candidates are scored with 8 bins (the reference's default, parameters.h:344)");
-		if (b->C != 1) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "score_candidates: MCMI candidates are not available");
 		if (!b->init_sim) return fail(MTFHIP_ERR_LOGIC, "score_candidates before initializeSimilarity");
 		const int nblk = 1;
 		const size_t need = (size_t)std::max(cnt, 1) * nblk * b->mi_row_len;

@@ -1,0 +1,21 @@
+/*
+ * mtfhip_mi_pass2_unit.h -- body of the kernels_mi_pass2_*.hip translation units: the five (Hessian kind, Jacobian row) forms of pass 2 of the
+ * MI recompute iteration (k_mi_pass_grad_hess, mtfhip_mi_fused_device.h) for ONE state-space model and channel layout, named by
+ * MTFHIP_P2_SSM / MTFHIP_P2_MC / MTFHIP_P2_NAME.
+ */
+#include "mtfhip_mi_fused_device.h"
+
+namespace mtfhip {
+
+void MTFHIP_P2_NAME(const BatchView &bv, const ImgView &im, const MiPassArgs &pa, int hk, int hrow, double *partials, int nblk, hipStream_t st) {
+	const dim3 g = grid2(nblk, bv.B);
+#define MTFHIP_MI_P2(HK_, HR_) MTFHIP_LAUNCH((k_mi_pass_grad_hess<MTFHIP_P2_SSM, HK_, HR_, MTFHIP_P2_MC>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk)
+	if (hk == 0) MTFHIP_MI_P2(0, 0);
+	else if (hk == 1) MTFHIP_MI_P2(1, 0);
+	else if (hk == 2 && hrow == 2) MTFHIP_MI_P2(2, 2);
+	else if (hk == 2) MTFHIP_MI_P2(2, 0);
+	else MTFHIP_MI_P2(3, 1);
+#undef MTFHIP_MI_P2
+}
+
+} // namespace mtfhip
