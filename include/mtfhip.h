@@ -391,6 +391,10 @@ int mtfhip_sample_candidates_dev(mtfhip_batch *b, const double *dev_states, int 
 int mtfhip_timing_enable(mtfhip_ctx *ctx, int on);
 int mtfhip_timing_reset(mtfhip_ctx *ctx);
 int mtfhip_timing_get(mtfhip_ctx *ctx, const char *kernel_family, double *avg_ms, int *n_launches);
+/* 1 when the single-target launches carry the warp inside the kernel arguments (the library probes once per process that the
+ * runtime lays the kernel-argument segment out the way the kernels read it; MTFHIP_INLINE_WARP=0 or a failed probe: 0, and
+ * the warp is uploaded in front of every launch instead -- same results, 4-6 us more per iteration of a single target) */
+int mtfhip_batch_inline_warp(const mtfhip_batch *b);
 
 #ifdef __cplusplus
 }

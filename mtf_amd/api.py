@@ -449,6 +449,11 @@ class Batch:
         c = self._corners_in(corners)
         L.check(L.lib().mtfhip_batch_set_region(self._h, _p(c), C.byref(sm)))
 
+    @property
+    def inline_warp(self):
+        """True when single-target launches carry the warp in the kernel arguments (mtfhip_batch_inline_warp)"""
+        return bool(L.lib().mtfhip_batch_inline_warp(self._h))
+
     def track_targets_per_launch(self, sm):
         return L.lib().mtfhip_batch_track_targets_per_launch(self._h, C.byref(sm))
 

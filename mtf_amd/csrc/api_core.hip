@@ -373,7 +373,7 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 	if (r) return cleanup(r);
 	{
 		const char *iw_env = std::getenv("MTFHIP_INLINE_WARP");
-		b->inline_warp_ok = b->B == 1 && !(iw_env && iw_env[0] == '0');
+		b->inline_warp_ok = b->B == 1 && !(iw_env && iw_env[0] == '0') && kernarg_layout_verified(c->stream);
 		const char *lazy_env = std::getenv("MTFHIP_LAZY");
 		/* SSD and NCC have a fused kernel each; MI has its fused passes */
 		b->lz.enabled = (d->am == MTFHIP_AM_SSD || d->am == MTFHIP_AM_NCC || d->am == MTFHIP_AM_MI) && b->C == 1 &&
@@ -809,6 +809,6 @@ int mtfhip_timing_get(mtfhip_ctx *c, const char *family, double *avg_ms, int *n_
 	if (n_launches) *n_launches = n;
 	return MTFHIP_OK;
 }
-
+int mtfhip_batch_inline_warp(const mtfhip_batch *b) { return b && b->inline_warp_ok ? 1 : 0; }
 
 } /* extern "C" */

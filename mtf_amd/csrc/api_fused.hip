@@ -731,6 +731,7 @@ int mtfhip_batch_track_targets_per_launch(mtfhip_batch *b, const mtfhip_sm_desc 
 }
 
 static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners, bool slab_uploaded, bool resume = false);
+static int track_validate(mtfhip_batch *b, const mtfhip_sm_desc *sm);
 /* ---- the persistent one-launch loop (kernels_persist.hip) ---- */
 /* rows per workgroup so that every target's workgroups are resident together: the default decomposition when it fits, else the
  * smallest number of rows that does */
@@ -772,15 +773,16 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
  * active flags / iteration counts travel in ONE staged copy; the others take the two steps one after the other. */
 int mtfhip_batch_track_region(mtfhip_batch *b, const mtfhip_sm_desc *sm, const double *region_corners, int *n_iters, double *corners) {
 	if (!b || !sm || !region_corners) return fail(MTFHIP_ERR_INVALID_ARG, "track_region: NULL argument");
-	if (sm->max_iters <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "track: max_iters must be positive");
+	/* everything track_core would refuse is refused before the SSM is reset (the folded upload reads the pinned staging buffer
+	 * without an event guard: the loop that follows is what the host waits for) */
+	TRY(track_validate(b, sm));
 	const bool folded = !region_refreshes(sm);
 	TRY(set_region_core(b, region_corners, sm, folded));
 	return track_core(b, sm, n_iters, corners, folded);
 }
 
-static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners, bool slab_uploaded, bool resume) {
-	FLUSH_AM(b);   /* (none of the loop's kernels reads CURR_PTS: they warp the template grid themselves) */
-	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
+/* the argument / state checks of the device loop, without side effects (track_region runs them before it resets the SSM) */
+static int track_validate(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	TRY(check_sm(b, sm, "track"));
 	TRY(fused_channels_ok(b, "track"));
 	if (sm->max_iters <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "track: max_iters must be positive");
@@ -790,7 +792,13 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 	if (so_term >= 0 && b->C != 1) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: second-order Hessians of the multi-channel models use the per-function entry points");
 	if (so_term > 0 && !b->init_pix_hess) return fail(MTFHIP_ERR_LOGIC, "track: init_template was run without sec_ord_hess");
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "track before init_template");
-	TRY(need_image(b));
+	return need_image(b);
+}
+static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners, bool slab_uploaded, bool resume) {
+	FLUSH_AM(b);   /* (none of the loop's kernels reads CURR_PTS: they warp the template grid themselves) */
+	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
+	TRY(track_validate(b, sm));
+	const int so_term = second_order_term(sm);
 	hipStream_t st = b->ctx->stream;
 	const bool mi = b->desc.am == MTFHIP_AM_MI;
 	/* (the one-launch grid kernel has no Levenberg-Marquardt: with it ICLK takes the fused launch + finish per pass) */

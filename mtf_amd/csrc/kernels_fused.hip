@@ -118,6 +118,38 @@ void launch_finish_track_mi(const BatchView &bv, const mtfhip_sm_desc &sm, const
 	MTFHIP_LAUNCH(k_finish_track_mi, dim3(bv.B), dim3(64), 0, st, bv, sm, ts, sum_std, gmode, mi_H, gpart, ng, rows);
 }
 
+/* The single-target launches read the warp and the state out of the kernel-argument segment at an offset computed from the C++
+ * layout of (BatchView, ImgView, FusedArgs) -- fused_lk_body's static_asserts check the structs, not what the runtime actually
+ * puts into the segment.  This probe has the fused kernels' leading parameters, reads the seventeen doubles with the same
+ * arithmetic and hands them back: the library asks once per process and keeps the warp upload in front of every launch if the
+ * answer is not what it passed in. */
+__global__ void k_kernarg_probe(BatchView bv, ImgView im, FusedArgs fa, double *out) {
+	const char *kernarg = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
+	const double *kw = reinterpret_cast<const double *>(kernarg + sizeof(BatchView) + sizeof(ImgView) + offsetof(FusedArgs, iw));
+	if (threadIdx.x < 17) out[threadIdx.x] = kw[threadIdx.x];
+	if (threadIdx.x == 17) out[17] = (double)(bv.B + im.w + fa.mode);   /* (the arguments are live) */
+}
+bool kernarg_layout_verified(hipStream_t st) {
+	static int state = -1;   /* -1 not asked, 0 no, 1 yes */
+	if (state >= 0) return state == 1;
+	state = 0;
+	double *d_out = nullptr;
+	if (hipMalloc(&d_out, sizeof(double) * 18) != hipSuccess) { (void)hipGetLastError(); return false; }
+	BatchView bv{}; ImgView im{}; FusedArgs fa{};
+	bv.B = 1; im.w = 2; fa.mode = 3; fa.inline_warp = 1;
+	for (int q = 0; q < 9; ++q) fa.iw[q] = 0.5 + 1.25 * q;
+	for (int q = 0; q < 8; ++q) fa.is[q] = -3.0 - 0.75 * q;
+	double h[18] = {0};
+	hipLaunchKernelGGL(k_kernarg_probe, dim3(1), dim3(64), 0, st, bv, im, fa, d_out);
+	bool ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, st) == hipSuccess &&
+		hipStreamSynchronize(st) == hipSuccess;
+	(void)hipFree(d_out);
+	for (int q = 0; ok && q < 9; ++q) ok = h[q] == fa.iw[q];
+	for (int q = 0; ok && q < 8; ++q) ok = h[9 + q] == fa.is[q];
+	state = ok ? 1 : 0;
+	return ok;
+}
+
 #ifdef MTFHIP_FIN_TRACE
 void debug_fin_trace(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fin_trace), sizeof(unsigned long long) * 16); }
 #endif

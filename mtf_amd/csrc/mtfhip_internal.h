@@ -157,6 +157,8 @@ struct FusedArgs {
 	int fast_math;
 };
 
+/* one-time probe: does the kernel-argument segment hold (BatchView, ImgView, FusedArgs) where fused_lk_body's inline-warp path reads them? */
+bool kernarg_layout_verified(hipStream_t st);
 /* ---- launchers (all asynchronous on `st`) ---- */
 void launch_apply_warp(const BatchView &bv, hipStream_t st);
 void launch_grad_pts(const BatchView &bv, double eps, hipStream_t st);

@@ -864,3 +864,32 @@ def test_deferred_calls_survive_an_image_change(gpu_ctx, frame, frame2, monkeypa
         vals[lazy] = b.read(L.BUF_IT).copy()
         b.close()
     assert np.array_equal(vals[0], vals[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("am", [L.AM_SSD, L.AM_NCC])
+@pytest.mark.parametrize("ssm", [L.SSM_HOMOGRAPHY, L.SSM_AFFINE])
+def test_inline_warp_probe_and_equivalence(gpu_ctx, frame, frame2, ssm, am, monkeypatch):
+    """Single-target launches read the warp / state from the kernel-argument segment (fused_lk_body, `inline_warp`): the library
+    probes once per process that the runtime lays the segment out as the kernels assume (k_kernarg_probe) -- on gfx950 the probe
+    must succeed -- and the path gives the bits of the upload-first path (MTFHIP_INLINE_WARP=0), through iterate and through
+    the device loop."""
+    rng = np.random.default_rng(5)
+    corners = (synth.square_corners(250, 260, 70) + rng.uniform(-2, 2, size=(2, 4)))[None]
+    out = {}
+    for inline in ("1", "0"):
+        monkeypatch.setenv("MTFHIP_INLINE_WARP", inline)
+        gpu_ctx.set_image(frame)
+        b = mtf_amd.Batch(gpu_ctx, am, ssm, 40, 40, 1)
+        assert b.inline_warp == (inline == "1")
+        b.set_math_mode(mtf_amd.MATH_REPLAY)
+        b.set_corners(corners)
+        sm = mtf_amd.sm_desc(L.SM_ESM, materialize=1, leven_marq=0, max_iters=6, epsilon=-1.0)
+        b.init_template(sm)
+        gpu_ctx.set_image(frame2)
+        f, g, H = b.iterate(sm)
+        n_it, final = b.track(sm)
+        out[inline] = (f.copy(), g.copy(), H.copy(), final.copy(), b.read(L.BUF_IT).copy())
+        b.close()
+    for a, r in zip(out["1"], out["0"]):
+        assert np.array_equal(a, r)
