@@ -50,7 +50,7 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(sm, mode, res, targets):
+def pmc_traffic(sm, mode, res, targets, per_launch=None):
     """HBM bytes per launch of the fused kernel from the PMC passes of tools/profile_round.sh (profiles/pmc_latest.json: separate
     --pmc runs, KiB units, gfx950 FETCH_SIZE x2 correction).  Only reported for the workload it was collected on AND only while
     the kernel sources are the ones it was collected on (kernel_sources_sha): a stale figure is withheld, not printed."""
@@ -62,6 +62,9 @@ def pmc_traffic(sm, mode, res, targets):
         d = json.load(open(path))
         if d.get("j0_recompute", False) != (os.environ.get("MTFHIP_J0_RECOMPUTE", "1") != "0"):
             return None      # the profile was taken with the other J0 source
+        if per_launch is not None and float(d.get("targets_per_launch", targets)) != float(per_launch):
+            pmc_traffic.note = "withheld: profiles/pmc_latest.json counts launches of %s targets, this run launches %s" % (d.get("targets_per_launch", targets), per_launch)
+            return None
         pmc_traffic.commit = d.get("commit")
         if d.get("kernel_sources_sha") != kernel_sources_sha():
             pmc_traffic.note = "withheld: profiles/pmc_latest.json was collected on other kernel sources (%s, now %s); re-run tools/profile_round.sh" % (
@@ -689,6 +692,10 @@ def main():
     run(k_steps)
     torch.cuda.synchronize(dev)
     kern_ms, kern_n = ctx.timing_get("fused_lk")
+    # launches of the fused kernel overlap when the loop keeps two chunks of targets in flight on two queues: the time the kernel was
+    # executing is the union of the launches' intervals (equal to their sum on one queue)
+    busy_ms, busy_n = ctx.timing_get_busy("fused_lk")
+    fin_ms, fin_n = ctx.timing_get("finish_track")
     ctx.timing(False)
     # the lean variant of the same workload (nothing materialised: the form the device-side loop needs): FP64-issue / latency bound
     lean = None
@@ -720,7 +727,11 @@ def main():
         if B % per_launch:                                 # a ragged last chunk would mix two launch sizes in the average
             per_launch = B / float(-(-B // per_launch))
         bytes_per_launch = float(bpp) * N * per_launch
-        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        queues = batch.track_queues(sm)
+        # algorithmic bytes of the timed launches / time during which the kernel was executing.  One queue: = bytes per launch / average
+        # launch duration.  Two queues: the launches overlap, one of them sees bytes_per_launch / avg_kernel_ms, together they reach this
+        achieved = bytes_per_launch * busy_n / (busy_ms * 1e-3) / 1e9 if busy_ms > 0 else 0.0
+        in_flight = kern_ms * kern_n / busy_ms if busy_ms > 0 else 0.0
         out = {
             "metric": "LK iters/sec (warp+grad+Hessian), ESM+%s%s+Homography 200x200" % ("MC" if CH > 1 else "", args.am.upper()),
             "value": B * world * args.steps / dt,
@@ -734,8 +745,13 @@ def main():
                        "targets_per_gpu": B, "n_pix": N, "channels": CH, "mode": args.mode, "frame": "%dx%d float32%s" % (H, W, " x %d channels" % CH if CH > 1 else ""),
                        "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.sm, args.mode, res, B) if (args.am == "ssd" and CH == 1) else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.sm, args.mode, res, B, per_launch) if (args.am == "ssd" and CH == 1) else None,
                          "kernel": "k_fused_%s" % args.am, "avg_kernel_ms": kern_ms, "launches_timed": kern_n,
+                         "queues": queues, "kernel_busy_ms": busy_ms, "launches_in_flight": in_flight,
+                         "per_launch_GBs": bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None,
+                         "formula": "achieved = bytes_per_launch x launches_timed / kernel_busy_ms (kernel_busy_ms = union of the launches' "
+                                    "event intervals) = per_launch_GBs x launches_in_flight",
+                         "avg_finish_ms": fin_ms,
                          "algorithmic_bytes_per_pixel": bpp, "j0_rows": "rebuilt from dI0_dx" if j0_rec else "read back", "bytes_per_launch": bytes_per_launch,
                          "targets_per_launch": per_launch,
                          # what the figure means: algorithmic bytes / kernel time.  The read set of a launch (grid points, I0, dI0_dx:

@@ -299,6 +299,9 @@ int mtfhip_batch_track_trace(mtfhip_batch *b, int max_passes);
 int mtfhip_batch_track_trace_read(mtfhip_batch *b, double *dst);
 /* how many targets one launch of the loop above covers (all of them, or an Infinity-Cache sized chunk) */
 int mtfhip_batch_track_targets_per_launch(mtfhip_batch *b, const mtfhip_sm_desc *sm);
+/* how many queues (HIP streams) the loop above keeps busy with independent chunks of the targets: 2 for the launches that write the
+ * interface arrays (one chunk's solve + update runs under the other's pixel pass), else 1; MTFHIP_TRACK_STREAMS=1 forces 1 */
+int mtfhip_batch_track_queues(mtfhip_batch *b, const mtfhip_sm_desc *sm);
 
 /* ---- candidate scoring (PF / NN batch axis): target 0's template, C warps ----
  * per candidate: setState -> updatePixVals -> updateSimilarity(false) -> getLikelihood
@@ -391,6 +394,11 @@ int mtfhip_sample_candidates_dev(mtfhip_batch *b, const double *dev_states, int 
 int mtfhip_timing_enable(mtfhip_ctx *ctx, int on);
 int mtfhip_timing_reset(mtfhip_ctx *ctx);
 int mtfhip_timing_get(mtfhip_ctx *ctx, const char *kernel_family, double *avg_ms, int *n_launches);
+/* time (ms) during which at least one launch of the family was executing since the last reset -- the union of the timed
+ * launches' intervals -- and their number.  The device-side loop keeps two chunks of targets in flight on two queues
+ * (mtfhip_batch_track), so launches of one kernel overlap there: bytes moved / busy time is the bandwidth the kernel's launches
+ * reached together, bytes per launch / average duration what one of them saw. */
+int mtfhip_timing_get_busy(mtfhip_ctx *ctx, const char *kernel_family, double *busy_ms, int *n_launches);
 /* 1 when the single-target launches carry the warp inside the kernel arguments (the library probes once per process that the
  * runtime lays the kernel-argument segment out the way the kernels read it; MTFHIP_INLINE_WARP=0 or a failed probe: 0, and
  * the warp is uploaded in front of every launch instead -- same results, 4-6 us more per iteration of a single target) */

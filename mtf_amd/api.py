@@ -151,6 +151,12 @@ class Context:
         L.check(L.lib().mtfhip_timing_get(self._h, family.encode(), C.byref(avg), C.byref(n)))
         return avg.value, n.value
 
+    def timing_get_busy(self, family):
+        """(ms during which at least one launch of the family was executing, launches): the union of their intervals"""
+        busy, n = C.c_double(), C.c_int()
+        L.check(L.lib().mtfhip_timing_get_busy(self._h, family.encode(), C.byref(busy), C.byref(n)))
+        return busy.value, n.value
+
 
 class Batch:
     """B independent targets (AM + SSM pairs) sharing the context's current image."""
@@ -456,6 +462,10 @@ class Batch:
 
     def track_targets_per_launch(self, sm):
         return L.lib().mtfhip_batch_track_targets_per_launch(self._h, C.byref(sm))
+
+    def track_queues(self, sm):
+        """queues the device-side loop keeps busy with independent chunks of targets (mtfhip_batch_track_queues)"""
+        return L.lib().mtfhip_batch_track_queues(self._h, C.byref(sm))
 
     def iterate(self, sm):
         f = np.empty(self.B)

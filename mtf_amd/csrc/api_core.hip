@@ -5,6 +5,7 @@
  * No CPU fallback exists: every entry point either runs its HIP kernels or returns an error.
  */
 #include "mtfhip_api_internal.h"
+#include <algorithm>
 
 /* Kernel arguments in device memory instead of host-coherent memory: the fused kernel's first instruction is a
  * scalar load of its 400-byte argument block, and every step is two launches, so the PCIe round trip of that load is
@@ -75,6 +76,12 @@ void mtfhip_ctx_destroy(mtfhip_ctx *c) {
 		if (c->raw) (void)hipFree(c->raw);
 		if (c->tmp_a) (void)hipFree(c->tmp_a);
 		if (c->tmp_b) (void)hipFree(c->tmp_b);
+		for (int q = 0; q < 3; ++q) {
+			if (c->extra_streams[q]) (void)hipStreamDestroy(c->extra_streams[q]);
+			if (c->ev_join[q]) (void)hipEventDestroy(c->ev_join[q]);
+		}
+		if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+		if (c->ev_ref) (void)hipEventDestroy(c->ev_ref);
 		if (c->own_stream) (void)hipStreamDestroy(c->stream);
 	} catch (...) {
 	}
@@ -783,10 +790,15 @@ int mtfhip_timing_enable(mtfhip_ctx *c, int on) {
 }
 static void drain(mtfhip_ctx *c) {
 	(void)hipStreamSynchronize(c->stream);
+	for (hipStream_t s : c->extra_streams) if (s) (void)hipStreamSynchronize(s);
 	for (auto &kv : c->timers) {
 		for (auto &p : kv.second.pending) {
-			float ms = 0;
-			if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { kv.second.total_ms += ms; kv.second.n += 1; }
+			float ms = 0, t0 = 0;
+			if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+				kv.second.total_ms += ms; kv.second.n += 1;
+				if (c->ev_ref && hipEventElapsedTime(&t0, c->ev_ref, p.first) == hipSuccess) kv.second.spans.emplace_back((double)t0, (double)t0 + ms);
+				else (void)hipGetLastError();
+			}
 			c->free_events.push_back(p.first);
 			c->free_events.push_back(p.second);
 		}
@@ -796,7 +808,31 @@ static void drain(mtfhip_ctx *c) {
 int mtfhip_timing_reset(mtfhip_ctx *c) {
 	if (!c) return fail(MTFHIP_ERR_INVALID_ARG, "timing_reset: NULL ctx");
 	drain(c);
-	for (auto &kv : c->timers) { kv.second.total_ms = 0; kv.second.n = 0; kv.second.launches = 0; }
+	for (auto &kv : c->timers) { kv.second.total_ms = 0; kv.second.n = 0; kv.second.launches = 0; kv.second.spans.clear(); }
+	if (!c->ev_ref && hipEventCreate(&c->ev_ref) != hipSuccess) { (void)hipGetLastError(); c->ev_ref = nullptr; }
+	if (c->ev_ref) { (void)hipEventRecord(c->ev_ref, c->stream); (void)hipStreamSynchronize(c->stream); }
+	return MTFHIP_OK;
+}
+/* time during which at least one launch of the family was executing (the union of its launches' intervals) and their number:
+ * equal to n x the average of mtfhip_timing_get while launches follow each other on one queue, smaller when they overlap */
+int mtfhip_timing_get_busy(mtfhip_ctx *c, const char *family, double *busy_ms, int *n_launches) {
+	if (!c || !family) return fail(MTFHIP_ERR_INVALID_ARG, "timing_get_busy: NULL argument");
+	drain(c);
+	auto it = c->timers.find(family);
+	double busy = 0; int n = 0;
+	if (it != c->timers.end()) {
+		std::vector<std::pair<double, double>> sp = it->second.spans;
+		std::sort(sp.begin(), sp.end());
+		double cur_a = 0, cur_b = -1;
+		for (const auto &iv : sp) {
+			if (cur_b < cur_a || iv.first > cur_b) { if (cur_b >= cur_a) busy += cur_b - cur_a; cur_a = iv.first; cur_b = iv.second; }
+			else if (iv.second > cur_b) cur_b = iv.second;
+		}
+		if (cur_b >= cur_a) busy += cur_b - cur_a;
+		n = (int)sp.size();
+	}
+	if (busy_ms) *busy_ms = busy;
+	if (n_launches) *n_launches = n;
 	return MTFHIP_OK;
 }
 int mtfhip_timing_get(mtfhip_ctx *c, const char *family, double *avg_ms, int *n_launches) {

@@ -5,6 +5,7 @@
  * No CPU fallback exists: every entry point either runs its HIP kernels or returns an error.
  */
 #include "mtfhip_api_internal.h"
+#include <chrono>
 
 extern "C" {
 
@@ -719,6 +720,23 @@ static int track_chunk(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const Fu
 	const int n_chunks = (b->B + chunk - 1) / chunk;
 	return (b->B + n_chunks - 1) / n_chunks;   /* balanced: 100 targets -> 50 + 50, not 65 + 35 */
 }
+/* Queues of the device-side loop.  Two for the launches that materialise the interface arrays (HBM-bound: ESM / FCLK full mode, NCC,
+ * the multi-channel models): the solve + update of one chunk of targets -- one-wave workgroups, a 6.5 us chain of dependent
+ * latencies -- and the fill / drain of its pixel pass then run under the other chunk's pixel pass.  Measured at 200 x 200 x 64 (one
+ * call): 61.5 -> 49-52 us per step in calls of >= 100 iterations, 64.5 -> 59-63 at 20; the lean / ICLK launches (issue-bound) gain
+ * 0-4 %, small patches lose (50 x 50: -7 %): they keep one queue.  MTFHIP_TRACK_STREAMS=1 selects the single queue, 3 / 4 more
+ * queues (measured slower), 12 two queues for every launch kind (A/B knob). */
+static int track_queues(const mtfhip_batch *b, const FusedArgs &fa) {
+	const char *e_want = std::getenv("MTFHIP_TRACK_STREAMS");   /* (read per call: the tests switch it) */
+	const int want = e_want ? std::atoi(e_want) : 2;
+	if (want < 2 || b->B < 2 || b->d_trace) return 1;
+	if (!fa.materialize && want < 12) return 1;
+	/* small passes are launch- and latency-sized, not bandwidth-sized: 8 x 200 x 200 and 64 x 50 x 50 measured 5-14 % slower on two queues
+	 * in 20-iteration calls, 16 / 32 / 48 x 200 x 200 6-22 % faster */
+	static const double min_rows = std::getenv("MTFHIP_TRACK_STREAMS_MIN_ROWS") ? std::atof(std::getenv("MTFHIP_TRACK_STREAMS_MIN_ROWS")) : 0.5e6;
+	if ((double)b->B * b->N < min_rows && want < 12) return 1;
+	return std::min(std::min(want % 10, 4), b->B);
+}
 int mtfhip_batch_track_targets_per_launch(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	FLUSH(b);
 	if (check_sm(b, sm, "track_targets_per_launch") != MTFHIP_OK) return 0;
@@ -727,7 +745,19 @@ int mtfhip_batch_track_targets_per_launch(mtfhip_batch *b, const mtfhip_sm_desc 
 	if (one_launch) return b->B;
 	FusedArgs fa;
 	if (fused_args(b, sm, fa) != MTFHIP_OK) return 0;
-	return track_chunk(b, sm, fa);
+	const int chunk = track_chunk(b, sm, fa), nq = track_queues(b, fa);
+	return nq >= 2 ? std::min(chunk, (b->B + nq - 1) / nq) : chunk;
+}
+int mtfhip_batch_track_queues(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
+	FLUSH(b);
+	if (check_sm(b, sm, "track_queues") != MTFHIP_OK) return 0;
+	if (b->desc.am == MTFHIP_AM_MI) return 1;
+	const bool one_launch = b->C == 1 && sm->sm == MTFHIP_SM_ICLK && (sm->hess_type == 0 || (sm->hess_type == 2 && b->desc.am == MTFHIP_AM_SSD)) &&
+		b->N <= kIclkTrackMaxPix;
+	if (one_launch) return 1;
+	FusedArgs fa;
+	if (fused_args(b, sm, fa) != MTFHIP_OK) return 0;
+	return track_queues(b, fa);
 }
 
 static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners, bool slab_uploaded, bool resume = false);
@@ -828,11 +858,12 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 	 * and two rejections never follow each other (the pass after an undo skips the test) */
 	const int max_passes = (sm->leven_marq && sm->sm == MTFHIP_SM_FCLK) ? 2 * sm->max_iters : sm->max_iters;
 	std::vector<int> h_active;
-	auto all_converged = [&](const int *d_flags, int n, int it) -> bool {
+	auto all_converged = [&](const int *d_flags, int n, int it, hipStream_t on = nullptr) -> bool {
 		if (!(sm->epsilon > 0) || (it + 1) % 8 != 0 || it + 1 >= max_passes) return false;
+		if (!on) on = st;
 		h_active.resize(n);
-		if (hipMemcpyAsync(h_active.data(), d_flags, sizeof(int) * n, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
-		if (hipStreamSynchronize(st) != hipSuccess) return false;
+		if (hipMemcpyAsync(h_active.data(), d_flags, sizeof(int) * n, hipMemcpyDeviceToHost, on) != hipSuccess) return false;
+		if (hipStreamSynchronize(on) != hipSuccess) return false;
 		for (int v : h_active) if (v) return false;
 		return true;
 	};
@@ -914,7 +945,40 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 		 * starts.  A chunk is sized so that what an iteration reads once (J0, I0, grid: 88 B/px for ESM) stays resident in
 		 * the 256 MB Infinity Cache from one iteration to the next -- B = 64 at 200 x 200; larger batches used to fall back
 		 * to plain HBM for both streams (0.62 instead of 0.75 of peak).  See track_chunk(). */
-		const int chunk = track_chunk(b, sm, fa);
+		int chunk = track_chunk(b, sm, fa);
+		/* two chunks of targets in flight on two queues where that pays (track_queues); each chunk's pixel pass is then cut for half
+		 * the resident workgroups, so that the two launches in flight fill the device once */
+		static const bool stagger_ok = !(std::getenv("MTFHIP_TRACK_STAGGER") && std::getenv("MTFHIP_TRACK_STAGGER")[0] == '0');
+		int n_streams = track_queues(b, fa);
+		if (n_streams >= 2) {
+			mtfhip_ctx *c = b->ctx;
+			if (!c->ev_fork && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); n_streams = 1; }
+			for (int q = 0; q + 1 < n_streams; ++q)
+				if (!c->extra_streams[q] && (hipStreamCreateWithFlags(&c->extra_streams[q], hipStreamNonBlocking) != hipSuccess ||
+					hipEventCreateWithFlags(&c->ev_join[q], hipEventDisableTiming) != hipSuccess)) { (void)hipGetLastError(); n_streams = 1; break; }
+		}
+		if (n_streams >= 2) {
+			const int part_sz = (b->B + n_streams - 1) / n_streams;
+			if (chunk > part_sz) chunk = part_sz;
+			if (!stagger_ok) {   /* (staggered queues wait for the first queue's first pixel pass anyway, which is behind the slab upload) */
+				HIP_TRY(hipEventRecord(b->ctx->ev_fork, st));
+				for (int q = 0; q + 1 < n_streams; ++q) HIP_TRY(hipStreamWaitEvent(b->ctx->extra_streams[q], b->ctx->ev_fork, 0));
+			}
+		}
+		/* The later queues start a quarter of a period behind the first (a spinning one-wave kernel; the period is estimated from the
+		 * bytes a pass moves): in lockstep -- where two queues started together stay -- the fill and drain phases of the two pixel passes
+		 * coincide and so do the two solves: 55 us per step of 64 x 200 x 200 against 49-52 out of phase.  A/B at that size, three
+		 * boxes: no delay 1.05-1.10 M iters/s in 20-iteration calls and 1.13-1.19 M in 200-iteration ones, 15 us 1.13-1.15 M and
+		 * 1.28-1.30 M, 25 / 30 / 35 us in between and less repeatable.  MTFHIP_TRACK_STAGGER_US: > 0 that many microseconds, 0 the
+		 * later queues wait for the first queue's first pixel pass instead (the r03 first version). */
+		static const double stagger_env = std::getenv("MTFHIP_TRACK_STAGGER_US") ? std::atof(std::getenv("MTFHIP_TRACK_STAGGER_US")) : -1.0;
+		double stagger_us = stagger_env;
+		if (stagger_env < 0) stagger_us = 0.25 * ((double)b->B * b->N * 130.0 / 6.5e6 + 8.0) * (2.0 / n_streams);
+		if (n_streams >= 2 && stagger_ok && stagger_us > 0) {   /* the delayed queues start from the slab upload */
+			HIP_TRY(hipEventRecord(b->ctx->ev_fork, st));
+		}
+		struct ChunkRun { BatchView bc; FusedArgs fc; TrackState tc; int nblk_c, t0, nt; double *part; hipStream_t s; bool done; };
+		std::vector<ChunkRun> runs;
 		for (int t0 = 0; t0 < b->B; t0 += chunk) {
 			const int nt = std::min(chunk, b->B - t0);
 			BatchView bc = bv;
@@ -929,22 +993,54 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 				ncc ? ts.ncc_tm + 52 * (size_t)t0 : nullptr, 0, ts.lm ? ts.lm + (size_t)kLmStride * t0 : nullptr, nullptr,
 				ts.trace ? ts.trace + (size_t)t0 * ts.trace_cap * kTraceStride : nullptr, ts.trace_cap,
 				ts.h_extra ? ts.h_extra + (size_t)t0 * b->S * b->S : nullptr, ts.h_extra_scale};
-			int nblk_c; { int rows; fused_decomposition(b->N, nt, nblk_c, rows); fc.rows_per_block = rows; }
+			int nblk_c; { int rows; fused_decomposition(b->N, nt, nblk_c, rows, MTFHIP_SLOTS / n_streams); fc.rows_per_block = rows; }
+			if (nblk_c > b->nblk_max) { int rows; fused_decomposition(b->N, nt, nblk_c, rows); fc.rows_per_block = rows; }
 			double *part = b->d_partials + (size_t)t0 * b->nblk_max * RL;
+			const int q = (int)(runs.size() % (size_t)n_streams);
+			runs.push_back(ChunkRun{bc, fc, tc, nblk_c, t0, nt, part, q == 0 ? st : b->ctx->extra_streams[q - 1], false});
+		}
+		const auto dbg_t0 = std::chrono::steady_clock::now();
+		/* the chunks of a group (one per queue) advance together, pass by pass, so that both queues are fed from the start */
+		for (size_t g0 = 0; g0 < runs.size(); g0 += (size_t)n_streams) {
+			const size_t g1 = std::min(runs.size(), g0 + (size_t)n_streams);
 			for (int it = 0; it < max_passes; ++it) {
-				{
-					TimedScope tsc(b->ctx, "fused_lk");
-					launch_fused_ssd(bc, b->ctx->img, fc, part, nblk_c, st);
+				bool all_done = true;
+				for (size_t k = g0; k < g1; ++k) {
+					ChunkRun &r = runs[k];
+					if (r.done) continue;
+					/* the queues are started half a period apart (queue k's first pixel pass waits for queue k - 1's): in lockstep both
+					 * would solve at the same time and nothing would overlap */
+					if (n_streams >= 2 && it == 0 && k > g0 && stagger_ok) {
+						(void)hipStreamWaitEvent(r.s, b->ctx->ev_fork, 0);
+						if (stagger_us > 0) launch_queue_delay(stagger_us * (double)(k - g0), r.s);
+					}
+					{
+						TimedScope tsc(b->ctx, "fused_lk", r.s);
+						launch_fused_ssd(r.bc, b->ctx->img, r.fc, r.part, r.nblk_c, r.s);
+					}
+					if (n_streams >= 2 && it == 0 && k + 1 < g1 && stagger_ok && stagger_us <= 0) (void)hipEventRecord(b->ctx->ev_fork, r.s);
+					if (so_term >= 0) {
+						TimedScope tsc(b->ctx, "second_order", r.s);
+						launch_second_order_ssd(r.bc, b->ctx->img, so_term, fa.chained, b->d0_variant, fa.grad_eps, b->hess_eps, b->norm_mult, b->norm_add,
+							b->d_d2_part + (size_t)r.t0 * nb2 * 64, nb2, b->d_d2_out + (size_t)r.t0 * b->S * b->S, r.s, 1,
+							ncc ? SecondOrderNcc{r.part, r.nblk_c, r.tc.ncc} : SecondOrderNcc{nullptr, 0, nullptr});
+					}
+					{
+						TimedScope tsc(b->ctx, "finish_track", r.s);
+						launch_finish_track(r.bc, *sm, r.tc, r.part, r.nblk_c, r.s);
+					}
+					if (all_converged(r.tc.active, r.nt, it, r.s)) r.done = true;
+					all_done = all_done && r.done;
 				}
-				if (so_term >= 0) {
-					TimedScope tsc(b->ctx, "second_order");
-					launch_second_order_ssd(bc, b->ctx->img, so_term, fa.chained, b->d0_variant, fa.grad_eps, b->hess_eps, b->norm_mult, b->norm_add,
-						b->d_d2_part + (size_t)t0 * nb2 * 64, nb2, b->d_d2_out + (size_t)t0 * b->S * b->S, st, 1,
-						ncc ? SecondOrderNcc{part, nblk_c, tc.ncc} : SecondOrderNcc{nullptr, 0, nullptr});
-				}
-				launch_finish_track(bc, *sm, tc, part, nblk_c, st);
-				if (all_converged(tc.active, nt, it)) break;
+				if (all_done) break;
 			}
+		}
+		if (std::getenv("MTFHIP_TRACK_DEBUG_TIMING"))
+			std::fprintf(stderr, "[track] %d queues, %d passes enqueued in %.1f us\n", n_streams, max_passes,
+				std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count());
+		for (int q = 0; q + 1 < n_streams; ++q) {
+			HIP_TRY(hipEventRecord(b->ctx->ev_join[q], b->ctx->extra_streams[q]));
+			HIP_TRY(hipStreamWaitEvent(st, b->ctx->ev_join[q], 0));
 		}
 	}
 	/* the slab (warps, states, corners, iteration counts) comes back either through a kernel that writes it into host-coherent

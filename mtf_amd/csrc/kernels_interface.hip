@@ -570,6 +570,23 @@ __global__ __launch_bounds__(64) void k_finish(const double *partials, int nblk,
 }
 
 
+/* holds a queue for `ticks` of the constant-rate wall clock: the device-side loop starts its second queue half a period behind
+ * the first (api_fused.hip, track_core) */
+__global__ void k_queue_delay(unsigned long long ticks) {
+	const unsigned long long t0 = wall_clock64();
+	while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+void launch_queue_delay(double microseconds, hipStream_t st) {
+	static double ticks_per_us = 0;
+	if (ticks_per_us == 0) {
+		int dev = 0, khz = 0;
+		if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) { (void)hipGetLastError(); khz = 100000; }
+		ticks_per_us = khz / 1000.0;
+	}
+	if (microseconds <= 0) return;
+	MTFHIP_LAUNCH(k_queue_delay, dim3(1), dim3(64), 0, st, (unsigned long long)(microseconds * ticks_per_us));
+}
+
 /* ===================================================================== */
 /* launchers                                                              */
 /* ===================================================================== */

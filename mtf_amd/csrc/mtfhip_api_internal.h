@@ -141,12 +141,19 @@ struct Timer {
 	double total_ms = 0;
 	int n = 0;
 	long launches = 0;
+	/* [start, end) of every timed launch in ms since the context's reference event: launches of one family can overlap when the
+	 * device-side loop runs on two queues, and the time the family was executing is then the union, not the sum */
+	std::vector<std::pair<double, double>> spans;
 };
 
 struct mtfhip_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
+	/* second queue of the device-side loop (track_core: two chunks of independent targets in flight, one's solve + update under the
+	 * other's pixel pass); created on first use, ordered against `stream` by the two events */
+	hipStream_t extra_streams[3] = {nullptr, nullptr, nullptr};
+	hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
 	ImgView img{nullptr, 0, 0, 0};
 	float *img_owned = nullptr;
 	size_t img_capacity = 0;
@@ -156,6 +163,7 @@ struct mtfhip_ctx {
 	bool timing = false;
 	int timing_stride = 1;   /* events are recorded around every timing_stride-th launch of a family */
 	std::map<std::string, Timer> timers;
+	hipEvent_t ev_ref = nullptr;   /* recorded by timing_reset: origin of Timer::spans */
 	std::vector<hipEvent_t> free_events;
 	std::vector<struct mtfhip_batch *> batches;   /* live batches: deferred work is flushed before the image changes */
 };
@@ -164,7 +172,8 @@ struct TimedScope {
 	mtfhip_ctx *ctx;
 	hipEvent_t a = nullptr, b = nullptr;
 	Timer *tm = nullptr;
-	TimedScope(mtfhip_ctx *c, const char *family) : ctx(c) {
+	hipStream_t on;
+	TimedScope(mtfhip_ctx *c, const char *family, hipStream_t stream = nullptr) : ctx(c), on(stream ? stream : c->stream) {
 		if (!ctx->timing) return;
 		Timer *cand = &ctx->timers[family];
 		if ((cand->launches++ % ctx->timing_stride) != 0) return;
@@ -176,11 +185,11 @@ struct TimedScope {
 			return e;
 		};
 		a = get(); b = get();
-		(void)hipEventRecord(a, ctx->stream);
+		(void)hipEventRecord(a, on);
 	}
 	~TimedScope() {
 		if (!tm) return;
-		(void)hipEventRecord(b, ctx->stream);
+		(void)hipEventRecord(b, on);
 		tm->pending.emplace_back(a, b);
 	}
 };

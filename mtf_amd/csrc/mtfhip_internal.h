@@ -64,7 +64,7 @@ constexpr int kMaxS = 8;
 /* Work decomposition of the fused kernel: every target is cut into nblk chunks of `rows` 256-pixel rows so that
  * B * nblk is as close as possible to the number of resident workgroups -- one full round of workgroups, no
  * half-empty tail round (a 2.5-round grid costs ~8 % against a 2- or 1-round grid) */
-inline void fused_decomposition(int N, int B, int &nblk, int &rows) {
+inline void fused_decomposition(int N, int B, int &nblk, int &rows, int slots = MTFHIP_SLOTS) {
 	const int total_rows = (N + kBlock - 1) / kBlock;
 	int nb_max = (total_rows + MTFHIP_MIN_ROWS - 1) / MTFHIP_MIN_ROWS;
 	if (nb_max < 1) nb_max = 1;
@@ -76,7 +76,7 @@ inline void fused_decomposition(int N, int B, int &nblk, int &rows) {
 		const int r = (total_rows + nb - 1) / nb;
 		const int real_nb = (total_rows + r - 1) / r;
 		const long blocks = (long)B * real_nb;
-		const long rounds = (blocks + MTFHIP_SLOTS - 1) / MTFHIP_SLOTS;
+		const long rounds = (blocks + slots - 1) / slots;
 		const double cost = (double)rounds * (r + 1.5);
 		if (cost < best - 1e-9) { best = cost; best_nb = real_nb; }
 	}
@@ -159,6 +159,7 @@ struct FusedArgs {
 
 /* one-time probe: does the kernel-argument segment hold (BatchView, ImgView, FusedArgs) where fused_lk_body's inline-warp path reads them? */
 bool kernarg_layout_verified(hipStream_t st);
+void launch_queue_delay(double microseconds, hipStream_t st);
 /* ---- launchers (all asynchronous on `st`) ---- */
 void launch_apply_warp(const BatchView &bv, hipStream_t st);
 void launch_grad_pts(const BatchView &bv, double eps, hipStream_t st);

@@ -893,3 +893,37 @@ def test_inline_warp_probe_and_equivalence(gpu_ctx, frame, frame2, ssm, am, monk
         b.close()
     for a, r in zip(out["1"], out["0"]):
         assert np.array_equal(a, r)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sm_kind,am", [(L.SM_ESM, L.AM_SSD), (L.SM_FCLK, L.AM_SSD), (L.SM_ESM, L.AM_NCC)])
+def test_two_queue_device_loop_equals_single_queue(oracle, gpu_ctx, frame, frame2, sm_kind, am, monkeypatch):
+    """The device-side loop keeps two chunks of independent targets in flight on two queues when the launches materialise the
+    interface arrays (track_queues in api_fused.hip): same per-target arithmetic, another cut of the pixel pass (half the resident
+    workgroups per chunk), so the results agree with the single-queue loop to summation order -- iteration counts, final corners,
+    and the arrays the last pass materialised -- and with the oracle's tracker."""
+    rng = np.random.default_rng(23)
+    B, res = 14, 200          # 14 x 40 000 rows: above the two-queue threshold, odd split (7 + 7)
+    monkeypatch.setenv("MTFHIP_TRACK_STREAMS_MIN_ROWS", "0")
+    corners = np.stack([synth.square_corners(140 + 17 * (t % 7), 150 + 23 * (t // 7) + 5 * (t % 3), 200.0) for t in range(B)])
+    out = {}
+    for q in ("1", "2"):
+        monkeypatch.setenv("MTFHIP_TRACK_STREAMS", q)
+        gpu_ctx.set_image(frame)
+        b = mtf_amd.Batch(gpu_ctx, am, L.SSM_HOMOGRAPHY, res, res, B)
+        b.set_corners(corners)
+        sm = mtf_amd.sm_desc(sm_kind, materialize=1, leven_marq=0, max_iters=12, epsilon=1e-4)
+        b.init_template(sm)
+        assert b.track_queues(sm) == int(q)
+        gpu_ctx.set_image(frame2)
+        n_it, final = b.track(sm)
+        out[q] = (n_it.copy(), final.copy(), b.read(L.BUF_IT).copy(), b.read(L.BUF_JT).copy())
+        b.close()
+    assert np.array_equal(out["1"][0], out["2"][0])
+    np.testing.assert_allclose(out["2"][1], out["1"][1], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(out["2"][2], out["1"][2], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(out["2"][3], out["1"][3], rtol=0, atol=1e-5 * np.abs(out["1"][3]).max())
+    o_ssm = oracle.SSM(L.SSM_HOMOGRAPHY, res, res); o_am = oracle.AM(am, res, res); o_am.set_curr_img(frame)
+    trk = oracle.Tracker(sm_kind, o_am, o_ssm, leven_marq=0, max_iters=12, epsilon=1e-4)
+    trk.initialize(corners[B - 1]); o_am.set_curr_img(frame2); trk.update()
+    np.testing.assert_allclose(out["2"][1][B - 1], trk.get_region(), rtol=0, atol=2e-4)

@@ -31,7 +31,11 @@ import os, sys, subprocess
 sys.path.insert(0, ".")
 import bench
 commit = open(".git_head").read().strip() if os.path.exists(".git_head") else None
-json.dump({"kernel": "k_fused_ssd", "bench_args": "$args", "commit": commit, "kernel_sources_sha": bench.kernel_sources_sha(), "j0_recompute": os.environ.get("MTFHIP_J0_RECOMPUTE", "1") != "0", "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w,
+try:
+    per_launch = json.loads(open("$out/${tag}_bench.json").read().strip().splitlines()[-1])["roofline"]["targets_per_launch"]
+except Exception:
+    per_launch = None
+json.dump({"kernel": "k_fused_ssd", "bench_args": "$args", "commit": commit, "targets_per_launch": per_launch, "kernel_sources_sha": bench.kernel_sources_sha(), "j0_recompute": os.environ.get("MTFHIP_J0_RECOMPUTE", "1") != "0", "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w,
            "traffic_bytes_per_launch": (2.0 * f + w) * 1024.0,
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE half-count, MI355X_MICROARCH.md HBM section)"},
           open("$out/${tag}_pmc_traffic.json", "w"), indent=1)
