@@ -730,6 +730,8 @@ static int track_queues(const mtfhip_batch *b, const FusedArgs &fa) {
 	const char *e_want = std::getenv("MTFHIP_TRACK_STREAMS");   /* (read per call: the tests switch it) */
 	const int want = e_want ? std::atoi(e_want) : 2;
 	if (want < 2 || b->B < 2 || b->d_trace) return 1;
+	/* launches that write nothing are issue-bound: ESM's lean pass gains 3-6 % in 200-iteration calls and loses 4-5 % in 20-iteration
+	 * ones, FCLK's and ICLK's gain nothing */
 	if (!fa.materialize && want < 12) return 1;
 	/* small passes are launch- and latency-sized, not bandwidth-sized: 8 x 200 x 200 and 64 x 50 x 50 measured 5-14 % slower on two queues
 	 * in 20-iteration calls, 16 / 32 / 48 x 200 x 200 6-22 % faster */
