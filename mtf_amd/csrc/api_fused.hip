@@ -809,8 +809,18 @@ int mtfhip_batch_track_region(mtfhip_batch *b, const mtfhip_sm_desc *sm, const d
 	 * without an event guard: the loop that follows is what the host waits for) */
 	TRY(track_validate(b, sm));
 	const bool folded = !region_refreshes(sm);
+	static const bool dbg = std::getenv("MTFHIP_TRACK_DEBUG_TIMING") != nullptr;
+	const auto t0 = std::chrono::steady_clock::now();
 	TRY(set_region_core(b, region_corners, sm, folded));
-	return track_core(b, sm, n_iters, corners, folded);
+	const auto t1 = std::chrono::steady_clock::now();
+	const int r = track_core(b, sm, n_iters, corners, folded);
+	if (dbg) {
+		const auto t2 = std::chrono::steady_clock::now();
+		static double acc1 = 0, acc2 = 0; static int n = 0;
+		acc1 += std::chrono::duration<double, std::micro>(t1 - t0).count(); acc2 += std::chrono::duration<double, std::micro>(t2 - t1).count();
+		if (++n % 100 == 0) { std::fprintf(stderr, "[track_region] set_region %.1f us, track %.1f us (mean of 100)\n", acc1 / 100, acc2 / 100); acc1 = acc2 = 0; }
+	}
+	return r;
 }
 
 /* the argument / state checks of the device loop, without side effects (track_region runs them before it resets the SSM) */
@@ -998,7 +1008,10 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 			int nblk_c; { int rows; fused_decomposition(b->N, nt, nblk_c, rows, MTFHIP_SLOTS / n_streams); fc.rows_per_block = rows; }
 			if (nblk_c > b->nblk_max) { int rows; fused_decomposition(b->N, nt, nblk_c, rows); fc.rows_per_block = rows; }
 			double *part = b->d_partials + (size_t)t0 * b->nblk_max * RL;
-			const int q = (int)(runs.size() % (size_t)n_streams);
+			/* MTFHIP_TRACK_SERIALIZE=1: the same chunks and the same cut of the pixel pass, one queue -- for the PMC passes, whose
+			 * per-dispatch counters are device-wide and would include the launch in flight on the other queue */
+			static const bool serialize = std::getenv("MTFHIP_TRACK_SERIALIZE") && std::getenv("MTFHIP_TRACK_SERIALIZE")[0] == '1';
+			const int q = serialize ? 0 : (int)(runs.size() % (size_t)n_streams);
 			runs.push_back(ChunkRun{bc, fc, tc, nblk_c, t0, nt, part, q == 0 ? st : b->ctx->extra_streams[q - 1], false});
 		}
 		const auto dbg_t0 = std::chrono::steady_clock::now();

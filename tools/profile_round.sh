@@ -8,13 +8,13 @@ tag=$1; shift
 args="${*:---steps 50 --warmup 10}"
 out=gpurun_out/profile
 mkdir -p $out
-python bench.py $args > $out/${tag}_bench.json 2> $out/${tag}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o $tag -- python bench.py $args --no-cpu > $out/${tag}_trace.log 2>&1
-cp $out/trace/${tag}_kernel_stats.csv $out/${tag}_kernel_stats.csv
+# (the PMC passes come first: the bench line quotes their traffic figure, and only for the kernel sources it was taken on)
+python bench.py $args --no-cpu --no-lean > $out/${tag}_bench_pre.json 2> $out/${tag}_bench.err
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $out/pmc/p$i -o pmc -- python bench.py --steps 10 --warmup 2 --no-cpu ${args##*--warmup [0-9]*} > $out/pmc_p$i.log 2>&1
+  # device-wide counters per dispatch: the two-queue loop is serialised for these passes (same launches, one queue)
+  MTFHIP_TRACK_SERIALIZE=1 rocprofv3 --pmc $grp --output-format csv -d $out/pmc/p$i -o pmc -- python bench.py --steps 10 --warmup 2 --no-cpu --no-lean ${args##*--warmup [0-9]*} > $out/pmc_p$i.log 2>&1
 done
 python tools/pmc_summary.py $out/pmc > $out/${tag}_pmc_summary.txt
 python - <<PY
@@ -32,7 +32,7 @@ sys.path.insert(0, ".")
 import bench
 commit = open(".git_head").read().strip() if os.path.exists(".git_head") else None
 try:
-    per_launch = json.loads(open("$out/${tag}_bench.json").read().strip().splitlines()[-1])["roofline"]["targets_per_launch"]
+    per_launch = json.loads(open("$out/${tag}_bench_pre.json").read().strip().splitlines()[-1])["roofline"]["targets_per_launch"]
 except Exception:
     per_launch = None
 json.dump({"kernel": "k_fused_ssd", "bench_args": "$args", "commit": commit, "targets_per_launch": per_launch, "kernel_sources_sha": bench.kernel_sources_sha(), "j0_recompute": os.environ.get("MTFHIP_J0_RECOMPUTE", "1") != "0", "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w,
@@ -40,4 +40,12 @@ json.dump({"kernel": "k_fused_ssd", "bench_args": "$args", "commit": commit, "ta
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE half-count, MI355X_MICROARCH.md HBM section)"},
           open("$out/${tag}_pmc_traffic.json", "w"), indent=1)
 PY
+cp $out/${tag}_pmc_traffic.json profiles/pmc_latest.json
+python bench.py $args > $out/${tag}_bench.json 2>> $out/${tag}_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o $tag -- python bench.py $args --no-cpu > $out/${tag}_trace.log 2>&1
+cp $out/trace/${tag}_kernel_stats.csv $out/${tag}_kernel_stats.csv
+# the same command with the loop on one queue: the kernel with the device to itself (r01 / r02 figures are of this form)
+MTFHIP_TRACK_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace1q -o ${tag}_1q -- python bench.py $args --no-cpu --no-lean > $out/${tag}_trace1q.log 2>&1
+cp $out/trace1q/${tag}_1q_kernel_stats.csv $out/${tag}_kernel_stats_one_queue.csv
+MTFHIP_TRACK_STREAMS=1 python bench.py $args --no-cpu --no-lean > $out/${tag}_bench_one_queue.json 2>> $out/${tag}_bench.err
 cat $out/${tag}_bench.json | cut -c1-400; head -5 $out/${tag}_kernel_stats.csv | cut -c1-200; cat $out/${tag}_pmc_traffic.json
