@@ -81,6 +81,7 @@ void mtfhip_ctx_destroy(mtfhip_ctx *c) {
 			if (c->ev_join[q]) (void)hipEventDestroy(c->ev_join[q]);
 		}
 		if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+		if (c->d_phase) (void)hipFree(c->d_phase);
 		if (c->ev_ref) (void)hipEventDestroy(c->ev_ref);
 		if (c->own_stream) (void)hipStreamDestroy(c->stream);
 	} catch (...) {

@@ -969,6 +969,12 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 				if (!c->extra_streams[q] && (hipStreamCreateWithFlags(&c->extra_streams[q], hipStreamNonBlocking) != hipSuccess ||
 					hipEventCreateWithFlags(&c->ev_join[q], hipEventDisableTiming) != hipSuccess)) { (void)hipGetLastError(); n_streams = 1; break; }
 		}
+		const char *e_ph = std::getenv("MTFHIP_TRACK_PHASE");   /* fraction of a period the queues are kept apart; 0 = no control */
+		const double phase_frac = e_ph ? std::atof(e_ph) : 0.35;
+		if (n_streams == 2 && phase_frac > 0) {
+			if (!b->ctx->d_phase && hipMalloc(&b->ctx->d_phase, sizeof(unsigned long long) * 4) != hipSuccess) { (void)hipGetLastError(); b->ctx->d_phase = nullptr; }
+			if (b->ctx->d_phase) HIP_TRY(hipMemsetAsync(b->ctx->d_phase, 0, sizeof(unsigned long long) * 4, st));
+		}
 		if (n_streams >= 2) {
 			const int part_sz = (b->B + n_streams - 1) / n_streams;
 			if (chunk > part_sz) chunk = part_sz;
@@ -1042,7 +1048,12 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 					}
 					{
 						TimedScope tsc(b->ctx, "finish_track", r.s);
-						launch_finish_track(r.bc, *sm, r.tc, r.part, r.nblk_c, r.s);
+						PhaseCtl pc{nullptr, nullptr, 0.0};
+						if (n_streams == 2 && phase_frac > 0 && b->ctx->d_phase) {
+							const int qi = (int)((k - g0) & 1);
+							pc = PhaseCtl{b->ctx->d_phase + qi, b->ctx->d_phase + (1 - qi), phase_frac};
+						}
+						launch_finish_track(r.bc, *sm, r.tc, r.part, r.nblk_c, r.s, pc);
 					}
 					if (all_converged(r.tc.active, r.nt, it, r.s)) r.done = true;
 					all_done = all_done && r.done;

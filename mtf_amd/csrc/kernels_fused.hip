@@ -23,9 +23,22 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FAST_WAVES) void k_fused_fast(BatchV
 
 
 /* stand-alone finish: one wave per target */
+/* pc (two-queue loop): the queues run best half a period apart -- one's fill / drain / solve under the other's streaming (48-49 us per
+ * step of 64 x 200 x 200, the two pixel passes starting 23-25 us apart) -- but started together, or on some boxes by themselves, they
+ * stay close to lockstep (55-56 us).  Each queue's solve stamps the wall clock when it ends, and ends no sooner than `frac` of its own
+ * last period after the other queue's stamp: a queue that runs too close behind the other is held back until it is not. */
 __global__ __launch_bounds__(256) void k_finish_track(BatchView bv, mtfhip_sm_desc sm, TrackState ts,
-	const double *partials, int nblk) {
+	const double *partials, int nblk, PhaseCtl pc) {
 	finish_track_body(bv, sm, ts, partials, nblk, blockIdx.x);
+	if (pc.mine && blockIdx.x == 0 && threadIdx.x == 0) {
+		const unsigned long long prev = ld_coh(pc.mine), other = ld_coh(pc.other);
+		unsigned long long now = wall_clock64();   /* 100 MHz */
+		if (prev && other && now > prev && now - prev < 50000ull) {   /* (a period of less than 500 us: the queue is in its stride) */
+			const unsigned long long min_lag = (unsigned long long)((double)(now - prev) * pc.frac);
+			while (now > other && now - other < min_lag) { __builtin_amdgcn_s_sleep(8); now = wall_clock64(); }
+		}
+		st_coh(pc.mine, now);
+	}
 }
 
 
@@ -108,9 +121,9 @@ void launch_fused_ssd(const BatchView &bv, const ImgView &im, const FusedArgs &f
 	else launch_fused_mode<MTFHIP_SSM_AFFINE, false>(bv, im, fa, partials, nblk, st);
 }
 void launch_finish_track(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, const double *partials,
-	int nblk, hipStream_t st) {
+	int nblk, hipStream_t st, PhaseCtl pc) {
 	/* NCC rows are 72 wide: two waves load them, the first one solves; many block rows (a single large target): 240 lanes sum them */
-	MTFHIP_LAUNCH(k_finish_track, dim3(bv.B), dim3(nblk > 8 ? 256 : (bv.am == MTFHIP_AM_NCC ? 128 : 64)), 0, st, bv, sm, ts, partials, nblk);
+	MTFHIP_LAUNCH(k_finish_track, dim3(bv.B), dim3(nblk > 8 ? 256 : (bv.am == MTFHIP_AM_NCC ? 128 : 64)), 0, st, bv, sm, ts, partials, nblk, pc);
 }
 
 void launch_finish_track_mi(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, int sum_std, int gmode,

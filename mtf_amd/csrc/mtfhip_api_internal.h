@@ -154,6 +154,7 @@ struct mtfhip_ctx {
 	 * other's pixel pass); created on first use, ordered against `stream` by the two events */
 	hipStream_t extra_streams[3] = {nullptr, nullptr, nullptr};
 	hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+	unsigned long long *d_phase = nullptr;   /* [4] wall-clock stamps of the queues' last solve (PhaseCtl) */
 	ImgView img{nullptr, 0, 0, 0};
 	float *img_owned = nullptr;
 	size_t img_capacity = 0;

@@ -322,8 +322,10 @@ void launch_track_persist(const BatchView &bv, const ImgView &im, const FusedArg
 	double *partials, int nblk, const PersistState &ps, int max_passes, hipStream_t st);
 bool launch_init_grid_ingest(const BatchView &bv, const double *host_w0_dev, int resx, int resy, double lo_x, double lo_y,
 	double hi_x, double hi_y, int force_unit_z, const void *src_host, void *dst, size_t bytes, int write_curr, hipStream_t st);
+/* phase control of the two-queue loop (k_finish_track): this queue's and the other queue's time stamps, the fraction of a period to keep */
+struct PhaseCtl { unsigned long long *mine; const unsigned long long *other; double frac; };
 void launch_finish_track(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, const double *partials,
-	int nblk, hipStream_t st);
+	int nblk, hipStream_t st, PhaseCtl pc = PhaseCtl{nullptr, nullptr, 0.0});
 
 } // namespace mtfhip
 #endif
