@@ -145,12 +145,19 @@ __device__ __forceinline__ void publish_target(const HostPublish &pub, int t, do
 	}
 }
 
+#ifdef MTFHIP_GRID_TRACE   /* tools/grid_trace.sh: wall-clock stamps (100 MHz) of one workgroup's phases */
+__device__ unsigned long long g_grid_trace[32];
+#define GRID_STAMP(k) do { if (blockIdx.x == 100 && threadIdx.x == 0) g_grid_trace[k] = wall_clock64(); } while (0)
+#else
+#define GRID_STAMP(k) do { } while (0)
+#endif
 template <int AM, int PPT, bool FAST>
 __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im, mtfhip_sm_desc sm, TrackState ts,
 	const double *h0inv_all, const double *ncc_sc_all, double norm_mult, double norm_add, HostPublish pub) {
 	__shared__ double red[4 * 8];
 	__shared__ double sW[9], sSt[8], sHinv[64], sH8[64], sIc[12], sCr[8];
 	__shared__ int sDone;
+	GRID_STAMP(0);
 	const int t = blockIdx.x, N = bv.N, S = bv.S, tid = threadIdx.x;
 	const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY;
 	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * N;
@@ -189,7 +196,9 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 	if (tid < 9) sW[tid] = bv.warps[9 * t + tid];
 	if (tid < 8) sSt[tid] = bv.states[8 * t + tid];
 	if (tid == 0) sDone = 0;
+	GRID_STAMP(1);
 	__syncthreads();
+	GRID_STAMP(2);
 	int n_it = 0;
 	double f_last = 0;
 	if constexpr (FAST) {
@@ -232,7 +241,9 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 			}
 		}
 		const double nN = (double)N, inv_n = 1.0 / nN, inv_cn = 1.0 / cn;
+		GRID_STAMP(3);
 		for (int it = 0; it < sm.max_iters; ++it) {
+			if (it < 12) GRID_STAMP(4 + it);
 			double m[K];
 #pragma unroll
 			for (int q = 0; q < K; ++q) m[q] = 0.0;
@@ -347,6 +358,7 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 			++n_it;
 			if (change < sm.epsilon) break;   /* uniform: every thread holds the same numbers */
 		}
+		GRID_STAMP(16);
 		/* (every thread holds the same W / St / Cr: the first lanes store one entry each) */
 #pragma unroll
 		for (int q = 0; q < 9; ++q) if (tid == q) bv.warps[9 * t + q] = W[q];
@@ -360,7 +372,9 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 			for (int q = 0; q < 9; ++q) if (tid == q) wq = W[q];
 #pragma unroll
 			for (int q = 0; q < 8; ++q) if (tid == q) { sq = St[q]; cq = Cr[q]; }
+			GRID_STAMP(17);
 			publish_target(pub, t, wq, sq, cq, n_it);
+			GRID_STAMP(18);
 		}
 		return;
 	}
@@ -535,4 +549,10 @@ void launch_sample_candidates(const BatchView &bv, const ImgView &im, const doub
 	if (bv.am == MTFHIP_AM_NCC) MTFHIP_LAUNCH(k_ncc_feature_rows, dim3(C), dim3(kBlock), 0, st, bv.N, dev_feat);
 }
 
+#ifdef MTFHIP_GRID_TRACE
+void debug_grid_trace(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_grid_trace), sizeof(unsigned long long) * 32); }
+#endif
 } // namespace mtfhip
+#ifdef MTFHIP_GRID_TRACE
+extern "C" void mtfhip_debug_grid_trace(unsigned long long *out) { mtfhip::debug_grid_trace(out); }
+#endif
