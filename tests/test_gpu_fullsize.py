@@ -164,6 +164,41 @@ def test_config4_pf_10000_candidates(gpu_ctx, big_frames):
     assert b.score_candidates(states[:100]).max() < 1.0
 
 
+def test_config4_pf_sharded_world8_full_size(big_frames):
+    """Config 4 as `bench.py --workload pf --gpus 8` runs it, at its full size: 10 000 particles x 2 500 px sharded over EIGHT ranks
+    (threads of this process over the loopback communicator: block bounds, one in-place all-gather of 1 250 weights per rank,
+    replicated proposals / scan / selection) -- every rank ends four iterations with the unsharded filter's particle set, weights
+    and estimate, bit for bit, and the estimate follows the known synthetic warp."""
+    from mtf_amd.sm import Comm, ParticleFilter
+    from test_gpu_trackers import _run_ranks
+    f0, f1, p_true = big_frames
+    corners = synth.square_corners(512, 512, 100)
+    kw = dict(n_particles=10000, ssm_sigma=(1.0, 0.5, 1, 1, 1, 1, 1, 1), corner_based_sampling=1, likelihood_alpha=5.0, seed=11, mean_type=1)
+
+    def run(comm):
+        ctx = mtf_amd.Context(0)
+        ctx.set_image(f0)
+        pf = ParticleFilter(ctx, L.SSM_HOMOGRAPHY, 50, 50, comm=comm, **kw)
+        pf.initialize(corners[None])
+        ctx.set_image(f1)
+        for _ in range(4):
+            pf.iteration()
+        st, ar, w, ids = pf.particles()
+        out = (st.copy(), w.copy(), ids.copy(), pf.get_region().copy())
+        pf.close(); ctx.close()
+        return out
+    ref = run(None)
+    comms = Comm.loopback(8)
+    got = _run_ranks(8, lambda r: run(comms[r]))
+    for c in comms:
+        c.close()
+    for r in range(8):
+        for a, b, what in zip(got[r], ref, ("states", "weights", "ids", "corners")):
+            assert np.array_equal(a, b), "rank %d: %s differ from the unsharded filter" % (r, what)
+    err = np.linalg.norm(ref[3][0] - gt_corners(corners, p_true), axis=0)
+    assert err.max() < 3.0     # a particle filter's estimate: within a few pixels of the true warp after four iterations
+
+
 def test_config5_mi_400x400_64_targets(gpu_ctx):
     """Config 5: ESM + MI (8 bins) + Homography, 400 x 400, 64 concurrent targets on a 2048 x 2048 frame."""
     f0 = synth.make_frame(2048, 2048)
