@@ -752,6 +752,11 @@ def main():
                          "formula": "achieved = bytes_per_launch x launches_timed / kernel_busy_ms (kernel_busy_ms = union of the launches' "
                                     "event intervals) = per_launch_GBs x launches_in_flight",
                          "avg_finish_ms": fin_ms,
+                         # the event pass perturbs the overlap of the two queues (events are recorded around every launch); the timed
+                         # region has no events: its algorithmic bytes / its wall time -- solves, cold first passes and call overhead
+                         # included -- is a lower bound on what the fused launches reached there
+                         "timed_region_GBs": float(bpp) * N * B * args.steps / dt / 1e9,
+                         "timed_region_frac": float(bpp) * N * B * args.steps / dt / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_pixel": bpp, "j0_rows": "rebuilt from dI0_dx" if j0_rec else "read back", "bytes_per_launch": bytes_per_launch,
                          "targets_per_launch": per_launch,
                          # what the figure means: algorithmic bytes / kernel time.  The read set of a launch (grid points, I0, dI0_dx:
