@@ -960,7 +960,6 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 		int chunk = track_chunk(b, sm, fa);
 		/* two chunks of targets in flight on two queues where that pays (track_queues); each chunk's pixel pass is then cut for half
 		 * the resident workgroups, so that the two launches in flight fill the device once */
-		static const bool stagger_ok = !(std::getenv("MTFHIP_TRACK_STAGGER") && std::getenv("MTFHIP_TRACK_STAGGER")[0] == '0');
 		int n_streams = track_queues(b, fa);
 		if (n_streams >= 2) {
 			mtfhip_ctx *c = b->ctx;
@@ -975,25 +974,22 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 			if (!b->ctx->d_phase && hipMalloc(&b->ctx->d_phase, sizeof(unsigned long long) * 4) != hipSuccess) { (void)hipGetLastError(); b->ctx->d_phase = nullptr; }
 			if (b->ctx->d_phase) HIP_TRY(hipMemsetAsync(b->ctx->d_phase, 0, sizeof(unsigned long long) * 4, st));
 		}
-		if (n_streams >= 2) {
-			const int part_sz = (b->B + n_streams - 1) / n_streams;
-			if (chunk > part_sz) chunk = part_sz;
-			if (!stagger_ok) {   /* (staggered queues wait for the first queue's first pixel pass anyway, which is behind the slab upload) */
-				HIP_TRY(hipEventRecord(b->ctx->ev_fork, st));
-				for (int q = 0; q + 1 < n_streams; ++q) HIP_TRY(hipStreamWaitEvent(b->ctx->extra_streams[q], b->ctx->ev_fork, 0));
-			}
-		}
-		/* The later queues start a quarter of a period behind the first (a spinning one-wave kernel; the period is estimated from the
-		 * bytes a pass moves): in lockstep -- where two queues started together stay -- the fill and drain phases of the two pixel passes
-		 * coincide and so do the two solves: 55 us per step of 64 x 200 x 200 against 49-52 out of phase.  A/B at that size, three
-		 * boxes: no delay 1.05-1.10 M iters/s in 20-iteration calls and 1.13-1.19 M in 200-iteration ones, 15 us 1.13-1.15 M and
-		 * 1.28-1.30 M, 25 / 30 / 35 us in between and less repeatable.  MTFHIP_TRACK_STAGGER_US: > 0 that many microseconds, 0 the
-		 * later queues wait for the first queue's first pixel pass instead (the r03 first version). */
+		/* The queues start a quarter of a period apart (a spinning one-wave kernel in front of the later one; the period is estimated from
+		 * the bytes a pass moves): started together they stay in lockstep on some boxes -- the fill and drain phases of the two pixel
+		 * passes coincide and so do the two solves, 55 us per step of 64 x 200 x 200 against 49 out of phase (from there on the solve
+		 * kernels keep them apart, PhaseCtl).  A/B at that size, three boxes: no delay 1.05-1.10 M iters/s in 20-iteration calls and
+		 * 1.13-1.19 M in 200-iteration ones, 15 us 1.13-1.15 M and 1.28-1.30 M, 25 / 30 / 35 us in between and less repeatable.
+		 * MTFHIP_TRACK_STAGGER_US: > 0 that many microseconds, 0 none.
+		 * The context's own stream takes the LATER chunk of a pair: it is then the last to finish, and the join at the end of the call finds
+		 * the other queue's event already signalled instead of paying a cross-queue wait (~12 us) in front of the result read-back. */
 		static const double stagger_env = std::getenv("MTFHIP_TRACK_STAGGER_US") ? std::atof(std::getenv("MTFHIP_TRACK_STAGGER_US")) : -1.0;
 		double stagger_us = stagger_env;
 		if (stagger_env < 0) stagger_us = 0.25 * ((double)b->B * b->N * 130.0 / 6.5e6 + 8.0) * (2.0 / n_streams);
-		if (n_streams >= 2 && stagger_ok && stagger_us > 0) {   /* the delayed queues start from the slab upload */
-			HIP_TRY(hipEventRecord(b->ctx->ev_fork, st));
+		if (n_streams >= 2) {
+			const int part_sz = (b->B + n_streams - 1) / n_streams;
+			if (chunk > part_sz) chunk = part_sz;
+			HIP_TRY(hipEventRecord(b->ctx->ev_fork, st));   /* the slab upload */
+			for (int q = 0; q + 1 < n_streams; ++q) HIP_TRY(hipStreamWaitEvent(b->ctx->extra_streams[q], b->ctx->ev_fork, 0));
 		}
 		struct ChunkRun { BatchView bc; FusedArgs fc; TrackState tc; int nblk_c, t0, nt; double *part; hipStream_t s; bool done; };
 		std::vector<ChunkRun> runs;
@@ -1017,8 +1013,8 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 			/* MTFHIP_TRACK_SERIALIZE=1: the same chunks and the same cut of the pixel pass, one queue -- for the PMC passes, whose
 			 * per-dispatch counters are device-wide and would include the launch in flight on the other queue */
 			static const bool serialize = std::getenv("MTFHIP_TRACK_SERIALIZE") && std::getenv("MTFHIP_TRACK_SERIALIZE")[0] == '1';
-			const int q = serialize ? 0 : (int)(runs.size() % (size_t)n_streams);
-			runs.push_back(ChunkRun{bc, fc, tc, nblk_c, t0, nt, part, q == 0 ? st : b->ctx->extra_streams[q - 1], false});
+			const int q = serialize ? n_streams - 1 : (int)(runs.size() % (size_t)n_streams);
+			runs.push_back(ChunkRun{bc, fc, tc, nblk_c, t0, nt, part, q == n_streams - 1 ? st : b->ctx->extra_streams[q], false});
 		}
 		const auto dbg_t0 = std::chrono::steady_clock::now();
 		/* the chunks of a group (one per queue) advance together, pass by pass, so that both queues are fed from the start */
@@ -1029,17 +1025,11 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 				for (size_t k = g0; k < g1; ++k) {
 					ChunkRun &r = runs[k];
 					if (r.done) continue;
-					/* the queues are started half a period apart (queue k's first pixel pass waits for queue k - 1's): in lockstep both
-					 * would solve at the same time and nothing would overlap */
-					if (n_streams >= 2 && it == 0 && k > g0 && stagger_ok) {
-						(void)hipStreamWaitEvent(r.s, b->ctx->ev_fork, 0);
-						if (stagger_us > 0) launch_queue_delay(stagger_us * (double)(k - g0), r.s);
-					}
+					if (n_streams >= 2 && it == 0 && k > g0 && stagger_us > 0) launch_queue_delay(stagger_us * (double)(k - g0), r.s);
 					{
 						TimedScope tsc(b->ctx, "fused_lk", r.s);
 						launch_fused_ssd(r.bc, b->ctx->img, r.fc, r.part, r.nblk_c, r.s);
 					}
-					if (n_streams >= 2 && it == 0 && k + 1 < g1 && stagger_ok && stagger_us <= 0) (void)hipEventRecord(b->ctx->ev_fork, r.s);
 					if (so_term >= 0) {
 						TimedScope tsc(b->ctx, "second_order", r.s);
 						launch_second_order_ssd(r.bc, b->ctx->img, so_term, fa.chained, b->d0_variant, fa.grad_eps, b->hess_eps, b->norm_mult, b->norm_add,
