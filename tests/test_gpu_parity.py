@@ -896,8 +896,11 @@ def test_inline_warp_probe_and_equivalence(gpu_ctx, frame, frame2, ssm, am, monk
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sm_kind,am", [(L.SM_ESM, L.AM_SSD), (L.SM_FCLK, L.AM_SSD), (L.SM_ESM, L.AM_NCC)])
-def test_two_queue_device_loop_equals_single_queue(oracle, gpu_ctx, frame, frame2, sm_kind, am, monkeypatch):
+@pytest.mark.parametrize("sm_kind,am,extra", [(L.SM_ESM, L.AM_SSD, dict()), (L.SM_FCLK, L.AM_SSD, dict()), (L.SM_ESM, L.AM_NCC, dict()),
+                                              (L.SM_ESM, L.AM_SSD, dict(leven_marq=1)), (L.SM_FCLK, L.AM_SSD, dict(leven_marq=1)),
+                                              (L.SM_FCLK, L.AM_SSD, dict(sec_ord_hess=1, hess_type=2)), (L.SM_ESM, L.AM_NCC, dict(sec_ord_hess=1, hess_type=5))],
+                         ids=lambda v: "_".join("%s%s" % kv for kv in v.items()) if isinstance(v, dict) else str(v))
+def test_two_queue_device_loop_equals_single_queue(oracle, gpu_ctx, frame, frame2, sm_kind, am, extra, monkeypatch):
     """The device-side loop keeps two chunks of independent targets in flight on two queues when the launches materialise the
     interface arrays (track_queues in api_fused.hip): same per-target arithmetic, another cut of the pixel pass (half the resident
     workgroups per chunk), so the results agree with the single-queue loop to summation order -- iteration counts, final corners,
@@ -912,7 +915,9 @@ def test_two_queue_device_loop_equals_single_queue(oracle, gpu_ctx, frame, frame
         gpu_ctx.set_image(frame)
         b = mtf_amd.Batch(gpu_ctx, am, L.SSM_HOMOGRAPHY, res, res, B)
         b.set_corners(corners)
-        sm = mtf_amd.sm_desc(sm_kind, materialize=1, leven_marq=0, max_iters=12, epsilon=1e-4)
+        params = dict(leven_marq=0, max_iters=12, epsilon=1e-4)
+        params.update(extra)
+        sm = mtf_amd.sm_desc(sm_kind, materialize=1, **params)
         b.init_template(sm)
         assert b.track_queues(sm) == int(q)
         gpu_ctx.set_image(frame2)
@@ -924,6 +929,6 @@ def test_two_queue_device_loop_equals_single_queue(oracle, gpu_ctx, frame, frame
     np.testing.assert_allclose(out["2"][2], out["1"][2], rtol=0, atol=1e-7)
     np.testing.assert_allclose(out["2"][3], out["1"][3], rtol=0, atol=1e-5 * np.abs(out["1"][3]).max())
     o_ssm = oracle.SSM(L.SSM_HOMOGRAPHY, res, res); o_am = oracle.AM(am, res, res); o_am.set_curr_img(frame)
-    trk = oracle.Tracker(sm_kind, o_am, o_ssm, leven_marq=0, max_iters=12, epsilon=1e-4)
+    trk = oracle.Tracker(sm_kind, o_am, o_ssm, **params)
     trk.initialize(corners[B - 1]); o_am.set_curr_img(frame2); trk.update()
     np.testing.assert_allclose(out["2"][1][B - 1], trk.get_region(), rtol=0, atol=2e-4)
