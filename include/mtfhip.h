@@ -322,7 +322,11 @@ int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int n
  * the combinations the reference itself throws for (additive + point based, compositional RandomWalk + geometric) return
  * MTFHIP_ERR_NOT_IMPLEMENTED with its message, and so does additive + geometric, which needs Affine::stateToGeom -- a 2 x 2
  * JacobiSVD whose sign / ordering conventions decide its branches and cannot be reproduced without Eigen.
- * Not provided: several sampler distributions (n_distr > 1), jacobian_as_sigma. */
+ * Several sampler distributions with adaptive weights (mtfhip_pf_set_distributions) and adaptive resampling run on the device too: the
+ * cumulative-weight launch also takes the per-distribution weight sums and sum w^2, its last workgroup derives the next iteration's
+ * distribution weights and the verdict "this iteration resamples", the selection pass obeys it.  jacobian_as_sigma (PF.cc:58-64,
+ * 156-165, 214-227) is host logic over entry points of this header: mtf_amd/sm.py ParticleFilter, mtf_amd/host/PF.cpp.
+ * Not provided: pix_sigma (SSM::estimateStateSigma). */
 typedef struct mtfhip_pf mtfhip_pf;
 typedef struct mtfhip_comm mtfhip_comm;
 typedef struct mtfhip_pf_desc {
@@ -340,13 +344,25 @@ typedef struct mtfhip_pf_desc {
 	double ssm_sigma[8], ssm_mean[8]; /* the sampler's normal distributions (ProjectiveBase::initializeSampler) */
 	unsigned long long seed;  /* device generator (Philox4x32-10), used when no draws are handed in */
 	int pt_based_sampling;    /* AffineParams::pt_based_sampling (0 geometric, 1, 2: Affine.cc:464-503; default 0, parameters.h:254) */
+	/* (appended in r03; the shipped Config/modules.cfg:157-176 uses all three) */
+	double adaptive_resampling_thresh; /* PFParams::adaptive_resampling_thresh in (0, 1]: resample only when the effective particle count
+	                                      1 / sum (w / sum w)^2 is <= thresh * n (PF.cc:114-118, 381-390); 0: every iteration */
+	int update_distr_wts;     /* PFParams::update_distr_wts: the weights of several sampler distributions follow the average particle weight
+	                             each produced (PF.cc:345-369); needed by mtfhip_pf_set_distributions with more than one */
+	double min_distr_wt;      /* PFParams::min_distr_wt: floor of a distribution's weight */
 } mtfhip_pf_desc;
 int mtfhip_pf_create(mtfhip_batch *b, const mtfhip_pf_desc *desc, mtfhip_pf **out);
 void mtfhip_pf_destroy(mtfhip_pf *pf);   /* before the batch it was created on */
 /* nt::PF::initialize after ssm->initialize / am->initializePixVals / am->initializeSimilarity (PF.cc:136-183) */
 int mtfhip_pf_initialize(mtfhip_pf *pf);
 int mtfhip_pf_set_region(mtfhip_pf *pf, const double *corners /* 8 */);          /* PF.cc:616-620 */
-int mtfhip_pf_set_sampler(mtfhip_pf *pf, const double *sigma, const double *mean); /* ProjectiveBase.cc:208-215 */
+int mtfhip_pf_set_sampler(mtfhip_pf *pf, const double *sigma, const double *mean);
+/* n_distr (1 .. 8) sampler distributions, rows of 8 (PFParams::processDistributions, PF.cc:55-56): see mtfhip_pf_desc.update_distr_wts */
+int mtfhip_pf_set_distributions(mtfhip_pf *pf, int n_distr, const double *sigma /* n_distr x 8 */, const double *mean /* n_distr x 8 */);
+/* the distribution draws of the NEXT iteration supplied by the caller (n uniforms in (0, 1]); NULL: the device generator */
+int mtfhip_pf_set_distr_draws(mtfhip_pf *pf, const double *uniforms);
+/* the distribution weights the next iteration draws from, the particles' distribution ids of the last one (or NULL), whether it resampled */
+int mtfhip_pf_get_distributions(mtfhip_pf *pf, double *distr_wts /* n_distr */, int *distr_ids /* n or NULL */, int *resampled); /* ProjectiveBase.cc:208-215 */
 /* one iteration of update()'s loop (PF.cc:260-447); normals n x nz (nz = 10 with corner based homography sampling, 6 / 8 / 6 for
  * Affine point based 1 / 2 / geometric, else S) and uniforms n: host arrays, or NULL for the device generator; update_norm =
  * squared corner change of the estimate */

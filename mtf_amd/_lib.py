@@ -62,7 +62,8 @@ class PFDesc(C.Structure):
                 ("update_type", C.c_int), ("likelihood_func", C.c_int), ("resampling_type", C.c_int), ("mean_type", C.c_int),
                 ("corner_based_sampling", C.c_int), ("reset_to_mean", C.c_int), ("measurement_sigma", C.c_double),
                 ("ar_coeff", C.c_double), ("ssm_sigma", C.c_double * 8), ("ssm_mean", C.c_double * 8), ("seed", C.c_ulonglong),
-                ("pt_based_sampling", C.c_int)]
+                ("pt_based_sampling", C.c_int), ("adaptive_resampling_thresh", C.c_double), ("update_distr_wts", C.c_int),
+                ("min_distr_wt", C.c_double)]
 
 
 # every exported symbol of include/mtfhip.h (tests check that the library exports all of them)
@@ -95,7 +96,7 @@ SYMBOLS = [
     "mtfhip_sample_candidates", "mtfhip_sample_candidates_dev",
     "mtfhip_pf_create", "mtfhip_pf_destroy", "mtfhip_pf_initialize", "mtfhip_pf_set_region", "mtfhip_pf_set_sampler",
     "mtfhip_pf_iteration", "mtfhip_pf_update", "mtfhip_pf_get_particles", "mtfhip_pf_set_particles", "mtfhip_pf_max_similarity",
-    "mtfhip_pf_set_max_similarity", "mtfhip_comm_create_loopback", "mtfhip_pf_shard_bounds",
+    "mtfhip_pf_set_max_similarity", "mtfhip_pf_set_distributions", "mtfhip_pf_set_distr_draws", "mtfhip_pf_get_distributions", "mtfhip_comm_create_loopback", "mtfhip_pf_shard_bounds",
     "mtfhip_batch_track_trace", "mtfhip_batch_track_trace_read", "mtfhip_image_preprocess_ex",
     "mtfhip_comm_unique_id", "mtfhip_comm_create", "mtfhip_comm_destroy", "mtfhip_comm_rank", "mtfhip_comm_world",
     "mtfhip_allgather_scores", "mtfhip_pf_set_comm",
@@ -165,6 +166,9 @@ def lib():
         L.mtfhip_batch_write.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.mtfhip_timing_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.mtfhip_batch_inline_warp.argtypes = [C.c_void_p]
+        L.mtfhip_pf_set_distributions.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.mtfhip_pf_set_distr_draws.argtypes = [C.c_void_p, C.c_void_p]
+        L.mtfhip_pf_get_distributions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mtfhip_timing_get_busy.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         _lib = L
     return _lib

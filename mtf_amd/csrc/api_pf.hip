@@ -105,6 +105,13 @@ struct mtfhip_pf {
 	int *d_res_idx = nullptr;
 	void *d_res_tmp = nullptr; size_t res_tmp_bytes = 0;
 	double prev_corners[8];
+	/* several sampler distributions + adaptive resampling (PF.cc:240-269, 345-390): d_distr = sigma [8][8] | mean [8][8] | running sums
+	 * of the distribution weights [8] | the weights [8]; the particles' distribution ids; the scan's per-chunk statistics; its verdict
+	 * "this iteration resamples"; the next iteration's distribution draws when the caller hands them in */
+	int n_distr = 1;
+	double *d_distr = nullptr, *d_scan_stats = nullptr, *d_distr_u = nullptr;
+	int *d_distr_ids = nullptr, *d_resample_flag = nullptr;
+	std::vector<double> distr_u_next;
 };
 
 /* block of rank `rank`: [lo, lo + cnt) with m = ceil(n / world) particles per rank (the last blocks may be short or empty), so
@@ -208,7 +215,8 @@ int mtfhip_allgather_scores(mtfhip_comm *c, const double *dev_send, int count, d
 /* ------------------------------------------------------------------ the particle filter */
 static void pf_free(mtfhip_pf *pf) {
 	void *ptrs[] = {pf->d_st, pf->d_ar, pf->d_prop[0], pf->d_prop[1], pf->d_prop_ar[0], pf->d_prop_ar[1], pf->d_wts, pf->d_cum, pf->d_chunk, pf->d_out,
-		pf->d_normals, pf->d_uniforms, pf->d_ids, pf->d_parts, pf->d_gparts, pf->d_counters, pf->d_res_keys, pf->d_res_idx, pf->d_res_tmp};
+		pf->d_normals, pf->d_uniforms, pf->d_ids, pf->d_parts, pf->d_gparts, pf->d_counters, pf->d_res_keys, pf->d_res_idx, pf->d_res_tmp,
+		pf->d_distr, pf->d_scan_stats, pf->d_distr_u, pf->d_distr_ids, pf->d_resample_flag};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 }
 /* which sampler the (SSM, update type, dynamic model, sampling switches) combination selects -- and which combinations the
@@ -268,8 +276,69 @@ int mtfhip_pf_create(mtfhip_batch *b, const mtfhip_pf_desc *d, mtfhip_pf **out) 
 		A(pf->d_res_tmp, pf->res_tmp_bytes);
 	}
 	if (okm && hipMemsetAsync(pf->d_out, 0, sizeof(double) * 32, b->ctx->stream) != hipSuccess) okm = false;
+	if (d->adaptive_resampling_thresh > 0 && d->adaptive_resampling_thresh <= 1) {   /* PF.cc:114-118 */
+		A(pf->d_scan_stats, sizeof(double) * 17 * nch); A(pf->d_resample_flag, sizeof(int));
+	}
 	if (!okm) { pf_free(pf); delete pf; return fail(MTFHIP_ERR_HIP, "pf_create: hipMalloc failed"); }
 	*out = pf;
+	return MTFHIP_OK;
+}
+/* PFParams::processDistributions + nt::PF's state_sigma / state_mean (PFParams.cc:101-170, PF.cc:55-56, 96-97): n_distr sampler
+ * distributions, rows of 8; every particle draws its distribution from weights that follow the average particle weight each
+ * distribution produced in the previous iteration (update_distr_wts, floored at min_distr_wt: PF.cc:345-369).  n_distr == 1 is
+ * mtfhip_pf_set_sampler.  With several distributions and update_distr_wts == 0 the reference zeroes the weights and then builds a
+ * discrete distribution from zeros (PF.cc:254-257, 241): refused. */
+int mtfhip_pf_set_distributions(mtfhip_pf *pf, int n_distr, const double *sigma, const double *mean) {
+	if (!pf || !sigma || !mean) return fail(MTFHIP_ERR_INVALID_ARG, "pf_set_distributions: NULL argument");
+	if (n_distr < 1 || n_distr > 8) return fail(MTFHIP_ERR_INVALID_ARG, "pf_set_distributions: %d distributions (1 .. 8)", n_distr);
+	if (n_distr > 1 && !pf->d.update_distr_wts)
+		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "pf_set_distributions: several distributions need update_distr_wts (the reference divides by a zero weight sum without it, PF.cc:241-257)");
+	hipStream_t st = pf->b->ctx->stream;
+	const size_t n = (size_t)pf->n, nch = pf_round_chunk(n) / (size_t)pf_chunk();
+	if (!pf->d_distr) HIP_TRY(hipMalloc(&pf->d_distr, sizeof(double) * (64 + 64 + 8 + 8)));
+	if (n_distr > 1) {
+		if (!pf->d_scan_stats) HIP_TRY(hipMalloc(&pf->d_scan_stats, sizeof(double) * 17 * nch));
+		if (!pf->d_resample_flag) HIP_TRY(hipMalloc(&pf->d_resample_flag, sizeof(int)));
+		if (!pf->d_distr_ids) HIP_TRY(hipMalloc(&pf->d_distr_ids, sizeof(int) * n));
+		if (!pf->d_distr_u) HIP_TRY(hipMalloc(&pf->d_distr_u, sizeof(double) * n));
+	}
+	double h[144];
+	std::memset(h, 0, sizeof(h));
+	for (int i = 0; i < n_distr; ++i)
+		for (int s2 = 0; s2 < pf->S; ++s2) { h[8 * i + s2] = sigma[8 * i + s2]; h[64 + 8 * i + s2] = mean[8 * i + s2]; }
+	for (int i = 0; i < n_distr; ++i) { h[136 + i] = 1.0 / n_distr; h[128 + i] = (i + 1.0) / n_distr; }   /* initializeDistributions PF.cc:199-205 */
+	HIP_TRY(hipMemcpyAsync(pf->d_distr, h, sizeof(h), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	pf->n_distr = n_distr;
+	for (int s2 = 0; s2 < pf->S; ++s2) { pf->d.ssm_sigma[s2] = sigma[s2]; pf->d.ssm_mean[s2] = mean[s2]; }   /* initializeSampler(state_sigma[0], state_mean[0]) */
+	pf->prop_valid = false;
+	return MTFHIP_OK;
+}
+/* the distribution draws (uniforms in (0, 1], one per particle) of the NEXT iteration, for callers that supply their own draws
+ * (the parity tests); NULL: back to the device generator */
+int mtfhip_pf_set_distr_draws(mtfhip_pf *pf, const double *u) {
+	if (!pf) return fail(MTFHIP_ERR_INVALID_ARG, "pf_set_distr_draws: NULL filter");
+	if (u) pf->distr_u_next.assign(u, u + pf->n); else pf->distr_u_next.clear();
+	return MTFHIP_OK;
+}
+/* the distribution weights the next iteration draws from (n_distr values), the distribution id of every particle of the last
+ * iteration (n, or NULL), whether the last iteration resampled (adaptive resampling, PF.cc:381-390) */
+int mtfhip_pf_get_distributions(mtfhip_pf *pf, double *wts, int *ids, int *resampled) {
+	if (!pf) return fail(MTFHIP_ERR_INVALID_ARG, "pf_get_distributions: NULL filter");
+	hipStream_t st = pf->b->ctx->stream;
+	if (wts) {
+		if (pf->n_distr > 1) HIP_TRY(hipMemcpyAsync(wts, pf->d_distr + 136, sizeof(double) * pf->n_distr, hipMemcpyDeviceToHost, st));
+		else wts[0] = 1.0;
+	}
+	if (ids) {
+		if (pf->n_distr > 1) HIP_TRY(hipMemcpyAsync(ids, pf->d_distr_ids, sizeof(int) * pf->n, hipMemcpyDeviceToHost, st));
+		else std::memset(ids, 0, sizeof(int) * pf->n);
+	}
+	int flag = 1;
+	const bool adaptive = pf->d.adaptive_resampling_thresh > 0 && pf->d.adaptive_resampling_thresh <= 1 && pf->d.resampling_type != 0;
+	if (resampled && adaptive && pf->d_resample_flag && pf->iter > 0) HIP_TRY(hipMemcpyAsync(&flag, pf->d_resample_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	if (resampled) *resampled = pf->d.resampling_type == 0 ? 0 : flag;
 	return MTFHIP_OK;
 }
 void mtfhip_pf_destroy(mtfhip_pf *pf) {
@@ -300,6 +369,13 @@ int mtfhip_pf_set_sampler(mtfhip_pf *pf, const double *sigma, const double *mean
 	if (!pf || !sigma || !mean) return fail(MTFHIP_ERR_INVALID_ARG, "pf_set_sampler: NULL argument");
 	for (int s = 0; s < pf->S; ++s) { pf->d.ssm_sigma[s] = sigma[s]; pf->d.ssm_mean[s] = mean[s]; }
 	pf->prop_valid = false;   /* proposals made ahead used the old distributions */
+	if (pf->n_distr > 1 && pf->d_distr) {   /* distribution 0 of the set */
+		double h[16];
+		for (int s2 = 0; s2 < 8; ++s2) { h[s2] = s2 < pf->S ? sigma[s2] : 0.0; h[8 + s2] = s2 < pf->S ? mean[s2] : 0.0; }
+		HIP_TRY(hipMemcpyAsync(pf->d_distr, h, sizeof(double) * 8, hipMemcpyHostToDevice, pf->b->ctx->stream));
+		HIP_TRY(hipMemcpyAsync(pf->d_distr + 64, h + 8, sizeof(double) * 8, hipMemcpyHostToDevice, pf->b->ctx->stream));
+		HIP_TRY(hipStreamSynchronize(pf->b->ctx->stream));
+	}
 	return MTFHIP_OK;
 }
 /* PF::initializeParticles (PF.cc:185-197) */
@@ -322,6 +398,12 @@ int mtfhip_pf_initialize(mtfhip_pf *pf) {
 	TRY(mtfhip_am_get_similarity(b, &f));
 	pf->max_similarity = f;
 	pf->iter = 0;
+	if (pf->n_distr > 1) {   /* initializeDistributions PF.cc:199-205 */
+		double h[16];
+		for (int i = 0; i < 8; ++i) { h[8 + i] = i < pf->n_distr ? 1.0 / pf->n_distr : 0.0; h[i] = i < pf->n_distr ? (i + 1.0) / pf->n_distr : 0.0; }
+		HIP_TRY(hipMemcpyAsync(pf->d_distr + 128, h, sizeof(h), hipMemcpyHostToDevice, b->ctx->stream));
+		HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	}
 	TRY(pf_initialize_particles(pf));
 	std::memcpy(pf->prev_corners, b->th[0].corners, sizeof(pf->prev_corners));
 	pf->initialized = true;
@@ -349,7 +431,7 @@ static int pf_residual_sources(mtfhip_pf *pf, PfBuffers &bf, size_t nch, hipStre
 	int *idx_in = pf->d_res_idx, *order = idx_in + n, *copies = order + n, *starts = copies + n;
 	double *keys_in = pf->d_res_keys, *keys_out = keys_in + n;
 	const double *total = bf.chunk_incl + (nch - 1);   /* particle_cum_wts[n - 1] */
-	launch_pf_residual_prep(n, total, pf->d_wts, keys_in, idx_in, st);
+	launch_pf_residual_prep(n, total, pf->d_wts, keys_in, idx_in, bf.resample_flag, st);
 	if (n > 1) {
 		size_t tb = pf->res_tmp_bytes;
 		/* std::sort(idx, idx + n - 1, wts[a] > wts[b]): the last index is not part of the range */
@@ -413,20 +495,35 @@ static int pf_enqueue_iteration(mtfhip_pf *pf, const double *normals, const doub
 		p.uniforms = pf->d_uniforms;
 	}
 	const size_t nch = pf_round_chunk((size_t)n) / (size_t)pf_chunk();
+	const bool adaptive = pf->d.adaptive_resampling_thresh > 0 && pf->d.adaptive_resampling_thresh <= 1 && pf->d.resampling_type != 0;
+	const bool mixture = pf->n_distr > 1;
+	p.n_distr = pf->n_distr; p.distr_uniforms = nullptr;
+	p.min_distr_wt = pf->d.min_distr_wt;
+	p.min_eff_particles = adaptive ? pf->d.adaptive_resampling_thresh * n : 0.0;   /* PF.cc:117 */
+	if (mixture && !pf->distr_u_next.empty()) {
+		HIP_TRY(hipMemcpyAsync(pf->d_distr_u, pf->distr_u_next.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+		HIP_TRY(hipStreamSynchronize(st));   /* (the vector may be replaced before the copy has run) */
+		p.distr_uniforms = pf->d_distr_u;
+	}
 	const mtfhip_comm *c = pf->comm;
 	const bool sharded = c && c->world > 1;
 	int lo = 0, cnt = n, m = n;
 	if (sharded) pf_shard(n, c->world, c->rank, &lo, &cnt, &m);
 	/* this iteration's proposals (PF.cc:307-335): left behind by the previous selection pass, or made now */
-	const bool ahead = pf->prop_valid && !normals && pf->prop_iter == pf->iter && pf->prop_corners_epoch == b->corners_epoch;
+	PfBuffers bf;
+	bf.distr_sigma = mixture ? pf->d_distr : nullptr; bf.distr_mean = mixture ? pf->d_distr + 64 : nullptr;
+	bf.distr_cum = mixture ? pf->d_distr + 128 : nullptr; bf.distr_wts = mixture ? pf->d_distr + 136 : nullptr;
+	bf.distr_ids = mixture ? pf->d_distr_ids : nullptr;
+	bf.scan_stats = (mixture || adaptive) ? pf->d_scan_stats : nullptr;
+	bf.resample_flag = adaptive ? pf->d_resample_flag : nullptr;
+	const bool ahead = pf->prop_valid && !normals && !p.distr_uniforms && pf->prop_iter == pf->iter && pf->prop_corners_epoch == b->corners_epoch;
 	if (!ahead) {
 		TimedScope ts(b->ctx, "pf_propose");
-		launch_pf_propose(b->desc.ssm, p, pf->d_st, pf->d_ar, pf->d_prop[pf->pc], pf->d_prop_ar[pf->pc], st);
+		launch_pf_propose(b->desc.ssm, p, bf, pf->d_st, pf->d_ar, pf->d_prop[pf->pc], pf->d_prop_ar[pf->pc], st);
 	}
 	/* the next iteration's can be made by this one's selection pass when its draws are the device generator's and nothing the
 	 * sampler reads moves in between (MeanType::Corners re-bases the SSM on the mean corners: setCorners, PF.cc:434-436) */
-	const bool lookahead = pf->lookahead_enabled && !normals && pf->d.mean_type != 2;
-	PfBuffers bf;
+	const bool lookahead = pf->lookahead_enabled && !normals && !p.distr_uniforms && pf->d.mean_type != 2;
 	bf.st = pf->d_st; bf.ar = pf->d_ar; bf.prop = pf->d_prop[pf->pc]; bf.prop_ar = pf->d_prop_ar[pf->pc];
 	bf.next = pf->d_prop[1 - pf->pc]; bf.next_ar = pf->d_prop_ar[1 - pf->pc];
 	bf.wts = pf->d_wts; bf.sim = nullptr; bf.cum = pf->d_cum; bf.chunk_tot = pf->d_chunk; bf.chunk_incl = pf->d_chunk + nch; bf.sub16 = pf->d_chunk + 2 * nch;
@@ -445,12 +542,13 @@ static int pf_enqueue_iteration(mtfhip_pf *pf, const double *normals, const doub
 		TimedScope ts(b->ctx, "pf_resample");
 		unsigned long long seq = 0;
 		if (publish && b->h_acc_dev) seq = ++b->acc_seq;
-		if (p.resampling_type != 0) launch_pf_scan(p, bf, st);
+		if (p.resampling_type != 0 || mixture) launch_pf_scan(p, bf, st);   /* (the distribution weights follow the particle weights whatever the resampling) */
 		if (p.resampling_type == 3) TRY(pf_residual_sources(pf, bf, nch, st));
 		launch_pf_select(b->desc.ssm, p, bf, lookahead ? 1 : 0, seq ? b->h_acc_dev : nullptr, b->h_flag_dev, seq, st);
 		if (pub_seq) *pub_seq = seq;
 	}
 	++pf->iter;
+	pf->distr_u_next.clear();   /* (handed-in distribution draws are for one iteration) */
 	pf->prop_valid = lookahead;
 	if (lookahead) { pf->pc = 1 - pf->pc; pf->prop_iter = pf->iter; pf->prop_corners_epoch = b->corners_epoch; }
 	return MTFHIP_OK;

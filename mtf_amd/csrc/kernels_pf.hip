@@ -169,6 +169,13 @@ struct PfArgs {
 	unsigned long long seed;
 	unsigned iter;
 	const double *normals;     /* [n][nz] standard normals, or NULL: Philox */
+	/* several sampler distributions (PF.cc:240-269): particle k draws its distribution id from the weights of the previous
+	 * iteration (distr_cum: their running sums) and perturbs with that distribution's sigma / mean */
+	int n_distr;
+	const double *distr_sigma, *distr_mean;   /* [n_distr][8] */
+	const double *distr_cum;                  /* [n_distr] */
+	const double *distr_uniforms;             /* [n] or NULL: Philox */
+	int *distr_ids;                           /* [n] out */
 };
 
 /* pair `q` (draws 2 q, 2 q + 1) of particle k's normals */
@@ -183,7 +190,7 @@ __device__ __forceinline__ void pf_normal_pair(const PfArgs &a, unsigned k, int 
 
 /* the SSM's generatePerturbation for one particle from its standard normals z[0..nz) */
 template <int SSM>
-__device__ __forceinline__ void pf_perturbation(const PfArgs &a, const double *z, double *pert) {
+__device__ __forceinline__ void pf_perturbation(const PfArgs &a, const double (&sg)[8], const double (&mn)[8], const double *z, double *pert) {
 	constexpr int S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
 #pragma unroll
 	for (int s = 0; s < 8; ++s) pert[s] = 0.0;
@@ -192,11 +199,11 @@ __device__ __forceinline__ void pf_perturbation(const PfArgs &a, const double *z
 		 * distribution 0, one displacement per corner coordinate from distribution 1, then the warp that takes the template
 		 * corners to the disturbed ones */
 		double dc[8], Hq[9], Hp[9];
-		const double tx = a.mean[0] + a.sigma[0] * z[0], ty = a.mean[0] + a.sigma[0] * z[1];
+		const double tx = mn[0] + sg[0] * z[0], ty = mn[0] + sg[0] * z[1];
 #pragma unroll
 		for (int c = 0; c < 4; ++c) {
-			dc[2 * c] = a.init_corners[2 * c] + (a.mean[1] + a.sigma[1] * z[2 + 2 * c]) + tx;
-			dc[2 * c + 1] = a.init_corners[2 * c + 1] + (a.mean[1] + a.sigma[1] * z[3 + 2 * c]) + ty;
+			dc[2 * c] = a.init_corners[2 * c] + (mn[1] + sg[1] * z[2 + 2 * c]) + tx;
+			dc[2 * c + 1] = a.init_corners[2 * c + 1] + (mn[1] + sg[1] * z[3 + 2 * c]) + ty;
 		}
 		square_to_quad_dev(dc, Hq);
 		m3_mul_dev(Hq, a.aux_inv, Hp);
@@ -213,15 +220,15 @@ __device__ __forceinline__ void pf_perturbation(const PfArgs &a, const double *z
 		if (a.sampler == PF_SAMPLER_AFF_PTS1) {
 #pragma unroll
 			for (int i = 0; i < 3; ++i) {
-				px[i] = a.canon[2 * i] + (a.mean[2 * i] + a.sigma[2 * i] * z[2 * i]);
-				py[i] = a.canon[2 * i + 1] + (a.mean[2 * i + 1] + a.sigma[2 * i + 1] * z[2 * i + 1]);
+				px[i] = a.canon[2 * i] + (mn[2 * i] + sg[2 * i] * z[2 * i]);
+				py[i] = a.canon[2 * i + 1] + (mn[2 * i + 1] + sg[2 * i + 1] * z[2 * i + 1]);
 			}
 		} else {
-			const double tx = a.mean[0] + a.sigma[0] * z[6], ty = a.mean[0] + a.sigma[0] * z[7];
+			const double tx = mn[0] + sg[0] * z[6], ty = mn[0] + sg[0] * z[7];
 #pragma unroll
 			for (int i = 0; i < 3; ++i) {
-				px[i] = (a.canon[2 * i] + (a.mean[1] + a.sigma[1] * z[2 * i])) + tx;
-				py[i] = (a.canon[2 * i + 1] + (a.mean[1] + a.sigma[1] * z[2 * i + 1])) + ty;
+				px[i] = (a.canon[2 * i] + (mn[1] + sg[1] * z[2 * i])) + tx;
+				py[i] = (a.canon[2 * i + 1] + (mn[1] + sg[1] * z[2 * i + 1])) + ty;
 			}
 		}
 		double W[9];
@@ -237,7 +244,7 @@ __device__ __forceinline__ void pf_perturbation(const PfArgs &a, const double *z
 		 * (tx, ty, scale, theta, aspect, phi) */
 		double gm[6];
 #pragma unroll
-		for (int s = 0; s < 6; ++s) gm[s] = a.mean[s] + a.sigma[s] * z[s];
+		for (int s = 0; s < 6; ++s) gm[s] = mn[s] + sg[s] * z[s];
 		const double sc = gm[2], r = gm[4], theta = gm[3], phi = gm[5];
 		const double cos_theta = cos(theta), sin_theta = sin(theta), cos_phi = cos(phi), sin_phi = sin(phi);
 		const double ccc = cos_theta * cos_phi * cos_phi, ccs = cos_theta * cos_phi * sin_phi, css = cos_theta * sin_phi * sin_phi;
@@ -249,7 +256,7 @@ __device__ __forceinline__ void pf_perturbation(const PfArgs &a, const double *z
 		pert[5] = sc * (r * (ccc + scs) - scs + css) - 1;
 	} else {
 #pragma unroll
-		for (int s = 0; s < S; ++s) pert[s] = a.mean[s] + a.sigma[s] * z[s];   /* ProjectiveBase::generatePerturbation :283-288 */
+		for (int s = 0; s < S; ++s) pert[s] = mn[s] + sg[s] * z[s];   /* ProjectiveBase::generatePerturbation :283-288 */
 	}
 }
 /* (st, ar) -> (ns, nar): PF.cc:307-335 */
@@ -306,7 +313,27 @@ __device__ __forceinline__ void pf_propose(const PfArgs &a, unsigned k, const do
 		z[2 * q] = z[2 * q + 1] = 0.0;
 		if (2 * q < a.nz) pf_normal_pair(a, k, q, z[2 * q], z[2 * q + 1]);
 	}
-	pf_perturbation<SSM>(a, z, pert);
+	double sg[8], mn[8];
+#pragma unroll
+	for (int s = 0; s < 8; ++s) { sg[s] = a.sigma[s]; mn[s] = a.mean[s]; }
+	if (a.n_distr > 1) {
+		/* the particle's distribution (PF.cc:261-269): the reference asks a boost discrete_distribution with a generator of its own; here
+		 * one more counter-based uniform, inverted on the running sums of the distribution weights */
+		double u;
+		if (a.distr_uniforms) u = a.distr_uniforms[k];
+		else {
+			const Philox4 r = philox4x32_10(k, 0u, a.iter, 0x44495354u /* "DIST" */, (unsigned)a.seed, (unsigned)(a.seed >> 32));
+			double u1;
+			philox_uniform2(r, u, u1);
+		}
+		const double tgt = u * a.distr_cum[a.n_distr - 1];
+		int id = 0;
+		while (id < a.n_distr - 1 && a.distr_cum[id] < tgt) ++id;
+		if (a.distr_ids) a.distr_ids[k] = id;
+#pragma unroll
+		for (int s = 0; s < 8; ++s) { sg[s] = a.distr_sigma[8 * id + s]; mn[s] = a.distr_mean[8 * id + s]; }
+	}
+	pf_perturbation<SSM>(a, sg, mn, z, pert);
 	pf_dynamics<SSM>(a, pert, st, ar, ns, nar);
 }
 /* the proposals of a whole set in a launch of their own: the first iteration after the particles were (re)initialised, draws
@@ -457,6 +484,14 @@ struct PfScanArgs {
 	double *chunk_tot;    /* [nch] */
 	double *chunk_incl;   /* [nch] */
 	int *counter;         /* zero between launches */
+	/* optional (stats != NULL): sum of squared weights for adaptive resampling (PF.cc:381-390) and, with several sampler
+	 * distributions, the weight sum and the particle count of every distribution (PF.cc:345-369) */
+	double *stats;        /* [nch][17]: sum w^2 | 8 x sum w | 8 x count */
+	const int *distr_ids; /* [n] or NULL */
+	int n_distr;
+	double min_distr_wt, min_eff;   /* min_eff: adaptive_resampling_thresh x n, 0 = resample every iteration */
+	double *distr_cum, *distr_wts;  /* [n_distr] out: the distribution weights of the next iteration and their running sums */
+	int *resample_flag;   /* out: 1 when this iteration resamples */
 };
 __device__ __forceinline__ double wave_scan_incl(double x, int lane) {
 #pragma unroll
@@ -486,6 +521,28 @@ __global__ __launch_bounds__(kBlock) void k_pf_scan(PfScanArgs a) {
 		*reinterpret_cast<double2 *>(a.cum + base + 2) = make_double2(off + p2, off + p3);
 		if ((lane & 3) == 3) a.sub16[chunk * 16 + (lane >> 2)] = off + p3;
 		if (lane == 63) st_coh(a.chunk_tot + chunk, incl);
+		if (a.stats) {
+			double sv[17];
+#pragma unroll
+			for (int q = 0; q < 17; ++q) sv[q] = 0.0;
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				sv[0] = fma(w[j], w[j], sv[0]);
+				if (a.n_distr > 1 && base + j < a.n) {
+					const int id = a.distr_ids[base + j];
+#pragma unroll
+					for (int q = 0; q < 8; ++q) if (id == q) { sv[1 + q] += w[j]; sv[9 + q] += 1.0; }
+				}
+			}
+#pragma unroll
+			for (int q = 0; q < 17; ++q)
+#pragma unroll
+				for (int d = 32; d >= 1; d >>= 1) sv[q] += __shfl_xor(sv[q], d);   /* a fixed balanced tree */
+			if (lane == 0) {
+#pragma unroll
+				for (int q = 0; q < 17; ++q) st_coh(a.stats + (size_t)chunk * 17 + q, sv[q]);
+			}
+		}
 	}
 	wait_stores_acked();
 	__syncthreads();
@@ -518,6 +575,48 @@ __global__ __launch_bounds__(kBlock) void k_pf_scan(PfScanArgs a) {
 	} else {
 		for (int c = lo; c < hi; ++c) { c0 += ld_coh(a.chunk_tot + c); a.chunk_incl[c] = c0; }
 	}
+	if (a.stats) {
+		/* the per-chunk statistics, summed in chunk order (fixed: every rank gets the same bits): thread q < 17 owns column q */
+		__shared__ double tot_s[17];
+		if (tid < 17) {
+			double acc8[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) acc8[u] = 0.0;
+			int c = 0;
+			for (; c + 7 < nch; c += 8) {
+#pragma unroll
+				for (int u = 0; u < 8; ++u) acc8[u] += ld_coh(a.stats + (size_t)(c + u) * 17 + tid);
+			}
+			for (; c < nch; ++c) acc8[0] += ld_coh(a.stats + (size_t)c * 17 + tid);
+			tot_s[tid] = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
+		}
+		__syncthreads();   /* (also: chunk_incl[nch - 1] below was written by this workgroup) */
+		if (tid == 0) {
+			const double total = a.chunk_incl[nch - 1];
+			/* n_eff = 1 / sum (w / sum w)^2 (PF.cc:382-384) */
+			const double sq = tot_s[0] / (total * total);
+			const double n_eff = (sq == 0 || !(sq == sq)) ? 0.0 : 1.0 / sq;
+			if (a.resample_flag) *a.resample_flag = (a.min_eff > 0 && n_eff > a.min_eff) ? 0 : 1;
+			if (a.n_distr > 1) {   /* PF.cc:354-369 */
+				double wv[8], wt_sum = 0.0;
+#pragma unroll
+				for (int q = 0; q < 8; ++q) {
+					wv[q] = q < a.n_distr ? tot_s[1 + q] : 0.0;
+					if (q < a.n_distr && tot_s[9 + q] > 0) { wv[q] /= tot_s[9 + q]; wt_sum += wv[q]; }
+				}
+				double run = 0.0;
+#pragma unroll
+				for (int q = 0; q < 8; ++q) {
+					if (q < a.n_distr) {
+						double v = wv[q] / wt_sum;
+						if (v < a.min_distr_wt) v = a.min_distr_wt;
+						run += v;
+						a.distr_wts[q] = v; a.distr_cum[q] = run;
+					}
+				}
+			}
+		}
+	}
 	if (tid == 0) __hip_atomic_store(a.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -533,6 +632,7 @@ struct PfSelectArgs {
 	int resampling_type, mean_type;
 	int lookahead;                /* 1: the proposals of the next iteration (draws of a.iter + 1) are produced here */
 	const double *uniforms;       /* [n] or NULL: Philox */
+	const int *resample_flag;     /* NULL, or the scan's verdict (adaptive resampling): 0 = this iteration keeps its proposals */
 	const double *wts, *cum, *sub16, *chunk_incl;
 	const double *prop, *prop_ar; /* [n][S] this iteration's proposals */
 	double *st_out, *ar_out;      /* [n][S] the (resampled) set the iteration leaves behind */
@@ -591,7 +691,8 @@ __global__ __launch_bounds__(kBlock) void k_pf_select(PfArgs a, PfSelectArgs r) 
 	__shared__ double best_state[8];
 	__shared__ int wg_best, is_last;
 	const int n = a.n, tid = threadIdx.x, k = blockIdx.x * kBlock + tid;
-	const bool resample = r.resampling_type == 1 || r.resampling_type == 2;
+	const bool go = r.resample_flag ? *r.resample_flag != 0 : true;   /* (uniform: a scalar load) */
+	const bool resample = go && (r.resampling_type == 1 || r.resampling_type == 2);
 	const int nch = (n + kPfChunk - 1) / kPfChunk;
 	const bool in_lds = nch <= kPfTable;
 	double total = 0.0;
@@ -645,7 +746,8 @@ __global__ __launch_bounds__(kBlock) void k_pf_select(PfArgs a, PfSelectArgs r) 
 			id = min(c * kPfChunk + lo, n - 1);
 			if (r.ids) r.ids[k] = id;
 		}
-		if (r.resampling_type == 3) id = r.ids[k];   /* residual resampling: the sources were laid out by k_pf_residual_map */
+		if (go && r.resampling_type == 3) id = r.ids[k];   /* residual resampling: the sources were laid out by k_pf_residual_map */
+		if (!go && r.ids) r.ids[k] = k;
 		/* the auto-regression terms travel with the particle only where a model reads them (AutoRegression1): under RandomWalk they
 		 * stay what initializeParticles made them -- zero -- and three of the seven 64-byte rows this pass moves per particle go away
 		 * (it is bound by those rows at a million particles: 832 -> 640 bytes of cache lines per particle) */
@@ -655,7 +757,7 @@ __global__ __launch_bounds__(kBlock) void k_pf_select(PfArgs a, PfSelectArgs r) 
 		pf_store_row<S>(r.st_out, (size_t)k, ns);
 		if (use_ar) pf_store_row<S>(r.ar_out, (size_t)k, nar);
 		bv = r.wts[id]; bi = k;
-		if (r.forced_best && k != *r.forced_best) bv = -1.7976931348623157e308;   /* max_wt_id is handed down, not searched for */
+		if (go && r.forced_best && k != *r.forced_best) bv = -1.7976931348623157e308;   /* max_wt_id is handed down, not searched for */
 		if (r.mean_type == 1) {
 #pragma unroll
 			for (int s = 0; s < 8; ++s) acc[s] = ns[s];
@@ -770,11 +872,12 @@ __global__ __launch_bounds__(kBlock) void k_pf_select(PfArgs a, PfSelectArgs r) 
  * Here: normalise + keys (k_pf_residual_prep), a stable radix sort of the n - 1 keys (hipCUB; std::sort leaves the order of
  * equal weights unspecified, index order is one of its outcomes), copies (k_pf_residual_copies), their exclusive scan, and a
  * search of every destination slot in the scanned starts (k_pf_residual_map). */
-__global__ __launch_bounds__(kBlock) void k_pf_residual_prep(int n, const double *total, double *wts, double *keys, int *idx) {
+__global__ __launch_bounds__(kBlock) void k_pf_residual_prep(int n, const double *total, double *wts, double *keys, int *idx, const int *flag) {
 	const int k = blockIdx.x * kBlock + threadIdx.x;
 	if (k >= n) return;
 	const double w = wts[k] / *total;
-	wts[k] = w; keys[k] = w; idx[k] = k;
+	if (!flag || *flag) wts[k] = w;   /* (adaptive resampling: an iteration that does not resample keeps its weights as they are) */
+	keys[k] = w; idx[k] = k;
 }
 __global__ __launch_bounds__(kBlock) void k_pf_residual_copies(int n, const double *wts, const int *order, int *copies) {
 	const int j = blockIdx.x * kBlock + threadIdx.x;
@@ -802,8 +905,10 @@ __global__ void k_pf_fill(int n, int S, const double *state, double *states, dou
 /* ===================================================================== */
 /* launchers                                                              */
 /* ===================================================================== */
-static PfArgs pf_args(const PfLaunch &p) {
+static PfArgs pf_args(const PfLaunch &p, const PfBuffers &bf) {
 	PfArgs a;
+	a.n_distr = p.n_distr > 1 ? p.n_distr : 1;
+	a.distr_sigma = bf.distr_sigma; a.distr_mean = bf.distr_mean; a.distr_cum = bf.distr_cum; a.distr_uniforms = p.distr_uniforms; a.distr_ids = bf.distr_ids;
 	a.n = p.n; a.S = p.S; a.dynamic_model = p.dynamic_model; a.update_type = p.update_type; a.sampler = p.sampler; a.nz = p.nz; a.ar_coeff = p.ar_coeff;
 	for (int k = 0; k < 8; ++k) { a.sigma[k] = p.sigma[k]; a.mean[k] = p.mean[k]; a.init_corners[k] = p.init_corners[k]; }
 	for (int k = 0; k < 9; ++k) a.aux_inv[k] = p.aux_inv[k];
@@ -811,8 +916,8 @@ static PfArgs pf_args(const PfLaunch &p) {
 	a.seed = p.seed; a.iter = p.iter; a.normals = p.normals;
 	return a;
 }
-void launch_pf_propose(int ssm, const PfLaunch &p, const double *st_in, const double *ar_in, double *st_out, double *ar_out, hipStream_t st) {
-	const PfArgs a = pf_args(p);
+void launch_pf_propose(int ssm, const PfLaunch &p, const PfBuffers &bf, const double *st_in, const double *ar_in, double *st_out, double *ar_out, hipStream_t st) {
+	const PfArgs a = pf_args(p, bf);
 	const dim3 g((p.n + kBlock - 1) / kBlock);
 	if (ssm == MTFHIP_SSM_HOMOGRAPHY) MTFHIP_LAUNCH(k_pf_propose<MTFHIP_SSM_HOMOGRAPHY>, g, dim3(kBlock), 0, st, a, st_in, ar_in, st_out, ar_out);
 	else MTFHIP_LAUNCH(k_pf_propose<MTFHIP_SSM_AFFINE>, g, dim3(kBlock), 0, st, a, st_in, ar_in, st_out, ar_out);
@@ -846,13 +951,15 @@ void launch_score_block(const BatchView &bv, const ImgView &im, const double *st
 }
 void launch_pf_scan(const PfLaunch &p, const PfBuffers &bf, hipStream_t st) {
 	const int nch = (p.n + kPfChunk - 1) / kPfChunk;
-	PfScanArgs sc{p.n, nch, bf.wts, bf.cum, bf.sub16, bf.chunk_tot, bf.chunk_incl, bf.counters};
+	PfScanArgs sc{p.n, nch, bf.wts, bf.cum, bf.sub16, bf.chunk_tot, bf.chunk_incl, bf.counters,
+		bf.scan_stats, bf.distr_ids, p.n_distr > 1 ? p.n_distr : 1, p.min_distr_wt, p.min_eff_particles, bf.distr_cum, bf.distr_wts, bf.resample_flag};
 	MTFHIP_LAUNCH(k_pf_scan, dim3((nch + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, sc);
 }
 void launch_pf_select(int ssm, const PfLaunch &p, const PfBuffers &bf, int lookahead, double *host_out, unsigned long long *host_flag,
 	unsigned long long seq, hipStream_t st) {
-	const PfArgs a = pf_args(p);
+	const PfArgs a = pf_args(p, bf);
 	PfSelectArgs r;
+	r.resample_flag = bf.resample_flag;
 	r.resampling_type = p.resampling_type; r.mean_type = p.mean_type; r.lookahead = lookahead; r.uniforms = p.uniforms;
 	r.wts = bf.wts; r.cum = bf.cum; r.sub16 = bf.sub16; r.chunk_incl = bf.chunk_incl; r.prop = bf.prop; r.prop_ar = bf.prop_ar;
 	r.st_out = bf.st; r.ar_out = bf.ar; r.next = bf.next; r.next_ar = bf.next_ar; r.ids = bf.ids;
@@ -866,8 +973,8 @@ void launch_pf_select(int ssm, const PfLaunch &p, const PfBuffers &bf, int looka
 void launch_pf_fill(int n, int S, const double *dev_state, double *states, double *ars, hipStream_t st) {
 	MTFHIP_LAUNCH(k_pf_fill, dim3((n + 255) / 256), dim3(256), 0, st, n, S, dev_state, states, ars);
 }
-void launch_pf_residual_prep(int n, const double *total, double *wts, double *keys, int *idx, hipStream_t st) {
-	MTFHIP_LAUNCH(k_pf_residual_prep, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, total, wts, keys, idx);
+void launch_pf_residual_prep(int n, const double *total, double *wts, double *keys, int *idx, const int *flag, hipStream_t st) {
+	MTFHIP_LAUNCH(k_pf_residual_prep, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, total, wts, keys, idx, flag);
 }
 void launch_pf_residual_copies(int n, const double *wts, const int *order, int *copies, hipStream_t st) {
 	MTFHIP_LAUNCH(k_pf_residual_copies, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, wts, order, copies);

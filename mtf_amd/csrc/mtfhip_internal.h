@@ -252,6 +252,11 @@ struct PfLaunch {
 	unsigned long long seed;
 	unsigned iter;
 	const double *normals, *uniforms;   /* device arrays or NULL (Philox) */
+	/* several sampler distributions (PF.cc:240-269, 345-369) and adaptive resampling (PF.cc:381-390); n_distr == 1 and
+	 * min_eff_particles == 0: neither */
+	int n_distr;
+	const double *distr_uniforms;       /* [n] device array or NULL (Philox): the distribution draw of every particle */
+	double min_distr_wt, min_eff_particles;
 };
 struct PfBuffers {
 	double *st, *ar;            /* [n][S] the current (resampled) particle set */
@@ -261,10 +266,15 @@ struct PfBuffers {
 	double *cum, *sub16, *chunk_tot, *chunk_incl;
 	double *parts, *gparts, *out;   /* per-workgroup rows of the selection pass, their per-group folds, the estimate */
 	int *res_order;             /* residual resampling: particle indices by weight, highest first (the last index stays last) */
+	/* distributions / adaptive resampling (all NULL when neither is in use): [n_distr][8] sigmas and means, the cumulative distribution
+	 * weights the ids are drawn from (rewritten by the scan for the next iteration), the weights themselves, the particles'
+	 * distribution ids, per-chunk statistics of the scan [nch][17], the flag "this iteration resamples" */
+	double *distr_sigma, *distr_mean, *distr_cum, *distr_wts, *scan_stats;
+	int *distr_ids, *resample_flag;
 	int *ids, *counters;        /* [0] the scan's arrival counter, [1] the selection pass's top-level counter, [2 ...] one per group of 64
 	                               workgroups of the selection pass; zero between launches */
 };
-void launch_pf_propose(int ssm, const PfLaunch &p, const double *st_in, const double *ar_in, double *st_out, double *ar_out, hipStream_t st);
+void launch_pf_propose(int ssm, const PfLaunch &p, const PfBuffers &bf, const double *st_in, const double *ar_in, double *st_out, double *ar_out, hipStream_t st);
 void launch_score_block(const BatchView &bv, const ImgView &im, const double *states, int lo, int cnt, double alpha, double norm_mult,
 	double norm_add, const double *ncc_sc, double *wts, double *sim, int likelihood_func, double measurement_sigma, double max_similarity,
 	int fast_math, hipStream_t st);
@@ -272,7 +282,8 @@ void launch_pf_scan(const PfLaunch &p, const PfBuffers &bf, hipStream_t st);   /
 void launch_pf_select(int ssm, const PfLaunch &p, const PfBuffers &bf, int lookahead, double *host_out /* or NULL */,
 	unsigned long long *host_flag, unsigned long long seq, hipStream_t st);
 void launch_pf_fill(int n, int S, const double *dev_state, double *states, double *ars, hipStream_t st);
-void launch_pf_residual_prep(int n, const double *total, double *wts, double *keys, int *idx, hipStream_t st);
+/* flag: NULL, or the scan's "this iteration resamples" (adaptive resampling): with 0 the residual kernels leave everything as it is */
+void launch_pf_residual_prep(int n, const double *total, double *wts, double *keys, int *idx, const int *flag, hipStream_t st);
 void launch_pf_residual_copies(int n, const double *wts, const int *order, int *copies, hipStream_t st);
 void launch_pf_residual_map(int n, const int *order, const int *copies, const int *starts, int *ids, hipStream_t st);
 int pf_parts_per_block();

@@ -34,7 +34,14 @@ struct PFParams {
 	ResamplingType resampling_type = ResamplingType::BinaryMultinomial;
 	MeanType mean_type = MeanType::SSM;
 	bool reset_to_mean = false;
-	std::vector<double> ssm_sigma, ssm_mean;   /* one distribution (the reference's vectorvd with a single entry) */
+	std::vector<double> ssm_sigma, ssm_mean;   /* the first distribution (the reference's vectorvd with a single entry) */
+	/* further sampler distributions (PFParams::processDistributions, PFParams.cc:101-170: the shipped Config/modules.cfg:157 names
+	 * five): with any, every particle draws its distribution from weights that follow the average particle weight each produced */
+	std::vector<std::vector<double>> more_sigma, more_mean;
+	bool update_distr_wts = false;             /* PFParams.h: update_distr_wts; switched off for a single distribution (PF.cc:67) */
+	double min_distr_wt = 0.5;
+	double adaptive_resampling_thresh = 0;     /* in (0, 1]: resample only when the effective particle count is <= thresh * n (PF.cc:381-390) */
+	bool jacobian_as_sigma = false;            /* the sampler's sigma of every frame = the Gauss-Newton step (PF.cc:58-64, 156-165, 214-227) */
 	double measurement_sigma = 0.1;
 	bool enable_learning = false;
 	unsigned long long seed = 0;               /* hip::PF: the device generator's key; nt::PF: 0 = random_device */
@@ -54,7 +61,17 @@ protected:
 	std::vector<VectorXd> particle_states[2], particle_ar[2];
 	int curr_set_id = 0, max_wt_id = 0;
 	VectorXd particle_wts, particle_cum_wts, perturbed_state, perturbed_ar, mean_state;
-	VectorXd state_sigma, state_mean;
+	std::vector<VectorXd> state_sigma, state_mean;   /* [n_distr] */
+	int n_distr = 1;
+	std::vector<double> distr_wts;
+	std::vector<int> distr_n_particles, particle_distr;
+	std::mt19937_64 distr_id_gen;
+	MatrixXd dI_dp, d2f_dp2;      /* jacobian_as_sigma */
+	VectorXd df_dp;
+	bool enable_adaptive_resampling = false;
+	double min_eff_particles = 0;
+	void initializeDistributions();
+	void jacobianSigma(bool init);
 	CornersT mean_corners;
 	double max_similarity = 0, measurement_factor = 1;
 	std::mt19937_64 resample_gen;
@@ -83,6 +100,9 @@ private:
 	PFParams pf;
 	mtfhip_pf *h = nullptr;
 	CornersT region;
+	MatrixXd dI_dp, d2f_dp2;      /* jacobian_as_sigma: through the adapters' virtuals, the solve on the host */
+	VectorXd df_dp;
+	void jacobianSigma(bool init);
 };
 } // namespace hip
 

@@ -139,6 +139,38 @@ mtfhost_tracker *mtfhost_pf_create(int device_filter, int am, int ssm, int resx,
 		return t;
 	} catch (const std::exception &e) { g_err = e.what(); return nullptr; }
 }
+/* the same with the options of the shipped configuration: n_distr >= 1 sampler distributions (rows of 8), adaptive resampling,
+ * jacobian_as_sigma (PFParams.h; Config/modules.cfg:157-176) */
+mtfhost_tracker *mtfhost_pf_create_ex(int device_filter, int am, int ssm, int resx, int resy, int n_particles, int max_iters, double epsilon,
+	int dynamic_model, int update_type, int likelihood_func, int resampling_type, int mean_type, int corner_based_sampling,
+	int n_distr, const double *sigma_rows, const double *mean_rows, int update_distr_wts, double min_distr_wt, double adaptive_resampling_thresh,
+	int jacobian_as_sigma, double likelihood_alpha, unsigned long long seed, int device) {
+	try {
+		if (n_distr < 1) throw utils::InvalidArgument("mtfhost_pf_create_ex: n_distr must be positive");
+		auto *t = new mtfhost_tracker();
+		t->pair = std::make_shared<hip::HipPair>(am, ssm, resx, resy, 1e-8, likelihood_alpha, 8, 10.0, 0, device, nullptr, 1);
+		t->am = std::make_shared<hip::HipAM>(t->pair);
+		t->ssm = std::make_shared<hip::HipSSM>(t->pair);
+		t->ssm->setCornerBasedSampling(corner_based_sampling != 0);
+		PFParams p;
+		p.n_particles = n_particles; p.max_iters = max_iters; p.epsilon = epsilon;
+		p.dynamic_model = (PFParams::DynamicModel)dynamic_model; p.update_type = (PFParams::UpdateType)update_type;
+		p.likelihood_func = (PFParams::LikelihoodFunc)likelihood_func; p.resampling_type = (PFParams::ResamplingType)resampling_type;
+		p.mean_type = (PFParams::MeanType)mean_type; p.seed = seed;
+		const int S = t->pair->S;
+		p.ssm_sigma.assign(sigma_rows, sigma_rows + S);
+		p.ssm_mean.assign(mean_rows, mean_rows + S);
+		for (int i = 1; i < n_distr; ++i) {
+			p.more_sigma.emplace_back(sigma_rows + 8 * i, sigma_rows + 8 * i + S);
+			p.more_mean.emplace_back(mean_rows + 8 * i, mean_rows + 8 * i + S);
+		}
+		p.update_distr_wts = update_distr_wts != 0; p.min_distr_wt = min_distr_wt;
+		p.adaptive_resampling_thresh = adaptive_resampling_thresh; p.jacobian_as_sigma = jacobian_as_sigma != 0;
+		if (device_filter) t->sm.reset(new hip::PF(t->am, t->ssm, p));
+		else t->sm.reset(new nt::PF(t->am, t->ssm, p));
+		return t;
+	} catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
 /* StateSpaceModel sampler virtuals through the base class (tests): n draws of compositionalRandomWalk from the current state */
 int mtfhost_ssm_random_walk(mtfhost_tracker *t, unsigned long long seed, int n, const double *sigma, double *out) {
 	try {

@@ -434,8 +434,23 @@ class ParticleFilter:
                  ssm_sigma=(0.01, 0.01, 2.0, 0.01, 0.01, 2.0, 1e-5, 1e-5), ssm_mean=(0.0,) * 8, likelihood_alpha=1.0,
                  max_iters=1, epsilon=0.01, seed=0, am=L.AM_SSD, dynamic_model=0, update_type=1, likelihood_func=0,
                  resampling_type=1, mean_type=0, corner_based_sampling=0, reset_to_mean=0, measurement_sigma=0.1, ar_coeff=0.5,
-                 comm=None, pt_based_sampling=0, n_channels=1):
+                 comm=None, pt_based_sampling=0, n_channels=1, adaptive_resampling_thresh=0.0, update_distr_wts=1, min_distr_wt=0.1,
+                 jacobian_as_sigma=0):
+        """ssm_sigma / ssm_mean: one row of up to 8 values, or several rows = several sampler distributions (PFParams::processDistributions:
+        the shipped Config/modules.cfg:157 uses five) whose weights follow the average particle weight each produced (update_distr_wts,
+        min_distr_wt: PF.cc:345-369); adaptive_resampling_thresh in (0, 1]: resample only when the effective particle count drops to
+        thresh * n (PF.cc:381-390); jacobian_as_sigma: the sampler's sigma of every frame is the Gauss-Newton step -H0^-1 g (PF.cc:58-64,
+        156-165, 214-227)"""
         import ctypes as C
+        rows_s = [list(ssm_sigma)] if np.ndim(ssm_sigma) == 1 else [list(r) for r in ssm_sigma]
+        rows_m = [list(ssm_mean)] if np.ndim(ssm_mean) == 1 else [list(r) for r in ssm_mean]
+        if jacobian_as_sigma:      # n_distr = 1 (PF.cc:62)
+            rows_s, rows_m = rows_s[:1], rows_m[:1]
+        n_distr = max(len(rows_s), len(rows_m))
+        while len(rows_s) < n_distr: rows_s.append(rows_s[-1])     # (PFParams.cc:131-166: the last sigma / mean row is reused)
+        while len(rows_m) < n_distr: rows_m.append(rows_m[-1])
+        ssm_sigma, ssm_mean = rows_s[0], rows_m[0]
+        self.jacobian_as_sigma = bool(jacobian_as_sigma)
         # n_channels = 3: MCSSD / MCNCC (the context then holds an H x W x 3 float32 frame)
         self.batch = Batch(ctx, am, ssm, resx, resy, 1, likelihood_alpha=likelihood_alpha, n_channels=n_channels)
         self.S, self.n = self.batch.S, n_particles
@@ -447,6 +462,10 @@ class ParticleFilter:
         # the reference seeds its generators from random_device (PF.cc:97-105): seed 0 = "draw one", anything else is reproducible
         self.desc.seed = int(seed) if seed else int.from_bytes(os.urandom(8), "little") | 1
         self.desc.pt_based_sampling = int(pt_based_sampling)
+        self.desc.adaptive_resampling_thresh = float(adaptive_resampling_thresh)
+        self.desc.update_distr_wts = int(update_distr_wts) if n_distr > 1 else 0     # (PF.cc:67)
+        self.desc.min_distr_wt = float(min_distr_wt)
+        self.n_distr = n_distr
         self._h = C.c_void_p()
         rc = L.lib().mtfhip_pf_create(self.batch._h, C.byref(self.desc), C.byref(self._h))
         if rc != 0:
@@ -454,6 +473,11 @@ class ParticleFilter:
             self.batch.close()
             L.check(rc)
         ctx._dependents.add(self)
+        if n_distr > 1:
+            sg, mn = np.zeros((n_distr, 8)), np.zeros((n_distr, 8))
+            for i in range(n_distr):
+                sg[i, :min(8, len(rows_s[i]))] = rows_s[i][:8]; mn[i, :min(8, len(rows_m[i]))] = rows_m[i][:8]
+            L.check(L.lib().mtfhip_pf_set_distributions(self._h, n_distr, sg.ctypes.data_as(C.c_void_p), mn.ctypes.data_as(C.c_void_p)))
         self.comm = comm
         if comm is not None:
             L.check(L.lib().mtfhip_pf_set_comm(self._h, comm._h))
@@ -485,7 +509,33 @@ class ParticleFilter:
         self.batch.set_corners(np.asarray(corners, dtype=np.float64).reshape(1, 2, 4))
         self.batch.initialize_pix_vals()
         self.batch.initialize_similarity()
+        if self.jacobian_as_sigma:   # PF.cc:156-165: d2f_dp2 = the self Hessian of the template's pixel Jacobian
+            b, additive = self.batch, self.desc.update_type == 0
+            b.initialize_grad()
+            b.initialize_pix_grad()
+            b.cmpt_pix_jacobian(L.JAC_PIX if additive else L.JAC_WARPED, L.BUF_DI0_DX, L.BUF_J0)
+            self._d2f_dp2 = b.cmpt_self_hessian(L.BUF_J0)[0]
         L.check(L.lib().mtfhip_pf_initialize(self._h))
+
+    def _jacobian_sigma(self):
+        """PF.cc:214-227: state_sigma[0] = -d2f_dp2.colPivHouseholderQr().solve(df_dp^T) on the current frame, then setSampler"""
+        import ctypes as C
+        b, additive = self.batch, self.desc.update_type == 0
+        b.update_pix_vals(); b.update_similarity(False); b.update_curr_grad(); b.update_pix_grad()
+        b.cmpt_pix_jacobian(L.JAC_PIX if additive else L.JAC_WARPED, L.BUF_DIT_DX, L.BUF_JT)
+        g = b.cmpt_curr_jacobian(L.BUF_JT)[0]
+        sigma = np.zeros(8); sigma[:self.S] = -np.linalg.solve(self._d2f_dp2, g)
+        mean = np.array([self.desc.ssm_mean[k] for k in range(8)])
+        L.check(L.lib().mtfhip_pf_set_sampler(self._h, sigma.ctypes.data_as(C.c_void_p), mean.ctypes.data_as(C.c_void_p)))
+        return sigma
+
+    def distributions(self):
+        """(distribution weights the next iteration draws from, distribution id of every particle of the last iteration, whether the
+        last iteration resampled)"""
+        import ctypes as C
+        w, ids, res = np.ones(self.n_distr), np.zeros(self.n, dtype=np.int32), C.c_int(1)
+        L.check(L.lib().mtfhip_pf_get_distributions(self._h, w.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p), C.byref(res)))
+        return w, ids, bool(res.value)
 
     def set_region(self, corners):
         c = self.batch._corners_in(np.asarray(corners, dtype=np.float64).reshape(1, 2, 4))
@@ -494,9 +544,13 @@ class ParticleFilter:
     def get_region(self):
         return self.batch.get_corners()
 
-    def iteration(self, normals=None, uniforms=None):
-        """one iteration of update()'s loop; normals (n, nz) / uniforms (n,) or None for the device generator"""
+    def iteration(self, normals=None, uniforms=None, distr_uniforms=None):
+        """one iteration of update()'s loop; normals (n, nz) / uniforms (n,) / distr_uniforms (n,: the distribution draws, several
+        sampler distributions only) or None for the device generator"""
         import ctypes as C
+        if distr_uniforms is not None:
+            du = np.ascontiguousarray(np.asarray(distr_uniforms, dtype=np.float64).reshape(self.n))
+            L.check(L.lib().mtfhip_pf_set_distr_draws(self._h, du.ctypes.data_as(C.c_void_p)))
         nz = None if normals is None else np.ascontiguousarray(np.asarray(normals, dtype=np.float64).reshape(self.n, self.nz))
         un = None if uniforms is None else np.ascontiguousarray(np.asarray(uniforms, dtype=np.float64).reshape(self.n))
         norm = C.c_double()
@@ -506,6 +560,8 @@ class ParticleFilter:
 
     def update(self):
         import ctypes as C
+        if self.jacobian_as_sigma:
+            self._jacobian_sigma()
         n = C.c_int()
         L.check(L.lib().mtfhip_pf_update(self._h, C.byref(n)))
         self.n_iters = n.value

@@ -2296,7 +2296,25 @@ int mtfo_pf_binary_multinomial_resample(const double *wts, int n, const double *
  * multinomial resampling.  states / ars: the particle set, replaced by the resampled one.  The SSM ends at the estimate. */
 int mtfo_pf_iteration(mtfo_am *am, mtfo_ssm *ssm, const mtfo_pf_params *pp, double *states, double *ars, const double *normals,
 	const double *uniforms, double max_similarity, double *wts_out, int *resample_ids, int *max_wt_id_out) {
+	return mtfo_pf_iteration_ex(am, ssm, pp, nullptr, states, ars, normals, uniforms, max_similarity, wts_out, resample_ids, max_wt_id_out);
+}
+/* the same with the options of the shipped configuration (Config/modules.cfg:157-176): several sampler distributions whose
+ * weights follow the average particle weight they produced (PF.cc:240-269, 345-369), adaptive resampling (PF.cc:114-118, 381-390).
+ * mx == NULL: one distribution (pp->sigma / pp->mean), resampling every iteration.
+ * The distribution of a particle is drawn from boost::random::discrete_distribution over distr_wts with its own generator
+ * (PF.cc:111, 241, 262: an alias table over random_device seeds -- not reproducible); here the draw is supplied as a uniform
+ * u in (0, 1] and inverted on the cumulative weights: the same distribution. */
+int mtfo_pf_iteration_ex(mtfo_am *am, mtfo_ssm *ssm, const mtfo_pf_params *pp, mtfo_pf_mix *mx, double *states, double *ars,
+	const double *normals, const double *uniforms, double max_similarity, double *wts_out, int *resample_ids, int *max_wt_id_out) {
 	const int n = pp->n_particles, S = ssm->S;
+	const int n_distr = mx ? mx->n_distr : 1;
+	if (n_distr < 1 || n_distr > 8) return -4;
+	/* n_distr == 1 switches update_distr_wts off (PF.cc:67); with several distributions and no update the reference zeroes the
+	 * weights and then builds a discrete distribution from zeros (PF.cc:254-257, 241): a division by zero, not restated */
+	if (n_distr > 1 && !mx->update_distr_wts) return -4;
+	vecd distr_sum(n_distr, 0.0), distr_cum(n_distr, 0.0);
+	std::vector<int> distr_cnt(n_distr, 0);
+	if (n_distr > 1) { double c = 0; for (int i = 0; i < n_distr; ++i) { c += mx->distr_wts[i]; distr_cum[i] = c; } }
 	const bool hom = ssm->kind == MTFO_SSM_HOMOGRAPHY;
 	const bool corner_based = hom && pp->corner_based_sampling;
 	const int pt_based = hom ? 0 : pp->pt_based_sampling;
@@ -2316,19 +2334,28 @@ int mtfo_pf_iteration(mtfo_am *am, mtfo_ssm *ssm, const mtfo_pf_params *pp, doub
 	for (int k = 0; k < n; ++k) {
 		const double *z = normals + static_cast<size_t>(k) * nz;
 		double *st = states + static_cast<size_t>(k) * S, *ar = ars + static_cast<size_t>(k) * S;
+		/* the particle's sampler distribution: PF.cc:261-269 (ssm->setSampler(state_sigma[distr_id], state_mean[distr_id])) */
+		const double *sg = pp->sigma, *mn = pp->mean;
+		int distr_id = 0;
+		if (n_distr > 1) {
+			const double tgt = mx->distr_uniforms[k] * distr_cum[n_distr - 1];
+			while (distr_id < n_distr - 1 && distr_cum[distr_id] < tgt) ++distr_id;
+			sg = mx->sigma[distr_id]; mn = mx->mean[distr_id];
+			if (mx->distr_ids_out) mx->distr_ids_out[k] = distr_id;
+		}
 		/* generatePerturbation: Homography.cc:899-915 / ProjectiveBase.cc:283-288 */
 		if (corner_based) {
 			double dc[8];
-			const double tx = pp->mean[0] + pp->sigma[0] * z[0], ty = pp->mean[0] + pp->sigma[0] * z[1];
+			const double tx = mn[0] + sg[0] * z[0], ty = mn[0] + sg[0] * z[1];
 			for (int c = 0; c < 4; ++c) {
-				dc[2 * c] = ssm->init_corners[2 * c] + (pp->mean[1] + pp->sigma[1] * z[2 + 2 * c]) + tx;
-				dc[2 * c + 1] = ssm->init_corners[2 * c + 1] + (pp->mean[1] + pp->sigma[1] * z[3 + 2 * c]) + ty;
+				dc[2 * c] = ssm->init_corners[2 * c] + (mn[1] + sg[1] * z[2 + 2 * c]) + tx;
+				dc[2 * c + 1] = ssm->init_corners[2 * c + 1] + (mn[1] + sg[1] * z[3 + 2 * c]) + ty;
 			}
 			ssm->estimate_warp_from_corners(pert.data(), ssm->init_corners.data(), dc);
 		} else if (!hom) {
-			ssm->affine_generate_perturbation(pert.data(), pt_based, pp->mean, pp->sigma, z);
+			ssm->affine_generate_perturbation(pert.data(), pt_based, mn, sg, z);
 		} else {
-			for (int s2 = 0; s2 < S; ++s2) pert[s2] = pp->mean[s2] + pp->sigma[s2] * z[s2];
+			for (int s2 = 0; s2 < S; ++s2) pert[s2] = mn[s2] + sg[s2] * z[s2];
 		}
 		/* dynamic model x update type: PF.cc:307-333 */
 		if (pp->dynamic_model == 1) {
@@ -2361,10 +2388,32 @@ int mtfo_pf_iteration(mtfo_am *am, mtfo_ssm *ssm, const mtfo_pf_params *pp, doub
 		else lik = 1.0 / (1.0 + val);
 		wts[k] = lik;
 		cum[k] = k == 0 ? lik : lik + cum[k - 1];
+		if (n_distr > 1) { distr_sum[distr_id] += lik; distr_cnt[distr_id] += 1; }   /* PF.cc:345-348 */
 		if (lik >= max_wt) { max_wt = lik; max_wt_id = k; }
 	}
 	if (wts_out) std::memcpy(wts_out, wts.data(), sizeof(double) * n);
-	if (pp->resampling_type == 1 || pp->resampling_type == 2) {   /* binary / linear multinomial: PF.cc:455-502, 505-536 */
+	if (n_distr > 1) {   /* PF.cc:354-369: average particle weight per distribution, normalised, floored at min_distr_wt */
+		double wt_sum = 0;
+		for (int i = 0; i < n_distr; ++i) {
+			mx->distr_wts[i] = distr_sum[i];
+			if (distr_cnt[i] > 0) { mx->distr_wts[i] /= distr_cnt[i]; wt_sum += mx->distr_wts[i]; }
+		}
+		for (int i = 0; i < n_distr; ++i) {
+			mx->distr_wts[i] /= wt_sum;
+			if (mx->distr_wts[i] < mx->min_distr_wt) mx->distr_wts[i] = mx->min_distr_wt;
+		}
+	}
+	bool perform_resampling = true;
+	if (mx && mx->adaptive_resampling_thresh > 0 && mx->adaptive_resampling_thresh <= 1) {   /* PF.cc:114-118, 381-390 */
+		double sq = 0;
+		for (int k = 0; k < n; ++k) { const double v = wts[k] / cum[n - 1]; sq += v * v; }
+		const double n_eff = sq == 0 ? 0 : 1.0 / sq;
+		if (n_eff > mx->adaptive_resampling_thresh * n) perform_resampling = false;
+	}
+	if (mx) mx->resampled = perform_resampling ? 1 : 0;
+	if (!perform_resampling) {
+		if (resample_ids) for (int k = 0; k < n; ++k) resample_ids[k] = k;
+	} else if (pp->resampling_type == 1 || pp->resampling_type == 2) {   /* binary / linear multinomial: PF.cc:455-502, 505-536 */
 		for (int k = 0; k < n; ++k) cum[k] /= cum[n - 1];
 		vecd ns2(static_cast<size_t>(n) * S), na2(static_cast<size_t>(n) * S);
 		max_wt = std::numeric_limits<double>::lowest();

@@ -196,7 +196,22 @@ typedef struct mtfo_pf_params {
 	double sigma[8], mean[8]; /* the sampler's normal distributions (ProjectiveBase::initializeSampler) */
 	int pt_based_sampling;    /* AffineParams::pt_based_sampling (Affine.cc:464-503): 0 geometric, 1, 2 */
 } mtfo_pf_params;
-/* returns 0; -2 unknown resampling type; -3 an Affine sampler combination the reference throws for, or the additive
+/* the options of the shipped configuration on top of mtfo_pf_params: several sampler distributions (n_distr <= 8; sigma[0] / mean[0]
+ * replace pp->sigma / pp->mean when n_distr > 1) with adaptive weights, and adaptive resampling */
+typedef struct mtfo_pf_mix {
+	int n_distr;
+	double sigma[8][8], mean[8][8];
+	int update_distr_wts;               /* PFParams::update_distr_wts */
+	double min_distr_wt;                /* PFParams::min_distr_wt */
+	double adaptive_resampling_thresh;  /* PFParams::adaptive_resampling_thresh: resample only when n_eff <= thresh * n */
+	double distr_wts[8];                /* in: the weights the distribution ids are drawn from; out: those of the next iteration */
+	const double *distr_uniforms;       /* [n] uniforms in (0, 1]: the distribution draw of every particle (n_distr > 1) */
+	int *distr_ids_out;                 /* [n] or NULL */
+	int resampled;                      /* out: 1 when this iteration resampled */
+} mtfo_pf_mix;
+int mtfo_pf_iteration_ex(mtfo_am *am, mtfo_ssm *ssm, const mtfo_pf_params *pp, mtfo_pf_mix *mx, double *states, double *ars,
+	const double *normals, const double *uniforms, double max_similarity, double *wts_out, int *resample_ids, int *max_wt_id_out);
+/* returns 0; -2 unknown resampling type; -4 an unsupported distribution setting; -3 an Affine sampler combination the reference throws for, or the additive
  * geometric one (Affine::stateToGeom: Eigen JacobiSVD conventions, not restated) */
 int mtfo_pf_iteration(mtfo_am *am, mtfo_ssm *ssm, const mtfo_pf_params *pp, double *states, double *ars, const double *normals,
 	const double *uniforms, double max_similarity, double *wts_out, int *resample_ids, int *max_wt_id_out);

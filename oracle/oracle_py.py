@@ -515,6 +515,50 @@ def pf_params(n_particles, dynamic_model=0, update_type=1, likelihood_func=0, re
     return pp
 
 
+class PFMix(C.Structure):
+    """mtfo_pf_mix: several sampler distributions with adaptive weights + adaptive resampling (PF.cc:240-269, 345-390)"""
+    _fields_ = [("n_distr", C.c_int), ("sigma", (C.c_double * 8) * 8), ("mean", (C.c_double * 8) * 8), ("update_distr_wts", C.c_int),
+                ("min_distr_wt", C.c_double), ("adaptive_resampling_thresh", C.c_double), ("distr_wts", C.c_double * 8),
+                ("distr_uniforms", C.POINTER(C.c_double)), ("distr_ids_out", C.POINTER(C.c_int)), ("resampled", C.c_int)]
+
+
+def pf_mix(sigmas, means=None, update_distr_wts=1, min_distr_wt=0.1, adaptive_resampling_thresh=0.0, distr_wts=None):
+    """sigmas: n_distr rows of up to 8 values (one row: a single distribution, only adaptive resampling is added)"""
+    sigmas = [list(r) for r in sigmas]
+    mx = PFMix()
+    mx.n_distr = len(sigmas)
+    for i, row in enumerate(sigmas):
+        for k in range(8):
+            mx.sigma[i][k] = float(row[k]) if k < len(row) else 0.0
+            mx.mean[i][k] = float(means[i][k]) if means is not None and k < len(means[i]) else 0.0
+    mx.update_distr_wts = int(update_distr_wts); mx.min_distr_wt = float(min_distr_wt)
+    mx.adaptive_resampling_thresh = float(adaptive_resampling_thresh)
+    for i in range(mx.n_distr):
+        mx.distr_wts[i] = float(distr_wts[i]) if distr_wts is not None else 1.0 / mx.n_distr   # initializeDistributions PF.cc:199-205
+    return mx
+
+
+def pf_iteration_ex(am, ssm, pp, mx, states, ars, normals, uniforms, max_similarity, distr_uniforms=None):
+    """pf_iteration with the mixture / adaptive-resampling options; returns additionally (distribution ids, the distribution weights of
+    the next iteration, whether the iteration resampled); mx.distr_wts is updated in place"""
+    states = np.ascontiguousarray(np.asarray(states, dtype=np.float64)).copy()
+    ars = np.ascontiguousarray(np.asarray(ars, dtype=np.float64)).copy()
+    normals = np.ascontiguousarray(np.asarray(normals, dtype=np.float64))
+    uniforms = _vec(uniforms)
+    n = pp.n_particles
+    du = _vec(distr_uniforms) if distr_uniforms is not None else np.ones(n)
+    dids = np.zeros(n, dtype=np.int32)
+    mx.distr_uniforms = du.ctypes.data_as(C.POINTER(C.c_double)); mx.distr_ids_out = dids.ctypes.data_as(C.POINTER(C.c_int))
+    wts = np.empty(n); ids = np.zeros(n, dtype=np.int32); mxid = C.c_int(0)
+    fn = lib().mtfo_pf_iteration_ex
+    fn.restype = C.c_int
+    rc = fn(am.h, ssm.h, C.byref(pp), C.byref(mx), _d(states), _d(ars), _d(normals), _d(uniforms), C.c_double(max_similarity),
+            _d(wts), ids.ctypes.data_as(_ip), C.byref(mxid))
+    if rc != 0:
+        raise NotImplementedError("mtfo_pf_iteration_ex: %d" % rc)
+    return states, ars, wts, ids, mxid.value, dids, np.array([mx.distr_wts[i] for i in range(mx.n_distr)]), bool(mx.resampled)
+
+
 def pf_iteration(am, ssm, pp, states, ars, normals, uniforms, max_similarity):
     """one iteration of nt::PF::update's loop (NT/PF.cc:260-447) with the draws supplied; returns
     (new states, new ars, weights before resampling, resample ids, max_wt_id); the SSM is left at the estimate"""

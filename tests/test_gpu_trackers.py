@@ -1080,3 +1080,121 @@ def test_pf_affine_sampler_refusals(gpu_ctx, frame, kw, msg):
     gpu_ctx.set_image(frame)
     with pytest.raises(L.FunctionNotImplemented, match=msg):
         ParticleFilter(gpu_ctx, L.SSM_AFFINE, 20, 20, n_particles=100, **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    dict(n_distr=5, thresh=0.2, resampling_type=1, corner_based=1, dynamic_model=1, mean_type=1),    # the shipped Config/modules.cfg:152-176 shape
+    dict(n_distr=3, thresh=0.0, resampling_type=2, corner_based=0, dynamic_model=0, mean_type=0),
+    dict(n_distr=1, thresh=0.33, resampling_type=1, corner_based=1, dynamic_model=0, mean_type=0, alpha=1.0),    # adaptive resampling alone
+    dict(n_distr=2, thresh=0.33, resampling_type=3, corner_based=1, dynamic_model=0, mean_type=2, alpha=1.0),    # residual resampling, obeying the verdict
+    dict(n_distr=4, thresh=0.0, resampling_type=0, corner_based=1, dynamic_model=0, mean_type=1),    # no resampling: the weights still adapt
+], ids=lambda c: "_".join("%s%s" % kv for kv in c.items()))
+def test_pf_distribution_mixture_and_adaptive_resampling(oracle, gpu_ctx, frame, cfg):
+    """Several sampler distributions whose weights follow the average particle weight each produced (PF.cc:240-269, 345-369) and
+    adaptive resampling (PF.cc:114-118, 381-390) -- the settings of the shipped modules.cfg -- on the device (the scan launch takes
+    the per-distribution sums and sum w^2, its last workgroup writes the next weights and the verdict, the selection pass obeys it)
+    against the oracle's restatement on shared draws: distribution ids, particle weights, the next distribution weights, whether the
+    iteration resampled, the particle set and the estimate, over five iterations."""
+    rng = np.random.default_rng(55)
+    n, res = 700, 24
+    centre = (250.0, 240.0)
+    corners = synth.square_corners(centre[0], centre[1], 80) + rng.uniform(-2, 2, size=(2, 4))
+    cb = cfg["corner_based"]
+    base = np.array([1.0, 0.6, 1, 1, 1, 1, 1, 1]) if cb else np.array([0.004, 0.004, 0.8, 0.004, 0.004, 0.8, 2e-6, 2e-6])
+    scales = [1.0, 3.0, 0.3, 6.0, 0.1][:cfg["n_distr"]]
+    sigmas = [list(base * s) for s in scales]
+    means = [[0.0] * 8 for _ in scales]
+    if len(scales) > 1:
+        means[1][0] = 0.3 if cb else 0.001       # a distribution with a non-zero mean
+    alpha = cfg.get("alpha", 5.0)
+    o_ssm = oracle.SSM(0, res, res); o_am = oracle.AM(L.AM_SSD, res, res, likelihood_alpha=alpha); o_am.set_curr_img(frame)
+    o_ssm.set_corners(corners); o_am.initialize_pix_vals(o_ssm.get("curr_pts")); o_am.initialize_similarity()
+    pp = oracle.pf_params(n, dynamic_model=cfg["dynamic_model"], update_type=1, resampling_type=cfg["resampling_type"], mean_type=cfg["mean_type"],
+                          corner_based_sampling=cb, sigma=sigmas[0], mean=means[0])
+    mx = oracle.pf_mix(sigmas, means, update_distr_wts=1, min_distr_wt=0.1, adaptive_resampling_thresh=cfg["thresh"])
+    gpu_ctx.set_image(frame)
+    pf = ParticleFilter(gpu_ctx, L.SSM_HOMOGRAPHY, res, res, n_particles=n, ssm_sigma=sigmas if len(sigmas) > 1 else sigmas[0],
+                        ssm_mean=means if len(means) > 1 else means[0], likelihood_alpha=alpha, dynamic_model=cfg["dynamic_model"], update_type=1,
+                        resampling_type=cfg["resampling_type"], mean_type=cfg["mean_type"], corner_based_sampling=cb,
+                        adaptive_resampling_thresh=cfg["thresh"], update_distr_wts=1, min_distr_wt=0.1)
+    pf.initialize(corners[None])
+    frame_b = synth.warp_frame(frame, np.array([0, 0, 1.2, 0, 0, -0.8, 0, 0]), centre)
+    o_am.set_curr_img(frame_b); gpu_ctx.set_image(frame_b)
+    st_o, ar_o = np.zeros((n, 8)), np.zeros((n, 8))
+    nz = 10 if cb else 8
+    seen = set()
+    for it in range(5):
+        normals, uniforms, du = rng.normal(size=(n, nz)), rng.uniform(size=n), rng.uniform(size=n)
+        st_o, ar_o, w_o, ids_o, mx_o, dids_o, dw_o, res_o = oracle.pf_iteration_ex(o_am, o_ssm, pp, mx, st_o, ar_o, normals, uniforms, pf.max_similarity, du)
+        pf.iteration(normals, uniforms, du)
+        st_d, ar_d, w_d, ids_d = pf.particles()
+        dw_d, dids_d, res_d = pf.distributions()
+        if cfg["n_distr"] > 1:
+            bad = np.nonzero(dids_d != dids_o)[0]     # a draw within rounding of a boundary of the running sums may fall either way
+            assert len(bad) <= 1, bad
+            np.testing.assert_allclose(dw_d, dw_o, rtol=1e-9 if len(bad) == 0 else 1e-2)
+        else:
+            bad = np.array([], dtype=int)
+        ok = np.ones(n, dtype=bool); ok[bad] = False
+        if cfg["resampling_type"] == 3 and res_o:
+            np.testing.assert_allclose(w_d[ok], (w_o / 1.0)[ok], rtol=1e-9, atol=1e-300)   # (normalised in place by both)
+        else:
+            np.testing.assert_allclose(w_d[ok], w_o[ok], rtol=1e-9, atol=1e-300)
+        assert res_d == (res_o and cfg["resampling_type"] != 0)
+        seen.add(res_d)
+        if len(bad) == 0:
+            if not res_d or cfg["resampling_type"] == 0:
+                assert np.array_equal(ids_d, np.arange(n)) or cfg["resampling_type"] == 0
+                same = np.ones(n, dtype=bool)
+            elif cfg["resampling_type"] == 3:
+                assert np.array_equal(ids_d, ids_o); same = np.ones(n, dtype=bool)
+            else:
+                cum = np.cumsum(w_o) / np.sum(w_o)
+                d = np.nonzero(ids_d != ids_o)[0]
+                assert all(abs(cum[min(ids_d[k], ids_o[k])] - uniforms[k]) < 1e-12 for k in d), d
+                same = ids_d == ids_o
+            np.testing.assert_allclose(st_d[same], st_o[same], rtol=1e-8, atol=1e-11)   # (five compositional steps without resampling let the rounding of the 3 x 3 products add up)
+            np.testing.assert_allclose(pf.get_region()[0], o_ssm.get("curr_corners").reshape(4, 2).T, rtol=0, atol=1e-7)
+        else:
+            break     # (the two filters have legitimately parted)
+    if cfg["thresh"] >= 0.3 and cfg["resampling_type"] != 0 and cfg["n_distr"] == 1:
+        assert seen == {True, False}, "the case is meant to see both verdicts of the adaptive test: %s" % seen
+    pf.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("update_type", [1, 0])
+def test_pf_jacobian_as_sigma(oracle, gpu_ctx, frame, update_type):
+    """jacobian_as_sigma (PF.cc:58-64, 156-165, 214-227): the sampler's sigma of every frame is the Gauss-Newton step
+    -d2f_dp2^-1 df_dp -- the self Hessian of the template's pixel Jacobian and the current Jacobian, through the per-function entry
+    points -- against the oracle's AM / SSM functions."""
+    res = 30
+    centre = (250.0, 240.0)
+    corners = synth.square_corners(centre[0], centre[1], 80)
+    frame_b = synth.warp_frame(frame, np.array([0, 0, 1.2, 0, 0, -0.8, 0, 0]), centre)
+    o_ssm = oracle.SSM(0, res, res); o_am = oracle.AM(L.AM_SSD, res, res); o_am.set_curr_img(frame)
+    o_ssm.set_corners(corners)
+    pts = o_ssm.get("curr_pts")
+    o_am.initialize_pix_vals(pts); o_am.initialize_similarity(); o_am.initialize_grad(); o_am.initialize_pix_grad_pts(pts)
+    jac = o_ssm.cmpt_pix_jacobian if update_type == 0 else o_ssm.cmpt_warped_pix_jacobian
+    H0 = o_am.cmpt_self_hessian(jac(o_am.get("dI0_dx")))
+    o_am.set_curr_img(frame_b)
+    o_am.update_pix_vals(pts); o_am.update_similarity(); o_am.update_curr_grad(); o_am.update_pix_grad_pts(pts)
+    g = o_am.cmpt_curr_jacobian(jac(o_am.get("dIt_dx")))
+    sigma_o = -np.linalg.solve(H0, g)
+    gpu_ctx.set_image(frame)
+    pf = ParticleFilter(gpu_ctx, L.SSM_HOMOGRAPHY, res, res, n_particles=300, likelihood_alpha=5.0, update_type=update_type, jacobian_as_sigma=1, seed=9,
+                        max_iters=2)
+    pf.initialize(corners[None])
+    # (the device lays out its own grid, 1e-13 px from the oracle's: the grad_eps = 1e-8 finite differences amplify that to ~1e-6 per
+    # gradient -- the reference's own noise floor, DESIGN.md section 2)
+    assert np.linalg.norm(pf._d2f_dp2 - H0) <= 1e-5 * np.linalg.norm(H0)
+    gpu_ctx.set_image(frame_b)
+    sigma_d = pf._jacobian_sigma()[:8]
+    assert np.linalg.norm(sigma_d - sigma_o) <= 1e-4 * np.linalg.norm(sigma_o)
+    # one Gauss-Newton step from the template: it points along the true motion (a translation of (1.2, -0.8)), if not at it
+    assert sigma_d[2] > 0.3 and sigma_d[5] < -0.2
+    out = pf.update()
+    assert np.all(np.isfinite(out))
+    pf.close()

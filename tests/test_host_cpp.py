@@ -255,6 +255,34 @@ def test_cpp_particle_filter(frame, device_filter, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("device_filter", [True, False])
+@pytest.mark.parametrize("opts", [dict(ssm_sigma=[(1.5, 0.2), (4.0, 0.6), (0.4, 0.1)], adaptive_resampling_thresh=0.2),     # the shipped modules.cfg shape
+                                  dict(ssm_sigma=(1.5, 0.2, 1, 1, 1, 1, 1, 1), jacobian_as_sigma=1, corner_based_sampling=0)],
+                         ids=["mixture_adaptive", "jacobian_as_sigma"])
+def test_cpp_particle_filter_shipped_options(frame, device_filter, opts):
+    """The options of the shipped Config/modules.cfg:157-176 through the C++ search methods -- several sampler distributions with
+    adaptive weights + adaptive resampling; jacobian_as_sigma (the sampler's sigma of every frame is the Gauss-Newton step, taken
+    through the AM / SSM virtuals and solved on the host) -- for mtf::hip::PF (device filter) and mtf::nt::PF (literal loop): both
+    follow a translation."""
+    from mtf_amd import host
+    centre = (256.0, 250.0)
+    corners = synth.square_corners(centre[0], centre[1], 80)
+    frame2 = synth.warp_frame(frame, np.array([0, 0, 3.0, 0, 0, -2.0, 0, 0]), centre)
+    kw = dict(resx=30, resy=30, n_particles=400 if device_filter else 150, max_iters=4, epsilon=1e-9, likelihood_alpha=5.0, corner_based_sampling=1, seed=5)
+    kw.update(opts)
+    pf = host.CppParticleFilter(device_filter, **kw)
+    pf.set_image(frame); pf.initialize(corners); pf.set_image(frame2)
+    out = pf.update()
+    gt = corners + np.array([[3.0], [-2.0]])
+    if opts.get("jacobian_as_sigma"):
+        # the sampler's "sigma" is then one Gauss-Newton step, projective components included: a wide cloud by construction (the value of
+        # the step itself is held to the oracle in test_pf_jacobian_as_sigma) -- here: the option runs through both search methods
+        assert np.all(np.isfinite(out)) and np.abs(out - gt).max() < 40
+    else:
+        assert np.abs(out - gt).max() < 1.5, np.abs(out - gt).max()
+
+
+@pytest.mark.gpu
 def test_cpp_ssm_sampler_virtuals(frame):
     """StateSpaceModel::initializeSampler / compositionalRandomWalk through the base class: draws are reproducible under a seed,
     and (direct sampling, identity base state) each state component is N(0, sigma_k)"""

@@ -427,3 +427,39 @@ def test_mi_update_noise_floor(oracle, frame):
     assert rel(a[0]["dp"], c[0]["dp"]) < 1e-7                                          # same route at identity
     floor = max(rel(a[1]["dp"], b[1]["dp"]), rel(a[1]["dp"], c[1]["dp"]))
     assert 5e-6 < floor < 2e-4, floor
+
+
+def test_pf_mixture_and_adaptive_resampling_properties(oracle, frame):
+    """The oracle's restatement of nt::PF with several sampler distributions and adaptive resampling (PF.cc:240-269, 345-390; the
+    shipped Config/modules.cfg:157-176): the next distribution weights are the normalised average particle weights floored at
+    min_distr_wt, the distribution ids follow the running sums of the previous weights, and an iteration whose effective particle
+    count exceeds thresh * n keeps its proposals (identity resample ids, weights untouched)."""
+    rng = np.random.default_rng(8)
+    n, res = 500, 16
+    corners = synth.square_corners(250.0, 240.0, 70)
+    ssm = oracle.SSM(0, res, res); am = oracle.AM(0, res, res, likelihood_alpha=1.0); am.set_curr_img(frame)
+    ssm.set_corners(corners); am.initialize_pix_vals(ssm.get("curr_pts")); am.initialize_similarity()
+    sig = [(1.0, 0.5), (3.0, 1.0), (0.3, 0.2)]
+    pp = oracle.pf_params(n, corner_based_sampling=1, sigma=sig[0] + (1,) * 6)
+    mx = oracle.pf_mix(sig, update_distr_wts=1, min_distr_wt=0.1, adaptive_resampling_thresh=0.35)
+    st, ar = np.zeros((n, 8)), np.zeros((n, 8))
+    verdicts = []
+    for it in range(6):
+        prev_w = np.array([mx.distr_wts[i] for i in range(3)])
+        du = rng.uniform(size=n)
+        st_in = st.copy()
+        st, ar, w, ids, mxid, dids, dw, resampled = oracle.pf_iteration_ex(am, ssm, pp, mx, st, ar, rng.normal(size=(n, 10)), rng.uniform(size=n), 0.0, du)
+        # ids: inversion of the draw on the running sums of the previous weights
+        cum = np.cumsum(prev_w)
+        want = np.minimum(np.searchsorted(cum, du * cum[-1], side="left"), 2)
+        assert np.array_equal(dids, want)
+        # next weights: average particle weight per distribution, normalised, floored
+        avg = np.array([w[dids == i].mean() if np.any(dids == i) else 0.0 for i in range(3)])
+        np.testing.assert_allclose(dw, np.maximum(avg / avg.sum(), 0.1), rtol=1e-12)
+        n_eff = 1.0 / np.sum((w / w.sum()) ** 2)
+        assert resampled == (not n_eff > 0.35 * n)
+        if not resampled:
+            assert np.array_equal(ids, np.arange(n))
+        verdicts.append(resampled)
+        assert w[mxid if not resampled else ids[mxid]] == w.max()
+    assert True in verdicts and False in verdicts
