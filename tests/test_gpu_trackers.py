@@ -914,6 +914,9 @@ def _run_ranks(world, fn):
     dict(corner_based_sampling=1, dynamic_model=0, update_type=1, mean_type=0, resampling_type=1),     # config 4
     dict(corner_based_sampling=1, dynamic_model=1, update_type=1, mean_type=1, resampling_type=2),     # shipped cfg: AR1, mean of states
     dict(corner_based_sampling=0, dynamic_model=0, update_type=0, mean_type=2, resampling_type=0, likelihood_func=2),
+    # the shipped modules.cfg shape: several sampler distributions with adaptive weights + adaptive resampling (replicated on every rank)
+    dict(corner_based_sampling=1, dynamic_model=1, update_type=1, mean_type=1, resampling_type=1, adaptive_resampling_thresh=0.3,
+         ssm_sigma=[(1.0, 0.6), (3.0, 1.2), (0.3, 0.2)], likelihood_alpha=1.0),
 ])
 def test_pf_sharded_loopback_equals_unsharded(frame, world, n, cfg):
     """The sharded filter as bench.py --workload pf --gpus N runs it -- mtfhip_pf_set_comm, block bounds with a ragged (or
@@ -925,7 +928,8 @@ def test_pf_sharded_loopback_equals_unsharded(frame, world, n, cfg):
     corners = synth.square_corners(250.0, 240.0, 80) + np.array([[0.3, -0.2, 0.1, 0.4], [0.2, 0.1, -0.3, 0.2]])
     sigma = (1.0, 0.6, 1, 1, 1, 1, 1, 1) if cfg["corner_based_sampling"] else (0.004, 0.004, 0.8, 0.004, 0.004, 0.8, 2e-6, 2e-6)
     frame_b = synth.warp_frame(frame, np.array([0, 0, 1.2, 0, 0, -0.8, 0, 0]), (250.0, 240.0))
-    kw = dict(n_particles=n, ssm_sigma=sigma, likelihood_alpha=5.0, seed=77, **cfg)
+    kw = dict(n_particles=n, ssm_sigma=sigma, likelihood_alpha=5.0, seed=77)
+    kw.update(cfg)
 
     def run(comm):
         ctx = mtf_amd.Context(0)
