@@ -195,6 +195,9 @@ int mtfhip_ssm_update_grad_pts(mtfhip_batch *b, double grad_eps);
  * grad_buf is MTFHIP_BUF_DI0_DX or _DIT_DX, dst_buf is MTFHIP_BUF_J0 / _JT / _JM */
 int mtfhip_ssm_cmpt_pix_jacobian(mtfhip_batch *b, int variant, int grad_buf, int dst_buf);
 int mtfhip_ssm_get_corners(mtfhip_batch *b, double *corners /* B x 8 */);
+/* StateSpaceModel::estimateStateSigma (StateSpaceModel.h:336-338; ProjectiveBase.cc:201-213): state_sigma[k] = pix_sigma / the mean
+ * over the sample points of |column k of dw/dp| -- nt::PF's pix_sigma -> sampler sigma (PF.cc:142-149) */
+int mtfhip_ssm_estimate_state_sigma(mtfhip_batch *b, double pix_sigma, double *state_sigma /* B x S */);
 int mtfhip_ssm_get_init_corners(mtfhip_batch *b, double *corners /* B x 8 */);
 int mtfhip_ssm_get_state(mtfhip_batch *b, double *states /* B x S */);
 int mtfhip_ssm_get_warp(mtfhip_batch *b, double *warps /* B x 9 row-major */);
@@ -326,7 +329,7 @@ int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int n
  * cumulative-weight launch also takes the per-distribution weight sums and sum w^2, its last workgroup derives the next iteration's
  * distribution weights and the verdict "this iteration resamples", the selection pass obeys it.  jacobian_as_sigma (PF.cc:58-64,
  * 156-165, 214-227) is host logic over entry points of this header: mtf_amd/sm.py ParticleFilter, mtf_amd/host/PF.cpp.
- * Not provided: pix_sigma (SSM::estimateStateSigma). */
+ * pix_sigma (PF.cc:142-149) likewise: mtfhip_ssm_estimate_state_sigma gives the sigma rows, the host installs them at initialize(). */
 typedef struct mtfhip_pf mtfhip_pf;
 typedef struct mtfhip_comm mtfhip_comm;
 typedef struct mtfhip_pf_desc {

@@ -100,7 +100,7 @@ SYMBOLS = [
     "mtfhip_batch_track_trace", "mtfhip_batch_track_trace_read", "mtfhip_image_preprocess_ex",
     "mtfhip_comm_unique_id", "mtfhip_comm_create", "mtfhip_comm_destroy", "mtfhip_comm_rank", "mtfhip_comm_world",
     "mtfhip_allgather_scores", "mtfhip_pf_set_comm",
-    "mtfhip_timing_enable", "mtfhip_timing_reset", "mtfhip_timing_get", "mtfhip_timing_get_busy", "mtfhip_batch_track_queues", "mtfhip_batch_inline_warp",
+    "mtfhip_timing_enable", "mtfhip_timing_reset", "mtfhip_timing_get", "mtfhip_timing_get_busy", "mtfhip_ssm_estimate_state_sigma", "mtfhip_batch_track_queues", "mtfhip_batch_inline_warp",
 ]
 
 
@@ -166,6 +166,7 @@ def lib():
         L.mtfhip_batch_write.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.mtfhip_timing_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.mtfhip_batch_inline_warp.argtypes = [C.c_void_p]
+        L.mtfhip_ssm_estimate_state_sigma.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
         L.mtfhip_pf_set_distributions.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.mtfhip_pf_set_distr_draws.argtypes = [C.c_void_p, C.c_void_p]
         L.mtfhip_pf_get_distributions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -258,6 +258,12 @@ class Batch:
         s = _f64(states).reshape(self.B, self.S)
         L.check(L.lib().mtfhip_ssm_set_state(self._h, _p(s)))
 
+    def estimate_state_sigma(self, pix_sigma):
+        """StateSpaceModel::estimateStateSigma (ProjectiveBase.cc:201-213): (B, S) sampler sigmas for a pixel sigma"""
+        out = np.empty((self.B, self.S))
+        L.check(L.lib().mtfhip_ssm_estimate_state_sigma(self._h, C.c_double(float(pix_sigma)), _p(out)))
+        return out
+
     def compositional_update(self, dps):
         s = _f64(dps).reshape(self.B, self.S)
         L.check(L.lib().mtfhip_ssm_compositional_update(self._h, _p(s)))

@@ -661,6 +661,41 @@ int mtfhip_ssm_get_corners(mtfhip_batch *b, double *corners) {
 	for (int t = 0; t < b->B; ++t) std::memcpy(corners + 8 * t, b->th[t].corners, sizeof(double) * 8);
 	return MTFHIP_OK;
 }
+/* ProjectiveBase::estimateStateSigma (SSM/src/ProjectiveBase.cc:201-213): state_sigma[k] = pix_sigma / mean over the points of the
+ * norm of column k of the 2 x S point Jacobian dw/dp (Homography::getCurrPixGrad Homography.cc:143-155, Affine::getInitPixGrad
+ * Affine.cc:152-158) -- how nt::PF turns pix_sigma into sampler sigmas (PF.cc:142-149).  Host arithmetic on the points read back. */
+int mtfhip_ssm_estimate_state_sigma(mtfhip_batch *b, double pix_sigma, double *state_sigma) {
+	if (!b || !state_sigma) return fail(MTFHIP_ERR_INVALID_ARG, "estimate_state_sigma: NULL argument");
+	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "estimate_state_sigma before set_corners");
+	FLUSH(b);
+	TRY(ensure_pts(b));
+	const size_t NP = (size_t)b->NP;
+	std::vector<double> ip(2 * NP * b->B), cp(2 * NP * b->B), cz(NP * b->B);
+	hipStream_t st = b->ctx->stream;
+	HIP_TRY(hipMemcpyAsync(ip.data(), b->buf[MTFHIP_BUF_INIT_PTS], sizeof(double) * ip.size(), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(cp.data(), b->buf[MTFHIP_BUF_CURR_PTS], sizeof(double) * cp.size(), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(cz.data(), b->buf[MTFHIP_BUF_CURR_Z], sizeof(double) * cz.size(), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	const bool hom = b->desc.ssm == MTFHIP_SSM_HOMOGRAPHY;
+	for (int t = 0; t < b->B; ++t) {
+		double mean[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		for (size_t i = 0; i < NP; ++i) {
+			const double x = ip[2 * (t * NP + i)], y = ip[2 * (t * NP + i) + 1];
+			double c0[8], c1[8];   /* the two rows of dw/dp */
+			if (hom) {
+				const double cx = cp[2 * (t * NP + i)], cy = cp[2 * (t * NP + i) + 1], inv_d = 1.0 / cz[t * NP + i];
+				const double r0[8] = {x, y, 1, 0, 0, 0, -x * cx, -y * cx}, r1[8] = {0, 0, 0, x, y, 1, -x * cy, -y * cy};
+				for (int k = 0; k < 8; ++k) { c0[k] = r0[k] * inv_d; c1[k] = r1[k] * inv_d; }
+			} else {
+				const double r0[8] = {1, 0, x, y, 0, 0, 0, 0}, r1[8] = {0, 1, 0, 0, x, y, 0, 0};
+				for (int k = 0; k < 8; ++k) { c0[k] = r0[k]; c1[k] = r1[k]; }
+			}
+			for (int k = 0; k < b->S; ++k) mean[k] += std::sqrt(c0[k] * c0[k] + c1[k] * c1[k]);
+		}
+		for (int k = 0; k < b->S; ++k) state_sigma[(size_t)t * b->S + k] = pix_sigma / (mean[k] / (double)NP);
+	}
+	return MTFHIP_OK;
+}
 int mtfhip_ssm_get_init_corners(mtfhip_batch *b, double *corners) {
 	if (!b || !corners) return fail(MTFHIP_ERR_INVALID_ARG, "get_init_corners: NULL argument");
 	for (int t = 0; t < b->B; ++t) std::memcpy(corners + 8 * t, b->th[t].init_corners, sizeof(double) * 8);

@@ -48,6 +48,8 @@ def lib():
         H.mtfhost_pf_create_ex.restype = C.c_void_p
         H.mtfhost_pf_create_ex.argtypes = [C.c_int] * 7 + [C.c_double] + [C.c_int] * 6 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double,
                                            C.c_int, C.c_double, C.c_ulonglong, C.c_int]
+        H.mtfhost_pf_create_pix.restype = C.c_void_p
+        H.mtfhost_pf_create_pix.argtypes = H.mtfhost_pf_create_ex.argtypes + [C.c_void_p]
         H.mtfhost_ssm_random_walk.argtypes = [C.c_void_p, C.c_ulonglong, C.c_int, C.c_void_p, C.c_void_p]
         H.mtfhost_ssm_pts_after_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _h = H
@@ -152,7 +154,7 @@ class CppParticleFilter(CppTracker):
     def __init__(self, device_filter=True, am=_lib.AM_SSD, ssm=_lib.SSM_HOMOGRAPHY, resx=50, resy=50, n_particles=500, max_iters=1,
                  epsilon=0.01, dynamic_model=0, update_type=1, likelihood_func=0, resampling_type=1, mean_type=0,
                  corner_based_sampling=1, ssm_sigma=(0.01, 0.01, 2.0, 0.01, 0.01, 2.0, 1e-5, 1e-5), likelihood_alpha=1.0, seed=1,
-                 device=0, ssm_mean=None, update_distr_wts=1, min_distr_wt=0.1, adaptive_resampling_thresh=0.0, jacobian_as_sigma=0):
+                 device=0, ssm_mean=None, update_distr_wts=1, min_distr_wt=0.1, adaptive_resampling_thresh=0.0, jacobian_as_sigma=0, pix_sigma=None):
         """ssm_sigma: one row, or several rows = several sampler distributions (PFParams::processDistributions)"""
         rows = [list(ssm_sigma)] if np.ndim(ssm_sigma) == 1 else [list(r) for r in ssm_sigma]
         mrows = [[0.0] * 8 for _ in rows] if ssm_mean is None else ([list(ssm_mean)] if np.ndim(ssm_mean) == 1 else [list(r) for r in ssm_mean])
@@ -160,10 +162,14 @@ class CppParticleFilter(CppTracker):
         sg = np.zeros((len(rows), 8)); mn = np.zeros((len(rows), 8))
         for i, r in enumerate(rows): sg[i, :min(8, len(r))] = r[:8]
         for i, r in enumerate(mrows[:len(rows)]): mn[i, :min(8, len(r))] = r[:8]
-        h = lib().mtfhost_pf_create_ex(int(bool(device_filter)), am, ssm, resx, resy, n_particles, max_iters, epsilon, dynamic_model,
-                                       update_type, likelihood_func, resampling_type, mean_type, int(bool(corner_based_sampling)),
-                                       len(rows), sg.ctypes.data_as(C.c_void_p), mn.ctypes.data_as(C.c_void_p), int(update_distr_wts),
-                                       float(min_distr_wt), float(adaptive_resampling_thresh), int(jacobian_as_sigma), likelihood_alpha, seed, device)
+        px = None if pix_sigma is None else np.ascontiguousarray(np.atleast_1d(np.asarray(pix_sigma, dtype=np.float64)))
+        if px is not None:
+            sg = np.ones((len(px), 8)); mn = np.zeros((len(px), 8))
+        h = lib().mtfhost_pf_create_pix(int(bool(device_filter)), am, ssm, resx, resy, n_particles, max_iters, epsilon, dynamic_model,
+                                        update_type, likelihood_func, resampling_type, mean_type, int(bool(corner_based_sampling)),
+                                        sg.shape[0], sg.ctypes.data_as(C.c_void_p), mn.ctypes.data_as(C.c_void_p), int(update_distr_wts),
+                                        float(min_distr_wt), float(adaptive_resampling_thresh), int(jacobian_as_sigma), likelihood_alpha, seed, device,
+                                        None if px is None else px.ctypes.data_as(C.c_void_p))
         if not h:
             raise HostError(lib().mtfhost_last_error().decode("utf-8", "replace"))
         self._h = C.c_void_p(h)

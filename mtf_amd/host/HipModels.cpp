@@ -328,6 +328,10 @@ void HipSSM::initializeSampler(const VectorXd &sg, const VectorXd &mn) {
 	}
 	sampler_ready = true;
 }
+void HipSSM::estimateStateSigma(VectorXd &state_sigma, double pix_sigma) {
+	state_sigma.resize(p->S);
+	HipPair::check(mtfhip_ssm_estimate_state_sigma(p->b, pix_sigma, state_sigma.data()));
+}
 void HipSSM::setSamplerSeed(unsigned long long seed) {
 	if (!sampler_ready) throw utils::LogicError("setSamplerSeed before initializeSampler");
 	for (int s = 0; s < p->S; ++s) { rng->gen[s].seed(seed * 1000003ULL + s); rng->dist[s].reset(); }

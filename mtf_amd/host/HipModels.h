@@ -180,6 +180,7 @@ public:
 	 * of an iteration in one launch instead.  The reference draws from boost::mt11213b seeded by random_device; here
 	 * std::mt19937_64, seeded the same way unless setSamplerSeed() fixes it. */
 	void initializeSampler(const VectorXd &state_sigma, const VectorXd &state_mean) override;
+	void estimateStateSigma(VectorXd &state_sigma, double pix_sigma) override;   /* ProjectiveBase.cc:201-213 */
 	void setSampler(const VectorXd &state_sigma, const VectorXd &state_mean) override;
 	void setSamplerMean(const VectorXd &mean) override;
 	void setSamplerSigma(const VectorXd &sigma) override;

@@ -16,6 +16,9 @@ PF::PF(AM a, SSM s, const PFParams &pp) : SearchMethod(a, s, SMParams()), pf(pp)
 	std::vector<std::vector<double>> sg{pf.ssm_sigma}, mn{pf.ssm_mean.empty() ? std::vector<double>(1, 0.0) : pf.ssm_mean};
 	for (const auto &r : pf.more_sigma) sg.push_back(r);
 	for (const auto &r : pf.more_mean) mn.push_back(r);
+	using_pix_sigma = !pf.pix_sigma.empty() && pf.pix_sigma[0] > 0;   /* PFParams.cc:105-116 */
+	if (using_pix_sigma) { sg.assign(pf.pix_sigma.size(), std::vector<double>(1, 1.0)); mn.assign(pf.pix_sigma.size(), std::vector<double>(1, 0.0)); }
+	if (pf.jacobian_as_sigma) using_pix_sigma = false;   /* PF.cc:58-64 */
 	n_distr = pf.jacobian_as_sigma ? 1 : (int)std::max(sg.size(), mn.size());   /* PF.cc:58-63 */
 	state_sigma.assign(n_distr, VectorXd(S)); state_mean.assign(n_distr, VectorXd(S));
 	for (int i = 0; i < n_distr; ++i) {
@@ -70,6 +73,8 @@ void PF::jacobianSigma(bool init) {
 void PF::initialize(const CornersT &corners) {   /* :136-183 */
 	am->clearInitStatus(); ssm->clearInitStatus();
 	ssm->initialize(corners, am->getNChannels());
+	if (using_pix_sigma)   /* :142-149 */
+		for (int i = 0; i < n_distr; ++i) { state_mean[i].fill(0.0); ssm->estimateStateSigma(state_sigma[i], pf.pix_sigma[i]); }
 	ssm->initializeSampler(state_sigma[0], state_mean[0]);
 	am->initializePixVals(ssm->getPts());
 	am->initializeSimilarity();
@@ -233,6 +238,8 @@ PF::PF(std::shared_ptr<HipAM> a, std::shared_ptr<HipSSM> s, const PFParams &pp) 
 	std::vector<std::vector<double>> sg{pf.ssm_sigma}, mn{pf.ssm_mean.empty() ? std::vector<double>(1, 0.0) : pf.ssm_mean};
 	for (const auto &r : pf.more_sigma) sg.push_back(r);
 	for (const auto &r : pf.more_mean) mn.push_back(r);
+	const bool pix = !pf.jacobian_as_sigma && !pf.pix_sigma.empty() && pf.pix_sigma[0] > 0;   /* sigmas estimated at initialize() */
+	if (pix) { sg.assign(pf.pix_sigma.size(), std::vector<double>(1, 1.0)); mn.assign(pf.pix_sigma.size(), std::vector<double>(1, 0.0)); }
 	const int n_distr = pf.jacobian_as_sigma ? 1 : (int)std::max(sg.size(), mn.size());
 	d.adaptive_resampling_thresh = pf.adaptive_resampling_thresh;
 	d.update_distr_wts = (n_distr > 1 && pf.update_distr_wts) ? 1 : 0;
@@ -280,6 +287,14 @@ void PF::initialize(const CornersT &corners) {   /* NT/PF.cc:136-183 */
 	ssm->initialize(corners, am->getNChannels());
 	am->initializePixVals(ssm->getPts());
 	am->initializeSimilarity();
+	if (!pf.jacobian_as_sigma && !pf.pix_sigma.empty() && pf.pix_sigma[0] > 0) {   /* NT/PF.cc:142-149 */
+		const int n_distr = (int)pf.pix_sigma.size(), S = ssm_state_size;
+		std::vector<double> fs(8 * (size_t)n_distr, 0.0), fm(8 * (size_t)n_distr, 0.0);
+		VectorXd sg;
+		for (int i = 0; i < n_distr; ++i) { ssm->estimateStateSigma(sg, pf.pix_sigma[i]); for (int k = 0; k < S; ++k) fs[8 * i + k] = sg[k]; }
+		if (n_distr > 1) HipPair::check(mtfhip_pf_set_distributions(h, n_distr, fs.data(), fm.data()));
+		else HipPair::check(mtfhip_pf_set_sampler(h, fs.data(), fm.data()));
+	}
 	if (pf.jacobian_as_sigma) jacobianSigma(true);
 	HipPair::check(mtfhip_pf_initialize(h));
 }

@@ -38,6 +38,8 @@ struct PFParams {
 	/* further sampler distributions (PFParams::processDistributions, PFParams.cc:101-170: the shipped Config/modules.cfg:157 names
 	 * five): with any, every particle draws its distribution from weights that follow the average particle weight each produced */
 	std::vector<std::vector<double>> more_sigma, more_mean;
+	std::vector<double> pix_sigma;             /* with pix_sigma[0] > 0: one sampler distribution per entry, its state sigma estimated by the
+	                                              SSM at initialize() (PFParams.cc:105-116, PF.cc:142-149); ssm_sigma is then not used */
 	bool update_distr_wts = false;             /* PFParams.h: update_distr_wts; switched off for a single distribution (PF.cc:67) */
 	double min_distr_wt = 0.5;
 	double adaptive_resampling_thresh = 0;     /* in (0, 1]: resample only when the effective particle count is <= thresh * n (PF.cc:381-390) */
@@ -63,6 +65,7 @@ protected:
 	VectorXd particle_wts, particle_cum_wts, perturbed_state, perturbed_ar, mean_state;
 	std::vector<VectorXd> state_sigma, state_mean;   /* [n_distr] */
 	int n_distr = 1;
+	bool using_pix_sigma = false;
 	std::vector<double> distr_wts;
 	std::vector<int> distr_n_particles, particle_distr;
 	std::mt19937_64 distr_id_gen;

@@ -141,10 +141,23 @@ mtfhost_tracker *mtfhost_pf_create(int device_filter, int am, int ssm, int resx,
 }
 /* the same with the options of the shipped configuration: n_distr >= 1 sampler distributions (rows of 8), adaptive resampling,
  * jacobian_as_sigma (PFParams.h; Config/modules.cfg:157-176) */
+/* pix_sigma != NULL: n_distr values, the sigma rows are then estimated at initialize() (PFParams.cc:105-116) */
+mtfhost_tracker *mtfhost_pf_create_pix(int device_filter, int am, int ssm, int resx, int resy, int n_particles, int max_iters, double epsilon,
+	int dynamic_model, int update_type, int likelihood_func, int resampling_type, int mean_type, int corner_based_sampling,
+	int n_distr, const double *sigma_rows, const double *mean_rows, int update_distr_wts, double min_distr_wt, double adaptive_resampling_thresh,
+	int jacobian_as_sigma, double likelihood_alpha, unsigned long long seed, int device, const double *pix_sigma);
 mtfhost_tracker *mtfhost_pf_create_ex(int device_filter, int am, int ssm, int resx, int resy, int n_particles, int max_iters, double epsilon,
 	int dynamic_model, int update_type, int likelihood_func, int resampling_type, int mean_type, int corner_based_sampling,
 	int n_distr, const double *sigma_rows, const double *mean_rows, int update_distr_wts, double min_distr_wt, double adaptive_resampling_thresh,
 	int jacobian_as_sigma, double likelihood_alpha, unsigned long long seed, int device) {
+	return mtfhost_pf_create_pix(device_filter, am, ssm, resx, resy, n_particles, max_iters, epsilon, dynamic_model, update_type, likelihood_func,
+		resampling_type, mean_type, corner_based_sampling, n_distr, sigma_rows, mean_rows, update_distr_wts, min_distr_wt, adaptive_resampling_thresh,
+		jacobian_as_sigma, likelihood_alpha, seed, device, nullptr);
+}
+mtfhost_tracker *mtfhost_pf_create_pix(int device_filter, int am, int ssm, int resx, int resy, int n_particles, int max_iters, double epsilon,
+	int dynamic_model, int update_type, int likelihood_func, int resampling_type, int mean_type, int corner_based_sampling,
+	int n_distr, const double *sigma_rows, const double *mean_rows, int update_distr_wts, double min_distr_wt, double adaptive_resampling_thresh,
+	int jacobian_as_sigma, double likelihood_alpha, unsigned long long seed, int device, const double *pix_sigma) {
 	try {
 		if (n_distr < 1) throw utils::InvalidArgument("mtfhost_pf_create_ex: n_distr must be positive");
 		auto *t = new mtfhost_tracker();
@@ -164,6 +177,7 @@ mtfhost_tracker *mtfhost_pf_create_ex(int device_filter, int am, int ssm, int re
 			p.more_sigma.emplace_back(sigma_rows + 8 * i, sigma_rows + 8 * i + S);
 			p.more_mean.emplace_back(mean_rows + 8 * i, mean_rows + 8 * i + S);
 		}
+		if (pix_sigma) p.pix_sigma.assign(pix_sigma, pix_sigma + n_distr);
 		p.update_distr_wts = update_distr_wts != 0; p.min_distr_wt = min_distr_wt;
 		p.adaptive_resampling_thresh = adaptive_resampling_thresh; p.jacobian_as_sigma = jacobian_as_sigma != 0;
 		if (device_filter) t->sm.reset(new hip::PF(t->am, t->ssm, p));

@@ -435,8 +435,10 @@ class ParticleFilter:
                  max_iters=1, epsilon=0.01, seed=0, am=L.AM_SSD, dynamic_model=0, update_type=1, likelihood_func=0,
                  resampling_type=1, mean_type=0, corner_based_sampling=0, reset_to_mean=0, measurement_sigma=0.1, ar_coeff=0.5,
                  comm=None, pt_based_sampling=0, n_channels=1, adaptive_resampling_thresh=0.0, update_distr_wts=1, min_distr_wt=0.1,
-                 jacobian_as_sigma=0):
-        """ssm_sigma / ssm_mean: one row of up to 8 values, or several rows = several sampler distributions (PFParams::processDistributions:
+                 jacobian_as_sigma=0, pix_sigma=None):
+        """pix_sigma: one value per sampler distribution; with pix_sigma[0] > 0 the sampler sigmas are estimated from them at
+        initialize() (PFParams::processDistributions PFParams.cc:105-116, PF.cc:142-149: SSM::estimateStateSigma) and ssm_sigma is ignored.
+        ssm_sigma / ssm_mean: one row of up to 8 values, or several rows = several sampler distributions (PFParams::processDistributions:
         the shipped Config/modules.cfg:157 uses five) whose weights follow the average particle weight each produced (update_distr_wts,
         min_distr_wt: PF.cc:345-369); adaptive_resampling_thresh in (0, 1]: resample only when the effective particle count drops to
         thresh * n (PF.cc:381-390); jacobian_as_sigma: the sampler's sigma of every frame is the Gauss-Newton step -H0^-1 g (PF.cc:58-64,
@@ -444,6 +446,11 @@ class ParticleFilter:
         import ctypes as C
         rows_s = [list(ssm_sigma)] if np.ndim(ssm_sigma) == 1 else [list(r) for r in ssm_sigma]
         rows_m = [list(ssm_mean)] if np.ndim(ssm_mean) == 1 else [list(r) for r in ssm_mean]
+        self.pix_sigma = None
+        if pix_sigma is not None and len(np.atleast_1d(pix_sigma)) and float(np.atleast_1d(pix_sigma)[0]) > 0:
+            self.pix_sigma = [float(v) for v in np.atleast_1d(pix_sigma)]
+            rows_s = [[1.0] * 8 for _ in self.pix_sigma]       # placeholders until initialize() knows the points
+            rows_m = [[0.0] * 8 for _ in self.pix_sigma]
         if jacobian_as_sigma:      # n_distr = 1 (PF.cc:62)
             rows_s, rows_m = rows_s[:1], rows_m[:1]
         n_distr = max(len(rows_s), len(rows_m))
@@ -509,6 +516,16 @@ class ParticleFilter:
         self.batch.set_corners(np.asarray(corners, dtype=np.float64).reshape(1, 2, 4))
         self.batch.initialize_pix_vals()
         self.batch.initialize_similarity()
+        if self.pix_sigma is not None:   # PF.cc:142-149: one estimated sigma row per distribution, zero means
+            import ctypes as C
+            sg = np.zeros((self.n_distr, 8)); mn = np.zeros((self.n_distr, 8))
+            for i in range(self.n_distr):
+                sg[i, :self.S] = self.batch.estimate_state_sigma(self.pix_sigma[i])[0]
+            if self.n_distr > 1:
+                L.check(L.lib().mtfhip_pf_set_distributions(self._h, self.n_distr, sg.ctypes.data_as(C.c_void_p), mn.ctypes.data_as(C.c_void_p)))
+            else:
+                L.check(L.lib().mtfhip_pf_set_sampler(self._h, sg[0].ctypes.data_as(C.c_void_p), mn[0].ctypes.data_as(C.c_void_p)))
+            self.state_sigma = sg
         if self.jacobian_as_sigma:   # PF.cc:156-165: d2f_dp2 = the self Hessian of the template's pixel Jacobian
             b, additive = self.batch, self.desc.update_type == 0
             b.initialize_grad()

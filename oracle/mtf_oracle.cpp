@@ -2134,6 +2134,26 @@ int mtfo_ssm_state_size(const mtfo_ssm *s) { return s->S; }
 int mtfo_ssm_n_pts(const mtfo_ssm *s) { return s->n; }
 void mtfo_ssm_set_corners(mtfo_ssm *s, const double *c) { s->set_corners(c); }
 void mtfo_ssm_set_state(mtfo_ssm *s, const double *p) { s->set_state(p); }
+/* ProjectiveBase::estimateStateSigma SSM/src/ProjectiveBase.cc:201-213 with Homography::getCurrPixGrad (Homography.cc:143-155) /
+ * Affine::getCurrPixGrad = getInitPixGrad (Affine.h:30-32, Affine.cc:152-158) */
+void mtfo_ssm_estimate_state_sigma(mtfo_ssm *s, double pix_sigma, double *state_sigma) {
+	const int n = s->n, S = s->S;
+	vecd mean(S, 0.0);
+	for (int i = 0; i < n; ++i) {
+		const double x = s->init_pts[2 * i], y = s->init_pts[2 * i + 1];
+		double g[2][8] = {{0}};
+		if (s->kind == MTFO_SSM_HOMOGRAPHY) {
+			const double cx = s->curr_pts[2 * i], cy = s->curr_pts[2 * i + 1], inv_d = 1.0 / s->curr_pts_hm[3 * i + 2];
+			const double r0[8] = {x, y, 1, 0, 0, 0, -x * cx, -y * cx}, r1[8] = {0, 0, 0, x, y, 1, -x * cy, -y * cy};
+			for (int k = 0; k < 8; ++k) { g[0][k] = r0[k] * inv_d; g[1][k] = r1[k] * inv_d; }
+		} else {
+			const double r0[6] = {1, 0, x, y, 0, 0}, r1[6] = {0, 1, 0, 0, x, y};
+			for (int k = 0; k < 6; ++k) { g[0][k] = r0[k]; g[1][k] = r1[k]; }
+		}
+		for (int k = 0; k < S; ++k) mean[k] += std::sqrt(g[0][k] * g[0][k] + g[1][k] * g[1][k]);
+	}
+	for (int k = 0; k < S; ++k) state_sigma[k] = pix_sigma / (mean[k] / n);
+}
 void mtfo_ssm_compositional_update(mtfo_ssm *s, const double *dp) { s->compositional_update(dp); }
 void mtfo_ssm_invert_state(mtfo_ssm *s, double *inv, const double *p) { s->invert_state(inv, p); }
 void mtfo_ssm_update_grad_pts(mtfo_ssm *s, double eps) { s->update_grad_pts(eps); }

@@ -66,6 +66,7 @@ int mtfo_ssm_state_size(const mtfo_ssm *s);
 int mtfo_ssm_n_pts(const mtfo_ssm *s);
 void mtfo_ssm_set_corners(mtfo_ssm *s, const double *corners);
 void mtfo_ssm_set_state(mtfo_ssm *s, const double *state);
+void mtfo_ssm_estimate_state_sigma(mtfo_ssm *s, double pix_sigma, double *state_sigma /* S */);
 void mtfo_ssm_compositional_update(mtfo_ssm *s, const double *state_update);
 void mtfo_ssm_invert_state(mtfo_ssm *s, double *inv_state, const double *state);
 void mtfo_ssm_update_grad_pts(mtfo_ssm *s, double grad_eps);

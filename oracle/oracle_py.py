@@ -175,6 +175,11 @@ class SSM:
         p = _vec(p)
         lib().mtfo_ssm_set_state(self.h, _d(p))
 
+    def estimate_state_sigma(self, pix_sigma):
+        out = np.empty(self.S)
+        lib().mtfo_ssm_estimate_state_sigma(self.h, C.c_double(float(pix_sigma)), _d(out))
+        return out
+
     def compositional_update(self, dp):
         dp = _vec(dp)
         lib().mtfo_ssm_compositional_update(self.h, _d(dp))

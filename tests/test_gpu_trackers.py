@@ -1202,3 +1202,35 @@ def test_pf_jacobian_as_sigma(oracle, gpu_ctx, frame, update_type):
     out = pf.update()
     assert np.all(np.isfinite(out))
     pf.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ssm", [L.SSM_HOMOGRAPHY, L.SSM_AFFINE])
+def test_estimate_state_sigma_and_pix_sigma_filter(oracle, gpu_ctx, frame, ssm):
+    """StateSpaceModel::estimateStateSigma (ProjectiveBase.cc:201-213: pix_sigma over the mean column norms of dw/dp) against the
+    oracle, at the initial region and after a state change; and nt::PF's pix_sigma route (PFParams.cc:105-116, PF.cc:142-149): one
+    estimated sigma row per distribution."""
+    res = 24
+    corners = synth.square_corners(250.0, 240.0, 80) + np.array([[0.5, -1.0, 2.0, 0.3], [1.0, 0.2, -0.4, 0.9]])
+    o_ssm = oracle.SSM(ssm, res, res); o_ssm.set_corners(corners)
+    gpu_ctx.set_image(frame)
+    b = mtf_amd.Batch(gpu_ctx, L.AM_SSD, ssm, res, res, 1)
+    b.set_corners(corners[None])
+    np.testing.assert_allclose(b.estimate_state_sigma(0.5)[0], o_ssm.estimate_state_sigma(0.5), rtol=1e-9)
+    p = (np.array([0.01, -0.02, 1.5, 0.015, 0.01, -2.0, 2e-5, -1e-5]) if ssm == L.SSM_HOMOGRAPHY else np.array([1.5, -2.0, 0.01, -0.02, 0.015, 0.01]))
+    b.set_state(p[None]); o_ssm.set_state(p)
+    np.testing.assert_allclose(b.estimate_state_sigma(2.0)[0], o_ssm.estimate_state_sigma(2.0), rtol=1e-9)
+    b.close()
+    if ssm == L.SSM_HOMOGRAPHY:
+        pf = ParticleFilter(gpu_ctx, ssm, res, res, n_particles=500, pix_sigma=(0.5, 2.0), likelihood_alpha=5.0, corner_based_sampling=0, seed=3,
+                            update_distr_wts=1)
+        pf.initialize(corners[None])
+        o2 = oracle.SSM(ssm, res, res); o2.set_corners(corners)
+        np.testing.assert_allclose(pf.state_sigma[0, :8], o2.estimate_state_sigma(0.5), rtol=1e-9)
+        np.testing.assert_allclose(pf.state_sigma[1, :8], o2.estimate_state_sigma(2.0), rtol=1e-9)
+        gpu_ctx.set_image(synth.warp_frame(frame, np.array([0, 0, 1.0, 0, 0, -0.6, 0, 0]), (250.0, 240.0)))
+        pf.iteration()
+        st, ar, w, ids = pf.particles()
+        dw, dids, res_d = pf.distributions()
+        assert set(np.unique(dids)) == {0, 1} and np.all(np.isfinite(st)) and abs(dw.sum() - 1.0) < 0.2
+        pf.close()

@@ -257,8 +257,9 @@ def test_cpp_particle_filter(frame, device_filter, n):
 @pytest.mark.gpu
 @pytest.mark.parametrize("device_filter", [True, False])
 @pytest.mark.parametrize("opts", [dict(ssm_sigma=[(1.5, 0.2), (4.0, 0.6), (0.4, 0.1)], adaptive_resampling_thresh=0.2),     # the shipped modules.cfg shape
-                                  dict(ssm_sigma=(1.5, 0.2, 1, 1, 1, 1, 1, 1), jacobian_as_sigma=1, corner_based_sampling=0)],
-                         ids=["mixture_adaptive", "jacobian_as_sigma"])
+                                  dict(ssm_sigma=(1.5, 0.2, 1, 1, 1, 1, 1, 1), jacobian_as_sigma=1, corner_based_sampling=0),
+                                  dict(pix_sigma=(0.6, 2.0), corner_based_sampling=0)],    # sigmas from StateSpaceModel::estimateStateSigma
+                         ids=["mixture_adaptive", "jacobian_as_sigma", "pix_sigma"])
 def test_cpp_particle_filter_shipped_options(frame, device_filter, opts):
     """The options of the shipped Config/modules.cfg:157-176 through the C++ search methods -- several sampler distributions with
     adaptive weights + adaptive resampling; jacobian_as_sigma (the sampler's sigma of every frame is the Gauss-Newton step, taken
@@ -278,6 +279,8 @@ def test_cpp_particle_filter_shipped_options(frame, device_filter, opts):
         # the sampler's "sigma" is then one Gauss-Newton step, projective components included: a wide cloud by construction (the value of
         # the step itself is held to the oracle in test_pf_jacobian_as_sigma) -- here: the option runs through both search methods
         assert np.all(np.isfinite(out)) and np.abs(out - gt).max() < 40
+    elif "pix_sigma" in opts:
+        assert np.abs(out - gt).max() < 3.0, np.abs(out - gt).max()   # an 8-dof direct-sampling cloud: coarser than the corner-based one
     else:
         assert np.abs(out - gt).max() < 1.5, np.abs(out - gt).max()
 
