@@ -109,6 +109,9 @@ struct MiPassArgs {
 #endif
 constexpr int kQR = MTFHIP_MI_QR;     /* row stride (doubles) of a wave's absolute table Q[r][c][s]: 64 = dense */
 constexpr int kRS2 = MTFHIP_MI_RS2;   /* slot-major row stride: >= 64 + 8 * 3 padded slots; 100 = 4 mod 32 keeps 4 rows x 4 slots on 16 banks */
+__device__ __forceinline__ void lds_add_f64(double *p, double v) {
+	(void)__builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)p, v);
+}
 struct ClassSort { int slot; unsigned long long ends; int total; };   /* ends: byte c = end slot of class c (<= 88) */
 __device__ __forceinline__ ClassSort class_sort8(int key /* 0..7, or negative: not placed */) {
 	ClassSort cs;
@@ -196,6 +199,17 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 		const unsigned i = base + lane;
 		const double vm = i < N ? 1.0 : 0.0;   /* lanes behind the end of the patch contribute zeros */
 		const double2 pxy = p_cur; const double z = z_cur, i0 = i0_cur, g0x = g0x_cur, g0y = g0y_cur;
+		/* the template's row when it is read back (j0_mode 2): requested FIRST, so that the wait in front of its use leaves the
+		 * texel fetch of the next chunk and the operand prefetch behind it in flight (vmcnt counts in order; requested where it
+		 * is used, the wait was vmcnt(0) -- and because the two forms share registers, the rebuilt form waited as well) */
+		double j0[8];
+#pragma unroll
+		for (int s = 0; s < 8; ++s) j0[s] = 0.0;
+		if (pa.j0_mode == 2) {
+			const unsigned ic = min(i, N - 1);
+#pragma unroll
+			for (int s = 0; s < S; ++s) j0[s] = ld_off<double>(J0 + (size_t)s * N, ic * 8u);
+		}
 		const MiTex tx_nx = mi_issue<SSM, true, MC>(im, W, q_nx.x, q_nx.y, z_nx, uz, pa.grad_eps, Cc, ch_nx);
 		const unsigned ch_here = ch_cur;
 		ch_cur = ch_nx;
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 		tx_cur = tx_nx;
 		const double x = pxy.x, y = pxy.y;
 		/* steepest-descent row of the pixel (Homography.cc:252-289, Affine.cc:213-242) */
-		double jt[8], j0[8];
+		double jt[8];
 		if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
 			const double dwx_dx = fma(-W.m[6], sp.wx, W.m[0]), dwx_dy = fma(-W.m[7], sp.wx, W.m[1]);
 			const double dwy_dx = fma(-W.m[6], sp.wy, W.m[3]), dwy_dy = fma(-W.m[7], sp.wy, W.m[4]);
@@ -215,8 +229,6 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 			jt[0] = Ix; jt[1] = Iy; jt[2] = Ix * x; jt[3] = Ix * y; jt[4] = Iy * x; jt[5] = Iy * y; jt[6] = jt[7] = 0.0;
 		}
 		/* the template's row: rebuilt from dI0_dx as the fused LK kernel does, or read back */
-#pragma unroll
-		for (int s = 0; s < 8; ++s) j0[s] = 0.0;
 		if (pa.j0_mode == 1) {
 			if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
 				const double inv0 = (pa.j0_init_variant || uz) ? 1.0 : 1.0 / z;
@@ -224,10 +236,6 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 			} else {
 				j0[0] = g0x; j0[1] = g0y; j0[2] = g0x * x; j0[3] = g0x * y; j0[4] = g0y * x; j0[5] = g0y * y;
 			}
-		} else if (pa.j0_mode == 2) {
-			const unsigned ic = min(i, N - 1);
-#pragma unroll
-			for (int s = 0; s < S; ++s) j0[s] = ld_off<double>(J0 + (size_t)s * N, ic * 8u);
 		}
 		const BsplWin4 a = bspl_window4<HK == 1 || HK == 2>(sp.it, nb, pa.hist_norm);
 		const BsplWin4 c0 = bspl_window4<HK == 3>(i0, nb, pa.hist_norm);
@@ -311,7 +319,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 					const int r = c - 1 + lb, cc = c - 1 + lk;   /* result lane: block = k, row = m, column = s in its half */
 					if (r >= 0 && r < nb && cc >= 0 && cc < nb) {
 						double *qe = qabs + r * kQR + cc * 8 + li;
-						qe[0] += acc0; qe[4] += acc1;
+						/* ds_add_f64 without return: the wave is the only writer of its table, so the sum is the same as a
+						 * read-modify-write -- which cost an LDS round trip behind the accumulators' matrix products at every
+						 * class boundary (up to eight per chunk) */
+						lds_add_f64(qe, acc0); lds_add_f64(qe + 4, acc1);
 					}
 					acc0 = 0.0; acc1 = 0.0;
 					do { ++c; } while (c < 8 && (int)((cs.ends >> (8 * c)) & 255) <= end);
@@ -319,6 +330,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 				}
 			};
 			double a_d = pd[0], a_w = pw[0], a_r0 = pr0[0], a_r1 = pr1[0], a_ht = pht[0];
+			/* (kept apart from the requests above: merged into ds_read2 pairs, the loop head had to wait for both groups --
+			 * lgkmcnt(0) in every trip, i.e. the requests issued just before the back edge were waited for at once) */
+			asm volatile("" ::: "memory");
 			double b_d = pd[4], b_w = pw[4], b_r0 = pr0[4], b_r1 = pr1[4], b_ht = pht[4];
 			for (int g = 0; g < cs.total; g += 8) {
 				{
