@@ -113,19 +113,34 @@ __device__ __forceinline__ void lds_add_f64(double *p, double v) {
 	(void)__builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)p, v);
 }
 struct ClassSort { int slot; unsigned long long ends; int total; };   /* ends: byte c = end slot of class c (<= 88) */
+/* inclusive prefix sum over the 64 lanes (row_shr 1 / 2 / 4 / 8 inside the rows of 16, then row_bcast:15 / :31 across them) */
+__device__ __forceinline__ unsigned wave_scan_u32(unsigned x) {
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
+	return x;
+}
+/* Counting sort of the wave's keys: eight 8-bit counters packed into two words (a class holds at most 64 pixels, the padded total
+ * is at most 88: no byte ever carries), one prefix sum per word gives every lane its rank inside its class and lane 63 the class
+ * sizes; sizes padded to multiples of four and multiplied by 0x0101...01 are the classes' end slots.  (r03: eight ballots, each a
+ * VALU -> SALU -> VALU round trip, took ~25 us of the pass.) */
 __device__ __forceinline__ ClassSort class_sort8(int key /* 0..7, or negative: not placed */) {
 	ClassSort cs;
-	cs.slot = 0; cs.ends = 0;
-	int off = 0;
-#pragma unroll
-	for (int c = 0; c < 8; ++c) {
-		const unsigned long long m = __builtin_amdgcn_ballot_w64(key == c);
-		const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-		cs.slot = key == c ? off + rank : cs.slot;
-		off += (__builtin_popcountll(m) + 3) & ~3;
-		cs.ends |= (unsigned long long)off << (8 * c);
-	}
-	cs.total = off;
+	const unsigned sh = ((unsigned)key & 3u) * 8u;
+	const unsigned lo = (key >= 0 && key < 4) ? 1u << sh : 0u, hi = key >= 4 ? 1u << sh : 0u;
+	const unsigned slo = wave_scan_u32(lo), shi = wave_scan_u32(hi);
+	const unsigned long long counts = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)slo, 63) |
+		((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)shi, 63) << 32);
+	const unsigned long long padded = (counts + 0x0303030303030303ull) & 0xFCFCFCFCFCFCFCFCull;
+	cs.ends = padded * 0x0101010101010101ull;
+	const unsigned long long starts = cs.ends - padded;
+	const unsigned rank = ((key >= 4 ? shi : slo) >> sh) & 255u;                       /* 1-based */
+	const unsigned start = (unsigned)(starts >> (8u * ((unsigned)key & 7u))) & 255u;
+	cs.slot = key >= 0 ? (int)(start + rank) - 1 : 0;
+	cs.total = (int)(cs.ends >> 56);
 	return cs;
 }
 constexpr int kMiFastRow = 16 + 64 + 512;
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 		/* df_dIt = sum gradIt(r) matI0(c) T_curr(r, c), df_dI0 = sum gradI0(r) matIt(c) T_init(r, c) (MI.cc:406-415, 432-441),
 		 * factored: the inner sums over the second window first.  Taps outside the histogram meet the tables' zero border. */
 		double dft = 0, df0 = 0;
-#if defined(MTFHIP_MI_ABL) && MTFHIP_MI_ABL >= 2
+#if defined(MTFHIP_MI_ABL) && MTFHIP_MI_ABL == 2
 		dft = a.d[0] + c0.w[1]; df0 = c0.d[2] + a.w[3];
 		if (false) {
 #else
@@ -257,7 +272,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 			}
 			dft *= vm;
 		}
-#if defined(MTFHIP_MI_ABL) && MTFHIP_MI_ABL >= 2
+#if defined(MTFHIP_MI_ABL) && MTFHIP_MI_ABL == 2
 		if (false) {
 #else
 		if (pa.need_df0) {
@@ -276,7 +291,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 			const double jg = pa.g_mean ? 0.5 * (j0[s] + jt[s]) : jt[s];
 			acc[s] = fma(dft, jg, acc[s]); acc[8 + s] = fma(df0, j0[s], acc[8 + s]);
 		}
-#ifdef MTFHIP_MI_ABL   /* ablation builds (tools/mi_ablation.sh): 1 no bin mode, 2 no table sums either */
+#if defined(MTFHIP_MI_ABL) && MTFHIP_MI_ABL <= 2   /* ablation builds (tools/mi_ablation.sh): 1 no bin mode, 2 no table sums either */
 		if constexpr (SORTED) { acc[0] += a.d[0] + a.h[1] + jt[3] + jt[7]; } else
 #endif
 		if constexpr (SORTED) {
@@ -291,7 +306,11 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 				}
 			}
 			const bool valid = i < N;
+#if defined(MTFHIP_MI_ABL) && MTFHIP_MI_ABL == 4   /* ablation: no sort (one class of 64 slots) */
+			ClassSort cs; cs.slot = lane; cs.ends = 0x4040404040404040ull; cs.total = 64;
+#else
 			const ClassSort cs = class_sort8(valid ? a.row0 : -1);
+#endif
 			if (valid) {
 #pragma unroll
 				for (int k = 0; k < 4; ++k) { sd[k * kRS2 + cs.slot] = a.d[k]; sw[k * kRS2 + cs.slot] = a.w[k]; }
@@ -334,7 +353,11 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 			 * lgkmcnt(0) in every trip, i.e. the requests issued just before the back edge were waited for at once) */
 			asm volatile("" ::: "memory");
 			double b_d = pd[4], b_w = pw[4], b_r0 = pr0[4], b_r1 = pr1[4], b_ht = pht[4];
+#if defined(MTFHIP_MI_ABL) && MTFHIP_MI_ABL == 3   /* ablation: sort and stores, no block products */
+			for (int g = 0; g < 0; g += 8) {
+#else
 			for (int g = 0; g < cs.total; g += 8) {
+#endif
 				{
 					const double av = a_d * a_w;   /* block = gradient tap k, row = weight tap m */
 					acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, a_r0, acc0, 0, 0, 0);
