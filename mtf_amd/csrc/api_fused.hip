@@ -775,6 +775,12 @@ static void persist_decomposition(const mtfhip_batch *b, int &nblk, int &rows) {
 		rows = (total_rows + per_target - 1) / per_target;
 		nblk = (total_rows + rows - 1) / rows;
 	}
+	static const int forced = std::getenv("MTFHIP_PERSIST_NBLK") ? std::atoi(std::getenv("MTFHIP_PERSIST_NBLK")) : 0;   /* experiments */
+	if (forced > 0 && forced < nblk) {
+		const int total_rows = (b->N + kBlock - 1) / kBlock;
+		rows = (total_rows + forced - 1) / forced;
+		nblk = (total_rows + rows - 1) / rows;
+	}
 }
 static unsigned long long persist_timeout_ticks() {   /* 100 MHz ticks; MTFHIP_PERSIST_TIMEOUT_US for tests (default 20 ms) */
 	const char *e = std::getenv("MTFHIP_PERSIST_TIMEOUT_US");
@@ -906,6 +912,12 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 		}
 		ts.h_extra = b->d_d2_out; ts.h_extra_scale = so_term == 1 ? 0.5 : 1.0;
 	}
+	{
+		/* tolerance mode + a definite first-order system: the register-resident finish (finish_track_fast_body) */
+		const char *e = std::getenv("MTFHIP_FAST_FINISH");   /* (read per call: the tests compare the two bodies in one process) */
+		const bool enabled = !(e && e[0] == '0');
+		ts.fast_finish = (enabled && b->math_mode == MTFHIP_MATH_FAST && !ncc && !mi && so_term < 0) ? 1 : 0;
+	}
 	BatchView bv = b->view();
 	unsigned long long pub_seq = 0;   /* non-zero: the loop's own kernel delivers the results to the host */
 	bool persisted = false;
@@ -1006,7 +1018,7 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 				ts.init_corners_hm + 12 * (size_t)t0, ts.active + t0, ts.n_iters + t0, ncc ? ts.ncc + 8 * (size_t)t0 : nullptr,
 				ncc ? ts.ncc_tm + 52 * (size_t)t0 : nullptr, 0, ts.lm ? ts.lm + (size_t)kLmStride * t0 : nullptr, nullptr,
 				ts.trace ? ts.trace + (size_t)t0 * ts.trace_cap * kTraceStride : nullptr, ts.trace_cap,
-				ts.h_extra ? ts.h_extra + (size_t)t0 * b->S * b->S : nullptr, ts.h_extra_scale};
+				ts.h_extra ? ts.h_extra + (size_t)t0 * b->S * b->S : nullptr, ts.h_extra_scale, ts.fast_finish};
 			int nblk_c; { int rows; fused_decomposition(b->N, nt, nblk_c, rows, MTFHIP_SLOTS / n_streams); fc.rows_per_block = rows; }
 			if (nblk_c > b->nblk_max) { int rows; fused_decomposition(b->N, nt, nblk_c, rows); fc.rows_per_block = rows; }
 			double *part = b->d_partials + (size_t)t0 * b->nblk_max * RL;

@@ -29,7 +29,8 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FAST_WAVES) void k_fused_fast(BatchV
  * last period after the other queue's stamp: a queue that runs too close behind the other is held back until it is not. */
 __global__ __launch_bounds__(256) void k_finish_track(BatchView bv, mtfhip_sm_desc sm, TrackState ts,
 	const double *partials, int nblk, PhaseCtl pc) {
-	finish_track_body(bv, sm, ts, partials, nblk, blockIdx.x);
+	if (ts.fast_finish) finish_track_fast_body(bv, sm, ts, partials, nblk, blockIdx.x);
+	else finish_track_body(bv, sm, ts, partials, nblk, blockIdx.x);
 	if (pc.mine && blockIdx.x == 0 && threadIdx.x == 0) {
 		const unsigned long long prev = ld_coh(pc.mine), other = ld_coh(pc.other);
 		unsigned long long now = wall_clock64();   /* 100 MHz */

@@ -42,7 +42,8 @@ __global__ __launch_bounds__(kBlock, 1) void k_track_persist(BatchView bv, ImgVi
 		const unsigned want = ps.gen_base + (unsigned)pass + 1u;
 		if (s_last) {
 			if (tid == 0) st_coh(ps.arrive + t, 0);
-			finish_track_body<true>(bv, sm, ts, partials, nblk, t);
+			if (ts.fast_finish) finish_track_fast_body<true>(bv, sm, ts, partials, nblk, t);
+			else finish_track_body<true>(bv, sm, ts, partials, nblk, t);
 			wait_stores_acked();
 			__syncthreads();
 			if (tid == 0) st_coh(ps.gen + t, want);

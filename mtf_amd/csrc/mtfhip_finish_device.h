@@ -365,5 +365,255 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 	FIN_STAMP(6);
 }
 
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Tolerance-mode finish (TrackState::fast_finish: MTFHIP_MATH_FAST, SSD family, first-order Hessian, no pivoting needed).
+ * finish_track_body keeps the reference's expressions and IEEE divisions and eliminates in LDS with two barriers per pivot --
+ * ~3.7 us of dependent latency behind the row sums on a workgroup that has nothing else to do.  Here every lane of wave 0 holds
+ * the whole 8 x 8 system in registers and solves it redundantly: LDL^T without pivoting (the SSD Hessians are negated Gram
+ * matrices; a zero pivot leaves its unknown at zero, as there), reciprocals by v_rcp_f64 + two Newton steps, the inverse of
+ * the update through cofactors with the determinant cancelled, no equilibration (scaling by powers of two changes nothing
+ * without pivoting).  No LDS and no barrier between the reduced row and the stores.  Same g, H, Levenberg-Marquardt logic,
+ * update and convergence test as finish_track_body; results agree with it to rounding (~1e-13 relative on dp).
+ * --------------------------------------------------------------------------------------------------------------------- */
+template <bool COH = false>
+__device__ __forceinline__ void finish_track_fast_body(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts,
+	const double *partials, int nblk, int t) {
+	auto LD = [](const double *p) -> double { if constexpr (COH) return ld_coh(p); else return *p; };
+	auto LDI = [](const int *p) -> int { if constexpr (COH) return ld_coh(p); else return *p; };
+	auto ST = [](double *p, double v) { if constexpr (COH) st_coh(p, v); else *p = v; };
+	auto STI = [](int *p, int v) { if constexpr (COH) st_coh(p, v); else *p = v; };
+	__shared__ double f_acc[ACC_COUNT], f_h0[64], f_w[9], f_cr[8], f_ic[12], f_lm[kLmStride + 1], f_part[3][80];
+	const int lane = threadIdx.x;
+	const bool wv0 = lane < 64;
+	const int S = bv.S;
+	constexpr int RL = ACC_COUNT;
+	const int act = LDI(ts.active + t);
+	FIN_STAMP(0);
+	const int n_it_prev = LDI(ts.n_iters + t);
+	double *lmp = ts.lm ? ts.lm + (size_t)t * kLmStride : nullptr;
+	double v_h0 = 0, v_w = 0, v_cr = 0, v_ic = 0, v_acc = 0, v_lm = 0, v_f = 0;
+	if (wv0) {
+		/* (the Levenberg-Marquardt block and an external similarity ride on the same round trip) */
+		if (lmp && lane < kLmStride) v_lm = LD(lmp + lane);
+		if (ts.f_ext && lane == 0) v_f = LD(ts.f_ext + t);
+		v_h0 = ts.h0[(size_t)t * 64 + lane];
+		if (lane < 9) v_w = LD(bv.warps + 9 * t + lane);
+		if (lane < 8) v_cr = LD(ts.corners + 8 * t + lane);
+		if (lane < 12) v_ic = ts.init_corners_hm[12 * t + lane];
+	}
+	/* fixed-order sum of the block rows: the same runs and the same order as finish_track_body */
+	const int n_runs = (nblk > 8 && blockDim.x >= 240) ? 3 : 1;
+	const int run_len = n_runs == 1 ? nblk : ((nblk + 3 * 8 - 1) / (3 * 8)) * 8;
+	{
+		const int run = n_runs == 1 ? 0 : lane / 80, col = n_runs == 1 ? lane : lane % 80;
+		if (col < RL && run < n_runs) {
+			const int b0 = run * run_len, b1 = (b0 + run_len < nblk) ? b0 + run_len : nblk;
+			const double *p = partials + (size_t)t * nblk * RL + col;
+			auto ld = [&](size_t off) -> double { return LD(p + off); };
+			double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
+			int b = b0;
+			for (; b + 7 < b1; b += 8) {
+				s0 += ld((size_t)b * RL); s1 += ld((size_t)(b + 1) * RL);
+				s2 += ld((size_t)(b + 2) * RL); s3 += ld((size_t)(b + 3) * RL);
+				s4 += ld((size_t)(b + 4) * RL); s5 += ld((size_t)(b + 5) * RL);
+				s6 += ld((size_t)(b + 6) * RL); s7 += ld((size_t)(b + 7) * RL);
+			}
+			for (; b < b1; ++b) s0 += ld((size_t)b * RL);
+			const double v = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+			if (n_runs == 1) v_acc = v; else f_part[run][col] = v;
+		}
+	}
+	if (!act) return;
+	FIN_STAMP(1);
+	if (wv0) {
+		f_h0[lane] = v_h0;
+		if (lane < 9) f_w[lane] = v_w;
+		if (lane < 8) f_cr[lane] = v_cr;
+		if (lane < 12) f_ic[lane] = v_ic;
+		if (lane < kLmStride) f_lm[lane] = v_lm;
+		if (lane == 0) f_lm[kLmStride] = v_f;
+	}
+	if (n_runs > 1) {
+		__syncthreads();
+		if (lane < RL) v_acc = (f_part[0][lane] + f_part[1][lane]) + f_part[2][lane];
+	}
+	if (lane < RL) { f_acc[lane] = v_acc; ST(ts.acc + (size_t)t * RL + lane, v_acc); }
+	__syncthreads();
+	if (!wv0) return;   /* the rest is wave 0's, without barriers */
+	FIN_STAMP(2);
+	/* ---- Levenberg-Marquardt accept / undo (NT/ESM.cc:186-232, NT/FCLK.cc:205-250, NT/ICLK.cc:181-199) ---- */
+	double lm_delta = 0.0;
+	int lm_iter_id = n_it_prev;
+	bool undo = false;
+	const double f_now = ts.f_ext ? f_lm[kLmStride] : -f_acc[ACC_RR] / 2;
+	if (lmp) {
+		const double prev_f = f_lm[0];
+		lm_delta = f_lm[1];
+		const bool state_reset = f_lm[2] != 0.0;
+		lm_iter_id = (int)f_lm[3];
+		if (!state_reset && lm_iter_id > 0) {
+			if (f_now < prev_f) { lm_delta *= sm.lm_delta_update; undo = true; }
+			else if (f_now > prev_f) lm_delta /= sm.lm_delta_update;
+		}
+		if (lane == 0) {
+			ST(lmp + 1, lm_delta);
+			if (undo) ST(lmp + 2, 1.0);
+			else { ST(lmp + 2, 0.0); if (!state_reset) ST(lmp + 0, f_now); }
+		}
+	}
+	const bool use_h0 = (sm.hess_type == 0) || (sm.sm == MTFHIP_SM_ICLK);
+	const bool sum_h0 = (sm.sm == MTFHIP_SM_ESM) && (sm.hess_type == 2 || sm.hess_type == 4);
+	const double gscale = (sm.sm == MTFHIP_SM_ESM) ? 0.5 : 1.0;
+	/* ---- the system, lower triangle, in the registers of every lane ---- */
+	/* (every LDS operand is requested unconditionally and up front -- one wait; guarded reads were 36 round trips) */
+	double aH[36], aG[8], hI[36];
+#pragma unroll
+	for (int k = 0; k < 36; ++k) aH[k] = f_acc[ACC_H + k];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) aG[k] = f_acc[ACC_G + k];
+#pragma unroll
+	for (int r = 0; r < 8; ++r)
+#pragma unroll
+		for (int c = 0; c <= r; ++c) hI[r * (r + 1) / 2 + c] = f_h0[(r * S + c) & 63];
+	double M[8][8], y[8];
+#pragma unroll
+	for (int r = 0; r < 8; ++r) {
+#pragma unroll
+		for (int c = 0; c <= r; ++c) {
+			const int kk = c * 8 - (c * (c - 1)) / 2 + (r - c);
+			const double h0v = hI[r * (r + 1) / 2 + c];
+			double v = use_h0 ? h0v : -aH[kk];
+			if (sum_h0) v = (v + h0v) * 0.5;
+			M[r][c] = r < S ? v : (r == c ? -1.0 : 0.0);   /* (c <= r) */
+		}
+		y[r] = r < S ? gscale * aG[r] : 0.0;
+	}
+	FIN_STAMP(3);
+	double *trec = (ts.trace && n_it_prev < ts.trace_cap) ? ts.trace + ((size_t)t * ts.trace_cap + n_it_prev) * kTraceStride : nullptr;   /* debug trace */
+	if (trec && lane == 0) {
+#pragma unroll
+		for (int r = 0; r < 8; ++r) {
+#pragma unroll
+			for (int c = 0; c < 8; ++c) trec[8 * r + c] = (r < S && c < S) ? (c <= r ? M[r][c] : M[c][r]) : 0.0;
+			trec[64 + r] = y[r];
+		}
+		trec[88] = f_now; trec[90] = undo ? 1.0 : 0.0; trec[91] = lm_delta; trec[92] = 1.0;
+	}
+	double dp[8];
+	if (!undo) {
+		if (lmp) {   /* hessian(i, i) += leven_marq_delta * hessian(i, i) (NT/ESM.cc:262-265) */
+#pragma unroll
+			for (int r = 0; r < 8; ++r) if (r < S) M[r][r] *= 1.0 + lm_delta;
+		}
+		/* L D L^T in place (L below the diagonal, D on it), then L z = g, D w = z, L^T x = w; dp = -x */
+		double inv[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const double d = M[k][k];
+			inv[k] = d != 0 ? rcp_fast(d) : 0.0;
+			double l[8];
+#pragma unroll
+			for (int i = k + 1; i < 8; ++i) l[i] = M[i][k] * inv[k];
+#pragma unroll
+			for (int i = k + 1; i < 8; ++i) {
+#pragma unroll
+				for (int j = k + 1; j <= i; ++j) M[i][j] = fma(-l[i], M[j][k], M[i][j]);
+			}
+#pragma unroll
+			for (int i = k + 1; i < 8; ++i) { M[i][k] = l[i]; y[i] = fma(-l[i], y[k], y[i]); }
+		}
+#pragma unroll
+		for (int k = 7; k >= 0; --k) {
+			double x = y[k] * inv[k];
+#pragma unroll
+			for (int i = k + 1; i < 8; ++i) x = fma(-M[i][k], dp[i], x);
+			dp[k] = x;
+		}
+#pragma unroll
+		for (int k = 0; k < 8; ++k) dp[k] = k < S ? -dp[k] : 0.0;
+		if (lmp) {
+#pragma unroll
+			for (int q = 0; q < 8; ++q) if (lane == q) ST(lmp + 4 + q, dp[q]);
+		}
+	} else {
+		/* undo: the previous state_update is taken back */
+#pragma unroll
+		for (int q = 0; q < 8; ++q) dp[q] = f_lm[4 + q];
+	}
+	FIN_STAMP(4);
+	/* ---- compositional update (Homography.cc:73-92,109-114, Affine.cc:90-106,145-150) and the corner test ---- */
+	const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY;
+	double U[9];
+	if (hom) {
+		U[0] = 1 + dp[0]; U[1] = dp[1]; U[2] = dp[2]; U[3] = dp[3]; U[4] = 1 + dp[4]; U[5] = dp[5]; U[6] = dp[6]; U[7] = dp[7]; U[8] = 1;
+	} else {
+		U[0] = 1 + dp[2]; U[1] = dp[3]; U[2] = dp[0]; U[3] = dp[4]; U[4] = 1 + dp[5]; U[5] = dp[1]; U[6] = 0; U[7] = 0; U[8] = 1;
+	}
+	/* ICLK applies the inverse of the solved update (NT/ICLK.cc:266-267); undo: ESM / FCLK apply the inverse of the previous
+	 * update (NT/ESM.cc:194-195), ICLK re-applies it (NT/ICLK.cc:188) */
+	if ((sm.sm == MTFHIP_SM_ICLK) != undo) {
+		double c[9];   /* cofactors; normalised by the (2, 2) entry: the determinant cancels */
+		c[0] = U[4] * U[8] - U[5] * U[7]; c[1] = U[2] * U[7] - U[1] * U[8]; c[2] = U[1] * U[5] - U[2] * U[4];
+		c[3] = U[5] * U[6] - U[3] * U[8]; c[4] = U[0] * U[8] - U[2] * U[6]; c[5] = U[2] * U[3] - U[0] * U[5];
+		c[6] = U[3] * U[7] - U[4] * U[6]; c[7] = U[1] * U[6] - U[0] * U[7]; c[8] = U[0] * U[4] - U[1] * U[3];
+		const double ic8 = rcp_fast(c[8]);
+#pragma unroll
+		for (int q = 0; q < 8; ++q) U[q] = c[q] * ic8;
+		U[8] = 1;
+		if (!hom) { U[6] = 0; U[7] = 0; }
+	}
+	double Wn[9];
+#pragma unroll
+	for (int r = 0; r < 3; ++r) {
+		const double w0 = f_w[3 * r], w1 = f_w[3 * r + 1], w2 = f_w[3 * r + 2];
+#pragma unroll
+		for (int c2 = 0; c2 < 3; ++c2) Wn[3 * r + c2] = fma(w0, U[c2], fma(w1, U[3 + c2], w2 * U[6 + c2]));
+	}
+	if (hom) {
+		const double in22 = rcp_fast(Wn[8]);
+#pragma unroll
+		for (int q = 0; q < 8; ++q) Wn[q] *= in22;
+		Wn[8] = 1;
+	}
+	double St[8];
+	if (hom) { St[0] = Wn[0] - 1; St[1] = Wn[1]; St[2] = Wn[2]; St[3] = Wn[3]; St[4] = Wn[4] - 1; St[5] = Wn[5]; St[6] = Wn[6]; St[7] = Wn[7]; }
+	else { St[0] = Wn[2]; St[1] = Wn[5]; St[2] = Wn[0] - 1; St[3] = Wn[1]; St[4] = Wn[3]; St[5] = Wn[4] - 1; St[6] = 0; St[7] = 0; }
+	double Cr[8], change = 0;
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		const double X = f_ic[3 * q], Y = f_ic[3 * q + 1], Z = f_ic[3 * q + 2];
+		double nx = fma(Wn[0], X, fma(Wn[1], Y, Wn[2] * Z)), ny = fma(Wn[3], X, fma(Wn[4], Y, Wn[5] * Z));
+		if (hom) { const double idn = rcp_fast(fma(Wn[6], X, fma(Wn[7], Y, Wn[8] * Z))); nx *= idn; ny *= idn; }
+		const double ddx = f_cr[2 * q] - nx, ddy = f_cr[2 * q + 1] - ny;
+		change += ddx * ddx + ddy * ddy;
+		Cr[2 * q] = nx; Cr[2 * q + 1] = ny;
+	}
+	FIN_STAMP(5);
+	/* (every lane holds the same numbers: lane q stores entry q) */
+	double wq = 0, sq = 0, cq = 0;
+#pragma unroll
+	for (int q = 0; q < 9; ++q) if (lane == q) wq = Wn[q];
+#pragma unroll
+	for (int q = 0; q < 8; ++q) if (lane == q) { sq = St[q]; cq = Cr[q]; }
+	if (lane < 9) ST(bv.warps + 9 * t + lane, wq);
+	if (lane < S) ST(bv.states + 8 * t + lane, sq);
+	if (lane < 8) ST(ts.corners + 8 * t + lane, cq);
+	if (lane != 0) return;
+	if (trec) {
+#pragma unroll
+		for (int q = 0; q < 8; ++q) { trec[72 + q] = dp[q]; trec[80 + q] = Cr[q]; }
+		trec[89] = (double)n_it_prev;
+	}
+	const int n_it = n_it_prev + 1;
+	STI(ts.n_iters + t, n_it);
+	if (lmp) {
+		const int id = lm_iter_id + ((undo && sm.sm == MTFHIP_SM_FCLK) ? 0 : 1);
+		ST(lmp + 3, (double)id);
+		if ((!undo && change < sm.epsilon) || id >= sm.max_iters) STI(ts.active + t, 0);
+	} else if (change < sm.epsilon || n_it >= sm.max_iters) STI(ts.active + t, 0);
+	FIN_STAMP(6);
+}
+
 } // namespace mtfhip
 #endif

@@ -114,6 +114,7 @@ struct TrackState {
 	 * NULL: none. */
 	const double *h_extra;
 	double h_extra_scale;
+	int fast_finish;      /* tolerance mode, SSD family, first-order Hessian from the reduced row or the constant one: finish_track_fast_body */
 };
 constexpr int kLmStride = 12;
 constexpr int kTraceStride = 96;

@@ -932,3 +932,47 @@ def test_two_queue_device_loop_equals_single_queue(oracle, gpu_ctx, frame, frame
     trk = oracle.Tracker(sm_kind, o_am, o_ssm, **params)
     trk.initialize(corners[B - 1]); o_am.set_curr_img(frame2); trk.update()
     np.testing.assert_allclose(out["2"][1][B - 1], trk.get_region(), rtol=0, atol=2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ssm,res", [(L.SSM_HOMOGRAPHY, 60), (L.SSM_AFFINE, 40), (L.SSM_HOMOGRAPHY, 200)])
+@pytest.mark.parametrize("sm_kind,extra", [(L.SM_ESM, dict()), (L.SM_ESM, dict(leven_marq=1)), (L.SM_FCLK, dict(leven_marq=1)), (L.SM_FCLK, dict(hess_type=0)),
+                                           (L.SM_ICLK, dict()), (L.SM_ICLK, dict(leven_marq=1)), (L.SM_ESM, dict(hess_type=2, jac_type=1))],
+                         ids=lambda v: "_".join("%s%s" % kv for kv in v.items()) if isinstance(v, dict) else str(v))
+def test_register_resident_finish_equals_reference_finish(gpu_ctx, frame, frame2, ssm, res, sm_kind, extra, monkeypatch):
+    """finish_track_fast_body (tolerance mode, SSD: the system solved by L D L^T in the registers of every lane, reciprocals, no LDS
+    elimination) against finish_track_body (the reference's expressions, IEEE divisions, Gauss-Jordan in LDS) on the same reduced
+    rows: per-pass trace records -- H as the search method holds it, g, the state update, corners, the Levenberg-Marquardt
+    decisions -- and the final state, for one target (157 block rows at 200 x 200: the three-run row sum) and a batch."""
+    for B in (1, 5):
+        corners = np.stack([synth.square_corners(250 + 9 * t, 240 - 7 * t, float(res) * 1.2) for t in range(B)])
+        out = {}
+        for ff in ("0", "1"):
+            monkeypatch.setenv("MTFHIP_FAST_FINISH", ff)
+            gpu_ctx.set_image(frame)
+            b = mtf_amd.Batch(gpu_ctx, L.AM_SSD, ssm, res, res, B)
+            b.set_corners(corners)
+            params = dict(leven_marq=0, max_iters=8, epsilon=1e-6)
+            params.update(extra)
+            sm = mtf_amd.sm_desc(sm_kind, materialize=0, **params)
+            b.init_template(sm)
+            gpu_ctx.set_image(frame2)
+            b.track_trace(8)
+            n_it, final = b.track(sm)
+            out[ff] = (n_it.copy(), final.copy(), b.read_track_trace(n_it), b.get_state().copy())
+            b.close()
+        assert np.array_equal(out["0"][0], out["1"][0])
+        np.testing.assert_allclose(out["1"][1], out["0"][1], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(out["1"][3], out["0"][3], rtol=1e-5, atol=1e-9)
+        t0, t1 = out["0"][2], out["1"][2]
+        for t in range(B):
+            assert len(t0[t]) == len(t1[t]) > 0
+            for k, (r0, r1) in enumerate(zip(t0[t], t1[t])):
+                # pass 0 starts from the same reduced row: H and g are the same numbers, dp differs by the solver's rounding (condition
+                # number x eps); later passes start from states that differ by that much, and g = H dp amplifies it
+                tol = 0.0 if k == 0 else 1e-6
+                np.testing.assert_allclose(r1["H"], r0["H"], rtol=0, atol=tol * np.abs(r0["H"]).max())
+                np.testing.assert_allclose(r1["g"], r0["g"], rtol=0, atol=tol * np.abs(t0[t][0]["g"]).max())   # (g -> 0 with convergence)
+                np.testing.assert_allclose(r1["dp"], r0["dp"], rtol=0, atol=(1e-7 if k == 0 else 1e-5) * np.abs(r0["dp"]).max())
+                np.testing.assert_allclose(r1["corners"], r0["corners"], rtol=0, atol=1e-7 if k == 0 else 1e-6)
+                assert r1["undo"] == r0["undo"] and np.isclose(r1["lm_delta"], r0["lm_delta"], rtol=1e-12)
