@@ -293,6 +293,10 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters /
  * mtfhip_batch_set_region + mtfhip_batch_track; one staged upload per frame where the search method keeps its template Jacobian. */
 int mtfhip_batch_track_region(mtfhip_batch *b, const mtfhip_sm_desc *sm, const double *region_corners /* B x 8 */,
 	int *n_iters /* B */, double *corners /* B x 8 */);
+/* GridTracker::update's patch half (SM/src/GridTracker.cc:345-363) in one call: mtfhip_batch_track_region with regions / corners as
+ * row-major 2 x 4 arrays per patch (x row, y row) and the patch centroids (utils::getCentroid, miscUtils.h:473-480) */
+int mtfhip_grid_update(mtfhip_batch *b, const mtfhip_sm_desc *sm, const double *regions_2x4 /* B x 2 x 4 */, int *n_iters /* B, or NULL */,
+	double *corners_2x4 /* B x 2 x 4, or NULL */, double *centroids /* B x 2, or NULL */);
 /* Debug trace of the loop above: with max_passes > 0 every pass also records what it solved, per target
  * [max_passes][96]: H (64, row-major 8 x 8, before Levenberg-Marquardt damping) | g (8) | the state update applied (8) | the
  * corners it produced (8) | f | pass | LM undo | LM damping | 1 when H was recorded (the one-launch grid loop uses the

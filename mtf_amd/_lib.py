@@ -90,7 +90,7 @@ SYMBOLS = [
     "mtfhip_am_initialize_pix_hess_warped", "mtfhip_am_update_pix_hess_warped", "mtfhip_ssm_cmpt_pix_hessian",
     "mtfhip_sm_mean_pix_hessian", "mtfhip_am_cmpt_init_hessian2", "mtfhip_am_cmpt_curr_hessian2",
     "mtfhip_am_cmpt_self_hessian2", "mtfhip_am_cmpt_sum_of_hessians2",
-    "mtfhip_batch_init_template", "mtfhip_batch_set_region", "mtfhip_batch_iterate", "mtfhip_batch_track", "mtfhip_batch_track_region",
+    "mtfhip_batch_init_template", "mtfhip_batch_set_region", "mtfhip_batch_iterate", "mtfhip_batch_track", "mtfhip_batch_track_region", "mtfhip_grid_update",
     "mtfhip_batch_track_targets_per_launch",
     "mtfhip_score_candidates", "mtfhip_score_candidates_dev",
     "mtfhip_sample_candidates", "mtfhip_sample_candidates_dev",
@@ -147,6 +147,7 @@ def lib():
         L.mtfhip_image_pyramid_level.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.mtfhip_image_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.mtfhip_image_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.mtfhip_grid_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mtfhip_ssm_update_grad_pts.argtypes = [C.c_void_p, C.c_double]
         L.mtfhip_ssm_update_hess_pts.argtypes = [C.c_void_p, C.c_double]
         for fn in ("mtfhip_am_initialize_pix_hess", "mtfhip_am_update_pix_hess"):

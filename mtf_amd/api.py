@@ -519,6 +519,19 @@ class Batch:
         L.check(fn(self._h, C.byref(sm), pr, pn, pc))
         return n.copy(), c.transpose(0, 2, 1).copy()
 
+    def grid_update(self, regions, sm):
+        """GridTracker::update's patch half in one C-ABI call (mtfhip_grid_update): regions (B, 2, 4) -> iteration counts, corners
+        (B, 2, 4), centroids (B, 2).  The returned arrays are this object's reused buffers: valid until the next call."""
+        gu = getattr(self, "_gu", None)
+        if gu is None:     # per-frame call: buffers, their pointers and the bound function are built once
+            n, c, m = np.empty(self.B, dtype=np.int32), np.empty((self.B, 2, 4)), np.empty((self.B, 2))
+            gu = self._gu = (n, c, m, _p(n), _p(c), _p(m), L.lib().mtfhip_grid_update, None)
+        n, c, m, pn, pc, pm, fn, _ = gu
+        r = regions if (type(regions) is np.ndarray and regions.dtype == np.float64 and regions.flags.c_contiguous and regions.size == 8 * self.B) \
+            else np.ascontiguousarray(np.asarray(regions, dtype=np.float64).reshape(self.B, 2, 4))
+        L.check(fn(self._h, C.byref(sm), r.ctypes.data, pn, pc, pm))
+        return n, c, m
+
     # ---------------------------------------------------------- candidate scoring
     def score_candidates(self, states, want_similarity=False):
         s = _f64(states).reshape(-1, self.S)

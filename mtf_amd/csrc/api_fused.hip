@@ -829,6 +829,27 @@ int mtfhip_batch_track_region(mtfhip_batch *b, const mtfhip_sm_desc *sm, const d
 	return r;
 }
 
+/* GridTracker::update's patch half as ONE call (SM/src/GridTracker.cc:345-363): every patch tracker is reset to its region and
+ * runs its update(); regions and corners in the reference's CornersT layout as a row-major host array sees it (2 x 4: the x row,
+ * then the y row), plus the patch centroids utils::getCentroid (miscUtils.h:473-480: the mean of the four corners) hands to the
+ * robust estimator.  (The layout conversion and the centroids were ~9 of the ~14 us a frame spent in the Python layer.) */
+int mtfhip_grid_update(mtfhip_batch *b, const mtfhip_sm_desc *sm, const double *regions_2x4, int *n_iters, double *corners_2x4, double *centroids) {
+	if (!b || !sm || !regions_2x4) return fail(MTFHIP_ERR_INVALID_ARG, "grid_update: NULL argument");
+	const size_t B = (size_t)b->B;
+	static thread_local std::vector<double> in, out;
+	in.resize(8 * B); out.resize(8 * B);
+	for (size_t t = 0; t < B; ++t)
+		for (int q = 0; q < 4; ++q) { in[8 * t + 2 * q] = regions_2x4[8 * t + q]; in[8 * t + 2 * q + 1] = regions_2x4[8 * t + 4 + q]; }
+	TRY(mtfhip_batch_track_region(b, sm, in.data(), n_iters, out.data()));
+	for (size_t t = 0; t < B; ++t) {
+		const double *c = &out[8 * t];
+		if (corners_2x4)
+			for (int q = 0; q < 4; ++q) { corners_2x4[8 * t + q] = c[2 * q]; corners_2x4[8 * t + 4 + q] = c[2 * q + 1]; }
+		if (centroids) { centroids[2 * t] = (c[0] + c[2] + c[4] + c[6]) * 0.25; centroids[2 * t + 1] = (c[1] + c[3] + c[5] + c[7]) * 0.25; }
+	}
+	return MTFHIP_OK;
+}
+
 /* the argument / state checks of the device loop, without side effects (track_region runs them before it resets the SSM) */
 static int track_validate(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	TRY(check_sm(b, sm, "track"));

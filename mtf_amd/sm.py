@@ -353,10 +353,15 @@ class GridTracker:
         the grid laid over that region (the reference's reset_at_each_frame behaviour), in the same C-ABI call."""
         if region_corners is None:
             corners = self.tracker.update()
-        else:
-            pc = region_corners if np.ndim(region_corners) == 3 else self.patch_corners(region_corners)
+            return corners, np.add.reduce(corners, axis=2) * 0.25   # utils::getCentroid miscUtils.h:473-480 (mean of the four corners)
+        pc = region_corners if np.ndim(region_corners) == 3 else self.patch_corners(region_corners)
+        if self.tracker.host_solve:
             corners = self.tracker.update_region(pc)
-        return corners, np.add.reduce(corners, axis=2) * 0.25   # utils::getCentroid miscUtils.h:473-480 (mean of the four corners)
+            return corners, np.add.reduce(corners, axis=2) * 0.25
+        # one C-ABI call for the frame: reset + update of every patch, layout conversion and centroids included (mtfhip_grid_update)
+        n, corners, centroids = self.tracker.batch.grid_update(pc, self.tracker.sm)
+        self.tracker.n_iters = n.copy()
+        return corners.copy(), centroids.copy()
 
     @property
     def n_iters(self):
