@@ -463,3 +463,28 @@ def test_pf_mixture_and_adaptive_resampling_properties(oracle, frame):
         verdicts.append(resampled)
         assert w[mxid if not resampled else ids[mxid]] == w.max()
     assert True in verdicts and False in verdicts
+
+
+@pytest.mark.parametrize("ssm_kind", [0, 1])
+def test_estimate_state_sigma_against_its_definition(oracle, ssm_kind):
+    """StateSpaceModel::estimateStateSigma (ProjectiveBase.cc:201-213): state_sigma[k] = pix_sigma / mean_p |d curr_pt_p / d state_k| --
+    moving state component k by its sigma moves the sample points by pix_sigma on average.  The analytic columns (getCurrPixGrad)
+    are checked against central differences of setState."""
+    ssm = oracle.SSM(ssm_kind, 12, 9)
+    ssm.set_corners(synth.square_corners(140, 120, 60) + np.array([[1.5, -2.0, 0.5, 3.0], [0.7, 1.1, -2.2, 0.4]]))
+    p0 = np.array([0.02, -0.01, 1.2, 0.015, -0.02, -0.8, 3e-5, -2e-5]) if ssm_kind == 0 else np.array([1.2, -0.8, 0.02, -0.01, 0.015, -0.02])
+    ssm.set_state(p0)
+    sigma = ssm.estimate_state_sigma(1.7)
+    assert sigma.shape == (ssm.S,) and np.all(sigma > 0)
+    steps = np.where(np.abs(p0) > 1e-3, 1e-6, 1e-9) if ssm_kind == 0 else np.full(6, 1e-6)
+    for k in range(ssm.S):
+        d = np.zeros(ssm.S); d[k] = steps[k]
+        ssm.set_state(p0 + d); a = ssm.get("curr_pts").copy()
+        ssm.set_state(p0 - d); b = ssm.get("curr_pts").copy()
+        col = ((a - b) / (2 * steps[k])).reshape(-1, 2)      # (n, 2): d pt / d state_k
+        mean_norm = np.sqrt((col ** 2).sum(axis=1)).mean()
+        # (Homography::getCurrPixGrad, Homography.cc:143-155, divides the NORMALISED init point by the un-normalised denominator of
+        # the homogeneous grid setCorners keeps: exact where that grid has z = 1, a fraction of a percent off elsewhere)
+        np.testing.assert_allclose(sigma[k], 1.7 / mean_norm, rtol=1e-5 if ssm_kind == 1 else 5e-3)
+    ssm.set_state(p0)
+    np.testing.assert_allclose(ssm.estimate_state_sigma(3.4), 2 * sigma, rtol=1e-14)   # linear in pix_sigma
