@@ -370,6 +370,19 @@ int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 static int set_region_core(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm, bool for_track);
 int mtfhip_batch_set_region(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm) { return set_region_core(b, corners, sm, false); }
 
+/* the one-launch grid kernel (k_iclk_track: a patch's whole ICLK update() in one workgroup) takes ICLK with a constant Hessian -- up to
+ * four pixels per thread, where every per-pixel operand of the loop stays in registers: 3.1-4.4 us per iteration at 25 x 25 and
+ * 32 x 32 against 8.8-12 for a launch per pass.  Above that the template Jacobian is re-read in every iteration and the kernel
+ * falls behind the launch-per-pass loop (40 x 40: 11.3-16.9 against 9.9-13.7 us; 50 x 50 x 256: 35.3 against 14.9;
+ * profiles/r03_experiments.md), so larger patches take that loop.  MTFHIP_ICLK_ONE_LAUNCH_MAX moves the boundary (experiments). */
+static int iclk_one_launch_max_pix() {
+	static const int v = std::getenv("MTFHIP_ICLK_ONE_LAUNCH_MAX") ? std::atoi(std::getenv("MTFHIP_ICLK_ONE_LAUNCH_MAX")) : 4 * kBlock;
+	return v < kIclkTrackMaxPix ? v : kIclkTrackMaxPix;
+}
+static bool iclk_one_launch(const mtfhip_batch *b, const mtfhip_sm_desc *sm) {
+	return b->C == 1 && sm->sm == MTFHIP_SM_ICLK && (sm->hess_type == 0 || (sm->hess_type == 2 && b->desc.am == MTFHIP_AM_SSD)) &&
+		b->N <= iclk_one_launch_max_pix();
+}
 static bool region_refreshes(const mtfhip_sm_desc *sm) { return sm->sm == MTFHIP_SM_ESM || (sm->sm == MTFHIP_SM_FCLK && sm->hess_type == 0); }
 
 static int set_region_core(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm, bool for_track) {
@@ -742,8 +755,7 @@ static int track_queues(const mtfhip_batch *b, const FusedArgs &fa) {
 int mtfhip_batch_track_targets_per_launch(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	FLUSH(b);
 	if (check_sm(b, sm, "track_targets_per_launch") != MTFHIP_OK) return 0;
-	const bool one_launch = b->C == 1 && sm->sm == MTFHIP_SM_ICLK && (sm->hess_type == 0 || (sm->hess_type == 2 && b->desc.am == MTFHIP_AM_SSD)) &&
-		b->N <= kIclkTrackMaxPix;
+	const bool one_launch = iclk_one_launch(b, sm);
 	if (one_launch) return b->B;
 	FusedArgs fa;
 	if (fused_args(b, sm, fa) != MTFHIP_OK) return 0;
@@ -754,8 +766,7 @@ int mtfhip_batch_track_queues(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	FLUSH(b);
 	if (check_sm(b, sm, "track_queues") != MTFHIP_OK) return 0;
 	if (b->desc.am == MTFHIP_AM_MI) return 1;
-	const bool one_launch = b->C == 1 && sm->sm == MTFHIP_SM_ICLK && (sm->hess_type == 0 || (sm->hess_type == 2 && b->desc.am == MTFHIP_AM_SSD)) &&
-		b->N <= kIclkTrackMaxPix;
+	const bool one_launch = iclk_one_launch(b, sm);
 	if (one_launch) return 1;
 	FusedArgs fa;
 	if (fused_args(b, sm, fa) != MTFHIP_OK) return 0;
@@ -871,8 +882,7 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 	hipStream_t st = b->ctx->stream;
 	const bool mi = b->desc.am == MTFHIP_AM_MI;
 	/* (the one-launch grid kernel has no Levenberg-Marquardt: with it ICLK takes the fused launch + finish per pass) */
-	const bool one_launch = !mi && b->C == 1 && !sm->leven_marq && sm->sm == MTFHIP_SM_ICLK && (sm->hess_type == 0 || (sm->hess_type == 2 && b->desc.am == MTFHIP_AM_SSD)) &&
-		b->N <= kIclkTrackMaxPix && so_term < 0;
+	const bool one_launch = !mi && !sm->leven_marq && iclk_one_launch(b, sm) && so_term < 0;
 	FusedArgs fa;
 	if (!one_launch && !mi) TRY(fused_args(b, sm, fa));
 	else { fa.materialize = 0; fa.mode = 2; fa.active = nullptr; fa.rows_per_block = 1; fa.j0_recompute = 0; fa.inline_warp = 0; fa.fast_math = 0; }
