@@ -3,6 +3,7 @@
  * (one of the translation units of libmtfhip.so; conventions and the shared device helpers: mtfhip_device.h)
  */
 #include "mtfhip_device.h"
+#include "mtfhip_mi_device.h"
 
 namespace mtfhip {
 
@@ -292,13 +293,29 @@ __global__ __launch_bounds__(64) void k_plane_sum_finish(const double *partials,
  *   term  3:  r * D0                 cmptInitHessian (2nd order), SSDBase.cc:313-343   (ICLK Std)
  * d0_variant: how init_pix_hessian was produced (Warped at the identity warp by initialize, Init after setRegion).
  * With nc.rows set the weights are NCC's: term 0 df_dIt Dt (NCC.cc:401-410), 1 df_dIt Dt + df_dI0 D0, 2 df_dIt (D0 + Dt) / 2,
- * 3 df_dI0 D0 (NCC.cc:391-400). */
+ * 3 df_dI0 D0 (NCC.cc:391-400).  With mi.tb set they are MI's per-pixel gradients, same assignment (MI.cc:659-695). */
 template <int SSM>
 __global__ __launch_bounds__(kBlock) void k_second_order_ssd(BatchView bv, ImgView im, int term, int chained, int d0_variant,
-	double grad_eps, double hess_eps, double norm_mult, double norm_add, double *partials, int nblk, int own_pts, SecondOrderNcc nc) {
+	double grad_eps, double hess_eps, double norm_mult, double norm_add, double *partials, int nblk, int own_pts, SecondOrderNcc nc,
+	SecondOrderMi mi) {
 	constexpr int S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
 	__shared__ double lds[4 * S * S];
 	const int t = blockIdx.y, N = bv.N;
+	/* MI (MI.cc:659-695): the weights are its per-pixel gradients df_dIt = sum_r gradIt(r) sum_c matI0(c) T_curr(r, c) and df_dI0 =
+	 * sum_r gradI0(r) sum_c matIt(c) T_init(r, c) (MI.cc:406-415, 432-441) -- the gradient-factor tables of this iteration, staged
+	 * with the zero border the un-clamped windows index into ((bin + 1) in both directions, as pass 2 of the recompute form) */
+	constexpr int kTR = 12;
+	__shared__ double mi_tc[kTR * MI_NB], mi_ti[kTR * MI_NB];
+	const bool is_mi = mi.tb != nullptr;
+	if (is_mi) {
+		const double *tb = mi.tb + (size_t)t * MI_SIZE;
+		for (int k = threadIdx.x; k < kTR * MI_NB; k += kBlock) {
+			const int r = k / MI_NB - 1, c = k % MI_NB - 1;
+			const bool in = r >= 0 && r < 8 && c >= 0 && c < 8;
+			mi_tc[k] = in ? tb[MI_T_CURR + r * MI_NB + c] : 0.0; mi_ti[k] = in ? tb[MI_T_INIT + r * MI_NB + c] : 0.0;
+		}
+		__syncthreads();
+	}
 	/* NCC (NCC.cc:391-410): the weights are its gradients df_dIt = (I0c / c - f Itc / b) / b and df_dI0 = (Itc / b - f I0c / c) / c
 	 * (NCC.cc:163-234), functions of this pass's It moments: every workgroup sums the three moment columns of the fused pass's
 	 * partial rows (same order everywhere: identical scalars in every workgroup) instead of waiting for a launch that would */
@@ -411,6 +428,28 @@ __global__ __launch_bounds__(kBlock) void k_second_order_ssd(BatchView bv, ImgVi
 			wt = term == 0 ? dft : (term == 1 ? dft : (term == 2 ? dft / 2.0 : 0.0));
 			w0 = term == 1 ? df0 : (term == 2 ? dft / 2.0 : (term == 3 ? df0 : 0.0));
 		}
+		if (is_mi) {
+			const BsplWin4 a = bspl_window4<false>(norm_mult * cv + norm_add, 8, mi.hist_norm), c0 = bspl_window4<false>(I0[i], 8, mi.hist_norm);
+			double dft = 0, df0 = 0;
+			{
+				const double *T0 = mi_tc + a.row0 * MI_NB + c0.row0;
+#pragma unroll
+				for (int r2 = 0; r2 < 4; ++r2) {
+					const double *Tr = T0 + r2 * MI_NB;
+					dft = fma(a.d[r2], fma(c0.w[3], Tr[3], fma(c0.w[2], Tr[2], fma(c0.w[1], Tr[1], c0.w[0] * Tr[0]))), dft);
+				}
+			}
+			{
+				const double *T0 = mi_ti + c0.row0 * MI_NB + a.row0;
+#pragma unroll
+				for (int r2 = 0; r2 < 4; ++r2) {
+					const double *Tr = T0 + r2 * MI_NB;
+					df0 = fma(c0.d[r2], fma(a.w[3], Tr[3], fma(a.w[2], Tr[2], fma(a.w[1], Tr[1], a.w[0] * Tr[0]))), df0);
+				}
+			}
+			wt = term == 0 ? dft : (term == 1 ? dft : (term == 2 ? dft / 2.0 : 0.0));
+			w0 = term == 1 ? df0 : (term == 2 ? dft / 2.0 : (term == 3 ? df0 : 0.0));
+		}
 		if (term != 3) {
 #pragma unroll
 			for (int k = 0; k < S * S; ++k) acc[k] = fma(wt, d2[k], acc[k]);
@@ -489,14 +528,15 @@ void launch_weighted_plane_sum(const BatchView &bv, const double *d2a, const dou
 	MTFHIP_LAUNCH(k_plane_sum_finish, dim3(bv.B), dim3(64), 0, st, partials, nblk, bv.S * bv.S, out);
 }
 void launch_second_order_ssd(const BatchView &bv, const ImgView &im, int term, int chained, int d0_variant, double grad_eps,
-	double hess_eps, double norm_mult, double norm_add, double *partials, int nblk, double *out, hipStream_t st, int own_pts, SecondOrderNcc nc) {
+	double hess_eps, double norm_mult, double norm_add, double *partials, int nblk, double *out, hipStream_t st, int own_pts, SecondOrderNcc nc,
+	SecondOrderMi mi) {
 	const dim3 grid(nblk, bv.B);
 	if (bv.ssm == MTFHIP_SSM_HOMOGRAPHY)
 		MTFHIP_LAUNCH(k_second_order_ssd<MTFHIP_SSM_HOMOGRAPHY>, grid, dim3(kBlock), 0, st, bv, im, term, chained, d0_variant, grad_eps,
-			hess_eps, norm_mult, norm_add, partials, nblk, own_pts, nc);
+			hess_eps, norm_mult, norm_add, partials, nblk, own_pts, nc, mi);
 	else
 		MTFHIP_LAUNCH(k_second_order_ssd<MTFHIP_SSM_AFFINE>, grid, dim3(kBlock), 0, st, bv, im, term, chained, d0_variant, grad_eps,
-			hess_eps, norm_mult, norm_add, partials, nblk, own_pts, nc);
+			hess_eps, norm_mult, norm_add, partials, nblk, own_pts, nc, mi);
 	MTFHIP_LAUNCH(k_plane_sum_finish, dim3(bv.B), dim3(64), 0, st, partials, nblk, bv.S * bv.S, out);
 }
 

@@ -312,9 +312,12 @@ void launch_mean_planes(const double *a, const double *b, double *o, size_t n, h
 /* NCC weights for the fused second-order term: the fused NCC pass's partial rows of this iteration ([B][nblk][NCC_ACC_COUNT]) and
  * the template scalars ([B][8]: mean(I0), |I0 - mean|); rows == nullptr selects SSD's residual weights */
 struct SecondOrderNcc { const double *rows; int nblk; const double *sc; };
+/* MI weights for the fused second-order term (MI.cc:659-695: df_dI0 / df_dIt of the pixel): the gradient-factor tables of this
+ * iteration ([B][MI_SIZE], k_mi_tables_iter) and the histogram normaliser; tb == nullptr: not MI.  Eight bins (the recompute passes). */
+struct SecondOrderMi { const double *tb; double hist_norm; };
 void launch_second_order_ssd(const BatchView &bv, const ImgView &im, int term, int chained, int d0_variant, double grad_eps,
 	double hess_eps, double norm_mult, double norm_add, double *partials, int nblk, double *out, hipStream_t st, int own_pts = 0,
-	SecondOrderNcc nc = SecondOrderNcc{nullptr, 0, nullptr});
+	SecondOrderNcc nc = SecondOrderNcc{nullptr, 0, nullptr}, SecondOrderMi mi = SecondOrderMi{nullptr, 0.0});
 /* pre-processing / pyramid (float32 images) */
 void launch_hist_eq(float *gray, int rows, int cols, unsigned *hist256, float *lut256, hipStream_t st);
 void launch_to_gray(const void *raw, int rows, int cols, size_t stride_bytes, int channels, int depth_f32, float *out, hipStream_t st);

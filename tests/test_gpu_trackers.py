@@ -385,13 +385,64 @@ def test_device_loop_second_order_hessians(oracle, gpu_ctx, frame, sm_kind, ssm,
         trk1.initialize(corners[t]); o_am1.set_curr_img(frame_b); trk1.update()
         assert rel(trk1.trace()[0]["H"], tr[0]["H"]) > 1e-4   # (the parity gate above is 1e-5)
     b.track_trace(0); b.close()
-    # MI second order stays with the per-function entry points; NCC has no second-order self Hessian (AppearanceModel.h:188-191)
+    # MI's second-order SELF Hessian stays with the per-function entry points; NCC has no second-order self Hessian (AppearanceModel.h:188-191)
     gpu_ctx.set_image(frame)
-    for bad_am, kw in ((L.AM_MI, dict(hess_type=2)), (L.AM_NCC, dict(hess_type=0))):
+    for bad_am, kw in ((L.AM_MI, dict(hess_type=1)), (L.AM_NCC, dict(hess_type=0))):
         trk = LKTracker(gpu_ctx, L.SM_FCLK, L.SSM_HOMOGRAPHY, 30, 30, 2, host_solve=False, am=bad_am, sec_ord_hess=1, max_iters=5, **kw)
         with pytest.raises(mtf_amd.FunctionNotImplemented):
             trk.initialize(corners[:2])
             trk.update()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sm_kind,ssm,extra", [
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, dict(hess_type=5)), (L.SM_ESM, L.SSM_AFFINE, dict(hess_type=5, chained_warp=0)),
+    (L.SM_ESM, L.SSM_AFFINE, dict(hess_type=3, jac_type=0)), (L.SM_FCLK, L.SSM_HOMOGRAPHY, dict(hess_type=2)),
+    (L.SM_FCLK, L.SSM_AFFINE, dict(hess_type=2, chained_warp=0)), (L.SM_ICLK, L.SSM_AFFINE, dict(hess_type=2)),
+    (L.SM_ICLK, L.SSM_HOMOGRAPHY, dict(hess_type=2))],
+    ids=lambda v: "_".join("%s%s" % kv for kv in v.items()) if isinstance(v, dict) else str(v))
+def test_device_loop_second_order_hessians_mi(oracle, gpu_ctx, frame, sm_kind, ssm, extra):
+    """sec_ord_hess with MI in mtfhip_batch_iterate / mtfhip_batch_track (MI.cc:659-695: cmptInitHessian / cmptCurrHessian + sum_p df_dI(p)
+    d2I_dp2(p), the Std Hessian types of the three search methods): one more pixel pass per iteration weights the pixel-Hessian
+    blocks with MI's own per-pixel gradients, taken from the iteration's gradient-factor tables -- first-pass H / g / update and
+    the final region against the oracle's second-order trackers; the term is not vacuous."""
+    rng = np.random.default_rng(31)
+    res, B = 40, 2
+    p_true = synth.random_small_homography(rng, 0.25)
+    frame_b = synth.warp_frame(frame, p_true, (256.0, 256.0))
+    corners = np.stack([synth.square_corners(200.0 + 60 * i, 230.0 + 25 * i, 90) + 0.25 * i for i in range(B)])
+    params = dict(leven_marq=0, max_iters=10, epsilon=1e-5, sec_ord_hess=1)
+    params.update(extra)
+    gpu_ctx.set_image(frame)
+    b = mtf_amd.Batch(gpu_ctx, L.AM_MI, ssm, res, res, B)
+    b.set_corners(corners)
+    sm = mtf_amd.sm_desc(sm_kind, materialize=0, **params)
+    b.init_template(sm)
+    gpu_ctx.set_image(frame_b)
+    f, g, H = b.iterate(sm)
+    b.track_trace(params["max_iters"] * 2)
+    n_it, final = b.track(sm)
+    recs = b.read_track_trace(n_it)
+    rel = lambda a, r: float(np.linalg.norm(np.asarray(a) - np.asarray(r)) / max(np.linalg.norm(r), 1e-300))
+    S = b.S
+    for t in range(B):
+        o_ssm = oracle.SSM(ssm, res, res); o_am = oracle.AM(L.AM_MI, res, res); o_am.set_curr_img(frame)
+        trk = oracle.Tracker(sm_kind, o_am, o_ssm, **params)
+        trk.initialize(corners[t]); o_am.set_curr_img(frame_b)
+        iters = trk.update()
+        tr = trk.trace()
+        d0 = recs[t][0]
+        assert d0["has_H"] and rel(d0["H"], tr[0]["H"]) < 2e-5 and rel(d0["g"], tr[0]["g"]) < 2e-5 and rel(d0["dp"], tr[0]["dp"]) < 1e-4, \
+            (rel(d0["H"], tr[0]["H"]), rel(d0["g"], tr[0]["g"]), rel(d0["dp"], tr[0]["dp"]))
+        assert rel(H[t].reshape(S, S), tr[0]["H"]) < 2e-5 and rel(g[t], tr[0]["g"]) < 2e-5      # iterate: the same first pass
+        o_ssm1 = oracle.SSM(ssm, res, res); o_am1 = oracle.AM(L.AM_MI, res, res); o_am1.set_curr_img(frame)
+        trk1 = oracle.Tracker(sm_kind, o_am1, o_ssm1, **dict(params, sec_ord_hess=0))
+        trk1.initialize(corners[t]); o_am1.set_curr_img(frame_b); trk1.update()
+        assert rel(trk1.trace()[0]["H"], tr[0]["H"]) > 1e-4
+        # (MI's loops are not contractions everywhere: the final region is compared where the oracle itself converged)
+        if iters < params["max_iters"]:
+            np.testing.assert_allclose(final[t], trk.get_region(), rtol=0, atol=5e-3)
+    b.track_trace(0); b.close()
 
 
 @pytest.mark.parametrize("am", [L.AM_SSD, L.AM_NCC, L.AM_MI])
