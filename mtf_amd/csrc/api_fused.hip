@@ -24,10 +24,11 @@ static int check_sm(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const char 
 	}
 	if (b->desc.am == MTFHIP_AM_MI) {
 		/* fused MI iteration: every first-order Jacobian / Hessian type of the three search methods; with sec_ord_hess the Std types
-		 * (MI.cc:659-695: cmptInitHessian / cmptCurrHessian + sum_p df_dI(p) d2I_dp2(p)) -- the second-order SELF Hessian
-		 * (MI.cc:697-735, its own per-pixel weight and an initial Hessian of that form) stays with the per-function entry points */
-		if (sm->sec_ord_hess && !(sm->sm == MTFHIP_SM_ESM ? (sm->hess_type == 3 || sm->hess_type == 5) : sm->hess_type == 2))
-			return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: second-order MI Hessians of the self / sum types go through the per-function entry points", fn);
+		 * (MI.cc:659-695: cmptInitHessian / cmptCurrHessian + sum_p df_dI(p) d2I_dp2(p)) and the self types (MI.cc:697-735: the
+		 * current pixel Hessian under the self gradient factor; the initial self Hessian takes its second-order part at
+		 * initialize / setRegion).  SumOfStd keeps the materialising passes: not here. */
+		if (sm->sec_ord_hess && sm->sm == MTFHIP_SM_ESM && sm->hess_type == 4)
+			return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: the second-order SumOfStd Hessian of MI goes through the per-function entry points", fn);
 		return MTFHIP_OK;
 	}
 	if (b->desc.am != MTFHIP_AM_SSD) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: unknown appearance model", fn);
@@ -315,6 +316,15 @@ int lazy_try_similarity(mtfhip_batch *b) {
  * MI recompute passes are single-channel (mi_fast_ok). */
 static int fused_channels_ok(const mtfhip_batch *b, const char *fn) { (void)b; (void)fn; return MTFHIP_OK; }
 
+/* the initial self Hessian a search method keeps (NT/ESM.cc:133-141, NT/FCLK.cc:120-128, NT/ICLK.cc:96-118).  MI with sec_ord_hess: its
+ * second-order form (MI.cc:697-735) over the template's pixel Hessian, which is materialised for this one call. */
+static int init_self_hessian(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *H0) {
+	if (b->desc.am == MTFHIP_AM_MI && sm->sec_ord_hess && b->C == 1) {
+		TRY(mtfhip_ssm_cmpt_pix_hessian(b, b->d0_variant, MTFHIP_BUF_D2I0_DX2, MTFHIP_BUF_DI0_DX, MTFHIP_BUF_D2I0_DP2));
+		return mtfhip_am_cmpt_self_hessian2(b, MTFHIP_BUF_J0, MTFHIP_BUF_D2I0_DP2, H0);
+	}
+	return mtfhip_am_cmpt_self_hessian(b, MTFHIP_BUF_J0, H0);
+}
 int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	FLUSH(b);
 	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
@@ -343,7 +353,7 @@ int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	TRY(mtfhip_am_initialize_grad(b));
 	TRY(mtfhip_am_initialize_hess(b));
 	std::vector<double> H0((size_t)b->B * b->S * b->S), h0dev((size_t)b->B * 64, 0.0);
-	TRY(mtfhip_am_cmpt_self_hessian(b, MTFHIP_BUF_J0, H0.data()));
+	TRY(init_self_hessian(b, sm, H0.data()));
 	for (int t = 0; t < b->B; ++t) {
 		std::memset(b->th[t].h0, 0, sizeof(b->th[t].h0));
 		std::memcpy(b->th[t].h0, &H0[(size_t)t * b->S * b->S], sizeof(double) * b->S * b->S);
@@ -406,7 +416,8 @@ static int set_region_core(mtfhip_batch *b, const double *corners, const mtfhip_
 	const bool need_h0 = sm->hess_type == 0 || (sm->sm == MTFHIP_SM_ESM && sm->hess_type == 2);
 	if (need_h0) {
 		std::vector<double> H0((size_t)b->B * b->S * b->S), h0dev((size_t)b->B * 64, 0.0), hinv((size_t)b->B * 64, 0.0);
-		TRY(mtfhip_am_cmpt_self_hessian(b, MTFHIP_BUF_J0, H0.data()));
+		if (b->desc.am == MTFHIP_AM_MI && sm->sec_ord_hess) b->d0_variant = MTFHIP_JAC_INIT;   /* (setRegion: cmptInitPixHessian, NT/ESM.cc:160-163) */
+		TRY(init_self_hessian(b, sm, H0.data()));
 		for (int t = 0; t < b->B; ++t) {
 			std::memset(b->th[t].h0, 0, sizeof(b->th[t].h0));
 			std::memcpy(b->th[t].h0, &H0[(size_t)t * b->S * b->S], sizeof(double) * b->S * b->S);
@@ -450,8 +461,12 @@ int fused_args(const mtfhip_batch *b, const mtfhip_sm_desc *sm, FusedArgs &fa) {
 
 /* The second-order term an SSD search method adds to its Hessian (k_second_order_ssd's `term`), -1 for none:
  * SSD's self Hessians are first order by definition (SSDBase.h:95-98) and InitialSelf never looks at the frame. */
-static int second_order_term(const mtfhip_sm_desc *sm) {
+/* MI (am = MTFHIP_AM_MI): its self Hessian has a second-order form of its own (MI.cc:697-735) -- term 4, the current pixel Hessian
+ * weighted by sum_r gradIt(r) sum_t matIt(t) self_grad_factor(r, t) -- for CurrentSelf and ESM's SumOfSelf (whose other half, the
+ * initial self Hessian, carries its second-order part since initialize / setRegion). */
+static int second_order_term(const mtfhip_sm_desc *sm, int am = MTFHIP_AM_SSD) {
 	if (!sm->sec_ord_hess) return -1;
+	if (am == MTFHIP_AM_MI && (sm->hess_type == 1 || (sm->sm == MTFHIP_SM_ESM && sm->hess_type == 2))) return 4;
 	switch (sm->sm) {
 	case MTFHIP_SM_FCLK: return sm->hess_type == 2 ? 0 : -1;
 	case MTFHIP_SM_ESM: return sm->hess_type == 5 ? 0 : (sm->hess_type == 4 ? 1 : (sm->hess_type == 3 ? 2 : -1));
@@ -597,7 +612,6 @@ static MiFastPlan mi_fast_plan(const mtfhip_batch *b, const MiPlan &pl, const in
 }
 static int mi_gmode(const MiPlan &pl) { return pl.iclk ? 0 : (pl.fclk ? 1 : (pl.orig_jac ? 2 : 3)); }
 /* enqueues pass 1, the tables, pass 2 and the finish; do_track: the finish also solves, updates and tests convergence */
-static int second_order_term(const mtfhip_sm_desc *sm);
 /* so_own_pts: -1 no second-order term; 1 inside the device loop (points re-derived from the warp), 0 from CURR_PTS (iterate) */
 static int mi_enqueue_fast(mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPlan &pl, const int *active, const TrackState &ts, int do_track,
 	int so_own_pts = -1) {
@@ -618,7 +632,7 @@ static int mi_enqueue_fast(mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPl
 		/* sec_ord_hess: sum_p df_dI(p) d2I_dp2(p) with MI's own per-pixel gradients, from this iteration's tables (one more pixel pass) */
 		TimedScope tsc(b->ctx, "second_order");
 		const int nb2 = simple_blocks_per_target(b->N);
-		launch_second_order_ssd(bv, b->ctx->img, second_order_term(sm), sm->chained_warp ? 1 : 0, b->d0_variant, b->desc.grad_eps, b->hess_eps,
+		launch_second_order_ssd(bv, b->ctx->img, second_order_term(sm, MTFHIP_AM_MI), sm->chained_warp ? 1 : 0, b->d0_variant, b->desc.grad_eps, b->hess_eps,
 			b->norm_mult, b->norm_add, b->d_d2_part, nb2, b->d_d2_out, st, so_own_pts, SecondOrderNcc{nullptr, 0, nullptr},
 			SecondOrderMi{b->d_mi_tb, b->mi_hist_norm});
 	}
@@ -630,12 +644,12 @@ static int mi_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, doub
 	const int S = b->S;
 	hipStream_t st = b->ctx->stream;
 	const MiPlan pl(sm);
-	const int term = second_order_term(sm);
+	const int term = second_order_term(sm, MTFHIP_AM_MI);
 	const int S2 = S * S;
 	std::vector<double> so;
 	if (term >= 0) {
 		if (!mi_fast_ok(b, sm, pl)) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "iterate: second-order MI Hessians need the recompute passes (tolerance mode, 8 bins, nothing materialised)");
-		if (term != 0 && !b->init_pix_hess) return fail(MTFHIP_ERR_LOGIC, "iterate: init_template was run without sec_ord_hess");
+		if (term != 0 && term != 4 && !b->init_pix_hess) return fail(MTFHIP_ERR_LOGIC, "iterate: init_template was run without sec_ord_hess");
 		TRY(ensure_pts(b));
 		if (!b->d_d2_part) {
 			const int nb2 = simple_blocks_per_target(b->N);
@@ -671,7 +685,7 @@ static int mi_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, doub
 				: (pl.esm && sm->hess_type == 2) ? 0.5 * (hv + h.h0[k])
 				: pl.hk == MiPlan::H_SUM_STD ? 0.5 * (hv + H2[c * S + r])
 				: hv;
-			if (term >= 0) Ht[k] += so[(size_t)t * S2 + k];   /* (k_plane_sum_finish: entry (r, c) at c S + r, as Ht) */
+			if (term >= 0) Ht[k] += ((pl.esm && sm->hess_type == 2) ? 0.5 : 1.0) * so[(size_t)t * S2 + k];   /* (k_plane_sum_finish: entry (r, c) at c S + r, as Ht) */
 		}
 	}
 	return MTFHIP_OK;
@@ -897,11 +911,11 @@ static int track_validate(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	TRY(check_sm(b, sm, "track"));
 	TRY(fused_channels_ok(b, "track"));
 	if (sm->max_iters <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "track: max_iters must be positive");
-	const int so_term = second_order_term(sm);
+	const int so_term = second_order_term(sm, b->desc.am);
 	if (b->desc.am == MTFHIP_AM_MI && so_term >= 0 && !mi_fast_ok(b, sm, MiPlan(sm)))
 		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: second-order MI Hessians need the recompute passes (tolerance mode, 8 bins, nothing materialised)");
 	if (so_term >= 0 && b->C != 1) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: second-order Hessians of the multi-channel models use the per-function entry points");
-	if (so_term > 0 && !b->init_pix_hess) return fail(MTFHIP_ERR_LOGIC, "track: init_template was run without sec_ord_hess");
+	if (so_term > 0 && so_term != 4 && !b->init_pix_hess) return fail(MTFHIP_ERR_LOGIC, "track: init_template was run without sec_ord_hess");
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "track before init_template");
 	return need_image(b);
 }
@@ -909,7 +923,7 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 	FLUSH_AM(b);   /* (none of the loop's kernels reads CURR_PTS: they warp the template grid themselves) */
 	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
 	TRY(track_validate(b, sm));
-	const int so_term = second_order_term(sm);
+	const int so_term = second_order_term(sm, b->desc.am);
 	hipStream_t st = b->ctx->stream;
 	const bool mi = b->desc.am == MTFHIP_AM_MI;
 	/* (the one-launch grid kernel has no Levenberg-Marquardt: with it ICLK takes the fused launch + finish per pass) */
@@ -972,7 +986,8 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 			HIP_TRY(hipMalloc(&b->d_d2_part, sizeof(double) * 64 * (size_t)nb2 * b->B));
 			HIP_TRY(hipMalloc(&b->d_d2_out, sizeof(double) * 64 * (size_t)b->B));
 		}
-		ts.h_extra = b->d_d2_out; ts.h_extra_scale = so_term == 1 ? 0.5 : 1.0;
+		/* (halved with the rest of the sum: ESM SumOfStd, NT/ESM.cc:339; MI's SumOfSelf, NT/ESM.cc:333) */
+		ts.h_extra = b->d_d2_out; ts.h_extra_scale = (so_term == 1 || (so_term == 4 && sm->sm == MTFHIP_SM_ESM && sm->hess_type == 2)) ? 0.5 : 1.0;
 	}
 	{
 		/* tolerance mode + a definite first-order system: the register-resident finish (finish_track_fast_body) */

@@ -291,6 +291,7 @@ __global__ __launch_bounds__(64) void k_plane_sum_finish(const double *partials,
  *   term  1:  r * (D0 + Dt)          cmptSumOfHessians (2nd order), SSDBase.cc:377-415 (ESM SumOfStd)
  *   term  2: -r * ((D0 + Dt) / 2)    cmptCurrHessian on the mean pixel Hessian, NT/ESM.cc:324-327 (ESM Original)
  *   term  3:  r * D0                 cmptInitHessian (2nd order), SSDBase.cc:313-343   (ICLK Std)
+ *   term  4: (MI only) hist_grad_term * Dt   cmptSelfHessian (2nd order), MI.cc:697-735 (CurrentSelf, SumOfSelf)
  * d0_variant: how init_pix_hessian was produced (Warped at the identity warp by initialize, Init after setRegion).
  * With nc.rows set the weights are NCC's: term 0 df_dIt Dt (NCC.cc:401-410), 1 df_dIt Dt + df_dI0 D0, 2 df_dIt (D0 + Dt) / 2,
  * 3 df_dI0 D0 (NCC.cc:391-400).  With mi.tb set they are MI's per-pixel gradients, same assignment (MI.cc:659-695). */
@@ -305,14 +306,14 @@ __global__ __launch_bounds__(kBlock) void k_second_order_ssd(BatchView bv, ImgVi
 	 * sum_r gradI0(r) sum_c matIt(c) T_init(r, c) (MI.cc:406-415, 432-441) -- the gradient-factor tables of this iteration, staged
 	 * with the zero border the un-clamped windows index into ((bin + 1) in both directions, as pass 2 of the recompute form) */
 	constexpr int kTR = 12;
-	__shared__ double mi_tc[kTR * MI_NB], mi_ti[kTR * MI_NB];
+	__shared__ double mi_tc[kTR * MI_NB], mi_ti[kTR * MI_NB];   /* (term 4: mi_tc holds the self table) */
 	const bool is_mi = mi.tb != nullptr;
 	if (is_mi) {
 		const double *tb = mi.tb + (size_t)t * MI_SIZE;
 		for (int k = threadIdx.x; k < kTR * MI_NB; k += kBlock) {
 			const int r = k / MI_NB - 1, c = k % MI_NB - 1;
 			const bool in = r >= 0 && r < 8 && c >= 0 && c < 8;
-			mi_tc[k] = in ? tb[MI_T_CURR + r * MI_NB + c] : 0.0; mi_ti[k] = in ? tb[MI_T_INIT + r * MI_NB + c] : 0.0;
+			mi_tc[k] = in ? tb[(term == 4 ? MI_T_SELF : MI_T_CURR) + r * MI_NB + c] : 0.0; mi_ti[k] = in ? tb[MI_T_INIT + r * MI_NB + c] : 0.0;
 		}
 		__syncthreads();
 	}
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(kBlock) void k_second_order_ssd(BatchView bv, ImgVi
 	const double *cz = bv.buf[MTFHIP_BUF_CURR_Z] + (size_t)t * N;
 	const double *I0 = bv.buf[MTFHIP_BUF_I0] + (size_t)t * N;
 	const double *g0 = bv.buf[MTFHIP_BUF_DI0_DX] + (size_t)t * N * 2;
-	const double2 *h0 = term != 0 ? reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_D2I0_DX2] + (size_t)t * N * 4) : nullptr;
+	const double2 *h0 = (term != 0 && term != 4) ? reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_D2I0_DX2] + (size_t)t * N * 4) : nullptr;
 	const double heps2 = 2 * hess_eps;
 	const double hmult = norm_mult / (heps2 * heps2), gmult = norm_mult / (2 * grad_eps);
 	double acc[S * S];
@@ -449,12 +450,22 @@ __global__ __launch_bounds__(kBlock) void k_second_order_ssd(BatchView bv, ImgVi
 			}
 			wt = term == 0 ? dft : (term == 1 ? dft : (term == 2 ? dft / 2.0 : 0.0));
 			w0 = term == 1 ? df0 : (term == 2 ? dft / 2.0 : (term == 3 ? df0 : 0.0));
+			if (term == 4) {   /* MI.cc:710-723: hist_grad_term = sum_r gradIt(r) sum_t matIt(t) self_grad_factor(r, t) */
+				const double *T0 = mi_tc + a.row0 * MI_NB + a.row0;
+				double hg = 0;
+#pragma unroll
+				for (int r2 = 0; r2 < 4; ++r2) {
+					const double *Tr = T0 + r2 * MI_NB;
+					hg = fma(a.d[r2], fma(a.w[3], Tr[3], fma(a.w[2], Tr[2], fma(a.w[1], Tr[1], a.w[0] * Tr[0]))), hg);
+				}
+				wt = hg; w0 = 0.0;
+			}
 		}
 		if (term != 3) {
 #pragma unroll
 			for (int k = 0; k < S * S; ++k) acc[k] = fma(wt, d2[k], acc[k]);
 		}
-		if (term != 0) {
+		if (term != 0 && term != 4) {
 			const double2 ma = h0[2 * i], mb = h0[2 * i + 1];
 			pix_hessian_block<SSM>(d2, d0_variant, Wid, st0, p0.x, p0.y, p0.x, p0.y, 1.0, ma.x, ma.y, mb.x, mb.y, g0[i], g0[N + i]);
 #pragma unroll

@@ -179,8 +179,10 @@ __device__ __forceinline__ void finish_track_body(const BatchView &bv, const mtf
 			if (ht == 3) return n_hess(1, 2, r, c, kk) + ex;
 			return 0.5 * (n_hess(0, 0, r, c, kk) + n_hess(1, 1, r, c, kk)) + ex;
 		}
-		double v = use_h0 ? h0s[b2 * S + a] : -acc_s[ACC_H + kk];
-		if (sum_h0) v = (v + h0s[b2 * S + a]) * 0.5;
+		/* (the constant Hessian as entry (r, c), not from a triangle: MI's initial self Hessian with its second-order part is not
+		 * symmetric in the homography's last two rows / columns; every other one is, and reads the same numbers) */
+		double v = use_h0 ? h0s[c * S + r] : -acc_s[ACC_H + kk];
+		if (sum_h0) v = (v + h0s[c * S + r]) * 0.5;
 		/* sec_ord_hess: + sum_p df_dI[p] d2I_dp2[:, p] (SSDBase.cc:313-415); the homography blocks are not symmetric in their
 		 * last two rows / columns (Homography.cc:421,613,796), so the entry is taken as (r, c), not from a triangle */
 		if (ts.h_extra) v += ts.h_extra_scale * ts.h_extra[(size_t)t * S * S + c * S + r];

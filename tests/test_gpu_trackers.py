@@ -385,9 +385,9 @@ def test_device_loop_second_order_hessians(oracle, gpu_ctx, frame, sm_kind, ssm,
         trk1.initialize(corners[t]); o_am1.set_curr_img(frame_b); trk1.update()
         assert rel(trk1.trace()[0]["H"], tr[0]["H"]) > 1e-4   # (the parity gate above is 1e-5)
     b.track_trace(0); b.close()
-    # MI's second-order SELF Hessian stays with the per-function entry points; NCC has no second-order self Hessian (AppearanceModel.h:188-191)
+    # NCC has no second-order self Hessian (AppearanceModel.h:188-191)
     gpu_ctx.set_image(frame)
-    for bad_am, kw in ((L.AM_MI, dict(hess_type=1)), (L.AM_NCC, dict(hess_type=0))):
+    for bad_am, kw in ((L.AM_NCC, dict(hess_type=0)),):
         trk = LKTracker(gpu_ctx, L.SM_FCLK, L.SSM_HOMOGRAPHY, 30, 30, 2, host_solve=False, am=bad_am, sec_ord_hess=1, max_iters=5, **kw)
         with pytest.raises(mtf_amd.FunctionNotImplemented):
             trk.initialize(corners[:2])
@@ -399,7 +399,11 @@ def test_device_loop_second_order_hessians(oracle, gpu_ctx, frame, sm_kind, ssm,
     (L.SM_ESM, L.SSM_HOMOGRAPHY, dict(hess_type=5)), (L.SM_ESM, L.SSM_AFFINE, dict(hess_type=5, chained_warp=0)),
     (L.SM_ESM, L.SSM_AFFINE, dict(hess_type=3, jac_type=0)), (L.SM_FCLK, L.SSM_HOMOGRAPHY, dict(hess_type=2)),
     (L.SM_FCLK, L.SSM_AFFINE, dict(hess_type=2, chained_warp=0)), (L.SM_ICLK, L.SSM_AFFINE, dict(hess_type=2)),
-    (L.SM_ICLK, L.SSM_HOMOGRAPHY, dict(hess_type=2))],
+    (L.SM_ICLK, L.SSM_HOMOGRAPHY, dict(hess_type=2)),
+    # the self types (MI.cc:697-735): InitialSelf = the initial self Hessian with its second-order part, CurrentSelf, SumOfSelf
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, dict(hess_type=0)), (L.SM_ESM, L.SSM_AFFINE, dict(hess_type=1)), (L.SM_ESM, L.SSM_HOMOGRAPHY, dict(hess_type=2)),
+    (L.SM_FCLK, L.SSM_AFFINE, dict(hess_type=0)), (L.SM_FCLK, L.SSM_HOMOGRAPHY, dict(hess_type=1)), (L.SM_ICLK, L.SSM_AFFINE, dict(hess_type=0)),
+    (L.SM_ESM, L.SSM_AFFINE, dict(hess_type=1, chained_warp=0))],
     ids=lambda v: "_".join("%s%s" % kv for kv in v.items()) if isinstance(v, dict) else str(v))
 def test_device_loop_second_order_hessians_mi(oracle, gpu_ctx, frame, sm_kind, ssm, extra):
     """sec_ord_hess with MI in mtfhip_batch_iterate / mtfhip_batch_track (MI.cc:659-695: cmptInitHessian / cmptCurrHessian + sum_p df_dI(p)
