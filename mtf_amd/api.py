@@ -287,9 +287,13 @@ class Batch:
         self.cmpt_pix_jacobian(JAC_WARPED, grad_buf, dst_buf)
 
     def get_corners(self):
-        out = np.empty((self.B, 8))
-        L.check(L.lib().mtfhip_ssm_get_corners(self._h, _p(out)))
-        return self._corners_out(out)
+        g = self.__dict__.get("_gc")
+        if g is None:     # per-frame call: the buffer, its ctypes pointer (3-4 us to build) and the bound function are made once
+            out = np.empty((self.B, 8))
+            g = self._gc = (out, _p(out), L.lib().mtfhip_ssm_get_corners)
+        out, po, fn = g
+        L.check(fn(self._h, po))
+        return self._corners_out(out)   # (a copy)
 
     def get_state(self):
         out = np.empty((self.B, self.S))
@@ -481,10 +485,13 @@ class Batch:
         return f, g, H.transpose(0, 2, 1).copy()
 
     def track(self, sm):
-        n = np.empty(self.B, dtype=np.int32)
-        c = np.empty((self.B, 8))
-        L.check(L.lib().mtfhip_batch_track(self._h, C.byref(sm), _p(n), _p(c)))
-        return n, self._corners_out(c)
+        g = self.__dict__.get("_tk")
+        if g is None:     # (as get_corners: one update() per frame)
+            n, c = np.empty(self.B, dtype=np.int32), np.empty((self.B, 8))
+            g = self._tk = (n, c, _p(n), _p(c), L.lib().mtfhip_batch_track)
+        n, c, pn, pc, fn = g
+        L.check(fn(self._h, C.byref(sm), pn, pc))
+        return n.copy(), self._corners_out(c)
 
     def track_trace(self, max_passes):
         """debug trace of the device-side loop on (max_passes > 0) / off (0): mtfhip_batch_track_trace"""

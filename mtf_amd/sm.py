@@ -581,11 +581,15 @@ class ParticleFilter:
         return norm.value
 
     def update(self):
-        import ctypes as C
         if self.jacobian_as_sigma:
             self._jacobian_sigma()
-        n = C.c_int()
-        L.check(L.lib().mtfhip_pf_update(self._h, C.byref(n)))
+        u = self.__dict__.get("_upd")
+        if u is None:     # per-frame call: the out-parameter and the bound function are made once
+            import ctypes as C
+            n = C.c_int()
+            u = self._upd = (n, C.byref(n), L.lib().mtfhip_pf_update)
+        n, pn, fn = u
+        L.check(fn(self._h, pn))
         self.n_iters = n.value
         return self.batch.get_corners()
 
