@@ -400,25 +400,31 @@ __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, P
 		for (int k = 0; k < K; ++k) {
 			double it;
 			if constexpr (FAST) {
+				/* (this loop is bound by FP64 issue, ~35 double-rate instructions per candidate-pixel: the cell fractions come from
+				 * v_fract_f64 -- exact, the same bits as x - (double)(int)x for the non-negative coordinates the fast path accepts --
+				 * instead of convert-back + subtract.  A reciprocal with one Newton step instead of two saved as much again, but its
+				 * last-bit differences flip round(w n) ties of the residual resampler against the oracle: not taken.) */
 				double wx = fma(W[k][0], q.x, fma(W[k][1], q.y, uz ? W[k][2] : W[k][2] * z));
 				double wy = fma(W[k][3], q.x, fma(W[k][4], q.y, uz ? W[k][5] : W[k][5] * z));
 				if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
-					const double inv = rcp_fast(fma(W[k][6], q.x, fma(W[k][7], q.y, uz ? W[k][8] : W[k][8] * z)));
+					const double dd = fma(W[k][6], q.x, fma(W[k][7], q.y, uz ? W[k][8] : W[k][8] * z));
+					const double inv = rcp_fast(dd);
 					wx *= inv; wy *= inv;
 				}
 				const int lx = (int)wx, ly = (int)wy;
 				const bool ok = (wx >= 0) & (wy >= 0) & (lx < iw1) & (ly < ih1);
 				double v;
 				if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
+					const double fx = __builtin_amdgcn_fract(wx), fy = __builtin_amdgcn_fract(wy);
 					if constexpr (MC) {
 						const unsigned off = (unsigned)(ly * stride + lx * (int)Cc + ch) * 4u;
 						const float t00 = ld_off<float>(img, off), t01 = ld_off<float>(img, off + 4u * Cc);
 						const float t10 = ld_off<float>(img + stride, off), t11 = ld_off<float>(img + stride, off + 4u * Cc);
-						v = bilin_val_fast(t00, t01, t10, t11, wx - (double)lx, wy - (double)ly);
+						v = bilin_val_fast(t00, t01, t10, t11, fx, fy);
 					} else {
 						const unsigned off = (unsigned)(ly * stride + lx) * 4u;
 						const PfTexPair t0 = ld_off<PfTexPair>(img, off), t1 = ld_off<PfTexPair>(img + stride, off);
-						v = bilin_val_fast(t0.a, t0.b, t1.a, t1.b, wx - (double)lx, wy - (double)ly);
+						v = bilin_val_fast(t0.a, t0.b, t1.a, t1.b, fx, fy);
 					}
 				} else {
 					if constexpr (MC) v = pix_val_mc(im, wx, wy, ch); else v = pix_val_fast(im, wx, wy);
