@@ -269,3 +269,20 @@ def mi_curr_grad(I0n, Itn, n_bins=8, pre_seed=10.0):
     hj = (pre_seed + Bt @ B0.T) * norm
     G = 1.0 + np.log(hj) - np.log(hc)[:, None]
     return np.einsum("rp,rc,cp->p", -bspline3_d1(X) * norm, G, B0)
+
+
+# ------------------------------------------------------------------ sampler sigmas from a pixel sigma
+def estimate_state_sigma(init_pts, curr_pts, curr_D, pix_sigma, affine=False):
+    """StateSpaceModel::estimateStateSigma (SSM/src/ProjectiveBase.cc:201-213): state_sigma[k] = pix_sigma / mean_p |d pt_p / d state_k|, the
+    columns being getCurrPixGrad's -- Homography.cc:143-155 (rows [x y 1 0 0 0 -x cx -y cx] / D and [0 0 0 x y 1 -x cy -y cy] / D with
+    (x, y) the init point, (cx, cy) the current one, D the current homogeneous denominator), Affine.cc:152-158 ([1 0 x y 0 0], [0 1 0 0 x y])."""
+    x, y = init_pts
+    if affine:
+        r0 = np.stack([np.ones_like(x), np.zeros_like(x), x, y, np.zeros_like(x), np.zeros_like(x)])
+        r1 = np.stack([np.zeros_like(x), np.ones_like(x), np.zeros_like(x), np.zeros_like(x), x, y])
+    else:
+        cx, cy = curr_pts
+        z = np.zeros_like(x); o = np.ones_like(x)
+        r0 = np.stack([x, y, o, z, z, z, -x * cx, -y * cx]) / curr_D
+        r1 = np.stack([z, z, z, x, y, o, -x * cy, -y * cy]) / curr_D
+    return pix_sigma / np.sqrt(r0 ** 2 + r1 ** 2).mean(axis=1)

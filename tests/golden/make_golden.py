@@ -141,6 +141,16 @@ def main():
     out.update({"so_corners": corners, "so_p": pa, "so_img_hess_head": Hi[:16].reshape(16, 4), "so_pix_hess_head": D[:8],
                 "so_H_curr2": so_H})
 
+    # --- sampler sigmas from a pixel sigma (estimateStateSigma), at a non-identity state, both SSMs
+    ess_corners = synth.square_corners(96, 90, 64) + rng.uniform(-2, 2, size=(2, 4))
+    ess_p = synth.random_small_homography(rng, 0.4)
+    ip, ihm = R.grid_from_corners(ess_corners, 14, 11)
+    cp, chm = R.warp_pts(R.hom_matrix(ess_p), ihm)
+    ess_pa = rng.uniform(-1, 1, 6) * [1.5, 1.5, 0.03, 0.03, 0.03, 0.03]
+    ipa, _ = R.grid_from_corners(ess_corners, 14, 11, affine=True)
+    out.update({"ess_corners": ess_corners, "ess_p": ess_p, "ess_pa": ess_pa,
+                "ess_hom": R.estimate_state_sigma(ip, cp, chm[2], 1.3), "ess_aff": R.estimate_state_sigma(ipa, None, None, 1.3, affine=True)})
+
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lk_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

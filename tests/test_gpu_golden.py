@@ -116,3 +116,13 @@ def test_pf_scores_golden(gpu_ctx, gimg, math):
     lik = b.score_candidates(G["pf_states"])
     np.testing.assert_allclose(lik, G["pf_likelihood"], rtol=1e-9)
     b.close()
+
+
+def test_estimate_state_sigma_golden(gpu_ctx, gimg):
+    """mtfhip_ssm_estimate_state_sigma (StateSpaceModel::estimateStateSigma) against the fixture, at a non-identity state"""
+    for ssm, key, pkey in ((L.SSM_HOMOGRAPHY, "ess_hom", "ess_p"), (L.SSM_AFFINE, "ess_aff", "ess_pa")):
+        b = mtf_amd.Batch(gpu_ctx, L.AM_SSD, ssm, 14, 11, 1)
+        b.set_corners(G["ess_corners"][None])
+        b.set_state(G[pkey][None])
+        np.testing.assert_allclose(b.estimate_state_sigma(1.3)[0], G[key], rtol=1e-9)
+        b.close()

@@ -156,6 +156,16 @@ def test_pf_scores_golden(oracle, img):
     np.testing.assert_allclose(lik, G["pf_likelihood"], rtol=1e-9)
 
 
+def test_estimate_state_sigma_golden(oracle):
+    """StateSpaceModel::estimateStateSigma of the oracle against the NumPy restatement (ProjectiveBase.cc:201-213), at a non-identity state"""
+    ssm = oracle.SSM(oracle.SSM_HOM, 14, 11)
+    ssm.set_corners(G["ess_corners"]); ssm.set_state(G["ess_p"])
+    np.testing.assert_allclose(ssm.estimate_state_sigma(1.3), G["ess_hom"], rtol=1e-10)
+    ssa = oracle.SSM(oracle.SSM_AFF, 14, 11)
+    ssa.set_corners(G["ess_corners"]); ssa.set_state(G["ess_pa"])
+    np.testing.assert_allclose(ssa.estimate_state_sigma(1.3), G["ess_aff"], rtol=1e-10)
+
+
 def test_golden_generator_is_reproducible(tmp_path):
     """The committed fixture is exactly what the committed generator produces."""
     import subprocess, sys, shutil
