@@ -269,10 +269,10 @@ int mtfhip_am_cmpt_sum_of_hessians2(mtfhip_batch *b, int j0_buf, int jt_buf, int
  * returns MTFHIP_ERR_NOT_IMPLEMENTED and belongs to the per-function entry points above -- which defer and fuse the same
  * way internally when the call sequence is one of the search methods' ("Deferred fusion").
  * sec_ord_hess = 1 is honoured by init_template / iterate / track for SSD (SSDBase.cc:313-415), NCC (NCC.cc:391-410) and MI
- * (MI.cc:659-735, on its recompute passes: tolerance mode, 8 bins): one more pixel pass per iteration accumulates
+ * (MI.cc:659-735, 8 bins): one more pixel pass per iteration accumulates
  * sum_p df_dI[p] d2I_dp2[:, p] -- MI's self types: its self gradient factor as the weight -- without building the S^2 x N matrices,
  * and the device loop solves the then indefinite system with pivoting.  NCC's self Hessian types (no second-order cmptSelfHessian
- * in the reference, AppearanceModel.h:188-191), MI's SumOfStd and the multi-channel models return MTFHIP_ERR_NOT_IMPLEMENTED for it.
+ * in the reference, AppearanceModel.h:188-191), MI with another bin count and the multi-channel models return MTFHIP_ERR_NOT_IMPLEMENTED for it.
  * init_template = the body of nt::{ESM,FCLK,ICLK}::initialize after ssm->initialize
  * (NT/ESM.cc:110-146, NT/FCLK.cc:102-169, NT/ICLK.cc:71-128): I0, dI0_dx, J0 and the constant
  * Hessian from the current image at the current points. */

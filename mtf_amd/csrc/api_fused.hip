@@ -26,9 +26,7 @@ static int check_sm(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const char 
 		/* fused MI iteration: every first-order Jacobian / Hessian type of the three search methods; with sec_ord_hess the Std types
 		 * (MI.cc:659-695: cmptInitHessian / cmptCurrHessian + sum_p df_dI(p) d2I_dp2(p)) and the self types (MI.cc:697-735: the
 		 * current pixel Hessian under the self gradient factor; the initial self Hessian takes its second-order part at
-		 * initialize / setRegion).  SumOfStd keeps the materialising passes: not here. */
-		if (sm->sec_ord_hess && sm->sm == MTFHIP_SM_ESM && sm->hess_type == 4)
-			return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: the second-order SumOfStd Hessian of MI goes through the per-function entry points", fn);
+		 * initialize / setRegion).  Eight bins (the weights are read from the 8-bin gradient-factor tables). */
 		return MTFHIP_OK;
 	}
 	if (b->desc.am != MTFHIP_AM_SSD) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "%s: unknown appearance model", fn);
@@ -612,6 +610,15 @@ static MiFastPlan mi_fast_plan(const mtfhip_batch *b, const MiPlan &pl, const in
 }
 static int mi_gmode(const MiPlan &pl) { return pl.iclk ? 0 : (pl.fclk ? 1 : (pl.orig_jac ? 2 : 3)); }
 /* enqueues pass 1, the tables, pass 2 and the finish; do_track: the finish also solves, updates and tests convergence */
+/* sec_ord_hess: sum_p df_dI(p) d2I_dp2(p) with MI's own per-pixel gradients / self gradient factor, from this iteration's tables
+ * (d_mi_tb: filled by launch_mi_tables_iter in both forms of the iteration) -- one more pixel pass into d_d2_out */
+static void mi_second_order(mtfhip_batch *b, const mtfhip_sm_desc *sm, int own_pts) {
+	TimedScope tsc(b->ctx, "second_order");
+	const int nb2 = simple_blocks_per_target(b->N);
+	launch_second_order_ssd(b->view(), b->ctx->img, second_order_term(sm, MTFHIP_AM_MI), sm->chained_warp ? 1 : 0, b->d0_variant, b->desc.grad_eps,
+		b->hess_eps, b->norm_mult, b->norm_add, b->d_d2_part, nb2, b->d_d2_out, b->ctx->stream, own_pts, SecondOrderNcc{nullptr, 0, nullptr},
+		SecondOrderMi{b->d_mi_tb, b->mi_hist_norm});
+}
 /* so_own_pts: -1 no second-order term; 1 inside the device loop (points re-derived from the warp), 0 from CURR_PTS (iterate) */
 static int mi_enqueue_fast(mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPlan &pl, const int *active, const TrackState &ts, int do_track,
 	int so_own_pts = -1) {
@@ -628,14 +635,7 @@ static int mi_enqueue_fast(mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPl
 		TimedScope tsc(b->ctx, "mi_pass2");
 		launch_mi_pass_grad_hess(bv, b->ctx->img, fp, b->d_mi_part, nblk, st);
 	}
-	if (so_own_pts >= 0) {
-		/* sec_ord_hess: sum_p df_dI(p) d2I_dp2(p) with MI's own per-pixel gradients, from this iteration's tables (one more pixel pass) */
-		TimedScope tsc(b->ctx, "second_order");
-		const int nb2 = simple_blocks_per_target(b->N);
-		launch_second_order_ssd(bv, b->ctx->img, second_order_term(sm, MTFHIP_AM_MI), sm->chained_warp ? 1 : 0, b->d0_variant, b->desc.grad_eps, b->hess_eps,
-			b->norm_mult, b->norm_add, b->d_d2_part, nb2, b->d_d2_out, st, so_own_pts, SecondOrderNcc{nullptr, 0, nullptr},
-			SecondOrderMi{b->d_mi_tb, b->mi_hist_norm});
-	}
+	if (so_own_pts >= 0) mi_second_order(b, sm, so_own_pts);
 	launch_mi_finish_fast(bv, *sm, ts, fp, mi_gmode(pl), do_track, b->d_mi_part, nblk, b->d_mi_H, b->d_mi_H + 64 * (size_t)b->B, b->d_mi_red, st);
 	b->it_valid = b->dit_valid = b->jt_valid = false;
 	return MTFHIP_OK;
@@ -648,7 +648,7 @@ static int mi_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, doub
 	const int S2 = S * S;
 	std::vector<double> so;
 	if (term >= 0) {
-		if (!mi_fast_ok(b, sm, pl)) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "iterate: second-order MI Hessians need the recompute passes (tolerance mode, 8 bins, nothing materialised)");
+		if (b->desc.mi_n_bins != 8) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "iterate: second-order MI Hessians with other than 8 bins go through the per-function entry points");
 		if (term != 0 && term != 4 && !b->init_pix_hess) return fail(MTFHIP_ERR_LOGIC, "iterate: init_template was run without sec_ord_hess");
 		TRY(ensure_pts(b));
 		if (!b->d_d2_part) {
@@ -660,8 +660,10 @@ static int mi_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, doub
 	if (mi_fast_ok(b, sm, pl)) {
 		TrackState ts{b->d_acc, b->d_h0, b->d_corners, b->d_init_corners_hm, b->d_active, b->d_iters, nullptr, nullptr, 1, nullptr, nullptr};
 		TRY(mi_enqueue_fast(b, sm, pl, nullptr, ts, 0, term >= 0 ? 0 : -1));
-	} else
-	TRY(mi_enqueue(b, sm, pl, nullptr));
+	} else {
+		TRY(mi_enqueue(b, sm, pl, nullptr));
+		if (term >= 0) mi_second_order(b, sm, 0);
+	}
 	if (term >= 0) {
 		so.resize((size_t)S2 * b->B);
 		HIP_TRY(hipMemcpyAsync(so.data(), b->d_d2_out, sizeof(double) * so.size(), hipMemcpyDeviceToHost, st));
@@ -685,7 +687,7 @@ static int mi_iterate(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *f, doub
 				: (pl.esm && sm->hess_type == 2) ? 0.5 * (hv + h.h0[k])
 				: pl.hk == MiPlan::H_SUM_STD ? 0.5 * (hv + H2[c * S + r])
 				: hv;
-			if (term >= 0) Ht[k] += ((pl.esm && sm->hess_type == 2) ? 0.5 : 1.0) * so[(size_t)t * S2 + k];   /* (k_plane_sum_finish: entry (r, c) at c S + r, as Ht) */
+			if (term >= 0) Ht[k] += ((term == 1 || (pl.esm && sm->hess_type == 2)) ? 0.5 : 1.0) * so[(size_t)t * S2 + k];   /* (k_plane_sum_finish: entry (r, c) at c S + r, as Ht) */
 		}
 	}
 	return MTFHIP_OK;
@@ -912,8 +914,8 @@ static int track_validate(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	TRY(fused_channels_ok(b, "track"));
 	if (sm->max_iters <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "track: max_iters must be positive");
 	const int so_term = second_order_term(sm, b->desc.am);
-	if (b->desc.am == MTFHIP_AM_MI && so_term >= 0 && !mi_fast_ok(b, sm, MiPlan(sm)))
-		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: second-order MI Hessians need the recompute passes (tolerance mode, 8 bins, nothing materialised)");
+	if (b->desc.am == MTFHIP_AM_MI && so_term >= 0 && b->desc.mi_n_bins != 8)
+		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: second-order MI Hessians with other than 8 bins go through the per-function entry points");
 	if (so_term >= 0 && b->C != 1) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "track: second-order Hessians of the multi-channel models use the per-function entry points");
 	if (so_term > 0 && so_term != 4 && !b->init_pix_hess) return fail(MTFHIP_ERR_LOGIC, "track: init_template was run without sec_ord_hess");
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "track before init_template");
@@ -1011,6 +1013,7 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 				TRY(mi_enqueue_fast(b, sm, pl, b->d_active, ts, 1, so_term >= 0 ? 1 : -1));
 			} else {
 				TRY(mi_enqueue(b, sm, pl, b->d_active, false));
+				if (so_term >= 0) mi_second_order(b, sm, 1);
 				launch_finish_track_mi(bv, *sm, ts, pl.hk == MiPlan::H_SUM_STD, gmode, b->d_mi_H, b->d_partials, ng, b->d_mi_red, st);
 			}
 			if (all_converged(b->d_active, b->B, it)) break;

@@ -403,7 +403,10 @@ def test_device_loop_second_order_hessians(oracle, gpu_ctx, frame, sm_kind, ssm,
     # the self types (MI.cc:697-735): InitialSelf = the initial self Hessian with its second-order part, CurrentSelf, SumOfSelf
     (L.SM_ESM, L.SSM_HOMOGRAPHY, dict(hess_type=0)), (L.SM_ESM, L.SSM_AFFINE, dict(hess_type=1)), (L.SM_ESM, L.SSM_HOMOGRAPHY, dict(hess_type=2)),
     (L.SM_FCLK, L.SSM_AFFINE, dict(hess_type=0)), (L.SM_FCLK, L.SSM_HOMOGRAPHY, dict(hess_type=1)), (L.SM_ICLK, L.SSM_AFFINE, dict(hess_type=0)),
-    (L.SM_ESM, L.SSM_AFFINE, dict(hess_type=1, chained_warp=0))],
+    (L.SM_ESM, L.SSM_AFFINE, dict(hess_type=1, chained_warp=0)),
+    # SumOfStd keeps the materialising passes (two Hessian passes); `replay`: the materialising passes for a type the recompute form also has
+    (L.SM_ESM, L.SSM_HOMOGRAPHY, dict(hess_type=4)), (L.SM_ESM, L.SSM_AFFINE, dict(hess_type=4, chained_warp=0)),
+    (L.SM_FCLK, L.SSM_HOMOGRAPHY, dict(hess_type=2, replay=1)), (L.SM_ESM, L.SSM_AFFINE, dict(hess_type=1, replay=1))],
     ids=lambda v: "_".join("%s%s" % kv for kv in v.items()) if isinstance(v, dict) else str(v))
 def test_device_loop_second_order_hessians_mi(oracle, gpu_ctx, frame, sm_kind, ssm, extra):
     """sec_ord_hess with MI in mtfhip_batch_iterate / mtfhip_batch_track (MI.cc:659-695: cmptInitHessian / cmptCurrHessian + sum_p df_dI(p)
@@ -417,8 +420,11 @@ def test_device_loop_second_order_hessians_mi(oracle, gpu_ctx, frame, sm_kind, s
     corners = np.stack([synth.square_corners(200.0 + 60 * i, 230.0 + 25 * i, 90) + 0.25 * i for i in range(B)])
     params = dict(leven_marq=0, max_iters=10, epsilon=1e-5, sec_ord_hess=1)
     params.update(extra)
+    replay = params.pop("replay", 0)
     gpu_ctx.set_image(frame)
     b = mtf_amd.Batch(gpu_ctx, L.AM_MI, ssm, res, res, B)
+    if replay:
+        b.set_math_mode(mtf_amd.MATH_REPLAY)
     b.set_corners(corners)
     sm = mtf_amd.sm_desc(sm_kind, materialize=0, **params)
     b.init_template(sm)
