@@ -16,9 +16,9 @@ __global__ __launch_bounds__(kBlock, MTFHIP_FUSED_WAVES) void k_fused_ncc(BatchV
 	fused_lk_body<MTFHIP_AM_NCC, SSM, CHAINED, MODE, MAT>(bv, im, fa, partials, nblk);
 }
 /* tolerance-mode lean launches (see fused_lk_body) */
-template <int AM, int SSM, int MODE>
+template <int AM, int SSM, int MODE, bool CHAINED>
 __global__ __launch_bounds__(kBlock, MTFHIP_FAST_WAVES) void k_fused_fast(BatchView bv, ImgView im, FusedArgs fa, double *partials, int nblk) {
-	fused_lk_body<AM, SSM, true, MODE, false, true>(bv, im, fa, partials, nblk);
+	fused_lk_body<AM, SSM, CHAINED, MODE, false, true>(bv, im, fa, partials, nblk);
 }
 
 
@@ -100,9 +100,12 @@ static void launch_fused_mode(const BatchView &bv, const ImgView &im, const Fuse
 template <int AM, int SSM>
 static void launch_fused_fast(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk, hipStream_t st) {
 	dim3 g = grid2(nblk, bv.B);
-	if (fa.mode == 0) MTFHIP_LAUNCH((k_fused_fast<AM, SSM, 0>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
-	else if (fa.mode == 1) MTFHIP_LAUNCH((k_fused_fast<AM, SSM, 1>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
-	else MTFHIP_LAUNCH((k_fused_fast<AM, SSM, 2>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
+	/* (ICLK takes no gradient: one instantiation) */
+	if (fa.mode == 2) MTFHIP_LAUNCH((k_fused_fast<AM, SSM, 2, true>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
+	else if (fa.mode == 0 && fa.chained) MTFHIP_LAUNCH((k_fused_fast<AM, SSM, 0, true>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
+	else if (fa.mode == 0) MTFHIP_LAUNCH((k_fused_fast<AM, SSM, 0, false>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
+	else if (fa.chained) MTFHIP_LAUNCH((k_fused_fast<AM, SSM, 1, true>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
+	else MTFHIP_LAUNCH((k_fused_fast<AM, SSM, 1, false>), g, dim3(kBlock), 0, st, bv, im, fa, partials, nblk);
 }
 void launch_fused_ssd(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk,
 	hipStream_t st) {

@@ -66,9 +66,7 @@ static void launch_persist_mode(const BatchView &bv, const ImgView &im, const Fu
 	double *partials, int nblk, const PersistState &ps, int max_passes, hipStream_t st) {
 	const dim3 g = grid2(nblk, bv.B);
 #define MTFHIP_PERSIST(CH, MD) MTFHIP_LAUNCH((k_track_persist<AM, SSM, CH, MD, FAST>), g, dim3(kBlock), 0, st, bv, im, fa, sm, ts, partials, nblk, ps, max_passes)
-	if constexpr (FAST) {   /* (the tolerance-mode row is the same for both routes: instantiated chained) */
-		if (fa.mode == 0) MTFHIP_PERSIST(true, 0); else if (fa.mode == 1) MTFHIP_PERSIST(true, 1); else MTFHIP_PERSIST(true, 2);
-	} else if (fa.chained) {
+	if (fa.chained || (FAST && fa.mode == 2)) {   /* (ICLK takes no gradient: the tolerance-mode body is instantiated once for it) */
 		if (fa.mode == 0) MTFHIP_PERSIST(true, 0); else if (fa.mode == 1) MTFHIP_PERSIST(true, 1); else MTFHIP_PERSIST(true, 2);
 	} else {
 		if (fa.mode == 0) MTFHIP_PERSIST(false, 0); else if (fa.mode == 1) MTFHIP_PERSIST(false, 1); else MTFHIP_PERSIST(false, 2);

@@ -125,6 +125,15 @@ __device__ __forceinline__ double rcp_fast(double d) {
 	e = fma(-d, r, 1.0);
 	return fma(r, e, r);
 }
+/* The step the reference's central difference actually takes.  imgUtils.cc:233-254 samples at fl(w + eps) and fl(w - eps): on a
+ * coordinate of a few hundred pixels eps = 1e-8 is rounded to the coordinate's ulp grid (2^-44 in [256, 512): 175 921.86 ulps become
+ * 175 922), a SYSTEMATIC relative error of ~8e-7 .. 1e-5 of every gradient that the division by the nominal 2 eps does not undo.
+ * Inside one bilinear cell inc - dec = slope * (fl(w + eps) - fl(w - eps)) exactly (the subtraction of the two neighbours is
+ * exact), so the closed-form slope times this step is the reference's value without its per-pixel rounding noise.
+ * fd_step_sym: the same for a step that is not the nominal eps (updateGradPts' eps * warp column); both neighbours are rounded on
+ * the grid of w's binade, so the up-step is the down-step except across a power of two (one grid unit on one pixel). */
+__device__ __forceinline__ double fd_step(double w, double eps) { return (w + eps) - (w - eps); }
+__device__ __forceinline__ double fd_step_sym(double w, double e) { const double h = (w + e) - w; return h + h; }
 /* bilinear interpolant of one cell and its two partial derivatives at fractional position (dx, dy):
  *   v = t00 + dx a + dy b + dx dy c,  dv/dx = a + dy c,  dv/dy = b + dx c   (a = t01 - t00, b = t10 - t00, c = t11 - t10 - a)
  * The reference's central difference with step 1e-8 (imgUtils.cc:233-254) of this function is exactly dv/dx, dv/dy

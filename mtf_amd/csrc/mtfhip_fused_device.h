@@ -73,19 +73,27 @@ struct Tex {
  * NCC's similarity, Jacobians and first-order Hessians are functions of (NCC.cc:124-389 restated in ncc_from_moments,
  * api_fused.hip) -- Gram(row) | sum Jt | sum It Jt | sum I0 Jt | sum It J0 | sum It, It^2, I0 It -- so an NCC iteration
  * needs no second pass over the pixels for the means; the partial rows are NCC_ACC_COUNT wide. */
-/* FAST (lean launches only, MAT = false, instantiated with CHAINED = true): tolerance-mode arithmetic -- one reciprocal
- * per point, FMA-contracted warp / interpolant / rows, and the closed-form gradient of the bilinear interpolant instead of
- * its 1e-8 central difference on the wave-uniform interior path (on integer coordinates, cell edges and the border the wave
- * falls back to the replay of the reference's five samples, SURVEY A4's corner case).  The chained and the non-chained
- * route (Homography.cc:803-827 + cmptInitPixJacobian) are the same mathematical row, so FAST serves both. */
+/* FAST (lean launches only, MAT = false): tolerance-mode arithmetic -- one reciprocal per point, FMA-contracted warp / interpolant /
+ * rows, and on the wave-uniform interior path the closed-form slope of the bilinear cell times the ROUNDED step the reference's 1e-8
+ * central difference takes (fd_step, mtfhip_device.h) instead of four more samples: the reference's gradient without its per-pixel
+ * rounding noise but WITH its systematic step quantisation, which is what brings H / g / dp inside 1e-5 of the reference-parameter
+ * oracle.  The chained route (getImgGrad at the warped point) and the non-chained route (Homography.cc:803-827 / Affine.cc:293-313 +
+ * cmptInitPixJacobian) are the same mathematical row but quantise differently, so both are instantiated (r04; r03 served both with
+ * the chained form).  On integer coordinates, cell edges and the border the wave falls back to the replay of the reference's five
+ * samples, SURVEY A4's corner case. */
 /* PERSIST (kernels_persist.hip): the body runs once per iteration inside one launch; the warp and the state were written by another
  * workgroup a moment ago, so they are read with agent-scope loads and moved back to scalar registers (a plain load of memory the
  * kernel itself modifies would be kept in vector registers: 26 of them). */
-__device__ __forceinline__ double uniform_fresh_load(const double *p) {
-	const double v = ld_coh(p);
+/* the general sampler as a real call: the rare path's registers do not count against the row loop's */
+__device__ __attribute__((noinline)) double pix_val_call(const float *data, int w, int h, int stride, double x, double y) {
+	ImgView im; im.data = data; im.w = w; im.h = h; im.stride = stride;
+	return pix_val(im, x, y);
+}
+__device__ __forceinline__ double to_uniform(double v) {
 	const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
 	return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double uniform_fresh_load(const double *p) { return to_uniform(ld_coh(p)); }
 /* MC (kernels_fused_mc.hip): the multi-channel models -- MCSSD / MCNCC = SSD / NCC constructed with n_channels = 3 (AM/src/MCSSD.cc)
  * -- through the same pass.  A row of every per-pixel array is a (pixel, channel) pair, row = pixel * C + channel
  * (mc::getPixVals imgUtils.cc:867-882): the grid point is the pixel's, the texels are the channel's (interleaved image), and
@@ -101,6 +109,26 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 	constexpr int K = NCC ? NCC_ACC_COUNT : 48;
 	constexpr int ROW_LEN = NCC ? NCC_ACC_COUNT : ACC_COUNT;
 	__shared__ double lds[4 * K];
+	/* NCC + ESM carries 71 accumulators (142 VGPRs) and every instantiation of it sat at the 256-register limit with reloads inside the
+	 * row loop (r03: 36-140 B of scratch per lane).  The sixteen sums that are touched once per row and feed nothing in the row -- sum
+	 * I0 Jt and sum It J0 -- live in LDS instead (one slot per thread and sum, ds_add_f64 without return: the LDS pipe, not a VALU
+	 * slot) and come back into the accumulator row just before the workgroup reduction. */
+	constexpr bool PARK = NCC && MODE == 1;
+	static_assert(NCC_ITJ0 == NCC_I0J + 8, "the parked accumulators are one contiguous run");
+	/* PARK_I0J: sum I0 Jt parked as well (what the instantiation needs to stay clear of scratch, from -Rpass-analysis=kernel-resource-usage) */
+#ifndef MTFHIP_PARK_FAST_CHAINED
+#define MTFHIP_PARK_FAST_CHAINED 0   /* measured r04 (64 x 200 x 200 lean): 0 -> 26.7 us with 14 registers in scratch, 8 -> 28.4, 16 -> 29.9 */
+#endif
+	constexpr int NPARK = !PARK ? 0 : ((FAST && CHAINED) ? MTFHIP_PARK_FAST_CHAINED : 16);
+	constexpr bool PARK_I0J = NPARK == 16, PARK_ITJ0 = NPARK >= 8;
+	__shared__ double park[NPARK ? 16 * kBlock : 1];
+	auto park_add = [&](int a, double v) {
+		(void)__builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)&park[a * kBlock + (int)threadIdx.x], v);
+	};
+	if constexpr (NPARK > 0) {
+#pragma unroll
+		for (int a = 0; a < 16; ++a) park[a * kBlock + threadIdx.x] = 0.0;
+	}
 	const int t = blockIdx.y;
 	const unsigned N = (unsigned)bv.N;
 	/* The per-target scalars (live flag, warp, state) sit a scalar-load round trip behind the kernel arguments and
@@ -150,6 +178,14 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 	double ex0, ex1, ex2, ey0, ey1, ey2;
 	double aa, ab, ac, ad;   /* affine a,b,c,d (Affine.cc:216-217) */
 	auto setup_target = [&]() {
+		if constexpr (!PERSIST) {
+			/* wsrc / st are generic pointers (kernarg segment or global), so the loads above are vector loads of a wave-uniform address
+			 * and the warp would sit in 26 VGPRs for the whole pass (r03 ISA): move it to scalar registers here, behind the first row's
+			 * vector loads (nothing waits for the warp before this point) */
+#pragma unroll
+			for (int q = 0; q < 9; ++q) W.m[q] = to_uniform(W.m[q]);
+			st2 = to_uniform(st2); st3 = to_uniform(st3); st4 = to_uniform(st4); st5 = to_uniform(st5);
+		}
 		ex0 = W.m[0] * eps; ex1 = W.m[3] * eps; ex2 = W.m[6] * eps;
 		ey0 = W.m[1] * eps; ey1 = W.m[4] * eps; ey2 = W.m[7] * eps;
 		aa = st2 + 1; ab = st3; ac = st4; ad = st5 + 1;
@@ -259,7 +295,7 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 		const unsigned o8 = i * 8u;
 		/* the four finite-difference sample points */
 		double px0, py0, px1, py1, px2, py2, px3, py3;
-		if constexpr (MODE != 2) {
+		auto fd_points = [&]() {
 			if constexpr (CHAINED) {
 				/* utils::getImgGrad at the warped point (imgUtils.cc:233-254) */
 				px0 = wx + eps; py0 = wy; px1 = wx - eps; py1 = wy;
@@ -279,9 +315,28 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 				px0 = wx + ex0; py0 = wy + ex1; px1 = wx - ex0; py1 = wy - ex1;
 				px2 = wx + ey0; py2 = wy + ey1; px3 = wx - ey0; py3 = wy - ey1;
 			}
+		};
+		constexpr bool QSTEP = FAST && !CHAINED && MODE != 2;   /* tolerance mode, non-chained: rounded steps instead of the four points */
+		if constexpr (MODE != 2 && !QSTEP) fd_points();
+		/* QSTEP: px0 - px1, py0 - py1 (x direction) and px2 - px3, py2 - py3 (y direction) of updateGradPts, taken of the ROUNDED
+		 * numerators and denominators (Homography.cc:803-827: px = (cx +- ex0) / (D +- ex2), to second order in eps
+		 * px0 - px1 = ((n0 - n1) - wx (d0 - d1)) / D; Affine.cc:293-313: px = wx +- ex0) */
+		double dpx_x = 0, dpy_x = 0, dpx_y = 0, dpy_y = 0;
+		if constexpr (QSTEP && SSM == MTFHIP_SSM_HOMOGRAPHY) {
+			const double inv = tcur.inv;
+			const double dd_x = fd_step_sym(D, ex2), dd_y = fd_step_sym(D, ey2);
+			dpx_x = fma(-wx, dd_x, fd_step_sym(cx, ex0)) * inv; dpy_x = fma(-wy, dd_x, fd_step_sym(cy, ex1)) * inv;
+			dpx_y = fma(-wx, dd_y, fd_step_sym(cx, ey0)) * inv; dpy_y = fma(-wy, dd_y, fd_step_sym(cy, ey1)) * inv;
+		} else if constexpr (QSTEP) {
+			dpx_x = fd_step_sym(wx, ex0); dpy_x = fd_step_sym(wy, ex1); dpx_y = fd_step_sym(wx, ey0); dpy_y = fd_step_sym(wy, ey1);
 		}
 		bool fast = tcur.ok;
-		if constexpr (MODE != 2 && CHAINED) {
+		if constexpr (QSTEP) {
+			/* all four points strictly inside the cell, with the whole step as the margin where half of it would do (a few more
+			 * waves than necessary take the five-sample path, which is the reference's own arithmetic) */
+			const double mx = fmax(fabs(dpx_x), fabs(dpx_y)), my = fmax(fabs(dpy_x), fabs(dpy_y));
+			fast = fast & (wx - mx > lxd) & (wx + mx < lxd + 1) & (wy - my > lyd) & (wy + my < lyd + 1);
+		} else if constexpr (MODE != 2 && CHAINED) {
 			/* axis-aligned neighbours of a centre that is strictly inside the cell (eps > 0, rounding is monotonic):
 			 * wx + eps >= wx > lx and wx - eps <= wx < lx + 1 hold already, so in_cell reduces to the other bound */
 			fast = fast & (px0 < lxd + 1) & (px1 > lxd) & (py2 < lyd + 1) & (py3 > lyd);
@@ -298,7 +353,15 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 			double v, bgx, bgy;
 			bilin_fast(tcur.t00, tcur.t01, tcur.t10, tcur.t11, wx - lxd, wy - lyd, v, bgx, bgy);
 			it = fma(fa.norm_mult, v, fa.norm_add);
-			if constexpr (MODE != 2) { gx = bgx * fa.norm_mult; gy = bgy * fa.norm_mult; }
+			if constexpr (MODE != 2 && CHAINED) {
+				/* utils::getImgGrad (imgUtils.cc:233-254) inside one cell: inc - dec = slope * ((wx + eps) - (wx - eps)) exactly,
+				 * the ROUNDED step included (fd_step, mtfhip_device.h) */
+				gx = bgx * (fd_step(wx, eps) * gmult); gy = bgy * (fd_step(wy, eps) * gmult);
+			} else if constexpr (MODE != 2) {
+				/* getWarpedImgGrad (imgUtils.cc:177-202) inside one cell: inc - dec = slope_x (px0 - px1) + slope_y (py0 - py1)
+				 * (the cross term x0 y0 - x1 y1 = (x0 - x1) ybar + (y0 - y1) xbar is inside the slopes at the centre) */
+				gx = fma(bgx, dpx_x, bgy * dpy_x) * gmult; gy = fma(bgx, dpx_y, bgy * dpy_y) * gmult;
+			}
 		} else if (!FAST && __builtin_amdgcn_ballot_w64(!fast) == 0) {
 			const double t00 = tcur.t00, t01 = tcur.t01, t10 = tcur.t10, t11 = tcur.t11;
 			auto bl = [&](double dx, double dy) { if constexpr (MC) return bilin_mc(t00, t01, t10, t11, dx, dy); else return bilin(t00, t01, t10, t11, dx, dy); };
@@ -316,6 +379,7 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 			const int ch = cur.ch;
 			it = fa.norm_mult * pix_val_mc(im, wx, wy, ch) + fa.norm_add;
 			if constexpr (MODE != 2) {
+				if constexpr (QSTEP) fd_points();
 				gx = (pix_val_mc(im, px0, py0, ch) - pix_val_mc(im, px1, py1, ch)) * gmult;
 				gy = (pix_val_mc(im, px2, py2, ch) - pix_val_mc(im, px3, py3, ch)) * gmult;
 			}
@@ -323,10 +387,11 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 			/* border / integer coordinates / cell edges in a tolerance-mode launch: the reference's five samples one after the other
 			 * (utils::getPixVal + getImgGrad, imgUtils.h:91-113, imgUtils.cc:233-254).  Rare, so written for few live registers, not
 			 * for speed: the cached-cell form below keeps a dozen values alive across the hot loop's accumulators. */
-			it = fa.norm_mult * pix_val(im, wx, wy) + fa.norm_add;
+			it = fa.norm_mult * pix_val_call(img, iw, ih_, istride, wx, wy) + fa.norm_add;
 			if constexpr (MODE != 2) {
-				gx = (pix_val(im, px0, py0) - pix_val(im, px1, py1)) * gmult;
-				gy = (pix_val(im, px2, py2) - pix_val(im, px3, py3)) * gmult;
+				if constexpr (QSTEP) fd_points();
+				gx = (pix_val_call(img, iw, ih_, istride, px0, py0) - pix_val_call(img, iw, ih_, istride, px1, py1)) * gmult;
+				gy = (pix_val_call(img, iw, ih_, istride, px2, py2) - pix_val_call(img, iw, ih_, istride, px3, py3)) * gmult;
 			}
 		} else {
 			const Cell c = load_cell(im, wx, wy);
@@ -348,22 +413,86 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 		}
 		if constexpr (MAT) st_off<double>(It, o8, it);
 
+		if constexpr (FAST) {
+			/* Tolerance mode: the same sums, ordered for short live ranges (r04: the NCC instantiations sat at 256 VGPRs with reloads
+			 * inside the row loop).  A steepest-descent row is linear in the pixel's (Ix, Iy) -- row = L(x, y) (Ix, Iy) for every SSM
+			 * and route -- so the template's row is consumed before the current one is built, and ESM's mean row (hess_mean) is rebuilt
+			 * from the mean gradient instead of keeping both rows alive. */
+			constexpr bool HOM = SSM == MTFHIP_SSM_HOMOGRAPHY;
+			auto sd_row = [&](double *o, double Ix, double Iy) {
+				if constexpr (HOM) hom_row_fast(o, Ix, Iy, x, y);   /* Homography.cc:166-186, 282-289 */
+				else { o[0] = Ix; o[1] = Iy; o[2] = Ix * x; o[3] = Ix * y; o[4] = Iy * x; o[5] = Iy * y; o[6] = o[7] = 0.0; }   /* Affine.cc:160-182 */
+			};
+			double Ix0 = 0.0, Iy0 = 0.0;
+			double r0[8];
+			if constexpr (MODE != 0) {
+				if constexpr (JR) {
+					/* Warped at the identity = gradient / z, Init = gradient (z folds to 1 in the unit-z instantiation; affine: z = 1) */
+					Ix0 = cur.j0[0]; Iy0 = cur.j0[1];
+					if constexpr (HOM) { const double inv0 = fa.j0_init_variant ? 1.0 : 1.0 / cur.z; Ix0 *= inv0; Iy0 *= inv0; }
+					sd_row(r0, Ix0, Iy0);
+				} else {
+#pragma unroll
+					for (int s = 0; s < S; ++s) r0[s] = cur.j0[s];
+				}
+#pragma unroll
+				for (int s = 0; s < S; ++s) {
+					if constexpr (PARK_ITJ0) park_add(8 + s, it * r0[s]);
+					else if constexpr (NCC) acc[NCC_ITJ0 + s] = fma(it, r0[s], acc[NCC_ITJ0 + s]);
+					else acc[36 + s] = fma(MODE == 1 ? -r : r, r0[s], acc[36 + s]);
+				}
+			}
+			if constexpr (MODE != 2) {
+				double Ix, Iy;
+				if constexpr (!CHAINED) {
+					Ix = gx; Iy = gy;   /* cmptInitPixJacobian of the warped image's gradient */
+				} else if constexpr (HOM) {
+					/* Homography.cc:252-264 with the point's reciprocal reused */
+					const double dwx_dx = fma(-W.m[6], wx, W.m[0]), dwx_dy = fma(-W.m[7], wx, W.m[1]);
+					const double dwy_dx = fma(-W.m[6], wy, W.m[3]), dwy_dy = fma(-W.m[7], wy, W.m[4]);
+					Ix = fma(dwx_dx, gx, dwy_dx * gy) * tcur.inv;
+					Iy = fma(dwx_dy, gx, dwy_dy * gy) * tcur.inv;
+				} else {
+					Ix = fma(gx, aa, gy * ac); Iy = fma(gx, ab, gy * ad);   /* Affine.cc:213-242, factored */
+				}
+				double row[8];
+				sd_row(row, Ix, Iy);
+#pragma unroll
+				for (int s = 0; s < S; ++s) {
+					if constexpr (NCC) {
+						acc[NCC_SJ + s] += row[s];
+						acc[NCC_ITJ + s] = fma(it, row[s], acc[NCC_ITJ + s]);
+						if constexpr (PARK_I0J) park_add(s, cur.i0 * row[s]);
+						else acc[NCC_I0J + s] = fma(cur.i0, row[s], acc[NCC_I0J + s]);
+					} else {
+						acc[36 + s] = fma(-r, row[s], acc[36 + s]);
+					}
+				}
+				if constexpr (MODE == 1) {
+					if (fa.hess_mean) {
+						if constexpr (JR) sd_row(row, 0.5 * (Ix0 + Ix), 0.5 * (Iy0 + Iy));
+						else {
+#pragma unroll
+							for (int s = 0; s < S; ++s) row[s] = 0.5 * (r0[s] + row[s]);
+						}
+					}
+				}
+				int k = 0;
+#pragma unroll
+				for (int a = 0; a < 8; ++a)
+#pragma unroll
+					for (int b = a; b < 8; ++b) {
+						if (a < S && b < S) acc[k] = fma(row[a], row[b], acc[k]);
+						++k;
+					}
+			}
+			return;
+		}
+
 		double row[8];
 		if constexpr (MODE != 2) {
 			if constexpr (MAT) { st_off<double>(dIt, o8, gx); st_off<double>(dIt + N, o8, gy); }
-			if constexpr (FAST && SSM == MTFHIP_SSM_HOMOGRAPHY) {
-				/* the same row (Homography.cc:252-289) with the point's reciprocal reused and FMAs */
-				const double inv_det = tcur.inv;
-				const double dwx_dx = fma(-W.m[6], wx, W.m[0]), dwx_dy = fma(-W.m[7], wx, W.m[1]);
-				const double dwy_dx = fma(-W.m[6], wy, W.m[3]), dwy_dy = fma(-W.m[7], wy, W.m[4]);
-				const double Ix = fma(dwx_dx, gx, dwy_dx * gy) * inv_det;
-				const double Iy = fma(dwx_dy, gx, dwy_dy * gy) * inv_det;
-				hom_row_fast(row, Ix, Iy, x, y);
-			} else if constexpr (FAST) {
-				const double Ix = fma(gx, aa, gy * ac), Iy = fma(gx, ab, gy * ad);   /* Affine.cc:213-242, factored */
-				row[0] = Ix; row[1] = Iy; row[2] = Ix * x; row[3] = Ix * y; row[4] = Iy * x; row[5] = Iy * y;
-				row[6] = row[7] = 0.0;
-			} else if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+			if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
 				if constexpr (CHAINED) {
 					/* Homography::cmptWarpedPixJacobian SSM/src/Homography.cc:231-294 */
 					double inv_det = 1.0 / D;
@@ -403,14 +532,7 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 		if constexpr (MODE != 0) {
 			if constexpr (JR) {
 				const double g0x = cur.j0[0], g0y = cur.j0[1];
-				if constexpr (FAST && SSM == MTFHIP_SSM_HOMOGRAPHY) {
-					/* Warped at the identity = gradient / z, Init = gradient (z folds to 1 in the unit-z instantiation) */
-					const double inv0 = fa.j0_init_variant ? 1.0 : 1.0 / cur.z;
-					hom_row_fast(r0, g0x * inv0, g0y * inv0, x, y);
-				} else if constexpr (FAST) {
-					r0[0] = g0x; r0[1] = g0y; r0[2] = g0x * x; r0[3] = g0x * y; r0[4] = g0y * x; r0[5] = g0y * y;
-					r0[6] = r0[7] = 0.0;
-				} else if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+				if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
 					double Ix0 = g0x, Iy0 = g0y;
 					if (!fa.j0_init_variant) {   /* produced by cmptWarpedPixJacobian at the identity warp (chained initialize) */
 						const double inv_det0 = 1.0 / cur.z;
@@ -441,12 +563,16 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 				for (int s = 0; s < S; ++s) {
 					acc[NCC_SJ + s] += row[s];
 					acc[NCC_ITJ + s] = fma(it, row[s], acc[NCC_ITJ + s]);
-					acc[NCC_I0J + s] = fma(cur.i0, row[s], acc[NCC_I0J + s]);
+					if constexpr (PARK_I0J) park_add(s, cur.i0 * row[s]);
+					else acc[NCC_I0J + s] = fma(cur.i0, row[s], acc[NCC_I0J + s]);
 				}
 			}
 			if constexpr (MODE != 0) {
 #pragma unroll
-				for (int s = 0; s < S; ++s) acc[NCC_ITJ0 + s] = fma(it, r0[s], acc[NCC_ITJ0 + s]);
+				for (int s = 0; s < S; ++s) {
+					if constexpr (PARK_ITJ0) park_add(8 + s, it * r0[s]);
+					else acc[NCC_ITJ0 + s] = fma(it, r0[s], acc[NCC_ITJ0 + s]);
+				}
 			}
 			if constexpr (MODE == 1) {
 				if (fa.hess_mean) {
@@ -535,6 +661,10 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 	}
 	if (!live) return;
 	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * ROW_LEN;
+	if constexpr (NPARK > 0) {   /* (a thread's LDS operations execute in order: its own sums are complete) */
+#pragma unroll
+		for (int a = PARK_I0J ? 0 : 8; a < (PARK_ITJ0 ? 16 : 8); ++a) acc[NCC_I0J + a] = park[a * kBlock + threadIdx.x];
+	}
 	block_reduce_store<K, PERSIST>(acc, dst, lds);
 	if (!PERSIST && fa.inline_warp && blockIdx.x == 0 && threadIdx.x < 17) {   /* keep the device copy current for whoever reads it next */
 		const double v = kw[threadIdx.x];   /* iw[9] | is[8] */

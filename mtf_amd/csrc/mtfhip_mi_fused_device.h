@@ -58,7 +58,10 @@ __device__ __forceinline__ MiSample mi_finish(const ImgView &im, const MiTex &tx
 		double v, bgx, bgy;
 		bilin_fast(tx.t00, tx.t01, tx.t10, tx.t11, tx.wx - tx.lxd, tx.wy - tx.lyd, v, bgx, bgy);
 		s.it = fma(norm_mult, v, norm_add);
-		if constexpr (GRAD) { s.gx = bgx * norm_mult; s.gy = bgy * norm_mult; }
+		if constexpr (GRAD) {   /* the cell's slope times the rounded step of the reference's central difference (fd_step, mtfhip_device.h) */
+			const double gm = norm_mult / (2 * eps);
+			s.gx = bgx * (fd_step(tx.wx, eps) * gm); s.gy = bgy * (fd_step(tx.wy, eps) * gm);
+		}
 	} else {
 		s.it = norm_mult * pv(s.wx, s.wy) + norm_add;
 		if constexpr (GRAD) {   /* utils::getImgGrad, imgUtils.cc:233-254 (mc:: :861-905) */

@@ -267,12 +267,13 @@ def _fused_follow(oracle, gpu_ctx, frame, am, case, materialize, grid):
     assert len(trace) >= 2
     tight = grid == "oracle_grid"
     b.set_math_mode(mtf_amd.MATH_REPLAY)
-    # Tolerance-mode arithmetic (the lean launch: FMA, one reciprocal per point, CLOSED-FORM gradient of the interpolant) is
-    # checked against TWO oracles.  The reference's grad_eps = 1e-8 step is quantised by the coordinates it is added to
-    # (ulp(250) / 1e-8 = 5.7e-6 relative on every gradient, up to ~1.1e-5 on the entries of H that are sums of squares of the
-    # largest rows): that noise is the oracle's, not the device's.  So (i) the same restatement run with grad_eps = 1e-6 -- a
-    # hundred times less quantisation noise, still no truncation error because the interpolant is linear along each axis -- must
-    # agree to 2e-6, which pins the closed form itself, and (ii) the reference's own 1e-8 trace must agree to its noise floor.
+    # Tolerance-mode arithmetic (the lean launch: FMA, one reciprocal per point, the CLOSED-FORM slope of the bilinear cell times the
+    # ROUNDED step of the reference's central difference -- fd_step, mtfhip_device.h) is held to the reference-parameter oracle
+    # (grad_eps = 1e-8): the step 1e-8 is quantised by the coordinates it is added to (175 921.86 ulps of a coordinate in [256, 512)
+    # become 175 922: a systematic ~1e-6 .. 1e-5 on every gradient), r03's closed form did not carry that factor and sat 1e-5 from
+    # the oracle in H; r04's does: (ii) H and g within 2e-6, dp within north_star's 1e-5.  (i) The same restatement run with
+    # grad_eps = 1e-6 (a hundred times less quantisation) is now the farther one: its distance is bounded by the quantisation itself
+    # and recorded.
     o_am6 = oracle.AM(am, res, res, grad_eps=1e-6); o_ssm6 = oracle.SSM(ssm, res, res)
     o_am6.set_curr_img(frame); o_ssm6.set_corners(corners)
     trk6 = oracle.Tracker(sm_kind, o_am6, o_ssm6, **dict(params, max_iters=1))
@@ -288,27 +289,28 @@ def _fused_follow(oracle, gpu_ctx, frame, am, case, materialize, grid):
             # (i) against the low-noise oracle at the device's current state
             o_ssm6.set_state(b.get_state()[0]); trk6.update(); r6 = trk6.trace()[0]
             assert rel(ff[0], r6["f"]) < 1e-8, it
-            assert rel(Hf[0], r6["H"]) < 2e-6, it
-            assert np.linalg.norm(gf[0] - r6["g"]) < 2e-6 * max(np.linalg.norm(r6["g"]), gs), it
-            # measured, not just bounded: the distances of this case go to the parity record (profiles/r03_parity_record.jsonl)
+            assert rel(Hf[0], r6["H"]) < 2e-5, it
+            assert np.linalg.norm(gf[0] - r6["g"]) < 2e-5 * max(np.linalg.norm(r6["g"]), gs), it
+            # measured, not just bounded: the distances of this case go to the parity record (profiles/r04_parity_record.jsonl)
             fast_vs_6["H"] = max(fast_vs_6["H"], rel(Hf[0], r6["H"])); fast_vs_8["H"] = max(fast_vs_8["H"], rel(Hf[0], rec["H"]))
             fast_vs_6["g"] = max(fast_vs_6["g"], float(np.linalg.norm(gf[0] - r6["g"]) / max(np.linalg.norm(r6["g"]), gs)))
             fast_vs_8["g"] = max(fast_vs_8["g"], float(np.linalg.norm(gf[0] - rec["g"]) / max(np.linalg.norm(rec["g"]), gs)))
             if it <= 1:
                 fast_vs_6["dp"] = max(fast_vs_6["dp"], rel(dpf, r6["dp"])); fast_vs_8["dp"] = max(fast_vs_8["dp"], rel(dpf, rec["dp"]))
             if it <= 1 and am != L.AM_MI:
-                assert rel(gf[0], r6["g"]) < 1e-5 and rel(dpf, r6["dp"]) < 1e-5, it     # plain relative while g, dp are far from zero
-            # (ii) against the reference's own arithmetic, to ITS noise floor
+                assert rel(gf[0], r6["g"]) < 2e-5 and rel(dpf, r6["dp"]) < 2e-5, it     # plain relative while g, dp are far from zero
+                assert rel(gf[0], rec["g"]) < 1e-5 and rel(dpf, rec["dp"]) < 1e-5, it
+            # (ii) against the reference's own arithmetic
             assert rel(ff[0], rec["f"]) < 1e-8, it
-            assert rel(Hf[0], rec["H"]) < 2e-5, it
-            assert np.linalg.norm(gf[0] - rec["g"]) < 1e-5 * max(np.linalg.norm(rec["g"]), gs), it
+            assert rel(Hf[0], rec["H"]) < (1e-5 if am == L.AM_MI else 2e-6), it
+            assert np.linalg.norm(gf[0] - rec["g"]) < (1e-5 if am == L.AM_MI else 2e-6) * max(np.linalg.norm(rec["g"]), gs), it
             cf = b.apply_warp_to_corners(corners[None], dpf[None])[0]
             cr = b.apply_warp_to_corners(corners[None], rec["dp"][None])[0]
             if am == L.AM_MI:   # the oracle's own dp moves by 1.5e-5 .. 2.8e-5 here when grad_eps goes from 1e-8 to 2e-8, or
                 # chained_warp from 1 to 0 (tests/test_oracle_relations.py::test_mi_update_noise_floor): that is the floor
-                assert rel(dpf, rec["dp"]) < 5e-5 or np.abs(cf - cr).max() < 1e-5, it
+                assert rel(dpf, rec["dp"]) < 1e-5 or np.abs(cf - cr).max() < 1e-5, it
             else:
-                assert rel(dpf, rec["dp"]) < 2e-5 or np.abs(cf - cr).max() < 1e-6, it
+                assert rel(dpf, rec["dp"]) < 1e-5 or np.abs(cf - cr).max() < 1e-6, it
         f, g, H = b.iterate(sm)
         dp = -oracle.colpiv_qr_solve(H[0], g[0])
         if it <= 1 and not tight:    # plain relative errors while g and dp are far from zero (north_star's literal wording)
@@ -393,9 +395,9 @@ def _device_loop_per_iteration(oracle, gpu_ctx, frame, frame2, corners, sm_kind,
     """The device-side loop against the CPU trackers ITERATION BY ITERATION (mtfhip_batch_track_trace).
     (a) injected: every oracle iteration k is replayed as ONE pass of the device loop (the loop's own kernels: fused pass + finish,
         or the one-launch grid kernel) started from the oracle's state before k -- identical inputs, so H_k, g_k, dp_k compare
-        directly: replay arithmetic against the reference-parameter oracle (grad_eps 1e-8) within north_star's 1e-5; the
-        tolerance-mode arithmetic against the low-noise oracle (grad_eps 1e-6) within 1e-5 (measured ~1e-6), and its distance to
-        the 1e-8 oracle -- that oracle's own finite-difference noise -- is RECORDED per case (profiles/r03_parity_record.jsonl).
+        directly: replay AND tolerance-mode arithmetic against the reference-parameter oracle (grad_eps 1e-8) within north_star's
+        1e-5 (r04: the tolerance mode carries the reference's rounded finite-difference step, fd_step); its distance to the low-noise
+        oracle (grad_eps 1e-6) is RECORDED per case (profiles/r04_parity_record.jsonl).
     (b) free running: the whole loop in one call, every pass compared with the oracle's own trajectory relative to the size of
         the first update (later updates shrink towards zero, so their plain relative error measures nothing)."""
     B = corners.shape[0]
@@ -423,7 +425,7 @@ def _device_loop_per_iteration(oracle, gpu_ctx, frame, frame2, corners, sm_kind,
     gpu_ctx.set_image(frame2)
     b.track_trace(params["max_iters"])
     worst = {}
-    for mode, name, eps_ref in ((mtf_amd.MATH_REPLAY, "replay", 1e-8), (mtf_amd.MATH_FAST, "fast", 1e-6)):
+    for mode, name, eps_ref in ((mtf_amd.MATH_REPLAY, "replay", 1e-8), (mtf_amd.MATH_FAST, "fast", 1e-8)):
         b.set_math_mode(mode)
         # ---- (a) injected single passes along the oracle's trajectory
         ref = traces[eps_ref]
@@ -467,9 +469,9 @@ def _device_loop_per_iteration(oracle, gpu_ctx, frame, frame2, corners, sm_kind,
                         w[q] = max(w[q], e[q])
                 w["corners_px"] = max(w.get("corners_px", 0.0), e["corners_px"])
                 assert ok, (name, t, k, e)
-                if name == "fast" and k < len(traces[1e-8][t]) and k <= 1:
+                if name == "fast" and k < len(traces[1e-6][t]) and k <= 1:
                     # the two oracles share a trajectory only while their own difference is small: the first iterations
-                    e8 = _trace_errors(recs[t][0], traces[1e-8][t][k], am)
+                    e8 = _trace_errors(recs[t][0], traces[1e-6][t][k], am)
                     for q in w8:
                         w8[q] = max(w8[q], e8[q])
                 dp = ref[t][k]["dp"]
@@ -480,7 +482,7 @@ def _device_loop_per_iteration(oracle, gpu_ctx, frame, frame2, corners, sm_kind,
             b.compositional_update(upd)
         worst[name] = w
         if name == "fast":
-            worst["fast_vs_grad_eps_1e-8_first_two_iterations"] = w8
+            worst["fast_vs_grad_eps_1e-6_first_two_iterations"] = w8
         # ---- (b) the free-running loop
         b.set_corners(corners)
         n_it, final = b.track(smN)
