@@ -361,6 +361,23 @@ int mtfhip_pf_set_comm(mtfhip_pf *pf, mtfhip_comm *c) {
 			HIP_TRY(hipMalloc(&pf->d_wts, sizeof(double) * need));
 			pf->wts_capacity = need;
 		}
+		/* Every rank scores a block of ITS OWN proposals and resamples from the gathered weights: the design relies on the ranks
+		 * drawing identical proposals, i.e. on one Philox key.  One 8-byte all-gather at set-up makes a mismatch an error instead of a
+		 * silently wrong estimate (r03 advisor finding: a front end that randomised seed 0 per process). */
+		hipStream_t st = pf->b->ctx->stream;
+		double mine; static_assert(sizeof(mine) == sizeof(pf->d.seed), "the seed travels as the bits of one double");
+		std::memcpy(&mine, &pf->d.seed, sizeof(mine));
+		std::vector<double> all((size_t)c->world);
+		HIP_TRY(hipMemcpyAsync(pf->d_wts + c->rank, &mine, sizeof(double), hipMemcpyHostToDevice, st));
+		TRY(mtfhip_allgather_scores(c, pf->d_wts + c->rank, 1, pf->d_wts, st));
+		HIP_TRY(hipMemcpyAsync(all.data(), pf->d_wts, sizeof(double) * (size_t)c->world, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		for (int q = 0; q < c->world; ++q)
+			if (std::memcmp(&all[(size_t)q], &mine, sizeof(double)) != 0) {
+				pf->comm = nullptr;
+				return fail(MTFHIP_ERR_INVALID_ARG, "pf_set_comm: rank %d's filter was created with another seed than rank %d's: a sharded filter needs "
+					"ONE seed on every rank (identical proposals)", q, c->rank);
+			}
 	}
 	return MTFHIP_OK;
 }

@@ -419,6 +419,10 @@ class Comm:
         dist.broadcast_object_list(box, src=0)
         return cls(rank, world, device, box[0])
 
+    def world_as_seen(self):
+        """the communicator's own rank count (mtfhip_comm_world)"""
+        return int(L.lib().mtfhip_comm_world(self._h))
+
     def allgather(self, dev_send, count, dev_recv, stream=None):
         import ctypes as C
         L.check(L.lib().mtfhip_allgather_scores(self._h, C.c_void_p(dev_send), int(count), C.c_void_p(dev_recv),
@@ -449,6 +453,11 @@ class ParticleFilter:
         thresh * n (PF.cc:381-390); jacobian_as_sigma: the sampler's sigma of every frame is the Gauss-Newton step -H0^-1 g (PF.cc:58-64,
         156-165, 214-227)"""
         import ctypes as C
+        # seed 0 = "draw one" (below) -- but only an unsharded filter may: the ranks of a sharded one must propose identical particles
+        # (each scores a block of ITS proposals, the all-gather mixes the weights), so there seed 0 is refused before anything is
+        # created (mtfhip_pf_set_comm cross-checks the seeds of all ranks as well)
+        if not seed and comm is not None and comm.world > 1:
+            raise ValueError("ParticleFilter(comm=...) over %d ranks needs an explicit non-zero seed shared by every rank" % comm.world)
         rows_s = [list(ssm_sigma)] if np.ndim(ssm_sigma) == 1 else [list(r) for r in ssm_sigma]
         rows_m = [list(ssm_mean)] if np.ndim(ssm_mean) == 1 else [list(r) for r in ssm_mean]
         self.pix_sigma = None

@@ -1018,6 +1018,30 @@ def test_pf_sharded_loopback_equals_unsharded(frame, world, n, cfg):
                 assert np.array_equal(a, b), "rank %d iteration %d: %s differ from the unsharded filter" % (r, it, what)
 
 
+def test_pf_sharded_filter_refuses_mismatched_seeds(frame):
+    """every rank of a sharded filter scores a block of ITS OWN proposals: ranks with different Philox keys would mix the weights of
+    different particle sets.  mtfhip_pf_set_comm gathers the seeds once and refuses (r03 advisor finding); the Python front end refuses
+    seed 0 (= draw one per process) with a communicator of more than one rank before anything is created."""
+    from mtf_amd.sm import Comm
+    world = 2
+    comms = Comm.loopback(world)
+
+    def run(r):
+        ctx = mtf_amd.Context(0)
+        ctx.set_image(frame)
+        try:
+            with pytest.raises(mtf_amd.MtfHipError, match="seed"):
+                ParticleFilter(ctx, L.SSM_HOMOGRAPHY, 20, 20, n_particles=64, seed=11 + r, comm=comms[r])
+            with pytest.raises(ValueError, match="seed"):
+                ParticleFilter(ctx, L.SSM_HOMOGRAPHY, 20, 20, n_particles=64, seed=0, comm=comms[r])
+        finally:
+            ctx.close()
+        return True
+    assert all(_run_ranks(world, run))
+    for c in comms:
+        c.close()
+
+
 def test_pf_shard_bounds_and_inplace_allgather(gpu_ctx):
     """mtfhip_pf_shard_bounds is the partition the sharded filter uses, and the loopback all-gather in its in-place form leaves
     the flat vector on every rank (ragged world: the last block is short, the tail of the buffer is padding)"""
