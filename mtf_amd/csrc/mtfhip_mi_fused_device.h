@@ -105,13 +105,29 @@ struct MiPassArgs {
  * block products into that class's accumulators -- Q_rel[fl][k][m][s] -- plus one for sum hess_term J J^T.  ~20 groups x 3
  * = 60 matrix instructions per chunk instead of 144; the classes are folded into the absolute table once per workgroup. */
 #ifndef MTFHIP_MI_RS2
-#define MTFHIP_MI_RS2 100
+#define MTFHIP_MI_RS2 104
 #endif
 #ifndef MTFHIP_MI_QR
 #define MTFHIP_MI_QR 64
 #endif
 constexpr int kQR = MTFHIP_MI_QR;     /* row stride (doubles) of a wave's absolute table Q[r][c][s]: 64 = dense */
-constexpr int kRS2 = MTFHIP_MI_RS2;   /* slot-major row stride: >= 64 + 8 * 3 padded slots; 100 = 4 mod 32 keeps 4 rows x 4 slots on 16 banks */
+constexpr int kRS2 = MTFHIP_MI_RS2;   /* row stride of the sorted staging rows: >= 96 columns (64 + 8 * 3 padded slots, rounded up to whole steps of 16);
+                                        * 104 = 8 mod 32: the four rows x eight columns a half-wave reads in one step land on 32 different 8-byte banks */
+static_assert(kRS2 >= 96 && kRS2 % 32 == 8, "sorted staging rows: one step of 16 columns per read, rows 8 banks apart");
+/* Physical column of sorted slot s (r04).  A step of the group loop reads 16 consecutive COLUMNS = one class-aligned quad of every
+ * block; lane (li, lb, lk) of the 4x4x4 block products works on block lb's quad, member lk.  The block index sits in the LOW bits of
+ * the column (a half-wave's eight columns are 0..7 of the window, consecutive, not {0, 1, 4, 5, 8, 9, 12, 13}). */
+/* column of member m of block b's quad in step j: the window of step j is columns [16 j, 16 j + 16); the block index is skewed by
+ * j / 2 so that consecutive quads of a block -- consecutive lanes of the staging stores -- fall on different banks: member -> 4 m,
+ * step parity -> 16, (b + j / 2) & 3 -> the low two bits: eight consecutive quads cover the 32 banks once (measured without the skew:
+ * the 17 staging stores ran 3-way conflicted, +90 us on the pass) */
+__device__ __forceinline__ int window_col(int j, int b, int m) { return 16 * j + ((b + (j >> 1)) & 3) + 4 * m; }
+__device__ __forceinline__ int sorted_col(int s, int qb /* quads per block = steps of the chunk */) {
+	const int q = s >> 2, m = s & 3;
+	const int b = (q >= qb ? 1 : 0) + (q >= 2 * qb ? 1 : 0) + (q >= 3 * qb ? 1 : 0);   /* block b takes the quads [b qb, (b + 1) qb): contiguous in sorted order */
+	const int j = q - b * qb;
+	return window_col(j, b, m);
+}
 __device__ __forceinline__ void lds_add_f64(double *p, double v) {
 	(void)__builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)p, v);
 }
@@ -173,6 +189,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 	if constexpr (SORTED) { for (int k2 = lane; k2 < SLAB; k2 += 64) sd[k2] = 0.0; }
 	else if constexpr (HK != 0) { for (int k2 = 0; k2 < 2 * kWinRows + 9; ++k2) gd[k2 * kRS + lane] = 0.0; }
 	__syncthreads();
+#ifdef MTFHIP_MI_DESYNC   /* experiment: the two workgroups that share a CU start half a chunk apart (matrix phase of one under the sampling phase of the other) */
+	if (((blockIdx.y * gridDim.x + blockIdx.x) >> 8) & 1) __builtin_amdgcn_s_sleep(MTFHIP_MI_DESYNC);
+#endif
 	const unsigned N = (unsigned)bv.N;            /* rows: (pixel, channel) pairs */
 	const unsigned NPt = MC ? (unsigned)bv.NP : N, Cc = MC ? (unsigned)bv.C : 1u;
 	auto pix_of = [&](unsigned i) -> unsigned { if constexpr (MC) return Cc == 3u ? i / 3u : i / Cc; else return i; };
@@ -187,7 +206,12 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 	double acc[16];
 #pragma unroll
 	for (int k = 0; k < 16; ++k) acc[k] = 0.0;
-	double cq[8], chs = 0.0;   /* dense: (Rg, Cg, Sg) blocks; sorted: two running accumulators, flushed per class */
+	double cq[8], chs = 0.0;   /* dense: (Rg, Cg, Sg) blocks */
+	double chs4[4] = {0.0, 0.0, 0.0, 0.0};   /* sorted: the four 4 x 4 tiles of sum hess_term J J^T, per block = per quad of pixels (summed over the blocks at the end) */
+	/* sorted: Q_rel[t][m = lk][s = 4 h + li] of the class this lane's block is in, q<t><h>; carried ACROSS chunks (a block leaves its
+	 * class only when its next quad is of another one) */
+	double q00 = 0, q01 = 0, q10 = 0, q11 = 0, q20 = 0, q21 = 0, q30 = 0, q31 = 0;
+	int cls = 8;   /* 8: none */
 #pragma unroll
 	for (int k = 0; k < 8; ++k) cq[k] = 0.0;
 	const int li = lane & 3, lb = (lane >> 2) & 3, lk = lane >> 4;
@@ -314,75 +338,89 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 #else
 			const ClassSort cs = class_sort8(valid ? a.row0 : -1);
 #endif
+			const int steps = (cs.total + 15) >> 4;   /* quads per block */
+			const int mycol = sorted_col(cs.slot, steps);
 			if (valid) {
 #pragma unroll
-				for (int k = 0; k < 4; ++k) { sd[k * kRS2 + cs.slot] = a.d[k]; sw[k * kRS2 + cs.slot] = a.w[k]; }
+				for (int k = 0; k < 4; ++k) { sd[k * kRS2 + mycol] = a.d[k]; sw[k * kRS2 + mycol] = a.w[k]; }
 #pragma unroll
-				for (int s2 = 0; s2 < 8; ++s2) srw[s2 * kRS2 + cs.slot] = jt[s2];
-				sht[cs.slot] = hess_term;
+				for (int s2 = 0; s2 < 8; ++s2) srw[s2 * kRS2 + mycol] = jt[s2];
+				sht[mycol] = hess_term;
 			}
 			__builtin_amdgcn_wave_barrier();
-			/* groups of four slots in slot order; the operands of the next group are requested before the current one's block
-			 * products are issued (padding slots carry a zero gradient tap and a zero hess_term: reading one group past the end
-			 * is harmless).  At a class boundary the two running accumulators -- Q_rel[fl][k][m][s half] -- are added into this
-			 * wave's absolute table: Q[(fl - 1 + k, fl - 1 + m)][s]. */
-			const double *pd = sd + lb * kRS2 + lk, *pw = sw + li * kRS2 + lk, *pr0 = srw + li * kRS2 + lk, *pr1 = pr0 + 4 * kRS2;
-			const double *pht = sht + lk;
-			const bool hx = (lb >> 1) != 0, hy = (lb & 1) != 0;   /* sum hess_term J J^T: block (lb >> 1, lb & 1) of the 8 x 8, from the J operands already held */
-			int c = 0;
-			while (((cs.ends >> (8 * c)) & 255) == 0) ++c;   /* first class with pixels (a chunk has at least one) */
-			int bound = (int)((cs.ends >> (8 * c)) & 255);
-			double acc0 = 0.0, acc1 = 0.0;
-			/* two groups per trip, each group's operands requested two groups ahead (one group ahead the LDS latency was exposed
-			 * behind three block products in every trip).  An odd number of groups ends with an all-zero padding group: slots
-			 * behind the last class keep a zero gradient tap and a zero hess_term, and kRS2 leaves room for the look-ahead. */
-			auto flush_if = [&](int end) {
-				if (end == bound) {
-					const int r = c - 1 + lb, cc = c - 1 + lk;   /* result lane: block = k, row = m, column = s in its half */
-					if (r >= 0 && r < nb && cc >= 0 && cc < nb) {
-						double *qe = qabs + r * kQR + cc * 8 + li;
-						/* ds_add_f64 without return: the wave is the only writer of its table, so the sum is the same as a
-						 * read-modify-write -- which cost an LDS round trip behind the accumulators' matrix products at every
-						 * class boundary (up to eight per chunk) */
-						lds_add_f64(qe, acc0); lds_add_f64(qe + 4, acc1);
-					}
-					acc0 = 0.0; acc1 = 0.0;
-					do { ++c; } while (c < 8 && (int)((cs.ends >> (8 * c)) & 255) <= end);
-					bound = c < 8 ? (int)((cs.ends >> (8 * c)) & 255) : 1 << 30;
-				}
+			/* r04: steps of SIXTEEN pixels.  The four blocks of a 4x4x4 product are four quads of pixels (r03: the four gradient taps of
+			 * one quad), so a lane works on ONE pixel per step -- its block's quad, member lk -- and reads that pixel's weight tap li,
+			 * its four gradient taps, J[li], J[4 + li] and hess_term: 8 operands per lane per 16 pixels where the tap-block form read 5
+			 * per 4 (20 per 16).  The group loop was bound by the CU's LDS pipe (80 LDS against 48 matrix cycles per round of four
+			 * groups); now the twelve block products of a step (4 taps x 2 halves of J into Q_rel[t][m][s], 2 x 2 tiles of sum hess_term
+			 * J J^T) are what a step costs.  The price: a block's accumulators belong to the class of ITS quad.  Block b takes the quads
+			 * [b steps, (b + 1) steps) of the sorted order, so it crosses each class boundary of its range once; when its next quad is of
+			 * another class its sums go to the wave's absolute table through ds_add_f64 (measured: with the quads dealt round-robin and a
+			 * flush at every chunk end the four blocks hit the same addresses at the same time -- the adds were 210 us of a 420 us pass).
+			 * Slots behind the last class keep a zero gradient tap and a zero hess_term: a partly filled range adds zeros. */
+			const double *pw = sw + li * kRS2, *pd = sd, *pja = srw + li * kRS2, *pjb = pja + 4 * kRS2, *pht = sht;   /* + this lane's column of the step */
+			/* class of the quad that starts at slot s0 = number of classes that end at or before it (empty classes included: they end
+			 * where their predecessor does); byte-wise on the packed end slots, no borrow between bytes: (s0 | 0x80) - end >= 0x80 - 88 > 0 */
+			const unsigned ends_lo = (unsigned)cs.ends, ends_hi = (unsigned)(cs.ends >> 32);
+			auto class_of = [&](int s0) -> int {
+				const unsigned S = (unsigned)s0 * 0x01010101u | 0x80808080u;
+				return __builtin_popcount((S - ends_lo) & 0x80808080u) + __builtin_popcount((S - ends_hi) & 0x80808080u);
 			};
-			double a_d = pd[0], a_w = pw[0], a_r0 = pr0[0], a_r1 = pr1[0], a_ht = pht[0];
-			/* (kept apart from the requests above: merged into ds_read2 pairs, the loop head had to wait for both groups --
-			 * lgkmcnt(0) in every trip, i.e. the requests issued just before the back edge were waited for at once) */
-			asm volatile("" ::: "memory");
-			double b_d = pd[4], b_w = pw[4], b_r0 = pr0[4], b_r1 = pr1[4], b_ht = pht[4];
-#if defined(MTFHIP_MI_ABL) && MTFHIP_MI_ABL == 3   /* ablation: sort and stores, no block products */
-			for (int g = 0; g < 0; g += 8) {
-#else
-			for (int g = 0; g < cs.total; g += 8) {
+			/* leave class `cls` for `to`: Q[(cls - 1 + t, cls - 1 + m)][s] += q<t><h>.  Result layout of the block product: column s' = li,
+			 * block = lb, row m = lk. */
+			auto leave_class = [&](int to) {
+#if !(defined(MTFHIP_MI_ABL) && MTFHIP_MI_ABL == 5)   /* ablation 5: class boundaries without the table update */
+				const int cc = cls - 1 + lk;
+				if (cls < 8 && cc >= 0 && cc < nb) {
+					double *qe = qabs + (cls - 1) * kQR + cc * 8 + li;
+					if (cls >= 1) { lds_add_f64(qe, q00); lds_add_f64(qe + 4, q01); }
+					lds_add_f64(qe + kQR, q10); lds_add_f64(qe + kQR + 4, q11);
+					if (cls + 1 < nb) { lds_add_f64(qe + 2 * kQR, q20); lds_add_f64(qe + 2 * kQR + 4, q21); }
+					if (cls + 2 < nb) { lds_add_f64(qe + 3 * kQR, q30); lds_add_f64(qe + 3 * kQR + 4, q31); }
+				}
 #endif
+				q00 = q01 = q10 = q11 = q20 = q21 = q30 = q31 = 0.0;
+				cls = to;
+			};
+			int o = window_col(0, lb, lk);
+			double c_w = pw[o], c_d0 = pd[o], c_d1 = pd[kRS2 + o], c_d2 = pd[2 * kRS2 + o], c_d3 = pd[3 * kRS2 + o], c_ja = pja[o], c_jb = pjb[o], c_ht = pht[o];
+			const int s_first = 4 * lb * steps;   /* first slot of this block's range */
+			{
+				const int c_first = class_of(s_first);
+				/* (a range that starts behind the last class -- class 8 -- holds zeros: the block keeps what it has) */
+				if (c_first != cls && c_first < 8) leave_class(c_first);
+			}
+#if defined(MTFHIP_MI_ABL) && MTFHIP_MI_ABL == 3   /* ablation: sort and stores, no block products */
+			for (int j = 0; j < 0; ++j) {
+#else
+#pragma unroll 1
+			for (int j = 0; j < steps; ++j) {
+#endif
+				/* operands of the next step first (one step past the end reads the columns behind the window: discarded) */
+				o = window_col(j + 1, lb, lk);
+				const double n_w = pw[o], n_d0 = pd[o], n_d1 = pd[kRS2 + o], n_d2 = pd[2 * kRS2 + o], n_d3 = pd[3 * kRS2 + o];
+				const double n_ja = pja[o], n_jb = pjb[o], n_ht = pht[o];
 				{
-					const double av = a_d * a_w;   /* block = gradient tap k, row = weight tap m */
-					acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, a_r0, acc0, 0, 0, 0);
-					acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, a_r1, acc1, 0, 0, 0);
-					chs = __builtin_amdgcn_mfma_f64_4x4x4f64((hx ? a_r1 : a_r0) * a_ht, hy ? a_r1 : a_r0, chs, 0, 0, 0);
+					const double u0 = c_d0 * c_w, u1 = c_d1 * c_w, u2 = c_d2 * c_w, u3 = c_d3 * c_w;   /* row = weight tap li, k = this pixel */
+					q00 = __builtin_amdgcn_mfma_f64_4x4x4f64(u0, c_ja, q00, 0, 0, 0); q01 = __builtin_amdgcn_mfma_f64_4x4x4f64(u0, c_jb, q01, 0, 0, 0);
+					q10 = __builtin_amdgcn_mfma_f64_4x4x4f64(u1, c_ja, q10, 0, 0, 0); q11 = __builtin_amdgcn_mfma_f64_4x4x4f64(u1, c_jb, q11, 0, 0, 0);
+					q20 = __builtin_amdgcn_mfma_f64_4x4x4f64(u2, c_ja, q20, 0, 0, 0); q21 = __builtin_amdgcn_mfma_f64_4x4x4f64(u2, c_jb, q21, 0, 0, 0);
+					q30 = __builtin_amdgcn_mfma_f64_4x4x4f64(u3, c_ja, q30, 0, 0, 0); q31 = __builtin_amdgcn_mfma_f64_4x4x4f64(u3, c_jb, q31, 0, 0, 0);
+					const double ha = c_ja * c_ht, hb = c_jb * c_ht;   /* sum hess_term J J^T: tile (X, Y) = rows 4 X + i weighted, columns 4 Y + j */
+					chs4[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ha, c_ja, chs4[0], 0, 0, 0); chs4[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ha, c_jb, chs4[1], 0, 0, 0);
+					chs4[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(hb, c_jb, chs4[3], 0, 0, 0);   /* (tile (1, 0) is the transpose of (0, 1): mirrored at the end) */
 				}
-				a_d = pd[g + 8]; a_w = pw[g + 8]; a_r0 = pr0[g + 8]; a_r1 = pr1[g + 8]; a_ht = pht[g + 8];
-				flush_if(g + 4);
-				{
-					const double av = b_d * b_w;
-					acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b_r0, acc0, 0, 0, 0);
-					acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b_r1, acc1, 0, 0, 0);
-					chs = __builtin_amdgcn_mfma_f64_4x4x4f64((hx ? b_r1 : b_r0) * b_ht, hy ? b_r1 : b_r0, chs, 0, 0, 0);
+				if (j + 1 < steps) {
+					const int cls_nx = class_of(s_first + 4 * (j + 1));
+					if (cls_nx != cls && cls_nx < 8) leave_class(cls_nx);
 				}
-				b_d = pd[g + 12]; b_w = pw[g + 12]; b_r0 = pr0[g + 12]; b_r1 = pr1[g + 12]; b_ht = pht[g + 12];
-				flush_if(g + 8);
+				c_w = n_w; c_d0 = n_d0; c_d1 = n_d1; c_d2 = n_d2; c_d3 = n_d3; c_ja = n_ja; c_jb = n_jb; c_ht = n_ht;
 			}
 			__builtin_amdgcn_wave_barrier();
 			if (valid) {   /* padding slots must keep a zero gradient tap and a zero hess_term */
 #pragma unroll
-				for (int k = 0; k < 4; ++k) sd[k * kRS2 + cs.slot] = 0.0;
-				sht[cs.slot] = 0.0;
+				for (int k = 0; k < 4; ++k) sd[k * kRS2 + mycol] = 0.0;
+				sht[mycol] = 0.0;
 			}
 		} else if constexpr (HK != 0) {
 			const BsplWin4 &A = HK == 3 ? c0 : a;
@@ -431,6 +469,16 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 			for (int k = 0; k < 4; ++k) { rg[k * kRS] = 0.0; rwd[k * kRS] = 0.0; }
 		}
 	}
+	if constexpr (SORTED) {   /* what the blocks still hold goes to the wave's table */
+		const int cc = cls - 1 + lk;
+		if (cls < 8 && cc >= 0 && cc < nb) {
+			double *qe = qabs + (cls - 1) * kQR + cc * 8 + li;
+			if (cls >= 1) { lds_add_f64(qe, q00); lds_add_f64(qe + 4, q01); }
+			lds_add_f64(qe + kQR, q10); lds_add_f64(qe + kQR + 4, q11);
+			if (cls + 1 < nb) { lds_add_f64(qe + 2 * kQR, q20); lds_add_f64(qe + 2 * kQR + 4, q21); }
+			if (cls + 2 < nb) { lds_add_f64(qe + 3 * kQR, q30); lds_add_f64(qe + 3 * kQR + 4, q31); }
+		}
+	}
 	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * kMiFastRow;
 	__syncthreads();
 	{
@@ -454,11 +502,23 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 		}
 		constexpr int hl = SORTED ? 64 : ql;   /* sorted: only the H blocks go through qred, in front of the first wave's Q table */
 		static_assert(!SORTED || 4 * 64 <= 17 * kRS2, "H blocks of the four waves must fit in front of the first Q table");
-		qred[wave * hl + (4 * (lb >> 1) + lk) * 8 + 4 * (lb & 1) + li] = chs;
+		if constexpr (SORTED) {
+			/* (block_reduce_store above used the first 64 doubles as its scratch) */
+			for (int k2 = threadIdx.x; k2 < 4 * 64; k2 += kBlock) qred[k2] = 0.0;
+			__syncthreads();
+			/* tile (X, Y) of every block: row 4 X + lk, column 4 Y + li.  The four blocks of a wave meet through ds_add_f64; the target --
+			 * the first 256 doubles of the slabs, nobody's staging rows any more */
+#pragma unroll
+			for (int xy = 0; xy < 4; ++xy) if (xy != 2) lds_add_f64(qred + wave * hl + (4 * (xy >> 1) + lk) * 8 + 4 * (xy & 1) + li, chs4[xy]);
+		} else {
+			qred[wave * hl + (4 * (lb >> 1) + lk) * 8 + 4 * (lb & 1) + li] = chs;
+		}
 		__syncthreads();
 		if constexpr (SORTED) {
-			for (int k2 = threadIdx.x; k2 < 64; k2 += kBlock)
-				dst[16 + k2] = (qred[k2] + qred[64 + k2]) + (qred[128 + k2] + qred[192 + k2]);
+			for (int k2 = threadIdx.x; k2 < 64; k2 += kBlock) {
+				const int r = k2 >> 3, c = k2 & 7, src = (r >= 4 && c < 4) ? c * 8 + r : k2;   /* the lower-left tile from the upper-right one */
+				dst[16 + k2] = (qred[src] + qred[64 + src]) + (qred[128 + src] + qred[192 + src]);
+			}
 			const double *q0 = slabs + 17 * kRS2;
 			for (int k2 = threadIdx.x; k2 < 512; k2 += kBlock) {
 				const int q = (k2 >> 6) * kQR + (k2 & 63);
