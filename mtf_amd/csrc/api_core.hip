@@ -480,7 +480,10 @@ int mtfhip_ssm_set_corners(mtfhip_batch *b, const double *corners) { return set_
 
 /* for_track: the upload also carries active = 1 / iteration counts = 0, i.e. it is the slab mtfhip_batch_track would
  * upload next (mtfhip_batch_track_region: one staging pass and one copy per frame instead of two) */
-int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track) {
+/* defer_grid (mtfhip_batch_track_region in front of the one-launch ICLK kernel): the host half only -- mirrors, the staged corners and NCC
+ * scalars -- the kernel that follows ingests them and lays out the grid itself (RegionIngest); an affine SSM then needs no map on the
+ * host at all (5.9 us of closed-form homographies per 256-patch frame), a homography one still has to know whether the grids are affine */
+int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track, bool defer_grid) {
 	FLUSH_AM(b);   /* pending calls are replayed (with the points they need); the points themselves are about to change */
 	if (b) ++b->lz.epoch;
 	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
@@ -499,11 +502,13 @@ int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track) {
 	static const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 	int unit_z = 1;
 	for (int t = 0; t < b->B; ++t) {
-		M3 W0;
-		if (!rect_to_quad(lo_x, lo_y, hi_x, hi_y, corners + 8 * t, W0)) return fail(MTFHIP_ERR_INVALID_ARG, "set_corners: degenerate corners for target %d", t);
-		if (!hom || (std::fabs(W0.m[6]) < 1e-15 && std::fabs(W0.m[7]) < 1e-15)) {
-			if (hom) { W0.m[6] = 0; W0.m[7] = 0; }
-		} else unit_z = 0;
+		M3 W0 = m3_identity();
+		if (!(defer_grid && !hom)) {   /* (deferred + affine: the kernel reports degenerate corners through n_iters = -1) */
+			if (!rect_to_quad(lo_x, lo_y, hi_x, hi_y, corners + 8 * t, W0)) return fail(MTFHIP_ERR_INVALID_ARG, "set_corners: degenerate corners for target %d", t);
+			if (!hom || (std::fabs(W0.m[6]) < 1e-15 && std::fabs(W0.m[7]) < 1e-15)) {
+				if (hom) { W0.m[6] = 0; W0.m[7] = 0; }
+			} else unit_z = 0;
+		}
 		TargetHost &h = b->th[t];
 		std::memcpy(h.corners, corners + 8 * t, sizeof(double) * 8);
 		std::memcpy(h.init_corners, corners + 8 * t, sizeof(double) * 8);
@@ -525,6 +530,13 @@ int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track) {
 		if (for_track) s_it[t] = 0;
 	}
 	b->unit_z = hom ? unit_z : 1;
+	if (defer_grid) {
+		b->warps_dirty = false;   /* the kernel that follows starts every target from the identity */
+		b->have_corners = true;
+		b->pts_stale = true;
+		++b->corners_epoch;
+		return MTFHIP_OK;
+	}
 	const size_t up_bytes = for_track ? b->slab_bytes : b->slab_dbl_bytes;
 	bool grid_done = false;
 	if (b->h_stage_a_dev) {

@@ -377,7 +377,7 @@ int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
  * off): the SSM is reset to the new corners; ESM (and FCLK with the InitialSelf Hessian) recompute init_pix_jacobian with
  * cmptInitPixJacobian on the new grid and, for the Hessian types that use it, the constant self Hessian; ICLK keeps its
  * template Jacobian.  The template (I0, dI0_dx) is kept in every case. */
-static int set_region_core(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm, bool for_track);
+static int set_region_core(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm, bool for_track, bool defer_grid = false);
 int mtfhip_batch_set_region(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm) { return set_region_core(b, corners, sm, false); }
 
 /* the one-launch grid kernel (k_iclk_track: a patch's whole ICLK update() in one workgroup) takes ICLK with a constant Hessian -- up to
@@ -395,13 +395,13 @@ static bool iclk_one_launch(const mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 }
 static bool region_refreshes(const mtfhip_sm_desc *sm) { return sm->sm == MTFHIP_SM_ESM || (sm->sm == MTFHIP_SM_FCLK && sm->hess_type == 0); }
 
-static int set_region_core(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm, bool for_track) {
+static int set_region_core(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm, bool for_track, bool defer_grid) {
 	FLUSH_AM(b);   /* (the current points are about to be replaced: only pending calls need them brought up to date) */
 	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
 	TRY(check_sm(b, sm, "set_region"));
 	TRY(fused_channels_ok(b, "set_region"));
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "set_region before init_template");
-	TRY(set_corners_core(b, corners, for_track));
+	TRY(set_corners_core(b, corners, for_track, defer_grid));
 	const bool refresh = region_refreshes(sm);
 	if (!refresh) {
 		/* back on exactly the grid the kept template Jacobian was computed on: its rows can still be rebuilt from dI0_dx */
@@ -820,7 +820,7 @@ int mtfhip_batch_track_queues(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	return track_queues(b, fa);
 }
 
-static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners, bool slab_uploaded, bool resume = false);
+static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners, bool slab_uploaded, bool resume = false, bool region_mode = false);
 static int track_validate(mtfhip_batch *b, const mtfhip_sm_desc *sm);
 /* ---- the persistent one-launch loop (kernels_persist.hip) ---- */
 /* rows per workgroup so that every target's workgroups are resident together: the default decomposition when it fits, else the
@@ -874,10 +874,17 @@ int mtfhip_batch_track_region(mtfhip_batch *b, const mtfhip_sm_desc *sm, const d
 	TRY(track_validate(b, sm));
 	const bool folded = !region_refreshes(sm);
 	static const bool dbg = std::getenv("MTFHIP_TRACK_DEBUG_TIMING") != nullptr;
+	/* r04: in front of the one-launch ICLK kernel (the grid tracker's patches) the reset needs no launch of its own -- every workgroup
+	 * ingests its patch's corners from the pinned staging buffer and lays out its own grid (RegionIngest, k_iclk_track).
+	 * MTFHIP_GRID_FUSED=0 keeps the ingest + k_init_grid launch in front of the loop (A/B, and the bit-identity test). */
+	const char *e_gf = std::getenv("MTFHIP_GRID_FUSED");   /* (read per call: the A/B test flips it) */
+	const bool fused_ok = !(e_gf && e_gf[0] == '0');
+	const bool region_mode = fused_ok && folded && b->desc.am != MTFHIP_AM_MI && !sm->leven_marq && iclk_one_launch(b, sm) && second_order_term(sm, b->desc.am) < 0 &&
+		b->h_stage_a_dev && b->h_pub_dev;
 	const auto t0 = std::chrono::steady_clock::now();
-	TRY(set_region_core(b, region_corners, sm, folded));
+	TRY(set_region_core(b, region_corners, sm, folded, region_mode));
 	const auto t1 = std::chrono::steady_clock::now();
-	const int r = track_core(b, sm, n_iters, corners, folded);
+	const int r = track_core(b, sm, n_iters, corners, folded, false, region_mode);
 	if (dbg) {
 		const auto t2 = std::chrono::steady_clock::now();
 		static double acc1 = 0, acc2 = 0; static int n = 0;
@@ -921,7 +928,7 @@ static int track_validate(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "track before init_template");
 	return need_image(b);
 }
-static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners, bool slab_uploaded, bool resume) {
+static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *corners, bool slab_uploaded, bool resume, bool region_mode) {
 	FLUSH_AM(b);   /* (none of the loop's kernels reads CURR_PTS: they warp the template grid themselves) */
 	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
 	TRY(track_validate(b, sm));
@@ -1025,7 +1032,18 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 			pub_seq = ++b->acc_seq;
 			pub = HostPublish{b->h_pub_dev, b->slab_dbl_bytes, b->B, b->d_fin_count, b->h_flag_dev, pub_seq};
 		}
-		launch_iclk_track(bv, b->ctx->img, *sm, ts, b->d_h0inv, b->d_ncc, b->norm_mult, b->norm_add, b->math_mode == MTFHIP_MATH_FAST, pub, st);
+		RegionIngest rg{};
+		if (region_mode) {
+			/* (the staging slab of set_corners_core: w 9 | s 8 | corners 8 | init_corners_hm 12 | NCC scalars 8 | w0 9 per target) */
+			const double *stage = reinterpret_cast<const double *>(b->h_stage_a_dev);
+			const bool homg = b->desc.ssm == MTFHIP_SSM_HOMOGRAPHY;
+			rg.corners = stage + 17 * (size_t)b->B; rg.ncc = stage + 37 * (size_t)b->B;
+			rg.d_ncc = b->d_ncc; rg.d_w0 = b->d_w0; rg.d_init_corners_hm = b->d_init_corners_hm;
+			rg.lo_x = homg ? -0.5 : 1 - b->desc.resx / 2.0; rg.lo_y = homg ? -0.5 : 1 - b->desc.resy / 2.0;
+			rg.hi_x = homg ? 0.5 : b->desc.resx / 2.0; rg.hi_y = homg ? 0.5 : b->desc.resy / 2.0;
+			rg.resx = b->desc.resx; rg.resy = b->desc.resy; rg.force_unit_z = homg ? 0 : 1;
+		}
+		launch_iclk_track(bv, b->ctx->img, *sm, ts, b->d_h0inv, b->d_ncc, b->norm_mult, b->norm_add, b->math_mode == MTFHIP_MATH_FAST, pub, rg, st);
 	} else if (so_term < 0 && persist_fits(b, sm, fa)) {
 		/* a grid that fits the device at one workgroup per CU (a single large target, a few small ones): every pass of the loop in
 		 * ONE launch, the workgroups meeting at an in-kernel barrier between the pixel pass and the solve (kernels_persist.hip) */
@@ -1178,6 +1196,9 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 			if (n_iters) n_iters[t] = iters[t];
 			if (corners) std::memcpy(corners + 8 * t, cr + 8 * t, sizeof(double) * 8);
 		}
+		if (region_mode)
+			for (int t = 0; t < b->B; ++t)
+				if (iters[t] < 0) return fail(MTFHIP_ERR_INVALID_ARG, "track_region: degenerate corners for target %d", t);
 	}
 	if (persisted) {
 		/* a workgroup that could not wait any longer for its peers (CUs held by another process) leaves its target active with

@@ -153,20 +153,27 @@ __device__ unsigned long long g_grid_trace[32];
 #endif
 template <int AM, int PPT, bool FAST>
 __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im, mtfhip_sm_desc sm, TrackState ts,
-	const double *h0inv_all, const double *ncc_sc_all, double norm_mult, double norm_add, HostPublish pub) {
+	const double *h0inv_all, const double *ncc_sc_all, double norm_mult, double norm_add, HostPublish pub, RegionIngest rg) {
 	__shared__ double red[4 * 8];
-	__shared__ double sW[9], sSt[8], sHinv[64], sH8[64], sIc[12], sCr[8];
+	__shared__ double sW[9], sSt[8], sHinv[64], sH8[64], sIc[12], sCr[8], sNc[8];
 	__shared__ int sDone;
 	GRID_STAMP(0);
 	const int t = blockIdx.x, N = bv.N, S = bv.S, tid = threadIdx.x;
 	const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY;
+	const bool region = rg.corners != nullptr;   /* (uniform: a kernel argument) */
 	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * N;
 	const double2 *ih = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]) + (size_t)t * N;
 	const double *iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * N;
 	const double *I0 = bv.buf[MTFHIP_BUF_I0] + (size_t)t * N;
 	const double *J0 = bv.buf[MTFHIP_BUF_J0] + (size_t)t * N * S;
-	const double m0 = AM == MTFHIP_AM_NCC ? ncc_sc_all[t * 8 + 0] : 0.0;
-	const double cn = AM == MTFHIP_AM_NCC ? ncc_sc_all[t * 8 + 1] : 1.0;
+	if (region) {
+		/* the patch's region and its template's NCC scalars from the pinned staging buffer: one PCIe round trip per workgroup, under
+		 * the template operands' fetch below */
+		if (tid < 8) sCr[tid] = rg.corners[8 * (size_t)t + tid];
+		else if (tid < 16) sNc[tid - 8] = AM == MTFHIP_AM_NCC ? rg.ncc[8 * (size_t)t + tid - 8] : 0.0;
+	}
+	double m0 = (AM == MTFHIP_AM_NCC && !region) ? ncc_sc_all[t * 8 + 0] : 0.0;
+	double cn = (AM == MTFHIP_AM_NCC && !region) ? ncc_sc_all[t * 8 + 1] : 1.0;
 	/* Everything that does not change over the iterations is fetched ONCE: the thread's grid points, template values
 	 * and J0 rows into registers, the inverse Hessian and the corner sets into LDS.  An iteration then touches global
 	 * memory only for its texels (the loop is a chain of dependent latencies: one workgroup per patch, nothing to
@@ -180,8 +187,10 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 		const int i = tid + k * kBlock;
 		const int ic = i < N ? i : N - 1;
 		if constexpr (HOIST_P) {
-			hpv[k] = bv.unit_z ? ip[ic] : ih[ic];
-			zv[k] = bv.unit_z ? 1.0 : iz[ic];
+			if (!region) {
+				hpv[k] = bv.unit_z ? ip[ic] : ih[ic];
+				zv[k] = bv.unit_z ? 1.0 : iz[ic];
+			}
 		}
 		i0v[k] = i < N ? I0[ic] : 0.0;
 		if constexpr (HOIST_J) {
@@ -191,16 +200,64 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 	}
 	if (tid < 64) sHinv[tid] = h0inv_all[(size_t)t * 64 + tid];
 	if (tid < 64) { const int r = tid >> 3, c = tid & 7; sH8[tid] = (r < S && c < S) ? h0inv_all[(size_t)t * 64 + c * S + r] : 0.0; }   /* [r][c], zero padded */
-	if (tid < 12) sIc[tid] = ts.init_corners_hm[12 * t + tid];
-	if (tid < 8) sCr[tid] = ts.corners[8 * t + tid];
-	if (tid < 9) sW[tid] = bv.warps[9 * t + tid];
-	if (tid < 8) sSt[tid] = bv.states[8 * t + tid];
+	if (!region) {
+		if (tid < 12) sIc[tid] = ts.init_corners_hm[12 * t + tid];
+		if (tid < 8) sCr[tid] = ts.corners[8 * t + tid];
+		if (tid < 9) sW[tid] = bv.warps[9 * t + tid];
+		if (tid < 8) sSt[tid] = bv.states[8 * t + tid];
+	} else {
+		/* the SSM's reset (setCorners: identity warp, zero state, init_corners_hm = (x, y, 1)) */
+		if (tid < 9) sW[tid] = (tid == 0 || tid == 4 || tid == 8) ? 1.0 : 0.0;
+		if (tid < 8) sSt[tid] = 0.0;
+	}
 	if (tid == 0) sDone = 0;
 	GRID_STAMP(1);
 	__syncthreads();
 	GRID_STAMP(2);
 	int n_it = 0;
 	double f_last = 0;
+	bool region_bad = false;
+	if (region) {
+		static_assert(PPT <= 8, "region mode keeps the grid in registers");
+		/* every thread derives the same map from the same eight numbers (~40 flops and a dozen divisions: cheaper than a broadcast
+		 * and its barrier), then its own grid points: ProjectiveBase::getPtsFromCorners + Homography / Affine::setCorners exactly as
+		 * k_init_grid lays them out (same expressions, same order: the loop that follows must not depend on who built the grid) */
+		double q8[8], W0[9];
+#pragma unroll
+		for (int q = 0; q < 8; ++q) q8[q] = sCr[q];
+		region_bad = !rect_to_quad_hd(rg.lo_x, rg.lo_y, rg.hi_x, rg.hi_y, q8, W0);
+		if (region_bad) {
+#pragma unroll
+			for (int q = 0; q < 9; ++q) W0[q] = (q == 0 || q == 4 || q == 8) ? 1.0 : 0.0;
+		}
+		/* (set_corners_core: a homography grid whose projective entries vanish is laid out with exact zeros) */
+		if (hom && fabs(W0[6]) < 1e-15 && fabs(W0[7]) < 1e-15) { W0[6] = 0; W0[7] = 0; }
+		if constexpr (AM == MTFHIP_AM_NCC) { m0 = sNc[0]; cn = sNc[1]; }
+		double2 *ipw = const_cast<double2 *>(ip), *ihw = const_cast<double2 *>(ih);
+		double *izw = const_cast<double *>(iz);
+#pragma unroll
+		for (int k = 0; k < PPT; ++k) {
+			const int i = tid + k * kBlock;
+			const int ic = i < N ? i : N - 1;
+			const int col = ic % rg.resx, row = ic / rg.resx;
+			const double nx = (rg.resx == 1 || col == rg.resx - 1) ? rg.hi_x : rg.lo_x + col * ((rg.hi_x - rg.lo_x) / (rg.resx - 1));
+			const double ny = (rg.resy == 1 || row == rg.resy - 1) ? rg.hi_y : rg.lo_y + row * ((rg.hi_y - rg.lo_y) / (rg.resy - 1));
+			const double X = W0[0] * nx + W0[1] * ny + W0[2] * 1.0;
+			const double Y = W0[3] * nx + W0[4] * ny + W0[5] * 1.0;
+			const double Z = W0[6] * nx + W0[7] * ny + W0[8] * 1.0;
+			/* (a parallelogram's map has Z = 1.0 exactly and x / 1.0 == x: the two divisions per point are skipped, same bits) */
+			const double2 p = (W0[6] == 0 && W0[7] == 0 && W0[8] == 1.0) ? make_double2(X, Y) : make_double2(X / Z, Y / Z);
+			const double z = rg.force_unit_z ? 1.0 : Z;
+			const double2 hxy = rg.force_unit_z ? p : make_double2(X, Y);
+			if constexpr (HOIST_P) { hpv[k] = bv.unit_z ? p : hxy; zv[k] = bv.unit_z ? 1.0 : z; }
+			if (i < N) { ipw[i] = p; izw[i] = z; ihw[i] = hxy; }
+		}
+		/* the slab entries the ingest used to bring: this workgroup's piece, for the calls that come after the frame */
+		if (tid < 9) rg.d_w0[9 * (size_t)t + tid] = W0[tid];
+		if (tid < 12) { const double v = (tid % 3 == 2) ? 1.0 : q8[2 * (tid / 3) + tid % 3]; sIc[tid] = v; rg.d_init_corners_hm[12 * (size_t)t + tid] = v; }
+		if (AM == MTFHIP_AM_NCC && tid < 8) rg.d_ncc[8 * (size_t)t + tid] = sNc[tid];
+		__syncthreads();   /* sIc */
+	}
 	if constexpr (FAST) {
 		/* Tolerance mode: ONE workgroup-wide reduction per iteration instead of four (NCC) / two (SSD), and no serial section.
 		 * NCC's similarity and df_dI0 . J0 are functions of raw moments -- sum It, sum It^2, sum I0 It, sum It J0 plus the
@@ -242,7 +299,8 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 		}
 		const double nN = (double)N, inv_n = 1.0 / nN, inv_cn = 1.0 / cn;
 		GRID_STAMP(3);
-		for (int it = 0; it < sm.max_iters; ++it) {
+		const int max_it = region_bad ? 0 : sm.max_iters;   /* degenerate region corners: no iteration, n_iters = -1 tells the host */
+		for (int it = 0; it < max_it; ++it) {
 			if (it < 12) GRID_STAMP(4 + it);
 			double m[K];
 #pragma unroll
@@ -364,6 +422,7 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 		for (int q = 0; q < 9; ++q) if (tid == q) bv.warps[9 * t + q] = W[q];
 #pragma unroll
 		for (int q = 0; q < 8; ++q) if (tid == q) { bv.states[8 * t + q] = St[q]; ts.corners[8 * t + q] = Cr[q]; }
+		if (region_bad) n_it = -1;
 		if (tid == 0) { ts.n_iters[t] = n_it; ts.acc[(size_t)t * ACC_COUNT + ACC_RR] = f_last; }
 		if (pub.host && tid < 64) {
 			/* lane q holds entry q after the selects below (register arrays cannot be indexed by the lane id) */
@@ -378,7 +437,7 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 		}
 		return;
 	}
-	for (int it = 0; it < sm.max_iters; ++it) {
+	for (int it = 0; it < (region_bad ? 0 : sm.max_iters); ++it) {
 		double W[9];
 #pragma unroll
 		for (int q = 0; q < 9; ++q) W[q] = sW[q];
@@ -510,6 +569,7 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 	if (tid < 9) bv.warps[9 * t + tid] = sW[tid];
 	if (tid < 8) bv.states[8 * t + tid] = sSt[tid];
 	if (tid < 8) ts.corners[8 * t + tid] = sCr[tid];
+	if (region_bad) n_it = -1;
 	if (tid == 0) { ts.n_iters[t] = n_it; ts.acc[(size_t)t * ACC_COUNT + ACC_RR] = f_last; }
 	if (pub.host && tid < 64) publish_target(pub, t, tid < 9 ? sW[tid] : 0.0, tid < 8 ? sSt[tid] : 0.0, tid < 8 ? sCr[tid] : 0.0, n_it);
 }
@@ -521,27 +581,26 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 
 template <int AM, bool FAST>
 static bool launch_iclk_track_am(const BatchView &bv, const ImgView &im, const mtfhip_sm_desc &sm, const TrackState &ts,
-	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, const HostPublish &pub, hipStream_t st) {
+	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, const HostPublish &pub, const RegionIngest &rg, hipStream_t st) {
 	const int ppt = (bv.N + kBlock - 1) / kBlock;
-#define MTFHIP_ICLK_CASE(P) MTFHIP_LAUNCH((k_iclk_track<AM, P, FAST>), dim3(bv.B), dim3(kBlock), 0, st, bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, pub)
+#define MTFHIP_ICLK_CASE(P) MTFHIP_LAUNCH((k_iclk_track<AM, P, FAST>), dim3(bv.B), dim3(kBlock), 0, st, bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, pub, rg)
 	if (ppt <= 1) MTFHIP_ICLK_CASE(1);
 	else if (ppt <= 2) MTFHIP_ICLK_CASE(2);
 	else if (ppt <= 3) MTFHIP_ICLK_CASE(3);
 	else if (ppt <= 4) MTFHIP_ICLK_CASE(4);
 	else if (ppt <= 8) MTFHIP_ICLK_CASE(8);
-	else if (ppt <= 16) MTFHIP_ICLK_CASE(16);
 	else return false;
 #undef MTFHIP_ICLK_CASE
 	return true;
 }
 bool launch_iclk_track(const BatchView &bv, const ImgView &im, const mtfhip_sm_desc &sm, const TrackState &ts,
-	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, int fast_math, const HostPublish &pub, hipStream_t st) {
+	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, int fast_math, const HostPublish &pub, const RegionIngest &rg, hipStream_t st) {
 	if (fast_math) {
-		if (bv.am == MTFHIP_AM_NCC) return launch_iclk_track_am<MTFHIP_AM_NCC, true>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, pub, st);
-		return launch_iclk_track_am<MTFHIP_AM_SSD, true>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, pub, st);
+		if (bv.am == MTFHIP_AM_NCC) return launch_iclk_track_am<MTFHIP_AM_NCC, true>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, pub, rg, st);
+		return launch_iclk_track_am<MTFHIP_AM_SSD, true>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, pub, rg, st);
 	}
-	if (bv.am == MTFHIP_AM_NCC) return launch_iclk_track_am<MTFHIP_AM_NCC, false>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, pub, st);
-	return launch_iclk_track_am<MTFHIP_AM_SSD, false>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, pub, st);
+	if (bv.am == MTFHIP_AM_NCC) return launch_iclk_track_am<MTFHIP_AM_NCC, false>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, pub, rg, st);
+	return launch_iclk_track_am<MTFHIP_AM_SSD, false>(bv, im, sm, ts, h0inv, ncc_sc, norm_mult, norm_add, pub, rg, st);
 }
 void launch_sample_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C, double norm_mult,
 	double norm_add, double *dev_feat, hipStream_t st) {

@@ -105,34 +105,7 @@ static void state_from_warp(int ssm, double *p, const M3 &W) {
  * rectangle's normalisation and scaled to m[8] = 1, is the same matrix to rounding -- ~40 flops instead of an 8 x 8
  * elimination per target (GridTracker sets 256 of them per frame).  false: degenerate corners. */
 static bool rect_to_quad(double lo_x, double lo_y, double hi_x, double hi_y, const double *q, M3 &H) {
-	const double x0 = q[0], y0 = q[1], x1 = q[2], y1 = q[3], x2 = q[4], y2 = q[5], x3 = q[6], y3 = q[7];
-	const double dx1 = x1 - x2, dx2 = x3 - x2, sx = x0 - x1 + x2 - x3;
-	const double dy1 = y1 - y2, dy2 = y3 - y2, sy = y0 - y1 + y2 - y3;
-	double a, b, c, d, e, f, g, h;
-	if (sx == 0 && sy == 0) {   /* parallelogram: affine */
-		a = x1 - x0; b = x3 - x0; c = x0; d = y1 - y0; e = y3 - y0; f = y0; g = 0; h = 0;
-		if (a * e - b * d == 0) return false;
-	} else {
-		const double den = dx1 * dy2 - dy1 * dx2;
-		if (den == 0) return false;
-		g = (sx * dy2 - dx2 * sy) / den; h = (dx1 * sy - sx * dy1) / den;
-		a = x1 - x0 + g * x1; b = x3 - x0 + h * x3; c = x0;
-		d = y1 - y0 + g * y1; e = y3 - y0 + h * y3; f = y0;
-	}
-	/* (u, v) = ((x - lo_x) / wx, (y - lo_y) / wy) */
-	const double wx = hi_x - lo_x, wy = hi_y - lo_y;
-	const double r0[3] = {a, b, c}, r1[3] = {d, e, f}, r2[3] = {g, h, 1.0};
-	const double *rows[3] = {r0, r1, r2};
-	double m[9];
-	for (int r = 0; r < 3; ++r) {
-		m[3 * r] = rows[r][0] / wx; m[3 * r + 1] = rows[r][1] / wy;
-		m[3 * r + 2] = rows[r][2] - rows[r][0] * lo_x / wx - rows[r][1] * lo_y / wy;
-	}
-	if (m[8] == 0 || !std::isfinite(m[8])) return false;
-	if (m[8] == 1.0) for (int i = 0; i < 9; ++i) H.m[i] = m[i];   /* (x / 1.0 == x: a parallelogram's nine divisions are skipped) */
-	else for (int i = 0; i < 9; ++i) H.m[i] = m[i] / m[8];
-	H.m[8] = 1;
-	return true;
+	return rect_to_quad_hd(lo_x, lo_y, hi_x, hi_y, q, H.m);   /* (one set of expressions for host and device: mtfhip_internal.h) */
 }
 
 /* ------------------------------------------------------------------ handles */
@@ -524,7 +497,7 @@ static inline mtfhip::MiJ0Rebuild mi_j0_rebuild(const mtfhip_batch *b) {
 /* ---- functions defined in one api_*.hip unit and used in another ---- */
 enum { LAZY_CURR_JAC = 0, LAZY_DIFF_JAC = 1, LAZY_INIT_JAC = 2 };
 int ensure_pts(mtfhip_batch *b);
-int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track);   /* api_core.hip */
+int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track, bool defer_grid = false);   /* api_core.hip */
 int do_update_grad_pts(mtfhip_batch *b, double grad_eps);
 int gemv_to_host(mtfhip_batch *b, const double *v1, int j1, const double *v2, int j2, int sum_mode, double *g, int diff);
 int ncc_template_moments(mtfhip_batch *b);

@@ -130,6 +130,52 @@ struct PersistState {
 /* results of the one-launch loop delivered straight into the host-coherent mirror of the state slab (warps | states | corners |
  * ... | iteration counts) by the workgroup that produced them; the last workgroup to finish raises the flag the host spins on.
  * host == NULL: nothing is published (k_publish_host does it in a launch of its own). */
+/* The square-to-quadrilateral map behind set_corners (see rect_to_quad, mtfhip_api_internal.h), as ONE set of expressions for the host
+ * and for the kernel that lays out a patch's grid itself (k_iclk_track in region mode): both are compiled without contraction, so the
+ * nine entries are the same bits on either side.  H: row-major 3 x 3, H[8] = 1; false: degenerate corners. */
+__host__ __device__ inline bool rect_to_quad_hd(double lo_x, double lo_y, double hi_x, double hi_y, const double *q, double *H) {
+	const double x0 = q[0], y0 = q[1], x1 = q[2], y1 = q[3], x2 = q[4], y2 = q[5], x3 = q[6], y3 = q[7];
+	const double dx1 = x1 - x2, dx2 = x3 - x2, sx = x0 - x1 + x2 - x3;
+	const double dy1 = y1 - y2, dy2 = y3 - y2, sy = y0 - y1 + y2 - y3;
+	double a, b, c, d, e, f, g, h;
+	if (sx == 0 && sy == 0) {   /* parallelogram: affine */
+		a = x1 - x0; b = x3 - x0; c = x0; d = y1 - y0; e = y3 - y0; f = y0; g = 0; h = 0;
+		if (a * e - b * d == 0) return false;
+	} else {
+		const double den = dx1 * dy2 - dy1 * dx2;
+		if (den == 0) return false;
+		g = (sx * dy2 - dx2 * sy) / den; h = (dx1 * sy - sx * dy1) / den;
+		a = x1 - x0 + g * x1; b = x3 - x0 + h * x3; c = x0;
+		d = y1 - y0 + g * y1; e = y3 - y0 + h * y3; f = y0;
+	}
+	/* (u, v) = ((x - lo_x) / wx, (y - lo_y) / wy) */
+	const double wx = hi_x - lo_x, wy = hi_y - lo_y;
+	const double rows[3][3] = {{a, b, c}, {d, e, f}, {g, h, 1.0}};
+	double m[9];
+	for (int r = 0; r < 3; ++r) {
+		m[3 * r] = rows[r][0] / wx; m[3 * r + 1] = rows[r][1] / wy;
+		m[3 * r + 2] = rows[r][2] - rows[r][0] * lo_x / wx - rows[r][1] * lo_y / wy;
+	}
+	if (m[8] == 0 || !(m[8] - m[8] == 0)) return false;   /* zero, infinite or NaN */
+	if (m[8] == 1.0) for (int i = 0; i < 9; ++i) H[i] = m[i];   /* (x / 1.0 == x: a parallelogram's nine divisions are skipped) */
+	else for (int i = 0; i < 9; ++i) H[i] = m[i] / m[8];
+	H[8] = 1;
+	return true;
+}
+
+/* k_iclk_track in REGION mode (mtfhip_batch_track_region / mtfhip_grid_update, r04): the workgroup of a patch takes the patch's region
+ * corners (and its template's NCC scalars) straight from the pinned staging buffer, derives the square-to-quadrilateral map, lays out
+ * its own sample grid -- kept in registers for the loop, written to INIT_PTS / INIT_HXY / INIT_Z for whoever asks later -- and starts
+ * from the identity warp: what set_corners' ingest + k_init_grid did in a launch of their own in front of the loop (7.8 us of a 64 us
+ * frame, plus the gap).  corners == NULL: off (the slab and the grid are already on the device). */
+struct RegionIngest {
+	const double *corners;      /* device-visible pinned host memory: [B][8], (x, y) per corner, TL TR BR BL */
+	const double *ncc;          /* likewise: [B][8] NCC scalars of the templates (slab layout) */
+	double *d_ncc, *d_w0, *d_init_corners_hm;   /* the slab's device copies of what the workgroup derives */
+	double lo_x, lo_y, hi_x, hi_y;
+	int resx, resy, force_unit_z;
+};
+
 struct HostPublish {
 	char *host;
 	size_t dbl_bytes;   /* offset of the int part of the slab */
@@ -328,9 +374,9 @@ void launch_resize_linear(const float *src, int srows, int scols, float *dst, in
 void launch_sample_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C, double norm_mult,
 	double norm_add, double *dev_feat, hipStream_t st);
 /* whole ICLK loop in one launch, one workgroup per target (N <= 16 * kBlock); false if N is too large */
-constexpr int kIclkTrackMaxPix = 16 * kBlock;
+constexpr int kIclkTrackMaxPix = 8 * kBlock;   /* (the grid points of a thread's pixels stay in registers: k_iclk_track) */
 bool launch_iclk_track(const BatchView &bv, const ImgView &im, const mtfhip_sm_desc &sm, const TrackState &ts,
-	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, int fast_math, const HostPublish &pub, hipStream_t st);
+	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, int fast_math, const HostPublish &pub, const RegionIngest &rg, hipStream_t st);
 void launch_ingest_host(const void *src_host, void *dst, size_t bytes, hipStream_t st);
 void launch_fused_mc(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk, hipStream_t st);   /* bv.C > 1 */
 void launch_track_persist(const BatchView &bv, const ImgView &im, const FusedArgs &fa, const mtfhip_sm_desc &sm, const TrackState &ts,

@@ -138,6 +138,50 @@ def test_config3_grid_256_patches(gpu_ctx, big_frames):
         assert np.median(err) < 0.05 and (err < 0.5).mean() > 0.97
 
 
+@pytest.mark.parametrize("am,ssm,patch", [(L.AM_NCC, L.SSM_AFFINE, 25), (L.AM_SSD, L.SSM_HOMOGRAPHY, 30)])
+def test_grid_frame_region_mode_equals_separate_reset(gpu_ctx, big_frames, am, ssm, patch):
+    """r04: the grid frame is ONE launch -- every workgroup of k_iclk_track ingests its patch's region corners from the pinned staging
+    buffer, derives the square-to-quadrilateral map and lays out its own grid (RegionIngest) -- against the r03 form (slab ingest +
+    k_init_grid in a launch of their own, MTFHIP_GRID_FUSED=0): bit-identical corners, iteration counts AND template grids (the
+    kernel also writes INIT_PTS / INIT_HXY / INIT_Z for the calls that come after the frame), in both arithmetic modes; a patch with
+    degenerate corners is reported as the separate reset reports it."""
+    import os
+    f0, f1, p_true = big_frames
+    region = synth.square_corners(512, 512, 400)
+    if ssm == L.SSM_HOMOGRAPHY:   # a general quadrilateral: the patch grids are projective (unit_z = 0)
+        region = region + np.array([[3.0, -2.0, 5.0, -4.0], [-1.5, 2.5, 4.0, -3.0]])
+    gpu_ctx.set_image(f0)
+    gt = GridTracker(gpu_ctx, grid_size=8, patch_size=patch, am=am, ssm=ssm, max_iters=10, epsilon=1e-4)
+    gt.initialize(region)
+    b = gt.tracker.batch
+    gpu_ctx.set_image(f1)
+    out = {}
+    for math in (mtf_amd.MATH_FAST, mtf_amd.MATH_REPLAY):
+        b.set_math_mode(math)
+        for mode in ("0", "1"):
+            os.environ["MTFHIP_GRID_FUSED"] = mode
+            try:
+                c, cen = gt.update(region)
+                out[mode] = (c.copy(), cen.copy(), gt.tracker.n_iters.copy() if hasattr(gt.tracker, "n_iters") else None,
+                             b.read(L.BUF_INIT_PTS).copy(), b.read(L.BUF_INIT_HXY).copy(), b.read(L.BUF_INIT_Z).copy(), b.get_state().copy())
+            finally:
+                del os.environ["MTFHIP_GRID_FUSED"]
+        for x, y, what in zip(out["0"], out["1"], ("corners", "centroids", "n_iters", "init_pts", "init_hxy", "init_z", "state")):
+            if x is not None:
+                assert np.array_equal(x, y), what
+    # degenerate corners (three collinear points) in one patch: an error either way
+    bad = gt.patch_corners(region).copy()
+    bad[5] = np.array([[100.0, 110.0, 120.0, 130.0], [200.0, 200.0, 200.0, 200.0]])
+    for mode in ("0", "1"):
+        os.environ["MTFHIP_GRID_FUSED"] = mode
+        try:
+            with pytest.raises(mtf_amd.MtfHipError, match="degenerate"):
+                gt.update(bad)
+        finally:
+            del os.environ["MTFHIP_GRID_FUSED"]
+    gt.update(region)   # and the tracker is usable afterwards
+
+
 def test_config4_pf_10000_candidates(gpu_ctx, big_frames):
     """Config 4: 10 000 candidates x 2 500 px: permutation and sharding equivariance, identity candidate."""
     f0, f1, _ = big_frames
