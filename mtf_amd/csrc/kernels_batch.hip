@@ -417,22 +417,22 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 			if (change < sm.epsilon) break;   /* uniform: every thread holds the same numbers */
 		}
 		GRID_STAMP(16);
-		/* (every thread holds the same W / St / Cr: the first lanes store one entry each) */
-#pragma unroll
-		for (int q = 0; q < 9; ++q) if (tid == q) bv.warps[9 * t + q] = W[q];
-#pragma unroll
-		for (int q = 0; q < 8; ++q) if (tid == q) { bv.states[8 * t + q] = St[q]; ts.corners[8 * t + q] = Cr[q]; }
+		/* every thread holds the same W / St / Cr: lane q takes entry q through selects (register arrays cannot be indexed by the lane
+		 * id) and ONE store per array goes out.  (r03 stored entry by entry under `if (tid == q)`: 25 one-lane stores whose address
+		 * register the compiler reused, each behind an s_waitcnt vmcnt(0) for the one before -- a chain of store round trips that was
+		 * 5 us between the last iteration and the publish, r04 phase trace.) */
 		if (region_bad) n_it = -1;
-		if (tid == 0) { ts.n_iters[t] = n_it; ts.acc[(size_t)t * ACC_COUNT + ACC_RR] = f_last; }
-		if (pub.host && tid < 64) {
-			/* lane q holds entry q after the selects below (register arrays cannot be indexed by the lane id) */
+		if (tid < 64) {
 			double wq = 0, sq = 0, cq = 0;
 #pragma unroll
-			for (int q = 0; q < 9; ++q) if (tid == q) wq = W[q];
+			for (int q = 0; q < 9; ++q) wq = tid == q ? W[q] : wq;
 #pragma unroll
-			for (int q = 0; q < 8; ++q) if (tid == q) { sq = St[q]; cq = Cr[q]; }
+			for (int q = 0; q < 8; ++q) { sq = tid == q ? St[q] : sq; cq = tid == q ? Cr[q] : cq; }
 			GRID_STAMP(17);
-			publish_target(pub, t, wq, sq, cq, n_it);
+			if (pub.host) publish_target(pub, t, wq, sq, cq, n_it);   /* the host's copy first: it is what the caller waits for */
+			if (tid < 9) bv.warps[9 * t + tid] = wq;
+			if (tid < 8) { bv.states[8 * t + tid] = sq; ts.corners[8 * t + tid] = cq; }
+			if (tid == 0) { ts.n_iters[t] = n_it; ts.acc[(size_t)t * ACC_COUNT + ACC_RR] = f_last; }
 			GRID_STAMP(18);
 		}
 		return;
