@@ -356,7 +356,9 @@ typedef struct mtfhip_pf_desc {
 	double adaptive_resampling_thresh; /* PFParams::adaptive_resampling_thresh in (0, 1]: resample only when the effective particle count
 	                                      1 / sum (w / sum w)^2 is <= thresh * n (PF.cc:114-118, 381-390); 0: every iteration */
 	int update_distr_wts;     /* PFParams::update_distr_wts: the weights of several sampler distributions follow the average particle weight
-	                             each produced (PF.cc:345-369); needed by mtfhip_pf_set_distributions with more than one */
+	                             each produced (PF.cc:345-369); REQUIRED by mtfhip_pf_set_distributions with more than one distribution: without it the
+	                             reference zeroes the weights and draws from an all-zero discrete distribution (NT/PF.cc:241-257), which every front end
+	                             of this library refuses (MTFHIP_ERR_NOT_IMPLEMENTED; mtf::hip::PF, nt::PF of the harness, the Python wrapper, the oracle) */
 	double min_distr_wt;      /* PFParams::min_distr_wt: floor of a distribution's weight */
 } mtfhip_pf_desc;
 int mtfhip_pf_create(mtfhip_batch *b, const mtfhip_pf_desc *desc, mtfhip_pf **out);
@@ -369,7 +371,10 @@ int mtfhip_pf_set_sampler(mtfhip_pf *pf, const double *sigma, const double *mean
 int mtfhip_pf_set_distributions(mtfhip_pf *pf, int n_distr, const double *sigma /* n_distr x 8 */, const double *mean /* n_distr x 8 */);
 /* the distribution draws of the NEXT iteration supplied by the caller (n uniforms in (0, 1]); NULL: the device generator */
 int mtfhip_pf_set_distr_draws(mtfhip_pf *pf, const double *uniforms);
-/* the distribution weights the next iteration draws from, the particles' distribution ids of the last one (or NULL), whether it resampled */
+/* the distribution weights the next iteration draws from, the particles' distribution ids (or NULL), whether the last iteration resampled.
+ * The ids belong to the particles' CURRENT proposals: with look-ahead proposals (the default with the device generator: the selection
+ * pass of iteration t already draws iteration t + 1) those are the PENDING iteration's draws, not the ones the last weights were
+ * produced by; MTFHIP_PF_LOOKAHEAD=0, or draws handed in by the caller, keep them those of the last iteration. */
 int mtfhip_pf_get_distributions(mtfhip_pf *pf, double *distr_wts /* n_distr */, int *distr_ids /* n or NULL */, int *resampled); /* ProjectiveBase.cc:208-215 */
 /* one iteration of update()'s loop (PF.cc:260-447); normals n x nz (nz = 10 with corner based homography sampling, 6 / 8 / 6 for
  * Affine point based 1 / 2 / geometric, else S) and uniforms n: host arrays, or NULL for the device generator; update_norm =

@@ -1127,6 +1127,13 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 			runs.push_back(ChunkRun{bc, fc, tc, nblk_c, t0, nt, part, q == n_streams - 1 ? st : b->ctx->extra_streams[q], false});
 		}
 		const auto dbg_t0 = std::chrono::steady_clock::now();
+		/* Every way out of the loop below joins the extra queues: the normal path with an event the context's stream waits on; an
+		 * early return (a failed launch or copy: TRY / HIP_TRY) by draining them here -- kernels still in flight on an extra queue
+		 * would otherwise race with whatever the caller enqueues next on the context's stream (r03 advisor finding). */
+		struct QueueJoin {
+			mtfhip_ctx *c; int n; bool joined = false;
+			~QueueJoin() { if (!joined) for (int q = 0; q + 1 < n; ++q) if (c->extra_streams[q]) (void)hipStreamSynchronize(c->extra_streams[q]); }
+		} queue_join{b->ctx, n_streams};
 		/* the chunks of a group (one per queue) advance together, pass by pass, so that both queues are fed from the start */
 		for (size_t g0 = 0; g0 < runs.size(); g0 += (size_t)n_streams) {
 			const size_t g1 = std::min(runs.size(), g0 + (size_t)n_streams);
@@ -1168,6 +1175,7 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 			HIP_TRY(hipEventRecord(b->ctx->ev_join[q], b->ctx->extra_streams[q]));
 			HIP_TRY(hipStreamWaitEvent(st, b->ctx->ev_join[q], 0));
 		}
+		queue_join.joined = true;
 	}
 	/* the slab (warps, states, corners, iteration counts) comes back either through a kernel that writes it into host-coherent
 	 * memory and raises a flag the host spins on, or as one copy + one sync (MTFHIP_ZERO_COPY=0) */

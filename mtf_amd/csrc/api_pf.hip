@@ -321,8 +321,9 @@ int mtfhip_pf_set_distr_draws(mtfhip_pf *pf, const double *u) {
 	if (u) pf->distr_u_next.assign(u, u + pf->n); else pf->distr_u_next.clear();
 	return MTFHIP_OK;
 }
-/* the distribution weights the next iteration draws from (n_distr values), the distribution id of every particle of the last
- * iteration (n, or NULL), whether the last iteration resampled (adaptive resampling, PF.cc:381-390) */
+/* the distribution weights the next iteration draws from (n_distr values), the distribution id of every particle's CURRENT proposal (n,
+ * or NULL: with look-ahead on, k_pf_select has already drawn the pending iteration's -- see mtfhip.h), whether the last iteration
+ * resampled (adaptive resampling, PF.cc:381-390) */
 int mtfhip_pf_get_distributions(mtfhip_pf *pf, double *wts, int *ids, int *resampled) {
 	if (!pf) return fail(MTFHIP_ERR_INVALID_ARG, "pf_get_distributions: NULL filter");
 	hipStream_t st = pf->b->ctx->stream;

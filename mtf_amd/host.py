@@ -1,5 +1,7 @@
-"""ctypes view of libmtfhost.so: the C++ host layer (mtf::hip::HipAM / HipSSM adapter classes driven by
-mtf::nt::ESM / FCLK / ICLK, mtf_amd/host/*.cpp) -- the reference-language side of the drop-in boundary."""
+"""ctypes view of the C++ host layer -- the reference-language side of the drop-in boundary: libmtfhost.so = the PRODUCT (mtf::hip::HipAM /
+HipSSM adapter classes, mtf::hip::LK / PF device drivers, mtf_amd/host/*.cpp), libmtfharness.so = the HARNESS (the reference's callers
+mtf::nt::ESM / FCLK / ICLK / PF restated over the virtuals, the templated SearchMethod<AM, SSM> shape, and the C wrapper this module
+binds, mtf_amd/host/harness/*.cpp)."""
 import ctypes as C
 import os
 import sys
@@ -10,7 +12,8 @@ import numpy as np
 from . import _lib
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmtfhost.so")
+LIB_PATH = os.path.join(_HERE, "libmtfharness.so")   # the C wrapper lives with the restated callers; it links libmtfhost.so (the product)
+PRODUCT_LIB_PATH = os.path.join(_HERE, "libmtfhost.so")
 HOST_SRC = os.path.join(_HERE, "host")
 _h = None
 
@@ -25,7 +28,7 @@ def lib():
     if _h is None:
         _lib.lib()   # loads libmtfhip.so (and torch's HIP runtime first, when present)
         if not os.path.exists(LIB_PATH):
-            raise ImportError("libmtfhost.so is missing: run __graft_entry__.build()")
+            raise ImportError("libmtfharness.so is missing: run __graft_entry__.build()")
         H = C.CDLL(LIB_PATH)
         H.mtfhost_last_error.restype = C.c_char_p
         H.mtfhost_create.restype = C.c_void_p
@@ -50,6 +53,8 @@ def lib():
                                            C.c_int, C.c_double, C.c_ulonglong, C.c_int]
         H.mtfhost_pf_create_pix.restype = C.c_void_p
         H.mtfhost_pf_create_pix.argtypes = H.mtfhost_pf_create_ex.argtypes + [C.c_void_p]
+        H.mtfhost_templated_fclk.argtypes = [C.c_int] * 5 + [C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         H.mtfhost_ssm_random_walk.argtypes = [C.c_void_p, C.c_ulonglong, C.c_int, C.c_void_p, C.c_void_p]
         H.mtfhost_ssm_pts_after_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _h = H
@@ -154,7 +159,7 @@ class CppParticleFilter(CppTracker):
     def __init__(self, device_filter=True, am=_lib.AM_SSD, ssm=_lib.SSM_HOMOGRAPHY, resx=50, resy=50, n_particles=500, max_iters=1,
                  epsilon=0.01, dynamic_model=0, update_type=1, likelihood_func=0, resampling_type=1, mean_type=0,
                  corner_based_sampling=1, ssm_sigma=(0.01, 0.01, 2.0, 0.01, 0.01, 2.0, 1e-5, 1e-5), likelihood_alpha=1.0, seed=1,
-                 device=0, ssm_mean=None, update_distr_wts=1, min_distr_wt=0.1, adaptive_resampling_thresh=0.0, jacobian_as_sigma=0, pix_sigma=None):
+                 device=0, ssm_mean=None, update_distr_wts=0, min_distr_wt=0.1, adaptive_resampling_thresh=0.0, jacobian_as_sigma=0, pix_sigma=None):
         """ssm_sigma: one row, or several rows = several sampler distributions (PFParams::processDistributions)"""
         rows = [list(ssm_sigma)] if np.ndim(ssm_sigma) == 1 else [list(r) for r in ssm_sigma]
         mrows = [[0.0] * 8 for _ in rows] if ssm_mean is None else ([list(ssm_mean)] if np.ndim(ssm_mean) == 1 else [list(r) for r in ssm_mean])
@@ -194,3 +199,16 @@ def qr_solve(A, b):
     x = np.empty(n)
     _check(lib().mtfhost_qr_solve(n, Af.ctypes.data_as(C.c_void_p), bb.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p)))
     return x
+
+
+def templated_fclk(frame0, frame1, corners, am=_lib.AM_SSD, ssm=_lib.SSM_HOMOGRAPHY, resx=40, resy=40, max_iters=10, epsilon=1e-4, hess_type=1, device=0):
+    """FCLK<HipAM, HipSSM> in the reference's TEMPLATED search-method shape (harness/TemplatedSM.h: models by value, built from
+    `const AM::ParamType *` / `const SSM::ParamType *`): initialize on frame0, one update() on frame1 -> (corners (2, 4), iterations)"""
+    assert frame0.dtype == np.float32 and frame1.dtype == np.float32 and frame0.shape == frame1.shape and frame0.flags["C_CONTIGUOUS"] and frame1.flags["C_CONTIGUOUS"]
+    c = np.ascontiguousarray(np.asarray(corners, dtype=np.float64).reshape(2, 4).T.ravel())
+    out = np.zeros(8)
+    n = C.c_int(0)
+    _check(lib().mtfhost_templated_fclk(am, ssm, resx, resy, max_iters, epsilon, hess_type, device, frame0.ctypes.data_as(C.c_void_p),
+                                        frame1.ctypes.data_as(C.c_void_p), frame0.shape[0], frame0.shape[1], frame0.shape[1],
+                                        c.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.byref(n)))
+    return out.reshape(4, 2).T.copy(), n.value

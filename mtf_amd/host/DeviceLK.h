@@ -1,7 +1,7 @@
 /*
  * DeviceLK.h -- mtf::hip::LK: nt::ESM / nt::FCLK / nt::ICLK as ONE C-ABI call per update().
  *
- * mtf::nt::ESM / FCLK / ICLK (SearchMethods.h) are the literal search methods: a loop over the AM / SSM virtuals, as
+ * mtf::nt::ESM / FCLK / ICLK (harness/SearchMethods.h: restated callers, test infrastructure) are the literal search methods: a loop over the AM / SSM virtuals, as
  * SM/src/NT/ESM.cc:170-296, NT/FCLK.cc:187-342 and NT/ICLK.cc:160-298 write it, which the library serves call by call
  * (20-37 us per loop pass for one target).  This class is the registration a maintainer adds next to them for a HipAM / HipSSM
  * pair (the counterpart of mtf::hip::PF): the same parameters -- the reference's class defaults included, Levenberg-Marquardt on --
@@ -13,7 +13,7 @@
 #define MTF_AMD_HOST_DEVICE_LK_H
 
 #include "HipModels.h"
-#include "SearchMethods.h"
+#include "SearchMethod.h"
 
 namespace mtf {
 namespace hip {

@@ -77,6 +77,13 @@ HipAM::HipAM(std::shared_ptr<HipPair> pair) : p(pair) {
 	p->init_hess_key = d2I0_dx2.data();
 	p->curr_hess_key = d2It_dx2.data();
 }
+static std::shared_ptr<HipPair> pair_of(const std::shared_ptr<HipLink> &link, int n_channels, const char *who) {
+	if (!link) throw utils::InvalidArgument(std::string(who) + " :: the parameter block carries no HipLink (the AM and the SSM of a tracker share one)");
+	return link->pair(n_channels);
+}
+HipAM::HipAM(const ParamType *params, int n_channels) : HipAM(pair_of(params ? params->link : nullptr, n_channels, "HipAM")) {
+	learning_rate = params->learning_rate;
+}
 const double *HipAM::hessPtsArg(const HessPtsT &pts) const { return pts.data() == p->hess_pts_key ? nullptr : pts.data(); }
 const double *HipAM::ptsArg(const PtsT &pts) const { return pts.data() == p->pts_key ? nullptr : pts.data(); }
 const double *HipAM::gradPtsArg(const GradPtsT &pts) const { return pts.data() == p->grad_pts_key ? nullptr : pts.data(); }
@@ -204,9 +211,13 @@ HipSSM::HipSSM(std::shared_ptr<HipPair> pair) : p(pair) {
 	hess_pts.resize(16, p->n_pix);
 	p->hess_pts_key = hess_pts.data();
 	curr_state.resize(p->S);
-	std::memset(curr_corners.v, 0, sizeof(curr_corners.v));
+	std::memset(curr_corners.data(), 0, sizeof(double) * 8);
 	p->pts_key = curr_pts.data();
 	p->grad_pts_key = grad_pts.data();
+}
+HipSSM::HipSSM(const ParamType *params) : HipSSM(pair_of(params ? params->link : nullptr, 1, "HipSSM")) {
+	corner_based_sampling = params->corner_based_sampling;
+	pt_based_sampling = params->pt_based_sampling;
 }
 void HipSSM::syncSmall() {
 	HipPair::check(mtfhip_ssm_get_corners(p->b, curr_corners.data()));
@@ -359,14 +370,14 @@ void HipSSM::generatePerturbation(VectorXd &pert) {
 		const double tx = draw(0), ty = draw(0);
 		double rd[8];
 		for (int c = 0; c < 4; ++c) { rd[2 * c] = draw(1); rd[2 * c + 1] = draw(1); }
-		for (int c = 0; c < 4; ++c) { dc.v[2 * c] = ic.v[2 * c] + rd[2 * c] + tx; dc.v[2 * c + 1] = ic.v[2 * c + 1] + rd[2 * c + 1] + ty; }
+		for (int c = 0; c < 4; ++c) { dc.data()[2 * c] = ic.data()[2 * c] + rd[2 * c] + tx; dc.data()[2 * c + 1] = ic.data()[2 * c + 1] + rd[2 * c + 1] + ty; }
 		estimateWarpFromCorners(pert, ic, dc);
 		return;
 	}
 	if (p->ssm == MTFHIP_SSM_AFFINE && pt_based_sampling) {
 		CornersT ic;
 		HipPair::check(mtfhip_ssm_get_init_corners(p->b, ic.data()));
-		const double ox[3] = {ic.v[4], ic.v[6], (ic.v[0] + ic.v[2]) / 2.0}, oy[3] = {ic.v[5], ic.v[7], (ic.v[1] + ic.v[3]) / 2.0};
+		const double ox[3] = {ic.data()[4], ic.data()[6], (ic.data()[0] + ic.data()[2]) / 2.0}, oy[3] = {ic.data()[5], ic.data()[7], (ic.data()[1] + ic.data()[3]) / 2.0};
 		double px[3], py[3];
 		if (pt_based_sampling == 1) {
 			for (int i = 0; i < 3; ++i) { px[i] = ox[i] + draw(2 * i); py[i] = oy[i] + draw(2 * i + 1); }

@@ -48,9 +48,35 @@ struct HipPair {
 	int hessianBuffer(const MatrixXd &D, bool may_register);
 };
 
+/* What the AM and the SSM of ONE tracker share, in the form the reference's templated search methods can carry it.
+ * SearchMethod<AM, SSM> holds its models BY VALUE and builds them from `const AM::ParamType *` / `const SSM::ParamType *`
+ * (SM/include/mtf/SM/SearchMethod.h:13-19, SM/src/ESM.cc:79-118; the models' own constructors: AM/include/mtf/AM/SSD.h
+ * `SSD(const ParamType *ssd_params = nullptr, const int _n_channels = 1)`, SSM/include/mtf/SSM/Homography.h
+ * `Homography(const ParamType *params_in = nullptr)`), so the two adapter objects cannot be handed a shared pair by the caller: both
+ * parameter blocks point at one HipLink, and whichever model is constructed first creates the pair (context + one-target batch). */
+struct HipLink {
+	int am = MTFHIP_AM_SSD, ssm = MTFHIP_SSM_HOMOGRAPHY, resx = 50, resy = 50;   /* AMParams / SSMParams: resx, resy */
+	double grad_eps = 1e-8, likelihood_alpha = 1.0;                           /* AMParams::grad_eps; SSDParams / NCCParams / MIParams::likelihood_alpha */
+	int mi_n_bins = 8; double mi_pre_seed = 10; int mi_pou = 0;                /* MIParams */
+	int device = 0; void *stream = nullptr;
+	std::shared_ptr<HipPair> pair(int n_channels = 1) {
+		if (!p) p = std::make_shared<HipPair>(am, ssm, resx, resy, grad_eps, likelihood_alpha, mi_n_bins, mi_pre_seed, mi_pou, device, stream, n_channels);
+		else if (n_channels > 1 && n_channels != p->n_channels)   /* (SearchMethod<AM, SSM> constructs the AM first: it fixes the channel count) */
+			throw utils::InvalidArgument("HipLink :: the pair exists with another channel count");
+		return p;
+	}
+private:
+	std::shared_ptr<HipPair> p;
+};
+struct HipAMParams { std::shared_ptr<HipLink> link; double learning_rate = 0.5; };
+struct HipSSMParams { std::shared_ptr<HipLink> link; bool corner_based_sampling = true; int pt_based_sampling = 0; };
+
 class HipAM : public AppearanceModel {
 public:
+	typedef HipAMParams ParamType;
 	HipAM(std::shared_ptr<HipPair> pair);
+	/* the constructor SearchMethod<AM, SSM> calls (am(am_params): n_channels defaults as in the reference's models) */
+	explicit HipAM(const ParamType *params, int n_channels = 1);
 	unsigned int getResX() const override { return p->resx; }
 	unsigned int getResY() const override { return p->resy; }
 	unsigned int getNPix() const override { return p->n_pix; }
@@ -140,7 +166,9 @@ private:
 
 class HipSSM : public StateSpaceModel {
 public:
+	typedef HipSSMParams ParamType;
 	HipSSM(std::shared_ptr<HipPair> pair);
+	explicit HipSSM(const ParamType *params);   /* ssm(ssm_params) of SearchMethod<AM, SSM> */
 	unsigned int getStateSize() override { return p->S; }
 	unsigned int getResX() override { return p->resx; }
 	unsigned int getResY() override { return p->resy; }

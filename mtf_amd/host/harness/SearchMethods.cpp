@@ -4,59 +4,9 @@
 
 namespace mtf {
 
-/* column-pivoted Householder QR solve, the algorithm behind Eigen's ColPivHouseholderQR::solve */
-void utils::colPivHouseholderQrSolve(const MatrixXd &Ain, const VectorXd &b, VectorXd &x) {
-	const int n = Ain.rows();
-	if (Ain.cols() != n || b.size() != n) throw InvalidArgument("colPivHouseholderQrSolve: size mismatch");
-	MatrixXd A = Ain;
-	std::vector<double> rhs(b.data(), b.data() + n), v(n);
-	std::vector<int> perm(n);
-	for (int j = 0; j < n; ++j) perm[j] = j;
-	int rank = n;
-	for (int k = 0; k < n; ++k) {
-		int piv = k;
-		double best = -1;
-		for (int j = k; j < n; ++j) {
-			double s = 0;
-			for (int i = k; i < n; ++i) s += A(i, j) * A(i, j);
-			if (s > best) { best = s; piv = j; }
-		}
-		if (best <= 0) { rank = k; break; }
-		if (piv != k) {
-			for (int i = 0; i < n; ++i) std::swap(A(i, piv), A(i, k));
-			std::swap(perm[piv], perm[k]);
-		}
-		const double norm = std::sqrt(best);
-		const double alpha = A(k, k) > 0 ? -norm : norm;
-		double vnorm2 = 0;
-		for (int i = k; i < n; ++i) { v[i] = A(i, k); if (i == k) v[i] -= alpha; vnorm2 += v[i] * v[i]; }
-		if (vnorm2 > 0) {
-			for (int j = k; j < n; ++j) {
-				double dot = 0;
-				for (int i = k; i < n; ++i) dot += v[i] * A(i, j);
-				const double f = 2 * dot / vnorm2;
-				for (int i = k; i < n; ++i) A(i, j) -= f * v[i];
-			}
-			double dot = 0;
-			for (int i = k; i < n; ++i) dot += v[i] * rhs[i];
-			const double f = 2 * dot / vnorm2;
-			for (int i = k; i < n; ++i) rhs[i] -= f * v[i];
-		}
-	}
-	std::vector<double> y(n, 0.0);
-	for (int k = rank - 1; k >= 0; --k) {
-		double s = rhs[k];
-		for (int j = k + 1; j < rank; ++j) s -= A(k, j) * y[j];
-		y[k] = s / A(k, k);
-	}
-	x.resize(n);
-	for (int k = 0; k < n; ++k) x[perm[k]] = y[k];
-}
-
 namespace nt {
 
-SearchMethod::SearchMethod(AM _am, SSM _ssm, const SMParams &_params) : am(_am), ssm(_ssm), params(_params) {
-	ssm_state_size = (int)ssm->getStateSize();
+LKSearchMethod::LKSearchMethod(AM _am, SSM _ssm, const SMParams &_params) : SearchMethod(_am, _ssm, _params) {
 	const int n = (int)am->getPatchSize();
 	init_pix_jacobian.resize(n, ssm_state_size);
 	curr_pix_jacobian.resize(n, ssm_state_size);
@@ -68,7 +18,7 @@ SearchMethod::SearchMethod(AM _am, SSM _ssm, const SMParams &_params) : am(_am),
 }
 
 /* ESM::initializePixJacobian NT/ESM.cc:379-388 (same shape in FCLK :113-133 and ICLK :78-95) */
-void SearchMethod::initPixJacobian(MatrixXd &J) {
+void LKSearchMethod::initPixJacobian(MatrixXd &J) {
 	if (params.chained_warp) {
 		am->initializePixGrad(ssm->getPts());
 		ssm->cmptWarpedPixJacobian(J, am->getInitPixGrad());
@@ -79,7 +29,7 @@ void SearchMethod::initPixJacobian(MatrixXd &J) {
 	}
 }
 /* ESM::updatePixJacobian NT/ESM.cc:390-408 */
-void SearchMethod::updatePixJacobian(MatrixXd &J) {
+void LKSearchMethod::updatePixJacobian(MatrixXd &J) {
 	if (params.chained_warp) {
 		am->updatePixGrad(ssm->getPts());
 		ssm->cmptWarpedPixJacobian(J, am->getCurrPixGrad());
@@ -90,19 +40,19 @@ void SearchMethod::updatePixJacobian(MatrixXd &J) {
 	}
 }
 /* ESM::initializePixHessian NT/ESM.cc:406-416 ; FCLK NT/FCLK.cc:121-142 ; ICLK NT/ICLK.cc:96-113 */
-void SearchMethod::initPixHess() {
+void LKSearchMethod::initPixHess() {
 	if (params.chained_warp) am->initializePixHess(ssm->getPts());
 	else {
 		ssm->initializeHessPts(am->getHessOffset());
 		am->initializePixHess(ssm->getPts(), ssm->getHessPts());
 	}
 }
-void SearchMethod::pixHessianFromInit(MatrixXd &D) {
+void LKSearchMethod::pixHessianFromInit(MatrixXd &D) {
 	if (params.chained_warp) ssm->cmptWarpedPixHessian(D, am->getInitPixHess(), am->getInitPixGrad());
 	else ssm->cmptInitPixHessian(D, am->getInitPixHess(), am->getInitPixGrad());
 }
 /* ESM::updatePixHessian NT/ESM.cc:418-432 ; FCLK NT/FCLK.cc:243-257 ; ICLK NT/ICLK.cc:223-237 */
-void SearchMethod::updatePixHessian(MatrixXd &D) {
+void LKSearchMethod::updatePixHessian(MatrixXd &D) {
 	if (params.chained_warp) {
 		am->updatePixHess(ssm->getPts());
 		ssm->cmptWarpedPixHessian(D, am->getCurrPixHess(), am->getCurrPixGrad());
@@ -112,11 +62,11 @@ void SearchMethod::updatePixHessian(MatrixXd &D) {
 		ssm->cmptInitPixHessian(D, am->getCurrPixHess(), am->getCurrPixGrad());
 	}
 }
-void SearchMethod::selfHessian(MatrixXd &H, const MatrixXd &J, const MatrixXd &D) {
+void LKSearchMethod::selfHessian(MatrixXd &H, const MatrixXd &J, const MatrixXd &D) {
 	if (params.sec_ord_hess) am->cmptSelfHessian(H, J, D);
 	else am->cmptSelfHessian(H, J);
 }
-void SearchMethod::dampAndSolve(double delta) {
+void LKSearchMethod::dampAndSolve(double delta) {
 	if (params.leven_marq)
 		for (int i = 0; i < ssm_state_size; ++i) hessian(i, i) += delta * hessian(i, i);
 	utils::colPivHouseholderQrSolve(hessian, jacobian, state_update);
@@ -124,7 +74,7 @@ void SearchMethod::dampAndSolve(double delta) {
 }
 
 /* ------------------------------------------------------------------ ESM */
-ESM::ESM(AM a, SSM s, const SMParams &p) : SearchMethod(a, s, p) {
+ESM::ESM(AM a, SSM s, const SMParams &p) : LKSearchMethod(a, s, p) {
 	name = "esm_nt";
 	if (params.hess_type < 0) params.hess_type = SumOfSelf;
 	const int n = (int)am->getPatchSize(), s2 = ssm_state_size * ssm_state_size;
@@ -219,7 +169,7 @@ void ESM::update() {
 		dampAndSolve(leven_marq_delta);
 		prev_corners = ssm->getCorners();
 		ssm->compositionalUpdate(state_update);
-		const double update_norm = prev_corners.squaredDistance(ssm->getCorners());
+		const double update_norm = utils::squaredDistance(prev_corners, ssm->getCorners());
 		if (update_norm < params.epsilon) break;
 		am->clearFirstIter();
 	}
@@ -227,7 +177,7 @@ void ESM::update() {
 }
 
 /* ------------------------------------------------------------------ FCLK */
-FCLK::FCLK(AM a, SSM s, const SMParams &p) : SearchMethod(a, s, p) {
+FCLK::FCLK(AM a, SSM s, const SMParams &p) : LKSearchMethod(a, s, p) {
 	name = "fclk_nt";
 	if (params.hess_type < 0) params.hess_type = CurrentSelf;
 	if (params.sec_ord_hess) {   /* NT/FCLK.cc:66-75 */
@@ -301,7 +251,7 @@ void FCLK::update() {
 		dampAndSolve(leven_marq_delta);
 		prev_corners = ssm->getCorners();
 		ssm->compositionalUpdate(state_update);
-		const double update_norm = prev_corners.squaredDistance(ssm->getCorners());
+		const double update_norm = utils::squaredDistance(prev_corners, ssm->getCorners());
 		if (update_norm < params.epsilon) break;
 		am->clearFirstIter();
 		++iter_id;
@@ -310,7 +260,7 @@ void FCLK::update() {
 }
 
 /* ------------------------------------------------------------------ ICLK */
-ICLK::ICLK(AM a, SSM s, const SMParams &p) : SearchMethod(a, s, p) {
+ICLK::ICLK(AM a, SSM s, const SMParams &p) : LKSearchMethod(a, s, p) {
 	name = "iclk_nt";
 	if (params.hess_type < 0) params.hess_type = InitialSelf;
 	if (params.sec_ord_hess) {   /* NT/ICLK.cc:61-67 */
@@ -376,7 +326,7 @@ void ICLK::update() {
 		prev_corners = ssm->getCorners();
 		ssm->invertState(inv_update, state_update);
 		ssm->compositionalUpdate(inv_update);
-		const double update_norm = prev_corners.squaredDistance(ssm->getCorners());
+		const double update_norm = utils::squaredDistance(prev_corners, ssm->getCorners());
 		if (update_norm < params.epsilon) break;
 		am->clearFirstIter();
 	}

@@ -4,50 +4,25 @@
  * SM/src/NT/ESM.cc:170-296, NT/FCLK.cc:171-358, NT/ICLK.cc:160-299), parameters with the reference's names,
  * enums and class defaults (SM/src/ESMParams.cc:4-15, FCLKParams.cc:4-17, ICLKParams.cc:4-14).
  * They are the callers of the hot path: nothing here knows whether the AM / SSM run on a GPU.
+ * HARNESS (libmtfharness.so), not product: condensed restatements of the reference's callers, kept so that the adapters can be
+ * driven through the reference's own virtual-call sequence in tests and in the drop-in bench line.  An MTF build has the originals.
  */
 #ifndef MTF_AMD_HOST_SEARCH_METHODS_H
 #define MTF_AMD_HOST_SEARCH_METHODS_H
 
 #include <memory>
 
-#include "AppearanceModel.h"
-#include "StateSpaceModel.h"
+#include "../SearchMethod.h"
 
 namespace mtf {
 namespace nt {
 
-struct SMParams {
-	int max_iters = 30;
-	double epsilon = 1e-4;
-	int jac_type = 1;          /* ESMParams::JacType { Original, DiffOfJacs } */
-	int hess_type = -1;        /* per-SM enum; -1 = the SM's class default */
-	bool sec_ord_hess = false;
-	bool chained_warp = true;
-	bool leven_marq = true;
-	double lm_delta_init = 0.01;
-	double lm_delta_update = 10;
-	bool enable_learning = false;   /* ESM / FC / IC_ENABLE_LEARNING: am->updateModel(ssm->getPts()) after update() (NT/ESM.cc:293-295) */
-};
-
-class SearchMethod {
+/* what the three Lucas-Kanade loops share (the reference keeps these members in every NT class): the SM-owned pixel Jacobians /
+ * Hessians and the steps ESM, FCLK and ICLK all take */
+class LKSearchMethod : public SearchMethod {
 public:
-	typedef std::shared_ptr<AppearanceModel> AM;
-	typedef std::shared_ptr<StateSpaceModel> SSM;
-	std::string name;
-	SearchMethod(AM _am, SSM _ssm, const SMParams &_params);
-	virtual ~SearchMethod() {}
-	virtual void initialize(const CornersT &corners) = 0;
-	virtual void update() = 0;
-	virtual void setRegion(const CornersT &corners) { ssm->setCorners(corners); }
-	virtual const CornersT &getRegion() { return ssm->getCorners(); }
-	void setLearning(bool on) { params.enable_learning = on; }
-	virtual void setImage(const ImageView &img) { am->setCurrImg(img); }
-	int getItersDone() const { return iters_done; }
+	LKSearchMethod(AM _am, SSM _ssm, const SMParams &_params);
 protected:
-	AM am;
-	SSM ssm;
-	SMParams params;
-	int ssm_state_size, iters_done = 0;
 	MatrixXd init_pix_jacobian, curr_pix_jacobian, mean_pix_jacobian;
 	MatrixXd init_pix_hessian, curr_pix_hessian, mean_pix_hessian;   /* S^2 x N, sec_ord_hess only */
 	RowVectorXd jacobian;
@@ -63,7 +38,7 @@ protected:
 	void dampAndSolve(double delta);    /* hessian += delta*diag(hessian); state_update = -H^-1 g */
 };
 
-class ESM : public SearchMethod {
+class ESM : public LKSearchMethod {
 public:
 	enum HessType { InitialSelf, CurrentSelf, SumOfSelf, Original, SumOfStd, Std };
 	ESM(AM am, SSM ssm, const SMParams &params);
@@ -71,7 +46,7 @@ public:
 	void update() override;
 	void setRegion(const CornersT &corners) override;
 };
-class FCLK : public SearchMethod {
+class FCLK : public LKSearchMethod {
 public:
 	enum HessType { InitialSelf, CurrentSelf, Std };
 	FCLK(AM am, SSM ssm, const SMParams &params);
@@ -79,7 +54,7 @@ public:
 	void update() override;
 	void setRegion(const CornersT &corners) override;
 };
-class ICLK : public SearchMethod {
+class ICLK : public LKSearchMethod {
 public:
 	enum HessType { InitialSelf, CurrentSelf, Std };
 	ICLK(AM am, SSM ssm, const SMParams &params);

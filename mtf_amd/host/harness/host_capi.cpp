@@ -1,16 +1,19 @@
 /*
  * host_capi.cpp -- a small C wrapper around the C++ host layer (mtf::hip::HipAM / HipSSM driven by
  * mtf::nt::ESM / FCLK / ICLK), the equivalent of the reference's pyMTF create / setRegion / getRegion
- * (Examples/cpp/pyMTF.cc:35-62), so that the test-suite can drive the C++ objects.
+ * (Examples/cpp/pyMTF.cc:35-62), so that the test-suite can drive the C++ objects.  HARNESS (libmtfharness.so): it constructs the
+ * product's adapters and device drivers (libmtfhost.so) AND the restated reference callers that live next to it.
  */
 #include <cstring>
 #include <memory>
 #include <string>
 
-#include "HipModels.h"
+#include "../HipModels.h"
+#include "../DeviceLK.h"
+#include "../DevicePF.h"
 #include "SearchMethods.h"
 #include "PF.h"
-#include "DeviceLK.h"
+#include "TemplatedSM.h"
 
 using namespace mtf;
 
@@ -31,7 +34,7 @@ mtfhost_tracker *mtfhost_create(int sm, int am, int ssm, int resx, int resy, int
 	int jac_type, int hess_type, int chained_warp, int leven_marq, double lm_delta_init, double lm_delta_update,
 	int device, int sec_ord_hess, int n_channels) {
 	try {
-		auto *t = new mtfhost_tracker();
+		std::unique_ptr<mtfhost_tracker> t(new mtfhost_tracker());   /* (a constructor below may throw: nothing leaks) */
 		t->pair = std::make_shared<hip::HipPair>(am, ssm, resx, resy, 1e-8, 1.0, 8, 10.0, 0, device, nullptr, n_channels);
 		t->am = std::make_shared<hip::HipAM>(t->pair);
 		t->ssm = std::make_shared<hip::HipSSM>(t->pair);
@@ -45,8 +48,8 @@ mtfhost_tracker *mtfhost_create(int sm, int am, int ssm, int resx, int resy, int
 		else if (sm == MTFHIP_SM_ESM) t->sm.reset(new nt::ESM(t->am, t->ssm, p));
 		else if (sm == MTFHIP_SM_FCLK) t->sm.reset(new nt::FCLK(t->am, t->ssm, p));
 		else if (sm == MTFHIP_SM_ICLK) t->sm.reset(new nt::ICLK(t->am, t->ssm, p));
-		else { delete t; g_err = "unknown search method"; return nullptr; }
-		return t;
+		else { g_err = "unknown search method"; return nullptr; }
+		return t.release();
 	} catch (const std::exception &e) { g_err = e.what(); return nullptr; }
 }
 void mtfhost_destroy(mtfhost_tracker *t) { delete t; }
@@ -69,11 +72,11 @@ int mtfhost_set_image(mtfhost_tracker *t, const float *img, int rows, int cols, 
 }
 int mtfhost_initialize(mtfhost_tracker *t, const double *corners) {
 	return guarded(t, [](mtfhost_tracker *tt, const void *in, void *) {
-		CornersT c; std::memcpy(c.v, in, sizeof(c.v)); tt->sm->initialize(c); }, corners, nullptr);
+		CornersT c; std::memcpy(c.data(), in, sizeof(double) * 8); tt->sm->initialize(c); }, corners, nullptr);
 }
 int mtfhost_set_region(mtfhost_tracker *t, const double *corners) {
 	return guarded(t, [](mtfhost_tracker *tt, const void *in, void *) {
-		CornersT c; std::memcpy(c.v, in, sizeof(c.v)); tt->sm->setRegion(c); }, corners, nullptr);
+		CornersT c; std::memcpy(c.data(), in, sizeof(double) * 8); tt->sm->setRegion(c); }, corners, nullptr);
 }
 int mtfhost_update(mtfhost_tracker *t, int *iters_done) {
 	return guarded(t, [](mtfhost_tracker *tt, const void *, void *out) {
@@ -81,7 +84,7 @@ int mtfhost_update(mtfhost_tracker *t, int *iters_done) {
 }
 int mtfhost_get_region(mtfhost_tracker *t, double *corners) {
 	return guarded(t, [](mtfhost_tracker *tt, const void *, void *out) {
-		std::memcpy(out, tt->sm->getRegion().v, sizeof(double) * 8); }, nullptr, corners);
+		std::memcpy(out, tt->sm->getRegion().data(), sizeof(double) * 8); }, nullptr, corners);
 }
 /* the SSM's host-side algebra through the StateSpaceModel virtuals (tests): what = 0 getIdentityWarp(out S), 1 composeWarps(out S;
  * a, b states), 2 estimateWarpFromCorners(out S; a, b corners 2 x 4), 3 applyWarpToCorners(out 8; a corners, b state),
@@ -123,7 +126,7 @@ mtfhost_tracker *mtfhost_pf_create(int device_filter, int am, int ssm, int resx,
 	int dynamic_model, int update_type, int likelihood_func, int resampling_type, int mean_type, int corner_based_sampling,
 	const double *ssm_sigma, double likelihood_alpha, unsigned long long seed, int device) {
 	try {
-		auto *t = new mtfhost_tracker();
+		std::unique_ptr<mtfhost_tracker> t(new mtfhost_tracker());   /* (a constructor below may throw: nothing leaks) */
 		t->pair = std::make_shared<hip::HipPair>(am, ssm, resx, resy, 1e-8, likelihood_alpha, 8, 10.0, 0, device, nullptr, 1);
 		t->am = std::make_shared<hip::HipAM>(t->pair);
 		t->ssm = std::make_shared<hip::HipSSM>(t->pair);
@@ -136,7 +139,7 @@ mtfhost_tracker *mtfhost_pf_create(int device_filter, int am, int ssm, int resx,
 		p.ssm_sigma.assign(ssm_sigma, ssm_sigma + t->pair->S);
 		if (device_filter) t->sm.reset(new hip::PF(t->am, t->ssm, p));
 		else t->sm.reset(new nt::PF(t->am, t->ssm, p));
-		return t;
+		return t.release();
 	} catch (const std::exception &e) { g_err = e.what(); return nullptr; }
 }
 /* the same with the options of the shipped configuration: n_distr >= 1 sampler distributions (rows of 8), adaptive resampling,
@@ -160,7 +163,7 @@ mtfhost_tracker *mtfhost_pf_create_pix(int device_filter, int am, int ssm, int r
 	int jacobian_as_sigma, double likelihood_alpha, unsigned long long seed, int device, const double *pix_sigma) {
 	try {
 		if (n_distr < 1) throw utils::InvalidArgument("mtfhost_pf_create_ex: n_distr must be positive");
-		auto *t = new mtfhost_tracker();
+		std::unique_ptr<mtfhost_tracker> t(new mtfhost_tracker());   /* (a constructor below may throw: nothing leaks) */
 		t->pair = std::make_shared<hip::HipPair>(am, ssm, resx, resy, 1e-8, likelihood_alpha, 8, 10.0, 0, device, nullptr, 1);
 		t->am = std::make_shared<hip::HipAM>(t->pair);
 		t->ssm = std::make_shared<hip::HipSSM>(t->pair);
@@ -171,18 +174,18 @@ mtfhost_tracker *mtfhost_pf_create_pix(int device_filter, int am, int ssm, int r
 		p.likelihood_func = (PFParams::LikelihoodFunc)likelihood_func; p.resampling_type = (PFParams::ResamplingType)resampling_type;
 		p.mean_type = (PFParams::MeanType)mean_type; p.seed = seed;
 		const int S = t->pair->S;
-		p.ssm_sigma.assign(sigma_rows, sigma_rows + S);
-		p.ssm_mean.assign(mean_rows, mean_rows + S);
-		for (int i = 1; i < n_distr; ++i) {
-			p.more_sigma.emplace_back(sigma_rows + 8 * i, sigma_rows + 8 * i + S);
-			p.more_mean.emplace_back(mean_rows + 8 * i, mean_rows + 8 * i + S);
+		if (pix_sigma) p.pix_sigma.assign(pix_sigma, pix_sigma + n_distr);   /* (ssm_sigma is then not used: left empty, PFParams.h) */
+		else {
+			p.ssm_sigma.assign(sigma_rows, sigma_rows + S);
+			for (int i = 1; i < n_distr; ++i) p.more_sigma.emplace_back(sigma_rows + 8 * i, sigma_rows + 8 * i + S);
 		}
-		if (pix_sigma) p.pix_sigma.assign(pix_sigma, pix_sigma + n_distr);
+		p.ssm_mean.assign(mean_rows, mean_rows + S);
+		for (int i = 1; i < n_distr; ++i) p.more_mean.emplace_back(mean_rows + 8 * i, mean_rows + 8 * i + S);
 		p.update_distr_wts = update_distr_wts != 0; p.min_distr_wt = min_distr_wt;
 		p.adaptive_resampling_thresh = adaptive_resampling_thresh; p.jacobian_as_sigma = jacobian_as_sigma != 0;
 		if (device_filter) t->sm.reset(new hip::PF(t->am, t->ssm, p));
 		else t->sm.reset(new nt::PF(t->am, t->ssm, p));
-		return t;
+		return t.release();
 	} catch (const std::exception &e) { g_err = e.what(); return nullptr; }
 }
 /* StateSpaceModel sampler virtuals through the base class (tests): n draws of compositionalRandomWalk from the current state */
@@ -227,3 +230,25 @@ int mtfhost_qr_solve(int n, const double *A_colmajor, const double *b, double *x
 }
 
 } // extern "C"
+
+/* the reference's TEMPLATED search-method shape over the adapters (TemplatedSM.h): FCLK<HipAM, HipSSM> built from
+ * `const AM::ParamType *` / `const SSM::ParamType *`, one initialize on frame0 and one update() on frame1; out: corners (2 x 4), *iters */
+extern "C" int mtfhost_templated_fclk(int am, int ssm, int resx, int resy, int max_iters, double epsilon, int hess_type, int device,
+	const float *frame0, const float *frame1, int rows, int cols, int step, const double *corners_2x4, double *out_corners_2x4, int *iters) {
+	try {
+		auto link = std::make_shared<hip::HipLink>();
+		link->am = am; link->ssm = ssm; link->resx = resx; link->resy = resy; link->device = device;
+		hip::HipAM::ParamType amp; amp.link = link;
+		hip::HipSSM::ParamType ssmp; ssmp.link = link;
+		templated::FCLKParams fp; fp.max_iters = max_iters; fp.epsilon = epsilon; fp.hess_type = hess_type;
+		templated::FCLK<hip::HipAM, hip::HipSSM> sm(&fp, &amp, &ssmp);
+		CornersT c; std::memcpy(c.data(), corners_2x4, sizeof(double) * 8);
+		sm.setImage(ImageView{frame0, rows, cols, step});
+		sm.initialize(c);
+		sm.setImage(ImageView{frame1, rows, cols, step});
+		const int n = sm.update();
+		if (iters) *iters = n;
+		std::memcpy(out_corners_2x4, sm.getRegion().data(), sizeof(double) * 8);
+		return 0;
+	} catch (const std::exception &e) { g_err = e.what(); return -1; }
+}

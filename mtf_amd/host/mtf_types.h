@@ -1,9 +1,13 @@
 /*
  * mtf_types.h -- the handful of dense types the AM / SSM interface passes around, with the reference's
- * names and memory layouts (Macros/include/mtf/Macros/common.h:190-258: Eigen, column-major).  Eigen is
- * not available in this image, so these are plain storage classes -- enough for the interface and for the
- * search-method loops, which only need element access, `data()`, and a few S x S operations.
- * With real Eigen a maintainer drops this header and includes <Eigen/Dense>.
+ * names and memory layouts (Macros/include/mtf/Macros/common.h:190-258: Eigen, column-major).
+ *
+ * With Eigen on the include path these ARE the reference's typedefs (the adapters then compile against the types an MTF build
+ * uses: SURVEY.md section 7).  Eigen is not available in this image, so without it they are plain storage classes -- enough for the
+ * interface and for the search-method loops, which only need element access, `data()`, and a few S x S operations.
+ * -DMTF_AMD_NO_EIGEN forces the storage classes, -DMTF_AMD_USE_EIGEN forces Eigen (a compile error if it is absent).
+ * Code above this header uses only what both offer: (i, j) / (i) access, data(), rows(), cols(), size(), resize(), fill(), and the
+ * free helpers below (squaredDistance, colPivHouseholderQrSolve).
  */
 #ifndef MTF_AMD_HOST_TYPES_H
 #define MTF_AMD_HOST_TYPES_H
@@ -14,6 +18,30 @@
 #include <string>
 #include <vector>
 
+#if !defined(MTF_AMD_NO_EIGEN) && !defined(MTF_AMD_USE_EIGEN) && defined(__has_include)
+#if __has_include(<Eigen/Dense>)
+#define MTF_AMD_USE_EIGEN 1
+#endif
+#endif
+
+#ifdef MTF_AMD_USE_EIGEN
+#include <Eigen/Dense>
+namespace mtf {
+/* Macros/include/mtf/Macros/common.h:190-258 */
+using Eigen::MatrixXd;
+using Eigen::VectorXd;
+using Eigen::RowVectorXd;
+typedef Eigen::Matrix<double, 2, Eigen::Dynamic> PtsT;        /* Matrix2Xd */
+typedef Eigen::Matrix<double, 8, Eigen::Dynamic> GradPtsT;    /* Matrix8Xd */
+typedef Eigen::Matrix<double, 16, Eigen::Dynamic> HessPtsT;   /* Matrix16Xd */
+typedef Eigen::Matrix<double, Eigen::Dynamic, 2> PixGradT;    /* MatrixX2d */
+typedef Eigen::Matrix<double, 4, Eigen::Dynamic> PixHessT;    /* Matrix4Xd */
+typedef VectorXd PixValT;
+typedef Eigen::Matrix<double, 2, 4> CornersT;                 /* Matrix24d: TL TR BR BL */
+namespace utils {
+inline double squaredDistance(const CornersT &a, const CornersT &b) { return (a - b).squaredNorm(); }
+}
+#else
 namespace mtf {
 
 /* column-major dynamic matrix of doubles */
@@ -66,17 +94,21 @@ typedef VectorXd PixValT;
 
 /* 2 x 4 corners, TL TR BR BL (Matrix24d) */
 struct CornersT {
-	double v[8];
+	double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	double &operator()(int r, int c) { return v[2 * c + r]; }
 	double operator()(int r, int c) const { return v[2 * c + r]; }
 	double *data() { return v; }
 	const double *data() const { return v; }
-	double squaredDistance(const CornersT &o) const {
-		double s = 0;
-		for (int i = 0; i < 8; ++i) { double d = v[i] - o.v[i]; s += d * d; }
-		return s;
-	}
 };
+
+namespace utils {
+inline double squaredDistance(const CornersT &a, const CornersT &b) {
+	double s = 0;
+	for (int i = 0; i < 8; ++i) { const double d = a.data()[i] - b.data()[i]; s += d * d; }
+	return s;
+}
+}
+#endif   /* MTF_AMD_USE_EIGEN */
 
 /* the float32 single-channel image the AM borrows (cv::Mat CV_32FC1 in the reference) */
 struct ImageView {
@@ -101,7 +133,11 @@ struct InvalidTrackerState : Exception { explicit InvalidTrackerState(const std:
 
 /* x = A^{-1} b through a column-pivoted Householder QR (what the SMs call on Eigen:
  * hessian.colPivHouseholderQr().solve(...), SM/src/NT/FCLK.cc:298) */
-void colPivHouseholderQrSolve(const MatrixXd &A, const VectorXd &b, VectorXd &x);
+void colPivHouseholderQrSolve(const MatrixXd &A, const double *b, int n, VectorXd &x);
+inline void colPivHouseholderQrSolve(const MatrixXd &A, const VectorXd &b, VectorXd &x) { colPivHouseholderQrSolve(A, b.data(), (int)b.size(), x); }
+#ifdef MTF_AMD_USE_EIGEN   /* (without Eigen RowVectorXd IS VectorXd) */
+inline void colPivHouseholderQrSolve(const MatrixXd &A, const RowVectorXd &b, VectorXd &x) { colPivHouseholderQrSolve(A, b.data(), (int)b.size(), x); }
+#endif
 } // namespace utils
 
 } // namespace mtf

@@ -443,13 +443,14 @@ class ParticleFilter:
                  ssm_sigma=(0.01, 0.01, 2.0, 0.01, 0.01, 2.0, 1e-5, 1e-5), ssm_mean=(0.0,) * 8, likelihood_alpha=1.0,
                  max_iters=1, epsilon=0.01, seed=0, am=L.AM_SSD, dynamic_model=0, update_type=1, likelihood_func=0,
                  resampling_type=1, mean_type=0, corner_based_sampling=0, reset_to_mean=0, measurement_sigma=0.1, ar_coeff=0.5,
-                 comm=None, pt_based_sampling=0, n_channels=1, adaptive_resampling_thresh=0.0, update_distr_wts=1, min_distr_wt=0.1,
+                 comm=None, pt_based_sampling=0, n_channels=1, adaptive_resampling_thresh=0.0, update_distr_wts=0, min_distr_wt=0.1,
                  jacobian_as_sigma=0, pix_sigma=None):
         """pix_sigma: one value per sampler distribution; with pix_sigma[0] > 0 the sampler sigmas are estimated from them at
         initialize() (PFParams::processDistributions PFParams.cc:105-116, PF.cc:142-149: SSM::estimateStateSigma) and ssm_sigma is ignored.
         ssm_sigma / ssm_mean: one row of up to 8 values, or several rows = several sampler distributions (PFParams::processDistributions:
         the shipped Config/modules.cfg:157 uses five) whose weights follow the average particle weight each produced (update_distr_wts,
-        min_distr_wt: PF.cc:345-369); adaptive_resampling_thresh in (0, 1]: resample only when the effective particle count drops to
+        min_distr_wt: PF.cc:345-369 -- update_distr_wts defaults to the reference's 0, and several distributions WITHOUT it are refused by
+        every front end: the reference then draws from an all-zero discrete distribution, NT/PF.cc:241-257); adaptive_resampling_thresh in (0, 1]: resample only when the effective particle count drops to
         thresh * n (PF.cc:381-390); jacobian_as_sigma: the sampler's sigma of every frame is the Gauss-Newton step -H0^-1 g (PF.cc:58-64,
         156-165, 214-227)"""
         import ctypes as C
@@ -561,8 +562,9 @@ class ParticleFilter:
         return sigma
 
     def distributions(self):
-        """(distribution weights the next iteration draws from, distribution id of every particle of the last iteration, whether the
-        last iteration resampled)"""
+        """(distribution weights the next iteration draws from, distribution id of every particle's CURRENT proposal -- with look-ahead
+        proposals, the default with the device generator, those are the pending iteration's draws (mtfhip.h) --, whether the last
+        iteration resampled)"""
         import ctypes as C
         w, ids, res = np.ones(self.n_distr), np.zeros(self.n, dtype=np.int32), C.c_int(1)
         L.check(L.lib().mtfhip_pf_get_distributions(self._h, w.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p), C.byref(res)))

@@ -977,7 +977,7 @@ def _run_ranks(world, fn):
     dict(corner_based_sampling=0, dynamic_model=0, update_type=0, mean_type=2, resampling_type=0, likelihood_func=2),
     # the shipped modules.cfg shape: several sampler distributions with adaptive weights + adaptive resampling (replicated on every rank)
     dict(corner_based_sampling=1, dynamic_model=1, update_type=1, mean_type=1, resampling_type=1, adaptive_resampling_thresh=0.3,
-         ssm_sigma=[(1.0, 0.6), (3.0, 1.2), (0.3, 0.2)], likelihood_alpha=1.0),
+         ssm_sigma=[(1.0, 0.6), (3.0, 1.2), (0.3, 0.2)], likelihood_alpha=1.0, update_distr_wts=1),
 ])
 def test_pf_sharded_loopback_equals_unsharded(frame, world, n, cfg):
     """The sharded filter as bench.py --workload pf --gpus N runs it -- mtfhip_pf_set_comm, block bounds with a ragged (or

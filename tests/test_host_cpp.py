@@ -18,6 +18,58 @@ def test_host_library_builds_and_qr_matches_numpy():
         np.testing.assert_allclose(host.qr_solve(A, b), np.linalg.solve(A, b), rtol=1e-8)
 
 
+def test_product_library_holds_adapters_only():
+    """libmtfhost.so = the adapters (HipAM, HipSSM) + the device drivers (hip::LK, hip::PF); the restated reference callers
+    (nt::ESM / FCLK / ICLK / PF) and the C wrapper live in libmtfharness.so.  A translation unit that only uses the adapters links
+    against the product alone."""
+    import os
+    import subprocess
+    import tempfile
+    host.build()
+    syms = subprocess.run(["nm", "-DC", host.PRODUCT_LIB_PATH], stdout=subprocess.PIPE, text=True, check=True).stdout
+    for restated in ("mtf::nt::ESM::", "mtf::nt::FCLK::", "mtf::nt::ICLK::", "mtf::nt::PF::", "mtfhost_create"):
+        assert restated not in syms, restated
+    for product in ("mtf::hip::HipAM::updatePixVals", "mtf::hip::HipSSM::compositionalUpdate", "mtf::hip::LK::update", "mtf::hip::PF::update",
+                    "mtf::utils::colPivHouseholderQrSolve"):
+        assert product in syms, product
+    hsyms = subprocess.run(["nm", "-DC", host.LIB_PATH], stdout=subprocess.PIPE, text=True, check=True).stdout
+    assert "mtf::nt::ESM::update" in hsyms and "mtfhost_create" in hsyms
+    src = """
+#include "HipModels.h"
+#include "DeviceLK.h"
+#include "DevicePF.h"
+// what SearchMethod<AM, SSM> needs of its models (SM/include/mtf/SM/SearchMethod.h:13-19): ParamType and the pointer constructors
+template <class AM, class SSM> struct Holder {
+  typedef typename AM::ParamType AMParams; typedef typename SSM::ParamType SSMParams;
+  Holder(const AMParams *a, const SSMParams *s) : am(a), ssm(s) {}
+  AM am; SSM ssm;
+};
+int main(int argc, char **) {
+  if (argc > 99) {   // never executed here (no device): instantiation + link is the test
+    auto link = std::make_shared<mtf::hip::HipLink>();
+    mtf::hip::HipAM::ParamType ap; ap.link = link; mtf::hip::HipSSM::ParamType sp; sp.link = link;
+    Holder<mtf::hip::HipAM, mtf::hip::HipSSM> h(&ap, &sp);
+    return (int)h.am.getNPix() + (int)h.ssm.getStateSize();
+  }
+  return 0;
+}
+"""
+    hdir = os.path.join(os.path.dirname(host.PRODUCT_LIB_PATH), "host")
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.cpp"), "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.run(["g++", "-std=c++17", "-I", hdir, os.path.join(d, "t.cpp"), "-o", exe, "-L", os.path.dirname(host.PRODUCT_LIB_PATH),
+                        "-lmtfhost", "-lmtfhip", "-Wl,-rpath," + os.path.dirname(host.PRODUCT_LIB_PATH)], check=True)
+        assert "libmtfharness" not in subprocess.run(["ldd", exe], stdout=subprocess.PIPE, text=True).stdout
+
+
+def test_host_types_switch_to_eigen_when_present():
+    """with <Eigen/Dense> on the include path the host layer compiles against the reference's own typedefs"""
+    import os
+    t = open(os.path.join(os.path.dirname(host.PRODUCT_LIB_PATH), "host", "mtf_types.h")).read()
+    assert "__has_include(<Eigen/Dense>)" in t and "typedef Eigen::Matrix<double, 2, 4> CornersT" in t
+
+
 def test_host_qr_matches_oracle_qr(oracle):
     rng = np.random.default_rng(3)
     A = rng.normal(size=(8, 8)); A = -(A @ A.T) - np.eye(8)
@@ -256,9 +308,9 @@ def test_cpp_particle_filter(frame, device_filter, n):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("device_filter", [True, False])
-@pytest.mark.parametrize("opts", [dict(ssm_sigma=[(1.5, 0.2), (4.0, 0.6), (0.4, 0.1)], adaptive_resampling_thresh=0.2),     # the shipped modules.cfg shape
+@pytest.mark.parametrize("opts", [dict(ssm_sigma=[(1.5, 0.2), (4.0, 0.6), (0.4, 0.1)], adaptive_resampling_thresh=0.2, update_distr_wts=1),     # the shipped modules.cfg shape
                                   dict(ssm_sigma=(1.5, 0.2, 1, 1, 1, 1, 1, 1), jacobian_as_sigma=1, corner_based_sampling=0),
-                                  dict(pix_sigma=(0.6, 2.0), corner_based_sampling=0)],    # sigmas from StateSpaceModel::estimateStateSigma
+                                  dict(pix_sigma=(0.6, 2.0), corner_based_sampling=0, update_distr_wts=1)],    # sigmas from StateSpaceModel::estimateStateSigma
                          ids=["mixture_adaptive", "jacobian_as_sigma", "pix_sigma"])
 def test_cpp_particle_filter_shipped_options(frame, device_filter, opts):
     """The options of the shipped Config/modules.cfg:157-176 through the C++ search methods -- several sampler distributions with
@@ -283,6 +335,27 @@ def test_cpp_particle_filter_shipped_options(frame, device_filter, opts):
         assert np.abs(out - gt).max() < 3.0, np.abs(out - gt).max()   # an 8-dof direct-sampling cloud: coarser than the corner-based one
     else:
         assert np.abs(out - gt).max() < 1.5, np.abs(out - gt).max()
+
+
+@pytest.mark.gpu
+def test_several_distributions_without_update_distr_wts_refused_by_every_front_end(gpu_ctx, frame):
+    """PFParams::update_distr_wts defaults to 0 in the reference, and with several sampler distributions it then zeroes the weights and
+    draws every particle's distribution from an all-zero discrete distribution (NT/PF.cc:241-257).  r03 had three behaviours for
+    that configuration (C ABI refused, the C++ nt::PF produced NaN probabilities, the Python wrapper silently switched the flag on):
+    now one -- every front end refuses, with the reason, and nothing leaks when mtf::hip::PF's constructor throws."""
+    from mtf_amd import host
+    from mtf_amd.sm import ParticleFilter
+    two = [(1.5, 0.2), (4.0, 0.6)]
+    gpu_ctx.set_image(frame)
+    with pytest.raises(mtf_amd.FunctionNotImplemented, match="update_distr_wts"):
+        ParticleFilter(gpu_ctx, L.SSM_HOMOGRAPHY, 20, 20, n_particles=64, ssm_sigma=two, corner_based_sampling=1, seed=3)
+    for device_filter in (True, False):
+        for _ in range(3):   # (the constructor throws after the adapters exist: repeated, it must not accumulate device filters)
+            with pytest.raises(host.HostError, match="update_distr_wts"):
+                host.CppParticleFilter(device_filter, resx=20, resy=20, n_particles=64, ssm_sigma=two, corner_based_sampling=1, seed=3)
+    # a pix_sigma-only configuration (PF.h: "ssm_sigma is then not used") constructs without an ssm_sigma row
+    pf = host.CppParticleFilter(True, resx=20, resy=20, n_particles=64, pix_sigma=(0.8,), ssm_sigma=(), corner_based_sampling=0, seed=3)
+    pf.set_image(frame); pf.initialize(synth.square_corners(256.0, 250.0, 60)); pf.update()
 
 
 @pytest.mark.gpu
@@ -317,3 +390,21 @@ def test_getters_are_never_stale_with_eager_getters(oracle, frame):
         pts = tr.pts_after_update(dp, True, res * res)
         np.testing.assert_allclose(pts, o_ssm.get("curr_pts").reshape(-1, 2).T, rtol=0, atol=1e-9)
     np.testing.assert_allclose(tr.get_region(), o_ssm.get("curr_corners").reshape(4, 2).T, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("am,ssm,hess_type", [(L.AM_SSD, L.SSM_HOMOGRAPHY, 1), (L.AM_NCC, L.SSM_AFFINE, 2)])
+def test_templated_search_method_shape_instantiates_the_adapters(oracle, frame, am, ssm, hess_type):
+    """SearchMethod<AM, SSM> of the reference keeps its models BY VALUE and builds them from `const AM::ParamType *` /
+    `const SSM::ParamType *` (SM/include/mtf/SM/SearchMethod.h:13-19): HipAM / HipSSM provide ParamType + those constructors
+    (sharing one HipLink), and FCLK<HipAM, HipSSM> in that shape (harness/TemplatedSM.h) lands where the oracle's FCLK does."""
+    rng = np.random.default_rng(31)
+    corners = synth.square_corners(240.0, 250.0, 80)
+    frame2 = synth.warp_frame(frame, synth.random_small_homography(rng, 0.4), (240.0, 250.0))
+    got, n = host.templated_fclk(frame, frame2, corners, am=am, ssm=ssm, resx=40, resy=40, max_iters=15, epsilon=1e-4, hess_type=hess_type)
+    o_ssm = oracle.SSM(ssm, 40, 40); o_am = oracle.AM(am, 40, 40); o_am.set_curr_img(frame)
+    trk = oracle.Tracker(L.SM_FCLK, o_am, o_ssm, leven_marq=0, max_iters=15, epsilon=1e-4, hess_type=hess_type)
+    trk.initialize(corners); o_am.set_curr_img(frame2)
+    iters = trk.update()
+    assert abs(n - iters) <= 1
+    np.testing.assert_allclose(got, trk.get_region(), rtol=0, atol=2e-4)
