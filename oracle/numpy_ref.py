@@ -286,3 +286,119 @@ def estimate_state_sigma(init_pts, curr_pts, curr_D, pix_sigma, affine=False):
         r0 = np.stack([x, y, o, z, z, z, -x * cx, -y * cx]) / curr_D
         r1 = np.stack([z, z, z, x, y, o, -x * cy, -y * cy]) / curr_D
     return pix_sigma / np.sqrt(r0 ** 2 + r1 ** 2).mean(axis=1)
+
+
+# ------------------------------------------------------------------ r04: second-order Hessians of NCC and MI, PF resampling / estimates, mc::
+def ncc_curr_hessian_ref_form(J, m):
+    """NCC::cmptCurrHessian (AM/src/NCC.cc:307-335), the reference's FORM: with Jc = (J - column means) / b,
+    H = -f Jc^T Jc - (Jc^T ut)(u0^T Jc) - (Jc^T u0)(ut^T Jc) + 3 (Jc^T ut)(ut^T Jc).
+    (The exact second derivative of f = u0 . ut has 3 f in the last term -- d2f/dIt2 = [-f P - ut u0^T - u0 ut^T + 3 f ut ut^T] / b^2 --
+    the reference writes 3; the two agree at f = 1.  The fixture follows the reference.)"""
+    Jc = (J - J.mean(axis=0)) / m["b"]
+    vt, v0 = Jc.T @ m["ut"], Jc.T @ m["u0"]
+    return -m["f"] * (Jc.T @ Jc) - np.outer(vt, v0) - np.outer(v0, vt) + 3.0 * np.outer(vt, vt)
+
+
+def ncc_init_hessian_ref_form(J, m):
+    """NCC::cmptInitHessian (NCC.cc:282-305): the same four terms with the roles of the two patches swapped in the last one, and --
+    a quirk kept on purpose -- the template Jacobian divided by b, the CURRENT patch's norm, not c."""
+    Jc = (J - J.mean(axis=0)) / m["b"]
+    vt, v0 = Jc.T @ m["ut"], Jc.T @ m["u0"]
+    return -m["f"] * (Jc.T @ Jc) - np.outer(vt, v0) - np.outer(v0, vt) + 3.0 * np.outer(v0, v0)
+
+
+def image_hessian_stencil(img, wx, wy):
+    """utils::getImgHess at hess_eps = 1 (Utilities/src/imgUtils.cc:334-366): Ixx, Iyy from samples two pixels apart, Ixy from the four
+    diagonal neighbours; (N, 2, 2)."""
+    c = bilinear(img, wx, wy)
+    Hi = np.empty((np.size(wx), 2, 2))
+    Hi[:, 0, 0] = (bilinear(img, wx + 2, wy) + bilinear(img, wx - 2, wy) - 2 * c) / 4
+    Hi[:, 1, 1] = (bilinear(img, wx, wy + 2) + bilinear(img, wx, wy - 2) - 2 * c) / 4
+    Hi[:, 0, 1] = Hi[:, 1, 0] = ((bilinear(img, wx + 1, wy + 1) + bilinear(img, wx - 1, wy - 1)) -
+                                 (bilinear(img, wx + 1, wy - 1) + bilinear(img, wx - 1, wy + 1))) / 4
+    return Hi
+
+
+def affine_pix_hessian(Hi, A2, P):
+    """d2 I(A u + t) / dp2 for the compositional affine parameters: P^T (A2^T Hess A2) P per pixel (the warp is linear in its
+    parameters: no second term, SSM/src/Affine.cc:264-291); (N, S, S)."""
+    Hw = np.einsum("ia,nij,jb->nab", A2, Hi, A2)
+    return np.einsum("nis,nij,njt->nst", P, Hw, P)
+
+
+def _mi_tables(I0n, Itn, n_bins, pre_seed):
+    N = I0n.size
+    bins = np.arange(n_bins, dtype=np.float64)
+    X = bins[:, None] - Itn[None, :]
+    Bt, B0 = bspline3(X), bspline3(bins[:, None] - I0n[None, :])
+    seed_h = n_bins * pre_seed
+    norm = 1.0 / (N + seed_h * n_bins)
+    hc = (seed_h + Bt.sum(axis=1)) * norm
+    return X, Bt, B0, norm, hc
+
+
+def mi_self_hessian2(Itn, J, D, n_bins=8, pre_seed=10.0):
+    """MI::cmptSelfHessian with pixel Hessians (AM/src/MI.cc:697-735), densely: the joint histogram of the current patch WITH ITSELF
+    (cmptSelfHist :639-657), G = 1 + log h_self(r, t) - log h_c(r);
+    H = sum_p [ (sum_r b3''(r - It_p) norm sum_t b3(t - It_p) G(r, t)) J_p^T J_p + (sum_r d/dIt b3(r - It_p) norm sum_t b3(t - It_p) G(r, t)) D_p ]
+        + sum_{r,t} (1 / h_self(r, t) - 1 / h_c(r)) Q(r, t)^T Q(r, t),   Q(r, t) = sum_p d/dIt b3(r - It_p) norm b3(t - It_p) J_p."""
+    Itn = np.asarray(Itn, dtype=np.float64)
+    X, Bt, _, norm, hc = _mi_tables(Itn, Itn, n_bins, pre_seed)
+    hs = (pre_seed + Bt @ Bt.T) * norm
+    G = 1.0 + np.log(hs) - np.log(hc)[:, None]
+    dBt = -bspline3_d1(X) * norm
+    d2Bt = bspline3_d2(X) * norm
+    inner = np.einsum("rt,tp->rp", G, Bt)
+    hess_term = np.einsum("rp,rp->p", d2Bt, inner)
+    grad_term = np.einsum("rp,rp->p", dBt, inner)
+    H = J.T @ (hess_term[:, None] * J) + np.einsum("p,pst->st", grad_term, D)
+    Q = np.einsum("rp,tp,ps->rts", dBt, Bt, J)
+    fac = 1.0 / hs - 1.0 / hc[:, None]
+    return H + np.einsum("rt,rts,rtu->su", fac, Q, Q)
+
+
+# --- particle filter: weights -> cumulative weights -> resampling -> estimate (SM/src/NT/PF.cc:345-614)
+def pf_multinomial_ids(w, u):
+    """binary / linear multinomial resampling (NT/PF.cc:455-536): particle k takes the smallest index whose NORMALISED cumulative weight
+    reaches its draw u_k"""
+    cum = np.cumsum(w)
+    return np.searchsorted(cum / cum[-1], u, side="left").clip(0, len(w) - 1)
+
+
+def pf_residual_ids(w):
+    """residual resampling (NT/PF.cc:538-582): weights normalised; the indices EXCEPT THE LAST ONE sorted by weight, highest first
+    (std::sort(idx, idx + n - 1): the range ends one short; ties: index order is one of its outcomes -- the fixture has no ties);
+    every particle in that order copied round(w n) times until n slots are filled, the rest take the first of the order"""
+    n = len(w)
+    wn = w / w.sum()
+    order = list(np.argsort(-wn[:n - 1], kind="stable")) + [n - 1]
+    ids = []
+    for i in order:
+        c = int(np.floor(wn[i] * n + 0.5))   # C round(): half away from zero; the weights are positive
+        ids.extend([i] * c)
+        if len(ids) >= n:
+            break
+    ids = ids[:n] + [order[0]] * max(0, n - len(ids))
+    return np.array(ids), order[0]
+
+
+def running_mean(rows):
+    """mean += (x - mean) / (k + 1) (ProjectiveBase::estimateMeanOfSamples ProjectiveBase.cc:313-319, PF::updateMeanCorners NT/PF.cc:607-614)"""
+    m = np.zeros_like(np.asarray(rows[0], dtype=np.float64))
+    for k, x in enumerate(rows):
+        m = m + (x - m) / (k + 1)
+    return m
+
+
+# --- mc:: sampling (Utilities/src/imgUtils.cc:861-1005): the channels of a 32FC3 frame are sampled independently, rows = (pixel, channel)
+def mc_pix_vals(img3, pts):
+    """(N * C,) in (pixel, channel) order"""
+    C = img3.shape[2]
+    return np.stack([bilinear(img3[:, :, c], pts[0], pts[1]) for c in range(C)], axis=1).ravel()
+
+
+def mc_img_grad(img3, pts, eps=1e-8):
+    """(N * C, 2) in (pixel, channel) order"""
+    C = img3.shape[2]
+    g = np.stack([img_grad(img3[:, :, c], pts, eps) for c in range(C)], axis=1)   # (N, C, 2)
+    return g.reshape(-1, 2)
