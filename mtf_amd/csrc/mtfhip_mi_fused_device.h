@@ -162,6 +162,28 @@ __device__ __forceinline__ ClassSort class_sort8(int key /* 0..7, or negative: n
 	cs.total = (int)(cs.ends >> 56);
 	return cs;
 }
+/* r04, the self-Hessian bin mode in MOMENT form.  Both windows of a pixel are the window of It, so gradient tap k and weight tap m
+ * are fixed polynomials of ONE number, phi = It - fl (bspl_window4: tap k lies in piece k of the cubic B-spline):
+ *   w0 = (1 - phi)^3 / 6        w1 = c23 - phi^2 + phi^3 / 2        w2 = (c23 - 1/2) + (phi + phi^2 - phi^3) / 2        w3 = phi^3 / 6
+ *   d0 = -(1 - phi)^2 / 2       d1 = -2 phi + 3 phi^2 / 2           d2 = 1/2 + phi - 3 phi^2 / 2                          d3 = phi^2 / 2     (x -hist_norm' sign folded: d = dw/dIt x norm)
+ * (c23 = 0.66666666666, the reference's truncated constant, histUtils.h:11), hence d_k w_m = sum_j C[k][m][j] phi^j, j = 0..5, and
+ *   Q_rel[fl][k][m][s] = sum_{p in class fl} d_k w_m J_s = sum_j C[k][m][j] M[fl][j][s],      M[fl][j][s] = sum_p phi_p^j J_s(p).
+ * The pass accumulates the 6 x 8 moments per class (48 multiply-adds per pixel instead of 128: four block products per 16 pixels instead
+ * of eight, one staged number per pixel instead of eight window taps) and the workgroup turns them into Q once, at the end. */
+struct MiMomentCoef { double c[4][4][6]; };
+__host__ __device__ constexpr MiMomentCoef mi_moment_coef() {
+	constexpr double c23 = 0.66666666666;
+	const double w[4][4] = {{1.0 / 6, -0.5, 0.5, -1.0 / 6}, {c23, 0.0, -1.0, 0.5}, {c23 - 0.5, 0.5, 0.5, -0.5}, {0.0, 0.0, 0.0, 1.0 / 6}};   /* coefficients of phi^0..3 */
+	const double d[4][3] = {{-0.5, 1.0, -0.5}, {0.0, -2.0, 1.5}, {0.5, 1.0, -1.5}, {0.0, 0.0, 0.5}};                                      /* phi^0..2, x hist_norm */
+	MiMomentCoef o{};
+	for (int k = 0; k < 4; ++k)
+		for (int m = 0; m < 4; ++m) {
+			for (int j = 0; j < 6; ++j) o.c[k][m][j] = 0.0;
+			for (int a = 0; a < 3; ++a)
+				for (int b = 0; b < 4; ++b) o.c[k][m][a + b] += d[k][a] * w[m][b];
+		}
+	return o;
+}
 constexpr int kMiFastRow = 16 + 64 + 512;
 constexpr int kTRows = 12;   /* gradient-factor tables in LDS, indexed with (bin + 1) in both directions, zero borders */
 template <int SSM, int HK, int HROW, bool MC = false>
@@ -169,7 +191,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 	constexpr int S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
 	constexpr int nb = 8;
 	constexpr bool SORTED = HK == 1;
-	constexpr int SLAB = SORTED ? 17 * kRS2 + 8 * kQR : (HK ? (2 * kWinRows + 9) * kRS : 0);   /* dense: gd[11] | wd[11] | rw[8] | ht ; sorted: d[4] | w[4] | rw[8] | ht | Q[512] */
+	constexpr int kSRows = 11;   /* sorted staging rows: valid | phi | J[8] | hess_term */
+	constexpr int SLAB = SORTED ? kSRows * kRS2 + 8 * kQR : (HK ? (2 * kWinRows + 9) * kRS : 0);   /* dense: gd[11] | wd[11] | rw[8] | ht ; sorted: valid | phi | rw[8] | ht | M[8 classes][8 powers][8] */
 	__shared__ __attribute__((aligned(16))) double Tc[kTRows * MI_NB], Ti[kTRows * MI_NB], Th[HK == 1 ? kTRows * MI_NB : 1];
 	__shared__ __attribute__((aligned(16))) double slabs[HK ? 4 * SLAB : 4 * 16];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -184,8 +207,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 	}
 	const double *Tq = HK == 1 ? Th : (HK == 2 ? Tc : Ti);
 	double *gd = slabs + (size_t)wave * SLAB, *wd = gd + kWinRows * kRS, *rw = wd + kWinRows * kRS, *hts = rw + 8 * kRS;
-	double *sd = slabs + (size_t)wave * SLAB, *sw = sd + 4 * kRS2, *srw = sw + 4 * kRS2, *sht = srw + 8 * kRS2;   /* sorted form */
-	double *qabs = sht + kRS2;   /* this wave's Q[(r, c)][s] */
+	double *sd = slabs + (size_t)wave * SLAB, *sphi = sd + kRS2, *srw = sphi + kRS2, *sht = srw + 8 * kRS2;   /* sorted form: sd = the validity row */
+	double *qabs = sht + kRS2;   /* this wave's moment table M[class][power][s] */
 	if constexpr (SORTED) { for (int k2 = lane; k2 < SLAB; k2 += 64) sd[k2] = 0.0; }
 	else if constexpr (HK != 0) { for (int k2 = 0; k2 < 2 * kWinRows + 9; ++k2) gd[k2 * kRS + lane] = 0.0; }
 	__syncthreads();
@@ -208,9 +231,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 	for (int k = 0; k < 16; ++k) acc[k] = 0.0;
 	double cq[8], chs = 0.0;   /* dense: (Rg, Cg, Sg) blocks */
 	double chs4[4] = {0.0, 0.0, 0.0, 0.0};   /* sorted: the four 4 x 4 tiles of sum hess_term J J^T, per block = per quad of pixels (summed over the blocks at the end) */
-	/* sorted: Q_rel[t][m = lk][s = 4 h + li] of the class this lane's block is in, q<t><h>; carried ACROSS chunks (a block leaves its
+	/* sorted: the moments M[j][s] = sum phi^j J_s of the class this lane's block is in; carried ACROSS chunks (a block leaves its
 	 * class only when its next quad is of another one) */
-	double q00 = 0, q01 = 0, q10 = 0, q11 = 0, q20 = 0, q21 = 0, q30 = 0, q31 = 0;
+	double q00 = 0, q01 = 0, q10 = 0, q11 = 0;   /* M[class][power 4 T + lk][s = 4 h + li]: q<T><h> */
 	int cls = 8;   /* 8: none */
 #pragma unroll
 	for (int k = 0; k < 8; ++k) cq[k] = 0.0;
@@ -341,24 +364,20 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 			const int steps = (cs.total + 15) >> 4;   /* quads per block */
 			const int mycol = sorted_col(cs.slot, steps);
 			if (valid) {
-#pragma unroll
-				for (int k = 0; k < 4; ++k) { sd[k * kRS2 + mycol] = a.d[k]; sw[k * kRS2 + mycol] = a.w[k]; }
+				sd[mycol] = 1.0; sphi[mycol] = sp.it - (double)a.row0;   /* phi = It - fl: every tap of the window is a polynomial of it */
 #pragma unroll
 				for (int s2 = 0; s2 < 8; ++s2) srw[s2 * kRS2 + mycol] = jt[s2];
 				sht[mycol] = hess_term;
 			}
 			__builtin_amdgcn_wave_barrier();
-			/* r04: steps of SIXTEEN pixels.  The four blocks of a 4x4x4 product are four quads of pixels (r03: the four gradient taps of
-			 * one quad), so a lane works on ONE pixel per step -- its block's quad, member lk -- and reads that pixel's weight tap li,
-			 * its four gradient taps, J[li], J[4 + li] and hess_term: 8 operands per lane per 16 pixels where the tap-block form read 5
-			 * per 4 (20 per 16).  The group loop was bound by the CU's LDS pipe (80 LDS against 48 matrix cycles per round of four
-			 * groups); now the twelve block products of a step (4 taps x 2 halves of J into Q_rel[t][m][s], 2 x 2 tiles of sum hess_term
-			 * J J^T) are what a step costs.  The price: a block's accumulators belong to the class of ITS quad.  Block b takes the quads
-			 * [b steps, (b + 1) steps) of the sorted order, so it crosses each class boundary of its range once; when its next quad is of
-			 * another class its sums go to the wave's absolute table through ds_add_f64 (measured: with the quads dealt round-robin and a
-			 * flush at every chunk end the four blocks hit the same addresses at the same time -- the adds were 210 us of a 420 us pass).
-			 * Slots behind the last class keep a zero gradient tap and a zero hess_term: a partly filled range adds zeros. */
-			const double *pw = sw + li * kRS2, *pd = sd, *pja = srw + li * kRS2, *pjb = pja + 4 * kRS2, *pht = sht;   /* + this lane's column of the step */
+			/* r04: steps of SIXTEEN pixels, moment form.  The four blocks of a 4x4x4 product are four quads of pixels, so a lane works on
+			 * ONE pixel per step -- its block's quad, member lk -- and reads that pixel's validity, phi, J[li], J[4 + li] and hess_term:
+			 * 5 operands per lane per 16 pixels (r03's tap-block form: 5 per 4).  Seven block products per step: the moments
+			 * M[4 T + i][4 h + j] += (valid phi^(4 T + i)) J[4 h + j] (T: powers 0-3 | 4, 5; h: the halves of J) and the three upper tiles of
+			 * sum hess_term J J^T.  A block's accumulators belong to the class of ITS quad: block b takes the quads [b steps, (b + 1) steps)
+			 * of the sorted order, crosses each class boundary of its range once, and when its next quad is of another class its sums
+			 * go to the wave's moment table through ds_add_f64.  Slots behind a class's last pixel have valid = 0 and hess_term = 0. */
+			const double *pv = sd, *pp_ = sphi, *pja = srw + li * kRS2, *pjb = pja + 4 * kRS2, *pht = sht;   /* + this lane's column of the step */
 			/* class of the quad that starts at slot s0 = number of classes that end at or before it (empty classes included: they end
 			 * where their predecessor does); byte-wise on the packed end slots, no borrow between bytes: (s0 | 0x80) - end >= 0x80 - 88 > 0 */
 			const unsigned ends_lo = (unsigned)cs.ends, ends_hi = (unsigned)(cs.ends >> 32);
@@ -366,24 +385,27 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 				const unsigned S = (unsigned)s0 * 0x01010101u | 0x80808080u;
 				return __builtin_popcount((S - ends_lo) & 0x80808080u) + __builtin_popcount((S - ends_hi) & 0x80808080u);
 			};
-			/* leave class `cls` for `to`: Q[(cls - 1 + t, cls - 1 + m)][s] += q<t><h>.  Result layout of the block product: column s' = li,
-			 * block = lb, row m = lk. */
+			/* leave class `cls` for `to`: M[cls][4 T + lk][4 h + li] += q<T><h>.  Result layout of the block product: column = li, block = lb,
+			 * row = lk. */
 			auto leave_class = [&](int to) {
 #if !(defined(MTFHIP_MI_ABL) && MTFHIP_MI_ABL == 5)   /* ablation 5: class boundaries without the table update */
-				const int cc = cls - 1 + lk;
-				if (cls < 8 && cc >= 0 && cc < nb) {
-					double *qe = qabs + (cls - 1) * kQR + cc * 8 + li;
-					if (cls >= 1) { lds_add_f64(qe, q00); lds_add_f64(qe + 4, q01); }
-					lds_add_f64(qe + kQR, q10); lds_add_f64(qe + kQR + 4, q11);
-					if (cls + 1 < nb) { lds_add_f64(qe + 2 * kQR, q20); lds_add_f64(qe + 2 * kQR + 4, q21); }
-					if (cls + 2 < nb) { lds_add_f64(qe + 3 * kQR, q30); lds_add_f64(qe + 3 * kQR + 4, q31); }
+				if (cls < 8) {
+					double *qe = qabs + cls * 64 + lk * 8 + li;
+					lds_add_f64(qe, q00); lds_add_f64(qe + 4, q01);
+					if (lk < 2) { lds_add_f64(qe + 32, q10); lds_add_f64(qe + 36, q11); }   /* powers 4, 5 */
 				}
 #endif
-				q00 = q01 = q10 = q11 = q20 = q21 = q30 = q31 = 0.0;
+				q00 = q01 = q10 = q11 = 0.0;
 				cls = to;
 			};
+			/* the A operands of a lane: valid phi^li and valid phi^(4 + li) (li < 2; the rest of that tile is padding) */
+			auto powers = [&](double v, double ph, double &lo, double &hi) {
+				const double p2 = ph * ph, p3 = p2 * ph, p4 = p2 * p2, p5 = p4 * ph;
+				lo = v * (li == 0 ? 1.0 : (li == 1 ? ph : (li == 2 ? p2 : p3)));
+				hi = v * (li == 0 ? p4 : (li == 1 ? p5 : 0.0));
+			};
 			int o = window_col(0, lb, lk);
-			double c_w = pw[o], c_d0 = pd[o], c_d1 = pd[kRS2 + o], c_d2 = pd[2 * kRS2 + o], c_d3 = pd[3 * kRS2 + o], c_ja = pja[o], c_jb = pjb[o], c_ht = pht[o];
+			double c_v = pv[o], c_ph = pp_[o], c_ja = pja[o], c_jb = pjb[o], c_ht = pht[o];
 			const int s_first = 4 * lb * steps;   /* first slot of this block's range */
 			{
 				const int c_first = class_of(s_first);
@@ -398,14 +420,12 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 #endif
 				/* operands of the next step first (one step past the end reads the columns behind the window: discarded) */
 				o = window_col(j + 1, lb, lk);
-				const double n_w = pw[o], n_d0 = pd[o], n_d1 = pd[kRS2 + o], n_d2 = pd[2 * kRS2 + o], n_d3 = pd[3 * kRS2 + o];
-				const double n_ja = pja[o], n_jb = pjb[o], n_ht = pht[o];
+				const double n_v = pv[o], n_ph = pp_[o], n_ja = pja[o], n_jb = pjb[o], n_ht = pht[o];
 				{
-					const double u0 = c_d0 * c_w, u1 = c_d1 * c_w, u2 = c_d2 * c_w, u3 = c_d3 * c_w;   /* row = weight tap li, k = this pixel */
-					q00 = __builtin_amdgcn_mfma_f64_4x4x4f64(u0, c_ja, q00, 0, 0, 0); q01 = __builtin_amdgcn_mfma_f64_4x4x4f64(u0, c_jb, q01, 0, 0, 0);
-					q10 = __builtin_amdgcn_mfma_f64_4x4x4f64(u1, c_ja, q10, 0, 0, 0); q11 = __builtin_amdgcn_mfma_f64_4x4x4f64(u1, c_jb, q11, 0, 0, 0);
-					q20 = __builtin_amdgcn_mfma_f64_4x4x4f64(u2, c_ja, q20, 0, 0, 0); q21 = __builtin_amdgcn_mfma_f64_4x4x4f64(u2, c_jb, q21, 0, 0, 0);
-					q30 = __builtin_amdgcn_mfma_f64_4x4x4f64(u3, c_ja, q30, 0, 0, 0); q31 = __builtin_amdgcn_mfma_f64_4x4x4f64(u3, c_jb, q31, 0, 0, 0);
+					double a_lo, a_hi;
+					powers(c_v, c_ph, a_lo, a_hi);
+					q00 = __builtin_amdgcn_mfma_f64_4x4x4f64(a_lo, c_ja, q00, 0, 0, 0); q01 = __builtin_amdgcn_mfma_f64_4x4x4f64(a_lo, c_jb, q01, 0, 0, 0);
+					q10 = __builtin_amdgcn_mfma_f64_4x4x4f64(a_hi, c_ja, q10, 0, 0, 0); q11 = __builtin_amdgcn_mfma_f64_4x4x4f64(a_hi, c_jb, q11, 0, 0, 0);
 					const double ha = c_ja * c_ht, hb = c_jb * c_ht;   /* sum hess_term J J^T: tile (X, Y) = rows 4 X + i weighted, columns 4 Y + j */
 					chs4[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ha, c_ja, chs4[0], 0, 0, 0); chs4[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ha, c_jb, chs4[1], 0, 0, 0);
 					chs4[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(hb, c_jb, chs4[3], 0, 0, 0);   /* (tile (1, 0) is the transpose of (0, 1): mirrored at the end) */
@@ -414,14 +434,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 					const int cls_nx = class_of(s_first + 4 * (j + 1));
 					if (cls_nx != cls && cls_nx < 8) leave_class(cls_nx);
 				}
-				c_w = n_w; c_d0 = n_d0; c_d1 = n_d1; c_d2 = n_d2; c_d3 = n_d3; c_ja = n_ja; c_jb = n_jb; c_ht = n_ht;
+				c_v = n_v; c_ph = n_ph; c_ja = n_ja; c_jb = n_jb; c_ht = n_ht;
 			}
 			__builtin_amdgcn_wave_barrier();
-			if (valid) {   /* padding slots must keep a zero gradient tap and a zero hess_term */
-#pragma unroll
-				for (int k = 0; k < 4; ++k) sd[k * kRS2 + mycol] = 0.0;
-				sht[mycol] = 0.0;
-			}
+			if (valid) { sd[mycol] = 0.0; sht[mycol] = 0.0; }   /* padding slots must keep valid = 0 and a zero hess_term */
 		} else if constexpr (HK != 0) {
 			const BsplWin4 &A = HK == 3 ? c0 : a;
 			const BsplWin4 &Bw = HK == 1 ? a : (HK == 2 ? c0 : a);
@@ -470,13 +486,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 		}
 	}
 	if constexpr (SORTED) {   /* what the blocks still hold goes to the wave's table */
-		const int cc = cls - 1 + lk;
-		if (cls < 8 && cc >= 0 && cc < nb) {
-			double *qe = qabs + (cls - 1) * kQR + cc * 8 + li;
-			if (cls >= 1) { lds_add_f64(qe, q00); lds_add_f64(qe + 4, q01); }
-			lds_add_f64(qe + kQR, q10); lds_add_f64(qe + kQR + 4, q11);
-			if (cls + 1 < nb) { lds_add_f64(qe + 2 * kQR, q20); lds_add_f64(qe + 2 * kQR + 4, q21); }
-			if (cls + 2 < nb) { lds_add_f64(qe + 3 * kQR, q30); lds_add_f64(qe + 3 * kQR + 4, q31); }
+		if (cls < 8) {
+			double *qe = qabs + cls * 64 + lk * 8 + li;
+			lds_add_f64(qe, q00); lds_add_f64(qe + 4, q01);
+			if (lk < 2) { lds_add_f64(qe + 32, q10); lds_add_f64(qe + 36, q11); }
 		}
 	}
 	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * kMiFastRow;
@@ -501,7 +514,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 		}
 		}
 		constexpr int hl = SORTED ? 64 : ql;   /* sorted: only the H blocks go through qred, in front of the first wave's Q table */
-		static_assert(!SORTED || 4 * 64 <= 17 * kRS2, "H blocks of the four waves must fit in front of the first Q table");
+		static_assert(!SORTED || 4 * 64 <= kSRows * kRS2, "H blocks of the four waves must fit in front of the first moment table");
 		if constexpr (SORTED) {
 			/* (block_reduce_store above used the first 64 doubles as its scratch) */
 			for (int k2 = threadIdx.x; k2 < 4 * 64; k2 += kBlock) qred[k2] = 0.0;
@@ -519,10 +532,37 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 				const int r = k2 >> 3, c = k2 & 7, src = (r >= 4 && c < 4) ? c * 8 + r : k2;   /* the lower-left tile from the upper-right one */
 				dst[16 + k2] = (qred[src] + qred[64 + src]) + (qred[128 + src] + qred[192 + src]);
 			}
-			const double *q0 = slabs + 17 * kRS2;
+			/* the four waves' moment tables -> one (in the first wave's, in place), then Q[(r, c)][s] = hist_norm sum_fl sum_j C[k][m][j] M[fl][j][s]
+			 * over the classes whose window holds both bins: k = r - (fl - 1), m = c - (fl - 1) in 0..3 */
+			double *m0 = slabs + kSRows * kRS2;
+			double msum[2];
+#pragma unroll
+			for (int u = 0; u < 2; ++u) { const int k2 = threadIdx.x + u * kBlock; msum[u] = (m0[k2] + m0[SLAB + k2]) + (m0[2 * SLAB + k2] + m0[3 * SLAB + k2]); }
+			__syncthreads();
+#pragma unroll
+			for (int u = 0; u < 2; ++u) m0[threadIdx.x + u * kBlock] = msum[u];
+			__syncthreads();
+			constexpr MiMomentCoef CF = mi_moment_coef();
 			for (int k2 = threadIdx.x; k2 < 512; k2 += kBlock) {
-				const int q = (k2 >> 6) * kQR + (k2 & 63);
-				dst[80 + k2] = (q0[q] + q0[SLAB + q]) + (q0[2 * SLAB + q] + q0[3 * SLAB + q]);
+				const int r = k2 >> 6, c = (k2 >> 3) & 7, sx = k2 & 7;
+				double qv = 0.0;
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					const int fl = r + 1 - k, m = c - (fl - 1);
+					if (fl >= 0 && fl < 8 && m >= 0 && m < 4) {
+						const double *mm = m0 + fl * 64 + sx;
+						double acc6 = 0.0;
+#pragma unroll
+						for (int j = 0; j < 6; ++j) {
+							double cf = 0.0;   /* C[k][m][j]: k static, m dynamic */
+#pragma unroll
+							for (int mq = 0; mq < 4; ++mq) cf = m == mq ? CF.c[k][mq][j] : cf;
+							acc6 = fma(cf, mm[j * 8], acc6);
+						}
+						qv += acc6;
+					}
+				}
+				dst[80 + k2] = qv * pa.hist_norm;
 			}
 		} else {
 			for (int k2 = threadIdx.x; k2 < ql; k2 += kBlock)
