@@ -84,8 +84,9 @@ struct Tex {
 /* PERSIST (kernels_persist.hip): the body runs once per iteration inside one launch; the warp and the state were written by another
  * workgroup a moment ago, so they are read with agent-scope loads and moved back to scalar registers (a plain load of memory the
  * kernel itself modifies would be kept in vector registers: 26 of them). */
-/* the general sampler as a real call: the rare path's registers do not count against the row loop's */
-__device__ __attribute__((noinline)) double pix_val_call(const float *data, int w, int h, int stride, double x, double y) {
+/* the general sampler from its scalar arguments.  (Tried as a real call -- __attribute__((noinline)) -- so that the rare path's registers
+ * would not count against the row loop's: no spill went away, and a 64 x 50 x 50 lean launch went from 13.1 to 14.6 us: inlined.) */
+__device__ __forceinline__ double pix_val_call(const float *data, int w, int h, int stride, double x, double y) {
 	ImgView im; im.data = data; im.w = w; im.h = h; im.stride = stride;
 	return pix_val(im, x, y);
 }
@@ -178,6 +179,7 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 	double ex0, ex1, ex2, ey0, ey1, ey2;
 	double aa, ab, ac, ad;   /* affine a,b,c,d (Affine.cc:216-217) */
 	auto setup_target = [&]() {
+#ifndef MTFHIP_NO_UNIFORM_WARP
 		if constexpr (!PERSIST) {
 			/* wsrc / st are generic pointers (kernarg segment or global), so the loads above are vector loads of a wave-uniform address
 			 * and the warp would sit in 26 VGPRs for the whole pass (r03 ISA): move it to scalar registers here, behind the first row's
@@ -186,6 +188,7 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 			for (int q = 0; q < 9; ++q) W.m[q] = to_uniform(W.m[q]);
 			st2 = to_uniform(st2); st3 = to_uniform(st3); st4 = to_uniform(st4); st5 = to_uniform(st5);
 		}
+#endif
 		ex0 = W.m[0] * eps; ex1 = W.m[3] * eps; ex2 = W.m[6] * eps;
 		ey0 = W.m[1] * eps; ey1 = W.m[4] * eps; ey2 = W.m[7] * eps;
 		aa = st2 + 1; ab = st3; ac = st4; ad = st5 + 1;
