@@ -139,8 +139,17 @@ __device__ __forceinline__ void publish_target(const HostPublish &pub, int t, do
 		const int done = __hip_atomic_fetch_add(pub.count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
 		if (done == (int)gridDim.x - 1) {
 			__hip_atomic_store(pub.count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			/* Every workgroup's results left as system-scope (write-through) stores that were acknowledged before it counted itself in,
+			 * and this one has acquired the counter: they are performed, and the flag -- one more posted write of the same device -- cannot
+			 * pass them on the link.  A system-scope RELEASE here (r03: __threadfence_system + a release store) writes back the whole L2
+			 * twice -- since r04 that includes the 6 MB of template grids the same launch laid out -- for nothing the host reads:
+			 * 2.5 us of a 50 us frame (MTFHIP_GRID_PUBLISH_FENCE=1 at build time keeps the fences). */
+#ifdef MTFHIP_GRID_PUBLISH_FENCE
 			__threadfence_system();
 			__hip_atomic_store(pub.flag, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+			__hip_atomic_store(pub.flag, pub.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
 		}
 	}
 }
@@ -166,12 +175,11 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 	const double *iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * N;
 	const double *I0 = bv.buf[MTFHIP_BUF_I0] + (size_t)t * N;
 	const double *J0 = bv.buf[MTFHIP_BUF_J0] + (size_t)t * N * S;
-	if (region) {
-		/* the patch's region and its template's NCC scalars from the pinned staging buffer: one PCIe round trip per workgroup, under
-		 * the template operands' fetch below */
-		if (tid < 8) sCr[tid] = rg.corners[8 * (size_t)t + tid];
-		else if (tid < 16) sNc[tid - 8] = AM == MTFHIP_AM_NCC ? rg.ncc[8 * (size_t)t + tid - 8] : 0.0;
-	}
+	/* region mode: the patch's region and its template's NCC scalars from the pinned staging buffer -- one PCIe round trip per workgroup.
+	 * The load is issued here, its LDS store (which waits for it) only behind the template operands' loads below, so that the two
+	 * latencies overlap (program order is wait order: stored right away, the PCIe read was 1.1 us in front of everything else) */
+	double ingest = 0.0;
+	if (region && tid < 16) ingest = tid < 8 ? rg.corners[8 * (size_t)t + tid] : (AM == MTFHIP_AM_NCC ? rg.ncc[8 * (size_t)t + tid - 8] : 0.0);
 	double m0 = (AM == MTFHIP_AM_NCC && !region) ? ncc_sc_all[t * 8 + 0] : 0.0;
 	double cn = (AM == MTFHIP_AM_NCC && !region) ? ncc_sc_all[t * 8 + 1] : 1.0;
 	/* Everything that does not change over the iterations is fetched ONCE: the thread's grid points, template values
@@ -200,6 +208,8 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 	}
 	if (tid < 64) sHinv[tid] = h0inv_all[(size_t)t * 64 + tid];
 	if (tid < 64) { const int r = tid >> 3, c = tid & 7; sH8[tid] = (r < S && c < S) ? h0inv_all[(size_t)t * 64 + c * S + r] : 0.0; }   /* [r][c], zero padded */
+	asm volatile("" ::: "memory");   /* (the loads above are issued before the ingest is waited for) */
+	if (region && tid < 16) { if (tid < 8) sCr[tid] = ingest; else sNc[tid - 8] = ingest; }
 	if (!region) {
 		if (tid < 12) sIc[tid] = ts.init_corners_hm[12 * t + tid];
 		if (tid < 8) sCr[tid] = ts.corners[8 * t + tid];
