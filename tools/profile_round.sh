@@ -42,7 +42,8 @@ json.dump({"kernel": "k_fused_ssd", "bench_args": "$args", "commit": commit, "ta
 PY
 cp $out/${tag}_pmc_traffic.json profiles/pmc_latest.json
 python bench.py $args > $out/${tag}_bench.json 2>> $out/${tag}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o $tag -- python bench.py $args --no-cpu > $out/${tag}_trace.log 2>&1
+# (--no-lean: the lean and single-target sub-records launch the SAME kernels at other sizes and would be averaged into the headline's rows)
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o $tag -- python bench.py $args --no-cpu --no-lean > $out/${tag}_trace.log 2>&1
 cp $out/trace/${tag}_kernel_stats.csv $out/${tag}_kernel_stats.csv
 # the same command with the loop on one queue: the kernel with the device to itself (r01 / r02 figures are of this form)
 MTFHIP_TRACK_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace1q -o ${tag}_1q -- python bench.py $args --no-cpu --no-lean > $out/${tag}_trace1q.log 2>&1
