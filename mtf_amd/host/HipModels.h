@@ -93,6 +93,9 @@ public:
 	void syncPixGrad();                                               /* explicit read-back of both gradients */
 
 	void setCurrImg(const ImageView &img) override;
+#ifdef MTF_AMD_USE_OPENCV
+	void setCurrImg(const cv::Mat &img) { setCurrImg(imageView(img)); }   /* the reference's signature (ImageBase.h:92) */
+#endif
 	void initializePixVals(const PtsT &init_pts) override;
 	void initializePixGrad(const GradPtsT &warped_offset_pts) override;
 	void initializePixGrad(const PtsT &init_pts) override;

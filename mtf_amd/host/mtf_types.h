@@ -110,12 +110,32 @@ inline double squaredDistance(const CornersT &a, const CornersT &b) {
 }
 #endif   /* MTF_AMD_USE_EIGEN */
 
-/* the float32 single-channel image the AM borrows (cv::Mat CV_32FC1 in the reference) */
+/* the float32 image the AM borrows (cv::Mat CV_32FC1 / CV_32FC3 in the reference) */
 struct ImageView {
 	const float *data;
 	int rows, cols, step; /* step in elements (floats) */
 	int channels = 1;     /* 1: CV_32FC1, 3: CV_32FC3 interleaved */
 };
+} // namespace mtf
+/* With OpenCV on the include path an ImageView is made from the `const cv::Mat &` the reference's setCurrImg / setImage take
+ * (AM/include/mtf/AM/ImageBase.h:92, include/mtf/TrackerBase.h:22-26): `am.setCurrImg(mtf::imageView(img))`, or directly through the
+ * cv::Mat overloads the adapters then declare (HipModels.h).  -DMTF_AMD_NO_OPENCV switches it off. */
+#if !defined(MTF_AMD_NO_OPENCV) && defined(__has_include)
+#if __has_include(<opencv2/core/core.hpp>)
+#include <opencv2/core/core.hpp>
+#define MTF_AMD_USE_OPENCV 1
+#endif
+#endif
+namespace mtf {
+#ifdef MTF_AMD_USE_OPENCV
+inline ImageView imageView(const cv::Mat &img) {
+	if (img.depth() != CV_32F || (img.channels() != 1 && img.channels() != 3))
+		throw std::invalid_argument("ImageBase::setCurrImg: a CV_32FC1 / CV_32FC3 image is expected");   /* ImageBase.cc:55-59 */
+	ImageView v{reinterpret_cast<const float *>(img.data), img.rows, img.cols, (int)(img.step / sizeof(float))};
+	v.channels = img.channels();
+	return v;
+}
+#endif
 
 namespace utils {
 /* Utilities/include/mtf/Utilities/excpUtils.h:8-55 */

@@ -68,6 +68,8 @@ def test_host_types_switch_to_eigen_when_present():
     import os
     t = open(os.path.join(os.path.dirname(host.PRODUCT_LIB_PATH), "host", "mtf_types.h")).read()
     assert "__has_include(<Eigen/Dense>)" in t and "typedef Eigen::Matrix<double, 2, 4> CornersT" in t
+    # and with OpenCV the adapters take the reference's `const cv::Mat &`
+    assert "__has_include(<opencv2/core/core.hpp>)" in t and "imageView(const cv::Mat &img)" in t
 
 
 def test_host_qr_matches_oracle_qr(oracle):
