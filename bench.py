@@ -353,13 +353,19 @@ class PfDeviceEngine:
     def n_ranks(self):
         return int(self.comm.world_as_seen()) if self.comm is not None else 1
 
-    def make_filter(self, n, sharded, iters):
+    exchanges = ("collective", "peer")   # of the sharded filter: RCCL all-gather | peer stores + arrival counters (mtfhip_pf_set_exchange)
+
+    def make_filter(self, n, sharded, iters, exchange="collective"):
         from mtf_amd.sm import ParticleFilter
         pf = ParticleFilter(self.ctx, self.mtf.SSM_HOMOGRAPHY, 50, 50, n_particles=n, ssm_sigma=(1.0, 0.5, 1, 1, 1, 1, 1, 1), corner_based_sampling=1,
                             dynamic_model=0, update_type=1, likelihood_func=0, resampling_type=1, mean_type=0, likelihood_alpha=1.0,
-                            max_iters=iters, epsilon=-1.0, seed=self.synth.DEFAULT_SEED, comm=self.comm if sharded else None)
+                            max_iters=iters, epsilon=-1.0, seed=self.synth.DEFAULT_SEED, comm=self.comm if sharded else None,
+                            exchange=exchange if sharded else "collective")
         pf.initialize(self.corners[None])
         return pf
+
+    def estimate(self, pf):
+        return [float(v) for v in np.asarray(pf.get_region()).ravel()]
 
     def sync(self):
         self.torch.cuda.synchronize(self.dev)
@@ -424,8 +430,17 @@ class PfStubEngine:
     def n_ranks(self):
         return self.dist.get_world_size() if self.dist is not None else 1
 
-    def make_filter(self, n, sharded, iters):
+    exchanges = ("collective", "peer")
+
+    def make_filter(self, n, sharded, iters, exchange="collective"):
+        # (the stub's peer exchange IS its collective; MTFHIP_BENCH_STUB_PEER_FAIL=<rank> makes that rank fail to set it up, the case
+        # pf_strong_record has to survive without leaving the other ranks in a collective of their own)
+        if sharded and exchange == "peer" and os.environ.get("MTFHIP_BENCH_STUB_PEER_FAIL", "") == str(self.rank):
+            raise RuntimeError("stub: rank %d cannot map the peers' mailboxes" % self.rank)
         return PfStubEngine._Filter(self, n, sharded, iters)
+
+    def estimate(self, pf):
+        return [pf.checksum]
 
     def sync(self):
         pass
@@ -459,27 +474,53 @@ def pf_strong_record(eng, dist, world, sizes=((10000, 100), (100000, 30), (10000
                     "resampling and estimate replicated on identical data (SM/src/PF.cc:262-306)",
            "expected_model_DESIGN_section_6": {str(k): v for k, v in PF_STRONG_MODEL.items()}}
 
-    def sync_all():
-        eng.sync()
-        if dist is not None:
-            dist.barrier()
+    def all_ok(ok):
+        # a step that can fail on ONE rank (mapping a peer's mailbox, a wait that gave up) is followed by this agreement, so that
+        # either every rank goes on or none does -- nobody is left alone in the next collective
+        return eng.reduce_max(0.0 if ok else 1.0) == 0.0
 
+    labels = [("one_gpu", False, "collective")]
+    if world > 1:
+        labels += [("sharded" if x == "collective" else "sharded_" + x, True, x) for x in getattr(eng, "exchanges", ("collective",))]
+    rec["exchanges"] = {"sharded": "one in-place RCCL all-gather per iteration (the default)",
+                        "sharded_peer": "mtfhip_pf_set_exchange(PEER): the scoring kernel stores into every rank's mailbox, the scan waits "
+                                        "for arrival counters; opt-in, first run between GPUs is this record's"}
     for C, steps in sizes:
         row = {"particles": C, "updates_timed": steps}
-        for label in ("one_gpu", "sharded"):
-            if label == "sharded" and world == 1:
+        estimates = {}
+        for label, sharded, exchange in labels:
+            pf, err = None, None
+            try:
+                pf = eng.make_filter(C, sharded, iters_per_update, exchange)
+            except Exception as e:   # noqa: BLE001  (reported in the record)
+                err = "set-up: %s" % (e,)
+            if not all_ok(err is None):
+                row[label] = {"error": err or "another rank could not set this exchange up"}
+                if pf is not None:
+                    pf.close()
                 continue
-            pf = eng.make_filter(C, label == "sharded", iters_per_update)
-            for _ in range(3):
-                pf.update()
-            sync_all()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                pf.update()
-            sync_all()
-            dt = time.perf_counter() - t0
+            # warm-up, then the timed updates: each phase ends in the agreement above, which is also the barrier of the timed region
+            # (every rank starts its clock behind one all-reduce and stops it behind its own synchronize; MAX over ranks below)
+            dt = 0.0
+            for phase, count in (("warm-up", 3), ("run", steps)):
+                try:
+                    t0 = time.perf_counter()
+                    for _ in range(count):
+                        pf.update()
+                    eng.sync()
+                    dt = time.perf_counter() - t0
+                except Exception as e:   # noqa: BLE001
+                    err = "%s: %s" % (phase, e)
+                if not all_ok(err is None):
+                    err = err or "another rank failed while running this exchange"
+                    break
+            if err is not None:
+                row[label] = {"error": err}
+                pf.close()
+                continue
             dt_max = eng.reduce_max(dt)
             mine = eng.kernel_times(pf)
+            mine["estimate"] = eng.estimate(pf)
             if dist is not None:
                 allr = [None] * world
                 dist.all_gather_object(allr, mine)
@@ -490,14 +531,19 @@ def pf_strong_record(eng, dist, world, sizes=((10000, 100), (100000, 30), (10000
             row[label] = {"value": C * iters_per_update * steps / t_use, "unit": "candidates/s", "us_per_iteration": t_use / (steps * iters_per_update) * 1e6,
                           "score_kernel_ms_per_rank": [a["score_kernel_ms"] for a in allr],
                           "scan_select_ms_per_rank": [a["scan_select_ms"] for a in allr],
-                          "allgather_ms": max(a["allgather_ms"] for a in allr)}
+                          "allgather_ms": max(a["allgather_ms"] for a in allr),
+                          "estimates_equal_across_ranks": all(a["estimate"] == allr[0]["estimate"] for a in allr)}
+            estimates[label] = allr[0]["estimate"]
             if "checksum" in mine:
                 row[label]["checksums_equal_across_ranks"] = len({a["checksum"] for a in allr}) == 1
             if label == "one_gpu" and dist is not None:
                 row[label]["us_per_iteration_slowest_gpu"] = dt_max / (steps * iters_per_update) * 1e6
             pf.close()
-        if "sharded" in row:
-            row["speedup_valueN_over_value1"] = row["sharded"]["value"] / row["one_gpu"]["value"]
+        # every form ran the same number of iterations from the same seed on the same frame: the estimates must be the same bits
+        row["estimates_equal_across_forms"] = all(v == estimates["one_gpu"] for v in estimates.values()) if "one_gpu" in estimates else None
+        for label in ("sharded", "sharded_peer"):
+            if label in row and "value" in row[label]:
+                row["speedup_valueN_over_value1" + ("" if label == "sharded" else "_peer")] = row[label]["value"] / row["one_gpu"]["value"]
         rec["sizes"].append(row)
     eng.close()
     return rec

@@ -405,6 +405,25 @@ int mtfhip_comm_world(const mtfhip_comm *comm);
 /* in place when dev_send == dev_recv + rank * count_per_rank (ncclAllGather's in-place form) */
 int mtfhip_allgather_scores(mtfhip_comm *comm, const double *dev_send, int count_per_rank, double *dev_recv /* world x count */, void *hip_stream);
 int mtfhip_pf_set_comm(mtfhip_pf *pf, mtfhip_comm *comm);   /* shard the filter's scoring over the communicator's ranks */
+/* How the sharded filter's weights travel (collective call: every rank, after mtfhip_pf_set_comm).
+ * COLLECTIVE, the default: one in-place all-gather per iteration (RCCL), enqueued between the scoring and the scan.
+ * PEER: no collective and no extra launch -- the scoring kernel stores each weight into every rank's mailbox (fine-grained device
+ * memory mapped into the peers with hipIpcOpenMemHandle at this call; loopback ranks share an address space) and adds to an arrival
+ * counter per rank; the scan waits for the counters (bounded: a rank that never arrives becomes MTFHIP_ERR_HIP at the next estimate).
+ * Two mailbox vectors alternate, so a rank may run one iteration ahead of the slowest.  Up to 8 ranks (one node).  The result is
+ * the same bits as with the collective: the same weights reach the same places.  Measured on one GPU only (loopback ranks); between
+ * GPUs it is an opt-in until a multi-GPU node has run it -- DESIGN.md section 6. */
+enum { MTFHIP_PF_EXCHANGE_COLLECTIVE = 0, MTFHIP_PF_EXCHANGE_PEER = 1 };
+int mtfhip_pf_set_exchange(mtfhip_pf *pf, int mode);
+/* The two halves of the PEER set-up for a host program that moves the handles itself (as it moves mtfhip_comm_unique_id's bytes):
+ * export -> this rank's mailbox as a 64-byte hipIpc handle; connect <- the handles of all ranks, rank-major (the own one is skipped).
+ * connect also compares the seeds the ranks left in their mailboxes (identical proposals need ONE seed).
+ * mtfhip_comm_create_detached: a communicator that is rank and world only -- no RCCL behind it, no all-gather; a filter sharded over
+ * it exchanges through export / connect + peer stores.  (Two processes on ONE GPU can run it, which RCCL refuses: the cross-process
+ * half of the exchange -- IPC mapping, system-scope counters -- is tested that way, tests/test_gpu_trackers.py.) */
+int mtfhip_pf_exchange_export(mtfhip_pf *pf, void *handle64);
+int mtfhip_pf_exchange_connect(mtfhip_pf *pf, const void *handles /* world x 64 bytes */);
+int mtfhip_comm_create_detached(int rank, int world, int device, mtfhip_comm **out);
 /* the partition mtfhip_pf_set_comm uses (host arithmetic, no device): rank's block [lo, lo + count), per_rank = ceil(n / world) */
 int mtfhip_pf_shard_bounds(int n_particles, int world, int rank, int *lo, int *count, int *per_rank);
 

@@ -99,7 +99,7 @@ SYMBOLS = [
     "mtfhip_pf_set_max_similarity", "mtfhip_pf_set_distributions", "mtfhip_pf_set_distr_draws", "mtfhip_pf_get_distributions", "mtfhip_comm_create_loopback", "mtfhip_pf_shard_bounds",
     "mtfhip_batch_track_trace", "mtfhip_batch_track_trace_read", "mtfhip_image_preprocess_ex",
     "mtfhip_comm_unique_id", "mtfhip_comm_create", "mtfhip_comm_destroy", "mtfhip_comm_rank", "mtfhip_comm_world",
-    "mtfhip_allgather_scores", "mtfhip_pf_set_comm",
+    "mtfhip_allgather_scores", "mtfhip_pf_set_comm", "mtfhip_pf_set_exchange", "mtfhip_pf_exchange_export", "mtfhip_pf_exchange_connect", "mtfhip_comm_create_detached",
     "mtfhip_timing_enable", "mtfhip_timing_reset", "mtfhip_timing_get", "mtfhip_timing_get_busy", "mtfhip_ssm_estimate_state_sigma", "mtfhip_batch_track_queues", "mtfhip_batch_inline_warp",
 ]
 

@@ -1257,7 +1257,7 @@ int mtfhip_batch_track_trace_read(mtfhip_batch *b, double *dst) {
  * similarity at their global indices.  SSD / NCC (also multi-channel): k_pf_score; MI (8 bins): the histogram pass over the candidate
  * axis + k_mi_cand_score.  Shared by mtfhip_score_candidates_dev and the particle filter. */
 int score_block_dev(mtfhip_batch *b, const double *dev_states, int lo, int cnt, double *wts, double *sim, int likelihood_func,
-	double measurement_sigma, double max_similarity) {
+	double measurement_sigma, double max_similarity, const PfPeerPush *peer) {
 	hipStream_t st = b->ctx->stream;
 	if (b->desc.am == MTFHIP_AM_MI) {
 		if (b->desc.mi_n_bins != 8) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "score_candidates: MI candidates are scored with 8 bins (the reference's default, parameters.h:344)");
@@ -1277,6 +1277,7 @@ int score_block_dev(mtfhip_batch *b, const double *dev_states, int lo, int cnt, 
 		fp.active = nullptr; fp.tb = b->d_mi_tb;
 		launch_mi_score_candidates(b->view_raw(), b->ctx->img, fp, dev_states, lo, cnt, b->d_cand_mi, nblk, b->mi_row_len, b->desc.mi_pre_seed,
 			b->desc.likelihood_alpha, likelihood_func, measurement_sigma, max_similarity, wts, sim, st);
+		if (peer && cnt > 0) launch_pf_peer_push(*peer, wts, lo, cnt, st);   /* (the MI scorer does not store to the peers itself) */
 		return MTFHIP_OK;
 	}
 	const double *ncc_sc = nullptr;
@@ -1287,7 +1288,7 @@ int score_block_dev(mtfhip_batch *b, const double *dev_states, int lo, int cnt, 
 	}
 	/* (view_raw: the candidates bring their own warps; a stale device copy of the batch's warp is not uploaded for them) */
 	launch_score_block(b->view_raw(), b->ctx->img, dev_states, lo, cnt, b->desc.likelihood_alpha, b->norm_mult, b->norm_add, ncc_sc, wts, sim,
-		likelihood_func, measurement_sigma, max_similarity, b->math_mode == MTFHIP_MATH_FAST, st);
+		likelihood_func, measurement_sigma, max_similarity, b->math_mode == MTFHIP_MATH_FAST, peer, st);
 	return MTFHIP_OK;
 }
 int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int C, double *dev_lik, double *dev_sim) {

@@ -65,6 +65,7 @@ struct LoopGroup {
 	int arrived = 0;
 	unsigned long gen = 0;
 	std::vector<const double *> send;
+	std::vector<void *> mailbox;   /* peer-store exchange: every member's mailbox (the same address space: no IPC mapping) */
 	void barrier() {
 		std::unique_lock<std::mutex> lk(mu);
 		const unsigned long g = gen;
@@ -74,8 +75,9 @@ struct LoopGroup {
 };
 struct mtfhip_comm {
 	int rank = 0, world = 1, device = 0;
-	rccl_comm_t comm = nullptr;   /* NULL when world == 1 or loopback */
+	rccl_comm_t comm = nullptr;   /* NULL when world == 1, loopback or detached */
 	LoopGroup *loop = nullptr;
+	bool detached = false;        /* rank and world only: no collective (the sharded filter then exchanges through peer stores) */
 };
 
 struct mtfhip_pf {
@@ -112,6 +114,25 @@ struct mtfhip_pf {
 	double *d_distr = nullptr, *d_scan_stats = nullptr, *d_distr_u = nullptr;
 	int *d_distr_ids = nullptr, *d_resample_flag = nullptr;
 	std::vector<double> distr_u_next;
+	/* the peer-store exchange (mtfhip_pf_set_exchange; PfPeerPush / PfPeerWait in mtfhip_internal.h).  mailbox: wts[2][cap] doubles |
+	 * counters[kPfMaxPeers] | the storing launch's own arrival counter; base[q]: rank q's mailbox as this process addresses it (own rank: mailbox; RCCL ranks: an IPC mapping;
+	 * loopback ranks: the pointer itself) */
+	struct Peer {
+		bool on = false;
+		void *mailbox = nullptr;
+		size_t cap = 0;
+		void *base[kPfMaxPeers] = {};
+		bool mapped[kPfMaxPeers] = {};
+		unsigned long long epoch = 0, expected[kPfMaxPeers] = {};
+		int *h_err = nullptr, *h_err_dev = nullptr;
+		/* behind the two weight vectors: counters[kPfMaxPeers] | the storing launch's own arrival counter | the filter's seed */
+		static constexpr int kTailWords = kPfMaxPeers + 2;
+		double *wts(int q, int parity) const { return static_cast<double *>(base[q]) + (size_t)parity * cap; }
+		unsigned long long *counters(int q) const { return reinterpret_cast<unsigned long long *>(static_cast<double *>(base[q]) + 2 * cap); }
+		unsigned long long *seed_slot(int q) const { return counters(q) + kPfMaxPeers + 1; }
+	} peer;
+	/* the weights of the last iteration: the mailbox vector of the last exchange, or d_wts */
+	double *last_wts() const { return peer.on && peer.epoch ? peer.wts(comm->rank, (int)(peer.epoch & 1)) : d_wts; }
 };
 
 /* block of rank `rank`: [lo, lo + cnt) with m = ceil(n / world) particles per rank (the last blocks may be short or empty), so
@@ -159,11 +180,21 @@ int mtfhip_comm_create(const void *id128, int rank, int world, int device, mtfhi
 	*out = c;
 	return MTFHIP_OK;
 }
+/* rank `rank` of `world` with nothing behind it: the ranks' few set-up bytes (the mailbox handles of mtfhip_pf_exchange_export) are
+ * moved by the host program, and the weights by the peer-store exchange.  For ranks that RCCL cannot or need not join -- and what
+ * lets two processes share one GPU in tests/test_gpu_trackers.py (RCCL refuses duplicate devices). */
+int mtfhip_comm_create_detached(int rank, int world, int device, mtfhip_comm **out) {
+	if (!out || world < 1 || rank < 0 || rank >= world) return fail(MTFHIP_ERR_INVALID_ARG, "comm_create_detached: invalid rank %d / world %d", rank, world);
+	mtfhip_comm *c = new mtfhip_comm;
+	c->rank = rank; c->world = world; c->device = device; c->detached = world > 1;
+	*out = c;
+	return MTFHIP_OK;
+}
 /* `world` loopback ranks on one device: out[r] is rank r's communicator; each is used by its own host thread */
 int mtfhip_comm_create_loopback(int world, int device, mtfhip_comm **out) {
 	if (!out || world < 1) return fail(MTFHIP_ERR_INVALID_ARG, "comm_create_loopback: invalid world %d", world);
 	LoopGroup *g = new LoopGroup;
-	g->world = world; g->refs = world; g->send.assign((size_t)world, nullptr);
+	g->world = world; g->refs = world; g->send.assign((size_t)world, nullptr); g->mailbox.assign((size_t)world, nullptr);
 	for (int r = 0; r < world; ++r) {
 		mtfhip_comm *c = new mtfhip_comm;
 		c->rank = r; c->world = world; c->device = device; c->loop = g;
@@ -203,6 +234,7 @@ int mtfhip_allgather_scores(mtfhip_comm *c, const double *dev_send, int count, d
 		g->barrier();                                 /* nobody's send block is overwritten before everybody has read it */
 		return MTFHIP_OK;
 	}
+	if (c->detached) return fail(MTFHIP_ERR_LOGIC, "allgather_scores: a detached communicator has no collective");
 	if (c->world == 1 || !c->comm) {
 		if (!in_place) HIP_TRY(hipMemcpyAsync(dev_recv, dev_send, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, st));
 		return MTFHIP_OK;
@@ -218,6 +250,9 @@ static void pf_free(mtfhip_pf *pf) {
 		pf->d_normals, pf->d_uniforms, pf->d_ids, pf->d_parts, pf->d_gparts, pf->d_counters, pf->d_res_keys, pf->d_res_idx, pf->d_res_tmp,
 		pf->d_distr, pf->d_scan_stats, pf->d_distr_u, pf->d_distr_ids, pf->d_resample_flag};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
+	for (int q = 0; q < kPfMaxPeers; ++q) if (pf->peer.mapped[q]) (void)hipIpcCloseMemHandle(pf->peer.base[q]);
+	if (pf->peer.mailbox) (void)hipFree(pf->peer.mailbox);
+	if (pf->peer.h_err) (void)hipHostFree(pf->peer.h_err);
 }
 /* which sampler the (SSM, update type, dynamic model, sampling switches) combination selects -- and which combinations the
  * reference itself refuses */
@@ -365,6 +400,7 @@ int mtfhip_pf_set_comm(mtfhip_pf *pf, mtfhip_comm *c) {
 		/* Every rank scores a block of ITS OWN proposals and resamples from the gathered weights: the design relies on the ranks
 		 * drawing identical proposals, i.e. on one Philox key.  One 8-byte all-gather at set-up makes a mismatch an error instead of a
 		 * silently wrong estimate (r03 advisor finding: a front end that randomised seed 0 per process). */
+		if (c->detached) return MTFHIP_OK;   /* (no collective: the seeds are compared through the mailboxes, mtfhip_pf_exchange_connect) */
 		hipStream_t st = pf->b->ctx->stream;
 		double mine; static_assert(sizeof(mine) == sizeof(pf->d.seed), "the seed travels as the bits of one double");
 		std::memcpy(&mine, &pf->d.seed, sizeof(mine));
@@ -381,6 +417,116 @@ int mtfhip_pf_set_comm(mtfhip_pf *pf, mtfhip_comm *c) {
 			}
 	}
 	return MTFHIP_OK;
+}
+/* How a sharded filter's weights reach the other ranks.  COLLECTIVE (the default): one in-place all-gather per iteration,
+ * enqueued by the host between the scoring and the scan.  PEER: the scoring kernel stores every weight into every rank's mailbox
+ * and the scan waits for the ranks' arrival counters -- nothing is enqueued between the two kernels (mtfhip_internal.h, PfPeerPush).
+ * The mailboxes are fine-grained device memory, mapped into the other ranks once, at set-up:
+ *   mtfhip_pf_exchange_export   this rank's mailbox as a 64-byte hipIpc handle
+ *   mtfhip_pf_exchange_connect  the handles of all ranks -> mapped; the seeds the ranks left in their mailboxes are compared
+ *   mtfhip_pf_set_exchange      both, with the handles moved by the communicator itself (RCCL ranks: over its all-gather; loopback
+ *                               ranks share an address space and exchange the pointers)
+ * A DETACHED communicator (mtfhip_comm_create_detached: rank and world, no RCCL behind it) has no collective: the host program moves
+ * the handles -- as it moves RCCL's unique id -- and only the peer exchange is available.  World sizes up to kPfMaxPeers (one node). */
+static int pf_peer_alloc(mtfhip_pf *pf) {
+	mtfhip_comm *c = pf->comm;
+	if (!c || c->world < 2) return fail(MTFHIP_ERR_LOGIC, "pf exchange: the peer exchange belongs to a sharded filter (mtfhip_pf_set_comm with world > 1 first)");
+	if (c->world > kPfMaxPeers) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "pf exchange: the peer exchange serves up to %d ranks (one node), not %d", kPfMaxPeers, c->world);
+	mtfhip_pf::Peer &pr = pf->peer;
+	if (pr.mailbox) return MTFHIP_OK;
+	hipStream_t st = pf->b->ctx->stream;
+	int lo, cnt, m;
+	pf_shard(pf->n, c->world, c->rank, &lo, &cnt, &m);
+	pr.cap = (std::max(pf->wts_capacity, (size_t)m * c->world) + 1) & ~(size_t)1;
+	const size_t bytes = sizeof(double) * 2 * pr.cap + sizeof(unsigned long long) * mtfhip_pf::Peer::kTailWords;
+	HIP_TRY(hipExtMallocWithFlags(&pr.mailbox, bytes, hipDeviceMallocFinegrained));
+	HIP_TRY(hipMemsetAsync(pr.mailbox, 0, bytes, st));
+	pr.base[c->rank] = pr.mailbox;
+	HIP_TRY(hipMemcpyAsync(pr.seed_slot(c->rank), &pf->d.seed, sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pr.h_err), sizeof(int), hipHostMallocMapped));
+	*pr.h_err = 0;
+	HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&pr.h_err_dev), pr.h_err, 0));
+	HIP_TRY(hipStreamSynchronize(st));   /* the counters are zero and the seed is in place before anybody can learn where they are */
+	return MTFHIP_OK;
+}
+/* every base[] is in place: the ranks must have been created with one seed (identical proposals: see mtfhip_pf_set_comm) */
+static int pf_peer_finish(mtfhip_pf *pf) {
+	mtfhip_comm *c = pf->comm;
+	mtfhip_pf::Peer &pr = pf->peer;
+	hipStream_t st = pf->b->ctx->stream;
+	for (int q = 0; q < c->world; ++q) {
+		unsigned long long theirs = 0;
+		HIP_TRY(hipMemcpyAsync(&theirs, pr.seed_slot(q), sizeof(theirs), hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		if (theirs != pf->d.seed)
+			return fail(MTFHIP_ERR_INVALID_ARG, "pf exchange: rank %d's filter was created with another seed than rank %d's: a sharded filter needs ONE seed "
+				"on every rank (identical proposals)", q, c->rank);
+	}
+	pr.on = true;
+	return MTFHIP_OK;
+}
+int mtfhip_pf_exchange_export(mtfhip_pf *pf, void *handle64) {
+	if (!pf || !handle64) return fail(MTFHIP_ERR_INVALID_ARG, "pf_exchange_export: NULL argument");
+	static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C ABI hands the mailbox handle over as 64 bytes");
+	TRY(pf_peer_alloc(pf));
+	hipIpcMemHandle_t h;
+	HIP_TRY(hipIpcGetMemHandle(&h, pf->peer.mailbox));
+	std::memcpy(handle64, &h, sizeof(h));
+	return MTFHIP_OK;
+}
+int mtfhip_pf_exchange_connect(mtfhip_pf *pf, const void *handles /* world x 64 bytes, rank-major */) {
+	if (!pf || !handles) return fail(MTFHIP_ERR_INVALID_ARG, "pf_exchange_connect: NULL argument");
+	mtfhip_pf::Peer &pr = pf->peer;
+	if (!pr.mailbox) return fail(MTFHIP_ERR_LOGIC, "pf_exchange_connect before pf_exchange_export");
+	mtfhip_comm *c = pf->comm;
+	for (int q = 0; q < c->world; ++q) {
+		if (q == c->rank || pr.mapped[q]) continue;
+		hipIpcMemHandle_t h;
+		std::memcpy(&h, static_cast<const char *>(handles) + sizeof(h) * (size_t)q, sizeof(h));
+		const hipError_t e = hipIpcOpenMemHandle(&pr.base[q], h, hipIpcMemLazyEnablePeerAccess);
+		if (e != hipSuccess) return fail(MTFHIP_ERR_HIP, "pf_exchange_connect: rank %d cannot map rank %d's mailbox (hipIpcOpenMemHandle: %s)", c->rank, q, hipGetErrorString(e));
+		pr.mapped[q] = true;
+	}
+	return pf_peer_finish(pf);
+}
+int mtfhip_pf_set_exchange(mtfhip_pf *pf, int mode) {
+	if (!pf) return fail(MTFHIP_ERR_INVALID_ARG, "pf_set_exchange: NULL filter");
+	if (mode == MTFHIP_PF_EXCHANGE_COLLECTIVE) {
+		if (pf->comm && pf->comm->detached) return fail(MTFHIP_ERR_LOGIC, "pf_set_exchange: a detached communicator has no collective");
+		pf->peer.on = false;
+		return MTFHIP_OK;
+	}
+	if (mode != MTFHIP_PF_EXCHANGE_PEER) return fail(MTFHIP_ERR_INVALID_ARG, "pf_set_exchange: unknown mode %d", mode);
+	mtfhip_pf::Peer &pr = pf->peer;
+	if (pr.mailbox && pr.base[pf->comm ? (pf->comm->rank + 1) % std::max(pf->comm->world, 1) : 0]) { pr.on = true; return MTFHIP_OK; }   /* (connected before: switched back on) */
+	mtfhip_comm *c = pf->comm;
+	if (c && c->detached) return fail(MTFHIP_ERR_LOGIC, "pf_set_exchange: a detached communicator cannot move the mailbox handles itself: "
+		"mtfhip_pf_exchange_export, the host program's own transport, mtfhip_pf_exchange_connect");
+	TRY(pf_peer_alloc(pf));
+	hipStream_t st = pf->b->ctx->stream;
+	if (c->loop) {
+		LoopGroup *g = c->loop;
+		g->mailbox[(size_t)c->rank] = pr.mailbox;
+		g->barrier();
+		for (int q = 0; q < c->world; ++q) pr.base[q] = g->mailbox[(size_t)q];
+		g->barrier();   /* (the table may be reused by another filter of the group) */
+		return pf_peer_finish(pf);
+	}
+	hipIpcMemHandle_t mine;
+	static_assert(sizeof(hipIpcMemHandle_t) % sizeof(double) == 0, "the handle travels as doubles over the weight all-gather");
+	constexpr int hw = (int)(sizeof(hipIpcMemHandle_t) / sizeof(double));
+	HIP_TRY(hipIpcGetMemHandle(&mine, pr.mailbox));
+	double *d_h = nullptr;
+	HIP_TRY(hipMalloc(&d_h, sizeof(hipIpcMemHandle_t) * (size_t)c->world));
+	std::vector<hipIpcMemHandle_t> all((size_t)c->world);
+	int rc = MTFHIP_OK;
+	if (hipMemcpyAsync(d_h + (size_t)c->rank * hw, &mine, sizeof(mine), hipMemcpyHostToDevice, st) != hipSuccess) rc = MTFHIP_ERR_HIP;
+	if (rc == MTFHIP_OK) rc = mtfhip_allgather_scores(c, d_h + (size_t)c->rank * hw, hw, d_h, st);
+	if (rc == MTFHIP_OK && hipMemcpyAsync(all.data(), d_h, sizeof(hipIpcMemHandle_t) * (size_t)c->world, hipMemcpyDeviceToHost, st) != hipSuccess) rc = MTFHIP_ERR_HIP;
+	if (rc == MTFHIP_OK && hipStreamSynchronize(st) != hipSuccess) rc = MTFHIP_ERR_HIP;
+	(void)hipFree(d_h);
+	if (rc != MTFHIP_OK) return fail(rc, "pf_set_exchange: the exchange of the mailbox handles failed");
+	return mtfhip_pf_exchange_connect(pf, all.data());
 }
 /* ProjectiveBase::setSampler (ProjectiveBase.cc:208-215) */
 int mtfhip_pf_set_sampler(mtfhip_pf *pf, const double *sigma, const double *mean) {
@@ -449,7 +595,7 @@ static int pf_residual_sources(mtfhip_pf *pf, PfBuffers &bf, size_t nch, hipStre
 	int *idx_in = pf->d_res_idx, *order = idx_in + n, *copies = order + n, *starts = copies + n;
 	double *keys_in = pf->d_res_keys, *keys_out = keys_in + n;
 	const double *total = bf.chunk_incl + (nch - 1);   /* particle_cum_wts[n - 1] */
-	launch_pf_residual_prep(n, total, pf->d_wts, keys_in, idx_in, bf.resample_flag, st);
+	launch_pf_residual_prep(n, total, bf.wts, keys_in, idx_in, bf.resample_flag, st);
 	if (n > 1) {
 		size_t tb = pf->res_tmp_bytes;
 		/* std::sort(idx, idx + n - 1, wts[a] > wts[b]): the last index is not part of the range */
@@ -457,7 +603,7 @@ static int pf_residual_sources(mtfhip_pf *pf, PfBuffers &bf, size_t nch, hipStre
 			return fail(MTFHIP_ERR_HIP, "pf_iteration: radix sort of the particle weights failed");
 	}
 	HIP_TRY(hipMemcpyAsync(order + (n - 1), idx_in + (n - 1), sizeof(int), hipMemcpyDeviceToDevice, st));
-	launch_pf_residual_copies(n, pf->d_wts, order, copies, st);
+	launch_pf_residual_copies(n, bf.wts, order, copies, st);
 	{
 		size_t tb = pf->res_tmp_bytes;
 		if (hipcub::DeviceScan::ExclusiveSum(pf->d_res_tmp, tb, (const int *)copies, starts, n, st) != hipSuccess)
@@ -544,15 +690,41 @@ static int pf_enqueue_iteration(mtfhip_pf *pf, const double *normals, const doub
 	const bool lookahead = pf->lookahead_enabled && !normals && !p.distr_uniforms && pf->d.mean_type != 2;
 	bf.st = pf->d_st; bf.ar = pf->d_ar; bf.prop = pf->d_prop[pf->pc]; bf.prop_ar = pf->d_prop_ar[pf->pc];
 	bf.next = pf->d_prop[1 - pf->pc]; bf.next_ar = pf->d_prop_ar[1 - pf->pc];
-	bf.wts = pf->d_wts; bf.sim = nullptr; bf.cum = pf->d_cum; bf.chunk_tot = pf->d_chunk; bf.chunk_incl = pf->d_chunk + nch; bf.sub16 = pf->d_chunk + 2 * nch;
+	/* peer exchange: this iteration's weights live in the mailbox vector of its parity, here and on every other rank */
+	const bool peer = sharded && pf->peer.on;
+	if (sharded && !peer && c->detached)
+		return fail(MTFHIP_ERR_LOGIC, "pf_iteration: a filter sharded over a detached communicator needs the peer exchange connected first (mtfhip_pf_exchange_export / _connect)");
+	PfPeerPush push{};
+	PfPeerWait pwait{};
+	if (peer) {
+		mtfhip_pf::Peer &pr = pf->peer;
+		const int parity = (int)(++pr.epoch & 1);
+		push.world = pwait.world = c->world; push.rank = pwait.rank = c->rank;
+		for (int q = 0; q < c->world; ++q) {
+			int qlo, qcnt, qm;
+			pf_shard(n, c->world, q, &qlo, &qcnt, &qm);
+			pr.expected[q] += qcnt > 0 ? 1u : 0u;   /* one arrival per storing launch; an empty block launches nothing */
+			push.wts[q] = pr.wts(q, parity); push.counters[q] = pr.counters(q);
+			push.arrive = reinterpret_cast<unsigned *>(pr.counters(c->rank) + kPfMaxPeers);   /* (the word behind the counters) */
+			pwait.expected[q] = pr.expected[q];
+		}
+		pwait.counters = pr.counters(c->rank); pwait.err = pr.h_err_dev;
+	}
+	bf.wts = peer ? pf->peer.wts(c->rank, (int)(pf->peer.epoch & 1)) : pf->d_wts; bf.sim = nullptr; bf.cum = pf->d_cum; bf.chunk_tot = pf->d_chunk; bf.chunk_incl = pf->d_chunk + nch; bf.sub16 = pf->d_chunk + 2 * nch;
 	bf.res_order = nullptr;
 	bf.parts = pf->d_parts; bf.gparts = pf->d_gparts; bf.out = pf->d_out; bf.ids = pf->d_ids; bf.counters = pf->d_counters;
 	/* scoring: setState -> updatePixVals -> updateSimilarity -> likelihood per particle (PF.cc:341-365); sharded: this rank's block */
 	{
 		TimedScope ts(b->ctx, "pf_score");
-		TRY(score_block_dev(b, bf.prop, lo, cnt, bf.wts, bf.sim, p.likelihood_func, p.measurement_sigma, p.max_similarity));
+		TRY(score_block_dev(b, bf.prop, lo, cnt, bf.wts, bf.sim, p.likelihood_func, p.measurement_sigma, p.max_similarity, peer ? &push : nullptr));
 	}
-	if (sharded) {
+	if (peer) {
+		/* Loopback ranks share one GPU and its few hardware queues: a spinning scan of one rank could sit in front of the scoring launch of
+		 * another.  There the host threads meet once every rank's scoring has completed, and the waits below pass at once; the stores, the
+		 * counters and the two mailbox vectors are exercised as between GPUs.  RCCL ranks (one GPU each) enqueue straight through. */
+		TimedScope ts(b->ctx, "pf_peer_exchange");   /* (empty between GPUs: a marker that this exchange was the one in use) */
+		if (c->loop) { HIP_TRY(hipStreamSynchronize(st)); c->loop->barrier(); }
+	} else if (sharded) {
 		TimedScope ts(b->ctx, "pf_allgather");
 		TRY(mtfhip_allgather_scores(pf->comm, pf->d_wts + (size_t)c->rank * m, m, pf->d_wts, st));   /* in place: block r of m weights at r m */
 	}
@@ -560,7 +732,8 @@ static int pf_enqueue_iteration(mtfhip_pf *pf, const double *normals, const doub
 		TimedScope ts(b->ctx, "pf_resample");
 		unsigned long long seq = 0;
 		if (publish && b->h_acc_dev) seq = ++b->acc_seq;
-		if (p.resampling_type != 0 || mixture) launch_pf_scan(p, bf, st);   /* (the distribution weights follow the particle weights whatever the resampling) */
+		if (p.resampling_type != 0 || mixture) launch_pf_scan(p, bf, peer ? &pwait : nullptr, st);   /* (the distribution weights follow the particle weights whatever the resampling) */
+		else if (peer) launch_pf_peer_wait(pwait, st);
 		if (p.resampling_type == 3) TRY(pf_residual_sources(pf, bf, nch, st));
 		launch_pf_select(b->desc.ssm, p, bf, lookahead ? 1 : 0, seq ? b->h_acc_dev : nullptr, b->h_flag_dev, seq, st);
 		if (pub_seq) *pub_seq = seq;
@@ -584,6 +757,8 @@ static int pf_collect_estimate(mtfhip_pf *pf, unsigned long long pub_seq, double
 		HIP_TRY(hipMemcpyAsync(out, pf->d_out, sizeof(out), hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
 	}
+	if (pf->peer.on && pf->peer.h_err && __atomic_load_n(pf->peer.h_err, __ATOMIC_ACQUIRE) != 0)
+		return fail(MTFHIP_ERR_HIP, "pf_iteration: rank %d gave up waiting for another rank's weights (peer-store exchange): the estimate is not valid", pf->comm ? pf->comm->rank : 0);
 	if (pf->d.mean_type == 2) TRY(mtfhip_ssm_set_corners(b, out + 10));
 	else TRY(mtfhip_ssm_set_state(b, out));
 	double un = 0;
@@ -639,7 +814,7 @@ int mtfhip_pf_get_particles(mtfhip_pf *pf, double *states, double *ars, double *
 	const size_t nS = (size_t)pf->n * pf->S;
 	if (states) HIP_TRY(hipMemcpyAsync(states, pf->d_st, sizeof(double) * nS, hipMemcpyDeviceToHost, st));
 	if (ars) HIP_TRY(hipMemcpyAsync(ars, pf->d_ar, sizeof(double) * nS, hipMemcpyDeviceToHost, st));
-	if (wts) HIP_TRY(hipMemcpyAsync(wts, pf->d_wts, sizeof(double) * pf->n, hipMemcpyDeviceToHost, st));
+	if (wts) HIP_TRY(hipMemcpyAsync(wts, pf->last_wts(), sizeof(double) * pf->n, hipMemcpyDeviceToHost, st));
 	if (resample_ids) HIP_TRY(hipMemcpyAsync(resample_ids, pf->d_ids, sizeof(int) * pf->n, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	return MTFHIP_OK;

@@ -365,7 +365,48 @@ struct PfScoreArgs {
 	double measurement_sigma, max_similarity;
 	double *wts;                   /* [>= n] particle_wts, written at the particles' global indices */
 	double *sim;                   /* [n] similarities or NULL */
+	PfPeerPush peer;               /* world > 0: the weights also go to every other rank's mailbox (mtfhip_internal.h) */
 };
+/* A weight for the peers: a relaxed system-scope store -- it goes through to the peer's memory, and the wave's vmcnt tells when it
+ * has (what every release fence relies on), so no fence and no L2 write-back per workgroup.  (First version: a system-scope release
+ * per scoring workgroup.  Each is a write-back of the whole L2: the scoring launch of a 1 250-particle block went from 40 to 131 us.) */
+__device__ __forceinline__ void pf_peer_store(const PfPeerPush &peer, int idx, double w) {
+	for (int q = 0; q < peer.world; ++q)
+		if (q != peer.rank) __hip_atomic_store(peer.wts[q] + idx, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+/* ... and the arrival: wave 0 of every workgroup (the wave whose lanes stored) waits for its stores to be acknowledged and counts
+ * itself in on this rank's own counter (agent scope, like the scan's); the LAST workgroup of the launch then adds one arrival to
+ * this rank's entry in every peer's counters, release at system scope -- once per launch. */
+__device__ __forceinline__ void pf_peer_arrive(const PfPeerPush &peer, unsigned n_workgroups) {
+	if (threadIdx.x >= 64) return;
+	wait_stores_acked();
+	if (threadIdx.x != 0) return;
+	if (__hip_atomic_fetch_add(peer.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != n_workgroups - 1) return;
+	__hip_atomic_store(peer.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   /* zero between launches */
+	for (int q = 0; q < peer.world; ++q)
+		if (q != peer.rank) (void)__hip_atomic_fetch_add(peer.counters[q] + peer.rank, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+/* every workgroup of the first kernel that reads the gathered weights: thread q waits for rank q's arrivals.  The spin is bounded
+ * (~seconds): a peer that never arrives becomes an error the host reports (PfPeerWait::err), not a hung queue. */
+constexpr unsigned kPfPeerSpinLimit = 1u << 21;
+__device__ __forceinline__ void pf_peer_wait(const PfPeerWait &w) {
+	if (w.world == 0) return;
+	const int q = threadIdx.x;
+	if (q < w.world && q != w.rank) {
+		unsigned long long need = 0;
+#pragma unroll
+		for (int r = 0; r < kPfMaxPeers; ++r) if (r == q) need = w.expected[r];
+		unsigned spins = 0;
+		while (__hip_atomic_load(w.counters + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need) {
+			__builtin_amdgcn_s_sleep(8);
+			/* (once a wait has given up every later one does at its first look: a failed filter drains in milliseconds) */
+			if ((++spins & 1023u) == 1u && __hip_atomic_load(w.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
+			if (spins > kPfPeerSpinLimit) { __hip_atomic_store(w.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+		}
+	}
+	__syncthreads();
+	__atomic_thread_fence(__ATOMIC_ACQUIRE);   /* (system scope: the peers' weights, not a cached older exchange) */
+}
 struct __attribute__((packed, aligned(4))) PfTexPair { float a, b; };
 /* MC: the multi-channel models (MCSSD / MCNCC = SSD / NCC built with n_channels = 3, AM/src/MCSSD.cc): a row of the per-pixel
  * arrays is a (pixel, channel) pair, row = pixel * C + channel (mc::getPixVals imgUtils.cc:867-882); the grid point is the
@@ -469,8 +510,18 @@ __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, P
 		}
 		if (s.wts) s.wts[cand] = w;
 		if (s.sim) s.sim[cand] = f;
+		if (s.peer.world) pf_peer_store(s.peer, cand, w);
 	}
+	if (s.peer.world) pf_peer_arrive(s.peer, gridDim.x);
 }
+/* the same for a scorer that does not store to the peers itself (MI): 64 weights per workgroup, stored by wave 0 */
+constexpr int kPfPushPerGroup = 64;
+__global__ __launch_bounds__(64) void k_pf_peer_push(PfPeerPush peer, const double *wts, int lo, int cnt) {
+	const int i = blockIdx.x * kPfPushPerGroup + threadIdx.x;
+	if (i < cnt) pf_peer_store(peer, lo + i, wts[lo + i]);
+	pf_peer_arrive(peer, gridDim.x);
+}
+__global__ __launch_bounds__(kBlock) void k_pf_peer_wait(PfPeerWait w) { pf_peer_wait(w); }
 
 /* ===================================================================== */
 /* launch 2: cumulative weights                                           */
@@ -498,6 +549,7 @@ struct PfScanArgs {
 	double min_distr_wt, min_eff;   /* min_eff: adaptive_resampling_thresh x n, 0 = resample every iteration */
 	double *distr_cum, *distr_wts;  /* [n_distr] out: the distribution weights of the next iteration and their running sums */
 	int *resample_flag;   /* out: 1 when this iteration resamples */
+	PfPeerWait wait;      /* sharded filter with the peer-store exchange: the weights are complete when the peers have arrived */
 };
 /* inclusive prefix sum over the wave with DPP moves (row_shr 1 / 2 / 4 / 8 inside the rows of 16, row_bcast:15 / :31 across them; a
  * lane without a source adds 0.0): ~18 VALU instructions instead of six ds_bpermute round trips through the LDS crossbar (~120
@@ -518,6 +570,7 @@ __global__ __launch_bounds__(kBlock) void k_pf_scan(PfScanArgs a) {
 	const int chunk = blockIdx.x * (kBlock / 64) + wave;
 	const int base = chunk * kPfChunk + 4 * lane;
 	const int nch = a.nch;
+	pf_peer_wait(a.wait);
 	if (chunk < nch) {
 		double w[4];
 		if (base + 3 < a.n) {
@@ -955,17 +1008,24 @@ static void launch_pf_score_args(const BatchView &bv, const ImgView &im, const P
  * mtfhip_score_candidates: PF.cc:247-262, 341-365 per candidate) */
 void launch_score_block(const BatchView &bv, const ImgView &im, const double *states, int lo, int cnt, double alpha, double norm_mult,
 	double norm_add, const double *ncc_sc, double *wts, double *sim, int likelihood_func, double measurement_sigma, double max_similarity,
-	int fast_math, hipStream_t st) {
+	int fast_math, const PfPeerPush *peer, hipStream_t st) {
 	PfScoreArgs s;
 	s.prop = states; s.lo = lo; s.cnt = cnt; s.alpha = alpha; s.norm_mult = norm_mult; s.norm_add = norm_add; s.ncc_sc = ncc_sc;
 	s.likelihood_func = likelihood_func; s.measurement_sigma = measurement_sigma; s.max_similarity = max_similarity;
 	s.wts = wts; s.sim = sim;
+	if (peer) s.peer = *peer; else s.peer = PfPeerPush{};
 	launch_pf_score_args(bv, im, s, fast_math, st);
 }
-void launch_pf_scan(const PfLaunch &p, const PfBuffers &bf, hipStream_t st) {
+void launch_pf_peer_push(const PfPeerPush &peer, const double *wts, int lo, int cnt, hipStream_t st) {
+	if (cnt <= 0) return;
+	MTFHIP_LAUNCH(k_pf_peer_push, dim3((cnt + kPfPushPerGroup - 1) / kPfPushPerGroup), dim3(64), 0, st, peer, wts, lo, cnt);
+}
+void launch_pf_peer_wait(const PfPeerWait &w, hipStream_t st) { MTFHIP_LAUNCH(k_pf_peer_wait, dim3(1), dim3(kBlock), 0, st, w); }
+void launch_pf_scan(const PfLaunch &p, const PfBuffers &bf, const PfPeerWait *wait, hipStream_t st) {
 	const int nch = (p.n + kPfChunk - 1) / kPfChunk;
 	PfScanArgs sc{p.n, nch, bf.wts, bf.cum, bf.sub16, bf.chunk_tot, bf.chunk_incl, bf.counters,
-		bf.scan_stats, bf.distr_ids, p.n_distr > 1 ? p.n_distr : 1, p.min_distr_wt, p.min_eff_particles, bf.distr_cum, bf.distr_wts, bf.resample_flag};
+		bf.scan_stats, bf.distr_ids, p.n_distr > 1 ? p.n_distr : 1, p.min_distr_wt, p.min_eff_particles, bf.distr_cum, bf.distr_wts, bf.resample_flag,
+		wait ? *wait : PfPeerWait{}};
 	MTFHIP_LAUNCH(k_pf_scan, dim3((nch + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, sc);
 }
 void launch_pf_select(int ssm, const PfLaunch &p, const PfBuffers &bf, int lookahead, double *host_out, unsigned long long *host_flag,

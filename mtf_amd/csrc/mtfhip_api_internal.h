@@ -507,6 +507,7 @@ int fused_args(const mtfhip_batch *b, const mtfhip_sm_desc *sm, FusedArgs &fa);
 int mi_blocks(const mtfhip_batch *b);
 int push_ncc(mtfhip_batch *b);
 int score_block_dev(mtfhip_batch *b, const double *dev_states, int lo, int cnt, double *wts, double *sim, int likelihood_func,
-	double measurement_sigma, double max_similarity);   /* api_fused.hip */
+	double measurement_sigma, double max_similarity, const mtfhip::PfPeerPush *peer = nullptr);   /* api_fused.hip; peer: also store the
+	                                                                                       weights to the other ranks' mailboxes */
 } /* extern "C" */
 #endif

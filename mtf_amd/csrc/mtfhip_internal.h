@@ -321,11 +321,34 @@ struct PfBuffers {
 	int *ids, *counters;        /* [0] the scan's arrival counter, [1] the selection pass's top-level counter, [2 ...] one per group of 64
 	                               workgroups of the selection pass; zero between launches */
 };
+/* Peer-store exchange of the sharded filter's weights (the alternative to the all-gather, api_pf.hip: mtfhip_pf_set_exchange): every
+ * rank owns a MAILBOX -- two weight vectors (the exchanges alternate between them, so a rank that runs one iteration ahead never
+ * overwrites what a slower one still reads) and one arrival counter per source rank.  The scoring kernel stores every weight it
+ * produces into every rank's mailbox (peer memory, mapped once at set-up); the last of its workgroups to finish adds 1 to its
+ * rank's counter in every mailbox (release, system scope); the first kernel that reads the weights spins until every counter
+ * has reached the count the host knows it must reach (acquire, system scope).  No host-enqueued collective, no extra launch. */
+constexpr int kPfMaxPeers = 8;
+struct PfPeerPush {
+	int world, rank;                              /* world == 0: no peer stores */
+	double *wts[kPfMaxPeers];                     /* every rank's weight vector of this exchange (own rank: unused, the scorer's wts) */
+	unsigned long long *counters[kPfMaxPeers];    /* every rank's arrival counters [world]: this rank bumps entry `rank` */
+	unsigned *arrive;                             /* this rank's own: the workgroups of the storing launch count themselves in; zero between launches */
+};
+struct PfPeerWait {
+	int world, rank;                              /* world == 0: nothing to wait for */
+	const unsigned long long *counters;           /* this rank's mailbox counters [world] */
+	unsigned long long expected[kPfMaxPeers];     /* what each must have reached before the weights are complete */
+	int *err;                                     /* host-mapped: set to 1 when the bounded spin gave up */
+};
 void launch_pf_propose(int ssm, const PfLaunch &p, const PfBuffers &bf, const double *st_in, const double *ar_in, double *st_out, double *ar_out, hipStream_t st);
 void launch_score_block(const BatchView &bv, const ImgView &im, const double *states, int lo, int cnt, double alpha, double norm_mult,
 	double norm_add, const double *ncc_sc, double *wts, double *sim, int likelihood_func, double measurement_sigma, double max_similarity,
-	int fast_math, hipStream_t st);
-void launch_pf_scan(const PfLaunch &p, const PfBuffers &bf, hipStream_t st);   /* weights -> chunk-local cumulative weights + chunk table */
+	int fast_math, const PfPeerPush *peer /* or NULL */, hipStream_t st);
+/* weights [lo, lo + cnt) of `wts` -> every other rank's mailbox + the arrival: for scorers that do not store to the peers themselves */
+void launch_pf_peer_push(const PfPeerPush &peer, const double *wts, int lo, int cnt, hipStream_t st);
+void launch_pf_peer_wait(const PfPeerWait &w, hipStream_t st);   /* the wait in a launch of its own (no scan in this iteration) */
+/* weights -> chunk-local cumulative weights + chunk table; wait != NULL: every workgroup first waits for the peers' weights */
+void launch_pf_scan(const PfLaunch &p, const PfBuffers &bf, const PfPeerWait *wait, hipStream_t st);
 void launch_pf_select(int ssm, const PfLaunch &p, const PfBuffers &bf, int lookahead, double *host_out /* or NULL */,
 	unsigned long long *host_flag, unsigned long long seq, hipStream_t st);
 void launch_pf_fill(int n, int S, const double *dev_state, double *states, double *ars, hipStream_t st);

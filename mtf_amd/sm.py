@@ -401,6 +401,17 @@ class Comm:
             out.append(c)
         return out
 
+    @classmethod
+    def detached(cls, rank, world, device=0):
+        """rank and world with no collective behind them (mtfhip_comm_create_detached): a filter sharded over it exchanges its
+        weights through peer stores, and the host program moves the mailbox handles (ParticleFilter(exchange_transport=...))"""
+        import ctypes as C
+        c = cls.__new__(cls)
+        c._h = C.c_void_p()
+        L.check(L.lib().mtfhip_comm_create_detached(int(rank), int(world), int(device), C.byref(c._h)))
+        c.rank, c.world, c.is_detached = rank, world, world > 1
+        return c
+
     @staticmethod
     def shard_bounds(n, world, rank):
         """(lo, count, per_rank) of mtfhip_pf_shard_bounds: the block a rank scores, per_rank = ceil(n / world)"""
@@ -444,7 +455,7 @@ class ParticleFilter:
                  max_iters=1, epsilon=0.01, seed=0, am=L.AM_SSD, dynamic_model=0, update_type=1, likelihood_func=0,
                  resampling_type=1, mean_type=0, corner_based_sampling=0, reset_to_mean=0, measurement_sigma=0.1, ar_coeff=0.5,
                  comm=None, pt_based_sampling=0, n_channels=1, adaptive_resampling_thresh=0.0, update_distr_wts=0, min_distr_wt=0.1,
-                 jacobian_as_sigma=0, pix_sigma=None):
+                 jacobian_as_sigma=0, pix_sigma=None, exchange="collective", exchange_transport=None):
         """pix_sigma: one value per sampler distribution; with pix_sigma[0] > 0 the sampler sigmas are estimated from them at
         initialize() (PFParams::processDistributions PFParams.cc:105-116, PF.cc:142-149: SSM::estimateStateSigma) and ssm_sigma is ignored.
         ssm_sigma / ssm_mean: one row of up to 8 values, or several rows = several sampler distributions (PFParams::processDistributions:
@@ -503,6 +514,23 @@ class ParticleFilter:
         self.comm = comm
         if comm is not None:
             L.check(L.lib().mtfhip_pf_set_comm(self._h, comm._h))
+        # how the weights of a sharded filter travel: "collective" (one RCCL all-gather per iteration, the default) or "peer" (the
+        # scoring kernel stores into every rank's mailbox, the scan waits for arrival counters: mtfhip_pf_set_exchange)
+        if exchange not in ("collective", "peer"):
+            raise ValueError("exchange must be 'collective' or 'peer', not %r" % (exchange,))
+        self.exchange = exchange
+        if exchange == "peer" and exchange_transport is not None:
+            # the host program moves the 64-byte mailbox handles: exchange_transport(mine: bytes) -> [every rank's bytes, rank-major]
+            buf = (C.c_char * 64)()
+            L.check(L.lib().mtfhip_pf_exchange_export(self._h, buf))
+            handles = list(exchange_transport(bytes(buf)))
+            if len(handles) != comm.world or any(len(h) != 64 for h in handles):
+                raise ValueError("exchange_transport must return the %d ranks' 64-byte handles" % comm.world)
+            L.check(L.lib().mtfhip_pf_exchange_connect(self._h, (C.c_char * (64 * comm.world)).from_buffer_copy(b"".join(handles))))
+        elif exchange == "peer":
+            L.check(L.lib().mtfhip_pf_set_exchange(self._h, 1))
+        elif comm is not None and getattr(comm, "is_detached", False):
+            raise ValueError("a detached communicator has no collective: exchange='peer' with an exchange_transport")
         if ssm == L.SSM_HOMOGRAPHY:
             self.nz = 10 if corner_based_sampling else 8
         else:

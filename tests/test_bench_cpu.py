@@ -35,6 +35,23 @@ def test_bench_gpus2_self_spawns_and_reports_pf_strong():
         sh = row["sharded"]
         assert len(sh["score_kernel_ms_per_rank"]) == 2 and sh["allgather_ms"] >= 0 and sh["value"] > 0
         assert sh["checksums_equal_across_ranks"]      # one all-gather left the same flat weight vector on both ranks (ragged 1003 too)
+        # the peer-store exchange is timed beside the collective, and every form must end on the same estimate
+        assert row["sharded_peer"]["value"] > 0 and row["estimates_equal_across_forms"] and "speedup_valueN_over_value1_peer" in row
+
+
+def test_pf_strong_survives_a_rank_that_cannot_set_the_peer_exchange_up():
+    """One rank failing to map the peers' mailboxes (here: the stub raising on rank 1) must not leave the other rank alone in a
+    collective: every fallible phase of pf_strong_record ends in an agreement, the row reports the error, the rest of the record and
+    the JSON line are produced as usual."""
+    env = _clean_env()
+    env["MTFHIP_BENCH_STUB_PEER_FAIL"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "1"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    for row in d["pf_strong"]["sizes"]:
+        assert "error" in row["sharded_peer"] and "value" not in row["sharded_peer"]
+        assert row["sharded"]["value"] > 0 and row["estimates_equal_across_forms"]
 
 
 def test_bench_single_rank_stub_line():

@@ -208,11 +208,13 @@ def test_config4_pf_10000_candidates(gpu_ctx, big_frames):
     assert b.score_candidates(states[:100]).max() < 1.0
 
 
-def test_config4_pf_sharded_world8_full_size(big_frames):
+@pytest.mark.parametrize("exchange", ["collective", "peer"])
+def test_config4_pf_sharded_world8_full_size(big_frames, exchange):
     """Config 4 as `bench.py --workload pf --gpus 8` runs it, at its full size: 10 000 particles x 2 500 px sharded over EIGHT ranks
     (threads of this process over the loopback communicator: block bounds, one in-place all-gather of 1 250 weights per rank,
     replicated proposals / scan / selection) -- every rank ends four iterations with the unsharded filter's particle set, weights
-    and estimate, bit for bit, and the estimate follows the known synthetic warp."""
+    and estimate, bit for bit, and the estimate follows the known synthetic warp.  exchange="peer": the weights travel as stores
+    of the scoring kernel into the eight mailboxes instead (mtfhip_pf_set_exchange), same bits."""
     from mtf_amd.sm import Comm, ParticleFilter
     from test_gpu_trackers import _run_ranks
     f0, f1, p_true = big_frames
@@ -222,7 +224,7 @@ def test_config4_pf_sharded_world8_full_size(big_frames):
     def run(comm):
         ctx = mtf_amd.Context(0)
         ctx.set_image(f0)
-        pf = ParticleFilter(ctx, L.SSM_HOMOGRAPHY, 50, 50, comm=comm, **kw)
+        pf = ParticleFilter(ctx, L.SSM_HOMOGRAPHY, 50, 50, comm=comm, exchange=exchange if comm is not None else "collective", **kw)
         pf.initialize(corners[None])
         ctx.set_image(f1)
         for _ in range(4):

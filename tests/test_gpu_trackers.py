@@ -1,4 +1,5 @@
 """GPU: the search-method drivers (mtf_amd/sm.py) end to end -- the callers of the hot path."""
+import os
 import numpy as np
 import pytest
 
@@ -979,12 +980,15 @@ def _run_ranks(world, fn):
     dict(corner_based_sampling=1, dynamic_model=1, update_type=1, mean_type=1, resampling_type=1, adaptive_resampling_thresh=0.3,
          ssm_sigma=[(1.0, 0.6), (3.0, 1.2), (0.3, 0.2)], likelihood_alpha=1.0, update_distr_wts=1),
 ])
-def test_pf_sharded_loopback_equals_unsharded(frame, world, n, cfg):
+@pytest.mark.parametrize("exchange", ["collective", "peer"])
+def test_pf_sharded_loopback_equals_unsharded(frame, world, n, cfg, exchange):
     """The sharded filter as bench.py --workload pf --gpus N runs it -- mtfhip_pf_set_comm, block bounds with a ragged (or
     empty) last block, ONE in-place all-gather of ceil(n / world) weights per rank, replicated proposals and resampling --
     executed with world ranks as threads of this process over a loopback communicator (the exchange is a rendezvous + device
     copies; everything else is the RCCL path), three iterations with the device generator, against the unsharded filter:
-    every rank must hold bit-identical weights, resample ids, particle sets and estimates."""
+    every rank must hold bit-identical weights, resample ids, particle sets and estimates.
+    exchange="peer": the same with mtfhip_pf_set_exchange(PEER) -- the scoring kernel's stores into every rank's mailbox, the
+    arrival counters the scan waits for, the two alternating mailbox vectors (three iterations use both)."""
     from mtf_amd.sm import Comm
     corners = synth.square_corners(250.0, 240.0, 80) + np.array([[0.3, -0.2, 0.1, 0.4], [0.2, 0.1, -0.3, 0.2]])
     sigma = (1.0, 0.6, 1, 1, 1, 1, 1, 1) if cfg["corner_based_sampling"] else (0.004, 0.004, 0.8, 0.004, 0.004, 0.8, 2e-6, 2e-6)
@@ -995,7 +999,7 @@ def test_pf_sharded_loopback_equals_unsharded(frame, world, n, cfg):
     def run(comm):
         ctx = mtf_amd.Context(0)
         ctx.set_image(frame)
-        pf = ParticleFilter(ctx, L.SSM_HOMOGRAPHY, 24, 24, comm=comm, **kw)
+        pf = ParticleFilter(ctx, L.SSM_HOMOGRAPHY, 24, 24, comm=comm, exchange=exchange if comm is not None else "collective", **kw)
         pf.initialize(corners[None])
         ctx.set_image(frame_b)
         rec = []
@@ -1016,6 +1020,101 @@ def test_pf_sharded_loopback_equals_unsharded(frame, world, n, cfg):
                 if what == "ids" and cfg["resampling_type"] == 0:
                     continue
                 assert np.array_equal(a, b), "rank %d iteration %d: %s differ from the unsharded filter" % (r, it, what)
+
+
+@pytest.mark.parametrize("am,resampling_type,n", [(L.AM_NCC, 3, 1000), (L.AM_MI, 1, 300), (L.AM_SSD, 3, 10001)])
+def test_pf_peer_exchange_other_scorers_and_update(frame, am, resampling_type, n):
+    """The peer-store exchange on the paths the main test does not take: the NCC scorer, the MI scorer (which does not store to the
+    peers itself: a push launch of its own follows it), residual resampling (the weights are normalised in place, in the mailbox), and
+    mtfhip_pf_update's back-to-back iterations (five exchanges enqueued without the host in between, both mailbox vectors reused).
+    World 3 (a ragged last block) against the unsharded filter, bit for bit; and the refusals of mtfhip_pf_set_exchange."""
+    from mtf_amd.sm import Comm
+    corners = synth.square_corners(250.0, 240.0, 80) + np.array([[0.3, -0.2, 0.1, 0.4], [0.2, 0.1, -0.3, 0.2]])
+    frame_b = synth.warp_frame(frame, np.array([0, 0, 1.2, 0, 0, -0.8, 0, 0]), (250.0, 240.0))
+    kw = dict(n_particles=n, ssm_sigma=(1.0, 0.6, 1, 1, 1, 1, 1, 1), likelihood_alpha=5.0, seed=91, am=am, corner_based_sampling=1,
+              resampling_type=resampling_type, max_iters=5, epsilon=-1.0)
+    world = 3
+
+    def run(comm):
+        ctx = mtf_amd.Context(0)
+        ctx.set_image(frame)
+        pf = ParticleFilter(ctx, L.SSM_HOMOGRAPHY, 20, 20, comm=comm, exchange="peer" if comm is not None else "collective", **kw)
+        pf.initialize(corners[None])
+        ctx.set_image(frame_b)
+        ctx.timing(1); ctx.timing_reset()
+        pf.update()
+        st, ar, w, ids = pf.particles()
+        if comm is not None:   # the exchange that ran was the peer one: five of them, and no all-gather
+            assert ctx.timing_get("pf_peer_exchange")[1] == 5 and ctx.timing_get("pf_allgather")[1] == 0
+        ctx.timing(False)
+        out = (st.copy(), ar.copy(), w.copy(), ids.copy(), pf.get_region().copy())
+        pf.close(); ctx.close()
+        return out
+    ref = run(None)
+    comms = Comm.loopback(world)
+    got = _run_ranks(world, lambda r: run(comms[r]))
+    for c in comms:
+        c.close()
+    for r in range(world):
+        for a, b, what in zip(got[r], ref, ("states", "ars", "weights", "ids", "corners")):
+            assert np.array_equal(a, b), "rank %d: %s differ from the unsharded filter" % (r, what)
+    # an unsharded filter has nobody to exchange with
+    ctx = mtf_amd.Context(0)
+    ctx.set_image(frame)
+    with pytest.raises(mtf_amd.MtfHipError, match="sharded"):
+        ParticleFilter(ctx, L.SSM_HOMOGRAPHY, 20, 20, n_particles=64, seed=3, exchange="peer")
+    with pytest.raises(ValueError, match="exchange"):
+        ParticleFilter(ctx, L.SSM_HOMOGRAPHY, 20, 20, n_particles=64, seed=3, exchange="ring")
+    ctx.close()
+
+
+@pytest.mark.parametrize("world,n", [(2, 2001), (4, 10000)])
+def test_pf_peer_exchange_between_processes(tmp_path, world, n):
+    """The cross-process half of the peer-store exchange, on one GPU: `world` PROCESSES share GPU 0 (RCCL would refuse the duplicate
+    device; the communicator is a detached one), each exports its mailbox as a hipIpc handle, the handles travel through files, every
+    rank maps the others' (hipIpcOpenMemHandle), and the weights then move as system-scope stores of the scoring kernel into the mapped
+    mailboxes, the scans waiting on the mapped arrival counters -- three host-stepped iterations and six chained ones.  Every rank
+    must end with the particle set, weights, resample ids and estimate of an unsharded filter run the same way (tests/helpers/
+    pf_peer_rank.py with world 1), bit for bit.  What this leaves untested is only the link: peers on OTHER GPUs (xGMI)."""
+    import subprocess
+    import sys
+    helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "pf_peer_rank.py")
+
+    def spawn(rank, w, scratch):
+        os.makedirs(scratch, exist_ok=True)
+        return subprocess.Popen([sys.executable, helper, str(rank), str(w), scratch, str(n)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    ref_dir, sh_dir = str(tmp_path / "ref"), str(tmp_path / "sharded")
+    procs = [spawn(0, 1, ref_dir)] + [spawn(r, world, sh_dir) for r in range(world)]
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, out[-3000:]
+    ref = np.load(os.path.join(ref_dir, "result_0.npz"))
+    for r in range(world):
+        got = np.load(os.path.join(sh_dir, "result_%d.npz" % r))
+        for k in ref.files:
+            assert np.array_equal(got[k], ref[k]), "rank %d: %s differs from the unsharded filter" % (r, k)
+
+
+def test_pf_peer_exchange_refuses_mismatched_seeds_between_processes(tmp_path):
+    """a detached communicator has no all-gather to compare the seeds with at mtfhip_pf_set_comm: they are compared through the
+    mailboxes when the peers are connected, and a mismatch is refused on both ranks"""
+    import subprocess
+    import sys
+    helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "pf_peer_rank.py")
+    scratch = str(tmp_path / "s")
+    os.makedirs(scratch)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, PF_PEER_TEST_SEED=str(500 + r))
+        procs.append(subprocess.Popen([sys.executable, helper, str(r), "2", scratch, "600"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env))
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode != 0 and "another seed" in out, out[-2000:]
 
 
 def test_pf_sharded_filter_refuses_mismatched_seeds(frame):
