@@ -336,6 +336,67 @@ PF_STRONG_MODEL = {
 }
 
 
+PF_PEER_CHILD_TIMEOUT_S = 150
+PF_FILTER_KW = dict(ssm_sigma=(1.0, 0.5, 1, 1, 1, 1, 1, 1), corner_based_sampling=1, dynamic_model=0, update_type=1, likelihood_func=0,
+                    resampling_type=1, mean_type=0, likelihood_alpha=1.0, epsilon=-1.0)
+
+
+def pf_file_transport(scratch, rank, world, timeout_s=60.0):
+    """the host program's own transport for the 64-byte mailbox handles of the peer-store exchange: one file per rank in a directory
+    every rank can see (mtf_amd.sm.ParticleFilter(exchange_transport=...))"""
+    def transport(mine):
+        tmp = os.path.join(scratch, "handle_%d.tmp" % rank)
+        with open(tmp, "wb") as f:
+            f.write(mine)
+        os.rename(tmp, os.path.join(scratch, "handle_%d.bin" % rank))
+        out, t0 = [], time.time()
+        for q in range(world):
+            path = os.path.join(scratch, "handle_%d.bin" % q)
+            while not os.path.exists(path):
+                if time.time() - t0 > timeout_s:
+                    raise RuntimeError("rank %d never published its mailbox handle" % q)
+                time.sleep(0.005)
+            with open(path, "rb") as f:
+                out.append(f.read())
+        return out
+    return transport
+
+
+def pf_peer_child(argv):
+    """`bench.py --pf-peer-child rank world device scratch particles steps iters`: ONE rank of the sharded filter with the peer-store
+    exchange, in a process of its own -- a detached communicator (no RCCL, no torch.distributed), the mailbox handles through files.
+    PfDeviceEngine.peer_row starts one per rank and reads result_<rank>.json: the exchange has never met a second GPU, and whatever it
+    does there (an unmappable peer, a fault on a remote store) ends this process, not the one that owns the headline."""
+    rank, world, device, scratch, n, steps, iters = int(argv[0]), int(argv[1]), int(argv[2]), argv[3], int(argv[4]), int(argv[5]), int(argv[6])
+    import mtf_amd
+    from mtf_amd import synth
+    from mtf_amd.sm import Comm, ParticleFilter
+    ctx = mtf_amd.Context(device)
+    ctx.set_image(synth.make_frame(1024, 1024))
+    comm = Comm.detached(rank, world, device)
+    pf = ParticleFilter(ctx, mtf_amd.SSM_HOMOGRAPHY, 50, 50, n_particles=n, max_iters=iters, seed=synth.DEFAULT_SEED, comm=comm, exchange="peer",
+                        exchange_transport=pf_file_transport(scratch, rank, world), **PF_FILTER_KW)
+    pf.initialize(synth.square_corners(512, 512, 100)[None])
+    for _ in range(3):
+        pf.update()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pf.update()             # (returns with the estimate on the host: the stream has drained)
+    dt = time.perf_counter() - t0
+    ctx.timing(True); ctx.timing_reset()
+    for _ in range(3):
+        pf.update()
+    res = {"seconds": dt, "score_kernel_ms": ctx.timing_get("pf_score")[0], "scan_select_ms": ctx.timing_get("pf_resample")[0],
+           "allgather_ms": ctx.timing_get("pf_allgather")[0], "peer_exchanges_timed": ctx.timing_get("pf_peer_exchange")[1],
+           "estimate": [float(v) for v in np.asarray(pf.get_region()).ravel()]}
+    ctx.timing(False)
+    tmp = os.path.join(scratch, "result_%d.tmp" % rank)
+    with open(tmp, "w") as f:
+        json.dump(res, f)
+    os.rename(tmp, os.path.join(scratch, "result_%d.json" % rank))
+    pf.close(); ctx.close(); comm.close()
+
+
 class PfDeviceEngine:
     """the sharded particle filter on the GPUs: mtf_amd.sm.ParticleFilter over the C-ABI, RCCL communicator bootstrapped through
     torch.distributed (Comm.torch_bootstrap broadcasts the 128-byte unique id)"""
@@ -346,6 +407,8 @@ class PfDeviceEngine:
         from mtf_amd import synth
         from mtf_amd.sm import Comm
         self.torch, self.mtf, self.synth, self.ctx, self.dev, self.dist = torch, mtf_amd, synth, ctx, dev, dist
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.world, self.local_rank = world, local_rank
         self.corners = synth.square_corners(512, 512, 100)
         ctx.set_image(synth.make_frame(1024, 1024))
         self.comm = Comm.torch_bootstrap(local_rank) if world > 1 else None
@@ -353,16 +416,35 @@ class PfDeviceEngine:
     def n_ranks(self):
         return int(self.comm.world_as_seen()) if self.comm is not None else 1
 
-    exchanges = ("collective", "peer")   # of the sharded filter: RCCL all-gather | peer stores + arrival counters (mtfhip_pf_set_exchange)
+    # the forms of the sharded filter: the RCCL all-gather in this process; the peer-store exchange in a child process per rank (peer_row)
+    exchanges = ("collective", "peer")
+    peer_in_child_process = True
 
     def make_filter(self, n, sharded, iters, exchange="collective"):
         from mtf_amd.sm import ParticleFilter
-        pf = ParticleFilter(self.ctx, self.mtf.SSM_HOMOGRAPHY, 50, 50, n_particles=n, ssm_sigma=(1.0, 0.5, 1, 1, 1, 1, 1, 1), corner_based_sampling=1,
-                            dynamic_model=0, update_type=1, likelihood_func=0, resampling_type=1, mean_type=0, likelihood_alpha=1.0,
-                            max_iters=iters, epsilon=-1.0, seed=self.synth.DEFAULT_SEED, comm=self.comm if sharded else None,
-                            exchange=exchange if sharded else "collective")
+        pf = ParticleFilter(self.ctx, self.mtf.SSM_HOMOGRAPHY, 50, 50, n_particles=n, max_iters=iters, seed=self.synth.DEFAULT_SEED,
+                            comm=self.comm if sharded else None, exchange=exchange if sharded else "collective", **PF_FILTER_KW)
         pf.initialize(self.corners[None])
         return pf
+
+    def peer_row(self, n, steps, iters, scratch):
+        """this rank's share of the sharded_peer form: a child process (pf_peer_child) on this rank's GPU; -> its result dict, or
+        {"error": ...}.  The parent's own context stays idle meanwhile."""
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--pf-peer-child", str(self.rank), str(self.world), str(self.local_rank), scratch,
+               str(n), str(steps), str(iters)]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
+                                                                "LOCAL_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        try:
+            p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=PF_PEER_CHILD_TIMEOUT_S)
+        except subprocess.TimeoutExpired:
+            return {"error": "the rank's process did not finish within %d s" % PF_PEER_CHILD_TIMEOUT_S}
+        path = os.path.join(scratch, "result_%d.json" % self.rank)
+        if p.returncode != 0 or not os.path.exists(path):
+            return {"error": "exit code %d: %s" % (p.returncode, (p.stdout or "").strip()[-400:])}
+        with open(path) as f:
+            return json.load(f)
 
     def estimate(self, pf):
         return [float(v) for v in np.asarray(pf.get_region()).ravel()]
@@ -462,6 +544,34 @@ class PfStubEngine:
         pass
 
 
+def pf_strong_peer_children(eng, dist, world, C, steps, iters_per_update):
+    """the sharded_peer form on the GPUs: every rank runs its share in a child process (PfDeviceEngine.peer_row), the ranks' results are
+    gathered, the slowest rank sets the time.  The children synchronise through the exchange itself: nobody gets through an iteration
+    before everybody's weights have arrived."""
+    import tempfile
+    box = [tempfile.mkdtemp(prefix="mtfhip_pf_peer_") if eng.rank == 0 else None]
+    if dist is not None:
+        dist.broadcast_object_list(box, src=0)
+    mine = eng.peer_row(C, steps, iters_per_update, box[0])
+    if dist is not None:
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+    else:
+        allr = [mine]
+    if eng.rank == 0:
+        import shutil
+        shutil.rmtree(box[0], ignore_errors=True)
+    bad = [(r, a["error"]) for r, a in enumerate(allr) if "error" in a]
+    if bad:
+        return {"error": "; ".join("rank %d: %s" % b for b in bad)}
+    t = max(a["seconds"] for a in allr)
+    return {"value": C * iters_per_update * steps / t, "unit": "candidates/s", "us_per_iteration": t / (steps * iters_per_update) * 1e6,
+            "score_kernel_ms_per_rank": [a["score_kernel_ms"] for a in allr], "scan_select_ms_per_rank": [a["scan_select_ms"] for a in allr],
+            "allgather_ms": max(a["allgather_ms"] for a in allr), "peer_exchanges_timed_per_rank": [a["peer_exchanges_timed"] for a in allr],
+            "estimates_equal_across_ranks": all(a["estimate"] == allr[0]["estimate"] for a in allr), "estimate": allr[0]["estimate"],
+            "process": "one child process per rank (detached communicator, mailbox handles through files): isolated from the headline"}
+
+
 def pf_strong_record(eng, dist, world, sizes=((10000, 100), (100000, 30), (1000000, 8)), iters_per_update=10):
     """north_star's split (SM/src/PF.cc:195-306): the particle axis sharded over the ranks, ONE all-gather of the weights per iteration
     through the C-ABI collective (RCCL), scan + selection replicated.  For every size: the unsharded filter on one GPU (every rank runs
@@ -489,6 +599,11 @@ def pf_strong_record(eng, dist, world, sizes=((10000, 100), (100000, 30), (10000
         row = {"particles": C, "updates_timed": steps}
         estimates = {}
         for label, sharded, exchange in labels:
+            if exchange == "peer" and getattr(eng, "peer_in_child_process", False):
+                row[label] = pf_strong_peer_children(eng, dist, world, C, steps, iters_per_update)
+                if "estimate" in row[label]:
+                    estimates[label] = row[label].pop("estimate")
+                continue
             pf, err = None, None
             try:
                 pf = eng.make_filter(C, sharded, iters_per_update, exchange)
@@ -866,6 +981,8 @@ def secondary_workload(args):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--pf-peer-child":
+        return pf_peer_child(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="lk", choices=["lk", "grid", "pf", "mi", "dropin"],
                     help="lk = the headline metric (default); the others are the secondary metrics of BASELINE.md")

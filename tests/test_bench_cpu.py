@@ -60,3 +60,25 @@ def test_bench_single_rank_stub_line():
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["pf_strong"]["n_ranks"] == 1 and "sharded" not in d["pf_strong"]["sizes"][0]
+
+
+def test_pf_strong_peer_children_row_from_rank_results():
+    """the sharded_peer row is assembled from the child processes' results (PfDeviceEngine.peer_row): the slowest rank sets the time,
+    a failed rank turns the row into an error that names it"""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class Eng:
+        rank = 0
+
+        def __init__(self, res):
+            self.res = res
+
+        def peer_row(self, n, steps, iters, scratch):
+            assert os.path.isdir(scratch)
+            return self.res
+    ok = {"seconds": 0.5, "score_kernel_ms": 0.01, "scan_select_ms": 0.02, "allgather_ms": 0.0, "peer_exchanges_timed": 30, "estimate": [1.0, 2.0]}
+    row = bench.pf_strong_peer_children(Eng(ok), None, 1, 10000, 5, 10)
+    assert row["value"] == 10000 * 10 * 5 / 0.5 and row["estimate"] == [1.0, 2.0] and row["estimates_equal_across_ranks"]
+    row = bench.pf_strong_peer_children(Eng({"error": "exit code 1: boom"}), None, 1, 10000, 5, 10)
+    assert "rank 0" in row["error"] and "boom" in row["error"]

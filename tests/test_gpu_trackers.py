@@ -1100,6 +1100,34 @@ def test_pf_peer_exchange_between_processes(tmp_path, world, n):
             assert np.array_equal(got[k], ref[k]), "rank %d: %s differs from the unsharded filter" % (r, k)
 
 
+def test_bench_pf_peer_child_ranks(tmp_path, gpu_ctx):
+    """bench.py's sharded_peer form of the pf_strong record runs every rank in a child process (`bench.py --pf-peer-child ...`, so
+    that nothing the never-yet-multi-GPU exchange does can take the headline line down).  Two such children on GPU 0: both finish, time
+    the same number of exchanges, and end on the estimate of the unsharded filter after the same 9 updates x 10 iterations."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    scratch = str(tmp_path)
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--pf-peer-child", str(r), "2", "0", scratch, "10000", "3", "10"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, out[-3000:]
+    res = [json.load(open(os.path.join(scratch, "result_%d.json" % r))) for r in range(2)]
+    gpu_ctx.set_image(synth.make_frame(1024, 1024))
+    pf = ParticleFilter(gpu_ctx, L.SSM_HOMOGRAPHY, 50, 50, n_particles=10000, max_iters=10, seed=synth.DEFAULT_SEED, **bench.PF_FILTER_KW)
+    pf.initialize(synth.square_corners(512, 512, 100)[None])
+    for _ in range(9):
+        pf.update()
+    want = [float(v) for v in np.asarray(pf.get_region()).ravel()]
+    pf.close()
+    for r in range(2):
+        assert res[r]["estimate"] == want and res[r]["peer_exchanges_timed"] == 30 and res[r]["allgather_ms"] == 0 and res[r]["seconds"] > 0
+
+
 def test_pf_peer_exchange_refuses_mismatched_seeds_between_processes(tmp_path):
     """a detached communicator has no all-gather to compare the seeds with at mtfhip_pf_set_comm: they are compared through the
     mailboxes when the peers are connected, and a mismatch is refused on both ranks"""
