@@ -595,12 +595,18 @@ def pf_strong_record(eng, dist, world, sizes=((10000, 100), (100000, 30), (10000
     rec["exchanges"] = {"sharded": "one in-place RCCL all-gather per iteration (the default)",
                         "sharded_peer": "mtfhip_pf_set_exchange(PEER): the scoring kernel stores into every rank's mailbox, the scan waits "
                                         "for arrival counters; opt-in, first run between GPUs is this record's"}
+    peer_gave_up = None
     for C, steps in sizes:
         row = {"particles": C, "updates_timed": steps}
         estimates = {}
         for label, sharded, exchange in labels:
             if exchange == "peer" and getattr(eng, "peer_in_child_process", False):
+                if peer_gave_up:   # (one failure is the answer; the remaining sizes would only run into the same time-outs)
+                    row[label] = {"error": "skipped: " + peer_gave_up}
+                    continue
                 row[label] = pf_strong_peer_children(eng, dist, world, C, steps, iters_per_update)
+                if "error" in row[label]:
+                    peer_gave_up = "the form failed at %d particles" % C
                 if "estimate" in row[label]:
                     estimates[label] = row[label].pop("estimate")
                 continue
