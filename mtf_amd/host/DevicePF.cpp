@@ -80,6 +80,9 @@ void PF::jacobianSigma(bool init) {   /* NT/PF.cc:156-165, 214-227 through the a
 	HipPair::check(mtfhip_pf_set_sampler(h, sigma, mean));
 }
 void PF::setComm(mtfhip_comm *comm) { HipPair::check(mtfhip_pf_set_comm(h, comm)); }
+void PF::setPeerExchange(bool on) { HipPair::check(mtfhip_pf_set_exchange(h, on ? MTFHIP_PF_EXCHANGE_PEER : MTFHIP_PF_EXCHANGE_COLLECTIVE)); }
+void PF::exportMailbox(void *handle64) { HipPair::check(mtfhip_pf_exchange_export(h, handle64)); }
+void PF::connectMailboxes(const void *handles) { HipPair::check(mtfhip_pf_exchange_connect(h, handles)); }
 void PF::initialize(const CornersT &corners) {   /* NT/PF.cc:136-183 */
 	am->clearInitStatus(); ssm->clearInitStatus();
 	ssm->initialize(corners, am->getNChannels());

@@ -23,6 +23,11 @@ public:
 	void setRegion(const CornersT &corners) override;
 	const CornersT &getRegion() override;
 	void setComm(mtfhip_comm *comm);   /* shard the scoring over the communicator's ranks (one RCCL all-gather per iteration) */
+	/* the weights as peer stores of the scoring kernel instead of the all-gather (mtfhip.h: mtfhip_pf_set_exchange); with a detached
+	 * communicator the host program moves the 64-byte handles: exportMailbox(mine), its own transport, connectMailboxes(all) */
+	void setPeerExchange(bool on = true);
+	void exportMailbox(void *handle64);
+	void connectMailboxes(const void *handles /* world x 64 bytes */);
 	mtfhip_pf *handle() { return h; }
 private:
 	std::shared_ptr<HipAM> ham;
