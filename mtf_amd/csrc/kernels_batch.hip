@@ -44,6 +44,48 @@ __device__ __forceinline__ void block_allsum_dpp(double *v, double *lds /* [4][K
 	for (int k = 0; k < K; ++k) v[k] = (lds[k] + lds[K + k]) + (lds[2 * K + k] + lds[3 * K + k]);
 }
 
+/* Twelve sums at once, by halving: the two cross-row levels of the wave are exchanges of register halves between lanes
+ * (v_permlane32_swap / v_permlane16_swap, gfx950) -- after the first every lane carries six of the twelve, after the second three --
+ * and only those three go through the four in-row DPP steps.  63 VALU instructions per wave instead of the 12 x 18 of one wave_sum_dpp
+ * per value, on a loop whose critical path is this reduction (k_iclk_track: one wave per SIMD, an FP64 instruction every ~7 cycles).
+ * Row r of a wave ends with the wave totals of indices (r >= 2 ? 6 : 0) + (r & 1 ? 3 : 0) + {0, 1, 2} in every lane. */
+__device__ __forceinline__ double swap_add32(double a, double b) {   /* lanes 0..31: a[l] + a[l + 32]; lanes 32..63: b[l - 32] + b[l] */
+	const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+	const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+	return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double swap_add16(double a, double b) {   /* even rows: a[row] + a[row + 1]; odd rows: b[row - 1] + b[row] */
+	const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+	const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+	return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double row_sum_dpp(double x) {   /* the sum over the lane's row of 16, in every lane of the row */
+#define MTFHIP_ROW_STEP(CTRL) { \
+		const int tl = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false), th = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false); \
+		x += __hiloint2double(th, tl); }
+	MTFHIP_ROW_STEP(0xB1) MTFHIP_ROW_STEP(0x4E) MTFHIP_ROW_STEP(0x141) MTFHIP_ROW_STEP(0x140)   /* quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror */
+#undef MTFHIP_ROW_STEP
+	return x;
+}
+/* v[0..12) summed over the workgroup, every thread gets every total (lds: [4][12]) */
+__device__ __forceinline__ void block_allsum_h12(double *v, double *lds) {
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	double h6[6], h3[3];
+#pragma unroll
+	for (int j = 0; j < 6; ++j) h6[j] = swap_add32(v[j], v[j + 6]);
+#pragma unroll
+	for (int j = 0; j < 3; ++j) h3[j] = row_sum_dpp(swap_add16(h6[j], h6[j + 3]));
+	__syncthreads();   /* previous round's readers are done with lds */
+	if ((lane & 15) == 0) {
+		const int base = wave * 12 + ((lane & 32) ? 6 : 0) + ((lane & 16) ? 3 : 0);
+#pragma unroll
+		for (int j = 0; j < 3; ++j) lds[base + j] = h3[j];
+	}
+	__syncthreads();
+#pragma unroll
+	for (int k = 0; k < 12; ++k) v[k] = (lds[k] + lds[12 + k]) + (lds[24 + k] + lds[36 + k]);
+}
+
 /* NN-SM dataset generation (SM/src/NT/NN.cc:131-191): per sample state, setState -> updatePixVals ->
  * updateDistFeat into row `c` of the n_samples x N feature matrix.  SSD's feature is the patch itself
  * (AM/include/mtf/AM/SSDBase.h:116-125); NCC's is the centred patch over its norm (AM/src/NCC.cc:530-537),
@@ -307,14 +349,47 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 				block_allsum<16>(tc, redk);
 			}
 		}
+		/* The texels of the whole loop from LDS: the patch moves by a fraction of its size over the iterations, so a window of the frame
+		 * around its corners (kWinW x kWinH texels, centred on their bounding box, clamped into the image) is fetched ONCE -- one global
+		 * round trip, what the first iteration's texel fetch cost anyway -- and every later iteration reads its four texels per sample
+		 * from LDS (~100 ns) instead of L2 (~1 us of every 3.3 us iteration, section 4.4's phase trace).  A wave any of whose samples
+		 * leaves the window (or a patch larger than it, or a frame smaller) takes the global path: same texels, same arithmetic, same bits. */
+		constexpr int kWinW = 64, kWinH = 64;
+		__shared__ float win[kWinW * kWinH];
+		int wx0 = 0, wy0 = 0;
+		bool win_ok = false;
+#ifndef MTFHIP_GRID_NO_WINDOW
+		{
+			const double mnx = fmin(fmin(Cr[0], Cr[2]), fmin(Cr[4], Cr[6])), mxx = fmax(fmax(Cr[0], Cr[2]), fmax(Cr[4], Cr[6]));
+			const double mny = fmin(fmin(Cr[1], Cr[3]), fmin(Cr[5], Cr[7])), mxy = fmax(fmax(Cr[1], Cr[3]), fmax(Cr[5], Cr[7]));
+			const double cxm = 0.5 * (mnx + mxx), cym = 0.5 * (mny + mxy);
+			/* (NaN corners fail every comparison) */
+			win_ok = (mxx - mnx < kWinW - 6) & (mxy - mny < kWinH - 6) & (cxm > -1e6) & (cxm < 1e6) & (cym > -1e6) & (cym < 1e6) &
+				(im.w >= kWinW) & (im.h >= kWinH) & !region_bad;
+			if (win_ok) {
+				wx0 = min(max((int)floor(cxm) - kWinW / 2, 0), im.w - kWinW);
+				wy0 = min(max((int)floor(cym) - kWinH / 2, 0), im.h - kWinH);
+				float tv[kWinW * kWinH / kBlock];
+#pragma unroll
+				for (int j = 0; j < kWinW * kWinH / kBlock; ++j) {
+					const int idx = tid + j * kBlock;
+					tv[j] = im.data[(unsigned)((wy0 + idx / kWinW) * im.stride + wx0 + idx % kWinW)];
+				}
+#pragma unroll
+				for (int j = 0; j < kWinW * kWinH / kBlock; ++j) win[tid + j * kBlock] = tv[j];
+			}
+		}
+		__syncthreads();   /* (win_ok is uniform: every thread holds the same corners) */
+#endif
+		const double winx0 = (double)wx0, winx1 = (double)(wx0 + kWinW - 1), winy0 = (double)wy0, winy1 = (double)(wy0 + kWinH - 1);
 		const double nN = (double)N, inv_n = 1.0 / nN, inv_cn = 1.0 / cn;
 		GRID_STAMP(3);
 		const int max_it = region_bad ? 0 : sm.max_iters;   /* degenerate region corners: no iteration, n_iters = -1 tells the host */
 		for (int it = 0; it < max_it; ++it) {
 			if (it < 12) GRID_STAMP(4 + it);
-			double m[K];
+			double m[12];   /* K sums, padded to the twelve block_allsum_h12 takes */
 #pragma unroll
-			for (int q = 0; q < K; ++q) m[q] = 0.0;
+			for (int q = 0; q < 12; ++q) m[q] = 0.0;
 #pragma unroll
 			for (int k = 0; k < PPT; ++k) {
 				const int i = tid + k * kBlock;
@@ -326,7 +401,14 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 #if defined(MTFHIP_GRID_ABL) && (MTFHIP_GRID_ABL & 1)   /* ablation builds (tools/grid_ablation.sh): no texel fetch */
 				const double v = i < N ? wx + wy : 0.0;
 #else
-				const double v = i < N ? fma(norm_mult, pix_val_fast(im, wx, wy), norm_add) : 0.0;
+				double pv;
+				const bool inw = win_ok & (wx >= winx0) & (wx < winx1) & (wy >= winy0) & (wy < winy1);   /* lx + 1, ly + 1 inside as well */
+				if (__builtin_amdgcn_ballot_w64(!inw) == 0) {
+					const int lx = (int)wx, ly = (int)wy;
+					const float *wp = win + ((ly - wy0) * kWinW + (lx - wx0));
+					pv = bilin_val_fast(wp[0], wp[1], wp[kWinW], wp[kWinW + 1], wx - (double)lx, wy - (double)ly);
+				} else pv = pix_val_fast(im, wx, wy);
+				const double v = i < N ? fma(norm_mult, pv, norm_add) : 0.0;
 #endif
 				const double i0 = i0v[k];
 				if constexpr (NCC) {
@@ -341,7 +423,11 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 					if (s < S) m[K - 8 + s] = fma(wgt, HOIST_J ? j0v[HOIST_J ? k : 0][s] : J0[(size_t)s * N + ick], m[K - 8 + s]);
 			}
 #if !(defined(MTFHIP_GRID_ABL) && (MTFHIP_GRID_ABL & 2))   /* ablation: no workgroup reduction */
+#ifdef MTFHIP_GRID_DPP_REDUCE   /* (r03 / early r04: one DPP wave sum per value) */
 			block_allsum_dpp<K>(m, redk);
+#else
+			block_allsum_h12(m, redk);
+#endif
 #endif
 			double g[8];
 			if constexpr (NCC) {
@@ -370,11 +456,22 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 			 * operation): it is written for DEPTH -- pairwise sums, reciprocals instead of divisions, the affine inverse in closed
 			 * form -- not for operation count (the straightforward form was 2.2 us of a 4.8 us iteration). */
 			double dp[8];
+#ifdef MTFHIP_GRID_REDUNDANT_SOLVE   /* (every thread forms all eight rows: 64 LDS reads + 120 FP64 instructions per iteration) */
 #pragma unroll
 			for (int r = 0; r < 8; ++r) {
 				const double *h = sH8 + 8 * r;
 				dp[r] = -(((h[0] * g[0] + h[1] * g[1]) + (h[2] * g[2] + h[3] * g[3])) + ((h[4] * g[4] + h[5] * g[5]) + (h[6] * g[6] + h[7] * g[7])));
 			}
+#else
+			{
+				/* lane l forms row l & 7 of -H0^-1 g (the same expression as above, so the same bits) and the eight results come back
+				 * through the scalar unit: 8 LDS reads + 15 FP64 instructions + 16 v_readlane instead of 64 + 120 */
+				const double *h = sH8 + 8 * (tid & 7);
+				const double mine = -(((h[0] * g[0] + h[1] * g[1]) + (h[2] * g[2] + h[3] * g[3])) + ((h[4] * g[4] + h[5] * g[5]) + (h[6] * g[6] + h[7] * g[7])));
+#pragma unroll
+				for (int r = 0; r < 8; ++r) dp[r] = readlane_f64(mine, r);
+			}
+#endif
 			double Wn[9];
 			if (hom) {
 				const double U0 = 1 + dp[0], U1 = dp[1], U2 = dp[2], U3 = dp[3], U4 = 1 + dp[4], U5 = dp[5], U6 = dp[6], U7 = dp[7];
