@@ -67,7 +67,10 @@ __device__ __forceinline__ double row_sum_dpp(double x) {   /* the sum over the 
 #undef MTFHIP_ROW_STEP
 	return x;
 }
-/* v[0..12) summed over the workgroup, every thread gets every total (lds: [4][12]) */
+/* v[0..12) summed over the workgroup, every thread gets every total.  lds: [4][12], a buffer the caller ALTERNATES between
+ * consecutive calls (the readers of one round are then separated from the next writers of the same buffer by the round in between:
+ * one barrier per call).  The four waves' totals are combined by lanes 0..11 (one index each) and handed to everybody through the
+ * scalar unit: 4 LDS reads + 3 additions + 24 v_readlane instead of 48 broadcast reads + 36 additions per thread. */
 __device__ __forceinline__ void block_allsum_h12(double *v, double *lds) {
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	double h6[6], h3[3];
@@ -75,15 +78,16 @@ __device__ __forceinline__ void block_allsum_h12(double *v, double *lds) {
 	for (int j = 0; j < 6; ++j) h6[j] = swap_add32(v[j], v[j + 6]);
 #pragma unroll
 	for (int j = 0; j < 3; ++j) h3[j] = row_sum_dpp(swap_add16(h6[j], h6[j + 3]));
-	__syncthreads();   /* previous round's readers are done with lds */
 	if ((lane & 15) == 0) {
 		const int base = wave * 12 + ((lane & 32) ? 6 : 0) + ((lane & 16) ? 3 : 0);
 #pragma unroll
 		for (int j = 0; j < 3; ++j) lds[base + j] = h3[j];
 	}
 	__syncthreads();
+	const int k = lane < 12 ? lane : 0;
+	const double mine = (lds[k] + lds[12 + k]) + (lds[24 + k] + lds[36 + k]);
 #pragma unroll
-	for (int k = 0; k < 12; ++k) v[k] = (lds[k] + lds[12 + k]) + (lds[24 + k] + lds[36 + k]);
+	for (int q = 0; q < 12; ++q) v[q] = readlane_f64(mine, q);
 }
 
 /* NN-SM dataset generation (SM/src/NT/NN.cc:131-191): per sample state, setState -> updatePixVals ->
@@ -176,9 +180,21 @@ __device__ __forceinline__ void publish_target(const HostPublish &pub, int t, do
 		__hip_atomic_store(p + 17 * Bt + 8 * (size_t)t + lane, cq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 	if (lane == 0) __hip_atomic_store(reinterpret_cast<int *>(pub.host + pub.dbl_bytes) + Bt + t, n_it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef MTFHIP_GRID_PUBLISH_FENCE
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   /* (the whole wave's stores: s_waitcnt vmcnt(0) is per wave) */
+#else
+	/* The stores above are write-through (system scope): when the wave's vmcnt has drained they are performed, which is all the
+	 * counter has to order -- an agent-scope release here and an acq_rel on the counter wrote this XCD's L2 back twice and invalidated
+	 * it once per workgroup (the launch has just laid 6 MB of template grids into the L2s): ~3 of the 7 us between the last iteration
+	 * and the end of the workgroup, r04 phase trace.  The counter itself is an agent-scope atomic: performed at the memory side. */
+	wait_stores_acked();
+#endif
 	if (lane == 0) {
+#ifdef MTFHIP_GRID_PUBLISH_FENCE
 		const int done = __hip_atomic_fetch_add(pub.count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#else
+		const int done = __hip_atomic_fetch_add(pub.count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 		if (done == (int)gridDim.x - 1) {
 			__hip_atomic_store(pub.count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			/* Every workgroup's results left as system-scope (write-through) stores that were acknowledged before it counted itself in,
@@ -320,7 +336,7 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 		 * in registers.  An iteration is two barriers instead of nine. */
 		constexpr bool NCC = AM == MTFHIP_AM_NCC;
 		constexpr int K = NCC ? 11 : 9;
-		__shared__ double redk[4 * 16];
+		__shared__ double redk[2 * 4 * 16];   /* (two buffers: block_allsum_h12) */
 		double W[9], St[8], Cr[8];
 #pragma unroll
 		for (int q = 0; q < 9; ++q) W[q] = sW[q];
@@ -426,7 +442,7 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 #ifdef MTFHIP_GRID_DPP_REDUCE   /* (r03 / early r04: one DPP wave sum per value) */
 			block_allsum_dpp<K>(m, redk);
 #else
-			block_allsum_h12(m, redk);
+			block_allsum_h12(m, redk + ((it + 1) & 1) * 64);   /* (round 0 in the buffer the template sums above did not use) */
 #endif
 #endif
 			double g[8];

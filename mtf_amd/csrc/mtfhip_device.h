@@ -185,23 +185,67 @@ __device__ __forceinline__ Warp9 load_warp(const double *p) {
 
 /* halving butterfly over the 64 lanes of a wave: on entry every lane holds K partial sums in
  * v[0..K); on exit slot j of lane l holds the wave total of index final_index<K,32>(j, l). */
+/* The exchanges stay in the VALU (r04): lane l's partner is l ^ MASK as with __shfl_xor -- the same pairs, so the same bits -- but
+ * the value arrives by v_permlane32_swap / v_permlane16_swap (MASK 32 / 16: two instructions exchange a register between the halves
+ * of the wave / of every row pair, and a halving step needs no keep / send selects: swap(a, b) leaves "mine and the partner's a" in
+ * the low half and "the partner's and my b" in the high half) or by DPP moves inside the row of 16 (row_ror:8, row_shl / shr:4 by
+ * bank, the two quad permutations) instead of a ds_bpermute round trip through the LDS crossbar (~120 cycles each, 140 of them in
+ * the tail of every fused-LK workgroup). */
+template <int MASK>
+__device__ __forceinline__ double lane_xor_f64(double x) {
+	static_assert(MASK == 8 || MASK == 4 || MASK == 2 || MASK == 1, "in-row partners only");
+	int lo = __double2loint(x), hi = __double2hiint(x);
+	if constexpr (MASK == 8) {          /* row_ror:8 */
+		lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xF, 0xF, false);
+	} else if constexpr (MASK == 4) {   /* banks 0, 2 read lane + 4 (row_shl:4), banks 1, 3 lane - 4 (row_shr:4) */
+		const int l1 = __builtin_amdgcn_update_dpp(0, lo, 0x104, 0xF, 0x5, false), h1 = __builtin_amdgcn_update_dpp(0, hi, 0x104, 0xF, 0x5, false);
+		lo = __builtin_amdgcn_update_dpp(l1, lo, 0x114, 0xF, 0xA, false); hi = __builtin_amdgcn_update_dpp(h1, hi, 0x114, 0xF, 0xA, false);
+	} else if constexpr (MASK == 2) {   /* quad_perm [2, 3, 0, 1] */
+		lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, false);
+	} else {                            /* quad_perm [1, 0, 3, 2] */
+		lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
+	}
+	return __hiloint2double(hi, lo);
+}
+/* MASK 32 / 16: (a, b) -> lanes without the bit: a + partner's a; lanes with it: partner's b + b */
+template <int MASK>
+__device__ __forceinline__ double swap_pair_add(double a, double b) {
+	static_assert(MASK == 32 || MASK == 16, "cross-row partners only");
+	if constexpr (MASK == 32) {
+		const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+		const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+		return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+	} else {
+		const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+		const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+		return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+	}
+}
 template <int K, int MASK>
 __device__ __forceinline__ void wave_halve(double *v, int lane) {
 	if constexpr (MASK == 0) {
 		return;
 	} else if constexpr (K % 2 == 0) {
 		constexpr int H = K / 2;
-		const bool up = (lane & MASK) != 0;
+		if constexpr (MASK >= 16) {
 #pragma unroll
-		for (int j = 0; j < H; ++j) {
-			double keep = up ? v[j + H] : v[j];
-			double send = up ? v[j] : v[j + H];
-			v[j] = keep + __shfl_xor(send, MASK);
+			for (int j = 0; j < H; ++j) v[j] = swap_pair_add<MASK>(v[j], v[j + H]);
+		} else {
+			const bool up = (lane & MASK) != 0;
+#pragma unroll
+			for (int j = 0; j < H; ++j) {
+				double keep = up ? v[j + H] : v[j];
+				double send = up ? v[j] : v[j + H];
+				v[j] = keep + lane_xor_f64<MASK>(send);
+			}
 		}
 		wave_halve<H, (MASK >> 1)>(v, lane);
 	} else {
 #pragma unroll
-		for (int j = 0; j < K; ++j) v[j] += __shfl_xor(v[j], MASK);
+		for (int j = 0; j < K; ++j) {
+			if constexpr (MASK >= 16) v[j] = swap_pair_add<MASK>(v[j], v[j]);   /* (both halves: own + partner's) */
+			else v[j] += lane_xor_f64<MASK>(v[j]);
+		}
 		wave_halve<K, (MASK >> 1)>(v, lane);
 	}
 }
