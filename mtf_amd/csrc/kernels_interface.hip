@@ -519,15 +519,17 @@ __global__ __launch_bounds__(1024) void k_finish_host(const double *partials, in
 		__syncthreads();
 		if (j == 0) for (int g = 1; g < G; ++g) mine += part[g][k];
 	}
-	if (j == 0 && k < row_len) out_host[(size_t)t * row_len + k] = mine;
-	__threadfence_system();
+	/* write-through (system-scope) stores, acknowledged before the workgroup counts itself in; the last arriver's flag is one more
+	 * posted write of the same device behind them.  No fence: a system-scope release is a write-back of every L2 (2.5 us, measured on
+	 * the grid kernel's publish in r04) for lines the host never reads -- the protocol of publish_target, kernels_batch.hip. */
+	if (j == 0 && k < row_len) __hip_atomic_store(out_host + (size_t)t * row_len + k, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	wait_stores_acked();
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		const int done = __hip_atomic_fetch_add(count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+		const int done = __hip_atomic_fetch_add(count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (done == (int)gridDim.x - 1) {
 			__hip_atomic_store(count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			__threadfence_system();
-			__hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(flag_host, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 	}
 }
@@ -535,15 +537,15 @@ __global__ __launch_bounds__(1024) void k_finish_host(const double *partials, in
  * spinning on: replaces a device-to-host copy + stream synchronisation at the end of the device-side loop */
 __global__ __launch_bounds__(256) void k_publish_host(const unsigned *src, unsigned *dst_host, unsigned n_words, int *count,
 	unsigned long long *flag_host, unsigned long long seq) {
-	for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n_words; i += gridDim.x * 256) dst_host[i] = src[i];
-	__threadfence_system();
+	for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n_words; i += gridDim.x * 256)
+		__hip_atomic_store(dst_host + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	wait_stores_acked();   /* (as k_finish_host: acknowledged write-through stores, then the counter, then the flag) */
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		const int done = __hip_atomic_fetch_add(count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+		const int done = __hip_atomic_fetch_add(count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (done == (int)gridDim.x - 1) {
 			__hip_atomic_store(count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			__threadfence_system();
-			__hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(flag_host, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 	}
 }

@@ -911,8 +911,8 @@ __global__ __launch_bounds__(kBlock) void k_pf_select(PfArgs a, PfSelectArgs r) 
 	if (lane < 32) r.out[lane] = o;
 	if (r.pub.host) {
 		if (lane < 32) __hip_atomic_store(r.pub.host + lane, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-		__threadfence_system();
-		if (lane == 0) __hip_atomic_store(r.pub.flag, r.pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		wait_stores_acked();   /* (one wave: its write-through stores are performed, the flag is a posted write behind them -- no L2 write-back) */
+		if (lane == 0) __hip_atomic_store(r.pub.flag, r.pub.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 	};
 	if (is_last && tid < 64) estimate_tail();
