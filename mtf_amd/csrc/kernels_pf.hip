@@ -445,10 +445,12 @@ __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, P
 				 * v_fract_f64 -- exact, the same bits as x - (double)(int)x for the non-negative coordinates the fast path accepts --
 				 * instead of convert-back + subtract.  A reciprocal with one Newton step instead of two saved as much again, but its
 				 * last-bit differences flip round(w n) ties of the residual resampler against the oracle: not taken.) */
-				double wx = fma(W[k][0], q.x, fma(W[k][1], q.y, uz ? W[k][2] : W[k][2] * z));
-				double wy = fma(W[k][3], q.x, fma(W[k][4], q.y, uz ? W[k][5] : W[k][5] * z));
+				/* (z is exactly 1.0 on a unit-z grid and x * 1.0 == x: no select on the flag -- a per-lane select of a wave-uniform
+				 * condition was two moves + two v_cndmask per coordinate, 8 of the 44 VALU instructions of a candidate-sample) */
+				double wx = fma(W[k][0], q.x, fma(W[k][1], q.y, W[k][2] * z));
+				double wy = fma(W[k][3], q.x, fma(W[k][4], q.y, W[k][5] * z));
 				if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
-					const double dd = fma(W[k][6], q.x, fma(W[k][7], q.y, uz ? W[k][8] : W[k][8] * z));
+					const double dd = fma(W[k][6], q.x, fma(W[k][7], q.y, W[k][8] * z));
 					const double inv = rcp_fast(dd);
 					wx *= inv; wy *= inv;
 				}

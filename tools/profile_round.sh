@@ -14,7 +14,7 @@ i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   # device-wide counters per dispatch: the two-queue loop is serialised for these passes (same launches, one queue)
-  MTFHIP_TRACK_SERIALIZE=1 rocprofv3 --pmc $grp --output-format csv -d $out/pmc/p$i -o pmc -- python bench.py --steps 10 --warmup 2 --no-cpu --no-lean ${args##*--warmup [0-9]*} > $out/pmc_p$i.log 2>&1
+  MTFHIP_TRACK_SERIALIZE=1 timeout 400 rocprofv3 --pmc $grp --output-format csv -d $out/pmc/p$i -o pmc -- python bench.py --steps 10 --warmup 2 --no-cpu --no-lean ${args##*--warmup [0-9]*} > $out/pmc_p$i.log 2>&1
 done
 python tools/pmc_summary.py $out/pmc > $out/${tag}_pmc_summary.txt
 python - <<PY
@@ -43,10 +43,10 @@ PY
 cp $out/${tag}_pmc_traffic.json profiles/pmc_latest.json
 python bench.py $args > $out/${tag}_bench.json 2>> $out/${tag}_bench.err
 # (--no-lean: the lean and single-target sub-records launch the SAME kernels at other sizes and would be averaged into the headline's rows)
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o $tag -- python bench.py $args --no-cpu --no-lean > $out/${tag}_trace.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o $tag -- python bench.py $args --no-cpu --no-lean > $out/${tag}_trace.log 2>&1
 cp $out/trace/${tag}_kernel_stats.csv $out/${tag}_kernel_stats.csv
 # the same command with the loop on one queue: the kernel with the device to itself (r01 / r02 figures are of this form)
-MTFHIP_TRACK_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace1q -o ${tag}_1q -- python bench.py $args --no-cpu --no-lean > $out/${tag}_trace1q.log 2>&1
+MTFHIP_TRACK_STREAMS=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace1q -o ${tag}_1q -- python bench.py $args --no-cpu --no-lean > $out/${tag}_trace1q.log 2>&1
 cp $out/trace1q/${tag}_1q_kernel_stats.csv $out/${tag}_kernel_stats_one_queue.csv
 MTFHIP_TRACK_STREAMS=1 python bench.py $args --no-cpu --no-lean > $out/${tag}_bench_one_queue.json 2>> $out/${tag}_bench.err
 cat $out/${tag}_bench.json | cut -c1-400; head -5 $out/${tag}_kernel_stats.csv | cut -c1-200; cat $out/${tag}_pmc_traffic.json

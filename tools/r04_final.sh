@@ -19,12 +19,12 @@ for i in 1 2; do timeout 300 python bench.py --steps 20 --warmup 5 2>/dev/null |
 for wl in grid pf mi; do
   steps=200; [ $wl = mi ] && steps=5
   timeout 600 python bench.py --workload $wl --steps $steps --warmup 5 --cpu-seconds 4 2>/dev/null | tail -1 | tee $out/${wl}_bench.json >> $out/secondary_bench_lines.jsonl
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$wl -o $wl -- python bench.py --workload $wl --steps $steps --warmup 5 --no-cpu > $out/${wl}_trace.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$wl -o $wl -- python bench.py --workload $wl --steps $steps --warmup 5 --no-cpu > $out/${wl}_trace.log 2>&1
   find $out/trace_$wl -name '*kernel_stats.csv' -exec cp {} $out/${wl}_kernel_stats.csv \;
 done
 for n in 100000 1000000; do timeout 600 python bench.py --workload pf --particles $n --steps 50 --warmup 5 --no-cpu 2>/dev/null | tail -1 >> $out/secondary_bench_lines.jsonl; done
 timeout 600 python bench.py --workload pf --particles 10000 --pf-iters 10 --steps 50 --warmup 5 --no-cpu 2>/dev/null | tail -1 >> $out/secondary_bench_lines.jsonl
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_pf1m -o pf1m -- python bench.py --workload pf --particles 1000000 --steps 20 --warmup 3 --no-cpu > $out/pf1m_trace.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_pf1m -o pf1m -- python bench.py --workload pf --particles 1000000 --steps 20 --warmup 3 --no-cpu > $out/pf1m_trace.log 2>&1
 find $out/trace_pf1m -name '*kernel_stats.csv' -exec cp {} $out/pf1m_kernel_stats.csv \;
 timeout 300 python bench.py --workload dropin --sm esm --steps 200 --warmup 20 --cpu-seconds 3 2>/dev/null | tail -1 >> $out/secondary_bench_lines.jsonl
 timeout 300 python bench.py --workload dropin --sm esm --device-loop --steps 200 --warmup 20 --no-cpu 2>/dev/null | tail -1 >> $out/secondary_bench_lines.jsonl
@@ -32,8 +32,8 @@ timeout 300 python bench.py --workload dropin --sm esm --device-loop --steps 200
 i=0
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $out/pmc_mi/p$i -o pmc -- python bench.py --workload mi --steps 3 --warmup 1 --no-cpu > $out/pmc_mi_p$i.log 2>&1
-  rocprofv3 --pmc $grp --output-format csv -d $out/pmc_pf/p$i -o pmc -- python bench.py --workload pf --steps 10 --warmup 2 --no-cpu > $out/pmc_pf_p$i.log 2>&1
+  timeout 400 rocprofv3 --pmc $grp --output-format csv -d $out/pmc_mi/p$i -o pmc -- python bench.py --workload mi --steps 3 --warmup 1 --no-cpu > $out/pmc_mi_p$i.log 2>&1
+  timeout 400 rocprofv3 --pmc $grp --output-format csv -d $out/pmc_pf/p$i -o pmc -- python bench.py --workload pf --steps 10 --warmup 2 --no-cpu > $out/pmc_pf_p$i.log 2>&1
 done
 python tools/pmc_summary.py $out/pmc_mi > $out/mi_pmc_summary.txt
 python tools/pmc_summary.py $out/pmc_pf > $out/pf_pmc_summary.txt
@@ -43,6 +43,9 @@ timeout 600 python bench.py --pf-strong 1 --steps 50 --warmup 10 --no-cpu --no-l
 [ -x scratch/fp64_rate_test ] && ./scratch/fp64_rate_test | grep "cycles/instr" > $out/fp64_rates.txt
 : > $out/grid_fused_ab.jsonl
 for gf in 0 1; do MTFHIP_GRID_FUSED=$gf timeout 300 python bench.py --workload grid --steps 300 --warmup 20 --no-cpu 2>/dev/null | tail -1 >> $out/grid_fused_ab.jsonl; done
+# 2c. the peer-store exchange's cost inside the kernels it lives in (eight loopback ranks, both exchanges), the grid kernel's phases
+timeout 300 python tools/pf_peer_probe.py 2>/dev/null > $out/pf_peer_probe.json
+[ -f scratch/libmtfhip_gtrace.so ] && MTFHIP_LIB=scratch/libmtfhip_gtrace.so timeout 120 python tools/grid_trace.py 2>/dev/null > $out/grid_phase_trace.txt
 # 3. configuration table
 ct=$out/config_table.jsonl; : > $ct
 run() { timeout 300 python bench.py "$@" --no-cpu 2>/dev/null | tail -1 >> $ct; }
