@@ -1286,9 +1286,19 @@ int score_block_dev(mtfhip_batch *b, const double *dev_states, int lo, int cnt, 
 		TRY(push_ncc(b));
 		ncc_sc = b->d_ncc;
 	}
+	/* the template grid's own corners (set_corners lays a unit-z grid out INSIDE them: the lattice's end points are the corners):
+	 * what lets the scorer skip the border test of a candidate whose warped corners are inside the frame */
+	double hull_buf[8];
+	const double *hull = nullptr;
+	if (b->unit_z && b->B >= 1) {
+		const double *ic = b->th[0].init_corners_hm;
+		bool unit = true;
+		for (int q = 0; q < 4; ++q) { hull_buf[2 * q] = ic[3 * q]; hull_buf[2 * q + 1] = ic[3 * q + 1]; unit = unit && ic[3 * q + 2] == 1.0; }
+		if (unit) hull = hull_buf;
+	}
 	/* (view_raw: the candidates bring their own warps; a stale device copy of the batch's warp is not uploaded for them) */
 	launch_score_block(b->view_raw(), b->ctx->img, dev_states, lo, cnt, b->desc.likelihood_alpha, b->norm_mult, b->norm_add, ncc_sc, wts, sim,
-		likelihood_func, measurement_sigma, max_similarity, b->math_mode == MTFHIP_MATH_FAST, peer, st);
+		likelihood_func, measurement_sigma, max_similarity, b->math_mode == MTFHIP_MATH_FAST, peer, hull, st);
 	return MTFHIP_OK;
 }
 int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int C, double *dev_lik, double *dev_sim) {

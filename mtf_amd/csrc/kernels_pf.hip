@@ -366,6 +366,11 @@ struct PfScoreArgs {
 	double *wts;                   /* [>= n] particle_wts, written at the particles' global indices */
 	double *sim;                   /* [n] similarities or NULL */
 	PfPeerPush peer;               /* world > 0: the weights also go to every other rank's mailbox (mtfhip_internal.h) */
+	/* hull_ok: the template grid is a unit-z grid laid out inside the quadrilateral hull[] = x0 y0 ... x3 y3 (its own corners, in the
+	 * grid's coordinates).  A candidate whose warped hull lies inside the image, denominators positive, has EVERY sample inside (the
+	 * map is projective: a point of the hull goes to a convex combination of the warped corners): its samples skip the border test. */
+	int hull_ok;
+	double hull[8];
 };
 /* A weight for the peers: a relaxed system-scope store -- it goes through to the peer's memory, and the wave's vmcnt tells when it
  * has (what every release fence relies on), so no fence and no L2 write-back per workgroup.  (First version: a system-scope release
@@ -431,6 +436,29 @@ __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, P
 	double acc[K * M];
 #pragma unroll
 	for (int k = 0; k < K * M; ++k) acc[k] = 0.0;
+	/* the workgroup's four candidates x the hull's four corners, one per lane (lanes 16.. repeat them): all sixteen inside? */
+	bool all_inside = false;
+	if constexpr (FAST) {
+		if (s.hull_ok) {
+			const int kk = (tid >> 2) & 3, cc = tid & 3;
+			double Wl[9];
+			warp_from_state_dev<SSM>(s.prop + (size_t)min(c0 + kk, cend - 1) * S, Wl);
+			const double X = cc == 0 ? s.hull[0] : cc == 1 ? s.hull[2] : cc == 2 ? s.hull[4] : s.hull[6];
+			const double Y = cc == 0 ? s.hull[1] : cc == 1 ? s.hull[3] : cc == 2 ? s.hull[5] : s.hull[7];
+			double hx = fma(Wl[0], X, fma(Wl[1], Y, Wl[2])), hy = fma(Wl[3], X, fma(Wl[4], Y, Wl[5]));
+			bool in = true;
+			if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+				const double dd = fma(Wl[6], X, fma(Wl[7], Y, Wl[8]));
+				in = dd > 1e-9;
+				hx /= dd; hy /= dd;
+			}
+			/* (a margin of a thousandth of a pixel: the samples' own rounding is ~1e-13) */
+			in = in & (hx > 1e-3) & (hy > 1e-3) & (hx < (double)iw1 - 1e-3) & (hy < (double)ih1 - 1e-3);
+			all_inside = __builtin_amdgcn_ballot_w64(!in) == 0;
+		}
+	}
+	auto pixel_loop = [&](auto inside_tag) {
+	constexpr bool INSIDE = decltype(inside_tag)::value;
 	for (unsigned i = tid; i < N; i += kBlock) {
 		const unsigned pi = MC ? i / Cc : i;          /* the row's pixel */
 		const int ch = MC ? (int)(i - pi * Cc) : 0;   /* ... and channel */
@@ -455,9 +483,9 @@ __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, P
 					wx *= inv; wy *= inv;
 				}
 				const int lx = (int)wx, ly = (int)wy;
-				const bool ok = (wx >= 0) & (wy >= 0) & (lx < iw1) & (ly < ih1);
+				const bool ok = INSIDE | ((wx >= 0) & (wy >= 0) & (lx < iw1) & (ly < ih1));
 				double v;
-				if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
+				if (INSIDE || __builtin_amdgcn_ballot_w64(!ok) == 0) {
 					const double fx = __builtin_amdgcn_fract(wx), fy = __builtin_amdgcn_fract(wy);
 					if constexpr (MC) {
 						const unsigned off = (unsigned)(ly * stride + lx * (int)Cc + ch) * 4u;
@@ -489,6 +517,8 @@ __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, P
 			}
 		}
 	}
+	};
+	if (all_inside) pixel_loop(std::true_type{}); else pixel_loop(std::false_type{});
 	block_reduce_store<K * M>(acc, tot, red);
 	__syncthreads();
 	const int k = tid, cand = c0 + k;
@@ -1010,12 +1040,14 @@ static void launch_pf_score_args(const BatchView &bv, const ImgView &im, const P
  * mtfhip_score_candidates: PF.cc:247-262, 341-365 per candidate) */
 void launch_score_block(const BatchView &bv, const ImgView &im, const double *states, int lo, int cnt, double alpha, double norm_mult,
 	double norm_add, const double *ncc_sc, double *wts, double *sim, int likelihood_func, double measurement_sigma, double max_similarity,
-	int fast_math, const PfPeerPush *peer, hipStream_t st) {
+	int fast_math, const PfPeerPush *peer, const double *hull, hipStream_t st) {
 	PfScoreArgs s;
 	s.prop = states; s.lo = lo; s.cnt = cnt; s.alpha = alpha; s.norm_mult = norm_mult; s.norm_add = norm_add; s.ncc_sc = ncc_sc;
 	s.likelihood_func = likelihood_func; s.measurement_sigma = measurement_sigma; s.max_similarity = max_similarity;
 	s.wts = wts; s.sim = sim;
 	if (peer) s.peer = *peer; else s.peer = PfPeerPush{};
+	s.hull_ok = hull ? 1 : 0;
+	for (int q = 0; q < 8; ++q) s.hull[q] = hull ? hull[q] : 0.0;
 	launch_pf_score_args(bv, im, s, fast_math, st);
 }
 void launch_pf_peer_push(const PfPeerPush &peer, const double *wts, int lo, int cnt, hipStream_t st) {

@@ -343,7 +343,7 @@ struct PfPeerWait {
 void launch_pf_propose(int ssm, const PfLaunch &p, const PfBuffers &bf, const double *st_in, const double *ar_in, double *st_out, double *ar_out, hipStream_t st);
 void launch_score_block(const BatchView &bv, const ImgView &im, const double *states, int lo, int cnt, double alpha, double norm_mult,
 	double norm_add, const double *ncc_sc, double *wts, double *sim, int likelihood_func, double measurement_sigma, double max_similarity,
-	int fast_math, const PfPeerPush *peer /* or NULL */, hipStream_t st);
+	int fast_math, const PfPeerPush *peer /* or NULL */, const double *hull /* [8] host, or NULL: PfScoreArgs::hull */, hipStream_t st);
 /* weights [lo, lo + cnt) of `wts` -> every other rank's mailbox + the arrival: for scorers that do not store to the peers themselves */
 void launch_pf_peer_push(const PfPeerPush &peer, const double *wts, int lo, int cnt, hipStream_t st);
 void launch_pf_peer_wait(const PfPeerWait &w, hipStream_t st);   /* the wait in a launch of its own (no scan in this iteration) */

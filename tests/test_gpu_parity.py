@@ -571,6 +571,43 @@ def test_pf_candidate_scores(oracle, gpu_ctx, frame, am):
     np.testing.assert_allclose(lik, lik_o, rtol=1e-9 if am != L.AM_MI else 1e-7)   # (MI: exp(-alpha (1 / f - 1)^2) amplifies f's 1e-12)
 
 
+@pytest.mark.parametrize("am,ssm", [(L.AM_SSD, L.SSM_HOMOGRAPHY), (L.AM_NCC, L.SSM_HOMOGRAPHY), (L.AM_SSD, L.SSM_AFFINE)])
+def test_pf_candidate_scores_at_the_frame_border(oracle, gpu_ctx, frame, am, ssm):
+    """The scorer skips the per-sample border test for a workgroup whose four candidates have their warped template corners inside
+    the frame (PfScoreArgs::hull): candidates that sit well inside, that touch the border, that straddle it and that lie mostly
+    outside, mixed so that workgroups of every kind occur -- all against the oracle (constant border 128, imgUtils.h:91-113), in both
+    arithmetic modes; and a projective candidate whose denominator changes sign over the template (no fast path for it)."""
+    h, w = frame.shape
+    corners = synth.square_corners(60.0, 58.0, 100)                      # 10 .. 110: ten pixels from the left / top border
+    o_am, o_ssm, b = make_pair(oracle, gpu_ctx, frame, am, ssm, 50, corners)
+    pts0 = o_ssm.get("curr_pts")
+    o_am.initialize_pix_vals(pts0); o_am.initialize_similarity()
+    b.initialize_pix_vals(); b.initialize_similarity()
+    rng = np.random.default_rng(5)
+    S = 8 if ssm == L.SSM_HOMOGRAPHY else 6
+    n = 240
+    states = np.zeros((n, S))
+    tx, ty = (2, 5) if ssm == L.SSM_HOMOGRAPHY else (0, 1)
+    shift = np.concatenate([rng.uniform(-9.9, 5.0, n // 4), rng.uniform(-10.5, -9.5, n // 4), rng.uniform(-60.0, -10.0, n // 4), rng.uniform(-140.0, 20.0, n // 4)])
+    states[:, tx] = rng.permutation(shift)
+    states[:, ty] = rng.permutation(shift) * 0.7
+    if ssm == L.SSM_HOMOGRAPHY:
+        states[:, [0, 1, 3, 4]] = rng.normal(0, 0.01, (n, 4))
+        states[:, 6:8] = rng.normal(0, 1e-5, (n, 2))
+        states[7, 6] = -1.0 / 60.0                                          # the denominator 1 + p6 x crosses zero inside the template
+    else:
+        states[:, 2:6] = rng.normal(0, 0.01, (n, 4))
+    lik_o, sim_o = oracle.pf_score(o_am, o_ssm, states)
+    for mode in (L.MATH_FAST, L.MATH_REPLAY):
+        b.set_math_mode(mode)
+        lik, sim = b.score_candidates(states, want_similarity=True)
+        keep = np.isfinite(sim_o)
+        if ssm == L.SSM_HOMOGRAPHY:
+            keep[7] = False      # (samples next to the pole are ill-conditioned in any arithmetic: scored, not compared)
+        np.testing.assert_allclose(sim[keep], sim_o[keep], rtol=1e-9, err_msg="mode %d" % mode)
+        np.testing.assert_allclose(lik[keep], lik_o[keep], rtol=1e-9, atol=1e-300)
+
+
 def test_border_and_integer_coordinate_cases(oracle, gpu_ctx, frame):
     """Constant border (128) outside the image and at the last row/column, and the dx == 0 branch at
     exact integer coordinates (imgUtils.h:96-108) -- samples and both gradient flavours."""
