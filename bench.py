@@ -329,10 +329,11 @@ def stub_mode():
 
 
 # the expected 1 -> 8 curve of the sharded filter, from single-GPU terms (us per iteration)
-PF_STRONG_MODEL = {
-    10000: {"T1_us": 85, "T8_terms_us": {"score": 8, "allgather": 25, "scan_select": 24, "host": 9}, "T8_us": 66, "speedup": 1.3},
-    100000: {"T1_us": 474, "T8_terms_us": {"score": 47, "allgather": 35, "scan_select": 36, "host": 12}, "T8_us": 130, "speedup": 3.6},
-    1000000: {"T1_us": 3846, "T8_terms_us": {"score": 451, "allgather": 75, "scan_select": 155, "host": 20}, "T8_us": 701, "speedup": 5.5},
+PF_STRONG_MODEL = {   # (chained update() form; one-GPU terms of profiles/r04_pf_strong_one_rank.json, the all-gather estimated)
+    10000: {"T1_us": 59, "T8_terms_us": {"score": 7, "allgather": 25, "scan_select": 23}, "T8_us": 55, "speedup": 1.1,
+            "T8_us_peer_stores": 34, "speedup_peer_stores": 1.7},
+    100000: {"T1_us": 352, "T8_terms_us": {"score": 41, "allgather": 35, "scan_select": 37}, "T8_us": 113, "speedup": 3.1},
+    1000000: {"T1_us": 3322, "T8_terms_us": {"score": 392, "allgather": 75, "scan_select": 194}, "T8_us": 661, "speedup": 5.0},
 }
 
 
