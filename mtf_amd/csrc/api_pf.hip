@@ -386,6 +386,8 @@ void mtfhip_pf_destroy(mtfhip_pf *pf) {
  * distributes the weights; proposals and resampling are replicated (identical draws and identical weights on every rank) */
 int mtfhip_pf_set_comm(mtfhip_pf *pf, mtfhip_comm *c) {
 	if (!pf) return fail(MTFHIP_ERR_INVALID_ARG, "pf_set_comm: NULL filter");
+	if (pf->peer.mailbox && c != pf->comm)
+		return fail(MTFHIP_ERR_LOGIC, "pf_set_comm: this filter's peer exchange was set up over another communicator (its mailbox is sized and mapped for that one)");
 	pf->comm = c;
 	if (c && c->world > 1) {
 		int lo, cnt, m;

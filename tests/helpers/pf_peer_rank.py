@@ -43,6 +43,21 @@ def main():
                         comm=comm, exchange="peer" if comm is not None else "collective", exchange_transport=transport if comm is not None else None)
     pf.initialize(corners[None])
     ctx.set_image(frame_b)
+    idle = os.environ.get("PF_PEER_TEST_IDLE_RANK", "")
+    if idle != "":
+        # one rank connects and then never iterates: the others' scans must give up (bounded spin) and say so, not hang
+        if int(idle) == rank:
+            time.sleep(float(os.environ.get("PF_PEER_TEST_IDLE_SECONDS", "12")))
+            pf.close(); ctx.close(); comm.close()
+            return
+        t0 = time.time()
+        try:
+            pf.iteration()
+        except mtf_amd.MtfHipError as e:
+            print("GAVE_UP after %.1f s: %s" % (time.time() - t0, e))
+            pf.close(); ctx.close(); comm.close()
+            return
+        raise SystemExit("the iteration came back although rank %s never stored its weights" % idle)
     rec = {}
     for it in range(3):              # the host in between ...
         pf.iteration()

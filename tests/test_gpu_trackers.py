@@ -1128,6 +1128,26 @@ def test_bench_pf_peer_child_ranks(tmp_path, gpu_ctx):
         assert res[r]["estimate"] == want and res[r]["peer_exchanges_timed"] == 30 and res[r]["allgather_ms"] == 0 and res[r]["seconds"] > 0
 
 
+def test_pf_peer_exchange_gives_up_on_a_rank_that_never_arrives(tmp_path):
+    """The device-side wait of the peer exchange is bounded: with one rank connected but never iterating, the other rank's scan spins
+    for a couple of seconds, raises the filter's error word, and the iteration comes back as MTFHIP_ERR_HIP -- a failed rank costs
+    seconds and an error, never a hung queue (what lets bench.py run the exchange's first multi-GPU measurement unattended)."""
+    import subprocess
+    import sys
+    helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "pf_peer_rank.py")
+    scratch = str(tmp_path / "s")
+    os.makedirs(scratch)
+    env = dict(os.environ, PF_PEER_TEST_IDLE_RANK="1")
+    procs = [subprocess.Popen([sys.executable, helper, str(r), "2", scratch, "2000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+             for r in range(2)]
+    outs = []
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        outs.append(out)
+        assert p.returncode == 0, out[-2000:]
+    assert "GAVE_UP" in outs[0] and "waiting for another rank" in outs[0], outs[0][-2000:]
+
+
 def test_pf_peer_exchange_refuses_mismatched_seeds_between_processes(tmp_path):
     """a detached communicator has no all-gather to compare the seeds with at mtfhip_pf_set_comm: they are compared through the
     mailboxes when the peers are connected, and a mismatch is refused on both ranks"""
