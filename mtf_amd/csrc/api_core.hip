@@ -483,6 +483,36 @@ int mtfhip_ssm_set_corners(mtfhip_batch *b, const double *corners) { return set_
 /* defer_grid (mtfhip_batch_track_region in front of the one-launch ICLK kernel): the host half only -- mirrors, the staged corners and NCC
  * scalars -- the kernel that follows ingests them and lays out the grid itself (RegionIngest); an affine SSM then needs no map on the
  * host at all (5.9 us of closed-form homographies per 256-patch frame), a homography one still has to know whether the grids are affine */
+/* the host half of a deferred affine reset (set_corners_core): mirrors and the staged slab entries the launch did not need.  Called once
+ * the loop kernel is enqueued; a no-op when nothing is pending. */
+void set_corners_finish_deferred(mtfhip_batch *b) {
+	const double *corners = b->deferred_corners;
+	if (!corners) return;
+	b->deferred_corners = nullptr;
+	const size_t Bt = (size_t)b->B;
+	double *sp = reinterpret_cast<double *>(b->h_stage_a);
+	double *s_w = sp, *s_s = sp + 9 * Bt, *s_ic = sp + 25 * Bt, *s_w0 = sp + 45 * Bt;
+	int *s_act = reinterpret_cast<int *>(b->h_stage_a + b->slab_dbl_bytes), *s_it = s_act + Bt;
+	static const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+	for (int t = 0; t < b->B; ++t) {
+		TargetHost &h = b->th[t];
+		std::memcpy(h.corners, corners + 8 * t, sizeof(double) * 8);
+		std::memcpy(h.init_corners, corners + 8 * t, sizeof(double) * 8);
+		for (int q = 0; q < 4; ++q) {
+			h.init_corners_hm[3 * q] = corners[8 * t + 2 * q];
+			h.init_corners_hm[3 * q + 1] = corners[8 * t + 2 * q + 1];
+			h.init_corners_hm[3 * q + 2] = 1;
+		}
+		h.warp = m3_identity();
+		std::memset(h.state, 0, sizeof(h.state));
+		std::memcpy(s_w + 9 * t, ident, sizeof(ident));
+		std::memset(s_s + 8 * t, 0, sizeof(double) * 8);
+		std::memcpy(s_ic + 12 * t, h.init_corners_hm, sizeof(double) * 12);
+		std::memcpy(s_w0 + 9 * t, ident, sizeof(ident));   /* (affine + deferred: the map is the kernel's business; the slab keeps the identity as before) */
+		s_act[t] = b->deferred_for_track ? 1 : 0;
+		if (b->deferred_for_track) s_it[t] = 0;
+	}
+}
 int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track, bool defer_grid) {
 	FLUSH_AM(b);   /* pending calls are replayed (with the points they need); the points themselves are about to change */
 	if (b) ++b->lz.epoch;
@@ -501,6 +531,25 @@ int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track, boo
 	int *s_act = reinterpret_cast<int *>(b->h_stage_a + b->slab_dbl_bytes), *s_it = s_act + Bt;
 	static const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 	int unit_z = 1;
+	/* Deferred + affine (the grid tracker's frame, one launch): the kernel that follows reads only the corners and the template's
+	 * NCC scalars from the staging buffer and starts every patch from the identity -- those two go in now, the host mirrors and
+	 * the rest of the staged slab are written by set_corners_finish_deferred() AFTER the launch, while the device works
+	 * (2-2.5 us of a 45 us frame at 256 patches). */
+	if (defer_grid && !hom) {
+		std::memcpy(s_cr, corners, sizeof(double) * 8 * Bt);
+		for (int t = 0; t < b->B; ++t) {
+			const TargetHost &h = b->th[t];
+			double *q8 = s_nc + 8 * t;
+			q8[0] = h.I0_mean; q8[1] = h.c; q8[2] = h.It_mean; q8[3] = h.b; q8[4] = h.f; q8[5] = h.gmean; q8[6] = q8[7] = 0;
+		}
+		b->deferred_corners = corners; b->deferred_for_track = for_track;
+		b->unit_z = 1;
+		b->warps_dirty = false;
+		b->have_corners = true;
+		b->pts_stale = true;
+		++b->corners_epoch;
+		return MTFHIP_OK;
+	}
 	for (int t = 0; t < b->B; ++t) {
 		M3 W0 = m3_identity();
 		if (!(defer_grid && !hom)) {   /* (deferred + affine: the kernel reports degenerate corners through n_iters = -1) */

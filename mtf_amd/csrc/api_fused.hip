@@ -882,9 +882,13 @@ int mtfhip_batch_track_region(mtfhip_batch *b, const mtfhip_sm_desc *sm, const d
 	const bool region_mode = fused_ok && folded && b->desc.am != MTFHIP_AM_MI && !sm->leven_marq && iclk_one_launch(b, sm) && second_order_term(sm, b->desc.am) < 0 &&
 		b->h_stage_a_dev && b->h_pub_dev;
 	const auto t0 = std::chrono::steady_clock::now();
-	TRY(set_region_core(b, region_corners, sm, folded, region_mode));
+	{
+		const int rs = set_region_core(b, region_corners, sm, folded, region_mode);
+		if (rs != MTFHIP_OK) { set_corners_finish_deferred(b); return rs; }
+	}
 	const auto t1 = std::chrono::steady_clock::now();
 	const int r = track_core(b, sm, n_iters, corners, folded, false, region_mode);
+	set_corners_finish_deferred(b);   /* (a call that failed before its launch: nothing stays pending on the caller's buffer) */
 	if (dbg) {
 		const auto t2 = std::chrono::steady_clock::now();
 		static double acc1 = 0, acc2 = 0; static int n = 0;
@@ -1044,6 +1048,7 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 			rg.resx = b->desc.resx; rg.resy = b->desc.resy; rg.force_unit_z = homg ? 0 : 1;
 		}
 		launch_iclk_track(bv, b->ctx->img, *sm, ts, b->d_h0inv, b->d_ncc, b->norm_mult, b->norm_add, b->math_mode == MTFHIP_MATH_FAST, pub, rg, st);
+		set_corners_finish_deferred(b);   /* the host half of a deferred reset, under the kernel */
 	} else if (so_term < 0 && persist_fits(b, sm, fa)) {
 		/* a grid that fits the device at one workgroup per CU (a single large target, a few small ones): every pass of the loop in
 		 * ONE launch, the workgroups meeting at an in-kernel barrier between the pixel pass and the solve (kernels_persist.hip) */

@@ -256,6 +256,10 @@ struct mtfhip_batch {
 	int *d_fin_count = nullptr;
 	int nblk_max;
 	int unit_z = 1;
+	/* a deferred affine reset whose host half is still to be written (set_corners_core / set_corners_finish_deferred): the caller's
+	 * corners, valid for the duration of the C-ABI call that deferred them */
+	const double *deferred_corners = nullptr;
+	bool deferred_for_track = false;
 	bool have_corners = false, init_pix_vals = false, init_pix_grad = false, init_sim = false, init_grad = false;
 	bool it_valid = false, dit_valid = false, jt_valid = false;
 	std::vector<TargetHost> th;
@@ -498,6 +502,7 @@ static inline mtfhip::MiJ0Rebuild mi_j0_rebuild(const mtfhip_batch *b) {
 enum { LAZY_CURR_JAC = 0, LAZY_DIFF_JAC = 1, LAZY_INIT_JAC = 2 };
 int ensure_pts(mtfhip_batch *b);
 int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track, bool defer_grid = false);   /* api_core.hip */
+void set_corners_finish_deferred(mtfhip_batch *b);
 int do_update_grad_pts(mtfhip_batch *b, double grad_eps);
 int gemv_to_host(mtfhip_batch *b, const double *v1, int j1, const double *v2, int j2, int sum_mode, double *g, int diff);
 int ncc_template_moments(mtfhip_batch *b);
