@@ -329,11 +329,11 @@ def stub_mode():
 
 
 # the expected 1 -> 8 curve of the sharded filter, from single-GPU terms (us per iteration)
-PF_STRONG_MODEL = {   # (chained update() form; one-GPU terms of profiles/r04_pf_strong_one_rank.json, the all-gather estimated)
-    10000: {"T1_us": 59, "T8_terms_us": {"score": 7, "allgather": 25, "scan_select": 23}, "T8_us": 55, "speedup": 1.1,
-            "T8_us_peer_stores": 34, "speedup_peer_stores": 1.7},
-    100000: {"T1_us": 352, "T8_terms_us": {"score": 41, "allgather": 35, "scan_select": 37}, "T8_us": 113, "speedup": 3.1},
-    1000000: {"T1_us": 3322, "T8_terms_us": {"score": 392, "allgather": 75, "scan_select": 194}, "T8_us": 661, "speedup": 5.0},
+PF_STRONG_MODEL = {   # (chained update() form; one-GPU terms of profiles/r04_pf_strong_one_rank.json, `score` = one rank's block launched alone, the all-gather estimated)
+    10000: {"T1_us": 59, "T8_terms_us": {"score": 12.5, "allgather": 25, "scan_select": 23}, "T8_us": 60, "speedup": 1.0,
+            "T8_us_peer_stores": 40, "speedup_peer_stores": 1.5},
+    100000: {"T1_us": 352, "T8_terms_us": {"score": 48, "allgather": 35, "scan_select": 37}, "T8_us": 120, "speedup": 2.9},
+    1000000: {"T1_us": 3322, "T8_terms_us": {"score": 412, "allgather": 75, "scan_select": 194}, "T8_us": 681, "speedup": 4.9},
 }
 
 

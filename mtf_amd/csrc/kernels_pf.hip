@@ -416,9 +416,13 @@ struct __attribute__((packed, aligned(4))) PfTexPair { float a, b; };
 /* MC: the multi-channel models (MCSSD / MCNCC = SSD / NCC built with n_channels = 3, AM/src/MCSSD.cc): a row of the per-pixel
  * arrays is a (pixel, channel) pair, row = pixel * C + channel (mc::getPixVals imgUtils.cc:867-882); the grid point is the
  * pixel's, the texels the channel's (interleaved image); replay arithmetic uses mc::PixVal's weights-first order (pix_val_mc). */
-template <int SSM, bool NCC, bool FAST, bool MC>
+/* K candidates per workgroup: 4 amortises the per-pixel operands (grid point, template value) over four warps; small blocks -- a
+ * rank's share of a sharded filter, the reference's shipped 500 particles -- take 2 or 1, so that the launch still covers the device
+ * (1 250 candidates are 313 workgroups at K = 4: one per CU and a 14 us launch).  A candidate's sums do not depend on K: the same
+ * pixels per thread, the same xor butterfly, the same order over the waves. */
+template <int SSM, bool NCC, bool FAST, bool MC, int K>
 __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, PfScoreArgs s) {
-	constexpr int K = 4, M = NCC ? 3 : 1, S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
+	constexpr int M = NCC ? 3 : 1, S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
 	__shared__ double red[4 * K * M], tot[K * M];
 	const int c0 = s.lo + blockIdx.x * K, cend = s.lo + s.cnt;
 	const int tid = threadIdx.x;
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, P
 	bool all_inside = false;
 	if constexpr (FAST) {
 		if (s.hull_ok) {
-			const int kk = (tid >> 2) & 3, cc = tid & 3;
+			const int kk = (tid >> 2) & (K - 1), cc = tid & 3;
 			double Wl[9];
 			warp_from_state_dev<SSM>(s.prop + (size_t)min(c0 + kk, cend - 1) * S, Wl);
 			const double X = cc == 0 ? s.hull[0] : cc == 1 ? s.hull[2] : cc == 2 ? s.hull[4] : s.hull[6];
@@ -1022,9 +1026,15 @@ void launch_pf_propose(int ssm, const PfLaunch &p, const PfBuffers &bf, const do
 }
 static void launch_pf_score_args(const BatchView &bv, const ImgView &im, const PfScoreArgs &s, int fast_math, hipStream_t st) {
 	if (s.cnt <= 0) return;
-	const dim3 g((s.cnt + 3) / 4);
+	/* candidates per workgroup (see k_pf_score); MTFHIP_PF_K pins it (experiments) */
+	static const int k_env = std::getenv("MTFHIP_PF_K") ? std::atoi(std::getenv("MTFHIP_PF_K")) : 0;
+	const int kc = (k_env == 1 || k_env == 2 || k_env == 4) ? k_env : (s.cnt <= 1536 ? 1 : (s.cnt <= 4096 ? 2 : 4));
+	const dim3 g((s.cnt + kc - 1) / kc);
 	const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY, ncc = s.ncc_sc != nullptr, mc = bv.C > 1;
-#define MTFHIP_PF_SCORE(SSM_, NCC_, FAST_, MC_) MTFHIP_LAUNCH((k_pf_score<SSM_, NCC_, FAST_, MC_>), g, dim3(kBlock), 0, st, bv, im, s)
+#define MTFHIP_PF_SCORE(SSM_, NCC_, FAST_, MC_) do { \
+		if (kc == 1) MTFHIP_LAUNCH((k_pf_score<SSM_, NCC_, FAST_, MC_, 1>), g, dim3(kBlock), 0, st, bv, im, s); \
+		else if (kc == 2) MTFHIP_LAUNCH((k_pf_score<SSM_, NCC_, FAST_, MC_, 2>), g, dim3(kBlock), 0, st, bv, im, s); \
+		else MTFHIP_LAUNCH((k_pf_score<SSM_, NCC_, FAST_, MC_, 4>), g, dim3(kBlock), 0, st, bv, im, s); } while (0)
 #define MTFHIP_PF_SCORE_MC(SSM_, NCC_, FAST_) do { if (mc) MTFHIP_PF_SCORE(SSM_, NCC_, FAST_, true); else MTFHIP_PF_SCORE(SSM_, NCC_, FAST_, false); } while (0)
 	if (fast_math) {
 		if (hom) { if (ncc) MTFHIP_PF_SCORE_MC(MTFHIP_SSM_HOMOGRAPHY, true, true); else MTFHIP_PF_SCORE_MC(MTFHIP_SSM_HOMOGRAPHY, false, true); }
