@@ -420,10 +420,17 @@ struct __attribute__((packed, aligned(4))) PfTexPair { float a, b; };
  * rank's share of a sharded filter, the reference's shipped 500 particles -- take 2 or 1, so that the launch still covers the device
  * (1 250 candidates are 313 workgroups at K = 4: one per CU and a 14 us launch).  A candidate's sums do not depend on K: the same
  * pixels per thread, the same xor butterfly, the same order over the waves. */
+#ifdef MTFHIP_PF_TRACE   /* tools/pf_score_trace.sh: wall-clock stamps (100 MHz) of workgroup 0's phases */
+__device__ unsigned long long g_pf_trace[16];
+#define PF_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_pf_trace[k] = wall_clock64(); } while (0)
+#else
+#define PF_STAMP(k) do { } while (0)
+#endif
 template <int SSM, bool NCC, bool FAST, bool MC, int K>
 __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, PfScoreArgs s) {
 	constexpr int M = NCC ? 3 : 1, S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
 	__shared__ double red[4 * K * M], tot[K * M];
+	PF_STAMP(0);
 	const int c0 = s.lo + blockIdx.x * K, cend = s.lo + s.cnt;
 	const int tid = threadIdx.x;
 	double W[K][9];
@@ -461,6 +468,7 @@ __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, P
 			all_inside = __builtin_amdgcn_ballot_w64(!in) == 0;
 		}
 	}
+	PF_STAMP(1);
 	auto pixel_loop = [&](auto inside_tag) {
 	constexpr bool INSIDE = decltype(inside_tag)::value;
 	for (unsigned i = tid; i < N; i += kBlock) {
@@ -523,8 +531,10 @@ __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, P
 	}
 	};
 	if (all_inside) pixel_loop(std::true_type{}); else pixel_loop(std::false_type{});
+	PF_STAMP(2);
 	block_reduce_store<K * M>(acc, tot, red);
 	__syncthreads();
+	PF_STAMP(3);
 	const int k = tid, cand = c0 + k;
 	if (k < K && cand < cend) {
 		double f, lik;
@@ -549,6 +559,7 @@ __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, P
 		if (s.peer.world) pf_peer_store(s.peer, cand, w);
 	}
 	if (s.peer.world) pf_peer_arrive(s.peer, gridDim.x);
+	PF_STAMP(4);
 }
 /* the same for a scorer that does not store to the peers itself (MI): 64 weights per workgroup, stored by wave 0 */
 constexpr int kPfPushPerGroup = 64;
@@ -1099,7 +1110,14 @@ void launch_pf_residual_copies(int n, const double *wts, const int *order, int *
 void launch_pf_residual_map(int n, const int *order, const int *copies, const int *starts, int *ids, hipStream_t st) {
 	MTFHIP_LAUNCH(k_pf_residual_map, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, order, copies, starts, ids);
 }
+#ifdef MTFHIP_PF_TRACE
+void debug_pf_trace(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pf_trace), sizeof(unsigned long long) * 16); }
+#endif
 int pf_parts_per_block() { return kPfPart; }
 int pf_chunk() { return kPfChunk; }
 
 } // namespace mtfhip
+#ifdef MTFHIP_PF_TRACE
+namespace mtfhip { void debug_pf_trace(unsigned long long *out); }
+extern "C" void mtfhip_debug_pf_trace(unsigned long long *out) { mtfhip::debug_pf_trace(out); }
+#endif
