@@ -461,7 +461,8 @@ __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, P
 			if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
 				const double dd = fma(Wl[6], X, fma(Wl[7], Y, Wl[8]));
 				in = dd > 1e-9;
-				hx /= dd; hy /= dd;
+				const double inv = rcp_fast(dd);   /* (the margin below is 1e-3 px: no need for an IEEE division in every wave's prologue) */
+				hx *= inv; hy *= inv;
 			}
 			/* (a margin of a thousandth of a pixel: the samples' own rounding is ~1e-13) */
 			in = in & (hx > 1e-3) & (hy > 1e-3) & (hx < (double)iw1 - 1e-3) & (hy < (double)ih1 - 1e-3);
