@@ -298,6 +298,41 @@ int mtfhip_batch_track_region(mtfhip_batch *b, const mtfhip_sm_desc *sm, const d
  * row-major 2 x 4 arrays per patch (x row, y row) and the patch centroids (utils::getCentroid, miscUtils.h:473-480) */
 int mtfhip_grid_update(mtfhip_batch *b, const mtfhip_sm_desc *sm, const double *regions_2x4 /* B x 2 x 4 */, int *n_iters /* B, or NULL */,
 	double *corners_2x4 /* B x 2 x 4, or NULL */, double *centroids /* B x 2, or NULL */);
+/* GridTrackerParams (SM/include/mtf/SM/GridTracker.h:8-60, SM/src/GridTracker.cc:20-94): the fields that shape the frame.  Class
+ * defaults 10 x 10 patches of 10 x 10, reset_at_each_frame 1, dyn_patch_size 0, patch_centroid_inside 1
+ * (Config/parameters.h:505-510; shipped Config/modules.cfg:75-80: grid_res 10, grid_patch_size 25). */
+typedef struct mtfhip_grid_desc {
+	int grid_size_x, grid_size_y;
+	int patch_size_x, patch_size_y;
+	int reset_at_each_frame;      /* 0: patch trackers run on; 1: re-initialised on the new grid every frame; other: setRegion only (GridTracker.cc:136,273) */
+	int dyn_patch_size;           /* 1: a patch is the quadrilateral of its four surrounding grid points */
+	int patch_centroid_inside;    /* 1: patch_size rectangles centred on the centroid of the four surrounding grid points */
+} mtfhip_grid_desc;
+/* GridTrackerParams::updateRes (GridTracker.cc:86-94): the sampling resolution of the grid SSM -- grid_size + 1 when
+ * dyn_patch_size || patch_centroid_inside, else grid_size */
+int mtfhip_grid_res(const mtfhip_grid_desc *g, int *resx, int *resy);
+/* GridTracker::resetTrackers' geometry (GridTracker.cc:345-380) for the grid SSM laid over region_corners (CornersT: x, y per
+ * corner, TL TR BR BL): grid_pts = ssm.getPts() after ssm.setCorners(region) -- the resx x resy unit-square grid through the
+ * 4-corner DLT homography (ProjectiveBase::getPtsFromCorners ProjectiveBase.cc:20-25; Homography and Affine both, with
+ * normalized_init = 0), row-major (y outer) -- and the corners resetTrackers hands patch tracker k = row * grid_size_x + col:
+ * the four surrounding points (_linear_idx, :139-146, :357-367), then unless dyn_patch_size the patch_size rectangle
+ * (utils::Corners(cv::Rect_<double>) miscUtils.h:42-52) centred on their centroid (patch_centroid_inside) or on grid point k.
+ * Host arithmetic only: no device, no batch.  grid_pts (2 x resx*resy, x, y interleaved) may be NULL. */
+int mtfhip_grid_layout(const mtfhip_grid_desc *g, const double *region_corners /* 8 */, double *grid_pts /* or NULL */,
+	double *patch_corners /* grid_size_x * grid_size_y x 8 */);
+/* One frame of GridTracker's patch half for a batch of grid_size_x * grid_size_y patch trackers, CornersT layout throughout:
+ * with region_corners the patches are first laid over that region (mtfhip_grid_layout) and reset -- setRegion, in the same launch
+ * as the update where the search method allows it -- then every patch tracker runs its update(); centroids are utils::getCentroid
+ * into cv::Point2f (miscUtils.h:472-480: rounded to float), the points GridTracker::update hands to ssm.estimateWarpFromPts
+ * (GridTracker.cc:254-267).  region_corners NULL: update only. */
+int mtfhip_grid_frame(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_grid_desc *g, const double *region_corners /* 8 or NULL */,
+	int *n_iters /* B or NULL */, double *corners /* B x 8 or NULL */, float *centroids /* B x 2 or NULL */);
+/* resetTrackers(reinit) (GridTracker.cc:345-392) for the same batch: the patches laid over region_corners, then every patch tracker
+ * initialize()d on the current image (reinit != 0: mtfhip_ssm_set_corners + mtfhip_batch_init_template) or setRegion()ed
+ * (mtfhip_batch_set_region).  Nothing is waited for; patch_corners / prev_pts (the centroids of the regions the trackers report
+ * afterwards = of the patches) may be NULL. */
+int mtfhip_grid_reset(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_grid_desc *g, const double *region_corners /* 8 */, int reinit,
+	double *patch_corners /* B x 8 or NULL */, float *prev_pts /* B x 2 or NULL */);
 /* Debug trace of the loop above: with max_passes > 0 every pass also records what it solved, per target
  * [max_passes][96]: H (64, row-major 8 x 8, before Levenberg-Marquardt damping) | g (8) | the state update applied (8) | the
  * corners it produced (8) | f | pass | LM undo | LM damping | 1 when H was recorded (the one-launch grid loop uses the

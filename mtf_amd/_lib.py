@@ -66,6 +66,12 @@ class PFDesc(C.Structure):
                 ("min_distr_wt", C.c_double)]
 
 
+class GridDesc(C.Structure):
+    """mtfhip_grid_desc = GridTrackerParams (SM/src/GridTracker.cc:20-94)"""
+    _fields_ = [("grid_size_x", C.c_int), ("grid_size_y", C.c_int), ("patch_size_x", C.c_int), ("patch_size_y", C.c_int),
+                ("reset_at_each_frame", C.c_int), ("dyn_patch_size", C.c_int), ("patch_centroid_inside", C.c_int)]
+
+
 # every exported symbol of include/mtfhip.h (tests check that the library exports all of them)
 SYMBOLS = [
     "mtfhip_last_error", "mtfhip_device_count", "mtfhip_ctx_create", "mtfhip_ctx_destroy",
@@ -91,6 +97,7 @@ SYMBOLS = [
     "mtfhip_sm_mean_pix_hessian", "mtfhip_am_cmpt_init_hessian2", "mtfhip_am_cmpt_curr_hessian2",
     "mtfhip_am_cmpt_self_hessian2", "mtfhip_am_cmpt_sum_of_hessians2",
     "mtfhip_batch_init_template", "mtfhip_batch_set_region", "mtfhip_batch_iterate", "mtfhip_batch_track", "mtfhip_batch_track_region", "mtfhip_grid_update",
+    "mtfhip_grid_res", "mtfhip_grid_layout", "mtfhip_grid_frame", "mtfhip_grid_reset",
     "mtfhip_batch_track_targets_per_launch",
     "mtfhip_score_candidates", "mtfhip_score_candidates_dev",
     "mtfhip_sample_candidates", "mtfhip_sample_candidates_dev",
@@ -148,6 +155,10 @@ def lib():
         L.mtfhip_image_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.mtfhip_image_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.mtfhip_grid_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mtfhip_grid_res.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mtfhip_grid_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mtfhip_grid_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mtfhip_grid_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.mtfhip_ssm_update_grad_pts.argtypes = [C.c_void_p, C.c_double]
         L.mtfhip_ssm_update_hess_pts.argtypes = [C.c_void_p, C.c_double]
         for fn in ("mtfhip_am_initialize_pix_hess", "mtfhip_am_update_pix_hess"):

@@ -542,6 +542,27 @@ class Batch:
         L.check(fn(self._h, C.byref(sm), r.ctypes.data, pn, pc, pm))
         return n, c, m
 
+    def grid_frame(self, gd, sm, region=None):
+        """one frame of GridTracker's patch half (mtfhip_grid_frame): with `region` (2 x 4) the patches are laid over it and reset
+        (setRegion) in the same call, then every patch tracker updates.  -> iteration counts, corners (B, 2, 4), centroids (B, 2)
+        float32 as the reference's cv::Point2f.  Reused buffers: valid until the next call."""
+        gf = getattr(self, "_gf", None)
+        if gf is None:
+            n, c, m, r = np.empty(self.B, dtype=np.int32), np.empty((self.B, 4, 2)), np.empty((self.B, 2), dtype=np.float32), np.empty(8)
+            gf = self._gf = (n, c, m, r, _p(n), _p(c), _p(m), _p(r), L.lib().mtfhip_grid_frame)
+        n, c, m, r, pn, pc, pm, pr, fn = gf
+        if region is not None:
+            r[...] = np.asarray(region, dtype=np.float64).reshape(2, 4).T.ravel()
+        L.check(fn(self._h, C.byref(sm), C.byref(gd), pr if region is not None else None, pn, pc, pm))
+        return n, c.transpose(0, 2, 1), m
+
+    def grid_reset(self, gd, sm, region, reinit):
+        """GridTracker::resetTrackers(reinit) (mtfhip_grid_reset) -> patch corners (B, 2, 4), prev_pts (B, 2) float32"""
+        pcs, pp = np.empty((self.B, 4, 2)), np.empty((self.B, 2), dtype=np.float32)
+        r = np.ascontiguousarray(np.asarray(region, dtype=np.float64).reshape(2, 4).T)
+        L.check(L.lib().mtfhip_grid_reset(self._h, C.byref(sm), C.byref(gd), _p(r), int(bool(reinit)), _p(pcs), _p(pp)))
+        return pcs.transpose(0, 2, 1).copy(), pp
+
     # ---------------------------------------------------------- candidate scoring
     def score_candidates(self, states, want_similarity=False):
         s = _f64(states).reshape(-1, self.S)

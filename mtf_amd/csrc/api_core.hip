@@ -868,6 +868,71 @@ int mtfhip_ssm_apply_warp_to_pts(int ssm, const double *in_pts, int n_pts, const
 	}
 	return MTFHIP_OK;
 }
+/* ------------------------------------------------------------------ GridTracker's patch layout (host arithmetic only) */
+static int grid_desc_ok(const mtfhip_grid_desc *g, const char *fn) {
+	if (!g) return fail(MTFHIP_ERR_INVALID_ARG, "%s: NULL grid description", fn);
+	if (g->grid_size_x <= 0 || g->grid_size_y <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "%s: grid_size must be positive", fn);
+	if (g->patch_size_x <= 0 || g->patch_size_y <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "%s: patch_size must be positive", fn);
+	return MTFHIP_OK;
+}
+/* Eigen's LinSpaced as utils::getNormUnitSquarePts uses it (warpUtils.cc:15-34): lo + i * step, the last element pinned to hi */
+static inline double lin_spaced_h(int i, int n, double lo, double hi) { return (n == 1 || i == n - 1) ? hi : lo + i * ((hi - lo) / (n - 1)); }
+/* GridTrackerParams::updateRes SM/src/GridTracker.cc:86-94 */
+int mtfhip_grid_res(const mtfhip_grid_desc *g, int *resx, int *resy) {
+	TRY(grid_desc_ok(g, "grid_res"));
+	if (!resx || !resy) return fail(MTFHIP_ERR_INVALID_ARG, "grid_res: NULL argument");
+	const int extra = (g->dyn_patch_size || g->patch_centroid_inside) ? 1 : 0;
+	*resx = g->grid_size_x + extra; *resy = g->grid_size_y + extra;
+	return MTFHIP_OK;
+}
+/* GridTracker::resetTrackers' geometry SM/src/GridTracker.cc:345-380 over ssm.getPts() of the grid SSM after setCorners(region)
+ * (ProjectiveBase::setCorners -> getPtsFromCorners ProjectiveBase.cc:20-36: the resx x resy grid of the unit square through the
+ * 4-corner homography; Affine::setCorners Affine.cc:75-79 takes the same route with normalized_init = 0 -- its pixel-sized
+ * normalised square instead of the unit one is the same uniform grid).  The grid point is evaluated, not interpolated between
+ * the region's corners: for a region that is not a parallelogram the two differ. */
+int mtfhip_grid_layout(const mtfhip_grid_desc *g, const double *region, double *grid_pts, double *patch_corners) {
+	int resx, resy;
+	TRY(mtfhip_grid_res(g, &resx, &resy));
+	if (!region || !patch_corners) return fail(MTFHIP_ERR_INVALID_ARG, "grid_layout: NULL argument");
+	M3 W;
+	if (!rect_to_quad(-0.5, -0.5, 0.5, 0.5, region, W)) return fail(MTFHIP_ERR_INVALID_ARG, "grid_layout: degenerate region corners");
+	static thread_local std::vector<double> pts;
+	pts.resize(2 * (size_t)resx * resy);
+	for (int r = 0; r < resy; ++r) {
+		const double ny = lin_spaced_h(r, resy, -0.5, 0.5);
+		for (int c = 0; c < resx; ++c) {
+			const double nx = lin_spaced_h(c, resx, -0.5, 0.5);
+			const double X = W.m[0] * nx + W.m[1] * ny + W.m[2], Y = W.m[3] * nx + W.m[4] * ny + W.m[5], Z = W.m[6] * nx + W.m[7] * ny + W.m[8];
+			const size_t i = (size_t)r * resx + c;
+			pts[2 * i] = X / Z; pts[2 * i + 1] = Y / Z;
+		}
+	}
+	if (grid_pts) std::memcpy(grid_pts, pts.data(), sizeof(double) * pts.size());
+	const bool surround = g->dyn_patch_size || g->patch_centroid_inside;
+	const int sub_x = g->grid_size_x + 1;   /* _linear_idx(idy, idx) = idy * (grid_size_x + 1) + idx, :139-146 */
+	const double half_x = g->patch_size_x / 2.0, half_y = g->patch_size_y / 2.0;   /* centrod_dist_x / _y :156-157 */
+	for (int k = 0; k < g->grid_size_x * g->grid_size_y; ++k) {
+		const int row = k / g->grid_size_x, col = k % g->grid_size_x;   /* :354-355 */
+		double *pc = patch_corners + 8 * (size_t)k;
+		if (surround) {   /* :357-367 TL, TR, BR, BL of the cell (without the extra row / column the reads have no meaning: the reference overwrites them) */
+			const int id[4] = {row * sub_x + col, row * sub_x + col + 1, (row + 1) * sub_x + col + 1, (row + 1) * sub_x + col};
+			for (int q = 0; q < 4; ++q) { pc[2 * q] = pts[2 * (size_t)id[q]]; pc[2 * q + 1] = pts[2 * (size_t)id[q] + 1]; }
+		}
+		if (!g->dyn_patch_size) {   /* :369-380 */
+			double cx = pts[2 * (size_t)k], cy = pts[2 * (size_t)k + 1];   /* ssm.getPts().col(tracker_id) */
+			if (g->patch_centroid_inside) {   /* utils::getCentroid miscUtils.h:481-487 */
+				cx = (pc[0] + pc[2] + pc[4] + pc[6]) / 4.0;
+				cy = (pc[1] + pc[3] + pc[5] + pc[7]) / 4.0;
+			}
+			const double min_x = cx - half_x, min_y = cy - half_y;   /* utils::Corners(cv::Rect_<double>) miscUtils.h:42-52 */
+			const double max_x = min_x + g->patch_size_x, max_y = min_y + g->patch_size_y;
+			pc[0] = pc[6] = min_x; pc[2] = pc[4] = max_x;
+			pc[1] = pc[3] = min_y; pc[5] = pc[7] = max_y;
+		}
+	}
+	return MTFHIP_OK;
+}
+
 /* ProjectiveBase::additiveUpdate SSM/src/ProjectiveBase.cc:51-55: curr_state += update; setState(curr_state) */
 int mtfhip_ssm_additive_update(mtfhip_batch *b, const double *state_updates) {
 	if (!b || !state_updates) return fail(MTFHIP_ERR_INVALID_ARG, "additive_update: NULL argument");

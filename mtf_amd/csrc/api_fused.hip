@@ -919,6 +919,52 @@ int mtfhip_grid_update(mtfhip_batch *b, const mtfhip_sm_desc *sm, const double *
 	return MTFHIP_OK;
 }
 
+/* utils::getCentroid(cv::Point2f &, corners) miscUtils.h:472-480: the mean of the four corners, rounded to float */
+static inline void centroid_f(float *dst, const double *c) {
+	dst[0] = static_cast<float>((c[0] + c[2] + c[4] + c[6]) / 4.0);
+	dst[1] = static_cast<float>((c[1] + c[3] + c[5] + c[7]) / 4.0);
+}
+static int grid_batch_ok(const mtfhip_batch *b, const mtfhip_grid_desc *g, const char *fn) {
+	if (!b || !g) return fail(MTFHIP_ERR_INVALID_ARG, "%s: NULL argument", fn);
+	if (g->grid_size_x <= 0 || g->grid_size_y <= 0 || g->grid_size_x * g->grid_size_y != b->B)   /* GridTracker.cc:124-129 */
+		return fail(MTFHIP_ERR_INVALID_ARG, "%s: mismatch between the grid dimensions (%d x %d) and the batch's %d patch trackers", fn, g->grid_size_x, g->grid_size_y, b->B);
+	return MTFHIP_OK;
+}
+/* GridTracker::update's patch loop (GridTracker.cc:254-261), with the reset that preceded it folded in when a region is given */
+int mtfhip_grid_frame(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_grid_desc *g, const double *region, int *n_iters, double *corners, float *centroids) {
+	if (!sm) return fail(MTFHIP_ERR_INVALID_ARG, "grid_frame: NULL argument");
+	TRY(grid_batch_ok(b, g, "grid_frame"));
+	const size_t B = (size_t)b->B;
+	static thread_local std::vector<double> patches, out;
+	static thread_local std::vector<int> iters;
+	out.resize(8 * B); iters.resize(B);
+	if (region) {
+		patches.resize(8 * B);
+		TRY(mtfhip_grid_layout(g, region, nullptr, patches.data()));
+		TRY(mtfhip_batch_track_region(b, sm, patches.data(), n_iters ? n_iters : iters.data(), out.data()));
+	} else TRY(mtfhip_batch_track(b, sm, n_iters ? n_iters : iters.data(), out.data()));
+	if (corners) std::memcpy(corners, out.data(), sizeof(double) * 8 * B);
+	if (centroids) for (size_t t = 0; t < B; ++t) centroid_f(centroids + 2 * t, &out[8 * t]);
+	return MTFHIP_OK;
+}
+/* GridTracker::resetTrackers(reinit) GridTracker.cc:345-392 */
+int mtfhip_grid_reset(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_grid_desc *g, const double *region, int reinit, double *patch_corners, float *prev_pts) {
+	if (!sm || !region) return fail(MTFHIP_ERR_INVALID_ARG, "grid_reset: NULL argument");
+	TRY(grid_batch_ok(b, g, "grid_reset"));
+	const size_t B = (size_t)b->B;
+	static thread_local std::vector<double> patches;
+	patches.resize(8 * B);
+	TRY(mtfhip_grid_layout(g, region, nullptr, patches.data()));
+	if (reinit) {   /* tracker->initialize(patch_corners): NT/ICLK.cc:71-128 etc. */
+		TRY(mtfhip_ssm_set_corners(b, patches.data()));
+		TRY(mtfhip_batch_init_template(b, sm));
+	} else TRY(mtfhip_batch_set_region(b, patches.data(), sm));   /* tracker->setRegion(patch_corners) */
+	if (patch_corners) std::memcpy(patch_corners, patches.data(), sizeof(double) * 8 * B);
+	/* :387 getCentroid(prev_pts[id], tracker->getRegion()): both resets leave the tracker's region = the patch corners */
+	if (prev_pts) for (size_t t = 0; t < B; ++t) centroid_f(prev_pts + 2 * t, &patches[8 * t]);
+	return MTFHIP_OK;
+}
+
 /* the argument / state checks of the device loop, without side effects (track_region runs them before it resets the SSM) */
 static int track_validate(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	TRY(check_sm(b, sm, "track"));

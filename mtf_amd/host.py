@@ -57,6 +57,12 @@ def lib():
                                              C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         H.mtfhost_ssm_random_walk.argtypes = [C.c_void_p, C.c_ulonglong, C.c_int, C.c_void_p, C.c_void_p]
         H.mtfhost_ssm_pts_after_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        H.mtfhost_grid_create.restype = C.c_void_p
+        H.mtfhost_grid_create.argtypes = [C.c_int] * 12 + [C.c_double, C.c_int, C.c_int, C.c_int]
+        H.mtfhost_grid_destroy.argtypes = [C.c_void_p]
+        H.mtfhost_grid_set_estimator.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        H.mtfhost_grid_call.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        H.mtfhost_grid_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         _h = H
     return _h
 
@@ -212,3 +218,84 @@ def templated_fclk(frame0, frame1, corners, am=_lib.AM_SSD, ssm=_lib.SSM_HOMOGRA
                                         frame1.ctypes.data_as(C.c_void_p), frame0.shape[0], frame0.shape[1], frame0.shape[1],
                                         c.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.byref(n)))
     return out.reshape(4, 2).T.copy(), n.value
+
+
+_GRID_EST = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_double))
+
+
+class CppGridTracker:
+    """mtf::hip::Grid (mtf_amd/host/DeviceGrid.h): GridTracker<SSM> with the reference's parameter block over one batch of patch
+    trackers on the device.  estimator(prev_pts (n, 2), curr_pts (n, 2)) -> state update replaces the built-in least-squares fit."""
+
+    def __init__(self, grid_size=10, patch_size=10, patch_sm=_lib.SM_ICLK, patch_am=_lib.AM_NCC, patch_ssm=_lib.SSM_AFFINE,
+                 grid_ssm=_lib.SSM_HOMOGRAPHY, reset_at_each_frame=1, dyn_patch_size=0, patch_centroid_inside=1, max_iters=30, epsilon=1e-4,
+                 hess_type=-1, leven_marq=0, device=0, estimator=None, grid_size_y=None, patch_size_y=None):
+        gy, py = grid_size_y or grid_size, patch_size_y or patch_size
+        h = lib().mtfhost_grid_create(grid_size, gy, patch_size, py, reset_at_each_frame, dyn_patch_size, patch_centroid_inside, patch_sm,
+                                      patch_am, patch_ssm, grid_ssm, max_iters, epsilon, hess_type, leven_marq, device)
+        if not h:
+            raise HostError(lib().mtfhost_last_error().decode("utf-8", "replace"))
+        self._h = C.c_void_p(h)
+        self.n, self.S = grid_size * gy, 8 if grid_ssm == _lib.SSM_HOMOGRAPHY else 6
+        self._img, self._cb = None, None
+        if estimator is not None:
+            S = self.S
+
+            def cb(_user, cnt, prev, curr, out):
+                a = np.ctypeslib.as_array(prev, shape=(cnt, 2)).astype(np.float64)
+                b = np.ctypeslib.as_array(curr, shape=(cnt, 2)).astype(np.float64)
+                upd = np.asarray(estimator(a, b), dtype=np.float64)
+                for i in range(S):
+                    out[i] = upd[i]
+            self._cb = _GRID_EST(cb)
+            _check(lib().mtfhost_grid_set_estimator(self._h, C.cast(self._cb, C.c_void_p), None))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and not sys.is_finalizing():
+            lib().mtfhost_grid_destroy(self._h)
+            self._h = None
+
+    def set_image(self, img):
+        assert img.dtype == np.float32 and img.flags["C_CONTIGUOUS"] and img.ndim == 2
+        self._img = img
+        _check(lib().mtfhost_grid_call(self._h, 0, None, img.ctypes.data_as(C.c_void_p), img.shape[0], img.shape[1], img.shape[1]))
+
+    def _corners_call(self, what, corners):
+        c = np.ascontiguousarray(np.asarray(corners, dtype=np.float64).reshape(2, 4).T.ravel())
+        _check(lib().mtfhost_grid_call(self._h, what, c.ctypes.data_as(C.c_void_p), None, 0, 0, 0))
+
+    def initialize(self, corners):
+        self._corners_call(1, corners)
+
+    def set_region(self, corners):
+        self._corners_call(3, corners)
+
+    def update(self):
+        _check(lib().mtfhost_grid_call(self._h, 2, None, None, 0, 0, 0))
+        return self.get_region()
+
+    def _get(self, what, size):
+        out = np.empty(size)
+        _check(lib().mtfhost_grid_get(self._h, what, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def get_region(self):
+        return self._get(0, 8).reshape(4, 2).T.copy()
+
+    def patch_corners(self):
+        return self._get(1, 8 * self.n).reshape(self.n, 4, 2).transpose(0, 2, 1).copy()
+
+    def patch_regions(self):
+        return self._get(6, 8 * self.n).reshape(self.n, 4, 2).transpose(0, 2, 1).copy()
+
+    def prev_pts(self):
+        return self._get(2, 2 * self.n).reshape(self.n, 2)
+
+    def curr_pts(self):
+        return self._get(3, 2 * self.n).reshape(self.n, 2)
+
+    def ssm_update(self):
+        return self._get(4, self.S)
+
+    def patch_iters(self):
+        return self._get(5, self.n).astype(np.int32)

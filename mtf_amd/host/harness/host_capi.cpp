@@ -11,6 +11,7 @@
 #include "../HipModels.h"
 #include "../DeviceLK.h"
 #include "../DevicePF.h"
+#include "../DeviceGrid.h"
 #include "SearchMethods.h"
 #include "PF.h"
 #include "TemplatedSM.h"
@@ -251,4 +252,68 @@ extern "C" int mtfhost_templated_fclk(int am, int ssm, int resx, int resy, int m
 		std::memcpy(out_corners_2x4, sm.getRegion().data(), sizeof(double) * 8);
 		return 0;
 	} catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
+/* ---- mtf::hip::Grid (DeviceGrid.h): GridTracker<SSM> over one batch of patch trackers ---- */
+struct mtfhost_grid { std::unique_ptr<hip::Grid> g; };
+typedef void (*mtfhost_grid_estimator)(void *user, int n, const float *prev_pts, const float *curr_pts, double *ssm_update);
+extern "C" {
+mtfhost_grid *mtfhost_grid_create(int grid_size_x, int grid_size_y, int patch_size_x, int patch_size_y, int reset_at_each_frame, int dyn_patch_size,
+	int patch_centroid_inside, int patch_sm, int patch_am, int patch_ssm, int grid_ssm, int max_iters, double epsilon, int hess_type, int leven_marq, int device) {
+	try {
+		GridTrackerParams gp;
+		gp.grid_size_x = grid_size_x; gp.grid_size_y = grid_size_y; gp.patch_size_x = patch_size_x; gp.patch_size_y = patch_size_y;
+		gp.reset_at_each_frame = reset_at_each_frame; gp.dyn_patch_size = dyn_patch_size != 0; gp.patch_centroid_inside = patch_centroid_inside != 0;
+		nt::SMParams p;
+		p.max_iters = max_iters; p.epsilon = epsilon; p.hess_type = hess_type; p.leven_marq = leven_marq != 0;
+		std::unique_ptr<mtfhost_grid> h(new mtfhost_grid());
+		h->g.reset(new hip::Grid(gp, patch_sm, patch_am, patch_ssm, p, grid_ssm, device));
+		return h.release();
+	} catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+void mtfhost_grid_destroy(mtfhost_grid *h) { delete h; }
+int mtfhost_grid_set_estimator(mtfhost_grid *h, mtfhost_grid_estimator est, void *user) {
+	if (!h) { g_err = "NULL grid"; return -1; }
+	if (!est) return 0;
+	h->g->setEstimator([est, user](VectorXd &u, const std::vector<GridPt> &a, const std::vector<GridPt> &c) {
+		std::vector<float> fa(2 * a.size()), fc(2 * c.size());
+		for (size_t i = 0; i < a.size(); ++i) { fa[2 * i] = a[i].x; fa[2 * i + 1] = a[i].y; fc[2 * i] = c[i].x; fc[2 * i + 1] = c[i].y; }
+		est(user, (int)a.size(), fa.data(), fc.data(), u.data());
+	});
+	return 0;
+}
+/* what: 0 setImage(img) 1 initialize(corners) 2 update() 3 setRegion(corners) */
+int mtfhost_grid_call(mtfhost_grid *h, int what, const double *corners, const float *img, int rows, int cols, int step) {
+	try {
+		CornersT c;
+		if (corners) std::memcpy(c.data(), corners, sizeof(double) * 8);
+		switch (what) {
+		case 0: h->g->setImage(ImageView{img, rows, cols, step}); break;
+		case 1: h->g->initialize(c); break;
+		case 2: h->g->update(); break;
+		case 3: h->g->setRegion(c); break;
+		default: g_err = "mtfhost_grid_call: unknown selector"; return -1;
+		}
+		return 0;
+	} catch (const utils::Exception &e) { g_err = std::string(e.type()) + ": " + e.what(); return -1; }
+	catch (const std::exception &e) { g_err = e.what(); return -2; }
+}
+/* what: 0 region (8) 1 patch corners of the last reset (n x 8) 2 prev_pts (n x 2) 3 curr_pts (n x 2) 4 ssm_update (S) 5 patch iteration
+ * counts (n, as doubles) 6 the patch trackers' regions after the last update (n x 8) */
+int mtfhost_grid_get(mtfhost_grid *h, int what, double *dst) {
+	try {
+		hip::Grid &g = *h->g;
+		switch (what) {
+		case 0: std::memcpy(dst, g.getRegion().data(), sizeof(double) * 8); break;
+		case 1: std::memcpy(dst, g.getPatchCorners().data(), sizeof(double) * g.getPatchCorners().size()); break;
+		case 2: for (size_t i = 0; i < g.getPrevPts().size(); ++i) { dst[2 * i] = g.getPrevPts()[i].x; dst[2 * i + 1] = g.getPrevPts()[i].y; } break;
+		case 3: for (size_t i = 0; i < g.getCurrPts().size(); ++i) { dst[2 * i] = g.getCurrPts()[i].x; dst[2 * i + 1] = g.getCurrPts()[i].y; } break;
+		case 4: std::memcpy(dst, g.getSSMUpdate().data(), sizeof(double) * g.getSSMUpdate().size()); break;
+		case 5: for (size_t i = 0; i < g.getPatchIters().size(); ++i) dst[i] = g.getPatchIters()[i]; break;
+		case 6: std::memcpy(dst, g.getPatchRegions().data(), sizeof(double) * g.getPatchRegions().size()); break;
+		default: g_err = "mtfhost_grid_get: unknown selector"; return -1;
+		}
+		return 0;
+	} catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
 }

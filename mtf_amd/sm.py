@@ -313,44 +313,145 @@ class NTSearchMethod:
         return b.get_corners()
 
 
-class GridTracker:
-    """The patch-tracking half of GridTracker (SM/src/GridTracker.cc:247-261,345-392): grid_size x grid_size
-    independent ICLK patch trackers (default NCC + Affine, `patch_size` square patches centred on the grid
-    points of the region, dyn_patch_size = 0), all patches of a frame in ONE kernel launch.  The robust
-    SSM fit over the patch centroids (estimateWarpFromPts, RANSAC/LMS) is out of scope (SURVEY.md section 2);
-    `update` returns the per-patch corners and centroids that feed it."""
+def least_squares_estimator(ssm):
+    """An all-points least-squares fit of the grid SSM to the patch centroids, standing in for ssm.estimateWarpFromPts
+    (SSM/src/Homography.cc:885-897, Affine.cc:359-369 -> utils::estimateHomography / estimateAffine: RANSAC / LMedS over the same
+    point pairs, out of scope -- SURVEY.md section 2).  Returns f(prev_pts (n, 2), curr_pts (n, 2)) -> state update in the SSM's
+    own parameterisation (homography [h00-1, h01, h02, h10, h11-1, h12, h20, h21]; affine [tx, ty, a-1, b, c, d-1])."""
+    def fit(prev_pts, curr_pts):
+        a, b = np.asarray(prev_pts, dtype=np.float64), np.asarray(curr_pts, dtype=np.float64)
+        n = len(a)
+        if ssm == L.SSM_AFFINE:
+            A = np.hstack([a, np.ones((n, 1))])
+            M = np.linalg.lstsq(A, b, rcond=None)[0].T          # 2 x 3
+            return np.array([M[0, 2], M[1, 2], M[0, 0] - 1, M[0, 1], M[1, 0], M[1, 1] - 1])
+        # normalised DLT (Hartley): both point sets to zero mean and mean distance sqrt(2)
+        def norm(p):
+            m = p.mean(axis=0)
+            sc = np.sqrt(2.0) / max(np.sqrt(((p - m) ** 2).sum(axis=1)).mean(), 1e-300)
+            T = np.array([[sc, 0, -sc * m[0]], [0, sc, -sc * m[1]], [0, 0, 1.0]])
+            return (p - m) * sc, T
+        an, Ta = norm(a)
+        bn, Tb = norm(b)
+        rows = []
+        for (x, y), (u, v) in zip(an, bn):
+            rows.append([-x, -y, -1, 0, 0, 0, u * x, u * y, u])
+            rows.append([0, 0, 0, -x, -y, -1, v * x, v * y, v])
+        h = np.linalg.svd(np.asarray(rows))[2][-1].reshape(3, 3)
+        H = np.linalg.inv(Tb) @ h @ Ta
+        H = H / H[2, 2]
+        return np.array([H[0, 0] - 1, H[0, 1], H[0, 2], H[1, 0], H[1, 1] - 1, H[1, 2], H[2, 0], H[2, 1]])
+    return fit
 
-    def __init__(self, ctx, grid_size=16, patch_size=25, am=L.AM_NCC, ssm=L.SSM_AFFINE, max_iters=30, epsilon=1e-4):
+
+class GridTracker:
+    """GridTracker<SSM> (SM/src/GridTracker.cc): grid_size x grid_size independent patch trackers laid over the tracked region by a
+    grid SSM, all patches of a frame in ONE kernel launch (ICLK with a constant Hessian; other search methods take the loop of
+    mtfhip_batch_track).  Parameter names, defaults and modes are GridTrackerParams' (GridTracker.cc:20-94, Config/parameters.h:505-510):
+    patch_centroid_inside = 1 (default): the grid SSM has (grid_size + 1)^2 points and a patch is the patch_size rectangle centred on
+    the centroid of its four surrounding grid points; 0: grid_size^2 points, patches centred on them; dyn_patch_size = 1: a patch is
+    the quadrilateral of its four surrounding points.  reset_at_each_frame: 0 the patch trackers run on, 1 they are re-initialised
+    on the new grid after every frame, 2 (any other value) only setRegion().  The grid points are ssm.getPts() of the grid SSM
+    (the unit-square grid through the 4-corner homography, ProjectiveBase.cc:20-36) -- mtfhip_grid_layout.
+    The robust fit of the grid SSM to the patch centroids (estimateWarpFromPts: RANSAC / LMedS) is out of scope (SURVEY.md section
+    2): `estimator(prev_pts, curr_pts) -> state update` is pluggable, default an all-points least-squares fit."""
+
+    def __init__(self, ctx, grid_size=10, patch_size=10, am=L.AM_NCC, ssm=L.SSM_AFFINE, max_iters=30, epsilon=1e-4, sm=L.SM_ICLK,
+                 reset_at_each_frame=1, dyn_patch_size=0, patch_centroid_inside=1, grid_ssm=L.SSM_HOMOGRAPHY, estimator=None,
+                 grid_size_y=None, patch_size_y=None, **sm_params):
         self.grid_size, self.patch_size = grid_size, patch_size
-        self.n = grid_size * grid_size
-        self.tracker = LKTracker(ctx, L.SM_ICLK, ssm, patch_size, patch_size, self.n, host_solve=False, am=am,
-                                 max_iters=max_iters, epsilon=epsilon, hess_type=0, materialize=0)
+        self.gd = L.GridDesc(grid_size, grid_size_y or grid_size, patch_size, patch_size_y or patch_size, int(reset_at_each_frame),
+                             int(bool(dyn_patch_size)), int(bool(patch_centroid_inside)))
+        self.n = self.gd.grid_size_x * self.gd.grid_size_y
+        self.grid_ssm = grid_ssm
+        self.estimator = estimator if estimator is not None else least_squares_estimator(grid_ssm)
+        sm_params.setdefault("hess_type", 0)
+        sm_params.setdefault("materialize", 0)
+        self.tracker = LKTracker(ctx, sm, ssm, self.gd.patch_size_x, self.gd.patch_size_y, self.n, host_solve=False, am=am,
+                                 max_iters=max_iters, epsilon=epsilon, **sm_params)
+        self.region = None
+        self._pending_region = None      # reset_at_each_frame = 2: the setRegion of the patch trackers rides in the next frame's launch
+        self.prev_pts = np.zeros((self.n, 2), dtype=np.float32)
+        self.curr_pts = np.zeros((self.n, 2), dtype=np.float32)
+        self.ssm_update = np.zeros(8 if grid_ssm == L.SSM_HOMOGRAPHY else 6)
+
+    def res(self):
+        """GridTrackerParams::updateRes: the sampling resolution of the grid SSM"""
+        import ctypes as C
+        rx, ry = C.c_int(), C.c_int()
+        L.check(L.lib().mtfhip_grid_res(C.byref(self.gd), C.byref(rx), C.byref(ry)))
+        return rx.value, ry.value
+
+    def _layout(self, region_corners, want_pts=False):
+        import ctypes as C
+        r = np.ascontiguousarray(np.asarray(region_corners, dtype=np.float64).reshape(2, 4).T)
+        rx, ry = self.res()
+        pts = np.empty((rx * ry, 2)) if want_pts else None
+        pcs = np.empty((self.n, 4, 2))
+        L.check(L.lib().mtfhip_grid_layout(C.byref(self.gd), r.ctypes.data, pts.ctypes.data if want_pts else None, pcs.ctypes.data))
+        return pts, pcs.transpose(0, 2, 1).copy()
+
+    def grid_pts(self, region_corners):
+        """ssm.getPts() of the grid SSM laid over the region: (resx * resy, 2), row-major"""
+        return self._layout(region_corners, True)[0]
 
     def patch_corners(self, region_corners):
-        """axis-aligned patch_size squares centred on the grid_size^2 grid points of the region
-        (GridTracker::resetTrackers :357-380 with patch_centroid_inside = 0)."""
-        c = np.asarray(region_corners, dtype=np.float64).reshape(2, 4)
-        u = np.linspace(0.0, 1.0, self.grid_size)
-        out = np.empty((self.n, 2, 4))
-        half = self.patch_size / 2.0
-        k = 0
-        for r in range(self.grid_size):
-            for q in range(self.grid_size):
-                top = c[:, 0] + (c[:, 1] - c[:, 0]) * u[q]
-                bot = c[:, 3] + (c[:, 2] - c[:, 3]) * u[q]
-                ctr = top + (bot - top) * u[r]
-                x0, y0 = ctr[0] - half, ctr[1] - half
-                out[k] = [[x0, x0 + self.patch_size, x0 + self.patch_size, x0],
-                          [y0, y0, y0 + self.patch_size, y0 + self.patch_size]]
-                k += 1
-        return out
+        """the corners GridTracker::resetTrackers (:345-380) hands the patch trackers: (n, 2, 4)"""
+        return self._layout(region_corners)[1]
 
+    # GridTracker::initialize :233-246
     def initialize(self, region_corners):
-        self.tracker.initialize(self.patch_corners(region_corners))
+        self.region = np.asarray(region_corners, dtype=np.float64).reshape(2, 4).copy()
+        _, pp = self.tracker.batch.grid_reset(self.gd, self.tracker.sm, self.region, True)
+        self.prev_pts[...] = pp
+        self.curr_pts[...] = pp
+        self._pending_region = None
 
-    def update(self, region_corners=None):
-        """GridTracker::update's patch half (GridTracker.cc:345-363).  With region_corners the patch trackers are first reset to
-        the grid laid over that region (the reference's reset_at_each_frame behaviour), in the same C-ABI call."""
+    # GridTracker::setRegion :287-292
+    def set_region(self, region_corners):
+        self.region = np.asarray(region_corners, dtype=np.float64).reshape(2, 4).copy()
+        self._reset()
+
+    def get_region(self):
+        return self.region.copy()
+
+    def _reset(self):
+        """resetTrackers(reinit_at_each_frame) :345-392"""
+        if self.gd.reset_at_each_frame == 1:
+            _, pp = self.tracker.batch.grid_reset(self.gd, self.tracker.sm, self.region, True)
+            self.prev_pts[...] = pp
+            self._pending_region = None
+        else:
+            # setRegion only: it rides in the next frame's launch (mtfhip_grid_frame with a region); the centroids are the patches'
+            pcs = self.patch_corners(self.region)
+            self.prev_pts[...] = (pcs.sum(axis=2) / 4.0).astype(np.float32)
+            self._pending_region = self.region
+
+    # GridTracker::update :247-285
+    def update(self):
+        """one frame: every patch tracker's update() (one launch), the fit of the grid SSM to prev_pts -> curr_pts, the region warped by
+        it, and the reset the parameters ask for.  Returns the region's corners (2 x 4)."""
+        if self.region is None:
+            raise RuntimeError("GridTracker.update before initialize")
+        n, _, cen = self.tracker.batch.grid_frame(self.gd, self.tracker.sm, self._pending_region)
+        self._pending_region = None
+        self.tracker.n_iters = n.copy()
+        self.curr_pts[...] = cen
+        upd = np.asarray(self.estimator(self.prev_pts.astype(np.float64), self.curr_pts.astype(np.float64)), dtype=np.float64)
+        self.ssm_update = upd
+        from .api import apply_warp_to_pts
+        # ssm.applyWarpToCorners(opt_warped_corners, ssm.getCorners(), ssm_update); ssm.setCorners(opt_warped_corners) :270-272
+        self.region = apply_warp_to_pts(self.grid_ssm, self.region, upd)
+        if self.gd.reset_at_each_frame:
+            self._reset()
+        else:
+            self.prev_pts[...] = self.curr_pts
+        return self.region.copy()
+
+    def update_patches(self, region_corners=None):
+        """The patch half of a frame alone (GridTracker.cc:254-261), for callers that own the region: with region_corners (2 x 4, or
+        the (n, 2, 4) patch corners themselves) the patch trackers are first reset to the grid laid over that region (setRegion),
+        in the same C-ABI call and -- for ICLK -- the same launch.  Returns the patches' corners (n, 2, 4) and centroids (n, 2)."""
         if region_corners is None:
             corners = self.tracker.update()
             return corners, np.add.reduce(corners, axis=2) * 0.25   # utils::getCentroid miscUtils.h:473-480 (mean of the four corners)

@@ -2099,6 +2099,121 @@ struct mtfo_tracker {
 };
 
 /* ===================================================================== */
+/* GridTracker (SM/src/GridTracker.cc): the patch layout and the frame loop */
+/* ===================================================================== */
+/* GridTracker<SSM> over patch trackers that are the restated nt:: search methods above.  The robust fit of the grid SSM to the
+ * patch centroids (ssm.estimateWarpFromPts -> utils::estimateHomography / estimateAffine: RANSAC / LMedS, SURVEY.md section 2: out
+ * of scope) is a callback the test supplies; everything else of initialize / update / setRegion / resetTrackers is restated. */
+struct mtfo_grid {
+	mtfo_grid_params p;
+	int resx, resy, n;
+	mtfo_ssm *ssm;                       /* the grid SSM: (resx x resy) points laid over the tracked region */
+	std::vector<mtfo_tracker *> trackers;
+	std::vector<int> linear_idx;         /* _linear_idx: (grid_size_y + 1) x (grid_size_x + 1), GridTracker.cc:139-146 */
+	vecd patch_corners;                  /* n x 8: what resetTrackers handed tracker k (CornersT layout: x, y per corner) */
+	std::vector<float> prev_pts, curr_pts;   /* std::vector<cv::Point2f> (GridTracker.h:102-103): centroids are rounded to float */
+	vecd ssm_update, region;
+	double centroid_dist_x, centroid_dist_y;
+	bool reinit_at_each_frame;
+	mtfo_grid_estimator est = nullptr; void *est_user = nullptr;
+
+	/* GridTrackerParams::updateRes SM/src/GridTracker.cc:86-94 */
+	static void update_res(const mtfo_grid_params &gp, int &rx, int &ry) {
+		if (gp.dyn_patch_size || gp.patch_centroid_inside) { rx = gp.grid_size_x + 1; ry = gp.grid_size_y + 1; }
+		else { rx = gp.grid_size_x; ry = gp.grid_size_y; }
+	}
+
+	/* constructor SM/src/GridTracker.cc:97-160 (the checks of :124-134 are made by mtfo_grid_create) */
+	mtfo_grid(const mtfo_grid_params &gp, mtfo_ssm *grid_ssm, mtfo_tracker **trk, int n_trk) : p(gp), ssm(grid_ssm) {
+		update_res(p, resx, resy);
+		n = p.grid_size_x * p.grid_size_y;
+		for (int i = 0; i < n_trk; ++i) trackers.push_back(trk[i]);
+		reinit_at_each_frame = p.reset_at_each_frame == 1;                        /* :136 */
+		const int sub_x = p.grid_size_x + 1, sub_y = p.grid_size_y + 1;            /* :139-146 */
+		linear_idx.resize(static_cast<size_t>(sub_x) * sub_y);
+		for (int idy = 0; idy < sub_y; ++idy)
+			for (int idx = 0; idx < sub_x; ++idx) linear_idx[static_cast<size_t>(idy) * sub_x + idx] = idy * sub_x + idx;
+		patch_corners.assign(static_cast<size_t>(8) * n, 0.0);
+		prev_pts.assign(static_cast<size_t>(2) * n, 0.f); curr_pts = prev_pts;     /* :153-154 */
+		ssm_update.assign(ssm->S, 0.0); region.assign(8, 0.0);
+		centroid_dist_x = p.patch_size_x / 2.0;                                   /* :156-157 */
+		centroid_dist_y = p.patch_size_y / 2.0;
+	}
+	int lin(int r, int c) const { return linear_idx[static_cast<size_t>(r) * (p.grid_size_x + 1) + c]; }
+
+	/* the corners resetTrackers builds for one patch, SM/src/GridTracker.cc:354-380 */
+	void layout_patch(int tracker_id, double *pc /* 8: x, y per corner */) const {
+		const int row_id = tracker_id / p.grid_size_x, col_id = tracker_id % p.grid_size_x;   /* :354-355 */
+		const double *pts = ssm->curr_pts.data();                                              /* ssm.getPts(): 2 x (resx * resy) */
+		/* :357-367 -- the four surrounding grid points TL, TR, BR, BL.  With dyn_patch_size = patch_centroid_inside = 0 the SSM has
+		 * only grid_size^2 points and these reads index past what the layout means (the reference overwrites the result below, and its
+		 * Eigen bounds asserts are compiled out by NDEBUG): they are skipped here. */
+		if (p.dyn_patch_size || p.patch_centroid_inside) {
+			const int id[4] = {lin(row_id, col_id), lin(row_id, col_id + 1), lin(row_id + 1, col_id + 1), lin(row_id + 1, col_id)};
+			for (int q = 0; q < 4; ++q) { pc[2 * q] = pts[2 * id[q]]; pc[2 * q + 1] = pts[2 * id[q] + 1]; }
+		}
+		if (!p.dyn_patch_size) {                                                               /* :369-380 */
+			double cx = pts[2 * tracker_id], cy = pts[2 * tracker_id + 1];                       /* ssm.getPts().col(tracker_id) */
+			if (p.patch_centroid_inside) {                                                       /* utils::getCentroid miscUtils.h:481-487 */
+				cx = (pc[0] + pc[2] + pc[4] + pc[6]) / 4.0;
+				cy = (pc[1] + pc[3] + pc[5] + pc[7]) / 4.0;
+			}
+			/* utils::Corners(cv::Rect_<double>(x, y, w, h)) miscUtils.h:42-52 */
+			const double min_x = cx - centroid_dist_x, min_y = cy - centroid_dist_y;
+			const double max_x = min_x + p.patch_size_x, max_y = min_y + p.patch_size_y;
+			pc[0] = pc[6] = min_x; pc[2] = pc[4] = max_x;
+			pc[1] = pc[3] = min_y; pc[5] = pc[7] = max_y;
+		}
+	}
+	/* utils::getCentroid(cv::Point2f&, corners) miscUtils.h:472-480: rounded to float */
+	static void centroid_f(float *dst, const double *c) {
+		dst[0] = static_cast<float>((c[0] + c[2] + c[4] + c[6]) / 4.0);
+		dst[1] = static_cast<float>((c[1] + c[3] + c[5] + c[7]) / 4.0);
+	}
+	/* GridTracker::resetTrackers SM/src/GridTracker.cc:345-392 */
+	void reset_trackers(bool reinit) {
+		for (int tracker_id = 0; tracker_id < n; ++tracker_id) {
+			double *pc = &patch_corners[static_cast<size_t>(8) * tracker_id];
+			layout_patch(tracker_id, pc);
+			if (!trackers.empty()) {
+				if (reinit) trackers[tracker_id]->initialize(pc);                                /* :381-385 */
+				else trackers[tracker_id]->set_region(pc);
+				centroid_f(&prev_pts[2 * tracker_id], trackers[tracker_id]->ssm->curr_corners.data());   /* :387 */
+			} else centroid_f(&prev_pts[2 * tracker_id], pc);
+		}
+	}
+	/* GridTracker::initialize :233-246 */
+	void initialize(const double *corners) {
+		ssm->set_corners(corners);   /* ssm.initialize(corners) = setCorners + the init flag (StateSpaceModel.h:84-92) */
+		reset_trackers(true);
+		curr_pts = prev_pts;
+		region = ssm->curr_corners;
+	}
+	/* GridTracker::update :247-285 (fb_err_thresh = 0: no forward-backward estimation) */
+	int update() {
+		for (int tracker_id = 0; tracker_id < n; ++tracker_id) {
+			trackers[tracker_id]->update();
+			centroid_f(&curr_pts[2 * tracker_id], trackers[tracker_id]->ssm->curr_corners.data());
+		}
+		if (!est) return -1;
+		est(est_user, n, prev_pts.data(), curr_pts.data(), ssm_update.data());                   /* ssm.estimateWarpFromPts :267 */
+		double opt_warped_corners[8];
+		ssm->apply_warp_to_corners(opt_warped_corners, ssm->curr_corners.data(), ssm_update.data());   /* :270-271 */
+		ssm->set_corners(opt_warped_corners);                                                    /* :272 */
+		if (p.reset_at_each_frame) reset_trackers(reinit_at_each_frame);                         /* :273-274 */
+		else prev_pts = curr_pts;
+		region = ssm->curr_corners;
+		return 0;
+	}
+	/* GridTracker::setRegion :287-292 */
+	void set_region(const double *corners) {
+		ssm->set_corners(corners);
+		reset_trackers(reinit_at_each_frame);
+		region = ssm->curr_corners;
+	}
+};
+
+/* ===================================================================== */
 /* C API                                                                  */
 /* ===================================================================== */
 extern "C" {
@@ -2499,6 +2614,30 @@ int mtfo_pf_iteration_ex(mtfo_am *am, mtfo_ssm *ssm, const mtfo_pf_params *pp, m
 	}
 	if (max_wt_id_out) *max_wt_id_out = max_wt_id;
 	return 0;
+}
+
+/* ---- GridTracker (SM/src/GridTracker.cc) ---- */
+void mtfo_grid_res(const mtfo_grid_params *gp, int *resx, int *resy) { mtfo_grid::update_res(*gp, *resx, *resy); }
+mtfo_grid *mtfo_grid_create(const mtfo_grid_params *gp, mtfo_ssm *grid_ssm, mtfo_tracker **trackers, int n_trackers) {
+	int rx, ry; mtfo_grid::update_res(*gp, rx, ry);
+	if (!grid_ssm || grid_ssm->resx != rx || grid_ssm->resy != ry) return nullptr;            /* GridTracker.cc:130-134 */
+	if (n_trackers != 0 && n_trackers != gp->grid_size_x * gp->grid_size_y) return nullptr;  /* :124-129 (0: layout only) */
+	return new mtfo_grid(*gp, grid_ssm, trackers, n_trackers);
+}
+void mtfo_grid_destroy(mtfo_grid *g) { delete g; }
+void mtfo_grid_set_estimator(mtfo_grid *g, mtfo_grid_estimator est, void *user) { g->est = est; g->est_user = user; }
+void mtfo_grid_initialize(mtfo_grid *g, const double *corners) { g->initialize(corners); }
+int mtfo_grid_update(mtfo_grid *g) { return g->update(); }
+void mtfo_grid_set_region(mtfo_grid *g, const double *corners) { g->set_region(corners); }
+void mtfo_grid_get(const mtfo_grid *g, int what, double *dst) {
+	switch (what) {
+	case 0: std::copy(g->region.begin(), g->region.end(), dst); break;
+	case 1: std::copy(g->patch_corners.begin(), g->patch_corners.end(), dst); break;
+	case 2: for (size_t i = 0; i < g->prev_pts.size(); ++i) dst[i] = g->prev_pts[i]; break;
+	case 3: for (size_t i = 0; i < g->curr_pts.size(); ++i) dst[i] = g->curr_pts[i]; break;
+	case 4: std::copy(g->ssm_update.begin(), g->ssm_update.end(), dst); break;
+	default: break;
+	}
 }
 
 } // extern "C"

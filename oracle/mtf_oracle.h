@@ -217,6 +217,29 @@ int mtfo_pf_iteration_ex(mtfo_am *am, mtfo_ssm *ssm, const mtfo_pf_params *pp, m
 int mtfo_pf_iteration(mtfo_am *am, mtfo_ssm *ssm, const mtfo_pf_params *pp, double *states, double *ars, const double *normals,
 	const double *uniforms, double max_similarity, double *wts_out, int *resample_ids, int *max_wt_id_out);
 
+/* ---- GridTracker (SM/src/GridTracker.cc:20-94 parameters, :97-160 constructor, :233-292 initialize / update / setRegion,
+ * :345-392 resetTrackers): the patch layout over a grid SSM and the frame loop over patch trackers.  The robust fit of the grid
+ * SSM to the patch centroids (estimateWarpFromPts: RANSAC / LMedS, out of scope) is a callback. ---- */
+typedef struct mtfo_grid_params {
+	int grid_size_x, grid_size_y, patch_size_x, patch_size_y;
+	int reset_at_each_frame;      /* 0 never, 1 re-initialise the patch trackers every frame, 2 setRegion only (GridTracker.cc:136) */
+	int dyn_patch_size, patch_centroid_inside;
+} mtfo_grid_params;
+/* estimateWarpFromPts(ssm_update, mask, prev_pts, curr_pts, est_params): n float point pairs -> S doubles */
+typedef void (*mtfo_grid_estimator)(void *user, int n, const float *prev_pts, const float *curr_pts, double *ssm_update);
+typedef struct mtfo_grid mtfo_grid;
+void mtfo_grid_res(const mtfo_grid_params *gp, int *resx, int *resy);   /* GridTrackerParams::updateRes */
+/* grid_ssm: resolution mtfo_grid_res; trackers: grid_size_x * grid_size_y patch trackers, or none (n_trackers 0: initialize / set_region
+ * then only lay the patches out).  NULL on the mismatches the reference's constructor throws for. */
+mtfo_grid *mtfo_grid_create(const mtfo_grid_params *gp, mtfo_ssm *grid_ssm, mtfo_tracker **trackers, int n_trackers);
+void mtfo_grid_destroy(mtfo_grid *g);
+void mtfo_grid_set_estimator(mtfo_grid *g, mtfo_grid_estimator est, void *user);
+void mtfo_grid_initialize(mtfo_grid *g, const double *corners);
+int mtfo_grid_update(mtfo_grid *g);   /* -1 without an estimator */
+void mtfo_grid_set_region(mtfo_grid *g, const double *corners);
+/* what: 0 region corners (8) 1 patch corners handed to the trackers (n x 8) 2 prev_pts (n x 2, float values) 3 curr_pts 4 ssm_update (S) */
+void mtfo_grid_get(const mtfo_grid *g, int what, double *dst);
+
 #ifdef __cplusplus
 }
 #endif

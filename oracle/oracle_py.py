@@ -485,6 +485,91 @@ class Tracker:
         return out
 
 
+class GridParams(C.Structure):
+    """GridTrackerParams (SM/src/GridTracker.cc:20-94); class defaults GridTracker.h:8-24, shipped values Config/modules.cfg:75-80"""
+    _fields_ = [("grid_size_x", C.c_int), ("grid_size_y", C.c_int), ("patch_size_x", C.c_int), ("patch_size_y", C.c_int),
+                ("reset_at_each_frame", C.c_int), ("dyn_patch_size", C.c_int), ("patch_centroid_inside", C.c_int)]
+
+
+_GRID_EST = C.CFUNCTYPE(None, C.c_void_p, C.c_int, _fp, _fp, _dp)
+
+
+def grid_res(gp):
+    rx, ry = C.c_int(), C.c_int()
+    lib().mtfo_grid_res(C.byref(gp), C.byref(rx), C.byref(ry))
+    return rx.value, ry.value
+
+
+class Grid:
+    """GridTracker<SSM> (SM/src/GridTracker.cc) over `trackers` (oracle Tracker objects, one per patch; none = layout only).
+    estimator(prev_pts n x 2, curr_pts n x 2) -> ssm_update stands for ssm.estimateWarpFromPts (out of scope)."""
+
+    def __init__(self, grid_ssm, trackers=(), grid_size=10, patch_size=10, reset_at_each_frame=1, dyn_patch_size=0,
+                 patch_centroid_inside=1, estimator=None, grid_size_y=None, patch_size_y=None):
+        self.gp = GridParams(grid_size, grid_size_y or grid_size, patch_size, patch_size_y or patch_size, reset_at_each_frame,
+                             dyn_patch_size, patch_centroid_inside)
+        self.ssm, self.trackers = grid_ssm, list(trackers)
+        self.n = self.gp.grid_size_x * self.gp.grid_size_y
+        arr = (C.c_void_p * max(1, len(self.trackers)))(*[t.h for t in self.trackers])
+        lib().mtfo_grid_create.restype = C.c_void_p
+        lib().mtfo_grid_create.argtypes = [C.POINTER(GridParams), C.c_void_p, C.POINTER(C.c_void_p), C.c_int]
+        h = lib().mtfo_grid_create(C.byref(self.gp), grid_ssm.h, arr, len(self.trackers))
+        if not h:
+            raise ValueError("GridTracker: mismatch between the grid dimensions and the trackers / the SSM resolution")
+        self.h = C.c_void_p(h)
+        self._cb = None
+        if estimator is not None:
+            self.set_estimator(estimator)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().mtfo_grid_destroy(self.h)
+            self.h = None
+
+    def set_estimator(self, fn):
+        n, S = self.n, self.ssm.S
+
+        def cb(_user, cnt, prev, curr, out):
+            a = np.ctypeslib.as_array(prev, shape=(cnt, 2)).astype(np.float64)
+            b = np.ctypeslib.as_array(curr, shape=(cnt, 2)).astype(np.float64)
+            upd = np.asarray(fn(a, b), dtype=np.float64)
+            for i in range(S):
+                out[i] = upd[i]
+        self._cb = _GRID_EST(cb)
+        lib().mtfo_grid_set_estimator(self.h, self._cb, None)
+
+    def _get(self, what, size):
+        out = np.empty(size)
+        lib().mtfo_grid_get(self.h, what, _d(out))
+        return out
+
+    def initialize(self, corners):
+        lib().mtfo_grid_initialize(self.h, _d(pts_to_flat(corners)))
+
+    def set_region(self, corners):
+        lib().mtfo_grid_set_region(self.h, _d(pts_to_flat(corners)))
+
+    def update(self):
+        if lib().mtfo_grid_update(self.h) != 0:
+            raise RuntimeError("GridTracker.update without an estimator")
+
+    def get_region(self):
+        return self._get(0, 8).reshape(4, 2).T
+
+    def patch_corners(self):
+        """n x 2 x 4: what resetTrackers handed each patch tracker"""
+        return self._get(1, 8 * self.n).reshape(self.n, 4, 2).transpose(0, 2, 1).copy()
+
+    def prev_pts(self):
+        return self._get(2, 2 * self.n).reshape(self.n, 2)
+
+    def curr_pts(self):
+        return self._get(3, 2 * self.n).reshape(self.n, 2)
+
+    def ssm_update(self):
+        return self._get(4, self.ssm.S)
+
+
 def pf_score(am, ssm, states):
     states = np.ascontiguousarray(np.asarray(states, dtype=np.float64))
     n = states.shape[0]
