@@ -788,7 +788,7 @@ def secondary_workload(args):
         patches = gt.patch_corners(region)
 
         def step():
-            gt.update(patches)     # setRegion + update of every patch tracker: one C-ABI call, one upload, one launch of the loop
+            gt.update_patches(patches)     # setRegion + update of every patch tracker: one C-ABI call, one upload, one launch of the loop
         dt = timed(step)
         kernel_pass(step)
         kms, kn = ctx.timing_get("iclk_track")

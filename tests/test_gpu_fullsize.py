@@ -118,21 +118,21 @@ def test_config3_grid_256_patches(gpu_ctx, big_frames):
     patches = gt.patch_corners(region)
     assert patches.shape == (256, 2, 4)
     gpu_ctx.set_image(f1)
-    corners, centroids = gt.update()
+    corners, centroids = gt.update_patches()
     want = np.stack([gt_corners(patches[k], p_true).mean(axis=1) for k in range(256)])
     err = np.abs(centroids - want).max(axis=1)
     assert np.median(err) < 0.05 and (err < 0.5).mean() > 0.97
     # idempotence: re-initialised on the same frame, a second update leaves every patch where it is
     gpu_ctx.set_image(f0); gt.initialize(region)
-    c0, _ = gt.update()
+    c0, _ = gt.update_patches()
     np.testing.assert_allclose(c0, patches, atol=1e-6)
     # the frame loop as GridTracker::update runs it -- every patch tracker reset to the grid, then updated -- in ONE call
     # (mtfhip_batch_track_region) against the two calls, in both arithmetic modes
     for math in (mtf_amd.MATH_FAST, mtf_amd.MATH_REPLAY):
         gt.tracker.batch.set_math_mode(math)
         gpu_ctx.set_image(f1)
-        gt.tracker.set_region(patches); two, _ = gt.update()
-        one, cen = gt.update(region)
+        gt.tracker.set_region(patches); two, _ = gt.update_patches()
+        one, cen = gt.update_patches(region)
         assert np.array_equal(one, two)
         err = np.abs(cen - want).max(axis=1)
         assert np.median(err) < 0.05 and (err < 0.5).mean() > 0.97
@@ -161,7 +161,7 @@ def test_grid_frame_region_mode_equals_separate_reset(gpu_ctx, big_frames, am, s
         for mode in ("0", "1"):
             os.environ["MTFHIP_GRID_FUSED"] = mode
             try:
-                c, cen = gt.update(region)
+                c, cen = gt.update_patches(region)
                 out[mode] = (c.copy(), cen.copy(), gt.tracker.n_iters.copy() if hasattr(gt.tracker, "n_iters") else None,
                              b.read(L.BUF_INIT_PTS).copy(), b.read(L.BUF_INIT_HXY).copy(), b.read(L.BUF_INIT_Z).copy(), b.get_state().copy())
             finally:
@@ -176,10 +176,10 @@ def test_grid_frame_region_mode_equals_separate_reset(gpu_ctx, big_frames, am, s
         os.environ["MTFHIP_GRID_FUSED"] = mode
         try:
             with pytest.raises(mtf_amd.MtfHipError, match="degenerate"):
-                gt.update(bad)
+                gt.update_patches(bad)
         finally:
             del os.environ["MTFHIP_GRID_FUSED"]
-    gt.update(region)   # and the tracker is usable afterwards
+    gt.update_patches(region)   # and the tracker is usable afterwards
 
 
 def test_config4_pf_10000_candidates(gpu_ctx, big_frames):

@@ -1,0 +1,184 @@
+"""GridTracker (SM/src/GridTracker.cc) end to end on the device: the Python driver (mtf_amd.sm.GridTracker) and the C++ driver
+(mtf::hip::Grid, libmtfhost.so) against the oracle's restatement of initialize / update / setRegion / resetTrackers over its own
+per-patch nt:: trackers, frame after frame, in the three patch modes and the three reset modes, for grid SSMs of both kinds and
+regions that are not parallelograms.  The estimator (estimateWarpFromPts: out of scope) is the same function on both sides."""
+import numpy as np
+import pytest
+
+import mtf_amd
+from mtf_amd import _lib as L
+from mtf_amd import host, synth
+from mtf_amd.sm import GridTracker, least_squares_estimator
+
+pytestmark = pytest.mark.gpu
+
+CENTRE = (256.0, 256.0)
+REGIONS = {
+    "square": synth.square_corners(CENTRE[0], CENTRE[1], 280),
+    "quad": synth.square_corners(CENTRE[0], CENTRE[1], 280) + np.array([[3.0, -2.0, 5.0, -4.0], [-1.5, 2.5, 4.0, -3.0]]),
+    "projective": np.array([[130.0, 390, 370, 150], [125, 140, 385, 360]]),
+}
+
+
+def _frames(frame, n, seed):
+    rng = np.random.default_rng(seed)
+    out, cur = [], frame
+    for _ in range(n):
+        cur = synth.warp_frame(cur, synth.random_small_homography(rng, 0.15), CENTRE)
+        out.append(cur)
+    return out
+
+
+def _oracle_grid(oracle, frame, grid_ssm, patch_am, patch_ssm, patch_sm, gs, ps, mode, reset, est, max_iters=20, hess_type=0):
+    dyn, inside = mode
+    gp = oracle.GridParams(gs, gs, ps, ps, reset, dyn, inside)
+    res = oracle.grid_res(gp)
+    gssm = oracle.SSM(grid_ssm, res[0], res[1])
+    ams, trks = [], []
+    for _ in range(gs * gs):
+        am = oracle.AM(patch_am, ps, ps); am.set_curr_img(frame)
+        ssm = oracle.SSM(patch_ssm, ps, ps)
+        trks.append(oracle.Tracker(patch_sm, am, ssm, leven_marq=0, max_iters=max_iters, epsilon=1e-4, hess_type=hess_type))
+        ams.append(am)
+    g = oracle.Grid(gssm, trks, grid_size=gs, patch_size=ps, reset_at_each_frame=reset, dyn_patch_size=dyn, patch_centroid_inside=inside, estimator=est)
+    return g, ams
+
+
+MODES = {"centroid_inside": (0, 1), "grid_points": (0, 0), "dyn_patch": (1, 0)}
+
+
+def _compare(o, patch_corners, prev_pts, curr_pts, region, step):
+    np.testing.assert_allclose(patch_corners, o.patch_corners(), rtol=0, atol=2e-3, err_msg="patch corners, frame %d" % step)
+    np.testing.assert_allclose(prev_pts, o.prev_pts(), rtol=0, atol=2e-3, err_msg="prev_pts, frame %d" % step)
+    if curr_pts is not None:
+        np.testing.assert_allclose(curr_pts, o.curr_pts(), rtol=0, atol=2e-3, err_msg="curr_pts, frame %d" % step)
+    np.testing.assert_allclose(region, o.get_region(), rtol=0, atol=2e-3, err_msg="region, frame %d" % step)
+
+
+@pytest.mark.parametrize("mode", sorted(MODES))
+@pytest.mark.parametrize("reset", [1, 2, 0])
+@pytest.mark.parametrize("region,grid_ssm", [("square", L.SSM_HOMOGRAPHY), ("quad", L.SSM_HOMOGRAPHY), ("projective", L.SSM_HOMOGRAPHY), ("quad", L.SSM_AFFINE)])
+def test_python_grid_tracker_follows_oracle(oracle, gpu_ctx, frame, mode, reset, region, grid_ssm):
+    gs, ps = 5, 25
+    est = least_squares_estimator(grid_ssm)
+    frames = _frames(frame, 3, 77)
+    o, ams = _oracle_grid(oracle, frame, grid_ssm, oracle.AM_NCC, oracle.SSM_AFF, oracle.SM_ICLK, gs, ps, MODES[mode], reset, est)
+    gpu_ctx.set_image(frame)
+    g = GridTracker(gpu_ctx, grid_size=gs, patch_size=ps, am=L.AM_NCC, ssm=L.SSM_AFFINE, max_iters=20, epsilon=1e-4, reset_at_each_frame=reset,
+                    dyn_patch_size=MODES[mode][0], patch_centroid_inside=MODES[mode][1], grid_ssm=grid_ssm, estimator=est)
+    assert g.res() == oracle.grid_res(o.gp)
+    g.initialize(REGIONS[region]); o.initialize(REGIONS[region])
+    # the layout itself to 1e-9 px (the verdict's bar), then the tracked quantities
+    np.testing.assert_allclose(g.patch_corners(REGIONS[region]), o.patch_corners(), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(g.grid_pts(REGIONS[region]), o.ssm.get("curr_pts").reshape(-1, 2), rtol=0, atol=1e-9)
+    _compare(o, g.patch_corners(g.get_region()), g.prev_pts, g.curr_pts, g.get_region(), 0)
+    for k, f in enumerate(frames):
+        gpu_ctx.set_image(f)
+        for am in ams:
+            am.set_curr_img(f)
+        g.update(); o.update()
+        np.testing.assert_allclose(g.ssm_update, o.ssm_update(), rtol=0, atol=2e-5)
+        _compare(o, g.patch_corners(g.get_region()) if reset else o.patch_corners(), g.prev_pts, g.curr_pts, g.get_region(), k + 1)
+    # setRegion between frames (GridTracker.cc:287-292)
+    moved = g.get_region() + np.array([[1.5], [-0.75]])
+    g.set_region(moved); o.set_region(moved)
+    gpu_ctx.set_image(frames[0])
+    for am in ams:
+        am.set_curr_img(frames[0])
+    g.update(); o.update()
+    _compare(o, g.patch_corners(g.get_region()) if reset else o.patch_corners(), g.prev_pts, g.curr_pts, g.get_region(), 9)
+    g.tracker.batch.close()
+
+
+@pytest.mark.parametrize("patch_sm,patch_am,patch_ssm,hess", [(L.SM_FCLK, L.AM_SSD, L.SSM_HOMOGRAPHY, 1), (L.SM_ESM, L.AM_NCC, L.SSM_AFFINE, 2)])
+def test_python_grid_tracker_other_patch_trackers(oracle, gpu_ctx, frame, patch_sm, patch_am, patch_ssm, hess):
+    """grid_sm / grid_am / grid_ssm are free in the reference (mtf.h:777-801): FCLK + SSD + homography and ESM + NCC + affine patches,
+    which take the launch-per-pass device loop instead of the one-launch ICLK kernel"""
+    gs, ps = 3, 30
+    est = least_squares_estimator(L.SSM_HOMOGRAPHY)
+    frames = _frames(frame, 2, 78)
+    o, ams = _oracle_grid(oracle, frame, L.SSM_HOMOGRAPHY, patch_am, patch_ssm, patch_sm, gs, ps, (0, 1), 1, est, hess_type=hess)
+    gpu_ctx.set_image(frame)
+    g = GridTracker(gpu_ctx, grid_size=gs, patch_size=ps, am=patch_am, ssm=patch_ssm, sm=patch_sm, max_iters=20, epsilon=1e-4, hess_type=hess, estimator=est)
+    g.initialize(REGIONS["quad"]); o.initialize(REGIONS["quad"])
+    for k, f in enumerate(frames):
+        gpu_ctx.set_image(f)
+        for am in ams:
+            am.set_curr_img(f)
+        g.update(); o.update()
+        _compare(o, g.patch_corners(g.get_region()), g.prev_pts, g.curr_pts, g.get_region(), k + 1)
+    g.tracker.batch.close()
+
+
+@pytest.mark.parametrize("mode,reset,region,grid_ssm", [("centroid_inside", 1, "quad", L.SSM_HOMOGRAPHY), ("centroid_inside", 2, "projective", L.SSM_HOMOGRAPHY),
+                                                        ("grid_points", 1, "square", L.SSM_AFFINE), ("dyn_patch", 0, "quad", L.SSM_HOMOGRAPHY),
+                                                        ("dyn_patch", 1, "projective", L.SSM_AFFINE)])
+def test_cpp_grid_driver_follows_oracle(oracle, frame, mode, reset, region, grid_ssm):
+    """mtf::hip::Grid (libmtfhost.so) with the reference's parameter block: setImage / initialize / update / setRegion / getRegion"""
+    gs, ps = 5, 25
+    est = least_squares_estimator(grid_ssm)
+    frames = _frames(frame, 3, 79)
+    o, ams = _oracle_grid(oracle, frame, grid_ssm, oracle.AM_NCC, oracle.SSM_AFF, oracle.SM_ICLK, gs, ps, MODES[mode], reset, est)
+    g = host.CppGridTracker(grid_size=gs, patch_size=ps, patch_sm=L.SM_ICLK, patch_am=L.AM_NCC, patch_ssm=L.SSM_AFFINE, grid_ssm=grid_ssm,
+                            reset_at_each_frame=reset, dyn_patch_size=MODES[mode][0], patch_centroid_inside=MODES[mode][1], max_iters=20, epsilon=1e-4,
+                            hess_type=0, estimator=est)
+    g.set_image(frame)
+    g.initialize(REGIONS[region]); o.initialize(REGIONS[region])
+    np.testing.assert_allclose(g.patch_corners(), o.patch_corners(), rtol=0, atol=1e-9)
+    _compare(o, g.patch_corners(), g.prev_pts(), g.curr_pts(), g.get_region(), 0)
+    for k, f in enumerate(frames):
+        g.set_image(f)
+        for am in ams:
+            am.set_curr_img(f)
+        g.update(); o.update()
+        np.testing.assert_allclose(g.ssm_update(), o.ssm_update(), rtol=0, atol=2e-5)
+        _compare(o, g.patch_corners() if reset else o.patch_corners(), g.prev_pts(), g.curr_pts(), g.get_region(), k + 1)
+    moved = g.get_region() + np.array([[-2.0], [1.25]])
+    g.set_region(moved); o.set_region(moved)
+    g.set_image(frames[1])
+    for am in ams:
+        am.set_curr_img(frames[1])
+    g.update(); o.update()
+    _compare(o, g.patch_corners() if reset else o.patch_corners(), g.prev_pts(), g.curr_pts(), g.get_region(), 9)
+
+
+def test_cpp_grid_driver_builtin_estimator_and_refusals(frame):
+    """the built-in all-points least-squares fit (normal equations in the normalised frame) against the NumPy one (SVD), and the
+    constructor's refusals (GridTracker.cc:124-134 equivalents)"""
+    g = host.CppGridTracker(grid_size=6, patch_size=25, max_iters=15, hess_type=0)
+    g.set_image(frame)
+    g.initialize(REGIONS["quad"])
+    f2 = _frames(frame, 1, 80)[0]
+    g.set_image(f2)
+    g.update()
+    assert np.isfinite(g.get_region()).all()
+    # (with reset_at_each_frame = 1 prev_pts are replaced by the reset: the fit is checked on instances that do not reset)
+    h = host.CppGridTracker(grid_size=6, patch_size=25, max_iters=15, hess_type=0, reset_at_each_frame=0)
+    h.set_image(frame); h.initialize(REGIONS["quad"])
+    prev = h.prev_pts().copy()
+    h.set_image(f2); h.update()
+    # (h22 = 1 against |h| = 1: two algebraic least-squares problems that agree on the noise-free fit, so they are compared through
+    # what they do to the region's corners, not entry by entry)
+    from mtf_amd.api import apply_warp_to_pts
+    want = least_squares_estimator(L.SSM_HOMOGRAPHY)(prev, h.curr_pts())
+    np.testing.assert_allclose(apply_warp_to_pts(L.SSM_HOMOGRAPHY, REGIONS["quad"], h.ssm_update()),
+                               apply_warp_to_pts(L.SSM_HOMOGRAPHY, REGIONS["quad"], want), rtol=0, atol=1e-3)
+    a = host.CppGridTracker(grid_size=6, patch_size=25, max_iters=15, hess_type=0, reset_at_each_frame=0, grid_ssm=L.SSM_AFFINE)
+    a.set_image(frame); a.initialize(REGIONS["quad"])
+    prev = a.prev_pts().copy()
+    a.set_image(f2); a.update()
+    np.testing.assert_allclose(a.ssm_update(), least_squares_estimator(L.SSM_AFFINE)(prev, a.curr_pts()), rtol=0, atol=1e-8)
+    with pytest.raises(host.HostError):
+        host.CppGridTracker(grid_size=0, patch_size=25)
+    with pytest.raises(host.HostError, match="before initialize"):
+        host.CppGridTracker(grid_size=2, patch_size=25).update()
+
+
+def test_grid_frame_abi_refuses_a_mismatched_batch(gpu_ctx, frame):
+    gpu_ctx.set_image(frame)
+    g = GridTracker(gpu_ctx, grid_size=3, patch_size=25, max_iters=5)
+    g.initialize(REGIONS["square"])
+    wrong = L.GridDesc(4, 4, 25, 25, 1, 0, 1)
+    with pytest.raises(mtf_amd.MtfHipError, match="mismatch between the grid dimensions"):
+        g.tracker.batch.grid_frame(wrong, g.tracker.sm, REGIONS["square"])
+    g.tracker.batch.close()

@@ -232,7 +232,7 @@ def test_grid_patch_trackers_one_launch(oracle, gpu_ctx, frame, am, ssm):
     gt.initialize(region)
     patches = gt.patch_corners(region)
     gpu_ctx.set_image(frame2)
-    corners, centroids = gt.update()
+    corners, centroids = gt.update_patches()
     assert corners.shape == (36, 2, 4) and centroids.shape == (36, 2)
     for t in range(0, 36, 5):
         o_ssm = oracle.SSM(ssm, 25, 25); o_am = oracle.AM(am, 25, 25); o_am.set_curr_img(frame)
@@ -268,8 +268,8 @@ def test_track_region_equals_set_region_then_track(gpu_ctx, frame, sm_kind, am):
         frame2 = synth.warp_frame(frame, synth.random_small_homography(rng, 0.2), centre)
         gpu_ctx.set_image(frame2)
         a.tracker.set_region(patches)
-        ca, _ = a.update()
-        cb, _ = b.update(region if k % 2 == 0 else patches)
+        ca, _ = a.update_patches()
+        cb, _ = b.update_patches(region if k % 2 == 0 else patches)
         assert np.array_equal(ca, cb)
         assert np.array_equal(a.n_iters, b.n_iters)
         assert np.array_equal(a.tracker.get_region(), b.tracker.get_region())
@@ -297,8 +297,8 @@ def test_copy_and_sync_fallback_gives_the_same_results(gpu_ctx, frame, monkeypat
                             likelihood_alpha=5.0, mean_type=1)
         pf.initialize(synth.square_corners(250.0, 240.0, 60)[None])
         gpu_ctx.set_image(frame2)
-        c1, _ = g.update(region)
-        c2, _ = g.update()
+        c1, _ = g.update_patches(region)
+        c2, _ = g.update_patches()
         l1 = lk.update().copy()
         lk.set_region(lk.get_region()); l2 = lk.update().copy()
         pf.iteration(normals, uniforms)

@@ -13,11 +13,11 @@ gt.initialize(region); ctx.set_image(f1)
 pcs = [gt.patch_corners(region + np.array([[dx], [dy]])) for dx, dy in ((0, 0), (1.25, -0.5), (-2.0, 0.75))]
 ref = []
 for pc in pcs:
-    c, cen = gt.update(pc); ref.append((c.copy(), cen.copy(), gt.n_iters.copy()))
+    c, cen = gt.update_patches(pc); ref.append((c.copy(), cen.copy(), gt.n_iters.copy()))
 bad = 0
 for k in range(6000):
     i = k % 3
-    c, cen = gt.update(pcs[i])
+    c, cen = gt.update_patches(pcs[i])
     if not (np.array_equal(c, ref[i][0]) and np.array_equal(cen, ref[i][1]) and np.array_equal(gt.n_iters, ref[i][2])):
         bad += 1
 print("frames 6000 mismatches", bad)

@@ -21,7 +21,7 @@ lib = L.lib()
 lib.mtfhip_debug_grid_trace.argtypes = [C.c_void_p]
 n = 0
 for k in range(60):
-    gt.update(pc)
+    gt.update_patches(pc)
     if k >= 10:
         t = np.zeros(32, dtype=np.uint64)
         lib.mtfhip_debug_grid_trace(t.ctypes.data_as(C.c_void_p))
