@@ -463,6 +463,7 @@ int mtfhip_batch_write(mtfhip_batch *b, int id, const double *src) {
 	if (id == MTFHIP_BUF_J0 || id == MTFHIP_BUF_DI0_DX || id == MTFHIP_BUF_INIT_PTS || id == MTFHIP_BUF_INIT_Z) b->j0_is_template = false;
 	/* a caller that supplies its own homogeneous grid gets the general (non unit-z) kernels */
 	if (id == MTFHIP_BUF_INIT_Z || id == MTFHIP_BUF_INIT_HXY) b->unit_z = 0;
+	if (id == MTFHIP_BUF_INIT_PTS || id == MTFHIP_BUF_INIT_Z || id == MTFHIP_BUF_INIT_HXY) b->grid_from_corners = false;
 	return MTFHIP_OK;
 }
 
@@ -472,6 +473,7 @@ void *mtfhip_batch_device_ptr(mtfhip_batch *b, int id) {
 	if (lazy_flush(b) != MTFHIP_OK || ensure_df(b) != MTFHIP_OK) return nullptr;
 	b->lz.enabled = false; b->lz.no_cache = true;
 	if (ensure_buf(b, id) != MTFHIP_OK) return nullptr;
+	if (id == MTFHIP_BUF_INIT_PTS || id == MTFHIP_BUF_INIT_Z || id == MTFHIP_BUF_INIT_HXY) b->grid_from_corners = false;   /* (the caller may lay out its own grid) */
 	return b->buf[id];
 }
 
@@ -536,6 +538,9 @@ int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track, boo
 	 * the rest of the staged slab are written by set_corners_finish_deferred() AFTER the launch, while the device works
 	 * (2-2.5 us of a 45 us frame at 256 patches). */
 	if (defer_grid && !hom) {
+		/* (r04 advisor: nothing is committed before the corners have been looked at -- the cheap part of the map's degeneracy test) */
+		for (int t = 0; t < b->B; ++t)
+			if (quad_degenerate_hd(corners + 8 * t)) return fail(MTFHIP_ERR_INVALID_ARG, "set_corners: degenerate corners for target %d", t);
 		std::memcpy(s_cr, corners, sizeof(double) * 8 * Bt);
 		for (int t = 0; t < b->B; ++t) {
 			const TargetHost &h = b->th[t];
@@ -544,6 +549,7 @@ int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track, boo
 		}
 		b->deferred_corners = corners; b->deferred_for_track = for_track;
 		b->unit_z = 1;
+		b->grid_from_corners = true;
 		b->warps_dirty = false;
 		b->have_corners = true;
 		b->pts_stale = true;
@@ -579,6 +585,7 @@ int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track, boo
 		if (for_track) s_it[t] = 0;
 	}
 	b->unit_z = hom ? unit_z : 1;
+	b->grid_from_corners = true;   /* (k_init_grid, or the grid kernel's region mode, lays the lattice out inside these corners) */
 	if (defer_grid) {
 		b->warps_dirty = false;   /* the kernel that follows starts every target from the identity */
 		b->have_corners = true;

@@ -1077,10 +1077,10 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 		}
 	} else if (one_launch) {
 		TimedScope tsc(b->ctx, "iclk_track");
-		HostPublish pub{nullptr, 0, 0, nullptr, nullptr, 0};
+		HostPublish pub{nullptr, 0, 0, nullptr, nullptr, 0, 0};
 		if (b->h_pub_dev) {
 			pub_seq = ++b->acc_seq;
-			pub = HostPublish{b->h_pub_dev, b->slab_dbl_bytes, b->B, b->d_fin_count, b->h_flag_dev, pub_seq};
+			pub = HostPublish{b->h_pub_dev, b->slab_dbl_bytes, b->B, b->d_fin_count, b->h_flag_dev, pub_seq, publish_fenced()};
 		}
 		RegionIngest rg{};
 		if (region_mode) {
@@ -1341,7 +1341,7 @@ int score_block_dev(mtfhip_batch *b, const double *dev_states, int lo, int cnt, 
 	 * what lets the scorer skip the border test of a candidate whose warped corners are inside the frame */
 	double hull_buf[8];
 	const double *hull = nullptr;
-	if (b->unit_z && b->B >= 1) {
+	if (b->unit_z && b->grid_from_corners && b->B >= 1) {
 		const double *ic = b->th[0].init_corners_hm;
 		bool unit = true;
 		for (int q = 0; q < 4; ++q) { hull_buf[2 * q] = ic[3 * q]; hull_buf[2 * q + 1] = ic[3 * q + 1]; unit = unit && ic[3 * q + 2] == 1.0; }

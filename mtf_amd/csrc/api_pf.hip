@@ -114,8 +114,8 @@ struct mtfhip_pf {
 	double *d_distr = nullptr, *d_scan_stats = nullptr, *d_distr_u = nullptr;
 	int *d_distr_ids = nullptr, *d_resample_flag = nullptr;
 	std::vector<double> distr_u_next;
-	/* the peer-store exchange (mtfhip_pf_set_exchange; PfPeerPush / PfPeerWait in mtfhip_internal.h).  mailbox: wts[2][cap] doubles |
-	 * counters[kPfMaxPeers] | the storing launch's own arrival counter; base[q]: rank q's mailbox as this process addresses it (own rank: mailbox; RCCL ranks: an IPC mapping;
+	/* the peer-store exchange (mtfhip_pf_set_exchange; PfPeerPush / PfPeerWait in mtfhip_internal.h).  mailbox: header (counters[kPfMaxPeers] |
+	 * the storing launch's own arrival counter | seed | n | cap) | wts[2][cap] doubles; base[q]: rank q's mailbox as this process addresses it (own rank: mailbox; RCCL ranks: an IPC mapping;
 	 * loopback ranks: the pointer itself) */
 	struct Peer {
 		bool on = false;
@@ -125,11 +125,14 @@ struct mtfhip_pf {
 		bool mapped[kPfMaxPeers] = {};
 		unsigned long long epoch = 0, expected[kPfMaxPeers] = {};
 		int *h_err = nullptr, *h_err_dev = nullptr;
-		/* behind the two weight vectors: counters[kPfMaxPeers] | the storing launch's own arrival counter | the filter's seed */
-		static constexpr int kTailWords = kPfMaxPeers + 2;
-		double *wts(int q, int parity) const { return static_cast<double *>(base[q]) + (size_t)parity * cap; }
-		unsigned long long *counters(int q) const { return reinterpret_cast<unsigned long long *>(static_cast<double *>(base[q]) + 2 * cap); }
-		unsigned long long *seed_slot(int q) const { return counters(q) + kPfMaxPeers + 1; }
+		/* a FIXED-SIZE header in front of the two weight vectors -- counters[kPfMaxPeers] | the storing launch's own arrival counter | the
+		 * filter's seed | its particle count | its vector capacity -- so that a rank can read what a peer was created with BEFORE it
+		 * addresses anything whose position depends on it (r04 advisor: ranks created with different n_particles / capacities stored
+		 * outside the peer's allocation) */
+		static constexpr int kHeadWords = (kPfMaxPeers + 4 + 15) & ~15;   /* whole 128-byte lines: the vectors stay line aligned */
+		double *wts(int q, int parity) const { return static_cast<double *>(base[q]) + kHeadWords + (size_t)parity * cap; }
+		unsigned long long *counters(int q) const { return static_cast<unsigned long long *>(base[q]); }
+		unsigned long long *seed_slot(int q) const { return counters(q) + kPfMaxPeers + 1; }   /* seed | n_particles | cap */
 	} peer;
 	/* the weights of the last iteration: the mailbox vector of the last exchange, or d_wts */
 	double *last_wts() const { return peer.on && peer.epoch ? peer.wts(comm->rank, (int)(peer.epoch & 1)) : d_wts; }
@@ -404,19 +407,27 @@ int mtfhip_pf_set_comm(mtfhip_pf *pf, mtfhip_comm *c) {
 		 * silently wrong estimate (r03 advisor finding: a front end that randomised seed 0 per process). */
 		if (c->detached) return MTFHIP_OK;   /* (no collective: the seeds are compared through the mailboxes, mtfhip_pf_exchange_connect) */
 		hipStream_t st = pf->b->ctx->stream;
-		double mine; static_assert(sizeof(mine) == sizeof(pf->d.seed), "the seed travels as the bits of one double");
-		std::memcpy(&mine, &pf->d.seed, sizeof(mine));
-		std::vector<double> all((size_t)c->world);
-		HIP_TRY(hipMemcpyAsync(pf->d_wts + c->rank, &mine, sizeof(double), hipMemcpyHostToDevice, st));
-		TRY(mtfhip_allgather_scores(c, pf->d_wts + c->rank, 1, pf->d_wts, st));
-		HIP_TRY(hipMemcpyAsync(all.data(), pf->d_wts, sizeof(double) * (size_t)c->world, hipMemcpyDeviceToHost, st));
-		HIP_TRY(hipStreamSynchronize(st));
-		for (int q = 0; q < c->world; ++q)
-			if (std::memcmp(&all[(size_t)q], &mine, sizeof(double)) != 0) {
-				pf->comm = nullptr;
-				return fail(MTFHIP_ERR_INVALID_ARG, "pf_set_comm: rank %d's filter was created with another seed than rank %d's: a sharded filter needs "
-					"ONE seed on every rank (identical proposals)", q, c->rank);
-			}
+		static_assert(sizeof(double) == sizeof(pf->d.seed), "the seed travels as the bits of one double");
+		/* ... and the particle count: every rank lays the gathered weights out with its own n (r04 advisor) */
+		for (int what = 0; what < 2; ++what) {
+			double mine;
+			if (what == 0) std::memcpy(&mine, &pf->d.seed, sizeof(mine)); else mine = (double)pf->n;
+			std::vector<double> all((size_t)c->world);
+			HIP_TRY(hipMemcpyAsync(pf->d_wts + c->rank, &mine, sizeof(double), hipMemcpyHostToDevice, st));
+			HIP_TRY(hipStreamSynchronize(st));
+			TRY(mtfhip_allgather_scores(c, pf->d_wts + c->rank, 1, pf->d_wts, st));
+			HIP_TRY(hipMemcpyAsync(all.data(), pf->d_wts, sizeof(double) * (size_t)c->world, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipStreamSynchronize(st));
+			for (int q = 0; q < c->world; ++q)
+				if (std::memcmp(&all[(size_t)q], &mine, sizeof(double)) != 0) {
+					pf->comm = nullptr;
+					if (what == 0)
+						return fail(MTFHIP_ERR_INVALID_ARG, "pf_set_comm: rank %d's filter was created with another seed than rank %d's: a sharded filter needs "
+							"ONE seed on every rank (identical proposals)", q, c->rank);
+					return fail(MTFHIP_ERR_INVALID_ARG, "pf_set_comm: rank %d's filter holds %d particles, rank %d's %d: a sharded filter needs the same n_particles on every rank",
+						q, (int)all[(size_t)q], c->rank, pf->n);
+				}
+		}
 	}
 	return MTFHIP_OK;
 }
@@ -440,11 +451,12 @@ static int pf_peer_alloc(mtfhip_pf *pf) {
 	int lo, cnt, m;
 	pf_shard(pf->n, c->world, c->rank, &lo, &cnt, &m);
 	pr.cap = (std::max(pf->wts_capacity, (size_t)m * c->world) + 1) & ~(size_t)1;
-	const size_t bytes = sizeof(double) * 2 * pr.cap + sizeof(unsigned long long) * mtfhip_pf::Peer::kTailWords;
+	const size_t bytes = sizeof(double) * 2 * pr.cap + sizeof(unsigned long long) * mtfhip_pf::Peer::kHeadWords;
 	HIP_TRY(hipExtMallocWithFlags(&pr.mailbox, bytes, hipDeviceMallocFinegrained));
 	HIP_TRY(hipMemsetAsync(pr.mailbox, 0, bytes, st));
 	pr.base[c->rank] = pr.mailbox;
-	HIP_TRY(hipMemcpyAsync(pr.seed_slot(c->rank), &pf->d.seed, sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+	const unsigned long long ident[3] = {pf->d.seed, (unsigned long long)pf->n, (unsigned long long)pr.cap};
+	HIP_TRY(hipMemcpyAsync(pr.seed_slot(c->rank), ident, sizeof(ident), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pr.h_err), sizeof(int), hipHostMallocMapped));
 	*pr.h_err = 0;
 	HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&pr.h_err_dev), pr.h_err, 0));
@@ -457,12 +469,16 @@ static int pf_peer_finish(mtfhip_pf *pf) {
 	mtfhip_pf::Peer &pr = pf->peer;
 	hipStream_t st = pf->b->ctx->stream;
 	for (int q = 0; q < c->world; ++q) {
-		unsigned long long theirs = 0;
-		HIP_TRY(hipMemcpyAsync(&theirs, pr.seed_slot(q), sizeof(theirs), hipMemcpyDeviceToHost, st));
+		unsigned long long theirs[3] = {0, 0, 0};   /* seed | n_particles | capacity: at fixed offsets of the peer's mailbox */
+		HIP_TRY(hipMemcpyAsync(theirs, pr.seed_slot(q), sizeof(theirs), hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
-		if (theirs != pf->d.seed)
+		if (theirs[0] != pf->d.seed)
 			return fail(MTFHIP_ERR_INVALID_ARG, "pf exchange: rank %d's filter was created with another seed than rank %d's: a sharded filter needs ONE seed "
 				"on every rank (identical proposals)", q, c->rank);
+		/* every rank addresses the peers' vectors with its own particle count and capacity: they must be the peers' too */
+		if (theirs[1] != (unsigned long long)pf->n || theirs[2] != (unsigned long long)pr.cap)
+			return fail(MTFHIP_ERR_INVALID_ARG, "pf exchange: rank %d's filter holds %llu particles in vectors of %llu, rank %d's %d in %zu: a sharded filter needs "
+				"the same n_particles on every rank", q, theirs[1], theirs[2], c->rank, pf->n, pr.cap);
 	}
 	pr.on = true;
 	return MTFHIP_OK;
@@ -698,21 +714,25 @@ static int pf_enqueue_iteration(mtfhip_pf *pf, const double *normals, const doub
 		return fail(MTFHIP_ERR_LOGIC, "pf_iteration: a filter sharded over a detached communicator needs the peer exchange connected first (mtfhip_pf_exchange_export / _connect)");
 	PfPeerPush push{};
 	PfPeerWait pwait{};
+	/* (the exchange's epoch and the expected arrival counts are committed only once the storing launch has been enqueued: a call that
+	 * fails before it must not leave this rank one exchange ahead of its peers -- every later wait would then spin to its limit) */
+	unsigned long long new_epoch = pf->peer.epoch, new_expected[kPfMaxPeers] = {};
 	if (peer) {
 		mtfhip_pf::Peer &pr = pf->peer;
-		const int parity = (int)(++pr.epoch & 1);
+		new_epoch = pr.epoch + 1;
+		const int parity = (int)(new_epoch & 1);
 		push.world = pwait.world = c->world; push.rank = pwait.rank = c->rank;
 		for (int q = 0; q < c->world; ++q) {
 			int qlo, qcnt, qm;
 			pf_shard(n, c->world, q, &qlo, &qcnt, &qm);
-			pr.expected[q] += qcnt > 0 ? 1u : 0u;   /* one arrival per storing launch; an empty block launches nothing */
+			new_expected[q] = pr.expected[q] + (qcnt > 0 ? 1u : 0u);   /* one arrival per storing launch; an empty block launches nothing */
 			push.wts[q] = pr.wts(q, parity); push.counters[q] = pr.counters(q);
 			push.arrive = reinterpret_cast<unsigned *>(pr.counters(c->rank) + kPfMaxPeers);   /* (the word behind the counters) */
-			pwait.expected[q] = pr.expected[q];
+			pwait.expected[q] = new_expected[q];
 		}
 		pwait.counters = pr.counters(c->rank); pwait.err = pr.h_err_dev;
 	}
-	bf.wts = peer ? pf->peer.wts(c->rank, (int)(pf->peer.epoch & 1)) : pf->d_wts; bf.sim = nullptr; bf.cum = pf->d_cum; bf.chunk_tot = pf->d_chunk; bf.chunk_incl = pf->d_chunk + nch; bf.sub16 = pf->d_chunk + 2 * nch;
+	bf.wts = peer ? pf->peer.wts(c->rank, (int)(new_epoch & 1)) : pf->d_wts; bf.sim = nullptr; bf.cum = pf->d_cum; bf.chunk_tot = pf->d_chunk; bf.chunk_incl = pf->d_chunk + nch; bf.sub16 = pf->d_chunk + 2 * nch;
 	bf.res_order = nullptr;
 	bf.parts = pf->d_parts; bf.gparts = pf->d_gparts; bf.out = pf->d_out; bf.ids = pf->d_ids; bf.counters = pf->d_counters;
 	/* scoring: setState -> updatePixVals -> updateSimilarity -> likelihood per particle (PF.cc:341-365); sharded: this rank's block */
@@ -721,6 +741,8 @@ static int pf_enqueue_iteration(mtfhip_pf *pf, const double *normals, const doub
 		TRY(score_block_dev(b, bf.prop, lo, cnt, bf.wts, bf.sim, p.likelihood_func, p.measurement_sigma, p.max_similarity, peer ? &push : nullptr));
 	}
 	if (peer) {
+		pf->peer.epoch = new_epoch;
+		for (int q = 0; q < c->world; ++q) pf->peer.expected[q] = new_expected[q];
 		/* Loopback ranks share one GPU and its few hardware queues: a spinning scan of one rank could sit in front of the scoring launch of
 		 * another.  There the host threads meet once every rank's scoring has completed, and the waits below pass at once; the stores, the
 		 * counters and the two mailbox vectors are exercised as between GPUs.  RCCL ranks (one GPU each) enqueue straight through. */

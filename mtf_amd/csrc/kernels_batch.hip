@@ -168,8 +168,8 @@ __device__ __forceinline__ double pix_val_select(const ImgView &im, double x, do
  * last workgroup of the launch releases the host (one kernel launch and its gap less per frame than k_publish_host).
  * Called by wave 0 only, lane q holding entry q: the stores are system-scope (write-through to the pinned page), ONE agent-scope
  * release per workgroup orders them before the counter -- a system-scope fence in every wave of every workgroup walks the L2
- * for dirty lines 1024 times and cost 25 us of a 47 us launch -- and only the last arriver pays the system-scope release
- * (cumulative over the counter it acquired) before it raises the flag. */
+ * for dirty lines 1024 times and cost 25 us of a 47 us launch -- and (fenced form) only the last arriver pays the system-scope release
+ * before it raises the flag. */
 __device__ __forceinline__ void publish_target(const HostPublish &pub, int t, double wq, double sq, double cq, int n_it) {
 	const int lane = threadIdx.x;
 	double *p = reinterpret_cast<double *>(pub.host);
@@ -180,34 +180,27 @@ __device__ __forceinline__ void publish_target(const HostPublish &pub, int t, do
 		__hip_atomic_store(p + 17 * Bt + 8 * (size_t)t + lane, cq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 	if (lane == 0) __hip_atomic_store(reinterpret_cast<int *>(pub.host + pub.dbl_bytes) + Bt + t, n_it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#ifdef MTFHIP_GRID_PUBLISH_FENCE
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   /* (the whole wave's stores: s_waitcnt vmcnt(0) is per wave) */
-#else
-	/* The stores above are write-through (system scope): when the wave's vmcnt has drained they are performed, which is all the
-	 * counter has to order -- an agent-scope release here and an acq_rel on the counter wrote this XCD's L2 back twice and invalidated
-	 * it once per workgroup (the launch has just laid 6 MB of template grids into the L2s): ~3 of the 7 us between the last iteration
-	 * and the end of the workgroup, r04 phase trace.  The counter itself is an agent-scope atomic: performed at the memory side. */
-	wait_stores_acked();
-#endif
+	/* Default: the stores above are write-through (system scope): when the wave's vmcnt has drained they are performed, which is all
+	 * the counter has to order -- an agent-scope release here and an acq_rel on the counter wrote this XCD's L2 back twice and
+	 * invalidated it once per workgroup (the launch has just laid 6 MB of template grids into the L2s): ~3 of the 7 us between the last
+	 * iteration and the end of the workgroup, r04 phase trace.  The counter itself is an agent-scope atomic: performed at the memory
+	 * side.  pub.fenced (MTFHIP_PUBLISH_FENCE=1, publish_fenced()): the release / acq_rel / system-release form the memory model asks for. */
+	if (pub.fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   /* (the whole wave's stores: s_waitcnt vmcnt(0) is per wave) */
+	else wait_stores_acked();
 	if (lane == 0) {
-#ifdef MTFHIP_GRID_PUBLISH_FENCE
-		const int done = __hip_atomic_fetch_add(pub.count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-#else
-		const int done = __hip_atomic_fetch_add(pub.count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
+		const int done = pub.fenced ? __hip_atomic_fetch_add(pub.count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+		                            : __hip_atomic_fetch_add(pub.count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (done == (int)gridDim.x - 1) {
 			__hip_atomic_store(pub.count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			/* Every workgroup's results left as system-scope (write-through) stores that were acknowledged before it counted itself in,
-			 * and this one has acquired the counter: they are performed, and the flag -- one more posted write of the same device -- cannot
-			 * pass them on the link.  A system-scope RELEASE here (r03: __threadfence_system + a release store) writes back the whole L2
-			 * twice -- since r04 that includes the 6 MB of template grids the same launch laid out -- for nothing the host reads:
-			 * 2.5 us of a 50 us frame (MTFHIP_GRID_PUBLISH_FENCE=1 at build time keeps the fences). */
-#ifdef MTFHIP_GRID_PUBLISH_FENCE
-			__threadfence_system();
-			__hip_atomic_store(pub.flag, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-#else
-			__hip_atomic_store(pub.flag, pub.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#endif
+			 * and this one has read the counter they all bumped (a RELAXED read-modify-write at the memory side, not an acquire): the
+			 * stores are performed, and the flag -- one more posted write of the same device -- cannot pass them on the link.  A
+			 * system-scope RELEASE here (r03: __threadfence_system + a release store) writes back the whole L2 twice -- since r04 that
+			 * includes the 6 MB of template grids the same launch laid out -- for nothing the host reads: 2.5 us of a 50 us frame. */
+			if (pub.fenced) {
+				__threadfence_system();
+				__hip_atomic_store(pub.flag, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			} else __hip_atomic_store(pub.flag, pub.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 	}
 }

@@ -503,10 +503,26 @@ __global__ __launch_bounds__(128) void k_finish_rows(const double *partials, int
 	if (k >= row_len) return;
 	out[(size_t)t * row_len + k] = column_sum(partials + (size_t)t * nblk * row_len + k, nblk, row_len);
 }
+/* the hand-over every publishing workgroup ends in, once its own results have been issued as system-scope stores: stores performed
+ * (acknowledged write-through stores, or -- fenced -- an agent-scope release), the workgroup counted in, the flag raised by the last
+ * arriver.  See publish_fenced() in mtfhip_internal.h for the two forms. */
+__device__ __forceinline__ void publish_arrive(int *count, unsigned long long *flag_host, unsigned long long seq, int fenced) {
+	if (fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); else wait_stores_acked();
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		const int done = fenced ? __hip_atomic_fetch_add(count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+		                        : __hip_atomic_fetch_add(count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (done == (int)gridDim.x - 1) {
+			__hip_atomic_store(count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (fenced) { __threadfence_system(); __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+			else __hip_atomic_store(flag_host, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+	}
+}
 /* the same, delivered straight into host-coherent pinned memory: every target's row, then -- by the workgroup that
  * finishes last -- a sequence number the host is spinning on (system-scope release after the rows) */
 __global__ __launch_bounds__(1024) void k_finish_host(const double *partials, int nblk, int row_len, double *out_host, int *count,
-	unsigned long long *flag_host, unsigned long long seq) {
+	unsigned long long *flag_host, unsigned long long seq, int fenced) {
 	/* blockDim.x = 128 G: group j sums the rows j, j + G, ... of its column, group 0 adds the G partial sums in order -- a single
 	 * target has hundreds of block rows, and one thread per column walking all of them was most of this kernel's 4 us */
 	__shared__ double part[8][128];
@@ -523,31 +539,15 @@ __global__ __launch_bounds__(1024) void k_finish_host(const double *partials, in
 	 * posted write of the same device behind them.  No fence: a system-scope release is a write-back of every L2 (2.5 us, measured on
 	 * the grid kernel's publish in r04) for lines the host never reads -- the protocol of publish_target, kernels_batch.hip. */
 	if (j == 0 && k < row_len) __hip_atomic_store(out_host + (size_t)t * row_len + k, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-	wait_stores_acked();
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		const int done = __hip_atomic_fetch_add(count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (done == (int)gridDim.x - 1) {
-			__hip_atomic_store(count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			__hip_atomic_store(flag_host, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-		}
-	}
+	publish_arrive(count, flag_host, seq, fenced);
 }
 /* a device buffer delivered straight into host-coherent pinned memory (32-bit words), then the sequence number the host is
  * spinning on: replaces a device-to-host copy + stream synchronisation at the end of the device-side loop */
 __global__ __launch_bounds__(256) void k_publish_host(const unsigned *src, unsigned *dst_host, unsigned n_words, int *count,
-	unsigned long long *flag_host, unsigned long long seq) {
+	unsigned long long *flag_host, unsigned long long seq, int fenced) {
 	for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n_words; i += gridDim.x * 256)
 		__hip_atomic_store(dst_host + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-	wait_stores_acked();   /* (as k_finish_host: acknowledged write-through stores, then the counter, then the flag) */
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		const int done = __hip_atomic_fetch_add(count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (done == (int)gridDim.x - 1) {
-			__hip_atomic_store(count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			__hip_atomic_store(flag_host, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-		}
-	}
+	publish_arrive(count, flag_host, seq, fenced);   /* (as k_finish_host) */
 }
 /* the other direction: the staged state slab is read from pinned host memory by the kernel itself (16 bytes per lane, one PCIe
  * round trip) instead of through a copy-engine transfer and the cross-queue dependency that follows it */
@@ -686,14 +686,14 @@ void launch_ncc_hess(const BatchView &bv, const double *sc, const double *colmea
 void launch_finish_host(double *partials, int nblk, int row_len, double *out_host, int *count, unsigned long long *flag_host,
 	unsigned long long seq, int B, hipStream_t st) {
 	const int G = nblk >= 256 ? 8 : (nblk >= 64 ? 4 : 1);
-	MTFHIP_LAUNCH(k_finish_host, dim3(B), dim3(128 * G), 0, st, partials, nblk, row_len, out_host, count, flag_host, seq);
+	MTFHIP_LAUNCH(k_finish_host, dim3(B), dim3(128 * G), 0, st, partials, nblk, row_len, out_host, count, flag_host, seq, publish_fenced());
 }
 void launch_publish_host(const void *src, void *dst_host, size_t bytes, int *count, unsigned long long *flag_host,
 	unsigned long long seq, hipStream_t st) {
 	const unsigned n_words = (unsigned)(bytes / 4);
 	const unsigned blocks = std::max(1u, std::min(64u, (n_words + 1023) / 1024));
 	MTFHIP_LAUNCH(k_publish_host, dim3(blocks), dim3(256), 0, st, static_cast<const unsigned *>(src), static_cast<unsigned *>(dst_host),
-		n_words, count, flag_host, seq);
+		n_words, count, flag_host, seq, publish_fenced());
 }
 void launch_ingest_host(const void *src_host, void *dst, size_t bytes, hipStream_t st) {
 	const unsigned n16 = (unsigned)(bytes / 16), n_tail = (unsigned)((bytes % 16) / 4);   /* (the slab is a multiple of 4 bytes) */

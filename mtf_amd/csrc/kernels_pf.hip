@@ -741,7 +741,7 @@ __global__ __launch_bounds__(kBlock) void k_pf_scan(PfScanArgs a) {
  * [18..25] the state of the workgroup's best particle */
 constexpr int kPfPart = 26;
 constexpr int kPfTable = 4096;   /* chunk table in LDS: up to 1 048 576 particles; beyond, the table is searched in memory */
-struct PfPublish { double *host; unsigned long long *flag, seq; };
+struct PfPublish { double *host; unsigned long long *flag, seq; int fenced; };
 struct PfSelectArgs {
 	int resampling_type, mean_type;
 	int lookahead;                /* 1: the proposals of the next iteration (draws of a.iter + 1) are produced here */
@@ -959,8 +959,15 @@ __global__ __launch_bounds__(kBlock) void k_pf_select(PfArgs a, PfSelectArgs r) 
 	if (lane < 32) r.out[lane] = o;
 	if (r.pub.host) {
 		if (lane < 32) __hip_atomic_store(r.pub.host + lane, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-		wait_stores_acked();   /* (one wave: its write-through stores are performed, the flag is a posted write behind them -- no L2 write-back) */
-		if (lane == 0) __hip_atomic_store(r.pub.flag, r.pub.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		/* (one wave: its write-through stores are performed, the flag is a posted write behind them -- no L2 write-back; fenced =
+		 * MTFHIP_PUBLISH_FENCE=1, publish_fenced(): the system-scope release the memory model asks for) */
+		if (r.pub.fenced) {
+			__threadfence_system();
+			if (lane == 0) __hip_atomic_store(r.pub.flag, r.pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		} else {
+			wait_stores_acked();
+			if (lane == 0) __hip_atomic_store(r.pub.flag, r.pub.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
 	}
 	};
 	if (is_last && tid < 64) estimate_tail();
@@ -1094,7 +1101,7 @@ void launch_pf_select(int ssm, const PfLaunch &p, const PfBuffers &bf, int looka
 	r.st_out = bf.st; r.ar_out = bf.ar; r.next = bf.next; r.next_ar = bf.next_ar; r.ids = bf.ids;
 	r.forced_best = p.resampling_type == 3 ? bf.res_order : nullptr;
 	for (int k = 0; k < 12; ++k) r.init_corners_hm[k] = p.init_corners_hm[k];
-	r.parts = bf.parts; r.gparts = bf.gparts; r.counter = bf.counters + 1; r.out = bf.out; r.pub = PfPublish{host_out, host_flag, seq};
+	r.parts = bf.parts; r.gparts = bf.gparts; r.counter = bf.counters + 1; r.out = bf.out; r.pub = PfPublish{host_out, host_flag, seq, publish_fenced()};
 	const dim3 g((p.n + kBlock - 1) / kBlock);
 	if (ssm == MTFHIP_SSM_HOMOGRAPHY) MTFHIP_LAUNCH(k_pf_select<MTFHIP_SSM_HOMOGRAPHY>, g, dim3(kBlock), 0, st, a, r);
 	else MTFHIP_LAUNCH(k_pf_select<MTFHIP_SSM_AFFINE>, g, dim3(kBlock), 0, st, a, r);

@@ -256,6 +256,10 @@ struct mtfhip_batch {
 	int *d_fin_count = nullptr;
 	int nblk_max;
 	int unit_z = 1;
+	/* INIT_PTS is the lattice set_corners (or the grid kernel's region mode) laid out INSIDE init_corners: what lets the candidate scorer
+	 * trust the corners as the hull of the sample points.  Cleared when the caller writes a grid of its own (mtfhip_batch_write /
+	 * mtfhip_batch_device_ptr of INIT_PTS / INIT_HXY / INIT_Z). */
+	bool grid_from_corners = false;
 	/* a deferred affine reset whose host half is still to be written (set_corners_core / set_corners_finish_deferred): the caller's
 	 * corners, valid for the duration of the C-ABI call that deferred them */
 	const double *deferred_corners = nullptr;

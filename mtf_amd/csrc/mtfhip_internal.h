@@ -5,6 +5,7 @@
 #ifndef MTFHIP_INTERNAL_H
 #define MTFHIP_INTERNAL_H
 
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include "../../include/mtfhip.h"
 
@@ -163,6 +164,17 @@ __host__ __device__ inline bool rect_to_quad_hd(double lo_x, double lo_y, double
 	return true;
 }
 
+/* rect_to_quad_hd's first refusals alone (collinear / coincident corners), ~12 flops: what a deferred reset checks on the host BEFORE it
+ * commits anything, so that degenerate corners are an error without a state change, as on the non-deferred path (the kernel's own
+ * report through n_iters = -1 stays as the backstop for the map's remaining refusal, a vanishing m[8]) */
+__host__ __device__ inline bool quad_degenerate_hd(const double *q) {
+	const double x0 = q[0], y0 = q[1], x1 = q[2], y1 = q[3], x2 = q[4], y2 = q[5], x3 = q[6], y3 = q[7];
+	const double dx1 = x1 - x2, dx2 = x3 - x2, sx = x0 - x1 + x2 - x3;
+	const double dy1 = y1 - y2, dy2 = y3 - y2, sy = y0 - y1 + y2 - y3;
+	if (sx == 0 && sy == 0) return (x1 - x0) * (y3 - y0) - (x3 - x0) * (y1 - y0) == 0;
+	return dx1 * dy2 - dy1 * dx2 == 0;
+}
+
 /* k_iclk_track in REGION mode (mtfhip_batch_track_region / mtfhip_grid_update, r04): the workgroup of a patch takes the patch's region
  * corners (and its template's NCC scalars) straight from the pinned staging buffer, derives the square-to-quadrilateral map, lays out
  * its own sample grid -- kept in registers for the loop, written to INIT_PTS / INIT_HXY / INIT_Z for whoever asks later -- and starts
@@ -182,7 +194,18 @@ struct HostPublish {
 	int B;
 	int *count;
 	unsigned long long *flag, seq;
+	int fenced;         /* publish_fenced(): the release / acquire form of the hand-over instead of acknowledged write-through stores */
 };
+/* How a kernel hands results to the host (k_finish_host, k_publish_host, publish_target, the particle filter's estimate).  Default:
+ * relaxed system-scope (write-through) stores, s_waitcnt vmcnt(0), a relaxed agent-scope arrival counter, a relaxed system-scope flag
+ * store by the last arriver -- what a release does in hardware minus the L2 write-backs (2.5 us each), but a data race under the
+ * HIP / HSA memory model: it relies on the stores being write-through atomics, on per-wave vmcnt and on ordered posted writes
+ * (r04 advisor).  MTFHIP_PUBLISH_FENCE=1 restores the model-conforming form at run time for every publisher: agent-scope release
+ * before the counter, acq_rel on the counter, __threadfence_system() + a system-scope release store of the flag. */
+inline int publish_fenced() {
+	static const int v = [] { const char *e = std::getenv("MTFHIP_PUBLISH_FENCE"); return (e && e[0] == '1') ? 1 : 0; }();
+	return v;
+}
 
 struct FusedArgs {
 	int mode;          /* accumulation mode: 0 FCLK-type, 1 ESM-type, 2 ICLK-lite (see k_fused_ssd) */

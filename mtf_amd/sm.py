@@ -619,6 +619,8 @@ class ParticleFilter:
         # scoring kernel stores into every rank's mailbox, the scan waits for arrival counters: mtfhip_pf_set_exchange)
         if exchange not in ("collective", "peer"):
             raise ValueError("exchange must be 'collective' or 'peer', not %r" % (exchange,))
+        if exchange == "peer" and exchange_transport is not None and comm is None:
+            raise ValueError("exchange='peer' with an exchange_transport belongs to a filter sharded over a communicator (comm=...)")
         self.exchange = exchange
         if exchange == "peer" and exchange_transport is not None:
             # the host program moves the 64-byte mailbox handles: exchange_transport(mine: bytes) -> [every rank's bytes, rank-major]

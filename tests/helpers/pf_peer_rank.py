@@ -15,6 +15,7 @@ from mtf_amd.sm import Comm, ParticleFilter  # noqa: E402
 
 def main():
     rank, world, scratch, n = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
+    n += int(os.environ.get("PF_PEER_TEST_EXTRA_PARTICLES", "0"))   # (a rank created with another particle count: must be refused)
 
     def transport(mine):
         tmp = os.path.join(scratch, "handle_%d.tmp" % rank)

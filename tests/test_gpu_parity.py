@@ -608,6 +608,43 @@ def test_pf_candidate_scores_at_the_frame_border(oracle, gpu_ctx, frame, am, ssm
         np.testing.assert_allclose(lik[keep], lik_o[keep], rtol=1e-9, atol=1e-300)
 
 
+@pytest.mark.parametrize("via", ["write", "device_ptr"])
+def test_pf_candidate_scores_with_a_caller_supplied_grid(oracle, gpu_ctx, frame, via):
+    """r04 advisor: a caller that replaces INIT_PTS (mtfhip_batch_write, or a raw device pointer) must not leave the scorer trusting
+    the corners set_corners saw as the hull of the sample points -- here the corners are a 20 px square well inside the frame while
+    the grid that is actually sampled spans 100 px and crosses the border under the candidates' shifts.  Against the oracle, which
+    samples the same big grid."""
+    small = synth.square_corners(60.0, 58.0, 20)
+    big = synth.square_corners(60.0, 58.0, 100)
+    o_am, o_ssm, b = make_pair(oracle, gpu_ctx, frame, L.AM_SSD, L.SSM_AFFINE, 50, big)
+    b.set_corners(small[None])
+    grid = o_ssm.get("init_pts").reshape(-1, 2).T          # the oracle's SSM holds the big grid
+    if via == "write":
+        b.write(L.BUF_INIT_PTS, grid[None])
+    else:
+        import torch
+        ptr = b.device_ptr(L.BUF_INIT_PTS)
+        host = np.ascontiguousarray(grid.T)                # (x, y) interleaved
+        t = torch.from_numpy(host).to("cuda:0")
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(ctypes.c_void_p(ptr), ctypes.c_void_p(t.data_ptr()), ctypes.c_size_t(host.nbytes), 3) == 0   # device to device
+        torch.cuda.synchronize()
+    o_am.initialize_pix_vals(o_ssm.get("curr_pts")); o_am.initialize_similarity()
+    b.initialize_pix_vals(grid[None]); b.initialize_similarity()
+    rng = np.random.default_rng(6)
+    n = 64
+    states = np.zeros((n, 6))
+    states[:, 0] = rng.uniform(-30.0, -5.0, n)      # the small square stays inside (50 - 30 > 0), the big grid (10 .. 110) does not
+    states[:, 1] = rng.uniform(-30.0, -5.0, n)
+    lik_o, sim_o = oracle.pf_score(o_am, o_ssm, states)
+    for mode in (L.MATH_FAST, L.MATH_REPLAY):
+        b.set_math_mode(mode)
+        lik, sim = b.score_candidates(states, want_similarity=True)
+        np.testing.assert_allclose(sim, sim_o, rtol=1e-9, err_msg="mode %d" % mode)
+        np.testing.assert_allclose(lik, lik_o, rtol=1e-9, atol=1e-300)
+
+
 def test_border_and_integer_coordinate_cases(oracle, gpu_ctx, frame):
     """Constant border (128) outside the image and at the last row/column, and the dx == 0 branch at
     exact integer coordinates (imgUtils.h:96-108) -- samples and both gradient flavours."""

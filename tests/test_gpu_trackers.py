@@ -1165,6 +1165,44 @@ def test_pf_peer_exchange_refuses_mismatched_seeds_between_processes(tmp_path):
         assert p.returncode != 0 and "another seed" in out, out[-2000:]
 
 
+def test_pf_peer_exchange_refuses_mismatched_particle_counts_between_processes(tmp_path):
+    """r04 advisor: every rank addresses the peers' mailboxes with its OWN particle count and vector capacity -- ranks created with
+    different n_particles stored outside the peer's allocation.  The mailbox header (fixed offsets) carries n and the capacity next to
+    the seed; a mismatch is refused on both ranks when the peers are connected, before any weight is stored."""
+    import subprocess
+    import sys
+    helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "pf_peer_rank.py")
+    scratch = str(tmp_path / "s")
+    os.makedirs(scratch)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, PF_PEER_TEST_EXTRA_PARTICLES=str(4096 * r))
+        procs.append(subprocess.Popen([sys.executable, helper, str(r), "2", scratch, "600"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env))
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode != 0 and "same n_particles" in out, out[-2000:]
+
+
+def test_pf_sharded_filter_refuses_mismatched_particle_counts(frame):
+    """the same on the collective path: mtfhip_pf_set_comm gathers the particle counts next to the seeds"""
+    from mtf_amd.sm import Comm
+    world = 2
+    comms = Comm.loopback(world)
+
+    def run(r):
+        ctx = mtf_amd.Context(0)
+        ctx.set_image(frame)
+        try:
+            with pytest.raises(mtf_amd.MtfHipError, match="n_particles"):
+                ParticleFilter(ctx, L.SSM_HOMOGRAPHY, 20, 20, n_particles=64 + 64 * r, seed=11, comm=comms[r])
+        finally:
+            ctx.close()
+        return True
+    assert all(_run_ranks(world, run))
+    for c in comms:
+        c.close()
+
+
 def test_pf_sharded_filter_refuses_mismatched_seeds(frame):
     """every rank of a sharded filter scores a block of ITS OWN proposals: ranks with different Philox keys would mix the weights of
     different particle sets.  mtfhip_pf_set_comm gathers the seeds once and refuses (r03 advisor finding); the Python front end refuses
@@ -1466,3 +1504,24 @@ def test_estimate_state_sigma_and_pix_sigma_filter(oracle, gpu_ctx, frame, ssm):
         dw, dids, res_d = pf.distributions()
         assert set(np.unique(dids)) == {0, 1} and np.all(np.isfinite(st)) and abs(dw.sum() - 1.0) < 0.2
         pf.close()
+
+
+def test_host_publish_protocols_under_stress_fenced_and_not(tmp_path):
+    """r04 advisor: the host publishes (k_finish_host, k_publish_host, the grid kernel's publish_target, the particle filter's estimate)
+    hand their results over with acknowledged write-through stores instead of release fences; MTFHIP_PUBLISH_FENCE=1 restores the
+    fenced, memory-model-conforming form at run time.  tools/publish_stress.py -- hundreds of interface-mode iterations, device-loop
+    calls and filter iterations, each compared bit for bit with the first of its kind -- in both forms, and both forms end on the
+    same bits."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dumps = []
+    for fenced in ("0", "1"):
+        dump = str(tmp_path / ("d%s.npz" % fenced))
+        env = dict(os.environ, MTFHIP_PUBLISH_FENCE=fenced, PUBLISH_STRESS_N="400", PUBLISH_STRESS_DUMP=dump)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "publish_stress.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                           env=env, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:]
+        assert ("fenced" if fenced == "1" else "acknowledged stores") in r.stdout
+        dumps.append(np.load(dump))
+    assert np.array_equal(dumps[0]["ref"], dumps[1]["ref"]) and not dumps[0]["bad"].any() and not dumps[1]["bad"].any()

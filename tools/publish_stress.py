@@ -15,7 +15,7 @@ for host_solve in (True, False):
     sm.initialize(corners)
     ctx.set_image(f1)
     ref = None; n_bad = 0
-    for k in range(1500):
+    for k in range(int(os.environ.get("PUBLISH_STRESS_N", "1500"))):
         sm.set_region(corners)
         c = np.array(sm.update())
         if ref is None: ref = c.copy()
@@ -27,11 +27,14 @@ ref = []
 for rep in range(2):
     pf.initialize(corners[:1]); ctx.set_image(f1)
     n_bad = 0
-    for k in range(1500):
+    for k in range(int(os.environ.get("PUBLISH_STRESS_N", "1500"))):
         pf.iteration()
         c = np.array(pf.get_region())
         if rep == 0: ref.append(c.copy())
         elif not np.array_equal(c, ref[k]): n_bad += 1
     ctx.set_image(f0)
 bad["pf"] = n_bad
-print("mismatches", bad)
+print("mismatches", bad, "fenced" if os.environ.get("MTFHIP_PUBLISH_FENCE") == "1" else "acknowledged stores")
+if os.environ.get("PUBLISH_STRESS_DUMP"):
+    np.savez(os.environ["PUBLISH_STRESS_DUMP"], ref=np.asarray(ref), bad=np.asarray([bad[k] for k in sorted(bad)]))
+sys.exit(1 if any(bad.values()) else 0)
