@@ -34,6 +34,20 @@ for rep in range(2):
         elif not np.array_equal(c, ref[k]): n_bad += 1
     ctx.set_image(f0)
 bad["pf"] = n_bad
+# the grid kernel's own publish (publish_target): one launch per frame
+from mtf_amd.sm import GridTracker
+ctx.set_image(f0)
+gt = GridTracker(ctx, grid_size=16, patch_size=25, max_iters=10, epsilon=-1.0)
+region = synth.square_corners(512, 512, 400)
+gt.initialize(region); ctx.set_image(f1)
+gref = None; n_bad = 0
+for k in range(int(os.environ.get("PUBLISH_STRESS_N", "1500"))):
+    c, cen = gt.update_patches(region)
+    if gref is None: gref = (c.copy(), cen.copy())
+    elif not (np.array_equal(c, gref[0]) and np.array_equal(cen, gref[1])): n_bad += 1
+bad["grid"] = n_bad
+ref = [np.asarray(ref).ravel(), gref[0].ravel()]
+ref = np.concatenate(ref)
 print("mismatches", bad, "fenced" if os.environ.get("MTFHIP_PUBLISH_FENCE") == "1" else "acknowledged stores")
 if os.environ.get("PUBLISH_STRESS_DUMP"):
     np.savez(os.environ["PUBLISH_STRESS_DUMP"], ref=np.asarray(ref), bad=np.asarray([bad[k] for k in sorted(bad)]))
