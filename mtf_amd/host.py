@@ -220,6 +220,25 @@ def templated_fclk(frame0, frame1, corners, am=_lib.AM_SSD, ssm=_lib.SSM_HOMOGRA
     return out.reshape(4, 2).T.copy(), n.value
 
 
+def templated_sm(sm, frame0, frame1, corners, am=_lib.AM_SSD, ssm=_lib.SSM_HOMOGRAPHY, resx=40, resy=40, max_iters=10, epsilon=1e-4, jac_type=1,
+                 hess_type=2, leven_marq=0, move=None, device=0):
+    """ESM<HipAM, HipSSM> (sm = SM_ESM) / ICLK<HipAM, HipSSM> (sm = SM_ICLK) in the reference's templated shape (harness/TemplatedSM.h):
+    initialize on frame0, update() on frame1; with move = (dx, dy) then setRegion(result + move) and a second update().
+    -> (corners (2, 4), corners after the second update or None, [iterations, iterations])"""
+    assert frame0.dtype == np.float32 and frame1.dtype == np.float32 and frame0.shape == frame1.shape and frame0.flags["C_CONTIGUOUS"] and frame1.flags["C_CONTIGUOUS"]
+    c = np.ascontiguousarray(np.asarray(corners, dtype=np.float64).reshape(2, 4).T.ravel())
+    out, out2 = np.zeros(8), np.zeros(8)
+    n = (C.c_int * 2)(0, 0)
+    mv = np.ascontiguousarray(np.asarray(move, dtype=np.float64)) if move is not None else None
+    fn = lib().mtfhost_templated_sm
+    fn.argtypes = [C.c_int] * 6 + [C.c_double] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(fn(sm, am, ssm, resx, resy, max_iters, epsilon, jac_type, hess_type, leven_marq, device, frame0.ctypes.data_as(C.c_void_p),
+              frame1.ctypes.data_as(C.c_void_p), frame0.shape[0], frame0.shape[1], frame0.shape[1], c.ctypes.data_as(C.c_void_p),
+              mv.ctypes.data_as(C.c_void_p) if mv is not None else None, out.ctypes.data_as(C.c_void_p),
+              out2.ctypes.data_as(C.c_void_p) if mv is not None else None, n))
+    return out.reshape(4, 2).T.copy(), (out2.reshape(4, 2).T.copy() if mv is not None else None), [n[0], n[1]]
+
+
 _GRID_EST = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_double))
 
 

@@ -317,3 +317,42 @@ int mtfhost_grid_get(mtfhost_grid *h, int what, double *dst) {
 	} catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
 }
+
+/* the same for the templated ESM<HipAM, HipSSM> (sm = 0) and ICLK<HipAM, HipSSM> (sm = 2): initialize on frame0, update() on frame1; then --
+ * move != NULL -- setRegion(the result shifted by move (dx, dy)) and a second update() on frame1.  out: corners after the first update
+ * (2 x 4), out2: after the second (or NULL); iters: two counts */
+extern "C" int mtfhost_templated_sm(int sm, int am, int ssm, int resx, int resy, int max_iters, double epsilon, int jac_type, int hess_type, int leven_marq,
+	int device, const float *frame0, const float *frame1, int rows, int cols, int step, const double *corners_2x4, const double *move,
+	double *out_corners_2x4, double *out2_corners_2x4, int *iters) {
+	try {
+		auto link = std::make_shared<hip::HipLink>();
+		link->am = am; link->ssm = ssm; link->resx = resx; link->resy = resy; link->device = device;
+		hip::HipAM::ParamType amp; amp.link = link;
+		hip::HipSSM::ParamType ssmp; ssmp.link = link;
+		CornersT c; std::memcpy(c.data(), corners_2x4, sizeof(double) * 8);
+		auto run = [&](auto &tracker) {
+			tracker.setImage(ImageView{frame0, rows, cols, step});
+			tracker.initialize(c);
+			tracker.setImage(ImageView{frame1, rows, cols, step});
+			iters[0] = tracker.update();
+			std::memcpy(out_corners_2x4, tracker.getRegion().data(), sizeof(double) * 8);
+			if (move && out2_corners_2x4) {
+				CornersT m = tracker.getRegion();
+				for (int q = 0; q < 4; ++q) { m(0, q) += move[0]; m(1, q) += move[1]; }
+				tracker.setRegion(m);
+				iters[1] = tracker.update();
+				std::memcpy(out2_corners_2x4, tracker.getRegion().data(), sizeof(double) * 8);
+			}
+		};
+		if (sm == MTFHIP_SM_ESM) {
+			templated::ESMParams p; p.max_iters = max_iters; p.epsilon = epsilon; p.jac_type = jac_type; p.hess_type = hess_type; p.leven_marq = leven_marq != 0;
+			templated::ESM<hip::HipAM, hip::HipSSM> t(&p, &amp, &ssmp);
+			run(t);
+		} else if (sm == MTFHIP_SM_ICLK) {
+			templated::ICLKParams p; p.max_iters = max_iters; p.epsilon = epsilon; p.hess_type = hess_type; p.leven_marq = leven_marq != 0;
+			templated::ICLK<hip::HipAM, hip::HipSSM> t(&p, &amp, &ssmp);
+			run(t);
+		} else { g_err = "mtfhost_templated_sm: ESM (0) or ICLK (2)"; return -1; }
+		return 0;
+	} catch (const std::exception &e) { g_err = e.what(); return -1; }
+}

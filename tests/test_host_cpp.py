@@ -410,3 +410,36 @@ def test_templated_search_method_shape_instantiates_the_adapters(oracle, frame, 
     iters = trk.update()
     assert abs(n - iters) <= 1
     np.testing.assert_allclose(got, trk.get_region(), rtol=0, atol=2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sm,am,ssm,jac_type,hess_type,leven_marq", [
+    (L.SM_ESM, L.AM_SSD, L.SSM_HOMOGRAPHY, 1, 2, 0),      # the shipped ESM: DiffOfJacs + SumOfSelf
+    (L.SM_ESM, L.AM_NCC, L.SSM_AFFINE, 0, 3, 0),          # Original + Original: the mean Jacobian
+    (L.SM_ESM, L.AM_SSD, L.SSM_HOMOGRAPHY, 1, 0, 1),      # InitialSelf + Levenberg-Marquardt (init_d2f_dp2 re-read every pass)
+    (L.SM_ESM, L.AM_NCC, L.SSM_HOMOGRAPHY, 1, 4, 0),      # SumOfStd
+    (L.SM_ICLK, L.AM_SSD, L.SSM_HOMOGRAPHY, 1, 0, 0),     # the shipped ICLK: InitialSelf
+    (L.SM_ICLK, L.AM_NCC, L.SSM_AFFINE, 1, 0, 1),         # + Levenberg-Marquardt (d2f_dp2_orig)
+    (L.SM_ICLK, L.AM_SSD, L.SSM_AFFINE, 1, 1, 0),         # CurrentSelf: dIt_dpssm sized in the constructor
+    (L.SM_ICLK, L.AM_NCC, L.SSM_HOMOGRAPHY, 1, 2, 0),     # Std
+])
+def test_templated_esm_and_iclk_shapes_over_the_adapters(oracle, frame, sm, am, ssm, jac_type, hess_type, leven_marq):
+    """ESM<AM, SSM> / ICLK<AM, SSM> of the reference (SM/src/ESM.cc:14-316, ICLK.cc:13-263) -- models by value built from ParamType
+    pointers, init_pix_jacobian & co. sized from am.getPatchSize() / ssm.getStateSize(), setRegion's own refresh -- instantiated over
+    HipAM / HipSSM (harness/TemplatedSM.h) and run against the oracle's trackers: update(), setRegion(), update()."""
+    rng = np.random.default_rng(33)
+    corners = synth.square_corners(240.0, 250.0, 80)
+    frame2 = synth.warp_frame(frame, synth.random_small_homography(rng, 0.4), (240.0, 250.0))
+    move = (0.75, -0.5)
+    got, got2, n = host.templated_sm(sm, frame, frame2, corners, am=am, ssm=ssm, resx=40, resy=40, max_iters=15, epsilon=1e-4, jac_type=jac_type,
+                                     hess_type=hess_type, leven_marq=leven_marq, move=move)
+    o_ssm = oracle.SSM(ssm, 40, 40); o_am = oracle.AM(am, 40, 40); o_am.set_curr_img(frame)
+    trk = oracle.Tracker(sm, o_am, o_ssm, leven_marq=leven_marq, max_iters=15, epsilon=1e-4, hess_type=hess_type, jac_type=jac_type, chained_warp=1)
+    trk.initialize(corners); o_am.set_curr_img(frame2)
+    iters = trk.update()
+    assert abs(n[0] - iters) <= 1
+    np.testing.assert_allclose(got, trk.get_region(), rtol=0, atol=2e-4)
+    trk.set_region(trk.get_region() + np.array(move)[:, None])
+    iters2 = trk.update()
+    assert abs(n[1] - iters2) <= 1
+    np.testing.assert_allclose(got2, trk.get_region(), rtol=0, atol=5e-4)
