@@ -595,8 +595,9 @@ static bool mi_fast_ok(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const Mi
 	static const bool enabled = !(std::getenv("MTFHIP_MI_RECOMPUTE") && std::getenv("MTFHIP_MI_RECOMPUTE")[0] == '0');
 	return enabled && b->math_mode == MTFHIP_MATH_FAST && b->desc.mi_n_bins == 8 && !sm->materialize && pl.hk != MiPlan::H_SUM_STD;
 }
-static MiFastPlan mi_fast_plan(const mtfhip_batch *b, const MiPlan &pl, const int *active) {
+static MiFastPlan mi_fast_plan(const mtfhip_batch *b, const MiPlan &pl, const int *active, const mtfhip_sm_desc *sm) {
 	MiFastPlan fp;
+	fp.nonchained = (sm && !sm->chained_warp) ? 1 : 0;
 	fp.hk = pl.hk == MiPlan::H_CONST ? 0 : (pl.hk == MiPlan::H_SELF_JT ? 1 : (pl.hk == MiPlan::H_INIT_J0 ? 3 : 2));
 	fp.hrow = pl.hk == MiPlan::H_CURR_JM ? 2 : (pl.hk == MiPlan::H_INIT_J0 ? 1 : 0);
 	fp.need_dft = !pl.iclk; fp.need_df0 = !(pl.fclk || pl.orig_jac); fp.g_mean = pl.orig_jac;
@@ -624,7 +625,7 @@ static int mi_enqueue_fast(mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPl
 	int so_own_pts = -1) {
 	const int nblk = mi_blocks(b);
 	hipStream_t st = b->ctx->stream;
-	const MiFastPlan fp = mi_fast_plan(b, pl, active);
+	const MiFastPlan fp = mi_fast_plan(b, pl, active, sm);
 	const BatchView bv = b->view();
 	{
 		TimedScope tsc(b->ctx, "mi_pass1");

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void k_mi_finish_fast(BatchView bv, mtfhip_
 static MiPassArgs make_args(const MiFastPlan &pl) {
 	MiPassArgs pa;
 	pa.nb = 8; pa.j0_mode = pl.j0_mode; pa.j0_init_variant = pl.j0_init_variant; pa.need_dft = pl.need_dft; pa.need_df0 = pl.need_df0;
-	pa.g_mean = pl.g_mean; pa.table_off = 0; pa.transpose_q = pl.hk == 3;
+	pa.g_mean = pl.g_mean; pa.table_off = 0; pa.transpose_q = pl.hk == 3; pa.nonchained = pl.nonchained;
 	pa.grad_eps = pl.grad_eps; pa.norm_mult = pl.norm_mult; pa.norm_add = pl.norm_add; pa.hist_norm = pl.hist_norm;
 	pa.active = pl.active; pa.tb = pl.tb; pa.cand_states = nullptr;
 	return pa;

@@ -296,6 +296,7 @@ struct MiFastPlan {
 	int j0_mode;          /* 0 the template's row is not needed, 1 rebuilt from dI0_dx, 2 read from J0 */
 	int j0_init_variant;
 	int need_dft, need_df0, g_mean;
+	int nonchained = 0;   /* the search method's chained_warp = 0: pass 2 takes the rounded steps of updateGradPts' four points (mi_finish) */
 	double grad_eps, norm_mult, norm_add, hist_norm;
 	const int *active;    /* device flags, NULL = all */
 	const double *tb;     /* [B][MI_SIZE] */

@@ -26,9 +26,11 @@ struct MiTex { double wx, wy, inv, lxd, lyd; float t00, t01, t10, t11; bool ok; 
 /* MC: the multi-channel models (MCMI = MI constructed with n_channels = 3, AM/src/MCMI.cc): a row is a (pixel, channel) pair, the
  * pixel's grid point is shared by its rows, the texels of channel ch sit at x * C + ch of the interleaved 32FC3 frame
  * (imgUtils.cc:861-1005) */
+/* nonch (the non-chained route, updateGradPts + getWarpedImgGrad): the four finite-difference points are eps times a column of the
+ * warp away from the centre, not eps: the interior test takes a bound of that distance as its margin */
 template <int SSM, bool GRAD, bool MC = false>
 __device__ __forceinline__ MiTex mi_issue(const ImgView &im, const Warp9 &W, double hx, double hy, double z, bool uz, double eps,
-	unsigned Cc = 1u, unsigned ch = 0u) {
+	unsigned Cc = 1u, unsigned ch = 0u, bool nonch = false) {
 	MiTex s;
 	s.wx = fma(W.m[0], hx, fma(W.m[1], hy, uz ? W.m[2] : W.m[2] * z));
 	s.wy = fma(W.m[3], hx, fma(W.m[4], hy, uz ? W.m[5] : W.m[5] * z));
@@ -40,7 +42,15 @@ __device__ __forceinline__ MiTex mi_issue(const ImgView &im, const Warp9 &W, dou
 	const int lx = (int)s.wx, ly = (int)s.wy;
 	s.lxd = (double)lx; s.lyd = (double)ly;
 	s.ok = (s.wx >= 0) & (s.wy >= 0) & (lx < im.w - 1) & (ly < im.h - 1);
-	if constexpr (GRAD) s.ok = s.ok & (s.wx - eps > s.lxd) & (s.wx + eps < s.lxd + 1) & (s.wy - eps > s.lyd) & (s.wy + eps < s.lyd + 1);
+	if constexpr (GRAD) {
+		double mg = eps;
+		if (nonch) {   /* |d(wx, wy)| <= eps (|W00| + |W01| ... + (|W20| + |W21|) max(|wx|, |wy|)) / |D|, doubled */
+			const double w1 = fmax(fmax(fabs(W.m[0]), fabs(W.m[1])), fmax(fabs(W.m[3]), fabs(W.m[4])));
+			const double w2 = fmax(fabs(W.m[6]), fabs(W.m[7]));
+			mg = 2 * eps * fabs(s.inv) * fma(w2, fmax(fabs(s.wx), fabs(s.wy)), w1);
+		}
+		s.ok = s.ok & (s.wx - mg > s.lxd) & (s.wx + mg < s.lxd + 1) & (s.wy - mg > s.lyd) & (s.wy + mg < s.lyd + 1);
+	}
 	const unsigned off = s.ok ? (MC ? (unsigned)(ly * im.stride + lx * (int)Cc) + ch : (unsigned)(ly * im.stride + lx)) * 4u : 0u;
 	const float *r0 = reinterpret_cast<const float *>(reinterpret_cast<const char *>(im.data) + off);
 	const float *r1 = r0 + im.stride;
@@ -48,9 +58,16 @@ __device__ __forceinline__ MiTex mi_issue(const ImgView &im, const Warp9 &W, dou
 	return s;
 }
 /* stage 2: value (and gradient with respect to the warped coordinates) from the fetched cell */
+/* nonch (GRAD only; W = the warp): the NON-CHAINED route -- gx, gy are then the gradient with respect to the TEMPLATE coordinates as
+ * updateGradPts + getWarpedImgGrad produce it (Homography.cc:803-827 / Affine.cc:293-313, imgUtils.cc:177-202), ready for
+ * cmptInitPixJacobian (no chain rule at the caller).  Interior path: the cell's slopes times the ROUNDED steps the reference's four
+ * offset points take -- numerators and denominator rounded on their own grids, px0 - px1 = ((n0 - n1) - wx (d0 - d1)) / D to second
+ * order in eps -- the QSTEP form of the fused LK body (mtfhip_fused_device.h); r04 ran both routes through the chained form and sat
+ * 4.9e-6 (H) / 2.3e-5 (dp) from the non-chained oracle.  The homogeneous coordinates are rebuilt from the warped point and 1 / inv:
+ * only their binades matter to the rounded steps. */
 template <int SSM, bool GRAD, bool MC = false>
 __device__ __forceinline__ MiSample mi_finish(const ImgView &im, const MiTex &tx, double eps, double norm_mult, double norm_add, bool lane_valid,
-	int ch = 0) {
+	int ch = 0, bool nonch = false, const Warp9 &W = Warp9{}) {
 	auto pv = [&](double x, double y) -> double { if constexpr (MC) return pix_val_mc(im, x, y, ch); else return pix_val(im, x, y); };
 	MiSample s;
 	s.wx = tx.wx; s.wy = tx.wy; s.inv = tx.inv; s.gx = s.gy = 0.0;
@@ -60,14 +77,40 @@ __device__ __forceinline__ MiSample mi_finish(const ImgView &im, const MiTex &tx
 		s.it = fma(norm_mult, v, norm_add);
 		if constexpr (GRAD) {   /* the cell's slope times the rounded step of the reference's central difference (fd_step, mtfhip_device.h) */
 			const double gm = norm_mult / (2 * eps);
-			s.gx = bgx * (fd_step(tx.wx, eps) * gm); s.gy = bgy * (fd_step(tx.wy, eps) * gm);
+			if (nonch) {
+				double dpx_x, dpy_x, dpx_y, dpy_y;
+				if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+					const double D = rcp_fast(tx.inv), cx = tx.wx * D, cy = tx.wy * D;
+					const double dd_x = fd_step_sym(D, W.m[6] * eps), dd_y = fd_step_sym(D, W.m[7] * eps);
+					dpx_x = fma(-tx.wx, dd_x, fd_step_sym(cx, W.m[0] * eps)) * tx.inv; dpy_x = fma(-tx.wy, dd_x, fd_step_sym(cy, W.m[3] * eps)) * tx.inv;
+					dpx_y = fma(-tx.wx, dd_y, fd_step_sym(cx, W.m[1] * eps)) * tx.inv; dpy_y = fma(-tx.wy, dd_y, fd_step_sym(cy, W.m[4] * eps)) * tx.inv;
+				} else {
+					dpx_x = fd_step_sym(tx.wx, W.m[0] * eps); dpy_x = fd_step_sym(tx.wy, W.m[3] * eps);
+					dpx_y = fd_step_sym(tx.wx, W.m[1] * eps); dpy_y = fd_step_sym(tx.wy, W.m[4] * eps);
+				}
+				s.gx = fma(bgx, dpx_x, bgy * dpy_x) * gm; s.gy = fma(bgx, dpx_y, bgy * dpy_y) * gm;
+			} else {
+				s.gx = bgx * (fd_step(tx.wx, eps) * gm); s.gy = bgy * (fd_step(tx.wy, eps) * gm);
+			}
 		}
 	} else {
 		s.it = norm_mult * pv(s.wx, s.wy) + norm_add;
-		if constexpr (GRAD) {   /* utils::getImgGrad, imgUtils.cc:233-254 (mc:: :861-905) */
+		if constexpr (GRAD) {
 			const double gm = norm_mult / (2 * eps);
-			s.gx = (pv(s.wx + eps, s.wy) - pv(s.wx - eps, s.wy)) * gm;
-			s.gy = (pv(s.wx, s.wy + eps) - pv(s.wx, s.wy - eps)) * gm;
+			if (nonch) {   /* the reference's four offset points, Homography.cc:803-827 / Affine.cc:293-313, sampled one by one (imgUtils.cc:177-202) */
+				const double ex0 = W.m[0] * eps, ex1 = W.m[3] * eps, ey0 = W.m[1] * eps, ey1 = W.m[4] * eps;
+				if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
+					const double D = 1.0 / tx.inv, cx = tx.wx * D, cy = tx.wy * D, ex2 = W.m[6] * eps, ey2 = W.m[7] * eps;
+					s.gx = (pv((cx + ex0) / (D + ex2), (cy + ex1) / (D + ex2)) - pv((cx - ex0) / (D - ex2), (cy - ex1) / (D - ex2))) * gm;
+					s.gy = (pv((cx + ey0) / (D + ey2), (cy + ey1) / (D + ey2)) - pv((cx - ey0) / (D - ey2), (cy - ey1) / (D - ey2))) * gm;
+				} else {
+					s.gx = (pv(s.wx + ex0, s.wy + ex1) - pv(s.wx - ex0, s.wy - ex1)) * gm;
+					s.gy = (pv(s.wx + ey0, s.wy + ey1) - pv(s.wx - ey0, s.wy - ey1)) * gm;
+				}
+			} else {   /* utils::getImgGrad, imgUtils.cc:233-254 (mc:: :861-905) */
+				s.gx = (pv(s.wx + eps, s.wy) - pv(s.wx - eps, s.wy)) * gm;
+				s.gy = (pv(s.wx, s.wy + eps) - pv(s.wx, s.wy - eps)) * gm;
+			}
 		}
 	}
 	return s;
@@ -84,6 +127,7 @@ struct MiPassArgs {
 	int g_mean;             /* ESM jac_type Original: df_dIt . (J0 + Jt) / 2 */
 	int table_off;          /* pass 2, Hessian: MI_T_SELF / MI_T_CURR / MI_T_INIT */
 	int transpose_q;
+	int nonchained;         /* pass 2: the search method's chained_warp = 0 (updateGradPts + getWarpedImgGrad + cmptInitPixJacobian) */
 	double grad_eps, norm_mult, norm_add, hist_norm;
 	const int *active;
 	const double *tb;       /* [B][MI_SIZE] */
@@ -186,7 +230,9 @@ __host__ __device__ constexpr MiMomentCoef mi_moment_coef() {
 }
 constexpr int kMiFastRow = 16 + 64 + 512;
 constexpr int kTRows = 12;   /* gradient-factor tables in LDS, indexed with (bin + 1) in both directions, zero borders */
-template <int SSM, int HK, int HROW, bool MC = false>
+/* NONCH: the search method's chained_warp = 0 (mi_finish's non-chained form + cmptInitPixJacobian rows); its own instantiation so that
+ * the chained kernels keep their register budget */
+template <int SSM, int HK, int HROW, bool MC = false, bool NONCH = false>
 __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, ImgView im, MiPassArgs pa, double *partials, int nblk) {
 	constexpr int S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
 	constexpr int nb = 8;
@@ -256,7 +302,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 	};
 	/* two-stage pipeline as in pass 1 */
 	prefetch(min(base + lane, N - 1));
-	MiTex tx_cur = mi_issue<SSM, true, MC>(im, W, q_nx.x, q_nx.y, z_nx, uz, pa.grad_eps, Cc, ch_nx);
+	constexpr bool nonch = NONCH;
+	MiTex tx_cur = mi_issue<SSM, true, MC>(im, W, q_nx.x, q_nx.y, z_nx, uz, pa.grad_eps, Cc, ch_nx, nonch);
 	unsigned ch_cur = ch_nx;
 	double2 p_cur = p_nx; double z_cur = z_nx, i0_cur = i0_nx, g0x_cur = g0x_nx, g0y_cur = g0y_nx;
 	prefetch(min(base + lane + stride, N - 1));
@@ -275,22 +322,28 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 #pragma unroll
 			for (int s = 0; s < S; ++s) j0[s] = ld_off<double>(J0 + (size_t)s * N, ic * 8u);
 		}
-		const MiTex tx_nx = mi_issue<SSM, true, MC>(im, W, q_nx.x, q_nx.y, z_nx, uz, pa.grad_eps, Cc, ch_nx);
+		const MiTex tx_nx = mi_issue<SSM, true, MC>(im, W, q_nx.x, q_nx.y, z_nx, uz, pa.grad_eps, Cc, ch_nx, nonch);
 		const unsigned ch_here = ch_cur;
 		ch_cur = ch_nx;
 		p_cur = p_nx; z_cur = z_nx; i0_cur = i0_nx; g0x_cur = g0x_nx; g0y_cur = g0y_nx;
 		prefetch(min(i + 2 * stride, N - 1));
-		const MiSample sp = mi_finish<SSM, true, MC>(im, tx_cur, pa.grad_eps, pa.norm_mult, pa.norm_add, i < N, (int)ch_here);
+		const MiSample sp = mi_finish<SSM, true, MC>(im, tx_cur, pa.grad_eps, pa.norm_mult, pa.norm_add, i < N, (int)ch_here, nonch, W);
 		tx_cur = tx_nx;
 		const double x = pxy.x, y = pxy.y;
 		/* steepest-descent row of the pixel (Homography.cc:252-289, Affine.cc:213-242) */
 		double jt[8];
 		if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
-			const double dwx_dx = fma(-W.m[6], sp.wx, W.m[0]), dwx_dy = fma(-W.m[7], sp.wx, W.m[1]);
-			const double dwy_dx = fma(-W.m[6], sp.wy, W.m[3]), dwy_dy = fma(-W.m[7], sp.wy, W.m[4]);
-			hom_row_fast(jt, fma(dwx_dx, sp.gx, dwy_dx * sp.gy) * sp.inv, fma(dwx_dy, sp.gx, dwy_dy * sp.gy) * sp.inv, x, y);
+			double Ix, Iy;
+			if (nonch) { Ix = sp.gx; Iy = sp.gy; }   /* cmptInitPixJacobian (Homography.cc:157-191): the gradient is already with respect to the template */
+			else {
+				const double dwx_dx = fma(-W.m[6], sp.wx, W.m[0]), dwx_dy = fma(-W.m[7], sp.wx, W.m[1]);
+				const double dwy_dx = fma(-W.m[6], sp.wy, W.m[3]), dwy_dy = fma(-W.m[7], sp.wy, W.m[4]);
+				Ix = fma(dwx_dx, sp.gx, dwy_dx * sp.gy) * sp.inv; Iy = fma(dwx_dy, sp.gx, dwy_dy * sp.gy) * sp.inv;
+			}
+			hom_row_fast(jt, Ix, Iy, x, y);
 		} else {
-			const double Ix = fma(sp.gx, W.m[0], sp.gy * W.m[3]), Iy = fma(sp.gx, W.m[1], sp.gy * W.m[4]);
+			/* (Affine.cc:160-182 / :213-242) */
+			const double Ix = nonch ? sp.gx : fma(sp.gx, W.m[0], sp.gy * W.m[3]), Iy = nonch ? sp.gy : fma(sp.gx, W.m[1], sp.gy * W.m[4]);
 			jt[0] = Ix; jt[1] = Iy; jt[2] = Ix * x; jt[3] = Ix * y; jt[4] = Iy * x; jt[5] = Iy * y; jt[6] = jt[7] = 0.0;
 		}
 		/* the template's row: rebuilt from dI0_dx as the fused LK kernel does, or read back */

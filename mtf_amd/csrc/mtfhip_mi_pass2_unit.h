@@ -9,7 +9,9 @@ namespace mtfhip {
 
 void MTFHIP_P2_NAME(const BatchView &bv, const ImgView &im, const MiPassArgs &pa, int hk, int hrow, double *partials, int nblk, hipStream_t st) {
 	const dim3 g = grid2(nblk, bv.B);
-#define MTFHIP_MI_P2(HK_, HR_) MTFHIP_LAUNCH((k_mi_pass_grad_hess<MTFHIP_P2_SSM, HK_, HR_, MTFHIP_P2_MC>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk)
+#define MTFHIP_MI_P2(HK_, HR_) do { \
+		if (pa.nonchained) MTFHIP_LAUNCH((k_mi_pass_grad_hess<MTFHIP_P2_SSM, HK_, HR_, MTFHIP_P2_MC, true>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk); \
+		else MTFHIP_LAUNCH((k_mi_pass_grad_hess<MTFHIP_P2_SSM, HK_, HR_, MTFHIP_P2_MC, false>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk); } while (0)
 	if (hk == 0) MTFHIP_MI_P2(0, 0);
 	else if (hk == 1) MTFHIP_MI_P2(1, 0);
 	else if (hk == 2 && hrow == 2) MTFHIP_MI_P2(2, 2);

@@ -297,20 +297,21 @@ def _fused_follow(oracle, gpu_ctx, frame, am, case, materialize, grid):
             fast_vs_8["g"] = max(fast_vs_8["g"], float(np.linalg.norm(gf[0] - rec["g"]) / max(np.linalg.norm(rec["g"]), gs)))
             if it <= 1:
                 fast_vs_6["dp"] = max(fast_vs_6["dp"], rel(dpf, r6["dp"])); fast_vs_8["dp"] = max(fast_vs_8["dp"], rel(dpf, rec["dp"]))
-            if it <= 1 and am != L.AM_MI:
-                assert rel(gf[0], r6["g"]) < 2e-5 and rel(dpf, r6["dp"]) < 2e-5, it     # plain relative while g, dp are far from zero
+            if it <= 1:
+                # plain relative while g, dp are far from zero -- MI included since r05: its pass 2 takes the non-chained route's own
+                # rounded steps (mi_finish, NONCH) instead of running both routes through the chained form (r04: H 4.9e-6, dp 2.3e-5 on
+                # ESM + MI chained_warp = 0; now 1.6e-7 / 1.9e-6, profiles/r05_parity_record.jsonl)
+                if am != L.AM_MI:   # (MI's update moves by 1.5e-5 .. 2.8e-5 between the 1e-8 and the 1e-6 oracle: test_mi_update_noise_floor)
+                    assert rel(gf[0], r6["g"]) < 2e-5 and rel(dpf, r6["dp"]) < 2e-5, it
                 assert rel(gf[0], rec["g"]) < 1e-5 and rel(dpf, rec["dp"]) < 1e-5, it
-            # (ii) against the reference's own arithmetic
+            # (ii) against the reference's own arithmetic: one set of bounds for SSD, NCC and MI
             assert rel(ff[0], rec["f"]) < 1e-8, it
-            assert rel(Hf[0], rec["H"]) < (1e-5 if am == L.AM_MI else 2e-6), it
-            assert np.linalg.norm(gf[0] - rec["g"]) < (1e-5 if am == L.AM_MI else 2e-6) * max(np.linalg.norm(rec["g"]), gs), it
+            assert rel(Hf[0], rec["H"]) < 2e-6, it
+            assert np.linalg.norm(gf[0] - rec["g"]) < 2e-6 * max(np.linalg.norm(rec["g"]), gs), it
             cf = b.apply_warp_to_corners(corners[None], dpf[None])[0]
             cr = b.apply_warp_to_corners(corners[None], rec["dp"][None])[0]
-            if am == L.AM_MI:   # the oracle's own dp moves by 1.5e-5 .. 2.8e-5 here when grad_eps goes from 1e-8 to 2e-8, or
-                # chained_warp from 1 to 0 (tests/test_oracle_relations.py::test_mi_update_noise_floor): that is the floor
-                assert rel(dpf, rec["dp"]) < 1e-5 or np.abs(cf - cr).max() < 1e-5, it
-            else:
-                assert rel(dpf, rec["dp"]) < 1e-5 or np.abs(cf - cr).max() < 1e-6, it
+            # (later passes: dp itself goes to zero, so either its relative error or what it does to the corners)
+            assert rel(dpf, rec["dp"]) < 1e-5 or np.abs(cf - cr).max() < 1e-6, it
         f, g, H = b.iterate(sm)
         dp = -oracle.colpiv_qr_solve(H[0], g[0])
         if it <= 1 and not tight:    # plain relative errors while g and dp are far from zero (north_star's literal wording)
