@@ -402,3 +402,82 @@ def mc_img_grad(img3, pts, eps=1e-8):
     C = img3.shape[2]
     g = np.stack([img_grad(img3[:, :, c], pts, eps) for c in range(C)], axis=1)   # (N, C, 2)
     return g.reshape(-1, 2)
+
+
+# ---------------------------------------------------------------------------------------------
+# r05 fixtures (tests/golden/make_golden3.py): GridTracker's patch layout, NN dataset rows, the stochastic samplers with given draws
+# ---------------------------------------------------------------------------------------------
+def grid_layout(region, grid_x, grid_y, patch_x, patch_y, dyn_patch_size, patch_centroid_inside):
+    """GridTracker::resetTrackers' geometry (SM/src/GridTracker.cc:345-380) from the description of the algorithm: a grid SSM with
+    (grid + 1)^2 points when patches are built from the cells' corners (dyn_patch_size or patch_centroid_inside), else grid^2 points;
+    its points are the uniform grid of the unit square pushed through the homography that takes the square's corners to the region's;
+    patch (r, c) is the cell's quadrilateral, or the patch-size rectangle centred on the cell's centroid / on grid point (r, c).
+    -> (grid points (n_pts, 2), patch corners (n, 2, 4) TL TR BR BL)."""
+    extra = 1 if (dyn_patch_size or patch_centroid_inside) else 0
+    rx, ry = grid_x + extra, grid_y + extra
+    pts, _ = grid_from_corners(np.asarray(region, dtype=np.float64), rx, ry)
+    P = pts.T.reshape(ry, rx, 2)
+    out = np.empty((grid_x * grid_y, 2, 4))
+    for r in range(grid_y):
+        for c in range(grid_x):
+            k = r * grid_x + c
+            if extra:
+                quad = np.stack([P[r, c], P[r, c + 1], P[r + 1, c + 1], P[r + 1, c]], axis=1)   # (2, 4)
+            if dyn_patch_size:
+                out[k] = quad
+                continue
+            ctr = quad.mean(axis=1) if patch_centroid_inside else P[r, c]
+            x0, y0 = ctr[0] - patch_x / 2.0, ctr[1] - patch_y / 2.0
+            out[k] = [[x0, x0 + patch_x, x0 + patch_x, x0], [y0, y0, y0 + patch_y, y0 + patch_y]]
+    return pts.T.copy(), out
+
+
+def nn_dataset_rows(img, init_hm, perts, ncc=False):
+    """NN::generateDataset (SM/src/NT/NN.cc:131-191) for a homography SSM with compositional updates: per sample the SSM is moved by
+    the INVERSE of the perturbation (invertState: inverse matrix scaled to h22 = 1; compositionalUpdate: right-multiply, rescale),
+    the patch is sampled there and turned into the AM's distance feature -- SSD: the pixel values (SSDBase.h:116-125); NCC: centred
+    and scaled to unit norm (NCC.cc:530-537) -- and the SSM is moved back by the perturbation itself, so that the warp the next sample
+    starts from is the accumulated product, not exactly the identity.  init_hm: (3, N) homogeneous template grid."""
+    W = np.eye(3)
+    rows = []
+    for p in perts:
+        Wp = hom_matrix(p)
+        inv = np.linalg.inv(Wp)
+        inv = inv / inv[2, 2]
+        W = W @ inv
+        W = W / W[2, 2]
+        q = W @ init_hm
+        It = bilinear(img, q[0] / q[2], q[1] / q[2])
+        if ncc:
+            It = It - It.mean()
+            It = It / np.linalg.norm(It)
+        rows.append(It)
+        W = W @ Wp
+        W = W / W[2, 2]
+    return np.stack(rows)
+
+
+def hom_corner_sampler(init_corners, sigma, mean, z):
+    """Homography::generatePerturbation with corner based sampling (SSM/src/Homography.cc:899-909): one translation from distribution 0
+    (two draws), eight corner offsets from distribution 1, the state of the 4-point homography init_corners -> disturbed corners.
+    z: ten standard normals in the order the reference draws them (t_x, t_y, then x, y per corner)."""
+    t = mean[0] + sigma[0] * z[:2]
+    d = (mean[1] + sigma[1] * z[2:10]).reshape(4, 2).T
+    H = dlt(init_corners, init_corners + d + t[:, None])
+    return np.array([H[0, 0] - 1, H[0, 1], H[0, 2], H[1, 0], H[1, 1] - 1, H[1, 2], H[2, 0], H[2, 1]])
+
+
+def aff_point_sampler(init_corners, mode, sigma, mean, z):
+    """Affine::generatePerturbation with pt_based_sampling 1 / 2 (SSM/src/Affine.cc:464-494): the bottom-right corner, the bottom-left
+    corner and the centre of the top edge are disturbed -- mode 1: coordinate j by distribution j (six draws); mode 2: every coordinate
+    by distribution 1 (six draws), then one translation by distribution 0 (two draws) -- and the perturbation is the affine map of the
+    three point pairs, as a state [tx, ty, a - 1, b, c, d - 1]."""
+    c = np.asarray(init_corners, dtype=np.float64)
+    orig = np.stack([c[:, 2], c[:, 3], (c[:, 0] + c[:, 1]) / 2.0], axis=1)     # (2, 3)
+    if mode == 1:
+        pert = orig + (np.asarray(mean[:6]) + np.asarray(sigma[:6]) * z[:6]).reshape(3, 2).T
+    else:
+        pert = orig + (mean[1] + sigma[1] * z[:6]).reshape(3, 2).T + (mean[0] + sigma[0] * z[6:8])[:, None]
+    A = np.vstack([orig, np.ones(3)])                                           # 3 x 3, exact for three non-collinear points
+    M = pert @ np.linalg.inv(A)                                                 # 2 x 3
+    return np.array([M[0, 2], M[1, 2], M[0, 0] - 1, M[0, 1], M[1, 0], M[1, 1] - 1])
