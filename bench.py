@@ -76,6 +76,32 @@ def pmc_traffic(sm, mode, res, targets, per_launch=None):
         return None
 
 
+def pmc_secondary(workload, kernel):
+    """per-launch PMC averages of a secondary workload's kernel (profiles/pmc_secondary_latest.json, tools/pmc_secondary_json.py):
+    FETCH_SIZE / WRITE_SIZE -> traffic_bytes_per_launch, SQ_INSTS_VALU, LDS counters.  Quoted only when the file was collected on the
+    kernel sources being run (kernel_sources_sha); otherwise withheld with the reason."""
+    path = os.path.join(ROOT, "profiles", "pmc_secondary_latest.json")
+    pmc_secondary.note = None
+    try:
+        d = json.load(open(path))
+    except Exception:
+        pmc_secondary.note = "no profiles/pmc_secondary_latest.json"
+        return None
+    if d.get("kernel_sources_sha") != kernel_sources_sha():
+        pmc_secondary.note = "withheld: profiles/pmc_secondary_latest.json was collected on other kernel sources (%s, now %s)" % (d.get("kernel_sources_sha"), kernel_sources_sha())
+        return None
+    rec = (d.get(workload) or {}).get(kernel)
+    if rec is None:
+        pmc_secondary.note = "profiles/pmc_secondary_latest.json holds no %s / %s" % (workload, kernel)
+    return rec
+
+
+# FP64 issue ceiling of a SIMD at two waves per SIMD: cycles per v_fma_f64 at the nominal 2.4 GHz (tools/fp64_rate_test.hip,
+# profiles/r04_fp64_rates.txt: 6.9 at one wave, 5.9 - 6.0 at two, 5.3 at four)
+FP64_ISSUE_CYCLES = {1: 6.9, 2: 5.92, 4: 5.28}
+N_SIMDS, NOMINAL_HZ = 1024, 2.4e9
+
+
 def host_cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -787,21 +813,35 @@ def secondary_workload(args):
         ctx.set_image(frame1)
         patches = gt.patch_corners(region)
 
+        gframe, gd_, gsm_ = gt.tracker.batch.grid_frame, gt.gd, gt.tracker.sm
+
         def step():
-            gt.update_patches(patches)     # setRegion + update of every patch tracker: one C-ABI call, one upload, one launch of the loop
+            gframe(gd_, gsm_, region)      # the patches laid over the region (the reference's layout), setRegion + update of every patch tracker: one C-ABI call, one launch
         dt = timed(step)
         kernel_pass(step)
         kms, kn = ctx.timing_get("iclk_track")
-        gb = 84.0 * 625 * 256 * args.grid_iters   # ICLK (InitialSelf) + Affine moves (36 + 8 S) N = 84 N bytes per patch-iteration
+        # What a frame MOVES ("never credit bytes that were not moved"): the patch operands are read once and stay in
+        # registers / LDS for the ten iterations -- I0 8 B + the template's SD rows 8 S B per pixel, the 64 x 64 texel window (16 KB), and
+        # the template grid the region mode lays out for later callers (INIT_PTS 16 + INIT_HXY 16 + INIT_Z 8 B per pixel, written) --
+        # ~19 MB per frame, not the 84 B x N x iterations (134 MB) an HBM roofline of the ICLK iteration would credit.  The frame is a
+        # LATENCY figure: 256 workgroups, one per patch, ten dependent iterations each.
+        moved = (8.0 + 8.0 * 6 + 40.0) * 625 * 256 + 256 * 64 * 64 * 4.0
+        pm = pmc_secondary("grid", "k_iclk_track")
+        frame_us = dt / args.steps * 1e6
         out.update({"metric": "grid patch-iterations/sec, GridTracker 256 patches ICLK+NCC+Affine 25x25",
                     "value": 256 * args.grid_iters * args.steps * world / dt, "unit": "patch-iters/s",
                     "ms_per_step": dt / args.steps * 1e3, "scaling": "weak",
-                    "config": {"workload": "256 patches x %d ICLK iterations per step, one launch per frame" % args.grid_iters},
-                    "roofline": {"bound": "hbm", "note": "latency bound by construction: 256 workgroups, one per patch, ten dependent iterations "
-                                 "each; the patch operands (35 KB) are register / L2 resident after the first iteration",
-                                 "achieved": gb / (kms * 1e-3) / 1e9 if kms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": gb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms > 0 else None, "traffic": None,
-                                 "kernel": "k_iclk_track", "avg_kernel_ms": kms, "launches_timed": kn, "algorithmic_bytes_per_launch": gb}})
+                    "config": {"workload": "256 patches x %d ICLK iterations per step, one launch per frame; the reference's shipped patch layout "
+                                           "(patch_centroid_inside = 1: 17 x 17 grid SSM points, patches centred on the cells' centroids, "
+                                           "mtfhip_grid_frame = layout + setRegion + update in one C-ABI call)" % args.grid_iters,
+                               "frame_us": frame_us, "kernel_us": kms * 1e3, "kernel_share_of_frame": kms * 1e3 / frame_us if frame_us > 0 else None},
+                    "roofline": {"bound": "latency", "note": "256 workgroups, one per patch, ten dependent iterations each: neither HBM nor FP64 issue "
+                                 "bounds a frame; achieved / frac are the bytes actually moved per launch over the kernel time, for what they are",
+                                 "achieved": moved / (kms * 1e-3) / 1e9 if kms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": moved / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms > 0 else None,
+                                 "traffic": pm.get("traffic_bytes_per_launch") if pm else None, "traffic_note": getattr(pmc_secondary, "note", None),
+                                 "kernel": "k_iclk_track", "avg_kernel_ms": kms, "launches_timed": kn, "moved_bytes_per_launch_estimate": moved,
+                                 "kernel_sources_sha": kernel_sources_sha()}})
         if rank == 0 and not args.no_cpu:
             import oracle_py as O
             ssm = O.SSM(O.SSM_AFF, 25, 25); am = O.AM(O.AM_NCC, 25, 25); am.set_curr_img(frame0)
@@ -855,8 +895,10 @@ def secondary_workload(args):
                                                     "samples_per_s": C * 2500 * KI * args.steps / dt},
                     "roofline": {"bound": "fp64-valu", "note": "the candidate scorer is not HBM bound (SURVEY 8d: ~1 MB of compulsory traffic for 25 M "
                                  "samples): fraction of the FP64 vector peak at ~60 flop per sample, and the texel gather rate served by L1 / L2",
-                                 "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6, "traffic": None,
-                                 "kernel": "k_pf_score", "avg_kernel_ms": kms,
+                                 "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
+                                 "traffic": (pmc_secondary("pf", "k_pf_score") or {}).get("traffic_bytes_per_launch") if C == 10000 and world == 1 else None,
+                                 "traffic_note": getattr(pmc_secondary, "note", None) if C == 10000 and world == 1 else "PMC passes are taken at 10 000 particles on one rank",
+                                 "kernel": "k_pf_score", "avg_kernel_ms": kms, "kernel_sources_sha": kernel_sources_sha(),
                                  "launches_timed": kn, "samples_per_launch": n_local * 2500,
                                  "texel_gather_GBs": n_local * 2500 * 16 / (kms * 1e-3) / 1e9 if kms > 0 else None}})
         if rank == 0 and world == 1 and not args.no_cpu:
@@ -951,11 +993,27 @@ def secondary_workload(args):
             Cn = 3 if mc else 1   # rows are (pixel, channel) pairs; the pixel's grid point (16 B) is shared by its rows
             bpr = (12.0 + 16.0 / Cn) + (28.0 + 16.0 / Cn)
             mi_bytes = bpr * res * res * Cn * B
-            mi_roof = {"bound": "hbm", "note": "72 B/px (multi-channel: 50.7 B per (pixel, channel) row) moved per iteration (the materialising form moved 324); the two passes are bound by "
-                       "FP64 / LDS / matrix-core issue, not by HBM: the fraction is reported for what it is",
-                       "achieved": mi_bytes / ((p1 + p2) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": mi_bytes / ((p1 + p2) * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_mi_pass_hist + k_mi_pass_grad_hess",
-                       "avg_kernel_ms": {"pass1": p1, "pass2": p2}, "launches_timed": n1, "algorithmic_bytes_per_row": bpr, "rows_per_target": res * res * Cn}
+            # The passes are bound by FP64 VALU issue at two waves per SIMD (r04 PMC: one VALU instruction per 5.8 cycles and SIMD against the
+            # measured 5.9 ceiling), not by HBM: `frac` = the cycles the counted VALU instructions need at that ceiling / the cycles the
+            # kernels took (both passes; counters from profiles/pmc_secondary_latest.json, quoted only for the kernel sources being run);
+            # the HBM figure rides along as hbm_frac.
+            standard = (not mc) and B == 64 and res == 400
+            pm1 = pmc_secondary("mi", "k_mi_pass_hist") if standard else None
+            pm2 = pmc_secondary("mi", "k_mi_pass_grad_hess") if standard else None
+            note = getattr(pmc_secondary, "note", None) if standard else "PMC passes are taken on the 64 x 400 x 400 single-channel workload"
+            valu = (pm1.get("SQ_INSTS_VALU", 0) + pm2.get("SQ_INSTS_VALU", 0)) if (pm1 and pm2) else None
+            issue_s = valu * FP64_ISSUE_CYCLES[2] / N_SIMDS / NOMINAL_HZ if valu else None
+            hbm_GBs = mi_bytes / ((p1 + p2) * 1e-3) / 1e9
+            mi_roof = {"bound": "fp64-valu-issue", "note": "VALU issue at two waves per SIMD (one FP64 instruction per %.2f cycles and SIMD at the nominal "
+                       "2.4 GHz, profiles/r04_fp64_rates.txt); 72 B/px (multi-channel: 50.7 B per (pixel, channel) row) are moved per iteration" % FP64_ISSUE_CYCLES[2],
+                       "achieved": valu / ((p1 + p2) * 1e-3) / 1e9 if valu else None, "peak": N_SIMDS * NOMINAL_HZ / FP64_ISSUE_CYCLES[2] / 1e9,
+                       "unit": "G VALU wave-instructions/s", "frac": issue_s / ((p1 + p2) * 1e-3) if issue_s else None,
+                       "valu_instructions_per_launch": {"pass1": pm1.get("SQ_INSTS_VALU") if pm1 else None, "pass2": pm2.get("SQ_INSTS_VALU") if pm2 else None},
+                       "traffic": (pm1["traffic_bytes_per_launch"] + pm2["traffic_bytes_per_launch"]) if (pm1 and pm2 and "traffic_bytes_per_launch" in pm1 and "traffic_bytes_per_launch" in pm2) else None,
+                       "traffic_note": note, "algorithmic_bytes_per_iteration": mi_bytes,
+                       "hbm_GBs": hbm_GBs, "hbm_frac": hbm_GBs / HBM_PEAK_GBS, "kernel": "k_mi_pass_hist + k_mi_pass_grad_hess",
+                       "avg_kernel_ms": {"pass1": p1, "pass2": p2}, "launches_timed": n1, "algorithmic_bytes_per_row": bpr, "rows_per_target": res * res * Cn,
+                       "kernel_sources_sha": kernel_sources_sha()}
         else:
             mi_roof = None
         out.update({"roofline": mi_roof})
@@ -1128,8 +1186,10 @@ def main():
     k_steps = max(200, args.steps)
     ctx.timing(1)
     ctx.timing_reset()
-    run(k_steps)
+    t_ev = time.perf_counter()
+    n_ev, _ = run(k_steps)
     torch.cuda.synchronize(dev)
+    ev_pass_s = time.perf_counter() - t_ev   # (includes the setRegion in front of the loop: a few hundred microseconds of k_steps steps)
     kern_ms, kern_n = ctx.timing_get("fused_lk")
     # launches of the fused kernel overlap when the loop keeps two chunks of targets in flight on two queues: the time the kernel was
     # executing is the union of the launches' intervals (equal to their sum on one queue)
@@ -1228,6 +1288,10 @@ def main():
                          "formula": "achieved = bytes_per_launch x launches_timed / kernel_busy_ms (kernel_busy_ms = union of the launches' "
                                     "event intervals) = per_launch_GBs x launches_in_flight",
                          "avg_finish_ms": fin_ms,
+                         # `frac` comes from the event pass, `value` / `ms_per_step` from the timed region: two executions of the same loop,
+                         # side by side (the event pass records two events per launch and is the slower, i.e. the conservative one)
+                         "event_pass": {"steps": k_steps, "ms_per_step_wall": ev_pass_s / k_steps * 1e3, "kernel_busy_ms_per_step": busy_ms / k_steps,
+                                        "timed_region_ms_per_step": dt / args.steps * 1e3},
                          # the event pass perturbs the overlap of the two queues (events are recorded around every launch); the timed
                          # region has no events: its algorithmic bytes / its wall time -- solves, cold first passes and call overhead
                          # included -- is a lower bound on what the fused launches reached there
