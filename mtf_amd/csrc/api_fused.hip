@@ -625,13 +625,16 @@ static int mi_enqueue_fast(mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPl
 	int so_own_pts = -1) {
 	const int nblk = mi_blocks(b);
 	hipStream_t st = b->ctx->stream;
-	const MiFastPlan fp = mi_fast_plan(b, pl, active, sm);
+	MiFastPlan fp = mi_fast_plan(b, pl, active, sm);
+	if (!b->d_mi_poly) HIP_TRY(hipMalloc(&b->d_mi_poly, sizeof(double) * (size_t)mi_poly_size() * b->B));
+	fp.poly = b->d_mi_poly;
 	const BatchView bv = b->view();
 	{
 		TimedScope tsc(b->ctx, "mi_pass1");
 		launch_mi_pass_hist(bv, b->ctx->img, fp, b->d_mi_part, nblk, b->mi_row_len, st);
 	}
 	launch_mi_tables_iter(bv, 8, b->desc.mi_pre_seed, b->mi_hist_norm, fp.hk == 1 ? 1 : 0, b->d_mi_part, nblk, b->mi_row_len, b->d_mi_tb, b->d_mi_f, st);
+	if (fp.hk <= 1) launch_mi_poly_tables(bv, b->d_mi_tb, b->mi_hist_norm, fp.hk == 1 ? 1 : 0, b->d_mi_poly, st);   /* (the dense Hessian kinds read the tables themselves) */
 	{
 		TimedScope tsc(b->ctx, "mi_pass2");
 		launch_mi_pass_grad_hess(bv, b->ctx->img, fp, b->d_mi_part, nblk, st);

@@ -215,6 +215,67 @@ __global__ __launch_bounds__(kBlock) void k_mi_finish_fast(BatchView bv, mtfhip_
 	finish_track_body(bv, sm, ts, rows, 1, t);
 }
 
+/* The gradient-factor tables of an iteration as per-class polynomials for pass 2 (kMiPoly*, mtfhip_mi_fused_device.h): one workgroup per
+ * target, 2 x 64 x 12 + 8 x 5 coefficients of 16 multiply-adds each -- negligible next to the passes, and it runs once per target
+ * instead of once per workgroup of pass 2.  Tables are indexed with (bin + 1) and have a zero border of one bin below and three above
+ * (window rows fl .. fl + 3 for fl <= 7): the taps on the non-existent bins -1, 8, 9 contribute nothing (MI.cc:114-117). */
+__global__ __launch_bounds__(kBlock) void k_mi_poly_tables(const double *tb_all, double hist_norm, int with_self, double *poly_all) {
+	__shared__ double Tc[12 * 12], Ti[12 * 12], Th[12 * 12];
+	const int t = blockIdx.x;
+	const double *tb = tb_all + (size_t)t * MI_SIZE;
+	for (int k = threadIdx.x; k < 144; k += kBlock) {
+		const int r = k / 12 - 1, c = k % 12 - 1;
+		const bool in = r >= 0 && r < 8 && c >= 0 && c < 8;
+		Tc[k] = in ? tb[MI_T_CURR + r * MI_NB + c] : 0.0; Ti[k] = in ? tb[MI_T_INIT + r * MI_NB + c] : 0.0;
+		Th[k] = (in && with_self) ? tb[MI_T_SELF + r * MI_NB + c] : 0.0;
+	}
+	__syncthreads();
+	constexpr MiPolyCoef CF = mi_poly_coef();
+	double *out = poly_all + (size_t)t * kMiPolySize;
+	for (int k = threadIdx.x; k < 2 * 64 * kMiPolyPair; k += kBlock) {
+		const int which = k / (64 * kMiPolyPair), e = k % (64 * kMiPolyPair);
+		const int pair = e / kMiPolyPair, ab = e % kMiPolyPair, a = ab >> 2, b = ab & 3;
+		const int f1 = pair >> 3, f2 = pair & 7;   /* rows by the differentiated window's class, columns by the other's */
+		const double *T = which ? Ti : Tc;
+		double acc = 0.0;
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			double dc = 0.0;
+#pragma unroll
+			for (int aa = 0; aa < 3; ++aa) dc = a == aa ? CF.d[r][aa] : dc;
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				double wc = 0.0;
+#pragma unroll
+				for (int bb = 0; bb < 4; ++bb) wc = b == bb ? CF.w[c][bb] : wc;
+				acc = fma(dc * wc, T[(f1 + r) * 12 + f2 + c], acc);
+			}
+		}
+		out[k] = acc * hist_norm;
+	}
+	for (int k = threadIdx.x; k < 64; k += kBlock) {
+		const int fl = k >> 3, j = k & 7;
+		double acc = 0.0;
+		if (j < 5) {
+#pragma unroll
+			for (int r = 0; r < 4; ++r)
+#pragma unroll
+				for (int c = 0; c < 4; ++c)
+#pragma unroll
+					for (int a = 0; a < 2; ++a) {
+						const int b = j - a;
+						if (b >= 0 && b < 4) {
+							double wc = 0.0;
+#pragma unroll
+							for (int bb = 0; bb < 4; ++bb) wc = b == bb ? CF.w[c][bb] : wc;
+							acc = fma(CF.h[r][a] * wc, Th[(fl + r) * 12 + fl + c], acc);
+						}
+					}
+		}
+		out[kMiPolyH + k] = acc * hist_norm;
+	}
+}
+
 /* ===================================================================== */
 /* launchers                                                              */
 /* ===================================================================== */
@@ -223,7 +284,7 @@ static MiPassArgs make_args(const MiFastPlan &pl) {
 	pa.nb = 8; pa.j0_mode = pl.j0_mode; pa.j0_init_variant = pl.j0_init_variant; pa.need_dft = pl.need_dft; pa.need_df0 = pl.need_df0;
 	pa.g_mean = pl.g_mean; pa.table_off = 0; pa.transpose_q = pl.hk == 3; pa.nonchained = pl.nonchained;
 	pa.grad_eps = pl.grad_eps; pa.norm_mult = pl.norm_mult; pa.norm_add = pl.norm_add; pa.hist_norm = pl.hist_norm;
-	pa.active = pl.active; pa.tb = pl.tb; pa.cand_states = nullptr;
+	pa.active = pl.active; pa.tb = pl.tb; pa.poly = pl.poly; pa.cand_states = nullptr;
 	return pa;
 }
 template <int SSM, bool MC>
@@ -257,6 +318,10 @@ void launch_mi_score_candidates(const BatchView &bv, const ImgView &im, const Mi
 	MTFHIP_LAUNCH(k_mi_cand_score, dim3(cnt), dim3(64), 0, st, cnt, lo, (const double *)partials, nblk, row_len, pl.tb, pre_seed, pl.hist_norm, alpha,
 		likelihood_func, measurement_sigma, max_similarity, wts, sim);
 }
+void launch_mi_poly_tables(const BatchView &bv, const double *tb, double hist_norm, int with_self, double *poly, hipStream_t st) {
+	MTFHIP_LAUNCH(k_mi_poly_tables, dim3(bv.B), dim3(kBlock), 0, st, tb, hist_norm, with_self, poly);
+}
+int mi_poly_size() { return kMiPolySize; }
 /* pass 2 is instantiated per (SSM, channels) in its own translation unit: kernels_mi_pass2_*.hip */
 void launch_mi_pass2_hom(const BatchView &bv, const ImgView &im, const MiPassArgs &pa, int hk, int hrow, double *partials, int nblk, hipStream_t st);
 void launch_mi_pass2_aff(const BatchView &bv, const ImgView &im, const MiPassArgs &pa, int hk, int hrow, double *partials, int nblk, hipStream_t st);

@@ -199,6 +199,7 @@ struct mtfhip_batch {
 	double *d_ncc = nullptr, *d_colmean = nullptr; /* [B][8] NCC scalars / column means */
 	/* MI: per-target table block, block partial rows, similarity and Hessian outputs */
 	double *d_mi_tb = nullptr, *d_mi_part = nullptr, *d_mi_f = nullptr, *d_mi_H = nullptr;
+	double *d_mi_poly = nullptr;   /* [B][mi_poly_size()], allocated by the first recompute iteration */
 	double *d_mi_red = nullptr;   /* [B][mi_row_len] block rows summed (the Hessian assembly then reads one row per target) */
 	double *d_h0inv = nullptr; /* [B][64] inverse of the constant Hessian (one-launch ICLK) */
 	double *d_d2_part = nullptr, *d_d2_out = nullptr, *d_d2_w = nullptr; /* second-order term: block rows, [B][64] sums, MI self weights */

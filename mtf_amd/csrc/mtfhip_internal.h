@@ -300,7 +300,10 @@ struct MiFastPlan {
 	double grad_eps, norm_mult, norm_add, hist_norm;
 	const int *active;    /* device flags, NULL = all */
 	const double *tb;     /* [B][MI_SIZE] */
+	const double *poly = nullptr;   /* [B][mi_poly_size()]: the tables as per-class polynomials (launch_mi_poly_tables), read by pass 2 */
 };
+void launch_mi_poly_tables(const BatchView &bv, const double *tb, double hist_norm, int with_self, double *poly, hipStream_t st);
+int mi_poly_size();
 void launch_mi_pass_hist(const BatchView &bv, const ImgView &im, const MiFastPlan &pl, double *partials, int nblk, int row_len, hipStream_t st);
 void launch_mi_pass_grad_hess(const BatchView &bv, const ImgView &im, const MiFastPlan &pl, double *partials, int nblk, hipStream_t st);
 void launch_mi_finish_fast(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, const MiFastPlan &pl, int gmode, int do_track,

@@ -131,6 +131,7 @@ struct MiPassArgs {
 	double grad_eps, norm_mult, norm_add, hist_norm;
 	const int *active;
 	const double *tb;       /* [B][MI_SIZE] */
+	const double *poly;     /* [B][kMiPolySize]: the gradient-factor tables as per-class polynomials (k_mi_poly_tables) */
 	const double *cand_states;   /* candidate mode of pass 1 (k_mi_pass_hist<.., CAND = true>): [n][S] warps of ONE template */
 };
 
@@ -228,6 +229,24 @@ __host__ __device__ constexpr MiMomentCoef mi_moment_coef() {
 		}
 	return o;
 }
+/* r05: the table sums of pass 2 as POLYNOMIALS.  With fl = floor(It), phi = It - fl (and fl0, phi0 of the template value) the taps
+ * of a pixel's windows are fixed polynomials of phi / phi0 (above), so
+ *   df_dIt = sum_r d_r(phi) sum_c w_c(phi0) T_curr[fl - 1 + r][fl0 - 1 + c] = sum_{a <= 2, b <= 3} PT[fl][fl0][a][b] phi^a phi0^b
+ *   df_dI0 = sum_r d_r(phi0) sum_c w_c(phi) T_init[fl0 - 1 + r][fl - 1 + c] = sum_{a <= 2, b <= 3} PI[fl0][fl][a][b] phi0^a phi^b
+ *   hess_term = sum_r h_r(phi) sum_c w_c(phi) T_self[fl - 1 + r][fl - 1 + c] = sum_{j <= 4} PH[fl][j] phi^j
+ * with coefficients that depend on the iteration's tables only: k_mi_poly_tables builds them once per target and iteration (12 per
+ * class pair), pass 2 evaluates 11 + 11 + 4 multiply-adds per pixel by Horner's rule instead of two B-spline windows (~90 instructions)
+ * and three 4 x 4 table contractions (60 multiply-adds, 48 LDS reads).  Bins outside the histogram meet the zero border of the
+ * tables when the coefficients are built, which is what the reference's clamped id range amounts to (MI.cc:114-117). */
+constexpr int kMiPolyPair = 12;                      /* [a = 0..2][b = 0..3] */
+constexpr int kMiPolyT = 0, kMiPolyI = 64 * kMiPolyPair, kMiPolyH = 2 * 64 * kMiPolyPair, kMiPolySize = 2 * 64 * kMiPolyPair + 64;
+struct MiPolyCoef { double w[4][4], d[4][3], h[4][2]; };   /* coefficients of phi^0.. of tap k's weight, derivative (x -1: d = -dw/dv) and second derivative; x hist_norm outside */
+__host__ __device__ constexpr MiPolyCoef mi_poly_coef() {
+	constexpr double c23 = 0.66666666666;
+	return MiPolyCoef{{{1.0 / 6, -0.5, 0.5, -1.0 / 6}, {c23, 0.0, -1.0, 0.5}, {c23 - 0.5, 0.5, 0.5, -0.5}, {0.0, 0.0, 0.0, 1.0 / 6}},
+		{{-0.5, 1.0, -0.5}, {0.0, -2.0, 1.5}, {0.5, 1.0, -1.5}, {0.0, 0.0, 0.5}},
+		{{1.0, -1.0}, {-2.0, 3.0}, {1.0, -3.0}, {0.0, 1.0}}};
+}
 constexpr int kMiFastRow = 16 + 64 + 512;
 constexpr int kTRows = 12;   /* gradient-factor tables in LDS, indexed with (bin + 1) in both directions, zero borders */
 /* NONCH: the search method's chained_warp = 0 (mi_finish's non-chained form + cmptInitPixJacobian rows); its own instantiation so that
@@ -237,23 +256,29 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 	constexpr int S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
 	constexpr int nb = 8;
 	constexpr bool SORTED = HK == 1;
-	constexpr int kSRows = 11;   /* sorted staging rows: valid | phi | J[8] | hess_term */
+	constexpr int kSRows = 15;   /* sorted staging rows: valid phi^0..5 | J[8] | hess_term */
 	constexpr int SLAB = SORTED ? kSRows * kRS2 + 8 * kQR : (HK ? (2 * kWinRows + 9) * kRS : 0);   /* dense: gd[11] | wd[11] | rw[8] | ht ; sorted: valid | phi | rw[8] | ht | M[8 classes][8 powers][8] */
-	__shared__ __attribute__((aligned(16))) double Tc[kTRows * MI_NB], Ti[kTRows * MI_NB], Th[HK == 1 ? kTRows * MI_NB : 1];
+	constexpr bool POLY = HK == 0 || HK == 1;   /* the table sums as per-class polynomials (no window is needed: the bin mode of the self Hessian is in moment form) */
+	__shared__ __attribute__((aligned(16))) double Tc[POLY ? 2 : kTRows * MI_NB], Ti[POLY ? 2 : kTRows * MI_NB], Th[1];
+	__shared__ __attribute__((aligned(16))) double Pl[POLY ? kMiPolySize : 2];
 	__shared__ __attribute__((aligned(16))) double slabs[HK ? 4 * SLAB : 4 * 16];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int t = blockIdx.y;
 	if (pa.active && !pa.active[t]) return;
 	const double *tb = pa.tb + (size_t)t * MI_SIZE;
-	for (int k = threadIdx.x; k < kTRows * MI_NB; k += kBlock) {
-		const int r = k / MI_NB - 1, c = k % MI_NB - 1;
-		const bool in = r >= 0 && r < nb && c >= 0 && c < nb;
-		Tc[k] = in ? tb[MI_T_CURR + r * MI_NB + c] : 0.0; Ti[k] = in ? tb[MI_T_INIT + r * MI_NB + c] : 0.0;
-		if constexpr (HK == 1) Th[k] = in ? tb[MI_T_SELF + r * MI_NB + c] : 0.0;
+	if constexpr (POLY) {
+		const double *pl = pa.poly + (size_t)t * kMiPolySize;
+		for (int k = threadIdx.x; k < kMiPolySize; k += kBlock) Pl[k] = pl[k];
+	} else {
+		for (int k = threadIdx.x; k < kTRows * MI_NB; k += kBlock) {
+			const int r = k / MI_NB - 1, c = k % MI_NB - 1;
+			const bool in = r >= 0 && r < nb && c >= 0 && c < nb;
+			Tc[k] = in ? tb[MI_T_CURR + r * MI_NB + c] : 0.0; Ti[k] = in ? tb[MI_T_INIT + r * MI_NB + c] : 0.0;
+		}
 	}
 	const double *Tq = HK == 1 ? Th : (HK == 2 ? Tc : Ti);
 	double *gd = slabs + (size_t)wave * SLAB, *wd = gd + kWinRows * kRS, *rw = wd + kWinRows * kRS, *hts = rw + 8 * kRS;
-	double *sd = slabs + (size_t)wave * SLAB, *sphi = sd + kRS2, *srw = sphi + kRS2, *sht = srw + 8 * kRS2;   /* sorted form: sd = the validity row */
+	double *sd = slabs + (size_t)wave * SLAB, *srw = sd + 6 * kRS2, *sht = srw + 8 * kRS2;   /* sorted form: sd = the six power rows valid phi^k (r05: staged once per pixel instead of rebuilt by every lane of every step) */
 	double *qabs = sht + kRS2;   /* this wave's moment table M[class][power][s] */
 	if constexpr (SORTED) { for (int k2 = lane; k2 < SLAB; k2 += 64) sd[k2] = 0.0; }
 	else if constexpr (HK != 0) { for (int k2 = 0; k2 < 2 * kWinRows + 9; ++k2) gd[k2 * kRS + lane] = 0.0; }
@@ -355,17 +380,42 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 				j0[0] = g0x; j0[1] = g0y; j0[2] = g0x * x; j0[3] = g0x * y; j0[4] = g0y * x; j0[5] = g0y * y;
 			}
 		}
-		const BsplWin4 a = bspl_window4<HK == 1 || HK == 2>(sp.it, nb, pa.hist_norm);
-		const BsplWin4 c0 = bspl_window4<HK == 3>(i0, nb, pa.hist_norm);
+		BsplWin4 a, c0;
+		double dft = 0, df0 = 0;
+		int fl_it = 0; double phi_it = 0.0, hess_term = 0.0;
+		if constexpr (POLY) {
+			/* class and fraction of both pixel values; the three table sums by Horner's rule on the class pair's coefficients (see kMiPoly*) */
+			fl_it = min(max((int)sp.it, 0), nb - 1); phi_it = sp.it - (double)fl_it;
+			const int fl0 = min(max((int)i0, 0), nb - 1);
+			const double phi0 = i0 - (double)fl0;
+#if defined(MTFHIP_MI_ABL) && MTFHIP_MI_ABL == 2
+			dft = phi_it + phi0; df0 = phi0;
+#else
+			if (pa.need_dft) {
+				const double *c = Pl + kMiPolyT + (fl_it * 8 + fl0) * kMiPolyPair;
+				const double r0 = fma(fma(fma(c[3], phi0, c[2]), phi0, c[1]), phi0, c[0]);
+				const double r1 = fma(fma(fma(c[7], phi0, c[6]), phi0, c[5]), phi0, c[4]);
+				const double r2 = fma(fma(fma(c[11], phi0, c[10]), phi0, c[9]), phi0, c[8]);
+				dft = fma(fma(r2, phi_it, r1), phi_it, r0) * vm;
+			}
+			if (pa.need_df0) {
+				const double *c = Pl + kMiPolyI + (fl0 * 8 + fl_it) * kMiPolyPair;
+				const double r0 = fma(fma(fma(c[3], phi_it, c[2]), phi_it, c[1]), phi_it, c[0]);
+				const double r1 = fma(fma(fma(c[7], phi_it, c[6]), phi_it, c[5]), phi_it, c[4]);
+				const double r2 = fma(fma(fma(c[11], phi_it, c[10]), phi_it, c[9]), phi_it, c[8]);
+				df0 = fma(fma(r2, phi0, r1), phi0, r0) * vm;
+			}
+#endif
+			if constexpr (SORTED) {
+				const double *c = Pl + kMiPolyH + fl_it * 8;
+				hess_term = fma(fma(fma(fma(c[4], phi_it, c[3]), phi_it, c[2]), phi_it, c[1]), phi_it, c[0]);
+			}
+		} else {
+		a = bspl_window4<HK == 1 || HK == 2>(sp.it, nb, pa.hist_norm);
+		c0 = bspl_window4<HK == 3>(i0, nb, pa.hist_norm);
 		/* df_dIt = sum gradIt(r) matI0(c) T_curr(r, c), df_dI0 = sum gradI0(r) matIt(c) T_init(r, c) (MI.cc:406-415, 432-441),
 		 * factored: the inner sums over the second window first.  Taps outside the histogram meet the tables' zero border. */
-		double dft = 0, df0 = 0;
-#if defined(MTFHIP_MI_ABL) && MTFHIP_MI_ABL == 2
-		dft = a.d[0] + c0.w[1]; df0 = c0.d[2] + a.w[3];
-		if (false) {
-#else
 		if (pa.need_dft) {
-#endif
 			const double *T0 = Tc + a.row0 * MI_NB + c0.row0;
 #pragma unroll
 			for (int r = 0; r < 4; ++r) {
@@ -375,11 +425,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 			}
 			dft *= vm;
 		}
-#if defined(MTFHIP_MI_ABL) && MTFHIP_MI_ABL == 2
-		if (false) {
-#else
 		if (pa.need_df0) {
-#endif
 			const double *T0 = Ti + c0.row0 * MI_NB + a.row0;
 #pragma unroll
 			for (int r = 0; r < 4; ++r) {
@@ -389,35 +435,28 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 			}
 			df0 *= vm;
 		}
+		}
 #pragma unroll
 		for (int s = 0; s < 8; ++s) {
 			const double jg = pa.g_mean ? 0.5 * (j0[s] + jt[s]) : jt[s];
 			acc[s] = fma(dft, jg, acc[s]); acc[8 + s] = fma(df0, j0[s], acc[8 + s]);
 		}
 #if defined(MTFHIP_MI_ABL) && MTFHIP_MI_ABL <= 2   /* ablation builds (tools/mi_ablation.sh): 1 no bin mode, 2 no table sums either */
-		if constexpr (SORTED) { acc[0] += a.d[0] + a.h[1] + jt[3] + jt[7]; } else
+		if constexpr (SORTED) { acc[0] += hess_term + jt[3] + jt[7]; } else
 #endif
 		if constexpr (SORTED) {
-			double hess_term = 0;
-			{
-				const double *T0 = Tq + a.row0 * MI_NB + a.row0;
-#pragma unroll
-				for (int r = 0; r < 4; ++r) {
-					const double *Tr = T0 + r * MI_NB;
-					const double inner = fma(a.w[3], Tr[3], fma(a.w[2], Tr[2], fma(a.w[1], Tr[1], a.w[0] * Tr[0])));
-					hess_term = fma(a.h[r], inner, hess_term);
-				}
-			}
 			const bool valid = i < N;
 #if defined(MTFHIP_MI_ABL) && MTFHIP_MI_ABL == 4   /* ablation: no sort (one class of 64 slots) */
 			ClassSort cs; cs.slot = lane; cs.ends = 0x4040404040404040ull; cs.total = 64;
 #else
-			const ClassSort cs = class_sort8(valid ? a.row0 : -1);
+			const ClassSort cs = class_sort8(valid ? fl_it : -1);
 #endif
 			const int steps = (cs.total + 15) >> 4;   /* quads per block */
 			const int mycol = sorted_col(cs.slot, steps);
 			if (valid) {
-				sd[mycol] = 1.0; sphi[mycol] = sp.it - (double)a.row0;   /* phi = It - fl: every tap of the window is a polynomial of it */
+				const double ph = phi_it;   /* phi = It - fl: every tap of the window is a polynomial of it */
+				const double ph2 = ph * ph, ph3 = ph2 * ph, ph4 = ph2 * ph2, ph5 = ph4 * ph;
+				sd[mycol] = 1.0; sd[kRS2 + mycol] = ph; sd[2 * kRS2 + mycol] = ph2; sd[3 * kRS2 + mycol] = ph3; sd[4 * kRS2 + mycol] = ph4; sd[5 * kRS2 + mycol] = ph5;
 #pragma unroll
 				for (int s2 = 0; s2 < 8; ++s2) srw[s2 * kRS2 + mycol] = jt[s2];
 				sht[mycol] = hess_term;
@@ -430,7 +469,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 			 * sum hess_term J J^T.  A block's accumulators belong to the class of ITS quad: block b takes the quads [b steps, (b + 1) steps)
 			 * of the sorted order, crosses each class boundary of its range once, and when its next quad is of another class its sums
 			 * go to the wave's moment table through ds_add_f64.  Slots behind a class's last pixel have valid = 0 and hess_term = 0. */
-			const double *pv = sd, *pp_ = sphi, *pja = srw + li * kRS2, *pjb = pja + 4 * kRS2, *pht = sht;   /* + this lane's column of the step */
+			/* A operands: row li of the low tile = valid phi^li, row li of the high tile = valid phi^(4 + li) for li < 2; rows 2, 3 of the high
+			 * tile are padding -- their results (rows 2, 3 of q10 / q11) are never flushed, so those lanes may read any finite row */
+			const double *plo = sd + li * kRS2, *phi_ = sd + (4 + (li & 1)) * kRS2, *pja = srw + li * kRS2, *pjb = pja + 4 * kRS2, *pht = sht;   /* + this lane's column of the step */
 			/* class of the quad that starts at slot s0 = number of classes that end at or before it (empty classes included: they end
 			 * where their predecessor does); byte-wise on the packed end slots, no borrow between bytes: (s0 | 0x80) - end >= 0x80 - 88 > 0 */
 			const unsigned ends_lo = (unsigned)cs.ends, ends_hi = (unsigned)(cs.ends >> 32);
@@ -451,14 +492,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 				q00 = q01 = q10 = q11 = 0.0;
 				cls = to;
 			};
-			/* the A operands of a lane: valid phi^li and valid phi^(4 + li) (li < 2; the rest of that tile is padding) */
-			auto powers = [&](double v, double ph, double &lo, double &hi) {
-				const double p2 = ph * ph, p3 = p2 * ph, p4 = p2 * p2, p5 = p4 * ph;
-				lo = v * (li == 0 ? 1.0 : (li == 1 ? ph : (li == 2 ? p2 : p3)));
-				hi = v * (li == 0 ? p4 : (li == 1 ? p5 : 0.0));
-			};
 			int o = window_col(0, lb, lk);
-			double c_v = pv[o], c_ph = pp_[o], c_ja = pja[o], c_jb = pjb[o], c_ht = pht[o];
+			double c_lo = plo[o], c_hi = phi_[o], c_ja = pja[o], c_jb = pjb[o], c_ht = pht[o];
 			const int s_first = 4 * lb * steps;   /* first slot of this block's range */
 			{
 				const int c_first = class_of(s_first);
@@ -473,10 +508,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 #endif
 				/* operands of the next step first (one step past the end reads the columns behind the window: discarded) */
 				o = window_col(j + 1, lb, lk);
-				const double n_v = pv[o], n_ph = pp_[o], n_ja = pja[o], n_jb = pjb[o], n_ht = pht[o];
+				const double n_lo = plo[o], n_hi = phi_[o], n_ja = pja[o], n_jb = pjb[o], n_ht = pht[o];
 				{
-					double a_lo, a_hi;
-					powers(c_v, c_ph, a_lo, a_hi);
+					const double a_lo = c_lo, a_hi = c_hi;
 					q00 = __builtin_amdgcn_mfma_f64_4x4x4f64(a_lo, c_ja, q00, 0, 0, 0); q01 = __builtin_amdgcn_mfma_f64_4x4x4f64(a_lo, c_jb, q01, 0, 0, 0);
 					q10 = __builtin_amdgcn_mfma_f64_4x4x4f64(a_hi, c_ja, q10, 0, 0, 0); q11 = __builtin_amdgcn_mfma_f64_4x4x4f64(a_hi, c_jb, q11, 0, 0, 0);
 					const double ha = c_ja * c_ht, hb = c_jb * c_ht;   /* sum hess_term J J^T: tile (X, Y) = rows 4 X + i weighted, columns 4 Y + j */
@@ -487,15 +521,19 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 					const int cls_nx = class_of(s_first + 4 * (j + 1));
 					if (cls_nx != cls && cls_nx < 8) leave_class(cls_nx);
 				}
-				c_v = n_v; c_ph = n_ph; c_ja = n_ja; c_jb = n_jb; c_ht = n_ht;
+				c_lo = n_lo; c_hi = n_hi; c_ja = n_ja; c_jb = n_jb; c_ht = n_ht;
 			}
 			__builtin_amdgcn_wave_barrier();
-			if (valid) { sd[mycol] = 0.0; sht[mycol] = 0.0; }   /* padding slots must keep valid = 0 and a zero hess_term */
+			if (valid) {   /* padding slots must keep zero power rows (valid = 0) and a zero hess_term */
+#pragma unroll
+				for (int k2 = 0; k2 < 6; ++k2) sd[k2 * kRS2 + mycol] = 0.0;
+				sht[mycol] = 0.0;
+			}
 		} else if constexpr (HK != 0) {
 			const BsplWin4 &A = HK == 3 ? c0 : a;
 			const BsplWin4 &Bw = HK == 1 ? a : (HK == 2 ? c0 : a);
 			/* pixel mode: the scalar hess_term and the dense windows (MI.cc:478-496, 574-583, 620-629) */
-			double hess_term = 0;
+			hess_term = 0;
 			{
 				const double *T0 = Tq + A.row0 * MI_NB + Bw.row0;
 #pragma unroll
