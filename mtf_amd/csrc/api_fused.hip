@@ -629,11 +629,21 @@ static int mi_enqueue_fast(mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPl
 	if (!b->d_mi_poly) HIP_TRY(hipMalloc(&b->d_mi_poly, sizeof(double) * (size_t)mi_poly_size() * b->B));
 	fp.poly = b->d_mi_poly;
 	const BatchView bv = b->view();
+	/* pass 1 holds 45.7 KB of LDS per workgroup: THREE workgroups per CU, so mi_blocks' ~4 per CU ran as one full round and a second one
+	 * at a third of the occupancy (1024 workgroups over 768 slots; r05 ablation: the pass is bound by its sampling, 105 of 120 us, not
+	 * by the block products).  Its own count: the largest multiple of the resident slots that the partial-row buffer holds. */
+	int nblk1 = nblk;
+	{
+		static const char *e_b1 = std::getenv("MTFHIP_MI_PASS1_BLOCKS");
+		const int slots = 3 * std::max(b->ctx->n_cus, 1);
+		if (e_b1) nblk1 = std::min(nblk, std::max(1, std::atoi(e_b1)));
+		else if ((long)nblk * b->B > slots && slots / b->B >= 1) nblk1 = std::min(nblk, slots / b->B);
+	}
 	{
 		TimedScope tsc(b->ctx, "mi_pass1");
-		launch_mi_pass_hist(bv, b->ctx->img, fp, b->d_mi_part, nblk, b->mi_row_len, st);
+		launch_mi_pass_hist(bv, b->ctx->img, fp, b->d_mi_part, nblk1, b->mi_row_len, st);
 	}
-	launch_mi_tables_iter(bv, 8, b->desc.mi_pre_seed, b->mi_hist_norm, fp.hk == 1 ? 1 : 0, b->d_mi_part, nblk, b->mi_row_len, b->d_mi_tb, b->d_mi_f, st);
+	launch_mi_tables_iter(bv, 8, b->desc.mi_pre_seed, b->mi_hist_norm, fp.hk == 1 ? 1 : 0, b->d_mi_part, nblk1, b->mi_row_len, b->d_mi_tb, b->d_mi_f, st);
 	if (fp.hk <= 1) launch_mi_poly_tables(bv, b->d_mi_tb, b->mi_hist_norm, fp.hk == 1 ? 1 : 0, b->d_mi_poly, st);   /* (the dense Hessian kinds read the tables themselves) */
 	{
 		TimedScope tsc(b->ctx, "mi_pass2");

@@ -65,52 +65,80 @@ __global__ __launch_bounds__(kBlock) void k_mi_pass_hist(BatchView bv, ImgView i
 	const double one0 = li == 0 ? 1.0 : 0.0;
 	const unsigned stride = (unsigned)nblk * kBlock;
 	unsigned base = (blockIdx.x * (kBlock / 64) + wave) * 64;
-	/* two-stage pipeline: grid point + template value two chunks ahead, warp + texel fetch one chunk ahead */
-	double2 q_nx = make_double2(0.0, 0.0); double z_nx = 1.0, i0_nx = 0.0, i0_cur;
+	/* Software pipeline with build-time depths (MTFHIP_MI_OP_AHEAD / MTFHIP_MI_TEX_AHEAD): the operands of chunk n + TD + PF are requested
+	 * while chunk n is processed, the texels of chunk n + TD.  r05 measured deeper pipelines on the hypothesis that the pass waits for
+	 * memory round trips (its sampling alone is 105 of its 120 us: tools/mi1_ablation.sh): (1, 1) 117.4 us, (3, 1) 121.0, (3, 2) 122.8,
+	 * (3, 3) 125.3, (5, 2) 127.1 -- it does not; the per-pixel time is the same from 8 to 192 targets (MALL-resident or not), so the
+	 * pass is bound by instruction issue, not by latency or bandwidth.  (1, 1) = the r03 depths stay. */
+	constexpr int PF = kMiOpAhead, TD = kMiTexAhead;
+	double2 qf[PF]; double zf[PF], i0f[PF + TD]; unsigned chf[PF + TD];
 	/* every load of the loop is issued unconditionally (the third homogeneous coordinate is fetched from the template when it is
 	 * not needed): with guarded loads the compiler cannot count what is in flight and waits with vmcnt(0), which exposes the
 	 * full memory latency of the just-issued prefetch in front of every chunk (65 % of the wave cycles in the first version) */
 	const double *zsrc = uz ? I0 : iz;
-	unsigned ch_nx = 0;   /* MC: the channel of the row whose operands q_nx ... hold */
-	auto fetch = [&](unsigned i) {
+	auto fetch = [&](unsigned i, double2 &q, double &z, double &i0v, unsigned &ch) {
 		const unsigned pi = pix_of(i);
-		if constexpr (MC) ch_nx = i - pi * Cc;
-		q_nx = ld_off<double2>(pp, pi * 16u); i0_nx = ld_off<double>(I0, i * 8u);
-		z_nx = ld_off<double>(zsrc, (uz ? i : pi) * 8u);
+		ch = 0;
+		if constexpr (MC) ch = i - pi * Cc;
+		q = ld_off<double2>(pp, pi * 16u); i0v = ld_off<double>(I0, i * 8u);
+		z = ld_off<double>(zsrc, (uz ? i : pi) * 8u);
 	};
-	fetch(min(base + lane, N - 1));
-	MiTex tx_cur = mi_issue<SSM, false, MC>(im, W, q_nx.x, q_nx.y, z_nx, uz, pa.grad_eps, Cc, ch_nx);
-	unsigned ch_cur = ch_nx;
-	i0_cur = i0_nx;
-	fetch(min(base + lane + stride, N - 1));
+	/* prologue: texels of the first TD chunks, operands of the PF chunks behind them.  i0f / chf: [0 .. TD) belong to the chunks whose
+	 * texels are in flight (tx[0] = the chunk about to be processed), [TD .. TD + PF) to the operand ring */
+	MiTex tx[TD];
+#pragma unroll
+	for (int k = 0; k < TD; ++k) {
+		double2 q; double z;
+		fetch(min(base + lane + (unsigned)k * stride, N - 1), q, z, i0f[k], chf[k]);
+		tx[k] = mi_issue<SSM, false, MC>(im, W, q.x, q.y, z, uz, pa.grad_eps, Cc, chf[k]);
+	}
+#pragma unroll
+	for (int k = 0; k < PF; ++k) fetch(min(base + lane + (unsigned)(TD + k) * stride, N - 1), qf[k], zf[k], i0f[TD + k], chf[TD + k]);
 	for (; base < N; base += stride) {
 		const unsigned i = base + lane;
 		const double vm = i < N ? 1.0 : 0.0;   /* lanes behind the end of the patch carry zero weights */
-		const double i0 = i0_cur;
-		const MiTex tx_nx = mi_issue<SSM, false, MC>(im, W, q_nx.x, q_nx.y, z_nx, uz, pa.grad_eps, Cc, ch_nx);
-		const unsigned ch_here = ch_cur;
-		ch_cur = ch_nx;
-		i0_cur = i0_nx;
-		fetch(min(i + 2 * stride, N - 1));
-		const MiSample sp = mi_finish<SSM, false, MC>(im, tx_cur, pa.grad_eps, pa.norm_mult, pa.norm_add, i < N, (int)ch_here);
-		tx_cur = tx_nx;
+		const double i0 = i0f[0];
+		const unsigned ch_here = chf[0];
+		/* texels of chunk n + TD (its operands are the oldest of the ring), operands of chunk n + TD + PF */
+		const MiTex tx_new = mi_issue<SSM, false, MC>(im, W, qf[0].x, qf[0].y, zf[0], uz, pa.grad_eps, Cc, chf[TD]);
+#pragma unroll
+		for (int k = 0; k + 1 < PF; ++k) { qf[k] = qf[k + 1]; zf[k] = zf[k + 1]; }
+#pragma unroll
+		for (int k = 0; k + 1 < PF + TD; ++k) { i0f[k] = i0f[k + 1]; chf[k] = chf[k + 1]; }
+		fetch(min(i + (unsigned)(TD + PF) * stride, N - 1), qf[PF - 1], zf[PF - 1], i0f[PF + TD - 1], chf[PF + TD - 1]);
+		const MiSample sp = mi_finish<SSM, false, MC>(im, tx[0], pa.grad_eps, pa.norm_mult, pa.norm_add, i < N, (int)ch_here);
+#pragma unroll
+		for (int k = 0; k + 1 < TD; ++k) tx[k] = tx[k + 1];
+		tx[TD - 1] = tx_new;
+#if defined(MTFHIP_MI1_ABL) && MTFHIP_MI1_ABL >= 4   /* ablation builds (tools/mi1_ablation.sh): 4 sampling only */
+		bj8 += sp.it + i0 * vm;
+#else
 		const BsplWin4 a = bspl_window4<false>(sp.it, nb, pa.hist_norm);
 		const BsplWin4 b = bspl_window4<false>(i0, nb, pa.hist_norm);
+#if defined(MTFHIP_MI1_ABL) && MTFHIP_MI1_ABL == 3   /* 3: + windows, no staging, no products */
+		bj8 += (a.w[0] + a.w[1] + a.w[2] + a.w[3]) * vm + b.w[0] + b.w[1] + b.w[2] + b.w[3] + a.row0 + b.row0;
+#else
 		double *ra = wa + a.row0 * kRS + lane, *rb = wb + b.row0 * kRS + lane;
 #pragma unroll
 		for (int k = 0; k < 4; ++k) { ra[k * kRS] = a.w[k] * vm; rb[k * kRS] = b.w[k]; }
 		__builtin_amdgcn_wave_barrier();
+#if !(defined(MTFHIP_MI1_ABL) && MTFHIP_MI1_ABL == 2)   /* 2: + staging, no products */
 #pragma unroll
 		for (int qq = 0; qq < 16; ++qq) {
 			const int p = 4 * qq + lk;
 			const double av = wa[(1 + 4 * (lb >> 1) + li) * kRS + p], bvv = wb[(1 + 4 * (lb & 1) + li) * kRS + p];
 			bj8 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bvv, bj8, 0, 0, 0);
+#if !(defined(MTFHIP_MI1_ABL) && MTFHIP_MI1_ABL == 1)   /* 1: no histogram product */
 			bh8 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, one0, bh8, 0, 0, 0);
+#endif
 			if constexpr (SELF) bs8 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, wa[(1 + 4 * (lb & 1) + li) * kRS + p], bs8, 0, 0, 0);
 		}
+#endif
 		__builtin_amdgcn_wave_barrier();
 #pragma unroll
 		for (int k = 0; k < 4; ++k) { ra[k * kRS] = 0.0; rb[k * kRS] = 0.0; }   /* leave the slabs clean: 8 stores instead of 22 */
+#endif
+#endif
 	}
 	__syncthreads();
 	double *red = slabs;

@@ -14,6 +14,13 @@ namespace mtfhip {
 #define MTFHIP_MI_RS 65   /* r03 A/B (profiles/r03_experiments.md): any stride that is not a multiple of 4 -- 65, 66, 67, 69, 70, 73 -- takes pass 1
                             * from 150 to 119 us; 68 (kMiRowMfma), 72 and 80 put the per-lane-row window stores of lanes 4 / 8 / 12 apart on one bank */
 #endif
+#ifndef MTFHIP_MI_OP_AHEAD
+#define MTFHIP_MI_OP_AHEAD 1
+#endif
+#ifndef MTFHIP_MI_TEX_AHEAD
+#define MTFHIP_MI_TEX_AHEAD 1
+#endif
+constexpr int kMiOpAhead = MTFHIP_MI_OP_AHEAD, kMiTexAhead = MTFHIP_MI_TEX_AHEAD;   /* pass 1's software pipeline: chunks of operands / texels in flight (kernels_mi_fused.hip) */
 constexpr int kRS = MTFHIP_MI_RS;   /* slab row stride, doubles (build-time knob of tools/r03_mi_stride_ab.sh) */
 
 /* warp one grid point and sample the current image there (tolerance-mode arithmetic); GRAD: also the gradient with
