@@ -1166,6 +1166,24 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 			HIP_TRY(hipEventRecord(b->ctx->ev_fork, st));   /* the slab upload */
 			for (int q = 0; q + 1 < n_streams; ++q) HIP_TRY(hipStreamWaitEvent(b->ctx->extra_streams[q], b->ctx->ev_fork, 0));
 		}
+		/* small batches (a single tracker's target, a handful of them): one launch per pass instead of two -- the pixel pass's last
+		 * workgroup runs the finish (kernels_step.hip).  MEASURED r05 (one box, ESM + SSD + homography, 200 iterations per call): 200 x 200
+		 * full 12.22 -> 12.54 us per iteration, lean 10.92 -> 10.79, 50 x 50 lean 10.55 -> 10.44: nothing.  The r04 verdict's estimate (a
+		 * launch boundary = the finish kernel's 4.9 us) does not hold: the in-kernel hand-over -- acknowledged stores, an agent-scope
+		 * arrival, ~160 rows read back past the L2 -- costs what the boundary cost, as the persistent loop's did in r03.  Opt-in
+		 * (MTFHIP_STEP=1) and bit-identical to the two-launch loop (test_one_launch_per_pass_equals_two_launch_loop);
+		 * MTFHIP_STEP_MAX_TARGETS bounds the batch size it takes (default 8). */
+		bool use_step = false;
+		{
+			const char *e_st = std::getenv("MTFHIP_STEP");   /* (read per call: the tests flip it) */
+			const char *e_mx = std::getenv("MTFHIP_STEP_MAX_TARGETS");
+			const int max_t = e_mx ? std::atoi(e_mx) : 8;
+			use_step = (e_st && e_st[0] == '1') && so_term < 0 && n_streams == 1 && b->B <= max_t && track_step_available(bv, fa);
+			if (use_step && !b->d_persist) {
+				HIP_TRY(hipMalloc(&b->d_persist, 2 * sizeof(int) * (size_t)b->B));
+				HIP_TRY(hipMemsetAsync(b->d_persist, 0, 2 * sizeof(int) * (size_t)b->B, st));
+			}
+		}
 		struct ChunkRun { BatchView bc; FusedArgs fc; TrackState tc; int nblk_c, t0, nt; double *part; hipStream_t s; bool done; };
 		std::vector<ChunkRun> runs;
 		for (int t0 = 0; t0 < b->B; t0 += chunk) {
@@ -1208,6 +1226,14 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 					ChunkRun &r = runs[k];
 					if (r.done) continue;
 					if (n_streams >= 2 && it == 0 && k > g0 && stagger_us > 0) launch_queue_delay(stagger_us * (double)(k - g0), r.s);
+					if (use_step) {
+						/* one launch per pass: the last workgroup to arrive solves and updates (kernels_step.hip) */
+						TimedScope tsc(b->ctx, "track_step", r.s);
+						launch_track_step(r.bc, b->ctx->img, r.fc, *sm, r.tc, r.part, r.nblk_c, b->d_persist + r.t0, r.s);
+						if (all_converged(r.tc.active, r.nt, it, r.s)) r.done = true;
+						all_done = all_done && r.done;
+						continue;
+					}
 					{
 						TimedScope tsc(b->ctx, "fused_lk", r.s);
 						launch_fused_ssd(r.bc, b->ctx->img, r.fc, r.part, r.nblk_c, r.s);

@@ -103,7 +103,9 @@ __device__ __forceinline__ double bilin_mc(double t00, double t01, double t10, d
 	const double ly_lx = (1 - dx) * (1 - dy), ly_ux = dx * (1 - dy), uy_lx = (1 - dx) * dy, uy_ux = dx * dy;
 	return t00 * ly_lx + t01 * ly_ux + t10 * uy_lx + t11 * uy_ux;
 }
-template <int AM, int SSM, bool CHAINED, int MODE, bool MAT, bool FAST = false, bool PERSIST = false, bool MC = false>
+/* COHROW: the workgroup's partial row leaves as write-through stores (the persistent loop, and the one-launch-per-pass kernel of
+ * kernels_step.hip whose last-arriving workgroup reads every row in the same launch) */
+template <int AM, int SSM, bool CHAINED, int MODE, bool MAT, bool FAST = false, bool PERSIST = false, bool MC = false, bool COHROW = PERSIST>
 __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk) {
 	constexpr int S = (SSM == MTFHIP_SSM_HOMOGRAPHY) ? 8 : 6;
 	constexpr bool NCC = AM == MTFHIP_AM_NCC;
@@ -668,7 +670,7 @@ __device__ __forceinline__ void fused_lk_body(const BatchView &bv, const ImgView
 #pragma unroll
 		for (int a = PARK_I0J ? 0 : 8; a < (PARK_ITJ0 ? 16 : 8); ++a) acc[NCC_I0J + a] = park[a * kBlock + threadIdx.x];
 	}
-	block_reduce_store<K, PERSIST>(acc, dst, lds);
+	block_reduce_store<K, COHROW>(acc, dst, lds);
 	if (!PERSIST && fa.inline_warp && blockIdx.x == 0 && threadIdx.x < 17) {   /* keep the device copy current for whoever reads it next */
 		const double v = kw[threadIdx.x];   /* iw[9] | is[8] */
 		if (threadIdx.x < 9) bv.warps[9 * t + threadIdx.x] = v;

@@ -429,6 +429,10 @@ bool launch_iclk_track(const BatchView &bv, const ImgView &im, const mtfhip_sm_d
 	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, int fast_math, const HostPublish &pub, const RegionIngest &rg, hipStream_t st);
 void launch_ingest_host(const void *src_host, void *dst, size_t bytes, hipStream_t st);
 void launch_fused_mc(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk, hipStream_t st);   /* bv.C > 1 */
+/* one launch per pass with the finish folded in behind a last-arriver counter (kernels_step.hip); arrive: [B] ints, zero between launches */
+bool track_step_available(const BatchView &bv, const FusedArgs &fa);
+void launch_track_step(const BatchView &bv, const ImgView &im, const FusedArgs &fa, const mtfhip_sm_desc &sm, const TrackState &ts,
+	double *partials, int nblk, int *arrive, hipStream_t st);
 void launch_track_persist(const BatchView &bv, const ImgView &im, const FusedArgs &fa, const mtfhip_sm_desc &sm, const TrackState &ts,
 	double *partials, int nblk, const PersistState &ps, int max_passes, hipStream_t st);
 bool launch_init_grid_ingest(const BatchView &bv, const double *host_w0_dev, int resx, int resy, double lo_x, double lo_y,

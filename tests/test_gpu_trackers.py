@@ -1525,3 +1525,52 @@ def test_host_publish_protocols_under_stress_fenced_and_not(tmp_path):
         assert ("fenced" if fenced == "1" else "acknowledged stores") in r.stdout
         dumps.append(np.load(dump))
     assert np.array_equal(dumps[0]["ref"], dumps[1]["ref"]) and not dumps[0]["bad"].any() and not dumps[1]["bad"].any()
+
+
+@pytest.mark.parametrize("B,res", [(1, 200), (1, 50), (3, 64), (8, 40)])
+@pytest.mark.parametrize("sm_kind,am,ssm,extra", [
+    (L.SM_ESM, L.AM_SSD, L.SSM_HOMOGRAPHY, dict()), (L.SM_ESM, L.AM_SSD, L.SSM_HOMOGRAPHY, dict(leven_marq=1)),
+    (L.SM_FCLK, L.AM_SSD, L.SSM_AFFINE, dict(chained_warp=0)), (L.SM_ICLK, L.AM_SSD, L.SSM_HOMOGRAPHY, dict()),
+    (L.SM_ESM, L.AM_NCC, L.SSM_HOMOGRAPHY, dict()), (L.SM_FCLK, L.AM_NCC, L.SSM_AFFINE, dict(hess_type=2)),
+    (L.SM_ICLK, L.AM_NCC, L.SSM_AFFINE, dict(leven_marq=1))],
+    ids=lambda v: "_".join("%s%s" % kv for kv in v.items()) if isinstance(v, dict) else str(v))
+@pytest.mark.parametrize("materialize", [0, 1])
+def test_one_launch_per_pass_equals_two_launch_loop(gpu_ctx, frame, frame2, B, res, sm_kind, am, ssm, extra, materialize, monkeypatch):
+    """r05: for small batches a pass of the device-side loop is ONE launch -- the pixel pass's last-arriving workgroup sums the partial
+    rows, solves and updates (kernels_step.hip) -- against the two launches it replaces (MTFHIP_STEP=0): the same decomposition, rows,
+    summation order and finish bodies, so iteration counts, corners, states and the per-pass trace records are the same BITS; and a
+    second call (setRegion + update) continues from a clean arrival counter."""
+    if res > 64 and ssm == L.SSM_AFFINE and am == L.AM_NCC:
+        pytest.skip("covered at the smaller sizes")
+    corners = np.stack([synth.square_corners(200 + 31 * t, 230 + 17 * t, float(res if res <= 64 else 200) * (1.0 if res > 64 else 1.5)) for t in range(B)])
+    out = {}
+    for step in ("0", "1"):
+        monkeypatch.setenv("MTFHIP_STEP", step)
+        gpu_ctx.set_image(frame)
+        b = mtf_amd.Batch(gpu_ctx, am, ssm, res, res, B)
+        b.set_corners(corners)
+        params = dict(leven_marq=0, max_iters=9, epsilon=1e-5)
+        params.update(extra)
+        sm = mtf_amd.sm_desc(sm_kind, materialize=materialize, **params)
+        b.init_template(sm)
+        gpu_ctx.set_image(frame2)
+        b.track_trace(12)
+        n1, c1 = b.track(sm)
+        tr = b.read_track_trace(n1)
+        st1 = b.get_state().copy()
+        b.set_region(c1 + 0.4, sm)
+        n2, c2 = b.track(sm)
+        out[step] = (n1.copy(), c1.copy(), st1, n2.copy(), c2.copy(), b.get_state().copy(), tr)
+        if materialize and sm_kind != L.SM_ICLK:
+            out[step] += (b.read(L.BUF_IT).copy(), b.read(L.BUF_JT).copy())
+        b.close()
+    for k in range(6):
+        assert np.array_equal(out["0"][k], out["1"][k]), k
+    for t in range(B):
+        assert len(out["0"][6][t]) == len(out["1"][6][t])
+        for ra, rb in zip(out["0"][6][t], out["1"][6][t]):
+            for key in ("H", "g", "dp", "corners"):
+                assert np.array_equal(ra[key], rb[key]), (t, key)
+            assert ra["f"] == rb["f"] and ra["undo"] == rb["undo"]
+    for k in range(7, len(out["0"])):
+        assert np.array_equal(out["0"][k], out["1"][k]), k
