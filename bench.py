@@ -842,6 +842,20 @@ def secondary_workload(args):
                                  "traffic": pm.get("traffic_bytes_per_launch") if pm else None, "traffic_note": getattr(pmc_secondary, "note", None),
                                  "kernel": "k_iclk_track", "avg_kernel_ms": kms, "launches_timed": kn, "moved_bytes_per_launch_estimate": moved,
                                  "kernel_sources_sha": kernel_sources_sha()}})
+        # the same frame with the loop on the C++ side (mtf::hip::Grid, libmtfhost.so): no Python in the timed path
+        if rank == 0:
+            try:
+                from mtf_amd import host
+                cg = host.CppGridTracker(grid_size=16, patch_size=25, patch_sm=mtf_amd.SM_ICLK, patch_am=mtf_amd.AM_NCC, patch_ssm=mtf_amd.SSM_AFFINE,
+                                         grid_ssm=mtf_amd.SSM_HOMOGRAPHY, reset_at_each_frame=2, max_iters=args.grid_iters, epsilon=-1.0, hess_type=0, device=local_rank)
+                cg.set_image(frame0); cg.initialize(region); cg.set_image(frame1)
+                out["config"]["cpp_driver"] = {"frame_us_c_abi_loop": cg.bench_frames(region, max(args.steps, 100), 0),
+                                               "frame_us_grid_update_setregion_mode": cg.bench_frames(region, max(args.steps, 100), 1),
+                                               "note": "mtfhip_grid_frame in a C++ loop | mtf::hip::Grid::update() = that launch + the all-points least-squares "
+                                                       "estimator on the host + resetTrackers(setRegion), reset_at_each_frame = 2"}
+                del cg
+            except Exception as e:   # (the host libraries are optional for this line)
+                out["config"]["cpp_driver"] = {"error": str(e)[:200]}
         if rank == 0 and not args.no_cpu:
             import oracle_py as O
             ssm = O.SSM(O.SSM_AFF, 25, 25); am = O.AM(O.AM_NCC, 25, 25); am.set_curr_img(frame0)

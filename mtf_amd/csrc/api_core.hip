@@ -406,6 +406,8 @@ void mtfhip_batch_destroy(mtfhip_batch *b) {
 			b->d_mi_f, b->d_mi_H, b->d_h0inv, b->d_d2_part, b->d_d2_out, b->d_d2_w, b->d_it_shadow, b->d_ncc_tm, b->d_mi_red, b->d_lm, b->d_persist, b->d_trace, b->d_cand_mi, b->d_mi_poly};
 		for (void *p : ptrs)
 			if (p) (void)hipFree(p);
+		if (b->h_init_rec) (void)hipHostFree(b->h_init_rec);
+		if (b->h_init_flag) (void)hipHostFree(b->h_init_flag);
 		if (b->h_acc) (void)hipHostFree(b->h_acc);
 		if (b->h_flag) (void)hipHostFree(b->h_flag);
 		if (b->h_pub) (void)hipHostFree(b->h_pub);

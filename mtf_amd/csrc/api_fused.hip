@@ -323,6 +323,56 @@ static int init_self_hessian(mtfhip_batch *b, const mtfhip_sm_desc *sm, double *
 	}
 	return mtfhip_am_cmpt_self_hessian(b, MTFHIP_BUF_J0, H0);
 }
+/* nt::ICLK::initialize of small single-channel SSD / NCC patches in ONE launch (kernels_init.hip): the grid tracker re-initialises its
+ * 256 patch trackers after every frame with the shipped reset_at_each_frame = 1 (GridTracker.cc:273-274, 345-392), and call by call
+ * that was 385 us per frame against 42 us for tracking them (r05, tools/grid_modes_probe.py).  Nothing is waited for: the small
+ * results the host mirrors hold (H0, NCC scalars, template moments) arrive in a pinned record and are folded in by the next entry
+ * point that flushes (pull_init_mirrors).  MTFHIP_INIT_FUSED=0 keeps the call-by-call form (A/B and the equality test). */
+static bool template_init_fused_ok(const mtfhip_batch *b, const mtfhip_sm_desc *sm) {
+	const char *e = std::getenv("MTFHIP_INIT_FUSED");   /* (read per call: the tests flip it) */
+	if (e && e[0] == '0') return false;
+	const int am = b->desc.am;
+	if (am != MTFHIP_AM_SSD && am != MTFHIP_AM_NCC) return false;
+	const bool const_h = sm->hess_type == 0 || (sm->hess_type == 2 && am == MTFHIP_AM_SSD);
+	return sm->sm == MTFHIP_SM_ICLK && const_h && sm->chained_warp && !sm->sec_ord_hess && b->C == 1 && b->N <= kTemplateInitMaxPix &&
+		b->h_flag_dev != nullptr && b->ctx->img.data != nullptr && b->ctx->img.channels == 1;
+}
+static int init_template_fused(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
+	(void)sm;
+	hipStream_t st = b->ctx->stream;
+	const bool ncc = b->desc.am == MTFHIP_AM_NCC;
+	TRY(need_image(b));
+	for (int id : {MTFHIP_BUF_I0, MTFHIP_BUF_IT, MTFHIP_BUF_DI0_DX, MTFHIP_BUF_DIT_DX, MTFHIP_BUF_J0, MTFHIP_BUF_DF_DI0, MTFHIP_BUF_DF_DIT}) TRY(ensure_buf(b, id));
+	if (!b->h_init_rec) {
+		HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_init_rec), sizeof(double) * kInitRec * (size_t)b->B, hipHostMallocMapped));
+		HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&b->h_init_rec_dev), b->h_init_rec, 0));
+		HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_init_flag), sizeof(unsigned long long), hipHostMallocMapped));
+		*b->h_init_flag = 0;
+		HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&b->h_init_flag_dev), b->h_init_flag, 0));
+	}
+	if (ncc && !b->d_ncc_tm) HIP_TRY(hipMalloc(&b->d_ncc_tm, sizeof(double) * 52 * (size_t)b->B));
+	++b->frame_count;   /* ImageBase.cc:74 */
+	const unsigned long long seq = ++b->init_seq;
+	{
+		TimedScope tsc(b->ctx, "template_init");
+		launch_template_init(b->view(), b->ctx->img, b->desc.grad_eps, b->norm_mult, b->norm_add, b->d_h0, b->d_h0inv, ncc ? b->d_ncc : nullptr,
+			ncc ? b->d_ncc_tm : nullptr, InitPublish{b->h_init_rec_dev, b->d_fin_count, b->h_init_flag_dev, seq, publish_fenced()}, st);
+	}
+	/* (the kernel also zeroes the gradient vectors df_dI0 / df_dIt: initializeSimilarity / initializeGrad) */
+	touch(b, MTFHIP_BUF_DI0_DX); touch(b, MTFHIP_BUF_J0);
+	b->init_pix_vals = b->it_valid = true;
+	b->init_pix_grad = b->dit_valid = true;
+	b->init_sim = b->init_grad = true;
+	for (auto &h : b->th) h.f = ncc ? 1.0 : 0.0;
+	b->ncc_host_newer = false;       /* (the kernel wrote d_ncc itself) */
+	b->init_mirror_seq = seq;
+	b->j0_is_template = true;
+	b->j0_template_corners_epoch = b->corners_epoch;
+	b->j0_variant = MTFHIP_JAC_WARPED;
+	b->template_corners.resize(8 * (size_t)b->B);
+	for (int t = 0; t < b->B; ++t) std::memcpy(&b->template_corners[8 * t], b->th[t].init_corners, sizeof(double) * 8);
+	return MTFHIP_OK;
+}
 int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	FLUSH(b);
 	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
@@ -331,6 +381,7 @@ int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "init_template before set_corners");
 	/* am->clearInitStatus() (NT/ESM.cc:113, NT/FCLK.cc:105, NT/ICLK.cc:74) */
 	b->init_pix_vals = b->init_pix_grad = b->init_sim = b->init_grad = false;
+	if (template_init_fused_ok(b, sm)) return init_template_fused(b, sm);
 	TRY(mtfhip_am_initialize_pix_vals(b, nullptr));
 	if (sm->chained_warp) {
 		TRY(mtfhip_am_initialize_pix_grad(b, nullptr));

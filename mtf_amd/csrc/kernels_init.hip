@@ -1,0 +1,250 @@
+/*
+ * kernels_init.hip -- a small patch's whole nt::ICLK::initialize in ONE launch (r05): GridTracker::resetTrackers(reinit = true)
+ * re-initialises every patch tracker on the new grid after every frame (SM/src/GridTracker.cc:345-392 with the shipped
+ * reset_at_each_frame = 1, Config/modules.cfg:80), i.e. per patch the body of NT/ICLK.cc:71-128:
+ *     am->initializePixVals(pts)  am->initializePixGrad(pts)  ssm->cmptWarpedPixJacobian(J0, dI0_dx)
+ *     am->initializeSimilarity()  am->initializeGrad()  am->initializeHess()  am->cmptSelfHessian(H0, J0)
+ * Call by call that is ~15 launches and six host round trips (NCC's mean and norm, the Hessian read back for its inversion on the
+ * host, the template moments of the fused NCC path): 385 us per frame of 256 patches against 42 us for tracking them.  Here one
+ * workgroup per patch samples the template, takes its finite-difference gradient, writes the steepest-descent rows, reduces the
+ * moments everything else is a function of -- sum I0, |I0 - mean|^2, sum J0, sum I0 J0, Gram(J0) -- forms the constant self
+ * Hessian (SSD: -J0^T J0, SSDBase.cc:268-285; NCC: NCC.cc:337-389 in raw moments, the algebra of api_fused.hip::ncc_assemble),
+ * inverts it (scaled, partially pivoted Gauss-Jordan on one wave) and leaves the small results both in device memory (for the
+ * tracking launches that follow) and in a pinned host record the library folds into its mirrors when somebody asks for them.
+ * One of the translation units of libmtfhip.so.
+ *
+ * Per-pixel arithmetic is the interface kernels' (k_sample, k_img_grad, k_pix_jacobian at the identity warp): I0, dI0_dx and J0 are
+ * the same bits.  The reduced quantities are summed in another order (one workgroup instead of a grid + a fixed-order finish): they
+ * agree to rounding (tests/test_gpu_grid.py::test_fused_template_init_equals_call_by_call).
+ */
+#include "mtfhip_device.h"
+
+namespace mtfhip {
+
+template <int K>
+__device__ __forceinline__ void init_allsum(double *v, double *lds /* [4][K] */) {
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+	for (int k = 0; k < K; ++k) v[k] = wave_sum_dpp(v[k]);
+	__syncthreads();   /* previous round's readers are done with lds */
+	if (lane == 0) {
+#pragma unroll
+		for (int k = 0; k < K; ++k) lds[wave * K + k] = v[k];
+	}
+	__syncthreads();
+#pragma unroll
+	for (int k = 0; k < K; ++k) v[k] = (lds[k] + lds[K + k]) + (lds[2 * K + k] + lds[3 * K + k]);
+}
+
+/* H (S x S column-major, packed) -> its inverse, or zeros when a pivot vanishes (a flat template: no update, as invert_definite on the
+ * host).  One wave: lane (i, j) = (lane >> 3, lane & 7) owns A[i][j] and A[i][8 + j] of the augmented matrix in LDS; diagonal
+ * equilibration and partial pivoting as the host routine.  a: [8][17] doubles. */
+__device__ __forceinline__ void invert_definite_wave(int S, const double *Hs /* LDS, packed S x S */, double *a, double *out /* global, packed */) {
+	const int lane = threadIdx.x & 63, i = lane >> 3, j = lane & 7;
+	constexpr int LD = 17;
+	const bool in = i < S && j < S;
+	const double di = i < S ? fabs(Hs[i * S + i]) : 1.0, dj = j < S ? fabs(Hs[j * S + j]) : 1.0;
+	const double sci = di > 0 ? 1.0 / sqrt(di) : 1.0, scj = dj > 0 ? 1.0 / sqrt(dj) : 1.0;
+	a[i * LD + j] = in ? Hs[j * S + i] * sci * scj : (i == j ? 1.0 : 0.0);
+	a[i * LD + 8 + j] = i == j ? 1.0 : 0.0;
+	__builtin_amdgcn_wave_barrier();
+	bool singular = false;
+	for (int k = 0; k < S; ++k) {
+		/* pivot row: the largest |A[r][k]|, r >= k (every lane walks the <= 8 candidates: same result everywhere) */
+		int piv = k; double best = fabs(a[k * LD + k]);
+		for (int r = k + 1; r < S; ++r) { const double v = fabs(a[r * LD + k]); if (v > best) { best = v; piv = r; } }
+		if (best == 0) { singular = true; break; }
+		__builtin_amdgcn_wave_barrier();
+		if (piv != k && i == 0) {   /* lanes 0..7 swap both halves of the two rows */
+			const double t0 = a[piv * LD + j], t1 = a[piv * LD + 8 + j];
+			a[piv * LD + j] = a[k * LD + j]; a[piv * LD + 8 + j] = a[k * LD + 8 + j];
+			a[k * LD + j] = t0; a[k * LD + 8 + j] = t1;
+		}
+		__builtin_amdgcn_wave_barrier();
+		const double p = a[k * LD + k];
+		__builtin_amdgcn_wave_barrier();
+		if (i == 0) { a[k * LD + j] /= p; a[k * LD + 8 + j] /= p; }
+		__builtin_amdgcn_wave_barrier();
+		const double f = a[i * LD + k], r0 = a[k * LD + j], r1 = a[k * LD + 8 + j];
+		__builtin_amdgcn_wave_barrier();
+		if (i != k && f != 0) { a[i * LD + j] -= f * r0; a[i * LD + 8 + j] -= f * r1; }
+		__builtin_amdgcn_wave_barrier();
+	}
+	if (in) out[j * S + i] = singular ? 0.0 : a[i * LD + 8 + j] * sci * scj;
+}
+
+template <int AM, int PPT>
+__global__ __launch_bounds__(kBlock) void k_template_init(BatchView bv, ImgView im, double grad_eps, double norm_mult, double norm_add,
+	double *h0_all /* [B][64] */, double *h0inv_all /* [B][64] */, double *ncc_all /* [B][8] */, double *ncc_tm_all /* [B][52] */, InitPublish pub) {
+	constexpr bool NCC = AM == MTFHIP_AM_NCC;
+	__shared__ double red[4 * 16];
+	__shared__ double sG[36], sSJ[8], sIJ[8], sH[64], sA[8 * 17], sRec[kInitRec];
+	const int t = blockIdx.x, N = bv.N, S = bv.S, tid = threadIdx.x;
+	const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY;
+	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * N;
+	const double *iz = bv.buf[MTFHIP_BUF_INIT_Z] + (size_t)t * N;
+	double *I0 = bv.buf[MTFHIP_BUF_I0] + (size_t)t * N, *It = bv.buf[MTFHIP_BUF_IT] + (size_t)t * N;
+	double *dI0 = bv.buf[MTFHIP_BUF_DI0_DX] + (size_t)t * 2 * N, *dIt = bv.buf[MTFHIP_BUF_DIT_DX] + (size_t)t * 2 * N;
+	double *J0 = bv.buf[MTFHIP_BUF_J0] + (size_t)t * N * S;
+	double *df0 = bv.buf[MTFHIP_BUF_DF_DI0] + (size_t)t * N, *dft = bv.buf[MTFHIP_BUF_DF_DIT] + (size_t)t * N;
+	const double gmult = norm_mult / (2 * grad_eps);
+	double i0v[PPT], jv[PPT][8];
+#pragma unroll
+	for (int k = 0; k < PPT; ++k) {
+		const int i = tid + k * kBlock;
+		i0v[k] = 0.0;
+#pragma unroll
+		for (int s = 0; s < 8; ++s) jv[k][s] = 0.0;
+		if (i < N) {
+			const double2 p = ip[i];
+			/* ImageBase::initializePixVals ImageBase.cc:62-99 (k_sample) */
+			const double v = norm_mult * pix_val(im, p.x, p.y) + norm_add;
+			/* ImageBase::initializePixGrad(pts) ImageBase.cc:101-132 -> utils::getImgGrad imgUtils.cc:233-254 (k_img_grad) */
+			const Cell c = load_cell(im, p.x, p.y);
+			double inc = pix_val_cell(im, c, p.x + grad_eps, p.y), dec = pix_val_cell(im, c, p.x - grad_eps, p.y);
+			const double gx = (inc - dec) * gmult;
+			inc = pix_val_cell(im, c, p.x, p.y + grad_eps); dec = pix_val_cell(im, c, p.x, p.y - grad_eps);
+			const double gy = (inc - dec) * gmult;
+			/* cmptWarpedPixJacobian at the identity warp and zero state (Homography.cc:231-294, Affine.cc:213-242; k_pix_jacobian's
+			 * expressions with W = I, so the same bits) */
+			double r[8];
+#pragma unroll
+			for (int s = 0; s < 8; ++s) r[s] = 0.0;
+			if (hom) {
+				const double inv_det = 1.0 / (bv.unit_z ? 1.0 : iz[i]);
+				const double dwx_dx = (1.0 - 0.0 * p.x), dwx_dy = (0.0 - 0.0 * p.x), dwy_dx = (0.0 - 0.0 * p.y), dwy_dy = (1.0 - 0.0 * p.y);
+				const double Ix = (dwx_dx * gx + dwy_dx * gy) * inv_det, Iy = (dwx_dy * gx + dwy_dy * gy) * inv_det;
+				hom_row(r, Ix, Iy, p.x, p.y, p.x, p.y);
+			} else {
+				const double a = 0.0 + 1, b = 0.0, cc = 0.0, d = 0.0 + 1;
+				const double Ixx = gx * p.x, Ixy = gx * p.y, Iyy = gy * p.y, Iyx = gy * p.x;
+				r[0] = gx * a + gy * cc; r[1] = gx * b + gy * d;
+				r[2] = Ixx * a + Iyx * cc; r[3] = Ixy * a + Iyy * cc; r[4] = Ixx * b + Iyx * d; r[5] = Ixy * b + Iyy * d;
+			}
+			I0[i] = v; It[i] = v;                                 /* (It = I0 and dIt_dx = dI0_dx on initialisation, ImageBase.cc:95, 128) */
+			dI0[i] = gx; dI0[N + i] = gy; dIt[i] = gx; dIt[N + i] = gy;
+			df0[i] = 0.0; dft[i] = 0.0;                          /* initializeSimilarity / initializeGrad: the gradient vectors start at zero (SSDBase.cc:29-63, NCC.cc:97-122) */
+#pragma unroll
+			for (int s = 0; s < 8; ++s) if (s < S) J0[(size_t)s * N + i] = r[s];
+			i0v[k] = v;
+#pragma unroll
+			for (int s = 0; s < 8; ++s) jv[k][s] = r[s];
+		}
+	}
+	/* the moments: sum I0 first (the norm is of the CENTRED template, NCC.cc:62-75: two passes as the reference) */
+	double m0 = 0.0, cn = 1.0;
+	if constexpr (NCC) {
+		double s1[1] = {0.0};
+#pragma unroll
+		for (int k = 0; k < PPT; ++k) s1[0] += i0v[k];
+		init_allsum<1>(s1, red);
+		m0 = s1[0] / (double)N;
+		double s2[1] = {0.0};
+#pragma unroll
+		for (int k = 0; k < PPT; ++k) { const int i = tid + k * kBlock; const double dv = i < N ? i0v[k] - m0 : 0.0; s2[0] = fma(dv, dv, s2[0]); }
+		init_allsum<1>(s2, red);
+		cn = sqrt(s2[0]);
+	}
+	{
+		double m[16];
+#pragma unroll
+		for (int q = 0; q < 16; ++q) m[q] = 0.0;
+#pragma unroll
+		for (int k = 0; k < PPT; ++k)
+#pragma unroll
+			for (int s = 0; s < 8; ++s) { m[s] += jv[k][s]; m[8 + s] = fma(i0v[k], jv[k][s], m[8 + s]); }
+		init_allsum<16>(m, red);
+		/* (register arrays cannot be indexed by the thread id: selects) */
+		double sj = 0, ij = 0;
+#pragma unroll
+		for (int q = 0; q < 8; ++q) { sj = tid == q ? m[q] : sj; ij = tid == q ? m[8 + q] : ij; }
+		if (tid < 8) { sSJ[tid] = sj; sIJ[tid] = ij; }
+	}
+	/* Gram(J0): the upper triangle in ACC_H's order, 36 sums in three rounds of twelve */
+#pragma unroll
+	for (int part = 0; part < 3; ++part) {
+		double g[12];
+#pragma unroll
+		for (int q = 0; q < 12; ++q) g[q] = 0.0;
+#pragma unroll
+		for (int k = 0; k < PPT; ++k) {
+			int idx = 0;
+#pragma unroll
+			for (int a = 0; a < 8; ++a)
+#pragma unroll
+				for (int c = a; c < 8; ++c) {
+					if (idx >= 12 * part && idx < 12 * part + 12) g[idx - 12 * part] = fma(jv[k][a], jv[k][c], g[idx - 12 * part]);
+					++idx;
+				}
+		}
+		init_allsum<12>(g, red);
+		double mine = 0;
+#pragma unroll
+		for (int q = 0; q < 12; ++q) mine = tid == q ? g[q] : mine;
+		if (tid < 12) sG[12 * part + tid] = mine;
+	}
+	__syncthreads();
+	/* the constant self Hessian, column-major S x S packed (what init_template keeps in th[].h0 / d_h0) */
+	if (tid < 64) {
+		const int a = tid >> 3, c = tid & 7;
+		if (a < S && c < S) {
+			const int lo = a < c ? a : c, hi = a < c ? c : a;
+			const double G = sG[lo * 8 - (lo * (lo - 1)) / 2 + (hi - lo)];
+			double h;
+			if constexpr (NCC) {
+				/* cmptSelfHessian = -(Gram - sJ sJ^T / N) / b^2 + ut ut^T, ut = (sum It J - mt sJ) / b^2, at It = I0: b = c, mt = m0 (NCC.cc:337-389) */
+				const double inv_b2 = 1.0 / (cn * cn);
+				const double ua = (sIJ[a] - m0 * sSJ[a]) * inv_b2, uc = (sIJ[c] - m0 * sSJ[c]) * inv_b2;
+				h = -(G - sSJ[a] * sSJ[c] / (double)N) * inv_b2 + ua * uc;
+			} else h = -G;   /* SSDBase.cc:268-285 */
+			sH[c * S + a] = h;
+		}
+	}
+	__syncthreads();
+	if (tid < 64) invert_definite_wave(S, sH, sA, h0inv_all + (size_t)t * 64);
+	/* device copies + the host record: H0 64 | NCC scalars 8 (I0_mean, c, It_mean, b, f, gmean, 0, 0) | sum J0 8 | sum I0 J0 8 | Gram 36 */
+	if (tid < kInitRec) {
+		double v = 0.0;
+		if (tid < 64) v = tid < S * S ? sH[tid] : 0.0;
+		else if (tid < 72) { const int q = tid - 64; v = NCC ? (q == 0 ? m0 : (q == 1 ? cn : (q == 2 ? m0 : (q == 3 ? cn : (q == 4 ? 1.0 : 0.0))))) : 0.0; }
+		else if (tid < 80) v = sSJ[tid - 72];
+		else if (tid < 88) v = sIJ[tid - 80];
+		else if (tid < 124) v = sG[tid - 88];
+		sRec[tid] = v;
+		if (tid < 64) h0_all[(size_t)t * 64 + tid] = v;
+		if (NCC && tid >= 64 && tid < 72 && ncc_all) ncc_all[(size_t)t * 8 + tid - 64] = v;
+		if (NCC && tid >= 72 && tid < 124 && ncc_tm_all) ncc_tm_all[(size_t)t * 52 + tid - 72] = v;
+		if (pub.host) __hip_atomic_store(pub.host + (size_t)t * kInitRec + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+	if (pub.host) {
+		/* the hand-over of every host publisher (publish_fenced(), mtfhip_internal.h) */
+		if (pub.fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); else wait_stores_acked();
+		__syncthreads();
+		if (tid == 0) {
+			const int done = pub.fenced ? __hip_atomic_fetch_add(pub.count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+			                            : __hip_atomic_fetch_add(pub.count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (done == (int)gridDim.x - 1) {
+				__hip_atomic_store(pub.count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (pub.fenced) { __threadfence_system(); __hip_atomic_store(pub.flag, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+				else __hip_atomic_store(pub.flag, pub.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			}
+		}
+	}
+}
+
+template <int AM>
+static void launch_init_am(const BatchView &bv, const ImgView &im, double grad_eps, double norm_mult, double norm_add, double *h0, double *h0inv,
+	double *ncc, double *ncc_tm, const InitPublish &pub, hipStream_t st) {
+	const int ppt = (bv.N + kBlock - 1) / kBlock;
+#define MTFHIP_INIT_CASE(P) MTFHIP_LAUNCH((k_template_init<AM, P>), dim3(bv.B), dim3(kBlock), 0, st, bv, im, grad_eps, norm_mult, norm_add, h0, h0inv, ncc, ncc_tm, pub)
+	if (ppt <= 1) MTFHIP_INIT_CASE(1); else if (ppt == 2) MTFHIP_INIT_CASE(2); else if (ppt == 3) MTFHIP_INIT_CASE(3); else MTFHIP_INIT_CASE(4);
+#undef MTFHIP_INIT_CASE
+}
+/* N <= kTemplateInitMaxPix, single channel, SSD or NCC */
+void launch_template_init(const BatchView &bv, const ImgView &im, double grad_eps, double norm_mult, double norm_add, double *h0, double *h0inv,
+	double *ncc, double *ncc_tm, const InitPublish &pub, hipStream_t st) {
+	if (bv.am == MTFHIP_AM_NCC) launch_init_am<MTFHIP_AM_NCC>(bv, im, grad_eps, norm_mult, norm_add, h0, h0inv, ncc, ncc_tm, pub, st);
+	else launch_init_am<MTFHIP_AM_SSD>(bv, im, grad_eps, norm_mult, norm_add, h0, h0inv, ncc, ncc_tm, pub, st);
+}
+
+} // namespace mtfhip

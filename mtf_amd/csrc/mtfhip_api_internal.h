@@ -200,6 +200,11 @@ struct mtfhip_batch {
 	/* MI: per-target table block, block partial rows, similarity and Hessian outputs */
 	double *d_mi_tb = nullptr, *d_mi_part = nullptr, *d_mi_f = nullptr, *d_mi_H = nullptr;
 	double *d_mi_poly = nullptr;   /* [B][mi_poly_size()], allocated by the first recompute iteration */
+	/* the fused template initialisation (kernels_init.hip, init_template's ICLK fast path): its small results arrive in this pinned
+	 * record (kInitRec doubles per target) behind init_flag; init_mirror_seq != 0: the host mirrors (th[].h0, NCC scalars and template
+	 * moments) are older than the device copies until pull_init_mirrors() has folded the record in (lazy_flush does) */
+	double *h_init_rec = nullptr, *h_init_rec_dev = nullptr;
+	unsigned long long *h_init_flag = nullptr, *h_init_flag_dev = nullptr, init_seq = 0, init_mirror_seq = 0;
 	double *d_mi_red = nullptr;   /* [B][mi_row_len] block rows summed (the Hessian assembly then reads one row per target) */
 	double *d_h0inv = nullptr; /* [B][64] inverse of the constant Hessian (one-launch ICLK) */
 	double *d_d2_part = nullptr, *d_d2_out = nullptr, *d_d2_w = nullptr; /* second-order term: block rows, [B][64] sums, MI self weights */
@@ -427,6 +432,36 @@ static int wait_host_flag(mtfhip_batch *b, unsigned long long seq) {
 	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
 	if (__atomic_load_n(b->h_flag, __ATOMIC_ACQUIRE) == seq) return MTFHIP_OK;
 	return fail(MTFHIP_ERR_HIP, "device results were not delivered to host memory");
+}
+/* fold the record of a fused template initialisation into the host mirrors (see mtfhip_batch::init_mirror_seq) */
+static int pull_init_mirrors(mtfhip_batch *b) {
+	if (!b->init_mirror_seq) return MTFHIP_OK;
+	const unsigned long long seq = b->init_mirror_seq;
+	const auto t0 = std::chrono::steady_clock::now();
+	bool ok = false;
+	for (unsigned spins = 0;; ++spins) {
+		if (__atomic_load_n(b->h_init_flag, __ATOMIC_ACQUIRE) == seq) { ok = true; break; }
+		cpu_relax();
+		if ((spins & 0x3ff) == 0x3ff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+	}
+	if (!ok) {
+		HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+		if (__atomic_load_n(b->h_init_flag, __ATOMIC_ACQUIRE) != seq) return fail(MTFHIP_ERR_HIP, "the template initialisation's results were not delivered to host memory");
+	}
+	const bool ncc = b->desc.am == MTFHIP_AM_NCC;
+	for (int t = 0; t < b->B; ++t) {
+		const double *r = b->h_init_rec + (size_t)t * mtfhip::kInitRec;
+		TargetHost &h = b->th[t];
+		std::memcpy(h.h0, r, sizeof(double) * 64);
+		if (ncc) {
+			h.I0_mean = r[64]; h.c = r[65]; h.It_mean = r[66]; h.b = r[67]; h.f = r[68]; h.gmean = r[69];
+			std::memcpy(h.ncc_sj0, r + 72, sizeof(double) * 8);
+			std::memcpy(h.ncc_i0j0, r + 80, sizeof(double) * 8);
+			std::memcpy(h.ncc_gram0, r + 88, sizeof(double) * 36);
+		}
+	}
+	b->init_mirror_seq = 0;
+	return MTFHIP_OK;
 }
 /* fixed-order sum of the per-workgroup rows -> h_acc ([B][row_len]) on the host, and wait for it */
 static int read_rows(mtfhip_batch *b, int nblk, int row_len) {

@@ -429,6 +429,14 @@ bool launch_iclk_track(const BatchView &bv, const ImgView &im, const mtfhip_sm_d
 	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, int fast_math, const HostPublish &pub, const RegionIngest &rg, hipStream_t st);
 void launch_ingest_host(const void *src_host, void *dst, size_t bytes, hipStream_t st);
 void launch_fused_mc(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk, hipStream_t st);   /* bv.C > 1 */
+/* a small patch's whole nt::ICLK::initialize in one launch (kernels_init.hip): template sample, gradient, steepest-descent rows,
+ * moments, constant self Hessian and its inverse; the small results also go to a pinned host record of kInitRec doubles per target
+ * (H0 64 | NCC scalars 8 | sum J0 8 | sum I0 J0 8 | Gram(J0) 36 | pad) behind the usual publish hand-over */
+constexpr int kInitRec = 128;
+constexpr int kTemplateInitMaxPix = 4 * 256;
+struct InitPublish { double *host; int *count; unsigned long long *flag, seq; int fenced; };
+void launch_template_init(const BatchView &bv, const ImgView &im, double grad_eps, double norm_mult, double norm_add, double *h0, double *h0inv,
+	double *ncc, double *ncc_tm, const InitPublish &pub, hipStream_t st);
 /* one launch per pass with the finish folded in behind a last-arriver counter (kernels_step.hip); arrive: [B] ints, zero between launches */
 bool track_step_available(const BatchView &bv, const FusedArgs &fa);
 void launch_track_step(const BatchView &bv, const ImgView &im, const FusedArgs &fa, const mtfhip_sm_desc &sm, const TrackState &ts,

@@ -318,3 +318,13 @@ class CppGridTracker:
 
     def patch_iters(self):
         return self._get(5, self.n).astype(np.int32)
+
+    def bench_frames(self, region, n_frames=300, what=0):
+        """microseconds per frame of a loop that runs on the C++ side: what = 0 mtfhip_grid_frame(region) calls (layout + setRegion + update,
+        one launch), 1 mtf::hip::Grid::update() (the same + the estimator + the reset of the parameters)"""
+        c = np.ascontiguousarray(np.asarray(region, dtype=np.float64).reshape(2, 4).T.ravel())
+        us = C.c_double()
+        fn = lib().mtfhost_grid_bench
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
+        _check(fn(self._h, int(what), int(n_frames), c.ctypes.data_as(C.c_void_p), C.byref(us)))
+        return us.value

@@ -79,6 +79,7 @@ public:
 	const std::vector<double> &getPatchRegions() const { return patch_regions; }
 	mtfhip_batch *batch() { return b; }
 	const mtfhip_sm_desc &desc() const { return d; }
+	const mtfhip_grid_desc &gridDesc() const { return gd; }
 private:
 	GridTrackerParams params;
 	mtfhip_grid_desc gd;

@@ -4,6 +4,7 @@
  * (Examples/cpp/pyMTF.cc:35-62), so that the test-suite can drive the C++ objects.  HARNESS (libmtfharness.so): it constructs the
  * product's adapters and device drivers (libmtfhost.so) AND the restated reference callers that live next to it.
  */
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -353,6 +354,33 @@ extern "C" int mtfhost_templated_sm(int sm, int am, int ssm, int resx, int resy,
 			templated::ICLK<hip::HipAM, hip::HipSSM> t(&p, &amp, &ssmp);
 			run(t);
 		} else { g_err = "mtfhost_templated_sm: ESM (0) or ICLK (2)"; return -1; }
+		return 0;
+	} catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
+/* frame loops timed on the C++ side (no Python in the timed path; bench.py --workload grid reports them next to its own):
+ * what = 0: n_frames calls of mtfhip_grid_frame(region) -- layout + setRegion + update of every patch in one C-ABI call
+ * what = 1: n_frames of hip::Grid::update() -- the same launch + the estimator + the reset the parameters ask for (GridTracker.cc:247-285)
+ * out: microseconds per frame (wall clock, steady_clock around the whole loop, a warm-up of n_frames / 10 + 5 frames in front) */
+extern "C" int mtfhost_grid_bench(mtfhost_grid *h, int what, int n_frames, const double *region_corners, double *us_per_frame) {
+	try {
+		hip::Grid &g = *h->g;
+		mtfhip_grid_desc gd;
+		{   /* the driver's own description, from its parameters */
+			CornersT c; std::memcpy(c.data(), region_corners, sizeof(double) * 8);
+			g.setRegion(c);
+		}
+		const int B = mtfhip_batch_n_targets(g.batch());
+		std::vector<int> it(B); std::vector<double> cr(8 * (size_t)B); std::vector<float> cen(2 * (size_t)B);
+		gd = g.gridDesc();
+		auto frame = [&]() {
+			if (what == 0) hip::HipPair::check(mtfhip_grid_frame(g.batch(), &g.desc(), &gd, region_corners, it.data(), cr.data(), cen.data()));
+			else g.update();
+		};
+		for (int k = 0; k < n_frames / 10 + 5; ++k) frame();
+		const auto t0 = std::chrono::steady_clock::now();
+		for (int k = 0; k < n_frames; ++k) frame();
+		*us_per_frame = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / n_frames;
 		return 0;
 	} catch (const std::exception &e) { g_err = e.what(); return -1; }
 }

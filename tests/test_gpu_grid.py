@@ -182,3 +182,52 @@ def test_grid_frame_abi_refuses_a_mismatched_batch(gpu_ctx, frame):
     with pytest.raises(mtf_amd.MtfHipError, match="mismatch between the grid dimensions"):
         g.tracker.batch.grid_frame(wrong, g.tracker.sm, REGIONS["square"])
     g.tracker.batch.close()
+
+
+@pytest.mark.parametrize("am,ssm,ps", [(L.AM_NCC, L.SSM_AFFINE, 25), (L.AM_SSD, L.SSM_AFFINE, 25), (L.AM_NCC, L.SSM_HOMOGRAPHY, 30), (L.AM_SSD, L.SSM_HOMOGRAPHY, 16),
+                                       (L.AM_NCC, L.SSM_AFFINE, 32)])
+def test_fused_template_init_equals_call_by_call(oracle, gpu_ctx, frame, am, ssm, ps, monkeypatch):
+    """r05: nt::ICLK::initialize of small patches in ONE launch (kernels_init.hip, init_template's fast path) against the call-by-call
+    form (MTFHIP_INIT_FUSED=0: ~15 launches, six host round trips): the per-pixel arrays -- I0, It, dI0_dx, J0 -- are the same BITS; the
+    reduced quantities (constant self Hessian, its inverse as the tracking launch uses it, NCC scalars) agree to rounding; the frames
+    tracked afterwards land on the same corners; and the host mirrors are folded in lazily (the interface getters see them)."""
+    gs = 4
+    f2 = _frames(frame, 1, 81)[0]
+    region = REGIONS["quad"]
+    out = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("MTFHIP_INIT_FUSED", fused)
+        gpu_ctx.set_image(frame)
+        g = GridTracker(gpu_ctx, grid_size=gs, patch_size=ps, am=am, ssm=ssm, max_iters=15, epsilon=1e-5, reset_at_each_frame=1)
+        g.initialize(region)
+        b = g.tracker.batch
+        arrays = [b.read(L.BUF_I0).copy(), b.read(L.BUF_IT).copy(), b.read(L.BUF_DI0_DX).copy(), b.read(L.BUF_J0).copy()]
+        H0 = b.cmpt_self_hessian(L.BUF_J0).copy() if am == L.AM_SSD else None     # through the interface: the host mirrors must be current
+        gpu_ctx.set_image(f2)
+        c1, cen1 = g.update_patches()
+        n1 = g.n_iters.copy()
+        r2 = g.update()            # a whole frame: track, fit, re-initialise on the new grid (fused or not), ...
+        c3, _ = g.update_patches() # ... and track from the re-initialised templates
+        out[fused] = (arrays, H0, c1.copy(), n1, r2.copy(), c3.copy())
+        b.close()
+    for x, y, what in zip(out["0"][0], out["1"][0], ("I0", "It", "dI0_dx", "J0")):
+        assert np.array_equal(x, y), what
+    if out["0"][1] is not None:
+        np.testing.assert_allclose(out["1"][1], out["0"][1], rtol=1e-12)
+    assert np.array_equal(out["0"][3], out["1"][3])
+    np.testing.assert_allclose(out["1"][2], out["0"][2], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(out["1"][4], out["0"][4], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(out["1"][5], out["0"][5], rtol=0, atol=1e-6)
+    # and against the oracle's own initialize + update of one patch
+    gpu_ctx.set_image(frame)
+    g = GridTracker(gpu_ctx, grid_size=gs, patch_size=ps, am=am, ssm=ssm, max_iters=15, epsilon=1e-5)
+    g.initialize(region)
+    patches = g.patch_corners(region)
+    gpu_ctx.set_image(f2)
+    c, _ = g.update_patches()
+    for t in (0, 7, 15):
+        o_ssm = oracle.SSM(ssm, ps, ps); o_am = oracle.AM(am, ps, ps); o_am.set_curr_img(frame)
+        trk = oracle.Tracker(L.SM_ICLK, o_am, o_ssm, leven_marq=0, max_iters=15, epsilon=1e-5, hess_type=0)
+        trk.initialize(patches[t]); o_am.set_curr_img(f2); trk.update()
+        np.testing.assert_allclose(c[t], trk.get_region(), rtol=0, atol=5e-4)
+    g.tracker.batch.close()
