@@ -337,7 +337,7 @@ static bool template_init_fused_ok(const mtfhip_batch *b, const mtfhip_sm_desc *
 	return sm->sm == MTFHIP_SM_ICLK && const_h && sm->chained_warp && !sm->sec_ord_hess && b->C == 1 && b->N <= kTemplateInitMaxPix &&
 		b->h_flag_dev != nullptr && b->ctx->img.data != nullptr && b->ctx->img.channels == 1;
 }
-static int init_template_fused(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
+static int init_template_fused(mtfhip_batch *b, const mtfhip_sm_desc *sm, const RegionIngest *rg = nullptr) {
 	(void)sm;
 	hipStream_t st = b->ctx->stream;
 	const bool ncc = b->desc.am == MTFHIP_AM_NCC;
@@ -356,7 +356,7 @@ static int init_template_fused(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	{
 		TimedScope tsc(b->ctx, "template_init");
 		launch_template_init(b->view(), b->ctx->img, b->desc.grad_eps, b->norm_mult, b->norm_add, b->d_h0, b->d_h0inv, ncc ? b->d_ncc : nullptr,
-			ncc ? b->d_ncc_tm : nullptr, InitPublish{b->h_init_rec_dev, b->d_fin_count, b->h_init_flag_dev, seq, publish_fenced()}, st);
+			ncc ? b->d_ncc_tm : nullptr, InitPublish{b->h_init_rec_dev, b->d_fin_count, b->h_init_flag_dev, seq, publish_fenced()}, rg ? *rg : RegionIngest{}, st);
 	}
 	/* (the kernel also zeroes the gradient vectors df_dI0 / df_dIt: initializeSimilarity / initializeGrad) */
 	touch(b, MTFHIP_BUF_DI0_DX); touch(b, MTFHIP_BUF_J0);
@@ -372,6 +372,30 @@ static int init_template_fused(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	b->template_corners.resize(8 * (size_t)b->B);
 	for (int t = 0; t < b->B; ++t) std::memcpy(&b->template_corners[8 * t], b->th[t].init_corners, sizeof(double) * 8);
 	return MTFHIP_OK;
+}
+/* resetTrackers(reinit) for the patches of a grid: setCorners + initialize of every patch tracker in ONE launch -- the host half of the
+ * reset (mirrors, staged corners; set_corners_core deferred) and k_template_init in region mode, which reads the patch corners from the
+ * pinned staging buffer and lays out its own grid (as k_iclk_track does for the per-frame setRegion) */
+static int grid_reinit_fused(mtfhip_batch *b, const mtfhip_sm_desc *sm, const double *patches) {
+	FLUSH_AM(b);   /* (the current points are about to be replaced: no apply_warp for them -- 7 us per frame when this was FLUSH) */
+	touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b));
+	TRY(check_sm(b, sm, "init_template"));
+	TRY(need_image(b));
+	TRY(set_corners_core(b, patches, false, true));
+	b->init_pix_vals = b->init_pix_grad = b->init_sim = b->init_grad = false;
+	const bool homg = b->desc.ssm == MTFHIP_SSM_HOMOGRAPHY;
+	RegionIngest rg{};
+	const double *stage = reinterpret_cast<const double *>(b->h_stage_a_dev);
+	rg.corners = stage + 17 * (size_t)b->B; rg.ncc = nullptr;
+	rg.d_ncc = b->d_ncc; rg.d_w0 = b->d_w0; rg.d_init_corners_hm = b->d_init_corners_hm;
+	rg.lo_x = homg ? -0.5 : 1 - b->desc.resx / 2.0; rg.lo_y = homg ? -0.5 : 1 - b->desc.resy / 2.0;
+	rg.hi_x = homg ? 0.5 : b->desc.resx / 2.0; rg.hi_y = homg ? 0.5 : b->desc.resy / 2.0;
+	rg.resx = b->desc.resx; rg.resy = b->desc.resy; rg.force_unit_z = homg ? 0 : 1;
+	const int rc = init_template_fused(b, sm, &rg);
+	set_corners_finish_deferred(b);   /* the host half of a deferred reset (a no-op when nothing was deferred) */
+	b->warps_dirty = true;   /* the device slab still holds the previous frame's warps: whoever needs them next uploads the (identity) mirrors */
+	if (rc == MTFHIP_OK) { HIP_TRY(hipEventRecord(b->ev_a, b->ctx->stream)); b->stage_a_busy = true; }   /* the kernel reads the staging buffer */
+	return rc;
 }
 int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	FLUSH(b);
@@ -1021,8 +1045,12 @@ int mtfhip_grid_reset(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_gr
 	patches.resize(8 * B);
 	TRY(mtfhip_grid_layout(g, region, nullptr, patches.data()));
 	if (reinit) {   /* tracker->initialize(patch_corners): NT/ICLK.cc:71-128 etc. */
-		TRY(mtfhip_ssm_set_corners(b, patches.data()));
-		TRY(mtfhip_batch_init_template(b, sm));
+		const char *e_gf = std::getenv("MTFHIP_GRID_FUSED");
+		if (!(e_gf && e_gf[0] == '0') && b->h_stage_a_dev && template_init_fused_ok(b, sm)) TRY(grid_reinit_fused(b, sm, patches.data()));
+		else {
+			TRY(mtfhip_ssm_set_corners(b, patches.data()));
+			TRY(mtfhip_batch_init_template(b, sm));
+		}
 	} else TRY(mtfhip_batch_set_region(b, patches.data(), sm));   /* tracker->setRegion(patch_corners) */
 	if (patch_corners) std::memcpy(patch_corners, patches.data(), sizeof(double) * 8 * B);
 	/* :387 getCentroid(prev_pts[id], tracker->getRegion()): both resets leave the tracker's region = the patch corners */

@@ -75,10 +75,12 @@ __device__ __forceinline__ void invert_definite_wave(int S, const double *Hs /* 
 
 template <int AM, int PPT>
 __global__ __launch_bounds__(kBlock) void k_template_init(BatchView bv, ImgView im, double grad_eps, double norm_mult, double norm_add,
-	double *h0_all /* [B][64] */, double *h0inv_all /* [B][64] */, double *ncc_all /* [B][8] */, double *ncc_tm_all /* [B][52] */, InitPublish pub) {
+	double *h0_all /* [B][64] */, double *h0inv_all /* [B][64] */, double *ncc_all /* [B][8] */, double *ncc_tm_all /* [B][52] */, InitPublish pub,
+	RegionIngest rg) {
 	constexpr bool NCC = AM == MTFHIP_AM_NCC;
 	__shared__ double red[4 * 16];
-	__shared__ double sG[36], sSJ[8], sIJ[8], sH[64], sA[8 * 17], sRec[kInitRec];
+	__shared__ double sSum[56], sRed56[4 * 56], sH[64], sA[8 * 17], sRec[kInitRec];
+	const double *sG = sSum, *sSJ = sSum + 36, *sIJ = sSum + 44;
 	const int t = blockIdx.x, N = bv.N, S = bv.S, tid = threadIdx.x;
 	const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY;
 	const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * N;
@@ -88,7 +90,67 @@ __global__ __launch_bounds__(kBlock) void k_template_init(BatchView bv, ImgView 
 	double *J0 = bv.buf[MTFHIP_BUF_J0] + (size_t)t * N * S;
 	double *df0 = bv.buf[MTFHIP_BUF_DF_DI0] + (size_t)t * N, *dft = bv.buf[MTFHIP_BUF_DF_DIT] + (size_t)t * N;
 	const double gmult = norm_mult / (2 * grad_eps);
+	/* REGION mode (rg.corners != NULL; mtfhip_grid_reset): the patch's corners come straight from the pinned staging buffer and the
+	 * workgroup lays out its own grid first -- ProjectiveBase::getPtsFromCorners + Homography / Affine::setCorners with the expressions of
+	 * k_init_grid and of k_iclk_track's region mode (one set, rect_to_quad_hd) -- instead of a set_corners launch in front of this one */
+	const bool region = rg.corners != nullptr;
+	__shared__ double sCr[8];
+	double W0[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+	if (region) {
+		if (tid < 8) sCr[tid] = rg.corners[8 * (size_t)t + tid];
+		__syncthreads();
+		double q8[8];
+#pragma unroll
+		for (int q = 0; q < 8; ++q) q8[q] = sCr[q];
+		const bool bad = !rect_to_quad_hd(rg.lo_x, rg.lo_y, rg.hi_x, rg.hi_y, q8, W0);
+		if (bad) {
+#pragma unroll
+			for (int q = 0; q < 9; ++q) W0[q] = (q == 0 || q == 4 || q == 8) ? 1.0 : 0.0;
+		}
+		if (hom && fabs(W0[6]) < 1e-15 && fabs(W0[7]) < 1e-15) { W0[6] = 0; W0[7] = 0; }
+		/* (degenerate corners are refused on the host before the launch -- set_corners_core, quad_degenerate_hd: the identity is only a safe stand-in) */
+		if (tid < 9) rg.d_w0[9 * (size_t)t + tid] = W0[tid];
+		if (tid < 12) rg.d_init_corners_hm[12 * (size_t)t + tid] = (tid % 3 == 2) ? 1.0 : q8[2 * (tid / 3) + tid % 3];
+	}
+	double2 *ipw = const_cast<double2 *>(ip), *ihw = reinterpret_cast<double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]) + (size_t)t * N;
+	double *izw = const_cast<double *>(iz);
 	double i0v[PPT], jv[PPT][8];
+	/* phase 1: every pixel's grid point and the four texels of its bilinear cell, requested back to back (unconditional loads at a
+	 * clamped address: a sample outside the frame keeps valid = false and takes the general sampler in phase 2) -- sample by sample
+	 * the five pix_val calls of a pixel were a chain of memory round trips, 15 per thread (27.7 us for 256 patches of 25 x 25) */
+	double2 pk[PPT]; double zk[PPT];
+	Cell ck[PPT];
+#pragma unroll
+	for (int k = 0; k < PPT; ++k) {
+		const int i = tid + k * kBlock;
+		const int ic = i < N ? i : N - 1;
+		double2 p; double zi = 1.0;
+		if (region) {
+			const int col = ic % rg.resx, row = ic / rg.resx;
+			const double nx = (rg.resx == 1 || col == rg.resx - 1) ? rg.hi_x : rg.lo_x + col * ((rg.hi_x - rg.lo_x) / (rg.resx - 1));
+			const double ny = (rg.resy == 1 || row == rg.resy - 1) ? rg.hi_y : rg.lo_y + row * ((rg.hi_y - rg.lo_y) / (rg.resy - 1));
+			const double X = W0[0] * nx + W0[1] * ny + W0[2] * 1.0;
+			const double Y = W0[3] * nx + W0[4] * ny + W0[5] * 1.0;
+			const double Z = W0[6] * nx + W0[7] * ny + W0[8] * 1.0;
+			p = (W0[6] == 0 && W0[7] == 0 && W0[8] == 1.0) ? make_double2(X, Y) : make_double2(X / Z, Y / Z);
+			zi = rg.force_unit_z ? 1.0 : Z;
+			if (i < N) { ipw[i] = p; izw[i] = zi; ihw[i] = rg.force_unit_z ? p : make_double2(X, Y); }
+		} else { p = ip[ic]; zi = bv.unit_z ? 1.0 : iz[ic]; }
+		pk[k] = p; zk[k] = zi;
+		/* load_cell (mtfhip_device.h) with the loads hoisted out of its branches */
+		Cell c;
+		const double w = (double)(unsigned int)im.w, h = (double)(unsigned int)im.h;
+		const bool in0 = !((p.x < 0) || (p.x >= w) || (p.y < 0) || (p.y >= h));
+		const int lx = in0 ? (int)p.x : 0, ly = in0 ? (int)p.y : 0;
+		const double dx = p.x - lx, dy = p.y - ly;
+		const int ux = dx == 0 ? lx : lx + 1, uy = dy == 0 ? ly : ly + 1;
+		c.valid = in0 && !(ux >= im.w || uy >= im.h);
+		c.lx = c.valid ? lx : -1; c.ly = c.valid ? ly : -1; c.ux = c.valid ? ux : -1; c.uy = c.valid ? uy : -1;
+		const int slx = c.valid ? lx : 0, sly = c.valid ? ly : 0, sux = c.valid ? ux : 0, suy = c.valid ? uy : 0;
+		const float *r0 = im.data + (size_t)sly * im.stride, *r1 = im.data + (size_t)suy * im.stride;
+		c.t00 = r0[slx]; c.t01 = r0[sux]; c.t10 = r1[slx]; c.t11 = r1[sux];
+		ck[k] = c;
+	}
 #pragma unroll
 	for (int k = 0; k < PPT; ++k) {
 		const int i = tid + k * kBlock;
@@ -96,11 +158,11 @@ __global__ __launch_bounds__(kBlock) void k_template_init(BatchView bv, ImgView 
 #pragma unroll
 		for (int s = 0; s < 8; ++s) jv[k][s] = 0.0;
 		if (i < N) {
-			const double2 p = ip[i];
-			/* ImageBase::initializePixVals ImageBase.cc:62-99 (k_sample) */
-			const double v = norm_mult * pix_val(im, p.x, p.y) + norm_add;
+			const double2 p = pk[k]; const double zi = zk[k];
+			const Cell &c = ck[k];
+			/* ImageBase::initializePixVals ImageBase.cc:62-99 (k_sample: pix_val; from the fetched cell it is the same expression) */
+			const double v = norm_mult * pix_val_cell(im, c, p.x, p.y) + norm_add;
 			/* ImageBase::initializePixGrad(pts) ImageBase.cc:101-132 -> utils::getImgGrad imgUtils.cc:233-254 (k_img_grad) */
-			const Cell c = load_cell(im, p.x, p.y);
 			double inc = pix_val_cell(im, c, p.x + grad_eps, p.y), dec = pix_val_cell(im, c, p.x - grad_eps, p.y);
 			const double gx = (inc - dec) * gmult;
 			inc = pix_val_cell(im, c, p.x, p.y + grad_eps); dec = pix_val_cell(im, c, p.x, p.y - grad_eps);
@@ -111,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void k_template_init(BatchView bv, ImgView 
 #pragma unroll
 			for (int s = 0; s < 8; ++s) r[s] = 0.0;
 			if (hom) {
-				const double inv_det = 1.0 / (bv.unit_z ? 1.0 : iz[i]);
+				const double inv_det = 1.0 / (bv.unit_z ? 1.0 : zi);
 				const double dwx_dx = (1.0 - 0.0 * p.x), dwx_dy = (0.0 - 0.0 * p.x), dwy_dx = (0.0 - 0.0 * p.y), dwy_dy = (1.0 - 0.0 * p.y);
 				const double Ix = (dwx_dx * gx + dwy_dx * gy) * inv_det, Iy = (dwx_dy * gx + dwy_dy * gy) * inv_det;
 				hom_row(r, Ix, Iy, p.x, p.y, p.x, p.y);
@@ -145,43 +207,24 @@ __global__ __launch_bounds__(kBlock) void k_template_init(BatchView bv, ImgView 
 		init_allsum<1>(s2, red);
 		cn = sqrt(s2[0]);
 	}
+	/* Gram(J0) (upper triangle in ACC_H's order, 36) | sum J0 (8) | sum I0 J0 (8) | pad: one halving reduction of 56 values
+	 * (block_reduce_store, mtfhip_device.h) instead of a wave sum per value */
 	{
-		double m[16];
+		double acc[56];
 #pragma unroll
-		for (int q = 0; q < 16; ++q) m[q] = 0.0;
-#pragma unroll
-		for (int k = 0; k < PPT; ++k)
-#pragma unroll
-			for (int s = 0; s < 8; ++s) { m[s] += jv[k][s]; m[8 + s] = fma(i0v[k], jv[k][s], m[8 + s]); }
-		init_allsum<16>(m, red);
-		/* (register arrays cannot be indexed by the thread id: selects) */
-		double sj = 0, ij = 0;
-#pragma unroll
-		for (int q = 0; q < 8; ++q) { sj = tid == q ? m[q] : sj; ij = tid == q ? m[8 + q] : ij; }
-		if (tid < 8) { sSJ[tid] = sj; sIJ[tid] = ij; }
-	}
-	/* Gram(J0): the upper triangle in ACC_H's order, 36 sums in three rounds of twelve */
-#pragma unroll
-	for (int part = 0; part < 3; ++part) {
-		double g[12];
-#pragma unroll
-		for (int q = 0; q < 12; ++q) g[q] = 0.0;
+		for (int q = 0; q < 56; ++q) acc[q] = 0.0;
 #pragma unroll
 		for (int k = 0; k < PPT; ++k) {
 			int idx = 0;
 #pragma unroll
 			for (int a = 0; a < 8; ++a)
 #pragma unroll
-				for (int c = a; c < 8; ++c) {
-					if (idx >= 12 * part && idx < 12 * part + 12) g[idx - 12 * part] = fma(jv[k][a], jv[k][c], g[idx - 12 * part]);
-					++idx;
-				}
-		}
-		init_allsum<12>(g, red);
-		double mine = 0;
+				for (int c = a; c < 8; ++c) { acc[idx] = fma(jv[k][a], jv[k][c], acc[idx]); ++idx; }
 #pragma unroll
-		for (int q = 0; q < 12; ++q) mine = tid == q ? g[q] : mine;
-		if (tid < 12) sG[12 * part + tid] = mine;
+			for (int s = 0; s < 8; ++s) { acc[36 + s] += jv[k][s]; acc[44 + s] = fma(i0v[k], jv[k][s], acc[44 + s]); }
+		}
+		__syncthreads();   /* (red: the readers of the reductions above are done) */
+		block_reduce_store<56>(acc, sSum, sRed56);
 	}
 	__syncthreads();
 	/* the constant self Hessian, column-major S x S packed (what init_template keeps in th[].h0 / d_h0) */
@@ -234,17 +277,17 @@ __global__ __launch_bounds__(kBlock) void k_template_init(BatchView bv, ImgView 
 
 template <int AM>
 static void launch_init_am(const BatchView &bv, const ImgView &im, double grad_eps, double norm_mult, double norm_add, double *h0, double *h0inv,
-	double *ncc, double *ncc_tm, const InitPublish &pub, hipStream_t st) {
+	double *ncc, double *ncc_tm, const InitPublish &pub, const RegionIngest &rg, hipStream_t st) {
 	const int ppt = (bv.N + kBlock - 1) / kBlock;
-#define MTFHIP_INIT_CASE(P) MTFHIP_LAUNCH((k_template_init<AM, P>), dim3(bv.B), dim3(kBlock), 0, st, bv, im, grad_eps, norm_mult, norm_add, h0, h0inv, ncc, ncc_tm, pub)
+#define MTFHIP_INIT_CASE(P) MTFHIP_LAUNCH((k_template_init<AM, P>), dim3(bv.B), dim3(kBlock), 0, st, bv, im, grad_eps, norm_mult, norm_add, h0, h0inv, ncc, ncc_tm, pub, rg)
 	if (ppt <= 1) MTFHIP_INIT_CASE(1); else if (ppt == 2) MTFHIP_INIT_CASE(2); else if (ppt == 3) MTFHIP_INIT_CASE(3); else MTFHIP_INIT_CASE(4);
 #undef MTFHIP_INIT_CASE
 }
 /* N <= kTemplateInitMaxPix, single channel, SSD or NCC */
 void launch_template_init(const BatchView &bv, const ImgView &im, double grad_eps, double norm_mult, double norm_add, double *h0, double *h0inv,
-	double *ncc, double *ncc_tm, const InitPublish &pub, hipStream_t st) {
-	if (bv.am == MTFHIP_AM_NCC) launch_init_am<MTFHIP_AM_NCC>(bv, im, grad_eps, norm_mult, norm_add, h0, h0inv, ncc, ncc_tm, pub, st);
-	else launch_init_am<MTFHIP_AM_SSD>(bv, im, grad_eps, norm_mult, norm_add, h0, h0inv, ncc, ncc_tm, pub, st);
+	double *ncc, double *ncc_tm, const InitPublish &pub, const RegionIngest &rg, hipStream_t st) {
+	if (bv.am == MTFHIP_AM_NCC) launch_init_am<MTFHIP_AM_NCC>(bv, im, grad_eps, norm_mult, norm_add, h0, h0inv, ncc, ncc_tm, pub, rg, st);
+	else launch_init_am<MTFHIP_AM_SSD>(bv, im, grad_eps, norm_mult, norm_add, h0, h0inv, ncc, ncc_tm, pub, rg, st);
 }
 
 } // namespace mtfhip

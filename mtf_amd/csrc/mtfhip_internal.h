@@ -436,7 +436,7 @@ constexpr int kInitRec = 128;
 constexpr int kTemplateInitMaxPix = 4 * 256;
 struct InitPublish { double *host; int *count; unsigned long long *flag, seq; int fenced; };
 void launch_template_init(const BatchView &bv, const ImgView &im, double grad_eps, double norm_mult, double norm_add, double *h0, double *h0inv,
-	double *ncc, double *ncc_tm, const InitPublish &pub, hipStream_t st);
+	double *ncc, double *ncc_tm, const InitPublish &pub, const RegionIngest &rg, hipStream_t st);   /* rg.corners != NULL: the kernel lays out the grid itself */
 /* one launch per pass with the finish folded in behind a last-arriver counter (kernels_step.hip); arrive: [B] ints, zero between launches */
 bool track_step_available(const BatchView &bv, const FusedArgs &fa);
 void launch_track_step(const BatchView &bv, const ImgView &im, const FusedArgs &fa, const mtfhip_sm_desc &sm, const TrackState &ts,

@@ -143,15 +143,32 @@ void Grid::leastSquaresFit(int ssm, VectorXd &u, const std::vector<GridPt> &a, c
 	};
 	double amx, amy, asc, cmx, cmy, csc;
 	norm(a, amx, amy, asc); norm(c, cmx, cmy, csc);
-	std::vector<double> N(64, 0.0), rhs(8, 0.0);
+	/* normal equations of the rows [x y 1 0 0 0 -Xx -Xy | X], [0 0 0 x y 1 -Yx -Yy | Y]: their 8 x 8 matrix is made of 23 sums over the
+	 * points (the two 3 x 3 diagonal blocks are the same, the coupling blocks share their entries), ~35 flops per point instead of the
+	 * 144 of the two outer products */
+	double sxx = 0, sxy = 0, sx = 0, syy = 0, sy = 0;
+	double Xx = 0, Xy = 0, X1 = 0, Yx = 0, Yy = 0, Y1 = 0, Xxx = 0, Xxy = 0, Xyy = 0, Yxx = 0, Yxy = 0, Yyy = 0, Rxx = 0, Rxy = 0, Ryy = 0, Rx = 0, Ry = 0;
 	for (int i = 0; i < n; ++i) {
 		const double x = (a[i].x - amx) * asc, y = (a[i].y - amy) * asc, X = (c[i].x - cmx) * csc, Y = (c[i].y - cmy) * csc;
-		const double r1[8] = {x, y, 1, 0, 0, 0, -X * x, -X * y}, r2[8] = {0, 0, 0, x, y, 1, -Y * x, -Y * y};
-		for (int p = 0; p < 8; ++p) {
-			for (int q = 0; q < 8; ++q) N[p * 8 + q] += r1[p] * r1[q] + r2[p] * r2[q];
-			rhs[p] += r1[p] * X + r2[p] * Y;
+		const double xx = x * x, xy = x * y, yy = y * y, R = X * X + Y * Y;
+		sxx += xx; sxy += xy; sx += x; syy += yy; sy += y;
+		Xx += X * x; Xy += X * y; X1 += X; Yx += Y * x; Yy += Y * y; Y1 += Y;
+		Xxx += X * xx; Xxy += X * xy; Xyy += X * yy; Yxx += Y * xx; Yxy += Y * xy; Yyy += Y * yy;
+		Rxx += R * xx; Rxy += R * xy; Ryy += R * yy; Rx += R * x; Ry += R * y;
+	}
+	const double sn = (double)n;
+	std::vector<double> N(64, 0.0), rhs(8, 0.0);
+	const double A3[3][3] = {{sxx, sxy, sx}, {sxy, syy, sy}, {sx, sy, sn}};
+	const double BX[3][2] = {{Xxx, Xxy}, {Xxy, Xyy}, {Xx, Xy}}, BY[3][2] = {{Yxx, Yxy}, {Yxy, Yyy}, {Yx, Yy}};
+	for (int p = 0; p < 3; ++p) {
+		for (int q = 0; q < 3; ++q) { N[p * 8 + q] = A3[p][q]; N[(3 + p) * 8 + 3 + q] = A3[p][q]; }
+		for (int k = 0; k < 2; ++k) {
+			N[p * 8 + 6 + k] = -BX[p][k]; N[(6 + k) * 8 + p] = -BX[p][k];
+			N[(3 + p) * 8 + 6 + k] = -BY[p][k]; N[(6 + k) * 8 + 3 + p] = -BY[p][k];
 		}
 	}
+	N[6 * 8 + 6] = Rxx; N[6 * 8 + 7] = Rxy; N[7 * 8 + 6] = Rxy; N[7 * 8 + 7] = Ryy;
+	rhs[0] = Xx; rhs[1] = Xy; rhs[2] = X1; rhs[3] = Yx; rhs[4] = Yy; rhs[5] = Y1; rhs[6] = -Rx; rhs[7] = -Ry;
 	if (!solveSym(8, N, rhs)) throw utils::InvalidTrackerState("GridTracker :: degenerate point set");
 	/* H = Tc^-1 * Hn * Ta */
 	const double Hn[9] = {rhs[0], rhs[1], rhs[2], rhs[3], rhs[4], rhs[5], rhs[6], rhs[7], 1.0};

@@ -197,11 +197,13 @@ def test_fused_template_init_equals_call_by_call(oracle, gpu_ctx, frame, am, ssm
     out = {}
     for fused in ("0", "1"):
         monkeypatch.setenv("MTFHIP_INIT_FUSED", fused)
+        monkeypatch.setenv("MTFHIP_GRID_FUSED", fused)   # (the fused reset also lays the grid out in the same launch)
         gpu_ctx.set_image(frame)
         g = GridTracker(gpu_ctx, grid_size=gs, patch_size=ps, am=am, ssm=ssm, max_iters=15, epsilon=1e-5, reset_at_each_frame=1)
         g.initialize(region)
         b = g.tracker.batch
-        arrays = [b.read(L.BUF_I0).copy(), b.read(L.BUF_IT).copy(), b.read(L.BUF_DI0_DX).copy(), b.read(L.BUF_J0).copy()]
+        arrays = [b.read(L.BUF_I0).copy(), b.read(L.BUF_IT).copy(), b.read(L.BUF_DI0_DX).copy(), b.read(L.BUF_J0).copy(), b.read(L.BUF_INIT_PTS).copy(),
+                  b.read(L.BUF_CURR_PTS).copy(), b.get_state().copy(), b.get_corners().copy()]
         H0 = b.cmpt_self_hessian(L.BUF_J0).copy() if am == L.AM_SSD else None     # through the interface: the host mirrors must be current
         gpu_ctx.set_image(f2)
         c1, cen1 = g.update_patches()
@@ -210,7 +212,7 @@ def test_fused_template_init_equals_call_by_call(oracle, gpu_ctx, frame, am, ssm
         c3, _ = g.update_patches() # ... and track from the re-initialised templates
         out[fused] = (arrays, H0, c1.copy(), n1, r2.copy(), c3.copy())
         b.close()
-    for x, y, what in zip(out["0"][0], out["1"][0], ("I0", "It", "dI0_dx", "J0")):
+    for x, y, what in zip(out["0"][0], out["1"][0], ("I0", "It", "dI0_dx", "J0", "init_pts", "curr_pts", "state", "corners")):
         assert np.array_equal(x, y), what
     if out["0"][1] is not None:
         np.testing.assert_allclose(out["1"][1], out["0"][1], rtol=1e-12)
