@@ -107,6 +107,7 @@ int mtfhip_image_upload_mc(mtfhip_ctx *c, const float *host_img, int height, int
 	if (channels != 1 && channels != 3) return fail(MTFHIP_ERR_INVALID_ARG, "image_upload: %d channels (1 or 3 expected)", channels);
 	if (height <= 0 || width <= 0 || row_stride < width * channels) return fail(MTFHIP_ERR_INVALID_ARG, "image_upload: bad shape %dx%d stride %d", height, width, row_stride);
 	if ((double)height * width * channels * 4.0 >= 4294967296.0) return fail(MTFHIP_ERR_INVALID_ARG, "image_upload: %dx%dx%d floats exceed the 4 GiB a 32-bit texel offset can address", height, width, channels);
+	if (height >= (1 << 24) || (double)width * channels >= (double)(1 << 24)) return fail(MTFHIP_ERR_INVALID_ARG, "image_upload: %d rows of %d floats: 2^24 or more of either (the samplers' 24-bit row x pitch product)", height, width * channels);
 	HIP_TRY(hipSetDevice(c->device));
 	const int logical_width = width;
 	width *= channels;   /* floats per row */
@@ -128,6 +129,8 @@ int mtfhip_image_borrow(mtfhip_ctx *c, const float *dev_img, int height, int wid
 	if (c) TRY(lazy_flush_ctx(c));
 	if (!c || !dev_img) return fail(MTFHIP_ERR_INVALID_ARG, "image_borrow: NULL argument");
 	if (height <= 0 || width <= 0 || row_stride < width) return fail(MTFHIP_ERR_INVALID_ARG, "image_borrow: bad shape");
+	if ((double)height * row_stride * 4.0 >= 4294967296.0 || height >= (1 << 24) || row_stride >= (1 << 24))
+		return fail(MTFHIP_ERR_INVALID_ARG, "image_borrow: %d rows of %d floats exceed what a 32-bit texel offset / a 24-bit row x pitch product can address", height, row_stride);
 	c->img = ImgView{dev_img, height, width, row_stride};
 	return MTFHIP_OK;
 }

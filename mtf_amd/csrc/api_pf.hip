@@ -93,6 +93,7 @@ struct mtfhip_pf {
 	 * only); valid while nothing they depend on has changed -- the particle set, the sampler's distributions, the template
 	 * corners.  MTFHIP_PF_LOOKAHEAD=0: every iteration proposes in a launch of its own. */
 	bool lookahead_enabled = true, prop_valid = false;
+	bool local_enabled = true, pert_ahead_enabled = true;   /* MTFHIP_PF_LOCAL=0 / MTFHIP_PF_PERT_AHEAD=0 at creation: the scan launch / the draws inside the selection pass */
 	unsigned prop_iter = 0;
 	long prop_corners_epoch = -1;
 	int pc = 0;
@@ -101,6 +102,11 @@ struct mtfhip_pf {
 	double *d_prop[2] = {nullptr, nullptr}, *d_prop_ar[2] = {nullptr, nullptr}; /* proposals: this iteration's | the next one's */
 	double *d_wts = nullptr, *d_cum = nullptr, *d_chunk = nullptr, *d_out = nullptr, *d_normals = nullptr, *d_uniforms = nullptr;
 	double *d_parts = nullptr, *d_gparts = nullptr;   /* per-workgroup rows of the selection pass and their per-group folds */
+	/* perturbations drawn ahead (PfSelectPlan): buffer q holds those of iteration pert_iter[q] (-1: none) for the template corners of
+	 * pert_epoch[q] and the sampler of pert_gen[q]; the selection pass of iteration t reads buffer (t + 1) & 1 and fills t & 1 with t + 2's */
+	double *d_pert[2] = {nullptr, nullptr};
+	long pert_iter[2] = {-1, -1}, pert_epoch[2] = {-1, -1};
+	unsigned pert_gen[2] = {0, 0}, sampler_gen = 0;
 	int *d_ids = nullptr, *d_counters = nullptr;
 	/* residual resampling (PF.cc:538-582): sort keys in / out, particle order in / out, copies, their starts, hipCUB's scratch */
 	double *d_res_keys = nullptr;
@@ -251,7 +257,7 @@ int mtfhip_allgather_scores(mtfhip_comm *c, const double *dev_send, int count, d
 static void pf_free(mtfhip_pf *pf) {
 	void *ptrs[] = {pf->d_st, pf->d_ar, pf->d_prop[0], pf->d_prop[1], pf->d_prop_ar[0], pf->d_prop_ar[1], pf->d_wts, pf->d_cum, pf->d_chunk, pf->d_out,
 		pf->d_normals, pf->d_uniforms, pf->d_ids, pf->d_parts, pf->d_gparts, pf->d_counters, pf->d_res_keys, pf->d_res_idx, pf->d_res_tmp,
-		pf->d_distr, pf->d_scan_stats, pf->d_distr_u, pf->d_distr_ids, pf->d_resample_flag};
+		pf->d_distr, pf->d_scan_stats, pf->d_distr_u, pf->d_distr_ids, pf->d_resample_flag, pf->d_pert[0], pf->d_pert[1]};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	for (int q = 0; q < kPfMaxPeers; ++q) if (pf->peer.mapped[q]) (void)hipIpcCloseMemHandle(pf->peer.base[q]);
 	if (pf->peer.mailbox) (void)hipFree(pf->peer.mailbox);
@@ -294,11 +300,14 @@ int mtfhip_pf_create(mtfhip_batch *b, const mtfhip_pf_desc *d, mtfhip_pf **out) 
 	mtfhip_pf *pf = new mtfhip_pf;
 	pf->b = b; pf->d = *d; pf->n = d->n_particles; pf->S = b->S; pf->sampler = sampler; pf->nz = nz;
 	{ const char *e = std::getenv("MTFHIP_PF_LOOKAHEAD"); pf->lookahead_enabled = !(e && e[0] == '0'); }
+	{ const char *e = std::getenv("MTFHIP_PF_LOCAL"); pf->local_enabled = !(e && e[0] == '0'); }
+	{ const char *e = std::getenv("MTFHIP_PF_PERT_AHEAD"); pf->pert_ahead_enabled = !(e && e[0] == '0'); }
 	const size_t nS = (size_t)pf->n * pf->S, n = (size_t)pf->n, npad = pf_round_chunk(n), nch = npad / (size_t)pf_chunk();
 	bool okm = true;
 	auto A = [&](auto &p, size_t bytes) { if (hipMalloc(reinterpret_cast<void **>(&p), bytes) != hipSuccess) okm = false; };
 	A(pf->d_st, sizeof(double) * nS); A(pf->d_ar, sizeof(double) * nS);
 	for (int k = 0; k < 2; ++k) { A(pf->d_prop[k], sizeof(double) * nS); A(pf->d_prop_ar[k], sizeof(double) * nS); }
+	for (int k = 0; k < 2; ++k) A(pf->d_pert[k], sizeof(double) * 8 * n);
 	A(pf->d_wts, sizeof(double) * npad); pf->wts_capacity = npad;
 	A(pf->d_cum, sizeof(double) * npad); A(pf->d_chunk, sizeof(double) * (2 + 16) * nch);   /* chunk totals | their prefix | sub-block sums */
 	const size_t nblk = (n + 255) / 256, ngrp = (nblk + 63) / 64;
@@ -350,6 +359,7 @@ int mtfhip_pf_set_distributions(mtfhip_pf *pf, int n_distr, const double *sigma,
 	pf->n_distr = n_distr;
 	for (int s2 = 0; s2 < pf->S; ++s2) { pf->d.ssm_sigma[s2] = sigma[s2]; pf->d.ssm_mean[s2] = mean[s2]; }   /* initializeSampler(state_sigma[0], state_mean[0]) */
 	pf->prop_valid = false;
+	++pf->sampler_gen;
 	return MTFHIP_OK;
 }
 /* the distribution draws (uniforms in (0, 1], one per particle) of the NEXT iteration, for callers that supply their own draws
@@ -551,6 +561,7 @@ int mtfhip_pf_set_sampler(mtfhip_pf *pf, const double *sigma, const double *mean
 	if (!pf || !sigma || !mean) return fail(MTFHIP_ERR_INVALID_ARG, "pf_set_sampler: NULL argument");
 	for (int s = 0; s < pf->S; ++s) { pf->d.ssm_sigma[s] = sigma[s]; pf->d.ssm_mean[s] = mean[s]; }
 	pf->prop_valid = false;   /* proposals made ahead used the old distributions */
+	++pf->sampler_gen;        /* ... and so did the perturbations drawn ahead */
 	if (pf->n_distr > 1 && pf->d_distr) {   /* distribution 0 of the set */
 		double h[16];
 		for (int s2 = 0; s2 < 8; ++s2) { h[s2] = s2 < pf->S ? sigma[s2] : 0.0; h[8 + s2] = s2 < pf->S ? mean[s2] : 0.0; }
@@ -580,6 +591,7 @@ int mtfhip_pf_initialize(mtfhip_pf *pf) {
 	TRY(mtfhip_am_get_similarity(b, &f));
 	pf->max_similarity = f;
 	pf->iter = 0;
+	pf->pert_iter[0] = pf->pert_iter[1] = -1;
 	if (pf->n_distr > 1) {   /* initializeDistributions PF.cc:199-205 */
 		double h[16];
 		for (int i = 0; i < 8; ++i) { h[8 + i] = i < pf->n_distr ? 1.0 / pf->n_distr : 0.0; h[i] = i < pf->n_distr ? (i + 1.0) / pf->n_distr : 0.0; }
@@ -756,10 +768,24 @@ static int pf_enqueue_iteration(mtfhip_pf *pf, const double *normals, const doub
 		TimedScope ts(b->ctx, "pf_resample");
 		unsigned long long seq = 0;
 		if (publish && b->h_acc_dev) seq = ++b->acc_seq;
-		if (p.resampling_type != 0 || mixture) launch_pf_scan(p, bf, peer ? &pwait : nullptr, st);   /* (the distribution weights follow the particle weights whatever the resampling) */
+		/* small sets with multinomial resampling: the selection pass scans the weights itself (k_pf_select, LOCAL) -- MTFHIP_PF_LOCAL=0: the
+		 * scan launch in front, as for every other case */
+		const bool local_env = pf->local_enabled, pert_env = pf->pert_ahead_enabled;   /* (read when the filter was created) */
+		PfSelectPlan plan;
+		plan.local = local_env && (p.resampling_type == 1 || p.resampling_type == 2) && !mixture && !bf.scan_stats && n <= pf_local_max();
+		if (plan.local) { if (peer) plan.wait = &pwait; }
+		else if (p.resampling_type != 0 || mixture) launch_pf_scan(p, bf, peer ? &pwait : nullptr, st);   /* (the distribution weights follow the particle weights whatever the resampling) */
 		else if (peer) launch_pf_peer_wait(pwait, st);
 		if (p.resampling_type == 3) TRY(pf_residual_sources(pf, bf, nch, st));
-		launch_pf_select(b->desc.ssm, p, bf, lookahead ? 1 : 0, seq ? b->h_acc_dev : nullptr, b->h_flag_dev, seq, st);
+		/* the perturbations of the next iteration, drawn two launches ago; this launch draws those of the one after */
+		const unsigned it = pf->iter;
+		if (lookahead && pert_env && !mixture) {
+			const int bi = (int)((it + 1) & 1u);
+			if (pf->pert_iter[bi] == (long)it + 1 && pf->pert_epoch[bi] == b->corners_epoch && pf->pert_gen[bi] == pf->sampler_gen) plan.pert_in = pf->d_pert[bi];
+			plan.pert_out = pf->d_pert[it & 1u];
+		}
+		launch_pf_select(b->desc.ssm, p, bf, lookahead ? 1 : 0, seq ? b->h_acc_dev : nullptr, b->h_flag_dev, seq, plan, st);
+		if (plan.pert_out) { pf->pert_iter[it & 1u] = (long)it + 2; pf->pert_epoch[it & 1u] = b->corners_epoch; pf->pert_gen[it & 1u] = pf->sampler_gen; }
 		if (pub_seq) *pub_seq = seq;
 	}
 	++pf->iter;

@@ -179,12 +179,12 @@ struct PfArgs {
 };
 
 /* pair `q` (draws 2 q, 2 q + 1) of particle k's normals */
-__device__ __forceinline__ void pf_normal_pair(const PfArgs &a, unsigned k, int q, double &z0, double &z1) {
+__device__ __forceinline__ void pf_normal_pair(const PfArgs &a, unsigned iter, unsigned k, int q, double &z0, double &z1) {
 	if (a.normals) {
 		const double2 v = *reinterpret_cast<const double2 *>(a.normals + (size_t)k * a.nz + 2 * q);   /* nz is even: rows and pairs are 16-byte aligned */
 		z0 = v.x; z1 = v.y;
 	} else {
-		philox_normal2(a.seed, a.iter, k, (unsigned)q, z0, z1);
+		philox_normal2(a.seed, iter, k, (unsigned)q, z0, z1);
 	}
 }
 
@@ -271,9 +271,11 @@ __device__ __forceinline__ void pf_dynamics(const PfArgs &a, const double *pert,
 		double B[9], P[9], A[9], BA[9], W[9], Bi[9], AW[9];
 		warp_from_state_dev<SSM>(st, B); warp_from_state_dev<SSM>(pert, P); warp_from_state_dev<SSM>(ar, A);
 		m3_mul_dev(B, A, BA); m3_mul_dev(BA, P, W);
-		if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) { const double n22 = W[8]; for (int q = 0; q < 9; ++q) W[q] /= n22; }
+		if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) { const double n22 = W[8];
+_Pragma("unroll") for (int q = 0; q < 9; ++q) W[q] /= n22; }
 		m3_inv_dev(B, Bi); m3_mul_dev(Bi, W, AW);
-		if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) { const double n22 = AW[8]; for (int q = 0; q < 9; ++q) AW[q] /= n22; }
+		if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) { const double n22 = AW[8];
+_Pragma("unroll") for (int q = 0; q < 9; ++q) AW[q] /= n22; }
 		state_from_warp_dev<SSM>(ns, W); state_from_warp_dev<SSM>(nar, AW);
 #pragma unroll
 		for (int s = 0; s < 8; ++s) nar[s] *= a.ar_coeff;
@@ -284,7 +286,8 @@ __device__ __forceinline__ void pf_dynamics(const PfArgs &a, const double *pert,
 		double B[9], P[9], W[9];
 		warp_from_state_dev<SSM>(st, B); warp_from_state_dev<SSM>(pert, P);
 		m3_mul_dev(B, P, W);
-		if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) { const double n22 = W[8]; for (int q = 0; q < 9; ++q) W[q] /= n22; }
+		if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) { const double n22 = W[8];
+_Pragma("unroll") for (int q = 0; q < 9; ++q) W[q] /= n22; }
 		state_from_warp_dev<SSM>(ns, W);
 	}
 }
@@ -304,14 +307,15 @@ __device__ __forceinline__ void pf_store_row(double *base, size_t k, const doubl
 #pragma unroll
 	for (int s2 = 0; s2 < 4; ++s2) if (2 * s2 < S) p[s2] = make_double2(v[2 * s2], v[2 * s2 + 1]);
 }
-/* one thread: (st, ar) of particle k -> its proposal */
+/* one thread: particle k's perturbation of iteration a.iter -- a function of the counter-based draws and the sampler only, NOT of
+ * the particle's state: it can be made before the resampling that decides which state it is applied to (k_pf_select's second role) */
 template <int SSM>
-__device__ __forceinline__ void pf_propose(const PfArgs &a, unsigned k, const double *st, const double *ar, double *ns, double *nar) {
-	double z[10], pert[8];
+__device__ __forceinline__ void pf_draw_perturbation(const PfArgs &a, unsigned iter, unsigned k, double *pert) {
+	double z[10];
 #pragma unroll
 	for (int q = 0; q < 5; ++q) {
 		z[2 * q] = z[2 * q + 1] = 0.0;
-		if (2 * q < a.nz) pf_normal_pair(a, k, q, z[2 * q], z[2 * q + 1]);
+		if (2 * q < a.nz) pf_normal_pair(a, iter, k, q, z[2 * q], z[2 * q + 1]);
 	}
 	double sg[8], mn[8];
 #pragma unroll
@@ -322,7 +326,7 @@ __device__ __forceinline__ void pf_propose(const PfArgs &a, unsigned k, const do
 		double u;
 		if (a.distr_uniforms) u = a.distr_uniforms[k];
 		else {
-			const Philox4 r = philox4x32_10(k, 0u, a.iter, 0x44495354u /* "DIST" */, (unsigned)a.seed, (unsigned)(a.seed >> 32));
+			const Philox4 r = philox4x32_10(k, 0u, iter, 0x44495354u /* "DIST" */, (unsigned)a.seed, (unsigned)(a.seed >> 32));
 			double u1;
 			philox_uniform2(r, u, u1);
 		}
@@ -334,6 +338,12 @@ __device__ __forceinline__ void pf_propose(const PfArgs &a, unsigned k, const do
 		for (int s = 0; s < 8; ++s) { sg[s] = a.distr_sigma[8 * id + s]; mn[s] = a.distr_mean[8 * id + s]; }
 	}
 	pf_perturbation<SSM>(a, sg, mn, z, pert);
+}
+/* one thread: (st, ar) of particle k -> its proposal */
+template <int SSM>
+__device__ __forceinline__ void pf_propose(const PfArgs &a, unsigned iter, unsigned k, const double *st, const double *ar, double *ns, double *nar) {
+	double pert[8];
+	pf_draw_perturbation<SSM>(a, iter, k, pert);
 	pf_dynamics<SSM>(a, pert, st, ar, ns, nar);
 }
 /* the proposals of a whole set in a launch of their own: the first iteration after the particles were (re)initialised, draws
@@ -345,7 +355,7 @@ __global__ __launch_bounds__(kBlock) void k_pf_propose(PfArgs a, const double *s
 	if (k >= a.n) return;
 	double st[8], ar[8], ns[8], nar[8];
 	pf_load_row<S>(st_in, (size_t)k, st); pf_load_row<S>(ar_in, (size_t)k, ar);
-	pf_propose<SSM>(a, (unsigned)k, st, ar, ns, nar);
+	pf_propose<SSM>(a, a.iter, (unsigned)k, st, ar, ns, nar);
 	pf_store_row<S>(st_out, (size_t)k, ns); pf_store_row<S>(ar_out, (size_t)k, nar);
 }
 
@@ -371,6 +381,7 @@ struct PfScoreArgs {
 	 * map is projective: a point of the hull goes to a convex combination of the warped corners): its samples skip the border test. */
 	int hull_ok;
 	double hull[8];
+	int lean_ok;                   /* 0: experiments (MTFHIP_PF_LEAN=0) */
 };
 /* A weight for the peers: a relaxed system-scope store -- it goes through to the peer's memory, and the wave's vmcnt tells when it
  * has (what every release fence relies on), so no fence and no L2 write-back per workgroup.  (First version: a system-scope release
@@ -470,8 +481,12 @@ __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, P
 		}
 	}
 	PF_STAMP(1);
-	auto pixel_loop = [&](auto inside_tag) {
+	/* LEAN (wave-uniform, decided once): a unit-z grid and the identity pixel normalisation -- W2 * 1.0 and fma(1.0, v, 0.0) are the
+	 * same bits without the instruction: 4 of the 44 VALU instructions of a homography candidate-sample, on a loop that sits at the
+	 * measured FP64 issue ceiling (profiles/r04_fp64_rates.txt) */
+	auto pixel_loop = [&](auto inside_tag, auto lean_tag) {
 	constexpr bool INSIDE = decltype(inside_tag)::value;
+	constexpr bool LEAN = FAST && decltype(lean_tag)::value;
 	for (unsigned i = tid; i < N; i += kBlock) {
 		const unsigned pi = MC ? i / Cc : i;          /* the row's pixel */
 		const int ch = MC ? (int)(i - pi * Cc) : 0;   /* ... and channel */
@@ -488,10 +503,10 @@ __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, P
 				 * last-bit differences flip round(w n) ties of the residual resampler against the oracle: not taken.) */
 				/* (z is exactly 1.0 on a unit-z grid and x * 1.0 == x: no select on the flag -- a per-lane select of a wave-uniform
 				 * condition was two moves + two v_cndmask per coordinate, 8 of the 44 VALU instructions of a candidate-sample) */
-				double wx = fma(W[k][0], q.x, fma(W[k][1], q.y, W[k][2] * z));
-				double wy = fma(W[k][3], q.x, fma(W[k][4], q.y, W[k][5] * z));
+				double wx = fma(W[k][0], q.x, fma(W[k][1], q.y, LEAN ? W[k][2] : W[k][2] * z));
+				double wy = fma(W[k][3], q.x, fma(W[k][4], q.y, LEAN ? W[k][5] : W[k][5] * z));
 				if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
-					const double dd = fma(W[k][6], q.x, fma(W[k][7], q.y, W[k][8] * z));
+					const double dd = fma(W[k][6], q.x, fma(W[k][7], q.y, LEAN ? W[k][8] : W[k][8] * z));
 					const double inv = rcp_fast(dd);
 					wx *= inv; wy *= inv;
 				}
@@ -506,14 +521,16 @@ __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, P
 						const float t10 = ld_off<float>(img + stride, off), t11 = ld_off<float>(img + stride, off + 4u * Cc);
 						v = bilin_val_fast(t00, t01, t10, t11, fx, fy);
 					} else {
-						const unsigned off = (unsigned)(ly * stride + lx) * 4u;
+						/* (v_mul_lo_u32 is a quarter-rate instruction, 16 cycles of a ~900-cycle iteration each: the row and the pitch are
+						 * below 2^24 -- mtfhip_image_upload / _borrow refuse larger frames -- so the 24-bit multiply-add, full rate, gives the same offset) */
+						const unsigned off = (__umul24((unsigned)ly, (unsigned)stride) + (unsigned)lx) * 4u;
 						const PfTexPair t0 = ld_off<PfTexPair>(img, off), t1 = ld_off<PfTexPair>(img + stride, off);
 						v = bilin_val_fast(t0.a, t0.b, t1.a, t1.b, fx, fy);
 					}
 				} else {
 					if constexpr (MC) v = pix_val_mc(im, wx, wy, ch); else v = pix_val_fast(im, wx, wy);
 				}
-				it = fma(s.norm_mult, v, s.norm_add);
+				it = LEAN ? v : fma(s.norm_mult, v, s.norm_add);
 			} else {   /* the reference's operation order (ProjectiveBase.cc:41-49, imgUtils.h:91-113, 505-551) */
 				double wx = W[k][0] * q.x + W[k][1] * q.y + W[k][2] * z, wy = W[k][3] * q.x + W[k][4] * q.y + W[k][5] * z;
 				if constexpr (SSM == MTFHIP_SSM_HOMOGRAPHY) {
@@ -531,7 +548,9 @@ __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, P
 		}
 	}
 	};
-	if (all_inside) pixel_loop(std::true_type{}); else pixel_loop(std::false_type{});
+	const bool lean = FAST && uz && s.lean_ok && s.norm_mult == 1.0 && s.norm_add == 0.0;
+	if (lean) { if (all_inside) pixel_loop(std::true_type{}, std::true_type{}); else pixel_loop(std::false_type{}, std::true_type{}); }
+	else { if (all_inside) pixel_loop(std::true_type{}, std::false_type{}); else pixel_loop(std::false_type{}, std::false_type{}); }
 	PF_STAMP(2);
 	block_reduce_store<K * M>(acc, tot, red);
 	__syncthreads();
@@ -759,7 +778,17 @@ struct PfSelectArgs {
 	int *counter;                 /* [1 + ceil(nblocks / 64)]: top-level counter, then one per group; zero between launches */
 	double *out;                  /* [32]: estimate state (8) | max_wt | max_wt_id | mean corners (8) */
 	PfPublish pub;
+	/* workgroups [0, nsel) select; workgroups [nsel, gridDim.x) (pert_out != NULL) draw the perturbations of iteration pert_out_iter =
+	 * a.iter + 2 into pert_out [n][8]: they need nothing of this iteration, run beside the selection on otherwise idle CUs, and the
+	 * selection pass after next finds them done (pert_in: those of a.iter + 1, drawn two launches ago) -- Philox + Box-Muller + the
+	 * corner-based homography were 5 of this launch's 16 us at 10 000 particles, behind the estimate but in front of the next scorer */
+	int nsel;
+	const double *pert_in;
+	double *pert_out;
+	unsigned pert_out_iter;
+	PfPeerWait wait;              /* LOCAL: this launch is the first reader of the gathered weights */
 };
+constexpr int kPfLocalMax = 16384;   /* LOCAL: particles whose cumulative weights fit one workgroup's LDS (128 KB of the 160) */
 /* a folded row: best weight and its index, the sixteen sums, the state of the best particle (all wave-uniform) */
 struct PfRow { double v; int i; double sum[16]; double st[8]; };
 /* element `idx` (per-lane) of a small uniform array without indexing registers dynamically */
@@ -796,21 +825,93 @@ __device__ __forceinline__ void pf_fold64(const double *rows, int count, int lan
 #pragma unroll
 	for (int q = 0; q < 8; ++q) o.st[q] = __shfl(x[18 + q], bl);
 }
-template <int SSM>
+/* LOCAL (n <= kPfLocalMax, multinomial resampling, no scan statistics): no k_pf_scan launch in front -- every workgroup builds
+ * the cumulative weights of the WHOLE set in its own LDS (10 000 weights are 80 KB, read from L2 by 40 workgroups), with the scan's
+ * arithmetic (chunk-local sums by wave_scan_incl, the chunk totals' prefix in the order of its last workgroup: the same bits), and
+ * the three-level search reads LDS instead of four cache lines.  One launch and two dependent memory round trips less per iteration
+ * (k_pf_scan: 5.4 us + the launch gap at 10 000 particles). */
+template <int SSM, bool LOCAL>
 __global__ __launch_bounds__(kBlock) void k_pf_select(PfArgs a, PfSelectArgs r) {
 	constexpr int S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
-	__shared__ double table[kPfTable];
+	__shared__ double table[LOCAL ? 64 : kPfTable];
+	__shared__ double lcum[LOCAL ? kPfLocalMax : 1];
+	__shared__ double ctot[64];
 	__shared__ double lds[4 * 16];
 	__shared__ double red_v[kBlock / 64]; __shared__ int red_i[kBlock / 64];
 	__shared__ double best_state[8];
 	__shared__ int wg_best, is_last;
-	const int n = a.n, tid = threadIdx.x, k = blockIdx.x * kBlock + tid;
+	const int n = a.n, tid = threadIdx.x;
+	if ((int)blockIdx.x >= r.nsel) {   /* the perturbations of the iteration after next */
+		const int kp = ((int)blockIdx.x - r.nsel) * kBlock + tid;
+		if (kp < n) {
+			double pert[8];
+			pf_draw_perturbation<SSM>(a, r.pert_out_iter, (unsigned)kp, pert);
+			pf_store_row<8>(r.pert_out, (size_t)kp, pert);
+		}
+		return;
+	}
+	const int k = blockIdx.x * kBlock + tid;
 	const bool go = r.resample_flag ? *r.resample_flag != 0 : true;   /* (uniform: a scalar load) */
 	const bool resample = go && (r.resampling_type == 1 || r.resampling_type == 2);
 	const int nch = (n + kPfChunk - 1) / kPfChunk;
-	const bool in_lds = nch <= kPfTable;
+	const bool in_lds = LOCAL || nch <= kPfTable;
 	double total = 0.0;
-	if (resample) {
+	/* (requested now, used after the search: the row this thread's successor is proposed from) */
+	double pin[8];
+#pragma unroll
+	for (int q = 0; q < 8; ++q) pin[q] = 0.0;
+	const bool have_pert = r.lookahead && r.pert_in != nullptr;
+	if (have_pert && k < n) pf_load_row<8>(r.pert_in, (size_t)k, pin);
+	if constexpr (LOCAL) {
+		pf_peer_wait(r.wait);
+		if (resample) {
+			const int lane = tid & 63, wave = tid >> 6;
+			constexpr int kB = 8;   /* chunks per wave in flight: wave w takes chunks w, w + 4, ... */
+			for (int cb = wave; cb < nch; cb += 4 * kB) {
+				double w[kB][4];
+#pragma unroll
+				for (int u = 0; u < kB; ++u) {
+					const int c = cb + 4 * u, base = c * kPfChunk + 4 * lane;
+#pragma unroll
+					for (int j = 0; j < 4; ++j) w[u][j] = 0.0;
+					if (c < nch) {   /* k_pf_scan's loads */
+						if (base + 3 < n) {
+							const double2 v0 = *reinterpret_cast<const double2 *>(r.wts + base), v1 = *reinterpret_cast<const double2 *>(r.wts + base + 2);
+							w[u][0] = v0.x; w[u][1] = v0.y; w[u][2] = v1.x; w[u][3] = v1.y;
+						} else {
+#pragma unroll
+							for (int j = 0; j < 4; ++j) w[u][j] = base + j < n ? r.wts[base + j] : 0.0;
+						}
+					}
+				}
+#pragma unroll
+				for (int u = 0; u < kB; ++u) {
+					const int c = cb + 4 * u, base = c * kPfChunk + 4 * lane;
+					if (c < nch) {   /* ... and its sums */
+						const double p0 = w[u][0], p1 = p0 + w[u][1], p2 = p1 + w[u][2], p3 = p2 + w[u][3];
+						const double incl = wave_scan_incl(p3, lane);
+						const double off = incl - p3;
+						*reinterpret_cast<double2 *>(lcum + base) = make_double2(off + p0, off + p1);
+						*reinterpret_cast<double2 *>(lcum + base + 2) = make_double2(off + p2, off + p3);
+						if (lane == 63) ctot[c] = incl;
+					}
+				}
+			}
+			__syncthreads();
+			/* the chunk totals' inclusive prefix as k_pf_scan's last workgroup takes it with one total per thread (nch <= 64: wave 0) */
+			if (tid < 64) {
+				const double tv0 = tid < nch ? ctot[tid] : 0.0;
+				double run = 0.0;
+				run += tv0;
+				const double ri = wave_scan_incl(run, tid);
+				double c0 = ri - run;
+				c0 += tv0;
+				if (tid < nch) table[tid] = c0;
+			}
+			__syncthreads();
+			total = table[nch - 1];
+		}
+	} else if (resample) {
 		if (in_lds) for (int j = tid; j < nch; j += kBlock) table[j] = r.chunk_incl[j];
 		total = r.chunk_incl[nch - 1];
 		__syncthreads();
@@ -835,9 +936,17 @@ __global__ __launch_bounds__(kBlock) void k_pf_select(PfArgs a, PfSelectArgs r) 
 			/* inside the chunk: the sixteen 16-particle sub-blocks (their end sums are contiguous: two cache lines), then the sixteen
 			 * particles of the sub-block (two more) -- two rounds of independent loads, four lines; bisecting cum[] itself touched six
 			 * and took eight dependent rounds */
-			const double *cl = r.cum + (size_t)c * kPfChunk;
+			const double *cl = LOCAL ? lcum + (size_t)c * kPfChunk : r.cum + (size_t)c * kPfChunk;
 			int lo;
-			{
+			if constexpr (LOCAL) {   /* (the sub-block end sums are cum[16 q + 15]) */
+				double v[16];
+#pragma unroll
+				for (int q = 0; q < 16; ++q) v[q] = cl[16 * q + 15];
+				int cnt = 0;
+#pragma unroll
+				for (int q = 0; q < 16; ++q) cnt += (off + v[q] < tgt) ? 1 : 0;
+				lo = 16 * min(cnt, 15);
+			} else {
 				const double2 *p2 = reinterpret_cast<const double2 *>(r.sub16 + (size_t)c * 16);
 				double2 v[8];
 #pragma unroll
@@ -914,7 +1023,7 @@ __global__ __launch_bounds__(kBlock) void k_pf_select(PfArgs a, PfSelectArgs r) 
 	 * the last one of a group folds the group's rows (one row per lane, every load in flight at once -- a single workgroup
 	 * walking thousands of rows through L2-bypassing loads was 340 of the 410 us of this kernel at a million particles), the last
 	 * group to finish folds the group rows.  Sums are taken in a fixed tree, the same on every rank. ---- */
-	const int nparts = gridDim.x, ngroups = (nparts + 63) / 64, grp = blockIdx.x >> 6;
+	const int nparts = r.nsel, ngroups = (nparts + 63) / 64, grp = blockIdx.x >> 6;
 	const int gsize = min(64, nparts - grp * 64);
 	if (tid == 0) is_last = __hip_atomic_fetch_add(r.counter + 1 + grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1;
 	__syncthreads();
@@ -977,10 +1086,9 @@ __global__ __launch_bounds__(kBlock) void k_pf_select(PfArgs a, PfSelectArgs r) 
 	 * estimate, prepares and enqueues the next iteration meanwhile. */
 	if (k < n && r.lookahead) {
 		const bool use_ar = a.dynamic_model == 1;
-		PfArgs an = a;
-		an.iter = a.iter + 1;
 		double ps[8], pa[8];
-		pf_propose<SSM>(an, (unsigned)k, ns, nar, ps, pa);
+		if (have_pert) pf_dynamics<SSM>(a, pin, ns, nar, ps, pa);
+		else pf_propose<SSM>(a, a.iter + 1, (unsigned)k, ns, nar, ps, pa);
 		pf_store_row<S>(r.next, (size_t)k, ps);
 		if (use_ar) pf_store_row<S>(r.next_ar, (size_t)k, pa);
 	}
@@ -1076,6 +1184,7 @@ void launch_score_block(const BatchView &bv, const ImgView &im, const double *st
 	s.wts = wts; s.sim = sim;
 	if (peer) s.peer = *peer; else s.peer = PfPeerPush{};
 	s.hull_ok = hull ? 1 : 0;
+	{ static const bool lean_env = !(std::getenv("MTFHIP_PF_LEAN") && std::getenv("MTFHIP_PF_LEAN")[0] == '0'); s.lean_ok = lean_env ? 1 : 0; }
 	for (int q = 0; q < 8; ++q) s.hull[q] = hull ? hull[q] : 0.0;
 	launch_pf_score_args(bv, im, s, fast_math, st);
 }
@@ -1092,7 +1201,7 @@ void launch_pf_scan(const PfLaunch &p, const PfBuffers &bf, const PfPeerWait *wa
 	MTFHIP_LAUNCH(k_pf_scan, dim3((nch + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, sc);
 }
 void launch_pf_select(int ssm, const PfLaunch &p, const PfBuffers &bf, int lookahead, double *host_out, unsigned long long *host_flag,
-	unsigned long long seq, hipStream_t st) {
+	unsigned long long seq, const PfSelectPlan &plan, hipStream_t st) {
 	const PfArgs a = pf_args(p, bf);
 	PfSelectArgs r;
 	r.resample_flag = bf.resample_flag;
@@ -1102,10 +1211,20 @@ void launch_pf_select(int ssm, const PfLaunch &p, const PfBuffers &bf, int looka
 	r.forced_best = p.resampling_type == 3 ? bf.res_order : nullptr;
 	for (int k = 0; k < 12; ++k) r.init_corners_hm[k] = p.init_corners_hm[k];
 	r.parts = bf.parts; r.gparts = bf.gparts; r.counter = bf.counters + 1; r.out = bf.out; r.pub = PfPublish{host_out, host_flag, seq, publish_fenced()};
-	const dim3 g((p.n + kBlock - 1) / kBlock);
-	if (ssm == MTFHIP_SSM_HOMOGRAPHY) MTFHIP_LAUNCH(k_pf_select<MTFHIP_SSM_HOMOGRAPHY>, g, dim3(kBlock), 0, st, a, r);
-	else MTFHIP_LAUNCH(k_pf_select<MTFHIP_SSM_AFFINE>, g, dim3(kBlock), 0, st, a, r);
+	const int nsel = (p.n + kBlock - 1) / kBlock;
+	r.nsel = nsel; r.pert_in = plan.pert_in; r.pert_out = plan.pert_out; r.pert_out_iter = p.iter + 2;
+	r.wait = plan.wait ? *plan.wait : PfPeerWait{};
+	const dim3 g(plan.pert_out ? 2 * nsel : nsel);
+	const bool hom = ssm == MTFHIP_SSM_HOMOGRAPHY;
+	if (plan.local) {
+		if (hom) MTFHIP_LAUNCH((k_pf_select<MTFHIP_SSM_HOMOGRAPHY, true>), g, dim3(kBlock), 0, st, a, r);
+		else MTFHIP_LAUNCH((k_pf_select<MTFHIP_SSM_AFFINE, true>), g, dim3(kBlock), 0, st, a, r);
+	} else {
+		if (hom) MTFHIP_LAUNCH((k_pf_select<MTFHIP_SSM_HOMOGRAPHY, false>), g, dim3(kBlock), 0, st, a, r);
+		else MTFHIP_LAUNCH((k_pf_select<MTFHIP_SSM_AFFINE, false>), g, dim3(kBlock), 0, st, a, r);
+	}
 }
+int pf_local_max() { return kPfLocalMax; }
 void launch_pf_fill(int n, int S, const double *dev_state, double *states, double *ars, hipStream_t st) {
 	MTFHIP_LAUNCH(k_pf_fill, dim3((n + 255) / 256), dim3(256), 0, st, n, S, dev_state, states, ars);
 }

@@ -376,8 +376,13 @@ void launch_pf_peer_push(const PfPeerPush &peer, const double *wts, int lo, int 
 void launch_pf_peer_wait(const PfPeerWait &w, hipStream_t st);   /* the wait in a launch of its own (no scan in this iteration) */
 /* weights -> chunk-local cumulative weights + chunk table; wait != NULL: every workgroup first waits for the peers' weights */
 void launch_pf_scan(const PfLaunch &p, const PfBuffers &bf, const PfPeerWait *wait, hipStream_t st);
+/* local: no scan in front, the launch builds the cumulative weights in LDS itself (n <= pf_local_max(), multinomial resampling, no scan
+ * statistics; wait: the peers' weights, as the scan's); pert_in: the perturbations of iteration p.iter + 1 drawn ahead (NULL: the
+ * selection pass draws them itself); pert_out: where extra workgroups leave those of p.iter + 2 (NULL: none) -- [n][8] each */
+struct PfSelectPlan { int local = 0; const PfPeerWait *wait = nullptr; const double *pert_in = nullptr; double *pert_out = nullptr; };
+int pf_local_max();
 void launch_pf_select(int ssm, const PfLaunch &p, const PfBuffers &bf, int lookahead, double *host_out /* or NULL */,
-	unsigned long long *host_flag, unsigned long long seq, hipStream_t st);
+	unsigned long long *host_flag, unsigned long long seq, const PfSelectPlan &plan, hipStream_t st);
 void launch_pf_fill(int n, int S, const double *dev_state, double *states, double *ars, hipStream_t st);
 /* flag: NULL, or the scan's "this iteration resamples" (adaptive resampling): with 0 the residual kernels leave everything as it is */
 void launch_pf_residual_prep(int n, const double *total, double *wts, double *keys, int *idx, const int *flag, hipStream_t st);

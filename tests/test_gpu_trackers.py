@@ -1290,6 +1290,50 @@ def test_pf_lookahead_proposals_equal_separate_proposals(gpu_ctx, frame, cfg, mo
             assert np.array_equal(a, b), it
 
 
+@pytest.mark.parametrize("cfg", [dict(dynamic_model=0, mean_type=0), dict(dynamic_model=1, mean_type=1),
+                                 dict(dynamic_model=0, mean_type=0, update_type=0, corner_based_sampling=0),
+                                 dict(dynamic_model=0, mean_type=0, n_particles=257), dict(dynamic_model=1, mean_type=0, n_particles=16384),
+                                 dict(dynamic_model=0, mean_type=0, n_particles=16385), dict(dynamic_model=0, mean_type=0, ssm=1, pt_based_sampling=1)])
+def test_pf_selection_pass_that_scans_itself_and_perturbations_drawn_ahead(gpu_ctx, frame, cfg, monkeypatch):
+    """Up to 16 384 particles with multinomial resampling the selection pass builds the cumulative weights in its own LDS (no k_pf_scan
+    launch: MTFHIP_PF_LOCAL=0 restores it), and the perturbations of iteration t + 2 are drawn by extra workgroups of iteration t's
+    selection launch (MTFHIP_PF_PERT_AHEAD=0: inside the look-ahead proposal): the same particle sets, resample ids, weights and
+    estimates bit for bit in all four combinations -- also across set_region / set_sampler / set_particles, which invalidate what
+    was drawn ahead, and through the chained update()"""
+    corners = synth.square_corners(250.0, 240.0, 80)
+    kw = dict(n_particles=2500, ssm_sigma=(1.0, 0.6, 1, 1, 1, 1, 1, 1), corner_based_sampling=1, likelihood_alpha=5.0, seed=11)
+    kw.update(cfg)
+    ssm = L.SSM_AFFINE if kw.pop("ssm", 0) else L.SSM_HOMOGRAPHY
+    if ssm == L.SSM_AFFINE:
+        kw.pop("corner_based_sampling"); kw["ssm_sigma"] = (0.8, 0.8, 0.6, 0.6, 0.5, 0.5)
+    elif not kw["corner_based_sampling"]:
+        kw["ssm_sigma"] = (0.004, 0.004, 0.8, 0.004, 0.004, 0.8, 2e-6, 2e-6)
+    gpu_ctx.set_image(frame)
+    rec = {}
+    for local, ahead in (("1", "1"), ("0", "0"), ("1", "0"), ("0", "1")):
+        monkeypatch.setenv("MTFHIP_PF_LOCAL", local); monkeypatch.setenv("MTFHIP_PF_PERT_AHEAD", ahead)
+        pf = ParticleFilter(gpu_ctx, ssm, 20, 20, epsilon=-1.0, max_iters=3, **kw); pf.initialize(corners[None])
+        out = []
+        for it in range(8):
+            if it == 3:
+                pf.set_region(corners + 0.75)
+            if it == 4:
+                L.check(L.lib().mtfhip_pf_set_sampler(pf._h, (L.C.c_double * 8)(*([1.5 * v for v in kw["ssm_sigma"]] + [0.0] * 2)[:8]), (L.C.c_double * 8)()))
+            if it == 5:
+                st, ar, _, _ = pf.particles(); pf.set_particles(st[::-1].copy(), ar[::-1].copy())
+            if it == 6:
+                pf.update()      # three iterations enqueued back to back
+            else:
+                pf.iteration()
+            out.append([x.copy() for x in pf.particles()] + [pf.get_region().copy(), pf.batch.get_state().copy()])
+        rec[(local, ahead)] = out
+        pf.close()
+    for key in (("0", "0"), ("1", "0"), ("0", "1")):
+        for it in range(8):
+            for a, b in zip(rec[("1", "1")][it], rec[key][it]):
+                assert np.array_equal(a, b), (key, it)
+
+
 def test_pf_update_chained_iterations_equal_single_steps(gpu_ctx, frame):
     """mtfhip_pf_update with a negative epsilon enqueues its iterations back to back and reads only the last estimate back:
     same particle set and estimate as the same number of mtfhip_pf_iteration calls"""
