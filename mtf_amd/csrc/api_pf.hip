@@ -93,6 +93,7 @@ struct mtfhip_pf {
 	 * only); valid while nothing they depend on has changed -- the particle set, the sampler's distributions, the template
 	 * corners.  MTFHIP_PF_LOOKAHEAD=0: every iteration proposes in a launch of its own. */
 	bool lookahead_enabled = true, prop_valid = false;
+	bool skip_unread_estimates = true;   /* MTFHIP_PF_SKIP_ESTIMATE=0 at creation: every iteration of a chained update() computes its estimate */
 	bool local_enabled = true, pert_ahead_enabled = true;   /* MTFHIP_PF_LOCAL=0 / MTFHIP_PF_PERT_AHEAD=0 at creation: the scan launch / the draws inside the selection pass */
 	unsigned prop_iter = 0;
 	long prop_corners_epoch = -1;
@@ -301,6 +302,7 @@ int mtfhip_pf_create(mtfhip_batch *b, const mtfhip_pf_desc *d, mtfhip_pf **out) 
 	pf->b = b; pf->d = *d; pf->n = d->n_particles; pf->S = b->S; pf->sampler = sampler; pf->nz = nz;
 	{ const char *e = std::getenv("MTFHIP_PF_LOOKAHEAD"); pf->lookahead_enabled = !(e && e[0] == '0'); }
 	{ const char *e = std::getenv("MTFHIP_PF_LOCAL"); pf->local_enabled = !(e && e[0] == '0'); }
+	{ const char *e = std::getenv("MTFHIP_PF_SKIP_ESTIMATE"); pf->skip_unread_estimates = !(e && e[0] == '0'); }
 	{ const char *e = std::getenv("MTFHIP_PF_PERT_AHEAD"); pf->pert_ahead_enabled = !(e && e[0] == '0'); }
 	const size_t nS = (size_t)pf->n * pf->S, n = (size_t)pf->n, npad = pf_round_chunk(n), nch = npad / (size_t)pf_chunk();
 	bool okm = true;
@@ -772,6 +774,7 @@ static int pf_enqueue_iteration(mtfhip_pf *pf, const double *normals, const doub
 		 * scan launch in front, as for every other case */
 		const bool local_env = pf->local_enabled, pert_env = pf->pert_ahead_enabled;   /* (read when the filter was created) */
 		PfSelectPlan plan;
+		plan.estimate = (publish || !pf->skip_unread_estimates) ? 1 : 0;   /* (publish == false: a chained iteration whose estimate nobody reads) */
 		plan.local = local_env && (p.resampling_type == 1 || p.resampling_type == 2) && !mixture && !bf.scan_stats && n <= pf_local_max();
 		if (plan.local) { if (peer) plan.wait = &pwait; }
 		else if (p.resampling_type != 0 || mixture) launch_pf_scan(p, bf, peer ? &pwait : nullptr, st);   /* (the distribution weights follow the particle weights whatever the resampling) */

@@ -782,6 +782,10 @@ struct PfSelectArgs {
 	 * a.iter + 2 into pert_out [n][8]: they need nothing of this iteration, run beside the selection on otherwise idle CUs, and the
 	 * selection pass after next finds them done (pert_in: those of a.iter + 1, drawn two launches ago) -- Philox + Box-Muller + the
 	 * corner-based homography were 5 of this launch's 16 us at 10 000 particles, behind the estimate but in front of the next scorer */
+	/* 0: no estimate from this launch (PF.cc:421-437 computes it every iteration; with a negative epsilon and MeanType other than
+	 * Corners only the LAST iteration's is ever read -- mtfhip_pf_update's chained form): no best-particle search, no per-workgroup
+	 * rows, no last-arriver fold, ~3 us of the launch's dependent chain at 10 000 particles */
+	int estimate;
 	int nsel;
 	const double *pert_in;
 	double *pert_out;
@@ -979,9 +983,10 @@ __global__ __launch_bounds__(kBlock) void k_pf_select(PfArgs a, PfSelectArgs r) 
 		if (use_ar) pf_load_row<S>(r.prop_ar, (size_t)id, nar);
 		pf_store_row<S>(r.st_out, (size_t)k, ns);
 		if (use_ar) pf_store_row<S>(r.ar_out, (size_t)k, nar);
-		bv = r.wts[id]; bi = k;
+		if (r.estimate) { bv = r.wts[id]; bi = k; }
 		if (go && r.forced_best && k != *r.forced_best) bv = -1.7976931348623157e308;   /* max_wt_id is handed down, not searched for */
-		if (r.mean_type == 1) {
+		if (!r.estimate) {
+		} else if (r.mean_type == 1) {
 #pragma unroll
 			for (int s = 0; s < 8; ++s) acc[s] = ns[s];
 		} else if (r.mean_type == 2) {   /* updateMeanCorners :607-614 */
@@ -996,6 +1001,8 @@ __global__ __launch_bounds__(kBlock) void k_pf_select(PfArgs a, PfSelectArgs r) 
 			}
 		}
 	}
+	/* (estimate == 0: an iteration in the middle of a chained update() -- nobody reads its estimate, PfSelectArgs::estimate) */
+	if (r.estimate) {
 	/* the best of the (resampled) set, last index on ties (`>=` in index order, PF.cc:378-381, 487-490) */
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1) {
@@ -1080,6 +1087,7 @@ __global__ __launch_bounds__(kBlock) void k_pf_select(PfArgs a, PfSelectArgs r) 
 	}
 	};
 	if (is_last && tid < 64) estimate_tail();
+	}
 	/* The next iteration's proposal of this thread's particle (PF.cc:207-245 one iteration ahead: a pure function of the resampled
 	 * state and the particle's counter-based draws) -- AFTER the estimate has gone out: it is 5 of the 16 us of this launch at
 	 * 10 000 particles (Philox + Box-Muller + the corner-based homography per particle), and the host, which only waits for the
@@ -1212,7 +1220,7 @@ void launch_pf_select(int ssm, const PfLaunch &p, const PfBuffers &bf, int looka
 	for (int k = 0; k < 12; ++k) r.init_corners_hm[k] = p.init_corners_hm[k];
 	r.parts = bf.parts; r.gparts = bf.gparts; r.counter = bf.counters + 1; r.out = bf.out; r.pub = PfPublish{host_out, host_flag, seq, publish_fenced()};
 	const int nsel = (p.n + kBlock - 1) / kBlock;
-	r.nsel = nsel; r.pert_in = plan.pert_in; r.pert_out = plan.pert_out; r.pert_out_iter = p.iter + 2;
+	r.estimate = plan.estimate; r.nsel = nsel; r.pert_in = plan.pert_in; r.pert_out = plan.pert_out; r.pert_out_iter = p.iter + 2;
 	r.wait = plan.wait ? *plan.wait : PfPeerWait{};
 	const dim3 g(plan.pert_out ? 2 * nsel : nsel);
 	const bool hom = ssm == MTFHIP_SSM_HOMOGRAPHY;

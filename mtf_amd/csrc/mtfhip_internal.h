@@ -379,7 +379,7 @@ void launch_pf_scan(const PfLaunch &p, const PfBuffers &bf, const PfPeerWait *wa
 /* local: no scan in front, the launch builds the cumulative weights in LDS itself (n <= pf_local_max(), multinomial resampling, no scan
  * statistics; wait: the peers' weights, as the scan's); pert_in: the perturbations of iteration p.iter + 1 drawn ahead (NULL: the
  * selection pass draws them itself); pert_out: where extra workgroups leave those of p.iter + 2 (NULL: none) -- [n][8] each */
-struct PfSelectPlan { int local = 0; const PfPeerWait *wait = nullptr; const double *pert_in = nullptr; double *pert_out = nullptr; };
+struct PfSelectPlan { int local = 0; const PfPeerWait *wait = nullptr; const double *pert_in = nullptr; double *pert_out = nullptr; int estimate = 1; };
 int pf_local_max();
 void launch_pf_select(int ssm, const PfLaunch &p, const PfBuffers &bf, int lookahead, double *host_out /* or NULL */,
 	unsigned long long *host_flag, unsigned long long seq, const PfSelectPlan &plan, hipStream_t st);
