@@ -324,7 +324,7 @@ int mtfhip_grid_layout(const mtfhip_grid_desc *g, const double *region_corners /
  * with region_corners the patches are first laid over that region (mtfhip_grid_layout) and reset -- setRegion, in the same launch
  * as the update where the search method allows it -- then every patch tracker runs its update(); centroids are utils::getCentroid
  * into cv::Point2f (miscUtils.h:472-480: rounded to float), the points GridTracker::update hands to ssm.estimateWarpFromPts
- * (GridTracker.cc:254-267).  region_corners NULL: update only. */
+ * (GridTracker.cc:256-270).  region_corners NULL: update only. */
 int mtfhip_grid_frame(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_grid_desc *g, const double *region_corners /* 8 or NULL */,
 	int *n_iters /* B or NULL */, double *corners /* B x 8 or NULL */, float *centroids /* B x 2 or NULL */);
 /* resetTrackers(reinit) (GridTracker.cc:345-392) for the same batch: the patches laid over region_corners, then every patch tracker
