@@ -355,11 +355,12 @@ def stub_mode():
 
 
 # the expected 1 -> 8 curve of the sharded filter, from single-GPU terms (us per iteration)
-PF_STRONG_MODEL = {   # (chained update() form; one-GPU terms of profiles/r04_pf_strong_one_rank.json, `score` = one rank's block launched alone, the all-gather estimated)
-    10000: {"T1_us": 59, "T8_terms_us": {"score": 12.5, "allgather": 25, "scan_select": 23}, "T8_us": 60, "speedup": 1.0,
-            "T8_us_peer_stores": 40, "speedup_peer_stores": 1.5},
-    100000: {"T1_us": 352, "T8_terms_us": {"score": 48, "allgather": 35, "scan_select": 37}, "T8_us": 120, "speedup": 2.9},
-    1000000: {"T1_us": 3322, "T8_terms_us": {"score": 412, "allgather": 75, "scan_select": 194}, "T8_us": 681, "speedup": 4.9},
+PF_STRONG_MODEL = {   # (chained update() form; one-GPU terms of profiles/r05_pf_strong_one_rank.json by HIP events, `score` = one rank's block launched alone (r04 measurement), the all-gather estimated)
+    10000: {"T1_us": 49, "T8_terms_us": {"score": 12.5, "allgather": 25, "scan_select": 13.6}, "T8_us": 51, "speedup": 0.96,
+            "T8_us_peer_stores": 30, "speedup_peer_stores": 1.6,
+            "north_star_6x": "not reachable: T1 / 6 = 8.2 us is less than one rank's scoring launch (12.5 us) and less than the replicated selection pass (13.6 us)"},
+    100000: {"T1_us": 333, "T8_terms_us": {"score": 48, "allgather": 35, "scan_select": 27.6}, "T8_us": 111, "speedup": 3.0},
+    1000000: {"T1_us": 3231, "T8_terms_us": {"score": 412, "allgather": 75, "scan_select": 197}, "T8_us": 684, "speedup": 4.7},
 }
 
 
