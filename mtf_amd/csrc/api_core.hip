@@ -493,10 +493,23 @@ int mtfhip_ssm_set_corners(mtfhip_batch *b, const double *corners) { return set_
 /* the host half of a deferred affine reset (set_corners_core): mirrors and the staged slab entries the launch did not need.  Called once
  * the loop kernel is enqueued; a no-op when nothing is pending. */
 void set_corners_finish_deferred(mtfhip_batch *b) {
+	const size_t Bt = (size_t)b->B;
+	if (b->deferred_layout) {
+		/* the patches the kernel laid out for itself, once more on the host (the same expressions: grid_pt_hd) -- under the kernel */
+		b->deferred_layout = false;
+		b->deferred_patches.resize(8 * Bt);
+		if (mtfhip_grid_layout(&b->deferred_gdesc, b->deferred_region, nullptr, b->deferred_patches.data()) == MTFHIP_OK) {
+			b->deferred_corners = b->deferred_patches.data();
+			std::memcpy(reinterpret_cast<double *>(b->h_stage_a) + 17 * Bt, b->deferred_patches.data(), sizeof(double) * 8 * Bt);   /* the slab's corners */
+			if (b->deferred_template_check && b->j0_is_template && b->template_corners.size() == 8 * Bt &&
+				std::memcmp(b->template_corners.data(), b->deferred_patches.data(), sizeof(double) * 8 * Bt) == 0)
+				b->j0_template_corners_epoch = b->corners_epoch;   /* (set_region_core's test, with the corners it did not have yet) */
+		}
+		b->deferred_template_check = false;
+	}
 	const double *corners = b->deferred_corners;
 	if (!corners) return;
 	b->deferred_corners = nullptr;
-	const size_t Bt = (size_t)b->B;
 	double *sp = reinterpret_cast<double *>(b->h_stage_a);
 	double *s_w = sp, *s_s = sp + 9 * Bt, *s_ic = sp + 25 * Bt, *s_w0 = sp + 45 * Bt;
 	int *s_act = reinterpret_cast<int *>(b->h_stage_a + b->slab_dbl_bytes), *s_it = s_act + Bt;
@@ -520,12 +533,13 @@ void set_corners_finish_deferred(mtfhip_batch *b) {
 		if (b->deferred_for_track) s_it[t] = 0;
 	}
 }
-int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track, bool defer_grid) {
+int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track, bool defer_grid, bool layout_later) {
 	FLUSH_AM(b);   /* pending calls are replayed (with the points they need); the points themselves are about to change */
 	if (b) ++b->lz.epoch;
 	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
-	if (!b || !corners) return fail(MTFHIP_ERR_INVALID_ARG, "set_corners: NULL argument");
+	if (!b || (!corners && !layout_later)) return fail(MTFHIP_ERR_INVALID_ARG, "set_corners: NULL argument");
 	const bool hom = b->desc.ssm == MTFHIP_SSM_HOMOGRAPHY;
+	if (layout_later && !(defer_grid && !hom)) return fail(MTFHIP_ERR_LOGIC, "set_corners: a layout behind the launch needs the deferred affine reset");
 	/* normalised grid extents: ProjectiveBase.cc:14 (unit square) ; Affine.cc:56-57 */
 	double lo_x = -0.5, lo_y = -0.5, hi_x = 0.5, hi_y = 0.5;
 	if (!hom) { lo_x = 1 - b->desc.resx / 2.0; lo_y = 1 - b->desc.resy / 2.0; hi_x = b->desc.resx / 2.0; hi_y = b->desc.resy / 2.0; }
@@ -544,15 +558,19 @@ int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track, boo
 	 * (2-2.5 us of a 45 us frame at 256 patches). */
 	if (defer_grid && !hom) {
 		/* (r04 advisor: nothing is committed before the corners have been looked at -- the cheap part of the map's degeneracy test) */
-		for (int t = 0; t < b->B; ++t)
-			if (quad_degenerate_hd(corners + 8 * t)) return fail(MTFHIP_ERR_INVALID_ARG, "set_corners: degenerate corners for target %d", t);
-		std::memcpy(s_cr, corners, sizeof(double) * 8 * Bt);
+		/* (layout_later: fixed-size rectangles the kernel lays out itself -- never degenerate -- reach the slab in set_corners_finish_deferred) */
+		if (!layout_later) {
+			for (int t = 0; t < b->B; ++t)
+				if (quad_degenerate_hd(corners + 8 * t)) return fail(MTFHIP_ERR_INVALID_ARG, "set_corners: degenerate corners for target %d", t);
+			std::memcpy(s_cr, corners, sizeof(double) * 8 * Bt);
+		}
 		for (int t = 0; t < b->B; ++t) {
 			const TargetHost &h = b->th[t];
 			double *q8 = s_nc + 8 * t;
 			q8[0] = h.I0_mean; q8[1] = h.c; q8[2] = h.It_mean; q8[3] = h.b; q8[4] = h.f; q8[5] = h.gmean; q8[6] = q8[7] = 0;
 		}
-		b->deferred_corners = corners; b->deferred_for_track = for_track;
+		b->deferred_corners = layout_later ? nullptr : corners; b->deferred_for_track = for_track;
+		b->deferred_layout = layout_later;
 		b->unit_z = 1;
 		b->grid_from_corners = true;
 		b->warps_dirty = false;
@@ -887,8 +905,7 @@ static int grid_desc_ok(const mtfhip_grid_desc *g, const char *fn) {
 	if (g->patch_size_x <= 0 || g->patch_size_y <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "%s: patch_size must be positive", fn);
 	return MTFHIP_OK;
 }
-/* Eigen's LinSpaced as utils::getNormUnitSquarePts uses it (warpUtils.cc:15-34): lo + i * step, the last element pinned to hi */
-static inline double lin_spaced_h(int i, int n, double lo, double hi) { return (n == 1 || i == n - 1) ? hi : lo + i * ((hi - lo) / (n - 1)); }
+/* (Eigen's LinSpaced as utils::getNormUnitSquarePts uses it, warpUtils.cc:15-34, is lin_spaced_hd in mtfhip_internal.h) */
 /* GridTrackerParams::updateRes SM/src/GridTracker.cc:86-94 */
 int mtfhip_grid_res(const mtfhip_grid_desc *g, int *resx, int *resy) {
 	TRY(grid_desc_ok(g, "grid_res"));
@@ -908,17 +925,11 @@ int mtfhip_grid_layout(const mtfhip_grid_desc *g, const double *region, double *
 	if (!region || !patch_corners) return fail(MTFHIP_ERR_INVALID_ARG, "grid_layout: NULL argument");
 	M3 W;
 	if (!rect_to_quad(-0.5, -0.5, 0.5, 0.5, region, W)) return fail(MTFHIP_ERR_INVALID_ARG, "grid_layout: degenerate region corners");
+	/* every grid point once (grid_pt_hd: the expression k_iclk_track's own layout evaluates per patch, mtfhip_internal.h), then the patches
+	 * from them as grid_patch_corners_hd assembles them */
 	static thread_local std::vector<double> pts;
 	pts.resize(2 * (size_t)resx * resy);
-	for (int r = 0; r < resy; ++r) {
-		const double ny = lin_spaced_h(r, resy, -0.5, 0.5);
-		for (int c = 0; c < resx; ++c) {
-			const double nx = lin_spaced_h(c, resx, -0.5, 0.5);
-			const double X = W.m[0] * nx + W.m[1] * ny + W.m[2], Y = W.m[3] * nx + W.m[4] * ny + W.m[5], Z = W.m[6] * nx + W.m[7] * ny + W.m[8];
-			const size_t i = (size_t)r * resx + c;
-			pts[2 * i] = X / Z; pts[2 * i + 1] = Y / Z;
-		}
-	}
+	for (int i = 0; i < resx * resy; ++i) grid_pt_hd(W.m, resx, resy, i, &pts[2 * (size_t)i], &pts[2 * (size_t)i + 1]);
 	if (grid_pts) std::memcpy(grid_pts, pts.data(), sizeof(double) * pts.size());
 	const bool surround = g->dyn_patch_size || g->patch_centroid_inside;
 	const int sub_x = g->grid_size_x + 1;   /* _linear_idx(idy, idx) = idy * (grid_size_x + 1) + idx, :139-146 */

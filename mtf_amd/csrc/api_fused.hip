@@ -452,7 +452,7 @@ int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
  * off): the SSM is reset to the new corners; ESM (and FCLK with the InitialSelf Hessian) recompute init_pix_jacobian with
  * cmptInitPixJacobian on the new grid and, for the Hessian types that use it, the constant self Hessian; ICLK keeps its
  * template Jacobian.  The template (I0, dI0_dx) is kept in every case. */
-static int set_region_core(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm, bool for_track, bool defer_grid = false);
+static int set_region_core(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm, bool for_track, bool defer_grid = false, bool layout_later = false);
 int mtfhip_batch_set_region(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm) { return set_region_core(b, corners, sm, false); }
 
 /* the one-launch grid kernel (k_iclk_track: a patch's whole ICLK update() in one workgroup) takes ICLK with a constant Hessian -- up to
@@ -470,14 +470,19 @@ static bool iclk_one_launch(const mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 }
 static bool region_refreshes(const mtfhip_sm_desc *sm) { return sm->sm == MTFHIP_SM_ESM || (sm->sm == MTFHIP_SM_FCLK && sm->hess_type == 0); }
 
-static int set_region_core(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm, bool for_track, bool defer_grid) {
+static int set_region_core(mtfhip_batch *b, const double *corners, const mtfhip_sm_desc *sm, bool for_track, bool defer_grid, bool layout_later) {
 	FLUSH_AM(b);   /* (the current points are about to be replaced: only pending calls need them brought up to date) */
 	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
 	TRY(check_sm(b, sm, "set_region"));
 	TRY(fused_channels_ok(b, "set_region"));
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "set_region before init_template");
-	TRY(set_corners_core(b, corners, for_track, defer_grid));
+	TRY(set_corners_core(b, corners, for_track, defer_grid, layout_later));
 	const bool refresh = region_refreshes(sm);
+	if (layout_later) {
+		if (refresh) return fail(MTFHIP_ERR_LOGIC, "set_region: a layout behind the launch with a search method that refreshes its template Jacobian");
+		b->deferred_template_check = true;   /* (the comparison below, once the host has the corners: set_corners_finish_deferred) */
+		return MTFHIP_OK;
+	}
 	if (!refresh) {
 		/* back on exactly the grid the kept template Jacobian was computed on: its rows can still be rebuilt from dI0_dx */
 		if (b->j0_is_template && b->template_corners.size() == 8 * (size_t)b->B &&
@@ -956,7 +961,10 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
  * tracker->setRegion(patch corners); tracker->update()) and a pyramid level with the level above's result.  For the search
  * methods that keep their template Jacobian (ICLK; FCLK without the InitialSelf Hessian) the reset state and the loop's
  * active flags / iteration counts travel in ONE staged copy; the others take the two steps one after the other. */
-int mtfhip_batch_track_region(mtfhip_batch *b, const mtfhip_sm_desc *sm, const double *region_corners, int *n_iters, double *corners) {
+/* grid != NULL (mtfhip_grid_frame): region_corners is the GRID's region (8 doubles) and the patches are laid over it -- by the kernel
+ * itself where the one-launch region mode applies and the patches are fixed-size rectangles (the host layout then runs behind the launch),
+ * by mtfhip_grid_layout in front of the call otherwise */
+static int track_region_impl(mtfhip_batch *b, const mtfhip_sm_desc *sm, const double *region_corners, int *n_iters, double *corners, const mtfhip_grid_desc *grid) {
 	if (!b || !sm || !region_corners) return fail(MTFHIP_ERR_INVALID_ARG, "track_region: NULL argument");
 	/* everything track_core would refuse is refused before the SSM is reset (the folded upload reads the pinned staging buffer
 	 * without an event guard: the loop that follows is what the host waits for) */
@@ -971,9 +979,26 @@ int mtfhip_batch_track_region(mtfhip_batch *b, const mtfhip_sm_desc *sm, const d
 	const bool region_mode = fused_ok && folded && b->desc.am != MTFHIP_AM_MI && !sm->leven_marq && iclk_one_launch(b, sm) && second_order_term(sm, b->desc.am) < 0 &&
 		b->h_stage_a_dev && b->h_pub_dev;
 	const auto t0 = std::chrono::steady_clock::now();
+	static thread_local std::vector<double> patches;
+	bool layout_later = false;
+	if (grid) {
+		const char *e_ld = std::getenv("MTFHIP_GRID_LAYOUT_DEV");   /* (=0: the host lays the patches out in front of the launch, the r05 first form) */
+		layout_later = region_mode && b->desc.ssm != MTFHIP_SSM_HOMOGRAPHY && !grid->dyn_patch_size && !(e_ld && e_ld[0] == '0');
+		if (layout_later) {
+			M3 Wr;
+			if (!rect_to_quad(-0.5, -0.5, 0.5, 0.5, region_corners, Wr)) return fail(MTFHIP_ERR_INVALID_ARG, "grid_layout: degenerate region corners");
+			b->deferred_gdesc = *grid;
+			std::memcpy(b->deferred_region, region_corners, sizeof(b->deferred_region));
+			std::memcpy(b->deferred_region_map, Wr.m, sizeof(b->deferred_region_map));
+		} else {
+			patches.resize(8 * (size_t)b->B);
+			TRY(mtfhip_grid_layout(grid, region_corners, nullptr, patches.data()));
+			region_corners = patches.data();
+		}
+	}
 	{
-		const int rs = set_region_core(b, region_corners, sm, folded, region_mode);
-		if (rs != MTFHIP_OK) { set_corners_finish_deferred(b); return rs; }
+		const int rs = set_region_core(b, layout_later ? nullptr : region_corners, sm, folded, region_mode, layout_later);
+		if (rs != MTFHIP_OK) { b->deferred_layout = false; b->deferred_template_check = false; set_corners_finish_deferred(b); return rs; }
 	}
 	const auto t1 = std::chrono::steady_clock::now();
 	const int r = track_core(b, sm, n_iters, corners, folded, false, region_mode);
@@ -985,6 +1010,9 @@ int mtfhip_batch_track_region(mtfhip_batch *b, const mtfhip_sm_desc *sm, const d
 		if (++n % 100 == 0) { std::fprintf(stderr, "[track_region] set_region %.1f us, track %.1f us (mean of 100)\n", acc1 / 100, acc2 / 100); acc1 = acc2 = 0; }
 	}
 	return r;
+}
+int mtfhip_batch_track_region(mtfhip_batch *b, const mtfhip_sm_desc *sm, const double *region_corners, int *n_iters, double *corners) {
+	return track_region_impl(b, sm, region_corners, n_iters, corners, nullptr);
 }
 
 /* GridTracker::update's patch half as ONE call (SM/src/GridTracker.cc:345-363): every patch tracker is reset to its region and
@@ -1024,14 +1052,11 @@ int mtfhip_grid_frame(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_gr
 	if (!sm) return fail(MTFHIP_ERR_INVALID_ARG, "grid_frame: NULL argument");
 	TRY(grid_batch_ok(b, g, "grid_frame"));
 	const size_t B = (size_t)b->B;
-	static thread_local std::vector<double> patches, out;
+	static thread_local std::vector<double> out;
 	static thread_local std::vector<int> iters;
 	out.resize(8 * B); iters.resize(B);
-	if (region) {
-		patches.resize(8 * B);
-		TRY(mtfhip_grid_layout(g, region, nullptr, patches.data()));
-		TRY(mtfhip_batch_track_region(b, sm, patches.data(), n_iters ? n_iters : iters.data(), out.data()));
-	} else TRY(mtfhip_batch_track(b, sm, n_iters ? n_iters : iters.data(), out.data()));
+	if (region) TRY(track_region_impl(b, sm, region, n_iters ? n_iters : iters.data(), out.data(), g));
+	else TRY(mtfhip_batch_track(b, sm, n_iters ? n_iters : iters.data(), out.data()));
 	if (corners) std::memcpy(corners, out.data(), sizeof(double) * 8 * B);
 	if (centroids) for (size_t t = 0; t < B; ++t) centroid_f(centroids + 2 * t, &out[8 * t]);
 	return MTFHIP_OK;
@@ -1185,6 +1210,12 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 			rg.lo_x = homg ? -0.5 : 1 - b->desc.resx / 2.0; rg.lo_y = homg ? -0.5 : 1 - b->desc.resy / 2.0;
 			rg.hi_x = homg ? 0.5 : b->desc.resx / 2.0; rg.hi_y = homg ? 0.5 : b->desc.resy / 2.0;
 			rg.resx = b->desc.resx; rg.resy = b->desc.resy; rg.force_unit_z = homg ? 0 : 1;
+			if (b->deferred_layout) {   /* the kernel lays its patches out itself (track_region_impl) */
+				const mtfhip_grid_desc &gd = b->deferred_gdesc;
+				rg.layout = 1;
+				rg.grid = GridLayoutHD{gd.grid_size_x, gd.grid_size_y, gd.patch_size_x, gd.patch_size_y, gd.dyn_patch_size ? 1 : 0, gd.patch_centroid_inside ? 1 : 0};
+				std::memcpy(rg.region_map, b->deferred_region_map, sizeof(rg.region_map));
+			}
 		}
 		launch_iclk_track(bv, b->ctx->img, *sm, ts, b->d_h0inv, b->d_ncc, b->norm_mult, b->norm_add, b->math_mode == MTFHIP_MATH_FAST, pub, rg, st);
 		set_corners_finish_deferred(b);   /* the host half of a deferred reset, under the kernel */

@@ -229,8 +229,43 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 	/* region mode: the patch's region and its template's NCC scalars from the pinned staging buffer -- one PCIe round trip per workgroup.
 	 * The load is issued here, its LDS store (which waits for it) only behind the template operands' loads below, so that the two
 	 * latencies overlap (program order is wait order: stored right away, the PCIe read was 1.1 us in front of everything else) */
+	/* layout mode (RegionIngest::layout, r05): the patch's corners are computed HERE from the grid's region (kernel arguments: no memory
+	 * round trip at all), and in tolerance mode the NCC scalars' PCIe read is not waited for before the first reduction of the loop */
+	const bool lay = region && rg.layout != 0;
+	const bool late_ncc = FAST && lay && AM == MTFHIP_AM_NCC;
+	double q8lay[8];
+#pragma unroll
+	for (int q = 0; q < 8; ++q) q8lay[q] = 0.0;
+	if (lay) {
+		/* grid_patch_corners_hd (mtfhip_internal.h) with the cell's four grid points on four lanes: a point is four IEEE divisions (two in
+		 * lin_spaced_hd, two projective), ~1 us as a dependent chain of sixteen on a wave that has its SIMD to itself; lane q & 3 evaluates
+		 * point q -- the same expressions, so the same bits -- and v_readlane hands the eight coordinates to everybody */
+		const GridLayoutHD &gl = rg.grid;
+		const int extra = (gl.dyn_patch_size || gl.patch_centroid_inside) ? 1 : 0;
+		const int gresx = gl.grid_size_x + extra, gresy = gl.grid_size_y + extra, sub_x = gl.grid_size_x + 1;
+		const int prow = t / gl.grid_size_x, pcol = t % gl.grid_size_x, lq = tid & 3;
+		const int pid = extra ? (prow + (lq >> 1)) * sub_x + pcol + ((lq == 1 || lq == 2) ? 1 : 0) : t;   /* TL, TR, BR, BL of the cell | the patch's own point */
+		double gx, gy;
+		grid_pt_hd(rg.region_map, gresx, gresy, pid, &gx, &gy);
+		if (extra) {
+#pragma unroll
+			for (int q = 0; q < 4; ++q) { q8lay[2 * q] = readlane_f64(gx, q); q8lay[2 * q + 1] = readlane_f64(gy, q); }
+		}
+		if (!gl.dyn_patch_size) {
+			double cx = readlane_f64(gx, 0), cy = readlane_f64(gy, 0);
+			if (gl.patch_centroid_inside) {
+				cx = (q8lay[0] + q8lay[2] + q8lay[4] + q8lay[6]) / 4.0;
+				cy = (q8lay[1] + q8lay[3] + q8lay[5] + q8lay[7]) / 4.0;
+			}
+			const double half_x = gl.patch_size_x / 2.0, half_y = gl.patch_size_y / 2.0;
+			const double min_x = cx - half_x, min_y = cy - half_y;
+			const double max_x = min_x + gl.patch_size_x, max_y = min_y + gl.patch_size_y;
+			q8lay[0] = q8lay[6] = min_x; q8lay[2] = q8lay[4] = max_x;
+			q8lay[1] = q8lay[3] = min_y; q8lay[5] = q8lay[7] = max_y;
+		}
+	}
 	double ingest = 0.0;
-	if (region && tid < 16) ingest = tid < 8 ? rg.corners[8 * (size_t)t + tid] : (AM == MTFHIP_AM_NCC ? rg.ncc[8 * (size_t)t + tid - 8] : 0.0);
+	if (region && tid < 16 && !(lay && tid < 8)) ingest = tid < 8 ? rg.corners[8 * (size_t)t + tid] : (AM == MTFHIP_AM_NCC ? rg.ncc[8 * (size_t)t + tid - 8] : 0.0);
 	double m0 = (AM == MTFHIP_AM_NCC && !region) ? ncc_sc_all[t * 8 + 0] : 0.0;
 	double cn = (AM == MTFHIP_AM_NCC && !region) ? ncc_sc_all[t * 8 + 1] : 1.0;
 	/* Everything that does not change over the iterations is fetched ONCE: the thread's grid points, template values
@@ -257,10 +292,26 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 			for (int s = 0; s < 8; ++s) j0v[k][s] = (s < S && i < N) ? J0[(size_t)s * N + ic] : 0.0;
 		}
 	}
+	/* NCC, tolerance mode: sum J0 | sum I0 J0 of this patch's template, reduced when the template was (ncc_template_moments: sum J0 | sum
+	 * I0 J0 | Gram).  Requested HERE with the other operands (r05): they are uniform (scalar) loads, and behind the grid layout their
+	 * round trip sat in front of the loop -- the first LDS read after them waits on the same counter */
+	double tc[16];
+#pragma unroll
+	for (int q = 0; q < 16; ++q) tc[q] = 0.0;
+	if constexpr (FAST && AM == MTFHIP_AM_NCC) {
+		if (ts.ncc_tm) {
+#pragma unroll
+			for (int q = 0; q < 16; ++q) tc[q] = ts.ncc_tm[(size_t)t * 52 + q];
+		}
+	}
 	if (tid < 64) sHinv[tid] = h0inv_all[(size_t)t * 64 + tid];
 	if (tid < 64) { const int r = tid >> 3, c = tid & 7; sH8[tid] = (r < S && c < S) ? h0inv_all[(size_t)t * 64 + c * S + r] : 0.0; }   /* [r][c], zero padded */
 	asm volatile("" ::: "memory");   /* (the loads above are issued before the ingest is waited for) */
-	if (region && tid < 16) { if (tid < 8) sCr[tid] = ingest; else sNc[tid - 8] = ingest; }
+	if (region && tid < 16) { if (tid < 8) { if (!lay) sCr[tid] = ingest; } else if (!late_ncc) sNc[tid - 8] = ingest; }
+	if (lay && tid == 0) {
+#pragma unroll
+		for (int q = 0; q < 8; ++q) sCr[q] = q8lay[q];
+	}
 	if (!region) {
 		if (tid < 12) sIc[tid] = ts.init_corners_hm[12 * t + tid];
 		if (tid < 8) sCr[tid] = ts.corners[8 * t + tid];
@@ -278,6 +329,33 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 	int n_it = 0;
 	double f_last = 0;
 	bool region_bad = false;
+	/* Tolerance mode reads the texels of the whole loop from an LDS window around the corners (below).  Where the window sits depends on
+	 * the corners only, so its fetch is REQUESTED here, in front of the map's divisions and the grid layout (~1.2 us of dependent FP64 in
+	 * region mode), and stored behind them: the round trip runs under that arithmetic instead of after it (r05). */
+	constexpr int kWinW = 64, kWinH = 64;
+	int wx0 = 0, wy0 = 0;
+	bool win_ok = false;
+	float win_tv[FAST ? kWinW * kWinH / kBlock : 1];
+#ifndef MTFHIP_GRID_NO_WINDOW
+	if constexpr (FAST) {
+		const double c0 = sCr[0], c1 = sCr[1], c2 = sCr[2], c3 = sCr[3], c4 = sCr[4], c5 = sCr[5], c6 = sCr[6], c7 = sCr[7];
+		const double mnx = fmin(fmin(c0, c2), fmin(c4, c6)), mxx = fmax(fmax(c0, c2), fmax(c4, c6));
+		const double mny = fmin(fmin(c1, c3), fmin(c5, c7)), mxy = fmax(fmax(c1, c3), fmax(c5, c7));
+		const double cxm = 0.5 * (mnx + mxx), cym = 0.5 * (mny + mxy);
+		/* (NaN corners fail every comparison) */
+		win_ok = (mxx - mnx < kWinW - 6) & (mxy - mny < kWinH - 6) & (cxm > -1e6) & (cxm < 1e6) & (cym > -1e6) & (cym < 1e6) &
+			(im.w >= kWinW) & (im.h >= kWinH);
+		if (win_ok) {
+			wx0 = min(max((int)floor(cxm) - kWinW / 2, 0), im.w - kWinW);
+			wy0 = min(max((int)floor(cym) - kWinH / 2, 0), im.h - kWinH);
+#pragma unroll
+			for (int j = 0; j < kWinW * kWinH / kBlock; ++j) {
+				const int idx = tid + j * kBlock;
+				win_tv[j] = im.data[(unsigned)((wy0 + idx / kWinW) * im.stride + wx0 + idx % kWinW)];
+			}
+		}
+	}
+#endif
 	if (region) {
 		static_assert(PPT <= 8, "region mode keeps the grid in registers");
 		/* every thread derives the same map from the same eight numbers (~40 flops and a dozen divisions: cheaper than a broadcast
@@ -293,7 +371,7 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 		}
 		/* (set_corners_core: a homography grid whose projective entries vanish is laid out with exact zeros) */
 		if (hom && fabs(W0[6]) < 1e-15 && fabs(W0[7]) < 1e-15) { W0[6] = 0; W0[7] = 0; }
-		if constexpr (AM == MTFHIP_AM_NCC) { m0 = sNc[0]; cn = sNc[1]; }
+		if constexpr (AM == MTFHIP_AM_NCC) { if (!late_ncc) { m0 = sNc[0]; cn = sNc[1]; } }
 		double2 *ipw = const_cast<double2 *>(ip), *ihw = const_cast<double2 *>(ih);
 		double *izw = const_cast<double *>(iz);
 #pragma unroll
@@ -316,7 +394,7 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 		/* the slab entries the ingest used to bring: this workgroup's piece, for the calls that come after the frame */
 		if (tid < 9) rg.d_w0[9 * (size_t)t + tid] = W0[tid];
 		if (tid < 12) { const double v = (tid % 3 == 2) ? 1.0 : q8[2 * (tid / 3) + tid % 3]; sIc[tid] = v; rg.d_init_corners_hm[12 * (size_t)t + tid] = v; }
-		if (AM == MTFHIP_AM_NCC && tid < 8) rg.d_ncc[8 * (size_t)t + tid] = sNc[tid];
+		if (AM == MTFHIP_AM_NCC && tid < 8 && !late_ncc) rg.d_ncc[8 * (size_t)t + tid] = sNc[tid];
 		__syncthreads();   /* sIc */
 	}
 	if constexpr (FAST) {
@@ -335,15 +413,8 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 		for (int q = 0; q < 9; ++q) W[q] = sW[q];
 #pragma unroll
 		for (int q = 0; q < 8; ++q) { St[q] = sSt[q]; Cr[q] = sCr[q]; }
-		double tc[16];   /* NCC: sum J0 | sum I0 J0 of this patch */
-#pragma unroll
-		for (int q = 0; q < 16; ++q) tc[q] = 0.0;
 		if constexpr (NCC) {
-			if (ts.ncc_tm) {
-				/* the template's moments were reduced when the template was (ncc_template_moments: sum J0 | sum I0 J0 | Gram) */
-#pragma unroll
-				for (int q = 0; q < 16; ++q) tc[q] = ts.ncc_tm[(size_t)t * 52 + q];
-			} else {
+			if (!ts.ncc_tm) {
 #pragma unroll
 				for (int k = 0; k < PPT; ++k) {
 					const int i = tid + k * kBlock;
@@ -363,35 +434,25 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 		 * round trip, what the first iteration's texel fetch cost anyway -- and every later iteration reads its four texels per sample
 		 * from LDS (~100 ns) instead of L2 (~1 us of every 3.3 us iteration, section 4.4's phase trace).  A wave any of whose samples
 		 * leaves the window (or a patch larger than it, or a frame smaller) takes the global path: same texels, same arithmetic, same bits. */
-		constexpr int kWinW = 64, kWinH = 64;
 		__shared__ float win[kWinW * kWinH];
-		int wx0 = 0, wy0 = 0;
-		bool win_ok = false;
 #ifndef MTFHIP_GRID_NO_WINDOW
-		{
-			const double mnx = fmin(fmin(Cr[0], Cr[2]), fmin(Cr[4], Cr[6])), mxx = fmax(fmax(Cr[0], Cr[2]), fmax(Cr[4], Cr[6]));
-			const double mny = fmin(fmin(Cr[1], Cr[3]), fmin(Cr[5], Cr[7])), mxy = fmax(fmax(Cr[1], Cr[3]), fmax(Cr[5], Cr[7]));
-			const double cxm = 0.5 * (mnx + mxx), cym = 0.5 * (mny + mxy);
-			/* (NaN corners fail every comparison) */
-			win_ok = (mxx - mnx < kWinW - 6) & (mxy - mny < kWinH - 6) & (cxm > -1e6) & (cxm < 1e6) & (cym > -1e6) & (cym < 1e6) &
-				(im.w >= kWinW) & (im.h >= kWinH) & !region_bad;
-			if (win_ok) {
-				wx0 = min(max((int)floor(cxm) - kWinW / 2, 0), im.w - kWinW);
-				wy0 = min(max((int)floor(cym) - kWinH / 2, 0), im.h - kWinH);
-				float tv[kWinW * kWinH / kBlock];
+		win_ok = win_ok & !region_bad;
+		if (win_ok) {
 #pragma unroll
-				for (int j = 0; j < kWinW * kWinH / kBlock; ++j) {
-					const int idx = tid + j * kBlock;
-					tv[j] = im.data[(unsigned)((wy0 + idx / kWinW) * im.stride + wx0 + idx % kWinW)];
-				}
-#pragma unroll
-				for (int j = 0; j < kWinW * kWinH / kBlock; ++j) win[tid + j * kBlock] = tv[j];
-			}
+			for (int j = 0; j < kWinW * kWinH / kBlock; ++j) win[tid + j * kBlock] = win_tv[j];
 		}
 		__syncthreads();   /* (win_ok is uniform: every thread holds the same corners) */
 #endif
+		/* constant over the iterations: this lane's row of H0^-1 and the template's homogeneous corners -- one LDS round trip each per
+		 * iteration on a loop that is a chain of dependent latencies (r05) */
+		double hrow[8], Ic[12];
+#pragma unroll
+		for (int q = 0; q < 8; ++q) hrow[q] = sH8[8 * (tid & 7) + q];
+#pragma unroll
+		for (int q = 0; q < 12; ++q) Ic[q] = sIc[q];
 		const double winx0 = (double)wx0, winx1 = (double)(wx0 + kWinW - 1), winy0 = (double)wy0, winy1 = (double)(wy0 + kWinH - 1);
-		const double nN = (double)N, inv_n = 1.0 / nN, inv_cn = 1.0 / cn;
+		const double nN = (double)N, inv_n = 1.0 / nN;
+		double inv_cn = 1.0 / cn;
 		GRID_STAMP(3);
 		const int max_it = region_bad ? 0 : sm.max_iters;   /* degenerate region corners: no iteration, n_iters = -1 tells the host */
 		for (int it = 0; it < max_it; ++it) {
@@ -431,6 +492,9 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 				for (int s = 0; s < 8; ++s)
 					if (s < S) m[K - 8 + s] = fma(wgt, HOIST_J ? j0v[HOIST_J ? k : 0][s] : J0[(size_t)s * N + ick], m[K - 8 + s]);
 			}
+			/* (layout mode: the template's NCC scalars come over PCIe and are first needed behind this reduction, whose barrier also
+			 * publishes them to the workgroup -- by now the read has long returned) */
+			if (late_ncc && it == 0 && tid >= 8 && tid < 16) sNc[tid - 8] = ingest;
 #if !(defined(MTFHIP_GRID_ABL) && (MTFHIP_GRID_ABL & 2))   /* ablation: no workgroup reduction */
 #ifdef MTFHIP_GRID_DPP_REDUCE   /* (r03 / early r04: one DPP wave sum per value) */
 			block_allsum_dpp<K>(m, redk);
@@ -438,12 +502,19 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 			block_allsum_h12(m, redk + ((it + 1) & 1) * 64);   /* (round 0 in the buffer the template sums above did not use) */
 #endif
 #endif
+			if (late_ncc && it == 0) {
+				m0 = sNc[0]; cn = sNc[1]; inv_cn = 1.0 / cn;
+				if (tid < 8) rg.d_ncc[8 * (size_t)t + tid] = sNc[tid];
+			}
 			double g[8];
 			if constexpr (NCC) {
 				/* (the whole section runs on one wave per SIMD with nothing to overlap: an IEEE division is ~30 dependent
 				 * instructions, so the ~40 of the straightforward form were 3 us of every 7 us iteration -- reciprocals once) */
-				const double mt = m[0] * inv_n, b2 = fma(-nN * mt, mt, m[1]), b = sqrt(b2);
-				const double inv_b = rcp_fast(b), inv_bc = inv_b * inv_cn, inv_b2 = inv_b * inv_b;
+				/* (r05: 1 / b from v_rsq_f64 + two Newton steps and b = b2 / b, instead of sqrt -- itself a reciprocal square root with
+				 * corrections -- followed by a reciprocal: ~15 dependent instructions less) */
+				const double mt = m[0] * inv_n, b2 = fma(-nN * mt, mt, m[1]);
+				const double inv_b = rsq_fast(b2), b = b2 * inv_b;
+				const double inv_bc = inv_b * inv_cn, inv_b2 = inv_b * inv_b;
 				const double f = fma(-nN * m0, mt, m[2]) * inv_bc;
 				f_last = f;
 				const double b_c = b * inv_cn;
@@ -475,7 +546,7 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 			{
 				/* lane l forms row l & 7 of -H0^-1 g (the same expression as above, so the same bits) and the eight results come back
 				 * through the scalar unit: 8 LDS reads + 15 FP64 instructions + 16 v_readlane instead of 64 + 120 */
-				const double *h = sH8 + 8 * (tid & 7);
+				const double *h = hrow;
 				const double mine = -(((h[0] * g[0] + h[1] * g[1]) + (h[2] * g[2] + h[3] * g[3])) + ((h[4] * g[4] + h[5] * g[5]) + (h[6] * g[6] + h[7] * g[7])));
 #pragma unroll
 				for (int r = 0; r < 8; ++r) dp[r] = readlane_f64(mine, r);
@@ -513,7 +584,7 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 			double ch[4];
 #pragma unroll
 			for (int q = 0; q < 4; ++q) {
-				const double X = sIc[3 * q], Y = sIc[3 * q + 1], Z = sIc[3 * q + 2];
+				const double X = Ic[3 * q], Y = Ic[3 * q + 1], Z = Ic[3 * q + 2];
 				double nx = (Wn[0] * X + Wn[1] * Y) + Wn[2] * Z, ny = (Wn[3] * X + Wn[4] * Y) + Wn[5] * Z;
 				if (hom) { const double idn = rcp_fast((Wn[6] * X + Wn[7] * Y) + Wn[8] * Z); nx *= idn; ny *= idn; }
 				const double ddx = Cr[2 * q] - nx, ddy = Cr[2 * q + 1] - ny;

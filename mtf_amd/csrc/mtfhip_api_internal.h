@@ -270,6 +270,13 @@ struct mtfhip_batch {
 	 * corners, valid for the duration of the C-ABI call that deferred them */
 	const double *deferred_corners = nullptr;
 	bool deferred_for_track = false;
+	/* mtfhip_grid_frame, fixed-size patches (r05): the kernel lays its patches out itself from the grid's region (RegionIngest::layout),
+	 * so the HOST layout -- for the mirrors, the staged slab and the template-grid comparison -- is also deferred behind the launch:
+	 * set_corners_finish_deferred runs mtfhip_grid_layout into deferred_patches first */
+	bool deferred_layout = false, deferred_template_check = false;
+	mtfhip_grid_desc deferred_gdesc{};
+	double deferred_region[8] = {0, 0, 0, 0, 0, 0, 0, 0}, deferred_region_map[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+	std::vector<double> deferred_patches;
 	bool have_corners = false, init_pix_vals = false, init_pix_grad = false, init_sim = false, init_grad = false;
 	bool it_valid = false, dit_valid = false, jt_valid = false;
 	std::vector<TargetHost> th;
@@ -541,7 +548,7 @@ static inline mtfhip::MiJ0Rebuild mi_j0_rebuild(const mtfhip_batch *b) {
 /* ---- functions defined in one api_*.hip unit and used in another ---- */
 enum { LAZY_CURR_JAC = 0, LAZY_DIFF_JAC = 1, LAZY_INIT_JAC = 2 };
 int ensure_pts(mtfhip_batch *b);
-int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track, bool defer_grid = false);   /* api_core.hip */
+int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track, bool defer_grid = false, bool layout_later = false);   /* api_core.hip */
 void set_corners_finish_deferred(mtfhip_batch *b);
 int do_update_grad_pts(mtfhip_batch *b, double grad_eps);
 int gemv_to_host(mtfhip_batch *b, const double *v1, int j1, const double *v2, int j2, int sum_mode, double *g, int diff);

@@ -125,6 +125,14 @@ __device__ __forceinline__ double rcp_fast(double d) {
 	e = fma(-d, r, 1.0);
 	return fma(r, e, r);
 }
+/* 1 / sqrt(x) to ~1 ulp: v_rsq_f64 (~2^-26 relative) + two Newton steps (y <- y + y (1 - x y^2) / 2); x > 0, no scaling */
+__device__ __forceinline__ double rsq_fast(double x) {
+	double y = __builtin_amdgcn_rsq(x);
+	double e = fma(-x * y, y, 1.0);
+	y = fma(0.5 * y, e, y);
+	e = fma(-x * y, y, 1.0);
+	return fma(0.5 * y, e, y);
+}
 /* The step the reference's central difference actually takes.  imgUtils.cc:233-254 samples at fl(w + eps) and fl(w - eps): on a
  * coordinate of a few hundred pixels eps = 1e-8 is rounded to the coordinate's ulp grid (2^-44 in [256, 512): 175 921.86 ulps become
  * 175 922), a SYSTEMATIC relative error of ~8e-7 .. 1e-5 of every gradient that the division by the nominal 2 eps does not undo.

@@ -175,6 +175,44 @@ __host__ __device__ inline bool quad_degenerate_hd(const double *q) {
 	return dx1 * dy2 - dy1 * dx2 == 0;
 }
 
+/* GridTracker::resetTrackers' geometry for ONE patch (SM/src/GridTracker.cc:345-380; mtfhip_grid_layout, api_core.hip, describes it): the
+ * grid SSM's points are the resx x resy grid of the unit square through the region's 4-corner map Wr = rect_to_quad(-0.5 .. 0.5, region),
+ * a patch is the cell spanned by four of them (dyn_patch_size), a fixed-size rectangle centred on its own point, or one centred on the
+ * cell's centroid (patch_centroid_inside).  One set of expressions for the host layout and for the kernel that lays its own patch out
+ * (k_iclk_track, RegionIngest::layout; both compiled without contraction: the same bits). */
+struct GridLayoutHD { int grid_size_x, grid_size_y, patch_size_x, patch_size_y, dyn_patch_size, patch_centroid_inside; };
+__host__ __device__ inline double lin_spaced_hd(int i, int n, double lo, double hi) { return (n == 1 || i == n - 1) ? hi : lo + i * ((hi - lo) / (n - 1)); }
+__host__ __device__ inline void grid_pt_hd(const double *Wr, int resx, int resy, int idx, double *x, double *y) {
+	const int r = idx / resx, c = idx % resx;
+	const double ny = lin_spaced_hd(r, resy, -0.5, 0.5), nx = lin_spaced_hd(c, resx, -0.5, 0.5);
+	const double X = Wr[0] * nx + Wr[1] * ny + Wr[2], Y = Wr[3] * nx + Wr[4] * ny + Wr[5], Z = Wr[6] * nx + Wr[7] * ny + Wr[8];
+	*x = X / Z; *y = Y / Z;
+}
+__host__ __device__ inline void grid_patch_corners_hd(const GridLayoutHD &g, const double *Wr, int k, double *pc) {
+	const int extra = (g.dyn_patch_size || g.patch_centroid_inside) ? 1 : 0;
+	const int resx = g.grid_size_x + extra, resy = g.grid_size_y + extra;
+	const bool surround = extra != 0;
+	const int sub_x = g.grid_size_x + 1;   /* _linear_idx(idy, idx) = idy * (grid_size_x + 1) + idx, :139-146 */
+	const int row = k / g.grid_size_x, col = k % g.grid_size_x;   /* :354-355 */
+	for (int q = 0; q < 8; ++q) pc[q] = 0.0;
+	if (surround) {   /* :357-367 TL, TR, BR, BL of the cell */
+		const int id[4] = {row * sub_x + col, row * sub_x + col + 1, (row + 1) * sub_x + col + 1, (row + 1) * sub_x + col};
+		for (int q = 0; q < 4; ++q) grid_pt_hd(Wr, resx, resy, id[q], pc + 2 * q, pc + 2 * q + 1);
+	}
+	if (!g.dyn_patch_size) {   /* :369-380 */
+		double cx, cy;
+		if (g.patch_centroid_inside) {   /* utils::getCentroid miscUtils.h:481-487 */
+			cx = (pc[0] + pc[2] + pc[4] + pc[6]) / 4.0;
+			cy = (pc[1] + pc[3] + pc[5] + pc[7]) / 4.0;
+		} else grid_pt_hd(Wr, resx, resy, k, &cx, &cy);   /* ssm.getPts().col(tracker_id) */
+		const double half_x = g.patch_size_x / 2.0, half_y = g.patch_size_y / 2.0;   /* centrod_dist_x / _y :156-157 */
+		const double min_x = cx - half_x, min_y = cy - half_y;   /* utils::Corners(cv::Rect_<double>) miscUtils.h:42-52 */
+		const double max_x = min_x + g.patch_size_x, max_y = min_y + g.patch_size_y;
+		pc[0] = pc[6] = min_x; pc[2] = pc[4] = max_x;
+		pc[1] = pc[3] = min_y; pc[5] = pc[7] = max_y;
+	}
+}
+
 /* k_iclk_track in REGION mode (mtfhip_batch_track_region / mtfhip_grid_update, r04): the workgroup of a patch takes the patch's region
  * corners (and its template's NCC scalars) straight from the pinned staging buffer, derives the square-to-quadrilateral map, lays out
  * its own sample grid -- kept in registers for the loop, written to INIT_PTS / INIT_HXY / INIT_Z for whoever asks later -- and starts
@@ -186,6 +224,12 @@ struct RegionIngest {
 	double *d_ncc, *d_w0, *d_init_corners_hm;   /* the slab's device copies of what the workgroup derives */
 	double lo_x, lo_y, hi_x, hi_y;
 	int resx, resy, force_unit_z;
+	/* layout != 0 (mtfhip_grid_frame with fixed-size patches, r05): the workgroup computes its patch's corners itself from the GRID's
+	 * region (grid_patch_corners_hd over region_map = rect_to_quad(-0.5 .. 0.5, region), formed on the host once) -- `corners` is not
+	 * read: no PCIe round trip in front of the grid layout, and the host lays the patches out for its mirrors AFTER the launch */
+	int layout;
+	GridLayoutHD grid;
+	double region_map[9];
 };
 
 struct HostPublish {

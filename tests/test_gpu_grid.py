@@ -233,3 +233,41 @@ def test_fused_template_init_equals_call_by_call(oracle, gpu_ctx, frame, am, ssm
         trk.initialize(patches[t]); o_am.set_curr_img(f2); trk.update()
         np.testing.assert_allclose(c[t], trk.get_region(), rtol=0, atol=5e-4)
     g.tracker.batch.close()
+
+
+@pytest.mark.parametrize("mode", sorted(MODES))
+@pytest.mark.parametrize("am,region", [(L.AM_NCC, "projective"), (L.AM_SSD, "quad"), (L.AM_NCC, "square")])
+def test_grid_frame_patches_laid_out_by_the_kernel_equal_the_host_layout(gpu_ctx, frame, mode, am, region, monkeypatch):
+    """r05: with fixed-size patches mtfhip_grid_frame hands the kernel the GRID's region and every workgroup computes its own patch
+    corners (grid_patch_corners_hd, the expressions of mtfhip_grid_layout) -- no PCIe read in front of the grid layout, and the host
+    lays the patches out for its mirrors behind the launch.  MTFHIP_GRID_LAYOUT_DEV=0 keeps the host layout in front: the same
+    iteration counts, corners, centroids, template grids, states and patch regions bit for bit, in both arithmetic modes, frame after
+    frame; dyn_patch_size patches always take the host layout."""
+    dyn, inside = MODES[mode]
+    reg = REGIONS[region]
+    frames = _frames(frame, 3, 21)
+    rec = {}
+    for dev in ("1", "0"):
+        monkeypatch.setenv("MTFHIP_GRID_LAYOUT_DEV", dev)
+        gpu_ctx.set_image(frame)
+        gt = GridTracker(gpu_ctx, grid_size=6, patch_size=21, am=am, ssm=L.SSM_AFFINE, grid_ssm=L.SSM_HOMOGRAPHY, max_iters=8, epsilon=1e-4,
+                         dyn_patch_size=dyn, patch_centroid_inside=inside, reset_at_each_frame=2)
+        gt.initialize(reg)
+        b = gt.tracker.batch
+        out = []
+        for k, f in enumerate(frames):
+            gpu_ctx.set_image(f)
+            b.set_math_mode(mtf_amd.MATH_FAST if k != 1 else mtf_amd.MATH_REPLAY)
+            n, c, m = b.grid_frame(gt.gd, gt.tracker.sm, reg + 0.3 * k)
+            out.append([n.copy(), c.copy(), m.copy(), b.read(L.BUF_INIT_PTS).copy(), b.read(L.BUF_INIT_HXY).copy(), b.read(L.BUF_INIT_Z).copy(),
+                        b.get_state().copy(), b.get_corners().copy()])
+            # ... and what the host mirrors hold afterwards: a plain update() from there
+            n2, c2, m2 = b.grid_frame(gt.gd, gt.tracker.sm, None)
+            out[-1] += [n2.copy(), c2.copy(), m2.copy()]
+        rec[dev] = out
+        del gt
+    for k in range(len(frames)):
+        for x, y, what in zip(rec["1"][k], rec["0"][k], ("n_iters", "corners", "centroids", "init_pts", "init_hxy", "init_z", "state", "corner mirrors",
+                                                       "n_iters of the next update", "corners of the next update", "centroids of the next update")):
+            assert np.array_equal(x, y), (k, what)
+    assert all((r[0] > 0).all() for r in rec["1"])

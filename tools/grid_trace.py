@@ -1,5 +1,5 @@
 """Prints the phase durations of one workgroup of k_iclk_track (grid frame, 256 patches x 10 iterations) from a
--DMTFHIP_GRID_TRACE build (tools/grid_trace.sh): MTFHIP_LIB=scratch/libmtfhip_gtrace.so python tools/grid_trace.py"""
+-DMTFHIP_GRID_TRACE build (tools/grid_trace.sh): MTFHIP_LIB=build/variants/libmtfhip_gtrace.so python tools/grid_trace.py"""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -21,7 +21,7 @@ lib = L.lib()
 lib.mtfhip_debug_grid_trace.argtypes = [C.c_void_p]
 n = 0
 for k in range(60):
-    gt.update_patches(pc)
+    gt.tracker.batch.grid_frame(gt.gd, gt.tracker.sm, region)   # (mtfhip_grid_frame: the kernel lays its patches out itself; MTFHIP_GRID_LAYOUT_DEV=0: the host does)
     if k >= 10:
         t = np.zeros(32, dtype=np.uint64)
         lib.mtfhip_debug_grid_trace(t.ctypes.data_as(C.c_void_p))
