@@ -961,6 +961,9 @@ int mtfhip_batch_track(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, 
  * tracker->setRegion(patch corners); tracker->update()) and a pyramid level with the level above's result.  For the search
  * methods that keep their template Jacobian (ICLK; FCLK without the InitialSelf Hessian) the reset state and the loop's
  * active flags / iteration counts travel in ONE staged copy; the others take the two steps one after the other. */
+/* MTFHIP_TRACK_DEBUG_TIMING: host-side stamps of a one-launch frame (before the launch call | after it | after the deferred host half) */
+static const bool g_track_dbg_timing = std::getenv("MTFHIP_TRACK_DEBUG_TIMING") != nullptr;
+static thread_local std::chrono::steady_clock::time_point g_track_dbg_t[3];
 /* grid != NULL (mtfhip_grid_frame): region_corners is the GRID's region (8 doubles) and the patches are laid over it -- by the kernel
  * itself where the one-launch region mode applies and the patches are fixed-size rectangles (the host layout then runs behind the launch),
  * by mtfhip_grid_layout in front of the call otherwise */
@@ -1005,9 +1008,14 @@ static int track_region_impl(mtfhip_batch *b, const mtfhip_sm_desc *sm, const do
 	set_corners_finish_deferred(b);   /* (a call that failed before its launch: nothing stays pending on the caller's buffer) */
 	if (dbg) {
 		const auto t2 = std::chrono::steady_clock::now();
-		static double acc1 = 0, acc2 = 0; static int n = 0;
-		acc1 += std::chrono::duration<double, std::micro>(t1 - t0).count(); acc2 += std::chrono::duration<double, std::micro>(t2 - t1).count();
-		if (++n % 100 == 0) { std::fprintf(stderr, "[track_region] set_region %.1f us, track %.1f us (mean of 100)\n", acc1 / 100, acc2 / 100); acc1 = acc2 = 0; }
+		static double acc1 = 0, acc2 = 0, acc3 = 0, acc4 = 0, acc5 = 0, acc6 = 0; static int n = 0;
+		auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::micro>(c - a).count(); };
+		acc1 += us(t0, t1); acc2 += us(t1, t2); acc3 += us(t1, g_track_dbg_t[0]); acc4 += us(g_track_dbg_t[0], g_track_dbg_t[1]); acc5 += us(g_track_dbg_t[1], g_track_dbg_t[2]); acc6 += us(g_track_dbg_t[2], t2);
+		if (++n % 100 == 0) {
+			std::fprintf(stderr, "[track_region] set_region %.1f us, track %.1f us = before the launch %.1f + launch call %.1f + deferred host half %.1f + wait and copy-out %.1f (mean of 100)\n",
+				acc1 / 100, acc2 / 100, acc3 / 100, acc4 / 100, acc5 / 100, acc6 / 100);
+			acc1 = acc2 = acc3 = acc4 = acc5 = acc6 = 0;
+		}
 	}
 	return r;
 }
@@ -1217,8 +1225,12 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 				std::memcpy(rg.region_map, b->deferred_region_map, sizeof(rg.region_map));
 			}
 		}
+		const bool dbg_t = g_track_dbg_timing;
+		if (dbg_t) g_track_dbg_t[0] = std::chrono::steady_clock::now();
 		launch_iclk_track(bv, b->ctx->img, *sm, ts, b->d_h0inv, b->d_ncc, b->norm_mult, b->norm_add, b->math_mode == MTFHIP_MATH_FAST, pub, rg, st);
+		if (dbg_t) g_track_dbg_t[1] = std::chrono::steady_clock::now();
 		set_corners_finish_deferred(b);   /* the host half of a deferred reset, under the kernel */
+		if (dbg_t) g_track_dbg_t[2] = std::chrono::steady_clock::now();
 	} else if (so_term < 0 && persist_fits(b, sm, fa)) {
 		/* a grid that fits the device at one workgroup per CU (a single large target, a few small ones): every pass of the loop in
 		 * ONE launch, the workgroups meeting at an in-kernel barrier between the pixel pass and the solve (kernels_persist.hip) */
