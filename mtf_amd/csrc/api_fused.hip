@@ -686,6 +686,13 @@ static MiFastPlan mi_fast_plan(const mtfhip_batch *b, const MiPlan &pl, const in
 	fp.j0_mode = !need_j0 ? 0 : (rb.dI0 ? 1 : 2);
 	fp.j0_init_variant = rb.init_variant;
 	fp.grad_eps = b->desc.grad_eps; fp.norm_mult = b->norm_mult; fp.norm_add = b->norm_add; fp.hist_norm = b->mi_hist_norm;
+	{
+		/* (partition of unity, MI.cc:80-94: pixel values are mapped to [1, n_bins - 2], so every cubic B-spline window lies inside the bins and its
+		 * weights sum to one: the histogram of It is the joint histogram's row sum to rounding -- MTFHIP_MI_HIST_ROWSUM=0: its own block product) */
+		const char *e_rs = std::getenv("MTFHIP_MI_HIST_ROWSUM");   /* (read per plan: the parity test flips it) */
+		const bool rowsum_env = !(e_rs && e_rs[0] == '0');
+		fp.hist_from_joint = (rowsum_env && b->desc.mi_partition_of_unity) ? 1 : 0;
+	}
 	fp.active = active; fp.tb = b->d_mi_tb;
 	return fp;
 }

@@ -61,6 +61,7 @@ __global__ __launch_bounds__(kBlock) void k_mi_pass_hist(BatchView bv, ImgView i
 	const double *I0 = bv.buf[MTFHIP_BUF_I0] + tt * N;
 	for (int k2 = 0; k2 < 2 * kWinRows; ++k2) wa[k2 * kRS + lane] = 0.0;   /* the slabs start clean and every chunk leaves them clean */
 	double bj8 = 0.0, bs8 = 0.0, bh8 = 0.0;
+	const bool hfj = !CAND && pa.hist_from_joint != 0;
 	const int li = lane & 3, lb = (lane >> 2) & 3, lk = lane >> 4;
 	const double one0 = li == 0 ? 1.0 : 0.0;
 	const unsigned stride = (unsigned)nblk * kBlock;
@@ -123,6 +124,15 @@ __global__ __launch_bounds__(kBlock) void k_mi_pass_hist(BatchView bv, ImgView i
 		for (int k = 0; k < 4; ++k) { ra[k * kRS] = a.w[k] * vm; rb[k * kRS] = b.w[k]; }
 		__builtin_amdgcn_wave_barrier();
 #if !(defined(MTFHIP_MI1_ABL) && MTFHIP_MI1_ABL == 2)   /* 2: + staging, no products */
+		if (hfj) {   /* (uniform) the histogram comes out of the joint histogram's rows at the end: two block products per step instead of three */
+#pragma unroll
+			for (int qq = 0; qq < 16; ++qq) {
+				const int p = 4 * qq + lk;
+				const double av = wa[(1 + 4 * (lb >> 1) + li) * kRS + p], bvv = wb[(1 + 4 * (lb & 1) + li) * kRS + p];
+				bj8 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bvv, bj8, 0, 0, 0);
+				if constexpr (SELF) bs8 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, wa[(1 + 4 * (lb & 1) + li) * kRS + p], bs8, 0, 0, 0);
+			}
+		} else {
 #pragma unroll
 		for (int qq = 0; qq < 16; ++qq) {
 			const int p = 4 * qq + lk;
@@ -132,6 +142,7 @@ __global__ __launch_bounds__(kBlock) void k_mi_pass_hist(BatchView bv, ImgView i
 			bh8 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, one0, bh8, 0, 0, 0);
 #endif
 			if constexpr (SELF) bs8 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, wa[(1 + 4 * (lb & 1) + li) * kRS + p], bs8, 0, 0, 0);
+		}
 		}
 #endif
 		__builtin_amdgcn_wave_barrier();
@@ -151,7 +162,18 @@ __global__ __launch_bounds__(kBlock) void k_mi_pass_hist(BatchView bv, ImgView i
 	}
 	__syncthreads();
 	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * row_len;
-	for (int k2 = threadIdx.x; k2 < rl; k2 += kBlock) dst[k2] = (red[k2] + red[rl + k2]) + (red[2 * rl + k2] + red[3 * rl + k2]);
+	for (int k2 = threadIdx.x; k2 < rl; k2 += kBlock) {
+		double v = (red[k2] + red[rl + k2]) + (red[2 * rl + k2] + red[3 * rl + k2]);
+		if (hfj && k2 < nb) {   /* histogram row k2 = sum over the eight columns of the joint histogram's row k2 (each the four waves' sum, fixed order) */
+			v = 0.0;
+#pragma unroll
+			for (int c = 0; c < nb; ++c) {
+				const int e = nb + k2 * nb + c;
+				v += (red[e] + red[rl + e]) + (red[2 * rl + e] + red[3 * rl + e]);
+			}
+		}
+		dst[k2] = v;
+	}
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -310,7 +332,7 @@ __global__ __launch_bounds__(kBlock) void k_mi_poly_tables(const double *tb_all,
 static MiPassArgs make_args(const MiFastPlan &pl) {
 	MiPassArgs pa;
 	pa.nb = 8; pa.j0_mode = pl.j0_mode; pa.j0_init_variant = pl.j0_init_variant; pa.need_dft = pl.need_dft; pa.need_df0 = pl.need_df0;
-	pa.g_mean = pl.g_mean; pa.table_off = 0; pa.transpose_q = pl.hk == 3; pa.nonchained = pl.nonchained;
+	pa.g_mean = pl.g_mean; pa.table_off = 0; pa.transpose_q = pl.hk == 3; pa.nonchained = pl.nonchained; pa.hist_from_joint = pl.hist_from_joint;
 	pa.grad_eps = pl.grad_eps; pa.norm_mult = pl.norm_mult; pa.norm_add = pl.norm_add; pa.hist_norm = pl.hist_norm;
 	pa.active = pl.active; pa.tb = pl.tb; pa.poly = pl.poly; pa.cand_states = nullptr;
 	return pa;

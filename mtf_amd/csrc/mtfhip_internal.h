@@ -341,6 +341,8 @@ struct MiFastPlan {
 	int j0_init_variant;
 	int need_dft, need_df0, g_mean;
 	int nonchained = 0;   /* the search method's chained_warp = 0: pass 2 takes the rounded steps of updateGradPts' four points (mi_finish) */
+	int hist_from_joint = 0;   /* pass 1: the histogram of It as the row sums of the joint histogram (partition of unity: every window of I0 lies
+	                              inside the bins and sums to one) instead of a block product of its own -- a third of the pass's matrix work */
 	double grad_eps, norm_mult, norm_add, hist_norm;
 	const int *active;    /* device flags, NULL = all */
 	const double *tb;     /* [B][MI_SIZE] */

@@ -135,6 +135,7 @@ struct MiPassArgs {
 	int table_off;          /* pass 2, Hessian: MI_T_SELF / MI_T_CURR / MI_T_INIT */
 	int transpose_q;
 	int nonchained;         /* pass 2: the search method's chained_warp = 0 (updateGradPts + getWarpedImgGrad + cmptInitPixJacobian) */
+	int hist_from_joint;    /* pass 1: no histogram product; the histogram row = the row sums of the joint histogram (MiFastPlan) */
 	double grad_eps, norm_mult, norm_add, hist_norm;
 	const int *active;
 	const double *tb;       /* [B][MI_SIZE] */

@@ -21,7 +21,8 @@ def rel(a, b):
 
 def make_pair(oracle, ctx, img, am, ssm, res, corners, **kw):
     o_ssm = oracle.SSM(ssm, res, res)
-    o_am = oracle.AM(am, res, res, **kw)
+    o_names = {"mi_pou": "pou", "mi_n_bins": "n_bins", "mi_pre_seed": "pre_seed"}   # (the C ABI's field names -> the oracle's)
+    o_am = oracle.AM(am, res, res, **{o_names.get(k, k): v for k, v in kw.items()})
     o_am.set_curr_img(img)
     ctx.set_image(img)
     b = mtf_amd.Batch(ctx, am, ssm, res, res, 1, **{k: v for k, v in kw.items()})
@@ -219,6 +220,17 @@ def test_fused_mi_iterations_follow_oracle(oracle, gpu_ctx, frame, case, materia
     _fused_follow(oracle, gpu_ctx, frame, L.AM_MI, case, materialize, grid)
 
 
+@pytest.mark.parametrize("rowsum", ["1", "0"])
+@pytest.mark.parametrize("materialize", [1, 0])
+@pytest.mark.parametrize("case", [MI_CASES[0], MI_CASES[1], MI_CASES[4], MI_CASES[5], MI_CASES[6]], ids=_case_id)
+def test_fused_mi_partition_of_unity(oracle, gpu_ctx, frame, case, materialize, rowsum, monkeypatch):
+    """mi_pou = 1, what the shipped Config/modules.cfg:117 sets (MI.cc:80-94: pixel values mapped to [1, n_bins - 2], every B-spline window
+    inside the bins).  There the recompute pass takes the histogram of It as the row sums of the joint histogram (the windows of I0 sum to
+    one) instead of a block product of its own; MTFHIP_MI_HIST_ROWSUM=0 keeps the product: both held to the oracle like every other case"""
+    monkeypatch.setenv("MTFHIP_MI_HIST_ROWSUM", rowsum)
+    _fused_follow(oracle, gpu_ctx, frame, L.AM_MI, case, materialize, "device_grid", am_kw=dict(mi_pou=1))
+
+
 @pytest.mark.parametrize("grid", ["oracle_grid", "device_grid"])
 @pytest.mark.parametrize("materialize", [1, 0])
 @pytest.mark.parametrize("case", SM_CASES, ids=_case_id)
@@ -226,7 +238,7 @@ def test_fused_iterations_follow_oracle(oracle, gpu_ctx, frame, case, materializ
     _fused_follow(oracle, gpu_ctx, frame, L.AM_SSD, case, materialize, grid)
 
 
-def _fused_follow(oracle, gpu_ctx, frame, am, case, materialize, grid):
+def _fused_follow(oracle, gpu_ctx, frame, am, case, materialize, grid, am_kw=None):
     """Drive the SM loop on the host exactly as the reference does (solve + compositional update on the
     CPU), with the device producing f, g, H per iteration; compare every iteration with the oracle's
     trace of nt::ESM / nt::FCLK / nt::ICLK::update.
@@ -247,7 +259,7 @@ def _fused_follow(oracle, gpu_ctx, frame, am, case, materialize, grid):
 
     params = dict(leven_marq=0, max_iters=8)
     params.update(extra)
-    o_am, o_ssm, b = make_pair(oracle, gpu_ctx, frame, am, ssm, res, corners)
+    o_am, o_ssm, b = make_pair(oracle, gpu_ctx, frame, am, ssm, res, corners, **(am_kw or {}))
     ncc = am == L.AM_NCC
     if grid == "oracle_grid":
         hm = o_ssm.get("init_pts_hm").reshape(-1, 3)
@@ -274,7 +286,8 @@ def _fused_follow(oracle, gpu_ctx, frame, am, case, materialize, grid):
     # the oracle in H; r04's does: (ii) H and g within 2e-6, dp within north_star's 1e-5.  (i) The same restatement run with
     # grad_eps = 1e-6 (a hundred times less quantisation) is now the farther one: its distance is bounded by the quantisation itself
     # and recorded.
-    o_am6 = oracle.AM(am, res, res, grad_eps=1e-6); o_ssm6 = oracle.SSM(ssm, res, res)
+    o_kw = {{"mi_pou": "pou", "mi_n_bins": "n_bins", "mi_pre_seed": "pre_seed"}.get(k, k): v for k, v in (am_kw or {}).items()}
+    o_am6 = oracle.AM(am, res, res, grad_eps=1e-6, **o_kw); o_ssm6 = oracle.SSM(ssm, res, res)
     o_am6.set_curr_img(frame); o_ssm6.set_corners(corners)
     trk6 = oracle.Tracker(sm_kind, o_am6, o_ssm6, **dict(params, max_iters=1))
     trk6.initialize(corners); o_am6.set_curr_img(frame2)
