@@ -54,6 +54,14 @@ for cfg in "1 1 1" "0 1 1" "1 0 1" "1 1 0" "0 0 0"; do
     python -c "import json,sys; d=json.loads(sys.stdin.read()); c=d['config']; print(json.dumps({'local': $1, 'pert_ahead': $2, 'skip_estimate': $3, 'us_per_iteration': c['us_per_iteration'], 'score_us': c['score_kernel_ms']*1e3, 'resample_us': c['resample_kernels_ms']*1e3}))" >> $out/pf_forms_ab.jsonl
 done
 timeout 300 python tools/grid_modes_probe.py 2>/dev/null > $out/grid_modes_probe.txt
+# the grid frame with the host layout in front of the launch / the kernel's own layout (C++ loop and Python), and the frame's host-side stamps
+: > $out/grid_layout_ab.txt
+for d in 1 0 1 0; do MTFHIP_GRID_LAYOUT_DEV=$d timeout 300 python bench.py --workload grid --steps 300 --warmup 20 --no-cpu 2>/dev/null | tail -1 |
+  python -c "import json,sys; d=json.loads(sys.stdin.read()); c=d['config']; print('MTFHIP_GRID_LAYOUT_DEV=$d frame %.2f us kernel %.2f us; C++ loop %.2f us, Grid::update() %.2f us' % (c['frame_us'], c['kernel_us'], c['cpp_driver']['frame_us_c_abi_loop'], c['cpp_driver']['frame_us_grid_update_setregion_mode']))" >> $out/grid_layout_ab.txt; done
+MTFHIP_TRACK_DEBUG_TIMING=1 timeout 300 python tools/grid_modes_probe.py 2>&1 | grep track_region | tail -3 >> $out/grid_layout_ab.txt
+# MI with partition of unity (the shipped mi_pou = 1): histogram as the joint histogram's row sums / as its own block product
+: > $out/mi_pou_ab.txt
+for r in 1 0 1 0; do MTFHIP_MI_HIST_ROWSUM=$r timeout 300 python tools/mi_pou_probe.py 2>/dev/null | tail -1 >> $out/mi_pou_ab.txt; done
 timeout 300 python tools/grid_reinit_probe.py 2>/dev/null > $out/grid_reinit_probe.txt
 timeout 600 python bench.py --pf-strong 1 --steps 50 --warmup 10 --no-cpu --no-lean 2>/dev/null | tail -1 > $out/pf_strong_one_rank.json
 timeout 300 python tools/pf_peer_probe.py 2>/dev/null > $out/pf_peer_probe.json
@@ -91,5 +99,5 @@ for f in ("final_bench_lines", "secondary_bench_lines", "config_table"):
         print("%-100s %12.0f %9.2f us k=%s frac=%s lean=%s" % ((d.get("config") or {}).get("workload", d["metric"])[:100], d["value"], d["ms_per_step"] * 1e3,
               r.get("avg_kernel_ms"), r.get("frac"), (d.get("lean") or {}).get("value")))
 PY
-cat $out/pf_forms_ab.jsonl; cat $out/grid_modes_probe.txt
+cat $out/pf_forms_ab.jsonl; cat $out/grid_modes_probe.txt; cat $out/grid_layout_ab.txt; cat $out/mi_pou_ab.txt
 head -6 $out/r05_kernel_stats.csv | cut -c1-200; cat $out/r05_pmc_traffic.json
