@@ -376,12 +376,12 @@ static int init_template_fused(mtfhip_batch *b, const mtfhip_sm_desc *sm, const 
 /* resetTrackers(reinit) for the patches of a grid: setCorners + initialize of every patch tracker in ONE launch -- the host half of the
  * reset (mirrors, staged corners; set_corners_core deferred) and k_template_init in region mode, which reads the patch corners from the
  * pinned staging buffer and lays out its own grid (as k_iclk_track does for the per-frame setRegion) */
-static int grid_reinit_fused(mtfhip_batch *b, const mtfhip_sm_desc *sm, const double *patches) {
+static int grid_reinit_fused(mtfhip_batch *b, const mtfhip_sm_desc *sm, const double *patches, bool layout_later = false) {
 	FLUSH_AM(b);   /* (the current points are about to be replaced: no apply_warp for them -- 7 us per frame when this was FLUSH) */
 	touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b));
 	TRY(check_sm(b, sm, "init_template"));
 	TRY(need_image(b));
-	TRY(set_corners_core(b, patches, false, true));
+	TRY(set_corners_core(b, layout_later ? nullptr : patches, false, true, layout_later));   /* (layout_later: b->deferred_gdesc / _region / _region_map are set, mtfhip_grid_reset) */
 	b->init_pix_vals = b->init_pix_grad = b->init_sim = b->init_grad = false;
 	const bool homg = b->desc.ssm == MTFHIP_SSM_HOMOGRAPHY;
 	RegionIngest rg{};
@@ -391,8 +391,16 @@ static int grid_reinit_fused(mtfhip_batch *b, const mtfhip_sm_desc *sm, const do
 	rg.lo_x = homg ? -0.5 : 1 - b->desc.resx / 2.0; rg.lo_y = homg ? -0.5 : 1 - b->desc.resy / 2.0;
 	rg.hi_x = homg ? 0.5 : b->desc.resx / 2.0; rg.hi_y = homg ? 0.5 : b->desc.resy / 2.0;
 	rg.resx = b->desc.resx; rg.resy = b->desc.resy; rg.force_unit_z = homg ? 0 : 1;
+	if (layout_later) {
+		const mtfhip_grid_desc &gd = b->deferred_gdesc;
+		rg.layout = 1;
+		rg.grid = GridLayoutHD{gd.grid_size_x, gd.grid_size_y, gd.patch_size_x, gd.patch_size_y, gd.dyn_patch_size ? 1 : 0, gd.patch_centroid_inside ? 1 : 0};
+		std::memcpy(rg.region_map, b->deferred_region_map, sizeof(rg.region_map));
+	}
 	const int rc = init_template_fused(b, sm, &rg);
-	set_corners_finish_deferred(b);   /* the host half of a deferred reset (a no-op when nothing was deferred) */
+	set_corners_finish_deferred(b);   /* the host half of a deferred reset (a no-op when nothing was deferred): under the kernel */
+	/* (init_template_fused took the template corners from the mirrors, which the deferred half has only now brought up to date) */
+	for (int t = 0; t < b->B; ++t) std::memcpy(&b->template_corners[8 * t], b->th[t].init_corners, sizeof(double) * 8);
 	b->warps_dirty = true;   /* the device slab still holds the previous frame's warps: whoever needs them next uploads the (identity) mirrors */
 	if (rc == MTFHIP_OK) { HIP_TRY(hipEventRecord(b->ev_a, b->ctx->stream)); b->stage_a_busy = true; }   /* the kernel reads the staging buffer */
 	return rc;
@@ -1083,10 +1091,24 @@ int mtfhip_grid_reset(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_gr
 	const size_t B = (size_t)b->B;
 	static thread_local std::vector<double> patches;
 	patches.resize(8 * B);
-	TRY(mtfhip_grid_layout(g, region, nullptr, patches.data()));
-	if (reinit) {   /* tracker->initialize(patch_corners): NT/ICLK.cc:71-128 etc. */
-		const char *e_gf = std::getenv("MTFHIP_GRID_FUSED");
-		if (!(e_gf && e_gf[0] == '0') && b->h_stage_a_dev && template_init_fused_ok(b, sm)) TRY(grid_reinit_fused(b, sm, patches.data()));
+	const char *e_gf = std::getenv("MTFHIP_GRID_FUSED"), *e_ld = std::getenv("MTFHIP_GRID_LAYOUT_DEV");
+	const bool fused = reinit && !(e_gf && e_gf[0] == '0') && b->h_stage_a_dev && template_init_fused_ok(b, sm);
+	/* fixed-size patches of an affine patch SSM: k_template_init lays its patch out itself and the host layout runs behind the launch */
+	const bool layout_later = fused && b->desc.ssm != MTFHIP_SSM_HOMOGRAPHY && !g->dyn_patch_size && !(e_ld && e_ld[0] == '0');
+	if (layout_later) {
+		M3 Wr;
+		if (!rect_to_quad(-0.5, -0.5, 0.5, 0.5, region, Wr)) return fail(MTFHIP_ERR_INVALID_ARG, "grid_layout: degenerate region corners");
+		b->deferred_gdesc = *g;
+		std::memcpy(b->deferred_region, region, sizeof(b->deferred_region));
+		std::memcpy(b->deferred_region_map, Wr.m, sizeof(b->deferred_region_map));
+		const int rc = grid_reinit_fused(b, sm, nullptr, true);
+		if (rc != MTFHIP_OK) { b->deferred_layout = false; return rc; }
+		if (b->deferred_patches.size() != 8 * B) return fail(MTFHIP_ERR_LOGIC, "grid_reset: the deferred layout did not run");
+		std::memcpy(patches.data(), b->deferred_patches.data(), sizeof(double) * 8 * B);
+	} else TRY(mtfhip_grid_layout(g, region, nullptr, patches.data()));
+	if (layout_later) {
+	} else if (reinit) {   /* tracker->initialize(patch_corners): NT/ICLK.cc:71-128 etc. */
+		if (fused) TRY(grid_reinit_fused(b, sm, patches.data()));
 		else {
 			TRY(mtfhip_ssm_set_corners(b, patches.data()));
 			TRY(mtfhip_batch_init_template(b, sm));

@@ -236,34 +236,7 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 	double q8lay[8];
 #pragma unroll
 	for (int q = 0; q < 8; ++q) q8lay[q] = 0.0;
-	if (lay) {
-		/* grid_patch_corners_hd (mtfhip_internal.h) with the cell's four grid points on four lanes: a point is four IEEE divisions (two in
-		 * lin_spaced_hd, two projective), ~1 us as a dependent chain of sixteen on a wave that has its SIMD to itself; lane q & 3 evaluates
-		 * point q -- the same expressions, so the same bits -- and v_readlane hands the eight coordinates to everybody */
-		const GridLayoutHD &gl = rg.grid;
-		const int extra = (gl.dyn_patch_size || gl.patch_centroid_inside) ? 1 : 0;
-		const int gresx = gl.grid_size_x + extra, gresy = gl.grid_size_y + extra, sub_x = gl.grid_size_x + 1;
-		const int prow = t / gl.grid_size_x, pcol = t % gl.grid_size_x, lq = tid & 3;
-		const int pid = extra ? (prow + (lq >> 1)) * sub_x + pcol + ((lq == 1 || lq == 2) ? 1 : 0) : t;   /* TL, TR, BR, BL of the cell | the patch's own point */
-		double gx, gy;
-		grid_pt_hd(rg.region_map, gresx, gresy, pid, &gx, &gy);
-		if (extra) {
-#pragma unroll
-			for (int q = 0; q < 4; ++q) { q8lay[2 * q] = readlane_f64(gx, q); q8lay[2 * q + 1] = readlane_f64(gy, q); }
-		}
-		if (!gl.dyn_patch_size) {
-			double cx = readlane_f64(gx, 0), cy = readlane_f64(gy, 0);
-			if (gl.patch_centroid_inside) {
-				cx = (q8lay[0] + q8lay[2] + q8lay[4] + q8lay[6]) / 4.0;
-				cy = (q8lay[1] + q8lay[3] + q8lay[5] + q8lay[7]) / 4.0;
-			}
-			const double half_x = gl.patch_size_x / 2.0, half_y = gl.patch_size_y / 2.0;
-			const double min_x = cx - half_x, min_y = cy - half_y;
-			const double max_x = min_x + gl.patch_size_x, max_y = min_y + gl.patch_size_y;
-			q8lay[0] = q8lay[6] = min_x; q8lay[2] = q8lay[4] = max_x;
-			q8lay[1] = q8lay[3] = min_y; q8lay[5] = q8lay[7] = max_y;
-		}
-	}
+	if (lay) grid_patch_corners_lanes(rg.grid, rg.region_map, t, q8lay);   /* (mtfhip_device.h) */
 	double ingest = 0.0;
 	if (region && tid < 16 && !(lay && tid < 8)) ingest = tid < 8 ? rg.corners[8 * (size_t)t + tid] : (AM == MTFHIP_AM_NCC ? rg.ncc[8 * (size_t)t + tid - 8] : 0.0);
 	double m0 = (AM == MTFHIP_AM_NCC && !region) ? ncc_sc_all[t * 8 + 0] : 0.0;

@@ -97,11 +97,17 @@ __global__ __launch_bounds__(kBlock) void k_template_init(BatchView bv, ImgView 
 	__shared__ double sCr[8];
 	double W0[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 	if (region) {
-		if (tid < 8) sCr[tid] = rg.corners[8 * (size_t)t + tid];
-		__syncthreads();
 		double q8[8];
+		if (rg.layout) {
+			/* (r05) the patch laid out HERE from the grid's region -- kernel arguments only: no PCIe read in front of everything, and the host
+			 * lays the patches out for its mirrors behind the launch (RegionIngest::layout, mtfhip_grid_reset) */
+			grid_patch_corners_lanes(rg.grid, rg.region_map, t, q8);
+		} else {
+			if (tid < 8) sCr[tid] = rg.corners[8 * (size_t)t + tid];
+			__syncthreads();
 #pragma unroll
-		for (int q = 0; q < 8; ++q) q8[q] = sCr[q];
+			for (int q = 0; q < 8; ++q) q8[q] = sCr[q];
+		}
 		const bool bad = !rect_to_quad_hd(rg.lo_x, rg.lo_y, rg.hi_x, rg.hi_y, q8, W0);
 		if (bad) {
 #pragma unroll

@@ -334,6 +334,36 @@ __device__ __forceinline__ void block_reduce_store(double *v, double *dst, doubl
 	}
 }
 
+/* grid_patch_corners_hd (mtfhip_internal.h) with the cell's four grid points on four lanes: a point is four IEEE divisions (two in
+ * lin_spaced_hd, two projective), ~1 us as a dependent chain of sixteen on a wave that has its SIMD to itself; lane q & 3 evaluates
+ * point q -- the same expressions, so the same bits -- and v_readlane hands the eight coordinates to everybody (every wave does the same) */
+__device__ __forceinline__ void grid_patch_corners_lanes(const GridLayoutHD &gl, const double *Wr, int t, double *q8) {
+	const int extra = (gl.dyn_patch_size || gl.patch_centroid_inside) ? 1 : 0;
+	const int gresx = gl.grid_size_x + extra, gresy = gl.grid_size_y + extra, sub_x = gl.grid_size_x + 1;
+	const int prow = t / gl.grid_size_x, pcol = t % gl.grid_size_x, lq = threadIdx.x & 3;
+	const int pid = extra ? (prow + (lq >> 1)) * sub_x + pcol + ((lq == 1 || lq == 2) ? 1 : 0) : t;   /* TL, TR, BR, BL of the cell | the patch's own point */
+	double gx, gy;
+	grid_pt_hd(Wr, gresx, gresy, pid, &gx, &gy);
+#pragma unroll
+	for (int q = 0; q < 8; ++q) q8[q] = 0.0;
+	if (extra) {
+#pragma unroll
+		for (int q = 0; q < 4; ++q) { q8[2 * q] = readlane_f64(gx, q); q8[2 * q + 1] = readlane_f64(gy, q); }
+	}
+	if (!gl.dyn_patch_size) {
+		double cx = readlane_f64(gx, 0), cy = readlane_f64(gy, 0);
+		if (gl.patch_centroid_inside) {
+			cx = (q8[0] + q8[2] + q8[4] + q8[6]) / 4.0;
+			cy = (q8[1] + q8[3] + q8[5] + q8[7]) / 4.0;
+		}
+		const double half_x = gl.patch_size_x / 2.0, half_y = gl.patch_size_y / 2.0;
+		const double min_x = cx - half_x, min_y = cy - half_y;
+		const double max_x = min_x + gl.patch_size_x, max_y = min_y + gl.patch_size_y;
+		q8[0] = q8[6] = min_x; q8[2] = q8[4] = max_x;
+		q8[1] = q8[3] = min_y; q8[5] = q8[7] = max_y;
+	}
+}
+
 /* steepest-descent row of one pixel: S values */
 template <int SSM>
 struct Row { double v[SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6]; };

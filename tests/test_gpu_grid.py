@@ -246,7 +246,7 @@ def test_grid_frame_patches_laid_out_by_the_kernel_equal_the_host_layout(gpu_ctx
     dyn, inside = MODES[mode]
     reg = REGIONS[region]
     frames = _frames(frame, 3, 21)
-    rec = {}
+    rec, reinit = {}, {}
     for dev in ("1", "0"):
         monkeypatch.setenv("MTFHIP_GRID_LAYOUT_DEV", dev)
         gpu_ctx.set_image(frame)
@@ -264,8 +264,16 @@ def test_grid_frame_patches_laid_out_by_the_kernel_equal_the_host_layout(gpu_ctx
             # ... and what the host mirrors hold afterwards: a plain update() from there
             n2, c2, m2 = b.grid_frame(gt.gd, gt.tracker.sm, None)
             out[-1] += [n2.copy(), c2.copy(), m2.copy()]
+        # resetTrackers(reinit = true) on the last frame: k_template_init lays its patches out itself in the same way
+        b.set_math_mode(mtf_amd.MATH_FAST)
+        pcs, pp = b.grid_reset(gt.gd, gt.tracker.sm, reg + 1.0, True)
+        n3, c3, m3 = b.grid_frame(gt.gd, gt.tracker.sm, None)
+        reinit[dev] = [pcs.copy(), pp.copy(), b.read(L.BUF_I0).copy(), b.read(L.BUF_J0).copy(), b.read(L.BUF_INIT_PTS).copy(), b.get_corners().copy(),
+                       n3.copy(), c3.copy(), m3.copy()]
         rec[dev] = out
         del gt
+    for x, y, what in zip(reinit["1"], reinit["0"], ("patch corners", "prev_pts", "I0", "J0", "init_pts", "corner mirrors", "n_iters", "corners", "centroids")):
+        assert np.array_equal(x, y), ("reinit", what)
     for k in range(len(frames)):
         for x, y, what in zip(rec["1"][k], rec["0"][k], ("n_iters", "corners", "centroids", "init_pts", "init_hxy", "init_z", "state", "corner mirrors",
                                                        "n_iters of the next update", "corners of the next update", "centroids of the next update")):
