@@ -1618,3 +1618,15 @@ def test_one_launch_per_pass_equals_two_launch_loop(gpu_ctx, frame, frame2, B, r
             assert ra["f"] == rb["f"] and ra["undo"] == rb["undo"]
     for k in range(7, len(out["0"])):
         assert np.array_equal(out["0"][k], out["1"][k]), k
+
+
+def test_frames_beyond_the_samplers_offset_arithmetic_are_refused(gpu_ctx, frame):
+    """the candidate scorer multiplies row x pitch with the 24-bit multiplier (r05) and every sampler keeps texel offsets in 32 bits: a
+    borrowed frame whose pitch or height reaches 2^24, or whose extent reaches 4 GiB, is refused when it is handed over, not sampled"""
+    import torch
+    t = torch.zeros(64, 64, dtype=torch.float32, device="cuda:0")
+    for h, w, stride in ((4, 8, 1 << 24), (1 << 24, 8, 8), (40000, 30000, 30000)):
+        with pytest.raises(mtf_amd.MtfHipError, match="exceed"):
+            gpu_ctx.set_image_device(t.data_ptr(), h, w, stride, keep=t)
+    gpu_ctx.set_image_device(t.data_ptr(), 64, 64, keep=t)   # (a legal one is still taken)
+    gpu_ctx.set_image(frame)
