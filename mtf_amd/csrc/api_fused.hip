@@ -377,11 +377,15 @@ static int init_template_fused(mtfhip_batch *b, const mtfhip_sm_desc *sm, const 
  * reset (mirrors, staged corners; set_corners_core deferred) and k_template_init in region mode, which reads the patch corners from the
  * pinned staging buffer and lays out its own grid (as k_iclk_track does for the per-frame setRegion) */
 static int grid_reinit_fused(mtfhip_batch *b, const mtfhip_sm_desc *sm, const double *patches, bool layout_later = false) {
+	static const bool dbg = std::getenv("MTFHIP_TRACK_DEBUG_TIMING") != nullptr;
+	const auto t0 = std::chrono::steady_clock::now();
 	FLUSH_AM(b);   /* (the current points are about to be replaced: no apply_warp for them -- 7 us per frame when this was FLUSH) */
 	touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b));
 	TRY(check_sm(b, sm, "init_template"));
 	TRY(need_image(b));
+	const auto t1 = std::chrono::steady_clock::now();
 	TRY(set_corners_core(b, layout_later ? nullptr : patches, false, true, layout_later));   /* (layout_later: b->deferred_gdesc / _region / _region_map are set, mtfhip_grid_reset) */
+	const auto t2 = std::chrono::steady_clock::now();
 	b->init_pix_vals = b->init_pix_grad = b->init_sim = b->init_grad = false;
 	const bool homg = b->desc.ssm == MTFHIP_SSM_HOMOGRAPHY;
 	RegionIngest rg{};
@@ -398,7 +402,15 @@ static int grid_reinit_fused(mtfhip_batch *b, const mtfhip_sm_desc *sm, const do
 		std::memcpy(rg.region_map, b->deferred_region_map, sizeof(rg.region_map));
 	}
 	const int rc = init_template_fused(b, sm, &rg);
+	const auto t3 = std::chrono::steady_clock::now();
 	set_corners_finish_deferred(b);   /* the host half of a deferred reset (a no-op when nothing was deferred): under the kernel */
+	if (dbg) {
+		const auto t4 = std::chrono::steady_clock::now();
+		auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::micro>(c - a).count(); };
+		static double a1 = 0, a2 = 0, a3 = 0, a4 = 0; static int n = 0;
+		a1 += us(t0, t1); a2 += us(t1, t2); a3 += us(t2, t3); a4 += us(t3, t4);
+		if (++n % 100 == 0) { std::fprintf(stderr, "[grid_reinit] flush + checks %.1f us, set_corners (deferred) %.1f, init_template_fused (launch) %.1f, deferred host half %.1f (mean of 100)\n", a1 / 100, a2 / 100, a3 / 100, a4 / 100); a1 = a2 = a3 = a4 = 0; }
+	}
 	/* (init_template_fused took the template corners from the mirrors, which the deferred half has only now brought up to date) */
 	for (int t = 0; t < b->B; ++t) std::memcpy(&b->template_corners[8 * t], b->th[t].init_corners, sizeof(double) * 8);
 	b->warps_dirty = true;   /* the device slab still holds the previous frame's warps: whoever needs them next uploads the (identity) mirrors */
@@ -1105,15 +1117,15 @@ int mtfhip_grid_reset(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_gr
 		if (rc != MTFHIP_OK) { b->deferred_layout = false; return rc; }
 		if (b->deferred_patches.size() != 8 * B) return fail(MTFHIP_ERR_LOGIC, "grid_reset: the deferred layout did not run");
 		std::memcpy(patches.data(), b->deferred_patches.data(), sizeof(double) * 8 * B);
-	} else TRY(mtfhip_grid_layout(g, region, nullptr, patches.data()));
-	if (layout_later) {
-	} else if (reinit) {   /* tracker->initialize(patch_corners): NT/ICLK.cc:71-128 etc. */
-		if (fused) TRY(grid_reinit_fused(b, sm, patches.data()));
+	} else {
+		TRY(mtfhip_grid_layout(g, region, nullptr, patches.data()));
+		if (!reinit) TRY(mtfhip_batch_set_region(b, patches.data(), sm));   /* tracker->setRegion(patch_corners) */
+		else if (fused) TRY(grid_reinit_fused(b, sm, patches.data()));       /* tracker->initialize(patch_corners): NT/ICLK.cc:71-128 etc. */
 		else {
 			TRY(mtfhip_ssm_set_corners(b, patches.data()));
 			TRY(mtfhip_batch_init_template(b, sm));
 		}
-	} else TRY(mtfhip_batch_set_region(b, patches.data(), sm));   /* tracker->setRegion(patch_corners) */
+	}
 	if (patch_corners) std::memcpy(patch_corners, patches.data(), sizeof(double) * 8 * B);
 	/* :387 getCentroid(prev_pts[id], tracker->getRegion()): both resets leave the tracker's region = the patch corners */
 	if (prev_pts) for (size_t t = 0; t < B; ++t) centroid_f(prev_pts + 2 * t, &patches[8 * t]);
