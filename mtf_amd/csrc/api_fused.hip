@@ -750,8 +750,9 @@ static int mi_enqueue_fast(mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPl
 		TimedScope tsc(b->ctx, "mi_pass1");
 		launch_mi_pass_hist(bv, b->ctx->img, fp, b->d_mi_part, nblk1, b->mi_row_len, st);
 	}
-	launch_mi_tables_iter(bv, 8, b->desc.mi_pre_seed, b->mi_hist_norm, fp.hk == 1 ? 1 : 0, b->d_mi_part, nblk1, b->mi_row_len, b->d_mi_tb, b->d_mi_f, st);
-	if (fp.hk <= 1) launch_mi_poly_tables(bv, b->d_mi_tb, b->mi_hist_norm, fp.hk == 1 ? 1 : 0, b->d_mi_poly, st);   /* (the dense Hessian kinds read the tables themselves) */
+	/* (the dense Hessian kinds read the tables themselves: no polynomial tables) */
+	if (fp.hk <= 1) launch_mi_tables_poly(bv, 8, b->desc.mi_pre_seed, b->mi_hist_norm, fp.hk == 1 ? 1 : 0, b->d_mi_part, nblk1, b->mi_row_len, b->d_mi_tb, b->d_mi_f, b->d_mi_poly, st);
+	else launch_mi_tables_iter(bv, 8, b->desc.mi_pre_seed, b->mi_hist_norm, fp.hk == 1 ? 1 : 0, b->d_mi_part, nblk1, b->mi_row_len, b->d_mi_tb, b->d_mi_f, st);
 	{
 		TimedScope tsc(b->ctx, "mi_pass2");
 		launch_mi_pass_grad_hess(bv, b->ctx->img, fp, b->d_mi_part, nblk, st);

@@ -178,41 +178,7 @@ __global__ __launch_bounds__(kBlock) void k_mi_hist_finish(int nb, double pre_se
 __global__ __launch_bounds__(kBlock) void k_mi_tables_iter(int nb, double pre_seed, double norm_mult, int with_self, const double *partials,
 	int nblk, int row_len, double *tb_all, double *f_out) {
 	__shared__ double red[kBlock];
-	const int t = blockIdx.x;
-	double *tb = tb_all + (size_t)t * MI_SIZE;
-	const double *p = partials + (size_t)t * nblk * row_len;
-	const double hist_seed = nb * pre_seed;
-	for (int k = threadIdx.x; k < nb + nb * nb * (with_self ? 2 : 1); k += kBlock) {
-		const double s = column_sum(p + k, nblk, row_len);
-		if (k < nb) {
-			const double hv = (s + hist_seed) * norm_mult;
-			tb[MI_HIST_CURR + k] = hv; tb[MI_LOG_CURR + k] = log(hv);
-		} else if (k < nb + nb * nb) {
-			const int q = k - nb, r = q / nb, c = q % nb;
-			const double jv = (s + pre_seed) * norm_mult;
-			tb[MI_JOINT + r * MI_NB + c] = jv; tb[MI_JOINT_LOG + r * MI_NB + c] = log(jv);
-		} else {
-			const int q = k - nb - nb * nb, r = q / nb, c = q % nb;
-			tb[MI_SELF_JOINT + r * MI_NB + c] = (s + pre_seed) * norm_mult;
-		}
-	}
-	__syncthreads();
-	double part = 0;
-	for (int q = threadIdx.x; q < nb * nb; q += kBlock) {
-		const int r = q / nb, c = q % nb;
-		const double jv = tb[MI_JOINT + r * MI_NB + c], lg = tb[MI_JOINT_LOG + r * MI_NB + c];
-		part += jv * (lg - tb[MI_LOG_CURR + r] - tb[MI_LOG_INIT + c]);
-		tb[MI_T_CURR + r * MI_NB + c] = 1 + lg - tb[MI_LOG_CURR + r];
-		tb[MI_T_INIT + r * MI_NB + c] = 1 + tb[MI_JOINT_LOG + c * MI_NB + r] - tb[MI_LOG_INIT + r];   /* (init, curr) indexing */
-		if (with_self) tb[MI_T_SELF + r * MI_NB + c] = 1 + log(tb[MI_SELF_JOINT + r * MI_NB + c]) - tb[MI_LOG_CURR + r];
-	}
-	red[threadIdx.x] = part;
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		double s = 0;
-		for (int i = 0; i < kBlock; ++i) s += red[i];
-		f_out[t] = s;
-	}
+	mi_tables_iter_body(nb, pre_seed, norm_mult, with_self, partials, nblk, row_len, tb_all, f_out, red);
 }
 /* gradient-factor tables refreshed by updateCurrGrad / updateInitGrad (MI.cc:399-403, 427-431) */
 __global__ __launch_bounds__(kBlock) void k_mi_factor(int nb, int curr, double *tb_all) {

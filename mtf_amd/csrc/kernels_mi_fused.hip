@@ -269,8 +269,11 @@ __global__ __launch_bounds__(kBlock) void k_mi_finish_fast(BatchView bv, mtfhip_
  * target, 2 x 64 x 12 + 8 x 5 coefficients of 16 multiply-adds each -- negligible next to the passes, and it runs once per target
  * instead of once per workgroup of pass 2.  Tables are indexed with (bin + 1) and have a zero border of one bin below and three above
  * (window rows fl .. fl + 3 for fl <= 7): the taps on the non-existent bins -1, 8, 9 contribute nothing (MI.cc:114-117). */
-__global__ __launch_bounds__(kBlock) void k_mi_poly_tables(const double *tb_all, double hist_norm, int with_self, double *poly_all) {
-	__shared__ double Tc[12 * 12], Ti[12 * 12], Th[12 * 12];
+/* POLY_ONLY = false (k_mi_tables_poly, r05): k_mi_tables_iter's work first -- block rows of pass 1 -> histograms, logs, similarity, the
+ * gradient-factor tables (mi_tables_iter_body) -- then, behind a barrier (the same workgroup wrote the tables it now reads), the
+ * polynomial tables: one launch between the passes instead of two (6.3 + 5.7 us each with a launch gap, of a 430 us iteration) */
+template <bool POLY_ONLY>
+__device__ __forceinline__ void mi_poly_tables_body(const double *tb_all, double hist_norm, int with_self, double *poly_all, double *Tc, double *Ti, double *Th) {
 	const int t = blockIdx.x;
 	const double *tb = tb_all + (size_t)t * MI_SIZE;
 	for (int k = threadIdx.x; k < 144; k += kBlock) {
@@ -325,6 +328,19 @@ __global__ __launch_bounds__(kBlock) void k_mi_poly_tables(const double *tb_all,
 		out[kMiPolyH + k] = acc * hist_norm;
 	}
 }
+__global__ __launch_bounds__(kBlock) void k_mi_poly_tables(const double *tb_all, double hist_norm, int with_self, double *poly_all) {
+	__shared__ double Tc[12 * 12], Ti[12 * 12], Th[12 * 12];
+	mi_poly_tables_body<true>(tb_all, hist_norm, with_self, poly_all, Tc, Ti, Th);
+}
+__global__ __launch_bounds__(kBlock) void k_mi_tables_poly(int nb, double pre_seed, double norm_mult, int with_self, const double *partials, int nblk, int row_len,
+	double *tb_all, double *f_out, double *poly_all) {
+	__shared__ double red[kBlock];
+	__shared__ double Tc[12 * 12], Ti[12 * 12], Th[12 * 12];
+	mi_tables_iter_body(nb, pre_seed, norm_mult, with_self, partials, nblk, row_len, tb_all, f_out, red);
+	__threadfence_block();
+	__syncthreads();
+	mi_poly_tables_body<false>(tb_all, norm_mult, with_self, poly_all, Tc, Ti, Th);
+}
 
 /* ===================================================================== */
 /* launchers                                                              */
@@ -370,6 +386,10 @@ void launch_mi_score_candidates(const BatchView &bv, const ImgView &im, const Mi
 }
 void launch_mi_poly_tables(const BatchView &bv, const double *tb, double hist_norm, int with_self, double *poly, hipStream_t st) {
 	MTFHIP_LAUNCH(k_mi_poly_tables, dim3(bv.B), dim3(kBlock), 0, st, tb, hist_norm, with_self, poly);
+}
+void launch_mi_tables_poly(const BatchView &bv, int nb, double pre_seed, double norm_mult, int with_self, const double *partials, int nblk, int row_len,
+	double *tb, double *f_out, double *poly, hipStream_t st) {
+	MTFHIP_LAUNCH(k_mi_tables_poly, dim3(bv.B), dim3(kBlock), 0, st, nb, pre_seed, norm_mult, with_self, partials, nblk, row_len, tb, f_out, poly);
 }
 int mi_poly_size() { return kMiPolySize; }
 /* pass 2 is instantiated per (SSM, channels) in its own translation unit: kernels_mi_pass2_*.hip */

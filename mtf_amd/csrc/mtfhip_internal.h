@@ -349,6 +349,9 @@ struct MiFastPlan {
 	const double *poly = nullptr;   /* [B][mi_poly_size()]: the tables as per-class polynomials (launch_mi_poly_tables), read by pass 2 */
 };
 void launch_mi_poly_tables(const BatchView &bv, const double *tb, double hist_norm, int with_self, double *poly, hipStream_t st);
+/* launch_mi_tables_iter + launch_mi_poly_tables in one launch (hist_norm is the tables' norm_mult) */
+void launch_mi_tables_poly(const BatchView &bv, int nb, double pre_seed, double norm_mult, int with_self, const double *partials, int nblk, int row_len,
+	double *tb, double *f_out, double *poly, hipStream_t st);
 int mi_poly_size();
 void launch_mi_pass_hist(const BatchView &bv, const ImgView &im, const MiFastPlan &pl, double *partials, int nblk, int row_len, hipStream_t st);
 void launch_mi_pass_grad_hess(const BatchView &bv, const ImgView &im, const MiFastPlan &pl, double *partials, int nblk, hipStream_t st);
