@@ -850,11 +850,20 @@ def secondary_workload(args):
                 cg = host.CppGridTracker(grid_size=16, patch_size=25, patch_sm=mtf_amd.SM_ICLK, patch_am=mtf_amd.AM_NCC, patch_ssm=mtf_amd.SSM_AFFINE,
                                          grid_ssm=mtf_amd.SSM_HOMOGRAPHY, reset_at_each_frame=2, max_iters=args.grid_iters, epsilon=-1.0, hess_type=0, device=local_rank)
                 cg.set_image(frame0); cg.initialize(region); cg.set_image(frame1)
-                out["config"]["cpp_driver"] = {"frame_us_c_abi_loop": cg.bench_frames(region, max(args.steps, 100), 0),
+                cpp_us = cg.bench_frames(region, args.steps, 0)     # (its own untimed frames first, then EXACTLY args.steps frames between two clock reads; every frame ends with the host holding its results)
+                out["config"]["cpp_driver"] = {"frame_us_c_abi_loop": cpp_us,
                                                "frame_us_grid_update_setregion_mode": cg.bench_frames(region, max(args.steps, 100), 1),
                                                "note": "mtfhip_grid_frame in a C++ loop | mtf::hip::Grid::update() = that launch + the all-points least-squares "
                                                        "estimator on the host + resetTrackers(setRegion), reset_at_each_frame = 2"}
                 del cg
+                if world == 1 and cpp_us > 0:
+                    # r04 verdict item 6: no Python wrapper in the timed path -- the line's value is the C++ loop's; the Python loop's figure stays beside it
+                    out["config"]["python_wrapper_loop"] = {"value": out["value"], "frame_us": frame_us}
+                    out["value"] = 256 * args.grid_iters / (cpp_us * 1e-6)
+                    out["ms_per_step"] = cpp_us * 1e-3
+                    out["config"]["frame_us"] = cpp_us
+                    out["config"]["kernel_share_of_frame"] = kms * 1e3 / cpp_us
+                    out["config"]["timed_by"] = "mtfhost_grid_bench: mtfhip_grid_frame in a C++ loop (libmtfhost.so), steady_clock around exactly --steps frames"
             except Exception as e:   # (the host libraries are optional for this line)
                 out["config"]["cpp_driver"] = {"error": str(e)[:200]}
         if rank == 0 and not args.no_cpu:
