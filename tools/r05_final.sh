@@ -57,7 +57,7 @@ timeout 300 python tools/grid_modes_probe.py 2>/dev/null > $out/grid_modes_probe
 # the grid frame with the host layout in front of the launch / the kernel's own layout (C++ loop and Python), and the frame's host-side stamps
 : > $out/grid_layout_ab.txt
 for d in 1 0 1 0; do MTFHIP_GRID_LAYOUT_DEV=$d timeout 300 python bench.py --workload grid --steps 300 --warmup 20 --no-cpu 2>/dev/null | tail -1 |
-  python -c "import json,sys; d=json.loads(sys.stdin.read()); c=d['config']; print('MTFHIP_GRID_LAYOUT_DEV=$d frame %.2f us kernel %.2f us; C++ loop %.2f us, Grid::update() %.2f us' % (c['frame_us'], c['kernel_us'], c['cpp_driver']['frame_us_c_abi_loop'], c['cpp_driver']['frame_us_grid_update_setregion_mode']))" >> $out/grid_layout_ab.txt; done
+  python -c "import json,sys; d=json.loads(sys.stdin.read()); c=d['config']; print('MTFHIP_GRID_LAYOUT_DEV=$d frame %.2f us kernel %.2f us; C++ loop %.2f us, Grid::update() %.2f us' % ((c.get('python_wrapper_loop') or c)['frame_us'], c['kernel_us'], c['cpp_driver']['frame_us_c_abi_loop'], c['cpp_driver']['frame_us_grid_update_setregion_mode']))" >> $out/grid_layout_ab.txt; done
 MTFHIP_TRACK_DEBUG_TIMING=1 timeout 300 python tools/grid_modes_probe.py 2>&1 | grep track_region | tail -3 >> $out/grid_layout_ab.txt
 # MI with partition of unity (the shipped mi_pou = 1): histogram as the joint histogram's row sums / as its own block product
 : > $out/mi_pou_ab.txt
