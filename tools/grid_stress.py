@@ -21,3 +21,24 @@ for k in range(6000):
     if not (np.array_equal(c, ref[i][0]) and np.array_equal(cen, ref[i][1]) and np.array_equal(gt.n_iters, ref[i][2])):
         bad += 1
 print("frames 6000 mismatches", bad)
+# r05: the same through mtfhip_grid_frame (the kernel lays its own patch out from the grid's region, the host lays the patches out behind the
+# launch) with a fused re-initialisation (mtfhip_grid_reset, reinit) every 50 frames: every frame and every re-initialised template against
+# the first occurrence of its (region, frame-since-reinit) pair
+b, gd, sm = gt.tracker.batch, gt.gd, gt.tracker.sm
+regions = [region + np.array([[dx], [dy]]) for dx, dy in ((0, 0), (1.25, -0.5), (-2.0, 0.75))]
+ref2, bad2, n2 = {}, 0, 0
+ctx.set_image(f0); b.grid_reset(gd, sm, regions[0], True); ctx.set_image(f1)
+for k in range(3000):
+    i = k % 3
+    if k % 50 == 0:
+        ctx.set_image(f0); pcs_r, pp = b.grid_reset(gd, sm, regions[i], True); ctx.set_image(f1)
+        key, val = ("reinit", i), (pcs_r.copy(), pp.copy(), b.read(mtf_amd._lib.BUF_I0).copy())
+    else:
+        n, c, m = b.grid_frame(gd, sm, regions[i])
+        key, val = ("frame", i, (k // 50) % 3), (n.copy(), c.copy(), m.copy())
+    if key in ref2:
+        n2 += 1
+        if not all(np.array_equal(x, y) for x, y in zip(val, ref2[key])): bad2 += 1
+    else:
+        ref2[key] = val
+print("grid_frame / grid_reset(reinit) frames compared", n2, "mismatches", bad2)
