@@ -543,7 +543,7 @@ int protect_stale(mtfhip_batch *b, bool w0, bool wt) {
 /* replays the recorded calls through the un-fused kernels, in the order they were made */
 int lazy_flush(mtfhip_batch *b, bool pts) {
 	mtfhip_batch::Lazy &L = b->lz;
-	if (b->init_mirror_seq) TRY(pull_init_mirrors(b));   /* (a fused template initialisation left its small results in a pinned record) */
+	if (b->init_mirror_seq && !b->hold_init_pull) TRY(pull_init_mirrors(b));   /* (a fused template initialisation left its small results in a pinned record) */
 	/* whatever follows a full flush may launch a kernel that reads the current points; so may the replayed calls */
 	if (pts || L.pv || L.gp || L.pg || L.pj) TRY(ensure_pts(b));
 	if (!L.any()) return MTFHIP_OK;

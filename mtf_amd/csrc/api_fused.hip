@@ -379,6 +379,10 @@ static int init_template_fused(mtfhip_batch *b, const mtfhip_sm_desc *sm, const 
 static int grid_reinit_fused(mtfhip_batch *b, const mtfhip_sm_desc *sm, const double *patches, bool layout_later = false) {
 	static const bool dbg = std::getenv("MTFHIP_TRACK_DEBUG_TIMING") != nullptr;
 	const auto t0 = std::chrono::steady_clock::now();
+	/* a record of the PREVIOUS fused initialisation that nobody has asked for (reset-every-frame mode: mtfhip_grid_frame holds it back) is
+	 * superseded by this one: every mirror it would fill is rewritten by the new record -- not folding it in saves the host 1 KB per patch of
+	 * cold reads (12 us per frame at 256 patches).  With recorded interface calls pending the flush below still wants it. */
+	if (b->init_mirror_seq && !b->lz.any()) b->init_mirror_seq = 0;
 	FLUSH_AM(b);   /* (the current points are about to be replaced: no apply_warp for them -- 7 us per frame when this was FLUSH) */
 	touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b));
 	TRY(check_sm(b, sm, "init_template"));
@@ -1092,7 +1096,19 @@ int mtfhip_grid_frame(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_gr
 	static thread_local std::vector<int> iters;
 	out.resize(8 * B); iters.resize(B);
 	if (region) TRY(track_region_impl(b, sm, region, n_iters ? n_iters : iters.data(), out.data(), g));
-	else TRY(mtfhip_batch_track(b, sm, n_iters ? n_iters : iters.data(), out.data()));
+	else {
+		/* reset-every-frame mode: this call follows mtfhip_grid_reset(reinit), whose k_template_init may still be running.  The one-launch
+		 * loop kernel reads nothing of that kernel's host record, so it is enqueued behind it right away (r05: the host used to wait for the
+		 * record and copy 1 KB per patch first -- launch latency + 256 KB of memcpy exposed in every frame); the record is folded into the
+		 * mirrors by the next call that flushes without this flag.  MTFHIP_GRID_HOLD_PULL=0: the r05 first form. */
+		const char *e_hp = std::getenv("MTFHIP_GRID_HOLD_PULL");
+		const bool hold = b->init_mirror_seq != 0 && !(e_hp && e_hp[0] == '0') && b->h_stage_b_dev && b->h_pub_dev && b->desc.am != MTFHIP_AM_MI && !sm->leven_marq &&
+			iclk_one_launch(b, sm) && second_order_term(sm, b->desc.am) < 0 && ((37 * sizeof(double) * B) % 16) == 0;
+		b->hold_init_pull = hold;
+		const int rc = mtfhip_batch_track(b, sm, n_iters ? n_iters : iters.data(), out.data());
+		b->hold_init_pull = false;
+		if (rc != MTFHIP_OK) return rc;
+	}
 	if (corners) std::memcpy(corners, out.data(), sizeof(double) * 8 * B);
 	if (centroids) for (size_t t = 0; t < B; ++t) centroid_f(centroids + 2 * t, &out[8 * t]);
 	return MTFHIP_OK;
@@ -1164,7 +1180,10 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 		/* (h_stage_b needs no guard: every return path below has waited for the device to finish this call's work) */
 		std::memcpy(b->h_stage_b + 45 * sizeof(double) * (size_t)b->B, b->h_stage_a + 45 * sizeof(double) * (size_t)b->B, 9 * sizeof(double) * (size_t)b->B);
 		fill_stage(b, b->h_stage_b, nullptr, 1, true);
-		if (b->h_stage_b_dev) launch_ingest_host(b->h_stage_b_dev, b->d_slab, b->slab_bytes, st);
+		/* (a pending fused initialisation, hold_init_pull: the mirrors' NCC scalars are older than d_ncc, which k_template_init wrote) */
+		const bool keep_ncc = b->hold_init_pull && b->init_mirror_seq != 0;
+		if (b->h_stage_b_dev) launch_ingest_host(b->h_stage_b_dev, b->d_slab, b->slab_bytes, st, keep_ncc ? 37 * sizeof(double) * (size_t)b->B : 0, keep_ncc ? 8 * sizeof(double) * (size_t)b->B : 0);
+		else if (keep_ncc) return fail(MTFHIP_ERR_LOGIC, "track: a held template-initialisation record needs the host-visible staging buffer");
 		else HIP_TRY(hipMemcpyAsync(b->d_slab, b->h_stage_b, b->slab_bytes, hipMemcpyHostToDevice, st));
 	}
 	b->warps_dirty = false;   /* the slab carries the warps */

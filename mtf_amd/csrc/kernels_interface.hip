@@ -551,9 +551,12 @@ __global__ __launch_bounds__(256) void k_publish_host(const unsigned *src, unsig
 }
 /* the other direction: the staged state slab is read from pinned host memory by the kernel itself (16 bytes per lane, one PCIe
  * round trip) instead of through a copy-engine transfer and the cross-queue dependency that follows it */
-__global__ __launch_bounds__(256) void k_ingest_host(const uint4 *src_host, uint4 *dst, unsigned n16, const unsigned *src_tail, unsigned *dst_tail, unsigned n_tail) {
+/* [skip_lo, skip_hi): 16-byte units that are NOT copied (a section of the slab whose device copy is newer than the host's: the NCC scalars
+ * behind a fused template initialisation whose record the host has not folded in yet) */
+__global__ __launch_bounds__(256) void k_ingest_host(const uint4 *src_host, uint4 *dst, unsigned n16, const unsigned *src_tail, unsigned *dst_tail, unsigned n_tail,
+	unsigned skip_lo, unsigned skip_hi) {
 	const unsigned i = blockIdx.x * 256 + threadIdx.x;
-	if (i < n16) dst[i] = src_host[i];
+	if (i < n16 && !(i >= skip_lo && i < skip_hi)) dst[i] = src_host[i];
 	if (i < n_tail) dst_tail[i] = src_tail[i];
 }
 /* fixed-order sum of the per-workgroup rows: out[t][k] = sum_b partials[t][b][k] */
@@ -695,12 +698,12 @@ void launch_publish_host(const void *src, void *dst_host, size_t bytes, int *cou
 	MTFHIP_LAUNCH(k_publish_host, dim3(blocks), dim3(256), 0, st, static_cast<const unsigned *>(src), static_cast<unsigned *>(dst_host),
 		n_words, count, flag_host, seq, publish_fenced());
 }
-void launch_ingest_host(const void *src_host, void *dst, size_t bytes, hipStream_t st) {
+void launch_ingest_host(const void *src_host, void *dst, size_t bytes, hipStream_t st, size_t skip_off, size_t skip_len) {
 	const unsigned n16 = (unsigned)(bytes / 16), n_tail = (unsigned)((bytes % 16) / 4);   /* (the slab is a multiple of 4 bytes) */
 	const unsigned blocks = std::max(1u, (std::max(n16, n_tail) + 255) / 256);
 	MTFHIP_LAUNCH(k_ingest_host, dim3(blocks), dim3(256), 0, st, static_cast<const uint4 *>(src_host), static_cast<uint4 *>(dst), n16,
 		reinterpret_cast<const unsigned *>(static_cast<const char *>(src_host) + 16 * (size_t)n16),
-		reinterpret_cast<unsigned *>(static_cast<char *>(dst) + 16 * (size_t)n16), n_tail);
+		reinterpret_cast<unsigned *>(static_cast<char *>(dst) + 16 * (size_t)n16), n_tail, (unsigned)(skip_off / 16), (unsigned)((skip_off + skip_len) / 16));
 }
 void launch_finish_rows(double *partials, int nblk, int row_len, double *out, int B, hipStream_t st) {
 	MTFHIP_LAUNCH(k_finish_rows, dim3(B, (row_len + 127) / 128), dim3(128), 0, st, partials, nblk, row_len, out);

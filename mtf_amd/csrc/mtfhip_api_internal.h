@@ -250,6 +250,10 @@ struct mtfhip_batch {
 	double *d_trace = nullptr; int trace_cap = 0;   /* [B][trace_cap][kTraceStride] debug trace of the device-side loop, or NULL */
 	/* NCC: a fused iteration updated the scalars (It_mean, a, b, f) on the host only; the un-fused kernels read d_ncc */
 	bool ncc_host_newer = false;
+	/* mtfhip_grid_frame behind a fused re-initialisation (reset-every-frame mode): the loop kernel is ENQUEUED behind k_template_init instead
+	 * of the host first waiting for that kernel's record and folding 1 KB per patch into its mirrors -- lazy_flush leaves the record
+	 * pending while this is set, and the slab upload of the call leaves the device's NCC scalars (the kernel's own) alone */
+	bool hold_init_pull = false;
 	size_t slab_bytes = 0, slab_dbl_bytes = 0;
 	double *h_acc = nullptr; /* pinned */
 	/* Zero-copy read-back of the reduced rows: h_acc is host-coherent pinned memory the reduction kernel writes directly

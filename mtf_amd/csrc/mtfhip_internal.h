@@ -481,7 +481,8 @@ void launch_sample_candidates(const BatchView &bv, const ImgView &im, const doub
 constexpr int kIclkTrackMaxPix = 8 * kBlock;   /* (the grid points of a thread's pixels stay in registers: k_iclk_track) */
 bool launch_iclk_track(const BatchView &bv, const ImgView &im, const mtfhip_sm_desc &sm, const TrackState &ts,
 	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, int fast_math, const HostPublish &pub, const RegionIngest &rg, hipStream_t st);
-void launch_ingest_host(const void *src_host, void *dst, size_t bytes, hipStream_t st);
+/* skip_off / skip_len (multiples of 16 bytes): a section that is left as it is on the device */
+void launch_ingest_host(const void *src_host, void *dst, size_t bytes, hipStream_t st, size_t skip_off = 0, size_t skip_len = 0);
 void launch_fused_mc(const BatchView &bv, const ImgView &im, const FusedArgs &fa, double *partials, int nblk, hipStream_t st);   /* bv.C > 1 */
 /* a small patch's whole nt::ICLK::initialize in one launch (kernels_init.hip): template sample, gradient, steepest-descent rows,
  * moments, constant self Hessian and its inverse; the small results also go to a pinned host record of kInitRec doubles per target

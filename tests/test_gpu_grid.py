@@ -210,7 +210,11 @@ def test_fused_template_init_equals_call_by_call(oracle, gpu_ctx, frame, am, ssm
         n1 = g.n_iters.copy()
         r2 = g.update()            # a whole frame: track, fit, re-initialise on the new grid (fused or not), ...
         c3, _ = g.update_patches() # ... and track from the re-initialised templates
-        out[fused] = (arrays, H0, c1.copy(), n1, r2.copy(), c3.copy())
+        r4 = g.update(); r5 = g.update()   # two more frames: each re-initialisation supersedes the record of the one before (never folded in) ...
+        # ... and the getters that read the host mirrors still see the LAST template's (the pending record is folded in when they ask)
+        H5 = b.cmpt_self_hessian(L.BUF_J0).copy() if am == L.AM_SSD else None
+        f5 = np.asarray(b.get_similarity()).copy()
+        out[fused] = (arrays, H0, c1.copy(), n1, r2.copy(), c3.copy(), r4.copy(), r5.copy(), H5, f5)
         b.close()
     for x, y, what in zip(out["0"][0], out["1"][0], ("I0", "It", "dI0_dx", "J0", "init_pts", "curr_pts", "state", "corners")):
         assert np.array_equal(x, y), what
@@ -220,6 +224,11 @@ def test_fused_template_init_equals_call_by_call(oracle, gpu_ctx, frame, am, ssm
     np.testing.assert_allclose(out["1"][2], out["0"][2], rtol=0, atol=1e-8)
     np.testing.assert_allclose(out["1"][4], out["0"][4], rtol=0, atol=1e-6)
     np.testing.assert_allclose(out["1"][5], out["0"][5], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(out["1"][6], out["0"][6], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(out["1"][7], out["0"][7], rtol=0, atol=1e-5)
+    if out["0"][8] is not None:
+        np.testing.assert_allclose(out["1"][8], out["0"][8], rtol=1e-7)   # (the two forms sit on regions that agree to ~1e-6 px by now)
+    np.testing.assert_allclose(out["1"][9], out["0"][9], rtol=1e-7, atol=1e-9)
     # and against the oracle's own initialize + update of one patch
     gpu_ctx.set_image(frame)
     g = GridTracker(gpu_ctx, grid_size=gs, patch_size=ps, am=am, ssm=ssm, max_iters=15, epsilon=1e-5)
