@@ -337,7 +337,7 @@ static bool template_init_fused_ok(const mtfhip_batch *b, const mtfhip_sm_desc *
 	return sm->sm == MTFHIP_SM_ICLK && const_h && sm->chained_warp && !sm->sec_ord_hess && b->C == 1 && b->N <= kTemplateInitMaxPix &&
 		b->h_flag_dev != nullptr && b->ctx->img.data != nullptr && b->ctx->img.channels == 1;
 }
-static int init_template_fused(mtfhip_batch *b, const mtfhip_sm_desc *sm, const RegionIngest *rg = nullptr) {
+static int init_template_fused(mtfhip_batch *b, const mtfhip_sm_desc *sm, const RegionIngest *rg = nullptr, bool publish_host = true) {
 	(void)sm;
 	hipStream_t st = b->ctx->stream;
 	const bool ncc = b->desc.am == MTFHIP_AM_NCC;
@@ -356,7 +356,8 @@ static int init_template_fused(mtfhip_batch *b, const mtfhip_sm_desc *sm, const 
 	{
 		TimedScope tsc(b->ctx, "template_init");
 		launch_template_init(b->view(), b->ctx->img, b->desc.grad_eps, b->norm_mult, b->norm_add, b->d_h0, b->d_h0inv, ncc ? b->d_ncc : nullptr,
-			ncc ? b->d_ncc_tm : nullptr, InitPublish{b->h_init_rec_dev, b->d_fin_count, b->h_init_flag_dev, seq, publish_fenced()}, rg ? *rg : RegionIngest{}, st);
+			ncc ? b->d_ncc_tm : nullptr, publish_host ? InitPublish{b->h_init_rec_dev, b->d_fin_count, b->h_init_flag_dev, seq, publish_fenced()} : InitPublish{nullptr, nullptr, nullptr, 0, 0},
+			rg ? *rg : RegionIngest{}, st);
 	}
 	/* (the kernel also zeroes the gradient vectors df_dI0 / df_dIt: initializeSimilarity / initializeGrad) */
 	touch(b, MTFHIP_BUF_DI0_DX); touch(b, MTFHIP_BUF_J0);
@@ -366,6 +367,7 @@ static int init_template_fused(mtfhip_batch *b, const mtfhip_sm_desc *sm, const 
 	for (auto &h : b->th) h.f = ncc ? 1.0 : 0.0;
 	b->ncc_host_newer = false;       /* (the kernel wrote d_ncc itself) */
 	b->init_mirror_seq = seq;
+	b->init_rec_device = !publish_host;
 	b->j0_is_template = true;
 	b->j0_template_corners_epoch = b->corners_epoch;
 	b->j0_variant = MTFHIP_JAC_WARPED;
@@ -405,7 +407,10 @@ static int grid_reinit_fused(mtfhip_batch *b, const mtfhip_sm_desc *sm, const do
 		rg.grid = GridLayoutHD{gd.grid_size_x, gd.grid_size_y, gd.patch_size_x, gd.patch_size_y, gd.dyn_patch_size ? 1 : 0, gd.patch_centroid_inside ? 1 : 0};
 		std::memcpy(rg.region_map, b->deferred_region_map, sizeof(rg.region_map));
 	}
-	const int rc = init_template_fused(b, sm, &rg);
+	/* (no host publish: a grid re-initialises every frame and its records are superseded unread -- the pinned stores and their acknowledgement
+	 * were ~2 us at the tail of every workgroup; a caller that does read the mirrors copies d_h0 / d_ncc / d_ncc_tm, pull_init_mirrors) */
+	static const bool rec_pinned = std::getenv("MTFHIP_GRID_INIT_PUBLISH") && std::getenv("MTFHIP_GRID_INIT_PUBLISH")[0] == '1';
+	const int rc = init_template_fused(b, sm, &rg, rec_pinned);
 	const auto t3 = std::chrono::steady_clock::now();
 	set_corners_finish_deferred(b);   /* the host half of a deferred reset (a no-op when nothing was deferred): under the kernel */
 	if (dbg) {

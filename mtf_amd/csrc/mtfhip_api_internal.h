@@ -205,6 +205,7 @@ struct mtfhip_batch {
 	 * moments) are older than the device copies until pull_init_mirrors() has folded the record in (lazy_flush does) */
 	double *h_init_rec = nullptr, *h_init_rec_dev = nullptr;
 	unsigned long long *h_init_flag = nullptr, *h_init_flag_dev = nullptr, init_seq = 0, init_mirror_seq = 0;
+	bool init_rec_device = false;   /* the pending record was NOT published to pinned memory (grid re-initialisations, r05): pull_init_mirrors copies d_h0 / d_ncc / d_ncc_tm instead */
 	double *d_mi_red = nullptr;   /* [B][mi_row_len] block rows summed (the Hessian assembly then reads one row per target) */
 	double *d_h0inv = nullptr; /* [B][64] inverse of the constant Hessian (one-launch ICLK) */
 	double *d_d2_part = nullptr, *d_d2_out = nullptr, *d_d2_w = nullptr; /* second-order term: block rows, [B][64] sums, MI self weights */
@@ -447,6 +448,33 @@ static int wait_host_flag(mtfhip_batch *b, unsigned long long seq) {
 /* fold the record of a fused template initialisation into the host mirrors (see mtfhip_batch::init_mirror_seq) */
 static int pull_init_mirrors(mtfhip_batch *b) {
 	if (!b->init_mirror_seq) return MTFHIP_OK;
+	const bool ncc_am = b->desc.am == MTFHIP_AM_NCC;
+	if (b->init_rec_device) {
+		/* the kernel left its results on the device only (what it publishes otherwise is a copy of d_h0 | d_ncc | d_ncc_tm): three small copies and
+		 * a synchronisation, paid by the rare caller that reads the mirrors behind a grid re-initialisation instead of by every frame */
+		static thread_local std::vector<double> h0v, ncv, tmv;
+		const size_t Bt = (size_t)b->B;
+		h0v.resize(64 * Bt); ncv.resize(8 * Bt); tmv.resize(52 * Bt);
+		HIP_TRY(hipMemcpyAsync(h0v.data(), b->d_h0, sizeof(double) * 64 * Bt, hipMemcpyDeviceToHost, b->ctx->stream));
+		if (ncc_am) {
+			HIP_TRY(hipMemcpyAsync(ncv.data(), b->d_ncc, sizeof(double) * 8 * Bt, hipMemcpyDeviceToHost, b->ctx->stream));
+			HIP_TRY(hipMemcpyAsync(tmv.data(), b->d_ncc_tm, sizeof(double) * 52 * Bt, hipMemcpyDeviceToHost, b->ctx->stream));
+		}
+		HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+		for (int t = 0; t < b->B; ++t) {
+			TargetHost &h = b->th[t];
+			std::memcpy(h.h0, &h0v[64 * (size_t)t], sizeof(double) * 64);
+			if (ncc_am) {
+				const double *r = &ncv[8 * (size_t)t], *m = &tmv[52 * (size_t)t];
+				h.I0_mean = r[0]; h.c = r[1]; h.It_mean = r[2]; h.b = r[3]; h.f = r[4]; h.gmean = r[5];
+				std::memcpy(h.ncc_sj0, m, sizeof(double) * 8);
+				std::memcpy(h.ncc_i0j0, m + 8, sizeof(double) * 8);
+				std::memcpy(h.ncc_gram0, m + 16, sizeof(double) * 36);
+			}
+		}
+		b->init_mirror_seq = 0; b->init_rec_device = false;
+		return MTFHIP_OK;
+	}
 	const unsigned long long seq = b->init_mirror_seq;
 	const auto t0 = std::chrono::steady_clock::now();
 	bool ok = false;
