@@ -333,6 +333,41 @@ int mtfhip_grid_frame(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_gr
  * afterwards = of the patches) may be NULL. */
 int mtfhip_grid_reset(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_grid_desc *g, const double *region_corners /* 8 */, int reinit,
 	double *patch_corners /* B x 8 or NULL */, float *prev_pts /* B x 2 or NULL */);
+/* ---- GridTracker's forward-backward error estimation (SM/src/GridTracker.cc:186-190 enable, :241-243 / :266 prev_img, :294-343
+ * backwardEstimation; shipped Config/modules.cfg:81-82: grid_fb_err_thresh 2, grid_fb_reinit 1) ---- */
+typedef struct mtfhip_grid_fb_desc {
+	double fb_err_thresh;   /* > 0: a patch whose backward track misses its starting point by more than this (squared distance of the
+	                           cv::Point2f centroids, :309-313) is left out of the fit */
+	int fb_reinit;          /* 1: every patch tracker is re-initialised at its tracked location before it runs backwards (:297-299) */
+	int n_model_pts;        /* est_params.n_model_pts (SSM/src/SSMEstimatorParams.cc:63; shipped Config/modules.cfg:39: 4): the surviving
+	                           set is filled up to it in tracker order (:321-332) */
+} mtfhip_grid_fb_desc;
+/* prev_img = curr_img.clone() (GridTracker.cc:241-243, :266): the current image of the context becomes its previous image.  An image
+ * the context owns (mtfhip_image_upload / _preprocess) is kept without a copy -- the next frame goes to the other of two device
+ * buffers --, a borrowed one is copied device-to-device on the context's stream. */
+int mtfhip_image_keep_prev(mtfhip_ctx *ctx);
+int mtfhip_image_has_prev(mtfhip_ctx *ctx);
+/* setImage(prev_img) / setImage(curr_img) of every tracker on the context (GridTracker.cc:300, :304): current and previous image change
+ * places; a second call changes them back */
+int mtfhip_image_swap_prev(mtfhip_ctx *ctx);
+/* The patch loop of backwardEstimation (:295-306) for the whole batch: location = getRegion(); initialize(location) on the current
+ * frame when fb_reinit; setImage(prev_img); update(); fb_prev_pts = getCentroid(getRegion()) (cv::Point2f: rounded to float);
+ * setImage(curr_img); setRegion(location).  Needs mtfhip_image_keep_prev.  n_iters (B), fb_corners (B x 8: where the patch trackers
+ * arrived on the previous frame) and fb_prev_pts (B x 2) may be NULL. */
+int mtfhip_grid_backward(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_grid_desc *g, const mtfhip_grid_fb_desc *fb, int *n_iters,
+	double *fb_corners, float *fb_prev_pts);
+/* The mask half of backwardEstimation (:307-332): fb_err_mask[k] = the squared distance fb_prev_pts[k] - prev_pts[k] (float differences,
+ * double squares) is not above fb_err_thresh; the surviving (prev, curr) pairs in tracker order, filled up to n_model_pts with the
+ * first rejected ones (their mask set) when fewer survive -- what estimateWarpFromPts is then handed (:334-335).  Host arithmetic
+ * only.  prev_masked / curr_masked (n x 2 each) may be NULL. */
+int mtfhip_grid_fb_mask(int n, const float *prev_pts, const float *curr_pts, const float *fb_prev_pts, const mtfhip_grid_fb_desc *fb,
+	unsigned char *fb_err_mask, float *prev_masked, float *curr_masked, int *n_masked);
+/* GridTracker::update's patch loop with the estimation on (:254-266): mtfhip_grid_frame (region_corners as there), then
+ * mtfhip_grid_backward and mtfhip_grid_fb_mask against prev_pts (the centroids the last reset / frame left, B x 2). */
+int mtfhip_grid_frame_fb(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_grid_desc *g, const mtfhip_grid_fb_desc *fb,
+	const double *region_corners /* 8 or NULL */, const float *prev_pts /* B x 2 */, int *n_iters /* B or NULL */, double *corners /* B x 8 or NULL */,
+	float *centroids /* B x 2 or NULL */, float *fb_prev_pts /* B x 2 */, unsigned char *fb_err_mask /* B */, float *prev_masked /* B x 2 or NULL */,
+	float *curr_masked /* B x 2 or NULL */, int *n_masked);
 /* Debug trace of the loop above: with max_passes > 0 every pass also records what it solved, per target
  * [max_passes][96]: H (64, row-major 8 x 8, before Levenberg-Marquardt damping) | g (8) | the state update applied (8) | the
  * corners it produced (8) | f | pass | LM undo | LM damping | 1 when H was recorded (the one-launch grid loop uses the

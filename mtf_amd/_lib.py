@@ -72,6 +72,11 @@ class GridDesc(C.Structure):
                 ("reset_at_each_frame", C.c_int), ("dyn_patch_size", C.c_int), ("patch_centroid_inside", C.c_int)]
 
 
+class GridFbDesc(C.Structure):
+    """mtfhip_grid_fb_desc: GridTrackerParams::fb_err_thresh / fb_reinit (SM/src/GridTracker.cc:186-190, 294-343) and est_params.n_model_pts"""
+    _fields_ = [("fb_err_thresh", C.c_double), ("fb_reinit", C.c_int), ("n_model_pts", C.c_int)]
+
+
 # every exported symbol of include/mtfhip.h (tests check that the library exports all of them)
 SYMBOLS = [
     "mtfhip_last_error", "mtfhip_device_count", "mtfhip_ctx_create", "mtfhip_ctx_destroy",
@@ -98,6 +103,7 @@ SYMBOLS = [
     "mtfhip_am_cmpt_self_hessian2", "mtfhip_am_cmpt_sum_of_hessians2",
     "mtfhip_batch_init_template", "mtfhip_batch_set_region", "mtfhip_batch_iterate", "mtfhip_batch_track", "mtfhip_batch_track_region", "mtfhip_grid_update",
     "mtfhip_grid_res", "mtfhip_grid_layout", "mtfhip_grid_frame", "mtfhip_grid_reset",
+    "mtfhip_image_keep_prev", "mtfhip_image_has_prev", "mtfhip_image_swap_prev", "mtfhip_grid_backward", "mtfhip_grid_fb_mask", "mtfhip_grid_frame_fb",
     "mtfhip_batch_track_targets_per_launch",
     "mtfhip_score_candidates", "mtfhip_score_candidates_dev",
     "mtfhip_sample_candidates", "mtfhip_sample_candidates_dev",
@@ -159,6 +165,12 @@ def lib():
         L.mtfhip_grid_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mtfhip_grid_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mtfhip_grid_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.mtfhip_image_keep_prev.argtypes = [C.c_void_p]
+        L.mtfhip_image_has_prev.argtypes = [C.c_void_p]
+        L.mtfhip_image_swap_prev.argtypes = [C.c_void_p]
+        L.mtfhip_grid_backward.argtypes = [C.c_void_p] * 7
+        L.mtfhip_grid_fb_mask.argtypes = [C.c_int] + [C.c_void_p] * 8
+        L.mtfhip_grid_frame_fb.argtypes = [C.c_void_p] * 14
         L.mtfhip_ssm_update_grad_pts.argtypes = [C.c_void_p, C.c_double]
         L.mtfhip_ssm_update_hess_pts.argtypes = [C.c_void_p, C.c_double]
         for fn in ("mtfhip_am_initialize_pix_hess", "mtfhip_am_update_pix_hess"):

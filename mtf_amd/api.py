@@ -137,6 +137,18 @@ class Context:
         L.check(L.lib().mtfhip_image_download(self._h, _p(out), r, c))
         return out
 
+    def keep_prev(self):
+        """prev_img = curr_img.clone() (SM/src/GridTracker.cc:241-243, 266): the current image becomes the context's previous image
+        (no copy for an uploaded / pre-processed image: the next frame goes to the other of two device buffers)"""
+        L.check(L.lib().mtfhip_image_keep_prev(self._h))
+
+    def has_prev(self):
+        return bool(L.lib().mtfhip_image_has_prev(self._h))
+
+    def swap_prev(self):
+        """setImage(prev_img) / setImage(curr_img) (GridTracker.cc:300, 304): current and previous image change places"""
+        L.check(L.lib().mtfhip_image_swap_prev(self._h))
+
     def set_image_device(self, dev_ptr, height, width, row_stride=None, keep=None):
         """Adopt a float32 image already resident in HBM (e.g. a torch tensor's data_ptr())."""
         self._img_keep = keep
@@ -562,6 +574,28 @@ class Batch:
         r = np.ascontiguousarray(np.asarray(region, dtype=np.float64).reshape(2, 4).T)
         L.check(L.lib().mtfhip_grid_reset(self._h, C.byref(sm), C.byref(gd), _p(r), int(bool(reinit)), _p(pcs), _p(pp)))
         return pcs.transpose(0, 2, 1).copy(), pp
+
+    def grid_backward(self, gd, sm, fb):
+        """the patch loop of GridTracker::backwardEstimation (mtfhip_grid_backward) -> iteration counts, the regions reached on the
+        previous frame (B, 2, 4), fb_prev_pts (B, 2) float32"""
+        n, c, m = np.empty(self.B, dtype=np.int32), np.empty((self.B, 4, 2)), np.empty((self.B, 2), dtype=np.float32)
+        L.check(L.lib().mtfhip_grid_backward(self._h, C.addressof(sm), C.addressof(gd), C.addressof(fb), _p(n), _p(c), _p(m)))
+        return n, c.transpose(0, 2, 1).copy(), m
+
+    def grid_frame_fb(self, gd, sm, fb, prev_pts, region=None):
+        """GridTracker::update's patch loop + backwardEstimation (mtfhip_grid_frame_fb) -> dict(n_iters, corners (B, 2, 4), centroids,
+        fb_prev_pts, fb_err_mask (B,) bool, prev_masked (c, 2), curr_masked (c, 2))"""
+        B = self.B
+        n, c, m = np.empty(B, dtype=np.int32), np.empty((B, 4, 2)), np.empty((B, 2), dtype=np.float32)
+        fbp, mask = np.empty((B, 2), dtype=np.float32), np.empty(B, dtype=np.uint8)
+        pm, cm, cnt = np.empty((B, 2), dtype=np.float32), np.empty((B, 2), dtype=np.float32), C.c_int()
+        pp = np.ascontiguousarray(prev_pts, dtype=np.float32).reshape(B, 2)
+        r = None if region is None else np.ascontiguousarray(np.asarray(region, dtype=np.float64).reshape(2, 4).T)
+        L.check(L.lib().mtfhip_grid_frame_fb(self._h, C.addressof(sm), C.addressof(gd), C.addressof(fb), None if r is None else _p(r), _p(pp), _p(n), _p(c), _p(m),
+                                             _p(fbp), _p(mask), _p(pm), _p(cm), C.addressof(cnt)))
+        k = cnt.value
+        return dict(n_iters=n, corners=c.transpose(0, 2, 1).copy(), centroids=m, fb_prev_pts=fbp, fb_err_mask=mask.astype(bool), prev_masked=pm[:k].copy(),
+                    curr_masked=cm[:k].copy())
 
     # ---------------------------------------------------------- candidate scoring
     def score_candidates(self, states, want_similarity=False):

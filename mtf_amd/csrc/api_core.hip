@@ -73,6 +73,7 @@ void mtfhip_ctx_destroy(mtfhip_ctx *c) {
 			for (auto &p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
 		for (auto e : c->free_events) (void)hipEventDestroy(e);
 		if (c->img_owned) (void)hipFree(c->img_owned);
+		if (c->prev_owned) (void)hipFree(c->prev_owned);
 		if (c->raw) (void)hipFree(c->raw);
 		if (c->tmp_a) (void)hipFree(c->tmp_a);
 		if (c->tmp_b) (void)hipFree(c->tmp_b);
@@ -132,6 +133,41 @@ int mtfhip_image_borrow(mtfhip_ctx *c, const float *dev_img, int height, int wid
 	if ((double)height * row_stride * 4.0 >= 4294967296.0 || height >= (1 << 24) || row_stride >= (1 << 24))
 		return fail(MTFHIP_ERR_INVALID_ARG, "image_borrow: %d rows of %d floats exceed what a 32-bit texel offset / a 24-bit row x pitch product can address", height, row_stride);
 	c->img = ImgView{dev_img, height, width, row_stride};
+	return MTFHIP_OK;
+}
+
+/* prev_img = curr_img.clone() (SM/src/GridTracker.cc:241-243, 266) */
+int mtfhip_image_keep_prev(mtfhip_ctx *c) {
+	if (!c) return fail(MTFHIP_ERR_INVALID_ARG, "image_keep_prev: NULL argument");
+	if (!c->img.data) return fail(MTFHIP_ERR_LOGIC, "image_keep_prev: no current image");
+	if (c->img.data == c->prev.data) { c->prev = c->img; return MTFHIP_OK; }   /* kept already, no frame since */
+	if (c->img.data == c->img_owned) {
+		/* the context's own buffer: it becomes the previous frame's and the next upload / pre-processing pass fills the other one */
+		std::swap(c->img_owned, c->prev_owned);
+		std::swap(c->img_capacity, c->prev_capacity);
+		c->prev = c->img;
+		return MTFHIP_OK;
+	}
+	HIP_TRY(hipSetDevice(c->device));
+	const size_t row = (size_t)c->img.w * c->img.channels, need = row * c->img.h;
+	if (need > c->prev_capacity) {
+		if (c->prev_owned) HIP_TRY(hipFree(c->prev_owned));
+		c->prev_owned = nullptr; c->prev_capacity = 0;
+		HIP_TRY(hipMalloc(&c->prev_owned, need * sizeof(float)));
+		c->prev_capacity = need;
+	}
+	HIP_TRY(hipMemcpy2DAsync(c->prev_owned, row * sizeof(float), c->img.data, (size_t)c->img.stride * sizeof(float), row * sizeof(float), (size_t)c->img.h,
+		hipMemcpyDeviceToDevice, c->stream));
+	c->prev = ImgView{c->prev_owned, c->img.h, c->img.w, (int)row, c->img.channels};
+	return MTFHIP_OK;
+}
+int mtfhip_image_has_prev(mtfhip_ctx *c) { return c && c->prev.data ? 1 : 0; }
+/* tracker->setImage(prev_img) ... tracker->setImage(curr_img) (GridTracker.cc:300-304): the two views change places */
+int mtfhip_image_swap_prev(mtfhip_ctx *c) {
+	if (!c) return fail(MTFHIP_ERR_INVALID_ARG, "image_swap_prev: NULL argument");
+	if (!c->prev.data || !c->img.data) return fail(MTFHIP_ERR_LOGIC, "image_swap_prev: no previous image (mtfhip_image_keep_prev)");
+	TRY(lazy_flush_ctx(c));
+	std::swap(c->img, c->prev);
 	return MTFHIP_OK;
 }
 

@@ -434,7 +434,15 @@ int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm) {
 	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "init_template before set_corners");
 	/* am->clearInitStatus() (NT/ESM.cc:113, NT/FCLK.cc:105, NT/ICLK.cc:74) */
 	b->init_pix_vals = b->init_pix_grad = b->init_sim = b->init_grad = false;
-	if (template_init_fused_ok(b, sm)) return init_template_fused(b, sm);
+	/* k_template_init samples INIT_PTS and builds J0 at the identity warp: that is the current image at the current points only while no
+	 * setState / compositionalUpdate / update() has moved the warp since set_corners (the mirrors are exact: set_corners_core stores the
+	 * identity itself, and every state change goes through them) */
+	bool at_identity = true;
+	{
+		const M3 I = m3_identity();
+		for (const TargetHost &h : b->th) if (std::memcmp(h.warp.m, I.m, sizeof(I.m)) != 0) { at_identity = false; break; }
+	}
+	if (at_identity && template_init_fused_ok(b, sm)) return init_template_fused(b, sm);
 	TRY(mtfhip_am_initialize_pix_vals(b, nullptr));
 	if (sm->chained_warp) {
 		TRY(mtfhip_am_initialize_pix_grad(b, nullptr));
@@ -1092,6 +1100,21 @@ static int grid_batch_ok(const mtfhip_batch *b, const mtfhip_grid_desc *g, const
 		return fail(MTFHIP_ERR_INVALID_ARG, "%s: mismatch between the grid dimensions (%d x %d) and the batch's %d patch trackers", fn, g->grid_size_x, g->grid_size_y, b->B);
 	return MTFHIP_OK;
 }
+/* every patch tracker's update() behind a reset that may still be running (mtfhip_grid_frame without a region; the backward pass) */
+static int grid_track_plain(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, double *out) {
+	/* reset-every-frame mode: this call follows mtfhip_grid_reset(reinit), whose k_template_init may still be running.  The one-launch
+	 * loop kernel reads nothing of that kernel's host record, so it is enqueued behind it right away (r05: the host used to wait for the
+	 * record and copy 1 KB per patch first -- launch latency + 256 KB of memcpy exposed in every frame); the record is folded into the
+	 * mirrors by the next call that flushes without this flag.  MTFHIP_GRID_HOLD_PULL=0: the r05 first form. */
+	const size_t B = (size_t)b->B;
+	const char *e_hp = std::getenv("MTFHIP_GRID_HOLD_PULL");
+	const bool hold = b->init_mirror_seq != 0 && !(e_hp && e_hp[0] == '0') && b->h_stage_b_dev && b->h_pub_dev && b->desc.am != MTFHIP_AM_MI && !sm->leven_marq &&
+		iclk_one_launch(b, sm) && second_order_term(sm, b->desc.am) < 0 && ((37 * sizeof(double) * B) % 16) == 0;
+	b->hold_init_pull = hold;
+	const int rc = mtfhip_batch_track(b, sm, n_iters, out);
+	b->hold_init_pull = false;
+	return rc;
+}
 /* GridTracker::update's patch loop (GridTracker.cc:254-261), with the reset that preceded it folded in when a region is given */
 int mtfhip_grid_frame(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_grid_desc *g, const double *region, int *n_iters, double *corners, float *centroids) {
 	if (!sm) return fail(MTFHIP_ERR_INVALID_ARG, "grid_frame: NULL argument");
@@ -1101,22 +1124,91 @@ int mtfhip_grid_frame(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_gr
 	static thread_local std::vector<int> iters;
 	out.resize(8 * B); iters.resize(B);
 	if (region) TRY(track_region_impl(b, sm, region, n_iters ? n_iters : iters.data(), out.data(), g));
-	else {
-		/* reset-every-frame mode: this call follows mtfhip_grid_reset(reinit), whose k_template_init may still be running.  The one-launch
-		 * loop kernel reads nothing of that kernel's host record, so it is enqueued behind it right away (r05: the host used to wait for the
-		 * record and copy 1 KB per patch first -- launch latency + 256 KB of memcpy exposed in every frame); the record is folded into the
-		 * mirrors by the next call that flushes without this flag.  MTFHIP_GRID_HOLD_PULL=0: the r05 first form. */
-		const char *e_hp = std::getenv("MTFHIP_GRID_HOLD_PULL");
-		const bool hold = b->init_mirror_seq != 0 && !(e_hp && e_hp[0] == '0') && b->h_stage_b_dev && b->h_pub_dev && b->desc.am != MTFHIP_AM_MI && !sm->leven_marq &&
-			iclk_one_launch(b, sm) && second_order_term(sm, b->desc.am) < 0 && ((37 * sizeof(double) * B) % 16) == 0;
-		b->hold_init_pull = hold;
-		const int rc = mtfhip_batch_track(b, sm, n_iters ? n_iters : iters.data(), out.data());
-		b->hold_init_pull = false;
-		if (rc != MTFHIP_OK) return rc;
-	}
+	else TRY(grid_track_plain(b, sm, n_iters ? n_iters : iters.data(), out.data()));
 	if (corners) std::memcpy(corners, out.data(), sizeof(double) * 8 * B);
 	if (centroids) for (size_t t = 0; t < B; ++t) centroid_f(centroids + 2 * t, &out[8 * t]);
 	return MTFHIP_OK;
+}
+
+/* ---- forward-backward error estimation (GridTracker.cc:186-190, 263-266, 294-343) ---- */
+/* the mask half of backwardEstimation (:307-332): host arithmetic, no device */
+int mtfhip_grid_fb_mask(int n, const float *prev_pts, const float *curr_pts, const float *fb_prev_pts, const mtfhip_grid_fb_desc *fb,
+	unsigned char *fb_err_mask, float *prev_masked, float *curr_masked, int *n_masked) {
+	if (n < 0 || !prev_pts || !curr_pts || !fb_prev_pts || !fb || !fb_err_mask || !n_masked) return fail(MTFHIP_ERR_INVALID_ARG, "grid_fb_mask: NULL argument");
+	int cnt = 0;
+	auto keep = [&](int id) {
+		if (prev_masked) { prev_masked[2 * cnt] = prev_pts[2 * id]; prev_masked[2 * cnt + 1] = prev_pts[2 * id + 1]; }
+		if (curr_masked) { curr_masked[2 * cnt] = curr_pts[2 * id]; curr_masked[2 * cnt + 1] = curr_pts[2 * id + 1]; }
+		++cnt;
+	};
+	for (int id = 0; id < n; ++id) {
+		/* cv::Point2f members: the difference is a float, the squares and their sum doubles (:309-312) */
+		const float dxf = fb_prev_pts[2 * id] - prev_pts[2 * id], dyf = fb_prev_pts[2 * id + 1] - prev_pts[2 * id + 1];
+		const double dx = dxf, dy = dyf;
+		if (dx * dx + dy * dy > fb->fb_err_thresh) fb_err_mask[id] = 0;
+		else { fb_err_mask[id] = 1; keep(id); }
+	}
+	if (cnt < fb->n_model_pts) {   /* :321-332: filled up in tracker order to what the estimator needs */
+		for (int id = 0; id < n; ++id) {
+			if (fb_err_mask[id]) continue;
+			keep(id);
+			fb_err_mask[id] = 1;
+			if (cnt == fb->n_model_pts) break;
+		}
+	}
+	*n_masked = cnt;
+	return MTFHIP_OK;
+}
+/* the patch half of backwardEstimation (:295-306) for every patch tracker of the batch at once: re-initialised at its tracked location on the
+ * current frame (fb_reinit), run on the PREVIOUS frame (mtfhip_image_keep_prev), centroid of where it arrives, then back on the current
+ * frame and setRegion(location) */
+int mtfhip_grid_backward(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_grid_desc *g, const mtfhip_grid_fb_desc *fb, int *n_iters, double *fb_corners,
+	float *fb_prev_pts) {
+	if (!sm || !fb) return fail(MTFHIP_ERR_INVALID_ARG, "grid_backward: NULL argument");
+	TRY(grid_batch_ok(b, g, "grid_backward"));
+	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "grid_backward before the patch trackers were initialised");
+	mtfhip_ctx *c = b->ctx;
+	if (!c->prev.data) return fail(MTFHIP_ERR_LOGIC, "grid_backward: no previous image (mtfhip_image_keep_prev)");
+	if (c->prev.h != c->img.h || c->prev.w != c->img.w || c->prev.channels != c->img.channels)
+		return fail(MTFHIP_ERR_INVALID_ARG, "grid_backward: the previous image is %dx%dx%d, the current one %dx%dx%d", c->prev.h, c->prev.w, c->prev.channels, c->img.h, c->img.w, c->img.channels);
+	TRY(track_validate(b, sm));
+	const size_t B = (size_t)b->B;
+	static thread_local std::vector<double> loc, out;
+	static thread_local std::vector<int> iters;
+	loc.resize(8 * B); out.resize(8 * B); iters.resize(B);
+	FLUSH(b);
+	for (size_t t = 0; t < B; ++t) std::memcpy(&loc[8 * t], b->th[t].corners, sizeof(double) * 8);   /* tracker_location = getRegion().clone() :296 */
+	if (fb->fb_reinit) {                                                                               /* tracker->initialize(tracker_location) :297-299 */
+		const char *e_gf = std::getenv("MTFHIP_GRID_FUSED");
+		const bool fused = !(e_gf && e_gf[0] == '0') && b->h_stage_a_dev && template_init_fused_ok(b, sm);
+		if (fused) TRY(grid_reinit_fused(b, sm, loc.data()));
+		else {
+			TRY(mtfhip_ssm_set_corners(b, loc.data()));
+			TRY(mtfhip_batch_init_template(b, sm));
+		}
+	}
+	TRY(mtfhip_image_swap_prev(c));                                                                    /* tracker->setImage(prev_img) :300 */
+	const int rc = grid_track_plain(b, sm, n_iters ? n_iters : iters.data(), out.data());              /* tracker->update() :301 */
+	const int rs = mtfhip_image_swap_prev(c);                                                          /* tracker->setImage(curr_img) :304 */
+	if (rc != MTFHIP_OK) return rc;
+	if (rs != MTFHIP_OK) return rs;
+	if (fb_corners) std::memcpy(fb_corners, out.data(), sizeof(double) * 8 * B);
+	if (fb_prev_pts) for (size_t t = 0; t < B; ++t) centroid_f(fb_prev_pts + 2 * t, &out[8 * t]);      /* getCentroid(fb_prev_pts[id], getRegion()) :302 */
+	return mtfhip_batch_set_region(b, loc.data(), sm);                                                 /* tracker->setRegion(tracker_location) :305 */
+}
+/* GridTracker::update's patch loop followed by backwardEstimation (:254-266): mtfhip_grid_frame, mtfhip_grid_backward and the mask in one call */
+int mtfhip_grid_frame_fb(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_grid_desc *g, const mtfhip_grid_fb_desc *fb, const double *region,
+	const float *prev_pts, int *n_iters, double *corners, float *centroids, float *fb_prev_pts, unsigned char *fb_err_mask, float *prev_masked, float *curr_masked,
+	int *n_masked) {
+	if (!fb || !prev_pts || !fb_prev_pts || !fb_err_mask || !n_masked) return fail(MTFHIP_ERR_INVALID_ARG, "grid_frame_fb: NULL argument");
+	if (!(fb->fb_err_thresh > 0)) return fail(MTFHIP_ERR_INVALID_ARG, "grid_frame_fb: fb_err_thresh must be positive (GridTracker.cc:186: the estimation is off otherwise; use mtfhip_grid_frame)");
+	TRY(grid_batch_ok(b, g, "grid_frame_fb"));
+	static thread_local std::vector<float> cen;
+	cen.resize(2 * (size_t)b->B);
+	TRY(mtfhip_grid_frame(b, sm, g, region, n_iters, corners, cen.data()));
+	if (centroids) std::memcpy(centroids, cen.data(), sizeof(float) * cen.size());
+	TRY(mtfhip_grid_backward(b, sm, g, fb, nullptr, nullptr, fb_prev_pts));
+	return mtfhip_grid_fb_mask(b->B, prev_pts, cen.data(), fb_prev_pts, fb, fb_err_mask, prev_masked, curr_masked, n_masked);
 }
 /* GridTracker::resetTrackers(reinit) GridTracker.cc:345-392 */
 int mtfhip_grid_reset(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_grid_desc *g, const double *region, int reinit, double *patch_corners, float *prev_pts) {

@@ -131,6 +131,11 @@ struct mtfhip_ctx {
 	ImgView img{nullptr, 0, 0, 0};
 	float *img_owned = nullptr;
 	size_t img_capacity = 0;
+	/* the previous frame (GridTracker's prev_img = curr_img.clone(), SM/src/GridTracker.cc:241-243, 266): mtfhip_image_keep_prev.  An image
+	 * the context owns is kept by exchanging the two owned buffers (the next upload fills the other one: no copy); a borrowed one is copied. */
+	ImgView prev{nullptr, 0, 0, 0};
+	float *prev_owned = nullptr;
+	size_t prev_capacity = 0;
 	unsigned char *raw = nullptr; size_t raw_capacity = 0;      /* staging of the raw frame (pre-processing) */
 	float *tmp_a = nullptr, *tmp_b = nullptr; size_t tmp_capacity = 0; /* gray / row-pass intermediates */
 	int n_cus = 0;   /* compute units: the persistent loop needs its whole grid resident */
@@ -556,7 +561,17 @@ int lazy_try_similarity(mtfhip_batch *b);
 int do_cmpt_pix_jacobian(mtfhip_batch *b, int variant, int grad_buf, int dst_buf);
 static int do_mean_jacobian(mtfhip_batch *b);
 static int lazy_flush_ctx(mtfhip_ctx *c) {   /* called by everything that replaces the current image */
-	for (mtfhip_batch *b : c->batches) { int rc = lazy_flush(b); if (rc) return rc; ++b->lz.epoch; }
+	for (mtfhip_batch *b : c->batches) {
+		/* the record of a fused template initialisation does not depend on the image any more (d_h0 / d_ncc / d_ncc_tm are written): with no
+		 * recorded interface calls to replay it stays pending -- a reset-every-frame video loop (setImage, update, reset) would otherwise pay
+		 * three device-to-host copies and a synchronisation per frame for mirrors the next re-initialisation supersedes unread */
+		const bool hold = b->hold_init_pull;
+		if (!b->lz.any()) b->hold_init_pull = true;
+		const int rc = lazy_flush(b);
+		b->hold_init_pull = hold;
+		if (rc) return rc;
+		++b->lz.epoch;
+	}
 	return MTFHIP_OK;
 }
 #define FLUSH(b) do { if (b) { int _rc = lazy_flush(b); if (_rc) return _rc; } } while (0)

@@ -58,7 +58,7 @@ def lib():
         H.mtfhost_ssm_random_walk.argtypes = [C.c_void_p, C.c_ulonglong, C.c_int, C.c_void_p, C.c_void_p]
         H.mtfhost_ssm_pts_after_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         H.mtfhost_grid_create.restype = C.c_void_p
-        H.mtfhost_grid_create.argtypes = [C.c_int] * 12 + [C.c_double, C.c_int, C.c_int, C.c_int]
+        H.mtfhost_grid_create.argtypes = [C.c_int] * 12 + [C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]
         H.mtfhost_grid_destroy.argtypes = [C.c_void_p]
         H.mtfhost_grid_set_estimator.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         H.mtfhost_grid_call.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -248,10 +248,12 @@ class CppGridTracker:
 
     def __init__(self, grid_size=10, patch_size=10, patch_sm=_lib.SM_ICLK, patch_am=_lib.AM_NCC, patch_ssm=_lib.SSM_AFFINE,
                  grid_ssm=_lib.SSM_HOMOGRAPHY, reset_at_each_frame=1, dyn_patch_size=0, patch_centroid_inside=1, max_iters=30, epsilon=1e-4,
-                 hess_type=-1, leven_marq=0, device=0, estimator=None, grid_size_y=None, patch_size_y=None):
+                 hess_type=-1, leven_marq=0, device=0, estimator=None, grid_size_y=None, patch_size_y=None, fb_err_thresh=0.0, fb_reinit=1,
+                 n_model_pts=4):
         gy, py = grid_size_y or grid_size, patch_size_y or patch_size
         h = lib().mtfhost_grid_create(grid_size, gy, patch_size, py, reset_at_each_frame, dyn_patch_size, patch_centroid_inside, patch_sm,
-                                      patch_am, patch_ssm, grid_ssm, max_iters, epsilon, hess_type, leven_marq, device)
+                                      patch_am, patch_ssm, grid_ssm, max_iters, epsilon, hess_type, leven_marq, device, float(fb_err_thresh),
+                                      int(fb_reinit), int(n_model_pts))
         if not h:
             raise HostError(lib().mtfhost_last_error().decode("utf-8", "replace"))
         self._h = C.c_void_p(h)
@@ -315,6 +317,12 @@ class CppGridTracker:
 
     def ssm_update(self):
         return self._get(4, self.S)
+
+    def fb_prev_pts(self):
+        return self._get(7, 2 * self.n).reshape(self.n, 2)
+
+    def fb_err_mask(self):
+        return self._get(8, self.n).astype(bool)
 
     def patch_iters(self):
         return self._get(5, self.n).astype(np.int32)

@@ -37,6 +37,12 @@ Grid::Grid(const GridTrackerParams &gp, int patch_sm, int patch_am, int patch_ss
 	prev_pts.resize(n); curr_pts.resize(n); cen.resize(2 * (size_t)n); n_iters.assign(n, 0);   /* :153-154 */
 	patch_corners.assign(8 * (size_t)n, 0.0); patch_regions.assign(8 * (size_t)n, 0.0);
 	ssm_update.resize(grid_ssm == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6);
+	if (gp.fb_err_thresh > 0) {   /* :186-190 */
+		enable_fb_err_est = true;
+		fbd = mtfhip_grid_fb_desc{gp.fb_err_thresh, gp.fb_reinit ? 1 : 0, gp.n_model_pts};
+		fb_prev_pts.resize(n); fb_err_mask.assign(n, 0);
+		fb_cen.resize(2 * (size_t)n); prev_f.resize(2 * (size_t)n); prev_masked.resize(2 * (size_t)n); curr_masked.resize(2 * (size_t)n);
+	}
 	const int gs = grid_ssm;
 	estimator = [gs](VectorXd &u, const std::vector<GridPt> &a, const std::vector<GridPt> &c) { leastSquaresFit(gs, u, a, c); };
 }
@@ -75,6 +81,7 @@ void Grid::initialize(const CornersT &corners) {
 	have_template = false;
 	resetTrackers(true);           /* :235 */
 	curr_pts = prev_pts;           /* :236-239 */
+	if (enable_fb_err_est) HipPair::check(mtfhip_image_keep_prev(ctx));   /* prev_img = curr_img.clone() :241-243 */
 }
 
 void Grid::setRegion(const CornersT &corners) {
@@ -85,10 +92,24 @@ void Grid::setRegion(const CornersT &corners) {
 void Grid::update() {
 	if (!have_template) throw utils::LogicError("GridTracker :: update before initialize");
 	/* :254-261 every patch tracker's update() + getCentroid(curr_pts[id], getRegion()) */
-	HipPair::check(mtfhip_grid_frame(b, &d, &gd, have_pending ? pending_region.data() : nullptr, n_iters.data(), patch_regions.data(), cen.data()));
-	have_pending = false;
-	for (int k = 0; k < n; ++k) { curr_pts[k].x = cen[2 * k]; curr_pts[k].y = cen[2 * k + 1]; }
-	estimator(ssm_update, prev_pts, curr_pts);                                             /* :267 */
+	if (enable_fb_err_est) {
+		/* :263-266 backwardEstimation(); prev_img = curr_img.clone() */
+		for (int k = 0; k < n; ++k) { prev_f[2 * k] = prev_pts[k].x; prev_f[2 * k + 1] = prev_pts[k].y; }
+		int n_masked = 0;
+		HipPair::check(mtfhip_grid_frame_fb(b, &d, &gd, &fbd, have_pending ? pending_region.data() : nullptr, prev_f.data(), n_iters.data(), patch_regions.data(),
+			cen.data(), fb_cen.data(), fb_err_mask.data(), prev_masked.data(), curr_masked.data(), &n_masked));
+		have_pending = false;
+		HipPair::check(mtfhip_image_keep_prev(ctx));
+		std::vector<GridPt> pm(n_masked), cm(n_masked);
+		for (int k = 0; k < n_masked; ++k) { pm[k].x = prev_masked[2 * k]; pm[k].y = prev_masked[2 * k + 1]; cm[k].x = curr_masked[2 * k]; cm[k].y = curr_masked[2 * k + 1]; }
+		for (int k = 0; k < n; ++k) { curr_pts[k].x = cen[2 * k]; curr_pts[k].y = cen[2 * k + 1]; fb_prev_pts[k].x = fb_cen[2 * k]; fb_prev_pts[k].y = fb_cen[2 * k + 1]; }
+		estimator(ssm_update, pm, cm);                                                     /* :334-335 */
+	} else {
+		HipPair::check(mtfhip_grid_frame(b, &d, &gd, have_pending ? pending_region.data() : nullptr, n_iters.data(), patch_regions.data(), cen.data()));
+		have_pending = false;
+		for (int k = 0; k < n; ++k) { curr_pts[k].x = cen[2 * k]; curr_pts[k].y = cen[2 * k + 1]; }
+		estimator(ssm_update, prev_pts, curr_pts);                                         /* :267 */
+	}
 	/* :270-272 ssm.applyWarpToCorners(opt_warped_corners, ssm.getCorners(), ssm_update); ssm.setCorners(opt_warped_corners) */
 	CornersT warped;
 	HipPair::check(mtfhip_ssm_apply_warp_to_pts(grid_ssm, region.data(), 4, ssm_update.data(), warped.data()));

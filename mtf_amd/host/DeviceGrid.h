@@ -4,6 +4,8 @@
  * (update :254-261, resetTrackers :345-392); here the patches are the targets of one mtfhip_batch and a frame is one C-ABI call
  * (mtfhip_grid_frame: every patch's whole update() in one launch for ICLK with a constant Hessian) plus, with
  * reset_at_each_frame = 1, the re-initialisation of the patch trackers on the new grid (mtfhip_grid_reset, not waited for).
+ * fb_err_thresh > 0 (the shipped configuration): backwardEstimation (:294-343) is the second batch pass of mtfhip_grid_frame_fb on the
+ * previous frame, which the context keeps resident (mtfhip_image_keep_prev: the two frames alternate between two device buffers).
  * TrackerBase-shaped: setImage / initialize / update / setRegion / getRegion with the reference's parameter block.
  *
  * The robust fit of the grid SSM to the patch centroids -- ssm.estimateWarpFromPts (SSM/src/Homography.cc:885-897, Affine.cc:359-369 ->
@@ -34,6 +36,9 @@ struct GridTrackerParams {
 	int reset_at_each_frame = 1;
 	bool dyn_patch_size = false;
 	bool patch_centroid_inside = true;
+	double fb_err_thresh = 0;   /* > 0: forward-backward error estimation (GridTracker.cc:186-190); shipped Config/modules.cfg:81: 2 */
+	bool fb_reinit = true;      /* GridTracker.h: GT_FB_REINIT; shipped Config/modules.cfg:82: 1 */
+	int n_model_pts = 4;        /* est_params.n_model_pts (SSMEstimatorParams.cc:63; shipped Config/modules.cfg:39) */
 	int getResX() const { return resx(); }
 	int getResY() const { return resy(); }
 	mtfhip_grid_desc desc() const {
@@ -74,6 +79,9 @@ public:
 	const std::vector<GridPt> &getCurrPts() const { return curr_pts; }
 	const VectorXd &getSSMUpdate() const { return ssm_update; }
 	const std::vector<int> &getPatchIters() const { return n_iters; }
+	/* forward-backward estimation (fb_err_thresh > 0): where every patch tracker came back to on the previous frame and which ones were kept */
+	const std::vector<GridPt> &getFbPrevPts() const { return fb_prev_pts; }
+	const std::vector<unsigned char> &getFbErrMask() const { return fb_err_mask; }
 	/* the corners the last reset handed the patch trackers (n x 8, CornersT layout) and the patch trackers' regions after update() */
 	const std::vector<double> &getPatchCorners() const { return patch_corners; }
 	const std::vector<double> &getPatchRegions() const { return patch_regions; }
@@ -89,8 +97,11 @@ private:
 	int n, grid_ssm, n_channels = 1;
 	bool reinit_at_each_frame, have_pending = false, have_template = false;
 	CornersT region, pending_region;
-	std::vector<GridPt> prev_pts, curr_pts;
-	std::vector<float> cen;
+	std::vector<GridPt> prev_pts, curr_pts, fb_prev_pts;
+	std::vector<unsigned char> fb_err_mask;
+	bool enable_fb_err_est = false;
+	mtfhip_grid_fb_desc fbd{0, 1, 4};
+	std::vector<float> cen, fb_cen, prev_f, prev_masked, curr_masked;
 	std::vector<int> n_iters;
 	std::vector<double> patch_corners, patch_regions;
 	VectorXd ssm_update;

@@ -260,9 +260,11 @@ struct mtfhost_grid { std::unique_ptr<hip::Grid> g; };
 typedef void (*mtfhost_grid_estimator)(void *user, int n, const float *prev_pts, const float *curr_pts, double *ssm_update);
 extern "C" {
 mtfhost_grid *mtfhost_grid_create(int grid_size_x, int grid_size_y, int patch_size_x, int patch_size_y, int reset_at_each_frame, int dyn_patch_size,
-	int patch_centroid_inside, int patch_sm, int patch_am, int patch_ssm, int grid_ssm, int max_iters, double epsilon, int hess_type, int leven_marq, int device) {
+	int patch_centroid_inside, int patch_sm, int patch_am, int patch_ssm, int grid_ssm, int max_iters, double epsilon, int hess_type, int leven_marq, int device,
+	double fb_err_thresh, int fb_reinit, int n_model_pts) {
 	try {
 		GridTrackerParams gp;
+		gp.fb_err_thresh = fb_err_thresh; gp.fb_reinit = fb_reinit != 0; gp.n_model_pts = n_model_pts;
 		gp.grid_size_x = grid_size_x; gp.grid_size_y = grid_size_y; gp.patch_size_x = patch_size_x; gp.patch_size_y = patch_size_y;
 		gp.reset_at_each_frame = reset_at_each_frame; gp.dyn_patch_size = dyn_patch_size != 0; gp.patch_centroid_inside = patch_centroid_inside != 0;
 		nt::SMParams p;
@@ -300,7 +302,7 @@ int mtfhost_grid_call(mtfhost_grid *h, int what, const double *corners, const fl
 	catch (const std::exception &e) { g_err = e.what(); return -2; }
 }
 /* what: 0 region (8) 1 patch corners of the last reset (n x 8) 2 prev_pts (n x 2) 3 curr_pts (n x 2) 4 ssm_update (S) 5 patch iteration
- * counts (n, as doubles) 6 the patch trackers' regions after the last update (n x 8) */
+ * counts (n, as doubles) 6 the patch trackers' regions after the last update (n x 8) 7 fb_prev_pts (n x 2) 8 fb_err_mask (n, 0 / 1) */
 int mtfhost_grid_get(mtfhost_grid *h, int what, double *dst) {
 	try {
 		hip::Grid &g = *h->g;
@@ -312,6 +314,8 @@ int mtfhost_grid_get(mtfhost_grid *h, int what, double *dst) {
 		case 4: std::memcpy(dst, g.getSSMUpdate().data(), sizeof(double) * g.getSSMUpdate().size()); break;
 		case 5: for (size_t i = 0; i < g.getPatchIters().size(); ++i) dst[i] = g.getPatchIters()[i]; break;
 		case 6: std::memcpy(dst, g.getPatchRegions().data(), sizeof(double) * g.getPatchRegions().size()); break;
+		case 7: for (size_t i = 0; i < g.getFbPrevPts().size(); ++i) { dst[2 * i] = g.getFbPrevPts()[i].x; dst[2 * i + 1] = g.getFbPrevPts()[i].y; } break;
+		case 8: for (size_t i = 0; i < g.getFbErrMask().size(); ++i) dst[i] = g.getFbErrMask()[i]; break;
 		default: g_err = "mtfhost_grid_get: unknown selector"; return -1;
 		}
 		return 0;

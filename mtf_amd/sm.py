@@ -353,12 +353,19 @@ class GridTracker:
     the quadrilateral of its four surrounding points.  reset_at_each_frame: 0 the patch trackers run on, 1 they are re-initialised
     on the new grid after every frame, 2 (any other value) only setRegion().  The grid points are ssm.getPts() of the grid SSM
     (the unit-square grid through the 4-corner homography, ProjectiveBase.cc:20-36) -- mtfhip_grid_layout.
+    fb_err_thresh > 0 (shipped Config/modules.cfg:81: 2) switches the forward-backward error estimation on (:186-190, 294-343): after the
+    frame's update every patch tracker -- re-initialised at its tracked location when fb_reinit (shipped 1) -- runs on the PREVIOUS frame,
+    and the patches whose round trip misses their starting centroid by more than the threshold are left out of the fit (filled up to
+    n_model_pts = est_params.n_model_pts, shipped 4).
     The robust fit of the grid SSM to the patch centroids (estimateWarpFromPts: RANSAC / LMedS) is out of scope (SURVEY.md section
     2): `estimator(prev_pts, curr_pts) -> state update` is pluggable, default an all-points least-squares fit."""
 
     def __init__(self, ctx, grid_size=10, patch_size=10, am=L.AM_NCC, ssm=L.SSM_AFFINE, max_iters=30, epsilon=1e-4, sm=L.SM_ICLK,
                  reset_at_each_frame=1, dyn_patch_size=0, patch_centroid_inside=1, grid_ssm=L.SSM_HOMOGRAPHY, estimator=None,
-                 grid_size_y=None, patch_size_y=None, **sm_params):
+                 grid_size_y=None, patch_size_y=None, fb_err_thresh=0.0, fb_reinit=1, n_model_pts=4, **sm_params):
+        self.ctx = ctx
+        self.fb = L.GridFbDesc(float(fb_err_thresh), int(bool(fb_reinit)), int(n_model_pts)) if fb_err_thresh > 0 else None   # enable_fb_err_est :186-190
+        self.fb_prev_pts = self.fb_err_mask = None
         self.grid_size, self.patch_size = grid_size, patch_size
         self.gd = L.GridDesc(grid_size, grid_size_y or grid_size, patch_size, patch_size_y or patch_size, int(reset_at_each_frame),
                              int(bool(dyn_patch_size)), int(bool(patch_centroid_inside)))
@@ -406,6 +413,8 @@ class GridTracker:
         self.prev_pts[...] = pp
         self.curr_pts[...] = pp
         self._pending_region = None
+        if self.fb is not None:
+            self.ctx.keep_prev()         # prev_img = curr_img.clone() :241-243
 
     # GridTracker::setRegion :287-292
     def set_region(self, region_corners):
@@ -433,11 +442,21 @@ class GridTracker:
         it, and the reset the parameters ask for.  Returns the region's corners (2 x 4)."""
         if self.region is None:
             raise RuntimeError("GridTracker.update before initialize")
-        n, _, cen = self.tracker.batch.grid_frame(self.gd, self.tracker.sm, self._pending_region)
-        self._pending_region = None
-        self.tracker.n_iters = n.copy()
-        self.curr_pts[...] = cen
-        upd = np.asarray(self.estimator(self.prev_pts.astype(np.float64), self.curr_pts.astype(np.float64)), dtype=np.float64)
+        if self.fb is not None:
+            # :263-266 backwardEstimation(); prev_img = curr_img.clone()
+            r = self.tracker.batch.grid_frame_fb(self.gd, self.tracker.sm, self.fb, self.prev_pts, self._pending_region)
+            self._pending_region = None
+            self.tracker.n_iters = r["n_iters"].copy()
+            self.curr_pts[...] = r["centroids"]
+            self.fb_prev_pts, self.fb_err_mask = r["fb_prev_pts"], r["fb_err_mask"]
+            self.ctx.keep_prev()
+            upd = np.asarray(self.estimator(r["prev_masked"].astype(np.float64), r["curr_masked"].astype(np.float64)), dtype=np.float64)
+        else:
+            n, _, cen = self.tracker.batch.grid_frame(self.gd, self.tracker.sm, self._pending_region)
+            self._pending_region = None
+            self.tracker.n_iters = n.copy()
+            self.curr_pts[...] = cen
+            upd = np.asarray(self.estimator(self.prev_pts.astype(np.float64), self.curr_pts.astype(np.float64)), dtype=np.float64)
         self.ssm_update = upd
         from .api import apply_warp_to_pts
         # ssm.applyWarpToCorners(opt_warped_corners, ssm.getCorners(), ssm_update); ssm.setCorners(opt_warped_corners) :270-272

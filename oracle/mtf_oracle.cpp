@@ -2116,6 +2116,13 @@ struct mtfo_grid {
 	double centroid_dist_x, centroid_dist_y;
 	bool reinit_at_each_frame;
 	mtfo_grid_estimator est = nullptr; void *est_user = nullptr;
+	/* forward-backward error estimation (GridTracker.h:104-106, GridTracker.cc:186-190) */
+	bool enable_fb_err_est = false;
+	const float *curr_img = nullptr; int img_h = 0, img_w = 0;   /* curr_img: a header on the caller's buffer (:227) */
+	std::vector<float> prev_img;                                   /* prev_img = curr_img.clone() (:241-243, :266) */
+	std::vector<float> fb_prev_pts; std::vector<unsigned char> fb_err_mask;
+	vecd fb_locations, fb_regions;                                 /* n x 8 each (records for the parity tests) */
+	std::vector<float> est_prev, est_curr;                         /* the pairs the estimator saw in the last update */
 
 	/* GridTrackerParams::updateRes SM/src/GridTracker.cc:86-94 */
 	static void update_res(const mtfo_grid_params &gp, int &rx, int &ry) {
@@ -2138,7 +2145,19 @@ struct mtfo_grid {
 		ssm_update.assign(ssm->S, 0.0); region.assign(8, 0.0);
 		centroid_dist_x = p.patch_size_x / 2.0;                                   /* :156-157 */
 		centroid_dist_y = p.patch_size_y / 2.0;
+		if (p.fb_err_thresh > 0) {                                                /* :186-190 */
+			enable_fb_err_est = true;
+			fb_prev_pts.assign(static_cast<size_t>(2) * n, 0.f);
+			fb_err_mask.assign(n, 0);
+			fb_locations.assign(static_cast<size_t>(8) * n, 0.0); fb_regions = fb_locations;
+		}
 	}
+	/* GridTracker::setImage :205-231 without the pyramid branch */
+	void set_image(const float *img, int h, int w) {
+		for (auto *t : trackers) { t->am->img = img; t->am->h = h; t->am->w = w; }
+		curr_img = img; img_h = h; img_w = w;
+	}
+	void clone_prev() { prev_img.assign(curr_img, curr_img + static_cast<size_t>(img_h) * img_w); }
 	int lin(int r, int c) const { return linear_idx[static_cast<size_t>(r) * (p.grid_size_x + 1) + c]; }
 
 	/* the corners resetTrackers builds for one patch, SM/src/GridTracker.cc:354-380 */
@@ -2188,15 +2207,69 @@ struct mtfo_grid {
 		reset_trackers(true);
 		curr_pts = prev_pts;
 		region = ssm->curr_corners;
+		if (enable_fb_err_est) {                                                                 /* :241-243 */
+			if (!curr_img) return;   /* (mtfo_grid_set_image was not used: mtfo_grid_update then reports -3) */
+			clone_prev();
+		}
 	}
-	/* GridTracker::update :247-285 (fb_err_thresh = 0: no forward-backward estimation) */
+	/* the second half of GridTracker::backwardEstimation :307-332: which patch trackers came back to where they started, and the point
+	 * pairs of those -- filled up in tracker order to n_model_pts when fewer survive */
+	static void fb_mask(int n, const float *prev_pts, const float *curr_pts, const float *fb_prev_pts, double fb_err_thresh, int n_model_pts,
+		unsigned char *fb_err_mask, std::vector<float> &prev_masked, std::vector<float> &curr_masked) {
+		prev_masked.clear(); curr_masked.clear();                                                 /* :307 */
+		auto push = [&](int id) {
+			prev_masked.push_back(prev_pts[2 * id]); prev_masked.push_back(prev_pts[2 * id + 1]);
+			curr_masked.push_back(curr_pts[2 * id]); curr_masked.push_back(curr_pts[2 * id + 1]);
+		};
+		for (int tracker_id = 0; tracker_id < n; ++tracker_id) {
+			/* :309-310: Point2f members: the difference is taken in float, then widened */
+			const double diff_x = fb_prev_pts[2 * tracker_id] - prev_pts[2 * tracker_id];
+			const double diff_y = fb_prev_pts[2 * tracker_id + 1] - prev_pts[2 * tracker_id + 1];
+			if (diff_x * diff_x + diff_y * diff_y > fb_err_thresh) fb_err_mask[tracker_id] = 0;   /* :312-313 */
+			else { fb_err_mask[tracker_id] = 1; push(tracker_id); }                              /* :314-318 */
+		}
+		if (static_cast<int>(prev_masked.size() / 2) < n_model_pts) {                             /* :321-332 */
+			for (int tracker_id = 0; tracker_id < n; ++tracker_id) {
+				if (fb_err_mask[tracker_id]) continue;
+				push(tracker_id);
+				fb_err_mask[tracker_id] = 1;
+				if (static_cast<int>(prev_masked.size() / 2) == n_model_pts) break;
+			}
+		}
+	}
+	/* GridTracker::backwardEstimation :294-343 */
+	int backward_estimation() {
+		for (int tracker_id = 0; tracker_id < n; ++tracker_id) {
+			mtfo_tracker *t = trackers[tracker_id];
+			double *loc = &fb_locations[static_cast<size_t>(8) * tracker_id];
+			std::copy(t->ssm->curr_corners.begin(), t->ssm->curr_corners.end(), loc);             /* getRegion().clone() :296 */
+			if (p.fb_reinit) t->initialize(loc);                                                  /* :297-299 */
+			t->am->img = prev_img.data();                                                         /* setImage(prev_img) :300 */
+			t->update();                                                                          /* :301 */
+			centroid_f(&fb_prev_pts[2 * tracker_id], t->ssm->curr_corners.data());                /* :302 */
+			std::copy(t->ssm->curr_corners.begin(), t->ssm->curr_corners.end(), &fb_regions[static_cast<size_t>(8) * tracker_id]);
+			t->am->img = curr_img;                                                                /* setImage(curr_img) :304 */
+			t->set_region(loc);                                                                   /* :305 */
+		}
+		fb_mask(n, prev_pts.data(), curr_pts.data(), fb_prev_pts.data(), p.fb_err_thresh, p.n_model_pts, fb_err_mask.data(), est_prev, est_curr);
+		est(est_user, static_cast<int>(est_prev.size() / 2), est_prev.data(), est_curr.data(), ssm_update.data());   /* :334-335 */
+		return 0;
+	}
+	/* GridTracker::update :247-285 */
 	int update() {
+		if (enable_fb_err_est && prev_img.empty()) return -3;
 		for (int tracker_id = 0; tracker_id < n; ++tracker_id) {
 			trackers[tracker_id]->update();
 			centroid_f(&curr_pts[2 * tracker_id], trackers[tracker_id]->ssm->curr_corners.data());
 		}
 		if (!est) return -1;
-		est(est_user, n, prev_pts.data(), curr_pts.data(), ssm_update.data());                   /* ssm.estimateWarpFromPts :267 */
+		if (enable_fb_err_est) {                                                                 /* :263-266 */
+			backward_estimation();
+			clone_prev();
+		} else {
+			est_prev = prev_pts; est_curr = curr_pts;
+			est(est_user, n, prev_pts.data(), curr_pts.data(), ssm_update.data());               /* ssm.estimateWarpFromPts :267 */
+		}
 		double opt_warped_corners[8];
 		ssm->apply_warp_to_corners(opt_warped_corners, ssm->curr_corners.data(), ssm_update.data());   /* :270-271 */
 		ssm->set_corners(opt_warped_corners);                                                    /* :272 */
@@ -2626,6 +2699,14 @@ mtfo_grid *mtfo_grid_create(const mtfo_grid_params *gp, mtfo_ssm *grid_ssm, mtfo
 }
 void mtfo_grid_destroy(mtfo_grid *g) { delete g; }
 void mtfo_grid_set_estimator(mtfo_grid *g, mtfo_grid_estimator est, void *user) { g->est = est; g->est_user = user; }
+void mtfo_grid_set_image(mtfo_grid *g, const float *img, int h, int w) { g->set_image(img, h, w); }
+int mtfo_grid_fb_mask(int n, const float *prev_pts, const float *curr_pts, const float *fb_prev_pts, double fb_err_thresh, int n_model_pts,
+	unsigned char *fb_err_mask, float *prev_masked, float *curr_masked) {
+	std::vector<float> a, b;
+	mtfo_grid::fb_mask(n, prev_pts, curr_pts, fb_prev_pts, fb_err_thresh, n_model_pts, fb_err_mask, a, b);
+	std::copy(a.begin(), a.end(), prev_masked); std::copy(b.begin(), b.end(), curr_masked);
+	return static_cast<int>(a.size() / 2);
+}
 void mtfo_grid_initialize(mtfo_grid *g, const double *corners) { g->initialize(corners); }
 int mtfo_grid_update(mtfo_grid *g) { return g->update(); }
 void mtfo_grid_set_region(mtfo_grid *g, const double *corners) { g->set_region(corners); }
@@ -2636,6 +2717,16 @@ void mtfo_grid_get(const mtfo_grid *g, int what, double *dst) {
 	case 2: for (size_t i = 0; i < g->prev_pts.size(); ++i) dst[i] = g->prev_pts[i]; break;
 	case 3: for (size_t i = 0; i < g->curr_pts.size(); ++i) dst[i] = g->curr_pts[i]; break;
 	case 4: std::copy(g->ssm_update.begin(), g->ssm_update.end(), dst); break;
+	case 5: for (size_t i = 0; i < g->fb_prev_pts.size(); ++i) dst[i] = g->fb_prev_pts[i]; break;
+	case 6: for (size_t i = 0; i < g->fb_err_mask.size(); ++i) dst[i] = g->fb_err_mask[i]; break;
+	case 7: std::copy(g->fb_locations.begin(), g->fb_locations.end(), dst); break;
+	case 8: std::copy(g->fb_regions.begin(), g->fb_regions.end(), dst); break;
+	case 9: {
+		const size_t c = g->est_prev.size() / 2;
+		dst[0] = static_cast<double>(c);
+		for (size_t i = 0; i < 2 * c; ++i) { dst[1 + i] = g->est_prev[i]; dst[1 + 2 * c + i] = g->est_curr[i]; }
+		break;
+	}
 	default: break;
 	}
 }

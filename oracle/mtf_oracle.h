@@ -218,12 +218,16 @@ int mtfo_pf_iteration(mtfo_am *am, mtfo_ssm *ssm, const mtfo_pf_params *pp, doub
 	const double *uniforms, double max_similarity, double *wts_out, int *resample_ids, int *max_wt_id_out);
 
 /* ---- GridTracker (SM/src/GridTracker.cc:20-94 parameters, :97-160 constructor, :233-292 initialize / update / setRegion,
- * :345-392 resetTrackers): the patch layout over a grid SSM and the frame loop over patch trackers.  The robust fit of the grid
- * SSM to the patch centroids (estimateWarpFromPts: RANSAC / LMedS, out of scope) is a callback. ---- */
+ * :294-343 backwardEstimation, :345-392 resetTrackers): the patch layout over a grid SSM, the frame loop over patch trackers and the
+ * forward-backward error estimate.  The robust fit of the grid SSM to the patch centroids (estimateWarpFromPts: RANSAC / LMedS, out
+ * of scope) is a callback. ---- */
 typedef struct mtfo_grid_params {
 	int grid_size_x, grid_size_y, patch_size_x, patch_size_y;
 	int reset_at_each_frame;      /* 0 never, 1 re-initialise the patch trackers every frame, 2 setRegion only (GridTracker.cc:136) */
 	int dyn_patch_size, patch_centroid_inside;
+	double fb_err_thresh;         /* > 0: forward-backward error estimation (GridTracker.cc:186-190); shipped Config/modules.cfg:81: 2 */
+	int fb_reinit;                /* re-initialise every patch tracker at its tracked location before the backward pass (:298-300); shipped 1 */
+	int n_model_pts;              /* est_params.n_model_pts (SSMEstimatorParams.cc:63, shipped Config/modules.cfg:39: 4): the masked set is filled up to it (:322-332) */
 } mtfo_grid_params;
 /* estimateWarpFromPts(ssm_update, mask, prev_pts, curr_pts, est_params): n float point pairs -> S doubles */
 typedef void (*mtfo_grid_estimator)(void *user, int n, const float *prev_pts, const float *curr_pts, double *ssm_update);
@@ -234,10 +238,19 @@ void mtfo_grid_res(const mtfo_grid_params *gp, int *resx, int *resy);   /* GridT
 mtfo_grid *mtfo_grid_create(const mtfo_grid_params *gp, mtfo_ssm *grid_ssm, mtfo_tracker **trackers, int n_trackers);
 void mtfo_grid_destroy(mtfo_grid *g);
 void mtfo_grid_set_estimator(mtfo_grid *g, mtfo_grid_estimator est, void *user);
+/* GridTracker::setImage :205-231 (enable_pyr off): every patch tracker's setImage(img) and curr_img = img.  The buffer is borrowed, as a
+ * cv::Mat header borrows it; prev_img is the grid's own clone (:241-243, :266). */
+void mtfo_grid_set_image(mtfo_grid *g, const float *img, int h, int w);
+/* the mask half of GridTracker::backwardEstimation (:307-332) alone: fb_err_mask (n) and the surviving point pairs (up to n x 2 each,
+ * filled up to n_model_pts in tracker order); returns their count */
+int mtfo_grid_fb_mask(int n, const float *prev_pts, const float *curr_pts, const float *fb_prev_pts, double fb_err_thresh, int n_model_pts,
+	unsigned char *fb_err_mask, float *prev_masked, float *curr_masked);
 void mtfo_grid_initialize(mtfo_grid *g, const double *corners);
 int mtfo_grid_update(mtfo_grid *g);   /* -1 without an estimator */
 void mtfo_grid_set_region(mtfo_grid *g, const double *corners);
-/* what: 0 region corners (8) 1 patch corners handed to the trackers (n x 8) 2 prev_pts (n x 2, float values) 3 curr_pts 4 ssm_update (S) */
+/* what: 0 region corners (8) 1 patch corners handed to the trackers (n x 8) 2 prev_pts (n x 2, float values) 3 curr_pts 4 ssm_update (S)
+ * 5 fb_prev_pts (n x 2) 6 fb_err_mask (n, 0 / 1) 7 the tracker locations the backward pass started from (n x 8) 8 the regions the patch
+ * trackers reached on the previous frame (n x 8) 9 the point pairs handed to the estimator in the last update: count, then prev (count x 2), curr (count x 2) */
 void mtfo_grid_get(const mtfo_grid *g, int what, double *dst);
 
 #ifdef __cplusplus

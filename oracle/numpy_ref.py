@@ -481,3 +481,27 @@ def aff_point_sampler(init_corners, mode, sigma, mean, z):
     A = np.vstack([orig, np.ones(3)])                                           # 3 x 3, exact for three non-collinear points
     M = pert @ np.linalg.inv(A)                                                 # 2 x 3
     return np.array([M[0, 2], M[1, 2], M[0, 0] - 1, M[0, 1], M[1, 0], M[1, 1] - 1])
+
+
+# ---------------------------------------------------------------------------------------------
+# r06 fixtures (tests/golden/make_golden4.py): GridTracker's forward-backward mask
+# ---------------------------------------------------------------------------------------------
+def grid_fb_mask(prev_pts, curr_pts, fb_prev_pts, fb_err_thresh, n_model_pts):
+    """The selection half of GridTracker::backwardEstimation (SM/src/GridTracker.cc:307-332) from its description: a patch is kept when the
+    squared distance between the centroid its backward track reached and the one it started from (single-precision points: the
+    coordinate differences are single-precision numbers, their squares and the sum are not) does not exceed the threshold; when fewer
+    than n_model_pts are kept, rejected patches are re-admitted in index order until that many are there, and their pairs go BEHIND
+    the kept ones.  -> (mask (n,) bool, prev pairs (c, 2) float32, curr pairs (c, 2) float32)."""
+    a = np.asarray(prev_pts, dtype=np.float32)
+    b = np.asarray(curr_pts, dtype=np.float32)
+    fb = np.asarray(fb_prev_pts, dtype=np.float32)
+    d = (fb - a).astype(np.float64)                      # float32 subtraction, widened afterwards
+    keep = d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] <= fb_err_thresh
+    order = list(np.flatnonzero(keep))
+    if len(order) < n_model_pts:
+        extra = list(np.flatnonzero(~keep)[:n_model_pts - len(order)])
+        order += extra
+        keep = keep.copy()
+        keep[extra] = True
+    idx = np.asarray(order, dtype=np.int64)
+    return keep, a[idx], b[idx]

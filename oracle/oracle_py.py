@@ -488,7 +488,8 @@ class Tracker:
 class GridParams(C.Structure):
     """GridTrackerParams (SM/src/GridTracker.cc:20-94); class defaults GridTracker.h:8-24, shipped values Config/modules.cfg:75-80"""
     _fields_ = [("grid_size_x", C.c_int), ("grid_size_y", C.c_int), ("patch_size_x", C.c_int), ("patch_size_y", C.c_int),
-                ("reset_at_each_frame", C.c_int), ("dyn_patch_size", C.c_int), ("patch_centroid_inside", C.c_int)]
+                ("reset_at_each_frame", C.c_int), ("dyn_patch_size", C.c_int), ("patch_centroid_inside", C.c_int),
+                ("fb_err_thresh", C.c_double), ("fb_reinit", C.c_int), ("n_model_pts", C.c_int)]
 
 
 _GRID_EST = C.CFUNCTYPE(None, C.c_void_p, C.c_int, _fp, _fp, _dp)
@@ -500,14 +501,26 @@ def grid_res(gp):
     return rx.value, ry.value
 
 
+def grid_fb_mask(prev_pts, curr_pts, fb_prev_pts, fb_err_thresh, n_model_pts=4):
+    """GridTracker::backwardEstimation :307-332 -> (fb_err_mask (n,) bool, prev_masked (c, 2) float32, curr_masked (c, 2) float32)"""
+    a, b, fb = (np.ascontiguousarray(x, dtype=np.float32) for x in (prev_pts, curr_pts, fb_prev_pts))
+    n = len(a)
+    mask = np.zeros(n, dtype=np.uint8)
+    pm, cm = np.zeros((n, 2), dtype=np.float32), np.zeros((n, 2), dtype=np.float32)
+    lib().mtfo_grid_fb_mask.argtypes = [C.c_int, _fp, _fp, _fp, C.c_double, C.c_int, C.POINTER(C.c_ubyte), _fp, _fp]
+    c = lib().mtfo_grid_fb_mask(n, _f(a), _f(b), _f(fb), float(fb_err_thresh), int(n_model_pts), mask.ctypes.data_as(C.POINTER(C.c_ubyte)), _f(pm), _f(cm))
+    return mask.astype(bool), pm[:c].copy(), cm[:c].copy()
+
+
 class Grid:
     """GridTracker<SSM> (SM/src/GridTracker.cc) over `trackers` (oracle Tracker objects, one per patch; none = layout only).
     estimator(prev_pts n x 2, curr_pts n x 2) -> ssm_update stands for ssm.estimateWarpFromPts (out of scope)."""
 
     def __init__(self, grid_ssm, trackers=(), grid_size=10, patch_size=10, reset_at_each_frame=1, dyn_patch_size=0,
-                 patch_centroid_inside=1, estimator=None, grid_size_y=None, patch_size_y=None):
+                 patch_centroid_inside=1, estimator=None, grid_size_y=None, patch_size_y=None, fb_err_thresh=0.0, fb_reinit=1,
+                 n_model_pts=4):
         self.gp = GridParams(grid_size, grid_size_y or grid_size, patch_size, patch_size_y or patch_size, reset_at_each_frame,
-                             dyn_patch_size, patch_centroid_inside)
+                             dyn_patch_size, patch_centroid_inside, float(fb_err_thresh), int(fb_reinit), int(n_model_pts))
         self.ssm, self.trackers = grid_ssm, list(trackers)
         self.n = self.gp.grid_size_x * self.gp.grid_size_y
         arr = (C.c_void_p * max(1, len(self.trackers)))(*[t.h for t in self.trackers])
@@ -543,6 +556,13 @@ class Grid:
         lib().mtfo_grid_get(self.h, what, _d(out))
         return out
 
+    def set_image(self, img):
+        """GridTracker::setImage: every patch tracker's setImage(img) and curr_img = img (borrowed: kept alive here)"""
+        self._img = np.ascontiguousarray(img, dtype=np.float32)
+        for t in self.trackers:
+            t.am._img = self._img
+        lib().mtfo_grid_set_image(self.h, _f(self._img), self._img.shape[0], self._img.shape[1])
+
     def initialize(self, corners):
         lib().mtfo_grid_initialize(self.h, _d(pts_to_flat(corners)))
 
@@ -550,8 +570,31 @@ class Grid:
         lib().mtfo_grid_set_region(self.h, _d(pts_to_flat(corners)))
 
     def update(self):
-        if lib().mtfo_grid_update(self.h) != 0:
+        rc = lib().mtfo_grid_update(self.h)
+        if rc == -3:
+            raise RuntimeError("GridTracker.update with forward-backward estimation needs Grid.set_image before initialize")
+        if rc != 0:
             raise RuntimeError("GridTracker.update without an estimator")
+
+    def fb_prev_pts(self):
+        return self._get(5, 2 * self.n).reshape(self.n, 2)
+
+    def fb_err_mask(self):
+        return self._get(6, self.n).astype(bool)
+
+    def fb_locations(self):
+        """n x 2 x 4: the tracker locations the backward pass started from"""
+        return self._get(7, 8 * self.n).reshape(self.n, 4, 2).transpose(0, 2, 1).copy()
+
+    def fb_regions(self):
+        """n x 2 x 4: where the patch trackers arrived on the previous frame"""
+        return self._get(8, 8 * self.n).reshape(self.n, 4, 2).transpose(0, 2, 1).copy()
+
+    def estimator_pairs(self):
+        """the point pairs the estimator was handed in the last update: (prev (c, 2), curr (c, 2))"""
+        raw = self._get(9, 1 + 4 * self.n)
+        c = int(raw[0])
+        return raw[1:1 + 2 * c].reshape(c, 2).copy(), raw[1 + 2 * c:1 + 4 * c].reshape(c, 2).copy()
 
     def get_region(self):
         return self._get(0, 8).reshape(4, 2).T
