@@ -47,12 +47,18 @@ def _oracle_grid(oracle, frame, grid_ssm, patch_am, patch_ssm, patch_sm, gs, ps,
 MODES = {"centroid_inside": (0, 1), "grid_points": (0, 0), "dyn_patch": (1, 0)}
 
 
+# r06 (was 2e-3 px throughout): the cv::Point2f centroids to one float ulp of a coordinate of a few hundred pixels (values that agree to
+# ~1e-7 px in double may round to neighbouring floats), the double-precision region and patch corners -- which have been through the
+# all-points fit of those floats -- to 1e-4 px; measured: <= 1.6e-5 px and <= 6e-6 px (profiles/r06_parity_record.jsonl)
+PT_ULP, REGION_ATOL = 4e-5, 1e-4
+
+
 def _compare(o, patch_corners, prev_pts, curr_pts, region, step):
-    np.testing.assert_allclose(patch_corners, o.patch_corners(), rtol=0, atol=2e-3, err_msg="patch corners, frame %d" % step)
-    np.testing.assert_allclose(prev_pts, o.prev_pts(), rtol=0, atol=2e-3, err_msg="prev_pts, frame %d" % step)
+    np.testing.assert_allclose(patch_corners, o.patch_corners(), rtol=0, atol=REGION_ATOL, err_msg="patch corners, frame %d" % step)
+    np.testing.assert_allclose(prev_pts, o.prev_pts(), rtol=0, atol=PT_ULP, err_msg="prev_pts, frame %d" % step)
     if curr_pts is not None:
-        np.testing.assert_allclose(curr_pts, o.curr_pts(), rtol=0, atol=2e-3, err_msg="curr_pts, frame %d" % step)
-    np.testing.assert_allclose(region, o.get_region(), rtol=0, atol=2e-3, err_msg="region, frame %d" % step)
+        np.testing.assert_allclose(curr_pts, o.curr_pts(), rtol=0, atol=PT_ULP, err_msg="curr_pts, frame %d" % step)
+    np.testing.assert_allclose(region, o.get_region(), rtol=0, atol=REGION_ATOL, err_msg="region, frame %d" % step)
 
 
 @pytest.mark.parametrize("mode", sorted(MODES))
@@ -351,7 +357,9 @@ def test_grid_forward_backward_follows_oracle(oracle, gpu_ctx, frame, parity_rec
                 assert not o.fb_err_mask()[7] and o.fb_err_mask().sum() >= gs * gs - 4
         np.testing.assert_allclose(get["curr"](), o.curr_pts(), rtol=0, atol=ULP, err_msg="curr_pts, frame %d" % k)
         np.testing.assert_allclose(get["prev"](), o.prev_pts(), rtol=0, atol=ULP, err_msg="prev_pts, frame %d" % k)
-        np.testing.assert_allclose(get["upd"](), o.ssm_update(), rtol=0, atol=2e-6, err_msg="ssm_update, frame %d" % k)
+        # (the fit sees cv::Point2f centroids: values that agree to ~1e-7 px in double can round to neighbouring floats, 3e-5 px apart at a few
+        # hundred pixels, and the all-points fit passes that on to its translation entries at about the same size)
+        np.testing.assert_allclose(get["upd"](), o.ssm_update(), rtol=0, atol=2e-5, err_msg="ssm_update, frame %d" % k)
         np.testing.assert_allclose(g.get_region(), o.get_region(), rtol=0, atol=2e-4, err_msg="region, frame %d" % k)
         worst["curr"] = max(worst["curr"], float(np.abs(get["curr"]() - o.curr_pts()).max()))
         worst["upd"] = max(worst["upd"], float(np.abs(get["upd"]() - o.ssm_update()).max()))
@@ -362,13 +370,14 @@ def test_grid_forward_backward_follows_oracle(oracle, gpu_ctx, frame, parity_rec
 
 
 @pytest.mark.parametrize("fb_reinit", [0, 1])
-def test_grid_backward_abi_patch_regions_follow_oracle(oracle, gpu_ctx, frame, fb_reinit):
+def test_grid_backward_abi_patch_regions_follow_oracle(oracle, frame, fb_reinit):
     """mtfhip_grid_backward alone, in double precision (before the cv::Point2f rounding): where every patch tracker arrives on the previous
     frame against the oracle's per-patch trackers at 1e-6 px, the iteration counts, that the current image is the current one again
     afterwards and the trackers sit on their forward locations (setRegion(tracker_location)); and the refusals."""
     gs, ps = 4, 25
     est = least_squares_estimator(L.SSM_HOMOGRAPHY)
     f2 = _frames(frame, 1, 92)[0]
+    gpu_ctx = mtf_amd.Context(0)     # (its own context: the session's has kept a previous image in the tests above)
     gpu_ctx.set_image(frame)
     g = GridTracker(gpu_ctx, grid_size=gs, patch_size=ps, am=L.AM_NCC, ssm=L.SSM_AFFINE, max_iters=25, epsilon=1e-6, reset_at_each_frame=0, estimator=est)
     b = g.tracker.batch
@@ -405,12 +414,13 @@ def test_grid_backward_abi_patch_regions_follow_oracle(oracle, gpu_ctx, frame, f
     with pytest.raises(mtf_amd.MtfHipError, match="mismatch between the grid dimensions"):
         b.grid_backward(wrong, g.tracker.sm, fbd)
     b.close()
+    gpu_ctx.close()
 
 
 @pytest.mark.parametrize("am,ssm,ps", [(L.AM_NCC, L.SSM_AFFINE, 25), (L.AM_SSD, L.SSM_AFFINE, 25), (L.AM_NCC, L.SSM_HOMOGRAPHY, 30)])
 def test_grid_template_init_and_first_iteration_against_the_oracles_trackers(oracle, gpu_ctx, frame, parity_record, am, ssm, ps):
     """r05's verdict: k_template_init and the one-launch grid loop were checked against the call-by-call HIP form only.  Here against the
-    oracle's nt::ICLK::initialize arrays directly -- I0 and dI0_dx bit for bit, J0 / H0 to rounding -- and, per patch, g, the state
+    oracle's nt::ICLK::initialize arrays directly -- I0, dI0_dx, J0 / H0 to the rounding of the sample points -- and, per patch, g, the state
     update and the corners of every iteration of the first frame at the north-star tolerance (1e-5 relative), the tracked corners at
     1e-6 px in double (before any cv::Point2f rounding)."""
     gs = 4
@@ -435,10 +445,13 @@ def test_grid_template_init_and_first_iteration_against_the_oracles_trackers(ora
         o_am.set_curr_img(frame)
         trk = oracle.Tracker(oracle.SM_ICLK, o_am, o_ssm, leven_marq=0, max_iters=12, epsilon=1e-6, hess_type=0)
         trk.initialize(patches[t])
-        assert np.array_equal(I0[t], o_am.get("I0")), "I0 of patch %d" % t
-        assert np.array_equal(dI0[t], o_am.get("dI0_dx").reshape(2, -1).T), "dI0_dx of patch %d" % t
-        J0_o = o_ssm.cmpt_warped_pix_jacobian(o_am.get("dI0_dx")).reshape(S, -1).T
-        np.testing.assert_allclose(J0[t], J0_o, rtol=1e-12, atol=1e-9, err_msg="J0 of patch %d" % t)
+        # (the sample points themselves agree to ~1e-12 px -- closed-form square-to-quadrilateral map against the oracle's SVD DLT -- so the
+        # samples are compared at that distance times the image gradient, not bit for bit; the finite difference over 2e-8 px amplifies it)
+        np.testing.assert_allclose(I0[t], o_am.get("I0"), rtol=0, atol=1e-9, err_msg="I0 of patch %d" % t)
+        np.testing.assert_allclose(dI0[t], o_am.get("dI0_dx").reshape(2, -1).T, rtol=0, atol=2e-5, err_msg="dI0_dx of patch %d" % t)
+        # J0: the oracle's cmptWarpedPixJacobian of the DEVICE's gradient (the formula, free of the finite difference's amplification) ...
+        J0_o = o_ssm.cmpt_warped_pix_jacobian(np.ascontiguousarray(dI0[t].T).ravel()).reshape(S, -1).T
+        np.testing.assert_allclose(J0[t], J0_o, rtol=1e-11, atol=1e-9, err_msg="J0 of patch %d" % t)
         worst["J0"] = max(worst["J0"], float(np.abs(J0[t] - J0_o).max() / np.abs(J0_o).max()))
         o_am.set_curr_img(f2)
         n_o = trk.update()
@@ -446,17 +459,18 @@ def test_grid_template_init_and_first_iteration_against_the_oracles_trackers(ora
         assert n[t] == n_o == len(rec)
         if H0 is not None:
             e = np.linalg.norm(H0[t] - rec[0]["H"]) / np.linalg.norm(rec[0]["H"])
-            assert e < 1e-11, "H0 of patch %d: %.3e" % (t, e)
+            assert e < 1e-7, "H0 of patch %d: %.3e" % (t, e)
             worst["H0"] = max(worst["H0"], float(e))
+        g0, d0 = np.linalg.norm(rec[0]["g"]), np.linalg.norm(rec[0]["dp"])
         for k in range(n_o):
-            eg = np.linalg.norm(trace[t][k]["g"] - rec[k]["g"]) / np.linalg.norm(rec[k]["g"])
-            ed = np.linalg.norm(trace[t][k]["dp"] - rec[k]["dp"]) / max(np.linalg.norm(rec[k]["dp"]), 1e-9)
+            # north-star tolerance (1e-5 relative) on the first iteration; the later ones -- g and the update shrink towards zero as the
+            # patch converges, the reference's own finite-difference noise floor does not -- on the first iteration's scale, as
+            # _fused_follow holds g to its Cauchy-Schwarz scale
+            eg = np.linalg.norm(trace[t][k]["g"] - rec[k]["g"]) / (np.linalg.norm(rec[k]["g"]) if k == 0 else g0)
+            ed = np.linalg.norm(trace[t][k]["dp"] - rec[k]["dp"]) / (np.linalg.norm(rec[k]["dp"]) if k == 0 else d0)
             ec = np.abs(trace[t][k]["corners"] - rec[k]["corners"]).max()
-            # (late iterations: g and dp go to zero, their relative error is then that of a difference of nearly equal numbers -- the
-            # north-star tolerance is held on the first five iterations as in _fused_follow, and the absolute one on all of them)
-            if k < 5:
-                assert eg < 1e-5 and ed < 1e-5, "patch %d iteration %d: g %.3e dp %.3e" % (t, k, eg, ed)
-                worst["g"], worst["dp"] = max(worst["g"], float(eg)), max(worst["dp"], float(ed))
+            assert eg < 1e-5 and ed < 1e-5, "patch %d iteration %d: g %.3e dp %.3e" % (t, k, eg, ed)
+            worst["g"], worst["dp"] = max(worst["g"], float(eg)), max(worst["dp"], float(ed))
             assert ec < 1e-6, "patch %d iteration %d: corners %.3e px" % (t, k, ec)
             worst["corners"] = max(worst["corners"], float(ec))
         np.testing.assert_allclose(corners[t], trk.get_region(), rtol=0, atol=1e-6)
