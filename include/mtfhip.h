@@ -363,7 +363,9 @@ int mtfhip_grid_backward(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip
 int mtfhip_grid_fb_mask(int n, const float *prev_pts, const float *curr_pts, const float *fb_prev_pts, const mtfhip_grid_fb_desc *fb,
 	unsigned char *fb_err_mask, float *prev_masked, float *curr_masked, int *n_masked);
 /* GridTracker::update's patch loop with the estimation on (:254-266): mtfhip_grid_frame (region_corners as there), then
- * mtfhip_grid_backward and mtfhip_grid_fb_mask against prev_pts (the centroids the last reset / frame left, B x 2). */
+ * mtfhip_grid_backward and mtfhip_grid_fb_mask against prev_pts (the centroids the last reset / frame left, B x 2).  With
+ * g->reset_at_each_frame != 0 the caller's resetTrackers follows (:273-274: mtfhip_grid_reset, or the region of the next frame) and
+ * replaces whatever setRegion(tracker_location) would leave, so that last step of the backward pass is left out. */
 int mtfhip_grid_frame_fb(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_grid_desc *g, const mtfhip_grid_fb_desc *fb,
 	const double *region_corners /* 8 or NULL */, const float *prev_pts /* B x 2 */, int *n_iters /* B or NULL */, double *corners /* B x 8 or NULL */,
 	float *centroids /* B x 2 or NULL */, float *fb_prev_pts /* B x 2 */, unsigned char *fb_err_mask /* B */, float *prev_masked /* B x 2 or NULL */,

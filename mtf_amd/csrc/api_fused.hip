@@ -1162,8 +1162,14 @@ int mtfhip_grid_fb_mask(int n, const float *prev_pts, const float *curr_pts, con
 /* the patch half of backwardEstimation (:295-306) for every patch tracker of the batch at once: re-initialised at its tracked location on the
  * current frame (fb_reinit), run on the PREVIOUS frame (mtfhip_image_keep_prev), centroid of where it arrives, then back on the current
  * frame and setRegion(location) */
+static int grid_backward_impl(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_grid_desc *g, const mtfhip_grid_fb_desc *fb, int *n_iters, double *fb_corners,
+	float *fb_prev_pts, bool restore);
 int mtfhip_grid_backward(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_grid_desc *g, const mtfhip_grid_fb_desc *fb, int *n_iters, double *fb_corners,
 	float *fb_prev_pts) {
+	return grid_backward_impl(b, sm, g, fb, n_iters, fb_corners, fb_prev_pts, true);
+}
+static int grid_backward_impl(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_grid_desc *g, const mtfhip_grid_fb_desc *fb, int *n_iters, double *fb_corners,
+	float *fb_prev_pts, bool restore) {
 	if (!sm || !fb) return fail(MTFHIP_ERR_INVALID_ARG, "grid_backward: NULL argument");
 	TRY(grid_batch_ok(b, g, "grid_backward"));
 	if (!b->init_pix_vals) return fail(MTFHIP_ERR_LOGIC, "grid_backward before the patch trackers were initialised");
@@ -1194,6 +1200,7 @@ int mtfhip_grid_backward(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip
 	if (rs != MTFHIP_OK) return rs;
 	if (fb_corners) std::memcpy(fb_corners, out.data(), sizeof(double) * 8 * B);
 	if (fb_prev_pts) for (size_t t = 0; t < B; ++t) centroid_f(fb_prev_pts + 2 * t, &out[8 * t]);      /* getCentroid(fb_prev_pts[id], getRegion()) :302 */
+	if (!restore) return MTFHIP_OK;
 	return mtfhip_batch_set_region(b, loc.data(), sm);                                                 /* tracker->setRegion(tracker_location) :305 */
 }
 /* GridTracker::update's patch loop followed by backwardEstimation (:254-266): mtfhip_grid_frame, mtfhip_grid_backward and the mask in one call */
@@ -1207,7 +1214,11 @@ int mtfhip_grid_frame_fb(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip
 	cen.resize(2 * (size_t)b->B);
 	TRY(mtfhip_grid_frame(b, sm, g, region, n_iters, corners, cen.data()));
 	if (centroids) std::memcpy(centroids, cen.data(), sizeof(float) * cen.size());
-	TRY(mtfhip_grid_backward(b, sm, g, fb, nullptr, nullptr, fb_prev_pts));
+	/* GridTracker::update goes on to resetTrackers when reset_at_each_frame != 0 (:273-274): every patch tracker is then initialize()d or
+	 * setRegion()ed on the new grid, which replaces all that setRegion(tracker_location) (:305) would leave -- the SSM's state; with fb_reinit
+	 * the template is the backward pass's either way -- so that call is left out here (MTFHIP_GRID_FB_RESTORE=1 keeps it) */
+	static const bool always_restore = std::getenv("MTFHIP_GRID_FB_RESTORE") && std::getenv("MTFHIP_GRID_FB_RESTORE")[0] == '1';
+	TRY(grid_backward_impl(b, sm, g, fb, nullptr, nullptr, fb_prev_pts, always_restore || g->reset_at_each_frame == 0));
 	return mtfhip_grid_fb_mask(b->B, prev_pts, cen.data(), fb_prev_pts, fb, fb_err_mask, prev_masked, curr_masked, n_masked);
 }
 /* GridTracker::resetTrackers(reinit) GridTracker.cc:345-392 */

@@ -327,6 +327,17 @@ class CppGridTracker:
     def patch_iters(self):
         return self._get(5, self.n).astype(np.int32)
 
+    def bench_video(self, frame_a, frame_b, n_frames=200):
+        """the video loop on the C++ side: per frame setImage(the other of two frames) + update() -> (us per frame in update(), us per frame in
+        setImage = the host-to-device copy of the frame)"""
+        assert frame_a.dtype == np.float32 and frame_b.dtype == np.float32 and frame_a.shape == frame_b.shape and frame_a.flags["C_CONTIGUOUS"] and frame_b.flags["C_CONTIGUOUS"]
+        us = (C.c_double * 2)()
+        fn = lib().mtfhost_grid_bench_video
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _check(fn(self._h, int(n_frames), frame_a.ctypes.data_as(C.c_void_p), frame_b.ctypes.data_as(C.c_void_p), frame_a.shape[0], frame_a.shape[1],
+                  frame_a.shape[1], C.cast(us, C.c_void_p)))
+        return us[0], us[1]
+
     def bench_frames(self, region, n_frames=300, what=0):
         """microseconds per frame of a loop that runs on the C++ side: what = 0 mtfhip_grid_frame(region) calls (layout + setRegion + update,
         one launch), 1 mtf::hip::Grid::update() (the same + the estimator + the reset of the parameters)"""

@@ -388,3 +388,27 @@ extern "C" int mtfhost_grid_bench(mtfhost_grid *h, int what, int n_frames, const
 		return 0;
 	} catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
+
+/* the video loop as runMTF drives a tracker (Examples/cpp/runMTF.cc:650-720): per frame setImage(next frame) -- the caller's buffer is
+ * overwritten in place, so the device copy is refreshed -- then update().  Two frames alternate (the motion A -> B,
+ * then B -> A: the region oscillates and the loop is stationary).  us[0] = per frame in update() alone, us[1] = per frame in setImage
+ * (the host-to-device copy of the frame), both over exactly n_frames frames after n_frames / 10 + 5 untimed ones. */
+extern "C" int mtfhost_grid_bench_video(mtfhost_grid *h, int n_frames, const float *frame_a, const float *frame_b, int rows, int cols, int step, double *us) {
+	try {
+		hip::Grid &g = *h->g;
+		double t_upd = 0, t_img = 0;
+		for (int k = -(n_frames / 10 + 5); k < n_frames; ++k) {
+			const auto t0 = std::chrono::steady_clock::now();
+			g.setImage(ImageView{(k & 1) ? frame_a : frame_b, rows, cols, step});
+			const auto t1 = std::chrono::steady_clock::now();
+			g.update();
+			const auto t2 = std::chrono::steady_clock::now();
+			if (k >= 0) {
+				t_img += std::chrono::duration<double, std::micro>(t1 - t0).count();
+				t_upd += std::chrono::duration<double, std::micro>(t2 - t1).count();
+			}
+		}
+		us[0] = t_upd / n_frames; us[1] = t_img / n_frames;
+		return 0;
+	} catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
