@@ -347,6 +347,80 @@ def self_spawn_if_needed(args, argv):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+CONFIGS_CHILD_TIMEOUT_S = 90
+
+
+def _compact(line):
+    """the fields of a secondary workload's line the headline's `configs` block keeps"""
+    roof = line.get("roofline") or {}
+    cfg = line.get("config") or {}
+    akm = roof.get("avg_kernel_ms")
+    if isinstance(akm, dict):
+        kernel_us = {k: (v * 1e3 if v is not None else None) for k, v in akm.items()}
+    else:
+        kernel_us = akm * 1e3 if akm else None
+    par = line.get("parity")
+    if isinstance(par, dict) and "pass" in par:
+        par = {"pass": par["pass"], "budget": par.get("budget"),
+               "first_pass_g_dp": [(par.get("vs_reference_parameters_grad_eps_1e-8") or {}).get("g"), (par.get("vs_reference_parameters_grad_eps_1e-8") or {}).get("dp")]}
+    cb = line.get("cpu_baseline") or None
+    rec = {"metric": line.get("metric"), "value": line.get("value"), "unit": line.get("unit"), "ms_per_step": line.get("ms_per_step"), "steps": line.get("steps"),
+           "workload": cfg.get("workload"), "dominant_kernel": roof.get("kernel"), "dominant_kernel_us_by_events": kernel_us,
+           "roofline": {"bound": roof.get("bound"), "frac": roof.get("frac"), "achieved": roof.get("achieved"), "peak": roof.get("peak"), "unit": roof.get("unit")},
+           "cpu_baseline": ({"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"), "sample": cb.get("sample")} if cb else None),
+           "parity": par}
+    for k in ("us_per_iteration", "iterations_per_step", "frame_us", "kernel_us", "score_kernel_ms", "resample_kernels_ms"):
+        if k in cfg:
+            rec[k] = cfg[k]
+    vl = (cfg.get("cpp_driver") or {}).get("video_loop")
+    if vl:
+        rec["video_loop_update_us"] = {k: v.get("update_us") for k, v in vl.items() if isinstance(v, dict)}
+    if "hbm_frac" in roof:
+        rec["roofline"]["hbm_frac"] = roof["hbm_frac"]
+    return rec
+
+
+def configs_block(args):
+    """r05 verdict item 2: configs 3 / 4 / 5 of BASELINE.json in the driver's own line.  Each is this file's secondary workload run as a
+    child process at a reduced step count (its own context on the same GPU; the parent's device work is over) -- a failure or a hang
+    there (timeout: the child is killed) becomes {"error": ...} and cannot take the headline down."""
+    import subprocess
+    me = os.path.abspath(__file__)
+    cpu = "%.1f" % min(args.cpu_seconds, 1.5)
+    specs = [
+        ("config3_grid_256_iclk_ncc_affine", ["--workload", "grid", "--steps", "100", "--warmup", "10", "--cpu-seconds", cpu]),
+        ("config4_pf_10k_chained", ["--workload", "pf", "--particles", "10000", "--pf-iters", "10", "--steps", "40", "--warmup", "5", "--cpu-seconds", cpu]),
+        ("config4_pf_10k_host_stepped", ["--workload", "pf", "--particles", "10000", "--pf-iters", "1", "--steps", "200", "--warmup", "20", "--no-cpu"]),
+        ("config5_mi_64x400x400", ["--workload", "mi", "--steps", "6", "--warmup", "2", "--cpu-seconds", cpu]),
+        ("nn_dataset_10k_50x50", ["--workload", "nn", "--steps", "10", "--warmup", "2", "--cpu-seconds", cpu]),
+    ]
+    env = os.environ.copy()
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = {}
+    for name, argv in specs:
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, me] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=CONFIGS_CHILD_TIMEOUT_S)
+            line = None
+            for ln in r.stdout.decode("utf-8", "replace").splitlines():
+                if ln.startswith("{"):
+                    line = ln
+            if r.returncode != 0 or line is None:
+                out[name] = {"error": "rc %d: %s" % (r.returncode, r.stderr.decode("utf-8", "replace")[-300:])}
+            else:
+                out[name] = _compact(json.loads(line))
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": "no line within %d s (child killed)" % CONFIGS_CHILD_TIMEOUT_S}
+        except Exception as e:   # noqa: BLE001
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out[name]["wall_s"] = time.perf_counter() - t0
+    out["note"] = ("configs 3 / 4 / 5 of BASELINE.json (+ the NN dataset axis) at reduced step counts, each `python bench.py --workload ...` as a child process on the "
+                   "same GPU after the headline's timed regions; full lines: profiles/r06_secondary_bench_lines.jsonl")
+    return out
+
+
+
 def stub_mode():
     """MTFHIP_BENCH_STUB=1: the launch / rendezvous / barrier / max-over-ranks / JSON skeleton of this file with the device work replaced
     by stand-ins and gloo instead of RCCL, so that tests/test_bench_cpu.py can run `bench.py --gpus 2` on a box without GPUs.  A stub
@@ -1111,10 +1185,14 @@ def main():
     ap.add_argument("--math", default="fast", choices=["fast", "replay"],
                     help="arithmetic of the non-materialising kernels: fast = FMA / one reciprocal per point / closed-form gradient "
                          "(within 1e-5), replay = the reference's rounding bit for bit (mtfhip_batch_set_math_mode)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-lean", action="store_true", help="skip the lean and single-target sub-records of the headline line")
+    ap.add_argument("--event-stride", type=int, default=0, help="lk workload: HIP events around every n-th fused launch inside the timed regions; 0 (default) = none -- "
+                    "at the driver's 20 steps a region is 1 ms and even every 4th launch instrumented costs 12 %% of it (1.19 M -> 1.05 M iters/s, r06 A/B)")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each (value = the median region)")
+    ap.add_argument("--configs", type=int, default=-1, help="append the `configs` block (BASELINE.json's configs 3 / 4 / 5 at reduced step counts, child "
+                    "processes) to the lk line: -1 = at --gpus 1 with the default workload shape (default), 0 = never, 1 = always")
     ap.add_argument("--pf-strong", type=int, default=-1, help="append the sharded-filter strong-scaling record (pf_strong) to the lk line: "
                     "-1 = when --gpus > 1 (default), 0 = never, 1 = always (on one GPU it exercises the code path with one rank)")
     args = ap.parse_args()
@@ -1197,10 +1275,15 @@ def main():
     # template Jacobian of ESM (164 MB written) and leave the timed steps to start on a cold Infinity Cache
     # `--repeats` such regions (r03 verdict: one 1 ms region is one sample; the builder's own eight runs spanned 5 %): each is W untimed
     # warm-up steps + EXACTLY K timed steps between barrier + synchronize, MAX over ranks; value = the median region, min / max beside it
+    # r05 verdict item 8: roofline.frac and value from the SAME execution -- HIP events around every --event-stride-th fused launch INSIDE the
+    # timed region (mtfhip_timing_enable(ctx, n > 1): two event records per sampled launch, on the queue the launch goes to)
     def timed_region():
         run(max(1, args.warmup))
         batch.set_state(np.zeros((B, 8)))
         sm.max_iters = args.steps
+        if args.event_stride > 0:
+            ctx.timing(args.event_stride if args.event_stride > 1 else True)
+            ctx.timing_reset()          # (drains and synchronises: in front of the barrier, outside the clock)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -1211,13 +1294,19 @@ def main():
             dist.barrier()
         d = time.perf_counter() - t0
         assert int(n_it.min()) == args.steps and int(n_it.max()) == args.steps
+        km_r, kn_r = (0.0, 0)
+        if args.event_stride > 0:
+            ctx.timing(False)
+            km_r, kn_r = ctx.timing_get("fused_lk")
         if dist is not None:
             tmax = torch.tensor([d], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             d = float(tmax.item())
-        return d
-    region_s = [timed_region() for _ in range(max(1, args.repeats))]
-    dt = float(sorted(region_s)[(len(region_s) - 1) // 2])   # (an actual region: ms_per_step x steps is one region's wall time)
+        return d, km_r, kn_r
+    regions = [timed_region() for _ in range(max(1, args.repeats))]
+    region_s = [r[0] for r in regions]
+    dt, region_kern_ms, region_kern_n = sorted(regions)[(len(regions) - 1) // 2]   # (an actual region: ms_per_step x steps is one region's wall time)
+    dt = float(dt)
     # kernel duration for the roofline: hipEvents around EVERY fused launch of a second, untimed pass of the same loop (at least 200
     # launches whatever --steps is -- with 40 the first launches after the region reset still weighed on the average, 0.720-0.727
     # against 0.734-0.738 for the same code at --steps 200; the events cost ~5 % of a step, which is why they stay out of the timed
@@ -1296,8 +1385,17 @@ def main():
         queues = batch.track_queues(sm)
         # algorithmic bytes of the timed launches / time during which the kernel was executing.  One queue: = bytes per launch / average
         # launch duration.  Two queues: the launches overlap, one of them sees bytes_per_launch / avg_kernel_ms, together they reach this
-        achieved = bytes_per_launch * busy_n / (busy_ms * 1e-3) / 1e9 if busy_ms > 0 else 0.0
-        in_flight = kern_ms * kern_n / busy_ms if busy_ms > 0 else 0.0
+        ev_achieved = bytes_per_launch * busy_n / (busy_ms * 1e-3) / 1e9 if busy_ms > 0 else 0.0     # the separate, fully instrumented event pass
+        ev_in_flight = kern_ms * kern_n / busy_ms if busy_ms > 0 else 0.0
+        # the timed region itself (the execution `value` comes from): sampled launch durations, and the region's algorithmic bytes over its wall time
+        launches_per_step = B / float(per_launch)
+        same = region_kern_n > 0 and region_kern_ms > 0
+        launch_ms_per_step = region_kern_ms * launches_per_step if same else None
+        in_flight = launch_ms_per_step / (dt / args.steps * 1e3) if same else None
+        # `achieved` / `frac` are the timed region's own: its algorithmic bytes over its wall time -- the execution `value` is read from, so the two
+        # cannot disagree (frac = value x bytes per target-iteration / peak).  The wall time contains the solves, cold first passes and call
+        # overhead: a lower bound on the rate while the fused kernel runs.  The event-instrumented second pass rides along as `event_pass`.
+        achieved = float(bpp) * N * B * args.steps / dt / 1e9
         out = {
             "metric": "LK iters/sec (warp+grad+Hessian), ESM+%s%s+Homography 200x200" % ("MC" if CH > 1 else "", args.am.upper()),
             "value": B * world * args.steps / dt,
@@ -1321,21 +1419,21 @@ def main():
                          # 256 MB Infinity Cache, only the non-temporal stores of the materialised arrays reach HBM
                          "dram_frac": achieved / HBM_PEAK_GBS * float(88 if materialize and args.sm != "iclk" else (8 if materialize else 0)) / bpp,
                          "traffic": pmc_traffic(args.sm, args.mode, res, B, per_launch) if (args.am == "ssd" and CH == 1) else None,
-                         "kernel": "k_fused_%s" % args.am, "avg_kernel_ms": kern_ms, "launches_timed": kern_n,
-                         "queues": queues, "kernel_busy_ms": busy_ms, "launches_in_flight": in_flight,
-                         "per_launch_GBs": bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None,
-                         "formula": "achieved = bytes_per_launch x launches_timed / kernel_busy_ms (kernel_busy_ms = union of the launches' "
-                                    "event intervals) = per_launch_GBs x launches_in_flight",
+                         "kernel": "k_fused_%s" % args.am, "avg_kernel_ms": region_kern_ms if same else kern_ms, "launches_timed": region_kern_n if same else kern_n,
+                         "avg_kernel_ms_source": ("HIP events around every %d-th fused launch inside the median timed region" % args.event_stride) if same else
+                                                 "the event pass below (no events inside the timed regions: --event-stride 0)",
+                         "queues": queues, "launches_in_flight": in_flight if same else ev_in_flight,
+                         "per_launch_GBs": bytes_per_launch / ((region_kern_ms if same else kern_ms) * 1e-3) / 1e9 if (region_kern_ms if same else kern_ms) > 0 else None,
+                         "launch_ms_per_step": launch_ms_per_step, "ms_per_step": dt / args.steps * 1e3,
+                         "formula": "same execution as `value`: achieved = algorithmic bytes of the K timed steps (bytes_per_launch x launches) / the median "
+                                    "region's wall time; that wall time contains the kernel's busy time plus the solves, so achieved is a lower bound on the "
+                                    "rate while the fused kernel runs and kernel time per step <= ms_per_step by construction",
                          "avg_finish_ms": fin_ms,
-                         # `frac` comes from the event pass, `value` / `ms_per_step` from the timed region: two executions of the same loop,
-                         # side by side (the event pass records two events per launch and is the slower, i.e. the conservative one)
+                         # a second, untimed execution with events around EVERY launch (the union of their intervals = the time the kernel was
+                         # executing): the instrumented loop is the slower one, its figure rides along
                          "event_pass": {"steps": k_steps, "ms_per_step_wall": ev_pass_s / k_steps * 1e3, "kernel_busy_ms_per_step": busy_ms / k_steps,
-                                        "timed_region_ms_per_step": dt / args.steps * 1e3},
-                         # the event pass perturbs the overlap of the two queues (events are recorded around every launch); the timed
-                         # region has no events: its algorithmic bytes / its wall time -- solves, cold first passes and call overhead
-                         # included -- is a lower bound on what the fused launches reached there
-                         "timed_region_GBs": float(bpp) * N * B * args.steps / dt / 1e9,
-                         "timed_region_frac": float(bpp) * N * B * args.steps / dt / 1e9 / HBM_PEAK_GBS,
+                                        "avg_kernel_ms": kern_ms, "launches_timed": kern_n, "launches_in_flight": ev_in_flight, "achieved": ev_achieved,
+                                        "frac": ev_achieved / HBM_PEAK_GBS, "formula": "bytes_per_launch x launches / union of the launches' event intervals"},
                          "algorithmic_bytes_per_pixel": bpp, "j0_rows": "rebuilt from dI0_dx" if j0_rec else "read back", "bytes_per_launch": bytes_per_launch,
                          "targets_per_launch": per_launch,
                          # what the figure means: algorithmic bytes / kernel time.  The read set of a launch (grid points, I0, dI0_dx:
@@ -1343,10 +1441,10 @@ def main():
                          # served from there; the 88 B/px of non-temporal stores do reach HBM.
                          "infinity_cache_resident_read_bytes": float(bpp - (88 if materialize and args.sm != "iclk" else (8 if materialize else 0))) * N * per_launch,
                          "hbm_write_bytes": float(88 if materialize and args.sm != "iclk" else (8 if materialize else 0)) * N * per_launch,
-                         "timing": "hipEvents around every fused launch of an untimed second pass (%d launches), recorded on the queue each launch "
-                                   "goes to; rocprofv3 --kernel-trace of the same command with --no-cpu --no-lean (the lean and single-target "
-                                   "sub-records launch the same kernel at other sizes): profiles/r04_kernel_stats.csv (one queue: "
-                                   "profiles/r04_kernel_stats_one_queue.csv)" % kern_n,
+                         "timing": "wall clock of the timed regions (events inside them with --event-stride n: every n-th fused launch, now %d) and hipEvents around every "
+                                   "launch of an untimed second pass (%d launches, on the queue each launch goes to); rocprofv3 --kernel-trace of the same command with --no-cpu --no-lean --configs 0 (the lean, "
+                                   "single-target and configs sub-records launch the same kernel at other sizes): profiles/r06_kernel_stats.csv (one queue: "
+                                   "profiles/r06_kernel_stats_one_queue.csv)" % (args.event_stride, kern_n),
                          "traffic_source": "rocprofv3 --pmc passes of tools/profile_round.sh on these kernel sources (profiles/pmc_latest.json: "
                                            "(2 x FETCH_SIZE + WRITE_SIZE) KiB, the guide's gfx950 correction); counters cannot be read inside a timed run",
                          "traffic_commit": getattr(pmc_traffic, "commit", None), "traffic_note": getattr(pmc_traffic, "note", None),
@@ -1383,6 +1481,11 @@ def main():
         dog.cancel()
         if out is not None:
             out["pf_strong"] = rec
+    if out is not None and (args.configs == 1 or (args.configs < 0 and world == 1 and not args.no_cpu and CH == 1 and args.mode == "full")):
+        try:
+            out["configs"] = configs_block(args)
+        except Exception as e:   # noqa: BLE001
+            out["configs"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if out is not None:
         print(json.dumps(out), flush=True)
     ctx.close()    # handles released while the HIP runtime is whole (the library's atexit hook would do the same)
