@@ -382,7 +382,7 @@ int mtfhip_batch_create(mtfhip_ctx *c, const mtfhip_patch_desc *d, int n_targets
 	ALLOC(b->d_colmean, sizeof(double) * 8 * n_targets);
 	if (d->am == MTFHIP_AM_MI) {
 		const int nb = d->mi_n_bins;
-		b->mi_row_len = std::max(std::max(nb + 2 * nb * nb, 36 + nb * nb * b->S), nb == 8 ? mi_fast_row_len() : 0);   /* widest of the MI partial rows (fused passes incl.) */
+		b->mi_row_len = std::max(std::max(nb + 2 * nb * nb, 36 + nb * nb * b->S), nb <= 10 ? mi_fast_row_len(nb) : 0);   /* widest of the MI partial rows (fused passes incl.) */
 		/* hist_norm_mult = 1 / (patch_size + hist_pre_seed * n_bins), hist_pre_seed = n_bins * pre_seed (MI.cc:97,104) */
 		b->mi_hist_norm = 1.0 / ((double)b->N + (nb * d->mi_pre_seed) * nb);
 		ALLOC(b->d_mi_tb, sizeof(double) * MI_SIZE * n_targets);

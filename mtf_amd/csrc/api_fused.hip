@@ -710,10 +710,15 @@ static int mi_enqueue(mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPlan &p
  * materialised, every first-order type but SumOfStd (two Hessian passes: it keeps the materialising form). */
 static bool mi_fast_ok(const mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPlan &pl) {
 	static const bool enabled = !(std::getenv("MTFHIP_MI_RECOMPUTE") && std::getenv("MTFHIP_MI_RECOMPUTE")[0] == '0');
-	return enabled && b->math_mode == MTFHIP_MATH_FAST && b->desc.mi_n_bins == 8 && !sm->materialize && pl.hk != MiPlan::H_SUM_STD;
+	/* r06: other bin counts up to ten (the shipped mi_n_bins 10, Config/modules.cfg:115) in the polynomial forms of pass 2 -- the constant and the
+	 * self Hessian, single channel; 8 bins: every first-order form but SumOfStd */
+	const int nb = b->desc.mi_n_bins;
+	const bool bins_ok = nb == 8 || (nb <= 10 && b->C == 1 && (pl.hk == MiPlan::H_CONST || pl.hk == MiPlan::H_SELF_JT));
+	return enabled && b->math_mode == MTFHIP_MATH_FAST && bins_ok && !sm->materialize && pl.hk != MiPlan::H_SUM_STD;
 }
 static MiFastPlan mi_fast_plan(const mtfhip_batch *b, const MiPlan &pl, const int *active, const mtfhip_sm_desc *sm) {
 	MiFastPlan fp;
+	fp.nb = b->desc.mi_n_bins;
 	fp.nonchained = (sm && !sm->chained_warp) ? 1 : 0;
 	fp.hk = pl.hk == MiPlan::H_CONST ? 0 : (pl.hk == MiPlan::H_SELF_JT ? 1 : (pl.hk == MiPlan::H_INIT_J0 ? 3 : 2));
 	fp.hrow = pl.hk == MiPlan::H_CURR_JM ? 2 : (pl.hk == MiPlan::H_INIT_J0 ? 1 : 0);
@@ -750,7 +755,7 @@ static int mi_enqueue_fast(mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPl
 	const int nblk = mi_blocks(b);
 	hipStream_t st = b->ctx->stream;
 	MiFastPlan fp = mi_fast_plan(b, pl, active, sm);
-	if (!b->d_mi_poly) HIP_TRY(hipMalloc(&b->d_mi_poly, sizeof(double) * (size_t)mi_poly_size() * b->B));
+	if (!b->d_mi_poly) HIP_TRY(hipMalloc(&b->d_mi_poly, sizeof(double) * (size_t)mi_poly_size(b->desc.mi_n_bins) * b->B));
 	fp.poly = b->d_mi_poly;
 	const BatchView bv = b->view();
 	/* pass 1 holds 45.7 KB of LDS per workgroup: THREE workgroups per CU, so mi_blocks' ~4 per CU ran as one full round and a second one
@@ -768,8 +773,8 @@ static int mi_enqueue_fast(mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPl
 		launch_mi_pass_hist(bv, b->ctx->img, fp, b->d_mi_part, nblk1, b->mi_row_len, st);
 	}
 	/* (the dense Hessian kinds read the tables themselves: no polynomial tables) */
-	if (fp.hk <= 1) launch_mi_tables_poly(bv, 8, b->desc.mi_pre_seed, b->mi_hist_norm, fp.hk == 1 ? 1 : 0, b->d_mi_part, nblk1, b->mi_row_len, b->d_mi_tb, b->d_mi_f, b->d_mi_poly, st);
-	else launch_mi_tables_iter(bv, 8, b->desc.mi_pre_seed, b->mi_hist_norm, fp.hk == 1 ? 1 : 0, b->d_mi_part, nblk1, b->mi_row_len, b->d_mi_tb, b->d_mi_f, st);
+	if (fp.hk <= 1) launch_mi_tables_poly(bv, fp.nb, b->desc.mi_pre_seed, b->mi_hist_norm, fp.hk == 1 ? 1 : 0, b->d_mi_part, nblk1, b->mi_row_len, b->d_mi_tb, b->d_mi_f, b->d_mi_poly, st);
+	else launch_mi_tables_iter(bv, fp.nb, b->desc.mi_pre_seed, b->mi_hist_norm, fp.hk == 1 ? 1 : 0, b->d_mi_part, nblk1, b->mi_row_len, b->d_mi_tb, b->d_mi_f, st);
 	{
 		TimedScope tsc(b->ctx, "mi_pass2");
 		launch_mi_pass_grad_hess(bv, b->ctx->img, fp, b->d_mi_part, nblk, st);
@@ -1642,7 +1647,8 @@ int score_block_dev(mtfhip_batch *b, const double *dev_states, int lo, int cnt, 
 	double measurement_sigma, double max_similarity, const PfPeerPush *peer) {
 	hipStream_t st = b->ctx->stream;
 	if (b->desc.am == MTFHIP_AM_MI) {
-		if (b->desc.mi_n_bins != 8) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "score_candidates: MI candidates are scored with 8 bins (the reference's default, parameters.h:344)");
+		if (!(b->desc.mi_n_bins == 8 || (b->desc.mi_n_bins <= 10 && b->C == 1)))
+			return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "score_candidates: MI candidates are scored with up to 10 bins (multi-channel: 8, the reference's default, parameters.h:344)");
 		if (!b->init_sim) return fail(MTFHIP_ERR_LOGIC, "score_candidates before initializeSimilarity");
 		const int nblk = 1;
 		const size_t need = (size_t)std::max(cnt, 1) * nblk * b->mi_row_len;
@@ -1654,6 +1660,7 @@ int score_block_dev(mtfhip_batch *b, const double *dev_states, int lo, int cnt, 
 			b->cand_mi_capacity = need;
 		}
 		MiFastPlan fp;
+		fp.nb = b->desc.mi_n_bins;
 		fp.hk = 0; fp.hrow = 0; fp.j0_mode = 0; fp.j0_init_variant = 0; fp.need_dft = 0; fp.need_df0 = 0; fp.g_mean = 0;
 		fp.grad_eps = b->desc.grad_eps; fp.norm_mult = b->norm_mult; fp.norm_add = b->norm_add; fp.hist_norm = b->mi_hist_norm;
 		fp.active = nullptr; fp.tb = b->d_mi_tb;

@@ -295,7 +295,8 @@ int mtfhip_pf_create(mtfhip_batch *b, const mtfhip_pf_desc *d, mtfhip_pf **out) 
 	if (d->dynamic_model < 0 || d->dynamic_model > 1 || d->update_type < 0 || d->update_type > 1 || d->likelihood_func < 0 || d->likelihood_func > 2 ||
 		d->mean_type < 0 || d->mean_type > 2) return fail(MTFHIP_ERR_INVALID_ARG, "pf_create: enum value out of range (PFParams.h:10-33)");
 	if (d->resampling_type < 0 || d->resampling_type > 3) return fail(MTFHIP_ERR_INVALID_ARG, "pf_create: unknown resampling type %d", d->resampling_type);
-	if (b->desc.am == MTFHIP_AM_MI && b->desc.mi_n_bins != 8) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "pf_create: MI particles are scored with 8 bins");
+	if (b->desc.am == MTFHIP_AM_MI && !(b->desc.mi_n_bins == 8 || (b->desc.mi_n_bins <= 10 && b->C == 1)))
+		return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "pf_create: MI particles are scored with up to 10 bins (multi-channel: 8)");
 	int sampler = 0, nz = 0;
 	TRY(pf_pick_sampler(b, d, &sampler, &nz));
 	mtfhip_pf *pf = new mtfhip_pf;

@@ -1,5 +1,5 @@
 /*
- * kernels_mi_fused.hip -- the recompute form of the MI Lucas-Kanade iteration (MTFHIP_MATH_FAST, 8 bins)
+ * kernels_mi_fused.hip -- the recompute form of the MI Lucas-Kanade iteration (MTFHIP_MATH_FAST; 8 bins, or up to 10: r06)
  * (one of the translation units of libmtfhip.so; conventions and the shared device helpers: mtfhip_device.h, mtfhip_mi_device.h)
  *
  * The materialising form (api_fused.hip::mi_enqueue with the kernels of kernels_mi.hip) runs the fused LK kernel first
@@ -32,10 +32,15 @@ namespace mtfhip {
  * ------------------------------------------------------------------------------------------- */
 /* CAND: the candidate axis (PF / NN, SM/src/PF.cc:247-262 with MI as the appearance model): blockIdx.y is a candidate of target 0 --
  * its warp comes from the candidate's state, the template arrays are target 0's */
-template <int SSM, bool SELF, bool CAND = false, bool MC = false>
+/* NB (r06): 8 = the r03-r05 kernel (pa.nb == 8: the 8 x 8 histograms are the four 4 x 4 blocks of ONE block product per step).  10: up to
+ * ten bins at run time (pa.nb; the shipped mi_n_bins 10): the histograms are 3 x 3 tiles of 4 x 4 -- bins padded to twelve, rows nb .. 11 hold
+ * the taps that fall outside the histogram and are not stored -- i.e. three block products per step: tiles (0..1, 0..1) | (2, 0) (2, 1) (0, 2)
+ * (1, 2) | (2, 2). */
+template <int SSM, bool SELF, bool CAND = false, bool MC = false, int NB = 8>
 __global__ __launch_bounds__(kBlock) void k_mi_pass_hist(BatchView bv, ImgView im, MiPassArgs pa, double *partials, int nblk, int row_len) {
+	constexpr int kWinRows = NB + 3;   /* rows (bin + 1): row 0 and the rows behind bin NB - 1 take the taps outside the histogram */
 	__shared__ __attribute__((aligned(16))) double slabs[4 * 2 * kWinRows * kRS];
-	constexpr int nb = 8;
+	const int nb = NB == 8 ? 8 : pa.nb;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int t = blockIdx.y;
 	if (!CAND && pa.active && !pa.active[t]) return;
@@ -61,9 +66,12 @@ __global__ __launch_bounds__(kBlock) void k_mi_pass_hist(BatchView bv, ImgView i
 	const double *I0 = bv.buf[MTFHIP_BUF_I0] + tt * N;
 	for (int k2 = 0; k2 < 2 * kWinRows; ++k2) wa[k2 * kRS + lane] = 0.0;   /* the slabs start clean and every chunk leaves them clean */
 	double bj8 = 0.0, bs8 = 0.0, bh8 = 0.0;
+	double bjB = 0.0, bjC = 0.0, bsB = 0.0, bsC = 0.0, bhB = 0.0;   /* NB = 10: the second and third tile sets */
 	const bool hfj = !CAND && pa.hist_from_joint != 0;
 	const int li = lane & 3, lb = (lane >> 2) & 3, lk = lane >> 4;
 	const double one0 = li == 0 ? 1.0 : 0.0;
+	/* tile (row, column) of block lb in the second set: (2, 0) (2, 1) (0, 2) (1, 2) */
+	const int trB = lb < 2 ? 2 : lb - 2, tcB = lb < 2 ? lb : 2;
 	const unsigned stride = (unsigned)nblk * kBlock;
 	unsigned base = (blockIdx.x * (kBlock / 64) + wave) * 64;
 	/* Software pipeline with build-time depths (MTFHIP_MI_OP_AHEAD / MTFHIP_MI_TEX_AHEAD): the operands of chunk n + TD + PF are requested
@@ -124,6 +132,28 @@ __global__ __launch_bounds__(kBlock) void k_mi_pass_hist(BatchView bv, ImgView i
 		for (int k = 0; k < 4; ++k) { ra[k * kRS] = a.w[k] * vm; rb[k * kRS] = b.w[k]; }
 		__builtin_amdgcn_wave_barrier();
 #if !(defined(MTFHIP_MI1_ABL) && MTFHIP_MI1_ABL == 2)   /* 2: + staging, no products */
+		if constexpr (NB != 8) {
+			/* (uniform branches on hfj: the histogram as the joint histogram's row sums, or as block products of its own) */
+#pragma unroll
+			for (int qq = 0; qq < 16; ++qq) {
+				const int p = 4 * qq + lk;
+				const double av = wa[(1 + 4 * (lb >> 1) + li) * kRS + p], bvv = wb[(1 + 4 * (lb & 1) + li) * kRS + p];
+				const double avB = wa[(1 + 4 * trB + li) * kRS + p], bvB = wb[(1 + 4 * tcB + li) * kRS + p];
+				const double avC = wa[(9 + li) * kRS + p], bvC = wb[(9 + li) * kRS + p];
+				bj8 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bvv, bj8, 0, 0, 0);
+				bjB = __builtin_amdgcn_mfma_f64_4x4x4f64(avB, bvB, bjB, 0, 0, 0);
+				bjC = __builtin_amdgcn_mfma_f64_4x4x4f64(avC, bvC, bjC, 0, 0, 0);
+				if (!hfj) {
+					bh8 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, one0, bh8, 0, 0, 0);
+					bhB = __builtin_amdgcn_mfma_f64_4x4x4f64(avB, one0, bhB, 0, 0, 0);
+				}
+				if constexpr (SELF) {
+					bs8 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, wa[(1 + 4 * (lb & 1) + li) * kRS + p], bs8, 0, 0, 0);
+					bsB = __builtin_amdgcn_mfma_f64_4x4x4f64(avB, wa[(1 + 4 * tcB + li) * kRS + p], bsB, 0, 0, 0);
+					bsC = __builtin_amdgcn_mfma_f64_4x4x4f64(avC, avC, bsC, 0, 0, 0);
+				}
+			}
+		} else
 		if (hfj) {   /* (uniform) the histogram comes out of the joint histogram's rows at the end: two block products per step instead of three */
 #pragma unroll
 			for (int qq = 0; qq < 16; ++qq) {
@@ -153,23 +183,45 @@ __global__ __launch_bounds__(kBlock) void k_mi_pass_hist(BatchView bv, ImgView i
 	}
 	__syncthreads();
 	double *red = slabs;
-	constexpr int rl = nb + nb * nb + (SELF ? nb * nb : 0);
+	const int rl = nb + nb * nb + (SELF ? nb * nb : 0);
 	{
 		const int r = 4 * (lb >> 1) + (lane >> 4), c = 4 * (lb & 1) + (lane & 3);
-		red[wave * rl + nb + r * nb + c] = bj8;
-		if constexpr (SELF) red[wave * rl + nb + nb * nb + r * nb + c] = bs8;
-		if ((lb & 1) == 0 && (lane & 3) == 0) red[wave * rl + r] = bh8;
+		if (NB == 8 || (r < nb && c < nb)) {
+			red[wave * rl + nb + r * nb + c] = bj8;
+			if constexpr (SELF) red[wave * rl + nb + nb * nb + r * nb + c] = bs8;
+		}
+		if ((lb & 1) == 0 && (lane & 3) == 0 && (NB == 8 || r < nb)) red[wave * rl + r] = bh8;
+		if constexpr (NB != 8) {
+			const int rB = 4 * trB + (lane >> 4), cB = 4 * tcB + (lane & 3);
+			if (rB < nb && cB < nb) {
+				red[wave * rl + nb + rB * nb + cB] = bjB;
+				if constexpr (SELF) red[wave * rl + nb + nb * nb + rB * nb + cB] = bsB;
+			}
+			if (lb == 0 && (lane & 3) == 0 && rB < nb) red[wave * rl + rB] = bhB;   /* (block 0 of the second set: tile row 2, the histogram's bins 8 ..) */
+			const int rC = 8 + (lane >> 4), cC = 8 + (lane & 3);
+			if (lb == 0 && rC < nb && cC < nb) {
+				red[wave * rl + nb + rC * nb + cC] = bjC;
+				if constexpr (SELF) red[wave * rl + nb + nb * nb + rC * nb + cC] = bsC;
+			}
+		}
 	}
 	__syncthreads();
 	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * row_len;
 	for (int k2 = threadIdx.x; k2 < rl; k2 += kBlock) {
 		double v = (red[k2] + red[rl + k2]) + (red[2 * rl + k2] + red[3 * rl + k2]);
-		if (hfj && k2 < nb) {   /* histogram row k2 = sum over the eight columns of the joint histogram's row k2 (each the four waves' sum, fixed order) */
+		if (hfj && k2 < nb) {   /* histogram row k2 = sum over the columns of the joint histogram's row k2 (each the four waves' sum, fixed order) */
 			v = 0.0;
+			if constexpr (NB == 8) {
 #pragma unroll
-			for (int c = 0; c < nb; ++c) {
-				const int e = nb + k2 * nb + c;
-				v += (red[e] + red[rl + e]) + (red[2 * rl + e] + red[3 * rl + e]);
+				for (int c = 0; c < 8; ++c) {
+					const int e = nb + k2 * nb + c;
+					v += (red[e] + red[rl + e]) + (red[2 * rl + e] + red[3 * rl + e]);
+				}
+			} else {
+				for (int c = 0; c < nb; ++c) {
+					const int e = nb + k2 * nb + c;
+					v += (red[e] + red[rl + e]) + (red[2 * rl + e] + red[3 * rl + e]);
+				}
 			}
 		}
 		dst[k2] = v;
@@ -180,19 +232,31 @@ __global__ __launch_bounds__(kBlock) void k_mi_pass_hist(BatchView bv, ImgView i
  * candidate mode: the histogram rows of a candidate -> MI (MI.cc:369-381) -> its likelihood (MI.cc:384-387) -> the particle
  * weight (PF.cc:341-365).  One wave per candidate, lane = bin pair; the wave sum is a fixed butterfly.
  * ------------------------------------------------------------------------------------------- */
-__global__ __launch_bounds__(64) void k_mi_cand_score(int n, int lo, const double *partials, int nblk, int row_len, const double *tb0, double pre_seed,
+__global__ __launch_bounds__(64) void k_mi_cand_score(int nb, int n, int lo, const double *partials, int nblk, int row_len, const double *tb0, double pre_seed,
 	double hist_norm, double alpha, int likelihood_func, double measurement_sigma, double max_similarity, double *wts, double *sim) {
-	constexpr int nb = 8;
 	const int cnd = blockIdx.x, lane = threadIdx.x;
 	if (cnd >= n) return;
 	const double *p = partials + (size_t)cnd * nblk * row_len;
-	const int r = lane >> 3, c = lane & 7;
-	const double js = column_sum(p + nb + lane, nblk, row_len);
-	const double hs = lane < nb ? column_sum(p + lane, nblk, row_len) : 0.0;
-	const double jv = (js + pre_seed) * hist_norm;
-	const double lhc_own = lane < nb ? log((hs + nb * pre_seed) * hist_norm) : 0.0;   /* log curr_hist(lane) */
-	const double lhc = __shfl(lhc_own, r);
-	double part = jv * (log(jv) - lhc - tb0[MI_LOG_INIT + c]);
+	double part = 0.0;
+	if (nb == 8) {   /* (the r03 form: one bin pair per lane) */
+		const int r = lane >> 3, c = lane & 7;
+		const double js = column_sum(p + nb + lane, nblk, row_len);
+		const double hs = lane < nb ? column_sum(p + lane, nblk, row_len) : 0.0;
+		const double jv = (js + pre_seed) * hist_norm;
+		const double lhc_own = lane < nb ? log((hs + nb * pre_seed) * hist_norm) : 0.0;   /* log curr_hist(lane) */
+		const double lhc = __shfl(lhc_own, r);
+		part = jv * (log(jv) - lhc - tb0[MI_LOG_INIT + c]);
+	} else {
+		const double hs = lane < nb ? column_sum(p + lane, nblk, row_len) : 0.0;
+		const double lhc_own = lane < nb ? log((hs + nb * pre_seed) * hist_norm) : 0.0;
+		for (int e0 = 0; e0 < nb * nb; e0 += 64) {   /* (uniform trip count: the shuffles below are taken by every lane) */
+			const int e = e0 + lane, ec = e < nb * nb ? e : 0, r = ec / nb, c = ec - r * nb;
+			const double js = column_sum(p + nb + ec, nblk, row_len);
+			const double jv = (js + pre_seed) * hist_norm;
+			const double lhc = __shfl(lhc_own, r);
+			if (e < nb * nb) part += jv * (log(jv) - lhc - tb0[MI_LOG_INIT + c]);
+		}
+	}
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
 	if (lane == 0) {
@@ -214,15 +278,19 @@ __global__ __launch_bounds__(64) void k_mi_cand_score(int n, int lo, const doubl
  * out_H [B][64] column-major S x S Hessian of the pass, out_g [B][16] the two Jacobian products (for iterate's host solve).
  * gmode: 0 ICLK (df_dI0 . J0), 1 FCLK (df_dIt . Jt), 2 ESM Original (df_dIt . Jm), 3 ESM DiffOfJacs.
  * ------------------------------------------------------------------------------------------- */
+template <int NB>
 __global__ __launch_bounds__(kBlock) void k_mi_finish_fast(BatchView bv, mtfhip_sm_desc sm, TrackState ts, int have_hess, int transpose_q,
-	int joint_off, int hist_off, int sum_h0_host, int gmode, int do_track, const double *partials, int nblk, const double *tb_all,
+	int joint_off, int hist_off, int nb_rt, int gmode, int do_track, const double *partials, int nblk, const double *tb_all,
 	double *out_H, double *out_g, double *rows) {
-	__shared__ double gs[16], Hs[64], Q[512], fac[64];
+	constexpr int kRowF = mi_fast_row_nb(NB);
+	__shared__ double gs[16], Hs[64], Q[NB * NB * 8], fac[NB == 8 ? 64 : 128];
+	const int nb = NB == 8 ? 8 : nb_rt;
 	const int t = blockIdx.x, S = bv.S;
 	if (do_track && !ts.active[t]) return;   /* (uniform per workgroup) */
-	const double *p = partials + (size_t)t * nblk * kMiFastRow;
+	const double *p = partials + (size_t)t * nblk * kRowF;
 	const double *tb = tb_all + (size_t)t * MI_SIZE;
-	const int ncol = have_hess ? kMiFastRow : 16;
+	const int ncol = have_hess ? kRowF : 16;
+	if constexpr (NB == 8) {
 	if (have_hess && threadIdx.x >= kBlock - 64) {
 		/* the 64 bin-pair factors (1 / joint - 1 / hist), one per thread of the last wave, while the others sum the block rows:
 		 * evaluated inside the assembly loop below they were 64 dependent global loads and 128 divisions per entry of H */
@@ -231,8 +299,22 @@ __global__ __launch_bounds__(kBlock) void k_mi_finish_fast(BatchView bv, mtfhip_
 		const double hv = tb[hist_off + (transpose_q ? cc : rr)];
 		fac[k] = (1.0 / jv) - (1.0 / hv);
 	}
+	} else {
+	if (have_hess && threadIdx.x >= kBlock - 128) {
+		const int k = threadIdx.x - (kBlock - 128), rr = k / NB, cc = k % NB;
+		if (k < NB * NB) {
+			double fv = 0.0;   /* (pairs of bins beyond pa.nb: their Q rows are zero) */
+			if (rr < nb && cc < nb) {
+				const double jv = tb[joint_off + rr * MI_NB + cc];
+				const double hv = tb[hist_off + (transpose_q ? cc : rr)];
+				fv = (1.0 / jv) - (1.0 / hv);
+			}
+			fac[k] = fv;
+		}
+	}
+	}
 	for (int k = threadIdx.x; k < ncol; k += kBlock) {
-		const double s = column_sum(p + k, nblk, kMiFastRow);
+		const double s = column_sum(p + k, nblk, kRowF);
 		if (k < 16) gs[k] = s; else if (k < 80) Hs[k - 16] = s; else Q[k - 80] = s;
 	}
 	__syncthreads();
@@ -243,11 +325,11 @@ __global__ __launch_bounds__(kBlock) void k_mi_finish_fast(BatchView bv, mtfhip_
 		if (have_hess && r2 < S && c2 < S) {
 			const int a = r2 < c2 ? r2 : c2, b2 = r2 < c2 ? c2 : r2;
 			h = Hs[a * 8 + b2];
-			for (int rr = 0; rr < 8; ++rr)
-				for (int cc = 0; cc < 8; ++cc) {
+			for (int rr = 0; rr < (NB == 8 ? 8 : nb); ++rr)
+				for (int cc = 0; cc < (NB == 8 ? 8 : nb); ++cc) {
 					/* MI.cc:497-511, 590-600, 626-636: joint_hist_jacobian.row(idx)^T row(idx) * (1 / joint - 1 / hist) */
-					const double *q = Q + (rr * 8 + cc) * 8;
-					h += q[r2] * q[c2] * fac[rr * 8 + cc];
+					const double *q = Q + (rr * NB + cc) * 8;
+					h += q[r2] * q[c2] * fac[rr * NB + cc];
 				}
 			out_H[(size_t)t * 64 + c2 * S + r2] = h;
 		}
@@ -272,23 +354,26 @@ __global__ __launch_bounds__(kBlock) void k_mi_finish_fast(BatchView bv, mtfhip_
 /* POLY_ONLY = false (k_mi_tables_poly, r05): k_mi_tables_iter's work first -- block rows of pass 1 -> histograms, logs, similarity, the
  * gradient-factor tables (mi_tables_iter_body) -- then, behind a barrier (the same workgroup wrote the tables it now reads), the
  * polynomial tables: one launch between the passes instead of two (6.3 + 5.7 us each with a launch gap, of a 430 us iteration) */
-template <bool POLY_ONLY>
-__device__ __forceinline__ void mi_poly_tables_body(const double *tb_all, double hist_norm, int with_self, double *poly_all, double *Tc, double *Ti, double *Th) {
+template <bool POLY_ONLY, int NB = 8>
+__device__ __forceinline__ void mi_poly_tables_body(const double *tb_all, double hist_norm, int with_self, double *poly_all, double *Tc, double *Ti, double *Th, int nb_rt = 8) {
 	const int t = blockIdx.x;
+	const int nb = NB == 8 ? 8 : nb_rt;
+	constexpr int TS = NB + 4;   /* table rows / columns: (bin + 1) with a zero border of one bin below and three above */
+	constexpr int kPolyH = mi_poly_h(NB), kPolySz = mi_poly_size_nb(NB), NP = NB * NB;
 	const double *tb = tb_all + (size_t)t * MI_SIZE;
-	for (int k = threadIdx.x; k < 144; k += kBlock) {
-		const int r = k / 12 - 1, c = k % 12 - 1;
-		const bool in = r >= 0 && r < 8 && c >= 0 && c < 8;
+	for (int k = threadIdx.x; k < TS * TS; k += kBlock) {
+		const int r = k / TS - 1, c = k % TS - 1;
+		const bool in = r >= 0 && r < nb && c >= 0 && c < nb;
 		Tc[k] = in ? tb[MI_T_CURR + r * MI_NB + c] : 0.0; Ti[k] = in ? tb[MI_T_INIT + r * MI_NB + c] : 0.0;
 		Th[k] = (in && with_self) ? tb[MI_T_SELF + r * MI_NB + c] : 0.0;
 	}
 	__syncthreads();
 	constexpr MiPolyCoef CF = mi_poly_coef();
-	double *out = poly_all + (size_t)t * kMiPolySize;
-	for (int k = threadIdx.x; k < 2 * 64 * kMiPolyPair; k += kBlock) {
-		const int which = k / (64 * kMiPolyPair), e = k % (64 * kMiPolyPair);
+	double *out = poly_all + (size_t)t * kPolySz;
+	for (int k = threadIdx.x; k < 2 * NP * kMiPolyPair; k += kBlock) {
+		const int which = k / (NP * kMiPolyPair), e = k % (NP * kMiPolyPair);
 		const int pair = e / kMiPolyPair, ab = e % kMiPolyPair, a = ab >> 2, b = ab & 3;
-		const int f1 = pair >> 3, f2 = pair & 7;   /* rows by the differentiated window's class, columns by the other's */
+		const int f1 = pair / NB, f2 = pair % NB;   /* rows by the differentiated window's class, columns by the other's */
 		const double *T = which ? Ti : Tc;
 		double acc = 0.0;
 #pragma unroll
@@ -301,12 +386,12 @@ __device__ __forceinline__ void mi_poly_tables_body(const double *tb_all, double
 				double wc = 0.0;
 #pragma unroll
 				for (int bb = 0; bb < 4; ++bb) wc = b == bb ? CF.w[c][bb] : wc;
-				acc = fma(dc * wc, T[(f1 + r) * 12 + f2 + c], acc);
+				acc = fma(dc * wc, T[(f1 + r) * TS + f2 + c], acc);
 			}
 		}
 		out[k] = acc * hist_norm;
 	}
-	for (int k = threadIdx.x; k < 64; k += kBlock) {
+	for (int k = threadIdx.x; k < NB * 8; k += kBlock) {
 		const int fl = k >> 3, j = k & 7;
 		double acc = 0.0;
 		if (j < 5) {
@@ -321,25 +406,26 @@ __device__ __forceinline__ void mi_poly_tables_body(const double *tb_all, double
 							double wc = 0.0;
 #pragma unroll
 							for (int bb = 0; bb < 4; ++bb) wc = b == bb ? CF.w[c][bb] : wc;
-							acc = fma(CF.h[r][a] * wc, Th[(fl + r) * 12 + fl + c], acc);
+							acc = fma(CF.h[r][a] * wc, Th[(fl + r) * TS + fl + c], acc);
 						}
 					}
 		}
-		out[kMiPolyH + k] = acc * hist_norm;
+		out[kPolyH + k] = acc * hist_norm;
 	}
 }
 __global__ __launch_bounds__(kBlock) void k_mi_poly_tables(const double *tb_all, double hist_norm, int with_self, double *poly_all) {
 	__shared__ double Tc[12 * 12], Ti[12 * 12], Th[12 * 12];
 	mi_poly_tables_body<true>(tb_all, hist_norm, with_self, poly_all, Tc, Ti, Th);
 }
+template <int NB>
 __global__ __launch_bounds__(kBlock) void k_mi_tables_poly(int nb, double pre_seed, double norm_mult, int with_self, const double *partials, int nblk, int row_len,
 	double *tb_all, double *f_out, double *poly_all) {
 	__shared__ double red[kBlock];
-	__shared__ double Tc[12 * 12], Ti[12 * 12], Th[12 * 12];
+	__shared__ double Tc[(NB + 4) * (NB + 4)], Ti[(NB + 4) * (NB + 4)], Th[(NB + 4) * (NB + 4)];
 	mi_tables_iter_body(nb, pre_seed, norm_mult, with_self, partials, nblk, row_len, tb_all, f_out, red);
 	__threadfence_block();
 	__syncthreads();
-	mi_poly_tables_body<false>(tb_all, norm_mult, with_self, poly_all, Tc, Ti, Th);
+	mi_poly_tables_body<false, NB>(tb_all, norm_mult, with_self, poly_all, Tc, Ti, Th, nb);
 }
 
 /* ===================================================================== */
@@ -347,7 +433,7 @@ __global__ __launch_bounds__(kBlock) void k_mi_tables_poly(int nb, double pre_se
 /* ===================================================================== */
 static MiPassArgs make_args(const MiFastPlan &pl) {
 	MiPassArgs pa;
-	pa.nb = 8; pa.j0_mode = pl.j0_mode; pa.j0_init_variant = pl.j0_init_variant; pa.need_dft = pl.need_dft; pa.need_df0 = pl.need_df0;
+	pa.nb = pl.nb; pa.j0_mode = pl.j0_mode; pa.j0_init_variant = pl.j0_init_variant; pa.need_dft = pl.need_dft; pa.need_df0 = pl.need_df0;
 	pa.g_mean = pl.g_mean; pa.table_off = 0; pa.transpose_q = pl.hk == 3; pa.nonchained = pl.nonchained; pa.hist_from_joint = pl.hist_from_joint;
 	pa.grad_eps = pl.grad_eps; pa.norm_mult = pl.norm_mult; pa.norm_add = pl.norm_add; pa.hist_norm = pl.hist_norm;
 	pa.active = pl.active; pa.tb = pl.tb; pa.poly = pl.poly; pa.cand_states = nullptr;
@@ -356,6 +442,13 @@ static MiPassArgs make_args(const MiFastPlan &pl) {
 template <int SSM, bool MC>
 static void launch_pass1(const BatchView &bv, const ImgView &im, const MiPassArgs &pa, bool self, double *partials, int nblk, int row_len, hipStream_t st) {
 	const dim3 g = grid2(nblk, bv.B);
+	if constexpr (!MC) {
+		if (pa.nb != 8) {   /* up to ten bins (single channel) */
+			if (self) MTFHIP_LAUNCH((k_mi_pass_hist<SSM, true, false, false, 10>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
+			else MTFHIP_LAUNCH((k_mi_pass_hist<SSM, false, false, false, 10>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
+			return;
+		}
+	}
 	if (self) MTFHIP_LAUNCH((k_mi_pass_hist<SSM, true, false, MC>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
 	else MTFHIP_LAUNCH((k_mi_pass_hist<SSM, false, false, MC>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
 }
@@ -377,11 +470,15 @@ void launch_mi_score_candidates(const BatchView &bv, const ImgView &im, const Mi
 	pa.cand_states = dev_states + (size_t)lo * bv.S;
 	const dim3 g(nblk, cnt);
 	const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY, mc = bv.C > 1;
-	if (hom && mc) MTFHIP_LAUNCH((k_mi_pass_hist<MTFHIP_SSM_HOMOGRAPHY, false, true, true>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
+	if (!mc && pa.nb != 8) {
+		if (hom) MTFHIP_LAUNCH((k_mi_pass_hist<MTFHIP_SSM_HOMOGRAPHY, false, true, false, 10>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
+		else MTFHIP_LAUNCH((k_mi_pass_hist<MTFHIP_SSM_AFFINE, false, true, false, 10>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
+	}
+	else if (hom && mc) MTFHIP_LAUNCH((k_mi_pass_hist<MTFHIP_SSM_HOMOGRAPHY, false, true, true>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
 	else if (hom) MTFHIP_LAUNCH((k_mi_pass_hist<MTFHIP_SSM_HOMOGRAPHY, false, true, false>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
 	else if (mc) MTFHIP_LAUNCH((k_mi_pass_hist<MTFHIP_SSM_AFFINE, false, true, true>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
 	else MTFHIP_LAUNCH((k_mi_pass_hist<MTFHIP_SSM_AFFINE, false, true, false>), g, dim3(kBlock), 0, st, bv, im, pa, partials, nblk, row_len);
-	MTFHIP_LAUNCH(k_mi_cand_score, dim3(cnt), dim3(64), 0, st, cnt, lo, (const double *)partials, nblk, row_len, pl.tb, pre_seed, pl.hist_norm, alpha,
+	MTFHIP_LAUNCH(k_mi_cand_score, dim3(cnt), dim3(64), 0, st, pl.nb, cnt, lo, (const double *)partials, nblk, row_len, pl.tb, pre_seed, pl.hist_norm, alpha,
 		likelihood_func, measurement_sigma, max_similarity, wts, sim);
 }
 void launch_mi_poly_tables(const BatchView &bv, const double *tb, double hist_norm, int with_self, double *poly, hipStream_t st) {
@@ -389,25 +486,31 @@ void launch_mi_poly_tables(const BatchView &bv, const double *tb, double hist_no
 }
 void launch_mi_tables_poly(const BatchView &bv, int nb, double pre_seed, double norm_mult, int with_self, const double *partials, int nblk, int row_len,
 	double *tb, double *f_out, double *poly, hipStream_t st) {
-	MTFHIP_LAUNCH(k_mi_tables_poly, dim3(bv.B), dim3(kBlock), 0, st, nb, pre_seed, norm_mult, with_self, partials, nblk, row_len, tb, f_out, poly);
+	if (nb == 8) MTFHIP_LAUNCH(k_mi_tables_poly<8>, dim3(bv.B), dim3(kBlock), 0, st, nb, pre_seed, norm_mult, with_self, partials, nblk, row_len, tb, f_out, poly);
+	else MTFHIP_LAUNCH(k_mi_tables_poly<10>, dim3(bv.B), dim3(kBlock), 0, st, nb, pre_seed, norm_mult, with_self, partials, nblk, row_len, tb, f_out, poly);
 }
-int mi_poly_size() { return kMiPolySize; }
+int mi_poly_size(int nb) { return nb == 8 ? mi_poly_size_nb(8) : mi_poly_size_nb(10); }
 /* pass 2 is instantiated per (SSM, channels) in its own translation unit: kernels_mi_pass2_*.hip */
 void launch_mi_pass2_hom(const BatchView &bv, const ImgView &im, const MiPassArgs &pa, int hk, int hrow, double *partials, int nblk, hipStream_t st);
 void launch_mi_pass2_aff(const BatchView &bv, const ImgView &im, const MiPassArgs &pa, int hk, int hrow, double *partials, int nblk, hipStream_t st);
 void launch_mi_pass2_hom_mc(const BatchView &bv, const ImgView &im, const MiPassArgs &pa, int hk, int hrow, double *partials, int nblk, hipStream_t st);
 void launch_mi_pass2_aff_mc(const BatchView &bv, const ImgView &im, const MiPassArgs &pa, int hk, int hrow, double *partials, int nblk, hipStream_t st);
+void launch_mi_pass2_hom_nb10(const BatchView &bv, const ImgView &im, const MiPassArgs &pa, int hk, int hrow, double *partials, int nblk, hipStream_t st);
+void launch_mi_pass2_aff_nb10(const BatchView &bv, const ImgView &im, const MiPassArgs &pa, int hk, int hrow, double *partials, int nblk, hipStream_t st);
 void launch_mi_pass_grad_hess(const BatchView &bv, const ImgView &im, const MiFastPlan &pl, double *partials, int nblk, hipStream_t st) {
 	const MiPassArgs pa = make_args(pl);
 	const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY, mc = bv.C > 1;
+	if (pl.nb != 8) { (hom ? launch_mi_pass2_hom_nb10 : launch_mi_pass2_aff_nb10)(bv, im, pa, pl.hk, pl.hrow, partials, nblk, st); return; }
 	(hom ? (mc ? launch_mi_pass2_hom_mc : launch_mi_pass2_hom) : (mc ? launch_mi_pass2_aff_mc : launch_mi_pass2_aff))(bv, im, pa, pl.hk, pl.hrow, partials, nblk, st);
 }
 void launch_mi_finish_fast(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, const MiFastPlan &pl, int gmode, int do_track,
 	const double *partials, int nblk, double *out_H, double *out_g, double *rows, hipStream_t st) {
 	const int joint = pl.hk == 1 ? MI_SELF_JOINT : MI_JOINT, hist = pl.hk == 3 ? MI_HIST_INIT : MI_HIST_CURR;
-	MTFHIP_LAUNCH(k_mi_finish_fast, dim3(bv.B), dim3(kBlock), 0, st, bv, sm, ts, pl.hk != 0, pl.hk == 3, joint, hist, 0, gmode, do_track,
+	if (pl.nb == 8) MTFHIP_LAUNCH(k_mi_finish_fast<8>, dim3(bv.B), dim3(kBlock), 0, st, bv, sm, ts, pl.hk != 0, pl.hk == 3, joint, hist, 8, gmode, do_track,
+		partials, nblk, pl.tb, out_H, out_g, rows);
+	else MTFHIP_LAUNCH(k_mi_finish_fast<10>, dim3(bv.B), dim3(kBlock), 0, st, bv, sm, ts, pl.hk != 0, pl.hk == 3, joint, hist, pl.nb, gmode, do_track,
 		partials, nblk, pl.tb, out_H, out_g, rows);
 }
-int mi_fast_row_len() { return kMiFastRow; }
+int mi_fast_row_len(int nb) { return nb == 8 ? mi_fast_row_nb(8) : mi_fast_row_nb(10); }
 
 } // namespace mtfhip

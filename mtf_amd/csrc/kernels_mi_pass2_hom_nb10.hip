@@ -1,0 +1,6 @@
+/* pass 2 of the MI recompute iteration, homography, up to ten bins (see mtfhip_mi_pass2_unit.h) */
+#define MTFHIP_P2_SSM MTFHIP_SSM_HOMOGRAPHY
+#define MTFHIP_P2_MC false
+#define MTFHIP_P2_NB 10
+#define MTFHIP_P2_NAME launch_mi_pass2_hom_nb10
+#include "mtfhip_mi_pass2_unit.h"

@@ -335,6 +335,7 @@ void launch_mi_grad_gemv(const BatchView &bv, int nb, double norm_mult, const do
 	const double *Jt, const double *J0, const MiJ0Rebuild &rb, double *df_dIt, double *df_dI0, double *partials, int nblk, hipStream_t st);
 /* ---- the recompute form of the MI iteration (kernels_mi_fused.hip; tolerance-mode arithmetic, 8 bins) ---- */
 struct MiFastPlan {
+	int nb = 8;           /* the AM's n_bins: 8 -> the NB = 8 kernels, otherwise (<= 10; hk 0 / 1) the NB = 10 ones */
 	int hk;               /* Hessian pass: 0 none (constant Hessian), 1 self(Jt), 2 curr, 3 init(J0) */
 	int hrow;             /* pixel Jacobian of the Hessian pass: 0 Jt, 1 J0, 2 (J0 + Jt) / 2 */
 	int j0_mode;          /* 0 the template's row is not needed, 1 rebuilt from dI0_dx, 2 read from J0 */
@@ -352,7 +353,7 @@ void launch_mi_poly_tables(const BatchView &bv, const double *tb, double hist_no
 /* launch_mi_tables_iter + launch_mi_poly_tables in one launch (hist_norm is the tables' norm_mult) */
 void launch_mi_tables_poly(const BatchView &bv, int nb, double pre_seed, double norm_mult, int with_self, const double *partials, int nblk, int row_len,
 	double *tb, double *f_out, double *poly, hipStream_t st);
-int mi_poly_size();
+int mi_poly_size(int nb = 8);
 void launch_mi_pass_hist(const BatchView &bv, const ImgView &im, const MiFastPlan &pl, double *partials, int nblk, int row_len, hipStream_t st);
 void launch_mi_pass_grad_hess(const BatchView &bv, const ImgView &im, const MiFastPlan &pl, double *partials, int nblk, hipStream_t st);
 void launch_mi_finish_fast(const BatchView &bv, const mtfhip_sm_desc &sm, const TrackState &ts, const MiFastPlan &pl, int gmode, int do_track,
@@ -360,7 +361,7 @@ void launch_mi_finish_fast(const BatchView &bv, const mtfhip_sm_desc &sm, const 
 void launch_mi_score_candidates(const BatchView &bv, const ImgView &im, const MiFastPlan &pl, const double *dev_states, int lo, int cnt,
 	double *partials, int nblk, int row_len, double pre_seed, double alpha, int likelihood_func, double measurement_sigma, double max_similarity,
 	double *wts, double *sim, hipStream_t st);
-int mi_fast_row_len();
+int mi_fast_row_len(int nb = 8);
 /* ---- particle filter (kernels_pf.hip): proposal + scoring, cumulative weights, resampling + estimate ---- */
 enum { PF_SAMPLER_STATE = 0,       /* one normal per state component (ProjectiveBase::generatePerturbation) */
 	PF_SAMPLER_HOM_CORNERS = 1,    /* Homography, corner based: 10 normals (Homography.cc:899-911) */

@@ -5,6 +5,7 @@
  * to compile.  Overview of the passes: kernels_mi_fused.hip.
  */
 #pragma once
+#include <type_traits>
 #include "mtfhip_mi_device.h"
 #include "mtfhip_finish_device.h"
 
@@ -127,7 +128,7 @@ __device__ __forceinline__ MiSample mi_finish(const ImgView &im, const MiTex &tx
  * histogram (bspl_window4) and are never read by the bin mode */
 constexpr int kWinRows = 11;
 struct MiPassArgs {
-	int nb;                 /* 8 */
+	int nb;                 /* the AM's n_bins: 8 in the NB = 8 instantiations, <= 10 in the NB = 10 ones */
 	int j0_mode;            /* pass 2: 0 no template row needed, 1 rebuilt from dI0_dx, 2 read from J0 */
 	int j0_init_variant;    /* with j0_mode 1: Init variant (gradient as is) instead of Warped at identity (gradient / z) */
 	int need_dft, need_df0; /* which Jacobian products the search method uses */
@@ -215,6 +216,26 @@ __device__ __forceinline__ ClassSort class_sort8(int key /* 0..7, or negative: n
 	cs.total = (int)(cs.ends >> 56);
 	return cs;
 }
+/* the same for up to twelve classes (the NB = 10 instantiations of pass 2: n_bins 10 as shipped, Config/modules.cfg:115): three words of four
+ * 8-bit counters; the padded total is at most 64 + 3 x 10 = 94 (ten classes), no byte carries.  ends12: byte c of (lo | hi << 64-bit) */
+struct ClassSort12 { int slot; unsigned e0, e1, e2; int total; };
+__device__ __forceinline__ ClassSort12 class_sort12(int key /* 0..11, or negative: not placed */, int n_classes) {
+	ClassSort12 cs;
+	const unsigned sh = ((unsigned)key & 3u) * 8u;
+	const unsigned w0 = (key >= 0 && key < 4) ? 1u << sh : 0u, w1 = (key >= 4 && key < 8) ? 1u << sh : 0u, w2 = key >= 8 ? 1u << sh : 0u;
+	const unsigned s0 = wave_scan_u32(w0), s1 = wave_scan_u32(w1), s2 = wave_scan_u32(w2);
+	const unsigned c0 = (unsigned)__builtin_amdgcn_readlane((int)s0, 63), c1 = (unsigned)__builtin_amdgcn_readlane((int)s1, 63), c2 = (unsigned)__builtin_amdgcn_readlane((int)s2, 63);
+	const unsigned p0 = (c0 + 0x03030303u) & 0xFCFCFCFCu, p1 = (c1 + 0x03030303u) & 0xFCFCFCFCu, p2 = (c2 + 0x03030303u) & 0xFCFCFCFCu;
+	/* inclusive byte-wise prefix sums inside a word (x 0x01010101), then the words' totals carried over */
+	const unsigned i0 = p0 * 0x01010101u, i1 = p1 * 0x01010101u, i2 = p2 * 0x01010101u;
+	const unsigned t0 = i0 >> 24, t1 = t0 + (i1 >> 24);
+	cs.e0 = i0; cs.e1 = i1 + t0 * 0x01010101u; cs.e2 = i2 + t1 * 0x01010101u;
+	const unsigned ew = key < 4 ? cs.e0 : (key < 8 ? cs.e1 : cs.e2), pw = key < 4 ? p0 : (key < 8 ? p1 : p2), sw = key < 4 ? s0 : (key < 8 ? s1 : s2);
+	const unsigned start = ((ew - pw) >> sh) & 255u, rank = (sw >> sh) & 255u;   /* (ew - pw: byte-wise, no borrow: every end >= its class's padded size) */
+	cs.slot = key >= 0 ? (int)(start + rank) - 1 : 0;
+	cs.total = (int)((n_classes <= 4 ? cs.e0 : (n_classes <= 8 ? cs.e1 : cs.e2)) >> 24);   /* (classes behind n_classes are empty: the top byte of the last used word is the end of everything) */
+	return cs;
+}
 /* r04, the self-Hessian bin mode in MOMENT form.  Both windows of a pixel are the window of It, so gradient tap k and weight tap m
  * are fixed polynomials of ONE number, phi = It - fl (bspl_window4: tap k lies in piece k of the cubic B-spline):
  *   w0 = (1 - phi)^3 / 6        w1 = c23 - phi^2 + phi^3 / 2        w2 = (c23 - 1/2) + (phi + phi^2 - phi^3) / 2        w3 = phi^3 / 6
@@ -247,7 +268,13 @@ __host__ __device__ constexpr MiMomentCoef mi_moment_coef() {
  * and three 4 x 4 table contractions (60 multiply-adds, 48 LDS reads).  Bins outside the histogram meet the zero border of the
  * tables when the coefficients are built, which is what the reference's clamped id range amounts to (MI.cc:114-117). */
 constexpr int kMiPolyPair = 12;                      /* [a = 0..2][b = 0..3] */
-constexpr int kMiPolyT = 0, kMiPolyI = 64 * kMiPolyPair, kMiPolyH = 2 * 64 * kMiPolyPair, kMiPolySize = 2 * 64 * kMiPolyPair + 64;
+/* per instantiation (NB = the bin count the tables are laid out for): [NB^2 class pairs][12] of df_dIt | the same of df_dI0 | [NB][8] of hess_term */
+__host__ __device__ constexpr int mi_poly_t(int) { return 0; }
+__host__ __device__ constexpr int mi_poly_i(int NB) { return NB * NB * kMiPolyPair; }
+__host__ __device__ constexpr int mi_poly_h(int NB) { return 2 * NB * NB * kMiPolyPair; }
+__host__ __device__ constexpr int mi_poly_size_nb(int NB) { return 2 * NB * NB * kMiPolyPair + NB * 8; }
+__host__ __device__ constexpr int mi_fast_row_nb(int NB) { return 16 + 64 + NB * NB * 8; }   /* block rows of pass 2: g (16) | sum hess_term J J^T (64) | Q[(r, c)][s] */
+constexpr int kMiPolyT = 0, kMiPolyI = mi_poly_i(8), kMiPolyH = mi_poly_h(8), kMiPolySize = mi_poly_size_nb(8);
 struct MiPolyCoef { double w[4][4], d[4][3], h[4][2]; };   /* coefficients of phi^0.. of tap k's weight, derivative (x -1: d = -dw/dv) and second derivative; x hist_norm outside */
 __host__ __device__ constexpr MiPolyCoef mi_poly_coef() {
 	constexpr double c23 = 0.66666666666;
@@ -255,28 +282,35 @@ __host__ __device__ constexpr MiPolyCoef mi_poly_coef() {
 		{{-0.5, 1.0, -0.5}, {0.0, -2.0, 1.5}, {0.5, 1.0, -1.5}, {0.0, 0.0, 0.5}},
 		{{1.0, -1.0}, {-2.0, 3.0}, {1.0, -3.0}, {0.0, 1.0}}};
 }
-constexpr int kMiFastRow = 16 + 64 + 512;
+constexpr int kMiFastRow = mi_fast_row_nb(8);
 constexpr int kTRows = 12;   /* gradient-factor tables in LDS, indexed with (bin + 1) in both directions, zero borders */
 /* NONCH: the search method's chained_warp = 0 (mi_finish's non-chained form + cmptInitPixJacobian rows); its own instantiation so that
  * the chained kernels keep their register budget */
-template <int SSM, int HK, int HROW, bool MC = false, bool NONCH = false>
+/* NB (r06): the bin count the class tables are laid out for.  8 = the reference's default (parameters.h:344), the r03-r05 kernels unchanged
+ * (pa.nb == 8).  10 = the shipped configuration (Config/modules.cfg:115-117: mi_n_bins 10, partition of unity) and every other count up to
+ * ten: pa.nb classes and bins at run time, ten-class sort, the moment table M[class][power][s] SHARED by the four waves (ds_add_f64
+ * at class boundaries only) so that the workgroup stays under half a CU's LDS -- constant-Hessian and self-Hessian forms (HK 0 / 1). */
+template <int SSM, int HK, int HROW, bool MC = false, bool NONCH = false, int NB = 8>
 __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, ImgView im, MiPassArgs pa, double *partials, int nblk) {
 	constexpr int S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
-	constexpr int nb = 8;
+	static_assert(NB == 8 || (NB == 10 && HK <= 1), "pass 2: 8 bins in every form, up to 10 in the polynomial forms (HK 0 / 1)");
+	const int nb = NB == 8 ? 8 : pa.nb;   /* (NB == 8: folded as a constant) */
 	constexpr bool SORTED = HK == 1;
+	constexpr bool SHARED_M = NB != 8;
 	constexpr int kSRows = 15;   /* sorted staging rows: valid phi^0..5 | J[8] | hess_term */
-	constexpr int SLAB = SORTED ? kSRows * kRS2 + 8 * kQR : (HK ? (2 * kWinRows + 9) * kRS : 0);   /* dense: gd[11] | wd[11] | rw[8] | ht ; sorted: valid | phi | rw[8] | ht | M[8 classes][8 powers][8] */
+	constexpr int kRowF = mi_fast_row_nb(NB), kPolyI = mi_poly_i(NB), kPolyH = mi_poly_h(NB), kPolySz = mi_poly_size_nb(NB);
+	constexpr int SLAB = SORTED ? kSRows * kRS2 + (SHARED_M ? 0 : 8 * kQR) : (HK ? (2 * kWinRows + 9) * kRS : 0);   /* dense: gd[11] | wd[11] | rw[8] | ht ; sorted: valid | phi | rw[8] | ht | M[8 classes][8 powers][8] */
 	constexpr bool POLY = HK == 0 || HK == 1;   /* the table sums as per-class polynomials (no window is needed: the bin mode of the self Hessian is in moment form) */
 	__shared__ __attribute__((aligned(16))) double Tc[POLY ? 2 : kTRows * MI_NB], Ti[POLY ? 2 : kTRows * MI_NB], Th[1];
-	__shared__ __attribute__((aligned(16))) double Pl[POLY ? kMiPolySize : 2];
-	__shared__ __attribute__((aligned(16))) double slabs[HK ? 4 * SLAB : 4 * 16];
+	__shared__ __attribute__((aligned(16))) double Pl[POLY ? kPolySz : 2];
+	__shared__ __attribute__((aligned(16))) double slabs[HK ? 4 * SLAB + (SORTED && SHARED_M ? NB * kQR : 0) : 4 * 16];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int t = blockIdx.y;
 	if (pa.active && !pa.active[t]) return;
 	const double *tb = pa.tb + (size_t)t * MI_SIZE;
 	if constexpr (POLY) {
-		const double *pl = pa.poly + (size_t)t * kMiPolySize;
-		for (int k = threadIdx.x; k < kMiPolySize; k += kBlock) Pl[k] = pl[k];
+		const double *pl = pa.poly + (size_t)t * kPolySz;
+		for (int k = threadIdx.x; k < kPolySz; k += kBlock) Pl[k] = pl[k];
 	} else {
 		for (int k = threadIdx.x; k < kTRows * MI_NB; k += kBlock) {
 			const int r = k / MI_NB - 1, c = k % MI_NB - 1;
@@ -287,8 +321,11 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 	const double *Tq = HK == 1 ? Th : (HK == 2 ? Tc : Ti);
 	double *gd = slabs + (size_t)wave * SLAB, *wd = gd + kWinRows * kRS, *rw = wd + kWinRows * kRS, *hts = rw + 8 * kRS;
 	double *sd = slabs + (size_t)wave * SLAB, *srw = sd + 6 * kRS2, *sht = srw + 8 * kRS2;   /* sorted form: sd = the six power rows valid phi^k (r05: staged once per pixel instead of rebuilt by every lane of every step) */
-	double *qabs = sht + kRS2;   /* this wave's moment table M[class][power][s] */
-	if constexpr (SORTED) { for (int k2 = lane; k2 < SLAB; k2 += 64) sd[k2] = 0.0; }
+	double *qabs = SHARED_M ? slabs + 4 * SLAB : sht + kRS2;   /* this wave's moment table M[class][power][s] (NB != 8: the workgroup's) */
+	if constexpr (SORTED) {
+		for (int k2 = lane; k2 < SLAB; k2 += 64) sd[k2] = 0.0;
+		if constexpr (SHARED_M) { for (int k2 = threadIdx.x; k2 < NB * kQR; k2 += kBlock) qabs[k2] = 0.0; }
+	}
 	else if constexpr (HK != 0) { for (int k2 = 0; k2 < 2 * kWinRows + 9; ++k2) gd[k2 * kRS + lane] = 0.0; }
 	__syncthreads();
 #ifdef MTFHIP_MI_DESYNC   /* experiment: the two workgroups that share a CU start half a chunk apart (matrix phase of one under the sampling phase of the other) */
@@ -313,7 +350,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 	/* sorted: the moments M[j][s] = sum phi^j J_s of the class this lane's block is in; carried ACROSS chunks (a block leaves its
 	 * class only when its next quad is of another one) */
 	double q00 = 0, q01 = 0, q10 = 0, q11 = 0;   /* M[class][power 4 T + lk][s = 4 h + li]: q<T><h> */
-	int cls = 8;   /* 8: none */
+	int cls = NB;   /* NB: none */
 #pragma unroll
 	for (int k = 0; k < 8; ++k) cq[k] = 0.0;
 	const int li = lane & 3, lb = (lane >> 2) & 3, lk = lane >> 4;
@@ -395,19 +432,20 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 			/* class and fraction of both pixel values; the three table sums by Horner's rule on the class pair's coefficients (see kMiPoly*) */
 			fl_it = min(max((int)sp.it, 0), nb - 1); phi_it = sp.it - (double)fl_it;
 			const int fl0 = min(max((int)i0, 0), nb - 1);
+			constexpr int kPairStride = NB;   /* class pairs are laid out [NB][NB] whatever pa.nb is */
 			const double phi0 = i0 - (double)fl0;
 #if defined(MTFHIP_MI_ABL) && MTFHIP_MI_ABL == 2
 			dft = phi_it + phi0; df0 = phi0;
 #else
 			if (pa.need_dft) {
-				const double *c = Pl + kMiPolyT + (fl_it * 8 + fl0) * kMiPolyPair;
+				const double *c = Pl + kMiPolyT + (fl_it * kPairStride + fl0) * kMiPolyPair;
 				const double r0 = fma(fma(fma(c[3], phi0, c[2]), phi0, c[1]), phi0, c[0]);
 				const double r1 = fma(fma(fma(c[7], phi0, c[6]), phi0, c[5]), phi0, c[4]);
 				const double r2 = fma(fma(fma(c[11], phi0, c[10]), phi0, c[9]), phi0, c[8]);
 				dft = fma(fma(r2, phi_it, r1), phi_it, r0) * vm;
 			}
 			if (pa.need_df0) {
-				const double *c = Pl + kMiPolyI + (fl0 * 8 + fl_it) * kMiPolyPair;
+				const double *c = Pl + kPolyI + (fl0 * kPairStride + fl_it) * kMiPolyPair;
 				const double r0 = fma(fma(fma(c[3], phi_it, c[2]), phi_it, c[1]), phi_it, c[0]);
 				const double r1 = fma(fma(fma(c[7], phi_it, c[6]), phi_it, c[5]), phi_it, c[4]);
 				const double r2 = fma(fma(fma(c[11], phi_it, c[10]), phi_it, c[9]), phi_it, c[8]);
@@ -415,7 +453,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 			}
 #endif
 			if constexpr (SORTED) {
-				const double *c = Pl + kMiPolyH + fl_it * 8;
+				const double *c = Pl + kPolyH + fl_it * 8;
 				hess_term = fma(fma(fma(fma(c[4], phi_it, c[3]), phi_it, c[2]), phi_it, c[1]), phi_it, c[0]);
 			}
 		} else {
@@ -457,7 +495,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 #if defined(MTFHIP_MI_ABL) && MTFHIP_MI_ABL == 4   /* ablation: no sort (one class of 64 slots) */
 			ClassSort cs; cs.slot = lane; cs.ends = 0x4040404040404040ull; cs.total = 64;
 #else
-			const ClassSort cs = class_sort8(valid ? fl_it : -1);
+			using SortT = typename std::conditional<NB == 8, ClassSort, ClassSort12>::type;
+			SortT cs;
+			if constexpr (NB == 8) cs = class_sort8(valid ? fl_it : -1);
+			else cs = class_sort12(valid ? fl_it : -1, nb);
 #endif
 			const int steps = (cs.total + 15) >> 4;   /* quads per block */
 			const int mycol = sorted_col(cs.slot, steps);
@@ -482,16 +523,20 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 			const double *plo = sd + li * kRS2, *phi_ = sd + (4 + (li & 1)) * kRS2, *pja = srw + li * kRS2, *pjb = pja + 4 * kRS2, *pht = sht;   /* + this lane's column of the step */
 			/* class of the quad that starts at slot s0 = number of classes that end at or before it (empty classes included: they end
 			 * where their predecessor does); byte-wise on the packed end slots, no borrow between bytes: (s0 | 0x80) - end >= 0x80 - 88 > 0 */
-			const unsigned ends_lo = (unsigned)cs.ends, ends_hi = (unsigned)(cs.ends >> 32);
+			unsigned ends_lo, ends_hi, ends_x = 0xFFFFFFFFu;   /* (ends_x: the third word of the ten-class sort; 0xFF bytes are never "at or before") */
+			if constexpr (NB == 8) { ends_lo = (unsigned)cs.ends; ends_hi = (unsigned)(cs.ends >> 32); }
+			else { ends_lo = cs.e0; ends_hi = cs.e1; ends_x = cs.e2; }
 			auto class_of = [&](int s0) -> int {
 				const unsigned S = (unsigned)s0 * 0x01010101u | 0x80808080u;
-				return __builtin_popcount((S - ends_lo) & 0x80808080u) + __builtin_popcount((S - ends_hi) & 0x80808080u);
+				int c = __builtin_popcount((S - ends_lo) & 0x80808080u) + __builtin_popcount((S - ends_hi) & 0x80808080u);
+				if constexpr (NB != 8) c += __builtin_popcount((S - ends_x) & 0x80808080u);
+				return c;
 			};
 			/* leave class `cls` for `to`: M[cls][4 T + lk][4 h + li] += q<T><h>.  Result layout of the block product: column = li, block = lb,
 			 * row = lk. */
 			auto leave_class = [&](int to) {
 #if !(defined(MTFHIP_MI_ABL) && MTFHIP_MI_ABL == 5)   /* ablation 5: class boundaries without the table update */
-				if (cls < 8) {
+				if (cls < NB) {
 					double *qe = qabs + cls * 64 + lk * 8 + li;
 					lds_add_f64(qe, q00); lds_add_f64(qe + 4, q01);
 					if (lk < 2) { lds_add_f64(qe + 32, q10); lds_add_f64(qe + 36, q11); }   /* powers 4, 5 */
@@ -505,8 +550,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 			const int s_first = 4 * lb * steps;   /* first slot of this block's range */
 			{
 				const int c_first = class_of(s_first);
-				/* (a range that starts behind the last class -- class 8 -- holds zeros: the block keeps what it has) */
-				if (c_first != cls && c_first < 8) leave_class(c_first);
+				/* (a range that starts behind the last class -- class NB -- holds zeros: the block keeps what it has) */
+				if (c_first != cls && c_first < NB) leave_class(c_first);
 			}
 #if defined(MTFHIP_MI_ABL) && MTFHIP_MI_ABL == 3   /* ablation: sort and stores, no block products */
 			for (int j = 0; j < 0; ++j) {
@@ -527,7 +572,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 				}
 				if (j + 1 < steps) {
 					const int cls_nx = class_of(s_first + 4 * (j + 1));
-					if (cls_nx != cls && cls_nx < 8) leave_class(cls_nx);
+					if (cls_nx != cls && cls_nx < NB) leave_class(cls_nx);
 				}
 				c_lo = n_lo; c_hi = n_hi; c_ja = n_ja; c_jb = n_jb; c_ht = n_ht;
 			}
@@ -585,13 +630,13 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 		}
 	}
 	if constexpr (SORTED) {   /* what the blocks still hold goes to the wave's table */
-		if (cls < 8) {
+		if (cls < NB) {
 			double *qe = qabs + cls * 64 + lk * 8 + li;
 			lds_add_f64(qe, q00); lds_add_f64(qe + 4, q01);
 			if (lk < 2) { lds_add_f64(qe + 32, q10); lds_add_f64(qe + 36, q11); }
 		}
 	}
-	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * kMiFastRow;
+	double *dst = partials + ((size_t)t * nblk + blockIdx.x) * kRowF;
 	__syncthreads();
 	{
 		double *red = slabs;   /* >= 4 * 16 doubles in every instantiation */
@@ -633,22 +678,24 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 			}
 			/* the four waves' moment tables -> one (in the first wave's, in place), then Q[(r, c)][s] = hist_norm sum_fl sum_j C[k][m][j] M[fl][j][s]
 			 * over the classes whose window holds both bins: k = r - (fl - 1), m = c - (fl - 1) in 0..3 */
-			double *m0 = slabs + kSRows * kRS2;
-			double msum[2];
+			double *m0 = SHARED_M ? slabs + 4 * SLAB : slabs + kSRows * kRS2;
+			if constexpr (!SHARED_M) {
+				double msum[2];
 #pragma unroll
-			for (int u = 0; u < 2; ++u) { const int k2 = threadIdx.x + u * kBlock; msum[u] = (m0[k2] + m0[SLAB + k2]) + (m0[2 * SLAB + k2] + m0[3 * SLAB + k2]); }
-			__syncthreads();
+				for (int u = 0; u < 2; ++u) { const int k2 = threadIdx.x + u * kBlock; msum[u] = (m0[k2] + m0[SLAB + k2]) + (m0[2 * SLAB + k2] + m0[3 * SLAB + k2]); }
+				__syncthreads();
 #pragma unroll
-			for (int u = 0; u < 2; ++u) m0[threadIdx.x + u * kBlock] = msum[u];
-			__syncthreads();
+				for (int u = 0; u < 2; ++u) m0[threadIdx.x + u * kBlock] = msum[u];
+				__syncthreads();
+			}
 			constexpr MiMomentCoef CF = mi_moment_coef();
-			for (int k2 = threadIdx.x; k2 < 512; k2 += kBlock) {
-				const int r = k2 >> 6, c = (k2 >> 3) & 7, sx = k2 & 7;
+			for (int k2 = threadIdx.x; k2 < NB * NB * 8; k2 += kBlock) {
+				const int r = NB == 8 ? k2 >> 6 : k2 / (NB * 8), c = NB == 8 ? (k2 >> 3) & 7 : (k2 >> 3) % NB, sx = k2 & 7;
 				double qv = 0.0;
 #pragma unroll
 				for (int k = 0; k < 4; ++k) {
 					const int fl = r + 1 - k, m = c - (fl - 1);
-					if (fl >= 0 && fl < 8 && m >= 0 && m < 4) {
+					if (fl >= 0 && fl < nb && m >= 0 && m < 4) {
 						const double *mm = m0 + fl * 64 + sx;
 						double acc6 = 0.0;
 #pragma unroll

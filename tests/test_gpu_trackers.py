@@ -456,6 +456,54 @@ def test_device_loop_second_order_hessians_mi(oracle, gpu_ctx, frame, sm_kind, s
     b.track_trace(0); b.close()
 
 
+@pytest.mark.parametrize("n_bins,pou", [(10, 1), (10, 0), (6, 0)])
+@pytest.mark.parametrize("sm_kind,ssm,extra", [(L.SM_ESM, L.SSM_HOMOGRAPHY, dict()), (L.SM_FCLK, L.SSM_AFFINE, dict()), (L.SM_ICLK, L.SSM_HOMOGRAPHY, dict()),
+                                               (L.SM_ESM, L.SSM_AFFINE, dict(hess_type=0, leven_marq=1))])
+def test_mi_shipped_bin_count_device_loop_and_candidates(oracle, gpu_ctx, frame, n_bins, pou, sm_kind, ssm, extra):
+    """r06: MI as Config/modules.cfg ships it (mi_n_bins 10, mi_pou 1) and other counts up to ten through the device-side loop
+    (mtfhip_batch_track: the recompute passes' NB = 10 kernels + k_mi_finish_fast<10>) -- per-pass H / g / update of the first pass and
+    the final region against the oracle's trackers -- and through the candidate scorer (k_mi_pass_hist<.., CAND, NB = 10> + the
+    generic k_mi_cand_score) against the oracle's per-candidate loop."""
+    rng = np.random.default_rng(57)
+    res, B = 40, 3
+    frame_b = synth.warp_frame(frame, synth.random_small_homography(rng, 0.25), (256.0, 256.0))
+    corners = np.stack([synth.square_corners(190.0 + 55 * i, 225.0 + 30 * i, 90) + 0.25 * i for i in range(B)])
+    params = dict(leven_marq=0, max_iters=8, epsilon=1e-5)
+    params.update(extra)
+    gpu_ctx.set_image(frame)
+    b = mtf_amd.Batch(gpu_ctx, L.AM_MI, ssm, res, res, B, mi_n_bins=n_bins, mi_pou=pou, likelihood_alpha=0.05)
+    b.set_corners(corners)
+    sm = mtf_amd.sm_desc(sm_kind, materialize=0, **params)
+    b.init_template(sm)
+    # candidates of target 0 on the template's own frame
+    S = b.S
+    states = synth.pf_candidate_states(rng, 70)[:, :S] if ssm == L.SSM_HOMOGRAPHY else rng.normal(size=(70, 6)) * np.array([1.5, 1.5, .01, .01, .01, .01])
+    o_ssm0 = oracle.SSM(ssm, res, res); o_am0 = oracle.AM(L.AM_MI, res, res, n_bins=n_bins, pou=pou, likelihood_alpha=0.05); o_am0.set_curr_img(frame)
+    o_ssm0.set_corners(corners[0]); o_am0.initialize_pix_vals(o_ssm0.get("curr_pts")); o_am0.initialize_similarity()
+    lik_o, sim_o = oracle.pf_score(o_am0, o_ssm0, states)
+    lik, sim = b.score_candidates(states, want_similarity=True)
+    np.testing.assert_allclose(sim, sim_o, rtol=1e-8)
+    np.testing.assert_allclose(lik, lik_o, rtol=1e-6, atol=1e-300)
+    gpu_ctx.set_image(frame_b)
+    b.track_trace(params["max_iters"] * 2)
+    n_it, final = b.track(sm)
+    recs = b.read_track_trace(n_it)
+    rel = lambda a, r: float(np.linalg.norm(np.asarray(a) - np.asarray(r)) / max(np.linalg.norm(r), 1e-300))
+    for t in range(B):
+        o_ssm = oracle.SSM(ssm, res, res); o_am = oracle.AM(L.AM_MI, res, res, n_bins=n_bins, pou=pou); o_am.set_curr_img(frame)
+        trk = oracle.Tracker(sm_kind, o_am, o_ssm, **params)
+        trk.initialize(corners[t]); o_am.set_curr_img(frame_b)
+        iters = trk.update()
+        tr = trk.trace()
+        d0 = recs[t][0]
+        assert rel(d0["g"], tr[0]["g"]) < 1e-5 and rel(d0["dp"], tr[0]["dp"]) < 1e-4, (rel(d0["g"], tr[0]["g"]), rel(d0["dp"], tr[0]["dp"]))
+        if d0["has_H"]:
+            assert rel(d0["H"], tr[0]["H"]) < 1e-5, rel(d0["H"], tr[0]["H"])
+        if iters < params["max_iters"]:
+            np.testing.assert_allclose(final[t], trk.get_region(), rtol=0, atol=5e-3)
+    b.track_trace(0); b.close()
+
+
 @pytest.mark.parametrize("am", [L.AM_SSD, L.AM_NCC, L.AM_MI])
 @pytest.mark.parametrize("math", [mtf_amd.MATH_REPLAY, mtf_amd.MATH_FAST])
 def test_multichannel_candidate_scores_and_particle_filter(oracle, gpu_ctx, am, math):
