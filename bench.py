@@ -250,7 +250,7 @@ def parity_gate(ctx, am_name, res, frame0, frame1, corners):
     return worst
 
 
-def loop_parity(ctx, sm_kind, am, ssm, res, frame0, frame1, corners, max_iters, hess_type=None):
+def loop_parity(ctx, sm_kind, am, ssm, res, frame0, frame1, corners, max_iters, hess_type=None, am_kw=None):
     """One target of a secondary workload through the device-side loop in tolerance mode with the per-pass trace on
     (mtfhip_batch_track_trace), against the CPU trackers with grad_eps 1e-8 (the reference's) and 1e-6 (low finite-difference
     noise): H, g, dp of the first pass (identical state) and every later update relative to the first one, final corners."""
@@ -262,7 +262,9 @@ def loop_parity(ctx, sm_kind, am, ssm, res, frame0, frame1, corners, max_iters, 
         kw["hess_type"] = hess_type
     rel = lambda a, r: float(np.linalg.norm(np.asarray(a) - np.asarray(r)) / max(np.linalg.norm(r), 1e-300))
     ctx.set_image(frame0)
-    b = mtf_amd.Batch(ctx, am, ssm, res, res, 1)
+    am_kw = am_kw or {}
+    o_kw = {{"mi_pou": "pou", "mi_n_bins": "n_bins"}.get(k, k): v for k, v in am_kw.items()}
+    b = mtf_amd.Batch(ctx, am, ssm, res, res, 1, **am_kw)
     b.set_math_mode(mtf_amd.MATH_FAST)
     b.set_corners(corners[None])
     sm = mtf_amd.sm_desc(sm_kind, materialize=0, **kw)
@@ -274,7 +276,7 @@ def loop_parity(ctx, sm_kind, am, ssm, res, frame0, frame1, corners, max_iters, 
     out = {}
     otr = {}
     for eps, name in ((1e-8, "vs_reference_parameters_grad_eps_1e-8"), (1e-6, "vs_low_noise_oracle_grad_eps_1e-6")):
-        o_ssm = O.SSM(ssm, res, res); o_am = O.AM(am, res, res, grad_eps=eps); o_am.set_curr_img(frame0)
+        o_ssm = O.SSM(ssm, res, res); o_am = O.AM(am, res, res, grad_eps=eps, **o_kw); o_am.set_curr_img(frame0)
         trk = O.Tracker(sm_kind, o_am, o_ssm, **kw)
         trk.initialize(corners); o_am.set_curr_img(frame1); trk.update()
         tr = trk.trace()
@@ -392,6 +394,7 @@ def configs_block(args):
         ("config4_pf_10k_chained", ["--workload", "pf", "--particles", "10000", "--pf-iters", "10", "--steps", "40", "--warmup", "5", "--cpu-seconds", cpu]),
         ("config4_pf_10k_host_stepped", ["--workload", "pf", "--particles", "10000", "--pf-iters", "1", "--steps", "200", "--warmup", "20", "--no-cpu"]),
         ("config5_mi_64x400x400", ["--workload", "mi", "--steps", "6", "--warmup", "2", "--cpu-seconds", cpu]),
+        ("config5_mi_64x400x400_shipped_10_bins_pou", ["--workload", "mi", "--mi-bins", "10", "--mi-pou", "1", "--steps", "6", "--warmup", "2", "--cpu-seconds", cpu]),
         ("nn_dataset_10k_50x50", ["--workload", "nn", "--steps", "10", "--warmup", "2", "--cpu-seconds", cpu]),
     ]
     env = os.environ.copy()
@@ -1074,7 +1077,11 @@ def secondary_workload(args):
     else:  # mi
         H = W = 2048
         mc = args.channels == 3   # MCMI: MI over (pixel, channel) rows of a 32FC3 frame (AM/src/MCMI.cc)
-        amp = dict(n_channels=3) if mc else None
+        amp = dict(n_channels=3) if mc else {}
+        if args.mi_bins != 8 or args.mi_pou:
+            amp.update(mi_n_bins=args.mi_bins, mi_pou=args.mi_pou)
+        amp = amp or None
+        mi_kw = dict(mi_n_bins=args.mi_bins, mi_pou=args.mi_pou)
         frame0 = synth.make_frame_mc(H, W) if mc else synth.make_frame(H, W)
         p_true = synth.random_small_homography(rng, 0.3)
         frame1 = synth.warp_frame(frame0, p_true, (W / 2.0, H / 2.0))
@@ -1110,7 +1117,7 @@ def secondary_workload(args):
             # measured 5.9 ceiling), not by HBM: `frac` = the cycles the counted VALU instructions need at that ceiling / the cycles the
             # kernels took (both passes; counters from profiles/pmc_secondary_latest.json, quoted only for the kernel sources being run);
             # the HBM figure rides along as hbm_frac.
-            standard = (not mc) and B == 64 and res == 400
+            standard = (not mc) and B == 64 and res == 400 and args.mi_bins == 8 and not args.mi_pou
             pm1 = pmc_secondary("mi", "k_mi_pass_hist") if standard else None
             pm2 = pmc_secondary("mi", "k_mi_pass_grad_hess") if standard else None
             note = getattr(pmc_secondary, "note", None) if standard else "PMC passes are taken on the 64 x 400 x 400 single-channel workload"
@@ -1132,14 +1139,14 @@ def secondary_workload(args):
         out.update({"roofline": mi_roof})
         out.update({"metric": "ESM+MI target-iterations/sec, %dx%d, %d targets" % (res, res, B),
                     "value": B * KI * args.steps * world / dt, "unit": "target-iters/s", "ms_per_step": dt / args.steps * 1e3,
-                    "scaling": "weak", "config": {"workload": "ESM+%s(8 bins)+Homography %dx%d%s x %d targets per GPU, %s" %
-                                                  ("MCMI" if mc else "MI", res, res, "x3" if mc else "", B, {"fused": "fused MI passes (mtfhip_batch_iterate) + host solve",
+                    "scaling": "weak", "config": {"workload": "ESM+%s(%d bins%s)+Homography %dx%d%s x %d targets per GPU, %s" %
+                                                  ("MCMI" if mc else "MI", args.mi_bins, ", partition of unity" if args.mi_pou else "", res, res, "x3" if mc else "", B, {"fused": "fused MI passes (mtfhip_batch_iterate) + host solve",
                                                                  "device": "fused MI passes, solve + update on the device (mtfhip_batch_track), %d iterations per step" % KI,
                                                                  "interface": "per-function entry points"}[args.mi_path]),
                                                   "iterations_per_step": KI}})
         if rank == 0 and not args.no_cpu and not mc:
             import oracle_py as O
-            ssm = O.SSM(O.SSM_HOM, res, res); am = O.AM(O.AM_MI, res, res); am.set_curr_img(frame0)
+            ssm = O.SSM(O.SSM_HOM, res, res); am = O.AM(O.AM_MI, res, res, n_bins=args.mi_bins, pou=args.mi_pou); am.set_curr_img(frame0)
             trk = O.Tracker(O.SM_ESM, am, ssm, leven_marq=0, max_iters=2, epsilon=-1.0)
             trk.initialize(corners[0]); am.set_curr_img(frame1)
             n, t0 = 0, time.perf_counter()
@@ -1148,7 +1155,7 @@ def secondary_workload(args):
             out["cpu_baseline"] = {"value": n / (time.perf_counter() - t0), "unit": "target-iters/s", "cores": 1, "kind": "port",
                                    "sample": "%d ESM+MI iterations of one %dx%d target" % (n, res, res)}
             if args.mi_path == "device":
-                out["parity"] = loop_parity(ctx, mtf_amd.SM_ESM, mtf_amd.AM_MI, mtf_amd.SSM_HOMOGRAPHY, res, frame0, frame1, corners[0], 4)
+                out["parity"] = loop_parity(ctx, mtf_amd.SM_ESM, mtf_amd.AM_MI, mtf_amd.SSM_HOMOGRAPHY, res, frame0, frame1, corners[0], 4, am_kw=mi_kw)
                 out["parity"]["budget_note"] = ("MI's update is ill-conditioned: the two oracles themselves differ by 1e-5 .. 1e-4 in dp "
                                                 "(tests/test_oracle_relations.py::test_mi_update_noise_floor); H and g are the 1e-5 quantities")
     if rank == 0:
@@ -1178,6 +1185,8 @@ def main():
     ap.add_argument("--am", default="ssd", choices=["ssd", "ncc"], help="appearance model (lk and dropin workloads)")
     ap.add_argument("--mi-path", default="device", choices=["fused", "device", "interface"],
                     help="mi workload: fused iterate + host solve, the device-side loop, or one call per virtual")
+    ap.add_argument("--mi-bins", type=int, default=8, help="mi workload: n_bins (BASELINE.json config 5: 8; the shipped Config/modules.cfg:115: 10)")
+    ap.add_argument("--mi-pou", type=int, default=0, help="mi workload: partition of unity (the shipped Config/modules.cfg:117: 1)")
     ap.add_argument("--lm", type=int, default=1, help="dropin workload: Levenberg-Marquardt (the reference's class default is on)")
     ap.add_argument("--device-loop", action="store_true", help="dropin workload: the C++ search method is mtf::hip::LK (whole update() in one C-ABI call)")
     ap.add_argument("--mode", default="full", choices=["full", "lean"],

@@ -33,12 +33,10 @@ namespace mtfhip {
 /* CAND: the candidate axis (PF / NN, SM/src/PF.cc:247-262 with MI as the appearance model): blockIdx.y is a candidate of target 0 --
  * its warp comes from the candidate's state, the template arrays are target 0's */
 /* NB (r06): 8 = the r03-r05 kernel (pa.nb == 8: the 8 x 8 histograms are the four 4 x 4 blocks of ONE block product per step).  10: up to
- * ten bins at run time (pa.nb; the shipped mi_n_bins 10): the histograms are 3 x 3 tiles of 4 x 4 -- bins padded to twelve, rows nb .. 11 hold
- * the taps that fall outside the histogram and are not stored -- i.e. three block products per step: tiles (0..1, 0..1) | (2, 0) (2, 1) (0, 2)
- * (1, 2) | (2, 2). */
+ * ten bins at run time (pa.nb; the shipped mi_n_bins 10): the histograms come out of ONE 16 x 16 tile product per four pixels. */
 template <int SSM, bool SELF, bool CAND = false, bool MC = false, int NB = 8>
 __global__ __launch_bounds__(kBlock) void k_mi_pass_hist(BatchView bv, ImgView im, MiPassArgs pa, double *partials, int nblk, int row_len) {
-	constexpr int kWinRows = NB + 3;   /* rows (bin + 1): row 0 and the rows behind bin NB - 1 take the taps outside the histogram */
+	constexpr int kWinRows = NB == 8 ? 11 : NB + 2;   /* rows (bin + 1): row 0 and the rows behind bin nb - 1 take the taps outside the histogram */
 	__shared__ __attribute__((aligned(16))) double slabs[4 * 2 * kWinRows * kRS];
 	const int nb = NB == 8 ? 8 : pa.nb;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -66,12 +64,10 @@ __global__ __launch_bounds__(kBlock) void k_mi_pass_hist(BatchView bv, ImgView i
 	const double *I0 = bv.buf[MTFHIP_BUF_I0] + tt * N;
 	for (int k2 = 0; k2 < 2 * kWinRows; ++k2) wa[k2 * kRS + lane] = 0.0;   /* the slabs start clean and every chunk leaves them clean */
 	double bj8 = 0.0, bs8 = 0.0, bh8 = 0.0;
-	double bjB = 0.0, bjC = 0.0, bsB = 0.0, bsC = 0.0, bhB = 0.0;   /* NB = 10: the second and third tile sets */
+	mfma_d4 cj16 = {0.0, 0.0, 0.0, 0.0}, cs16 = {0.0, 0.0, 0.0, 0.0};   /* NB = 10: the 16 x 16 tile's accumulators */
 	const bool hfj = !CAND && pa.hist_from_joint != 0;
 	const int li = lane & 3, lb = (lane >> 2) & 3, lk = lane >> 4;
 	const double one0 = li == 0 ? 1.0 : 0.0;
-	/* tile (row, column) of block lb in the second set: (2, 0) (2, 1) (0, 2) (1, 2) */
-	const int trB = lb < 2 ? 2 : lb - 2, tcB = lb < 2 ? lb : 2;
 	const unsigned stride = (unsigned)nblk * kBlock;
 	unsigned base = (blockIdx.x * (kBlock / 64) + wave) * 64;
 	/* Software pipeline with build-time depths (MTFHIP_MI_OP_AHEAD / MTFHIP_MI_TEX_AHEAD): the operands of chunk n + TD + PF are requested
@@ -128,30 +124,28 @@ __global__ __launch_bounds__(kBlock) void k_mi_pass_hist(BatchView bv, ImgView i
 		bj8 += (a.w[0] + a.w[1] + a.w[2] + a.w[3]) * vm + b.w[0] + b.w[1] + b.w[2] + b.w[3] + a.row0 + b.row0;
 #else
 		double *ra = wa + a.row0 * kRS + lane, *rb = wb + b.row0 * kRS + lane;
+		/* NB != 8: rows 0 .. nb + 1 only (NB + 2 rows: three workgroups per CU as the 8-bin kernel; with NB + 3 the allocation granule made it two and
+		 * the pass 224 us instead of 115) -- the one tap that can reach bin nb + 1 (the last of a window at fl = nb - 1) is stored onto the row of
+		 * bin nb, which nobody reads either */
+		const int ka3 = (NB != 8 && a.row0 + 3 > nb + 1) ? 2 * kRS : 3 * kRS, kb3 = (NB != 8 && b.row0 + 3 > nb + 1) ? 2 * kRS : 3 * kRS;
 #pragma unroll
-		for (int k = 0; k < 4; ++k) { ra[k * kRS] = a.w[k] * vm; rb[k * kRS] = b.w[k]; }
+		for (int k = 0; k < 3; ++k) { ra[k * kRS] = a.w[k] * vm; rb[k * kRS] = b.w[k]; }
+		ra[ka3] = a.w[3] * vm; rb[kb3] = b.w[3];
 		__builtin_amdgcn_wave_barrier();
 #if !(defined(MTFHIP_MI1_ABL) && MTFHIP_MI1_ABL == 2)   /* 2: + staging, no products */
 		if constexpr (NB != 8) {
-			/* (uniform branches on hfj: the histogram as the joint histogram's row sums, or as block products of its own) */
+			/* one 16 x 16 tile (v_mfma_f64_16x16x4_f64: lane l supplies A[i = l % 16][k = l / 16], B[k][j = l % 16] and receives D[i = l / 16 + 4 v][j = l % 16]
+			 * in element v): rows / columns = bins, column nb of B all ones so that D[r][nb] is the histogram of It (as k_mi_hist, kernels_mi.hip).
+			 * Two LDS reads and one matrix instruction per four pixels for any count up to ten -- the 3 x 3 tiles of 4 x 4 block products this
+			 * replaced (r06 first form: three instructions, six reads) took pass 1 from 115 to 214 us at 10 bins. */
+			const int idx = lane & 15, kq = lane >> 4, row = 1 + (idx < nb ? idx : nb - 1);
 #pragma unroll
-			for (int qq = 0; qq < 16; ++qq) {
-				const int p = 4 * qq + lk;
-				const double av = wa[(1 + 4 * (lb >> 1) + li) * kRS + p], bvv = wb[(1 + 4 * (lb & 1) + li) * kRS + p];
-				const double avB = wa[(1 + 4 * trB + li) * kRS + p], bvB = wb[(1 + 4 * tcB + li) * kRS + p];
-				const double avC = wa[(9 + li) * kRS + p], bvC = wb[(9 + li) * kRS + p];
-				bj8 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bvv, bj8, 0, 0, 0);
-				bjB = __builtin_amdgcn_mfma_f64_4x4x4f64(avB, bvB, bjB, 0, 0, 0);
-				bjC = __builtin_amdgcn_mfma_f64_4x4x4f64(avC, bvC, bjC, 0, 0, 0);
-				if (!hfj) {
-					bh8 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, one0, bh8, 0, 0, 0);
-					bhB = __builtin_amdgcn_mfma_f64_4x4x4f64(avB, one0, bhB, 0, 0, 0);
-				}
-				if constexpr (SELF) {
-					bs8 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, wa[(1 + 4 * (lb & 1) + li) * kRS + p], bs8, 0, 0, 0);
-					bsB = __builtin_amdgcn_mfma_f64_4x4x4f64(avB, wa[(1 + 4 * tcB + li) * kRS + p], bsB, 0, 0, 0);
-					bsC = __builtin_amdgcn_mfma_f64_4x4x4f64(avC, avC, bsC, 0, 0, 0);
-				}
+			for (int ks = 0; ks < 16; ++ks) {
+				const int p = 4 * ks + kq;
+				const double av0 = wa[row * kRS + p], bv0 = wb[row * kRS + p];
+				const double av = idx < nb ? av0 : 0.0;
+				cj16 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, idx < nb ? bv0 : (idx == nb ? 1.0 : 0.0), cj16, 0, 0, 0);
+				if constexpr (SELF) cs16 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, av, cs16, 0, 0, 0);
 			}
 		} else
 		if (hfj) {   /* (uniform) the histogram comes out of the joint histogram's rows at the end: two block products per step instead of three */
@@ -177,31 +171,29 @@ __global__ __launch_bounds__(kBlock) void k_mi_pass_hist(BatchView bv, ImgView i
 #endif
 		__builtin_amdgcn_wave_barrier();
 #pragma unroll
-		for (int k = 0; k < 4; ++k) { ra[k * kRS] = 0.0; rb[k * kRS] = 0.0; }   /* leave the slabs clean: 8 stores instead of 22 */
+		for (int k = 0; k < 3; ++k) { ra[k * kRS] = 0.0; rb[k * kRS] = 0.0; }   /* leave the slabs clean: 8 stores instead of 22 */
+		ra[ka3] = 0.0; rb[kb3] = 0.0;
 #endif
 #endif
 	}
 	__syncthreads();
 	double *red = slabs;
 	const int rl = nb + nb * nb + (SELF ? nb * nb : 0);
-	{
+	if constexpr (NB == 8) {
 		const int r = 4 * (lb >> 1) + (lane >> 4), c = 4 * (lb & 1) + (lane & 3);
-		if (NB == 8 || (r < nb && c < nb)) {
-			red[wave * rl + nb + r * nb + c] = bj8;
-			if constexpr (SELF) red[wave * rl + nb + nb * nb + r * nb + c] = bs8;
-		}
-		if ((lb & 1) == 0 && (lane & 3) == 0 && (NB == 8 || r < nb)) red[wave * rl + r] = bh8;
-		if constexpr (NB != 8) {
-			const int rB = 4 * trB + (lane >> 4), cB = 4 * tcB + (lane & 3);
-			if (rB < nb && cB < nb) {
-				red[wave * rl + nb + rB * nb + cB] = bjB;
-				if constexpr (SELF) red[wave * rl + nb + nb * nb + rB * nb + cB] = bsB;
-			}
-			if (lb == 0 && (lane & 3) == 0 && rB < nb) red[wave * rl + rB] = bhB;   /* (block 0 of the second set: tile row 2, the histogram's bins 8 ..) */
-			const int rC = 8 + (lane >> 4), cC = 8 + (lane & 3);
-			if (lb == 0 && rC < nb && cC < nb) {
-				red[wave * rl + nb + rC * nb + cC] = bjC;
-				if constexpr (SELF) red[wave * rl + nb + nb * nb + rC * nb + cC] = bsC;
+		red[wave * rl + nb + r * nb + c] = bj8;
+		if constexpr (SELF) red[wave * rl + nb + nb * nb + r * nb + c] = bs8;
+		if ((lb & 1) == 0 && (lane & 3) == 0) red[wave * rl + r] = bh8;
+	} else {
+		const int j = lane & 15;
+#pragma unroll
+		for (int v = 0; v < 4; ++v) {
+			const int i = (lane >> 4) + 4 * v;
+			if (i < nb) {
+				if (j < nb) {
+					red[wave * rl + nb + i * nb + j] = cj16[v];
+					if constexpr (SELF) red[wave * rl + nb + nb * nb + i * nb + j] = cs16[v];
+				} else if (j == nb) red[wave * rl + i] = cj16[v];
 			}
 		}
 	}
