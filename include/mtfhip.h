@@ -506,6 +506,28 @@ int mtfhip_pf_shard_bounds(int n_particles, int world, int rank, int *lo, int *c
 int mtfhip_sample_candidates(mtfhip_batch *b, const double *states /* C x S */, int n_samples, double *features /* C x N */);
 int mtfhip_sample_candidates_dev(mtfhip_batch *b, const double *dev_states, int n_samples, double *dev_features);
 
+/* NN::generateDataset itself (SM/src/NT/NN.cc:131-191, compositional update) in one launch: per sample the perturbation p -- row c of
+ * perturbations_in, or (NULL) drawn on the device as ProjectiveBase::generatePerturbation does (ProjectiveBase.cc:283-288: component k ~
+ * N(mean[k], sigma[k]); Philox4x32-10 + Box-Muller keyed by (seed, c): a pure function of the sample's index) --, the SSM moved by
+ * invertState(p) (Homography.cc:109-114, Affine.cc:145-150) through compositionalUpdate (Homography.cc:73-92), updatePixVals, and
+ * updateDistFeat into row c: SSD the patch (SSDBase.h:116-125), NCC centred and of unit norm (NCC.cc:530-537), MI the 5 x N matrix
+ * floor(It) | four cubic B-spline weights (MI.cc:736-747); multi-channel models: rows of N = n_pix x n_channels entries.  The batch holds
+ * ONE target; its SSM is left where it was (the reference's compositionalUpdate(p) back).  additive_update (NNParams): not implemented. */
+typedef struct mtfhip_nn_desc {
+	int n_samples;
+	int additive_update;      /* NNParams::additive_update (SM/src/NT/NNParams.cc): must be 0 */
+	double sigma[8], mean[8]; /* state_sigma[0] / state_mean[0] of NN::initialize (NT/NN.cc:56-84); several distributions: one call per distribution
+	                             with its rows (row_lo / row_count of the _dev form) */
+	unsigned long long seed;
+} mtfhip_nn_desc;
+int mtfhip_nn_feature_size(mtfhip_batch *b, int *feat_size);   /* am->getDistFeatSize(): N, MI 5 N */
+/* host form: perturbations_in (n_samples x S, or NULL: drawn), perturbations_out (n_samples x S, or NULL), features (n_samples x feat_size) */
+int mtfhip_nn_dataset(mtfhip_batch *b, const mtfhip_nn_desc *d, const double *perturbations_in, double *perturbations_out, double *features);
+/* device form (the dataset stays in HBM; RCCL all-gather of row blocks): rows [row_lo, row_lo + row_count) of the n_samples x feat_size
+ * matrix into dev_features[row_count][feat_size]; dev_perturbations_in / _out are indexed by the GLOBAL sample index (n_samples x S) */
+int mtfhip_nn_dataset_dev(mtfhip_batch *b, const mtfhip_nn_desc *d, const double *dev_perturbations_in, double *dev_perturbations_out,
+	double *dev_features, int row_lo, int row_count);
+
 /* ---- measurement hooks ---- */
 /* average duration in milliseconds of the launches of the named kernel family since the last
  * reset, measured with hipEvents on the context's stream (0 if timing is disabled).

@@ -77,6 +77,11 @@ class GridFbDesc(C.Structure):
     _fields_ = [("fb_err_thresh", C.c_double), ("fb_reinit", C.c_int), ("n_model_pts", C.c_int)]
 
 
+class NnDesc(C.Structure):
+    """mtfhip_nn_desc: NN::generateDataset's parameters (SM/src/NT/NN.cc:56-84, 131-191)"""
+    _fields_ = [("n_samples", C.c_int), ("additive_update", C.c_int), ("sigma", C.c_double * 8), ("mean", C.c_double * 8), ("seed", C.c_ulonglong)]
+
+
 # every exported symbol of include/mtfhip.h (tests check that the library exports all of them)
 SYMBOLS = [
     "mtfhip_last_error", "mtfhip_device_count", "mtfhip_ctx_create", "mtfhip_ctx_destroy",
@@ -106,7 +111,7 @@ SYMBOLS = [
     "mtfhip_image_keep_prev", "mtfhip_image_has_prev", "mtfhip_image_swap_prev", "mtfhip_grid_backward", "mtfhip_grid_fb_mask", "mtfhip_grid_frame_fb",
     "mtfhip_batch_track_targets_per_launch",
     "mtfhip_score_candidates", "mtfhip_score_candidates_dev",
-    "mtfhip_sample_candidates", "mtfhip_sample_candidates_dev",
+    "mtfhip_sample_candidates", "mtfhip_sample_candidates_dev", "mtfhip_nn_feature_size", "mtfhip_nn_dataset", "mtfhip_nn_dataset_dev",
     "mtfhip_pf_create", "mtfhip_pf_destroy", "mtfhip_pf_initialize", "mtfhip_pf_set_region", "mtfhip_pf_set_sampler",
     "mtfhip_pf_iteration", "mtfhip_pf_update", "mtfhip_pf_get_particles", "mtfhip_pf_set_particles", "mtfhip_pf_max_similarity",
     "mtfhip_pf_set_max_similarity", "mtfhip_pf_set_distributions", "mtfhip_pf_set_distr_draws", "mtfhip_pf_get_distributions", "mtfhip_comm_create_loopback", "mtfhip_pf_shard_bounds",
@@ -185,6 +190,9 @@ def lib():
         L.mtfhip_score_candidates_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.mtfhip_sample_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.mtfhip_sample_candidates_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.mtfhip_nn_feature_size.argtypes = [C.c_void_p, C.c_void_p]
+        L.mtfhip_nn_dataset.argtypes = [C.c_void_p] * 5
+        L.mtfhip_nn_dataset_dev.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int]
         L.mtfhip_batch_device_ptr.argtypes = [C.c_void_p, C.c_int]
         L.mtfhip_batch_read.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.mtfhip_batch_write.argtypes = [C.c_void_p, C.c_int, C.c_void_p]

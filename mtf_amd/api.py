@@ -597,6 +597,39 @@ class Batch:
         return dict(n_iters=n, corners=c.transpose(0, 2, 1).copy(), centroids=m, fb_prev_pts=fbp, fb_err_mask=mask.astype(bool), prev_masked=pm[:k].copy(),
                     curr_masked=cm[:k].copy())
 
+    # ---------------------------------------------------------- NN dataset generation
+    def nn_feature_size(self):
+        """am->getDistFeatSize(): N (SSD, NCC), 5 N (MI)"""
+        f = C.c_int()
+        L.check(L.lib().mtfhip_nn_feature_size(self._h, C.addressof(f)))
+        return f.value
+
+    def nn_desc(self, n_samples, sigma, mean=None, seed=0):
+        d = L.NnDesc()
+        d.n_samples, d.additive_update, d.seed = int(n_samples), 0, int(seed)
+        sg = np.zeros(8); sg[:self.S] = np.asarray(sigma, dtype=np.float64)[:self.S]
+        mn = np.zeros(8)
+        if mean is not None:
+            mn[:self.S] = np.asarray(mean, dtype=np.float64)[:self.S]
+        for k in range(8):
+            d.sigma[k] = sg[k]; d.mean[k] = mn[k]
+        return d
+
+    def nn_dataset(self, n_samples, sigma, mean=None, seed=0, perturbations=None):
+        """NN::generateDataset (mtfhip_nn_dataset): perturbations given (n_samples, S) or drawn on the device -> (perturbations, features
+        (n_samples, feat_size)) on the host"""
+        d = self.nn_desc(n_samples, sigma, mean, seed)
+        F = self.nn_feature_size()
+        feat, pout = np.empty((n_samples, F)), np.empty((n_samples, self.S))
+        pin = None if perturbations is None else np.ascontiguousarray(np.asarray(perturbations, dtype=np.float64).reshape(n_samples, self.S))
+        L.check(L.lib().mtfhip_nn_dataset(self._h, C.addressof(d), None if pin is None else _p(pin), _p(pout), _p(feat)))
+        return pout, feat
+
+    def nn_dataset_dev(self, desc, dev_features_ptr, row_lo, row_count, dev_perts_in_ptr=None, dev_perts_out_ptr=None):
+        """rows [row_lo, row_lo + row_count) of the dataset into device memory (mtfhip_nn_dataset_dev); pointers are device addresses"""
+        L.check(L.lib().mtfhip_nn_dataset_dev(self._h, C.addressof(desc), C.c_void_p(dev_perts_in_ptr) if dev_perts_in_ptr else None,
+                                              C.c_void_p(dev_perts_out_ptr) if dev_perts_out_ptr else None, C.c_void_p(dev_features_ptr), int(row_lo), int(row_count)))
+
     # ---------------------------------------------------------- candidate scoring
     def score_candidates(self, states, want_similarity=False):
         s = _f64(states).reshape(-1, self.S)

@@ -1749,6 +1749,53 @@ int mtfhip_sample_candidates(mtfhip_batch *b, const double *states, int C, doubl
 	return rc;
 }
 
+/* NN::generateDataset (SM/src/NT/NN.cc:131-191) */
+int mtfhip_nn_feature_size(mtfhip_batch *b, int *feat_size) {
+	if (!b || !feat_size) return fail(MTFHIP_ERR_INVALID_ARG, "nn_feature_size: NULL argument");
+	*feat_size = b->desc.am == MTFHIP_AM_MI ? 5 * b->N : b->N;   /* MI.cc:122: feat_size = 5 * patch_size; SSDBase.h:116-125, NCC.cc:530-537: patch_size */
+	return MTFHIP_OK;
+}
+int mtfhip_nn_dataset_dev(mtfhip_batch *b, const mtfhip_nn_desc *d, const double *dev_perturbations_in, double *dev_perturbations_out, double *dev_features,
+	int row_lo, int row_count) {
+	FLUSH(b);
+	if (!b || !d || !dev_features) return fail(MTFHIP_ERR_INVALID_ARG, "nn_dataset: NULL argument");
+	if (d->n_samples <= 0 || row_lo < 0 || row_count < 0 || row_lo + row_count > d->n_samples)
+		return fail(MTFHIP_ERR_INVALID_ARG, "nn_dataset: rows [%d, %d) of %d samples", row_lo, row_lo + row_count, d->n_samples);
+	if (d->additive_update) return fail(MTFHIP_ERR_NOT_IMPLEMENTED, "nn_dataset: additive_update (NNParams, NT/NN.cc:150-152): the compositional form only");
+	if (!b->have_corners) return fail(MTFHIP_ERR_LOGIC, "nn_dataset before set_corners");
+	if (b->B != 1) return fail(MTFHIP_ERR_INVALID_ARG, "nn_dataset: one template per batch (the batch has %d targets)", b->B);
+	TRY(need_image(b));
+	for (int s = 0; s < b->S; ++s) if (!(d->sigma[s] >= 0)) return fail(MTFHIP_ERR_INVALID_ARG, "nn_dataset: sigma[%d] = %g", s, d->sigma[s]);
+	NnArgs a;
+	a.perts_in = dev_perturbations_in; a.perts_out = dev_perturbations_out;
+	for (int s = 0; s < 8; ++s) { a.sigma[s] = s < b->S ? d->sigma[s] : 0.0; a.mean[s] = s < b->S ? d->mean[s] : 0.0; }
+	a.seed = d->seed;
+	std::memcpy(a.base, b->th[0].warp.m, sizeof(a.base));
+	a.row_lo = row_lo; a.norm_mult = b->norm_mult; a.norm_add = b->norm_add;
+	TimedScope ts(b->ctx, "nn_dataset");
+	launch_nn_dataset(b->view_raw(), b->ctx->img, a, row_count, dev_features, b->ctx->stream);
+	return MTFHIP_OK;
+}
+int mtfhip_nn_dataset(mtfhip_batch *b, const mtfhip_nn_desc *d, const double *perturbations_in, double *perturbations_out, double *features) {
+	if (!b || !d || !features) return fail(MTFHIP_ERR_INVALID_ARG, "nn_dataset: NULL argument");
+	if (d->n_samples <= 0) return fail(MTFHIP_ERR_INVALID_ARG, "nn_dataset: n_samples must be positive");
+	int F = 0;
+	TRY(mtfhip_nn_feature_size(b, &F));
+	const size_t C = (size_t)d->n_samples;
+	double *d_p = nullptr, *d_feat = nullptr;
+	HIP_TRY(hipMalloc(&d_p, sizeof(double) * C * b->S));
+	if (hipMalloc(&d_feat, sizeof(double) * C * F) != hipSuccess) { (void)hipFree(d_p); return fail(MTFHIP_ERR_HIP, "hipMalloc of the %d x %d feature matrix failed", d->n_samples, F); }
+	int rc = MTFHIP_OK;
+	hipStream_t st = b->ctx->stream;
+	if (perturbations_in && hipMemcpyAsync(d_p, perturbations_in, sizeof(double) * C * b->S, hipMemcpyHostToDevice, st) != hipSuccess) rc = fail(MTFHIP_ERR_HIP, "perturbation upload failed");
+	if (rc == MTFHIP_OK) rc = mtfhip_nn_dataset_dev(b, d, perturbations_in ? d_p : nullptr, d_p, d_feat, 0, d->n_samples);
+	if (rc == MTFHIP_OK && perturbations_out && hipMemcpyAsync(perturbations_out, d_p, sizeof(double) * C * b->S, hipMemcpyDeviceToHost, st) != hipSuccess) rc = fail(MTFHIP_ERR_HIP, "perturbation read-back failed");
+	if (rc == MTFHIP_OK && hipMemcpyAsync(features, d_feat, sizeof(double) * C * F, hipMemcpyDeviceToHost, st) != hipSuccess) rc = fail(MTFHIP_ERR_HIP, "feature read-back failed");
+	if (hipStreamSynchronize(st) != hipSuccess && rc == MTFHIP_OK) rc = fail(MTFHIP_ERR_HIP, "stream synchronisation failed");
+	(void)hipFree(d_p); (void)hipFree(d_feat);
+	return rc;
+}
+
 
 } /* extern "C" */
 

@@ -476,6 +476,17 @@ void launch_sym5(const float *src, float *tmp, float *dst, int rows, int cols, c
 void launch_pyr_down(const float *src, int srows, int scols, float *dst, int drows, int dcols, hipStream_t st);
 void launch_resize_linear(const float *src, int srows, int scols, float *dst, int drows, int dcols, hipStream_t st);
 /* NN dataset rows: features of C warped patches of target 0 (SSD: It, NCC: centred / normalised It) */
+/* nt::NN's dataset generation in one launch (kernels_nn.hip) */
+struct NnArgs {
+	const double *perts_in;   /* [n_samples][S] device: the perturbations (any sampler of the SSM, made by the caller), or NULL: drawn on the device */
+	double *perts_out;        /* [n_samples][S] device or NULL: the perturbations used (NN keeps them: ssm_perturbations, NT/NN.cc:141-147) */
+	double sigma[8], mean[8]; /* ProjectiveBase::generatePerturbation: component k ~ N(mean_k, sigma_k) */
+	unsigned long long seed;
+	double base[9];           /* the SSM's current warp */
+	int row_lo;               /* global index of the launch's first sample (row sharding: draws are keyed by the global index) */
+	double norm_mult, norm_add;
+};
+void launch_nn_dataset(const BatchView &bv, const ImgView &im, const NnArgs &a, int count, double *feat, hipStream_t st);
 void launch_sample_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C, double norm_mult,
 	double norm_add, double *dev_feat, hipStream_t st);
 /* whole ICLK loop in one launch, one workgroup per target (N <= 16 * kBlock); false if N is too large */

@@ -21,6 +21,14 @@ def shard_sizes(n_items, world):
     return [shard_bounds(n_items, r, world)[1] - shard_bounds(n_items, r, world)[0] for r in range(world)]
 
 
+def padded_shard(n_items, rank, world):
+    """the particle filter's partition (mtfhip_pf_shard_bounds): ceil(n / world) items per rank of a world x ceil(n / world) buffer, the last
+    ranks' blocks ragged or empty -> (lo, count, per_rank).  Row blocks of this shape go through ONE all_gather_into_tensor."""
+    m = -(-int(n_items) // int(world))
+    lo = min(rank * m, int(n_items))
+    return lo, max(0, min(int(n_items), (rank + 1) * m) - lo), m
+
+
 class ShardedTargets:
     """Independent targets (concurrent trackers of config 5, GridTracker patches) sharded over the ranks of a process
     group: rank r owns the contiguous block shard_bounds(n_targets, r, world) and tracks it with its own Batch -- no

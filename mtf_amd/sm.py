@@ -801,32 +801,74 @@ class ParticleFilter:
 
 
 class NNDataset:
-    """Dataset generation of nt::NN (SM/src/NT/NN.cc:131-191, compositional update): sample perturbations of the
-    tracked region, warp by each INVERSE perturbation, and keep the AM's distance feature of every warped patch.
-    The C x N feature matrix comes from one mtfhip_sample_candidates call; the index structure built over it
-    (FLANN in the reference, NN.cc:99-128) is outside the path -- `nearest` is the exhaustive search."""
+    """Dataset generation of nt::NN (SM/src/NT/NN.cc:131-191, compositional update) in ONE launch (mtfhip_nn_dataset: perturbation draw or
+    the caller's perturbations, invertState, compositionalUpdate, updatePixVals, updateDistFeat per sample -- SSD, NCC and MI features,
+    single- and multi-channel).  Several sampler distributions (NN.cc:56-84: state_sigma[k], distr_n_samples[k]) are consecutive row
+    blocks, one launch each.  With `group` (a torch.distributed process group) the rows are block-partitioned over its ranks and one
+    all-gather leaves the whole matrix on every rank (SURVEY.md section 8e's partition; the draws are keyed by the global sample index).
+    The index built over the matrix (FLANN / GNN in the reference, NN.cc:99-128) is outside the path -- `nearest` is the exhaustive search."""
 
     def __init__(self, ctx, am=L.AM_SSD, ssm=L.SSM_HOMOGRAPHY, resx=50, resy=50, n_samples=1000,
-                 ssm_sigma=(0.01, 0.01, 2.0, 0.01, 0.01, 2.0, 1e-5, 1e-5), seed=0):
-        self.batch = Batch(ctx, am, ssm, resx, resy, 1)
+                 ssm_sigma=(0.01, 0.01, 2.0, 0.01, 0.01, 2.0, 1e-5, 1e-5), ssm_mean=None, seed=0, am_params=None, distr_n_samples=None):
+        self.batch = Batch(ctx, am, ssm, resx, resy, 1, **(am_params or {}))
         self.S = self.batch.S
-        self.n = n_samples
-        self.sigma = np.asarray(ssm_sigma, dtype=np.float64)[: self.S]
-        self.rng = np.random.default_rng(seed)
+        self.n = int(n_samples)
+        sg = np.atleast_2d(np.asarray(ssm_sigma, dtype=np.float64))
+        self.sigmas = [row[: self.S] for row in sg]
+        mn = np.zeros_like(sg) if ssm_mean is None else np.atleast_2d(np.asarray(ssm_mean, dtype=np.float64))
+        self.means = [row[: self.S] for row in mn]
+        # distr_n_samples (NN.cc:60-73): samples per distribution; default: equal shares, the remainder to the last one
+        k = len(self.sigmas)
+        if distr_n_samples is None:
+            distr_n_samples = [self.n // k] * k
+            distr_n_samples[-1] += self.n - sum(distr_n_samples)
+        assert sum(distr_n_samples) == self.n and len(distr_n_samples) == k
+        self.distr_n_samples = list(distr_n_samples)
+        self.seed = int(seed)
+        self.sigma = self.sigmas[0]
+        self.rng = np.random.default_rng(seed)     # (for callers that make their own perturbations)
         self.perturbations = None
         self.features = None
 
+    def feature_size(self):
+        return self.batch.nn_feature_size()
+
     def initialize(self, corners, perturbations=None):
+        """NN::initialize's dataset half (NT/NN.cc:85-113): template at `corners`, then generateDataset -> features (n, feat_size)"""
         b = self.batch
         b.set_corners(np.asarray(corners, dtype=np.float64).reshape(1, 2, 4))
         b.initialize_pix_vals()
-        if perturbations is None:    # ProjectiveBase::generatePerturbation: independent N(0, sigma_k) per component
-            perturbations = self.rng.normal(0.0, 1.0, size=(self.n, self.S)) * self.sigma
-        self.perturbations = np.ascontiguousarray(perturbations, dtype=np.float64).reshape(-1, self.S)
-        inv = np.stack([b.invert_state(q[None])[0] for q in self.perturbations])
-        base = np.repeat(b.get_state(), len(inv), axis=0)
-        states = ParticleFilter._compose(self, base, inv)       # curr_warp * inverse(perturbation)
-        self.features = b.sample_candidates(states)
+        perts, feats, lo = [], [], 0
+        for k, cnt in enumerate(self.distr_n_samples):
+            if cnt == 0:
+                continue
+            pin = None if perturbations is None else np.asarray(perturbations, dtype=np.float64).reshape(self.n, self.S)[lo:lo + cnt]
+            p, f = b.nn_dataset(cnt, self.sigmas[k], self.means[k], seed=self.seed + k, perturbations=pin)
+            perts.append(p); feats.append(f); lo += cnt
+        self.perturbations, self.features = np.concatenate(perts), np.concatenate(feats)
+        return self.features
+
+    def initialize_sharded(self, corners, group=None, device=None):
+        """the same with the rows block-partitioned over the ranks of `group` (torch.distributed; backend nccl = RCCL on the GPUs of a node, gloo
+        in the CPU tests' stand-in): rank r generates rows mtf_amd.dist.shard_bounds(n, r, world) into its slice of a device buffer and ONE
+        all-gather completes the matrix on every rank.  Single distribution.  -> torch tensor (n, feat_size) on `device`."""
+        import torch
+        import torch.distributed as tdist
+        from . import dist as mdist
+        world = tdist.get_world_size(group) if tdist.is_initialized() else 1
+        rank = tdist.get_rank(group) if tdist.is_initialized() else 0
+        b = self.batch
+        b.set_corners(np.asarray(corners, dtype=np.float64).reshape(1, 2, 4))
+        b.initialize_pix_vals()
+        F, n = self.feature_size(), self.n
+        lo, cnt, m = mdist.padded_shard(n, rank, world)       # rows per rank of the padded buffer (the filter's partition: ceil(n / world))
+        buf = torch.zeros((m * world, F), dtype=torch.float64, device=device)
+        d = b.nn_desc(n, self.sigmas[0], self.means[0], self.seed)
+        b.nn_dataset_dev(d, buf[rank * m:].data_ptr(), lo, cnt)
+        b.ctx.synchronize()
+        if world > 1:
+            tdist.all_gather_into_tensor(buf, buf[rank * m:(rank + 1) * m].clone(), group=group)
+        self.features = buf[:n]
         return self.features
 
     def nearest(self, feature):

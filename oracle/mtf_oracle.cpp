@@ -2443,6 +2443,56 @@ void mtfo_am_get(const mtfo_am *a, int what, double *dst) {
 	std::copy(v->begin(), v->end(), dst);
 }
 
+/* utils::bSpl3 Utilities/include/mtf/Utilities/histUtils.h:161-175 */
+static double bspl3_plain(double x) {
+	if ((x > -2) && (x <= -1)) { double temp = 2 + x; return (temp * temp * temp) / 6; }
+	else if ((x > -1) && (x <= 0)) return (4 - 3 * x * x * (2 + x)) / 6;
+	else if ((x > 0) && (x <= 1)) return (4 - 3 * x * x * (2 - x)) / 6;
+	else if ((x > 1) && (x < 2)) { double temp = 2 - x; return (temp * temp * temp) / 6; }
+	return 0;
+}
+/* am->getDistFeatSize(): SSDBase.h:116-125 / NCC.cc:530-537 patch_size; MI.cc:122 5 * patch_size */
+int mtfo_am_dist_feat_size(const mtfo_am *a) { return a->kind == MTFO_AM_MI ? 5 * a->n : a->n; }
+/* AM::updateDistFeat(double *feat_addr) from the current pixel values It */
+void mtfo_am_update_dist_feat(const mtfo_am *a, double *feat) {
+	const int n = a->n;
+	if (a->kind == MTFO_AM_SSD) {                 /* SSDBase.h:120-125: the patch itself */
+		for (int i = 0; i < n; ++i) feat[i] = a->It[i];
+	} else if (a->kind == MTFO_AM_NCC) {          /* NCC.cc:530-537: It - mean, then / norm */
+		double mean = 0;
+		for (int i = 0; i < n; ++i) mean += a->It[i];
+		mean /= n;
+		double sq = 0;
+		for (int i = 0; i < n; ++i) { feat[i] = a->It[i] - mean; sq += feat[i] * feat[i]; }
+		const double nrm = std::sqrt(sq);
+		for (int i = 0; i < n; ++i) feat[i] /= nrm;
+	} else {                                      /* MI.cc:736-747: row-major 5 x patch_size */
+		for (int i = 0; i < n; ++i) {
+			const int pix_val_floor = static_cast<int>(a->It[i]);
+			double pix_diff = std::max(0, pix_val_floor - 1) - a->It[i];   /* std_bspl_ids(floor, 0) = max(0, floor - 1), MI.cc:115 */
+			feat[i] = pix_val_floor;
+			feat[n + i] = bspl3_plain(pix_diff);
+			feat[2 * static_cast<size_t>(n) + i] = bspl3_plain(++pix_diff);
+			feat[3 * static_cast<size_t>(n) + i] = bspl3_plain(++pix_diff);
+			feat[4 * static_cast<size_t>(n) + i] = bspl3_plain(++pix_diff);
+		}
+	}
+}
+/* NN::generateDataset SM/src/NT/NN.cc:131-191 for given perturbations (generatePerturbation's draws are the caller's), compositional update:
+ * the SSM walks W <- W inverse(P_k), the row is taken, W <- W P_k -- as the reference does, rounding of the round trip included */
+void mtfo_nn_generate_dataset(mtfo_am *am, mtfo_ssm *ssm, const double *perturbations, int n_samples, double *dataset) {
+	const int S = ssm->S, F = mtfo_am_dist_feat_size(am);
+	vecd inv(S);
+	for (int sample_id = 0; sample_id < n_samples; ++sample_id) {
+		const double *pert = perturbations + static_cast<size_t>(sample_id) * S;
+		ssm->invert_state(inv.data(), pert);                         /* :153 */
+		ssm->compositional_update(inv.data());                       /* :154 */
+		am->update_pix_vals(ssm->curr_pts.data());                   /* :158 */
+		mtfo_am_update_dist_feat(am, dataset + static_cast<size_t>(sample_id) * F);   /* :159 */
+		ssm->compositional_update(pert);                             /* :183-187 */
+	}
+}
+
 mtfo_tracker *mtfo_tracker_create(int sm_kind, mtfo_am *am, mtfo_ssm *ssm, const mtfo_sm_params *params) {
 	return new mtfo_tracker(sm_kind, am, ssm, *params);
 }

@@ -145,6 +145,11 @@ void mtfo_am_cmpt_sum_of_hessians(mtfo_am *a, double *H,
 	const double *J0, const double *Jt, int S);
 /* what: 0 I0 1 It 2 dI0_dx(2N) 3 dIt_dx(2N) 4 df_dI0 5 df_dIt 6 d2I0_dx2(4N) 7 d2It_dx2(4N) */
 void mtfo_am_get(const mtfo_am *a, int what, double *dst);
+/* AM::getDistFeatSize / updateDistFeat (SSDBase.h:116-125, NCC.cc:530-537, MI.cc:122, 736-747) and NN::generateDataset (NT/NN.cc:131-191) for
+ * given perturbations (n_samples x S): dataset n_samples x feat_size */
+int mtfo_am_dist_feat_size(const mtfo_am *a);
+void mtfo_am_update_dist_feat(const mtfo_am *a, double *feat);
+void mtfo_nn_generate_dataset(mtfo_am *am, mtfo_ssm *ssm, const double *perturbations, int n_samples, double *dataset);
 
 /* ---- search methods (NT ESM / FCLK / ICLK) ---- */
 typedef struct mtfo_sm_params {

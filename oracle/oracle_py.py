@@ -613,6 +613,22 @@ class Grid:
         return self._get(4, self.ssm.S)
 
 
+def nn_generate_dataset(am, ssm, perturbations):
+    """NN::generateDataset (SM/src/NT/NN.cc:131-191) for given perturbations (n, S) -> dataset (n, feat_size)"""
+    p = np.ascontiguousarray(np.asarray(perturbations, dtype=np.float64).reshape(-1, ssm.S))
+    F = lib().mtfo_am_dist_feat_size(am.h)
+    out = np.empty((len(p), F))
+    lib().mtfo_nn_generate_dataset(am.h, ssm.h, _d(p), len(p), _d(out))
+    return out
+
+
+def am_dist_feat(am):
+    F = lib().mtfo_am_dist_feat_size(am.h)
+    out = np.empty(F)
+    lib().mtfo_am_update_dist_feat(am.h, _d(out))
+    return out
+
+
 def pf_score(am, ssm, states):
     states = np.ascontiguousarray(np.asarray(states, dtype=np.float64))
     n = states.shape[0]

@@ -317,7 +317,7 @@ def test_nn_dataset_generation(gpu_ctx, frame):
     gpu_ctx.set_image(frame)
     ds = NNDataset(gpu_ctx, am=L.AM_SSD, resx=40, resy=40, n_samples=300, seed=5)
     corners = synth.square_corners(250, 260, 90)
-    perts = ds.rng.normal(0, 1, size=(300, 8)) * ds.sigma
+    perts = np.random.default_rng(5).normal(0, 1, size=(300, 8)) * ds.sigma
     perts[0] = 0
     feats = ds.initialize(corners, perts)
     assert feats.shape == (300, 1600)
