@@ -1036,6 +1036,74 @@ def secondary_workload(args):
         pf.close()
         if comm is not None:
             comm.close()
+    elif args.workload == "nn":
+        # nt::NN's dataset generation (SM/src/NT/NN.cc:131-191): C perturbed samples of a 50 x 50 template -> the C x N feature matrix the
+        # index is built over, ONE launch (k_nn_dataset); rows block-partitioned over the ranks + one all-gather.  The one
+        # batch kernel of the path that is bound by what it WRITES: 8 N C bytes (SSD / NCC features; MI 40 N C).
+        import torch.distributed as tdist
+        from mtf_amd import dist as mdist
+        from mtf_amd.sm import NNDataset
+        frame0 = synth.make_frame(1024, 1024)
+        corners = synth.square_corners(512, 512, 100)
+        ctx.set_image(frame0)
+        C = args.samples
+        am_id = {"ssd": mtf_amd.AM_SSD, "ncc": mtf_amd.AM_NCC, "mi": mtf_amd.AM_MI}[args.nn_am]
+        am_kw = dict(mi_n_bins=args.mi_bins, mi_pou=args.mi_pou) if args.nn_am == "mi" else {}
+        sigma = (0.01, 0.01, 2.0, 0.01, 0.01, 2.0, 1e-5, 1e-5)
+        ds = NNDataset(ctx, am=am_id, ssm=mtf_amd.SSM_HOMOGRAPHY, resx=50, resy=50, n_samples=C, ssm_sigma=sigma, seed=synth.DEFAULT_SEED, am_params=am_kw)
+        b = ds.batch
+        b.set_corners(corners.reshape(1, 2, 4)); b.initialize_pix_vals()
+        F = ds.feature_size()
+        lo, cnt, m = mdist.padded_shard(C, rank, world)
+        buf = torch.zeros((m * world, F), dtype=torch.float64, device=dev)
+        perts = torch.zeros((C, 8), dtype=torch.float64, device=dev)
+        d = b.nn_desc(C, sigma, None, synth.DEFAULT_SEED)
+        mine = buf[rank * m:(rank + 1) * m]
+
+        def step():
+            b.nn_dataset_dev(d, mine.data_ptr(), lo, cnt, None, perts.data_ptr())
+            if world > 1:
+                ctx.synchronize()      # (the library's stream -> torch's: the collective reads the block)
+                tdist.all_gather_into_tensor(buf, mine)
+        dt = timed(step)
+        kernel_pass(step)
+        kms, kn = ctx.timing_get("nn_dataset")
+        row_bytes = 8.0 * F
+        gbs = row_bytes * cnt / (kms * 1e-3) / 1e9 if kms > 0 else None
+        out.update({"metric": "NN dataset samples/sec, %s features of a 50x50 Homography template, %d samples" % (args.nn_am.upper(), C),
+                    "value": C * args.steps / dt, "unit": "samples/s", "ms_per_step": dt / args.steps * 1e3, "scaling": "strong",
+                    "config": {"workload": "nt::NN::generateDataset: %d samples x %d feature entries (perturbation draw, invertState, compositionalUpdate, updatePixVals, "
+                                           "updateDistFeat) in one launch per rank, rows block-partitioned over %d rank(s)%s" %
+                                           (C, F, world, " + one all-gather" if world > 1 else ""),
+                               "kernel_us": kms * 1e3, "samples_per_rank": cnt, "feature_size": F, "dataset_bytes": row_bytes * C},
+                    "roofline": {"bound": "hbm", "note": "write-bound: 8 B x feature_size x samples streamed out with non-temporal stores; the template grid (16 B/px) and "
+                                 "the texels are re-read from L2 by every sample and not credited",
+                                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS if gbs else None,
+                                 "traffic": (pmc_secondary("nn", "k_nn_dataset") or {}).get("traffic_bytes_per_launch") if (C == 10000 and world == 1 and args.nn_am == "ssd") else None,
+                                 "traffic_note": getattr(pmc_secondary, "note", None),
+                                 "kernel": "k_nn_dataset", "avg_kernel_ms": kms, "launches_timed": kn, "algorithmic_bytes_per_launch": row_bytes * cnt,
+                                 "kernel_sources_sha": kernel_sources_sha()}})
+        if rank == 0 and not args.no_cpu:
+            import oracle_py as O
+            o_ssm = O.SSM(O.SSM_HOM, 50, 50)
+            o_am = O.AM({"ssd": O.AM_SSD, "ncc": O.AM_NCC, "mi": O.AM_MI}[args.nn_am], 50, 50, **({"n_bins": args.mi_bins, "pou": args.mi_pou} if args.nn_am == "mi" else {}))
+            o_am.set_curr_img(frame0); o_ssm.set_corners(corners); o_am.initialize_pix_vals(o_ssm.get("curr_pts"))
+            # parity in the same run: the first rows of this rank's block against the oracle's generateDataset on the perturbations the device drew
+            k = min(64, cnt)
+            torch.cuda.synchronize(dev)
+            p_host = perts[lo:lo + k].cpu().numpy()
+            want = O.nn_generate_dataset(o_am, o_ssm, p_host)
+            got = mine[:k].cpu().numpy()
+            err = float(np.abs(got - want).max())
+            out["parity"] = {"pass": bool(err <= 1e-9), "budget": 1e-9, "max_abs_feature_difference": err, "rows": k,
+                             "note": "device rows vs the oracle's NN::generateDataset on the device-drawn perturbations (pixel values 0..255)"}
+            n, t0 = 0, time.perf_counter()
+            chunk = rng.normal(size=(200, 8)) * np.asarray(sigma)
+            while time.perf_counter() - t0 < args.cpu_seconds:
+                O.nn_generate_dataset(o_am, o_ssm, chunk); n += len(chunk)
+            out["cpu_baseline"] = {"value": n / (time.perf_counter() - t0), "unit": "samples/s", "cores": 1, "kind": "port",
+                                   "sample": "%d samples of the oracle's generateDataset (50x50, same AM)" % n}
+        ds.batch.close()
     elif args.workload == "dropin":
         # the literal drop-in boundary: C++ mtf::nt::ESM / FCLK / ICLK driving mtf::hip::HipAM / HipSSM through the
         # reference's virtuals (one C-ABI call per virtual), ONE target -- configs 1 / 2 as an MTF user runs them
@@ -1169,9 +1237,11 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--pf-peer-child":
         return pf_peer_child(sys.argv[2:])
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="lk", choices=["lk", "grid", "pf", "mi", "dropin"],
+    ap.add_argument("--workload", default="lk", choices=["lk", "grid", "pf", "mi", "nn", "dropin"],
                     help="lk = the headline metric (default); the others are the secondary metrics of BASELINE.md")
     ap.add_argument("--particles", type=int, default=10000)
+    ap.add_argument("--samples", type=int, default=10000, help="nn workload: dataset samples (the shipped Config/modules.cfg nn_n_samples: 1000 .. 100 000 in use)")
+    ap.add_argument("--nn-am", default="ssd", choices=["ssd", "ncc", "mi"], help="nn workload: appearance model whose updateDistFeat fills the rows")
     ap.add_argument("--pf-iters", type=int, default=1, help="pf workload: iterations per update() call (epsilon < 0: enqueued back to back)")
     ap.add_argument("--grid-iters", type=int, default=10)
     ap.add_argument("--gpus", type=int, default=1)
