@@ -1772,8 +1772,29 @@ int mtfhip_nn_dataset_dev(mtfhip_batch *b, const mtfhip_nn_desc *d, const double
 	a.seed = d->seed;
 	std::memcpy(a.base, b->th[0].warp.m, sizeof(a.base));
 	a.row_lo = row_lo; a.norm_mult = b->norm_mult; a.norm_add = b->norm_add;
+	/* the template grid's own corners, as the candidate scorer takes them: a sample whose warped hull is inside the frame skips the border test */
+	double hull_buf[8];
+	const double *hull = nullptr;
+	if (b->unit_z && b->grid_from_corners) {
+		const double *ic = b->th[0].init_corners_hm;
+		bool unit = true;
+		for (int q = 0; q < 4; ++q) { hull_buf[2 * q] = ic[3 * q]; hull_buf[2 * q + 1] = ic[3 * q + 1]; unit = unit && ic[3 * q + 2] == 1.0; }
+		if (unit) hull = hull_buf;
+	}
+	/* tolerance mode: the samples' warps go through a scratch array (k_nn_warps -> k_nn_rows), grown to the largest launch so far */
+	double *warps = nullptr;
+	if (nn_two_launch_ok(b->view_raw(), b->ctx->img, b->math_mode == MTFHIP_MATH_FAST)) {
+		const size_t need = nn_warps_bytes(row_count);
+		if (need > b->nn_warps_cap) {
+			HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+			if (b->d_nn_warps) { (void)hipFree(b->d_nn_warps); b->d_nn_warps = nullptr; b->nn_warps_cap = 0; }
+			HIP_TRY(hipMalloc(&b->d_nn_warps, need));
+			b->nn_warps_cap = need;
+		}
+		warps = b->d_nn_warps;
+	}
 	TimedScope ts(b->ctx, "nn_dataset");
-	launch_nn_dataset(b->view_raw(), b->ctx->img, a, row_count, dev_features, b->ctx->stream);
+	launch_nn_dataset(b->view_raw(), b->ctx->img, a, row_count, dev_features, warps, hull, b->ctx->stream);
 	return MTFHIP_OK;
 }
 int mtfhip_nn_dataset(mtfhip_batch *b, const mtfhip_nn_desc *d, const double *perturbations_in, double *perturbations_out, double *features) {

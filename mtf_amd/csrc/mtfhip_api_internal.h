@@ -252,6 +252,7 @@ struct mtfhip_batch {
 	bool pts_stale = false;
 	double *d_it_shadow = nullptr;
 	double *d_ncc_tm = nullptr;   /* [B][52] NCC template moments for the device-side finish */
+	double *d_nn_warps = nullptr; size_t nn_warps_cap = 0;   /* NN dataset, tolerance mode: the samples' warps between k_nn_warps and k_nn_rows */
 	double *d_lm = nullptr;       /* [B][kLmStride] Levenberg-Marquardt state of the device-side loop */
 	double *d_trace = nullptr; int trace_cap = 0;   /* [B][trace_cap][kTraceStride] debug trace of the device-side loop, or NULL */
 	/* NCC: a fused iteration updated the scalars (It_mean, a, b, f) on the host only; the un-fused kernels read d_ncc */

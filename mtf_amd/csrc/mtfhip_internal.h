@@ -486,7 +486,9 @@ struct NnArgs {
 	int row_lo;               /* global index of the launch's first sample (row sharding: draws are keyed by the global index) */
 	double norm_mult, norm_add;
 };
-void launch_nn_dataset(const BatchView &bv, const ImgView &im, const NnArgs &a, int count, double *feat, hipStream_t st);
+void launch_nn_dataset(const BatchView &bv, const ImgView &im, const NnArgs &a, int count, double *feat, double *warps, const double *hull, hipStream_t st);
+size_t nn_warps_bytes(int count);
+bool nn_two_launch_ok(const BatchView &bv, const ImgView &im, int fast_math);
 void launch_sample_candidates(const BatchView &bv, const ImgView &im, const double *dev_states, int C, double norm_mult,
 	double norm_add, double *dev_feat, hipStream_t st);
 /* whole ICLK loop in one launch, one workgroup per target (N <= 16 * kBlock); false if N is too large */

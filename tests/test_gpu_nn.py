@@ -107,10 +107,48 @@ def test_nn_dataset_device_draws_and_row_blocks(gpu_ctx, frame):
         b.nn_dataset_dev(d, buf[lo:].data_ptr(), lo, cnt)
     gpu_ctx.synchronize()
     assert np.array_equal(buf.cpu().numpy(), f1)
-    # zero sigma: every sample is the template
+    # zero sigma: every sample is the template -- to rounding in tolerance mode (k_nn_rows: reciprocal + factored interpolant), bit
+    # for bit in the reference's operation order
+    _, f0 = b.nn_dataset(16, np.zeros(8), None, seed=3)
+    np.testing.assert_allclose(f0, np.repeat(b.read(L.BUF_I0), 16, axis=0), rtol=0, atol=1e-11)
+    b.set_math_mode(mtf_amd.MATH_REPLAY)
     _, f0 = b.nn_dataset(16, np.zeros(8), None, seed=3)
     assert np.array_equal(f0, np.repeat(b.read(L.BUF_I0), 16, axis=0))
     b.close()
+
+
+@pytest.mark.parametrize("ssm", [L.SSM_HOMOGRAPHY, L.SSM_AFFINE], ids=["hom", "aff"])
+@pytest.mark.parametrize("am,am_kw", [(L.AM_SSD, {}), (L.AM_NCC, {}), (L.AM_MI, dict(mi_n_bins=10, mi_pou=1))], ids=["ssd", "ncc", "mi10pou"])
+@pytest.mark.parametrize("where", ["inside", "border"])
+def test_nn_two_launch_form_equals_workgroup_form(gpu_ctx, frame, am, am_kw, ssm, where):
+    """tolerance mode's two launches (k_nn_warps: a thread per sample forms its warp; k_nn_rows: a workgroup per sample, a quarter row per wave)
+    against the workgroup-per-sample form in the reference's operation order (MATH_REPLAY): the same perturbations bit for bit (one sampler), rows to 1e-9 of a pixel value -- for templates whose samples
+    stay inside the frame (no border test at all) and for ones that cross it (border value 128, mixed waves)"""
+    gpu_ctx.set_image(frame)
+    res, n = 50, 333                   # (2500 entries: 19.5 pair-rounds of 128 -- a ragged last round and an idle tail in the last wave; 333 samples: a ragged last block of k_nn_warps)
+    h, w = frame.shape[:2]
+    corners = synth.square_corners(w / 2, h / 2, 100) if where == "inside" else synth.square_corners(w - 40.0, 35.0, 100)
+    S = 8 if ssm == L.SSM_HOMOGRAPHY else 6
+    sigma = (SIGMA_H if S == 8 else SIGMA_A) * 2.0
+    rows = {}
+    for mode in (mtf_amd.MATH_FAST, mtf_amd.MATH_REPLAY):
+        b = mtf_amd.Batch(gpu_ctx, am, ssm, res, res, 1, **am_kw)
+        b.set_math_mode(mode)
+        b.set_corners(corners[None]); b.initialize_pix_vals()
+        rows[mode] = b.nn_dataset(n, sigma, None, seed=5)
+        b.close()
+    (pf, ff), (pr, fr) = rows[mtf_amd.MATH_FAST], rows[mtf_amd.MATH_REPLAY]
+    assert np.array_equal(pf, pr)
+    N = res * res
+    if where == "border" and am == L.AM_SSD:
+        assert (fr == 128.0).mean() > 0.05          # samples did leave the frame (border value 128)
+    if am == L.AM_MI:
+        keep = (ff[:, :N] == fr[:, :N])             # floor(It): a value within rounding of an integer may land on either side
+        assert (~keep).mean() < 1e-6
+        d = np.abs(ff[:, N:].reshape(n, 4, N) - fr[:, N:].reshape(n, 4, N)).max(axis=1)
+        assert d[keep].max() < 1e-9
+    else:
+        np.testing.assert_allclose(ff, fr, rtol=0, atol=1e-9 if am == L.AM_SSD else 1e-12)
 
 
 def test_nn_dataset_full_size_properties_and_refusals(gpu_ctx, frame):

@@ -9,7 +9,7 @@ mkdir -p "$out"
 i=0
 for grp in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d "$out/p$i" -o pmc -- python bench.py $args --no-cpu > "$out/p$i.log" 2>&1
+  timeout 150 rocprofv3 --pmc $grp --output-format csv -d "$out/p$i" -o pmc -- python bench.py $args --no-cpu > "$out/p$i.log" 2>&1
 done
 python tools/pmc_summary.py "$out" > "$out/summary.txt"
 cat "$out/summary.txt"

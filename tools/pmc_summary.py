@@ -13,7 +13,7 @@ for f in sorted(glob.glob(root + "/p*/*counter_collection.csv")):
         agg[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
 kernels = sorted({k[0] for k in agg})
 for kn in kernels:
-    if not any(s in kn for s in ("fused", "score", "finish_track", "ncc", "mi_", "pf_", "iclk", "persist")):
+    if not any(s in kn for s in ("fused", "score", "finish_track", "ncc", "mi_", "pf_", "iclk", "persist", "k_nn_", "template_init", "grid_fb")):
         continue
     print(kn)
     for (k, c), v in sorted(agg.items()):
