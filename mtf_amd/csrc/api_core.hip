@@ -442,9 +442,10 @@ void mtfhip_batch_destroy(mtfhip_batch *b) {
 			if (b->buf[i]) (void)hipFree(b->buf[i]);
 		void *ptrs[] = {b->d_slab, b->d_partials, b->d_acc, b->d_scratch_pts, b->d_h0,
 			b->d_cand, b->d_colmean, b->d_mi_tb, b->d_mi_part,
-			b->d_mi_f, b->d_mi_H, b->d_h0inv, b->d_d2_part, b->d_d2_out, b->d_d2_w, b->d_it_shadow, b->d_ncc_tm, b->d_mi_red, b->d_lm, b->d_persist, b->d_trace, b->d_cand_mi, b->d_mi_poly, b->d_nn_warps};
+			b->d_mi_f, b->d_mi_H, b->d_h0inv, b->d_d2_part, b->d_d2_out, b->d_d2_w, b->d_it_shadow, b->d_ncc_tm, b->d_mi_red, b->d_lm, b->d_persist, b->d_trace, b->d_cand_mi, b->d_mi_poly, b->d_nn_warps, b->d_fb};
 		for (void *p : ptrs)
 			if (p) (void)hipFree(p);
+		if (b->h_fb) (void)hipHostFree(b->h_fb);
 		if (b->h_init_rec) (void)hipHostFree(b->h_init_rec);
 		if (b->h_init_flag) (void)hipHostFree(b->h_init_flag);
 		if (b->h_acc) (void)hipHostFree(b->h_acc);

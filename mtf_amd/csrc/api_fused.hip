@@ -1217,12 +1217,44 @@ int mtfhip_grid_frame_fb(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip
 	TRY(grid_batch_ok(b, g, "grid_frame_fb"));
 	static thread_local std::vector<float> cen;
 	cen.resize(2 * (size_t)b->B);
+	static const bool always_restore = std::getenv("MTFHIP_GRID_FB_RESTORE") && std::getenv("MTFHIP_GRID_FB_RESTORE")[0] == '1';
+	/* The shipped configuration (reset_at_each_frame 1, fb_reinit 1; Config/modules.cfg:80-82) in ONE launch: k_grid_fb runs a patch's update(), its
+	 * initialize(tracker_location) and its update() on the previous frame back to back in the patch's workgroup and leaves the trackers as the
+	 * forward pass left them -- the caller's resetTrackers(reinit) (:273-274) re-initialises them next.  Tolerance mode, ICLK with a constant
+	 * Hessian over SSD / NCC, an affine patch SSM (a tracked patch stays a parallelogram: a unit-z lattice), <= 1024 pixels.  MTFHIP_GRID_FB_FUSED=0:
+	 * the three launches. */
+	{
+		const char *e_ff = std::getenv("MTFHIP_GRID_FB_FUSED");   /* (read per call: the tests compare the two forms in one process) */
+		mtfhip_ctx *c = b->ctx;
+		const bool fused = !(e_ff && e_ff[0] == '0') && !region && fb->fb_reinit && g->reset_at_each_frame == 1 && !always_restore &&
+			b->math_mode == MTFHIP_MATH_FAST && b->desc.ssm == MTFHIP_SSM_AFFINE && template_init_fused_ok(b, sm) && iclk_one_launch(b, sm) && !sm->leven_marq &&
+			second_order_term(sm, b->desc.am) < 0 && b->N <= 4 * kBlock && b->h_pub_dev && !b->d_trace && b->init_pix_vals &&
+			(b->desc.am != MTFHIP_AM_NCC || b->d_ncc_tm) && c->prev.data && c->img.data && c->prev.h == c->img.h && c->prev.w == c->img.w &&
+			c->prev.channels == c->img.channels;
+		if (fused) {
+			const size_t B = (size_t)b->B;
+			if (!b->h_fb) {
+				HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_fb), sizeof(double) * 9 * B, hipHostMallocMapped));
+				HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&b->h_fb_dev), b->h_fb, 0));
+				HIP_TRY(hipMalloc(&b->d_fb, sizeof(double) * 9 * B));
+			}
+			b->fb_fused_req = true;
+			const int rc = mtfhip_grid_frame(b, sm, g, nullptr, n_iters, corners, cen.data());
+			b->fb_fused_req = false;
+			if (rc != MTFHIP_OK) return rc;
+			if (centroids) std::memcpy(centroids, cen.data(), sizeof(float) * cen.size());
+			for (size_t t = 0; t < B; ++t) {
+				if (b->h_fb[9 * t + 8] < 0) return fail(MTFHIP_ERR_INVALID_ARG, "grid_frame_fb: degenerate tracked corners for patch %d", (int)t);
+				centroid_f(fb_prev_pts + 2 * t, b->h_fb + 9 * t);                                        /* getCentroid(fb_prev_pts[id], getRegion()) :302 */
+			}
+			return mtfhip_grid_fb_mask(b->B, prev_pts, cen.data(), fb_prev_pts, fb, fb_err_mask, prev_masked, curr_masked, n_masked);
+		}
+	}
 	TRY(mtfhip_grid_frame(b, sm, g, region, n_iters, corners, cen.data()));
 	if (centroids) std::memcpy(centroids, cen.data(), sizeof(float) * cen.size());
 	/* GridTracker::update goes on to resetTrackers when reset_at_each_frame != 0 (:273-274): every patch tracker is then initialize()d or
 	 * setRegion()ed on the new grid, which replaces all that setRegion(tracker_location) (:305) would leave -- the SSM's state; with fb_reinit
 	 * the template is the backward pass's either way -- so that call is left out here (MTFHIP_GRID_FB_RESTORE=1 keeps it) */
-	static const bool always_restore = std::getenv("MTFHIP_GRID_FB_RESTORE") && std::getenv("MTFHIP_GRID_FB_RESTORE")[0] == '1';
 	TRY(grid_backward_impl(b, sm, g, fb, nullptr, nullptr, fb_prev_pts, always_restore || g->reset_at_each_frame == 0));
 	return mtfhip_grid_fb_mask(b->B, prev_pts, cen.data(), fb_prev_pts, fb, fb_err_mask, prev_masked, curr_masked, n_masked);
 }
@@ -1376,7 +1408,8 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 			if (all_converged(b->d_active, b->B, it)) break;
 		}
 	} else if (one_launch) {
-		TimedScope tsc(b->ctx, "iclk_track");
+		const bool fb_fused = b->fb_fused_req;   /* (mtfhip_grid_frame_fb: the frame's three per-patch steps in one launch, k_grid_fb) */
+		TimedScope tsc(b->ctx, fb_fused ? "grid_fb" : "iclk_track");
 		HostPublish pub{nullptr, 0, 0, nullptr, nullptr, 0, 0};
 		if (b->h_pub_dev) {
 			pub_seq = ++b->acc_seq;
@@ -1401,6 +1434,16 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 		}
 		const bool dbg_t = g_track_dbg_timing;
 		if (dbg_t) g_track_dbg_t[0] = std::chrono::steady_clock::now();
+		if (fb_fused) {
+			if (region_mode || !pub.host) return fail(MTFHIP_ERR_LOGIC, "track: the one-launch forward-backward frame takes the plain mode with a host record");
+			const bool homg = b->desc.ssm == MTFHIP_SSM_HOMOGRAPHY;
+			RegionIngest geo{};   /* (the template lattice's geometry: what grid_reinit_fused hands k_template_init) */
+			geo.lo_x = homg ? -0.5 : 1 - b->desc.resx / 2.0; geo.lo_y = homg ? -0.5 : 1 - b->desc.resy / 2.0;
+			geo.hi_x = homg ? 0.5 : b->desc.resx / 2.0; geo.hi_y = homg ? 0.5 : b->desc.resy / 2.0;
+			geo.resx = b->desc.resx; geo.resy = b->desc.resy; geo.force_unit_z = homg ? 0 : 1;
+			if (!launch_grid_fb(bv, b->ctx->img, b->ctx->prev, *sm, ts, b->d_h0inv, b->d_ncc, b->norm_mult, b->norm_add, b->desc.grad_eps, pub, GridFbOut{b->h_fb_dev, b->d_fb}, geo, st))
+				return fail(MTFHIP_ERR_LOGIC, "track: patch too large for the one-launch forward-backward frame");
+		} else
 		launch_iclk_track(bv, b->ctx->img, *sm, ts, b->d_h0inv, b->d_ncc, b->norm_mult, b->norm_add, b->math_mode == MTFHIP_MATH_FAST, pub, rg, st);
 		if (dbg_t) g_track_dbg_t[1] = std::chrono::steady_clock::now();
 		set_corners_finish_deferred(b);   /* the host half of a deferred reset, under the kernel */

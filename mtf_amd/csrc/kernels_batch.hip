@@ -4,92 +4,13 @@
  * (one of the translation units of libmtfhip.so; conventions and the shared device helpers: mtfhip_device.h)
  */
 #include "mtfhip_device.h"
+#include "mtfhip_grid_device.h"
 
 namespace mtfhip {
 
 /* ===================================================================== */
 /* one-launch inverse-compositional tracker for small patches (GridTracker) */
 /* ===================================================================== */
-/* sum of K per-thread values over the workgroup, result broadcast to every thread */
-template <int K>
-__device__ __forceinline__ void block_allsum(double *v, double *lds /* [4][K] */) {
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-	for (int k = 0; k < K; ++k)
-#pragma unroll
-		for (int m = 32; m >= 1; m >>= 1) v[k] += __shfl_xor(v[k], m);
-	__syncthreads();   /* previous round's readers are done with lds */
-	if (lane == 0) {
-#pragma unroll
-		for (int k = 0; k < K; ++k) lds[wave * K + k] = v[k];
-	}
-	__syncthreads();
-#pragma unroll
-	for (int k = 0; k < K; ++k) v[k] = (lds[k] + lds[K + k]) + (lds[2 * K + k] + lds[3 * K + k]);
-}
-
-/* the same with DPP wave sums (wave_sum_dpp): for loops whose critical path is this reduction */
-template <int K>
-__device__ __forceinline__ void block_allsum_dpp(double *v, double *lds /* [4][K] */) {
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-	for (int k = 0; k < K; ++k) v[k] = wave_sum_dpp(v[k]);
-	__syncthreads();   /* previous round's readers are done with lds */
-	if (lane == 0) {
-#pragma unroll
-		for (int k = 0; k < K; ++k) lds[wave * K + k] = v[k];
-	}
-	__syncthreads();
-#pragma unroll
-	for (int k = 0; k < K; ++k) v[k] = (lds[k] + lds[K + k]) + (lds[2 * K + k] + lds[3 * K + k]);
-}
-
-/* Twelve sums at once, by halving: the two cross-row levels of the wave are exchanges of register halves between lanes
- * (v_permlane32_swap / v_permlane16_swap, gfx950) -- after the first every lane carries six of the twelve, after the second three --
- * and only those three go through the four in-row DPP steps.  63 VALU instructions per wave instead of the 12 x 18 of one wave_sum_dpp
- * per value, on a loop whose critical path is this reduction (k_iclk_track: one wave per SIMD, an FP64 instruction every ~7 cycles).
- * Row r of a wave ends with the wave totals of indices (r >= 2 ? 6 : 0) + (r & 1 ? 3 : 0) + {0, 1, 2} in every lane. */
-__device__ __forceinline__ double swap_add32(double a, double b) {   /* lanes 0..31: a[l] + a[l + 32]; lanes 32..63: b[l - 32] + b[l] */
-	const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
-	const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
-	return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-}
-__device__ __forceinline__ double swap_add16(double a, double b) {   /* even rows: a[row] + a[row + 1]; odd rows: b[row - 1] + b[row] */
-	const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
-	const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
-	return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-}
-__device__ __forceinline__ double row_sum_dpp(double x) {   /* the sum over the lane's row of 16, in every lane of the row */
-#define MTFHIP_ROW_STEP(CTRL) { \
-		const int tl = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false), th = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false); \
-		x += __hiloint2double(th, tl); }
-	MTFHIP_ROW_STEP(0xB1) MTFHIP_ROW_STEP(0x4E) MTFHIP_ROW_STEP(0x141) MTFHIP_ROW_STEP(0x140)   /* quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror */
-#undef MTFHIP_ROW_STEP
-	return x;
-}
-/* v[0..12) summed over the workgroup, every thread gets every total.  lds: [4][12], a buffer the caller ALTERNATES between
- * consecutive calls (the readers of one round are then separated from the next writers of the same buffer by the round in between:
- * one barrier per call).  The four waves' totals are combined by lanes 0..11 (one index each) and handed to everybody through the
- * scalar unit: 4 LDS reads + 3 additions + 24 v_readlane instead of 48 broadcast reads + 36 additions per thread. */
-__device__ __forceinline__ void block_allsum_h12(double *v, double *lds) {
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	double h6[6], h3[3];
-#pragma unroll
-	for (int j = 0; j < 6; ++j) h6[j] = swap_add32(v[j], v[j + 6]);
-#pragma unroll
-	for (int j = 0; j < 3; ++j) h3[j] = row_sum_dpp(swap_add16(h6[j], h6[j + 3]));
-	if ((lane & 15) == 0) {
-		const int base = wave * 12 + ((lane & 32) ? 6 : 0) + ((lane & 16) ? 3 : 0);
-#pragma unroll
-		for (int j = 0; j < 3; ++j) lds[base + j] = h3[j];
-	}
-	__syncthreads();
-	const int k = lane < 12 ? lane : 0;
-	const double mine = (lds[k] + lds[12 + k]) + (lds[24 + k] + lds[36 + k]);
-#pragma unroll
-	for (int q = 0; q < 12; ++q) v[q] = readlane_f64(mine, q);
-}
-
 /* NN-SM dataset generation (SM/src/NT/NN.cc:131-191): per sample state, setState -> updatePixVals ->
  * updateDistFeat into row `c` of the n_samples x N feature matrix.  SSD's feature is the patch itself
  * (AM/include/mtf/AM/SSDBase.h:116-125); NCC's is the centred patch over its norm (AM/src/NCC.cc:530-537),
@@ -162,47 +83,6 @@ __device__ __forceinline__ double pix_val_select(const ImgView &im, double x, do
 	const double t00 = r0[lx], t01 = r0[uxc], t10 = r1[lx], t11 = r1[uxc];
 	const double v = t00 * (1 - dx) * (1 - dy) + t01 * dx * (1 - dy) + t10 * (1 - dx) * dy + t11 * dx * dy;
 	return (in0 && in1) ? v : 128.0;
-}
-
-/* the tail of k_iclk_track: target t's final warp / state / corners / iteration count go to the host mirror of the slab, and the
- * last workgroup of the launch releases the host (one kernel launch and its gap less per frame than k_publish_host).
- * Called by wave 0 only, lane q holding entry q: the stores are system-scope (write-through to the pinned page), ONE agent-scope
- * release per workgroup orders them before the counter -- a system-scope fence in every wave of every workgroup walks the L2
- * for dirty lines 1024 times and cost 25 us of a 47 us launch -- and (fenced form) only the last arriver pays the system-scope release
- * before it raises the flag. */
-__device__ __forceinline__ void publish_target(const HostPublish &pub, int t, double wq, double sq, double cq, int n_it) {
-	const int lane = threadIdx.x;
-	double *p = reinterpret_cast<double *>(pub.host);
-	const size_t Bt = (size_t)pub.B;
-	if (lane < 9) __hip_atomic_store(p + 9 * (size_t)t + lane, wq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-	if (lane < 8) {
-		__hip_atomic_store(p + 9 * Bt + 8 * (size_t)t + lane, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-		__hip_atomic_store(p + 17 * Bt + 8 * (size_t)t + lane, cq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-	}
-	if (lane == 0) __hip_atomic_store(reinterpret_cast<int *>(pub.host + pub.dbl_bytes) + Bt + t, n_it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-	/* Default: the stores above are write-through (system scope): when the wave's vmcnt has drained they are performed, which is all
-	 * the counter has to order -- an agent-scope release here and an acq_rel on the counter wrote this XCD's L2 back twice and
-	 * invalidated it once per workgroup (the launch has just laid 6 MB of template grids into the L2s): ~3 of the 7 us between the last
-	 * iteration and the end of the workgroup, r04 phase trace.  The counter itself is an agent-scope atomic: performed at the memory
-	 * side.  pub.fenced (MTFHIP_PUBLISH_FENCE=1, publish_fenced()): the release / acq_rel / system-release form the memory model asks for. */
-	if (pub.fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   /* (the whole wave's stores: s_waitcnt vmcnt(0) is per wave) */
-	else wait_stores_acked();
-	if (lane == 0) {
-		const int done = pub.fenced ? __hip_atomic_fetch_add(pub.count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
-		                            : __hip_atomic_fetch_add(pub.count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (done == (int)gridDim.x - 1) {
-			__hip_atomic_store(pub.count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			/* Every workgroup's results left as system-scope (write-through) stores that were acknowledged before it counted itself in,
-			 * and this one has read the counter they all bumped (a RELAXED read-modify-write at the memory side, not an acquire): the
-			 * stores are performed, and the flag -- one more posted write of the same device -- cannot pass them on the link.  A
-			 * system-scope RELEASE here (r03: __threadfence_system + a release store) writes back the whole L2 twice -- since r04 that
-			 * includes the 6 MB of template grids the same launch laid out -- for nothing the host reads: 2.5 us of a 50 us frame. */
-			if (pub.fenced) {
-				__threadfence_system();
-				__hip_atomic_store(pub.flag, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-			} else __hip_atomic_store(pub.flag, pub.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-		}
-	}
 }
 
 #ifdef MTFHIP_GRID_TRACE   /* tools/grid_trace.sh: wall-clock stamps (100 MHz) of one workgroup's phases */

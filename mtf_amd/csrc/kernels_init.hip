@@ -18,60 +18,9 @@
  * agree to rounding (tests/test_gpu_grid.py::test_fused_template_init_equals_call_by_call).
  */
 #include "mtfhip_device.h"
+#include "mtfhip_grid_device.h"
 
 namespace mtfhip {
-
-template <int K>
-__device__ __forceinline__ void init_allsum(double *v, double *lds /* [4][K] */) {
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-	for (int k = 0; k < K; ++k) v[k] = wave_sum_dpp(v[k]);
-	__syncthreads();   /* previous round's readers are done with lds */
-	if (lane == 0) {
-#pragma unroll
-		for (int k = 0; k < K; ++k) lds[wave * K + k] = v[k];
-	}
-	__syncthreads();
-#pragma unroll
-	for (int k = 0; k < K; ++k) v[k] = (lds[k] + lds[K + k]) + (lds[2 * K + k] + lds[3 * K + k]);
-}
-
-/* H (S x S column-major, packed) -> its inverse, or zeros when a pivot vanishes (a flat template: no update, as invert_definite on the
- * host).  One wave: lane (i, j) = (lane >> 3, lane & 7) owns A[i][j] and A[i][8 + j] of the augmented matrix in LDS; diagonal
- * equilibration and partial pivoting as the host routine.  a: [8][17] doubles. */
-__device__ __forceinline__ void invert_definite_wave(int S, const double *Hs /* LDS, packed S x S */, double *a, double *out /* global, packed */) {
-	const int lane = threadIdx.x & 63, i = lane >> 3, j = lane & 7;
-	constexpr int LD = 17;
-	const bool in = i < S && j < S;
-	const double di = i < S ? fabs(Hs[i * S + i]) : 1.0, dj = j < S ? fabs(Hs[j * S + j]) : 1.0;
-	const double sci = di > 0 ? 1.0 / sqrt(di) : 1.0, scj = dj > 0 ? 1.0 / sqrt(dj) : 1.0;
-	a[i * LD + j] = in ? Hs[j * S + i] * sci * scj : (i == j ? 1.0 : 0.0);
-	a[i * LD + 8 + j] = i == j ? 1.0 : 0.0;
-	__builtin_amdgcn_wave_barrier();
-	bool singular = false;
-	for (int k = 0; k < S; ++k) {
-		/* pivot row: the largest |A[r][k]|, r >= k (every lane walks the <= 8 candidates: same result everywhere) */
-		int piv = k; double best = fabs(a[k * LD + k]);
-		for (int r = k + 1; r < S; ++r) { const double v = fabs(a[r * LD + k]); if (v > best) { best = v; piv = r; } }
-		if (best == 0) { singular = true; break; }
-		__builtin_amdgcn_wave_barrier();
-		if (piv != k && i == 0) {   /* lanes 0..7 swap both halves of the two rows */
-			const double t0 = a[piv * LD + j], t1 = a[piv * LD + 8 + j];
-			a[piv * LD + j] = a[k * LD + j]; a[piv * LD + 8 + j] = a[k * LD + 8 + j];
-			a[k * LD + j] = t0; a[k * LD + 8 + j] = t1;
-		}
-		__builtin_amdgcn_wave_barrier();
-		const double p = a[k * LD + k];
-		__builtin_amdgcn_wave_barrier();
-		if (i == 0) { a[k * LD + j] /= p; a[k * LD + 8 + j] /= p; }
-		__builtin_amdgcn_wave_barrier();
-		const double f = a[i * LD + k], r0 = a[k * LD + j], r1 = a[k * LD + 8 + j];
-		__builtin_amdgcn_wave_barrier();
-		if (i != k && f != 0) { a[i * LD + j] -= f * r0; a[i * LD + 8 + j] -= f * r1; }
-		__builtin_amdgcn_wave_barrier();
-	}
-	if (in) out[j * S + i] = singular ? 0.0 : a[i * LD + 8 + j] * sci * scj;
-}
 
 template <int AM, int PPT>
 __global__ __launch_bounds__(kBlock) void k_template_init(BatchView bv, ImgView im, double grad_eps, double norm_mult, double norm_add,

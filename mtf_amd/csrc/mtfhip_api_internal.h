@@ -252,6 +252,9 @@ struct mtfhip_batch {
 	bool pts_stale = false;
 	double *d_it_shadow = nullptr;
 	double *d_ncc_tm = nullptr;   /* [B][52] NCC template moments for the device-side finish */
+	/* the one-launch forward-backward frame (k_grid_fb): requested by mtfhip_grid_frame_fb around its track call */
+	bool fb_fused_req = false;
+	double *h_fb = nullptr, *h_fb_dev = nullptr, *d_fb = nullptr;   /* [B][9] the backward pass's corners | iteration count: pinned host copy, device copy */
 	double *d_nn_warps = nullptr; size_t nn_warps_cap = 0;   /* NN dataset, tolerance mode: the samples' warps between k_nn_warps and k_nn_rows */
 	double *d_lm = nullptr;       /* [B][kLmStride] Levenberg-Marquardt state of the device-side loop */
 	double *d_trace = nullptr; int trace_cap = 0;   /* [B][trace_cap][kTraceStride] debug trace of the device-side loop, or NULL */

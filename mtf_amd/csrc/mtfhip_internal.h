@@ -493,6 +493,11 @@ void launch_sample_candidates(const BatchView &bv, const ImgView &im, const doub
 	double norm_add, double *dev_feat, hipStream_t st);
 /* whole ICLK loop in one launch, one workgroup per target (N <= 16 * kBlock); false if N is too large */
 constexpr int kIclkTrackMaxPix = 8 * kBlock;   /* (the grid points of a thread's pixels stay in registers: k_iclk_track) */
+/* k_grid_fb (kernels_grid_fb.hip): a frame's forward pass, the re-initialisation at the tracked location and the backward pass on the
+ * previous frame in one launch; per patch the backward pass leaves 8 corners + its iteration count (-1: degenerate tracked corners) */
+struct GridFbOut { double *host; double *dev; };   /* [B][9] each: device-visible pinned memory | device memory (either may be NULL) */
+bool launch_grid_fb(const BatchView &bv, const ImgView &im, const ImgView &imp, const mtfhip_sm_desc &sm, const TrackState &ts, const double *h0inv,
+	const double *ncc_sc, double norm_mult, double norm_add, double grad_eps, const HostPublish &pub, const GridFbOut &fo, const RegionIngest &rg, hipStream_t st);
 bool launch_iclk_track(const BatchView &bv, const ImgView &im, const mtfhip_sm_desc &sm, const TrackState &ts,
 	const double *h0inv, const double *ncc_sc, double norm_mult, double norm_add, int fast_math, const HostPublish &pub, const RegionIngest &rg, hipStream_t st);
 /* skip_off / skip_len (multiples of 16 bytes): a section that is left as it is on the device */

@@ -477,3 +477,43 @@ def test_grid_template_init_and_first_iteration_against_the_oracles_trackers(ora
     parity_record.append(dict(test="grid_template_init_and_first_iteration", am=int(am), ssm=int(ssm), patch=ps, **worst))
     b.track_trace(0)
     b.close()
+
+
+@pytest.mark.parametrize("ps", [16, 25, 32])
+@pytest.mark.parametrize("am", [L.AM_NCC, L.AM_SSD], ids=["ncc", "ssd"])
+def test_grid_fb_one_launch_equals_three(frame, am, ps, monkeypatch):
+    """the shipped configuration's frame (reset_at_each_frame 1, fb_err_thresh 2, fb_reinit 1) as ONE launch (k_grid_fb: a patch's update(),
+    initialize(tracker_location) and update() on the previous frame in its workgroup) against the three launches with two host waits
+    (k_iclk_track, k_template_init, k_iclk_track; MTFHIP_GRID_FB_FUSED=0): the same expressions in the same order, so the same bits --
+    iteration counts, patch regions, centroids, fb_prev_pts, the mask, the fitted update and the grid's region -- over four frames, the
+    third of them with a spoiled patch (a backward pass that does not come home).  1, 3 and 4 pixels per thread."""
+    gs = 5
+    est = least_squares_estimator(L.SSM_HOMOGRAPHY)
+    kw = dict(grid_size=gs, patch_size=ps, max_iters=12, epsilon=1e-4, reset_at_each_frame=1, grid_ssm=L.SSM_HOMOGRAPHY, estimator=est, fb_err_thresh=2.0, fb_reinit=1,
+              n_model_pts=4, am=am, ssm=L.SSM_AFFINE)
+    ctxs = [mtf_amd.Context(0), mtf_amd.Context(0)]
+    gts = [GridTracker(c, **kw) for c in ctxs]
+    forms = ["1", "0"]
+    for c, g, f in zip(ctxs, gts, forms):
+        monkeypatch.setenv("MTFHIP_GRID_FB_FUSED", f)
+        c.set_image(frame); g.initialize(REGIONS["quad"])
+    frames = _frames(frame, 4, 17)
+    for k, fr in enumerate(frames):
+        if k == 2:
+            fr = _spoil(fr, gts[0].prev_pts[7])
+        rec = []
+        for c, g, f in zip(ctxs, gts, forms):
+            monkeypatch.setenv("MTFHIP_GRID_FB_FUSED", f)
+            c.set_image(fr); g.update()
+            rec.append(dict(curr=g.curr_pts.copy(), fb=g.fb_prev_pts.copy(), mask=g.fb_err_mask.copy(), upd=np.array(g.ssm_update), region=g.get_region().copy(),
+                            n_iters=np.array(g.n_iters) if hasattr(g, "n_iters") else None, patches=np.array(g.patch_regions) if hasattr(g, "patch_regions") else None))
+        a, b = rec
+        for key in a:
+            if a[key] is not None:
+                assert np.array_equal(a[key], b[key]), "%s differs between the one-launch and the three-launch frame, frame %d" % (key, k)
+        if k == 2:
+            assert not a["mask"][7]
+    for g in gts:
+        g.tracker.batch.close()
+    for c in ctxs:
+        c.close()
