@@ -146,7 +146,11 @@ int mtfhip_image_shape(mtfhip_ctx *ctx, int *rows, int *cols);
 
 /* ImageBase::setCurrImg (AM/src/ImageBase.cc:38-60).  The reference borrows the caller's
  * cv::Mat buffer, which the caller overwrites in place every frame, so upload must be
- * repeated per frame; `borrow` adopts a float32 image that is already in HBM. */
+ * repeated per frame; `borrow` adopts a float32 image that is already in HBM.
+ * A BORROWED image must stay unchanged until the next call of this library that synchronises with the context's stream
+ * (mtfhip_ctx_synchronize, any call that returns results to the host): since r05 mtfhip_batch_init_template (its fused form) and
+ * mtfhip_grid_reset(reinit) return with their sampling kernel still running.  Uploaded images are safe: the next upload is
+ * ordered behind that kernel on the stream. */
 int mtfhip_image_upload(mtfhip_ctx *ctx, const float *host_img, int height, int width, int row_stride);
 /* CV_32FC3 input of the multi-channel appearance models: `channels` (1 or 3) interleaved floats per pixel, row_stride in floats */
 int mtfhip_image_upload_mc(mtfhip_ctx *ctx, const float *host_img, int height, int width, int row_stride, int channels);
@@ -275,7 +279,9 @@ int mtfhip_am_cmpt_sum_of_hessians2(mtfhip_batch *b, int j0_buf, int jt_buf, int
  * in the reference, AppearanceModel.h:188-191), MI with another bin count and the multi-channel models return MTFHIP_ERR_NOT_IMPLEMENTED for it.
  * init_template = the body of nt::{ESM,FCLK,ICLK}::initialize after ssm->initialize
  * (NT/ESM.cc:110-146, NT/FCLK.cc:102-169, NT/ICLK.cc:71-128): I0, dI0_dx, J0 and the constant
- * Hessian from the current image at the current points. */
+ * Hessian from the current image at the current points.  ICLK with a constant Hessian over SSD / NCC, <= 1024 pixels, at the identity
+ * warp: one launch (k_template_init), ASYNCHRONOUS -- the call returns with the kernel enqueued; its small results reach the host
+ * mirrors when a later call asks for them (see mtfhip_image_borrow for what that means for a borrowed image). */
 int mtfhip_batch_init_template(mtfhip_batch *b, const mtfhip_sm_desc *sm);
 /* setRegion of the search method between frames (NT/ESM.cc:148-168, NT/FCLK.cc:360-376, NT/ICLK.cc:131-157): SSM reset to
  * the new corners, template kept; ESM (and FCLK / InitialSelf) refresh init_pix_jacobian on the new grid and the constant
@@ -365,7 +371,11 @@ int mtfhip_grid_fb_mask(int n, const float *prev_pts, const float *curr_pts, con
 /* GridTracker::update's patch loop with the estimation on (:254-266): mtfhip_grid_frame (region_corners as there), then
  * mtfhip_grid_backward and mtfhip_grid_fb_mask against prev_pts (the centroids the last reset / frame left, B x 2).  With
  * g->reset_at_each_frame != 0 the caller's resetTrackers follows (:273-274: mtfhip_grid_reset, or the region of the next frame) and
- * replaces whatever setRegion(tracker_location) would leave, so that last step of the backward pass is left out. */
+ * replaces whatever setRegion(tracker_location) would leave, so that last step of the backward pass is left out.
+ * The shipped configuration (g->reset_at_each_frame == 1, fb->fb_reinit, no region; tolerance mode, ICLK with a constant Hessian over SSD / NCC, an
+ * affine patch SSM, <= 1024 pixels) is ONE launch (k_grid_fb, kernels_grid_fb.hip): a patch's update(), initialize(tracker_location) and
+ * update() on the previous frame run back to back in its workgroup, bit-identical to the three launches (MTFHIP_GRID_FB_FUSED=0).  The patch
+ * trackers are then left as the FORWARD pass left them (state, corners, template): the caller's mtfhip_grid_reset(reinit) re-initialises them. */
 int mtfhip_grid_frame_fb(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_grid_desc *g, const mtfhip_grid_fb_desc *fb,
 	const double *region_corners /* 8 or NULL */, const float *prev_pts /* B x 2 */, int *n_iters /* B or NULL */, double *corners /* B x 8 or NULL */,
 	float *centroids /* B x 2 or NULL */, float *fb_prev_pts /* B x 2 */, unsigned char *fb_err_mask /* B */, float *prev_masked /* B x 2 or NULL */,

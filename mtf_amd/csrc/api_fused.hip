@@ -384,13 +384,19 @@ static int grid_reinit_fused(mtfhip_batch *b, const mtfhip_sm_desc *sm, const do
 	/* a record of the PREVIOUS fused initialisation that nobody has asked for (reset-every-frame mode: mtfhip_grid_frame holds it back) is
 	 * superseded by this one: every mirror it would fill is rewritten by the new record -- not folding it in saves the host 1 KB per patch of
 	 * cold reads (12 us per frame at 256 patches).  With recorded interface calls pending the flush below still wants it. */
-	if (b->init_mirror_seq && !b->lz.any()) b->init_mirror_seq = 0;
-	FLUSH_AM(b);   /* (the current points are about to be replaced: no apply_warp for them -- 7 us per frame when this was FLUSH) */
-	touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b));
-	TRY(check_sm(b, sm, "init_template"));
-	TRY(need_image(b));
+	/* (r05 advisor: a call that fails before the new launch is enqueued -- check_sm, need_image, degenerate corners in set_corners_core -- must not
+	 * leave the mirrors older than d_h0 / d_ncc / d_ncc_tm with nothing pending: the dropped record is put back on those paths) */
+	const unsigned long long dropped_seq = (b->init_mirror_seq && !b->lz.any()) ? b->init_mirror_seq : 0;
+	const bool dropped_dev = b->init_rec_device;
+	if (dropped_seq) b->init_mirror_seq = 0;
+#define REINIT_TRY(expr) do { const int _rc = (expr); if (_rc != MTFHIP_OK) { if (dropped_seq && !b->init_mirror_seq) { b->init_mirror_seq = dropped_seq; b->init_rec_device = dropped_dev; } return _rc; } } while (0)
+	REINIT_TRY(lazy_flush(b, false));   /* (the current points are about to be replaced: no apply_warp for them -- 7 us per frame when this was FLUSH) */
+	touch_all(b); b->lz.it_epoch = -1; REINIT_TRY(ensure_df(b));
+	REINIT_TRY(check_sm(b, sm, "init_template"));
+	REINIT_TRY(need_image(b));
 	const auto t1 = std::chrono::steady_clock::now();
-	TRY(set_corners_core(b, layout_later ? nullptr : patches, false, true, layout_later));   /* (layout_later: b->deferred_gdesc / _region / _region_map are set, mtfhip_grid_reset) */
+	REINIT_TRY(set_corners_core(b, layout_later ? nullptr : patches, false, true, layout_later));   /* (layout_later: b->deferred_gdesc / _region / _region_map are set, mtfhip_grid_reset) */
+#undef REINIT_TRY
 	const auto t2 = std::chrono::steady_clock::now();
 	b->init_pix_vals = b->init_pix_grad = b->init_sim = b->init_grad = false;
 	const bool homg = b->desc.ssm == MTFHIP_SSM_HOMOGRAPHY;
@@ -761,6 +767,8 @@ static int mi_enqueue_fast(mtfhip_batch *b, const mtfhip_sm_desc *sm, const MiPl
 	/* pass 1 holds 45.7 KB of LDS per workgroup: THREE workgroups per CU, so mi_blocks' ~4 per CU ran as one full round and a second one
 	 * at a third of the occupancy (1024 workgroups over 768 slots; r05 ablation: the pass is bound by its sampling, 105 of 120 us, not
 	 * by the block products).  Its own count: the largest multiple of the resident slots that the partial-row buffer holds. */
+	/* (r05 advisor: nblk1 follows the device's resident slots, so tolerance mode's summation grouping -- and with it the last bits of its sums --
+	 * depends on the CU count: results are reproducible run to run on one device, not bit for bit across devices; MTFHIP_MI_PASS1_BLOCKS pins it) */
 	int nblk1 = nblk;
 	{
 		static const char *e_b1 = std::getenv("MTFHIP_MI_PASS1_BLOCKS");

@@ -690,6 +690,9 @@ struct PfSelectArgs {
 	unsigned pert_out_iter;
 	PfPeerWait wait;              /* LOCAL: this launch is the first reader of the gathered weights */
 };
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "kernels_pf.hip: k_pf_select<.., LOCAL> keeps 16 384 cumulative weights (128 KB) in one workgroup's LDS -- gfx950's 160 KB; this library is built for gfx950 only (Makefile: ARCH)"
+#endif
 constexpr int kPfLocalMax = 16384;   /* LOCAL: particles whose cumulative weights fit one workgroup's LDS (128 KB of the 160) */
 /* a folded row: best weight and its index, the sixteen sums, the state of the best particle (all wave-uniform) */
 struct PfRow { double v; int i; double sum[16]; double st[8]; };
