@@ -19,6 +19,8 @@
 #include "mtfhip_device.h"
 #include "mtfhip_rng_device.h"
 #include <type_traits>
+#include <map>
+#include <tuple>
 
 namespace mtfhip {
 
@@ -245,6 +247,7 @@ __global__ __launch_bounds__(kBlock) void k_nn_rows(BatchView bv, ImgView im, co
 	constexpr int EM = kNnRowKeep;                               /* entries of a row a lane holds at a time */
 	constexpr int kChunk = 4 * 64 * EM;                          /* entries of a row the workgroup holds at a time */
 	const int R = (N + 127) / 128;                               /* the row in pair-rounds of 128 entries (lane l: entries 128 r + 2 l, 128 r + 2 l + 1) */
+	const int lds_entries = 128 * 4 * (((R < kChunk / 128 ? R : kChunk / 128) + 3) / 4);   /* what the launcher sized the LDS for: the largest chunk of the row */
 	/* The workgroups are persistent (the launch fills the device once; a sample is a quarter row per wave, so 10 000 samples do not leave
 	 * the last fifth of the resident slots one wave each).  Rows longer than 3072 entries are walked chunk by chunk (SSD / MI: a row's
 	 * entries are independent). */
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void k_nn_rows(BatchView bv, ImgView im, co
 		 * wave-instruction per ~22 cycles whatever its width (PMC, r06: 4.1 of them per wave-pixel -- grid 1, texel pairs 2, store 1 / 2, and
 		 * 16 M of them in 573 us on 256 CUs; the candidate scorer sits on the same rate), so the 16-byte grid load of every pixel
 		 * of every sample was a quarter of the kernel.  (Keeping them in registers instead: 169 VGPRs, two workgroups per CU, slower.) */
-		double *lz = reinterpret_cast<double *>(nn_lds + kChunk);
+		double *lz = reinterpret_cast<double *>(nn_lds + lds_entries);
 		if (c0 > 0) __syncthreads();
 		for (int j = threadIdx.x; j < 128 * 4 * R4; j += kBlock) {   /* (every entry a wave may touch: past the row's end, copies of its last point) */
 			const int i = min(128 * c0 + j, N - 1);
@@ -394,12 +397,16 @@ static void launch_nn_rows(const BatchView &bv, const ImgView &im, const NnArgs 
 	const double h[8] = {hull ? hull[0] : 0, hull ? hull[1] : 0, hull ? hull[2] : 0, hull ? hull[3] : 0, hull ? hull[4] : 0, hull ? hull[5] : 0, hull ? hull[6] : 0, hull ? hull[7] : 0};
 	MTFHIP_LAUNCH((k_nn_warps<SSM>), dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, a, count, warps, im.w, im.h, ok, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
 	/* persistent workgroups: as many as the device holds at once (occupancy x compute units), at most one per sample */
-	constexpr size_t kChunkEntries = 4 * 64 * kNnRowKeep;
-	const size_t lds = kChunkEntries * (bv.unit_z ? 16 : 24);   /* (48 KB / 72 KB: the whole chunk, so that the occupancy below is a constant of the kernel) */
-	static int resident[2][3][2] = {};
-	const int zi = bv.unit_z ? 0 : 1;
+	/* dynamic LDS: the grid points of the chunk the row needs (a 50 x 50 row: 20 pair-rounds = 40 KB, four workgroups per CU; the full 3072-entry
+	 * chunk is 48 KB: three), z behind them for grids that are not unit-z.  The resident count is a property of (kernel, LDS bytes): cached per pair. */
+	constexpr int kChunkEntries = 4 * 64 * kNnRowKeep;
+	const int rounds = (bv.N + 127) / 128, r4 = ((rounds < kChunkEntries / 128 ? rounds : kChunkEntries / 128) + 3) / 4;
+	const int lds_entries = 128 * 4 * r4;
+	const size_t lds = (size_t)lds_entries * (bv.unit_z ? 16 : 24);
+	static std::map<std::tuple<int, int, size_t>, int> resident_cache;
 	const int ai = bv.am == MTFHIP_AM_NCC ? 1 : (bv.am == MTFHIP_AM_MI ? 2 : 0), si = SSM == MTFHIP_SSM_HOMOGRAPHY ? 0 : 1;
-	if (!resident[si][ai][zi]) {
+	int &resident = resident_cache[std::make_tuple(si, ai, lds)];
+	if (!resident) {
 		int per_cu = 0, dev = 0;
 		hipDeviceProp_t prop;
 		hipError_t e = hipGetDevice(&dev);
@@ -409,9 +416,9 @@ static void launch_nn_rows(const BatchView &bv, const ImgView &im, const NnArgs 
 			else if (ai == 2) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nn_rows<SSM, MTFHIP_AM_MI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_nn_rows<SSM, MTFHIP_AM_MI>, kBlock, lds); }
 			else { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nn_rows<SSM, MTFHIP_AM_SSD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_nn_rows<SSM, MTFHIP_AM_SSD>, kBlock, lds); }
 		}
-		resident[si][ai][zi] = (e == hipSuccess && per_cu > 0) ? per_cu * prop.multiProcessorCount : 1024;
+		resident = (e == hipSuccess && per_cu > 0) ? per_cu * prop.multiProcessorCount : 1024;
 	}
-	const dim3 g((unsigned)(count < resident[si][ai][zi] ? count : resident[si][ai][zi])), blk(kBlock);
+	const dim3 g((unsigned)(count < resident ? count : resident)), blk(kBlock);
 #define MTFHIP_NN_ROWS(A) MTFHIP_LAUNCH((k_nn_rows<SSM, A>), g, blk, lds, st, bv, im, warps, count, a.norm_mult, a.norm_add, feat)
 	if (bv.am == MTFHIP_AM_NCC) MTFHIP_NN_ROWS(MTFHIP_AM_NCC);
 	else if (bv.am == MTFHIP_AM_MI) MTFHIP_NN_ROWS(MTFHIP_AM_MI);
