@@ -64,7 +64,7 @@ __global__ __launch_bounds__(kBlock) void k_mi_pass_hist(BatchView bv, ImgView i
 	const double *I0 = bv.buf[MTFHIP_BUF_I0] + tt * N;
 	for (int k2 = 0; k2 < 2 * kWinRows; ++k2) wa[k2 * kRS + lane] = 0.0;   /* the slabs start clean and every chunk leaves them clean */
 	double bj8 = 0.0, bs8 = 0.0, bh8 = 0.0;
-	mfma_d4 cj16 = {0.0, 0.0, 0.0, 0.0}, cs16 = {0.0, 0.0, 0.0, 0.0};   /* NB = 10: the 16 x 16 tile's accumulators */
+	double cj3[3] = {0.0, 0.0, 0.0};   /* NB != 8: the joint histogram's blocks (lb, 0 .. 2) */
 	const bool hfj = !CAND && pa.hist_from_joint != 0;
 	const int li = lane & 3, lb = (lane >> 2) & 3, lk = lane >> 4;
 	const double one0 = li == 0 ? 1.0 : 0.0;
@@ -134,18 +134,27 @@ __global__ __launch_bounds__(kBlock) void k_mi_pass_hist(BatchView bv, ImgView i
 		__builtin_amdgcn_wave_barrier();
 #if !(defined(MTFHIP_MI1_ABL) && MTFHIP_MI1_ABL == 2)   /* 2: + staging, no products */
 		if constexpr (NB != 8) {
-			/* one 16 x 16 tile (v_mfma_f64_16x16x4_f64: lane l supplies A[i = l % 16][k = l / 16], B[k][j = l % 16] and receives D[i = l / 16 + 4 v][j = l % 16]
-			 * in element v): rows / columns = bins, column nb of B all ones so that D[r][nb] is the histogram of It (as k_mi_hist, kernels_mi.hip).
-			 * Two LDS reads and one matrix instruction per four pixels for any count up to ten -- the 3 x 3 tiles of 4 x 4 block products this
-			 * replaced (r06 first form: three instructions, six reads) took pass 1 from 115 to 214 us at 10 bins. */
-			const int idx = lane & 15, kq = lane >> 4, row = 1 + (idx < nb ? idx : nb - 1);
+			/* Up to twelve bins as three groups of four: lane group lb (0..2; group 3 idles) owns the It-bins 4 lb .. 4 lb + 3 and keeps its A operand
+			 * over the step's instructions -- three 4 x 4 x 4 block products against the three I0-bin groups give the joint histogram (block (lb, t)),
+			 * the operand against itself the diagonal blocks of the self-joint histogram and against the next group's rows its first off-diagonal
+			 * blocks; the self-joint histogram is BANDED (a window covers four consecutive bins: |r - c| <= 3), so those five blocks and their
+			 * mirror images are all of it.  Five LDS reads and five block instructions (~19 cycles each, profiles/r04_fp64_rates.txt) per four pixels;
+			 * r06's first forms: 3 x 3 + 3 x 3 block products with six + six reads 214 us, two 16 x 16 x 4 tiles (120-160 cycles each whatever is in
+			 * them) 218 us, one tile + the band blocks 193 us -- against the 8-bin kernel's 115. */
+			const int rA = 1 + 4 * lb + li, rS = 1 + 4 * (lb + 1) + li;
+			const double *pa = wa + (rA < kWinRows ? rA : kWinRows - 1) * kRS + lk, *ps = wa + (rS < kWinRows ? rS : kWinRows - 1) * kRS + lk;   /* (rows past bin nb + 1 do not exist: their blocks are dropped at the end) */
+			const double *pb0 = wb + (1 + li) * kRS + lk, *pb1 = wb + (5 + li) * kRS + lk, *pb2 = wb + ((9 + li < kWinRows) ? 9 + li : kWinRows - 1) * kRS + lk;
 #pragma unroll
 			for (int ks = 0; ks < 16; ++ks) {
-				const int p = 4 * ks + kq;
-				const double av0 = wa[row * kRS + p], bv0 = wb[row * kRS + p];
-				const double av = idx < nb ? av0 : 0.0;
-				cj16 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, idx < nb ? bv0 : (idx == nb ? 1.0 : 0.0), cj16, 0, 0, 0);
-				if constexpr (SELF) cs16 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, av, cs16, 0, 0, 0);
+				const double av = pa[4 * ks];
+				cj3[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, pb0[4 * ks], cj3[0], 0, 0, 0);
+				cj3[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, pb1[4 * ks], cj3[1], 0, 0, 0);
+				cj3[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, pb2[4 * ks], cj3[2], 0, 0, 0);
+				if (!hfj) bh8 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, one0, bh8, 0, 0, 0);   /* (uniform; with partition of unity the histogram is the joint histogram's row sums) */
+				if constexpr (SELF) {
+					bs8 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, av, bs8, 0, 0, 0);
+					bj8 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, ps[4 * ks], bj8, 0, 0, 0);   /* (bj8 is free at NB != 8: the first off-diagonal blocks) */
+				}
 			}
 		} else
 		if (hfj) {   /* (uniform) the histogram comes out of the joint histogram's rows at the end: two block products per step instead of three */
@@ -185,15 +194,19 @@ __global__ __launch_bounds__(kBlock) void k_mi_pass_hist(BatchView bv, ImgView i
 		if constexpr (SELF) red[wave * rl + nb + nb * nb + r * nb + c] = bs8;
 		if ((lb & 1) == 0 && (lane & 3) == 0) red[wave * rl + r] = bh8;
 	} else {
-		const int j = lane & 15;
+		/* block lb of every accumulator: rows 4 lb + (lane >> 4); what lies outside the band of the self-joint histogram is zero */
+		double *rj = red + wave * rl + nb, *rs = rj + nb * nb;
+		if constexpr (SELF) { for (int k2 = lane; k2 < nb * nb; k2 += 64) rs[k2] = 0.0; }
+		__builtin_amdgcn_wave_barrier();
+		const int r = 4 * lb + (lane >> 4), ci = lane & 3;
+		if (lb < 3 && r < nb) {
 #pragma unroll
-		for (int v = 0; v < 4; ++v) {
-			const int i = (lane >> 4) + 4 * v;
-			if (i < nb) {
-				if (j < nb) {
-					red[wave * rl + nb + i * nb + j] = cj16[v];
-					if constexpr (SELF) red[wave * rl + nb + nb * nb + i * nb + j] = cs16[v];
-				} else if (j == nb) red[wave * rl + i] = cj16[v];
+			for (int tb = 0; tb < 3; ++tb) { const int c = 4 * tb + ci; if (c < nb) rj[r * nb + c] = cj3[tb]; }
+			if (ci == 0) red[wave * rl + r] = bh8;   /* (hfj: overwritten by the row sums below) */
+			if constexpr (SELF) {
+				const int cd = 4 * lb + ci, co = 4 * (lb + 1) + ci;
+				if (cd < nb) rs[r * nb + cd] = bs8;
+				if (co < nb) { rs[r * nb + co] = bj8; rs[co * nb + r] = bj8; }
 			}
 		}
 	}
