@@ -394,7 +394,7 @@ __device__ __forceinline__ void mi_poly_tables_body(const double *tb_all, double
 				acc = fma(dc * wc, T[(f1 + r) * TS + f2 + c], acc);
 			}
 		}
-		out[which * NP * kMiPolyPair + mi_pair_index<NB>(f1, f2) * kMiPolyPair + ab] = acc * hist_norm;   /* (mi_pair_index: the bank-skewed place of the pair) */
+		out[k] = acc * hist_norm;
 	}
 	for (int k = threadIdx.x; k < NB * 8; k += kBlock) {
 		const int fl = k >> 3, j = k & 7;

@@ -268,13 +268,6 @@ __host__ __device__ constexpr MiMomentCoef mi_moment_coef() {
  * and three 4 x 4 table contractions (60 multiply-adds, 48 LDS reads).  Bins outside the histogram meet the zero border of the
  * tables when the coefficients are built, which is what the reference's clamped id range amounts to (MI.cc:114-117). */
 constexpr int kMiPolyPair = 12;                      /* [a = 0..2][b = 0..3] */
-/* Where class pair (a, b) sits in its table.  A pair's twelve coefficients are 96 bytes, so pair indices that differ by a multiple of 8 share
- * their LDS banks -- and with the plain [a][b] layout of eight classes the pairs (a, b) and (a + 1, b) are exactly 8 apart: the neighbouring
- * pixels of a wave, whose classes differ by one all the time, read their coefficients 2-way conflicted (r05 PMC of pass 2: conflict cycles a
- * third of the LDS-active ones).  Eight classes: column (b + 5 a) mod 8 -- the differences that then collide ((da, db) with db + 5 da = 0 mod
- * 8: (1, 3), (3, 1), (2, -2) ...) are the rare ones; (1, 0), (0, 1), (1, 1), (1, -1), (2, 2), (2, 1), (1, 2), (2, 0) do not.  Other counts
- * (rows of ten pairs = 960 bytes = 192 mod 256: (1, 0) is clear already) keep the plain layout. */
-template <int NB> __host__ __device__ __forceinline__ constexpr int mi_pair_index(int a, int b) { return NB == 8 ? a * 8 + ((b + 5 * a) & 7) : a * NB + b; }
 /* per instantiation (NB = the bin count the tables are laid out for): [NB^2 class pairs][12] of df_dIt | the same of df_dI0 | [NB][8] of hess_term */
 __host__ __device__ constexpr int mi_poly_t(int) { return 0; }
 __host__ __device__ constexpr int mi_poly_i(int NB) { return NB * NB * kMiPolyPair; }
@@ -439,19 +432,20 @@ __global__ __launch_bounds__(kBlock, 2) void k_mi_pass_grad_hess(BatchView bv, I
 			/* class and fraction of both pixel values; the three table sums by Horner's rule on the class pair's coefficients (see kMiPoly*) */
 			fl_it = min(max((int)sp.it, 0), nb - 1); phi_it = sp.it - (double)fl_it;
 			const int fl0 = min(max((int)i0, 0), nb - 1);
+			constexpr int kPairStride = NB;   /* class pairs are laid out [NB][NB] whatever pa.nb is */
 			const double phi0 = i0 - (double)fl0;
 #if defined(MTFHIP_MI_ABL) && MTFHIP_MI_ABL == 2
 			dft = phi_it + phi0; df0 = phi0;
 #else
 			if (pa.need_dft) {
-				const double *c = Pl + kMiPolyT + mi_pair_index<NB>(fl_it, fl0) * kMiPolyPair;
+				const double *c = Pl + kMiPolyT + (fl_it * kPairStride + fl0) * kMiPolyPair;
 				const double r0 = fma(fma(fma(c[3], phi0, c[2]), phi0, c[1]), phi0, c[0]);
 				const double r1 = fma(fma(fma(c[7], phi0, c[6]), phi0, c[5]), phi0, c[4]);
 				const double r2 = fma(fma(fma(c[11], phi0, c[10]), phi0, c[9]), phi0, c[8]);
 				dft = fma(fma(r2, phi_it, r1), phi_it, r0) * vm;
 			}
 			if (pa.need_df0) {
-				const double *c = Pl + kPolyI + mi_pair_index<NB>(fl0, fl_it) * kMiPolyPair;
+				const double *c = Pl + kPolyI + (fl0 * kPairStride + fl_it) * kMiPolyPair;
 				const double r0 = fma(fma(fma(c[3], phi_it, c[2]), phi_it, c[1]), phi_it, c[0]);
 				const double r1 = fma(fma(fma(c[7], phi_it, c[6]), phi_it, c[5]), phi_it, c[4]);
 				const double r2 = fma(fma(fma(c[11], phi_it, c[10]), phi_it, c[9]), phi_it, c[8]);
