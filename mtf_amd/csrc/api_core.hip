@@ -571,6 +571,7 @@ void set_corners_finish_deferred(mtfhip_batch *b) {
 	}
 }
 int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track, bool defer_grid, bool layout_later) {
+	b->fresh_reinit = false;   /* (grid_reinit_fused sets it again behind this call) */
 	FLUSH_AM(b);   /* pending calls are replayed (with the points they need); the points themselves are about to change */
 	if (b) ++b->lz.epoch;
 	if (b) { touch_all(b); b->lz.it_epoch = -1; TRY(ensure_df(b)); }
@@ -683,6 +684,7 @@ int ensure_pts(mtfhip_batch *b) {
 	return MTFHIP_OK;
 }
 static int apply_states(mtfhip_batch *b) {
+	b->fresh_reinit = false;
 	if (b->inline_warp_ok) b->warps_dirty = true;   /* uploaded by whoever needs it, or carried by the next fused launch */
 	else TRY(push_warps(b));
 	b->pts_stale = true;   /* refreshed by the next entry point that may read them (lazy_flush) */

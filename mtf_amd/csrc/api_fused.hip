@@ -429,6 +429,8 @@ static int grid_reinit_fused(mtfhip_batch *b, const mtfhip_sm_desc *sm, const do
 	/* (init_template_fused took the template corners from the mirrors, which the deferred half has only now brought up to date) */
 	for (int t = 0; t < b->B; ++t) std::memcpy(&b->template_corners[8 * t], b->th[t].init_corners, sizeof(double) * 8);
 	b->warps_dirty = true;   /* the device slab still holds the previous frame's warps: whoever needs them next uploads the (identity) mirrors */
+	/* ... except the one-launch loop kernels, which start a freshly re-initialised patch from init_corners_hm (TrackState::fresh_reset) */
+	b->fresh_reinit = rc == MTFHIP_OK && !(std::getenv("MTFHIP_GRID_FRESH") && std::getenv("MTFHIP_GRID_FRESH")[0] == '0');
 	if (rc == MTFHIP_OK) { HIP_TRY(hipEventRecord(b->ev_a, b->ctx->stream)); b->stage_a_busy = true; }   /* the kernel reads the staging buffer */
 	return rc;
 }
@@ -1329,7 +1331,11 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 	else { fa.materialize = 0; fa.mode = 2; fa.active = nullptr; fa.rows_per_block = 1; fa.j0_recompute = 0; fa.inline_warp = 0; fa.fast_math = 0; }
 	/* active = 1, iters = 0, corners, warps, states, NCC scalars: one pinned async copy of the whole slab
 	 * (w0 is copied along; init_grid consumed it long ago) */
-	if (!slab_uploaded) {
+	/* right behind a fused grid re-initialisation the one-launch kernels need nothing of the slab's warps / states / corners (identity, zero, the
+	 * templates' own corners: TrackState::fresh_reset): no fill_stage, no ingest launch (5 us + its gap per frame of a reset-every-frame loop) */
+	const bool fresh = b->fresh_reinit && one_launch && !region_mode && !slab_uploaded && !resume && b->h_pub_dev && b->d_trace == nullptr;
+	b->fresh_reinit = false;
+	if (!slab_uploaded && !fresh) {
 		/* (h_stage_b needs no guard: every return path below has waited for the device to finish this call's work) */
 		std::memcpy(b->h_stage_b + 45 * sizeof(double) * (size_t)b->B, b->h_stage_a + 45 * sizeof(double) * (size_t)b->B, 9 * sizeof(double) * (size_t)b->B);
 		fill_stage(b, b->h_stage_b, nullptr, 1, true);
@@ -1362,6 +1368,7 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 	};
 	TrackState ts{b->d_acc, b->d_h0, b->d_corners, b->d_init_corners_hm, b->d_active, b->d_iters, ncc ? b->d_ncc : nullptr, ncc ? b->d_ncc_tm : nullptr, 0, nullptr, nullptr,
 		b->d_trace, b->trace_cap};
+	ts.fresh_reset = fresh ? 1 : 0;
 	if (b->d_trace && !resume) HIP_TRY(hipMemsetAsync(b->d_trace, 0, sizeof(double) * kTraceStride * (size_t)b->trace_cap * b->B, st));
 	if (mi && b->d_trace) ts.f_ext = b->d_mi_f;   /* (the trace records the similarity; Levenberg-Marquardt sets it below as well) */
 	if (sm->leven_marq && resume) { ts.lm = b->d_lm; if (mi) ts.f_ext = b->d_mi_f; }

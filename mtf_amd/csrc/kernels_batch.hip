@@ -167,9 +167,15 @@ __global__ __launch_bounds__(kBlock) void k_iclk_track(BatchView bv, ImgView im,
 	}
 	if (!region) {
 		if (tid < 12) sIc[tid] = ts.init_corners_hm[12 * t + tid];
-		if (tid < 8) sCr[tid] = ts.corners[8 * t + tid];
-		if (tid < 9) sW[tid] = bv.warps[9 * t + tid];
-		if (tid < 8) sSt[tid] = bv.states[8 * t + tid];
+		if (ts.fresh_reset) {   /* (uniform) behind a fused re-initialisation: identity warp, zero state, the template's own corners (x, y, 1 per corner) */
+			if (tid < 8) sCr[tid] = ts.init_corners_hm[12 * t + 3 * (tid >> 1) + (tid & 1)];
+			if (tid < 9) sW[tid] = (tid == 0 || tid == 4 || tid == 8) ? 1.0 : 0.0;
+			if (tid < 8) sSt[tid] = 0.0;
+		} else {
+			if (tid < 8) sCr[tid] = ts.corners[8 * t + tid];
+			if (tid < 9) sW[tid] = bv.warps[9 * t + tid];
+			if (tid < 8) sSt[tid] = bv.states[8 * t + tid];
+		}
 	} else {
 		/* the SSM's reset (setCorners: identity warp, zero state, init_corners_hm = (x, y, 1)) */
 		if (tid < 9) sW[tid] = (tid == 0 || tid == 4 || tid == 8) ? 1.0 : 0.0;

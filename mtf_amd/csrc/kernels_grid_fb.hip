@@ -198,9 +198,15 @@ __global__ __launch_bounds__(kBlock) void k_grid_fb(BatchView bv, ImgView im, Im
 		}
 		if (tid < 64) { const int r = tid >> 3, c = tid & 7; sH8[tid] = (r < S && c < S) ? h0inv_all[(size_t)t * 64 + c * S + r] : 0.0; }
 		if (tid < 12) sIc[tid] = ts.init_corners_hm[12 * t + tid];
-		if (tid < 8) sCr[tid] = ts.corners[8 * t + tid];
-		if (tid < 9) sW[tid] = bv.warps[9 * t + tid];
-		if (tid < 8) sSt[tid] = bv.states[8 * t + tid];
+		if (ts.fresh_reset) {   /* (uniform) behind a fused re-initialisation: identity warp, zero state, the template's own corners (k_iclk_track) */
+			if (tid < 8) sCr[tid] = ts.init_corners_hm[12 * t + 3 * (tid >> 1) + (tid & 1)];
+			if (tid < 9) sW[tid] = (tid == 0 || tid == 4 || tid == 8) ? 1.0 : 0.0;
+			if (tid < 8) sSt[tid] = 0.0;
+		} else {
+			if (tid < 8) sCr[tid] = ts.corners[8 * t + tid];
+			if (tid < 9) sW[tid] = bv.warps[9 * t + tid];
+			if (tid < 8) sSt[tid] = bv.states[8 * t + tid];
+		}
 		__syncthreads();
 		double W[9], St[8], Ic[12], hrow[8];
 #pragma unroll

@@ -253,6 +253,10 @@ struct mtfhip_batch {
 	double *d_it_shadow = nullptr;
 	double *d_ncc_tm = nullptr;   /* [B][52] NCC template moments for the device-side finish */
 	/* the one-launch forward-backward frame (k_grid_fb): requested by mtfhip_grid_frame_fb around its track call */
+	/* set by a fused grid re-initialisation (grid_reinit_fused: identity warps, zero states, corners = the templates' corners on host AND device),
+	 * cleared by whatever changes the mirrors' warps / states / corners next (set_corners_core, apply_states) and consumed by the next track_core:
+	 * its one-launch kernel then starts from init_corners_hm and the slab is not uploaded (TrackState::fresh_reset) */
+	bool fresh_reinit = false;
 	bool fb_fused_req = false;
 	double *h_fb = nullptr, *h_fb_dev = nullptr, *d_fb = nullptr;   /* [B][9] the backward pass's corners | iteration count: pinned host copy, device copy */
 	double *d_nn_warps = nullptr; size_t nn_warps_cap = 0;   /* NN dataset, tolerance mode: the samples' warps between k_nn_warps and k_nn_rows */
@@ -571,7 +575,7 @@ static int lazy_flush_ctx(mtfhip_ctx *c) {   /* called by everything that replac
 		 * three device-to-host copies and a synchronisation per frame for mirrors the next re-initialisation supersedes unread */
 		const bool hold = b->hold_init_pull;
 		if (!b->lz.any()) b->hold_init_pull = true;
-		const int rc = lazy_flush(b);
+		const int rc = lazy_flush(b, false);   /* (pts = false: the current points follow the warp when an un-fused kernel next asks -- refreshing them at every setImage was one k_apply_warp launch per frame of a video loop; recorded calls that read them refresh them inside) */
 		b->hold_init_pull = hold;
 		if (rc) return rc;
 		++b->lz.epoch;

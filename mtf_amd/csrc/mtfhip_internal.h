@@ -116,6 +116,10 @@ struct TrackState {
 	const double *h_extra;
 	double h_extra_scale;
 	int fast_finish;      /* tolerance mode, SSD family, first-order Hessian from the reduced row or the constant one: finish_track_fast_body */
+	/* k_iclk_track / k_grid_fb, plain mode, right behind a fused re-initialisation (k_template_init in region mode, mtfhip_grid_reset): every patch
+	 * starts from the identity warp and the zero state at its template's corners, which that kernel left in init_corners_hm -- the slab's warps /
+	 * states / corners are not read, so the host does not upload them (one ingest launch and its gap less per frame, r06) */
+	int fresh_reset;
 };
 constexpr int kLmStride = 12;
 constexpr int kTraceStride = 96;
