@@ -21,6 +21,7 @@
 #include <type_traits>
 #include <map>
 #include <tuple>
+#include <mutex>
 
 namespace mtfhip {
 
@@ -404,6 +405,8 @@ static void launch_nn_rows(const BatchView &bv, const ImgView &im, const NnArgs 
 	const int lds_entries = 128 * 4 * r4;
 	const size_t lds = (size_t)lds_entries * (bv.unit_z ? 16 : 24);
 	static std::map<std::tuple<int, int, size_t>, int> resident_cache;
+	static std::mutex resident_mutex;   /* (contexts on several host threads: the loopback ranks of the tests) */
+	std::lock_guard<std::mutex> resident_lock(resident_mutex);
 	const int ai = bv.am == MTFHIP_AM_NCC ? 1 : (bv.am == MTFHIP_AM_MI ? 2 : 0), si = SSM == MTFHIP_SSM_HOMOGRAPHY ? 0 : 1;
 	int &resident = resident_cache[std::make_tuple(si, ai, lds)];
 	if (!resident) {
