@@ -255,10 +255,10 @@ __global__ __launch_bounds__(kBlock) void k_nn_rows(BatchView bv, ImgView im, co
 	for (int c0 = 0; c0 < R; c0 += kChunk / 128) {
 		const int Rc = min(R - c0, kChunk / 128), R4 = (Rc + 3) / 4, E = 2 * R4;   /* wave w takes pair-rounds c0 + [w R4, (w + 1) R4) of the chunk */
 		auto pix = [&](int k) { return 128 * (c0 + wave * R4 + (k >> 1)) + 2 * lane + (k & 1); };
-		/* The chunk's grid points go to LDS once per workgroup and are read from there by every sample: a CU's vector memory path takes one
-		 * wave-instruction per ~22 cycles whatever its width (PMC, r06: 4.1 of them per wave-pixel -- grid 1, texel pairs 2, store 1 / 2, and
-		 * 16 M of them in 573 us on 256 CUs; the candidate scorer sits on the same rate), so the 16-byte grid load of every pixel
-		 * of every sample was a quarter of the kernel.  (Keeping them in registers instead: 169 VGPRs, two workgroups per CU, slower.) */
+		/* The chunk's grid points go to LDS once per workgroup and are read from there by every sample (r06 PMC: 3.6 vector-memory reads per
+		 * wave-pixel with the 16-byte grid load of every pixel of every sample among them; through LDS 573 -> 542 us per 100 000 samples.
+		 * Keeping them in registers instead: 169 VGPRs, two workgroups per CU, 639 us.  Forming the warp inside this kernel for launches of at
+		 * most one sample per resident workgroup instead of a k_nn_warps launch in front: 20.8 -> 27.2 us per 1000 samples, not kept.) */
 		double *lz = reinterpret_cast<double *>(nn_lds + lds_entries);
 		if (c0 > 0) __syncthreads();
 		for (int j = threadIdx.x; j < 128 * 4 * R4; j += kBlock) {   /* (every entry a wave may touch: past the row's end, copies of its last point) */
