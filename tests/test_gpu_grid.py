@@ -479,9 +479,10 @@ def test_grid_template_init_and_first_iteration_against_the_oracles_trackers(ora
     b.close()
 
 
+@pytest.mark.parametrize("where", ["centre", "border"])
 @pytest.mark.parametrize("ps", [16, 25, 32])
 @pytest.mark.parametrize("am", [L.AM_NCC, L.AM_SSD], ids=["ncc", "ssd"])
-def test_grid_fb_one_launch_equals_three(frame, am, ps, monkeypatch):
+def test_grid_fb_one_launch_equals_three(frame, am, ps, where, monkeypatch):
     """the shipped configuration's frame (reset_at_each_frame 1, fb_err_thresh 2, fb_reinit 1) as ONE launch (k_grid_fb: a patch's update(),
     initialize(tracker_location) and update() on the previous frame in its workgroup) against the three launches with two host waits
     (k_iclk_track, k_template_init, k_iclk_track; MTFHIP_GRID_FB_FUSED=0): the same expressions in the same order, so the same bits --
@@ -496,7 +497,10 @@ def test_grid_fb_one_launch_equals_three(frame, am, ps, monkeypatch):
     forms = ["1", "0"]
     for c, g, f in zip(ctxs, gts, forms):
         monkeypatch.setenv("MTFHIP_GRID_FB_FUSED", f)
-        c.set_image(frame); g.initialize(REGIONS["quad"])
+        # "border": the grid reaches past the frame's right and lower edges -- patches whose samples take the border value 128, whose texel
+        # windows are clamped into the frame or unusable (the global sampling path), templates re-initialised partly outside the frame
+        region = REGIONS["quad"] if where == "centre" else REGIONS["quad"] + np.array([[118.0], [112.0]])
+        c.set_image(frame); g.initialize(region)
     frames = _frames(frame, 4, 17)
     for k, fr in enumerate(frames):
         if k == 2:
