@@ -372,10 +372,11 @@ int mtfhip_grid_fb_mask(int n, const float *prev_pts, const float *curr_pts, con
  * mtfhip_grid_backward and mtfhip_grid_fb_mask against prev_pts (the centroids the last reset / frame left, B x 2).  With
  * g->reset_at_each_frame != 0 the caller's resetTrackers follows (:273-274: mtfhip_grid_reset, or the region of the next frame) and
  * replaces whatever setRegion(tracker_location) would leave, so that last step of the backward pass is left out.
- * The shipped configuration (g->reset_at_each_frame == 1, fb->fb_reinit, no region; tolerance mode, ICLK with a constant Hessian over SSD / NCC, an
- * affine patch SSM, <= 1024 pixels) is ONE launch (k_grid_fb, kernels_grid_fb.hip): a patch's update(), initialize(tracker_location) and
- * update() on the previous frame run back to back in its workgroup, bit-identical to the three launches (MTFHIP_GRID_FB_FUSED=0).  The patch
- * trackers are then left as the FORWARD pass left them (state, corners, template): the caller's mtfhip_grid_reset(reinit) re-initialises them. */
+ * The reset-every-frame configuration (g->reset_at_each_frame == 1, no region -- the shipped one, with fb->fb_reinit; tolerance mode, ICLK with a
+ * constant Hessian over SSD / NCC, <= 1024 pixels; with fb_reinit an affine patch SSM) is ONE launch (k_grid_fb, kernels_grid_fb.hip): a patch's
+ * update(), its initialize(tracker_location) when fb_reinit, and its update() on the previous frame run back to back in its workgroup,
+ * bit-identical to the launch-by-launch form (MTFHIP_GRID_FB_FUSED=0).  The patch trackers are then left as the FORWARD pass left them (state,
+ * corners, template): the caller's mtfhip_grid_reset(reinit) re-initialises them. */
 int mtfhip_grid_frame_fb(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip_grid_desc *g, const mtfhip_grid_fb_desc *fb,
 	const double *region_corners /* 8 or NULL */, const float *prev_pts /* B x 2 */, int *n_iters /* B or NULL */, double *corners /* B x 8 or NULL */,
 	float *centroids /* B x 2 or NULL */, float *fb_prev_pts /* B x 2 */, unsigned char *fb_err_mask /* B */, float *prev_masked /* B x 2 or NULL */,

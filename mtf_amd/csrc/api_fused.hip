@@ -1236,8 +1236,9 @@ int mtfhip_grid_frame_fb(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip
 	{
 		const char *e_ff = std::getenv("MTFHIP_GRID_FB_FUSED");   /* (read per call: the tests compare the two forms in one process) */
 		mtfhip_ctx *c = b->ctx;
-		const bool fused = !(e_ff && e_ff[0] == '0') && !region && fb->fb_reinit && g->reset_at_each_frame == 1 && !always_restore &&
-			b->math_mode == MTFHIP_MATH_FAST && b->desc.ssm == MTFHIP_SSM_AFFINE && template_init_fused_ok(b, sm) && iclk_one_launch(b, sm) && !sm->leven_marq &&
+		const bool reinit_ok = !fb->fb_reinit || (b->desc.ssm == MTFHIP_SSM_AFFINE && template_init_fused_ok(b, sm));   /* (fb_reinit 0: the backward loop keeps the forward pass's template and state) */
+		const bool fused = !(e_ff && e_ff[0] == '0') && !region && reinit_ok && g->reset_at_each_frame == 1 && !always_restore &&
+			b->math_mode == MTFHIP_MATH_FAST && (b->desc.am == MTFHIP_AM_SSD || b->desc.am == MTFHIP_AM_NCC) && b->C == 1 && sm->sm == MTFHIP_SM_ICLK && iclk_one_launch(b, sm) && !sm->leven_marq &&
 			second_order_term(sm, b->desc.am) < 0 && b->N <= 4 * kBlock && b->h_pub_dev && !b->d_trace && b->init_pix_vals &&
 			(b->desc.am != MTFHIP_AM_NCC || b->d_ncc_tm) && c->prev.data && c->img.data && c->prev.h == c->img.h && c->prev.w == c->img.w &&
 			c->prev.channels == c->img.channels;
@@ -1248,7 +1249,7 @@ int mtfhip_grid_frame_fb(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip
 				HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&b->h_fb_dev), b->h_fb, 0));
 				HIP_TRY(hipMalloc(&b->d_fb, sizeof(double) * 9 * B));
 			}
-			b->fb_fused_req = true;
+			b->fb_fused_req = true; b->fb_fused_reinit = fb->fb_reinit != 0;
 			const int rc = mtfhip_grid_frame(b, sm, g, nullptr, n_iters, corners, cen.data());
 			b->fb_fused_req = false;
 			if (rc != MTFHIP_OK) return rc;
@@ -1456,7 +1457,7 @@ static int track_core(mtfhip_batch *b, const mtfhip_sm_desc *sm, int *n_iters, d
 			geo.lo_x = homg ? -0.5 : 1 - b->desc.resx / 2.0; geo.lo_y = homg ? -0.5 : 1 - b->desc.resy / 2.0;
 			geo.hi_x = homg ? 0.5 : b->desc.resx / 2.0; geo.hi_y = homg ? 0.5 : b->desc.resy / 2.0;
 			geo.resx = b->desc.resx; geo.resy = b->desc.resy; geo.force_unit_z = homg ? 0 : 1;
-			if (!launch_grid_fb(bv, b->ctx->img, b->ctx->prev, *sm, ts, b->d_h0inv, b->d_ncc, b->norm_mult, b->norm_add, b->desc.grad_eps, pub, GridFbOut{b->h_fb_dev, b->d_fb}, geo, st))
+			if (!launch_grid_fb(bv, b->ctx->img, b->ctx->prev, *sm, ts, b->d_h0inv, b->d_ncc, b->norm_mult, b->norm_add, b->desc.grad_eps, pub, GridFbOut{b->h_fb_dev, b->d_fb, b->fb_fused_reinit ? 1 : 0}, geo, st))
 				return fail(MTFHIP_ERR_LOGIC, "track: patch too large for the one-launch forward-backward frame");
 		} else
 		launch_iclk_track(bv, b->ctx->img, *sm, ts, b->d_h0inv, b->d_ncc, b->norm_mult, b->norm_add, b->math_mode == MTFHIP_MATH_FAST, pub, rg, st);

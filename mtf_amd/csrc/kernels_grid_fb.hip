@@ -170,6 +170,8 @@ __global__ __launch_bounds__(kBlock) void k_grid_fb(BatchView bv, ImgView im, Im
 
 	/* ---- phase A: tracker->update() on the current frame (k_iclk_track, plain mode) ---- */
 	double Cf[8];   /* where the forward pass arrives: the backward pass's template region */
+	double Cb[8];   /* where the backward pass arrives */
+	int n_it_b = 0;
 	{
 		const double2 *ip = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_PTS]) + (size_t)t * N;
 		const double2 *ih = reinterpret_cast<const double2 *>(bv.buf[MTFHIP_BUF_INIT_HXY]) + (size_t)t * N;
@@ -229,7 +231,15 @@ __global__ __launch_bounds__(kBlock) void k_grid_fb(BatchView bv, ImgView im, Im
 			v = tid == 26 ? (double)n_it : v;
 			sFwd[tid] = v;
 		}
+		if (!fo.reinit) {
+			/* fb_reinit = 0 (:297-299 skipped): setImage(prev_img); update() with the template and from the state the forward pass left */
+#pragma unroll
+			for (int q = 0; q < 8; ++q) Cb[q] = Cf[q];
+			double f_b = 0;
+			run_loop(imp, hpv, zv, i0v, j0v, tc, m0, cn, W, St, Cb, Ic, hrow, n_it_b, f_b);
+		}
 	}
+	if (fo.reinit) {   /* (uniform) */
 
 	/* ---- phase B: tracker->initialize(tracker_location) on the current frame (k_template_init, region mode; nothing written per pixel) ---- */
 	double W0[9];
@@ -357,8 +367,6 @@ __global__ __launch_bounds__(kBlock) void k_grid_fb(BatchView bv, ImgView im, Im
 	__syncthreads();
 
 	/* ---- phase C: tracker->setImage(prev_img); update() from the identity warp at tracker_location ---- */
-	double Cb[8];
-	int n_it_b = 0;
 	{
 		if (tid < 64) { const int r = tid >> 3, c = tid & 7; sH8[tid] = (r < S && c < S) ? sHinv[c * S + r] : 0.0; }
 		__syncthreads();
@@ -374,6 +382,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_fb(BatchView bv, ImgView im, Im
 		if (!bad) run_loop(imp, hpb, zb, i0b, jb, tc, m0b, cnb, W, St, Cb, Ic, hrow, n_it_b, f_b);
 		else n_it_b = -1;
 	}
+	}   /* fo.reinit */
 
 	/* ---- results: the backward corners, then k_iclk_track's record of the forward pass (device slab, host mirror, flag) ---- */
 	if (tid < 64) {

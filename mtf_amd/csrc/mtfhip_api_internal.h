@@ -257,7 +257,7 @@ struct mtfhip_batch {
 	 * cleared by whatever changes the mirrors' warps / states / corners next (set_corners_core, apply_states) and consumed by the next track_core:
 	 * its one-launch kernel then starts from init_corners_hm and the slab is not uploaded (TrackState::fresh_reset) */
 	bool fresh_reinit = false;
-	bool fb_fused_req = false;
+	bool fb_fused_req = false, fb_fused_reinit = true;
 	double *h_fb = nullptr, *h_fb_dev = nullptr, *d_fb = nullptr;   /* [B][9] the backward pass's corners | iteration count: pinned host copy, device copy */
 	double *d_nn_warps = nullptr; size_t nn_warps_cap = 0;   /* NN dataset, tolerance mode: the samples' warps between k_nn_warps and k_nn_rows */
 	double *d_lm = nullptr;       /* [B][kLmStride] Levenberg-Marquardt state of the device-side loop */

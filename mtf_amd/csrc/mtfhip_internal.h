@@ -499,7 +499,7 @@ void launch_sample_candidates(const BatchView &bv, const ImgView &im, const doub
 constexpr int kIclkTrackMaxPix = 8 * kBlock;   /* (the grid points of a thread's pixels stay in registers: k_iclk_track) */
 /* k_grid_fb (kernels_grid_fb.hip): a frame's forward pass, the re-initialisation at the tracked location and the backward pass on the
  * previous frame in one launch; per patch the backward pass leaves 8 corners + its iteration count (-1: degenerate tracked corners) */
-struct GridFbOut { double *host; double *dev; };   /* [B][9] each: device-visible pinned memory | device memory (either may be NULL) */
+struct GridFbOut { double *host; double *dev; int reinit; };   /* [B][9] each: device-visible pinned memory | device memory (either may be NULL); reinit = fb_reinit: 0 = the backward pass keeps the forward pass's template and state (GridTracker.cc:297-299 skipped) */
 bool launch_grid_fb(const BatchView &bv, const ImgView &im, const ImgView &imp, const mtfhip_sm_desc &sm, const TrackState &ts, const double *h0inv,
 	const double *ncc_sc, double norm_mult, double norm_add, double grad_eps, const HostPublish &pub, const GridFbOut &fo, const RegionIngest &rg, hipStream_t st);
 bool launch_iclk_track(const BatchView &bv, const ImgView &im, const mtfhip_sm_desc &sm, const TrackState &ts,
