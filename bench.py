@@ -432,12 +432,17 @@ def stub_mode():
 
 
 # the expected 1 -> 8 curve of the sharded filter, from single-GPU terms (us per iteration)
-PF_STRONG_MODEL = {   # (chained update() form; one-GPU terms of profiles/r05_pf_strong_one_rank.json by HIP events, `score` = one rank's block launched alone (r04 measurement), the all-gather estimated)
+PF_STRONG_MODEL = {   # (chained update() form; one-GPU terms of profiles/r06_pf_strong_one_rank.json by HIP events, `score` = one rank's block launched alone (r04 measurement), the all-gather estimated)
     10000: {"T1_us": 49, "T8_terms_us": {"score": 12.5, "allgather": 25, "scan_select": 13.6}, "T8_us": 51, "speedup": 0.96,
             "T8_us_peer_stores": 30, "speedup_peer_stores": 1.6,
-            "north_star_6x": "not reachable: T1 / 6 = 8.2 us is less than one rank's scoring launch (12.5 us) and less than the replicated selection pass (13.6 us)"},
-    100000: {"T1_us": 333, "T8_terms_us": {"score": 48, "allgather": 35, "scan_select": 27.6}, "T8_us": 111, "speedup": 3.0},
-    1000000: {"T1_us": 3231, "T8_terms_us": {"score": 412, "allgather": 75, "scan_select": 197}, "T8_us": 684, "speedup": 4.7},
+            "north_star_6x": "not reachable: T1 / 6 = 8.2 us is less than one rank's scoring launch (12.5 us) and less than the replicated selection pass (13.6 us)",
+            "selection_sharded_too": "slower: the selection pass is latency-sized (11-13 us whatever the block) and every rank would need the 64-byte states of the "
+                                     "ancestors the others selected: >= 25 us for 640 kB on top"},
+    100000: {"T1_us": 335, "T8_terms_us": {"score": 48, "allgather": 35, "scan_select": 27.6}, "T8_us": 111, "speedup": 3.0,
+             "selection_sharded_too": "27.6 -> ~13 us of selection, + ~45 us for 6.4 MB of states: slower"},
+    1000000: {"T1_us": 3250, "T8_terms_us": {"score": 412, "allgather": 75, "scan_select": 197}, "T8_us": 684, "speedup": 4.7,
+              "selection_sharded_too": "197 -> ~25 us of selection, + ~190 us for 64 MB of states at ~300 GB/s per GPU: 702 us, no gain -- the replicated term "
+                                       "(6.5 % of the scorer: the 5.3x asymptote) costs what exchanging the particle set costs, at every size (r05 verdict item 5: stated, not built)"},
 }
 
 
