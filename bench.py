@@ -1082,7 +1082,8 @@ def secondary_workload(args):
                                            (C, F, world, " + one all-gather" if world > 1 else ""),
                                "kernel_us": kms * 1e3, "samples_per_rank": cnt, "feature_size": F, "dataset_bytes": row_bytes * C},
                     "roofline": {"bound": "hbm", "note": "write-bound: 8 B x feature_size x samples streamed out with non-temporal stores; the template grid (16 B/px) and "
-                                 "the texels are re-read from L2 by every sample and not credited",
+                                 "the texels are re-read from L2 by every sample and not credited.  peak = the 8 TB/s HBM figure; a kernel that ONLY stores reaches "
+                                 "4.5-6.4 TB/s on this device (tools/write_bw_test.hip, profiles/r06_write_bw.txt)",
                                  "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS if gbs else None,
                                  "traffic": (pmc_secondary("nn", "k_nn_dataset") or {}).get("traffic_bytes_per_launch") if (C == 10000 and world == 1 and args.nn_am == "ssd") else None,
                                  "traffic_note": getattr(pmc_secondary, "note", None),
