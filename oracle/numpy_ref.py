@@ -457,6 +457,18 @@ def nn_dataset_rows(img, init_hm, perts, ncc=False):
     return np.stack(rows)
 
 
+def nn_mi_dist_feat(It, n_bins, pou):
+    """MI::updateDistFeat (AM/src/MI.cc:736-747) of raw pixel values It (N,): the AM's pixel normalisation first (MI.cc:80-94: [0, 255] ->
+    [0, n_bins - 1], with partition of unity [1, n_bins - 2], over PIX_MAX - PIX_MIN + 1 = 256), then per pixel the 5 x N matrix, row-major:
+    floor(v) | bSpl3(d), bSpl3(d + 1), bSpl3(d + 2), bSpl3(d + 3) with d = first id of the floor's B-spline window (max(floor - 1, 0), the
+    standard ids of histUtils) - v.  -> (5 N,)"""
+    lo, hi = (1.0, n_bins - 2.0) if pou else (0.0, n_bins - 1.0)
+    v = (hi - lo) / 256.0 * np.asarray(It, dtype=np.float64) + lo
+    fl = np.floor(v)
+    d = np.maximum(fl - 1.0, 0.0) - v
+    return np.concatenate([fl, bspline3(d), bspline3(d + 1.0), bspline3(d + 2.0), bspline3(d + 3.0)])
+
+
 def hom_corner_sampler(init_corners, sigma, mean, z):
     """Homography::generatePerturbation with corner based sampling (SSM/src/Homography.cc:899-909): one translation from distribution 0
     (two draws), eight corner offsets from distribution 1, the state of the 4-point homography init_corners -> disturbed corners.

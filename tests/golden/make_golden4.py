@@ -2,7 +2,7 @@
 """Generates tests/golden/lk_golden4.npz (r06) from the independent NumPy re-derivation (oracle/numpy_ref.py): the selection half of
 GridTracker's forward-backward error estimation (SM/src/GridTracker.cc:307-332) -- cases where every patch survives, where some are
 rejected, where fewer than n_model_pts survive and the set is filled up in tracker order, where none survives, and distances that sit
-on the threshold to the last single-precision bit.
+on the threshold to the last single-precision bit; and nt::NN's dataset rows for the MI appearance model (MI.cc:736-747) from lk_golden3's raw rows.
 PARITY UNPINNED with respect to the reference itself (it ships no vectors and cannot be built here).
 
 Run from the repo root:  python tests/golden/make_golden4.py
@@ -47,6 +47,12 @@ def main():
         mask, pm, cm = R.grid_fb_mask(prev_c, curr_c, fb_c, thresh, nm)
         out.update({"fb_%s_prev" % name: prev_c, "fb_%s_curr" % name: curr_c, "fb_%s_fb" % name: fb_c, "fb_%s_params" % name: np.array([thresh, nm]),
                     "fb_%s_mask" % name: mask, "fb_%s_prev_masked" % name: pm, "fb_%s_curr_masked" % name: cm})
+    # ---- NN dataset rows of the MI appearance model (MI.cc:736-747): lk_golden3's raw rows (its perturbations, its template) through the AM's pixel
+    # normalisation and updateDistFeat, for the reference's default (8 bins) and the shipped configuration (10 bins, partition of unity)
+    g3 = np.load(os.path.join(ROOT, "tests", "golden", "lk_golden3.npz"))
+    raw = g3["nn_rows_ssd"]
+    out["nn_mi_rows_8"] = np.stack([R.nn_mi_dist_feat(r, 8, False) for r in raw])
+    out["nn_mi_rows_10pou"] = np.stack([R.nn_mi_dist_feat(r, 10, True) for r in raw])
     path = os.path.join(ROOT, "tests", "golden", "lk_golden4.npz")
     np.savez_compressed(path, **out)
     print("wrote %s (%d arrays, %d bytes)" % (path, len(out), os.path.getsize(path)))

@@ -50,6 +50,25 @@ def test_nn_dataset_rows_golden(gpu_ctx, gimg, am):
     ds.batch.close()
 
 
+G4 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lk_golden4.npz"))
+
+
+@pytest.mark.parametrize("math", [mtf_amd.MATH_REPLAY, mtf_amd.MATH_FAST], ids=["replay", "fast"])
+@pytest.mark.parametrize("n_bins,pou", [(8, 0), (10, 1)], ids=["8", "10pou"])
+def test_nn_dataset_mi_rows_golden(gpu_ctx, gimg, n_bins, pou, math):
+    """nt::NN's dataset for the MI appearance model (MI.cc:80-94, 736-747) in both arithmetic modes (workgroup-per-sample kernel / k_nn_warps +
+    k_nn_rows) against lk_golden4's NumPy rows: floor(It) exactly (none of these values sits within rounding of an integer), weights to 1e-8"""
+    ds = NNDataset(gpu_ctx, am=L.AM_MI, resx=24, resy=24, n_samples=len(G["nn_perts"]), am_params=dict(mi_n_bins=n_bins, mi_pou=pou))
+    ds.batch.set_math_mode(math)
+    feats = ds.initialize(G["nn_corners"], G["nn_perts"])
+    want = G4["nn_mi_rows_%s" % ("10pou" if pou else "8")]
+    N = 24 * 24
+    assert feats.shape == want.shape
+    assert np.array_equal(feats[:, :N], want[:, :N])
+    np.testing.assert_allclose(feats[:, N:], want[:, N:], rtol=0, atol=1e-8)
+    ds.batch.close()
+
+
 @pytest.mark.parametrize("math", [mtf_amd.MATH_REPLAY, mtf_amd.MATH_FAST])
 def test_homography_corner_sampler_golden(gpu_ctx, gimg, math):
     """one iteration of the device filter without resampling, RandomWalk + compositional from the identity: the particles are the

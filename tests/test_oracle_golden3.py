@@ -61,6 +61,27 @@ def test_nn_dataset_rows_golden(oracle, img, am):
         ssm.compositional_update(p)
 
 
+G4 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lk_golden4.npz"))
+
+
+@pytest.mark.parametrize("n_bins,pou", [(8, 0), (10, 1)], ids=["8", "10pou"])
+def test_nn_dataset_mi_rows_golden(oracle, img, n_bins, pou):
+    """the same dataset for the MI appearance model: MI's pixel normalisation (MI.cc:80-94) + MI::updateDistFeat (MI.cc:736-747) -- the oracle's
+    generateDataset against lk_golden4's rows (NumPy, from lk_golden3's raw rows): floor(It) exactly, the four B-spline weights to 1e-9"""
+    res = 24
+    ssm = oracle.SSM(oracle.SSM_HOM, res, res)
+    o_am = oracle.AM(oracle.AM_MI, res, res, n_bins=n_bins, pou=pou)
+    o_am.set_curr_img(img)
+    ssm.set_corners(G["nn_corners"])
+    o_am.initialize_pix_vals(ssm.get("curr_pts"))
+    got = oracle.nn_generate_dataset(o_am, ssm, G["nn_perts"])
+    want = G4["nn_mi_rows_%s" % ("10pou" if pou else "8")]
+    N = res * res
+    assert got.shape == want.shape == (len(G["nn_perts"]), 5 * N)
+    assert np.array_equal(got[:, :N], want[:, :N])
+    np.testing.assert_allclose(got[:, N:], want[:, N:], rtol=0, atol=1e-9)
+
+
 def test_homography_corner_sampler_golden(oracle, img):
     """Homography::generatePerturbation, corner based (Homography.cc:899-909), through one filter iteration without resampling: with
     RandomWalk + compositional updates from the identity the particles ARE the perturbations"""
