@@ -82,3 +82,17 @@ def test_pf_strong_peer_children_row_from_rank_results():
     assert row["value"] == 10000 * 10 * 5 / 0.5 and row["estimate"] == [1.0, 2.0] and row["estimates_equal_across_ranks"]
     row = bench.pf_strong_peer_children(Eng({"error": "exit code 1: boom"}), None, 1, 10000, 5, 10)
     assert "rank 0" in row["error"] and "boom" in row["error"]
+
+
+def test_headline_line_survives_a_fault_in_native_code_inside_the_pf_record():
+    """r06: rank 0 dying of a signal inside the sharded-filter record (simulated: SIGSEGV raised there, MTFHIP_BENCH_STUB_CRASH=1) -- what a
+    fault inside RCCL or a peer mapping would be on the first real multi-GPU node -- still leaves exactly ONE JSON line on stdout: the
+    guardian child prints the headline with pf_strong = {"error": ...}.  And when nothing dies the guardian stays silent (the tests above)."""
+    env = _clean_env()
+    env["MTFHIP_BENCH_STUB_CRASH"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "1"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (p.stdout[-1000:], p.stderr[-1000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "died" in d["pf_strong"]["error"]
