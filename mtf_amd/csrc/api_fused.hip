@@ -1746,7 +1746,8 @@ int score_block_dev(mtfhip_batch *b, const double *dev_states, int lo, int cnt, 
 	}
 	/* (view_raw: the candidates bring their own warps; a stale device copy of the batch's warp is not uploaded for them) */
 	launch_score_block(b->view_raw(), b->ctx->img, dev_states, lo, cnt, b->desc.likelihood_alpha, b->norm_mult, b->norm_add, ncc_sc, wts, sim,
-		likelihood_func, measurement_sigma, max_similarity, b->math_mode == MTFHIP_MATH_FAST, peer, hull, st);
+		likelihood_func, measurement_sigma, max_similarity, b->math_mode == MTFHIP_MATH_FAST, peer, hull,
+		(b->math_mode == MTFHIP_MATH_FAST && b->C == 1) ? pair_image_if_it_pays(b->ctx, cnt) : nullptr, st);
 	return MTFHIP_OK;
 }
 int mtfhip_score_candidates_dev(mtfhip_batch *b, const double *dev_states, int C, double *dev_lik, double *dev_sim) {

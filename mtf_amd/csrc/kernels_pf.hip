@@ -280,6 +280,11 @@ struct PfScoreArgs {
 	int hull_ok;
 	double hull[8];
 	int lean_ok;                   /* 0: experiments (MTFHIP_PF_LEAN=0) */
+	/* the row-pair copy of the frame (mtfhip_ctx::pair_owned; NULL: none): pair[2 (y W + x)] = I[y][x] | I[y + 1][x] -- a sample's cell is ONE
+	 * 16-byte gather instead of two 8-byte ones (r06: the loop sits on the vector memory path as much as on FP64 issue -- 39.1 -> 36.0 us per
+	 * 10 000 candidates, 3041 -> 2684 per million) */
+	const float *pair;
+	int pair_w;
 };
 /* A weight for the peers: a relaxed system-scope store -- it goes through to the peer's memory, and the wave's vmcnt tells when it
  * has (what every release fence relies on), so no fence and no L2 write-back per workgroup.  (First version: a system-scope release
@@ -322,6 +327,7 @@ __device__ __forceinline__ void pf_peer_wait(const PfPeerWait &w) {
 	__atomic_thread_fence(__ATOMIC_ACQUIRE);   /* (system scope: the peers' weights, not a cached older exchange) */
 }
 struct __attribute__((packed, aligned(4))) PfTexPair { float a, b; };
+struct __attribute__((packed, aligned(4))) PfTexQuad { float t00, t10, t01, t11; };   /* a cell of the row-pair image: (x, y) (x, y + 1) (x + 1, y) (x + 1, y + 1) */
 /* MC: the multi-channel models (MCSSD / MCNCC = SSD / NCC built with n_channels = 3, AM/src/MCSSD.cc): a row of the per-pixel
  * arrays is a (pixel, channel) pair, row = pixel * C + channel (mc::getPixVals imgUtils.cc:867-882); the grid point is the
  * pixel's, the texels the channel's (interleaved image); replay arithmetic uses mc::PixVal's weights-first order (pix_val_mc). */
@@ -335,7 +341,7 @@ __device__ unsigned long long g_pf_trace[16];
 #else
 #define PF_STAMP(k) do { } while (0)
 #endif
-template <int SSM, bool NCC, bool FAST, bool MC, int K>
+template <int SSM, bool NCC, bool FAST, bool MC, int K, bool PAIR = false>
 __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, PfScoreArgs s) {
 	constexpr int M = NCC ? 3 : 1, S = SSM == MTFHIP_SSM_HOMOGRAPHY ? 8 : 6;
 	__shared__ double red[4 * K * M], tot[K * M];
@@ -422,8 +428,13 @@ __global__ __launch_bounds__(kBlock) void k_pf_score(BatchView bv, ImgView im, P
 						/* (v_mul_lo_u32 is a quarter-rate instruction, 16 cycles of a ~900-cycle iteration each: the row and the pitch are
 						 * below 2^24 -- mtfhip_image_upload / _borrow refuse larger frames -- so the 24-bit multiply-add, full rate, gives the same offset) */
 						const unsigned off = (__umul24((unsigned)ly, (unsigned)stride) + (unsigned)lx) * 4u;
-						const PfTexPair t0 = ld_off<PfTexPair>(img, off), t1 = ld_off<PfTexPair>(img + stride, off);
-						v = bilin_val_fast(t0.a, t0.b, t1.a, t1.b, fx, fy);
+						if constexpr (PAIR) {   /* (a launch parameter as a template argument: with both forms behind a run-time flag the loop was 1.7 x slower in either) */
+							const PfTexQuad q4 = ld_off<PfTexQuad>(s.pair, (__umul24((unsigned)ly, (unsigned)s.pair_w) + (unsigned)lx) * 8u);
+							v = bilin_val_fast(q4.t00, q4.t01, q4.t10, q4.t11, fx, fy);
+						} else {
+							const PfTexPair t0 = ld_off<PfTexPair>(img, off), t1 = ld_off<PfTexPair>(img + stride, off);
+							v = bilin_val_fast(t0.a, t0.b, t1.a, t1.b, fx, fy);
+						}
 					}
 				} else {
 					if constexpr (MC) v = pix_val_mc(im, wx, wy, ch); else v = pix_val_fast(im, wx, wy);
@@ -1067,11 +1078,13 @@ static void launch_pf_score_args(const BatchView &bv, const ImgView &im, const P
 	const int kc = (k_env == 1 || k_env == 2 || k_env == 4) ? k_env : (s.cnt <= 1536 ? 1 : (s.cnt <= 4096 ? 2 : 4));
 	const dim3 g((s.cnt + kc - 1) / kc);
 	const bool hom = bv.ssm == MTFHIP_SSM_HOMOGRAPHY, ncc = s.ncc_sc != nullptr, mc = bv.C > 1;
-#define MTFHIP_PF_SCORE(SSM_, NCC_, FAST_, MC_) do { \
-		if (kc == 1) MTFHIP_LAUNCH((k_pf_score<SSM_, NCC_, FAST_, MC_, 1>), g, dim3(kBlock), 0, st, bv, im, s); \
-		else if (kc == 2) MTFHIP_LAUNCH((k_pf_score<SSM_, NCC_, FAST_, MC_, 2>), g, dim3(kBlock), 0, st, bv, im, s); \
-		else MTFHIP_LAUNCH((k_pf_score<SSM_, NCC_, FAST_, MC_, 4>), g, dim3(kBlock), 0, st, bv, im, s); } while (0)
-#define MTFHIP_PF_SCORE_MC(SSM_, NCC_, FAST_) do { if (mc) MTFHIP_PF_SCORE(SSM_, NCC_, FAST_, true); else MTFHIP_PF_SCORE(SSM_, NCC_, FAST_, false); } while (0)
+#define MTFHIP_PF_SCORE(SSM_, NCC_, FAST_, MC_, PAIR_) do { \
+		if (kc == 1) MTFHIP_LAUNCH((k_pf_score<SSM_, NCC_, FAST_, MC_, 1, PAIR_>), g, dim3(kBlock), 0, st, bv, im, s); \
+		else if (kc == 2) MTFHIP_LAUNCH((k_pf_score<SSM_, NCC_, FAST_, MC_, 2, PAIR_>), g, dim3(kBlock), 0, st, bv, im, s); \
+		else MTFHIP_LAUNCH((k_pf_score<SSM_, NCC_, FAST_, MC_, 4, PAIR_>), g, dim3(kBlock), 0, st, bv, im, s); } while (0)
+	const bool pair = fast_math && !mc && s.pair != nullptr;   /* tolerance mode, one channel: the cell from the row-pair copy of the frame */
+#define MTFHIP_PF_SCORE_MC(SSM_, NCC_, FAST_) do { if (mc) MTFHIP_PF_SCORE(SSM_, NCC_, FAST_, true, false); \
+		else if (pair && FAST_) MTFHIP_PF_SCORE(SSM_, NCC_, FAST_, false, (FAST_)); else MTFHIP_PF_SCORE(SSM_, NCC_, FAST_, false, false); } while (0)
 	if (fast_math) {
 		if (hom) { if (ncc) MTFHIP_PF_SCORE_MC(MTFHIP_SSM_HOMOGRAPHY, true, true); else MTFHIP_PF_SCORE_MC(MTFHIP_SSM_HOMOGRAPHY, false, true); }
 		else { if (ncc) MTFHIP_PF_SCORE_MC(MTFHIP_SSM_AFFINE, true, true); else MTFHIP_PF_SCORE_MC(MTFHIP_SSM_AFFINE, false, true); }
@@ -1086,8 +1099,9 @@ static void launch_pf_score_args(const BatchView &bv, const ImgView &im, const P
  * mtfhip_score_candidates: PF.cc:247-262, 341-365 per candidate) */
 void launch_score_block(const BatchView &bv, const ImgView &im, const double *states, int lo, int cnt, double alpha, double norm_mult,
 	double norm_add, const double *ncc_sc, double *wts, double *sim, int likelihood_func, double measurement_sigma, double max_similarity,
-	int fast_math, const PfPeerPush *peer, const double *hull, hipStream_t st) {
+	int fast_math, const PfPeerPush *peer, const double *hull, const float *pair, hipStream_t st) {
 	PfScoreArgs s;
+	s.pair = (fast_math && bv.C == 1) ? pair : nullptr; s.pair_w = im.w;
 	s.prop = states; s.lo = lo; s.cnt = cnt; s.alpha = alpha; s.norm_mult = norm_mult; s.norm_add = norm_add; s.ncc_sc = ncc_sc;
 	s.likelihood_func = likelihood_func; s.measurement_sigma = measurement_sigma; s.max_similarity = max_similarity;
 	s.wts = wts; s.sim = sim;

@@ -151,4 +151,19 @@ void launch_resize_linear(const float *src, int srows, int scols, float *dst, in
 	MTFHIP_LAUNCH(k_resize_linear, dim3((dcols + kBlock - 1) / kBlock, drows), dim3(kBlock), 0, st, src, srows, scols, drows, dcols, dst);
 }
 
+/* pair[2 (y W + x)] = I[y][x], pair[2 (y W + x) + 1] = I[min(y + 1, H - 1)][x]: a bilinear cell's four texels in 16 contiguous bytes */
+__global__ __launch_bounds__(kBlock) void k_pair_image(ImgView im, float2 *pair) {
+	const size_t n = (size_t)im.w * im.h;
+	for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+		const int y = (int)(i / (size_t)im.w), x = (int)(i - (size_t)y * im.w);
+		const int y1 = y + 1 < im.h ? y + 1 : y;
+		pair[i] = make_float2(im.data[(size_t)y * im.stride + x], im.data[(size_t)y1 * im.stride + x]);
+	}
+}
+void launch_pair_image(const ImgView &im, float *pair, hipStream_t st) {
+	const size_t n = (size_t)im.w * im.h;
+	const unsigned blocks = (unsigned)std::min<size_t>((n + kBlock - 1) / kBlock, 4096);
+	MTFHIP_LAUNCH(k_pair_image, dim3(blocks), dim3(kBlock), 0, st, im, reinterpret_cast<float2 *>(pair));
+}
+
 } // namespace mtfhip

@@ -138,6 +138,13 @@ struct mtfhip_ctx {
 	size_t prev_capacity = 0;
 	unsigned char *raw = nullptr; size_t raw_capacity = 0;      /* staging of the raw frame (pre-processing) */
 	float *tmp_a = nullptr, *tmp_b = nullptr; size_t tmp_capacity = 0; /* gray / row-pass intermediates */
+	/* The current image with every texel next to the one BELOW it -- pair[2 (y W + x)] = I[y][x], pair[2 (y W + x) + 1] = I[y + 1][x] -- so that
+	 * the four texels of a bilinear cell are 16 contiguous bytes: ONE gather per sample instead of two for the kernels that sit on the vector
+	 * memory path (the candidate scorer; r06 -- the NN rows kernel gained nothing from it).  Built on demand (ensure_pair_image) for images the context owns (an uploaded or derived
+	 * image cannot change behind the library's back; a borrowed one can), rebuilt when img_serial has moved. */
+	float *pair_owned = nullptr; size_t pair_capacity = 0;
+	unsigned long long img_serial = 1, pair_serial = 0, pair_demand_serial = 0;
+	size_t pair_demand = 0;   /* candidates scored on the current image so far without the copy (pair_image_if_it_pays) */
 	int n_cus = 0;   /* compute units: the persistent loop needs its whole grid resident */
 	bool timing = false;
 	int timing_stride = 1;   /* events are recorded around every timing_stride-th launch of a family */
@@ -603,6 +610,8 @@ static inline mtfhip::MiJ0Rebuild mi_j0_rebuild(const mtfhip_batch *b) {
 /* ---- functions defined in one api_*.hip unit and used in another ---- */
 enum { LAZY_CURR_JAC = 0, LAZY_DIFF_JAC = 1, LAZY_INIT_JAC = 2 };
 int ensure_pts(mtfhip_batch *b);
+const float *ensure_pair_image(mtfhip_ctx *c);   /* NULL: not applicable (borrowed / multi-channel / too large / MTFHIP_PAIR_IMAGE=0) */
+const float *pair_image_if_it_pays(mtfhip_ctx *c, int n_candidates);
 int set_corners_core(mtfhip_batch *b, const double *corners, bool for_track, bool defer_grid = false, bool layout_later = false);   /* api_core.hip */
 void set_corners_finish_deferred(mtfhip_batch *b);
 int do_update_grad_pts(mtfhip_batch *b, double grad_eps);

@@ -424,7 +424,7 @@ struct PfPeerWait {
 void launch_pf_propose(int ssm, const PfLaunch &p, const PfBuffers &bf, const double *st_in, const double *ar_in, double *st_out, double *ar_out, hipStream_t st);
 void launch_score_block(const BatchView &bv, const ImgView &im, const double *states, int lo, int cnt, double alpha, double norm_mult,
 	double norm_add, const double *ncc_sc, double *wts, double *sim, int likelihood_func, double measurement_sigma, double max_similarity,
-	int fast_math, const PfPeerPush *peer /* or NULL */, const double *hull /* [8] host, or NULL: PfScoreArgs::hull */, hipStream_t st);
+	int fast_math, const PfPeerPush *peer /* or NULL */, const double *hull /* [8] host, or NULL: PfScoreArgs::hull */, const float *pair /* the row-pair copy of the frame, or NULL */, hipStream_t st);
 /* weights [lo, lo + cnt) of `wts` -> every other rank's mailbox + the arrival: for scorers that do not store to the peers themselves */
 void launch_pf_peer_push(const PfPeerPush &peer, const double *wts, int lo, int cnt, hipStream_t st);
 void launch_pf_peer_wait(const PfPeerWait &w, hipStream_t st);   /* the wait in a launch of its own (no scan in this iteration) */
@@ -490,6 +490,7 @@ struct NnArgs {
 	int row_lo;               /* global index of the launch's first sample (row sharding: draws are keyed by the global index) */
 	double norm_mult, norm_add;
 };
+void launch_pair_image(const ImgView &im, float *pair /* [h][w][2] */, hipStream_t st);
 void launch_nn_dataset(const BatchView &bv, const ImgView &im, const NnArgs &a, int count, double *feat, double *warps, const double *hull, hipStream_t st);
 size_t nn_warps_bytes(int count);
 bool nn_two_launch_ok(const BatchView &bv, const ImgView &im, int fast_math);

@@ -153,3 +153,55 @@ def test_flat_template_has_no_update(gpu_ctx):
             np.testing.assert_allclose(final[0], c, rtol=0, atol=atol)
             assert n_it[0] == 1                                          # converged at once: zero update
         b.close()
+
+
+@pytest.mark.gpu
+def test_row_pair_image_gives_the_same_scores_and_follows_the_image(gpu_ctx, monkeypatch):
+    """r06: the candidate scorer gathers a bilinear cell from the row-pair copy of an UPLOADED frame (one 16-byte load: pair[2 (y W + x)] =
+    I[y][x] | I[y + 1][x]) -- the same four texels as the two 8-byte gathers, so the same bits (MTFHIP_PAIR_IMAGE=0: the two gathers); the
+    copy is rebuilt when the image is replaced (upload, keep_prev + upload, swap_prev) and not used for a borrowed image.  (It is built once
+    enough candidates have been scored on an image, MTFHIP_PAIR_IMAGE_AFTER: 0 here.)"""
+    monkeypatch.setenv("MTFHIP_PAIR_IMAGE_AFTER", "0")
+    import torch
+    import mtf_amd
+    from mtf_amd import _lib as L
+    from mtf_amd import synth
+    f0, f1 = synth.make_frame(384, 416), synth.make_frame(384, 416, seed=77)
+    corners = synth.square_corners(200, 180, 90)
+    rng = np.random.default_rng(3)
+    states = rng.normal(size=(513, 8)) * np.array([0.02, 0.02, 3.0, 0.02, 0.02, 3.0, 1e-4, 1e-4])
+    states[:40, 2] -= 160.0          # some candidates across the left border: the per-sample path
+
+    def scores(img, pair, borrow=None):
+        monkeypatch.setenv("MTFHIP_PAIR_IMAGE", pair)
+        if borrow is None:
+            gpu_ctx.set_image(img)
+        else:
+            gpu_ctx.set_image_device(borrow.data_ptr(), img.shape[0], img.shape[1], keep=borrow)
+        b = mtf_amd.Batch(gpu_ctx, L.AM_NCC, L.SSM_HOMOGRAPHY, 40, 40, 1)
+        b.set_corners(corners[None]); b.initialize_pix_vals(); b.initialize_similarity()
+        lik, sim = b.score_candidates(states, want_similarity=True)
+        _, rows = b.nn_dataset(64, np.array([0.01, 0.01, 2.0, 0.01, 0.01, 2.0, 1e-5, 1e-5]), None, seed=4)
+        b.close()
+        return lik, sim, rows
+    a = scores(f0, "1"); b0 = scores(f0, "0")
+    for x, y in zip(a, b0):
+        assert np.array_equal(x, y)
+    c = scores(f1, "1"); d = scores(f1, "0")          # a new frame: the copy follows it
+    for x, y in zip(c, d):
+        assert np.array_equal(x, y)
+    assert not np.array_equal(a[1], c[1])
+    gpu_ctx.keep_prev(); e = scores(f0, "1")           # the other buffer of the context
+    for x, y in zip(e, b0):
+        assert np.array_equal(x, y)
+    gpu_ctx.swap_prev()                                 # current <-> previous: f1 again (swap back before the next upload)
+    monkeypatch.setenv("MTFHIP_PAIR_IMAGE", "1")
+    b = mtf_amd.Batch(gpu_ctx, L.AM_NCC, L.SSM_HOMOGRAPHY, 40, 40, 1)
+    b.set_corners(corners[None]); b.initialize_pix_vals(); b.initialize_similarity()
+    assert np.array_equal(b.score_candidates(states, want_similarity=True)[1], d[1])
+    b.close()
+    gpu_ctx.swap_prev()
+    t = torch.from_numpy(f1).to("cuda:0")
+    g = scores(f1, "1", borrow=t)                       # a borrowed image: no copy, the two gathers
+    for x, y in zip(g, d):
+        assert np.array_equal(x, y)
