@@ -372,7 +372,8 @@ int mtfhip_grid_fb_mask(int n, const float *prev_pts, const float *curr_pts, con
  * mtfhip_grid_backward and mtfhip_grid_fb_mask against prev_pts (the centroids the last reset / frame left, B x 2).  With
  * g->reset_at_each_frame != 0 the caller's resetTrackers follows (:273-274: mtfhip_grid_reset, or the region of the next frame) and
  * replaces whatever setRegion(tracker_location) would leave, so that last step of the backward pass is left out.
- * The reset-every-frame configuration (g->reset_at_each_frame == 1, no region -- the shipped one, with fb->fb_reinit; tolerance mode, ICLK with a
+ * The reset-every-frame configuration (g->reset_at_each_frame == 1, no region -- the shipped one, with fb->fb_reinit; also reset_at_each_frame == 0
+ * without fb_reinit, setRegion(tracker_location) following as one more call; tolerance mode, ICLK with a
  * constant Hessian over SSD / NCC, <= 1024 pixels; with fb_reinit an affine patch SSM) is ONE launch (k_grid_fb, kernels_grid_fb.hip): a patch's
  * update(), its initialize(tracker_location) when fb_reinit, and its update() on the previous frame run back to back in its workgroup,
  * bit-identical to the launch-by-launch form (MTFHIP_GRID_FB_FUSED=0).  The patch trackers are then left as the FORWARD pass left them (state,

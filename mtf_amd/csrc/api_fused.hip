@@ -1237,7 +1237,10 @@ int mtfhip_grid_frame_fb(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip
 		const char *e_ff = std::getenv("MTFHIP_GRID_FB_FUSED");   /* (read per call: the tests compare the two forms in one process) */
 		mtfhip_ctx *c = b->ctx;
 		const bool reinit_ok = !fb->fb_reinit || (b->desc.ssm == MTFHIP_SSM_AFFINE && template_init_fused_ok(b, sm));   /* (fb_reinit 0: the backward loop keeps the forward pass's template and state) */
-		const bool fused = !(e_ff && e_ff[0] == '0') && !region && reinit_ok && g->reset_at_each_frame == 1 && !always_restore &&
+		/* reset_at_each_frame 1: the caller's reset follows, nothing to restore.  0 without fb_reinit: the template is untouched, setRegion(tracker_location)
+		 * (:305) is one more call behind the launch.  (0 with fb_reinit would have to keep the backward template: the launch-by-launch form.) */
+		const bool restore_after = g->reset_at_each_frame == 0 && !fb->fb_reinit;
+		const bool fused = !(e_ff && e_ff[0] == '0') && !region && reinit_ok && (g->reset_at_each_frame == 1 || restore_after) && !always_restore &&
 			b->math_mode == MTFHIP_MATH_FAST && (b->desc.am == MTFHIP_AM_SSD || b->desc.am == MTFHIP_AM_NCC) && b->C == 1 && sm->sm == MTFHIP_SM_ICLK && iclk_one_launch(b, sm) && !sm->leven_marq &&
 			second_order_term(sm, b->desc.am) < 0 && b->N <= 4 * kBlock && b->h_pub_dev && !b->d_trace && b->init_pix_vals &&
 			(b->desc.am != MTFHIP_AM_NCC || b->d_ncc_tm) && c->prev.data && c->img.data && c->prev.h == c->img.h && c->prev.w == c->img.w &&
@@ -1257,6 +1260,12 @@ int mtfhip_grid_frame_fb(mtfhip_batch *b, const mtfhip_sm_desc *sm, const mtfhip
 			for (size_t t = 0; t < B; ++t) {
 				if (b->h_fb[9 * t + 8] < 0) return fail(MTFHIP_ERR_INVALID_ARG, "grid_frame_fb: degenerate tracked corners for patch %d", (int)t);
 				centroid_f(fb_prev_pts + 2 * t, b->h_fb + 9 * t);                                        /* getCentroid(fb_prev_pts[id], getRegion()) :302 */
+			}
+			if (restore_after) {                                                                           /* tracker->setRegion(tracker_location) :305 */
+				static thread_local std::vector<double> loc;
+				loc.resize(8 * B);
+				for (size_t t = 0; t < B; ++t) std::memcpy(&loc[8 * t], b->th[t].corners, sizeof(double) * 8);   /* (the forward pass's: what the kernel left) */
+				TRY(mtfhip_batch_set_region(b, loc.data(), sm));
 			}
 			return mtfhip_grid_fb_mask(b->B, prev_pts, cen.data(), fb_prev_pts, fb, fb_err_mask, prev_masked, curr_masked, n_masked);
 		}

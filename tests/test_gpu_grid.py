@@ -479,11 +479,11 @@ def test_grid_template_init_and_first_iteration_against_the_oracles_trackers(ora
     b.close()
 
 
-@pytest.mark.parametrize("fb_reinit", [1, 0])
+@pytest.mark.parametrize("reset,fb_reinit", [(1, 1), (1, 0), (0, 0)], ids=["reset1-reinit1", "reset1-reinit0", "reset0-reinit0"])
 @pytest.mark.parametrize("where", ["centre", "border"])
 @pytest.mark.parametrize("ps", [16, 25, 32])
 @pytest.mark.parametrize("am", [L.AM_NCC, L.AM_SSD], ids=["ncc", "ssd"])
-def test_grid_fb_one_launch_equals_three(frame, am, ps, where, fb_reinit, monkeypatch):
+def test_grid_fb_one_launch_equals_three(frame, am, ps, where, reset, fb_reinit, monkeypatch):
     """the shipped configuration's frame (reset_at_each_frame 1, fb_err_thresh 2, fb_reinit 1) as ONE launch (k_grid_fb: a patch's update(),
     initialize(tracker_location) and update() on the previous frame in its workgroup) against the three launches with two host waits
     (k_iclk_track, k_template_init, k_iclk_track; MTFHIP_GRID_FB_FUSED=0): the same expressions in the same order, so the same bits --
@@ -491,7 +491,7 @@ def test_grid_fb_one_launch_equals_three(frame, am, ps, where, fb_reinit, monkey
     third of them with a spoiled patch (a backward pass that does not come home).  1, 3 and 4 pixels per thread."""
     gs = 5
     est = least_squares_estimator(L.SSM_HOMOGRAPHY)
-    kw = dict(grid_size=gs, patch_size=ps, max_iters=12, epsilon=1e-4, reset_at_each_frame=1, grid_ssm=L.SSM_HOMOGRAPHY, estimator=est, fb_err_thresh=2.0, fb_reinit=fb_reinit,
+    kw = dict(grid_size=gs, patch_size=ps, max_iters=12, epsilon=1e-4, reset_at_each_frame=reset, grid_ssm=L.SSM_HOMOGRAPHY, estimator=est, fb_err_thresh=2.0, fb_reinit=fb_reinit,
               n_model_pts=4, am=am, ssm=L.SSM_AFFINE)
     ctxs = [mtf_amd.Context(0), mtf_amd.Context(0)]
     gts = [GridTracker(c, **kw) for c in ctxs]
