@@ -406,6 +406,7 @@ def _compact(line):
     vl = (cfg.get("cpp_driver") or {}).get("video_loop")
     if vl:
         rec["video_loop_update_us"] = {k: v.get("update_us") for k, v in vl.items() if isinstance(v, dict)}
+        rec["video_loop_set_image_us"] = {k: v.get("set_image_us") for k, v in vl.items() if isinstance(v, dict)}
     if "hbm_frac" in roof:
         rec["roofline"]["hbm_frac"] = roof["hbm_frac"]
     return rec
